@@ -1,0 +1,324 @@
+"""ctypes binding of the CPU ORACLE (oracle/rb_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: importable from tests/, __graft_entry__.smoke() and bench.py's
+``cpu_baseline`` leg — never from the product package (rna-bloom_amd/).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "librb_oracle.so")
+
+FWD, CANON, RC = 0, 1, 2
+REVCOMP, COUNT_IF_PRESENT, STORE_READ_PAIRS = 1, 2, 4
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "rb_oracle.c")
+    hdr = os.path.join(_HERE, "rb_oracle.h")
+    if (force or not os.path.exists(_SO)
+            or os.path.getmtime(_SO) < max(os.path.getmtime(src), os.path.getmtime(hdr))):
+        subprocess.check_call(["make", "-C", _HERE, "-s"])
+    return _SO
+
+
+_lib = None
+
+
+class AddStats(C.Structure):
+    _fields_ = [("reads", C.c_int64), ("reads_skipped", C.c_int64), ("segments", C.c_int64),
+                ("kmers", C.c_int64), ("pairs", C.c_int64)]
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    L = C.CDLL(build())
+    u64, i64, i32, u32, f32 = C.c_uint64, C.c_int64, C.c_int, C.c_uint32, C.c_float
+    vp, cp = C.c_void_p, C.c_char_p
+
+    def sig(name, res, *args):
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = list(args)
+
+    sig("rbo_seed", u64, C.c_uint)
+    sig("rbo_mstab", u64, C.c_uint, i32)
+    sig("rbo_ntp64", u64, cp, i32)
+    sig("rbo_ntp64rc", u64, cp, i32)
+    sig("rbo_ntpc64", u64, cp, i32, vp)
+    sig("rbo_roll_f", u64, u64, C.c_uint, C.c_uint, i32)
+    sig("rbo_roll_r", u64, u64, C.c_uint, C.c_uint, i32)
+    sig("rbo_roll_f_back", u64, u64, C.c_uint, C.c_uint, i32)
+    sig("rbo_ntm64", None, u64, vp, i32, i32)
+    sig("rbo_combine", u64, u64, u64)
+    sig("rbo_combine3", u64, u64, u64, u64)
+    sig("rbo_hash_region", i64, cp, i64, i64, i32, i32, i32, vp, vp)
+    sig("rbo_hash_pairs_region", i64, cp, i64, i64, i32, i32, i32, i32, vp, vp, vp)
+    sig("rbo_neighbors", None, u64, u64, C.c_uint, i32, i32, i32, i32, vp, vp, vp)
+    sig("rbo_variant", None, u64, u64, C.c_uint, C.c_uint, i32, i32, i32, i32, vp, vp, vp)
+    sig("rbo_rng31", u32, u64, u64, u32)
+    sig("rbo_minifloat_increment", C.c_uint8, C.c_uint8, u32)
+    sig("rbo_minifloat_to_float", f32, C.c_uint8)
+    sig("rbo_expected_size", i64, i64, f32, i32)
+    sig("rbo_bloom_new", vp, i64, i32)
+    sig("rbo_bloom_free", None, vp)
+    sig("rbo_bloom_clear", None, vp)
+    sig("rbo_bloom_add", None, vp, vp)
+    sig("rbo_bloom_lookup", i32, vp, vp)
+    sig("rbo_bloom_lookup_then_add", i32, vp, vp)
+    sig("rbo_bloom_popcount", i64, vp)
+    sig("rbo_bloom_fpr", f32, vp)
+    sig("rbo_bloom_bytes", vp, vp, vp)
+    sig("rbo_bloom_size", i64, vp)
+    sig("rbo_cbf_new", vp, i64, i32)
+    sig("rbo_cbf_free", None, vp)
+    sig("rbo_cbf_clear", None, vp)
+    sig("rbo_cbf_increment", None, vp, vp, u32)
+    sig("rbo_cbf_increment_and_get", f32, vp, vp, u32)
+    sig("rbo_cbf_get_count", f32, vp, vp)
+    sig("rbo_cbf_popcount", i64, vp)
+    sig("rbo_cbf_fpr", f32, vp)
+    sig("rbo_cbf_bytes", vp, vp, vp)
+    sig("rbo_graph_new", vp, i64, i64, i64, i32, i32, i32, i32, i32, i32, u64)
+    sig("rbo_graph_free", None, vp)
+    sig("rbo_graph_clear", None, vp)
+    sig("rbo_graph_set_read_pair_distance", None, vp, i32)
+    sig("rbo_graph_init_fragment_pairs", None, vp, i64, i32, i32)
+    sig("rbo_graph_max_hash", i32, vp)
+    sig("rbo_graph_ordinal", u64, vp)
+    sig("rbo_graph_set_ordinal", None, vp, u64)
+    for n in ("add", "add_if_absent", "add_count_if_present", "add_dbg_only", "add_count_only",
+              "add_read_pair", "add_fragment_pair"):
+        sig("rbo_graph_" + n, None, vp, vp)
+    sig("rbo_graph_contains", i32, vp, vp)
+    sig("rbo_graph_get_count", f32, vp, vp)
+    sig("rbo_graph_lookup_read_pair", i32, vp, vp)
+    sig("rbo_graph_lookup_fragment_pair", i32, vp, vp)
+    for n in ("dbgbf", "cbf", "rpkbf", "fpkbf"):
+        sig("rbo_graph_" + n, vp, vp)
+    sig("rbo_graph_add_reads", None, vp, vp, vp, vp, i64, i32, C.c_uint, vp)
+    sig("rbo_graph_add_reads_mt", None, vp, vp, vp, vp, i64, i32, C.c_uint, i32, vp)
+    sig("rbo_segments", i64, vp, vp, i64, i32, i32, vp, i64)
+    sig("rbo_graph_get_kmers", i64, vp, vp, i64, vp, vp, vp)
+    sig("rbo_graph_neighbors", None, vp, u64, u64, C.c_uint, i32, vp, vp, vp)
+    sig("rbo_minimizers", i64, vp, i64, i32, i32, i32, vp, vp)
+    sig("rbo_strobemers", i64, vp, i64, i32, i32, i32, i32, vp, vp, vp)
+    _lib = L
+    return L
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def _b(s):
+    return s if isinstance(s, bytes) else s.encode()
+
+
+def ntm64(base, k, m):
+    out = np.zeros(m, np.uint64)
+    lib().rbo_ntm64(int(base), _p(out), k, m)
+    return out
+
+
+def hash_region(seq, k, h, mode, start=0, end=None):
+    seq = _b(seq)
+    end = len(seq) if end is None else end
+    n = max(0, end - start - k + 1)
+    out = np.zeros((n, h), np.uint64)
+    fr = np.zeros((n, 2), np.uint64)
+    got = lib().rbo_hash_region(seq, start, end, k, h, mode, _p(out), _p(fr))
+    assert got == n
+    return out, fr
+
+
+def hash_pairs_region(seq, k, h, d, mode, start=0, end=None):
+    seq = _b(seq)
+    end = len(seq) if end is None else end
+    n = max(0, end - start - k - d + 1)
+    p = np.zeros((n, h), np.uint64)
+    l = np.zeros((n, h), np.uint64)
+    r = np.zeros((n, h), np.uint64)
+    got = lib().rbo_hash_pairs_region(seq, start, end, k, h, d, mode, _p(p), _p(l), _p(r))
+    assert got == n
+    return p, l, r
+
+
+def neighbors(f, r, char_out, k, h, canonical, direction):
+    of = np.zeros(4, np.uint64)
+    orr = np.zeros(4, np.uint64)
+    oh = np.zeros((4, h), np.uint64)
+    lib().rbo_neighbors(int(f), int(r), char_out, k, h, int(canonical), direction, _p(of), _p(orr), _p(oh))
+    return of, orr, oh
+
+
+def variant(f, r, char_out, char_in, k, h, canonical, side):
+    of = np.zeros(1, np.uint64)
+    orr = np.zeros(1, np.uint64)
+    oh = np.zeros(h, np.uint64)
+    lib().rbo_variant(int(f), int(r), char_out, char_in, k, h, int(canonical), side, _p(of), _p(orr), _p(oh))
+    return int(of[0]), int(orr[0]), oh
+
+
+def segments(seq, qual, k, min_q):
+    seq = _b(seq)
+    cap = len(seq) // max(k, 1) + 2
+    out = np.zeros((cap, 2), np.int64)
+    sb = C.create_string_buffer(seq, len(seq))
+    qb = C.create_string_buffer(_b(qual), len(seq)) if qual is not None else None
+    n = lib().rbo_segments(C.cast(sb, C.c_void_p), C.cast(qb, C.c_void_p) if qb else None,
+                           len(seq), k, min_q, _p(out), cap)
+    return out[:n].copy()
+
+
+def minimizers(seq, k, w, mode):
+    seq = _b(seq)
+    n = max(0, len(seq) - k + 1 - w + 1)
+    oh = np.zeros(n, np.uint64)
+    op = np.zeros(n, np.int64)
+    sb = C.create_string_buffer(seq, len(seq))
+    got = lib().rbo_minimizers(C.cast(sb, C.c_void_p), len(seq), k, w, mode, _p(oh), _p(op))
+    return oh[:got], op[:got]
+
+
+def strobemers(seq, k, n, wmin, wmax):
+    seq = _b(seq)
+    cap = max(0, len(seq) - k + 1)
+    oh = np.zeros(cap, np.uint64)
+    os_ = np.zeros(cap, np.int32)
+    oe = np.zeros(cap, np.int32)
+    sb = C.create_string_buffer(seq, len(seq))
+    got = lib().rbo_strobemers(C.cast(sb, C.c_void_p), len(seq), k, n, wmin, wmax, _p(oh), _p(os_), _p(oe))
+    return oh[:got], os_[:got], oe[:got]
+
+
+def pack_reads(reads, quals=None):
+    """list of bytes -> (concatenated uint8 array, qual array or None, int64 offsets[n+1])."""
+    lens = np.fromiter((len(r) for r in reads), np.int64, len(reads))
+    off = np.zeros(len(reads) + 1, np.int64)
+    np.cumsum(lens, out=off[1:])
+    seq = np.frombuffer(b"".join(reads), np.uint8).copy() if len(reads) else np.zeros(0, np.uint8)
+    q = None
+    if quals is not None:
+        q = np.frombuffer(b"".join(quals), np.uint8).copy() if len(quals) else np.zeros(0, np.uint8)
+        assert q.size == seq.size
+    return seq, q, off
+
+
+class Graph:
+    """Sequential oracle graph — mirrors rnabloom.graph.BloomFilterDeBruijnGraph."""
+
+    def __init__(self, dbgbf_bits, cbf_bytes, pkbf_bits, dbg_h=2, cbf_h=2, pk_h=2, k=25,
+                 stranded=False, use_read_pairs=True, rng_seed=0):
+        self.L = lib()
+        self.k, self.stranded = k, stranded
+        self.h = max(dbg_h, cbf_h)
+        self.pk_h = pk_h
+        self.g = self.L.rbo_graph_new(dbgbf_bits, cbf_bytes, pkbf_bits, dbg_h, cbf_h, pk_h, k,
+                                      int(stranded), int(use_read_pairs), rng_seed)
+
+    def __del__(self):
+        if getattr(self, "g", None):
+            self.L.rbo_graph_free(self.g)
+            self.g = None
+
+    def clear(self):
+        self.L.rbo_graph_clear(self.g)
+
+    def set_read_pair_distance(self, d):
+        self.L.rbo_graph_set_read_pair_distance(self.g, d)
+
+    def init_fragment_pairs(self, bits, pk_h, d):
+        self.L.rbo_graph_init_fragment_pairs(self.g, bits, pk_h, d)
+
+    def _h(self, h):
+        a = np.ascontiguousarray(h, np.uint64)
+        return a
+
+    def add(self, h):
+        a = self._h(h); self.L.rbo_graph_add(self.g, _p(a))
+
+    def add_if_absent(self, h):
+        a = self._h(h); self.L.rbo_graph_add_if_absent(self.g, _p(a))
+
+    def add_count_if_present(self, h):
+        a = self._h(h); self.L.rbo_graph_add_count_if_present(self.g, _p(a))
+
+    def add_dbg_only(self, h):
+        a = self._h(h); self.L.rbo_graph_add_dbg_only(self.g, _p(a))
+
+    def add_count_only(self, h):
+        a = self._h(h); self.L.rbo_graph_add_count_only(self.g, _p(a))
+
+    def add_read_pair(self, h):
+        a = self._h(h); self.L.rbo_graph_add_read_pair(self.g, _p(a))
+
+    def contains(self, h):
+        a = self._h(h); return bool(self.L.rbo_graph_contains(self.g, _p(a)))
+
+    def get_count(self, h):
+        a = self._h(h); return float(self.L.rbo_graph_get_count(self.g, _p(a)))
+
+    def lookup_read_pair(self, h):
+        a = self._h(h); return bool(self.L.rbo_graph_lookup_read_pair(self.g, _p(a)))
+
+    def add_reads(self, seq, qual, offsets, min_q=3, flags=0, threads=1):
+        st = AddStats()
+        n = len(offsets) - 1
+        self.L.rbo_graph_add_reads_mt(self.g, _p(seq), _p(qual), _p(offsets), n, min_q, flags,
+                                      threads, C.byref(st))
+        return st
+
+    def _bloom_bytes(self, which):
+        b = getattr(self.L, "rbo_graph_" + which)(self.g)
+        if not b:
+            return None
+        n = C.c_int64()
+        p = self.L.rbo_bloom_bytes(b, C.byref(n))
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (n.value,)).copy()
+
+    def dbgbf_bytes(self):
+        return self._bloom_bytes("dbgbf")
+
+    def rpkbf_bytes(self):
+        return self._bloom_bytes("rpkbf")
+
+    def fpkbf_bytes(self):
+        return self._bloom_bytes("fpkbf")
+
+    def cbf_bytes(self):
+        c = self.L.rbo_graph_cbf(self.g)
+        n = C.c_int64()
+        p = self.L.rbo_cbf_bytes(c, C.byref(n))
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (n.value,)).copy()
+
+    def popcounts(self):
+        L = self.L
+        r = L.rbo_graph_rpkbf(self.g)
+        return (L.rbo_bloom_popcount(L.rbo_graph_dbgbf(self.g)), L.rbo_cbf_popcount(L.rbo_graph_cbf(self.g)),
+                L.rbo_bloom_popcount(r) if r else 0)
+
+    def fprs(self):
+        L = self.L
+        r = L.rbo_graph_rpkbf(self.g)
+        return (L.rbo_bloom_fpr(L.rbo_graph_dbgbf(self.g)), L.rbo_cbf_fpr(L.rbo_graph_cbf(self.g)),
+                L.rbo_bloom_fpr(r) if r else 0.0)
+
+    def get_kmers(self, seq):
+        seq = _b(seq)
+        n = max(0, len(seq) - self.k + 1)
+        f = np.zeros(n, np.uint64); r = np.zeros(n, np.uint64); c = np.zeros(n, np.float32)
+        sb = C.create_string_buffer(seq, len(seq))
+        got = self.L.rbo_graph_get_kmers(self.g, C.cast(sb, C.c_void_p), len(seq), _p(f), _p(r), _p(c))
+        assert got == n
+        return f, r, c
+
+    def neighbors(self, f, r, char_out, direction):
+        of = np.zeros(4, np.uint64); orr = np.zeros(4, np.uint64); c = np.zeros(4, np.float32)
+        self.L.rbo_graph_neighbors(self.g, int(f), int(r), char_out, direction, _p(of), _p(orr), _p(c))
+        return of, orr, c
