@@ -1,0 +1,198 @@
+/*
+ * rb_capi.h — C ABI of librb_hip.so, the MI355X (gfx950) implementation of RNA-Bloom's k-mer
+ * hashing / Bloom-filter de Bruijn graph hot path.
+ *
+ * This is the drop-in boundary: plain C, opaque handles, host pointers + sizes, int status codes
+ * (0 = RB_OK; message via rb_last_error()).  The reference (bcgsc/RNA-Bloom v2.0.1, Java) has no
+ * FFI seam of its own; the entry points below are what a JNI shim for
+ * rnabloom.bloom.{BloomFilter,CountingBloomFilter}, rnabloom.bloom.hash.* and
+ * rnabloom.graph.BloomFilterDeBruijnGraph would bind (INTEGRATION.md shows that shim).  Each
+ * declaration cites the reference method(s) it replaces; R/ = src/rnabloom/ in the reference tree.
+ *
+ * Semantics are those of the reference run with ONE worker thread (-t 1): filters end up exactly as
+ * if the reads had been processed one after another, k-mers left to right.
+ * All entry points are synchronous: when they return, results are visible to the next call.
+ */
+#ifndef RB_CAPI_H
+#define RB_CAPI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RB_OK 0
+#define RB_ERR_INVALID 1   /* bad argument                    (Java: IllegalArgumentException) */
+#define RB_ERR_HIP 2       /* HIP runtime / device failure    (Java: RuntimeException)         */
+#define RB_ERR_NOMEM 3     /* device or host allocation failed (Java: OutOfMemoryError)        */
+#define RB_ERR_STATE 4     /* filter not initialised etc.     (Java: NullPointerException path) */
+
+typedef struct rb_graph rb_graph; /* BloomFilterDeBruijnGraph + its 4 filters, device resident */
+typedef struct rb_batch rb_batch; /* a batch of reads, device resident, 2-bit packed          */
+
+/* which-filter selectors: R/graph/BloomFilterDeBruijnGraph.java:39-43 */
+enum { RB_DBGBF = 0, RB_CBF = 1, RB_RPKBF = 2, RB_FPKBF = 3 };
+
+/* BloomFilterDeBruijnGraph(long dbgbfNumBits, long cbfNumBytes, long pkbfNumBits, int dbgbfNumHash,
+ *   int cbfNumHash, int pkbfNumHash, int k, boolean stranded, boolean useReadPairedKmers)
+ * R/graph/BloomFilterDeBruijnGraph.java:75-104 */
+typedef struct rb_graph_params {
+    int64_t dbgbf_bits;           /* dbgbfNumBits  (any positive long, not a power of two) */
+    int64_t cbf_bytes;            /* cbfNumBytes                                             */
+    int64_t pkbf_bits;            /* pkbfNumBits   (rpkbf; fpkbf via rb_graph_init_fragment_pairs) */
+    int32_t dbgbf_num_hash;       /* 1..RB_MAX_HASH */
+    int32_t cbf_num_hash;
+    int32_t pkbf_num_hash;
+    int32_t k;                    /* 1..RB_MAX_K */
+    int32_t stranded;             /* 0 => CanonicalHashFunction, 1 => HashFunction            */
+    int32_t use_read_paired_kmers;
+    int32_t device;               /* HIP device ordinal                                       */
+    int32_t reserved0;
+    uint64_t rng_seed;            /* seed of the counter-based generator that replaces the
+                                     unseeded Math.random() of R/util/MiniFloat.java:34        */
+    int64_t max_batch_kmers;      /* 0 = default; upper bound on k-mers per internal sub-batch */
+} rb_graph_params;
+
+#define RB_MAX_HASH 8
+#define RB_MAX_K 256
+
+/* flags of rb_graph_add_* : constructor arguments of the stage-1 workers,
+ * R/RNABloom.java:535-548 (FastqToGraphWorker) / :655-668 (FastaToGraphWorker) */
+#define RB_ADD_REVCOMP 1u          /* reverseComplement: RC iterators (no-op when !stranded,
+                                      R/bloom/hash/CanonicalHashFunction.java:188-206)          */
+#define RB_ADD_COUNT_IF_PRESENT 2u /* incrementIfPresent: graph::addCountIfPresent             */
+#define RB_ADD_STORE_READ_PAIRS 4u /* storeReadPairedKmers: graph.addReadSingleKmerPair        */
+
+typedef struct rb_add_stats {
+    int64_t reads;    /* reads consumed (each takes one op ordinal)                 */
+    int64_t kmers;    /* graph.add / addCountIfPresent calls performed              */
+    int64_t pairs;    /* graph.addReadSingleKmerPair calls performed                */
+    int64_t distinct; /* distinct k-mer hashes seen per sub-batch, summed           */
+    int64_t conflict_ops; /* ops replayed in order because they shared a counter with another k-mer */
+} rb_add_stats;
+
+const char *rb_last_error(void); /* thread-local message of the last failing call */
+int rb_version(void);
+
+/* ---- graph lifetime: ctor :75-104, destroyXxx / clearXxx :332-350 (explicit off-heap lifetime,
+ *      R/bloom/buffer/UnsafeByteBuffer.java:44,152-155) ---- */
+int rb_graph_create(const rb_graph_params *p, rb_graph **out);
+int rb_graph_destroy(rb_graph *g);
+int rb_graph_clear(rb_graph *g, unsigned which_mask /* bit i = filter i; also resets the op ordinal when all */);
+/* setReadPairedKmerDistance :375-377, setFragPairedKmerDistance :367-369 */
+int rb_graph_set_read_paired_kmer_distance(rb_graph *g, int d);
+int rb_graph_set_frag_paired_kmer_distance(rb_graph *g, int d);
+/* initializePairKmersBloomFilter(long pkbfNumBits, int pkbfNumHash) :352-359 */
+int rb_graph_init_fragment_pairs(rb_graph *g, int64_t pkbf_bits, int pkbf_num_hash);
+int rb_graph_get_op_ordinal(rb_graph *g, uint64_t *out);
+int rb_graph_set_op_ordinal(rb_graph *g, uint64_t v);
+
+/* ---- read batches (the build's counterpart of FastqReader/FastaReader + the per-read regex
+ *      segmentation of R/RNABloom.java:572-577, R/util/SeqUtils.java:1432-1438) ----
+ * seq: concatenated ASCII bases; qual: concatenated PHRED+33 or NULL (FASTA: no quality pass);
+ * offsets[n_reads+1]: read i = seq[offsets[i], offsets[i+1]).  A base is usable iff it is one of
+ * ACGTUacgtu and (qual == NULL or '!'+min_base_qual <= qual <= '~').  Encoding to the packed
+ * device format (2-bit codes + validity bit per base) runs on the GPU. */
+int rb_batch_create_ascii(int device, const char *seq, const char *qual, const int64_t *offsets,
+                          int64_t n_reads, int min_base_qual, rb_batch **out);
+int rb_batch_destroy(rb_batch *b);
+int rb_batch_info(const rb_batch *b, int64_t *n_reads, int64_t *n_bases, int64_t *device_bytes);
+/* copy reads [first, first+n) back as ASCII with 'N' at unusable positions (for checkers) */
+int rb_batch_download_ascii(const rb_batch *b, int64_t first, int64_t n, char *seq /* len = sum of lens */,
+                            int64_t *offsets /* n+1 */);
+/* synthetic paired-end reads generated on the device (bench data; SURVEY.md §8(d) model).
+ * Produces 2*n_pairs reads: left reads 0..n_pairs-1 then right reads (as sequenced). */
+typedef struct rb_synth_params {
+    int64_t n_pairs;
+    int64_t genome_bases;   /* G */
+    int32_t read_len;       /* 150 */
+    int32_t frag_mean, frag_sd;
+    float sub_rate;         /* substitution errors (error bases are masked unusable, like PHRED 2) */
+    float n_rate;
+    float expr_sigma;       /* log-normal sigma; 0 => uniform expression */
+    uint64_t seed;
+    int32_t tx_min, tx_max; /* transcript length range */
+} rb_synth_params;
+int rb_batch_create_synthetic(int device, const rb_synth_params *p, rb_batch **out);
+
+/* ---- stage-1 insert: FastqToGraphWorker.run R/RNABloom.java:551-634 /
+ *      FastaToGraphWorker.run :672-724, i.e. per k-mer graph.add (BloomFilterDeBruijnGraph.java:405-412)
+ *      or addCountIfPresent (:424-428), per paired k-mer addReadSingleKmerPair (:455-457) ---- */
+int rb_graph_add_batch(rb_graph *g, const rb_batch *b, unsigned flags, rb_add_stats *stats);
+/* reads [first, first+n) of the batch only */
+int rb_graph_add_batch_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigned flags,
+                             rb_add_stats *stats);
+/* convenience: rb_batch_create_ascii + rb_graph_add_batch + rb_batch_destroy */
+int rb_graph_add_reads(rb_graph *g, const char *seq, const char *qual, const int64_t *offsets,
+                       int64_t n_reads, int min_base_qual, unsigned flags, rb_add_stats *stats);
+
+/* ---- per-hash mutators (h0 = hashVals[0]; the library expands it with NTM64 using the graph's k,
+ *      R/bloom/hash/NTHash.java:518-527).  n ops are applied in array order; each takes one op
+ *      ordinal.  op = one of RB_OP_*. ---- */
+enum {
+    RB_OP_ADD = 0,              /* add(long[])              :405-412 */
+    RB_OP_ADD_IF_ABSENT = 1,    /* addIfAbsent              :414-422 */
+    RB_OP_ADD_COUNT_IF_PRESENT = 2, /* addCountIfPresent    :424-428 */
+    RB_OP_ADD_DBG_ONLY = 3,     /* addDbgOnly               :430-436 */
+    RB_OP_ADD_COUNT_ONLY = 4,   /* addCountOnly             :438-440 */
+    RB_OP_ADD_READ_PAIR = 5,    /* addReadSingleKmerPair    :455-457 (h0 = pair hash) */
+    RB_OP_ADD_FRAG_PAIR = 6     /* addFragmentSingleKmerPair:459-461 */
+};
+int rb_graph_apply(rb_graph *g, int op, const uint64_t *h0, size_t n);
+
+/* ---- queries ---- */
+/* contains(long[]) :538-540 -> dbgbf.lookup R/bloom/BloomFilter.java:170-178 */
+int rb_graph_contains(rb_graph *g, const uint64_t *h0, size_t n, uint8_t *out);
+/* getCount(long[]) :562-570 = dbgbf.lookup ? cbf.getCount + 1 : 0 */
+int rb_graph_count(rb_graph *g, const uint64_t *h0, size_t n, float *out);
+/* BloomFilter.lookup(long) on any bit filter / CountingBloomFilter.getCount(long) :231-233 */
+int rb_filter_lookup(rb_graph *g, int which, const uint64_t *h0, size_t n, uint8_t *out);
+int rb_filter_get_count(rb_graph *g, const uint64_t *h0, size_t n, float *out);
+/* getKmers(String) :1224-1226 -> {Canonical,}HashFunction.getKmers: for every window of every
+ * read of the batch: forward hash, reverse hash (0 when stranded), count (0 for windows that
+ * contain a non-ACGTU base).  koffsets[n_reads+1] receives the per-read output offsets
+ * (read i has max(0,len_i-k+1) windows); pass f=r=count=NULL to query sizes only. */
+int rb_graph_kmers(rb_graph *g, const char *seq, const int64_t *offsets, int64_t n_reads,
+                   int64_t *koffsets, uint64_t *f, uint64_t *r, float *count);
+/* Kmer.getSuccessors/getPredecessors R/graph/Kmer.java:210-255, CanonicalKmer.java:226-270:
+ * for each (f, r, char_out) the 4 neighbours in order A,C,G,T: forward hash, reverse hash and
+ * graph.getCount.  direction 0 = successors (char_out = first base), 1 = predecessors
+ * (char_out = last base).  Callers apply their minKmerCov threshold to count4. */
+int rb_graph_neighbors(rb_graph *g, const uint64_t *f, const uint64_t *r, const uint8_t *char_out,
+                       size_t n, int direction, uint64_t *f4, uint64_t *r4, float *count4);
+
+/* ---- filter state: popcount / FPR / raw bytes (the on-disk format of
+ *      R/bloom/BloomFilter.java:113-124 is exactly these bytes,
+ *      R/bloom/buffer/UnsafeByteBuffer.java:160-201) ---- */
+int rb_filter_size(rb_graph *g, int which, int64_t *size /* bits or bytes */, int64_t *nbytes, int *num_hash);
+/* bit filters: set bits (UnsafeByteBuffer.bitPopCount :131-150); cbf: non-zero bytes (:121-129) */
+int rb_filter_popcount(rb_graph *g, int which, int64_t *out);
+int rb_filter_fpr(rb_graph *g, int which, float *out); /* BloomFilter.getFPR :185-194 */
+int rb_filter_export(rb_graph *g, int which, void *dst, size_t nbytes);
+int rb_filter_import(rb_graph *g, int which, const void *src, size_t nbytes);
+int64_t rb_expected_size(int64_t n, float fpr, int num_hash); /* BloomFilter.getExpectedSize :196-199 */
+
+/* ---- hash-only test hook: {,Canonical,ReverseComplement}NTHashIterator over every usable
+ *      segment of every read of a batch.  mode 0 fwd, 1 canonical, 2 reverse-complement.
+ *      out_h0[count] in read order; out_read/out_pos optional.  Call with out_h0 == NULL to get
+ *      the count. ---- */
+int rb_nthash_batch(const rb_batch *b, int k, int mode, int64_t first, int64_t n, int64_t *count,
+                    uint64_t *out_h0, uint32_t *out_read, uint32_t *out_pos);
+
+/* ---- instrumentation: per-kernel-class HIP-event timing on the library's own stream ---- */
+#define RB_PROF_MAX 32
+typedef struct rb_profile {
+    int32_t n;
+    const char *name[RB_PROF_MAX];
+    double ms[RB_PROF_MAX];        /* accumulated since last reset */
+    int64_t launches[RB_PROF_MAX];
+} rb_profile;
+int rb_graph_profile_enable(rb_graph *g, int on);
+int rb_graph_profile_get(rb_graph *g, rb_profile *out, int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,511 @@
+// rb_batch.hip — device-resident read batches: ASCII -> packed 2-bit + validity encode, synthetic
+// read generation, download, and the window-hash kernels (ntHash over every usable segment).
+//
+// Replaces, for the hot path: FastqReader/FastaReader record fetch + the regex segmentation of
+// R/RNABloom.java:572-577 (R/util/SeqUtils.java:1432-1438) + {,Canonical,ReverseComplement}
+// NTHashIterator (R/bloom/hash/NTHashIterator.java:45-69 etc.).  A k-mer window is hashed iff all
+// of its k bases are usable, which is exactly the set of windows the nested regex runs yield.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "rb_internal.hpp"
+#include "rb_kernels.hpp"
+
+using namespace rb;
+
+namespace {
+
+constexpr int TPB = 256;
+inline unsigned blocks_for(int64_t n, int tpb = TPB) { return (unsigned)((n + tpb - 1) / tpb); }
+
+// ---------------------------------------------------------------- encode ----
+__global__ void k_encode_ascii(const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual,
+                               const int64_t *__restrict__ off, const uint32_t *__restrict__ woff,
+                               int64_t n_reads, int64_t n_words, int min_q,
+                               uint64_t *__restrict__ codes, uint32_t *__restrict__ valid,
+                               uint32_t *__restrict__ word_read) {
+    int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_words) return;
+    // owning read: largest r with woff[r] <= w  (reads with zero words are skipped automatically)
+    int64_t lo = 0, hi = n_reads;   // invariant woff[lo] <= w < woff[hi]
+    while (hi - lo > 1) {
+        int64_t mid = (lo + hi) >> 1;
+        if (woff[mid] <= (uint32_t)w) lo = mid; else hi = mid;
+    }
+    const int64_t r = lo;
+    const int64_t base0 = off[r], len = off[r + 1] - base0;
+    const int64_t b0 = (w - woff[r]) * 32;
+    uint64_t c = 0;
+    uint32_t v = 0;
+    for (int i = 0; i < 32; ++i) {
+        int64_t b = b0 + i;
+        if (b >= len) break;
+        uint32_t ch = seq[base0 + b];
+        uint32_t code = 4;
+        switch (ch) {   // [ACGTU], CASE_INSENSITIVE  (R/util/SeqUtils.java:1436-1438)
+            case 'A': case 'a': code = 0; break;
+            case 'C': case 'c': code = 1; break;
+            case 'G': case 'g': code = 2; break;
+            case 'T': case 't': case 'U': case 'u': code = 3; break;
+            default: break;
+        }
+        bool ok = code < 4;
+        if (qual) {     // PHRED33.substring(minQual): '!'+minQual .. '~'  (SeqUtils.java:1426-1434)
+            uint32_t q = qual[base0 + b];
+            ok = ok && (q >= (uint32_t)(33 + min_q)) && (q <= (uint32_t)'~');
+        }
+        if (ok) {
+            c |= (uint64_t)code << (2 * i);
+            v |= 1u << i;
+        }
+    }
+    codes[w] = c;
+    valid[w] = v;
+    word_read[w] = (uint32_t)r;
+}
+
+__global__ void k_decode_ascii(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
+                               const uint32_t *__restrict__ word_read, const uint32_t *__restrict__ woff,
+                               const uint32_t *__restrict__ len, int64_t w0, int64_t nw,
+                               const int64_t *__restrict__ out_off, uint32_t first_read,
+                               uint8_t *__restrict__ out) {
+    int64_t w = w0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= w0 + nw) return;
+    uint32_t r = word_read[w];
+    uint32_t b0 = (uint32_t)(w - woff[r]) * 32u, L = len[r];
+    uint64_t c = codes[w];
+    uint32_t v = valid[w];
+    uint8_t *dst = out + out_off[r - first_read];
+    for (uint32_t i = 0; i < 32 && b0 + i < L; ++i)
+        dst[b0 + i] = ((v >> i) & 1u) ? (uint8_t)("ACGT"[(c >> (2 * i)) & 3]) : (uint8_t)'N';
+}
+
+// ------------------------------------------------------------- synthetic ----
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ void k_synth_genome(uint64_t *g, int64_t n_words, uint64_t seed) {
+    int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w < n_words) g[w] = mix64(seed ^ ((uint64_t)w * 0xD1B54A32D192ED03ull));
+}
+__device__ __forceinline__ uint32_t genome_base(const uint64_t *g, int64_t i) {
+    return (uint32_t)(g[i >> 5] >> (2 * (i & 31))) & 3u;
+}
+__global__ void k_synth_reads(const uint64_t *__restrict__ genome, const int64_t *__restrict__ tstart,
+                              const int32_t *__restrict__ tlen, const float *__restrict__ cdf,
+                              int n_tx, int64_t n_pairs, int L, int words_per_read, float frag_mean,
+                              float frag_sd, float sub_rate, float n_rate, uint64_t seed,
+                              uint64_t *__restrict__ codes, uint32_t *__restrict__ valid,
+                              uint32_t *__restrict__ word_read) {
+    int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t n_words = 2 * n_pairs * words_per_read;
+    if (w >= n_words) return;
+    int64_t r = w / words_per_read;
+    int c = (int)(w - r * words_per_read);
+    bool right = r >= n_pairs;
+    int64_t p = right ? r - n_pairs : r;
+    uint64_t s0 = mix64(seed ^ ((uint64_t)p * 0x9E3779B97F4A7C15ull));
+    uint64_t s1 = mix64(s0), s2 = mix64(s1), s3 = mix64(s2);
+    float u0 = (float)(s0 >> 40) * (1.0f / 16777216.0f);
+    int lo = 0, hi = n_tx - 1;   // first t with cdf[t] > u0
+    while (lo < hi) {
+        int mid = (lo + hi) >> 1;
+        if (cdf[mid] > u0) hi = mid; else lo = mid + 1;
+    }
+    int t = lo;
+    float u1 = ((float)(s1 >> 40) + 0.5f) * (1.0f / 16777216.0f);
+    float u2 = (float)(s2 >> 40) * (1.0f / 16777216.0f);
+    float nrm = sqrtf(-2.0f * logf(u1)) * cosf(6.2831853f * u2);
+    int flen = (int)rintf(frag_mean + frag_sd * nrm);
+    int tl = tlen[t];
+    flen = flen < L ? L : flen;
+    flen = flen > tl ? tl : flen;
+    double u3 = (double)(s3 >> 11) * (1.0 / 9007199254740992.0);
+    int64_t fstart = tstart[t] + (int64_t)(u3 * (double)(tl - flen + 1));
+    uint64_t cw = 0;
+    uint32_t vw = 0;
+    for (int i = 0; i < 32; ++i) {
+        int b = c * 32 + i;
+        if (b >= L) break;
+        uint32_t code = right ? 3u - genome_base(genome, fstart + flen - 1 - b)
+                              : genome_base(genome, fstart + b);
+        uint64_t e = mix64(seed ^ 0xA5A5A5A5ull ^ ((uint64_t)r * 0xC2B2AE3D27D4EB4Full) ^ (uint64_t)b);
+        float ue = (float)(e >> 40) * (1.0f / 16777216.0f);
+        float un = (float)((e >> 16) & 0xFFFFFFu) * (1.0f / 16777216.0f);
+        bool ok = true;
+        if (ue < sub_rate) { code = (code + 1u + (uint32_t)(e & 0xFFFFu) % 3u) & 3u; ok = false; }
+        if (un < n_rate) ok = false;
+        cw |= (uint64_t)code << (2 * i);
+        if (ok) vw |= 1u << i;
+    }
+    codes[w] = cw;
+    valid[w] = vw;
+    word_read[w] = (uint32_t)r;
+}
+
+struct HostGuard {   // frees partially built batches on exceptions
+    rb_batch *b;
+    ~HostGuard() { if (b) rb_batch_destroy(b); }
+};
+
+void alloc_batch_arrays(rb_batch *b) {
+    size_t nw = (size_t)std::max<int64_t>(b->n_words, 1), nr = (size_t)std::max<int64_t>(b->n_reads, 1);
+    RB_HIP(hipMalloc(&b->codes, nw * 8));
+    RB_HIP(hipMalloc(&b->valid, nw * 4));
+    RB_HIP(hipMalloc(&b->word_read, nw * 4));
+    RB_HIP(hipMalloc(&b->woff, (nr + 1) * 4));
+    RB_HIP(hipMalloc(&b->len, nr * 4));
+    b->device_bytes = nw * 16 + (nr + 1) * 4 + nr * 4;
+}
+
+}  // namespace
+
+// --------------------------------------------------------------- window kernels ----
+namespace rb {
+
+__global__ void k_count_windows(const uint32_t *__restrict__ valid, const uint32_t *__restrict__ word_read,
+                                const uint32_t *__restrict__ woff, const uint32_t *__restrict__ len,
+                                int64_t w0, int64_t nw, int span, uint32_t *__restrict__ cnt) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nw) return;
+    int64_t w = w0 + i;
+    uint32_t r = word_read[w];
+    uint32_t wr = woff[r];
+    uint32_t L = len[r];
+    uint32_t b0 = (uint32_t)(w - wr) * 32u;
+    uint32_t n = 0;
+    if ((uint64_t)b0 + (uint64_t)span <= L) {
+        uint64_t bend64 = (uint64_t)b0 + 32u + (uint64_t)span - 1u;
+        uint32_t bend = bend64 < L ? (uint32_t)bend64 : L;
+        uint32_t run = 0, cur = 0;
+        for (uint32_t b = b0; b < bend; ++b) {
+            if ((b & 31u) == 0) cur = valid[wr + (b >> 5)];
+            run = ((cur >> (b & 31u)) & 1u) ? run + 1u : 0u;
+            n += run >= (uint32_t)span;
+        }
+    }
+    cnt[i] = n;
+}
+
+template <int MODE>
+__global__ void k_hash_windows(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
+                               const uint32_t *__restrict__ word_read, const uint32_t *__restrict__ woff,
+                               const uint32_t *__restrict__ len, int64_t w0, int64_t nw, int k,
+                               const uint32_t *__restrict__ chunk_off, uint32_t first_read,
+                               uint32_t pos_bits, uint64_t *__restrict__ keys,
+                               uint32_t *__restrict__ vals, uint32_t *__restrict__ out_read,
+                               uint32_t *__restrict__ out_pos) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nw) return;
+    int64_t w = w0 + i;
+    const uint32_t r = word_read[w];
+    const uint32_t wr = woff[r];
+    const uint32_t L = len[r];
+    const uint32_t b0 = (uint32_t)(w - wr) * 32u;
+    if ((uint64_t)b0 + (uint64_t)k > L) return;
+    const uint64_t bend64 = (uint64_t)b0 + 32u + (uint64_t)k - 1u;
+    const uint32_t bend = bend64 < L ? (uint32_t)bend64 : L;
+    const uint64_t *cw = codes + wr;
+    const uint32_t *vw = valid + wr;
+    uint32_t out = chunk_off[i];
+    uint32_t run = 0, cur_v = 0;
+    uint64_t cur_c = 0, f = 0, rv = 0;
+    const uint32_t uk = (uint32_t)k;
+    for (uint32_t b = b0; b < bend; ++b) {
+        if ((b & 31u) == 0) { cur_c = cw[b >> 5]; cur_v = vw[b >> 5]; }
+        if (!((cur_v >> (b & 31u)) & 1u)) { run = 0; f = 0; rv = 0; continue; }
+        const uint32_t code = (uint32_t)(cur_c >> (2u * (b & 31u))) & 3u;
+        if (run < uk) {
+            // growing window: f = rotl(f,1)^seed(in) ; r ^= rotl(seedc(in), index) — after k bases
+            // these equal NTP64 / NTP64RC from scratch (R/bloom/hash/NTHash.java:332-337,367-373)
+            if (MODE != 2) f = rotl(f, 1) ^ seed_of(code);
+            if (MODE != 0) rv ^= rotl(seed_of(3u - code), run);
+            ++run;
+        } else {
+            const uint32_t bo = b - uk;
+            const uint32_t oc = (uint32_t)(cw[bo >> 5] >> (2u * (bo & 31u))) & 3u;
+            // rolling: NTHash.java:491-495 / :584-586 / :627-629
+            if (MODE != 2) f = rotl(f, 1) ^ rotl(seed_of(oc), uk) ^ seed_of(code);
+            if (MODE != 0) rv = rotr(rv, 1) ^ rotr(seed_of(3u - oc), 1) ^ rotl(seed_of(3u - code), uk - 1u);
+        }
+        if (run >= uk) {
+            const uint32_t p = b - uk + 1u;
+            uint64_t h0 = (MODE == 0) ? f : (MODE == 2) ? rv : canonical(f, rv);
+            keys[out] = h0;
+            if (vals) vals[out] = ((r - first_read) << pos_bits) | p;
+            if (out_read) { out_read[out] = r; out_pos[out] = p; }
+            ++out;
+        }
+    }
+}
+
+void launch_count_windows(const rb_batch *b, int64_t w0, int64_t nw, int span, uint32_t *cnt, hipStream_t s) {
+    if (nw <= 0) return;
+    hipLaunchKernelGGL(k_count_windows, dim3(blocks_for(nw)), dim3(TPB), 0, s, b->valid, b->word_read,
+                       b->woff, b->len, w0, nw, span, cnt);
+}
+void launch_hash_windows(const rb_batch *b, int64_t w0, int64_t nw, int k, int mode,
+                         const uint32_t *chunk_off, uint32_t first_read, uint32_t pos_bits,
+                         uint64_t *keys, uint32_t *vals, uint32_t *out_read, uint32_t *out_pos,
+                         hipStream_t s) {
+    if (nw <= 0) return;
+    dim3 g(blocks_for(nw)), t(TPB);
+#define RB_LAUNCH_HASH(M)                                                                        \
+    hipLaunchKernelGGL(k_hash_windows<M>, g, t, 0, s, b->codes, b->valid, b->word_read, b->woff, \
+                       b->len, w0, nw, k, chunk_off, first_read, pos_bits, keys, vals, out_read, out_pos)
+    if (mode == 0) RB_LAUNCH_HASH(0);
+    else if (mode == 2) RB_LAUNCH_HASH(2);
+    else RB_LAUNCH_HASH(1);
+#undef RB_LAUNCH_HASH
+}
+
+}  // namespace rb
+
+// ------------------------------------------------------------------- C ABI ----
+extern "C" {
+
+int rb_batch_destroy(rb_batch *b) {
+    if (!b) return RB_OK;
+    (void)hipSetDevice(b->device);
+    if (b->codes) (void)hipFree(b->codes);
+    if (b->valid) (void)hipFree(b->valid);
+    if (b->word_read) (void)hipFree(b->word_read);
+    if (b->woff) (void)hipFree(b->woff);
+    if (b->len) (void)hipFree(b->len);
+    delete b;
+    return RB_OK;
+}
+
+int rb_batch_info(const rb_batch *b, int64_t *n_reads, int64_t *n_bases, int64_t *device_bytes) {
+    if (!b) { set_error("rb_batch_info: null batch"); return RB_ERR_INVALID; }
+    if (n_reads) *n_reads = b->n_reads;
+    if (n_bases) *n_bases = b->n_bases;
+    if (device_bytes) *device_bytes = (int64_t)b->device_bytes;
+    return RB_OK;
+}
+
+int rb_batch_create_ascii(int device, const char *seq, const char *qual, const int64_t *offsets,
+                          int64_t n_reads, int min_base_qual, rb_batch **out) {
+    try {
+        RB_REQUIRE(out && offsets && n_reads >= 0 && (seq || n_reads == 0 || offsets[n_reads] == offsets[0]),
+                   "rb_batch_create_ascii: null argument");
+        RB_REQUIRE(min_base_qual >= 0 && min_base_qual < 94, "rb_batch_create_ascii: min_base_qual out of range");
+        RB_HIP(hipSetDevice(device));
+        rb_batch *b = new rb_batch();
+        HostGuard guard{b};
+        b->device = device;
+        b->n_reads = n_reads;
+        std::vector<uint32_t> woff((size_t)n_reads + 1), len((size_t)std::max<int64_t>(n_reads, 1));
+        uint64_t words = 0;
+        uint32_t max_len = 0;
+        for (int64_t i = 0; i < n_reads; ++i) {
+            int64_t l = offsets[i + 1] - offsets[i];
+            RB_REQUIRE(l >= 0 && l < (int64_t)1 << 30, "rb_batch_create_ascii: read %lld has invalid length", (long long)i);
+            woff[(size_t)i] = (uint32_t)words;
+            len[(size_t)i] = (uint32_t)l;
+            words += (uint64_t)((l + 31) / 32);
+            RB_REQUIRE(words < 0xFFFFFFF0ull, "rb_batch_create_ascii: batch too large (> 2^32 words)");
+            max_len = std::max(max_len, (uint32_t)l);
+        }
+        woff[(size_t)n_reads] = (uint32_t)words;
+        b->n_words = (int64_t)words;
+        b->max_len = max_len;
+        const int64_t base0 = n_reads ? offsets[0] : 0;
+        b->n_bases = n_reads ? offsets[n_reads] - base0 : 0;
+        alloc_batch_arrays(b);
+        RB_HIP(hipMemcpy(b->woff, woff.data(), ((size_t)n_reads + 1) * 4, hipMemcpyHostToDevice));
+        b->h_woff = woff;
+        if (n_reads) RB_HIP(hipMemcpy(b->len, len.data(), (size_t)n_reads * 4, hipMemcpyHostToDevice));
+        if (words) {
+            uint8_t *d_seq = nullptr, *d_qual = nullptr;
+            int64_t *d_off = nullptr;
+            size_t nb = (size_t)b->n_bases;
+            RB_HIP(hipMalloc(&d_seq, std::max<size_t>(nb, 1)));
+            try {
+                RB_HIP(hipMemcpy(d_seq, seq + base0, nb, hipMemcpyHostToDevice));
+                if (qual) {
+                    RB_HIP(hipMalloc(&d_qual, std::max<size_t>(nb, 1)));
+                    RB_HIP(hipMemcpy(d_qual, qual + base0, nb, hipMemcpyHostToDevice));
+                }
+                std::vector<int64_t> rel((size_t)n_reads + 1);
+                for (int64_t i = 0; i <= n_reads; ++i) rel[(size_t)i] = offsets[i] - base0;
+                RB_HIP(hipMalloc(&d_off, ((size_t)n_reads + 1) * 8));
+                RB_HIP(hipMemcpy(d_off, rel.data(), ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice));
+                hipLaunchKernelGGL(k_encode_ascii, dim3(blocks_for((int64_t)words)), dim3(TPB), 0, 0, d_seq,
+                                   d_qual, d_off, b->woff, n_reads, (int64_t)words, min_base_qual, b->codes,
+                                   b->valid, b->word_read);
+                RB_HIP(hipGetLastError());
+                RB_HIP(hipDeviceSynchronize());
+            } catch (...) {
+                (void)hipFree(d_seq); if (d_qual) (void)hipFree(d_qual); if (d_off) (void)hipFree(d_off);
+                throw;
+            }
+            (void)hipFree(d_seq); if (d_qual) (void)hipFree(d_qual); (void)hipFree(d_off);
+        }
+        guard.b = nullptr;
+        *out = b;
+        return RB_OK;
+    } catch (const HipError &e) { return e.code; }
+    catch (const std::bad_alloc &) { set_error("host allocation failed"); return RB_ERR_NOMEM; }
+}
+
+int rb_batch_download_ascii(const rb_batch *b, int64_t first, int64_t n, char *seq, int64_t *offsets) {
+    try {
+        RB_REQUIRE(b && offsets && first >= 0 && n >= 0 && first + n <= b->n_reads, "rb_batch_download_ascii: bad range");
+        RB_HIP(hipSetDevice(b->device));
+        std::vector<uint32_t> len((size_t)std::max<int64_t>(n, 1)), woff(2);
+        if (n) RB_HIP(hipMemcpy(len.data(), b->len + first, (size_t)n * 4, hipMemcpyDeviceToHost));
+        offsets[0] = 0;
+        for (int64_t i = 0; i < n; ++i) offsets[i + 1] = offsets[i] + len[(size_t)i];
+        if (!n || !offsets[n] || !seq) return RB_OK;
+        RB_HIP(hipMemcpy(&woff[0], b->woff + first, 4, hipMemcpyDeviceToHost));
+        RB_HIP(hipMemcpy(&woff[1], b->woff + first + n, 4, hipMemcpyDeviceToHost));
+        int64_t *d_off = nullptr; uint8_t *d_out = nullptr;
+        RB_HIP(hipMalloc(&d_off, ((size_t)n + 1) * 8));
+        RB_HIP(hipMalloc(&d_out, (size_t)offsets[n]));
+        RB_HIP(hipMemcpy(d_off, offsets, ((size_t)n + 1) * 8, hipMemcpyHostToDevice));
+        int64_t nw = (int64_t)woff[1] - woff[0];
+        hipLaunchKernelGGL(k_decode_ascii, dim3(blocks_for(nw)), dim3(TPB), 0, 0, b->codes, b->valid,
+                           b->word_read, b->woff, b->len, (int64_t)woff[0], nw, d_off, (uint32_t)first, d_out);
+        hipError_t e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpy(seq, d_out, (size_t)offsets[n], hipMemcpyDeviceToHost);
+        (void)hipFree(d_off); (void)hipFree(d_out);
+        RB_HIP(e);
+        return RB_OK;
+    } catch (const HipError &e) { return e.code; }
+}
+
+int rb_batch_create_synthetic(int device, const rb_synth_params *p, rb_batch **out) {
+    try {
+        RB_REQUIRE(p && out && p->n_pairs > 0 && p->genome_bases >= 1024 && p->read_len > 0,
+                   "rb_batch_create_synthetic: bad parameters");
+        RB_REQUIRE(p->tx_min >= p->read_len && p->tx_max >= p->tx_min, "rb_batch_create_synthetic: transcript range must cover read_len");
+        RB_HIP(hipSetDevice(device));
+        // transcript table + expression CDF on the host (small)
+        uint64_t st = p->seed * 0x9E3779B97F4A7C15ull + 12345;
+        auto next = [&st]() { st += 0x9E3779B97F4A7C15ull; uint64_t z = st;
+            z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31); };
+        auto unif = [&next]() { return (double)(next() >> 11) * (1.0 / 9007199254740992.0); };
+        std::vector<int64_t> tstart; std::vector<int32_t> tlen;
+        int64_t pos = 0;
+        while (pos < p->genome_bases) {
+            int64_t l = p->tx_min + (int64_t)(unif() * (double)(p->tx_max - p->tx_min + 1));
+            if (pos + l > p->genome_bases) l = p->genome_bases - pos;
+            if (l < p->tx_min) { if (!tlen.empty()) tlen.back() += (int32_t)l; else { tstart.push_back(pos); tlen.push_back((int32_t)l); } break; }
+            tstart.push_back(pos); tlen.push_back((int32_t)l); pos += l;
+        }
+        RB_REQUIRE(!tlen.empty() && tlen[0] >= p->read_len, "rb_batch_create_synthetic: genome too small");
+        std::vector<double> wgt(tlen.size());
+        double tot = 0;
+        for (size_t i = 0; i < tlen.size(); ++i) {
+            double e = 1.0;
+            if (p->expr_sigma > 0) {
+                double u1 = std::max(unif(), 1e-300), u2 = unif();
+                e = exp((double)p->expr_sigma * sqrt(-2.0 * log(u1)) * cos(6.283185307179586 * u2));
+            }
+            wgt[i] = e * tlen[i]; tot += wgt[i];
+        }
+        std::vector<float> cdf(tlen.size());
+        double acc = 0;
+        for (size_t i = 0; i < tlen.size(); ++i) { acc += wgt[i] / tot; cdf[i] = (float)acc; }
+        cdf.back() = 2.0f;
+
+        rb_batch *b = new rb_batch();
+        HostGuard guard{b};
+        b->device = device;
+        b->n_reads = 2 * p->n_pairs;
+        int wpr = (p->read_len + 31) / 32;
+        RB_REQUIRE((uint64_t)b->n_reads * (uint64_t)wpr < 0xFFFFFFF0ull, "rb_batch_create_synthetic: batch too large");
+        b->n_words = b->n_reads * wpr;
+        b->n_bases = b->n_reads * p->read_len;
+        b->max_len = (uint32_t)p->read_len;
+        alloc_batch_arrays(b);
+        {   // woff / len are arithmetic progressions: fill from host in slabs
+            const size_t slab = 1 << 22;
+            std::vector<uint32_t> tmp(slab);
+            b->h_woff.resize((size_t)b->n_reads + 1);
+            for (size_t i = 0; i <= (size_t)b->n_reads; ++i) b->h_woff[i] = (uint32_t)(i * (size_t)wpr);
+            RB_HIP(hipMemcpy(b->woff, b->h_woff.data(), ((size_t)b->n_reads + 1) * 4, hipMemcpyHostToDevice));
+            std::fill(tmp.begin(), tmp.end(), (uint32_t)p->read_len);
+            for (size_t base = 0; base < (size_t)b->n_reads; base += slab) {
+                size_t m = std::min(slab, (size_t)b->n_reads - base);
+                RB_HIP(hipMemcpy(b->len + base, tmp.data(), m * 4, hipMemcpyHostToDevice));
+            }
+        }
+        uint64_t *d_genome = nullptr; int64_t *d_ts = nullptr; int32_t *d_tl = nullptr; float *d_cdf = nullptr;
+        int64_t gw = (p->genome_bases + 31) / 32 + 1;
+        hipError_t err = hipSuccess;
+        auto chk = [&err](hipError_t e) { if (err == hipSuccess) err = e; };
+        chk(hipMalloc(&d_genome, (size_t)gw * 8));
+        chk(hipMalloc(&d_ts, tstart.size() * 8));
+        chk(hipMalloc(&d_tl, tlen.size() * 4));
+        chk(hipMalloc(&d_cdf, cdf.size() * 4));
+        if (err == hipSuccess) {
+            chk(hipMemcpy(d_ts, tstart.data(), tstart.size() * 8, hipMemcpyHostToDevice));
+            chk(hipMemcpy(d_tl, tlen.data(), tlen.size() * 4, hipMemcpyHostToDevice));
+            chk(hipMemcpy(d_cdf, cdf.data(), cdf.size() * 4, hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(k_synth_genome, dim3(blocks_for(gw)), dim3(TPB), 0, 0, d_genome, gw, p->seed);
+            hipLaunchKernelGGL(k_synth_reads, dim3(blocks_for(b->n_words)), dim3(TPB), 0, 0, d_genome, d_ts, d_tl,
+                               d_cdf, (int)tlen.size(), p->n_pairs, (int)p->read_len, wpr, (float)p->frag_mean,
+                               (float)p->frag_sd, p->sub_rate, p->n_rate, p->seed, b->codes, b->valid, b->word_read);
+            chk(hipGetLastError());
+            chk(hipDeviceSynchronize());
+        }
+        if (d_genome) (void)hipFree(d_genome);
+        if (d_ts) (void)hipFree(d_ts);
+        if (d_tl) (void)hipFree(d_tl);
+        if (d_cdf) (void)hipFree(d_cdf);
+        RB_HIP(err);
+        guard.b = nullptr;
+        *out = b;
+        return RB_OK;
+    } catch (const HipError &e) { return e.code; }
+    catch (const std::bad_alloc &) { set_error("host allocation failed"); return RB_ERR_NOMEM; }
+}
+
+int rb_nthash_batch(const rb_batch *b, int k, int mode, int64_t first, int64_t n, int64_t *count,
+                    uint64_t *out_h0, uint32_t *out_read, uint32_t *out_pos) {
+    try {
+        RB_REQUIRE(b && count && k >= 1 && k <= RB_MAX_K && mode >= 0 && mode <= 2, "rb_nthash_batch: bad argument");
+        RB_REQUIRE(first >= 0 && n >= 0 && first + n <= b->n_reads, "rb_nthash_batch: bad read range");
+        RB_HIP(hipSetDevice(b->device));
+        *count = 0;
+        if (n == 0) return RB_OK;
+        uint32_t wo[2];
+        RB_HIP(hipMemcpy(&wo[0], b->woff + first, 4, hipMemcpyDeviceToHost));
+        RB_HIP(hipMemcpy(&wo[1], b->woff + first + n, 4, hipMemcpyDeviceToHost));
+        int64_t w0 = wo[0], nw = (int64_t)wo[1] - wo[0];
+        if (nw == 0) return RB_OK;
+        DevBuf cnt, off, tmp, keys, rd, ps;
+        struct Rel { DevBuf *b[6]; ~Rel() { for (auto x : b) x->release(); } } rel{{&cnt, &off, &tmp, &keys, &rd, &ps}};
+        cnt.reserve(((size_t)nw + 1) * 4); off.reserve(((size_t)nw + 1) * 4);
+        RB_HIP(hipMemsetAsync(cnt.p, 0, ((size_t)nw + 1) * 4, 0));
+        launch_count_windows(b, w0, nw, k, cnt.as<uint32_t>(), 0);
+        size_t tb = scan_temp_bytes((size_t)nw + 1);
+        tmp.reserve(tb);
+        exclusive_scan_u32(tmp.p, tb, cnt.as<uint32_t>(), off.as<uint32_t>(), (size_t)nw + 1, 0);
+        uint32_t total = 0;
+        RB_HIP(hipMemcpy(&total, off.as<uint32_t>() + nw, 4, hipMemcpyDeviceToHost));
+        *count = total;
+        if (!out_h0 || total == 0) return RB_OK;
+        keys.reserve((size_t)total * 8);
+        if (out_read) { rd.reserve((size_t)total * 4); ps.reserve((size_t)total * 4); }
+        launch_hash_windows(b, w0, nw, k, mode, off.as<uint32_t>(), 0, 0, keys.as<uint64_t>(), nullptr,
+                            out_read ? rd.as<uint32_t>() : nullptr, out_read ? ps.as<uint32_t>() : nullptr, 0);
+        RB_HIP(hipGetLastError());
+        RB_HIP(hipMemcpy(out_h0, keys.p, (size_t)total * 8, hipMemcpyDeviceToHost));
+        if (out_read) {
+            RB_HIP(hipMemcpy(out_read, rd.p, (size_t)total * 4, hipMemcpyDeviceToHost));
+            if (out_pos) RB_HIP(hipMemcpy(out_pos, ps.p, (size_t)total * 4, hipMemcpyDeviceToHost));
+        }
+        return RB_OK;
+    } catch (const HipError &e) { return e.code; }
+}
+
+}  // extern "C"

@@ -1,0 +1,117 @@
+// rb_device.hpp — gfx950 device primitives for the ntHash / Bloom-dBG path.
+// 64-bit integer/bit work only (no MFMA: nothing here is GEMM shaped).
+// Reference citations: R/ = src/rnabloom/ of bcgsc/RNA-Bloom v2.0.1.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rb {
+
+// 2-bit base codes of the packed device format: A=0 C=1 G=2 T/U=3, complement = 3 - code.
+// Seeds: R/bloom/hash/NTHash.java:39-43.
+__device__ __forceinline__ uint64_t seed_of(uint32_t code) {
+    // select chain compiles to v_cndmask pairs; no table memory traffic
+    uint64_t s = 0x3c8bfbb395c60474ull;                  // A
+    s = (code == 1) ? 0x3193c18562a02b4cull : s;         // C
+    s = (code == 2) ? 0x20323ed082572324ull : s;         // G
+    s = (code == 3) ? 0x295549f54be24456ull : s;         // T/U
+    return s;
+}
+__device__ __forceinline__ uint64_t rotl(uint64_t v, uint32_t s) {
+    s &= 63u;
+    return (v << s) | (v >> ((64u - s) & 63u));
+}
+__device__ __forceinline__ uint64_t rotr(uint64_t v, uint32_t s) {
+    s &= 63u;
+    return (v >> s) | (v << ((64u - s) & 63u));
+}
+__host__ __device__ __forceinline__ int64_t as_signed(uint64_t v) { return (int64_t)v; }
+
+// canonical = SIGNED min (rhVal<fhVal ? rhVal : fhVal), R/bloom/hash/NTHash.java:488,494
+__device__ __forceinline__ uint64_t canonical(uint64_t f, uint64_t r) {
+    return ((int64_t)r < (int64_t)f) ? r : f;
+}
+__device__ __forceinline__ uint64_t smin(uint64_t a, uint64_t b) {   // Math.min(long,long)
+    return ((int64_t)a < (int64_t)b) ? a : b;
+}
+
+// NTM64(bVal, hVal, k, m): hVal[i] = t ^ (t >>> 27), t = bVal * (i ^ k*multiSeed)
+// R/bloom/hash/NTHash.java:518-527
+__host__ __device__ __forceinline__ uint64_t multi_hash(uint64_t b, uint32_t i, uint64_t kmul) {
+    if (i == 0) return b;
+    uint64_t t = b * ((uint64_t)i ^ kmul);
+    return t ^ (t >> 27);
+}
+__host__ __device__ __forceinline__ uint64_t kmul_of(int k) {
+    return (uint64_t)(int64_t)k * 0x90b45d39fb6da1faull;
+}
+// HashFunction.combineHashValues, R/bloom/hash/HashFunction.java:260-263 (sign-extended int literal)
+__host__ __device__ __forceinline__ uint64_t combine(uint64_t a, uint64_t b) {
+    return a ^ (b + 0xFFFFFFFF9E3779B9ull + (a << 6) + (b >> 2));
+}
+
+// getIndex: (hashVal >>> 1) % size, R/bloom/BloomFilter.java:108-111.
+// Exact remainder for an arbitrary 63-bit size via Lemire's fastmod with a 128-bit reciprocal
+// M = floor((2^128-1)/d) + 1:   x mod d = mulhi128(M * x mod 2^128, d).
+struct Mod {
+    uint64_t d, m_lo, m_hi;
+};
+__host__ inline Mod make_mod(uint64_t d) {
+    Mod m;
+    m.d = d;
+    unsigned __int128 M = ~(unsigned __int128)0 / d + 1;
+    m.m_lo = (uint64_t)M;
+    m.m_hi = (uint64_t)(M >> 64);
+    return m;
+}
+__device__ __forceinline__ uint64_t fastmod(uint64_t x, const Mod &m) {
+    // lowbits = (M * x) mod 2^128
+    uint64_t lo = m.m_lo * x;
+    uint64_t hi = __umul64hi(m.m_lo, x) + m.m_hi * x;
+    // result = (lowbits * d) >> 128
+    uint64_t t = __umul64hi(lo, m.d);            // carry part of lo*d
+    uint64_t p_lo = hi * m.d;
+    uint64_t p_hi = __umul64hi(hi, m.d);
+    uint64_t s = p_lo + t;
+    return p_hi + (s < p_lo ? 1ull : 0ull);
+}
+__device__ __forceinline__ uint64_t index_of(uint64_t h, const Mod &m) { return fastmod(h >> 1, m); }
+
+// shared counter-based generator (see oracle/rb_oracle.c rbo_rng31): 31 uniform bits from
+// (seed, op ordinal, position in read)
+__host__ __device__ __forceinline__ uint32_t rng31(uint64_t seed, uint64_t ordinal, uint32_t pos) {
+    uint64_t z = seed ^ (ordinal * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)pos * 0xC2B2AE3D27D4EB4Full);
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    z ^= z >> 31;
+    return (uint32_t)(z >> 33);
+}
+// MiniFloat.increment R/util/MiniFloat.java:31-38 on counter bytes 0..127; rnd31 replaces
+// (int)(Math.random()*Integer.MAX_VALUE).  Returns the byte after the attempt.
+__host__ __device__ __forceinline__ uint32_t minifloat_inc(uint32_t b, uint32_t rnd31) {
+    if (b <= 7u) return b + 1u;
+    if (b < 127u) {
+        uint32_t s = (b >> 3) - 1u;
+        if ((rnd31 & ((1u << s) - 1u)) == 0u) return b + 1u;
+    }
+    return b;
+}
+// MiniFloat.toFloat :40-45
+__host__ __device__ __forceinline__ float minifloat_to_float(uint32_t b) {
+    if (b <= 7u) return (float)b;
+    uint32_t e = (b >> 3) - 1u;                    // 0..14
+    return (float)(((b & 7u) | 8u) << e);          // exact: < 2^24
+}
+
+// bit filters are addressed as 32-bit little-endian words: bit i -> word i>>5, mask 1<<(i&31),
+// which is byte i>>3, mask 1<<(i&7) of the reference layout (UnsafeBitBuffer.java:42-48).
+__device__ __forceinline__ bool bit_test(const uint32_t *bits, uint64_t i) {
+    return (bits[i >> 5] >> (uint32_t)(i & 31u)) & 1u;
+}
+__device__ __forceinline__ void bit_set(uint32_t *bits, uint64_t i) {
+    uint32_t m = 1u << (uint32_t)(i & 31u);
+    if (!(bits[i >> 5] & m)) atomicOr(&bits[i >> 5], m);   // test-before-set halves write traffic
+}
+
+}  // namespace rb

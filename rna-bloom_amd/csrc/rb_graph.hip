@@ -1,0 +1,1148 @@
+// rb_graph.hip — the Bloom-filter de Bruijn graph on one MI355X: filters resident in HBM, the
+// order-exact batched insert pipeline, batched queries, and the C ABI around them.
+//
+// Insert pipeline ("sorted-batch engine"): the sequential semantics of
+//   for each read, for each k-mer left to right:  if (dbgbf.lookupThenAdd(h)) cbf.increment(h)
+// (R/graph/BloomFilterDeBruijnGraph.java:405-412 driven by R/RNABloom.java:551-634) are reproduced
+// exactly by
+//   1. hashing every usable window into (h0, occurrence-id) records in read order,
+//   2. a stable sort by h0 — every distinct k-mer becomes one run whose occurrences stay in order,
+//   3. per DISTINCT k-mer: Bloom-bit test against the pre-batch state, first-setter arbitration
+//      between new k-mers that share a bit (smallest probe id wins, as it would sequentially),
+//      bit set with atomicOr, and the count of occurrences whose lookupThenAdd returned true,
+//   4. counter-claim detection of k-mers that share a counting-Bloom byte with another k-mer of the
+//      batch; k-mers without such a neighbour commute and are applied independently (all their
+//      increments simulated in registers, in occurrence order), the rest are replayed in global
+//      occurrence order.
+#include <math.h>
+#include <stdarg.h>
+#include <string.h>
+
+#include <algorithm>
+#include <new>
+#include <vector>
+
+#include "rb_internal.hpp"
+#include "rb_kernels.hpp"
+
+using namespace rb;
+
+namespace rb {
+static thread_local char g_err[768] = "";
+void set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+}  // namespace rb
+
+namespace {
+
+constexpr int TPB = 256;
+inline unsigned blocks_for(int64_t n, int tpb = TPB) { return (unsigned)((n + tpb - 1) / tpb); }
+
+struct BitFilter {
+    uint32_t *bits = nullptr;
+    int64_t size = 0, nbytes = 0;
+    size_t alloc = 0;
+    int num_hash = 0;
+    Mod mod{1, 0, 0};
+};
+
+// everything a kernel needs to address the filters (passed by value)
+struct FilterView {
+    uint32_t *dbg; Mod dbg_mod; int dbg_h;
+    uint8_t *cbf;  Mod cbf_mod; int cbf_h;
+    uint64_t kmul;        // k * multiSeed
+    uint64_t seed;        // rng seed
+    uint64_t ordinal0;    // op ordinal of occurrence value 0
+    uint32_t pos_bits;    // occurrence value = (read_rel << pos_bits) | pos
+};
+
+// open-addressing table slot: key (empty = ~0) + 64-bit payload (identity of atomicMin = ~0)
+struct Slot { unsigned long long key; unsigned long long val; };
+
+__device__ __forceinline__ uint64_t slot_of(uint64_t key, uint32_t log2cap) {
+    return (key * 0x9E3779B97F4A7C15ull) >> (64u - log2cap);
+}
+__device__ __forceinline__ Slot *table_insert(Slot *t, uint32_t log2cap, uint64_t key) {
+    const uint64_t mask = (1ull << log2cap) - 1ull;
+    uint64_t s = slot_of(key, log2cap);
+    for (;;) {
+        unsigned long long cur = __hip_atomic_load(&t[s].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == key) return &t[s];
+        if (cur == ~0ull) {
+            unsigned long long old = atomicCAS(&t[s].key, ~0ull, (unsigned long long)key);
+            if (old == ~0ull || old == key) return &t[s];
+        }
+        s = (s + 1ull) & mask;
+    }
+}
+__device__ __forceinline__ const Slot *table_find(const Slot *t, uint32_t log2cap, uint64_t key) {
+    const uint64_t mask = (1ull << log2cap) - 1ull;
+    uint64_t s = slot_of(key, log2cap);
+    for (;;) {
+        unsigned long long cur = t[s].key;
+        if (cur == key) return &t[s];
+        if (cur == ~0ull) return nullptr;
+        s = (s + 1ull) & mask;
+    }
+}
+
+// op kinds of the counting-Bloom state machine
+enum : uint32_t { K_INC = 0, K_INC_IF_POS = 1, K_INC_IF_ZERO = 2 };
+// pipeline modes
+enum : int { M_ADD = 0, M_ADD_IF_ABSENT = 1, M_COUNT_IF_PRESENT = 2, M_COUNT_ONLY = 4 };
+
+// status word per distinct k-mer: bits 0..7 premask (bit j: probe j was set before the batch),
+// bit 8 all_pre, bits 12..13 kind of first op, bits 14..15 kind of the remaining ops, bit 16 conflict
+constexpr uint32_t ST_ALLPRE = 1u << 8;
+
+// CountingBloomFilter.increment(long[]) :170-194 on a register copy of the cbf_h bytes.
+// c[j] mirrors counts[idx_j]; duplicated indices stay consistent because both copies move together.
+__device__ __forceinline__ void cbf_step(uint32_t *c, int h, uint32_t kind, uint32_t rnd31) {
+    uint32_t mn = c[0];
+    for (int j = 1; j < h; ++j) mn = c[j] < mn ? c[j] : mn;
+    if (kind == K_INC_IF_POS && mn == 0u) return;    // addCountIfPresent :424-428
+    if (kind == K_INC_IF_ZERO && mn != 0u) return;   // addIfAbsent else-branch :419-421
+    uint32_t up = minifloat_inc(mn, rnd31);
+    if (up != mn)
+        for (int j = 0; j < h; ++j) if (c[j] == mn) c[j] = up;
+}
+__device__ __forceinline__ uint32_t occ_rnd(const FilterView &fv, uint32_t v) {
+    return rng31(fv.seed, fv.ordinal0 + (uint64_t)(v >> fv.pos_bits), v & ((1u << fv.pos_bits) - 1u));
+}
+
+// ---- stage 3a: test Bloom bits of each distinct k-mer against the pre-batch state ----
+__global__ void k_dbg_test(FilterView fv, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ starts,
+                           const uint32_t *__restrict__ vals, uint32_t n_distinct, int mode,
+                           Slot *ftable, uint32_t f_log2, uint32_t *__restrict__ status) {
+    uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n_distinct) return;
+    const uint64_t h0 = uniq[d];
+    uint32_t premask = 0, all = 1;
+    const uint32_t v_first = vals[starts[d]];
+    for (int j = 0; j < fv.dbg_h; ++j) {
+        uint64_t idx = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.dbg_mod);
+        if (bit_test(fv.dbg, idx)) premask |= 1u << j;
+        else {
+            all = 0;
+            if (mode == M_ADD || mode == M_ADD_IF_ABSENT) {
+                // sequentially, the getAndSet with the smallest (occurrence, probe) id is the one
+                // that finds the bit clear (R/bloom/BloomFilter.java:147-155)
+                Slot *s = table_insert(ftable, f_log2, idx);
+                atomicMin(&s->val, ((unsigned long long)v_first << 4) | (unsigned long long)j);
+            }
+        }
+    }
+    status[d] = premask | (all ? ST_ALLPRE : 0u);
+}
+
+// ---- stage 3b: resolve found-flag of the first occurrence, set bits, claim counters ----
+__global__ void k_dbg_set_claim(FilterView fv, const uint64_t *__restrict__ uniq,
+                                const uint32_t *__restrict__ counts, const uint32_t *__restrict__ starts,
+                                const uint32_t *__restrict__ vals, uint32_t n_distinct, int mode,
+                                const Slot *ftable, uint32_t f_log2, Slot *ctable, uint32_t c_log2,
+                                uint32_t *__restrict__ status, uint32_t *__restrict__ nops) {
+    uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n_distinct) return;
+    const uint64_t h0 = uniq[d];
+    const uint32_t m = counts[d];
+    uint32_t st = status[d];
+    const bool all_pre = st & ST_ALLPRE;
+    uint32_t ops = 0, kfirst = K_INC, krest = K_INC;
+    if (mode == M_COUNT_ONLY) {
+        ops = m;
+    } else if (mode == M_COUNT_IF_PRESENT) {
+        ops = all_pre ? m : 0u;                   // dbgbf never changes in this mode
+        kfirst = krest = K_INC_IF_POS;
+    } else {
+        bool found_first = true;
+        if (!all_pre) {
+            const uint32_t v_first = vals[starts[d]];
+            for (int j = 0; j < fv.dbg_h; ++j) {
+                if ((st >> j) & 1u) continue;
+                uint64_t idx = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.dbg_mod);
+                const Slot *s = table_find(ftable, f_log2, idx);
+                unsigned long long mine = ((unsigned long long)v_first << 4) | (unsigned long long)j;
+                // old bit value seen by this probe = an earlier probe of the batch already set it
+                if (!(s->val < mine)) found_first = false;
+                bit_set(fv.dbg, idx);
+            }
+        }
+        if (mode == M_ADD) {
+            ops = found_first ? m : m - 1u;       // only re-sightings (or false positives) count
+        } else {                                  // M_ADD_IF_ABSENT :414-422
+            ops = m;
+            kfirst = found_first ? K_INC_IF_ZERO : K_INC;
+            krest = K_INC_IF_ZERO;
+        }
+    }
+    nops[d] = ops;
+    status[d] = (st & 0x1FFu) | (kfirst << 12) | (krest << 14);
+    if (ops) {
+        for (int j = 0; j < fv.cbf_h; ++j) {
+            uint64_t idx = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod);
+            Slot *s = table_insert(ctable, c_log2, idx);
+            // low word: min owner, high word: ~max owner (both via atomicMin on 32-bit halves)
+            uint32_t *w = reinterpret_cast<uint32_t *>(&s->val);
+            atomicMin(&w[0], d);
+            atomicMin(&w[1], ~d);
+        }
+    }
+}
+
+// ---- stage 4: apply counter updates of k-mers that own their counters alone ----
+constexpr uint32_t LIGHT_OPS = 96;
+__global__ void k_cbf_apply(FilterView fv, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ counts,
+                            const uint32_t *__restrict__ starts, const uint32_t *__restrict__ vals,
+                            uint32_t n_distinct, const Slot *ctable, uint32_t c_log2,
+                            const uint32_t *__restrict__ status, const uint32_t *__restrict__ nops,
+                            uint32_t *__restrict__ heavy_list, uint32_t *__restrict__ conf_kmers,
+                            uint32_t *__restrict__ counters /* [0]=heavy n, [1]=conflict kmers, [2]=conflict ops */) {
+    uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n_distinct) return;
+    const uint32_t ops = nops[d];
+    if (!ops) return;
+    const uint64_t h0 = uniq[d];
+    uint64_t idx[RB_MAX_HASH];
+    bool conflict = false;
+    for (int j = 0; j < fv.cbf_h; ++j) {
+        idx[j] = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod);
+        const Slot *s = table_find(ctable, c_log2, idx[j]);
+        const uint32_t *w = reinterpret_cast<const uint32_t *>(&s->val);
+        conflict |= (w[0] != ~w[1]);
+    }
+    if (conflict) {
+        uint32_t at = atomicAdd(&counters[1], 1u);
+        conf_kmers[at] = d;
+        atomicAdd(&counters[2], ops);
+        return;
+    }
+    if (ops > LIGHT_OPS) {
+        uint32_t at = atomicAdd(&counters[0], 1u);
+        heavy_list[at] = d;
+        return;
+    }
+    uint32_t c[RB_MAX_HASH], c0[RB_MAX_HASH];
+    for (int j = 0; j < fv.cbf_h; ++j) c0[j] = c[j] = fv.cbf[idx[j]];
+    const uint32_t st = status[d];
+    const uint32_t base = starts[d] + counts[d] - ops;
+    uint32_t kind = (st >> 12) & 3u;
+    for (uint32_t i = 0; i < ops; ++i) {
+        uint32_t mn = c[0];
+        for (int j = 1; j < fv.cbf_h; ++j) mn = c[j] < mn ? c[j] : mn;
+        uint32_t rnd = (mn >= 16u && mn < 127u) ? occ_rnd(fv, vals[base + i]) : 0u;
+        cbf_step(c, fv.cbf_h, kind, rnd);
+        kind = (st >> 14) & 3u;
+    }
+    for (int j = 0; j < fv.cbf_h; ++j)
+        if (c[j] != c0[j]) fv.cbf[idx[j]] = (uint8_t)c[j];
+}
+
+// one wavefront per high-multiplicity k-mer: lanes fetch 64 occurrences at a time, compute each
+// one's random draw, and the increment chain hops from success to success with ballots
+__global__ void __launch_bounds__(64) k_cbf_heavy(FilterView fv, const uint64_t *__restrict__ uniq,
+                            const uint32_t *__restrict__ counts, const uint32_t *__restrict__ starts,
+                            const uint32_t *__restrict__ vals, const uint32_t *__restrict__ status,
+                            const uint32_t *__restrict__ nops, const uint32_t *__restrict__ heavy_list,
+                            const uint32_t *__restrict__ counters) {
+    const uint32_t n_heavy = counters[0];
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t hi = blockIdx.x; hi < n_heavy; hi += gridDim.x) {
+        const uint32_t d = heavy_list[hi];
+        const uint64_t h0 = uniq[d];
+        const uint32_t ops = nops[d];
+        const uint32_t st = status[d];
+        uint64_t idx[RB_MAX_HASH];
+        uint32_t c[RB_MAX_HASH], c0[RB_MAX_HASH];
+        for (int j = 0; j < fv.cbf_h; ++j) {
+            idx[j] = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod);
+            c0[j] = c[j] = fv.cbf[idx[j]];
+        }
+        const uint32_t base = starts[d] + counts[d] - ops;
+        const uint32_t krest = (st >> 14) & 3u;
+        uint32_t done = 0;
+        {   // the first op may have its own kind
+            uint32_t mn = c[0];
+            for (int j = 1; j < fv.cbf_h; ++j) mn = c[j] < mn ? c[j] : mn;
+            uint32_t rnd = (mn >= 16u && mn < 127u) ? occ_rnd(fv, vals[base]) : 0u;
+            cbf_step(c, fv.cbf_h, (st >> 12) & 3u, rnd);
+            done = 1;
+        }
+        while (done < ops) {
+            uint32_t mn = c[0];
+            for (int j = 1; j < fv.cbf_h; ++j) mn = c[j] < mn ? c[j] : mn;
+            if (mn >= 127u) break;                                   // saturated: nothing changes any more
+            if (krest == K_INC_IF_POS && mn == 0u) break;            // stays zero for ever
+            if (krest == K_INC_IF_ZERO && mn != 0u) break;           // stays positive for ever
+            if (mn < 16u) {                                          // deterministic region: one step
+                cbf_step(c, fv.cbf_h, krest, 0u);
+                ++done;
+                continue;
+            }
+            // probabilistic region: examine up to 64 pending occurrences at once
+            const uint32_t i = done + lane;
+            const uint32_t shift = (mn >> 3) - 1u;
+            bool ok = false;
+            if (i < ops) ok = (occ_rnd(fv, vals[base + i]) & ((1u << shift) - 1u)) == 0u;
+            const unsigned long long win = __ballot(ok);
+            if (!win) { done += 64u; continue; }
+            const uint32_t first = (uint32_t)__ffsll((long long)win) - 1u;
+            cbf_step(c, fv.cbf_h, krest, 0u);                        // rnd 0 always succeeds
+            done += first + 1u;
+        }
+        if (lane == 0)
+            for (int j = 0; j < fv.cbf_h; ++j)
+                if (c[j] != c0[j]) fv.cbf[idx[j]] = (uint8_t)c[j];
+    }
+}
+
+// ---- conflict path: expand the ops of conflicting k-mers, sort by occurrence, replay in order ----
+__global__ void k_conf_offsets(const uint32_t *__restrict__ conf_kmers, const uint32_t *__restrict__ nops,
+                               uint32_t n_conf, uint32_t *__restrict__ sizes) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_conf) sizes[i] = nops[conf_kmers[i]];
+    if (i == n_conf) sizes[i] = 0;
+}
+__global__ void k_conf_expand(const uint32_t *__restrict__ conf_kmers, const uint32_t *__restrict__ conf_off,
+                              const uint32_t *__restrict__ counts, const uint32_t *__restrict__ starts,
+                              const uint32_t *__restrict__ vals, const uint32_t *__restrict__ status,
+                              const uint32_t *__restrict__ nops, uint32_t n_conf,
+                              uint64_t *__restrict__ op_key, uint32_t *__restrict__ op_val) {
+    // one wavefront per conflicting k-mer
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+    if (wave >= n_conf) return;
+    const uint32_t d = conf_kmers[wave];
+    const uint32_t ops = nops[d], st = status[d];
+    const uint32_t base = starts[d] + counts[d] - ops, out = conf_off[wave];
+    for (uint32_t i = lane; i < ops; i += 64u) {
+        op_key[out + i] = vals[base + i];
+        uint32_t kind = i == 0 ? (st >> 12) & 3u : (st >> 14) & 3u;
+        op_val[out + i] = d | (kind << 30);
+    }
+}
+// v0 replay: strictly sequential, one lane.  Correct by construction; replaced by a parallel
+// component-wise replay once parity is established.
+__global__ void k_conf_replay_serial(FilterView fv, const uint64_t *__restrict__ uniq,
+                                     const uint64_t *__restrict__ op_key, const uint32_t *__restrict__ op_val,
+                                     uint32_t n_ops) {
+    if (blockIdx.x != 0 || threadIdx.x != 0) return;
+    for (uint32_t i = 0; i < n_ops; ++i) {
+        const uint32_t v = (uint32_t)op_key[i];
+        const uint32_t d = op_val[i] & 0x3FFFFFFFu, kind = op_val[i] >> 30;
+        const uint64_t h0 = uniq[d];
+        uint64_t idx[RB_MAX_HASH];
+        uint32_t c[RB_MAX_HASH], c0[RB_MAX_HASH];
+        for (int j = 0; j < fv.cbf_h; ++j) {
+            idx[j] = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod);
+            c0[j] = c[j] = fv.cbf[idx[j]];
+        }
+        cbf_step(c, fv.cbf_h, kind, occ_rnd(fv, v));
+        for (int j = 0; j < fv.cbf_h; ++j)
+            if (c[j] != c0[j]) fv.cbf[idx[j]] = (uint8_t)c[j];
+    }
+}
+
+// ---- paired k-mers: {,Canonical,ReverseComplement}PairedNTHashIterator + rpkbf.add ----
+// (R/bloom/hash/PairedNTHashIterator.java:56-83, CanonicalPaired… :36-60, ReverseComplementPaired…
+//  :33-56; R/RNABloom.java:587-591).  Pure OR => order independent => direct atomicOr.
+template <int MODE>
+__global__ void k_pairs_insert(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
+                               const uint32_t *__restrict__ word_read, const uint32_t *__restrict__ woff,
+                               const uint32_t *__restrict__ len, int64_t w0, int64_t nw, int k, int dist,
+                               uint32_t *bits, Mod mod, int num_hash, uint64_t kmul,
+                               unsigned long long *__restrict__ n_pairs) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nw) return;
+    const int64_t w = w0 + i;
+    const uint32_t r = word_read[w], wr = woff[r], L = len[r];
+    const uint32_t b0 = (uint32_t)(w - wr) * 32u;
+    const uint32_t uk = (uint32_t)k, ud = (uint32_t)dist, span = uk + ud;
+    if ((uint64_t)b0 + span > L) return;
+    const uint64_t bend64 = (uint64_t)b0 + 32u + span - 1u;
+    const uint32_t bend = bend64 < L ? (uint32_t)bend64 : L;
+    const uint64_t *cw = codes + wr;
+    const uint32_t *vw = valid + wr;
+    uint64_t fR = 0, rR = 0, fL = 0, rL = 0;
+    uint32_t runR = 0, runL = 0, runall = 0, cnt = 0;
+    auto code_at = [&](uint32_t b) { return (uint32_t)(cw[b >> 5] >> (2u * (b & 31u))) & 3u; };
+    auto valid_at = [&](uint32_t b) { return (vw[b >> 5] >> (b & 31u)) & 1u; };
+    for (uint32_t b = b0; b < bend; ++b) {
+        // right-hand window ends at base b
+        if (!valid_at(b)) { runR = 0; fR = 0; rR = 0; runall = 0; }
+        else {
+            const uint32_t code = code_at(b);
+            if (runR < uk) { fR = rotl(fR, 1) ^ seed_of(code); rR ^= rotl(seed_of(3u - code), runR); ++runR; }
+            else {
+                const uint32_t oc = code_at(b - uk);
+                fR = rotl(fR, 1) ^ rotl(seed_of(oc), uk) ^ seed_of(code);
+                rR = rotr(rR, 1) ^ rotr(seed_of(3u - oc), 1) ^ rotl(seed_of(3u - code), uk - 1u);
+            }
+            ++runall;
+        }
+        // left-hand window ends at base b - dist
+        if (b >= b0 + ud) {
+            const uint32_t bl = b - ud;
+            if (!valid_at(bl)) { runL = 0; fL = 0; rL = 0; }
+            else {
+                const uint32_t code = code_at(bl);
+                if (runL < uk) { fL = rotl(fL, 1) ^ seed_of(code); rL ^= rotl(seed_of(3u - code), runL); ++runL; }
+                else {
+                    const uint32_t oc = code_at(bl - uk);
+                    fL = rotl(fL, 1) ^ rotl(seed_of(oc), uk) ^ seed_of(code);
+                    rL = rotr(rL, 1) ^ rotr(seed_of(3u - oc), 1) ^ rotl(seed_of(3u - code), uk - 1u);
+                }
+            }
+        }
+        if (runall >= span) {   // all bases of [p, p+dist+k) usable: both windows lie in one segment
+            uint64_t P;
+            if (MODE == 0) P = combine(fL, fR);
+            else if (MODE == 2) P = combine(rR, rL);
+            else P = smin(combine(fL, fR), combine(rR, rL));
+            for (int j = 0; j < num_hash; ++j) bit_set(bits, index_of(multi_hash(P, (uint32_t)j, kmul), mod));
+            ++cnt;
+        }
+    }
+    if (cnt) atomicAdd(n_pairs, (unsigned long long)cnt);
+}
+
+// ---- direct (order-independent) bit-filter ops and queries on arrays of base hashes ----
+__global__ void k_bits_add(uint32_t *bits, Mod mod, int num_hash, uint64_t kmul, const uint64_t *__restrict__ h0, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    for (int j = 0; j < num_hash; ++j) bit_set(bits, index_of(multi_hash(h0[i], (uint32_t)j, kmul), mod));
+}
+__device__ __forceinline__ bool bits_lookup(const uint32_t *bits, const Mod &mod, int num_hash, uint64_t kmul, uint64_t h0) {
+    for (int j = 0; j < num_hash; ++j)     // early exit, R/bloom/BloomFilter.java:170-178
+        if (!bit_test(bits, index_of(multi_hash(h0, (uint32_t)j, kmul), mod))) return false;
+    return true;
+}
+// CountingBloomFilter.getCount(long[]) :235-251 (zero check inside the h>=1 loop)
+__device__ __forceinline__ float cbf_get_count(const uint8_t *cbf, const Mod &mod, int num_hash, uint64_t kmul, uint64_t h0) {
+    uint32_t mn = cbf[index_of(h0, mod)];
+    for (int j = 1; j < num_hash; ++j) {
+        uint32_t c = cbf[index_of(multi_hash(h0, (uint32_t)j, kmul), mod)];
+        if (c < mn) mn = c;
+        if (mn == 0u) return 0.0f;
+    }
+    return minifloat_to_float(mn);
+}
+__device__ __forceinline__ float graph_count(const FilterView &fv, uint64_t h0) {   // BloomFilterDeBruijnGraph.java:562-570
+    if (!bits_lookup(fv.dbg, fv.dbg_mod, fv.dbg_h, fv.kmul, h0)) return 0.0f;
+    return cbf_get_count(fv.cbf, fv.cbf_mod, fv.cbf_h, fv.kmul, h0) + 1.0f;
+}
+__global__ void k_bits_lookup(const uint32_t *bits, Mod mod, int num_hash, uint64_t kmul, const uint64_t *__restrict__ h0, size_t n, uint8_t *out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = bits_lookup(bits, mod, num_hash, kmul, h0[i]) ? 1 : 0;
+}
+__global__ void k_graph_count(FilterView fv, const uint64_t *__restrict__ h0, size_t n, float *out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = graph_count(fv, h0[i]);
+}
+__global__ void k_cbf_count(FilterView fv, const uint64_t *__restrict__ h0, size_t n, float *out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = cbf_get_count(fv.cbf, fv.cbf_mod, fv.cbf_h, fv.kmul, h0[i]);
+}
+
+// getKmers: hash EVERY window of a read (unusable bases hash as seed 0, exactly like seedTab's
+// zero rows, R/bloom/hash/NTHash.java:133-166), count = 0 for windows containing an unusable base
+// (R/bloom/hash/CanonicalHashFunction.java:46-78).  One thread per 32-window chunk.
+__global__ void k_get_kmers(FilterView fv, int stranded, const uint64_t *__restrict__ codes,
+                            const uint32_t *__restrict__ valid, const uint32_t *__restrict__ word_read,
+                            const uint32_t *__restrict__ woff, const uint32_t *__restrict__ len,
+                            int64_t n_words, int k, const int64_t *__restrict__ koff,
+                            uint64_t *__restrict__ out_f, uint64_t *__restrict__ out_r, float *__restrict__ out_c) {
+    int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_words) return;
+    const uint32_t r = word_read[w], wr = woff[r], L = len[r];
+    const uint32_t b0 = (uint32_t)(w - wr) * 32u, uk = (uint32_t)k;
+    if ((uint64_t)b0 + uk > L) return;
+    const uint64_t bend64 = (uint64_t)b0 + 32u + uk - 1u;
+    const uint32_t bend = bend64 < L ? (uint32_t)bend64 : L;
+    const uint64_t *cw = codes + wr;
+    const uint32_t *vw = valid + wr;
+    uint64_t f = 0, rv = 0;
+    uint32_t filled = 0, run = 0;
+    for (uint32_t b = b0; b < bend; ++b) {
+        const bool ok = (vw[b >> 5] >> (b & 31u)) & 1u;
+        const uint64_t s_in = ok ? seed_of((uint32_t)(cw[b >> 5] >> (2u * (b & 31u))) & 3u) : 0ull;
+        const uint64_t sc_in = ok ? seed_of(3u - ((uint32_t)(cw[b >> 5] >> (2u * (b & 31u))) & 3u)) : 0ull;
+        run = ok ? run + 1u : 0u;
+        if (filled < uk) { f = rotl(f, 1) ^ s_in; rv ^= rotl(sc_in, filled); ++filled; }
+        else {
+            const uint32_t bo = b - uk;
+            const bool oko = (vw[bo >> 5] >> (bo & 31u)) & 1u;
+            const uint32_t oc = (uint32_t)(cw[bo >> 5] >> (2u * (bo & 31u))) & 3u;
+            const uint64_t s_out = oko ? seed_of(oc) : 0ull, sc_out = oko ? seed_of(3u - oc) : 0ull;
+            f = rotl(f, 1) ^ rotl(s_out, uk) ^ s_in;
+            rv = rotr(rv, 1) ^ rotr(sc_out, 1) ^ rotl(sc_in, uk - 1u);
+        }
+        if (filled >= uk) {
+            const uint32_t p = b - uk + 1u;
+            const int64_t o = koff[r] + p;
+            const uint64_t base = stranded ? f : canonical(f, rv);
+            out_f[o] = f;
+            out_r[o] = stranded ? 0ull : rv;
+            out_c[o] = run >= uk ? graph_count(fv, base) : 0.0f;
+        }
+    }
+}
+
+// Kmer.getSuccessors / getPredecessors: the four neighbours' hashes and counts
+// (R/bloom/hash/{,Canonical}{Successors,Predecessors}NTHashIterator.java; R/graph/Kmer.java:210-255)
+__device__ __forceinline__ uint32_t code_of_char(uint32_t ch) {
+    switch (ch) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2;
+                  case 'T': case 't': case 'U': case 'u': return 3; default: return 4; }
+}
+__global__ void k_neighbors(FilterView fv, int stranded, int k, int direction, const uint64_t *__restrict__ f,
+                            const uint64_t *__restrict__ r, const uint8_t *__restrict__ ch, size_t n,
+                            uint64_t *__restrict__ f4, uint64_t *__restrict__ r4, float *__restrict__ c4) {
+    size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n * 4) return;
+    const size_t i = t >> 2;
+    const uint32_t in = (uint32_t)(t & 3u), uk = (uint32_t)k;
+    const uint32_t oc = code_of_char(ch[i]);
+    const uint64_t s_out = oc < 4 ? seed_of(oc) : 0ull, sc_out = oc < 4 ? seed_of(3u - oc) : 0ull;
+    uint64_t nf, nr = 0;
+    if (direction == 0) {
+        nf = rotl(f[i], 1) ^ rotl(s_out, uk) ^ seed_of(in);
+        if (!stranded) nr = rotr(r[i], 1) ^ rotr(sc_out, 1) ^ rotl(seed_of(3u - in), uk - 1u);
+    } else {
+        nf = rotr(f[i], 1) ^ rotr(s_out, 1) ^ rotl(seed_of(in), uk - 1u);
+        if (!stranded) nr = rotl(r[i], 1) ^ rotl(sc_out, uk) ^ seed_of(3u - in);
+    }
+    f4[t] = nf;
+    if (r4) r4[t] = nr;
+    c4[t] = graph_count(fv, stranded ? nf : smin(nf, nr));
+}
+
+// ---- popcounts (UnsafeByteBuffer.bitPopCount :131-150 / popCount :121-129) ----
+__global__ void k_popcount_bits(const uint32_t *__restrict__ w, size_t n_words, unsigned long long *out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long c = 0;
+    for (; i < n_words; i += (size_t)gridDim.x * blockDim.x) c += __popc(w[i]);
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+__global__ void k_count_nonzero_bytes(const uint32_t *__restrict__ w, size_t n_words, unsigned long long *out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long c = 0;
+    for (; i < n_words; i += (size_t)gridDim.x * blockDim.x) {
+        uint32_t x = w[i];
+        c += ((x & 0xFFu) != 0) + ((x & 0xFF00u) != 0) + ((x & 0xFF0000u) != 0) + ((x & 0xFF000000u) != 0);
+    }
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
+__global__ void k_iota(uint32_t *v, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = (uint32_t)i;
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ graph object ----
+struct rb_graph {
+    rb_graph_params p{};
+    int k = 0, H = 0;
+    bool stranded = false;
+    BitFilter dbg, rpk, fpk;
+    uint8_t *cbf = nullptr;
+    int64_t cbf_size = 0;
+    size_t cbf_alloc = 0;
+    Mod cbf_mod{1, 0, 0};
+    int cbf_h = 0;
+    int read_d = -1, frag_d = -1;
+    uint64_t ordinal = 0;
+    int64_t max_batch_kmers = 0;
+    hipStream_t stream = nullptr;
+    // scratch (grow-only)
+    DevBuf chunk_cnt, chunk_off, keys0, keys1, vals0, vals1, uniq, counts, starts, status, nops, temp,
+        ftable, ctable, heavy, confk, conf_sizes, conf_off, opk0, opk1, opv0, opv1, devctr, qbuf0, qbuf1, qbuf2, qbuf3;
+    // profiling
+    bool prof_on = false;
+    struct ProfEntry { const char *name; double ms; int64_t launches; };
+    std::vector<ProfEntry> prof;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    FilterView view(uint64_t ordinal0, uint32_t pos_bits) const {
+        FilterView fv;
+        fv.dbg = dbg.bits; fv.dbg_mod = dbg.mod; fv.dbg_h = dbg.num_hash;
+        fv.cbf = cbf; fv.cbf_mod = cbf_mod; fv.cbf_h = cbf_h;
+        fv.kmul = kmul_of(k); fv.seed = p.rng_seed; fv.ordinal0 = ordinal0; fv.pos_bits = pos_bits;
+        return fv;
+    }
+    void prof_begin() { if (prof_on) RB_HIP(hipEventRecord(ev0, stream)); }
+    void prof_end(const char *name) {
+        if (!prof_on) return;
+        RB_HIP(hipEventRecord(ev1, stream));
+        RB_HIP(hipEventSynchronize(ev1));
+        float ms = 0;
+        RB_HIP(hipEventElapsedTime(&ms, ev0, ev1));
+        for (auto &e : prof) if (!strcmp(e.name, name)) { e.ms += ms; e.launches++; return; }
+        prof.push_back({name, ms, 1});
+    }
+};
+
+namespace {
+
+void alloc_bits(BitFilter &f, int64_t bits, int num_hash) {
+    f.size = bits;
+    f.nbytes = bits / 8 + ((bits % 8) ? 1 : 0);   // UnsafeBitBuffer.java:34-37
+    f.alloc = (((size_t)f.nbytes + 3) / 4 + 1) * 4;
+    f.num_hash = num_hash;
+    f.mod = make_mod((uint64_t)bits);
+    RB_HIP(hipMalloc(&f.bits, f.alloc));
+    RB_HIP(hipMemset(f.bits, 0, f.alloc));
+}
+void free_bits(BitFilter &f) { if (f.bits) (void)hipFree(f.bits); f = BitFilter(); }
+
+uint32_t log2_ceil(uint64_t x) { uint32_t l = 0; while ((1ull << l) < x) ++l; return l; }
+
+BitFilter *bit_filter(rb_graph *g, int which) {
+    switch (which) { case RB_DBGBF: return &g->dbg; case RB_RPKBF: return &g->rpk; case RB_FPKBF: return &g->fpk; default: return nullptr; }
+}
+
+// The order-exact pipeline over N (h0, occurrence) records already sitting in keys0/vals0.
+void run_pipeline(rb_graph *g, size_t N, int mode, uint64_t ordinal0, uint32_t pos_bits, rb_add_stats *stats) {
+    hipStream_t s = g->stream;
+    if (N == 0) return;
+    // 2. stable sort by base hash
+    g->prof_begin();
+    size_t tb = sort_pairs_temp_bytes(N);
+    g->temp.reserve(std::max({tb, rle_temp_bytes(N), scan_temp_bytes(N + 1)}));
+    g->keys1.reserve(N * 8); g->vals1.reserve(N * 4);
+    sort_pairs_u64_u32(g->temp.p, g->temp.cap, g->keys0.as<uint64_t>(), g->keys1.as<uint64_t>(),
+                       g->vals0.as<uint32_t>(), g->vals1.as<uint32_t>(), N, 0, 64, s);
+    g->prof_end("sort_occurrences");
+    // runs of equal hash = distinct k-mers
+    g->prof_begin();
+    g->uniq.reserve(N * 8); g->counts.reserve((N + 1) * 4); g->starts.reserve((N + 1) * 4);
+    g->devctr.reserve(64);
+    uint32_t *ctr = g->devctr.as<uint32_t>();
+    RB_HIP(hipMemsetAsync(ctr, 0, 64, s));
+    run_length_encode_u64(g->temp.p, g->temp.cap, g->keys1.as<uint64_t>(), N, g->uniq.as<uint64_t>(),
+                          g->counts.as<uint32_t>(), ctr + 8, s);
+    uint32_t D = 0;
+    RB_HIP(hipMemcpyAsync(&D, ctr + 8, 4, hipMemcpyDeviceToHost, s));
+    RB_HIP(hipStreamSynchronize(s));
+    exclusive_scan_u32(g->temp.p, g->temp.cap, g->counts.as<uint32_t>(), g->starts.as<uint32_t>(), D, s);
+    g->prof_end("distinct_runs");
+    if (stats) stats->distinct += D;
+    RB_REQUIRE(D < (1u << 30), "sub-batch has too many distinct k-mers (%u)", D);
+
+    FilterView fv = g->view(ordinal0, pos_bits);
+    const uint64_t *uniq = g->uniq.as<uint64_t>();
+    const uint32_t *counts = g->counts.as<uint32_t>(), *starts = g->starts.as<uint32_t>(), *vals = g->vals1.as<uint32_t>();
+    g->status.reserve((size_t)D * 4); g->nops.reserve((size_t)D * 4);
+    g->heavy.reserve((size_t)D * 4); g->confk.reserve((size_t)D * 4);
+    uint32_t *status = g->status.as<uint32_t>(), *nops = g->nops.as<uint32_t>();
+    const bool uses_dbg = (mode == M_ADD || mode == M_ADD_IF_ABSENT);
+    uint32_t f_log2 = 1, c_log2 = log2_ceil(2ull * (uint64_t)D * (uint64_t)g->cbf_h + 2);
+    g->prof_begin();
+    if (uses_dbg) {
+        f_log2 = log2_ceil(2ull * (uint64_t)D * (uint64_t)g->dbg.num_hash + 2);
+        g->ftable.reserve(sizeof(Slot) << f_log2);
+        RB_HIP(hipMemsetAsync(g->ftable.p, 0xFF, sizeof(Slot) << f_log2, s));
+    }
+    g->ctable.reserve(sizeof(Slot) << c_log2);
+    RB_HIP(hipMemsetAsync(g->ctable.p, 0xFF, sizeof(Slot) << c_log2, s));
+    g->prof_end("table_clear");
+    if (mode != M_COUNT_ONLY) {
+        g->prof_begin();
+        hipLaunchKernelGGL(k_dbg_test, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, uniq, starts, vals, D, mode,
+                           g->ftable.as<Slot>(), f_log2, status);
+        g->prof_end("dbg_test");
+    } else RB_HIP(hipMemsetAsync(status, 0, (size_t)D * 4, s));
+    g->prof_begin();
+    hipLaunchKernelGGL(k_dbg_set_claim, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, uniq, counts, starts, vals, D, mode,
+                       g->ftable.as<Slot>(), f_log2, g->ctable.as<Slot>(), c_log2, status, nops);
+    g->prof_end("dbg_set_claim");
+    g->prof_begin();
+    hipLaunchKernelGGL(k_cbf_apply, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, uniq, counts, starts, vals, D,
+                       g->ctable.as<Slot>(), c_log2, status, nops, g->heavy.as<uint32_t>(), g->confk.as<uint32_t>(), ctr);
+    g->prof_end("cbf_apply");
+    uint32_t hc[3] = {0, 0, 0};
+    RB_HIP(hipMemcpyAsync(hc, ctr, 12, hipMemcpyDeviceToHost, s));
+    RB_HIP(hipStreamSynchronize(s));
+    if (hc[0]) {
+        g->prof_begin();
+        hipLaunchKernelGGL(k_cbf_heavy, dim3(std::min<uint32_t>(hc[0], 16384u)), dim3(64), 0, s, fv, uniq, counts, starts,
+                           vals, status, nops, g->heavy.as<uint32_t>(), ctr);
+        g->prof_end("cbf_heavy");
+    }
+    if (hc[1]) {
+        const uint32_t nck = hc[1], nco = hc[2];
+        g->prof_begin();
+        g->conf_sizes.reserve(((size_t)nck + 1) * 4); g->conf_off.reserve(((size_t)nck + 1) * 4);
+        g->opk0.reserve((size_t)nco * 8); g->opk1.reserve((size_t)nco * 8);
+        g->opv0.reserve((size_t)nco * 4); g->opv1.reserve((size_t)nco * 4);
+        hipLaunchKernelGGL(k_conf_offsets, dim3(blocks_for(nck + 1)), dim3(TPB), 0, s, g->confk.as<uint32_t>(), nops,
+                           nck, g->conf_sizes.as<uint32_t>());
+        g->temp.reserve(std::max(scan_temp_bytes((size_t)nck + 1), sort_pairs_temp_bytes(nco)));
+        exclusive_scan_u32(g->temp.p, g->temp.cap, g->conf_sizes.as<uint32_t>(), g->conf_off.as<uint32_t>(), (size_t)nck + 1, s);
+        hipLaunchKernelGGL(k_conf_expand, dim3(blocks_for((int64_t)nck * 64)), dim3(TPB), 0, s, g->confk.as<uint32_t>(),
+                           g->conf_off.as<uint32_t>(), counts, starts, vals, status, nops, nck,
+                           g->opk0.as<uint64_t>(), g->opv0.as<uint32_t>());
+        sort_pairs_u64_u32(g->temp.p, g->temp.cap, g->opk0.as<uint64_t>(), g->opk1.as<uint64_t>(),
+                           g->opv0.as<uint32_t>(), g->opv1.as<uint32_t>(), nco, 0, 32, s);
+        g->prof_end("conflict_gather_sort");
+        g->prof_begin();
+        hipLaunchKernelGGL(k_conf_replay_serial, dim3(1), dim3(64), 0, s, fv, uniq, g->opk1.as<uint64_t>(),
+                           g->opv1.as<uint32_t>(), nco);
+        g->prof_end("conflict_replay");
+        if (stats) stats->conflict_ops += nco;
+    }
+    RB_HIP(hipGetLastError());
+}
+
+void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigned flags, rb_add_stats *stats) {
+    RB_REQUIRE(b->device == g->p.device, "batch lives on device %d, graph on %d", b->device, g->p.device);
+    RB_REQUIRE(first >= 0 && n >= 0 && first + n <= b->n_reads, "rb_graph_add_batch: bad read range");
+    RB_HIP(hipSetDevice(g->p.device));
+    hipStream_t s = g->stream;
+    const int mode_hash = g->stranded ? ((flags & RB_ADD_REVCOMP) ? 2 : 0) : 1;
+    const int mode = (flags & RB_ADD_COUNT_IF_PRESENT) ? M_COUNT_IF_PRESENT : M_ADD;
+    const bool pairs = (flags & RB_ADD_STORE_READ_PAIRS) != 0;
+    if (pairs) RB_REQUIRE(g->rpk.bits && g->read_d > 0, "STORE_READ_PAIRS needs use_read_paired_kmers and a read pair distance > 0");
+    uint32_t pos_bits = 1;
+    while ((1u << pos_bits) <= b->max_len && pos_bits < 31) ++pos_bits;
+    const int64_t max_reads = (int64_t)1 << (32 - pos_bits);
+    const int64_t max_words = std::max<int64_t>(g->max_batch_kmers / 32, 1);
+    const std::vector<uint32_t> &wo = b->h_woff;
+    int64_t r0 = first;
+    const int64_t rend = first + n;
+    while (r0 < rend) {
+        // largest r1 with words(r0..r1) <= max_words and r1-r0 <= max_reads (at least one read)
+        int64_t hi = std::min(rend, r0 + max_reads);
+        int64_t lo = r0 + 1;
+        while (lo < hi) {
+            int64_t mid = (lo + hi + 1) >> 1;
+            if ((int64_t)wo[(size_t)mid] - (int64_t)wo[(size_t)r0] <= max_words) lo = mid; else hi = mid - 1;
+        }
+        const int64_t r1 = lo;
+        const int64_t w0 = wo[(size_t)r0], nw = (int64_t)wo[(size_t)r1] - w0;
+        uint32_t N = 0;
+        if (nw > 0) {
+            g->prof_begin();
+            g->chunk_cnt.reserve(((size_t)nw + 1) * 4); g->chunk_off.reserve(((size_t)nw + 1) * 4);
+            RB_HIP(hipMemsetAsync(g->chunk_cnt.as<uint32_t>() + nw, 0, 4, s));
+            launch_count_windows(b, w0, nw, g->k, g->chunk_cnt.as<uint32_t>(), s);
+            g->temp.reserve(scan_temp_bytes((size_t)nw + 1));
+            exclusive_scan_u32(g->temp.p, g->temp.cap, g->chunk_cnt.as<uint32_t>(), g->chunk_off.as<uint32_t>(), (size_t)nw + 1, s);
+            RB_HIP(hipMemcpyAsync(&N, g->chunk_off.as<uint32_t>() + nw, 4, hipMemcpyDeviceToHost, s));
+            RB_HIP(hipStreamSynchronize(s));
+            g->prof_end("count_windows");
+            if (N) {
+                g->prof_begin();
+                g->keys0.reserve((size_t)N * 8); g->vals0.reserve((size_t)N * 4);
+                launch_hash_windows(b, w0, nw, g->k, mode_hash, g->chunk_off.as<uint32_t>(), (uint32_t)r0, pos_bits,
+                                    g->keys0.as<uint64_t>(), g->vals0.as<uint32_t>(), nullptr, nullptr, s);
+                g->prof_end("hash_windows");
+            }
+            if (pairs) {
+                g->prof_begin();
+                g->devctr.reserve(64);
+                unsigned long long *pc = reinterpret_cast<unsigned long long *>(g->devctr.as<uint32_t>() + 12);
+                RB_HIP(hipMemsetAsync(pc, 0, 8, s));
+                dim3 gr(blocks_for(nw)), th(TPB);
+#define RB_LAUNCH_PAIRS(M)                                                                                   \
+    hipLaunchKernelGGL(k_pairs_insert<M>, gr, th, 0, s, b->codes, b->valid, b->word_read, b->woff, b->len, w0, nw, \
+                       g->k, g->read_d, g->rpk.bits, g->rpk.mod, g->rpk.num_hash, kmul_of(g->k), pc)
+                if (mode_hash == 0) RB_LAUNCH_PAIRS(0); else if (mode_hash == 2) RB_LAUNCH_PAIRS(2); else RB_LAUNCH_PAIRS(1);
+#undef RB_LAUNCH_PAIRS
+                unsigned long long np = 0;
+                RB_HIP(hipMemcpyAsync(&np, pc, 8, hipMemcpyDeviceToHost, s));
+                RB_HIP(hipStreamSynchronize(s));
+                g->prof_end("pairs_insert");
+                if (stats) stats->pairs += (int64_t)np;
+            }
+        }
+        run_pipeline(g, N, mode, g->ordinal + (uint64_t)(r0 - first), pos_bits, stats);
+        if (stats) { stats->kmers += N; stats->reads += r1 - r0; }
+        r0 = r1;
+    }
+    g->ordinal += (uint64_t)n;
+    RB_HIP(hipStreamSynchronize(s));
+}
+
+template <typename F> int guarded(F &&f) {
+    try { f(); return RB_OK; }
+    catch (const HipError &e) { return e.code; }
+    catch (const std::bad_alloc &) { set_error("host allocation failed"); return RB_ERR_NOMEM; }
+}
+
+// upload n base hashes into a scratch buffer
+uint64_t *upload_h0(rb_graph *g, DevBuf &buf, const uint64_t *h0, size_t n) {
+    buf.reserve(std::max<size_t>(n, 1) * 8);
+    RB_HIP(hipMemcpyAsync(buf.p, h0, n * 8, hipMemcpyHostToDevice, g->stream));
+    return buf.as<uint64_t>();
+}
+
+}  // namespace
+
+// ----------------------------------------------------------------------- C ABI ----
+extern "C" {
+
+int rb_version(void) { return 1; }
+const char *rb_last_error(void) { return rb::g_err; }
+
+int rb_graph_create(const rb_graph_params *p, rb_graph **out) {
+    rb_graph *g = nullptr;
+    int rc = guarded([&] {
+        RB_REQUIRE(p && out, "rb_graph_create: null argument");
+        RB_REQUIRE(p->k >= 1 && p->k <= RB_MAX_K, "rb_graph_create: k=%d out of range [1,%d]", p->k, RB_MAX_K);
+        RB_REQUIRE(p->dbgbf_bits > 0 && p->cbf_bytes > 0, "rb_graph_create: filter sizes must be positive");
+        RB_REQUIRE(p->dbgbf_num_hash >= 1 && p->dbgbf_num_hash <= RB_MAX_HASH && p->cbf_num_hash >= 1 &&
+                   p->cbf_num_hash <= RB_MAX_HASH, "rb_graph_create: numHash out of range [1,%d]", RB_MAX_HASH);
+        if (p->use_read_paired_kmers)
+            RB_REQUIRE(p->pkbf_bits > 0 && p->pkbf_num_hash >= 1 && p->pkbf_num_hash <= RB_MAX_HASH,
+                       "rb_graph_create: pair filter parameters invalid");
+        int ndev = 0;
+        RB_HIP(hipGetDeviceCount(&ndev));
+        RB_REQUIRE(p->device >= 0 && p->device < ndev, "rb_graph_create: device %d not present (%d devices)", p->device, ndev);
+        RB_HIP(hipSetDevice(p->device));
+        g = new rb_graph();
+        g->p = *p;
+        g->k = p->k;
+        g->stranded = p->stranded != 0;
+        g->H = std::max(p->dbgbf_num_hash, p->cbf_num_hash);
+        g->max_batch_kmers = p->max_batch_kmers > 0 ? p->max_batch_kmers : ((int64_t)1 << 28);
+        RB_REQUIRE(g->max_batch_kmers <= ((int64_t)1 << 31), "rb_graph_create: max_batch_kmers above 2^31");
+        RB_HIP(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+        RB_HIP(hipEventCreate(&g->ev0));
+        RB_HIP(hipEventCreate(&g->ev1));
+        alloc_bits(g->dbg, p->dbgbf_bits, p->dbgbf_num_hash);
+        g->cbf_size = p->cbf_bytes;
+        g->cbf_alloc = (((size_t)p->cbf_bytes + 3) / 4 + 1) * 4;
+        g->cbf_h = p->cbf_num_hash;
+        g->cbf_mod = make_mod((uint64_t)p->cbf_bytes);
+        RB_HIP(hipMalloc(&g->cbf, g->cbf_alloc));
+        RB_HIP(hipMemset(g->cbf, 0, g->cbf_alloc));
+        if (p->use_read_paired_kmers) alloc_bits(g->rpk, p->pkbf_bits, p->pkbf_num_hash);
+        RB_HIP(hipDeviceSynchronize());
+        *out = g;
+    });
+    if (rc != RB_OK && g) { rb_graph_destroy(g); }
+    return rc;
+}
+
+int rb_graph_destroy(rb_graph *g) {
+    if (!g) return RB_OK;
+    (void)hipSetDevice(g->p.device);
+    if (g->stream) (void)hipStreamSynchronize(g->stream);
+    free_bits(g->dbg); free_bits(g->rpk); free_bits(g->fpk);
+    if (g->cbf) (void)hipFree(g->cbf);
+    DevBuf *bufs[] = {&g->chunk_cnt, &g->chunk_off, &g->keys0, &g->keys1, &g->vals0, &g->vals1, &g->uniq, &g->counts,
+                      &g->starts, &g->status, &g->nops, &g->temp, &g->ftable, &g->ctable, &g->heavy, &g->confk,
+                      &g->conf_sizes, &g->conf_off, &g->opk0, &g->opk1, &g->opv0, &g->opv1, &g->devctr, &g->qbuf0,
+                      &g->qbuf1, &g->qbuf2, &g->qbuf3};
+    for (auto *b : bufs) b->release();
+    if (g->ev0) (void)hipEventDestroy(g->ev0);
+    if (g->ev1) (void)hipEventDestroy(g->ev1);
+    if (g->stream) (void)hipStreamDestroy(g->stream);
+    delete g;
+    return RB_OK;
+}
+
+int rb_graph_clear(rb_graph *g, unsigned which_mask) {
+    return guarded([&] {
+        RB_REQUIRE(g, "rb_graph_clear: null graph");
+        RB_HIP(hipSetDevice(g->p.device));
+        if ((which_mask & 1u) && g->dbg.bits) RB_HIP(hipMemsetAsync(g->dbg.bits, 0, g->dbg.alloc, g->stream));
+        if ((which_mask & 2u) && g->cbf) RB_HIP(hipMemsetAsync(g->cbf, 0, g->cbf_alloc, g->stream));
+        if ((which_mask & 4u) && g->rpk.bits) RB_HIP(hipMemsetAsync(g->rpk.bits, 0, g->rpk.alloc, g->stream));
+        if ((which_mask & 8u) && g->fpk.bits) RB_HIP(hipMemsetAsync(g->fpk.bits, 0, g->fpk.alloc, g->stream));
+        if ((which_mask & 3u) == 3u) g->ordinal = 0;
+        RB_HIP(hipStreamSynchronize(g->stream));
+    });
+}
+
+int rb_graph_set_read_paired_kmer_distance(rb_graph *g, int d) {
+    if (!g) { set_error("null graph"); return RB_ERR_INVALID; }
+    g->read_d = d; return RB_OK;
+}
+int rb_graph_set_frag_paired_kmer_distance(rb_graph *g, int d) {
+    if (!g) { set_error("null graph"); return RB_ERR_INVALID; }
+    g->frag_d = d; return RB_OK;
+}
+int rb_graph_init_fragment_pairs(rb_graph *g, int64_t pkbf_bits, int pkbf_num_hash) {
+    return guarded([&] {
+        RB_REQUIRE(g && pkbf_bits > 0 && pkbf_num_hash >= 1 && pkbf_num_hash <= RB_MAX_HASH, "rb_graph_init_fragment_pairs: bad argument");
+        RB_HIP(hipSetDevice(g->p.device));
+        if (!g->fpk.bits) alloc_bits(g->fpk, pkbf_bits, pkbf_num_hash);   // :352-359: create once, else empty()
+        else RB_HIP(hipMemset(g->fpk.bits, 0, g->fpk.alloc));
+    });
+}
+int rb_graph_get_op_ordinal(rb_graph *g, uint64_t *out) {
+    if (!g || !out) { set_error("null argument"); return RB_ERR_INVALID; }
+    *out = g->ordinal; return RB_OK;
+}
+int rb_graph_set_op_ordinal(rb_graph *g, uint64_t v) {
+    if (!g) { set_error("null graph"); return RB_ERR_INVALID; }
+    g->ordinal = v; return RB_OK;
+}
+
+int rb_graph_add_batch_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigned flags, rb_add_stats *stats) {
+    return guarded([&] {
+        RB_REQUIRE(g && b, "rb_graph_add_batch: null argument");
+        if (stats) memset(stats, 0, sizeof *stats);
+        add_range(g, b, first, n, flags, stats);
+    });
+}
+int rb_graph_add_batch(rb_graph *g, const rb_batch *b, unsigned flags, rb_add_stats *stats) {
+    if (!b) { set_error("rb_graph_add_batch: null batch"); return RB_ERR_INVALID; }
+    return rb_graph_add_batch_range(g, b, 0, b->n_reads, flags, stats);
+}
+int rb_graph_add_reads(rb_graph *g, const char *seq, const char *qual, const int64_t *offsets, int64_t n_reads,
+                       int min_base_qual, unsigned flags, rb_add_stats *stats) {
+    if (!g) { set_error("rb_graph_add_reads: null graph"); return RB_ERR_INVALID; }
+    rb_batch *b = nullptr;
+    int rc = rb_batch_create_ascii(g->p.device, seq, qual, offsets, n_reads, min_base_qual, &b);
+    if (rc != RB_OK) return rc;
+    rc = rb_graph_add_batch(g, b, flags, stats);
+    rb_batch_destroy(b);
+    return rc;
+}
+
+int rb_graph_apply(rb_graph *g, int op, const uint64_t *h0, size_t n) {
+    return guarded([&] {
+        RB_REQUIRE(g && (h0 || n == 0), "rb_graph_apply: null argument");
+        RB_REQUIRE(op >= RB_OP_ADD && op <= RB_OP_ADD_FRAG_PAIR, "rb_graph_apply: unknown op %d", op);
+        RB_HIP(hipSetDevice(g->p.device));
+        hipStream_t s = g->stream;
+        if (op == RB_OP_ADD_DBG_ONLY || op == RB_OP_ADD_READ_PAIR || op == RB_OP_ADD_FRAG_PAIR) {
+            BitFilter *f = op == RB_OP_ADD_DBG_ONLY ? &g->dbg : op == RB_OP_ADD_READ_PAIR ? &g->rpk : &g->fpk;
+            if (!f->bits) { set_error("rb_graph_apply: filter not initialised"); throw HipError{RB_ERR_STATE}; }
+            if (n) {
+                uint64_t *d = upload_h0(g, g->qbuf0, h0, n);
+                hipLaunchKernelGGL(k_bits_add, dim3(blocks_for((int64_t)n)), dim3(TPB), 0, s, f->bits, f->mod, f->num_hash,
+                                   kmul_of(g->k), d, n);
+                RB_HIP(hipGetLastError());
+            }
+            RB_HIP(hipStreamSynchronize(s));
+            return;
+        }
+        const int mode = op == RB_OP_ADD ? M_ADD : op == RB_OP_ADD_IF_ABSENT ? M_ADD_IF_ABSENT
+                       : op == RB_OP_ADD_COUNT_IF_PRESENT ? M_COUNT_IF_PRESENT : M_COUNT_ONLY;
+        size_t done = 0;
+        const size_t chunk = (size_t)g->max_batch_kmers;
+        while (done < n) {
+            size_t m = std::min(chunk, n - done);
+            g->keys0.reserve(m * 8); g->vals0.reserve(m * 4);
+            RB_HIP(hipMemcpyAsync(g->keys0.p, h0 + done, m * 8, hipMemcpyHostToDevice, s));
+            hipLaunchKernelGGL(k_iota, dim3(blocks_for((int64_t)m)), dim3(TPB), 0, s, g->vals0.as<uint32_t>(), m);
+            run_pipeline(g, m, mode, g->ordinal, 0, nullptr);
+            g->ordinal += m;
+            done += m;
+        }
+        RB_HIP(hipStreamSynchronize(s));
+    });
+}
+
+int rb_filter_lookup(rb_graph *g, int which, const uint64_t *h0, size_t n, uint8_t *out) {
+    return guarded([&] {
+        RB_REQUIRE(g && (n == 0 || (h0 && out)), "rb_filter_lookup: null argument");
+        BitFilter *f = bit_filter(g, which);
+        RB_REQUIRE(f, "rb_filter_lookup: filter %d is not a bit filter", which);
+        if (!f->bits) { set_error("rb_filter_lookup: filter %d not initialised", which); throw HipError{RB_ERR_STATE}; }
+        if (!n) return;
+        RB_HIP(hipSetDevice(g->p.device));
+        uint64_t *d = upload_h0(g, g->qbuf0, h0, n);
+        g->qbuf1.reserve(n);
+        hipLaunchKernelGGL(k_bits_lookup, dim3(blocks_for((int64_t)n)), dim3(TPB), 0, g->stream, f->bits, f->mod, f->num_hash,
+                           kmul_of(g->k), d, n, g->qbuf1.as<uint8_t>());
+        RB_HIP(hipGetLastError());
+        RB_HIP(hipMemcpyAsync(out, g->qbuf1.p, n, hipMemcpyDeviceToHost, g->stream));
+        RB_HIP(hipStreamSynchronize(g->stream));
+    });
+}
+int rb_graph_contains(rb_graph *g, const uint64_t *h0, size_t n, uint8_t *out) { return rb_filter_lookup(g, RB_DBGBF, h0, n, out); }
+
+static int count_common(rb_graph *g, const uint64_t *h0, size_t n, float *out, bool graph_level) {
+    return guarded([&] {
+        RB_REQUIRE(g && (n == 0 || (h0 && out)), "rb_graph_count: null argument");
+        if (!n) return;
+        RB_HIP(hipSetDevice(g->p.device));
+        uint64_t *d = upload_h0(g, g->qbuf0, h0, n);
+        g->qbuf1.reserve(n * 4);
+        FilterView fv = g->view(0, 0);
+        if (graph_level) hipLaunchKernelGGL(k_graph_count, dim3(blocks_for((int64_t)n)), dim3(TPB), 0, g->stream, fv, d, n, g->qbuf1.as<float>());
+        else hipLaunchKernelGGL(k_cbf_count, dim3(blocks_for((int64_t)n)), dim3(TPB), 0, g->stream, fv, d, n, g->qbuf1.as<float>());
+        RB_HIP(hipGetLastError());
+        RB_HIP(hipMemcpyAsync(out, g->qbuf1.p, n * 4, hipMemcpyDeviceToHost, g->stream));
+        RB_HIP(hipStreamSynchronize(g->stream));
+    });
+}
+int rb_graph_count(rb_graph *g, const uint64_t *h0, size_t n, float *out) { return count_common(g, h0, n, out, true); }
+int rb_filter_get_count(rb_graph *g, const uint64_t *h0, size_t n, float *out) { return count_common(g, h0, n, out, false); }
+
+int rb_graph_kmers(rb_graph *g, const char *seq, const int64_t *offsets, int64_t n_reads, int64_t *koffsets,
+                   uint64_t *f, uint64_t *r, float *count) {
+    return guarded([&] {
+        RB_REQUIRE(g && offsets && koffsets && n_reads >= 0, "rb_graph_kmers: null argument");
+        koffsets[0] = 0;
+        for (int64_t i = 0; i < n_reads; ++i) {
+            int64_t l = offsets[i + 1] - offsets[i];
+            koffsets[i + 1] = koffsets[i] + (l >= g->k ? l - g->k + 1 : 0);
+        }
+        const int64_t total = koffsets[n_reads];
+        if (!f || !count || total == 0) return;
+        rb_batch *b = nullptr;
+        int rc = rb_batch_create_ascii(g->p.device, seq, nullptr, offsets, n_reads, 0, &b);
+        if (rc != RB_OK) throw HipError{rc};
+        struct G { rb_batch *b; ~G() { rb_batch_destroy(b); } } guard{b};
+        RB_HIP(hipSetDevice(g->p.device));
+        g->qbuf0.reserve(((size_t)n_reads + 1) * 8); g->qbuf1.reserve((size_t)total * 8);
+        g->qbuf2.reserve((size_t)total * 8); g->qbuf3.reserve((size_t)total * 4);
+        RB_HIP(hipMemcpyAsync(g->qbuf0.p, koffsets, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, g->stream));
+        hipLaunchKernelGGL(k_get_kmers, dim3(blocks_for(b->n_words)), dim3(TPB), 0, g->stream, g->view(0, 0), (int)g->stranded,
+                           b->codes, b->valid, b->word_read, b->woff, b->len, b->n_words, g->k, g->qbuf0.as<int64_t>(),
+                           g->qbuf1.as<uint64_t>(), g->qbuf2.as<uint64_t>(), g->qbuf3.as<float>());
+        RB_HIP(hipGetLastError());
+        RB_HIP(hipMemcpyAsync(f, g->qbuf1.p, (size_t)total * 8, hipMemcpyDeviceToHost, g->stream));
+        if (r) RB_HIP(hipMemcpyAsync(r, g->qbuf2.p, (size_t)total * 8, hipMemcpyDeviceToHost, g->stream));
+        RB_HIP(hipMemcpyAsync(count, g->qbuf3.p, (size_t)total * 4, hipMemcpyDeviceToHost, g->stream));
+        RB_HIP(hipStreamSynchronize(g->stream));
+    });
+}
+
+int rb_graph_neighbors(rb_graph *g, const uint64_t *f, const uint64_t *r, const uint8_t *char_out, size_t n,
+                       int direction, uint64_t *f4, uint64_t *r4, float *count4) {
+    return guarded([&] {
+        RB_REQUIRE(g && (n == 0 || (f && char_out && f4 && count4)), "rb_graph_neighbors: null argument");
+        RB_REQUIRE(g->stranded || n == 0 || r, "rb_graph_neighbors: reverse hashes required for a canonical graph");
+        RB_REQUIRE(direction == 0 || direction == 1, "rb_graph_neighbors: direction must be 0 or 1");
+        if (!n) return;
+        RB_HIP(hipSetDevice(g->p.device));
+        hipStream_t s = g->stream;
+        g->qbuf0.reserve(n * 8 * 2 + n); g->qbuf1.reserve(n * 32); g->qbuf2.reserve(n * 32); g->qbuf3.reserve(n * 16);
+        uint64_t *df = g->qbuf0.as<uint64_t>(), *dr = df + n;
+        uint8_t *dc = reinterpret_cast<uint8_t *>(dr + n);
+        RB_HIP(hipMemcpyAsync(df, f, n * 8, hipMemcpyHostToDevice, s));
+        if (r) RB_HIP(hipMemcpyAsync(dr, r, n * 8, hipMemcpyHostToDevice, s));
+        RB_HIP(hipMemcpyAsync(dc, char_out, n, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_neighbors, dim3(blocks_for((int64_t)n * 4)), dim3(TPB), 0, s, g->view(0, 0), (int)g->stranded, g->k,
+                           direction, df, dr, dc, n, g->qbuf1.as<uint64_t>(), g->qbuf2.as<uint64_t>(), g->qbuf3.as<float>());
+        RB_HIP(hipGetLastError());
+        RB_HIP(hipMemcpyAsync(f4, g->qbuf1.p, n * 32, hipMemcpyDeviceToHost, s));
+        if (r4) RB_HIP(hipMemcpyAsync(r4, g->qbuf2.p, n * 32, hipMemcpyDeviceToHost, s));
+        RB_HIP(hipMemcpyAsync(count4, g->qbuf3.p, n * 16, hipMemcpyDeviceToHost, s));
+        RB_HIP(hipStreamSynchronize(s));
+    });
+}
+
+int rb_filter_size(rb_graph *g, int which, int64_t *size, int64_t *nbytes, int *num_hash) {
+    if (!g) { set_error("null graph"); return RB_ERR_INVALID; }
+    if (which == RB_CBF) {
+        if (size) *size = g->cbf_size;
+        if (nbytes) *nbytes = g->cbf_size;
+        if (num_hash) *num_hash = g->cbf_h;
+        return RB_OK;
+    }
+    BitFilter *f = bit_filter(g, which);
+    if (!f) { set_error("rb_filter_size: unknown filter %d", which); return RB_ERR_INVALID; }
+    if (!f->bits) { set_error("rb_filter_size: filter %d not initialised", which); return RB_ERR_STATE; }
+    if (size) *size = f->size;
+    if (nbytes) *nbytes = f->nbytes;
+    if (num_hash) *num_hash = f->num_hash;
+    return RB_OK;
+}
+
+int rb_filter_popcount(rb_graph *g, int which, int64_t *out) {
+    return guarded([&] {
+        RB_REQUIRE(g && out, "rb_filter_popcount: null argument");
+        RB_HIP(hipSetDevice(g->p.device));
+        g->devctr.reserve(64);
+        unsigned long long *acc = reinterpret_cast<unsigned long long *>(g->devctr.as<uint32_t>() + 14);
+        RB_HIP(hipMemsetAsync(acc, 0, 8, g->stream));
+        if (which == RB_CBF) {
+            size_t nw = g->cbf_alloc / 4;   // padding bytes are zero
+            hipLaunchKernelGGL(k_count_nonzero_bytes, dim3(std::min<unsigned>(blocks_for((int64_t)nw), 8192u)), dim3(TPB), 0, g->stream,
+                               reinterpret_cast<const uint32_t *>(g->cbf), nw, acc);
+        } else {
+            BitFilter *f = bit_filter(g, which);
+            RB_REQUIRE(f, "rb_filter_popcount: unknown filter %d", which);
+            if (!f->bits) { set_error("rb_filter_popcount: filter %d not initialised", which); throw HipError{RB_ERR_STATE}; }
+            size_t nw = f->alloc / 4;
+            hipLaunchKernelGGL(k_popcount_bits, dim3(std::min<unsigned>(blocks_for((int64_t)nw), 8192u)), dim3(TPB), 0, g->stream, f->bits, nw, acc);
+        }
+        RB_HIP(hipGetLastError());
+        unsigned long long v = 0;
+        RB_HIP(hipMemcpyAsync(&v, acc, 8, hipMemcpyDeviceToHost, g->stream));
+        RB_HIP(hipStreamSynchronize(g->stream));
+        *out = (int64_t)v;
+    });
+}
+
+int rb_filter_fpr(rb_graph *g, int which, float *out) {
+    int64_t pop = 0, size = 0; int h = 0;
+    int rc = rb_filter_popcount(g, which, &pop);
+    if (rc != RB_OK) return rc;
+    rc = rb_filter_size(g, which, &size, nullptr, &h);
+    if (rc != RB_OK) return rc;
+    if (!out) { set_error("null argument"); return RB_ERR_INVALID; }
+    *out = (float)pow((double)pop / (double)size, h);   // BloomFilter.getFPR :185-194
+    return RB_OK;
+}
+
+int rb_filter_export(rb_graph *g, int which, void *dst, size_t nbytes) {
+    return guarded([&] {
+        RB_REQUIRE(g && dst, "rb_filter_export: null argument");
+        RB_HIP(hipSetDevice(g->p.device));
+        const void *src; size_t have;
+        if (which == RB_CBF) { src = g->cbf; have = (size_t)g->cbf_size; }
+        else {
+            BitFilter *f = bit_filter(g, which);
+            RB_REQUIRE(f, "rb_filter_export: unknown filter %d", which);
+            if (!f->bits) { set_error("rb_filter_export: filter %d not initialised", which); throw HipError{RB_ERR_STATE}; }
+            src = f->bits; have = (size_t)f->nbytes;
+        }
+        RB_REQUIRE(nbytes == have, "rb_filter_export: buffer is %zu bytes, filter has %zu", nbytes, have);
+        RB_HIP(hipStreamSynchronize(g->stream));
+        RB_HIP(hipMemcpy(dst, src, have, hipMemcpyDeviceToHost));
+    });
+}
+
+int rb_filter_import(rb_graph *g, int which, const void *srcp, size_t nbytes) {
+    return guarded([&] {
+        RB_REQUIRE(g && srcp, "rb_filter_import: null argument");
+        RB_HIP(hipSetDevice(g->p.device));
+        void *dst; size_t have, alloc;
+        if (which == RB_CBF) { dst = g->cbf; have = (size_t)g->cbf_size; alloc = g->cbf_alloc; }
+        else {
+            BitFilter *f = bit_filter(g, which);
+            RB_REQUIRE(f, "rb_filter_import: unknown filter %d", which);
+            if (!f->bits) { set_error("rb_filter_import: filter %d not initialised", which); throw HipError{RB_ERR_STATE}; }
+            dst = f->bits; have = (size_t)f->nbytes; alloc = f->alloc;
+        }
+        RB_REQUIRE(nbytes == have, "rb_filter_import: buffer is %zu bytes, filter has %zu", nbytes, have);
+        RB_HIP(hipStreamSynchronize(g->stream));
+        RB_HIP(hipMemset(dst, 0, alloc));
+        RB_HIP(hipMemcpy(dst, srcp, have, hipMemcpyHostToDevice));
+    });
+}
+
+int64_t rb_expected_size(int64_t n, float fpr, int num_hash) {   // BloomFilter.getExpectedSize :196-199
+    double r = (double)(-num_hash) / log(1 - exp(log((double)fpr) / (double)num_hash));
+    return (int64_t)ceil((double)n * r);
+}
+
+int rb_graph_profile_enable(rb_graph *g, int on) {
+    if (!g) { set_error("null graph"); return RB_ERR_INVALID; }
+    g->prof_on = on != 0; return RB_OK;
+}
+int rb_graph_profile_get(rb_graph *g, rb_profile *out, int reset) {
+    if (!g || !out) { set_error("null argument"); return RB_ERR_INVALID; }
+    out->n = 0;
+    for (auto &e : g->prof) {
+        if (out->n >= RB_PROF_MAX) break;
+        out->name[out->n] = e.name; out->ms[out->n] = e.ms; out->launches[out->n] = e.launches; out->n++;
+    }
+    if (reset) g->prof.clear();
+    return RB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,93 @@
+// rb_internal.hpp — host-side internals shared by the translation units of librb_hip.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/rb_capi.h"
+#include "rb_device.hpp"
+
+namespace rb {
+
+void set_error(const char *fmt, ...);
+
+struct HipError {
+    int code;
+};
+
+#define RB_HIP(expr)                                                                        \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) {                                                             \
+            ::rb::set_error("%s:%d: %s -> %s", __FILE__, __LINE__, #expr, hipGetErrorString(_e)); \
+            throw ::rb::HipError{_e == hipErrorOutOfMemory ? RB_ERR_NOMEM : RB_ERR_HIP};    \
+        }                                                                                   \
+    } while (0)
+
+#define RB_REQUIRE(cond, ...)                          \
+    do {                                               \
+        if (!(cond)) {                                 \
+            ::rb::set_error(__VA_ARGS__);              \
+            throw ::rb::HipError{RB_ERR_INVALID};      \
+        }                                              \
+    } while (0)
+
+// grow-only device buffer
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    void reserve(size_t bytes) {
+        if (bytes <= cap) return;
+        if (p) RB_HIP(hipFree(p));
+        p = nullptr; cap = 0;
+        size_t want = bytes + (bytes >> 3) + 256;
+        RB_HIP(hipMalloc(&p, want));
+        cap = want;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+    }
+    template <typename T> T *as() const { return reinterpret_cast<T *>(p); }
+};
+
+}  // namespace rb
+
+// ---- device-resident read batch (packed) ----
+// Read r occupies words [woff[r], woff[r+1]) ; word w holds 32 bases: 2-bit codes in codes[w]
+// (base i at bits 2i..2i+1, LSB first) and one usable-bit per base in valid[w].
+struct rb_batch {
+    int device = 0;
+    int64_t n_reads = 0, n_bases = 0, n_words = 0;
+    uint32_t max_len = 0;
+    uint64_t *codes = nullptr;     // [n_words]
+    uint32_t *valid = nullptr;     // [n_words]
+    uint32_t *word_read = nullptr; // [n_words] owning read of each word
+    uint32_t *woff = nullptr;      // [n_reads+1]
+    uint32_t *len = nullptr;       // [n_reads]
+    size_t device_bytes = 0;
+    std::vector<uint32_t> h_woff;  // host copy of woff (sub-batch splitting)
+};
+
+namespace rb {
+
+// rocPRIM-backed primitives (rb_sort.hip)
+size_t sort_pairs_temp_bytes(size_t n);
+void sort_pairs_u64_u32(void *temp, size_t temp_bytes, uint64_t *keys_in, uint64_t *keys_out,
+                        uint32_t *vals_in, uint32_t *vals_out, size_t n, int begin_bit, int end_bit,
+                        hipStream_t s);
+size_t sort_pairs32_temp_bytes(size_t n);
+void sort_pairs_u64_u64(void *temp, size_t temp_bytes, uint64_t *keys_in, uint64_t *keys_out,
+                        uint64_t *vals_in, uint64_t *vals_out, size_t n, int begin_bit, int end_bit,
+                        hipStream_t s);
+size_t scan_temp_bytes(size_t n);
+void exclusive_scan_u32(void *temp, size_t temp_bytes, const uint32_t *in, uint32_t *out, size_t n,
+                        hipStream_t s);
+size_t rle_temp_bytes(size_t n);
+void run_length_encode_u64(void *temp, size_t temp_bytes, const uint64_t *keys, size_t n,
+                           uint64_t *uniq, uint32_t *counts, uint32_t *n_runs_dev, hipStream_t s);
+
+}  // namespace rb

@@ -1,0 +1,246 @@
+"""GPU parity tests: the HIP path (through the C ABI) vs the CPU oracle on the same seeded inputs.
+Bit-exact bar: hash values, dbgbf / rpkbf / fpkbf bytes, cbf bytes, popcounts, counts."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import rbo
+from rnabloom import _native as N
+from rnabloom import synth
+from rnabloom.graph import BloomFilterDeBruijnGraph, ReadBatch
+
+
+def make_reads(n_pairs, G, err, n_rate, seed, sigma=2.0, uniform=False):
+    d = synth.generate_pairs(n_pairs, G=G, err=err, n_rate=n_rate, seed=seed, sigma=sigma, uniform_expr=uniform)
+    ls, off = synth.flat(d["left"]); lq, _ = synth.flat(d["lqual"])
+    rs, _ = synth.flat(d["right"]); rq, _ = synth.flat(d["rqual"])
+    return (ls, lq, off), (rs, rq, off)
+
+
+def ragged_reads(seed, n=400):
+    rng = np.random.default_rng(seed)
+    reads, quals = [], []
+    for i in range(n):
+        L = int(rng.choice([0, 1, 10, 24, 25, 26, 31, 32, 33, 57, 64, 65, 100, 150, 151, 300, 1000]))
+        s = np.frombuffer(b"ACGTacgtUuNRY", np.uint8)[rng.choice(13, L, p=[.2, .2, .2, .2, .03, .03, .03, .03, .01, .01, .03, .02, .01])]
+        q = np.where(rng.random(L) < 0.03, ord("#"), ord("I")).astype(np.uint8)
+        q[rng.random(L) < 0.01] = ord("$")
+        reads.append(s.tobytes()); quals.append(q.tobytes())
+    return reads, quals
+
+
+@pytest.mark.parametrize("k", [1, 5, 25, 32, 33, 35, 64, 65, 130])
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_nthash_batch_matches_iterators(k, mode):
+    reads, quals = ragged_reads(k * 3 + mode)
+    b = ReadBatch.from_reads(reads, quals, 3)
+    h0, rd, ps = b.nthash(k, mode, with_positions=True)
+    exp_h, exp_r, exp_p = [], [], []
+    for i, (s, q) in enumerate(zip(reads, quals)):
+        if len(s) < k:
+            continue
+        for a, e in rbo.segments(s, q, k, 3):
+            h, _ = rbo.hash_region(s, k, 1, mode, a, e)
+            exp_h.append(h[:, 0]); exp_r.append(np.full(len(h), i)); exp_p.append(np.arange(a, a + len(h)))
+    exp_h = np.concatenate(exp_h) if exp_h else np.zeros(0, np.uint64)
+    assert len(h0) == len(exp_h)
+    assert (h0 == exp_h).all()
+    if len(h0):
+        assert (rd == np.concatenate(exp_r)).all() and (ps == np.concatenate(exp_p)).all()
+
+
+def test_batch_roundtrip_download():
+    reads, quals = ragged_reads(99, 100)
+    b = ReadBatch.from_reads(reads, None)
+    seq, off = b.download()
+    for i, s in enumerate(reads):
+        got = bytes(seq[off[i]:off[i + 1]])
+        exp = bytes(c if c in b"ACGT" else (ord("T") if c in b"Uu" else (c - 32 if c in b"acgt" else ord("N"))) for c in s)
+        assert got == exp
+
+
+def graph_pair(dbg_bits, cbf_bytes, pk_bits, k=25, stranded=False, dbg_h=2, cbf_h=2, pk_h=2, seed=7, pairs=True,
+               max_batch=0):
+    og = rbo.Graph(dbg_bits, cbf_bytes, pk_bits, dbg_h, cbf_h, pk_h, k, stranded, pairs, seed)
+    gg = BloomFilterDeBruijnGraph(dbg_bits, cbf_bytes, pk_bits, dbg_h, cbf_h, pk_h, k, stranded, pairs,
+                                  rngSeed=seed, maxBatchKmers=max_batch)
+    return og, gg
+
+
+def assert_same_state(og, gg, pairs=True):
+    assert (gg.exportFilter(N.DBGBF) == og.dbgbf_bytes()).all(), "dbgbf differs"
+    c_g, c_o = gg.exportFilter(N.CBF), og.cbf_bytes()
+    bad = np.nonzero(c_g != c_o)[0]
+    assert bad.size == 0, "cbf differs at %d bytes, first %s: gpu %s oracle %s" % (bad.size, bad[:5], c_g[bad[:5]], c_o[bad[:5]])
+    if pairs:
+        assert (gg.exportFilter(N.RPKBF) == og.rpkbf_bytes()).all(), "rpkbf differs"
+    pc = og.popcounts()
+    assert gg.popcount(N.DBGBF) == pc[0] and gg.popcount(N.CBF) == pc[1]
+    if pairs:
+        assert gg.popcount(N.RPKBF) == pc[2]
+
+
+@pytest.mark.parametrize("case", [
+    # (n_pairs, G, err, sizes(dbg,cbf,pk), max_batch)   small filters => many collisions/conflicts
+    dict(n=2000, G=30000, err=0.002, sizes=(400_003, 3_000_017, 90_001), mb=0),
+    dict(n=2000, G=30000, err=0.002, sizes=(60_013, 200_003, 9_001), mb=0),          # heavy collisions
+    dict(n=3000, G=8000, err=0.0, sizes=(300_007, 2_000_003, 70_001), mb=50_000),    # deep coverage, many sub-batches
+    dict(n=1500, G=50000, err=0.01, sizes=(1_000_003, 8_000_009, 200_003), mb=0),
+])
+def test_stage1_paired_end_bit_exact(case):
+    (ls, lq, off), (rs, rq, _) = make_reads(case["n"], case["G"], case["err"], 1e-3, seed=case["n"] + case["G"])
+    og, gg = graph_pair(*case["sizes"], max_batch=case["mb"])
+    d = 150 - 25 - 10
+    og.set_read_pair_distance(d); gg.setReadPairedKmerDistance(d)
+    # forward file first, then the reverse-complemented file (R/RNABloom.java:1301-1311)
+    so = og.add_reads(ls, lq, off, 3, rbo.STORE_READ_PAIRS)
+    sg = gg.addReads(ls, lq, off, 3, storeReadPairedKmers=True)
+    assert (sg.kmers, sg.pairs, sg.reads) == (so.kmers, so.pairs, so.reads + so.reads_skipped)
+    assert_same_state(og, gg)
+    so = og.add_reads(rs, rq, off, 3, rbo.STORE_READ_PAIRS | rbo.REVCOMP)
+    sg = gg.addReads(rs, rq, off, 3, reverseComplement=True, storeReadPairedKmers=True)
+    assert (sg.kmers, sg.pairs) == (so.kmers, so.pairs)
+    assert_same_state(og, gg)
+    assert gg.getOpOrdinal() == 2 * case["n"]
+    fo = og.fprs()
+    assert gg.getDbgbfFPR() == fo[0] and gg.getCbfFPR() == fo[1] and gg.getRpkbfFPR() == fo[2]
+
+
+@pytest.mark.parametrize("stranded", [False, True])
+@pytest.mark.parametrize("h", [(1, 1, 1), (3, 2, 1), (2, 4, 3)])
+def test_stage1_hash_counts_and_strandedness(stranded, h):
+    (ls, lq, off), (rs, rq, _) = make_reads(800, 20000, 0.003, 1e-3, seed=31)
+    og, gg = graph_pair(500_009, 1_000_003, 50_021, k=31, stranded=stranded, dbg_h=h[0], cbf_h=h[1], pk_h=h[2])
+    og.set_read_pair_distance(60); gg.setReadPairedKmerDistance(60)
+    og.add_reads(ls, lq, off, 3, rbo.STORE_READ_PAIRS)
+    gg.addReads(ls, lq, off, 3, storeReadPairedKmers=True)
+    og.add_reads(rs, rq, off, 3, rbo.STORE_READ_PAIRS | rbo.REVCOMP)
+    gg.addReads(rs, rq, off, 3, reverseComplement=True, storeReadPairedKmers=True)
+    assert_same_state(og, gg)
+
+
+def test_high_multiplicity_probabilistic_regime():
+    # 4 kb "transcriptome" at ~500x: most counters go far beyond 16, exercising the shared RNG,
+    # the wave-per-k-mer heavy path and ordered conflict replay
+    (ls, lq, off), _ = make_reads(6000, 4000, 0.001, 1e-3, seed=77, uniform=True)
+    og, gg = graph_pair(100_003, 150_001, 20_011)
+    og.add_reads(ls, lq, off, 3, 0)
+    st = gg.addReads(ls, lq, off, 3)
+    assert st.conflict_ops > 0
+    assert_same_state(og, gg, pairs=False)
+    assert og.cbf_bytes().max() > 24
+
+
+def test_batch_partition_independence():
+    (ls, lq, off), _ = make_reads(1500, 10000, 0.002, 1e-3, seed=5)
+    _, g1 = graph_pair(200_003, 900_001, 20_011)
+    _, g2 = graph_pair(200_003, 900_001, 20_011, max_batch=20_000)
+    g1.addReads(ls, lq, off, 3)
+    b = ReadBatch.from_ascii(ls, lq, off, 3)
+    for first in range(0, 1500, 333):
+        g2.addBatch(b, first=first, n=min(333, 1500 - first))
+    for w in (N.DBGBF, N.CBF):
+        assert (g1.exportFilter(w) == g2.exportFilter(w)).all()
+
+
+def test_fasta_and_empty_inputs():
+    og, gg = graph_pair(100_003, 300_007, 10_007, pairs=False)
+    reads = [b"", b"ACGT", b"ACGTNNNN" * 10, b"A" * 200, b"ACGTTGCAAGGCTTAGCATCGATCGATTAGC" * 5, b"N" * 100]
+    seq, _, off = rbo.pack_reads(reads)
+    so = og.add_reads(seq, None, off, 3, 0)
+    sg = gg.addReads(seq, None, off, 3)
+    assert sg.kmers == so.kmers
+    assert_same_state(og, gg, pairs=False)
+    sg = gg.addReads(np.zeros(0, np.uint8), None, np.zeros(1, np.int64), 3)
+    assert sg.kmers == 0 and sg.reads == 0
+    assert_same_state(og, gg, pairs=False)
+
+
+def test_per_hash_ops_match_oracle_sequence():
+    rng = np.random.default_rng(3)
+    og, gg = graph_pair(20_011, 30_011, 5_003)
+    pool = rng.integers(0, 1 << 63, 300, dtype=np.int64).astype(np.uint64) * np.uint64(2) + np.uint64(1)
+    for rnd, (op_o, op_g) in enumerate([("add", "add"), ("add_if_absent", "addIfAbsent"),
+                                        ("add_count_if_present", "addCountIfPresent"), ("add", "add"),
+                                        ("add_count_only", "addCountOnly"), ("add_dbg_only", "addDbgOnly"),
+                                        ("add_if_absent", "addIfAbsent"), ("add_count_if_present", "addCountIfPresent")]):
+        hs = pool[rng.integers(0, len(pool), 4000)]
+        for h in hs:
+            getattr(og, op_o)(rbo.ntm64(int(h), 25, 2))
+        getattr(gg, op_g)(hs)
+        assert_same_state(og, gg)
+    q = pool[:200]
+    exp_c = np.array([og.get_count(rbo.ntm64(int(h), 25, 2)) for h in q], np.float32)
+    exp_b = np.array([og.contains(rbo.ntm64(int(h), 25, 2)) for h in q])
+    assert (gg.getCount(q) == exp_c).all() and (gg.contains(q) == exp_b).all()
+    ph = rng.integers(0, 1 << 62, 500, dtype=np.int64).astype(np.uint64)
+    for h in ph[:250]:
+        og.add_read_pair(rbo.ntm64(int(h), 25, 2))
+    gg.addReadSingleKmerPair(ph[:250])
+    assert (gg.exportFilter(N.RPKBF) == og.rpkbf_bytes()).all()
+    exp = np.array([og.lookup_read_pair(rbo.ntm64(int(h), 25, 2)) for h in ph])
+    assert (gg.lookupReadKmerPair(ph) == exp).all()
+
+
+def test_queries_get_kmers_and_neighbors():
+    (ls, lq, off), _ = make_reads(1500, 12000, 0.002, 1e-3, seed=21)
+    for stranded in (False, True):
+        og, gg = graph_pair(300_007, 2_000_003, 10_007, stranded=stranded, pairs=False)
+        og.add_reads(ls, lq, off, 3, 0); gg.addReads(ls, lq, off, 3)
+        reads = [bytes(ls[off[i]:off[i + 1]]) for i in range(0, 60)] + [b"ACGT", b"", b"ACGTN" * 30]
+        ko, f, r, c = gg.getKmers(reads)
+        for i, s in enumerate(reads):
+            ef, er, ec = og.get_kmers(s)
+            a, b = ko[i], ko[i + 1]
+            assert b - a == len(ef)
+            assert (f[a:b] == ef).all() and (c[a:b] == ec).all()
+            if not stranded:
+                assert (r[a:b] == er).all()
+        s = reads[0]
+        ef, er, _ = og.get_kmers(s)
+        idx = np.arange(0, len(ef), 7)
+        for direction in (0, 1):
+            ch = np.array([s[i] if direction == 0 else s[i + 24] for i in idx], np.uint8)
+            f4, r4, c4 = gg.getNeighbors(ef[idx], er[idx], ch, direction)
+            for j, i in enumerate(idx):
+                of, orr, oc = og.neighbors(ef[i], er[i], int(ch[j]), direction)
+                assert (f4[j] == of).all() and (c4[j] == oc).all()
+                if not stranded:
+                    assert (r4[j] == orr).all()
+
+
+def test_export_import_roundtrip_and_errors():
+    og, gg = graph_pair(100_003, 300_007, 10_007)
+    (ls, lq, off), _ = make_reads(300, 5000, 0.0, 0.0, seed=2)
+    gg.setReadPairedKmerDistance(115)
+    gg.addReads(ls, lq, off, 3, storeReadPairedKmers=True)
+    snap = [gg.exportFilter(w) for w in (N.DBGBF, N.CBF, N.RPKBF)]
+    assert [len(s) for s in snap] == [(100_003 + 7) // 8, 300_007, (10_007 + 7) // 8]
+    gg.clearAllBf()
+    assert gg.popcount(N.DBGBF) == 0 and gg.popcount(N.CBF) == 0 and gg.getOpOrdinal() == 0
+    for w, s in zip((N.DBGBF, N.CBF, N.RPKBF), snap):
+        gg.importFilter(w, s)
+        assert (gg.exportFilter(w) == s).all()
+    with pytest.raises(N.NativeError):
+        gg.importFilter(N.CBF, snap[0])                 # wrong size
+    with pytest.raises(N.NativeError):
+        gg.popcount(N.FPKBF)                            # fragment pair filter not initialised
+    with pytest.raises(N.NativeError):
+        BloomFilterDeBruijnGraph(0, 10, 10, 2, 2, 2, 25, False, True)
+    gg.initializePairKmersBloomFilter(5003, 2)
+    assert gg.popcount(N.FPKBF) == 0
+
+
+def test_synthetic_generator_consistency():
+    b = ReadBatch.synthetic(5000, 1 << 16, seed=9)
+    assert b.n_reads == 10000
+    seq, off = b.download()
+    assert (np.diff(off) == 150).all()
+    frac_n = (seq == ord("N")).mean()
+    assert 0.0003 < frac_n < 0.003
+    og, gg = graph_pair(2_000_003, 16_000_057, 400_009)
+    og.set_read_pair_distance(115); gg.setReadPairedKmerDistance(115)
+    og.add_reads(seq, None, off, 3, rbo.STORE_READ_PAIRS)
+    gg.addBatch(b, storeReadPairedKmers=True)
+    assert_same_state(og, gg)
