@@ -1,0 +1,172 @@
+#!/usr/bin/env python3
+"""bench.py — k-mers/s hashed + inserted into the Bloom dBG (k=25, 150 bp paired-end reads).
+
+One "step" = one full stage-1 pass (R/RNABloom.java:7123-7188 populateGraph2) over the synthetic
+read set, starting from cleared filters: forward (left) file, then the reverse-complemented (right)
+file, every k-mer through graph.add and every read-paired k-mer through rpkbf.add.  Reads are
+generated on the device before the timed region and stay resident in HBM (packed 2-bit format).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--pairs P] [--genome G] [--nk NK]
+
+For N>1 launch through torch.distributed.run (one rank per GPU).  Multi-GPU mode shards the READS
+across ranks; every rank owns a full set of filters for its shard of the input (see DESIGN.md
+§Multi-GPU for what this round does and does not implement).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "rna-bloom_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0           # MI355X spec HBM3E bandwidth (MI355X_MICROARCH.md)
+BYTES_PER_KMER_SORT = 12 * 2 * 8  # see DESIGN.md §Roofline: radix sort moves (8 B key + 4 B value) in+out per pass, 8 passes
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--pairs", type=int, default=50_000_000, help="read pairs (BASELINE config 2: 50M)")
+    ap.add_argument("--genome", type=int, default=64_000_000, help="synthetic transcriptome bases")
+    ap.add_argument("--nk", type=int, default=450_000_000, help="expected distinct k-mers (-nk) sizing the filters")
+    ap.add_argument("--k", type=int, default=25)
+    ap.add_argument("--fpr", type=float, default=0.01)
+    ap.add_argument("--err", type=float, default=0.001)
+    ap.add_argument("--batch-kmers", type=int, default=0)
+    ap.add_argument("--cpu-sample-pairs", type=int, default=400_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-stages", action="store_true", help="per-stage HIP-event timing inside the timed region")
+    return ap.parse_args()
+
+
+def main():
+    a = parse()
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+
+    from rnabloom import _native as N
+    from rnabloom.graph import BloomFilterDeBruijnGraph, ReadBatch
+
+    k = a.k
+    pairs_total = a.pairs
+    pairs_rank = pairs_total // world           # strong scaling: the fixed job is split across ranks
+    dbg_bits = N.lib.rb_expected_size(a.nk, a.fpr, 2)
+    cbf_bytes = N.lib.rb_expected_size(a.nk, a.fpr, 2)
+    pk_bits = N.lib.rb_expected_size(a.nk, a.fpr, 2)
+    dist_pk = max(1, 150 - k - 10)              # R/RNABloom.java:1022 (minNumKmerPairs 10)
+
+    batch = ReadBatch.synthetic(pairs_rank, a.genome, 150, 300, 30, a.err, 1e-4, 2.0, seed=0x5EED + rank, device=local)
+    g = BloomFilterDeBruijnGraph(dbg_bits, cbf_bytes, pk_bits, 2, 2, 2, k, False, True, device=local, rngSeed=1,
+                                 maxBatchKmers=a.batch_kmers)
+    g.setReadPairedKmerDistance(dist_pk)
+
+    def step():
+        g.clearAllBf()
+        s1 = g.addBatch(batch, storeReadPairedKmers=True, first=0, n=pairs_rank)
+        s2 = g.addBatch(batch, reverseComplement=True, storeReadPairedKmers=True, first=pairs_rank, n=pairs_rank)
+        return s1, s2
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    g.profileEnable(True)   # HIP events on the library's own stream, around every stage launch
+    g.profileGet(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    kmers = pairs_ins = distinct = conflict = 0
+    for _ in range(a.steps):
+        s1, s2 = step()
+        kmers += s1.kmers + s2.kmers
+        pairs_ins += s1.pairs + s2.pairs
+        distinct += s1.distinct + s2.distinct
+        conflict += s1.conflict_ops + s2.conflict_ops
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        c = torch.tensor([kmers], device="cuda", dtype=torch.int64)
+        dist.all_reduce(c, op=dist.ReduceOp.SUM)
+        kmers_all = int(c.item())
+    else:
+        kmers_all = kmers
+    prof = g.profileGet(reset=True)
+
+    if rank == 0:
+        ms_step = dt / a.steps * 1e3
+        value = kmers_all / dt
+        # dominant kernel class from the live HIP-event timings
+        dom = max(prof.items(), key=lambda kv: kv[1][0]) if prof else ("none", (0.0, 0))
+        dom_name, (dom_ms, dom_launches) = dom
+        roof = None
+        if dom_launches:
+            per_launch_kmers = kmers / max(dom_launches, 1)
+            alg_bytes = per_launch_kmers * BYTES_PER_KMER_SORT
+            avg_s = dom_ms / dom_launches * 1e-3
+            achieved = alg_bytes / avg_s / 1e9
+            roof = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                    "avg_launch_ms": round(dom_ms / dom_launches, 3), "launches": dom_launches}
+        out = {
+            "metric": "k-mers/sec hashed+inserted into Bloom dBG (k=25, 50M 150bp reads)",
+            "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": ms_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "u64", "data": "synthetic",
+            "config": {"workload": "%dM synthetic 150bp paired-end reads, k=%d, Bloom FPR %.2f, nk=%d (configs[1])"
+                       % (pairs_total // 1_000_000, k, a.fpr, a.nk),
+                       "pairs": pairs_total, "genome_bases": a.genome, "dbgbf_bits": dbg_bits, "cbf_bytes": cbf_bytes,
+                       "rpkbf_bits": pk_bits, "kmers_per_step": kmers_all // a.steps,
+                       "read_pairs_per_step": pairs_ins // a.steps, "distinct_per_step": distinct // a.steps,
+                       "conflict_ops_per_step": conflict // a.steps, "parallelism": "reads sharded x%d" % world},
+            "stages_ms_per_step": {n: round(v[0] / a.steps, 2) for n, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
+            "roofline": roof,
+        }
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(a, batch, dbg_bits, cbf_bytes, pk_bits, dist_pk)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(a, batch, dbg_bits, cbf_bytes, pk_bits, dist_pk):
+    """The oracle (C restatement of the reference's FastqToGraphWorker loop, T threads pulling reads
+    under one lock, non-atomic byte RMW) on a bounded sample of the SAME reads and filter sizes."""
+    import numpy as np
+    from oracle import rbo
+    n = min(a.cpu_sample_pairs, batch.n_reads // 2)
+    cores = os.cpu_count() or 1
+    seq, off = batch.download(0, n)
+    og = rbo.Graph(dbg_bits, cbf_bytes, pk_bits, 2, 2, 2, a.k, False, True, 1)
+    og.set_read_pair_distance(dist_pk)
+    t0 = time.perf_counter()
+    st = og.add_reads(seq, None, off, 3, rbo.STORE_READ_PAIRS, threads=cores)
+    dt = time.perf_counter() - t0
+    return {"value": st.kmers / dt, "unit": "k-mers/s", "cores": cores, "kind": "port",
+            "sample": "first %d left reads of the same synthetic set (%d k-mers), same filter sizes, %.1f s"
+                      % (n, st.kmers, dt)}
+
+
+if __name__ == "__main__":
+    main()

@@ -306,30 +306,73 @@ __global__ void k_conf_offsets(const uint32_t *__restrict__ conf_kmers, const ui
     if (i < n_conf) sizes[i] = nops[conf_kmers[i]];
     if (i == n_conf) sizes[i] = 0;
 }
+// connected components of the "shares a counter" graph between conflicting k-mers, by min-label
+// propagation through the claim-table slots (components are tiny: the graph is far below the
+// percolation threshold for any sane filter size).  slot.lo starts as the smallest owner id.
+__global__ void k_label_init(const uint32_t *__restrict__ conf_kmers, uint32_t n_conf, uint32_t *__restrict__ label) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_conf) label[conf_kmers[i]] = conf_kmers[i];
+}
+__global__ void k_label_push(FilterView fv, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ conf_kmers,
+                             uint32_t n_conf, Slot *ctable, uint32_t c_log2, const uint32_t *__restrict__ label) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_conf) return;
+    const uint32_t d = conf_kmers[i], l = label[d];
+    const uint64_t h0 = uniq[d];
+    for (int j = 0; j < fv.cbf_h; ++j) {
+        Slot *sl = const_cast<Slot *>(table_find(ctable, c_log2, index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod)));
+        atomicMin(reinterpret_cast<uint32_t *>(&sl->val), l);
+    }
+}
+__global__ void k_label_pull(FilterView fv, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ conf_kmers,
+                             uint32_t n_conf, const Slot *ctable, uint32_t c_log2, uint32_t *__restrict__ label,
+                             uint32_t *__restrict__ changed) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_conf) return;
+    const uint32_t d = conf_kmers[i];
+    const uint64_t h0 = uniq[d];
+    uint32_t l = label[d], l0 = l;
+    for (int j = 0; j < fv.cbf_h; ++j) {
+        const Slot *sl = table_find(ctable, c_log2, index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod));
+        uint32_t v = __hip_atomic_load(reinterpret_cast<const uint32_t *>(&sl->val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        l = v < l ? v : l;
+    }
+    if (l != l0) { label[d] = l; *changed = 1u; }
+}
+__global__ void k_conf_kmer_keys(const uint32_t *__restrict__ conf_kmers, const uint32_t *__restrict__ label,
+                                 uint32_t n_conf, uint64_t *__restrict__ keys) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_conf) { uint32_t d = conf_kmers[i]; keys[i] = ((uint64_t)label[d] << 32) | d; }
+}
 __global__ void k_conf_expand(const uint32_t *__restrict__ conf_kmers, const uint32_t *__restrict__ conf_off,
                               const uint32_t *__restrict__ counts, const uint32_t *__restrict__ starts,
                               const uint32_t *__restrict__ vals, const uint32_t *__restrict__ status,
-                              const uint32_t *__restrict__ nops, uint32_t n_conf,
+                              const uint32_t *__restrict__ nops, const uint32_t *__restrict__ label, uint32_t n_conf,
                               uint64_t *__restrict__ op_key, uint32_t *__restrict__ op_val) {
     // one wavefront per conflicting k-mer
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
     if (wave >= n_conf) return;
     const uint32_t d = conf_kmers[wave];
     const uint32_t ops = nops[d], st = status[d];
+    const uint64_t hi = (uint64_t)label[d] << 32;
     const uint32_t base = starts[d] + counts[d] - ops, out = conf_off[wave];
     for (uint32_t i = lane; i < ops; i += 64u) {
-        op_key[out + i] = vals[base + i];
+        op_key[out + i] = hi | vals[base + i];
         uint32_t kind = i == 0 ? (st >> 12) & 3u : (st >> 14) & 3u;
         op_val[out + i] = d | (kind << 30);
     }
 }
-// v0 replay: strictly sequential, one lane.  Correct by construction; replaced by a parallel
-// component-wise replay once parity is established.
-__global__ void k_conf_replay_serial(FilterView fv, const uint64_t *__restrict__ uniq,
-                                     const uint64_t *__restrict__ op_key, const uint32_t *__restrict__ op_val,
-                                     uint32_t n_ops) {
-    if (blockIdx.x != 0 || threadIdx.x != 0) return;
-    for (uint32_t i = 0; i < n_ops; ++i) {
+
+__device__ __forceinline__ uint32_t lower_bound_u64(const uint64_t *a, uint32_t n, uint64_t key) {
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (a[mid] < key) lo = mid + 1; else hi = mid; }
+    return lo;
+}
+// ordered replay of one component's ops [os,oe) by a single lane with read-modify-write on the
+// counting filter itself (nobody else touches these counters during the batch)
+__device__ void replay_serial(const FilterView &fv, const uint64_t *__restrict__ uniq, const uint64_t *__restrict__ op_key,
+                              const uint32_t *__restrict__ op_val, uint32_t os, uint32_t oe) {
+    for (uint32_t i = os; i < oe; ++i) {
         const uint32_t v = (uint32_t)op_key[i];
         const uint32_t d = op_val[i] & 0x3FFFFFFFu, kind = op_val[i] >> 30;
         const uint64_t h0 = uniq[d];
@@ -337,11 +380,108 @@ __global__ void k_conf_replay_serial(FilterView fv, const uint64_t *__restrict__
         uint32_t c[RB_MAX_HASH], c0[RB_MAX_HASH];
         for (int j = 0; j < fv.cbf_h; ++j) {
             idx[j] = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod);
-            c0[j] = c[j] = fv.cbf[idx[j]];
+            c0[j] = c[j] = *(volatile uint8_t *)&fv.cbf[idx[j]];
         }
-        cbf_step(c, fv.cbf_h, kind, occ_rnd(fv, v));
+        uint32_t mn = c[0];
+        for (int j = 1; j < fv.cbf_h; ++j) mn = c[j] < mn ? c[j] : mn;
+        cbf_step(c, fv.cbf_h, kind, (mn >= 16u && mn < 127u) ? occ_rnd(fv, v) : 0u);
         for (int j = 0; j < fv.cbf_h; ++j)
-            if (c[j] != c0[j]) fv.cbf[idx[j]] = (uint8_t)c[j];
+            if (c[j] != c0[j]) *(volatile uint8_t *)&fv.cbf[idx[j]] = (uint8_t)c[j];
+    }
+}
+constexpr uint32_t SMALL_COMPONENT_OPS = 48;
+constexpr uint32_t MAX_COMPONENT_KMERS = 8;
+// one thread per conflicting k-mer (sorted by component label): component heads either replay a
+// small component themselves or queue it for the wave-cooperative kernel
+__global__ void k_conf_replay_small(FilterView fv, const uint64_t *__restrict__ uniq, const uint64_t *__restrict__ kmer_keys,
+                                    uint32_t n_conf, const uint64_t *__restrict__ op_key, const uint32_t *__restrict__ op_val,
+                                    uint32_t n_ops, uint32_t *__restrict__ big_list, uint32_t *__restrict__ n_big) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_conf) return;
+    const uint32_t lab = (uint32_t)(kmer_keys[i] >> 32);
+    if (i > 0 && (uint32_t)(kmer_keys[i - 1] >> 32) == lab) return;   // not a component head
+    const uint32_t os = lower_bound_u64(op_key, n_ops, (uint64_t)lab << 32);
+    const uint32_t oe = lower_bound_u64(op_key, n_ops, ((uint64_t)lab + 1ull) << 32);
+    if (oe - os > SMALL_COMPONENT_OPS) { big_list[atomicAdd(n_big, 1u)] = i; return; }
+    replay_serial(fv, uniq, op_key, op_val, os, oe);
+}
+// one wavefront per large component: the component's counters live in LDS; 64 ops are examined at
+// a time against the current state and the chain hops from one state-changing op to the next
+__global__ void __launch_bounds__(64) k_conf_replay_big(FilterView fv, const uint64_t *__restrict__ uniq,
+                                    const uint64_t *__restrict__ kmer_keys, uint32_t n_conf,
+                                    const uint64_t *__restrict__ op_key, const uint32_t *__restrict__ op_val, uint32_t n_ops,
+                                    const uint32_t *__restrict__ big_list, const uint32_t *__restrict__ n_big) {
+    __shared__ uint64_t s_idx[MAX_COMPONENT_KMERS * RB_MAX_HASH];   // unique counter indices
+    __shared__ uint32_t s_val[MAX_COMPONENT_KMERS * RB_MAX_HASH];   // their current bytes
+    __shared__ uint32_t s_val0[MAX_COMPONENT_KMERS * RB_MAX_HASH];
+    __shared__ uint32_t s_slot[MAX_COMPONENT_KMERS][RB_MAX_HASH];   // k-mer probe -> unique counter
+    __shared__ uint32_t s_d[MAX_COMPONENT_KMERS];
+    __shared__ uint32_t s_nu;
+    const uint32_t lane = threadIdx.x;
+    const int H = fv.cbf_h;
+    for (uint32_t bi = blockIdx.x; bi < *n_big; bi += gridDim.x) {
+        const uint32_t i0 = big_list[bi];
+        const uint32_t lab = (uint32_t)(kmer_keys[i0] >> 32);
+        uint32_t nk = 1;
+        while (i0 + nk < n_conf && (uint32_t)(kmer_keys[i0 + nk] >> 32) == lab && nk <= MAX_COMPONENT_KMERS) ++nk;
+        const uint32_t os = lower_bound_u64(op_key, n_ops, (uint64_t)lab << 32);
+        const uint32_t oe = lower_bound_u64(op_key, n_ops, ((uint64_t)lab + 1ull) << 32);
+        if (nk > MAX_COMPONENT_KMERS) {          // rare: very large component -> plain ordered replay
+            if (lane == 0) replay_serial(fv, uniq, op_key, op_val, os, oe);
+            continue;
+        }
+        __syncthreads();
+        if (lane == 0) {                         // build the component's counter table (tiny)
+            uint32_t nu = 0;
+            for (uint32_t q = 0; q < nk; ++q) {
+                const uint32_t d = (uint32_t)kmer_keys[i0 + q];
+                s_d[q] = d;
+                const uint64_t h0 = uniq[d];
+                for (int j = 0; j < H; ++j) {
+                    const uint64_t idx = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod);
+                    uint32_t u = 0;
+                    while (u < nu && s_idx[u] != idx) ++u;
+                    if (u == nu) { s_idx[u] = idx; s_val0[u] = s_val[u] = fv.cbf[idx]; ++nu; }
+                    s_slot[q][j] = u;
+                }
+            }
+            s_nu = nu;
+        }
+        __syncthreads();
+        for (uint32_t base = os; base < oe; base += 64u) {
+            const uint32_t i = base + lane;
+            uint32_t q = 0, kind = 0, rnd = 0;
+            const bool live = i < oe;
+            if (live) {
+                const uint32_t ov = op_val[i], d = ov & 0x3FFFFFFFu;
+                kind = ov >> 30;
+                while (q < nk && s_d[q] != d) ++q;
+                rnd = occ_rnd(fv, (uint32_t)op_key[i]);
+            }
+            uint32_t cursor = 0;                 // ops below cursor are settled
+            while (cursor < 64u) {
+                bool changes = false;
+                if (live && lane >= cursor) {
+                    uint32_t mn = s_val[s_slot[q][0]];
+                    for (int j = 1; j < H; ++j) { uint32_t c = s_val[s_slot[q][j]]; mn = c < mn ? c : mn; }
+                    const bool gate = !((kind == K_INC_IF_POS && mn == 0u) || (kind == K_INC_IF_ZERO && mn != 0u));
+                    changes = gate && minifloat_inc(mn, rnd) != mn;
+                }
+                const unsigned long long win = __ballot(changes);
+                if (!win) break;
+                const uint32_t first = (uint32_t)__ffsll((long long)win) - 1u;
+                if (lane == first) {             // apply: every probe equal to the minimum moves up
+                    uint32_t mn = s_val[s_slot[q][0]];
+                    for (int j = 1; j < H; ++j) { uint32_t c = s_val[s_slot[q][j]]; mn = c < mn ? c : mn; }
+                    for (int j = 0; j < H; ++j) if (s_val[s_slot[q][j]] == mn) s_val[s_slot[q][j]] = mn + 1u;
+                }
+                __syncthreads();
+                cursor = first + 1u;
+            }
+            __syncthreads();
+        }
+        if (lane < s_nu && s_val[lane] != s_val0[lane]) fv.cbf[s_idx[lane]] = (uint8_t)s_val[lane];
+        __syncthreads();
     }
 }
 
@@ -560,7 +700,7 @@ struct rb_graph {
     hipStream_t stream = nullptr;
     // scratch (grow-only)
     DevBuf chunk_cnt, chunk_off, keys0, keys1, vals0, vals1, uniq, counts, starts, status, nops, temp,
-        ftable, ctable, heavy, confk, conf_sizes, conf_off, opk0, opk1, opv0, opv1, devctr, qbuf0, qbuf1, qbuf2, qbuf3;
+        ftable, ctable, heavy, confk, conf_sizes, conf_off, opk0, opk1, opv0, opv1, label, kk0, kk1, biglist, devctr, qbuf0, qbuf1, qbuf2, qbuf3;
     // profiling
     bool prof_on = false;
     struct ProfEntry { const char *name; double ms; int64_t launches; };
@@ -679,19 +819,42 @@ void run_pipeline(rb_graph *g, size_t N, int mode, uint64_t ordinal0, uint32_t p
         g->conf_sizes.reserve(((size_t)nck + 1) * 4); g->conf_off.reserve(((size_t)nck + 1) * 4);
         g->opk0.reserve((size_t)nco * 8); g->opk1.reserve((size_t)nco * 8);
         g->opv0.reserve((size_t)nco * 4); g->opv1.reserve((size_t)nco * 4);
-        hipLaunchKernelGGL(k_conf_offsets, dim3(blocks_for(nck + 1)), dim3(TPB), 0, s, g->confk.as<uint32_t>(), nops,
-                           nck, g->conf_sizes.as<uint32_t>());
-        g->temp.reserve(std::max(scan_temp_bytes((size_t)nck + 1), sort_pairs_temp_bytes(nco)));
+        g->label.reserve((size_t)D * 4); g->kk0.reserve((size_t)nck * 8); g->kk1.reserve((size_t)nck * 8);
+        g->biglist.reserve((size_t)nck * 4);
+        const uint32_t *confk = g->confk.as<uint32_t>();
+        uint32_t *label = g->label.as<uint32_t>();
+        // components by min-label propagation; ctr[3] = changed flag, ctr[4] = number of big components
+        hipLaunchKernelGGL(k_label_init, dim3(blocks_for(nck)), dim3(TPB), 0, s, confk, nck, label);
+        for (int it = 0;; ++it) {
+            RB_REQUIRE(it < 100000, "component labelling did not converge");
+            RB_HIP(hipMemsetAsync(ctr + 3, 0, 4, s));
+            hipLaunchKernelGGL(k_label_push, dim3(blocks_for(nck)), dim3(TPB), 0, s, fv, uniq, confk, nck,
+                               g->ctable.as<Slot>(), c_log2, label);
+            hipLaunchKernelGGL(k_label_pull, dim3(blocks_for(nck)), dim3(TPB), 0, s, fv, uniq, confk, nck,
+                               g->ctable.as<Slot>(), c_log2, label, ctr + 3);
+            uint32_t changed = 0;
+            RB_HIP(hipMemcpyAsync(&changed, ctr + 3, 4, hipMemcpyDeviceToHost, s));
+            RB_HIP(hipStreamSynchronize(s));
+            if (!changed) break;
+        }
+        g->prof_end("conflict_components");
+        g->prof_begin();
+        hipLaunchKernelGGL(k_conf_kmer_keys, dim3(blocks_for(nck)), dim3(TPB), 0, s, confk, label, nck, g->kk0.as<uint64_t>());
+        hipLaunchKernelGGL(k_conf_offsets, dim3(blocks_for(nck + 1)), dim3(TPB), 0, s, confk, nops, nck, g->conf_sizes.as<uint32_t>());
+        g->temp.reserve(std::max({scan_temp_bytes((size_t)nck + 1), sort_pairs_temp_bytes(nco), sort_keys_temp_bytes(nck)}));
         exclusive_scan_u32(g->temp.p, g->temp.cap, g->conf_sizes.as<uint32_t>(), g->conf_off.as<uint32_t>(), (size_t)nck + 1, s);
-        hipLaunchKernelGGL(k_conf_expand, dim3(blocks_for((int64_t)nck * 64)), dim3(TPB), 0, s, g->confk.as<uint32_t>(),
-                           g->conf_off.as<uint32_t>(), counts, starts, vals, status, nops, nck,
-                           g->opk0.as<uint64_t>(), g->opv0.as<uint32_t>());
+        hipLaunchKernelGGL(k_conf_expand, dim3(blocks_for((int64_t)nck * 64)), dim3(TPB), 0, s, confk, g->conf_off.as<uint32_t>(),
+                           counts, starts, vals, status, nops, label, nck, g->opk0.as<uint64_t>(), g->opv0.as<uint32_t>());
+        sort_keys_u64(g->temp.p, g->temp.cap, g->kk0.as<uint64_t>(), g->kk1.as<uint64_t>(), nck, 0, 64, s);
         sort_pairs_u64_u32(g->temp.p, g->temp.cap, g->opk0.as<uint64_t>(), g->opk1.as<uint64_t>(),
-                           g->opv0.as<uint32_t>(), g->opv1.as<uint32_t>(), nco, 0, 32, s);
+                           g->opv0.as<uint32_t>(), g->opv1.as<uint32_t>(), nco, 0, 64, s);
         g->prof_end("conflict_gather_sort");
         g->prof_begin();
-        hipLaunchKernelGGL(k_conf_replay_serial, dim3(1), dim3(64), 0, s, fv, uniq, g->opk1.as<uint64_t>(),
-                           g->opv1.as<uint32_t>(), nco);
+        RB_HIP(hipMemsetAsync(ctr + 4, 0, 4, s));
+        hipLaunchKernelGGL(k_conf_replay_small, dim3(blocks_for(nck)), dim3(TPB), 0, s, fv, uniq, g->kk1.as<uint64_t>(), nck,
+                           g->opk1.as<uint64_t>(), g->opv1.as<uint32_t>(), nco, g->biglist.as<uint32_t>(), ctr + 4);
+        hipLaunchKernelGGL(k_conf_replay_big, dim3(std::min<uint32_t>(nck, 4096u)), dim3(64), 0, s, fv, uniq, g->kk1.as<uint64_t>(), nck,
+                           g->opk1.as<uint64_t>(), g->opv1.as<uint32_t>(), nco, g->biglist.as<uint32_t>(), ctr + 4);
         g->prof_end("conflict_replay");
         if (stats) stats->conflict_ops += nco;
     }
@@ -837,7 +1000,7 @@ int rb_graph_destroy(rb_graph *g) {
     if (g->cbf) (void)hipFree(g->cbf);
     DevBuf *bufs[] = {&g->chunk_cnt, &g->chunk_off, &g->keys0, &g->keys1, &g->vals0, &g->vals1, &g->uniq, &g->counts,
                       &g->starts, &g->status, &g->nops, &g->temp, &g->ftable, &g->ctable, &g->heavy, &g->confk,
-                      &g->conf_sizes, &g->conf_off, &g->opk0, &g->opk1, &g->opv0, &g->opv1, &g->devctr, &g->qbuf0,
+                      &g->conf_sizes, &g->conf_off, &g->opk0, &g->opk1, &g->opv0, &g->opv1, &g->label, &g->kk0, &g->kk1, &g->biglist, &g->devctr, &g->qbuf0,
                       &g->qbuf1, &g->qbuf2, &g->qbuf3};
     for (auto *b : bufs) b->release();
     if (g->ev0) (void)hipEventDestroy(g->ev0);

@@ -83,6 +83,9 @@ size_t sort_pairs32_temp_bytes(size_t n);
 void sort_pairs_u64_u64(void *temp, size_t temp_bytes, uint64_t *keys_in, uint64_t *keys_out,
                         uint64_t *vals_in, uint64_t *vals_out, size_t n, int begin_bit, int end_bit,
                         hipStream_t s);
+size_t sort_keys_temp_bytes(size_t n);
+void sort_keys_u64(void *temp, size_t temp_bytes, uint64_t *keys_in, uint64_t *keys_out, size_t n, int begin_bit,
+                   int end_bit, hipStream_t s);
 size_t scan_temp_bytes(size_t n);
 void exclusive_scan_u32(void *temp, size_t temp_bytes, const uint32_t *in, uint32_t *out, size_t n,
                         hipStream_t s);

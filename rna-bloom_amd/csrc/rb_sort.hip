@@ -32,6 +32,15 @@ void sort_pairs_u64_u64(void *temp, size_t temp_bytes, uint64_t *keys_in, uint64
     RB_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n,
                                      (unsigned)begin_bit, (unsigned)end_bit, s));
 }
+size_t sort_keys_temp_bytes(size_t n) {
+    size_t bytes = 0;
+    RB_HIP(rocprim::radix_sort_keys(nullptr, bytes, (uint64_t *)nullptr, (uint64_t *)nullptr, n, 0, 64));
+    return bytes;
+}
+void sort_keys_u64(void *temp, size_t temp_bytes, uint64_t *keys_in, uint64_t *keys_out, size_t n, int begin_bit,
+                   int end_bit, hipStream_t s) {
+    RB_HIP(rocprim::radix_sort_keys(temp, temp_bytes, keys_in, keys_out, n, (unsigned)begin_bit, (unsigned)end_bit, s));
+}
 size_t scan_temp_bytes(size_t n) {
     size_t bytes = 0;
     RB_HIP(rocprim::exclusive_scan(nullptr, bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr,
