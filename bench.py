@@ -156,16 +156,32 @@ def cpu_baseline(a, batch, dbg_bits, cbf_bytes, pk_bits, dist_pk):
     import numpy as np
     from oracle import rbo
     n = min(a.cpu_sample_pairs, batch.n_reads // 2)
-    cores = os.cpu_count() or 1
+    ncpu = os.cpu_count() or 1
     seq, off = batch.download(0, n)
     og = rbo.Graph(dbg_bits, cbf_bytes, pk_bits, 2, 2, 2, a.k, False, True, 1)
     og.set_read_pair_distance(dist_pk)
+    # the reference's workers serialise on one reader lock, so more threads is not always faster:
+    # probe a few thread counts on a small slice and time the full sample with the best one
+    probe_n = max(1, min(n // 8, 50_000))
+    cands = sorted({t for t in (8, 16, 32, 64, ncpu) if t <= ncpu})
+    best_t, best_rate, sweep = cands[0], 0.0, {}
+    for t in cands:
+        og.clear()
+        t0 = time.perf_counter()
+        st = og.add_reads(seq[: off[probe_n]], None, off[: probe_n + 1], 3, rbo.STORE_READ_PAIRS, threads=t)
+        rate = st.kmers / (time.perf_counter() - t0)
+        sweep[t] = round(rate / 1e6, 2)
+        if rate > best_rate:
+            best_t, best_rate = t, rate
+    og.clear()
     t0 = time.perf_counter()
-    st = og.add_reads(seq, None, off, 3, rbo.STORE_READ_PAIRS, threads=cores)
+    st = og.add_reads(seq, None, off, 3, rbo.STORE_READ_PAIRS, threads=best_t)
     dt = time.perf_counter() - t0
-    return {"value": st.kmers / dt, "unit": "k-mers/s", "cores": cores, "kind": "port",
-            "sample": "first %d left reads of the same synthetic set (%d k-mers), same filter sizes, %.1f s"
-                      % (n, st.kmers, dt)}
+    return {"value": st.kmers / dt, "unit": "k-mers/s", "cores": best_t, "kind": "port", "host_cpus": ncpu,
+            "thread_sweep_Mkmers_per_s": sweep,
+            "sample": "first %d left reads of the same synthetic set (%d k-mers + read pairs), same filter sizes, "
+                      "%.1f s with the best of the probed thread counts; C restatement of the reference's "
+                      "FastqToGraphWorker loop (no JVM in the image)" % (n, st.kmers, dt)}
 
 
 if __name__ == "__main__":

@@ -49,7 +49,8 @@ typedef struct rb_graph_params {
     int32_t stranded;             /* 0 => CanonicalHashFunction, 1 => HashFunction            */
     int32_t use_read_paired_kmers;
     int32_t device;               /* HIP device ordinal                                       */
-    int32_t reserved0;
+    int32_t group_bits;           /* tuning: top hash bits the occurrence sort groups on (0 = default 32,
+                                     max 64); any value gives identical results (DESIGN.md "split runs") */
     uint64_t rng_seed;            /* seed of the counter-based generator that replaces the
                                      unseeded Math.random() of R/util/MiniFloat.java:34        */
     int64_t max_batch_kmers;      /* 0 = default; upper bound on k-mers per internal sub-batch */

@@ -16,6 +16,7 @@
 //      occurrence order.
 #include <math.h>
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -697,6 +698,7 @@ struct rb_graph {
     int read_d = -1, frag_d = -1;
     uint64_t ordinal = 0;
     int64_t max_batch_kmers = 0;
+    int sort_begin_bit = 32;
     hipStream_t stream = nullptr;
     // scratch (grow-only)
     DevBuf chunk_cnt, chunk_off, keys0, keys1, vals0, vals1, uniq, counts, starts, status, nops, temp,
@@ -754,8 +756,13 @@ void run_pipeline(rb_graph *g, size_t N, int mode, uint64_t ordinal0, uint32_t p
     size_t tb = sort_pairs_temp_bytes(N);
     g->temp.reserve(std::max({tb, rle_temp_bytes(N), scan_temp_bytes(N + 1)}));
     g->keys1.reserve(N * 8); g->vals1.reserve(N * 4);
+    // Grouping, not ordering, is what the later stages need: a STABLE sort on the top 32 hash bits
+    // puts equal hashes next to each other except where two different hashes share the prefix; such
+    // a hash then simply shows up as several runs, which the pipeline treats as separate k-mers
+    // that share all their bits/counters — the first-setter arbitration and the ordered conflict
+    // replay already make that case exact (DESIGN.md §Pipeline "split runs").
     sort_pairs_u64_u32(g->temp.p, g->temp.cap, g->keys0.as<uint64_t>(), g->keys1.as<uint64_t>(),
-                       g->vals0.as<uint32_t>(), g->vals1.as<uint32_t>(), N, 0, 64, s);
+                       g->vals0.as<uint32_t>(), g->vals1.as<uint32_t>(), N, g->sort_begin_bit, 64, s);
     g->prof_end("sort_occurrences");
     // runs of equal hash = distinct k-mers
     g->prof_begin();
@@ -973,6 +980,9 @@ int rb_graph_create(const rb_graph_params *p, rb_graph **out) {
         g->stranded = p->stranded != 0;
         g->H = std::max(p->dbgbf_num_hash, p->cbf_num_hash);
         g->max_batch_kmers = p->max_batch_kmers > 0 ? p->max_batch_kmers : ((int64_t)1 << 28);
+        RB_REQUIRE(p->group_bits >= 0 && p->group_bits <= 64, "rb_graph_create: group_bits out of range [0,64]");
+        if (p->group_bits) g->sort_begin_bit = 64 - p->group_bits;
+        if (const char *e = getenv("RB_SORT_BEGIN_BIT")) g->sort_begin_bit = std::max(0, std::min(63, atoi(e)));
         RB_REQUIRE(g->max_batch_kmers <= ((int64_t)1 << 31), "rb_graph_create: max_batch_kmers above 2^31");
         RB_HIP(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
         RB_HIP(hipEventCreate(&g->ev0));

@@ -8,38 +8,45 @@
 
 namespace rb {
 
+// rocPRIM (ROCm 7.2) routes 4K < n <= 1M through a merge-sort sub-algorithm that returns WRONGLY
+// ORDERED output when begin_bit > 0 (verified on gfx950: bad order + instability at n = 250000,
+// begin_bit = 32; onesweep and the single-block sort are correct and stable).  MergeSortLimit = 0
+// disables that sub-algorithm.
+using sort_config = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
+                                               rocprim::default_config, 0>;
+
 size_t sort_pairs_temp_bytes(size_t n) {
     size_t bytes = 0;
-    RB_HIP(rocprim::radix_sort_pairs(nullptr, bytes, (uint64_t *)nullptr, (uint64_t *)nullptr,
+    RB_HIP(rocprim::radix_sort_pairs<sort_config>(nullptr, bytes, (uint64_t *)nullptr, (uint64_t *)nullptr,
                                      (uint32_t *)nullptr, (uint32_t *)nullptr, n, 0, 64));
     return bytes;
 }
 void sort_pairs_u64_u32(void *temp, size_t temp_bytes, uint64_t *keys_in, uint64_t *keys_out,
                         uint32_t *vals_in, uint32_t *vals_out, size_t n, int begin_bit, int end_bit,
                         hipStream_t s) {
-    RB_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n,
+    RB_HIP(rocprim::radix_sort_pairs<sort_config>(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n,
                                      (unsigned)begin_bit, (unsigned)end_bit, s));
 }
 size_t sort_pairs32_temp_bytes(size_t n) {
     size_t bytes = 0;
-    RB_HIP(rocprim::radix_sort_pairs(nullptr, bytes, (uint64_t *)nullptr, (uint64_t *)nullptr,
+    RB_HIP(rocprim::radix_sort_pairs<sort_config>(nullptr, bytes, (uint64_t *)nullptr, (uint64_t *)nullptr,
                                      (uint64_t *)nullptr, (uint64_t *)nullptr, n, 0, 64));
     return bytes;
 }
 void sort_pairs_u64_u64(void *temp, size_t temp_bytes, uint64_t *keys_in, uint64_t *keys_out,
                         uint64_t *vals_in, uint64_t *vals_out, size_t n, int begin_bit, int end_bit,
                         hipStream_t s) {
-    RB_HIP(rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n,
+    RB_HIP(rocprim::radix_sort_pairs<sort_config>(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n,
                                      (unsigned)begin_bit, (unsigned)end_bit, s));
 }
 size_t sort_keys_temp_bytes(size_t n) {
     size_t bytes = 0;
-    RB_HIP(rocprim::radix_sort_keys(nullptr, bytes, (uint64_t *)nullptr, (uint64_t *)nullptr, n, 0, 64));
+    RB_HIP(rocprim::radix_sort_keys<sort_config>(nullptr, bytes, (uint64_t *)nullptr, (uint64_t *)nullptr, n, 0, 64));
     return bytes;
 }
 void sort_keys_u64(void *temp, size_t temp_bytes, uint64_t *keys_in, uint64_t *keys_out, size_t n, int begin_bit,
                    int end_bit, hipStream_t s) {
-    RB_HIP(rocprim::radix_sort_keys(temp, temp_bytes, keys_in, keys_out, n, (unsigned)begin_bit, (unsigned)end_bit, s));
+    RB_HIP(rocprim::radix_sort_keys<sort_config>(temp, temp_bytes, keys_in, keys_out, n, (unsigned)begin_bit, (unsigned)end_bit, s));
 }
 size_t scan_temp_bytes(size_t n) {
     size_t bytes = 0;

@@ -21,7 +21,7 @@ class GraphParams(C.Structure):
     _fields_ = [("dbgbf_bits", C.c_int64), ("cbf_bytes", C.c_int64), ("pkbf_bits", C.c_int64),
                 ("dbgbf_num_hash", C.c_int32), ("cbf_num_hash", C.c_int32), ("pkbf_num_hash", C.c_int32),
                 ("k", C.c_int32), ("stranded", C.c_int32), ("use_read_paired_kmers", C.c_int32),
-                ("device", C.c_int32), ("reserved0", C.c_int32), ("rng_seed", C.c_uint64),
+                ("device", C.c_int32), ("group_bits", C.c_int32), ("rng_seed", C.c_uint64),
                 ("max_batch_kmers", C.c_int64)]
 
 

@@ -102,9 +102,9 @@ class BloomFilterDeBruijnGraph:
     """R/graph/BloomFilterDeBruijnGraph.java:75-104 constructor signature (+ device, rngSeed)."""
 
     def __init__(self, dbgbfNumBits, cbfNumBytes, pkbfNumBits, dbgbfNumHash, cbfNumHash, pkbfNumHash, k,
-                 stranded, useReadPairedKmers, device=0, rngSeed=0, maxBatchKmers=0):
+                 stranded, useReadPairedKmers, device=0, rngSeed=0, maxBatchKmers=0, groupBits=0):
         self.p = N.GraphParams(dbgbfNumBits, cbfNumBytes, pkbfNumBits, dbgbfNumHash, cbfNumHash, pkbfNumHash,
-                               k, int(stranded), int(useReadPairedKmers), device, 0, rngSeed, maxBatchKmers)
+                               k, int(stranded), int(useReadPairedKmers), device, groupBits, rngSeed, maxBatchKmers)
         self.h = C.c_void_p()
         check(lib.rb_graph_create(C.byref(self.p), C.byref(self.h)))
         self.k = k

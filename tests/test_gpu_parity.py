@@ -61,10 +61,10 @@ def test_batch_roundtrip_download():
 
 
 def graph_pair(dbg_bits, cbf_bytes, pk_bits, k=25, stranded=False, dbg_h=2, cbf_h=2, pk_h=2, seed=7, pairs=True,
-               max_batch=0):
+               max_batch=0, group_bits=0):
     og = rbo.Graph(dbg_bits, cbf_bytes, pk_bits, dbg_h, cbf_h, pk_h, k, stranded, pairs, seed)
     gg = BloomFilterDeBruijnGraph(dbg_bits, cbf_bytes, pk_bits, dbg_h, cbf_h, pk_h, k, stranded, pairs,
-                                  rngSeed=seed, maxBatchKmers=max_batch)
+                                  rngSeed=seed, maxBatchKmers=max_batch, groupBits=group_bits)
     return og, gg
 
 
@@ -130,6 +130,18 @@ def test_high_multiplicity_probabilistic_regime():
     assert st.conflict_ops > 0
     assert_same_state(og, gg, pairs=False)
     assert og.cbf_bytes().max() > 24
+
+
+@pytest.mark.parametrize("group_bits", [64, 20, 8, 1])
+def test_grouping_prefix_does_not_change_results(group_bits):
+    # fewer grouping bits => the same hash appears as several runs ("split runs"); results must not move
+    (ls, lq, off), _ = make_reads(2500, 6000, 0.002, 1e-3, seed=13)
+    og, gg = graph_pair(150_001, 400_009, 20_011, group_bits=group_bits)
+    og.set_read_pair_distance(115); gg.setReadPairedKmerDistance(115)
+    og.add_reads(ls, lq, off, 3, rbo.STORE_READ_PAIRS)
+    gg.addReads(ls, lq, off, 3, storeReadPairedKmers=True)
+    assert_same_state(og, gg)
+    assert og.cbf_bytes().max() > 16
 
 
 def test_batch_partition_independence():
