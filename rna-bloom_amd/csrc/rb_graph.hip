@@ -738,6 +738,7 @@ void alloc_bits(BitFilter &f, int64_t bits, int num_hash) {
     f.mod = make_mod((uint64_t)bits);
     RB_HIP(hipMalloc(&f.bits, f.alloc));
     RB_HIP(hipMemset(f.bits, 0, f.alloc));
+    RB_HIP(hipDeviceSynchronize());   // hipMemset is asynchronous; the graph's stream is non-blocking
 }
 void free_bits(BitFilter &f) { if (f.bits) (void)hipFree(f.bits); f = BitFilter(); }
 
@@ -1046,7 +1047,7 @@ int rb_graph_init_fragment_pairs(rb_graph *g, int64_t pkbf_bits, int pkbf_num_ha
         RB_REQUIRE(g && pkbf_bits > 0 && pkbf_num_hash >= 1 && pkbf_num_hash <= RB_MAX_HASH, "rb_graph_init_fragment_pairs: bad argument");
         RB_HIP(hipSetDevice(g->p.device));
         if (!g->fpk.bits) alloc_bits(g->fpk, pkbf_bits, pkbf_num_hash);   // :352-359: create once, else empty()
-        else RB_HIP(hipMemset(g->fpk.bits, 0, g->fpk.alloc));
+        else { RB_HIP(hipMemset(g->fpk.bits, 0, g->fpk.alloc)); RB_HIP(hipDeviceSynchronize()); }
     });
 }
 int rb_graph_get_op_ordinal(rb_graph *g, uint64_t *out) {
@@ -1295,6 +1296,7 @@ int rb_filter_import(rb_graph *g, int which, const void *srcp, size_t nbytes) {
         RB_HIP(hipStreamSynchronize(g->stream));
         RB_HIP(hipMemset(dst, 0, alloc));
         RB_HIP(hipMemcpy(dst, srcp, have, hipMemcpyHostToDevice));
+        RB_HIP(hipDeviceSynchronize());
     });
 }
 
