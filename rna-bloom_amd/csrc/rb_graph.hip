@@ -115,37 +115,147 @@ __device__ __forceinline__ uint32_t occ_rnd(const FilterView &fv, uint32_t v) {
     return rng31(fv.seed, fv.ordinal0 + (uint64_t)(v >> fv.pos_bits), v & ((1u << fv.pos_bits) - 1u));
 }
 
-// ---- stage 3a: test Bloom bits of each distinct k-mer against the pre-batch state ----
-__global__ void k_dbg_test(FilterView fv, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ starts,
-                           const uint32_t *__restrict__ vals, uint32_t n_distinct, int mode,
-                           Slot *ftable, uint32_t f_log2, uint32_t *__restrict__ status) {
+// Random-draw "strength" of every occurrence, in sorted order: the number of trailing zero bits of
+// its 31-bit draw (capped at 15).  MiniFloat.increment at byte b >= 16 succeeds iff
+// rnd % 2^s == 0 with s = (b>>3)-1 <= 14, i.e. iff strength >= s — so the per-run state machines
+// only compare bytes and never evaluate the generator inside their sequential loops.
+__global__ void k_strength(FilterView fv, const uint32_t *__restrict__ vals, size_t n, uint8_t *__restrict__ tz) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t r = occ_rnd(fv, vals[i]) | 0x8000u;          // bit 15 caps the count at 15
+    tz[i] = (uint8_t)(__ffs((int)r) - 1);
+}
+// first index in [pos,end) whose strength byte is >= s (s in 1..15), or end.  8 bytes per load.
+__device__ __forceinline__ uint32_t next_success(const uint8_t *__restrict__ tz, uint32_t pos, uint32_t end, uint32_t s) {
+    const uint64_t add = (uint64_t)(0x80u - s) * 0x0101010101010101ull;
+    while (pos < end) {
+        const uint32_t a = pos & ~7u;
+        uint64_t w = *reinterpret_cast<const uint64_t *>(tz + a);      // tz is allocated with 8 bytes of slack
+        uint64_t hit = (w + add) & 0x8080808080808080ull;              // bytes are <= 15: no carries
+        hit &= ~0ull << (8u * (pos - a));                              // ignore bytes below pos
+        if (hit) {
+            const uint32_t q = a + ((uint32_t)__ffsll((long long)hit) - 1u) / 8u;
+            return q < end ? q : end;
+        }
+        pos = a + 8u;
+    }
+    return end;
+}
+// all `ops` increments of one run applied to the register copy c[] of its counters, in order.
+// kind0 applies to the first op, kind to the others; tz = strengths of the ops (tz[0] = first op).
+__device__ __forceinline__ void run_ops(uint32_t *c, int h, uint32_t kind0, uint32_t kind, const uint8_t *__restrict__ tz,
+                                        uint32_t base, uint32_t ops) {
+    auto minimum = [&]() { uint32_t mn = c[0]; for (int j = 1; j < h; ++j) mn = c[j] < mn ? c[j] : mn; return mn; };
+    auto bump = [&](uint32_t mn) { for (int j = 0; j < h; ++j) if (c[j] == mn) c[j] = mn + 1u; };
+    uint32_t i = 0;
+    {   // first op (its kind may differ)
+        const uint32_t mn = minimum();
+        const bool gate = !((kind0 == K_INC_IF_POS && mn == 0u) || (kind0 == K_INC_IF_ZERO && mn != 0u));
+        if (gate && mn < 127u && (mn < 16u || tz[base] >= (mn >> 3) - 1u)) bump(mn);
+        i = 1;
+    }
+    while (i < ops) {
+        const uint32_t mn = minimum();
+        if (mn >= 127u) break;                                    // saturated
+        if (kind == K_INC_IF_POS && mn == 0u) break;              // stays zero for the rest of the run
+        if (kind == K_INC_IF_ZERO && mn != 0u) break;             // stays positive
+        if (mn < 16u) { bump(mn); ++i; continue; }                // deterministic region
+        const uint32_t q = next_success(tz, base + i, base + ops, (mn >> 3) - 1u);
+        if (q >= base + ops) break;
+        bump(mn);
+        i = q - base + 1u;
+    }
+}
+
+// Counter bytes live in 0..127 (MiniFloat saturates at Byte.MAX_VALUE, R/util/MiniFloat.java:32), so
+// bit 7 of a counting-Bloom byte is free.  During a sub-batch it serves as a "claimed by a k-mer of
+// this sub-batch" marker: the atomicOr that claims a counter also returns its value, and a k-mer that
+// finds the marker already set knows it shares the counter with another k-mer (=> ordered replay).
+constexpr uint32_t CLAIM = 0x80u;
+__device__ __forceinline__ uint32_t cbf_claim(uint8_t *cbf, uint64_t idx) {       // returns old byte
+    uint32_t *w = reinterpret_cast<uint32_t *>(cbf) + (idx >> 2);
+    const uint32_t sh = 8u * (uint32_t)(idx & 3u);
+    return (atomicOr(w, CLAIM << sh) >> sh) & 0xFFu;
+}
+__device__ __forceinline__ void cbf_release(uint8_t *cbf, uint64_t idx) {
+    uint32_t *w = reinterpret_cast<uint32_t *>(cbf) + (idx >> 2);
+    atomicAnd(w, ~(CLAIM << (8u * (uint32_t)(idx & 3u))));
+}
+
+// status word per distinct run: bits 0..7 premask, bit 8 all_pre, bit 9 claimed counters,
+// bit 10 saw a foreign claim, bits 12..13 kind of first op, 14..15 kind of the other ops
+constexpr uint32_t ST_CLAIMED = 1u << 9, ST_FOREIGN = 1u << 10;
+
+// ---- stage A: per distinct run — test Bloom bits against the pre-batch state, register the run's
+// first probe ids for bits it may be the first to set, claim its counters (reading them) ----
+__global__ void k_probe(FilterView fv, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ counts,
+                        const uint32_t *__restrict__ starts, const uint32_t *__restrict__ vals, uint32_t n_distinct,
+                        int mode, Slot *ftable, uint32_t f_log2, uint32_t *__restrict__ status,
+                        uint64_t *__restrict__ cvals, uint64_t *__restrict__ foreign_idx,
+                        uint32_t *__restrict__ counters /* [5] = number of foreign claims */) {
     uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= n_distinct) return;
     const uint64_t h0 = uniq[d];
     uint32_t premask = 0, all = 1;
-    const uint32_t v_first = vals[starts[d]];
-    for (int j = 0; j < fv.dbg_h; ++j) {
-        uint64_t idx = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.dbg_mod);
-        if (bit_test(fv.dbg, idx)) premask |= 1u << j;
-        else {
-            all = 0;
-            if (mode == M_ADD || mode == M_ADD_IF_ABSENT) {
-                // sequentially, the getAndSet with the smallest (occurrence, probe) id is the one
-                // that finds the bit clear (R/bloom/BloomFilter.java:147-155)
-                Slot *s = table_insert(ftable, f_log2, idx);
-                atomicMin(&s->val, ((unsigned long long)v_first << 4) | (unsigned long long)j);
-            }
+    if (mode != M_COUNT_ONLY) {
+        uint64_t idx[RB_MAX_HASH];
+        for (int j = 0; j < fv.dbg_h; ++j) {
+            idx[j] = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.dbg_mod);
+            if (bit_test(fv.dbg, idx[j])) premask |= 1u << j; else all = 0;
+        }
+        if (!all && (mode == M_ADD || mode == M_ADD_IF_ABSENT)) {
+            // sequentially, the getAndSet with the smallest (occurrence, probe) id is the one that
+            // finds the bit clear (R/bloom/BloomFilter.java:147-155)
+            const unsigned long long v_first = vals[starts[d]];
+            for (int j = 0; j < fv.dbg_h; ++j)
+                if (!((premask >> j) & 1u)) {
+                    Slot *s = table_insert(ftable, f_log2, idx[j]);
+                    atomicMin(&s->val, (v_first << 4) | (unsigned long long)j);
+                }
         }
     }
-    status[d] = premask | (all ? ST_ALLPRE : 0u);
+    uint32_t st = premask | (all ? ST_ALLPRE : 0u);
+    // can this run have counting-Bloom ops?  (exact number is known in stage B)
+    bool may_count = true;
+    if (mode == M_COUNT_IF_PRESENT) may_count = all;
+    if (may_count) {
+        uint64_t cidx[RB_MAX_HASH], cv = 0;
+        for (int j = 0; j < fv.cbf_h; ++j) {
+            cidx[j] = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod);
+            int dup = -1;
+            for (int q = 0; q < j; ++q) if (cidx[q] == cidx[j]) dup = q;
+            uint32_t byte;
+            if (dup >= 0) byte = (uint32_t)(cv >> (8 * dup)) & 0xFFu;
+            else {
+                byte = cbf_claim(fv.cbf, cidx[j]);
+                if (byte & CLAIM) {                     // somebody else of this sub-batch owns it too
+                    st |= ST_FOREIGN;
+                    foreign_idx[atomicAdd(&counters[5], 1u)] = cidx[j];
+                    byte &= 0x7Fu;
+                }
+            }
+            cv |= (uint64_t)byte << (8 * j);
+        }
+        cvals[d] = cv;
+        st |= ST_CLAIMED;
+    }
+    status[d] = st;
+}
+__global__ void k_cs_build(const uint64_t *__restrict__ foreign_idx, uint32_t n, Slot *cs, uint32_t cs_log2) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) table_insert(cs, cs_log2, foreign_idx[i]);
 }
 
-// ---- stage 3b: resolve found-flag of the first occurrence, set bits, claim counters ----
-__global__ void k_dbg_set_claim(FilterView fv, const uint64_t *__restrict__ uniq,
-                                const uint32_t *__restrict__ counts, const uint32_t *__restrict__ starts,
-                                const uint32_t *__restrict__ vals, uint32_t n_distinct, int mode,
-                                const Slot *ftable, uint32_t f_log2, Slot *ctable, uint32_t c_log2,
-                                uint32_t *__restrict__ status, uint32_t *__restrict__ nops) {
+// ---- stage B: resolve the found-flag of the first occurrence, set Bloom bits, then apply the
+// counter updates of runs that own their counters alone; queue the rest ----
+__global__ void k_resolve_apply(FilterView fv, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ counts,
+                                const uint32_t *__restrict__ starts, const uint32_t *__restrict__ vals,
+                                uint32_t n_distinct, int mode, uint32_t LIGHT_OPS, const Slot *ftable, uint32_t f_log2,
+                                const Slot *cs, uint32_t cs_log2, uint32_t n_foreign,
+                                uint32_t *__restrict__ status, uint32_t *__restrict__ nops,
+                                const uint64_t *__restrict__ cvals, const uint8_t *__restrict__ tz,
+                                uint32_t *__restrict__ heavy_list, uint32_t *__restrict__ conf_kmers,
+                                uint32_t *__restrict__ counters /* [0]=heavy n, [1]=conflict runs, [2]=conflict ops */) {
     uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= n_distinct) return;
     const uint64_t h0 = uniq[d];
@@ -161,14 +271,13 @@ __global__ void k_dbg_set_claim(FilterView fv, const uint64_t *__restrict__ uniq
     } else {
         bool found_first = true;
         if (!all_pre) {
-            const uint32_t v_first = vals[starts[d]];
+            const unsigned long long v_first = vals[starts[d]];
             for (int j = 0; j < fv.dbg_h; ++j) {
                 if ((st >> j) & 1u) continue;
                 uint64_t idx = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.dbg_mod);
                 const Slot *s = table_find(ftable, f_log2, idx);
-                unsigned long long mine = ((unsigned long long)v_first << 4) | (unsigned long long)j;
                 // old bit value seen by this probe = an earlier probe of the batch already set it
-                if (!(s->val < mine)) found_first = false;
+                if (!(s->val < ((v_first << 4) | (unsigned long long)j))) found_first = false;
                 bit_set(fv.dbg, idx);
             }
         }
@@ -181,73 +290,39 @@ __global__ void k_dbg_set_claim(FilterView fv, const uint64_t *__restrict__ uniq
         }
     }
     nops[d] = ops;
-    status[d] = (st & 0x1FFu) | (kfirst << 12) | (krest << 14);
-    if (ops) {
-        for (int j = 0; j < fv.cbf_h; ++j) {
-            uint64_t idx = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod);
-            Slot *s = table_insert(ctable, c_log2, idx);
-            // low word: min owner, high word: ~max owner (both via atomicMin on 32-bit halves)
-            uint32_t *w = reinterpret_cast<uint32_t *>(&s->val);
-            atomicMin(&w[0], d);
-            atomicMin(&w[1], ~d);
-        }
-    }
-}
-
-// ---- stage 4: apply counter updates of k-mers that own their counters alone ----
-constexpr uint32_t LIGHT_OPS = 96;
-__global__ void k_cbf_apply(FilterView fv, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ counts,
-                            const uint32_t *__restrict__ starts, const uint32_t *__restrict__ vals,
-                            uint32_t n_distinct, const Slot *ctable, uint32_t c_log2,
-                            const uint32_t *__restrict__ status, const uint32_t *__restrict__ nops,
-                            uint32_t *__restrict__ heavy_list, uint32_t *__restrict__ conf_kmers,
-                            uint32_t *__restrict__ counters /* [0]=heavy n, [1]=conflict kmers, [2]=conflict ops */) {
-    uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
-    if (d >= n_distinct) return;
-    const uint32_t ops = nops[d];
-    if (!ops) return;
-    const uint64_t h0 = uniq[d];
+    st = (st & 0x7FFu) | (kfirst << 12) | (krest << 14);
+    status[d] = st;
+    if (!(st & ST_CLAIMED)) return;
     uint64_t idx[RB_MAX_HASH];
-    bool conflict = false;
+    bool conflict = (st & ST_FOREIGN) != 0;
     for (int j = 0; j < fv.cbf_h; ++j) {
         idx[j] = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod);
-        const Slot *s = table_find(ctable, c_log2, idx[j]);
-        const uint32_t *w = reinterpret_cast<const uint32_t *>(&s->val);
-        conflict |= (w[0] != ~w[1]);
+        if (n_foreign && !conflict) conflict = table_find(cs, cs_log2, idx[j]) != nullptr;
+    }
+    if (ops == 0) {                               // nothing to count: just drop the claim marks
+        for (int j = 0; j < fv.cbf_h; ++j) cbf_release(fv.cbf, idx[j]);
+        return;
     }
     if (conflict) {
-        uint32_t at = atomicAdd(&counters[1], 1u);
-        conf_kmers[at] = d;
+        conf_kmers[atomicAdd(&counters[1], 1u)] = d;
         atomicAdd(&counters[2], ops);
-        return;
+        return;                                   // marks are dropped by k_conf_release before the replay
     }
-    if (ops > LIGHT_OPS) {
-        uint32_t at = atomicAdd(&counters[0], 1u);
-        heavy_list[at] = d;
-        return;
-    }
-    uint32_t c[RB_MAX_HASH], c0[RB_MAX_HASH];
-    for (int j = 0; j < fv.cbf_h; ++j) c0[j] = c[j] = fv.cbf[idx[j]];
-    const uint32_t st = status[d];
-    const uint32_t base = starts[d] + counts[d] - ops;
-    uint32_t kind = (st >> 12) & 3u;
-    for (uint32_t i = 0; i < ops; ++i) {
-        uint32_t mn = c[0];
-        for (int j = 1; j < fv.cbf_h; ++j) mn = c[j] < mn ? c[j] : mn;
-        uint32_t rnd = (mn >= 16u && mn < 127u) ? occ_rnd(fv, vals[base + i]) : 0u;
-        cbf_step(c, fv.cbf_h, kind, rnd);
-        kind = (st >> 14) & 3u;
-    }
-    for (int j = 0; j < fv.cbf_h; ++j)
-        if (c[j] != c0[j]) fv.cbf[idx[j]] = (uint8_t)c[j];
+    if (ops > LIGHT_OPS) { heavy_list[atomicAdd(&counters[0], 1u)] = d; return; }
+    uint32_t c[RB_MAX_HASH];
+    const uint64_t cv = cvals[d];
+    for (int j = 0; j < fv.cbf_h; ++j) c[j] = (uint32_t)(cv >> (8 * j)) & 0xFFu;
+    run_ops(c, fv.cbf_h, kfirst, krest, tz, starts[d] + m - ops, ops);
+    for (int j = 0; j < fv.cbf_h; ++j) fv.cbf[idx[j]] = (uint8_t)c[j];   // also clears the claim mark
 }
 
-// one wavefront per high-multiplicity k-mer: lanes fetch 64 occurrences at a time, compute each
+// one wavefront per high-multiplicity run: lanes fetch 64 occurrences at a time, compute each
 // one's random draw, and the increment chain hops from success to success with ballots
 __global__ void __launch_bounds__(64) k_cbf_heavy(FilterView fv, const uint64_t *__restrict__ uniq,
                             const uint32_t *__restrict__ counts, const uint32_t *__restrict__ starts,
                             const uint32_t *__restrict__ vals, const uint32_t *__restrict__ status,
-                            const uint32_t *__restrict__ nops, const uint32_t *__restrict__ heavy_list,
+                            const uint32_t *__restrict__ nops, const uint64_t *__restrict__ cvals,
+                            const uint8_t *__restrict__ tz, const uint32_t *__restrict__ heavy_list,
                             const uint32_t *__restrict__ counters) {
     const uint32_t n_heavy = counters[0];
     const uint32_t lane = threadIdx.x;
@@ -256,11 +331,12 @@ __global__ void __launch_bounds__(64) k_cbf_heavy(FilterView fv, const uint64_t 
         const uint64_t h0 = uniq[d];
         const uint32_t ops = nops[d];
         const uint32_t st = status[d];
+        const uint64_t cv = cvals[d];
         uint64_t idx[RB_MAX_HASH];
-        uint32_t c[RB_MAX_HASH], c0[RB_MAX_HASH];
+        uint32_t c[RB_MAX_HASH];
         for (int j = 0; j < fv.cbf_h; ++j) {
             idx[j] = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod);
-            c0[j] = c[j] = fv.cbf[idx[j]];
+            c[j] = (uint32_t)(cv >> (8 * j)) & 0xFFu;
         }
         const uint32_t base = starts[d] + counts[d] - ops;
         const uint32_t krest = (st >> 14) & 3u;
@@ -268,8 +344,10 @@ __global__ void __launch_bounds__(64) k_cbf_heavy(FilterView fv, const uint64_t 
         {   // the first op may have its own kind
             uint32_t mn = c[0];
             for (int j = 1; j < fv.cbf_h; ++j) mn = c[j] < mn ? c[j] : mn;
-            uint32_t rnd = (mn >= 16u && mn < 127u) ? occ_rnd(fv, vals[base]) : 0u;
-            cbf_step(c, fv.cbf_h, (st >> 12) & 3u, rnd);
+            const uint32_t k0 = (st >> 12) & 3u;
+            const bool gate = !((k0 == K_INC_IF_POS && mn == 0u) || (k0 == K_INC_IF_ZERO && mn != 0u));
+            if (gate && mn < 127u && (mn < 16u || tz[base] >= (mn >> 3) - 1u))
+                for (int j = 0; j < fv.cbf_h; ++j) if (c[j] == mn) c[j] = mn + 1u;
             done = 1;
         }
         while (done < ops) {
@@ -287,7 +365,7 @@ __global__ void __launch_bounds__(64) k_cbf_heavy(FilterView fv, const uint64_t 
             const uint32_t i = done + lane;
             const uint32_t shift = (mn >> 3) - 1u;
             bool ok = false;
-            if (i < ops) ok = (occ_rnd(fv, vals[base + i]) & ((1u << shift) - 1u)) == 0u;
+            if (i < ops) ok = tz[base + i] >= shift;
             const unsigned long long win = __ballot(ok);
             if (!win) { done += 64u; continue; }
             const uint32_t first = (uint32_t)__ffsll((long long)win) - 1u;
@@ -295,9 +373,16 @@ __global__ void __launch_bounds__(64) k_cbf_heavy(FilterView fv, const uint64_t 
             done += first + 1u;
         }
         if (lane == 0)
-            for (int j = 0; j < fv.cbf_h; ++j)
-                if (c[j] != c0[j]) fv.cbf[idx[j]] = (uint8_t)c[j];
+            for (int j = 0; j < fv.cbf_h; ++j) fv.cbf[idx[j]] = (uint8_t)c[j];   // clears the claim mark too
     }
+}
+// drop the claim marks of the counters of conflicting runs before they are replayed in order
+__global__ void k_conf_release(FilterView fv, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ conf_kmers,
+                               uint32_t n_conf) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_conf) return;
+    const uint64_t h0 = uniq[conf_kmers[i]];
+    for (int j = 0; j < fv.cbf_h; ++j) cbf_release(fv.cbf, index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod));
 }
 
 // ---- conflict path: expand the ops of conflicting k-mers, sort by occurrence, replay in order ----
@@ -322,7 +407,7 @@ __global__ void k_label_push(FilterView fv, const uint64_t *__restrict__ uniq, c
     const uint64_t h0 = uniq[d];
     for (int j = 0; j < fv.cbf_h; ++j) {
         Slot *sl = const_cast<Slot *>(table_find(ctable, c_log2, index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod)));
-        atomicMin(reinterpret_cast<uint32_t *>(&sl->val), l);
+        if (sl) atomicMin(reinterpret_cast<uint32_t *>(&sl->val), l);   // unshared counters are not in the set
     }
 }
 __global__ void k_label_pull(FilterView fv, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ conf_kmers,
@@ -335,6 +420,7 @@ __global__ void k_label_pull(FilterView fv, const uint64_t *__restrict__ uniq, c
     uint32_t l = label[d], l0 = l;
     for (int j = 0; j < fv.cbf_h; ++j) {
         const Slot *sl = table_find(ctable, c_log2, index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod));
+        if (!sl) continue;
         uint32_t v = __hip_atomic_load(reinterpret_cast<const uint32_t *>(&sl->val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         l = v < l ? v : l;
     }
@@ -390,7 +476,7 @@ __device__ void replay_serial(const FilterView &fv, const uint64_t *__restrict__
             if (c[j] != c0[j]) *(volatile uint8_t *)&fv.cbf[idx[j]] = (uint8_t)c[j];
     }
 }
-constexpr uint32_t SMALL_COMPONENT_OPS = 48;
+constexpr uint32_t SMALL_COMPONENT_OPS = 256;
 constexpr uint32_t MAX_COMPONENT_KMERS = 8;
 // one thread per conflicting k-mer (sorted by component label): component heads either replay a
 // small component themselves or queue it for the wave-cooperative kernel
@@ -699,10 +785,11 @@ struct rb_graph {
     uint64_t ordinal = 0;
     int64_t max_batch_kmers = 0;
     int sort_begin_bit = 32;
+    uint32_t light_ops = 96;
     hipStream_t stream = nullptr;
     // scratch (grow-only)
     DevBuf chunk_cnt, chunk_off, keys0, keys1, vals0, vals1, uniq, counts, starts, status, nops, temp,
-        ftable, ctable, heavy, confk, conf_sizes, conf_off, opk0, opk1, opv0, opv1, label, kk0, kk1, biglist, devctr, qbuf0, qbuf1, qbuf2, qbuf3;
+        ftable, ctable, heavy, confk, conf_sizes, conf_off, opk0, opk1, opv0, opv1, label, kk0, kk1, biglist, cvals, foreign, tz, devctr, qbuf0, qbuf1, qbuf2, qbuf3;
     // profiling
     bool prof_on = false;
     struct ProfEntry { const char *name; double ms; int64_t launches; };
@@ -765,6 +852,11 @@ void run_pipeline(rb_graph *g, size_t N, int mode, uint64_t ordinal0, uint32_t p
     sort_pairs_u64_u32(g->temp.p, g->temp.cap, g->keys0.as<uint64_t>(), g->keys1.as<uint64_t>(),
                        g->vals0.as<uint32_t>(), g->vals1.as<uint32_t>(), N, g->sort_begin_bit, 64, s);
     g->prof_end("sort_occurrences");
+    g->prof_begin();
+    g->tz.reserve(N + 16);
+    hipLaunchKernelGGL(k_strength, dim3(blocks_for((int64_t)N)), dim3(TPB), 0, s, g->view(ordinal0, pos_bits),
+                       g->vals1.as<uint32_t>(), N, g->tz.as<uint8_t>());
+    g->prof_end("strengths");
     // runs of equal hash = distinct k-mers
     g->prof_begin();
     g->uniq.reserve(N * 8); g->counts.reserve((N + 1) * 4); g->starts.reserve((N + 1) * 4);
@@ -784,41 +876,47 @@ void run_pipeline(rb_graph *g, size_t N, int mode, uint64_t ordinal0, uint32_t p
     FilterView fv = g->view(ordinal0, pos_bits);
     const uint64_t *uniq = g->uniq.as<uint64_t>();
     const uint32_t *counts = g->counts.as<uint32_t>(), *starts = g->starts.as<uint32_t>(), *vals = g->vals1.as<uint32_t>();
-    g->status.reserve((size_t)D * 4); g->nops.reserve((size_t)D * 4);
+    g->status.reserve((size_t)D * 4); g->nops.reserve((size_t)D * 4); g->cvals.reserve((size_t)D * 8);
     g->heavy.reserve((size_t)D * 4); g->confk.reserve((size_t)D * 4);
+    g->foreign.reserve((size_t)D * 8 * (size_t)g->cbf_h);
     uint32_t *status = g->status.as<uint32_t>(), *nops = g->nops.as<uint32_t>();
     const bool uses_dbg = (mode == M_ADD || mode == M_ADD_IF_ABSENT);
-    uint32_t f_log2 = 1, c_log2 = log2_ceil(2ull * (uint64_t)D * (uint64_t)g->cbf_h + 2);
-    g->prof_begin();
+    uint32_t f_log2 = 1, c_log2 = 1;
     if (uses_dbg) {
+        g->prof_begin();
         f_log2 = log2_ceil(2ull * (uint64_t)D * (uint64_t)g->dbg.num_hash + 2);
         g->ftable.reserve(sizeof(Slot) << f_log2);
         RB_HIP(hipMemsetAsync(g->ftable.p, 0xFF, sizeof(Slot) << f_log2, s));
+        g->prof_end("table_clear");
     }
-    g->ctable.reserve(sizeof(Slot) << c_log2);
-    RB_HIP(hipMemsetAsync(g->ctable.p, 0xFF, sizeof(Slot) << c_log2, s));
-    g->prof_end("table_clear");
-    if (mode != M_COUNT_ONLY) {
+    g->prof_begin();
+    hipLaunchKernelGGL(k_probe, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, uniq, counts, starts, vals, D, mode,
+                       g->ftable.as<Slot>(), f_log2, status, g->cvals.as<uint64_t>(), g->foreign.as<uint64_t>(), ctr);
+    uint32_t n_foreign = 0;
+    RB_HIP(hipMemcpyAsync(&n_foreign, ctr + 5, 4, hipMemcpyDeviceToHost, s));
+    RB_HIP(hipStreamSynchronize(s));
+    g->prof_end("probe_claim");
+    if (n_foreign) {   // the set of counters claimed by more than one run
         g->prof_begin();
-        hipLaunchKernelGGL(k_dbg_test, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, uniq, starts, vals, D, mode,
-                           g->ftable.as<Slot>(), f_log2, status);
-        g->prof_end("dbg_test");
-    } else RB_HIP(hipMemsetAsync(status, 0, (size_t)D * 4, s));
+        c_log2 = log2_ceil(2ull * (uint64_t)n_foreign + 2);
+        g->ctable.reserve(sizeof(Slot) << c_log2);
+        RB_HIP(hipMemsetAsync(g->ctable.p, 0xFF, sizeof(Slot) << c_log2, s));
+        hipLaunchKernelGGL(k_cs_build, dim3(blocks_for(n_foreign)), dim3(TPB), 0, s, g->foreign.as<uint64_t>(), n_foreign,
+                           g->ctable.as<Slot>(), c_log2);
+        g->prof_end("conflict_set");
+    }
     g->prof_begin();
-    hipLaunchKernelGGL(k_dbg_set_claim, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, uniq, counts, starts, vals, D, mode,
-                       g->ftable.as<Slot>(), f_log2, g->ctable.as<Slot>(), c_log2, status, nops);
-    g->prof_end("dbg_set_claim");
-    g->prof_begin();
-    hipLaunchKernelGGL(k_cbf_apply, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, uniq, counts, starts, vals, D,
-                       g->ctable.as<Slot>(), c_log2, status, nops, g->heavy.as<uint32_t>(), g->confk.as<uint32_t>(), ctr);
-    g->prof_end("cbf_apply");
+    hipLaunchKernelGGL(k_resolve_apply, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, uniq, counts, starts, vals, D, mode, g->light_ops,
+                       g->ftable.as<Slot>(), f_log2, g->ctable.as<Slot>(), c_log2, n_foreign, status, nops,
+                       g->cvals.as<uint64_t>(), g->tz.as<uint8_t>(), g->heavy.as<uint32_t>(), g->confk.as<uint32_t>(), ctr);
     uint32_t hc[3] = {0, 0, 0};
     RB_HIP(hipMemcpyAsync(hc, ctr, 12, hipMemcpyDeviceToHost, s));
     RB_HIP(hipStreamSynchronize(s));
+    g->prof_end("resolve_apply");
     if (hc[0]) {
         g->prof_begin();
         hipLaunchKernelGGL(k_cbf_heavy, dim3(std::min<uint32_t>(hc[0], 16384u)), dim3(64), 0, s, fv, uniq, counts, starts,
-                           vals, status, nops, g->heavy.as<uint32_t>(), ctr);
+                           vals, status, nops, g->cvals.as<uint64_t>(), g->tz.as<uint8_t>(), g->heavy.as<uint32_t>(), ctr);
         g->prof_end("cbf_heavy");
     }
     if (hc[1]) {
@@ -831,6 +929,7 @@ void run_pipeline(rb_graph *g, size_t N, int mode, uint64_t ordinal0, uint32_t p
         g->biglist.reserve((size_t)nck * 4);
         const uint32_t *confk = g->confk.as<uint32_t>();
         uint32_t *label = g->label.as<uint32_t>();
+        hipLaunchKernelGGL(k_conf_release, dim3(blocks_for(nck)), dim3(TPB), 0, s, fv, uniq, confk, nck);
         // components by min-label propagation; ctr[3] = changed flag, ctr[4] = number of big components
         hipLaunchKernelGGL(k_label_init, dim3(blocks_for(nck)), dim3(TPB), 0, s, confk, nck, label);
         for (int it = 0;; ++it) {
@@ -980,9 +1079,10 @@ int rb_graph_create(const rb_graph_params *p, rb_graph **out) {
         g->k = p->k;
         g->stranded = p->stranded != 0;
         g->H = std::max(p->dbgbf_num_hash, p->cbf_num_hash);
-        g->max_batch_kmers = p->max_batch_kmers > 0 ? p->max_batch_kmers : ((int64_t)1 << 28);
+        g->max_batch_kmers = p->max_batch_kmers > 0 ? p->max_batch_kmers : ((int64_t)1 << 30);
         RB_REQUIRE(p->group_bits >= 0 && p->group_bits <= 64, "rb_graph_create: group_bits out of range [0,64]");
         if (p->group_bits) g->sort_begin_bit = 64 - p->group_bits;
+        if (const char *e = getenv("RB_LIGHT_OPS")) g->light_ops = (uint32_t)std::max(1, atoi(e));
         if (const char *e = getenv("RB_SORT_BEGIN_BIT")) g->sort_begin_bit = std::max(0, std::min(63, atoi(e)));
         RB_REQUIRE(g->max_batch_kmers <= ((int64_t)1 << 31), "rb_graph_create: max_batch_kmers above 2^31");
         RB_HIP(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
@@ -1011,7 +1111,7 @@ int rb_graph_destroy(rb_graph *g) {
     if (g->cbf) (void)hipFree(g->cbf);
     DevBuf *bufs[] = {&g->chunk_cnt, &g->chunk_off, &g->keys0, &g->keys1, &g->vals0, &g->vals1, &g->uniq, &g->counts,
                       &g->starts, &g->status, &g->nops, &g->temp, &g->ftable, &g->ctable, &g->heavy, &g->confk,
-                      &g->conf_sizes, &g->conf_off, &g->opk0, &g->opk1, &g->opv0, &g->opv1, &g->label, &g->kk0, &g->kk1, &g->biglist, &g->devctr, &g->qbuf0,
+                      &g->conf_sizes, &g->conf_off, &g->opk0, &g->opk1, &g->opv0, &g->opv1, &g->label, &g->kk0, &g->kk1, &g->biglist, &g->cvals, &g->foreign, &g->tz, &g->devctr, &g->qbuf0,
                       &g->qbuf1, &g->qbuf2, &g->qbuf3};
     for (auto *b : bufs) b->release();
     if (g->ev0) (void)hipEventDestroy(g->ev0);
@@ -1293,6 +1393,11 @@ int rb_filter_import(rb_graph *g, int which, const void *srcp, size_t nbytes) {
             dst = f->bits; have = (size_t)f->nbytes; alloc = f->alloc;
         }
         RB_REQUIRE(nbytes == have, "rb_filter_import: buffer is %zu bytes, filter has %zu", nbytes, have);
+        if (which == RB_CBF) {   // counters are MiniFloat bytes 0..127; bit 7 is the library's transient claim mark
+            const uint8_t *b = static_cast<const uint8_t *>(srcp);
+            for (size_t i = 0; i < nbytes; ++i)
+                RB_REQUIRE(!(b[i] & 0x80u), "rb_filter_import: counter byte %zu is %u (> 127, not a MiniFloat count)", i, (unsigned)b[i]);
+        }
         RB_HIP(hipStreamSynchronize(g->stream));
         RB_HIP(hipMemset(dst, 0, alloc));
         RB_HIP(hipMemcpy(dst, srcp, have, hipMemcpyHostToDevice));
