@@ -25,7 +25,29 @@ for p in (ROOT, os.path.join(ROOT, "rna-bloom_amd")):
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0           # MI355X spec HBM3E bandwidth (MI355X_MICROARCH.md)
-BYTES_PER_KMER_SORT = 12 * 2 * 8  # see DESIGN.md §Roofline: radix sort moves (8 B key + 4 B value) in+out per pass, 8 passes
+SECTOR = 64                     # bytes moved per random probe (SURVEY.md §8(d) sector model; matches FETCH_SIZE)
+
+
+def algorithmic_bytes(stage, n_kmers, n_pairs, n_runs, words, group_bits=32, h=2):
+    """ALGORITHMIC bytes one step moves in each pipeline stage.
+    n_kmers = k-mer occurrences, n_pairs = paired k-mers, n_runs = distinct runs, words = 32-base words."""
+    passes = -(-group_bits // 8)
+    model = {
+        # 8-bit onesweep: one histogram read of the keys + per pass (8 B key + 4 B value) in and out
+        "sort_occurrences": n_kmers * (8 + passes * 2 * 12),
+        # packed reads in (8 B codes + 4 B validity + 4 B owner per word), (h0, occurrence) out
+        "hash_windows": words * 16 + n_kmers * 12,
+        "count_windows": words * 12,
+        "strengths": n_kmers * 5,
+        "distinct_runs": n_kmers * 8 + n_runs * 16,
+        # per run: h Bloom-bit sector reads + h counter claims (atomic = sector read + write) + 36 B of records
+        "probe_claim": n_runs * (h * SECTOR + h * 2 * SECTOR + 36),
+        # per run: h counter byte stores (sector write), one strength sector, 40 B of records
+        "resolve_apply": n_runs * (h * SECTOR + SECTOR + 40),
+        # per pair: h bit-sets (atomic RMW on a sector); reads are re-walked: 16 B per word
+        "pairs_insert": words * 16 + n_pairs * h * 2 * SECTOR,
+    }
+    return model.get(stage)
 
 
 def parse():
@@ -40,7 +62,7 @@ def parse():
     ap.add_argument("--fpr", type=float, default=0.01)
     ap.add_argument("--err", type=float, default=0.001)
     ap.add_argument("--batch-kmers", type=int, default=0)
-    ap.add_argument("--cpu-sample-pairs", type=int, default=400_000)
+    ap.add_argument("--cpu-sample-pairs", type=int, default=8_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-stages", action="store_true", help="per-stage HIP-event timing inside the timed region")
     return ap.parse_args()
@@ -120,14 +142,21 @@ def main():
         dom = max(prof.items(), key=lambda kv: kv[1][0]) if prof else ("none", (0.0, 0))
         dom_name, (dom_ms, dom_launches) = dom
         roof = None
+        words = 2 * pairs_rank * 5 * a.steps
+        per_stage = {}
+        for name, (ms, launches) in prof.items():
+            ab = algorithmic_bytes(name, kmers, pairs_ins, distinct, words)
+            if ab and ms > 0:
+                per_stage[name] = round(ab / (ms * 1e-3) / 1e9, 1)
         if dom_launches:
-            per_launch_kmers = kmers / max(dom_launches, 1)
-            alg_bytes = per_launch_kmers * BYTES_PER_KMER_SORT
-            avg_s = dom_ms / dom_launches * 1e-3
-            achieved = alg_bytes / avg_s / 1e9
-            roof = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                    "avg_launch_ms": round(dom_ms / dom_launches, 3), "launches": dom_launches}
+            ab = algorithmic_bytes(dom_name, kmers, pairs_ins, distinct, words)
+            if ab:
+                achieved = ab / (dom_ms * 1e-3) / 1e9      # = bytes per launch / average launch duration
+                roof = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                        "algorithmic_bytes_per_launch": int(ab / dom_launches),
+                        "avg_launch_ms": round(dom_ms / dom_launches, 3), "launches": dom_launches,
+                        "all_stages_GBps": per_stage}
         out = {
             "metric": "k-mers/sec hashed+inserted into Bloom dBG (k=25, 50M 150bp reads)",
             "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
