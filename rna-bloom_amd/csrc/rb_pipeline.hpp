@@ -1,0 +1,214 @@
+// rb_pipeline.hpp — device helpers, per-graph state and host utilities shared by the single-GPU
+// engine (rb_graph.hip) and the sharded engine (rb_shard.hip).
+#pragma once
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "rb_internal.hpp"
+#include "rb_kernels.hpp"
+
+namespace rb {
+
+constexpr int TPB = 256;
+inline unsigned blocks_for(int64_t n, int tpb = TPB) { return (unsigned)((n + tpb - 1) / tpb); }
+
+struct BitFilter {
+    uint32_t *bits = nullptr;
+    int64_t size = 0, nbytes = 0;
+    size_t alloc = 0;
+    int num_hash = 0;
+    Mod mod{1, 0, 0};
+};
+
+// everything a kernel needs to address the filters (passed by value)
+struct FilterView {
+    uint32_t *dbg; Mod dbg_mod; int dbg_h;
+    uint8_t *cbf;  Mod cbf_mod; int cbf_h;
+    uint64_t kmul;        // k * multiSeed
+    uint64_t seed;        // rng seed
+    uint64_t ordinal0;    // op ordinal of occurrence value 0
+    uint32_t pos_bits;    // occurrence value = (read_rel << pos_bits) | pos
+};
+
+// open-addressing table slot: key (empty = ~0) + 64-bit payload (identity of atomicMin = ~0)
+struct Slot { unsigned long long key; unsigned long long val; };
+
+__device__ __forceinline__ uint64_t slot_of(uint64_t key, uint32_t log2cap) {
+    return (key * 0x9E3779B97F4A7C15ull) >> (64u - log2cap);
+}
+__device__ __forceinline__ Slot *table_insert(Slot *t, uint32_t log2cap, uint64_t key) {
+    const uint64_t mask = (1ull << log2cap) - 1ull;
+    uint64_t s = slot_of(key, log2cap);
+    for (;;) {
+        unsigned long long cur = __hip_atomic_load(&t[s].key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur == key) return &t[s];
+        if (cur == ~0ull) {
+            unsigned long long old = atomicCAS(&t[s].key, ~0ull, (unsigned long long)key);
+            if (old == ~0ull || old == key) return &t[s];
+        }
+        s = (s + 1ull) & mask;
+    }
+}
+__device__ __forceinline__ const Slot *table_find(const Slot *t, uint32_t log2cap, uint64_t key) {
+    const uint64_t mask = (1ull << log2cap) - 1ull;
+    uint64_t s = slot_of(key, log2cap);
+    for (;;) {
+        unsigned long long cur = t[s].key;
+        if (cur == key) return &t[s];
+        if (cur == ~0ull) return nullptr;
+        s = (s + 1ull) & mask;
+    }
+}
+
+// op kinds of the counting-Bloom state machine
+enum : uint32_t { K_INC = 0, K_INC_IF_POS = 1, K_INC_IF_ZERO = 2 };
+// pipeline modes
+enum : int { M_ADD = 0, M_ADD_IF_ABSENT = 1, M_COUNT_IF_PRESENT = 2, M_COUNT_ONLY = 4 };
+
+// status word per distinct k-mer: bits 0..7 premask (bit j: probe j was set before the batch),
+// bit 8 all_pre, bits 12..13 kind of first op, bits 14..15 kind of the remaining ops, bit 16 conflict
+constexpr uint32_t ST_ALLPRE = 1u << 8;
+
+// CountingBloomFilter.increment(long[]) :170-194 on a register copy of the cbf_h bytes.
+// c[j] mirrors counts[idx_j]; duplicated indices stay consistent because both copies move together.
+__device__ __forceinline__ void cbf_step(uint32_t *c, int h, uint32_t kind, uint32_t rnd31) {
+    uint32_t mn = c[0];
+    for (int j = 1; j < h; ++j) mn = c[j] < mn ? c[j] : mn;
+    if (kind == K_INC_IF_POS && mn == 0u) return;    // addCountIfPresent :424-428
+    if (kind == K_INC_IF_ZERO && mn != 0u) return;   // addIfAbsent else-branch :419-421
+    uint32_t up = minifloat_inc(mn, rnd31);
+    if (up != mn)
+        for (int j = 0; j < h; ++j) if (c[j] == mn) c[j] = up;
+}
+__device__ __forceinline__ uint32_t occ_rnd(const FilterView &fv, uint32_t v) {
+    return rng31(fv.seed, fv.ordinal0 + (uint64_t)(v >> fv.pos_bits), v & ((1u << fv.pos_bits) - 1u));
+}
+
+// Random-draw "strength" of every occurrence, in sorted order: the number of trailing zero bits of
+// its 31-bit draw (capped at 15).  MiniFloat.increment at byte b >= 16 succeeds iff
+// rnd % 2^s == 0 with s = (b>>3)-1 <= 14, i.e. iff strength >= s — so the per-run state machines
+// only compare bytes and never evaluate the generator inside their sequential loops.
+static __global__ void k_strength(FilterView fv, const uint32_t *__restrict__ vals, size_t n, uint8_t *__restrict__ tz) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t r = occ_rnd(fv, vals[i]) | 0x8000u;          // bit 15 caps the count at 15
+    tz[i] = (uint8_t)(__ffs((int)r) - 1);
+}
+// first index in [pos,end) whose strength byte is >= s (s in 1..15), or end.  8 bytes per load.
+__device__ __forceinline__ uint32_t next_success(const uint8_t *__restrict__ tz, uint32_t pos, uint32_t end, uint32_t s) {
+    const uint64_t add = (uint64_t)(0x80u - s) * 0x0101010101010101ull;
+    while (pos < end) {
+        const uint32_t a = pos & ~7u;
+        uint64_t w = *reinterpret_cast<const uint64_t *>(tz + a);      // tz is allocated with 8 bytes of slack
+        uint64_t hit = (w + add) & 0x8080808080808080ull;              // bytes are <= 15: no carries
+        hit &= ~0ull << (8u * (pos - a));                              // ignore bytes below pos
+        if (hit) {
+            const uint32_t q = a + ((uint32_t)__ffsll((long long)hit) - 1u) / 8u;
+            return q < end ? q : end;
+        }
+        pos = a + 8u;
+    }
+    return end;
+}
+// all `ops` increments of one run applied to the register copy c[] of its counters, in order.
+// kind0 applies to the first op, kind to the others; tz = strengths of the ops (tz[0] = first op).
+__device__ __forceinline__ void run_ops(uint32_t *c, int h, uint32_t kind0, uint32_t kind, const uint8_t *__restrict__ tz,
+                                        uint32_t base, uint32_t ops) {
+    auto minimum = [&]() { uint32_t mn = c[0]; for (int j = 1; j < h; ++j) mn = c[j] < mn ? c[j] : mn; return mn; };
+    auto bump = [&](uint32_t mn) { for (int j = 0; j < h; ++j) if (c[j] == mn) c[j] = mn + 1u; };
+    uint32_t i = 0;
+    {   // first op (its kind may differ)
+        const uint32_t mn = minimum();
+        const bool gate = !((kind0 == K_INC_IF_POS && mn == 0u) || (kind0 == K_INC_IF_ZERO && mn != 0u));
+        if (gate && mn < 127u && (mn < 16u || tz[base] >= (mn >> 3) - 1u)) bump(mn);
+        i = 1;
+    }
+    while (i < ops) {
+        const uint32_t mn = minimum();
+        if (mn >= 127u) break;                                    // saturated
+        if (kind == K_INC_IF_POS && mn == 0u) break;              // stays zero for the rest of the run
+        if (kind == K_INC_IF_ZERO && mn != 0u) break;             // stays positive
+        if (mn < 16u) { bump(mn); ++i; continue; }                // deterministic region
+        const uint32_t q = next_success(tz, base + i, base + ops, (mn >> 3) - 1u);
+        if (q >= base + ops) break;
+        bump(mn);
+        i = q - base + 1u;
+    }
+}
+
+// Counter bytes live in 0..127 (MiniFloat saturates at Byte.MAX_VALUE, R/util/MiniFloat.java:32), so
+// bit 7 of a counting-Bloom byte is free.  During a sub-batch it serves as a "claimed by a k-mer of
+// this sub-batch" marker: the atomicOr that claims a counter also returns its value, and a k-mer that
+// finds the marker already set knows it shares the counter with another k-mer (=> ordered replay).
+constexpr uint32_t CLAIM = 0x80u;
+__device__ __forceinline__ uint32_t cbf_claim(uint8_t *cbf, uint64_t idx) {       // returns old byte
+    uint32_t *w = reinterpret_cast<uint32_t *>(cbf) + (idx >> 2);
+    const uint32_t sh = 8u * (uint32_t)(idx & 3u);
+    return (atomicOr(w, CLAIM << sh) >> sh) & 0xFFu;
+}
+__device__ __forceinline__ void cbf_release(uint8_t *cbf, uint64_t idx) {
+    uint32_t *w = reinterpret_cast<uint32_t *>(cbf) + (idx >> 2);
+    atomicAnd(w, ~(CLAIM << (8u * (uint32_t)(idx & 3u))));
+}
+
+// status word per distinct run: bits 0..7 premask, bit 8 all_pre, bit 9 claimed counters,
+// bit 10 saw a foreign claim, bits 12..13 kind of first op, 14..15 kind of the other ops
+constexpr uint32_t ST_CLAIMED = 1u << 9, ST_FOREIGN = 1u << 10;
+
+
+inline uint32_t log2_ceil(uint64_t x) { uint32_t l = 0; while ((1ull << l) < x) ++l; return l; }
+
+}  // namespace rb
+
+// ------------------------------------------------------------------ graph object ----
+struct ShardState;
+using rb::BitFilter; using rb::FilterView; using rb::Mod; using rb::DevBuf; using rb::kmul_of;
+struct rb_graph {
+    // sharded mode (rb_shard.hip): this handle owns index range [lo,hi) of every filter
+    int shard_rank = 0, shard_count = 1;
+    ShardState *shard = nullptr;
+    rb_graph_params p{};
+    int k = 0, H = 0;
+    bool stranded = false;
+    BitFilter dbg, rpk, fpk;
+    uint8_t *cbf = nullptr;
+    int64_t cbf_size = 0;
+    size_t cbf_alloc = 0;
+    Mod cbf_mod{1, 0, 0};
+    int cbf_h = 0;
+    int read_d = -1, frag_d = -1;
+    uint64_t ordinal = 0;
+    int64_t max_batch_kmers = 0;
+    int sort_begin_bit = 32;
+    uint32_t light_ops = 96;
+    hipStream_t stream = nullptr;
+    // scratch (grow-only)
+    DevBuf chunk_cnt, chunk_off, keys0, keys1, vals0, vals1, uniq, counts, starts, status, nops, temp,
+        ftable, ctable, heavy, confk, conf_sizes, conf_off, opk0, opk1, opv0, opv1, label, kk0, kk1, biglist, cvals, foreign, tz, devctr, qbuf0, qbuf1, qbuf2, qbuf3;
+    // profiling
+    bool prof_on = false;
+    struct ProfEntry { const char *name; double ms; int64_t launches; };
+    std::vector<ProfEntry> prof;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    FilterView view(uint64_t ordinal0, uint32_t pos_bits) const {
+        FilterView fv;
+        fv.dbg = dbg.bits; fv.dbg_mod = dbg.mod; fv.dbg_h = dbg.num_hash;
+        fv.cbf = cbf; fv.cbf_mod = cbf_mod; fv.cbf_h = cbf_h;
+        fv.kmul = kmul_of(k); fv.seed = p.rng_seed; fv.ordinal0 = ordinal0; fv.pos_bits = pos_bits;
+        return fv;
+    }
+    void prof_begin() { if (prof_on) RB_HIP(hipEventRecord(ev0, stream)); }
+    void prof_end(const char *name) {
+        if (!prof_on) return;
+        RB_HIP(hipEventRecord(ev1, stream));
+        RB_HIP(hipEventSynchronize(ev1));
+        float ms = 0;
+        RB_HIP(hipEventElapsedTime(&ms, ev0, ev1));
+        for (auto &e : prof) if (!strcmp(e.name, name)) { e.ms += ms; e.launches++; return; }
+        prof.push_back({name, ms, 1});
+    }
+};
+
