@@ -182,6 +182,55 @@ int64_t rb_expected_size(int64_t n, float fpr, int num_hash); /* BloomFilter.get
 int rb_nthash_batch(const rb_batch *b, int k, int mode, int64_t first, int64_t n, int64_t *count,
                     uint64_t *out_h0, uint32_t *out_read, uint32_t *out_pos);
 
+/* ---- sharded engine (one process per GPU; filters split by index range across `count` shards) ----
+ * Multi-GPU counterpart of rb_graph_add_batch.  The reference is a single shared-memory process, so
+ * there is no reference interface for this; the phases below are what bench.py / rnabloom.sharded
+ * drive, with torch.distributed (RCCL all_to_all / all_gather) moving the byte buffers between
+ * ranks.  Shard s of a filter of `size` indices owns [s*span, min(size,(s+1)*span)), span =
+ * roundup64(ceil(size/count)); k-mer hash space is split by the top log2(count) bits of hashVals[0]
+ * (count must be a power of two).  All `dev` pointers are DEVICE pointers owned by the caller
+ * (exchange buffers).  Results equal the single-GPU / sequential results bit for bit.
+ *
+ * per global sub-batch (every rank, lock step):
+ *   hash      local reads -> (h0, occ) records bucketed by k-mer owner, pair probes by rpkbf owner
+ *   [all_to_all records, pair probes]
+ *   group     received records -> runs -> Bloom-bit / counter requests bucketed by filter owner
+ *   [all_to_all requests]
+ *   serve     owner: bit tests + first-setter arbitration + bit sets, counter claims, pair bit sets
+ *   [all_to_all replies back]
+ *   resolve   found flags, op counts, counter updates of runs that own their counters alone
+ *   [all_to_all counter writes]     apply_writes
+ *   [all_gather conflict ops + counters]   conflict_replay (every rank replays the same small set)
+ */
+enum {
+    RB_SLOT_REC_KEYS = 0,   /* u64 h0, bucketed by k-mer owner          */
+    RB_SLOT_REC_OCC = 1,    /* u32 occurrence ids (same order)          */
+    RB_SLOT_PAIR_IDX = 2,   /* u64 global rpkbf bit indices, by owner   */
+    RB_SLOT_DREQ_IDX = 3,   /* u64 global dbgbf bit index               */
+    RB_SLOT_DREQ_PROBE = 4, /* u64 (occ_first << 4 | probe)             */
+    RB_SLOT_CREQ_IDX = 5,   /* u64 global counter index                 */
+    RB_SLOT_W_IDX = 6,      /* u64 global counter index                 */
+    RB_SLOT_W_VAL = 7,      /* u8 new byte, 0xFF = just drop the claim  */
+    RB_SLOT_CONF_OPS = 8,   /* 16 B records {u32 occ, u32 kind, u64 h0} */
+    RB_SLOT_CONF_CTR = 9,   /* 16 B records {u64 global index, u64 value} */
+    RB_SLOT_COUNT = 10
+};
+int rb_graph_create_shard(const rb_graph_params *p, int shard_rank, int shard_count, rb_graph **out);
+int rb_shard_hash(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, uint32_t read_rel_base,
+                  uint32_t pos_bits, unsigned flags, int64_t *rec_counts /*[count]*/, int64_t *pair_counts /*[count]*/);
+int rb_shard_group(rb_graph *g, const void *keys_dev, const void *occ_dev, int64_t n, uint64_t ordinal0,
+                   uint32_t pos_bits, int mode, int64_t *dreq_counts, int64_t *creq_counts);
+int rb_shard_serve(rb_graph *g, int mode, const void *dreq_idx_dev, const void *dreq_probe_dev, int64_t nd,
+                   const void *creq_idx_dev, int64_t nc, const void *pair_idx_dev, int64_t np,
+                   void *dreply_dev /* u8[nd] */, void *creply_dev /* u8[nc] */);
+int rb_shard_resolve(rb_graph *g, int mode, const void *dreply_dev, const void *creply_dev, int64_t *w_counts,
+                     int64_t *n_conf_ops, int64_t *n_conf_ctr, rb_add_stats *stats);
+int rb_shard_apply_writes(rb_graph *g, const void *w_idx_dev, const void *w_val_dev, int64_t n);
+int rb_shard_conflict_replay(rb_graph *g, const void *ops_dev, int64_t n_ops, const void *ctr_dev, int64_t n_ctr);
+/* copy an internal slot (bucketed by destination) into a caller-owned device buffer */
+int rb_shard_take(rb_graph *g, int slot, void *dst_dev, int64_t nbytes);
+int rb_shard_span(rb_graph *g, int which, int64_t *span, int64_t *lo, int64_t *hi);
+
 /* ---- instrumentation: per-kernel-class HIP-event timing on the library's own stream ---- */
 #define RB_PROF_MAX 32
 typedef struct rb_profile {

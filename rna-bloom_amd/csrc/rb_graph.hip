@@ -169,66 +169,6 @@ __global__ void k_resolve_apply(FilterView fv, const uint64_t *__restrict__ uniq
     for (int j = 0; j < fv.cbf_h; ++j) fv.cbf[idx[j]] = (uint8_t)c[j];   // also clears the claim mark
 }
 
-// one wavefront per high-multiplicity run: lanes fetch 64 occurrences at a time, compute each
-// one's random draw, and the increment chain hops from success to success with ballots
-__global__ void __launch_bounds__(64) k_cbf_heavy(FilterView fv, const uint64_t *__restrict__ uniq,
-                            const uint32_t *__restrict__ counts, const uint32_t *__restrict__ starts,
-                            const uint32_t *__restrict__ vals, const uint32_t *__restrict__ status,
-                            const uint32_t *__restrict__ nops, const uint64_t *__restrict__ cvals,
-                            const uint8_t *__restrict__ tz, const uint32_t *__restrict__ heavy_list,
-                            const uint32_t *__restrict__ counters) {
-    const uint32_t n_heavy = counters[0];
-    const uint32_t lane = threadIdx.x;
-    for (uint32_t hi = blockIdx.x; hi < n_heavy; hi += gridDim.x) {
-        const uint32_t d = heavy_list[hi];
-        const uint64_t h0 = uniq[d];
-        const uint32_t ops = nops[d];
-        const uint32_t st = status[d];
-        const uint64_t cv = cvals[d];
-        uint64_t idx[RB_MAX_HASH];
-        uint32_t c[RB_MAX_HASH];
-        for (int j = 0; j < fv.cbf_h; ++j) {
-            idx[j] = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod);
-            c[j] = (uint32_t)(cv >> (8 * j)) & 0xFFu;
-        }
-        const uint32_t base = starts[d] + counts[d] - ops;
-        const uint32_t krest = (st >> 14) & 3u;
-        uint32_t done = 0;
-        {   // the first op may have its own kind
-            uint32_t mn = c[0];
-            for (int j = 1; j < fv.cbf_h; ++j) mn = c[j] < mn ? c[j] : mn;
-            const uint32_t k0 = (st >> 12) & 3u;
-            const bool gate = !((k0 == K_INC_IF_POS && mn == 0u) || (k0 == K_INC_IF_ZERO && mn != 0u));
-            if (gate && mn < 127u && (mn < 16u || tz[base] >= (mn >> 3) - 1u))
-                for (int j = 0; j < fv.cbf_h; ++j) if (c[j] == mn) c[j] = mn + 1u;
-            done = 1;
-        }
-        while (done < ops) {
-            uint32_t mn = c[0];
-            for (int j = 1; j < fv.cbf_h; ++j) mn = c[j] < mn ? c[j] : mn;
-            if (mn >= 127u) break;                                   // saturated: nothing changes any more
-            if (krest == K_INC_IF_POS && mn == 0u) break;            // stays zero for ever
-            if (krest == K_INC_IF_ZERO && mn != 0u) break;           // stays positive for ever
-            if (mn < 16u) {                                          // deterministic region: one step
-                cbf_step(c, fv.cbf_h, krest, 0u);
-                ++done;
-                continue;
-            }
-            // probabilistic region: examine up to 64 pending occurrences at once
-            const uint32_t i = done + lane;
-            const uint32_t shift = (mn >> 3) - 1u;
-            bool ok = false;
-            if (i < ops) ok = tz[base + i] >= shift;
-            const unsigned long long win = __ballot(ok);
-            if (!win) { done += 64u; continue; }
-            const uint32_t first = (uint32_t)__ffsll((long long)win) - 1u;
-            cbf_step(c, fv.cbf_h, krest, 0u);                        // rnd 0 always succeeds
-            done += first + 1u;
-        }
-        if (lane == 0)
-            for (int j = 0; j < fv.cbf_h; ++j) fv.cbf[idx[j]] = (uint8_t)c[j];   // clears the claim mark too
-    }
-}
 // drop the claim marks of the counters of conflicting runs before they are replayed in order
 __global__ void k_conf_release(FilterView fv, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ conf_kmers,
                                uint32_t n_conf) {
@@ -433,7 +373,8 @@ __global__ void k_pairs_insert(const uint64_t *__restrict__ codes, const uint32_
                                const uint32_t *__restrict__ word_read, const uint32_t *__restrict__ woff,
                                const uint32_t *__restrict__ len, int64_t w0, int64_t nw, int k, int dist,
                                uint32_t *bits, Mod mod, int num_hash, uint64_t kmul,
-                               unsigned long long *__restrict__ n_pairs) {
+                               unsigned long long *__restrict__ n_pairs,
+                               const uint32_t *__restrict__ chunk_off, uint64_t *__restrict__ out_idx) {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nw) return;
     const int64_t w = w0 + i;
@@ -481,7 +422,12 @@ __global__ void k_pairs_insert(const uint64_t *__restrict__ codes, const uint32_
             if (MODE == 0) P = combine(fL, fR);
             else if (MODE == 2) P = combine(rR, rL);
             else P = smin(combine(fL, fR), combine(rR, rL));
-            for (int j = 0; j < num_hash; ++j) bit_set(bits, index_of(multi_hash(P, (uint32_t)j, kmul), mod));
+            if (out_idx) {   // sharded engine: collect global bit indices instead of setting local bits
+                for (int j = 0; j < num_hash; ++j)
+                    out_idx[((size_t)chunk_off[i] + cnt) * (size_t)num_hash + j] = index_of(multi_hash(P, (uint32_t)j, kmul), mod);
+            } else {
+                for (int j = 0; j < num_hash; ++j) bit_set(bits, index_of(multi_hash(P, (uint32_t)j, kmul), mod));
+            }
             ++cnt;
         }
     }
@@ -623,29 +569,21 @@ __global__ void k_iota(uint32_t *v, size_t n) {
 
 }  // namespace
 
-namespace {
-
-void alloc_bits(BitFilter &f, int64_t bits, int num_hash) {
-    f.size = bits;
-    f.nbytes = bits / 8 + ((bits % 8) ? 1 : 0);   // UnsafeBitBuffer.java:34-37
-    f.alloc = (((size_t)f.nbytes + 3) / 4 + 1) * 4;
-    f.num_hash = num_hash;
-    f.mod = make_mod((uint64_t)bits);
-    RB_HIP(hipMalloc(&f.bits, f.alloc));
-    RB_HIP(hipMemset(f.bits, 0, f.alloc));
-    RB_HIP(hipDeviceSynchronize());   // hipMemset is asynchronous; the graph's stream is non-blocking
-}
-void free_bits(BitFilter &f) { if (f.bits) (void)hipFree(f.bits); f = BitFilter(); }
-
-
-BitFilter *bit_filter(rb_graph *g, int which) {
-    switch (which) { case RB_DBGBF: return &g->dbg; case RB_RPKBF: return &g->rpk; case RB_FPKBF: return &g->fpk; default: return nullptr; }
+// Stable grouping of N (h0, occ) records sitting in keys0/vals0: sort on the top hash bits,
+// draw strengths, run-length encode.  Leaves keys1/vals1 (sorted), tz, uniq/counts/starts.
+void rb::launch_pairs(rb_graph *g, const rb_batch *b, int64_t w0, int64_t nw, int mode_hash, const uint32_t *chunk_off,
+                      uint64_t *out_idx, unsigned long long *pc) {
+    dim3 gr(blocks_for(nw)), th(TPB);
+#define RB_LAUNCH_PAIRS(M)                                                                                          \
+    hipLaunchKernelGGL(k_pairs_insert<M>, gr, th, 0, g->stream, b->codes, b->valid, b->word_read, b->woff, b->len, w0, nw, \
+                       g->k, g->read_d, g->rpk.bits, g->rpk.mod, g->rpk.num_hash, kmul_of(g->k), pc, chunk_off, out_idx)
+    if (mode_hash == 0) RB_LAUNCH_PAIRS(0); else if (mode_hash == 2) RB_LAUNCH_PAIRS(2); else RB_LAUNCH_PAIRS(1);
+#undef RB_LAUNCH_PAIRS
 }
 
-// The order-exact pipeline over N (h0, occurrence) records already sitting in keys0/vals0.
-void run_pipeline(rb_graph *g, size_t N, int mode, uint64_t ordinal0, uint32_t pos_bits, rb_add_stats *stats) {
+uint32_t rb::group_records(rb_graph *g, size_t N, uint64_t ordinal0, uint32_t pos_bits, rb_add_stats *stats,
+                           uint32_t **ctr_out) {
     hipStream_t s = g->stream;
-    if (N == 0) return;
     // 2. stable sort by base hash
     g->prof_begin();
     size_t tb = sort_pairs_temp_bytes(N);
@@ -669,6 +607,7 @@ void run_pipeline(rb_graph *g, size_t N, int mode, uint64_t ordinal0, uint32_t p
     g->uniq.reserve(N * 8); g->counts.reserve((N + 1) * 4); g->starts.reserve((N + 1) * 4);
     g->devctr.reserve(64);
     uint32_t *ctr = g->devctr.as<uint32_t>();
+    if (ctr_out) *ctr_out = ctr;
     RB_HIP(hipMemsetAsync(ctr, 0, 64, s));
     run_length_encode_u64(g->temp.p, g->temp.cap, g->keys1.as<uint64_t>(), N, g->uniq.as<uint64_t>(),
                           g->counts.as<uint32_t>(), ctr + 8, s);
@@ -680,6 +619,38 @@ void run_pipeline(rb_graph *g, size_t N, int mode, uint64_t ordinal0, uint32_t p
     if (stats) stats->distinct += D;
     RB_REQUIRE(D < (1u << 30), "sub-batch has too many distinct k-mers (%u)", D);
 
+    return D;
+}
+
+namespace {
+
+}  // namespace
+void rb::alloc_bits(BitFilter &f, int64_t bits, int num_hash, int64_t lo, int64_t hi) {
+    f.size = bits;
+    f.lo = lo; f.hi = hi;
+    const int64_t local = hi - lo;
+    f.nbytes = local / 8 + ((local % 8) ? 1 : 0);   // UnsafeBitBuffer.java:34-37 (whole filter when lo=0,hi=bits)
+    f.alloc = (((size_t)f.nbytes + 3) / 4 + 1) * 4;
+    f.num_hash = num_hash;
+    f.mod = make_mod((uint64_t)bits);
+    RB_HIP(hipMalloc(&f.bits, f.alloc));
+    RB_HIP(hipMemset(f.bits, 0, f.alloc));
+    RB_HIP(hipDeviceSynchronize());   // hipMemset is asynchronous; the graph's stream is non-blocking
+}
+void rb::free_bits(BitFilter &f) { if (f.bits) (void)hipFree(f.bits); f = BitFilter(); }
+namespace {
+
+
+BitFilter *bit_filter(rb_graph *g, int which) {
+    switch (which) { case RB_DBGBF: return &g->dbg; case RB_RPKBF: return &g->rpk; case RB_FPKBF: return &g->fpk; default: return nullptr; }
+}
+
+// The order-exact pipeline over N (h0, occurrence) records already sitting in keys0/vals0.
+void run_pipeline(rb_graph *g, size_t N, int mode, uint64_t ordinal0, uint32_t pos_bits, rb_add_stats *stats) {
+    hipStream_t s = g->stream;
+    if (N == 0) return;
+    uint32_t *ctr = nullptr;
+    const uint32_t D = group_records(g, N, ordinal0, pos_bits, stats, &ctr);
     FilterView fv = g->view(ordinal0, pos_bits);
     const uint64_t *uniq = g->uniq.as<uint64_t>();
     const uint32_t *counts = g->counts.as<uint32_t>(), *starts = g->starts.as<uint32_t>(), *vals = g->vals1.as<uint32_t>();
@@ -723,7 +694,7 @@ void run_pipeline(rb_graph *g, size_t N, int mode, uint64_t ordinal0, uint32_t p
     if (hc[0]) {
         g->prof_begin();
         hipLaunchKernelGGL(k_cbf_heavy, dim3(std::min<uint32_t>(hc[0], 16384u)), dim3(64), 0, s, fv, uniq, counts, starts,
-                           vals, status, nops, g->cvals.as<uint64_t>(), g->tz.as<uint8_t>(), g->heavy.as<uint32_t>(), ctr);
+                           vals, status, nops, g->cvals.as<uint64_t>(), g->tz.as<uint8_t>(), g->heavy.as<uint32_t>(), ctr, (uint64_t *)nullptr);
         g->prof_end("cbf_heavy");
     }
     if (hc[1]) {
@@ -824,12 +795,7 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
                 g->devctr.reserve(64);
                 unsigned long long *pc = reinterpret_cast<unsigned long long *>(g->devctr.as<uint32_t>() + 12);
                 RB_HIP(hipMemsetAsync(pc, 0, 8, s));
-                dim3 gr(blocks_for(nw)), th(TPB);
-#define RB_LAUNCH_PAIRS(M)                                                                                   \
-    hipLaunchKernelGGL(k_pairs_insert<M>, gr, th, 0, s, b->codes, b->valid, b->word_read, b->woff, b->len, w0, nw, \
-                       g->k, g->read_d, g->rpk.bits, g->rpk.mod, g->rpk.num_hash, kmul_of(g->k), pc)
-                if (mode_hash == 0) RB_LAUNCH_PAIRS(0); else if (mode_hash == 2) RB_LAUNCH_PAIRS(2); else RB_LAUNCH_PAIRS(1);
-#undef RB_LAUNCH_PAIRS
+                launch_pairs(g, b, w0, nw, mode_hash, nullptr, nullptr, pc);
                 unsigned long long np = 0;
                 RB_HIP(hipMemcpyAsync(&np, pc, 8, hipMemcpyDeviceToHost, s));
                 RB_HIP(hipStreamSynchronize(s));
@@ -843,12 +809,6 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
     }
     g->ordinal += (uint64_t)n;
     RB_HIP(hipStreamSynchronize(s));
-}
-
-template <typename F> int guarded(F &&f) {
-    try { f(); return RB_OK; }
-    catch (const HipError &e) { return e.code; }
-    catch (const std::bad_alloc &) { set_error("host allocation failed"); return RB_ERR_NOMEM; }
 }
 
 // upload n base hashes into a scratch buffer
@@ -895,14 +855,14 @@ int rb_graph_create(const rb_graph_params *p, rb_graph **out) {
         RB_HIP(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
         RB_HIP(hipEventCreate(&g->ev0));
         RB_HIP(hipEventCreate(&g->ev1));
-        alloc_bits(g->dbg, p->dbgbf_bits, p->dbgbf_num_hash);
-        g->cbf_size = p->cbf_bytes;
+        alloc_bits(g->dbg, p->dbgbf_bits, p->dbgbf_num_hash, 0, p->dbgbf_bits);
+        g->cbf_size = p->cbf_bytes; g->cbf_lo = 0; g->cbf_hi = p->cbf_bytes;
         g->cbf_alloc = (((size_t)p->cbf_bytes + 3) / 4 + 1) * 4;
         g->cbf_h = p->cbf_num_hash;
         g->cbf_mod = make_mod((uint64_t)p->cbf_bytes);
         RB_HIP(hipMalloc(&g->cbf, g->cbf_alloc));
         RB_HIP(hipMemset(g->cbf, 0, g->cbf_alloc));
-        if (p->use_read_paired_kmers) alloc_bits(g->rpk, p->pkbf_bits, p->pkbf_num_hash);
+        if (p->use_read_paired_kmers) alloc_bits(g->rpk, p->pkbf_bits, p->pkbf_num_hash, 0, p->pkbf_bits);
         RB_HIP(hipDeviceSynchronize());
         *out = g;
     });
@@ -914,6 +874,7 @@ int rb_graph_destroy(rb_graph *g) {
     if (!g) return RB_OK;
     (void)hipSetDevice(g->p.device);
     if (g->stream) (void)hipStreamSynchronize(g->stream);
+    rb::shard_free(g);
     free_bits(g->dbg); free_bits(g->rpk); free_bits(g->fpk);
     if (g->cbf) (void)hipFree(g->cbf);
     DevBuf *bufs[] = {&g->chunk_cnt, &g->chunk_off, &g->keys0, &g->keys1, &g->vals0, &g->vals1, &g->uniq, &g->counts,
@@ -953,7 +914,7 @@ int rb_graph_init_fragment_pairs(rb_graph *g, int64_t pkbf_bits, int pkbf_num_ha
     return guarded([&] {
         RB_REQUIRE(g && pkbf_bits > 0 && pkbf_num_hash >= 1 && pkbf_num_hash <= RB_MAX_HASH, "rb_graph_init_fragment_pairs: bad argument");
         RB_HIP(hipSetDevice(g->p.device));
-        if (!g->fpk.bits) alloc_bits(g->fpk, pkbf_bits, pkbf_num_hash);   // :352-359: create once, else empty()
+        if (!g->fpk.bits) alloc_bits(g->fpk, pkbf_bits, pkbf_num_hash, 0, pkbf_bits);   // :352-359: create once, else empty()
         else { RB_HIP(hipMemset(g->fpk.bits, 0, g->fpk.alloc)); RB_HIP(hipDeviceSynchronize()); }
     });
 }
@@ -1119,7 +1080,7 @@ int rb_filter_size(rb_graph *g, int which, int64_t *size, int64_t *nbytes, int *
     if (!g) { set_error("null graph"); return RB_ERR_INVALID; }
     if (which == RB_CBF) {
         if (size) *size = g->cbf_size;
-        if (nbytes) *nbytes = g->cbf_size;
+        if (nbytes) *nbytes = g->cbf_hi - g->cbf_lo;
         if (num_hash) *num_hash = g->cbf_h;
         return RB_OK;
     }
@@ -1174,7 +1135,7 @@ int rb_filter_export(rb_graph *g, int which, void *dst, size_t nbytes) {
         RB_REQUIRE(g && dst, "rb_filter_export: null argument");
         RB_HIP(hipSetDevice(g->p.device));
         const void *src; size_t have;
-        if (which == RB_CBF) { src = g->cbf; have = (size_t)g->cbf_size; }
+        if (which == RB_CBF) { src = g->cbf; have = (size_t)(g->cbf_hi - g->cbf_lo); }
         else {
             BitFilter *f = bit_filter(g, which);
             RB_REQUIRE(f, "rb_filter_export: unknown filter %d", which);
@@ -1192,7 +1153,7 @@ int rb_filter_import(rb_graph *g, int which, const void *srcp, size_t nbytes) {
         RB_REQUIRE(g && srcp, "rb_filter_import: null argument");
         RB_HIP(hipSetDevice(g->p.device));
         void *dst; size_t have, alloc;
-        if (which == RB_CBF) { dst = g->cbf; have = (size_t)g->cbf_size; alloc = g->cbf_alloc; }
+        if (which == RB_CBF) { dst = g->cbf; have = (size_t)(g->cbf_hi - g->cbf_lo); alloc = g->cbf_alloc; }
         else {
             BitFilter *f = bit_filter(g, which);
             RB_REQUIRE(f, "rb_filter_import: unknown filter %d", which);

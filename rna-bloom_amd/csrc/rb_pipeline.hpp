@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <new>
 #include <vector>
 
 #include "rb_internal.hpp"
@@ -20,6 +21,7 @@ struct BitFilter {
     size_t alloc = 0;
     int num_hash = 0;
     Mod mod{1, 0, 0};
+    int64_t lo = 0, hi = 0;   // index range held locally ([0,size) unless sharded)
 };
 
 // everything a kernel needs to address the filters (passed by value)
@@ -158,6 +160,80 @@ __device__ __forceinline__ void cbf_release(uint8_t *cbf, uint64_t idx) {
 constexpr uint32_t ST_CLAIMED = 1u << 9, ST_FOREIGN = 1u << 10;
 
 
+template <typename F> int guarded(F &&f) {
+    try { f(); return RB_OK; }
+    catch (const HipError &e) { return e.code; }
+    catch (const std::bad_alloc &) { set_error("host allocation failed"); return RB_ERR_NOMEM; }
+}
+void alloc_bits(BitFilter &f, int64_t bits, int num_hash, int64_t lo, int64_t hi);
+void free_bits(BitFilter &f);
+// one wavefront per high-multiplicity run: lanes fetch 64 occurrences at a time, compute each
+// one's random draw, and the increment chain hops from success to success with ballots
+static __global__ void __launch_bounds__(64) k_cbf_heavy(FilterView fv, const uint64_t *__restrict__ uniq,
+                            const uint32_t *__restrict__ counts, const uint32_t *__restrict__ starts,
+                            const uint32_t *__restrict__ vals, const uint32_t *__restrict__ status,
+                            const uint32_t *__restrict__ nops, const uint64_t *__restrict__ cvals,
+                            const uint8_t *__restrict__ tz, const uint32_t *__restrict__ heavy_list,
+                            const uint32_t *__restrict__ counters, uint64_t *__restrict__ cfinal) {
+    const uint32_t n_heavy = counters[0];
+    const uint32_t lane = threadIdx.x;
+    for (uint32_t hi = blockIdx.x; hi < n_heavy; hi += gridDim.x) {
+        const uint32_t d = heavy_list[hi];
+        const uint64_t h0 = uniq[d];
+        const uint32_t ops = nops[d];
+        const uint32_t st = status[d];
+        const uint64_t cv = cvals[d];
+        uint64_t idx[RB_MAX_HASH];
+        uint32_t c[RB_MAX_HASH];
+        for (int j = 0; j < fv.cbf_h; ++j) {
+            idx[j] = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod);
+            c[j] = (uint32_t)(cv >> (8 * j)) & 0xFFu;
+        }
+        const uint32_t base = starts[d] + counts[d] - ops;
+        const uint32_t krest = (st >> 14) & 3u;
+        uint32_t done = 0;
+        {   // the first op may have its own kind
+            uint32_t mn = c[0];
+            for (int j = 1; j < fv.cbf_h; ++j) mn = c[j] < mn ? c[j] : mn;
+            const uint32_t k0 = (st >> 12) & 3u;
+            const bool gate = !((k0 == K_INC_IF_POS && mn == 0u) || (k0 == K_INC_IF_ZERO && mn != 0u));
+            if (gate && mn < 127u && (mn < 16u || tz[base] >= (mn >> 3) - 1u))
+                for (int j = 0; j < fv.cbf_h; ++j) if (c[j] == mn) c[j] = mn + 1u;
+            done = 1;
+        }
+        while (done < ops) {
+            uint32_t mn = c[0];
+            for (int j = 1; j < fv.cbf_h; ++j) mn = c[j] < mn ? c[j] : mn;
+            if (mn >= 127u) break;                                   // saturated: nothing changes any more
+            if (krest == K_INC_IF_POS && mn == 0u) break;            // stays zero for ever
+            if (krest == K_INC_IF_ZERO && mn != 0u) break;           // stays positive for ever
+            if (mn < 16u) {                                          // deterministic region: one step
+                cbf_step(c, fv.cbf_h, krest, 0u);
+                ++done;
+                continue;
+            }
+            // probabilistic region: examine up to 64 pending occurrences at once
+            const uint32_t i = done + lane;
+            const uint32_t shift = (mn >> 3) - 1u;
+            bool ok = false;
+            if (i < ops) ok = tz[base + i] >= shift;
+            const unsigned long long win = __ballot(ok);
+            if (!win) { done += 64u; continue; }
+            const uint32_t first = (uint32_t)__ffsll((long long)win) - 1u;
+            cbf_step(c, fv.cbf_h, krest, 0u);                        // rnd 0 always succeeds
+            done += first + 1u;
+        }
+        if (lane == 0) {
+            if (cfinal) {                        // sharded engine: the counters live on other ranks
+                uint64_t out = 0;
+                for (int j = 0; j < fv.cbf_h; ++j) out |= (uint64_t)c[j] << (8 * j);
+                cfinal[d] = out;
+            } else
+                for (int j = 0; j < fv.cbf_h; ++j) fv.cbf[idx[j]] = (uint8_t)c[j];   // clears the claim mark too
+        }
+    }
+}
+
 inline uint32_t log2_ceil(uint64_t x) { uint32_t l = 0; while ((1ull << l) < x) ++l; return l; }
 
 }  // namespace rb
@@ -174,7 +250,8 @@ struct rb_graph {
     bool stranded = false;
     BitFilter dbg, rpk, fpk;
     uint8_t *cbf = nullptr;
-    int64_t cbf_size = 0;
+    int64_t cbf_size = 0;      // global number of counters
+    int64_t cbf_lo = 0, cbf_hi = 0;   // counters held locally ([0,cbf_size) unless sharded)
     size_t cbf_alloc = 0;
     Mod cbf_mod{1, 0, 0};
     int cbf_h = 0;
@@ -212,3 +289,12 @@ struct rb_graph {
     }
 };
 
+
+namespace rb {
+// sort + strengths + run-length encode of the N records in g->keys0/vals0 (rb_graph.hip)
+uint32_t group_records(rb_graph *g, size_t N, uint64_t ordinal0, uint32_t pos_bits, rb_add_stats *stats, uint32_t **ctr_out);
+// paired k-mer walker: inserts into g->rpk (out_idx == nullptr) or collects global bit indices
+void shard_free(rb_graph *g);   // rb_shard.hip
+void launch_pairs(rb_graph *g, const rb_batch *b, int64_t w0, int64_t nw, int mode_hash, const uint32_t *chunk_off,
+                  uint64_t *out_idx, unsigned long long *n_pairs_dev);
+}  // namespace rb

@@ -15,6 +15,9 @@ ADD_REVCOMP, ADD_COUNT_IF_PRESENT, ADD_STORE_READ_PAIRS = 1, 2, 4
 OP_ADD, OP_ADD_IF_ABSENT, OP_ADD_COUNT_IF_PRESENT, OP_ADD_DBG_ONLY, OP_ADD_COUNT_ONLY, \
     OP_ADD_READ_PAIR, OP_ADD_FRAG_PAIR = range(7)
 PROF_MAX = 32
+SLOT_REC_KEYS, SLOT_REC_OCC, SLOT_PAIR_IDX, SLOT_DREQ_IDX, SLOT_DREQ_PROBE, SLOT_CREQ_IDX, SLOT_W_IDX, SLOT_W_VAL, \
+    SLOT_CONF_OPS, SLOT_CONF_CTR = range(10)
+MODE_ADD, MODE_COUNT_IF_PRESENT = 0, 2
 
 
 class GraphParams(C.Structure):
@@ -77,6 +80,15 @@ SYMBOLS = [
     ("rb_filter_import", _i32, [_vp, _i32, _vp, _sz]),
     ("rb_expected_size", _i64, [_i64, C.c_float, _i32]),
     ("rb_nthash_batch", _i32, [_vp, _i32, _i32, _i64, _i64, C.POINTER(_i64), _vp, _vp, _vp]),
+    ("rb_graph_create_shard", _i32, [C.POINTER(GraphParams), _i32, _i32, C.POINTER(_vp)]),
+    ("rb_shard_hash", _i32, [_vp, _vp, _i64, _i64, _u32, _u32, C.c_uint, C.POINTER(_i64), C.POINTER(_i64)]),
+    ("rb_shard_group", _i32, [_vp, _vp, _vp, _i64, _u64, _u32, _i32, C.POINTER(_i64), C.POINTER(_i64)]),
+    ("rb_shard_serve", _i32, [_vp, _i32, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),
+    ("rb_shard_resolve", _i32, [_vp, _i32, _vp, _vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(AddStats)]),
+    ("rb_shard_apply_writes", _i32, [_vp, _vp, _vp, _i64]),
+    ("rb_shard_conflict_replay", _i32, [_vp, _vp, _i64, _vp, _i64]),
+    ("rb_shard_take", _i32, [_vp, _i32, _vp, _i64]),
+    ("rb_shard_span", _i32, [_vp, _i32, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     ("rb_graph_profile_enable", _i32, [_vp, _i32]),
     ("rb_graph_profile_get", _i32, [_vp, C.POINTER(Profile), _i32]),
 ]

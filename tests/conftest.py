@@ -11,6 +11,14 @@ for p in (ROOT, os.path.join(ROOT, "rna-bloom_amd"), os.path.join(ROOT, "tests")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # PyTorch bundles its own HIP runtime; it has to be the first one initialised in the process
+    # (rnabloom.sharded and bench.py use torch tensors as exchange buffers next to librb_hip.so).
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
+    except Exception:
+        pass
 
 
 @pytest.fixture(scope="session")
