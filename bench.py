@@ -8,9 +8,10 @@ generated on the device before the timed region and stay resident in HBM (packed
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--pairs P] [--genome G] [--nk NK]
 
-For N>1 launch through torch.distributed.run (one rank per GPU).  Multi-GPU mode shards the READS
-across ranks; every rank owns a full set of filters for its shard of the input (see DESIGN.md
-§Multi-GPU for what this round does and does not implement).
+For N>1 launch through torch.distributed.run (one rank per GPU): reads are data-parallel, every filter
+is sharded by index range and the k-mer space by hash prefix; records / probes / replies / counter
+writes travel by RCCL all_to_all (rnabloom/sharded.py, csrc/rb_shard.hip).  The job
+(total read pairs) is fixed, so scaling is "strong".
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -64,7 +65,7 @@ def parse():
     ap.add_argument("--batch-kmers", type=int, default=0)
     ap.add_argument("--cpu-sample-pairs", type=int, default=8_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--profile-stages", action="store_true", help="per-stage HIP-event timing inside the timed region")
+    ap.add_argument("--force-sharded", action="store_true", help="use the sharded engine + RCCL collectives even on 1 GPU")
     return ap.parse_args()
 
 
@@ -76,10 +77,12 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     torch.cuda.set_device(local)
+    sharded_mode = world > 1 or a.force_sharded
+    if sharded_mode:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
 
     from rnabloom import _native as N
     from rnabloom.graph import BloomFilterDeBruijnGraph, ReadBatch
@@ -93,19 +96,38 @@ def main():
     dist_pk = max(1, 150 - k - 10)              # R/RNABloom.java:1022 (minNumKmerPairs 10)
 
     batch = ReadBatch.synthetic(pairs_rank, a.genome, 150, 300, 30, a.err, 1e-4, 2.0, seed=0x5EED + rank, device=local)
-    g = BloomFilterDeBruijnGraph(dbg_bits, cbf_bytes, pk_bits, 2, 2, 2, k, False, True, device=local, rngSeed=1,
-                                 maxBatchKmers=a.batch_kmers)
-    g.setReadPairedKmerDistance(dist_pk)
+    if not sharded_mode:
+        g = BloomFilterDeBruijnGraph(dbg_bits, cbf_bytes, pk_bits, 2, 2, 2, k, False, True, device=local, rngSeed=1,
+                                     maxBatchKmers=a.batch_kmers)
+        g.setReadPairedKmerDistance(dist_pk)
 
-    def step():
-        g.clearAllBf()
-        s1 = g.addBatch(batch, storeReadPairedKmers=True, first=0, n=pairs_rank)
-        s2 = g.addBatch(batch, reverseComplement=True, storeReadPairedKmers=True, first=pairs_rank, n=pairs_rank)
-        return s1, s2
+        def step():
+            g.clearAllBf()
+            s1 = g.addBatch(batch, storeReadPairedKmers=True, first=0, n=pairs_rank)
+            s2 = g.addBatch(batch, reverseComplement=True, storeReadPairedKmers=True, first=pairs_rank, n=pairs_rank)
+            return s1, s2
+    else:
+        # filters sharded by index range over the ranks, k-mer space by hash prefix; reads are
+        # data-parallel; RCCL all_to_all / all_gather move records, probes, replies and writes
+        from types import SimpleNamespace
+        from rnabloom import sharded
+        sr = sharded.ShardRank((dbg_bits, cbf_bytes, pk_bits, 2, 2, 2, k, 0, 1, local, 0, 1, a.batch_kmers), rank, world, local)
+        sr.set_read_pair_distance(dist_pk)
+        pos_bits, rps = sharded.plan(150, k, world, a.batch_kmers or (1 << 30))
+        g = SimpleNamespace(profileEnable=lambda on: check_(sr, on), profileGet=lambda reset=True: prof_(sr, reset))
+
+        def step():
+            sr.clear()
+            out = []
+            for first, fl in ((0, N.ADD_STORE_READ_PAIRS), (pairs_rank, N.ADD_STORE_READ_PAIRS | N.ADD_REVCOMP)):
+                before = dict(sr.stats)
+                sharded.run_distributed(sr.add_range(batch, first, pairs_rank, fl, rps, pos_bits))
+                out.append(SimpleNamespace(**{kk: sr.stats[kk] - before[kk] for kk in before}))
+            return out
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if sharded_mode:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -124,7 +146,7 @@ def main():
         conflict += s1.conflict_ops + s2.conflict_ops
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if sharded_mode:
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
@@ -167,16 +189,29 @@ def main():
                        "pairs": pairs_total, "genome_bases": a.genome, "dbgbf_bits": dbg_bits, "cbf_bytes": cbf_bytes,
                        "rpkbf_bits": pk_bits, "kmers_per_step": kmers_all // a.steps,
                        "read_pairs_per_step": pairs_ins // a.steps, "distinct_per_step": distinct // a.steps,
-                       "conflict_ops_per_step": conflict // a.steps, "parallelism": "reads sharded x%d" % world},
+                       "conflict_ops_per_step": conflict // a.steps, "parallelism": ("single GPU" if not sharded_mode else "filters index-sharded x%d, k-mers hash-sharded, RCCL all_to_all" % world)},
             "stages_ms_per_step": {n: round(v[0] / a.steps, 2) for n, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
             "roofline": roof,
         }
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a, batch, dbg_bits, cbf_bytes, pk_bits, dist_pk)
         print(json.dumps(out))
-    if world > 1:
+    if sharded_mode:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def check_(sr, on):
+    from rnabloom import _native as N
+    N.check(N.lib.rb_graph_profile_enable(sr.h, int(on)))
+
+
+def prof_(sr, reset):
+    import ctypes as C
+    from rnabloom import _native as N
+    p = N.Profile()
+    N.check(N.lib.rb_graph_profile_get(sr.h, C.byref(p), int(reset)))
+    return {p.name[i].decode(): (p.ms[i], p.launches[i]) for i in range(p.n)}
 
 
 def cpu_baseline(a, batch, dbg_bits, cbf_bytes, pk_bits, dist_pk):

@@ -747,6 +747,7 @@ void run_pipeline(rb_graph *g, size_t N, int mode, uint64_t ordinal0, uint32_t p
 }
 
 void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigned flags, rb_add_stats *stats) {
+    RB_REQUIRE(!g->shard, "rb_graph_add_batch: this handle is one shard of a distributed graph; drive it with the rb_shard_* phases");
     RB_REQUIRE(b->device == g->p.device, "batch lives on device %d, graph on %d", b->device, g->p.device);
     RB_REQUIRE(first >= 0 && n >= 0 && first + n <= b->n_reads, "rb_graph_add_batch: bad read range");
     RB_HIP(hipSetDevice(g->p.device));
@@ -953,6 +954,7 @@ int rb_graph_apply(rb_graph *g, int op, const uint64_t *h0, size_t n) {
     return guarded([&] {
         RB_REQUIRE(g && (h0 || n == 0), "rb_graph_apply: null argument");
         RB_REQUIRE(op >= RB_OP_ADD && op <= RB_OP_ADD_FRAG_PAIR, "rb_graph_apply: unknown op %d", op);
+        RB_REQUIRE(!g->shard, "rb_graph_apply: not available on a shard handle");
         RB_HIP(hipSetDevice(g->p.device));
         hipStream_t s = g->stream;
         if (op == RB_OP_ADD_DBG_ONLY || op == RB_OP_ADD_READ_PAIR || op == RB_OP_ADD_FRAG_PAIR) {
@@ -989,6 +991,7 @@ int rb_filter_lookup(rb_graph *g, int which, const uint64_t *h0, size_t n, uint8
         RB_REQUIRE(g && (n == 0 || (h0 && out)), "rb_filter_lookup: null argument");
         BitFilter *f = bit_filter(g, which);
         RB_REQUIRE(f, "rb_filter_lookup: filter %d is not a bit filter", which);
+        RB_REQUIRE(!g->shard, "rb_filter_lookup: queries are not available on a shard handle");
         if (!f->bits) { set_error("rb_filter_lookup: filter %d not initialised", which); throw HipError{RB_ERR_STATE}; }
         if (!n) return;
         RB_HIP(hipSetDevice(g->p.device));
@@ -1006,6 +1009,7 @@ int rb_graph_contains(rb_graph *g, const uint64_t *h0, size_t n, uint8_t *out) {
 static int count_common(rb_graph *g, const uint64_t *h0, size_t n, float *out, bool graph_level) {
     return guarded([&] {
         RB_REQUIRE(g && (n == 0 || (h0 && out)), "rb_graph_count: null argument");
+        RB_REQUIRE(!g->shard, "rb_graph_count: queries are not available on a shard handle");
         if (!n) return;
         RB_HIP(hipSetDevice(g->p.device));
         uint64_t *d = upload_h0(g, g->qbuf0, h0, n);
@@ -1025,6 +1029,7 @@ int rb_graph_kmers(rb_graph *g, const char *seq, const int64_t *offsets, int64_t
                    uint64_t *f, uint64_t *r, float *count) {
     return guarded([&] {
         RB_REQUIRE(g && offsets && koffsets && n_reads >= 0, "rb_graph_kmers: null argument");
+        RB_REQUIRE(!g->shard, "rb_graph_kmers: queries are not available on a shard handle");
         koffsets[0] = 0;
         for (int64_t i = 0; i < n_reads; ++i) {
             int64_t l = offsets[i + 1] - offsets[i];
@@ -1057,6 +1062,7 @@ int rb_graph_neighbors(rb_graph *g, const uint64_t *f, const uint64_t *r, const 
         RB_REQUIRE(g && (n == 0 || (f && char_out && f4 && count4)), "rb_graph_neighbors: null argument");
         RB_REQUIRE(g->stranded || n == 0 || r, "rb_graph_neighbors: reverse hashes required for a canonical graph");
         RB_REQUIRE(direction == 0 || direction == 1, "rb_graph_neighbors: direction must be 0 or 1");
+        RB_REQUIRE(!g->shard, "rb_graph_neighbors: queries are not available on a shard handle");
         if (!n) return;
         RB_HIP(hipSetDevice(g->p.device));
         hipStream_t s = g->stream;

@@ -1,0 +1,83 @@
+"""world_size-2 gloo test (CPU) of the multi-rank exchange layer: run_distributed (torch.distributed
+all_to_all / all_gather, what runs over RCCL on the GPUs) must deliver exactly what run_loopback
+delivers — and run_loopback + the HIP phase functions are what tests/test_gpu_sharded.py proves
+bit-exact against the oracle."""
+import os
+import pickle
+import sys
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def toy(rank, G, log):
+    """A rank coroutine with the same yield protocol as ShardRank.substep, on CPU tensors."""
+    rng = np.random.default_rng(100 + rank)
+    n_all = yield ("ints", [5 + rank, rank * 7])
+    log.append(("ints", n_all))
+    for rnd in range(4):
+        counts = [int(c) for c in rng.integers(0, 50, G)]
+        if rnd == 2:
+            counts = [0] * G                                   # empty exchange
+        if rnd == 3:
+            counts[rank] = 0
+        send = torch.from_numpy(rng.integers(0, 256, sum(counts), dtype=np.uint8))
+        recv, rc = yield ("a2a", send, counts)
+        log.append(("a2a", recv.clone().numpy().tobytes(), list(rc)))
+        reply = (recv.to(torch.int16) * 3 % 251).to(torch.uint8)  # reply travels the reverse way
+        back, bc = yield ("a2a", reply, rc)
+        log.append(("back", back.clone().numpy().tobytes(), list(bc)))
+        assert bc == counts
+    g = torch.from_numpy(rng.integers(0, 256, 16 * rank, dtype=np.uint8))   # rank 0 contributes nothing
+    allg = yield ("gather", g)
+    log.append(("gather", allg.clone().numpy().tobytes()))
+    allg = yield ("gather", torch.zeros(0, dtype=torch.uint8))
+    log.append(("gather0", allg.clone().numpy().tobytes()))
+
+
+def _worker(rank, world, port, outdir):
+    sys.path.insert(0, os.path.join(ROOT, "rna-bloom_amd"))
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    from rnabloom.sharded import run_distributed
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    log = []
+    run_distributed(toy(rank, world, log))
+    dist.barrier()
+    dist.destroy_process_group()
+    with open(os.path.join(outdir, "r%d.pkl" % rank), "wb") as fh:
+        pickle.dump(log, fh)
+
+
+@pytest.mark.parametrize("world", [2])
+def test_run_distributed_equals_loopback(world):
+    from rnabloom.sharded import run_loopback
+    logs = [[] for _ in range(world)]
+    run_loopback([toy(r, world, logs[r]) for r in range(world)])
+    with tempfile.TemporaryDirectory() as d:
+        mp.spawn(_worker, args=(world, 29500 + os.getpid() % 400, d), nprocs=world, join=True)
+        for r in range(world):
+            with open(os.path.join(d, "r%d.pkl" % r), "rb") as fh:
+                got = pickle.load(fh)
+            assert len(got) == len(logs[r])
+            for a, b in zip(got, logs[r]):
+                assert a[0] == b[0]
+                if a[0] == "ints":
+                    assert [list(x) for x in a[1]] == [list(x) for x in b[1]]
+                else:
+                    assert a[1:] == b[1:], (r, a[0])
+
+
+def test_plan_limits():
+    from rnabloom.sharded import plan
+    pos_bits, reads = plan(150, 25, 8, 1 << 30)
+    assert (1 << pos_bits) > 150 and reads * 8 < (1 << (32 - pos_bits)) and reads * 150 * 8 <= (1 << 30)
+    pos_bits, reads = plan(100_000, 35, 2, 1 << 28)
+    assert (1 << pos_bits) > 100_000 and reads >= 1
