@@ -352,6 +352,11 @@ int rb_batch_create_ascii(int device, const char *seq, const char *qual, const i
         woff[(size_t)n_reads] = (uint32_t)words;
         b->n_words = (int64_t)words;
         b->max_len = max_len;
+        {   // uniform word count per read?
+            uint32_t wpr = n_reads ? (uint32_t)((len[0] + 31) / 32) : 0;
+            for (int64_t i = 0; i < n_reads && wpr; ++i) if ((len[(size_t)i] + 31) / 32 != wpr) wpr = 0;
+            b->wpr_uniform = wpr;
+        }
         const int64_t base0 = n_reads ? offsets[0] : 0;
         b->n_bases = n_reads ? offsets[n_reads] - base0 : 0;
         alloc_batch_arrays(b);
@@ -461,6 +466,7 @@ int rb_batch_create_synthetic(int device, const rb_synth_params *p, rb_batch **o
         b->n_words = b->n_reads * wpr;
         b->n_bases = b->n_reads * p->read_len;
         b->max_len = (uint32_t)p->read_len;
+        b->wpr_uniform = (uint32_t)((p->read_len + 31) / 32);
         alloc_batch_arrays(b);
         {   // woff / len are arithmetic progressions: fill from host in slabs
             const size_t slab = 1 << 22;

@@ -368,60 +368,55 @@ __global__ void __launch_bounds__(64) k_conf_replay_big(FilterView fv, const uin
 // ---- paired k-mers: {,Canonical,ReverseComplement}PairedNTHashIterator + rpkbf.add ----
 // (R/bloom/hash/PairedNTHashIterator.java:56-83, CanonicalPaired… :36-60, ReverseComplementPaired…
 //  :33-56; R/RNABloom.java:587-591).  Pure OR => order independent => direct atomicOr.
+// first unusable base at or after p (or L) — word-wise scan of the validity bits
+__device__ __forceinline__ uint32_t next_unusable(const uint32_t *__restrict__ vw, uint32_t p, uint32_t L) {
+    while (p < L) {
+        const uint32_t w = ~vw[p >> 5] >> (p & 31u);           // zero bits of the mask, shifted to bit 0
+        if (w) { const uint32_t q = p + (uint32_t)__ffs((int)w) - 1u; return q < L ? q : L; }
+        p = (p | 31u) + 1u;
+    }
+    return L;
+}
 template <int MODE>
 __global__ void k_pairs_insert(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
                                const uint32_t *__restrict__ word_read, const uint32_t *__restrict__ woff,
                                const uint32_t *__restrict__ len, int64_t w0, int64_t nw, int k, int dist,
                                uint32_t *bits, Mod mod, int num_hash, uint64_t kmul,
                                unsigned long long *__restrict__ n_pairs,
-                               const uint32_t *__restrict__ chunk_off, uint64_t *__restrict__ out_idx) {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= nw) return;
+                               const uint32_t *__restrict__ chunk_off, uint64_t *__restrict__ out_idx,
+                               uint32_t wpr_uniform) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nw) return;
+    // uniform-length batches: chunk-major order, so that all lanes of a wavefront work on the same
+    // chunk number (for 150 bp reads with d = 115 only chunk 0 of each read has paired k-mers)
+    int64_t i = t;
+    if (wpr_uniform) { const int64_t nreads = nw / wpr_uniform; i = (t % nreads) * wpr_uniform + t / nreads; }
     const int64_t w = w0 + i;
     const uint32_t r = word_read[w], wr = woff[r], L = len[r];
     const uint32_t b0 = (uint32_t)(w - wr) * 32u;
     const uint32_t uk = (uint32_t)k, ud = (uint32_t)dist, span = uk + ud;
     if ((uint64_t)b0 + span > L) return;
-    const uint64_t bend64 = (uint64_t)b0 + 32u + span - 1u;
-    const uint32_t bend = bend64 < L ? (uint32_t)bend64 : L;
+    const uint32_t pe = (b0 + 32u < L - span + 1u) ? b0 + 32u : L - span + 1u;   // pair starts handled here: [b0, pe)
     const uint64_t *cw = codes + wr;
     const uint32_t *vw = valid + wr;
-    uint64_t fR = 0, rR = 0, fL = 0, rL = 0;
-    uint32_t runR = 0, runL = 0, runall = 0, cnt = 0;
     auto code_at = [&](uint32_t b) { return (uint32_t)(cw[b >> 5] >> (2u * (b & 31u))) & 3u; };
-    auto valid_at = [&](uint32_t b) { return (vw[b >> 5] >> (b & 31u)) & 1u; };
-    for (uint32_t b = b0; b < bend; ++b) {
-        // right-hand window ends at base b
-        if (!valid_at(b)) { runR = 0; fR = 0; rR = 0; runall = 0; }
-        else {
-            const uint32_t code = code_at(b);
-            if (runR < uk) { fR = rotl(fR, 1) ^ seed_of(code); rR ^= rotl(seed_of(3u - code), runR); ++runR; }
-            else {
-                const uint32_t oc = code_at(b - uk);
-                fR = rotl(fR, 1) ^ rotl(seed_of(oc), uk) ^ seed_of(code);
-                rR = rotr(rR, 1) ^ rotr(seed_of(3u - oc), 1) ^ rotl(seed_of(3u - code), uk - 1u);
-            }
-            ++runall;
+    uint32_t cnt = 0, p = b0;
+    while (p < pe) {
+        const uint32_t nz = next_unusable(vw, p, L);
+        if (nz < p + span) { p = nz + 1u; continue; }          // no pair can start in [p, nz]
+        const uint32_t plast = (pe - 1u < nz - span) ? pe - 1u : nz - span;
+        // both windows from scratch (k steps), then roll: NTHash.java:332-337,367-373 / :491-495
+        uint64_t fL = 0, rL = 0, fR = 0, rR = 0;
+        for (uint32_t q = 0; q < uk; ++q) {
+            const uint32_t cl = code_at(p + q), cr = code_at(p + ud + q);
+            fL = rotl(fL, 1) ^ seed_of(cl); rL ^= rotl(seed_of(3u - cl), q);
+            fR = rotl(fR, 1) ^ seed_of(cr); rR ^= rotl(seed_of(3u - cr), q);
         }
-        // left-hand window ends at base b - dist
-        if (b >= b0 + ud) {
-            const uint32_t bl = b - ud;
-            if (!valid_at(bl)) { runL = 0; fL = 0; rL = 0; }
-            else {
-                const uint32_t code = code_at(bl);
-                if (runL < uk) { fL = rotl(fL, 1) ^ seed_of(code); rL ^= rotl(seed_of(3u - code), runL); ++runL; }
-                else {
-                    const uint32_t oc = code_at(bl - uk);
-                    fL = rotl(fL, 1) ^ rotl(seed_of(oc), uk) ^ seed_of(code);
-                    rL = rotr(rL, 1) ^ rotr(seed_of(3u - oc), 1) ^ rotl(seed_of(3u - code), uk - 1u);
-                }
-            }
-        }
-        if (runall >= span) {   // all bases of [p, p+dist+k) usable: both windows lie in one segment
+        for (;;) {
             uint64_t P;
-            if (MODE == 0) P = combine(fL, fR);
-            else if (MODE == 2) P = combine(rR, rL);
-            else P = smin(combine(fL, fR), combine(rR, rL));
+            if (MODE == 0) P = combine(fL, fR);                 // PairedNTHashIterator.java:69
+            else if (MODE == 2) P = combine(rR, rL);            // ReverseComplementPaired… :44
+            else P = smin(combine(fL, fR), combine(rR, rL));    // CanonicalPaired… :44 (signed min)
             if (out_idx) {   // sharded engine: collect global bit indices instead of setting local bits
                 for (int j = 0; j < num_hash; ++j)
                     out_idx[((size_t)chunk_off[i] + cnt) * (size_t)num_hash + j] = index_of(multi_hash(P, (uint32_t)j, kmul), mod);
@@ -429,9 +424,17 @@ __global__ void k_pairs_insert(const uint64_t *__restrict__ codes, const uint32_
                 for (int j = 0; j < num_hash; ++j) bit_set(bits, index_of(multi_hash(P, (uint32_t)j, kmul), mod));
             }
             ++cnt;
+            if (p == plast) break;
+            const uint32_t ol = code_at(p), il = code_at(p + uk), orr = code_at(p + ud), ir = code_at(p + ud + uk);
+            fL = rotl(fL, 1) ^ rotl(seed_of(ol), uk) ^ seed_of(il);
+            rL = rotr(rL, 1) ^ rotr(seed_of(3u - ol), 1) ^ rotl(seed_of(3u - il), uk - 1u);
+            fR = rotl(fR, 1) ^ rotl(seed_of(orr), uk) ^ seed_of(ir);
+            rR = rotr(rR, 1) ^ rotr(seed_of(3u - orr), 1) ^ rotl(seed_of(3u - ir), uk - 1u);
+            ++p;
         }
+        p = plast + 1u;
     }
-    if (cnt) atomicAdd(n_pairs, (unsigned long long)cnt);
+    if (cnt && n_pairs) atomicAdd(n_pairs, (unsigned long long)cnt);
 }
 
 // ---- direct (order-independent) bit-filter ops and queries on arrays of base hashes ----
@@ -576,7 +579,8 @@ void rb::launch_pairs(rb_graph *g, const rb_batch *b, int64_t w0, int64_t nw, in
     dim3 gr(blocks_for(nw)), th(TPB);
 #define RB_LAUNCH_PAIRS(M)                                                                                          \
     hipLaunchKernelGGL(k_pairs_insert<M>, gr, th, 0, g->stream, b->codes, b->valid, b->word_read, b->woff, b->len, w0, nw, \
-                       g->k, g->read_d, g->rpk.bits, g->rpk.mod, g->rpk.num_hash, kmul_of(g->k), pc, chunk_off, out_idx)
+                       g->k, g->read_d, g->rpk.bits, g->rpk.mod, g->rpk.num_hash, kmul_of(g->k), pc, chunk_off, out_idx,                   \
+                       (b->wpr_uniform && nw % b->wpr_uniform == 0) ? b->wpr_uniform : 0u)
     if (mode_hash == 0) RB_LAUNCH_PAIRS(0); else if (mode_hash == 2) RB_LAUNCH_PAIRS(2); else RB_LAUNCH_PAIRS(1);
 #undef RB_LAUNCH_PAIRS
 }
@@ -693,7 +697,7 @@ void run_pipeline(rb_graph *g, size_t N, int mode, uint64_t ordinal0, uint32_t p
     g->prof_end("resolve_apply");
     if (hc[0]) {
         g->prof_begin();
-        hipLaunchKernelGGL(k_cbf_heavy, dim3(std::min<uint32_t>(hc[0], 16384u)), dim3(64), 0, s, fv, uniq, counts, starts,
+        hipLaunchKernelGGL(k_cbf_heavy, dim3(std::min<uint32_t>(hc[0], 262144u)), dim3(64), 0, s, fv, uniq, counts, starts,
                            vals, status, nops, g->cvals.as<uint64_t>(), g->tz.as<uint8_t>(), g->heavy.as<uint32_t>(), ctr, (uint64_t *)nullptr);
         g->prof_end("cbf_heavy");
     }
@@ -738,7 +742,7 @@ void run_pipeline(rb_graph *g, size_t N, int mode, uint64_t ordinal0, uint32_t p
         RB_HIP(hipMemsetAsync(ctr + 4, 0, 4, s));
         hipLaunchKernelGGL(k_conf_replay_small, dim3(blocks_for(nck)), dim3(TPB), 0, s, fv, uniq, g->kk1.as<uint64_t>(), nck,
                            g->opk1.as<uint64_t>(), g->opv1.as<uint32_t>(), nco, g->biglist.as<uint32_t>(), ctr + 4);
-        hipLaunchKernelGGL(k_conf_replay_big, dim3(std::min<uint32_t>(nck, 4096u)), dim3(64), 0, s, fv, uniq, g->kk1.as<uint64_t>(), nck,
+        hipLaunchKernelGGL(k_conf_replay_big, dim3(std::min<uint32_t>(nck, 262144u)), dim3(64), 0, s, fv, uniq, g->kk1.as<uint64_t>(), nck,
                            g->opk1.as<uint64_t>(), g->opv1.as<uint32_t>(), nco, g->biglist.as<uint32_t>(), ctr + 4);
         g->prof_end("conflict_replay");
         if (stats) stats->conflict_ops += nco;

@@ -63,6 +63,7 @@ struct rb_batch {
     int device = 0;
     int64_t n_reads = 0, n_bases = 0, n_words = 0;
     uint32_t max_len = 0;
+    uint32_t wpr_uniform = 0;      // words per read when every read has the same word count, else 0
     uint64_t *codes = nullptr;     // [n_words]
     uint32_t *valid = nullptr;     // [n_words]
     uint32_t *word_read = nullptr; // [n_words] owning read of each word

@@ -141,6 +141,13 @@ def _split(t, counts):
     return out
 
 
+def _sync(t):
+    """torch ops and collectives are asynchronous on torch's stream; the library works on its own
+    (non-blocking) stream, so results must be complete before their pointers are handed over."""
+    if t is not None and t.is_cuda:
+        torch.cuda.synchronize(t.device)
+
+
 def run_loopback(gens):
     """Drive G coroutines (virtual ranks on one device) in lock step."""
     G = len(gens)
@@ -161,6 +168,7 @@ def run_loopback(gens):
             res = [cat] * G
         else:
             raise ValueError(kind)
+        _sync(reqs[0][1] if kind != "ints" else None)
         nxt, done = [], 0
         for g, r in zip(gens, res):
             try:
@@ -207,6 +215,7 @@ def run_distributed(gen, group=None):
                 res = torch.cat([o[:s] for o, s in zip(outs, sizes)]) if mx else t
             else:
                 raise ValueError(kind)
+            _sync(req[1] if kind != "ints" else None)
             req = gen.send(res)
     except StopIteration:
         return
