@@ -208,9 +208,22 @@ k_hash_windows(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ 
                const uint32_t *__restrict__ chunk_off, uint32_t first_read, uint32_t pos_bits,
                uint64_t *__restrict__ keys, uint32_t *__restrict__ vals, uint32_t *__restrict__ out_read,
                uint32_t *__restrict__ out_pos) {
-    __shared__ uint64_t s_key[HASH_SLAB];
-    __shared__ uint32_t s_val[HASH_SLAB];
-    __shared__ uint32_t s_pos[HASH_SLAB];
+    // threads write runs of ~32 records at a stride of ~32 records: without the +1-per-32 skew all
+    // lanes of a wavefront would hit the same LDS banks (64-way conflict on every ds_write)
+    __shared__ uint64_t s_key[HASH_SLAB + HASH_SLAB / 32 + 1];
+    __shared__ uint32_t s_val[HASH_SLAB + HASH_SLAB / 32 + 1];
+    __shared__ uint32_t s_pos[HASH_SLAB + HASH_SLAB / 32 + 1];
+    // roll tables: entry [out*4+in] holds everything a rolling step xors in besides the rotated hash
+    //   forward: rotl(seed(out),k) ^ seed(in)            (NTHash.java:584-586)
+    //   reverse: rotr(seedc(out),1) ^ rotl(seedc(in),k-1) (NTHash.java:491-495 / :627-629)
+    __shared__ uint64_t s_tf[16], s_tr[16];
+    const uint32_t uk = (uint32_t)k;
+    if (threadIdx.x < 16) {
+        const uint32_t oc = threadIdx.x >> 2, ic = threadIdx.x & 3u;
+        s_tf[threadIdx.x] = rotl(seed_of(oc), uk) ^ seed_of(ic);
+        s_tr[threadIdx.x] = rotr(seed_of(3u - oc), 1) ^ rotl(seed_of(3u - ic), uk - 1u);
+    }
+    __syncthreads();
     const int64_t blk0 = (int64_t)blockIdx.x * HASH_TPB;
     const int64_t i = blk0 + threadIdx.x;
     const int64_t blk_end = (blk0 + HASH_TPB < nw) ? blk0 + HASH_TPB : nw;
@@ -218,10 +231,9 @@ k_hash_windows(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ 
     if (O0 == O1) return;
     // per-thread walker state
     uint32_t r = 0, L = 0, b = 0, bend = 0, run = 0, cur_v = 0, out = 0;
-    uint64_t cur_c = 0, f = 0, rv = 0;
+    uint64_t cur_c = 0, f = 0, rv = 0, hist = 0;   // hist: 2-bit codes of the last 32 bases
     const uint64_t *cw = codes;
     const uint32_t *vw = valid;
-    const uint32_t uk = (uint32_t)k;
     if (i < nw) {
         const int64_t w = w0 + i;
         r = word_read[w];
@@ -237,6 +249,7 @@ k_hash_windows(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ 
         } else bend = b0;                       // no window starts in this chunk
         out = chunk_off[i];
     }
+    const bool short_k = uk <= 31u;             // the outgoing base is still in `hist`
     for (uint32_t slab0 = O0; slab0 < O1; slab0 += HASH_SLAB) {
         const uint32_t slab1 = (slab0 + HASH_SLAB < O1) ? slab0 + HASH_SLAB : O1;
         bool reload = true;                     // the walker may resume in the middle of a word
@@ -251,15 +264,17 @@ k_hash_windows(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ 
                 if (MODE != 0) rv ^= rotl(seed_of(3u - code), run);
                 ++run;
             } else {
-                const uint32_t bo = b - uk;
-                const uint32_t oc = (uint32_t)(cw[bo >> 5] >> (2u * (bo & 31u))) & 3u;
-                // rolling: NTHash.java:491-495 / :584-586 / :627-629
-                if (MODE != 2) f = rotl(f, 1) ^ rotl(seed_of(oc), uk) ^ seed_of(code);
-                if (MODE != 0) rv = rotr(rv, 1) ^ rotr(seed_of(3u - oc), 1) ^ rotl(seed_of(3u - code), uk - 1u);
+                uint32_t oc;
+                if (short_k) oc = (uint32_t)(hist >> (2u * (uk - 1u))) & 3u;
+                else { const uint32_t bo = b - uk; oc = (uint32_t)(cw[bo >> 5] >> (2u * (bo & 31u))) & 3u; }
+                const uint32_t t = oc * 4u + code;
+                if (MODE != 2) f = rotl(f, 1) ^ s_tf[t];
+                if (MODE != 0) rv = rotr(rv, 1) ^ s_tr[t];
             }
+            hist = (hist << 2) | code;
             if (run >= uk) {
                 const uint32_t p = b - uk + 1u;
-                const uint32_t o = out - slab0;
+                const uint32_t o0 = out - slab0, o = o0 + (o0 >> 5);
                 s_key[o] = (MODE == 0) ? f : (MODE == 2) ? rv : canonical(f, rv);
                 s_val[o] = out_read ? r : (((r - first_read) << pos_bits) | p);
                 if (out_read) s_pos[o] = p;
@@ -270,11 +285,12 @@ k_hash_windows(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ 
         __syncthreads();
         const uint32_t n = slab1 - slab0;
         for (uint32_t j = threadIdx.x; j < n; j += HASH_TPB) {
-            keys[slab0 + j] = s_key[j];
-            if (vals) vals[slab0 + j] = s_val[j];
+            const uint32_t q = j + (j >> 5);
+            keys[slab0 + j] = s_key[q];
+            if (vals) vals[slab0 + j] = s_val[q];
             if (out_read) {
-                out_read[slab0 + j] = s_val[j];
-                out_pos[slab0 + j] = s_pos[j];
+                out_read[slab0 + j] = s_val[q];
+                out_pos[slab0 + j] = s_pos[q];
             }
         }
         __syncthreads();

@@ -68,6 +68,8 @@ __global__ void k_probe(FilterView fv, const uint64_t *__restrict__ uniq, const 
         }
     }
     uint32_t st = premask | (all ? ST_ALLPRE : 0u);
+    uint32_t n_foreign = 0;
+    for (int j = 0; j < fv.cbf_h; ++j) foreign_idx[(size_t)d * fv.cbf_h + j] = ~0ull;
     // can this run have counting-Bloom ops?  (exact number is known in stage B)
     bool may_count = true;
     if (mode == M_COUNT_IF_PRESENT) may_count = all;
@@ -83,7 +85,8 @@ __global__ void k_probe(FilterView fv, const uint64_t *__restrict__ uniq, const 
                 byte = cbf_claim(fv.cbf, cidx[j]);
                 if (byte & CLAIM) {                     // somebody else of this sub-batch owns it too
                     st |= ST_FOREIGN;
-                    foreign_idx[atomicAdd(&counters[5], 1u)] = cidx[j];
+                    foreign_idx[(size_t)d * fv.cbf_h + j] = cidx[j];
+                    ++n_foreign;
                     byte &= 0x7Fu;
                 }
             }
@@ -93,10 +96,11 @@ __global__ void k_probe(FilterView fv, const uint64_t *__restrict__ uniq, const 
         st |= ST_CLAIMED;
     }
     status[d] = st;
+    if (n_foreign) atomicAdd(&counters[16 + 16 * (blockIdx.x & 31u)], n_foreign);   // 32 spread counters
 }
-__global__ void k_cs_build(const uint64_t *__restrict__ foreign_idx, uint32_t n, Slot *cs, uint32_t cs_log2) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) table_insert(cs, cs_log2, foreign_idx[i]);
+__global__ void k_cs_build(const uint64_t *__restrict__ foreign_idx, size_t n, Slot *cs, uint32_t cs_log2) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && foreign_idx[i] != ~0ull) table_insert(cs, cs_log2, foreign_idx[i]);
 }
 
 // ---- stage B: resolve the found-flag of the first occurrence, set Bloom bits, then apply the
@@ -106,9 +110,7 @@ __global__ void k_resolve_apply(FilterView fv, const uint64_t *__restrict__ uniq
                                 uint32_t n_distinct, int mode, uint32_t LIGHT_OPS, const Slot *ftable, uint32_t f_log2,
                                 const Slot *cs, uint32_t cs_log2, uint32_t n_foreign,
                                 uint32_t *__restrict__ status, uint32_t *__restrict__ nops,
-                                const uint64_t *__restrict__ cvals, const uint8_t *__restrict__ tz,
-                                uint32_t *__restrict__ heavy_list, uint32_t *__restrict__ conf_kmers,
-                                uint32_t *__restrict__ counters /* [0]=heavy n, [1]=conflict runs, [2]=conflict ops */) {
+                                const uint64_t *__restrict__ cvals, const uint8_t *__restrict__ tz) {
     uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= n_distinct) return;
     const uint64_t h0 = uniq[d];
@@ -156,12 +158,8 @@ __global__ void k_resolve_apply(FilterView fv, const uint64_t *__restrict__ uniq
         for (int j = 0; j < fv.cbf_h; ++j) cbf_release(fv.cbf, idx[j]);
         return;
     }
-    if (conflict) {
-        conf_kmers[atomicAdd(&counters[1], 1u)] = d;
-        atomicAdd(&counters[2], ops);
-        return;                                   // marks are dropped by k_conf_release before the replay
-    }
-    if (ops > LIGHT_OPS) { heavy_list[atomicAdd(&counters[0], 1u)] = d; return; }
+    if (conflict) { status[d] = st | RUN_CONFLICT; return; }   // marks are dropped by k_conf_release before the replay
+    if (ops > LIGHT_OPS) { status[d] = st | RUN_HEAVY; return; }
     uint32_t c[RB_MAX_HASH];
     const uint64_t cv = cvals[d];
     for (int j = 0; j < fv.cbf_h; ++j) c[j] = (uint32_t)(cv >> (8 * j)) & 0xFFu;
@@ -609,10 +607,10 @@ uint32_t rb::group_records(rb_graph *g, size_t N, uint64_t ordinal0, uint32_t po
     // runs of equal hash = distinct k-mers
     g->prof_begin();
     g->uniq.reserve(N * 8); g->counts.reserve((N + 1) * 4); g->starts.reserve((N + 1) * 4);
-    g->devctr.reserve(64);
+    g->devctr.reserve(DEVCTR_BYTES);
     uint32_t *ctr = g->devctr.as<uint32_t>();
     if (ctr_out) *ctr_out = ctr;
-    RB_HIP(hipMemsetAsync(ctr, 0, 64, s));
+    RB_HIP(hipMemsetAsync(ctr, 0, DEVCTR_BYTES, s));
     run_length_encode_u64(g->temp.p, g->temp.cap, g->keys1.as<uint64_t>(), N, g->uniq.as<uint64_t>(),
                           g->counts.as<uint32_t>(), ctr + 8, s);
     uint32_t D = 0;
@@ -675,26 +673,36 @@ void run_pipeline(rb_graph *g, size_t N, int mode, uint64_t ordinal0, uint32_t p
     hipLaunchKernelGGL(k_probe, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, uniq, counts, starts, vals, D, mode,
                        g->ftable.as<Slot>(), f_log2, status, g->cvals.as<uint64_t>(), g->foreign.as<uint64_t>(), ctr);
     uint32_t n_foreign = 0;
-    RB_HIP(hipMemcpyAsync(&n_foreign, ctr + 5, 4, hipMemcpyDeviceToHost, s));
-    RB_HIP(hipStreamSynchronize(s));
+    {
+        uint32_t spread[16 * 32];
+        RB_HIP(hipMemcpyAsync(spread, ctr + 16, sizeof spread, hipMemcpyDeviceToHost, s));
+        RB_HIP(hipStreamSynchronize(s));
+        for (int q = 0; q < 32; ++q) n_foreign += spread[16 * q];
+    }
     g->prof_end("probe_claim");
     if (n_foreign) {   // the set of counters claimed by more than one run
         g->prof_begin();
         c_log2 = log2_ceil(2ull * (uint64_t)n_foreign + 2);
         g->ctable.reserve(sizeof(Slot) << c_log2);
         RB_HIP(hipMemsetAsync(g->ctable.p, 0xFF, sizeof(Slot) << c_log2, s));
-        hipLaunchKernelGGL(k_cs_build, dim3(blocks_for(n_foreign)), dim3(TPB), 0, s, g->foreign.as<uint64_t>(), n_foreign,
+        const size_t nfe = (size_t)D * (size_t)g->cbf_h;
+        hipLaunchKernelGGL(k_cs_build, dim3(blocks_for((int64_t)nfe)), dim3(TPB), 0, s, g->foreign.as<uint64_t>(), nfe,
                            g->ctable.as<Slot>(), c_log2);
         g->prof_end("conflict_set");
     }
     g->prof_begin();
     hipLaunchKernelGGL(k_resolve_apply, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, uniq, counts, starts, vals, D, mode, g->light_ops,
                        g->ftable.as<Slot>(), f_log2, g->ctable.as<Slot>(), c_log2, n_foreign, status, nops,
-                       g->cvals.as<uint64_t>(), g->tz.as<uint8_t>(), g->heavy.as<uint32_t>(), g->confk.as<uint32_t>(), ctr);
-    uint32_t hc[3] = {0, 0, 0};
-    RB_HIP(hipMemcpyAsync(hc, ctr, 12, hipMemcpyDeviceToHost, s));
-    RB_HIP(hipStreamSynchronize(s));
+                       g->cvals.as<uint64_t>(), g->tz.as<uint8_t>());
     g->prof_end("resolve_apply");
+    g->prof_begin();
+    g->temp.reserve(select_temp_bytes(D));
+    select_flagged(g->temp.p, g->temp.cap, status, RUN_HEAVY, D, g->heavy.as<uint32_t>(), ctr + 0, s);
+    select_flagged(g->temp.p, g->temp.cap, status, RUN_CONFLICT, D, g->confk.as<uint32_t>(), ctr + 1, s);
+    uint32_t hc[2] = {0, 0};
+    RB_HIP(hipMemcpyAsync(hc, ctr, 8, hipMemcpyDeviceToHost, s));
+    RB_HIP(hipStreamSynchronize(s));
+    g->prof_end("compact_lists");
     if (hc[0]) {
         g->prof_begin();
         hipLaunchKernelGGL(k_cbf_heavy, dim3(std::min<uint32_t>(hc[0], 262144u)), dim3(64), 0, s, fv, uniq, counts, starts,
@@ -702,9 +710,15 @@ void run_pipeline(rb_graph *g, size_t N, int mode, uint64_t ordinal0, uint32_t p
         g->prof_end("cbf_heavy");
     }
     if (hc[1]) {
-        const uint32_t nck = hc[1], nco = hc[2];
+        const uint32_t nck = hc[1];
         g->prof_begin();
         g->conf_sizes.reserve(((size_t)nck + 1) * 4); g->conf_off.reserve(((size_t)nck + 1) * 4);
+        hipLaunchKernelGGL(k_conf_offsets, dim3(blocks_for(nck + 1)), dim3(TPB), 0, s, g->confk.as<uint32_t>(), nops, nck, g->conf_sizes.as<uint32_t>());
+        g->temp.reserve(scan_temp_bytes((size_t)nck + 1));
+        exclusive_scan_u32(g->temp.p, g->temp.cap, g->conf_sizes.as<uint32_t>(), g->conf_off.as<uint32_t>(), (size_t)nck + 1, s);
+        uint32_t nco = 0;
+        RB_HIP(hipMemcpyAsync(&nco, g->conf_off.as<uint32_t>() + nck, 4, hipMemcpyDeviceToHost, s));
+        RB_HIP(hipStreamSynchronize(s));
         g->opk0.reserve((size_t)nco * 8); g->opk1.reserve((size_t)nco * 8);
         g->opv0.reserve((size_t)nco * 4); g->opv1.reserve((size_t)nco * 4);
         g->label.reserve((size_t)D * 4); g->kk0.reserve((size_t)nck * 8); g->kk1.reserve((size_t)nck * 8);
@@ -729,9 +743,7 @@ void run_pipeline(rb_graph *g, size_t N, int mode, uint64_t ordinal0, uint32_t p
         g->prof_end("conflict_components");
         g->prof_begin();
         hipLaunchKernelGGL(k_conf_kmer_keys, dim3(blocks_for(nck)), dim3(TPB), 0, s, confk, label, nck, g->kk0.as<uint64_t>());
-        hipLaunchKernelGGL(k_conf_offsets, dim3(blocks_for(nck + 1)), dim3(TPB), 0, s, confk, nops, nck, g->conf_sizes.as<uint32_t>());
-        g->temp.reserve(std::max({scan_temp_bytes((size_t)nck + 1), sort_pairs_temp_bytes(nco), sort_keys_temp_bytes(nck)}));
-        exclusive_scan_u32(g->temp.p, g->temp.cap, g->conf_sizes.as<uint32_t>(), g->conf_off.as<uint32_t>(), (size_t)nck + 1, s);
+        g->temp.reserve(std::max(sort_pairs_temp_bytes(nco), sort_keys_temp_bytes(nck)));
         hipLaunchKernelGGL(k_conf_expand, dim3(blocks_for((int64_t)nck * 64)), dim3(TPB), 0, s, confk, g->conf_off.as<uint32_t>(),
                            counts, starts, vals, status, nops, label, nck, g->opk0.as<uint64_t>(), g->opv0.as<uint32_t>());
         sort_keys_u64(g->temp.p, g->temp.cap, g->kk0.as<uint64_t>(), g->kk1.as<uint64_t>(), nck, 0, 64, s);
@@ -797,7 +809,7 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
             }
             if (pairs) {
                 g->prof_begin();
-                g->devctr.reserve(64);
+                g->devctr.reserve(DEVCTR_BYTES);
                 unsigned long long *pc = reinterpret_cast<unsigned long long *>(g->devctr.as<uint32_t>() + 12);
                 RB_HIP(hipMemsetAsync(pc, 0, 8, s));
                 launch_pairs(g, b, w0, nw, mode_hash, nullptr, nullptr, pc);
@@ -1107,7 +1119,7 @@ int rb_filter_popcount(rb_graph *g, int which, int64_t *out) {
     return guarded([&] {
         RB_REQUIRE(g && out, "rb_filter_popcount: null argument");
         RB_HIP(hipSetDevice(g->p.device));
-        g->devctr.reserve(64);
+        g->devctr.reserve(DEVCTR_BYTES);
         unsigned long long *acc = reinterpret_cast<unsigned long long *>(g->devctr.as<uint32_t>() + 14);
         RB_HIP(hipMemsetAsync(acc, 0, 8, g->stream));
         if (which == RB_CBF) {

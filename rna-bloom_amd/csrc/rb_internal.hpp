@@ -90,6 +90,10 @@ void sort_keys_u64(void *temp, size_t temp_bytes, uint64_t *keys_in, uint64_t *k
 size_t scan_temp_bytes(size_t n);
 void exclusive_scan_u32(void *temp, size_t temp_bytes, const uint32_t *in, uint32_t *out, size_t n,
                         hipStream_t s);
+// indices i in [0,n) with (status[i] & mask) != 0, in order; count written to *count_dev
+size_t select_temp_bytes(size_t n);
+void select_flagged(void *temp, size_t temp_bytes, const uint32_t *status, uint32_t mask, size_t n, uint32_t *out,
+                    uint32_t *count_dev, hipStream_t s);
 size_t rle_temp_bytes(size_t n);
 void run_length_encode_u64(void *temp, size_t temp_bytes, const uint64_t *keys, size_t n,
                            uint64_t *uniq, uint32_t *counts, uint32_t *n_runs_dev, hipStream_t s);

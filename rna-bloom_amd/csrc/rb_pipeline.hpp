@@ -13,6 +13,7 @@
 namespace rb {
 
 constexpr int TPB = 256;
+constexpr size_t DEVCTR_BYTES = 4096;   // small device-side counter block per graph
 inline unsigned blocks_for(int64_t n, int tpb = TPB) { return (unsigned)((n + tpb - 1) / tpb); }
 
 struct BitFilter {
@@ -158,6 +159,9 @@ __device__ __forceinline__ void cbf_release(uint8_t *cbf, uint64_t idx) {
 // status word per distinct run: bits 0..7 premask, bit 8 all_pre, bit 9 claimed counters,
 // bit 10 saw a foreign claim, bits 12..13 kind of first op, 14..15 kind of the other ops
 constexpr uint32_t ST_CLAIMED = 1u << 9, ST_FOREIGN = 1u << 10;
+// outcome of the resolve stage (lists are built from these flags by stream compaction: a single
+// shared atomic cursor saturates at ~88 M increments/s and would dominate the stage)
+constexpr uint32_t RUN_CONFLICT = 1u << 17, RUN_RELEASE = 1u << 18, RUN_WRITES = 1u << 19, RUN_HEAVY = 1u << 20;
 
 
 template <typename F> int guarded(F &&f) {

@@ -134,7 +134,6 @@ __global__ void k_make_requests(FilterView fv, const uint64_t *__restrict__ uniq
     }
 }
 
-constexpr uint32_t RUN_CONFLICT = 1u << 17, RUN_RELEASE = 1u << 18, RUN_WRITES = 1u << 19;
 __global__ void k_resolve_shard(FilterView fv, const uint32_t *__restrict__ counts, const uint32_t *__restrict__ starts,
                                 uint32_t D, int mode, uint32_t light_ops, const uint32_t *__restrict__ dreq_pos,
                                 const uint8_t *__restrict__ dreply, const uint32_t *__restrict__ creq_pos,
@@ -497,7 +496,7 @@ int rb_shard_hash(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, uint
             const size_t np = (size_t)P * (size_t)g->rpk.num_hash;
             if (np) {
                 S->stage0.reserve(np * 8);
-                g->devctr.reserve(64);
+                g->devctr.reserve(DEVCTR_BYTES);
                 unsigned long long *pc = reinterpret_cast<unsigned long long *>(g->devctr.as<uint32_t>() + 12);
                 RB_HIP(hipMemsetAsync(pc, 0, 8, s));
                 launch_pairs(g, b, w0, nw, mode_hash, g->chunk_off.as<uint32_t>(), S->stage0.as<uint64_t>(), pc);
@@ -581,7 +580,7 @@ int rb_shard_serve(rb_graph *g, int mode, const void *dreq_idx_dev, const void *
         }
         if (nc) {
             S->own_foreign.reserve((size_t)nc * 8);
-            g->devctr.reserve(64);
+            g->devctr.reserve(DEVCTR_BYTES);
             uint32_t *ctr = g->devctr.as<uint32_t>();
             RB_HIP(hipMemsetAsync(ctr, 0, 64, s));
             hipLaunchKernelGGL(k_own_claim, dim3(blocks_for(nc)), dim3(TPB), 0, s, g->cbf, (uint64_t)g->cbf_lo, (const uint64_t *)creq_idx_dev,
@@ -622,7 +621,7 @@ int rb_shard_resolve(rb_graph *g, int mode, const void *dreply_dev, const void *
         FilterView fv = g->view(S->ordinal0, S->pos_bits);
         g->status.reserve((size_t)D * 4); g->nops.reserve((size_t)D * 4); g->cvals.reserve((size_t)D * 8);
         g->heavy.reserve((size_t)D * 4); S->conf_list.reserve((size_t)D * 4); S->cfinal.reserve((size_t)D * 8);
-        g->devctr.reserve(64);
+        g->devctr.reserve(DEVCTR_BYTES);
         uint32_t *ctr = g->devctr.as<uint32_t>();
         RB_HIP(hipMemsetAsync(ctr, 0, 64, s));
         hipLaunchKernelGGL(k_resolve_shard, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, g->counts.as<uint32_t>(), g->starts.as<uint32_t>(), D, mode,
@@ -699,7 +698,7 @@ int rb_shard_conflict_replay(rb_graph *g, const void *ops_dev, int64_t n_ops, co
         hipLaunchKernelGGL(k_split_ctr, dim3(blocks_for((int64_t)nc)), dim3(TPB), 0, s, (const ConfCtr *)ctr_dev, nc, S->ck0.as<uint64_t>(), S->cv0.as<uint64_t>());
         g->temp.reserve(std::max({sort_pairs32_temp_bytes(nc), rle_temp_bytes(nc), scan_temp_bytes(nc + 1), sort_pairs_temp_bytes((size_t)n_ops + 1)}));
         sort_pairs_u64_u64(g->temp.p, g->temp.cap, S->ck0.as<uint64_t>(), S->ck1.as<uint64_t>(), S->cv0.as<uint64_t>(), S->cv1.as<uint64_t>(), nc, 0, 64, s);
-        g->devctr.reserve(64);
+        g->devctr.reserve(DEVCTR_BYTES);
         uint32_t *ctr = g->devctr.as<uint32_t>();
         RB_HIP(hipMemsetAsync(ctr, 0, 64, s));
         run_length_encode_u64(g->temp.p, g->temp.cap, S->ck1.as<uint64_t>(), nc, S->cuniq.as<uint64_t>(), S->ccnt.as<uint32_t>(), ctr + 8, s);

@@ -58,6 +58,22 @@ void exclusive_scan_u32(void *temp, size_t temp_bytes, const uint32_t *in, uint3
                         hipStream_t s) {
     RB_HIP(rocprim::exclusive_scan(temp, temp_bytes, in, out, 0u, n, rocprim::plus<uint32_t>(), s));
 }
+struct MaskFlag {
+    uint32_t mask;
+    __host__ __device__ bool operator()(uint32_t st) const { return (st & mask) != 0u; }
+};
+size_t select_temp_bytes(size_t n) {
+    size_t bytes = 0;
+    auto flags = rocprim::make_transform_iterator((const uint32_t *)nullptr, MaskFlag{1u});
+    RB_HIP(rocprim::select(nullptr, bytes, rocprim::counting_iterator<uint32_t>(0), flags, (uint32_t *)nullptr,
+                           (uint32_t *)nullptr, n));
+    return bytes;
+}
+void select_flagged(void *temp, size_t temp_bytes, const uint32_t *status, uint32_t mask, size_t n, uint32_t *out,
+                    uint32_t *count_dev, hipStream_t s) {
+    auto flags = rocprim::make_transform_iterator(status, MaskFlag{mask});
+    RB_HIP(rocprim::select(temp, temp_bytes, rocprim::counting_iterator<uint32_t>(0), flags, out, count_dev, n, s));
+}
 size_t rle_temp_bytes(size_t n) {
     size_t bytes = 0;
     RB_HIP(rocprim::run_length_encode(nullptr, bytes, (const uint64_t *)nullptr, n,
