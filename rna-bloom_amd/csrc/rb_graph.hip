@@ -288,33 +288,57 @@ __global__ void k_conf_replay_small(FilterView fv, const uint64_t *__restrict__ 
 __global__ void __launch_bounds__(64) k_conf_replay_big(FilterView fv, const uint64_t *__restrict__ uniq,
                                     const uint64_t *__restrict__ kmer_keys, uint32_t n_conf,
                                     const uint64_t *__restrict__ op_key, const uint32_t *__restrict__ op_val, uint32_t n_ops,
-                                    const uint32_t *__restrict__ big_list, const uint32_t *__restrict__ n_big) {
+                                    const uint32_t *__restrict__ big_list, const uint32_t *__restrict__ n_big,
+                                    uint32_t *__restrict__ dbg) {
     __shared__ uint64_t s_idx[MAX_COMPONENT_KMERS * RB_MAX_HASH];   // unique counter indices
     __shared__ uint32_t s_val[MAX_COMPONENT_KMERS * RB_MAX_HASH];   // their current bytes
     __shared__ uint32_t s_val0[MAX_COMPONENT_KMERS * RB_MAX_HASH];
     __shared__ uint32_t s_slot[MAX_COMPONENT_KMERS][RB_MAX_HASH];   // k-mer probe -> unique counter
-    __shared__ uint32_t s_d[MAX_COMPONENT_KMERS];
-    __shared__ uint32_t s_nu;
+    __shared__ uint64_t s_h0[MAX_COMPONENT_KMERS];
+    __shared__ uint32_t s_nu, s_nk;
     const uint32_t lane = threadIdx.x;
     const int H = fv.cbf_h;
     for (uint32_t bi = blockIdx.x; bi < *n_big; bi += gridDim.x) {
         const uint32_t i0 = big_list[bi];
         const uint32_t lab = (uint32_t)(kmer_keys[i0] >> 32);
-        uint32_t nk = 1;
-        while (i0 + nk < n_conf && (uint32_t)(kmer_keys[i0 + nk] >> 32) == lab && nk <= MAX_COMPONENT_KMERS) ++nk;
+        const uint32_t i1 = lower_bound_u64(kmer_keys, n_conf, ((uint64_t)lab + 1ull) << 32);   // runs [i0,i1)
         const uint32_t os = lower_bound_u64(op_key, n_ops, (uint64_t)lab << 32);
         const uint32_t oe = lower_bound_u64(op_key, n_ops, ((uint64_t)lab + 1ull) << 32);
-        if (nk > MAX_COMPONENT_KMERS) {          // rare: very large component -> plain ordered replay
+        // distinct hashes of the component (a hash split into many runs is still one k-mer)
+        __syncthreads();
+        if (lane == 0) s_nk = 0;
+        __syncthreads();
+        bool overflow = false;
+        for (uint32_t rb0 = i0; rb0 < i1 && !overflow; rb0 += 64u) {
+            const bool have = rb0 + lane < i1;
+            const uint64_t h = have ? uniq[(uint32_t)kmer_keys[rb0 + lane]] : 0ull;
+            unsigned long long pending = __ballot(have);
+            while (pending) {
+                const int leader = __ffsll((long long)pending) - 1;
+                const uint64_t hl = __shfl(h, leader, 64);
+                pending &= ~__ballot(have && h == hl);
+                uint32_t q = 0, nkc = s_nk;
+                while (q < nkc && s_h0[q] != hl) ++q;
+                if (q == nkc) {
+                    if (nkc == MAX_COMPONENT_KMERS) { overflow = true; break; }
+                    __syncthreads();
+                    if (lane == 0) { s_h0[nkc] = hl; s_nk = nkc + 1u; }
+                    __syncthreads();
+                }
+            }
+        }
+        if (dbg && lane == 0) { atomicMax(&dbg[1], oe - os); atomicMax(&dbg[2], i1 - i0); atomicAdd(&dbg[3], oe - os); }
+        if (overflow) {                          // rare: many DIFFERENT k-mers in one component -> plain ordered replay
+            if (dbg && lane == 0) { atomicAdd(&dbg[0], 1u); atomicAdd(&dbg[4], oe - os); }
             if (lane == 0) replay_serial(fv, uniq, op_key, op_val, os, oe);
             continue;
         }
+        const uint32_t nk = s_nk;
         __syncthreads();
         if (lane == 0) {                         // build the component's counter table (tiny)
             uint32_t nu = 0;
             for (uint32_t q = 0; q < nk; ++q) {
-                const uint32_t d = (uint32_t)kmer_keys[i0 + q];
-                s_d[q] = d;
-                const uint64_t h0 = uniq[d];
+                const uint64_t h0 = s_h0[q];
                 for (int j = 0; j < H; ++j) {
                     const uint64_t idx = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod);
                     uint32_t u = 0;
@@ -331,9 +355,10 @@ __global__ void __launch_bounds__(64) k_conf_replay_big(FilterView fv, const uin
             uint32_t q = 0, kind = 0, rnd = 0;
             const bool live = i < oe;
             if (live) {
-                const uint32_t ov = op_val[i], d = ov & 0x3FFFFFFFu;
+                const uint32_t ov = op_val[i];
+                const uint64_t h = uniq[ov & 0x3FFFFFFFu];
                 kind = ov >> 30;
-                while (q < nk && s_d[q] != d) ++q;
+                while (q < nk && s_h0[q] != h) ++q;
                 rnd = occ_rnd(fv, (uint32_t)op_key[i]);
             }
             uint32_t cursor = 0;                 // ops below cursor are settled
@@ -755,8 +780,16 @@ void run_pipeline(rb_graph *g, size_t N, int mode, uint64_t ordinal0, uint32_t p
         hipLaunchKernelGGL(k_conf_replay_small, dim3(blocks_for(nck)), dim3(TPB), 0, s, fv, uniq, g->kk1.as<uint64_t>(), nck,
                            g->opk1.as<uint64_t>(), g->opv1.as<uint32_t>(), nco, g->biglist.as<uint32_t>(), ctr + 4);
         hipLaunchKernelGGL(k_conf_replay_big, dim3(std::min<uint32_t>(nck, 262144u)), dim3(64), 0, s, fv, uniq, g->kk1.as<uint64_t>(), nck,
-                           g->opk1.as<uint64_t>(), g->opv1.as<uint32_t>(), nco, g->biglist.as<uint32_t>(), ctr + 4);
+                           g->opk1.as<uint64_t>(), g->opv1.as<uint32_t>(), nco, g->biglist.as<uint32_t>(), ctr + 4,
+                           getenv("RB_DEBUG") ? ctr + 600 : (uint32_t *)nullptr);
         g->prof_end("conflict_replay");
+        if (getenv("RB_DEBUG")) {
+            uint32_t nb = 0;
+            RB_HIP(hipMemcpy(&nb, ctr + 4, 4, hipMemcpyDeviceToHost));
+            uint32_t dv[5];
+            RB_HIP(hipMemcpy(dv, ctr + 600, 20, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[rb] N=%zu D=%u heavy=%u conflict_runs=%u conflict_ops=%u big_components=%u n_foreign=%u | big: serial_fallback=%u (ops %u) max_ops=%u max_runs=%u ops_in_big=%u\n", N, D, hc[0], nck, nco, nb, n_foreign, dv[0], dv[4], dv[1], dv[2], dv[3]);
+        }
         if (stats) stats->conflict_ops += nco;
     }
     RB_HIP(hipGetLastError());

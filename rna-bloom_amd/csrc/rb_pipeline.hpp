@@ -216,16 +216,24 @@ static __global__ void __launch_bounds__(64) k_cbf_heavy(FilterView fv, const ui
                 ++done;
                 continue;
             }
-            // probabilistic region: examine up to 64 pending occurrences at once
-            const uint32_t i = done + lane;
+            // probabilistic region: every lane examines 8 pending occurrences (one 8-byte load)
             const uint32_t shift = (mn >> 3) - 1u;
-            bool ok = false;
-            if (i < ops) ok = tz[base + i] >= shift;
-            const unsigned long long win = __ballot(ok);
-            if (!win) { done += 64u; continue; }
-            const uint32_t first = (uint32_t)__ffsll((long long)win) - 1u;
+            const uint32_t pos = base + done, end = base + ops;
+            const uint32_t a0 = pos & ~7u;                               // aligned start of the 512-byte window
+            const uint32_t mine = a0 + 8u * lane;
+            uint32_t hit = 0xFFFFFFFFu;                                  // absolute index of my first success
+            if (mine < end) {
+                uint64_t w = *reinterpret_cast<const uint64_t *>(tz + mine);
+                uint64_t m = (w + (uint64_t)(0x80u - shift) * 0x0101010101010101ull) & 0x8080808080808080ull;
+                if (mine < pos) m &= ~0ull << (8u * (pos - mine));        // bytes before the cursor
+                if (m) { uint32_t q = mine + ((uint32_t)__ffsll((long long)m) - 1u) / 8u; if (q < end) hit = q; }
+            }
+            const unsigned long long win = __ballot(hit != 0xFFFFFFFFu);
+            if (!win) { done = (a0 + 512u) - base; continue; }
+            const uint32_t first_lane = (uint32_t)__ffsll((long long)win) - 1u;
+            const uint32_t q = __shfl(hit, (int)first_lane, 64);
             cbf_step(c, fv.cbf_h, krest, 0u);                        // rnd 0 always succeeds
-            done += first + 1u;
+            done = q - base + 1u;
         }
         if (lane == 0) {
             if (cfinal) {                        // sharded engine: the counters live on other ranks
