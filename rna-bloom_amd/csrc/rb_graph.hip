@@ -595,57 +595,67 @@ __global__ void k_iota(uint32_t *v, size_t n) {
 
 }  // namespace
 
-// Stable grouping of N (h0, occ) records sitting in keys0/vals0: sort on the top hash bits,
-// draw strengths, run-length encode.  Leaves keys1/vals1 (sorted), tz, uniq/counts/starts.
 void rb::launch_pairs(rb_graph *g, const rb_batch *b, int64_t w0, int64_t nw, int mode_hash, const uint32_t *chunk_off,
-                      uint64_t *out_idx, unsigned long long *pc) {
+                      uint64_t *out_idx, unsigned long long *pc, hipStream_t st) {
+    if (!st) st = g->stream;
     dim3 gr(blocks_for(nw)), th(TPB);
 #define RB_LAUNCH_PAIRS(M)                                                                                          \
-    hipLaunchKernelGGL(k_pairs_insert<M>, gr, th, 0, g->stream, b->codes, b->valid, b->word_read, b->woff, b->len, w0, nw, \
-                       g->k, g->read_d, g->rpk.bits, g->rpk.mod, g->rpk.num_hash, kmul_of(g->k), pc, chunk_off, out_idx,                   \
+    hipLaunchKernelGGL(k_pairs_insert<M>, gr, th, 0, st, b->codes, b->valid, b->word_read, b->woff, b->len, w0, nw, \
+                       g->k, g->read_d, g->rpk.bits, g->rpk.mod, g->rpk.num_hash, kmul_of(g->k), pc, chunk_off, out_idx, \
                        (b->wpr_uniform && nw % b->wpr_uniform == 0) ? b->wpr_uniform : 0u)
     if (mode_hash == 0) RB_LAUNCH_PAIRS(0); else if (mode_hash == 2) RB_LAUNCH_PAIRS(2); else RB_LAUNCH_PAIRS(1);
 #undef RB_LAUNCH_PAIRS
 }
 
-uint32_t rb::group_records(rb_graph *g, size_t N, uint64_t ordinal0, uint32_t pos_bits, rb_add_stats *stats,
-                           uint32_t **ctr_out) {
-    hipStream_t s = g->stream;
-    // 2. stable sort by base hash
-    g->prof_begin();
-    size_t tb = sort_pairs_temp_bytes(N);
-    g->temp.reserve(std::max({tb, rle_temp_bytes(N), scan_temp_bytes(N + 1)}));
-    g->keys1.reserve(N * 8); g->vals1.reserve(N * 4);
+// Stable grouping of N (h0, occ) records sitting in keys0/vals0 into slot `slot`: sort on the top hash
+// bits, draw strengths, run-length encode.  Asynchronous on `st`; group_finish reads the run count.
+void rb::group_enqueue(rb_graph *g, int slot, size_t N, uint64_t ordinal0, uint32_t pos_bits, hipStream_t st, DevBuf &temp,
+                       DevBuf &ctrbuf) {
+    rb_graph::GroupSlot &S = g->slots[slot];
+    S.N = N; S.D = 0;
+    ctrbuf.reserve(DEVCTR_BYTES);
+    uint32_t *ctr = ctrbuf.as<uint32_t>();
+    RB_HIP(hipMemsetAsync(ctr, 0, DEVCTR_BYTES, st));
+    if (N == 0) return;
+    g->prof_begin(st);
+    temp.reserve(std::max({sort_pairs_temp_bytes(N), rle_temp_bytes(N), scan_temp_bytes(N + 1)}));
+    S.keys1.reserve(N * 8); S.vals1.reserve(N * 4);
     // Grouping, not ordering, is what the later stages need: a STABLE sort on the top 32 hash bits
     // puts equal hashes next to each other except where two different hashes share the prefix; such
     // a hash then simply shows up as several runs, which the pipeline treats as separate k-mers
     // that share all their bits/counters — the first-setter arbitration and the ordered conflict
     // replay already make that case exact (DESIGN.md §Pipeline "split runs").
-    sort_pairs_u64_u32(g->temp.p, g->temp.cap, g->keys0.as<uint64_t>(), g->keys1.as<uint64_t>(),
-                       g->vals0.as<uint32_t>(), g->vals1.as<uint32_t>(), N, g->sort_begin_bit, 64, s);
-    g->prof_end("sort_occurrences");
-    g->prof_begin();
-    g->tz.reserve(N + 16);
-    hipLaunchKernelGGL(k_strength, dim3(blocks_for((int64_t)N)), dim3(TPB), 0, s, g->view(ordinal0, pos_bits),
-                       g->vals1.as<uint32_t>(), N, g->tz.as<uint8_t>());
-    g->prof_end("strengths");
-    // runs of equal hash = distinct k-mers
-    g->prof_begin();
-    g->uniq.reserve(N * 8); g->counts.reserve((N + 1) * 4); g->starts.reserve((N + 1) * 4);
-    g->devctr.reserve(DEVCTR_BYTES);
-    uint32_t *ctr = g->devctr.as<uint32_t>();
-    if (ctr_out) *ctr_out = ctr;
-    RB_HIP(hipMemsetAsync(ctr, 0, DEVCTR_BYTES, s));
-    run_length_encode_u64(g->temp.p, g->temp.cap, g->keys1.as<uint64_t>(), N, g->uniq.as<uint64_t>(),
-                          g->counts.as<uint32_t>(), ctr + 8, s);
+    sort_pairs_u64_u32(temp.p, temp.cap, g->keys0.as<uint64_t>(), S.keys1.as<uint64_t>(), g->vals0.as<uint32_t>(),
+                       S.vals1.as<uint32_t>(), N, g->sort_begin_bit, 64, st);
+    g->prof_end("sort_occurrences", st);
+    g->prof_begin(st);
+    S.tz.reserve(N + 16);
+    hipLaunchKernelGGL(k_strength, dim3(blocks_for((int64_t)N)), dim3(TPB), 0, st, g->view(ordinal0, pos_bits), S.vals1.as<uint32_t>(),
+                       N, S.tz.as<uint8_t>());
+    g->prof_end("strengths", st);
+    g->prof_begin(st);   // runs of equal hash = distinct k-mers
+    S.uniq.reserve(N * 8); S.counts.reserve((N + 1) * 4); S.starts.reserve((N + 1) * 4);
+    run_length_encode_u64(temp.p, temp.cap, S.keys1.as<uint64_t>(), N, S.uniq.as<uint64_t>(), S.counts.as<uint32_t>(), ctr + 8, st);
+    g->prof_end("distinct_runs", st);
+}
+uint32_t rb::group_finish(rb_graph *g, int slot, hipStream_t st, DevBuf &temp, DevBuf &ctrbuf, hipStream_t scan_stream) {
+    rb_graph::GroupSlot &S = g->slots[slot];
+    if (S.N == 0) { RB_HIP(hipStreamSynchronize(st)); return 0; }
     uint32_t D = 0;
-    RB_HIP(hipMemcpyAsync(&D, ctr + 8, 4, hipMemcpyDeviceToHost, s));
-    RB_HIP(hipStreamSynchronize(s));
-    exclusive_scan_u32(g->temp.p, g->temp.cap, g->counts.as<uint32_t>(), g->starts.as<uint32_t>(), D, s);
-    g->prof_end("distinct_runs");
-    if (stats) stats->distinct += D;
+    RB_HIP(hipMemcpyAsync(&D, ctrbuf.as<uint32_t>() + 8, 4, hipMemcpyDeviceToHost, st));
+    RB_HIP(hipStreamSynchronize(st));
     RB_REQUIRE(D < (1u << 30), "sub-batch has too many distinct k-mers (%u)", D);
-
+    S.D = D;
+    // run start offsets, on the consumer's stream with the consumer's temporary storage
+    temp.reserve(scan_temp_bytes((size_t)D + 1));
+    exclusive_scan_u32(temp.p, temp.cap, S.counts.as<uint32_t>(), S.starts.as<uint32_t>(), D, scan_stream);
+    return D;
+}
+uint32_t rb::group_records(rb_graph *g, size_t N, uint64_t ordinal0, uint32_t pos_bits, rb_add_stats *stats, uint32_t **ctr_out) {
+    group_enqueue(g, g->cur, N, ordinal0, pos_bits, g->stream, g->temp, g->devctr);
+    const uint32_t D = group_finish(g, g->cur, g->stream, g->temp, g->devctr, g->stream);
+    if (ctr_out) *ctr_out = g->devctr.as<uint32_t>();
+    if (stats) stats->distinct += D;
     return D;
 }
 
@@ -673,14 +683,22 @@ BitFilter *bit_filter(rb_graph *g, int which) {
 }
 
 // The order-exact pipeline over N (h0, occurrence) records already sitting in keys0/vals0.
+void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, uint32_t pos_bits, rb_add_stats *stats);
 void run_pipeline(rb_graph *g, size_t N, int mode, uint64_t ordinal0, uint32_t pos_bits, rb_add_stats *stats) {
-    hipStream_t s = g->stream;
     if (N == 0) return;
-    uint32_t *ctr = nullptr;
-    const uint32_t D = group_records(g, N, ordinal0, pos_bits, stats, &ctr);
+    const uint32_t D = group_records(g, N, ordinal0, pos_bits, stats, nullptr);
+    run_core(g, N, D, mode, ordinal0, pos_bits, stats);
+}
+// stages A/B + heavy + conflict path on the grouped sub-batch in slot g->cur (consumer stream)
+void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, uint32_t pos_bits, rb_add_stats *stats) {
+    hipStream_t s = g->stream;
+    if (N == 0 || D == 0) return;
+    g->devctr.reserve(DEVCTR_BYTES);
+    uint32_t *ctr = g->devctr.as<uint32_t>();
+    RB_HIP(hipMemsetAsync(ctr, 0, DEVCTR_BYTES, s));
     FilterView fv = g->view(ordinal0, pos_bits);
-    const uint64_t *uniq = g->uniq.as<uint64_t>();
-    const uint32_t *counts = g->counts.as<uint32_t>(), *starts = g->starts.as<uint32_t>(), *vals = g->vals1.as<uint32_t>();
+    const uint64_t *uniq = g->uniq().as<uint64_t>();
+    const uint32_t *counts = g->counts().as<uint32_t>(), *starts = g->starts().as<uint32_t>(), *vals = g->vals1().as<uint32_t>();
     g->status.reserve((size_t)D * 4); g->nops.reserve((size_t)D * 4); g->cvals.reserve((size_t)D * 8);
     g->heavy.reserve((size_t)D * 4); g->confk.reserve((size_t)D * 4);
     g->foreign.reserve((size_t)D * 8 * (size_t)g->cbf_h);
@@ -718,7 +736,7 @@ void run_pipeline(rb_graph *g, size_t N, int mode, uint64_t ordinal0, uint32_t p
     g->prof_begin();
     hipLaunchKernelGGL(k_resolve_apply, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, uniq, counts, starts, vals, D, mode, g->light_ops,
                        g->ftable.as<Slot>(), f_log2, g->ctable.as<Slot>(), c_log2, n_foreign, status, nops,
-                       g->cvals.as<uint64_t>(), g->tz.as<uint8_t>());
+                       g->cvals.as<uint64_t>(), g->tz().as<uint8_t>());
     g->prof_end("resolve_apply");
     g->prof_begin();
     g->temp.reserve(select_temp_bytes(D));
@@ -731,7 +749,7 @@ void run_pipeline(rb_graph *g, size_t N, int mode, uint64_t ordinal0, uint32_t p
     if (hc[0]) {
         g->prof_begin();
         hipLaunchKernelGGL(k_cbf_heavy, dim3(std::min<uint32_t>(hc[0], 262144u)), dim3(64), 0, s, fv, uniq, counts, starts,
-                           vals, status, nops, g->cvals.as<uint64_t>(), g->tz.as<uint8_t>(), g->heavy.as<uint32_t>(), ctr, (uint64_t *)nullptr);
+                           vals, status, nops, g->cvals.as<uint64_t>(), g->tz().as<uint8_t>(), g->heavy.as<uint32_t>(), ctr, (uint64_t *)nullptr);
         g->prof_end("cbf_heavy");
     }
     if (hc[1]) {
@@ -810,55 +828,76 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
     const int64_t max_reads = (int64_t)1 << (32 - pos_bits);
     const int64_t max_words = std::max<int64_t>(g->max_batch_kmers / 32, 1);
     const std::vector<uint32_t> &wo = b->h_woff;
-    int64_t r0 = first;
-    const int64_t rend = first + n;
-    while (r0 < rend) {
-        // largest r1 with words(r0..r1) <= max_words and r1-r0 <= max_reads (at least one read)
-        int64_t hi = std::min(rend, r0 + max_reads);
-        int64_t lo = r0 + 1;
-        while (lo < hi) {
-            int64_t mid = (lo + hi + 1) >> 1;
-            if ((int64_t)wo[(size_t)mid] - (int64_t)wo[(size_t)r0] <= max_words) lo = mid; else hi = mid - 1;
-        }
-        const int64_t r1 = lo;
-        const int64_t w0 = wo[(size_t)r0], nw = (int64_t)wo[(size_t)r1] - w0;
-        uint32_t N = 0;
-        if (nw > 0) {
-            g->prof_begin();
-            g->chunk_cnt.reserve(((size_t)nw + 1) * 4); g->chunk_off.reserve(((size_t)nw + 1) * 4);
-            RB_HIP(hipMemsetAsync(g->chunk_cnt.as<uint32_t>() + nw, 0, 4, s));
-            launch_count_windows(b, w0, nw, g->k, g->chunk_cnt.as<uint32_t>(), s);
-            g->temp.reserve(scan_temp_bytes((size_t)nw + 1));
-            exclusive_scan_u32(g->temp.p, g->temp.cap, g->chunk_cnt.as<uint32_t>(), g->chunk_off.as<uint32_t>(), (size_t)nw + 1, s);
-            RB_HIP(hipMemcpyAsync(&N, g->chunk_off.as<uint32_t>() + nw, 4, hipMemcpyDeviceToHost, s));
-            RB_HIP(hipStreamSynchronize(s));
-            g->prof_end("count_windows");
-            if (N) {
-                g->prof_begin();
-                g->keys0.reserve((size_t)N * 8); g->vals0.reserve((size_t)N * 4);
-                launch_hash_windows(b, w0, nw, g->k, mode_hash, g->chunk_off.as<uint32_t>(), (uint32_t)r0, pos_bits,
-                                    g->keys0.as<uint64_t>(), g->vals0.as<uint32_t>(), nullptr, nullptr, s);
-                g->prof_end("hash_windows");
+    // plan the sub-batches
+    struct Sub { int64_t r0, r1, w0, nw; uint32_t N; };
+    std::vector<Sub> subs;
+    {
+        int64_t r0 = first;
+        const int64_t rend = first + n;
+        while (r0 < rend) {
+            // largest r1 with words(r0..r1) <= max_words and r1-r0 <= max_reads (at least one read)
+            int64_t hi = std::min(rend, r0 + max_reads);
+            int64_t lo = r0 + 1;
+            while (lo < hi) {
+                int64_t mid = (lo + hi + 1) >> 1;
+                if ((int64_t)wo[(size_t)mid] - (int64_t)wo[(size_t)r0] <= max_words) lo = mid; else hi = mid - 1;
             }
-            if (pairs) {
-                g->prof_begin();
-                g->devctr.reserve(DEVCTR_BYTES);
-                unsigned long long *pc = reinterpret_cast<unsigned long long *>(g->devctr.as<uint32_t>() + 12);
-                RB_HIP(hipMemsetAsync(pc, 0, 8, s));
-                launch_pairs(g, b, w0, nw, mode_hash, nullptr, nullptr, pc);
-                unsigned long long np = 0;
-                RB_HIP(hipMemcpyAsync(&np, pc, 8, hipMemcpyDeviceToHost, s));
-                RB_HIP(hipStreamSynchronize(s));
-                g->prof_end("pairs_insert");
-                if (stats) stats->pairs += (int64_t)np;
+            subs.push_back({r0, lo, (int64_t)wo[(size_t)r0], (int64_t)wo[(size_t)lo] - (int64_t)wo[(size_t)r0], 0u});
+            r0 = lo;
+        }
+    }
+    hipStream_t sp = g->stream2;
+    unsigned long long *pc = nullptr;
+    // producer: hash + group sub-batch i into slot i&1 on the producer stream (touches scratch and,
+    // for the order-independent paired k-mers, rpkbf only)
+    auto prepare = [&](size_t i) {
+        Sub &sb = subs[i];
+        sb.N = 0;
+        const int slot = (int)(i & 1u);
+        g->devctr2.reserve(DEVCTR_BYTES);
+        if (sb.nw > 0) {
+            g->prof_begin(sp);
+            g->chunk_cnt.reserve(((size_t)sb.nw + 1) * 4); g->chunk_off.reserve(((size_t)sb.nw + 1) * 4);
+            RB_HIP(hipMemsetAsync(g->chunk_cnt.as<uint32_t>() + sb.nw, 0, 4, sp));
+            launch_count_windows(b, sb.w0, sb.nw, g->k, g->chunk_cnt.as<uint32_t>(), sp);
+            g->temp2.reserve(scan_temp_bytes((size_t)sb.nw + 1));
+            exclusive_scan_u32(g->temp2.p, g->temp2.cap, g->chunk_cnt.as<uint32_t>(), g->chunk_off.as<uint32_t>(), (size_t)sb.nw + 1, sp);
+            RB_HIP(hipMemcpyAsync(&sb.N, g->chunk_off.as<uint32_t>() + sb.nw, 4, hipMemcpyDeviceToHost, sp));
+            g->prof_end("count_windows", sp);
+            RB_HIP(hipStreamSynchronize(sp));
+            if (sb.N) {
+                g->prof_begin(sp);
+                g->keys0.reserve((size_t)sb.N * 8); g->vals0.reserve((size_t)sb.N * 4);
+                launch_hash_windows(b, sb.w0, sb.nw, g->k, mode_hash, g->chunk_off.as<uint32_t>(), (uint32_t)sb.r0, pos_bits,
+                                    g->keys0.as<uint64_t>(), g->vals0.as<uint32_t>(), nullptr, nullptr, sp);
+                g->prof_end("hash_windows", sp);
             }
         }
-        run_pipeline(g, N, mode, g->ordinal + (uint64_t)(r0 - first), pos_bits, stats);
-        if (stats) { stats->kmers += N; stats->reads += r1 - r0; }
-        r0 = r1;
+        group_enqueue(g, slot, sb.N, g->ordinal + (uint64_t)(sb.r0 - first), pos_bits, sp, g->temp2, g->devctr2);
+        if (pairs && sb.nw > 0) {   // after group_enqueue: it zeroes the producer's counter block
+            g->prof_begin(sp);
+            pc = reinterpret_cast<unsigned long long *>(g->devctr2.as<uint32_t>() + 12);
+            launch_pairs(g, b, sb.w0, sb.nw, mode_hash, nullptr, nullptr, pc, sp);
+            g->prof_end("pairs_insert", sp);
+        }
+    };
+    if (!subs.empty()) prepare(0);
+    for (size_t i = 0; i < subs.size(); ++i) {
+        const int slot = (int)(i & 1u);
+        unsigned long long np = 0;
+        if (pairs && subs[i].nw > 0) RB_HIP(hipMemcpyAsync(&np, reinterpret_cast<unsigned long long *>(g->devctr2.as<uint32_t>() + 12), 8, hipMemcpyDeviceToHost, sp));
+        const uint32_t D = group_finish(g, slot, sp, g->temp, g->devctr2, s);   // drains the producer stream
+        if (stats) { stats->pairs += (int64_t)np; stats->distinct += D; }
+        if (i + 1 < subs.size()) prepare(i + 1);      // overlaps with the filter stages below
+        g->cur = slot;
+        run_core(g, subs[i].N, D, mode, g->ordinal + (uint64_t)(subs[i].r0 - first), pos_bits, stats);
+        RB_HIP(hipStreamSynchronize(s));               // slot may be refilled after this
+        if (stats) { stats->kmers += subs[i].N; stats->reads += subs[i].r1 - subs[i].r0; }
     }
     g->ordinal += (uint64_t)n;
     RB_HIP(hipStreamSynchronize(s));
+    RB_HIP(hipStreamSynchronize(sp));
+    g->prof_collect();
 }
 
 // upload n base hashes into a scratch buffer
@@ -903,6 +942,13 @@ int rb_graph_create(const rb_graph_params *p, rb_graph **out) {
         if (const char *e = getenv("RB_SORT_BEGIN_BIT")) g->sort_begin_bit = std::max(0, std::min(63, atoi(e)));
         RB_REQUIRE(g->max_batch_kmers <= ((int64_t)1 << 31), "rb_graph_create: max_batch_kmers above 2^31");
         RB_HIP(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+        {   // the producer (hash + sort of the next sub-batch) is the critical path: give it priority
+            int lo_p = 0, hi_p = 0;
+            RB_HIP(hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
+            int pr = hi_p;
+            if (const char *e = getenv("RB_PRODUCER_PRIORITY")) pr = atoi(e);
+            RB_HIP(hipStreamCreateWithPriority(&g->stream2, hipStreamNonBlocking, pr));
+        }
         RB_HIP(hipEventCreate(&g->ev0));
         RB_HIP(hipEventCreate(&g->ev1));
         alloc_bits(g->dbg, p->dbgbf_bits, p->dbgbf_num_hash, 0, p->dbgbf_bits);
@@ -924,17 +970,22 @@ int rb_graph_destroy(rb_graph *g) {
     if (!g) return RB_OK;
     (void)hipSetDevice(g->p.device);
     if (g->stream) (void)hipStreamSynchronize(g->stream);
+    if (g->stream2) (void)hipStreamSynchronize(g->stream2);
     rb::shard_free(g);
     free_bits(g->dbg); free_bits(g->rpk); free_bits(g->fpk);
     if (g->cbf) (void)hipFree(g->cbf);
-    DevBuf *bufs[] = {&g->chunk_cnt, &g->chunk_off, &g->keys0, &g->keys1, &g->vals0, &g->vals1, &g->uniq, &g->counts,
-                      &g->starts, &g->status, &g->nops, &g->temp, &g->ftable, &g->ctable, &g->heavy, &g->confk,
-                      &g->conf_sizes, &g->conf_off, &g->opk0, &g->opk1, &g->opv0, &g->opv1, &g->label, &g->kk0, &g->kk1, &g->biglist, &g->cvals, &g->foreign, &g->tz, &g->devctr, &g->qbuf0,
+    DevBuf *bufs[] = {&g->chunk_cnt, &g->chunk_off, &g->keys0,  &g->vals0,   
+                       &g->status, &g->nops, &g->temp, &g->ftable, &g->ctable, &g->heavy, &g->confk,
+                      &g->conf_sizes, &g->conf_off, &g->opk0, &g->opk1, &g->opv0, &g->opv1, &g->label, &g->kk0, &g->kk1, &g->biglist, &g->cvals, &g->foreign,  &g->devctr, &g->qbuf0,
                       &g->qbuf1, &g->qbuf2, &g->qbuf3};
     for (auto *b : bufs) b->release();
     if (g->ev0) (void)hipEventDestroy(g->ev0);
     if (g->ev1) (void)hipEventDestroy(g->ev1);
     if (g->stream) (void)hipStreamDestroy(g->stream);
+    if (g->stream2) (void)hipStreamDestroy(g->stream2);
+    for (auto e : g->prof_pool) (void)hipEventDestroy(e);
+    for (auto &sl : g->slots) { sl.keys1.release(); sl.vals1.release(); sl.tz.release(); sl.uniq.release(); sl.counts.release(); sl.starts.release(); }
+    g->temp2.release(); g->devctr2.release();
     delete g;
     return RB_OK;
 }
@@ -1239,6 +1290,7 @@ int rb_graph_profile_enable(rb_graph *g, int on) {
 }
 int rb_graph_profile_get(rb_graph *g, rb_profile *out, int reset) {
     if (!g || !out) { set_error("null argument"); return RB_ERR_INVALID; }
+    g->prof_collect();
     out->n = 0;
     for (auto &e : g->prof) {
         if (out->n >= RB_PROF_MAX) break;

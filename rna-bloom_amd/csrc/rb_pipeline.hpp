@@ -272,15 +272,36 @@ struct rb_graph {
     int64_t max_batch_kmers = 0;
     int sort_begin_bit = 32;
     uint32_t light_ops = 96;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;    // consumer stream: everything that touches the filters
+    hipStream_t stream2 = nullptr;   // producer stream: hashing + grouping of the NEXT sub-batch (scratch only)
+    // grouped sub-batch, double buffered so that grouping of sub-batch i+1 overlaps the filter stages of i
+    struct GroupSlot { DevBuf keys1, vals1, tz, uniq, counts, starts; size_t N = 0; uint32_t D = 0; };
+    GroupSlot slots[2];
+    int cur = 0;
+    DevBuf &keys1() { return slots[cur].keys1; }
+    DevBuf &vals1() { return slots[cur].vals1; }
+    DevBuf &tz() { return slots[cur].tz; }
+    DevBuf &uniq() { return slots[cur].uniq; }
+    DevBuf &counts() { return slots[cur].counts; }
+    DevBuf &starts() { return slots[cur].starts; }
+    DevBuf temp2, devctr2;
     // scratch (grow-only)
-    DevBuf chunk_cnt, chunk_off, keys0, keys1, vals0, vals1, uniq, counts, starts, status, nops, temp,
-        ftable, ctable, heavy, confk, conf_sizes, conf_off, opk0, opk1, opv0, opv1, label, kk0, kk1, biglist, cvals, foreign, tz, devctr, qbuf0, qbuf1, qbuf2, qbuf3;
-    // profiling
+    DevBuf chunk_cnt, chunk_off, keys0, vals0, status, nops, temp,
+        ftable, ctable, heavy, confk, conf_sizes, conf_off, opk0, opk1, opv0, opv1, label, kk0, kk1, biglist, cvals, foreign, devctr, qbuf0, qbuf1, qbuf2, qbuf3;
+    // profiling: HIP events recorded on the stream a stage runs on; resolved lazily (no host sync
+    // inside the pipeline, so the two streams keep overlapping while timing is on)
     bool prof_on = false;
     struct ProfEntry { const char *name; double ms; int64_t launches; };
     std::vector<ProfEntry> prof;
+    struct ProfPending { const char *name; hipEvent_t e0, e1; };
+    std::vector<ProfPending> prof_pending;
+    std::vector<hipEvent_t> prof_pool;
+    hipEvent_t prof_open[2] = {nullptr, nullptr};
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t prof_event() {
+        if (!prof_pool.empty()) { hipEvent_t e = prof_pool.back(); prof_pool.pop_back(); return e; }
+        hipEvent_t e; RB_HIP(hipEventCreate(&e)); return e;
+    }
 
     FilterView view(uint64_t ordinal0, uint32_t pos_bits) const {
         FilterView fv;
@@ -289,15 +310,32 @@ struct rb_graph {
         fv.kmul = kmul_of(k); fv.seed = p.rng_seed; fv.ordinal0 = ordinal0; fv.pos_bits = pos_bits;
         return fv;
     }
-    void prof_begin() { if (prof_on) RB_HIP(hipEventRecord(ev0, stream)); }
-    void prof_end(const char *name) {
+    void prof_begin(hipStream_t st = nullptr) {
         if (!prof_on) return;
-        RB_HIP(hipEventRecord(ev1, stream));
-        RB_HIP(hipEventSynchronize(ev1));
-        float ms = 0;
-        RB_HIP(hipEventElapsedTime(&ms, ev0, ev1));
-        for (auto &e : prof) if (!strcmp(e.name, name)) { e.ms += ms; e.launches++; return; }
-        prof.push_back({name, ms, 1});
+        const int w = (st && st == stream2) ? 1 : 0;
+        prof_open[w] = prof_event();
+        RB_HIP(hipEventRecord(prof_open[w], w ? stream2 : stream));
+    }
+    void prof_end(const char *name, hipStream_t st = nullptr) {
+        if (!prof_on) return;
+        const int w = (st && st == stream2) ? 1 : 0;
+        if (!prof_open[w]) return;
+        hipEvent_t e1 = prof_event();
+        RB_HIP(hipEventRecord(e1, w ? stream2 : stream));
+        prof_pending.push_back({name, prof_open[w], e1});
+        prof_open[w] = nullptr;
+    }
+    void prof_collect() {   // call with both streams idle
+        for (auto &pp : prof_pending) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, pp.e0, pp.e1) == hipSuccess) {
+                bool found = false;
+                for (auto &e : prof) if (!strcmp(e.name, pp.name)) { e.ms += ms; e.launches++; found = true; break; }
+                if (!found) prof.push_back({pp.name, ms, 1});
+            }
+            prof_pool.push_back(pp.e0); prof_pool.push_back(pp.e1);
+        }
+        prof_pending.clear();
     }
 };
 
@@ -305,8 +343,11 @@ struct rb_graph {
 namespace rb {
 // sort + strengths + run-length encode of the N records in g->keys0/vals0 (rb_graph.hip)
 uint32_t group_records(rb_graph *g, size_t N, uint64_t ordinal0, uint32_t pos_bits, rb_add_stats *stats, uint32_t **ctr_out);
+// asynchronous halves of group_records: enqueue on `st` into slot `slot`; finish reads the run count
+void group_enqueue(rb_graph *g, int slot, size_t N, uint64_t ordinal0, uint32_t pos_bits, hipStream_t st, DevBuf &temp, DevBuf &ctrbuf);
+uint32_t group_finish(rb_graph *g, int slot, hipStream_t st, DevBuf &temp, DevBuf &ctrbuf, hipStream_t scan_stream);
 // paired k-mer walker: inserts into g->rpk (out_idx == nullptr) or collects global bit indices
 void shard_free(rb_graph *g);   // rb_shard.hip
 void launch_pairs(rb_graph *g, const rb_batch *b, int64_t w0, int64_t nw, int mode_hash, const uint32_t *chunk_off,
-                  uint64_t *out_idx, unsigned long long *n_pairs_dev);
+                  uint64_t *out_idx, unsigned long long *n_pairs_dev, hipStream_t st = nullptr);
 }  // namespace rb

@@ -390,6 +390,7 @@ int rb_graph_create_shard(const rb_graph_params *p, int shard_rank, int shard_co
         ShardState *S = g->shard = new ShardState();
         S->G = shard_count; S->log2G = (int)log2_ceil((uint64_t)shard_count);
         RB_HIP(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+        RB_HIP(hipStreamCreateWithFlags(&g->stream2, hipStreamNonBlocking));
         RB_HIP(hipEventCreate(&g->ev0));
         RB_HIP(hipEventCreate(&g->ev1));
         Geometry gd = geom(p->dbgbf_bits, shard_rank, shard_count);
@@ -534,8 +535,8 @@ int rb_shard_group(rb_graph *g, const void *keys_dev, const void *occ_dev, int64
         cidx.reserve(nc * 8);
         S->creq_dup.reserve(nc + 16);
         uint8_t *d_drop = S->stage2.as<uint8_t>(), *c_drop = d_drop + nd;
-        hipLaunchKernelGGL(k_make_requests, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, g->uniq.as<uint64_t>(), g->starts.as<uint32_t>(),
-                           g->vals1.as<uint32_t>(), D, mode, S->stage0.as<uint64_t>(), S->stage1.as<uint64_t>(), d_drop,
+        hipLaunchKernelGGL(k_make_requests, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, g->uniq().as<uint64_t>(), g->starts().as<uint32_t>(),
+                           g->vals1().as<uint32_t>(), D, mode, S->stage0.as<uint64_t>(), S->stage1.as<uint64_t>(), d_drop,
                            cidx.as<uint64_t>(), c_drop, S->creq_dup.as<uint8_t>());
         // Bloom-bit requests
         S->dreq_pos.reserve(nd * 4 + 16); S->creq_pos.reserve(nc * 4 + 16);
@@ -624,23 +625,23 @@ int rb_shard_resolve(rb_graph *g, int mode, const void *dreply_dev, const void *
         g->devctr.reserve(DEVCTR_BYTES);
         uint32_t *ctr = g->devctr.as<uint32_t>();
         RB_HIP(hipMemsetAsync(ctr, 0, 64, s));
-        hipLaunchKernelGGL(k_resolve_shard, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, g->counts.as<uint32_t>(), g->starts.as<uint32_t>(), D, mode,
+        hipLaunchKernelGGL(k_resolve_shard, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, g->counts().as<uint32_t>(), g->starts().as<uint32_t>(), D, mode,
                            g->light_ops, S->dreq_pos.as<uint32_t>(), (const uint8_t *)dreply_dev, S->creq_pos.as<uint32_t>(),
-                           S->creq_dup.as<uint8_t>(), (const uint8_t *)creply_dev, g->tz.as<uint8_t>(), g->status.as<uint32_t>(),
+                           S->creq_dup.as<uint8_t>(), (const uint8_t *)creply_dev, g->tz().as<uint8_t>(), g->status.as<uint32_t>(),
                            g->nops.as<uint32_t>(), g->cvals.as<uint64_t>(), S->cfinal.as<uint64_t>(), g->heavy.as<uint32_t>(),
                            S->conf_list.as<uint32_t>(), ctr);
         uint32_t hc[8];
         RB_HIP(hipMemcpyAsync(hc, ctr, 32, hipMemcpyDeviceToHost, s));
         RB_HIP(hipStreamSynchronize(s));
         if (hc[0])
-            hipLaunchKernelGGL(k_cbf_heavy, dim3(std::min<uint32_t>(hc[0], 16384u)), dim3(64), 0, s, fv, g->uniq.as<uint64_t>(), g->counts.as<uint32_t>(),
-                               g->starts.as<uint32_t>(), g->vals1.as<uint32_t>(), g->status.as<uint32_t>(), g->nops.as<uint32_t>(),
-                               g->cvals.as<uint64_t>(), g->tz.as<uint8_t>(), g->heavy.as<uint32_t>(), ctr, S->cfinal.as<uint64_t>());
+            hipLaunchKernelGGL(k_cbf_heavy, dim3(std::min<uint32_t>(hc[0], 16384u)), dim3(64), 0, s, fv, g->uniq().as<uint64_t>(), g->counts().as<uint32_t>(),
+                               g->starts().as<uint32_t>(), g->vals1().as<uint32_t>(), g->status.as<uint32_t>(), g->nops.as<uint32_t>(),
+                               g->cvals.as<uint64_t>(), g->tz().as<uint8_t>(), g->heavy.as<uint32_t>(), ctr, S->cfinal.as<uint64_t>());
         // counter writes / releases, bucketed by counter owner
         const size_t nc = (size_t)D * fv.cbf_h;
         S->stage0.reserve(nc * 8); S->stage2.reserve(2 * nc + 32);
         uint8_t *w_val = S->stage2.as<uint8_t>(), *w_drop = w_val + nc;
-        hipLaunchKernelGGL(k_emit_writes, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, g->uniq.as<uint64_t>(), D, g->status.as<uint32_t>(),
+        hipLaunchKernelGGL(k_emit_writes, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, g->uniq().as<uint64_t>(), D, g->status.as<uint32_t>(),
                            S->creq_dup.as<uint8_t>(), S->cfinal.as<uint64_t>(), S->stage0.as<uint64_t>(), w_val, w_drop);
         size_t kept = route(g, S->stage0.as<uint64_t>(), w_drop, nc, S->span[RB_CBF], w_counts);
         uint64_t *wi = (uint64_t *)slot_reserve(S, RB_SLOT_W_IDX, kept * 8);
@@ -658,8 +659,8 @@ int rb_shard_resolve(rb_graph *g, int mode, const void *dreply_dev, const void *
             ConfOp *oo = (ConfOp *)slot_reserve(S, RB_SLOT_CONF_OPS, (size_t)nco * sizeof(ConfOp));
             ConfCtr *oc = (ConfCtr *)slot_reserve(S, RB_SLOT_CONF_CTR, (size_t)ncc * sizeof(ConfCtr));
             RB_HIP(hipMemsetAsync(ctr + 7, 0, 4, s));
-            hipLaunchKernelGGL(k_conf_export, dim3(blocks_for((int64_t)nck * 64)), dim3(TPB), 0, s, fv, g->uniq.as<uint64_t>(), g->counts.as<uint32_t>(),
-                               g->starts.as<uint32_t>(), g->vals1.as<uint32_t>(), g->status.as<uint32_t>(), g->nops.as<uint32_t>(),
+            hipLaunchKernelGGL(k_conf_export, dim3(blocks_for((int64_t)nck * 64)), dim3(TPB), 0, s, fv, g->uniq().as<uint64_t>(), g->counts().as<uint32_t>(),
+                               g->starts().as<uint32_t>(), g->vals1().as<uint32_t>(), g->status.as<uint32_t>(), g->nops.as<uint32_t>(),
                                g->cvals.as<uint64_t>(), S->creq_dup.as<uint8_t>(), S->conf_list.as<uint32_t>(), g->conf_off.as<uint32_t>(), nck,
                                oo, oc, ctr + 7);
             *n_conf_ops = nco; *n_conf_ctr = ncc;
