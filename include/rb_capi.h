@@ -182,6 +182,24 @@ int64_t rb_expected_size(int64_t n, float fpr, int num_hash); /* BloomFilter.get
 int rb_nthash_batch(const rb_batch *b, int k, int mode, int64_t first, int64_t n, int64_t *count,
                     uint64_t *out_h0, uint32_t *out_read, uint32_t *out_pos);
 
+/* ---- sketching over long reads (BASELINE config 5): hash-only, no shared state => plain data
+ *      parallelism over reads (replicas on several GPUs, no collective).  Both hash EVERY window of a
+ *      read like the reference iterators do (no segmentation; unusable bases hash as seed 0). ----
+ * MinimizerHashIterator.next() R/bloom/hash/MinimizerHashIterator.java:27-128 over
+ * LongRollingWindow R/util/LongRollingWindow.java:23-83: for every window of w consecutive k-mers
+ * the SIGNED minimum of hVals[0] (mode 0 forward / 1 canonical / 2 reverse-complement iterator).
+ * moffsets[n_reads+1]: read i yields max(0, len_i-k+1-w+1) windows.  out_pos = leftmost position
+ * attaining the minimum (the reference's position differs only when the same hash value repeats
+ * inside one window — its circular buffer rescans in array order). */
+int rb_minimizers(int device, const char *seq, const int64_t *offsets, int64_t n_reads, int k, int w, int mode,
+                  int64_t *moffsets, uint64_t *out_hash, int64_t *out_pos);
+/* StrobeHashIterator.getInterval(p) R/bloom/hash/StrobeHashIterator.java:133-164 (as used by
+ * SeqSubsampler.strobemerBased R/util/SeqSubsampler.java:367): order-n randstrobes over FORWARD k-mer
+ * hashes, unsigned argmin of combineHashValues, ties -> rightmost, equal k-mer hash -> slide right.
+ * soffsets[n_reads+1]: read i yields numKmers - wMax*(n-2) - wMin strobemers if numKmers > wMax*(n-1). */
+int rb_strobemers(int device, const char *seq, const int64_t *offsets, int64_t n_reads, int k, int n, int wmin, int wmax,
+                  int64_t *soffsets, uint64_t *out_hash, int32_t *out_start, int32_t *out_end);
+
 /* ---- sharded engine (one process per GPU; filters split by index range across `count` shards) ----
  * Multi-GPU counterpart of rb_graph_add_batch.  The reference is a single shared-memory process, so
  * there is no reference interface for this; the phases below are what bench.py / rnabloom.sharded

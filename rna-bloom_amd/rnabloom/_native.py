@@ -80,6 +80,8 @@ SYMBOLS = [
     ("rb_filter_import", _i32, [_vp, _i32, _vp, _sz]),
     ("rb_expected_size", _i64, [_i64, C.c_float, _i32]),
     ("rb_nthash_batch", _i32, [_vp, _i32, _i32, _i64, _i64, C.POINTER(_i64), _vp, _vp, _vp]),
+    ("rb_minimizers", _i32, [_i32, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
+    ("rb_strobemers", _i32, [_i32, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     ("rb_graph_create_shard", _i32, [C.POINTER(GraphParams), _i32, _i32, C.POINTER(_vp)]),
     ("rb_shard_hash", _i32, [_vp, _vp, _i64, _i64, _u32, _u32, C.c_uint, C.POINTER(_i64), C.POINTER(_i64)]),
     ("rb_shard_group", _i32, [_vp, _vp, _vp, _i64, _u64, _u32, _i32, C.POINTER(_i64), C.POINTER(_i64)]),

@@ -263,3 +263,36 @@ class BloomFilterDeBruijnGraph:
         p = N.Profile()
         check(lib.rb_graph_profile_get(self.h, C.byref(p), int(reset)))
         return {p.name[i].decode(): (p.ms[i], p.launches[i]) for i in range(p.n)}
+
+
+# ---- sketching (BASELINE config 5): hash-only, no graph needed ----
+def _pack(reads):
+    lens = np.fromiter((len(r) for r in reads), np.int64, len(reads))
+    off = np.zeros(len(reads) + 1, np.int64)
+    np.cumsum(lens, out=off[1:])
+    seq = np.frombuffer(b"".join(reads), np.uint8) if len(reads) else np.zeros(0, np.uint8)
+    return seq, off
+
+
+def minimizers(reads, k, w, mode=1, device=0):
+    """MinimizerHashIterator over each read: (offsets[n+1], hash, pos)."""
+    seq, off = _pack(reads)
+    mo = np.zeros(len(reads) + 1, np.int64)
+    check(lib.rb_minimizers(device, _ptr(seq), _ptr(off), len(reads), k, w, mode, _ptr(mo), None, None))
+    t = int(mo[-1])
+    h = np.zeros(t, np.uint64); p = np.zeros(t, np.int64)
+    if t:
+        check(lib.rb_minimizers(device, _ptr(seq), _ptr(off), len(reads), k, w, mode, _ptr(mo), _ptr(h), _ptr(p)))
+    return mo, h, p
+
+
+def strobemers(reads, k, n, wmin, wmax, device=0):
+    """StrobeHashIterator.getInterval over each read: (offsets[n+1], hash, start, end)."""
+    seq, off = _pack(reads)
+    so = np.zeros(len(reads) + 1, np.int64)
+    check(lib.rb_strobemers(device, _ptr(seq), _ptr(off), len(reads), k, n, wmin, wmax, _ptr(so), None, None, None))
+    t = int(so[-1])
+    h = np.zeros(t, np.uint64); s = np.zeros(t, np.int32); e = np.zeros(t, np.int32)
+    if t:
+        check(lib.rb_strobemers(device, _ptr(seq), _ptr(off), len(reads), k, n, wmin, wmax, _ptr(so), _ptr(h), _ptr(s), _ptr(e)))
+    return so, h, s, e
