@@ -160,7 +160,10 @@ int rb_graph_kmers(rb_graph *g, const char *seq, const int64_t *offsets, int64_t
 /* Kmer.getSuccessors/getPredecessors R/graph/Kmer.java:210-255, CanonicalKmer.java:226-270:
  * for each (f, r, char_out) the 4 neighbours in order A,C,G,T: forward hash, reverse hash and
  * graph.getCount.  direction 0 = successors (char_out = first base), 1 = predecessors
- * (char_out = last base).  Callers apply their minKmerCov threshold to count4. */
+ * (char_out = last base); 2 = left variants (first base replaced, char_out = first base), 3 = right
+ * variants (last base replaced, char_out = last base) — Kmer.getLeftVariants/getRightVariants
+ * R/graph/Kmer.java:357-405 over R/bloom/hash/{,Canonical}{Left,Right}VariantsNTHashIterator.java; the
+ * entry whose base equals char_out is the k-mer itself.  Callers apply minKmerCov to count4. */
 int rb_graph_neighbors(rb_graph *g, const uint64_t *f, const uint64_t *r, const uint8_t *char_out,
                        size_t n, int direction, uint64_t *f4, uint64_t *r4, float *count4);
 

@@ -561,9 +561,15 @@ __global__ void k_neighbors(FilterView fv, int stranded, int k, int direction, c
     if (direction == 0) {
         nf = rotl(f[i], 1) ^ rotl(s_out, uk) ^ seed_of(in);
         if (!stranded) nr = rotr(r[i], 1) ^ rotr(sc_out, 1) ^ rotl(seed_of(3u - in), uk - 1u);
-    } else {
+    } else if (direction == 1) {
         nf = rotr(f[i], 1) ^ rotr(s_out, 1) ^ rotl(seed_of(in), uk - 1u);
         if (!stranded) nr = rotl(r[i], 1) ^ rotl(sc_out, uk) ^ seed_of(3u - in);
+    } else if (direction == 2) {   // left variants: replace the FIRST base ({,Canonical}LeftVariantsNTHashIterator.java)
+        nf = f[i] ^ rotl(s_out, uk - 1u) ^ rotl(seed_of(in), uk - 1u);
+        if (!stranded) nr = r[i] ^ sc_out ^ seed_of(3u - in);
+    } else {                       // right variants: replace the LAST base ({,Canonical}RightVariantsNTHashIterator.java)
+        nf = f[i] ^ s_out ^ seed_of(in);
+        if (!stranded) nr = r[i] ^ rotl(sc_out, uk - 1u) ^ rotl(seed_of(3u - in), uk - 1u);
     }
     f4[t] = nf;
     if (r4) r4[t] = nr;
@@ -1161,7 +1167,7 @@ int rb_graph_neighbors(rb_graph *g, const uint64_t *f, const uint64_t *r, const 
     return guarded([&] {
         RB_REQUIRE(g && (n == 0 || (f && char_out && f4 && count4)), "rb_graph_neighbors: null argument");
         RB_REQUIRE(g->stranded || n == 0 || r, "rb_graph_neighbors: reverse hashes required for a canonical graph");
-        RB_REQUIRE(direction == 0 || direction == 1, "rb_graph_neighbors: direction must be 0 or 1");
+        RB_REQUIRE(direction >= 0 && direction <= 3, "rb_graph_neighbors: direction must be 0..3");
         RB_REQUIRE(!g->shard, "rb_graph_neighbors: queries are not available on a shard handle");
         if (!n) return;
         RB_HIP(hipSetDevice(g->p.device));

@@ -222,6 +222,25 @@ def test_queries_get_kmers_and_neighbors():
                     assert (r4[j] == orr).all()
 
 
+def test_variants_match_oracle():
+    (ls, lq, off), _ = make_reads(600, 9000, 0.002, 0.0, seed=8)
+    for stranded in (False, True):
+        og, gg = graph_pair(200_003, 900_001, 10_007, stranded=stranded, pairs=False)
+        og.add_reads(ls, lq, off, 3, 0); gg.addReads(ls, lq, off, 3)
+        s = bytes(ls[off[3]:off[4]])
+        ef, er, _ = og.get_kmers(s)
+        idx = np.arange(0, len(ef), 11)
+        for side, direction in ((0, 2), (1, 3)):
+            ch = np.array([s[i] if side == 0 else s[i + 24] for i in idx], np.uint8)
+            f4, r4, c4 = gg.getNeighbors(ef[idx], er[idx], ch, direction)
+            for j, i in enumerate(idx):
+                for b, base in enumerate(b"ACGT"):
+                    vf, vr, vh = rbo.variant(int(ef[i]), int(er[i]), int(ch[j]), base, 25, 2, not stranded, side)
+                    assert int(f4[j, b]) == vf and c4[j, b] == og.get_count(vh)
+                    if not stranded:
+                        assert int(r4[j, b]) == vr
+
+
 def test_export_import_roundtrip_and_errors():
     og, gg = graph_pair(100_003, 300_007, 10_007)
     (ls, lq, off), _ = make_reads(300, 5000, 0.0, 0.0, seed=2)
