@@ -139,9 +139,7 @@ __global__ void k_resolve_shard(FilterView fv, const uint32_t *__restrict__ coun
                                 const uint8_t *__restrict__ dreply, const uint32_t *__restrict__ creq_pos,
                                 const uint8_t *__restrict__ c_dup, const uint8_t *__restrict__ creply,
                                 const uint8_t *__restrict__ tz, uint32_t *__restrict__ status, uint32_t *__restrict__ nops,
-                                uint64_t *__restrict__ cvals, uint64_t *__restrict__ cfinal, uint32_t *__restrict__ heavy_list,
-                                uint32_t *__restrict__ conf_list,
-                                uint32_t *__restrict__ counters /* [0] heavy, [1] conflict runs, [2] conflict ops, [6] conflict counters */) {
+                                uint64_t *__restrict__ cvals, uint64_t *__restrict__ cfinal) {
     uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= D) return;
     const uint32_t m = counts[d];
@@ -162,7 +160,6 @@ __global__ void k_resolve_shard(FilterView fv, const uint32_t *__restrict__ coun
     uint32_t c[RB_MAX_HASH];
     bool conflict = false;
     uint64_t cv = 0;
-    uint32_t n_unique = 0;
     for (int j = 0; j < fv.cbf_h; ++j) {
         const size_t q = (size_t)d * fv.cbf_h + j;
         const int src = c_dup[q];
@@ -171,7 +168,6 @@ __global__ void k_resolve_shard(FilterView fv, const uint32_t *__restrict__ coun
             const uint8_t r = creply[creq_pos[q]];
             c[j] = r & 0x7Fu;
             conflict |= (r & 0x80u) != 0;
-            ++n_unique;
         }
         cv |= (uint64_t)c[j] << (8 * j);
     }
@@ -179,15 +175,9 @@ __global__ void k_resolve_shard(FilterView fv, const uint32_t *__restrict__ coun
     uint32_t st = premask | (all_pre ? ST_ALLPRE : 0u) | (kfirst << 12) | (krest << 14);
     nops[d] = ops;
     if (ops == 0) { status[d] = st | RUN_RELEASE; return; }
-    if (conflict) {
-        status[d] = st | RUN_CONFLICT;
-        conf_list[atomicAdd(&counters[1], 1u)] = d;
-        atomicAdd(&counters[2], ops);
-        atomicAdd(&counters[6], n_unique);
-        return;
-    }
+    if (conflict) { status[d] = st | RUN_CONFLICT; return; }
+    if (ops > light_ops) { status[d] = st | RUN_WRITES | RUN_HEAVY; return; }
     status[d] = st | RUN_WRITES;
-    if (ops > light_ops) { heavy_list[atomicAdd(&counters[0], 1u)] = d; return; }
     run_ops(c, fv.cbf_h, kfirst, krest, tz, starts[d] + m - ops, ops);
     uint64_t out = 0;
     for (int j = 0; j < fv.cbf_h; ++j) out |= (uint64_t)c[j] << (8 * j);
@@ -220,7 +210,7 @@ __global__ void k_conf_export(FilterView fv, const uint64_t *__restrict__ uniq, 
                               const uint32_t *__restrict__ status, const uint32_t *__restrict__ nops,
                               const uint64_t *__restrict__ cvals, const uint8_t *__restrict__ c_dup,
                               const uint32_t *__restrict__ conf_list, const uint32_t *__restrict__ conf_off, uint32_t n_conf,
-                              ConfOp *__restrict__ ops_out, ConfCtr *__restrict__ ctr_out, uint32_t *__restrict__ ctr_cursor) {
+                              ConfOp *__restrict__ ops_out, ConfCtr *__restrict__ ctr_out) {
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
     if (wave >= n_conf) return;
     const uint32_t d = conf_list[wave];
@@ -236,12 +226,12 @@ __global__ void k_conf_export(FilterView fv, const uint64_t *__restrict__ uniq, 
     }
     if (lane == 0) {
         const uint64_t cv = cvals[d];
-        for (int j = 0; j < fv.cbf_h; ++j) {
-            if (c_dup[(size_t)d * fv.cbf_h + j] != j) continue;
+        for (int j = 0; j < fv.cbf_h; ++j) {   // fixed stride; a duplicated probe leaves a sentinel (index ~0)
             ConfCtr c;
-            c.idx = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod);
-            c.val = (cv >> (8 * j)) & 0xFFu;
-            ctr_out[atomicAdd(ctr_cursor, 1u)] = c;
+            const bool dup = c_dup[(size_t)d * fv.cbf_h + j] != j;
+            c.idx = dup ? ~0ull : index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod);
+            c.val = dup ? 0ull : ((cv >> (8 * j)) & 0xFFu);
+            ctr_out[(size_t)wave * fv.cbf_h + j] = c;
         }
     }
 }
@@ -267,16 +257,16 @@ __global__ void k_own_dbg_set(uint32_t *bits, uint64_t lo, const uint64_t *__res
     bit_set(bits, idx[i] - lo);
 }
 __global__ void k_own_claim(uint8_t *cbf, uint64_t lo, const uint64_t *__restrict__ idx, size_t n, uint8_t *__restrict__ reply,
-                            uint64_t *__restrict__ foreign, uint32_t *__restrict__ n_foreign) {
+                            uint32_t *__restrict__ spread /* 32 counters, 16 words apart */) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint32_t byte = cbf_claim(cbf, idx[i] - lo);
-    if (byte & CLAIM) foreign[atomicAdd(n_foreign, 1u)] = idx[i];
+    if (byte & CLAIM) atomicAdd(&spread[16 * (blockIdx.x & 31u)], 1u);
     reply[i] = (uint8_t)byte;                                         // bit 7 = claimed before by another run
 }
-__global__ void k_own_cs_build(const uint64_t *__restrict__ foreign, uint32_t n, Slot *cs, uint32_t cs_log2) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) table_insert(cs, cs_log2, foreign[i]);
+__global__ void k_own_cs_build(const uint64_t *__restrict__ idx, const uint8_t *__restrict__ reply, size_t n, Slot *cs, uint32_t cs_log2) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && (reply[i] & 0x80u)) table_insert(cs, cs_log2, idx[i]);
 }
 __global__ void k_own_claim_fin(const uint64_t *__restrict__ idx, size_t n, const Slot *cs, uint32_t cs_log2, uint8_t *__restrict__ reply) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -580,20 +570,21 @@ int rb_shard_serve(rb_graph *g, int mode, const void *dreq_idx_dev, const void *
                                    (uint8_t *)dreply_dev);
         }
         if (nc) {
-            S->own_foreign.reserve((size_t)nc * 8);
             g->devctr.reserve(DEVCTR_BYTES);
             uint32_t *ctr = g->devctr.as<uint32_t>();
-            RB_HIP(hipMemsetAsync(ctr, 0, 64, s));
+            RB_HIP(hipMemsetAsync(ctr, 0, DEVCTR_BYTES, s));
             hipLaunchKernelGGL(k_own_claim, dim3(blocks_for(nc)), dim3(TPB), 0, s, g->cbf, (uint64_t)g->cbf_lo, (const uint64_t *)creq_idx_dev,
-                               (size_t)nc, (uint8_t *)creply_dev, S->own_foreign.as<uint64_t>(), ctr + 5);
-            uint32_t nf = 0;
-            RB_HIP(hipMemcpyAsync(&nf, ctr + 5, 4, hipMemcpyDeviceToHost, s));
+                               (size_t)nc, (uint8_t *)creply_dev, ctr + 16);
+            uint32_t nf = 0, spread[16 * 32];
+            RB_HIP(hipMemcpyAsync(spread, ctr + 16, sizeof spread, hipMemcpyDeviceToHost, s));
             RB_HIP(hipStreamSynchronize(s));
+            for (int q = 0; q < 32; ++q) nf += spread[16 * q];
             if (nf) {
                 const uint32_t cs_log2 = log2_ceil(2ull * nf + 2);
                 S->own_cs.reserve(sizeof(Slot) << cs_log2);
                 RB_HIP(hipMemsetAsync(S->own_cs.p, 0xFF, sizeof(Slot) << cs_log2, s));
-                hipLaunchKernelGGL(k_own_cs_build, dim3(blocks_for(nf)), dim3(TPB), 0, s, S->own_foreign.as<uint64_t>(), nf, S->own_cs.as<Slot>(), cs_log2);
+                hipLaunchKernelGGL(k_own_cs_build, dim3(blocks_for(nc)), dim3(TPB), 0, s, (const uint64_t *)creq_idx_dev, (const uint8_t *)creply_dev,
+                                   (size_t)nc, S->own_cs.as<Slot>(), cs_log2);
                 hipLaunchKernelGGL(k_own_claim_fin, dim3(blocks_for(nc)), dim3(TPB), 0, s, (const uint64_t *)creq_idx_dev, (size_t)nc,
                                    S->own_cs.as<Slot>(), cs_log2, (uint8_t *)creply_dev);
             }
@@ -624,17 +615,19 @@ int rb_shard_resolve(rb_graph *g, int mode, const void *dreply_dev, const void *
         g->heavy.reserve((size_t)D * 4); S->conf_list.reserve((size_t)D * 4); S->cfinal.reserve((size_t)D * 8);
         g->devctr.reserve(DEVCTR_BYTES);
         uint32_t *ctr = g->devctr.as<uint32_t>();
-        RB_HIP(hipMemsetAsync(ctr, 0, 64, s));
+        RB_HIP(hipMemsetAsync(ctr, 0, DEVCTR_BYTES, s));
         hipLaunchKernelGGL(k_resolve_shard, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, g->counts().as<uint32_t>(), g->starts().as<uint32_t>(), D, mode,
                            g->light_ops, S->dreq_pos.as<uint32_t>(), (const uint8_t *)dreply_dev, S->creq_pos.as<uint32_t>(),
                            S->creq_dup.as<uint8_t>(), (const uint8_t *)creply_dev, g->tz().as<uint8_t>(), g->status.as<uint32_t>(),
-                           g->nops.as<uint32_t>(), g->cvals.as<uint64_t>(), S->cfinal.as<uint64_t>(), g->heavy.as<uint32_t>(),
-                           S->conf_list.as<uint32_t>(), ctr);
-        uint32_t hc[8];
-        RB_HIP(hipMemcpyAsync(hc, ctr, 32, hipMemcpyDeviceToHost, s));
+                           g->nops.as<uint32_t>(), g->cvals.as<uint64_t>(), S->cfinal.as<uint64_t>());
+        g->temp.reserve(select_temp_bytes(D));
+        select_flagged(g->temp.p, g->temp.cap, g->status.as<uint32_t>(), RUN_HEAVY, D, g->heavy.as<uint32_t>(), ctr + 0, s);
+        select_flagged(g->temp.p, g->temp.cap, g->status.as<uint32_t>(), RUN_CONFLICT, D, S->conf_list.as<uint32_t>(), ctr + 1, s);
+        uint32_t hc[2];
+        RB_HIP(hipMemcpyAsync(hc, ctr, 8, hipMemcpyDeviceToHost, s));
         RB_HIP(hipStreamSynchronize(s));
         if (hc[0])
-            hipLaunchKernelGGL(k_cbf_heavy, dim3(std::min<uint32_t>(hc[0], 16384u)), dim3(64), 0, s, fv, g->uniq().as<uint64_t>(), g->counts().as<uint32_t>(),
+            hipLaunchKernelGGL(k_cbf_heavy, dim3(std::min<uint32_t>(hc[0], 262144u)), dim3(64), 0, s, fv, g->uniq().as<uint64_t>(), g->counts().as<uint32_t>(),
                                g->starts().as<uint32_t>(), g->vals1().as<uint32_t>(), g->status.as<uint32_t>(), g->nops.as<uint32_t>(),
                                g->cvals.as<uint64_t>(), g->tz().as<uint8_t>(), g->heavy.as<uint32_t>(), ctr, S->cfinal.as<uint64_t>());
         // counter writes / releases, bucketed by counter owner
@@ -650,19 +643,21 @@ int rb_shard_resolve(rb_graph *g, int mode, const void *dreply_dev, const void *
         gather_to<uint8_t>(g, w_val, kept, wv);
         // conflicting runs: export their ops and counters for the replicated replay
         if (hc[1]) {
-            const uint32_t nck = hc[1], nco = hc[2], ncc = hc[6];
+            const uint32_t nck = hc[1], ncc = nck * (uint32_t)fv.cbf_h;
             g->conf_sizes.reserve(((size_t)nck + 1) * 4); g->conf_off.reserve(((size_t)nck + 1) * 4);
             hipLaunchKernelGGL(k_conf_sizes, dim3(blocks_for(nck + 1)), dim3(TPB), 0, s, S->conf_list.as<uint32_t>(), g->nops.as<uint32_t>(), nck,
                                g->conf_sizes.as<uint32_t>());
             g->temp.reserve(scan_temp_bytes((size_t)nck + 1));
             exclusive_scan_u32(g->temp.p, g->temp.cap, g->conf_sizes.as<uint32_t>(), g->conf_off.as<uint32_t>(), (size_t)nck + 1, s);
+            uint32_t nco = 0;
+            RB_HIP(hipMemcpyAsync(&nco, g->conf_off.as<uint32_t>() + nck, 4, hipMemcpyDeviceToHost, s));
+            RB_HIP(hipStreamSynchronize(s));
             ConfOp *oo = (ConfOp *)slot_reserve(S, RB_SLOT_CONF_OPS, (size_t)nco * sizeof(ConfOp));
             ConfCtr *oc = (ConfCtr *)slot_reserve(S, RB_SLOT_CONF_CTR, (size_t)ncc * sizeof(ConfCtr));
-            RB_HIP(hipMemsetAsync(ctr + 7, 0, 4, s));
             hipLaunchKernelGGL(k_conf_export, dim3(blocks_for((int64_t)nck * 64)), dim3(TPB), 0, s, fv, g->uniq().as<uint64_t>(), g->counts().as<uint32_t>(),
                                g->starts().as<uint32_t>(), g->vals1().as<uint32_t>(), g->status.as<uint32_t>(), g->nops.as<uint32_t>(),
                                g->cvals.as<uint64_t>(), S->creq_dup.as<uint8_t>(), S->conf_list.as<uint32_t>(), g->conf_off.as<uint32_t>(), nck,
-                               oo, oc, ctr + 7);
+                               oo, oc);
             *n_conf_ops = nco; *n_conf_ctr = ncc;
             if (stats) stats->conflict_ops += nco;
         }
@@ -701,7 +696,7 @@ int rb_shard_conflict_replay(rb_graph *g, const void *ops_dev, int64_t n_ops, co
         sort_pairs_u64_u64(g->temp.p, g->temp.cap, S->ck0.as<uint64_t>(), S->ck1.as<uint64_t>(), S->cv0.as<uint64_t>(), S->cv1.as<uint64_t>(), nc, 0, 64, s);
         g->devctr.reserve(DEVCTR_BYTES);
         uint32_t *ctr = g->devctr.as<uint32_t>();
-        RB_HIP(hipMemsetAsync(ctr, 0, 64, s));
+        RB_HIP(hipMemsetAsync(ctr, 0, DEVCTR_BYTES, s));
         run_length_encode_u64(g->temp.p, g->temp.cap, S->ck1.as<uint64_t>(), nc, S->cuniq.as<uint64_t>(), S->ccnt.as<uint32_t>(), ctr + 8, s);
         uint32_t M = 0;
         RB_HIP(hipMemcpyAsync(&M, ctr + 8, 4, hipMemcpyDeviceToHost, s));

@@ -77,6 +77,16 @@ class ShardRank:
 
     # ---- one global sub-batch; yields exchange requests, receives their results ----
     def substep(self, batch, first, n, pos_bits, flags, mode=N.MODE_ADD):
+        import os, time
+        trace = os.environ.get("RB_SHARD_TRACE")
+        t_last = [time.perf_counter()]
+
+        def mark(what):
+            if trace and self.rank == 0:
+                torch.cuda.synchronize()
+                now = time.perf_counter()
+                print("[shard] %-10s %8.1f ms" % (what, (now - t_last[0]) * 1e3), flush=True)
+                t_last[0] = now
         G = self.count
         n_all = yield ("ints", [int(n)])
         n_all = [x[0] for x in n_all]
@@ -85,38 +95,49 @@ class ShardRank:
         rec_c, pair_c = (C.c_int64 * G)(), (C.c_int64 * G)()
         check(lib.rb_shard_hash(self.h, batch.h, first, n, rel_base, pos_bits, flags, rec_c, pair_c))
         rec_c, pair_c = list(rec_c), list(pair_c)
+        mark("hash")
         keys = self._take(N.SLOT_REC_KEYS, 8 * sum(rec_c))
         occ = self._take(N.SLOT_REC_OCC, 4 * sum(rec_c))
         pidx = self._take(N.SLOT_PAIR_IDX, 8 * sum(pair_c))
         rkeys, rk_c = yield ("a2a", keys, [8 * c for c in rec_c])
         rocc, _ = yield ("a2a", occ, [4 * c for c in rec_c])
         rpidx, rp_c = yield ("a2a", pidx, [8 * c for c in pair_c])
+        mark("a2a_rec")
         nrec = sum(rk_c) // 8
         d_c, c_c = (C.c_int64 * G)(), (C.c_int64 * G)()
         check(lib.rb_shard_group(self.h, _ptr(rkeys), _ptr(rocc), nrec, self.ordinal, pos_bits, mode, d_c, c_c))
         d_c, c_c = list(d_c), list(c_c)
+        mark("group")
         o_didx, o_dc = yield ("a2a", self._take(N.SLOT_DREQ_IDX, 8 * sum(d_c)), [8 * c for c in d_c])
         o_dprobe, _ = yield ("a2a", self._take(N.SLOT_DREQ_PROBE, 8 * sum(d_c)), [8 * c for c in d_c])
         o_cidx, o_cc = yield ("a2a", self._take(N.SLOT_CREQ_IDX, 8 * sum(c_c)), [8 * c for c in c_c])
+        mark("a2a_req")
         nd, nc, np_ = sum(o_dc) // 8, sum(o_cc) // 8, sum(rp_c) // 8
         dreply = torch.empty(nd, dtype=torch.uint8, device=self.tdev)
         creply = torch.empty(nc, dtype=torch.uint8, device=self.tdev)
         check(lib.rb_shard_serve(self.h, mode, _ptr(o_didx), _ptr(o_dprobe), nd, _ptr(o_cidx), nc, _ptr(rpidx), np_,
                                  _ptr(dreply), _ptr(creply)))
+        mark("serve")
         my_dreply, _ = yield ("a2a", dreply, [c // 8 for c in o_dc])
         my_creply, _ = yield ("a2a", creply, [c // 8 for c in o_cc])
+        mark("a2a_reply")
         w_c = (C.c_int64 * G)()
         nco, ncc = C.c_int64(), C.c_int64()
         st = N.AddStats()
         check(lib.rb_shard_resolve(self.h, mode, _ptr(my_dreply), _ptr(my_creply), w_c, C.byref(nco), C.byref(ncc), C.byref(st)))
         w_c = list(w_c)
+        mark("resolve")
         o_widx, o_wc = yield ("a2a", self._take(N.SLOT_W_IDX, 8 * sum(w_c)), [8 * c for c in w_c])
         o_wval, _ = yield ("a2a", self._take(N.SLOT_W_VAL, sum(w_c)), w_c)
         check(lib.rb_shard_apply_writes(self.h, _ptr(o_widx), _ptr(o_wval), sum(o_wc) // 8))
+        mark("writes")
         all_ops = yield ("gather", self._take(N.SLOT_CONF_OPS, 16 * nco.value))
         all_ctr = yield ("gather", self._take(N.SLOT_CONF_CTR, 16 * ncc.value))
+        mark("gather")
         check(lib.rb_shard_conflict_replay(self.h, _ptr(all_ops), all_ops.numel() // 16, _ptr(all_ctr), all_ctr.numel() // 16))
+        mark("replay")
         self.ordinal += total_reads
+        del keys, occ, pidx, rkeys, rocc, rpidx, o_didx, o_dprobe, o_cidx, dreply, creply, my_dreply, my_creply, o_widx, o_wval, all_ops, all_ctr
         self.stats["kmers"] += sum(rec_c)
         self.stats["pairs"] += sum(pair_c) // max(1, self.p.pkbf_num_hash)
         self.stats["distinct"] += st.distinct
@@ -222,12 +243,14 @@ def run_distributed(gen, group=None):
 
 
 def plan(max_len, k, count, max_batch_kmers=1 << 30):
-    """(pos_bits, reads per rank per sub-batch) so that a global sub-batch stays within the limits."""
+    """(pos_bits, reads per rank per sub-batch) so that a global sub-batch stays within the limits.
+    Per rank a sub-batch is capped at 2^28 k-mers: exchange buffers (torch) and library scratch both
+    scale with it."""
     pos_bits = 1
     while (1 << pos_bits) <= max_len:
         pos_bits += 1
     per_read = max(1, max_len)
-    reads = max(1, (max_batch_kmers // count) // per_read)
+    reads = max(1, min(max_batch_kmers // count, 1 << 28) // per_read)
     reads = min(reads, ((1 << (32 - pos_bits)) - 1) // count)
     return pos_bits, max(1, reads)
 
