@@ -6,6 +6,7 @@
 // NTHashIterator (R/bloom/hash/NTHashIterator.java:45-69 etc.).  A k-mer window is hashed iff all
 // of its k bases are usable, which is exactly the set of windows the nested regex runs yield.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -198,8 +199,11 @@ __global__ void k_count_windows(const uint32_t *__restrict__ valid, const uint32
 // window.  Outputs of a 256-thread block are contiguous in the dense output array, so they are
 // staged through LDS in slabs of HASH_SLAB records and written back as full, coalesced lines
 // (direct per-thread 8-byte stores cost ~5x write amplification: 62 B/k-mer measured by WRITE_SIZE).
-constexpr int HASH_TPB = 256;
-constexpr uint32_t HASH_SLAB = 2048;
+#ifndef RB_HASH_TPB
+#define RB_HASH_TPB 64
+#endif
+constexpr int HASH_TPB = RB_HASH_TPB;   // one wavefront per block: every lane is busy in the single slab round
+constexpr uint32_t HASH_SLAB = 32u * RB_HASH_TPB;
 template <int MODE>
 __global__ void __launch_bounds__(HASH_TPB)
 k_hash_windows(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
@@ -207,7 +211,7 @@ k_hash_windows(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ 
                const uint32_t *__restrict__ len, int64_t w0, int64_t nw, int k,
                const uint32_t *__restrict__ chunk_off, uint32_t first_read, uint32_t pos_bits,
                uint64_t *__restrict__ keys, uint32_t *__restrict__ vals, uint32_t *__restrict__ out_read,
-               uint32_t *__restrict__ out_pos) {
+               uint32_t *__restrict__ out_pos, int64_t nthreads, int cw, int wpr, int cpr) {
     // threads write runs of ~32 records at a stride of ~32 records: without the +1-per-32 skew all
     // lanes of a wavefront would hit the same LDS banks (64-way conflict on every ds_write)
     __shared__ uint64_t s_key[HASH_SLAB + HASH_SLAB / 32 + 1];
@@ -224,27 +228,36 @@ k_hash_windows(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ 
         s_tr[threadIdx.x] = rotr(seed_of(3u - oc), 1) ^ rotl(seed_of(3u - ic), uk - 1u);
     }
     __syncthreads();
+    // thread -> chunk of `cw` consecutive words of ONE read.  Ragged batches use one word per thread
+    // (cw = 1, any word); uniform batches (wpr words per read) use cw > 1 so that the k-1 warm-up bases
+    // are amortised over more windows (150 bp reads: one thread per read, 150 steps for 126 windows).
     const int64_t blk0 = (int64_t)blockIdx.x * HASH_TPB;
-    const int64_t i = blk0 + threadIdx.x;
-    const int64_t blk_end = (blk0 + HASH_TPB < nw) ? blk0 + HASH_TPB : nw;
-    const uint32_t O0 = chunk_off[blk0], O1 = chunk_off[blk_end];   // chunk_off has nw+1 entries
+    const int64_t t = blk0 + threadIdx.x;
+    const int64_t blk_end = (blk0 + HASH_TPB < nthreads) ? blk0 + HASH_TPB : nthreads;
+    auto first_word = [&](int64_t tt) -> int64_t {   // index (relative to w0) of the first word of thread tt
+        if (cw <= 1) return tt;
+        if (tt >= nthreads) return nw;
+        return (tt / cpr) * wpr + (tt % cpr) * cw;
+    };
+    const uint32_t O0 = chunk_off[first_word(blk0)], O1 = chunk_off[first_word(blk_end)];   // chunk_off has nw+1 entries
     if (O0 == O1) return;
     // per-thread walker state
     uint32_t r = 0, L = 0, b = 0, bend = 0, run = 0, cur_v = 0, out = 0;
     uint64_t cur_c = 0, f = 0, rv = 0, hist = 0;   // hist: 2-bit codes of the last 32 bases
-    const uint64_t *cw = codes;
+    const uint64_t *cw_ = codes;
     const uint32_t *vw = valid;
-    if (i < nw) {
+    if (t < nthreads) {
+        const int64_t i = first_word(t);
         const int64_t w = w0 + i;
         r = word_read[w];
         const uint32_t wr = woff[r];
         L = len[r];
         const uint32_t b0 = (uint32_t)(w - wr) * 32u;
-        cw = codes + wr;
+        cw_ = codes + wr;
         vw = valid + wr;
         b = b0;
         if ((uint64_t)b0 + uk <= L) {
-            const uint64_t bend64 = (uint64_t)b0 + 32u + uk - 1u;
+            const uint64_t bend64 = (uint64_t)b0 + 32u * (uint64_t)(cw > 1 ? cw : 1) + uk - 1u;
             bend = bend64 < L ? (uint32_t)bend64 : L;
         } else bend = b0;                       // no window starts in this chunk
         out = chunk_off[i];
@@ -254,7 +267,7 @@ k_hash_windows(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ 
         const uint32_t slab1 = (slab0 + HASH_SLAB < O1) ? slab0 + HASH_SLAB : O1;
         bool reload = true;                     // the walker may resume in the middle of a word
         while (b < bend && out < slab1) {
-            if (reload || (b & 31u) == 0) { cur_c = cw[b >> 5]; cur_v = vw[b >> 5]; reload = false; }
+            if (reload || (b & 31u) == 0) { cur_c = cw_[b >> 5]; cur_v = vw[b >> 5]; reload = false; }
             if (!((cur_v >> (b & 31u)) & 1u)) { run = 0; f = 0; rv = 0; ++b; continue; }
             const uint32_t code = (uint32_t)(cur_c >> (2u * (b & 31u))) & 3u;
             if (run < uk) {
@@ -266,7 +279,7 @@ k_hash_windows(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ 
             } else {
                 uint32_t oc;
                 if (short_k) oc = (uint32_t)(hist >> (2u * (uk - 1u))) & 3u;
-                else { const uint32_t bo = b - uk; oc = (uint32_t)(cw[bo >> 5] >> (2u * (bo & 31u))) & 3u; }
+                else { const uint32_t bo = b - uk; oc = (uint32_t)(cw_[bo >> 5] >> (2u * (bo & 31u))) & 3u; }
                 const uint32_t t = oc * 4u + code;
                 if (MODE != 2) f = rotl(f, 1) ^ s_tf[t];
                 if (MODE != 0) rv = rotr(rv, 1) ^ s_tr[t];
@@ -297,6 +310,80 @@ k_hash_windows(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ 
     }
 }
 
+// Fast path for k <= 31, one 32-base word per thread, one wavefront per block.
+// Branch-free walker: a base that is unusable (or lies before the chunk) is treated as a "null" base
+// whose seed is 0 — it contributes nothing when it enters the window and nothing when it leaves, so
+// the rolling formulas (NTHash.java:491-495, 584-586) hold from the very first step and across
+// unusable bases; a window is emitted only when its last k bases were all usable (run >= k), and at
+// that point f / r equal NTP64 / NTP64RC from scratch.  Roll terms come from a 5x5 LDS table
+// indexed by (outgoing, incoming) in {null,A,C,G,T}.
+template <int MODE>
+__global__ void __launch_bounds__(64)
+k_hash_windows_fast(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
+                    const uint32_t *__restrict__ word_read, const uint32_t *__restrict__ woff,
+                    const uint32_t *__restrict__ len, int64_t w0, int64_t nw, int k,
+                    const uint32_t *__restrict__ chunk_off, uint32_t first_read, uint32_t pos_bits,
+                    uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+    constexpr uint32_t SLAB = 2048;                       // 64 threads x 32 windows
+    __shared__ uint64_t s_key[SLAB + SLAB / 32 + 1];
+    __shared__ uint32_t s_val[SLAB + SLAB / 32 + 1];
+    __shared__ uint64_t s_tf[25], s_tr[25];
+    const uint32_t uk = (uint32_t)k;
+    if (threadIdx.x < 25) {
+        const uint32_t o = threadIdx.x / 5u, in = threadIdx.x % 5u;   // 0 = null, 1..4 = A,C,G,T
+        const uint64_t so = o ? seed_of(o - 1u) : 0ull, si = in ? seed_of(in - 1u) : 0ull;
+        const uint64_t sco = o ? seed_of(4u - o) : 0ull, sci = in ? seed_of(4u - in) : 0ull;
+        s_tf[threadIdx.x] = rotl(so, uk) ^ si;
+        s_tr[threadIdx.x] = rotr(sco, 1) ^ rotl(sci, uk - 1u);
+    }
+    __syncthreads();
+    const int64_t blk0 = (int64_t)blockIdx.x * 64;
+    const int64_t i = blk0 + threadIdx.x;
+    const int64_t blk_end = (blk0 + 64 < nw) ? blk0 + 64 : nw;
+    const uint32_t O0 = chunk_off[blk0], O1 = chunk_off[blk_end];
+    if (O0 == O1) return;
+    if (i < nw) {
+        const int64_t w = w0 + i;
+        const uint32_t r = word_read[w], wr = woff[r], L = len[r];
+        const uint32_t c = (uint32_t)(w - wr), b0 = c * 32u;
+        if ((uint64_t)b0 + uk <= L) {
+            const uint32_t nwords = (L + 31u) >> 5;
+            // 64 bases of codes / validity starting at b0 (second word only if the read has it)
+            uint64_t clo = codes[w], chi = (c + 1u < nwords) ? codes[w + 1] : 0ull;
+            uint64_t vs = (uint64_t)valid[w] | ((c + 1u < nwords) ? ((uint64_t)valid[w + 1] << 32) : 0ull);
+            const uint32_t nb = ((b0 + 32u + uk - 1u < L) ? b0 + 32u + uk - 1u : L) - b0;   // bases to walk (<= 62)
+            uint64_t f = 0, rv = 0, hc = 0, hv = 0;      // hc/hv: codes / usable bits of the previous bases
+            uint32_t run = 0, out = chunk_off[i] - O0;
+            const uint32_t rel = (r - first_read) << pos_bits;
+            const uint32_t sh_c = 2u * (uk - 1u), sh_v = uk - 1u;
+            for (uint32_t j = 0; j < nb; ++j) {
+                const uint32_t code = (uint32_t)clo & 3u, ok = (uint32_t)vs & 1u;
+                clo = (clo >> 2) | (chi << 62); chi >>= 2; vs >>= 1;
+                const uint32_t in5 = ok ? code + 1u : 0u;
+                const uint32_t out5 = ((uint32_t)(hv >> sh_v) & 1u) ? ((uint32_t)(hc >> sh_c) & 3u) + 1u : 0u;
+                const uint32_t t = out5 * 5u + in5;
+                if (MODE != 2) f = rotl(f, 1) ^ s_tf[t];
+                if (MODE != 0) rv = rotr(rv, 1) ^ s_tr[t];
+                hc = (hc << 2) | code; hv = (hv << 1) | ok;
+                run = ok ? run + 1u : 0u;
+                if (run >= uk) {
+                    const uint32_t q = out + (out >> 5);
+                    s_key[q] = (MODE == 0) ? f : (MODE == 2) ? rv : canonical(f, rv);
+                    s_val[q] = rel | (b0 + j + 1u - uk);
+                    ++out;
+                }
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t n = O1 - O0;
+    for (uint32_t j = threadIdx.x; j < n; j += 64u) {
+        const uint32_t q = j + (j >> 5);
+        keys[O0 + j] = s_key[q];
+        vals[O0 + j] = s_val[q];
+    }
+}
+
 void launch_count_windows(const rb_batch *b, int64_t w0, int64_t nw, int span, uint32_t *cnt, hipStream_t s) {
     if (nw <= 0) return;
     hipLaunchKernelGGL(k_count_windows, dim3(blocks_for(nw)), dim3(TPB), 0, s, b->valid, b->word_read,
@@ -307,10 +394,28 @@ void launch_hash_windows(const rb_batch *b, int64_t w0, int64_t nw, int k, int m
                          uint64_t *keys, uint32_t *vals, uint32_t *out_read, uint32_t *out_pos,
                          hipStream_t s) {
     if (nw <= 0) return;
-    dim3 g(blocks_for(nw, HASH_TPB)), t(HASH_TPB);
+    if (k <= 31 && vals && !out_read && !getenv("RB_HASH_GENERIC")) {   // fast path (stage-1 insert at k <= 31)
+        dim3 g(blocks_for(nw, 64)), t(64);
+#define RB_LAUNCH_FAST(M)                                                                             \
+    hipLaunchKernelGGL(k_hash_windows_fast<M>, g, t, 0, s, b->codes, b->valid, b->word_read, b->woff, \
+                       b->len, w0, nw, k, chunk_off, first_read, pos_bits, keys, vals)
+        if (mode == 0) RB_LAUNCH_FAST(0); else if (mode == 2) RB_LAUNCH_FAST(2); else RB_LAUNCH_FAST(1);
+#undef RB_LAUNCH_FAST
+        return;
+    }
+    int cw = 1, wpr = 0, cpr = 0;
+    int64_t nthreads = nw;
+    if (getenv("RB_HASH_CW") && b->wpr_uniform && nw % b->wpr_uniform == 0) {   // experimental: several words per thread
+        wpr = (int)b->wpr_uniform;
+        cw = std::max(1, std::min(wpr, atoi(getenv("RB_HASH_CW"))));
+        cpr = (wpr + cw - 1) / cw;
+        nthreads = (nw / wpr) * cpr;
+        if (cw == 1) { wpr = 0; cpr = 0; }
+    }
+    dim3 g(blocks_for(nthreads, HASH_TPB)), t(HASH_TPB);
 #define RB_LAUNCH_HASH(M)                                                                        \
     hipLaunchKernelGGL(k_hash_windows<M>, g, t, 0, s, b->codes, b->valid, b->word_read, b->woff, \
-                       b->len, w0, nw, k, chunk_off, first_read, pos_bits, keys, vals, out_read, out_pos)
+                       b->len, w0, nw, k, chunk_off, first_read, pos_bits, keys, vals, out_read, out_pos, nthreads, cw, wpr, cpr)
     if (mode == 0) RB_LAUNCH_HASH(0);
     else if (mode == 2) RB_LAUNCH_HASH(2);
     else RB_LAUNCH_HASH(1);

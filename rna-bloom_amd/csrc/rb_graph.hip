@@ -894,10 +894,12 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
         if (pairs && subs[i].nw > 0) RB_HIP(hipMemcpyAsync(&np, reinterpret_cast<unsigned long long *>(g->devctr2.as<uint32_t>() + 12), 8, hipMemcpyDeviceToHost, sp));
         const uint32_t D = group_finish(g, slot, sp, g->temp, g->devctr2, s);   // drains the producer stream
         if (stats) { stats->pairs += (int64_t)np; stats->distinct += D; }
-        if (i + 1 < subs.size()) prepare(i + 1);      // overlaps with the filter stages below
+        const bool serial = getenv("RB_SERIAL") != nullptr;   // debugging / clean per-stage timing
+        if (!serial && i + 1 < subs.size()) prepare(i + 1);      // overlaps with the filter stages below
         g->cur = slot;
         run_core(g, subs[i].N, D, mode, g->ordinal + (uint64_t)(subs[i].r0 - first), pos_bits, stats);
         RB_HIP(hipStreamSynchronize(s));               // slot may be refilled after this
+        if (serial && i + 1 < subs.size()) prepare(i + 1);
         if (stats) { stats->kmers += subs[i].N; stats->reads += subs[i].r1 - subs[i].r0; }
     }
     g->ordinal += (uint64_t)n;
