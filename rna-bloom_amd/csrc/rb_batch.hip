@@ -323,7 +323,7 @@ k_hash_windows_fast(const uint64_t *__restrict__ codes, const uint32_t *__restri
                     const uint32_t *__restrict__ word_read, const uint32_t *__restrict__ woff,
                     const uint32_t *__restrict__ len, int64_t w0, int64_t nw, int k,
                     const uint32_t *__restrict__ chunk_off, uint32_t first_read, uint32_t pos_bits,
-                    uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+                    uint64_t *__restrict__ keys, uint32_t *__restrict__ vals, const uint32_t *__restrict__ keepmask) {
     constexpr uint32_t SLAB = 2048;                       // 64 threads x 32 windows
     __shared__ uint64_t s_key[SLAB + SLAB / 32 + 1];
     __shared__ uint32_t s_val[SLAB + SLAB / 32 + 1];
@@ -356,6 +356,7 @@ k_hash_windows_fast(const uint64_t *__restrict__ codes, const uint32_t *__restri
             uint32_t run = 0, out = chunk_off[i] - O0;
             const uint32_t rel = (r - first_read) << pos_bits;
             const uint32_t sh_c = 2u * (uk - 1u), sh_v = uk - 1u;
+            const uint32_t keep = keepmask ? keepmask[i] : 0xFFFFFFFFu;   // bit p-b0: window p survived the prefilter
             for (uint32_t j = 0; j < nb; ++j) {
                 const uint32_t code = (uint32_t)clo & 3u, ok = (uint32_t)vs & 1u;
                 clo = (clo >> 2) | (chi << 62); chi >>= 2; vs >>= 1;
@@ -366,7 +367,7 @@ k_hash_windows_fast(const uint64_t *__restrict__ codes, const uint32_t *__restri
                 if (MODE != 0) rv = rotr(rv, 1) ^ s_tr[t];
                 hc = (hc << 2) | code; hv = (hv << 1) | ok;
                 run = ok ? run + 1u : 0u;
-                if (run >= uk) {
+                if (run >= uk && ((keep >> (j + 1u - uk)) & 1u)) {
                     const uint32_t q = out + (out >> 5);
                     s_key[q] = (MODE == 0) ? f : (MODE == 2) ? rv : canonical(f, rv);
                     s_val[q] = rel | (b0 + j + 1u - uk);
@@ -384,6 +385,69 @@ k_hash_windows_fast(const uint64_t *__restrict__ codes, const uint32_t *__restri
     }
 }
 
+// Prefilter pass: same walker as k_hash_windows_fast, but instead of emitting it decides for every
+// usable window whether the occurrence can change anything: it is dropped iff the cache knows the
+// k-mer (full 64-bit match) with counter exponent >= s and the occurrence's draw strength is < s.
+template <int MODE>
+__global__ void __launch_bounds__(64)
+k_filter_windows_fast(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
+                      const uint32_t *__restrict__ word_read, const uint32_t *__restrict__ woff,
+                      const uint32_t *__restrict__ len, int64_t w0, int64_t nw, int k, uint32_t first_read,
+                      uint32_t pos_bits, uint64_t seed, uint64_t ordinal0, Npf cache, uint32_t *__restrict__ cnt,
+                      uint32_t *__restrict__ keepmask, uint32_t *__restrict__ total_spread) {
+    __shared__ uint64_t s_tf[25], s_tr[25];
+    const uint32_t uk = (uint32_t)k;
+    if (threadIdx.x < 25) {
+        const uint32_t o = threadIdx.x / 5u, in = threadIdx.x % 5u;
+        const uint64_t so = o ? seed_of(o - 1u) : 0ull, si = in ? seed_of(in - 1u) : 0ull;
+        const uint64_t sco = o ? seed_of(4u - o) : 0ull, sci = in ? seed_of(4u - in) : 0ull;
+        s_tf[threadIdx.x] = rotl(so, uk) ^ si;
+        s_tr[threadIdx.x] = rotr(sco, 1) ^ rotl(sci, uk - 1u);
+    }
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    uint32_t kept = 0, mask = 0, total = 0;
+    if (i < nw) {
+        const int64_t w = w0 + i;
+        const uint32_t r = word_read[w], wr = woff[r], L = len[r];
+        const uint32_t c = (uint32_t)(w - wr), b0 = c * 32u;
+        if ((uint64_t)b0 + uk <= L) {
+            const uint32_t nwords = (L + 31u) >> 5;
+            uint64_t clo = codes[w], chi = (c + 1u < nwords) ? codes[w + 1] : 0ull;
+            uint64_t vs = (uint64_t)valid[w] | ((c + 1u < nwords) ? ((uint64_t)valid[w + 1] << 32) : 0ull);
+            const uint32_t nb = ((b0 + 32u + uk - 1u < L) ? b0 + 32u + uk - 1u : L) - b0;
+            uint64_t f = 0, rv = 0, hc = 0, hv = 0;
+            uint32_t run = 0;
+            const uint64_t ordinal = ordinal0 + (uint64_t)(r - first_read);
+            const uint32_t sh_c = 2u * (uk - 1u), sh_v = uk - 1u;
+            for (uint32_t j = 0; j < nb; ++j) {
+                const uint32_t code = (uint32_t)clo & 3u, ok = (uint32_t)vs & 1u;
+                clo = (clo >> 2) | (chi << 62); chi >>= 2; vs >>= 1;
+                const uint32_t in5 = ok ? code + 1u : 0u;
+                const uint32_t out5 = ((uint32_t)(hv >> sh_v) & 1u) ? ((uint32_t)(hc >> sh_c) & 3u) + 1u : 0u;
+                const uint32_t t = out5 * 5u + in5;
+                if (MODE != 2) f = rotl(f, 1) ^ s_tf[t];
+                if (MODE != 0) rv = rotr(rv, 1) ^ s_tr[t];
+                hc = (hc << 2) | code; hv = (hv << 1) | ok;
+                run = ok ? run + 1u : 0u;
+                if (run >= uk) {
+                    const uint32_t p = b0 + j + 1u - uk;
+                    const uint64_t h0 = (MODE == 0) ? f : (MODE == 2) ? rv : canonical(f, rv);
+                    const uint32_t s_known = npf_lookup(cache, h0);
+                    bool keep = true;
+                    if (s_known) keep = draw_strength(rng31(seed, ordinal, p)) >= s_known;
+                    ++total;
+                    if (keep) { ++kept; mask |= 1u << (p - b0); }
+                }
+            }
+        }
+        cnt[i] = kept;
+        keepmask[i] = mask;
+    }
+    for (int o = 32; o > 0; o >>= 1) total += __shfl_down(total, o, 64);
+    if (threadIdx.x == 0 && total) atomicAdd(&total_spread[16u * (blockIdx.x & 31u)], total);
+}
+
 void launch_count_windows(const rb_batch *b, int64_t w0, int64_t nw, int span, uint32_t *cnt, hipStream_t s) {
     if (nw <= 0) return;
     hipLaunchKernelGGL(k_count_windows, dim3(blocks_for(nw)), dim3(TPB), 0, s, b->valid, b->word_read,
@@ -398,7 +462,7 @@ void launch_hash_windows(const rb_batch *b, int64_t w0, int64_t nw, int k, int m
         dim3 g(blocks_for(nw, 64)), t(64);
 #define RB_LAUNCH_FAST(M)                                                                             \
     hipLaunchKernelGGL(k_hash_windows_fast<M>, g, t, 0, s, b->codes, b->valid, b->word_read, b->woff, \
-                       b->len, w0, nw, k, chunk_off, first_read, pos_bits, keys, vals)
+                       b->len, w0, nw, k, chunk_off, first_read, pos_bits, keys, vals, (const uint32_t *)nullptr)
         if (mode == 0) RB_LAUNCH_FAST(0); else if (mode == 2) RB_LAUNCH_FAST(2); else RB_LAUNCH_FAST(1);
 #undef RB_LAUNCH_FAST
         return;
@@ -420,6 +484,29 @@ void launch_hash_windows(const rb_batch *b, int64_t w0, int64_t nw, int k, int m
     else if (mode == 2) RB_LAUNCH_HASH(2);
     else RB_LAUNCH_HASH(1);
 #undef RB_LAUNCH_HASH
+}
+
+void launch_filter_windows(const rb_batch *b, int64_t w0, int64_t nw, int k, int mode, uint32_t first_read,
+                           uint32_t pos_bits, uint64_t seed, uint64_t ordinal0, Npf cache, uint32_t *cnt, uint32_t *keepmask,
+                           uint32_t *total_spread, hipStream_t s) {
+    if (nw <= 0) return;
+    dim3 g(blocks_for(nw, 64)), t(64);
+#define RB_LAUNCH_FILT(M)                                                                                    \
+    hipLaunchKernelGGL(k_filter_windows_fast<M>, g, t, 0, s, b->codes, b->valid, b->word_read, b->woff, b->len, \
+                       w0, nw, k, first_read, pos_bits, seed, ordinal0, cache, cnt, keepmask, total_spread)
+    if (mode == 0) RB_LAUNCH_FILT(0); else if (mode == 2) RB_LAUNCH_FILT(2); else RB_LAUNCH_FILT(1);
+#undef RB_LAUNCH_FILT
+}
+void launch_hash_windows_masked(const rb_batch *b, int64_t w0, int64_t nw, int k, int mode, const uint32_t *chunk_off,
+                                const uint32_t *keepmask, uint32_t first_read, uint32_t pos_bits, uint64_t *keys, uint32_t *vals,
+                                hipStream_t s) {
+    if (nw <= 0) return;
+    dim3 g(blocks_for(nw, 64)), t(64);
+#define RB_LAUNCH_FASTM(M)                                                                            \
+    hipLaunchKernelGGL(k_hash_windows_fast<M>, g, t, 0, s, b->codes, b->valid, b->word_read, b->woff, \
+                       b->len, w0, nw, k, chunk_off, first_read, pos_bits, keys, vals, keepmask)
+    if (mode == 0) RB_LAUNCH_FASTM(0); else if (mode == 2) RB_LAUNCH_FASTM(2); else RB_LAUNCH_FASTM(1);
+#undef RB_LAUNCH_FASTM
 }
 
 }  // namespace rb

@@ -104,6 +104,35 @@ __host__ __device__ __forceinline__ float minifloat_to_float(uint32_t b) {
     return (float)(((b & 7u) | 8u) << e);          // exact: < 2^24
 }
 
+// ---- no-op prefilter cache (DESIGN.md §3 "no-op prefilter") ----
+// Direct-mapped table of 8-byte entries keyed by the FULL 64-bit base hash: p = h0 * C (C odd, a
+// bijection on 64 bits); slot = top L bits of p; entry = (low 64-L bits of p) << 4 | s.  An entry
+// asserts "this k-mer is in dbgbf and the exponent (min_counter>>3)-1 of its counting-Bloom minimum
+// is >= s" — counters only grow, so a stale entry stays true.  An occurrence whose draw strength is
+// below s cannot change any counter and may be dropped before sorting.
+struct Npf {
+    unsigned long long *tab;   // nullptr => disabled
+    uint32_t log2n;            // 16..27
+};
+__host__ __device__ __forceinline__ uint64_t npf_mix(uint64_t h0) { return h0 * 0x9E3779B97F4A7C15ull; }
+__device__ __forceinline__ uint32_t npf_lookup(const Npf &c, uint64_t h0) {       // 0 = unknown
+    const uint64_t p = npf_mix(h0);
+    const uint64_t e = c.tab[p >> (64u - c.log2n)];
+    const uint64_t low = p & ((1ull << (64u - c.log2n)) - 1ull);
+    return ((e >> 4) == low) ? (uint32_t)(e & 15ull) : 0u;
+}
+__device__ __forceinline__ void npf_store(const Npf &c, uint64_t h0, uint32_t s) { // s in 1..14; 8-byte store: never torn
+    const uint64_t p = npf_mix(h0);
+    const uint64_t low = p & ((1ull << (64u - c.log2n)) - 1ull);
+    c.tab[p >> (64u - c.log2n)] = (low << 4) | (uint64_t)s;
+}
+// trailing-zero strength of a draw, capped at 15 (see k_strength)
+__host__ __device__ __forceinline__ uint32_t draw_strength(uint32_t rnd31) {
+    uint32_t r = rnd31 | 0x8000u, n = 0;
+    while (!(r & 1u)) { r >>= 1; ++n; }
+    return n;
+}
+
 // bit filters are addressed as 32-bit little-endian words: bit i -> word i>>5, mask 1<<(i&31),
 // which is byte i>>3, mask 1<<(i&7) of the reference layout (UnsafeBitBuffer.java:42-48).
 __device__ __forceinline__ bool bit_test(const uint32_t *bits, uint64_t i) {

@@ -110,7 +110,7 @@ __global__ void k_resolve_apply(FilterView fv, const uint64_t *__restrict__ uniq
                                 uint32_t n_distinct, int mode, uint32_t LIGHT_OPS, const Slot *ftable, uint32_t f_log2,
                                 const Slot *cs, uint32_t cs_log2, uint32_t n_foreign,
                                 uint32_t *__restrict__ status, uint32_t *__restrict__ nops,
-                                const uint64_t *__restrict__ cvals, const uint8_t *__restrict__ tz) {
+                                const uint64_t *__restrict__ cvals, const uint8_t *__restrict__ tz, float *__restrict__ dbgf) {
     uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= n_distinct) return;
     const uint64_t h0 = uniq[d];
@@ -147,6 +147,14 @@ __global__ void k_resolve_apply(FilterView fv, const uint64_t *__restrict__ uniq
     nops[d] = ops;
     st = (st & 0x7FFu) | (kfirst << 12) | (krest << 14);
     status[d] = st;
+    if (dbgf && ops && (st & ST_CLAIMED)) {   // debug: expected fraction of ops that are guaranteed no-ops
+        const uint64_t cv0 = cvals[d];
+        uint32_t mn = 255;
+        for (int j = 0; j < fv.cbf_h; ++j) { uint32_t c = (uint32_t)(cv0 >> (8 * j)) & 0xFFu; mn = c < mn ? c : mn; }
+        float drop = (all_pre && mn >= 16u) ? (float)ops * (1.0f - 1.0f / (float)(1u << ((mn >> 3) - 1u))) : 0.0f;
+        atomicAdd(&dbgf[2 * (blockIdx.x & 63u)], drop);
+        atomicAdd(&dbgf[2 * (blockIdx.x & 63u) + 1], (float)ops);
+    }
     if (!(st & ST_CLAIMED)) return;
     uint64_t idx[RB_MAX_HASH];
     bool conflict = (st & ST_FOREIGN) != 0;
@@ -165,6 +173,11 @@ __global__ void k_resolve_apply(FilterView fv, const uint64_t *__restrict__ uniq
     for (int j = 0; j < fv.cbf_h; ++j) c[j] = (uint32_t)(cv >> (8 * j)) & 0xFFu;
     run_ops(c, fv.cbf_h, kfirst, krest, tz, starts[d] + m - ops, ops);
     for (int j = 0; j < fv.cbf_h; ++j) fv.cbf[idx[j]] = (uint8_t)c[j];   // also clears the claim mark
+    if (fv.npf.tab && mode != M_COUNT_ONLY) {   // the k-mer is in dbgbf now; remember its counter exponent
+        uint32_t mn = c[0];
+        for (int j = 1; j < fv.cbf_h; ++j) mn = c[j] < mn ? c[j] : mn;
+        if (mn >= 16u) npf_store(fv.npf, h0, (mn >> 3) - 1u);
+    }
 }
 
 // drop the claim marks of the counters of conflicting runs before they are replayed in order
@@ -742,8 +755,16 @@ void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, ui
     g->prof_begin();
     hipLaunchKernelGGL(k_resolve_apply, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, uniq, counts, starts, vals, D, mode, g->light_ops,
                        g->ftable.as<Slot>(), f_log2, g->ctable.as<Slot>(), c_log2, n_foreign, status, nops,
-                       g->cvals.as<uint64_t>(), g->tz().as<uint8_t>());
+                       g->cvals.as<uint64_t>(), g->tz().as<uint8_t>(), getenv("RB_DEBUG") ? reinterpret_cast<float *>(ctr + 700) : (float *)nullptr);
     g->prof_end("resolve_apply");
+    if (getenv("RB_DEBUG")) {
+        float df[128];
+        RB_HIP(hipMemcpyAsync(df, ctr + 700, sizeof df, hipMemcpyDeviceToHost, s));
+        RB_HIP(hipStreamSynchronize(s));
+        double dr = 0, tot = 0;
+        for (int q = 0; q < 64; ++q) { dr += df[2 * q]; tot += df[2 * q + 1]; }
+        fprintf(stderr, "[rb] droppable ops (perfect cache): %.1f%% of %.0f ops (N=%zu)\n", tot ? 100.0 * dr / tot : 0.0, tot, N);
+    }
     g->prof_begin();
     g->temp.reserve(select_temp_bytes(D));
     select_flagged(g->temp.p, g->temp.cap, status, RUN_HEAVY, D, g->heavy.as<uint32_t>(), ctr + 0, s);
@@ -835,7 +856,9 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
     const int64_t max_words = std::max<int64_t>(g->max_batch_kmers / 32, 1);
     const std::vector<uint32_t> &wo = b->h_woff;
     // plan the sub-batches
-    struct Sub { int64_t r0, r1, w0, nw; uint32_t N; };
+    struct Sub { int64_t r0, r1, w0, nw; uint32_t N; int64_t total; };
+    // occurrences that provably cannot change a counter are dropped before sorting (k <= 31 fast path)
+    const bool use_npf = g->npf_log2 && g->k <= 31 && (mode == M_ADD || mode == M_COUNT_IF_PRESENT);
     std::vector<Sub> subs;
     {
         int64_t r0 = first;
@@ -848,7 +871,7 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
                 int64_t mid = (lo + hi + 1) >> 1;
                 if ((int64_t)wo[(size_t)mid] - (int64_t)wo[(size_t)r0] <= max_words) lo = mid; else hi = mid - 1;
             }
-            subs.push_back({r0, lo, (int64_t)wo[(size_t)r0], (int64_t)wo[(size_t)lo] - (int64_t)wo[(size_t)r0], 0u});
+            subs.push_back({r0, lo, (int64_t)wo[(size_t)r0], (int64_t)wo[(size_t)lo] - (int64_t)wo[(size_t)r0], 0u, 0});
             r0 = lo;
         }
     }
@@ -861,22 +884,50 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
         sb.N = 0;
         const int slot = (int)(i & 1u);
         g->devctr2.reserve(DEVCTR_BYTES);
+        sb.total = 0;
         if (sb.nw > 0) {
-            g->prof_begin(sp);
+            const uint64_t ord0 = g->ordinal + (uint64_t)(sb.r0 - first);
             g->chunk_cnt.reserve(((size_t)sb.nw + 1) * 4); g->chunk_off.reserve(((size_t)sb.nw + 1) * 4);
-            RB_HIP(hipMemsetAsync(g->chunk_cnt.as<uint32_t>() + sb.nw, 0, 4, sp));
-            launch_count_windows(b, sb.w0, sb.nw, g->k, g->chunk_cnt.as<uint32_t>(), sp);
             g->temp2.reserve(scan_temp_bytes((size_t)sb.nw + 1));
-            exclusive_scan_u32(g->temp2.p, g->temp2.cap, g->chunk_cnt.as<uint32_t>(), g->chunk_off.as<uint32_t>(), (size_t)sb.nw + 1, sp);
-            RB_HIP(hipMemcpyAsync(&sb.N, g->chunk_off.as<uint32_t>() + sb.nw, 4, hipMemcpyDeviceToHost, sp));
-            g->prof_end("count_windows", sp);
-            RB_HIP(hipStreamSynchronize(sp));
-            if (sb.N) {
+            RB_HIP(hipMemsetAsync(g->chunk_cnt.as<uint32_t>() + sb.nw, 0, 4, sp));
+            if (use_npf) {
+                // pass 1: hash every window, ask the hot-k-mer cache whether the occurrence can matter
                 g->prof_begin(sp);
-                g->keys0.reserve((size_t)sb.N * 8); g->vals0.reserve((size_t)sb.N * 4);
-                launch_hash_windows(b, sb.w0, sb.nw, g->k, mode_hash, g->chunk_off.as<uint32_t>(), (uint32_t)sb.r0, pos_bits,
-                                    g->keys0.as<uint64_t>(), g->vals0.as<uint32_t>(), nullptr, nullptr, sp);
-                g->prof_end("hash_windows", sp);
+                g->chunk_mask.reserve(((size_t)sb.nw + 1) * 4);
+                g->npf_tot.reserve(2048);
+                RB_HIP(hipMemsetAsync(g->npf_tot.p, 0, 2048, sp));
+                FilterView fvp = g->view(ord0, pos_bits);
+                launch_filter_windows(b, sb.w0, sb.nw, g->k, mode_hash, (uint32_t)sb.r0, pos_bits, g->p.rng_seed, ord0, fvp.npf,
+                                      g->chunk_cnt.as<uint32_t>(), g->chunk_mask.as<uint32_t>(), g->npf_tot.as<uint32_t>(), sp);
+                exclusive_scan_u32(g->temp2.p, g->temp2.cap, g->chunk_cnt.as<uint32_t>(), g->chunk_off.as<uint32_t>(), (size_t)sb.nw + 1, sp);
+                uint32_t spread[16 * 32];
+                RB_HIP(hipMemcpyAsync(&sb.N, g->chunk_off.as<uint32_t>() + sb.nw, 4, hipMemcpyDeviceToHost, sp));
+                RB_HIP(hipMemcpyAsync(spread, g->npf_tot.p, sizeof spread, hipMemcpyDeviceToHost, sp));
+                g->prof_end("filter_windows", sp);
+                RB_HIP(hipStreamSynchronize(sp));
+                for (int q = 0; q < 32; ++q) sb.total += spread[16 * q];
+                if (sb.N) {
+                    g->prof_begin(sp);
+                    g->keys0.reserve((size_t)sb.N * 8); g->vals0.reserve((size_t)sb.N * 4);
+                    launch_hash_windows_masked(b, sb.w0, sb.nw, g->k, mode_hash, g->chunk_off.as<uint32_t>(), g->chunk_mask.as<uint32_t>(),
+                                               (uint32_t)sb.r0, pos_bits, g->keys0.as<uint64_t>(), g->vals0.as<uint32_t>(), sp);
+                    g->prof_end("hash_windows", sp);
+                }
+            } else {
+                g->prof_begin(sp);
+                launch_count_windows(b, sb.w0, sb.nw, g->k, g->chunk_cnt.as<uint32_t>(), sp);
+                exclusive_scan_u32(g->temp2.p, g->temp2.cap, g->chunk_cnt.as<uint32_t>(), g->chunk_off.as<uint32_t>(), (size_t)sb.nw + 1, sp);
+                RB_HIP(hipMemcpyAsync(&sb.N, g->chunk_off.as<uint32_t>() + sb.nw, 4, hipMemcpyDeviceToHost, sp));
+                g->prof_end("count_windows", sp);
+                RB_HIP(hipStreamSynchronize(sp));
+                sb.total = sb.N;
+                if (sb.N) {
+                    g->prof_begin(sp);
+                    g->keys0.reserve((size_t)sb.N * 8); g->vals0.reserve((size_t)sb.N * 4);
+                    launch_hash_windows(b, sb.w0, sb.nw, g->k, mode_hash, g->chunk_off.as<uint32_t>(), (uint32_t)sb.r0, pos_bits,
+                                        g->keys0.as<uint64_t>(), g->vals0.as<uint32_t>(), nullptr, nullptr, sp);
+                    g->prof_end("hash_windows", sp);
+                }
             }
         }
         group_enqueue(g, slot, sb.N, g->ordinal + (uint64_t)(sb.r0 - first), pos_bits, sp, g->temp2, g->devctr2);
@@ -900,7 +951,7 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
         run_core(g, subs[i].N, D, mode, g->ordinal + (uint64_t)(subs[i].r0 - first), pos_bits, stats);
         RB_HIP(hipStreamSynchronize(s));               // slot may be refilled after this
         if (serial && i + 1 < subs.size()) prepare(i + 1);
-        if (stats) { stats->kmers += subs[i].N; stats->reads += subs[i].r1 - subs[i].r0; }
+        if (stats) { stats->kmers += subs[i].total; stats->reads += subs[i].r1 - subs[i].r0; }
     }
     g->ordinal += (uint64_t)n;
     RB_HIP(hipStreamSynchronize(s));
@@ -967,6 +1018,17 @@ int rb_graph_create(const rb_graph_params *p, rb_graph **out) {
         RB_HIP(hipMalloc(&g->cbf, g->cbf_alloc));
         RB_HIP(hipMemset(g->cbf, 0, g->cbf_alloc));
         if (p->use_read_paired_kmers) alloc_bits(g->rpk, p->pkbf_bits, p->pkbf_num_hash, 0, p->pkbf_bits);
+        {   // no-op prefilter cache: one 8-byte entry per ~16 counters, 2^16..2^26 entries
+            const char *e = getenv("RB_NPF");
+            uint32_t l2 = log2_ceil((uint64_t)std::max<int64_t>(p->cbf_bytes / 16, 1));
+            l2 = std::max(16u, std::min(26u, l2));
+            if (e) l2 = (uint32_t)atoi(e);
+            if (l2 >= 8 && l2 <= 30) {
+                g->npf.reserve(sizeof(uint64_t) << l2);
+                RB_HIP(hipMemset(g->npf.p, 0, sizeof(uint64_t) << l2));
+                g->npf_log2 = l2;
+            }
+        }
         RB_HIP(hipDeviceSynchronize());
         *out = g;
     });
@@ -993,7 +1055,7 @@ int rb_graph_destroy(rb_graph *g) {
     if (g->stream2) (void)hipStreamDestroy(g->stream2);
     for (auto e : g->prof_pool) (void)hipEventDestroy(e);
     for (auto &sl : g->slots) { sl.keys1.release(); sl.vals1.release(); sl.tz.release(); sl.uniq.release(); sl.counts.release(); sl.starts.release(); }
-    g->temp2.release(); g->devctr2.release();
+    g->temp2.release(); g->devctr2.release(); g->npf.release(); g->chunk_mask.release(); g->npf_tot.release();
     delete g;
     return RB_OK;
 }
@@ -1006,6 +1068,7 @@ int rb_graph_clear(rb_graph *g, unsigned which_mask) {
         if ((which_mask & 2u) && g->cbf) RB_HIP(hipMemsetAsync(g->cbf, 0, g->cbf_alloc, g->stream));
         if ((which_mask & 4u) && g->rpk.bits) RB_HIP(hipMemsetAsync(g->rpk.bits, 0, g->rpk.alloc, g->stream));
         if ((which_mask & 8u) && g->fpk.bits) RB_HIP(hipMemsetAsync(g->fpk.bits, 0, g->fpk.alloc, g->stream));
+        if ((which_mask & 3u) && g->npf_log2) RB_HIP(hipMemsetAsync(g->npf.p, 0, sizeof(uint64_t) << g->npf_log2, g->stream));   // cache entries speak about dbgbf + cbf
         if ((which_mask & 3u) == 3u) g->ordinal = 0;
         RB_HIP(hipStreamSynchronize(g->stream));
     });
@@ -1281,6 +1344,7 @@ int rb_filter_import(rb_graph *g, int which, const void *srcp, size_t nbytes) {
                 RB_REQUIRE(!(b[i] & 0x80u), "rb_filter_import: counter byte %zu is %u (> 127, not a MiniFloat count)", i, (unsigned)b[i]);
         }
         RB_HIP(hipStreamSynchronize(g->stream));
+        if (g->npf_log2 && (which == RB_CBF || which == RB_DBGBF)) RB_HIP(hipMemset(g->npf.p, 0, sizeof(uint64_t) << g->npf_log2));
         RB_HIP(hipMemset(dst, 0, alloc));
         RB_HIP(hipMemcpy(dst, srcp, have, hipMemcpyHostToDevice));
         RB_HIP(hipDeviceSynchronize());

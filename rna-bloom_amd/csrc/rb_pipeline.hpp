@@ -33,6 +33,7 @@ struct FilterView {
     uint64_t seed;        // rng seed
     uint64_t ordinal0;    // op ordinal of occurrence value 0
     uint32_t pos_bits;    // occurrence value = (read_rel << pos_bits) | pos
+    Npf npf;              // no-op prefilter cache (tab == nullptr: off)
 };
 
 // open-addressing table slot: key (empty = ~0) + 64-bit payload (identity of atomicMin = ~0)
@@ -242,6 +243,11 @@ static __global__ void __launch_bounds__(64) k_cbf_heavy(FilterView fv, const ui
                 cfinal[d] = out;
             } else
                 for (int j = 0; j < fv.cbf_h; ++j) fv.cbf[idx[j]] = (uint8_t)c[j];   // clears the claim mark too
+            if (fv.npf.tab && (st & ST_ALLPRE)) {   // remember how hard this k-mer has become to increment
+                uint32_t mn = c[0];
+                for (int j = 1; j < fv.cbf_h; ++j) mn = c[j] < mn ? c[j] : mn;
+                if (mn >= 16u) npf_store(fv.npf, h0, (mn >> 3) - 1u);
+            }
         }
     }
 }
@@ -285,6 +291,9 @@ struct rb_graph {
     DevBuf &counts() { return slots[cur].counts; }
     DevBuf &starts() { return slots[cur].starts; }
     DevBuf temp2, devctr2;
+    // no-op prefilter
+    DevBuf npf, chunk_mask, npf_tot;
+    uint32_t npf_log2 = 0;
     // scratch (grow-only)
     DevBuf chunk_cnt, chunk_off, keys0, vals0, status, nops, temp,
         ftable, ctable, heavy, confk, conf_sizes, conf_off, opk0, opk1, opv0, opv1, label, kk0, kk1, biglist, cvals, foreign, devctr, qbuf0, qbuf1, qbuf2, qbuf3;
@@ -308,6 +317,8 @@ struct rb_graph {
         fv.dbg = dbg.bits; fv.dbg_mod = dbg.mod; fv.dbg_h = dbg.num_hash;
         fv.cbf = cbf; fv.cbf_mod = cbf_mod; fv.cbf_h = cbf_h;
         fv.kmul = kmul_of(k); fv.seed = p.rng_seed; fv.ordinal0 = ordinal0; fv.pos_bits = pos_bits;
+        fv.npf.tab = npf_log2 ? reinterpret_cast<unsigned long long *>(npf.p) : nullptr;
+        fv.npf.log2n = npf_log2;
         return fv;
     }
     void prof_begin(hipStream_t st = nullptr) {

@@ -144,6 +144,33 @@ def test_grouping_prefix_does_not_change_results(group_bits):
     assert og.cbf_bytes().max() > 16
 
 
+def test_noop_prefilter_many_sub_batches():
+    # deep coverage + tiny sub-batches: the hot-k-mer cache is filled by early sub-batches and drops
+    # provably ineffective occurrences of later ones; results must not move
+    (ls, lq, off), (rs, rq, _) = make_reads(8000, 3000, 0.001, 1e-3, seed=91, uniform=True)
+    og, gg = graph_pair(100_003, 170_003, 20_011, max_batch=40_000)
+    og.set_read_pair_distance(115); gg.setReadPairedKmerDistance(115)
+    so = og.add_reads(ls, lq, off, 3, rbo.STORE_READ_PAIRS)
+    sg = gg.addReads(ls, lq, off, 3, storeReadPairedKmers=True)
+    assert sg.kmers == so.kmers and sg.pairs == so.pairs
+    assert_same_state(og, gg)
+    so = og.add_reads(rs, rq, off, 3, rbo.STORE_READ_PAIRS | rbo.REVCOMP)
+    sg = gg.addReads(rs, rq, off, 3, reverseComplement=True, storeReadPairedKmers=True)
+    assert sg.kmers == so.kmers
+    assert_same_state(og, gg)
+    assert og.cbf_bytes().max() > 40
+    # incrementIfPresent path goes through the same prefilter
+    so = og.add_reads(ls, lq, off, 3, rbo.COUNT_IF_PRESENT)
+    sg = gg.addReads(ls, lq, off, 3, incrementIfPresent=True)
+    assert sg.kmers == so.kmers
+    assert_same_state(og, gg)
+    # clearing must invalidate the cache
+    og.clear(); gg.clearAllBf()
+    og.add_reads(rs[: off[500]], rq[: off[500]], off[:501], 3, 0)
+    gg.addReads(rs[: off[500]], rq[: off[500]], off[:501], 3)
+    assert_same_state(og, gg, pairs=False)
+
+
 def test_batch_partition_independence():
     (ls, lq, off), _ = make_reads(1500, 10000, 0.002, 1e-3, seed=5)
     _, g1 = graph_pair(200_003, 900_001, 20_011)
