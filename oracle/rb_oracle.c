@@ -196,14 +196,21 @@ void rbo_variant(uint64_t f, uint64_t r, unsigned char_out, unsigned char_in, in
 /* -------------------------------------------------------- MiniFloat + RNG ---- */
 
 /* Shared counter-based generator replacing the reference's unseeded Math.random()
- * (R/util/MiniFloat.java:34).  splitmix64 finaliser over (seed, ordinal, pos); 31 uniform bits. */
+ * (R/util/MiniFloat.java:34): splitmix64 over (seed, op ordinal) folded to 32 bits, then murmur3
+ * fmix32 with the position in the read; 31 uniform bits.  Mirrors csrc/rb_device.hpp rng31. */
 uint32_t rbo_rng31(uint64_t seed, uint64_t ordinal, uint32_t pos) {
-    uint64_t z = seed ^ (ordinal * 0x9E3779B97F4A7C15ULL) ^ ((uint64_t)pos * 0xC2B2AE3D27D4EB4FULL);
+    /* per-op part: one splitmix64 round folded to 32 bits */
+    uint64_t z = seed ^ (ordinal * 0x9E3779B97F4A7C15ULL);
     z += 0x9E3779B97F4A7C15ULL;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
     z ^= z >> 31;
-    return (uint32_t)(z >> 33);
+    uint32_t x = ((uint32_t)(z >> 32) ^ (uint32_t)z) ^ (pos * 0x9E3779B1u);
+    /* per-position part: murmur3 fmix32 */
+    x ^= x >> 16; x *= 0x85EBCA6Bu;
+    x ^= x >> 13; x *= 0xC2B2AE35u;
+    x ^= x >> 16;
+    return x >> 1;
 }
 /* MiniFloat.increment R/util/MiniFloat.java:31-38.  Java bytes are signed; counters live in
  * 0..127.  `(int)(random()*Integer.MAX_VALUE) % (1 << ((b>>3)-1)) == 0` becomes

@@ -394,7 +394,7 @@ k_filter_windows_fast(const uint64_t *__restrict__ codes, const uint32_t *__rest
                       const uint32_t *__restrict__ word_read, const uint32_t *__restrict__ woff,
                       const uint32_t *__restrict__ len, int64_t w0, int64_t nw, int k, uint32_t first_read,
                       uint32_t pos_bits, uint64_t seed, uint64_t ordinal0, Npf cache, uint32_t *__restrict__ cnt,
-                      uint32_t *__restrict__ keepmask, uint32_t *__restrict__ total_spread) {
+                      uint32_t *__restrict__ keepmask, uint32_t *__restrict__ total_spread, uint32_t dbg_flags) {
     __shared__ uint64_t s_tf[25], s_tr[25];
     const uint32_t uk = (uint32_t)k;
     if (threadIdx.x < 25) {
@@ -418,7 +418,7 @@ k_filter_windows_fast(const uint64_t *__restrict__ codes, const uint32_t *__rest
             const uint32_t nb = ((b0 + 32u + uk - 1u < L) ? b0 + 32u + uk - 1u : L) - b0;
             uint64_t f = 0, rv = 0, hc = 0, hv = 0;
             uint32_t run = 0;
-            const uint64_t ordinal = ordinal0 + (uint64_t)(r - first_read);
+            const uint32_t rstate = rng_read_state(seed, ordinal0 + (uint64_t)(r - first_read));
             const uint32_t sh_c = 2u * (uk - 1u), sh_v = uk - 1u;
             for (uint32_t j = 0; j < nb; ++j) {
                 const uint32_t code = (uint32_t)clo & 3u, ok = (uint32_t)vs & 1u;
@@ -433,9 +433,9 @@ k_filter_windows_fast(const uint64_t *__restrict__ codes, const uint32_t *__rest
                 if (run >= uk) {
                     const uint32_t p = b0 + j + 1u - uk;
                     const uint64_t h0 = (MODE == 0) ? f : (MODE == 2) ? rv : canonical(f, rv);
-                    const uint32_t s_known = npf_lookup(cache, h0);
+                    const uint32_t s_known = (dbg_flags & 1u) ? 0u : npf_lookup(cache, h0);
                     bool keep = true;
-                    if (s_known) keep = draw_strength(rng31(seed, ordinal, p)) >= s_known;
+                    if (s_known && !(dbg_flags & 2u)) keep = draw_strength(rng_pos(rstate, p)) >= s_known;
                     ++total;
                     if (keep) { ++kept; mask |= 1u << (p - b0); }
                 }
@@ -490,10 +490,11 @@ void launch_filter_windows(const rb_batch *b, int64_t w0, int64_t nw, int k, int
                            uint32_t pos_bits, uint64_t seed, uint64_t ordinal0, Npf cache, uint32_t *cnt, uint32_t *keepmask,
                            uint32_t *total_spread, hipStream_t s) {
     if (nw <= 0) return;
+    const uint32_t dbgf = getenv("RB_FILT_DBG") ? (uint32_t)atoi(getenv("RB_FILT_DBG")) : 0u;
     dim3 g(blocks_for(nw, 64)), t(64);
 #define RB_LAUNCH_FILT(M)                                                                                    \
     hipLaunchKernelGGL(k_filter_windows_fast<M>, g, t, 0, s, b->codes, b->valid, b->word_read, b->woff, b->len, \
-                       w0, nw, k, first_read, pos_bits, seed, ordinal0, cache, cnt, keepmask, total_spread)
+                       w0, nw, k, first_read, pos_bits, seed, ordinal0, cache, cnt, keepmask, total_spread, dbgf)
     if (mode == 0) RB_LAUNCH_FILT(0); else if (mode == 2) RB_LAUNCH_FILT(2); else RB_LAUNCH_FILT(1);
 #undef RB_LAUNCH_FILT
 }

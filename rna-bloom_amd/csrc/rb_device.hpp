@@ -79,13 +79,25 @@ __device__ __forceinline__ uint64_t index_of(uint64_t h, const Mod &m) { return 
 
 // shared counter-based generator (see oracle/rb_oracle.c rbo_rng31): 31 uniform bits from
 // (seed, op ordinal, position in read)
-__host__ __device__ __forceinline__ uint32_t rng31(uint64_t seed, uint64_t ordinal, uint32_t pos) {
-    uint64_t z = seed ^ (ordinal * 0x9E3779B97F4A7C15ull) ^ ((uint64_t)pos * 0xC2B2AE3D27D4EB4Full);
+__host__ __device__ __forceinline__ uint32_t rng_read_state(uint64_t seed, uint64_t ordinal) {
+    // per-op (per-read) part: one splitmix64 round, folded to 32 bits — hoisted out of per-window loops
+    uint64_t z = seed ^ (ordinal * 0x9E3779B97F4A7C15ull);
     z += 0x9E3779B97F4A7C15ull;
     z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
     z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
     z ^= z >> 31;
-    return (uint32_t)(z >> 33);
+    return (uint32_t)(z >> 32) ^ (uint32_t)z;
+}
+__host__ __device__ __forceinline__ uint32_t rng_pos(uint32_t read_state, uint32_t pos) {
+    // per-window part: murmur3 fmix32 over (state, position) — 32-bit multiplies only
+    uint32_t x = read_state ^ (pos * 0x9E3779B1u);
+    x ^= x >> 16; x *= 0x85EBCA6Bu;
+    x ^= x >> 13; x *= 0xC2B2AE35u;
+    x ^= x >> 16;
+    return x >> 1;                                   // 31 uniform bits
+}
+__host__ __device__ __forceinline__ uint32_t rng31(uint64_t seed, uint64_t ordinal, uint32_t pos) {
+    return rng_pos(rng_read_state(seed, ordinal), pos);
 }
 // MiniFloat.increment R/util/MiniFloat.java:31-38 on counter bytes 0..127; rnd31 replaces
 // (int)(Math.random()*Integer.MAX_VALUE).  Returns the byte after the attempt.
@@ -105,8 +117,9 @@ __host__ __device__ __forceinline__ float minifloat_to_float(uint32_t b) {
 }
 
 // ---- no-op prefilter cache (DESIGN.md §3 "no-op prefilter") ----
-// Direct-mapped table of 8-byte entries keyed by the FULL 64-bit base hash: p = h0 * C (C odd, a
-// bijection on 64 bits); slot = top L bits of p; entry = (low 64-L bits of p) << 4 | s.  An entry
+// Direct-mapped table of 8-byte entries keyed by the FULL 64-bit base hash: slot = low L bits of h0
+// (ntHash bits are all equally mixed; the signed canonical minimum only skews the TOP bits),
+// entry = (h0 >> L) << 4 | s — slot and tag together are all 64 bits, so a match is exact.  An entry
 // asserts "this k-mer is in dbgbf and the exponent (min_counter>>3)-1 of its counting-Bloom minimum
 // is >= s" — counters only grow, so a stale entry stays true.  An occurrence whose draw strength is
 // below s cannot change any counter and may be dropped before sorting.
@@ -114,23 +127,21 @@ struct Npf {
     unsigned long long *tab;   // nullptr => disabled
     uint32_t log2n;            // 16..27
 };
-__host__ __device__ __forceinline__ uint64_t npf_mix(uint64_t h0) { return h0 * 0x9E3779B97F4A7C15ull; }
 __device__ __forceinline__ uint32_t npf_lookup(const Npf &c, uint64_t h0) {       // 0 = unknown
-    const uint64_t p = npf_mix(h0);
-    const uint64_t e = c.tab[p >> (64u - c.log2n)];
-    const uint64_t low = p & ((1ull << (64u - c.log2n)) - 1ull);
-    return ((e >> 4) == low) ? (uint32_t)(e & 15ull) : 0u;
+    const uint64_t e = c.tab[h0 & ((1ull << c.log2n) - 1ull)];
+    return ((e >> 4) == (h0 >> c.log2n)) ? (uint32_t)(e & 15ull) : 0u;
 }
 __device__ __forceinline__ void npf_store(const Npf &c, uint64_t h0, uint32_t s) { // s in 1..14; 8-byte store: never torn
-    const uint64_t p = npf_mix(h0);
-    const uint64_t low = p & ((1ull << (64u - c.log2n)) - 1ull);
-    c.tab[p >> (64u - c.log2n)] = (low << 4) | (uint64_t)s;
+    c.tab[h0 & ((1ull << c.log2n) - 1ull)] = ((h0 >> c.log2n) << 4) | (uint64_t)s;
 }
 // trailing-zero strength of a draw, capped at 15 (see k_strength)
 __host__ __device__ __forceinline__ uint32_t draw_strength(uint32_t rnd31) {
-    uint32_t r = rnd31 | 0x8000u, n = 0;
-    while (!(r & 1u)) { r >>= 1; ++n; }
-    return n;
+    const uint32_t r = rnd31 | 0x8000u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__ffs((int)r) - 1u;
+#else
+    return (uint32_t)__builtin_ctz(r);
+#endif
 }
 
 // bit filters are addressed as 32-bit little-endian words: bit i -> word i>>5, mask 1<<(i&31),
