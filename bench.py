@@ -29,11 +29,16 @@ HBM_PEAK_GBS = 8000.0           # MI355X spec HBM3E bandwidth (MI355X_MICROARCH.
 SECTOR = 64                     # bytes moved per random probe (SURVEY.md §8(d) sector model; matches FETCH_SIZE)
 
 
-def algorithmic_bytes(stage, n_kmers, n_pairs, n_runs, words, group_bits=32, h=2):
+def algorithmic_bytes(stage, n_kmers, n_pairs, n_runs, words, n_sorted=None, group_bits=32, h=2):
     """ALGORITHMIC bytes one step moves in each pipeline stage.
-    n_kmers = k-mer occurrences, n_pairs = paired k-mers, n_runs = distinct runs, words = 32-base words."""
+    n_kmers = k-mer occurrences, n_sorted = occurrences that survive the no-op prefilter,
+    n_pairs = paired k-mers, n_runs = distinct runs, words = 32-base words."""
     passes = -(-group_bits // 8)
+    n_all = n_kmers
+    n_kmers = n_sorted if n_sorted is not None else n_kmers
     model = {
+        # prefilter: packed reads in (16 B/word), one 64 B cache sector per window, count + mask out (8 B/word)
+        "filter_windows": words * 24 + n_all * SECTOR,
         # 8-bit onesweep: one histogram read of the keys + per pass (8 B key + 4 B value) in and out
         "sort_occurrences": n_kmers * (8 + passes * 2 * 12),
         # packed reads in (8 B codes + 4 B validity + 4 B owner per word), (h0, occurrence) out
@@ -137,13 +142,14 @@ def main():
     g.profileGet(reset=True)
     barrier()
     t0 = time.perf_counter()
-    kmers = pairs_ins = distinct = conflict = 0
+    kmers = pairs_ins = distinct = conflict = n_sorted = 0
     for _ in range(a.steps):
         s1, s2 = step()
         kmers += s1.kmers + s2.kmers
         pairs_ins += s1.pairs + s2.pairs
         distinct += s1.distinct + s2.distinct
         conflict += s1.conflict_ops + s2.conflict_ops
+        n_sorted += getattr(s1, "sorted_kmers", s1.kmers) + getattr(s2, "sorted_kmers", s2.kmers)
     barrier()
     dt = time.perf_counter() - t0
     if sharded_mode:
@@ -167,11 +173,11 @@ def main():
         words = 2 * pairs_rank * 5 * a.steps
         per_stage = {}
         for name, (ms, launches) in prof.items():
-            ab = algorithmic_bytes(name, kmers, pairs_ins, distinct, words)
+            ab = algorithmic_bytes(name, kmers, pairs_ins, distinct, words, n_sorted)
             if ab and ms > 0:
                 per_stage[name] = round(ab / (ms * 1e-3) / 1e9, 1)
         if dom_launches:
-            ab = algorithmic_bytes(dom_name, kmers, pairs_ins, distinct, words)
+            ab = algorithmic_bytes(dom_name, kmers, pairs_ins, distinct, words, n_sorted)
             if ab:
                 achieved = ab / (dom_ms * 1e-3) / 1e9      # = bytes per launch / average launch duration
                 roof = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
@@ -188,7 +194,7 @@ def main():
                        % (pairs_total // 1_000_000, k, a.fpr, a.nk),
                        "pairs": pairs_total, "genome_bases": a.genome, "dbgbf_bits": dbg_bits, "cbf_bytes": cbf_bytes,
                        "rpkbf_bits": pk_bits, "kmers_per_step": kmers_all // a.steps,
-                       "read_pairs_per_step": pairs_ins // a.steps, "distinct_per_step": distinct // a.steps,
+                       "read_pairs_per_step": pairs_ins // a.steps, "distinct_per_step": distinct // a.steps, "sorted_kmers_per_step": n_sorted // a.steps,
                        "conflict_ops_per_step": conflict // a.steps, "parallelism": ("single GPU" if not sharded_mode else "filters index-sharded x%d, k-mers hash-sharded, RCCL all_to_all" % world)},
             "stages_ms_per_step": {n: round(v[0] / a.steps, 2) for n, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
             "roofline": roof,

@@ -72,6 +72,7 @@ typedef struct rb_add_stats {
     int64_t pairs;    /* graph.addReadSingleKmerPair calls performed                */
     int64_t distinct; /* distinct k-mer hashes seen per sub-batch, summed           */
     int64_t conflict_ops; /* ops replayed in order because they shared a counter with another k-mer */
+    int64_t sorted_kmers; /* occurrences that survived the no-op prefilter and were grouped (<= kmers) */
 } rb_add_stats;
 
 const char *rb_last_error(void); /* thread-local message of the last failing call */

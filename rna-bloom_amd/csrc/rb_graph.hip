@@ -951,7 +951,7 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
         run_core(g, subs[i].N, D, mode, g->ordinal + (uint64_t)(subs[i].r0 - first), pos_bits, stats);
         RB_HIP(hipStreamSynchronize(s));               // slot may be refilled after this
         if (serial && i + 1 < subs.size()) prepare(i + 1);
-        if (stats) { stats->kmers += subs[i].total; stats->reads += subs[i].r1 - subs[i].r0; }
+        if (stats) { stats->kmers += subs[i].total; stats->sorted_kmers += subs[i].N; stats->reads += subs[i].r1 - subs[i].r0; }
     }
     g->ordinal += (uint64_t)n;
     RB_HIP(hipStreamSynchronize(s));

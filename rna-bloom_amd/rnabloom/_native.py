@@ -30,7 +30,7 @@ class GraphParams(C.Structure):
 
 class AddStats(C.Structure):
     _fields_ = [("reads", C.c_int64), ("kmers", C.c_int64), ("pairs", C.c_int64),
-                ("distinct", C.c_int64), ("conflict_ops", C.c_int64)]
+                ("distinct", C.c_int64), ("conflict_ops", C.c_int64), ("sorted_kmers", C.c_int64)]
 
 
 class SynthParams(C.Structure):
