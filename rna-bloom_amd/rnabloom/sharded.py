@@ -244,13 +244,13 @@ def run_distributed(gen, group=None):
 
 def plan(max_len, k, count, max_batch_kmers=1 << 30):
     """(pos_bits, reads per rank per sub-batch) so that a global sub-batch stays within the limits.
-    Per rank a sub-batch is capped at 2^28 k-mers: exchange buffers (torch) and library scratch both
+    Per rank a sub-batch is capped at 2^27 k-mers: exchange buffers (torch) and library scratch both
     scale with it."""
     pos_bits = 1
     while (1 << pos_bits) <= max_len:
         pos_bits += 1
     per_read = max(1, max_len)
-    reads = max(1, min(max_batch_kmers // count, 1 << 28) // per_read)
+    reads = max(1, min(max_batch_kmers // count, 1 << 27) // per_read)   # 8-byte keys: < 2^31 bytes per exchange
     reads = min(reads, ((1 << (32 - pos_bits)) - 1) // count)
     return pos_bits, max(1, reads)
 

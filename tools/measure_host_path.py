@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive rate of the drop-in boundary: rb_graph_add_reads() handed HOST ASCII buffers
+(upload + GPU-side 2-bit encode + insert), vs the resident-batch rate bench.py reports."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "rna-bloom_amd")]
+import numpy as np
+from rnabloom import _native as N
+from rnabloom.graph import BloomFilterDeBruijnGraph, ReadBatch
+
+pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
+nk = 450_000_000 * pairs // 50_000_000
+size = N.lib.rb_expected_size(nk, 0.01, 2)
+b = ReadBatch.synthetic(pairs, 64_000_000 * pairs // 50_000_000, seed=0x5EED)
+seq, off = b.download(0, pairs)                     # left reads as host ASCII ('N' where unusable)
+qual = np.full(seq.size, ord("I"), np.uint8)
+g = BloomFilterDeBruijnGraph(size, size, size, 2, 2, 2, 25, False, True, rngSeed=1)
+g.setReadPairedKmerDistance(115)
+chunk = 2_000_000                                   # reads per rb_graph_add_reads call
+for rep in range(2):
+    g.clearAllBf()
+    t0 = time.perf_counter(); km = 0
+    for a in range(0, pairs, chunk):
+        e = min(pairs, a + chunk)
+        st = g.addReads(seq[off[a]:off[e]], qual[off[a]:off[e]], off[a:e + 1] - off[a], 3, storeReadPairedKmers=True)
+        km += st.kmers
+    dt = time.perf_counter() - t0
+g.clearAllBf()
+t0 = time.perf_counter()
+st = g.addBatch(b, storeReadPairedKmers=True, first=0, n=pairs)
+dr = time.perf_counter() - t0
+print("host ASCII path (seq+qual %.2f GB over PCIe, %d reads per call): %.2f G k-mers/s (%.2f s for %d k-mers)"
+      % (2 * seq.size / 1e9, chunk, km / dt / 1e9, dt, km))
+print("same reads, batch already resident in HBM: %.2f G k-mers/s" % (st.kmers / dr / 1e9))
