@@ -138,6 +138,8 @@ def main():
 
     for _ in range(a.warmup):
         step()
+    if sharded_mode and os.environ.get("RB_SHARD_TRACE"):
+        sharded.TRACE = {}
     g.profileEnable(True)   # HIP events on the library's own stream, around every stage launch
     g.profileGet(reset=True)
     barrier()
@@ -199,6 +201,8 @@ def main():
             "stages_ms_per_step": {n: round(v[0] / a.steps, 2) for n, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
             "roofline": roof,
         }
+        if sharded_mode and sharded.TRACE is not None:
+            out["shard_phase_ms_per_step"] = {kk: round(v / a.steps, 1) for kk, v in sorted(sharded.TRACE.items(), key=lambda kv: -kv[1])}
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a, batch, dbg_bits, cbf_bytes, pk_bits, dist_pk)
         print(json.dumps(out))

@@ -216,26 +216,36 @@ int rb_strobemers(int device, const char *seq, const int64_t *offsets, int64_t n
  * per global sub-batch (every rank, lock step):
  *   hash      local reads -> (h0, occ) records bucketed by k-mer owner, pair probes by rpkbf owner
  *   [all_to_all records, pair probes]
- *   group     received records -> runs -> Bloom-bit / counter requests bucketed by filter owner
+ *   group     received records -> no-op prefilter -> runs -> Bloom-bit / counter requests bucketed by
+ *             filter owner
  *   [all_to_all requests]
  *   serve     owner: bit tests + first-setter arbitration + bit sets, counter claims, pair bit sets
  *   [all_to_all replies back]
- *   resolve   found flags, op counts, counter updates of runs that own their counters alone
+ *   resolve   found flags, op counts, counter updates of runs that own their counters alone; for the
+ *             runs that share a counter: the (run, contested counter) edges
  *   [all_to_all counter writes]     apply_writes
- *   [all_gather conflict ops + counters]   conflict_replay (every rank replays the same small set)
+ *   [all_gather edges]
+ *   conflict_route    components of the edge graph (same on every rank); each rank sends its
+ *             conflicting runs + their pending occurrence ids to the rank owning the component
+ *   [all_to_all runs, ops]
+ *   conflict_replay   ordered replay of whole components on a private counter table
+ *   [all_to_all final counter bytes]   apply_writes
  */
 enum {
-    RB_SLOT_REC_KEYS = 0,   /* u64 h0, bucketed by k-mer owner          */
-    RB_SLOT_REC_OCC = 1,    /* u32 occurrence ids (same order)          */
-    RB_SLOT_PAIR_IDX = 2,   /* u64 global rpkbf bit indices, by owner   */
-    RB_SLOT_DREQ_IDX = 3,   /* u64 global dbgbf bit index               */
-    RB_SLOT_DREQ_PROBE = 4, /* u64 (occ_first << 4 | probe)             */
-    RB_SLOT_CREQ_IDX = 5,   /* u64 global counter index                 */
-    RB_SLOT_W_IDX = 6,      /* u64 global counter index                 */
-    RB_SLOT_W_VAL = 7,      /* u8 new byte, 0xFF = just drop the claim  */
-    RB_SLOT_CONF_OPS = 8,   /* 16 B records {u32 occ, u32 kind, u64 h0} */
-    RB_SLOT_CONF_CTR = 9,   /* 16 B records {u64 global index, u64 value} */
-    RB_SLOT_COUNT = 10
+    RB_SLOT_REC_KEYS = 0,    /* u64 h0, bucketed by k-mer owner          */
+    RB_SLOT_REC_OCC = 1,     /* u32 occurrence ids (same order)          */
+    RB_SLOT_PAIR_IDX = 2,    /* u64 global rpkbf bit indices, by owner   */
+    RB_SLOT_DREQ_IDX = 3,    /* u64 global dbgbf bit index               */
+    RB_SLOT_DREQ_PROBE = 4,  /* u64 (occ_first << 4 | probe)             */
+    RB_SLOT_CREQ_IDX = 5,    /* u64 global counter index                 */
+    RB_SLOT_W_IDX = 6,       /* u64 global counter index                 */
+    RB_SLOT_W_VAL = 7,       /* u8 new byte, 0xFF = just drop the claim  */
+    RB_SLOT_CONF_EDGES = 8,  /* 16 B {u64 counter index, u32 run id, u32 0}; run id = local number * count + rank */
+    RB_SLOT_CONF_RUNS = 9,   /* 24 B {u64 h0, u64 counter bytes, u32 component, u32 n_ops | kinds << 28}, by component owner */
+    RB_SLOT_CONF_OPS = 10,   /* u32 occurrence ids of those runs, run after run */
+    RB_SLOT_CW_IDX = 11,     /* u64 global counter index (replayed components) */
+    RB_SLOT_CW_VAL = 12,     /* u8 final byte                            */
+    RB_SLOT_COUNT = 13
 };
 int rb_graph_create_shard(const rb_graph_params *p, int shard_rank, int shard_count, rb_graph **out);
 int rb_shard_hash(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, uint32_t read_rel_base,
@@ -246,11 +256,17 @@ int rb_shard_serve(rb_graph *g, int mode, const void *dreq_idx_dev, const void *
                    const void *creq_idx_dev, int64_t nc, const void *pair_idx_dev, int64_t np,
                    void *dreply_dev /* u8[nd] */, void *creply_dev /* u8[nc] */);
 int rb_shard_resolve(rb_graph *g, int mode, const void *dreply_dev, const void *creply_dev, int64_t *w_counts,
-                     int64_t *n_conf_ops, int64_t *n_conf_ctr, rb_add_stats *stats);
+                     int64_t *n_conf_runs, int64_t *n_conf_edges, rb_add_stats *stats);
 int rb_shard_apply_writes(rb_graph *g, const void *w_idx_dev, const void *w_val_dev, int64_t n);
-int rb_shard_conflict_replay(rb_graph *g, const void *ops_dev, int64_t n_ops, const void *ctr_dev, int64_t n_ctr);
-/* copy an internal slot (bucketed by destination) into a caller-owned device buffer */
+/* edges_dev: the edges of ALL ranks (rank order); gid_bound > every run id in them */
+int rb_shard_conflict_route(rb_graph *g, const void *edges_dev, int64_t n_edges, int64_t gid_bound, int64_t *run_counts,
+                            int64_t *op_counts, rb_add_stats *stats);
+int rb_shard_conflict_replay(rb_graph *g, const void *runs_dev, int64_t n_runs, const void *ops_dev, int64_t n_ops,
+                             int64_t *w_counts);
+/* an internal slot (bucketed by destination): copy it out, or borrow the device pointer (valid until
+ * the phase that fills the slot runs again) */
 int rb_shard_take(rb_graph *g, int slot, void *dst_dev, int64_t nbytes);
+int rb_shard_slot(rb_graph *g, int slot, void **dev_ptr, int64_t *nbytes);
 int rb_shard_span(rb_graph *g, int which, int64_t *span, int64_t *lo, int64_t *hi);
 
 /* ---- instrumentation: per-kernel-class HIP-event timing on the library's own stream ---- */

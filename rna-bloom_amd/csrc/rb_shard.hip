@@ -5,12 +5,14 @@
 //   requester = owner of a k-mer (top log2 G bits of its hash): holds all occurrences of its k-mers
 //               in order, decides found-flags / op counts / counter updates;
 //   owner     = owner of a filter index range: tests & sets bits, arbitrates first setters, hands
-//               out counter claims, stores counter bytes.
+//               out counter claims, stores counter bytes;
+//   component owner = rank that replays one connected component of the "runs that share a counter"
+//               graph in global occurrence order (the rank holding the component's smallest run id).
 //
 // Exactness argument is unchanged: first-setter arbitration happens at the bit's owner over ALL
 // probes of the sub-batch; claim marks and the conflict set live at the counter's owner; runs whose
-// counters nobody else claimed commute; everything else is replayed in global occurrence order —
-// here by every rank redundantly on a private compact copy of the (few) contested counters.
+// counters nobody else claimed commute; everything else is replayed in global occurrence order by
+// exactly one rank per component, on a private table of that component's counters.
 #include "rb_pipeline.hpp"
 
 using namespace rb;
@@ -20,19 +22,21 @@ struct ShardState {
     int64_t span[4] = {0, 0, 0, 0};            // per filter (RB_DBGBF..RB_FPKBF)
     DevBuf slot[RB_SLOT_COUNT];
     size_t slot_bytes[RB_SLOT_COUNT] = {0};
-    // requester-side state carried from group -> resolve
-    uint32_t D = 0;
+    // requester-side state carried from group -> resolve -> conflict_route
+    uint32_t D = 0, n_conf = 0;
+    uint64_t n_kept = 0;                        // records that survived the prefilter in the last group()
     uint64_t ordinal0 = 0;
     uint32_t pos_bits = 0;
-    DevBuf dreq_pos, creq_pos;                 // [D*h] position of (run, probe) in the bucketed request order (~0 = none)
+    DevBuf dreq_pos, creq_pos;                 // [D*h] position of (run, probe) in the bucketed request order
     DevBuf creq_dup;                           // [D*h] for a duplicated counter: the earlier probe it copies
     DevBuf cfinal, conf_list;
     // routing scratch
-    DevBuf rkey0, rkey1, rval0, rval1, stage0, stage1, stage2, bounds;
+    DevBuf stage0, stage1, stage2, stage3, rhist, roffs, bounds;
     // owner-side scratch
-    DevBuf own_f, own_cs, own_foreign;
-    // conflict replay scratch
-    DevBuf ck0, ck1, cv0, cv1, cuniq, ccnt, cstart, cval, oslots, olabel, okey0, okey1, oval0, oval1;
+    DevBuf own_f, own_cs;
+    // conflict path scratch
+    DevBuf esz, eoff, etab, eslot, elabel, cdesc, cpos, cnops, cnoff;
+    DevBuf rk0, rk1, ok0, ok1, ov0, ov1, rtab, rslot, rbig;
 };
 
 namespace {
@@ -55,13 +59,106 @@ void *slot_reserve(ShardState *S, int slot, size_t bytes) {
 }
 
 // ---------------------------------------------------------------- routing ----
-__global__ void k_dest_keys(const uint64_t *__restrict__ idx, const uint8_t *__restrict__ drop, size_t n, uint64_t span,
-                            uint32_t G, uint64_t *__restrict__ key, uint64_t *__restrict__ val) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    key[i] = (drop && drop[i]) ? (uint64_t)G : idx[i] / span;
-    val[i] = i;
+// Stable multi-way partition of n items into G destination buckets in two passes over the items
+// (count, scatter).  A tile is 2048 items: 4 wavefronts x 8 rows of 64 consecutive items; ranks inside
+// a row come from ballots, row bases from a 32-row prefix per destination, tile bases from a global
+// exclusive scan over the [destination][tile] histogram.  No sort, no permutation gather.
+constexpr int RT_TPB = 256, RT_IPT = 8, RT_TILE = RT_TPB * RT_IPT;
+
+template <class F, bool SCATTER>
+__global__ void __launch_bounds__(RT_TPB) k_route(F f, size_t n, uint32_t G, uint32_t nb, uint32_t *__restrict__ hist_or_offs) {
+    __shared__ uint32_t s_cnt[4 * RT_IPT][64];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t r = threadIdx.x; r < 4u * RT_IPT * 64u; r += RT_TPB) (&s_cnt[0][0])[r] = 0u;
+    __syncthreads();
+    int dst[RT_IPT];
+    uint32_t rank[RT_IPT];
+    const size_t base = (size_t)blockIdx.x * RT_TILE + (size_t)wave * (64u * RT_IPT);
+#pragma unroll
+    for (int q = 0; q < RT_IPT; ++q) {
+        const size_t i = base + (size_t)q * 64u + lane;
+        const int d = (i < n) ? f.dest(i) : -1;
+        dst[q] = d; rank[q] = 0;
+        unsigned long long pending = __ballot(d >= 0);
+        while (pending) {
+            const int leader = __ffsll((long long)pending) - 1;
+            const int dl = __shfl(d, leader, 64);
+            const unsigned long long m = __ballot(d == dl);
+            if (d == dl) rank[q] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if ((int)lane == leader) s_cnt[wave * RT_IPT + q][dl] = (uint32_t)__popcll(m);
+            pending &= ~m;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < G) {
+        uint32_t run = SCATTER ? hist_or_offs[(size_t)threadIdx.x * nb + blockIdx.x] : 0u;
+        for (int r = 0; r < 4 * RT_IPT; ++r) { const uint32_t c = s_cnt[r][threadIdx.x]; s_cnt[r][threadIdx.x] = run; run += c; }
+        if (!SCATTER) hist_or_offs[(size_t)threadIdx.x * nb + blockIdx.x] = run;
+    }
+    if (!SCATTER) return;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < RT_IPT; ++q) {
+        const size_t i = base + (size_t)q * 64u + lane;
+        if (i >= n) continue;
+        if (dst[q] >= 0) f.emit(i, s_cnt[wave * RT_IPT + q][dst[q]] + rank[q]);
+        else f.drop(i);
+    }
 }
+__global__ void k_pick_bounds(const uint32_t *__restrict__ offs, uint32_t G, uint32_t nb, uint64_t *__restrict__ bounds) {
+    uint32_t g = threadIdx.x;
+    if (g <= G) bounds[g] = offs[(size_t)g * nb];
+}
+// counts[G] <- items per destination; `place(f, kept)` points the functor at its outputs once the
+// totals are known.  Returns the number of items kept.
+template <class F, class P>
+size_t route(rb_graph *g, F f, size_t n, int64_t *counts, P place, int buckets = 0) {
+    ShardState *S = g->shard;
+    hipStream_t s = g->stream;
+    const int B = buckets ? buckets : S->G;
+    for (int r = 0; r < B; ++r) counts[r] = 0;
+    if (n == 0) { place(f, (size_t)0); return 0; }
+    RB_REQUIRE(n < (1ull << 32), "route: too many items (%zu)", n);
+    const uint32_t nb = (uint32_t)((n + RT_TILE - 1) / RT_TILE);
+    const size_t nh = (size_t)B * nb + 1;
+    S->rhist.reserve(nh * 4); S->roffs.reserve(nh * 4); S->bounds.reserve(2 * (S->G + 2) * 8);
+    RB_HIP(hipMemsetAsync(S->rhist.as<uint32_t>() + (nh - 1), 0, 4, s));
+    hipLaunchKernelGGL((k_route<F, false>), dim3(nb), dim3(RT_TPB), 0, s, f, n, (uint32_t)B, nb, S->rhist.as<uint32_t>());
+    g->temp.reserve(scan_temp_bytes(nh));
+    exclusive_scan_u32(g->temp.p, g->temp.cap, S->rhist.as<uint32_t>(), S->roffs.as<uint32_t>(), nh, s);
+    hipLaunchKernelGGL(k_pick_bounds, dim3(1), dim3(128), 0, s, S->roffs.as<uint32_t>(), (uint32_t)B, nb, S->bounds.as<uint64_t>());
+    std::vector<uint64_t> b(B + 1);
+    RB_HIP(hipMemcpyAsync(b.data(), S->bounds.p, (B + 1) * 8, hipMemcpyDeviceToHost, s));
+    RB_HIP(hipStreamSynchronize(s));
+    for (int r = 0; r < B; ++r) counts[r] = (int64_t)(b[r + 1] - b[r]);
+    const size_t kept = (size_t)b[B];
+    place(f, kept);
+    hipLaunchKernelGGL((k_route<F, true>), dim3(nb), dim3(RT_TPB), 0, s, f, n, (uint32_t)B, nb, S->roffs.as<uint32_t>());
+    return kept;
+}
+// ordered compaction of the received records by the prefilter's verdicts (one bucket)
+struct RouteKeep {
+    const uint8_t *keep; const uint64_t *keys; const uint32_t *occ;
+    uint64_t *out_keys; uint32_t *out_occ;
+    __device__ int dest(size_t i) const { return keep[i] ? 0 : -1; }
+    __device__ void emit(size_t i, uint32_t pos) const { out_keys[pos] = keys[i]; out_occ[pos] = occ[i]; }
+    __device__ void drop(size_t) const {}
+};
+// the common case: items are global filter indices staged in an array, destination = index / span
+struct RouteIdx {
+    const uint64_t *idx; const uint8_t *drop_flag; uint64_t span;
+    const uint64_t *pay64; const uint8_t *pay8;             // optional payload columns
+    uint64_t *out_idx, *out64; uint8_t *out8; uint32_t *pos_of;
+    __device__ int dest(size_t i) const { return (drop_flag && drop_flag[i]) ? -1 : (int)(idx[i] / span); }
+    __device__ void emit(size_t i, uint32_t pos) const {
+        out_idx[pos] = idx[i];
+        if (pay64) out64[pos] = pay64[i];
+        if (pay8) out8[pos] = pay8[i];
+        if (pos_of) pos_of[i] = pos;
+    }
+    __device__ void drop(size_t i) const { if (pos_of) pos_of[i] = 0xFFFFFFFFu; }
+};
+
 // bounds[g] = first position whose key >= g, for g = 0..G (keys sorted ascending)
 __global__ void k_bounds(const uint64_t *__restrict__ key, size_t n, uint32_t G, uint32_t shift, uint64_t *__restrict__ bounds) {
     uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
@@ -70,58 +167,32 @@ __global__ void k_bounds(const uint64_t *__restrict__ key, size_t n, uint32_t G,
     while (lo < hi) { size_t mid = (lo + hi) >> 1; if ((key[mid] >> shift) < g) lo = mid + 1; else hi = mid; }
     bounds[g] = lo;
 }
-template <typename T>
-__global__ void k_gather(const T *__restrict__ src, const uint64_t *__restrict__ perm, size_t n, T *__restrict__ dst) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) dst[i] = src[perm[i]];
-}
-__global__ void k_inverse(const uint64_t *__restrict__ perm, size_t n_all, size_t n_kept, uint32_t *__restrict__ pos_of) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_all) pos_of[perm[i]] = i < n_kept ? (uint32_t)i : 0xFFFFFFFFu;
-}
-
-// Sort n items by destination = idx/span (dropped items last).  Leaves the permutation in
-// S->rval1 (u64 original positions) and per-destination counts in counts[G]; returns items kept.
-size_t route(rb_graph *g, const uint64_t *idx, const uint8_t *drop, size_t n, int64_t span, int64_t *counts) {
-    ShardState *S = g->shard;
-    hipStream_t s = g->stream;
-    for (int r = 0; r < S->G; ++r) counts[r] = 0;
-    if (n == 0) return 0;
-    S->rkey0.reserve(n * 8); S->rkey1.reserve(n * 8); S->rval0.reserve(n * 8); S->rval1.reserve(n * 8);
-    S->bounds.reserve((S->G + 2) * 8);
-    hipLaunchKernelGGL(k_dest_keys, dim3(blocks_for((int64_t)n)), dim3(TPB), 0, s, idx, drop, n, (uint64_t)span, (uint32_t)S->G,
-                       S->rkey0.as<uint64_t>(), S->rval0.as<uint64_t>());
-    g->temp.reserve(sort_pairs32_temp_bytes(n));
-    sort_pairs_u64_u64(g->temp.p, g->temp.cap, S->rkey0.as<uint64_t>(), S->rkey1.as<uint64_t>(), S->rval0.as<uint64_t>(),
-                       S->rval1.as<uint64_t>(), n, 0, S->log2G + 1, s);
-    hipLaunchKernelGGL(k_bounds, dim3(1), dim3(128), 0, s, S->rkey1.as<uint64_t>(), n, (uint32_t)S->G, 0u, S->bounds.as<uint64_t>());
-    std::vector<uint64_t> b(S->G + 1);
-    RB_HIP(hipMemcpyAsync(b.data(), S->bounds.p, (S->G + 1) * 8, hipMemcpyDeviceToHost, s));
-    RB_HIP(hipStreamSynchronize(s));
-    for (int r = 0; r < S->G; ++r) counts[r] = (int64_t)(b[r + 1] - b[r]);
-    return (size_t)b[S->G];
-}
-template <typename T> void gather_to(rb_graph *g, const T *src, size_t n, T *dst) {
-    if (!n) return;
-    hipLaunchKernelGGL(k_gather<T>, dim3(blocks_for((int64_t)n)), dim3(TPB), 0, g->stream, src, g->shard->rval1.as<uint64_t>(), n, dst);
-}
 
 // ------------------------------------------------------------- requester ----
+// no-op prefilter verdict per received record: keep unless the cache knows the k-mer
+// is in dbgbf with a counter exponent the occurrence's draw cannot beat
+__global__ void k_rec_keep(FilterView fv, const uint64_t *__restrict__ keys, const uint32_t *__restrict__ occ, size_t n,
+                           uint8_t *__restrict__ keep) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t s = npf_lookup(fv.npf, keys[i]);
+    keep[i] = (!s || draw_strength(occ_rnd(fv, occ[i])) >= s) ? 1u : 0u;
+}
 // per run: one Bloom-bit request per probe, one claim request per DISTINCT counter
 __global__ void k_make_requests(FilterView fv, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ starts,
                                 const uint32_t *__restrict__ vals, uint32_t D, int mode,
-                                uint64_t *__restrict__ d_idx, uint64_t *__restrict__ d_probe, uint8_t *__restrict__ d_drop,
+                                uint64_t *__restrict__ d_idx, uint64_t *__restrict__ d_probe,
                                 uint64_t *__restrict__ c_idx, uint8_t *__restrict__ c_drop, uint8_t *__restrict__ c_dup) {
     uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= D) return;
     const uint64_t h0 = uniq[d];
     const unsigned long long v_first = vals[starts[d]];
-    for (int j = 0; j < fv.dbg_h; ++j) {
-        const size_t q = (size_t)d * fv.dbg_h + j;
-        d_idx[q] = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.dbg_mod);
-        d_probe[q] = (v_first << 4) | (unsigned long long)j;
-        d_drop[q] = mode == M_COUNT_ONLY;
-    }
+    if (mode != M_COUNT_ONLY)
+        for (int j = 0; j < fv.dbg_h; ++j) {
+            const size_t q = (size_t)d * fv.dbg_h + j;
+            d_idx[q] = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.dbg_mod);
+            d_probe[q] = (v_first << 4) | (unsigned long long)j;
+        }
     uint64_t cidx[RB_MAX_HASH];
     for (int j = 0; j < fv.cbf_h; ++j) {
         const size_t q = (size_t)d * fv.cbf_h + j;
@@ -134,12 +205,15 @@ __global__ void k_make_requests(FilterView fv, const uint64_t *__restrict__ uniq
     }
 }
 
+// status bits 21..28: probes whose counter is claimed by another run of the sub-batch too
+constexpr uint32_t ST_CONTESTED_SHIFT = 21;
+
 __global__ void k_resolve_shard(FilterView fv, const uint32_t *__restrict__ counts, const uint32_t *__restrict__ starts,
                                 uint32_t D, int mode, uint32_t light_ops, const uint32_t *__restrict__ dreq_pos,
                                 const uint8_t *__restrict__ dreply, const uint32_t *__restrict__ creq_pos,
                                 const uint8_t *__restrict__ c_dup, const uint8_t *__restrict__ creply,
-                                const uint8_t *__restrict__ tz, uint32_t *__restrict__ status, uint32_t *__restrict__ nops,
-                                uint64_t *__restrict__ cvals, uint64_t *__restrict__ cfinal) {
+                                const uint8_t *__restrict__ tz, const uint64_t *__restrict__ uniq, uint32_t *__restrict__ status,
+                                uint32_t *__restrict__ nops, uint64_t *__restrict__ cvals, uint64_t *__restrict__ cfinal) {
     uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= D) return;
     const uint32_t m = counts[d];
@@ -158,7 +232,7 @@ __global__ void k_resolve_shard(FilterView fv, const uint32_t *__restrict__ coun
     else if (mode == M_ADD) ops = (all_pre || found_first) ? m : m - 1u;
     else { ops = m; kfirst = (all_pre || found_first) ? K_INC_IF_ZERO : K_INC; krest = K_INC_IF_ZERO; }
     uint32_t c[RB_MAX_HASH];
-    bool conflict = false;
+    uint32_t contested = 0;
     uint64_t cv = 0;
     for (int j = 0; j < fv.cbf_h; ++j) {
         const size_t q = (size_t)d * fv.cbf_h + j;
@@ -167,21 +241,26 @@ __global__ void k_resolve_shard(FilterView fv, const uint32_t *__restrict__ coun
         else {
             const uint8_t r = creply[creq_pos[q]];
             c[j] = r & 0x7Fu;
-            conflict |= (r & 0x80u) != 0;
+            if (r & 0x80u) contested |= 1u << j;
         }
         cv |= (uint64_t)c[j] << (8 * j);
     }
     cvals[d] = cv;
-    uint32_t st = premask | (all_pre ? ST_ALLPRE : 0u) | (kfirst << 12) | (krest << 14);
+    uint32_t st = premask | (all_pre ? ST_ALLPRE : 0u) | (kfirst << 12) | (krest << 14) | (contested << ST_CONTESTED_SHIFT);
     nops[d] = ops;
     if (ops == 0) { status[d] = st | RUN_RELEASE; return; }
-    if (conflict) { status[d] = st | RUN_CONFLICT; return; }
+    if (contested) { status[d] = st | RUN_CONFLICT; return; }
     if (ops > light_ops) { status[d] = st | RUN_WRITES | RUN_HEAVY; return; }
     status[d] = st | RUN_WRITES;
     run_ops(c, fv.cbf_h, kfirst, krest, tz, starts[d] + m - ops, ops);
     uint64_t out = 0;
     for (int j = 0; j < fv.cbf_h; ++j) out |= (uint64_t)c[j] << (8 * j);
     cfinal[d] = out;
+    if (fv.npf.tab && mode != M_COUNT_ONLY) {   // the k-mer is in dbgbf now; remember its counter exponent
+        uint32_t mn = c[0];
+        for (int j = 1; j < fv.cbf_h; ++j) mn = c[j] < mn ? c[j] : mn;
+        if (mn >= 16u) npf_store(fv.npf, uniq[d], (mn >> 3) - 1u);
+    }
 }
 __global__ void k_emit_writes(FilterView fv, const uint64_t *__restrict__ uniq, uint32_t D, const uint32_t *__restrict__ status,
                               const uint8_t *__restrict__ c_dup, const uint64_t *__restrict__ cfinal,
@@ -198,42 +277,90 @@ __global__ void k_emit_writes(FilterView fv, const uint64_t *__restrict__ uniq, 
         w_drop[q] = !send;
     }
 }
-struct ConfOp { uint32_t occ, kind; uint64_t h0; };
-struct ConfCtr { uint64_t idx, val; };
-__global__ void k_conf_sizes(const uint32_t *__restrict__ conf_list, const uint32_t *__restrict__ nops, uint32_t n, uint32_t *__restrict__ sizes) {
+
+// ---- conflict path, requester side: edges of the (run, contested counter) graph ----
+struct ConfEdge { uint64_t cidx; uint32_t gid, pad; };          // gid = local conflict-run number * G + rank
+struct ConfRun { uint64_t h0, cv; uint32_t label, nops_kinds; }; // nops | kfirst << 28 | krest << 30
+constexpr uint32_t NOPS_MASK = 0x0FFFFFFFu;
+
+__global__ void k_conf_sizes(const uint32_t *__restrict__ conf_list, const uint32_t *__restrict__ status, uint32_t n,
+                             uint32_t *__restrict__ esz) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) sizes[i] = nops[conf_list[i]];
-    if (i == n) sizes[i] = 0;
+    if (i < n) esz[i] = (uint32_t)__popc((status[conf_list[i]] >> ST_CONTESTED_SHIFT) & 0xFFu);
+    if (i == n) esz[i] = 0;
 }
-__global__ void k_conf_export(FilterView fv, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ counts,
-                              const uint32_t *__restrict__ starts, const uint32_t *__restrict__ vals,
-                              const uint32_t *__restrict__ status, const uint32_t *__restrict__ nops,
-                              const uint64_t *__restrict__ cvals, const uint8_t *__restrict__ c_dup,
-                              const uint32_t *__restrict__ conf_list, const uint32_t *__restrict__ conf_off, uint32_t n_conf,
-                              ConfOp *__restrict__ ops_out, ConfCtr *__restrict__ ctr_out) {
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
-    if (wave >= n_conf) return;
-    const uint32_t d = conf_list[wave];
-    const uint32_t ops = nops[d], st = status[d];
+__global__ void k_conf_edges(FilterView fv, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ conf_list,
+                             const uint32_t *__restrict__ status, const uint32_t *__restrict__ eoff, uint32_t n, uint32_t G,
+                             uint32_t rank, ConfEdge *__restrict__ out) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t d = conf_list[i];
     const uint64_t h0 = uniq[d];
-    const uint32_t base = starts[d] + counts[d] - ops, out = conf_off[wave];
-    for (uint32_t i = lane; i < ops; i += 64u) {
-        ConfOp o;
-        o.occ = vals[base + i];
-        o.kind = i == 0 ? (st >> 12) & 3u : (st >> 14) & 3u;
-        o.h0 = h0;
-        ops_out[out + i] = o;
+    uint32_t mask = (status[d] >> ST_CONTESTED_SHIFT) & 0xFFu, o = eoff[i];
+    while (mask) {
+        const int j = __ffs((int)mask) - 1;
+        mask &= mask - 1u;
+        ConfEdge e;
+        e.cidx = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod);
+        e.gid = i * G + rank; e.pad = 0;
+        out[o++] = e;
     }
-    if (lane == 0) {
-        const uint64_t cv = cvals[d];
-        for (int j = 0; j < fv.cbf_h; ++j) {   // fixed stride; a duplicated probe leaves a sentinel (index ~0)
-            ConfCtr c;
-            const bool dup = c_dup[(size_t)d * fv.cbf_h + j] != j;
-            c.idx = dup ? ~0ull : index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod);
-            c.val = dup ? 0ull : ((cv >> (8 * j)) & 0xFFu);
-            ctr_out[(size_t)wave * fv.cbf_h + j] = c;
-        }
-    }
+}
+// ---- components of the global edge list by min-label propagation (every rank, identical result) ----
+__global__ void k_edge_init(const ConfEdge *__restrict__ e, size_t n, Slot *tab, uint32_t log2cap, uint32_t *__restrict__ eslot,
+                            uint32_t *__restrict__ label) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    eslot[i] = (uint32_t)(table_insert(tab, log2cap, e[i].cidx) - tab);
+    label[e[i].gid] = e[i].gid;
+}
+__global__ void k_edge_push(const ConfEdge *__restrict__ e, size_t n, Slot *tab, const uint32_t *__restrict__ eslot,
+                            const uint32_t *__restrict__ label) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t l = __hip_atomic_load(&label[e[i].gid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    atomicMin(reinterpret_cast<uint32_t *>(&tab[eslot[i]].val), l);
+}
+__global__ void k_edge_pull(const ConfEdge *__restrict__ e, size_t n, const Slot *tab, const uint32_t *__restrict__ eslot,
+                            uint32_t *__restrict__ label, uint32_t *__restrict__ changed) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t l = __hip_atomic_load(reinterpret_cast<const uint32_t *>(&tab[eslot[i]].val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (atomicMin(&label[e[i].gid], l) > l) *changed = 1u;
+}
+__global__ void k_conf_desc(const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ conf_list, const uint32_t *__restrict__ status,
+                            const uint32_t *__restrict__ nops, const uint64_t *__restrict__ cvals, const uint32_t *__restrict__ label,
+                            uint32_t n, uint32_t G, uint32_t rank, ConfRun *__restrict__ desc) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t d = conf_list[i], st = status[d];
+    ConfRun r;
+    r.h0 = uniq[d]; r.cv = cvals[d];
+    r.label = label[i * G + rank];
+    r.nops_kinds = nops[d] | (((st >> 12) & 3u) << 28) | (((st >> 14) & 3u) << 30);
+    desc[i] = r;
+}
+struct RouteRuns {   // destination = rank of the component's smallest run id
+    const ConfRun *desc; uint32_t G;
+    ConfRun *out; uint32_t *pos_of, *nops_routed;
+    __device__ int dest(size_t i) const { return (int)(desc[i].label % G); }
+    __device__ void emit(size_t i, uint32_t pos) const { out[pos] = desc[i]; pos_of[i] = pos; nops_routed[pos] = desc[i].nops_kinds & NOPS_MASK; }
+    __device__ void drop(size_t) const {}
+};
+// one wavefront per conflicting run: its pending occurrence ids, in order, at the run's routed offset
+__global__ void k_conf_ops_out(const uint32_t *__restrict__ conf_list, const uint32_t *__restrict__ counts,
+                               const uint32_t *__restrict__ starts, const uint32_t *__restrict__ vals, const uint32_t *__restrict__ nops,
+                               const uint32_t *__restrict__ pos_of, const uint32_t *__restrict__ noff, uint32_t n,
+                               uint32_t *__restrict__ ops_out) {
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+    if (wave >= n) return;
+    const uint32_t d = conf_list[wave], ops = nops[d];
+    const uint32_t base = starts[d] + counts[d] - ops, out = noff[pos_of[wave]];
+    for (uint32_t i = lane; i < ops; i += 64u) ops_out[out + i] = vals[base + i];
+}
+__global__ void k_pick_u32(const uint32_t *__restrict__ a, const uint64_t *__restrict__ at, uint32_t n, uint64_t *__restrict__ out) {
+    uint32_t i = threadIdx.x;
+    if (i < n) out[i] = a[at[i]];
 }
 
 // ------------------------------------------------------------------ owner ----
@@ -283,73 +410,186 @@ __global__ void k_own_writes(uint8_t *cbf, uint64_t lo, const uint64_t *__restri
     if (val[i] == 0xFFu) cbf_release(cbf, idx[i] - lo); else cbf[idx[i] - lo] = val[i];
 }
 
-// -------------------------------------------------- distributed conflict replay ----
-__global__ void k_split_ctr(const ConfCtr *__restrict__ c, size_t n, uint64_t *__restrict__ k, uint64_t *__restrict__ v) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) { k[i] = c[i].idx; v[i] = c[i].val; }
-}
-__global__ void k_first_vals(const uint64_t *__restrict__ vals_sorted, const uint32_t *__restrict__ starts, uint32_t M, uint32_t *__restrict__ cval) {
+// ------------------------------------------ component owner: ordered replay ----
+__global__ void k_run_nops(const ConfRun *__restrict__ runs, uint32_t R, uint32_t *__restrict__ sizes, uint64_t *__restrict__ kk) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < M) cval[i] = (uint32_t)vals_sorted[starts[i]];
+    if (i < R) { sizes[i] = runs[i].nops_kinds & NOPS_MASK; kk[i] = ((uint64_t)runs[i].label << 32) | i; }
+    if (i == R) sizes[i] = 0;
 }
-__device__ __forceinline__ uint32_t find_u64(const uint64_t *a, uint32_t n, uint64_t key) {
+__global__ void k_run_expand(const ConfRun *__restrict__ runs, const uint32_t *__restrict__ noff, const uint32_t *__restrict__ occ,
+                             uint32_t R, uint64_t *__restrict__ op_key, uint32_t *__restrict__ op_val) {
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+    if (wave >= R) return;
+    const ConfRun r = runs[wave];
+    const uint32_t ops = r.nops_kinds & NOPS_MASK, o = noff[wave];
+    const uint64_t hi = (uint64_t)r.label << 32;
+    for (uint32_t i = lane; i < ops; i += 64u) {
+        op_key[o + i] = hi | occ[o + i];
+        op_val[o + i] = wave | ((i == 0 ? (r.nops_kinds >> 28) & 3u : r.nops_kinds >> 30) << 30);
+    }
+}
+// the component owner's private copy of every counter its runs touch: table slot <- pre-batch value
+__global__ void k_run_slots(FilterView fv, const ConfRun *__restrict__ runs, uint32_t R, Slot *tab, uint32_t log2cap,
+                            uint32_t *__restrict__ rslot) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R) return;
+    const ConfRun r = runs[i];
+    for (int j = 0; j < fv.cbf_h; ++j) {
+        Slot *s = table_insert(tab, log2cap, index_of(multi_hash(r.h0, (uint32_t)j, fv.kmul), fv.cbf_mod));
+        s->val = (r.cv >> (8 * j)) & 0xFFull;          // every claimer saw the same pre-batch byte
+        rslot[(size_t)i * fv.cbf_h + j] = (uint32_t)(s - tab);
+    }
+}
+__device__ __forceinline__ uint32_t lower_bound_u64(const uint64_t *a, uint32_t n, uint64_t key) {
     uint32_t lo = 0, hi = n;
     while (lo < hi) { uint32_t mid = (lo + hi) >> 1; if (a[mid] < key) lo = mid + 1; else hi = mid; }
     return lo;
 }
-__global__ void k_op_slots(FilterView fv, const ConfOp *__restrict__ ops, size_t n, const uint64_t *__restrict__ cuniq, uint32_t M,
-                           uint32_t *__restrict__ slots, uint32_t *__restrict__ label) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    for (int j = 0; j < fv.cbf_h; ++j) {
-        uint32_t s = find_u64(cuniq, M, index_of(multi_hash(ops[i].h0, (uint32_t)j, fv.kmul), fv.cbf_mod));
-        slots[i * fv.cbf_h + j] = s;
-        label[s] = s;
-    }
-}
-__global__ void k_op_labels(const uint32_t *__restrict__ slots, size_t n, int h, uint32_t *__restrict__ label, uint32_t *__restrict__ changed) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t m = 0xFFFFFFFFu;
-    for (int j = 0; j < h; ++j) { uint32_t l = __hip_atomic_load(&label[slots[i * h + j]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); m = l < m ? l : m; }
-    for (int j = 0; j < h; ++j) {
-        uint32_t old = atomicMin(&label[slots[i * h + j]], m);
-        if (old > m) *changed = 1u;
-    }
-}
-// labels may still point at a non-root after the loop converged pairwise; chase to the root
-__global__ void k_op_keys(const ConfOp *__restrict__ ops, const uint32_t *__restrict__ slots, size_t n, int h,
-                          const uint32_t *__restrict__ label, uint64_t *__restrict__ key, uint32_t *__restrict__ val) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t l = label[slots[i * h]];
-    while (label[l] != l) l = label[l];
-    key[i] = ((uint64_t)l << 32) | ops[i].occ;
-    val[i] = (uint32_t)i;
-}
-__global__ void k_conf_replay_sparse(FilterView fv, const ConfOp *__restrict__ ops, const uint32_t *__restrict__ slots,
-                                     const uint64_t *__restrict__ key, const uint32_t *__restrict__ order, size_t n,
-                                     uint32_t *__restrict__ cval) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t lab = (uint32_t)(key[i] >> 32);
-    if (i > 0 && (uint32_t)(key[i - 1] >> 32) == lab) return;       // not the first op of its component
-    for (size_t q = i; q < n && (uint32_t)(key[q] >> 32) == lab; ++q) {
-        const uint32_t o = order[q];
-        uint32_t c[RB_MAX_HASH], c0[RB_MAX_HASH];
-        for (int j = 0; j < fv.cbf_h; ++j) c0[j] = c[j] = *(volatile uint32_t *)&cval[slots[(size_t)o * fv.cbf_h + j]];
+__device__ void replay_serial_tab(const FilterView &fv, Slot *tab, const uint32_t *__restrict__ rslot, const uint64_t *__restrict__ op_key,
+                                  const uint32_t *__restrict__ op_val, uint32_t os, uint32_t oe) {
+    for (uint32_t i = os; i < oe; ++i) {
+        const uint32_t v = (uint32_t)op_key[i];
+        const uint32_t run = op_val[i] & 0x3FFFFFFFu, kind = op_val[i] >> 30;
+        uint32_t sl[RB_MAX_HASH], c[RB_MAX_HASH], c0[RB_MAX_HASH];
+        for (int j = 0; j < fv.cbf_h; ++j) {
+            sl[j] = rslot[(size_t)run * fv.cbf_h + j];
+            c0[j] = c[j] = (uint32_t) * (volatile unsigned long long *)&tab[sl[j]].val;
+        }
         uint32_t mn = c[0];
         for (int j = 1; j < fv.cbf_h; ++j) mn = c[j] < mn ? c[j] : mn;
-        cbf_step(c, fv.cbf_h, ops[o].kind, (mn >= 16u && mn < 127u) ? occ_rnd(fv, ops[o].occ) : 0u);
+        cbf_step(c, fv.cbf_h, kind, (mn >= 16u && mn < 127u) ? occ_rnd(fv, v) : 0u);
         for (int j = 0; j < fv.cbf_h; ++j)
-            if (c[j] != c0[j]) *(volatile uint32_t *)&cval[slots[(size_t)o * fv.cbf_h + j]] = c[j];
+            if (c[j] != c0[j]) *(volatile unsigned long long *)&tab[sl[j]].val = c[j];
     }
 }
-__global__ void k_conf_writeback(uint8_t *cbf, uint64_t lo, uint64_t hi, const uint64_t *__restrict__ cuniq, const uint32_t *__restrict__ cval, uint32_t M) {
+constexpr uint32_t SMALL_COMPONENT_OPS = 256;
+constexpr uint32_t MAX_COMPONENT_KMERS = 8;
+// one thread per run (sorted by component label): component heads either replay a small component
+// themselves or flag it for the wave-cooperative kernel
+__global__ void k_replay_small(FilterView fv, Slot *tab, const uint32_t *__restrict__ rslot, const uint64_t *__restrict__ run_keys,
+                               uint32_t R, const uint64_t *__restrict__ op_key, const uint32_t *__restrict__ op_val, uint32_t n_ops,
+                               uint32_t *__restrict__ big_flag) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= M) return;
-    const uint64_t idx = cuniq[i];
-    if (idx >= lo && idx < hi) cbf[idx - lo] = (uint8_t)cval[i];     // also clears the claim mark
+    if (i >= R) return;
+    big_flag[i] = 0;
+    const uint32_t lab = (uint32_t)(run_keys[i] >> 32);
+    if (i > 0 && (uint32_t)(run_keys[i - 1] >> 32) == lab) return;   // not a component head
+    const uint32_t os = lower_bound_u64(op_key, n_ops, (uint64_t)lab << 32);
+    const uint32_t oe = lower_bound_u64(op_key, n_ops, ((uint64_t)lab + 1ull) << 32);
+    if (oe - os > SMALL_COMPONENT_OPS) { big_flag[i] = 1u; return; }
+    replay_serial_tab(fv, tab, rslot, op_key, op_val, os, oe);
+}
+// one wavefront per large component: the component's counters live in LDS; 64 ops are examined at
+// a time against the current state and the chain hops from one state-changing op to the next
+__global__ void __launch_bounds__(64) k_replay_big(FilterView fv, Slot *tab, const uint32_t *__restrict__ rslot,
+                                    const ConfRun *__restrict__ runs, const uint64_t *__restrict__ run_keys, uint32_t R,
+                                    const uint64_t *__restrict__ op_key, const uint32_t *__restrict__ op_val, uint32_t n_ops,
+                                    const uint32_t *__restrict__ big_list, const uint32_t *__restrict__ n_big) {
+    __shared__ uint32_t s_tslot[MAX_COMPONENT_KMERS * RB_MAX_HASH];  // unique table slots
+    __shared__ uint32_t s_val[MAX_COMPONENT_KMERS * RB_MAX_HASH];    // their current bytes
+    __shared__ uint32_t s_val0[MAX_COMPONENT_KMERS * RB_MAX_HASH];
+    __shared__ uint32_t s_slot[MAX_COMPONENT_KMERS][RB_MAX_HASH];    // k-mer probe -> unique counter
+    __shared__ uint64_t s_h0[MAX_COMPONENT_KMERS];
+    __shared__ uint32_t s_run[MAX_COMPONENT_KMERS];                  // one run carrying that hash
+    __shared__ uint32_t s_nu, s_nk;
+    const uint32_t lane = threadIdx.x;
+    const int H = fv.cbf_h;
+    for (uint32_t bi = blockIdx.x; bi < *n_big; bi += gridDim.x) {
+        const uint32_t i0 = big_list[bi];
+        const uint32_t lab = (uint32_t)(run_keys[i0] >> 32);
+        const uint32_t i1 = lower_bound_u64(run_keys, R, ((uint64_t)lab + 1ull) << 32);   // runs [i0,i1)
+        const uint32_t os = lower_bound_u64(op_key, n_ops, (uint64_t)lab << 32);
+        const uint32_t oe = lower_bound_u64(op_key, n_ops, ((uint64_t)lab + 1ull) << 32);
+        // distinct hashes of the component (a hash split into many runs is still one k-mer)
+        __syncthreads();
+        if (lane == 0) s_nk = 0;
+        __syncthreads();
+        bool overflow = false;
+        for (uint32_t rb0 = i0; rb0 < i1 && !overflow; rb0 += 64u) {
+            const bool have = rb0 + lane < i1;
+            const uint32_t myrun = have ? (uint32_t)run_keys[rb0 + lane] : 0u;
+            const uint64_t h = have ? runs[myrun].h0 : 0ull;
+            unsigned long long pending = __ballot(have);
+            while (pending) {
+                const int leader = __ffsll((long long)pending) - 1;
+                const uint64_t hl = __shfl(h, leader, 64);
+                const uint32_t rl = __shfl(myrun, leader, 64);
+                pending &= ~__ballot(have && h == hl);
+                uint32_t q = 0, nkc = s_nk;
+                while (q < nkc && s_h0[q] != hl) ++q;
+                if (q == nkc) {
+                    if (nkc == MAX_COMPONENT_KMERS) { overflow = true; break; }
+                    __syncthreads();
+                    if (lane == 0) { s_h0[nkc] = hl; s_run[nkc] = rl; s_nk = nkc + 1u; }
+                    __syncthreads();
+                }
+            }
+        }
+        if (overflow) {                          // rare: many DIFFERENT k-mers in one component -> plain ordered replay
+            if (lane == 0) replay_serial_tab(fv, tab, rslot, op_key, op_val, os, oe);
+            continue;
+        }
+        const uint32_t nk = s_nk;
+        __syncthreads();
+        if (lane == 0) {                         // build the component's counter table (tiny)
+            uint32_t nu = 0;
+            for (uint32_t q = 0; q < nk; ++q)
+                for (int j = 0; j < H; ++j) {
+                    const uint32_t ts = rslot[(size_t)s_run[q] * H + j];
+                    uint32_t u = 0;
+                    while (u < nu && s_tslot[u] != ts) ++u;
+                    if (u == nu) { s_tslot[u] = ts; s_val0[u] = s_val[u] = (uint32_t)tab[ts].val; ++nu; }
+                    s_slot[q][j] = u;
+                }
+            s_nu = nu;
+        }
+        __syncthreads();
+        for (uint32_t base = os; base < oe; base += 64u) {
+            const uint32_t i = base + lane;
+            uint32_t q = 0, kind = 0, rnd = 0;
+            const bool live = i < oe;
+            if (live) {
+                const uint32_t ov = op_val[i];
+                const uint64_t h = runs[ov & 0x3FFFFFFFu].h0;
+                kind = ov >> 30;
+                while (q < nk && s_h0[q] != h) ++q;
+                rnd = occ_rnd(fv, (uint32_t)op_key[i]);
+            }
+            uint32_t cursor = 0;                 // ops below cursor are settled
+            while (cursor < 64u) {
+                bool changes = false;
+                if (live && lane >= cursor) {
+                    uint32_t mn = s_val[s_slot[q][0]];
+                    for (int j = 1; j < H; ++j) { uint32_t c = s_val[s_slot[q][j]]; mn = c < mn ? c : mn; }
+                    const bool gate = !((kind == K_INC_IF_POS && mn == 0u) || (kind == K_INC_IF_ZERO && mn != 0u));
+                    changes = gate && minifloat_inc(mn, rnd) != mn;
+                }
+                const unsigned long long win = __ballot(changes);
+                if (!win) break;
+                const uint32_t first = (uint32_t)__ffsll((long long)win) - 1u;
+                if (lane == first) {             // apply: every probe equal to the minimum moves up
+                    uint32_t mn = s_val[s_slot[q][0]];
+                    for (int j = 1; j < H; ++j) { uint32_t c = s_val[s_slot[q][j]]; mn = c < mn ? c : mn; }
+                    for (int j = 0; j < H; ++j) if (s_val[s_slot[q][j]] == mn) s_val[s_slot[q][j]] = mn + 1u;
+                }
+                __syncthreads();
+                cursor = first + 1u;
+            }
+            __syncthreads();
+        }
+        if (lane < s_nu && s_val[lane] != s_val0[lane]) tab[s_tslot[lane]].val = s_val[lane];
+        __syncthreads();
+    }
+}
+// every counter of the table goes back to its owner (the store also clears the claim mark)
+__global__ void k_tab_emit(const Slot *__restrict__ tab, size_t cap, uint64_t *__restrict__ idx, uint8_t *__restrict__ val,
+                           uint8_t *__restrict__ drop) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= cap) return;
+    const bool used = tab[i].key != ~0ull;
+    idx[i] = used ? tab[i].key : 0ull;
+    val[i] = (uint8_t)tab[i].val;
+    drop[i] = !used;
 }
 
 }  // namespace
@@ -400,6 +640,17 @@ int rb_graph_create_shard(const rb_graph_params *p, int shard_rank, int shard_co
             S->span[RB_RPKBF] = gp.span;
             alloc_bits(g->rpk, p->pkbf_bits, p->pkbf_num_hash, gp.lo, gp.hi);
         }
+        {   // no-op prefilter cache over this rank's k-mers (applied to the records it receives)
+            const char *e = getenv("RB_NPF");
+            uint32_t l2 = log2_ceil((uint64_t)std::max<int64_t>(p->cbf_bytes / 32 / shard_count, 1));
+            l2 = std::max(16u, std::min(28u, l2));
+            if (e) l2 = (uint32_t)atoi(e);
+            if (l2 >= 8 && l2 <= 30) {
+                g->npf.reserve(sizeof(uint64_t) << l2);
+                RB_HIP(hipMemset(g->npf.p, 0, sizeof(uint64_t) << l2));
+                g->npf_log2 = l2;
+            }
+        }
         RB_HIP(hipDeviceSynchronize());
         *out = g;
     });
@@ -431,6 +682,13 @@ int rb_shard_take(rb_graph *g, int slot, void *dst_dev, int64_t nbytes) {
     });
 }
 
+int rb_shard_slot(rb_graph *g, int slot, void **dev_ptr, int64_t *nbytes) {
+    if (!g || !g->shard || slot < 0 || slot >= RB_SLOT_COUNT || !dev_ptr || !nbytes) { set_error("rb_shard_slot: bad argument"); return RB_ERR_INVALID; }
+    *dev_ptr = g->shard->slot_bytes[slot] ? g->shard->slot[slot].p : nullptr;
+    *nbytes = (int64_t)g->shard->slot_bytes[slot];
+    return RB_OK;
+}
+
 int rb_shard_hash(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, uint32_t read_rel_base, uint32_t pos_bits,
                   unsigned flags, int64_t *rec_counts, int64_t *pair_counts) {
     return guarded([&] {
@@ -456,20 +714,19 @@ int rb_shard_hash(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, uint
         RB_HIP(hipMemcpyAsync(&N, g->chunk_off.as<uint32_t>() + nw, 4, hipMemcpyDeviceToHost, s));
         RB_HIP(hipStreamSynchronize(s));
         if (N) {
-            g->keys0.reserve((size_t)N * 8); g->vals0.reserve((size_t)N * 4);
-            // occ = (read_rel_base + r - first) << pos_bits | pos   (u32 wrap-around arithmetic)
-            launch_hash_windows(b, w0, nw, g->k, mode_hash, g->chunk_off.as<uint32_t>(), (uint32_t)first - read_rel_base, pos_bits,
-                                g->keys0.as<uint64_t>(), g->vals0.as<uint32_t>(), nullptr, nullptr, s);
             uint64_t *rk = (uint64_t *)slot_reserve(S, RB_SLOT_REC_KEYS, (size_t)N * 8);
             uint32_t *ro = (uint32_t *)slot_reserve(S, RB_SLOT_REC_OCC, (size_t)N * 4);
-            if (S->G == 1) {
-                RB_HIP(hipMemcpyAsync(rk, g->keys0.p, (size_t)N * 8, hipMemcpyDeviceToDevice, s));
-                RB_HIP(hipMemcpyAsync(ro, g->vals0.p, (size_t)N * 4, hipMemcpyDeviceToDevice, s));
+            if (S->G == 1) {   // occ = (read_rel_base + r - first) << pos_bits | pos   (u32 wrap-around arithmetic)
+                launch_hash_windows(b, w0, nw, g->k, mode_hash, g->chunk_off.as<uint32_t>(), (uint32_t)first - read_rel_base, pos_bits,
+                                    rk, ro, nullptr, nullptr, s);
                 rec_counts[0] = N;
             } else {   // stable 1-pass bucket by k-mer owner = top log2(G) hash bits
+                g->keys0.reserve((size_t)N * 8); g->vals0.reserve((size_t)N * 4);
+                launch_hash_windows(b, w0, nw, g->k, mode_hash, g->chunk_off.as<uint32_t>(), (uint32_t)first - read_rel_base, pos_bits,
+                                    g->keys0.as<uint64_t>(), g->vals0.as<uint32_t>(), nullptr, nullptr, s);
                 g->temp.reserve(sort_pairs_temp_bytes(N));
                 sort_pairs_u64_u32(g->temp.p, g->temp.cap, g->keys0.as<uint64_t>(), rk, g->vals0.as<uint32_t>(), ro, N, 64 - S->log2G, 64, s);
-                S->bounds.reserve((S->G + 2) * 8);
+                S->bounds.reserve(2 * (S->G + 2) * 8);
                 hipLaunchKernelGGL(k_bounds, dim3(1), dim3(128), 0, s, rk, (size_t)N, (uint32_t)S->G, (uint32_t)(64 - S->log2G), S->bounds.as<uint64_t>());
                 std::vector<uint64_t> bd(S->G + 1);
                 RB_HIP(hipMemcpyAsync(bd.data(), S->bounds.p, (S->G + 1) * 8, hipMemcpyDeviceToHost, s));
@@ -491,9 +748,8 @@ int rb_shard_hash(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, uint
                 unsigned long long *pc = reinterpret_cast<unsigned long long *>(g->devctr.as<uint32_t>() + 12);
                 RB_HIP(hipMemsetAsync(pc, 0, 8, s));
                 launch_pairs(g, b, w0, nw, mode_hash, g->chunk_off.as<uint32_t>(), S->stage0.as<uint64_t>(), pc);
-                size_t kept = route(g, S->stage0.as<uint64_t>(), nullptr, np, S->span[RB_RPKBF], pair_counts);
-                uint64_t *dst = (uint64_t *)slot_reserve(S, RB_SLOT_PAIR_IDX, kept * 8);
-                gather_to<uint64_t>(g, S->stage0.as<uint64_t>(), kept, dst);
+                RouteIdx f{S->stage0.as<uint64_t>(), nullptr, (uint64_t)S->span[RB_RPKBF], nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+                route(g, f, np, pair_counts, [&](RouteIdx &ff, size_t kept) { ff.out_idx = (uint64_t *)slot_reserve(S, RB_SLOT_PAIR_IDX, kept * 8); });
             }
         }
         RB_HIP(hipGetLastError());
@@ -510,37 +766,48 @@ int rb_shard_group(rb_graph *g, const void *keys_dev, const void *occ_dev, int64
         RB_HIP(hipSetDevice(g->p.device));
         hipStream_t s = g->stream;
         for (int r = 0; r < S->G; ++r) dreq_counts[r] = creq_counts[r] = 0;
-        S->D = 0; S->ordinal0 = ordinal0; S->pos_bits = pos_bits;
+        S->D = 0; S->n_conf = 0; S->n_kept = 0; S->ordinal0 = ordinal0; S->pos_bits = pos_bits;
         S->slot_bytes[RB_SLOT_DREQ_IDX] = S->slot_bytes[RB_SLOT_DREQ_PROBE] = S->slot_bytes[RB_SLOT_CREQ_IDX] = 0;
         if (n == 0) return;
         g->keys0.reserve((size_t)n * 8); g->vals0.reserve((size_t)n * 4);
-        RB_HIP(hipMemcpyAsync(g->keys0.p, keys_dev, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
-        RB_HIP(hipMemcpyAsync(g->vals0.p, occ_dev, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+        if (g->npf_log2 && (mode == M_ADD || mode == M_COUNT_IF_PRESENT)) {
+            // drop the occurrences whose draw cannot move a counter (exact: DESIGN.md §3 "no-op prefilter")
+            FilterView fv0 = g->view(ordinal0, pos_bits);
+            S->stage2.reserve((size_t)n + 16);
+            hipLaunchKernelGGL(k_rec_keep, dim3(blocks_for(n)), dim3(TPB), 0, s, fv0, (const uint64_t *)keys_dev, (const uint32_t *)occ_dev,
+                               (size_t)n, S->stage2.as<uint8_t>());
+            RouteKeep fk{S->stage2.as<uint8_t>(), (const uint64_t *)keys_dev, (const uint32_t *)occ_dev, g->keys0.as<uint64_t>(), g->vals0.as<uint32_t>()};
+            int64_t kept_c[1];
+            const size_t kept = route(g, fk, (size_t)n, kept_c, [](RouteKeep &, size_t) {}, 1);
+            S->n_kept = kept;
+            n = (int64_t)kept;
+            if (n == 0) return;
+        } else {
+            RB_HIP(hipMemcpyAsync(g->keys0.p, keys_dev, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
+            RB_HIP(hipMemcpyAsync(g->vals0.p, occ_dev, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+            S->n_kept = (uint64_t)n;
+        }
         const uint32_t D = group_records(g, (size_t)n, ordinal0, pos_bits, nullptr, nullptr);
         S->D = D;
         FilterView fv = g->view(ordinal0, pos_bits);
-        const size_t nd = (size_t)D * fv.dbg_h, nc = (size_t)D * fv.cbf_h;
-        S->stage0.reserve(nd * 8); S->stage1.reserve(nd * 8); S->stage2.reserve(nd + nc + 16);
-        DevBuf &cidx = S->cv0;   // reuse as staging for counter indices
-        cidx.reserve(nc * 8);
+        const size_t nd = mode == M_COUNT_ONLY ? 0 : (size_t)D * fv.dbg_h, nc = (size_t)D * fv.cbf_h;
+        S->stage0.reserve(nd * 8 + 16); S->stage1.reserve(nd * 8 + 16); S->stage3.reserve(nc * 8 + 16); S->stage2.reserve(nc + 16);
         S->creq_dup.reserve(nc + 16);
-        uint8_t *d_drop = S->stage2.as<uint8_t>(), *c_drop = d_drop + nd;
-        hipLaunchKernelGGL(k_make_requests, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, g->uniq().as<uint64_t>(), g->starts().as<uint32_t>(),
-                           g->vals1().as<uint32_t>(), D, mode, S->stage0.as<uint64_t>(), S->stage1.as<uint64_t>(), d_drop,
-                           cidx.as<uint64_t>(), c_drop, S->creq_dup.as<uint8_t>());
-        // Bloom-bit requests
         S->dreq_pos.reserve(nd * 4 + 16); S->creq_pos.reserve(nc * 4 + 16);
-        size_t kept = route(g, S->stage0.as<uint64_t>(), d_drop, nd, S->span[RB_DBGBF], dreq_counts);
-        uint64_t *di = (uint64_t *)slot_reserve(S, RB_SLOT_DREQ_IDX, kept * 8);
-        uint64_t *dp = (uint64_t *)slot_reserve(S, RB_SLOT_DREQ_PROBE, kept * 8);
-        gather_to<uint64_t>(g, S->stage0.as<uint64_t>(), kept, di);
-        gather_to<uint64_t>(g, S->stage1.as<uint64_t>(), kept, dp);
-        if (nd) hipLaunchKernelGGL(k_inverse, dim3(blocks_for((int64_t)nd)), dim3(TPB), 0, s, S->rval1.as<uint64_t>(), nd, kept, S->dreq_pos.as<uint32_t>());
-        // counter claims
-        kept = route(g, cidx.as<uint64_t>(), c_drop, nc, S->span[RB_CBF], creq_counts);
-        uint64_t *ci = (uint64_t *)slot_reserve(S, RB_SLOT_CREQ_IDX, kept * 8);
-        gather_to<uint64_t>(g, cidx.as<uint64_t>(), kept, ci);
-        if (nc) hipLaunchKernelGGL(k_inverse, dim3(blocks_for((int64_t)nc)), dim3(TPB), 0, s, S->rval1.as<uint64_t>(), nc, kept, S->creq_pos.as<uint32_t>());
+        hipLaunchKernelGGL(k_make_requests, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, g->uniq().as<uint64_t>(), g->starts().as<uint32_t>(),
+                           g->vals1().as<uint32_t>(), D, mode, S->stage0.as<uint64_t>(), S->stage1.as<uint64_t>(),
+                           S->stage3.as<uint64_t>(), S->stage2.as<uint8_t>(), S->creq_dup.as<uint8_t>());
+        // Bloom-bit requests (index + probe id), bucketed by bit owner
+        RouteIdx fd{S->stage0.as<uint64_t>(), nullptr, (uint64_t)S->span[RB_DBGBF], S->stage1.as<uint64_t>(), nullptr,
+                    nullptr, nullptr, nullptr, S->dreq_pos.as<uint32_t>()};
+        route(g, fd, nd, dreq_counts, [&](RouteIdx &ff, size_t kept) {
+            ff.out_idx = (uint64_t *)slot_reserve(S, RB_SLOT_DREQ_IDX, kept * 8);
+            ff.out64 = (uint64_t *)slot_reserve(S, RB_SLOT_DREQ_PROBE, kept * 8);
+        });
+        // counter claims, bucketed by counter owner
+        RouteIdx fc{S->stage3.as<uint64_t>(), S->stage2.as<uint8_t>(), (uint64_t)S->span[RB_CBF], nullptr, nullptr,
+                    nullptr, nullptr, nullptr, S->creq_pos.as<uint32_t>()};
+        route(g, fc, nc, creq_counts, [&](RouteIdx &ff, size_t kept) { ff.out_idx = (uint64_t *)slot_reserve(S, RB_SLOT_CREQ_IDX, kept * 8); });
         RB_HIP(hipGetLastError());
         RB_HIP(hipStreamSynchronize(s));
     });
@@ -599,16 +866,18 @@ int rb_shard_serve(rb_graph *g, int mode, const void *dreq_idx_dev, const void *
 }
 
 int rb_shard_resolve(rb_graph *g, int mode, const void *dreply_dev, const void *creply_dev, int64_t *w_counts,
-                     int64_t *n_conf_ops, int64_t *n_conf_ctr, rb_add_stats *stats) {
+                     int64_t *n_conf_runs, int64_t *n_conf_edges, rb_add_stats *stats) {
     return guarded([&] {
-        RB_REQUIRE(g && g->shard && w_counts && n_conf_ops && n_conf_ctr, "rb_shard_resolve: bad argument");
+        RB_REQUIRE(g && g->shard && w_counts && n_conf_runs && n_conf_edges, "rb_shard_resolve: bad argument");
         ShardState *S = g->shard;
         RB_HIP(hipSetDevice(g->p.device));
         hipStream_t s = g->stream;
         for (int r = 0; r < S->G; ++r) w_counts[r] = 0;
-        *n_conf_ops = *n_conf_ctr = 0;
-        S->slot_bytes[RB_SLOT_W_IDX] = S->slot_bytes[RB_SLOT_W_VAL] = S->slot_bytes[RB_SLOT_CONF_OPS] = S->slot_bytes[RB_SLOT_CONF_CTR] = 0;
+        *n_conf_runs = *n_conf_edges = 0;
+        S->n_conf = 0;
+        S->slot_bytes[RB_SLOT_W_IDX] = S->slot_bytes[RB_SLOT_W_VAL] = S->slot_bytes[RB_SLOT_CONF_EDGES] = 0;
         const uint32_t D = S->D;
+        if (stats) stats->sorted_kmers += (int64_t)S->n_kept;
         if (!D) return;
         FilterView fv = g->view(S->ordinal0, S->pos_bits);
         g->status.reserve((size_t)D * 4); g->nops.reserve((size_t)D * 4); g->cvals.reserve((size_t)D * 8);
@@ -618,8 +887,8 @@ int rb_shard_resolve(rb_graph *g, int mode, const void *dreply_dev, const void *
         RB_HIP(hipMemsetAsync(ctr, 0, DEVCTR_BYTES, s));
         hipLaunchKernelGGL(k_resolve_shard, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, g->counts().as<uint32_t>(), g->starts().as<uint32_t>(), D, mode,
                            g->light_ops, S->dreq_pos.as<uint32_t>(), (const uint8_t *)dreply_dev, S->creq_pos.as<uint32_t>(),
-                           S->creq_dup.as<uint8_t>(), (const uint8_t *)creply_dev, g->tz().as<uint8_t>(), g->status.as<uint32_t>(),
-                           g->nops.as<uint32_t>(), g->cvals.as<uint64_t>(), S->cfinal.as<uint64_t>());
+                           S->creq_dup.as<uint8_t>(), (const uint8_t *)creply_dev, g->tz().as<uint8_t>(), g->uniq().as<uint64_t>(),
+                           g->status.as<uint32_t>(), g->nops.as<uint32_t>(), g->cvals.as<uint64_t>(), S->cfinal.as<uint64_t>());
         g->temp.reserve(select_temp_bytes(D));
         select_flagged(g->temp.p, g->temp.cap, g->status.as<uint32_t>(), RUN_HEAVY, D, g->heavy.as<uint32_t>(), ctr + 0, s);
         select_flagged(g->temp.p, g->temp.cap, g->status.as<uint32_t>(), RUN_CONFLICT, D, S->conf_list.as<uint32_t>(), ctr + 1, s);
@@ -632,34 +901,32 @@ int rb_shard_resolve(rb_graph *g, int mode, const void *dreply_dev, const void *
                                g->cvals.as<uint64_t>(), g->tz().as<uint8_t>(), g->heavy.as<uint32_t>(), ctr, S->cfinal.as<uint64_t>());
         // counter writes / releases, bucketed by counter owner
         const size_t nc = (size_t)D * fv.cbf_h;
-        S->stage0.reserve(nc * 8); S->stage2.reserve(2 * nc + 32);
+        S->stage0.reserve(nc * 8 + 16); S->stage2.reserve(2 * nc + 32);
         uint8_t *w_val = S->stage2.as<uint8_t>(), *w_drop = w_val + nc;
         hipLaunchKernelGGL(k_emit_writes, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, g->uniq().as<uint64_t>(), D, g->status.as<uint32_t>(),
                            S->creq_dup.as<uint8_t>(), S->cfinal.as<uint64_t>(), S->stage0.as<uint64_t>(), w_val, w_drop);
-        size_t kept = route(g, S->stage0.as<uint64_t>(), w_drop, nc, S->span[RB_CBF], w_counts);
-        uint64_t *wi = (uint64_t *)slot_reserve(S, RB_SLOT_W_IDX, kept * 8);
-        uint8_t *wv = (uint8_t *)slot_reserve(S, RB_SLOT_W_VAL, kept);
-        gather_to<uint64_t>(g, S->stage0.as<uint64_t>(), kept, wi);
-        gather_to<uint8_t>(g, w_val, kept, wv);
-        // conflicting runs: export their ops and counters for the replicated replay
+        RouteIdx fw{S->stage0.as<uint64_t>(), w_drop, (uint64_t)S->span[RB_CBF], nullptr, w_val, nullptr, nullptr, nullptr, nullptr};
+        route(g, fw, nc, w_counts, [&](RouteIdx &ff, size_t kept) {
+            ff.out_idx = (uint64_t *)slot_reserve(S, RB_SLOT_W_IDX, kept * 8);
+            ff.out8 = (uint8_t *)slot_reserve(S, RB_SLOT_W_VAL, kept);
+        });
+        // conflicting runs: the edges (run, contested counter) every rank needs to find the components
         if (hc[1]) {
-            const uint32_t nck = hc[1], ncc = nck * (uint32_t)fv.cbf_h;
-            g->conf_sizes.reserve(((size_t)nck + 1) * 4); g->conf_off.reserve(((size_t)nck + 1) * 4);
-            hipLaunchKernelGGL(k_conf_sizes, dim3(blocks_for(nck + 1)), dim3(TPB), 0, s, S->conf_list.as<uint32_t>(), g->nops.as<uint32_t>(), nck,
-                               g->conf_sizes.as<uint32_t>());
+            const uint32_t nck = hc[1];
+            RB_REQUIRE((uint64_t)nck * (uint64_t)S->G < (1ull << 32), "too many conflicting runs in one sub-batch (%u)", nck);
+            S->n_conf = nck;
+            S->esz.reserve(((size_t)nck + 1) * 4); S->eoff.reserve(((size_t)nck + 1) * 4);
+            hipLaunchKernelGGL(k_conf_sizes, dim3(blocks_for(nck + 1)), dim3(TPB), 0, s, S->conf_list.as<uint32_t>(), g->status.as<uint32_t>(), nck,
+                               S->esz.as<uint32_t>());
             g->temp.reserve(scan_temp_bytes((size_t)nck + 1));
-            exclusive_scan_u32(g->temp.p, g->temp.cap, g->conf_sizes.as<uint32_t>(), g->conf_off.as<uint32_t>(), (size_t)nck + 1, s);
-            uint32_t nco = 0;
-            RB_HIP(hipMemcpyAsync(&nco, g->conf_off.as<uint32_t>() + nck, 4, hipMemcpyDeviceToHost, s));
+            exclusive_scan_u32(g->temp.p, g->temp.cap, S->esz.as<uint32_t>(), S->eoff.as<uint32_t>(), (size_t)nck + 1, s);
+            uint32_t ne = 0;
+            RB_HIP(hipMemcpyAsync(&ne, S->eoff.as<uint32_t>() + nck, 4, hipMemcpyDeviceToHost, s));
             RB_HIP(hipStreamSynchronize(s));
-            ConfOp *oo = (ConfOp *)slot_reserve(S, RB_SLOT_CONF_OPS, (size_t)nco * sizeof(ConfOp));
-            ConfCtr *oc = (ConfCtr *)slot_reserve(S, RB_SLOT_CONF_CTR, (size_t)ncc * sizeof(ConfCtr));
-            hipLaunchKernelGGL(k_conf_export, dim3(blocks_for((int64_t)nck * 64)), dim3(TPB), 0, s, fv, g->uniq().as<uint64_t>(), g->counts().as<uint32_t>(),
-                               g->starts().as<uint32_t>(), g->vals1().as<uint32_t>(), g->status.as<uint32_t>(), g->nops.as<uint32_t>(),
-                               g->cvals.as<uint64_t>(), S->creq_dup.as<uint8_t>(), S->conf_list.as<uint32_t>(), g->conf_off.as<uint32_t>(), nck,
-                               oo, oc);
-            *n_conf_ops = nco; *n_conf_ctr = ncc;
-            if (stats) stats->conflict_ops += nco;
+            ConfEdge *eo = (ConfEdge *)slot_reserve(S, RB_SLOT_CONF_EDGES, (size_t)ne * sizeof(ConfEdge));
+            hipLaunchKernelGGL(k_conf_edges, dim3(blocks_for(nck)), dim3(TPB), 0, s, fv, g->uniq().as<uint64_t>(), S->conf_list.as<uint32_t>(),
+                               g->status.as<uint32_t>(), S->eoff.as<uint32_t>(), nck, (uint32_t)S->G, (uint32_t)g->shard_rank, eo);
+            *n_conf_runs = nck; *n_conf_edges = ne;
         }
         if (stats) stats->distinct += D;
         RB_HIP(hipGetLastError());
@@ -678,55 +945,125 @@ int rb_shard_apply_writes(rb_graph *g, const void *w_idx_dev, const void *w_val_
     });
 }
 
-int rb_shard_conflict_replay(rb_graph *g, const void *ops_dev, int64_t n_ops, const void *ctr_dev, int64_t n_ctr) {
+int rb_shard_conflict_route(rb_graph *g, const void *edges_dev, int64_t n_edges, int64_t gid_bound, int64_t *run_counts,
+                            int64_t *op_counts, rb_add_stats *stats) {
     return guarded([&] {
-        RB_REQUIRE(g && g->shard && n_ops >= 0 && n_ctr >= 0, "rb_shard_conflict_replay: bad argument");
-        if (n_ctr == 0) return;
+        RB_REQUIRE(g && g->shard && run_counts && op_counts && n_edges >= 0 && gid_bound >= 0, "rb_shard_conflict_route: bad argument");
         ShardState *S = g->shard;
         RB_HIP(hipSetDevice(g->p.device));
         hipStream_t s = g->stream;
-        FilterView fv = g->view(S->ordinal0, S->pos_bits);
-        const ConfOp *ops = (const ConfOp *)ops_dev;
-        // 1. the distinct contested counters and their pre-batch values
-        const size_t nc = (size_t)n_ctr;
-        S->ck0.reserve(nc * 8); S->ck1.reserve(nc * 8); S->cv0.reserve(nc * 8); S->cv1.reserve(nc * 8);
-        S->cuniq.reserve(nc * 8); S->ccnt.reserve((nc + 1) * 4); S->cstart.reserve((nc + 1) * 4); S->cval.reserve(nc * 4);
-        hipLaunchKernelGGL(k_split_ctr, dim3(blocks_for((int64_t)nc)), dim3(TPB), 0, s, (const ConfCtr *)ctr_dev, nc, S->ck0.as<uint64_t>(), S->cv0.as<uint64_t>());
-        g->temp.reserve(std::max({sort_pairs32_temp_bytes(nc), rle_temp_bytes(nc), scan_temp_bytes(nc + 1), sort_pairs_temp_bytes((size_t)n_ops + 1)}));
-        sort_pairs_u64_u64(g->temp.p, g->temp.cap, S->ck0.as<uint64_t>(), S->ck1.as<uint64_t>(), S->cv0.as<uint64_t>(), S->cv1.as<uint64_t>(), nc, 0, 64, s);
+        for (int r = 0; r < S->G; ++r) run_counts[r] = op_counts[r] = 0;
+        S->slot_bytes[RB_SLOT_CONF_RUNS] = S->slot_bytes[RB_SLOT_CONF_OPS] = 0;
+        if (n_edges == 0) { RB_REQUIRE(S->n_conf == 0, "rb_shard_conflict_route: conflicting runs but no edges"); return; }
+        RB_REQUIRE(gid_bound < ((int64_t)1 << 32) && (int64_t)S->n_conf * S->G <= gid_bound, "rb_shard_conflict_route: gid_bound too small");
+        const ConfEdge *e = (const ConfEdge *)edges_dev;
+        const size_t ne = (size_t)n_edges;
+        // components of the global (run, contested counter) graph — identical on every rank
+        const uint32_t log2cap = log2_ceil(2ull * ne + 2);
+        S->etab.reserve(sizeof(Slot) << log2cap); S->eslot.reserve(ne * 4); S->elabel.reserve((size_t)gid_bound * 4 + 16);
+        RB_HIP(hipMemsetAsync(S->etab.p, 0xFF, sizeof(Slot) << log2cap, s));
         g->devctr.reserve(DEVCTR_BYTES);
         uint32_t *ctr = g->devctr.as<uint32_t>();
-        RB_HIP(hipMemsetAsync(ctr, 0, DEVCTR_BYTES, s));
-        run_length_encode_u64(g->temp.p, g->temp.cap, S->ck1.as<uint64_t>(), nc, S->cuniq.as<uint64_t>(), S->ccnt.as<uint32_t>(), ctr + 8, s);
-        uint32_t M = 0;
-        RB_HIP(hipMemcpyAsync(&M, ctr + 8, 4, hipMemcpyDeviceToHost, s));
-        RB_HIP(hipStreamSynchronize(s));
-        exclusive_scan_u32(g->temp.p, g->temp.cap, S->ccnt.as<uint32_t>(), S->cstart.as<uint32_t>(), M, s);
-        hipLaunchKernelGGL(k_first_vals, dim3(blocks_for(M)), dim3(TPB), 0, s, S->cv1.as<uint64_t>(), S->cstart.as<uint32_t>(), M, S->cval.as<uint32_t>());
-        if (n_ops) {
-            const size_t no = (size_t)n_ops;
-            const int h = fv.cbf_h;
-            S->oslots.reserve(no * h * 4); S->olabel.reserve((size_t)M * 4 + 16);
-            S->okey0.reserve(no * 8); S->okey1.reserve(no * 8); S->oval0.reserve(no * 4); S->oval1.reserve(no * 4);
-            hipLaunchKernelGGL(k_op_slots, dim3(blocks_for((int64_t)no)), dim3(TPB), 0, s, fv, ops, no, S->cuniq.as<uint64_t>(), M,
-                               S->oslots.as<uint32_t>(), S->olabel.as<uint32_t>());
-            for (int it = 0;; ++it) {   // components of the shares-a-counter graph
-                RB_REQUIRE(it < 100000, "conflict component labelling did not converge");
-                RB_HIP(hipMemsetAsync(ctr + 3, 0, 4, s));
-                hipLaunchKernelGGL(k_op_labels, dim3(blocks_for((int64_t)no)), dim3(TPB), 0, s, S->oslots.as<uint32_t>(), no, h, S->olabel.as<uint32_t>(), ctr + 3);
-                uint32_t changed = 0;
-                RB_HIP(hipMemcpyAsync(&changed, ctr + 3, 4, hipMemcpyDeviceToHost, s));
-                RB_HIP(hipStreamSynchronize(s));
-                if (!changed) break;
-            }
-            hipLaunchKernelGGL(k_op_keys, dim3(blocks_for((int64_t)no)), dim3(TPB), 0, s, ops, S->oslots.as<uint32_t>(), no, h, S->olabel.as<uint32_t>(),
-                               S->okey0.as<uint64_t>(), S->oval0.as<uint32_t>());
-            sort_pairs_u64_u32(g->temp.p, g->temp.cap, S->okey0.as<uint64_t>(), S->okey1.as<uint64_t>(), S->oval0.as<uint32_t>(), S->oval1.as<uint32_t>(), no, 0, 64, s);
-            hipLaunchKernelGGL(k_conf_replay_sparse, dim3(blocks_for((int64_t)no)), dim3(TPB), 0, s, fv, ops, S->oslots.as<uint32_t>(), S->okey1.as<uint64_t>(),
-                               S->oval1.as<uint32_t>(), no, S->cval.as<uint32_t>());
+        hipLaunchKernelGGL(k_edge_init, dim3(blocks_for((int64_t)ne)), dim3(TPB), 0, s, e, ne, S->etab.as<Slot>(), log2cap, S->eslot.as<uint32_t>(),
+                           S->elabel.as<uint32_t>());
+        for (int it = 0;; ++it) {
+            RB_REQUIRE(it < 100000, "conflict component labelling did not converge");
+            RB_HIP(hipMemsetAsync(ctr + 3, 0, 4, s));
+            hipLaunchKernelGGL(k_edge_push, dim3(blocks_for((int64_t)ne)), dim3(TPB), 0, s, e, ne, S->etab.as<Slot>(), S->eslot.as<uint32_t>(), S->elabel.as<uint32_t>());
+            hipLaunchKernelGGL(k_edge_pull, dim3(blocks_for((int64_t)ne)), dim3(TPB), 0, s, e, ne, S->etab.as<Slot>(), S->eslot.as<uint32_t>(), S->elabel.as<uint32_t>(), ctr + 3);
+            uint32_t changed = 0;
+            RB_HIP(hipMemcpyAsync(&changed, ctr + 3, 4, hipMemcpyDeviceToHost, s));
+            RB_HIP(hipStreamSynchronize(s));
+            if (!changed) break;
         }
-        hipLaunchKernelGGL(k_conf_writeback, dim3(blocks_for(M)), dim3(TPB), 0, s, g->cbf, (uint64_t)g->cbf_lo, (uint64_t)g->cbf_hi, S->cuniq.as<uint64_t>(),
-                           S->cval.as<uint32_t>(), M);
+        const uint32_t nck = S->n_conf;
+        if (!nck) return;
+        // this rank's conflicting runs -> the rank that owns their component
+        S->cdesc.reserve((size_t)nck * sizeof(ConfRun)); S->cpos.reserve((size_t)nck * 4);
+        S->cnops.reserve(((size_t)nck + 1) * 4); S->cnoff.reserve(((size_t)nck + 1) * 4);
+        hipLaunchKernelGGL(k_conf_desc, dim3(blocks_for(nck)), dim3(TPB), 0, s, g->uniq().as<uint64_t>(), S->conf_list.as<uint32_t>(), g->status.as<uint32_t>(),
+                           g->nops.as<uint32_t>(), g->cvals.as<uint64_t>(), S->elabel.as<uint32_t>(), nck, (uint32_t)S->G, (uint32_t)g->shard_rank,
+                           S->cdesc.as<ConfRun>());
+        RB_HIP(hipMemsetAsync(S->cnops.as<uint32_t>() + nck, 0, 4, s));
+        RouteRuns fr{S->cdesc.as<ConfRun>(), (uint32_t)S->G, nullptr, S->cpos.as<uint32_t>(), S->cnops.as<uint32_t>()};
+        route(g, fr, nck, run_counts, [&](RouteRuns &ff, size_t kept) { ff.out = (ConfRun *)slot_reserve(S, RB_SLOT_CONF_RUNS, kept * sizeof(ConfRun)); });
+        g->temp.reserve(scan_temp_bytes((size_t)nck + 1));
+        exclusive_scan_u32(g->temp.p, g->temp.cap, S->cnops.as<uint32_t>(), S->cnoff.as<uint32_t>(), (size_t)nck + 1, s);
+        // ops per destination = offsets at the run-bucket boundaries
+        std::vector<uint64_t> rb(S->G + 1), ob(S->G + 1);
+        rb[0] = 0;
+        for (int r = 0; r < S->G; ++r) rb[r + 1] = rb[r] + (uint64_t)run_counts[r];
+        S->bounds.reserve(2 * (S->G + 2) * 8);
+        RB_HIP(hipMemcpyAsync(S->bounds.p, rb.data(), (S->G + 1) * 8, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_pick_u32, dim3(1), dim3(128), 0, s, S->cnoff.as<uint32_t>(), S->bounds.as<uint64_t>(), (uint32_t)(S->G + 1),
+                           S->bounds.as<uint64_t>() + (S->G + 2));
+        RB_HIP(hipMemcpyAsync(ob.data(), S->bounds.as<uint64_t>() + (S->G + 2), (S->G + 1) * 8, hipMemcpyDeviceToHost, s));
+        RB_HIP(hipStreamSynchronize(s));
+        for (int r = 0; r < S->G; ++r) op_counts[r] = (int64_t)(ob[r + 1] - ob[r]);
+        const size_t nco = (size_t)ob[S->G];
+        uint32_t *oo = (uint32_t *)slot_reserve(S, RB_SLOT_CONF_OPS, nco * 4);
+        hipLaunchKernelGGL(k_conf_ops_out, dim3(blocks_for((int64_t)nck * 64)), dim3(TPB), 0, s, S->conf_list.as<uint32_t>(), g->counts().as<uint32_t>(),
+                           g->starts().as<uint32_t>(), g->vals1().as<uint32_t>(), g->nops.as<uint32_t>(), S->cpos.as<uint32_t>(),
+                           S->cnoff.as<uint32_t>(), nck, oo);
+        if (stats) stats->conflict_ops += (int64_t)nco;
+        RB_HIP(hipGetLastError());
+        RB_HIP(hipStreamSynchronize(s));
+    });
+}
+
+int rb_shard_conflict_replay(rb_graph *g, const void *runs_dev, int64_t n_runs, const void *ops_dev, int64_t n_ops, int64_t *w_counts) {
+    return guarded([&] {
+        RB_REQUIRE(g && g->shard && n_runs >= 0 && n_ops >= 0 && w_counts, "rb_shard_conflict_replay: bad argument");
+        ShardState *S = g->shard;
+        RB_HIP(hipSetDevice(g->p.device));
+        hipStream_t s = g->stream;
+        for (int r = 0; r < S->G; ++r) w_counts[r] = 0;
+        S->slot_bytes[RB_SLOT_CW_IDX] = S->slot_bytes[RB_SLOT_CW_VAL] = 0;
+        if (n_runs == 0) { RB_REQUIRE(n_ops == 0, "rb_shard_conflict_replay: ops without runs"); return; }
+        RB_REQUIRE(n_runs < (1ll << 30) && n_ops < (1ll << 32), "rb_shard_conflict_replay: too many runs/ops");
+        FilterView fv = g->view(S->ordinal0, S->pos_bits);
+        const ConfRun *runs = (const ConfRun *)runs_dev;
+        const uint32_t R = (uint32_t)n_runs, O = (uint32_t)n_ops;
+        const int h = fv.cbf_h;
+        S->cnops.reserve(((size_t)R + 1) * 4); S->cnoff.reserve(((size_t)R + 1) * 4);
+        S->rk0.reserve((size_t)R * 8); S->rk1.reserve((size_t)R * 8); S->rbig.reserve(((size_t)R + 1) * 8);
+        S->ok0.reserve((size_t)O * 8 + 16); S->ok1.reserve((size_t)O * 8 + 16); S->ov0.reserve((size_t)O * 4 + 16); S->ov1.reserve((size_t)O * 4 + 16);
+        hipLaunchKernelGGL(k_run_nops, dim3(blocks_for(R + 1)), dim3(TPB), 0, s, runs, R, S->cnops.as<uint32_t>(), S->rk0.as<uint64_t>());
+        g->temp.reserve(std::max({scan_temp_bytes((size_t)R + 1), sort_pairs_temp_bytes((size_t)O + 1), sort_keys_temp_bytes(R), select_temp_bytes(R)}));
+        exclusive_scan_u32(g->temp.p, g->temp.cap, S->cnops.as<uint32_t>(), S->cnoff.as<uint32_t>(), (size_t)R + 1, s);
+        uint32_t total = 0;
+        RB_HIP(hipMemcpyAsync(&total, S->cnoff.as<uint32_t>() + R, 4, hipMemcpyDeviceToHost, s));
+        // the component's counters: private table, pre-batch values
+        const uint32_t log2cap = log2_ceil(2ull * (uint64_t)R * (uint64_t)h + 2);
+        S->rtab.reserve(sizeof(Slot) << log2cap); S->rslot.reserve((size_t)R * h * 4);
+        RB_HIP(hipMemsetAsync(S->rtab.p, 0xFF, sizeof(Slot) << log2cap, s));
+        hipLaunchKernelGGL(k_run_slots, dim3(blocks_for(R)), dim3(TPB), 0, s, fv, runs, R, S->rtab.as<Slot>(), log2cap, S->rslot.as<uint32_t>());
+        RB_HIP(hipStreamSynchronize(s));
+        RB_REQUIRE(total == O, "rb_shard_conflict_replay: runs announce %u ops, got %u", total, O);
+        sort_keys_u64(g->temp.p, g->temp.cap, S->rk0.as<uint64_t>(), S->rk1.as<uint64_t>(), R, 0, 64, s);
+        if (O) {
+            hipLaunchKernelGGL(k_run_expand, dim3(blocks_for((int64_t)R * 64)), dim3(TPB), 0, s, runs, S->cnoff.as<uint32_t>(), (const uint32_t *)ops_dev, R,
+                               S->ok0.as<uint64_t>(), S->ov0.as<uint32_t>());
+            sort_pairs_u64_u32(g->temp.p, g->temp.cap, S->ok0.as<uint64_t>(), S->ok1.as<uint64_t>(), S->ov0.as<uint32_t>(), S->ov1.as<uint32_t>(), O, 0, 64, s);
+            uint32_t *big_flag = S->rbig.as<uint32_t>(), *big_list = big_flag + R;
+            g->devctr.reserve(DEVCTR_BYTES);
+            uint32_t *ctr = g->devctr.as<uint32_t>();
+            hipLaunchKernelGGL(k_replay_small, dim3(blocks_for(R)), dim3(TPB), 0, s, fv, S->rtab.as<Slot>(), S->rslot.as<uint32_t>(), S->rk1.as<uint64_t>(), R,
+                               S->ok1.as<uint64_t>(), S->ov1.as<uint32_t>(), O, big_flag);
+            select_flagged(g->temp.p, g->temp.cap, big_flag, 1u, R, big_list, ctr + 4, s);
+            hipLaunchKernelGGL(k_replay_big, dim3(std::min<uint32_t>(R, 65536u)), dim3(64), 0, s, fv, S->rtab.as<Slot>(), S->rslot.as<uint32_t>(), runs,
+                               S->rk1.as<uint64_t>(), R, S->ok1.as<uint64_t>(), S->ov1.as<uint32_t>(), O, big_list, ctr + 4);
+        }
+        // final bytes of every touched counter go back to the counter's owner
+        const size_t cap = (size_t)1 << log2cap;
+        S->stage0.reserve(cap * 8); S->stage2.reserve(2 * cap + 32);
+        uint8_t *w_val = S->stage2.as<uint8_t>(), *w_drop = w_val + cap;
+        hipLaunchKernelGGL(k_tab_emit, dim3(blocks_for((int64_t)cap)), dim3(TPB), 0, s, S->rtab.as<Slot>(), cap, S->stage0.as<uint64_t>(), w_val, w_drop);
+        RouteIdx fw{S->stage0.as<uint64_t>(), w_drop, (uint64_t)S->span[RB_CBF], nullptr, w_val, nullptr, nullptr, nullptr, nullptr};
+        route(g, fw, cap, w_counts, [&](RouteIdx &ff, size_t kept) {
+            ff.out_idx = (uint64_t *)slot_reserve(S, RB_SLOT_CW_IDX, kept * 8);
+            ff.out8 = (uint8_t *)slot_reserve(S, RB_SLOT_CW_VAL, kept);
+        });
         RB_HIP(hipGetLastError());
         RB_HIP(hipStreamSynchronize(s));
     });
@@ -739,9 +1076,9 @@ void shard_free(rb_graph *g) {
     ShardState *S = g->shard;
     if (!S) return;
     for (auto &b : S->slot) b.release();
-    DevBuf *bufs[] = {&S->dreq_pos, &S->creq_pos, &S->creq_dup, &S->cfinal, &S->conf_list, &S->rkey0, &S->rkey1, &S->rval0, &S->rval1,
-                      &S->stage0, &S->stage1, &S->stage2, &S->bounds, &S->own_f, &S->own_cs, &S->own_foreign, &S->ck0, &S->ck1, &S->cv0,
-                      &S->cv1, &S->cuniq, &S->ccnt, &S->cstart, &S->cval, &S->oslots, &S->olabel, &S->okey0, &S->okey1, &S->oval0, &S->oval1};
+    DevBuf *bufs[] = {&S->dreq_pos, &S->creq_pos, &S->creq_dup, &S->cfinal, &S->conf_list, &S->stage0, &S->stage1, &S->stage2, &S->stage3,
+                      &S->rhist, &S->roffs, &S->bounds, &S->own_f, &S->own_cs, &S->esz, &S->eoff, &S->etab, &S->eslot, &S->elabel, &S->cdesc,
+                      &S->cpos, &S->cnops, &S->cnoff, &S->rk0, &S->rk1, &S->ok0, &S->ok1, &S->ov0, &S->ov1, &S->rtab, &S->rslot, &S->rbig};
     for (auto *b : bufs) b->release();
     delete S;
     g->shard = nullptr;

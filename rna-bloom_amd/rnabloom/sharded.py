@@ -22,6 +22,30 @@ from . import _native as N
 from ._native import check, lib
 
 
+# phase tracer: set TRACE = {} to accumulate synchronous wall time (ms) per protocol phase, all ranks of
+# this process together (tools/loopback_bench.py, RB_SHARD_TRACE=1 in bench.py)
+TRACE = None
+_t_last = [0.0]
+
+
+def trace_mark(what):
+    if TRACE is None:
+        return
+    import time
+    if torch.cuda.is_available():
+        torch.cuda.synchronize()
+    now = time.perf_counter()
+    TRACE[what] = TRACE.get(what, 0.0) + (now - _t_last[0]) * 1e3
+    _t_last[0] = now
+
+
+class _DevView:
+    """CUDA-array-interface holder: lets torch wrap device memory owned by the library without a copy."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = dict(shape=(int(nbytes),), typestr="|u1", data=(int(ptr), False), version=2, strides=None)
+
+
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None and t.numel() else None
 
@@ -38,7 +62,7 @@ class ShardRank:
         self.h = C.c_void_p()
         check(lib.rb_graph_create_shard(C.byref(p), rank, count, C.byref(self.h)))
         self.ordinal = 0
-        self.stats = dict(kmers=0, pairs=0, distinct=0, conflict_ops=0, reads=0)
+        self.stats = dict(kmers=0, pairs=0, distinct=0, conflict_ops=0, reads=0, sorted_kmers=0)
 
     def destroy(self):
         if self.h:
@@ -57,6 +81,16 @@ class ShardRank:
     def clear(self):
         check(lib.rb_graph_clear(self.h, 15))
         self.ordinal = 0
+
+    def _slot(self, slot, nbytes=None):
+        """Zero-copy uint8 view of a library slot (valid until the phase that fills it runs again)."""
+        p, nb = C.c_void_p(), C.c_int64()
+        check(lib.rb_shard_slot(self.h, slot, C.byref(p), C.byref(nb)))
+        if nbytes is not None and nb.value != int(nbytes):
+            raise RuntimeError("slot %d holds %d bytes, expected %d" % (slot, nb.value, nbytes))
+        if not nb.value:
+            return torch.empty(0, dtype=torch.uint8, device=self.tdev)
+        return torch.as_tensor(_DevView(p.value, nb.value), device=self.tdev)
 
     def _take(self, slot, nbytes):
         t = torch.empty(int(nbytes), dtype=torch.uint8, device=self.tdev)
@@ -77,71 +111,67 @@ class ShardRank:
 
     # ---- one global sub-batch; yields exchange requests, receives their results ----
     def substep(self, batch, first, n, pos_bits, flags, mode=N.MODE_ADD):
-        import os, time
-        trace = os.environ.get("RB_SHARD_TRACE")
-        t_last = [time.perf_counter()]
-
-        def mark(what):
-            if trace and self.rank == 0:
-                torch.cuda.synchronize()
-                now = time.perf_counter()
-                print("[shard] %-10s %8.1f ms" % (what, (now - t_last[0]) * 1e3), flush=True)
-                t_last[0] = now
+        mark = trace_mark
         G = self.count
         n_all = yield ("ints", [int(n)])
         n_all = [x[0] for x in n_all]
         rel_base, total_reads = sum(n_all[: self.rank]), sum(n_all)
         assert total_reads < (1 << (32 - pos_bits)), "sub-batch has too many reads for the occurrence id"
-        rec_c, pair_c = (C.c_int64 * G)(), (C.c_int64 * G)()
+        cnt = lambda: (C.c_int64 * G)()
+        # hash: own reads -> records by k-mer owner, pair probes by rpkbf owner
+        rec_c, pair_c = cnt(), cnt()
         check(lib.rb_shard_hash(self.h, batch.h, first, n, rel_base, pos_bits, flags, rec_c, pair_c))
         rec_c, pair_c = list(rec_c), list(pair_c)
         mark("hash")
-        keys = self._take(N.SLOT_REC_KEYS, 8 * sum(rec_c))
-        occ = self._take(N.SLOT_REC_OCC, 4 * sum(rec_c))
-        pidx = self._take(N.SLOT_PAIR_IDX, 8 * sum(pair_c))
-        rkeys, rk_c = yield ("a2a", keys, [8 * c for c in rec_c])
-        rocc, _ = yield ("a2a", occ, [4 * c for c in rec_c])
-        rpidx, rp_c = yield ("a2a", pidx, [8 * c for c in pair_c])
-        mark("a2a_rec")
-        nrec = sum(rk_c) // 8
-        d_c, c_c = (C.c_int64 * G)(), (C.c_int64 * G)()
-        check(lib.rb_shard_group(self.h, _ptr(rkeys), _ptr(rocc), nrec, self.ordinal, pos_bits, mode, d_c, c_c))
+        send = [self._slot(N.SLOT_REC_KEYS, 8 * sum(rec_c)), self._slot(N.SLOT_REC_OCC, 4 * sum(rec_c)), self._slot(N.SLOT_PAIR_IDX, 8 * sum(pair_c))]
+        (rkeys, rocc, rpidx), (rk_c, _, rp_c) = yield ("a2a", send, [[8 * c for c in rec_c], [4 * c for c in rec_c], [8 * c for c in pair_c]])
+        # group: received records -> runs -> requests by filter owner
+        d_c, c_c = cnt(), cnt()
+        check(lib.rb_shard_group(self.h, _ptr(rkeys), _ptr(rocc), sum(rk_c) // 8, self.ordinal, pos_bits, mode, d_c, c_c))
         d_c, c_c = list(d_c), list(c_c)
         mark("group")
-        o_didx, o_dc = yield ("a2a", self._take(N.SLOT_DREQ_IDX, 8 * sum(d_c)), [8 * c for c in d_c])
-        o_dprobe, _ = yield ("a2a", self._take(N.SLOT_DREQ_PROBE, 8 * sum(d_c)), [8 * c for c in d_c])
-        o_cidx, o_cc = yield ("a2a", self._take(N.SLOT_CREQ_IDX, 8 * sum(c_c)), [8 * c for c in c_c])
-        mark("a2a_req")
+        send = [self._slot(N.SLOT_DREQ_IDX, 8 * sum(d_c)), self._slot(N.SLOT_DREQ_PROBE, 8 * sum(d_c)), self._slot(N.SLOT_CREQ_IDX, 8 * sum(c_c))]
+        (o_didx, o_dprobe, o_cidx), (o_dc, _, o_cc) = yield ("a2a", send, [[8 * c for c in d_c], [8 * c for c in d_c], [8 * c for c in c_c]])
+        # serve: this rank's filter ranges answer
         nd, nc, np_ = sum(o_dc) // 8, sum(o_cc) // 8, sum(rp_c) // 8
         dreply = torch.empty(nd, dtype=torch.uint8, device=self.tdev)
         creply = torch.empty(nc, dtype=torch.uint8, device=self.tdev)
         check(lib.rb_shard_serve(self.h, mode, _ptr(o_didx), _ptr(o_dprobe), nd, _ptr(o_cidx), nc, _ptr(rpidx), np_,
                                  _ptr(dreply), _ptr(creply)))
         mark("serve")
-        my_dreply, _ = yield ("a2a", dreply, [c // 8 for c in o_dc])
-        my_creply, _ = yield ("a2a", creply, [c // 8 for c in o_cc])
-        mark("a2a_reply")
-        w_c = (C.c_int64 * G)()
-        nco, ncc = C.c_int64(), C.c_int64()
+        (my_dreply, my_creply), _ = yield ("a2a", [dreply, creply], [[c // 8 for c in o_dc], [c // 8 for c in o_cc]], [d_c, c_c])
+        # resolve: runs that own their counters alone finish here
+        w_c, nconf, nedge = cnt(), C.c_int64(), C.c_int64()
         st = N.AddStats()
-        check(lib.rb_shard_resolve(self.h, mode, _ptr(my_dreply), _ptr(my_creply), w_c, C.byref(nco), C.byref(ncc), C.byref(st)))
+        check(lib.rb_shard_resolve(self.h, mode, _ptr(my_dreply), _ptr(my_creply), w_c, C.byref(nconf), C.byref(nedge), C.byref(st)))
         w_c = list(w_c)
         mark("resolve")
-        o_widx, o_wc = yield ("a2a", self._take(N.SLOT_W_IDX, 8 * sum(w_c)), [8 * c for c in w_c])
-        o_wval, _ = yield ("a2a", self._take(N.SLOT_W_VAL, sum(w_c)), w_c)
+        (o_widx, o_wval), (o_wc, _) = yield ("a2a", [self._slot(N.SLOT_W_IDX, 8 * sum(w_c)), self._slot(N.SLOT_W_VAL, sum(w_c))], [[8 * c for c in w_c], w_c])
         check(lib.rb_shard_apply_writes(self.h, _ptr(o_widx), _ptr(o_wval), sum(o_wc) // 8))
         mark("writes")
-        all_ops = yield ("gather", self._take(N.SLOT_CONF_OPS, 16 * nco.value))
-        all_ctr = yield ("gather", self._take(N.SLOT_CONF_CTR, 16 * ncc.value))
-        mark("gather")
-        check(lib.rb_shard_conflict_replay(self.h, _ptr(all_ops), all_ops.numel() // 16, _ptr(all_ctr), all_ctr.numel() // 16))
-        mark("replay")
+        # runs that share a counter: components -> component owner -> ordered replay -> counter owners
+        all_edges, e_sizes = yield ("gather", self._slot(N.SLOT_CONF_EDGES, 16 * nedge.value))
+        if sum(e_sizes):
+            run_c, op_c = cnt(), cnt()
+            check(lib.rb_shard_conflict_route(self.h, _ptr(all_edges), sum(e_sizes) // 16, G * (max(e_sizes) // 16), run_c, op_c, C.byref(st)))
+            run_c, op_c = list(run_c), list(op_c)
+            mark("conf_route")
+            send = [self._slot(N.SLOT_CONF_RUNS, 24 * sum(run_c)), self._slot(N.SLOT_CONF_OPS, 4 * sum(op_c))]
+            (r_runs, r_ops), (r_rc, r_oc) = yield ("a2a", send, [[24 * c for c in run_c], [4 * c for c in op_c]])
+            cw_c = cnt()
+            check(lib.rb_shard_conflict_replay(self.h, _ptr(r_runs), sum(r_rc) // 24, _ptr(r_ops), sum(r_oc) // 4, cw_c))
+            cw_c = list(cw_c)
+            mark("conf_replay")
+            (o_cwidx, o_cwval), (o_cwc, _) = yield ("a2a", [self._slot(N.SLOT_CW_IDX, 8 * sum(cw_c)), self._slot(N.SLOT_CW_VAL, sum(cw_c))],
+                                                    [[8 * c for c in cw_c], cw_c])
+            check(lib.rb_shard_apply_writes(self.h, _ptr(o_cwidx), _ptr(o_cwval), sum(o_cwc) // 8))
+            mark("conf_writes")
         self.ordinal += total_reads
-        del keys, occ, pidx, rkeys, rocc, rpidx, o_didx, o_dprobe, o_cidx, dreply, creply, my_dreply, my_creply, o_widx, o_wval, all_ops, all_ctr
         self.stats["kmers"] += sum(rec_c)
         self.stats["pairs"] += sum(pair_c) // max(1, self.p.pkbf_num_hash)
         self.stats["distinct"] += st.distinct
         self.stats["conflict_ops"] += st.conflict_ops
+        self.stats["sorted_kmers"] += st.sorted_kmers
         self.stats["reads"] += int(n)
 
     def add_range(self, batch, first, n, flags, reads_per_substep, pos_bits):
@@ -170,7 +200,9 @@ def _sync(t):
 
 
 def run_loopback(gens):
-    """Drive G coroutines (virtual ranks on one device) in lock step."""
+    """Drive G coroutines (virtual ranks on one device) in lock step.
+    Requests: ("ints", [..]) -> list over ranks;  ("a2a", tensors, byte counts per tensor [, known receive
+    counts]) -> (received tensors, received byte counts per tensor);  ("gather", tensor) -> (concatenation, sizes)."""
     G = len(gens)
     reqs = [next(g) for g in gens]
     while True:
@@ -179,17 +211,25 @@ def run_loopback(gens):
         if kind == "ints":
             res = [[r[1] for r in reqs]] * G
         elif kind == "a2a":
-            parts = [_split(r[1], r[2]) for r in reqs]
+            m = len(reqs[0][1])
             res = []
+            parts = [[_split(r[1][t], r[2][t]) for t in range(m)] for r in reqs]      # parts[src][t][dst]
             for dst in range(G):
-                segs = [parts[src][dst] for src in range(G)]
-                res.append((torch.cat(segs) if segs else reqs[dst][1][:0], [int(s.numel()) for s in segs]))
+                outs, cnts = [], []
+                for t in range(m):
+                    segs = [parts[src][t][dst] for src in range(G)]
+                    outs.append(torch.cat(segs) if G > 1 else segs[0])
+                    cnts.append([int(x.numel()) for x in segs])
+                res.append((outs, cnts))
         elif kind == "gather":
-            cat = torch.cat([r[1] for r in reqs])
-            res = [cat] * G
+            sizes = [int(r[1].numel()) for r in reqs]
+            cat = torch.cat([r[1] for r in reqs]) if G > 1 else reqs[0][1]
+            res = [(cat, sizes)] * G
         else:
             raise ValueError(kind)
-        _sync(reqs[0][1] if kind != "ints" else None)
+        if kind != "ints":
+            _sync(reqs[0][1][0] if kind == "a2a" else reqs[0][1])
+        trace_mark("exchange")
         nxt, done = [], 0
         for g, r in zip(gens, res):
             try:
@@ -215,28 +255,42 @@ def run_distributed(gen, group=None):
                 dist.all_gather_object(out, req[1], group=group)
                 res = out
             elif kind == "a2a":
-                send, counts = req[1], [int(c) for c in req[2]]
-                cin = torch.tensor(counts, dtype=torch.int64, device=send.device)
-                cout = torch.empty(world, dtype=torch.int64, device=send.device)
-                dist.all_to_all_single(cout, cin, group=group)
-                rc = [int(x) for x in cout.tolist()]
-                recv = torch.empty(sum(rc), dtype=torch.uint8, device=send.device)
-                dist.all_to_all_single(recv, send, output_split_sizes=rc, input_split_sizes=counts, group=group)
-                res = (recv, rc)
+                tensors, counts = req[1], [[int(c) for c in cs] for cs in req[2]]
+                dev = tensors[0].device
+                m = len(tensors)
+                if len(req) > 3:                      # receive counts already known (replies)
+                    rcs = [[int(c) for c in cs] for cs in req[3]]
+                else:                                 # one count exchange for all tensors of the phase
+                    cin = torch.tensor(counts, dtype=torch.int64, device=dev).t().contiguous()     # [world, m]
+                    cout = torch.empty_like(cin)
+                    dist.all_to_all_single(cout, cin, group=group)
+                    rcs = cout.t().tolist()
+                outs = []
+                for t, sc, rc in zip(tensors, counts, rcs):
+                    recv = torch.empty(sum(rc), dtype=torch.uint8, device=dev)
+                    dist.all_to_all_single(recv, t, output_split_sizes=rc, input_split_sizes=sc, group=group)
+                    outs.append(recv)
+                res = (outs, rcs)
             elif kind == "gather":
                 t = req[1]
-                sizes = [None] * world
-                dist.all_gather_object(sizes, int(t.numel()), group=group)
+                mine = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
+                allsz = torch.empty(world, dtype=torch.int64, device=t.device)
+                dist.all_gather_into_tensor(allsz, mine, group=group)
+                sizes = [int(x) for x in allsz.tolist()]
                 mx = max(sizes)
-                pad = torch.zeros(mx, dtype=torch.uint8, device=t.device)
-                pad[: t.numel()] = t
-                outs = [torch.empty(mx, dtype=torch.uint8, device=t.device) for _ in range(world)]
                 if mx:
-                    dist.all_gather(outs, pad, group=group)
-                res = torch.cat([o[:s] for o, s in zip(outs, sizes)]) if mx else t
+                    pad = torch.empty(mx, dtype=torch.uint8, device=t.device)
+                    pad[: t.numel()] = t
+                    out = torch.empty(mx * world, dtype=torch.uint8, device=t.device)
+                    dist.all_gather_into_tensor(out, pad, group=group)
+                    cat = torch.cat([out[r * mx: r * mx + s] for r, s in enumerate(sizes)]) if world > 1 else out[: sizes[0]]
+                else:
+                    cat = t
+                res = (cat, sizes)
             else:
                 raise ValueError(kind)
-            _sync(req[1] if kind != "ints" else None)
+            _sync(req[1][0] if kind == "a2a" else (req[1] if kind == "gather" else None))
+            trace_mark("exchange")
             req = gen.send(res)
     except StopIteration:
         return

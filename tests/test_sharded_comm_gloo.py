@@ -21,23 +21,25 @@ def toy(rank, G, log):
     n_all = yield ("ints", [5 + rank, rank * 7])
     log.append(("ints", n_all))
     for rnd in range(4):
-        counts = [int(c) for c in rng.integers(0, 50, G)]
+        counts = [[int(c) for c in rng.integers(0, 50, G)] for _ in range(3)]    # three tensors per exchange
         if rnd == 2:
-            counts = [0] * G                                   # empty exchange
+            counts[0] = [0] * G                                # one empty tensor
+            counts[2] = [0] * G
         if rnd == 3:
-            counts[rank] = 0
-        send = torch.from_numpy(rng.integers(0, 256, sum(counts), dtype=np.uint8))
+            for c in counts:
+                c[rank] = 0
+        send = [torch.from_numpy(rng.integers(0, 256, sum(c), dtype=np.uint8)) for c in counts]
         recv, rc = yield ("a2a", send, counts)
-        log.append(("a2a", recv.clone().numpy().tobytes(), list(rc)))
-        reply = (recv.to(torch.int16) * 3 % 251).to(torch.uint8)  # reply travels the reverse way
-        back, bc = yield ("a2a", reply, rc)
-        log.append(("back", back.clone().numpy().tobytes(), list(bc)))
-        assert bc == counts
+        log.append(("a2a", [t.clone().numpy().tobytes() for t in recv], [list(c) for c in rc]))
+        reply = [(t.to(torch.int16) * 3 % 251).to(torch.uint8) for t in recv]    # replies travel the reverse way,
+        back, bc = yield ("a2a", reply, rc, counts)                              # receive counts already known
+        log.append(("back", [t.clone().numpy().tobytes() for t in back], [list(c) for c in bc]))
+        assert [list(c) for c in bc] == counts
     g = torch.from_numpy(rng.integers(0, 256, 16 * rank, dtype=np.uint8))   # rank 0 contributes nothing
-    allg = yield ("gather", g)
-    log.append(("gather", allg.clone().numpy().tobytes()))
-    allg = yield ("gather", torch.zeros(0, dtype=torch.uint8))
-    log.append(("gather0", allg.clone().numpy().tobytes()))
+    allg, sizes = yield ("gather", g)
+    log.append(("gather", allg.clone().numpy().tobytes(), list(sizes)))
+    allg, sizes = yield ("gather", torch.zeros(0, dtype=torch.uint8))
+    log.append(("gather0", allg.clone().numpy().tobytes(), list(sizes)))
 
 
 def _worker(rank, world, port, outdir):
