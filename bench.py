@@ -9,7 +9,7 @@ generated on the device before the timed region and stay resident in HBM (packed
     python bench.py [--gpus N] [--steps K] [--warmup W] [--pairs P] [--genome G] [--nk NK]
 
 For N>1 launch through torch.distributed.run (one rank per GPU): reads are data-parallel, every filter
-is sharded by index range and the k-mer space by hash prefix; records / probes / replies / counter
+is sharded by index range and the k-mer space by hash bits; records / probes / replies / counter
 writes travel by RCCL all_to_all (rnabloom/sharded.py, csrc/rb_shard.hip).  The job
 (total read pairs) is fixed, so scaling is "strong".
 Prints ONE JSON line on rank 0.
@@ -100,7 +100,9 @@ def main():
     pk_bits = N.lib.rb_expected_size(a.nk, a.fpr, 2)
     dist_pk = max(1, 150 - k - 10)              # R/RNABloom.java:1022 (minNumKmerPairs 10)
 
-    batch = ReadBatch.synthetic(pairs_rank, a.genome, 150, 300, 30, a.err, 1e-4, 2.0, seed=0x5EED + rank, device=local)
+    # every rank holds a slice of the SAME read set (same transcriptome, same reads as the 1-GPU run)
+    batch = ReadBatch.synthetic(pairs_rank, a.genome, 150, 300, 30, a.err, 1e-4, 2.0, seed=0x5EED, device=local,
+                                pair_offset=rank * pairs_rank, total_pairs=pairs_rank * world)
     if not sharded_mode:
         g = BloomFilterDeBruijnGraph(dbg_bits, cbf_bytes, pk_bits, 2, 2, 2, k, False, True, device=local, rngSeed=1,
                                      maxBatchKmers=a.batch_kmers)
@@ -112,7 +114,7 @@ def main():
             s2 = g.addBatch(batch, reverseComplement=True, storeReadPairedKmers=True, first=pairs_rank, n=pairs_rank)
             return s1, s2
     else:
-        # filters sharded by index range over the ranks, k-mer space by hash prefix; reads are
+        # filters sharded by index range over the ranks, k-mer space by hash bits; reads are
         # data-parallel; RCCL all_to_all / all_gather move records, probes, replies and writes
         from types import SimpleNamespace
         from rnabloom import sharded

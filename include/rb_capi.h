@@ -116,6 +116,10 @@ typedef struct rb_synth_params {
     float expr_sigma;       /* log-normal sigma; 0 => uniform expression */
     uint64_t seed;
     int32_t tx_min, tx_max; /* transcript length range */
+    /* a slice of a larger read set (multi-GPU benches): this batch holds pairs
+     * [pair_offset, pair_offset + n_pairs) of a set of total_pairs pairs drawn with the same seed,
+     * so the ranks' batches together are exactly the single-GPU set.  total_pairs 0 = n_pairs. */
+    int64_t pair_offset, total_pairs;
 } rb_synth_params;
 int rb_batch_create_synthetic(int device, const rb_synth_params *p, rb_batch **out);
 
@@ -209,7 +213,7 @@ int rb_strobemers(int device, const char *seq, const int64_t *offsets, int64_t n
  * there is no reference interface for this; the phases below are what bench.py / rnabloom.sharded
  * drive, with torch.distributed (RCCL all_to_all / all_gather) moving the byte buffers between
  * ranks.  Shard s of a filter of `size` indices owns [s*span, min(size,(s+1)*span)), span =
- * roundup64(ceil(size/count)); k-mer hash space is split by the top log2(count) bits of hashVals[0]
+ * roundup64(ceil(size/count)); k-mer hash space is split by log2(count) bits of hashVals[0] (bits 40.., uniform even for canonical hashes)
  * (count must be a power of two).  All `dev` pointers are DEVICE pointers owned by the caller
  * (exchange buffers).  Results equal the single-GPU / sequential results bit for bit.
  *

@@ -101,8 +101,8 @@ __device__ __forceinline__ uint32_t genome_base(const uint64_t *g, int64_t i) {
 __global__ void k_synth_reads(const uint64_t *__restrict__ genome, const int64_t *__restrict__ tstart,
                               const int32_t *__restrict__ tlen, const float *__restrict__ cdf,
                               int n_tx, int64_t n_pairs, int L, int words_per_read, float frag_mean,
-                              float frag_sd, float sub_rate, float n_rate, uint64_t seed,
-                              uint64_t *__restrict__ codes, uint32_t *__restrict__ valid,
+                              float frag_sd, float sub_rate, float n_rate, uint64_t seed, int64_t pair_offset,
+                              int64_t total_pairs, uint64_t *__restrict__ codes, uint32_t *__restrict__ valid,
                               uint32_t *__restrict__ word_read) {
     int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t n_words = 2 * n_pairs * words_per_read;
@@ -110,7 +110,8 @@ __global__ void k_synth_reads(const uint64_t *__restrict__ genome, const int64_t
     int64_t r = w / words_per_read;
     int c = (int)(w - r * words_per_read);
     bool right = r >= n_pairs;
-    int64_t p = right ? r - n_pairs : r;
+    int64_t p = (right ? r - n_pairs : r) + pair_offset;       // pair id within the whole set
+    const int64_t rg = right ? total_pairs + p : p;             // read id within the whole set
     uint64_t s0 = mix64(seed ^ ((uint64_t)p * 0x9E3779B97F4A7C15ull));
     uint64_t s1 = mix64(s0), s2 = mix64(s1), s3 = mix64(s2);
     float u0 = (float)(s0 >> 40) * (1.0f / 16777216.0f);
@@ -136,7 +137,7 @@ __global__ void k_synth_reads(const uint64_t *__restrict__ genome, const int64_t
         if (b >= L) break;
         uint32_t code = right ? 3u - genome_base(genome, fstart + flen - 1 - b)
                               : genome_base(genome, fstart + b);
-        uint64_t e = mix64(seed ^ 0xA5A5A5A5ull ^ ((uint64_t)r * 0xC2B2AE3D27D4EB4Full) ^ (uint64_t)b);
+        uint64_t e = mix64(seed ^ 0xA5A5A5A5ull ^ ((uint64_t)rg * 0xC2B2AE3D27D4EB4Full) ^ (uint64_t)b);
         float ue = (float)(e >> 40) * (1.0f / 16777216.0f);
         float un = (float)((e >> 16) & 0xFFFFFFu) * (1.0f / 16777216.0f);
         bool ok = true;
@@ -635,6 +636,9 @@ int rb_batch_create_synthetic(int device, const rb_synth_params *p, rb_batch **o
     try {
         RB_REQUIRE(p && out && p->n_pairs > 0 && p->genome_bases >= 1024 && p->read_len > 0,
                    "rb_batch_create_synthetic: bad parameters");
+        RB_REQUIRE(p->pair_offset >= 0 && (p->total_pairs == 0 || p->pair_offset + p->n_pairs <= p->total_pairs),
+                   "rb_batch_create_synthetic: slice [%lld,+%lld) outside the set of %lld pairs", (long long)p->pair_offset,
+                   (long long)p->n_pairs, (long long)p->total_pairs);
         RB_REQUIRE(p->tx_min >= p->read_len && p->tx_max >= p->tx_min, "rb_batch_create_synthetic: transcript range must cover read_len");
         RB_HIP(hipSetDevice(device));
         // transcript table + expression CDF on the host (small)
@@ -704,7 +708,8 @@ int rb_batch_create_synthetic(int device, const rb_synth_params *p, rb_batch **o
             hipLaunchKernelGGL(k_synth_genome, dim3(blocks_for(gw)), dim3(TPB), 0, 0, d_genome, gw, p->seed);
             hipLaunchKernelGGL(k_synth_reads, dim3(blocks_for(b->n_words)), dim3(TPB), 0, 0, d_genome, d_ts, d_tl,
                                d_cdf, (int)tlen.size(), p->n_pairs, (int)p->read_len, wpr, (float)p->frag_mean,
-                               (float)p->frag_sd, p->sub_rate, p->n_rate, p->seed, b->codes, b->valid, b->word_read);
+                               (float)p->frag_sd, p->sub_rate, p->n_rate, p->seed, p->pair_offset,
+                               p->total_pairs > 0 ? p->total_pairs : p->n_pairs, b->codes, b->valid, b->word_read);
             chk(hipGetLastError());
             chk(hipDeviceSynchronize());
         }

@@ -2,7 +2,7 @@
 // [lo,hi) of every filter.  The phases mirror the single-GPU pipeline of rb_graph.hip, cut where data
 // has to move between ranks (see the protocol comment in include/rb_capi.h and DESIGN.md §6):
 //
-//   requester = owner of a k-mer (top log2 G bits of its hash): holds all occurrences of its k-mers
+//   requester = owner of a k-mer (log2 G middle bits of its hash): holds all occurrences of its k-mers
 //               in order, decides found-flags / op counts / counter updates;
 //   owner     = owner of a filter index range: tests & sets bits, arbitrates first setters, hands
 //               out counter claims, stores counter bytes;
@@ -159,12 +159,16 @@ struct RouteIdx {
     __device__ void drop(size_t i) const { if (pos_of) pos_of[i] = 0xFFFFFFFFu; }
 };
 
-// bounds[g] = first position whose key >= g, for g = 0..G (keys sorted ascending)
-__global__ void k_bounds(const uint64_t *__restrict__ key, size_t n, uint32_t G, uint32_t shift, uint64_t *__restrict__ bounds) {
+// k-mer owner = hash bits [OWNER_SHIFT, OWNER_SHIFT + log2 G).  Not the top bits: the canonical hash is a
+// SIGNED minimum of two hashes, which skews the sign bit 3:1 and the bits below it progressively
+// less; bits around 40 are uniform, so the ranks get equal shares of the k-mer space.
+constexpr int OWNER_SHIFT = 40;
+// bounds[g] = first position whose owner field >= g, for g = 0..G (records sorted by owner)
+__global__ void k_bounds(const uint64_t *__restrict__ key, size_t n, uint32_t G, uint64_t *__restrict__ bounds) {
     uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
     if (g > G) return;
     size_t lo = 0, hi = n;
-    while (lo < hi) { size_t mid = (lo + hi) >> 1; if ((key[mid] >> shift) < g) lo = mid + 1; else hi = mid; }
+    while (lo < hi) { size_t mid = (lo + hi) >> 1; if (((key[mid] >> OWNER_SHIFT) & (uint64_t)(G - 1u)) < g) lo = mid + 1; else hi = mid; }
     bounds[g] = lo;
 }
 
@@ -720,14 +724,14 @@ int rb_shard_hash(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, uint
                 launch_hash_windows(b, w0, nw, g->k, mode_hash, g->chunk_off.as<uint32_t>(), (uint32_t)first - read_rel_base, pos_bits,
                                     rk, ro, nullptr, nullptr, s);
                 rec_counts[0] = N;
-            } else {   // stable 1-pass bucket by k-mer owner = top log2(G) hash bits
+            } else {   // stable 1-pass bucket by k-mer owner
                 g->keys0.reserve((size_t)N * 8); g->vals0.reserve((size_t)N * 4);
                 launch_hash_windows(b, w0, nw, g->k, mode_hash, g->chunk_off.as<uint32_t>(), (uint32_t)first - read_rel_base, pos_bits,
                                     g->keys0.as<uint64_t>(), g->vals0.as<uint32_t>(), nullptr, nullptr, s);
                 g->temp.reserve(sort_pairs_temp_bytes(N));
-                sort_pairs_u64_u32(g->temp.p, g->temp.cap, g->keys0.as<uint64_t>(), rk, g->vals0.as<uint32_t>(), ro, N, 64 - S->log2G, 64, s);
+                sort_pairs_u64_u32(g->temp.p, g->temp.cap, g->keys0.as<uint64_t>(), rk, g->vals0.as<uint32_t>(), ro, N, OWNER_SHIFT, OWNER_SHIFT + S->log2G, s);
                 S->bounds.reserve(2 * (S->G + 2) * 8);
-                hipLaunchKernelGGL(k_bounds, dim3(1), dim3(128), 0, s, rk, (size_t)N, (uint32_t)S->G, (uint32_t)(64 - S->log2G), S->bounds.as<uint64_t>());
+                hipLaunchKernelGGL(k_bounds, dim3(1), dim3(128), 0, s, rk, (size_t)N, (uint32_t)S->G, S->bounds.as<uint64_t>());
                 std::vector<uint64_t> bd(S->G + 1);
                 RB_HIP(hipMemcpyAsync(bd.data(), S->bounds.p, (S->G + 1) * 8, hipMemcpyDeviceToHost, s));
                 RB_HIP(hipStreamSynchronize(s));

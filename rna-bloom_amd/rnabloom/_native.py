@@ -37,7 +37,7 @@ class SynthParams(C.Structure):
     _fields_ = [("n_pairs", C.c_int64), ("genome_bases", C.c_int64), ("read_len", C.c_int32),
                 ("frag_mean", C.c_int32), ("frag_sd", C.c_int32), ("sub_rate", C.c_float),
                 ("n_rate", C.c_float), ("expr_sigma", C.c_float), ("seed", C.c_uint64),
-                ("tx_min", C.c_int32), ("tx_max", C.c_int32)]
+                ("tx_min", C.c_int32), ("tx_max", C.c_int32), ("pair_offset", C.c_int64), ("total_pairs", C.c_int64)]
 
 
 class Profile(C.Structure):

@@ -50,9 +50,10 @@ class ReadBatch:
 
     @classmethod
     def synthetic(cls, n_pairs, genome_bases, read_len=150, frag_mean=300, frag_sd=30, sub_rate=0.001,
-                  n_rate=1e-4, expr_sigma=2.0, seed=0x5EED, tx_min=500, tx_max=4000, device=0):
+                  n_rate=1e-4, expr_sigma=2.0, seed=0x5EED, tx_min=500, tx_max=4000, device=0, pair_offset=0, total_pairs=0):
+        """pair_offset/total_pairs: this batch is the slice [pair_offset, +n_pairs) of a set of total_pairs pairs"""
         p = N.SynthParams(n_pairs, genome_bases, read_len, frag_mean, frag_sd, sub_rate, n_rate, expr_sigma,
-                          seed, tx_min, tx_max)
+                          seed, tx_min, tx_max, pair_offset, total_pairs)
         h = C.c_void_p()
         check(lib.rb_batch_create_synthetic(device, C.byref(p), C.byref(h)))
         return cls(h, device)

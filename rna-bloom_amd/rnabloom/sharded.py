@@ -304,7 +304,9 @@ def plan(max_len, k, count, max_batch_kmers=1 << 30):
     while (1 << pos_bits) <= max_len:
         pos_bits += 1
     per_read = max(1, max_len)
-    reads = max(1, min(max_batch_kmers // count, 1 << 27) // per_read)   # 8-byte keys: < 2^31 bytes per exchange
+    import os
+    cap = 1 << int(os.environ.get("RB_SHARD_RANK_LOG2", "27"))
+    reads = max(1, min(max_batch_kmers // count, cap) // per_read)
     reads = min(reads, ((1 << (32 - pos_bits)) - 1) // count)
     return pos_bits, max(1, reads)
 

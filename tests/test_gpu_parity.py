@@ -302,3 +302,20 @@ def test_synthetic_generator_consistency():
     og.add_reads(seq, None, off, 3, rbo.STORE_READ_PAIRS)
     gg.addBatch(b, storeReadPairedKmers=True)
     assert_same_state(og, gg)
+
+
+def test_synthetic_slices_are_the_whole_set():
+    """rank slices (pair_offset/total_pairs) of the device generator reassemble the single-batch read set"""
+    whole = ReadBatch.synthetic(3000, 1 << 16, seed=11)
+    seq, off = whole.download()
+    reads = seq.reshape(-1, 150)
+    for G in (2, 3):
+        per = 3000 // G
+        for r in range(G):
+            part = ReadBatch.synthetic(per, 1 << 16, seed=11, pair_offset=r * per, total_pairs=3000)
+            ps, _ = part.download()
+            pr = ps.reshape(-1, 150)
+            assert (pr[:per] == reads[r * per:(r + 1) * per]).all(), "left reads differ"
+            assert (pr[per:] == reads[3000 + r * per:3000 + (r + 1) * per]).all(), "right reads differ"
+    with pytest.raises(N.NativeError):
+        ReadBatch.synthetic(10, 1 << 16, pair_offset=5, total_pairs=12)

@@ -43,7 +43,8 @@ def main():
     sz = N.lib.rb_expected_size(a.nk, 0.01, 2)
     pairs_rank = a.pairs // G
     ranks = [sharded.ShardRank((sz, sz, sz, 2, 2, 2, k, 0, 1, 0, 0, 1, a.batch_kmers), r, G, 0) for r in range(G)]
-    batches = [ReadBatch.synthetic(pairs_rank, a.genome, 150, 300, 30, 0.001, 1e-4, 2.0, seed=0x5EED + r, device=0) for r in range(G)]
+    batches = [ReadBatch.synthetic(pairs_rank, a.genome, 150, 300, 30, 0.001, 1e-4, 2.0, seed=0x5EED, device=0,
+                                   pair_offset=r * pairs_rank, total_pairs=pairs_rank * G) for r in range(G)]
     for r in ranks:
         r.set_read_pair_distance(max(1, 150 - k - 10))
     pos_bits, rps = sharded.plan(150, k, G, a.batch_kmers or (1 << 30))
