@@ -142,6 +142,8 @@ def main():
         step()
     if sharded_mode and os.environ.get("RB_SHARD_TRACE"):
         sharded.TRACE = {}
+        torch.cuda.synchronize()
+        sharded._t_last[0] = time.perf_counter()
     g.profileEnable(True)   # HIP events on the library's own stream, around every stage launch
     g.profileGet(reset=True)
     barrier()
@@ -207,10 +209,18 @@ def main():
             out["shard_phase_ms_per_step"] = {kk: round(v / a.steps, 1) for kk, v in sorted(sharded.TRACE.items(), key=lambda kv: -kv[1])}
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(a, batch, dbg_bits, cbf_bytes, pk_bits, dist_pk)
-        print(json.dumps(out))
     if sharded_mode:
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes a version banner through C stdio; flush it first so the JSON is the LAST line
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 def check_(sr, on):

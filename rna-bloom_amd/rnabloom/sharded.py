@@ -298,14 +298,15 @@ def run_distributed(gen, group=None):
 
 def plan(max_len, k, count, max_batch_kmers=1 << 30):
     """(pos_bits, reads per rank per sub-batch) so that a global sub-batch stays within the limits.
-    Per rank a sub-batch is capped at 2^27 k-mers: exchange buffers (torch) and library scratch both
-    scale with it."""
+    Per rank a sub-batch is capped at 2^28 k-mers (RB_SHARD_RANK_LOG2): exchange buffers (torch) and
+    library scratch both scale with it.  Bigger sub-batches merge more occurrences per run and need
+    fewer exchange rounds; smaller ones keep the prefilter cache fresher and conflicts rarer."""
     pos_bits = 1
     while (1 << pos_bits) <= max_len:
         pos_bits += 1
     per_read = max(1, max_len)
     import os
-    cap = 1 << int(os.environ.get("RB_SHARD_RANK_LOG2", "27"))
+    cap = 1 << int(os.environ.get("RB_SHARD_RANK_LOG2", "28"))
     reads = max(1, min(max_batch_kmers // count, cap) // per_read)
     reads = min(reads, ((1 << (32 - pos_bits)) - 1) // count)
     return pos_bits, max(1, reads)
