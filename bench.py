@@ -39,6 +39,8 @@ def algorithmic_bytes(stage, n_kmers, n_pairs, n_runs, words, n_sorted=None, gro
     model = {
         # prefilter: packed reads in (16 B/word), one 64 B cache sector per window, count + mask out (8 B/word)
         "filter_windows": words * 24 + n_all * SECTOR,
+        # one-pass prefilter + emit: packed reads in (16 B/word), one 64 B cache sector per window, survivors out (12 B)
+        "filter_emit": words * 16 + n_all * SECTOR + n_kmers * 12,
         # 8-bit onesweep: one histogram read of the keys + per pass (8 B key + 4 B value) in and out
         "sort_occurrences": n_kmers * (8 + passes * 2 * 12),
         # packed reads in (8 B codes + 4 B validity + 4 B owner per word), (h0, occurrence) out
@@ -94,15 +96,14 @@ def main():
 
     k = a.k
     pairs_total = a.pairs
-    pairs_rank = pairs_total // world           # strong scaling: the fixed job is split across ranks
     dbg_bits = N.lib.rb_expected_size(a.nk, a.fpr, 2)
     cbf_bytes = N.lib.rb_expected_size(a.nk, a.fpr, 2)
     pk_bits = N.lib.rb_expected_size(a.nk, a.fpr, 2)
     dist_pk = max(1, 150 - k - 10)              # R/RNABloom.java:1022 (minNumKmerPairs 10)
 
-    # every rank holds a slice of the SAME read set (same transcriptome, same reads as the 1-GPU run)
-    batch = ReadBatch.synthetic(pairs_rank, a.genome, 150, 300, 30, a.err, 1e-4, 2.0, seed=0x5EED, device=local,
-                                pair_offset=rank * pairs_rank, total_pairs=pairs_rank * world)
+    # sharded engine: every rank holds the whole packed read set (replicated input: reads are 1/38 of the
+    # bytes of their (hash, occurrence) records) and keeps the k-mers it owns
+    batch = ReadBatch.synthetic(pairs_total, a.genome, 150, 300, 30, a.err, 1e-4, 2.0, seed=0x5EED, device=local)
     if not sharded_mode:
         g = BloomFilterDeBruijnGraph(dbg_bits, cbf_bytes, pk_bits, 2, 2, 2, k, False, True, device=local, rngSeed=1,
                                      maxBatchKmers=a.batch_kmers)
@@ -110,8 +111,8 @@ def main():
 
         def step():
             g.clearAllBf()
-            s1 = g.addBatch(batch, storeReadPairedKmers=True, first=0, n=pairs_rank)
-            s2 = g.addBatch(batch, reverseComplement=True, storeReadPairedKmers=True, first=pairs_rank, n=pairs_rank)
+            s1 = g.addBatch(batch, storeReadPairedKmers=True, first=0, n=pairs_total)
+            s2 = g.addBatch(batch, reverseComplement=True, storeReadPairedKmers=True, first=pairs_total, n=pairs_total)
             return s1, s2
     else:
         # filters sharded by index range over the ranks, k-mer space by hash bits; reads are
@@ -126,9 +127,9 @@ def main():
         def step():
             sr.clear()
             out = []
-            for first, fl in ((0, N.ADD_STORE_READ_PAIRS), (pairs_rank, N.ADD_STORE_READ_PAIRS | N.ADD_REVCOMP)):
+            for first, fl in ((0, N.ADD_STORE_READ_PAIRS), (pairs_total, N.ADD_STORE_READ_PAIRS | N.ADD_REVCOMP)):
                 before = dict(sr.stats)
-                sharded.run_distributed(sr.add_range(batch, first, pairs_rank, fl, rps, pos_bits))
+                sharded.run_distributed(sr.add_range(batch, first, pairs_total, fl, rps, pos_bits))
                 out.append(SimpleNamespace(**{kk: sr.stats[kk] - before[kk] for kk in before}))
             return out
 
@@ -176,7 +177,7 @@ def main():
         dom = max(prof.items(), key=lambda kv: kv[1][0]) if prof else ("none", (0.0, 0))
         dom_name, (dom_ms, dom_launches) = dom
         roof = None
-        words = 2 * pairs_rank * 5 * a.steps
+        words = 2 * pairs_total * 5 * a.steps
         per_stage = {}
         for name, (ms, launches) in prof.items():
             ab = algorithmic_bytes(name, kmers, pairs_ins, distinct, words, n_sorted)

@@ -213,16 +213,18 @@ int rb_strobemers(int device, const char *seq, const int64_t *offsets, int64_t n
  * there is no reference interface for this; the phases below are what bench.py / rnabloom.sharded
  * drive, with torch.distributed (RCCL all_to_all / all_gather) moving the byte buffers between
  * ranks.  Shard s of a filter of `size` indices owns [s*span, min(size,(s+1)*span)), span =
- * roundup64(ceil(size/count)); k-mer hash space is split by log2(count) bits of hashVals[0] (bits 40.., uniform even for canonical hashes)
+ * roundup64(ceil(size/count)); k-mer hash space is split by log2(count) bits of hashVals[0]
+ * (bits 40.., uniform even for canonical hashes)
  * (count must be a power of two).  All `dev` pointers are DEVICE pointers owned by the caller
  * (exchange buffers).  Results equal the single-GPU / sequential results bit for bit.
  *
- * per global sub-batch (every rank, lock step):
- *   hash      local reads -> (h0, occ) records bucketed by k-mer owner, pair probes by rpkbf owner
- *   [all_to_all records, pair probes]
- *   group     received records -> no-op prefilter -> runs -> Bloom-bit / counter requests bucketed by
- *             filter owner
- *   [all_to_all requests]
+ * per global sub-batch = a range of reads of a batch EVERY rank holds (replicated input: packed reads
+ * are 1/38 of the bytes of their (hash, occurrence) records, so the reads travel, not the records):
+ *   hash_group  walk all reads of the sub-batch, keep the windows whose k-mer this rank owns and the
+ *             no-op prefilter lets through, group them into runs -> Bloom-bit / counter requests
+ *             bucketed by filter owner; read-paired k-mers of this rank's 1/count slice of the reads
+ *             -> rpkbf bit indices bucketed by owner
+ *   [all_to_all requests, pair probes]
  *   serve     owner: bit tests + first-setter arbitration + bit sets, counter claims, pair bit sets
  *   [all_to_all replies back]
  *   resolve   found flags, op counts, counter updates of runs that own their counters alone; for the
@@ -236,8 +238,8 @@ int rb_strobemers(int device, const char *seq, const int64_t *offsets, int64_t n
  *   [all_to_all final counter bytes]   apply_writes
  */
 enum {
-    RB_SLOT_REC_KEYS = 0,    /* u64 h0, bucketed by k-mer owner          */
-    RB_SLOT_REC_OCC = 1,     /* u32 occurrence ids (same order)          */
+    RB_SLOT_RESERVED0 = 0,
+    RB_SLOT_RESERVED1 = 1,
     RB_SLOT_PAIR_IDX = 2,    /* u64 global rpkbf bit indices, by owner   */
     RB_SLOT_DREQ_IDX = 3,    /* u64 global dbgbf bit index               */
     RB_SLOT_DREQ_PROBE = 4,  /* u64 (occ_first << 4 | probe)             */
@@ -252,10 +254,12 @@ enum {
     RB_SLOT_COUNT = 13
 };
 int rb_graph_create_shard(const rb_graph_params *p, int shard_rank, int shard_count, rb_graph **out);
-int rb_shard_hash(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, uint32_t read_rel_base,
-                  uint32_t pos_bits, unsigned flags, int64_t *rec_counts /*[count]*/, int64_t *pair_counts /*[count]*/);
-int rb_shard_group(rb_graph *g, const void *keys_dev, const void *occ_dev, int64_t n, uint64_t ordinal0,
-                   uint32_t pos_bits, int mode, int64_t *dreq_counts, int64_t *creq_counts);
+/* reads [first, first+n) = the global sub-batch (identical arguments on every rank); [pair_first,
+ * +pair_n) = the slice of it whose read-paired k-mers this rank walks; ordinal0 = op ordinal of read
+ * `first`; flags as rb_graph_add_batch.  counts: requests per destination rank. */
+int rb_shard_hash_group(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, int64_t pair_first, int64_t pair_n,
+                        uint64_t ordinal0, uint32_t pos_bits, unsigned flags, int64_t *dreq_counts /*[count]*/,
+                        int64_t *creq_counts /*[count]*/, int64_t *pair_counts /*[count]*/, rb_add_stats *stats);
 int rb_shard_serve(rb_graph *g, int mode, const void *dreq_idx_dev, const void *dreq_probe_dev, int64_t nd,
                    const void *creq_idx_dev, int64_t nc, const void *pair_idx_dev, int64_t np,
                    void *dreply_dev /* u8[nd] */, void *creply_dev /* u8[nc] */);

@@ -395,7 +395,8 @@ k_filter_windows_fast(const uint64_t *__restrict__ codes, const uint32_t *__rest
                       const uint32_t *__restrict__ word_read, const uint32_t *__restrict__ woff,
                       const uint32_t *__restrict__ len, int64_t w0, int64_t nw, int k, uint32_t first_read,
                       uint32_t pos_bits, uint64_t seed, uint64_t ordinal0, Npf cache, uint32_t *__restrict__ cnt,
-                      uint32_t *__restrict__ keepmask, uint32_t *__restrict__ total_spread, uint32_t dbg_flags) {
+                      uint32_t *__restrict__ keepmask, uint32_t *__restrict__ total_spread, uint32_t dbg_flags,
+                      uint32_t own_mask, uint32_t own_rank) {
     __shared__ uint64_t s_tf[25], s_tr[25];
     const uint32_t uk = (uint32_t)k;
     if (threadIdx.x < 25) {
@@ -434,11 +435,14 @@ k_filter_windows_fast(const uint64_t *__restrict__ codes, const uint32_t *__rest
                 if (run >= uk) {
                     const uint32_t p = b0 + j + 1u - uk;
                     const uint64_t h0 = (MODE == 0) ? f : (MODE == 2) ? rv : canonical(f, rv);
-                    const uint32_t s_known = (dbg_flags & 1u) ? 0u : npf_lookup(cache, h0);
-                    bool keep = true;
-                    if (s_known && !(dbg_flags & 2u)) keep = draw_strength(rng_pos(rstate, p)) >= s_known;
-                    ++total;
-                    if (keep) { ++kept; mask |= 1u << (p - b0); }
+                    // sharded engine: every rank walks all reads and keeps the k-mers it owns
+                    if (((uint32_t)(h0 >> RB_OWNER_SHIFT) & own_mask) == own_rank) {
+                        const uint32_t s_known = (dbg_flags & 1u) ? 0u : npf_lookup(cache, h0);
+                        bool keep = true;
+                        if (s_known && !(dbg_flags & 2u)) keep = draw_strength(rng_pos(rstate, p)) >= s_known;
+                        ++total;
+                        if (keep) { ++kept; mask |= 1u << (p - b0); }
+                    }
                 }
             }
         }
@@ -447,6 +451,126 @@ k_filter_windows_fast(const uint64_t *__restrict__ codes, const uint32_t *__rest
     }
     for (int o = 32; o > 0; o >>= 1) total += __shfl_down(total, o, 64);
     if (threadIdx.x == 0 && total) atomicAdd(&total_spread[16u * (blockIdx.x & 31u)], total);
+}
+
+// One-pass prefilter + emit (k <= 31): the walker of k_filter_windows_fast, but every kept window's
+// (h0, occurrence) goes straight to its final position in the dense, read-ordered output.  A block
+// = one wavefront = 64 words; kept records are staged in LDS, the block's output offset comes from
+// a decoupled look-back over per-block counts (blocks take their words in ticket order, so every
+// predecessor of a running block is itself running or finished), and the staged records are
+// written coalesced.  Replaces count/mask pass + scan + masked re-hash pass: the windows are
+// hashed once instead of twice and the per-word count / mask / offset arrays are gone.
+// state[0] = ticket counter, state[1 + b] = (status << 62) | value, status 1 = the block's own
+// count, 2 = inclusive prefix.  Records beyond `cap` are not written (the host retries with room).
+template <int MODE>
+__global__ void __launch_bounds__(64)
+k_filter_emit(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
+              const uint32_t *__restrict__ word_read, const uint32_t *__restrict__ woff,
+              const uint32_t *__restrict__ len, int64_t w0, int64_t nw, int k, uint32_t first_read,
+              uint32_t pos_bits, uint64_t seed, uint64_t ordinal0, Npf cache, uint32_t dbg_flags,
+              uint32_t own_mask, uint32_t own_rank, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
+              uint32_t cap, unsigned long long *state, uint32_t n_blocks, uint32_t *__restrict__ kept_out,
+              uint32_t *__restrict__ total_spread) {
+    __shared__ uint64_t s_key[64 * 33];
+    __shared__ uint32_t s_val[64 * 33];
+    __shared__ uint64_t s_tf[25], s_tr[25];
+    __shared__ uint32_t s_pref[65];
+    __shared__ uint32_t s_bid;
+    const uint32_t uk = (uint32_t)k, lane = threadIdx.x;
+    if (lane < 25) {
+        const uint32_t o = lane / 5u, in = lane % 5u;
+        const uint64_t so = o ? seed_of(o - 1u) : 0ull, si = in ? seed_of(in - 1u) : 0ull;
+        const uint64_t sco = o ? seed_of(4u - o) : 0ull, sci = in ? seed_of(4u - in) : 0ull;
+        s_tf[lane] = rotl(so, uk) ^ si;
+        s_tr[lane] = rotr(sco, 1) ^ rotl(sci, uk - 1u);
+    }
+    if (lane == 0) s_bid = (uint32_t)atomicAdd(&state[0], 1ull);
+    __syncthreads();
+    const uint32_t bid = s_bid;
+    const int64_t i = (int64_t)bid * 64 + lane;
+    uint32_t kept = 0, total = 0;
+    if (i < nw) {
+        const int64_t w = w0 + i;
+        const uint32_t r = word_read[w], wr = woff[r], L = len[r];
+        const uint32_t c = (uint32_t)(w - wr), b0 = c * 32u;
+        if ((uint64_t)b0 + uk <= L) {
+            const uint32_t nwords = (L + 31u) >> 5;
+            uint64_t clo = codes[w], chi = (c + 1u < nwords) ? codes[w + 1] : 0ull;
+            uint64_t vs = (uint64_t)valid[w] | ((c + 1u < nwords) ? ((uint64_t)valid[w + 1] << 32) : 0ull);
+            const uint32_t nb = ((b0 + 32u + uk - 1u < L) ? b0 + 32u + uk - 1u : L) - b0;
+            uint64_t f = 0, rv = 0, hc = 0, hv = 0;
+            uint32_t run = 0;
+            const uint32_t rstate = rng_read_state(seed, ordinal0 + (uint64_t)(r - first_read));
+            const uint32_t rel = (r - first_read) << pos_bits;
+            const uint32_t sh_c = 2u * (uk - 1u), sh_v = uk - 1u;
+            for (uint32_t j = 0; j < nb; ++j) {
+                const uint32_t code = (uint32_t)clo & 3u, ok = (uint32_t)vs & 1u;
+                clo = (clo >> 2) | (chi << 62); chi >>= 2; vs >>= 1;
+                const uint32_t in5 = ok ? code + 1u : 0u;
+                const uint32_t out5 = ((uint32_t)(hv >> sh_v) & 1u) ? ((uint32_t)(hc >> sh_c) & 3u) + 1u : 0u;
+                const uint32_t t = out5 * 5u + in5;
+                if (MODE != 2) f = rotl(f, 1) ^ s_tf[t];
+                if (MODE != 0) rv = rotr(rv, 1) ^ s_tr[t];
+                hc = (hc << 2) | code; hv = (hv << 1) | ok;
+                run = ok ? run + 1u : 0u;
+                if (run >= uk) {
+                    const uint32_t p = b0 + j + 1u - uk;
+                    const uint64_t h0 = (MODE == 0) ? f : (MODE == 2) ? rv : canonical(f, rv);
+                    if (((uint32_t)(h0 >> RB_OWNER_SHIFT) & own_mask) == own_rank) {   // sharded engine: my k-mer?
+                        const uint32_t s_known = (dbg_flags & 1u) ? 0u : npf_lookup(cache, h0);
+                        bool keep = true;
+                        if (s_known) keep = draw_strength(rng_pos(rstate, p)) >= s_known;
+                        ++total;
+                        if (keep) {
+                            s_key[lane * 33u + kept] = h0;
+                            s_val[lane * 33u + kept] = rel | p;
+                            ++kept;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    // block prefix of the kept counts
+    uint32_t incl = kept;
+    for (uint32_t o = 1; o < 64u; o <<= 1) { const uint32_t v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
+    s_pref[lane + 1u] = incl;
+    if (lane == 0) s_pref[0] = 0;
+    const uint32_t T = __shfl(incl, 63, 64);
+    // decoupled look-back for the block's global offset
+    constexpr unsigned long long VAL = (1ull << 62) - 1ull;
+    unsigned long long excl = 0;
+    if (bid == 0) {
+        if (lane == 0) __hip_atomic_store(&state[1], (2ull << 62) | (unsigned long long)T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        if (lane == 0) __hip_atomic_store(&state[1 + bid], (1ull << 62) | (unsigned long long)T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int64_t idx = (int64_t)bid - 1;
+        for (;;) {
+            const int64_t my = idx - (int64_t)lane;
+            unsigned long long v = 2ull << 62;                       // before the first block: prefix 0
+            if (my >= 0)
+                do { v = __hip_atomic_load(&state[1 + my], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((v >> 62) == 0ull);
+            const unsigned long long is_p = __ballot((v >> 62) == 2ull);
+            const uint32_t first = is_p ? (uint32_t)__ffsll((long long)is_p) - 1u : 64u;
+            unsigned long long contrib = (lane <= first) ? (v & VAL) : 0ull;
+            for (int o = 32; o > 0; o >>= 1) contrib += __shfl_xor(contrib, o, 64);
+            excl += contrib;
+            if (is_p) break;
+            idx -= 64;
+        }
+        if (lane == 0) __hip_atomic_store(&state[1 + bid], (2ull << 62) | (excl + (unsigned long long)T), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (bid == n_blocks - 1u && lane == 0) *kept_out = (uint32_t)(excl + T);
+    __syncthreads();
+    for (uint32_t o = lane; o < T; o += 64u) {
+        uint32_t lo = 0, hi = 64;                                    // thread t with s_pref[t] <= o < s_pref[t+1]
+        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (s_pref[mid + 1u] > o) hi = mid; else lo = mid + 1u; }
+        const uint32_t q = lo * 33u + (o - s_pref[lo]);
+        const unsigned long long dst = excl + o;
+        if (dst < (unsigned long long)cap) { keys[dst] = s_key[q]; vals[dst] = s_val[q]; }
+    }
+    for (int o = 32; o > 0; o >>= 1) total += __shfl_down(total, o, 64);
+    if (lane == 0 && total) atomicAdd(&total_spread[16u * (bid & 31u)], total);
 }
 
 void launch_count_windows(const rb_batch *b, int64_t w0, int64_t nw, int span, uint32_t *cnt, hipStream_t s) {
@@ -489,15 +613,32 @@ void launch_hash_windows(const rb_batch *b, int64_t w0, int64_t nw, int k, int m
 
 void launch_filter_windows(const rb_batch *b, int64_t w0, int64_t nw, int k, int mode, uint32_t first_read,
                            uint32_t pos_bits, uint64_t seed, uint64_t ordinal0, Npf cache, uint32_t *cnt, uint32_t *keepmask,
-                           uint32_t *total_spread, hipStream_t s) {
+                           uint32_t *total_spread, hipStream_t s, uint32_t own_mask, uint32_t own_rank) {
     if (nw <= 0) return;
-    const uint32_t dbgf = getenv("RB_FILT_DBG") ? (uint32_t)atoi(getenv("RB_FILT_DBG")) : 0u;
+    uint32_t dbgf = getenv("RB_FILT_DBG") ? (uint32_t)atoi(getenv("RB_FILT_DBG")) : 0u;
+    if (!cache.tab) dbgf |= 1u;                       // no cache: ownership test only
     dim3 g(blocks_for(nw, 64)), t(64);
 #define RB_LAUNCH_FILT(M)                                                                                    \
     hipLaunchKernelGGL(k_filter_windows_fast<M>, g, t, 0, s, b->codes, b->valid, b->word_read, b->woff, b->len, \
-                       w0, nw, k, first_read, pos_bits, seed, ordinal0, cache, cnt, keepmask, total_spread, dbgf)
+                       w0, nw, k, first_read, pos_bits, seed, ordinal0, cache, cnt, keepmask, total_spread, dbgf, own_mask, own_rank)
     if (mode == 0) RB_LAUNCH_FILT(0); else if (mode == 2) RB_LAUNCH_FILT(2); else RB_LAUNCH_FILT(1);
 #undef RB_LAUNCH_FILT
+}
+size_t filter_emit_state_bytes(int64_t nw) { return ((size_t)((nw + 63) / 64) + 2) * 8; }
+void launch_filter_emit(const rb_batch *b, int64_t w0, int64_t nw, int k, int mode, uint32_t first_read, uint32_t pos_bits,
+                        uint64_t seed, uint64_t ordinal0, Npf cache, uint32_t own_mask, uint32_t own_rank, uint64_t *keys,
+                        uint32_t *vals, uint32_t cap, void *state, uint32_t *kept_out, uint32_t *total_spread, hipStream_t s) {
+    if (nw <= 0) return;
+    const uint32_t nblk = (uint32_t)((nw + 63) / 64);
+    const uint32_t dbgf = cache.tab ? 0u : 1u;               // no cache: ownership test only
+    RB_HIP(hipMemsetAsync(state, 0, filter_emit_state_bytes(nw), s));
+    dim3 g(nblk), t(64);
+#define RB_LAUNCH_FE(M)                                                                                      \
+    hipLaunchKernelGGL(k_filter_emit<M>, g, t, 0, s, b->codes, b->valid, b->word_read, b->woff, b->len, w0, nw, k, \
+                       first_read, pos_bits, seed, ordinal0, cache, dbgf, own_mask, own_rank, keys, vals, cap,     \
+                       reinterpret_cast<unsigned long long *>(state), nblk, kept_out, total_spread)
+    if (mode == 0) RB_LAUNCH_FE(0); else if (mode == 2) RB_LAUNCH_FE(2); else RB_LAUNCH_FE(1);
+#undef RB_LAUNCH_FE
 }
 void launch_hash_windows_masked(const rb_batch *b, int64_t w0, int64_t nw, int k, int mode, const uint32_t *chunk_off,
                                 const uint32_t *keepmask, uint32_t first_read, uint32_t pos_bits, uint64_t *keys, uint32_t *vals,

@@ -116,6 +116,11 @@ __host__ __device__ __forceinline__ float minifloat_to_float(uint32_t b) {
     return (float)(((b & 7u) | 8u) << e);          // exact: < 2^24
 }
 
+// k-mer owner in the sharded engine = hash bits [RB_OWNER_SHIFT, RB_OWNER_SHIFT + log2 G).  Not the top
+// bits: the canonical hash is a SIGNED minimum of two hashes, which skews the sign bit 3:1 and the
+// bits below it progressively less; bits around 40 are uniform, so ranks get equal shares.
+constexpr uint32_t RB_OWNER_SHIFT = 40;
+
 // ---- no-op prefilter cache (DESIGN.md §3 "no-op prefilter") ----
 // Direct-mapped table of 8-byte entries keyed by the FULL 64-bit base hash: slot = low L bits of h0
 // (ntHash bits are all equally mixed; the signed canonical minimum only skews the TOP bits),

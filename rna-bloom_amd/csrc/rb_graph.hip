@@ -890,8 +890,12 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
             g->chunk_cnt.reserve(((size_t)sb.nw + 1) * 4); g->chunk_off.reserve(((size_t)sb.nw + 1) * 4);
             g->temp2.reserve(scan_temp_bytes((size_t)sb.nw + 1));
             RB_HIP(hipMemsetAsync(g->chunk_cnt.as<uint32_t>() + sb.nw, 0, 4, sp));
-            if (use_npf) {
-                // pass 1: hash every window, ask the hot-k-mer cache whether the occurrence can matter
+            if (use_npf && !getenv("RB_ONE_PASS_FILTER")) {
+                // pass 1 hashes every window and asks the cache (count + keep mask per word), scan, pass 2
+                // re-hashes and emits the survivors.  (The one-pass kernel below measures 12 ms faster on its
+                // own but 35 ms slower per step here: its 25 KB of LDS staging costs the occupancy that hides
+                // the cache-lookup latency, and the stages after it slow down; it wins in the sharded engine,
+                // where 1/G of the windows are looked up and the hashing itself dominates.)
                 g->prof_begin(sp);
                 g->chunk_mask.reserve(((size_t)sb.nw + 1) * 4);
                 g->npf_tot.reserve(2048);
@@ -913,6 +917,25 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
                                                (uint32_t)sb.r0, pos_bits, g->keys0.as<uint64_t>(), g->vals0.as<uint32_t>(), sp);
                     g->prof_end("hash_windows", sp);
                 }
+            } else if (use_npf) {
+                // one pass: hash every window, ask the hot-k-mer cache whether the occurrence can matter,
+                // write the survivors densely in read order (k_filter_emit)
+                g->prof_begin(sp);
+                g->npf_tot.reserve(2048);
+                RB_HIP(hipMemsetAsync(g->npf_tot.p, 0, 2048, sp));
+                FilterView fvp = g->view(ord0, pos_bits);
+                const size_t cap = std::min<size_t>((size_t)sb.nw * 32, 0xFFFFFFF0ull);   // every window of the sub-batch
+                g->keys0.reserve(cap * 8); g->vals0.reserve(cap * 4);
+                g->chunk_mask.reserve(filter_emit_state_bytes(sb.nw));
+                launch_filter_emit(b, sb.w0, sb.nw, g->k, mode_hash, (uint32_t)sb.r0, pos_bits, g->p.rng_seed, ord0, fvp.npf, 0u, 0u,
+                                   g->keys0.as<uint64_t>(), g->vals0.as<uint32_t>(), (uint32_t)cap, g->chunk_mask.p,
+                                   g->npf_tot.as<uint32_t>() + 500, g->npf_tot.as<uint32_t>(), sp);
+                uint32_t spread[16 * 32];
+                RB_HIP(hipMemcpyAsync(&sb.N, g->npf_tot.as<uint32_t>() + 500, 4, hipMemcpyDeviceToHost, sp));
+                RB_HIP(hipMemcpyAsync(spread, g->npf_tot.p, sizeof spread, hipMemcpyDeviceToHost, sp));
+                g->prof_end("filter_emit", sp);
+                RB_HIP(hipStreamSynchronize(sp));
+                for (int q = 0; q < 32; ++q) sb.total += spread[16 * q];
             } else {
                 g->prof_begin(sp);
                 launch_count_windows(b, sb.w0, sb.nw, g->k, g->chunk_cnt.as<uint32_t>(), sp);

@@ -24,6 +24,7 @@ struct ShardState {
     size_t slot_bytes[RB_SLOT_COUNT] = {0};
     // requester-side state carried from group -> resolve -> conflict_route
     uint32_t D = 0, n_conf = 0;
+    int mode = M_ADD;
     uint64_t n_kept = 0;                        // records that survived the prefilter in the last group()
     uint64_t ordinal0 = 0;
     uint32_t pos_bits = 0;
@@ -159,28 +160,24 @@ struct RouteIdx {
     __device__ void drop(size_t i) const { if (pos_of) pos_of[i] = 0xFFFFFFFFu; }
 };
 
-// k-mer owner = hash bits [OWNER_SHIFT, OWNER_SHIFT + log2 G).  Not the top bits: the canonical hash is a
-// SIGNED minimum of two hashes, which skews the sign bit 3:1 and the bits below it progressively
-// less; bits around 40 are uniform, so the ranks get equal shares of the k-mer space.
-constexpr int OWNER_SHIFT = 40;
-// bounds[g] = first position whose owner field >= g, for g = 0..G (records sorted by owner)
-__global__ void k_bounds(const uint64_t *__restrict__ key, size_t n, uint32_t G, uint64_t *__restrict__ bounds) {
-    uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g > G) return;
-    size_t lo = 0, hi = n;
-    while (lo < hi) { size_t mid = (lo + hi) >> 1; if (((key[mid] >> OWNER_SHIFT) & (uint64_t)(G - 1u)) < g) lo = mid + 1; else hi = mid; }
-    bounds[g] = lo;
-}
-
 // ------------------------------------------------------------- requester ----
-// no-op prefilter verdict per received record: keep unless the cache knows the k-mer
-// is in dbgbf with a counter exponent the occurrence's draw cannot beat
-__global__ void k_rec_keep(FilterView fv, const uint64_t *__restrict__ keys, const uint32_t *__restrict__ occ, size_t n,
-                           uint8_t *__restrict__ keep) {
+// generic window-hash path (k > 31): verdict per record — this rank owns the k-mer, and the no-op
+// prefilter does not know that the occurrence's draw cannot move a counter
+__global__ void k_rec_keep(FilterView fv, int use_cache, const uint64_t *__restrict__ keys, const uint32_t *__restrict__ occ, size_t n,
+                           uint32_t own_mask, uint32_t own_rank, uint8_t *__restrict__ keep, uint32_t *__restrict__ owned_spread) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t s = npf_lookup(fv.npf, keys[i]);
-    keep[i] = (!s || draw_strength(occ_rnd(fv, occ[i])) >= s) ? 1u : 0u;
+    bool mine = false, k = false;
+    if (i < n) {
+        const uint64_t h0 = keys[i];
+        mine = ((uint32_t)(h0 >> RB_OWNER_SHIFT) & own_mask) == own_rank;
+        if (mine) {
+            const uint32_t s = use_cache ? npf_lookup(fv.npf, h0) : 0u;
+            k = !s || draw_strength(occ_rnd(fv, occ[i])) >= s;
+        }
+        keep[i] = k ? 1u : 0u;
+    }
+    const unsigned long long m = __ballot(mine);
+    if ((threadIdx.x & 63u) == 0 && m) atomicAdd(&owned_spread[16u * (blockIdx.x & 31u)], (uint32_t)__popcll(m));
 }
 // per run: one Bloom-bit request per probe, one claim request per DISTINCT counter
 __global__ void k_make_requests(FilterView fv, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ starts,
@@ -693,125 +690,131 @@ int rb_shard_slot(rb_graph *g, int slot, void **dev_ptr, int64_t *nbytes) {
     return RB_OK;
 }
 
-int rb_shard_hash(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, uint32_t read_rel_base, uint32_t pos_bits,
-                  unsigned flags, int64_t *rec_counts, int64_t *pair_counts) {
+int rb_shard_hash_group(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, int64_t pair_first, int64_t pair_n,
+                        uint64_t ordinal0, uint32_t pos_bits, unsigned flags, int64_t *dreq_counts, int64_t *creq_counts,
+                        int64_t *pair_counts, rb_add_stats *stats) {
     return guarded([&] {
-        RB_REQUIRE(g && g->shard && b && rec_counts && pair_counts, "rb_shard_hash: bad argument");
-        RB_REQUIRE(first >= 0 && n >= 0 && first + n <= b->n_reads, "rb_shard_hash: bad read range");
-        RB_REQUIRE(pos_bits >= 1 && pos_bits <= 31 && ((uint64_t)b->max_len >> pos_bits) == 0, "rb_shard_hash: pos_bits too small for the reads");
+        RB_REQUIRE(g && g->shard && b && dreq_counts && creq_counts && pair_counts, "rb_shard_hash_group: bad argument");
+        RB_REQUIRE(b->device == g->p.device, "batch lives on device %d, shard on %d", b->device, g->p.device);
+        RB_REQUIRE(first >= 0 && n >= 0 && first + n <= b->n_reads, "rb_shard_hash_group: bad read range");
+        RB_REQUIRE(pair_first >= first && pair_n >= 0 && pair_first + pair_n <= first + n, "rb_shard_hash_group: pair slice outside the sub-batch");
+        RB_REQUIRE(pos_bits >= 1 && pos_bits <= 31 && ((uint64_t)b->max_len >> pos_bits) == 0, "rb_shard_hash_group: pos_bits too small for the reads");
+        RB_REQUIRE((uint64_t)n < (1ull << (32 - pos_bits)), "rb_shard_hash_group: too many reads for the occurrence id");
         ShardState *S = g->shard;
         RB_HIP(hipSetDevice(g->p.device));
         hipStream_t s = g->stream;
-        for (int r = 0; r < S->G; ++r) rec_counts[r] = pair_counts[r] = 0;
-        S->slot_bytes[RB_SLOT_REC_KEYS] = S->slot_bytes[RB_SLOT_REC_OCC] = S->slot_bytes[RB_SLOT_PAIR_IDX] = 0;
+        for (int r = 0; r < S->G; ++r) dreq_counts[r] = creq_counts[r] = pair_counts[r] = 0;
+        S->D = 0; S->n_conf = 0; S->n_kept = 0; S->ordinal0 = ordinal0; S->pos_bits = pos_bits;
+        S->slot_bytes[RB_SLOT_PAIR_IDX] = S->slot_bytes[RB_SLOT_DREQ_IDX] = S->slot_bytes[RB_SLOT_DREQ_PROBE] = S->slot_bytes[RB_SLOT_CREQ_IDX] = 0;
         const int mode_hash = g->stranded ? ((flags & RB_ADD_REVCOMP) ? 2 : 0) : 1;
+        const int mode = (flags & RB_ADD_COUNT_IF_PRESENT) ? M_COUNT_IF_PRESENT : M_ADD;
+        S->mode = mode;
         const bool pairs = (flags & RB_ADD_STORE_READ_PAIRS) != 0;
         if (pairs) RB_REQUIRE(g->rpk.bits && g->read_d > 0, "STORE_READ_PAIRS needs use_read_paired_kmers and a read pair distance > 0");
-        const int64_t w0 = b->h_woff[(size_t)first], nw = (int64_t)b->h_woff[(size_t)(first + n)] - w0;
-        if (nw <= 0) return;
-        g->chunk_cnt.reserve(((size_t)nw + 1) * 4); g->chunk_off.reserve(((size_t)nw + 1) * 4);
-        g->temp.reserve(scan_temp_bytes((size_t)nw + 1));
-        uint32_t N = 0;
-        RB_HIP(hipMemsetAsync(g->chunk_cnt.as<uint32_t>() + nw, 0, 4, s));
-        launch_count_windows(b, w0, nw, g->k, g->chunk_cnt.as<uint32_t>(), s);
-        exclusive_scan_u32(g->temp.p, g->temp.cap, g->chunk_cnt.as<uint32_t>(), g->chunk_off.as<uint32_t>(), (size_t)nw + 1, s);
-        RB_HIP(hipMemcpyAsync(&N, g->chunk_off.as<uint32_t>() + nw, 4, hipMemcpyDeviceToHost, s));
-        RB_HIP(hipStreamSynchronize(s));
-        if (N) {
-            uint64_t *rk = (uint64_t *)slot_reserve(S, RB_SLOT_REC_KEYS, (size_t)N * 8);
-            uint32_t *ro = (uint32_t *)slot_reserve(S, RB_SLOT_REC_OCC, (size_t)N * 4);
-            if (S->G == 1) {   // occ = (read_rel_base + r - first) << pos_bits | pos   (u32 wrap-around arithmetic)
-                launch_hash_windows(b, w0, nw, g->k, mode_hash, g->chunk_off.as<uint32_t>(), (uint32_t)first - read_rel_base, pos_bits,
-                                    rk, ro, nullptr, nullptr, s);
-                rec_counts[0] = N;
-            } else {   // stable 1-pass bucket by k-mer owner
-                g->keys0.reserve((size_t)N * 8); g->vals0.reserve((size_t)N * 4);
-                launch_hash_windows(b, w0, nw, g->k, mode_hash, g->chunk_off.as<uint32_t>(), (uint32_t)first - read_rel_base, pos_bits,
-                                    g->keys0.as<uint64_t>(), g->vals0.as<uint32_t>(), nullptr, nullptr, s);
-                g->temp.reserve(sort_pairs_temp_bytes(N));
-                sort_pairs_u64_u32(g->temp.p, g->temp.cap, g->keys0.as<uint64_t>(), rk, g->vals0.as<uint32_t>(), ro, N, OWNER_SHIFT, OWNER_SHIFT + S->log2G, s);
-                S->bounds.reserve(2 * (S->G + 2) * 8);
-                hipLaunchKernelGGL(k_bounds, dim3(1), dim3(128), 0, s, rk, (size_t)N, (uint32_t)S->G, S->bounds.as<uint64_t>());
-                std::vector<uint64_t> bd(S->G + 1);
-                RB_HIP(hipMemcpyAsync(bd.data(), S->bounds.p, (S->G + 1) * 8, hipMemcpyDeviceToHost, s));
-                RB_HIP(hipStreamSynchronize(s));
-                for (int r = 0; r < S->G; ++r) rec_counts[r] = (int64_t)(bd[r + 1] - bd[r]);
-            }
-        }
-        if (pairs) {
-            uint32_t P = 0;
-            RB_HIP(hipMemsetAsync(g->chunk_cnt.as<uint32_t>() + nw, 0, 4, s));
-            launch_count_windows(b, w0, nw, g->k + g->read_d, g->chunk_cnt.as<uint32_t>(), s);
-            exclusive_scan_u32(g->temp.p, g->temp.cap, g->chunk_cnt.as<uint32_t>(), g->chunk_off.as<uint32_t>(), (size_t)nw + 1, s);
-            RB_HIP(hipMemcpyAsync(&P, g->chunk_off.as<uint32_t>() + nw, 4, hipMemcpyDeviceToHost, s));
-            RB_HIP(hipStreamSynchronize(s));
-            const size_t np = (size_t)P * (size_t)g->rpk.num_hash;
-            if (np) {
-                S->stage0.reserve(np * 8);
-                g->devctr.reserve(DEVCTR_BYTES);
-                unsigned long long *pc = reinterpret_cast<unsigned long long *>(g->devctr.as<uint32_t>() + 12);
-                RB_HIP(hipMemsetAsync(pc, 0, 8, s));
-                launch_pairs(g, b, w0, nw, mode_hash, g->chunk_off.as<uint32_t>(), S->stage0.as<uint64_t>(), pc);
-                RouteIdx f{S->stage0.as<uint64_t>(), nullptr, (uint64_t)S->span[RB_RPKBF], nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-                route(g, f, np, pair_counts, [&](RouteIdx &ff, size_t kept) { ff.out_idx = (uint64_t *)slot_reserve(S, RB_SLOT_PAIR_IDX, kept * 8); });
-            }
-        }
-        RB_HIP(hipGetLastError());
-        RB_HIP(hipStreamSynchronize(s));
-    });
-}
-
-int rb_shard_group(rb_graph *g, const void *keys_dev, const void *occ_dev, int64_t n, uint64_t ordinal0, uint32_t pos_bits,
-                   int mode, int64_t *dreq_counts, int64_t *creq_counts) {
-    return guarded([&] {
-        RB_REQUIRE(g && g->shard && dreq_counts && creq_counts && n >= 0, "rb_shard_group: bad argument");
-        RB_REQUIRE(n <= g->max_batch_kmers, "rb_shard_group: %lld records exceed max_batch_kmers", (long long)n);
-        ShardState *S = g->shard;
-        RB_HIP(hipSetDevice(g->p.device));
-        hipStream_t s = g->stream;
-        for (int r = 0; r < S->G; ++r) dreq_counts[r] = creq_counts[r] = 0;
-        S->D = 0; S->n_conf = 0; S->n_kept = 0; S->ordinal0 = ordinal0; S->pos_bits = pos_bits;
-        S->slot_bytes[RB_SLOT_DREQ_IDX] = S->slot_bytes[RB_SLOT_DREQ_PROBE] = S->slot_bytes[RB_SLOT_CREQ_IDX] = 0;
-        if (n == 0) return;
-        g->keys0.reserve((size_t)n * 8); g->vals0.reserve((size_t)n * 4);
-        if (g->npf_log2 && (mode == M_ADD || mode == M_COUNT_IF_PRESENT)) {
-            // drop the occurrences whose draw cannot move a counter (exact: DESIGN.md §3 "no-op prefilter")
-            FilterView fv0 = g->view(ordinal0, pos_bits);
-            S->stage2.reserve((size_t)n + 16);
-            hipLaunchKernelGGL(k_rec_keep, dim3(blocks_for(n)), dim3(TPB), 0, s, fv0, (const uint64_t *)keys_dev, (const uint32_t *)occ_dev,
-                               (size_t)n, S->stage2.as<uint8_t>());
-            RouteKeep fk{S->stage2.as<uint8_t>(), (const uint64_t *)keys_dev, (const uint32_t *)occ_dev, g->keys0.as<uint64_t>(), g->vals0.as<uint32_t>()};
-            int64_t kept_c[1];
-            const size_t kept = route(g, fk, (size_t)n, kept_c, [](RouteKeep &, size_t) {}, 1);
-            S->n_kept = kept;
-            n = (int64_t)kept;
-            if (n == 0) return;
-        } else {
-            RB_HIP(hipMemcpyAsync(g->keys0.p, keys_dev, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
-            RB_HIP(hipMemcpyAsync(g->vals0.p, occ_dev, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
-            S->n_kept = (uint64_t)n;
-        }
-        const uint32_t D = group_records(g, (size_t)n, ordinal0, pos_bits, nullptr, nullptr);
-        S->D = D;
+        const uint32_t own_mask = (uint32_t)S->G - 1u, own_rank = (uint32_t)g->shard_rank;
         FilterView fv = g->view(ordinal0, pos_bits);
-        const size_t nd = mode == M_COUNT_ONLY ? 0 : (size_t)D * fv.dbg_h, nc = (size_t)D * fv.cbf_h;
-        S->stage0.reserve(nd * 8 + 16); S->stage1.reserve(nd * 8 + 16); S->stage3.reserve(nc * 8 + 16); S->stage2.reserve(nc + 16);
-        S->creq_dup.reserve(nc + 16);
-        S->dreq_pos.reserve(nd * 4 + 16); S->creq_pos.reserve(nc * 4 + 16);
-        hipLaunchKernelGGL(k_make_requests, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, g->uniq().as<uint64_t>(), g->starts().as<uint32_t>(),
-                           g->vals1().as<uint32_t>(), D, mode, S->stage0.as<uint64_t>(), S->stage1.as<uint64_t>(),
-                           S->stage3.as<uint64_t>(), S->stage2.as<uint8_t>(), S->creq_dup.as<uint8_t>());
-        // Bloom-bit requests (index + probe id), bucketed by bit owner
-        RouteIdx fd{S->stage0.as<uint64_t>(), nullptr, (uint64_t)S->span[RB_DBGBF], S->stage1.as<uint64_t>(), nullptr,
-                    nullptr, nullptr, nullptr, S->dreq_pos.as<uint32_t>()};
-        route(g, fd, nd, dreq_counts, [&](RouteIdx &ff, size_t kept) {
-            ff.out_idx = (uint64_t *)slot_reserve(S, RB_SLOT_DREQ_IDX, kept * 8);
-            ff.out64 = (uint64_t *)slot_reserve(S, RB_SLOT_DREQ_PROBE, kept * 8);
-        });
-        // counter claims, bucketed by counter owner
-        RouteIdx fc{S->stage3.as<uint64_t>(), S->stage2.as<uint8_t>(), (uint64_t)S->span[RB_CBF], nullptr, nullptr,
-                    nullptr, nullptr, nullptr, S->creq_pos.as<uint32_t>()};
-        route(g, fc, nc, creq_counts, [&](RouteIdx &ff, size_t kept) { ff.out_idx = (uint64_t *)slot_reserve(S, RB_SLOT_CREQ_IDX, kept * 8); });
+        const bool use_cache = g->npf_log2 != 0;
+        // ---- every rank walks ALL reads of the sub-batch and keeps the windows whose k-mer it owns ----
+        const int64_t w0 = b->h_woff[(size_t)first], nw = (int64_t)b->h_woff[(size_t)(first + n)] - w0;
+        uint64_t owned = 0;
+        uint32_t N = 0;
+        if (nw > 0) {
+            g->chunk_cnt.reserve(((size_t)nw + 1) * 4); g->chunk_off.reserve(((size_t)nw + 1) * 4);
+            g->temp.reserve(scan_temp_bytes((size_t)nw + 1));
+            g->npf_tot.reserve(2048);
+            RB_HIP(hipMemsetAsync(g->npf_tot.p, 0, 2048, s));
+            RB_HIP(hipMemsetAsync(g->chunk_cnt.as<uint32_t>() + nw, 0, 4, s));
+            uint32_t spread[16 * 32];
+            if (g->k <= 31) {   // fast kernels: ownership + prefilter inside the window walk, then a masked emit
+                // (the one-pass k_filter_emit measured 1.5x slower here: see rb_graph.hip add_range)
+                g->chunk_mask.reserve(((size_t)nw + 1) * 4);
+                Npf cache = fv.npf;
+                if (!use_cache) cache.tab = nullptr;
+                launch_filter_windows(b, w0, nw, g->k, mode_hash, (uint32_t)first, pos_bits, g->p.rng_seed, ordinal0, cache,
+                                      g->chunk_cnt.as<uint32_t>(), g->chunk_mask.as<uint32_t>(), g->npf_tot.as<uint32_t>(), s, own_mask, own_rank);
+                exclusive_scan_u32(g->temp.p, g->temp.cap, g->chunk_cnt.as<uint32_t>(), g->chunk_off.as<uint32_t>(), (size_t)nw + 1, s);
+                RB_HIP(hipMemcpyAsync(&N, g->chunk_off.as<uint32_t>() + nw, 4, hipMemcpyDeviceToHost, s));
+                RB_HIP(hipMemcpyAsync(spread, g->npf_tot.p, sizeof spread, hipMemcpyDeviceToHost, s));
+                RB_HIP(hipStreamSynchronize(s));
+                for (int q = 0; q < 32; ++q) owned += spread[16 * q];
+                if (N) {
+                    g->keys0.reserve((size_t)N * 8); g->vals0.reserve((size_t)N * 4);
+                    launch_hash_windows_masked(b, w0, nw, g->k, mode_hash, g->chunk_off.as<uint32_t>(), g->chunk_mask.as<uint32_t>(),
+                                               (uint32_t)first, pos_bits, g->keys0.as<uint64_t>(), g->vals0.as<uint32_t>(), s);
+                }
+            } else {            // generic hash of every window, then one ordered compaction
+                uint32_t NA = 0;
+                launch_count_windows(b, w0, nw, g->k, g->chunk_cnt.as<uint32_t>(), s);
+                exclusive_scan_u32(g->temp.p, g->temp.cap, g->chunk_cnt.as<uint32_t>(), g->chunk_off.as<uint32_t>(), (size_t)nw + 1, s);
+                RB_HIP(hipMemcpyAsync(&NA, g->chunk_off.as<uint32_t>() + nw, 4, hipMemcpyDeviceToHost, s));
+                RB_HIP(hipStreamSynchronize(s));
+                if (NA) {
+                    S->stage0.reserve((size_t)NA * 8 + 16); S->stage1.reserve((size_t)NA * 4 + 16); S->stage2.reserve((size_t)NA + 16);
+                    launch_hash_windows(b, w0, nw, g->k, mode_hash, g->chunk_off.as<uint32_t>(), (uint32_t)first, pos_bits,
+                                        S->stage0.as<uint64_t>(), S->stage1.as<uint32_t>(), nullptr, nullptr, s);
+                    hipLaunchKernelGGL(k_rec_keep, dim3(blocks_for(NA)), dim3(TPB), 0, s, fv, (int)use_cache, S->stage0.as<uint64_t>(), S->stage1.as<uint32_t>(),
+                                       (size_t)NA, own_mask, own_rank, S->stage2.as<uint8_t>(), g->npf_tot.as<uint32_t>());
+                    g->keys0.reserve((size_t)NA * 8); g->vals0.reserve((size_t)NA * 4);
+                    RouteKeep fk{S->stage2.as<uint8_t>(), S->stage0.as<uint64_t>(), S->stage1.as<uint32_t>(), g->keys0.as<uint64_t>(), g->vals0.as<uint32_t>()};
+                    int64_t kept_c[1];
+                    N = (uint32_t)route(g, fk, (size_t)NA, kept_c, [](RouteKeep &, size_t) {}, 1);
+                    RB_HIP(hipMemcpyAsync(spread, g->npf_tot.p, sizeof spread, hipMemcpyDeviceToHost, s));
+                    RB_HIP(hipStreamSynchronize(s));
+                    for (int q = 0; q < 32; ++q) owned += spread[16 * q];
+                }
+            }
+        }
+        S->n_kept = N;
+        if (stats) { stats->kmers += (int64_t)owned; stats->sorted_kmers += (int64_t)N; }
+        // ---- read-paired k-mers of this rank's slice of the reads: bit indices bucketed by rpkbf owner ----
+        if (pairs && pair_n > 0) {
+            const int64_t pw0 = b->h_woff[(size_t)pair_first], pnw = (int64_t)b->h_woff[(size_t)(pair_first + pair_n)] - pw0;
+            if (pnw > 0) {
+                uint32_t P = 0;
+                g->chunk_cnt.reserve(((size_t)pnw + 1) * 4); g->chunk_off.reserve(((size_t)pnw + 1) * 4);
+                g->temp.reserve(scan_temp_bytes((size_t)pnw + 1));
+                RB_HIP(hipMemsetAsync(g->chunk_cnt.as<uint32_t>() + pnw, 0, 4, s));
+                launch_count_windows(b, pw0, pnw, g->k + g->read_d, g->chunk_cnt.as<uint32_t>(), s);
+                exclusive_scan_u32(g->temp.p, g->temp.cap, g->chunk_cnt.as<uint32_t>(), g->chunk_off.as<uint32_t>(), (size_t)pnw + 1, s);
+                RB_HIP(hipMemcpyAsync(&P, g->chunk_off.as<uint32_t>() + pnw, 4, hipMemcpyDeviceToHost, s));
+                RB_HIP(hipStreamSynchronize(s));
+                const size_t np = (size_t)P * (size_t)g->rpk.num_hash;
+                if (np) {
+                    S->stage0.reserve(np * 8);
+                    g->devctr.reserve(DEVCTR_BYTES);
+                    unsigned long long *pc = reinterpret_cast<unsigned long long *>(g->devctr.as<uint32_t>() + 12);
+                    RB_HIP(hipMemsetAsync(pc, 0, 8, s));
+                    launch_pairs(g, b, pw0, pnw, mode_hash, g->chunk_off.as<uint32_t>(), S->stage0.as<uint64_t>(), pc);
+                    RouteIdx f{S->stage0.as<uint64_t>(), nullptr, (uint64_t)S->span[RB_RPKBF], nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+                    route(g, f, np, pair_counts, [&](RouteIdx &ff, size_t kept) { ff.out_idx = (uint64_t *)slot_reserve(S, RB_SLOT_PAIR_IDX, kept * 8); });
+                    if (stats) stats->pairs += (int64_t)P;
+                }
+            }
+        }
+        if (stats) stats->reads += pair_n;
+        // ---- group this rank's records into runs; requests bucketed by filter owner ----
+        if (N) {
+            const uint32_t D = group_records(g, (size_t)N, ordinal0, pos_bits, nullptr, nullptr);
+            S->D = D;
+            const size_t nd = mode == M_COUNT_ONLY ? 0 : (size_t)D * fv.dbg_h, nc = (size_t)D * fv.cbf_h;
+            S->stage0.reserve(nd * 8 + 16); S->stage1.reserve(nd * 8 + 16); S->stage3.reserve(nc * 8 + 16); S->stage2.reserve(nc + 16);
+            S->creq_dup.reserve(nc + 16);
+            S->dreq_pos.reserve(nd * 4 + 16); S->creq_pos.reserve(nc * 4 + 16);
+            hipLaunchKernelGGL(k_make_requests, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, g->uniq().as<uint64_t>(), g->starts().as<uint32_t>(),
+                               g->vals1().as<uint32_t>(), D, mode, S->stage0.as<uint64_t>(), S->stage1.as<uint64_t>(),
+                               S->stage3.as<uint64_t>(), S->stage2.as<uint8_t>(), S->creq_dup.as<uint8_t>());
+            // Bloom-bit requests (index + probe id), bucketed by bit owner
+            RouteIdx fd{S->stage0.as<uint64_t>(), nullptr, (uint64_t)S->span[RB_DBGBF], S->stage1.as<uint64_t>(), nullptr,
+                        nullptr, nullptr, nullptr, S->dreq_pos.as<uint32_t>()};
+            route(g, fd, nd, dreq_counts, [&](RouteIdx &ff, size_t kept) {
+                ff.out_idx = (uint64_t *)slot_reserve(S, RB_SLOT_DREQ_IDX, kept * 8);
+                ff.out64 = (uint64_t *)slot_reserve(S, RB_SLOT_DREQ_PROBE, kept * 8);
+            });
+            // counter claims, bucketed by counter owner
+            RouteIdx fc{S->stage3.as<uint64_t>(), S->stage2.as<uint8_t>(), (uint64_t)S->span[RB_CBF], nullptr, nullptr,
+                        nullptr, nullptr, nullptr, S->creq_pos.as<uint32_t>()};
+            route(g, fc, nc, creq_counts, [&](RouteIdx &ff, size_t kept) { ff.out_idx = (uint64_t *)slot_reserve(S, RB_SLOT_CREQ_IDX, kept * 8); });
+        }
         RB_HIP(hipGetLastError());
         RB_HIP(hipStreamSynchronize(s));
     });
@@ -881,7 +884,6 @@ int rb_shard_resolve(rb_graph *g, int mode, const void *dreply_dev, const void *
         S->n_conf = 0;
         S->slot_bytes[RB_SLOT_W_IDX] = S->slot_bytes[RB_SLOT_W_VAL] = S->slot_bytes[RB_SLOT_CONF_EDGES] = 0;
         const uint32_t D = S->D;
-        if (stats) stats->sorted_kmers += (int64_t)S->n_kept;
         if (!D) return;
         FilterView fv = g->view(S->ordinal0, S->pos_bits);
         g->status.reserve((size_t)D * 4); g->nops.reserve((size_t)D * 4); g->cvals.reserve((size_t)D * 8);

@@ -6,9 +6,10 @@ the phase functions of the C ABI (`rb_shard_*`, csrc/rb_shard.hip); this module 
 buffers between ranks (all_to_all / all_gather) in the order the protocol requires.  Results are
 identical to the single-GPU path and to the sequential oracle (tests/test_gpu_sharded.py).
 
-Read distribution: a global sub-batch is the concatenation, in rank order, of the slices the ranks
-contribute to it; global order = sub-batch after sub-batch.  (A loader deals blocks of reads to the
-ranks in turn; bench.py generates each rank's blocks in place.)
+Read distribution: replicated.  Every rank holds the same packed read batch (2 bits per base — 1/38 of
+the bytes of the (hash, occurrence) records it expands to, so the reads are what a loader broadcasts)
+and walks all of it, keeping only the windows whose k-mer it owns; read-paired k-mers are walked by
+1/G of the reads per rank.  Insertion order = read order, exactly as on one GPU.
 """
 import ctypes as C
 
@@ -110,28 +111,24 @@ class ShardRank:
         return v.value
 
     # ---- one global sub-batch; yields exchange requests, receives their results ----
-    def substep(self, batch, first, n, pos_bits, flags, mode=N.MODE_ADD):
+    def substep(self, batch, first, n, pos_bits, flags):
+        """reads [first, first+n) of `batch` (every rank holds the same batch and passes the same range)"""
         mark = trace_mark
         G = self.count
-        n_all = yield ("ints", [int(n)])
-        n_all = [x[0] for x in n_all]
-        rel_base, total_reads = sum(n_all[: self.rank]), sum(n_all)
-        assert total_reads < (1 << (32 - pos_bits)), "sub-batch has too many reads for the occurrence id"
+        mode = N.MODE_COUNT_IF_PRESENT if (flags & N.ADD_COUNT_IF_PRESENT) else N.MODE_ADD
         cnt = lambda: (C.c_int64 * G)()
-        # hash: own reads -> records by k-mer owner, pair probes by rpkbf owner
-        rec_c, pair_c = cnt(), cnt()
-        check(lib.rb_shard_hash(self.h, batch.h, first, n, rel_base, pos_bits, flags, rec_c, pair_c))
-        rec_c, pair_c = list(rec_c), list(pair_c)
-        mark("hash")
-        send = [self._slot(N.SLOT_REC_KEYS, 8 * sum(rec_c)), self._slot(N.SLOT_REC_OCC, 4 * sum(rec_c)), self._slot(N.SLOT_PAIR_IDX, 8 * sum(pair_c))]
-        (rkeys, rocc, rpidx), (rk_c, _, rp_c) = yield ("a2a", send, [[8 * c for c in rec_c], [4 * c for c in rec_c], [8 * c for c in pair_c]])
-        # group: received records -> runs -> requests by filter owner
-        d_c, c_c = cnt(), cnt()
-        check(lib.rb_shard_group(self.h, _ptr(rkeys), _ptr(rocc), sum(rk_c) // 8, self.ordinal, pos_bits, mode, d_c, c_c))
-        d_c, c_c = list(d_c), list(c_c)
-        mark("group")
-        send = [self._slot(N.SLOT_DREQ_IDX, 8 * sum(d_c)), self._slot(N.SLOT_DREQ_PROBE, 8 * sum(d_c)), self._slot(N.SLOT_CREQ_IDX, 8 * sum(c_c))]
-        (o_didx, o_dprobe, o_cidx), (o_dc, _, o_cc) = yield ("a2a", send, [[8 * c for c in d_c], [8 * c for c in d_c], [8 * c for c in c_c]])
+        st = N.AddStats()
+        # hash + group: the windows whose k-mer this rank owns -> runs -> requests by filter owner;
+        # read pairs of this rank's slice of the reads -> probes by rpkbf owner
+        p0, p1 = first + n * self.rank // G, first + n * (self.rank + 1) // G
+        d_c, c_c, pair_c = cnt(), cnt(), cnt()
+        check(lib.rb_shard_hash_group(self.h, batch.h, first, n, p0, p1 - p0, self.ordinal, pos_bits, flags, d_c, c_c, pair_c, C.byref(st)))
+        d_c, c_c, pair_c = list(d_c), list(c_c), list(pair_c)
+        mark("hash_group")
+        send = [self._slot(N.SLOT_DREQ_IDX, 8 * sum(d_c)), self._slot(N.SLOT_DREQ_PROBE, 8 * sum(d_c)), self._slot(N.SLOT_CREQ_IDX, 8 * sum(c_c)),
+                self._slot(N.SLOT_PAIR_IDX, 8 * sum(pair_c))]
+        (o_didx, o_dprobe, o_cidx, rpidx), (o_dc, _, o_cc, rp_c) = yield ("a2a", send, [[8 * c for c in d_c], [8 * c for c in d_c], [8 * c for c in c_c],
+                                                                                       [8 * c for c in pair_c]])
         # serve: this rank's filter ranges answer
         nd, nc, np_ = sum(o_dc) // 8, sum(o_cc) // 8, sum(rp_c) // 8
         dreply = torch.empty(nd, dtype=torch.uint8, device=self.tdev)
@@ -142,7 +139,6 @@ class ShardRank:
         (my_dreply, my_creply), _ = yield ("a2a", [dreply, creply], [[c // 8 for c in o_dc], [c // 8 for c in o_cc]], [d_c, c_c])
         # resolve: runs that own their counters alone finish here
         w_c, nconf, nedge = cnt(), C.c_int64(), C.c_int64()
-        st = N.AddStats()
         check(lib.rb_shard_resolve(self.h, mode, _ptr(my_dreply), _ptr(my_creply), w_c, C.byref(nconf), C.byref(nedge), C.byref(st)))
         w_c = list(w_c)
         mark("resolve")
@@ -166,22 +162,14 @@ class ShardRank:
                                                     [[8 * c for c in cw_c], cw_c])
             check(lib.rb_shard_apply_writes(self.h, _ptr(o_cwidx), _ptr(o_cwval), sum(o_cwc) // 8))
             mark("conf_writes")
-        self.ordinal += total_reads
-        self.stats["kmers"] += sum(rec_c)
-        self.stats["pairs"] += sum(pair_c) // max(1, self.p.pkbf_num_hash)
-        self.stats["distinct"] += st.distinct
-        self.stats["conflict_ops"] += st.conflict_ops
-        self.stats["sorted_kmers"] += st.sorted_kmers
-        self.stats["reads"] += int(n)
+        self.ordinal += int(n)
+        for kk in ("kmers", "pairs", "distinct", "conflict_ops", "sorted_kmers", "reads"):
+            self.stats[kk] += getattr(st, kk)
 
     def add_range(self, batch, first, n, flags, reads_per_substep, pos_bits):
-        """Coroutine over all sub-batches of this rank's read range (ranks may hold different counts)."""
-        steps = -(-int(n) // reads_per_substep) if n else 0
-        steps_all = yield ("ints", [steps])
-        for t in range(max(x[0] for x in steps_all)):
-            a = min(int(n), t * reads_per_substep)
-            b = min(int(n), (t + 1) * reads_per_substep)
-            yield from self.substep(batch, first + a, b - a, pos_bits, flags)
+        """Coroutine over all sub-batches of reads [first, first+n) — the same call on every rank."""
+        for a in range(0, int(n), reads_per_substep):
+            yield from self.substep(batch, first + a, min(int(n), a + reads_per_substep) - a, pos_bits, flags)
 
 
 # ------------------------------------------------------------------ drivers ----
@@ -297,19 +285,16 @@ def run_distributed(gen, group=None):
 
 
 def plan(max_len, k, count, max_batch_kmers=1 << 30):
-    """(pos_bits, reads per rank per sub-batch) so that a global sub-batch stays within the limits.
-    Per rank a sub-batch is capped at 2^28 k-mers (RB_SHARD_RANK_LOG2): exchange buffers (torch) and
-    library scratch both scale with it.  Bigger sub-batches merge more occurrences per run and need
-    fewer exchange rounds; smaller ones keep the prefilter cache fresher and conflicts rarer."""
+    """(pos_bits, reads per GLOBAL sub-batch).  Every rank walks all reads of a sub-batch and keeps the
+    k-mers it owns, so library scratch scales with max_batch_kmers / count per rank.  Bigger sub-batches
+    merge more occurrences per run and need fewer exchange rounds; smaller ones keep the prefilter cache
+    fresher and conflicts rarer."""
     pos_bits = 1
     while (1 << pos_bits) <= max_len:
         pos_bits += 1
-    per_read = max(1, max_len)
-    import os
-    cap = 1 << int(os.environ.get("RB_SHARD_RANK_LOG2", "28"))
-    reads = max(1, min(max_batch_kmers // count, cap) // per_read)
-    reads = min(reads, ((1 << (32 - pos_bits)) - 1) // count)
-    return pos_bits, max(1, reads)
+    reads = max(1, max_batch_kmers // max(1, max_len))
+    reads = min(reads, (1 << (32 - pos_bits)) - 1)
+    return pos_bits, reads
 
 
 class LoopbackCluster:
@@ -327,13 +312,13 @@ class LoopbackCluster:
         for r in self.ranks:
             r.set_read_pair_distance(d)
 
-    def addBatches(self, batches, max_len, reverseComplement=False, storeReadPairedKmers=False, reads_per_substep=None):
-        """batches[r] = this rank's reads; global order = sub-batch by sub-batch, rank by rank."""
+    def addBatch(self, batch, max_len, reverseComplement=False, storeReadPairedKmers=False, reads_per_substep=None, first=0, n=None):
+        """every virtual rank walks the same batch; insertion order = read order, as on one GPU"""
         flags = (N.ADD_REVCOMP if reverseComplement else 0) | (N.ADD_STORE_READ_PAIRS if storeReadPairedKmers else 0)
         pos_bits, rps = plan(max_len, self.k, self.count, self.max_batch)
         rps = reads_per_substep or rps
-        gens = [r.add_range(b, 0, b.n_reads, flags, rps, pos_bits) for r, b in zip(self.ranks, batches)]
-        run_loopback(gens)
+        n = batch.n_reads - first if n is None else n
+        run_loopback([r.add_range(batch, first, n, flags, rps, pos_bits) for r in self.ranks])
 
     def exportFilter(self, which):
         return np.concatenate([r.local_filter(which) for r in self.ranks])

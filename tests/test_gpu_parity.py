@@ -319,3 +319,16 @@ def test_synthetic_slices_are_the_whole_set():
             assert (pr[per:] == reads[3000 + r * per:3000 + (r + 1) * per]).all(), "right reads differ"
     with pytest.raises(N.NativeError):
         ReadBatch.synthetic(10, 1 << 16, pair_offset=5, total_pairs=12)
+
+
+def test_one_pass_filter_kernel_matches(monkeypatch):
+    """the experimental one-pass prefilter+emit kernel (decoupled look-back) gives the same filters"""
+    monkeypatch.setenv("RB_ONE_PASS_FILTER", "1")
+    d = synth.generate_pairs(3000, G=2000, err=0.002, n_rate=1e-3, seed=21, uniform_expr=True)
+    og, gg = graph_pair(200_003, 300_007, 50_021, max_batch=40_000)
+    og.set_read_pair_distance(115); gg.setReadPairedKmerDistance(115)
+    s, off = synth.flat(d["left"]); q, _ = synth.flat(d["lqual"])
+    og.add_reads(s, q, off, 3, rbo.STORE_READ_PAIRS)
+    st = gg.addReads(s, q, off, 3, storeReadPairedKmers=True)
+    assert_same_state(og, gg)
+    assert st.sorted_kmers < st.kmers

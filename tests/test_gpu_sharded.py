@@ -1,5 +1,7 @@
 """Sharded (multi-GPU) engine on ONE GPU: G virtual ranks in one process (LoopbackCluster) must
-reproduce the sequential oracle bit for bit, for every G."""
+reproduce the sequential oracle bit for bit, for every G.  Every rank walks the same read batch and
+keeps the k-mers it owns, so the insertion order is the read order — the oracle consumes the same
+reads in the same order."""
 import numpy as np
 import pytest
 
@@ -12,66 +14,66 @@ from rnabloom.graph import ReadBatch
 from rnabloom.sharded import LoopbackCluster
 
 
-def deal(seq2d, qual2d, G, rps):
-    """global order = sub-batch by sub-batch, rank by rank, `rps` reads per rank per sub-batch"""
-    n = seq2d.shape[0]
-    owner = (np.arange(n) // rps) % G
-    order = []
-    blocks = -(-n // rps)
-    for t in range(0, blocks, G):
-        for r in range(G):
-            b = t + r
-            order.extend(range(b * rps, min(n, (b + 1) * rps)))
-    per_rank = [np.nonzero(owner == r)[0] for r in range(G)]
-    return per_rank, np.asarray(order)
+def check_filters(cl, og, pairs=True):
+    assert (cl.exportFilter(N.DBGBF) == og.dbgbf_bytes()).all(), "dbgbf differs"
+    if pairs:
+        assert (cl.exportFilter(N.RPKBF) == og.rpkbf_bytes()).all(), "rpkbf differs"
+    cg, co = cl.exportFilter(N.CBF), og.cbf_bytes()
+    bad = np.nonzero(cg != co)[0]
+    assert bad.size == 0, "cbf differs at %d bytes: %s gpu %s oracle %s" % (bad.size, bad[:6], cg[bad[:6]], co[bad[:6]])
 
 
 @pytest.mark.parametrize("G", [1, 2, 4, 8])
 @pytest.mark.parametrize("sizes", [(400_003, 3_000_017, 90_001), (70_001, 250_007, 9_001)])
 def test_loopback_matches_oracle(G, sizes):
     d = synth.generate_pairs(2400, G=25000, err=0.003, n_rate=1e-3, seed=17 + G)
-    rps = 160
-    for name, rc in (("left", False),):
-        pass
     og = rbo.Graph(*sizes, 2, 2, 2, 25, False, True, 9)
     cl = LoopbackCluster(G, *sizes, 2, 2, 2, 25, False, True, rngSeed=9)
     og.set_read_pair_distance(115); cl.setReadPairedKmerDistance(115)
     for name, rc in (("left", False), ("right", True)):
-        seq2d, qual2d = d[name], d[name[0] + "qual"]
-        per_rank, order = deal(seq2d, qual2d, G, rps)
-        # oracle consumes the reads in the global order the sharded engine defines
-        s, off = synth.flat(seq2d[order]); q, _ = synth.flat(qual2d[order])
+        s, off = synth.flat(d[name]); q, _ = synth.flat(d[name[0] + "qual"])
         og.add_reads(s, q, off, 3, rbo.STORE_READ_PAIRS | (rbo.REVCOMP if rc else 0))
-        batches = []
-        for r in range(G):
-            rs, roff = synth.flat(seq2d[per_rank[r]]); rq, _ = synth.flat(qual2d[per_rank[r]])
-            batches.append(ReadBatch.from_ascii(rs, rq, roff, 3))
-        cl.addBatches(batches, 150, reverseComplement=rc, storeReadPairedKmers=True, reads_per_substep=rps)
-        assert (cl.exportFilter(N.DBGBF) == og.dbgbf_bytes()).all(), "dbgbf differs"
-        assert (cl.exportFilter(N.RPKBF) == og.rpkbf_bytes()).all(), "rpkbf differs"
-        cg, co = cl.exportFilter(N.CBF), og.cbf_bytes()
-        bad = np.nonzero(cg != co)[0]
-        assert bad.size == 0, "cbf differs at %d bytes: %s gpu %s oracle %s" % (bad.size, bad[:6], cg[bad[:6]], co[bad[:6]])
+        cl.addBatch(ReadBatch.from_ascii(s, q, off, 3), 150, reverseComplement=rc, storeReadPairedKmers=True, reads_per_substep=577)
+        check_filters(cl, og)
     pc = og.popcounts()
     assert (cl.popcount(N.DBGBF), cl.popcount(N.CBF), cl.popcount(N.RPKBF)) == pc
     assert sum(r.stats["conflict_ops"] for r in cl.ranks) > 0
+    assert sum(r.stats["reads"] for r in cl.ranks) == 4800
     cl.destroy()
 
 
-def test_loopback_high_multiplicity():
+@pytest.mark.parametrize("k", [25, 33])
+def test_loopback_high_multiplicity(k):
+    """counts well into the probabilistic MiniFloat range, many sub-batches (the prefilter cache is hot);
+    k = 33 takes the generic window-hash path (ownership + prefilter applied to the records)"""
     d = synth.generate_pairs(5000, G=3000, err=0.001, n_rate=1e-3, seed=3, uniform_expr=True)
     sizes = (100_003, 150_001, 20_011)
-    og = rbo.Graph(*sizes, 2, 2, 2, 25, False, True, 1)
-    cl = LoopbackCluster(4, *sizes, 2, 2, 2, 25, False, True, rngSeed=1)
-    per_rank, order = deal(d["left"], d["lqual"], 4, 500)
-    s, off = synth.flat(d["left"][order]); q, _ = synth.flat(d["lqual"][order])
+    og = rbo.Graph(*sizes, 2, 2, 2, k, False, True, 1)
+    cl = LoopbackCluster(4, *sizes, 2, 2, 2, k, False, True, rngSeed=1)
+    s, off = synth.flat(d["left"]); q, _ = synth.flat(d["lqual"])
     og.add_reads(s, q, off, 3, 0)
-    batches = []
-    for r in range(4):
-        rs, roff = synth.flat(d["left"][per_rank[r]]); rq, _ = synth.flat(d["lqual"][per_rank[r]])
-        batches.append(ReadBatch.from_ascii(rs, rq, roff, 3))
-    cl.addBatches(batches, 150, reads_per_substep=500)
-    assert (cl.exportFilter(N.DBGBF) == og.dbgbf_bytes()).all()
-    assert (cl.exportFilter(N.CBF) == og.cbf_bytes()).all()
+    cl.addBatch(ReadBatch.from_ascii(s, q, off, 3), 150, reads_per_substep=500)
+    check_filters(cl, og, pairs=False)
     assert og.cbf_bytes().max() > 24
+    kept = sum(r.stats["sorted_kmers"] for r in cl.ranks)
+    assert kept < sum(r.stats["kmers"] for r in cl.ranks), "the prefilter dropped nothing"
+    cl.destroy()
+
+
+def test_loopback_stranded_count_if_present():
+    """stranded hashing (no canonical minimum) + the addCountIfPresent pass over a pre-built dbgbf"""
+    d = synth.generate_pairs(1500, G=6000, err=0.002, n_rate=1e-3, seed=5)
+    sizes = (200_003, 300_007, 20_011)
+    og = rbo.Graph(*sizes, 2, 2, 2, 25, True, False, 4)
+    cl = LoopbackCluster(2, *sizes, 2, 2, 2, 25, True, False, rngSeed=4)
+    s, off = synth.flat(d["left"]); q, _ = synth.flat(d["lqual"])
+    b = ReadBatch.from_ascii(s, q, off, 3)
+    og.add_reads(s, q, off, 3, 0)
+    cl.addBatch(b, 150, reads_per_substep=400)
+    check_filters(cl, og, pairs=False)
+    og.add_reads(s, q, off, 3, rbo.COUNT_IF_PRESENT)
+    from rnabloom.sharded import run_loopback, plan
+    pos_bits, _ = plan(150, 25, 2)
+    run_loopback([r.add_range(b, 0, b.n_reads, N.ADD_COUNT_IF_PRESENT, 400, pos_bits) for r in cl.ranks])
+    check_filters(cl, og, pairs=False)
     cl.destroy()

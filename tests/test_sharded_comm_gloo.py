@@ -80,6 +80,6 @@ def test_run_distributed_equals_loopback(world):
 def test_plan_limits():
     from rnabloom.sharded import plan
     pos_bits, reads = plan(150, 25, 8, 1 << 30)
-    assert (1 << pos_bits) > 150 and reads * 8 < (1 << (32 - pos_bits)) and reads * 150 * 8 <= (1 << 30)
+    assert (1 << pos_bits) > 150 and reads < (1 << (32 - pos_bits)) and reads * 150 <= (1 << 30)
     pos_bits, reads = plan(100_000, 35, 2, 1 << 28)
     assert (1 << pos_bits) > 100_000 and reads >= 1

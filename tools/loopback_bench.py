@@ -41,10 +41,8 @@ def main():
 
     G, k = a.ranks, a.k
     sz = N.lib.rb_expected_size(a.nk, 0.01, 2)
-    pairs_rank = a.pairs // G
     ranks = [sharded.ShardRank((sz, sz, sz, 2, 2, 2, k, 0, 1, 0, 0, 1, a.batch_kmers), r, G, 0) for r in range(G)]
-    batches = [ReadBatch.synthetic(pairs_rank, a.genome, 150, 300, 30, 0.001, 1e-4, 2.0, seed=0x5EED, device=0,
-                                   pair_offset=r * pairs_rank, total_pairs=pairs_rank * G) for r in range(G)]
+    batch = ReadBatch.synthetic(a.pairs, a.genome, 150, 300, 30, 0.001, 1e-4, 2.0, seed=0x5EED, device=0)   # shared by the ranks
     for r in ranks:
         r.set_read_pair_distance(max(1, 150 - k - 10))
     pos_bits, rps = sharded.plan(150, k, G, a.batch_kmers or (1 << 30))
@@ -52,8 +50,8 @@ def main():
     def step():
         for r in ranks:
             r.clear()
-        for first, fl in ((0, N.ADD_STORE_READ_PAIRS), (pairs_rank, N.ADD_STORE_READ_PAIRS | N.ADD_REVCOMP)):
-            sharded.run_loopback([r.add_range(b, first, pairs_rank, fl, rps, pos_bits) for r, b in zip(ranks, batches)])
+        for first, fl in ((0, N.ADD_STORE_READ_PAIRS), (a.pairs, N.ADD_STORE_READ_PAIRS | N.ADD_REVCOMP)):
+            sharded.run_loopback([r.add_range(batch, first, a.pairs, fl, rps, pos_bits) for r in ranks])
 
     for _ in range(a.warmup):
         step()
@@ -70,7 +68,7 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
     tot = {kk: sum(r.stats[kk] for r in ranks) // a.steps for kk in ranks[0].stats}
-    out = {"ranks": G, "pairs": a.pairs, "reads_per_rank_substep": rps, "wall_ms_per_step": round(dt * 1e3, 1),
+    out = {"ranks": G, "pairs": a.pairs, "reads_per_substep": rps, "wall_ms_per_step": round(dt * 1e3, 1),
            "per_rank_ms_if_concurrent": round(dt * 1e3 / G, 1),
            "projected_kmers_per_s_without_comm": round(tot["kmers"] / (dt / G)), "stats": tot}
     if a.trace:
