@@ -27,9 +27,15 @@ from ._native import check, lib
 # this process together (tools/loopback_bench.py, RB_SHARD_TRACE=1 in bench.py)
 TRACE = None
 _t_last = [0.0]
+import os as _os
+_DEBUG = bool(_os.environ.get("RB_SHARD_DEBUG"))
+_COPY_SLOTS = bool(_os.environ.get("RB_SHARD_COPY"))     # exchange from torch-owned copies instead of zero-copy views
 
 
 def trace_mark(what):
+    if _DEBUG:
+        import sys
+        print("[shard] after", what, file=sys.stderr, flush=True)
     if TRACE is None:
         return
     import time
@@ -91,6 +97,8 @@ class ShardRank:
             raise RuntimeError("slot %d holds %d bytes, expected %d" % (slot, nb.value, nbytes))
         if not nb.value:
             return torch.empty(0, dtype=torch.uint8, device=self.tdev)
+        if _COPY_SLOTS:
+            return self._take(slot, nb.value)
         return torch.as_tensor(_DevView(p.value, nb.value), device=self.tdev)
 
     def _take(self, slot, nbytes):
@@ -230,6 +238,35 @@ def run_loopback(gens):
         reqs = nxt
 
 
+# RCCL (2.26, ROCm 7.0) delivers WRONG DATA, silently, when one peer's share of an all_to_all_single
+# exceeds 1 GiB (seen on the 1.08 GB pair-probe exchange); keep every per-peer message well below that.
+A2A_CHUNK = 256 << 20
+
+
+def _all_to_all_bytes(dist, group, t, sc, rc, big):
+    """all_to_all_single of uint8 tensor t with per-peer byte counts sc (send) / rc (receive), in rounds of
+    at most A2A_CHUNK bytes per peer; `big` = the largest per-peer count on ANY rank (all ranks must run
+    the same number of rounds)."""
+    recv = torch.empty(sum(rc), dtype=torch.uint8, device=t.device)
+    if big <= A2A_CHUNK:
+        dist.all_to_all_single(recv, t, output_split_sizes=rc, input_split_sizes=sc, group=group)
+        return recv
+    soff = [sum(sc[:i]) for i in range(len(sc))]
+    roff = [sum(rc[:i]) for i in range(len(rc))]
+    for j in range(-(-big // A2A_CHUNK)):
+        lo = j * A2A_CHUNK
+        s_len = [max(0, min(c, lo + A2A_CHUNK) - lo) for c in sc]
+        r_len = [max(0, min(c, lo + A2A_CHUNK) - lo) for c in rc]
+        send_j = torch.cat([t[o + lo: o + lo + n] for o, n in zip(soff, s_len)])
+        recv_j = torch.empty(sum(r_len), dtype=torch.uint8, device=t.device)
+        dist.all_to_all_single(recv_j, send_j, output_split_sizes=r_len, input_split_sizes=s_len, group=group)
+        p = 0
+        for o, n in zip(roff, r_len):
+            recv[o + lo: o + lo + n] = recv_j[p: p + n]
+            p += n
+    return recv
+
+
 def run_distributed(gen, group=None):
     """Drive one rank's coroutine with torch.distributed collectives (RCCL for CUDA tensors, gloo for CPU)."""
     import torch.distributed as dist
@@ -253,11 +290,18 @@ def run_distributed(gen, group=None):
                     cout = torch.empty_like(cin)
                     dist.all_to_all_single(cout, cin, group=group)
                     rcs = cout.t().tolist()
+                bigs = torch.tensor([max(max(sc, default=0), max(rc, default=0)) for sc, rc in zip(counts, rcs)], dtype=torch.int64, device=dev)
+                if world > 1:
+                    dist.all_reduce(bigs, op=dist.ReduceOp.MAX, group=group)
+                bigs = bigs.tolist()
                 outs = []
-                for t, sc, rc in zip(tensors, counts, rcs):
-                    recv = torch.empty(sum(rc), dtype=torch.uint8, device=dev)
-                    dist.all_to_all_single(recv, t, output_split_sizes=rc, input_split_sizes=sc, group=group)
+                for t, sc, rc, big in zip(tensors, counts, rcs, bigs):
+                    recv = _all_to_all_bytes(dist, group, t, sc, rc, big)
                     outs.append(recv)
+                    if _DEBUG and world == 1:
+                        torch.cuda.synchronize()
+                        import sys
+                        print("[a2a] %d bytes same=%s" % (t.numel(), bool(torch.equal(recv, t))), file=sys.stderr, flush=True)
                 res = (outs, rcs)
             elif kind == "gather":
                 t = req[1]
@@ -267,11 +311,20 @@ def run_distributed(gen, group=None):
                 sizes = [int(x) for x in allsz.tolist()]
                 mx = max(sizes)
                 if mx:
-                    pad = torch.empty(mx, dtype=torch.uint8, device=t.device)
-                    pad[: t.numel()] = t
-                    out = torch.empty(mx * world, dtype=torch.uint8, device=t.device)
-                    dist.all_gather_into_tensor(out, pad, group=group)
-                    cat = torch.cat([out[r * mx: r * mx + s] for r, s in enumerate(sizes)]) if world > 1 else out[: sizes[0]]
+                    parts = [[] for _ in range(world)]
+                    for lo in range(0, mx, A2A_CHUNK):           # rounds of bounded size (see A2A_CHUNK)
+                        w = min(A2A_CHUNK, mx - lo)
+                        pad = torch.zeros(w, dtype=torch.uint8, device=t.device)
+                        mine_n = max(0, min(t.numel(), lo + w) - lo)
+                        pad[:mine_n] = t[lo: lo + mine_n]
+                        out = torch.empty(w * world, dtype=torch.uint8, device=t.device)
+                        dist.all_gather_into_tensor(out, pad, group=group)
+                        for r, sz in enumerate(sizes):
+                            n_r = max(0, min(sz, lo + w) - lo)
+                            if n_r:
+                                parts[r].append(out[r * w: r * w + n_r])
+                    flat = [p for r in range(world) for p in parts[r]]
+                    cat = torch.cat(flat) if len(flat) != 1 else flat[0]
                 else:
                     cat = t
                 res = (cat, sizes)

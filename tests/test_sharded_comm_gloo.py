@@ -42,13 +42,16 @@ def toy(rank, G, log):
     log.append(("gather0", allg.clone().numpy().tobytes(), list(sizes)))
 
 
-def _worker(rank, world, port, outdir):
+def _worker(rank, world, port, outdir, chunk):
     sys.path.insert(0, os.path.join(ROOT, "rna-bloom_amd"))
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
+    from rnabloom import sharded
     from rnabloom.sharded import run_distributed
+    if chunk:
+        sharded.A2A_CHUNK = chunk            # force the multi-round path (RCCL's 1 GiB per-peer limit)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     log = []
     run_distributed(toy(rank, world, log))
@@ -58,13 +61,13 @@ def _worker(rank, world, port, outdir):
         pickle.dump(log, fh)
 
 
-@pytest.mark.parametrize("world", [2])
-def test_run_distributed_equals_loopback(world):
+@pytest.mark.parametrize("world,chunk", [(2, 0), (2, 13)])
+def test_run_distributed_equals_loopback(world, chunk):
     from rnabloom.sharded import run_loopback
     logs = [[] for _ in range(world)]
     run_loopback([toy(r, world, logs[r]) for r in range(world)])
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(world, 29500 + os.getpid() % 400, d), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, 29500 + (os.getpid() + 7 * chunk) % 400, d, chunk), nprocs=world, join=True)
         for r in range(world):
             with open(os.path.join(d, "r%d.pkl" % r), "rb") as fh:
                 got = pickle.load(fh)
