@@ -239,8 +239,15 @@ def run_loopback(gens):
 
 
 # RCCL (2.26, ROCm 7.0) delivers WRONG DATA, silently, when one peer's share of an all_to_all_single
-# exceeds 1 GiB (seen on the 1.08 GB pair-probe exchange); keep every per-peer message well below that.
+# exceeds 1 GiB (seen on the 1.08 GB pair-probe exchange at world 1, where share = whole call).  Keep
+# every per-peer message AND every call's total well below that: rounds of A2A_CHUNK bytes per peer,
+# A2A_CHUNK = min(256 MiB, 512 MiB / world).
 A2A_CHUNK = 256 << 20
+A2A_CALL_TOTAL = 512 << 20
+
+
+def _chunk(world):
+    return max(1, min(A2A_CHUNK, A2A_CALL_TOTAL // max(1, world)))
 
 
 def _all_to_all_bytes(dist, group, t, sc, rc, big):
@@ -248,15 +255,16 @@ def _all_to_all_bytes(dist, group, t, sc, rc, big):
     at most A2A_CHUNK bytes per peer; `big` = the largest per-peer count on ANY rank (all ranks must run
     the same number of rounds)."""
     recv = torch.empty(sum(rc), dtype=torch.uint8, device=t.device)
-    if big <= A2A_CHUNK:
+    CH = _chunk(len(sc))
+    if big <= CH:
         dist.all_to_all_single(recv, t, output_split_sizes=rc, input_split_sizes=sc, group=group)
         return recv
     soff = [sum(sc[:i]) for i in range(len(sc))]
     roff = [sum(rc[:i]) for i in range(len(rc))]
-    for j in range(-(-big // A2A_CHUNK)):
-        lo = j * A2A_CHUNK
-        s_len = [max(0, min(c, lo + A2A_CHUNK) - lo) for c in sc]
-        r_len = [max(0, min(c, lo + A2A_CHUNK) - lo) for c in rc]
+    for j in range(-(-big // CH)):
+        lo = j * CH
+        s_len = [max(0, min(c, lo + CH) - lo) for c in sc]
+        r_len = [max(0, min(c, lo + CH) - lo) for c in rc]
         send_j = torch.cat([t[o + lo: o + lo + n] for o, n in zip(soff, s_len)])
         recv_j = torch.empty(sum(r_len), dtype=torch.uint8, device=t.device)
         dist.all_to_all_single(recv_j, send_j, output_split_sizes=r_len, input_split_sizes=s_len, group=group)
@@ -312,8 +320,9 @@ def run_distributed(gen, group=None):
                 mx = max(sizes)
                 if mx:
                     parts = [[] for _ in range(world)]
-                    for lo in range(0, mx, A2A_CHUNK):           # rounds of bounded size (see A2A_CHUNK)
-                        w = min(A2A_CHUNK, mx - lo)
+                    CH = _chunk(world)
+                    for lo in range(0, mx, CH):                  # rounds of bounded size (see A2A_CHUNK)
+                        w = min(CH, mx - lo)
                         pad = torch.zeros(w, dtype=torch.uint8, device=t.device)
                         mine_n = max(0, min(t.numel(), lo + w) - lo)
                         pad[:mine_n] = t[lo: lo + mine_n]
