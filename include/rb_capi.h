@@ -251,7 +251,9 @@ enum {
     RB_SLOT_CONF_OPS = 10,   /* u32 occurrence ids of those runs, run after run */
     RB_SLOT_CW_IDX = 11,     /* u64 global counter index (replayed components) */
     RB_SLOT_CW_VAL = 12,     /* u8 final byte                            */
-    RB_SLOT_COUNT = 13
+    RB_SLOT_Q_BIDX = 13,     /* u64 global bit indices of a query, by owner   */
+    RB_SLOT_Q_CIDX = 14,     /* u64 global counter indices of a query, by owner */
+    RB_SLOT_COUNT = 15
 };
 int rb_graph_create_shard(const rb_graph_params *p, int shard_rank, int shard_count, rb_graph **out);
 /* reads [first, first+n) = the global sub-batch (identical arguments on every rank); [pair_first,
@@ -276,6 +278,17 @@ int rb_shard_conflict_replay(rb_graph *g, const void *runs_dev, int64_t n_runs, 
 int rb_shard_take(rb_graph *g, int slot, void *dst_dev, int64_t nbytes);
 int rb_shard_slot(rb_graph *g, int slot, void **dev_ptr, int64_t *nbytes);
 int rb_shard_span(rb_graph *g, int which, int64_t *span, int64_t *lo, int64_t *hi);
+/* queries on a sharded graph (BloomFilter.lookup R/bloom/BloomFilter.java:139-147,
+ * CountingBloomFilter.getCount :196-210, BloomFilterDeBruijnGraph.getCount :562-570) for hashes any
+ * rank holds: make (indices bucketed by owner: slots Q_BIDX / Q_CIDX) -> [all_to_all] -> serve (bit /
+ * counter byte per index) -> [all_to_all back] -> finish.  what: 0 = lookup in bit filter
+ * `which_bits` (RB_DBGBF / RB_RPKBF), 1 = counting-filter count, 2 = graph count (count + 1, or 0 unless in dbgbf). */
+int rb_shard_query_make(rb_graph *g, int what, int which_bits, const uint64_t *h0_host, size_t n, int64_t *bit_counts,
+                        int64_t *ctr_counts);
+int rb_shard_query_serve(rb_graph *g, int which_bits, const void *bidx_dev, int64_t nb, const void *cidx_dev, int64_t nc,
+                         void *breply_dev /* u8[nb] */, void *creply_dev /* u8[nc] */);
+int rb_shard_query_finish(rb_graph *g, int which_bits, const void *breply_dev, const void *creply_dev,
+                          uint8_t *out8_host /* what 0 */, float *outf_host /* what 1, 2 */);
 
 /* ---- instrumentation: per-kernel-class HIP-event timing on the library's own stream ---- */
 #define RB_PROF_MAX 32

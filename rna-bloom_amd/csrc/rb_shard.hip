@@ -38,6 +38,10 @@ struct ShardState {
     // conflict path scratch
     DevBuf esz, eoff, etab, eslot, elabel, cdesc, cpos, cnops, cnoff;
     DevBuf rk0, rk1, ok0, ok1, ov0, ov1, rtab, rslot, rbig;
+    // queries
+    DevBuf q_h0, q_bpos, q_cpos, q_out;
+    size_t q_n = 0;
+    int q_what = 0;
 };
 
 namespace {
@@ -593,6 +597,39 @@ __global__ void k_tab_emit(const Slot *__restrict__ tab, size_t cap, uint64_t *_
     drop[i] = !used;
 }
 
+// ---------------------------------------------------------------- queries ----
+__global__ void k_query_idx(uint64_t kmul, Mod bmod, int bh, Mod cmod, int ch, const uint64_t *__restrict__ h0, size_t n,
+                            uint64_t *__restrict__ bidx, uint64_t *__restrict__ cidx) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t h = h0[i];
+    for (int j = 0; j < bh; ++j) bidx[i * bh + j] = index_of(multi_hash(h, (uint32_t)j, kmul), bmod);
+    for (int j = 0; j < ch; ++j) cidx[i * ch + j] = index_of(multi_hash(h, (uint32_t)j, kmul), cmod);
+}
+__global__ void k_query_bits(const uint32_t *__restrict__ bits, uint64_t lo, const uint64_t *__restrict__ idx, size_t n, uint8_t *__restrict__ reply) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) reply[i] = bit_test(bits, idx[i] - lo) ? 1u : 0u;
+}
+__global__ void k_query_ctrs(const uint8_t *__restrict__ cbf, uint64_t lo, const uint64_t *__restrict__ idx, size_t n, uint8_t *__restrict__ reply) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) reply[i] = cbf[idx[i] - lo];
+}
+// what: 0 bit-filter lookup (all bits set), 1 counting-filter count (MiniFloat of the minimum byte),
+//       2 graph count = lookup ? count + 1 : 0   (BloomFilterDeBruijnGraph.getCount :562-570)
+__global__ void k_query_combine(int what, int bh, int ch, const uint32_t *__restrict__ bpos, const uint8_t *__restrict__ breply,
+                                const uint32_t *__restrict__ cpos, const uint8_t *__restrict__ creply, size_t n,
+                                uint8_t *__restrict__ out8, float *__restrict__ outf) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    bool present = true;
+    for (int j = 0; j < bh; ++j) present = present && breply[bpos[i * bh + j]] != 0;
+    uint32_t mn = 0xFFu;
+    for (int j = 0; j < ch; ++j) { const uint32_t c = creply[cpos[i * ch + j]]; mn = c < mn ? c : mn; }
+    if (what == 0) out8[i] = present ? 1u : 0u;
+    else if (what == 1) outf[i] = minifloat_to_float(mn);
+    else outf[i] = present ? minifloat_to_float(mn) + 1.0f : 0.0f;   // +1 for the insert that only set the dbgbf bits (:565)
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------ C ABI ----
@@ -1075,6 +1112,76 @@ int rb_shard_conflict_replay(rb_graph *g, const void *runs_dev, int64_t n_runs, 
     });
 }
 
+// ---- queries against the sharded filters (any rank may ask about any hash) ----
+int rb_shard_query_make(rb_graph *g, int what, int which_bits, const uint64_t *h0_host, size_t n, int64_t *bit_counts, int64_t *ctr_counts) {
+    return guarded([&] {
+        RB_REQUIRE(g && g->shard && bit_counts && ctr_counts && (n == 0 || h0_host), "rb_shard_query_make: bad argument");
+        RB_REQUIRE(what >= 0 && what <= 2, "rb_shard_query_make: what must be 0 (lookup), 1 (cbf count) or 2 (graph count)");
+        ShardState *S = g->shard;
+        RB_HIP(hipSetDevice(g->p.device));
+        hipStream_t s = g->stream;
+        BitFilter *bf = which_bits == RB_DBGBF ? &g->dbg : which_bits == RB_RPKBF ? &g->rpk : nullptr;
+        if (what != 1) RB_REQUIRE(bf && bf->bits, "rb_shard_query_make: bit filter %d is not part of this sharded graph", which_bits);
+        for (int r = 0; r < S->G; ++r) bit_counts[r] = ctr_counts[r] = 0;
+        S->slot_bytes[RB_SLOT_Q_BIDX] = S->slot_bytes[RB_SLOT_Q_CIDX] = 0;
+        S->q_n = n; S->q_what = what;
+        if (!n) return;
+        const int bh = what != 1 ? bf->num_hash : 0, ch = what != 0 ? g->cbf_h : 0;
+        S->q_h0.reserve(n * 8); S->stage0.reserve(n * bh * 8 + 16); S->stage3.reserve(n * ch * 8 + 16);
+        S->q_bpos.reserve(n * bh * 4 + 16); S->q_cpos.reserve(n * ch * 4 + 16);
+        RB_HIP(hipMemcpyAsync(S->q_h0.p, h0_host, n * 8, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_query_idx, dim3(blocks_for((int64_t)n)), dim3(TPB), 0, s, kmul_of(g->k), bf ? bf->mod : g->cbf_mod, bh, g->cbf_mod, ch,
+                           S->q_h0.as<uint64_t>(), n, S->stage0.as<uint64_t>(), S->stage3.as<uint64_t>());
+        if (bh) {
+            RouteIdx fb{S->stage0.as<uint64_t>(), nullptr, (uint64_t)S->span[which_bits], nullptr, nullptr, nullptr, nullptr, nullptr, S->q_bpos.as<uint32_t>()};
+            route(g, fb, n * bh, bit_counts, [&](RouteIdx &ff, size_t kept) { ff.out_idx = (uint64_t *)slot_reserve(S, RB_SLOT_Q_BIDX, kept * 8); });
+        }
+        if (ch) {
+            RouteIdx fc{S->stage3.as<uint64_t>(), nullptr, (uint64_t)S->span[RB_CBF], nullptr, nullptr, nullptr, nullptr, nullptr, S->q_cpos.as<uint32_t>()};
+            route(g, fc, n * ch, ctr_counts, [&](RouteIdx &ff, size_t kept) { ff.out_idx = (uint64_t *)slot_reserve(S, RB_SLOT_Q_CIDX, kept * 8); });
+        }
+        RB_HIP(hipGetLastError());
+        RB_HIP(hipStreamSynchronize(s));
+    });
+}
+int rb_shard_query_serve(rb_graph *g, int which_bits, const void *bidx_dev, int64_t nb, const void *cidx_dev, int64_t nc,
+                         void *breply_dev, void *creply_dev) {
+    return guarded([&] {
+        RB_REQUIRE(g && g->shard && nb >= 0 && nc >= 0, "rb_shard_query_serve: bad argument");
+        RB_HIP(hipSetDevice(g->p.device));
+        hipStream_t s = g->stream;
+        if (nb) {
+            BitFilter *bf = which_bits == RB_DBGBF ? &g->dbg : which_bits == RB_RPKBF ? &g->rpk : nullptr;
+            RB_REQUIRE(bf && bf->bits, "rb_shard_query_serve: bit filter %d is not part of this sharded graph", which_bits);
+            hipLaunchKernelGGL(k_query_bits, dim3(blocks_for(nb)), dim3(TPB), 0, s, bf->bits, (uint64_t)bf->lo, (const uint64_t *)bidx_dev, (size_t)nb, (uint8_t *)breply_dev);
+        }
+        if (nc) hipLaunchKernelGGL(k_query_ctrs, dim3(blocks_for(nc)), dim3(TPB), 0, s, g->cbf, (uint64_t)g->cbf_lo, (const uint64_t *)cidx_dev, (size_t)nc, (uint8_t *)creply_dev);
+        RB_HIP(hipGetLastError());
+        RB_HIP(hipStreamSynchronize(s));
+    });
+}
+int rb_shard_query_finish(rb_graph *g, int which_bits, const void *breply_dev, const void *creply_dev, uint8_t *out8_host, float *outf_host) {
+    return guarded([&] {
+        RB_REQUIRE(g && g->shard, "rb_shard_query_finish: bad argument");
+        ShardState *S = g->shard;
+        const size_t n = S->q_n;
+        if (!n) return;
+        const int what = S->q_what;
+        RB_REQUIRE(what == 0 ? out8_host != nullptr : outf_host != nullptr, "rb_shard_query_finish: missing output array");
+        RB_HIP(hipSetDevice(g->p.device));
+        hipStream_t s = g->stream;
+        BitFilter *bf = which_bits == RB_DBGBF ? &g->dbg : which_bits == RB_RPKBF ? &g->rpk : nullptr;
+        const int bh = what != 1 ? bf->num_hash : 0, ch = what != 0 ? g->cbf_h : 0;
+        S->q_out.reserve(n * 4 + 16);
+        hipLaunchKernelGGL(k_query_combine, dim3(blocks_for((int64_t)n)), dim3(TPB), 0, s, what, bh, ch, S->q_bpos.as<uint32_t>(), (const uint8_t *)breply_dev,
+                           S->q_cpos.as<uint32_t>(), (const uint8_t *)creply_dev, n, S->q_out.as<uint8_t>(), S->q_out.as<float>());
+        RB_HIP(hipGetLastError());
+        if (what == 0) RB_HIP(hipMemcpyAsync(out8_host, S->q_out.p, n, hipMemcpyDeviceToHost, s));
+        else RB_HIP(hipMemcpyAsync(outf_host, S->q_out.p, n * 4, hipMemcpyDeviceToHost, s));
+        RB_HIP(hipStreamSynchronize(s));
+    });
+}
+
 }  // extern "C"
 
 namespace rb {
@@ -1084,7 +1191,7 @@ void shard_free(rb_graph *g) {
     for (auto &b : S->slot) b.release();
     DevBuf *bufs[] = {&S->dreq_pos, &S->creq_pos, &S->creq_dup, &S->cfinal, &S->conf_list, &S->stage0, &S->stage1, &S->stage2, &S->stage3,
                       &S->rhist, &S->roffs, &S->bounds, &S->own_f, &S->own_cs, &S->esz, &S->eoff, &S->etab, &S->eslot, &S->elabel, &S->cdesc,
-                      &S->cpos, &S->cnops, &S->cnoff, &S->rk0, &S->rk1, &S->ok0, &S->ok1, &S->ov0, &S->ov1, &S->rtab, &S->rslot, &S->rbig};
+                      &S->cpos, &S->cnops, &S->cnoff, &S->rk0, &S->rk1, &S->ok0, &S->ok1, &S->ov0, &S->ov1, &S->rtab, &S->rslot, &S->rbig, &S->q_h0, &S->q_bpos, &S->q_cpos, &S->q_out};
     for (auto *b : bufs) b->release();
     delete S;
     g->shard = nullptr;

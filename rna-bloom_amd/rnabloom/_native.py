@@ -16,7 +16,7 @@ OP_ADD, OP_ADD_IF_ABSENT, OP_ADD_COUNT_IF_PRESENT, OP_ADD_DBG_ONLY, OP_ADD_COUNT
     OP_ADD_READ_PAIR, OP_ADD_FRAG_PAIR = range(7)
 PROF_MAX = 32
 SLOT_RESERVED0, SLOT_RESERVED1, SLOT_PAIR_IDX, SLOT_DREQ_IDX, SLOT_DREQ_PROBE, SLOT_CREQ_IDX, SLOT_W_IDX, SLOT_W_VAL, \
-    SLOT_CONF_EDGES, SLOT_CONF_RUNS, SLOT_CONF_OPS, SLOT_CW_IDX, SLOT_CW_VAL = range(13)
+    SLOT_CONF_EDGES, SLOT_CONF_RUNS, SLOT_CONF_OPS, SLOT_CW_IDX, SLOT_CW_VAL, SLOT_Q_BIDX, SLOT_Q_CIDX = range(15)
 MODE_ADD, MODE_COUNT_IF_PRESENT = 0, 2
 
 
@@ -92,6 +92,9 @@ SYMBOLS = [
     ("rb_shard_conflict_replay", _i32, [_vp, _vp, _i64, _vp, _i64, C.POINTER(_i64)]),
     ("rb_shard_take", _i32, [_vp, _i32, _vp, _i64]),
     ("rb_shard_slot", _i32, [_vp, _i32, C.POINTER(_vp), C.POINTER(_i64)]),
+    ("rb_shard_query_make", _i32, [_vp, _i32, _i32, _vp, _sz, C.POINTER(_i64), C.POINTER(_i64)]),
+    ("rb_shard_query_serve", _i32, [_vp, _i32, _vp, _i64, _vp, _i64, _vp, _vp]),
+    ("rb_shard_query_finish", _i32, [_vp, _i32, _vp, _vp, _vp, _vp]),
     ("rb_shard_span", _i32, [_vp, _i32, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     ("rb_graph_profile_enable", _i32, [_vp, _i32]),
     ("rb_graph_profile_get", _i32, [_vp, C.POINTER(Profile), _i32]),

@@ -174,6 +174,27 @@ class ShardRank:
         for kk in ("kmers", "pairs", "distinct", "conflict_ops", "sorted_kmers", "reads"):
             self.stats[kk] += getattr(st, kk)
 
+    def query(self, what, h0, which_bits=N.DBGBF, out=None):
+        """Coroutine: what 0 = lookup in bit filter which_bits, 1 = counting-filter count, 2 = graph count, for the
+        hashes h0 (numpy u64; every rank calls this, possibly with an empty array).  The result lands in out[0]."""
+        G = self.count
+        a = np.ascontiguousarray(h0, dtype=np.uint64)
+        b_c, c_c = (C.c_int64 * G)(), (C.c_int64 * G)()
+        check(lib.rb_shard_query_make(self.h, what, which_bits, a.ctypes.data_as(C.c_void_p), a.size, b_c, c_c))
+        b_c, c_c = list(b_c), list(c_c)
+        (o_b, o_c), (o_bc, o_cc) = yield ("a2a", [self._slot(N.SLOT_Q_BIDX, 8 * sum(b_c)), self._slot(N.SLOT_Q_CIDX, 8 * sum(c_c))],
+                                          [[8 * c for c in b_c], [8 * c for c in c_c]])
+        nb, nc = sum(o_bc) // 8, sum(o_cc) // 8
+        brep = torch.empty(nb, dtype=torch.uint8, device=self.tdev)
+        crep = torch.empty(nc, dtype=torch.uint8, device=self.tdev)
+        check(lib.rb_shard_query_serve(self.h, which_bits, _ptr(o_b), nb, _ptr(o_c), nc, _ptr(brep), _ptr(crep)))
+        (my_b, my_c), _ = yield ("a2a", [brep, crep], [[c // 8 for c in o_bc], [c // 8 for c in o_cc]], [b_c, c_c])
+        res = np.zeros(a.size, np.uint8 if what == 0 else np.float32)
+        check(lib.rb_shard_query_finish(self.h, which_bits, _ptr(my_b), _ptr(my_c), res.ctypes.data_as(C.c_void_p) if what == 0 else None,
+                                        res.ctypes.data_as(C.c_void_p) if what != 0 else None))
+        if out is not None:
+            out.append(res.astype(bool) if what == 0 else res)
+
     def add_range(self, batch, first, n, flags, reads_per_substep, pos_bits):
         """Coroutine over all sub-batches of reads [first, first+n) — the same call on every rank."""
         for a in range(0, int(n), reads_per_substep):
@@ -381,6 +402,24 @@ class LoopbackCluster:
         rps = reads_per_substep or rps
         n = batch.n_reads - first if n is None else n
         run_loopback([r.add_range(batch, first, n, flags, rps, pos_bits) for r in self.ranks])
+
+    def _query(self, what, per_rank_h0, which_bits=N.DBGBF):
+        outs = [[] for _ in self.ranks]
+        run_loopback([r.query(what, h, which_bits, o) for r, h, o in zip(self.ranks, per_rank_h0, outs)])
+        return [o[0] for o in outs]
+
+    def contains(self, per_rank_h0):
+        """per_rank_h0[r] = the hashes virtual rank r asks about -> list of bool arrays"""
+        return self._query(0, per_rank_h0)
+
+    def getCount(self, per_rank_h0):
+        return self._query(2, per_rank_h0)
+
+    def getCbfCount(self, per_rank_h0):
+        return self._query(1, per_rank_h0)
+
+    def lookupReadKmerPair(self, per_rank_h0):
+        return self._query(0, per_rank_h0, N.RPKBF)
 
     def exportFilter(self, which):
         return np.concatenate([r.local_filter(which) for r in self.ranks])

@@ -77,3 +77,33 @@ def test_loopback_stranded_count_if_present():
     run_loopback([r.add_range(b, 0, b.n_reads, N.ADD_COUNT_IF_PRESENT, 400, pos_bits) for r in cl.ranks])
     check_filters(cl, og, pairs=False)
     cl.destroy()
+
+
+def test_loopback_queries_match_single_gpu():
+    """contains / getCount / counting-filter count / read-pair lookup on the sharded filters, asked from
+    different ranks, against the single-GPU graph built from the same reads (itself oracle-exact)"""
+    from rnabloom.graph import BloomFilterDeBruijnGraph
+    d = synth.generate_pairs(1500, G=5000, err=0.002, n_rate=1e-3, seed=13)
+    sizes = (300_007, 400_009, 50_021)
+    gg = BloomFilterDeBruijnGraph(*sizes, 2, 2, 2, 25, False, True, rngSeed=2)
+    cl = LoopbackCluster(4, *sizes, 2, 2, 2, 25, False, True, rngSeed=2)
+    gg.setReadPairedKmerDistance(115); cl.setReadPairedKmerDistance(115)
+    s, off = synth.flat(d["left"]); q, _ = synth.flat(d["lqual"])
+    b = ReadBatch.from_ascii(s, q, off, 3)
+    gg.addBatch(b, storeReadPairedKmers=True)
+    cl.addBatch(b, 150, storeReadPairedKmers=True, reads_per_substep=300)
+    reads = [bytes(s[off[i]:off[i + 1]]) for i in range(0, 40)]
+    _, f, r, _ = gg.getKmers(reads)
+    h_present = np.where(f.view(np.int64) < r.view(np.int64), f, r)          # canonical hashVals[0]
+    rng = np.random.default_rng(5)
+    h_random = rng.integers(0, 2 ** 63, 3000, dtype=np.uint64)
+    allh = np.concatenate([h_present, h_random])
+    parts = [allh[0::3], allh[1::3], np.zeros(0, np.uint64), allh[2::3]]     # rank 2 asks nothing
+    for got, ref in ((cl.contains(parts), gg.contains), (cl.getCount(parts), gg.getCount), (cl.getCbfCount(parts), gg.getCbfCount),
+                     (cl.lookupReadKmerPair(parts), gg.lookupReadKmerPair)):
+        for p, g_ in zip(parts, got):
+            assert g_.shape[0] == p.shape[0]
+            if p.size:
+                assert (g_ == ref(p)).all()
+    assert cl.contains(parts)[0].any() and cl.getCount(parts)[0].max() > 1
+    cl.destroy(); gg.destroy() if hasattr(gg, "destroy") else None
