@@ -259,6 +259,14 @@ int rb_graph_create_shard(const rb_graph_params *p, int shard_rank, int shard_co
 /* reads [first, first+n) = the global sub-batch (identical arguments on every rank); [pair_first,
  * +pair_n) = the slice of it whose read-paired k-mers this rank walks; ordinal0 = op ordinal of read
  * `first`; flags as rb_graph_add_batch.  counts: requests per destination rank. */
+/* optional look-ahead (k <= 31): enqueue the window-hash/prefilter pass of the NEXT sub-batch on the
+ * library's producer stream (begin), then its emit + sort + run grouping (emit; waits for the count of
+ * kept records only) — both return without waiting for the GPU, so the work overlaps the serve /
+ * resolve / conflict phases and the exchanges of the current sub-batch.  rb_shard_hash_group with the
+ * same arguments picks the prepared sub-batch up; with different arguments it starts from scratch. */
+int rb_shard_hash_begin(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, uint64_t ordinal0, uint32_t pos_bits,
+                        unsigned flags);
+int rb_shard_hash_emit(rb_graph *g);
 int rb_shard_hash_group(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, int64_t pair_first, int64_t pair_n,
                         uint64_t ordinal0, uint32_t pos_bits, unsigned flags, int64_t *dreq_counts /*[count]*/,
                         int64_t *creq_counts /*[count]*/, int64_t *pair_counts /*[count]*/, rb_add_stats *stats);

@@ -38,6 +38,19 @@ struct ShardState {
     // conflict path scratch
     DevBuf esz, eoff, etab, eslot, elabel, cdesc, cpos, cnops, cnoff;
     DevBuf rk0, rk1, ok0, ok1, ov0, ov1, rtab, rslot, rbig;
+    // sub-batch prepared ahead on the producer stream (rb_shard_hash_begin / _emit)
+    struct Prep {
+        int stage = 0;                          // 0 none, 1 filter pass enqueued, 2 emit + grouping enqueued
+        const rb_batch *b = nullptr;
+        int64_t first = 0, n = 0, w0 = 0, nw = 0;
+        uint64_t ordinal0 = 0;
+        uint32_t pos_bits = 0;
+        unsigned flags = 0;
+        int slot = 0;
+        uint32_t N = 0;
+        uint64_t owned = 0;
+    } prep;
+    uint32_t *pinned = nullptr;                 // [0] = kept records, [16 + 16 q] = owned windows (32 spread counters)
     // queries
     DevBuf q_h0, q_bpos, q_cpos, q_out;
     size_t q_n = 0;
@@ -632,6 +645,56 @@ __global__ void k_query_combine(int what, int bh, int ch, const uint32_t *__rest
 
 }  // namespace
 
+// ---- window hashing of a sub-batch on the producer stream (k <= 31): ownership + prefilter pass,
+//      then masked emit + grouping into the other GroupSlot; no host wait except for the record count ----
+namespace {
+void prep_filter(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, uint64_t ordinal0, uint32_t pos_bits, unsigned flags, hipStream_t st) {
+    ShardState *S = g->shard;
+    ShardState::Prep &P = S->prep;
+    P = ShardState::Prep();
+    P.b = b; P.first = first; P.n = n; P.ordinal0 = ordinal0; P.pos_bits = pos_bits; P.flags = flags;
+    P.w0 = b->h_woff[(size_t)first]; P.nw = (int64_t)b->h_woff[(size_t)(first + n)] - P.w0;
+    P.slot = 1 - g->cur;
+    P.stage = 1;
+    if (!S->pinned) RB_HIP(hipHostMalloc(reinterpret_cast<void **>(&S->pinned), 4096, hipHostMallocDefault));
+    memset(S->pinned, 0, 4096);
+    if (P.nw <= 0) return;
+    const int mode_hash = g->stranded ? ((flags & RB_ADD_REVCOMP) ? 2 : 0) : 1;
+    const size_t nw = (size_t)P.nw;
+    g->chunk_cnt.reserve((nw + 1) * 4); g->chunk_off.reserve((nw + 1) * 4); g->chunk_mask.reserve((nw + 1) * 4);
+    g->temp2.reserve(scan_temp_bytes(nw + 1));
+    g->npf_tot.reserve(2048);
+    RB_HIP(hipMemsetAsync(g->npf_tot.p, 0, 2048, st));
+    RB_HIP(hipMemsetAsync(g->chunk_cnt.as<uint32_t>() + nw, 0, 4, st));
+    FilterView fv = g->view(ordinal0, pos_bits);
+    Npf cache = fv.npf;
+    if (!g->npf_log2) cache.tab = nullptr;
+    launch_filter_windows(b, P.w0, P.nw, g->k, mode_hash, (uint32_t)first, pos_bits, g->p.rng_seed, ordinal0, cache,
+                          g->chunk_cnt.as<uint32_t>(), g->chunk_mask.as<uint32_t>(), g->npf_tot.as<uint32_t>(), st,
+                          (uint32_t)S->G - 1u, (uint32_t)g->shard_rank);
+    exclusive_scan_u32(g->temp2.p, g->temp2.cap, g->chunk_cnt.as<uint32_t>(), g->chunk_off.as<uint32_t>(), nw + 1, st);
+    RB_HIP(hipMemcpyAsync(&S->pinned[0], g->chunk_off.as<uint32_t>() + nw, 4, hipMemcpyDeviceToHost, st));
+    RB_HIP(hipMemcpyAsync(&S->pinned[16], g->npf_tot.p, 2048, hipMemcpyDeviceToHost, st));
+}
+void prep_emit(rb_graph *g, hipStream_t st) {
+    ShardState *S = g->shard;
+    ShardState::Prep &P = S->prep;
+    if (P.stage != 1) return;
+    RB_HIP(hipStreamSynchronize(st));                      // the filter pass (usually long finished)
+    P.N = S->pinned[0];
+    P.owned = 0;
+    for (int q = 0; q < 32; ++q) P.owned += S->pinned[16 + 16 * q];
+    if (P.N) {
+        const int mode_hash = g->stranded ? ((P.flags & RB_ADD_REVCOMP) ? 2 : 0) : 1;
+        g->keys0.reserve((size_t)P.N * 8); g->vals0.reserve((size_t)P.N * 4);
+        launch_hash_windows_masked(P.b, P.w0, P.nw, g->k, mode_hash, g->chunk_off.as<uint32_t>(), g->chunk_mask.as<uint32_t>(),
+                                   (uint32_t)P.first, P.pos_bits, g->keys0.as<uint64_t>(), g->vals0.as<uint32_t>(), st);
+    }
+    group_enqueue(g, P.slot, P.N, P.ordinal0, P.pos_bits, st, g->temp2, g->devctr2);
+    P.stage = 2;
+}
+}  // namespace
+
 // ------------------------------------------------------------------------ C ABI ----
 extern "C" {
 
@@ -727,6 +790,26 @@ int rb_shard_slot(rb_graph *g, int slot, void **dev_ptr, int64_t *nbytes) {
     return RB_OK;
 }
 
+int rb_shard_hash_begin(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, uint64_t ordinal0, uint32_t pos_bits, unsigned flags) {
+    return guarded([&] {
+        RB_REQUIRE(g && g->shard && b, "rb_shard_hash_begin: bad argument");
+        RB_REQUIRE(b->device == g->p.device, "batch lives on device %d, shard on %d", b->device, g->p.device);
+        RB_REQUIRE(first >= 0 && n >= 0 && first + n <= b->n_reads, "rb_shard_hash_begin: bad read range");
+        RB_REQUIRE(pos_bits >= 1 && pos_bits <= 31 && ((uint64_t)b->max_len >> pos_bits) == 0, "rb_shard_hash_begin: pos_bits too small for the reads");
+        RB_HIP(hipSetDevice(g->p.device));
+        g->shard->prep.stage = 0;
+        if (g->k > 31) return;                       // generic window-hash path: hash_group does it all
+        prep_filter(g, b, first, n, ordinal0, pos_bits, flags, g->stream2);
+    });
+}
+int rb_shard_hash_emit(rb_graph *g) {
+    return guarded([&] {
+        RB_REQUIRE(g && g->shard, "rb_shard_hash_emit: bad argument");
+        RB_HIP(hipSetDevice(g->p.device));
+        prep_emit(g, g->stream2);
+    });
+}
+
 int rb_shard_hash_group(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, int64_t pair_first, int64_t pair_n,
                         uint64_t ordinal0, uint32_t pos_bits, unsigned flags, int64_t *dreq_counts, int64_t *creq_counts,
                         int64_t *pair_counts, rb_add_stats *stats) {
@@ -755,31 +838,26 @@ int rb_shard_hash_group(rb_graph *g, const rb_batch *b, int64_t first, int64_t n
         const int64_t w0 = b->h_woff[(size_t)first], nw = (int64_t)b->h_woff[(size_t)(first + n)] - w0;
         uint64_t owned = 0;
         uint32_t N = 0;
+        bool prepared = false;
         if (nw > 0) {
-            g->chunk_cnt.reserve(((size_t)nw + 1) * 4); g->chunk_off.reserve(((size_t)nw + 1) * 4);
-            g->temp.reserve(scan_temp_bytes((size_t)nw + 1));
-            g->npf_tot.reserve(2048);
-            RB_HIP(hipMemsetAsync(g->npf_tot.p, 0, 2048, s));
-            RB_HIP(hipMemsetAsync(g->chunk_cnt.as<uint32_t>() + nw, 0, 4, s));
-            uint32_t spread[16 * 32];
-            if (g->k <= 31) {   // fast kernels: ownership + prefilter inside the window walk, then a masked emit
-                // (the one-pass k_filter_emit measured 1.5x slower here: see rb_graph.hip add_range)
-                g->chunk_mask.reserve(((size_t)nw + 1) * 4);
-                Npf cache = fv.npf;
-                if (!use_cache) cache.tab = nullptr;
-                launch_filter_windows(b, w0, nw, g->k, mode_hash, (uint32_t)first, pos_bits, g->p.rng_seed, ordinal0, cache,
-                                      g->chunk_cnt.as<uint32_t>(), g->chunk_mask.as<uint32_t>(), g->npf_tot.as<uint32_t>(), s, own_mask, own_rank);
-                exclusive_scan_u32(g->temp.p, g->temp.cap, g->chunk_cnt.as<uint32_t>(), g->chunk_off.as<uint32_t>(), (size_t)nw + 1, s);
-                RB_HIP(hipMemcpyAsync(&N, g->chunk_off.as<uint32_t>() + nw, 4, hipMemcpyDeviceToHost, s));
-                RB_HIP(hipMemcpyAsync(spread, g->npf_tot.p, sizeof spread, hipMemcpyDeviceToHost, s));
-                RB_HIP(hipStreamSynchronize(s));
-                for (int q = 0; q < 32; ++q) owned += spread[16 * q];
-                if (N) {
-                    g->keys0.reserve((size_t)N * 8); g->vals0.reserve((size_t)N * 4);
-                    launch_hash_windows_masked(b, w0, nw, g->k, mode_hash, g->chunk_off.as<uint32_t>(), g->chunk_mask.as<uint32_t>(),
-                                               (uint32_t)first, pos_bits, g->keys0.as<uint64_t>(), g->vals0.as<uint32_t>(), s);
-                }
+            if (g->k <= 31) {   // fast kernels on the producer stream: ownership + prefilter inside the window walk,
+                // then a masked emit + grouping (the one-pass k_filter_emit measured 1.5x slower here: see
+                // rb_graph.hip add_range).  Usually rb_shard_hash_begin/_emit did this ahead of time.
+                ShardState::Prep &P = S->prep;
+                const bool ready = P.stage && P.b == b && P.first == first && P.n == n && P.ordinal0 == ordinal0 && P.pos_bits == pos_bits && P.flags == flags;
+                if (!ready) prep_filter(g, b, first, n, ordinal0, pos_bits, flags, g->stream2);   // nothing prepared ahead: do it now
+                prep_emit(g, g->stream2);
+                prepared = true;
+                N = P.N; owned = P.owned;
             } else {            // generic hash of every window, then one ordered compaction
+                RB_HIP(hipStreamSynchronize(g->stream2));
+                S->prep.stage = 0;
+                g->chunk_cnt.reserve(((size_t)nw + 1) * 4); g->chunk_off.reserve(((size_t)nw + 1) * 4);
+                g->temp.reserve(scan_temp_bytes((size_t)nw + 1));
+                g->npf_tot.reserve(2048);
+                RB_HIP(hipMemsetAsync(g->npf_tot.p, 0, 2048, s));
+                RB_HIP(hipMemsetAsync(g->chunk_cnt.as<uint32_t>() + nw, 0, 4, s));
+                uint32_t spread[16 * 32];
                 uint32_t NA = 0;
                 launch_count_windows(b, w0, nw, g->k, g->chunk_cnt.as<uint32_t>(), s);
                 exclusive_scan_u32(g->temp.p, g->temp.cap, g->chunk_cnt.as<uint32_t>(), g->chunk_off.as<uint32_t>(), (size_t)nw + 1, s);
@@ -800,6 +878,12 @@ int rb_shard_hash_group(rb_graph *g, const rb_batch *b, int64_t first, int64_t n
                     for (int q = 0; q < 32; ++q) owned += spread[16 * q];
                 }
             }
+        }
+        uint32_t D_prepared = 0;
+        if (prepared) {   // drain the producer stream (it owns chunk_* / keys0 / the other GroupSlot) and switch slots
+            D_prepared = group_finish(g, S->prep.slot, g->stream2, g->temp, g->devctr2, s);
+            g->cur = S->prep.slot;
+            S->prep.stage = 0;
         }
         S->n_kept = N;
         if (stats) { stats->kmers += (int64_t)owned; stats->sorted_kmers += (int64_t)N; }
@@ -831,7 +915,7 @@ int rb_shard_hash_group(rb_graph *g, const rb_batch *b, int64_t first, int64_t n
         if (stats) stats->reads += pair_n;
         // ---- group this rank's records into runs; requests bucketed by filter owner ----
         if (N) {
-            const uint32_t D = group_records(g, (size_t)N, ordinal0, pos_bits, nullptr, nullptr);
+            const uint32_t D = prepared ? D_prepared : group_records(g, (size_t)N, ordinal0, pos_bits, nullptr, nullptr);
             S->D = D;
             const size_t nd = mode == M_COUNT_ONLY ? 0 : (size_t)D * fv.dbg_h, nc = (size_t)D * fv.cbf_h;
             S->stage0.reserve(nd * 8 + 16); S->stage1.reserve(nd * 8 + 16); S->stage3.reserve(nc * 8 + 16); S->stage2.reserve(nc + 16);
@@ -1193,6 +1277,7 @@ void shard_free(rb_graph *g) {
                       &S->rhist, &S->roffs, &S->bounds, &S->own_f, &S->own_cs, &S->esz, &S->eoff, &S->etab, &S->eslot, &S->elabel, &S->cdesc,
                       &S->cpos, &S->cnops, &S->cnoff, &S->rk0, &S->rk1, &S->ok0, &S->ok1, &S->ov0, &S->ov1, &S->rtab, &S->rslot, &S->rbig, &S->q_h0, &S->q_bpos, &S->q_cpos, &S->q_out};
     for (auto *b : bufs) b->release();
+    if (S->pinned) (void)hipHostFree(S->pinned);
     delete S;
     g->shard = nullptr;
 }

@@ -83,6 +83,8 @@ SYMBOLS = [
     ("rb_minimizers", _i32, [_i32, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
     ("rb_strobemers", _i32, [_i32, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     ("rb_graph_create_shard", _i32, [C.POINTER(GraphParams), _i32, _i32, C.POINTER(_vp)]),
+    ("rb_shard_hash_begin", _i32, [_vp, _vp, _i64, _i64, _u64, _u32, C.c_uint]),
+    ("rb_shard_hash_emit", _i32, [_vp]),
     ("rb_shard_hash_group", _i32, [_vp, _vp, _i64, _i64, _i64, _i64, _u64, _u32, C.c_uint, C.POINTER(_i64), C.POINTER(_i64),
                              C.POINTER(_i64), C.POINTER(AddStats)]),
     ("rb_shard_serve", _i32, [_vp, _i32, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),

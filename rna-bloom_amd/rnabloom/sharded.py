@@ -29,6 +29,9 @@ TRACE = None
 _t_last = [0.0]
 import os as _os
 _DEBUG = bool(_os.environ.get("RB_SHARD_DEBUG"))
+# look-ahead hashing of the next sub-batch: 0 off, 1 begin after this sub-batch's cache updates (resolve),
+# 2 begin right after this sub-batch's own hashing (maximum overlap, prefilter cache one sub-batch staler)
+_OVERLAP = int(_os.environ.get("RB_SHARD_OVERLAP", "1"))
 _COPY_SLOTS = bool(_os.environ.get("RB_SHARD_COPY"))     # exchange from torch-owned copies instead of zero-copy views
 
 
@@ -119,8 +122,10 @@ class ShardRank:
         return v.value
 
     # ---- one global sub-batch; yields exchange requests, receives their results ----
-    def substep(self, batch, first, n, pos_bits, flags):
-        """reads [first, first+n) of `batch` (every rank holds the same batch and passes the same range)"""
+    def substep(self, batch, first, n, pos_bits, flags, nxt=None):
+        """reads [first, first+n) of `batch` (every rank holds the same batch and passes the same range);
+        nxt = (first, n) of the following sub-batch, whose window hashing is enqueued ahead on the
+        library's producer stream so that it overlaps this sub-batch's filter phases and exchanges"""
         mark = trace_mark
         G = self.count
         mode = N.MODE_COUNT_IF_PRESENT if (flags & N.ADD_COUNT_IF_PRESENT) else N.MODE_ADD
@@ -132,6 +137,8 @@ class ShardRank:
         d_c, c_c, pair_c = cnt(), cnt(), cnt()
         check(lib.rb_shard_hash_group(self.h, batch.h, first, n, p0, p1 - p0, self.ordinal, pos_bits, flags, d_c, c_c, pair_c, C.byref(st)))
         d_c, c_c, pair_c = list(d_c), list(c_c), list(pair_c)
+        if nxt and _OVERLAP == 2:
+            check(lib.rb_shard_hash_begin(self.h, batch.h, nxt[0], nxt[1], self.ordinal + int(n), pos_bits, flags))
         mark("hash_group")
         send = [self._slot(N.SLOT_DREQ_IDX, 8 * sum(d_c)), self._slot(N.SLOT_DREQ_PROBE, 8 * sum(d_c)), self._slot(N.SLOT_CREQ_IDX, 8 * sum(c_c)),
                 self._slot(N.SLOT_PAIR_IDX, 8 * sum(pair_c))]
@@ -143,15 +150,21 @@ class ShardRank:
         creply = torch.empty(nc, dtype=torch.uint8, device=self.tdev)
         check(lib.rb_shard_serve(self.h, mode, _ptr(o_didx), _ptr(o_dprobe), nd, _ptr(o_cidx), nc, _ptr(rpidx), np_,
                                  _ptr(dreply), _ptr(creply)))
+        if nxt and _OVERLAP == 2:
+            check(lib.rb_shard_hash_emit(self.h))
         mark("serve")
         (my_dreply, my_creply), _ = yield ("a2a", [dreply, creply], [[c // 8 for c in o_dc], [c // 8 for c in o_cc]], [d_c, c_c])
         # resolve: runs that own their counters alone finish here
         w_c, nconf, nedge = cnt(), C.c_int64(), C.c_int64()
         check(lib.rb_shard_resolve(self.h, mode, _ptr(my_dreply), _ptr(my_creply), w_c, C.byref(nconf), C.byref(nedge), C.byref(st)))
         w_c = list(w_c)
+        if nxt and _OVERLAP == 1:            # after the cache updates of this sub-batch: fresher prefilter, less overlap
+            check(lib.rb_shard_hash_begin(self.h, batch.h, nxt[0], nxt[1], self.ordinal + int(n), pos_bits, flags))
         mark("resolve")
         (o_widx, o_wval), (o_wc, _) = yield ("a2a", [self._slot(N.SLOT_W_IDX, 8 * sum(w_c)), self._slot(N.SLOT_W_VAL, sum(w_c))], [[8 * c for c in w_c], w_c])
         check(lib.rb_shard_apply_writes(self.h, _ptr(o_widx), _ptr(o_wval), sum(o_wc) // 8))
+        if nxt and _OVERLAP == 1:
+            check(lib.rb_shard_hash_emit(self.h))
         mark("writes")
         # runs that share a counter: components -> component owner -> ordered replay -> counter owners
         all_edges, e_sizes = yield ("gather", self._slot(N.SLOT_CONF_EDGES, 16 * nedge.value))
@@ -198,7 +211,9 @@ class ShardRank:
     def add_range(self, batch, first, n, flags, reads_per_substep, pos_bits):
         """Coroutine over all sub-batches of reads [first, first+n) — the same call on every rank."""
         for a in range(0, int(n), reads_per_substep):
-            yield from self.substep(batch, first + a, min(int(n), a + reads_per_substep) - a, pos_bits, flags)
+            b = min(int(n), a + reads_per_substep)
+            nxt = (first + b, min(int(n), b + reads_per_substep) - b) if b < int(n) else None
+            yield from self.substep(batch, first + a, b - a, pos_bits, flags, nxt)
 
 
 # ------------------------------------------------------------------ drivers ----
