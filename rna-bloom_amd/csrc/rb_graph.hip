@@ -853,7 +853,11 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
     uint32_t pos_bits = 1;
     while ((1u << pos_bits) <= b->max_len && pos_bits < 31) ++pos_bits;
     const int64_t max_reads = (int64_t)1 << (32 - pos_bits);
-    const int64_t max_words = std::max<int64_t>(g->max_batch_kmers / 32, 1);
+    // max_batch_kmers bounds the RECORDS a sub-batch sorts.  With the prefilter most windows never
+    // become records, so a sub-batch may span twice as many windows (fewer, larger runs per k-mer); a
+    // sub-batch whose survivors exceed the bound after all (cold cache) is split and redone.
+    const bool npf_path = g->npf_log2 && g->k <= 31;
+    const int64_t max_words = std::max<int64_t>(std::min<int64_t>((npf_path ? 2 : 1) * g->max_batch_kmers, (int64_t)3 << 30) / 32, 1);
     const std::vector<uint32_t> &wo = b->h_woff;
     // plan the sub-batches
     struct Sub { int64_t r0, r1, w0, nw; uint32_t N; int64_t total; };
@@ -863,14 +867,24 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
     {
         int64_t r0 = first;
         const int64_t rend = first + n;
+        // Cold start (first insert into cleared filters): short sub-batches first, doubling up to the full
+        // size — the prefilter cache learns a k-mer's counter exponent only when a sub-batch retires, and
+        // with the producer running one sub-batch ahead the first full-size sub-batches would be sorted
+        // almost unfiltered (measured: 2.3 G of the 3.8 G sorted records of a 12.3 G-k-mer pass).
+        int64_t cur_words = max_words;
+        if (use_npf && g->ordinal == 0 && !getenv("RB_NO_RAMP")) {
+            const int div = getenv("RB_RAMP_DIV") ? std::max(1, atoi(getenv("RB_RAMP_DIV"))) : 64;
+            cur_words = std::min(max_words, std::max<int64_t>(max_words / div, 1 << 16));
+        }
         while (r0 < rend) {
-            // largest r1 with words(r0..r1) <= max_words and r1-r0 <= max_reads (at least one read)
+            // largest r1 with words(r0..r1) <= cur_words and r1-r0 <= max_reads (at least one read)
             int64_t hi = std::min(rend, r0 + max_reads);
             int64_t lo = r0 + 1;
             while (lo < hi) {
                 int64_t mid = (lo + hi + 1) >> 1;
-                if ((int64_t)wo[(size_t)mid] - (int64_t)wo[(size_t)r0] <= max_words) lo = mid; else hi = mid - 1;
+                if ((int64_t)wo[(size_t)mid] - (int64_t)wo[(size_t)r0] <= cur_words) lo = mid; else hi = mid - 1;
             }
+            cur_words = std::min(max_words, cur_words * 2);
             subs.push_back({r0, lo, (int64_t)wo[(size_t)r0], (int64_t)wo[(size_t)lo] - (int64_t)wo[(size_t)r0], 0u, 0});
             r0 = lo;
         }
@@ -879,7 +893,7 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
     unsigned long long *pc = nullptr;
     // producer: hash + group sub-batch i into slot i&1 on the producer stream (touches scratch and,
     // for the order-independent paired k-mers, rpkbf only)
-    auto prepare = [&](size_t i) {
+    auto prepare_once = [&](size_t i) -> bool {
         Sub &sb = subs[i];
         sb.N = 0;
         const int slot = (int)(i & 1u);
@@ -909,6 +923,13 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
                 RB_HIP(hipMemcpyAsync(spread, g->npf_tot.p, sizeof spread, hipMemcpyDeviceToHost, sp));
                 g->prof_end("filter_windows", sp);
                 RB_HIP(hipStreamSynchronize(sp));
+                if ((int64_t)sb.N > g->max_batch_kmers && sb.r1 - sb.r0 > 1) {   // too many survivors: halve and redo
+                    const int64_t mid = sb.r0 + (sb.r1 - sb.r0) / 2;
+                    Sub second{mid, sb.r1, (int64_t)wo[(size_t)mid], (int64_t)wo[(size_t)sb.r1] - (int64_t)wo[(size_t)mid], 0u, 0};
+                    sb.r1 = mid; sb.nw = (int64_t)wo[(size_t)mid] - sb.w0;
+                    subs.insert(subs.begin() + (std::ptrdiff_t)i + 1, second);   // invalidates sb
+                    return false;
+                }
                 for (int q = 0; q < 32; ++q) sb.total += spread[16 * q];
                 if (sb.N) {
                     g->prof_begin(sp);
@@ -960,7 +981,9 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
             launch_pairs(g, b, sb.w0, sb.nw, mode_hash, nullptr, nullptr, pc, sp);
             g->prof_end("pairs_insert", sp);
         }
+        return true;
     };
+    auto prepare = [&](size_t i) { while (!prepare_once(i)) {} };
     if (!subs.empty()) prepare(0);
     for (size_t i = 0; i < subs.size(); ++i) {
         const int slot = (int)(i & 1u);

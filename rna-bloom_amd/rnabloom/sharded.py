@@ -32,6 +32,7 @@ _DEBUG = bool(_os.environ.get("RB_SHARD_DEBUG"))
 # look-ahead hashing of the next sub-batch: 0 off, 1 begin after this sub-batch's cache updates (resolve),
 # 2 begin right after this sub-batch's own hashing (maximum overlap, prefilter cache one sub-batch staler)
 _OVERLAP = int(_os.environ.get("RB_SHARD_OVERLAP", "1"))
+_RAMP = not _os.environ.get("RB_NO_RAMP")
 _COPY_SLOTS = bool(_os.environ.get("RB_SHARD_COPY"))     # exchange from torch-owned copies instead of zero-copy views
 
 
@@ -210,9 +211,20 @@ class ShardRank:
 
     def add_range(self, batch, first, n, flags, reads_per_substep, pos_bits):
         """Coroutine over all sub-batches of reads [first, first+n) — the same call on every rank."""
-        for a in range(0, int(n), reads_per_substep):
-            b = min(int(n), a + reads_per_substep)
-            nxt = (first + b, min(int(n), b + reads_per_substep) - b) if b < int(n) else None
+        n = int(n)
+        # cold start (first insert into cleared filters): short sub-batches first, doubling up to the full
+        # size, so the prefilter cache knows the hot k-mers before the big sub-batches arrive
+        cur = reads_per_substep
+        if self.ordinal == 0 and _RAMP and reads_per_substep >= 64 * 1024:
+            cur = max(reads_per_substep // 64, 1024)
+        cuts, a = [0], 0
+        while a < n:
+            a = min(n, a + cur)
+            cuts.append(a)
+            cur = min(reads_per_substep, cur * 2)
+        for i in range(len(cuts) - 1):
+            a, b = cuts[i], cuts[i + 1]
+            nxt = (first + b, cuts[i + 2] - b) if i + 2 < len(cuts) else None
             yield from self.substep(batch, first + a, b - a, pos_bits, flags, nxt)
 
 

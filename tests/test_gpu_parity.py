@@ -325,10 +325,23 @@ def test_one_pass_filter_kernel_matches(monkeypatch):
     """the experimental one-pass prefilter+emit kernel (decoupled look-back) gives the same filters"""
     monkeypatch.setenv("RB_ONE_PASS_FILTER", "1")
     d = synth.generate_pairs(3000, G=2000, err=0.002, n_rate=1e-3, seed=21, uniform_expr=True)
-    og, gg = graph_pair(200_003, 300_007, 50_021, max_batch=40_000)
+    og, gg = graph_pair(200_003, 300_007, 50_021, max_batch=8_000)
     og.set_read_pair_distance(115); gg.setReadPairedKmerDistance(115)
     s, off = synth.flat(d["left"]); q, _ = synth.flat(d["lqual"])
     og.add_reads(s, q, off, 3, rbo.STORE_READ_PAIRS)
     st = gg.addReads(s, q, off, 3, storeReadPairedKmers=True)
     assert_same_state(og, gg)
     assert st.sorted_kmers < st.kmers
+
+
+def test_cold_subbatch_is_split_when_survivors_exceed_the_bound():
+    """a sub-batch may span 2x max_batch windows; when (cold cache) more than max_batch of them survive
+    the prefilter it is halved and redone — results stay exact and every k-mer is counted once"""
+    d = synth.generate_pairs(1200, G=60000, err=0.002, n_rate=1e-3, seed=33)      # low coverage: nothing to drop
+    og, gg = graph_pair(900_001, 1_200_007, 50_021, max_batch=20_000)
+    og.set_read_pair_distance(115); gg.setReadPairedKmerDistance(115)
+    s, off = synth.flat(d["left"]); q, _ = synth.flat(d["lqual"])
+    o_st = og.add_reads(s, q, off, 3, rbo.STORE_READ_PAIRS)
+    st = gg.addReads(s, q, off, 3, storeReadPairedKmers=True)
+    assert_same_state(og, gg)
+    assert st.kmers == o_st.kmers and st.reads == 1200
