@@ -23,6 +23,8 @@
 #include <new>
 #include <vector>
 
+#include <functional>
+
 #include "rb_pipeline.hpp"
 
 using namespace rb;
@@ -286,7 +288,7 @@ constexpr uint32_t MAX_COMPONENT_KMERS = 8;
 // small component themselves or queue it for the wave-cooperative kernel
 __global__ void k_conf_replay_small(FilterView fv, const uint64_t *__restrict__ uniq, const uint64_t *__restrict__ kmer_keys,
                                     uint32_t n_conf, const uint64_t *__restrict__ op_key, const uint32_t *__restrict__ op_val,
-                                    uint32_t n_ops, uint32_t *__restrict__ big_list, uint32_t *__restrict__ n_big) {
+                                    uint32_t n_ops, uint32_t *__restrict__ big_list, uint32_t *__restrict__ n_big, int store_cache) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_conf) return;
     const uint32_t lab = (uint32_t)(kmer_keys[i] >> 32);
@@ -295,6 +297,16 @@ __global__ void k_conf_replay_small(FilterView fv, const uint64_t *__restrict__ 
     const uint32_t oe = lower_bound_u64(op_key, n_ops, ((uint64_t)lab + 1ull) << 32);
     if (oe - os > SMALL_COMPONENT_OPS) { big_list[atomicAdd(n_big, 1u)] = i; return; }
     replay_serial(fv, uniq, op_key, op_val, os, oe);
+    if (store_cache && fv.npf.tab)   // the component's k-mers are in dbgbf; remember their counter exponents
+        for (uint32_t q = i; q < n_conf && (uint32_t)(kmer_keys[q] >> 32) == lab; ++q) {
+            const uint64_t h0 = uniq[(uint32_t)kmer_keys[q]];
+            uint32_t mn = 255u;
+            for (int j = 0; j < fv.cbf_h; ++j) {
+                const uint32_t c = *(volatile uint8_t *)&fv.cbf[index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod)];
+                mn = c < mn ? c : mn;
+            }
+            if (mn >= 16u && mn < 128u) npf_store(fv.npf, h0, (mn >> 3) - 1u);
+        }
 }
 // one wavefront per large component: the component's counters live in LDS; 64 ops are examined at
 // a time against the current state and the chain hops from one state-changing op to the next
@@ -302,7 +314,7 @@ __global__ void __launch_bounds__(64) k_conf_replay_big(FilterView fv, const uin
                                     const uint64_t *__restrict__ kmer_keys, uint32_t n_conf,
                                     const uint64_t *__restrict__ op_key, const uint32_t *__restrict__ op_val, uint32_t n_ops,
                                     const uint32_t *__restrict__ big_list, const uint32_t *__restrict__ n_big,
-                                    uint32_t *__restrict__ dbg) {
+                                    uint32_t *__restrict__ dbg, int store_cache) {
     __shared__ uint64_t s_idx[MAX_COMPONENT_KMERS * RB_MAX_HASH];   // unique counter indices
     __shared__ uint32_t s_val[MAX_COMPONENT_KMERS * RB_MAX_HASH];   // their current bytes
     __shared__ uint32_t s_val0[MAX_COMPONENT_KMERS * RB_MAX_HASH];
@@ -397,6 +409,11 @@ __global__ void __launch_bounds__(64) k_conf_replay_big(FilterView fv, const uin
             __syncthreads();
         }
         if (lane < s_nu && s_val[lane] != s_val0[lane]) fv.cbf[s_idx[lane]] = (uint8_t)s_val[lane];
+        if (store_cache && fv.npf.tab && lane < nk) {   // the component's k-mers are in dbgbf; remember their exponents
+            uint32_t mn = s_val[s_slot[lane][0]];
+            for (int j = 1; j < H; ++j) { const uint32_t c = s_val[s_slot[lane][j]]; mn = c < mn ? c : mn; }
+            if (mn >= 16u && mn < 128u) npf_store(fv.npf, s_h0[lane], (mn >> 3) - 1u);
+        }
         __syncthreads();
     }
 }
@@ -702,16 +719,18 @@ BitFilter *bit_filter(rb_graph *g, int which) {
 }
 
 // The order-exact pipeline over N (h0, occurrence) records already sitting in keys0/vals0.
-void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, uint32_t pos_bits, rb_add_stats *stats);
+void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, uint32_t pos_bits, rb_add_stats *stats,
+              const std::function<void()> *after_resolve = nullptr);
 void run_pipeline(rb_graph *g, size_t N, int mode, uint64_t ordinal0, uint32_t pos_bits, rb_add_stats *stats) {
     if (N == 0) return;
     const uint32_t D = group_records(g, N, ordinal0, pos_bits, stats, nullptr);
     run_core(g, N, D, mode, ordinal0, pos_bits, stats);
 }
 // stages A/B + heavy + conflict path on the grouped sub-batch in slot g->cur (consumer stream)
-void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, uint32_t pos_bits, rb_add_stats *stats) {
+void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, uint32_t pos_bits, rb_add_stats *stats,
+              const std::function<void()> *after_resolve) {
     hipStream_t s = g->stream;
-    if (N == 0 || D == 0) return;
+    if (N == 0 || D == 0) { if (after_resolve) (*after_resolve)(); return; }
     g->devctr.reserve(DEVCTR_BYTES);
     uint32_t *ctr = g->devctr.as<uint32_t>();
     RB_HIP(hipMemsetAsync(ctr, 0, DEVCTR_BYTES, s));
@@ -757,6 +776,9 @@ void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, ui
                        g->ftable.as<Slot>(), f_log2, g->ctable.as<Slot>(), c_log2, n_foreign, status, nops,
                        g->cvals.as<uint64_t>(), g->tz().as<uint8_t>(), getenv("RB_DEBUG") ? reinterpret_cast<float *>(ctr + 700) : (float *)nullptr);
     g->prof_end("resolve_apply");
+    // the runs that own their counters alone have updated counters and prefilter cache: the producer may
+    // filter the next sub-batch now (heavy and conflicting runs follow below, overlapped with it)
+    if (after_resolve) (*after_resolve)();
     if (getenv("RB_DEBUG")) {
         float df[128];
         RB_HIP(hipMemcpyAsync(df, ctr + 700, sizeof df, hipMemcpyDeviceToHost, s));
@@ -823,10 +845,10 @@ void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, ui
         g->prof_begin();
         RB_HIP(hipMemsetAsync(ctr + 4, 0, 4, s));
         hipLaunchKernelGGL(k_conf_replay_small, dim3(blocks_for(nck)), dim3(TPB), 0, s, fv, uniq, g->kk1.as<uint64_t>(), nck,
-                           g->opk1.as<uint64_t>(), g->opv1.as<uint32_t>(), nco, g->biglist.as<uint32_t>(), ctr + 4);
+                           g->opk1.as<uint64_t>(), g->opv1.as<uint32_t>(), nco, g->biglist.as<uint32_t>(), ctr + 4, (int)(mode != M_COUNT_ONLY));
         hipLaunchKernelGGL(k_conf_replay_big, dim3(std::min<uint32_t>(nck, 262144u)), dim3(64), 0, s, fv, uniq, g->kk1.as<uint64_t>(), nck,
                            g->opk1.as<uint64_t>(), g->opv1.as<uint32_t>(), nco, g->biglist.as<uint32_t>(), ctr + 4,
-                           getenv("RB_DEBUG") ? ctr + 600 : (uint32_t *)nullptr);
+                           getenv("RB_DEBUG") ? ctr + 600 : (uint32_t *)nullptr, (int)(mode != M_COUNT_ONLY));
         g->prof_end("conflict_replay");
         if (getenv("RB_DEBUG")) {
             uint32_t nb = 0;
@@ -992,9 +1014,19 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
         const uint32_t D = group_finish(g, slot, sp, g->temp, g->devctr2, s);   // drains the producer stream
         if (stats) { stats->pairs += (int64_t)np; stats->distinct += D; }
         const bool serial = getenv("RB_SERIAL") != nullptr;   // debugging / clean per-stage timing
-        if (!serial && i + 1 < subs.size()) prepare(i + 1);      // overlaps with the filter stages below
+        const bool early = getenv("RB_PREPARE_EARLY") != nullptr;   // A/B: producer a whole sub-batch ahead (staler cache)
+        if (!serial && early && i + 1 < subs.size()) prepare(i + 1);
         g->cur = slot;
-        run_core(g, subs[i].N, D, mode, g->ordinal + (uint64_t)(subs[i].r0 - first), pos_bits, stats);
+        // sub-batch i+1 is hashed / prefiltered as soon as sub-batch i's own-counter runs have retired (their
+        // cache updates are what the prefilter needs); its sort + grouping then overlap the heavy and
+        // conflicting runs of sub-batch i
+        const std::function<void()> next = [&]() {
+            if (serial || early || i + 1 >= subs.size()) return;
+            RB_HIP(hipEventRecord(g->ev0, s));
+            RB_HIP(hipStreamWaitEvent(sp, g->ev0, 0));
+            prepare(i + 1);
+        };
+        run_core(g, subs[i].N, D, mode, g->ordinal + (uint64_t)(subs[i].r0 - first), pos_bits, stats, &next);
         RB_HIP(hipStreamSynchronize(s));               // slot may be refilled after this
         if (serial && i + 1 < subs.size()) prepare(i + 1);
         if (stats) { stats->kmers += subs[i].total; stats->sorted_kmers += subs[i].N; stats->reads += subs[i].r1 - subs[i].r0; }
