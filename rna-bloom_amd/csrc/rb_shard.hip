@@ -267,7 +267,17 @@ __global__ void k_resolve_shard(FilterView fv, const uint32_t *__restrict__ coun
     uint32_t st = premask | (all_pre ? ST_ALLPRE : 0u) | (kfirst << 12) | (krest << 14) | (contested << ST_CONTESTED_SHIFT);
     nops[d] = ops;
     if (ops == 0) { status[d] = st | RUN_RELEASE; return; }
-    if (contested) { status[d] = st | RUN_CONFLICT; return; }
+    if (contested) {
+        status[d] = st | RUN_CONFLICT;
+        // replayed elsewhere; its pre-batch minimum is still a valid lower bound for the prefilter cache
+        // (the k-mer is in dbgbf: ops > 0 means present before or inserted by this sub-batch's serve)
+        if (fv.npf.tab && mode != M_COUNT_ONLY) {
+            uint32_t mn = c[0];
+            for (int j = 1; j < fv.cbf_h; ++j) mn = c[j] < mn ? c[j] : mn;
+            if (mn >= 16u) npf_store(fv.npf, uniq[d], (mn >> 3) - 1u);
+        }
+        return;
+    }
     if (ops > light_ops) { status[d] = st | RUN_WRITES | RUN_HEAVY; return; }
     status[d] = st | RUN_WRITES;
     run_ops(c, fv.cbf_h, kfirst, krest, tz, starts[d] + m - ops, ops);
