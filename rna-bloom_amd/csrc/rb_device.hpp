@@ -122,22 +122,52 @@ __host__ __device__ __forceinline__ float minifloat_to_float(uint32_t b) {
 constexpr uint32_t RB_OWNER_SHIFT = 40;
 
 // ---- no-op prefilter cache (DESIGN.md §3 "no-op prefilter") ----
-// Direct-mapped table of 8-byte entries keyed by the FULL 64-bit base hash: slot = low L bits of h0
+// 8-way set-associative table of 8-byte entries keyed by the FULL 64-bit base hash: a bucket is one
+// 64-byte line (one memory request per lookup, like a direct-mapped table), bucket = low B bits of h0
 // (ntHash bits are all equally mixed; the signed canonical minimum only skews the TOP bits),
-// entry = (h0 >> L) << 4 | s — slot and tag together are all 64 bits, so a match is exact.  An entry
+// entry = (h0 >> B) << 4 | s — bucket and tag together are all 64 bits, so a match is exact.  An entry
 // asserts "this k-mer is in dbgbf and the exponent (min_counter>>3)-1 of its counting-Bloom minimum
 // is >= s" — counters only grow, so a stale entry stays true.  An occurrence whose draw strength is
-// below s cannot change any counter and may be dropped before sorting.
+// below s cannot change any counter and may be dropped before sorting.  (Direct-mapped, the same
+// 2^28 entries missed ~25 % of the hot k-mers to slot collisions; every miss lets all occurrences
+// of the k-mer through to the sort.)
 struct Npf {
     unsigned long long *tab;   // nullptr => disabled
-    uint32_t log2n;            // 16..27
+    uint32_t log2n;            // log2 of the number of entries (8 per bucket), 16..28
 };
 __device__ __forceinline__ uint32_t npf_lookup(const Npf &c, uint64_t h0) {       // 0 = unknown
-    const uint64_t e = c.tab[h0 & ((1ull << c.log2n) - 1ull)];
-    return ((e >> 4) == (h0 >> c.log2n)) ? (uint32_t)(e & 15ull) : 0u;
+    const uint32_t B = c.log2n - 3u;
+    const ulonglong2 *b = reinterpret_cast<const ulonglong2 *>(c.tab + ((h0 & ((1ull << B) - 1ull)) << 3));
+    const uint64_t tag = h0 >> B;
+    uint32_t s = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const ulonglong2 e = b[q];
+        if ((e.x >> 4) == tag) { const uint32_t v = (uint32_t)(e.x & 15ull); s = v > s ? v : s; }
+        if ((e.y >> 4) == tag) { const uint32_t v = (uint32_t)(e.y & 15ull); s = v > s ? v : s; }
+    }
+    return s;
 }
-__device__ __forceinline__ void npf_store(const Npf &c, uint64_t h0, uint32_t s) { // s in 1..14; 8-byte store: never torn
-    c.tab[h0 & ((1ull << c.log2n) - 1ull)] = ((h0 >> c.log2n) << 4) | (uint64_t)s;
+// s in 1..14.  8-byte stores are never torn; two threads racing for one slot lose one entry at worst,
+// and a k-mer that ends up in two slots is harmless (lookup takes the larger exponent, both are true).
+__device__ __forceinline__ void npf_store(const Npf &c, uint64_t h0, uint32_t s) {
+    const uint32_t B = c.log2n - 3u;
+    unsigned long long *b = c.tab + ((h0 & ((1ull << B) - 1ull)) << 3);
+    const uint64_t tag = h0 >> B;
+    const uint32_t rot = (uint32_t)(h0 >> 52) & 7u;          // where the victim search starts
+    uint32_t victim = rot, vmin = 16u;
+#pragma unroll
+    for (uint32_t i = 0; i < 8u; ++i) {
+        const uint32_t q = (i + rot) & 7u;
+        const unsigned long long e = __hip_atomic_load(&b[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((e >> 4) == tag && e != 0ull) {                   // already here: raise, never lower
+            if ((uint32_t)(e & 15ull) < s) __hip_atomic_store(&b[q], (tag << 4) | (unsigned long long)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        const uint32_t es = (uint32_t)(e & 15ull);            // empty slots read 0: preferred victims
+        if (es < vmin) { vmin = es; victim = q; }
+    }
+    __hip_atomic_store(&b[victim], (tag << 4) | (unsigned long long)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // trailing-zero strength of a draw, capped at 15 (see k_strength)
 __host__ __device__ __forceinline__ uint32_t draw_strength(uint32_t rnd31) {
