@@ -1096,9 +1096,9 @@ int rb_graph_create(const rb_graph_params *p, rb_graph **out) {
         RB_HIP(hipMalloc(&g->cbf, g->cbf_alloc));
         RB_HIP(hipMemset(g->cbf, 0, g->cbf_alloc));
         if (p->use_read_paired_kmers) alloc_bits(g->rpk, p->pkbf_bits, p->pkbf_num_hash, 0, p->pkbf_bits);
-        {   // no-op prefilter cache: one 8-byte entry per ~32 counters, 2^16..2^28 entries (<= 2 GB)
+        {   // no-op prefilter cache: one 8-byte entry per ~64 counters, 2^16..2^28 entries (8-way buckets fill well: 2^27 entries hold the 64 M hot k-mers of config 2 as completely as 2^28)
             const char *e = getenv("RB_NPF");
-            uint32_t l2 = log2_ceil((uint64_t)std::max<int64_t>(p->cbf_bytes / 32, 1));
+            uint32_t l2 = log2_ceil((uint64_t)std::max<int64_t>(p->cbf_bytes / 64, 1));
             l2 = std::max(16u, std::min(28u, l2));
             if (e) l2 = (uint32_t)atoi(e);
             if (l2 >= 8 && l2 <= 30) {

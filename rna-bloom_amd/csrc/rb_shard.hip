@@ -753,7 +753,7 @@ int rb_graph_create_shard(const rb_graph_params *p, int shard_rank, int shard_co
         }
         {   // no-op prefilter cache over this rank's k-mers (applied to the records it receives)
             const char *e = getenv("RB_NPF");
-            uint32_t l2 = log2_ceil((uint64_t)std::max<int64_t>(p->cbf_bytes / 32 / shard_count, 1));
+            uint32_t l2 = log2_ceil((uint64_t)std::max<int64_t>(p->cbf_bytes / 64 / shard_count, 1));
             l2 = std::max(16u, std::min(28u, l2));
             if (e) l2 = (uint32_t)atoi(e);
             if (l2 >= 8 && l2 <= 30) {

@@ -1,0 +1,57 @@
+// gather_bench.hip — random-access ceiling of one MI355X: G lookups/s of independent random 8-byte /
+// 64-byte-line reads as a function of table size and of the number of independent loads a thread keeps
+// in flight.  Build: hipcc -O3 --offload-arch=gfx950 gather_bench.hip -o gather_bench
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+__device__ __forceinline__ uint64_t mix(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; return z ^ (z >> 31);
+}
+// K independent 8-byte loads per iteration, ITER iterations per thread; LINE=1: read the whole 64 B line (4 x 16 B)
+template <int K, int LINE>
+__global__ void k_gather(const uint64_t *__restrict__ tab, uint64_t mask, int iters, uint64_t *out) {
+    uint64_t s = mix((uint64_t)blockIdx.x * blockDim.x + threadIdx.x), acc = 0;
+    for (int it = 0; it < iters; ++it) {
+        uint64_t idx[K];
+#pragma unroll
+        for (int q = 0; q < K; ++q) { s = mix(s); idx[q] = s & mask; }
+#pragma unroll
+        for (int q = 0; q < K; ++q) {
+            if (LINE) {
+                const ulonglong2 *b = reinterpret_cast<const ulonglong2 *>(tab + (idx[q] & ~7ull));
+                ulonglong2 a0 = b[0], a1 = b[1], a2 = b[2], a3 = b[3];
+                acc += a0.x ^ a0.y ^ a1.x ^ a1.y ^ a2.x ^ a2.y ^ a3.x ^ a3.y;
+            } else acc += tab[idx[q]];
+        }
+    }
+    if (acc == 0x1234567ull) out[0] = acc;
+}
+template <int K, int LINE> double run(const uint64_t *tab, uint64_t n, uint64_t *out, int blocks, int tpb, int iters) {
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL((k_gather<K, LINE>), dim3(blocks), dim3(tpb), 0, 0, tab, n - 1, 2, out);
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((k_gather<K, LINE>), dim3(blocks), dim3(tpb), 0, 0, tab, n - 1, iters, out);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    return (double)blocks * tpb * iters * K / (ms * 1e-3) / 1e9;
+}
+int main() {
+    uint64_t *out; CK(hipMalloc(&out, 64));
+    const int blocks = 256 * 32, tpb = 256;
+    printf("%-10s %-6s %8s %8s %8s %8s\n", "table", "what", "K=1", "K=2", "K=4", "K=8");
+    for (int l2 = 20; l2 <= 28; l2 += 2) {          // entries of 8 B: 8 MB .. 2 GB
+        uint64_t n = 1ull << l2, *tab;
+        CK(hipMalloc(&tab, n * 8)); CK(hipMemset(tab, 1, n * 8));
+        const int iters = 64;
+        printf("%6.0f MB  8B     %8.1f %8.1f %8.1f %8.1f\n", n * 8 / 1048576.0, run<1, 0>(tab, n, out, blocks, tpb, iters), run<2, 0>(tab, n, out, blocks, tpb, iters),
+               run<4, 0>(tab, n, out, blocks, tpb, iters), run<8, 0>(tab, n, out, blocks, tpb, iters));
+        printf("%6.0f MB  line   %8.1f %8.1f %8.1f %8.1f\n", n * 8 / 1048576.0, run<1, 1>(tab, n, out, blocks, tpb, iters), run<2, 1>(tab, n, out, blocks, tpb, iters),
+               run<4, 1>(tab, n, out, blocks, tpb, iters), run<8, 1>(tab, n, out, blocks, tpb, iters));
+        CK(hipFree(tab));
+    }
+    return 0;
+}
