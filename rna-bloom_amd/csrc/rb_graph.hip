@@ -173,12 +173,18 @@ __global__ void k_resolve_apply(FilterView fv, const uint64_t *__restrict__ uniq
     uint32_t c[RB_MAX_HASH];
     const uint64_t cv = cvals[d];
     for (int j = 0; j < fv.cbf_h; ++j) c[j] = (uint32_t)(cv >> (8 * j)) & 0xFFu;
+    uint32_t mn0 = c[0];
+    for (int j = 1; j < fv.cbf_h; ++j) mn0 = c[j] < mn0 ? c[j] : mn0;
     run_ops(c, fv.cbf_h, kfirst, krest, tz, starts[d] + m - ops, ops);
     for (int j = 0; j < fv.cbf_h; ++j) fv.cbf[idx[j]] = (uint8_t)c[j];   // also clears the claim mark
     if (fv.npf.tab && mode != M_COUNT_ONLY) {   // the k-mer is in dbgbf now; remember its counter exponent
         uint32_t mn = c[0];
         for (int j = 1; j < fv.cbf_h; ++j) mn = c[j] < mn ? c[j] : mn;
-        if (mn >= 16u) npf_store(fv.npf, h0, (mn >> 3) - 1u);
+        // ... unless the cache evidently knows it already: same exponent as before the sub-batch and every
+        // op of the run succeeded (an up-to-date entry lets through only draws that succeed; the minimum
+        // rises by one per success) — saves the bucket read + write for most runs in steady state
+        const bool cached = mn0 >= 16u && (mn >> 3) == (mn0 >> 3) && mn - mn0 == ops;
+        if (mn >= 16u && !cached) npf_store(fv.npf, h0, (mn >> 3) - 1u);
     }
 }
 

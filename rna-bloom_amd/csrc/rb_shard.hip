@@ -280,6 +280,8 @@ __global__ void k_resolve_shard(FilterView fv, const uint32_t *__restrict__ coun
     }
     if (ops > light_ops) { status[d] = st | RUN_WRITES | RUN_HEAVY; return; }
     status[d] = st | RUN_WRITES;
+    uint32_t mn0 = c[0];
+    for (int j = 1; j < fv.cbf_h; ++j) mn0 = c[j] < mn0 ? c[j] : mn0;
     run_ops(c, fv.cbf_h, kfirst, krest, tz, starts[d] + m - ops, ops);
     uint64_t out = 0;
     for (int j = 0; j < fv.cbf_h; ++j) out |= (uint64_t)c[j] << (8 * j);
@@ -287,7 +289,9 @@ __global__ void k_resolve_shard(FilterView fv, const uint32_t *__restrict__ coun
     if (fv.npf.tab && mode != M_COUNT_ONLY) {   // the k-mer is in dbgbf now; remember its counter exponent
         uint32_t mn = c[0];
         for (int j = 1; j < fv.cbf_h; ++j) mn = c[j] < mn ? c[j] : mn;
-        if (mn >= 16u) npf_store(fv.npf, uniq[d], (mn >> 3) - 1u);
+        // (not when the cache evidently has it: same exponent and every op succeeded — see k_resolve_apply)
+        const bool cached = mn0 >= 16u && (mn >> 3) == (mn0 >> 3) && mn - mn0 == ops;
+        if (mn >= 16u && !cached) npf_store(fv.npf, uniq[d], (mn >> 3) - 1u);
     }
 }
 __global__ void k_emit_writes(FilterView fv, const uint64_t *__restrict__ uniq, uint32_t D, const uint32_t *__restrict__ status,
