@@ -75,6 +75,10 @@ __global__ void k_probe(FilterView fv, const uint64_t *__restrict__ uniq, const 
     // can this run have counting-Bloom ops?  (exact number is known in stage B)
     bool may_count = true;
     if (mode == M_COUNT_IF_PRESENT) may_count = all;
+    if (mode == M_ADD && !all && counts[d] == 1u) {   // first sighting, seen once: ops = 0 unless found by arbitration
+        may_count = false;                            // (sequencing-error k-mers: most runs of a real data set)
+        st |= ST_LATE;
+    }
     if (may_count) {
         uint64_t cidx[RB_MAX_HASH], cv = 0;
         for (int j = 0; j < fv.cbf_h; ++j) {
@@ -99,6 +103,45 @@ __global__ void k_probe(FilterView fv, const uint64_t *__restrict__ uniq, const 
     }
     status[d] = st;
     if (n_foreign) atomicAdd(&counters[16 + 16 * (blockIdx.x & 31u)], n_foreign);   // 32 spread counters
+}
+// between stage A and B: the single-occurrence runs of new k-mers learn from the first-setter table whether
+// their one occurrence counts after all (every missing bit was set by an EARLIER probe of the sub-batch);
+// only those claim their counters — the others never touch the counting filter
+__global__ void k_late_claim(FilterView fv, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ starts,
+                             const uint32_t *__restrict__ vals, uint32_t n_distinct, const Slot *ftable, uint32_t f_log2,
+                             uint32_t *__restrict__ status, uint64_t *__restrict__ cvals, uint64_t *__restrict__ foreign_idx,
+                             uint32_t *__restrict__ counters) {
+    uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n_distinct) return;
+    uint32_t st = status[d];
+    if (!(st & ST_LATE)) return;
+    const uint64_t h0 = uniq[d];
+    const unsigned long long v_first = vals[starts[d]];
+    bool found = true;
+    for (int j = 0; j < fv.dbg_h && found; ++j) {
+        if ((st >> j) & 1u) continue;
+        const Slot *s = table_find(ftable, f_log2, index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.dbg_mod));
+        if (!(s->val < ((v_first << 4) | (unsigned long long)j))) found = false;
+    }
+    if (!found) return;
+    st |= ST_LATE_FOUND | ST_CLAIMED;
+    uint64_t cidx[RB_MAX_HASH], cv = 0;
+    uint32_t n_foreign = 0;
+    for (int j = 0; j < fv.cbf_h; ++j) {
+        cidx[j] = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod);
+        int dup = -1;
+        for (int q = 0; q < j; ++q) if (cidx[q] == cidx[j]) dup = q;
+        uint32_t byte;
+        if (dup >= 0) byte = (uint32_t)(cv >> (8 * dup)) & 0xFFu;
+        else {
+            byte = cbf_claim(fv.cbf, cidx[j]);
+            if (byte & CLAIM) { st |= ST_FOREIGN; foreign_idx[(size_t)d * fv.cbf_h + j] = cidx[j]; ++n_foreign; byte &= 0x7Fu; }
+        }
+        cv |= (uint64_t)byte << (8 * j);
+    }
+    cvals[d] = cv;
+    status[d] = st;
+    if (n_foreign) atomicAdd(&counters[16 + 16 * (blockIdx.x & 31u)], n_foreign);
 }
 __global__ void k_cs_build(const uint64_t *__restrict__ foreign_idx, size_t n, Slot *cs, uint32_t cs_log2) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -127,7 +170,11 @@ __global__ void k_resolve_apply(FilterView fv, const uint64_t *__restrict__ uniq
         kfirst = krest = K_INC_IF_POS;
     } else {
         bool found_first = true;
-        if (!all_pre) {
+        if (st & ST_LATE) {                       // arbitration already looked up by k_late_claim
+            found_first = (st & ST_LATE_FOUND) != 0;
+            for (int j = 0; j < fv.dbg_h; ++j)
+                if (!((st >> j) & 1u)) bit_set(fv.dbg, index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.dbg_mod));
+        } else if (!all_pre) {
             const unsigned long long v_first = vals[starts[d]];
             for (int j = 0; j < fv.dbg_h; ++j) {
                 if ((st >> j) & 1u) continue;
@@ -759,6 +806,9 @@ void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, ui
     g->prof_begin();
     hipLaunchKernelGGL(k_probe, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, uniq, counts, starts, vals, D, mode,
                        g->ftable.as<Slot>(), f_log2, status, g->cvals.as<uint64_t>(), g->foreign.as<uint64_t>(), ctr);
+    if (mode == M_ADD)
+        hipLaunchKernelGGL(k_late_claim, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, uniq, starts, vals, D, g->ftable.as<Slot>(), f_log2,
+                           status, g->cvals.as<uint64_t>(), g->foreign.as<uint64_t>(), ctr);
     uint32_t n_foreign = 0;
     {
         uint32_t spread[16 * 32];

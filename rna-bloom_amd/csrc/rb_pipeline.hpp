@@ -160,6 +160,10 @@ __device__ __forceinline__ void cbf_release(uint8_t *cbf, uint64_t idx) {
 // status word per distinct run: bits 0..7 premask, bit 8 all_pre, bit 9 claimed counters,
 // bit 10 saw a foreign claim, bits 12..13 kind of first op, 14..15 kind of the other ops
 constexpr uint32_t ST_CLAIMED = 1u << 9, ST_FOREIGN = 1u << 10;
+// bit 11: single-occurrence run of a k-mer that is not in dbgbf yet — it counts only if an earlier probe
+// of the sub-batch set all its missing bits (a false positive in the making), so its counters are
+// claimed late, by k_late_claim, and only in that rare case; bit 16: that case applies
+constexpr uint32_t ST_LATE = 1u << 11, ST_LATE_FOUND = 1u << 16;
 // outcome of the resolve stage (lists are built from these flags by stream compaction: a single
 // shared atomic cursor saturates at ~88 M increments/s and would dominate the stage)
 constexpr uint32_t RUN_CONFLICT = 1u << 17, RUN_RELEASE = 1u << 18, RUN_WRITES = 1u << 19, RUN_HEAVY = 1u << 20;
