@@ -238,8 +238,8 @@ int rb_strobemers(int device, const char *seq, const int64_t *offsets, int64_t n
  *   [all_to_all final counter bytes]   apply_writes
  */
 enum {
-    RB_SLOT_RESERVED0 = 0,
-    RB_SLOT_RESERVED1 = 1,
+    RB_SLOT_REC_KEYS = 0,    /* split-reads mode: u64 h0 of the surviving records, bucketed by k-mer owner */
+    RB_SLOT_REC_OCC = 1,     /* u32 occurrence ids (same order)          */
     RB_SLOT_PAIR_IDX = 2,    /* u64 global rpkbf bit indices, by owner   */
     RB_SLOT_DREQ_IDX = 3,    /* u64 global dbgbf bit index               */
     RB_SLOT_DREQ_PROBE = 4,  /* u64 (occ_first << 4 | probe)             */
@@ -253,12 +253,27 @@ enum {
     RB_SLOT_CW_VAL = 12,     /* u8 final byte                            */
     RB_SLOT_Q_BIDX = 13,     /* u64 global bit indices of a query, by owner   */
     RB_SLOT_Q_CIDX = 14,     /* u64 global counter indices of a query, by owner */
-    RB_SLOT_COUNT = 15
+    RB_SLOT_CACHE_UPD = 15,  /* split-reads mode: 16 B {u64 h0, u64 exponent} prefilter-cache entries learnt this sub-batch */
+    RB_SLOT_COUNT = 16
 };
 int rb_graph_create_shard(const rb_graph_params *p, int shard_rank, int shard_count, rb_graph **out);
 /* reads [first, first+n) = the global sub-batch (identical arguments on every rank); [pair_first,
  * +pair_n) = the slice of it whose read-paired k-mers this rank walks; ordinal0 = op ordinal of read
  * `first`; flags as rb_graph_add_batch.  counts: requests per destination rank. */
+/* ---- split-reads mode (the default from 4 ranks up; rnabloom.sharded picks): every rank hashes only ITS slice
+ * of the sub-batch and prefilters it against a REPLICA of the whole prefilter cache; the survivors
+ * (12 B records) travel to the k-mer owners; what the owners learn (cache entries) is all-gathered and
+ * applied to every replica.  Hashing is then 1/count per rank instead of replicated.
+ *   hash   (own slice -> records bucketed by owner, pair probes)   [all_to_all records, pair probes]
+ *   group  (received records, source-rank order = read order -> runs -> requests)   [all_to_all requests]
+ *   serve / resolve / conflict_* as above; resolve also fills RB_SLOT_CACHE_UPD   [all_gather]   cache_apply */
+int rb_shard_set_cache_replication(rb_graph *g, int on);
+int rb_shard_hash(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, int64_t own_first, int64_t own_n,
+                  uint64_t ordinal0, uint32_t pos_bits, unsigned flags, int64_t *rec_counts /*[count]*/,
+                  int64_t *pair_counts /*[count]*/, rb_add_stats *stats);
+int rb_shard_group(rb_graph *g, const void *keys_dev, const void *occ_dev, int64_t n, uint64_t ordinal0,
+                   uint32_t pos_bits, unsigned flags, int64_t *dreq_counts, int64_t *creq_counts);
+int rb_shard_cache_apply(rb_graph *g, const void *upd_dev, int64_t n);
 /* optional look-ahead (k <= 31): enqueue the window-hash/prefilter pass of the NEXT sub-batch on the
  * library's producer stream (begin), then its emit + sort + run grouping (emit; waits for the count of
  * kept records only) — both return without waiting for the GPU, so the work overlaps the serve /

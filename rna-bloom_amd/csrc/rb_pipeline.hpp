@@ -183,7 +183,8 @@ static __global__ void __launch_bounds__(64) k_cbf_heavy(FilterView fv, const ui
                             const uint32_t *__restrict__ vals, const uint32_t *__restrict__ status,
                             const uint32_t *__restrict__ nops, const uint64_t *__restrict__ cvals,
                             const uint8_t *__restrict__ tz, const uint32_t *__restrict__ heavy_list,
-                            const uint32_t *__restrict__ counters, uint64_t *__restrict__ cfinal) {
+                            const uint32_t *__restrict__ counters, uint64_t *__restrict__ cfinal,
+                            uint8_t *__restrict__ cache_upd = nullptr /* sharded engine: exponent to broadcast */) {
     const uint32_t n_heavy = counters[0];
     const uint32_t lane = threadIdx.x;
     for (uint32_t hi = blockIdx.x; hi < n_heavy; hi += gridDim.x) {
@@ -250,7 +251,7 @@ static __global__ void __launch_bounds__(64) k_cbf_heavy(FilterView fv, const ui
             if (fv.npf.tab && (st & ST_ALLPRE)) {   // remember how hard this k-mer has become to increment
                 uint32_t mn = c[0];
                 for (int j = 1; j < fv.cbf_h; ++j) mn = c[j] < mn ? c[j] : mn;
-                if (mn >= 16u) npf_store(fv.npf, h0, (mn >> 3) - 1u);
+                if (mn >= 16u) { npf_store(fv.npf, h0, (mn >> 3) - 1u); if (cache_upd) cache_upd[d] = (uint8_t)((mn >> 3) - 1u); }
             }
         }
     }

@@ -50,6 +50,8 @@ struct ShardState {
         uint32_t N = 0;
         uint64_t owned = 0;
     } prep;
+    bool replicate_cache = false;               // split-reads mode: cache updates are broadcast to every rank
+    DevBuf cache_upd;                           // [D] exponent to broadcast per run (0 = none)
     uint32_t *pinned = nullptr;                 // [0] = kept records, [16 + 16 q] = owned windows (32 spread counters)
     // queries
     DevBuf q_h0, q_bpos, q_cpos, q_out;
@@ -231,9 +233,11 @@ __global__ void k_resolve_shard(FilterView fv, const uint32_t *__restrict__ coun
                                 const uint8_t *__restrict__ dreply, const uint32_t *__restrict__ creq_pos,
                                 const uint8_t *__restrict__ c_dup, const uint8_t *__restrict__ creply,
                                 const uint8_t *__restrict__ tz, const uint64_t *__restrict__ uniq, uint32_t *__restrict__ status,
-                                uint32_t *__restrict__ nops, uint64_t *__restrict__ cvals, uint64_t *__restrict__ cfinal) {
+                                uint32_t *__restrict__ nops, uint64_t *__restrict__ cvals, uint64_t *__restrict__ cfinal,
+                                uint8_t *__restrict__ cache_upd) {
     uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= D) return;
+    if (cache_upd) cache_upd[d] = 0;
     const uint32_t m = counts[d];
     uint32_t premask = 0;
     bool all_pre = true, found_first = true;
@@ -274,7 +278,7 @@ __global__ void k_resolve_shard(FilterView fv, const uint32_t *__restrict__ coun
         if (fv.npf.tab && mode != M_COUNT_ONLY) {
             uint32_t mn = c[0];
             for (int j = 1; j < fv.cbf_h; ++j) mn = c[j] < mn ? c[j] : mn;
-            if (mn >= 16u) npf_store(fv.npf, uniq[d], (mn >> 3) - 1u);
+            if (mn >= 16u) { npf_store(fv.npf, uniq[d], (mn >> 3) - 1u); if (cache_upd) cache_upd[d] = (uint8_t)((mn >> 3) - 1u); }
         }
         return;
     }
@@ -291,9 +295,29 @@ __global__ void k_resolve_shard(FilterView fv, const uint32_t *__restrict__ coun
         for (int j = 1; j < fv.cbf_h; ++j) mn = c[j] < mn ? c[j] : mn;
         // (not when the cache evidently has it: same exponent and every op succeeded — see k_resolve_apply)
         const bool cached = mn0 >= 16u && (mn >> 3) == (mn0 >> 3) && mn - mn0 == ops;
-        if (mn >= 16u && !cached) npf_store(fv.npf, uniq[d], (mn >> 3) - 1u);
+        if (mn >= 16u && !cached) { npf_store(fv.npf, uniq[d], (mn >> 3) - 1u); if (cache_upd) cache_upd[d] = (uint8_t)((mn >> 3) - 1u); }
     }
 }
+// cache updates of this sub-batch, compacted for the broadcast
+struct CacheUpd { uint64_t h0, e; };
+struct RouteUpd {
+    const uint8_t *upd; const uint64_t *uniq; CacheUpd *out;
+    __device__ int dest(size_t i) const { return upd[i] ? 0 : -1; }
+    __device__ void emit(size_t i, uint32_t pos) const { CacheUpd u; u.h0 = uniq[i]; u.e = upd[i]; out[pos] = u; }
+    __device__ void drop(size_t) const {}
+};
+__global__ void k_cache_apply(Npf cache, const CacheUpd *__restrict__ u, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) npf_store(cache, u[i].h0, (uint32_t)u[i].e);
+}
+// records of this rank's read slice, bucketed by the rank that owns their k-mer (stable)
+struct RouteRec {
+    const uint64_t *keys; const uint32_t *occ; const uint8_t *keep; uint32_t own_mask;
+    uint64_t *out_keys; uint32_t *out_occ;
+    __device__ int dest(size_t i) const { return (keep && !keep[i]) ? -1 : (int)((uint32_t)(keys[i] >> RB_OWNER_SHIFT) & own_mask); }
+    __device__ void emit(size_t i, uint32_t pos) const { out_keys[pos] = keys[i]; out_occ[pos] = occ[i]; }
+    __device__ void drop(size_t) const {}
+};
 __global__ void k_emit_writes(FilterView fv, const uint64_t *__restrict__ uniq, uint32_t D, const uint32_t *__restrict__ status,
                               const uint8_t *__restrict__ c_dup, const uint64_t *__restrict__ cfinal,
                               uint64_t *__restrict__ w_idx, uint8_t *__restrict__ w_val, uint8_t *__restrict__ w_drop) {
@@ -690,6 +714,29 @@ void prep_filter(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, uint6
     RB_HIP(hipMemcpyAsync(&S->pinned[0], g->chunk_off.as<uint32_t>() + nw, 4, hipMemcpyDeviceToHost, st));
     RB_HIP(hipMemcpyAsync(&S->pinned[16], g->npf_tot.p, 2048, hipMemcpyDeviceToHost, st));
 }
+// runs of the grouped sub-batch in slot g->cur -> Bloom-bit requests (index + probe id) and counter claims,
+// bucketed by filter owner
+void make_and_route_requests(rb_graph *g, uint32_t D, int mode, uint64_t ordinal0, uint32_t pos_bits, int64_t *dreq_counts, int64_t *creq_counts) {
+    ShardState *S = g->shard;
+    hipStream_t s = g->stream;
+    FilterView fv = g->view(ordinal0, pos_bits);
+    const size_t nd = mode == M_COUNT_ONLY ? 0 : (size_t)D * fv.dbg_h, nc = (size_t)D * fv.cbf_h;
+    S->stage0.reserve(nd * 8 + 16); S->stage1.reserve(nd * 8 + 16); S->stage3.reserve(nc * 8 + 16); S->stage2.reserve(nc + 16);
+    S->creq_dup.reserve(nc + 16);
+    S->dreq_pos.reserve(nd * 4 + 16); S->creq_pos.reserve(nc * 4 + 16);
+    hipLaunchKernelGGL(k_make_requests, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, g->uniq().as<uint64_t>(), g->starts().as<uint32_t>(),
+                       g->vals1().as<uint32_t>(), D, mode, S->stage0.as<uint64_t>(), S->stage1.as<uint64_t>(),
+                       S->stage3.as<uint64_t>(), S->stage2.as<uint8_t>(), S->creq_dup.as<uint8_t>());
+    RouteIdx fd{S->stage0.as<uint64_t>(), nullptr, (uint64_t)S->span[RB_DBGBF], S->stage1.as<uint64_t>(), nullptr,
+                nullptr, nullptr, nullptr, S->dreq_pos.as<uint32_t>()};
+    route(g, fd, nd, dreq_counts, [&](RouteIdx &ff, size_t kept) {
+        ff.out_idx = (uint64_t *)slot_reserve(S, RB_SLOT_DREQ_IDX, kept * 8);
+        ff.out64 = (uint64_t *)slot_reserve(S, RB_SLOT_DREQ_PROBE, kept * 8);
+    });
+    RouteIdx fc{S->stage3.as<uint64_t>(), S->stage2.as<uint8_t>(), (uint64_t)S->span[RB_CBF], nullptr, nullptr,
+                nullptr, nullptr, nullptr, S->creq_pos.as<uint32_t>()};
+    route(g, fc, nc, creq_counts, [&](RouteIdx &ff, size_t kept) { ff.out_idx = (uint64_t *)slot_reserve(S, RB_SLOT_CREQ_IDX, kept * 8); });
+}
 void prep_emit(rb_graph *g, hipStream_t st) {
     ShardState *S = g->shard;
     ShardState::Prep &P = S->prep;
@@ -757,7 +804,7 @@ int rb_graph_create_shard(const rb_graph_params *p, int shard_rank, int shard_co
         }
         {   // no-op prefilter cache over this rank's k-mers (applied to the records it receives)
             const char *e = getenv("RB_NPF");
-            uint32_t l2 = log2_ceil((uint64_t)std::max<int64_t>(p->cbf_bytes / 64 / shard_count, 1));
+            uint32_t l2 = log2_ceil((uint64_t)std::max<int64_t>(p->cbf_bytes / 64, 1));   // full size: in split-reads mode every rank holds a replica of all ranks' entries
             l2 = std::max(16u, std::min(28u, l2));
             if (e) l2 = (uint32_t)atoi(e);
             if (l2 >= 8 && l2 <= 30) {
@@ -931,27 +978,153 @@ int rb_shard_hash_group(rb_graph *g, const rb_batch *b, int64_t first, int64_t n
         if (N) {
             const uint32_t D = prepared ? D_prepared : group_records(g, (size_t)N, ordinal0, pos_bits, nullptr, nullptr);
             S->D = D;
-            const size_t nd = mode == M_COUNT_ONLY ? 0 : (size_t)D * fv.dbg_h, nc = (size_t)D * fv.cbf_h;
-            S->stage0.reserve(nd * 8 + 16); S->stage1.reserve(nd * 8 + 16); S->stage3.reserve(nc * 8 + 16); S->stage2.reserve(nc + 16);
-            S->creq_dup.reserve(nc + 16);
-            S->dreq_pos.reserve(nd * 4 + 16); S->creq_pos.reserve(nc * 4 + 16);
-            hipLaunchKernelGGL(k_make_requests, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, g->uniq().as<uint64_t>(), g->starts().as<uint32_t>(),
-                               g->vals1().as<uint32_t>(), D, mode, S->stage0.as<uint64_t>(), S->stage1.as<uint64_t>(),
-                               S->stage3.as<uint64_t>(), S->stage2.as<uint8_t>(), S->creq_dup.as<uint8_t>());
-            // Bloom-bit requests (index + probe id), bucketed by bit owner
-            RouteIdx fd{S->stage0.as<uint64_t>(), nullptr, (uint64_t)S->span[RB_DBGBF], S->stage1.as<uint64_t>(), nullptr,
-                        nullptr, nullptr, nullptr, S->dreq_pos.as<uint32_t>()};
-            route(g, fd, nd, dreq_counts, [&](RouteIdx &ff, size_t kept) {
-                ff.out_idx = (uint64_t *)slot_reserve(S, RB_SLOT_DREQ_IDX, kept * 8);
-                ff.out64 = (uint64_t *)slot_reserve(S, RB_SLOT_DREQ_PROBE, kept * 8);
-            });
-            // counter claims, bucketed by counter owner
-            RouteIdx fc{S->stage3.as<uint64_t>(), S->stage2.as<uint8_t>(), (uint64_t)S->span[RB_CBF], nullptr, nullptr,
-                        nullptr, nullptr, nullptr, S->creq_pos.as<uint32_t>()};
-            route(g, fc, nc, creq_counts, [&](RouteIdx &ff, size_t kept) { ff.out_idx = (uint64_t *)slot_reserve(S, RB_SLOT_CREQ_IDX, kept * 8); });
+            make_and_route_requests(g, D, mode, ordinal0, pos_bits, dreq_counts, creq_counts);
         }
         RB_HIP(hipGetLastError());
         RB_HIP(hipStreamSynchronize(s));
+    });
+}
+
+// ---- split-reads mode: each rank hashes ITS slice of the reads (prefilter against a replicated cache),
+//      the surviving records travel to the k-mer owners ----
+int rb_shard_set_cache_replication(rb_graph *g, int on) {
+    if (!g || !g->shard) { set_error("rb_shard_set_cache_replication: not a sharded graph"); return RB_ERR_INVALID; }
+    g->shard->replicate_cache = on != 0;
+    return RB_OK;
+}
+int rb_shard_hash(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, int64_t own_first, int64_t own_n, uint64_t ordinal0,
+                  uint32_t pos_bits, unsigned flags, int64_t *rec_counts, int64_t *pair_counts, rb_add_stats *stats) {
+    return guarded([&] {
+        RB_REQUIRE(g && g->shard && b && rec_counts && pair_counts, "rb_shard_hash: bad argument");
+        RB_REQUIRE(b->device == g->p.device, "batch lives on device %d, shard on %d", b->device, g->p.device);
+        RB_REQUIRE(first >= 0 && n >= 0 && first + n <= b->n_reads, "rb_shard_hash: bad read range");
+        RB_REQUIRE(own_first >= first && own_n >= 0 && own_first + own_n <= first + n, "rb_shard_hash: own slice outside the sub-batch");
+        RB_REQUIRE(pos_bits >= 1 && pos_bits <= 31 && ((uint64_t)b->max_len >> pos_bits) == 0, "rb_shard_hash: pos_bits too small for the reads");
+        RB_REQUIRE((uint64_t)n < (1ull << (32 - pos_bits)), "rb_shard_hash: too many reads for the occurrence id");
+        ShardState *S = g->shard;
+        RB_HIP(hipSetDevice(g->p.device));
+        RB_HIP(hipStreamSynchronize(g->stream2));
+        S->prep.stage = 0;
+        hipStream_t s = g->stream;
+        for (int r = 0; r < S->G; ++r) rec_counts[r] = pair_counts[r] = 0;
+        S->slot_bytes[RB_SLOT_REC_KEYS] = S->slot_bytes[RB_SLOT_REC_OCC] = S->slot_bytes[RB_SLOT_PAIR_IDX] = 0;
+        const int mode_hash = g->stranded ? ((flags & RB_ADD_REVCOMP) ? 2 : 0) : 1;
+        const bool pairs = (flags & RB_ADD_STORE_READ_PAIRS) != 0;
+        if (pairs) RB_REQUIRE(g->rpk.bits && g->read_d > 0, "STORE_READ_PAIRS needs use_read_paired_kmers and a read pair distance > 0");
+        const int64_t w0 = b->h_woff[(size_t)own_first], nw = (int64_t)b->h_woff[(size_t)(own_first + own_n)] - w0;
+        if (stats) stats->reads += own_n;
+        if (nw <= 0) return;
+        FilterView fv = g->view(ordinal0, pos_bits);
+        const bool use_cache = g->npf_log2 != 0;
+        const uint32_t own_mask = (uint32_t)S->G - 1u;
+        g->chunk_cnt.reserve(((size_t)nw + 1) * 4); g->chunk_off.reserve(((size_t)nw + 1) * 4);
+        g->temp.reserve(scan_temp_bytes((size_t)nw + 1));
+        g->npf_tot.reserve(2048);
+        RB_HIP(hipMemsetAsync(g->npf_tot.p, 0, 2048, s));
+        RB_HIP(hipMemsetAsync(g->chunk_cnt.as<uint32_t>() + nw, 0, 4, s));
+        uint32_t spread[16 * 32], N = 0;
+        uint64_t windows = 0;
+        const uint8_t *keep = nullptr;
+        const uint64_t *rk = nullptr; const uint32_t *ro = nullptr;
+        // occurrence id and generator ordinal are relative to the GLOBAL sub-batch start `first`
+        if (g->k <= 31) {
+            g->chunk_mask.reserve(((size_t)nw + 1) * 4);
+            Npf cache = fv.npf;
+            if (!use_cache) cache.tab = nullptr;
+            launch_filter_windows(b, w0, nw, g->k, mode_hash, (uint32_t)first, pos_bits, g->p.rng_seed, ordinal0, cache,
+                                  g->chunk_cnt.as<uint32_t>(), g->chunk_mask.as<uint32_t>(), g->npf_tot.as<uint32_t>(), s);
+            exclusive_scan_u32(g->temp.p, g->temp.cap, g->chunk_cnt.as<uint32_t>(), g->chunk_off.as<uint32_t>(), (size_t)nw + 1, s);
+            RB_HIP(hipMemcpyAsync(&N, g->chunk_off.as<uint32_t>() + nw, 4, hipMemcpyDeviceToHost, s));
+            RB_HIP(hipMemcpyAsync(spread, g->npf_tot.p, sizeof spread, hipMemcpyDeviceToHost, s));
+            RB_HIP(hipStreamSynchronize(s));
+            for (int q = 0; q < 32; ++q) windows += spread[16 * q];
+            if (N) {
+                g->keys0.reserve((size_t)N * 8); g->vals0.reserve((size_t)N * 4);
+                launch_hash_windows_masked(b, w0, nw, g->k, mode_hash, g->chunk_off.as<uint32_t>(), g->chunk_mask.as<uint32_t>(),
+                                           (uint32_t)first, pos_bits, g->keys0.as<uint64_t>(), g->vals0.as<uint32_t>(), s);
+                rk = g->keys0.as<uint64_t>(); ro = g->vals0.as<uint32_t>();
+            }
+        } else {            // generic hash of every window; the prefilter verdict rides along into the bucketing
+            launch_count_windows(b, w0, nw, g->k, g->chunk_cnt.as<uint32_t>(), s);
+            exclusive_scan_u32(g->temp.p, g->temp.cap, g->chunk_cnt.as<uint32_t>(), g->chunk_off.as<uint32_t>(), (size_t)nw + 1, s);
+            RB_HIP(hipMemcpyAsync(&N, g->chunk_off.as<uint32_t>() + nw, 4, hipMemcpyDeviceToHost, s));
+            RB_HIP(hipStreamSynchronize(s));
+            windows = N;
+            if (N) {
+                g->keys0.reserve((size_t)N * 8); g->vals0.reserve((size_t)N * 4); S->stage2.reserve((size_t)N + 16);
+                launch_hash_windows(b, w0, nw, g->k, mode_hash, g->chunk_off.as<uint32_t>(), (uint32_t)first, pos_bits,
+                                    g->keys0.as<uint64_t>(), g->vals0.as<uint32_t>(), nullptr, nullptr, s);
+                hipLaunchKernelGGL(k_rec_keep, dim3(blocks_for(N)), dim3(TPB), 0, s, fv, (int)use_cache, g->keys0.as<uint64_t>(), g->vals0.as<uint32_t>(),
+                                   (size_t)N, 0u, 0u, S->stage2.as<uint8_t>(), g->npf_tot.as<uint32_t>());
+                rk = g->keys0.as<uint64_t>(); ro = g->vals0.as<uint32_t>(); keep = S->stage2.as<uint8_t>();
+            }
+        }
+        size_t kept = 0;
+        if (N) {
+            RouteRec fr{rk, ro, keep, own_mask, nullptr, nullptr};
+            kept = route(g, fr, (size_t)N, rec_counts, [&](RouteRec &ff, size_t k_) {
+                ff.out_keys = (uint64_t *)slot_reserve(S, RB_SLOT_REC_KEYS, k_ * 8);
+                ff.out_occ = (uint32_t *)slot_reserve(S, RB_SLOT_REC_OCC, k_ * 4);
+            });
+        }
+        if (stats) { stats->kmers += (int64_t)windows; stats->sorted_kmers += (int64_t)kept; }
+        if (pairs) {
+            uint32_t P = 0;
+            RB_HIP(hipMemsetAsync(g->chunk_cnt.as<uint32_t>() + nw, 0, 4, s));
+            launch_count_windows(b, w0, nw, g->k + g->read_d, g->chunk_cnt.as<uint32_t>(), s);
+            exclusive_scan_u32(g->temp.p, g->temp.cap, g->chunk_cnt.as<uint32_t>(), g->chunk_off.as<uint32_t>(), (size_t)nw + 1, s);
+            RB_HIP(hipMemcpyAsync(&P, g->chunk_off.as<uint32_t>() + nw, 4, hipMemcpyDeviceToHost, s));
+            RB_HIP(hipStreamSynchronize(s));
+            const size_t np = (size_t)P * (size_t)g->rpk.num_hash;
+            if (np) {
+                S->stage0.reserve(np * 8);
+                g->devctr.reserve(DEVCTR_BYTES);
+                unsigned long long *pc = reinterpret_cast<unsigned long long *>(g->devctr.as<uint32_t>() + 12);
+                RB_HIP(hipMemsetAsync(pc, 0, 8, s));
+                launch_pairs(g, b, w0, nw, mode_hash, g->chunk_off.as<uint32_t>(), S->stage0.as<uint64_t>(), pc);
+                RouteIdx f{S->stage0.as<uint64_t>(), nullptr, (uint64_t)S->span[RB_RPKBF], nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+                route(g, f, np, pair_counts, [&](RouteIdx &ff, size_t k_) { ff.out_idx = (uint64_t *)slot_reserve(S, RB_SLOT_PAIR_IDX, k_ * 8); });
+                if (stats) stats->pairs += (int64_t)P;
+            }
+        }
+        RB_HIP(hipGetLastError());
+        RB_HIP(hipStreamSynchronize(s));
+    });
+}
+// the records this rank received (concatenated in source-rank order = read order) -> runs -> requests
+int rb_shard_group(rb_graph *g, const void *keys_dev, const void *occ_dev, int64_t n, uint64_t ordinal0, uint32_t pos_bits,
+                   unsigned flags, int64_t *dreq_counts, int64_t *creq_counts) {
+    return guarded([&] {
+        RB_REQUIRE(g && g->shard && dreq_counts && creq_counts && n >= 0, "rb_shard_group: bad argument");
+        RB_REQUIRE(n < ((int64_t)1 << 30), "rb_shard_group: %lld records in one sub-batch", (long long)n);
+        ShardState *S = g->shard;
+        RB_HIP(hipSetDevice(g->p.device));
+        hipStream_t s = g->stream;
+        for (int r = 0; r < S->G; ++r) dreq_counts[r] = creq_counts[r] = 0;
+        S->D = 0; S->n_conf = 0; S->n_kept = (uint64_t)n; S->ordinal0 = ordinal0; S->pos_bits = pos_bits;
+        S->slot_bytes[RB_SLOT_DREQ_IDX] = S->slot_bytes[RB_SLOT_DREQ_PROBE] = S->slot_bytes[RB_SLOT_CREQ_IDX] = 0;
+        const int mode = (flags & RB_ADD_COUNT_IF_PRESENT) ? M_COUNT_IF_PRESENT : M_ADD;
+        S->mode = mode;
+        if (n == 0) return;
+        g->keys0.reserve((size_t)n * 8); g->vals0.reserve((size_t)n * 4);
+        RB_HIP(hipMemcpyAsync(g->keys0.p, keys_dev, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
+        RB_HIP(hipMemcpyAsync(g->vals0.p, occ_dev, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+        const uint32_t D = group_records(g, (size_t)n, ordinal0, pos_bits, nullptr, nullptr);
+        S->D = D;
+        make_and_route_requests(g, D, mode, ordinal0, pos_bits, dreq_counts, creq_counts);
+        RB_HIP(hipGetLastError());
+        RB_HIP(hipStreamSynchronize(s));
+    });
+}
+int rb_shard_cache_apply(rb_graph *g, const void *upd_dev, int64_t n) {
+    return guarded([&] {
+        RB_REQUIRE(g && g->shard && n >= 0, "rb_shard_cache_apply: bad argument");
+        if (!n || !g->npf_log2) return;
+        RB_HIP(hipSetDevice(g->p.device));
+        FilterView fv = g->view(0, 0);
+        hipLaunchKernelGGL(k_cache_apply, dim3(blocks_for(n)), dim3(TPB), 0, g->stream, fv.npf, (const CacheUpd *)upd_dev, (size_t)n);
+        RB_HIP(hipGetLastError());
+        RB_HIP(hipStreamSynchronize(g->stream));
     });
 }
 
@@ -1017,19 +1190,21 @@ int rb_shard_resolve(rb_graph *g, int mode, const void *dreply_dev, const void *
         for (int r = 0; r < S->G; ++r) w_counts[r] = 0;
         *n_conf_runs = *n_conf_edges = 0;
         S->n_conf = 0;
-        S->slot_bytes[RB_SLOT_W_IDX] = S->slot_bytes[RB_SLOT_W_VAL] = S->slot_bytes[RB_SLOT_CONF_EDGES] = 0;
+        S->slot_bytes[RB_SLOT_W_IDX] = S->slot_bytes[RB_SLOT_W_VAL] = S->slot_bytes[RB_SLOT_CONF_EDGES] = S->slot_bytes[RB_SLOT_CACHE_UPD] = 0;
         const uint32_t D = S->D;
         if (!D) return;
         FilterView fv = g->view(S->ordinal0, S->pos_bits);
         g->status.reserve((size_t)D * 4); g->nops.reserve((size_t)D * 4); g->cvals.reserve((size_t)D * 8);
         g->heavy.reserve((size_t)D * 4); S->conf_list.reserve((size_t)D * 4); S->cfinal.reserve((size_t)D * 8);
+        if (S->replicate_cache) S->cache_upd.reserve((size_t)D + 16);
         g->devctr.reserve(DEVCTR_BYTES);
         uint32_t *ctr = g->devctr.as<uint32_t>();
         RB_HIP(hipMemsetAsync(ctr, 0, DEVCTR_BYTES, s));
         hipLaunchKernelGGL(k_resolve_shard, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, g->counts().as<uint32_t>(), g->starts().as<uint32_t>(), D, mode,
                            g->light_ops, S->dreq_pos.as<uint32_t>(), (const uint8_t *)dreply_dev, S->creq_pos.as<uint32_t>(),
                            S->creq_dup.as<uint8_t>(), (const uint8_t *)creply_dev, g->tz().as<uint8_t>(), g->uniq().as<uint64_t>(),
-                           g->status.as<uint32_t>(), g->nops.as<uint32_t>(), g->cvals.as<uint64_t>(), S->cfinal.as<uint64_t>());
+                           g->status.as<uint32_t>(), g->nops.as<uint32_t>(), g->cvals.as<uint64_t>(), S->cfinal.as<uint64_t>(),
+                           S->replicate_cache ? S->cache_upd.as<uint8_t>() : (uint8_t *)nullptr);
         g->temp.reserve(select_temp_bytes(D));
         select_flagged(g->temp.p, g->temp.cap, g->status.as<uint32_t>(), RUN_HEAVY, D, g->heavy.as<uint32_t>(), ctr + 0, s);
         select_flagged(g->temp.p, g->temp.cap, g->status.as<uint32_t>(), RUN_CONFLICT, D, S->conf_list.as<uint32_t>(), ctr + 1, s);
@@ -1039,7 +1214,13 @@ int rb_shard_resolve(rb_graph *g, int mode, const void *dreply_dev, const void *
         if (hc[0])
             hipLaunchKernelGGL(k_cbf_heavy, dim3(std::min<uint32_t>(hc[0], 262144u)), dim3(64), 0, s, fv, g->uniq().as<uint64_t>(), g->counts().as<uint32_t>(),
                                g->starts().as<uint32_t>(), g->vals1().as<uint32_t>(), g->status.as<uint32_t>(), g->nops.as<uint32_t>(),
-                               g->cvals.as<uint64_t>(), g->tz().as<uint8_t>(), g->heavy.as<uint32_t>(), ctr, S->cfinal.as<uint64_t>());
+                               g->cvals.as<uint64_t>(), g->tz().as<uint8_t>(), g->heavy.as<uint32_t>(), ctr, S->cfinal.as<uint64_t>(),
+                               S->replicate_cache ? S->cache_upd.as<uint8_t>() : (uint8_t *)nullptr);
+        if (S->replicate_cache) {   // what this sub-batch taught the prefilter cache, for every other rank's replica
+            RouteUpd fu{S->cache_upd.as<uint8_t>(), g->uniq().as<uint64_t>(), nullptr};
+            int64_t uc[1];
+            route(g, fu, (size_t)D, uc, [&](RouteUpd &ff, size_t kept) { ff.out = (CacheUpd *)slot_reserve(S, RB_SLOT_CACHE_UPD, kept * sizeof(CacheUpd)); }, 1);
+        }
         // counter writes / releases, bucketed by counter owner
         const size_t nc = (size_t)D * fv.cbf_h;
         S->stage0.reserve(nc * 8 + 16); S->stage2.reserve(2 * nc + 32);
@@ -1289,7 +1470,7 @@ void shard_free(rb_graph *g) {
     for (auto &b : S->slot) b.release();
     DevBuf *bufs[] = {&S->dreq_pos, &S->creq_pos, &S->creq_dup, &S->cfinal, &S->conf_list, &S->stage0, &S->stage1, &S->stage2, &S->stage3,
                       &S->rhist, &S->roffs, &S->bounds, &S->own_f, &S->own_cs, &S->esz, &S->eoff, &S->etab, &S->eslot, &S->elabel, &S->cdesc,
-                      &S->cpos, &S->cnops, &S->cnoff, &S->rk0, &S->rk1, &S->ok0, &S->ok1, &S->ov0, &S->ov1, &S->rtab, &S->rslot, &S->rbig, &S->q_h0, &S->q_bpos, &S->q_cpos, &S->q_out};
+                      &S->cpos, &S->cnops, &S->cnoff, &S->rk0, &S->rk1, &S->ok0, &S->ok1, &S->ov0, &S->ov1, &S->rtab, &S->rslot, &S->rbig, &S->q_h0, &S->q_bpos, &S->q_cpos, &S->q_out, &S->cache_upd};
     for (auto *b : bufs) b->release();
     if (S->pinned) (void)hipHostFree(S->pinned);
     delete S;

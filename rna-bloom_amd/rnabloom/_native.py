@@ -15,8 +15,8 @@ ADD_REVCOMP, ADD_COUNT_IF_PRESENT, ADD_STORE_READ_PAIRS = 1, 2, 4
 OP_ADD, OP_ADD_IF_ABSENT, OP_ADD_COUNT_IF_PRESENT, OP_ADD_DBG_ONLY, OP_ADD_COUNT_ONLY, \
     OP_ADD_READ_PAIR, OP_ADD_FRAG_PAIR = range(7)
 PROF_MAX = 32
-SLOT_RESERVED0, SLOT_RESERVED1, SLOT_PAIR_IDX, SLOT_DREQ_IDX, SLOT_DREQ_PROBE, SLOT_CREQ_IDX, SLOT_W_IDX, SLOT_W_VAL, \
-    SLOT_CONF_EDGES, SLOT_CONF_RUNS, SLOT_CONF_OPS, SLOT_CW_IDX, SLOT_CW_VAL, SLOT_Q_BIDX, SLOT_Q_CIDX = range(15)
+SLOT_REC_KEYS, SLOT_REC_OCC, SLOT_PAIR_IDX, SLOT_DREQ_IDX, SLOT_DREQ_PROBE, SLOT_CREQ_IDX, SLOT_W_IDX, SLOT_W_VAL, \
+    SLOT_CONF_EDGES, SLOT_CONF_RUNS, SLOT_CONF_OPS, SLOT_CW_IDX, SLOT_CW_VAL, SLOT_Q_BIDX, SLOT_Q_CIDX, SLOT_CACHE_UPD = range(16)
 MODE_ADD, MODE_COUNT_IF_PRESENT = 0, 2
 
 
@@ -83,6 +83,10 @@ SYMBOLS = [
     ("rb_minimizers", _i32, [_i32, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
     ("rb_strobemers", _i32, [_i32, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     ("rb_graph_create_shard", _i32, [C.POINTER(GraphParams), _i32, _i32, C.POINTER(_vp)]),
+    ("rb_shard_set_cache_replication", _i32, [_vp, _i32]),
+    ("rb_shard_hash", _i32, [_vp, _vp, _i64, _i64, _i64, _i64, _u64, _u32, C.c_uint, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(AddStats)]),
+    ("rb_shard_group", _i32, [_vp, _vp, _vp, _i64, _u64, _u32, C.c_uint, C.POINTER(_i64), C.POINTER(_i64)]),
+    ("rb_shard_cache_apply", _i32, [_vp, _vp, _i64]),
     ("rb_shard_hash_begin", _i32, [_vp, _vp, _i64, _i64, _u64, _u32, C.c_uint]),
     ("rb_shard_hash_emit", _i32, [_vp]),
     ("rb_shard_hash_group", _i32, [_vp, _vp, _i64, _i64, _i64, _i64, _u64, _u32, C.c_uint, C.POINTER(_i64), C.POINTER(_i64),

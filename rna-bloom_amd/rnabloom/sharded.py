@@ -33,6 +33,7 @@ _DEBUG = bool(_os.environ.get("RB_SHARD_DEBUG"))
 # 2 begin right after this sub-batch's own hashing (maximum overlap, prefilter cache one sub-batch staler)
 _OVERLAP = int(_os.environ.get("RB_SHARD_OVERLAP", "1"))
 _RAMP = not _os.environ.get("RB_NO_RAMP")
+_MODE = _os.environ.get("RB_SHARD_MODE")                  # "split" | "replicated" | unset (by rank count)
 _COPY_SLOTS = bool(_os.environ.get("RB_SHARD_COPY"))     # exchange from torch-owned copies instead of zero-copy views
 
 
@@ -64,7 +65,7 @@ def _ptr(t):
 class ShardRank:
     """One rank's shard of the graph + the coroutine that drives one global sub-batch."""
 
-    def __init__(self, params, rank, count, device):
+    def __init__(self, params, rank, count, device, mode=None):
         self.rank, self.count, self.device = rank, count, device
         self.tdev = torch.device("cuda", device)
         p = N.GraphParams(*params)
@@ -74,6 +75,12 @@ class ShardRank:
         check(lib.rb_graph_create_shard(C.byref(p), rank, count, C.byref(self.h)))
         self.ordinal = 0
         self.stats = dict(kmers=0, pairs=0, distinct=0, conflict_ops=0, reads=0, sorted_kmers=0)
+        # "split": every rank hashes its slice of the reads and sends the surviving records to the k-mer owners
+        # (hashing 1/G per rank, needs every link); "replicated": every rank hashes all reads and keeps its own
+        # k-mers (no record exchange — better when two ranks share ONE xGMI link)
+        self.mode = mode or _MODE or ("split" if count >= 4 else "replicated")
+        assert self.mode in ("split", "replicated")
+        check(lib.rb_shard_set_cache_replication(self.h, int(self.mode == "split")))
 
     def destroy(self):
         if self.h:
@@ -136,22 +143,37 @@ class ShardRank:
         # read pairs of this rank's slice of the reads -> probes by rpkbf owner
         p0, p1 = first + n * self.rank // G, first + n * (self.rank + 1) // G
         d_c, c_c, pair_c = cnt(), cnt(), cnt()
-        check(lib.rb_shard_hash_group(self.h, batch.h, first, n, p0, p1 - p0, self.ordinal, pos_bits, flags, d_c, c_c, pair_c, C.byref(st)))
-        d_c, c_c, pair_c = list(d_c), list(c_c), list(pair_c)
-        if nxt and _OVERLAP == 2:
-            check(lib.rb_shard_hash_begin(self.h, batch.h, nxt[0], nxt[1], self.ordinal + int(n), pos_bits, flags))
-        mark("hash_group")
-        send = [self._slot(N.SLOT_DREQ_IDX, 8 * sum(d_c)), self._slot(N.SLOT_DREQ_PROBE, 8 * sum(d_c)), self._slot(N.SLOT_CREQ_IDX, 8 * sum(c_c)),
-                self._slot(N.SLOT_PAIR_IDX, 8 * sum(pair_c))]
-        (o_didx, o_dprobe, o_cidx, rpidx), (o_dc, _, o_cc, rp_c) = yield ("a2a", send, [[8 * c for c in d_c], [8 * c for c in d_c], [8 * c for c in c_c],
-                                                                                       [8 * c for c in pair_c]])
+        split = self.mode == "split"
+        if split:
+            # hash own slice (prefilter against the replicated cache) -> records to the k-mer owners
+            rec_c = cnt()
+            check(lib.rb_shard_hash(self.h, batch.h, first, n, p0, p1 - p0, self.ordinal, pos_bits, flags, rec_c, pair_c, C.byref(st)))
+            rec_c, pair_c = list(rec_c), list(pair_c)
+            mark("hash")
+            send = [self._slot(N.SLOT_REC_KEYS, 8 * sum(rec_c)), self._slot(N.SLOT_REC_OCC, 4 * sum(rec_c)), self._slot(N.SLOT_PAIR_IDX, 8 * sum(pair_c))]
+            (rkeys, rocc, rpidx), (rk_c, _, rp_c) = yield ("a2a", send, [[8 * c for c in rec_c], [4 * c for c in rec_c], [8 * c for c in pair_c]])
+            check(lib.rb_shard_group(self.h, _ptr(rkeys), _ptr(rocc), sum(rk_c) // 8, self.ordinal, pos_bits, flags, d_c, c_c))
+            d_c, c_c = list(d_c), list(c_c)
+            mark("group")
+            send = [self._slot(N.SLOT_DREQ_IDX, 8 * sum(d_c)), self._slot(N.SLOT_DREQ_PROBE, 8 * sum(d_c)), self._slot(N.SLOT_CREQ_IDX, 8 * sum(c_c))]
+            (o_didx, o_dprobe, o_cidx), (o_dc, _, o_cc) = yield ("a2a", send, [[8 * c for c in d_c], [8 * c for c in d_c], [8 * c for c in c_c]])
+        else:
+            check(lib.rb_shard_hash_group(self.h, batch.h, first, n, p0, p1 - p0, self.ordinal, pos_bits, flags, d_c, c_c, pair_c, C.byref(st)))
+            d_c, c_c, pair_c = list(d_c), list(c_c), list(pair_c)
+            if nxt and _OVERLAP == 2:
+                check(lib.rb_shard_hash_begin(self.h, batch.h, nxt[0], nxt[1], self.ordinal + int(n), pos_bits, flags))
+            mark("hash_group")
+            send = [self._slot(N.SLOT_DREQ_IDX, 8 * sum(d_c)), self._slot(N.SLOT_DREQ_PROBE, 8 * sum(d_c)), self._slot(N.SLOT_CREQ_IDX, 8 * sum(c_c)),
+                    self._slot(N.SLOT_PAIR_IDX, 8 * sum(pair_c))]
+            (o_didx, o_dprobe, o_cidx, rpidx), (o_dc, _, o_cc, rp_c) = yield ("a2a", send, [[8 * c for c in d_c], [8 * c for c in d_c], [8 * c for c in c_c],
+                                                                                           [8 * c for c in pair_c]])
         # serve: this rank's filter ranges answer
         nd, nc, np_ = sum(o_dc) // 8, sum(o_cc) // 8, sum(rp_c) // 8
         dreply = torch.empty(nd, dtype=torch.uint8, device=self.tdev)
         creply = torch.empty(nc, dtype=torch.uint8, device=self.tdev)
         check(lib.rb_shard_serve(self.h, mode, _ptr(o_didx), _ptr(o_dprobe), nd, _ptr(o_cidx), nc, _ptr(rpidx), np_,
                                  _ptr(dreply), _ptr(creply)))
-        if nxt and _OVERLAP == 2:
+        if nxt and _OVERLAP == 2 and not split:
             check(lib.rb_shard_hash_emit(self.h))
         mark("serve")
         (my_dreply, my_creply), _ = yield ("a2a", [dreply, creply], [[c // 8 for c in o_dc], [c // 8 for c in o_cc]], [d_c, c_c])
@@ -159,14 +181,18 @@ class ShardRank:
         w_c, nconf, nedge = cnt(), C.c_int64(), C.c_int64()
         check(lib.rb_shard_resolve(self.h, mode, _ptr(my_dreply), _ptr(my_creply), w_c, C.byref(nconf), C.byref(nedge), C.byref(st)))
         w_c = list(w_c)
-        if nxt and _OVERLAP == 1:            # after the cache updates of this sub-batch: fresher prefilter, less overlap
+        if nxt and _OVERLAP == 1 and not split:   # after the cache updates of this sub-batch: fresher prefilter, less overlap
             check(lib.rb_shard_hash_begin(self.h, batch.h, nxt[0], nxt[1], self.ordinal + int(n), pos_bits, flags))
         mark("resolve")
         (o_widx, o_wval), (o_wc, _) = yield ("a2a", [self._slot(N.SLOT_W_IDX, 8 * sum(w_c)), self._slot(N.SLOT_W_VAL, sum(w_c))], [[8 * c for c in w_c], w_c])
         check(lib.rb_shard_apply_writes(self.h, _ptr(o_widx), _ptr(o_wval), sum(o_wc) // 8))
-        if nxt and _OVERLAP == 1:
+        if nxt and _OVERLAP == 1 and not split:
             check(lib.rb_shard_hash_emit(self.h))
         mark("writes")
+        if split:   # what the owners learnt about their k-mers' counters goes to every rank's prefilter cache
+            upd, u_sizes = yield ("gather", self._slot(N.SLOT_CACHE_UPD))
+            check(lib.rb_shard_cache_apply(self.h, _ptr(upd), sum(u_sizes) // 16))
+            mark("cache_upd")
         # runs that share a counter: components -> component owner -> ordered replay -> counter owners
         all_edges, e_sizes = yield ("gather", self._slot(N.SLOT_CONF_EDGES, 16 * nedge.value))
         if sum(e_sizes):
@@ -411,12 +437,12 @@ class LoopbackCluster:
     """G virtual ranks on one GPU — exercises the full sharded protocol without a second device."""
 
     def __init__(self, count, dbgbfNumBits, cbfNumBytes, pkbfNumBits, dbgbfNumHash, cbfNumHash, pkbfNumHash, k, stranded,
-                 useReadPairedKmers, device=0, rngSeed=0, maxBatchKmers=0, groupBits=0):
+                 useReadPairedKmers, device=0, rngSeed=0, maxBatchKmers=0, groupBits=0, mode=None):
         params = (dbgbfNumBits, cbfNumBytes, pkbfNumBits, dbgbfNumHash, cbfNumHash, pkbfNumHash, k, int(stranded),
                   int(useReadPairedKmers), device, groupBits, rngSeed, maxBatchKmers)
         self.k, self.count = k, count
         self.max_batch = maxBatchKmers or (1 << 30)
-        self.ranks = [ShardRank(params, r, count, device) for r in range(count)]
+        self.ranks = [ShardRank(params, r, count, device, mode) for r in range(count)]
 
     def setReadPairedKmerDistance(self, d):
         for r in self.ranks:

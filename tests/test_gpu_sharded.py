@@ -23,12 +23,13 @@ def check_filters(cl, og, pairs=True):
     assert bad.size == 0, "cbf differs at %d bytes: %s gpu %s oracle %s" % (bad.size, bad[:6], cg[bad[:6]], co[bad[:6]])
 
 
+@pytest.mark.parametrize("mode", ["replicated", "split"])
 @pytest.mark.parametrize("G", [1, 2, 4, 8])
 @pytest.mark.parametrize("sizes", [(400_003, 3_000_017, 90_001), (70_001, 250_007, 9_001)])
-def test_loopback_matches_oracle(G, sizes):
+def test_loopback_matches_oracle(G, sizes, mode):
     d = synth.generate_pairs(2400, G=25000, err=0.003, n_rate=1e-3, seed=17 + G)
     og = rbo.Graph(*sizes, 2, 2, 2, 25, False, True, 9)
-    cl = LoopbackCluster(G, *sizes, 2, 2, 2, 25, False, True, rngSeed=9)
+    cl = LoopbackCluster(G, *sizes, 2, 2, 2, 25, False, True, rngSeed=9, mode=mode)
     og.set_read_pair_distance(115); cl.setReadPairedKmerDistance(115)
     for name, rc in (("left", False), ("right", True)):
         s, off = synth.flat(d[name]); q, _ = synth.flat(d[name[0] + "qual"])
@@ -42,14 +43,15 @@ def test_loopback_matches_oracle(G, sizes):
     cl.destroy()
 
 
+@pytest.mark.parametrize("mode", ["replicated", "split"])
 @pytest.mark.parametrize("k", [25, 33])
-def test_loopback_high_multiplicity(k):
+def test_loopback_high_multiplicity(k, mode):
     """counts well into the probabilistic MiniFloat range, many sub-batches (the prefilter cache is hot);
     k = 33 takes the generic window-hash path (ownership + prefilter applied to the records)"""
     d = synth.generate_pairs(5000, G=3000, err=0.001, n_rate=1e-3, seed=3, uniform_expr=True)
     sizes = (100_003, 150_001, 20_011)
     og = rbo.Graph(*sizes, 2, 2, 2, k, False, True, 1)
-    cl = LoopbackCluster(4, *sizes, 2, 2, 2, k, False, True, rngSeed=1)
+    cl = LoopbackCluster(4, *sizes, 2, 2, 2, k, False, True, rngSeed=1, mode=mode)
     s, off = synth.flat(d["left"]); q, _ = synth.flat(d["lqual"])
     og.add_reads(s, q, off, 3, 0)
     cl.addBatch(ReadBatch.from_ascii(s, q, off, 3), 150, reads_per_substep=500)
@@ -65,7 +67,7 @@ def test_loopback_stranded_count_if_present():
     d = synth.generate_pairs(1500, G=6000, err=0.002, n_rate=1e-3, seed=5)
     sizes = (200_003, 300_007, 20_011)
     og = rbo.Graph(*sizes, 2, 2, 2, 25, True, False, 4)
-    cl = LoopbackCluster(2, *sizes, 2, 2, 2, 25, True, False, rngSeed=4)
+    cl = LoopbackCluster(2, *sizes, 2, 2, 2, 25, True, False, rngSeed=4, mode="split")
     s, off = synth.flat(d["left"]); q, _ = synth.flat(d["lqual"])
     b = ReadBatch.from_ascii(s, q, off, 3)
     og.add_reads(s, q, off, 3, 0)
