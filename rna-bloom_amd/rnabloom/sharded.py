@@ -189,12 +189,15 @@ class ShardRank:
         if nxt and _OVERLAP == 1 and not split:
             check(lib.rb_shard_hash_emit(self.h))
         mark("writes")
-        if split:   # what the owners learnt about their k-mers' counters goes to every rank's prefilter cache
-            upd, u_sizes = yield ("gather", self._slot(N.SLOT_CACHE_UPD))
+        # one all_gather: the (run, contested counter) edges of the runs that share a counter and, in split mode, what
+        # the owners learnt about their k-mers' counters (for every rank's prefilter cache replica)
+        if split:
+            (all_edges, e_sizes), (upd, u_sizes) = yield ("gather", [self._slot(N.SLOT_CONF_EDGES, 16 * nedge.value), self._slot(N.SLOT_CACHE_UPD)])
             check(lib.rb_shard_cache_apply(self.h, _ptr(upd), sum(u_sizes) // 16))
             mark("cache_upd")
-        # runs that share a counter: components -> component owner -> ordered replay -> counter owners
-        all_edges, e_sizes = yield ("gather", self._slot(N.SLOT_CONF_EDGES, 16 * nedge.value))
+        else:
+            all_edges, e_sizes = yield ("gather", self._slot(N.SLOT_CONF_EDGES, 16 * nedge.value))
+        # components -> component owner -> ordered replay -> counter owners
         if sum(e_sizes):
             run_c, op_c = cnt(), cnt()
             check(lib.rb_shard_conflict_route(self.h, _ptr(all_edges), sum(e_sizes) // 16, G * (max(e_sizes) // 16), run_c, op_c, C.byref(st)))
@@ -272,7 +275,8 @@ def _sync(t):
 def run_loopback(gens):
     """Drive G coroutines (virtual ranks on one device) in lock step.
     Requests: ("ints", [..]) -> list over ranks;  ("a2a", tensors, byte counts per tensor [, known receive
-    counts]) -> (received tensors, received byte counts per tensor);  ("gather", tensor) -> (concatenation, sizes)."""
+    counts]) -> (received tensors, received byte counts per tensor);  ("gather", tensor | [tensors]) ->
+    (concatenation over ranks, sizes) | [the same per tensor]."""
     G = len(gens)
     reqs = [next(g) for g in gens]
     while True:
@@ -292,13 +296,18 @@ def run_loopback(gens):
                     cnts.append([int(x.numel()) for x in segs])
                 res.append((outs, cnts))
         elif kind == "gather":
-            sizes = [int(r[1].numel()) for r in reqs]
-            cat = torch.cat([r[1] for r in reqs]) if G > 1 else reqs[0][1]
-            res = [(cat, sizes)] * G
+            many = isinstance(reqs[0][1], (list, tuple))
+            lists = [list(r[1]) if many else [r[1]] for r in reqs]
+            out = []
+            for t in range(len(lists[0])):
+                sizes = [int(l[t].numel()) for l in lists]
+                out.append((torch.cat([l[t] for l in lists]) if G > 1 else lists[0][t], sizes))
+            res = [out if many else out[0]] * G
         else:
             raise ValueError(kind)
         if kind != "ints":
-            _sync(reqs[0][1][0] if kind == "a2a" else reqs[0][1])
+            first = reqs[0][1][0] if isinstance(reqs[0][1], (list, tuple)) else reqs[0][1]
+            _sync(first)
         trace_mark("exchange")
         nxt, done = [], 0
         for g, r in zip(gens, res):
@@ -318,6 +327,7 @@ def run_loopback(gens):
 # A2A_CHUNK = min(256 MiB, 512 MiB / world).
 A2A_CHUNK = 256 << 20
 A2A_CALL_TOTAL = 512 << 20
+FUSE_LIMIT = 8 << 20      # phases whose largest per-peer message is below this travel as one fused collective
 
 
 def _chunk(world):
@@ -349,71 +359,120 @@ def _all_to_all_bytes(dist, group, t, sc, rc, big):
     return recv
 
 
+class _Driver:
+    """torch.distributed exchange layer for one rank: ONE data collective per protocol phase.  The tensors of a
+    phase are fused into one byte buffer per peer ([peer0: t0 t1 ..][peer1: t0 t1 ..]); their byte counts and
+    this rank's largest per-peer total travel in one small all_to_all, from which every rank derives the same
+    round count (no all_reduce)."""
+
+    def __init__(self, dist, group):
+        self.dist, self.group = dist, group
+        self.world = dist.get_world_size(group)
+        self.last_big = 0          # largest fused per-peer message of the last counted phase (same on every rank)
+
+    def a2a(self, tensors, counts, known_rcs=None):
+        dist, world, m = self.dist, self.world, len(tensors)
+        dev = tensors[0].device
+        tot_s = [sum(counts[t][p] for t in range(m)) for p in range(world)]
+        if known_rcs is not None:                       # replies: sizes follow from the requests just exchanged
+            rcs = [[int(c) for c in cs] for cs in known_rcs]
+            big = max(self.last_big, 1)                 # an upper bound every rank shares (replies are smaller)
+        else:
+            cin = torch.tensor([[counts[t][p] for t in range(m)] + [max(tot_s, default=0)] for p in range(world)], dtype=torch.int64, device=dev)
+            cout = torch.empty_like(cin)
+            dist.all_to_all_single(cout, cin, group=self.group)
+            rows = cout.tolist()
+            rcs = [[int(rows[p][t]) for p in range(world)] for t in range(m)]
+            big = max(max(int(r[m]) for r in rows), max(tot_s, default=0))
+            self.last_big = big
+        tot_r = [sum(rcs[t][p] for t in range(m)) for p in range(world)]
+        if m > 1 and big > FUSE_LIMIT:                  # bulky phase: fusing would copy more than a collective costs
+            outs = [_all_to_all_bytes(dist, self.group, tensors[t], counts[t], rcs[t], big) for t in range(m)]
+            return outs, rcs
+        if m == 1:
+            send = tensors[0]
+        else:
+            soffs = [[sum(counts[t][:p]) for p in range(world)] for t in range(m)]
+            send = torch.cat([tensors[t][soffs[t][p]: soffs[t][p] + counts[t][p]] for p in range(world) for t in range(m)])
+        recv = _all_to_all_bytes(dist, self.group, send, tot_s, tot_r, big)
+        if m == 1:
+            outs = [recv]
+        else:
+            outs, base = [], [sum(tot_r[:p]) for p in range(world)]
+            for t in range(m):
+                inner = [sum(rcs[u][p] for u in range(t)) for p in range(world)]
+                segs = [recv[base[p] + inner[p]: base[p] + inner[p] + rcs[t][p]] for p in range(world)]
+                outs.append(torch.cat(segs) if world > 1 else segs[0])
+        if _DEBUG and world == 1:
+            torch.cuda.synchronize()
+            import sys
+            print("[a2a] %d bytes same=%s" % (send.numel(), all(bool(torch.equal(o, t)) for o, t in zip(outs, tensors))), file=sys.stderr, flush=True)
+        return outs, rcs
+
+    def gather(self, tensors):
+        """all_gather of a list of byte tensors in one padded collective -> [(concatenation over ranks, sizes)] per tensor"""
+        dist, world, m = self.dist, self.world, len(tensors)
+        dev = tensors[0].device
+        mine = torch.tensor([int(t.numel()) for t in tensors], dtype=torch.int64, device=dev)
+        allsz = torch.empty(world * m, dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(allsz, mine, group=self.group)
+        allsz = allsz.view(world, m).tolist()
+        tot = [sum(int(x) for x in row) for row in allsz]
+        mx = max(tot)
+        if not mx:
+            return [(t, [0] * world) for t in tensors]
+        fused = torch.cat(tensors) if m > 1 else tensors[0]
+        parts = [[] for _ in range(world)]
+        CH = _chunk(world)
+        for lo in range(0, mx, CH):                      # rounds of bounded size (see A2A_CHUNK)
+            w = min(CH, mx - lo)
+            pad = torch.zeros(w, dtype=torch.uint8, device=dev)
+            mine_n = max(0, min(int(fused.numel()), lo + w) - lo)
+            pad[:mine_n] = fused[lo: lo + mine_n]
+            out = torch.empty(w * world, dtype=torch.uint8, device=dev)
+            dist.all_gather_into_tensor(out, pad, group=self.group)
+            for r in range(world):
+                n_r = max(0, min(tot[r], lo + w) - lo)
+                if n_r:
+                    parts[r].append(out[r * w: r * w + n_r])
+        per_rank = [torch.cat(p) if len(p) > 1 else (p[0] if p else fused[:0]) for p in parts]     # rank r's fused bytes
+        res = []
+        for t in range(m):
+            segs, sizes = [], []
+            for r in range(world):
+                o = sum(int(allsz[r][u]) for u in range(t))
+                n = int(allsz[r][t])
+                sizes.append(n)
+                if n:
+                    segs.append(per_rank[r][o: o + n])
+            res.append((torch.cat(segs) if len(segs) > 1 else (segs[0] if segs else fused[:0]), sizes))
+        return res
+
+
 def run_distributed(gen, group=None):
     """Drive one rank's coroutine with torch.distributed collectives (RCCL for CUDA tensors, gloo for CPU)."""
     import torch.distributed as dist
-    world = dist.get_world_size(group)
+    drv = _Driver(dist, group)
     try:
         req = next(gen)
         while True:
             kind = req[0]
             if kind == "ints":
-                out = [None] * world
+                out = [None] * drv.world
                 dist.all_gather_object(out, req[1], group=group)
                 res = out
             elif kind == "a2a":
-                tensors, counts = req[1], [[int(c) for c in cs] for cs in req[2]]
-                dev = tensors[0].device
-                m = len(tensors)
-                if len(req) > 3:                      # receive counts already known (replies)
-                    rcs = [[int(c) for c in cs] for cs in req[3]]
-                else:                                 # one count exchange for all tensors of the phase
-                    cin = torch.tensor(counts, dtype=torch.int64, device=dev).t().contiguous()     # [world, m]
-                    cout = torch.empty_like(cin)
-                    dist.all_to_all_single(cout, cin, group=group)
-                    rcs = cout.t().tolist()
-                bigs = torch.tensor([max(max(sc, default=0), max(rc, default=0)) for sc, rc in zip(counts, rcs)], dtype=torch.int64, device=dev)
-                if world > 1:
-                    dist.all_reduce(bigs, op=dist.ReduceOp.MAX, group=group)
-                bigs = bigs.tolist()
-                outs = []
-                for t, sc, rc, big in zip(tensors, counts, rcs, bigs):
-                    recv = _all_to_all_bytes(dist, group, t, sc, rc, big)
-                    outs.append(recv)
-                    if _DEBUG and world == 1:
-                        torch.cuda.synchronize()
-                        import sys
-                        print("[a2a] %d bytes same=%s" % (t.numel(), bool(torch.equal(recv, t))), file=sys.stderr, flush=True)
-                res = (outs, rcs)
+                counts = [[int(c) for c in cs] for cs in req[2]]
+                res = drv.a2a(req[1], counts, req[3] if len(req) > 3 else None)
             elif kind == "gather":
-                t = req[1]
-                mine = torch.tensor([t.numel()], dtype=torch.int64, device=t.device)
-                allsz = torch.empty(world, dtype=torch.int64, device=t.device)
-                dist.all_gather_into_tensor(allsz, mine, group=group)
-                sizes = [int(x) for x in allsz.tolist()]
-                mx = max(sizes)
-                if mx:
-                    parts = [[] for _ in range(world)]
-                    CH = _chunk(world)
-                    for lo in range(0, mx, CH):                  # rounds of bounded size (see A2A_CHUNK)
-                        w = min(CH, mx - lo)
-                        pad = torch.zeros(w, dtype=torch.uint8, device=t.device)
-                        mine_n = max(0, min(t.numel(), lo + w) - lo)
-                        pad[:mine_n] = t[lo: lo + mine_n]
-                        out = torch.empty(w * world, dtype=torch.uint8, device=t.device)
-                        dist.all_gather_into_tensor(out, pad, group=group)
-                        for r, sz in enumerate(sizes):
-                            n_r = max(0, min(sz, lo + w) - lo)
-                            if n_r:
-                                parts[r].append(out[r * w: r * w + n_r])
-                    flat = [p for r in range(world) for p in parts[r]]
-                    cat = torch.cat(flat) if len(flat) != 1 else flat[0]
-                else:
-                    cat = t
-                res = (cat, sizes)
+                many = isinstance(req[1], (list, tuple))
+                out = drv.gather(list(req[1]) if many else [req[1]])
+                res = out if many else out[0]
             else:
                 raise ValueError(kind)
-            _sync(req[1][0] if kind == "a2a" else (req[1] if kind == "gather" else None))
+            if kind != "ints":
+                first = req[1][0] if isinstance(req[1], (list, tuple)) else req[1]
+                _sync(first)
             trace_mark("exchange")
             req = gen.send(res)
     except StopIteration:

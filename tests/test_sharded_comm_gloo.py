@@ -40,6 +40,11 @@ def toy(rank, G, log):
     log.append(("gather", allg.clone().numpy().tobytes(), list(sizes)))
     allg, sizes = yield ("gather", torch.zeros(0, dtype=torch.uint8))
     log.append(("gather0", allg.clone().numpy().tobytes(), list(sizes)))
+    # several tensors in one gather (conflict edges + cache updates travel together)
+    ga = torch.from_numpy(rng.integers(0, 256, 5 + 9 * rank, dtype=np.uint8))
+    gb = torch.from_numpy(rng.integers(0, 256, 24 * (1 - rank % 2), dtype=np.uint8))
+    (a_all, a_sz), (b_all, b_sz) = yield ("gather", [ga, gb])
+    log.append(("gather2", a_all.clone().numpy().tobytes() + b_all.clone().numpy().tobytes(), list(a_sz) + list(b_sz)))
 
 
 def _worker(rank, world, port, outdir, chunk):
