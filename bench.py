@@ -204,7 +204,9 @@ def main():
         dom = max(prof.items(), key=lambda kv: kv[1][0]) if prof else ("none", (0.0, 0))
         dom_name, (dom_ms, dom_launches) = dom
         roof = None
-        words = 2 * pairs_total * 5 * a.steps
+        words = 2 * pairs_total * 5 * a.steps          # 32-base words this rank walks
+        if sharded_mode and sr.mode == "split":
+            words //= world
         per_stage = {}
         for name, (ms, launches) in prof.items():
             ab = algorithmic_bytes(name, kmers, pairs_ins, distinct, words, n_sorted)
@@ -238,7 +240,7 @@ def main():
         }
         if sharded_mode and sharded.TRACE is not None:
             out["shard_phase_ms_per_step"] = {kk: round(v / a.steps, 1) for kk, v in sorted(sharded.TRACE.items(), key=lambda kv: -kv[1])}
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:       # the CPU baseline is timed on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(a, batch, dbg_bits, cbf_bytes, pk_bits, dist_pk)
     if sharded_mode:
         dist.barrier()

@@ -1031,17 +1031,21 @@ int rb_shard_hash(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, int6
             g->chunk_mask.reserve(((size_t)nw + 1) * 4);
             Npf cache = fv.npf;
             if (!use_cache) cache.tab = nullptr;
+            g->prof_begin();
             launch_filter_windows(b, w0, nw, g->k, mode_hash, (uint32_t)first, pos_bits, g->p.rng_seed, ordinal0, cache,
                                   g->chunk_cnt.as<uint32_t>(), g->chunk_mask.as<uint32_t>(), g->npf_tot.as<uint32_t>(), s);
             exclusive_scan_u32(g->temp.p, g->temp.cap, g->chunk_cnt.as<uint32_t>(), g->chunk_off.as<uint32_t>(), (size_t)nw + 1, s);
             RB_HIP(hipMemcpyAsync(&N, g->chunk_off.as<uint32_t>() + nw, 4, hipMemcpyDeviceToHost, s));
             RB_HIP(hipMemcpyAsync(spread, g->npf_tot.p, sizeof spread, hipMemcpyDeviceToHost, s));
+            g->prof_end("filter_windows");
             RB_HIP(hipStreamSynchronize(s));
             for (int q = 0; q < 32; ++q) windows += spread[16 * q];
             if (N) {
                 g->keys0.reserve((size_t)N * 8); g->vals0.reserve((size_t)N * 4);
+                g->prof_begin();
                 launch_hash_windows_masked(b, w0, nw, g->k, mode_hash, g->chunk_off.as<uint32_t>(), g->chunk_mask.as<uint32_t>(),
                                            (uint32_t)first, pos_bits, g->keys0.as<uint64_t>(), g->vals0.as<uint32_t>(), s);
+                g->prof_end("hash_windows");
                 rk = g->keys0.as<uint64_t>(); ro = g->vals0.as<uint32_t>();
             }
         } else {            // generic hash of every window; the prefilter verdict rides along into the bucketing
