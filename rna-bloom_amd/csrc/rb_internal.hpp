@@ -94,10 +94,6 @@ void exclusive_scan_u32(void *temp, size_t temp_bytes, const uint32_t *in, uint3
 size_t select_temp_bytes(size_t n);
 void select_flagged(void *temp, size_t temp_bytes, const uint32_t *status, uint32_t mask, size_t n, uint32_t *out,
                     uint32_t *count_dev, hipStream_t s);
-// ordered compaction of (h0, occ) records by byte flags
-size_t select_records_temp_bytes(size_t n);
-void select_records(void *temp, size_t temp_bytes, const uint64_t *keys_in, const uint32_t *occ_in, const uint8_t *keep, size_t n,
-                    uint64_t *keys_out, uint32_t *occ_out, uint32_t *count_dev, hipStream_t s);
 size_t rle_temp_bytes(size_t n);
 void run_length_encode_u64(void *temp, size_t temp_bytes, const uint64_t *keys, size_t n,
                            uint64_t *uniq, uint32_t *counts, uint32_t *n_runs_dev, hipStream_t s);

@@ -74,23 +74,6 @@ void select_flagged(void *temp, size_t temp_bytes, const uint32_t *status, uint3
     auto flags = rocprim::make_transform_iterator(status, MaskFlag{mask});
     RB_HIP(rocprim::select(temp, temp_bytes, rocprim::counting_iterator<uint32_t>(0), flags, out, count_dev, n, s));
 }
-// ordered compaction of (h0, occ) records by a byte flag (the no-op prefilter verdicts, rb_shard.hip)
-struct ByteFlag {
-    __host__ __device__ bool operator()(uint8_t f) const { return f != 0; }
-};
-size_t select_records_temp_bytes(size_t n) {
-    size_t bytes = 0;
-    auto in = rocprim::make_zip_iterator(rocprim::make_tuple((const uint64_t *)nullptr, (const uint32_t *)nullptr));
-    auto out = rocprim::make_zip_iterator(rocprim::make_tuple((uint64_t *)nullptr, (uint32_t *)nullptr));
-    RB_HIP(rocprim::select(nullptr, bytes, in, (const uint8_t *)nullptr, out, (uint32_t *)nullptr, n));
-    return bytes;
-}
-void select_records(void *temp, size_t temp_bytes, const uint64_t *keys_in, const uint32_t *occ_in, const uint8_t *keep, size_t n,
-                    uint64_t *keys_out, uint32_t *occ_out, uint32_t *count_dev, hipStream_t s) {
-    auto in = rocprim::make_zip_iterator(rocprim::make_tuple(keys_in, occ_in));
-    auto out = rocprim::make_zip_iterator(rocprim::make_tuple(keys_out, occ_out));
-    RB_HIP(rocprim::select(temp, temp_bytes, in, keep, out, count_dev, n, s));
-}
 size_t rle_temp_bytes(size_t n) {
     size_t bytes = 0;
     RB_HIP(rocprim::run_length_encode(nullptr, bytes, (const uint64_t *)nullptr, n,
