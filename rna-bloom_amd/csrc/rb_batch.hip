@@ -389,16 +389,21 @@ k_hash_windows_fast(const uint64_t *__restrict__ codes, const uint32_t *__restri
 // Prefilter pass: same walker as k_hash_windows_fast, but instead of emitting it decides for every
 // usable window whether the occurrence can change anything: it is dropped iff the cache knows the
 // k-mer (full 64-bit match) with counter exponent >= s and the occurrence's draw strength is < s.
-template <int MODE>
+// MPF = the minimizer-bucketed cache (rb_device.hpp): the walker also rolls the canonical m-mer of every
+// position (order values in an LDS ring), the window's minimizer picks the bucket, and the bucket
+// image (16 words, LDS) is reloaded only when the minimizer changes — every ~5 windows.
+template <int MODE, bool MPF>
 __global__ void __launch_bounds__(64)
 k_filter_windows_fast(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
                       const uint32_t *__restrict__ word_read, const uint32_t *__restrict__ woff,
                       const uint32_t *__restrict__ len, int64_t w0, int64_t nw, int k, uint32_t first_read,
-                      uint32_t pos_bits, uint64_t seed, uint64_t ordinal0, Npf cache, uint32_t *__restrict__ cnt,
+                      uint32_t pos_bits, uint64_t seed, uint64_t ordinal0, Npf cache, Mpf mcache, uint32_t *__restrict__ cnt,
                       uint32_t *__restrict__ keepmask, uint32_t *__restrict__ total_spread, uint32_t dbg_flags,
                       uint32_t own_mask, uint32_t own_rank) {
     __shared__ uint64_t s_tf[25], s_tr[25];
-    const uint32_t uk = (uint32_t)k;
+    __shared__ uint32_t s_ring[MPF ? 16 * 64 : 1];              // [slot][lane]: order of the m-mer ending at base (slot mod 16)
+    __shared__ unsigned long long s_bkt[MPF ? 16 * 64 : 1];     // [slot][lane]: image of the current bucket
+    const uint32_t uk = (uint32_t)k, lane = threadIdx.x;
     if (threadIdx.x < 25) {
         const uint32_t o = threadIdx.x / 5u, in = threadIdx.x % 5u;
         const uint64_t so = o ? seed_of(o - 1u) : 0ull, si = in ? seed_of(in - 1u) : 0ull;
@@ -422,6 +427,11 @@ k_filter_windows_fast(const uint64_t *__restrict__ codes, const uint32_t *__rest
             uint32_t run = 0;
             const uint32_t rstate = rng_read_state(seed, ordinal0 + (uint64_t)(r - first_read));
             const uint32_t sh_c = 2u * (uk - 1u), sh_v = uk - 1u;
+            // minimizer state (MPF)
+            const uint32_t um = MPF ? mcache.m : 1u, uw = uk - um + 1u;           // m-mers per k-mer
+            const uint32_t mmask = (um >= 16u) ? 0xFFFFFFFFu : ((1u << (2u * um)) - 1u);
+            uint32_t mf = 0, mr = 0;
+            uint64_t cur_bkt = ~0ull;
             for (uint32_t j = 0; j < nb; ++j) {
                 const uint32_t code = (uint32_t)clo & 3u, ok = (uint32_t)vs & 1u;
                 clo = (clo >> 2) | (chi << 62); chi >>= 2; vs >>= 1;
@@ -432,12 +442,30 @@ k_filter_windows_fast(const uint64_t *__restrict__ codes, const uint32_t *__rest
                 if (MODE != 0) rv = rotr(rv, 1) ^ s_tr[t];
                 hc = (hc << 2) | code; hv = (hv << 1) | ok;
                 run = ok ? run + 1u : 0u;
+                if (MPF) {   // canonical m-mer ending at this base (garbage while run < m: never consulted then)
+                    mf = ((mf << 2) | code) & mmask;
+                    mr = (mr >> 2) | ((3u - code) << (2u * (um - 1u)));
+                    s_ring[(j & 15u) * 64u + lane] = mmer_order(mf < mr ? mf : mr);
+                }
                 if (run >= uk) {
                     const uint32_t p = b0 + j + 1u - uk;
                     const uint64_t h0 = (MODE == 0) ? f : (MODE == 2) ? rv : canonical(f, rv);
                     // sharded engine: every rank walks all reads and keeps the k-mers it owns
                     if (((uint32_t)(h0 >> RB_OWNER_SHIFT) & own_mask) == own_rank) {
-                        const uint32_t s_known = (dbg_flags & 1u) ? 0u : npf_lookup(cache, h0);
+                        uint32_t s_known = 0;
+                        if (MPF) {
+                            uint32_t omin = 0xFFFFFFFFu;                 // the window's m-mers end at bases j-uw+1 .. j
+                            for (uint32_t q = 0; q < uw; ++q) { const uint32_t o = s_ring[((j - q) & 15u) * 64u + lane]; omin = o < omin ? o : omin; }
+                            const uint64_t bkt = mpf_bucket(mcache, omin);
+                            if (bkt != cur_bkt) {     // new minimizer: fetch the two lines of its bucket
+                                const ulonglong2 *bp = reinterpret_cast<const ulonglong2 *>(mcache.tab + (bkt << 4));
+#pragma unroll
+                                for (int q = 0; q < 8; ++q) { const ulonglong2 e = bp[q]; s_bkt[(2 * q) * 64 + lane] = e.x; s_bkt[(2 * q + 1) * 64 + lane] = e.y; }
+                                cur_bkt = bkt;
+                            }
+                            s_known = mpf_match(&s_bkt[lane], 64u, h0);
+                        } else if (!(dbg_flags & 1u))
+                            s_known = npf_lookup(cache, h0);
                         bool keep = true;
                         if (s_known && !(dbg_flags & 2u)) keep = draw_strength(rng_pos(rstate, p)) >= s_known;
                         ++total;
@@ -613,15 +641,19 @@ void launch_hash_windows(const rb_batch *b, int64_t w0, int64_t nw, int k, int m
 
 void launch_filter_windows(const rb_batch *b, int64_t w0, int64_t nw, int k, int mode, uint32_t first_read,
                            uint32_t pos_bits, uint64_t seed, uint64_t ordinal0, Npf cache, uint32_t *cnt, uint32_t *keepmask,
-                           uint32_t *total_spread, hipStream_t s, uint32_t own_mask, uint32_t own_rank) {
+                           uint32_t *total_spread, hipStream_t s, uint32_t own_mask, uint32_t own_rank, Mpf mcache) {
     if (nw <= 0) return;
     uint32_t dbgf = getenv("RB_FILT_DBG") ? (uint32_t)atoi(getenv("RB_FILT_DBG")) : 0u;
     if (!cache.tab) dbgf |= 1u;                       // no cache: ownership test only
     dim3 g(blocks_for(nw, 64)), t(64);
-#define RB_LAUNCH_FILT(M)                                                                                    \
-    hipLaunchKernelGGL(k_filter_windows_fast<M>, g, t, 0, s, b->codes, b->valid, b->word_read, b->woff, b->len, \
-                       w0, nw, k, first_read, pos_bits, seed, ordinal0, cache, cnt, keepmask, total_spread, dbgf, own_mask, own_rank)
-    if (mode == 0) RB_LAUNCH_FILT(0); else if (mode == 2) RB_LAUNCH_FILT(2); else RB_LAUNCH_FILT(1);
+#define RB_LAUNCH_FILT(M, P)                                                                                    \
+    hipLaunchKernelGGL((k_filter_windows_fast<M, P>), g, t, 0, s, b->codes, b->valid, b->word_read, b->woff, b->len, \
+                       w0, nw, k, first_read, pos_bits, seed, ordinal0, cache, mcache, cnt, keepmask, total_spread, dbgf, own_mask, own_rank)
+    if (mcache.tab && mcache.m <= (uint32_t)k && (uint32_t)k - mcache.m + 1u <= 16u) {
+        if (mode == 0) RB_LAUNCH_FILT(0, true); else if (mode == 2) RB_LAUNCH_FILT(2, true); else RB_LAUNCH_FILT(1, true);
+    } else {
+        if (mode == 0) RB_LAUNCH_FILT(0, false); else if (mode == 2) RB_LAUNCH_FILT(2, false); else RB_LAUNCH_FILT(1, false);
+    }
 #undef RB_LAUNCH_FILT
 }
 size_t filter_emit_state_bytes(int64_t nw) { return ((size_t)((nw + 63) / 64) + 2) * 8; }

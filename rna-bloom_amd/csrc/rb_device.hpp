@@ -169,6 +169,86 @@ __device__ __forceinline__ void npf_store(const Npf &c, uint64_t h0, uint32_t s)
     }
     __hip_atomic_store(&b[victim], (tag << 4) | (unsigned long long)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// ---- minimizer-bucketed prefilter cache: same contract as Npf, different address ----
+// The device serves ~54 G random 64-byte lines/s; one line request per window is what
+// bounds the prefilter.  Consecutive k-mers of a read share their minimizer (the smallest canonical
+// m-mer inside the k-mer) for ~(k-m+2)/2 windows, so a table whose bucket is chosen by the MINIMIZER
+// lets a thread keep one bucket for several windows.  The bucket says nothing about h0, so exactness
+// comes from the position inside it: a bucket is 16 slots of 8 bytes (two 64 B lines) seen as 8 bins of
+// an A slot and a B slot.  k-mer h0 may live in the A slot of bin (h0 & 7), entry = (h0 >> 3) << 3 | s',
+// or in the B slot of bin ((h0 >> 3) & 7), entry = (h0 >> 6) << 6 | (h0 & 7) << 3 | s' — the slot gives
+// back three bits of h0, the entry the other 61: a match is exact, and an entry is one naturally atomic
+// 8-byte word (never torn).  0 = empty; s' = min(s, 7) (a lower bound stays a lower bound).  Two
+// independent candidate slots per k-mer (2-choice hashing without relocation) keep the ~5–10 k-mers of
+// one minimizer apart: with both candidates taken by hotter k-mers a k-mer stays uncached (≈ 2 %); the
+// first layout — both candidates in the same bin — lost 7 %, and spilling those into the hash-addressed
+// table made nearly every wavefront iteration wait for a second dependent lookup (filter 134 -> 207 ms).
+// A reader loads the bucket's two lines when its minimizer changes (every ~5 windows).
+// Both strands of a k-mer have the same canonical m-mers, hence the same bucket.
+struct Mpf {
+    unsigned long long *tab;   // nullptr => disabled
+    uint32_t log2b;            // log2 of the number of buckets (16 slots = 128 B each)
+    uint32_t m;                // minimizer length, <= 16 (2 bits per base in a u32)
+};
+// order of a canonical m-mer among the m-mers of a k-mer: a bijective mix of its 2-bit code
+__host__ __device__ __forceinline__ uint32_t mmer_order(uint32_t canon) {
+    uint32_t x = canon * 0x9E3779B1u;
+    x ^= x >> 15; x *= 0x85EBCA77u;
+    x ^= x >> 13;
+    return x;
+}
+__host__ __device__ __forceinline__ uint64_t mpf_bucket(const Mpf &c, uint32_t order_min) {
+    uint32_t x = order_min * 0xC2B2AE3Du;            // minima are small numbers: mix again before masking
+    x ^= x >> 16; x *= 0x27D4EB2Fu;
+    x ^= x >> 15;
+    return (uint64_t)(x & ((c.log2b >= 32u) ? 0xFFFFFFFFu : ((1u << c.log2b) - 1u)));
+}
+// minimizer order of the k-mer at position p of a read whose packed words start at `rw` (store side:
+// the resolve stages know a k-mer by hash + one occurrence id)
+__device__ __forceinline__ uint32_t window_min_order(const uint64_t *__restrict__ rw, uint32_t p, uint32_t k, uint32_t m) {
+    const uint32_t w = p >> 5, o = p & 31u;
+    uint64_t lo = rw[w], hi = (o + k > 32u) ? rw[w + 1] : 0ull;
+    lo = (lo >> (2u * o)) | (o ? (hi << (64u - 2u * o)) : 0ull);
+    hi = o ? (hi >> (2u * o)) : hi;                    // bases p.. as a 128-bit stream (k <= 31 + ...: 2 words suffice)
+    const uint32_t mmask = (m >= 16u) ? 0xFFFFFFFFu : ((1u << (2u * m)) - 1u);
+    uint32_t mf = 0, mr = 0, best = 0xFFFFFFFFu;
+    for (uint32_t j = 0; j < k; ++j) {
+        const uint32_t code = (uint32_t)lo & 3u;
+        lo = (lo >> 2) | (hi << 62); hi >>= 2;
+        mf = ((mf << 2) | code) & mmask;
+        mr = (mr >> 2) | ((3u - code) << (2u * (m - 1u)));
+        if (j + 1u >= m) { const uint32_t ord = mmer_order(mf < mr ? mf : mr); best = ord < best ? ord : best; }
+    }
+    return best;
+}
+__host__ __device__ __forceinline__ uint32_t mpf_slot_a(uint64_t h0) { return ((uint32_t)h0 & 7u) * 2u; }
+__host__ __device__ __forceinline__ uint32_t mpf_slot_b(uint64_t h0) { return (((uint32_t)h0 >> 3) & 7u) * 2u + 1u; }
+__host__ __device__ __forceinline__ unsigned long long mpf_tag_a(uint64_t h0) { return h0 >> 3; }
+__host__ __device__ __forceinline__ unsigned long long mpf_tag_b(uint64_t h0) { return ((h0 >> 6) << 3) | (h0 & 7ull); }
+// s in 1..14.  Raise an existing entry; else take an empty candidate slot; else replace the candidate with the
+// smaller exponent if ours is larger (the coldest k-mer costs the least when it misses).
+__device__ __forceinline__ void mpf_store(const Mpf &c, uint64_t bucket, uint64_t h0, uint32_t s) {
+    unsigned long long *b = c.tab + (bucket << 4);
+    const uint32_t sa = mpf_slot_a(h0), sb = mpf_slot_b(h0), sv = s > 7u ? 7u : s;
+    const unsigned long long na = (mpf_tag_a(h0) << 3) | sv, nb = (mpf_tag_b(h0) << 3) | sv;
+    const unsigned long long ea = __hip_atomic_load(&b[sa], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long eb = __hip_atomic_load(&b[sb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (ea && (ea >> 3) == mpf_tag_a(h0)) { if ((uint32_t)(ea & 7ull) < sv) __hip_atomic_store(&b[sa], na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+    if (eb && (eb >> 3) == mpf_tag_b(h0)) { if ((uint32_t)(eb & 7ull) < sv) __hip_atomic_store(&b[sb], nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+    if (!ea) { __hip_atomic_store(&b[sa], na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+    if (!eb) { __hip_atomic_store(&b[sb], nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+    const bool pick_b = (uint32_t)(eb & 7ull) < (uint32_t)(ea & 7ull);
+    if ((uint32_t)((pick_b ? eb : ea) & 7ull) < sv) __hip_atomic_store(&b[pick_b ? sb : sa], pick_b ? nb : na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// lookup in a bucket image held by the caller (16 words strided by `stride`)
+__device__ __forceinline__ uint32_t mpf_match(const unsigned long long *bkt, uint32_t stride, uint64_t h0) {
+    const unsigned long long ea = bkt[mpf_slot_a(h0) * stride], eb = bkt[mpf_slot_b(h0) * stride];
+    uint32_t s = 0;
+    if (ea && (ea >> 3) == mpf_tag_a(h0)) s = (uint32_t)(ea & 7ull);
+    if (eb && (eb >> 3) == mpf_tag_b(h0)) { const uint32_t v = (uint32_t)(eb & 7ull); s = v > s ? v : s; }
+    return s;
+}
+
 // trailing-zero strength of a draw, capped at 15 (see k_strength)
 __host__ __device__ __forceinline__ uint32_t draw_strength(uint32_t rnd31) {
     const uint32_t r = rnd31 | 0x8000u;

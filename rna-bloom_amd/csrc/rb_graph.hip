@@ -224,14 +224,14 @@ __global__ void k_resolve_apply(FilterView fv, const uint64_t *__restrict__ uniq
     for (int j = 1; j < fv.cbf_h; ++j) mn0 = c[j] < mn0 ? c[j] : mn0;
     run_ops(c, fv.cbf_h, kfirst, krest, tz, starts[d] + m - ops, ops);
     for (int j = 0; j < fv.cbf_h; ++j) fv.cbf[idx[j]] = (uint8_t)c[j];   // also clears the claim mark
-    if (fv.npf.tab && mode != M_COUNT_ONLY) {   // the k-mer is in dbgbf now; remember its counter exponent
+    if (cache_on(fv) && mode != M_COUNT_ONLY) {   // the k-mer is in dbgbf now; remember its counter exponent
         uint32_t mn = c[0];
         for (int j = 1; j < fv.cbf_h; ++j) mn = c[j] < mn ? c[j] : mn;
         // ... unless the cache evidently knows it already: same exponent as before the sub-batch and every
         // op of the run succeeded (an up-to-date entry lets through only draws that succeed; the minimum
         // rises by one per success) — saves the bucket read + write for most runs in steady state
         const bool cached = mn0 >= 16u && (mn >> 3) == (mn0 >> 3) && mn - mn0 == ops;
-        if (mn >= 16u && !cached) npf_store(fv.npf, h0, (mn >> 3) - 1u);
+        if (mn >= 16u && !cached) cache_store(fv, h0, vals[starts[d]], (mn >> 3) - 1u);
     }
 }
 
@@ -341,7 +341,8 @@ constexpr uint32_t MAX_COMPONENT_KMERS = 8;
 // small component themselves or queue it for the wave-cooperative kernel
 __global__ void k_conf_replay_small(FilterView fv, const uint64_t *__restrict__ uniq, const uint64_t *__restrict__ kmer_keys,
                                     uint32_t n_conf, const uint64_t *__restrict__ op_key, const uint32_t *__restrict__ op_val,
-                                    uint32_t n_ops, uint32_t *__restrict__ big_list, uint32_t *__restrict__ n_big, int store_cache) {
+                                    uint32_t n_ops, uint32_t *__restrict__ big_list, uint32_t *__restrict__ n_big, int store_cache,
+                                    const uint32_t *__restrict__ starts, const uint32_t *__restrict__ vals) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_conf) return;
     const uint32_t lab = (uint32_t)(kmer_keys[i] >> 32);
@@ -350,15 +351,16 @@ __global__ void k_conf_replay_small(FilterView fv, const uint64_t *__restrict__ 
     const uint32_t oe = lower_bound_u64(op_key, n_ops, ((uint64_t)lab + 1ull) << 32);
     if (oe - os > SMALL_COMPONENT_OPS) { big_list[atomicAdd(n_big, 1u)] = i; return; }
     replay_serial(fv, uniq, op_key, op_val, os, oe);
-    if (store_cache && fv.npf.tab)   // the component's k-mers are in dbgbf; remember their counter exponents
+    if (store_cache && cache_on(fv))   // the component's k-mers are in dbgbf; remember their counter exponents
         for (uint32_t q = i; q < n_conf && (uint32_t)(kmer_keys[q] >> 32) == lab; ++q) {
-            const uint64_t h0 = uniq[(uint32_t)kmer_keys[q]];
+            const uint32_t dq = (uint32_t)kmer_keys[q];
+            const uint64_t h0 = uniq[dq];
             uint32_t mn = 255u;
             for (int j = 0; j < fv.cbf_h; ++j) {
                 const uint32_t c = *(volatile uint8_t *)&fv.cbf[index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod)];
                 mn = c < mn ? c : mn;
             }
-            if (mn >= 16u && mn < 128u) npf_store(fv.npf, h0, (mn >> 3) - 1u);
+            if (mn >= 16u && mn < 128u) cache_store(fv, h0, vals[starts[dq]], (mn >> 3) - 1u);
         }
 }
 // one wavefront per large component: the component's counters live in LDS; 64 ops are examined at
@@ -367,7 +369,9 @@ __global__ void __launch_bounds__(64) k_conf_replay_big(FilterView fv, const uin
                                     const uint64_t *__restrict__ kmer_keys, uint32_t n_conf,
                                     const uint64_t *__restrict__ op_key, const uint32_t *__restrict__ op_val, uint32_t n_ops,
                                     const uint32_t *__restrict__ big_list, const uint32_t *__restrict__ n_big,
-                                    uint32_t *__restrict__ dbg, int store_cache) {
+                                    uint32_t *__restrict__ dbg, int store_cache,
+                                    const uint32_t *__restrict__ starts, const uint32_t *__restrict__ vals) {
+    __shared__ uint32_t s_drun[MAX_COMPONENT_KMERS];                // one run carrying each distinct hash
     __shared__ uint64_t s_idx[MAX_COMPONENT_KMERS * RB_MAX_HASH];   // unique counter indices
     __shared__ uint32_t s_val[MAX_COMPONENT_KMERS * RB_MAX_HASH];   // their current bytes
     __shared__ uint32_t s_val0[MAX_COMPONENT_KMERS * RB_MAX_HASH];
@@ -389,18 +393,20 @@ __global__ void __launch_bounds__(64) k_conf_replay_big(FilterView fv, const uin
         bool overflow = false;
         for (uint32_t rb0 = i0; rb0 < i1 && !overflow; rb0 += 64u) {
             const bool have = rb0 + lane < i1;
-            const uint64_t h = have ? uniq[(uint32_t)kmer_keys[rb0 + lane]] : 0ull;
+            const uint32_t myd = have ? (uint32_t)kmer_keys[rb0 + lane] : 0u;
+            const uint64_t h = have ? uniq[myd] : 0ull;
             unsigned long long pending = __ballot(have);
             while (pending) {
                 const int leader = __ffsll((long long)pending) - 1;
                 const uint64_t hl = __shfl(h, leader, 64);
+                const uint32_t dl = __shfl(myd, leader, 64);
                 pending &= ~__ballot(have && h == hl);
                 uint32_t q = 0, nkc = s_nk;
                 while (q < nkc && s_h0[q] != hl) ++q;
                 if (q == nkc) {
                     if (nkc == MAX_COMPONENT_KMERS) { overflow = true; break; }
                     __syncthreads();
-                    if (lane == 0) { s_h0[nkc] = hl; s_nk = nkc + 1u; }
+                    if (lane == 0) { s_h0[nkc] = hl; s_drun[nkc] = dl; s_nk = nkc + 1u; }
                     __syncthreads();
                 }
             }
@@ -462,10 +468,10 @@ __global__ void __launch_bounds__(64) k_conf_replay_big(FilterView fv, const uin
             __syncthreads();
         }
         if (lane < s_nu && s_val[lane] != s_val0[lane]) fv.cbf[s_idx[lane]] = (uint8_t)s_val[lane];
-        if (store_cache && fv.npf.tab && lane < nk) {   // the component's k-mers are in dbgbf; remember their exponents
+        if (store_cache && cache_on(fv) && lane < nk) {   // the component's k-mers are in dbgbf; remember their exponents
             uint32_t mn = s_val[s_slot[lane][0]];
             for (int j = 1; j < H; ++j) { const uint32_t c = s_val[s_slot[lane][j]]; mn = c < mn ? c : mn; }
-            if (mn >= 16u && mn < 128u) npf_store(fv.npf, s_h0[lane], (mn >> 3) - 1u);
+            if (mn >= 16u && mn < 128u) cache_store(fv, s_h0[lane], vals[starts[s_drun[lane]]], (mn >> 3) - 1u);
         }
         __syncthreads();
     }
@@ -901,10 +907,10 @@ void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, ui
         g->prof_begin();
         RB_HIP(hipMemsetAsync(ctr + 4, 0, 4, s));
         hipLaunchKernelGGL(k_conf_replay_small, dim3(blocks_for(nck)), dim3(TPB), 0, s, fv, uniq, g->kk1.as<uint64_t>(), nck,
-                           g->opk1.as<uint64_t>(), g->opv1.as<uint32_t>(), nco, g->biglist.as<uint32_t>(), ctr + 4, (int)(mode != M_COUNT_ONLY));
+                           g->opk1.as<uint64_t>(), g->opv1.as<uint32_t>(), nco, g->biglist.as<uint32_t>(), ctr + 4, (int)(mode != M_COUNT_ONLY), starts, vals);
         hipLaunchKernelGGL(k_conf_replay_big, dim3(std::min<uint32_t>(nck, 262144u)), dim3(64), 0, s, fv, uniq, g->kk1.as<uint64_t>(), nck,
                            g->opk1.as<uint64_t>(), g->opv1.as<uint32_t>(), nco, g->biglist.as<uint32_t>(), ctr + 4,
-                           getenv("RB_DEBUG") ? ctr + 600 : (uint32_t *)nullptr, (int)(mode != M_COUNT_ONLY));
+                           getenv("RB_DEBUG") ? ctr + 600 : (uint32_t *)nullptr, (int)(mode != M_COUNT_ONLY), starts, vals);
         g->prof_end("conflict_replay");
         if (getenv("RB_DEBUG")) {
             uint32_t nb = 0;
@@ -941,6 +947,11 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
     struct Sub { int64_t r0, r1, w0, nw; uint32_t N; int64_t total; };
     // occurrences that provably cannot change a counter are dropped before sorting (k <= 31 fast path)
     const bool use_npf = g->npf_log2 && g->k <= 31 && (mode == M_ADD || mode == M_COUNT_IF_PRESENT);
+    // the minimizer-bucketed cache replaces the hash-bucketed one on this path (lookups here, stores by the
+    // stages that retire runs, which find a k-mer's bucket from one of its occurrences in this batch)
+    g->use_mpf = use_npf && g->mpf_log2b && !getenv("RB_NO_MPF") && !getenv("RB_ONE_PASS_FILTER") && (uint32_t)g->k >= g->mpf_m && (uint32_t)g->k - g->mpf_m + 1u <= 16u;
+    g->seq_codes = b->codes; g->seq_woff = b->woff;
+    struct MpfScope { rb_graph *g; ~MpfScope() { g->use_mpf = false; g->seq_codes = nullptr; g->seq_woff = nullptr; } } mpf_scope{g};
     std::vector<Sub> subs;
     {
         int64_t r0 = first;
@@ -994,7 +1005,7 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
                 RB_HIP(hipMemsetAsync(g->npf_tot.p, 0, 2048, sp));
                 FilterView fvp = g->view(ord0, pos_bits);
                 launch_filter_windows(b, sb.w0, sb.nw, g->k, mode_hash, (uint32_t)sb.r0, pos_bits, g->p.rng_seed, ord0, fvp.npf,
-                                      g->chunk_cnt.as<uint32_t>(), g->chunk_mask.as<uint32_t>(), g->npf_tot.as<uint32_t>(), sp);
+                                      g->chunk_cnt.as<uint32_t>(), g->chunk_mask.as<uint32_t>(), g->npf_tot.as<uint32_t>(), sp, 0u, 0u, fvp.mpf);
                 exclusive_scan_u32(g->temp2.p, g->temp2.cap, g->chunk_cnt.as<uint32_t>(), g->chunk_off.as<uint32_t>(), (size_t)sb.nw + 1, sp);
                 uint32_t spread[16 * 32];
                 RB_HIP(hipMemcpyAsync(&sb.N, g->chunk_off.as<uint32_t>() + sb.nw, 4, hipMemcpyDeviceToHost, sp));
@@ -1073,6 +1084,7 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
         const bool early = getenv("RB_PREPARE_EARLY") != nullptr;   // A/B: producer a whole sub-batch ahead (staler cache)
         if (!serial && early && i + 1 < subs.size()) prepare(i + 1);
         g->cur = slot;
+        g->seq_first = (uint32_t)subs[i].r0;             // occurrence ids of this sub-batch are relative to its first read
         // sub-batch i+1 is hashed / prefiltered as soon as sub-batch i's own-counter runs have retired (their
         // cache updates are what the prefilter needs); its sort + grouping then overlap the heavy and
         // conflicting runs of sub-batch i
@@ -1163,6 +1175,18 @@ int rb_graph_create(const rb_graph_params *p, rb_graph **out) {
                 g->npf_log2 = l2;
             }
         }
+        {   // minimizer-bucketed variant for the k <= 31 insert path: 16 slots (128 B) per bucket + 1 overflow bit
+            const char *e = getenv("RB_MPF");
+            uint32_t lb = log2_ceil((uint64_t)std::max<int64_t>(p->cbf_bytes / 256, 1));
+            lb = std::max(12u, std::min(25u, lb));
+            if (e) lb = (uint32_t)atoi(e);
+            if (lb >= 8 && lb <= 28 && p->k <= 31 && p->k >= 8) {
+                g->mpf.reserve((size_t)128 << lb);
+                RB_HIP(hipMemset(g->mpf.p, 0, (size_t)128 << lb));
+                g->mpf_log2b = lb;
+                g->mpf_m = (uint32_t)std::min(getenv("RB_MPF_M") ? std::max(4, std::min(16, atoi(getenv("RB_MPF_M")))) : 16, p->k);
+            }
+        }
         RB_HIP(hipDeviceSynchronize());
         *out = g;
     });
@@ -1189,7 +1213,7 @@ int rb_graph_destroy(rb_graph *g) {
     if (g->stream2) (void)hipStreamDestroy(g->stream2);
     for (auto e : g->prof_pool) (void)hipEventDestroy(e);
     for (auto &sl : g->slots) { sl.keys1.release(); sl.vals1.release(); sl.tz.release(); sl.uniq.release(); sl.counts.release(); sl.starts.release(); }
-    g->temp2.release(); g->devctr2.release(); g->npf.release(); g->chunk_mask.release(); g->npf_tot.release();
+    g->temp2.release(); g->devctr2.release(); g->npf.release(); g->mpf.release(); g->chunk_mask.release(); g->npf_tot.release();
     delete g;
     return RB_OK;
 }
@@ -1203,6 +1227,7 @@ int rb_graph_clear(rb_graph *g, unsigned which_mask) {
         if ((which_mask & 4u) && g->rpk.bits) RB_HIP(hipMemsetAsync(g->rpk.bits, 0, g->rpk.alloc, g->stream));
         if ((which_mask & 8u) && g->fpk.bits) RB_HIP(hipMemsetAsync(g->fpk.bits, 0, g->fpk.alloc, g->stream));
         if ((which_mask & 3u) && g->npf_log2) RB_HIP(hipMemsetAsync(g->npf.p, 0, sizeof(uint64_t) << g->npf_log2, g->stream));   // cache entries speak about dbgbf + cbf
+        if ((which_mask & 3u) && g->mpf_log2b) RB_HIP(hipMemsetAsync(g->mpf.p, 0, (size_t)128 << g->mpf_log2b, g->stream));
         if ((which_mask & 3u) == 3u) g->ordinal = 0;
         RB_HIP(hipStreamSynchronize(g->stream));
     });
@@ -1479,6 +1504,7 @@ int rb_filter_import(rb_graph *g, int which, const void *srcp, size_t nbytes) {
         }
         RB_HIP(hipStreamSynchronize(g->stream));
         if (g->npf_log2 && (which == RB_CBF || which == RB_DBGBF)) RB_HIP(hipMemset(g->npf.p, 0, sizeof(uint64_t) << g->npf_log2));
+        if (g->mpf_log2b && (which == RB_CBF || which == RB_DBGBF)) RB_HIP(hipMemset(g->mpf.p, 0, (size_t)128 << g->mpf_log2b));
         RB_HIP(hipMemset(dst, 0, alloc));
         RB_HIP(hipMemcpy(dst, srcp, have, hipMemcpyHostToDevice));
         RB_HIP(hipDeviceSynchronize());

@@ -18,7 +18,8 @@ void launch_hash_windows(const rb_batch *b, int64_t w0, int64_t nw, int k, int m
 // (sharded engine; mask 0 = every window).  cache.tab == nullptr: no prefilter, ownership only.
 void launch_filter_windows(const rb_batch *b, int64_t w0, int64_t nw, int k, int mode, uint32_t first_read,
                            uint32_t pos_bits, uint64_t seed, uint64_t ordinal0, Npf cache, uint32_t *cnt, uint32_t *keepmask,
-                           uint32_t *total_spread, hipStream_t s, uint32_t own_mask = 0, uint32_t own_rank = 0);
+                           uint32_t *total_spread, hipStream_t s, uint32_t own_mask = 0, uint32_t own_rank = 0,
+                           Mpf mcache = Mpf{nullptr, 0, 0});   // mcache.tab != nullptr: minimizer-bucketed cache instead of `cache`
 // one pass: ownership test + prefilter + dense ordered emit of the kept (h0, occurrence) records into
 // keys/vals (capacity `cap` records; *kept_out = number kept even if it exceeds cap — then retry with
 // room).  `state`: scratch of filter_emit_state_bytes(nw) bytes.

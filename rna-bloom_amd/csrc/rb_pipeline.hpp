@@ -34,7 +34,25 @@ struct FilterView {
     uint64_t ordinal0;    // op ordinal of occurrence value 0
     uint32_t pos_bits;    // occurrence value = (read_rel << pos_bits) | pos
     Npf npf;              // no-op prefilter cache (tab == nullptr: off)
+    // minimizer-bucketed variant (k <= 31 insert path): lookups in the window-hash kernel, stores here need
+    // the k-mer's bases to find its bucket — the read batch view of the sub-batch being retired
+    Mpf mpf;
+    const uint64_t *seq_codes;   // packed reads (nullptr: no sequence context, e.g. rb_graph_apply)
+    const uint32_t *seq_woff;
+    uint32_t seq_first;          // read index of occurrence value 0's read
+    int k;
 };
+// remember a k-mer's counter exponent in whichever cache the insert path uses; occ = any occurrence of it
+__device__ __forceinline__ void cache_store(const FilterView &fv, uint64_t h0, uint32_t occ, uint32_t s) {
+    if (fv.mpf.tab) {
+        if (!fv.seq_codes) return;
+        const uint32_t r = fv.seq_first + (occ >> fv.pos_bits), p = occ & ((1u << fv.pos_bits) - 1u);
+        const uint32_t ord = window_min_order(fv.seq_codes + fv.seq_woff[r], p, (uint32_t)fv.k, fv.mpf.m);
+        mpf_store(fv.mpf, mpf_bucket(fv.mpf, ord), h0, s);
+    } else if (fv.npf.tab)
+        npf_store(fv.npf, h0, s);
+}
+__device__ __forceinline__ bool cache_on(const FilterView &fv) { return fv.mpf.tab ? fv.seq_codes != nullptr : fv.npf.tab != nullptr; }
 
 // open-addressing table slot: key (empty = ~0) + 64-bit payload (identity of atomicMin = ~0)
 struct Slot { unsigned long long key; unsigned long long val; };
@@ -248,10 +266,10 @@ static __global__ void __launch_bounds__(64) k_cbf_heavy(FilterView fv, const ui
                 cfinal[d] = out;
             } else
                 for (int j = 0; j < fv.cbf_h; ++j) fv.cbf[idx[j]] = (uint8_t)c[j];   // clears the claim mark too
-            if (fv.npf.tab && (st & ST_ALLPRE)) {   // remember how hard this k-mer has become to increment
+            if (cache_on(fv) && (st & ST_ALLPRE)) {   // remember how hard this k-mer has become to increment
                 uint32_t mn = c[0];
                 for (int j = 1; j < fv.cbf_h; ++j) mn = c[j] < mn ? c[j] : mn;
-                if (mn >= 16u) { npf_store(fv.npf, h0, (mn >> 3) - 1u); if (cache_upd) cache_upd[d] = (uint8_t)((mn >> 3) - 1u); }
+                if (mn >= 16u) { cache_store(fv, h0, vals[starts[d]], (mn >> 3) - 1u); if (cache_upd) cache_upd[d] = (uint8_t)((mn >> 3) - 1u); }
             }
         }
     }
@@ -299,6 +317,12 @@ struct rb_graph {
     // no-op prefilter
     DevBuf npf, chunk_mask, npf_tot;
     uint32_t npf_log2 = 0;
+    DevBuf mpf;                         // minimizer-bucketed cache (single-GPU k <= 31 insert path)
+    uint32_t mpf_log2b = 0, mpf_m = 0;
+    const uint64_t *seq_codes = nullptr;   // read batch view of the sub-batch being retired (add_range sets it)
+    const uint32_t *seq_woff = nullptr;
+    uint32_t seq_first = 0;
+    bool use_mpf = false;
     // scratch (grow-only)
     DevBuf chunk_cnt, chunk_off, keys0, vals0, status, nops, temp,
         ftable, ctable, heavy, confk, conf_sizes, conf_off, opk0, opk1, opv0, opv1, label, kk0, kk1, biglist, cvals, foreign, devctr, qbuf0, qbuf1, qbuf2, qbuf3;
@@ -324,6 +348,9 @@ struct rb_graph {
         fv.kmul = kmul_of(k); fv.seed = p.rng_seed; fv.ordinal0 = ordinal0; fv.pos_bits = pos_bits;
         fv.npf.tab = npf_log2 ? reinterpret_cast<unsigned long long *>(npf.p) : nullptr;
         fv.npf.log2n = npf_log2;
+        fv.mpf.tab = (use_mpf && mpf_log2b) ? reinterpret_cast<unsigned long long *>(mpf.p) : nullptr;
+        fv.mpf.log2b = mpf_log2b; fv.mpf.m = mpf_m;
+        fv.seq_codes = seq_codes; fv.seq_woff = seq_woff; fv.seq_first = seq_first; fv.k = k;
         return fv;
     }
     void prof_begin(hipStream_t st = nullptr) {
