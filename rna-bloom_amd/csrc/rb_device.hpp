@@ -237,6 +237,24 @@ __device__ __forceinline__ void mpf_store(const Mpf &c, uint64_t bucket, uint64_
     if (eb && (eb >> 3) == mpf_tag_b(h0)) { if ((uint32_t)(eb & 7ull) < sv) __hip_atomic_store(&b[sb], nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
     if (!ea) { __hip_atomic_store(&b[sa], na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
     if (!eb) { __hip_atomic_store(&b[sb], nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+    {   // both taken: one cuckoo step — move an occupant to ITS other candidate slot if that one is free
+        // (an entry plus its slot give the occupant's whole hash; every store writes a word that is valid for
+        // the slot it goes to, so racing stores can lose an entry but never forge one)
+        const uint64_t ha = ((ea >> 3) << 3) | (uint64_t)(sa >> 1);                                  // occupant of my A slot
+        const uint32_t ha_b = mpf_slot_b(ha);
+        if (!__hip_atomic_load(&b[ha_b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            __hip_atomic_store(&b[ha_b], (mpf_tag_b(ha) << 3) | (ea & 7ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&b[sa], na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        const uint64_t hb = (((eb >> 6) << 3 | (uint64_t)(sb >> 1)) << 3) | ((eb >> 3) & 7ull);    // occupant of my B slot
+        const uint32_t hb_a = mpf_slot_a(hb);
+        if (!__hip_atomic_load(&b[hb_a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+            __hip_atomic_store(&b[hb_a], (mpf_tag_a(hb) << 3) | (eb & 7ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&b[sb], nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+    }
     const bool pick_b = (uint32_t)(eb & 7ull) < (uint32_t)(ea & 7ull);
     if ((uint32_t)((pick_b ? eb : ea) & 7ull) < sv) __hip_atomic_store(&b[pick_b ? sb : sa], pick_b ? nb : na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
