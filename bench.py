@@ -29,7 +29,7 @@ HBM_PEAK_GBS = 8000.0           # MI355X spec HBM3E bandwidth (MI355X_MICROARCH.
 SECTOR = 64                     # bytes moved per random probe (SURVEY.md §8(d) sector model; matches FETCH_SIZE)
 
 
-def algorithmic_bytes(stage, n_kmers, n_pairs, n_runs, words, n_sorted=None, group_bits=32, h=2):
+def algorithmic_bytes(stage, n_kmers, n_pairs, n_runs, words, n_sorted=None, group_bits=32, h=2, sharded=False):
     """ALGORITHMIC bytes one step moves in each pipeline stage.
     n_kmers = k-mer occurrences, n_sorted = occurrences that survive the no-op prefilter,
     n_pairs = paired k-mers, n_runs = distinct runs, words = 32-base words."""
@@ -38,7 +38,9 @@ def algorithmic_bytes(stage, n_kmers, n_pairs, n_runs, words, n_sorted=None, gro
     n_kmers = n_sorted if n_sorted is not None else n_kmers
     model = {
         # prefilter: packed reads in (16 B/word), one 64 B cache sector per window, count + mask out (8 B/word)
-        "filter_windows": words * 24 + n_all * SECTOR,
+        # minimizer-bucketed cache (k <= 31): a 128 B bucket is fetched when the window's minimizer changes,
+        # on average every (k - m + 2) / 2 = 5.5 windows (k = 25, m = 16); sharded engine: one 64 B line per window
+        "filter_windows": words * 24 + (n_all * 128 * 2 // 11 if not sharded else n_all * SECTOR),
         # one-pass prefilter + emit: packed reads in (16 B/word), one 64 B cache sector per window, survivors out (12 B)
         "filter_emit": words * 16 + n_all * SECTOR + n_kmers * 12,
         # 8-bit onesweep: one histogram read of the keys + per pass (8 B key + 4 B value) in and out
@@ -209,11 +211,11 @@ def main():
             words //= world
         per_stage = {}
         for name, (ms, launches) in prof.items():
-            ab = algorithmic_bytes(name, kmers, pairs_ins, distinct, words, n_sorted)
+            ab = algorithmic_bytes(name, kmers, pairs_ins, distinct, words, n_sorted, sharded=sharded_mode)
             if ab and ms > 0:
                 per_stage[name] = round(ab / (ms * 1e-3) / 1e9, 1)
         if dom_launches:
-            ab = algorithmic_bytes(dom_name, kmers, pairs_ins, distinct, words, n_sorted)
+            ab = algorithmic_bytes(dom_name, kmers, pairs_ins, distinct, words, n_sorted, sharded=sharded_mode)
             if ab:
                 achieved = ab / (dom_ms * 1e-3) / 1e9      # = bytes per launch / average launch duration
                 default_cfg = (a.pairs, a.genome, a.nk, a.k, a.batch_kmers, sharded_mode) == (50_000_000, 64_000_000, 450_000_000, 25, 0, False)
