@@ -234,7 +234,7 @@ __global__ void k_resolve_shard(FilterView fv, const uint32_t *__restrict__ coun
                                 const uint8_t *__restrict__ c_dup, const uint8_t *__restrict__ creply,
                                 const uint8_t *__restrict__ tz, const uint64_t *__restrict__ uniq, uint32_t *__restrict__ status,
                                 uint32_t *__restrict__ nops, uint64_t *__restrict__ cvals, uint64_t *__restrict__ cfinal,
-                                uint8_t *__restrict__ cache_upd) {
+                                uint8_t *__restrict__ cache_upd, const uint32_t *__restrict__ vals) {
     uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= D) return;
     if (cache_upd) cache_upd[d] = 0;
@@ -275,10 +275,10 @@ __global__ void k_resolve_shard(FilterView fv, const uint32_t *__restrict__ coun
         status[d] = st | RUN_CONFLICT;
         // replayed elsewhere; its pre-batch minimum is still a valid lower bound for the prefilter cache
         // (the k-mer is in dbgbf: ops > 0 means present before or inserted by this sub-batch's serve)
-        if (fv.npf.tab && mode != M_COUNT_ONLY) {
+        if (cache_on(fv) && mode != M_COUNT_ONLY) {
             uint32_t mn = c[0];
             for (int j = 1; j < fv.cbf_h; ++j) mn = c[j] < mn ? c[j] : mn;
-            if (mn >= 16u) { npf_store(fv.npf, uniq[d], (mn >> 3) - 1u); if (cache_upd) cache_upd[d] = (uint8_t)((mn >> 3) - 1u); }
+            if (mn >= 16u) { cache_store(fv, uniq[d], vals[starts[d]], (mn >> 3) - 1u); if (cache_upd) cache_upd[d] = (uint8_t)((mn >> 3) - 1u); }
         }
         return;
     }
@@ -290,25 +290,35 @@ __global__ void k_resolve_shard(FilterView fv, const uint32_t *__restrict__ coun
     uint64_t out = 0;
     for (int j = 0; j < fv.cbf_h; ++j) out |= (uint64_t)c[j] << (8 * j);
     cfinal[d] = out;
-    if (fv.npf.tab && mode != M_COUNT_ONLY) {   // the k-mer is in dbgbf now; remember its counter exponent
+    if (cache_on(fv) && mode != M_COUNT_ONLY) {   // the k-mer is in dbgbf now; remember its counter exponent
         uint32_t mn = c[0];
         for (int j = 1; j < fv.cbf_h; ++j) mn = c[j] < mn ? c[j] : mn;
         // (not when the cache evidently has it: same exponent and every op succeeded — see k_resolve_apply)
         const bool cached = mn0 >= 16u && (mn >> 3) == (mn0 >> 3) && mn - mn0 == ops;
-        if (mn >= 16u && !cached) { npf_store(fv.npf, uniq[d], (mn >> 3) - 1u); if (cache_upd) cache_upd[d] = (uint8_t)((mn >> 3) - 1u); }
+        if (mn >= 16u && !cached) { cache_store(fv, uniq[d], vals[starts[d]], (mn >> 3) - 1u); if (cache_upd) cache_upd[d] = (uint8_t)((mn >> 3) - 1u); }
     }
 }
 // cache updates of this sub-batch, compacted for the broadcast
-struct CacheUpd { uint64_t h0, e; };
+struct CacheUpd { uint64_t h0, e; };      // e = exponent | minimizer bucket << 8 (bucket: minimizer-bucketed replicas only)
 struct RouteUpd {
-    const uint8_t *upd; const uint64_t *uniq; CacheUpd *out;
+    const uint8_t *upd; const uint64_t *uniq; const uint32_t *starts, *vals; FilterView fv; CacheUpd *out;
     __device__ int dest(size_t i) const { return upd[i] ? 0 : -1; }
-    __device__ void emit(size_t i, uint32_t pos) const { CacheUpd u; u.h0 = uniq[i]; u.e = upd[i]; out[pos] = u; }
+    __device__ void emit(size_t i, uint32_t pos) const {
+        CacheUpd u; u.h0 = uniq[i]; u.e = upd[i];
+        if (fv.mpf.tab && fv.seq_codes) {          // the receivers do not know which of its reads the k-mer came from: ship the bucket
+            const uint32_t occ = vals[starts[i]];
+            const uint32_t r = fv.seq_first + (occ >> fv.pos_bits), p = occ & ((1u << fv.pos_bits) - 1u);
+            u.e |= mpf_bucket(fv.mpf, window_min_order(fv.seq_codes + fv.seq_woff[r], p, (uint32_t)fv.k, fv.mpf.m)) << 8;
+        }
+        out[pos] = u;
+    }
     __device__ void drop(size_t) const {}
 };
-__global__ void k_cache_apply(Npf cache, const CacheUpd *__restrict__ u, size_t n) {
+__global__ void k_cache_apply(FilterView fv, const CacheUpd *__restrict__ u, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) npf_store(cache, u[i].h0, (uint32_t)u[i].e);
+    if (i >= n) return;
+    if (fv.mpf.tab) mpf_store(fv.mpf, u[i].e >> 8, u[i].h0, (uint32_t)(u[i].e & 0xFFull));
+    else if (fv.npf.tab) npf_store(fv.npf, u[i].h0, (uint32_t)(u[i].e & 0xFFull));
 }
 // records of this rank's read slice, bucketed by the rank that owns their k-mer (stable)
 struct RouteRec {
@@ -709,7 +719,7 @@ void prep_filter(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, uint6
     if (!g->npf_log2) cache.tab = nullptr;
     launch_filter_windows(b, P.w0, P.nw, g->k, mode_hash, (uint32_t)first, pos_bits, g->p.rng_seed, ordinal0, cache,
                           g->chunk_cnt.as<uint32_t>(), g->chunk_mask.as<uint32_t>(), g->npf_tot.as<uint32_t>(), st,
-                          (uint32_t)S->G - 1u, (uint32_t)g->shard_rank);
+                          (uint32_t)S->G - 1u, (uint32_t)g->shard_rank, fv.mpf);
     exclusive_scan_u32(g->temp2.p, g->temp2.cap, g->chunk_cnt.as<uint32_t>(), g->chunk_off.as<uint32_t>(), nw + 1, st);
     RB_HIP(hipMemcpyAsync(&S->pinned[0], g->chunk_off.as<uint32_t>() + nw, 4, hipMemcpyDeviceToHost, st));
     RB_HIP(hipMemcpyAsync(&S->pinned[16], g->npf_tot.p, 2048, hipMemcpyDeviceToHost, st));
@@ -813,6 +823,19 @@ int rb_graph_create_shard(const rb_graph_params *p, int shard_rank, int shard_co
                 g->npf_log2 = l2;
             }
         }
+        {   // minimizer-bucketed variant for the k <= 31 window-hash kernels (see rb_graph_create)
+            const char *e = getenv("RB_MPF");
+            uint32_t lb = log2_ceil((uint64_t)std::max<int64_t>(p->cbf_bytes / 256, 1));
+            lb = std::max(12u, std::min(25u, lb));
+            if (e) lb = (uint32_t)atoi(e);
+            if (lb >= 8 && lb <= 28 && p->k <= 31 && p->k >= 8 && !getenv("RB_NO_MPF")) {
+                g->mpf.reserve((size_t)128 << lb);
+                RB_HIP(hipMemset(g->mpf.p, 0, (size_t)128 << lb));
+                g->mpf_log2b = lb;
+                g->mpf_m = (uint32_t)std::min(16, p->k);
+                g->use_mpf = shard_count == 1 && (uint32_t)g->k - g->mpf_m + 1u <= 16u;   // split-reads mode turns it on (rb_shard_set_cache_replication)
+            }
+        }
         RB_HIP(hipDeviceSynchronize());
         *out = g;
     });
@@ -886,6 +909,7 @@ int rb_shard_hash_group(rb_graph *g, const rb_batch *b, int64_t first, int64_t n
         hipStream_t s = g->stream;
         for (int r = 0; r < S->G; ++r) dreq_counts[r] = creq_counts[r] = pair_counts[r] = 0;
         S->D = 0; S->n_conf = 0; S->n_kept = 0; S->ordinal0 = ordinal0; S->pos_bits = pos_bits;
+        g->seq_codes = b->codes; g->seq_woff = b->woff; g->seq_first = (uint32_t)first;   // occurrence ids -> bases, for the cache stores
         S->slot_bytes[RB_SLOT_PAIR_IDX] = S->slot_bytes[RB_SLOT_DREQ_IDX] = S->slot_bytes[RB_SLOT_DREQ_PROBE] = S->slot_bytes[RB_SLOT_CREQ_IDX] = 0;
         const int mode_hash = g->stranded ? ((flags & RB_ADD_REVCOMP) ? 2 : 0) : 1;
         const int mode = (flags & RB_ADD_COUNT_IF_PRESENT) ? M_COUNT_IF_PRESENT : M_ADD;
@@ -990,6 +1014,9 @@ int rb_shard_hash_group(rb_graph *g, const rb_batch *b, int64_t first, int64_t n
 int rb_shard_set_cache_replication(rb_graph *g, int on) {
     if (!g || !g->shard) { set_error("rb_shard_set_cache_replication: not a sharded graph"); return RB_ERR_INVALID; }
     g->shard->replicate_cache = on != 0;
+    // the minimizer-bucketed cache pays where every hashed window is looked up (split reads, or one rank); with
+    // replicated hashing most windows are only hashed, and its LDS footprint slows exactly that part down
+    g->use_mpf = g->mpf_log2b && (uint32_t)g->k >= g->mpf_m && (uint32_t)g->k - g->mpf_m + 1u <= 16u && (on || g->shard_count == 1);
     return RB_OK;
 }
 int rb_shard_hash(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, int64_t own_first, int64_t own_n, uint64_t ordinal0,
@@ -1005,6 +1032,7 @@ int rb_shard_hash(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, int6
         RB_HIP(hipSetDevice(g->p.device));
         RB_HIP(hipStreamSynchronize(g->stream2));
         S->prep.stage = 0;
+        g->seq_codes = b->codes; g->seq_woff = b->woff; g->seq_first = (uint32_t)first;   // occurrence ids -> bases, for the cache stores
         hipStream_t s = g->stream;
         for (int r = 0; r < S->G; ++r) rec_counts[r] = pair_counts[r] = 0;
         S->slot_bytes[RB_SLOT_REC_KEYS] = S->slot_bytes[RB_SLOT_REC_OCC] = S->slot_bytes[RB_SLOT_PAIR_IDX] = 0;
@@ -1033,7 +1061,7 @@ int rb_shard_hash(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, int6
             if (!use_cache) cache.tab = nullptr;
             g->prof_begin();
             launch_filter_windows(b, w0, nw, g->k, mode_hash, (uint32_t)first, pos_bits, g->p.rng_seed, ordinal0, cache,
-                                  g->chunk_cnt.as<uint32_t>(), g->chunk_mask.as<uint32_t>(), g->npf_tot.as<uint32_t>(), s);
+                                  g->chunk_cnt.as<uint32_t>(), g->chunk_mask.as<uint32_t>(), g->npf_tot.as<uint32_t>(), s, 0u, 0u, fv.mpf);
             exclusive_scan_u32(g->temp.p, g->temp.cap, g->chunk_cnt.as<uint32_t>(), g->chunk_off.as<uint32_t>(), (size_t)nw + 1, s);
             RB_HIP(hipMemcpyAsync(&N, g->chunk_off.as<uint32_t>() + nw, 4, hipMemcpyDeviceToHost, s));
             RB_HIP(hipMemcpyAsync(spread, g->npf_tot.p, sizeof spread, hipMemcpyDeviceToHost, s));
@@ -1123,10 +1151,10 @@ int rb_shard_group(rb_graph *g, const void *keys_dev, const void *occ_dev, int64
 int rb_shard_cache_apply(rb_graph *g, const void *upd_dev, int64_t n) {
     return guarded([&] {
         RB_REQUIRE(g && g->shard && n >= 0, "rb_shard_cache_apply: bad argument");
-        if (!n || !g->npf_log2) return;
+        if (!n || !(g->npf_log2 || g->mpf_log2b)) return;
         RB_HIP(hipSetDevice(g->p.device));
         FilterView fv = g->view(0, 0);
-        hipLaunchKernelGGL(k_cache_apply, dim3(blocks_for(n)), dim3(TPB), 0, g->stream, fv.npf, (const CacheUpd *)upd_dev, (size_t)n);
+        hipLaunchKernelGGL(k_cache_apply, dim3(blocks_for(n)), dim3(TPB), 0, g->stream, fv, (const CacheUpd *)upd_dev, (size_t)n);
         RB_HIP(hipGetLastError());
         RB_HIP(hipStreamSynchronize(g->stream));
     });
@@ -1208,7 +1236,7 @@ int rb_shard_resolve(rb_graph *g, int mode, const void *dreply_dev, const void *
                            g->light_ops, S->dreq_pos.as<uint32_t>(), (const uint8_t *)dreply_dev, S->creq_pos.as<uint32_t>(),
                            S->creq_dup.as<uint8_t>(), (const uint8_t *)creply_dev, g->tz().as<uint8_t>(), g->uniq().as<uint64_t>(),
                            g->status.as<uint32_t>(), g->nops.as<uint32_t>(), g->cvals.as<uint64_t>(), S->cfinal.as<uint64_t>(),
-                           S->replicate_cache ? S->cache_upd.as<uint8_t>() : (uint8_t *)nullptr);
+                           S->replicate_cache ? S->cache_upd.as<uint8_t>() : (uint8_t *)nullptr, g->vals1().as<uint32_t>());
         g->temp.reserve(select_temp_bytes(D));
         select_flagged(g->temp.p, g->temp.cap, g->status.as<uint32_t>(), RUN_HEAVY, D, g->heavy.as<uint32_t>(), ctr + 0, s);
         select_flagged(g->temp.p, g->temp.cap, g->status.as<uint32_t>(), RUN_CONFLICT, D, S->conf_list.as<uint32_t>(), ctr + 1, s);
@@ -1221,7 +1249,7 @@ int rb_shard_resolve(rb_graph *g, int mode, const void *dreply_dev, const void *
                                g->cvals.as<uint64_t>(), g->tz().as<uint8_t>(), g->heavy.as<uint32_t>(), ctr, S->cfinal.as<uint64_t>(),
                                S->replicate_cache ? S->cache_upd.as<uint8_t>() : (uint8_t *)nullptr);
         if (S->replicate_cache) {   // what this sub-batch taught the prefilter cache, for every other rank's replica
-            RouteUpd fu{S->cache_upd.as<uint8_t>(), g->uniq().as<uint64_t>(), nullptr};
+            RouteUpd fu{S->cache_upd.as<uint8_t>(), g->uniq().as<uint64_t>(), g->starts().as<uint32_t>(), g->vals1().as<uint32_t>(), fv, nullptr};
             int64_t uc[1];
             route(g, fu, (size_t)D, uc, [&](RouteUpd &ff, size_t kept) { ff.out = (CacheUpd *)slot_reserve(S, RB_SLOT_CACHE_UPD, kept * sizeof(CacheUpd)); }, 1);
         }
