@@ -345,3 +345,23 @@ def test_cold_subbatch_is_split_when_survivors_exceed_the_bound():
     st = gg.addReads(s, q, off, 3, storeReadPairedKmers=True)
     assert_same_state(og, gg)
     assert st.kmers == o_st.kmers and st.reads == 1200
+
+
+@pytest.mark.parametrize("env", [{}, {"RB_NO_MPF": "1"}, {"RB_NO_RAMP": "1"}, {"RB_PREPARE_EARLY": "1"}, {"RB_SERIAL": "1"},
+                                 {"RB_MPF": "8"}, {"RB_NPF": "8", "RB_NO_MPF": "1"}, {"RB_MPF_M": "9"}])
+def test_pipeline_switches_do_not_change_results(monkeypatch, env):
+    """every scheduling / cache switch of the insert path (minimizer- vs hash-bucketed cache, tiny caches that
+    thrash, minimizer length, cold-start ramp, producer one sub-batch ahead, serialised streams) is a pure
+    performance choice: the filters must come out identical to the oracle's"""
+    for k_, v in env.items():
+        monkeypatch.setenv(k_, v)
+    d = synth.generate_pairs(2500, G=4000, err=0.002, n_rate=1e-3, seed=77, uniform_expr=True)
+    og, gg = graph_pair(300_007, 400_009, 60_013, max_batch=15_000)
+    og.set_read_pair_distance(115); gg.setReadPairedKmerDistance(115)
+    for name, rc in (("left", False), ("right", True)):
+        s, off = synth.flat(d[name]); q, _ = synth.flat(d[name[0] + "qual"])
+        og.add_reads(s, q, off, 3, rbo.STORE_READ_PAIRS | (rbo.REVCOMP if rc else 0))
+        st = gg.addReads(s, q, off, 3, reverseComplement=rc, storeReadPairedKmers=True)
+        assert_same_state(og, gg)
+    assert og.cbf_bytes().max() > 30          # deep into the probabilistic counter range
+    assert st.sorted_kmers < st.kmers         # and the prefilter is doing something
