@@ -109,3 +109,21 @@ def test_loopback_queries_match_single_gpu():
                 assert (g_ == ref(p)).all()
     assert cl.contains(parts)[0].any() and cl.getCount(parts)[0].max() > 1
     cl.destroy(); gg.destroy() if hasattr(gg, "destroy") else None
+
+
+@pytest.mark.parametrize("overlap", [0, 1, 2])
+def test_loopback_lookahead_modes(monkeypatch, overlap):
+    """look-ahead hashing of the next sub-batch (replicated-hashing mode) is a scheduling choice only"""
+    from rnabloom import sharded
+    monkeypatch.setattr(sharded, "_OVERLAP", overlap)
+    d = synth.generate_pairs(2000, G=4000, err=0.002, n_rate=1e-3, seed=41, uniform_expr=True)
+    sizes = (200_003, 300_007, 40_009)
+    og = rbo.Graph(*sizes, 2, 2, 2, 25, False, True, 6)
+    cl = LoopbackCluster(2, *sizes, 2, 2, 2, 25, False, True, rngSeed=6, mode="replicated")
+    og.set_read_pair_distance(115); cl.setReadPairedKmerDistance(115)
+    s, off = synth.flat(d["left"]); q, _ = synth.flat(d["lqual"])
+    og.add_reads(s, q, off, 3, rbo.STORE_READ_PAIRS)
+    cl.addBatch(ReadBatch.from_ascii(s, q, off, 3), 150, storeReadPairedKmers=True, reads_per_substep=250)
+    check_filters(cl, og)
+    assert og.cbf_bytes().max() > 24
+    cl.destroy()
