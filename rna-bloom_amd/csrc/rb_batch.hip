@@ -709,74 +709,93 @@ int rb_batch_info(const rb_batch *b, int64_t *n_reads, int64_t *n_bases, int64_t
     return RB_OK;
 }
 
+}  // extern "C"
+
+namespace rb {
+// ASCII reads [first, first+n) -> packed batch, in two halves so that a caller can overlap the upload and the
+// GPU-side 2-bit encode of one chunk with whatever the GPU does for the previous one: begin() allocates,
+// enqueues the copies + encode kernel on `st` and returns; finish() waits for them and frees the staging.
+void ascii_batch_begin(AsciiUpload &u, int device, const char *seq, const char *qual, const int64_t *offsets, int64_t first, int64_t n_reads,
+                       int min_base_qual, hipStream_t st) {
+    RB_REQUIRE(offsets && n_reads >= 0 && (seq || n_reads == 0 || offsets[first + n_reads] == offsets[first]), "rb_batch_create_ascii: null argument");
+    RB_REQUIRE(min_base_qual >= 0 && min_base_qual < 94, "rb_batch_create_ascii: min_base_qual out of range");
+    RB_HIP(hipSetDevice(device));
+    offsets += first;
+    rb_batch *b = new rb_batch();
+    u.b = b; u.st = st;
+    b->device = device;
+    b->n_reads = n_reads;
+    std::vector<uint32_t> woff((size_t)n_reads + 1);
+    u.len.assign((size_t)std::max<int64_t>(n_reads, 1), 0u);
+    uint64_t words = 0;
+    uint32_t max_len = 0;
+    for (int64_t i = 0; i < n_reads; ++i) {
+        int64_t l = offsets[i + 1] - offsets[i];
+        RB_REQUIRE(l >= 0 && l < (int64_t)1 << 30, "rb_batch_create_ascii: read %lld has invalid length", (long long)(first + i));
+        woff[(size_t)i] = (uint32_t)words;
+        u.len[(size_t)i] = (uint32_t)l;
+        words += (uint64_t)((l + 31) / 32);
+        RB_REQUIRE(words < 0xFFFFFFF0ull, "rb_batch_create_ascii: batch too large (> 2^32 words)");
+        max_len = std::max(max_len, (uint32_t)l);
+    }
+    woff[(size_t)n_reads] = (uint32_t)words;
+    b->n_words = (int64_t)words;
+    b->max_len = max_len;
+    {   // uniform word count per read?
+        uint32_t wpr = n_reads ? (uint32_t)((u.len[0] + 31) / 32) : 0;
+        for (int64_t i = 0; i < n_reads && wpr; ++i) if ((u.len[(size_t)i] + 31) / 32 != wpr) wpr = 0;
+        b->wpr_uniform = wpr;
+    }
+    const int64_t base0 = n_reads ? offsets[0] : 0;
+    b->n_bases = n_reads ? offsets[n_reads] - base0 : 0;
+    alloc_batch_arrays(b);
+    b->h_woff = woff;
+    RB_HIP(hipMemcpyAsync(b->woff, b->h_woff.data(), ((size_t)n_reads + 1) * 4, hipMemcpyHostToDevice, st));
+    if (n_reads) RB_HIP(hipMemcpyAsync(b->len, u.len.data(), (size_t)n_reads * 4, hipMemcpyHostToDevice, st));
+    if (words) {
+        const size_t nb = (size_t)b->n_bases;
+        RB_HIP(hipMalloc(&u.d_seq, std::max<size_t>(nb, 1)));
+        RB_HIP(hipMemcpyAsync(u.d_seq, seq + base0, nb, hipMemcpyHostToDevice, st));
+        if (qual) {
+            RB_HIP(hipMalloc(&u.d_qual, std::max<size_t>(nb, 1)));
+            RB_HIP(hipMemcpyAsync(u.d_qual, qual + base0, nb, hipMemcpyHostToDevice, st));
+        }
+        u.rel.resize((size_t)n_reads + 1);
+        for (int64_t i = 0; i <= n_reads; ++i) u.rel[(size_t)i] = offsets[i] - base0;
+        RB_HIP(hipMalloc(&u.d_off, ((size_t)n_reads + 1) * 8));
+        RB_HIP(hipMemcpyAsync(u.d_off, u.rel.data(), ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_encode_ascii, dim3(blocks_for((int64_t)words)), dim3(TPB), 0, st, u.d_seq, u.d_qual, u.d_off, b->woff, n_reads,
+                           (int64_t)words, min_base_qual, b->codes, b->valid, b->word_read);
+        RB_HIP(hipGetLastError());
+    }
+}
+rb_batch *ascii_batch_finish(AsciiUpload &u) {
+    hipError_t e = hipStreamSynchronize(u.st);
+    u.drop();
+    rb_batch *b = u.b;
+    u.b = nullptr;
+    if (e != hipSuccess) { if (b) rb_batch_destroy(b); RB_HIP(e); }
+    return b;
+}
+void ascii_batch_abort(AsciiUpload &u) {
+    if (u.st) (void)hipStreamSynchronize(u.st);
+    u.drop();
+    if (u.b) { rb_batch_destroy(u.b); u.b = nullptr; }
+}
+}  // namespace rb
+
+extern "C" {
+
 int rb_batch_create_ascii(int device, const char *seq, const char *qual, const int64_t *offsets,
                           int64_t n_reads, int min_base_qual, rb_batch **out) {
+    rb::AsciiUpload u;
     try {
-        RB_REQUIRE(out && offsets && n_reads >= 0 && (seq || n_reads == 0 || offsets[n_reads] == offsets[0]),
-                   "rb_batch_create_ascii: null argument");
-        RB_REQUIRE(min_base_qual >= 0 && min_base_qual < 94, "rb_batch_create_ascii: min_base_qual out of range");
-        RB_HIP(hipSetDevice(device));
-        rb_batch *b = new rb_batch();
-        HostGuard guard{b};
-        b->device = device;
-        b->n_reads = n_reads;
-        std::vector<uint32_t> woff((size_t)n_reads + 1), len((size_t)std::max<int64_t>(n_reads, 1));
-        uint64_t words = 0;
-        uint32_t max_len = 0;
-        for (int64_t i = 0; i < n_reads; ++i) {
-            int64_t l = offsets[i + 1] - offsets[i];
-            RB_REQUIRE(l >= 0 && l < (int64_t)1 << 30, "rb_batch_create_ascii: read %lld has invalid length", (long long)i);
-            woff[(size_t)i] = (uint32_t)words;
-            len[(size_t)i] = (uint32_t)l;
-            words += (uint64_t)((l + 31) / 32);
-            RB_REQUIRE(words < 0xFFFFFFF0ull, "rb_batch_create_ascii: batch too large (> 2^32 words)");
-            max_len = std::max(max_len, (uint32_t)l);
-        }
-        woff[(size_t)n_reads] = (uint32_t)words;
-        b->n_words = (int64_t)words;
-        b->max_len = max_len;
-        {   // uniform word count per read?
-            uint32_t wpr = n_reads ? (uint32_t)((len[0] + 31) / 32) : 0;
-            for (int64_t i = 0; i < n_reads && wpr; ++i) if ((len[(size_t)i] + 31) / 32 != wpr) wpr = 0;
-            b->wpr_uniform = wpr;
-        }
-        const int64_t base0 = n_reads ? offsets[0] : 0;
-        b->n_bases = n_reads ? offsets[n_reads] - base0 : 0;
-        alloc_batch_arrays(b);
-        RB_HIP(hipMemcpy(b->woff, woff.data(), ((size_t)n_reads + 1) * 4, hipMemcpyHostToDevice));
-        b->h_woff = woff;
-        if (n_reads) RB_HIP(hipMemcpy(b->len, len.data(), (size_t)n_reads * 4, hipMemcpyHostToDevice));
-        if (words) {
-            uint8_t *d_seq = nullptr, *d_qual = nullptr;
-            int64_t *d_off = nullptr;
-            size_t nb = (size_t)b->n_bases;
-            RB_HIP(hipMalloc(&d_seq, std::max<size_t>(nb, 1)));
-            try {
-                RB_HIP(hipMemcpy(d_seq, seq + base0, nb, hipMemcpyHostToDevice));
-                if (qual) {
-                    RB_HIP(hipMalloc(&d_qual, std::max<size_t>(nb, 1)));
-                    RB_HIP(hipMemcpy(d_qual, qual + base0, nb, hipMemcpyHostToDevice));
-                }
-                std::vector<int64_t> rel((size_t)n_reads + 1);
-                for (int64_t i = 0; i <= n_reads; ++i) rel[(size_t)i] = offsets[i] - base0;
-                RB_HIP(hipMalloc(&d_off, ((size_t)n_reads + 1) * 8));
-                RB_HIP(hipMemcpy(d_off, rel.data(), ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice));
-                hipLaunchKernelGGL(k_encode_ascii, dim3(blocks_for((int64_t)words)), dim3(TPB), 0, 0, d_seq,
-                                   d_qual, d_off, b->woff, n_reads, (int64_t)words, min_base_qual, b->codes,
-                                   b->valid, b->word_read);
-                RB_HIP(hipGetLastError());
-                RB_HIP(hipDeviceSynchronize());
-            } catch (...) {
-                (void)hipFree(d_seq); if (d_qual) (void)hipFree(d_qual); if (d_off) (void)hipFree(d_off);
-                throw;
-            }
-            (void)hipFree(d_seq); if (d_qual) (void)hipFree(d_qual); (void)hipFree(d_off);
-        }
-        guard.b = nullptr;
-        *out = b;
+        RB_REQUIRE(out, "rb_batch_create_ascii: null argument");
+        rb::ascii_batch_begin(u, device, seq, qual, offsets, 0, n_reads, min_base_qual, nullptr);
+        *out = rb::ascii_batch_finish(u);
         return RB_OK;
-    } catch (const HipError &e) { return e.code; }
-    catch (const std::bad_alloc &) { set_error("host allocation failed"); return RB_ERR_NOMEM; }
+    } catch (const HipError &e) { rb::ascii_batch_abort(u); return e.code; }
+    catch (const std::bad_alloc &) { rb::ascii_batch_abort(u); set_error("host allocation failed"); return RB_ERR_NOMEM; }
 }
 
 int rb_batch_download_ascii(const rb_batch *b, int64_t first, int64_t n, char *seq, int64_t *offsets) {

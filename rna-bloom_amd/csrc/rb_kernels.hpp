@@ -31,4 +31,24 @@ void launch_hash_windows_masked(const rb_batch *b, int64_t w0, int64_t nw, int k
                                 const uint32_t *keepmask, uint32_t first_read, uint32_t pos_bits, uint64_t *keys, uint32_t *vals,
                                 hipStream_t s);
 
+// ASCII reads -> packed batch in two halves (rb_batch.hip): begin() allocates and enqueues the copies + the
+// encode kernel on `st` and returns; finish() waits for them and frees the staging buffers
+struct AsciiUpload {
+    rb_batch *b = nullptr;
+    uint8_t *d_seq = nullptr, *d_qual = nullptr;
+    int64_t *d_off = nullptr;
+    std::vector<uint32_t> len;
+    std::vector<int64_t> rel;
+    hipStream_t st = nullptr;
+    void drop() {
+        if (d_seq) (void)hipFree(d_seq);
+        if (d_qual) (void)hipFree(d_qual);
+        if (d_off) (void)hipFree(d_off);
+        d_seq = d_qual = nullptr; d_off = nullptr;
+    }
+};
+void ascii_batch_begin(AsciiUpload &u, int device, const char *seq, const char *qual, const int64_t *offsets, int64_t first, int64_t n_reads,
+                       int min_base_qual, hipStream_t st);
+rb_batch *ascii_batch_finish(AsciiUpload &u);
+void ascii_batch_abort(AsciiUpload &u);
 }  // namespace rb

@@ -160,11 +160,18 @@ class BloomFilterDeBruijnGraph:
 
     def addReads(self, seq, qual, offsets, minBaseQual=3, reverseComplement=False, incrementIfPresent=False,
                  storeReadPairedKmers=False):
-        b = ReadBatch.from_ascii(seq, qual, offsets, minBaseQual, self.device)
-        try:
-            return self.addBatch(b, reverseComplement, incrementIfPresent, storeReadPairedKmers)
-        finally:
-            b.close()
+        """host ASCII reads (the FastqToGraphWorker boundary): rb_graph_add_reads pins the buffers, uploads and
+        2-bit encodes them chunk by chunk, overlapped with the insert pipeline"""
+        flags = (N.ADD_REVCOMP if reverseComplement else 0) | (N.ADD_COUNT_IF_PRESENT if incrementIfPresent else 0) \
+            | (N.ADD_STORE_READ_PAIRS if storeReadPairedKmers else 0)
+        seq = np.ascontiguousarray(np.frombuffer(seq, np.uint8) if isinstance(seq, (bytes, bytearray)) else seq, dtype=np.uint8)
+        if qual is not None:
+            qual = np.ascontiguousarray(np.frombuffer(qual, np.uint8) if isinstance(qual, (bytes, bytearray)) else qual, dtype=np.uint8)
+        off = np.ascontiguousarray(offsets, dtype=np.int64)
+        st = N.AddStats()
+        check(lib.rb_graph_add_reads(self.h, _ptr(seq), _ptr(qual) if qual is not None else None, _ptr(off), off.size - 1, minBaseQual,
+                                     flags, C.byref(st)))
+        return st
 
     # ---- per-hash mutators (arrays are applied in order) ----
     def _apply(self, op, h0):

@@ -16,7 +16,7 @@ seq, off = b.download(0, pairs)                     # left reads as host ASCII (
 qual = np.full(seq.size, ord("I"), np.uint8)
 g = BloomFilterDeBruijnGraph(size, size, size, 2, 2, 2, 25, False, True, rngSeed=1)
 g.setReadPairedKmerDistance(115)
-chunk = 2_000_000                                   # reads per rb_graph_add_reads call
+chunk = int(sys.argv[2]) if len(sys.argv) > 2 else pairs   # reads per rb_graph_add_reads call (the library pipelines inside a call)
 for rep in range(2):
     g.clearAllBf()
     t0 = time.perf_counter(); km = 0
