@@ -47,7 +47,7 @@ def toy(rank, G, log):
     log.append(("gather2", a_all.clone().numpy().tobytes() + b_all.clone().numpy().tobytes(), list(a_sz) + list(b_sz)))
 
 
-def _worker(rank, world, port, outdir, chunk):
+def _worker(rank, world, port, outdir, chunk, fuse):
     sys.path.insert(0, os.path.join(ROOT, "rna-bloom_amd"))
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -57,6 +57,8 @@ def _worker(rank, world, port, outdir, chunk):
     from rnabloom.sharded import run_distributed
     if chunk:
         sharded.A2A_CHUNK = chunk            # force the multi-round path (RCCL's 1 GiB per-peer limit)
+    if fuse is not None:
+        sharded.FUSE_LIMIT = fuse            # 0: every tensor of a phase travels in its own collective
     dist.init_process_group("gloo", rank=rank, world_size=world)
     log = []
     run_distributed(toy(rank, world, log))
@@ -66,13 +68,13 @@ def _worker(rank, world, port, outdir, chunk):
         pickle.dump(log, fh)
 
 
-@pytest.mark.parametrize("world,chunk", [(2, 0), (2, 13)])
-def test_run_distributed_equals_loopback(world, chunk):
+@pytest.mark.parametrize("world,chunk,fuse", [(2, 0, None), (2, 13, None), (2, 0, 0), (2, 7, 0)])
+def test_run_distributed_equals_loopback(world, chunk, fuse):
     from rnabloom.sharded import run_loopback
     logs = [[] for _ in range(world)]
     run_loopback([toy(r, world, logs[r]) for r in range(world)])
     with tempfile.TemporaryDirectory() as d:
-        mp.spawn(_worker, args=(world, 29500 + (os.getpid() + 7 * chunk) % 400, d, chunk), nprocs=world, join=True)
+        mp.spawn(_worker, args=(world, 29500 + (os.getpid() + 7 * chunk + (3 if fuse == 0 else 0)) % 400, d, chunk, fuse), nprocs=world, join=True)
         for r in range(world):
             with open(os.path.join(d, "r%d.pkl" % r), "rb") as fh:
                 got = pickle.load(fh)
