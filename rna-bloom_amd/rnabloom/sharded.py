@@ -369,10 +369,22 @@ class _Driver:
         self.dist, self.group = dist, group
         self.world = dist.get_world_size(group)
         self.last_big = 0          # largest fused per-peer message of the last counted phase (same on every rank)
+        # gloo moves host memory: device tensors are staged through the CPU (multi-process tests on one GPU;
+        # RCCL refuses two ranks on the same device)
+        self.stage = dist.get_backend(group) == "gloo"
+
+    def _cpu(self, t):
+        return t.cpu() if (self.stage and t.is_cuda) else t
 
     def a2a(self, tensors, counts, known_rcs=None):
         dist, world, m = self.dist, self.world, len(tensors)
+        home = tensors[0].device
+        tensors = [self._cpu(t) for t in tensors]
         dev = tensors[0].device
+        outs, rcs = self._a2a(tensors, counts, known_rcs, dist, world, m, dev)
+        return [o.to(home) for o in outs] if dev != home else outs, rcs
+
+    def _a2a(self, tensors, counts, known_rcs, dist, world, m, dev):
         tot_s = [sum(counts[t][p] for t in range(m)) for p in range(world)]
         if known_rcs is not None:                       # replies: sizes follow from the requests just exchanged
             rcs = [[int(c) for c in cs] for cs in known_rcs]
@@ -411,6 +423,12 @@ class _Driver:
 
     def gather(self, tensors):
         """all_gather of a list of byte tensors in one padded collective -> [(concatenation over ranks, sizes)] per tensor"""
+        home = tensors[0].device
+        tensors = [self._cpu(t) for t in tensors]
+        res = self._gather(tensors)
+        return [(c.to(home), sz) for c, sz in res] if tensors[0].device != home else res
+
+    def _gather(self, tensors):
         dist, world, m = self.dist, self.world, len(tensors)
         dev = tensors[0].device
         mine = torch.tensor([int(t.numel()) for t in tensors], dtype=torch.int64, device=dev)
