@@ -113,12 +113,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = os.environ.get("RB_BENCH_BACKEND", "nccl")     # "gloo": several ranks on ONE GPU (functional check of this script)
+    if backend != "nccl":
+        local %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local)
     sharded_mode = world > 1 or a.force_sharded
     if sharded_mode:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     from rnabloom import _native as N
     from rnabloom.graph import BloomFilterDeBruijnGraph, ReadBatch
@@ -189,10 +195,11 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if sharded_mode:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        rdev = "cuda" if backend == "nccl" else "cpu"
+        t = torch.tensor([dt], device=rdev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        c = torch.tensor([kmers], device="cuda", dtype=torch.int64)
+        c = torch.tensor([kmers], device=rdev, dtype=torch.int64)
         dist.all_reduce(c, op=dist.ReduceOp.SUM)
         kmers_all = int(c.item())
     else:
@@ -236,7 +243,8 @@ def main():
                        "pairs": pairs_total, "genome_bases": a.genome, "dbgbf_bits": dbg_bits, "cbf_bytes": cbf_bytes,
                        "rpkbf_bits": pk_bits, "kmers_per_step": kmers_all // a.steps,
                        "read_pairs_per_step": pairs_ins // a.steps, "distinct_per_step": distinct // a.steps, "sorted_kmers_per_step": n_sorted // a.steps,
-                       "conflict_ops_per_step": conflict // a.steps, "parallelism": ("single GPU" if not sharded_mode else "filters index-sharded x%d, k-mers hash-sharded, RCCL all_to_all" % world)},
+                       "conflict_ops_per_step": conflict // a.steps, "parallelism": ("single GPU" if not sharded_mode else "filters index-sharded x%d, k-mers hash-sharded (%s mode), %s all_to_all"
+                                       % (world, sr.mode, "RCCL" if backend == "nccl" else backend))},
             "stages_ms_per_step": {n: round(v[0] / a.steps, 2) for n, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
             "roofline": roof,
         }
