@@ -365,3 +365,17 @@ def test_pipeline_switches_do_not_change_results(monkeypatch, env):
         assert_same_state(og, gg)
     assert og.cbf_bytes().max() > 30          # deep into the probabilistic counter range
     assert st.sorted_kmers < st.kmers         # and the prefilter is doing something
+
+
+@pytest.mark.parametrize("k", [9, 12, 16, 17, 20, 31])
+def test_small_and_boundary_k_through_the_prefiltered_path(k):
+    """k = 31 uses all 16 slots of the minimizer ring (k - m + 1 = 16), k <= 16 makes the minimizer the k-mer
+    itself, k = 9 is below the minimizer cache's range... all must stay exact"""
+    d = synth.generate_pairs(1500, G=1500, err=0.002, n_rate=1e-3, seed=100 + k, uniform_expr=True)
+    og, gg = graph_pair(150_001, 200_003, 30_011, k=k, max_batch=20_000)
+    og.set_read_pair_distance(100); gg.setReadPairedKmerDistance(100)
+    s, off = synth.flat(d["left"]); q, _ = synth.flat(d["lqual"])
+    og.add_reads(s, q, off, 3, rbo.STORE_READ_PAIRS)
+    st = gg.addReads(s, q, off, 3, storeReadPairedKmers=True)
+    assert_same_state(og, gg)
+    assert st.sorted_kmers < st.kmers
