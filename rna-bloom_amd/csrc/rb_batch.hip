@@ -430,7 +430,7 @@ k_filter_windows_fast(const uint64_t *__restrict__ codes, const uint32_t *__rest
             // minimizer state (MPF)
             const uint32_t um = MPF ? mcache.m : 1u, uw = uk - um + 1u;           // m-mers per k-mer
             const uint32_t mmask = (um >= 16u) ? 0xFFFFFFFFu : ((1u << (2u * um)) - 1u);
-            uint32_t mf = 0, mr = 0;
+            uint32_t mf = 0, mr = 0, blk_a = 0, blk_p = 0;               // position inside the current block of uw m-mers, its prefix minimum
             uint64_t cur_bkt = ~0ull;
             for (uint32_t j = 0; j < nb; ++j) {
                 const uint32_t code = (uint32_t)clo & 3u, ok = (uint32_t)vs & 1u;
@@ -442,10 +442,13 @@ k_filter_windows_fast(const uint64_t *__restrict__ codes, const uint32_t *__rest
                 if (MODE != 0) rv = rotr(rv, 1) ^ s_tr[t];
                 hc = (hc << 2) | code; hv = (hv << 1) | ok;
                 run = ok ? run + 1u : 0u;
+                uint32_t o_cur = 0;
                 if (MPF) {   // canonical m-mer ending at this base (garbage while run < m: never consulted then)
                     mf = ((mf << 2) | code) & mmask;
                     mr = (mr >> 2) | ((3u - code) << (2u * (um - 1u)));
-                    s_ring[(j & 15u) * 64u + lane] = mmer_order(mf < mr ? mf : mr);
+                    o_cur = mmer_order(mf < mr ? mf : mr);
+                    s_ring[blk_a * 64u + lane] = o_cur;
+                    blk_p = blk_a ? (o_cur < blk_p ? o_cur : blk_p) : o_cur;      // prefix minimum of the current block of uw positions
                 }
                 if (run >= uk) {
                     const uint32_t p = b0 + j + 1u - uk;
@@ -454,8 +457,11 @@ k_filter_windows_fast(const uint64_t *__restrict__ codes, const uint32_t *__rest
                     if (((uint32_t)(h0 >> RB_OWNER_SHIFT) & own_mask) == own_rank) {
                         uint32_t s_known = 0;
                         if (MPF) {
-                            uint32_t omin = 0xFFFFFFFFu;                 // the window's m-mers end at bases j-uw+1 .. j
-                            for (uint32_t q = 0; q < uw; ++q) { const uint32_t o = s_ring[((j - q) & 15u) * 64u + lane]; omin = o < omin ? o : omin; }
+                            // sliding-window minimum in O(1) (van Herk / Gil-Werman): the window's uw m-mers are the tail of the
+                            // previous block (its suffix minima replaced the block's ring entries when it completed) and
+                            // the head of the current block (running prefix minimum)
+                            uint32_t omin = blk_p;
+                            if (blk_a + 1u < uw) { const uint32_t sfx = s_ring[(blk_a + 1u) * 64u + lane]; omin = sfx < omin ? sfx : omin; }
                             const uint64_t bkt = mpf_bucket(mcache, omin);
                             if (bkt != cur_bkt) {     // new minimizer: fetch the two lines of its bucket
                                 const ulonglong2 *bp = reinterpret_cast<const ulonglong2 *>(mcache.tab + (bkt << 4));
@@ -471,6 +477,14 @@ k_filter_windows_fast(const uint64_t *__restrict__ codes, const uint32_t *__rest
                         ++total;
                         if (keep) { ++kept; mask |= 1u << (p - b0); }
                     }
+                }
+                if (MPF) {
+                    if (blk_a + 1u == uw) {   // block complete: turn its ring entries into suffix minima (uniform across the wavefront)
+                        uint32_t sm = 0xFFFFFFFFu;
+                        for (uint32_t q = uw; q-- > 0u;) { const uint32_t v = s_ring[q * 64u + lane]; sm = v < sm ? v : sm; s_ring[q * 64u + lane] = sm; }
+                        blk_a = 0;
+                    } else
+                        ++blk_a;
                 }
             }
         }
