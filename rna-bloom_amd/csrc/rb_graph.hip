@@ -937,14 +937,17 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
     const int mode = (flags & RB_ADD_COUNT_IF_PRESENT) ? M_COUNT_IF_PRESENT : M_ADD;
     const bool pairs = (flags & RB_ADD_STORE_READ_PAIRS) != 0;
     if (pairs) RB_REQUIRE(g->rpk.bits && g->read_d > 0, "STORE_READ_PAIRS needs use_read_paired_kmers and a read pair distance > 0");
+    // occurrence id = read index within the sub-batch << pos_bits | window start; window starts reach max_len - k
+    const uint32_t max_pos = b->max_len >= (uint32_t)g->k ? b->max_len - (uint32_t)g->k : 0u;
     uint32_t pos_bits = 1;
-    while ((1u << pos_bits) <= b->max_len && pos_bits < 31) ++pos_bits;
+    while ((1u << pos_bits) <= max_pos && pos_bits < 31) ++pos_bits;
     const int64_t max_reads = (int64_t)1 << (32 - pos_bits);
     // max_batch_kmers bounds the RECORDS a sub-batch sorts.  With the prefilter most windows never
-    // become records, so a sub-batch may span twice as many windows (fewer, larger runs per k-mer); a
+    // become records, so a sub-batch may span three times as many windows (fewer, larger runs per k-mer); a
     // sub-batch whose survivors exceed the bound after all (cold cache) is split and redone.
     const bool npf_path = g->npf_log2 && g->k <= 31;
-    const int64_t max_words = std::max<int64_t>(std::min<int64_t>((npf_path ? 2 : 1) * g->max_batch_kmers, (int64_t)3 << 30) / 32, 1);
+    const int wmul = getenv("RB_WINDOW_MUL") ? std::max(1, atoi(getenv("RB_WINDOW_MUL"))) : 3;
+    const int64_t max_words = std::max<int64_t>(std::min<int64_t>((npf_path ? wmul : 1) * g->max_batch_kmers, (int64_t)7 << 29) / 32, 1);
     const std::vector<uint32_t> &wo = b->h_woff;
     // plan the sub-batches
     struct Sub { int64_t r0, r1, w0, nw; uint32_t N; int64_t total; };
