@@ -379,3 +379,34 @@ def test_small_and_boundary_k_through_the_prefiltered_path(k):
     st = gg.addReads(s, q, off, 3, storeReadPairedKmers=True)
     assert_same_state(og, gg)
     assert st.sorted_kmers < st.kmers
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_ragged_reads_fuzz(seed):
+    """ragged read lengths (shorter than k up to several words), N runs, low-quality stretches, FASTA and FASTQ,
+    both strands' files, many small sub-batches: the prefiltered path (minimizer ring across word boundaries,
+    per-read word counts that differ) must stay exact"""
+    rng = np.random.default_rng(seed)
+    genome = rng.integers(0, 4, 3000, dtype=np.uint8)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    seqs, quals = [], []
+    for _ in range(2500):
+        L = int(rng.choice([5, 24, 25, 26, 31, 32, 33, 63, 64, 65, 97, 150, 151, 260]))
+        a = int(rng.integers(0, genome.size - L)) if L < genome.size else 0
+        s = acgt[genome[a:a + L]].copy()
+        q = np.full(L, ord("I"), np.uint8)
+        if rng.random() < 0.3 and L > 8:                       # an N run or a low-quality stretch somewhere
+            p, n = int(rng.integers(0, L - 4)), int(rng.integers(1, 5))
+            if rng.random() < 0.5: s[p:p + n] = ord("N")
+            else: q[p:p + n] = ord("#")
+        if rng.random() < 0.1: s = np.char.lower(s.view("S1")).view(np.uint8)   # lower case is legal (R/util/SeqUtils.java)
+        seqs.append(s); quals.append(q)
+    seq = np.concatenate(seqs); qual = np.concatenate(quals)
+    off = np.concatenate([[0], np.cumsum([x.size for x in seqs])]).astype(np.int64)
+    for use_qual in (True, False):
+        og, gg = graph_pair(120_011, 170_003, 20_011, max_batch=9_000)
+        og.set_read_pair_distance(40); gg.setReadPairedKmerDistance(40)
+        for rc in (False, True):
+            og.add_reads(seq, qual if use_qual else None, off, 3, rbo.STORE_READ_PAIRS | (rbo.REVCOMP if rc else 0))
+            gg.addReads(seq, qual if use_qual else None, off, 3, reverseComplement=rc, storeReadPairedKmers=True)
+            assert_same_state(og, gg)
