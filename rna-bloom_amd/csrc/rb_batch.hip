@@ -203,6 +203,9 @@ __global__ void k_count_windows(const uint32_t *__restrict__ valid, const uint32
 #ifndef RB_HASH_TPB
 #define RB_HASH_TPB 64
 #endif
+#ifndef RB_EMIT_SLAB
+#define RB_EMIT_SLAB 512
+#endif
 constexpr int HASH_TPB = RB_HASH_TPB;   // one wavefront per block: every lane is busy in the single slab round
 constexpr uint32_t HASH_SLAB = 32u * RB_HASH_TPB;
 template <int MODE>
@@ -325,7 +328,11 @@ k_hash_windows_fast(const uint64_t *__restrict__ codes, const uint32_t *__restri
                     const uint32_t *__restrict__ len, int64_t w0, int64_t nw, int k,
                     const uint32_t *__restrict__ chunk_off, uint32_t first_read, uint32_t pos_bits,
                     uint64_t *__restrict__ keys, uint32_t *__restrict__ vals, const uint32_t *__restrict__ keepmask) {
-    constexpr uint32_t SLAB = 2048;                       // 64 threads x 32 windows
+    // Records of the block's 64 words are contiguous in the output: they are staged through LDS and
+    // written back as full lines, SLAB records per round.  After the prefilter ~1/5 of the windows
+    // survive, so one round of 512 is the common case; a small slab keeps LDS at 6 KB per wavefront
+    // (occupancy 8 instead of 2 with a 2048-record slab) and this walker is latency-bound.
+    constexpr uint32_t SLAB = RB_EMIT_SLAB;
     __shared__ uint64_t s_key[SLAB + SLAB / 32 + 1];
     __shared__ uint32_t s_val[SLAB + SLAB / 32 + 1];
     __shared__ uint64_t s_tf[25], s_tr[25];
@@ -343,46 +350,54 @@ k_hash_windows_fast(const uint64_t *__restrict__ codes, const uint32_t *__restri
     const int64_t blk_end = (blk0 + 64 < nw) ? blk0 + 64 : nw;
     const uint32_t O0 = chunk_off[blk0], O1 = chunk_off[blk_end];
     if (O0 == O1) return;
+    // walker state (a lane without windows keeps nb = 0)
+    uint64_t clo = 0, chi = 0, vs = 0, f = 0, rv = 0, hc = 0, hv = 0;   // hc/hv: codes / usable bits of the previous bases
+    uint32_t nb = 0, j = 0, run = 0, out = 0, rel = 0, b0 = 0, keep = 0;
     if (i < nw) {
         const int64_t w = w0 + i;
         const uint32_t r = word_read[w], wr = woff[r], L = len[r];
-        const uint32_t c = (uint32_t)(w - wr), b0 = c * 32u;
-        if ((uint64_t)b0 + uk <= L) {
+        const uint32_t c = (uint32_t)(w - wr);
+        b0 = c * 32u;
+        keep = keepmask ? keepmask[i] : 0xFFFFFFFFu;      // bit p-b0: window p survived the prefilter
+        if ((uint64_t)b0 + uk <= L && keep) {
             const uint32_t nwords = (L + 31u) >> 5;
             // 64 bases of codes / validity starting at b0 (second word only if the read has it)
-            uint64_t clo = codes[w], chi = (c + 1u < nwords) ? codes[w + 1] : 0ull;
-            uint64_t vs = (uint64_t)valid[w] | ((c + 1u < nwords) ? ((uint64_t)valid[w + 1] << 32) : 0ull);
-            const uint32_t nb = ((b0 + 32u + uk - 1u < L) ? b0 + 32u + uk - 1u : L) - b0;   // bases to walk (<= 62)
-            uint64_t f = 0, rv = 0, hc = 0, hv = 0;      // hc/hv: codes / usable bits of the previous bases
-            uint32_t run = 0, out = chunk_off[i] - O0;
-            const uint32_t rel = (r - first_read) << pos_bits;
-            const uint32_t sh_c = 2u * (uk - 1u), sh_v = uk - 1u;
-            const uint32_t keep = keepmask ? keepmask[i] : 0xFFFFFFFFu;   // bit p-b0: window p survived the prefilter
-            for (uint32_t j = 0; j < nb; ++j) {
-                const uint32_t code = (uint32_t)clo & 3u, ok = (uint32_t)vs & 1u;
-                clo = (clo >> 2) | (chi << 62); chi >>= 2; vs >>= 1;
-                const uint32_t in5 = ok ? code + 1u : 0u;
-                const uint32_t out5 = ((uint32_t)(hv >> sh_v) & 1u) ? ((uint32_t)(hc >> sh_c) & 3u) + 1u : 0u;
-                const uint32_t t = out5 * 5u + in5;
-                if (MODE != 2) f = rotl(f, 1) ^ s_tf[t];
-                if (MODE != 0) rv = rotr(rv, 1) ^ s_tr[t];
-                hc = (hc << 2) | code; hv = (hv << 1) | ok;
-                run = ok ? run + 1u : 0u;
-                if (run >= uk && ((keep >> (j + 1u - uk)) & 1u)) {
-                    const uint32_t q = out + (out >> 5);
-                    s_key[q] = (MODE == 0) ? f : (MODE == 2) ? rv : canonical(f, rv);
-                    s_val[q] = rel | (b0 + j + 1u - uk);
-                    ++out;
-                }
-            }
+            clo = codes[w]; chi = (c + 1u < nwords) ? codes[w + 1] : 0ull;
+            vs = (uint64_t)valid[w] | ((c + 1u < nwords) ? ((uint64_t)valid[w + 1] << 32) : 0ull);
+            nb = ((b0 + 32u + uk - 1u < L) ? b0 + 32u + uk - 1u : L) - b0;   // bases to walk (<= 62)
+            out = chunk_off[i] - O0;
+            rel = (r - first_read) << pos_bits;
         }
     }
-    __syncthreads();
+    const uint32_t sh_c = 2u * (uk - 1u), sh_v = uk - 1u;
     const uint32_t n = O1 - O0;
-    for (uint32_t j = threadIdx.x; j < n; j += 64u) {
-        const uint32_t q = j + (j >> 5);
-        keys[O0 + j] = s_key[q];
-        vals[O0 + j] = s_val[q];
+    for (uint32_t slab0 = 0; slab0 < n; slab0 += SLAB) {
+        const uint32_t slab1 = (slab0 + SLAB < n) ? slab0 + SLAB : n;
+        while (j < nb && out < slab1) {
+            const uint32_t code = (uint32_t)clo & 3u, ok = (uint32_t)vs & 1u;
+            clo = (clo >> 2) | (chi << 62); chi >>= 2; vs >>= 1;
+            const uint32_t in5 = ok ? code + 1u : 0u;
+            const uint32_t out5 = ((uint32_t)(hv >> sh_v) & 1u) ? ((uint32_t)(hc >> sh_c) & 3u) + 1u : 0u;
+            const uint32_t t = out5 * 5u + in5;
+            if (MODE != 2) f = rotl(f, 1) ^ s_tf[t];
+            if (MODE != 0) rv = rotr(rv, 1) ^ s_tr[t];
+            hc = (hc << 2) | code; hv = (hv << 1) | ok;
+            run = ok ? run + 1u : 0u;
+            if (run >= uk && ((keep >> (j + 1u - uk)) & 1u)) {
+                const uint32_t o = out - slab0, q = o + (o >> 5);
+                s_key[q] = (MODE == 0) ? f : (MODE == 2) ? rv : canonical(f, rv);
+                s_val[q] = rel | (b0 + j + 1u - uk);
+                ++out;
+            }
+            ++j;
+        }
+        __syncthreads();
+        for (uint32_t x = threadIdx.x; x < slab1 - slab0; x += 64u) {
+            const uint32_t q = x + (x >> 5);
+            keys[O0 + slab0 + x] = s_key[q];
+            vals[O0 + slab0 + x] = s_val[q];
+        }
+        __syncthreads();
     }
 }
 
