@@ -510,6 +510,138 @@ k_filter_windows_fast(const uint64_t *__restrict__ codes, const uint32_t *__rest
     if (threadIdx.x == 0 && total) atomicAdd(&total_spread[16u * (blockIdx.x & 31u)], total);
 }
 
+// ---- one read per lane (k <= 31, uniform batches) ----
+// k_filter_windows_fast / k_hash_windows_fast give every lane one 32-base word: 32 windows for 32 + k-1
+// walker steps, i.e. 1.94 steps per window at k = 25 — and the SQ counters show both kernels bound by
+// instruction issue (filter: the vector ALU is busy 57% of all SIMD cycles at 3 wavefronts per SIMD),
+// not by memory.  When every read of the batch has the same number of words W <= RB_READ_WORDS, a lane
+// takes a whole read instead: 150 steps for the 126 windows of a 150-base read (1.19 per window), and
+// all lanes of a wavefront cross their word boundaries in the same step.  The read's code / usable
+// words are loaded into registers up front — a load inside the walk would stall the wavefront at every
+// word boundary.  The interface is that of the one-word kernel: one count and one 32-bit keep mask per
+// word (the word a window STARTS in).  Window start decided at base b: p = b + 1 - k.
+// (The emit pass stays one word per lane: its records are staged through LDS in output order, and with
+// a read per lane the 64 lanes of a wavefront fill a slab one after the other instead of together —
+// measured 36 -> 70 ms.)
+constexpr int RB_READ_WORDS = 8;
+
+template <int MODE, bool MPF>
+__global__ void __launch_bounds__(64)
+k_filter_reads(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
+               const uint32_t *__restrict__ word_read, const uint32_t *__restrict__ len, int64_t w0, int64_t nw, int k,
+               uint32_t W, uint32_t first_read, uint32_t pos_bits, uint64_t seed, uint64_t ordinal0, Npf cache, Mpf mcache,
+               uint32_t *__restrict__ cnt, uint32_t *__restrict__ keepmask, uint32_t *__restrict__ total_spread,
+               uint32_t dbg_flags, uint32_t own_mask, uint32_t own_rank) {
+    __shared__ uint64_t s_tf[25], s_tr[25];
+    __shared__ uint32_t s_ring[MPF ? 16 * 64 : 1];              // [slot][lane]: order of the m-mer ending at base (slot mod 16)
+    __shared__ unsigned long long s_bkt[MPF ? 16 * 64 : 1];     // [slot][lane]: image of the current bucket
+    const uint32_t uk = (uint32_t)k, lane = threadIdx.x;
+    if (threadIdx.x < 25) {
+        const uint32_t o = threadIdx.x / 5u, in = threadIdx.x % 5u;
+        const uint64_t so = o ? seed_of(o - 1u) : 0ull, si = in ? seed_of(in - 1u) : 0ull;
+        const uint64_t sco = o ? seed_of(4u - o) : 0ull, sci = in ? seed_of(4u - in) : 0ull;
+        s_tf[threadIdx.x] = rotl(so, uk) ^ si;
+        s_tr[threadIdx.x] = rotr(sco, 1) ^ rotl(sci, uk - 1u);
+    }
+    __syncthreads();
+    const int64_t w = ((int64_t)blockIdx.x * 64 + threadIdx.x) * (int64_t)W;   // the read's first word, relative to w0
+    uint32_t total = 0;
+    if (w < nw) {
+        const int64_t gw = w0 + w;
+        const uint32_t r = word_read[gw], L = len[r];
+        uint32_t done = 0;                                       // words whose count and mask are written
+        if (uk <= L) {
+            uint64_t carr[RB_READ_WORDS];
+            uint32_t varr[RB_READ_WORDS];
+#pragma unroll
+            for (int q = 0; q < RB_READ_WORDS; ++q) {
+                carr[q] = 0; varr[q] = 0;
+                if ((uint32_t)q < W) { carr[q] = codes[gw + q]; varr[q] = valid[gw + q]; }
+            }
+            const uint32_t rstate = rng_read_state(seed, ordinal0 + (uint64_t)(r - first_read));
+            const uint32_t sh_c = 2u * (uk - 1u), sh_v = uk - 1u;
+            const uint32_t um = MPF ? mcache.m : 1u, uw = uk - um + 1u;           // m-mers per k-mer
+            const uint32_t mmask = (um >= 16u) ? 0xFFFFFFFFu : ((1u << (2u * um)) - 1u);
+            uint32_t mf = 0, mr = 0, blk_a = 0, blk_p = 0;       // minimizer state, see k_filter_windows_fast
+            uint64_t cur_bkt = ~0ull;
+            uint64_t f = 0, rv = 0, hc = 0, hv = 0, cur_c = 0;
+            uint32_t run = 0, kept = 0, mask = 0, cur_v = 0;
+            uint32_t b = 0;
+            while (b < L) {
+                if ((b & 31u) == 0u) {                           // next code word
+                    const uint32_t wi = b >> 5;
+#pragma unroll
+                    for (int q = 0; q < RB_READ_WORDS; ++q) if ((uint32_t)q == wi) { cur_c = carr[q]; cur_v = varr[q]; }
+                }
+                const uint32_t pb = b + 1u - uk;                 // window start decided in this step (wraps while b + 1 < k)
+                if ((pb & 31u) == 0u && (int32_t)pb > 0) {       // first window of a new word: the previous word is final
+                    cnt[w + done] = kept; keepmask[w + done] = mask; ++done; kept = 0; mask = 0;
+                }
+                const uint32_t d1 = 32u - (b & 31u), d2 = 32u - (pb & 31u);
+                uint32_t stop = b + (d1 < d2 ? d1 : d2);
+                stop = stop < L ? stop : L;
+#pragma nounroll
+                for (; b < stop; ++b) {
+                    const uint32_t code = (uint32_t)cur_c & 3u, ok = cur_v & 1u;
+                    cur_c >>= 2; cur_v >>= 1;
+                    const uint32_t in5 = ok ? code + 1u : 0u;
+                    const uint32_t out5 = ((uint32_t)(hv >> sh_v) & 1u) ? ((uint32_t)(hc >> sh_c) & 3u) + 1u : 0u;
+                    const uint32_t tt = out5 * 5u + in5;
+                    if (MODE != 2) f = rotl(f, 1) ^ s_tf[tt];
+                    if (MODE != 0) rv = rotr(rv, 1) ^ s_tr[tt];
+                    hc = (hc << 2) | code; hv = (hv << 1) | ok;
+                    run = ok ? run + 1u : 0u;
+                    uint32_t o_cur = 0;
+                    if (MPF) {   // canonical m-mer ending at this base (garbage while run < m: never consulted then)
+                        mf = ((mf << 2) | code) & mmask;
+                        mr = (mr >> 2) | ((3u - code) << (2u * (um - 1u)));
+                        o_cur = mmer_order(mf < mr ? mf : mr);
+                        s_ring[blk_a * 64u + lane] = o_cur;
+                        blk_p = blk_a ? (o_cur < blk_p ? o_cur : blk_p) : o_cur;
+                    }
+                    if (run >= uk) {
+                        const uint32_t p = b + 1u - uk;
+                        const uint64_t h0 = (MODE == 0) ? f : (MODE == 2) ? rv : canonical(f, rv);
+                        // sharded engine: every rank walks all reads and keeps the k-mers it owns
+                        if (((uint32_t)(h0 >> RB_OWNER_SHIFT) & own_mask) == own_rank) {
+                            uint32_t s_known = 0;
+                            if (MPF) {
+                                uint32_t omin = blk_p;           // sliding-window minimum, see k_filter_windows_fast
+                                if (blk_a + 1u < uw) { const uint32_t sfx = s_ring[(blk_a + 1u) * 64u + lane]; omin = sfx < omin ? sfx : omin; }
+                                const uint64_t bkt = mpf_bucket(mcache, omin);
+                                if (bkt != cur_bkt) {            // new minimizer: fetch the two lines of its bucket
+                                    const ulonglong2 *bp = reinterpret_cast<const ulonglong2 *>(mcache.tab + (bkt << 4));
+#pragma unroll
+                                    for (int q = 0; q < 8; ++q) { const ulonglong2 e = bp[q]; s_bkt[(2 * q) * 64 + lane] = e.x; s_bkt[(2 * q + 1) * 64 + lane] = e.y; }
+                                    cur_bkt = bkt;
+                                }
+                                s_known = mpf_match(&s_bkt[lane], 64u, h0);
+                            } else if (!(dbg_flags & 1u))
+                                s_known = npf_lookup(cache, h0);
+                            bool keep = true;
+                            if (s_known && !(dbg_flags & 2u)) keep = draw_strength(rng_pos(rstate, p)) >= s_known;
+                            ++total;
+                            if (keep) { ++kept; mask |= 1u << (p & 31u); }
+                        }
+                    }
+                    if (MPF) {
+                        if (blk_a + 1u == uw) {   // block complete: turn its ring entries into suffix minima
+                            uint32_t sm = 0xFFFFFFFFu;
+                            for (uint32_t q = uw; q-- > 0u;) { const uint32_t v = s_ring[q * 64u + lane]; sm = v < sm ? v : sm; s_ring[q * 64u + lane] = sm; }
+                            blk_a = 0;
+                        } else
+                            ++blk_a;
+                    }
+                }
+            }
+            cnt[w + done] = kept; keepmask[w + done] = mask; ++done;       // the word the last window starts in
+        }
+        for (; done < W; ++done) { cnt[w + done] = 0; keepmask[w + done] = 0; }   // words no window starts in
+    }
+    for (int o = 32; o > 0; o >>= 1) total += __shfl_down(total, o, 64);
+    if (threadIdx.x == 0 && total) atomicAdd(&total_spread[16u * (blockIdx.x & 31u)], total);
+}
+
 // One-pass prefilter + emit (k <= 31): the walker of k_filter_windows_fast, but every kept window's
 // (h0, occurrence) goes straight to its final position in the dense, read-ordered output.  A block
 // = one wavefront = 64 words; kept records are staged in LDS, the block's output offset comes from
@@ -668,6 +800,13 @@ void launch_hash_windows(const rb_batch *b, int64_t w0, int64_t nw, int k, int m
 #undef RB_LAUNCH_HASH
 }
 
+// words per read if the read-per-lane kernels apply (uniform batch of short reads), else 0: one word per lane
+// (RB_READ_LANES=0 forces the one-word kernels)
+static uint32_t read_lane_words(const rb_batch *b, int64_t nw) {
+    static const bool off = getenv("RB_READ_LANES") && atoi(getenv("RB_READ_LANES")) == 0;
+    if (!off && b->wpr_uniform && b->wpr_uniform <= (uint32_t)RB_READ_WORDS && nw % b->wpr_uniform == 0) return b->wpr_uniform;
+    return 0u;
+}
 void launch_filter_windows(const rb_batch *b, int64_t w0, int64_t nw, int k, int mode, uint32_t first_read,
                            uint32_t pos_bits, uint64_t seed, uint64_t ordinal0, Npf cache, uint32_t *cnt, uint32_t *keepmask,
                            uint32_t *total_spread, hipStream_t s, uint32_t own_mask, uint32_t own_rank, Mpf mcache) {
@@ -678,7 +817,16 @@ void launch_filter_windows(const rb_batch *b, int64_t w0, int64_t nw, int k, int
 #define RB_LAUNCH_FILT(M, P)                                                                                    \
     hipLaunchKernelGGL((k_filter_windows_fast<M, P>), g, t, 0, s, b->codes, b->valid, b->word_read, b->woff, b->len, \
                        w0, nw, k, first_read, pos_bits, seed, ordinal0, cache, mcache, cnt, keepmask, total_spread, dbgf, own_mask, own_rank)
-    if (mcache.tab && mcache.m <= (uint32_t)k && (uint32_t)k - mcache.m + 1u <= 16u) {
+    const bool use_m = mcache.tab && mcache.m <= (uint32_t)k && (uint32_t)k - mcache.m + 1u <= 16u;
+    if (const uint32_t C = read_lane_words(b, nw)) {
+        dim3 gc(blocks_for(nw / C, 64));
+#define RB_LAUNCH_FC(M, P)                                                                                        \
+    hipLaunchKernelGGL((k_filter_reads<M, P>), gc, t, 0, s, b->codes, b->valid, b->word_read, b->len, w0, nw, k, C, \
+                       first_read, pos_bits, seed, ordinal0, cache, mcache, cnt, keepmask, total_spread, dbgf, own_mask, own_rank)
+        if (use_m) { if (mode == 0) RB_LAUNCH_FC(0, true); else if (mode == 2) RB_LAUNCH_FC(2, true); else RB_LAUNCH_FC(1, true); }
+        else { if (mode == 0) RB_LAUNCH_FC(0, false); else if (mode == 2) RB_LAUNCH_FC(2, false); else RB_LAUNCH_FC(1, false); }
+#undef RB_LAUNCH_FC
+    } else if (use_m) {
         if (mode == 0) RB_LAUNCH_FILT(0, true); else if (mode == 2) RB_LAUNCH_FILT(2, true); else RB_LAUNCH_FILT(1, true);
     } else {
         if (mode == 0) RB_LAUNCH_FILT(0, false); else if (mode == 2) RB_LAUNCH_FILT(2, false); else RB_LAUNCH_FILT(1, false);

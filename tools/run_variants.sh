@@ -1,10 +1,10 @@
 # A/B runs of bench.py under environment switches (development helper; run through gpurun)
 mkdir -p gpurun_out
-python -m pytest tests/test_gpu_parity.py tests/test_gpu_sharded.py -q -m gpu -x 2>&1 | tail -3
+python -m pytest tests/test_gpu_parity.py tests/test_gpu_sharded.py -q -m gpu -x 2>&1 | tail -5
 run() { name=$1; shift; env "$@" python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/v_$name.json 2> gpurun_out/v_$name.err; }
-run coop RB_X=0
-run nocoop RB_FILTER_COOP=0
-run coop2 RB_X=0
+run reads RB_X=0
+run reads2 RB_X=0
+run word RB_READ_LANES=0
 for f in gpurun_out/v_*.json; do echo $f; python - "$f" <<'PY'
 import json,sys
 d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
