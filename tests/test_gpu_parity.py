@@ -410,3 +410,34 @@ def test_ragged_reads_fuzz(seed):
             og.add_reads(seq, qual if use_qual else None, off, 3, rbo.STORE_READ_PAIRS | (rbo.REVCOMP if rc else 0))
             gg.addReads(seq, qual if use_qual else None, off, 3, reverseComplement=rc, storeReadPairedKmers=True)
             assert_same_state(og, gg)
+
+
+@pytest.mark.parametrize("words,k", [(1, 25), (2, 25), (5, 25), (5, 31), (8, 21), (9, 25)])
+def test_uniform_word_count_fuzz(words, k):
+    """every read has the same number of 32-base words but not the same length (the last word is partly filled),
+    with N runs and low-quality stretches: batches of up to 8 words per read take the one-read-per-lane prefilter
+    (k_filter_reads: words preloaded into registers, per-word counts / keep masks flushed at word boundaries,
+    trailing words without a window start zero-filled), 9 words fall back to one word per lane — same state"""
+    rng = np.random.default_rng(1000 * words + k)
+    genome = rng.integers(0, 4, 4000, dtype=np.uint8)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    seqs, quals = [], []
+    for _ in range(3000):
+        L = int(rng.integers(32 * (words - 1) + 1, 32 * words + 1))
+        a = int(rng.integers(0, genome.size - L))
+        s = acgt[genome[a:a + L]].copy()
+        q = np.full(L, ord("I"), np.uint8)
+        if rng.random() < 0.3 and L > 8:
+            p, n = int(rng.integers(0, L - 4)), int(rng.integers(1, 5))
+            if rng.random() < 0.5: s[p:p + n] = ord("N")
+            else: q[p:p + n] = ord("#")
+        seqs.append(s); quals.append(q)
+    seq = np.concatenate(seqs); qual = np.concatenate(quals)
+    off = np.concatenate([[0], np.cumsum([x.size for x in seqs])]).astype(np.int64)
+    og, gg = graph_pair(150_001, 200_003, 30_011, k=k, max_batch=15_000)
+    og.set_read_pair_distance(40); gg.setReadPairedKmerDistance(40)
+    for rc in (False, True):
+        og.add_reads(seq, qual, off, 3, rbo.STORE_READ_PAIRS | (rbo.REVCOMP if rc else 0))
+        st = gg.addReads(seq, qual, off, 3, reverseComplement=rc, storeReadPairedKmers=True)
+        assert_same_state(og, gg)
+    assert st.sorted_kmers < st.kmers or words == 1        # the prefilter did drop occurrences
