@@ -416,7 +416,7 @@ k_filter_windows_fast(const uint64_t *__restrict__ codes, const uint32_t *__rest
                       uint32_t *__restrict__ keepmask, uint32_t *__restrict__ total_spread, uint32_t dbg_flags,
                       uint32_t own_mask, uint32_t own_rank) {
     __shared__ uint64_t s_tf[25], s_tr[25];
-    __shared__ uint32_t s_ring[MPF ? 16 * 64 : 1];              // [slot][lane]: order of the m-mer ending at base (slot mod 16)
+    extern __shared__ uint32_t s_ring[];                        // [k-m+1][lane], dynamic: orders of the current block of m-mers / suffix minima of the previous one
     __shared__ unsigned long long s_bkt[MPF ? 16 * 64 : 1];     // [slot][lane]: image of the current bucket
     const uint32_t uk = (uint32_t)k, lane = threadIdx.x;
     if (threadIdx.x < 25) {
@@ -533,7 +533,7 @@ k_filter_reads(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ 
                uint32_t *__restrict__ cnt, uint32_t *__restrict__ keepmask, uint32_t *__restrict__ total_spread,
                uint32_t dbg_flags, uint32_t own_mask, uint32_t own_rank) {
     __shared__ uint64_t s_tf[25], s_tr[25];
-    __shared__ uint32_t s_ring[MPF ? 16 * 64 : 1];              // [slot][lane]: order of the m-mer ending at base (slot mod 16)
+    extern __shared__ uint32_t s_ring[];                        // [k-m+1][lane], dynamic: orders of the current block of m-mers / suffix minima of the previous one
     __shared__ unsigned long long s_bkt[MPF ? 16 * 64 : 1];     // [slot][lane]: image of the current bucket
     const uint32_t uk = (uint32_t)k, lane = threadIdx.x;
     if (threadIdx.x < 25) {
@@ -815,13 +815,14 @@ void launch_filter_windows(const rb_batch *b, int64_t w0, int64_t nw, int k, int
     if (!cache.tab) dbgf |= 1u;                       // no cache: ownership test only
     dim3 g(blocks_for(nw, 64)), t(64);
 #define RB_LAUNCH_FILT(M, P)                                                                                    \
-    hipLaunchKernelGGL((k_filter_windows_fast<M, P>), g, t, 0, s, b->codes, b->valid, b->word_read, b->woff, b->len, \
+    hipLaunchKernelGGL((k_filter_windows_fast<M, P>), g, t, ring_bytes, s, b->codes, b->valid, b->word_read, b->woff, b->len, \
                        w0, nw, k, first_read, pos_bits, seed, ordinal0, cache, mcache, cnt, keepmask, total_spread, dbgf, own_mask, own_rank)
     const bool use_m = mcache.tab && mcache.m <= (uint32_t)k && (uint32_t)k - mcache.m + 1u <= 16u;
+    const size_t ring_bytes = use_m ? ((size_t)k - mcache.m + 1u) * 64u * sizeof(uint32_t) : 0;   // LDS per wavefront: 12.7 KB -> 11.2 KB at k = 25
     if (const uint32_t C = read_lane_words(b, nw)) {
         dim3 gc(blocks_for(nw / C, 64));
 #define RB_LAUNCH_FC(M, P)                                                                                        \
-    hipLaunchKernelGGL((k_filter_reads<M, P>), gc, t, 0, s, b->codes, b->valid, b->word_read, b->len, w0, nw, k, C, \
+    hipLaunchKernelGGL((k_filter_reads<M, P>), gc, t, ring_bytes, s, b->codes, b->valid, b->word_read, b->len, w0, nw, k, C, \
                        first_read, pos_bits, seed, ordinal0, cache, mcache, cnt, keepmask, total_spread, dbgf, own_mask, own_rank)
         if (use_m) { if (mode == 0) RB_LAUNCH_FC(0, true); else if (mode == 2) RB_LAUNCH_FC(2, true); else RB_LAUNCH_FC(1, true); }
         else { if (mode == 0) RB_LAUNCH_FC(0, false); else if (mode == 2) RB_LAUNCH_FC(2, false); else RB_LAUNCH_FC(1, false); }

@@ -1026,6 +1026,15 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
                     return false;
                 }
                 for (int q = 0; q < 32; ++q) sb.total += spread[16 * q];
+                if (getenv("RB_WORD_STATS")) {   // development: how many words keep nothing?
+                    std::vector<uint32_t> hc((size_t)sb.nw);
+                    RB_HIP(hipMemcpy(hc.data(), g->chunk_cnt.p, (size_t)sb.nw * 4, hipMemcpyDeviceToHost));
+                    int64_t h[5] = {0, 0, 0, 0, 0}, waves = 0, empty_waves = 0;
+                    for (int64_t q = 0; q < sb.nw; ++q) { const uint32_t c = hc[(size_t)q]; ++h[c == 0 ? 0 : c <= 4 ? 1 : c <= 16 ? 2 : c < 32 ? 3 : 4]; }
+                    for (int64_t q = 0; q < sb.nw; q += 64) { bool any = false; for (int64_t z = q; z < std::min(q + 64, sb.nw); ++z) any |= hc[(size_t)z] != 0; ++waves; empty_waves += !any; }
+                    fprintf(stderr, "[word stats] words %lld: empty %.3f, 1-4 %.3f, 5-16 %.3f, 17-31 %.3f, 32 %.3f; empty 64-word groups %.3f\n", (long long)sb.nw,
+                            (double)h[0] / sb.nw, (double)h[1] / sb.nw, (double)h[2] / sb.nw, (double)h[3] / sb.nw, (double)h[4] / sb.nw, (double)empty_waves / waves);
+                }
                 if (sb.N) {
                     g->prof_begin(sp);
                     g->keys0.reserve((size_t)sb.N * 8); g->vals0.reserve((size_t)sb.N * 4);

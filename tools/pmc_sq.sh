@@ -13,6 +13,7 @@ from collections import defaultdict
 agg=defaultdict(lambda: defaultdict(float)); cnt=defaultdict(int)
 for r in csv.DictReader(open(sys.argv[1])):
     k=r["Kernel_Name"]
+    k=k.replace("(anonymous namespace)::","")
     k=re.sub(r"\(.*","",k).replace("void ","")
     if "rocprim" in k: k="rocprim:"+k.split("::")[-1][:40]
     agg[k][r["Counter_Name"]]+=float(r["Counter_Value"])
@@ -27,4 +28,4 @@ pass 1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS 
 pass 2 SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_VMEM_RD SQ_ACTIVE_INST_MISC
 pass 3 SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_BRANCH
 pass 4 SQ_INST_LEVEL_VMEM SQ_INST_LEVEL_LDS TCP_TCC_READ_REQ_LATENCY TCP_TCC_READ_REQ TA_BUSY TA_ADDR_STALLED_BY_TC_CYCLES TCP_PENDING_STALL_CYCLES
-head -8 $OUT/pass*.txt
+head -14 $OUT/pass1.txt $OUT/pass2.txt

@@ -1,13 +1,14 @@
 # A/B runs of bench.py under environment switches (development helper; run through gpurun)
 mkdir -p gpurun_out
-python -m pytest tests/test_gpu_parity.py tests/test_gpu_sharded.py -q -m gpu -x 2>&1 | tail -5
-run() { name=$1; shift; env "$@" python bench.py --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/v_$name.json 2> gpurun_out/v_$name.err; }
-run reads RB_X=0
-run reads2 RB_X=0
-run word RB_READ_LANES=0
+python -m pytest tests/test_gpu_parity.py -q -m gpu -x 2>&1 | tail -3
+run() { name=$1; shift; env "$@" python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/v_$name.json 2> gpurun_out/v_$name.err; }
+run base RB_X=0
+run mpf24 RB_MPF=24
+run base2 RB_X=0
+run mpf24b RB_MPF=24
 for f in gpurun_out/v_*.json; do echo $f; python - "$f" <<'PY'
 import json,sys
 d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-print(d['ms_per_step'], {k:d['stages_ms_per_step'][k] for k in ('filter_windows','hash_windows','sort_occurrences')}, d['config']['sorted_kmers_per_step'])
+print(d['ms_per_step'], {k:d['stages_ms_per_step'][k] for k in ('filter_windows','hash_windows','sort_occurrences')}, d['config']['sorted_kmers_per_step'], d['config']['conflict_ops_per_step'])
 PY
 done
