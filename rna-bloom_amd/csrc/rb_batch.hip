@@ -401,6 +401,101 @@ k_hash_windows_fast(const uint64_t *__restrict__ codes, const uint32_t *__restri
     }
 }
 
+// Emit pass after the prefilter, for sparse keep masks.  In steady state ~45% of the words keep no
+// window at all and most others keep 1-4, but k_hash_windows_fast walks all 64 words of a wavefront as
+// long as one of them keeps something — and the walker is bound by instruction issue.  Here a
+// wavefront takes RB_SPARSE_WORDS consecutive words, lists the ones that keep a window (ordered, in
+// LDS) and walks the list 64 entries at a time; the records of the listed words still follow each
+// other in the output, so the LDS slab / coalesced write-back is the same.
+#ifndef RB_SPARSE_WORDS
+#define RB_SPARSE_WORDS 512
+#endif
+template <int MODE>
+__global__ void __launch_bounds__(64)
+k_hash_windows_sparse(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
+                      const uint32_t *__restrict__ word_read, const uint32_t *__restrict__ woff,
+                      const uint32_t *__restrict__ len, int64_t w0, int64_t nw, int k,
+                      const uint32_t *__restrict__ chunk_off, uint32_t first_read, uint32_t pos_bits,
+                      uint64_t *__restrict__ keys, uint32_t *__restrict__ vals, const uint32_t *__restrict__ keepmask) {
+    constexpr uint32_t SLAB = RB_EMIT_SLAB, BW = RB_SPARSE_WORDS;
+    __shared__ uint64_t s_key[SLAB + SLAB / 32 + 1];
+    __shared__ uint32_t s_val[SLAB + SLAB / 32 + 1];
+    __shared__ uint64_t s_tf[25], s_tr[25];
+    __shared__ uint16_t s_list[BW];
+    const uint32_t uk = (uint32_t)k, lane = threadIdx.x;
+    const int64_t blk0 = (int64_t)blockIdx.x * BW;
+    const int64_t blk_end = (blk0 + BW < nw) ? blk0 + BW : nw;
+    const uint32_t O0 = chunk_off[blk0], O1 = chunk_off[blk_end];
+    if (O0 == O1) return;
+    if (threadIdx.x < 25) {
+        const uint32_t o = threadIdx.x / 5u, in = threadIdx.x % 5u;   // 0 = null, 1..4 = A,C,G,T
+        const uint64_t so = o ? seed_of(o - 1u) : 0ull, si = in ? seed_of(in - 1u) : 0ull;
+        const uint64_t sco = o ? seed_of(4u - o) : 0ull, sci = in ? seed_of(4u - in) : 0ull;
+        s_tf[threadIdx.x] = rotl(so, uk) ^ si;
+        s_tr[threadIdx.x] = rotr(sco, 1) ^ rotl(sci, uk - 1u);
+    }
+    uint32_t n_list = 0;                                           // uniform
+    for (uint32_t q = 0; q < BW; q += 64u) {
+        const int64_t i = blk0 + q + lane;
+        const bool ne = i < blk_end && chunk_off[i + 1] != chunk_off[i];
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(ne);
+        if (ne) s_list[n_list + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)(q + lane);
+        n_list += (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    const uint32_t sh_c = 2u * (uk - 1u), sh_v = uk - 1u;
+    for (uint32_t e0 = 0; e0 < n_list; e0 += 64u) {
+        const uint32_t e_last = (e0 + 64u < n_list) ? e0 + 63u : n_list - 1u;
+        // output range of this round's words, relative to O0
+        const uint32_t R0 = chunk_off[blk0 + s_list[e0]] - O0, R1 = chunk_off[blk0 + s_list[e_last] + 1] - O0;
+        // walker state (a lane without a word keeps nb = 0)
+        uint64_t clo = 0, chi = 0, vs = 0, f = 0, rv = 0, hc = 0, hv = 0;
+        uint32_t nb = 0, j = 0, run = 0, out = 0, rel = 0, b0 = 0, keep = 0;
+        if (e0 + lane < n_list) {
+            const int64_t i = blk0 + s_list[e0 + lane];
+            const int64_t w = w0 + i;
+            const uint32_t r = word_read[w], wr = woff[r], L = len[r];
+            const uint32_t c = (uint32_t)(w - wr);
+            b0 = c * 32u;
+            keep = keepmask[i];
+            const uint32_t nwords = (L + 31u) >> 5;
+            clo = codes[w]; chi = (c + 1u < nwords) ? codes[w + 1] : 0ull;
+            vs = (uint64_t)valid[w] | ((c + 1u < nwords) ? ((uint64_t)valid[w + 1] << 32) : 0ull);
+            nb = ((b0 + 32u + uk - 1u < L) ? b0 + 32u + uk - 1u : L) - b0;   // bases to walk (<= 62)
+            out = chunk_off[i] - O0;
+            rel = (r - first_read) << pos_bits;
+        }
+        for (uint32_t slab0 = R0; slab0 < R1; slab0 += SLAB) {
+            const uint32_t slab1 = (slab0 + SLAB < R1) ? slab0 + SLAB : R1;
+            while (j < nb && out < slab1) {
+                const uint32_t code = (uint32_t)clo & 3u, ok = (uint32_t)vs & 1u;
+                clo = (clo >> 2) | (chi << 62); chi >>= 2; vs >>= 1;
+                const uint32_t in5 = ok ? code + 1u : 0u;
+                const uint32_t out5 = ((uint32_t)(hv >> sh_v) & 1u) ? ((uint32_t)(hc >> sh_c) & 3u) + 1u : 0u;
+                const uint32_t t = out5 * 5u + in5;
+                if (MODE != 2) f = rotl(f, 1) ^ s_tf[t];
+                if (MODE != 0) rv = rotr(rv, 1) ^ s_tr[t];
+                hc = (hc << 2) | code; hv = (hv << 1) | ok;
+                run = ok ? run + 1u : 0u;
+                if (run >= uk && ((keep >> (j + 1u - uk)) & 1u)) {
+                    const uint32_t o = out - slab0, q = o + (o >> 5);
+                    s_key[q] = (MODE == 0) ? f : (MODE == 2) ? rv : canonical(f, rv);
+                    s_val[q] = rel | (b0 + j + 1u - uk);
+                    ++out;
+                }
+                ++j;
+            }
+            __syncthreads();
+            for (uint32_t x = threadIdx.x; x < slab1 - slab0; x += 64u) {
+                const uint32_t q = x + (x >> 5);
+                keys[O0 + slab0 + x] = s_key[q];
+                vals[O0 + slab0 + x] = s_val[q];
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // Prefilter pass: same walker as k_hash_windows_fast, but instead of emitting it decides for every
 // usable window whether the occurrence can change anything: it is dropped iff the cache knows the
 // k-mer (full 64-bit match) with counter exponent >= s and the occurrence's draw strength is < s.
@@ -854,6 +949,16 @@ void launch_hash_windows_masked(const rb_batch *b, int64_t w0, int64_t nw, int k
                                 const uint32_t *keepmask, uint32_t first_read, uint32_t pos_bits, uint64_t *keys, uint32_t *vals,
                                 hipStream_t s) {
     if (nw <= 0) return;
+    static const bool sparse = !(getenv("RB_SPARSE_EMIT") && atoi(getenv("RB_SPARSE_EMIT")) == 0);
+    if (keepmask && sparse) {
+        dim3 gs(blocks_for(nw, RB_SPARSE_WORDS)), ts(64);
+#define RB_LAUNCH_SP(M)                                                                                    \
+    hipLaunchKernelGGL(k_hash_windows_sparse<M>, gs, ts, 0, s, b->codes, b->valid, b->word_read, b->woff, \
+                       b->len, w0, nw, k, chunk_off, first_read, pos_bits, keys, vals, keepmask)
+        if (mode == 0) RB_LAUNCH_SP(0); else if (mode == 2) RB_LAUNCH_SP(2); else RB_LAUNCH_SP(1);
+#undef RB_LAUNCH_SP
+        return;
+    }
     dim3 g(blocks_for(nw, 64)), t(64);
 #define RB_LAUNCH_FASTM(M)                                                                            \
     hipLaunchKernelGGL(k_hash_windows_fast<M>, g, t, 0, s, b->codes, b->valid, b->word_read, b->woff, \

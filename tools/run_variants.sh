@@ -1,11 +1,10 @@
 # A/B runs of bench.py under environment switches (development helper; run through gpurun)
 mkdir -p gpurun_out
-python -m pytest tests/test_gpu_parity.py -q -m gpu -x 2>&1 | tail -3
+python -m pytest tests/test_gpu_parity.py tests/test_gpu_sharded.py -q -m gpu -x 2>&1 | tail -3
 run() { name=$1; shift; env "$@" python bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/v_$name.json 2> gpurun_out/v_$name.err; }
-run base RB_X=0
-run mpf24 RB_MPF=24
-run base2 RB_X=0
-run mpf24b RB_MPF=24
+run sparse RB_X=0
+run dense RB_SPARSE_EMIT=0
+run sparse2 RB_X=0
 for f in gpurun_out/v_*.json; do echo $f; python - "$f" <<'PY'
 import json,sys
 d=json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
