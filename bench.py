@@ -61,13 +61,17 @@ def algorithmic_bytes(stage, n_kmers, n_pairs, n_runs, words, n_sorted=None, gro
 
 
 # dominant-stage kernels in the committed rocprofv3 PMC summaries (profiles/r01_final_pmc_*.csv: separate
-# --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of this same command, values in KB per dispatch)
-PMC_KERNELS = {"filter_windows": "rb::k_filter_windows_fast", "hash_windows": "rb::k_hash_windows_fast",
-               "probe_claim": "k_probe", "resolve_apply": "k_resolve_apply", "pairs_insert": "k_pairs_insert"}
+# --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of this same command, values in KB per dispatch).
+# sort_occurrences is rocPRIM's onesweep: 1 histogram + 4 scatter dispatches per launch of the stage, under one kernel
+# name that also covers the (small) sorts of the conflict path, so its bytes are the name's total over the
+# number of sub-batches (= dispatches of k_probe) — an upper bound, the conflict sorts add < 8 %.
+PMC_KERNELS = {"filter_windows": "rb::k_filter_reads", "hash_windows": "rb::k_hash_windows_sparse",
+               "probe_claim": "k_probe", "resolve_apply": "k_resolve_apply", "pairs_insert": "k_pairs_insert",
+               "sort_occurrences": "rocprim::radix_sort_onesweep(pairs)"}
 
 
 def pmc_traffic(stage):
-    """HBM bytes per launch of the stage's kernel from the committed PMC summaries (None if absent).
+    """HBM bytes per launch of the stage's kernel(s) from the committed PMC summaries (None if absent).
     The stage kernels here issue random 8-byte / 4-byte accesses = single 64 B requests, so the guide's
     gfx950 x2 correction for 128 B streaming requests does not apply (calibrated against a known byte
     count of this access pattern)."""
@@ -79,11 +83,18 @@ def pmc_traffic(stage):
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             return None
-        for line in open(path).read().splitlines()[1:]:
-            cols = line.rsplit(",", 3)
-            if len(cols) == 4 and cols[0].startswith(kern):
-                tot += float(cols[3]) * 1024.0
-                break
+        rows = [line.rsplit(",", 3) for line in open(path).read().splitlines()[1:]]
+        rows = [r for r in rows if len(r) == 4]
+        hit = [r for r in rows if r[0].startswith(kern)]
+        if not hit:
+            return None
+        if stage == "sort_occurrences":
+            sub = [r for r in rows if r[0].startswith("k_probe")]
+            if not sub:
+                return None
+            tot += float(hit[0][2]) * 1024.0 / float(sub[0][1])
+        else:
+            tot += float(hit[0][3]) * 1024.0
     return tot or None
 
 

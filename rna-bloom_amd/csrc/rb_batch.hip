@@ -898,7 +898,7 @@ void launch_hash_windows(const rb_batch *b, int64_t w0, int64_t nw, int k, int m
 // words per read if the read-per-lane kernels apply (uniform batch of short reads), else 0: one word per lane
 // (RB_READ_LANES=0 forces the one-word kernels)
 static uint32_t read_lane_words(const rb_batch *b, int64_t nw) {
-    static const bool off = getenv("RB_READ_LANES") && atoi(getenv("RB_READ_LANES")) == 0;
+    const bool off = getenv("RB_READ_LANES") && atoi(getenv("RB_READ_LANES")) == 0;
     if (!off && b->wpr_uniform && b->wpr_uniform <= (uint32_t)RB_READ_WORDS && nw % b->wpr_uniform == 0) return b->wpr_uniform;
     return 0u;
 }
@@ -949,7 +949,7 @@ void launch_hash_windows_masked(const rb_batch *b, int64_t w0, int64_t nw, int k
                                 const uint32_t *keepmask, uint32_t first_read, uint32_t pos_bits, uint64_t *keys, uint32_t *vals,
                                 hipStream_t s) {
     if (nw <= 0) return;
-    static const bool sparse = !(getenv("RB_SPARSE_EMIT") && atoi(getenv("RB_SPARSE_EMIT")) == 0);
+    const bool sparse = !(getenv("RB_SPARSE_EMIT") && atoi(getenv("RB_SPARSE_EMIT")) == 0);
     if (keepmask && sparse) {
         dim3 gs(blocks_for(nw, RB_SPARSE_WORDS)), ts(64);
 #define RB_LAUNCH_SP(M)                                                                                    \
