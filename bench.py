@@ -167,7 +167,7 @@ def main():
         from rnabloom import sharded
         sr = sharded.ShardRank((dbg_bits, cbf_bytes, pk_bits, 2, 2, 2, k, 0, 1, local, 0, 1, a.batch_kmers), rank, world, local)
         sr.set_read_pair_distance(dist_pk)
-        pos_bits, rps = sharded.plan(150, k, world, a.batch_kmers or (1 << 30))
+        pos_bits, rps = sharded.plan(150, k, world, a.batch_kmers or sharded.default_batch_kmers(world, sr.mode))
         g = SimpleNamespace(profileEnable=lambda on: check_(sr, on), profileGet=lambda reset=True: prof_(sr, reset))
 
         def step():

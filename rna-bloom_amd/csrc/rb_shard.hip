@@ -879,7 +879,7 @@ int rb_shard_hash_begin(rb_graph *g, const rb_batch *b, int64_t first, int64_t n
         RB_REQUIRE(g && g->shard && b, "rb_shard_hash_begin: bad argument");
         RB_REQUIRE(b->device == g->p.device, "batch lives on device %d, shard on %d", b->device, g->p.device);
         RB_REQUIRE(first >= 0 && n >= 0 && first + n <= b->n_reads, "rb_shard_hash_begin: bad read range");
-        RB_REQUIRE(pos_bits >= 1 && pos_bits <= 31 && ((uint64_t)b->max_len >> pos_bits) == 0, "rb_shard_hash_begin: pos_bits too small for the reads");
+        RB_REQUIRE(pos_bits >= 1 && pos_bits <= 31 && ((uint64_t)(b->max_len >= (uint32_t)g->k ? b->max_len - (uint32_t)g->k : 0u) >> pos_bits) == 0, "rb_shard_hash_begin: pos_bits too small for the reads");
         RB_HIP(hipSetDevice(g->p.device));
         g->shard->prep.stage = 0;
         if (g->k > 31) return;                       // generic window-hash path: hash_group does it all
@@ -902,7 +902,7 @@ int rb_shard_hash_group(rb_graph *g, const rb_batch *b, int64_t first, int64_t n
         RB_REQUIRE(b->device == g->p.device, "batch lives on device %d, shard on %d", b->device, g->p.device);
         RB_REQUIRE(first >= 0 && n >= 0 && first + n <= b->n_reads, "rb_shard_hash_group: bad read range");
         RB_REQUIRE(pair_first >= first && pair_n >= 0 && pair_first + pair_n <= first + n, "rb_shard_hash_group: pair slice outside the sub-batch");
-        RB_REQUIRE(pos_bits >= 1 && pos_bits <= 31 && ((uint64_t)b->max_len >> pos_bits) == 0, "rb_shard_hash_group: pos_bits too small for the reads");
+        RB_REQUIRE(pos_bits >= 1 && pos_bits <= 31 && ((uint64_t)(b->max_len >= (uint32_t)g->k ? b->max_len - (uint32_t)g->k : 0u) >> pos_bits) == 0, "rb_shard_hash_group: pos_bits too small for the reads");
         RB_REQUIRE((uint64_t)n < (1ull << (32 - pos_bits)), "rb_shard_hash_group: too many reads for the occurrence id");
         ShardState *S = g->shard;
         RB_HIP(hipSetDevice(g->p.device));
@@ -1026,7 +1026,7 @@ int rb_shard_hash(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, int6
         RB_REQUIRE(b->device == g->p.device, "batch lives on device %d, shard on %d", b->device, g->p.device);
         RB_REQUIRE(first >= 0 && n >= 0 && first + n <= b->n_reads, "rb_shard_hash: bad read range");
         RB_REQUIRE(own_first >= first && own_n >= 0 && own_first + own_n <= first + n, "rb_shard_hash: own slice outside the sub-batch");
-        RB_REQUIRE(pos_bits >= 1 && pos_bits <= 31 && ((uint64_t)b->max_len >> pos_bits) == 0, "rb_shard_hash: pos_bits too small for the reads");
+        RB_REQUIRE(pos_bits >= 1 && pos_bits <= 31 && ((uint64_t)(b->max_len >= (uint32_t)g->k ? b->max_len - (uint32_t)g->k : 0u) >> pos_bits) == 0, "rb_shard_hash: pos_bits too small for the reads");
         RB_REQUIRE((uint64_t)n < (1ull << (32 - pos_bits)), "rb_shard_hash: too many reads for the occurrence id");
         ShardState *S = g->shard;
         RB_HIP(hipSetDevice(g->p.device));

@@ -78,7 +78,7 @@ class ShardRank:
         # "split": every rank hashes its slice of the reads and sends the surviving records to the k-mer owners
         # (hashing 1/G per rank, needs every link); "replicated": every rank hashes all reads and keeps its own
         # k-mers (no record exchange — better when two ranks share ONE xGMI link)
-        self.mode = mode or _MODE or ("split" if count >= 4 else "replicated")
+        self.mode = mode or default_mode(count)
         assert self.mode in ("split", "replicated")
         check(lib.rb_shard_set_cache_replication(self.h, int(self.mode == "split")))
 
@@ -497,13 +497,29 @@ def run_distributed(gen, group=None):
         return
 
 
+def default_mode(count):
+    return _MODE or ("split" if count >= 4 else "replicated")
+
+
+def default_batch_kmers(count, mode=None):
+    """k-mers per GLOBAL sub-batch when the caller names none.  With split reads a rank hashes 1/count of the
+    sub-batch and owns 1/count of its k-mers, so the sub-batch grows with the ranks (2^29 windows per rank, at
+    most 2^32): per-rank kernels stay large enough to fill the device (loopback, 8 ranks: 151 -> 126 ms per
+    rank from 2^30 to 2^32).  With replicated hashing every rank walks the whole sub-batch: 2^30."""
+    mode = mode or default_mode(count)
+    if mode != "split":
+        return 1 << 30
+    return min(1 << 32, (1 << 29) * max(2, count))
+
+
 def plan(max_len, k, count, max_batch_kmers=1 << 30):
     """(pos_bits, reads per GLOBAL sub-batch).  Every rank walks all reads of a sub-batch and keeps the
     k-mers it owns, so library scratch scales with max_batch_kmers / count per rank.  Bigger sub-batches
     merge more occurrences per run and need fewer exchange rounds; smaller ones keep the prefilter cache
-    fresher and conflicts rarer."""
+    fresher and conflicts rarer.  An occurrence id is (read << pos_bits) | window start, and window starts
+    stop at max_len - k."""
     pos_bits = 1
-    while (1 << pos_bits) <= max_len:
+    while (1 << pos_bits) <= max(1, max_len - k):
         pos_bits += 1
     reads = max(1, max_batch_kmers // max(1, max_len))
     reads = min(reads, (1 << (32 - pos_bits)) - 1)
@@ -518,7 +534,7 @@ class LoopbackCluster:
         params = (dbgbfNumBits, cbfNumBytes, pkbfNumBits, dbgbfNumHash, cbfNumHash, pkbfNumHash, k, int(stranded),
                   int(useReadPairedKmers), device, groupBits, rngSeed, maxBatchKmers)
         self.k, self.count = k, count
-        self.max_batch = maxBatchKmers or (1 << 30)
+        self.max_batch = maxBatchKmers or default_batch_kmers(count, mode)
         self.ranks = [ShardRank(params, r, count, device, mode) for r in range(count)]
 
     def setReadPairedKmerDistance(self, d):

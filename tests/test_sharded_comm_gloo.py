@@ -89,7 +89,11 @@ def test_run_distributed_equals_loopback(world, chunk, fuse):
 
 def test_plan_limits():
     from rnabloom.sharded import plan
+    from rnabloom.sharded import default_batch_kmers
     pos_bits, reads = plan(150, 25, 8, 1 << 30)
-    assert (1 << pos_bits) > 150 and reads < (1 << (32 - pos_bits)) and reads * 150 <= (1 << 30)
+    assert (1 << pos_bits) > 150 - 25 and reads < (1 << (32 - pos_bits)) and reads * 150 <= (1 << 30)
     pos_bits, reads = plan(100_000, 35, 2, 1 << 28)
-    assert (1 << pos_bits) > 100_000 and reads >= 1
+    assert (1 << pos_bits) > 100_000 - 35 and reads >= 1
+    pos_bits, reads = plan(150, 25, 8, default_batch_kmers(8, "split"))       # 2^32 windows
+    assert reads == (1 << 32) // 150 and pos_bits == 7 and reads < (1 << (32 - pos_bits))
+    assert default_batch_kmers(8, "replicated") == 1 << 30 and default_batch_kmers(4, "split") == 1 << 31

@@ -45,7 +45,7 @@ def main():
     batch = ReadBatch.synthetic(a.pairs, a.genome, 150, 300, 30, 0.001, 1e-4, 2.0, seed=0x5EED, device=0)   # shared by the ranks
     for r in ranks:
         r.set_read_pair_distance(max(1, 150 - k - 10))
-    pos_bits, rps = sharded.plan(150, k, G, a.batch_kmers or (1 << 30))
+    pos_bits, rps = sharded.plan(150, k, G, a.batch_kmers or sharded.default_batch_kmers(G, ranks[0].mode))
 
     def step():
         for r in ranks:
