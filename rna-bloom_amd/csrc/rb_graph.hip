@@ -483,6 +483,16 @@ __global__ void __launch_bounds__(64) k_conf_replay_big(FilterView fv, const uin
 // ---- paired k-mers: {,Canonical,ReverseComplement}PairedNTHashIterator + rpkbf.add ----
 // (R/bloom/hash/PairedNTHashIterator.java:56-83, CanonicalPaired… :36-60, ReverseComplementPaired…
 //  :33-56; R/RNABloom.java:587-591).  Pure OR => order independent => direct atomicOr.
+//
+// Two kernels.  k_pairs_reads (below) is the one that runs for k <= 31 and reads of at most 256 bases: one
+// read per lane, both windows rolled side by side.  k_pairs_insert is the general one (any k, any read
+// length, one thread per 32-base word, windows hashed from scratch and then rolled); it is compiled
+// WITHOUT optimisation on purpose: the optimised build sets ~2 % of the pair bits at wrong positions,
+// differently from run to run, as soon as a SIMD holds more than one of its wavefronts (> 65536 threads;
+// found by tests/test_gpu_fullsize.py, pinned by tests/test_gpu_parity.py::test_read_pairs_at_scale).
+// -O1, a forced s_waitcnt 0 after every instruction, dropping __restrict__, returning atomics and other
+// launch shapes all change the error rate, none of them to zero; unoptimised it is exact and 25x slower,
+// which is acceptable for the configurations that still reach it.
 // first unusable base at or after p (or L) — word-wise scan of the validity bits
 __device__ __forceinline__ uint32_t next_unusable(const uint32_t *__restrict__ vw, uint32_t p, uint32_t L) {
     while (p < L) {
@@ -493,7 +503,7 @@ __device__ __forceinline__ uint32_t next_unusable(const uint32_t *__restrict__ v
     return L;
 }
 template <int MODE>
-__global__ void k_pairs_insert(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
+__global__ void __attribute__((optnone)) k_pairs_insert(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
                                const uint32_t *__restrict__ word_read, const uint32_t *__restrict__ woff,
                                const uint32_t *__restrict__ len, int64_t w0, int64_t nw, int k, int dist,
                                uint32_t *bits, Mod mod, int num_hash, uint64_t kmul,
@@ -550,6 +560,121 @@ __global__ void k_pairs_insert(const uint64_t *__restrict__ codes, const uint32_
         p = plast + 1u;
     }
     if (cnt && n_pairs) atomicAdd(n_pairs, (unsigned long long)cnt);
+}
+
+// One read per lane (k <= 31, reads of <= 256 bases).  A pair (p, p + d) needs the window at p, the window at
+// p + d and no unusable base in [p, p + k + d).  The lane rolls the two windows side by side — the right one
+// over bases d.., the left one over bases 0.. — so a 150-base read with d = 115 takes L - d = 35 steps for its 11
+// pairs.  Unusable bases enter and leave the rolling hashes as null bases (see k_hash_windows_fast), and the
+// position of the last unusable base at or before the right window's end decides whether a pair exists: for
+// bases below d it is found once from the preloaded validity words, from d on the right stream keeps it.
+// The read's words are loaded into registers up front (static indices; a word boundary costs a select chain).
+// Sharded engine: with out_idx the global bit indices are written instead, at the per-word offsets
+// (chunk_off, relative to word w0) that launch_count_windows(k + d) + scan produced.
+template <int MODE>
+__global__ void __launch_bounds__(64)
+k_pairs_reads(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid, const uint32_t *__restrict__ woff,
+              const uint32_t *__restrict__ len, int64_t r0, int64_t nr, int64_t w0, int k, int dist, uint32_t *bits, Mod mod,
+              int num_hash, uint64_t kmul, unsigned long long *__restrict__ n_pairs, const uint32_t *__restrict__ chunk_off,
+              uint64_t *__restrict__ out_idx) {
+    __shared__ uint64_t s_tf[25], s_tr[25];
+    const uint32_t uk = (uint32_t)k, ud = (uint32_t)dist, span = uk + ud;
+    if (threadIdx.x < 25) {
+        const uint32_t o = threadIdx.x / 5u, in = threadIdx.x % 5u;   // 0 = null, 1..4 = A,C,G,T
+        const uint64_t so = o ? seed_of(o - 1u) : 0ull, si = in ? seed_of(in - 1u) : 0ull;
+        const uint64_t sco = o ? seed_of(4u - o) : 0ull, sci = in ? seed_of(4u - in) : 0ull;
+        s_tf[threadIdx.x] = rotl(so, uk) ^ si;
+        s_tr[threadIdx.x] = rotr(sco, 1) ^ rotl(sci, uk - 1u);
+    }
+    __syncthreads();
+    const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    uint32_t cnt = 0;
+    if (t < nr) {
+        const int64_t r = r0 + t;
+        const uint32_t wr = woff[r], L = len[r];
+        if (L >= span) {
+            const uint32_t nwords = (L + 31u) >> 5;
+            uint64_t carr[8];
+            uint32_t varr[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                carr[q] = 0; varr[q] = 0;
+                if ((uint32_t)q < nwords) { carr[q] = codes[wr + q]; varr[q] = valid[wr + q]; }
+            }
+            // last unusable base below d (as position + 1, 0 = none)
+            uint32_t lb = 0;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                if (32u * (uint32_t)q < ud) {
+                    const uint32_t hi = ud - 32u * (uint32_t)q;                       // positions of this word below d
+                    const uint32_t m = ~varr[q] & (hi >= 32u ? 0xFFFFFFFFu : ((1u << hi) - 1u));
+                    if (m) lb = 32u * (uint32_t)q + 32u - (uint32_t)__clz((int)m);
+                }
+            }
+            auto word_c = [&](uint32_t wi) { uint64_t v = 0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v = ((uint32_t)q == wi) ? carr[q] : v;
+                return v; };
+            auto word_v = [&](uint32_t wi) { uint32_t v = 0;
+#pragma unroll
+                for (int q = 0; q < 8; ++q) v = ((uint32_t)q == wi) ? varr[q] : v;
+                return v; };
+            uint64_t cR = word_c(ud >> 5) >> (2u * (ud & 31u)), cL = carr[0];
+            uint32_t vR = word_v(ud >> 5) >> (ud & 31u), vL = varr[0];
+            uint64_t fR = 0, rR = 0, fL = 0, rL = 0, hcR = 0, hcL = 0;
+            uint32_t hvR = 0, hvL = 0;
+            const uint32_t sh_c = 2u * (uk - 1u), sh_v = uk - 1u;
+            const uint32_t nsteps = L - ud;
+            const int64_t wrel = (int64_t)wr - w0;                  // the read's first word, relative to w0 (out_idx mode)
+            uint32_t obase = 0, ocnt = 0, oword = 0xFFFFFFFFu;
+#pragma nounroll
+            for (uint32_t j = 0; j < nsteps; ++j) {
+                const uint32_t e = ud + j;                            // base entering the right window
+                if (j && (e & 31u) == 0u) { cR = word_c(e >> 5); vR = word_v(e >> 5); }
+                if (j && (j & 31u) == 0u) { cL = word_c(j >> 5); vL = word_v(j >> 5); }
+                const uint32_t codeR = (uint32_t)cR & 3u, okR = vR & 1u, codeL = (uint32_t)cL & 3u, okL = vL & 1u;
+                cR >>= 2; vR >>= 1; cL >>= 2; vL >>= 1;
+                {
+                    const uint32_t in5 = okR ? codeR + 1u : 0u;
+                    const uint32_t out5 = ((hvR >> sh_v) & 1u) ? ((uint32_t)(hcR >> sh_c) & 3u) + 1u : 0u;
+                    const uint32_t tt = out5 * 5u + in5;
+                    fR = rotl(fR, 1) ^ s_tf[tt]; rR = rotr(rR, 1) ^ s_tr[tt];
+                    hcR = (hcR << 2) | codeR; hvR = (hvR << 1) | okR;
+                }
+                {
+                    const uint32_t in5 = okL ? codeL + 1u : 0u;
+                    const uint32_t out5 = ((hvL >> sh_v) & 1u) ? ((uint32_t)(hcL >> sh_c) & 3u) + 1u : 0u;
+                    const uint32_t tt = out5 * 5u + in5;
+                    fL = rotl(fL, 1) ^ s_tf[tt]; rL = rotr(rL, 1) ^ s_tr[tt];
+                    hcL = (hcL << 2) | codeL; hvL = (hvL << 1) | okL;
+                }
+                lb = okR ? lb : e + 1u;
+                if (j + 1u >= uk) {
+                    const uint32_t p = j + 1u - uk;                   // pair start: windows [p, p+k) and [p+d, p+d+k)
+                    if (lb <= p) {                                    // no unusable base in [p, p + span)
+                        uint64_t P;
+                        if (MODE == 0) P = combine(fL, fR);                 // PairedNTHashIterator.java:69
+                        else if (MODE == 2) P = combine(rR, rL);            // ReverseComplementPaired… :44
+                        else P = smin(combine(fL, fR), combine(rR, rL));    // CanonicalPaired… :44 (signed min)
+                        if (out_idx) {
+                            if ((p >> 5) != oword) { oword = p >> 5; obase = chunk_off[wrel + (int64_t)oword]; ocnt = 0; }
+                            for (int h = 0; h < num_hash; ++h)
+                                out_idx[((size_t)obase + ocnt) * (size_t)num_hash + h] = index_of(multi_hash(P, (uint32_t)h, kmul), mod);
+                            ++ocnt;
+                        } else {
+                            for (int h = 0; h < num_hash; ++h) bit_set(bits, index_of(multi_hash(P, (uint32_t)h, kmul), mod));
+                        }
+                        ++cnt;
+                    }
+                }
+            }
+        }
+    }
+    if (n_pairs) {
+        unsigned long long c = cnt;
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+        if (threadIdx.x == 0 && c) atomicAdd(n_pairs, c);
+    }
 }
 
 // ---- direct (order-independent) bit-filter ops and queries on arrays of base hashes ----
@@ -696,6 +821,24 @@ __global__ void k_iota(uint32_t *v, size_t n) {
 void rb::launch_pairs(rb_graph *g, const rb_batch *b, int64_t w0, int64_t nw, int mode_hash, const uint32_t *chunk_off,
                       uint64_t *out_idx, unsigned long long *pc, hipStream_t st) {
     if (!st) st = g->stream;
+    if (nw <= 0) return;
+    const bool general = g->k > 31 || b->max_len > 256u || (getenv("RB_PAIRS_GENERAL") && atoi(getenv("RB_PAIRS_GENERAL")));
+    if (!general) {
+        // the reads of words [w0, w0 + nw): both ends are read boundaries
+        const auto &wo = b->h_woff;
+        const int64_t r0 = std::lower_bound(wo.begin(), wo.end(), (uint32_t)w0) - wo.begin();
+        const int64_t r1 = std::lower_bound(wo.begin(), wo.end(), (uint32_t)(w0 + nw)) - wo.begin();
+        RB_REQUIRE(r0 < (int64_t)wo.size() && wo[(size_t)r0] == (uint32_t)w0 && r1 < (int64_t)wo.size() && wo[(size_t)r1] == (uint32_t)(w0 + nw),
+                   "launch_pairs: word range does not start and end at read boundaries");
+        if (r1 <= r0) return;
+        dim3 gr(blocks_for(r1 - r0, 64)), th(64);
+#define RB_LAUNCH_PR(M)                                                                                              \
+    hipLaunchKernelGGL(k_pairs_reads<M>, gr, th, 0, st, b->codes, b->valid, b->woff, b->len, r0, r1 - r0, w0, g->k, \
+                       g->read_d, g->rpk.bits, g->rpk.mod, g->rpk.num_hash, kmul_of(g->k), pc, chunk_off, out_idx)
+        if (mode_hash == 0) RB_LAUNCH_PR(0); else if (mode_hash == 2) RB_LAUNCH_PR(2); else RB_LAUNCH_PR(1);
+#undef RB_LAUNCH_PR
+        return;
+    }
     dim3 gr(blocks_for(nw)), th(TPB);
 #define RB_LAUNCH_PAIRS(M)                                                                                          \
     hipLaunchKernelGGL(k_pairs_insert<M>, gr, th, 0, st, b->codes, b->valid, b->word_read, b->woff, b->len, w0, nw, \

@@ -116,6 +116,16 @@ class NativeError(RuntimeError):
 
 
 def load():
+    # PyTorch (the multi-GPU driver's collectives) ships its own HIP / HSA runtime.  Two runtimes in one process
+    # cannot both open the device: loading librb_hip.so (which binds to /opt/rocm's) and importing torch afterwards
+    # ends in "no ROCm-capable device is detected" at the first HIP call.  So when torch is installed it is imported
+    # first and librb_hip.so binds to the runtime that is already loaded.  (A process that never imports torch —
+    # the reference's JVM through the JNI stub of INTEGRATION.md — can set RB_NO_TORCH_PRELOAD=1.)
+    if not os.environ.get("RB_NO_TORCH_PRELOAD"):
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     if not os.path.exists(LIB_PATH):
         raise ImportError("HIP library %s not built — run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(there is no CPU fallback)" % LIB_PATH)

@@ -443,3 +443,22 @@ def test_uniform_word_count_fuzz(words, k):
         st = gg.addReads(seq, qual, off, 3, reverseComplement=rc, storeReadPairedKmers=True)
         assert_same_state(og, gg)
     assert st.sorted_kmers < st.kmers or words == 1        # the prefilter did drop occurrences
+
+
+@pytest.mark.parametrize("general", [False, True])
+def test_read_pairs_at_scale(monkeypatch, general):
+    """200 000 synthetic 150-base reads against the oracle: enough wavefronts that every SIMD of the device holds
+    several of one kernel — the size at which the first paired-k-mer kernel set ~2 % of its bits at wrong
+    positions (optimised build of k_pairs_insert; smaller inputs were exact).  Both paired-k-mer kernels: one read
+    per lane (k_pairs_reads) and the general one (k_pairs_insert, compiled unoptimised)."""
+    if general:
+        monkeypatch.setenv("RB_PAIRS_GENERAL", "1")
+    n = 200_000
+    batch = ReadBatch.synthetic(n // 2, 2_000_000, 150, 300, 30, 0.002, 1e-3, 2.0, seed=99, device=0)
+    seq, off = batch.download(0, n)
+    og, gg = graph_pair(300_000_007, 300_000_007, 300_000_007, max_batch=0)
+    og.set_read_pair_distance(115); gg.setReadPairedKmerDistance(115)
+    og.add_reads(seq, None, off, 3, rbo.STORE_READ_PAIRS)
+    st = gg.addBatch(batch, storeReadPairedKmers=True, first=0, n=n)
+    assert st.pairs > 1_000_000
+    assert_same_state(og, gg)
