@@ -70,3 +70,33 @@ def test_strobemers_match_oracle():
         assert (h[a:b] == eh).all() and (s[a:b] == es).all() and (e[a:b] == ee).all()
         tot += len(eh)
     assert tot > 10000
+
+
+def test_long_reads_at_scale():
+    """6 000 long reads (~12 M bases): the k = 35 insert of the whole set against the oracle, minimizers and order-3
+    strobemers of the whole set in one call each, checked read by read at the beginning and at the end of the launch
+    (the device is full: a defect that needs several wavefronts of a kernel per SIMD shows only at this size)."""
+    reads = long_reads(6000, 9)
+    seq, _, off = rbo.pack_reads(reads)
+    sizes = (200_000_033, 200_000_033, 10_007)
+    og = rbo.Graph(*sizes, 2, 2, 2, 35, False, False, 4)
+    gg = G.BloomFilterDeBruijnGraph(*sizes, 2, 2, 2, 35, False, False, rngSeed=4)
+    so = og.add_reads(seq, None, off, 3, 0)
+    sg = gg.addReads(seq, None, off, 3)
+    assert sg.kmers == so.kmers > 9_000_000
+    assert np.array_equal(gg.exportFilter(N.DBGBF), og.dbgbf_bytes())
+    assert np.array_equal(gg.exportFilter(N.CBF), og.cbf_bytes())
+    sample = list(range(0, 25)) + list(range(len(reads) - 25, len(reads)))
+    for mode in (0, 1):
+        mo, h, p = G.minimizers(reads, 13, 15, mode)
+        assert mo[-1] > 9_000_000
+        for i in sample:
+            eh, ep = rbo.minimizers(reads[i], 13, 15, mode)
+            a, b = mo[i], mo[i + 1]
+            assert b - a == len(eh) and (h[a:b] == eh).all() and (p[a:b] == ep).all()
+    so_, h, s, e = G.strobemers(reads, 11, 3, 12, 61)
+    assert so_[-1] > 8_000_000
+    for i in sample:
+        eh, es, ee = rbo.strobemers(reads[i], 11, 3, 12, 61)
+        a, b = so_[i], so_[i + 1]
+        assert b - a == len(eh) and (h[a:b] == eh).all() and (s[a:b] == es).all() and (e[a:b] == ee).all()
