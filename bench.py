@@ -66,7 +66,7 @@ def algorithmic_bytes(stage, n_kmers, n_pairs, n_runs, words, n_sorted=None, gro
 # name that also covers the (small) sorts of the conflict path, so its bytes are the name's total over the
 # number of sub-batches (= dispatches of k_probe) — an upper bound, the conflict sorts add < 8 %.
 PMC_KERNELS = {"filter_windows": "rb::k_filter_reads", "hash_windows": "rb::k_hash_windows_sparse",
-               "probe_claim": "k_probe", "resolve_apply": "k_resolve_apply", "pairs_insert": "k_pairs_insert",
+               "probe_claim": "k_probe", "resolve_apply": "k_resolve_apply", "pairs_insert": "k_pairs_reads",
                "sort_occurrences": "rocprim::radix_sort_onesweep(pairs)"}
 
 
