@@ -484,7 +484,7 @@ __global__ void __launch_bounds__(64) k_conf_replay_big(FilterView fv, const uin
 // (R/bloom/hash/PairedNTHashIterator.java:56-83, CanonicalPaired… :36-60, ReverseComplementPaired…
 //  :33-56; R/RNABloom.java:587-591).  Pure OR => order independent => direct atomicOr.
 //
-// Two kernels.  k_pairs_reads (below) is the one that runs for k <= 31 and reads of at most 256 bases: one
+// Two kernels.  k_pairs_reads (below) is the one that runs for k <= 64 and reads of at most 384 bases: one
 // read per lane, both windows rolled side by side.  k_pairs_insert is the general one (any k, any read
 // length, one thread per 32-base word, windows hashed from scratch and then rolled); it is compiled
 // WITHOUT optimisation on purpose: the optimised build sets ~2 % of the pair bits at wrong positions,
@@ -562,7 +562,7 @@ __global__ void __attribute__((optnone)) k_pairs_insert(const uint64_t *__restri
     if (cnt && n_pairs) atomicAdd(n_pairs, (unsigned long long)cnt);
 }
 
-// One read per lane (k <= 31, reads of <= 256 bases).  A pair (p, p + d) needs the window at p, the window at
+// One read per lane (k <= 64, reads of <= 384 bases).  A pair (p, p + d) needs the window at p, the window at
 // p + d and no unusable base in [p, p + k + d).  The lane rolls the two windows side by side — the right one
 // over bases d.., the left one over bases 0.. — so a 150-base read with d = 115 takes L - d = 35 steps for its 11
 // pairs.  Unusable bases enter and leave the rolling hashes as null bases (see k_hash_windows_fast), and the
@@ -571,6 +571,7 @@ __global__ void __attribute__((optnone)) k_pairs_insert(const uint64_t *__restri
 // The read's words are loaded into registers up front (static indices; a word boundary costs a select chain).
 // Sharded engine: with out_idx the global bit indices are written instead, at the per-word offsets
 // (chunk_off, relative to word w0) that launch_count_windows(k + d) + scan produced.
+constexpr int PAIR_WORDS = 12;
 template <int MODE>
 __global__ void __launch_bounds__(64)
 k_pairs_reads(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid, const uint32_t *__restrict__ woff,
@@ -594,17 +595,17 @@ k_pairs_reads(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ v
         const uint32_t wr = woff[r], L = len[r];
         if (L >= span) {
             const uint32_t nwords = (L + 31u) >> 5;
-            uint64_t carr[8];
-            uint32_t varr[8];
+            uint64_t carr[PAIR_WORDS];
+            uint32_t varr[PAIR_WORDS];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
+            for (int q = 0; q < PAIR_WORDS; ++q) {
                 carr[q] = 0; varr[q] = 0;
                 if ((uint32_t)q < nwords) { carr[q] = codes[wr + q]; varr[q] = valid[wr + q]; }
             }
             // last unusable base below d (as position + 1, 0 = none)
             uint32_t lb = 0;
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
+            for (int q = 0; q < PAIR_WORDS; ++q) {
                 if (32u * (uint32_t)q < ud) {
                     const uint32_t hi = ud - 32u * (uint32_t)q;                       // positions of this word below d
                     const uint32_t m = ~varr[q] & (hi >= 32u ? 0xFFFFFFFFu : ((1u << hi) - 1u));
@@ -613,17 +614,18 @@ k_pairs_reads(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ v
             }
             auto word_c = [&](uint32_t wi) { uint64_t v = 0;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) v = ((uint32_t)q == wi) ? carr[q] : v;
+                for (int q = 0; q < PAIR_WORDS; ++q) v = ((uint32_t)q == wi) ? carr[q] : v;
                 return v; };
             auto word_v = [&](uint32_t wi) { uint32_t v = 0;
 #pragma unroll
-                for (int q = 0; q < 8; ++q) v = ((uint32_t)q == wi) ? varr[q] : v;
+                for (int q = 0; q < PAIR_WORDS; ++q) v = ((uint32_t)q == wi) ? varr[q] : v;
                 return v; };
             uint64_t cR = word_c(ud >> 5) >> (2u * (ud & 31u)), cL = carr[0];
             uint32_t vR = word_v(ud >> 5) >> (ud & 31u), vL = varr[0];
-            uint64_t fR = 0, rR = 0, fL = 0, rL = 0, hcR = 0, hcL = 0;
-            uint32_t hvR = 0, hvL = 0;
-            const uint32_t sh_c = 2u * (uk - 1u), sh_v = uk - 1u;
+            // histories of the last 64 bases of each stream: codes in 128 bits (lo = the latest 32), usable bits in 64
+            uint64_t fR = 0, rR = 0, fL = 0, rL = 0, hcR = 0, hcR2 = 0, hcL = 0, hcL2 = 0, hvR = 0, hvL = 0;
+            const uint32_t sh_v = uk - 1u, sh_c = 2u * ((uk - 1u) & 31u);
+            const bool far = uk > 32u;                                // the outgoing base sits in the older half
             const uint32_t nsteps = L - ud;
             const int64_t wrel = (int64_t)wr - w0;                  // the read's first word, relative to w0 (out_idx mode)
             uint32_t obase = 0, ocnt = 0, oword = 0xFFFFFFFFu;
@@ -636,17 +638,17 @@ k_pairs_reads(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ v
                 cR >>= 2; vR >>= 1; cL >>= 2; vL >>= 1;
                 {
                     const uint32_t in5 = okR ? codeR + 1u : 0u;
-                    const uint32_t out5 = ((hvR >> sh_v) & 1u) ? ((uint32_t)(hcR >> sh_c) & 3u) + 1u : 0u;
+                    const uint32_t out5 = ((uint32_t)(hvR >> sh_v) & 1u) ? ((uint32_t)((far ? hcR2 : hcR) >> sh_c) & 3u) + 1u : 0u;
                     const uint32_t tt = out5 * 5u + in5;
                     fR = rotl(fR, 1) ^ s_tf[tt]; rR = rotr(rR, 1) ^ s_tr[tt];
-                    hcR = (hcR << 2) | codeR; hvR = (hvR << 1) | okR;
+                    hcR2 = (hcR2 << 2) | (hcR >> 62); hcR = (hcR << 2) | codeR; hvR = (hvR << 1) | okR;
                 }
                 {
                     const uint32_t in5 = okL ? codeL + 1u : 0u;
-                    const uint32_t out5 = ((hvL >> sh_v) & 1u) ? ((uint32_t)(hcL >> sh_c) & 3u) + 1u : 0u;
+                    const uint32_t out5 = ((uint32_t)(hvL >> sh_v) & 1u) ? ((uint32_t)((far ? hcL2 : hcL) >> sh_c) & 3u) + 1u : 0u;
                     const uint32_t tt = out5 * 5u + in5;
                     fL = rotl(fL, 1) ^ s_tf[tt]; rL = rotr(rL, 1) ^ s_tr[tt];
-                    hcL = (hcL << 2) | codeL; hvL = (hvL << 1) | okL;
+                    hcL2 = (hcL2 << 2) | (hcL >> 62); hcL = (hcL << 2) | codeL; hvL = (hvL << 1) | okL;
                 }
                 lb = okR ? lb : e + 1u;
                 if (j + 1u >= uk) {
@@ -822,7 +824,7 @@ void rb::launch_pairs(rb_graph *g, const rb_batch *b, int64_t w0, int64_t nw, in
                       uint64_t *out_idx, unsigned long long *pc, hipStream_t st) {
     if (!st) st = g->stream;
     if (nw <= 0) return;
-    const bool general = g->k > 31 || b->max_len > 256u || (getenv("RB_PAIRS_GENERAL") && atoi(getenv("RB_PAIRS_GENERAL")));
+    const bool general = g->k > 64 || b->max_len > 32u * (uint32_t)PAIR_WORDS || (getenv("RB_PAIRS_GENERAL") && atoi(getenv("RB_PAIRS_GENERAL")));
     if (!general) {
         // the reads of words [w0, w0 + nw): both ends are read boundaries
         const auto &wo = b->h_woff;

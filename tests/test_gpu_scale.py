@@ -26,22 +26,23 @@ def same_state(og, g, pairs=True):
         assert np.array_equal(g.exportFilter(N.RPKBF), og.rpkbf_bytes()), "rpkbf differs"
 
 
-def synthetic(n_reads, genome=3_000_000, err=0.002, n_rate=1e-3, seed=5):
-    batch = ReadBatch.synthetic(n_reads // 2, genome, 150, 300, 30, err, n_rate, 2.0, seed=seed, device=0)
+def synthetic(n_reads, genome=3_000_000, err=0.002, n_rate=1e-3, seed=5, read_len=150):
+    batch = ReadBatch.synthetic(n_reads // 2, genome, read_len, 2 * read_len, 30, err, n_rate, 2.0, seed=seed, device=0)
     seq, off = batch.download(0, n_reads)
     return batch, seq, off
 
 
-@pytest.mark.parametrize("k,stranded,dist", [(25, False, 115), (31, True, 100), (35, False, 90), (64, True, 40)])
-def test_insert_at_scale(k, stranded, dist):
-    n = 200_000
-    batch, seq, off = synthetic(n, seed=k)
+@pytest.mark.parametrize("k,stranded,dist,read_len", [(25, False, 115, 150), (31, True, 100, 150), (35, False, 90, 150), (64, True, 40, 150),
+                                                      (25, False, 250, 300), (33, False, 60, 100)])
+def test_insert_at_scale(k, stranded, dist, read_len):
+    n = 200_000 if read_len <= 150 else 100_000
+    batch, seq, off = synthetic(n, seed=k + read_len, read_len=read_len)
     og = rbo.Graph(BITS, BITS, BITS, 2, 2, 2, k, stranded, True, 3)
     g = BloomFilterDeBruijnGraph(BITS, BITS, BITS, 2, 2, 2, k, stranded, True, rngSeed=3)
     og.set_read_pair_distance(dist); g.setReadPairedKmerDistance(dist)
     og.add_reads(seq, None, off, 3, rbo.STORE_READ_PAIRS)
     st = g.addBatch(batch, storeReadPairedKmers=True, first=0, n=n)
-    assert st.kmers > 60 * n and st.pairs > n
+    assert st.kmers > (read_len - k) * n // 2 and st.pairs > n
     same_state(og, g)
     # second pass over the same reads, reverse-complemented, counting only what is present
     og.add_reads(seq, None, off, 3, rbo.REVCOMP | rbo.COUNT_IF_PRESENT)

@@ -1,5 +1,7 @@
+"""Development aid: insert N synthetic reads on the GPU three times and compare the three filters with the CPU oracle
+(missing / extra bits of the read-pair filter, equality of dbgbf and cbf).  usage: compare_with_oracle.py N [first [total]]"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, os.environ.get("RB_TREE", "rna-bloom_amd"))):
     sys.path.insert(0, p)
 import numpy as np
