@@ -172,6 +172,19 @@ int rb_graph_kmers(rb_graph *g, const char *seq, const int64_t *offsets, int64_t
 int rb_graph_neighbors(rb_graph *g, const uint64_t *f, const uint64_t *r, const uint8_t *char_out,
                        size_t n, int direction, uint64_t *f4, uint64_t *r4, float *count4);
 
+/* Greedy maximum-coverage walks, batched: the loop the reference runs around Kmer.getMaxCovSuccessor /
+ * getMaxCovPredecessor (R/graph/Kmer.java:301-355) in GraphUtils.getMaxCoveragePath (R/util/GraphUtils.java:1591-1675)
+ * — one JNI call per batch of walks instead of 4 graph.getCount calls per step.  seeds / targets: n x k bases
+ * (ASCII, left to right; targets may be NULL).  direction 0 extends to the right (successors), 1 to the left
+ * (predecessors).  Per step the best neighbour is the first strict maximum of graph.getCount among A,C,G,T
+ * with count >= min_cov.  Walk i ends with out_reason[i] = 0 no such neighbour, 1 the best neighbour is the
+ * target (not appended), 2 it is a k-mer the walk appended before (not appended; Kmer.equals: same bases),
+ * 3 `bound` k-mers appended, 4 the seed holds a base outside ACGTU.  out_len[i] appended k-mers; for walk i and
+ * step j < out_len[i]: out_bases[i*bound + j] the base added (last base of the k-mer for direction 0, first base
+ * for direction 1), out_f / out_r (may be NULL) / out_count its forward hash, reverse hash, graph.getCount. */
+int rb_graph_walk(rb_graph *g, const char *seeds, const char *targets, size_t n, int direction, int bound, float min_cov,
+                  char *out_bases, uint64_t *out_f, uint64_t *out_r, float *out_count, int32_t *out_len, uint8_t *out_reason);
+
 /* ---- filter state: popcount / FPR / raw bytes (the on-disk format of
  *      R/bloom/BloomFilter.java:113-124 is exactly these bytes,
  *      R/bloom/buffer/UnsafeByteBuffer.java:160-201) ---- */

@@ -322,3 +322,40 @@ class Graph:
         of = np.zeros(4, np.uint64); orr = np.zeros(4, np.uint64); c = np.zeros(4, np.float32)
         self.L.rbo_graph_neighbors(self.g, int(f), int(r), char_out, direction, _p(of), _p(orr), _p(c))
         return of, orr, c
+
+
+def walk_max_cov(og, seed, direction, bound, min_cov=1.0, target=None, k=25, stranded=False):
+    """Restatement of the loop GraphUtils.getMaxCoveragePath runs in each direction (R/util/GraphUtils.java:1603-1620
+    to the right with Kmer.getMaxCovSuccessor, :1629-1672 to the left with getMaxCovPredecessor; R/graph/Kmer.java:301-355:
+    the FIRST strict maximum of graph.getCount among A,C,G,T with count >= minKmerCov).  Returns (appended bases as
+    bytes, counts, reason): 0 no neighbour, 1 the best neighbour equals the target (not appended), 2 it equals a k-mer
+    appended before (not appended), 3 bound reached, 4 the seed has a base outside ACGTU."""
+    seed = _b(seed).upper().replace(b"U", b"T")
+    if len(seed) != k or any(c not in b"ACGT" for c in seed):
+        return b"", [], 4
+    target = _b(target).upper().replace(b"U", b"T") if target is not None else None
+    _, fr = hash_region(seed, k, 1, 1)
+    f, r = int(fr[0, 0]), int(fr[0, 1])
+    cur = seed
+    seen = set()
+    out, counts = bytearray(), []
+    while len(out) < bound:
+        char_out = cur[0] if direction == 0 else cur[-1]
+        f4, r4, c4 = og.neighbors(f, r, char_out, direction)
+        best = -1
+        best_c = -1.0
+        for i in range(4):
+            if c4[i] >= min_cov and c4[i] > best_c:
+                best, best_c = i, float(c4[i])
+        if best < 0:
+            return bytes(out), counts, 0
+        nb = b"ACGT"[best:best + 1]
+        nxt = (cur[1:] + nb) if direction == 0 else (nb + cur[:-1])
+        if target is not None and nxt == target:
+            return bytes(out), counts, 1
+        if nxt in seen:
+            return bytes(out), counts, 2
+        seen.add(nxt)
+        out += nb; counts.append(best_c)
+        cur, f, r = nxt, int(f4[best]), int(r4[best])
+    return bytes(out), counts, 3

@@ -795,6 +795,95 @@ __global__ void k_neighbors(FilterView fv, int stranded, int k, int direction, c
     c4[t] = graph_count(fv, stranded ? nf : smin(nf, nr));
 }
 
+// ---- greedy maximum-coverage walk: the loop around Kmer.getMaxCovSuccessor / getMaxCovPredecessor ----
+// One lane per walk (R/util/GraphUtils.java:1591-1675 getMaxCoveragePath runs two of them; :1906-1990 the
+// lookahead-free part of greedyExtend*).  Per step: the 4 neighbours in order A,C,G,T
+// ({,Canonical}{Successors,Predecessors}NTHashIterator), graph.getCount of each, the FIRST strict maximum
+// among those with count >= min_cov (R/graph/Kmer.java:301-355).  The walk ends when there is none (reason 0),
+// when the best neighbour IS the target k-mer (1; not appended), when it is a k-mer the walk already appended
+// (2; not appended; Kmer.equals compares bytes: hashes are compared first, then the bases), or after `bound`
+// appended k-mers (3); a seed with a base outside ACGTU ends at once (4).
+// seq[i]: for a right walk the seed's bases followed by the appended ones; for a left walk the seed's bases
+// REVERSED followed by the prepended ones — either way k-mer number j of the walk (0-based) is seq[j+1 .. j+k].
+__global__ void k_walk_max_cov(FilterView fv, int stranded, int k, int direction, const uint8_t *__restrict__ seeds,
+                               const uint8_t *__restrict__ targets, size_t n, int bound, float min_cov,
+                               uint8_t *__restrict__ seq, uint64_t *__restrict__ out_f, uint64_t *__restrict__ out_r,
+                               float *__restrict__ out_c, int32_t *__restrict__ out_len, uint8_t *__restrict__ out_reason) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t uk = (uint32_t)k;
+    const size_t stride = (size_t)k + (size_t)bound;
+    uint8_t *sq = seq + i * stride;
+    uint64_t *pf = out_f + i * (size_t)bound, *pr = out_r + i * (size_t)bound;
+    float *pc = out_c + i * (size_t)bound;
+    // hashes of the seed (and of the target) from scratch: NTHash.java:332-337, 367-373
+    auto hash_kmer = [&](const uint8_t *b, uint64_t &f, uint64_t &r) -> bool {
+        f = 0; r = 0;
+        for (uint32_t q = 0; q < uk; ++q) {
+            const uint32_t c = code_of_char(b[q]);
+            if (c > 3u) return false;
+            f = rotl(f, 1) ^ seed_of(c);
+            r ^= rotl(seed_of(3u - c), q);
+        }
+        return true;
+    };
+    uint64_t f, r, tf = 0, tr = 0;
+    const uint8_t *sb = seeds + i * (size_t)k;
+    if (!hash_kmer(sb, f, r)) { out_len[i] = 0; out_reason[i] = 4; return; }
+    const uint8_t *tb = targets ? targets + i * (size_t)k : nullptr;
+    bool has_target = tb && hash_kmer(tb, tf, tr);
+    for (uint32_t q = 0; q < uk; ++q) sq[q] = (direction == 0) ? sb[q] : sb[uk - 1u - q];
+    const uint8_t acgt[4] = {'A', 'C', 'G', 'T'};
+    int len = 0;
+    uint8_t reason = 3;
+    while (len < bound) {
+        const uint32_t oc = code_of_char(sq[len]);            // base leaving: first base (right walk) / last base (left walk)
+        const uint64_t s_out = seed_of(oc), sc_out = seed_of(3u - oc);
+        float best_c = -1.0f;
+        uint64_t best_f = 0, best_r = 0;
+        uint32_t best_in = 0;
+        for (uint32_t in = 0; in < 4u; ++in) {
+            uint64_t nf, nr = 0;
+            if (direction == 0) {
+                nf = rotl(f, 1) ^ rotl(s_out, uk) ^ seed_of(in);
+                if (!stranded) nr = rotr(r, 1) ^ rotr(sc_out, 1) ^ rotl(seed_of(3u - in), uk - 1u);
+            } else {
+                nf = rotr(f, 1) ^ rotr(s_out, 1) ^ rotl(seed_of(in), uk - 1u);
+                if (!stranded) nr = rotl(r, 1) ^ rotl(sc_out, uk) ^ seed_of(3u - in);
+            }
+            const float c = graph_count(fv, stranded ? nf : smin(nf, nr));
+            if (c >= min_cov && c > best_c) { best_c = c; best_f = nf; best_r = nr; best_in = in; }
+        }
+        if (best_c < 0.0f) { reason = 0; break; }
+        const uint8_t nb = acgt[best_in];
+        // bases of the candidate: seq[len+1 .. len+k-1] + nb
+        auto same_as = [&](const uint8_t *other_fwd_or_rev, bool other_is_seq) -> bool {   // other: k bases in walk orientation
+            for (uint32_t q = 0; q + 1u < uk; ++q) if (code_of_char(sq[(size_t)len + 1u + q]) != code_of_char(other_fwd_or_rev[q])) return false;
+            (void)other_is_seq;
+            return code_of_char(other_fwd_or_rev[uk - 1u]) == best_in;
+        };
+        if (has_target && best_f == tf) {
+            bool eq = true;                                    // target bases are given left to right
+            for (uint32_t q = 0; q < uk && eq; ++q) {
+                const uint8_t cb = (q + 1u < uk) ? sq[(size_t)len + 1u + q] : nb;          // candidate in walk orientation
+                const uint8_t tq = (direction == 0) ? tb[q] : tb[uk - 1u - q];
+                eq = code_of_char(cb) == code_of_char(tq);
+            }
+            if (eq) { reason = 1; break; }
+        }
+        bool seen = false;
+        for (int j = 0; j < len && !seen; ++j)
+            if (pf[j] == best_f && same_as(sq + (size_t)j + 1u, true)) seen = true;
+        if (seen) { reason = 2; break; }
+        sq[(size_t)uk + (size_t)len] = nb;
+        pf[len] = best_f; pr[len] = best_r; pc[len] = best_c;
+        f = best_f; r = best_r;
+        ++len;
+    }
+    out_len[i] = len;
+    out_reason[i] = reason;
+}
+
 // ---- popcounts (UnsafeByteBuffer.bitPopCount :131-150 / popCount :121-129) ----
 __global__ void k_popcount_bits(const uint32_t *__restrict__ w, size_t n_words, unsigned long long *out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1629,6 +1718,40 @@ int rb_graph_neighbors(rb_graph *g, const uint64_t *f, const uint64_t *r, const 
         RB_HIP(hipMemcpyAsync(f4, g->qbuf1.p, n * 32, hipMemcpyDeviceToHost, s));
         if (r4) RB_HIP(hipMemcpyAsync(r4, g->qbuf2.p, n * 32, hipMemcpyDeviceToHost, s));
         RB_HIP(hipMemcpyAsync(count4, g->qbuf3.p, n * 16, hipMemcpyDeviceToHost, s));
+        RB_HIP(hipStreamSynchronize(s));
+    });
+}
+
+int rb_graph_walk(rb_graph *g, const char *seeds, const char *targets, size_t n, int direction, int bound, float min_cov,
+                  char *out_bases, uint64_t *out_f, uint64_t *out_r, float *out_count, int32_t *out_len, uint8_t *out_reason) {
+    return guarded([&] {
+        RB_REQUIRE(g && (n == 0 || (seeds && out_bases && out_f && out_count && out_len && out_reason)), "rb_graph_walk: null argument");
+        RB_REQUIRE(direction == 0 || direction == 1, "rb_graph_walk: direction must be 0 (right) or 1 (left)");
+        RB_REQUIRE(bound >= 1 && bound <= (1 << 20), "rb_graph_walk: bound out of range [1, 2^20]");
+        RB_REQUIRE(!g->shard, "rb_graph_walk: queries are not available on a shard handle");
+        if (!n) return;
+        RB_HIP(hipSetDevice(g->p.device));
+        hipStream_t s = g->stream;
+        const size_t k = (size_t)g->k, nb = n * (size_t)bound, stride = k + (size_t)bound;
+        g->qbuf0.reserve(n * k * 2 + n * stride + 64);          // seeds | targets | seq
+        g->qbuf1.reserve(nb * 8); g->qbuf2.reserve(nb * 8); g->qbuf3.reserve(nb * 4 + n * 4 + n + 64);
+        uint8_t *dseed = g->qbuf0.as<uint8_t>(), *dtarget = dseed + n * k, *dseq = dtarget + n * k;
+        float *dc = g->qbuf3.as<float>();
+        int32_t *dlen = reinterpret_cast<int32_t *>(dc + nb);
+        uint8_t *dreason = reinterpret_cast<uint8_t *>(dlen + n);
+        RB_HIP(hipMemcpyAsync(dseed, seeds, n * k, hipMemcpyHostToDevice, s));
+        if (targets) RB_HIP(hipMemcpyAsync(dtarget, targets, n * k, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_walk_max_cov, dim3(blocks_for((int64_t)n, 64)), dim3(64), 0, s, g->view(0, 0), (int)g->stranded, g->k, direction,
+                           dseed, targets ? dtarget : (const uint8_t *)nullptr, n, bound, min_cov, dseq, g->qbuf1.as<uint64_t>(),
+                           g->qbuf2.as<uint64_t>(), dc, dlen, dreason);
+        RB_HIP(hipGetLastError());
+        RB_HIP(hipMemcpyAsync(out_len, dlen, n * 4, hipMemcpyDeviceToHost, s));
+        RB_HIP(hipMemcpyAsync(out_reason, dreason, n, hipMemcpyDeviceToHost, s));
+        RB_HIP(hipMemcpyAsync(out_f, g->qbuf1.p, nb * 8, hipMemcpyDeviceToHost, s));
+        if (out_r) RB_HIP(hipMemcpyAsync(out_r, g->qbuf2.p, nb * 8, hipMemcpyDeviceToHost, s));
+        RB_HIP(hipMemcpyAsync(out_count, dc, nb * 4, hipMemcpyDeviceToHost, s));
+        // the appended bases of walk i are seq[i][k .. k+len)
+        RB_HIP(hipMemcpy2DAsync(out_bases, (size_t)bound, dseq + k, stride, (size_t)bound, n, hipMemcpyDeviceToHost, s));
         RB_HIP(hipStreamSynchronize(s));
     });
 }

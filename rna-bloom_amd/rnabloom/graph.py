@@ -232,6 +232,25 @@ class BloomFilterDeBruijnGraph:
         check(lib.rb_graph_neighbors(self.h, _ptr(f), _ptr(r), _ptr(ch), n, direction, _ptr(f4), _ptr(r4), _ptr(c4)))
         return f4, r4, c4
 
+    def walkMaxCov(self, seeds, direction, bound, minKmerCov=1.0, targets=None):
+        """Batched greedy maximum-coverage walks (the loop around Kmer.getMaxCovSuccessor / getMaxCovPredecessor,
+        R/graph/Kmer.java:301-355, as GraphUtils.getMaxCoveragePath runs it, R/util/GraphUtils.java:1591-1675).
+        seeds / targets: k-mers as bytes.  Returns (bases[n, bound], f[n, bound], r[n, bound], count[n, bound], len[n],
+        reason[n]); reason: 0 dead end, 1 reached the target, 2 met a k-mer of the walk again, 3 bound, 4 invalid seed."""
+        n = len(seeds)
+        k = self.k
+        sb = np.frombuffer(b"".join(seeds), np.uint8) if n else np.zeros(0, np.uint8)
+        assert sb.size == n * k, "every seed must have k bases"
+        tb = None
+        if targets is not None:
+            tb = np.frombuffer(b"".join(targets), np.uint8)
+            assert tb.size == n * k
+        bases = np.zeros((n, bound), np.uint8); f = np.zeros((n, bound), np.uint64); r = np.zeros((n, bound), np.uint64)
+        c = np.zeros((n, bound), np.float32); ln = np.zeros(n, np.int32); reason = np.zeros(n, np.uint8)
+        check(lib.rb_graph_walk(self.h, _ptr(sb), _ptr(tb) if tb is not None else None, n, direction, bound, float(minKmerCov),
+                                _ptr(bases), _ptr(f), _ptr(r), _ptr(c), _ptr(ln), _ptr(reason)))
+        return bases, f, r, c, ln, reason
+
     # ---- filter state ----
     def filterSize(self, which):
         s, nb, h = C.c_int64(), C.c_int64(), C.c_int()

@@ -462,3 +462,54 @@ def test_read_pairs_at_scale(monkeypatch, general):
     st = gg.addBatch(batch, storeReadPairedKmers=True, first=0, n=n)
     assert st.pairs > 1_000_000
     assert_same_state(og, gg)
+
+
+@pytest.mark.parametrize("stranded", [False, True])
+def test_max_cov_walks_match_oracle(stranded):
+    """rb_graph_walk: batched greedy maximum-coverage walks (Kmer.getMaxCovSuccessor / getMaxCovPredecessor in the loop
+    of GraphUtils.getMaxCoveragePath) against the step-by-step restatement over the oracle graph: appended bases, counts,
+    length and stop reason, both directions, several coverage thresholds, with and without a target, seeds with N."""
+    (ls, lq, off), _ = make_reads(2000, 6000, 0.004, 1e-3, seed=31)
+    og, gg = graph_pair(400_009, 2_000_003, 10_007, stranded=stranded, pairs=False)
+    og.add_reads(ls, lq, off, 3, 0); gg.addReads(ls, lq, off, 3)
+    rng = np.random.default_rng(5)
+    seeds, targets = [], []
+    for _ in range(400):
+        r = int(rng.integers(0, len(off) - 1)); p = int(rng.integers(0, 150 - 25 - 40))
+        s = bytes(ls[off[r] + p: off[r] + p + 25])
+        seeds.append(s)
+        q = p + int(rng.integers(1, 40))
+        targets.append(bytes(ls[off[r] + q: off[r] + q + 25]) if rng.random() < 0.7 else bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), 25)))
+    seeds[7] = seeds[7][:10] + b"N" + seeds[7][11:]
+    seeds[8] = seeds[8].lower()
+    reasons = set()
+    for direction in (0, 1):
+        for min_cov, bound, use_t in ((1.0, 60, True), (2.0, 35, False), (4.0, 10, True), (1.0, 1, True)):
+            tg = targets if use_t else None
+            if direction == 1 and tg is not None:      # walking left: aim at a k-mer to the left of the seed instead
+                tg = [bytes(ls[off[0] + 5: off[0] + 30])] * len(seeds)
+            bases, f, r, c, ln, reason = gg.walkMaxCov(seeds, direction, bound, min_cov, tg)
+            for i, s in enumerate(seeds):
+                eb, ec, er = rbo.walk_max_cov(og, s, direction, bound, min_cov, tg[i] if tg is not None else None, stranded=stranded)
+                assert int(reason[i]) == er and int(ln[i]) == len(eb), (direction, min_cov, i, int(reason[i]), er, int(ln[i]), len(eb))
+                assert bytes(bases[i, :ln[i]]) == eb and (c[i, :ln[i]] == np.array(ec, np.float32)).all()
+                reasons.add(er)
+    assert reasons >= {0, 1, 3, 4}
+
+
+def test_max_cov_walk_meets_its_own_path():
+    """a tandem repeat of period 30: the walk comes back to the first k-mer it appended after 30 steps and stops there
+    (reason 2, GraphUtils.java:1613-1615 `leftPathKmers.contains(best)`), in both directions; the seed itself is not
+    part of the visited set, so a period-1 step count of 30 — not 29 — is what the reference does"""
+    rng = np.random.default_rng(2)
+    unit = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), 30))
+    read = unit * 6
+    og, gg = graph_pair(200_003, 400_009, 10_007, pairs=False)
+    seq = np.frombuffer(read, np.uint8); off = np.array([0, len(read)], np.int64)
+    og.add_reads(seq, None, off, 3, 0); gg.addReads(seq, None, off, 3)
+    for direction in (0, 1):
+        seed = read[40:65]
+        bases, f, r, c, ln, reason = gg.walkMaxCov([seed], direction, 100, 1.0)
+        eb, ec, er = rbo.walk_max_cov(og, seed, direction, 100, 1.0)
+        assert (int(ln[0]), int(reason[0])) == (len(eb), er) == (30, 2)
+        assert bytes(bases[0, :30]) == eb
