@@ -359,3 +359,57 @@ def walk_max_cov(og, seed, direction, bound, min_cov=1.0, target=None, k=25, str
         out += nb; counts.append(best_c)
         cur, f, r = nxt, int(f4[best]), int(r4[best])
     return bytes(out), counts, 3
+
+
+def get_max_coverage_path(og, left, right, bound, min_cov=1.0, k=25, low_complexity=None, trace=None):
+    """Restatement of GraphUtils.getMaxCoveragePath(graph, left, right, bound, lookahead, minKmerCov)
+    (R/util/GraphUtils.java:1591-1675), statement by statement, over the oracle graph.  `low_complexity` is
+    SeqUtils.isLowComplexityShort (R/util/SeqUtils.java:499-543), passed in so that this file stays free of host code."""
+    def step(cur, direction):
+        """Kmer.getMaxCovSuccessor / getMaxCovPredecessor, R/graph/Kmer.java:301-355"""
+        _, fr = hash_region(cur, k, 1, 1)
+        f4, r4, c4 = og.neighbors(int(fr[0, 0]), int(fr[0, 1]), cur[0] if direction == 0 else cur[-1], direction)
+        best, best_c = -1, -1.0
+        for i in range(4):
+            if c4[i] >= min_cov and c4[i] > best_c:
+                best, best_c = i, float(c4[i])
+        if best < 0:
+            return None
+        nb = b"ACGT"[best:best + 1]
+        return (cur[1:] + nb) if direction == 0 else (nb + cur[:-1])
+
+    left, right = _b(left), _b(right)
+    left_set, left_path = set(), []
+    best = left
+    for _ in range(bound):
+        best = step(best, 0)
+        if best is None:
+            break
+        if best == right:
+            if trace is not None: trace.append("from the left")
+            return left_path
+        if best in left_set:
+            break
+        left_set.add(best); left_path.append(best)
+    right_set, right_path = set(), []
+    best = right
+    for _ in range(bound):
+        best = step(best, 1)
+        if best is None:
+            break
+        if best == left:
+            if trace is not None: trace.append("from the right")
+            return right_path
+        if best in right_set:
+            return None
+        if best in left_set:
+            if low_complexity(best):
+                return None
+            right_path.insert(0, best)
+            for idx in range(len(left_path) - 1, -1, -1):
+                if left_path[idx] == best:
+                    if trace is not None: trace.append("walks meet")
+                    return left_path[:idx] + right_path
+        else:
+            right_set.add(best); right_path.insert(0, best)
+    return None

@@ -1,0 +1,91 @@
+"""Host mirror of the part of rnabloom.util.GraphUtils that sits directly on the neighbour-extension loop, batched over
+many k-mer pairs: the graph work (every getMaxCovSuccessor / getMaxCovPredecessor step) runs in two rb_graph_walk calls
+per batch; what is left on the host is the bookkeeping of R/util/GraphUtils.java:1591-1675."""
+import math
+
+LOW_COMPLEXITY_THRESHOLD_SHORT_SEQ = 0.95          # R/util/SeqUtils.java:61
+_IDX = {65: 0, 67: 1, 71: 2, 84: 3, 85: 3}         # nucleotideArrayIndex, R/util/SeqUtils.java:315-330 (upper case only)
+
+
+def _java_round(x):
+    return int(math.floor(x + 0.5))                # Math.round(float)
+
+
+def isLowComplexityShort(seq):
+    """R/util/SeqUtils.java:499-543 (String version): homopolymer / di- / tri-nucleotide repeats counted over a sliding
+    window of three bases, then the two-letter content test.  length/2 and length/3 are integer divisions."""
+    seq = bytes(seq)
+    length = len(seq)
+    t1 = min(32767, _java_round(length * LOW_COMPLEXITY_THRESHOLD_SHORT_SEQ))
+    t2 = min(32767, _java_round((length // 2) * LOW_COMPLEXITY_THRESHOLD_SHORT_SEQ))
+    t3 = min(32767, _java_round((length // 3) * LOW_COMPLEXITY_THRESHOLD_SHORT_SEQ))
+    nf1 = [0] * 4
+    nf2 = [[0] * 4 for _ in range(4)]
+    nf3 = [[[0] * 4 for _ in range(4)] for _ in range(4)]
+    c3, c2, c1 = _IDX[seq[0]], _IDX[seq[1]], _IDX[seq[2]]
+    nf1[c3] += 1; nf1[c2] += 1; nf1[c1] += 1
+    nf2[c3][c2] += 1; nf2[c2][c1] += 1
+    nf3[c3][c2][c1] += 1
+    for ch in seq[3:]:
+        c3, c2, c1 = c2, c1, _IDX[ch]
+        nf1[c1] += 1
+        if nf1[c1] >= t1:
+            return True
+        nf2[c2][c1] += 1
+        if nf2[c2][c1] >= t2:
+            return True
+        nf3[c3][c2][c1] += 1
+        if nf3[c3][c2][c1] >= t3:
+            return True
+    return any(nf1[a] + nf1[b] >= t1 for a in range(4) for b in range(a + 1, 4))
+
+
+def _kmers_right(seed, appended, k):
+    s = seed + appended
+    return [s[j + 1:j + 1 + k] for j in range(len(appended))]
+
+
+def _kmers_left(seed, prepended, k):
+    """k-mers of a left walk in the order they were found (nearest to the seed first)"""
+    s = prepended[::-1] + seed
+    n = len(prepended)
+    return [s[n - 1 - j:n - 1 - j + k] for j in range(n)]
+
+
+def getMaxCoveragePaths(graph, lefts, rights, bound, minKmerCov=1.0):
+    """GraphUtils.getMaxCoveragePath(graph, left, right, bound, lookahead, minKmerCov) (R/util/GraphUtils.java:1591-1675) for
+    many (left, right) pairs at once.  lefts / rights: k-mers as upper-case bytes.  Returns, per pair, the list of k-mers
+    strictly between left and right along the path found, or None — exactly what the reference returns."""
+    n = len(lefts)
+    k = graph.k
+    out = [None] * n
+    bases, _, _, _, ln, reason = graph.walkMaxCov(lefts, 0, bound, minKmerCov, rights)      # :1603-1620
+    left_paths = []
+    todo = []
+    for i in range(n):
+        lp = _kmers_right(lefts[i], bytes(bases[i, :ln[i]]), k)
+        left_paths.append(lp)
+        if reason[i] == 1:
+            out[i] = lp                                                                     # :1609-1611
+        elif reason[i] != 4:
+            todo.append(i)
+    if todo:
+        bases, _, _, _, ln, reason = graph.walkMaxCov([rights[i] for i in todo], 1, bound, minKmerCov, [lefts[i] for i in todo])   # :1629-1672
+        for j, i in enumerate(todo):
+            if reason[j] == 4:
+                continue
+            rp = _kmers_left(rights[i], bytes(bases[j, :ln[j]]), k)
+            lp = left_paths[i]
+            lset = {km: idx for idx, km in reversed(list(enumerate(lp)))}                    # first index of every k-mer
+            last = {}
+            for idx, km in enumerate(lp):
+                last[km] = idx                                                              # descendingIterator finds the LAST equal one
+            hit = next((d for d, km in enumerate(rp) if km in lset), None)
+            if hit is not None:                                                             # :1644-1664: the right path meets the left path
+                best = rp[hit]
+                if isLowComplexityShort(best):
+                    continue
+                out[i] = lp[:last[best]] + [best] + rp[:hit][::-1]
+            elif reason[j] == 1:                                                            # :1637-1639
+                out[i] = rp[::-1]
+    return out

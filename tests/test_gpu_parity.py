@@ -513,3 +513,42 @@ def test_max_cov_walk_meets_its_own_path():
         eb, ec, er = rbo.walk_max_cov(og, seed, direction, 100, 1.0)
         assert (int(ln[0]), int(reason[0])) == (len(eb), er) == (30, 2)
         assert bytes(bases[0, :30]) == eb
+
+
+def test_get_max_coverage_paths_match_oracle():
+    """rnabloom.graphutils.getMaxCoveragePaths (two batched rb_graph_walk calls + the bookkeeping of
+    GraphUtils.getMaxCoveragePath) against the statement-by-statement restatement over the oracle graph: pairs taken
+    from the same read at various distances (connected from the left, only from the right, through an intersection of
+    the two walks, not at all), random pairs, low bounds."""
+    from rnabloom.graphutils import getMaxCoveragePaths, isLowComplexityShort
+    (ls, lq, off), _ = make_reads(2500, 5000, 0.006, 0.0, seed=41)
+    og, gg = graph_pair(300_007, 1_500_007, 10_007, pairs=False)
+    og.add_reads(ls, lq, off, 3, 0); gg.addReads(ls, lq, off, 3)
+    rng = np.random.default_rng(9)
+    # a fork right after `left`: X is followed by Y five times and by Z once, left = the last k-mer of X, right inside Z.
+    # The walk from the left takes the Y branch; the walk from the right comes back along Z and arrives at left itself.
+    X, Y, Z = (bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), 40)) for _ in range(3))
+    fork = [X + Y] * 5 + [X + Z]
+    fs = np.frombuffer(b"".join(fork), np.uint8); fo = np.arange(0, 81 * len(fork), 80, dtype=np.int64)
+    og.add_reads(fs, None, fo, 3, 0); gg.addReads(fs, None, fo, 3)
+    lefts, rights = [X[15:40]], [(X + Z)[50:75]]
+    for _ in range(500):
+        r = int(rng.integers(0, len(off) - 1)); p = int(rng.integers(0, 60))
+        d = int(rng.integers(1, 60))
+        lefts.append(bytes(ls[off[r] + p: off[r] + p + 25]))
+        if rng.random() < 0.85:
+            rights.append(bytes(ls[off[r] + p + d: off[r] + p + d + 25]))
+        else:
+            r2 = int(rng.integers(0, len(off) - 1))
+            rights.append(bytes(ls[off[r2] + 3: off[r2] + 28]))
+    kinds = set()
+    trace = []
+    for bound, min_cov in ((70, 1.0), (20, 2.0), (8, 1.0)):
+        got = getMaxCoveragePaths(gg, lefts, rights, bound, min_cov)
+        for i in range(len(lefts)):
+            exp = rbo.get_max_coverage_path(og, lefts[i], rights[i], bound, min_cov, low_complexity=isLowComplexityShort, trace=trace)
+            assert got[i] == exp, (bound, min_cov, i)
+            kinds.add(None if exp is None else (len(exp) > 0))
+    assert kinds == {None, True, False}
+    assert set(trace) == {"from the left", "from the right", "walks meet"}, set(trace)
+    assert isLowComplexityShort(b"A" * 25) and isLowComplexityShort(b"AC" * 12 + b"A") and not isLowComplexityShort(lefts[0])
