@@ -181,7 +181,8 @@ int rb_graph_neighbors(rb_graph *g, const uint64_t *f, const uint64_t *r, const 
  * target (not appended), 2 it is a k-mer the walk appended before (not appended; Kmer.equals: same bases),
  * 3 `bound` k-mers appended, 4 the seed holds a base outside ACGTU.  out_len[i] appended k-mers; for walk i and
  * step j < out_len[i]: out_bases[i*bound + j] the base added (last base of the k-mer for direction 0, first base
- * for direction 1), out_f / out_r (may be NULL) / out_count its forward hash, reverse hash, graph.getCount. */
+ * for direction 1), out_f / out_r / out_count (each may be NULL: 20 of the 21 bytes a step returns) its forward hash,
+ * reverse hash, graph.getCount. */
 int rb_graph_walk(rb_graph *g, const char *seeds, const char *targets, size_t n, int direction, int bound, float min_cov,
                   char *out_bases, uint64_t *out_f, uint64_t *out_r, float *out_count, int32_t *out_len, uint8_t *out_reason);
 

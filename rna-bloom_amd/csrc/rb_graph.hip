@@ -807,7 +807,7 @@ __global__ void k_neighbors(FilterView fv, int stranded, int k, int direction, c
 // REVERSED followed by the prepended ones — either way k-mer number j of the walk (0-based) is seq[j+1 .. j+k].
 __global__ void k_walk_max_cov(FilterView fv, int stranded, int k, int direction, const uint8_t *__restrict__ seeds,
                                const uint8_t *__restrict__ targets, size_t n, int bound, float min_cov,
-                               uint8_t *__restrict__ seq, uint64_t *__restrict__ out_f, uint64_t *__restrict__ out_r,
+                               uint8_t *__restrict__ seq, uint8_t *__restrict__ out_b, uint64_t *__restrict__ out_f, uint64_t *__restrict__ out_r,
                                float *__restrict__ out_c, int32_t *__restrict__ out_len, uint8_t *__restrict__ out_reason) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -876,6 +876,7 @@ __global__ void k_walk_max_cov(FilterView fv, int stranded, int k, int direction
             if (pf[j] == best_f && same_as(sq + (size_t)j + 1u, true)) seen = true;
         if (seen) { reason = 2; break; }
         sq[(size_t)uk + (size_t)len] = nb;
+        out_b[i * (size_t)bound + (size_t)len] = nb;
         pf[len] = best_f; pr[len] = best_r; pc[len] = best_c;
         f = best_f; r = best_r;
         ++len;
@@ -1725,7 +1726,7 @@ int rb_graph_neighbors(rb_graph *g, const uint64_t *f, const uint64_t *r, const 
 int rb_graph_walk(rb_graph *g, const char *seeds, const char *targets, size_t n, int direction, int bound, float min_cov,
                   char *out_bases, uint64_t *out_f, uint64_t *out_r, float *out_count, int32_t *out_len, uint8_t *out_reason) {
     return guarded([&] {
-        RB_REQUIRE(g && (n == 0 || (seeds && out_bases && out_f && out_count && out_len && out_reason)), "rb_graph_walk: null argument");
+        RB_REQUIRE(g && (n == 0 || (seeds && out_bases && out_len && out_reason)), "rb_graph_walk: null argument");
         RB_REQUIRE(direction == 0 || direction == 1, "rb_graph_walk: direction must be 0 (right) or 1 (left)");
         RB_REQUIRE(bound >= 1 && bound <= (1 << 20), "rb_graph_walk: bound out of range [1, 2^20]");
         RB_REQUIRE(!g->shard, "rb_graph_walk: queries are not available on a shard handle");
@@ -1733,25 +1734,24 @@ int rb_graph_walk(rb_graph *g, const char *seeds, const char *targets, size_t n,
         RB_HIP(hipSetDevice(g->p.device));
         hipStream_t s = g->stream;
         const size_t k = (size_t)g->k, nb = n * (size_t)bound, stride = k + (size_t)bound;
-        g->qbuf0.reserve(n * k * 2 + n * stride + 64);          // seeds | targets | seq
+        g->qbuf0.reserve(n * k * 2 + n * stride + nb + 64);     // seeds | targets | seq | appended bases
         g->qbuf1.reserve(nb * 8); g->qbuf2.reserve(nb * 8); g->qbuf3.reserve(nb * 4 + n * 4 + n + 64);
-        uint8_t *dseed = g->qbuf0.as<uint8_t>(), *dtarget = dseed + n * k, *dseq = dtarget + n * k;
+        uint8_t *dseed = g->qbuf0.as<uint8_t>(), *dtarget = dseed + n * k, *dseq = dtarget + n * k, *dbases = dseq + n * stride;
         float *dc = g->qbuf3.as<float>();
         int32_t *dlen = reinterpret_cast<int32_t *>(dc + nb);
         uint8_t *dreason = reinterpret_cast<uint8_t *>(dlen + n);
         RB_HIP(hipMemcpyAsync(dseed, seeds, n * k, hipMemcpyHostToDevice, s));
         if (targets) RB_HIP(hipMemcpyAsync(dtarget, targets, n * k, hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(k_walk_max_cov, dim3(blocks_for((int64_t)n, 64)), dim3(64), 0, s, g->view(0, 0), (int)g->stranded, g->k, direction,
-                           dseed, targets ? dtarget : (const uint8_t *)nullptr, n, bound, min_cov, dseq, g->qbuf1.as<uint64_t>(),
+                           dseed, targets ? dtarget : (const uint8_t *)nullptr, n, bound, min_cov, dseq, dbases, g->qbuf1.as<uint64_t>(),
                            g->qbuf2.as<uint64_t>(), dc, dlen, dreason);
         RB_HIP(hipGetLastError());
         RB_HIP(hipMemcpyAsync(out_len, dlen, n * 4, hipMemcpyDeviceToHost, s));
         RB_HIP(hipMemcpyAsync(out_reason, dreason, n, hipMemcpyDeviceToHost, s));
-        RB_HIP(hipMemcpyAsync(out_f, g->qbuf1.p, nb * 8, hipMemcpyDeviceToHost, s));
+        if (out_f) RB_HIP(hipMemcpyAsync(out_f, g->qbuf1.p, nb * 8, hipMemcpyDeviceToHost, s));
         if (out_r) RB_HIP(hipMemcpyAsync(out_r, g->qbuf2.p, nb * 8, hipMemcpyDeviceToHost, s));
-        RB_HIP(hipMemcpyAsync(out_count, dc, nb * 4, hipMemcpyDeviceToHost, s));
-        // the appended bases of walk i are seq[i][k .. k+len)
-        RB_HIP(hipMemcpy2DAsync(out_bases, (size_t)bound, dseq + k, stride, (size_t)bound, n, hipMemcpyDeviceToHost, s));
+        if (out_count) RB_HIP(hipMemcpyAsync(out_count, dc, nb * 4, hipMemcpyDeviceToHost, s));
+        RB_HIP(hipMemcpyAsync(out_bases, dbases, nb, hipMemcpyDeviceToHost, s));
         RB_HIP(hipStreamSynchronize(s));
     });
 }

@@ -232,7 +232,7 @@ class BloomFilterDeBruijnGraph:
         check(lib.rb_graph_neighbors(self.h, _ptr(f), _ptr(r), _ptr(ch), n, direction, _ptr(f4), _ptr(r4), _ptr(c4)))
         return f4, r4, c4
 
-    def walkMaxCov(self, seeds, direction, bound, minKmerCov=1.0, targets=None):
+    def walkMaxCov(self, seeds, direction, bound, minKmerCov=1.0, targets=None, hashes=True, counts=True):
         """Batched greedy maximum-coverage walks (the loop around Kmer.getMaxCovSuccessor / getMaxCovPredecessor,
         R/graph/Kmer.java:301-355, as GraphUtils.getMaxCoveragePath runs it, R/util/GraphUtils.java:1591-1675).
         seeds / targets: k-mers as bytes.  Returns (bases[n, bound], f[n, bound], r[n, bound], count[n, bound], len[n],
@@ -245,10 +245,13 @@ class BloomFilterDeBruijnGraph:
         if targets is not None:
             tb = np.frombuffer(b"".join(targets), np.uint8)
             assert tb.size == n * k
-        bases = np.zeros((n, bound), np.uint8); f = np.zeros((n, bound), np.uint64); r = np.zeros((n, bound), np.uint64)
-        c = np.zeros((n, bound), np.float32); ln = np.zeros(n, np.int32); reason = np.zeros(n, np.uint8)
+        bases = np.zeros((n, bound), np.uint8); ln = np.zeros(n, np.int32); reason = np.zeros(n, np.uint8)
+        f = np.zeros((n, bound), np.uint64) if hashes else None
+        r = np.zeros((n, bound), np.uint64) if hashes else None
+        c = np.zeros((n, bound), np.float32) if counts else None
         check(lib.rb_graph_walk(self.h, _ptr(sb), _ptr(tb) if tb is not None else None, n, direction, bound, float(minKmerCov),
-                                _ptr(bases), _ptr(f), _ptr(r), _ptr(c), _ptr(ln), _ptr(reason)))
+                                _ptr(bases), _ptr(f) if hashes else None, _ptr(r) if hashes else None, _ptr(c) if counts else None,
+                                _ptr(ln), _ptr(reason)))
         return bases, f, r, c, ln, reason
 
     # ---- filter state ----

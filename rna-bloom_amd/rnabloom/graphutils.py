@@ -59,7 +59,7 @@ def getMaxCoveragePaths(graph, lefts, rights, bound, minKmerCov=1.0):
     n = len(lefts)
     k = graph.k
     out = [None] * n
-    bases, _, _, _, ln, reason = graph.walkMaxCov(lefts, 0, bound, minKmerCov, rights)      # :1603-1620
+    bases, _, _, _, ln, reason = graph.walkMaxCov(lefts, 0, bound, minKmerCov, rights, hashes=False, counts=False)      # :1603-1620
     left_paths = []
     todo = []
     for i in range(n):
@@ -70,7 +70,7 @@ def getMaxCoveragePaths(graph, lefts, rights, bound, minKmerCov=1.0):
         elif reason[i] != 4:
             todo.append(i)
     if todo:
-        bases, _, _, _, ln, reason = graph.walkMaxCov([rights[i] for i in todo], 1, bound, minKmerCov, [lefts[i] for i in todo])   # :1629-1672
+        bases, _, _, _, ln, reason = graph.walkMaxCov([rights[i] for i in todo], 1, bound, minKmerCov, [lefts[i] for i in todo], hashes=False, counts=False)   # :1629-1672
         for j, i in enumerate(todo):
             if reason[j] == 4:
                 continue

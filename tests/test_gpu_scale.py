@@ -176,3 +176,28 @@ def test_queries_at_scale():
             exp = np.concatenate(exp) if exp else np.zeros(0, np.uint64)
             assert (h0[sel] == exp).all()
     g.destroy()
+
+
+def test_walks_at_scale():
+    """300 000 greedy maximum-coverage walks in one rb_graph_walk call per direction (one lane per walk, up to 80 steps):
+    a spread sample against the step-by-step oracle, plus invariants of every walk (each step's count is at least
+    min_cov; a walk that stopped at the bound has that many steps)."""
+    n = 100_000
+    batch, seq, off = synthetic(n, genome=400_000, seed=123)
+    small = BITS // 16
+    og = rbo.Graph(small, small, small, 2, 2, 2, 25, False, False, 2)
+    g = BloomFilterDeBruijnGraph(small, small, small, 2, 2, 2, 25, False, False, rngSeed=2)
+    og.add_reads(seq, None, off, 3, 0); g.addBatch(batch, first=0, n=n)
+    rng = np.random.default_rng(3)
+    reads = rng.integers(0, n, 300_000); pos = rng.integers(0, 100, 300_000)
+    seeds = [seq[off[r] + p: off[r] + p + 25].tobytes() for r, p in zip(reads, pos)]
+    for direction in (0, 1):
+        bases, f, r, c, ln, reason = g.walkMaxCov(seeds, direction, 80, 2.0)
+        ok = np.arange(80)[None, :] < ln[:, None]
+        assert (c[ok] >= 2.0).all() and (ln[reason == 3] == 80).all() and (ln[reason == 4] == 0).all()
+        assert (reason == 3).sum() > 1000 and (reason == 0).sum() > 1000
+        for i in list(range(0, 150)) + list(range(len(seeds) - 150, len(seeds))):
+            eb, ec, er = rbo.walk_max_cov(og, seeds[i], direction, 80, 2.0)
+            assert (int(ln[i]), int(reason[i])) == (len(eb), er) and bytes(bases[i, :ln[i]]) == eb
+            assert (c[i, :ln[i]] == np.array(ec, np.float32)).all()
+    g.destroy()
