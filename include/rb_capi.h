@@ -186,6 +186,16 @@ int rb_graph_neighbors(rb_graph *g, const uint64_t *f, const uint64_t *r, const 
 int rb_graph_walk(rb_graph *g, const char *seeds, const char *targets, size_t n, int direction, int bound, float min_cov,
                   char *out_bases, uint64_t *out_f, uint64_t *out_r, float *out_count, int32_t *out_len, uint8_t *out_reason);
 
+/* GraphUtils.greedyExtendRight / greedyExtendLeft(graph, source, lookahead, bound), batched
+ * (R/util/GraphUtils.java:1961-1976, :1906-1921): up to `bound` times greedyExtend{Right,Left}Once (:501-529, :564-592) —
+ * the neighbours with graph.getCount >= 1 (Kmer.getSuccessors / getPredecessors, R/graph/Kmer.java:199-255); none ends the
+ * walk (out_reason 0), one is taken, several are scored with getMaxMedianCoverage{Right,Left} (:248-310, :375-438: the
+ * best minimum k-mer coverage over the depth-first paths of exactly `lookahead` k-mers starting at the candidate) and
+ * the highest score wins, a tie going to the strictly larger count.  out_reason 3 = bound reached, 4 = seed with a
+ * base outside ACGTU.  Outputs as rb_graph_walk (out_count may be NULL).  lookahead <= 16. */
+int rb_graph_greedy_extend(rb_graph *g, const char *seeds, size_t n, int direction, int lookahead, int bound,
+                           char *out_bases, float *out_count, int32_t *out_len, uint8_t *out_reason);
+
 /* ---- filter state: popcount / FPR / raw bytes (the on-disk format of
  *      R/bloom/BloomFilter.java:113-124 is exactly these bytes,
  *      R/bloom/buffer/UnsafeByteBuffer.java:160-201) ---- */

@@ -413,3 +413,79 @@ def get_max_coverage_path(og, left, right, bound, min_cov=1.0, k=25, low_complex
         else:
             right_set.add(best); right_path.insert(0, best)
     return None
+
+
+def greedy_extend(og, source, direction, lookahead, bound, k=25):
+    """Restatement of GraphUtils.greedyExtendRight / greedyExtendLeft(graph, source, lookahead, bound)
+    (R/util/GraphUtils.java:1961-1976 / :1906-1921), greedyExtendRightOnce / LeftOnce (:501-529 / :564-592) and
+    getMaxMedianCoverageRight / Left (:248-310 / :375-438), statement by statement over the oracle graph.
+    A k-mer here is (bytes, count, f, r).  Returns (appended bases, their counts)."""
+    def neighbours(km):
+        """Kmer.getSuccessors / getPredecessors(k, numHash, graph): count >= 1, order A,C,G,T (R/graph/Kmer.java:199-255)"""
+        b, _, f, r = km
+        f4, r4, c4 = og.neighbors(f, r, b[0] if direction == 0 else b[-1], direction)
+        out = []
+        for i in range(4):
+            if c4[i] >= 1:
+                nb = b"ACGT"[i:i + 1]
+                out.append(((b[1:] + nb) if direction == 0 else (nb + b[:-1]), float(c4[i]), int(f4[i]), int(r4[i])))
+        return out
+
+    def max_median_coverage(src):
+        nbrs = neighbours(src)
+        if not nbrs:
+            return 0.0 if lookahead > 0 else src[1]
+        path = [src]
+        cursor = nbrs.pop(0)
+        path.append(cursor)
+        frontier = [nbrs]
+        best = 0.0
+        while frontier:
+            if len(path) < lookahead:
+                nbrs = neighbours(cursor)
+                if nbrs:
+                    cursor = nbrs.pop(0)
+                    path.append(cursor)
+                    frontier.append(nbrs)
+                    continue
+            if len(path) == lookahead:
+                cov = min(km[1] for km in path)
+                if best < cov:
+                    best = cov
+            while frontier:
+                nbrs = frontier[-1]
+                path.pop()
+                if not nbrs:
+                    frontier.pop()
+                else:
+                    cursor = nbrs.pop(0)
+                    path.append(cursor)
+                    break
+        return best
+
+    def extend_once(src):
+        cands = neighbours(src)
+        if not cands:
+            return None
+        if len(cands) == 1:
+            return cands[0]
+        best_cov, best = -1.0, None
+        for km in cands:
+            c = max_median_coverage(km)
+            if c > best_cov:
+                best, best_cov = km, c
+            elif c == best_cov and km[1] > best[1]:
+                best = km
+        return best
+
+    source = _b(source)
+    _, fr = hash_region(source, k, 1, 1)
+    nxt = (source, 0.0, int(fr[0, 0]), int(fr[0, 1]))
+    out, counts = bytearray(), []
+    for _ in range(bound):
+        nxt = extend_once(nxt)
+        if nxt is None:
+            break
+        out += nxt[0][-1:] if direction == 0 else nxt[0][:1]
+        counts.append(nxt[1])
+    return bytes(out), counts

@@ -885,6 +885,125 @@ __global__ void k_walk_max_cov(FilterView fv, int stranded, int k, int direction
     out_reason[i] = reason;
 }
 
+// ---- greedy extension with lookahead: GraphUtils.greedyExtendRight / greedyExtendLeft ----
+// (R/util/GraphUtils.java:1961-1976 / :1906-1921 around greedyExtendRightOnce / LeftOnce :501-529, :564-592, which
+// score each candidate neighbour with getMaxMedianCoverageRight / Left :248-310, :375-438 — despite the name the
+// best MINIMUM k-mer coverage over the depth-first paths of exactly `lookahead` k-mers that start at the candidate.)
+// One lane per walk.  Per step: candidates = neighbours with count >= 1 in order A,C,G,T (Kmer.getSuccessors,
+// R/graph/Kmer.java:228-255); none -> stop; one -> take it; else the candidate with the largest score, a tie
+// going to the larger count (strictly).  No visited set: the reference has none here.  The depth-first search keeps,
+// per level, the siblings not yet tried — the reference's `frontier` of neighbour deques.
+constexpr int WALK_MAX_LOOKAHEAD = 16;
+struct WalkCand { uint64_t f, r; float c; uint32_t in; };
+__device__ __forceinline__ int walk_neighbors(const FilterView &fv, int stranded, uint32_t uk, int direction, uint64_t f, uint64_t r,
+                                              uint32_t oc, float min_cov, WalkCand *out) {
+    const uint64_t s_out = seed_of(oc), sc_out = seed_of(3u - oc);
+    int n = 0;
+    for (uint32_t in = 0; in < 4u; ++in) {
+        uint64_t nf, nr = 0;
+        if (direction == 0) {
+            nf = rotl(f, 1) ^ rotl(s_out, uk) ^ seed_of(in);
+            if (!stranded) nr = rotr(r, 1) ^ rotr(sc_out, 1) ^ rotl(seed_of(3u - in), uk - 1u);
+        } else {
+            nf = rotr(f, 1) ^ rotr(s_out, 1) ^ rotl(seed_of(in), uk - 1u);
+            if (!stranded) nr = rotl(r, 1) ^ rotl(sc_out, uk) ^ seed_of(3u - in);
+        }
+        const float c = graph_count(fv, stranded ? nf : smin(nf, nr));
+        if (c >= min_cov) { out[n].f = nf; out[n].r = nr; out[n].c = c; out[n].in = in; ++n; }
+    }
+    return n;
+}
+__global__ void k_greedy_extend(FilterView fv, int stranded, int k, int direction, const uint8_t *__restrict__ seeds, size_t n,
+                                int lookahead, int bound, uint8_t *__restrict__ seq, uint8_t *__restrict__ out_b,
+                                float *__restrict__ out_c, int32_t *__restrict__ out_len, uint8_t *__restrict__ out_reason) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t uk = (uint32_t)k;
+    const size_t stride = (size_t)k + (size_t)bound + (size_t)WALK_MAX_LOOKAHEAD + 1;
+    uint8_t *sq = seq + i * stride;                    // walk orientation, see k_walk_max_cov; the search writes ahead of the walk
+    const uint8_t *sb = seeds + i * (size_t)k;
+    uint64_t f = 0, r = 0;
+    for (uint32_t q = 0; q < uk; ++q) {
+        const uint32_t c = code_of_char(sb[q]);
+        if (c > 3u) { out_len[i] = 0; out_reason[i] = 4; return; }
+        f = rotl(f, 1) ^ seed_of(c);
+        r ^= rotl(seed_of(3u - c), q);
+    }
+    for (uint32_t q = 0; q < uk; ++q) sq[q] = (direction == 0) ? sb[q] : sb[uk - 1u - q];
+    const uint8_t acgt[4] = {'A', 'C', 'G', 'T'};
+    int len = 0;
+    uint8_t reason = 3;
+    WalkCand cand[4];
+    WalkCand frontier[WALK_MAX_LOOKAHEAD][4];          // siblings not yet tried, per level of the search
+    int fr_n[WALK_MAX_LOOKAHEAD], fr_next[WALK_MAX_LOOKAHEAD];
+    WalkCand path[WALK_MAX_LOOKAHEAD + 1];             // path[0] = the candidate being scored ("source")
+    while (len < bound) {
+        const int nc = walk_neighbors(fv, stranded, uk, direction, f, r, code_of_char(sq[len]), 1.0f, cand);
+        if (nc == 0) { reason = 0; break; }
+        int best = 0;
+        if (nc > 1) {
+            float best_cov = -1.0f;
+            for (int ci = 0; ci < nc; ++ci) {
+                // getMaxMedianCoverageRight(graph, cand[ci], lookahead): sq[len + k] is the candidate's new base
+                sq[(size_t)len + uk] = acgt[cand[ci].in];
+                float score;
+                path[0] = cand[ci];
+                int psize = 1, depth = 0;                // psize = path.size(); depth = frontier.size()
+                WalkCand nb[4];
+                int nn = walk_neighbors(fv, stranded, uk, direction, cand[ci].f, cand[ci].r, code_of_char(sq[(size_t)len + 1u]), 1.0f, nb);
+                if (nn == 0) score = (lookahead > 0) ? 0.0f : cand[ci].c;
+                else {
+                    float best_path = 0.0f;
+                    for (int q = 0; q < nn; ++q) frontier[0][q] = nb[q];
+                    fr_n[0] = nn; fr_next[0] = 1; depth = 1;
+                    path[1] = nb[0]; psize = 2;
+                    sq[(size_t)len + uk + 1u] = acgt[nb[0].in];
+                    while (depth > 0) {
+                        if (psize < lookahead) {
+                            const WalkCand &cur = path[psize - 1];
+                            // cursor = k-mer number (psize-1) after the candidate: its leaving base is sq[len + 1 + (psize-1)]
+                            nn = walk_neighbors(fv, stranded, uk, direction, cur.f, cur.r, code_of_char(sq[(size_t)len + (size_t)psize]), 1.0f, nb);
+                            if (nn > 0) {
+                                for (int q = 0; q < nn; ++q) frontier[depth][q] = nb[q];
+                                fr_n[depth] = nn; fr_next[depth] = 1; ++depth;
+                                path[psize] = nb[0];
+                                sq[(size_t)len + uk + (size_t)psize] = acgt[nb[0].in];
+                                ++psize;
+                                continue;
+                            }
+                        }
+                        if (psize == lookahead) {
+                            float mn = path[0].c;
+                            for (int q = 1; q < psize; ++q) mn = path[q].c < mn ? path[q].c : mn;
+                            if (best_path < mn) best_path = mn;
+                        }
+                        while (depth > 0) {
+                            --psize;                                        // path.removeLast()
+                            if (fr_next[depth - 1] >= fr_n[depth - 1]) --depth;  // that level is exhausted
+                            else {
+                                path[psize] = frontier[depth - 1][fr_next[depth - 1]++];
+                                sq[(size_t)len + uk + (size_t)psize] = acgt[path[psize].in];
+                                ++psize;
+                                break;
+                            }
+                        }
+                    }
+                    score = best_path;
+                }
+                if (score > best_cov) { best = ci; best_cov = score; }
+                else if (score == best_cov && cand[ci].c > cand[best].c) best = ci;
+            }
+        }
+        sq[(size_t)len + uk] = acgt[cand[best].in];
+        out_b[i * (size_t)bound + (size_t)len] = acgt[cand[best].in];
+        out_c[i * (size_t)bound + (size_t)len] = cand[best].c;
+        f = cand[best].f; r = cand[best].r;
+        ++len;
+    }
+    out_len[i] = len;
+    out_reason[i] = reason;
+}
+
 // ---- popcounts (UnsafeByteBuffer.bitPopCount :131-150 / popCount :121-129) ----
 __global__ void k_popcount_bits(const uint32_t *__restrict__ w, size_t n_words, unsigned long long *out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1750,6 +1869,36 @@ int rb_graph_walk(rb_graph *g, const char *seeds, const char *targets, size_t n,
         RB_HIP(hipMemcpyAsync(out_reason, dreason, n, hipMemcpyDeviceToHost, s));
         if (out_f) RB_HIP(hipMemcpyAsync(out_f, g->qbuf1.p, nb * 8, hipMemcpyDeviceToHost, s));
         if (out_r) RB_HIP(hipMemcpyAsync(out_r, g->qbuf2.p, nb * 8, hipMemcpyDeviceToHost, s));
+        if (out_count) RB_HIP(hipMemcpyAsync(out_count, dc, nb * 4, hipMemcpyDeviceToHost, s));
+        RB_HIP(hipMemcpyAsync(out_bases, dbases, nb, hipMemcpyDeviceToHost, s));
+        RB_HIP(hipStreamSynchronize(s));
+    });
+}
+
+int rb_graph_greedy_extend(rb_graph *g, const char *seeds, size_t n, int direction, int lookahead, int bound,
+                           char *out_bases, float *out_count, int32_t *out_len, uint8_t *out_reason) {
+    return guarded([&] {
+        RB_REQUIRE(g && (n == 0 || (seeds && out_bases && out_len && out_reason)), "rb_graph_greedy_extend: null argument");
+        RB_REQUIRE(direction == 0 || direction == 1, "rb_graph_greedy_extend: direction must be 0 (right) or 1 (left)");
+        RB_REQUIRE(bound >= 1 && bound <= (1 << 20), "rb_graph_greedy_extend: bound out of range [1, 2^20]");
+        RB_REQUIRE(lookahead >= 0 && lookahead <= WALK_MAX_LOOKAHEAD, "rb_graph_greedy_extend: lookahead out of range [0, %d]", WALK_MAX_LOOKAHEAD);
+        RB_REQUIRE(!g->shard, "rb_graph_greedy_extend: queries are not available on a shard handle");
+        if (!n) return;
+        RB_HIP(hipSetDevice(g->p.device));
+        hipStream_t s = g->stream;
+        const size_t k = (size_t)g->k, nb = n * (size_t)bound, stride = k + (size_t)bound + (size_t)WALK_MAX_LOOKAHEAD + 1;
+        g->qbuf0.reserve(n * k + n * stride + nb + 64);          // seeds | seq | appended bases
+        g->qbuf3.reserve(nb * 4 + n * 4 + n + 64);
+        uint8_t *dseed = g->qbuf0.as<uint8_t>(), *dseq = dseed + n * k, *dbases = dseq + n * stride;
+        float *dc = g->qbuf3.as<float>();
+        int32_t *dlen = reinterpret_cast<int32_t *>(dc + nb);
+        uint8_t *dreason = reinterpret_cast<uint8_t *>(dlen + n);
+        RB_HIP(hipMemcpyAsync(dseed, seeds, n * k, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_greedy_extend, dim3(blocks_for((int64_t)n, 64)), dim3(64), 0, s, g->view(0, 0), (int)g->stranded, g->k, direction,
+                           dseed, n, lookahead, bound, dseq, dbases, dc, dlen, dreason);
+        RB_HIP(hipGetLastError());
+        RB_HIP(hipMemcpyAsync(out_len, dlen, n * 4, hipMemcpyDeviceToHost, s));
+        RB_HIP(hipMemcpyAsync(out_reason, dreason, n, hipMemcpyDeviceToHost, s));
         if (out_count) RB_HIP(hipMemcpyAsync(out_count, dc, nb * 4, hipMemcpyDeviceToHost, s));
         RB_HIP(hipMemcpyAsync(out_bases, dbases, nb, hipMemcpyDeviceToHost, s));
         RB_HIP(hipStreamSynchronize(s));

@@ -552,3 +552,32 @@ def test_get_max_coverage_paths_match_oracle():
     assert kinds == {None, True, False}
     assert set(trace) == {"from the left", "from the right", "walks meet"}, set(trace)
     assert isLowComplexityShort(b"A" * 25) and isLowComplexityShort(b"AC" * 12 + b"A") and not isLowComplexityShort(lefts[0])
+
+
+@pytest.mark.parametrize("stranded", [False, True])
+def test_greedy_extend_with_lookahead_matches_oracle(stranded):
+    """rb_graph_greedy_extend (GraphUtils.greedyExtendRight / Left: per step the candidate whose depth-first lookahead
+    paths have the best minimum coverage, ties to the larger count) against the statement-by-statement restatement over
+    the oracle graph — a graph with plenty of branches (high error rate, small filters => false-positive neighbours),
+    lookahead 0..6, both directions."""
+    (ls, lq, off), _ = make_reads(1500, 3000, 0.02, 0.0, seed=57)
+    og, gg = graph_pair(150_001, 600_011, 10_007, stranded=stranded, pairs=False)
+    og.add_reads(ls, lq, off, 3, 0); gg.addReads(ls, lq, off, 3)
+    rng = np.random.default_rng(15)
+    seeds = []
+    for _ in range(160):
+        r = int(rng.integers(0, len(off) - 1)); p = int(rng.integers(0, 120))
+        seeds.append(bytes(ls[off[r] + p: off[r] + p + 25]))
+    branched = 0
+    for direction in (0, 1):
+        for lookahead, bound in ((3, 40), (5, 25), (0, 10), (1, 10), (6, 12)):
+            bases, c, ln, reason = gg.greedyExtend(seeds, direction, lookahead, bound)
+            for i, s in enumerate(seeds):
+                eb, ec = rbo.greedy_extend(og, s, direction, lookahead, bound)
+                assert int(ln[i]) == len(eb) and bytes(bases[i, :ln[i]]) == eb, (direction, lookahead, i)
+                assert (c[i, :ln[i]] == np.array(ec, np.float32)).all()
+                assert int(reason[i]) == (3 if len(eb) == bound else 0)
+            if lookahead == 3:
+                plain = gg.walkMaxCov(seeds, direction, bound, 1.0, hashes=False)[0]
+                branched += int((plain != bases).any(axis=1).sum())
+    assert branched > 0          # the lookahead changed at least one decision of the plain maximum-count walk
