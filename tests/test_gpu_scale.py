@@ -200,4 +200,10 @@ def test_walks_at_scale():
             eb, ec, er = rbo.walk_max_cov(og, seeds[i], direction, 80, 2.0)
             assert (int(ln[i]), int(reason[i])) == (len(eb), er) and bytes(bases[i, :ln[i]]) == eb
             assert (c[i, :ln[i]] == np.array(ec, np.float32)).all()
+        # the same seeds through the lookahead extension (GraphUtils.greedyExtendRight / Left)
+        bases, c, ln, reason = g.greedyExtend(seeds, direction, 4, 40)
+        assert ((reason == 3) == (ln == 40)).all() and (reason == 3).sum() > 1000
+        for i in list(range(0, 100)) + list(range(len(seeds) - 100, len(seeds))):
+            eb, ec = rbo.greedy_extend(og, seeds[i].upper(), direction, 4, 40) if b"N" not in seeds[i] else (b"", [])
+            assert int(ln[i]) == len(eb) and bytes(bases[i, :ln[i]]) == eb and (c[i, :ln[i]] == np.array(ec, np.float32)).all()
     g.destroy()

@@ -34,3 +34,9 @@ for direction in (0, 1):
     print("direction %d: %d walks, bound %d: %.3f s = %.2f M walks/s, %.1f M extension steps/s (%.0f M getCount/s); mean length %.1f; reasons %s"
           % (direction, n_seeds, bound, dt, n_seeds / dt / 1e6, steps / dt / 1e6, 4 * steps / dt / 1e6, ln.mean(),
              dict(zip(*np.unique(reason, return_counts=True)))))
+for direction in (0, 1):
+    t0 = time.perf_counter()
+    bases, c, ln, reason = g.greedyExtend(seeds, direction, 5, bound)
+    dt = time.perf_counter() - t0
+    print("greedy extension, lookahead 5, direction %d: %d walks, bound %d: %.3f s = %.2f M walks/s, %.1f M extension steps/s; mean length %.1f"
+          % (direction, n_seeds, bound, dt, n_seeds / dt / 1e6, int(ln.sum()) / dt / 1e6, ln.mean()))
