@@ -65,6 +65,7 @@ typedef struct rb_graph_params {
                                       R/bloom/hash/CanonicalHashFunction.java:188-206)          */
 #define RB_ADD_COUNT_IF_PRESENT 2u /* incrementIfPresent: graph::addCountIfPresent             */
 #define RB_ADD_STORE_READ_PAIRS 4u /* storeReadPairedKmers: graph.addReadSingleKmerPair        */
+#define RB_ADD_PAIRS_IF_PRESENT 8u /* rb_graph_add_pairs: existingKmersOnly (both k-mers in dbgbf) */
 
 typedef struct rb_add_stats {
     int64_t reads;    /* reads consumed (each takes one op ordinal)                 */
@@ -127,6 +128,16 @@ int rb_batch_create_synthetic(int device, const rb_synth_params *p, rb_batch **o
  *      FastaToGraphWorker.run :672-724, i.e. per k-mer graph.add (BloomFilterDeBruijnGraph.java:405-412)
  *      or addCountIfPresent (:424-428), per paired k-mer addReadSingleKmerPair (:455-457) ---- */
 int rb_graph_add_batch(rb_graph *g, const rb_batch *b, unsigned flags, rb_add_stats *stats);
+/* PairedKmersToGraphWorker.run (R/RNABloom.java:436-524): the paired k-mers (distance = the read- or fragment-paired
+ * k-mer distance of `which` = RB_RPKBF / RB_FPKBF) of reads [first, first+n) into that pair filter — nothing else.
+ * flags: RB_ADD_REVCOMP, RB_ADD_PAIRS_IF_PRESENT (existingKmersOnly, :466-482: only pairs whose two k-mers are both
+ * in dbgbf).  stats: reads, pairs. */
+int rb_graph_add_pairs(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, int which, unsigned flags, rb_add_stats *stats);
+/* FragmentsToGraphWorker.run (R/RNABloom.java:1463-1539): for every fragment graph.addDbgOnly of each k-mer; with
+ * load_paired_kmers also addReadSingleKmerPair of its read-paired k-mers and, for fragments long enough to have one,
+ * addFragmentSingleKmerPair of its fragment-paired k-mers.  Needs rb_graph_init_fragment_pairs + both distances.
+ * stats: reads, kmers, pairs (read + fragment pairs). */
+int rb_graph_add_fragments(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, int load_paired_kmers, rb_add_stats *stats);
 /* reads [first, first+n) of the batch only */
 int rb_graph_add_batch_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigned flags,
                              rb_add_stats *stats);

@@ -258,6 +258,9 @@ class Graph:
     def add_read_pair(self, h):
         a = self._h(h); self.L.rbo_graph_add_read_pair(self.g, _p(a))
 
+    def add_fragment_pair(self, h):
+        a = self._h(h); self.L.rbo_graph_add_fragment_pair(self.g, _p(a))
+
     def contains(self, h):
         a = self._h(h); return bool(self.L.rbo_graph_contains(self.g, _p(a)))
 

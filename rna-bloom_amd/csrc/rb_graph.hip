@@ -571,13 +571,17 @@ __global__ void __attribute__((optnone)) k_pairs_insert(const uint64_t *__restri
 // The read's words are loaded into registers up front (static indices; a word boundary costs a select chain).
 // Sharded engine: with out_idx the global bit indices are written instead, at the per-word offsets
 // (chunk_off, relative to word w0) that launch_count_windows(k + d) + scan produced.
-constexpr int PAIR_WORDS = 12;
-template <int MODE>
+__device__ __forceinline__ bool bits_lookup(const uint32_t *bits, const Mod &mod, int num_hash, uint64_t kmul, uint64_t h0);
+// PAIR_WORDS: 12 (384 bases) for the stage-1 reads, 32 (1024 bases) for fragments.  min_len: reads shorter than that
+// contribute nothing (FragmentsToGraphWorker adds fragment pairs only where read pairs could start).  present: when
+// set, a pair is added only if both of its k-mers are in dbgbf (PairedKmersToGraphWorker with existingKmersOnly,
+// R/RNABloom.java:466-482: graph.contains(lHashVals) && graph.contains(rHashVals)).
+template <int MODE, int PAIR_WORDS>
 __global__ void __launch_bounds__(64)
 k_pairs_reads(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid, const uint32_t *__restrict__ woff,
               const uint32_t *__restrict__ len, int64_t r0, int64_t nr, int64_t w0, int k, int dist, uint32_t *bits, Mod mod,
               int num_hash, uint64_t kmul, unsigned long long *__restrict__ n_pairs, const uint32_t *__restrict__ chunk_off,
-              uint64_t *__restrict__ out_idx) {
+              uint64_t *__restrict__ out_idx, uint32_t min_len, const uint32_t *__restrict__ present, Mod present_mod, int present_h) {
     __shared__ uint64_t s_tf[25], s_tr[25];
     const uint32_t uk = (uint32_t)k, ud = (uint32_t)dist, span = uk + ud;
     if (threadIdx.x < 25) {
@@ -593,7 +597,7 @@ k_pairs_reads(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ v
     if (t < nr) {
         const int64_t r = r0 + t;
         const uint32_t wr = woff[r], L = len[r];
-        if (L >= span) {
+        if (L >= span && L >= min_len) {
             const uint32_t nwords = (L + 31u) >> 5;
             uint64_t carr[PAIR_WORDS];
             uint32_t varr[PAIR_WORDS];
@@ -653,7 +657,13 @@ k_pairs_reads(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ v
                 lb = okR ? lb : e + 1u;
                 if (j + 1u >= uk) {
                     const uint32_t p = j + 1u - uk;                   // pair start: windows [p, p+k) and [p+d, p+d+k)
-                    if (lb <= p) {                                    // no unusable base in [p, p + span)
+                    bool ok = lb <= p;                                // no unusable base in [p, p + span)
+                    if (ok && present) {
+                        const uint64_t hl = (MODE == 0) ? fL : (MODE == 2) ? rL : smin(fL, rL);
+                        const uint64_t hr = (MODE == 0) ? fR : (MODE == 2) ? rR : smin(fR, rR);
+                        ok = bits_lookup(present, present_mod, present_h, kmul, hl) && bits_lookup(present, present_mod, present_h, kmul, hr);
+                    }
+                    if (ok) {
                         uint64_t P;
                         if (MODE == 0) P = combine(fL, fR);                 // PairedNTHashIterator.java:69
                         else if (MODE == 2) P = combine(rR, rL);            // ReverseComplementPaired… :44
@@ -1029,25 +1039,35 @@ __global__ void k_iota(uint32_t *v, size_t n) {
 
 }  // namespace
 
+// one read per lane: pairs at distance `dist` of the reads of words [w0, w0 + nw) into bit filter `f`
+static void launch_pairs_reads(rb_graph *g, const rb_batch *b, int64_t w0, int64_t nw, int mode_hash, const BitFilter &f, int dist,
+                               uint32_t min_len, bool if_present, const uint32_t *chunk_off, uint64_t *out_idx, unsigned long long *pc,
+                               hipStream_t st) {
+    RB_REQUIRE(g->k <= 64 && b->max_len <= 1024u, "paired k-mers: k <= 64 and reads of at most 1024 bases only on this path");
+    // the reads of words [w0, w0 + nw): both ends are read boundaries
+    const auto &wo = b->h_woff;
+    const int64_t r0 = std::lower_bound(wo.begin(), wo.end(), (uint32_t)w0) - wo.begin();
+    const int64_t r1 = std::lower_bound(wo.begin(), wo.end(), (uint32_t)(w0 + nw)) - wo.begin();
+    RB_REQUIRE(r0 < (int64_t)wo.size() && wo[(size_t)r0] == (uint32_t)w0 && r1 < (int64_t)wo.size() && wo[(size_t)r1] == (uint32_t)(w0 + nw),
+               "launch_pairs: word range does not start and end at read boundaries");
+    if (r1 <= r0) return;
+    dim3 gr(blocks_for(r1 - r0, 64)), th(64);
+    const uint32_t *present = if_present ? g->dbg.bits : nullptr;
+#define RB_LAUNCH_PR(M, NW)                                                                                              \
+    hipLaunchKernelGGL((k_pairs_reads<M, NW>), gr, th, 0, st, b->codes, b->valid, b->woff, b->len, r0, r1 - r0, w0, g->k, \
+                       dist, f.bits, f.mod, f.num_hash, kmul_of(g->k), pc, chunk_off, out_idx, min_len, present, g->dbg.mod, g->dbg.num_hash)
+    if (b->max_len <= 384u) { if (mode_hash == 0) RB_LAUNCH_PR(0, 12); else if (mode_hash == 2) RB_LAUNCH_PR(2, 12); else RB_LAUNCH_PR(1, 12); }
+    else { if (mode_hash == 0) RB_LAUNCH_PR(0, 32); else if (mode_hash == 2) RB_LAUNCH_PR(2, 32); else RB_LAUNCH_PR(1, 32); }
+#undef RB_LAUNCH_PR
+}
+
 void rb::launch_pairs(rb_graph *g, const rb_batch *b, int64_t w0, int64_t nw, int mode_hash, const uint32_t *chunk_off,
                       uint64_t *out_idx, unsigned long long *pc, hipStream_t st) {
     if (!st) st = g->stream;
     if (nw <= 0) return;
-    const bool general = g->k > 64 || b->max_len > 32u * (uint32_t)PAIR_WORDS || (getenv("RB_PAIRS_GENERAL") && atoi(getenv("RB_PAIRS_GENERAL")));
+    const bool general = g->k > 64 || b->max_len > 384u || (getenv("RB_PAIRS_GENERAL") && atoi(getenv("RB_PAIRS_GENERAL")));
     if (!general) {
-        // the reads of words [w0, w0 + nw): both ends are read boundaries
-        const auto &wo = b->h_woff;
-        const int64_t r0 = std::lower_bound(wo.begin(), wo.end(), (uint32_t)w0) - wo.begin();
-        const int64_t r1 = std::lower_bound(wo.begin(), wo.end(), (uint32_t)(w0 + nw)) - wo.begin();
-        RB_REQUIRE(r0 < (int64_t)wo.size() && wo[(size_t)r0] == (uint32_t)w0 && r1 < (int64_t)wo.size() && wo[(size_t)r1] == (uint32_t)(w0 + nw),
-                   "launch_pairs: word range does not start and end at read boundaries");
-        if (r1 <= r0) return;
-        dim3 gr(blocks_for(r1 - r0, 64)), th(64);
-#define RB_LAUNCH_PR(M)                                                                                              \
-    hipLaunchKernelGGL(k_pairs_reads<M>, gr, th, 0, st, b->codes, b->valid, b->woff, b->len, r0, r1 - r0, w0, g->k, \
-                       g->read_d, g->rpk.bits, g->rpk.mod, g->rpk.num_hash, kmul_of(g->k), pc, chunk_off, out_idx)
-        if (mode_hash == 0) RB_LAUNCH_PR(0); else if (mode_hash == 2) RB_LAUNCH_PR(2); else RB_LAUNCH_PR(1);
-#undef RB_LAUNCH_PR
+        launch_pairs_reads(g, b, w0, nw, mode_hash, g->rpk, g->read_d, 0u, false, chunk_off, out_idx, pc, st);
         return;
     }
     dim3 gr(blocks_for(nw)), th(TPB);
@@ -1634,6 +1654,85 @@ int rb_graph_add_batch_range(rb_graph *g, const rb_batch *b, int64_t first, int6
         add_range(g, b, first, n, flags, stats);
     });
 }
+// PairedKmersToGraphWorker (R/RNABloom.java:436-524): paired k-mers only, optionally only where both k-mers are in dbgbf
+int rb_graph_add_pairs(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, int which, unsigned flags, rb_add_stats *stats) {
+    return guarded([&] {
+        RB_REQUIRE(g && b, "rb_graph_add_pairs: null argument");
+        RB_REQUIRE(!g->shard, "rb_graph_add_pairs: not available on a shard handle");
+        RB_REQUIRE(b->device == g->p.device, "batch lives on device %d, graph on %d", b->device, g->p.device);
+        RB_REQUIRE(first >= 0 && n >= 0 && first + n <= b->n_reads, "rb_graph_add_pairs: bad read range");
+        RB_REQUIRE(which == RB_RPKBF || which == RB_FPKBF, "rb_graph_add_pairs: which must be RB_RPKBF or RB_FPKBF");
+        RB_REQUIRE((flags & ~(RB_ADD_REVCOMP | RB_ADD_PAIRS_IF_PRESENT)) == 0u, "rb_graph_add_pairs: unknown flag");
+        BitFilter &f = which == RB_RPKBF ? g->rpk : g->fpk;
+        const int dist = which == RB_RPKBF ? g->read_d : g->frag_d;
+        if (!f.bits || dist <= 0) { set_error("rb_graph_add_pairs: pair filter %d not initialised or its k-mer distance not set", which); throw HipError{RB_ERR_STATE}; }
+        if (stats) memset(stats, 0, sizeof *stats);
+        if (!n) return;
+        RB_HIP(hipSetDevice(g->p.device));
+        const int64_t w0 = (int64_t)b->h_woff[(size_t)first], nw = (int64_t)b->h_woff[(size_t)(first + n)] - w0;
+        const int mode_hash = g->stranded ? ((flags & RB_ADD_REVCOMP) ? 2 : 0) : 1;
+        g->devctr.reserve(DEVCTR_BYTES);
+        unsigned long long *pc = reinterpret_cast<unsigned long long *>(g->devctr.as<uint32_t>() + 12);
+        RB_HIP(hipMemsetAsync(pc, 0, 8, g->stream));
+        if (nw > 0) launch_pairs_reads(g, b, w0, nw, mode_hash, f, dist, 0u, (flags & RB_ADD_PAIRS_IF_PRESENT) != 0, nullptr, nullptr, pc, g->stream);
+        RB_HIP(hipGetLastError());
+        unsigned long long np = 0;
+        RB_HIP(hipMemcpyAsync(&np, pc, 8, hipMemcpyDeviceToHost, g->stream));
+        RB_HIP(hipStreamSynchronize(g->stream));
+        if (stats) { stats->reads = n; stats->pairs = (int64_t)np; }
+    });
+}
+
+// FragmentsToGraphWorker (R/RNABloom.java:1463-1539): every k-mer of a fragment into dbgbf only; with loadPairedKmers also
+// its read-paired k-mers into rpkbf and — where those could start — its fragment-paired k-mers into fpkbf.  All pure ORs.
+int rb_graph_add_fragments(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, int load_paired_kmers, rb_add_stats *stats) {
+    return guarded([&] {
+        RB_REQUIRE(g && b, "rb_graph_add_fragments: null argument");
+        RB_REQUIRE(!g->shard, "rb_graph_add_fragments: not available on a shard handle");
+        RB_REQUIRE(b->device == g->p.device, "batch lives on device %d, graph on %d", b->device, g->p.device);
+        RB_REQUIRE(first >= 0 && n >= 0 && first + n <= b->n_reads, "rb_graph_add_fragments: bad read range");
+        if (load_paired_kmers && !(g->rpk.bits && g->read_d > 0 && g->fpk.bits && g->frag_d > 0)) {
+            set_error("rb_graph_add_fragments: loadPairedKmers needs rpkbf + fpkbf and both paired k-mer distances"); throw HipError{RB_ERR_STATE};
+        }
+        if (stats) memset(stats, 0, sizeof *stats);
+        if (!n) return;
+        RB_HIP(hipSetDevice(g->p.device));
+        hipStream_t s = g->stream;
+        const int64_t w0 = (int64_t)b->h_woff[(size_t)first], nw = (int64_t)b->h_woff[(size_t)(first + n)] - w0;
+        if (nw <= 0) return;
+        const int mode_hash = g->stranded ? 0 : 1;               // graph.getHashIterator: forward or canonical
+        // k-mers -> dbgbf (addDbgOnly, order independent): count, scan, hash, set bits
+        g->chunk_cnt.reserve(((size_t)nw + 1) * 4); g->chunk_off.reserve(((size_t)nw + 1) * 4);
+        g->temp.reserve(scan_temp_bytes((size_t)nw + 1));
+        RB_HIP(hipMemsetAsync(g->chunk_cnt.p, 0, ((size_t)nw + 1) * 4, s));
+        launch_count_windows(b, w0, nw, g->k, g->chunk_cnt.as<uint32_t>(), s);
+        exclusive_scan_u32(g->temp.p, g->temp.cap, g->chunk_cnt.as<uint32_t>(), g->chunk_off.as<uint32_t>(), (size_t)nw + 1, s);
+        uint32_t total = 0;
+        RB_HIP(hipMemcpyAsync(&total, g->chunk_off.as<uint32_t>() + nw, 4, hipMemcpyDeviceToHost, s));
+        RB_HIP(hipStreamSynchronize(s));
+        if (total) {
+            g->keys0.reserve((size_t)total * 8);
+            launch_hash_windows(b, w0, nw, g->k, mode_hash, g->chunk_off.as<uint32_t>(), 0, 0, g->keys0.as<uint64_t>(), nullptr, nullptr, nullptr, s);
+            hipLaunchKernelGGL(k_bits_add, dim3(blocks_for((int64_t)total)), dim3(TPB), 0, s, g->dbg.bits, g->dbg.mod, g->dbg.num_hash, kmul_of(g->k),
+                               g->keys0.as<uint64_t>(), (size_t)total);
+        }
+        unsigned long long np = 0;
+        if (load_paired_kmers) {
+            g->devctr.reserve(DEVCTR_BYTES);
+            unsigned long long *pc = reinterpret_cast<unsigned long long *>(g->devctr.as<uint32_t>() + 12);
+            RB_HIP(hipMemsetAsync(pc, 0, 8, s));
+            launch_pairs_reads(g, b, w0, nw, mode_hash, g->rpk, g->read_d, 0u, false, nullptr, nullptr, pc, s);
+            launch_pairs_reads(g, b, w0, nw, mode_hash, g->fpk, g->frag_d, (uint32_t)(g->k + g->read_d), false, nullptr, nullptr, pc, s);
+            RB_HIP(hipMemcpyAsync(&np, pc, 8, hipMemcpyDeviceToHost, s));
+        }
+        RB_HIP(hipGetLastError());
+        RB_HIP(hipStreamSynchronize(s));
+        // the prefilter cache speaks about dbgbf + cbf: new dbgbf bits do not falsify an entry (entries only ever
+        // understate), so it stays as it is
+        if (stats) { stats->reads = n; stats->kmers = total; stats->pairs = (int64_t)np; }
+    });
+}
+
 int rb_graph_add_batch(rb_graph *g, const rb_batch *b, unsigned flags, rb_add_stats *stats) {
     if (!b) { set_error("rb_graph_add_batch: null batch"); return RB_ERR_INVALID; }
     return rb_graph_add_batch_range(g, b, 0, b->n_reads, flags, stats);

@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "librb_hip.so")
 
 RB_OK = 0
 DBGBF, CBF, RPKBF, FPKBF = 0, 1, 2, 3
-ADD_REVCOMP, ADD_COUNT_IF_PRESENT, ADD_STORE_READ_PAIRS = 1, 2, 4
+ADD_REVCOMP, ADD_COUNT_IF_PRESENT, ADD_STORE_READ_PAIRS, ADD_PAIRS_IF_PRESENT = 1, 2, 4, 8
 OP_ADD, OP_ADD_IF_ABSENT, OP_ADD_COUNT_IF_PRESENT, OP_ADD_DBG_ONLY, OP_ADD_COUNT_ONLY, \
     OP_ADD_READ_PAIR, OP_ADD_FRAG_PAIR = range(7)
 PROF_MAX = 32
@@ -65,6 +65,8 @@ SYMBOLS = [
     ("rb_batch_create_synthetic", _i32, [_i32, C.POINTER(SynthParams), C.POINTER(_vp)]),
     ("rb_graph_add_batch", _i32, [_vp, _vp, C.c_uint, C.POINTER(AddStats)]),
     ("rb_graph_add_batch_range", _i32, [_vp, _vp, _i64, _i64, C.c_uint, C.POINTER(AddStats)]),
+    ("rb_graph_add_pairs", _i32, [_vp, _vp, _i64, _i64, _i32, C.c_uint, C.POINTER(AddStats)]),
+    ("rb_graph_add_fragments", _i32, [_vp, _vp, _i64, _i64, _i32, C.POINTER(AddStats)]),
     ("rb_graph_add_reads", _i32, [_vp, _vp, _vp, _vp, _i64, _i32, C.c_uint, C.POINTER(AddStats)]),
     ("rb_graph_apply", _i32, [_vp, _i32, _vp, _sz]),
     ("rb_graph_contains", _i32, [_vp, _vp, _sz, _vp]),

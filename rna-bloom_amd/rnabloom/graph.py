@@ -173,6 +173,21 @@ class BloomFilterDeBruijnGraph:
                                      flags, C.byref(st)))
         return st
 
+    def addPairs(self, batch, which=N.RPKBF, reverseComplement=False, existingKmersOnly=False, first=0, n=None):
+        """PairedKmersToGraphWorker (R/RNABloom.java:436-524): only the paired k-mers of the reads, into rpkbf (or fpkbf)"""
+        flags = (N.ADD_REVCOMP if reverseComplement else 0) | (N.ADD_PAIRS_IF_PRESENT if existingKmersOnly else 0)
+        n = batch.n_reads - first if n is None else n
+        st = N.AddStats()
+        check(lib.rb_graph_add_pairs(self.h, batch.h, first, n, which, flags, C.byref(st)))
+        return st
+
+    def addFragments(self, batch, loadPairedKmers=True, first=0, n=None):
+        """FragmentsToGraphWorker (R/RNABloom.java:1463-1539): k-mers into dbgbf only, plus read- and fragment-paired k-mers"""
+        n = batch.n_reads - first if n is None else n
+        st = N.AddStats()
+        check(lib.rb_graph_add_fragments(self.h, batch.h, first, n, int(loadPairedKmers), C.byref(st)))
+        return st
+
     # ---- per-hash mutators (arrays are applied in order) ----
     def _apply(self, op, h0):
         a = _u64(np.atleast_1d(h0))

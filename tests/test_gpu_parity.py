@@ -581,3 +581,73 @@ def test_greedy_extend_with_lookahead_matches_oracle(stranded):
                 plain = gg.walkMaxCov(seeds, direction, bound, 1.0, hashes=False)[0]
                 branched += int((plain != bases).any(axis=1).sum())
     assert branched > 0          # the lookahead changed at least one decision of the plain maximum-count walk
+
+
+@pytest.mark.parametrize("stranded", [False, True])
+def test_pair_only_and_fragment_workers_match_oracle(stranded):
+    """rb_graph_add_pairs (PairedKmersToGraphWorker: paired k-mers only, with and without existingKmersOnly) and
+    rb_graph_add_fragments (FragmentsToGraphWorker: dbgbf-only k-mers + read pairs + fragment pairs) against the same
+    loops written over the oracle's per-hash entry points, hash values from the oracle's iterators."""
+    k, read_d, frag_d, mode = 25, 60, 150, (0 if stranded else 1)
+    (ls, lq, off), _ = make_reads(700, 4000, 0.004, 1e-3, seed=77)
+    og, gg = graph_pair(300_007, 900_001, 200_003, stranded=stranded)
+    og.set_read_pair_distance(read_d); gg.setReadPairedKmerDistance(read_d)
+    og.init_fragment_pairs(250_007, 2, frag_d); gg.initializePairKmersBloomFilter(250_007, 2); gg.setFragPairedKmerDistance(frag_d)
+    # half of the reads go in as ordinary reads (so that some k-mers exist), then pairs of ALL reads, existing k-mers only
+    half = 350
+    og.add_reads(ls[:off[half]], lq[:off[half]], off[:half + 1], 3, 0); gg.addReads(ls[:off[half]], lq[:off[half]], off[:half + 1], 3)
+    batch = ReadBatch.from_ascii(ls, None, off, 3)
+    reads = [bytes(ls[off[i]:off[i + 1]]) for i in range(len(off) - 1)]
+
+    def oracle_pairs(seqs, d, add, existing):
+        n = 0
+        for s in seqs:
+            for a, b in rbo.segments(s, None, k, 3):
+                if b - a < k + d:
+                    continue
+                p, l, r = rbo.hash_pairs_region(s, k, 2, d, mode, int(a), int(b))
+                for i in range(p.shape[0]):
+                    if existing and not (og.contains(l[i]) and og.contains(r[i])):
+                        continue
+                    add(p[i]); n += 1
+        return n
+
+    n_exist = oracle_pairs(reads, read_d, og.add_read_pair, True)
+    st = gg.addPairs(batch, N.RPKBF, existingKmersOnly=True)
+    assert st.pairs == n_exist > 1000
+    assert_same_state(og, gg)
+    n_all = oracle_pairs(reads, read_d, og.add_read_pair, False)
+    st = gg.addPairs(batch, N.RPKBF)
+    assert st.pairs == n_all > n_exist
+    assert_same_state(og, gg)
+    # fragments: ACGT-only sequences of 60..400 bases
+    rng = np.random.default_rng(4)
+    genome = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 20_000)]
+    frags = []
+    for _ in range(500):
+        L = int(rng.integers(60, 400)); a = int(rng.integers(0, genome.size - L))
+        frags.append(genome[a:a + L].tobytes())
+    fseq = np.frombuffer(b"".join(frags), np.uint8); foff = np.concatenate([[0], np.cumsum([len(f) for f in frags])]).astype(np.int64)
+    fb = ReadBatch.from_ascii(fseq, None, foff, 3)
+    for load in (False, True):
+        n_k = n_p = 0
+        for s in frags:
+            hv, _ = rbo.hash_region(s, k, 2, mode)
+            for i in range(hv.shape[0]):
+                og.add_dbg_only(hv[i])
+            n_k += hv.shape[0]
+            if load and len(s) >= k + read_d:
+                p, _, _ = rbo.hash_pairs_region(s, k, 2, read_d, mode)
+                for i in range(p.shape[0]):
+                    og.add_read_pair(p[i])
+                n_p += p.shape[0]
+                if len(s) >= k + frag_d:
+                    p, _, _ = rbo.hash_pairs_region(s, k, 2, frag_d, mode)
+                    for i in range(p.shape[0]):
+                        og.add_fragment_pair(p[i])
+                    n_p += p.shape[0]
+        st = gg.addFragments(fb, loadPairedKmers=load)
+        assert (st.kmers, st.pairs) == (n_k, n_p)
+        assert_same_state(og, gg)
+        assert (gg.exportFilter(N.FPKBF) == og.fpkbf_bytes()).all()
+    assert gg.popcount(N.FPKBF) > 1000
