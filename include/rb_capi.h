@@ -166,6 +166,11 @@ int rb_graph_contains(rb_graph *g, const uint64_t *h0, size_t n, uint8_t *out);
 int rb_graph_count(rb_graph *g, const uint64_t *h0, size_t n, float *out);
 /* BloomFilter.lookup(long) on any bit filter / CountingBloomFilter.getCount(long) :231-233 */
 int rb_filter_lookup(rb_graph *g, int which, const uint64_t *h0, size_t n, uint8_t *out);
+/* BloomFilter.lookupThenAdd (R/bloom/BloomFilter.java:147-155) for an array of base hashes, IN ARRAY ORDER: out[i] = 1 iff
+ * every bit of element i was set before element i is added — by the state before the call or by an element earlier in
+ * the array — and all bits are set on return.  This is what graph.lookupAndAddAllPairedKmers
+ * (R/graph/BloomFilterDeBruijnGraph.java:513-526) and GraphUtils.java:640-650 AND together per sequence. */
+int rb_filter_lookup_then_add(rb_graph *g, int which, const uint64_t *h0, size_t n, uint8_t *out);
 int rb_filter_get_count(rb_graph *g, const uint64_t *h0, size_t n, float *out);
 /* getKmers(String) :1224-1226 -> {Canonical,}HashFunction.getKmers: for every window of every
  * read of the batch: forward hash, reverse hash (0 when stranded), count (0 for windows that

@@ -1014,6 +1014,41 @@ __global__ void k_greedy_extend(FilterView fv, int stranded, int k, int directio
     out_reason[i] = reason;
 }
 
+// ---- BloomFilter.lookupThenAdd over an array, in array order (R/bloom/BloomFilter.java:147-155) ----
+// Sequentially, element i finds bit b set iff b was set before the call or an earlier probe of the array set it:
+// the probe with the smallest (element, hash number) id among those that want a clear bit is its first setter.
+// Pass 1 tests the bits against the state before the call and registers candidates for first setter in a hash
+// table (atomicMin of the probe id); pass 2 answers every element from its own bits and the table; then all
+// bits are set.  Same arbitration as the dbgbf half of k_probe / k_late_claim.
+__global__ void k_lta_probe(const uint32_t *__restrict__ bits, Mod mod, int num_hash, uint64_t kmul, const uint64_t *__restrict__ h0,
+                            size_t n, Slot *ftable, uint32_t f_log2, uint8_t *__restrict__ premask) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t pm = 0;
+    for (int j = 0; j < num_hash; ++j) {
+        const uint64_t idx = index_of(multi_hash(h0[i], (uint32_t)j, kmul), mod);
+        if (bit_test(bits, idx)) pm |= 1u << j;
+        else {
+            Slot *s = table_insert(ftable, f_log2, idx);
+            atomicMin(&s->val, ((unsigned long long)i << 4) | (unsigned long long)j);
+        }
+    }
+    premask[i] = (uint8_t)pm;
+}
+__global__ void k_lta_resolve(Mod mod, int num_hash, uint64_t kmul, const uint64_t *__restrict__ h0, size_t n, const Slot *ftable,
+                              uint32_t f_log2, const uint8_t *__restrict__ premask, uint8_t *__restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t pm = premask[i];
+    bool found = true;
+    for (int j = 0; j < num_hash; ++j) {
+        if ((pm >> j) & 1u) continue;
+        const Slot *s = table_find(ftable, f_log2, index_of(multi_hash(h0[i], (uint32_t)j, kmul), mod));
+        if (!(s->val < (((unsigned long long)i << 4) | (unsigned long long)j))) found = false;   // no early exit in the reference either
+    }
+    out[i] = found ? 1 : 0;
+}
+
 // ---- popcounts (UnsafeByteBuffer.bitPopCount :131-150 / popCount :121-129) ----
 __global__ void k_popcount_bits(const uint32_t *__restrict__ w, size_t n_words, unsigned long long *out) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1861,6 +1896,33 @@ int rb_filter_lookup(rb_graph *g, int which, const uint64_t *h0, size_t n, uint8
         RB_HIP(hipGetLastError());
         RB_HIP(hipMemcpyAsync(out, g->qbuf1.p, n, hipMemcpyDeviceToHost, g->stream));
         RB_HIP(hipStreamSynchronize(g->stream));
+    });
+}
+int rb_filter_lookup_then_add(rb_graph *g, int which, const uint64_t *h0, size_t n, uint8_t *out) {
+    return guarded([&] {
+        RB_REQUIRE(g && (n == 0 || (h0 && out)), "rb_filter_lookup_then_add: null argument");
+        BitFilter *f = bit_filter(g, which);
+        RB_REQUIRE(f, "rb_filter_lookup_then_add: filter %d is not a bit filter", which);
+        RB_REQUIRE(!g->shard, "rb_filter_lookup_then_add: not available on a shard handle");
+        RB_REQUIRE(n < ((size_t)1 << 59), "rb_filter_lookup_then_add: too many elements");
+        if (!f->bits) { set_error("rb_filter_lookup_then_add: filter %d not initialised", which); throw HipError{RB_ERR_STATE}; }
+        if (!n) return;
+        RB_HIP(hipSetDevice(g->p.device));
+        hipStream_t s = g->stream;
+        uint64_t *d = upload_h0(g, g->qbuf0, h0, n);
+        g->qbuf1.reserve(n); g->qbuf2.reserve(n);
+        const uint32_t f_log2 = log2_ceil(2ull * (uint64_t)n * (uint64_t)f->num_hash + 2);
+        g->ftable.reserve(sizeof(Slot) << f_log2);
+        RB_HIP(hipMemsetAsync(g->ftable.p, 0xFF, sizeof(Slot) << f_log2, s));
+        const uint64_t kmul = kmul_of(g->k);
+        hipLaunchKernelGGL(k_lta_probe, dim3(blocks_for((int64_t)n)), dim3(TPB), 0, s, f->bits, f->mod, f->num_hash, kmul, d, n,
+                           g->ftable.as<Slot>(), f_log2, g->qbuf2.as<uint8_t>());
+        hipLaunchKernelGGL(k_lta_resolve, dim3(blocks_for((int64_t)n)), dim3(TPB), 0, s, f->mod, f->num_hash, kmul, d, n,
+                           g->ftable.as<Slot>(), f_log2, g->qbuf2.as<uint8_t>(), g->qbuf1.as<uint8_t>());
+        hipLaunchKernelGGL(k_bits_add, dim3(blocks_for((int64_t)n)), dim3(TPB), 0, s, f->bits, f->mod, f->num_hash, kmul, d, n);
+        RB_HIP(hipGetLastError());
+        RB_HIP(hipMemcpyAsync(out, g->qbuf1.p, n, hipMemcpyDeviceToHost, s));
+        RB_HIP(hipStreamSynchronize(s));
     });
 }
 int rb_graph_contains(rb_graph *g, const uint64_t *h0, size_t n, uint8_t *out) { return rb_filter_lookup(g, RB_DBGBF, h0, n, out); }

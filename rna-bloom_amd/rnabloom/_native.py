@@ -72,6 +72,7 @@ SYMBOLS = [
     ("rb_graph_contains", _i32, [_vp, _vp, _sz, _vp]),
     ("rb_graph_count", _i32, [_vp, _vp, _sz, _vp]),
     ("rb_filter_lookup", _i32, [_vp, _i32, _vp, _sz, _vp]),
+    ("rb_filter_lookup_then_add", _i32, [_vp, _i32, _vp, _sz, _vp]),
     ("rb_filter_get_count", _i32, [_vp, _vp, _sz, _vp]),
     ("rb_graph_kmers", _i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
     ("rb_graph_neighbors", _i32, [_vp, _vp, _vp, _vp, _sz, _i32, _vp, _vp, _vp]),

@@ -217,6 +217,12 @@ class BloomFilterDeBruijnGraph:
         check(lib.rb_filter_lookup(self.h, which, _ptr(a), a.size, _ptr(out)))
         return out.astype(bool)
 
+    def lookupThenAdd(self, which, h0):
+        """BloomFilter.lookupThenAdd for an array, in array order (R/bloom/BloomFilter.java:147-155)"""
+        a = _u64(np.atleast_1d(h0)); out = np.zeros(a.size, np.uint8)
+        check(lib.rb_filter_lookup_then_add(self.h, which, _ptr(a), a.size, _ptr(out)))
+        return out.astype(bool)
+
     def lookupReadKmerPair(self, pairHash): return self._lookup(N.RPKBF, pairHash)
     def lookupFragmentKmerPair(self, pairHash): return self._lookup(N.FPKBF, pairHash)
 

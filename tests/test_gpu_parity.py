@@ -651,3 +651,79 @@ def test_pair_only_and_fragment_workers_match_oracle(stranded):
         assert_same_state(og, gg)
         assert (gg.exportFilter(N.FPKBF) == og.fpkbf_bytes()).all()
     assert gg.popcount(N.FPKBF) > 1000
+
+
+@pytest.mark.parametrize("which,name", [(N.DBGBF, "dbgbf"), (N.RPKBF, "rpkbf")])
+def test_lookup_then_add_in_array_order(which, name):
+    """rb_filter_lookup_then_add: BloomFilter.lookupThenAdd over an array must answer as the sequential loop does — an
+    element is 'found' when earlier elements of the same array already set all of its bits.  A tiny filter (most
+    answers come from collisions inside the array), repeats, three rounds on the same filter."""
+    import ctypes as C
+    rng = np.random.default_rng(8)
+    og, gg = graph_pair(20_011, 30_011, 5_003)
+    ob = getattr(og.L, "rbo_graph_" + name)(og.g)
+    pool = rng.integers(0, 1 << 63, 3000, dtype=np.int64).astype(np.uint64)
+    seen_true = seen_false = 0
+    for rnd in range(3):
+        hs = pool[rng.integers(0, len(pool), 6000)]
+        exp = np.empty(hs.size, bool)
+        for i, h in enumerate(hs):
+            hv = rbo.ntm64(int(h), 25, 2)
+            exp[i] = bool(og.L.rbo_bloom_lookup_then_add(C.c_void_p(ob), hv.ctypes.data_as(C.c_void_p)))
+        got = gg.lookupThenAdd(which, hs)
+        assert (got == exp).all(), (rnd, int((got != exp).sum()))
+        seen_true += int(exp.sum()); seen_false += int((~exp).sum())
+        assert (gg.exportFilter(which) == getattr(og, name + "_bytes")()).all()
+    assert seen_true > 1000 and seen_false > 1000
+
+
+def test_standalone_filter_classes():
+    """rnabloom.bloom.BloomFilter / CountingBloomFilter (the reference's stand-alone filter classes) against the oracle's
+    stand-alone rbo_bloom and against an oracle graph's counting filter: add, lookup, lookupThenAdd, pop count, FPR,
+    bytes, counts after many increments of a small key set (probabilistic range), getBloomFilter(minCount)."""
+    import ctypes as C
+    from rnabloom.bloom import BloomFilter, CountingBloomFilter, PairedKeysBloomFilter
+    rng = np.random.default_rng(12)
+    L = rbo.lib()
+    size, h, k = 50_021, 3, 25
+    ob = L.rbo_bloom_new(size, h)
+    bf = BloomFilter(size, h, k)
+    keys = rng.integers(0, 1 << 63, 4000, dtype=np.int64).astype(np.uint64)
+    hv = lambda x: rbo.ntm64(int(x), k, h)
+    for x in keys[:2500]:
+        L.rbo_bloom_add(C.c_void_p(ob), hv(x).ctypes.data_as(C.c_void_p))
+    bf.add(keys[:2500])
+    exp = np.array([bool(L.rbo_bloom_lookup(C.c_void_p(ob), hv(x).ctypes.data_as(C.c_void_p))) for x in keys])
+    assert (bf.lookup(keys) == exp).all() and exp[:2500].all() and not exp.all()
+    order = keys[rng.integers(2000, 4000, 3000)]
+    exp = np.array([bool(L.rbo_bloom_lookup_then_add(C.c_void_p(ob), hv(x).ctypes.data_as(C.c_void_p))) for x in order])
+    assert (bf.lookupThenAdd(order) == exp).all()
+    assert bf.getPopCount() == L.rbo_bloom_popcount(C.c_void_p(ob)) and np.float32(bf.getFPR()) == np.float32(L.rbo_bloom_fpr(C.c_void_p(ob)))
+    n = C.c_int64(); p = L.rbo_bloom_bytes(C.c_void_p(ob), C.byref(n))
+    assert (bf.toBytes() == np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (n.value,))).all()
+    assert BloomFilter.getExpectedSize(1_000_000, 0.01, 2) == L.rbo_expected_size(1_000_000, 0.01, 2) == PairedKeysBloomFilter.getExpectedSize(1_000_000, 0.01, 2)
+    L.rbo_bloom_free(C.c_void_p(ob)); bf.destroy()
+    # counting filter: the oracle graph's cbf under addCountOnly is the same object (same generator: seed + op ordinal)
+    csize = 30_011
+    og = rbo.Graph(64, csize, 0, 1, 2, 1, k, True, False, 5)
+    cbf = CountingBloomFilter(csize, 2, k, rngSeed=5)
+    small = keys[:300]
+    for rnd in range(4):
+        seq = small[rng.integers(0, small.size, 5000)]
+        for x in seq:
+            og.add_count_only(rbo.ntm64(int(x), k, 2))
+        cbf.increment(seq)
+        assert (cbf.toBytes() == og.cbf_bytes()).all()
+    assert og.cbf_bytes().max() > 24
+    exp = np.array([L.rbo_cbf_get_count(C.c_void_p(L.rbo_graph_cbf(og.g)), rbo.ntm64(int(x), k, 2).ctypes.data_as(C.c_void_p)) for x in keys[:600]], np.float32)
+    assert (cbf.getCount(keys[:600]) == exp).all()
+    raw = og.cbf_bytes()
+    to_float = lambda b: float(b) if b <= 7 else float(((b & 7) | 8) * 2.0 ** ((b >> 3) - 1))     # MiniFloat.toFloat, R/util/MiniFloat.java:40-45
+    pops = []
+    for min_count in (20, 120):
+        want = np.packbits(np.array([to_float(int(b)) >= min_count for b in raw]), bitorder="little")
+        bmin = cbf.getBloomFilter(min_count)
+        assert (bmin.toBytes() == want).all()
+        pops.append(bmin.getPopCount()); bmin.destroy()
+    assert cbf.getPopCount() >= pops[0] > pops[1] >= 0
+    cbf.destroy()
