@@ -270,6 +270,9 @@ class Graph:
     def lookup_read_pair(self, h):
         a = self._h(h); return bool(self.L.rbo_graph_lookup_read_pair(self.g, _p(a)))
 
+    def lookup_fragment_pair(self, h):
+        a = self._h(h); return bool(self.L.rbo_graph_lookup_fragment_pair(self.g, _p(a)))
+
     def add_reads(self, seq, qual, offsets, min_q=3, flags=0, threads=1):
         st = AddStats()
         n = len(offsets) - 1

@@ -89,3 +89,62 @@ def getMaxCoveragePaths(graph, lefts, rights, bound, minKmerCov=1.0):
             elif reason[j] == 1:                                                            # :1637-1639
                 out[i] = rp[::-1]
     return out
+
+
+# ---- the k-mer-list pair helpers of BloomFilterDeBruijnGraph (R/graph/BloomFilterDeBruijnGraph.java:474-526), batched over sequences ----
+import numpy as np
+
+from . import _native as N
+
+
+def _combine(a, b):
+    """HashFunction.combineHashValues, R/bloom/hash/HashFunction.java:260-263 (uint64 arithmetic wraps like Java's long)"""
+    with np.errstate(over="ignore"):
+        return a ^ (b + np.uint64(0xFFFFFFFF9E3779B9) + (a << np.uint64(6)) + (b >> np.uint64(2)))
+
+
+def kmerPairHashValues(f, r, d, stranded):
+    """Kmer.getKmerPairHashValue / CanonicalKmer.getKmerPairHashValue (R/graph/Kmer.java:65-67, CanonicalKmer.java:61-72)
+    of the k-mers i and i + d of one sequence, for every i: combine(fL, fR), canonical: the signed minimum of that and
+    combine(rR, rL)."""
+    fl, fr = f[:-d], f[d:]
+    p = _combine(fl, fr)
+    if not stranded:
+        q = _combine(r[d:], r[:-d])
+        p = np.where(q.view(np.int64) < p.view(np.int64), q, p)
+    return p
+
+
+def _pairs_per_sequence(graph, seqs, d):
+    ko, f, r, _ = graph.getKmers(seqs)
+    out, spans = [], []
+    for i in range(len(seqs)):
+        a, b = int(ko[i]), int(ko[i + 1])
+        n = b - a - d
+        spans.append(max(n, 0))
+        if n > 0:
+            out.append(kmerPairHashValues(f[a:b], r[a:b], d, graph.stranded))
+    return (np.concatenate(out) if out else np.zeros(0, np.uint64)), spans
+
+
+def containsAllPairedKmers(graph, seqs, d):
+    """graph.containsAllPairedKmers(kmers) for many sequences (:496-511): False for a sequence without a pair"""
+    p, spans = _pairs_per_sequence(graph, seqs, d)
+    hit = graph.lookupFragmentKmerPair(p) if p.size else np.zeros(0, bool)
+    res, at = [], 0
+    for n in spans:
+        res.append(bool(n > 0 and hit[at:at + n].all()))
+        at += n
+    return res
+
+
+def lookupAndAddAllPairedKmers(graph, seqs, d):
+    """graph.lookupAndAddAllPairedKmers(kmers) for many sequences, in order (:513-526): per sequence the AND of
+    fpkbf.lookupThenAdd over its pairs (True for a sequence without a pair) — a later sequence sees the pairs of the earlier ones."""
+    p, spans = _pairs_per_sequence(graph, seqs, d)
+    hit = graph.lookupThenAdd(N.FPKBF, p) if p.size else np.zeros(0, bool)
+    res, at = [], 0
+    for n in spans:
+        res.append(bool(hit[at:at + n].all()))
+        at += n
+    return res

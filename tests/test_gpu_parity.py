@@ -727,3 +727,43 @@ def test_standalone_filter_classes():
         pops.append(bmin.getPopCount()); bmin.destroy()
     assert cbf.getPopCount() >= pops[0] > pops[1] >= 0
     cbf.destroy()
+
+
+@pytest.mark.parametrize("stranded", [False, True])
+def test_kmer_list_pair_helpers(stranded):
+    """graphutils.containsAllPairedKmers / lookupAndAddAllPairedKmers (BloomFilterDeBruijnGraph.java:496-526 over lists of
+    k-mers) for batches of sequences, against the same loops over the oracle's fragment pair filter; pair hash values
+    (Kmer / CanonicalKmer.getKmerPairHashValue) against the oracle's paired iterator."""
+    import ctypes as C
+    from rnabloom.graphutils import containsAllPairedKmers, lookupAndAddAllPairedKmers, kmerPairHashValues
+    k, d, mode = 25, 30, (0 if stranded else 1)
+    og, gg = graph_pair(100_003, 200_003, 50_021, stranded=stranded)
+    og.init_fragment_pairs(40_009, 2, d); gg.initializePairKmersBloomFilter(40_009, 2); gg.setFragPairedKmerDistance(d)
+    rng = np.random.default_rng(6)
+    genome = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 3000)]
+    seqs = []
+    for _ in range(300):
+        L = int(rng.integers(30, 140)); a = int(rng.integers(0, genome.size - L))
+        seqs.append(genome[a:a + L].tobytes())
+    ko, f, r, _ = gg.getKmers(seqs[:5])
+    for i in range(5):
+        if len(seqs[i]) >= k + d:
+            p, _, _ = rbo.hash_pairs_region(seqs[i], k, 1, d, mode)
+            assert (kmerPairHashValues(f[ko[i]:ko[i + 1]], r[ko[i]:ko[i + 1]], d, stranded) == p[:, 0]).all()
+    fp = og.L.rbo_graph_fpkbf(og.g)
+    for rnd in range(2):
+        exp_c, exp_l = [], []
+        for s in seqs:                                     # containsAll on the state before this round's adds
+            p = rbo.hash_pairs_region(s, k, 2, d, mode)[0] if len(s) >= k + d else np.zeros((0, 2), np.uint64)
+            exp_c.append(bool(p.shape[0] > 0 and all(og.lookup_fragment_pair(row) for row in p)))
+        assert containsAllPairedKmers(gg, seqs, d) == exp_c
+        for s in seqs:
+            p = rbo.hash_pairs_region(s, k, 2, d, mode)[0] if len(s) >= k + d else np.zeros((0, 2), np.uint64)
+            found = True
+            for row in p:
+                found &= bool(og.L.rbo_bloom_lookup_then_add(C.c_void_p(fp), np.ascontiguousarray(row).ctypes.data_as(C.c_void_p)))
+            exp_l.append(found)
+        assert lookupAndAddAllPairedKmers(gg, seqs, d) == exp_l
+        assert (gg.exportFilter(N.FPKBF) == og.fpkbf_bytes()).all()
+        assert rnd == 0 or all(exp_l)
+    assert any(exp_c) and not all(exp_c)
