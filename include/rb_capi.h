@@ -208,8 +208,11 @@ int rb_graph_walk(rb_graph *g, const char *seeds, const char *targets, size_t n,
  * walk (out_reason 0), one is taken, several are scored with getMaxMedianCoverage{Right,Left} (:248-310, :375-438: the
  * best minimum k-mer coverage over the depth-first paths of exactly `lookahead` k-mers starting at the candidate) and
  * the highest score wins, a tie going to the strictly larger count.  out_reason 3 = bound reached, 4 = seed with a
- * base outside ACGTU.  Outputs as rb_graph_walk (out_count may be NULL).  lookahead <= 16. */
-int rb_graph_greedy_extend(rb_graph *g, const char *seeds, size_t n, int direction, int lookahead, int bound,
+ * base outside ACGTU.  Outputs as rb_graph_walk (out_count may be NULL).  lookahead <= 16.
+ * gate (may be NULL): the `BloomFilter bf` of the gated variants (greedyExtendRight(graph, source, lookahead, bound, bf),
+ * :1978-1993; Kmer.getSuccessors(k, numHash, graph, bf), R/graph/Kmer.java:257-299: a neighbour must pass bf.lookup before
+ * its count is read) — another handle on the same device, same k, whose dbgbf is that filter. */
+int rb_graph_greedy_extend(rb_graph *g, const rb_graph *gate, const char *seeds, size_t n, int direction, int lookahead, int bound,
                            char *out_bases, float *out_count, int32_t *out_len, uint8_t *out_reason);
 
 /* ---- filter state: popcount / FPR / raw bytes (the on-disk format of

@@ -421,7 +421,7 @@ def get_max_coverage_path(og, left, right, bound, min_cov=1.0, k=25, low_complex
     return None
 
 
-def greedy_extend(og, source, direction, lookahead, bound, k=25):
+def greedy_extend(og, source, direction, lookahead, bound, k=25, gate=None, stranded=False):
     """Restatement of GraphUtils.greedyExtendRight / greedyExtendLeft(graph, source, lookahead, bound)
     (R/util/GraphUtils.java:1961-1976 / :1906-1921), greedyExtendRightOnce / LeftOnce (:501-529 / :564-592) and
     getMaxMedianCoverageRight / Left (:248-310 / :375-438), statement by statement over the oracle graph.
@@ -432,6 +432,11 @@ def greedy_extend(og, source, direction, lookahead, bound, k=25):
         f4, r4, c4 = og.neighbors(f, r, b[0] if direction == 0 else b[-1], direction)
         out = []
         for i in range(4):
+            if gate is not None:     # Kmer.getSuccessors(k, numHash, graph, bf) :257-299: bf.lookup(hVals) first; hVals[0] is canonical
+                fi, ri = int(f4[i]), int(r4[i])
+                sf, sr = fi - (1 << 64) if fi >> 63 else fi, ri - (1 << 64) if ri >> 63 else ri
+                if not gate(fi if (stranded or sf <= sr) else ri):
+                    continue
             if c4[i] >= 1:
                 nb = b"ACGT"[i:i + 1]
                 out.append(((b[1:] + nb) if direction == 0 else (nb + b[:-1]), float(c4[i]), int(f4[i]), int(r4[i])))

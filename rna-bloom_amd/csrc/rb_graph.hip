@@ -905,8 +905,9 @@ __global__ void k_walk_max_cov(FilterView fv, int stranded, int k, int direction
 // per level, the siblings not yet tried — the reference's `frontier` of neighbour deques.
 constexpr int WALK_MAX_LOOKAHEAD = 16;
 struct WalkCand { uint64_t f, r; float c; uint32_t in; };
-__device__ __forceinline__ int walk_neighbors(const FilterView &fv, int stranded, uint32_t uk, int direction, uint64_t f, uint64_t r,
-                                              uint32_t oc, float min_cov, WalkCand *out) {
+struct WalkGate { const uint32_t *bits; Mod mod; int num_hash; };      // the extra BloomFilter of the `bf` variants, bits == nullptr: none
+__device__ __forceinline__ int walk_neighbors(const FilterView &fv, const WalkGate &gate, int stranded, uint32_t uk, int direction,
+                                              uint64_t f, uint64_t r, uint32_t oc, float min_cov, WalkCand *out) {
     const uint64_t s_out = seed_of(oc), sc_out = seed_of(3u - oc);
     int n = 0;
     for (uint32_t in = 0; in < 4u; ++in) {
@@ -918,12 +919,14 @@ __device__ __forceinline__ int walk_neighbors(const FilterView &fv, int stranded
             nf = rotr(f, 1) ^ rotr(s_out, 1) ^ rotl(seed_of(in), uk - 1u);
             if (!stranded) nr = rotl(r, 1) ^ rotl(sc_out, uk) ^ seed_of(3u - in);
         }
-        const float c = graph_count(fv, stranded ? nf : smin(nf, nr));
+        const uint64_t h0 = stranded ? nf : smin(nf, nr);
+        if (gate.bits && !bits_lookup(gate.bits, gate.mod, gate.num_hash, fv.kmul, h0)) continue;   // Kmer.getSuccessors(k, numHash, graph, bf): bf.lookup first
+        const float c = graph_count(fv, h0);
         if (c >= min_cov) { out[n].f = nf; out[n].r = nr; out[n].c = c; out[n].in = in; ++n; }
     }
     return n;
 }
-__global__ void k_greedy_extend(FilterView fv, int stranded, int k, int direction, const uint8_t *__restrict__ seeds, size_t n,
+__global__ void k_greedy_extend(FilterView fv, WalkGate gate, int stranded, int k, int direction, const uint8_t *__restrict__ seeds, size_t n,
                                 int lookahead, int bound, uint8_t *__restrict__ seq, uint8_t *__restrict__ out_b,
                                 float *__restrict__ out_c, int32_t *__restrict__ out_len, uint8_t *__restrict__ out_reason) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -948,7 +951,7 @@ __global__ void k_greedy_extend(FilterView fv, int stranded, int k, int directio
     int fr_n[WALK_MAX_LOOKAHEAD], fr_next[WALK_MAX_LOOKAHEAD];
     WalkCand path[WALK_MAX_LOOKAHEAD + 1];             // path[0] = the candidate being scored ("source")
     while (len < bound) {
-        const int nc = walk_neighbors(fv, stranded, uk, direction, f, r, code_of_char(sq[len]), 1.0f, cand);
+        const int nc = walk_neighbors(fv, gate, stranded, uk, direction, f, r, code_of_char(sq[len]), 1.0f, cand);
         if (nc == 0) { reason = 0; break; }
         int best = 0;
         if (nc > 1) {
@@ -960,7 +963,7 @@ __global__ void k_greedy_extend(FilterView fv, int stranded, int k, int directio
                 path[0] = cand[ci];
                 int psize = 1, depth = 0;                // psize = path.size(); depth = frontier.size()
                 WalkCand nb[4];
-                int nn = walk_neighbors(fv, stranded, uk, direction, cand[ci].f, cand[ci].r, code_of_char(sq[(size_t)len + 1u]), 1.0f, nb);
+                int nn = walk_neighbors(fv, gate, stranded, uk, direction, cand[ci].f, cand[ci].r, code_of_char(sq[(size_t)len + 1u]), 1.0f, nb);
                 if (nn == 0) score = (lookahead > 0) ? 0.0f : cand[ci].c;
                 else {
                     float best_path = 0.0f;
@@ -972,7 +975,7 @@ __global__ void k_greedy_extend(FilterView fv, int stranded, int k, int directio
                         if (psize < lookahead) {
                             const WalkCand &cur = path[psize - 1];
                             // cursor = k-mer number (psize-1) after the candidate: its leaving base is sq[len + 1 + (psize-1)]
-                            nn = walk_neighbors(fv, stranded, uk, direction, cur.f, cur.r, code_of_char(sq[(size_t)len + (size_t)psize]), 1.0f, nb);
+                            nn = walk_neighbors(fv, gate, stranded, uk, direction, cur.f, cur.r, code_of_char(sq[(size_t)len + (size_t)psize]), 1.0f, nb);
                             if (nn > 0) {
                                 for (int q = 0; q < nn; ++q) frontier[depth][q] = nb[q];
                                 fr_n[depth] = nn; fr_next[depth] = 1; ++depth;
@@ -2036,9 +2039,13 @@ int rb_graph_walk(rb_graph *g, const char *seeds, const char *targets, size_t n,
     });
 }
 
-int rb_graph_greedy_extend(rb_graph *g, const char *seeds, size_t n, int direction, int lookahead, int bound,
+int rb_graph_greedy_extend(rb_graph *g, const rb_graph *gate, const char *seeds, size_t n, int direction, int lookahead, int bound,
                            char *out_bases, float *out_count, int32_t *out_len, uint8_t *out_reason) {
     return guarded([&] {
+        if (gate) {
+            RB_REQUIRE(gate->dbg.bits && !gate->shard && gate->p.device == g->p.device && gate->k == g->k,
+                       "rb_graph_greedy_extend: the gate must be a filter on the same device with the same k");
+        }
         RB_REQUIRE(g && (n == 0 || (seeds && out_bases && out_len && out_reason)), "rb_graph_greedy_extend: null argument");
         RB_REQUIRE(direction == 0 || direction == 1, "rb_graph_greedy_extend: direction must be 0 (right) or 1 (left)");
         RB_REQUIRE(bound >= 1 && bound <= (1 << 20), "rb_graph_greedy_extend: bound out of range [1, 2^20]");
@@ -2055,7 +2062,8 @@ int rb_graph_greedy_extend(rb_graph *g, const char *seeds, size_t n, int directi
         int32_t *dlen = reinterpret_cast<int32_t *>(dc + nb);
         uint8_t *dreason = reinterpret_cast<uint8_t *>(dlen + n);
         RB_HIP(hipMemcpyAsync(dseed, seeds, n * k, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_greedy_extend, dim3(blocks_for((int64_t)n, 64)), dim3(64), 0, s, g->view(0, 0), (int)g->stranded, g->k, direction,
+        WalkGate wg{gate ? gate->dbg.bits : nullptr, gate ? gate->dbg.mod : g->dbg.mod, gate ? gate->dbg.num_hash : 0};
+        hipLaunchKernelGGL(k_greedy_extend, dim3(blocks_for((int64_t)n, 64)), dim3(64), 0, s, g->view(0, 0), wg, (int)g->stranded, g->k, direction,
                            dseed, n, lookahead, bound, dseq, dbases, dc, dlen, dreason);
         RB_HIP(hipGetLastError());
         RB_HIP(hipMemcpyAsync(out_len, dlen, n * 4, hipMemcpyDeviceToHost, s));

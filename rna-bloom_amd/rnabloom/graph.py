@@ -275,16 +275,17 @@ class BloomFilterDeBruijnGraph:
                                 _ptr(ln), _ptr(reason)))
         return bases, f, r, c, ln, reason
 
-    def greedyExtend(self, seeds, direction, lookahead, bound, counts=True):
+    def greedyExtend(self, seeds, direction, lookahead, bound, counts=True, bf=None):
         """GraphUtils.greedyExtendRight (direction 0) / greedyExtendLeft (1) for many source k-mers at once
-        (R/util/GraphUtils.java:1961-1976, :1906-1921).  Returns (bases[n, bound], count[n, bound] or None, len[n], reason[n])."""
+        (R/util/GraphUtils.java:1961-1976, :1906-1921; with bf — a rnabloom.bloom.BloomFilter — the gated variants
+        :1978-1993, :1940-1955).  Returns (bases[n, bound], count[n, bound] or None, len[n], reason[n])."""
         n = len(seeds)
         sb = np.frombuffer(b"".join(seeds), np.uint8) if n else np.zeros(0, np.uint8)
         assert sb.size == n * self.k, "every seed must have k bases"
         bases = np.zeros((n, bound), np.uint8); ln = np.zeros(n, np.int32); reason = np.zeros(n, np.uint8)
         c = np.zeros((n, bound), np.float32) if counts else None
-        check(lib.rb_graph_greedy_extend(self.h, _ptr(sb), n, direction, lookahead, bound, _ptr(bases), _ptr(c) if counts else None,
-                                         _ptr(ln), _ptr(reason)))
+        check(lib.rb_graph_greedy_extend(self.h, bf._g.h if bf is not None else None, _ptr(sb), n, direction, lookahead, bound, _ptr(bases),
+                                         _ptr(c) if counts else None, _ptr(ln), _ptr(reason)))
         return bases, c, ln, reason
 
     # ---- filter state ----

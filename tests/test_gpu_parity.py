@@ -767,3 +767,38 @@ def test_kmer_list_pair_helpers(stranded):
         assert (gg.exportFilter(N.FPKBF) == og.fpkbf_bytes()).all()
         assert rnd == 0 or all(exp_l)
     assert any(exp_c) and not all(exp_c)
+
+
+def test_greedy_extend_with_bloom_filter_gate():
+    """the `bf` variants (greedyExtendRight(graph, source, lookahead, bound, bf): a neighbour must pass bf.lookup before its
+    count is read, Kmer.java:257-299): the gate is a stand-alone rnabloom.bloom.BloomFilter holding the k-mers of a third
+    of the reads; oracle: the same restatement with the oracle's stand-alone filter as the gate."""
+    import ctypes as C
+    from rnabloom.bloom import BloomFilter
+    (ls, lq, off), _ = make_reads(1200, 3000, 0.01, 0.0, seed=67)
+    og, gg = graph_pair(150_001, 600_011, 10_007, pairs=False)
+    og.add_reads(ls, lq, off, 3, 0); gg.addReads(ls, lq, off, 3)
+    third = 12                                            # the first 12 reads feed the gate: about a third of the genome
+    gb = ReadBatch.from_ascii(ls[:off[third]], None, off[:third + 1], 3)
+    h0 = gb.nthash(25, 1)
+    L = rbo.lib()
+    ob = L.rbo_bloom_new(400_009, 2)
+    bf = BloomFilter(400_009, 2, 25)
+    bf.add(h0)
+    for x in np.unique(h0):
+        L.rbo_bloom_add(C.c_void_p(ob), rbo.ntm64(int(x), 25, 2).ctypes.data_as(C.c_void_p))
+    n = C.c_int64(); p = L.rbo_bloom_bytes(C.c_void_p(ob), C.byref(n))
+    assert (bf.toBytes() == np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (n.value,))).all()
+    gate = lambda h: bool(L.rbo_bloom_lookup(C.c_void_p(ob), rbo.ntm64(int(h), 25, 2).ctypes.data_as(C.c_void_p)))
+    rng = np.random.default_rng(3)
+    seeds = [bytes(ls[off[r] + p: off[r] + p + 25]) for r, p in zip(rng.integers(0, 1200, 120), rng.integers(0, 120, 120))]
+    shorter = 0
+    for direction in (0, 1):
+        bases, c, ln, reason = gg.greedyExtend(seeds, direction, 4, 30, bf=bf)
+        free = gg.greedyExtend(seeds, direction, 4, 30)[2]
+        for i, s in enumerate(seeds):
+            eb, ec = rbo.greedy_extend(og, s, direction, 4, 30, gate=gate)
+            assert int(ln[i]) == len(eb) and bytes(bases[i, :ln[i]]) == eb and (c[i, :ln[i]] == np.array(ec, np.float32)).all()
+        shorter += int((ln < free).sum())
+    assert shorter > 10                                    # the gate did cut walks short
+    L.rbo_bloom_free(C.c_void_p(ob)); bf.destroy()
