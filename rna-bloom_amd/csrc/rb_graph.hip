@@ -819,6 +819,8 @@ __global__ void k_walk_max_cov(FilterView fv, int stranded, int k, int direction
                                const uint8_t *__restrict__ targets, size_t n, int bound, float min_cov,
                                uint8_t *__restrict__ seq, uint8_t *__restrict__ out_b, uint64_t *__restrict__ out_f, uint64_t *__restrict__ out_r,
                                float *__restrict__ out_c, int32_t *__restrict__ out_len, uint8_t *__restrict__ out_reason) {
+    __shared__ uint32_t s_seen[32][64];                   // [word][lane]: bitmap of the hashes the lane's walk appended
+    for (int q = 0; q < 32; ++q) s_seen[q][threadIdx.x] = 0u;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t uk = (uint32_t)k;
@@ -881,10 +883,15 @@ __global__ void k_walk_max_cov(FilterView fv, int stranded, int k, int direction
             }
             if (eq) { reason = 1; break; }
         }
+        // has the walk appended this k-mer before?  A per-lane bitmap of the appended hashes (1024 bits in LDS) says "no"
+        // for almost every step; only a set bit sends the lane through the list of its hashes (then bases)
+        const uint32_t hb = (uint32_t)((best_f * 0x9E3779B97F4A7C15ull) >> 54);       // 10 bits
         bool seen = false;
-        for (int j = 0; j < len && !seen; ++j)
-            if (pf[j] == best_f && same_as(sq + (size_t)j + 1u, true)) seen = true;
+        if ((s_seen[hb >> 5][threadIdx.x] >> (hb & 31u)) & 1u)
+            for (int j = 0; j < len && !seen; ++j)
+                if (pf[j] == best_f && same_as(sq + (size_t)j + 1u, true)) seen = true;
         if (seen) { reason = 2; break; }
+        s_seen[hb >> 5][threadIdx.x] |= 1u << (hb & 31u);
         sq[(size_t)uk + (size_t)len] = nb;
         out_b[i * (size_t)bound + (size_t)len] = nb;
         pf[len] = best_f; pr[len] = best_r; pc[len] = best_c;
