@@ -500,3 +500,26 @@ def greedy_extend(og, source, direction, lookahead, bound, k=25, gate=None, stra
         out += nxt[0][-1:] if direction == 0 else nxt[0][:1]
         counts.append(nxt[1])
     return bytes(out), counts
+
+
+def get_kmers_min_coverage(og, seq, min_cov):
+    """Restatement of HashFunction.getKmers(seq, numHash, graph, minCoverage), R/bloom/hash/HashFunction.java:86-134,
+    with Python lists standing in for the ArrayLists (object identity matters: `longestSegment != currentSegment`).
+    Returns the list of (k-mer index, count) of the returned segment."""
+    f, r, c = og.get_kmers(seq)
+    current = []
+    longest = current
+    current_min = longest_min = float("inf")
+    longest_len = 0
+    for i, x in enumerate(c):
+        if x >= min_cov:
+            current.append((i, float(x)))
+            current_min = min(current_min, float(x))
+        elif current:
+            if longest is not current:
+                n = len(current)
+                if n > longest_len or (n == longest_len and current_min > longest_min):
+                    longest, longest_min, longest_len = current, current_min, n
+            current = []
+            current_min = float("inf")
+    return longest

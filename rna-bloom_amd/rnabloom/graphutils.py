@@ -148,3 +148,38 @@ def lookupAndAddAllPairedKmers(graph, seqs, d):
         res.append(bool(hit[at:at + n].all()))
         at += n
     return res
+
+
+def getKmersMinCoverage(graph, seqs, minCoverage):
+    """HashFunction.getKmers(seq, numHash, graph, minCoverage) (R/bloom/hash/HashFunction.java:86-134) for many sequences:
+    the k-mers of the "longest" run with count >= minCoverage — with the reference's bookkeeping kept as it is: the
+    list that is open when the scan starts is the result unless a LATER closed run replaces it (its length is never
+    recorded, so any later closed run does), and a run still open at the end of the sequence is never compared.
+    Returns per sequence (first k-mer index, number of k-mers, their counts)."""
+    ko, _, _, c = graph.getKmers(seqs)
+    out = []
+    for i in range(len(seqs)):
+        cnt = c[int(ko[i]):int(ko[i + 1])]
+        cur_start, cur_len, cur_min = 0, 0, float("inf")
+        best = None                      # None: the result is still the list that was open at the start
+        first_open = True                # the current list IS that first list
+        first = (0, 0)
+        best_len, best_min = 0, float("inf")
+        for j, x in enumerate(cnt):
+            if x >= minCoverage:
+                if cur_len == 0:
+                    cur_start = j
+                cur_len += 1
+                cur_min = min(cur_min, float(x))
+            elif cur_len:
+                if first_open:
+                    first = (cur_start, cur_len)
+                elif cur_len > best_len or (cur_len == best_len and cur_min > best_min):
+                    best, best_len, best_min = (cur_start, cur_len), cur_len, cur_min
+                first_open = False
+                cur_len, cur_min = 0, float("inf")
+        if first_open:
+            first = (cur_start, cur_len) if cur_len else (0, 0)
+        s, n = best if best is not None else first
+        out.append((s, n, cnt[s:s + n].copy()))
+    return out

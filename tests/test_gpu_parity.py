@@ -802,3 +802,26 @@ def test_greedy_extend_with_bloom_filter_gate():
         shorter += int((ln < free).sum())
     assert shorter > 10                                    # the gate did cut walks short
     L.rbo_bloom_free(C.c_void_p(ob)); bf.destroy()
+
+
+def test_get_kmers_min_coverage_variant():
+    """graphutils.getKmersMinCoverage against the object-identity-faithful restatement of
+    HashFunction.getKmers(seq, numHash, graph, minCoverage) over the oracle graph: sequences with several runs above the
+    threshold (the reference keeps the first run only if no later closed run exists, and never looks at a run that is
+    still open at the end)."""
+    from rnabloom.graphutils import getKmersMinCoverage
+    (ls, lq, off), _ = make_reads(1500, 4000, 0.01, 0.0, seed=91)
+    og, gg = graph_pair(300_007, 1_200_007, 10_007, pairs=False)
+    og.add_reads(ls, lq, off, 3, 0); gg.addReads(ls, lq, off, 3)
+    rng = np.random.default_rng(2)
+    genome_like = [bytes(ls[off[i]:off[i + 1]]) for i in range(200)]
+    seqs = genome_like + [b"ACGT" * 10, b"", genome_like[0][:30] + b"N" + genome_like[1][:60]]
+    kinds = set()
+    for min_cov in (2.0, 6.0, 20.0):
+        got = getKmersMinCoverage(gg, seqs, min_cov)
+        for i, s in enumerate(seqs):
+            exp = rbo.get_kmers_min_coverage(og, s, min_cov)
+            st, n, cnt = got[i]
+            assert n == len(exp) and (n == 0 or (st == exp[0][0] and (cnt == np.array([x[1] for x in exp], np.float32)).all())), (min_cov, i)
+            kinds.add("empty" if n == 0 else ("from the start" if st == 0 else "later run"))
+    assert kinds == {"empty", "from the start", "later run"}
