@@ -238,6 +238,85 @@ class ShardRank:
         if out is not None:
             out.append(res.astype(bool) if what == 0 else res)
 
+    def walk(self, seeds, direction, bound, min_cov=1.0, out=None):
+        """Coroutine: greedy maximum-coverage walks (the semantics of rb_graph_walk without a target) on the SHARDED graph.
+        The filters are spread over the ranks, so every step is one query exchange for the 4 neighbours of every walk
+        that is still alive on any rank (rb_shard_query_*: 2 all-to-alls); the rolling hashes and the choice of the
+        neighbour are host arithmetic here (numpy) — a functional path for multi-GPU graphs, not a tuned one.
+        Every rank calls this with its own seeds (possibly none).  out gets (bases[n, bound], count[n, bound], len[n], reason[n])."""
+        k, stranded = int(self.p.k), bool(self.p.stranded)
+        n = len(seeds)
+        u64 = np.uint64
+        SEED = np.array([0x3c8bfbb395c60474, 0x3193c18562a02b4c, 0x20323ed082572324, 0x295549f54be24456], u64)   # NTHash.java:39-43
+        rotl = lambda v, s: (v << u64(s % 64)) | (v >> u64((64 - s % 64) % 64)) if s % 64 else v
+        rotr = lambda v, s: (v >> u64(s % 64)) | (v << u64((64 - s % 64) % 64)) if s % 64 else v
+        lut = np.full(256, 4, np.uint8)
+        for ch, c in ((b"A", 0), (b"C", 1), (b"G", 2), (b"T", 3), (b"U", 3), (b"a", 0), (b"c", 1), (b"g", 2), (b"t", 3), (b"u", 3)):
+            lut[ch[0]] = c
+        codes = lut[np.frombuffer(b"".join(seeds), np.uint8)].reshape(n, k) if n else np.zeros((0, k), np.uint8)
+        valid = (codes < 4).all(axis=1) if n else np.zeros(0, bool)
+        cc = np.where(codes < 4, codes, 0)
+        f = np.zeros(n, u64); r = np.zeros(n, u64)
+        with np.errstate(over="ignore"):
+            for q in range(k):                                     # NTP64 / NTP64RC from scratch (NTHash.java:332-337, 367-373)
+                f = rotl(f, 1) ^ SEED[cc[:, q]]
+                r = r ^ rotl(SEED[3 - cc[:, q]], q)
+        # seq[i]: the walk's bases in walk orientation (seed, reversed for a left walk, then the appended bases)
+        seq = np.zeros((n, k + bound), np.uint8)
+        seq[:, :k] = cc if direction == 0 else cc[:, ::-1]
+        hist = np.zeros((n, bound), u64)
+        bases = np.zeros((n, bound), np.uint8); counts = np.zeros((n, bound), np.float32)
+        ln = np.zeros(n, np.int32); reason = np.where(valid, 3, 4).astype(np.uint8)
+        alive = valid.copy()
+        acgt = np.frombuffer(b"ACGT", np.uint8)
+        for step in range(bound):
+            flags = yield ("ints", [int(alive.any())])
+            if not any(x[0] for x in flags):
+                break
+            idx = np.nonzero(alive)[0]
+            oc = seq[idx, step]                                    # base leaving the k-mer
+            s_out, sc_out = SEED[oc], SEED[3 - oc]
+            nf = np.zeros((idx.size, 4), u64); nr = np.zeros((idx.size, 4), u64)
+            with np.errstate(over="ignore"):
+                for b in range(4):
+                    if direction == 0:                             # NTHash.java:584-586 / :627-629
+                        nf[:, b] = rotl(f[idx], 1) ^ rotl(s_out, k) ^ SEED[b]
+                        nr[:, b] = rotr(r[idx], 1) ^ rotr(sc_out, 1) ^ rotl(SEED[3 - b], k - 1)
+                    else:                                          # NTM64B / NTPC64B :640-642 / :505-509
+                        nf[:, b] = rotr(f[idx], 1) ^ rotr(s_out, 1) ^ rotl(SEED[b], k - 1)
+                        nr[:, b] = rotl(r[idx], 1) ^ rotl(sc_out, k) ^ SEED[3 - b]
+            h0 = nf if stranded else np.where(nr.view(np.int64) < nf.view(np.int64), nr, nf)
+            res = []
+            yield from self.query(2, h0.reshape(-1), out=res)
+            c4 = res[0].reshape(-1, 4)
+            ok = c4 >= np.float32(min_cov)
+            masked = np.where(ok, c4, np.float32(-1))
+            best = masked.argmax(axis=1)                           # first strict maximum in A,C,G,T
+            has = ok.any(axis=1)
+            bf = nf[np.arange(idx.size), best]; br = nr[np.arange(idx.size), best]; bc = c4[np.arange(idx.size), best]
+            dead = idx[~has]
+            reason[dead] = 0; alive[dead] = False
+            keep = has.copy()
+            # a k-mer the walk appended before? (hash first, then the bases: Kmer.equals)
+            cand = np.nonzero(has)[0]
+            if step and cand.size:
+                hit = (hist[idx[cand], :step] == bf[cand, None])
+                for row in np.nonzero(hit.any(axis=1))[0]:
+                    i = idx[cand[row]]
+                    kmer = np.concatenate([seq[i, step + 1:step + k], [best[cand[row]]]])
+                    if any((seq[i, j + 1:j + 1 + k] == kmer).all() for j in np.nonzero(hit[row])[0]):
+                        keep[cand[row]] = False
+                        reason[i] = 2; alive[i] = False
+            sel = np.nonzero(keep)[0]
+            ii = idx[sel]
+            seq[ii, k + step] = best[sel]
+            hist[ii, step] = bf[sel]
+            bases[ii, step] = acgt[best[sel]]; counts[ii, step] = bc[sel]
+            f[ii] = bf[sel]; r[ii] = br[sel]
+            ln[ii] = step + 1
+        if out is not None:
+            out.append((bases, counts, ln, reason))
+
     def add_range(self, batch, first, n, flags, reads_per_substep, pos_bits):
         """Coroutine over all sub-batches of reads [first, first+n) — the same call on every rank."""
         n = int(n)
@@ -560,6 +639,12 @@ class LoopbackCluster:
 
     def getCount(self, per_rank_h0):
         return self._query(2, per_rank_h0)
+
+    def walkMaxCov(self, per_rank_seeds, direction, bound, minKmerCov=1.0):
+        """per_rank_seeds[r] = the seed k-mers of virtual rank r -> per rank (bases, count, len, reason), as graph.walkMaxCov"""
+        outs = [[] for _ in self.ranks]
+        run_loopback([r.walk(sd, direction, bound, minKmerCov, o) for r, sd, o in zip(self.ranks, per_rank_seeds, outs)])
+        return [o[0] for o in outs]
 
     def getCbfCount(self, per_rank_h0):
         return self._query(1, per_rank_h0)

@@ -127,3 +127,43 @@ def test_loopback_lookahead_modes(monkeypatch, overlap):
     check_filters(cl, og)
     assert og.cbf_bytes().max() > 24
     cl.destroy()
+
+
+@pytest.mark.parametrize("G,stranded", [(1, False), (2, False), (4, True), (8, False)])
+def test_walks_on_a_sharded_graph(G, stranded):
+    """ShardRank.walk (maximum-coverage walks over rb_shard_query exchanges, one exchange per step) must walk the sharded
+    graph exactly as rb_graph_walk walks the single-GPU graph built from the same reads: bases, counts, lengths,
+    reasons; ranks hold different numbers of seeds (one of them none), seeds with N, a loop."""
+    from rnabloom.graph import BloomFilterDeBruijnGraph
+    d = synth.generate_pairs(1500, G=4000, err=0.004, n_rate=1e-3, seed=77)
+    sizes = (300_007, 1_200_007, 50_021)
+    s, off = synth.flat(d["left"]); q, _ = synth.flat(d["lqual"])
+    unit = bytes(np.random.default_rng(1).choice(np.frombuffer(b"ACGT", np.uint8), 30)) * 5      # a tandem repeat: walks loop
+    s = np.concatenate([s, np.frombuffer(unit, np.uint8)]); q = np.concatenate([q, np.full(len(unit), ord("I"), np.uint8)])
+    off = np.concatenate([off, [off[-1] + len(unit)]])
+    g1 = BloomFilterDeBruijnGraph(*sizes, 2, 2, 2, 25, stranded, True, rngSeed=9)
+    cl = LoopbackCluster(G, *sizes, 2, 2, 2, 25, stranded, True, rngSeed=9)
+    g1.addReads(s, q, off, 3)
+    cl.addBatch(ReadBatch.from_ascii(s, q, off, 3), 150, reads_per_substep=700)
+    rng = np.random.default_rng(4)
+    seeds = [bytes(s[off[r] + p: off[r] + p + 25]) for r, p in zip(rng.integers(0, 1500, 240), rng.integers(0, 120, 240))]
+    seeds[3] = seeds[3][:8] + b"N" + seeds[3][9:]
+    seeds[5] = unit[40:65]
+    cuts = [0] + sorted(rng.integers(0, len(seeds), G - 1).tolist()) + [len(seeds)] if G > 1 else [0, len(seeds)]
+    if G > 2:
+        cuts[1] = cuts[0]                                   # rank 0 has no seeds at all
+    per_rank = [seeds[cuts[i]:cuts[i + 1]] for i in range(G)]
+    seen = set()
+    for direction in (0, 1):
+        for min_cov, bound in ((1.0, 45), (3.0, 12)):
+            eb, _, _, ec, el, er = g1.walkMaxCov(seeds, direction, bound, min_cov)
+            got = cl.walkMaxCov(per_rank, direction, bound, min_cov)
+            for rk in range(G):
+                bases, c, ln, reason = got[rk]
+                a, b = cuts[rk], cuts[rk + 1]
+                assert (ln == el[a:b]).all() and (reason == er[a:b]).all()
+                m = np.arange(bound)[None, :] < ln[:, None]
+                assert (bases[m] == eb[a:b][m]).all() and (c[m] == ec[a:b][m]).all()
+            seen |= set(er.tolist())
+    assert seen >= {0, 2, 3, 4}
+    g1.destroy(); cl.destroy()
