@@ -20,6 +20,13 @@ def _reads():
     return synth.generate_pairs(1800, G=5000, err=0.002, n_rate=1e-3, seed=29, uniform_expr=True)
 
 
+def _seeds(d):
+    from rnabloom import synth
+    s, off = synth.flat(d["left"])
+    rng = np.random.default_rng(3)
+    return [bytes(s[off[r] + p: off[r] + p + 25]) for r, p in zip(rng.integers(0, 1800, 90), rng.integers(0, 120, 90))]
+
+
 def _rank_main(rank, world, port, outdir, mode):
     for p in (ROOT, os.path.join(ROOT, "rna-bloom_amd"), os.path.join(ROOT, "tests")):
         if p not in sys.path:
@@ -46,6 +53,13 @@ def _rank_main(rank, world, port, outdir, mode):
     for which, tag in ((N.DBGBF, "dbg"), (N.CBF, "cbf"), (N.RPKBF, "rpk")):
         np.save(os.path.join(outdir, "%s%d.npy" % (tag, rank)), sr.local_filter(which))
     np.save(os.path.join(outdir, "stats%d.npy" % rank), np.array([sr.stats["kmers"], sr.stats["conflict_ops"], sr.stats["sorted_kmers"]]))
+    # maximum-coverage walks on the sharded graph: every rank walks its own slice of the seeds (rank 0: none)
+    seeds = _seeds(d)
+    mine = seeds[len(seeds) * rank // world: len(seeds) * (rank + 1) // world] if rank else []
+    res = []
+    sharded.run_distributed(sr.walk(mine, 0, 30, 2.0, res))
+    bases, counts, ln, reason = res[0]
+    np.save(os.path.join(outdir, "walk%d.npy" % rank), np.concatenate([bases, ln[:, None].astype(np.uint8), reason[:, None]], axis=1))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -72,4 +86,13 @@ def test_multiprocess_ranks_match_oracle(world, mode):
             assert bad.size == 0, "%s differs at %d bytes: %s" % (tag, bad.size, bad[:6])
         stats = np.sum([np.load(os.path.join(out, "stats%d.npy" % r)) for r in range(world)], axis=0)
         assert stats[0] == total and stats[1] > 0 and stats[2] < stats[0]
+        seeds = _seeds(d)
+        for r in range(1, world):
+            w = np.load(os.path.join(out, "walk%d.npy" % r))
+            mine = seeds[len(seeds) * r // world: len(seeds) * (r + 1) // world]
+            assert w.shape[0] == len(mine)
+            for i, sd in enumerate(mine):
+                eb, ec, er = rbo.walk_max_cov(og, sd, 0, 30, 2.0)
+                assert (int(w[i, 30]), int(w[i, 31])) == (len(eb), er) and bytes(w[i, :len(eb)]) == eb
+        assert np.load(os.path.join(out, "walk0.npy")).shape[0] == 0
     assert og.cbf_bytes().max() > 24
