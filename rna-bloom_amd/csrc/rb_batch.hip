@@ -605,6 +605,99 @@ k_filter_windows_fast(const uint64_t *__restrict__ codes, const uint32_t *__rest
     if (threadIdx.x == 0 && total) atomicAdd(&total_spread[16u * (blockIdx.x & 31u)], total);
 }
 
+// Emit pass that resumes from the rolling state the read-per-lane prefilter saved for every word (k_filter_reads:
+// (f, r) after base word_start + k - 2, i.e. just before the word's first window ends): 32 steps per word instead of
+// 32 + k - 1, and no history registers — at step t the base that leaves is base word_start - 1 + t (the word itself
+// shifted by one base, its predecessor's last base in front) and the base that enters is word_start + k - 1 + t
+// (the word and its successor, funnel-shifted).  A window is written iff its keep bit is set (keep bits exist only
+// for usable windows).  Otherwise k_hash_windows_sparse: list of the words that keep something, 512-record LDS slab.
+template <int MODE>
+__global__ void __launch_bounds__(64)
+k_hash_windows_resume(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
+                      const uint32_t *__restrict__ word_read, const uint32_t *__restrict__ woff,
+                      const uint32_t *__restrict__ len, int64_t w0, int64_t nw, int k,
+                      const uint32_t *__restrict__ chunk_off, uint32_t first_read, uint32_t pos_bits,
+                      uint64_t *__restrict__ keys, uint32_t *__restrict__ vals, const uint32_t *__restrict__ keepmask,
+                      const ulonglong2 *__restrict__ wstate) {
+    constexpr uint32_t SLAB = RB_EMIT_SLAB, BW = RB_SPARSE_WORDS;
+    __shared__ uint64_t s_key[SLAB + SLAB / 32 + 1];
+    __shared__ uint32_t s_val[SLAB + SLAB / 32 + 1];
+    __shared__ uint64_t s_tf[25], s_tr[25];
+    __shared__ uint16_t s_list[BW];
+    const uint32_t uk = (uint32_t)k, lane = threadIdx.x;
+    const int64_t blk0 = (int64_t)blockIdx.x * BW;
+    const int64_t blk_end = (blk0 + BW < nw) ? blk0 + BW : nw;
+    const uint32_t O0 = chunk_off[blk0], O1 = chunk_off[blk_end];
+    if (O0 == O1) return;
+    if (threadIdx.x < 25) {
+        const uint32_t o = threadIdx.x / 5u, in = threadIdx.x % 5u;   // 0 = null, 1..4 = A,C,G,T
+        const uint64_t so = o ? seed_of(o - 1u) : 0ull, si = in ? seed_of(in - 1u) : 0ull;
+        const uint64_t sco = o ? seed_of(4u - o) : 0ull, sci = in ? seed_of(4u - in) : 0ull;
+        s_tf[threadIdx.x] = rotl(so, uk) ^ si;
+        s_tr[threadIdx.x] = rotr(sco, 1) ^ rotl(sci, uk - 1u);
+    }
+    uint32_t n_list = 0;                                           // uniform
+    for (uint32_t q = 0; q < BW; q += 64u) {
+        const int64_t i = blk0 + q + lane;
+        const bool ne = i < blk_end && chunk_off[i + 1] != chunk_off[i];
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(ne);
+        if (ne) s_list[n_list + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)(q + lane);
+        n_list += (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    for (uint32_t e0 = 0; e0 < n_list; e0 += 64u) {
+        const uint32_t e_last = (e0 + 64u < n_list) ? e0 + 63u : n_list - 1u;
+        const uint32_t R0 = chunk_off[blk0 + s_list[e0]] - O0, R1 = chunk_off[blk0 + s_list[e_last] + 1] - O0;
+        uint64_t ins = 0, outs = 0, f = 0, rv = 0;                 // entering / leaving codes of steps t, t+1, ... at bits 0.., 2..
+        uint32_t inv = 0, outv = 0, j = 0, out = 0, rel = 0, b0 = 0, keep = 0;
+        if (e0 + lane < n_list) {
+            const int64_t i = blk0 + s_list[e0 + lane];
+            const int64_t w = w0 + i;
+            const uint32_t r = word_read[w], wr = woff[r], L = len[r];
+            const uint32_t c = (uint32_t)(w - wr);
+            b0 = c * 32u;
+            keep = keepmask[i];
+            const uint32_t nwords = (L + 31u) >> 5;
+            const uint64_t cur = codes[w], nxt = (c + 1u < nwords) ? codes[w + 1] : 0ull;
+            const uint32_t curv = valid[w], nxtv = (c + 1u < nwords) ? valid[w + 1] : 0u;
+            const uint32_t pl = c ? (uint32_t)(codes[w - 1] >> 62) : 0u, plv = c ? (valid[w - 1] >> 31) : 0u;
+            outs = (cur << 2) | pl;  outv = (curv << 1) | plv;                       // base b0 - 1 + t
+            const uint32_t sh = uk - 1u;                                              // base b0 + k - 1 + t
+            ins = sh ? ((cur >> (2u * sh)) | (nxt << (64u - 2u * sh))) : cur;
+            inv = sh ? ((curv >> sh) | (nxtv << (32u - sh))) : curv;
+            const ulonglong2 st = wstate[i];
+            f = st.x; rv = st.y;
+            out = chunk_off[i] - O0;
+            rel = (r - first_read) << pos_bits;
+        }
+        for (uint32_t slab0 = R0; slab0 < R1; slab0 += SLAB) {
+            const uint32_t slab1 = (slab0 + SLAB < R1) ? slab0 + SLAB : R1;
+            while (j < 32u && (keep >> j) != 0u && out < slab1) {   // nothing kept at or after window j: done
+                const uint32_t in5 = (inv & 1u) ? ((uint32_t)ins & 3u) + 1u : 0u;
+                const uint32_t out5 = (outv & 1u) ? ((uint32_t)outs & 3u) + 1u : 0u;
+                ins >>= 2; inv >>= 1; outs >>= 2; outv >>= 1;
+                const uint32_t t = out5 * 5u + in5;
+                if (MODE != 2) f = rotl(f, 1) ^ s_tf[t];
+                if (MODE != 0) rv = rotr(rv, 1) ^ s_tr[t];
+                if ((keep >> j) & 1u) {
+                    const uint32_t o = out - slab0, q = o + (o >> 5);
+                    s_key[q] = (MODE == 0) ? f : (MODE == 2) ? rv : canonical(f, rv);
+                    s_val[q] = rel | (b0 + j);
+                    ++out;
+                }
+                ++j;
+            }
+            __syncthreads();
+            for (uint32_t x = threadIdx.x; x < slab1 - slab0; x += 64u) {
+                const uint32_t q = x + (x >> 5);
+                keys[O0 + slab0 + x] = s_key[q];
+                vals[O0 + slab0 + x] = s_val[q];
+            }
+            __syncthreads();
+        }
+    }
+}
+
 // ---- one read per lane (k <= 31, uniform batches) ----
 // k_filter_windows_fast / k_hash_windows_fast give every lane one 32-base word: 32 windows for 32 + k-1
 // walker steps, i.e. 1.94 steps per window at k = 25 — and the SQ counters show both kernels bound by
@@ -626,7 +719,7 @@ k_filter_reads(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ 
                const uint32_t *__restrict__ word_read, const uint32_t *__restrict__ len, int64_t w0, int64_t nw, int k,
                uint32_t W, uint32_t first_read, uint32_t pos_bits, uint64_t seed, uint64_t ordinal0, Npf cache, Mpf mcache,
                uint32_t *__restrict__ cnt, uint32_t *__restrict__ keepmask, uint32_t *__restrict__ total_spread,
-               uint32_t dbg_flags, uint32_t own_mask, uint32_t own_rank) {
+               uint32_t dbg_flags, uint32_t own_mask, uint32_t own_rank, ulonglong2 *__restrict__ wstate) {
     __shared__ uint64_t s_tf[25], s_tr[25];
     extern __shared__ uint32_t s_ring[];                        // [k-m+1][lane], dynamic: orders of the current block of m-mers / suffix minima of the previous one
     __shared__ unsigned long long s_bkt[MPF ? 16 * 64 : 1];     // [slot][lane]: image of the current bucket
@@ -728,6 +821,9 @@ k_filter_reads(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ 
                             ++blk_a;
                     }
                 }
+                // the rolling state just before the first window of a word ends (the next base is word start + k - 1):
+                // the emit pass resumes from it instead of re-walking the k-1 bases in front of the word's windows
+                if (wstate && ((b + 1u - uk) & 31u) == 0u && b + 1u >= uk) wstate[w + ((b + 1u - uk) >> 5)] = make_ulonglong2(f, rv);
             }
             cnt[w + done] = kept; keepmask[w + done] = mask; ++done;       // the word the last window starts in
         }
@@ -904,7 +1000,7 @@ static uint32_t read_lane_words(const rb_batch *b, int64_t nw) {
 }
 void launch_filter_windows(const rb_batch *b, int64_t w0, int64_t nw, int k, int mode, uint32_t first_read,
                            uint32_t pos_bits, uint64_t seed, uint64_t ordinal0, Npf cache, uint32_t *cnt, uint32_t *keepmask,
-                           uint32_t *total_spread, hipStream_t s, uint32_t own_mask, uint32_t own_rank, Mpf mcache) {
+                           uint32_t *total_spread, hipStream_t s, uint32_t own_mask, uint32_t own_rank, Mpf mcache, void *wstate) {
     if (nw <= 0) return;
     uint32_t dbgf = getenv("RB_FILT_DBG") ? (uint32_t)atoi(getenv("RB_FILT_DBG")) : 0u;
     if (!cache.tab) dbgf |= 1u;                       // no cache: ownership test only
@@ -918,7 +1014,8 @@ void launch_filter_windows(const rb_batch *b, int64_t w0, int64_t nw, int k, int
         dim3 gc(blocks_for(nw / C, 64));
 #define RB_LAUNCH_FC(M, P)                                                                                        \
     hipLaunchKernelGGL((k_filter_reads<M, P>), gc, t, ring_bytes, s, b->codes, b->valid, b->word_read, b->len, w0, nw, k, C, \
-                       first_read, pos_bits, seed, ordinal0, cache, mcache, cnt, keepmask, total_spread, dbgf, own_mask, own_rank)
+                       first_read, pos_bits, seed, ordinal0, cache, mcache, cnt, keepmask, total_spread, dbgf, own_mask, own_rank, \
+                       reinterpret_cast<ulonglong2 *>(wstate))
         if (use_m) { if (mode == 0) RB_LAUNCH_FC(0, true); else if (mode == 2) RB_LAUNCH_FC(2, true); else RB_LAUNCH_FC(1, true); }
         else { if (mode == 0) RB_LAUNCH_FC(0, false); else if (mode == 2) RB_LAUNCH_FC(2, false); else RB_LAUNCH_FC(1, false); }
 #undef RB_LAUNCH_FC
@@ -945,11 +1042,21 @@ void launch_filter_emit(const rb_batch *b, int64_t w0, int64_t nw, int k, int mo
     if (mode == 0) RB_LAUNCH_FE(0); else if (mode == 2) RB_LAUNCH_FE(2); else RB_LAUNCH_FE(1);
 #undef RB_LAUNCH_FE
 }
+bool filter_saves_state(const rb_batch *b, int64_t nw) { return read_lane_words(b, nw) != 0u && !(getenv("RB_EMIT_RESUME") && atoi(getenv("RB_EMIT_RESUME")) == 0); }
 void launch_hash_windows_masked(const rb_batch *b, int64_t w0, int64_t nw, int k, int mode, const uint32_t *chunk_off,
                                 const uint32_t *keepmask, uint32_t first_read, uint32_t pos_bits, uint64_t *keys, uint32_t *vals,
-                                hipStream_t s) {
+                                hipStream_t s, const void *wstate) {
     if (nw <= 0) return;
     const bool sparse = !(getenv("RB_SPARSE_EMIT") && atoi(getenv("RB_SPARSE_EMIT")) == 0);
+    if (keepmask && wstate) {
+        dim3 gs(blocks_for(nw, RB_SPARSE_WORDS)), ts(64);
+#define RB_LAUNCH_RS(M)                                                                                    \
+    hipLaunchKernelGGL(k_hash_windows_resume<M>, gs, ts, 0, s, b->codes, b->valid, b->word_read, b->woff, \
+                       b->len, w0, nw, k, chunk_off, first_read, pos_bits, keys, vals, keepmask, reinterpret_cast<const ulonglong2 *>(wstate))
+        if (mode == 0) RB_LAUNCH_RS(0); else if (mode == 2) RB_LAUNCH_RS(2); else RB_LAUNCH_RS(1);
+#undef RB_LAUNCH_RS
+        return;
+    }
     if (keepmask && sparse) {
         dim3 gs(blocks_for(nw, RB_SPARSE_WORDS)), ts(64);
 #define RB_LAUNCH_SP(M)                                                                                    \

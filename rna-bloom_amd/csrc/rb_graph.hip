@@ -1429,8 +1429,10 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
                 g->npf_tot.reserve(2048);
                 RB_HIP(hipMemsetAsync(g->npf_tot.p, 0, 2048, sp));
                 FilterView fvp = g->view(ord0, pos_bits);
+                void *wstate = nullptr;
+                if (filter_saves_state(b, sb.nw)) { g->wstate.reserve(((size_t)sb.nw + 1) * 16); wstate = g->wstate.p; }
                 launch_filter_windows(b, sb.w0, sb.nw, g->k, mode_hash, (uint32_t)sb.r0, pos_bits, g->p.rng_seed, ord0, fvp.npf,
-                                      g->chunk_cnt.as<uint32_t>(), g->chunk_mask.as<uint32_t>(), g->npf_tot.as<uint32_t>(), sp, 0u, 0u, fvp.mpf);
+                                      g->chunk_cnt.as<uint32_t>(), g->chunk_mask.as<uint32_t>(), g->npf_tot.as<uint32_t>(), sp, 0u, 0u, fvp.mpf, wstate);
                 exclusive_scan_u32(g->temp2.p, g->temp2.cap, g->chunk_cnt.as<uint32_t>(), g->chunk_off.as<uint32_t>(), (size_t)sb.nw + 1, sp);
                 uint32_t spread[16 * 32];
                 RB_HIP(hipMemcpyAsync(&sb.N, g->chunk_off.as<uint32_t>() + sb.nw, 4, hipMemcpyDeviceToHost, sp));
@@ -1458,7 +1460,7 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
                     g->prof_begin(sp);
                     g->keys0.reserve((size_t)sb.N * 8); g->vals0.reserve((size_t)sb.N * 4);
                     launch_hash_windows_masked(b, sb.w0, sb.nw, g->k, mode_hash, g->chunk_off.as<uint32_t>(), g->chunk_mask.as<uint32_t>(),
-                                               (uint32_t)sb.r0, pos_bits, g->keys0.as<uint64_t>(), g->vals0.as<uint32_t>(), sp);
+                                               (uint32_t)sb.r0, pos_bits, g->keys0.as<uint64_t>(), g->vals0.as<uint32_t>(), sp, wstate);
                     g->prof_end("hash_windows", sp);
                 }
             } else if (use_npf) {
@@ -1647,7 +1649,7 @@ int rb_graph_destroy(rb_graph *g) {
     if (g->stream2) (void)hipStreamDestroy(g->stream2);
     for (auto e : g->prof_pool) (void)hipEventDestroy(e);
     for (auto &sl : g->slots) { sl.keys1.release(); sl.vals1.release(); sl.tz.release(); sl.uniq.release(); sl.counts.release(); sl.starts.release(); }
-    g->temp2.release(); g->devctr2.release(); g->npf.release(); g->mpf.release(); g->chunk_mask.release(); g->npf_tot.release();
+    g->temp2.release(); g->devctr2.release(); g->npf.release(); g->mpf.release(); g->chunk_mask.release(); g->npf_tot.release(); g->wstate.release();
     delete g;
     return RB_OK;
 }

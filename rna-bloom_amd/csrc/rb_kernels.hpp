@@ -19,7 +19,9 @@ void launch_hash_windows(const rb_batch *b, int64_t w0, int64_t nw, int k, int m
 void launch_filter_windows(const rb_batch *b, int64_t w0, int64_t nw, int k, int mode, uint32_t first_read,
                            uint32_t pos_bits, uint64_t seed, uint64_t ordinal0, Npf cache, uint32_t *cnt, uint32_t *keepmask,
                            uint32_t *total_spread, hipStream_t s, uint32_t own_mask = 0, uint32_t own_rank = 0,
-                           Mpf mcache = Mpf{nullptr, 0, 0});   // mcache.tab != nullptr: minimizer-bucketed cache instead of `cache`
+                           Mpf mcache = Mpf{nullptr, 0, 0},    // mcache.tab != nullptr: minimizer-bucketed cache instead of `cache`
+                           void *wstate = nullptr);            // filter_saves_state(): 16 B per word for the resuming emit pass
+bool filter_saves_state(const rb_batch *b, int64_t nw);
 // one pass: ownership test + prefilter + dense ordered emit of the kept (h0, occurrence) records into
 // keys/vals (capacity `cap` records; *kept_out = number kept even if it exceeds cap — then retry with
 // room).  `state`: scratch of filter_emit_state_bytes(nw) bytes.
@@ -29,7 +31,7 @@ void launch_filter_emit(const rb_batch *b, int64_t w0, int64_t nw, int k, int mo
                         uint32_t *vals, uint32_t cap, void *state, uint32_t *kept_out, uint32_t *total_spread, hipStream_t s);
 void launch_hash_windows_masked(const rb_batch *b, int64_t w0, int64_t nw, int k, int mode, const uint32_t *chunk_off,
                                 const uint32_t *keepmask, uint32_t first_read, uint32_t pos_bits, uint64_t *keys, uint32_t *vals,
-                                hipStream_t s);
+                                hipStream_t s, const void *wstate = nullptr);
 
 // ASCII reads -> packed batch in two halves (rb_batch.hip): begin() allocates and enqueues the copies + the
 // encode kernel on `st` and returns; finish() waits for them and frees the staging buffers

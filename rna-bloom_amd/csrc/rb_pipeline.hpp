@@ -315,7 +315,7 @@ struct rb_graph {
     DevBuf &starts() { return slots[cur].starts; }
     DevBuf temp2, devctr2;
     // no-op prefilter
-    DevBuf npf, chunk_mask, npf_tot;
+    DevBuf npf, chunk_mask, npf_tot, wstate;
     uint32_t npf_log2 = 0;
     DevBuf mpf;                         // minimizer-bucketed cache (single-GPU k <= 31 insert path)
     uint32_t mpf_log2b = 0, mpf_m = 0;
