@@ -37,16 +37,17 @@ def algorithmic_bytes(stage, n_kmers, n_pairs, n_runs, words, n_sorted=None, gro
     n_all = n_kmers
     n_kmers = n_sorted if n_sorted is not None else n_kmers
     model = {
-        # prefilter: packed reads in (16 B/word), one 64 B cache sector per window, count + mask out (8 B/word)
+        # prefilter: packed reads in (16 B/word), one 64 B cache sector per window, count + mask out (8 B/word),
+        # single GPU: + the rolling state saved for the emit pass (16 B/word)
         # minimizer-bucketed cache (k <= 31): a 128 B bucket is fetched when the window's minimizer changes,
         # on average every (k - m + 2) / 2 = 5.5 windows (k = 25, m = 16); sharded engine: one 64 B line per window
-        "filter_windows": words * 24 + (n_all * 128 * 2 // 11 if not sharded else n_all * SECTOR),
+        "filter_windows": words * (24 if sharded else 40) + (n_all * 128 * 2 // 11 if not sharded else n_all * SECTOR),
         # one-pass prefilter + emit: packed reads in (16 B/word), one 64 B cache sector per window, survivors out (12 B)
         "filter_emit": words * 16 + n_all * SECTOR + n_kmers * 12,
         # 8-bit onesweep: one histogram read of the keys + per pass (8 B key + 4 B value) in and out
         "sort_occurrences": n_kmers * (8 + passes * 2 * 12),
         # packed reads in (8 B codes + 4 B validity + 4 B owner per word), (h0, occurrence) out
-        "hash_windows": words * 16 + n_kmers * 12,
+        "hash_windows": words * (16 if sharded else 32) + n_kmers * 12,
         "count_windows": words * 12,
         "strengths": n_kmers * 5,
         "distinct_runs": n_kmers * 8 + n_runs * 16,
@@ -65,7 +66,7 @@ def algorithmic_bytes(stage, n_kmers, n_pairs, n_runs, words, n_sorted=None, gro
 # sort_occurrences is rocPRIM's onesweep: 1 histogram + 4 scatter dispatches per launch of the stage, under one kernel
 # name that also covers the (small) sorts of the conflict path, so its bytes are the name's total over the
 # number of sub-batches (= dispatches of k_probe) — an upper bound, the conflict sorts add < 8 %.
-PMC_KERNELS = {"filter_windows": "rb::k_filter_reads", "hash_windows": "rb::k_hash_windows_sparse",
+PMC_KERNELS = {"filter_windows": "rb::k_filter_reads", "hash_windows": "rb::k_hash_windows_resume",
                "probe_claim": "k_probe", "resolve_apply": "k_resolve_apply", "pairs_insert": "k_pairs_reads",
                "sort_occurrences": "rocprim::radix_sort_onesweep(pairs)"}
 
