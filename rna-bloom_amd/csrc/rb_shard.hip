@@ -45,6 +45,7 @@ struct ShardState {
         int64_t first = 0, n = 0, w0 = 0, nw = 0;
         uint64_t ordinal0 = 0;
         uint32_t pos_bits = 0;
+        void *wstate = nullptr;              // per-word rolling state of the prefilter pass (nullptr: none)
         unsigned flags = 0;
         int slot = 0;
         uint32_t N = 0;
@@ -717,9 +718,12 @@ void prep_filter(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, uint6
     FilterView fv = g->view(ordinal0, pos_bits);
     Npf cache = fv.npf;
     if (!g->npf_log2) cache.tab = nullptr;
+    void *wstate = nullptr;                                   // rolling state per word for the resuming emit pass (prep_emit)
+    if (filter_saves_state(b, P.nw)) { g->wstate.reserve(((size_t)P.nw + 1) * 16); wstate = g->wstate.p; }
+    P.wstate = wstate;
     launch_filter_windows(b, P.w0, P.nw, g->k, mode_hash, (uint32_t)first, pos_bits, g->p.rng_seed, ordinal0, cache,
                           g->chunk_cnt.as<uint32_t>(), g->chunk_mask.as<uint32_t>(), g->npf_tot.as<uint32_t>(), st,
-                          (uint32_t)S->G - 1u, (uint32_t)g->shard_rank, fv.mpf);
+                          (uint32_t)S->G - 1u, (uint32_t)g->shard_rank, fv.mpf, wstate);
     exclusive_scan_u32(g->temp2.p, g->temp2.cap, g->chunk_cnt.as<uint32_t>(), g->chunk_off.as<uint32_t>(), nw + 1, st);
     RB_HIP(hipMemcpyAsync(&S->pinned[0], g->chunk_off.as<uint32_t>() + nw, 4, hipMemcpyDeviceToHost, st));
     RB_HIP(hipMemcpyAsync(&S->pinned[16], g->npf_tot.p, 2048, hipMemcpyDeviceToHost, st));
@@ -759,7 +763,7 @@ void prep_emit(rb_graph *g, hipStream_t st) {
         const int mode_hash = g->stranded ? ((P.flags & RB_ADD_REVCOMP) ? 2 : 0) : 1;
         g->keys0.reserve((size_t)P.N * 8); g->vals0.reserve((size_t)P.N * 4);
         launch_hash_windows_masked(P.b, P.w0, P.nw, g->k, mode_hash, g->chunk_off.as<uint32_t>(), g->chunk_mask.as<uint32_t>(),
-                                   (uint32_t)P.first, P.pos_bits, g->keys0.as<uint64_t>(), g->vals0.as<uint32_t>(), st);
+                                   (uint32_t)P.first, P.pos_bits, g->keys0.as<uint64_t>(), g->vals0.as<uint32_t>(), st, P.wstate);
     }
     group_enqueue(g, P.slot, P.N, P.ordinal0, P.pos_bits, st, g->temp2, g->devctr2);
     P.stage = 2;
@@ -1060,8 +1064,10 @@ int rb_shard_hash(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, int6
             Npf cache = fv.npf;
             if (!use_cache) cache.tab = nullptr;
             g->prof_begin();
+            void *wstate = nullptr;
+            if (filter_saves_state(b, nw)) { g->wstate.reserve(((size_t)nw + 1) * 16); wstate = g->wstate.p; }
             launch_filter_windows(b, w0, nw, g->k, mode_hash, (uint32_t)first, pos_bits, g->p.rng_seed, ordinal0, cache,
-                                  g->chunk_cnt.as<uint32_t>(), g->chunk_mask.as<uint32_t>(), g->npf_tot.as<uint32_t>(), s, 0u, 0u, fv.mpf);
+                                  g->chunk_cnt.as<uint32_t>(), g->chunk_mask.as<uint32_t>(), g->npf_tot.as<uint32_t>(), s, 0u, 0u, fv.mpf, wstate);
             exclusive_scan_u32(g->temp.p, g->temp.cap, g->chunk_cnt.as<uint32_t>(), g->chunk_off.as<uint32_t>(), (size_t)nw + 1, s);
             RB_HIP(hipMemcpyAsync(&N, g->chunk_off.as<uint32_t>() + nw, 4, hipMemcpyDeviceToHost, s));
             RB_HIP(hipMemcpyAsync(spread, g->npf_tot.p, sizeof spread, hipMemcpyDeviceToHost, s));
@@ -1072,7 +1078,7 @@ int rb_shard_hash(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, int6
                 g->keys0.reserve((size_t)N * 8); g->vals0.reserve((size_t)N * 4);
                 g->prof_begin();
                 launch_hash_windows_masked(b, w0, nw, g->k, mode_hash, g->chunk_off.as<uint32_t>(), g->chunk_mask.as<uint32_t>(),
-                                           (uint32_t)first, pos_bits, g->keys0.as<uint64_t>(), g->vals0.as<uint32_t>(), s);
+                                           (uint32_t)first, pos_bits, g->keys0.as<uint64_t>(), g->vals0.as<uint32_t>(), s, wstate);
                 g->prof_end("hash_windows");
                 rk = g->keys0.as<uint64_t>(); ro = g->vals0.as<uint32_t>();
             }
