@@ -48,8 +48,8 @@ namespace {
 // first probe ids for bits it may be the first to set, claim its counters (reading them) ----
 __global__ void k_probe(FilterView fv, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ counts,
                         const uint32_t *__restrict__ starts, const uint32_t *__restrict__ vals, uint32_t n_distinct,
-                        int mode, Slot *ftable, uint32_t f_log2, uint32_t *__restrict__ status,
-                        uint64_t *__restrict__ cvals, uint64_t *__restrict__ foreign_idx,
+                        int mode, Slot *ftable /* null: arbitration by k_set_bits + collision table */, uint32_t f_log2,
+                        uint32_t *__restrict__ status, uint64_t *__restrict__ cvals, uint64_t *__restrict__ foreign_idx,
                         uint32_t *__restrict__ counters /* [5] = number of foreign claims */) {
     uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= n_distinct) return;
@@ -61,7 +61,7 @@ __global__ void k_probe(FilterView fv, const uint64_t *__restrict__ uniq, const 
             idx[j] = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.dbg_mod);
             if (bit_test(fv.dbg, idx[j])) premask |= 1u << j; else all = 0;
         }
-        if (!all && (mode == M_ADD || mode == M_ADD_IF_ABSENT)) {
+        if (ftable && !all && (mode == M_ADD || mode == M_ADD_IF_ABSENT)) {
             // sequentially, the getAndSet with the smallest (occurrence, probe) id is the one that
             // finds the bit clear (R/bloom/BloomFilter.java:147-155)
             const unsigned long long v_first = vals[starts[d]];
@@ -107,6 +107,75 @@ __global__ void k_probe(FilterView fv, const uint64_t *__restrict__ uniq, const 
     status[d] = st;
     if (n_foreign) atomicAdd(&counters[16 + 16 * (blockIdx.x & 31u)], n_foreign);   // 32 spread counters
 }
+// ---- first-setter arbitration without a table entry per new bit (the default) ----
+// Two new k-mers of one sub-batch rarely share a Bloom bit (touches^2 / 2 bits: ~0.2 M of 60 M on config 2), so
+// instead of registering every missing bit in a hash table the size of the sub-batch, the bits are set right after
+// stage A with a returning atomicOr: a probe that finds the bit set although it was clear before the sub-batch
+// (premask) COLLIDES with another probe of the sub-batch.  Only colliding bits get a table entry (min probe id over
+// the colliders, then over the probe that happened to get there first — it learns about the collision from the
+// table); a bit without an entry was touched by one probe only, which therefore found it clear.
+constexpr uint32_t ST_COLLIDE_SHIFT = 21;   // status bits 21..28: probe j found its bit set by another probe of the sub-batch
+__global__ void k_set_bits(FilterView fv, const uint64_t *__restrict__ uniq, uint32_t n_distinct, uint32_t *__restrict__ status,
+                           uint32_t *__restrict__ counters) {
+    uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n_distinct) return;
+    const uint32_t st = status[d];
+    if (st & ST_ALLPRE) return;
+    const uint64_t h0 = uniq[d];
+    uint32_t coll = 0;
+    for (int j = 0; j < fv.dbg_h; ++j) {
+        if ((st >> j) & 1u) continue;
+        const uint64_t idx = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.dbg_mod);
+        const uint32_t m = 1u << (uint32_t)(idx & 31u);
+        if (atomicOr(&fv.dbg[idx >> 5], m) & m) coll |= 1u << j;
+    }
+    if (coll) {
+        status[d] = st | (coll << ST_COLLIDE_SHIFT);
+        atomicAdd(&counters[17 + 16 * (blockIdx.x & 31u)], (uint32_t)__popc(coll));
+    }
+}
+// colliders register their probe ids ...
+__global__ void k_collide_insert(FilterView fv, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ starts,
+                                 const uint32_t *__restrict__ vals, uint32_t n_distinct, const uint32_t *__restrict__ status,
+                                 Slot *ftable, uint32_t f_log2) {
+    uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n_distinct) return;
+    const uint32_t coll = (status[d] >> ST_COLLIDE_SHIFT) & 0xFFu;
+    if (!coll) return;
+    const uint64_t h0 = uniq[d];
+    const unsigned long long v_first = vals[starts[d]];
+    for (int j = 0; j < fv.dbg_h; ++j)
+        if ((coll >> j) & 1u) {
+            Slot *s = table_insert(ftable, f_log2, index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.dbg_mod));
+            atomicMin(&s->val, (v_first << 4) | (unsigned long long)j);
+        }
+}
+// ... and the probes whose atomicOr got there first join the entries of the bits somebody collided on
+__global__ void k_collide_fixup(FilterView fv, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ starts,
+                                const uint32_t *__restrict__ vals, uint32_t n_distinct, const uint32_t *__restrict__ status,
+                                Slot *ftable, uint32_t f_log2) {
+    uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n_distinct) return;
+    const uint32_t st = status[d];
+    if (st & ST_ALLPRE) return;
+    const uint32_t mine = ~(st | (st >> ST_COLLIDE_SHIFT)) & ((1u << fv.dbg_h) - 1u);   // clear before, and set by me
+    if (!mine) return;
+    const uint64_t h0 = uniq[d];
+    unsigned long long v_first = ~0ull;
+    for (int j = 0; j < fv.dbg_h; ++j)
+        if ((mine >> j) & 1u) {
+            Slot *s = const_cast<Slot *>(table_find(ftable, f_log2, index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.dbg_mod)));
+            if (!s) continue;
+            if (v_first == ~0ull) v_first = vals[starts[d]];
+            atomicMin(&s->val, (v_first << 4) | (unsigned long long)j);
+        }
+}
+// did an earlier probe of the sub-batch set bit idx?  (table of all missing bits, or of the collided ones only)
+__device__ __forceinline__ bool set_earlier(const Slot *ftable, uint32_t f_log2, uint64_t idx, unsigned long long id) {
+    if (!ftable) return false;                    // no collision in this sub-batch at all
+    const Slot *s = table_find(ftable, f_log2, idx);
+    return s && s->val < id;
+}
 // between stage A and B: the single-occurrence runs of new k-mers learn from the first-setter table whether
 // their one occurrence counts after all (every missing bit was set by an EARLIER probe of the sub-batch);
 // only those claim their counters — the others never touch the counting filter
@@ -123,8 +192,8 @@ __global__ void k_late_claim(FilterView fv, const uint64_t *__restrict__ uniq, c
     bool found = true;
     for (int j = 0; j < fv.dbg_h && found; ++j) {
         if ((st >> j) & 1u) continue;
-        const Slot *s = table_find(ftable, f_log2, index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.dbg_mod));
-        if (!(s->val < ((v_first << 4) | (unsigned long long)j))) found = false;
+        if (!set_earlier(ftable, f_log2, index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.dbg_mod), (v_first << 4) | (unsigned long long)j))
+            found = false;
     }
     if (!found) return;
     st |= ST_LATE_FOUND | ST_CLAIMED;
@@ -156,7 +225,7 @@ __global__ void k_cs_build(const uint64_t *__restrict__ foreign_idx, size_t n, S
 __global__ void k_resolve_apply(FilterView fv, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ counts,
                                 const uint32_t *__restrict__ starts, const uint32_t *__restrict__ vals,
                                 uint32_t n_distinct, int mode, uint32_t LIGHT_OPS, const Slot *ftable, uint32_t f_log2,
-                                const Slot *cs, uint32_t cs_log2, uint32_t n_foreign,
+                                int bits_set /* k_set_bits ran */, const Slot *cs, uint32_t cs_log2, uint32_t n_foreign,
                                 uint32_t *__restrict__ status, uint32_t *__restrict__ nops,
                                 const uint64_t *__restrict__ cvals, const uint8_t *__restrict__ tz, float *__restrict__ dbgf) {
     uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
@@ -175,17 +244,17 @@ __global__ void k_resolve_apply(FilterView fv, const uint64_t *__restrict__ uniq
         bool found_first = true;
         if (st & ST_LATE) {                       // arbitration already looked up by k_late_claim
             found_first = (st & ST_LATE_FOUND) != 0;
-            for (int j = 0; j < fv.dbg_h; ++j)
-                if (!((st >> j) & 1u)) bit_set(fv.dbg, index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.dbg_mod));
+            if (!bits_set)
+                for (int j = 0; j < fv.dbg_h; ++j)
+                    if (!((st >> j) & 1u)) bit_set(fv.dbg, index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.dbg_mod));
         } else if (!all_pre) {
             const unsigned long long v_first = vals[starts[d]];
             for (int j = 0; j < fv.dbg_h; ++j) {
                 if ((st >> j) & 1u) continue;
                 uint64_t idx = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.dbg_mod);
-                const Slot *s = table_find(ftable, f_log2, idx);
                 // old bit value seen by this probe = an earlier probe of the batch already set it
-                if (!(s->val < ((v_first << 4) | (unsigned long long)j))) found_first = false;
-                bit_set(fv.dbg, idx);
+                if (!set_earlier(ftable, f_log2, idx, (v_first << 4) | (unsigned long long)j)) found_first = false;
+                if (!bits_set) bit_set(fv.dbg, idx);
             }
         }
         if (mode == M_ADD) {
@@ -1224,18 +1293,38 @@ void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, ui
     uint32_t *status = g->status.as<uint32_t>(), *nops = g->nops.as<uint32_t>();
     const bool uses_dbg = (mode == M_ADD || mode == M_ADD_IF_ABSENT);
     uint32_t f_log2 = 1, c_log2 = 1;
-    if (uses_dbg) {
+    const bool full_table = getenv("RB_FIRST_SETTER_TABLE") && atoi(getenv("RB_FIRST_SETTER_TABLE"));   // the older scheme: every missing bit gets an entry
+    const bool collide = uses_dbg && !full_table;
+    Slot *ftab = nullptr;                        // first-setter arbitration table (null: nothing to arbitrate)
+    if (uses_dbg && full_table) {
         g->prof_begin();
         f_log2 = log2_ceil(2ull * (uint64_t)D * (uint64_t)g->dbg.num_hash + 2);
         g->ftable.reserve(sizeof(Slot) << f_log2);
         RB_HIP(hipMemsetAsync(g->ftable.p, 0xFF, sizeof(Slot) << f_log2, s));
+        ftab = g->ftable.as<Slot>();
         g->prof_end("table_clear");
     }
     g->prof_begin();
     hipLaunchKernelGGL(k_probe, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, uniq, counts, starts, vals, D, mode,
-                       g->ftable.as<Slot>(), f_log2, status, g->cvals.as<uint64_t>(), g->foreign.as<uint64_t>(), ctr);
+                       ftab, f_log2, status, g->cvals.as<uint64_t>(), g->foreign.as<uint64_t>(), ctr);
+    if (collide) {
+        // set the new bits now; the probes that meet another probe of the sub-batch on a bit are counted
+        hipLaunchKernelGGL(k_set_bits, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, uniq, D, status, ctr);
+        uint32_t spread[16 * 32], n_collide = 0;
+        RB_HIP(hipMemcpyAsync(spread, ctr + 16, sizeof spread, hipMemcpyDeviceToHost, s));
+        RB_HIP(hipStreamSynchronize(s));
+        for (int q = 0; q < 32; ++q) n_collide += spread[16 * q + 1];
+        if (n_collide) {   // entries for the collided bits only: the colliders, then the probe that got there first
+            f_log2 = log2_ceil(4ull * (uint64_t)n_collide + 2);
+            g->ftable.reserve(sizeof(Slot) << f_log2);
+            RB_HIP(hipMemsetAsync(g->ftable.p, 0xFF, sizeof(Slot) << f_log2, s));
+            ftab = g->ftable.as<Slot>();
+            hipLaunchKernelGGL(k_collide_insert, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, uniq, starts, vals, D, status, ftab, f_log2);
+            hipLaunchKernelGGL(k_collide_fixup, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, uniq, starts, vals, D, status, ftab, f_log2);
+        }
+    }
     if (mode == M_ADD)
-        hipLaunchKernelGGL(k_late_claim, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, uniq, starts, vals, D, g->ftable.as<Slot>(), f_log2,
+        hipLaunchKernelGGL(k_late_claim, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, uniq, starts, vals, D, ftab, f_log2,
                            status, g->cvals.as<uint64_t>(), g->foreign.as<uint64_t>(), ctr);
     uint32_t n_foreign = 0;
     {
@@ -1257,7 +1346,7 @@ void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, ui
     }
     g->prof_begin();
     hipLaunchKernelGGL(k_resolve_apply, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, uniq, counts, starts, vals, D, mode, g->light_ops,
-                       g->ftable.as<Slot>(), f_log2, g->ctable.as<Slot>(), c_log2, n_foreign, status, nops,
+                       ftab, f_log2, (int)collide, g->ctable.as<Slot>(), c_log2, n_foreign, status, nops,
                        g->cvals.as<uint64_t>(), g->tz().as<uint8_t>(), getenv("RB_DEBUG") ? reinterpret_cast<float *>(ctr + 700) : (float *)nullptr);
     g->prof_end("resolve_apply");
     // the runs that own their counters alone have updated counters and prefilter cache: the producer may
