@@ -431,24 +431,46 @@ __global__ void k_pick_u32(const uint32_t *__restrict__ a, const uint64_t *__res
 }
 
 // ------------------------------------------------------------------ owner ----
-__global__ void k_own_dbg_test(uint32_t *bits, uint64_t lo, const uint64_t *__restrict__ idx, const uint64_t *__restrict__ probe,
-                               size_t n, int uses_f, Slot *ftable, uint32_t f_log2, uint8_t *__restrict__ reply) {
+// Bloom-bit requests at the owner: same arbitration as the single-GPU engine (rb_graph.hip, k_set_bits): test against
+// the pre-batch state, set with a returning atomicOr, and give a table entry only to the bits two requests of the
+// sub-batch met on.  reply bit 0 = set before the sub-batch, bit 1 = this probe is the sequentially first setter.
+__global__ void k_own_dbg_test(const uint32_t *bits, uint64_t lo, const uint64_t *__restrict__ idx, size_t n, uint8_t *__restrict__ reply) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const bool pre = bit_test(bits, idx[i] - lo);
-    reply[i] = pre ? 1u : 0u;
-    if (!pre && uses_f) {
-        Slot *s = table_insert(ftable, f_log2, idx[i]);
-        atomicMin(&s->val, (unsigned long long)probe[i]);
-    }
+    if (i < n) reply[i] = bit_test(bits, idx[i] - lo) ? 1u : 0u;
 }
-__global__ void k_own_dbg_set(uint32_t *bits, uint64_t lo, const uint64_t *__restrict__ idx, const uint64_t *__restrict__ probe,
-                              size_t n, const Slot *ftable, uint32_t f_log2, uint8_t *__restrict__ reply) {
+__global__ void k_own_dbg_set(uint32_t *bits, uint64_t lo, const uint64_t *__restrict__ idx, size_t n, uint8_t *__restrict__ reply,
+                              uint32_t *__restrict__ counters) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n || (reply[i] & 1u)) return;
-    const Slot *s = table_find(ftable, f_log2, idx[i]);
-    if (s->val == (unsigned long long)probe[i]) reply[i] |= 2u;      // this probe is the sequentially first setter
-    bit_set(bits, idx[i] - lo);
+    const uint64_t b = idx[i] - lo;
+    const uint32_t m = 1u << (uint32_t)(b & 31u);
+    if (atomicOr(&bits[b >> 5], m) & m) {          // another request of this sub-batch got there first
+        reply[i] = 4u;
+        atomicAdd(&counters[16 * (blockIdx.x & 31u)], 1u);
+    }
+}
+__global__ void k_own_collide_insert(const uint64_t *__restrict__ idx, const uint64_t *__restrict__ probe, size_t n,
+                                     const uint8_t *__restrict__ reply, Slot *ftable, uint32_t f_log2) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !(reply[i] & 4u)) return;
+    Slot *s = table_insert(ftable, f_log2, idx[i]);
+    atomicMin(&s->val, (unsigned long long)probe[i]);
+}
+__global__ void k_own_collide_fixup(const uint64_t *__restrict__ idx, const uint64_t *__restrict__ probe, size_t n,
+                                    const uint8_t *__restrict__ reply, Slot *ftable, uint32_t f_log2) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || reply[i] != 0u) return;          // clear before, and set by this request
+    Slot *s = const_cast<Slot *>(table_find(ftable, f_log2, idx[i]));
+    if (s) atomicMin(&s->val, (unsigned long long)probe[i]);
+}
+__global__ void k_own_dbg_first(const uint64_t *__restrict__ idx, const uint64_t *__restrict__ probe, size_t n,
+                                const Slot *ftable /* null: no two requests met */, uint32_t f_log2, uint8_t *__restrict__ reply) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t r = reply[i];
+    if (r & 1u) return;
+    const Slot *s = ftable ? table_find(ftable, f_log2, idx[i]) : nullptr;
+    reply[i] = (!s || s->val == (unsigned long long)probe[i]) ? 2u : 0u;
 }
 __global__ void k_own_claim(uint8_t *cbf, uint64_t lo, const uint64_t *__restrict__ idx, size_t n, uint8_t *__restrict__ reply,
                             uint32_t *__restrict__ spread /* 32 counters, 16 words apart */) {
@@ -1175,19 +1197,31 @@ int rb_shard_serve(rb_graph *g, int mode, const void *dreq_idx_dev, const void *
         hipStream_t s = g->stream;
         if (nd) {
             const int uses_f = (mode == M_ADD || mode == M_ADD_IF_ABSENT);
-            uint32_t f_log2 = 1;
+            const uint64_t *didx = (const uint64_t *)dreq_idx_dev, *dprobe = (const uint64_t *)dreq_probe_dev;
+            uint8_t *dreply = (uint8_t *)dreply_dev;
+            hipLaunchKernelGGL(k_own_dbg_test, dim3(blocks_for(nd)), dim3(TPB), 0, s, g->dbg.bits, (uint64_t)g->dbg.lo, didx, (size_t)nd, dreply);
             if (uses_f) {
-                f_log2 = log2_ceil(2ull * (uint64_t)nd + 2);
-                S->own_f.reserve(sizeof(Slot) << f_log2);
-                RB_HIP(hipMemsetAsync(S->own_f.p, 0xFF, sizeof(Slot) << f_log2, s));
+                g->devctr.reserve(DEVCTR_BYTES);
+                uint32_t *ctr = g->devctr.as<uint32_t>();
+                RB_HIP(hipMemsetAsync(ctr, 0, DEVCTR_BYTES, s));
+                hipLaunchKernelGGL(k_own_dbg_set, dim3(blocks_for(nd)), dim3(TPB), 0, s, g->dbg.bits, (uint64_t)g->dbg.lo, didx, (size_t)nd,
+                                   dreply, ctr + 16);
+                uint32_t n_collide = 0, spread[16 * 32];
+                RB_HIP(hipMemcpyAsync(spread, ctr + 16, sizeof spread, hipMemcpyDeviceToHost, s));
+                RB_HIP(hipStreamSynchronize(s));
+                for (int q = 0; q < 32; ++q) n_collide += spread[16 * q];
+                Slot *ftab = nullptr;
+                uint32_t f_log2 = 1;
+                if (n_collide) {
+                    f_log2 = log2_ceil(4ull * (uint64_t)n_collide + 2);
+                    S->own_f.reserve(sizeof(Slot) << f_log2);
+                    RB_HIP(hipMemsetAsync(S->own_f.p, 0xFF, sizeof(Slot) << f_log2, s));
+                    ftab = S->own_f.as<Slot>();
+                    hipLaunchKernelGGL(k_own_collide_insert, dim3(blocks_for(nd)), dim3(TPB), 0, s, didx, dprobe, (size_t)nd, dreply, ftab, f_log2);
+                    hipLaunchKernelGGL(k_own_collide_fixup, dim3(blocks_for(nd)), dim3(TPB), 0, s, didx, dprobe, (size_t)nd, dreply, ftab, f_log2);
+                }
+                hipLaunchKernelGGL(k_own_dbg_first, dim3(blocks_for(nd)), dim3(TPB), 0, s, didx, dprobe, (size_t)nd, ftab, f_log2, dreply);
             }
-            hipLaunchKernelGGL(k_own_dbg_test, dim3(blocks_for(nd)), dim3(TPB), 0, s, g->dbg.bits, (uint64_t)g->dbg.lo,
-                               (const uint64_t *)dreq_idx_dev, (const uint64_t *)dreq_probe_dev, (size_t)nd, uses_f, S->own_f.as<Slot>(), f_log2,
-                               (uint8_t *)dreply_dev);
-            if (uses_f)
-                hipLaunchKernelGGL(k_own_dbg_set, dim3(blocks_for(nd)), dim3(TPB), 0, s, g->dbg.bits, (uint64_t)g->dbg.lo,
-                                   (const uint64_t *)dreq_idx_dev, (const uint64_t *)dreq_probe_dev, (size_t)nd, S->own_f.as<Slot>(), f_log2,
-                                   (uint8_t *)dreply_dev);
         }
         if (nc) {
             g->devctr.reserve(DEVCTR_BYTES);
