@@ -314,6 +314,38 @@ k_hash_windows(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ 
     }
 }
 
+// The bases a word-per-lane walker consumes — the word's 32 window starts need 32 + k - 1 bases — as a stream of 2-bit
+// codes / usable bits, and the history the rolling hash takes its outgoing base from.  WIDE = 32 <= k <= 64: three
+// words in, 128 bits of code history; otherwise (k <= 31) two words and 64 bits, exactly the registers the
+// kernels below used before this struct existed.
+template <bool WIDE> struct WordWalk {
+    uint64_t clo = 0, chi = 0, c3 = 0, vs = 0, hc = 0, hc2 = 0, hv = 0;
+    uint32_t v3 = 0;
+    __device__ __forceinline__ void load(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid, int64_t w, uint32_t c, uint32_t nwords) {
+        clo = codes[w]; chi = (c + 1u < nwords) ? codes[w + 1] : 0ull;
+        vs = (uint64_t)valid[w] | ((c + 1u < nwords) ? ((uint64_t)valid[w + 1] << 32) : 0ull);
+        if (WIDE && c + 2u < nwords) { c3 = codes[w + 2]; v3 = valid[w + 2]; }
+    }
+    __device__ __forceinline__ void next(uint32_t &code, uint32_t &ok) {
+        code = (uint32_t)clo & 3u; ok = (uint32_t)vs & 1u;
+        if (WIDE) {
+            clo = (clo >> 2) | (chi << 62); chi = (chi >> 2) | (c3 << 62); c3 >>= 2;
+            vs = (vs >> 1) | ((uint64_t)(v3 & 1u) << 63); v3 >>= 1;
+        } else {
+            clo = (clo >> 2) | (chi << 62); chi >>= 2; vs >>= 1;
+        }
+    }
+    // 0 = null (unusable or before the walk), 1..4 = A,C,G,T: the base k - 1 steps back (sh_c = 2(k-1), sh_v = k-1)
+    __device__ __forceinline__ uint32_t out5(uint32_t sh_c, uint32_t sh_v) const {
+        const uint32_t oc = (!WIDE || sh_c < 64u) ? (uint32_t)(hc >> sh_c) & 3u : (uint32_t)(hc2 >> (sh_c - 64u)) & 3u;
+        return ((uint32_t)(hv >> sh_v) & 1u) ? oc + 1u : 0u;
+    }
+    __device__ __forceinline__ void push(uint32_t code, uint32_t ok) {
+        if (WIDE) hc2 = (hc2 << 2) | (hc >> 62);
+        hc = (hc << 2) | code; hv = (hv << 1) | ok;
+    }
+};
+
 // Fast path for k <= 31, one 32-base word per thread, one wavefront per block.
 // Branch-free walker: a base that is unusable (or lies before the chunk) is treated as a "null" base
 // whose seed is 0 — it contributes nothing when it enters the window and nothing when it leaves, so
@@ -321,7 +353,7 @@ k_hash_windows(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ 
 // unusable bases; a window is emitted only when its last k bases were all usable (run >= k), and at
 // that point f / r equal NTP64 / NTP64RC from scratch.  Roll terms come from a 5x5 LDS table
 // indexed by (outgoing, incoming) in {null,A,C,G,T}.
-template <int MODE>
+template <int MODE, bool WIDE>
 __global__ void __launch_bounds__(64)
 k_hash_windows_fast(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
                     const uint32_t *__restrict__ word_read, const uint32_t *__restrict__ woff,
@@ -351,7 +383,8 @@ k_hash_windows_fast(const uint64_t *__restrict__ codes, const uint32_t *__restri
     const uint32_t O0 = chunk_off[blk0], O1 = chunk_off[blk_end];
     if (O0 == O1) return;
     // walker state (a lane without windows keeps nb = 0)
-    uint64_t clo = 0, chi = 0, vs = 0, f = 0, rv = 0, hc = 0, hv = 0;   // hc/hv: codes / usable bits of the previous bases
+    WordWalk<WIDE> ww;                                    // incoming bases + codes / usable bits of the previous ones
+    uint64_t f = 0, rv = 0;
     uint32_t nb = 0, j = 0, run = 0, out = 0, rel = 0, b0 = 0, keep = 0;
     if (i < nw) {
         const int64_t w = w0 + i;
@@ -361,10 +394,9 @@ k_hash_windows_fast(const uint64_t *__restrict__ codes, const uint32_t *__restri
         keep = keepmask ? keepmask[i] : 0xFFFFFFFFu;      // bit p-b0: window p survived the prefilter
         if ((uint64_t)b0 + uk <= L && keep) {
             const uint32_t nwords = (L + 31u) >> 5;
-            // 64 bases of codes / validity starting at b0 (second word only if the read has it)
-            clo = codes[w]; chi = (c + 1u < nwords) ? codes[w + 1] : 0ull;
-            vs = (uint64_t)valid[w] | ((c + 1u < nwords) ? ((uint64_t)valid[w + 1] << 32) : 0ull);
-            nb = ((b0 + 32u + uk - 1u < L) ? b0 + 32u + uk - 1u : L) - b0;   // bases to walk (<= 62)
+            // 64 (96) bases of codes / validity starting at b0 (later words only if the read has them)
+            ww.load(codes, valid, w, c, nwords);
+            nb = ((b0 + 32u + uk - 1u < L) ? b0 + 32u + uk - 1u : L) - b0;   // bases to walk (<= 62; <= 95 WIDE)
             out = chunk_off[i] - O0;
             rel = (r - first_read) << pos_bits;
         }
@@ -374,14 +406,13 @@ k_hash_windows_fast(const uint64_t *__restrict__ codes, const uint32_t *__restri
     for (uint32_t slab0 = 0; slab0 < n; slab0 += SLAB) {
         const uint32_t slab1 = (slab0 + SLAB < n) ? slab0 + SLAB : n;
         while (j < nb && out < slab1) {
-            const uint32_t code = (uint32_t)clo & 3u, ok = (uint32_t)vs & 1u;
-            clo = (clo >> 2) | (chi << 62); chi >>= 2; vs >>= 1;
+            uint32_t code, ok;
+            ww.next(code, ok);
             const uint32_t in5 = ok ? code + 1u : 0u;
-            const uint32_t out5 = ((uint32_t)(hv >> sh_v) & 1u) ? ((uint32_t)(hc >> sh_c) & 3u) + 1u : 0u;
-            const uint32_t t = out5 * 5u + in5;
+            const uint32_t t = ww.out5(sh_c, sh_v) * 5u + in5;
             if (MODE != 2) f = rotl(f, 1) ^ s_tf[t];
             if (MODE != 0) rv = rotr(rv, 1) ^ s_tr[t];
-            hc = (hc << 2) | code; hv = (hv << 1) | ok;
+            ww.push(code, ok);
             run = ok ? run + 1u : 0u;
             if (run >= uk && ((keep >> (j + 1u - uk)) & 1u)) {
                 const uint32_t o = out - slab0, q = o + (o >> 5);
@@ -410,7 +441,7 @@ k_hash_windows_fast(const uint64_t *__restrict__ codes, const uint32_t *__restri
 #ifndef RB_SPARSE_WORDS
 #define RB_SPARSE_WORDS 512
 #endif
-template <int MODE>
+template <int MODE, bool WIDE>
 __global__ void __launch_bounds__(64)
 k_hash_windows_sparse(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
                       const uint32_t *__restrict__ word_read, const uint32_t *__restrict__ woff,
@@ -449,7 +480,8 @@ k_hash_windows_sparse(const uint64_t *__restrict__ codes, const uint32_t *__rest
         // output range of this round's words, relative to O0
         const uint32_t R0 = chunk_off[blk0 + s_list[e0]] - O0, R1 = chunk_off[blk0 + s_list[e_last] + 1] - O0;
         // walker state (a lane without a word keeps nb = 0)
-        uint64_t clo = 0, chi = 0, vs = 0, f = 0, rv = 0, hc = 0, hv = 0;
+        WordWalk<WIDE> ww;
+        uint64_t f = 0, rv = 0;
         uint32_t nb = 0, j = 0, run = 0, out = 0, rel = 0, b0 = 0, keep = 0;
         if (e0 + lane < n_list) {
             const int64_t i = blk0 + s_list[e0 + lane];
@@ -459,23 +491,21 @@ k_hash_windows_sparse(const uint64_t *__restrict__ codes, const uint32_t *__rest
             b0 = c * 32u;
             keep = keepmask[i];
             const uint32_t nwords = (L + 31u) >> 5;
-            clo = codes[w]; chi = (c + 1u < nwords) ? codes[w + 1] : 0ull;
-            vs = (uint64_t)valid[w] | ((c + 1u < nwords) ? ((uint64_t)valid[w + 1] << 32) : 0ull);
-            nb = ((b0 + 32u + uk - 1u < L) ? b0 + 32u + uk - 1u : L) - b0;   // bases to walk (<= 62)
+            ww.load(codes, valid, w, c, nwords);
+            nb = ((b0 + 32u + uk - 1u < L) ? b0 + 32u + uk - 1u : L) - b0;   // bases to walk (<= 62; <= 95 WIDE)
             out = chunk_off[i] - O0;
             rel = (r - first_read) << pos_bits;
         }
         for (uint32_t slab0 = R0; slab0 < R1; slab0 += SLAB) {
             const uint32_t slab1 = (slab0 + SLAB < R1) ? slab0 + SLAB : R1;
             while (j < nb && out < slab1) {
-                const uint32_t code = (uint32_t)clo & 3u, ok = (uint32_t)vs & 1u;
-                clo = (clo >> 2) | (chi << 62); chi >>= 2; vs >>= 1;
+                uint32_t code, ok;
+                ww.next(code, ok);
                 const uint32_t in5 = ok ? code + 1u : 0u;
-                const uint32_t out5 = ((uint32_t)(hv >> sh_v) & 1u) ? ((uint32_t)(hc >> sh_c) & 3u) + 1u : 0u;
-                const uint32_t t = out5 * 5u + in5;
+                const uint32_t t = ww.out5(sh_c, sh_v) * 5u + in5;
                 if (MODE != 2) f = rotl(f, 1) ^ s_tf[t];
                 if (MODE != 0) rv = rotr(rv, 1) ^ s_tr[t];
-                hc = (hc << 2) | code; hv = (hv << 1) | ok;
+                ww.push(code, ok);
                 run = ok ? run + 1u : 0u;
                 if (run >= uk && ((keep >> (j + 1u - uk)) & 1u)) {
                     const uint32_t o = out - slab0, q = o + (o >> 5);
@@ -502,7 +532,7 @@ k_hash_windows_sparse(const uint64_t *__restrict__ codes, const uint32_t *__rest
 // MPF = the minimizer-bucketed cache (rb_device.hpp): the walker also rolls the canonical m-mer of every
 // position (order values in an LDS ring), the window's minimizer picks the bucket, and the bucket
 // image (16 words, LDS) is reloaded only when the minimizer changes — every ~5 windows.
-template <int MODE, bool MPF>
+template <int MODE, bool MPF, bool WIDE>
 __global__ void __launch_bounds__(64)
 k_filter_windows_fast(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
                       const uint32_t *__restrict__ word_read, const uint32_t *__restrict__ woff,
@@ -530,10 +560,10 @@ k_filter_windows_fast(const uint64_t *__restrict__ codes, const uint32_t *__rest
         const uint32_t c = (uint32_t)(w - wr), b0 = c * 32u;
         if ((uint64_t)b0 + uk <= L) {
             const uint32_t nwords = (L + 31u) >> 5;
-            uint64_t clo = codes[w], chi = (c + 1u < nwords) ? codes[w + 1] : 0ull;
-            uint64_t vs = (uint64_t)valid[w] | ((c + 1u < nwords) ? ((uint64_t)valid[w + 1] << 32) : 0ull);
+            WordWalk<WIDE> ww;
+            ww.load(codes, valid, w, c, nwords);
             const uint32_t nb = ((b0 + 32u + uk - 1u < L) ? b0 + 32u + uk - 1u : L) - b0;
-            uint64_t f = 0, rv = 0, hc = 0, hv = 0;
+            uint64_t f = 0, rv = 0;
             uint32_t run = 0;
             const uint32_t rstate = rng_read_state(seed, ordinal0 + (uint64_t)(r - first_read));
             const uint32_t sh_c = 2u * (uk - 1u), sh_v = uk - 1u;
@@ -543,14 +573,13 @@ k_filter_windows_fast(const uint64_t *__restrict__ codes, const uint32_t *__rest
             uint32_t mf = 0, mr = 0, blk_a = 0, blk_p = 0;               // position inside the current block of uw m-mers, its prefix minimum
             uint64_t cur_bkt = ~0ull;
             for (uint32_t j = 0; j < nb; ++j) {
-                const uint32_t code = (uint32_t)clo & 3u, ok = (uint32_t)vs & 1u;
-                clo = (clo >> 2) | (chi << 62); chi >>= 2; vs >>= 1;
+                uint32_t code, ok;
+                ww.next(code, ok);
                 const uint32_t in5 = ok ? code + 1u : 0u;
-                const uint32_t out5 = ((uint32_t)(hv >> sh_v) & 1u) ? ((uint32_t)(hc >> sh_c) & 3u) + 1u : 0u;
-                const uint32_t t = out5 * 5u + in5;
+                const uint32_t t = ww.out5(sh_c, sh_v) * 5u + in5;
                 if (MODE != 2) f = rotl(f, 1) ^ s_tf[t];
                 if (MODE != 0) rv = rotr(rv, 1) ^ s_tr[t];
-                hc = (hc << 2) | code; hv = (hv << 1) | ok;
+                ww.push(code, ok);
                 run = ok ? run + 1u : 0u;
                 uint32_t o_cur = 0;
                 if (MPF) {   // canonical m-mer ending at this base (garbage while run < m: never consulted then)
@@ -875,23 +904,22 @@ k_filter_emit(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ v
         const uint32_t c = (uint32_t)(w - wr), b0 = c * 32u;
         if ((uint64_t)b0 + uk <= L) {
             const uint32_t nwords = (L + 31u) >> 5;
-            uint64_t clo = codes[w], chi = (c + 1u < nwords) ? codes[w + 1] : 0ull;
-            uint64_t vs = (uint64_t)valid[w] | ((c + 1u < nwords) ? ((uint64_t)valid[w + 1] << 32) : 0ull);
+            WordWalk<false> ww;
+            ww.load(codes, valid, w, c, nwords);
             const uint32_t nb = ((b0 + 32u + uk - 1u < L) ? b0 + 32u + uk - 1u : L) - b0;
-            uint64_t f = 0, rv = 0, hc = 0, hv = 0;
+            uint64_t f = 0, rv = 0;
             uint32_t run = 0;
             const uint32_t rstate = rng_read_state(seed, ordinal0 + (uint64_t)(r - first_read));
             const uint32_t rel = (r - first_read) << pos_bits;
             const uint32_t sh_c = 2u * (uk - 1u), sh_v = uk - 1u;
             for (uint32_t j = 0; j < nb; ++j) {
-                const uint32_t code = (uint32_t)clo & 3u, ok = (uint32_t)vs & 1u;
-                clo = (clo >> 2) | (chi << 62); chi >>= 2; vs >>= 1;
+                uint32_t code, ok;
+                ww.next(code, ok);
                 const uint32_t in5 = ok ? code + 1u : 0u;
-                const uint32_t out5 = ((uint32_t)(hv >> sh_v) & 1u) ? ((uint32_t)(hc >> sh_c) & 3u) + 1u : 0u;
-                const uint32_t t = out5 * 5u + in5;
+                const uint32_t t = ww.out5(sh_c, sh_v) * 5u + in5;
                 if (MODE != 2) f = rotl(f, 1) ^ s_tf[t];
                 if (MODE != 0) rv = rotr(rv, 1) ^ s_tr[t];
-                hc = (hc << 2) | code; hv = (hv << 1) | ok;
+                ww.push(code, ok);
                 run = ok ? run + 1u : 0u;
                 if (run >= uk) {
                     const uint32_t p = b0 + j + 1u - uk;
@@ -966,7 +994,7 @@ void launch_hash_windows(const rb_batch *b, int64_t w0, int64_t nw, int k, int m
     if (k <= 31 && vals && !out_read && !getenv("RB_HASH_GENERIC")) {   // fast path (stage-1 insert at k <= 31)
         dim3 g(blocks_for(nw, 64)), t(64);
 #define RB_LAUNCH_FAST(M)                                                                             \
-    hipLaunchKernelGGL(k_hash_windows_fast<M>, g, t, 0, s, b->codes, b->valid, b->word_read, b->woff, \
+    hipLaunchKernelGGL((k_hash_windows_fast<M, false>), g, t, 0, s, b->codes, b->valid, b->word_read, b->woff, \
                        b->len, w0, nw, k, chunk_off, first_read, pos_bits, keys, vals, (const uint32_t *)nullptr)
         if (mode == 0) RB_LAUNCH_FAST(0); else if (mode == 2) RB_LAUNCH_FAST(2); else RB_LAUNCH_FAST(1);
 #undef RB_LAUNCH_FAST
@@ -993,9 +1021,9 @@ void launch_hash_windows(const rb_batch *b, int64_t w0, int64_t nw, int k, int m
 
 // words per read if the read-per-lane kernels apply (uniform batch of short reads), else 0: one word per lane
 // (RB_READ_LANES=0 forces the one-word kernels)
-static uint32_t read_lane_words(const rb_batch *b, int64_t nw) {
+static uint32_t read_lane_words(const rb_batch *b, int64_t nw, int k) {
     const bool off = getenv("RB_READ_LANES") && atoi(getenv("RB_READ_LANES")) == 0;
-    if (!off && b->wpr_uniform && b->wpr_uniform <= (uint32_t)RB_READ_WORDS && nw % b->wpr_uniform == 0) return b->wpr_uniform;
+    if (!off && k <= 31 && b->wpr_uniform && b->wpr_uniform <= (uint32_t)RB_READ_WORDS && nw % b->wpr_uniform == 0) return b->wpr_uniform;
     return 0u;
 }
 void launch_filter_windows(const rb_batch *b, int64_t w0, int64_t nw, int k, int mode, uint32_t first_read,
@@ -1005,12 +1033,13 @@ void launch_filter_windows(const rb_batch *b, int64_t w0, int64_t nw, int k, int
     uint32_t dbgf = getenv("RB_FILT_DBG") ? (uint32_t)atoi(getenv("RB_FILT_DBG")) : 0u;
     if (!cache.tab) dbgf |= 1u;                       // no cache: ownership test only
     dim3 g(blocks_for(nw, 64)), t(64);
-#define RB_LAUNCH_FILT(M, P)                                                                                    \
-    hipLaunchKernelGGL((k_filter_windows_fast<M, P>), g, t, ring_bytes, s, b->codes, b->valid, b->word_read, b->woff, b->len, \
+#define RB_LAUNCH_FILT(M, P, W)                                                                                 \
+    hipLaunchKernelGGL((k_filter_windows_fast<M, P, W>), g, t, ring_bytes, s, b->codes, b->valid, b->word_read, b->woff, b->len, \
                        w0, nw, k, first_read, pos_bits, seed, ordinal0, cache, mcache, cnt, keepmask, total_spread, dbgf, own_mask, own_rank)
-    const bool use_m = mcache.tab && mcache.m <= (uint32_t)k && (uint32_t)k - mcache.m + 1u <= 16u;
+    RB_REQUIRE(k <= 64, "prefilter kernels take k <= 64");
+    const bool use_m = mcache.tab && k <= RB_MPF_MAX_K && mcache.m <= (uint32_t)k && (uint32_t)k - mcache.m + 1u <= RB_MPF_MAX_RING;
     const size_t ring_bytes = use_m ? ((size_t)k - mcache.m + 1u) * 64u * sizeof(uint32_t) : 0;   // LDS per wavefront: 12.7 KB -> 11.2 KB at k = 25
-    if (const uint32_t C = read_lane_words(b, nw)) {
+    if (const uint32_t C = read_lane_words(b, nw, k)) {
         dim3 gc(blocks_for(nw / C, 64));
 #define RB_LAUNCH_FC(M, P)                                                                                        \
     hipLaunchKernelGGL((k_filter_reads<M, P>), gc, t, ring_bytes, s, b->codes, b->valid, b->word_read, b->len, w0, nw, k, C, \
@@ -1020,9 +1049,11 @@ void launch_filter_windows(const rb_batch *b, int64_t w0, int64_t nw, int k, int
         else { if (mode == 0) RB_LAUNCH_FC(0, false); else if (mode == 2) RB_LAUNCH_FC(2, false); else RB_LAUNCH_FC(1, false); }
 #undef RB_LAUNCH_FC
     } else if (use_m) {
-        if (mode == 0) RB_LAUNCH_FILT(0, true); else if (mode == 2) RB_LAUNCH_FILT(2, true); else RB_LAUNCH_FILT(1, true);
-    } else {
-        if (mode == 0) RB_LAUNCH_FILT(0, false); else if (mode == 2) RB_LAUNCH_FILT(2, false); else RB_LAUNCH_FILT(1, false);
+        if (mode == 0) RB_LAUNCH_FILT(0, true, false); else if (mode == 2) RB_LAUNCH_FILT(2, true, false); else RB_LAUNCH_FILT(1, true, false);
+    } else if (k <= 31) {
+        if (mode == 0) RB_LAUNCH_FILT(0, false, false); else if (mode == 2) RB_LAUNCH_FILT(2, false, false); else RB_LAUNCH_FILT(1, false, false);
+    } else {   // 32 <= k <= 64: hash-bucketed cache, three words per lane
+        if (mode == 0) RB_LAUNCH_FILT(0, false, true); else if (mode == 2) RB_LAUNCH_FILT(2, false, true); else RB_LAUNCH_FILT(1, false, true);
     }
 #undef RB_LAUNCH_FILT
 }
@@ -1042,7 +1073,7 @@ void launch_filter_emit(const rb_batch *b, int64_t w0, int64_t nw, int k, int mo
     if (mode == 0) RB_LAUNCH_FE(0); else if (mode == 2) RB_LAUNCH_FE(2); else RB_LAUNCH_FE(1);
 #undef RB_LAUNCH_FE
 }
-bool filter_saves_state(const rb_batch *b, int64_t nw) { return read_lane_words(b, nw) != 0u && !(getenv("RB_EMIT_RESUME") && atoi(getenv("RB_EMIT_RESUME")) == 0); }
+bool filter_saves_state(const rb_batch *b, int64_t nw, int k) { return read_lane_words(b, nw, k) != 0u && !(getenv("RB_EMIT_RESUME") && atoi(getenv("RB_EMIT_RESUME")) == 0); }
 void launch_hash_windows_masked(const rb_batch *b, int64_t w0, int64_t nw, int k, int mode, const uint32_t *chunk_off,
                                 const uint32_t *keepmask, uint32_t first_read, uint32_t pos_bits, uint64_t *keys, uint32_t *vals,
                                 hipStream_t s, const void *wstate) {
@@ -1059,18 +1090,20 @@ void launch_hash_windows_masked(const rb_batch *b, int64_t w0, int64_t nw, int k
     }
     if (keepmask && sparse) {
         dim3 gs(blocks_for(nw, RB_SPARSE_WORDS)), ts(64);
-#define RB_LAUNCH_SP(M)                                                                                    \
-    hipLaunchKernelGGL(k_hash_windows_sparse<M>, gs, ts, 0, s, b->codes, b->valid, b->word_read, b->woff, \
+#define RB_LAUNCH_SP(M, W)                                                                                 \
+    hipLaunchKernelGGL((k_hash_windows_sparse<M, W>), gs, ts, 0, s, b->codes, b->valid, b->word_read, b->woff, \
                        b->len, w0, nw, k, chunk_off, first_read, pos_bits, keys, vals, keepmask)
-        if (mode == 0) RB_LAUNCH_SP(0); else if (mode == 2) RB_LAUNCH_SP(2); else RB_LAUNCH_SP(1);
+        if (k <= 31) { if (mode == 0) RB_LAUNCH_SP(0, false); else if (mode == 2) RB_LAUNCH_SP(2, false); else RB_LAUNCH_SP(1, false); }
+        else { if (mode == 0) RB_LAUNCH_SP(0, true); else if (mode == 2) RB_LAUNCH_SP(2, true); else RB_LAUNCH_SP(1, true); }
 #undef RB_LAUNCH_SP
         return;
     }
     dim3 g(blocks_for(nw, 64)), t(64);
-#define RB_LAUNCH_FASTM(M)                                                                            \
-    hipLaunchKernelGGL(k_hash_windows_fast<M>, g, t, 0, s, b->codes, b->valid, b->word_read, b->woff, \
+#define RB_LAUNCH_FASTM(M, W)                                                                         \
+    hipLaunchKernelGGL((k_hash_windows_fast<M, W>), g, t, 0, s, b->codes, b->valid, b->word_read, b->woff, \
                        b->len, w0, nw, k, chunk_off, first_read, pos_bits, keys, vals, keepmask)
-    if (mode == 0) RB_LAUNCH_FASTM(0); else if (mode == 2) RB_LAUNCH_FASTM(2); else RB_LAUNCH_FASTM(1);
+    if (k <= 31) { if (mode == 0) RB_LAUNCH_FASTM(0, false); else if (mode == 2) RB_LAUNCH_FASTM(2, false); else RB_LAUNCH_FASTM(1, false); }
+    else { if (mode == 0) RB_LAUNCH_FASTM(0, true); else if (mode == 2) RB_LAUNCH_FASTM(2, true); else RB_LAUNCH_FASTM(1, true); }
 #undef RB_LAUNCH_FASTM
 }
 

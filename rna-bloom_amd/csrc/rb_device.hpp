@@ -185,6 +185,12 @@ __device__ __forceinline__ void npf_store(const Npf &c, uint64_t h0, uint32_t s)
 // table made nearly every wavefront iteration wait for a second dependent lookup (filter 134 -> 207 ms).
 // A reader loads the bucket's two lines when its minimizer changes (every ~5 windows).
 // Both strands of a k-mer have the same canonical m-mers, hence the same bucket.
+// The minimizer-bucketed cache serves k <= 31 (ring of k - m + 1 <= 16 orders).  For 32 <= k <= 64 it was measured
+// and lost to the hash-bucketed table: a minimizer of a 35..63-mer is shared by 10..24 consecutive k-mers, the 16-slot
+// bucket overflows, the uncached k-mers keep all their occurrences (config 2 at k = 35 / 47 / 63: 3.5 / 4.7 / 5.0 G
+// records sorted instead of 1.9 / 1.8 / 1.6 G; step 552 / 664 / 726 ms against 498 / 466 / 440 ms).
+constexpr uint32_t RB_MPF_MAX_RING = 16u;
+constexpr int RB_MPF_MAX_K = 31;
 struct Mpf {
     unsigned long long *tab;   // nullptr => disabled
     uint32_t log2b;            // log2 of the number of buckets (16 slots = 128 B each)
@@ -207,14 +213,17 @@ __host__ __device__ __forceinline__ uint64_t mpf_bucket(const Mpf &c, uint32_t o
 // the resolve stages know a k-mer by hash + one occurrence id)
 __device__ __forceinline__ uint32_t window_min_order(const uint64_t *__restrict__ rw, uint32_t p, uint32_t k, uint32_t m) {
     const uint32_t w = p >> 5, o = p & 31u;
-    uint64_t lo = rw[w], hi = (o + k > 32u) ? rw[w + 1] : 0ull;
-    lo = (lo >> (2u * o)) | (o ? (hi << (64u - 2u * o)) : 0ull);
-    hi = o ? (hi >> (2u * o)) : hi;                    // bases p.. as a 128-bit stream (k <= 31 + ...: 2 words suffice)
+    uint64_t lo = rw[w], hi = (o + k > 32u) ? rw[w + 1] : 0ull, h2 = (o + k > 64u) ? rw[w + 2] : 0ull;
+    if (o) {                                           // bases p.. as a 192-bit stream (k <= 64: 3 words suffice)
+        lo = (lo >> (2u * o)) | (hi << (64u - 2u * o));
+        hi = (hi >> (2u * o)) | (h2 << (64u - 2u * o));
+        h2 >>= 2u * o;
+    }
     const uint32_t mmask = (m >= 16u) ? 0xFFFFFFFFu : ((1u << (2u * m)) - 1u);
     uint32_t mf = 0, mr = 0, best = 0xFFFFFFFFu;
     for (uint32_t j = 0; j < k; ++j) {
         const uint32_t code = (uint32_t)lo & 3u;
-        lo = (lo >> 2) | (hi << 62); hi >>= 2;
+        lo = (lo >> 2) | (hi << 62); hi = (hi >> 2) | (h2 << 62); h2 >>= 2;
         mf = ((mf << 2) | code) & mmask;
         mr = (mr >> 2) | ((3u - code) << (2u * (m - 1u)));
         if (j + 1u >= m) { const uint32_t ord = mmer_order(mf < mr ? mf : mr); best = ord < best ? ord : best; }

@@ -1453,17 +1453,19 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
     // max_batch_kmers bounds the RECORDS a sub-batch sorts.  With the prefilter most windows never
     // become records, so a sub-batch may span three times as many windows (fewer, larger runs per k-mer); a
     // sub-batch whose survivors exceed the bound after all (cold cache) is split and redone.
-    const bool npf_path = g->npf_log2 && g->k <= 31;
+    const bool wide_off = getenv("RB_WIDE_PREFILTER") && atoi(getenv("RB_WIDE_PREFILTER")) == 0;   // 32 <= k <= 64 without the prefilter
+    const bool npf_path = g->npf_log2 && (g->k <= 31 || (g->k <= 64 && !wide_off));
     const int wmul = getenv("RB_WINDOW_MUL") ? std::max(1, atoi(getenv("RB_WINDOW_MUL"))) : 3;
     const int64_t max_words = std::max<int64_t>(std::min<int64_t>((npf_path ? wmul : 1) * g->max_batch_kmers, (int64_t)7 << 29) / 32, 1);
     const std::vector<uint32_t> &wo = b->h_woff;
     // plan the sub-batches
     struct Sub { int64_t r0, r1, w0, nw; uint32_t N; int64_t total; };
-    // occurrences that provably cannot change a counter are dropped before sorting (k <= 31 fast path)
-    const bool use_npf = g->npf_log2 && g->k <= 31 && (mode == M_ADD || mode == M_COUNT_IF_PRESENT);
+    // occurrences that provably cannot change a counter are dropped before sorting (word-per-lane walkers: k <= 64;
+    // RB_WIDE_PREFILTER=0 sends 32 <= k <= 64 down the unfiltered generic path)
+    const bool use_npf = npf_path && (mode == M_ADD || mode == M_COUNT_IF_PRESENT);
     // the minimizer-bucketed cache replaces the hash-bucketed one on this path (lookups here, stores by the
     // stages that retire runs, which find a k-mer's bucket from one of its occurrences in this batch)
-    g->use_mpf = use_npf && g->mpf_log2b && !getenv("RB_NO_MPF") && !getenv("RB_ONE_PASS_FILTER") && (uint32_t)g->k >= g->mpf_m && (uint32_t)g->k - g->mpf_m + 1u <= 16u;
+    g->use_mpf = use_npf && g->mpf_log2b && !getenv("RB_NO_MPF") && (g->k > 31 || !getenv("RB_ONE_PASS_FILTER")) && (uint32_t)g->k >= g->mpf_m && (uint32_t)g->k - g->mpf_m + 1u <= RB_MPF_MAX_RING;
     g->seq_codes = b->codes; g->seq_woff = b->woff;
     struct MpfScope { rb_graph *g; ~MpfScope() { g->use_mpf = false; g->seq_codes = nullptr; g->seq_woff = nullptr; } } mpf_scope{g};
     std::vector<Sub> subs;
@@ -1507,7 +1509,7 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
             g->chunk_cnt.reserve(((size_t)sb.nw + 1) * 4); g->chunk_off.reserve(((size_t)sb.nw + 1) * 4);
             g->temp2.reserve(scan_temp_bytes((size_t)sb.nw + 1));
             RB_HIP(hipMemsetAsync(g->chunk_cnt.as<uint32_t>() + sb.nw, 0, 4, sp));
-            if (use_npf && !getenv("RB_ONE_PASS_FILTER")) {
+            if (use_npf && (g->k > 31 || !getenv("RB_ONE_PASS_FILTER"))) {
                 // pass 1 hashes every window and asks the cache (count + keep mask per word), scan, pass 2
                 // re-hashes and emits the survivors.  (The one-pass kernel below measures 12 ms faster on its
                 // own but 35 ms slower per step here: its 25 KB of LDS staging costs the occupancy that hides
@@ -1519,7 +1521,7 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
                 RB_HIP(hipMemsetAsync(g->npf_tot.p, 0, 2048, sp));
                 FilterView fvp = g->view(ord0, pos_bits);
                 void *wstate = nullptr;
-                if (filter_saves_state(b, sb.nw)) { g->wstate.reserve(((size_t)sb.nw + 1) * 16); wstate = g->wstate.p; }
+                if (filter_saves_state(b, sb.nw, g->k)) { g->wstate.reserve(((size_t)sb.nw + 1) * 16); wstate = g->wstate.p; }
                 launch_filter_windows(b, sb.w0, sb.nw, g->k, mode_hash, (uint32_t)sb.r0, pos_bits, g->p.rng_seed, ord0, fvp.npf,
                                       g->chunk_cnt.as<uint32_t>(), g->chunk_mask.as<uint32_t>(), g->npf_tot.as<uint32_t>(), sp, 0u, 0u, fvp.mpf, wstate);
                 exclusive_scan_u32(g->temp2.p, g->temp2.cap, g->chunk_cnt.as<uint32_t>(), g->chunk_off.as<uint32_t>(), (size_t)sb.nw + 1, sp);
@@ -1705,7 +1707,7 @@ int rb_graph_create(const rb_graph_params *p, rb_graph **out) {
             uint32_t lb = log2_ceil((uint64_t)std::max<int64_t>(p->cbf_bytes / 256, 1));
             lb = std::max(12u, std::min(25u, lb));
             if (e) lb = (uint32_t)atoi(e);
-            if (lb >= 8 && lb <= 28 && p->k <= 31 && p->k >= 8) {
+            if (lb >= 8 && lb <= 28 && p->k <= RB_MPF_MAX_K && p->k >= 8) {
                 g->mpf.reserve((size_t)128 << lb);
                 RB_HIP(hipMemset(g->mpf.p, 0, (size_t)128 << lb));
                 g->mpf_log2b = lb;

@@ -741,7 +741,7 @@ void prep_filter(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, uint6
     Npf cache = fv.npf;
     if (!g->npf_log2) cache.tab = nullptr;
     void *wstate = nullptr;                                   // rolling state per word for the resuming emit pass (prep_emit)
-    if (filter_saves_state(b, P.nw)) { g->wstate.reserve(((size_t)P.nw + 1) * 16); wstate = g->wstate.p; }
+    if (filter_saves_state(b, P.nw, g->k)) { g->wstate.reserve(((size_t)P.nw + 1) * 16); wstate = g->wstate.p; }
     P.wstate = wstate;
     launch_filter_windows(b, P.w0, P.nw, g->k, mode_hash, (uint32_t)first, pos_bits, g->p.rng_seed, ordinal0, cache,
                           g->chunk_cnt.as<uint32_t>(), g->chunk_mask.as<uint32_t>(), g->npf_tot.as<uint32_t>(), st,
@@ -1087,7 +1087,7 @@ int rb_shard_hash(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, int6
             if (!use_cache) cache.tab = nullptr;
             g->prof_begin();
             void *wstate = nullptr;
-            if (filter_saves_state(b, nw)) { g->wstate.reserve(((size_t)nw + 1) * 16); wstate = g->wstate.p; }
+            if (filter_saves_state(b, nw, g->k)) { g->wstate.reserve(((size_t)nw + 1) * 16); wstate = g->wstate.p; }
             launch_filter_windows(b, w0, nw, g->k, mode_hash, (uint32_t)first, pos_bits, g->p.rng_seed, ordinal0, cache,
                                   g->chunk_cnt.as<uint32_t>(), g->chunk_mask.as<uint32_t>(), g->npf_tot.as<uint32_t>(), s, 0u, 0u, fv.mpf, wstate);
             exclusive_scan_u32(g->temp.p, g->temp.cap, g->chunk_cnt.as<uint32_t>(), g->chunk_off.as<uint32_t>(), (size_t)nw + 1, s);

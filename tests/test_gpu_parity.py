@@ -416,6 +416,44 @@ def test_ragged_reads_fuzz(seed):
             assert_same_state(og, gg)
 
 
+@pytest.mark.parametrize("k,stranded", [(32, False), (33, False), (35, True), (47, False), (63, False), (64, False), (64, True)])
+def test_wide_k_takes_the_prefiltered_path(k, stranded, monkeypatch):
+    """32 <= k <= 64: the word-per-lane walkers with three words of input and 128 bits of history per lane
+    (WordWalk<true>), hash-bucketed hot-k-mer cache, masked / sparse emit — ragged reads with N runs and
+    low-quality stretches, both files, deep coverage so that the cache really drops occurrences, a
+    count-if-present pass, many small sub-batches; and the same through the unfiltered generic kernels"""
+    rng = np.random.default_rng(7000 + k)
+    genome = rng.integers(0, 4, 2500, dtype=np.uint8)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    seqs, quals = [], []
+    for _ in range(3000):
+        L = int(rng.choice([20, k - 1, k, k + 1, 64, 65, 96, 97, 128, 150, 151, 260, 301]))
+        a = int(rng.integers(0, genome.size - L))
+        s = acgt[genome[a:a + L]].copy()
+        q = np.full(L, ord("I"), np.uint8)
+        if rng.random() < 0.3 and L > 8:
+            p, n = int(rng.integers(0, L - 4)), int(rng.integers(1, 5))
+            if rng.random() < 0.5: s[p:p + n] = ord("N")
+            else: q[p:p + n] = ord("#")
+        seqs.append(s); quals.append(q)
+    seq = np.concatenate(seqs); qual = np.concatenate(quals)
+    off = np.concatenate([[0], np.cumsum([x.size for x in seqs])]).astype(np.int64)
+    for wide in ("1", "0"):
+        monkeypatch.setenv("RB_WIDE_PREFILTER", wide)
+        og, gg = graph_pair(150_001, 200_003, 30_011, k=k, stranded=stranded, max_batch=15_000)
+        og.set_read_pair_distance(30); gg.setReadPairedKmerDistance(30)
+        for rc in (False, True):
+            o_st = og.add_reads(seq, qual, off, 3, rbo.STORE_READ_PAIRS | (rbo.REVCOMP if rc else 0))
+            st = gg.addReads(seq, qual, off, 3, reverseComplement=rc, storeReadPairedKmers=True)
+            assert_same_state(og, gg)
+            assert st.kmers == o_st.kmers
+            assert (st.sorted_kmers < st.kmers) == (wide == "1")     # the cache drops occurrences only on the prefiltered path
+        og.add_reads(seq, qual, off, 3, rbo.COUNT_IF_PRESENT)
+        gg.addReads(seq, qual, off, 3, incrementIfPresent=True)
+        assert_same_state(og, gg)
+        assert og.cbf_bytes().max() > 30
+
+
 @pytest.mark.parametrize("words,k", [(1, 25), (2, 25), (5, 25), (5, 31), (8, 21), (9, 25)])
 def test_uniform_word_count_fuzz(words, k):
     """every read has the same number of 32-base words but not the same length (the last word is partly filled),
