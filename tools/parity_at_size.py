@@ -1,7 +1,7 @@
 """Parity of the single-GPU engine and of the sharded engine (8 virtual ranks split, 2 replicated) with the CPU oracle on a
 large synthetic paired-end set: N reads (default 4 M = 490 M k-mers; the oracle needs ~40 s for that), both files of the
 library, read-paired k-mers, filters sized so that counters reach the probabilistic range.  Prints one line per engine.
-    python tools/parity_at_size.py [N]"""
+    python tools/parity_at_size.py [N [k]]        (k = 35: the three-words-per-lane prefilter, generic kernels in the sharded engine)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "rna-bloom_amd")):
@@ -12,17 +12,18 @@ from rnabloom import _native as N
 from rnabloom.graph import BloomFilterDeBruijnGraph, ReadBatch
 from rnabloom.sharded import LoopbackCluster
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
+K = int(sys.argv[2]) if len(sys.argv) > 2 else 25
 bits = N.lib.rb_expected_size(18_000_000, 0.01, 2)
 batch = ReadBatch.synthetic(n // 2, 64_000_000 // 25, 150, 300, 30, 0.001, 1e-4, 2.0, seed=0x5EED, device=0)
 seq, off = batch.download(0, n)
 t = time.time()
-og = rbo.Graph(bits, bits, bits, 2, 2, 2, 25, False, True, 1)
+og = rbo.Graph(bits, bits, bits, 2, 2, 2, K, False, True, 1)
 og.set_read_pair_distance(115)
 og.add_reads(seq[:off[n // 2]], None, off[:n // 2 + 1], 3, rbo.STORE_READ_PAIRS)
 og.add_reads(seq[off[n // 2]:], None, off[n // 2:] - off[n // 2], 3, rbo.STORE_READ_PAIRS | rbo.REVCOMP)
 print("oracle %.1f s" % (time.time() - t), flush=True)
 ref = (og.dbgbf_bytes(), og.cbf_bytes(), og.rpkbf_bytes())
-g = BloomFilterDeBruijnGraph(bits, bits, bits, 2, 2, 2, 25, False, True, device=0, rngSeed=1, maxBatchKmers=1 << 26)
+g = BloomFilterDeBruijnGraph(bits, bits, bits, 2, 2, 2, K, False, True, device=0, rngSeed=1, maxBatchKmers=1 << 26)
 g.setReadPairedKmerDistance(115)
 s1 = g.addBatch(batch, storeReadPairedKmers=True, first=0, n=n // 2)
 s2 = g.addBatch(batch, reverseComplement=True, storeReadPairedKmers=True, first=n // 2, n=n // 2)
@@ -30,7 +31,7 @@ print("single: kmers", s1.kmers + s2.kmers, "sorted", s1.sorted_kmers + s2.sorte
       "equal:", [bool(np.array_equal(g.exportFilter(w), r)) for w, r in zip((N.DBGBF, N.CBF, N.RPKBF), ref)], "max counter", int(ref[1].max()), flush=True)
 g.destroy()
 for G, mode in ((8, "split"), (2, "replicated")):
-    cl = LoopbackCluster(G, bits, bits, bits, 2, 2, 2, 25, False, True, device=0, rngSeed=1, mode=mode, maxBatchKmers=1 << 27)
+    cl = LoopbackCluster(G, bits, bits, bits, 2, 2, 2, K, False, True, device=0, rngSeed=1, mode=mode, maxBatchKmers=1 << 27)
     cl.setReadPairedKmerDistance(115)
     cl.addBatch(batch, 150, storeReadPairedKmers=True, first=0, n=n // 2)
     cl.addBatch(batch, 150, reverseComplement=True, storeReadPairedKmers=True, first=n // 2, n=n // 2)
