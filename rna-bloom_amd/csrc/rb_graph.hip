@@ -1361,9 +1361,8 @@ void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, ui
         fprintf(stderr, "[rb] droppable ops (perfect cache): %.1f%% of %.0f ops (N=%zu)\n", tot ? 100.0 * dr / tot : 0.0, tot, N);
     }
     g->prof_begin();
-    g->temp.reserve(select_temp_bytes(D));
-    select_flagged(g->temp.p, g->temp.cap, status, RUN_HEAVY, D, g->heavy.as<uint32_t>(), ctr + 0, s);
-    select_flagged(g->temp.p, g->temp.cap, status, RUN_CONFLICT, D, g->confk.as<uint32_t>(), ctr + 1, s);
+    g->temp.reserve(select2_temp_bytes(D));
+    select_flagged2(g->temp.p, g->temp.cap, status, D, RUN_HEAVY, g->heavy.as<uint32_t>(), RUN_CONFLICT, g->confk.as<uint32_t>(), ctr + 0, s);
     uint32_t hc[2] = {0, 0};
     RB_HIP(hipMemcpyAsync(hc, ctr, 8, hipMemcpyDeviceToHost, s));
     RB_HIP(hipStreamSynchronize(s));

@@ -1277,9 +1277,8 @@ int rb_shard_resolve(rb_graph *g, int mode, const void *dreply_dev, const void *
                            S->creq_dup.as<uint8_t>(), (const uint8_t *)creply_dev, g->tz().as<uint8_t>(), g->uniq().as<uint64_t>(),
                            g->status.as<uint32_t>(), g->nops.as<uint32_t>(), g->cvals.as<uint64_t>(), S->cfinal.as<uint64_t>(),
                            S->replicate_cache ? S->cache_upd.as<uint8_t>() : (uint8_t *)nullptr, g->vals1().as<uint32_t>());
-        g->temp.reserve(select_temp_bytes(D));
-        select_flagged(g->temp.p, g->temp.cap, g->status.as<uint32_t>(), RUN_HEAVY, D, g->heavy.as<uint32_t>(), ctr + 0, s);
-        select_flagged(g->temp.p, g->temp.cap, g->status.as<uint32_t>(), RUN_CONFLICT, D, S->conf_list.as<uint32_t>(), ctr + 1, s);
+        g->temp.reserve(select2_temp_bytes(D));
+        select_flagged2(g->temp.p, g->temp.cap, g->status.as<uint32_t>(), D, RUN_HEAVY, g->heavy.as<uint32_t>(), RUN_CONFLICT, S->conf_list.as<uint32_t>(), ctr + 0, s);
         uint32_t hc[2];
         RB_HIP(hipMemcpyAsync(hc, ctr, 8, hipMemcpyDeviceToHost, s));
         RB_HIP(hipStreamSynchronize(s));
