@@ -390,16 +390,23 @@ __device__ __forceinline__ uint32_t lower_bound_u64(const uint64_t *a, uint32_t 
 // counting filter itself (nobody else touches these counters during the batch)
 __device__ void replay_serial(const FilterView &fv, const uint64_t *__restrict__ uniq, const uint64_t *__restrict__ op_key,
                               const uint32_t *__restrict__ op_val, uint32_t os, uint32_t oe) {
+    // consecutive ops of one run reuse its counter indices and the values this lane left there (nobody else writes
+    // them); a switch to another run of the component reloads — the runs share counters
+    uint64_t idx[RB_MAX_HASH];
+    uint32_t c[RB_MAX_HASH], cur_d = 0xFFFFFFFFu;
     for (uint32_t i = os; i < oe; ++i) {
         const uint32_t v = (uint32_t)op_key[i];
-        const uint32_t d = op_val[i] & 0x3FFFFFFFu, kind = op_val[i] >> 30;
-        const uint64_t h0 = uniq[d];
-        uint64_t idx[RB_MAX_HASH];
-        uint32_t c[RB_MAX_HASH], c0[RB_MAX_HASH];
-        for (int j = 0; j < fv.cbf_h; ++j) {
-            idx[j] = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod);
-            c0[j] = c[j] = *(volatile uint8_t *)&fv.cbf[idx[j]];
+        const uint32_t ov = op_val[i], d = ov & 0x3FFFFFFFu, kind = ov >> 30;
+        if (d != cur_d) {
+            const uint64_t h0 = uniq[d];
+            for (int j = 0; j < fv.cbf_h; ++j) {
+                idx[j] = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod);
+                c[j] = *(volatile uint8_t *)&fv.cbf[idx[j]];
+            }
+            cur_d = d;
         }
+        uint32_t c0[RB_MAX_HASH];
+        for (int j = 0; j < fv.cbf_h; ++j) c0[j] = c[j];
         uint32_t mn = c[0];
         for (int j = 1; j < fv.cbf_h; ++j) mn = c[j] < mn ? c[j] : mn;
         cbf_step(c, fv.cbf_h, kind, (mn >= 16u && mn < 127u) ? occ_rnd(fv, v) : 0u);
