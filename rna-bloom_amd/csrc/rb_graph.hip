@@ -367,14 +367,14 @@ __global__ void k_conf_expand(const uint32_t *__restrict__ conf_kmers, const uin
                               const uint32_t *__restrict__ vals, const uint32_t *__restrict__ status,
                               const uint32_t *__restrict__ nops, const uint32_t *__restrict__ label, uint32_t n_conf,
                               uint64_t *__restrict__ op_key, uint32_t *__restrict__ op_val) {
-    // one wavefront per conflicting k-mer
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63u;
+    // eight lanes per conflicting k-mer (a run brings ~5 ops on average; heavy ones loop)
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 3, lane = threadIdx.x & 7u;
     if (wave >= n_conf) return;
     const uint32_t d = conf_kmers[wave];
     const uint32_t ops = nops[d], st = status[d];
     const uint64_t hi = (uint64_t)label[d] << 32;
     const uint32_t base = starts[d] + counts[d] - ops, out = conf_off[wave];
-    for (uint32_t i = lane; i < ops; i += 64u) {
+    for (uint32_t i = lane; i < ops; i += 8u) {
         op_key[out + i] = hi | vals[base + i];
         uint32_t kind = i == 0 ? (st >> 12) & 3u : (st >> 14) & 3u;
         op_val[out + i] = d | (kind << 30);
@@ -1415,11 +1415,13 @@ void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, ui
         g->prof_begin();
         hipLaunchKernelGGL(k_conf_kmer_keys, dim3(blocks_for(nck)), dim3(TPB), 0, s, confk, label, nck, g->kk0.as<uint64_t>());
         g->temp.reserve(std::max(sort_pairs_temp_bytes(nco), sort_keys_temp_bytes(nck)));
-        hipLaunchKernelGGL(k_conf_expand, dim3(blocks_for((int64_t)nck * 64)), dim3(TPB), 0, s, confk, g->conf_off.as<uint32_t>(),
+        hipLaunchKernelGGL(k_conf_expand, dim3(blocks_for((int64_t)nck * 8)), dim3(TPB), 0, s, confk, g->conf_off.as<uint32_t>(),
                            counts, starts, vals, status, nops, label, nck, g->opk0.as<uint64_t>(), g->opv0.as<uint32_t>());
-        sort_keys_u64(g->temp.p, g->temp.cap, g->kk0.as<uint64_t>(), g->kk1.as<uint64_t>(), nck, 0, 64, s);
+        // labels are run numbers (< D); the list is in run order and the sort is stable, so the label bits suffice
+        const int label_end = 32 + (int)std::max(1u, log2_ceil((uint64_t)D));
+        sort_keys_u64(g->temp.p, g->temp.cap, g->kk0.as<uint64_t>(), g->kk1.as<uint64_t>(), nck, 32, label_end, s);
         sort_pairs_u64_u32(g->temp.p, g->temp.cap, g->opk0.as<uint64_t>(), g->opk1.as<uint64_t>(),
-                           g->opv0.as<uint32_t>(), g->opv1.as<uint32_t>(), nco, 0, 64, s);
+                           g->opv0.as<uint32_t>(), g->opv1.as<uint32_t>(), nco, 0, label_end, s);
         g->prof_end("conflict_gather_sort");
         g->prof_begin();
         RB_HIP(hipMemsetAsync(ctr + 4, 0, 4, s));
