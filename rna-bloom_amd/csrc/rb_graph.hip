@@ -74,7 +74,8 @@ __global__ void k_probe(FilterView fv, const uint64_t *__restrict__ uniq, const 
     }
     uint32_t st = premask | (all ? ST_ALLPRE : 0u);
     uint32_t n_foreign = 0;
-    for (int j = 0; j < fv.cbf_h; ++j) foreign_idx[(size_t)d * fv.cbf_h + j] = ~0ull;
+    uint64_t fidx[RB_MAX_HASH];                       // contested counters of this run (written only if there are any)
+    for (int j = 0; j < fv.cbf_h; ++j) fidx[j] = ~0ull;
     // can this run have counting-Bloom ops?  (exact number is known in stage B)
     bool may_count = true;
     if (mode == M_COUNT_IF_PRESENT) may_count = all;
@@ -94,7 +95,7 @@ __global__ void k_probe(FilterView fv, const uint64_t *__restrict__ uniq, const 
                 byte = cbf_claim(fv.cbf, cidx[j]);
                 if (byte & CLAIM) {                     // somebody else of this sub-batch owns it too
                     st |= ST_FOREIGN;
-                    foreign_idx[(size_t)d * fv.cbf_h + j] = cidx[j];
+                    fidx[j] = cidx[j];
                     ++n_foreign;
                     byte &= 0x7Fu;
                 }
@@ -105,7 +106,10 @@ __global__ void k_probe(FilterView fv, const uint64_t *__restrict__ uniq, const 
         st |= ST_CLAIMED;
     }
     status[d] = st;
-    if (n_foreign) atomicAdd(&counters[16 + 16 * (blockIdx.x & 31u)], n_foreign);   // 32 spread counters
+    if (n_foreign) {
+        for (int j = 0; j < fv.cbf_h; ++j) foreign_idx[(size_t)d * fv.cbf_h + j] = fidx[j];
+        atomicAdd(&counters[16 + 16 * (blockIdx.x & 31u)], n_foreign);   // 32 spread counters
+    }
 }
 // ---- first-setter arbitration without a table entry per new bit (the default) ----
 // Two new k-mers of one sub-batch rarely share a Bloom bit (touches^2 / 2 bits: ~0.2 M of 60 M on config 2), so
@@ -197,9 +201,10 @@ __global__ void k_late_claim(FilterView fv, const uint64_t *__restrict__ uniq, c
     }
     if (!found) return;
     st |= ST_LATE_FOUND | ST_CLAIMED;
-    uint64_t cidx[RB_MAX_HASH], cv = 0;
+    uint64_t cidx[RB_MAX_HASH], fidx[RB_MAX_HASH], cv = 0;
     uint32_t n_foreign = 0;
     for (int j = 0; j < fv.cbf_h; ++j) {
+        fidx[j] = ~0ull;
         cidx[j] = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod);
         int dup = -1;
         for (int q = 0; q < j; ++q) if (cidx[q] == cidx[j]) dup = q;
@@ -207,17 +212,25 @@ __global__ void k_late_claim(FilterView fv, const uint64_t *__restrict__ uniq, c
         if (dup >= 0) byte = (uint32_t)(cv >> (8 * dup)) & 0xFFu;
         else {
             byte = cbf_claim(fv.cbf, cidx[j]);
-            if (byte & CLAIM) { st |= ST_FOREIGN; foreign_idx[(size_t)d * fv.cbf_h + j] = cidx[j]; ++n_foreign; byte &= 0x7Fu; }
+            if (byte & CLAIM) { st |= ST_FOREIGN; fidx[j] = cidx[j]; ++n_foreign; byte &= 0x7Fu; }
         }
         cv |= (uint64_t)byte << (8 * j);
     }
     cvals[d] = cv;
     status[d] = st;
-    if (n_foreign) atomicAdd(&counters[16 + 16 * (blockIdx.x & 31u)], n_foreign);
+    if (n_foreign) {
+        for (int j = 0; j < fv.cbf_h; ++j) foreign_idx[(size_t)d * fv.cbf_h + j] = fidx[j];
+        atomicAdd(&counters[16 + 16 * (blockIdx.x & 31u)], n_foreign);
+    }
 }
-__global__ void k_cs_build(const uint64_t *__restrict__ foreign_idx, size_t n, Slot *cs, uint32_t cs_log2) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && foreign_idx[i] != ~0ull) table_insert(cs, cs_log2, foreign_idx[i]);
+__global__ void k_cs_build(const uint32_t *__restrict__ status, const uint64_t *__restrict__ foreign_idx, uint32_t n_distinct, int h,
+                           Slot *cs, uint32_t cs_log2) {
+    uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n_distinct || !(status[d] & ST_FOREIGN)) return;       // only these runs have written their entries
+    for (int j = 0; j < h; ++j) {
+        const uint64_t idx = foreign_idx[(size_t)d * h + j];
+        if (idx != ~0ull) table_insert(cs, cs_log2, idx);
+    }
 }
 
 // ---- stage B: resolve the found-flag of the first occurrence, set Bloom bits, then apply the
@@ -1346,8 +1359,7 @@ void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, ui
         c_log2 = log2_ceil(2ull * (uint64_t)n_foreign + 2);
         g->ctable.reserve(sizeof(Slot) << c_log2);
         RB_HIP(hipMemsetAsync(g->ctable.p, 0xFF, sizeof(Slot) << c_log2, s));
-        const size_t nfe = (size_t)D * (size_t)g->cbf_h;
-        hipLaunchKernelGGL(k_cs_build, dim3(blocks_for((int64_t)nfe)), dim3(TPB), 0, s, g->foreign.as<uint64_t>(), nfe,
+        hipLaunchKernelGGL(k_cs_build, dim3(blocks_for(D)), dim3(TPB), 0, s, status, g->foreign.as<uint64_t>(), D, g->cbf_h,
                            g->ctable.as<Slot>(), c_log2);
         g->prof_end("conflict_set");
     }
