@@ -224,12 +224,15 @@ __global__ void k_late_claim(FilterView fv, const uint64_t *__restrict__ uniq, c
     }
 }
 __global__ void k_cs_build(const uint32_t *__restrict__ status, const uint64_t *__restrict__ foreign_idx, uint32_t n_distinct, int h,
-                           Slot *cs, uint32_t cs_log2) {
+                           Slot *cs, uint32_t cs_log2, uint32_t *__restrict__ csf, uint32_t csf_log2) {
     uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= n_distinct || !(status[d] & ST_FOREIGN)) return;       // only these runs have written their entries
     for (int j = 0; j < h; ++j) {
         const uint64_t idx = foreign_idx[(size_t)d * h + j];
-        if (idx != ~0ull) table_insert(cs, cs_log2, idx);
+        if (idx == ~0ull) continue;
+        table_insert(cs, cs_log2, idx);
+        const uint64_t b = slot_of(idx, csf_log2);                  // cache-resident bit filter in front of the table (stage B)
+        atomicOr(&csf[b >> 5], 1u << (uint32_t)(b & 31u));
     }
 }
 
@@ -238,7 +241,8 @@ __global__ void k_cs_build(const uint32_t *__restrict__ status, const uint64_t *
 __global__ void k_resolve_apply(FilterView fv, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ counts,
                                 const uint32_t *__restrict__ starts, const uint32_t *__restrict__ vals,
                                 uint32_t n_distinct, int mode, uint32_t LIGHT_OPS, const Slot *ftable, uint32_t f_log2,
-                                int bits_set /* k_set_bits ran */, const Slot *cs, uint32_t cs_log2, uint32_t n_foreign,
+                                int bits_set /* k_set_bits ran */, const Slot *cs, uint32_t cs_log2, const uint32_t *__restrict__ csf, uint32_t csf_log2,
+                                uint32_t n_foreign,
                                 uint32_t *__restrict__ status, uint32_t *__restrict__ nops,
                                 const uint64_t *__restrict__ cvals, const uint8_t *__restrict__ tz, float *__restrict__ dbgf) {
     uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
@@ -294,7 +298,10 @@ __global__ void k_resolve_apply(FilterView fv, const uint64_t *__restrict__ uniq
     bool conflict = (st & ST_FOREIGN) != 0;
     for (int j = 0; j < fv.cbf_h; ++j) {
         idx[j] = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod);
-        if (n_foreign && !conflict) conflict = table_find(cs, cs_log2, idx[j]) != nullptr;
+        if (n_foreign && !conflict) {               // did another run claim this counter after this one?  (most have not: bit filter first)
+            const uint64_t b = slot_of(idx[j], csf_log2);
+            if ((csf[b >> 5] >> (uint32_t)(b & 31u)) & 1u) conflict = table_find(cs, cs_log2, idx[j]) != nullptr;
+        }
     }
     if (ops == 0) {                               // nothing to count: just drop the claim marks
         for (int j = 0; j < fv.cbf_h; ++j) cbf_release(fv.cbf, idx[j]);
@@ -1312,7 +1319,8 @@ void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, ui
     g->foreign.reserve((size_t)D * 8 * (size_t)g->cbf_h);
     uint32_t *status = g->status.as<uint32_t>(), *nops = g->nops.as<uint32_t>();
     const bool uses_dbg = (mode == M_ADD || mode == M_ADD_IF_ABSENT);
-    uint32_t f_log2 = 1, c_log2 = 1;
+    uint32_t f_log2 = 1, c_log2 = 1, csf_log2 = 16;
+    uint32_t *csf = nullptr;                     // bit filter over the contested counters, behind the table in g->ctable
     const bool full_table = getenv("RB_FIRST_SETTER_TABLE") && atoi(getenv("RB_FIRST_SETTER_TABLE"));   // the older scheme: every missing bit gets an entry
     const bool collide = uses_dbg && !full_table;
     Slot *ftab = nullptr;                        // first-setter arbitration table (null: nothing to arbitrate)
@@ -1357,15 +1365,19 @@ void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, ui
     if (n_foreign) {   // the set of counters claimed by more than one run
         g->prof_begin();
         c_log2 = log2_ceil(2ull * (uint64_t)n_foreign + 2);
-        g->ctable.reserve(sizeof(Slot) << c_log2);
-        RB_HIP(hipMemsetAsync(g->ctable.p, 0xFF, sizeof(Slot) << c_log2, s));
+        csf_log2 = std::max(16u, std::min(25u, log2_ceil(8ull * (uint64_t)n_foreign)));   // <= 12 % full, <= 4 MB
+        const size_t tab_bytes = sizeof(Slot) << c_log2;
+        g->ctable.reserve(tab_bytes + ((size_t)1 << (csf_log2 - 3)));
+        csf = reinterpret_cast<uint32_t *>(static_cast<char *>(g->ctable.p) + tab_bytes);
+        RB_HIP(hipMemsetAsync(g->ctable.p, 0xFF, tab_bytes, s));
+        RB_HIP(hipMemsetAsync(csf, 0, (size_t)1 << (csf_log2 - 3), s));
         hipLaunchKernelGGL(k_cs_build, dim3(blocks_for(D)), dim3(TPB), 0, s, status, g->foreign.as<uint64_t>(), D, g->cbf_h,
-                           g->ctable.as<Slot>(), c_log2);
+                           g->ctable.as<Slot>(), c_log2, csf, csf_log2);
         g->prof_end("conflict_set");
     }
     g->prof_begin();
     hipLaunchKernelGGL(k_resolve_apply, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, uniq, counts, starts, vals, D, mode, g->light_ops,
-                       ftab, f_log2, (int)collide, g->ctable.as<Slot>(), c_log2, n_foreign, status, nops,
+                       ftab, f_log2, (int)collide, g->ctable.as<Slot>(), c_log2, csf, csf_log2, n_foreign, status, nops,
                        g->cvals.as<uint64_t>(), g->tz().as<uint8_t>(), getenv("RB_DEBUG") ? reinterpret_cast<float *>(ctr + 700) : (float *)nullptr);
     g->prof_end("resolve_apply");
     // the runs that own their counters alone have updated counters and prefilter cache: the producer may
