@@ -300,7 +300,7 @@ __global__ void k_resolve_apply(FilterView fv, const uint64_t *__restrict__ uniq
         idx[j] = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod);
         if (n_foreign && !conflict) {               // did another run claim this counter after this one?  (most have not: bit filter first)
             const uint64_t b = slot_of(idx[j], csf_log2);
-            if ((csf[b >> 5] >> (uint32_t)(b & 31u)) & 1u) conflict = table_find(cs, cs_log2, idx[j]) != nullptr;
+            if (!csf || ((csf[b >> 5] >> (uint32_t)(b & 31u)) & 1u)) conflict = table_find(cs, cs_log2, idx[j]) != nullptr;
         }
     }
     if (ops == 0) {                               // nothing to count: just drop the claim marks
@@ -1377,7 +1377,7 @@ void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, ui
     }
     g->prof_begin();
     hipLaunchKernelGGL(k_resolve_apply, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, uniq, counts, starts, vals, D, mode, g->light_ops,
-                       ftab, f_log2, (int)collide, g->ctable.as<Slot>(), c_log2, csf, csf_log2, n_foreign, status, nops,
+                       ftab, f_log2, (int)collide, g->ctable.as<Slot>(), c_log2, getenv("RB_NO_CS_FILTER") ? (uint32_t *)nullptr : csf, csf_log2, n_foreign, status, nops,
                        g->cvals.as<uint64_t>(), g->tz().as<uint8_t>(), getenv("RB_DEBUG") ? reinterpret_cast<float *>(ctr + 700) : (float *)nullptr);
     g->prof_end("resolve_apply");
     // the runs that own their counters alone have updated counters and prefilter cache: the producer may
