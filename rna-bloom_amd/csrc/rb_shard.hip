@@ -480,14 +480,22 @@ __global__ void k_own_claim(uint8_t *cbf, uint64_t lo, const uint64_t *__restric
     if (byte & CLAIM) atomicAdd(&spread[16 * (blockIdx.x & 31u)], 1u);
     reply[i] = (uint8_t)byte;                                         // bit 7 = claimed before by another run
 }
-__global__ void k_own_cs_build(const uint64_t *__restrict__ idx, const uint8_t *__restrict__ reply, size_t n, Slot *cs, uint32_t cs_log2) {
+// contested counters: a table of their indices and, in front of it, a cache-resident bit filter over the same keys (most
+// claims are not contested and never reach the table; same arrangement as stage B of the single-GPU engine)
+__global__ void k_own_cs_build(const uint64_t *__restrict__ idx, const uint8_t *__restrict__ reply, size_t n, Slot *cs, uint32_t cs_log2,
+                               uint32_t *__restrict__ csf, uint32_t csf_log2) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && (reply[i] & 0x80u)) table_insert(cs, cs_log2, idx[i]);
+    if (i >= n || !(reply[i] & 0x80u)) return;
+    table_insert(cs, cs_log2, idx[i]);
+    const uint64_t b = slot_of(idx[i], csf_log2);
+    atomicOr(&csf[b >> 5], 1u << (uint32_t)(b & 31u));
 }
-__global__ void k_own_claim_fin(const uint64_t *__restrict__ idx, size_t n, const Slot *cs, uint32_t cs_log2, uint8_t *__restrict__ reply) {
+__global__ void k_own_claim_fin(const uint64_t *__restrict__ idx, size_t n, const Slot *cs, uint32_t cs_log2, const uint32_t *__restrict__ csf,
+                                uint32_t csf_log2, uint8_t *__restrict__ reply) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n || (reply[i] & 0x80u)) return;
-    if (table_find(cs, cs_log2, idx[i])) reply[i] |= 0x80u;
+    const uint64_t b = slot_of(idx[i], csf_log2);
+    if (((csf[b >> 5] >> (uint32_t)(b & 31u)) & 1u) && table_find(cs, cs_log2, idx[i])) reply[i] |= 0x80u;
 }
 __global__ void k_own_bits(uint32_t *bits, uint64_t lo, const uint64_t *__restrict__ idx, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1235,12 +1243,16 @@ int rb_shard_serve(rb_graph *g, int mode, const void *dreq_idx_dev, const void *
             for (int q = 0; q < 32; ++q) nf += spread[16 * q];
             if (nf) {
                 const uint32_t cs_log2 = log2_ceil(2ull * nf + 2);
-                S->own_cs.reserve(sizeof(Slot) << cs_log2);
-                RB_HIP(hipMemsetAsync(S->own_cs.p, 0xFF, sizeof(Slot) << cs_log2, s));
+                const uint32_t csf_log2 = std::max(16u, std::min(25u, log2_ceil(8ull * (uint64_t)nf)));
+                const size_t tab_bytes = sizeof(Slot) << cs_log2;
+                S->own_cs.reserve(tab_bytes + ((size_t)1 << (csf_log2 - 3)));
+                uint32_t *csf = reinterpret_cast<uint32_t *>(static_cast<char *>(S->own_cs.p) + tab_bytes);
+                RB_HIP(hipMemsetAsync(S->own_cs.p, 0xFF, tab_bytes, s));
+                RB_HIP(hipMemsetAsync(csf, 0, (size_t)1 << (csf_log2 - 3), s));
                 hipLaunchKernelGGL(k_own_cs_build, dim3(blocks_for(nc)), dim3(TPB), 0, s, (const uint64_t *)creq_idx_dev, (const uint8_t *)creply_dev,
-                                   (size_t)nc, S->own_cs.as<Slot>(), cs_log2);
+                                   (size_t)nc, S->own_cs.as<Slot>(), cs_log2, csf, csf_log2);
                 hipLaunchKernelGGL(k_own_claim_fin, dim3(blocks_for(nc)), dim3(TPB), 0, s, (const uint64_t *)creq_idx_dev, (size_t)nc,
-                                   S->own_cs.as<Slot>(), cs_log2, (uint8_t *)creply_dev);
+                                   S->own_cs.as<Slot>(), cs_log2, csf, csf_log2, (uint8_t *)creply_dev);
             }
         }
         if (np) {
