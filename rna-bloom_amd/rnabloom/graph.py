@@ -134,8 +134,15 @@ class BloomFilterDeBruijnGraph:
     def getK(self): return self.k
     def isStranded(self): return self.stranded
     def getMaxNumHash(self): return max(self.p.dbgbf_num_hash, self.p.cbf_num_hash)
-    def setReadPairedKmerDistance(self, d): check(lib.rb_graph_set_read_paired_kmer_distance(self.h, d))
-    def setFragPairedKmerDistance(self, d): check(lib.rb_graph_set_frag_paired_kmer_distance(self.h, d))
+    def setReadPairedKmerDistance(self, d):
+        check(lib.rb_graph_set_read_paired_kmer_distance(self.h, d)); self.readPairedKmersDistance = int(d)
+    def setFragPairedKmerDistance(self, d):
+        check(lib.rb_graph_set_frag_paired_kmer_distance(self.h, d)); self.fragmentPairedKmersDistance = int(d)
+    def getReadPairedKmerDistance(self): return getattr(self, "readPairedKmersDistance", 0)
+    def getFragPairedKmerDistance(self): return getattr(self, "fragmentPairedKmersDistance", 0)
+    def getDbgbfNumHash(self): return self.p.dbgbf_num_hash
+    def getCbfNumHash(self): return self.p.cbf_num_hash
+    def getPkbfNumHash(self): return self.p.pkbf_num_hash
 
     def initializePairKmersBloomFilter(self, pkbfNumBits, pkbfNumHash):
         check(lib.rb_graph_init_fragment_pairs(self.h, pkbfNumBits, pkbfNumHash))
@@ -287,6 +294,145 @@ class BloomFilterDeBruijnGraph:
         check(lib.rb_graph_greedy_extend(self.h, bf._g.h if bf is not None else None, _ptr(sb), n, direction, lookahead, bound, _ptr(bases),
                                          _ptr(c) if counts else None, _ptr(ln), _ptr(reason)))
         return bases, c, ln, reason
+
+    # ---- the reference's convenience methods, batched (R/graph/BloomFilterDeBruijnGraph.java; all device work goes through
+    # the calls above) ----
+    def _base_hash(self, f, r):
+        """hashVals[0] of a k-mer: forward hash when stranded, signed minimum of both strands otherwise (NTHash.java:449-475)"""
+        return f if self.stranded else np.where(r.view(np.int64) < f.view(np.int64), r, f)
+
+    def getCounts(self, h0):                                            # getCounts(String[]) :578-590, from hashes
+        return self.getCount(h0)
+
+    def getKmer(self, kmer):
+        """getKmer(String) :592-594 -> (fHashVal, rHashVal, count) of one k-mer string"""
+        ko, f, r, c = self.getKmers([kmer if isinstance(kmer, bytes) else kmer.encode()])
+        if ko[-1] != 1: raise ValueError("getKmer: the string must hold exactly one k-mer")
+        return int(f[0]), int(r[0]), float(c[0])
+
+    def containsSeq(self, kmers):                                       # contains(String) :534-536 for many k-mer strings
+        ko, f, r, _ = self.getKmers([x if isinstance(x, bytes) else x.encode() for x in kmers])
+        if int(ko[-1]) != len(kmers): raise ValueError("containsSeq: every string must hold exactly one k-mer")
+        return self.contains(self._base_hash(f, r))
+
+    def isValidSeq(self, seqs):
+        """isValidSeq(String) :1181-1194 for many sequences: every k-mer of the sequence is in dbgbf (True for a sequence
+        shorter than k, as in the reference, whose loop then never runs)"""
+        seqs = [x if isinstance(x, bytes) else x.encode() for x in seqs]
+        ko, f, r, _ = self.getKmers(seqs)
+        hit = self.contains(self._base_hash(f, r)) if f.size else np.zeros(0, bool)
+        return [bool(hit[int(ko[i]):int(ko[i + 1])].all()) for i in range(len(seqs))]
+
+    _ALT = {ord("A"): b"CGT", ord("C"): b"AGT", ord("G"): b"ACT", ord("T"): b"ACG", ord("U"): b"ACG"}   # SeqUtils.java:51-55
+
+    def _variants(self, kmer, pos):
+        kmer = kmer if isinstance(kmer, bytes) else kmer.encode()
+        alts = self._ALT.get(kmer[pos], b"ACGT")
+        cand = [kmer[:pos] + bytes([c]) + kmer[pos + 1:] for c in alts]
+        hit = self.containsSeq(cand)
+        return [v.decode() for v, ok in zip(cand, hit) if ok]
+
+    def getLeftVariants(self, kmer): return self._variants(kmer, 0)                 # :1056-1068
+    def getRightVariants(self, kmer): return self._variants(kmer, self.k - 1)       # :1109-1121
+
+    def getSuccessors(self, f, r, charOut, minKmerCov=1.0):
+        """Kmer.getSuccessors(k, numHash, graph, minKmerCov) (R/graph/Kmer.java:199-226) for many k-mers: the four
+        candidates in A,C,G,T order with a mask of those whose count reaches minKmerCov -> (f4, r4, count4, keep4)"""
+        f4, r4, c4 = self.getNeighbors(f, r, charOut, 0)
+        return f4, r4, c4, c4 >= np.float32(minKmerCov)
+
+    def getPredecessors(self, f, r, charOut, minKmerCov=1.0):           # Kmer.java:228-255
+        f4, r4, c4 = self.getNeighbors(f, r, charOut, 1)
+        return f4, r4, c4, c4 >= np.float32(minKmerCov)
+
+    def _pair_hashes(self, f, r, d):
+        from .graphutils import kmerPairHashValues
+        f, r = _u64(np.atleast_1d(f)), _u64(np.atleast_1d(r))
+        return kmerPairHashValues(f, r, d, self.stranded) if f.size > d > 0 else np.zeros(0, np.uint64)
+
+    def addReadPairedKmers(self, f, r):
+        """addReadPairedKmers(ArrayList<Kmer>) :485-494: k-mers i and i + readPairedKmersDistance of one sequence, given
+        by their hash values, into rpkbf"""
+        p = self._pair_hashes(f, r, self.getReadPairedKmerDistance())
+        if p.size: self.addReadSingleKmerPair(p)
+
+    def addFragmentPairKmers(self, f, r):                               # :474-483, into fpkbf
+        p = self._pair_hashes(f, r, self.getFragPairedKmerDistance())
+        if p.size: self.addFragmentSingleKmerPair(p)
+
+    def destroyRpkbf(self): self.clearRpkbf()       # :270-275 frees the filter; here its bits are cleared, the memory is
+    def destroyFpkbf(self): self.clearFpkbf()       # :263-268   kept until the graph is destroyed
+
+    # ---- persistence: the reference's own files (a graph saved here loads in RNA-Bloom and the other way round) ----
+    _EXT = {N.DBGBF: ".dbgbf", N.CBF: ".cbf", N.RPKBF: ".rpkbf", N.FPKBF: ".fpkbf"}     # :58-62
+
+    def saveDesc(self, graphFile):                                      # :297-305
+        with open(graphFile, "w") as w:
+            w.write("dbgbfCbfMaxNumHash:%d\nstranded:%s\nk:%d\nreadPairedKmersDistance:%d\nfragmentPairedKmersDistance:%d\n" % (
+                self.getMaxNumHash(), "true" if self.stranded else "false", self.k, self.getReadPairedKmerDistance(), self.getFragPairedKmerDistance()))
+
+    def _save_filter(self, graphFile, which):
+        """BloomFilter.save / CountingBloomFilter.save (R/bloom/BloomFilter.java:113-124, CountingBloomFilter.java:106-118):
+        <graph><ext>.desc with size / numhash / fpr, <graph><ext> with the raw bytes"""
+        size, _, h = self.filterSize(which)
+        path = str(graphFile) + self._EXT[which]
+        with open(path + ".desc", "w") as w:
+            w.write("size:%d\nnumhash:%d\nfpr:%s\n" % (size, h, str(np.float32(self._fpr(which)))))
+        self.exportFilter(which).tofile(path)
+
+    def _has(self, which):
+        try: return self.filterSize(which)[0] > 0
+        except Exception: return False
+
+    def save(self, graphFile):                                          # :307-329 (fpkbf is written by savePkbf)
+        self.saveDesc(graphFile)
+        self._save_filter(graphFile, N.DBGBF); self._save_filter(graphFile, N.CBF)
+        if self._has(N.RPKBF): self._save_filter(graphFile, N.RPKBF)
+
+    def savePkbf(self, graphFile):                                      # :331-339
+        self.saveDesc(graphFile); self._save_filter(graphFile, N.FPKBF)
+
+    @staticmethod
+    def _read_desc(path):
+        d = {}
+        with open(path) as r:
+            for line in r:
+                if ":" in line:
+                    key, val = line.rstrip("\n").split(":", 1)
+                    d[key] = val
+        return d
+
+    def restorePkbf(self, graphFile):                                   # :341-350
+        import os
+        path = str(graphFile) + self._EXT[N.FPKBF]
+        d = self._read_desc(path + ".desc")
+        self.initializePairKmersBloomFilter(int(d["size"]), int(d["numhash"]))
+        self.importFilter(N.FPKBF, np.fromfile(path, np.uint8))
+
+    def updateFragmentKmerDistance(self, graphFile):                    # :106-119
+        d = self._read_desc(graphFile)
+        if "fragmentPairedKmersDistance" in d: self.setFragPairedKmerDistance(int(d["fragmentPairedKmersDistance"]))
+
+    @classmethod
+    def fromFile(cls, graphFile, loadDbgBits=True, device=0, rngSeed=0):
+        """BloomFilterDeBruijnGraph(File graphFile, boolean loadDbgBits) :121-189"""
+        import os
+        g = str(graphFile)
+        d = cls._read_desc(g)
+        db, cb = cls._read_desc(g + ".dbgbf.desc"), cls._read_desc(g + ".cbf.desc")
+        rp = g + ".rpkbf"
+        has_rp = os.path.isfile(rp) and os.path.isfile(rp + ".desc")
+        rpd = cls._read_desc(rp + ".desc") if has_rp else {"size": "64", "numhash": "1"}
+        self = cls(int(db["size"]), int(cb["size"]), int(rpd["size"]), int(db["numhash"]), int(cb["numhash"]), int(rpd["numhash"]),
+                   int(d["k"]), d.get("stranded", "false").strip() == "true", has_rp, device=device, rngSeed=rngSeed)
+        if loadDbgBits: self.importFilter(N.DBGBF, np.fromfile(g + ".dbgbf", np.uint8))
+        self.importFilter(N.CBF, np.fromfile(g + ".cbf", np.uint8))
+        if has_rp: self.importFilter(N.RPKBF, np.fromfile(rp, np.uint8))
+        if "readPairedKmersDistance" in d and int(d["readPairedKmersDistance"]) > 0: self.setReadPairedKmerDistance(int(d["readPairedKmersDistance"]))
+        if "fragmentPairedKmersDistance" in d and int(d["fragmentPairedKmersDistance"]) > 0: self.setFragPairedKmerDistance(int(d["fragmentPairedKmersDistance"]))
+        fp = g + ".fpkbf"
+        if os.path.isfile(fp) and os.path.isfile(fp + ".desc"): self.restorePkbf(g)
+        return self
 
     # ---- filter state ----
     def filterSize(self, which):

@@ -865,3 +865,80 @@ def test_get_kmers_min_coverage_variant():
             assert n == len(exp) and (n == 0 or (st == exp[0][0] and (cnt == np.array([x[1] for x in exp], np.float32)).all())), (min_cov, i)
             kinds.add("empty" if n == 0 else ("from the start" if st == 0 else "later run"))
     assert kinds == {"empty", "from the start", "later run"}
+
+
+def test_reference_facade_and_graph_files(tmp_path):
+    """the per-element conveniences of the reference's facade (getKmer, contains(String), isValidSeq,
+    getLeft/RightVariants, getSuccessors/Predecessors, addReadPairedKmers / addFragmentPairKmers) against the oracle
+    graph, and the reference's file set (graph desc + .dbgbf/.cbf/.rpkbf/.fpkbf with their .desc): a saved graph comes
+    back byte for byte and answers the same"""
+    d = synth.generate_pairs(800, G=3000, err=0.002, n_rate=0.0, seed=4242)
+    og, gg = graph_pair(400_009, 500_009, 80_021, max_batch=30_000)
+    og.set_read_pair_distance(60); gg.setReadPairedKmerDistance(60)
+    s, off = synth.flat(d["left"]); q, _ = synth.flat(d["lqual"])
+    og.add_reads(s, q, off, 3, rbo.STORE_READ_PAIRS); gg.addReads(s, q, off, 3, storeReadPairedKmers=True)
+    og.init_fragment_pairs(70_001, 2, 40); gg.initializePairKmersBloomFilter(70_001, 2); gg.setFragPairedKmerDistance(40)
+    from rnabloom.graphutils import kmerPairHashValues
+    reads = [bytes(s[off[i]:off[i + 1]]) for i in range(40)]
+    rng = np.random.default_rng(5)
+    hv = lambda x: rbo.ntm64(int(x), 25, 2)
+    o_contains = lambda hs: np.array([og.contains(hv(x)) for x in hs], bool)
+    # pair lists of whole sequences (read pairs into rpkbf, fragment pairs into fpkbf)
+    for sq in reads[:10]:
+        f, r, _ = og.get_kmers(sq)
+        gg.addReadPairedKmers(f, r); gg.addFragmentPairKmers(f, r)
+        for x in kmerPairHashValues(f, r, 60, False): og.add_read_pair(hv(x))
+        for x in kmerPairHashValues(f, r, 40, False): og.add_fragment_pair(hv(x))
+    assert (gg.exportFilter(N.RPKBF) == og.rpkbf_bytes()).all() and (gg.exportFilter(N.FPKBF) == og.fpkbf_bytes()).all()
+    # k-mer strings: present ones, mutated ones
+    kms = []
+    for sq in reads[10:30]:
+        p = int(rng.integers(0, len(sq) - 25)); km = bytearray(sq[p:p + 25])
+        if b"N" in km: continue
+        kms.append(bytes(km))
+        km[int(rng.integers(0, 25))] = b"ACGT"[int(rng.integers(0, 4))]; kms.append(bytes(km))
+    exp = []
+    for km in kms:
+        f, r, c = og.get_kmers(km)
+        exp.append((int(f[0]), int(r[0]), float(c[0])))
+        assert gg.getKmer(km) == exp[-1]
+    canon = np.array([min(np.int64(np.uint64(e[0]).view(np.int64)), np.int64(np.uint64(e[1]).view(np.int64))) for e in exp]).view(np.uint64)
+    assert (gg.containsSeq(kms) == o_contains(canon)).all()
+    for km in kms[:12]:
+        for pos, fn in ((0, gg.getLeftVariants), (24, gg.getRightVariants)):
+            want = []
+            for c in {65: b"CGT", 67: b"AGT", 71: b"ACT", 84: b"ACG"}[km[pos]]:
+                v = km[:pos] + bytes([c]) + km[pos + 1:]
+                f, r, _ = og.get_kmers(v)
+                if og.contains(hv(np.array([min(f[0].view(np.int64), r[0].view(np.int64))]).view(np.uint64)[0])): want.append(v.decode())
+            assert fn(km) == want
+    seqs = reads[30:40] + [reads[31][:24], reads[32][:10] + b"ACGTACGTACGTACGTACGTACGTACGT" + reads[32][10:]]
+    want = []
+    for sq in seqs:
+        f, r, _ = og.get_kmers(sq)
+        hh = np.where(r.view(np.int64) < f.view(np.int64), r, f)
+        want.append(bool(o_contains(hh).all()) if hh.size else True)
+    assert gg.isValidSeq(seqs) == want and want[0] and not want[-1]
+    f, r, _ = og.get_kmers(reads[12]); ch = np.frombuffer(reads[12][:f.size], np.uint8)
+    f4, r4, c4, keep = gg.getSuccessors(f[:8], r[:8], ch[:8], 2.0)
+    p4 = gg.getPredecessors(f[:8], r[:8], np.frombuffer(reads[12][24:32], np.uint8), 2.0)
+    for i in range(8):
+        of4, or4, oc4 = og.neighbors(f[i], r[i], int(ch[i]), 0)
+        assert (f4[i] == of4).all() and (r4[i] == or4).all() and (c4[i] == oc4).all() and (keep[i] == (oc4 >= 2.0)).all()
+        of4, or4, oc4 = og.neighbors(f[i], r[i], int(reads[12][24 + i]), 1)
+        assert (p4[0][i] == of4).all() and (p4[1][i] == or4).all() and (p4[2][i] == oc4).all()
+    # files
+    path = str(tmp_path / "graph")
+    gg.save(path); gg.savePkbf(path)
+    desc = open(path).read().splitlines()
+    assert desc == ["dbgbfCbfMaxNumHash:2", "stranded:false", "k:25", "readPairedKmersDistance:60", "fragmentPairedKmersDistance:40"]
+    assert open(path + ".dbgbf.desc").read().startswith("size:400009\nnumhash:2\nfpr:")
+    assert np.array_equal(np.fromfile(path + ".cbf", np.uint8), og.cbf_bytes())
+    g2 = BloomFilterDeBruijnGraph.fromFile(path)
+    for w in (N.DBGBF, N.CBF, N.RPKBF, N.FPKBF):
+        assert np.array_equal(g2.exportFilter(w), gg.exportFilter(w))
+    assert g2.k == 25 and not g2.stranded and g2.getReadPairedKmerDistance() == 60 and g2.getFragPairedKmerDistance() == 40
+    assert (g2.containsSeq(kms) == gg.containsSeq(kms)).all() and g2.getKmer(kms[0]) == exp[0]
+    g3 = BloomFilterDeBruijnGraph.fromFile(path, loadDbgBits=False)
+    assert g3.popcount(N.DBGBF) == 0 and np.array_equal(g3.exportFilter(N.CBF), og.cbf_bytes())
+    g3.updateFragmentKmerDistance(path); assert g3.getFragPairedKmerDistance() == 40
