@@ -360,6 +360,12 @@ class BloomFilterDeBruijnGraph:
         p = self._pair_hashes(f, r, self.getFragPairedKmerDistance())
         if p.size: self.addFragmentSingleKmerPair(p)
 
+    def getDbgbf(self): return _FilterOfGraph(self, N.DBGBF)            # :277-291: the filter objects of a graph, as views
+    def getCbf(self): return _FilterOfGraph(self, N.CBF)
+    def getRpkbf(self): return _FilterOfGraph(self, N.RPKBF) if self._has(N.RPKBF) else None
+    def getFpkbf(self): return _FilterOfGraph(self, N.FPKBF) if self._has(N.FPKBF) else None
+    def getFpkbfFPR(self): return self.getPkbfFPR()
+
     def destroyRpkbf(self): self.clearRpkbf()       # :270-275 frees the filter; here its bits are cleared, the memory is
     def destroyFpkbf(self): self.clearFpkbf()       # :263-268   kept until the graph is destroyed
 
@@ -473,6 +479,22 @@ class BloomFilterDeBruijnGraph:
         p = N.Profile()
         check(lib.rb_graph_profile_get(self.h, C.byref(p), int(reset)))
         return {p.name[i].decode(): (p.ms[i], p.launches[i]) for i in range(p.n)}
+
+
+class _FilterOfGraph:
+    """One filter of a graph seen through the reference's BloomFilter / CountingBloomFilter methods that take a hash value
+    (R/bloom/BloomFilter.java:139-199, R/bloom/CountingBloomFilter.java:235-263); arrays in, arrays out."""
+
+    def __init__(self, graph, which): self.g, self.which = graph, which
+    def lookup(self, h0): return self.g.getCbfCount(h0) > 0 if self.which == N.CBF else self.g._lookup(self.which, h0)
+    def getCount(self, h0):
+        if self.which != N.CBF: raise TypeError("getCount is a counting-filter method")
+        return self.g.getCbfCount(h0)
+    def getFPR(self): return self.g._fpr(self.which)
+    def getPopCount(self): return self.g.popcount(self.which)
+    def getNumHash(self): return self.g.filterSize(self.which)[2]
+    def getSize(self): return self.g.filterSize(self.which)[0]
+    def toBytes(self): return self.g.exportFilter(self.which)
 
 
 # ---- sketching (BASELINE config 5): hash-only, no graph needed ----

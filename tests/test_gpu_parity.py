@@ -942,3 +942,7 @@ def test_reference_facade_and_graph_files(tmp_path):
     g3 = BloomFilterDeBruijnGraph.fromFile(path, loadDbgBits=False)
     assert g3.popcount(N.DBGBF) == 0 and np.array_equal(g3.exportFilter(N.CBF), og.cbf_bytes())
     g3.updateFragmentKmerDistance(path); assert g3.getFragPairedKmerDistance() == 40
+    # the graph's filters as objects
+    assert gg.getDbgbf().getPopCount() == og.popcounts()[0] and gg.getCbf().getNumHash() == 2 and gg.getRpkbf().getSize() == 80_021
+    assert (gg.getDbgbf().lookup(canon) == o_contains(canon)).all() and np.array_equal(gg.getFpkbf().toBytes(), og.fpkbf_bytes())
+    assert (gg.getCbf().getCount(canon) == gg.getCbfCount(canon)).all() and gg.getFpkbfFPR() == gg.getPkbfFPR()
