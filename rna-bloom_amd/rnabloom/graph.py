@@ -360,6 +360,22 @@ class BloomFilterDeBruijnGraph:
         p = self._pair_hashes(f, r, self.getFragPairedKmerDistance())
         if p.size: self.addFragmentSingleKmerPair(p)
 
+    def _iterate(self, seqs, mode):
+        b = ReadBatch.from_reads([x if isinstance(x, bytes) else x.encode() for x in seqs], device=self.device)
+        try:
+            return b.nthash(self.k, mode, with_positions=True)
+        finally:
+            b.close()
+
+    def getHashIterator(self, seqs):
+        """getHashIterator().start(seq) ... next() (:1196-1206) over many sequences at once: hashVals[0] of every k-mer of
+        every usable (ACGT) segment, with its sequence number and position — the strand-specific iterator for a stranded
+        graph, the canonical one otherwise"""
+        return self._iterate(seqs, 0 if self.stranded else 1)
+
+    def getReverseComplementHashIterator(self, seqs):                    # :1208-1214
+        return self._iterate(seqs, 2 if self.stranded else 1)
+
     def getDbgbf(self): return _FilterOfGraph(self, N.DBGBF)            # :277-291: the filter objects of a graph, as views
     def getCbf(self): return _FilterOfGraph(self, N.CBF)
     def getRpkbf(self): return _FilterOfGraph(self, N.RPKBF) if self._has(N.RPKBF) else None

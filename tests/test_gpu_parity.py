@@ -942,6 +942,15 @@ def test_reference_facade_and_graph_files(tmp_path):
     g3 = BloomFilterDeBruijnGraph.fromFile(path, loadDbgBits=False)
     assert g3.popcount(N.DBGBF) == 0 and np.array_equal(g3.exportFilter(N.CBF), og.cbf_bytes())
     g3.updateFragmentKmerDistance(path); assert g3.getFragPairedKmerDistance() == 40
+    # hash iterators over sequences
+    h0, rd, ps = gg.getHashIterator(reads[:5])
+    at = 0
+    for i, sq in enumerate(reads[:5]):
+        f, r, _ = og.get_kmers(sq)
+        hh = np.where(r.view(np.int64) < f.view(np.int64), r, f)
+        assert (h0[at:at + hh.size] == hh).all() and (rd[at:at + hh.size] == i).all() and (ps[at:at + hh.size] == np.arange(hh.size)).all()
+        at += hh.size
+    assert at == h0.size and (gg.getReverseComplementHashIterator(reads[:5])[0] == h0).all()     # canonical graph: same values
     # the graph's filters as objects
     assert gg.getDbgbf().getPopCount() == og.popcounts()[0] and gg.getCbf().getNumHash() == 2 and gg.getRpkbf().getSize() == 80_021
     assert (gg.getDbgbf().lookup(canon) == o_contains(canon)).all() and np.array_equal(gg.getFpkbf().toBytes(), og.fpkbf_bytes())
