@@ -1231,25 +1231,18 @@ void rb::group_enqueue(rb_graph *g, int slot, size_t N, uint64_t ordinal0, uint3
     RB_HIP(hipMemsetAsync(ctr, 0, DEVCTR_BYTES, st));
     if (N == 0) return;
     g->prof_begin(st);
-    temp.reserve(std::max({sort_pairs_temp_bytes(N), rle_temp_bytes(N), scan_temp_bytes(N + 1)}));
-    S.keys1.reserve(N * 8); S.vals1.reserve(N * 4);
-    // Grouping, not ordering, is what the later stages need: a STABLE sort on the top 32 hash bits
-    // puts equal hashes next to each other except where two different hashes share the prefix; such
-    // a hash then simply shows up as several runs, which the pipeline treats as separate k-mers
-    // that share all their bits/counters — the first-setter arbitration and the ordered conflict
-    // replay already make that case exact (DESIGN.md §Pipeline "split runs").
-    sort_pairs_u64_u32(temp.p, temp.cap, g->keys0.as<uint64_t>(), S.keys1.as<uint64_t>(), g->vals0.as<uint32_t>(),
-                       S.vals1.as<uint32_t>(), N, g->sort_begin_bit, 64, st);
-    g->prof_end("sort_occurrences", st);
-    g->prof_begin(st);
-    S.tz.reserve(N + 16);
-    hipLaunchKernelGGL(k_strength, dim3(blocks_for((int64_t)N)), dim3(TPB), 0, st, g->view(ordinal0, pos_bits), S.vals1.as<uint32_t>(),
-                       N, S.tz.as<uint8_t>());
-    g->prof_end("strengths", st);
-    g->prof_begin(st);   // runs of equal hash = distinct k-mers
+    // Grouping, not ordering, is what the later stages need (rb_group.hip): equal hashes next to each other with
+    // their occurrences in sequential order, except where a hash is cut into several runs — the pipeline treats
+    // such runs as separate k-mers that share all their bits/counters, which the first-setter arbitration and the
+    // ordered conflict replay already make exact (DESIGN.md §Pipeline "split runs").
+    const int group_bits = 64 - g->sort_begin_bit;
+    temp.reserve(group_temp_bytes(N, group_bits));
+    S.keys1.reserve(N * 8); S.valsT.reserve(N * 4); S.vals1.reserve(N * 4); S.tz.reserve(N + 16);
     S.uniq.reserve(N * 8); S.counts.reserve((N + 1) * 4); S.starts.reserve((N + 1) * 4);
-    run_length_encode_u64(temp.p, temp.cap, S.keys1.as<uint64_t>(), N, S.uniq.as<uint64_t>(), S.counts.as<uint32_t>(), ctr + 8, st);
-    g->prof_end("distinct_runs", st);
+    group_records_device(g->keys0.as<uint64_t>(), g->vals0.as<uint32_t>(), S.keys1.as<uint64_t>(), S.valsT.as<uint32_t>(), N, group_bits,
+                         g->p.rng_seed, ordinal0, pos_bits, temp.p, temp.cap, S.vals1.as<uint32_t>(), S.tz.as<uint8_t>(), S.uniq.as<uint64_t>(),
+                         S.counts.as<uint32_t>(), S.starts.as<uint32_t>(), ctr + 8, st);
+    g->prof_end("group_records", st);
 }
 uint32_t rb::group_finish(rb_graph *g, int slot, hipStream_t st, DevBuf &temp, DevBuf &ctrbuf, hipStream_t scan_stream) {
     rb_graph::GroupSlot &S = g->slots[slot];
@@ -1259,9 +1252,7 @@ uint32_t rb::group_finish(rb_graph *g, int slot, hipStream_t st, DevBuf &temp, D
     RB_HIP(hipStreamSynchronize(st));
     RB_REQUIRE(D < (1u << 30), "sub-batch has too many distinct k-mers (%u)", D);
     S.D = D;
-    // run start offsets, on the consumer's stream with the consumer's temporary storage
-    temp.reserve(scan_temp_bytes((size_t)D + 1));
-    exclusive_scan_u32(temp.p, temp.cap, S.counts.as<uint32_t>(), S.starts.as<uint32_t>(), D, scan_stream);
+    (void)temp; (void)scan_stream;   // the run starts come out of the grouping kernel
     return D;
 }
 uint32_t rb::group_records(rb_graph *g, size_t N, uint64_t ordinal0, uint32_t pos_bits, rb_add_stats *stats, uint32_t **ctr_out) {
@@ -1771,7 +1762,7 @@ int rb_graph_destroy(rb_graph *g) {
     if (g->stream) (void)hipStreamDestroy(g->stream);
     if (g->stream2) (void)hipStreamDestroy(g->stream2);
     for (auto e : g->prof_pool) (void)hipEventDestroy(e);
-    for (auto &sl : g->slots) { sl.keys1.release(); sl.vals1.release(); sl.tz.release(); sl.uniq.release(); sl.counts.release(); sl.starts.release(); }
+    for (auto &sl : g->slots) { sl.keys1.release(); sl.valsT.release(); sl.vals1.release(); sl.tz.release(); sl.uniq.release(); sl.counts.release(); sl.starts.release(); }
     g->temp2.release(); g->devctr2.release(); g->npf.release(); g->mpf.release(); g->chunk_mask.release(); g->npf_tot.release(); g->wstate.release();
     delete g;
     return RB_OK;

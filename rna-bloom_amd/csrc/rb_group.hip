@@ -1,0 +1,730 @@
+// rb_group.hip — grouping of the (h0, occurrence) records of a sub-batch, written for gfx950.
+//
+// What the insert pipeline needs from this stage is not a sorted array but
+// GROUPS: equal base hashes next to each other, the occurrences of one hash in sequential order
+// (BloomFilterDeBruijnGraph.add is applied per k-mer occurrence in input order,
+// R/graph/BloomFilterDeBruijnGraph.java:405-412), the draw strength of every occurrence, and the list of
+// runs (hash, count, start).  A hash may appear as several runs ("split runs"), so
+// the stage may group on as few hash bits as it likes.
+//
+// That freedom is what this file uses instead of a full 4-pass radix sort:
+//   1. MSD partition of the records on T = ceil(log2(N / 3072)) hash bits into 2^T "fine buckets" of ~2-3 K
+//      records, in one or two STABLE passes over HBM (k_part_count -> exclusive scan -> k_part_scatter; a tile
+//      of TPB x ITEMS records is ranked with wavefront ballots and staged through LDS so that every bucket
+//      receives one contiguous piece per tile; consecutive tiles are given to the same XCD so that the pieces
+//      of neighbouring tiles meet in one L2).  The second pass is segmented: its tiles never straddle a
+//      first-pass bucket, so its scanned histogram IS the table of fine-bucket bounds.
+//   2. k_group_buckets: one workgroup per fine bucket sorts it in LDS on the next 16 hash bits (two stable
+//      8-bit counting passes), computes the strengths, finds the run heads and writes (hash, count, start)
+//      for its runs at a global position obtained by a chained scan over the buckets (ticket + look-back).
+// Records are read 3 times and written 2.x times (12-byte records) instead of 5 + 4 times, and the separate
+// strength and run-length passes are gone.
+#include <stdlib.h>
+
+#include <algorithm>
+
+#include "rb_internal.hpp"
+
+namespace rb {
+
+// ---- geometry --------------------------------------------------------------------------------------
+constexpr uint32_t GR_KEY_TOP = 60;          // grouping uses hash bits below this one (the top bits of a canonical
+                                             // hash are skewed: it is a signed minimum of two hashes)
+constexpr uint32_t GR_MAX_GROUP_BITS = 36;
+constexpr uint32_t GR_TILE = 4096;           // records per partition tile and LDS capacity of the bucket kernel
+constexpr uint32_t GR_BUCKET_TARGET = 3072;  // T is chosen so that the average fine bucket is in (TARGET/2, TARGET]
+constexpr uint32_t GR_LOCAL_BITS = 8;        // per local pass
+constexpr uint32_t GR_PART_MAX_BITS = 10;    // per partition pass
+
+__device__ __forceinline__ uint32_t gr_digit(uint64_t key, uint32_t shift, uint32_t bits) {
+    return (uint32_t)(key >> shift) & ((1u << bits) - 1u);
+}
+__device__ __forceinline__ uint32_t gr_lanes_below(uint64_t m) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
+
+// Stable ranks inside one wavefront's ITEMS rows of 64 records: rank[r] = number of earlier records of this
+// wavefront (rows before r, lanes below in row r) with the same digit.  wc = this wavefront's counters
+// (zeroed, 2^bits entries); on return wc[d] = number of records of digit d in the wavefront.
+// dig[r] == ~0u marks an absent record; rows from `rows` on are absent altogether (wavefront-uniform).
+template <int ITEMS, typename CT>
+__device__ __forceinline__ void gr_wave_rank(const uint32_t (&dig)[ITEMS], uint32_t (&rank)[ITEMS], CT *wc, uint32_t bits, uint32_t rows) {
+    const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+        if ((uint32_t)r < rows) {
+            const bool valid = dig[r] != ~0u;
+            uint64_t m = __ballot(valid);
+            for (uint32_t b = 0; b < bits; ++b) {
+                const bool bit = (dig[r] >> b) & 1u;
+                const uint64_t bal = __ballot(bit);
+                m &= bit ? bal : ~bal;
+            }
+            uint32_t prior = 0;
+            if (valid) prior = (uint32_t)wc[dig[r]];
+            rank[r] = prior + gr_lanes_below(m);
+            if (valid && (m >> lane) == 1ull) wc[dig[r]] = (CT)(prior + (uint32_t)__popcll(m));   // highest lane of the group
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+// The same ranks with the match masks taken from LDS instead of `bits` ballots per row: every lane ORs its lane bit
+// into wm[digit] (ds_or_b64; the DS operations of a wavefront execute in issue order), reads the word back — that IS
+// the mask of the lanes of this row with the same digit — and the highest lane of each group clears it again.
+// wm = this wavefront's mask table (2^bits words, all zero on entry and on return).  ~6 DS operations per row
+// instead of ~12 VALU/SALU instructions per digit bit: the bucket kernel below is bound by instruction issue.
+template <int ITEMS, typename CT>
+__device__ __forceinline__ void gr_wave_rank_lds(const uint32_t (&dig)[ITEMS], uint32_t (&rank)[ITEMS], CT *wc, unsigned long long *wm, uint32_t rows) {
+    const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+        if ((uint32_t)r < rows) {
+            const bool valid = dig[r] != ~0u;
+            uint64_t m = 0;
+            uint32_t prior = 0;
+            if (valid) {
+                __hip_atomic_fetch_or(&wm[dig[r]], 1ull << lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                m = __hip_atomic_load(&wm[dig[r]], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                prior = (uint32_t)wc[dig[r]];
+            }
+            rank[r] = prior + gr_lanes_below(m);
+            if (valid && (m >> lane) == 1ull) {                                   // highest lane of the group
+                __hip_atomic_store(&wm[dig[r]], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                wc[dig[r]] = (CT)(prior + (uint32_t)__popcll(m));
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
+// exclusive scan of one value per thread over the block
+template <int TPB>
+__device__ __forceinline__ uint32_t gr_block_excl_scan(uint32_t v, uint32_t *s_wsum) {
+    const uint32_t lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    uint32_t inc = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o, 64);
+        if ((int)lane >= o) inc += t;
+    }
+    if (lane == 63u) s_wsum[w] = inc;
+    __syncthreads();
+    uint32_t base = 0;
+#pragma unroll
+    for (int i = 0; i < TPB / 64; ++i) {
+        const uint32_t t = s_wsum[i];
+        if ((uint32_t)i < w) base += t;
+    }
+    __syncthreads();
+    return base + inc - v;
+}
+
+// per-digit wavefront counters -> exclusive prefix over the wavefronts (in place) and, in dstart[], the exclusive
+// prefix over the digits of the per-digit totals.  Called by all threads, between barriers of the caller.
+template <int TPB, typename CT, typename DT>
+__device__ __forceinline__ void gr_digit_offsets(CT *wcnt /* [TPB/64][nb] */, DT *dstart /* [nb] */, uint32_t nb, uint32_t *s_wsum) {
+    constexpr int NW = TPB / 64;
+    const uint32_t per = (nb + TPB - 1) / TPB;       // nb <= 1024, TPB >= 256: at most 4 consecutive digits per thread
+    uint32_t tot[4] = {0, 0, 0, 0}, sum = 0;
+    for (uint32_t q = 0; q < per; ++q) {
+        const uint32_t d = threadIdx.x * per + q;
+        if (d < nb) {
+            uint32_t run = 0;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { const uint32_t t = (uint32_t)wcnt[(uint32_t)w * nb + d]; wcnt[(uint32_t)w * nb + d] = (CT)run; run += t; }
+            tot[q] = run; sum += run;
+        }
+    }
+    uint32_t base = gr_block_excl_scan<TPB>(sum, s_wsum);
+    for (uint32_t q = 0; q < per; ++q) {
+        const uint32_t d = threadIdx.x * per + q;
+        if (d < nb) { dstart[d] = (DT)base; base += tot[q]; }
+    }
+}
+
+// blocks b, b+8, b+16, ... run on the same XCD (observed, not promised: used for speed only): give every XCD a
+// contiguous range of tiles, so that the bucket pieces of consecutive tiles are written through the same L2
+__device__ __forceinline__ uint32_t gr_tile_of_block(uint32_t b, uint32_t grid_tiles, int xcd_map) {
+    if (!xcd_map) return b;
+    return (b & 7u) * (grid_tiles >> 3) + (b >> 3);
+}
+inline uint32_t gr_grid_for_tiles(uint32_t ntiles) { return ((ntiles + 7u) / 8u) * 8u; }
+
+// A partition pass works on tiles.  First pass: tile t = records [t*TILE, ...), histogram entry (d, t) at d*ntiles + t.
+// Second pass: the tiles of first-pass bucket b are tile_base[b] .. tile_base[b+1]-1 (GrTile descriptors written by
+// k_seg_tiles), histogram of bucket b = [d][local tile] at tile_base[b]*nb, so that ONE exclusive scan over all
+// entries yields final positions, bucket after bucket, digit after digit.
+struct GrTile { uint32_t start, count, hist_base, hist_stride; };
+struct GrTiling {
+    const GrTile *desc;          // nullptr: uniform tiling of [0, n)
+    const uint32_t *ntiles_dev;  // with desc: number of tiles actually in use (device)
+    uint32_t n, ntiles, grid_tiles;
+    int xcd_map;
+};
+__device__ __forceinline__ bool gr_get_tile(const GrTiling &tl, GrTile &t) {
+    const uint32_t i = gr_tile_of_block(blockIdx.x, tl.grid_tiles, tl.xcd_map);
+    if (!tl.desc) {
+        if (i >= tl.ntiles) return false;
+        t.start = i * GR_TILE; t.count = min(GR_TILE, tl.n - t.start); t.hist_base = i; t.hist_stride = tl.ntiles;
+        return true;
+    }
+    if (i >= *tl.ntiles_dev) return false;
+    t = tl.desc[i];
+    return true;
+}
+
+// ---- partition pass: histogram per (digit, tile) -----------------------------------------------------
+template <int TPB>
+__global__ void __launch_bounds__(TPB) k_part_count(const uint64_t *__restrict__ keys, GrTiling tl, uint32_t shift, uint32_t bits,
+                                                    uint32_t *__restrict__ hist) {
+    constexpr int ITEMS = GR_TILE / TPB;
+    __shared__ uint32_t s_h[1u << GR_PART_MAX_BITS];
+    GrTile t;
+    if (!gr_get_tile(tl, t)) return;
+    const uint32_t nb = 1u << bits;
+    for (uint32_t d = threadIdx.x; d < nb; d += TPB) s_h[d] = 0;
+    __syncthreads();
+    uint64_t k[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const uint32_t j = (uint32_t)i * TPB + threadIdx.x;
+        k[i] = j < t.count ? keys[t.start + j] : 0ull;
+    }
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const uint32_t j = (uint32_t)i * TPB + threadIdx.x;
+        if (j < t.count) atomicAdd(&s_h[gr_digit(k[i], shift, bits)], 1u);
+    }
+    __syncthreads();
+    for (uint32_t d = threadIdx.x; d < nb; d += TPB) hist[(size_t)t.hist_base + (size_t)d * t.hist_stride] = s_h[d];
+}
+
+// ---- partition pass: stable scatter ------------------------------------------------------------------
+template <int TPB, int MAXBITS>
+__global__ void __launch_bounds__(TPB) k_part_scatter(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, GrTiling tl,
+                                                      uint32_t shift, uint32_t bits, const uint32_t *__restrict__ goffs /* exclusive scan of hist */,
+                                                      uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out) {
+    constexpr uint32_t ITEMS = GR_TILE / TPB, NW = TPB / 64, SEG = 64 * ITEMS, MAXNB = 1u << MAXBITS;
+    __shared__ uint64_t s_keys[GR_TILE];
+    __shared__ uint32_t s_vals[GR_TILE];
+    __shared__ uint32_t s_cnt[NW * MAXNB / 2 > MAXNB ? NW * MAXNB / 2 : MAXNB];   // u16 per (wavefront, digit); later: u32 global bases per digit
+    __shared__ uint16_t s_dstart[MAXNB];
+    __shared__ uint32_t s_wsum[NW];
+    uint16_t *s_wcnt = reinterpret_cast<uint16_t *>(s_cnt);
+    GrTile t;
+    if (!gr_get_tile(tl, t)) return;
+    const uint32_t nb = 1u << bits;
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    for (uint32_t d = threadIdx.x; d < NW * nb; d += TPB) s_wcnt[d] = 0;
+    // rows of this wavefront: records w*SEG + r*64 + lane of the tile
+    uint64_t k[ITEMS];
+    uint32_t v[ITEMS], dig[ITEMS], rank[ITEMS];
+#pragma unroll
+    for (uint32_t r = 0; r < ITEMS; ++r) {
+        const uint32_t j = w * SEG + r * 64u + lane;
+        const bool ok = j < t.count;
+        k[r] = ok ? keys_in[t.start + j] : 0ull;
+        v[r] = ok ? vals_in[t.start + j] : 0u;
+        dig[r] = ok ? gr_digit(k[r], shift, bits) : ~0u;
+    }
+    const uint32_t rows = t.count > w * SEG ? min(ITEMS, (t.count - w * SEG + 63u) / 64u) : 0u;
+    __syncthreads();
+    gr_wave_rank<ITEMS>(dig, rank, s_wcnt + w * nb, bits, rows);
+    __syncthreads();
+    gr_digit_offsets<TPB>(s_wcnt, s_dstart, nb, s_wsum);
+    __syncthreads();
+#pragma unroll
+    for (uint32_t r = 0; r < ITEMS; ++r)
+        if (dig[r] != ~0u) {
+            const uint32_t p = (uint32_t)s_dstart[dig[r]] + (uint32_t)s_wcnt[w * nb + dig[r]] + rank[r];
+            s_keys[p] = k[r]; s_vals[p] = v[r];
+        }
+    __syncthreads();
+    for (uint32_t d = threadIdx.x; d < nb; d += TPB) s_cnt[d] = goffs[(size_t)t.hist_base + (size_t)d * t.hist_stride] - (uint32_t)s_dstart[d];
+    __syncthreads();
+    for (uint32_t j = threadIdx.x; j < t.count; j += TPB) {
+        const uint64_t key = s_keys[j];
+        const uint32_t g = s_cnt[gr_digit(key, shift, bits)] + j;
+        keys_out[g] = key; vals_out[g] = s_vals[j];
+    }
+}
+
+// first-pass bucket bounds -> tiles of the second pass.  One block; nb1 <= 1024 segments.
+__global__ void __launch_bounds__(1024) k_seg_tiles(const uint32_t *__restrict__ goffs1, uint32_t ntiles1, uint32_t nb1, uint32_t n, uint32_t nb2,
+                                                    GrTile *__restrict__ desc, uint32_t *__restrict__ seg_tile_base /* [nb1 + 1] */,
+                                                    uint32_t *__restrict__ seg_start /* [nb1 + 1] */, uint32_t *__restrict__ ntiles2_dev) {
+    __shared__ uint32_t s_wsum[16];
+    const uint32_t b = threadIdx.x;
+    uint32_t s = 0, e = 0;
+    if (b < nb1) { s = goffs1[(size_t)b * ntiles1]; e = b + 1u < nb1 ? goffs1[(size_t)(b + 1u) * ntiles1] : n; }
+    const uint32_t nt = (e - s + GR_TILE - 1u) / GR_TILE;
+    const uint32_t tb = gr_block_excl_scan<1024>(nt, s_wsum);
+    if (b < nb1) {
+        seg_tile_base[b] = tb; seg_start[b] = s;
+        for (uint32_t i = 0; i < nt; ++i) {
+            GrTile t; t.start = s + i * GR_TILE; t.count = min(GR_TILE, e - t.start); t.hist_base = tb * nb2 + i; t.hist_stride = nt;
+            desc[tb + i] = t;
+        }
+        if (b == nb1 - 1u) { seg_tile_base[nb1] = tb + nt; seg_start[nb1] = n; *ntiles2_dev = tb + nt; }
+    }
+}
+// fine-bucket bounds bstart[2^T + 1]
+__global__ void k_bucket_bounds(const uint32_t *__restrict__ goffs, uint32_t ntiles1, const uint32_t *__restrict__ seg_tile_base,
+                                const uint32_t *__restrict__ seg_start, uint32_t t_hi, uint32_t t_lo, uint32_t n, uint32_t *__restrict__ bstart) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x, nbk = 1u << (t_hi + t_lo);
+    if (p > nbk) return;
+    if (p == nbk) { bstart[p] = n; return; }
+    if (t_hi == 0) { bstart[p] = 0; return; }                                // no partition pass: one bucket
+    if (t_lo == 0) { bstart[p] = goffs[(size_t)p * ntiles1]; return; }      // single pass: goffs = first-pass offsets
+    const uint32_t b = p >> t_lo, lo = p & ((1u << t_lo) - 1u);
+    const uint32_t tb = seg_tile_base[b], nt = seg_tile_base[b + 1u] - tb;
+    bstart[p] = nt ? goffs[((size_t)tb << t_lo) + (size_t)lo * nt] : seg_start[b];
+}
+
+// ---- bucket kernel: LDS sort on 2 x 8 bits, strengths, runs --------------------------------------------
+struct GroupRng { uint64_t seed, ordinal0; uint32_t pos_bits; };
+constexpr unsigned long long GR_ST_AGG = 1ull << 62, GR_ST_PREFIX = 2ull << 62;
+
+// wavefront-wide look-back over the status words of the buckets before c: sum of their run counts
+__device__ __forceinline__ uint32_t gr_look_back(const unsigned long long *status, uint32_t c) {
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t sum = 0;
+    int64_t p = (int64_t)c - 1;
+    for (;;) {
+        const int64_t mine = p - (int64_t)lane;
+        unsigned long long st = GR_ST_PREFIX;                        // below bucket 0: an empty prefix
+        if (mine >= 0) st = __hip_atomic_load(&status[mine], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint64_t ready = __ballot((st >> 62) != 0ull), pref = __ballot((st >> 62) == 2ull);
+        const uint32_t n_ready = ready == ~0ull ? 64u : (uint32_t)__builtin_ctzll(~ready);   // lanes 0 .. n_ready-1 are published
+        const uint32_t first_pref = pref ? (uint32_t)__builtin_ctzll(pref) : 64u;
+        const uint32_t take = first_pref < n_ready ? first_pref + 1u : n_ready;
+        uint32_t val = lane < take ? (uint32_t)(st & 0xFFFFFFFFull) : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) val += __shfl_xor(val, o, 64);
+        sum += val;
+        if (first_pref < n_ready) return sum;
+        p -= (int64_t)take;
+        if (take == 0) __builtin_amdgcn_s_sleep(2);
+    }
+}
+
+template <int TPB>
+__global__ void __launch_bounds__(TPB) k_group_buckets(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+                                                       const uint32_t *__restrict__ bstart, uint32_t nbuckets,
+                                                       uint32_t shift_lo, uint32_t bits_lo, uint32_t shift_hi, uint32_t bits_hi,
+                                                       GroupRng rng, uint32_t *__restrict__ ticket, unsigned long long *__restrict__ status,
+                                                       uint32_t *__restrict__ big_list, uint32_t *__restrict__ n_big,
+                                                       uint32_t *__restrict__ vals_out, uint8_t *__restrict__ tz_out,
+                                                       uint64_t *__restrict__ uniq, uint32_t *__restrict__ counts, uint32_t *__restrict__ starts,
+                                                       uint32_t *__restrict__ n_runs_out) {
+    constexpr uint32_t ITEMS = GR_TILE / TPB, NW = TPB / 64, SEG = 64 * ITEMS, NB = 1u << GR_LOCAL_BITS;
+    __shared__ uint64_t s_keys[GR_TILE];
+    __shared__ uint32_t s_vals[GR_TILE];          // later: head positions (u16)
+    __shared__ uint16_t s_wcnt[NW * NB];
+    __shared__ unsigned long long s_wmask[NW * NB];
+    __shared__ uint16_t s_dstart[NB];
+    __shared__ uint32_t s_wsum[NW], s_seg[ITEMS * NW], s_misc[2];
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    for (uint32_t d = threadIdx.x; d < NW * NB; d += TPB) s_wmask[d] = 0ull;
+    // persistent workgroups: buckets are taken in ticket order, so every predecessor of a bucket has been taken by
+    // a running workgroup (the look-back below never waits for work that has not started)
+    for (;;) {
+    __syncthreads();
+    if (threadIdx.x == 0) s_misc[0] = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint32_t c = s_misc[0];
+    if (c >= nbuckets) return;
+    const uint32_t b0 = bstart[c], b1 = bstart[c + 1u];
+    const bool big = b1 - b0 > GR_TILE;              // does not fit LDS: left to k_group_big (its runs are appended after all of these)
+    const uint32_t cn = big ? 0u : b1 - b0;
+    const uint32_t rows = cn > w * SEG ? min(ITEMS, (cn - w * SEG + 63u) / 64u) : 0u;
+    uint64_t k[ITEMS];
+    uint32_t v[ITEMS], dig[ITEMS], rank[ITEMS];
+#pragma unroll
+    for (uint32_t r = 0; r < ITEMS; ++r) {
+        const uint32_t j = w * SEG + r * 64u + lane;
+        const bool ok = j < cn;
+        k[r] = ok ? keys_in[b0 + j] : 0ull;
+        v[r] = ok ? vals_in[b0 + j] : 0u;
+    }
+    if (big && threadIdx.x == 0) big_list[atomicAdd(n_big, 1u)] = c;
+    bool in_lds = false;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+        const uint32_t shift = pass ? shift_hi : shift_lo, bits = pass ? bits_hi : bits_lo;
+        if (bits == 0 || cn == 0) continue;
+        const uint32_t nb = 1u << bits;
+        if (in_lds) {
+#pragma unroll
+            for (uint32_t r = 0; r < ITEMS; ++r) {
+                const uint32_t j = w * SEG + r * 64u + lane;
+                if (j < cn) { k[r] = s_keys[j]; v[r] = s_vals[j]; }
+            }
+        }
+        __syncthreads();
+        for (uint32_t d = threadIdx.x; d < NW * nb; d += TPB) s_wcnt[d] = 0;
+#pragma unroll
+        for (uint32_t r = 0; r < ITEMS; ++r) {
+            const uint32_t j = w * SEG + r * 64u + lane;
+            dig[r] = j < cn ? gr_digit(k[r], shift, bits) : ~0u;
+        }
+        __syncthreads();
+        gr_wave_rank_lds<ITEMS>(dig, rank, s_wcnt + w * nb, s_wmask + w * NB, rows);
+        __syncthreads();
+        gr_digit_offsets<TPB>(s_wcnt, s_dstart, nb, s_wsum);
+        __syncthreads();
+#pragma unroll
+        for (uint32_t r = 0; r < ITEMS; ++r)
+            if (dig[r] != ~0u) {
+                const uint32_t p = (uint32_t)s_dstart[dig[r]] + (uint32_t)s_wcnt[w * nb + dig[r]] + rank[r];
+                s_keys[p] = k[r]; s_vals[p] = v[r];
+            }
+        __syncthreads();
+        in_lds = true;
+    }
+    if (!in_lds) {      // no local digit at all: keep the order
+#pragma unroll
+        for (uint32_t r = 0; r < ITEMS; ++r) {
+            const uint32_t j = w * SEG + r * 64u + lane;
+            if (j < cn) { s_keys[j] = k[r]; s_vals[j] = v[r]; }
+        }
+        __syncthreads();
+    }
+    // the bucket is grouped; thread t takes records t, t + TPB, ... : strengths, sorted occurrences, run heads
+    unsigned long long hb[ITEMS];
+    bool head[ITEMS];
+    const uint32_t pmask = (1u << rng.pos_bits) - 1u;
+#pragma unroll
+    for (uint32_t i = 0; i < ITEMS; ++i) {
+        const uint32_t j = i * TPB + threadIdx.x;
+        head[i] = false;
+        if (j < cn) {
+            const uint64_t key = s_keys[j];
+            head[i] = j == 0u || s_keys[j - 1u] != key;
+            const uint32_t occ = s_vals[j];
+            vals_out[b0 + j] = occ;
+            const uint32_t rr = rng31(rng.seed, rng.ordinal0 + (uint64_t)(occ >> rng.pos_bits), occ & pmask) | 0x8000u;
+            tz_out[b0 + j] = (uint8_t)(__ffs((int)rr) - 1);
+        }
+        hb[i] = __ballot(head[i]);
+        if (lane == 0) s_seg[i * NW + w] = (uint32_t)__popcll(hb[i]);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t run = 0;
+        for (uint32_t q = 0; q < ITEMS * NW; ++q) { const uint32_t t = s_seg[q]; s_seg[q] = run; run += t; }
+        s_misc[1] = run;
+    }
+    __syncthreads();                       // everybody has read s_vals: reuse it for the head positions
+    const uint32_t nruns = s_misc[1];
+    uint16_t *hpos = reinterpret_cast<uint16_t *>(s_vals);
+#pragma unroll
+    for (uint32_t i = 0; i < ITEMS; ++i)
+        if (head[i]) hpos[s_seg[i * NW + w] + gr_lanes_below(hb[i])] = (uint16_t)(i * TPB + threadIdx.x);
+    // global position of this bucket's runs: chained scan over the buckets
+    if (w == 0) {
+        if (lane == 0)
+            __hip_atomic_store(&status[c], (c == 0 ? GR_ST_PREFIX : GR_ST_AGG) | (unsigned long long)nruns, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t rb_ = 0;
+        if (c != 0) rb_ = gr_look_back(status, c);
+        if (lane == 0) {
+            s_misc[0] = rb_;
+            if (c != 0) __hip_atomic_store(&status[c], GR_ST_PREFIX | (unsigned long long)(rb_ + nruns), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (c == nbuckets - 1u) *n_runs_out = rb_ + nruns;
+        }
+    }
+    __syncthreads();
+    const uint32_t run_base = s_misc[0];
+    for (uint32_t i = threadIdx.x; i < nruns; i += TPB) {
+        const uint32_t j = hpos[i], e = i + 1u < nruns ? (uint32_t)hpos[i + 1u] : cn;
+        uniq[run_base + i] = s_keys[j];
+        starts[run_base + i] = b0 + j;
+        counts[run_base + i] = e - j;
+    }
+    }   // next bucket
+}
+
+// Buckets that do not fit LDS (a k-mer with thousands of surviving occurrences in the sub-batch, cold prefilter
+// cache): one workgroup per bucket sorts it on the same local digits with the same stable counting passes, but
+// through global memory (ping-pong between the record buffer the bucket lives in and the other one), piece by
+// piece, and then streams over the result: a run may span any number of pieces, so a hot k-mer stays ONE run
+// (k_cbf_heavy's case) instead of being cut.  Run slots are taken from the run counter the main kernel left
+// (atomicAdd per piece: the order of these few runs among themselves is arbitrary, which nothing depends on).
+template <int TPB>
+__global__ void __launch_bounds__(TPB) k_group_big(uint64_t *keys_a, uint32_t *vals_a, uint64_t *keys_b, uint32_t *vals_b,
+                                                   const uint32_t *__restrict__ bstart, const uint32_t *__restrict__ big_list,
+                                                   const uint32_t *__restrict__ n_big_dev,
+                                                   uint32_t shift_lo, uint32_t bits_lo, uint32_t shift_hi, uint32_t bits_hi, GroupRng rng,
+                                                   uint32_t *__restrict__ vals_out, uint8_t *__restrict__ tz_out,
+                                                   uint64_t *__restrict__ uniq, uint32_t *__restrict__ counts, uint32_t *__restrict__ starts,
+                                                   uint32_t *__restrict__ run_cursor) {
+    constexpr uint32_t ITEMS = GR_TILE / TPB, NW = TPB / 64, SEG = 64 * ITEMS, NB = 1u << GR_LOCAL_BITS;
+    __shared__ uint64_t s_keys[GR_TILE];
+    __shared__ uint16_t s_hpos[GR_TILE];
+    __shared__ uint16_t s_wcnt[NW * NB];
+    __shared__ unsigned long long s_wmask[NW * NB];
+    __shared__ uint32_t s_hist[NB], s_dbase[NB], s_tot[NB];
+    __shared__ uint32_t s_wsum[NW], s_seg[ITEMS * NW], s_misc[4];
+    __shared__ uint64_t s_carry_key;
+    const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    for (uint32_t d = threadIdx.x; d < NW * NB; d += TPB) s_wmask[d] = 0ull;
+    const uint32_t n_big = *n_big_dev;
+    const uint32_t pmask = (1u << rng.pos_bits) - 1u;
+    for (uint32_t bi = blockIdx.x; bi < n_big; bi += gridDim.x) {
+        const uint32_t c = big_list[bi], b0 = bstart[c], b1 = bstart[c + 1u];
+        uint64_t *ksrc = keys_a, *kdst = keys_b;
+        uint32_t *vsrc = vals_a, *vdst = vals_b;
+        for (int pass = 0; pass < 2; ++pass) {
+            const uint32_t shift = pass ? shift_hi : shift_lo, bits = pass ? bits_hi : bits_lo;
+            if (bits == 0) continue;
+            const uint32_t nb = 1u << bits;
+            __syncthreads();
+            for (uint32_t d = threadIdx.x; d < nb; d += TPB) s_hist[d] = 0;
+            __syncthreads();
+            for (uint32_t x = b0 + threadIdx.x; x < b1; x += TPB) atomicAdd(&s_hist[gr_digit(ksrc[x], shift, bits)], 1u);
+            __syncthreads();
+            {   // exclusive scan of the histogram -> running bases per digit
+                const uint32_t per = (nb + TPB - 1) / TPB;       // 1 (nb <= 256 <= TPB)
+                uint32_t vsum = 0;
+                if (threadIdx.x * per < nb) vsum = s_hist[threadIdx.x];
+                const uint32_t ex = gr_block_excl_scan<TPB>(vsum, s_wsum);
+                if (threadIdx.x < nb) s_dbase[threadIdx.x] = ex;
+            }
+            __syncthreads();
+            for (uint32_t p0 = b0; p0 < b1; p0 += GR_TILE) {
+                const uint32_t cn = min(GR_TILE, b1 - p0);
+                const uint32_t rows = cn > w * SEG ? min(ITEMS, (cn - w * SEG + 63u) / 64u) : 0u;
+                uint64_t k[ITEMS];
+                uint32_t v[ITEMS], dig[ITEMS], rank[ITEMS];
+#pragma unroll
+                for (uint32_t r = 0; r < ITEMS; ++r) {
+                    const uint32_t j = w * SEG + r * 64u + lane;
+                    const bool ok = j < cn;
+                    k[r] = ok ? ksrc[p0 + j] : 0ull;
+                    v[r] = ok ? vsrc[p0 + j] : 0u;
+                    dig[r] = ok ? gr_digit(k[r], shift, bits) : ~0u;
+                }
+                for (uint32_t d = threadIdx.x; d < NW * nb; d += TPB) s_wcnt[d] = 0;
+                __syncthreads();
+                gr_wave_rank_lds<ITEMS>(dig, rank, s_wcnt + w * nb, s_wmask + w * NB, rows);
+                __syncthreads();
+                if (threadIdx.x < nb) {      // exclusive prefix over the wavefronts, total of the piece
+                    uint32_t run = 0;
+#pragma unroll
+                    for (uint32_t ww = 0; ww < NW; ++ww) { const uint32_t t = s_wcnt[ww * nb + threadIdx.x]; s_wcnt[ww * nb + threadIdx.x] = (uint16_t)run; run += t; }
+                    s_tot[threadIdx.x] = run;
+                }
+                __syncthreads();
+#pragma unroll
+                for (uint32_t r = 0; r < ITEMS; ++r)
+                    if (dig[r] != ~0u) {
+                        const uint32_t g = b0 + s_dbase[dig[r]] + (uint32_t)s_wcnt[w * nb + dig[r]] + rank[r];
+                        kdst[g] = k[r]; vdst[g] = v[r];
+                    }
+                __syncthreads();
+                if (threadIdx.x < nb) s_dbase[threadIdx.x] += s_tot[threadIdx.x];
+                __syncthreads();
+            }
+            { uint64_t *t = ksrc; ksrc = kdst; kdst = t; }
+            { uint32_t *t = vsrc; vsrc = vdst; vdst = t; }
+            __threadfence();
+            __syncthreads();
+        }
+        // stream over the grouped bucket: strengths, occurrences, runs (the open run is carried from piece to piece)
+        uint32_t carry_start = b0;               // block-uniform copies; the key lives in s_carry_key
+        for (uint32_t p0 = b0; p0 < b1; p0 += GR_TILE) {
+            const uint32_t cn = min(GR_TILE, b1 - p0);
+            const bool first = p0 == b0;
+            __syncthreads();
+            for (uint32_t j = threadIdx.x; j < cn; j += TPB) s_keys[j] = ksrc[p0 + j];
+            __syncthreads();
+            unsigned long long hb[ITEMS];
+            bool head[ITEMS];
+            const uint64_t ckey = first ? 0ull : s_carry_key;
+#pragma unroll
+            for (uint32_t i = 0; i < ITEMS; ++i) {
+                const uint32_t j = i * TPB + threadIdx.x;
+                head[i] = false;
+                if (j < cn) {
+                    const uint64_t key = s_keys[j];
+                    head[i] = j == 0u ? (first || key != ckey) : s_keys[j - 1u] != key;
+                    const uint32_t occ = vsrc[p0 + j];
+                    vals_out[p0 + j] = occ;
+                    const uint32_t rr = rng31(rng.seed, rng.ordinal0 + (uint64_t)(occ >> rng.pos_bits), occ & pmask) | 0x8000u;
+                    tz_out[p0 + j] = (uint8_t)(__ffs((int)rr) - 1);
+                }
+                hb[i] = __ballot(head[i]);
+                if (lane == 0) s_seg[i * NW + w] = (uint32_t)__popcll(hb[i]);
+            }
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                uint32_t run = 0;
+                for (uint32_t q = 0; q < ITEMS * NW; ++q) { const uint32_t t = s_seg[q]; s_seg[q] = run; run += t; }
+                s_misc[1] = run;                                   // heads in this piece
+                const uint32_t closed = run - (first ? 1u : 0u);   // every head closes the run before it, except the very first
+                s_misc[0] = closed ? atomicAdd(run_cursor, closed) : 0u;
+            }
+            __syncthreads();
+            const uint32_t nheads = s_misc[1], base = s_misc[0];
+#pragma unroll
+            for (uint32_t i = 0; i < ITEMS; ++i)
+                if (head[i]) s_hpos[s_seg[i * NW + w] + gr_lanes_below(hb[i])] = (uint16_t)(i * TPB + threadIdx.x);
+            __syncthreads();
+            // head i closes: the carried run (i == 0, not the first piece) or the run that began at head i-1
+            for (uint32_t i = threadIdx.x; i < nheads; i += TPB) {
+                const uint32_t j = s_hpos[i];
+                if (i == 0u) {
+                    if (!first) { uniq[base] = ckey; starts[base] = carry_start; counts[base] = p0 + j - carry_start; }
+                } else {
+                    const uint32_t jp = s_hpos[i - 1u], slot = base + i - (first ? 1u : 0u);
+                    uniq[slot] = s_keys[jp]; starts[slot] = p0 + jp; counts[slot] = j - jp;
+                }
+            }
+            __syncthreads();
+            if (nheads) {                           // the last head of the piece opens the run that is carried on
+                const uint32_t jl = s_hpos[nheads - 1u];
+                carry_start = p0 + jl;
+                if (threadIdx.x == 0) s_carry_key = s_keys[jl];
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {                     // the run still open at the end of the bucket
+            const uint32_t slot = atomicAdd(run_cursor, 1u);
+            uniq[slot] = s_carry_key; starts[slot] = carry_start; counts[slot] = b1 - carry_start;
+        }
+        __syncthreads();
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------
+struct GroupPlan {
+    uint32_t n = 0, T = 0;
+    uint32_t t_lo = 0, t_hi = 0;             // partition passes (bits; 0 = no pass), MSD order: hi first
+    uint32_t shift_lo = 0, shift_hi = 0;
+    uint32_t l_lo = 0, l_hi = 0, lshift_lo = 0, lshift_hi = 0;   // local passes (LSD: lo first)
+    uint32_t ntiles = 0, ntiles2_max = 0, nbuckets = 1;
+    uint32_t tpb = 256;
+    int xcd_map = 1;
+    size_t hist_entries = 0;
+    // layout of the temporary storage
+    size_t off_status = 0, off_ticket = 0, off_bstart = 0, off_big = 0, off_hist = 0, off_goffs = 0, off_scan = 0, off_desc = 0, off_segtb = 0, off_segst = 0,
+           scan_bytes = 0, total = 0;
+};
+static size_t gr_align(size_t x) { return (x + 255) / 256 * 256; }
+
+static GroupPlan group_plan(size_t N, int group_bits) {
+    GroupPlan P;
+    P.n = (uint32_t)N;
+    const uint32_t gb = (uint32_t)std::max(1, std::min<int>(group_bits, (int)GR_MAX_GROUP_BITS));
+    uint32_t T = 0;
+    while (((size_t)GR_BUCKET_TARGET << T) < N) ++T;
+    if (const char *e = getenv("RB_GROUP_T")) T = (uint32_t)std::max(0, atoi(e));
+    T = std::min({T, gb, 2u * GR_PART_MAX_BITS});
+    P.T = T;
+    if (T <= GR_PART_MAX_BITS) { P.t_hi = T; P.t_lo = 0; }
+    else { P.t_hi = (T + 1u) / 2u; P.t_lo = T - P.t_hi; }
+    P.shift_hi = GR_KEY_TOP - P.t_hi;
+    P.shift_lo = GR_KEY_TOP - T;
+    const uint32_t L = std::min(gb - T, 2u * GR_LOCAL_BITS);
+    P.l_hi = (L + 1u) / 2u;
+    P.l_lo = L - P.l_hi;
+    P.lshift_hi = GR_KEY_TOP - T - P.l_hi;
+    P.lshift_lo = GR_KEY_TOP - T - L;
+    P.tpb = getenv("RB_GROUP_TPB") ? (uint32_t)atoi(getenv("RB_GROUP_TPB")) : 512u;
+    if (P.tpb != 256u) P.tpb = 512u;
+    P.xcd_map = getenv("RB_GROUP_XCD") ? atoi(getenv("RB_GROUP_XCD")) : 1;
+    P.ntiles = (uint32_t)((N + GR_TILE - 1) / GR_TILE);
+    P.ntiles2_max = P.t_lo ? P.ntiles + (1u << P.t_hi) : 0;
+    P.nbuckets = 1u << T;
+    if (T) P.hist_entries = std::max((size_t)P.ntiles << P.t_hi, (size_t)P.ntiles2_max << P.t_lo) + 1;
+    size_t o = 0;
+    P.off_status = o; o += gr_align((size_t)P.nbuckets * 8);
+    P.off_ticket = o; o += 256;
+    P.off_bstart = o; o += gr_align(((size_t)P.nbuckets + 1) * 4);
+    P.off_big = o; o += gr_align((size_t)P.nbuckets * 4);
+    if (T) {
+        P.off_hist = o; o += gr_align(P.hist_entries * 4);
+        P.off_goffs = o; o += gr_align(P.hist_entries * 4);
+        P.scan_bytes = gr_align(scan_temp_bytes(P.hist_entries));
+        P.off_scan = o; o += P.scan_bytes;
+        if (P.t_lo) {
+            P.off_desc = o; o += gr_align((size_t)P.ntiles2_max * sizeof(GrTile));
+            P.off_segtb = o; o += gr_align(((size_t)(1u << P.t_hi) + 1) * 4);
+            P.off_segst = o; o += gr_align(((size_t)(1u << P.t_hi) + 1) * 4);
+        }
+    }
+    P.total = o;
+    return P;
+}
+
+size_t group_temp_bytes(size_t N, int group_bits) { return group_plan(N, group_bits).total; }
+
+template <int TPB>
+static void part_pass(const GrTiling &tl, size_t entries, uint32_t shift, uint32_t bits, const uint64_t *kin, const uint32_t *vin, uint64_t *kout,
+                      uint32_t *vout, uint32_t *hist, uint32_t *goffs, void *scan_tmp, size_t scan_bytes, hipStream_t st) {
+    const dim3 grid(tl.grid_tiles), blk(TPB);
+    hipLaunchKernelGGL(k_part_count<TPB>, grid, blk, 0, st, kin, tl, shift, bits, hist);
+    exclusive_scan_u32(scan_tmp, scan_bytes, hist, goffs, entries, st);
+    if (bits <= 8u) hipLaunchKernelGGL((k_part_scatter<TPB, 8>), grid, blk, 0, st, kin, vin, tl, shift, bits, goffs, kout, vout);
+    else hipLaunchKernelGGL((k_part_scatter<TPB, GR_PART_MAX_BITS>), grid, blk, 0, st, kin, vin, tl, shift, bits, goffs, kout, vout);
+}
+
+// Groups the N records (keys0, vals0) — both arrays are clobbered; (keys_tmp, vals_tmp) is scratch of the same size.
+// Outputs: vals_out[N] occurrences in grouped order, tz_out[N] their strengths, runs (uniq, counts, starts) and
+// *n_runs_dev.  Everything is enqueued on `st`; nothing is synchronised.
+template <int TPB>
+static void group_records_impl(const GroupPlan &P, uint64_t *keys0, uint32_t *vals0, uint64_t *keys_tmp, uint32_t *vals_tmp, GroupRng rng, char *tp,
+                               uint32_t *vals_out, uint8_t *tz_out, uint64_t *uniq, uint32_t *counts, uint32_t *starts, uint32_t *n_runs_dev,
+                               hipStream_t st) {
+    unsigned long long *status = reinterpret_cast<unsigned long long *>(tp + P.off_status);
+    uint32_t *ticket = reinterpret_cast<uint32_t *>(tp + P.off_ticket);
+    uint32_t *bstart = reinterpret_cast<uint32_t *>(tp + P.off_bstart);
+    RB_HIP(hipMemsetAsync(status, 0, P.off_bstart, st));        // status words + ticket
+    const uint64_t *kin = keys0;
+    const uint32_t *vin = vals0;
+    if (P.T) {
+        uint32_t *hist = reinterpret_cast<uint32_t *>(tp + P.off_hist), *goffs = reinterpret_cast<uint32_t *>(tp + P.off_goffs);
+        void *scan_tmp = tp + P.off_scan;
+        GrTiling t1{nullptr, nullptr, P.n, P.ntiles, gr_grid_for_tiles(P.ntiles), P.xcd_map};
+        part_pass<TPB>(t1, (size_t)P.ntiles << P.t_hi, P.shift_hi, P.t_hi, kin, vin, keys_tmp, vals_tmp, hist, goffs, scan_tmp, P.scan_bytes, st);
+        kin = keys_tmp; vin = vals_tmp;
+        uint32_t *segtb = nullptr, *segst = nullptr;
+        if (P.t_lo) {
+            GrTile *desc = reinterpret_cast<GrTile *>(tp + P.off_desc);
+            segtb = reinterpret_cast<uint32_t *>(tp + P.off_segtb); segst = reinterpret_cast<uint32_t *>(tp + P.off_segst);
+            uint32_t *nt2 = ticket + 1;
+            hipLaunchKernelGGL(k_seg_tiles, dim3(1), dim3(1024), 0, st, goffs, P.ntiles, 1u << P.t_hi, P.n, 1u << P.t_lo, desc, segtb, segst, nt2);
+            RB_HIP(hipMemsetAsync(hist, 0, ((size_t)P.ntiles2_max << P.t_lo) * 4, st));
+            GrTiling t2{desc, nt2, P.n, P.ntiles2_max, gr_grid_for_tiles(P.ntiles2_max), P.xcd_map};
+            part_pass<TPB>(t2, (size_t)P.ntiles2_max << P.t_lo, P.shift_lo, P.t_lo, kin, vin, keys0, vals0, hist, goffs, scan_tmp, P.scan_bytes, st);
+            kin = keys0; vin = vals0;
+        }
+        hipLaunchKernelGGL(k_bucket_bounds, dim3((P.nbuckets + 256u) / 256u), dim3(256), 0, st, goffs, P.ntiles, segtb, segst, P.t_hi, P.t_lo, P.n, bstart);
+    } else
+        hipLaunchKernelGGL(k_bucket_bounds, dim3(1), dim3(64), 0, st, (const uint32_t *)nullptr, 0u, (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, 0u, P.n, bstart);
+    uint32_t *big_list = reinterpret_cast<uint32_t *>(tp + P.off_big), *n_big = ticket + 2;
+    const uint32_t bucket_grid = std::min(P.nbuckets, (uint32_t)(getenv("RB_GROUP_GRID") ? atoi(getenv("RB_GROUP_GRID")) : 768));
+    hipLaunchKernelGGL(k_group_buckets<TPB>, dim3(bucket_grid), dim3(TPB), 0, st, kin, vin, bstart, P.nbuckets, P.lshift_lo, P.l_lo, P.lshift_hi, P.l_hi,
+                       rng, ticket, status, big_list, n_big, vals_out, tz_out, uniq, counts, starts, n_runs_dev);
+    // the buckets that do not fit LDS (none in a warm steady state): sorted through the record buffer that is free now
+    uint64_t *ka = const_cast<uint64_t *>(kin), *kb = kin == keys0 ? keys_tmp : keys0;
+    uint32_t *va = const_cast<uint32_t *>(vin), *vb = vin == vals0 ? vals_tmp : vals0;
+    hipLaunchKernelGGL(k_group_big<512>, dim3(std::min(P.nbuckets, 2048u)), dim3(512), 0, st, ka, va, kb, vb, bstart, big_list, n_big,
+                       P.lshift_lo, P.l_lo, P.lshift_hi, P.l_hi, rng, vals_out, tz_out, uniq, counts, starts, n_runs_dev);
+    RB_HIP(hipGetLastError());
+}
+
+void group_records_device(uint64_t *keys0, uint32_t *vals0, uint64_t *keys_tmp, uint32_t *vals_tmp, size_t N, int group_bits,
+                          uint64_t seed, uint64_t ordinal0, uint32_t pos_bits, void *temp, size_t temp_bytes,
+                          uint32_t *vals_out, uint8_t *tz_out, uint64_t *uniq, uint32_t *counts, uint32_t *starts, uint32_t *n_runs_dev,
+                          hipStream_t st) {
+    RB_REQUIRE(N > 0 && N < (1ull << 32) - 2 * GR_TILE, "group_records_device: bad record count");
+    const GroupPlan P = group_plan(N, group_bits);
+    RB_REQUIRE(temp_bytes >= P.total, "group_records_device: temp too small");
+    const GroupRng rng{seed, ordinal0, pos_bits};
+    if (P.tpb == 512u) group_records_impl<512>(P, keys0, vals0, keys_tmp, vals_tmp, rng, static_cast<char *>(temp), vals_out, tz_out, uniq, counts, starts, n_runs_dev, st);
+    else group_records_impl<256>(P, keys0, vals0, keys_tmp, vals_tmp, rng, static_cast<char *>(temp), vals_out, tz_out, uniq, counts, starts, n_runs_dev, st);
+}
+
+}  // namespace rb

@@ -304,7 +304,7 @@ struct rb_graph {
     hipStream_t stream = nullptr;    // consumer stream: everything that touches the filters
     hipStream_t stream2 = nullptr;   // producer stream: hashing + grouping of the NEXT sub-batch (scratch only)
     // grouped sub-batch, double buffered so that grouping of sub-batch i+1 overlaps the filter stages of i
-    struct GroupSlot { DevBuf keys1, vals1, tz, uniq, counts, starts; size_t N = 0; uint32_t D = 0; };
+    struct GroupSlot { DevBuf keys1, valsT, vals1, tz, uniq, counts, starts; size_t N = 0; uint32_t D = 0; };
     GroupSlot slots[2];
     int cur = 0;
     DevBuf &keys1() { return slots[cur].keys1; }
