@@ -225,6 +225,17 @@ int rb_filter_fpr(rb_graph *g, int which, float *out); /* BloomFilter.getFPR :18
 int rb_filter_export(rb_graph *g, int which, void *dst, size_t nbytes);
 int rb_filter_import(rb_graph *g, int which, const void *src, size_t nbytes);
 int64_t rb_expected_size(int64_t n, float fpr, int num_hash); /* BloomFilter.getExpectedSize :196-199 */
+/* BloomFilterDeBruijnGraph.destroyDbgbf / destroyCbf / destroyRpkbf / destroyFpkbf R/graph/BloomFilterDeBruijnGraph.java:249-275
+ * (BloomFilter.destroy :244-246): frees the filter's device memory; rb_filter_size then reports RB_ERR_STATE and calls
+ * that need the filter fail.  rb_graph_init_fragment_pairs may create an fpkbf again (restorePkbf :341-350). */
+int rb_graph_destroy_filter(rb_graph *g, int which);
+/* CountingBloomFilter.incrementAndGet(long[]) R/bloom/CountingBloomFilter.java:196-222 for h0[0..n) one after the other,
+ * in array order (every call sees the increments before it); out[i] = MiniFloat.toFloat(updated).  Order-exact and serial
+ * on the device: meant for the subsampler's short per-read sequences, not for bulk counting (rb_graph_apply). */
+int rb_filter_increment_and_get(rb_graph *g, const uint64_t *h0, size_t n, float *out);
+/* CountingBloomFilter.getBloomFilter(minCov) R/bloom/CountingBloomFilter.java:328-338: bit i of filter `which` of `dst`
+ * (same number of bits as src has counters, same device) := MiniFloat.toFloat(counter i of src) >= min_cov. */
+int rb_cbf_to_bloom(rb_graph *src, float min_cov, rb_graph *dst, int which);
 
 /* ---- hash-only test hook: {,Canonical,ReverseComplement}NTHashIterator over every usable
  *      segment of every read of a batch.  mode 0 fwd, 1 canonical, 2 reverse-complement.
@@ -239,9 +250,8 @@ int rb_nthash_batch(const rb_batch *b, int k, int mode, int64_t first, int64_t n
  * MinimizerHashIterator.next() R/bloom/hash/MinimizerHashIterator.java:27-128 over
  * LongRollingWindow R/util/LongRollingWindow.java:23-83: for every window of w consecutive k-mers
  * the SIGNED minimum of hVals[0] (mode 0 forward / 1 canonical / 2 reverse-complement iterator).
- * moffsets[n_reads+1]: read i yields max(0, len_i-k+1-w+1) windows.  out_pos = leftmost position
- * attaining the minimum (the reference's position differs only when the same hash value repeats
- * inside one window — its circular buffer rescans in array order). */
+ * moffsets[n_reads+1]: read i yields max(0, len_i-k+1-w+1) windows.  out_pos = LongRollingWindow.getMinPos()
+ * (the rolling window is replayed exactly, including which of several equal minima it reports). */
 int rb_minimizers(int device, const char *seq, const int64_t *offsets, int64_t n_reads, int k, int w, int mode,
                   int64_t *moffsets, uint64_t *out_hash, int64_t *out_pos);
 /* StrobeHashIterator.getInterval(p) R/bloom/hash/StrobeHashIterator.java:133-164 (as used by
@@ -250,6 +260,41 @@ int rb_minimizers(int device, const char *seq, const int64_t *offsets, int64_t n
  * soffsets[n_reads+1]: read i yields numKmers - wMax*(n-2) - wMin strobemers if numKmers > wMax*(n-1). */
 int rb_strobemers(int device, const char *seq, const int64_t *offsets, int64_t n_reads, int k, int n, int wmin, int wmax,
                   int64_t *soffsets, uint64_t *out_hash, int32_t *out_start, int32_t *out_end);
+
+/* The other strobemer iterators, batched the same way (one thread per strobemer).  `count_in` (may be NULL): a handle
+ * whose counting filter is asked CountingBloomFilter.getCount(long) (R/bloom/CountingBloomFilter.java:235-251) for
+ * every hash without leaving the device — the "hash -> cbf.getCount" half of SeqSubsampler.strobemerBased / kmerBased
+ * (R/util/SeqSubsampler.java:389-395, 176-179); out_count then receives the counts.
+ * rb_randstrobes: StrobeHashIterator.next() / get() R/bloom/hash/StrobeHashIterator.java:73-131 and
+ * CanonicalStrobeHashIterator.next() / get() R/bloom/hash/CanonicalStrobeHashIterator.java:79-140.  out_pos: n
+ * positions per strobemer (the k-mer itself, then the strobes = getStrobes() / HashedPositions.pos). */
+#define RB_STROBE_CANONICAL 1 /* CanonicalStrobeHashIterator: strobes chosen on forward hashes, SIGNED min with the reverse chain */
+#define RB_STROBE_SLIDE 2     /* StrobeHashIterator.get / getInterval: the chosen strobe slides across equal k-mer hashes */
+#define RB_MAX_STROBES 8
+int rb_randstrobes(int device, const char *seq, const int64_t *offsets, int64_t n_reads, int k, int n, int wmin, int wmax, int flags,
+                   rb_graph *count_in, int64_t *soffsets, uint64_t *out_hash, int32_t *out_pos, float *out_count);
+/* Strobe3HashIterator / CanonicalStrobe3HashIterator next() / get() (R/bloom/hash/Strobe3HashIterator.java:78-151,
+ * R/bloom/hash/CanonicalStrobe3HashIterator.java:85-225): strobemers of positions getMin()..getMax(); read i yields
+ * numKmers - 2*wMin (canonical: numKmers - 2*wMax, if positive) when numKmers > 2*wMin.  out_pos: {pos1, p, pos3}. */
+int rb_strobe3(int device, const char *seq, const int64_t *offsets, int64_t n_reads, int k, int wmin, int wmax, int canonical,
+               rb_graph *count_in, int64_t *soffsets, uint64_t *out_hash, int32_t *out_pos, float *out_count);
+/* SeqSubsampler.kmerBased's k-mer pair hashes R/util/SeqSubsampler.java:176-179 (stranded: combine(h[i], h[i+shift]))
+ * and :266-268 (min_signed(combine(f[i], f[i+shift]), combine(r[i+shift], r[i]))): read i yields numKmers - shift. */
+int rb_kmer_pair_hashes(int device, const char *seq, const int64_t *offsets, int64_t n_reads, int k, int shift, int canonical,
+                        rb_graph *count_in, int64_t *poffsets, uint64_t *out_hash, float *out_count);
+/* MinimizerHashIterator.nextMinimizer() R/bloom/hash/MinimizerHashIterator.java:97-112 while hasNext(): the first
+ * window's minimizer, then one entry whenever the position of the window minimum moves (the sequence
+ * SeqUtils.getMinimizerChainString consumes, R/util/SeqUtils.java:1731-1757).  out_hash / out_pos need room for one
+ * entry per window (rb_minimizers' count); moffsets[n_reads+1] receives the per-read offsets of what was written. */
+int rb_minimizers_next(int device, const char *seq, const int64_t *offsets, int64_t n_reads, int k, int w, int mode,
+                       int64_t *moffsets, uint64_t *out_hash, int64_t *out_pos);
+/* GraphUtils.getMinimizers(seq, numKmers, itr, windowSize) R/util/GraphUtils.java:2462-2549: the distinct window
+ * minimizers of each read, sorted as signed longs.  Reads with numKmers <= windowSize yield ONE value,
+ * min_signed(stale[i], every k-mer hash), where stale[i] is what itr.hVals[0] held before the call (:2480-2488:
+ * 0 on a fresh iterator — pass stale = NULL — else the last hash of the previous sequence).  out needs room for
+ * max(1, windows) entries per read. */
+int rb_minimizer_set(int device, const char *seq, const int64_t *offsets, int64_t n_reads, int k, int w, int mode,
+                     const uint64_t *stale, int64_t *moffsets, uint64_t *out);
 
 /* ---- sharded engine (one process per GPU; filters split by index range across `count` shards) ----
  * Multi-GPU counterpart of rb_graph_add_batch.  The reference is a single shared-memory process, so

@@ -165,6 +165,14 @@ int64_t rbo_minimizers(const char *seq, int64_t len, int k, int w, int mode, uin
  * number of strobemers (numKmers - wMax*(n-2) - wMin, or 0). */
 int64_t rbo_strobemers(const char *seq, int64_t len, int k, int n, int wmin, int wmax,
                        uint64_t *out_hash, int32_t *out_start, int32_t *out_end);
+/* rb_oracle_sketch.c: the other sketch iterators and SeqSubsampler's hashing halves (citations there) */
+int64_t rbo_randstrobes(const char *seq, int64_t len, int k, int n, int wmin, int wmax, int flags /* 1 canonical, 2 slide */,
+                        uint64_t *out_hash, int32_t *out_pos /* n per strobemer */);
+int64_t rbo_strobe3(const char *seq, int64_t len, int k, int wmin, int wmax, int canonical, uint64_t *out_hash, int32_t *out_pos /* 3 per */);
+int64_t rbo_minimizers_next(const char *seq, int64_t len, int k, int w, int mode, uint64_t *out_hash, int64_t *out_pos);
+int64_t rbo_minimizer_set(const char *seq, int64_t len, int k, int w, int mode, uint64_t stale, uint64_t *out);
+int64_t rbo_kmer_pair_hashes(const char *seq, int64_t len, int k, int shift, int canonical, uint64_t *out);
+
 
 #ifdef __cplusplus
 }

@@ -108,6 +108,11 @@ def lib():
     sig("rbo_graph_neighbors", None, vp, u64, u64, C.c_uint, i32, vp, vp, vp)
     sig("rbo_minimizers", i64, vp, i64, i32, i32, i32, vp, vp)
     sig("rbo_strobemers", i64, vp, i64, i32, i32, i32, i32, vp, vp, vp)
+    sig("rbo_randstrobes", i64, vp, i64, i32, i32, i32, i32, i32, vp, vp)
+    sig("rbo_strobe3", i64, vp, i64, i32, i32, i32, i32, vp, vp)
+    sig("rbo_minimizers_next", i64, vp, i64, i32, i32, i32, vp, vp)
+    sig("rbo_minimizer_set", i64, vp, i64, i32, i32, i32, u64, vp)
+    sig("rbo_kmer_pair_hashes", i64, vp, i64, i32, i32, i32, vp)
     _lib = L
     return L
 
@@ -195,6 +200,51 @@ def strobemers(seq, k, n, wmin, wmax):
     sb = C.create_string_buffer(seq, len(seq))
     got = lib().rbo_strobemers(C.cast(sb, C.c_void_p), len(seq), k, n, wmin, wmax, _p(oh), _p(os_), _p(oe))
     return oh[:got], os_[:got], oe[:got]
+
+
+def randstrobes(seq, k, n, wmin, wmax, canonical=False, slide=False):
+    """StrobeHashIterator.next/get (slide=True: get) or CanonicalStrobeHashIterator.next/get: (hash, positions[n])"""
+    seq = _b(seq)
+    cap = max(0, len(seq) - k + 1)
+    oh = np.zeros(cap, np.uint64); op = np.zeros((cap, n), np.int32)
+    sb = C.create_string_buffer(seq, len(seq))
+    got = lib().rbo_randstrobes(C.cast(sb, C.c_void_p), len(seq), k, n, wmin, wmax, (1 if canonical else 0) | (2 if slide else 0), _p(oh), _p(op))
+    return oh[:got], op[:got]
+
+
+def strobe3(seq, k, wmin, wmax, canonical=False):
+    """Strobe3HashIterator / CanonicalStrobe3HashIterator: (hash, positions[3]) for p = getMin()..getMax()"""
+    seq = _b(seq)
+    cap = max(0, len(seq) - k + 1)
+    oh = np.zeros(cap, np.uint64); op = np.zeros((cap, 3), np.int32)
+    sb = C.create_string_buffer(seq, len(seq))
+    got = lib().rbo_strobe3(C.cast(sb, C.c_void_p), len(seq), k, wmin, wmax, 1 if canonical else 0, _p(oh), _p(op))
+    return oh[:got], op[:got]
+
+
+def minimizers_next(seq, k, w, mode):
+    seq = _b(seq)
+    n = max(0, len(seq) - k + 1 - w + 1)
+    oh = np.zeros(n, np.uint64); op = np.zeros(n, np.int64)
+    sb = C.create_string_buffer(seq, len(seq))
+    got = lib().rbo_minimizers_next(C.cast(sb, C.c_void_p), len(seq), k, w, mode, _p(oh), _p(op))
+    return oh[:got], op[:got]
+
+
+def minimizer_set(seq, k, w, mode, stale=0):
+    seq = _b(seq)
+    out = np.zeros(max(1, len(seq)), np.uint64)
+    sb = C.create_string_buffer(seq, max(1, len(seq)))
+    got = lib().rbo_minimizer_set(C.cast(sb, C.c_void_p), len(seq), k, w, mode, int(stale), _p(out))
+    return out[:got]
+
+
+def kmer_pair_hashes(seq, k, shift, canonical):
+    seq = _b(seq)
+    out = np.zeros(max(0, len(seq) - k + 1), np.uint64)
+    sb = C.create_string_buffer(seq, len(seq))
+    got = lib().rbo_kmer_pair_hashes(C.cast(sb, C.c_void_p), len(seq), k, shift, 1 if canonical else 0, _p(out))
+    return out[:got]
 
 
 def pack_reads(reads, quals=None):

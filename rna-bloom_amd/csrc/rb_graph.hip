@@ -1173,6 +1173,37 @@ __global__ void k_count_nonzero_bytes(const uint32_t *__restrict__ w, size_t n_w
     for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
 }
+// CountingBloomFilter.getBloomFilter(minCov) R/bloom/CountingBloomFilter.java:328-338: bit i of the new filter is set iff
+// MiniFloat.toFloat(counts[i]) >= minCov.  One thread per 32 counters = one output word.
+__global__ void k_cbf_to_bits(const uint8_t *__restrict__ cbf, int64_t n, float min_cov, uint32_t *__restrict__ bits) {
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w * 32 >= n) return;
+    uint32_t out = 0;
+    for (int b = 0; b < 32; ++b) {
+        const int64_t i = w * 32 + b;
+        if (i < n && minifloat_to_float((uint32_t)cbf[i] & 0x7Fu) >= min_cov) out |= 1u << b;
+    }
+    bits[w] = out;
+}
+// CountingBloomFilter.incrementAndGet(long[]) R/bloom/CountingBloomFilter.java:196-222, one call after the other in array
+// order (the subsampler's loops are sequential by nature: every result decides what happens next).  One lane walks the
+// array; op i draws from op ordinal ordinal0 + i, position 0 (as a per-hash API call does).
+__global__ void k_increment_and_get(FilterView fv, const uint64_t *__restrict__ h0, size_t n, float *__restrict__ out) {
+    if (blockIdx.x || threadIdx.x) return;
+    for (size_t i = 0; i < n; ++i) {
+        uint64_t idx[RB_MAX_HASH];
+        uint32_t mn = 0;
+        for (int j = 0; j < fv.cbf_h; ++j) {
+            idx[j] = index_of(multi_hash(h0[i], (uint32_t)j, fv.kmul), fv.cbf_mod);
+            const uint32_t c = fv.cbf[idx[j]];
+            mn = (j == 0 || c < mn) ? c : mn;
+        }
+        const uint32_t up = minifloat_inc(mn, rng31(fv.seed, fv.ordinal0 + (uint64_t)i, 0u));
+        if (up != mn)
+            for (int j = 0; j < fv.cbf_h; ++j) if (fv.cbf[idx[j]] == mn) fv.cbf[idx[j]] = (uint8_t)up;
+        out[i] = minifloat_to_float(up);
+    }
+}
 __global__ void k_iota(uint32_t *v, size_t n) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) v[i] = (uint32_t)i;
@@ -2061,7 +2092,8 @@ static int count_common(rb_graph *g, const uint64_t *h0, size_t n, float *out, b
         RB_HIP(hipSetDevice(g->p.device));
         uint64_t *d = upload_h0(g, g->qbuf0, h0, n);
         g->qbuf1.reserve(n * 4);
-        FilterView fv = g->view(0, 0);
+        RB_REQUIRE(g->cbf, "rb_filter_get_count: the counting filter has been destroyed");
+        FilterView fv = g->view(0, 0, graph_level);
         if (graph_level) hipLaunchKernelGGL(k_graph_count, dim3(blocks_for((int64_t)n)), dim3(TPB), 0, g->stream, fv, d, n, g->qbuf1.as<float>());
         else hipLaunchKernelGGL(k_cbf_count, dim3(blocks_for((int64_t)n)), dim3(TPB), 0, g->stream, fv, d, n, g->qbuf1.as<float>());
         RB_HIP(hipGetLastError());
@@ -2069,6 +2101,16 @@ static int count_common(rb_graph *g, const uint64_t *h0, size_t n, float *out, b
         RB_HIP(hipStreamSynchronize(g->stream));
     });
 }
+}  // extern "C"
+// CountingBloomFilter.getCount(long) for hashes that already sit in device memory (rb_sketch.hip: strobemer / k-mer-pair
+// hash -> count without a trip through the host); enqueued on the graph's stream, not synchronised
+void rb::cbf_counts_device(rb_graph *g, const uint64_t *d_h0, size_t n, float *d_out) {
+    RB_REQUIRE(g && !g->shard && g->cbf, "count lookup: handle without a local counting filter");
+    if (!n) return;
+    hipLaunchKernelGGL(k_cbf_count, dim3(blocks_for((int64_t)n)), dim3(TPB), 0, g->stream, g->view(0, 0, false), d_h0, n, d_out);
+    RB_HIP(hipGetLastError());
+}
+extern "C" {
 int rb_graph_count(rb_graph *g, const uint64_t *h0, size_t n, float *out) { return count_common(g, h0, n, out, true); }
 int rb_filter_get_count(rb_graph *g, const uint64_t *h0, size_t n, float *out) { return count_common(g, h0, n, out, false); }
 
@@ -2200,6 +2242,7 @@ int rb_graph_greedy_extend(rb_graph *g, const rb_graph *gate, const char *seeds,
 int rb_filter_size(rb_graph *g, int which, int64_t *size, int64_t *nbytes, int *num_hash) {
     if (!g) { set_error("null graph"); return RB_ERR_INVALID; }
     if (which == RB_CBF) {
+        if (!g->cbf) { set_error("rb_filter_size: filter %d not initialised", which); return RB_ERR_STATE; }
         if (size) *size = g->cbf_size;
         if (nbytes) *nbytes = g->cbf_hi - g->cbf_lo;
         if (num_hash) *num_hash = g->cbf_h;
@@ -2315,6 +2358,60 @@ int rb_graph_profile_get(rb_graph *g, rb_profile *out, int reset) {
     }
     if (reset) g->prof.clear();
     return RB_OK;
+}
+
+/* BloomFilterDeBruijnGraph.destroyDbgbf / destroyCbf / destroyRpkbf / destroyFpkbf :249-275: the memory goes back to the device */
+int rb_graph_destroy_filter(rb_graph *g, int which) {
+    return guarded([&] {
+        RB_REQUIRE(g && !g->shard, "rb_graph_destroy_filter: null or shard handle");
+        RB_HIP(hipSetDevice(g->p.device));
+        RB_HIP(hipStreamSynchronize(g->stream)); RB_HIP(hipStreamSynchronize(g->stream2));
+        if (which == RB_CBF) {
+            if (g->cbf) RB_HIP(hipFree(g->cbf));
+            g->cbf = nullptr; g->cbf_size = 0; g->cbf_lo = g->cbf_hi = 0; g->cbf_alloc = 0;
+        } else {
+            BitFilter *f = bit_filter(g, which);
+            RB_REQUIRE(f, "rb_graph_destroy_filter: unknown filter %d", which);
+            free_bits(*f);
+        }
+    });
+}
+
+int rb_filter_increment_and_get(rb_graph *g, const uint64_t *h0, size_t n, float *out) {
+    return guarded([&] {
+        RB_REQUIRE(g && !g->shard && g->cbf && (n == 0 || (h0 && out)), "rb_filter_increment_and_get: bad argument or no counting filter");
+        if (!n) return;
+        RB_HIP(hipSetDevice(g->p.device));
+        uint64_t *d = upload_h0(g, g->qbuf0, h0, n);
+        g->qbuf1.reserve(n * 4);
+        hipLaunchKernelGGL(k_increment_and_get, dim3(1), dim3(64), 0, g->stream, g->view(g->ordinal, 0, false), d, n, g->qbuf1.as<float>());
+        RB_HIP(hipGetLastError());
+        g->ordinal += n;
+        RB_HIP(hipMemcpyAsync(out, g->qbuf1.p, n * 4, hipMemcpyDeviceToHost, g->stream));
+        RB_HIP(hipStreamSynchronize(g->stream));
+        // the counters moved: what the prefilter caches assert stays true (counters only grow)
+    });
+}
+
+int rb_cbf_to_bloom(rb_graph *src, float min_cov, rb_graph *dst, int which) {
+    return guarded([&] {
+        RB_REQUIRE(src && dst && !src->shard && !dst->shard && src->cbf, "rb_cbf_to_bloom: bad handles");
+        BitFilter *f = bit_filter(dst, which);
+        RB_REQUIRE(f && f->bits, "rb_cbf_to_bloom: destination filter %d not initialised", which);
+        RB_REQUIRE(f->size == src->cbf_size && src->p.device == dst->p.device, "rb_cbf_to_bloom: size (%lld vs %lld) or device mismatch",
+                   (long long)f->size, (long long)src->cbf_size);
+        RB_HIP(hipSetDevice(src->p.device));
+        RB_HIP(hipStreamSynchronize(dst->stream));
+        const int64_t words = (src->cbf_size + 31) / 32;
+        hipLaunchKernelGGL(k_cbf_to_bits, dim3(blocks_for(words)), dim3(TPB), 0, src->stream, src->cbf, src->cbf_size, min_cov, f->bits);
+        RB_HIP(hipGetLastError());
+        RB_HIP(hipStreamSynchronize(src->stream));
+        if (which == RB_DBGBF) {
+            if (dst->npf_log2) RB_HIP(hipMemset(dst->npf.p, 0, sizeof(uint64_t) << dst->npf_log2));
+            if (dst->mpf_log2b) RB_HIP(hipMemset(dst->mpf.p, 0, (size_t)128 << dst->mpf_log2b));
+            RB_HIP(hipDeviceSynchronize());
+        }
+    });
 }
 
 }  // extern "C"

@@ -341,7 +341,9 @@ struct rb_graph {
         hipEvent_t e; RB_HIP(hipEventCreate(&e)); return e;
     }
 
-    FilterView view(uint64_t ordinal0, uint32_t pos_bits) const {
+    // need_all: the call works on dbgbf AND cbf (a filter freed by rb_graph_destroy_filter makes it fail loudly)
+    FilterView view(uint64_t ordinal0, uint32_t pos_bits, bool need_all = true) const {
+        if (need_all) RB_REQUIRE(dbg.bits && cbf, "this call needs dbgbf and cbf, and one of them has been destroyed");
         FilterView fv;
         fv.dbg = dbg.bits; fv.dbg_mod = dbg.mod; fv.dbg_h = dbg.num_hash;
         fv.cbf = cbf; fv.cbf_mod = cbf_mod; fv.cbf_h = cbf_h;
@@ -391,6 +393,7 @@ void group_enqueue(rb_graph *g, int slot, size_t N, uint64_t ordinal0, uint32_t 
 uint32_t group_finish(rb_graph *g, int slot, hipStream_t st, DevBuf &temp, DevBuf &ctrbuf, hipStream_t scan_stream);
 // paired k-mer walker: inserts into g->rpk (out_idx == nullptr) or collects global bit indices
 void shard_free(rb_graph *g);   // rb_shard.hip
+void cbf_counts_device(rb_graph *g, const uint64_t *d_h0, size_t n, float *d_out);   // rb_graph.hip
 void launch_pairs(rb_graph *g, const rb_batch *b, int64_t w0, int64_t nw, int mode_hash, const uint32_t *chunk_off,
                   uint64_t *out_idx, unsigned long long *n_pairs_dev, hipStream_t st = nullptr);
 }  // namespace rb

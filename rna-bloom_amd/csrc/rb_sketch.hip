@@ -40,19 +40,43 @@ __global__ void k_hash_all(const uint64_t *__restrict__ codes, const uint32_t *_
     }
 }
 
-// one thread per minimizer window: signed minimum over w consecutive k-mer hashes, leftmost on ties
+// MinimizerHashIterator.next() for every window of a read, one thread per read: LongRollingWindow
+// (R/util/LongRollingWindow.java:23-83) is replayed exactly — the value of a window is its signed minimum, but WHICH of
+// several equal minima the window reports depends on the history (a new value replaces the minimum only if strictly
+// smaller, :55-57; when the minimum leaves, the circular buffer is rescanned in ARRAY order, :52-54, 60-69) and
+// nextMinimizer() keys on that position.  The buffer is not materialised: after the roll that brings in k-mer
+// p + w - 1, slot s holds the k-mer q of the window with q mod w == s.
 __global__ void k_minimizers(const uint64_t *__restrict__ h, const int64_t *__restrict__ koff, const int64_t *__restrict__ moff,
                              int64_t n_reads, int64_t total, int w, uint64_t *__restrict__ out_hash, int64_t *__restrict__ out_pos) {
-    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= total) return;
-    int64_t lo = 0, hi = n_reads;      // read r with moff[r] <= t < moff[r+1]
-    while (hi - lo > 1) { int64_t mid = (lo + hi) >> 1; if (moff[mid] <= t) lo = mid; else hi = mid; }
-    const int64_t p = t - moff[lo];
-    const uint64_t *hh = h + koff[lo] + p;
-    int64_t best = (int64_t)hh[0], bi = 0;
-    for (int i = 1; i < w; ++i) { int64_t v = (int64_t)hh[i]; if (v < best) { best = v; bi = i; } }
-    out_hash[t] = (uint64_t)best;
-    out_pos[t] = p + bi;
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    const int64_t nwin = moff[r + 1] - moff[r];
+    if (nwin <= 0) return;
+    const uint64_t *hh = h + koff[r];
+    uint64_t *oh = out_hash + moff[r];
+    int64_t *op = out_pos ? out_pos + moff[r] : nullptr;
+    // first window: k-mers 0 .. w-2 in slots 0 .. w-2 and a 0 placeholder in slot w-1 (MinimizerHashIterator.java:54-62)
+    int min_index = 0;
+    int64_t mv = w > 1 ? (int64_t)hh[0] : 0;
+    for (int i = 1; i < w; ++i) { const int64_t v = i < w - 1 ? (int64_t)hh[i] : 0; if (v < mv) { mv = v; min_index = i; } }
+    int index = w - 2;
+    if (w == 1) { min_index = 0; index = -1; }
+    for (int64_t p = 0; p < nwin; ++p) {
+        const int64_t v = (int64_t)hh[p + w - 1];
+        if (++index >= w) index = 0;
+        if (min_index == index) {                      // the minimum is overwritten: rescan in array order
+            int best = 0; int64_t bv = 0;
+            for (int sl = 0; sl < w; ++sl) {
+                int64_t d = ((int64_t)sl - p) % w; if (d < 0) d += w;
+                const int64_t x = (int64_t)hh[p + d];
+                if (sl == 0 || x < bv) { bv = x; best = sl; }
+            }
+            min_index = best; mv = bv;
+        } else if (v < mv) { min_index = index; mv = v; }
+        oh[p] = (uint64_t)mv;
+        if (op) { int64_t d = ((int64_t)min_index - p) % w; if (d < 0) d += w; op[p] = p + d; }
+    }
+    (void)total;
 }
 
 // one thread per strobemer: StrobeHashIterator.getInterval (R/bloom/hash/StrobeHashIterator.java:133-164)
@@ -87,6 +111,175 @@ __global__ void k_strobemers(const uint64_t *__restrict__ h, const int64_t *__re
     out_hash[t] = sh;
     out_start[t] = (int32_t)p;
     out_end[t] = (int32_t)(last + k - 1);
+}
+
+
+// StrobeHashIterator.next / get and CanonicalStrobeHashIterator.next / get (R/bloom/hash/StrobeHashIterator.java:73-131,
+// R/bloom/hash/CanonicalStrobeHashIterator.java:79-140): order-n randstrobes, argmin_unsigned with ties to the right;
+// RB_STROBE_SLIDE = the forward iterator's get(): the chosen strobe slides across later equal k-mer hashes; canonical:
+// strobes are chosen on the forward hashes, the reverse hashes of the same positions are combined back to front and the
+// SIGNED minimum of the two is returned (:107).  One thread per strobemer; out_pos: n positions each.
+__global__ void k_randstrobes(const uint64_t *__restrict__ hf, const uint64_t *__restrict__ hr, const int64_t *__restrict__ koff,
+                              const int64_t *__restrict__ soff, int64_t n_reads, int64_t total, int n, int wmin, int wmax, int flags,
+                              uint64_t *__restrict__ out_hash, int32_t *__restrict__ out_pos) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    int64_t lo = 0, hi = n_reads;
+    while (hi - lo > 1) { int64_t mid = (lo + hi) >> 1; if (soff[mid] <= t) lo = mid; else hi = mid; }
+    const int64_t p = t - soff[lo];
+    const uint64_t *f = hf + koff[lo];
+    const int64_t nk = koff[lo + 1] - koff[lo];
+    const bool canonical = flags & RB_STROBE_CANONICAL, slide = (flags & RB_STROBE_SLIDE) && !canonical;
+    uint64_t sh = f[p];
+    int32_t positions[RB_MAX_STROBES];
+    positions[0] = (int32_t)p;
+    for (int s = 0; s < n - 1; ++s) {
+        int64_t pos2 = p + (int64_t)s * wmax + wmin;
+        uint64_t pos2k = f[pos2];
+        uint64_t hv = combine(sh, pos2k);
+        int64_t end = p + (int64_t)s * wmax + wmax;
+        if (end > nk) end = nk;
+        for (int64_t i = pos2 + 1; i < end; ++i) {
+            const uint64_t alt = f[i];
+            if (slide && alt == pos2k) pos2 = i;
+            else {
+                const uint64_t h2 = combine(sh, alt);
+                if (hv >= h2) { pos2 = i; pos2k = alt; hv = h2; }     // Long.compareUnsigned(h, h2) >= 0
+            }
+        }
+        sh = hv;
+        positions[s + 1] = (int32_t)pos2;
+    }
+    if (canonical) {
+        const uint64_t *r = hr + koff[lo];
+        uint64_t rs = r[positions[n - 1]];
+        for (int s = n - 2; s >= 0; --s) rs = combine(r[positions[s]], rs);
+        sh = smin(sh, rs);
+    }
+    out_hash[t] = sh;
+    if (out_pos) for (int s = 0; s < n; ++s) out_pos[t * n + s] = positions[s];
+}
+
+// Strobe3HashIterator / CanonicalStrobe3HashIterator (R/bloom/hash/Strobe3HashIterator.java:78-151,
+// R/bloom/hash/CanonicalStrobe3HashIterator.java:85-225): middle k-mer p, upstream strobe in [p-wMax+1, p-wMin],
+// downstream strobe in [p+wMin, p+wMax); comparisons unsigned, strict except where the reference has >= .
+__global__ void k_strobe3(const uint64_t *__restrict__ hf, const uint64_t *__restrict__ hr, const int64_t *__restrict__ koff,
+                          const int64_t *__restrict__ soff, int64_t n_reads, int64_t total, int wmin, int wmax, int canonical,
+                          uint64_t *__restrict__ out_hash, int32_t *__restrict__ out_pos) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    int64_t lo = 0, hi = n_reads;
+    while (hi - lo > 1) { int64_t mid = (lo + hi) >> 1; if (soff[mid] <= t) lo = mid; else hi = mid; }
+    const int64_t pos = t - soff[lo] + (canonical ? wmax : wmin);
+    const uint64_t *f = hf + koff[lo];
+    const int64_t nk = koff[lo + 1] - koff[lo];
+    const uint64_t fk = f[pos];
+    int64_t p1 = pos - wmax + 1 > 0 ? pos - wmax + 1 : 0;
+    uint64_t h1 = combine(f[p1], fk);
+    int64_t end = pos - wmin + 1;
+    for (int64_t i = p1 + 1; i < end; ++i) { const uint64_t h = combine(f[i], fk); if (h1 > h) { p1 = i; h1 = h; } }
+    int64_t p3 = pos + wmin;
+    uint64_t h3 = combine(h1, f[p3]);
+    end = pos + wmax < nk ? pos + wmax : nk;
+    for (int64_t i = p3 + 1; i < end; ++i) {
+        const uint64_t h = combine(h1, f[i]);
+        if (canonical ? h3 >= h : h3 > h) { p3 = i; h3 = h; }
+    }
+    uint64_t hv = h3;
+    if (canonical) {
+        const uint64_t *r = hr + koff[lo];
+        const uint64_t rk = r[pos];
+        int64_t q3 = pos + wmin;
+        uint64_t rh3 = combine(r[q3], rk);
+        int64_t rend = pos + wmax < nk ? pos + wmax : nk;
+        for (int64_t i = q3 + 1; i < rend; ++i) { const uint64_t h = combine(r[i], rk); if (rh3 >= h) { q3 = i; rh3 = h; } }
+        int64_t q1 = pos - wmax + 1 > 0 ? pos - wmax + 1 : 0;
+        uint64_t rh1 = combine(rh3, r[q1]);
+        rend = pos - wmin + 1;
+        for (int64_t i = q1 + 1; i < rend; ++i) { const uint64_t h = combine(rh3, r[i]); if (rh1 > h) { q1 = i; rh1 = h; } }
+        if (h3 > rh1) { hv = rh1; p1 = q1; p3 = q3; }
+    }
+    out_hash[t] = hv;
+    if (out_pos) { out_pos[3 * t] = (int32_t)p1; out_pos[3 * t + 1] = (int32_t)pos; out_pos[3 * t + 2] = (int32_t)p3; }
+}
+
+// SeqSubsampler.kmerBased pair hashes (R/util/SeqSubsampler.java:176-179, 266-268)
+__global__ void k_kmer_pairs(const uint64_t *__restrict__ hf, const uint64_t *__restrict__ hr, const int64_t *__restrict__ koff,
+                             const int64_t *__restrict__ poff, int64_t n_reads, int64_t total, int shift, int canonical,
+                             uint64_t *__restrict__ out_hash) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    int64_t lo = 0, hi = n_reads;
+    while (hi - lo > 1) { int64_t mid = (lo + hi) >> 1; if (poff[mid] <= t) lo = mid; else hi = mid; }
+    const int64_t i = t - poff[lo];
+    const uint64_t *f = hf + koff[lo];
+    uint64_t pf = combine(f[i], f[i + shift]);
+    if (canonical) { const uint64_t *r = hr + koff[lo]; pf = smin(pf, combine(r[i + shift], r[i])); }
+    out_hash[t] = pf;
+}
+
+// window minimizers -> flags: window p of a read opens a new minimizer iff it is the first window or the position of
+// its minimum differs from the previous window's (MinimizerHashIterator.nextMinimizer, :97-112; the position of the
+// leftmost minimum never moves left)
+__global__ void k_minimizer_flags(const int64_t *__restrict__ mpos, const int64_t *__restrict__ moff, int64_t n_reads, int64_t total,
+                                  uint32_t *__restrict__ flag) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    int64_t lo = 0, hi = n_reads;
+    while (hi - lo > 1) { int64_t mid = (lo + hi) >> 1; if (moff[mid] <= t) lo = mid; else hi = mid; }
+    flag[t] = (t == moff[lo] || mpos[t] != mpos[t - 1]) ? 1u : 0u;
+}
+__global__ void k_minimizer_compact(const uint64_t *__restrict__ mh, const int64_t *__restrict__ mpos, const uint32_t *__restrict__ flag,
+                                    const uint32_t *__restrict__ slot, int64_t total, uint64_t *__restrict__ out_hash, int64_t *__restrict__ out_pos) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total || !flag[t]) return;
+    out_hash[slot[t]] = mh[t];
+    if (out_pos) out_pos[slot[t]] = mpos[t];
+}
+// number of minimizers before each read's first window (for the per-read offsets)
+__global__ void k_gather_u32(const uint32_t *__restrict__ slot, const int64_t *__restrict__ moff, int64_t n_reads, int64_t total,
+                             uint32_t n_total, int64_t *__restrict__ out) {
+    int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r > n_reads) return;
+    out[r] = moff[r] < total ? (int64_t)slot[moff[r]] : (int64_t)n_total;
+}
+// getMinimizersSet for reads with numKmers <= windowSize: min_signed(stale, every k-mer hash) (R/util/GraphUtils.java:2480-2494)
+__global__ void k_short_read_min(const uint64_t *__restrict__ h, const int64_t *__restrict__ koff, const int64_t *__restrict__ kread,
+                                 int64_t n_short, const uint64_t *__restrict__ stale, uint64_t *__restrict__ out) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_short) return;
+    const int64_t r = kread[i];
+    uint64_t m = stale ? stale[r] : 0ull;
+    for (int64_t q = koff[r]; q < koff[r + 1]; ++q) m = smin(m, h[q]);
+    out[i] = m;
+}
+__global__ void k_scatter_u64(uint64_t *__restrict__ dst, const int64_t *__restrict__ where, const uint64_t *__restrict__ src, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[where[i]] = src[i];
+}
+__global__ void k_flip_sign(uint64_t *v, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] ^= 0x8000000000000000ull;
+}
+__global__ void k_set_keys(const uint64_t *__restrict__ val, const int64_t *__restrict__ off, int64_t n_reads, int64_t total,
+                           uint64_t *__restrict__ key_read) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    int64_t lo = 0, hi = n_reads;
+    while (hi - lo > 1) { int64_t mid = (lo + hi) >> 1; if (off[mid] <= t) lo = mid; else hi = mid; }
+    key_read[t] = (uint64_t)lo;
+}
+__global__ void k_unique_flags(const uint64_t *__restrict__ read, const uint64_t *__restrict__ val, int64_t total, uint32_t *__restrict__ flag) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total) return;
+    flag[t] = (t == 0 || read[t] != read[t - 1] || val[t] != val[t - 1]) ? 1u : 0u;
+}
+__global__ void k_unique_compact(const uint64_t *__restrict__ read, const uint64_t *__restrict__ val, const uint32_t *__restrict__ flag,
+                                 const uint32_t *__restrict__ slot, int64_t total, uint64_t *__restrict__ out, unsigned long long *__restrict__ per_read) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= total || !flag[t]) return;
+    out[slot[t]] = val[t] ^ 0x8000000000000000ull;
+    atomicAdd(&per_read[read[t]], 1ull);
 }
 
 struct BatchGuard { rb_batch *b; ~BatchGuard() { if (b) rb_batch_destroy(b); } };
@@ -136,7 +329,7 @@ int rb_minimizers(int device, const char *seq, const int64_t *offsets, int64_t n
         hash_all(device, seq, offsets, n_reads, k, mode, koff, d_koff, d_h);
         d_moff.reserve(((size_t)n_reads + 1) * 8); d_oh.reserve((size_t)total * 8); d_op.reserve((size_t)total * 8);
         RB_HIP(hipMemcpy(d_moff.p, moffsets, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(k_minimizers, dim3(blocks_for(total)), dim3(TPB), 0, 0, d_h.as<uint64_t>(), d_koff.as<int64_t>(), d_moff.as<int64_t>(),
+        hipLaunchKernelGGL(k_minimizers, dim3(blocks_for(n_reads, 64)), dim3(64), 0, 0, d_h.as<uint64_t>(), d_koff.as<int64_t>(), d_moff.as<int64_t>(),
                            n_reads, total, w, d_oh.as<uint64_t>(), d_op.as<int64_t>());
         RB_HIP(hipGetLastError());
         RB_HIP(hipMemcpy(out_hash, d_oh.p, (size_t)total * 8, hipMemcpyDeviceToHost));
@@ -169,6 +362,239 @@ int rb_strobemers(int device, const char *seq, const int64_t *offsets, int64_t n
         RB_HIP(hipMemcpy(out_hash, d_oh.p, (size_t)total * 8, hipMemcpyDeviceToHost));
         if (out_start) RB_HIP(hipMemcpy(out_start, d_os.p, (size_t)total * 4, hipMemcpyDeviceToHost));
         if (out_end) RB_HIP(hipMemcpy(out_end, d_oe.p, (size_t)total * 4, hipMemcpyDeviceToHost));
+    });
+}
+
+}  // extern "C"
+
+namespace {
+struct Bufs { std::vector<DevBuf *> v; ~Bufs() { for (auto b : v) b->release(); } };
+// forward (and reverse) all-window hashes
+void hash_fr(int device, const char *seq, const int64_t *offsets, int64_t n_reads, int k, bool need_r, std::vector<int64_t> &koff,
+             DevBuf &d_koff, DevBuf &d_f, DevBuf &d_r) {
+    hash_all(device, seq, offsets, n_reads, k, 0, koff, d_koff, d_f);
+    if (need_r) { std::vector<int64_t> k2; DevBuf dk2; hash_all(device, seq, offsets, n_reads, k, 2, k2, dk2, d_r); dk2.release(); }
+}
+void counts_out(rb_graph *count_in, int device, DevBuf &d_oh, int64_t total, float *out_count, DevBuf &d_cnt) {
+    if (!count_in || !out_count || !total) return;
+    RB_REQUIRE(count_in->p.device == device, "count_in lives on device %d, the reads are hashed on %d", count_in->p.device, device);
+    d_cnt.reserve((size_t)total * 4);
+    RB_HIP(hipDeviceSynchronize());
+    cbf_counts_device(count_in, d_oh.as<uint64_t>(), (size_t)total, d_cnt.as<float>());
+    RB_HIP(hipStreamSynchronize(count_in->stream));
+    RB_HIP(hipMemcpy(out_count, d_cnt.p, (size_t)total * 4, hipMemcpyDeviceToHost));
+}
+}  // namespace
+
+extern "C" {
+
+int rb_randstrobes(int device, const char *seq, const int64_t *offsets, int64_t n_reads, int k, int n, int wmin, int wmax, int flags,
+                   rb_graph *count_in, int64_t *soffsets, uint64_t *out_hash, int32_t *out_pos, float *out_count) {
+    DevBuf d_koff, d_f, d_r, d_soff, d_oh, d_op, d_cnt;
+    Bufs rel{{&d_koff, &d_f, &d_r, &d_soff, &d_oh, &d_op, &d_cnt}};
+    return guarded([&] {
+        RB_REQUIRE(offsets && soffsets && n_reads >= 0 && k >= 1 && k <= RB_MAX_K && n >= 2 && n <= RB_MAX_STROBES && wmin >= 1 && wmax >= wmin,
+                   "rb_randstrobes: bad argument");
+        RB_HIP(hipSetDevice(device));
+        std::vector<int64_t> koff;
+        soffsets[0] = 0;
+        for (int64_t i = 0; i < n_reads; ++i) {
+            int64_t l = offsets[i + 1] - offsets[i], nk = l >= k ? l - k + 1 : 0;
+            soffsets[i + 1] = soffsets[i] + ((nk > (int64_t)wmax * (n - 1)) ? nk - (int64_t)wmax * (n - 2) - wmin : 0);
+        }
+        const int64_t total = soffsets[n_reads];
+        if (!out_hash || !total) return;
+        hash_fr(device, seq, offsets, n_reads, k, (flags & RB_STROBE_CANONICAL) != 0, koff, d_koff, d_f, d_r);
+        d_soff.reserve(((size_t)n_reads + 1) * 8); d_oh.reserve((size_t)total * 8);
+        if (out_pos) d_op.reserve((size_t)total * 4 * (size_t)n);
+        RB_HIP(hipMemcpy(d_soff.p, soffsets, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_randstrobes, dim3(blocks_for(total)), dim3(TPB), 0, 0, d_f.as<uint64_t>(), d_r.as<uint64_t>(), d_koff.as<int64_t>(),
+                           d_soff.as<int64_t>(), n_reads, total, n, wmin, wmax, flags, d_oh.as<uint64_t>(), out_pos ? d_op.as<int32_t>() : nullptr);
+        RB_HIP(hipGetLastError());
+        RB_HIP(hipMemcpy(out_hash, d_oh.p, (size_t)total * 8, hipMemcpyDeviceToHost));
+        if (out_pos) RB_HIP(hipMemcpy(out_pos, d_op.p, (size_t)total * 4 * (size_t)n, hipMemcpyDeviceToHost));
+        counts_out(count_in, device, d_oh, total, out_count, d_cnt);
+    });
+}
+
+int rb_strobe3(int device, const char *seq, const int64_t *offsets, int64_t n_reads, int k, int wmin, int wmax, int canonical,
+               rb_graph *count_in, int64_t *soffsets, uint64_t *out_hash, int32_t *out_pos, float *out_count) {
+    DevBuf d_koff, d_f, d_r, d_soff, d_oh, d_op, d_cnt;
+    Bufs rel{{&d_koff, &d_f, &d_r, &d_soff, &d_oh, &d_op, &d_cnt}};
+    return guarded([&] {
+        RB_REQUIRE(offsets && soffsets && n_reads >= 0 && k >= 1 && k <= RB_MAX_K && wmin >= 1 && wmax >= wmin, "rb_strobe3: bad argument");
+        RB_HIP(hipSetDevice(device));
+        std::vector<int64_t> koff;
+        soffsets[0] = 0;
+        for (int64_t i = 0; i < n_reads; ++i) {
+            int64_t l = offsets[i + 1] - offsets[i], nk = l >= k ? l - k + 1 : 0, cnt = 0;
+            if (nk > (int64_t)wmin * 2) cnt = canonical ? nk - 2 * (int64_t)wmax : nk - 2 * (int64_t)wmin;   // getMax() + 1 - getMin()
+            soffsets[i + 1] = soffsets[i] + (cnt > 0 ? cnt : 0);
+        }
+        const int64_t total = soffsets[n_reads];
+        if (!out_hash || !total) return;
+        hash_fr(device, seq, offsets, n_reads, k, canonical != 0, koff, d_koff, d_f, d_r);
+        d_soff.reserve(((size_t)n_reads + 1) * 8); d_oh.reserve((size_t)total * 8);
+        if (out_pos) d_op.reserve((size_t)total * 12);
+        RB_HIP(hipMemcpy(d_soff.p, soffsets, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_strobe3, dim3(blocks_for(total)), dim3(TPB), 0, 0, d_f.as<uint64_t>(), d_r.as<uint64_t>(), d_koff.as<int64_t>(),
+                           d_soff.as<int64_t>(), n_reads, total, wmin, wmax, canonical, d_oh.as<uint64_t>(), out_pos ? d_op.as<int32_t>() : nullptr);
+        RB_HIP(hipGetLastError());
+        RB_HIP(hipMemcpy(out_hash, d_oh.p, (size_t)total * 8, hipMemcpyDeviceToHost));
+        if (out_pos) RB_HIP(hipMemcpy(out_pos, d_op.p, (size_t)total * 12, hipMemcpyDeviceToHost));
+        counts_out(count_in, device, d_oh, total, out_count, d_cnt);
+    });
+}
+
+int rb_kmer_pair_hashes(int device, const char *seq, const int64_t *offsets, int64_t n_reads, int k, int shift, int canonical,
+                        rb_graph *count_in, int64_t *poffsets, uint64_t *out_hash, float *out_count) {
+    DevBuf d_koff, d_f, d_r, d_poff, d_oh, d_cnt;
+    Bufs rel{{&d_koff, &d_f, &d_r, &d_poff, &d_oh, &d_cnt}};
+    return guarded([&] {
+        RB_REQUIRE(offsets && poffsets && n_reads >= 0 && k >= 1 && k <= RB_MAX_K && shift >= 1, "rb_kmer_pair_hashes: bad argument");
+        RB_HIP(hipSetDevice(device));
+        std::vector<int64_t> koff;
+        poffsets[0] = 0;
+        for (int64_t i = 0; i < n_reads; ++i) {
+            int64_t l = offsets[i + 1] - offsets[i], nk = l >= k ? l - k + 1 : 0;
+            poffsets[i + 1] = poffsets[i] + (nk > shift ? nk - shift : 0);
+        }
+        const int64_t total = poffsets[n_reads];
+        if (!out_hash || !total) return;
+        hash_fr(device, seq, offsets, n_reads, k, canonical != 0, koff, d_koff, d_f, d_r);
+        d_poff.reserve(((size_t)n_reads + 1) * 8); d_oh.reserve((size_t)total * 8);
+        RB_HIP(hipMemcpy(d_poff.p, poffsets, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(k_kmer_pairs, dim3(blocks_for(total)), dim3(TPB), 0, 0, d_f.as<uint64_t>(), d_r.as<uint64_t>(), d_koff.as<int64_t>(),
+                           d_poff.as<int64_t>(), n_reads, total, shift, canonical, d_oh.as<uint64_t>());
+        RB_HIP(hipGetLastError());
+        RB_HIP(hipMemcpy(out_hash, d_oh.p, (size_t)total * 8, hipMemcpyDeviceToHost));
+        counts_out(count_in, device, d_oh, total, out_count, d_cnt);
+    });
+}
+
+// window minimizers on the device (hashes, positions, per-read window offsets); returns the number of windows
+static int64_t window_minimizers(int device, const char *seq, const int64_t *offsets, int64_t n_reads, int k, int w, int mode,
+                                 std::vector<int64_t> &woff, std::vector<int64_t> &koff, DevBuf &d_koff, DevBuf &d_h, DevBuf &d_woff, DevBuf &d_mh, DevBuf &d_mp) {
+    woff.assign((size_t)n_reads + 1, 0);
+    for (int64_t i = 0; i < n_reads; ++i) {
+        int64_t l = offsets[i + 1] - offsets[i], nk = l >= k ? l - k + 1 : 0;
+        woff[(size_t)i + 1] = woff[(size_t)i] + (nk - w + 1 > 0 ? nk - w + 1 : 0);
+    }
+    const int64_t total = woff[(size_t)n_reads];
+    hash_all(device, seq, offsets, n_reads, k, mode, koff, d_koff, d_h);
+    if (!total) return 0;
+    d_woff.reserve(((size_t)n_reads + 1) * 8); d_mh.reserve((size_t)total * 8); d_mp.reserve((size_t)total * 8);
+    RB_HIP(hipMemcpy(d_woff.p, woff.data(), ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_minimizers, dim3(blocks_for(n_reads, 64)), dim3(64), 0, 0, d_h.as<uint64_t>(), d_koff.as<int64_t>(), d_woff.as<int64_t>(),
+                       n_reads, total, w, d_mh.as<uint64_t>(), d_mp.as<int64_t>());
+    RB_HIP(hipGetLastError());
+    return total;
+}
+
+int rb_minimizers_next(int device, const char *seq, const int64_t *offsets, int64_t n_reads, int k, int w, int mode, int64_t *moffsets,
+                       uint64_t *out_hash, int64_t *out_pos) {
+    DevBuf d_koff, d_h, d_woff, d_mh, d_mp, d_flag, d_slot, d_tmp, d_oh, d_op, d_mo;
+    Bufs rel{{&d_koff, &d_h, &d_woff, &d_mh, &d_mp, &d_flag, &d_slot, &d_tmp, &d_oh, &d_op, &d_mo}};
+    return guarded([&] {
+        RB_REQUIRE(offsets && moffsets && out_hash && n_reads >= 0 && k >= 1 && k <= RB_MAX_K && w >= 1 && mode >= 0 && mode <= 2, "rb_minimizers_next: bad argument");
+        RB_HIP(hipSetDevice(device));
+        std::vector<int64_t> woff, koff;
+        const int64_t total = window_minimizers(device, seq, offsets, n_reads, k, w, mode, woff, koff, d_koff, d_h, d_woff, d_mh, d_mp);
+        for (int64_t i = 0; i <= n_reads; ++i) moffsets[i] = 0;
+        if (!total) return;
+        RB_REQUIRE(total < (int64_t)0xFFFFFFF0, "rb_minimizers_next: too many windows in one call");
+        d_flag.reserve((size_t)total * 4 + 4); d_slot.reserve((size_t)total * 4 + 4); d_tmp.reserve(scan_temp_bytes((size_t)total + 1));
+        d_oh.reserve((size_t)total * 8); d_op.reserve((size_t)total * 8); d_mo.reserve(((size_t)n_reads + 1) * 8);
+        hipLaunchKernelGGL(k_minimizer_flags, dim3(blocks_for(total)), dim3(TPB), 0, 0, d_mp.as<int64_t>(), d_woff.as<int64_t>(), n_reads, total, d_flag.as<uint32_t>());
+        RB_HIP(hipMemsetAsync(d_flag.as<uint32_t>() + total, 0, 4, 0));
+        exclusive_scan_u32(d_tmp.p, d_tmp.cap, d_flag.as<uint32_t>(), d_slot.as<uint32_t>(), (size_t)total + 1, 0);
+        uint32_t n_out = 0;
+        RB_HIP(hipMemcpy(&n_out, d_slot.as<uint32_t>() + total, 4, hipMemcpyDeviceToHost));
+        hipLaunchKernelGGL(k_minimizer_compact, dim3(blocks_for(total)), dim3(TPB), 0, 0, d_mh.as<uint64_t>(), d_mp.as<int64_t>(), d_flag.as<uint32_t>(),
+                           d_slot.as<uint32_t>(), total, d_oh.as<uint64_t>(), d_op.as<int64_t>());
+        hipLaunchKernelGGL(k_gather_u32, dim3(blocks_for(n_reads + 1)), dim3(TPB), 0, 0, d_slot.as<uint32_t>(), d_woff.as<int64_t>(), n_reads, total, n_out,
+                           d_mo.as<int64_t>());
+        RB_HIP(hipGetLastError());
+        RB_HIP(hipMemcpy(moffsets, d_mo.p, ((size_t)n_reads + 1) * 8, hipMemcpyDeviceToHost));
+        RB_HIP(hipMemcpy(out_hash, d_oh.p, (size_t)n_out * 8, hipMemcpyDeviceToHost));
+        if (out_pos) RB_HIP(hipMemcpy(out_pos, d_op.p, (size_t)n_out * 8, hipMemcpyDeviceToHost));
+    });
+}
+
+int rb_minimizer_set(int device, const char *seq, const int64_t *offsets, int64_t n_reads, int k, int w, int mode, const uint64_t *stale,
+                     int64_t *moffsets, uint64_t *out) {
+    DevBuf d_koff, d_h, d_woff, d_mh, d_mp, d_flag, d_slot, d_tmp, d_v0, d_v1, d_r0, d_r1, d_eoff, d_kread, d_stale, d_per, d_out;
+    Bufs rel{{&d_koff, &d_h, &d_woff, &d_mh, &d_mp, &d_flag, &d_slot, &d_tmp, &d_v0, &d_v1, &d_r0, &d_r1, &d_eoff, &d_kread, &d_stale, &d_per, &d_out}};
+    return guarded([&] {
+        RB_REQUIRE(offsets && moffsets && out && n_reads >= 0 && k >= 1 && k <= RB_MAX_K && w >= 1 && mode >= 0 && mode <= 2, "rb_minimizer_set: bad argument");
+        RB_HIP(hipSetDevice(device));
+        std::vector<int64_t> woff, koff;
+        const int64_t total_w = window_minimizers(device, seq, offsets, n_reads, k, w, mode, woff, koff, d_koff, d_h, d_woff, d_mh, d_mp);
+        // entries to sort: every window minimizer of the long reads + one value per short read (numKmers <= windowSize)
+        std::vector<int64_t> eoff((size_t)n_reads + 1, 0), kread;
+        for (int64_t i = 0; i < n_reads; ++i) {
+            const int64_t nw = woff[(size_t)i + 1] - woff[(size_t)i], l = offsets[i + 1] - offsets[i];
+            const bool is_short = l - k + 1 <= w;                      // numKmers <= windowSize (numKmers may be <= 0)
+            if (is_short) kread.push_back(i);
+            eoff[(size_t)i + 1] = eoff[(size_t)i] + (is_short ? 1 : nw);
+        }
+        const int64_t total = eoff[(size_t)n_reads], n_short = (int64_t)kread.size();
+        for (int64_t i = 0; i <= n_reads; ++i) moffsets[i] = 0;
+        if (!total) return;
+        RB_REQUIRE(total < (int64_t)0xFFFFFFF0, "rb_minimizer_set: too many windows in one call");
+        d_v0.reserve((size_t)total * 8); d_v1.reserve((size_t)total * 8); d_r0.reserve((size_t)total * 8); d_r1.reserve((size_t)total * 8);
+        d_eoff.reserve(((size_t)n_reads + 1) * 8);
+        RB_HIP(hipMemcpy(d_eoff.p, eoff.data(), ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice));
+        // long reads: their window minimizers are consecutive in d_mh (window order = read order) and in the entry array
+        // (short reads have no windows), so copy read by read ranges: one device copy per maximal stretch of long reads
+        {
+            int64_t i = 0;
+            while (i < n_reads) {
+                if (woff[(size_t)i + 1] == woff[(size_t)i]) { ++i; continue; }
+                int64_t j = i;
+                while (j < n_reads && (offsets[j + 1] - offsets[j]) - k + 1 > w) ++j;
+                const int64_t cnt = woff[(size_t)j] - woff[(size_t)i];
+                if (cnt) RB_HIP(hipMemcpyAsync(d_v0.as<uint64_t>() + eoff[(size_t)i], d_mh.as<uint64_t>() + woff[(size_t)i], (size_t)cnt * 8, hipMemcpyDeviceToDevice, 0));
+                i = j > i ? j : i + 1;
+            }
+        }
+        if (n_short) {
+            d_kread.reserve((size_t)n_short * 8); d_per.reserve((size_t)n_short * 8);
+            RB_HIP(hipMemcpy(d_kread.p, kread.data(), (size_t)n_short * 8, hipMemcpyHostToDevice));
+            const uint64_t *d_st = nullptr;
+            if (stale) { d_stale.reserve((size_t)n_reads * 8); RB_HIP(hipMemcpy(d_stale.p, stale, (size_t)n_reads * 8, hipMemcpyHostToDevice)); d_st = d_stale.as<uint64_t>(); }
+            hipLaunchKernelGGL(k_short_read_min, dim3(blocks_for(n_short)), dim3(TPB), 0, 0, d_h.as<uint64_t>(), d_koff.as<int64_t>(), d_kread.as<int64_t>(), n_short,
+                               d_st, d_per.as<uint64_t>());
+            std::vector<int64_t> where((size_t)n_short);
+            for (int64_t q = 0; q < n_short; ++q) where[(size_t)q] = eoff[(size_t)kread[(size_t)q]];
+            RB_HIP(hipMemcpy(d_kread.p, where.data(), (size_t)n_short * 8, hipMemcpyHostToDevice));   // k_short_read_min has run: stream order
+            hipLaunchKernelGGL(k_scatter_u64, dim3(blocks_for(n_short)), dim3(TPB), 0, 0, d_v0.as<uint64_t>(), d_kread.as<int64_t>(), d_per.as<uint64_t>(), n_short);
+        }
+        // sort by (read, signed value): stable radix on the value (sign bit flipped), then on the read index
+        hipLaunchKernelGGL(k_set_keys, dim3(blocks_for(total)), dim3(TPB), 0, 0, d_v0.as<uint64_t>(), d_eoff.as<int64_t>(), n_reads, total, d_r0.as<uint64_t>());
+        hipLaunchKernelGGL(k_flip_sign, dim3(blocks_for(total)), dim3(TPB), 0, 0, d_v0.as<uint64_t>(), total);
+        d_tmp.reserve(std::max(sort_pairs32_temp_bytes((size_t)total), scan_temp_bytes((size_t)total + 1)));
+        sort_pairs_u64_u64(d_tmp.p, d_tmp.cap, d_v0.as<uint64_t>(), d_v1.as<uint64_t>(), d_r0.as<uint64_t>(), d_r1.as<uint64_t>(), (size_t)total, 0, 64, 0);
+        int rbits = 1; while (((int64_t)1 << rbits) < n_reads + 1) ++rbits;
+        sort_pairs_u64_u64(d_tmp.p, d_tmp.cap, d_r1.as<uint64_t>(), d_r0.as<uint64_t>(), d_v1.as<uint64_t>(), d_v0.as<uint64_t>(), (size_t)total, 0, rbits, 0);
+        // distinct (read, value) pairs
+        d_flag.reserve((size_t)total * 4 + 4); d_slot.reserve((size_t)total * 4 + 4);
+        hipLaunchKernelGGL(k_unique_flags, dim3(blocks_for(total)), dim3(TPB), 0, 0, d_r0.as<uint64_t>(), d_v0.as<uint64_t>(), total, d_flag.as<uint32_t>());
+        RB_HIP(hipMemsetAsync(d_flag.as<uint32_t>() + total, 0, 4, 0));
+        exclusive_scan_u32(d_tmp.p, d_tmp.cap, d_flag.as<uint32_t>(), d_slot.as<uint32_t>(), (size_t)total + 1, 0);
+        uint32_t n_out = 0;
+        RB_HIP(hipMemcpy(&n_out, d_slot.as<uint32_t>() + total, 4, hipMemcpyDeviceToHost));
+        d_out.reserve((size_t)n_out * 8 + 8);
+        d_mp.reserve(((size_t)n_reads + 1) * 8);                       // reuse: per-read counts
+        RB_HIP(hipMemset(d_mp.p, 0, ((size_t)n_reads + 1) * 8));
+        hipLaunchKernelGGL(k_unique_compact, dim3(blocks_for(total)), dim3(TPB), 0, 0, d_r0.as<uint64_t>(), d_v0.as<uint64_t>(), d_flag.as<uint32_t>(),
+                           d_slot.as<uint32_t>(), total, d_out.as<uint64_t>(), reinterpret_cast<unsigned long long *>(d_mp.p));
+        RB_HIP(hipGetLastError());
+        std::vector<unsigned long long> per((size_t)n_reads + 1);
+        RB_HIP(hipMemcpy(per.data(), d_mp.p, ((size_t)n_reads + 1) * 8, hipMemcpyDeviceToHost));
+        for (int64_t i = 0; i < n_reads; ++i) moffsets[i + 1] = moffsets[i] + (int64_t)per[(size_t)i];
+        RB_HIP(hipMemcpy(out, d_out.p, (size_t)n_out * 8, hipMemcpyDeviceToHost));
+        (void)total_w;
     });
 }
 

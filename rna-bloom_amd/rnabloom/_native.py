@@ -18,6 +18,7 @@ PROF_MAX = 32
 SLOT_REC_KEYS, SLOT_REC_OCC, SLOT_PAIR_IDX, SLOT_DREQ_IDX, SLOT_DREQ_PROBE, SLOT_CREQ_IDX, SLOT_W_IDX, SLOT_W_VAL, \
     SLOT_CONF_EDGES, SLOT_CONF_RUNS, SLOT_CONF_OPS, SLOT_CW_IDX, SLOT_CW_VAL, SLOT_Q_BIDX, SLOT_Q_CIDX, SLOT_CACHE_UPD = range(16)
 MODE_ADD, MODE_COUNT_IF_PRESENT = 0, 2
+STROBE_CANONICAL, STROBE_SLIDE = 1, 2
 
 
 class GraphParams(C.Structure):
@@ -84,9 +85,17 @@ SYMBOLS = [
     ("rb_filter_export", _i32, [_vp, _i32, _vp, _sz]),
     ("rb_filter_import", _i32, [_vp, _i32, _vp, _sz]),
     ("rb_expected_size", _i64, [_i64, C.c_float, _i32]),
+    ("rb_graph_destroy_filter", _i32, [_vp, _i32]),
+    ("rb_filter_increment_and_get", _i32, [_vp, _vp, _sz, _vp]),
+    ("rb_cbf_to_bloom", _i32, [_vp, C.c_float, _vp, _i32]),
     ("rb_nthash_batch", _i32, [_vp, _i32, _i32, _i64, _i64, C.POINTER(_i64), _vp, _vp, _vp]),
     ("rb_minimizers", _i32, [_i32, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
     ("rb_strobemers", _i32, [_i32, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    ("rb_randstrobes", _i32, [_i32, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    ("rb_strobe3", _i32, [_i32, _vp, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp]),
+    ("rb_kmer_pair_hashes", _i32, [_i32, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    ("rb_minimizers_next", _i32, [_i32, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
+    ("rb_minimizer_set", _i32, [_i32, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
     ("rb_graph_create_shard", _i32, [C.POINTER(GraphParams), _i32, _i32, C.POINTER(_vp)]),
     ("rb_shard_set_cache_replication", _i32, [_vp, _i32]),
     ("rb_shard_hash", _i32, [_vp, _vp, _i64, _i64, _i64, _i64, _u64, _u32, C.c_uint, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(AddStats)]),

@@ -16,14 +16,19 @@ class BloomFilter:
     """R/bloom/BloomFilter.java:40-258"""
 
     def __init__(self, size, numHash, k, device=0):
-        self.size, self.numHash, self.k = int(size), int(numHash), int(k)
+        self.size, self.numHash, self.k, self.device = int(size), int(numHash), int(k), int(device)
+        self.popcount = -1                                                      # :48, set by getFPR
         self._g = BloomFilterDeBruijnGraph(self.size, _TINY, 0, self.numHash, 1, 1, self.k, True, False, device=device)
 
     def add(self, h0): self._g.addDbgOnly(h0)                                   # :133-141
     def lookup(self, h0): return self._g.contains(h0)                           # :170-182
     def lookupThenAdd(self, h0): return self._g.lookupThenAdd(N.DBGBF, h0)      # :143-155, in array order
-    def getFPR(self): return self._g.getDbgbfFPR()                              # :185-194
+    def getFPR(self):                                                           # :185-194 (remembers the popcount it used)
+        self.popcount = self._g.popcount(N.DBGBF)
+        return self._g.getDbgbfFPR()
     def getPopCount(self): return self._g.popcount(N.DBGBF)
+    def getOptimalSize(self, fpr):                                              # :205-213: from the popcount of the last getFPR()
+        return self.getExpectedSize(self.popcount, fpr, self.numHash) if self.popcount > 0 else self.size
     def getNumHash(self): return self.numHash
     def getSize(self): return self.size
     def empty(self): self._g.clearDbgbf()                                       # :240-242
@@ -43,10 +48,15 @@ class CountingBloomFilter:
     MiniFloat.increment come from the library's counter-based generator (seed, op ordinal), so a run is reproducible."""
 
     def __init__(self, size, numHash, k, device=0, rngSeed=0):
-        self.size, self.numHash, self.k = int(size), int(numHash), int(k)
+        self.size, self.numHash, self.k, self.device, self.rngSeed = int(size), int(numHash), int(k), int(device), int(rngSeed)
         self._g = BloomFilterDeBruijnGraph(_TINY, self.size, 0, 1, self.numHash, 1, self.k, True, False, device=device, rngSeed=rngSeed)
 
     def increment(self, h0): self._g.addCountOnly(h0)                           # :170-194, in array order
+    def incrementAndGet(self, h0):                                              # :196-222, one call after the other
+        h = np.ascontiguousarray(np.atleast_1d(h0), np.uint64)
+        out = np.zeros(h.size, np.float32)
+        N.check(N.lib.rb_filter_increment_and_get(self._g.h, h.ctypes.data, h.size, out.ctypes.data))
+        return out
     def getCount(self, h0): return self._g.getCbfCount(h0)                      # :235-251
     def getFPR(self): return self._g.getCbfFPR()                                # :254-263
     def getPopCount(self): return self._g.popcount(N.CBF)                       # non-zero counters
@@ -58,19 +68,20 @@ class CountingBloomFilter:
     def fromBytes(self, data): self._g.importFilter(N.CBF, data)
 
     def getBloomFilter(self, minCount):
-        """:328-338 — the plain Bloom filter of the counters >= minCount (MiniFloat bytes compare like their values)"""
-        raw = self.toBytes()
-        vals = np.array([0.0] + [((b & 7) | 8) * 2.0 ** ((b >> 3) - 1) if b > 7 else float(b) for b in range(1, 128)], np.float32)
-        bf = BloomFilter(self.size, self.numHash, self.k)
-        keep = vals[np.minimum(raw, 127)] >= minCount
-        bf.fromBytes(np.packbits(keep, bitorder="little"))
+        """:328-338 — the plain Bloom filter of the counters with MiniFloat.toFloat(count) >= minCount, built on the device"""
+        bf = BloomFilter(self.size, self.numHash, self.k, device=self.device)
+        N.check(N.lib.rb_cbf_to_bloom(self._g.h, float(minCount), bf._g.h, N.DBGBF))
         return bf
 
 
-class PairedKeysBloomFilter:
-    """Only its static getExpectedSize is reached in the reference (R/RNABloom.java:7010); the live pair filters are
-    plain BloomFilters (R/graph/BloomFilterDeBruijnGraph.java:102, 354)."""
+class PairedKeysBloomFilter(BloomFilter):
+    """R/bloom/PairedKeysBloomFilter.java:40-231: one bit array addressed by the hash values of a k-mer PAIR — add / lookup /
+    lookupThenAdd / getFPR / getOptimalSize / empty / destroy are BloomFilter's statements on `bitArrayPair` (:133-170,
+    :205-230), so the class is BloomFilter under its own name.  (In the reference only the static getExpectedSize is
+    reached, R/RNABloom.java:7010; the live pair filters are plain BloomFilters, R/graph/BloomFilterDeBruijnGraph.java:102, 354.)"""
+
+    def getNumhash(self): return self.numHash                                   # :101-103 (sic)
 
     @staticmethod
-    def getExpectedSize(expNumElements, fpr, numHash):                          # R/bloom/PairedKeysBloomFilter.java:213-216
+    def getExpectedSize(expNumElements, fpr, numHash):                          # :213-216
         return BloomFilter.getExpectedSize(expNumElements, fpr, numHash)

@@ -12,6 +12,22 @@ from . import _native as N
 from ._native import check, lib
 
 
+def _java_float(x):
+    """Float.toString: shortest decimal that round-trips, plain notation for 1e-3 <= |x| < 1e7, else d.dddE[-]n"""
+    x = float(np.float32(x))
+    if x != x: return "NaN"
+    if x in (float("inf"), float("-inf")): return "Infinity" if x > 0 else "-Infinity"
+    if x == 0: return "0.0"
+    r = np.format_float_scientific(np.float32(x), unique=True, trim="0")      # e.g. 1.e-05 / 1.5e-05
+    mant, exp = r.split("e")
+    if mant.endswith("."): mant += "0"
+    e = int(exp)
+    if -3 <= e < 7:
+        p = np.format_float_positional(np.float32(x), unique=True, trim="0")
+        return p + "0" if p.endswith(".") else p
+    return "%sE%d" % (mant, e)
+
+
 def _ptr(a):
     return None if a is None else a.ctypes.data_as(C.c_void_p)
 
@@ -133,7 +149,7 @@ class BloomFilterDeBruijnGraph:
     # ---- parameters ----
     def getK(self): return self.k
     def isStranded(self): return self.stranded
-    def getMaxNumHash(self): return max(self.p.dbgbf_num_hash, self.p.cbf_num_hash)
+    def getMaxNumHash(self): return getattr(self, "dbgbfCbfMaxNumHash", max(self.p.dbgbf_num_hash, self.p.cbf_num_hash))
     def setReadPairedKmerDistance(self, d):
         check(lib.rb_graph_set_read_paired_kmer_distance(self.h, d)); self.readPairedKmersDistance = int(d)
     def setFragPairedKmerDistance(self, d):
@@ -326,11 +342,16 @@ class BloomFilterDeBruijnGraph:
     _ALT = {ord("A"): b"CGT", ord("C"): b"AGT", ord("G"): b"ACT", ord("T"): b"ACG", ord("U"): b"ACG"}   # SeqUtils.java:51-55
 
     def _variants(self, kmer, pos):
+        """getLeftVariants / getRightVariants(String): the k-mer is hashed once, its three alternatives come from the
+        variant iterators on the device (rb_graph_neighbors directions 2 / 3) and are kept when the graph contains them"""
         kmer = kmer if isinstance(kmer, bytes) else kmer.encode()
-        alts = self._ALT.get(kmer[pos], b"ACGT")
-        cand = [kmer[:pos] + bytes([c]) + kmer[pos + 1:] for c in alts]
-        hit = self.containsSeq(cand)
-        return [v.decode() for v, ok in zip(cand, hit) if ok]
+        f, r, _ = self.getKmer(kmer)
+        _, _, c4 = self.getNeighbors([f], [r], [kmer[pos]], 2 if pos == 0 else 3)
+        out = []
+        for c in self._ALT.get(kmer[pos], b"ACGT"):            # getAltNucleotides order, SeqUtils.java:51-55
+            if c4[0][b"ACGT".index(c)] > 0:
+                out.append((kmer[:pos] + bytes([c]) + kmer[pos + 1:]).decode())
+        return out
 
     def getLeftVariants(self, kmer): return self._variants(kmer, 0)                 # :1056-1068
     def getRightVariants(self, kmer): return self._variants(kmer, self.k - 1)       # :1109-1121
@@ -344,6 +365,15 @@ class BloomFilterDeBruijnGraph:
     def getPredecessors(self, f, r, charOut, minKmerCov=1.0):           # Kmer.java:228-255
         f4, r4, c4 = self.getNeighbors(f, r, charOut, 1)
         return f4, r4, c4, c4 >= np.float32(minKmerCov)
+
+    # Kmer.hasPredecessors / hasSuccessors / hasAtLeastX* / getNum* (R/graph/Kmer.java:97-197) for many k-mers: the
+    # neighbours graph.contains() accepts, i.e. those with getCount > 0 (getCount is cbf + 1 inside dbgbf, 0 outside)
+    def getNumPredecessors(self, f, r, lastBase): return (self.getNeighbors(f, r, lastBase, 1)[2] > 0).sum(axis=1)
+    def getNumSuccessors(self, f, r, firstBase): return (self.getNeighbors(f, r, firstBase, 0)[2] > 0).sum(axis=1)
+    def hasPredecessors(self, f, r, lastBase): return self.getNumPredecessors(f, r, lastBase) > 0
+    def hasSuccessors(self, f, r, firstBase): return self.getNumSuccessors(f, r, firstBase) > 0
+    def hasAtLeastXPredecessors(self, f, r, lastBase, x): return self.getNumPredecessors(f, r, lastBase) >= x
+    def hasAtLeastXSuccessors(self, f, r, firstBase, x): return self.getNumSuccessors(f, r, firstBase) >= x
 
     def _pair_hashes(self, f, r, d):
         from .graphutils import kmerPairHashValues
@@ -382,8 +412,10 @@ class BloomFilterDeBruijnGraph:
     def getFpkbf(self): return _FilterOfGraph(self, N.FPKBF) if self._has(N.FPKBF) else None
     def getFpkbfFPR(self): return self.getPkbfFPR()
 
-    def destroyRpkbf(self): self.clearRpkbf()       # :270-275 frees the filter; here its bits are cleared, the memory is
-    def destroyFpkbf(self): self.clearFpkbf()       # :263-268   kept until the graph is destroyed
+    def destroyDbgbf(self): check(lib.rb_graph_destroy_filter(self.h, N.DBGBF))      # :249-254: the device memory is freed
+    def destroyCbf(self): check(lib.rb_graph_destroy_filter(self.h, N.CBF))          # :256-261
+    def destroyFpkbf(self): check(lib.rb_graph_destroy_filter(self.h, N.FPKBF))      # :263-268
+    def destroyRpkbf(self): check(lib.rb_graph_destroy_filter(self.h, N.RPKBF))      # :270-275
 
     # ---- persistence: the reference's own files (a graph saved here loads in RNA-Bloom and the other way round) ----
     _EXT = {N.DBGBF: ".dbgbf", N.CBF: ".cbf", N.RPKBF: ".rpkbf", N.FPKBF: ".fpkbf"}     # :58-62
@@ -399,7 +431,7 @@ class BloomFilterDeBruijnGraph:
         size, _, h = self.filterSize(which)
         path = str(graphFile) + self._EXT[which]
         with open(path + ".desc", "w") as w:
-            w.write("size:%d\nnumhash:%d\nfpr:%s\n" % (size, h, str(np.float32(self._fpr(which)))))
+            w.write("size:%d\nnumhash:%d\nfpr:%s\n" % (size, h, _java_float(self._fpr(which))))
         self.exportFilter(which).tofile(path)
 
     def _has(self, which):
@@ -428,7 +460,9 @@ class BloomFilterDeBruijnGraph:
         import os
         path = str(graphFile) + self._EXT[N.FPKBF]
         d = self._read_desc(path + ".desc")
+        if self._has(N.FPKBF): self.destroyFpkbf()                     # :345-347: a new filter with the file's size and numhash
         self.initializePairKmersBloomFilter(int(d["size"]), int(d["numhash"]))
+        self.p.pkbf_num_hash = int(d["numhash"])
         self.importFilter(N.FPKBF, np.fromfile(path, np.uint8))
 
     def updateFragmentKmerDistance(self, graphFile):                    # :106-119
@@ -453,7 +487,8 @@ class BloomFilterDeBruijnGraph:
         if "readPairedKmersDistance" in d and int(d["readPairedKmersDistance"]) > 0: self.setReadPairedKmerDistance(int(d["readPairedKmersDistance"]))
         if "fragmentPairedKmersDistance" in d and int(d["fragmentPairedKmersDistance"]) > 0: self.setFragPairedKmerDistance(int(d["fragmentPairedKmersDistance"]))
         fp = g + ".fpkbf"
-        if os.path.isfile(fp) and os.path.isfile(fp + ".desc"): self.restorePkbf(g)
+        if os.path.isfile(fp) and os.path.isfile(fp + ".desc"): self.restorePkbf(g)     # pkbfNumHash from the loaded filter (:170-176)
+        if "dbgbfCbfMaxNumHash" in d: self.dbgbfCbfMaxNumHash = int(d["dbgbfCbfMaxNumHash"])
         return self
 
     # ---- filter state ----
@@ -544,3 +579,83 @@ def strobemers(reads, k, n, wmin, wmax, device=0):
     if t:
         check(lib.rb_strobemers(device, _ptr(seq), _ptr(off), len(reads), k, n, wmin, wmax, _ptr(so), _ptr(h), _ptr(s), _ptr(e)))
     return so, h, s, e
+
+
+def _count_handle(counts_from):
+    """the rb_graph handle behind a CountingBloomFilter / graph whose cbf is asked getCount(hash) on the device"""
+    if counts_from is None:
+        return None
+    g = getattr(counts_from, "_g", counts_from)
+    return g.h
+
+
+def randstrobes(reads, k, n, wmin, wmax, canonical=False, slide=False, counts_from=None, device=0):
+    """StrobeHashIterator.next()/get() (slide=True: get) or CanonicalStrobeHashIterator over each read:
+    (offsets[n_reads+1], hash, positions[., n], counts or None).  counts_from: a CountingBloomFilter (or graph) whose
+    getCount(hash) is evaluated in the same call (SeqSubsampler.strobemerBased's lookup half)."""
+    seq, off = _pack(reads)
+    so = np.zeros(len(reads) + 1, np.int64)
+    flags = (N.STROBE_CANONICAL if canonical else 0) | (N.STROBE_SLIDE if slide else 0)
+    check(lib.rb_randstrobes(device, _ptr(seq), _ptr(off), len(reads), k, n, wmin, wmax, flags, None, _ptr(so), None, None, None))
+    t = int(so[-1])
+    h = np.zeros(t, np.uint64); pos = np.zeros((t, n), np.int32)
+    cnt = np.zeros(t, np.float32) if counts_from is not None else None
+    if t:
+        check(lib.rb_randstrobes(device, _ptr(seq), _ptr(off), len(reads), k, n, wmin, wmax, flags, _count_handle(counts_from), _ptr(so),
+                                 _ptr(h), _ptr(pos), _ptr(cnt) if cnt is not None else None))
+    return so, h, pos, cnt
+
+
+def strobe3(reads, k, wmin, wmax, canonical=False, counts_from=None, device=0):
+    """Strobe3HashIterator / CanonicalStrobe3HashIterator over each read: (offsets, hash, positions[., 3], counts or None)"""
+    seq, off = _pack(reads)
+    so = np.zeros(len(reads) + 1, np.int64)
+    check(lib.rb_strobe3(device, _ptr(seq), _ptr(off), len(reads), k, wmin, wmax, int(canonical), None, _ptr(so), None, None, None))
+    t = int(so[-1])
+    h = np.zeros(t, np.uint64); pos = np.zeros((t, 3), np.int32)
+    cnt = np.zeros(t, np.float32) if counts_from is not None else None
+    if t:
+        check(lib.rb_strobe3(device, _ptr(seq), _ptr(off), len(reads), k, wmin, wmax, int(canonical), _count_handle(counts_from), _ptr(so),
+                             _ptr(h), _ptr(pos), _ptr(cnt) if cnt is not None else None))
+    return so, h, pos, cnt
+
+
+def kmerPairHashes(reads, k, shift, canonical=False, counts_from=None, device=0):
+    """SeqSubsampler.kmerBased's pair hashes (gap = shift - k) of each read: (offsets, hash, counts or None)"""
+    seq, off = _pack(reads)
+    po = np.zeros(len(reads) + 1, np.int64)
+    check(lib.rb_kmer_pair_hashes(device, _ptr(seq), _ptr(off), len(reads), k, shift, int(canonical), None, _ptr(po), None, None))
+    t = int(po[-1])
+    h = np.zeros(t, np.uint64)
+    cnt = np.zeros(t, np.float32) if counts_from is not None else None
+    if t:
+        check(lib.rb_kmer_pair_hashes(device, _ptr(seq), _ptr(off), len(reads), k, shift, int(canonical), _count_handle(counts_from), _ptr(po),
+                                      _ptr(h), _ptr(cnt) if cnt is not None else None))
+    return po, h, cnt
+
+
+def _windows(reads, k, w):
+    return sum(max(0, len(r) - k + 1 - w + 1) for r in reads)
+
+
+def nextMinimizers(reads, k, w, mode=1, device=0):
+    """the minimizers MinimizerHashIterator.nextMinimizer() walks through: (offsets, hash, pos)"""
+    seq, off = _pack(reads)
+    cap = _windows(reads, k, w)
+    mo = np.zeros(len(reads) + 1, np.int64)
+    h = np.zeros(max(1, cap), np.uint64); p = np.zeros(max(1, cap), np.int64)
+    check(lib.rb_minimizers_next(device, _ptr(seq), _ptr(off), len(reads), k, w, mode, _ptr(mo), _ptr(h), _ptr(p)))
+    t = int(mo[-1])
+    return mo, h[:t].copy(), p[:t].copy()
+
+
+def getMinimizers(reads, k, w, mode=1, stale=None, device=0):
+    """GraphUtils.getMinimizers for each read (sorted distinct window minimizers, signed order): (offsets, values).
+    stale[i]: what the iterator's hVals[0] held before read i (only reads with numKmers <= w look at it; default 0)."""
+    seq, off = _pack(reads)
+    cap = sum(max(1, len(r) - k + 1 - w + 1) for r in reads)
+    mo = np.zeros(len(reads) + 1, np.int64)
+    out = np.zeros(max(1, cap), np.uint64)
+    st = None if stale is None else np.ascontiguousarray(stale, np.uint64)
+    check(lib.rb_minimizer_set(device, _ptr(seq), _ptr(off), len(reads), k, w, mode, _ptr(st) if st is not None else None, _ptr(mo), _ptr(out)))
+    return mo, out[:int(mo[-1])].copy()

@@ -100,3 +100,88 @@ def test_long_reads_at_scale():
         eh, es, ee = rbo.strobemers(reads[i], 11, 3, 12, 61)
         a, b = so_[i], so_[i + 1]
         assert b - a == len(eh) and (h[a:b] == eh).all() and (s[a:b] == es).all() and (e[a:b] == ee).all()
+
+
+# ---- the other sketch iterators and SeqSubsampler's hashing halves (a20) ----
+EDGE_READS = [b"ACGT" * 10, b"", b"ACGTACGTAC", b"A" * 200, b"ACGTTGCA" * 40]
+
+
+@pytest.mark.parametrize("canonical,slide", [(False, False), (False, True), (True, False)])
+@pytest.mark.parametrize("n,wmin,wmax", [(3, 12, 61), (2, 12, 50), (4, 5, 9)])
+def test_randstrobes_match_oracle(canonical, slide, n, wmin, wmax):
+    reads = long_reads(30, 11) + EDGE_READS
+    so, h, pos, _ = G.randstrobes(reads, 11, n, wmin, wmax, canonical=canonical, slide=slide)
+    tot = 0
+    for i, sq in enumerate(reads):
+        eh, ep = rbo.randstrobes(sq, 11, n, wmin, wmax, canonical=canonical, slide=slide)
+        a, b = so[i], so[i + 1]
+        assert b - a == len(eh)
+        assert (h[a:b] == eh).all() and (pos[a:b] == ep).all()
+        tot += len(eh)
+    assert tot > 20000
+
+
+@pytest.mark.parametrize("canonical", [False, True])
+def test_strobe3_match_oracle(canonical):
+    reads = long_reads(30, 12) + EDGE_READS + [rbo_seq for rbo_seq in (b"ACGTGCTAGCTAGGATC" * 9, b"ACGTGCTAGCTAGGATC" * 3)]
+    so, h, pos, _ = G.strobe3(reads, 11, 12, 61, canonical=canonical)
+    tot = 0
+    for i, sq in enumerate(reads):
+        eh, ep = rbo.strobe3(sq, 11, 12, 61, canonical)
+        a, b = so[i], so[i + 1]
+        assert b - a == len(eh)
+        assert (h[a:b] == eh).all() and (pos[a:b] == ep).all()
+        tot += len(eh)
+    assert tot > 20000
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2])
+def test_next_minimizers_and_minimizer_sets_match_oracle(mode):
+    reads = long_reads(40, 13) + EDGE_READS + [b"ACGTACGTACGTACGTACGTACGTACG", b"ACGTACGTACGTACGTACGTACGTACGT", b"ACGTACGTACGTA", b"ACGTACGTACGT"]
+    k, w = 13, 15
+    mo, h, p = G.nextMinimizers(reads, k, w, mode)
+    rng = np.random.default_rng(5)
+    stale = rng.integers(0, 1 << 63, len(reads), dtype=np.int64).astype(np.uint64) * np.uint64(2)    # spans the sign bit
+    so, sv = G.getMinimizers(reads, k, w, mode)
+    so2, sv2 = G.getMinimizers(reads, k, w, mode, stale=stale)
+    for i, s in enumerate(reads):
+        eh, ep = rbo.minimizers_next(s, k, w, mode)
+        a, b = mo[i], mo[i + 1]
+        assert b - a == len(eh) and (h[a:b] == eh).all() and (p[a:b] == ep).all()
+        es = rbo.minimizer_set(s, k, w, mode)
+        assert (sv[so[i]:so[i + 1]] == es).all() and so[i + 1] - so[i] == len(es)
+        es2 = rbo.minimizer_set(s, k, w, mode, stale=int(stale[i]))
+        assert (sv2[so2[i]:so2[i + 1]] == es2).all() and so2[i + 1] - so2[i] == len(es2)
+    assert mo[-1] > 3000 and so[-1] > 3000
+
+
+@pytest.mark.parametrize("canonical", [False, True])
+def test_subsampler_hashing_halves(canonical):
+    """SeqSubsampler.strobemerBased / kmerBased: hash every strobemer / k-mer pair of a read and ask the counting filter
+    for its multiplicity (R/util/SeqSubsampler.java:389-395, 176-179, 266-268) — one call, counts looked up on the device"""
+    from rnabloom.bloom import CountingBloomFilter
+    reads = long_reads(25, 14)
+    k = 11
+    cbf = CountingBloomFilter(400_009, 2, k, rngSeed=3)
+    ocbf = rbo.Graph(64, 400_009, 0, 1, 2, 1, k, True, False, 3)
+    # fill with the strobemers of the first reads (several times each), as the subsampler does when it keeps a read
+    so, h, s, e = G.strobemers(reads[:10], k, 3, k + 1, 2 * k)
+    for _ in range(3):
+        cbf.increment(h)
+        for x in h: ocbf.add_count_only(rbo.ntm64(int(x), k, 2))
+    assert (cbf.toBytes() == ocbf.cbf_bytes()).all()
+
+    def ocount(x):           # CountingBloomFilter.getCount(long) on the oracle's counters (:235-251 + MiniFloat.toFloat :40-45)
+        raw = ocbf.cbf_bytes()
+        b = min(int(raw[(int(v) >> 1) % 400_009]) for v in rbo.ntm64(int(x), k, 2))
+        return float(b) if b <= 7 else float(((b & 7) | 8) << ((b >> 3) - 1))
+    so, h, s, e = G.strobemers(reads, k, 3, k + 1, 2 * k)
+    so2, h2, pos2, cnt = G.randstrobes(reads, k, 3, k + 1, 2 * k, slide=True, counts_from=cbf)
+    assert (so2 == so).all() and (h2 == h).all() and (pos2[:, 0] == s).all() and (pos2[:, 2] + k - 1 == e).all()
+    exp = np.array([ocount(x) for x in h], np.float32)
+    assert (cnt == exp).all() and (cnt >= 3).sum() > 100 and (cnt == 0).sum() > 100
+    # k-mer pairs (gap 1), stranded and canonical
+    po, ph, pc = G.kmerPairHashes(reads, k, k + 1, canonical=canonical, counts_from=cbf)
+    for i, sq in enumerate(reads):
+        assert (ph[po[i]:po[i + 1]] == rbo.kmer_pair_hashes(sq, k, k + 1, canonical)).all()
+    assert (pc == np.array([ocount(x) for x in ph], np.float32)).all()
