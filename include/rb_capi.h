@@ -296,6 +296,24 @@ int rb_minimizers_next(int device, const char *seq, const int64_t *offsets, int6
 int rb_minimizer_set(int device, const char *seq, const int64_t *offsets, int64_t n_reads, int k, int w, int mode,
                      const uint64_t *stale, int64_t *moffsets, uint64_t *out);
 
+/* ---- input formats ----
+ * FASTQ text -> the buffers rb_graph_add_reads / rb_batch_create_ascii take.  FastqReader.nextWithoutName
+ * R/io/FastqReader.java:140-186: four lines per record, line 1 starts with '@', line 3 with '+' (else RB_ERR_INVALID with
+ * the reference's message), a record cut off by the end of the text is dropped; lines end at \n, \r\n or \r.
+ * Threaded (n_threads <= 0: all hardware threads).  Call with offsets == NULL for the record count; seq / qual
+ * (qual may be NULL) need offsets[n_reads] bytes — len is always enough. */
+int rb_fastq_split(const char *text, size_t len, int n_threads, char *seq, char *qual, int64_t *offsets, int64_t cap_reads,
+                   int64_t *n_reads);
+/* .nbits files (R/io/NucleotideBitsReader.java, R/util/SeqBitsUtils.java:159-161, 236-263: per sequence a 4-byte
+ * big-endian length, then ceil(len/4) bytes of four 2-bit bases each, first base in the top bits, value - 128) straight
+ * into a packed device batch: the bytes are uploaded as they are and permuted on the GPU (every base is usable — the
+ * format has no code for N).  At most max_reads records (< 0: all); *consumed = bytes used; a truncated last record
+ * is left unread, as NucleotideBitsReader.next() returns null for it. */
+int rb_batch_create_nbits(int device, const void *bytes, size_t nbytes, int64_t max_reads, rb_batch **out, size_t *consumed);
+/* NucleotideBitsWriter.write R/io/NucleotideBitsWriter.java:24-31 for n_reads sequences; out == NULL: *written = size
+ * needed.  A base outside ACGTU is an error (the reference stores a RANDOM base there, SeqBitsUtils.java:154-155). */
+int rb_nbits_encode(const char *seq, const int64_t *offsets, int64_t n_reads, void *out, size_t cap, size_t *written);
+
 /* ---- sharded engine (one process per GPU; filters split by index range across `count` shards) ----
  * Multi-GPU counterpart of rb_graph_add_batch.  The reference is a single shared-memory process, so
  * there is no reference interface for this; the phases below are what bench.py / rnabloom.sharded

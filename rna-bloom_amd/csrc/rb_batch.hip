@@ -1380,3 +1380,130 @@ int rb_nthash_batch(const rb_batch *b, int k, int mode, int64_t first, int64_t n
 }
 
 }  // extern "C"
+
+// ------------------------------------------------------------ .nbits ingest ----
+// R/util/SeqBitsUtils.java:159-161, 236-263 / R/io/NucleotideBits{Reader,Writer}.java: a record is a 4-byte big-endian
+// length followed by ceil(len/4) bytes, each holding 4 bases MSB first (A0 C1 G2 T3), stored minus 128.  The packed
+// batch wants 32 bases per 64-bit word LSB first: one thread per output word reads 8 input bytes, undoes the offset
+// (xor 0x80) and reverses the order of the four 2-bit groups of every byte — a pure bit permutation, no table.
+namespace {
+__device__ __forceinline__ uint32_t nbits_byte_to_lsb_first(uint32_t b) {
+    b ^= 0x80u;                                                      // value + 128 (mod 256)
+    return ((b >> 6) & 3u) | (((b >> 4) & 3u) << 2) | (((b >> 2) & 3u) << 4) | ((b & 3u) << 6);
+}
+__global__ void k_decode_nbits(const uint8_t *__restrict__ raw, const int64_t *__restrict__ rec_off /* payload offset per read */,
+                               const uint32_t *__restrict__ woff, const uint32_t *__restrict__ len, int64_t n_reads, int64_t n_words,
+                               uint64_t *__restrict__ codes, uint32_t *__restrict__ valid, uint32_t *__restrict__ word_read) {
+    int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_words) return;
+    int64_t lo = 0, hi = n_reads;
+    while (hi - lo > 1) { int64_t mid = (lo + hi) >> 1; if (woff[mid] <= (uint32_t)w) lo = mid; else hi = mid; }
+    const int64_t r = lo;
+    const uint32_t L = len[r], b0 = (uint32_t)(w - woff[r]) * 32u;
+    const uint32_t nb = L - b0 < 32u ? L - b0 : 32u;                 // bases in this word
+    const uint8_t *src = raw + rec_off[r] + (b0 >> 2);
+    const uint32_t nbytes = (nb + 3u) >> 2;
+    uint64_t c = 0;
+    for (uint32_t i = 0; i < nbytes; ++i) c |= (uint64_t)nbits_byte_to_lsb_first(src[i]) << (8u * i);
+    const uint32_t v = nb == 32u ? 0xFFFFFFFFu : (1u << nb) - 1u;
+    if (nb < 32u) c &= (1ull << (2u * nb)) - 1ull;                   // the pad bases of the last byte are not part of the read
+    codes[w] = c; valid[w] = v; word_read[w] = (uint32_t)r;
+}
+}  // namespace
+
+extern "C" {
+
+int rb_batch_create_nbits(int device, const void *bytes, size_t nbytes, int64_t max_reads, rb_batch **out, size_t *consumed) {
+    uint8_t *d_raw = nullptr; int64_t *d_off = nullptr; rb_batch *b = nullptr;
+    try {
+        RB_REQUIRE(out && (bytes || nbytes == 0), "rb_batch_create_nbits: null argument");
+        RB_HIP(hipSetDevice(device));
+        const uint8_t *p = static_cast<const uint8_t *>(bytes);
+        std::vector<int64_t> rec_off;
+        std::vector<uint32_t> len, woff;
+        size_t pos = 0;
+        uint64_t words = 0;
+        uint32_t max_len = 0;
+        while (pos + 4 <= nbytes && (max_reads < 0 || (int64_t)len.size() < max_reads)) {      // NucleotideBitsReader.next(): length, then the bytes
+            const uint32_t l = ((uint32_t)p[pos] << 24) | ((uint32_t)p[pos + 1] << 16) | ((uint32_t)p[pos + 2] << 8) | (uint32_t)p[pos + 3];
+            RB_REQUIRE(l < (1u << 30), "rb_batch_create_nbits: record %zu has an invalid length %u", len.size(), l);
+            const size_t nb = ((size_t)l + 3) / 4;
+            if (pos + 4 + nb > nbytes) break;                        // truncated record: the reader returns null
+            rec_off.push_back((int64_t)(pos + 4)); len.push_back(l); woff.push_back((uint32_t)words);
+            words += ((uint64_t)l + 31) / 32;
+            RB_REQUIRE(words < 0xFFFFFFF0ull, "rb_batch_create_nbits: batch too large (> 2^32 words)");
+            max_len = std::max(max_len, l);
+            pos += 4 + nb;
+        }
+        woff.push_back((uint32_t)words);
+        const int64_t n_reads = (int64_t)len.size();
+        b = new rb_batch();
+        b->device = device; b->n_reads = n_reads; b->n_words = (int64_t)words; b->max_len = max_len;
+        b->n_bases = 0; for (uint32_t l : len) b->n_bases += l;
+        {
+            uint32_t wpr = n_reads ? (len[0] + 31) / 32 : 0;
+            for (int64_t i = 0; i < n_reads && wpr; ++i) if ((len[(size_t)i] + 31) / 32 != wpr) wpr = 0;
+            b->wpr_uniform = wpr;
+        }
+        alloc_batch_arrays(b);
+        b->h_woff = woff;
+        RB_HIP(hipMemcpy(b->woff, woff.data(), ((size_t)n_reads + 1) * 4, hipMemcpyHostToDevice));
+        if (n_reads) RB_HIP(hipMemcpy(b->len, len.data(), (size_t)n_reads * 4, hipMemcpyHostToDevice));
+        if (words) {
+            RB_HIP(hipMalloc(&d_raw, std::max<size_t>(pos, 1) + 8));
+            RB_HIP(hipMalloc(&d_off, (size_t)n_reads * 8));
+            RB_HIP(hipMemcpy(d_raw, p, pos, hipMemcpyHostToDevice));
+            RB_HIP(hipMemcpy(d_off, rec_off.data(), (size_t)n_reads * 8, hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(k_decode_nbits, dim3(blocks_for((int64_t)words)), dim3(TPB), 0, 0, d_raw, d_off, b->woff, b->len, n_reads, (int64_t)words,
+                               b->codes, b->valid, b->word_read);
+            RB_HIP(hipGetLastError());
+            RB_HIP(hipDeviceSynchronize());
+        }
+        if (d_raw) (void)hipFree(d_raw);
+        if (d_off) (void)hipFree(d_off);
+        if (consumed) *consumed = pos;
+        *out = b;
+        return RB_OK;
+    } catch (const HipError &e) {
+        if (d_raw) (void)hipFree(d_raw);
+        if (d_off) (void)hipFree(d_off);
+        if (b) rb_batch_destroy(b);
+        return e.code;
+    } catch (const std::bad_alloc &) { if (b) rb_batch_destroy(b); set_error("host allocation failed"); return RB_ERR_NOMEM; }
+}
+
+int rb_nbits_encode(const char *seq, const int64_t *offsets, int64_t n_reads, void *out, size_t cap, size_t *written) {
+    try {
+        RB_REQUIRE(offsets && written && n_reads >= 0 && (seq || n_reads == 0), "rb_nbits_encode: null argument");
+        size_t need = 0;
+        for (int64_t i = 0; i < n_reads; ++i) { const int64_t l = offsets[i + 1] - offsets[i]; RB_REQUIRE(l >= 0 && l < (1ll << 30), "rb_nbits_encode: bad length"); need += 4 + ((size_t)l + 3) / 4; }
+        *written = need;
+        if (!out) return RB_OK;                                          // size query
+        RB_REQUIRE(cap >= need, "rb_nbits_encode: buffer of %zu bytes, %zu needed", cap, need);
+        uint8_t *o = static_cast<uint8_t *>(out);
+        for (int64_t i = 0; i < n_reads; ++i) {
+            const char *s = seq + offsets[i];
+            const uint32_t l = (uint32_t)(offsets[i + 1] - offsets[i]);
+            *o++ = (uint8_t)(l >> 24); *o++ = (uint8_t)(l >> 16); *o++ = (uint8_t)(l >> 8); *o++ = (uint8_t)l;   // intToFourBytes: big endian
+            for (uint32_t q = 0; q < l; q += 4) {
+                uint32_t v = 0;
+                for (uint32_t j = 0; j < 4; ++j) {
+                    uint32_t code = 0;                                   // missing bases of the last byte are 0 (SeqBitsUtils.java:252-258)
+                    if (q + j < l) switch (s[q + j]) {
+                        case 'A': case 'a': code = 0; break;
+                        case 'C': case 'c': code = 1; break;
+                        case 'G': case 'g': code = 2; break;
+                        case 'T': case 't': case 'U': case 'u': code = 3; break;
+                        default:   // the reference writes a RANDOM base here (SeqBitsUtils.java:154-155): not reproducible
+                            RB_REQUIRE(false, "rb_nbits_encode: read %lld has a non-ACGTU base at %u (the .nbits format has no code for it)", (long long)i, q + j);
+                    }
+                    v = (v << 2) | code;
+                }
+                *o++ = (uint8_t)(v ^ 0x80u);                             // value - 128 as a signed byte
+            }
+        }
+        return RB_OK;
+    } catch (const HipError &e) { return e.code; }
+}
+
+}  // extern "C"

@@ -96,6 +96,9 @@ SYMBOLS = [
     ("rb_kmer_pair_hashes", _i32, [_i32, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     ("rb_minimizers_next", _i32, [_i32, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
     ("rb_minimizer_set", _i32, [_i32, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
+    ("rb_fastq_split", _i32, [_vp, _sz, _i32, _vp, _vp, _vp, _i64, C.POINTER(_i64)]),
+    ("rb_batch_create_nbits", _i32, [_i32, _vp, _sz, _i64, C.POINTER(_vp), C.POINTER(_sz)]),
+    ("rb_nbits_encode", _i32, [_vp, _vp, _i64, _vp, _sz, C.POINTER(_sz)]),
     ("rb_graph_create_shard", _i32, [C.POINTER(GraphParams), _i32, _i32, C.POINTER(_vp)]),
     ("rb_shard_set_cache_replication", _i32, [_vp, _i32]),
     ("rb_shard_hash", _i32, [_vp, _vp, _i64, _i64, _i64, _i64, _u64, _u32, C.c_uint, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(AddStats)]),

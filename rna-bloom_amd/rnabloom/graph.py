@@ -154,8 +154,8 @@ class BloomFilterDeBruijnGraph:
         check(lib.rb_graph_set_read_paired_kmer_distance(self.h, d)); self.readPairedKmersDistance = int(d)
     def setFragPairedKmerDistance(self, d):
         check(lib.rb_graph_set_frag_paired_kmer_distance(self.h, d)); self.fragmentPairedKmersDistance = int(d)
-    def getReadPairedKmerDistance(self): return getattr(self, "readPairedKmersDistance", 0)
-    def getFragPairedKmerDistance(self): return getattr(self, "fragmentPairedKmersDistance", 0)
+    def getReadPairedKmerDistance(self): return getattr(self, "readPairedKmersDistance", -1)     # :52-56: -1 until set
+    def getFragPairedKmerDistance(self): return getattr(self, "fragmentPairedKmersDistance", -1)
     def getDbgbfNumHash(self): return self.p.dbgbf_num_hash
     def getCbfNumHash(self): return self.p.cbf_num_hash
     def getPkbfNumHash(self): return self.p.pkbf_num_hash

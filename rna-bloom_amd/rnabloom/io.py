@@ -1,0 +1,56 @@
+"""Input formats of the reference at the C-ABI boundary: FASTQ text -> sequence / quality buffers
+(rnabloom.io.FastqReader: R/io/FastqReader.java:140-186, gzip through R/util/FileUtils.java:50-57) and .nbits 2-bit
+sequence files (R/io/NucleotideBitsReader.java / NucleotideBitsWriter.java).  Record splitting is the library's threaded
+splitter; 2-bit encoding, quality segmentation and the .nbits bit permutation run on the GPU."""
+import ctypes as C
+import gzip
+
+import numpy as np
+
+from . import _native as N
+from ._native import check, lib
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def splitFastq(text, threads=0, with_qual=True):
+    """FASTQ text (bytes / uint8 array) -> (seq uint8[], qual uint8[] or None, offsets int64[n+1])"""
+    t = np.frombuffer(text, np.uint8) if not isinstance(text, np.ndarray) else np.ascontiguousarray(text, np.uint8)
+    n = C.c_int64()
+    check(lib.rb_fastq_split(_ptr(t), t.size, threads, None, None, None, 0, C.byref(n)))
+    off = np.zeros(n.value + 1, np.int64)
+    seq = np.zeros(max(1, t.size), np.uint8)
+    qual = np.zeros(max(1, t.size), np.uint8) if with_qual else None
+    check(lib.rb_fastq_split(_ptr(t), t.size, threads, _ptr(seq), _ptr(qual), _ptr(off), n.value, C.byref(n)))
+    tot = int(off[-1])
+    return seq[:tot], (qual[:tot] if with_qual else None), off
+
+
+def readFastq(path, threads=0, with_qual=True):
+    """getTextFileReader + FastqReader over a whole file (.gz by extension, as FileUtils.getTextFileReader decides)"""
+    path = str(path)
+    with (gzip.open(path, "rb") if path.lower().endswith(".gz") else open(path, "rb")) as f:
+        return splitFastq(f.read(), threads, with_qual)
+
+
+def writeNbits(path, seq, offsets, append=False):
+    """NucleotideBitsWriter: 4-byte big-endian length + 2-bit bases (first base in the top bits, value - 128) per sequence"""
+    seq = np.ascontiguousarray(seq, np.uint8); off = np.ascontiguousarray(offsets, np.int64)
+    need = C.c_size_t()
+    check(lib.rb_nbits_encode(_ptr(seq), _ptr(off), off.size - 1, None, 0, C.byref(need)))
+    out = np.zeros(max(1, need.value), np.uint8)
+    check(lib.rb_nbits_encode(_ptr(seq), _ptr(off), off.size - 1, _ptr(out), out.size, C.byref(need)))
+    with open(str(path), "ab" if append else "wb") as f:
+        f.write(out[:need.value].tobytes())
+    return need.value
+
+
+def batchFromNbits(data, device=0, max_reads=-1):
+    """NucleotideBitsReader over a byte string -> ReadBatch on the device (decoded there); returns (batch, bytes consumed)"""
+    from .graph import ReadBatch
+    a = np.frombuffer(data, np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, np.uint8)
+    h = C.c_void_p(); used = C.c_size_t()
+    check(lib.rb_batch_create_nbits(device, _ptr(a), a.size, max_reads, C.byref(h), C.byref(used)))
+    return ReadBatch(h, device), used.value

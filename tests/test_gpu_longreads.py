@@ -185,3 +185,30 @@ def test_subsampler_hashing_halves(canonical):
     for i, sq in enumerate(reads):
         assert (ph[po[i]:po[i + 1]] == rbo.kmer_pair_hashes(sq, k, k + 1, canonical)).all()
     assert (pc == np.array([ocount(x) for x in ph], np.float32)).all()
+
+
+def test_nbits_files_decode_on_the_device_and_insert_like_ascii(tmp_path):
+    """.nbits (R/io/NucleotideBits{Reader,Writer}.java) -> packed batch by a GPU bit permute; same filters as from ASCII"""
+    from rnabloom import io as RIO
+    rng = np.random.default_rng(21)
+    reads = [bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), int(L)).tolist()) for L in list(range(0, 70)) + [150] * 40 + [999, 1000, 1001, 4097]]
+    seq, _, off = rbo.pack_reads(reads)
+    RIO.writeNbits(tmp_path / "r.nbits", seq, off)
+    data = (tmp_path / "r.nbits").read_bytes()
+    batch, used = RIO.batchFromNbits(data)
+    assert used == len(data) and batch.n_reads == len(reads)
+    s2, o2 = batch.download()
+    assert (o2 == off).all() and (s2 == seq).all()
+    # a truncated file: the last record is not returned (NucleotideBitsReader.next -> null), the rest is
+    b2, used2 = RIO.batchFromNbits(data[:-3])
+    assert b2.n_reads == len(reads) - 1 and used2 == len(data) - (4 + (4097 + 3) // 4)
+    b3, _ = RIO.batchFromNbits(data, max_reads=5)
+    assert b3.n_reads == 5
+    # insert from the .nbits batch == insert from ASCII
+    sizes = (600_011, 900_007, 64)
+    ga = G.BloomFilterDeBruijnGraph(*sizes, 2, 2, 1, 25, False, False, rngSeed=1)
+    gb = G.BloomFilterDeBruijnGraph(*sizes, 2, 2, 1, 25, False, False, rngSeed=1)
+    sa = ga.addReads(seq, None, off, 3)
+    sb = gb.addBatch(batch)
+    assert sa.kmers == sb.kmers > 10000
+    assert (ga.exportFilter(N.DBGBF) == gb.exportFilter(N.DBGBF)).all() and (ga.exportFilter(N.CBF) == gb.exportFilter(N.CBF)).all()
