@@ -1687,9 +1687,9 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
 }
 
 // upload n base hashes into a scratch buffer
-uint64_t *upload_h0(rb_graph *g, DevBuf &buf, const uint64_t *h0, size_t n) {
+uint64_t *upload_h0(rb_graph *g, DevBuf &buf, const uint64_t *h0, size_t n, hipStream_t st = nullptr) {
     buf.reserve(std::max<size_t>(n, 1) * 8);
-    RB_HIP(hipMemcpyAsync(buf.p, h0, n * 8, hipMemcpyHostToDevice, g->stream));
+    RB_HIP(hipMemcpyAsync(buf.p, h0, n * 8, hipMemcpyHostToDevice, st ? st : g->stream));
     return buf.as<uint64_t>();
 }
 
@@ -1788,6 +1788,12 @@ int rb_graph_destroy(rb_graph *g) {
                       &g->conf_sizes, &g->conf_off, &g->opk0, &g->opk1, &g->opv0, &g->opv1, &g->label, &g->kk0, &g->kk1, &g->biglist, &g->cvals, &g->foreign,  &g->devctr, &g->qbuf0,
                       &g->qbuf1, &g->qbuf2, &g->qbuf3};
     for (auto *b : bufs) b->release();
+    for (rb_query_ctx *c : g->qfree) {
+        c->b0.release(); c->b1.release(); c->b2.release(); c->b3.release();
+        if (c->st) (void)hipStreamDestroy(c->st);
+        delete c;
+    }
+    g->qfree.clear();
     if (g->ev0) (void)hipEventDestroy(g->ev0);
     if (g->ev1) (void)hipEventDestroy(g->ev1);
     if (g->stream) (void)hipStreamDestroy(g->stream);
@@ -1802,6 +1808,7 @@ int rb_graph_destroy(rb_graph *g) {
 int rb_graph_clear(rb_graph *g, unsigned which_mask) {
     return guarded([&] {
         RB_REQUIRE(g, "rb_graph_clear: null graph");
+        WriteLock wl(g->rw);
         RB_HIP(hipSetDevice(g->p.device));
         if ((which_mask & 1u) && g->dbg.bits) RB_HIP(hipMemsetAsync(g->dbg.bits, 0, g->dbg.alloc, g->stream));
         if ((which_mask & 2u) && g->cbf) RB_HIP(hipMemsetAsync(g->cbf, 0, g->cbf_alloc, g->stream));
@@ -1825,6 +1832,7 @@ int rb_graph_set_frag_paired_kmer_distance(rb_graph *g, int d) {
 int rb_graph_init_fragment_pairs(rb_graph *g, int64_t pkbf_bits, int pkbf_num_hash) {
     return guarded([&] {
         RB_REQUIRE(g && pkbf_bits > 0 && pkbf_num_hash >= 1 && pkbf_num_hash <= RB_MAX_HASH, "rb_graph_init_fragment_pairs: bad argument");
+        WriteLock wl(g->rw);
         RB_HIP(hipSetDevice(g->p.device));
         if (!g->fpk.bits) alloc_bits(g->fpk, pkbf_bits, pkbf_num_hash, 0, pkbf_bits);   // :352-359: create once, else empty()
         else { RB_HIP(hipMemset(g->fpk.bits, 0, g->fpk.alloc)); RB_HIP(hipDeviceSynchronize()); }
@@ -1842,6 +1850,7 @@ int rb_graph_set_op_ordinal(rb_graph *g, uint64_t v) {
 int rb_graph_add_batch_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigned flags, rb_add_stats *stats) {
     return guarded([&] {
         RB_REQUIRE(g && b, "rb_graph_add_batch: null argument");
+        WriteLock wl(g->rw);
         if (stats) memset(stats, 0, sizeof *stats);
         add_range(g, b, first, n, flags, stats);
     });
@@ -1850,6 +1859,7 @@ int rb_graph_add_batch_range(rb_graph *g, const rb_batch *b, int64_t first, int6
 int rb_graph_add_pairs(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, int which, unsigned flags, rb_add_stats *stats) {
     return guarded([&] {
         RB_REQUIRE(g && b, "rb_graph_add_pairs: null argument");
+        WriteLock wl(g->rw);
         RB_REQUIRE(!g->shard, "rb_graph_add_pairs: not available on a shard handle");
         RB_REQUIRE(b->device == g->p.device, "batch lives on device %d, graph on %d", b->device, g->p.device);
         RB_REQUIRE(first >= 0 && n >= 0 && first + n <= b->n_reads, "rb_graph_add_pairs: bad read range");
@@ -1880,6 +1890,7 @@ int rb_graph_add_pairs(rb_graph *g, const rb_batch *b, int64_t first, int64_t n,
 int rb_graph_add_fragments(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, int load_paired_kmers, rb_add_stats *stats) {
     return guarded([&] {
         RB_REQUIRE(g && b, "rb_graph_add_fragments: null argument");
+        WriteLock wl(g->rw);
         RB_REQUIRE(!g->shard, "rb_graph_add_fragments: not available on a shard handle");
         RB_REQUIRE(b->device == g->p.device, "batch lives on device %d, graph on %d", b->device, g->p.device);
         RB_REQUIRE(first >= 0 && n >= 0 && first + n <= b->n_reads, "rb_graph_add_fragments: bad read range");
@@ -1940,6 +1951,7 @@ int rb_graph_add_reads(rb_graph *g, const char *seq, const char *qual, const int
     rb::AsciiUpload up;
     hipStream_t st = nullptr;
     const char *pin_seq = nullptr, *pin_qual = nullptr;
+    WriteLock wl(g->rw);
     int rc = guarded([&] {
         RB_HIP(hipSetDevice(g->p.device));
         const int64_t base0 = n_reads ? offsets[0] : 0, nbases = n_reads ? offsets[n_reads] - base0 : 0;
@@ -2004,6 +2016,7 @@ int rb_graph_add_reads(rb_graph *g, const char *seq, const char *qual, const int
 int rb_graph_apply(rb_graph *g, int op, const uint64_t *h0, size_t n) {
     return guarded([&] {
         RB_REQUIRE(g && (h0 || n == 0), "rb_graph_apply: null argument");
+        WriteLock wl(g->rw);
         RB_REQUIRE(op >= RB_OP_ADD && op <= RB_OP_ADD_FRAG_PAIR, "rb_graph_apply: unknown op %d", op);
         RB_REQUIRE(!g->shard, "rb_graph_apply: not available on a shard handle");
         RB_HIP(hipSetDevice(g->p.device));
@@ -2045,19 +2058,21 @@ int rb_filter_lookup(rb_graph *g, int which, const uint64_t *h0, size_t n, uint8
         RB_REQUIRE(!g->shard, "rb_filter_lookup: queries are not available on a shard handle");
         if (!f->bits) { set_error("rb_filter_lookup: filter %d not initialised", which); throw HipError{RB_ERR_STATE}; }
         if (!n) return;
-        RB_HIP(hipSetDevice(g->p.device));
-        uint64_t *d = upload_h0(g, g->qbuf0, h0, n);
-        g->qbuf1.reserve(n);
-        hipLaunchKernelGGL(k_bits_lookup, dim3(blocks_for((int64_t)n)), dim3(TPB), 0, g->stream, f->bits, f->mod, f->num_hash,
-                           kmul_of(g->k), d, n, g->qbuf1.as<uint8_t>());
+        QueryLease q(g);
+        if (!f->bits) { set_error("rb_filter_lookup: filter %d not initialised", which); throw HipError{RB_ERR_STATE}; }
+        uint64_t *d = upload_h0(g, q.c->b0, h0, n, q.c->st);
+        q.c->b1.reserve(n);
+        hipLaunchKernelGGL(k_bits_lookup, dim3(blocks_for((int64_t)n)), dim3(TPB), 0, q.c->st, f->bits, f->mod, f->num_hash,
+                           kmul_of(g->k), d, n, q.c->b1.as<uint8_t>());
         RB_HIP(hipGetLastError());
-        RB_HIP(hipMemcpyAsync(out, g->qbuf1.p, n, hipMemcpyDeviceToHost, g->stream));
-        RB_HIP(hipStreamSynchronize(g->stream));
+        RB_HIP(hipMemcpyAsync(out, q.c->b1.p, n, hipMemcpyDeviceToHost, q.c->st));
+        RB_HIP(hipStreamSynchronize(q.c->st));
     });
 }
 int rb_filter_lookup_then_add(rb_graph *g, int which, const uint64_t *h0, size_t n, uint8_t *out) {
     return guarded([&] {
         RB_REQUIRE(g && (n == 0 || (h0 && out)), "rb_filter_lookup_then_add: null argument");
+        WriteLock wl(g->rw);
         BitFilter *f = bit_filter(g, which);
         RB_REQUIRE(f, "rb_filter_lookup_then_add: filter %d is not a bit filter", which);
         RB_REQUIRE(!g->shard, "rb_filter_lookup_then_add: not available on a shard handle");
@@ -2089,16 +2104,16 @@ static int count_common(rb_graph *g, const uint64_t *h0, size_t n, float *out, b
         RB_REQUIRE(g && (n == 0 || (h0 && out)), "rb_graph_count: null argument");
         RB_REQUIRE(!g->shard, "rb_graph_count: queries are not available on a shard handle");
         if (!n) return;
-        RB_HIP(hipSetDevice(g->p.device));
-        uint64_t *d = upload_h0(g, g->qbuf0, h0, n);
-        g->qbuf1.reserve(n * 4);
+        QueryLease q(g);
+        uint64_t *d = upload_h0(g, q.c->b0, h0, n, q.c->st);
+        q.c->b1.reserve(n * 4);
         RB_REQUIRE(g->cbf, "rb_filter_get_count: the counting filter has been destroyed");
         FilterView fv = g->view(0, 0, graph_level);
-        if (graph_level) hipLaunchKernelGGL(k_graph_count, dim3(blocks_for((int64_t)n)), dim3(TPB), 0, g->stream, fv, d, n, g->qbuf1.as<float>());
-        else hipLaunchKernelGGL(k_cbf_count, dim3(blocks_for((int64_t)n)), dim3(TPB), 0, g->stream, fv, d, n, g->qbuf1.as<float>());
+        if (graph_level) hipLaunchKernelGGL(k_graph_count, dim3(blocks_for((int64_t)n)), dim3(TPB), 0, q.c->st, fv, d, n, q.c->b1.as<float>());
+        else hipLaunchKernelGGL(k_cbf_count, dim3(blocks_for((int64_t)n)), dim3(TPB), 0, q.c->st, fv, d, n, q.c->b1.as<float>());
         RB_HIP(hipGetLastError());
-        RB_HIP(hipMemcpyAsync(out, g->qbuf1.p, n * 4, hipMemcpyDeviceToHost, g->stream));
-        RB_HIP(hipStreamSynchronize(g->stream));
+        RB_HIP(hipMemcpyAsync(out, q.c->b1.p, n * 4, hipMemcpyDeviceToHost, q.c->st));
+        RB_HIP(hipStreamSynchronize(q.c->st));
     });
 }
 }  // extern "C"
@@ -2130,18 +2145,19 @@ int rb_graph_kmers(rb_graph *g, const char *seq, const int64_t *offsets, int64_t
         int rc = rb_batch_create_ascii(g->p.device, seq, nullptr, offsets, n_reads, 0, &b);
         if (rc != RB_OK) throw HipError{rc};
         struct G { rb_batch *b; ~G() { rb_batch_destroy(b); } } guard{b};
-        RB_HIP(hipSetDevice(g->p.device));
-        g->qbuf0.reserve(((size_t)n_reads + 1) * 8); g->qbuf1.reserve((size_t)total * 8);
-        g->qbuf2.reserve((size_t)total * 8); g->qbuf3.reserve((size_t)total * 4);
-        RB_HIP(hipMemcpyAsync(g->qbuf0.p, koffsets, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, g->stream));
-        hipLaunchKernelGGL(k_get_kmers, dim3(blocks_for(b->n_words)), dim3(TPB), 0, g->stream, g->view(0, 0), (int)g->stranded,
-                           b->codes, b->valid, b->word_read, b->woff, b->len, b->n_words, g->k, g->qbuf0.as<int64_t>(),
-                           g->qbuf1.as<uint64_t>(), g->qbuf2.as<uint64_t>(), g->qbuf3.as<float>());
+        QueryLease q(g);
+        hipStream_t s = q.c->st;
+        q.c->b0.reserve(((size_t)n_reads + 1) * 8); q.c->b1.reserve((size_t)total * 8);
+        q.c->b2.reserve((size_t)total * 8); q.c->b3.reserve((size_t)total * 4);
+        RB_HIP(hipMemcpyAsync(q.c->b0.p, koffsets, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_get_kmers, dim3(blocks_for(b->n_words)), dim3(TPB), 0, s, g->view(0, 0), (int)g->stranded,
+                           b->codes, b->valid, b->word_read, b->woff, b->len, b->n_words, g->k, q.c->b0.as<int64_t>(),
+                           q.c->b1.as<uint64_t>(), q.c->b2.as<uint64_t>(), q.c->b3.as<float>());
         RB_HIP(hipGetLastError());
-        RB_HIP(hipMemcpyAsync(f, g->qbuf1.p, (size_t)total * 8, hipMemcpyDeviceToHost, g->stream));
-        if (r) RB_HIP(hipMemcpyAsync(r, g->qbuf2.p, (size_t)total * 8, hipMemcpyDeviceToHost, g->stream));
-        RB_HIP(hipMemcpyAsync(count, g->qbuf3.p, (size_t)total * 4, hipMemcpyDeviceToHost, g->stream));
-        RB_HIP(hipStreamSynchronize(g->stream));
+        RB_HIP(hipMemcpyAsync(f, q.c->b1.p, (size_t)total * 8, hipMemcpyDeviceToHost, s));
+        if (r) RB_HIP(hipMemcpyAsync(r, q.c->b2.p, (size_t)total * 8, hipMemcpyDeviceToHost, s));
+        RB_HIP(hipMemcpyAsync(count, q.c->b3.p, (size_t)total * 4, hipMemcpyDeviceToHost, s));
+        RB_HIP(hipStreamSynchronize(s));
     });
 }
 
@@ -2153,20 +2169,20 @@ int rb_graph_neighbors(rb_graph *g, const uint64_t *f, const uint64_t *r, const 
         RB_REQUIRE(direction >= 0 && direction <= 3, "rb_graph_neighbors: direction must be 0..3");
         RB_REQUIRE(!g->shard, "rb_graph_neighbors: queries are not available on a shard handle");
         if (!n) return;
-        RB_HIP(hipSetDevice(g->p.device));
-        hipStream_t s = g->stream;
-        g->qbuf0.reserve(n * 8 * 2 + n); g->qbuf1.reserve(n * 32); g->qbuf2.reserve(n * 32); g->qbuf3.reserve(n * 16);
-        uint64_t *df = g->qbuf0.as<uint64_t>(), *dr = df + n;
+        QueryLease q(g);
+        hipStream_t s = q.c->st;
+        q.c->b0.reserve(n * 8 * 2 + n); q.c->b1.reserve(n * 32); q.c->b2.reserve(n * 32); q.c->b3.reserve(n * 16);
+        uint64_t *df = q.c->b0.as<uint64_t>(), *dr = df + n;
         uint8_t *dc = reinterpret_cast<uint8_t *>(dr + n);
         RB_HIP(hipMemcpyAsync(df, f, n * 8, hipMemcpyHostToDevice, s));
         if (r) RB_HIP(hipMemcpyAsync(dr, r, n * 8, hipMemcpyHostToDevice, s));
         RB_HIP(hipMemcpyAsync(dc, char_out, n, hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(k_neighbors, dim3(blocks_for((int64_t)n * 4)), dim3(TPB), 0, s, g->view(0, 0), (int)g->stranded, g->k,
-                           direction, df, dr, dc, n, g->qbuf1.as<uint64_t>(), g->qbuf2.as<uint64_t>(), g->qbuf3.as<float>());
+                           direction, df, dr, dc, n, q.c->b1.as<uint64_t>(), q.c->b2.as<uint64_t>(), q.c->b3.as<float>());
         RB_HIP(hipGetLastError());
-        RB_HIP(hipMemcpyAsync(f4, g->qbuf1.p, n * 32, hipMemcpyDeviceToHost, s));
-        if (r4) RB_HIP(hipMemcpyAsync(r4, g->qbuf2.p, n * 32, hipMemcpyDeviceToHost, s));
-        RB_HIP(hipMemcpyAsync(count4, g->qbuf3.p, n * 16, hipMemcpyDeviceToHost, s));
+        RB_HIP(hipMemcpyAsync(f4, q.c->b1.p, n * 32, hipMemcpyDeviceToHost, s));
+        if (r4) RB_HIP(hipMemcpyAsync(r4, q.c->b2.p, n * 32, hipMemcpyDeviceToHost, s));
+        RB_HIP(hipMemcpyAsync(count4, q.c->b3.p, n * 16, hipMemcpyDeviceToHost, s));
         RB_HIP(hipStreamSynchronize(s));
     });
 }
@@ -2179,25 +2195,25 @@ int rb_graph_walk(rb_graph *g, const char *seeds, const char *targets, size_t n,
         RB_REQUIRE(bound >= 1 && bound <= (1 << 20), "rb_graph_walk: bound out of range [1, 2^20]");
         RB_REQUIRE(!g->shard, "rb_graph_walk: queries are not available on a shard handle");
         if (!n) return;
-        RB_HIP(hipSetDevice(g->p.device));
-        hipStream_t s = g->stream;
+        QueryLease q(g);
+        hipStream_t s = q.c->st;
         const size_t k = (size_t)g->k, nb = n * (size_t)bound, stride = k + (size_t)bound;
-        g->qbuf0.reserve(n * k * 2 + n * stride + nb + 64);     // seeds | targets | seq | appended bases
-        g->qbuf1.reserve(nb * 8); g->qbuf2.reserve(nb * 8); g->qbuf3.reserve(nb * 4 + n * 4 + n + 64);
-        uint8_t *dseed = g->qbuf0.as<uint8_t>(), *dtarget = dseed + n * k, *dseq = dtarget + n * k, *dbases = dseq + n * stride;
-        float *dc = g->qbuf3.as<float>();
+        q.c->b0.reserve(n * k * 2 + n * stride + nb + 64);     // seeds | targets | seq | appended bases
+        q.c->b1.reserve(nb * 8); q.c->b2.reserve(nb * 8); q.c->b3.reserve(nb * 4 + n * 4 + n + 64);
+        uint8_t *dseed = q.c->b0.as<uint8_t>(), *dtarget = dseed + n * k, *dseq = dtarget + n * k, *dbases = dseq + n * stride;
+        float *dc = q.c->b3.as<float>();
         int32_t *dlen = reinterpret_cast<int32_t *>(dc + nb);
         uint8_t *dreason = reinterpret_cast<uint8_t *>(dlen + n);
         RB_HIP(hipMemcpyAsync(dseed, seeds, n * k, hipMemcpyHostToDevice, s));
         if (targets) RB_HIP(hipMemcpyAsync(dtarget, targets, n * k, hipMemcpyHostToDevice, s));
         hipLaunchKernelGGL(k_walk_max_cov, dim3(blocks_for((int64_t)n, 64)), dim3(64), 0, s, g->view(0, 0), (int)g->stranded, g->k, direction,
-                           dseed, targets ? dtarget : (const uint8_t *)nullptr, n, bound, min_cov, dseq, dbases, g->qbuf1.as<uint64_t>(),
-                           g->qbuf2.as<uint64_t>(), dc, dlen, dreason);
+                           dseed, targets ? dtarget : (const uint8_t *)nullptr, n, bound, min_cov, dseq, dbases, q.c->b1.as<uint64_t>(),
+                           q.c->b2.as<uint64_t>(), dc, dlen, dreason);
         RB_HIP(hipGetLastError());
         RB_HIP(hipMemcpyAsync(out_len, dlen, n * 4, hipMemcpyDeviceToHost, s));
         RB_HIP(hipMemcpyAsync(out_reason, dreason, n, hipMemcpyDeviceToHost, s));
-        if (out_f) RB_HIP(hipMemcpyAsync(out_f, g->qbuf1.p, nb * 8, hipMemcpyDeviceToHost, s));
-        if (out_r) RB_HIP(hipMemcpyAsync(out_r, g->qbuf2.p, nb * 8, hipMemcpyDeviceToHost, s));
+        if (out_f) RB_HIP(hipMemcpyAsync(out_f, q.c->b1.p, nb * 8, hipMemcpyDeviceToHost, s));
+        if (out_r) RB_HIP(hipMemcpyAsync(out_r, q.c->b2.p, nb * 8, hipMemcpyDeviceToHost, s));
         if (out_count) RB_HIP(hipMemcpyAsync(out_count, dc, nb * 4, hipMemcpyDeviceToHost, s));
         RB_HIP(hipMemcpyAsync(out_bases, dbases, nb, hipMemcpyDeviceToHost, s));
         RB_HIP(hipStreamSynchronize(s));
@@ -2217,13 +2233,13 @@ int rb_graph_greedy_extend(rb_graph *g, const rb_graph *gate, const char *seeds,
         RB_REQUIRE(lookahead >= 0 && lookahead <= WALK_MAX_LOOKAHEAD, "rb_graph_greedy_extend: lookahead out of range [0, %d]", WALK_MAX_LOOKAHEAD);
         RB_REQUIRE(!g->shard, "rb_graph_greedy_extend: queries are not available on a shard handle");
         if (!n) return;
-        RB_HIP(hipSetDevice(g->p.device));
-        hipStream_t s = g->stream;
+        QueryLease q(g);
+        hipStream_t s = q.c->st;
         const size_t k = (size_t)g->k, nb = n * (size_t)bound, stride = k + (size_t)bound + (size_t)WALK_MAX_LOOKAHEAD + 1;
-        g->qbuf0.reserve(n * k + n * stride + nb + 64);          // seeds | seq | appended bases
-        g->qbuf3.reserve(nb * 4 + n * 4 + n + 64);
-        uint8_t *dseed = g->qbuf0.as<uint8_t>(), *dseq = dseed + n * k, *dbases = dseq + n * stride;
-        float *dc = g->qbuf3.as<float>();
+        q.c->b0.reserve(n * k + n * stride + nb + 64);          // seeds | seq | appended bases
+        q.c->b3.reserve(nb * 4 + n * 4 + n + 64);
+        uint8_t *dseed = q.c->b0.as<uint8_t>(), *dseq = dseed + n * k, *dbases = dseq + n * stride;
+        float *dc = q.c->b3.as<float>();
         int32_t *dlen = reinterpret_cast<int32_t *>(dc + nb);
         uint8_t *dreason = reinterpret_cast<uint8_t *>(dlen + n);
         RB_HIP(hipMemcpyAsync(dseed, seeds, n * k, hipMemcpyHostToDevice, s));
@@ -2260,6 +2276,7 @@ int rb_filter_size(rb_graph *g, int which, int64_t *size, int64_t *nbytes, int *
 int rb_filter_popcount(rb_graph *g, int which, int64_t *out) {
     return guarded([&] {
         RB_REQUIRE(g && out, "rb_filter_popcount: null argument");
+        WriteLock wl(g->rw);
         RB_HIP(hipSetDevice(g->p.device));
         g->devctr.reserve(DEVCTR_BYTES);
         unsigned long long *acc = reinterpret_cast<unsigned long long *>(g->devctr.as<uint32_t>() + 14);
@@ -2297,6 +2314,7 @@ int rb_filter_fpr(rb_graph *g, int which, float *out) {
 int rb_filter_export(rb_graph *g, int which, void *dst, size_t nbytes) {
     return guarded([&] {
         RB_REQUIRE(g && dst, "rb_filter_export: null argument");
+        WriteLock wl(g->rw);
         RB_HIP(hipSetDevice(g->p.device));
         const void *src; size_t have;
         if (which == RB_CBF) { src = g->cbf; have = (size_t)(g->cbf_hi - g->cbf_lo); }
@@ -2315,6 +2333,7 @@ int rb_filter_export(rb_graph *g, int which, void *dst, size_t nbytes) {
 int rb_filter_import(rb_graph *g, int which, const void *srcp, size_t nbytes) {
     return guarded([&] {
         RB_REQUIRE(g && srcp, "rb_filter_import: null argument");
+        WriteLock wl(g->rw);
         RB_HIP(hipSetDevice(g->p.device));
         void *dst; size_t have, alloc;
         if (which == RB_CBF) { dst = g->cbf; have = (size_t)(g->cbf_hi - g->cbf_lo); alloc = g->cbf_alloc; }
@@ -2364,6 +2383,7 @@ int rb_graph_profile_get(rb_graph *g, rb_profile *out, int reset) {
 int rb_graph_destroy_filter(rb_graph *g, int which) {
     return guarded([&] {
         RB_REQUIRE(g && !g->shard, "rb_graph_destroy_filter: null or shard handle");
+        WriteLock wl(g->rw);
         RB_HIP(hipSetDevice(g->p.device));
         RB_HIP(hipStreamSynchronize(g->stream)); RB_HIP(hipStreamSynchronize(g->stream2));
         if (which == RB_CBF) {
@@ -2380,6 +2400,7 @@ int rb_graph_destroy_filter(rb_graph *g, int which) {
 int rb_filter_increment_and_get(rb_graph *g, const uint64_t *h0, size_t n, float *out) {
     return guarded([&] {
         RB_REQUIRE(g && !g->shard && g->cbf && (n == 0 || (h0 && out)), "rb_filter_increment_and_get: bad argument or no counting filter");
+        WriteLock wl(g->rw);
         if (!n) return;
         RB_HIP(hipSetDevice(g->p.device));
         uint64_t *d = upload_h0(g, g->qbuf0, h0, n);
@@ -2395,7 +2416,10 @@ int rb_filter_increment_and_get(rb_graph *g, const uint64_t *h0, size_t n, float
 
 int rb_cbf_to_bloom(rb_graph *src, float min_cov, rb_graph *dst, int which) {
     return guarded([&] {
-        RB_REQUIRE(src && dst && !src->shard && !dst->shard && src->cbf, "rb_cbf_to_bloom: bad handles");
+        RB_REQUIRE(src && dst && !src->shard && !dst->shard, "rb_cbf_to_bloom: bad handles");
+        WriteLock l1(src < dst ? src->rw : dst->rw, std::defer_lock), l2(src < dst ? dst->rw : src->rw, std::defer_lock);
+        l1.lock(); if (src != dst) l2.lock();
+        RB_REQUIRE(src->cbf, "rb_cbf_to_bloom: the source has no counting filter");
         BitFilter *f = bit_filter(dst, which);
         RB_REQUIRE(f && f->bits, "rb_cbf_to_bloom: destination filter %d not initialised", which);
         RB_REQUIRE(f->size == src->cbf_size && src->p.device == dst->p.device, "rb_cbf_to_bloom: size (%lld vs %lld) or device mismatch",

@@ -4,7 +4,10 @@
 #include <string.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <mutex>
 #include <new>
+#include <shared_mutex>
 #include <vector>
 
 #include "rb_internal.hpp"
@@ -282,7 +285,21 @@ inline uint32_t log2_ceil(uint64_t x) { uint32_t l = 0; while ((1ull << l) < x) 
 // ------------------------------------------------------------------ graph object ----
 struct ShardState;
 using rb::BitFilter; using rb::FilterView; using rb::Mod; using rb::DevBuf; using rb::kmul_of;
+// Scratch + stream of one in-flight query.  The reference's stage-2 workers call contains / getCount / getKmers /
+// getSuccessors on ONE graph from T threads (R/RNABloom.java, e.g. :1984-2114), so every query call leases a context of
+// its own; inserts and everything else that changes a filter take the handle exclusively (rb_graph::rw).
+struct rb_query_ctx {
+    hipStream_t st = nullptr;
+    rb::DevBuf b0, b1, b2, b3;
+};
 struct rb_graph {
+    // one handle, many threads: queries share the handle (shared lock + a leased context each), mutators own it
+    std::shared_mutex rw;
+    std::mutex qm;
+    std::condition_variable qcv;
+    std::vector<rb_query_ctx *> qfree;
+    int qmade = 0;
+    static constexpr int kMaxQueryCtx = 32;
     // sharded mode (rb_shard.hip): this handle owns index range [lo,hi) of every filter
     int shard_rank = 0, shard_count = 1;
     ShardState *shard = nullptr;
@@ -386,6 +403,36 @@ struct rb_graph {
 
 
 namespace rb {
+// RAII: shared ownership of the handle + a query context (created on demand, at most kMaxQueryCtx per handle)
+struct QueryLease {
+    rb_graph *g;
+    rb_query_ctx *c = nullptr;
+    std::shared_lock<std::shared_mutex> lk;
+    explicit QueryLease(rb_graph *g_) : g(g_), lk(g_->rw) {
+        RB_HIP(hipSetDevice(g->p.device));
+        std::unique_lock<std::mutex> q(g->qm);
+        for (;;) {
+            if (!g->qfree.empty()) { c = g->qfree.back(); g->qfree.pop_back(); return; }
+            if (g->qmade < rb_graph::kMaxQueryCtx) {
+                ++g->qmade;
+                q.unlock();
+                c = new rb_query_ctx();
+                hipError_t e = hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking);
+                if (e != hipSuccess) { delete c; c = nullptr; q.lock(); --g->qmade; q.unlock(); RB_HIP(e); }
+                return;
+            }
+            g->qcv.wait(q);
+        }
+    }
+    ~QueryLease() {
+        if (!c) return;
+        { std::lock_guard<std::mutex> q(g->qm); g->qfree.push_back(c); }
+        g->qcv.notify_one();
+    }
+    QueryLease(const QueryLease &) = delete;
+    QueryLease &operator=(const QueryLease &) = delete;
+};
+using WriteLock = std::unique_lock<std::shared_mutex>;
 // sort + strengths + run-length encode of the N records in g->keys0/vals0 (rb_graph.hip)
 uint32_t group_records(rb_graph *g, size_t N, uint64_t ordinal0, uint32_t pos_bits, rb_add_stats *stats, uint32_t **ctr_out);
 // asynchronous halves of group_records: enqueue on `st` into slot `slot`; finish reads the run count

@@ -380,6 +380,7 @@ void counts_out(rb_graph *count_in, int device, DevBuf &d_oh, int64_t total, flo
     RB_REQUIRE(count_in->p.device == device, "count_in lives on device %d, the reads are hashed on %d", count_in->p.device, device);
     d_cnt.reserve((size_t)total * 4);
     RB_HIP(hipDeviceSynchronize());
+    std::shared_lock<std::shared_mutex> lk(count_in->rw);      // a query: may run beside other queries, not beside an insert
     cbf_counts_device(count_in, d_oh.as<uint64_t>(), (size_t)total, d_cnt.as<float>());
     RB_HIP(hipStreamSynchronize(count_in->stream));
     RB_HIP(hipMemcpy(out_count, d_cnt.p, (size_t)total * 4, hipMemcpyDeviceToHost));

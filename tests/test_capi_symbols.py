@@ -56,3 +56,49 @@ def test_expected_size_matches_reference_formula():
         f32 = C.c_float(fpr).value
         r = -h / math.log(1 - math.exp(math.log(f32) / h))
         assert N.lib.rb_expected_size(n, fpr, h) == math.ceil(n * r)
+
+
+# ---- the JNI layer as source (jni/rb_jni.c, java/rnabloom/graph/NativeGraph.java): no JDK in the image, so it is
+#      checked structurally and type-checked against the JNI declarations the shim uses ----
+def _jni_functions():
+    src = open(os.path.join(ROOT, "jni", "rb_jni.c")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    out = {}
+    for m in re.finditer(r"\bFN\((\w+)\)\s*\(", src):
+        depth, i = 0, src.index("{", m.end())
+        j = i
+        while True:
+            depth += src[j] == "{"; depth -= src[j] == "}"
+            j += 1
+            if depth == 0: break
+        out[m.group(1)] = src[i:j]
+    return out
+
+
+def test_every_native_method_has_a_jni_function_that_calls_the_c_abi():
+    java = open(os.path.join(ROOT, "java", "rnabloom", "graph", "NativeGraph.java")).read()
+    java = re.sub(r"/\*.*?\*/", "", java, flags=re.S)
+    natives = re.findall(r"public static native [\w\[\]]+ (\w+)\(", java)
+    fns = _jni_functions()
+    assert len(natives) >= 45 and sorted(natives) == sorted(fns), set(natives) ^ set(fns)
+    from rnabloom import _native as N
+    exported = {s[0] for s in N.SYMBOLS}
+    called = set()
+    for name, body in fns.items():
+        hits = set(re.findall(r"\b(rb_[a-z0-9_]+)\s*\(", body))
+        assert hits and hits <= exported, (name, hits - exported)
+        called |= hits
+    # everything a single-process host needs is reachable from Java (the rb_shard_* phases belong to the multi-GPU driver)
+    missing = {s for s in exported - called if not s.startswith("rb_shard_") and s not in (
+        "rb_last_error", "rb_graph_create_shard", "rb_graph_profile_enable", "rb_graph_profile_get", "rb_batch_create_synthetic",
+        "rb_batch_download_ascii", "rb_nthash_batch", "rb_graph_add_batch")}
+    assert not missing, missing
+
+
+def test_jni_shim_type_checks_against_the_jni_declarations_it_uses():
+    import shutil, subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc")
+    r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I" + os.path.join(ROOT, "tests", "jni_stub"),
+                        "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "jni", "rb_jni.c")], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
