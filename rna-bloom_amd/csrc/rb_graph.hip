@@ -582,13 +582,14 @@ __global__ void __launch_bounds__(64) k_conf_replay_big(FilterView fv, const uin
 //
 // Two kernels.  k_pairs_reads (below) is the one that runs for k <= 64 and reads of at most 384 bases: one
 // read per lane, both windows rolled side by side.  k_pairs_insert is the general one (any k, any read
-// length, one thread per 32-base word, windows hashed from scratch and then rolled); it is compiled
-// WITHOUT optimisation on purpose: the optimised build sets ~2 % of the pair bits at wrong positions,
-// differently from run to run, as soon as a SIMD holds more than one of its wavefronts (> 65536 threads;
-// found by tests/test_gpu_fullsize.py, pinned by tests/test_gpu_parity.py::test_read_pairs_at_scale).
-// -O1, a forced s_waitcnt 0 after every instruction, dropping __restrict__, returning atomics and other
-// launch shapes all change the error rate, none of them to zero; unoptimised it is exact and 25x slower,
-// which is acceptable for the configurations that still reach it.
+// length, one thread per 32-base word, windows hashed from scratch and then rolled).  Whether it sets bits or
+// collects bit indices (sharded engine) is a TEMPLATE parameter on purpose: with that choice made at run time
+// (`if (out_idx) ... else ...` inside the roll loop) hipcc 7.2's optimised gfx950 code set ~20 % of the pair bits of a
+// 200 000-read launch at wrong positions, differently from run to run, while the same source without the
+// never-taken branch — and every other restructuring of the loop — is exact (tools/pairs_variants.py is the
+// bisection: it rebuilds that kernel with -DRB_DIAG_PAIRS and counts the wrong bits; the unoptimised build was
+// exact too, which is how round 1 shipped it, 25x slower).  Both instantiations are covered at scale
+// (tests/test_gpu_parity.py::test_read_pairs_at_scale[general], tests/test_gpu_scale.py).
 // first unusable base at or after p (or L) — word-wise scan of the validity bits
 __device__ __forceinline__ uint32_t next_unusable(const uint32_t *__restrict__ vw, uint32_t p, uint32_t L) {
     while (p < L) {
@@ -598,8 +599,8 @@ __device__ __forceinline__ uint32_t next_unusable(const uint32_t *__restrict__ v
     }
     return L;
 }
-template <int MODE>
-__global__ void __attribute__((optnone)) k_pairs_insert(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
+template <int MODE, bool OUT>
+__global__ void k_pairs_insert(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
                                const uint32_t *__restrict__ word_read, const uint32_t *__restrict__ woff,
                                const uint32_t *__restrict__ len, int64_t w0, int64_t nw, int k, int dist,
                                uint32_t *bits, Mod mod, int num_hash, uint64_t kmul,
@@ -638,7 +639,7 @@ __global__ void __attribute__((optnone)) k_pairs_insert(const uint64_t *__restri
             if (MODE == 0) P = combine(fL, fR);                 // PairedNTHashIterator.java:69
             else if (MODE == 2) P = combine(rR, rL);            // ReverseComplementPaired… :44
             else P = smin(combine(fL, fR), combine(rR, rL));    // CanonicalPaired… :44 (signed min)
-            if (out_idx) {   // sharded engine: collect global bit indices instead of setting local bits
+            if (OUT) {       // sharded engine: collect global bit indices instead of setting local bits
                 for (int j = 0; j < num_hash; ++j)
                     out_idx[((size_t)chunk_off[i] + cnt) * (size_t)num_hash + j] = index_of(multi_hash(P, (uint32_t)j, kmul), mod);
             } else {
@@ -657,6 +658,64 @@ __global__ void __attribute__((optnone)) k_pairs_insert(const uint64_t *__restri
     }
     if (cnt && n_pairs) atomicAdd(n_pairs, (unsigned long long)cnt);
 }
+
+
+#ifdef RB_DIAG_PAIRS
+// The form that miscompiles (see above): identical to k_pairs_insert<1, false> except that the out_idx choice is a run-time
+// branch.  Only built with -DRB_DIAG_PAIRS, only launched by RB_PAIRS_VARIANT=9 (tools/pairs_variants.py).
+__global__ void k_pairs_insert_runtime_branch(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
+                               const uint32_t *__restrict__ word_read, const uint32_t *__restrict__ woff,
+                               const uint32_t *__restrict__ len, int64_t w0, int64_t nw, int k, int dist,
+                               uint32_t *bits, Mod mod, int num_hash, uint64_t kmul,
+                               unsigned long long *__restrict__ n_pairs,
+                               const uint32_t *__restrict__ chunk_off, uint64_t *__restrict__ out_idx,
+                               uint32_t wpr_uniform) {
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nw) return;
+    int64_t i = t;
+    if (wpr_uniform) { const int64_t nreads = nw / wpr_uniform; i = (t % nreads) * wpr_uniform + t / nreads; }
+    const int64_t w = w0 + i;
+    const uint32_t r = word_read[w], wr = woff[r], L = len[r];
+    const uint32_t b0 = (uint32_t)(w - wr) * 32u;
+    const uint32_t uk = (uint32_t)k, ud = (uint32_t)dist, span = uk + ud;
+    if ((uint64_t)b0 + span > L) return;
+    const uint32_t pe = (b0 + 32u < L - span + 1u) ? b0 + 32u : L - span + 1u;
+    const uint64_t *cw = codes + wr;
+    const uint32_t *vw = valid + wr;
+    auto code_at = [&](uint32_t b) { return (uint32_t)(cw[b >> 5] >> (2u * (b & 31u))) & 3u; };
+    uint32_t cnt = 0, p = b0;
+    while (p < pe) {
+        const uint32_t nz = next_unusable(vw, p, L);
+        if (nz < p + span) { p = nz + 1u; continue; }
+        const uint32_t plast = (pe - 1u < nz - span) ? pe - 1u : nz - span;
+        uint64_t fL = 0, rL = 0, fR = 0, rR = 0;
+        for (uint32_t q = 0; q < uk; ++q) {
+            const uint32_t cl = code_at(p + q), cr = code_at(p + ud + q);
+            fL = rotl(fL, 1) ^ seed_of(cl); rL ^= rotl(seed_of(3u - cl), q);
+            fR = rotl(fR, 1) ^ seed_of(cr); rR ^= rotl(seed_of(3u - cr), q);
+        }
+        for (;;) {
+            const uint64_t P = smin(combine(fL, fR), combine(rR, rL));
+            if (out_idx) {
+                for (int j = 0; j < num_hash; ++j)
+                    out_idx[((size_t)chunk_off[i] + cnt) * (size_t)num_hash + j] = index_of(multi_hash(P, (uint32_t)j, kmul), mod);
+            } else {
+                for (int j = 0; j < num_hash; ++j) bit_set(bits, index_of(multi_hash(P, (uint32_t)j, kmul), mod));
+            }
+            ++cnt;
+            if (p == plast) break;
+            const uint32_t ol = code_at(p), il = code_at(p + uk), orr = code_at(p + ud), ir = code_at(p + ud + uk);
+            fL = rotl(fL, 1) ^ rotl(seed_of(ol), uk) ^ seed_of(il);
+            rL = rotr(rL, 1) ^ rotr(seed_of(3u - ol), 1) ^ rotl(seed_of(3u - il), uk - 1u);
+            fR = rotl(fR, 1) ^ rotl(seed_of(orr), uk) ^ seed_of(ir);
+            rR = rotr(rR, 1) ^ rotr(seed_of(3u - orr), 1) ^ rotl(seed_of(3u - ir), uk - 1u);
+            ++p;
+        }
+        p = plast + 1u;
+    }
+    if (cnt && n_pairs) atomicAdd(n_pairs, (unsigned long long)cnt);
+}
+#endif
 
 // One read per lane (k <= 64, reads of <= 384 bases).  A pair (p, p + d) needs the window at p, the window at
 // p + d and no unusable base in [p, p + k + d).  The lane rolls the two windows side by side — the right one
@@ -1243,12 +1302,23 @@ void rb::launch_pairs(rb_graph *g, const rb_batch *b, int64_t w0, int64_t nw, in
         return;
     }
     dim3 gr(blocks_for(nw)), th(TPB);
+#ifdef RB_DIAG_PAIRS
+    if (getenv("RB_PAIRS_VARIANT") && atoi(getenv("RB_PAIRS_VARIANT")) == 9 && mode_hash == 1) {
+        hipLaunchKernelGGL(k_pairs_insert_runtime_branch, gr, th, 0, st, b->codes, b->valid, b->word_read, b->woff, b->len, w0, nw, g->k, g->read_d,
+                           g->rpk.bits, g->rpk.mod, g->rpk.num_hash, kmul_of(g->k), pc, chunk_off, out_idx,
+                           (b->wpr_uniform && nw % b->wpr_uniform == 0) ? b->wpr_uniform : 0u);
+        return;
+    }
+#endif
 #define RB_LAUNCH_PAIRS(M)                                                                                          \
-    hipLaunchKernelGGL(k_pairs_insert<M>, gr, th, 0, st, b->codes, b->valid, b->word_read, b->woff, b->len, w0, nw, \
+    if (out_idx) RB_LAUNCH_PAIRS2(M, true); else RB_LAUNCH_PAIRS2(M, false)
+#define RB_LAUNCH_PAIRS2(M, O)                                                                                      \
+    hipLaunchKernelGGL((k_pairs_insert<M, O>), gr, th, 0, st, b->codes, b->valid, b->word_read, b->woff, b->len, w0, nw, \
                        g->k, g->read_d, g->rpk.bits, g->rpk.mod, g->rpk.num_hash, kmul_of(g->k), pc, chunk_off, out_idx, \
                        (b->wpr_uniform && nw % b->wpr_uniform == 0) ? b->wpr_uniform : 0u)
-    if (mode_hash == 0) RB_LAUNCH_PAIRS(0); else if (mode_hash == 2) RB_LAUNCH_PAIRS(2); else RB_LAUNCH_PAIRS(1);
+    if (mode_hash == 0) { RB_LAUNCH_PAIRS(0); } else if (mode_hash == 2) { RB_LAUNCH_PAIRS(2); } else { RB_LAUNCH_PAIRS(1); }
 #undef RB_LAUNCH_PAIRS
+#undef RB_LAUNCH_PAIRS2
 }
 
 // Stable grouping of N (h0, occ) records sitting in keys0/vals0 into slot `slot`: sort on the top hash

@@ -119,8 +119,10 @@ def test_per_hash_operations_at_scale():
         g.destroy()
 
 
-@pytest.mark.parametrize("G,mode", [(2, "replicated"), (4, "split"), (8, "split")])
-def test_sharded_engine_at_scale(G, mode):
+@pytest.mark.parametrize("G,mode,general_pairs", [(2, "replicated", False), (4, "split", False), (8, "split", False), (2, "replicated", True), (4, "split", True)])
+def test_sharded_engine_at_scale(monkeypatch, G, mode, general_pairs):
+    if general_pairs:       # the general paired-k-mer kernel in its index-collecting instantiation (k_pairs_insert<M, true>)
+        monkeypatch.setenv("RB_PAIRS_GENERAL", "1")
     n = 200_000
     batch, seq, off = synthetic(n, seed=40 + G)
     og = rbo.Graph(BITS, BITS, BITS, 2, 2, 2, 25, False, True, 8)
