@@ -4,7 +4,7 @@ that hold at any size and that a wrong engine breaks:
 
   * sub-batch invariance: the engine is order-exact, so where the input is cut into sub-batches (2^30 or 2^28 records,
     with or without the cold-start ramp) cannot change a single bit or counter;
-  * engine invariance: the sharded engine (4 virtual ranks: routed probes, conflict components, replicated cache) must
+  * engine invariance: the sharded engine (8 virtual ranks: routed probes, conflict components, replicated cache) must
     produce the same three filters as the single-GPU engine;
   * idempotence of the Bloom bit sets: adding the same reads again leaves dbgbf and rpkbf unchanged (the counting
     filter moves on, and only upwards);
@@ -78,8 +78,8 @@ def test_config2_full_size_properties(monkeypatch):
         assert np.array_equal(gb.exportFilter(w), ref[w]), "filter %d depends on the sub-batch size" % w
     gb.destroy()
 
-    # engine invariance: 4 virtual ranks of the sharded engine
-    cl = sharded.LoopbackCluster(4, bits, bits, bits, 2, 2, 2, K, False, True, device=0, rngSeed=1)
+    # engine invariance: 8 virtual ranks of the sharded engine (the rank count of BASELINE configs 3 and 4)
+    cl = sharded.LoopbackCluster(8, bits, bits, bits, 2, 2, 2, K, False, True, device=0, rngSeed=1)
     cl.setReadPairedKmerDistance(150 - K - 10)
     cl.addBatch(batch, 150, reverseComplement=False, storeReadPairedKmers=True, first=0, n=PAIRS)
     cl.addBatch(batch, 150, reverseComplement=True, storeReadPairedKmers=True, first=PAIRS, n=PAIRS)
