@@ -44,8 +44,12 @@ def algorithmic_bytes(stage, n_kmers, n_pairs, n_runs, words, n_sorted=None, gro
         "filter_windows": words * (24 if sharded else 40) + (n_all * 128 * 2 // 11 if not sharded else n_all * SECTOR),
         # one-pass prefilter + emit: packed reads in (16 B/word), one 64 B cache sector per window, survivors out (12 B)
         "filter_emit": words * 16 + n_all * SECTOR + n_kmers * 12,
-        # 8-bit onesweep: one histogram read of the keys + per pass (8 B key + 4 B value) in and out
-        "sort_occurrences": n_kmers * (8 + passes * 2 * 12),
+        # grouping stage (csrc/rb_group.hip), per launch of each kernel: the histogram pass reads the 8-byte keys; a partition
+        # pass moves every 12-byte record in and out (two passes per sub-batch: the figure is per kernel launch set);
+        # the bucket kernel reads the records and writes occurrence (4 B) + strength (1 B) per record and 16 B per run
+        "group_part_count": n_kmers * 8 * 2,
+        "group_part_scatter": n_kmers * 24 * 2,
+        "group_buckets": n_kmers * (12 + 5) + n_runs * 16,
         # packed reads in (8 B codes + 4 B validity + 4 B owner per word), (h0, occurrence) out
         "hash_windows": words * (16 if sharded else 32) + n_kmers * 12,
         "count_windows": words * 12,
@@ -68,34 +72,33 @@ def algorithmic_bytes(stage, n_kmers, n_pairs, n_runs, words, n_sorted=None, gro
 # number of sub-batches (= dispatches of k_probe) — an upper bound, the conflict sorts add < 8 %.
 PMC_KERNELS = {"filter_windows": "rb::k_filter_reads", "hash_windows": "rb::k_hash_windows_resume",
                "probe_claim": "k_probe", "resolve_apply": "k_resolve_apply", "pairs_insert": "k_pairs_reads",
-               "sort_occurrences": "rocprim::radix_sort_onesweep(pairs)"}
+               "group_part_count": "rb::k_part_count", "group_part_scatter": "rb::k_part_scatter", "group_buckets": "rb::k_group_buckets"}
+PMC_FILES = ("r02_pmc_fetch_size.csv", "r02_pmc_write_size.csv")
+# Correction of FETCH_SIZE (MI355X_MICROARCH.md, HBM / rocprofv3 section: the counter tallies 128-byte requests of wide
+# coalesced streaming reads as 64 bytes; "other access widths are uncalibrated: calibrate on a known byte count in your
+# own access pattern").  Calibration committed in profiles/r02_pmc_calibration.txt: k_part_count reads exactly 8 bytes per
+# record in the 8-bytes-per-lane streaming pattern all grouping kernels use, and its FETCH_SIZE comes out at half of
+# that, so FETCH x 2 for the streaming kernels; the random-access kernels (one 64-byte request per lane access) x 1.
+FETCH_FACTOR = {"group_part_count": 2.0, "group_part_scatter": 2.0, "group_buckets": 2.0, "hash_windows": 2.0, "pairs_insert": 2.0}
 
 
 def pmc_traffic(stage):
-    """HBM bytes per launch of the stage's kernel(s) from the committed PMC summaries (None if absent).
-    The stage kernels here issue random 8-byte / 4-byte accesses = single 64 B requests, so the guide's
-    gfx950 x2 correction for 128 B streaming requests does not apply (calibrated against a known byte
-    count of this access pattern)."""
+    """HBM bytes per launch of the stage's kernel from the committed PMC summaries (None if absent): FETCH_SIZE (corrected
+    as the guide prescribes, see FETCH_FACTOR) + WRITE_SIZE, both in KB per dispatch in the summaries."""
     kern = PMC_KERNELS.get(stage)
     if not kern:
         return None
     tot = 0.0
-    for name in ("r01_final_pmc_fetch_size.csv", "r01_final_pmc_write_size.csv"):
+    for name in PMC_FILES:
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
             return None
         rows = [line.rsplit(",", 3) for line in open(path).read().splitlines()[1:]]
-        rows = [r for r in rows if len(r) == 4]
-        hit = [r for r in rows if r[0].startswith(kern)]
+        hit = [r for r in rows if len(r) == 4 and r[0].startswith(kern)]
         if not hit:
             return None
-        if stage == "sort_occurrences":
-            sub = [r for r in rows if r[0].startswith("k_probe")]
-            if not sub:
-                return None
-            tot += float(hit[0][2]) * 1024.0 / float(sub[0][1])
-        else:
-            tot += float(hit[0][3]) * 1024.0
+        per_dispatch = sum(float(r[2]) for r in hit) / sum(float(r[1]) for r in hit) * 1024.0
+        tot += per_dispatch * (FETCH_FACTOR.get(stage, 1.0) if "fetch" in name else 1.0)
     return tot or None
 
 
@@ -111,7 +114,7 @@ def parse():
     ap.add_argument("--fpr", type=float, default=0.01)
     ap.add_argument("--err", type=float, default=0.001)
     ap.add_argument("--batch-kmers", type=int, default=0)
-    ap.add_argument("--cpu-sample-pairs", type=int, default=8_000_000)
+    ap.add_argument("--cpu-sample-pairs", type=int, default=6_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-sharded", action="store_true", help="use the sharded engine + RCCL collectives even on 1 GPU")
     return ap.parse_args()
@@ -241,10 +244,11 @@ def main():
                 traffic = pmc_traffic(dom_name) if default_cfg else None      # the PMC passes profiled exactly this command
                 roof = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                        "traffic_source": "profiles/r01_final_pmc_{fetch,write}_size.csv (rocprofv3 --pmc passes of this command), bytes per launch" if traffic else None,
+                        "traffic_source": "profiles/r02_pmc_{fetch,write}_size.csv (separate rocprofv3 --pmc passes of this command), bytes per kernel launch, FETCH_SIZE x %.0f (calibration: profiles/r02_pmc_calibration.txt)" % FETCH_FACTOR.get(dom_name, 1.0) if traffic else None,
+                        "note": "dominant stage by HIP-event time on its own stream; achieved = model bytes / measured time, traffic = counters",
                         "algorithmic_bytes_per_launch": int(ab / dom_launches),
                         "avg_launch_ms": round(dom_ms / dom_launches, 3), "launches": dom_launches,
-                        "all_stages_GBps": per_stage}
+                        "all_stages_model_GBps": per_stage}
         out = {
             "metric": "k-mers/sec hashed+inserted into Bloom dBG (k=25, 50M 150bp reads)",
             "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -255,7 +259,11 @@ def main():
                        "pairs": pairs_total, "genome_bases": a.genome, "dbgbf_bits": dbg_bits, "cbf_bytes": cbf_bytes,
                        "rpkbf_bits": pk_bits, "kmers_per_step": kmers_all // a.steps,
                        "read_pairs_per_step": pairs_ins // a.steps, "distinct_per_step": distinct // a.steps, "sorted_kmers_per_step": n_sorted // a.steps,
-                       "conflict_ops_per_step": conflict // a.steps, "parallelism": ("single GPU" if not sharded_mode else "filters index-sharded x%d, k-mers hash-sharded (%s mode), %s all_to_all"
+                       "conflict_ops_per_step": conflict // a.steps,
+                       "mean_kmer_coverage": round(kmers_all / a.steps / max(1, a.genome), 1),
+                       "prefilter_survival": round(n_sorted / max(1, kmers), 4),
+                       "note": "throughput depends on the coverage: the no-op prefilter drops occurrences that provably cannot change a counter (here all but the survival fraction); at low coverage or k > 64 the same engine sorts every occurrence (DESIGN.md s5)",
+                       "parallelism": ("single GPU" if not sharded_mode else "filters index-sharded x%d, k-mers hash-sharded (%s mode), %s all_to_all"
                                        % (world, sr.mode, "RCCL" if backend == "nccl" else backend))},
             "stages_ms_per_step": {n: round(v[0] / a.steps, 2) for n, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
             "roofline": roof,
@@ -292,37 +300,51 @@ def prof_(sr, reset):
 
 
 def cpu_baseline(a, batch, dbg_bits, cbf_bytes, pk_bits, dist_pk):
-    """The oracle (C restatement of the reference's FastqToGraphWorker loop, T threads pulling reads
-    under one lock, non-atomic byte RMW) on a bounded sample of the SAME reads and filter sizes."""
+    """The oracle (C restatement of the reference's FastqToGraphWorker loop: T threads pulling reads under one lock,
+    non-atomic byte RMW) on bounded samples of the SAME reads and filter sizes.  Three timings, every one on
+    full-size filters (no cache-resident sweep): T = all useful threads and T = 8 with the reads in memory, and T = best
+    from FASTQ text through the reader lock (what `-stage 1` would time)."""
     import numpy as np
     from oracle import rbo
-    n = min(a.cpu_sample_pairs, batch.n_reads // 2)
     ncpu = os.cpu_count() or 1
+    n = min(a.cpu_sample_pairs, batch.n_reads // 2)
     seq, off = batch.download(0, n)
     og = rbo.Graph(dbg_bits, cbf_bytes, pk_bits, 2, 2, 2, a.k, False, True, 1)
     og.set_read_pair_distance(dist_pk)
-    # the reference's workers serialise on one reader lock, so more threads is not always faster:
-    # probe a few thread counts on a small slice and time the full sample with the best one
-    probe_n = max(1, min(n // 8, 50_000))
-    cands = sorted({t for t in (8, 16, 32, 64, ncpu) if t <= ncpu})
-    best_t, best_rate, sweep = cands[0], 0.0, {}
-    for t in cands:
+
+    def timed(nreads, threads):
         og.clear()
         t0 = time.perf_counter()
-        st = og.add_reads(seq[: off[probe_n]], None, off[: probe_n + 1], 3, rbo.STORE_READ_PAIRS, threads=t)
-        rate = st.kmers / (time.perf_counter() - t0)
-        sweep[t] = round(rate / 1e6, 2)
-        if rate > best_rate:
-            best_t, best_rate = t, rate
+        st = og.add_reads(seq[: off[nreads]], None, off[: nreads + 1], 3, rbo.STORE_READ_PAIRS, threads=threads)
+        dt = time.perf_counter() - t0
+        return st.kmers / dt, st.kmers, dt
+
+    # the reference's workers serialise on one reader lock, so more threads is not always faster: 1/8 of the sample per candidate
+    cands = sorted({t for t in (16, 32, 64, 128, ncpu) if t <= ncpu} | {min(8, ncpu)})
+    sweep = {t: timed(max(1, n // 8), t)[0] for t in cands}
+    best_t = max(sweep, key=sweep.get)
+    best_rate, best_kmers, best_dt = timed(n, best_t)
+    t8_rate, _, t8_dt = timed(max(1, n // 2), min(8, ncpu))
+    # with parsing: FASTQ text of a quarter of the sample (qualities 'I': the synthetic batch carries usable flags, not PHRED)
+    m = max(1, n // 4)
+    L = int(off[1] - off[0])
+    rec = np.empty((m, 2 * L + 16), np.uint8)
+    rec[:, :10] = np.frombuffer(b"@r" + b"0" * 8, np.uint8); rec[:, 10] = 10
+    rec[:, 11:11 + L] = seq[: m * L].reshape(m, L); rec[:, 11 + L] = 10
+    rec[:, 12 + L] = ord("+"); rec[:, 13 + L] = 10
+    rec[:, 14 + L:14 + 2 * L] = ord("I"); rec[:, 14 + 2 * L] = 10
+    text = np.ascontiguousarray(rec[:, :15 + 2 * L]).reshape(-1)
     og.clear()
     t0 = time.perf_counter()
-    st = og.add_reads(seq, None, off, 3, rbo.STORE_READ_PAIRS, threads=best_t)
-    dt = time.perf_counter() - t0
-    return {"value": st.kmers / dt, "unit": "k-mers/s", "cores": best_t, "kind": "port", "host_cpus": ncpu,
-            "thread_sweep_Mkmers_per_s": sweep,
-            "sample": "first %d left reads of the same synthetic set (%d k-mers + read pairs), same filter sizes, "
-                      "%.1f s with the best of the probed thread counts; C restatement of the reference's "
-                      "FastqToGraphWorker loop (no JVM in the image)" % (n, st.kmers, dt)}
+    stp = og.add_fastq(text, L, 3, rbo.STORE_READ_PAIRS, threads=best_t)
+    parse_dt = time.perf_counter() - t0
+    return {"value": best_rate, "unit": "k-mers/s", "cores": best_t, "kind": "port", "host_cpus": ncpu,
+            "t8_value": t8_rate, "with_fastq_parsing_value": stp.kmers / parse_dt,
+            "thread_sweep_Mkmers_per_s": {t: round(r / 1e6, 2) for t, r in sweep.items()},
+            "sample": "first %d left reads of the same synthetic set (%d k-mers + read pairs) at the best of the probed thread counts (%.1f s); "
+                      "T = 8 on half of them (%.1f s); from FASTQ text under the reader lock on a quarter (%.1f s); the thread sweep uses an eighth per "
+                      "candidate; all on the full-size filters; C restatement of the reference's FastqToGraphWorker loop (no JVM in the image)"
+                      % (n, best_kmers, best_dt, t8_dt, parse_dt)}
 
 
 if __name__ == "__main__":

@@ -214,6 +214,19 @@ int rb_graph_walk(rb_graph *g, const char *seeds, const char *targets, size_t n,
  * its count is read) — another handle on the same device, same k, whose dbgbf is that filter. */
 int rb_graph_greedy_extend(rb_graph *g, const rb_graph *gate, const char *seeds, size_t n, int direction, int lookahead, int bound,
                            char *out_bases, float *out_count, int32_t *out_len, uint8_t *out_reason);
+/* GraphUtils.naiveExtendRight / naiveExtendLeft R/util/GraphUtils.java:6780-7112, one walk per seed k-mer (n seeds of k
+ * bases): follow the only neighbour with count >= min_cov while the walk is unbranched.  mode 0 = the forms with a
+ * terminator set (:6780-6833, :6959-7012): every k-mer of the walk's terminator sequence term_seq[term_off[i], term_off[i+1])
+ * stops it, and so does a k-mer it added before; `cap` = room for added bases per walk (these forms have no bound; a walk
+ * that fills it reports reason 6 and can be continued from its last k-mer).  mode 1 = the bounded forms (:6835-6886,
+ * :7014-7065), mode 2 = naiveExtend{Right,Left}NoBackChecks (:6888-6933, :7067-7112); both write up to bound + 1 bases per
+ * walk (out_bases is n * (bound + 1)).  maxTipLength does not appear: it only feeds Kmer.hasDepthLeft / hasDepthRight,
+ * which never consult the graph and always return true (R/graph/Kmer.java:407-486).
+ * out_reason: 0 no neighbour, 1 back branch (a variant of the current k-mer in the base about to leave exists), 2 several
+ * neighbours, 3 bound, 4 seed with a base outside ACGTU, 5 terminator / already-added k-mer, 6 capacity, 7 the candidate
+ * repeats the seed or the k-mer added last (mode 2). */
+int rb_graph_naive_extend(rb_graph *g, const char *seeds, size_t n, int direction, int mode, int bound, int cap, float min_cov,
+                          const char *term_seq, const int64_t *term_off, char *out_bases, int32_t *out_len, uint8_t *out_reason);
 
 /* ---- filter state: popcount / FPR / raw bytes (the on-disk format of
  *      R/bloom/BloomFilter.java:113-124 is exactly these bytes,

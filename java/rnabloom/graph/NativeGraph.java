@@ -70,6 +70,10 @@ public final class NativeGraph {
     public static native void greedyExtend(long h, long gateHandleOr0, byte[] seeds, int n, int direction, int lookahead, int bound,
                                            byte[] outBases, float[] outCount, int[] outLen, byte[] outReason);
 
+    /** GraphUtils.naiveExtendRight / Left for n seeds: mode 0 terminator forms (termSeq / termOff, capacity cap), 1 bounded, 2 NoBackChecks. */
+    public static native void naiveExtend(long h, byte[] seeds, int n, int direction, int mode, int bound, int cap, float minKmerCov,
+                                          byte[] termSeq, long[] termOff, byte[] outBases, int[] outLen, byte[] outReason);
+
     // ---- filter state ----
     /** {size, bytes, numHash} */
     public static native long[] filterSize(long h, int which);

@@ -227,6 +227,18 @@ void FN(greedyExtend)(JNIEnv *e, jclass c, jlong h, jlong gate, jbyteArray seeds
     if (rc) throw_rc(e, rc);
 }
 
+void FN(naiveExtend)(JNIEnv *e, jclass c, jlong h, jbyteArray seeds, jint n, jint direction, jint mode, jint bound, jint cap, jfloat min_cov,
+                     jbyteArray term_seq, jlongArray term_off, jbyteArray out_bases, jintArray out_len, jbyteArray out_reason) {
+    jbyte *ps = ba(e, seeds), *pt = ba(e, term_seq), *ob = ba(e, out_bases), *orr = ba(e, out_reason);
+    jlong *po = la(e, term_off);
+    jint *ol = ia(e, out_len);
+    (void)c;
+    int rc = rb_graph_naive_extend(G(h), (const char *)ps, (size_t)n, direction, mode, bound, cap, min_cov, (const char *)pt, (const int64_t *)po, (char *)ob,
+                                   (int32_t *)ol, (uint8_t *)orr);
+    br(e, seeds, ps, JNI_ABORT); br(e, term_seq, pt, JNI_ABORT); lr(e, term_off, po, JNI_ABORT); br(e, out_bases, ob, 0); br(e, out_reason, orr, 0); ir(e, out_len, ol, 0);
+    if (rc) throw_rc(e, rc);
+}
+
 /* ---- filter state ---- */
 jlongArray FN(filterSize)(JNIEnv *e, jclass c, jlong h, jint which) {
     int64_t size = 0, nbytes = 0;

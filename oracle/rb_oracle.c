@@ -551,6 +551,67 @@ void rbo_graph_add_reads_mt(rbo_graph *g, const char *seq, const char *qual,
     g->ordinal += (uint64_t)n_reads;
     if (out) *out = w.st;
 }
+/* The same workers fed from FASTQ TEXT: the reader half of stage 1.  FastqReader.nextWithoutName is one synchronized block
+ * that pulls four lines (R/io/FastqReader.java:140-149), so T workers take turns parsing a record under the lock and hash /
+ * insert it outside — what `-stage 1` times on top of the in-memory loop above ("Parsed ... sequences", R/RNABloom.java:1243). */
+typedef struct {
+    rbo_graph *g; const char *text; int64_t len, pos, next; int min_q; unsigned flags; uint64_t base_ordinal; int64_t max_line;
+    pthread_mutex_t mu; rbo_add_stats st;
+} fq_work_t;
+static int64_t fq_line(const char *t, int64_t len, int64_t *pos, const char **start) {   /* one line; -1 at end of text */
+    int64_t p = *pos;
+    if (p >= len) return -1;
+    const char *nl = (const char *)memchr(t + p, '\n', (size_t)(len - p));
+    int64_t e = nl ? (int64_t)(nl - t) : len;
+    *start = t + p;
+    *pos = e + 1;
+    int64_t l = e - p;
+    if (l > 0 && t[e - 1] == '\r') --l;
+    return l;
+}
+static void *fq_worker_main(void *arg) {
+    fq_work_t *w = (fq_work_t *)arg;
+    rbo_graph *g = w->g;
+    int64_t maxlen = w->max_line;
+    uint64_t *hbuf = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(maxlen + 1) * (size_t)g->max_h);
+    uint64_t *pbuf = (uint64_t *)malloc(sizeof(uint64_t) * (size_t)(maxlen + 1) * (size_t)(g->pk_h > 0 ? g->pk_h : 1));
+    int64_t segcap = maxlen / (g->k > 0 ? g->k : 1) + 2;
+    int64_t *segbuf = (int64_t *)malloc(sizeof(int64_t) * 2 * (size_t)segcap);
+    rbo_add_stats st; memset(&st, 0, sizeof st);
+    for (;;) {
+        const char *l1, *sq, *l3, *ql;
+        pthread_mutex_lock(&w->mu);
+        int64_t n1 = fq_line(w->text, w->len, &w->pos, &l1), ns = fq_line(w->text, w->len, &w->pos, &sq);
+        int64_t n3 = fq_line(w->text, w->len, &w->pos, &l3), nq = fq_line(w->text, w->len, &w->pos, &ql);
+        int64_t i = w->next++;
+        pthread_mutex_unlock(&w->mu);
+        if (n1 < 0 || ns < 0 || n3 < 0 || nq < 0) break;                  /* NoSuchElementException -> null */
+        if (n1 < 1 || l1[0] != '@' || n3 < 1 || l3[0] != '+' || nq != ns || ns > maxlen) break;   /* FileFormatException */
+        process_read(g, sq, ql, ns, w->min_q, w->flags, w->base_ordinal + (uint64_t)i, &st, hbuf, pbuf, segbuf, segcap);
+    }
+    pthread_mutex_lock(&w->mu);
+    w->st.reads += st.reads; w->st.reads_skipped += st.reads_skipped; w->st.segments += st.segments;
+    w->st.kmers += st.kmers; w->st.pairs += st.pairs;
+    pthread_mutex_unlock(&w->mu);
+    free(hbuf); free(pbuf); free(segbuf);
+    return NULL;
+}
+void rbo_graph_add_fastq_mt(rbo_graph *g, const char *text, int64_t len, int64_t max_read_len, int min_base_qual, unsigned flags, int threads,
+                            rbo_add_stats *out) {
+    fq_work_t w; memset(&w, 0, sizeof w);
+    w.g = g; w.text = text; w.len = len; w.min_q = min_base_qual; w.flags = flags; w.base_ordinal = g->ordinal; w.max_line = max_read_len;
+    pthread_mutex_init(&w.mu, NULL);
+    if (threads <= 1) fq_worker_main(&w);
+    else {
+        pthread_t *t = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)threads);
+        for (int i = 0; i < threads; ++i) pthread_create(&t[i], NULL, fq_worker_main, &w);
+        for (int i = 0; i < threads; ++i) pthread_join(t[i], NULL);
+        free(t);
+    }
+    pthread_mutex_destroy(&w.mu);
+    g->ordinal += (uint64_t)w.st.reads + (uint64_t)w.st.reads_skipped;
+    if (out) *out = w.st;
+}
 void rbo_graph_add_reads(rbo_graph *g, const char *seq, const char *qual, const int64_t *offsets,
                          int64_t n_reads, int min_base_qual, unsigned flags, rbo_add_stats *st) {
     rbo_graph_add_reads_mt(g, seq, qual, offsets, n_reads, min_base_qual, flags, 1, st);

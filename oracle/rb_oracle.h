@@ -139,6 +139,9 @@ void rbo_graph_add_reads(rbo_graph *, const char *seq, const char *qual, const i
 void rbo_graph_add_reads_mt(rbo_graph *, const char *seq, const char *qual,
                             const int64_t *offsets, int64_t n_reads, int min_base_qual,
                             unsigned flags, int threads, rbo_add_stats *st);
+/* the same from FASTQ text under the reader lock (R/io/FastqReader.java:140-149): the with-parsing CPU baseline */
+void rbo_graph_add_fastq_mt(rbo_graph *g, const char *text, int64_t len, int64_t max_read_len, int min_base_qual, unsigned flags, int threads,
+                            rbo_add_stats *out);
 /* segmentation only: writes [start,end) pairs; returns number of segments (cap = max pairs) */
 int64_t rbo_segments(const char *seq, const char *qual, int64_t len, int k, int min_base_qual,
                      int64_t *out_se, int64_t cap);

@@ -103,6 +103,7 @@ def lib():
         sig("rbo_graph_" + n, vp, vp)
     sig("rbo_graph_add_reads", None, vp, vp, vp, vp, i64, i32, C.c_uint, vp)
     sig("rbo_graph_add_reads_mt", None, vp, vp, vp, vp, i64, i32, C.c_uint, i32, vp)
+    sig("rbo_graph_add_fastq_mt", None, vp, vp, i64, i64, i32, C.c_uint, i32, vp)
     sig("rbo_segments", i64, vp, vp, i64, i32, i32, vp, i64)
     sig("rbo_graph_get_kmers", i64, vp, vp, i64, vp, vp, vp)
     sig("rbo_graph_neighbors", None, vp, u64, u64, C.c_uint, i32, vp, vp, vp)
@@ -330,6 +331,12 @@ class Graph:
                                       threads, C.byref(st))
         return st
 
+    def add_fastq(self, text, max_read_len, min_q=3, flags=0, threads=1):
+        """FASTQ text (uint8 array) through the reader lock + workers; ordinals follow the order records were pulled"""
+        st = AddStats()
+        self.L.rbo_graph_add_fastq_mt(self.g, _p(text), text.size, max_read_len, min_q, flags, threads, C.byref(st))
+        return st
+
     def _bloom_bytes(self, which):
         b = getattr(self.L, "rbo_graph_" + which)(self.g)
         if not b:
@@ -550,6 +557,65 @@ def greedy_extend(og, source, direction, lookahead, bound, k=25, gate=None, stra
         out += nxt[0][-1:] if direction == 0 else nxt[0][:1]
         counts.append(nxt[1])
     return bytes(out), counts
+
+
+def naive_extend(og, seed, direction, mode, bound=0, min_cov=1.0, terminators=b"", k=25, cap=4096):
+    """GraphUtils.naiveExtendRight / naiveExtendLeft restated statement by statement over the oracle graph, with k-mers as
+    byte strings and every count taken from get_kmers of the k-mer STRING (no rolling): R/util/GraphUtils.java:6780-6833
+    (terminators, mode 0), :6835-6886 (bounded, mode 1), :6888-6933 (NoBackChecks, mode 2) and their Left twins.
+    Kmer.hasDepthLeft / hasDepthRight always return true (R/graph/Kmer.java:407-486).  Returns (appended bases, reason)."""
+    seed = _b(seed).upper().replace(b"U", b"T")
+    if len(seed) != k or any(c not in b"ACGT" for c in seed):
+        return b"", 4
+
+    def count(km):
+        return float(og.get_kmers(km)[2][0])
+
+    def neighbours(km):          # getSuccessors / getPredecessors(k, numHash, graph, result, minKmerCov): A,C,G,T order
+        out = []
+        for c in b"ACGT":
+            nb = km[1:] + bytes([c]) if direction == 0 else bytes([c]) + km[:-1]
+            if count(nb) >= min_cov:
+                out.append(nb)
+        return out
+
+    def back_variants(km):       # getLeftVariants (right walk) / getRightVariants (left walk), minKmerCov = 1
+        pos = 0 if direction == 0 else k - 1
+        return [km[:pos] + bytes([c]) + km[pos + 1:] for c in b"ACGT" if c != km[pos] and count(km[:pos] + bytes([c]) + km[pos + 1:]) >= 1]
+
+    terms = set()
+    t = _b(terminators).upper().replace(b"U", b"T")
+    for p in range(len(t) - k + 1):
+        terms.add(t[p:p + k])
+    used, result, length = set(), [], 0
+    nbrs = neighbours(seed)
+    best = seed
+    while nbrs:
+        if mode != 2 and back_variants(best):
+            return _join(result, direction), 1
+        if len(nbrs) == 1:
+            cand = nbrs.pop()
+        else:
+            return _join(result, direction), 2        # hasDepth* is true for every neighbour: the second one ends the walk
+        if mode == 0:
+            if cand in terms or cand in used:
+                return _join(result, direction), 5
+            if len(result) >= cap:
+                return _join(result, direction), 6
+        if mode == 2 and (cand == seed or (result and cand == result[-1])):
+            return _join(result, direction), 7
+        best = cand
+        result.append(best); used.add(best)
+        if mode != 0:
+            length += 1
+            if length > bound:
+                return _join(result, direction), 3
+        nbrs = neighbours(best)
+    return _join(result, direction), 0
+
+
+def _join(kmers, direction):
+    return bytes(km[-1] if direction == 0 else km[0] for km in kmers)
 
 
 def get_kmers_min_coverage(og, seq, min_cov):

@@ -111,6 +111,78 @@ __global__ void k_probe(FilterView fv, const uint64_t *__restrict__ uniq, const 
         atomicAdd(&counters[16 + 16 * (blockIdx.x & 31u)], n_foreign);   // 32 spread counters
     }
 }
+// The same stage for the common filter shape (2 hash functions each, no full first-setter table), written for memory-level
+// parallelism: a lane takes RUNS runs, computes all their indices, issues ALL Bloom-bit loads, then ALL counter claims
+// (returning atomics), and only then consumes the answers — 2 dependent round trips per lane instead of 4 per run
+// (k_probe spent 71 % of its wave cycles waiting, profiles/r01_sq_counters).  Semantics are k_probe's, line for line.
+template <int RUNS>
+__global__ void __launch_bounds__(256) k_probe_h2(FilterView fv, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ counts,
+                                                   uint32_t n_distinct, int mode, uint32_t *__restrict__ status, uint64_t *__restrict__ cvals,
+                                                   uint64_t *__restrict__ foreign_idx, uint32_t *__restrict__ counters) {
+    const uint32_t d0 = (blockIdx.x * blockDim.x + threadIdx.x) * RUNS;
+    uint64_t h0[RUNS], bi[RUNS][2], ci[RUNS][2];
+    uint32_t cnt[RUNS], w[RUNS][2];
+    bool live[RUNS];
+#pragma unroll
+    for (int r = 0; r < RUNS; ++r) {
+        live[r] = d0 + r < n_distinct;
+        h0[r] = live[r] ? uniq[d0 + r] : 0ull;
+        cnt[r] = live[r] ? counts[d0 + r] : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < RUNS; ++r) {
+        const uint64_t h1 = multi_hash(h0[r], 1u, fv.kmul);
+        bi[r][0] = index_of(h0[r], fv.dbg_mod); bi[r][1] = index_of(h1, fv.dbg_mod);
+        ci[r][0] = index_of(h0[r], fv.cbf_mod); ci[r][1] = index_of(h1, fv.cbf_mod);
+    }
+    if (mode != M_COUNT_ONLY) {
+#pragma unroll
+        for (int r = 0; r < RUNS; ++r) {                      // all bit loads in flight together
+            w[r][0] = live[r] ? fv.dbg[bi[r][0] >> 5] : 0u;
+            w[r][1] = live[r] ? fv.dbg[bi[r][1] >> 5] : 0u;
+        }
+    }
+    uint32_t st[RUNS];
+    bool claim[RUNS], dup[RUNS];
+#pragma unroll
+    for (int r = 0; r < RUNS; ++r) {
+        uint32_t premask = 0, all = 1;
+        if (mode != M_COUNT_ONLY) {
+            if ((w[r][0] >> (uint32_t)(bi[r][0] & 31u)) & 1u) premask |= 1u; else all = 0;
+            if ((w[r][1] >> (uint32_t)(bi[r][1] & 31u)) & 1u) premask |= 2u; else all = 0;
+        }
+        st[r] = premask | (all ? ST_ALLPRE : 0u);
+        bool may_count = true;
+        if (mode == M_COUNT_IF_PRESENT) may_count = all;
+        if (mode == M_ADD && !all && cnt[r] == 1u) { may_count = false; st[r] |= ST_LATE; }
+        claim[r] = live[r] && may_count;
+        dup[r] = ci[r][0] == ci[r][1];
+    }
+    uint32_t b0[RUNS], b1[RUNS];
+#pragma unroll
+    for (int r = 0; r < RUNS; ++r) {                          // all claims in flight together
+        b0[r] = claim[r] ? cbf_claim(fv.cbf, ci[r][0]) : 0u;
+        b1[r] = (claim[r] && !dup[r]) ? cbf_claim(fv.cbf, ci[r][1]) : 0u;
+    }
+    uint32_t n_foreign_total = 0;
+#pragma unroll
+    for (int r = 0; r < RUNS; ++r) {
+        if (!live[r]) continue;
+        const uint32_t d = d0 + r;
+        if (claim[r]) {
+            uint64_t f0 = ~0ull, f1 = ~0ull;
+            uint32_t nf = 0, v0 = b0[r], v1;
+            if (v0 & CLAIM) { st[r] |= ST_FOREIGN; f0 = ci[r][0]; ++nf; v0 &= 0x7Fu; }
+            if (dup[r]) v1 = v0;                                 // the same counter twice: one claim, the value mirrored
+            else { v1 = b1[r]; if (v1 & CLAIM) { st[r] |= ST_FOREIGN; f1 = ci[r][1]; ++nf; v1 &= 0x7Fu; } }
+            cvals[d] = (uint64_t)v0 | ((uint64_t)v1 << 8);
+            st[r] |= ST_CLAIMED;
+            if (nf) { foreign_idx[(size_t)d * 2] = f0; foreign_idx[(size_t)d * 2 + 1] = f1; n_foreign_total += nf; }
+        }
+        status[d] = st[r];
+    }
+    if (n_foreign_total) atomicAdd(&counters[16 + 16 * (blockIdx.x & 31u)], n_foreign_total);
+}
 // ---- first-setter arbitration without a table entry per new bit (the default) ----
 // Two new k-mers of one sub-batch rarely share a Bloom bit (touches^2 / 2 bits: ~0.2 M of 60 M on config 2), so
 // instead of registering every missing bit in a hash table the size of the sub-batch, the bits are set right after
@@ -1057,6 +1129,108 @@ __global__ void k_walk_max_cov(FilterView fv, int stranded, int k, int direction
     out_reason[i] = reason;
 }
 
+// ---- GraphUtils.naiveExtendRight / naiveExtendLeft (R/util/GraphUtils.java:6780-7112): extension through unbranched
+// stretches.  One lane per walk.  Per step, with `best` = the k-mer the walk stands on (the seed at first):
+//   * back-branch test (not in the NoBackChecks forms): any left (right walk) / right (left walk) variant of `best` —
+//     the base about to leave replaced — with count >= 1 ends the walk (:6794-6799; Kmer.hasDepthLeft / hasDepthRight
+//     never consult the graph and always answer true, R/graph/Kmer.java:407-486, so the variant's existence decides);
+//   * neighbours with count >= minKmerCov: none ends the walk, exactly one is taken, two or more end it ("too many good
+//     branches", :6805-6819 — again hasDepth* is always true);
+//   * mode 0 (terminators, :6780-6833 / :6959-7012): a candidate that is one of the walk's terminator k-mers (every
+//     k-mer of a per-walk sequence, Kmer.equals = same bases) or that the walk added before ends it, not added;
+//     mode 1 (bounded, :6835-6886 / :7014-7065): added, then the walk ends once ++length > bound (bound + 1 k-mers);
+//     mode 2 (NoBackChecks, :6888-6933 / :7067-7112): ends, not added, when the candidate equals the seed or the k-mer
+//     added last; else as mode 1.
+// reason: 0 no neighbour, 1 back branch, 2 several neighbours, 3 bound, 4 invalid seed, 5 terminator / used k-mer,
+// 6 output capacity reached (mode 0 has no bound of its own), 7 the candidate repeats the seed / the last k-mer.
+__global__ void k_naive_extend(FilterView fv, int stranded, int k, int direction, int mode, const uint8_t *__restrict__ seeds, size_t n,
+                               int bound, int cap, float min_cov, const uint8_t *__restrict__ term_seq, const int64_t *__restrict__ term_off,
+                               const uint64_t *__restrict__ term_f, const int64_t *__restrict__ term_koff,
+                               uint8_t *__restrict__ seq, uint8_t *__restrict__ out_b, uint64_t *__restrict__ wf,
+                               int32_t *__restrict__ out_len, uint8_t *__restrict__ out_reason) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t uk = (uint32_t)k;
+    const size_t stride = (size_t)k + (size_t)cap;
+    uint8_t *sq = seq + i * stride;                       // walk orientation: seed (reversed for a left walk), then the added bases
+    uint64_t *pf = wf + i * (size_t)cap;                  // forward hashes of the k-mers added (mode 0: the used set)
+    const uint8_t *sb = seeds + i * (size_t)k;
+    uint64_t f = 0, r = 0;
+    for (uint32_t q = 0; q < uk; ++q) {
+        const uint32_t c = code_of_char(sb[q]);
+        if (c > 3u) { out_len[i] = 0; out_reason[i] = 4; return; }
+        f = rotl(f, 1) ^ seed_of(c);
+        r ^= rotl(seed_of(3u - c), q);
+    }
+    for (uint32_t q = 0; q < uk; ++q) sq[q] = (direction == 0) ? sb[q] : sb[uk - 1u - q];
+    const uint64_t seed_f = f;
+    const uint8_t acgt[4] = {'A', 'C', 'G', 'T'};
+    int len = 0;
+    uint8_t reason = 3;
+    // candidate (walk orientation: sq[len+1 .. len+k-1] + nb) against k bases given left to right
+    auto cand_equals = [&](const uint8_t *other, uint32_t best_in) -> bool {
+        for (uint32_t q = 0; q < uk; ++q) {
+            const uint32_t cq = (q + 1u < uk) ? code_of_char(sq[(size_t)len + 1u + q]) : best_in;      // walk orientation
+            const uint32_t oq = code_of_char((direction == 0) ? other[q] : other[uk - 1u - q]);
+            if (cq != oq) return false;
+        }
+        return true;
+    };
+    for (;;) {
+        const uint32_t oc = code_of_char(sq[len]);            // base about to leave: first base (right walk) / last base (left walk)
+        const uint64_t s_out = seed_of(oc), sc_out = seed_of(3u - oc);
+        if (mode != 2) {                                      // back branches: variants of the current k-mer in that base
+            bool back = false;
+            for (uint32_t in = 0; in < 4u && !back; ++in) {
+                if (in == oc) continue;
+                uint64_t vf, vr = 0;
+                if (direction == 0) { vf = f ^ rotl(s_out, uk - 1u) ^ rotl(seed_of(in), uk - 1u); if (!stranded) vr = r ^ sc_out ^ seed_of(3u - in); }
+                else { vf = f ^ s_out ^ seed_of(in); if (!stranded) vr = r ^ rotl(sc_out, uk - 1u) ^ rotl(seed_of(3u - in), uk - 1u); }
+                back = graph_count(fv, stranded ? vf : smin(vf, vr)) >= 1.0f;
+            }
+            if (back) { reason = 1; break; }
+        }
+        uint32_t n_nb = 0, best_in = 0;
+        uint64_t best_f = 0, best_r = 0;
+        for (uint32_t in = 0; in < 4u; ++in) {
+            uint64_t nf, nr = 0;
+            if (direction == 0) { nf = rotl(f, 1) ^ rotl(s_out, uk) ^ seed_of(in); if (!stranded) nr = rotr(r, 1) ^ rotr(sc_out, 1) ^ rotl(seed_of(3u - in), uk - 1u); }
+            else { nf = rotr(f, 1) ^ rotr(s_out, 1) ^ rotl(seed_of(in), uk - 1u); if (!stranded) nr = rotl(r, 1) ^ rotl(sc_out, uk) ^ seed_of(3u - in); }
+            if (graph_count(fv, stranded ? nf : smin(nf, nr)) >= min_cov) { if (n_nb++ == 0) { best_in = in; best_f = nf; best_r = nr; } }
+        }
+        if (n_nb == 0) { reason = 0; break; }
+        if (n_nb > 1) { reason = 2; break; }
+        if (mode == 0) {
+            bool hit = false;
+            for (int64_t j = term_koff[i]; j < term_koff[i + 1] && !hit; ++j)
+                if (term_f[j] == best_f && cand_equals(term_seq + term_off[i] + (j - term_koff[i]), best_in)) hit = true;
+            for (int j = 0; j < len && !hit; ++j)
+                if (pf[j] == best_f) {                        // a k-mer the walk added: sq[j+1 .. j+k] in walk orientation
+                    bool eq = code_of_char(sq[(size_t)j + uk]) == best_in;
+                    for (uint32_t q = 0; q + 1u < uk && eq; ++q) eq = code_of_char(sq[(size_t)len + 1u + q]) == code_of_char(sq[(size_t)j + 1u + q]);
+                    hit = eq;
+                }
+            if (hit) { reason = 5; break; }
+            if (len >= cap) { reason = 6; break; }
+        } else if (mode == 2) {
+            bool rep = best_f == seed_f && cand_equals(sb, best_in);
+            if (!rep && len > 0 && pf[len - 1] == best_f) {   // equals the k-mer added last: sq[len .. len+k-1]
+                rep = code_of_char(sq[(size_t)len + uk - 1u]) == best_in;
+                for (uint32_t q = 0; q + 1u < uk && rep; ++q) rep = code_of_char(sq[(size_t)len + 1u + q]) == code_of_char(sq[(size_t)len + q]);
+            }
+            if (rep) { reason = 7; break; }
+        }
+        sq[(size_t)uk + (size_t)len] = acgt[best_in];
+        out_b[i * (size_t)cap + (size_t)len] = acgt[best_in];
+        pf[len] = best_f;
+        f = best_f; r = best_r;
+        ++len;
+        if (mode != 0 && len > bound) { reason = 3; break; }
+    }
+    out_len[i] = len;
+    out_reason[i] = reason;
+}
+
 // ---- greedy extension with lookahead: GraphUtils.greedyExtendRight / greedyExtendLeft ----
 // (R/util/GraphUtils.java:1961-1976 / :1906-1921 around greedyExtendRightOnce / LeftOnce :501-529, :564-592, which
 // score each candidate neighbour with getMaxMedianCoverageRight / Left :248-310, :375-438 — despite the name the
@@ -1331,7 +1505,6 @@ void rb::group_enqueue(rb_graph *g, int slot, size_t N, uint64_t ordinal0, uint3
     uint32_t *ctr = ctrbuf.as<uint32_t>();
     RB_HIP(hipMemsetAsync(ctr, 0, DEVCTR_BYTES, st));
     if (N == 0) return;
-    g->prof_begin(st);
     // Grouping, not ordering, is what the later stages need (rb_group.hip): equal hashes next to each other with
     // their occurrences in sequential order, except where a hash is cut into several runs — the pipeline treats
     // such runs as separate k-mers that share all their bits/counters, which the first-setter arbitration and the
@@ -1342,8 +1515,7 @@ void rb::group_enqueue(rb_graph *g, int slot, size_t N, uint64_t ordinal0, uint3
     S.uniq.reserve(N * 8); S.counts.reserve((N + 1) * 4); S.starts.reserve((N + 1) * 4);
     group_records_device(g->keys0.as<uint64_t>(), g->vals0.as<uint32_t>(), S.keys1.as<uint64_t>(), S.valsT.as<uint32_t>(), N, group_bits,
                          g->p.rng_seed, ordinal0, pos_bits, temp.p, temp.cap, S.vals1.as<uint32_t>(), S.tz.as<uint8_t>(), S.uniq.as<uint64_t>(),
-                         S.counts.as<uint32_t>(), S.starts.as<uint32_t>(), ctr + 8, st);
-    g->prof_end("group_records", st);
+                         S.counts.as<uint32_t>(), S.starts.as<uint32_t>(), ctr + 8, st, g);
 }
 uint32_t rb::group_finish(rb_graph *g, int slot, hipStream_t st, DevBuf &temp, DevBuf &ctrbuf, hipStream_t scan_stream) {
     rb_graph::GroupSlot &S = g->slots[slot];
@@ -1425,8 +1597,13 @@ void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, ui
         g->prof_end("table_clear");
     }
     g->prof_begin();
-    hipLaunchKernelGGL(k_probe, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, uniq, counts, starts, vals, D, mode,
-                       ftab, f_log2, status, g->cvals.as<uint64_t>(), g->foreign.as<uint64_t>(), ctr);
+    if (!ftab && fv.dbg_h == 2 && fv.cbf_h == 2 && !getenv("RB_PROBE_GENERIC")) {
+        constexpr int RUNS = 2;
+        hipLaunchKernelGGL(k_probe_h2<RUNS>, dim3(blocks_for(((int64_t)D + RUNS - 1) / RUNS)), dim3(TPB), 0, s, fv, uniq, counts, D, mode, status,
+                           g->cvals.as<uint64_t>(), g->foreign.as<uint64_t>(), ctr);
+    } else
+        hipLaunchKernelGGL(k_probe, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, uniq, counts, starts, vals, D, mode,
+                           ftab, f_log2, status, g->cvals.as<uint64_t>(), g->foreign.as<uint64_t>(), ctr);
     if (collide) {
         // set the new bits now; the probes that meet another probe of the sub-batch on a bit are counted
         hipLaunchKernelGGL(k_set_bits, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, uniq, D, status, ctr);
@@ -2321,6 +2498,74 @@ int rb_graph_greedy_extend(rb_graph *g, const rb_graph *gate, const char *seeds,
         RB_HIP(hipMemcpyAsync(out_reason, dreason, n, hipMemcpyDeviceToHost, s));
         if (out_count) RB_HIP(hipMemcpyAsync(out_count, dc, nb * 4, hipMemcpyDeviceToHost, s));
         RB_HIP(hipMemcpyAsync(out_bases, dbases, nb, hipMemcpyDeviceToHost, s));
+        RB_HIP(hipStreamSynchronize(s));
+    });
+}
+
+int rb_graph_naive_extend(rb_graph *g, const char *seeds, size_t n, int direction, int mode, int bound, int cap, float min_cov,
+                          const char *term_seq, const int64_t *term_off, char *out_bases, int32_t *out_len, uint8_t *out_reason) {
+    return guarded([&] {
+        RB_REQUIRE(g && (n == 0 || (seeds && out_bases && out_len && out_reason)), "rb_graph_naive_extend: null argument");
+        RB_REQUIRE(direction == 0 || direction == 1, "rb_graph_naive_extend: direction must be 0 (right) or 1 (left)");
+        RB_REQUIRE(mode >= 0 && mode <= 2, "rb_graph_naive_extend: mode must be 0 (terminators), 1 (bounded) or 2 (bounded, no back checks)");
+        RB_REQUIRE(mode == 0 ? (cap >= 1 && cap <= (1 << 20) && (n == 0 || (term_seq && term_off))) : (bound >= 0 && bound < (1 << 20)),
+                   "rb_graph_naive_extend: mode 0 needs a capacity and the terminator sequences, modes 1 / 2 a bound");
+        RB_REQUIRE(!g->shard, "rb_graph_naive_extend: queries are not available on a shard handle");
+        if (!n) return;
+        if (mode != 0) cap = bound + 1;                          // ++extensionLength > bound: up to bound + 1 k-mers
+        QueryLease q(g);
+        hipStream_t s = q.c->st;
+        const size_t k = (size_t)g->k, stride = k + (size_t)cap;
+        // terminators: forward hash of every k-mer of every terminator sequence (hashed on the host side of the call: they
+        // are short — the k-mers of the fragment being extended)
+        std::vector<int64_t> tko(n + 1, 0);
+        size_t tbytes = 0;
+        if (mode == 0) {
+            for (size_t i = 0; i < n; ++i) { const int64_t l = term_off[i + 1] - term_off[i]; tko[i + 1] = tko[i] + (l >= (int64_t)k ? l - (int64_t)k + 1 : 0); }
+            tbytes = (size_t)(term_off[n] - term_off[0]);
+        }
+        const size_t nt = (size_t)tko[n];
+        std::vector<uint64_t> tf(std::max<size_t>(nt, 1));
+        if (mode == 0) {
+            for (size_t i = 0; i < n; ++i) {
+                const char *t = term_seq + term_off[i];
+                const int64_t l = term_off[i + 1] - term_off[i];
+                for (int64_t p = 0; p + (int64_t)k <= l; ++p) {   // NTP64: forward hash from scratch (an N hashes as seed 0 and never equals a candidate)
+                    uint64_t f = 0;
+                    for (size_t x = 0; x < k; ++x) {
+                        uint64_t sd = 0;
+                        switch (t[p + (int64_t)x]) { case 'A': case 'a': sd = 0x3c8bfbb395c60474ull; break; case 'C': case 'c': sd = 0x3193c18562a02b4cull; break;
+                                                     case 'G': case 'g': sd = 0x20323ed082572324ull; break; case 'T': case 't': case 'U': case 'u': sd = 0x295549f54be24456ull; break; default: break; }
+                        f = ((f << 1) | (f >> 63)) ^ sd;
+                    }
+                    tf[(size_t)tko[i] + (size_t)p] = f;
+                }
+            }
+        }
+        q.c->b0.reserve(n * k + n * stride + n * (size_t)cap + tbytes + 64);   // seeds | seq | out bases | terminator text
+        q.c->b1.reserve(n * (size_t)cap * 8 + nt * 8 + 64);                    // walk hashes | terminator hashes
+        q.c->b2.reserve((n + 1) * 16 + 64);                                   // terminator offsets | terminator k-mer offsets
+        q.c->b3.reserve(n * 4 + n + 64);
+        uint8_t *dseed = q.c->b0.as<uint8_t>(), *dseq = dseed + n * k, *dbases = dseq + n * stride, *dterm = dbases + n * (size_t)cap;
+        uint64_t *dwf = q.c->b1.as<uint64_t>(), *dtf = dwf + n * (size_t)cap;
+        int64_t *dtoff = q.c->b2.as<int64_t>(), *dtko = dtoff + (n + 1);
+        int32_t *dlen = q.c->b3.as<int32_t>();
+        uint8_t *dreason = reinterpret_cast<uint8_t *>(dlen + n);
+        RB_HIP(hipMemcpyAsync(dseed, seeds, n * k, hipMemcpyHostToDevice, s));
+        std::vector<int64_t> rel(n + 1, 0);
+        if (mode == 0) {
+            for (size_t i = 0; i <= n; ++i) rel[i] = term_off[i] - term_off[0];
+            if (tbytes) RB_HIP(hipMemcpyAsync(dterm, term_seq + term_off[0], tbytes, hipMemcpyHostToDevice, s));
+            if (nt) RB_HIP(hipMemcpyAsync(dtf, tf.data(), nt * 8, hipMemcpyHostToDevice, s));
+        }
+        RB_HIP(hipMemcpyAsync(dtoff, rel.data(), (n + 1) * 8, hipMemcpyHostToDevice, s));
+        RB_HIP(hipMemcpyAsync(dtko, tko.data(), (n + 1) * 8, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(k_naive_extend, dim3(blocks_for((int64_t)n, 64)), dim3(64), 0, s, g->view(0, 0), (int)g->stranded, g->k, direction, mode, dseed, n,
+                           bound, cap, min_cov, dterm, dtoff, dtf, dtko, dseq, dbases, dwf, dlen, dreason);
+        RB_HIP(hipGetLastError());
+        RB_HIP(hipMemcpyAsync(out_len, dlen, n * 4, hipMemcpyDeviceToHost, s));
+        RB_HIP(hipMemcpyAsync(out_reason, dreason, n, hipMemcpyDeviceToHost, s));
+        RB_HIP(hipMemcpyAsync(out_bases, dbases, n * (size_t)cap, hipMemcpyDeviceToHost, s));
         RB_HIP(hipStreamSynchronize(s));
     });
 }

@@ -23,7 +23,7 @@
 
 #include <algorithm>
 
-#include "rb_internal.hpp"
+#include "rb_pipeline.hpp"
 
 namespace rb {
 
@@ -662,12 +662,16 @@ size_t group_temp_bytes(size_t N, int group_bits) { return group_plan(N, group_b
 
 template <int TPB>
 static void part_pass(const GrTiling &tl, size_t entries, uint32_t shift, uint32_t bits, const uint64_t *kin, const uint32_t *vin, uint64_t *kout,
-                      uint32_t *vout, uint32_t *hist, uint32_t *goffs, void *scan_tmp, size_t scan_bytes, hipStream_t st) {
+                      uint32_t *vout, uint32_t *hist, uint32_t *goffs, void *scan_tmp, size_t scan_bytes, hipStream_t st, rb_graph *prof) {
     const dim3 grid(tl.grid_tiles), blk(TPB);
+    if (prof) prof->prof_begin(st);
     hipLaunchKernelGGL(k_part_count<TPB>, grid, blk, 0, st, kin, tl, shift, bits, hist);
+    if (prof) { prof->prof_end("group_part_count", st); prof->prof_begin(st); }
     exclusive_scan_u32(scan_tmp, scan_bytes, hist, goffs, entries, st);
+    if (prof) { prof->prof_end("group_scan", st); prof->prof_begin(st); }
     if (bits <= 8u) hipLaunchKernelGGL((k_part_scatter<TPB, 8>), grid, blk, 0, st, kin, vin, tl, shift, bits, goffs, kout, vout);
     else hipLaunchKernelGGL((k_part_scatter<TPB, GR_PART_MAX_BITS>), grid, blk, 0, st, kin, vin, tl, shift, bits, goffs, kout, vout);
+    if (prof) prof->prof_end("group_part_scatter", st);
 }
 
 // Groups the N records (keys0, vals0) — both arrays are clobbered; (keys_tmp, vals_tmp) is scratch of the same size.
@@ -676,7 +680,7 @@ static void part_pass(const GrTiling &tl, size_t entries, uint32_t shift, uint32
 template <int TPB>
 static void group_records_impl(const GroupPlan &P, uint64_t *keys0, uint32_t *vals0, uint64_t *keys_tmp, uint32_t *vals_tmp, GroupRng rng, char *tp,
                                uint32_t *vals_out, uint8_t *tz_out, uint64_t *uniq, uint32_t *counts, uint32_t *starts, uint32_t *n_runs_dev,
-                               hipStream_t st) {
+                               hipStream_t st, rb_graph *prof) {
     unsigned long long *status = reinterpret_cast<unsigned long long *>(tp + P.off_status);
     uint32_t *ticket = reinterpret_cast<uint32_t *>(tp + P.off_ticket);
     uint32_t *bstart = reinterpret_cast<uint32_t *>(tp + P.off_bstart);
@@ -687,7 +691,7 @@ static void group_records_impl(const GroupPlan &P, uint64_t *keys0, uint32_t *va
         uint32_t *hist = reinterpret_cast<uint32_t *>(tp + P.off_hist), *goffs = reinterpret_cast<uint32_t *>(tp + P.off_goffs);
         void *scan_tmp = tp + P.off_scan;
         GrTiling t1{nullptr, nullptr, P.n, P.ntiles, gr_grid_for_tiles(P.ntiles), P.xcd_map};
-        part_pass<TPB>(t1, (size_t)P.ntiles << P.t_hi, P.shift_hi, P.t_hi, kin, vin, keys_tmp, vals_tmp, hist, goffs, scan_tmp, P.scan_bytes, st);
+        part_pass<TPB>(t1, (size_t)P.ntiles << P.t_hi, P.shift_hi, P.t_hi, kin, vin, keys_tmp, vals_tmp, hist, goffs, scan_tmp, P.scan_bytes, st, prof);
         kin = keys_tmp; vin = vals_tmp;
         uint32_t *segtb = nullptr, *segst = nullptr;
         if (P.t_lo) {
@@ -697,34 +701,37 @@ static void group_records_impl(const GroupPlan &P, uint64_t *keys0, uint32_t *va
             hipLaunchKernelGGL(k_seg_tiles, dim3(1), dim3(1024), 0, st, goffs, P.ntiles, 1u << P.t_hi, P.n, 1u << P.t_lo, desc, segtb, segst, nt2);
             RB_HIP(hipMemsetAsync(hist, 0, ((size_t)P.ntiles2_max << P.t_lo) * 4, st));
             GrTiling t2{desc, nt2, P.n, P.ntiles2_max, gr_grid_for_tiles(P.ntiles2_max), P.xcd_map};
-            part_pass<TPB>(t2, (size_t)P.ntiles2_max << P.t_lo, P.shift_lo, P.t_lo, kin, vin, keys0, vals0, hist, goffs, scan_tmp, P.scan_bytes, st);
+            part_pass<TPB>(t2, (size_t)P.ntiles2_max << P.t_lo, P.shift_lo, P.t_lo, kin, vin, keys0, vals0, hist, goffs, scan_tmp, P.scan_bytes, st, prof);
             kin = keys0; vin = vals0;
         }
         hipLaunchKernelGGL(k_bucket_bounds, dim3((P.nbuckets + 256u) / 256u), dim3(256), 0, st, goffs, P.ntiles, segtb, segst, P.t_hi, P.t_lo, P.n, bstart);
     } else
         hipLaunchKernelGGL(k_bucket_bounds, dim3(1), dim3(64), 0, st, (const uint32_t *)nullptr, 0u, (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, 0u, P.n, bstart);
     uint32_t *big_list = reinterpret_cast<uint32_t *>(tp + P.off_big), *n_big = ticket + 2;
+    if (prof) prof->prof_begin(st);
     const uint32_t bucket_grid = std::min(P.nbuckets, (uint32_t)(getenv("RB_GROUP_GRID") ? atoi(getenv("RB_GROUP_GRID")) : 768));
     hipLaunchKernelGGL(k_group_buckets<TPB>, dim3(bucket_grid), dim3(TPB), 0, st, kin, vin, bstart, P.nbuckets, P.lshift_lo, P.l_lo, P.lshift_hi, P.l_hi,
                        rng, ticket, status, big_list, n_big, vals_out, tz_out, uniq, counts, starts, n_runs_dev);
+    if (prof) { prof->prof_end("group_buckets", st); prof->prof_begin(st); }
     // the buckets that do not fit LDS (none in a warm steady state): sorted through the record buffer that is free now
     uint64_t *ka = const_cast<uint64_t *>(kin), *kb = kin == keys0 ? keys_tmp : keys0;
     uint32_t *va = const_cast<uint32_t *>(vin), *vb = vin == vals0 ? vals_tmp : vals0;
     hipLaunchKernelGGL(k_group_big<512>, dim3(std::min(P.nbuckets, 2048u)), dim3(512), 0, st, ka, va, kb, vb, bstart, big_list, n_big,
                        P.lshift_lo, P.l_lo, P.lshift_hi, P.l_hi, rng, vals_out, tz_out, uniq, counts, starts, n_runs_dev);
+    if (prof) prof->prof_end("group_big_buckets", st);
     RB_HIP(hipGetLastError());
 }
 
 void group_records_device(uint64_t *keys0, uint32_t *vals0, uint64_t *keys_tmp, uint32_t *vals_tmp, size_t N, int group_bits,
                           uint64_t seed, uint64_t ordinal0, uint32_t pos_bits, void *temp, size_t temp_bytes,
                           uint32_t *vals_out, uint8_t *tz_out, uint64_t *uniq, uint32_t *counts, uint32_t *starts, uint32_t *n_runs_dev,
-                          hipStream_t st) {
+                          hipStream_t st, rb_graph *prof) {
     RB_REQUIRE(N > 0 && N < (1ull << 32) - 2 * GR_TILE, "group_records_device: bad record count");
     const GroupPlan P = group_plan(N, group_bits);
     RB_REQUIRE(temp_bytes >= P.total, "group_records_device: temp too small");
     const GroupRng rng{seed, ordinal0, pos_bits};
-    if (P.tpb == 512u) group_records_impl<512>(P, keys0, vals0, keys_tmp, vals_tmp, rng, static_cast<char *>(temp), vals_out, tz_out, uniq, counts, starts, n_runs_dev, st);
-    else group_records_impl<256>(P, keys0, vals0, keys_tmp, vals_tmp, rng, static_cast<char *>(temp), vals_out, tz_out, uniq, counts, starts, n_runs_dev, st);
+    if (P.tpb == 512u) group_records_impl<512>(P, keys0, vals0, keys_tmp, vals_tmp, rng, static_cast<char *>(temp), vals_out, tz_out, uniq, counts, starts, n_runs_dev, st, prof);
+    else group_records_impl<256>(P, keys0, vals0, keys_tmp, vals_tmp, rng, static_cast<char *>(temp), vals_out, tz_out, uniq, counts, starts, n_runs_dev, st, prof);
 }
 
 }  // namespace rb

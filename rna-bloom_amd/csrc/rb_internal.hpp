@@ -109,6 +109,6 @@ size_t group_temp_bytes(size_t N, int group_bits);
 void group_records_device(uint64_t *keys0, uint32_t *vals0, uint64_t *keys_tmp, uint32_t *vals_tmp, size_t N, int group_bits,
                           uint64_t seed, uint64_t ordinal0, uint32_t pos_bits, void *temp, size_t temp_bytes,
                           uint32_t *vals_out, uint8_t *tz_out, uint64_t *uniq, uint32_t *counts, uint32_t *starts, uint32_t *n_runs_dev,
-                          hipStream_t st);
+                          hipStream_t st, struct rb_graph *prof = nullptr /* per-kernel HIP-event timing into this handle's profile */);
 
 }  // namespace rb

@@ -79,6 +79,7 @@ SYMBOLS = [
     ("rb_graph_neighbors", _i32, [_vp, _vp, _vp, _vp, _sz, _i32, _vp, _vp, _vp]),
     ("rb_graph_walk", _i32, [_vp, _vp, _vp, _sz, _i32, _i32, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("rb_graph_greedy_extend", _i32, [_vp, _vp, _vp, _sz, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    ("rb_graph_naive_extend", _i32, [_vp, _vp, _sz, _i32, _i32, _i32, _i32, C.c_float, _vp, _vp, _vp, _vp, _vp]),
     ("rb_filter_size", _i32, [_vp, _i32, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i32)]),
     ("rb_filter_popcount", _i32, [_vp, _i32, C.POINTER(_i64)]),
     ("rb_filter_fpr", _i32, [_vp, _i32, C.POINTER(C.c_float)]),

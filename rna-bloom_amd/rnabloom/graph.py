@@ -313,6 +313,30 @@ class BloomFilterDeBruijnGraph:
 
     # ---- the reference's convenience methods, batched (R/graph/BloomFilterDeBruijnGraph.java; all device work goes through
     # the calls above) ----
+    def greedyExtendOnce(self, seeds, direction, lookahead, bf=None):
+        """GraphUtils.greedyExtendRightOnce / greedyExtendLeftOnce(graph, source, lookahead[, bf]) (R/util/GraphUtils.java:501-625)
+        for many source k-mers: the chosen neighbour's base (b"" where the source has none) and its count"""
+        bases, cnt, ln, _ = self.greedyExtend(seeds, direction, lookahead, 1, bf=bf)
+        return [bytes(bases[i, :ln[i]]) for i in range(len(seeds))], cnt[:, 0]
+
+    def naiveExtend(self, seeds, direction, mode=1, bound=0, minKmerCov=1.0, terminators=None, cap=4096, maxTipLength=None):
+        """GraphUtils.naiveExtendRight / naiveExtendLeft (R/util/GraphUtils.java:6780-7112) for many seed k-mers.  mode 0: the
+        forms with a terminator set — terminators[i] = a sequence whose k-mers stop walk i (plus the k-mers it added); mode 1:
+        bounded; mode 2: NoBackChecks.  maxTipLength is accepted and unused, as in the reference's effect (Kmer.hasDepth* always
+        answers true).  Returns (list of appended bases, reason[n])."""
+        n = len(seeds)
+        sd = np.frombuffer(b"".join(s if isinstance(s, bytes) else s.encode() for s in seeds), np.uint8)
+        if sd.size != n * self.k: raise ValueError("naiveExtend: every seed must be one k-mer")
+        width = cap if mode == 0 else bound + 1
+        ob = np.zeros((n, max(1, width)), np.uint8); ol = np.zeros(n, np.int32); orr = np.zeros(n, np.uint8)
+        tseq = toff = None
+        if mode == 0:
+            tseq, toff = _pack([t if isinstance(t, bytes) else t.encode() for t in (terminators if terminators is not None else [b""] * n)])
+            if tseq.size == 0: tseq = np.zeros(1, np.uint8)
+        check(lib.rb_graph_naive_extend(self.h, _ptr(sd), n, direction, mode, bound, cap, C.c_float(minKmerCov), _ptr(tseq) if tseq is not None else None,
+                                        _ptr(toff) if toff is not None else None, _ptr(ob), _ptr(ol), _ptr(orr)))
+        return [bytes(ob[i, :ol[i]]) for i in range(n)], orr
+
     def _base_hash(self, f, r):
         """hashVals[0] of a k-mer: forward hash when stranded, signed minimum of both strands otherwise (NTHash.java:449-475)"""
         return f if self.stranded else np.where(r.view(np.int64) < f.view(np.int64), r, f)

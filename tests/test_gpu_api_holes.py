@@ -145,3 +145,43 @@ def test_kmer_neighbour_predicates():
         assert (gg.hasSuccessors(f, r, first) == (nsucc > 0)).all() and (gg.hasAtLeastXPredecessors(f, r, last, 2) == (npred >= 2)).all()
         branching += int((nsucc >= 2).sum() + (npred >= 2).sum())
     assert branching > 0
+
+
+@pytest.mark.parametrize("stranded", [False, True])
+def test_naive_extension_and_extend_once_match_the_restatement(stranded):
+    """GraphUtils.naiveExtendRight / Left (three forms each) and greedyExtendRightOnce / LeftOnce against step-by-step
+    restatements over the oracle graph (oracle/rbo.py::naive_extend, ::greedy_extend)"""
+    from rnabloom import synth
+    d = synth.generate_pairs(1500, G=6000, err=0.004, n_rate=5e-4, seed=58)
+    og = rbo.Graph(400_009, 700_001, 64, 2, 2, 1, 25, stranded, False, 3)
+    gg = BloomFilterDeBruijnGraph(400_009, 700_001, 64, 2, 2, 1, 25, stranded, False, rngSeed=3)
+    s, off = synth.flat(d["left"]); q, _ = synth.flat(d["lqual"])
+    og.add_reads(s, q, off, 3, 0); gg.addReads(s, q, off, 3)
+    rng = np.random.default_rng(4)
+    reads = [bytes(s[off[i]:off[i + 1]]) for i in range(200)]
+    seeds, frags = [], []
+    for sq in reads:
+        if b"N" in sq: continue
+        p = int(rng.integers(0, len(sq) - 60))
+        seeds.append(sq[p:p + 25]); frags.append(sq[p:p + 60])
+    seeds += [b"ACGTNACGTACGTACGTACGTACGT", b"A" * 25]
+    frags += [b"", b"A" * 30]
+    reasons = set()
+    for direction in (0, 1):
+        for mode, kw in ((1, dict(bound=12)), (1, dict(bound=0)), (2, dict(bound=20)), (0, dict(cap=30)), (1, dict(bound=40, minKmerCov=2.0))):
+            sd = seeds if direction == 0 else [f[-25:] if len(f) >= 25 else sdd for f, sdd in zip(frags, seeds)]
+            got, why = gg.naiveExtend(sd, direction, mode, terminators=frags if mode == 0 else None, **kw)
+            for i, km in enumerate(sd):
+                eb, er = rbo.naive_extend(og, km, direction, mode, bound=kw.get("bound", 0), min_cov=kw.get("minKmerCov", 1.0),
+                                          terminators=frags[i] if mode == 0 else b"", cap=kw.get("cap", 4096))
+                assert (got[i], int(why[i])) == (eb, er), (direction, mode, kw, i, km)
+                reasons.add(er)
+    assert {0, 1, 2, 3, 4, 5}.issubset(reasons), reasons
+    # greedyExtendRightOnce / LeftOnce = one step of the greedy extension
+    clean = [km for km in seeds if b"N" not in km]
+    for direction in (0, 1):
+        for la in (0, 3):
+            bases, cnt = gg.greedyExtendOnce(clean, direction, la)
+            for i in range(0, len(clean), 7):
+                eb, ec = rbo.greedy_extend(og, clean[i], direction, la, 1, stranded=stranded)
+                assert bases[i] == eb and (not eb or float(cnt[i]) == ec[0])

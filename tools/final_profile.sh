@@ -1,7 +1,10 @@
-# Collects everything profiles/ holds for a round (run through gpurun from the repo root):
-#   GPU test suite, default bench line, rocprofv3 kernel stats, PMC FETCH_SIZE / WRITE_SIZE passes, serial stage times.
+#!/bin/bash
+# Collects everything profiles/ holds for a round (run through gpurun from the repo root):  tools/final_profile.sh r02
+#   GPU test suite, default bench line, rocprofv3 kernel stats, PMC FETCH_SIZE / WRITE_SIZE passes (each in its own run),
+#   serial stage times, FETCH_SIZE calibration on k_part_count (known byte count).
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/final
+TAG=${1:-r02}
+OUT=$R/gpurun_out/final_$TAG
 mkdir -p $OUT
 cd $R
 python -m pytest tests -q -m gpu 2>&1 | tail -3 > $OUT/pytest_gpu.txt
@@ -14,4 +17,18 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/prof_$c -o p -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/bench_pmc_$c.json 2> $OUT/rocprof_$c.err
   python $R/profiles/summarize.py pmc $(find /tmp/prof_$c -name '*counter_collection.csv' | head -1) $c > $OUT/pmc_$c.csv
 done
-cat $OUT/pytest_gpu.txt; tail -c 600 $OUT/bench.json; head -12 $OUT/kernel_stats.csv; head -6 $OUT/pmc_FETCH_SIZE.csv
+python - <<PY > $OUT/pmc_calibration.txt
+import json
+b = json.load(open("$OUT/bench_pmc_FETCH_SIZE.json"))
+steps = b["steps"] + b["warmup"]
+sorted_total = b["config"]["sorted_kmers_per_step"] * steps
+rows = [l.rsplit(",", 3) for l in open("$OUT/pmc_FETCH_SIZE.csv").read().splitlines()[1:]]
+hit = [r for r in rows if r[0].startswith("rb::k_part_count")]
+fetch = sum(float(r[2]) for r in hit) * 1024
+known = 8.0 * 2 * sorted_total       # the histogram kernel reads the 8-byte key of every record, once per partition pass (2 passes)
+print("FETCH_SIZE calibration on rb::k_part_count (8-byte-per-lane coalesced streaming reads, nothing else read but %d B of tile descriptors):" % 16)
+print("  records per step %d x %d steps x 2 passes x 8 B = %.3f GB read by construction" % (b["config"]["sorted_kmers_per_step"], steps, known / 1e9))
+print("  FETCH_SIZE total over its %d dispatches        = %.3f GB" % (sum(int(r[1]) for r in hit), fetch / 1e9))
+print("  known / counter = %.3f   (the guide: 128-byte requests of coalesced streaming reads are tallied as 64 bytes -> x 2)" % (known / fetch))
+PY
+cat $OUT/pytest_gpu.txt; tail -c 1500 $OUT/bench.json; echo; head -14 $OUT/kernel_stats.csv; cat $OUT/pmc_calibration.txt; head -8 $OUT/pmc_FETCH_SIZE.csv
