@@ -1510,12 +1510,13 @@ void rb::group_enqueue(rb_graph *g, int slot, size_t N, uint64_t ordinal0, uint3
     // such runs as separate k-mers that share all their bits/counters, which the first-setter arbitration and the
     // ordered conflict replay already make exact (DESIGN.md §Pipeline "split runs").
     const int group_bits = 64 - g->sort_begin_bit;
-    temp.reserve(group_temp_bytes(N, group_bits));
+    const int bucket_target = g->shard ? 768 : 0;
+    temp.reserve(group_temp_bytes(N, group_bits, bucket_target));
     S.keys1.reserve(N * 8); S.valsT.reserve(N * 4); S.vals1.reserve(N * 4); S.tz.reserve(N + 16);
     S.uniq.reserve(N * 8); S.counts.reserve((N + 1) * 4); S.starts.reserve((N + 1) * 4);
     group_records_device(g->keys0.as<uint64_t>(), g->vals0.as<uint32_t>(), S.keys1.as<uint64_t>(), S.valsT.as<uint32_t>(), N, group_bits,
                          g->p.rng_seed, ordinal0, pos_bits, temp.p, temp.cap, S.vals1.as<uint32_t>(), S.tz.as<uint8_t>(), S.uniq.as<uint64_t>(),
-                         S.counts.as<uint32_t>(), S.starts.as<uint32_t>(), ctr + 8, st, g);
+                         S.counts.as<uint32_t>(), S.starts.as<uint32_t>(), ctr + 8, st, g, bucket_target);
 }
 uint32_t rb::group_finish(rb_graph *g, int slot, hipStream_t st, DevBuf &temp, DevBuf &ctrbuf, hipStream_t scan_stream) {
     rb_graph::GroupSlot &S = g->slots[slot];

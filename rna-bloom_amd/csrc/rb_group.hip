@@ -319,14 +319,15 @@ __global__ void __launch_bounds__(TPB) k_group_buckets(const uint64_t *__restric
                                                        uint64_t *__restrict__ uniq, uint32_t *__restrict__ counts, uint32_t *__restrict__ starts,
                                                        uint32_t *__restrict__ n_runs_out) {
     constexpr uint32_t ITEMS = GR_TILE / TPB, NW = TPB / 64, SEG = 64 * ITEMS, NB = 1u << GR_LOCAL_BITS;
+    static_assert(ITEMS * NW == 64, "the segment scan below is one wavefront wide");
     __shared__ uint64_t s_keys[GR_TILE];
     __shared__ uint32_t s_vals[GR_TILE];          // later: head positions (u16)
-    __shared__ uint16_t s_wcnt[NW * NB];
+    __shared__ uint16_t s_wcnt[2][NW * NB];       // one table per pass: each is cleaned right after its use, two barriers before the next
     __shared__ unsigned long long s_wmask[NW * NB];
     __shared__ uint16_t s_dstart[NB];
     __shared__ uint32_t s_wsum[NW], s_seg[ITEMS * NW], s_misc[2];
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    for (uint32_t d = threadIdx.x; d < NW * NB; d += TPB) s_wmask[d] = 0ull;
+    for (uint32_t d = threadIdx.x; d < NW * NB; d += TPB) { s_wmask[d] = 0ull; s_wcnt[0][d] = 0; s_wcnt[1][d] = 0; }
     // persistent workgroups: buckets are taken in ticket order, so every predecessor of a bucket has been taken by
     // a running workgroup (the look-back below never waits for work that has not started)
     for (;;) {
@@ -355,6 +356,7 @@ __global__ void __launch_bounds__(TPB) k_group_buckets(const uint64_t *__restric
         const uint32_t shift = pass ? shift_hi : shift_lo, bits = pass ? bits_hi : bits_lo;
         if (bits == 0 || cn == 0) continue;
         const uint32_t nb = 1u << bits;
+        uint16_t *wcnt = s_wcnt[pass];
         if (in_lds) {
 #pragma unroll
             for (uint32_t r = 0; r < ITEMS; ++r) {
@@ -362,25 +364,23 @@ __global__ void __launch_bounds__(TPB) k_group_buckets(const uint64_t *__restric
                 if (j < cn) { k[r] = s_keys[j]; v[r] = s_vals[j]; }
             }
         }
-        __syncthreads();
-        for (uint32_t d = threadIdx.x; d < NW * nb; d += TPB) s_wcnt[d] = 0;
 #pragma unroll
         for (uint32_t r = 0; r < ITEMS; ++r) {
             const uint32_t j = w * SEG + r * 64u + lane;
             dig[r] = j < cn ? gr_digit(k[r], shift, bits) : ~0u;
         }
+        gr_wave_rank_lds<ITEMS>(dig, rank, wcnt + w * nb, s_wmask + w * NB, rows);
         __syncthreads();
-        gr_wave_rank_lds<ITEMS>(dig, rank, s_wcnt + w * nb, s_wmask + w * NB, rows);
-        __syncthreads();
-        gr_digit_offsets<TPB>(s_wcnt, s_dstart, nb, s_wsum);
+        gr_digit_offsets<TPB>(wcnt, s_dstart, nb, s_wsum);
         __syncthreads();
 #pragma unroll
         for (uint32_t r = 0; r < ITEMS; ++r)
             if (dig[r] != ~0u) {
-                const uint32_t p = (uint32_t)s_dstart[dig[r]] + (uint32_t)s_wcnt[w * nb + dig[r]] + rank[r];
+                const uint32_t p = (uint32_t)s_dstart[dig[r]] + (uint32_t)wcnt[w * nb + dig[r]] + rank[r];
                 s_keys[p] = k[r]; s_vals[p] = v[r];
             }
         __syncthreads();
+        for (uint32_t d = threadIdx.x; d < NW * nb; d += TPB) wcnt[d] = 0;
         in_lds = true;
     }
     if (!in_lds) {      // no local digit at all: keep the order
@@ -391,47 +391,58 @@ __global__ void __launch_bounds__(TPB) k_group_buckets(const uint64_t *__restric
         }
         __syncthreads();
     }
-    // the bucket is grouped; thread t takes records t, t + TPB, ... : strengths, sorted occurrences, run heads
+    // the bucket is grouped; thread t takes records t, t + TPB, ... : run heads first (their number is what the buckets after
+    // this one wait for), then — while wavefront 0 looks back — sorted occurrences and strengths
     unsigned long long hb[ITEMS];
+    uint32_t occ[ITEMS];
     bool head[ITEMS];
-    const uint32_t pmask = (1u << rng.pos_bits) - 1u;
 #pragma unroll
     for (uint32_t i = 0; i < ITEMS; ++i) {
         const uint32_t j = i * TPB + threadIdx.x;
-        head[i] = false;
+        head[i] = false; occ[i] = 0;
         if (j < cn) {
             const uint64_t key = s_keys[j];
             head[i] = j == 0u || s_keys[j - 1u] != key;
-            const uint32_t occ = s_vals[j];
-            vals_out[b0 + j] = occ;
-            const uint32_t rr = rng31(rng.seed, rng.ordinal0 + (uint64_t)(occ >> rng.pos_bits), occ & pmask) | 0x8000u;
-            tz_out[b0 + j] = (uint8_t)(__ffs((int)rr) - 1);
+            occ[i] = s_vals[j];
         }
         hb[i] = __ballot(head[i]);
         if (lane == 0) s_seg[i * NW + w] = (uint32_t)__popcll(hb[i]);
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t run = 0;
-        for (uint32_t q = 0; q < ITEMS * NW; ++q) { const uint32_t t = s_seg[q]; s_seg[q] = run; run += t; }
-        s_misc[1] = run;
+    if (w == 0) {                          // exclusive scan of the 64 (row, wavefront) counts; the total is published at once
+        const uint32_t mine = s_seg[lane];
+        uint32_t inc = mine;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o, 64); if ((int)lane >= o) inc += t; }
+        s_seg[lane] = inc - mine;
+        if (lane == 63u) {
+            s_misc[1] = inc;
+            __hip_atomic_store(&status[c], (c == 0 ? GR_ST_PREFIX : GR_ST_AGG) | (unsigned long long)inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
-    __syncthreads();                       // everybody has read s_vals: reuse it for the head positions
+    __syncthreads();                       // everybody holds its occurrences in registers: s_vals becomes the head positions
     const uint32_t nruns = s_misc[1];
     uint16_t *hpos = reinterpret_cast<uint16_t *>(s_vals);
 #pragma unroll
     for (uint32_t i = 0; i < ITEMS; ++i)
         if (head[i]) hpos[s_seg[i * NW + w] + gr_lanes_below(hb[i])] = (uint16_t)(i * TPB + threadIdx.x);
-    // global position of this bucket's runs: chained scan over the buckets
-    if (w == 0) {
-        if (lane == 0)
-            __hip_atomic_store(&status[c], (c == 0 ? GR_ST_PREFIX : GR_ST_AGG) | (unsigned long long)nruns, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (w == 0) {                          // global position of this bucket's runs: chained scan over the buckets
         uint32_t rb_ = 0;
         if (c != 0) rb_ = gr_look_back(status, c);
         if (lane == 0) {
             s_misc[0] = rb_;
             if (c != 0) __hip_atomic_store(&status[c], GR_ST_PREFIX | (unsigned long long)(rb_ + nruns), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (c == nbuckets - 1u) *n_runs_out = rb_ + nruns;
+        }
+    }
+    const uint32_t pmask = (1u << rng.pos_bits) - 1u;
+#pragma unroll
+    for (uint32_t i = 0; i < ITEMS; ++i) {
+        const uint32_t j = i * TPB + threadIdx.x;
+        if (j < cn) {
+            vals_out[b0 + j] = occ[i];
+            const uint32_t rr = rng31(rng.seed, rng.ordinal0 + (uint64_t)(occ[i] >> rng.pos_bits), occ[i] & pmask) | 0x8000u;
+            tz_out[b0 + j] = (uint8_t)(__ffs((int)rr) - 1);
         }
     }
     __syncthreads();
@@ -613,12 +624,18 @@ struct GroupPlan {
 };
 static size_t gr_align(size_t x) { return (x + 255) / 256 * 256; }
 
-static GroupPlan group_plan(size_t N, int group_bits) {
+static GroupPlan group_plan(size_t N, int group_bits, int bucket_target = 0) {
     GroupPlan P;
     P.n = (uint32_t)N;
     const uint32_t gb = (uint32_t)std::max(1, std::min<int>(group_bits, (int)GR_MAX_GROUP_BITS));
     uint32_t T = 0;
-    while (((size_t)GR_BUCKET_TARGET << T) < N) ++T;
+    // smaller buckets = fewer distinct hashes per bucket = fewer hashes that agree in the 16 locally sorted bits and come out as
+    // split runs (1 % at 3072, 0.25 % at 768), at the price of more workgroup rounds in the bucket kernel.  The sharded engine asks
+    // for 768: its sub-batches are 4x longer, a split hash drags 4x more ops into the ordered conflict replay (measured with 8
+    // virtual ranks: conflict ops 179 M -> 101 M, conflict routing 249 -> 100 ms, grouping 135 -> 203 ms per pass).
+    const size_t target = getenv("RB_GROUP_TARGET") ? (size_t)std::max(64, std::min(atoi(getenv("RB_GROUP_TARGET")), (int)GR_TILE))
+                        : bucket_target > 0 ? (size_t)bucket_target : (size_t)GR_BUCKET_TARGET;
+    while ((target << T) < N) ++T;
     if (const char *e = getenv("RB_GROUP_T")) T = (uint32_t)std::max(0, atoi(e));
     T = std::min({T, gb, 2u * GR_PART_MAX_BITS});
     P.T = T;
@@ -658,7 +675,7 @@ static GroupPlan group_plan(size_t N, int group_bits) {
     return P;
 }
 
-size_t group_temp_bytes(size_t N, int group_bits) { return group_plan(N, group_bits).total; }
+size_t group_temp_bytes(size_t N, int group_bits, int bucket_target) { return group_plan(N, group_bits, bucket_target).total; }
 
 template <int TPB>
 static void part_pass(const GrTiling &tl, size_t entries, uint32_t shift, uint32_t bits, const uint64_t *kin, const uint32_t *vin, uint64_t *kout,
@@ -725,9 +742,9 @@ static void group_records_impl(const GroupPlan &P, uint64_t *keys0, uint32_t *va
 void group_records_device(uint64_t *keys0, uint32_t *vals0, uint64_t *keys_tmp, uint32_t *vals_tmp, size_t N, int group_bits,
                           uint64_t seed, uint64_t ordinal0, uint32_t pos_bits, void *temp, size_t temp_bytes,
                           uint32_t *vals_out, uint8_t *tz_out, uint64_t *uniq, uint32_t *counts, uint32_t *starts, uint32_t *n_runs_dev,
-                          hipStream_t st, rb_graph *prof) {
+                          hipStream_t st, rb_graph *prof, int bucket_target) {
     RB_REQUIRE(N > 0 && N < (1ull << 32) - 2 * GR_TILE, "group_records_device: bad record count");
-    const GroupPlan P = group_plan(N, group_bits);
+    const GroupPlan P = group_plan(N, group_bits, bucket_target);
     RB_REQUIRE(temp_bytes >= P.total, "group_records_device: temp too small");
     const GroupRng rng{seed, ordinal0, pos_bits};
     if (P.tpb == 512u) group_records_impl<512>(P, keys0, vals0, keys_tmp, vals_tmp, rng, static_cast<char *>(temp), vals_out, tz_out, uniq, counts, starts, n_runs_dev, st, prof);

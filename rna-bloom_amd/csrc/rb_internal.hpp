@@ -105,10 +105,11 @@ void run_length_encode_u64(void *temp, size_t temp_bytes, const uint64_t *keys, 
 // hand-written grouping stage of the insert pipeline (rb_group.hip): N (h0, occurrence) records -> occurrences in
 // grouped order, their draw strengths, runs (hash, count, start) and the run count, all on `st`, nothing synchronised.
 // keys0/vals0 are clobbered; keys_tmp/vals_tmp are scratch of the same size.
-size_t group_temp_bytes(size_t N, int group_bits);
+size_t group_temp_bytes(size_t N, int group_bits, int bucket_target = 0);
 void group_records_device(uint64_t *keys0, uint32_t *vals0, uint64_t *keys_tmp, uint32_t *vals_tmp, size_t N, int group_bits,
                           uint64_t seed, uint64_t ordinal0, uint32_t pos_bits, void *temp, size_t temp_bytes,
                           uint32_t *vals_out, uint8_t *tz_out, uint64_t *uniq, uint32_t *counts, uint32_t *starts, uint32_t *n_runs_dev,
-                          hipStream_t st, struct rb_graph *prof = nullptr /* per-kernel HIP-event timing into this handle's profile */);
+                          hipStream_t st, struct rb_graph *prof = nullptr /* per-kernel HIP-event timing into this handle's profile */,
+                          int bucket_target = 0 /* average fine-bucket size aimed at (0: the default, 3072) */);
 
 }  // namespace rb
