@@ -1510,7 +1510,7 @@ void rb::group_enqueue(rb_graph *g, int slot, size_t N, uint64_t ordinal0, uint3
     // such runs as separate k-mers that share all their bits/counters, which the first-setter arbitration and the
     // ordered conflict replay already make exact (DESIGN.md §Pipeline "split runs").
     const int group_bits = 64 - g->sort_begin_bit;
-    const int bucket_target = g->shard ? 768 : 0;
+    const int bucket_target = g->shard ? (getenv("RB_SHARD_GROUP_TARGET") ? atoi(getenv("RB_SHARD_GROUP_TARGET")) : 3072) : 0;
     temp.reserve(group_temp_bytes(N, group_bits, bucket_target));
     S.keys1.reserve(N * 8); S.valsT.reserve(N * 4); S.vals1.reserve(N * 4); S.tz.reserve(N + 16);
     S.uniq.reserve(N * 8); S.counts.reserve((N + 1) * 4); S.starts.reserve((N + 1) * 4);

@@ -313,7 +313,7 @@ template <int TPB>
 __global__ void __launch_bounds__(TPB) k_group_buckets(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                                                        const uint32_t *__restrict__ bstart, uint32_t nbuckets,
                                                        uint32_t shift_lo, uint32_t bits_lo, uint32_t shift_hi, uint32_t bits_hi,
-                                                       GroupRng rng, uint32_t *__restrict__ ticket, unsigned long long *__restrict__ status,
+                                                       GroupRng rng, uint32_t do_fix, uint32_t *__restrict__ ticket, unsigned long long *__restrict__ status,
                                                        uint32_t *__restrict__ big_list, uint32_t *__restrict__ n_big,
                                                        uint32_t *__restrict__ vals_out, uint8_t *__restrict__ tz_out,
                                                        uint64_t *__restrict__ uniq, uint32_t *__restrict__ counts, uint32_t *__restrict__ starts,
@@ -325,14 +325,15 @@ __global__ void __launch_bounds__(TPB) k_group_buckets(const uint64_t *__restric
     __shared__ uint16_t s_wcnt[2][NW * NB];       // one table per pass: each is cleaned right after its use, two barriers before the next
     __shared__ unsigned long long s_wmask[NW * NB];
     __shared__ uint16_t s_dstart[NB];
-    __shared__ uint32_t s_wsum[NW], s_seg[ITEMS * NW], s_misc[2];
+    __shared__ uint32_t s_wsum[NW], s_seg[ITEMS * NW], s_misc[2], s_fixn, s_redo;
+    __shared__ uint16_t s_fixlist[64];
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     for (uint32_t d = threadIdx.x; d < NW * NB; d += TPB) { s_wmask[d] = 0ull; s_wcnt[0][d] = 0; s_wcnt[1][d] = 0; }
     // persistent workgroups: buckets are taken in ticket order, so every predecessor of a bucket has been taken by
     // a running workgroup (the look-back below never waits for work that has not started)
     for (;;) {
     __syncthreads();
-    if (threadIdx.x == 0) s_misc[0] = atomicAdd(ticket, 1u);
+    if (threadIdx.x == 0) { s_misc[0] = atomicAdd(ticket, 1u); s_fixn = 0; s_redo = 0; }
     __syncthreads();
     const uint32_t c = s_misc[0];
     if (c >= nbuckets) return;
@@ -351,12 +352,10 @@ __global__ void __launch_bounds__(TPB) k_group_buckets(const uint64_t *__restric
     }
     if (big && threadIdx.x == 0) big_list[atomicAdd(n_big, 1u)] = c;
     bool in_lds = false;
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        const uint32_t shift = pass ? shift_hi : shift_lo, bits = pass ? bits_hi : bits_lo;
-        if (bits == 0 || cn == 0) continue;
+    // one stable counting pass over the bucket (from the registers the records were loaded into, later from LDS)
+    auto sort_pass = [&](uint32_t shift, uint32_t bits, uint16_t *wcnt) {
+        if (bits == 0 || cn == 0) return;
         const uint32_t nb = 1u << bits;
-        uint16_t *wcnt = s_wcnt[pass];
         if (in_lds) {
 #pragma unroll
             for (uint32_t r = 0; r < ITEMS; ++r) {
@@ -382,7 +381,66 @@ __global__ void __launch_bounds__(TPB) k_group_buckets(const uint64_t *__restric
         __syncthreads();
         for (uint32_t d = threadIdx.x; d < NW * nb; d += TPB) wcnt[d] = 0;
         in_lds = true;
-    }
+    };
+    // Two different hashes that agree in every sorted bit (bucket bits + local digits) sit interleaved in occurrence order and
+    // would come out as several runs each.  Such groups are few (hashes^2 / 2^17 per bucket): every change of hash inside a
+    // group is listed, and the wavefronts take the listed positions in turn — 64 lanes look at the 64 records around the
+    // position, and if it is the FIRST change of its group and the group has at most 32 records, every record of the group
+    // computes its rank under (hash, position) from the others' hashes (readlane loop) and moves there.  A longer group or a
+    // full list is reported; with do_fix = 2 (sharded engine: 4x longer sub-batches, longer runs, costlier conflicts) the
+    // bucket is then sorted again on 8 more bits (three passes), which leaves only short groups.  On one GPU that costs more
+    // than the conflicts it saves (group_buckets 39 -> 56 ms for 57 M -> 54 M conflicting ops), so long groups stay split there.
+    auto fix_groups = [&](uint32_t gshift, uint32_t gbits) {
+#pragma unroll
+        for (uint32_t i = 0; i < ITEMS; ++i) {
+            const uint32_t j = i * TPB + threadIdx.x;
+            if (j == 0u || j >= cn) continue;
+            const uint64_t k1 = s_keys[j], k0 = s_keys[j - 1u];
+            if (k1 != k0 && gr_digit(k0, gshift, gbits) == gr_digit(k1, gshift, gbits)) {
+                const uint32_t slot = atomicAdd(&s_fixn, 1u);
+                if (slot < 64u) s_fixlist[slot] = (uint16_t)j;
+            }
+        }
+        __syncthreads();
+        const uint32_t nfix = min(s_fixn, 64u);
+        if (s_fixn > 64u && threadIdx.x == 0) s_redo = 1u;
+        for (uint32_t m0 = 0; m0 < nfix; m0 += NW) {             // NW positions per round: all look, then all move
+            const uint32_t m = m0 + w;
+            uint64_t key = 0;
+            uint32_t val = 0, dst = ~0u;
+            if (m < nfix) {
+                const uint32_t j = s_fixlist[m];                 // lane 32 sits on j
+                const int pos = (int)j - 32 + (int)lane;
+                const bool valid = pos >= 0 && pos < (int)cn;
+                key = valid ? s_keys[pos] : 0ull;
+                val = valid ? s_vals[pos] : 0u;
+                const uint64_t kj = __shfl(key, 32, 64), k0 = __shfl(key, 31, 64);
+                const unsigned long long same = __ballot(valid && gr_digit(key, gshift, gbits) == gr_digit(kj, gshift, gbits));
+                const uint32_t nl = ~(uint32_t)same, nr = ~(uint32_t)(same >> 32);
+                const uint32_t lrun = nl ? (uint32_t)__builtin_clz(nl) : 32u;     // records of the group right before j (>= 1)
+                const uint32_t rrun = nr ? (uint32_t)__builtin_ctz(nr) : 32u;     // j and the records after it
+                const uint32_t a0 = 32u - lrun, e0 = 32u + rrun;
+                const unsigned long long left = ((1ull << 32) - 1ull) & ~((1ull << a0) - 1ull);    // lanes [a0, 32)
+                const unsigned long long eq0 = __ballot(key == k0);
+                if (lrun + rrun > 32u) {                         // may reach beyond what the window shows
+                    if (lane == 0) s_redo = 1u;
+                } else if ((eq0 & left) == left) {               // no earlier change of hash in the group: ours to sort
+                    uint32_t rk = 0;
+                    for (uint32_t q = a0; q < e0; ++q) {
+                        const uint64_t kq = ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(key >> 32), (int)q) << 32) |
+                                            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, (int)q);
+                        rk += (kq < key || (kq == key && q < lane)) ? 1u : 0u;
+                    }
+                    if (lane >= a0 && lane < e0) dst = (uint32_t)((int)j - 32 + (int)a0) + rk;
+                }
+            }
+            __syncthreads();
+            if (dst != ~0u) { s_keys[dst] = key; s_vals[dst] = val; }
+            __syncthreads();
+        }
+    };
+    sort_pass(shift_lo, bits_lo, s_wcnt[0]);
+    sort_pass(shift_hi, bits_hi, s_wcnt[1]);
     if (!in_lds) {      // no local digit at all: keep the order
 #pragma unroll
         for (uint32_t r = 0; r < ITEMS; ++r) {
@@ -390,6 +448,17 @@ __global__ void __launch_bounds__(TPB) k_group_buckets(const uint64_t *__restric
             if (j < cn) { s_keys[j] = k[r]; s_vals[j] = v[r]; }
         }
         __syncthreads();
+    }
+    if (do_fix && cn) {
+        fix_groups(shift_lo, bits_lo + bits_hi);
+        if (do_fix > 1u && s_redo) {                             // (uniform: read behind the barriers of fix_groups)
+            __syncthreads();
+            if (threadIdx.x == 0) { s_fixn = 0; s_redo = 0; }
+            sort_pass(shift_lo - GR_LOCAL_BITS, GR_LOCAL_BITS, s_wcnt[0]);
+            sort_pass(shift_lo, bits_lo, s_wcnt[1]);
+            sort_pass(shift_hi, bits_hi, s_wcnt[0]);
+            fix_groups(shift_lo - GR_LOCAL_BITS, bits_lo + bits_hi + GR_LOCAL_BITS);
+        }
     }
     // the bucket is grouped; thread t takes records t, t + TPB, ... : run heads first (their number is what the buckets after
     // this one wait for), then — while wavefront 0 looks back — sorted occurrences and strengths
@@ -616,6 +685,7 @@ struct GroupPlan {
     uint32_t l_lo = 0, l_hi = 0, lshift_lo = 0, lshift_hi = 0;   // local passes (LSD: lo first)
     uint32_t ntiles = 0, ntiles2_max = 0, nbuckets = 1;
     uint32_t tpb = 256;
+    uint32_t fix_cap = 0;                    // 1: groups of up to 32 records that agree in all sorted bits are sorted on the full hash; 2: buckets with longer ones are redone
     int xcd_map = 1;
     size_t hist_entries = 0;
     // layout of the temporary storage
@@ -629,10 +699,12 @@ static GroupPlan group_plan(size_t N, int group_bits, int bucket_target = 0) {
     P.n = (uint32_t)N;
     const uint32_t gb = (uint32_t)std::max(1, std::min<int>(group_bits, (int)GR_MAX_GROUP_BITS));
     uint32_t T = 0;
-    // smaller buckets = fewer distinct hashes per bucket = fewer hashes that agree in the 16 locally sorted bits and come out as
-    // split runs (1 % at 3072, 0.25 % at 768), at the price of more workgroup rounds in the bucket kernel.  The sharded engine asks
-    // for 768: its sub-batches are 4x longer, a split hash drags 4x more ops into the ordered conflict replay (measured with 8
-    // virtual ranks: conflict ops 179 M -> 101 M, conflict routing 249 -> 100 ms, grouping 135 -> 203 ms per pass).
+    // smaller buckets = fewer distinct hashes per bucket = fewer hashes that agree in the 16 locally sorted bits (1 % of the hashes
+    // at 3072, 0.25 % at 768) at the price of more workgroup rounds in the bucket kernel; since the bucket kernel repairs such
+    // groups itself, the target is 3072 everywhere.  A caller that names a target (the sharded engine: 4x longer sub-batches, so
+    // longer runs, and every conflicting op is routed between ranks) also gets the thorough repair (fix level 2).  Measured with
+    // 8 virtual ranks, per pass: no repair, 3072: 179 M conflicting ops; no repair, 768: 101 M (grouping 203 ms, conflict
+    // routing 100 ms); repair level 2, 3072: 68 M (grouping 172 ms, routing 39 ms).
     const size_t target = getenv("RB_GROUP_TARGET") ? (size_t)std::max(64, std::min(atoi(getenv("RB_GROUP_TARGET")), (int)GR_TILE))
                         : bucket_target > 0 ? (size_t)bucket_target : (size_t)GR_BUCKET_TARGET;
     while ((target << T) < N) ++T;
@@ -651,6 +723,9 @@ static GroupPlan group_plan(size_t N, int group_bits, int bucket_target = 0) {
     P.tpb = getenv("RB_GROUP_TPB") ? (uint32_t)atoi(getenv("RB_GROUP_TPB")) : 512u;
     if (P.tpb != 256u) P.tpb = 512u;
     P.xcd_map = getenv("RB_GROUP_XCD") ? atoi(getenv("RB_GROUP_XCD")) : 1;
+    // callers that ask for fewer grouping bits than we have want split runs (tests of the arbitration); everybody else gets them repaired
+    P.fix_cap = L == 2u * GR_LOCAL_BITS ? (bucket_target > 0 ? 2u : 1u) : 0u;
+    if (const char *e = getenv("RB_GROUP_FIX")) P.fix_cap = (uint32_t)std::max(0, std::min(atoi(e), 2));
     P.ntiles = (uint32_t)((N + GR_TILE - 1) / GR_TILE);
     P.ntiles2_max = P.t_lo ? P.ntiles + (1u << P.t_hi) : 0;
     P.nbuckets = 1u << T;
@@ -728,7 +803,7 @@ static void group_records_impl(const GroupPlan &P, uint64_t *keys0, uint32_t *va
     if (prof) prof->prof_begin(st);
     const uint32_t bucket_grid = std::min(P.nbuckets, (uint32_t)(getenv("RB_GROUP_GRID") ? atoi(getenv("RB_GROUP_GRID")) : 768));
     hipLaunchKernelGGL(k_group_buckets<TPB>, dim3(bucket_grid), dim3(TPB), 0, st, kin, vin, bstart, P.nbuckets, P.lshift_lo, P.l_lo, P.lshift_hi, P.l_hi,
-                       rng, ticket, status, big_list, n_big, vals_out, tz_out, uniq, counts, starts, n_runs_dev);
+                       rng, P.fix_cap, ticket, status, big_list, n_big, vals_out, tz_out, uniq, counts, starts, n_runs_dev);
     if (prof) { prof->prof_end("group_buckets", st); prof->prof_begin(st); }
     // the buckets that do not fit LDS (none in a warm steady state): sorted through the record buffer that is free now
     uint64_t *ka = const_cast<uint64_t *>(kin), *kb = kin == keys0 ? keys_tmp : keys0;

@@ -316,7 +316,7 @@ struct rb_graph {
     int read_d = -1, frag_d = -1;
     uint64_t ordinal = 0;
     int64_t max_batch_kmers = 0;
-    int sort_begin_bit = 32;
+    int sort_begin_bit = 28;
     uint32_t light_ops = 96;
     hipStream_t stream = nullptr;    // consumer stream: everything that touches the filters
     hipStream_t stream2 = nullptr;   // producer stream: hashing + grouping of the NEXT sub-batch (scratch only)

@@ -29,6 +29,35 @@ g.clearAllBf()
 t0 = time.perf_counter()
 st = g.addBatch(b, storeReadPairedKmers=True, first=0, n=pairs)
 dr = time.perf_counter() - t0
+# ---- the same reads as FASTQ text (R/io/FastqReader.java:140-186): file -> rb_fastq_split -> rb_graph_add_reads ----
+from rnabloom import io as rio
+L = int(off[1] - off[0])
+assert (np.diff(off) == L).all()
+rec = np.empty((pairs, 10 + 1 + L + 3 + L + 1), np.uint8)
+ids = np.arange(pairs, dtype=np.int64)
+rec[:, 0] = ord("@")
+for d in range(9):
+    rec[:, 9 - d] = ord("0") + (ids // 10 ** d) % 10
+rec[:, 10] = 10
+rec[:, 11:11 + L] = seq.reshape(pairs, L)
+rec[:, 11 + L] = 10; rec[:, 12 + L] = ord("+"); rec[:, 13 + L] = 10
+rec[:, 14 + L:14 + 2 * L] = qual.reshape(pairs, L)
+rec[:, 14 + 2 * L] = 10
+fq = os.path.join(os.environ.get("TMPDIR", "/tmp"), "rb_host_path_L.fq")
+rec.tofile(fq); fq_bytes = rec.size; del rec
+for rep in range(2):
+    g.clearAllBf()
+    t0 = time.perf_counter()
+    text = np.fromfile(fq, np.uint8)                       # page cache -> memory
+    t1 = time.perf_counter()
+    s2, q2, o2 = rio.splitFastq(text)
+    t2 = time.perf_counter()
+    st2 = g.addReads(s2, q2, o2, 3, storeReadPairedKmers=True)
+    t3 = time.perf_counter()
+assert st2.kmers == km and (s2 == seq).all() and (o2 == off).all()
+os.remove(fq)
+print("FASTQ file path (%.2f GB of text): read %.2f s (%.1f GB/s), rb_fastq_split %.2f s (%.1f GB/s), rb_graph_add_reads %.2f s -> %.2f G k-mers/s end to end"
+      % (fq_bytes / 1e9, t1 - t0, fq_bytes / 1e9 / (t1 - t0), t2 - t1, fq_bytes / 1e9 / (t2 - t1), t3 - t2, km / (t3 - t0) / 1e9))
 print("host ASCII path (seq+qual %.2f GB over PCIe, %d reads per call): %.2f G k-mers/s (%.2f s for %d k-mers)"
       % (2 * seq.size / 1e9, chunk, km / dt / 1e9, dt, km))
 print("same reads, batch already resident in HBM: %.2f G k-mers/s" % (st.kmers / dr / 1e9))
