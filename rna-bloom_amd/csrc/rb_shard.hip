@@ -1048,9 +1048,10 @@ int rb_shard_hash_group(rb_graph *g, const rb_batch *b, int64_t first, int64_t n
 int rb_shard_set_cache_replication(rb_graph *g, int on) {
     if (!g || !g->shard) { set_error("rb_shard_set_cache_replication: not a sharded graph"); return RB_ERR_INVALID; }
     g->shard->replicate_cache = on != 0;
-    // the minimizer-bucketed cache pays where every hashed window is looked up (split reads, or one rank); with
-    // replicated hashing most windows are only hashed, and its LDS footprint slows exactly that part down
-    g->use_mpf = g->mpf_log2b && (uint32_t)g->k >= g->mpf_m && (uint32_t)g->k - g->mpf_m + 1u <= 16u && (on || g->shard_count == 1);
+    // the minimizer-bucketed cache pays where a large share of the hashed windows is looked up (split reads, one rank, or
+    // replicated hashing on two ranks: 408 -> 397 ms per rank); with more ranks hashing everything, most windows are only
+    // hashed, and its LDS footprint slows exactly that part down
+    g->use_mpf = g->mpf_log2b && (uint32_t)g->k >= g->mpf_m && (uint32_t)g->k - g->mpf_m + 1u <= 16u && (on || g->shard_count <= 2 || (getenv("RB_SHARD_MPF") && atoi(getenv("RB_SHARD_MPF"))));
     return RB_OK;
 }
 int rb_shard_hash(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, int64_t own_first, int64_t own_n, uint64_t ordinal0,
