@@ -317,6 +317,15 @@ int rb_minimizer_set(int device, const char *seq, const int64_t *offsets, int64_
  * (qual may be NULL) need offsets[n_reads] bytes — len is always enough. */
 int rb_fastq_split(const char *text, size_t len, int n_threads, char *seq, char *qual, int64_t *offsets, int64_t cap_reads,
                    int64_t *n_reads);
+
+/* The same on the GPU: the text is uploaded as it is and lines, records (same rules, same error texts) and the 2-bit
+ * encoding + quality mask are found there — no host pass over the bytes, no intermediate buffers.
+ * rb_batch_create_fastq: at most 4 GiB of text; final = 0: the text is a piece of a longer input (a last line without an
+ * end of line belongs to the next piece); *consumed = where the records that were not complete start.
+ * rb_graph_add_fastq = FastqToGraphWorker's loop (R/RNABloom.java:526-643) over a whole file's text: 1 GiB pieces, the
+ * next piece is uploaded and parsed while the current one is inserted; *n_records (may be NULL) = records inserted. */
+int rb_batch_create_fastq(int device, const char *text, size_t len, int final, int min_base_qual, int use_qual, rb_batch **out, size_t *consumed);
+int rb_graph_add_fastq(rb_graph *g, const char *text, size_t len, int min_base_qual, unsigned flags, rb_add_stats *stats, int64_t *n_records);
 /* .nbits files (R/io/NucleotideBitsReader.java, R/util/SeqBitsUtils.java:159-161, 236-263: per sequence a 4-byte
  * big-endian length, then ceil(len/4) bytes of four 2-bit bases each, first base in the top bits, value - 128) straight
  * into a packed device batch: the bytes are uploaded as they are and permuted on the GPU (every base is usable — the

@@ -105,6 +105,11 @@ public final class NativeGraph {
     /** FASTQ text -> seq / qual (direct buffers of at least textLen bytes; qual may be null) + offsets; returns the record count.
      *  Call with offsets == null for the count only. */
     public static native long fastqSplit(ByteBuffer text, long textLen, int nThreads, ByteBuffer seq, ByteBuffer qual, long[] offsets);
+    /** FASTQ text (direct buffer) parsed and encoded on the GPU; isFinal = false: a piece of a longer input, consumed[0] = where the
+     *  next piece starts. */
+    public static native long batchCreateFastq(int device, ByteBuffer text, long textLen, boolean isFinal, int minBaseQual, boolean useQual, long[] consumed);
+    /** FastqToGraphWorker's loop over the text of a whole file (pieces of 1 GiB, parsed on the GPU); nRecords[0] = records inserted. */
+    public static native long[] addFastq(long h, ByteBuffer text, long textLen, int minBaseQual, int flags, long[] nRecords);
     /** NucleotideBitsWriter.write for nReads sequences; out == null: returns the size needed. */
     public static native long nbitsEncode(ByteBuffer seq, long[] offsets, int nReads, ByteBuffer out, long cap);
 }

@@ -93,6 +93,15 @@ jlong FN(batchCreateNbits)(JNIEnv *e, jclass c, jint device, jobject bytes, jlon
     if (consumed) { jlong u = (jlong)used; (*e)->SetLongArrayRegion(e, consumed, 0, 1, &u); }
     return (jlong)(intptr_t)b;
 }
+jlong FN(batchCreateFastq)(JNIEnv *e, jclass c, jint device, jobject text, jlong len, jboolean final, jint min_q, jboolean use_qual, jlongArray consumed) {
+    rb_batch *b = NULL;
+    size_t used = 0;
+    (void)c;
+    int rc = rb_batch_create_fastq(device, (const char *)direct(e, text), (size_t)len, final ? 1 : 0, min_q, use_qual ? 1 : 0, &b, &used);
+    if (rc) { throw_rc(e, rc); return 0; }
+    if (consumed) { jlong u = (jlong)used; (*e)->SetLongArrayRegion(e, consumed, 0, 1, &u); }
+    return (jlong)(intptr_t)b;
+}
 void FN(batchDestroy)(JNIEnv *e, jclass c, jlong b) { (void)c; int rc = rb_batch_destroy(B(b)); if (rc) throw_rc(e, rc); }
 jlongArray FN(batchInfo)(JNIEnv *e, jclass c, jlong b) {
     int64_t v[3] = {0, 0, 0};
@@ -133,6 +142,15 @@ jlongArray FN(addReads)(JNIEnv *e, jclass c, jlong h, jobject seq, jobject qual,
     int rc = rb_graph_add_reads(G(h), (const char *)direct(e, seq), (const char *)direct(e, qual), (const int64_t *)off, n, min_q, (unsigned)flags, &st);
     lr(e, offsets, off, JNI_ABORT);
     if (rc) { throw_rc(e, rc); return NULL; }
+    return stats_array(e, &st);
+}
+jlongArray FN(addFastq)(JNIEnv *e, jclass c, jlong h, jobject text, jlong len, jint min_q, jint flags, jlongArray n_records) {
+    rb_add_stats st;
+    int64_t recs = 0;
+    (void)c;
+    int rc = rb_graph_add_fastq(G(h), (const char *)direct(e, text), (size_t)len, min_q, (unsigned)flags, &st, &recs);
+    if (rc) { throw_rc(e, rc); return NULL; }
+    if (n_records) { jlong u = (jlong)recs; (*e)->SetLongArrayRegion(e, n_records, 0, 1, &u); }
     return stats_array(e, &st);
 }
 void FN(apply)(JNIEnv *e, jclass c, jlong h, jint op, jlongArray hashes, jint n) {

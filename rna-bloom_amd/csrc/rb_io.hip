@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "rb_pipeline.hpp"
+#include "rb_kernels.hpp"
 
 using namespace rb;
 
@@ -22,7 +23,209 @@ struct Chunk { size_t b, e; int64_t lines_before = 0; };
 inline bool eol_at(const char *t, size_t n, size_t i) { return t[i] == '\n' || (t[i] == '\r' && !(i + 1 < n && t[i + 1] == '\n')); }
 }  // namespace
 
+// ---------------------------------------------------------------------------------------------------------------------
+// The same record structure found on the GPU: the text is uploaded as it is (one PCIe crossing of the file's bytes instead
+// of a host pass over them plus two buffers), ends of line are counted per 8 KB tile, one scan turns the counts into line
+// numbers, every end of line writes the start of the line after it, a record is four consecutive entries of that table, and
+// the sequence line is 2-bit encoded straight from the text (the quality line is only looked at for the usable-base mask).
+namespace {
+constexpr uint32_t FQ_TILE = 8192, FQ_TPB = 256, FQ_PER = FQ_TILE / FQ_TPB;     // 32 bytes per thread
+
+// bit b of the result: text[i0 + b] ends a line (\n, or \r not followed by \n); bytes at or beyond n never do
+__device__ __forceinline__ uint32_t fq_eol_mask(const uint8_t *__restrict__ t, uint32_t i0, uint32_t n) {
+    if (i0 >= n) return 0u;
+    const uint4 a = *reinterpret_cast<const uint4 *>(t + i0), b = *reinterpret_cast<const uint4 *>(t + i0 + 16);   // padded allocation
+    const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    const uint32_t nxt = t[i0 + 32];
+    uint32_t m = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < 32u; ++q) {
+        const uint32_t c = (w[q >> 2] >> (8u * (q & 3u))) & 0xFFu;
+        const uint32_t d = q < 31u ? (w[(q + 1u) >> 2] >> (8u * ((q + 1u) & 3u))) & 0xFFu : nxt;
+        const bool eol = c == '\n' || (c == '\r' && d != '\n');
+        m |= (eol && i0 + q < n) ? 1u << q : 0u;
+    }
+    return m;
+}
+__global__ void __launch_bounds__(FQ_TPB) k_fq_eol_count(const uint8_t *__restrict__ t, uint32_t n, uint32_t *__restrict__ tile_cnt) {
+    __shared__ uint32_t s_w[FQ_TPB / 64];
+    const uint32_t i0 = blockIdx.x * FQ_TILE + threadIdx.x * FQ_PER;
+    uint32_t c = (uint32_t)__popc(fq_eol_mask(t, i0, n));
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+    if ((threadIdx.x & 63u) == 0) s_w[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) { uint32_t s = 0; for (uint32_t q = 0; q < FQ_TPB / 64; ++q) s += s_w[q]; tile_cnt[blockIdx.x] = s; }
+}
+// ls[0] = 0, ls[i] = start of line i = position after the i-th end of line
+__global__ void __launch_bounds__(FQ_TPB) k_fq_line_starts(const uint8_t *__restrict__ t, uint32_t n, const uint32_t *__restrict__ tile_base,
+                                                            uint32_t *__restrict__ ls) {
+    __shared__ uint32_t s_w[FQ_TPB / 64];
+    const uint32_t i0 = blockIdx.x * FQ_TILE + threadIdx.x * FQ_PER, lane = threadIdx.x & 63u, w = threadIdx.x >> 6;
+    uint32_t m = fq_eol_mask(t, i0, n);
+    const uint32_t mine = (uint32_t)__popc(m);
+    uint32_t inc = mine;
+    for (int o = 1; o < 64; o <<= 1) { const uint32_t x = __shfl_up(inc, o, 64); if ((int)lane >= o) inc += x; }
+    if (lane == 63u) s_w[w] = inc;
+    __syncthreads();
+    uint32_t base = tile_base[blockIdx.x] + inc - mine;
+    for (uint32_t q = 0; q < w; ++q) base += s_w[q];
+    if (blockIdx.x == 0 && threadIdx.x == 0) ls[0] = 0u;
+    while (m) {
+        const uint32_t b = (uint32_t)__ffs((int)m) - 1u;
+        m &= m - 1u;
+        ls[++base] = i0 + b + 1u;
+    }
+}
+// err[0]: a record whose line 1 does not start with '@'; err[1]: line 3 without '+'; err[2]: smallest record with different
+// numbers of bases and qualities; err[3]: longest read; err[4..5]: min / max words per read; bases: total
+__global__ void k_fq_records(const uint8_t *__restrict__ t, uint32_t n, const uint32_t *__restrict__ ls, uint32_t n_records, int use_qual,
+                             uint32_t *__restrict__ seq_pos, uint32_t *__restrict__ qual_pos, uint32_t *__restrict__ len,
+                             uint32_t *__restrict__ nwords, uint32_t *__restrict__ err, unsigned long long *__restrict__ bases) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t L = 0;
+    if (r < n_records) {
+        uint32_t s[4], e[4];
+        for (int f = 0; f < 4; ++f) {
+            s[f] = ls[4u * r + f];
+            const uint32_t j = ls[4u * r + f + 1u] - 1u;            // the end of line that closes it (n for an open last line)
+            uint32_t ce = j;
+            if (j < n && t[j] == '\n' && ce > s[f] && t[ce - 1u] == '\r') --ce;   // \r\n
+            e[f] = ce;
+        }
+        if (e[0] == s[0] || t[s[0]] != '@') err[0] = 1u;
+        if (e[2] == s[2] || t[s[2]] != '+') err[1] = 1u;
+        L = e[1] - s[1];
+        if (use_qual && e[3] - s[3] != L) atomicMin(&err[2], r);
+        seq_pos[r] = s[1]; qual_pos[r] = s[3]; len[r] = L;
+        const uint32_t nwd = (L + 31u) >> 5;
+        nwords[r] = nwd;
+        atomicMax(&err[3], L); atomicMin(&err[4], nwd); atomicMax(&err[5], nwd);
+    }
+    unsigned long long tot = L;
+    for (int o = 32; o > 0; o >>= 1) tot += __shfl_down(tot, o, 64);
+    if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(bases, tot);
+}
+// k_encode_ascii (rb_batch.hip) with the bases and qualities where the text has them
+__global__ void k_fq_encode(const uint8_t *__restrict__ t, const uint32_t *__restrict__ seq_pos, const uint32_t *__restrict__ qual_pos,
+                            const uint32_t *__restrict__ len, const uint32_t *__restrict__ woff, int64_t n_reads, int64_t n_words, int use_qual,
+                            int min_q, uint64_t *__restrict__ codes, uint32_t *__restrict__ valid, uint32_t *__restrict__ word_read) {
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_words) return;
+    int64_t lo = 0, hi = n_reads;                                   // owning read: largest r with woff[r] <= w
+    while (hi - lo > 1) { const int64_t mid = (lo + hi) >> 1; if (woff[mid] <= (uint32_t)w) lo = mid; else hi = mid; }
+    const uint32_t r = (uint32_t)lo, L = len[r], b0 = (uint32_t)(w - woff[r]) * 32u;
+    const uint8_t *sq = t + seq_pos[r], *ql = t + qual_pos[r];
+    uint64_t c = 0;
+    uint32_t v = 0;
+    for (uint32_t i = 0; i < 32u && b0 + i < L; ++i) {
+        uint32_t code = 4;
+        switch (sq[b0 + i]) {                                        // [ACGTU], CASE_INSENSITIVE (R/util/SeqUtils.java:1436-1438)
+            case 'A': case 'a': code = 0; break;
+            case 'C': case 'c': code = 1; break;
+            case 'G': case 'g': code = 2; break;
+            case 'T': case 't': case 'U': case 'u': code = 3; break;
+            default: break;
+        }
+        bool ok = code < 4u;
+        if (use_qual) { const uint32_t q = ql[b0 + i]; ok = ok && q >= (uint32_t)(33 + min_q) && q <= (uint32_t)'~'; }   // SeqUtils.java:1426-1434
+        if (ok) { c |= (uint64_t)code << (2u * i); v |= 1u << i; }
+    }
+    codes[w] = c; valid[w] = v; word_read[w] = r;
+}
+struct TmpBuf {                                                      // freed on every way out
+    void *p = nullptr;
+    ~TmpBuf() { if (p) (void)hipFree(p); }
+    template <class T> T *alloc(size_t n) { RB_HIP(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T))); return static_cast<T *>(p); }
+};
+}  // namespace
+
+namespace rb {
+FastqChunk fastq_batch_create(int device, const char *text, size_t n, bool final, int min_base_qual, bool use_qual, hipStream_t st) {
+    RB_REQUIRE(text || n == 0, "rb_batch_create_fastq: null text");
+    RB_REQUIRE(n < 0xFFFFFF00ull, "rb_batch_create_fastq: at most 4 GiB of text per call (got %zu bytes)", n);
+    RB_REQUIRE(min_base_qual >= 0 && min_base_qual < 94, "rb_batch_create_fastq: min_base_qual out of range");
+    RB_HIP(hipSetDevice(device));
+    if (!final && n && text[n - 1] == '\r') --n;                     // its \n may be the first byte of the next piece
+    FastqChunk out;
+    rb_batch *b = new rb_batch();
+    struct Guard { rb_batch *b; ~Guard() { if (b) rb_batch_destroy(b); } } guard{b};
+    b->device = device;
+    const uint32_t un = (uint32_t)n, ntiles = (un + FQ_TILE - 1) / FQ_TILE;
+    TmpBuf d_text, d_cnt, d_base, d_tmp, d_ls, d_sp, d_qp, d_len, d_nw, d_woff, d_err;
+    uint8_t *t = d_text.alloc<uint8_t>((size_t)ntiles * FQ_TILE + 64);
+    RB_HIP(hipMemsetAsync(t + n, 0, (size_t)ntiles * FQ_TILE + 64 - n, st));
+    if (n) RB_HIP(hipMemcpyAsync(t, text, n, hipMemcpyHostToDevice, st));
+    uint32_t *cnt = d_cnt.alloc<uint32_t>(ntiles + 1), *base = d_base.alloc<uint32_t>(ntiles + 1);
+    void *tmp = d_tmp.alloc<uint8_t>(scan_temp_bytes((size_t)ntiles + 1));
+    RB_HIP(hipMemsetAsync(cnt + ntiles, 0, 4, st));
+    if (ntiles) hipLaunchKernelGGL(k_fq_eol_count, dim3(ntiles), dim3(FQ_TPB), 0, st, t, un, cnt);
+    exclusive_scan_u32(tmp, scan_temp_bytes((size_t)ntiles + 1), cnt, base, (size_t)ntiles + 1, st);
+    uint32_t eols = 0;
+    RB_HIP(hipMemcpyAsync(&eols, base + ntiles, 4, hipMemcpyDeviceToHost, st));
+    RB_HIP(hipStreamSynchronize(st));
+    const bool open_tail = final && n > 0 && !(text[n - 1] == '\n' || text[n - 1] == '\r');
+    const uint64_t n_lines = (uint64_t)eols + (open_tail ? 1u : 0u);
+    const uint32_t R = (uint32_t)(n_lines / 4u);
+    uint32_t *ls = d_ls.alloc<uint32_t>((size_t)eols + 2);
+    if (ntiles) hipLaunchKernelGGL(k_fq_line_starts, dim3(ntiles), dim3(FQ_TPB), 0, st, t, un, base, ls);
+    else RB_HIP(hipMemsetAsync(ls, 0, 4, st));
+    const uint32_t sentinel = un + 1u;                                // "end of line" of an open last line = n
+    RB_HIP(hipMemcpyAsync(ls + eols + 1, &sentinel, 4, hipMemcpyHostToDevice, st));
+    uint32_t *sp = d_sp.alloc<uint32_t>(R), *qp = d_qp.alloc<uint32_t>(R), *ln = d_len.alloc<uint32_t>(R), *nw = d_nw.alloc<uint32_t>((size_t)R + 1),
+             *woff = d_woff.alloc<uint32_t>((size_t)R + 1);
+    uint32_t *err = d_err.alloc<uint32_t>(16);
+    const uint32_t err0[8] = {0u, 0u, ~0u, 0u, ~0u, 0u, 0u, 0u};
+    RB_HIP(hipMemcpyAsync(err, err0, sizeof err0, hipMemcpyHostToDevice, st));
+    RB_HIP(hipMemsetAsync(nw + R, 0, 4, st));
+    if (R) hipLaunchKernelGGL(k_fq_records, dim3((R + 255u) / 256u), dim3(256), 0, st, t, un, ls, R, use_qual ? 1 : 0, sp, qp, ln, nw, err,
+                              reinterpret_cast<unsigned long long *>(err + 6));
+    TmpBuf d_tmp2;
+    void *tmp2 = d_tmp2.alloc<uint8_t>(scan_temp_bytes((size_t)R + 1));
+    exclusive_scan_u32(tmp2, scan_temp_bytes((size_t)R + 1), nw, woff, (size_t)R + 1, st);
+    uint32_t herr[8], consumed32 = 0;
+    b->h_woff.assign((size_t)R + 1, 0u);
+    RB_HIP(hipMemcpyAsync(herr, err, sizeof herr, hipMemcpyDeviceToHost, st));
+    RB_HIP(hipMemcpyAsync(b->h_woff.data(), woff, ((size_t)R + 1) * 4, hipMemcpyDeviceToHost, st));
+    if ((uint64_t)4u * R <= eols) RB_HIP(hipMemcpyAsync(&consumed32, ls + (size_t)4u * R, 4, hipMemcpyDeviceToHost, st));
+    RB_HIP(hipStreamSynchronize(st));
+    RB_REQUIRE(!herr[0], "rb_batch_create_fastq: Line 1 of FASTQ record is expected to start with '@'");
+    RB_REQUIRE(!herr[1], "rb_batch_create_fastq: Line 3 of FASTQ record is expected to start with '+'");
+    RB_REQUIRE(herr[2] == ~0u, "rb_batch_create_fastq: record %u has different numbers of bases and qualities", herr[2]);
+    out.consumed = (uint64_t)4u * R <= eols ? (size_t)consumed32 : n;
+    out.records = R;
+    b->n_reads = R;
+    b->n_words = b->h_woff[R];
+    b->max_len = herr[3];
+    b->wpr_uniform = (R && herr[4] == herr[5]) ? herr[4] : 0u;
+    unsigned long long nb; memcpy(&nb, herr + 6, 8);
+    b->n_bases = (int64_t)nb;
+    RB_HIP(hipMalloc(&b->codes, (size_t)std::max<int64_t>(b->n_words, 1) * 8));
+    RB_HIP(hipMalloc(&b->valid, (size_t)std::max<int64_t>(b->n_words, 1) * 4));
+    RB_HIP(hipMalloc(&b->word_read, (size_t)std::max<int64_t>(b->n_words, 1) * 4));
+    RB_HIP(hipMalloc(&b->woff, ((size_t)R + 2) * 4));
+    RB_HIP(hipMalloc(&b->len, (size_t)std::max<uint32_t>(R, 1u) * 4));
+    b->device_bytes = (size_t)std::max<int64_t>(b->n_words, 1) * 16 + ((size_t)R + 2) * 4 + (size_t)std::max<uint32_t>(R, 1u) * 4;
+    RB_HIP(hipMemcpyAsync(b->woff, woff, ((size_t)R + 1) * 4, hipMemcpyDeviceToDevice, st));
+    if (R) RB_HIP(hipMemcpyAsync(b->len, ln, (size_t)R * 4, hipMemcpyDeviceToDevice, st));
+    if (b->n_words)
+        hipLaunchKernelGGL(k_fq_encode, dim3(blocks_for(b->n_words)), dim3(TPB), 0, st, t, sp, qp, ln, b->woff, (int64_t)R, b->n_words, use_qual ? 1 : 0,
+                           min_base_qual, b->codes, b->valid, b->word_read);
+    RB_HIP(hipGetLastError());
+    RB_HIP(hipStreamSynchronize(st));
+    out.b = b; guard.b = nullptr;
+    return out;
+}
+}  // namespace rb
+
 extern "C" {
+
+int rb_batch_create_fastq(int device, const char *text, size_t len, int final, int min_base_qual, int use_qual, rb_batch **out, size_t *consumed) {
+    return guarded([&] {
+        RB_REQUIRE(out && consumed, "rb_batch_create_fastq: null argument");
+        const FastqChunk c = rb::fastq_batch_create(device, text, len, final != 0, min_base_qual, use_qual != 0, nullptr);
+        *out = c.b; *consumed = c.consumed;
+    });
+}
 
 int rb_fastq_split(const char *text, size_t len, int n_threads, char *seq, char *qual, int64_t *offsets, int64_t cap_reads, int64_t *n_reads) {
     return guarded([&] {

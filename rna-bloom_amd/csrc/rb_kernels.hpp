@@ -53,4 +53,11 @@ void ascii_batch_begin(AsciiUpload &u, int device, const char *seq, const char *
                        int min_base_qual, hipStream_t st);
 rb_batch *ascii_batch_finish(AsciiUpload &u);
 void ascii_batch_abort(AsciiUpload &u);
+
+// FASTQ text -> packed batch, parsed on the GPU (rb_io.hip): uploads text[0, n) on `st`, finds the lines and the records
+// there and 2-bit encodes the sequence lines in place of a host-side split.  `final`: the text ends the input (a last line
+// without an end of line counts; otherwise it belongs to the caller's next piece).  consumed = bytes of the complete
+// records (where the next piece starts).  Synchronises `st`.
+struct FastqChunk { rb_batch *b = nullptr; size_t consumed = 0; int64_t records = 0; };
+FastqChunk fastq_batch_create(int device, const char *text, size_t n, bool final, int min_base_qual, bool use_qual, hipStream_t st);
 }  // namespace rb

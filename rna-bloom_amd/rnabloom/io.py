@@ -35,6 +35,15 @@ def readFastq(path, threads=0, with_qual=True):
         return splitFastq(f.read(), threads, with_qual)
 
 
+def batchFromFastq(text, device=0, minBaseQual=3, final=True, with_qual=True):
+    """FASTQ text -> ReadBatch on the device, records found and encoded there; returns (batch, bytes consumed)"""
+    from .graph import ReadBatch
+    t = np.frombuffer(text, np.uint8) if not isinstance(text, np.ndarray) else np.ascontiguousarray(text, np.uint8)
+    h = C.c_void_p(); used = C.c_size_t()
+    check(lib.rb_batch_create_fastq(device, _ptr(t), t.size, int(final), minBaseQual, int(with_qual), C.byref(h), C.byref(used)))
+    return ReadBatch(h, device), used.value
+
+
 def writeNbits(path, seq, offsets, append=False):
     """NucleotideBitsWriter: 4-byte big-endian length + 2-bit bases (first base in the top bits, value - 128) per sequence"""
     seq = np.ascontiguousarray(seq, np.uint8); off = np.ascontiguousarray(offsets, np.int64)

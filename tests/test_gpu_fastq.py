@@ -1,0 +1,110 @@
+"""FASTQ text parsed on the GPU (rb_batch_create_fastq / rb_graph_add_fastq) against the host-side splitter, which
+tests/test_io_formats.py checks against a line reader written like FastqReader (R/io/FastqReader.java:140-186)."""
+import os
+
+import numpy as np
+import pytest
+
+from test_io_formats import make_fastq
+
+pytestmark = pytest.mark.gpu
+
+
+def _same_batch(a, b):
+    assert a.n_reads == b.n_reads and a.info()["n_bases"] == b.info()["n_bases"]
+    sa, oa = a.download(); sb, ob = b.download()
+    assert (oa == ob).all() and (sa == sb).all()
+    if a.n_reads:
+        assert (a.nthash(7, 1) == b.nthash(7, 1)).all()
+
+
+@pytest.mark.parametrize("eol", [b"\n", b"\r\n", b"\r"])
+def test_gpu_fastq_records_match_the_host_splitter(eol):
+    from rnabloom import io as RIO, _native as N
+    from rnabloom.graph import ReadBatch
+    for n, tail in ((0, True), (1, True), (1, False), (7, True), (250, False), (3000, True)):
+        text = make_fastq(n, 5 + n, eol, tail)
+        for cut in (0, 1, 17, 40):                                # a truncated last record is dropped
+            t = text[:len(text) - cut] if cut and len(text) > cut else text
+            for use_qual in (True, False):
+                try:
+                    seq, qual, off = RIO.splitFastq(t, 4, with_qual=use_qual)
+                except N.NativeError as e:                         # cut inside the last quality line
+                    assert "bases and" in str(e) and use_qual
+                    with pytest.raises(N.NativeError, match="bases and"):
+                        RIO.batchFromFastq(t, with_qual=True)
+                    continue
+                want = ReadBatch.from_ascii(seq, qual, off, 3)
+                got, used = RIO.batchFromFastq(t, minBaseQual=3, with_qual=use_qual)
+                _same_batch(got, want)
+                assert used <= len(t)
+                got.close(); want.close()
+
+
+def test_gpu_fastq_pieces_resume_at_record_boundaries():
+    from rnabloom import io as RIO
+    for eol in (b"\n", b"\r\n", b"\r"):
+        text = make_fastq(400, 77, eol, True)
+        whole, used = RIO.batchFromFastq(text)
+        assert used == len(text)
+        sw, ow = whole.download()
+        for cut in (len(text) // 3, len(text) // 2 + 1, len(text) - 2, 8192, 8193, 16384 + 5):
+            cut = min(cut, len(text) - 1)
+            first, u1 = RIO.batchFromFastq(text[:cut], final=False)
+            assert 0 < u1 <= cut
+            rest, u2 = RIO.batchFromFastq(text[u1:], final=True)
+            assert u1 + u2 == len(text) and first.n_reads + rest.n_reads == whole.n_reads
+            s1, o1 = first.download(); s2, o2 = rest.download()
+            assert (np.concatenate([s1, s2]) == sw).all() and (np.concatenate([o1, o2[1:] + o1[-1]]) == ow).all()
+            first.close(); rest.close()
+        whole.close()
+
+
+def test_gpu_fastq_errors_are_the_reference_messages():
+    from rnabloom import io as RIO, _native as N
+    good = make_fastq(50, 3)
+    lines = good.split(b"\n")
+    bad1 = b"\n".join([b"read0"] + lines[1:])
+    bad3 = b"\n".join(lines[:6] + [b"-"] + lines[7:])
+    with pytest.raises(N.NativeError, match="Line 1 of FASTQ record is expected to start with '@'"):
+        RIO.batchFromFastq(bad1)
+    with pytest.raises(N.NativeError, match=r"Line 3 of FASTQ record is expected to start with '\+'"):
+        RIO.batchFromFastq(bad3)
+    short = b"\n".join(lines[:3] + [lines[3][:-1]] + lines[4:])
+    with pytest.raises(N.NativeError, match="record 0 has different numbers of bases and qualities"):
+        RIO.batchFromFastq(short)
+    b, used = RIO.batchFromFastq(short, with_qual=False)          # FASTA-like use: qualities ignored
+    assert b.n_reads == 50
+    b.close()
+
+
+def test_add_fastq_equals_add_reads_of_the_split_text(monkeypatch):
+    from rnabloom import io as RIO, _native as N
+    from rnabloom.graph import BloomFilterDeBruijnGraph
+    rng = np.random.default_rng(9)
+    genome = rng.choice(np.frombuffer(b"ACGT", np.uint8), 30000)
+    recs = []
+    for i in range(6000):
+        p = int(rng.integers(0, genome.size - 150)); L = int(rng.integers(30, 151))
+        sq = genome[p:p + L].copy()
+        sq[rng.random(L) < 0.01] = ord("N")
+        ql = np.full(L, ord("I"), np.uint8); ql[rng.random(L) < 0.02] = ord("#")
+        recs.append(b"@r%d\n" % i + sq.tobytes() + b"\n+\n" + ql.tobytes() + b"\n")
+    text = b"".join(recs)
+    sz = N.lib.rb_expected_size(60000, 0.01, 2)
+    def fresh():
+        g = BloomFilterDeBruijnGraph(sz, sz, sz, 2, 2, 2, 25, False, True, rngSeed=4)
+        g.setReadPairedKmerDistance(40)
+        return g
+    want = fresh()
+    seq, qual, off = RIO.splitFastq(text)
+    st0 = want.addReads(seq, qual, off, 3, storeReadPairedKmers=True)
+    for piece in (None, "20000", "700"):                          # one piece, many, pieces of a few records
+        if piece: monkeypatch.setenv("RB_FASTQ_PIECE", piece)
+        g = fresh()
+        st, n = g.addFastq(text, 3, storeReadPairedKmers=True)
+        assert n == 6000 and (st.kmers, st.pairs, st.reads) == (st0.kmers, st0.pairs, st0.reads)
+        for which in (N.DBGBF, N.CBF, N.RPKBF):
+            assert (g.exportFilter(which) == want.exportFilter(which)).all()
+        g.destroy()
+    want.destroy()

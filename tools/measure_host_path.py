@@ -55,7 +55,24 @@ for rep in range(2):
     st2 = g.addReads(s2, q2, o2, 3, storeReadPairedKmers=True)
     t3 = time.perf_counter()
 assert st2.kmers == km and (s2 == seq).all() and (o2 == off).all()
+# ---- the same file, records found on the GPU: file -> rb_graph_add_fastq ----
+for rep in range(2):
+    g.clearAllBf()
+    u0 = time.perf_counter()
+    text = np.fromfile(fq, np.uint8)
+    u1 = time.perf_counter()
+    st3, nrec = g.addFastq(text, 3, storeReadPairedKmers=True)
+    u2 = time.perf_counter()
+assert st3.kmers == km and nrec == pairs
+for rep in range(2):
+    g.clearAllBf()
+    m0 = time.perf_counter()
+    st4, nrec = g.addFastq(np.memmap(fq, np.uint8, "r"), 3, storeReadPairedKmers=True)      # no read() copy: the page cache is the source
+    m1 = time.perf_counter()
+assert st4.kmers == km
 os.remove(fq)
+print("FASTQ file path, records found on the GPU: read %.2f s, rb_graph_add_fastq %.2f s -> %.2f G k-mers/s end to end; from an mmap of the file: %.2f s -> %.2f G k-mers/s"
+      % (u1 - u0, u2 - u1, km / (u2 - u0) / 1e9, m1 - m0, km / (m1 - m0) / 1e9))
 print("FASTQ file path (%.2f GB of text): read %.2f s (%.1f GB/s), rb_fastq_split %.2f s (%.1f GB/s), rb_graph_add_reads %.2f s -> %.2f G k-mers/s end to end"
       % (fq_bytes / 1e9, t1 - t0, fq_bytes / 1e9 / (t1 - t0), t2 - t1, fq_bytes / 1e9 / (t2 - t1), t3 - t2, km / (t3 - t0) / 1e9))
 print("host ASCII path (seq+qual %.2f GB over PCIe, %d reads per call): %.2f G k-mers/s (%.2f s for %d k-mers)"
