@@ -76,10 +76,13 @@ PMC_KERNELS = {"filter_windows": "rb::k_filter_reads", "hash_windows": "rb::k_ha
 PMC_FILES = ("r02_pmc_fetch_size.csv", "r02_pmc_write_size.csv")
 # Correction of FETCH_SIZE (MI355X_MICROARCH.md, HBM / rocprofv3 section: the counter tallies 128-byte requests of wide
 # coalesced streaming reads as 64 bytes; "other access widths are uncalibrated: calibrate on a known byte count in your
-# own access pattern").  Calibration committed in profiles/r02_pmc_calibration.txt: k_part_count reads exactly 8 bytes per
-# record in the 8-bytes-per-lane streaming pattern all grouping kernels use, and its FETCH_SIZE comes out at half of
-# that, so FETCH x 2 for the streaming kernels; the random-access kernels (one 64-byte request per lane access) x 1.
-FETCH_FACTOR = {"group_part_count": 2.0, "group_part_scatter": 2.0, "group_buckets": 2.0, "hash_windows": 2.0, "pairs_insert": 2.0}
+# own access pattern").  Calibration committed in profiles/r02_pmc_calibration.txt: (1) k_part_count reads exactly 8 bytes per
+# record in the 8-bytes-per-lane streaming pattern all grouping kernels use, and its FETCH_SIZE comes out at half of that;
+# (2) tools/microbench/gather_bench calib: 2^28 random requests of 8 B, of one whole 64-byte line and of one whole 128-byte
+# bucket (8 x 16 B by one lane, the prefilter cache's access) are ALL tallied as 64 bytes per request.  So x 2 for the
+# streaming kernels and for filter_windows (its traffic is 128-byte bucket fetches), x 1 for kernels whose requests are
+# single words at random places.
+FETCH_FACTOR = {"filter_windows": 2.0, "group_part_count": 2.0, "group_part_scatter": 2.0, "group_buckets": 2.0, "hash_windows": 2.0}
 
 
 def pmc_traffic(stage):

@@ -211,12 +211,17 @@ __global__ void __launch_bounds__(TPB) k_part_scatter(const uint64_t *__restrict
     __shared__ uint32_t s_cnt[NW * MAXNB / 2 > MAXNB ? NW * MAXNB / 2 : MAXNB];   // u16 per (wavefront, digit); later: u32 global bases per digit
     __shared__ uint16_t s_dstart[MAXNB];
     __shared__ uint32_t s_wsum[NW];
+    // digits of up to 8 bits: match masks from LDS (gr_wave_rank_lds: the pass is bound by instruction issue, not by HBM);
+    // wider digits would need 64 KB of masks and keep the ballots
+    constexpr bool LDS_RANK = MAXBITS <= 8;
+    __shared__ unsigned long long s_wmask[LDS_RANK ? NW * MAXNB : 1];
     uint16_t *s_wcnt = reinterpret_cast<uint16_t *>(s_cnt);
     GrTile t;
     if (!gr_get_tile(tl, t)) return;
     const uint32_t nb = 1u << bits;
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     for (uint32_t d = threadIdx.x; d < NW * nb; d += TPB) s_wcnt[d] = 0;
+    if (LDS_RANK) for (uint32_t d = threadIdx.x; d < NW * nb; d += TPB) s_wmask[d] = 0ull;
     // rows of this wavefront: records w*SEG + r*64 + lane of the tile
     uint64_t k[ITEMS];
     uint32_t v[ITEMS], dig[ITEMS], rank[ITEMS];
@@ -230,7 +235,8 @@ __global__ void __launch_bounds__(TPB) k_part_scatter(const uint64_t *__restrict
     }
     const uint32_t rows = t.count > w * SEG ? min(ITEMS, (t.count - w * SEG + 63u) / 64u) : 0u;
     __syncthreads();
-    gr_wave_rank<ITEMS>(dig, rank, s_wcnt + w * nb, bits, rows);
+    if (LDS_RANK) gr_wave_rank_lds<ITEMS>(dig, rank, s_wcnt + w * nb, s_wmask + w * nb, rows);
+    else gr_wave_rank<ITEMS>(dig, rank, s_wcnt + w * nb, bits, rows);
     __syncthreads();
     gr_digit_offsets<TPB>(s_wcnt, s_dstart, nb, s_wsum);
     __syncthreads();

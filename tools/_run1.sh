@@ -1,6 +1,6 @@
 set -x
-timeout 900 python -m pytest tests/test_gpu_fastq.py -x -q > gpurun_out/pytest_fq.log 2>&1
-tail -15 gpurun_out/pytest_fq.log
-export TMPDIR=/tmp
-RB_HOST_TIMING=1 timeout 1200 python tools/measure_host_path.py 10000000 > gpurun_out/host_path.log 2>&1
-grep -v "^+" gpurun_out/host_path.log | tail -8
+R=$PWD
+cd /tmp && export TMPDIR=/tmp
+timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/prof_cal -o c -- $R/tools/microbench/gather_bench calib > $R/gpurun_out/calib.log 2>&1
+python $R/profiles/summarize.py pmc $(find /tmp/prof_cal -name '*counter_collection.csv' | head -1) FETCH_SIZE > $R/gpurun_out/calib_fetch.csv
+cat $R/gpurun_out/calib_fetch.csv

@@ -31,4 +31,15 @@ print("  records per step %d x %d steps x 2 passes x 8 B = %.3f GB read by const
 print("  FETCH_SIZE total over its %d dispatches        = %.3f GB" % (sum(int(r[1]) for r in hit), fetch / 1e9))
 print("  known / counter = %.3f   (the guide: 128-byte requests of coalesced streaming reads are tallied as 64 bytes -> x 2)" % (known / fetch))
 PY
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/prof_cal -o c -- $R/tools/microbench/gather_bench calib > $OUT/calib.log 2>&1
+python - <<PY >> $OUT/pmc_calibration.txt
+import subprocess, sys
+rows = subprocess.run([sys.executable, "$R/profiles/summarize.py", "pmc", subprocess.run("find /tmp/prof_cal -name '*counter_collection.csv' | head -1", shell=True, capture_output=True, text=True).stdout.strip(), "FETCH_SIZE"], capture_output=True, text=True).stdout.splitlines()[1:]
+print("FETCH_SIZE per random request (tools/microbench/gather_bench calib: 2^28 requests per kernel into a 4 GB table, one lane each):")
+for r in rows:
+    k, n, tot, _ = r.rsplit(",", 3)
+    if k.startswith("k_calib"):
+        print("  %-14s reads %3s bytes per request: FETCH_SIZE %.3f GB = %.1f bytes per request" % (k, k[k.index("<") + 1:-1], float(tot) * 1024 / 1e9, float(tot) * 1024 / 2 ** 28))
+print("  -> a 128-byte bucket read is tallied as 64 bytes like a 128-byte streaming request: x 2 for k_filter_reads' bucket fetches")
+PY
 cat $OUT/pytest_gpu.txt; tail -c 1500 $OUT/bench.json; echo; head -14 $OUT/kernel_stats.csv; cat $OUT/pmc_calibration.txt; head -8 $OUT/pmc_FETCH_SIZE.csv

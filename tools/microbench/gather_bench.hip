@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
@@ -39,7 +40,37 @@ template <int K, int LINE> double run(const uint64_t *tab, uint64_t n, uint64_t 
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     return (double)blocks * tpb * iters * K / (ms * 1e-3) / 1e9;
 }
-int main() {
+// what FETCH_SIZE tallies per random request (run under rocprofv3 --pmc FETCH_SIZE: `gather_bench calib`): one lane reads 8 B,
+// a whole 64-byte line (4 x 16 B) or a whole 128-byte bucket (8 x 16 B, the minimizer-bucketed prefilter cache's access) at a
+// random aligned place of a 4 GB table; every kernel issues exactly 2^28 such requests
+template <int BYTES>
+__global__ void k_calib(const uint64_t *__restrict__ tab, uint64_t mask, int iters, uint64_t *out) {
+    uint64_t s = mix((uint64_t)blockIdx.x * blockDim.x + threadIdx.x + 77), acc = 0;
+    for (int it = 0; it < iters; ++it) {
+        s = mix(s);
+        const uint64_t idx = s & mask;
+        if (BYTES == 8) acc += tab[idx];
+        else {
+            const ulonglong2 *b = reinterpret_cast<const ulonglong2 *>(tab + (idx & ~(uint64_t)(BYTES / 8 - 1)));
+#pragma unroll
+            for (int q = 0; q < BYTES / 16; ++q) { const ulonglong2 a = b[q]; acc += a.x ^ a.y; }
+        }
+    }
+    if (acc == 0x1234567ull) out[0] = acc;
+}
+static int calib() {
+    uint64_t *out, *tab; const uint64_t n = 1ull << 29;            // 4 GB
+    CK(hipMalloc(&out, 64)); CK(hipMalloc(&tab, n * 8)); CK(hipMemset(tab, 1, n * 8));
+    const int blocks = 1 << 14, tpb = 256, iters = 64;             // 2^14 * 2^8 * 2^6 = 2^28 requests per kernel
+    hipLaunchKernelGGL((k_calib<8>), dim3(blocks), dim3(tpb), 0, 0, tab, n - 1, iters, out);
+    hipLaunchKernelGGL((k_calib<64>), dim3(blocks), dim3(tpb), 0, 0, tab, n - 1, iters, out);
+    hipLaunchKernelGGL((k_calib<128>), dim3(blocks), dim3(tpb), 0, 0, tab, n - 1, iters, out);
+    CK(hipDeviceSynchronize());
+    printf("issued %llu requests per kernel (k_calib<8>, <64>, <128>)\n", (unsigned long long)blocks * tpb * iters);
+    return 0;
+}
+int main(int argc, char **argv) {
+    if (argc > 1 && !strcmp(argv[1], "calib")) return calib();
     uint64_t *out; CK(hipMalloc(&out, 64));
     const int blocks = 256 * 32, tpb = 256;
     printf("%-10s %-6s %8s %8s %8s %8s\n", "table", "what", "K=1", "K=2", "K=4", "K=8");
