@@ -175,7 +175,8 @@ int rb_filter_get_count(rb_graph *g, const uint64_t *h0, size_t n, float *out);
 /* getKmers(String) :1224-1226 -> {Canonical,}HashFunction.getKmers: for every window of every
  * read of the batch: forward hash, reverse hash (0 when stranded), count (0 for windows that
  * contain a non-ACGTU base).  koffsets[n_reads+1] receives the per-read output offsets
- * (read i has max(0,len_i-k+1) windows); pass f=r=count=NULL to query sizes only. */
+ * (read i has max(0,len_i-k+1) windows); pass f=r=count=NULL to query sizes only.  * On a shard handle (rb_graph_create_shard) only the hashes are local: count = 1 for a usable window, 0 otherwise; the counts of a
+ * distributed graph come from one rb_shard_query_* exchange (rnabloom/sharded.py::ShardRank.getKmers). */
 int rb_graph_kmers(rb_graph *g, const char *seq, const int64_t *offsets, int64_t n_reads,
                    int64_t *koffsets, uint64_t *f, uint64_t *r, float *count);
 /* Kmer.getSuccessors/getPredecessors R/graph/Kmer.java:210-255, CanonicalKmer.java:226-270:
@@ -184,7 +185,7 @@ int rb_graph_kmers(rb_graph *g, const char *seq, const int64_t *offsets, int64_t
  * (char_out = last base); 2 = left variants (first base replaced, char_out = first base), 3 = right
  * variants (last base replaced, char_out = last base) — Kmer.getLeftVariants/getRightVariants
  * R/graph/Kmer.java:357-405 over R/bloom/hash/{,Canonical}{Left,Right}VariantsNTHashIterator.java; the
- * entry whose base equals char_out is the k-mer itself.  Callers apply minKmerCov to count4. */
+ * entry whose base equals char_out is the k-mer itself.  Callers apply minKmerCov to count4.  * On a shard handle: candidate hashes only (count4 = 0), counts by rb_shard_query_* (ShardRank.neighbors). */
 int rb_graph_neighbors(rb_graph *g, const uint64_t *f, const uint64_t *r, const uint8_t *char_out,
                        size_t n, int direction, uint64_t *f4, uint64_t *r4, float *count4);
 

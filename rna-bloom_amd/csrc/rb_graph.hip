@@ -957,6 +957,8 @@ __global__ void k_cbf_count(FilterView fv, const uint64_t *__restrict__ h0, size
 // getKmers: hash EVERY window of a read (unusable bases hash as seed 0, exactly like seedTab's
 // zero rows, R/bloom/hash/NTHash.java:133-166), count = 0 for windows containing an unusable base
 // (R/bloom/hash/CanonicalHashFunction.java:46-78).  One thread per 32-window chunk.
+// HASH_ONLY (a shard of a distributed graph: the counts come from a query exchange): out_c = 1 where the window is usable
+template <bool HASH_ONLY>
 __global__ void k_get_kmers(FilterView fv, int stranded, const uint64_t *__restrict__ codes,
                             const uint32_t *__restrict__ valid, const uint32_t *__restrict__ word_read,
                             const uint32_t *__restrict__ woff, const uint32_t *__restrict__ len,
@@ -993,7 +995,7 @@ __global__ void k_get_kmers(FilterView fv, int stranded, const uint64_t *__restr
             const uint64_t base = stranded ? f : canonical(f, rv);
             out_f[o] = f;
             out_r[o] = stranded ? 0ull : rv;
-            out_c[o] = run >= uk ? graph_count(fv, base) : 0.0f;
+            out_c[o] = run >= uk ? (HASH_ONLY ? 1.0f : graph_count(fv, base)) : 0.0f;
         }
     }
 }
@@ -1004,6 +1006,7 @@ __device__ __forceinline__ uint32_t code_of_char(uint32_t ch) {
     switch (ch) { case 'A': case 'a': return 0; case 'C': case 'c': return 1; case 'G': case 'g': return 2;
                   case 'T': case 't': case 'U': case 'u': return 3; default: return 4; }
 }
+template <bool HASH_ONLY>
 __global__ void k_neighbors(FilterView fv, int stranded, int k, int direction, const uint64_t *__restrict__ f,
                             const uint64_t *__restrict__ r, const uint8_t *__restrict__ ch, size_t n,
                             uint64_t *__restrict__ f4, uint64_t *__restrict__ r4, float *__restrict__ c4) {
@@ -1029,7 +1032,7 @@ __global__ void k_neighbors(FilterView fv, int stranded, int k, int direction, c
     }
     f4[t] = nf;
     if (r4) r4[t] = nr;
-    c4[t] = graph_count(fv, stranded ? nf : smin(nf, nr));
+    c4[t] = HASH_ONLY ? 0.0f : graph_count(fv, stranded ? nf : smin(nf, nr));
 }
 
 // ---- greedy maximum-coverage walk: the loop around Kmer.getMaxCovSuccessor / getMaxCovPredecessor ----
@@ -2432,7 +2435,6 @@ int rb_graph_kmers(rb_graph *g, const char *seq, const int64_t *offsets, int64_t
                    uint64_t *f, uint64_t *r, float *count) {
     return guarded([&] {
         RB_REQUIRE(g && offsets && koffsets && n_reads >= 0, "rb_graph_kmers: null argument");
-        RB_REQUIRE(!g->shard, "rb_graph_kmers: queries are not available on a shard handle");
         koffsets[0] = 0;
         for (int64_t i = 0; i < n_reads; ++i) {
             int64_t l = offsets[i + 1] - offsets[i];
@@ -2449,9 +2451,16 @@ int rb_graph_kmers(rb_graph *g, const char *seq, const int64_t *offsets, int64_t
         q.c->b0.reserve(((size_t)n_reads + 1) * 8); q.c->b1.reserve((size_t)total * 8);
         q.c->b2.reserve((size_t)total * 8); q.c->b3.reserve((size_t)total * 4);
         RB_HIP(hipMemcpyAsync(q.c->b0.p, koffsets, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_get_kmers, dim3(blocks_for(b->n_words)), dim3(TPB), 0, s, g->view(0, 0), (int)g->stranded,
-                           b->codes, b->valid, b->word_read, b->woff, b->len, b->n_words, g->k, q.c->b0.as<int64_t>(),
-                           q.c->b1.as<uint64_t>(), q.c->b2.as<uint64_t>(), q.c->b3.as<float>());
+        // on a shard of a distributed graph only the hashes are local (count = 1 for a usable window): the caller gets the
+        // counts with one rb_shard_query_* exchange (rnabloom/sharded.py::ShardRank.getKmers)
+        if (g->shard)
+            hipLaunchKernelGGL(k_get_kmers<true>, dim3(blocks_for(b->n_words)), dim3(TPB), 0, s, g->view(0, 0), (int)g->stranded,
+                               b->codes, b->valid, b->word_read, b->woff, b->len, b->n_words, g->k, q.c->b0.as<int64_t>(),
+                               q.c->b1.as<uint64_t>(), q.c->b2.as<uint64_t>(), q.c->b3.as<float>());
+        else
+            hipLaunchKernelGGL(k_get_kmers<false>, dim3(blocks_for(b->n_words)), dim3(TPB), 0, s, g->view(0, 0), (int)g->stranded,
+                               b->codes, b->valid, b->word_read, b->woff, b->len, b->n_words, g->k, q.c->b0.as<int64_t>(),
+                               q.c->b1.as<uint64_t>(), q.c->b2.as<uint64_t>(), q.c->b3.as<float>());
         RB_HIP(hipGetLastError());
         RB_HIP(hipMemcpyAsync(f, q.c->b1.p, (size_t)total * 8, hipMemcpyDeviceToHost, s));
         if (r) RB_HIP(hipMemcpyAsync(r, q.c->b2.p, (size_t)total * 8, hipMemcpyDeviceToHost, s));
@@ -2466,7 +2475,6 @@ int rb_graph_neighbors(rb_graph *g, const uint64_t *f, const uint64_t *r, const 
         RB_REQUIRE(g && (n == 0 || (f && char_out && f4 && count4)), "rb_graph_neighbors: null argument");
         RB_REQUIRE(g->stranded || n == 0 || r, "rb_graph_neighbors: reverse hashes required for a canonical graph");
         RB_REQUIRE(direction >= 0 && direction <= 3, "rb_graph_neighbors: direction must be 0..3");
-        RB_REQUIRE(!g->shard, "rb_graph_neighbors: queries are not available on a shard handle");
         if (!n) return;
         QueryLease q(g);
         hipStream_t s = q.c->st;
@@ -2476,8 +2484,12 @@ int rb_graph_neighbors(rb_graph *g, const uint64_t *f, const uint64_t *r, const 
         RB_HIP(hipMemcpyAsync(df, f, n * 8, hipMemcpyHostToDevice, s));
         if (r) RB_HIP(hipMemcpyAsync(dr, r, n * 8, hipMemcpyHostToDevice, s));
         RB_HIP(hipMemcpyAsync(dc, char_out, n, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_neighbors, dim3(blocks_for((int64_t)n * 4)), dim3(TPB), 0, s, g->view(0, 0), (int)g->stranded, g->k,
-                           direction, df, dr, dc, n, q.c->b1.as<uint64_t>(), q.c->b2.as<uint64_t>(), q.c->b3.as<float>());
+        if (g->shard)      // hashes only (count4 = 0): the counts of a distributed graph come from a query exchange (ShardRank.neighbors)
+            hipLaunchKernelGGL(k_neighbors<true>, dim3(blocks_for((int64_t)n * 4)), dim3(TPB), 0, s, g->view(0, 0), (int)g->stranded, g->k,
+                               direction, df, dr, dc, n, q.c->b1.as<uint64_t>(), q.c->b2.as<uint64_t>(), q.c->b3.as<float>());
+        else
+            hipLaunchKernelGGL(k_neighbors<false>, dim3(blocks_for((int64_t)n * 4)), dim3(TPB), 0, s, g->view(0, 0), (int)g->stranded, g->k,
+                               direction, df, dr, dc, n, q.c->b1.as<uint64_t>(), q.c->b2.as<uint64_t>(), q.c->b3.as<float>());
         RB_HIP(hipGetLastError());
         RB_HIP(hipMemcpyAsync(f4, q.c->b1.p, n * 32, hipMemcpyDeviceToHost, s));
         if (r4) RB_HIP(hipMemcpyAsync(r4, q.c->b2.p, n * 32, hipMemcpyDeviceToHost, s));

@@ -238,6 +238,45 @@ class ShardRank:
         if out is not None:
             out.append(res.astype(bool) if what == 0 else res)
 
+    def getKmers(self, reads, out=None):
+        """Coroutine: graph.getKmers(String) (R/bloom/hash/CanonicalHashFunction.java:46-78) for this rank's list of sequences
+        on the SHARDED graph: the window hashes are rolled on this rank's GPU (rb_graph_kmers on a shard handle: hashes +
+        usable flags), the counts come from ONE query exchange.  out gets (koffsets, f, r, count) as graph.getKmers returns."""
+        lens = np.fromiter((len(x) for x in reads), np.int64, len(reads))
+        off = np.zeros(len(reads) + 1, np.int64); np.cumsum(lens, out=off[1:])
+        seq = np.frombuffer(b"".join(reads), np.uint8) if len(reads) else np.zeros(0, np.uint8)
+        ko = np.zeros(len(reads) + 1, np.int64)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        check(lib.rb_graph_kmers(self.h, vp(seq), vp(off), len(reads), vp(ko), None, None, None))
+        t = int(ko[-1])
+        f = np.zeros(t, np.uint64); r = np.zeros(t, np.uint64); usable = np.zeros(t, np.float32)
+        if t:
+            check(lib.rb_graph_kmers(self.h, vp(seq), vp(off), len(reads), vp(ko), vp(f), vp(r), vp(usable)))
+        h0 = f if self.p.stranded else np.where(r.view(np.int64) < f.view(np.int64), r, f)
+        ask = np.nonzero(usable > 0)[0]                          # windows with a non-ACGTU base count 0 without asking (:73-78)
+        res = []
+        yield from self.query(2, h0[ask], out=res)
+        cnt = np.zeros(t, np.float32)
+        cnt[ask] = res[0]
+        if out is not None:
+            out.append((ko, f, r, cnt))
+
+    def neighbors(self, f, r, char_out, direction, out=None):
+        """Coroutine: Kmer.getSuccessors / getPredecessors (direction 0 / 1, R/graph/Kmer.java:199-255) and the left / right
+        variants (2 / 3) for this rank's k-mers on the SHARDED graph: candidate hashes on this rank's GPU (rb_graph_neighbors on
+        a shard handle), their counts from one query exchange.  out gets (f4, r4, count4), shaped [n, 4]."""
+        f = np.ascontiguousarray(np.atleast_1d(f), np.uint64); r = np.ascontiguousarray(np.atleast_1d(r), np.uint64)
+        ch = np.ascontiguousarray(np.atleast_1d(char_out), np.uint8)
+        n = f.size
+        f4 = np.zeros((n, 4), np.uint64); r4 = np.zeros((n, 4), np.uint64); c4 = np.zeros((n, 4), np.float32)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p)
+        check(lib.rb_graph_neighbors(self.h, vp(f), vp(r), vp(ch), n, direction, vp(f4), vp(r4), vp(c4)))
+        h0 = f4 if self.p.stranded else np.where(r4.view(np.int64) < f4.view(np.int64), r4, f4)
+        res = []
+        yield from self.query(2, h0.reshape(-1), out=res)
+        if out is not None:
+            out.append((f4, r4, res[0].reshape(n, 4)))
+
     def walk(self, seeds, direction, bound, min_cov=1.0, out=None):
         """Coroutine: greedy maximum-coverage walks (the semantics of rb_graph_walk without a target) on the SHARDED graph.
         The filters are spread over the ranks, so every step is one query exchange for the 4 neighbours of every walk
@@ -644,6 +683,18 @@ class LoopbackCluster:
         """per_rank_seeds[r] = the seed k-mers of virtual rank r -> per rank (bases, count, len, reason), as graph.walkMaxCov"""
         outs = [[] for _ in self.ranks]
         run_loopback([r.walk(sd, direction, bound, minKmerCov, o) for r, sd, o in zip(self.ranks, per_rank_seeds, outs)])
+        return [o[0] for o in outs]
+
+    def getKmers(self, per_rank_reads):
+        """per_rank_reads[r] = the sequences virtual rank r asks about -> per rank (koffsets, f, r, count), as graph.getKmers"""
+        outs = [[] for _ in self.ranks]
+        run_loopback([rk.getKmers(rd, o) for rk, rd, o in zip(self.ranks, per_rank_reads, outs)])
+        return [o[0] for o in outs]
+
+    def getNeighbors(self, per_rank_frc, direction):
+        """per_rank_frc[r] = (f, r, charOut) of virtual rank r's k-mers -> per rank (f4, r4, count4), as graph.getNeighbors"""
+        outs = [[] for _ in self.ranks]
+        run_loopback([rk.neighbors(a, b, c, direction, o) for rk, (a, b, c), o in zip(self.ranks, per_rank_frc, outs)])
         return [o[0] for o in outs]
 
     def getCbfCount(self, per_rank_h0):

@@ -167,3 +167,43 @@ def test_walks_on_a_sharded_graph(G, stranded):
             seen |= set(er.tolist())
     assert seen >= {0, 2, 3, 4}
     g1.destroy(); cl.destroy()
+
+
+@pytest.mark.parametrize("G,stranded", [(1, False), (2, True), (4, False), (8, False)])
+def test_get_kmers_and_neighbours_on_a_sharded_graph(G, stranded):
+    """graph.getKmers and Kmer.getSuccessors / getPredecessors / variants on the sharded graph (hashes on the asking rank's GPU,
+    counts from one query exchange) against the single-GPU graph built from the same reads; ranks ask about different
+    sequences, one of them about none; sequences with N and shorter than k."""
+    from rnabloom.graph import BloomFilterDeBruijnGraph
+    d = synth.generate_pairs(1200, G=3000, err=0.004, n_rate=2e-3, seed=21)
+    sizes = (250_007, 1_000_003, 50_021)
+    s, off = synth.flat(d["left"]); q, _ = synth.flat(d["lqual"])
+    g1 = BloomFilterDeBruijnGraph(*sizes, 2, 2, 2, 25, stranded, True, rngSeed=5)
+    cl = LoopbackCluster(G, *sizes, 2, 2, 2, 25, stranded, True, rngSeed=5)
+    g1.addReads(s, q, off, 3)
+    cl.addBatch(ReadBatch.from_ascii(s, q, off, 3), 150, reads_per_substep=500)
+    rng = np.random.default_rng(8)
+    reads = [bytes(s[off[i]:off[i + 1]]) for i in rng.integers(0, 1200, 90)] + [b"ACGT", b"", b"ACGTNACGT" * 6]
+    rnd = bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), 80))          # mostly absent k-mers
+    reads.append(rnd)
+    cuts = [0] + sorted(rng.integers(0, len(reads), G - 1).tolist()) + [len(reads)] if G > 1 else [0, len(reads)]
+    if G > 2:
+        cuts[1] = cuts[0]
+    per_rank = [reads[cuts[i]:cuts[i + 1]] for i in range(G)]
+    got = cl.getKmers(per_rank)
+    allf, allr, allc = [], [], []
+    for rk in range(G):
+        ko, f, r, c = got[rk]
+        eko, ef, er, ec = g1.getKmers(per_rank[rk])
+        assert (ko == eko).all() and (f == ef).all() and (r == er).all() and (c == ec).all()
+        allf.append(f); allr.append(r); allc.append(c)
+    assert sum((c > 0).sum() for c in allc) > 1000 and sum((c == 0).sum() for c in allc) > 50
+    # neighbours of the k-mers found above (first base of each k-mer as charOut for successors, a fixed one otherwise)
+    for direction in (0, 1, 2, 3):
+        frc = [(allf[rk][:300], allr[rk][:300], np.full(min(300, allf[rk].size), b"ACGT"[direction], np.uint8)) for rk in range(G)]
+        res = cl.getNeighbors(frc, direction)
+        for rk in range(G):
+            ef4, er4, ec4 = g1.getNeighbors(*frc[rk], direction)
+            f4, r4, c4 = res[rk]
+            assert (f4 == ef4).all() and (r4 == er4).all() and (c4 == ec4).all()
+    g1.destroy(); cl.destroy()
