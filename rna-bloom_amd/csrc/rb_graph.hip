@@ -310,6 +310,7 @@ __global__ void k_cs_build(const uint32_t *__restrict__ status, const uint64_t *
 
 // ---- stage B: resolve the found-flag of the first occurrence, set Bloom bits, then apply the
 // counter updates of runs that own their counters alone; queue the rest ----
+__device__ unsigned long long g_dbg_hist[96];     // RB_DEBUG: ops by (true exponent, cached exponent); uncached ops by bucket occupancy
 __global__ void k_resolve_apply(FilterView fv, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ counts,
                                 const uint32_t *__restrict__ starts, const uint32_t *__restrict__ vals,
                                 uint32_t n_distinct, int mode, uint32_t LIGHT_OPS, const Slot *ftable, uint32_t f_log2,
@@ -364,6 +365,16 @@ __global__ void k_resolve_apply(FilterView fv, const uint64_t *__restrict__ uniq
         float drop = (all_pre && mn >= 16u) ? (float)ops * (1.0f - 1.0f / (float)(1u << ((mn >> 3) - 1u))) : 0.0f;
         atomicAdd(&dbgf[2 * (blockIdx.x & 63u)], drop);
         atomicAdd(&dbgf[2 * (blockIdx.x & 63u) + 1], (float)ops);
+        if (all_pre && mn >= 16u && fv.mpf.tab && fv.seq_codes) {     // what did the prefilter cache know about this k-mer?
+            const uint32_t occ = vals[starts[d]];
+            const uint32_t r = fv.seq_first + (occ >> fv.pos_bits), p = occ & ((1u << fv.pos_bits) - 1u);
+            const uint64_t bk = mpf_bucket(fv.mpf, window_min_order(fv.seq_codes + fv.seq_woff[r], p, (uint32_t)fv.k, fv.mpf.m));
+            const uint32_t sc = mpf_match(fv.mpf.tab + (bk << 4), 1u, h0), s0 = min((mn >> 3) - 1u, 7u);
+            atomicAdd(&g_dbg_hist[s0 * 8u + sc], (unsigned long long)ops);
+            uint32_t occupied = 0;
+            for (uint32_t q = 0; q < 16u; ++q) occupied += fv.mpf.tab[(bk << 4) + q] != 0ull;
+            if (sc == 0u) atomicAdd(&g_dbg_hist[64u + occupied], (unsigned long long)ops);
+        }
     }
     if (!(st & ST_CLAIMED)) return;
     uint64_t idx[RB_MAX_HASH];
@@ -1662,7 +1673,24 @@ void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, ui
         RB_HIP(hipStreamSynchronize(s));
         double dr = 0, tot = 0;
         for (int q = 0; q < 64; ++q) { dr += df[2 * q]; tot += df[2 * q + 1]; }
-        fprintf(stderr, "[rb] droppable ops (perfect cache): %.1f%% of %.0f ops (N=%zu)\n", tot ? 100.0 * dr / tot : 0.0, tot, N);
+        unsigned long long hh[96];
+        RB_HIP(hipMemcpyFromSymbol(hh, HIP_SYMBOL(g_dbg_hist), sizeof hh));
+        // (dr assumes UNFILTERED ops: with the prefilter on, the ops of a correctly cached k-mer are the ones that succeed; what a
+        // perfect cache would still drop are the no-op shares of the k-mers it does not hold — column 0 of the table below)
+        double miss = 0;
+        for (int s0 = 1; s0 < 8; ++s0) miss += (double)hh[s0 * 8] * (1.0 - 1.0 / (double)(1u << s0));
+        fprintf(stderr, "[rb] ops a perfect cache would drop: %.1f%% of %.0f ops (N=%zu; %.1f%% if no occurrence had been filtered)\n",
+                tot ? 100.0 * miss / tot : 0.0, tot, N, tot ? 100.0 * dr / tot : 0.0);
+        for (int s0 = 1; s0 < 8; ++s0) {
+            fprintf(stderr, "[rb]   true exponent %d: ops by cached exponent 0..7 (M):", s0);
+            for (int sc = 0; sc < 8; ++sc) fprintf(stderr, " %.1f", hh[s0 * 8 + sc] / 1e6);
+            fprintf(stderr, "\n");
+        }
+        fprintf(stderr, "[rb]   uncached ops by occupied slots of their bucket 0..16 (M):");
+        for (int q = 0; q <= 16; ++q) fprintf(stderr, " %.1f", hh[64 + q] / 1e6);
+        fprintf(stderr, "\n");
+        memset(hh, 0, sizeof hh);
+        RB_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_dbg_hist), hh, sizeof hh));
     }
     g->prof_begin();
     g->temp.reserve(select2_temp_bytes(D));

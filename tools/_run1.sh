@@ -1,1 +1,2 @@
-timeout 900 python -m pytest tests/test_gpu_sharded.py -x -q -k "get_kmers or walks" 2>&1 | tail -15
+RB_DEBUG=1 timeout 900 python bench.py --no-cpu-baseline --steps 1 --warmup 0 > gpurun_out/bench_dbg.log 2>&1
+grep "\[rb\]" gpurun_out/bench_dbg.log | grep -v "N=.*D=" | tail -64
