@@ -59,8 +59,9 @@ def algorithmic_bytes(stage, n_kmers, n_pairs, n_runs, words, n_sorted=None, gro
         "probe_claim": n_runs * (h * SECTOR + h * 2 * SECTOR + 36),
         # per run: h counter byte stores (sector write), one strength sector, 40 B of records
         "resolve_apply": n_runs * (h * SECTOR + SECTOR + 40),
-        # per pair: h bit-sets (atomic RMW on a sector); reads are re-walked: 16 B per word
-        "pairs_insert": words * 16 + n_pairs * h * 2 * SECTOR,
+        # per pair: h bit probes, test before set (one sector read; the write-back of the few new bits is not counted — the
+        # counters show 134 B per pair for h = 2); reads are re-walked: 16 B per word
+        "pairs_insert": words * 16 + n_pairs * h * SECTOR,
     }
     return model.get(stage)
 
