@@ -177,13 +177,22 @@ def main():
         sr.set_read_pair_distance(dist_pk)
         pos_bits, rps = sharded.plan(150, k, world, a.batch_kmers or sharded.default_batch_kmers(world, sr.mode))
         g = SimpleNamespace(profileEnable=lambda on: check_(sr, on), profileGet=lambda reset=True: prof_(sr, reset))
+        # RB_SHARD_DRIVER=native: phases AND exchanges inside the library (csrc/rb_comm.hip: ncclSend / ncclRecv groups on the
+        # library's stream, nothing interpreted between the phases).  The default stays the torch.distributed driver of
+        # rnabloom/sharded.py: it is the one that has run with several real processes (gloo, 2-4 ranks sharing the test GPU);
+        # the native driver has run with 1-8 virtual ranks (threads + device copies) and over RCCL at world 1 only.
+        native = os.environ.get("RB_SHARD_DRIVER", "").lower() == "native" and backend == "nccl"
+        comm = sharded.NativeComm.rccl(dist, local) if native else None
 
         def step():
             sr.clear()
             out = []
             for first, fl in ((0, N.ADD_STORE_READ_PAIRS), (pairs_total, N.ADD_STORE_READ_PAIRS | N.ADD_REVCOMP)):
                 before = dict(sr.stats)
-                sharded.run_distributed(sr.add_range(batch, first, pairs_total, fl, rps, pos_bits))
+                if native:
+                    sharded.add_range_native(sr, comm, batch, first, pairs_total, fl, rps, pos_bits)
+                else:
+                    sharded.run_distributed(sr.add_range(batch, first, pairs_total, fl, rps, pos_bits))
                 out.append(SimpleNamespace(**{kk: sr.stats[kk] - before[kk] for kk in before}))
             return out
 
@@ -268,7 +277,7 @@ def main():
                        "prefilter_survival": round(n_sorted / max(1, kmers), 4),
                        "note": "throughput depends on the coverage: the no-op prefilter drops occurrences that provably cannot change a counter (here all but the survival fraction); at low coverage or k > 64 the same engine sorts every occurrence (DESIGN.md s5)",
                        "parallelism": ("single GPU" if not sharded_mode else "filters index-sharded x%d, k-mers hash-sharded (%s mode), %s all_to_all"
-                                       % (world, sr.mode, "RCCL" if backend == "nccl" else backend))},
+                                       % (world, sr.mode, ("RCCL send/recv below the C ABI" if native else "RCCL") if backend == "nccl" else backend))},
             "stages_ms_per_step": {n: round(v[0] / a.steps, 2) for n, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
             "roofline": roof,
         }

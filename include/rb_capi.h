@@ -442,6 +442,24 @@ int rb_shard_query_serve(rb_graph *g, int which_bits, const void *bidx_dev, int6
 int rb_shard_query_finish(rb_graph *g, int which_bits, const void *breply_dev, const void *creply_dev,
                           uint8_t *out8_host /* what 0 */, float *outf_host /* what 1, 2 */);
 
+/* ---- the exchange driver below the C ABI (csrc/rb_comm.hip) ----
+ * rb_shard_add_range = rnabloom/sharded.py::ShardRank.add_range in the library: all sub-batches of reads [first, first + n)
+ * (the same call on every rank, every rank holding the same batch), every phase above and every exchange between them, on the
+ * handle's stream — nothing but per-peer byte counts visits the host, no interpreter between the phases.  ordinal0 = reads
+ * inserted since the last clear (the op ordinal of read `first`).  The communicator is either
+ *   RCCL (one process per GPU): rank 0 calls rb_shard_comm_unique_id, the 128 bytes travel to the other ranks by whatever the
+ *     host has (torch.distributed broadcast, MPI, a file), every rank calls rb_shard_comm_create_rccl; transfers are
+ *     ncclSend / ncclRecv groups in pieces of at most 256 MiB per peer (librccl.so is loaded with dlopen on first use), or
+ *   a loopback hub for `world` virtual ranks of ONE process on one GPU (one host thread per rank calls rb_shard_add_range with
+ *     the same hub; device-to-device copies): what the one-GPU tests drive the protocol with. */
+typedef struct rb_shard_comm rb_shard_comm;
+int rb_shard_comm_unique_id(void *out128);
+int rb_shard_comm_create_rccl(const void *id128, int rank, int world, int device, rb_shard_comm **out);
+int rb_shard_comm_create_loopback(int world, rb_shard_comm **out);
+int rb_shard_comm_destroy(rb_shard_comm *c);
+int rb_shard_add_range(rb_graph *g, rb_shard_comm *c, const rb_batch *b, int64_t first, int64_t n, unsigned flags,
+                       int64_t reads_per_substep, uint32_t pos_bits, uint64_t ordinal0, rb_add_stats *stats);
+
 /* ---- instrumentation: per-kernel-class HIP-event timing on the library's own stream ---- */
 #define RB_PROF_MAX 32
 typedef struct rb_profile {

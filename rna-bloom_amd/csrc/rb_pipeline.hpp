@@ -342,7 +342,8 @@ struct rb_graph {
     bool use_mpf = false;
     // scratch (grow-only)
     DevBuf chunk_cnt, chunk_off, keys0, vals0, status, nops, temp,
-        ftable, ctable, heavy, confk, conf_sizes, conf_off, opk0, opk1, opv0, opv1, label, kk0, kk1, biglist, cvals, foreign, devctr, qbuf0, qbuf1, qbuf2, qbuf3;
+        ftable, ctable, heavy, confk, conf_sizes, conf_off, opk0, opk1, opv0, opv1, label, kk0, kk1, biglist, cvals, foreign, devctr, qbuf0, qbuf1, qbuf2, qbuf3,
+        comm_keep, comm_dreply, comm_creply;          // exchange driver below the C ABI (rb_comm.hip)
     // profiling: HIP events recorded on the stream a stage runs on; resolved lazily (no host sync
     // inside the pipeline, so the two streams keep overlapping while timing is on)
     bool prof_on = false;

@@ -1561,3 +1561,7 @@ void shard_free(rb_graph *g) {
     g->shard = nullptr;
 }
 }  // namespace rb
+
+namespace rb {
+bool shard_is_split(const rb_graph *g) { return g && g->shard && g->shard->replicate_cache; }
+}  // namespace rb

@@ -376,6 +376,68 @@ class ShardRank:
 
 
 # ------------------------------------------------------------------ drivers ----
+class NativeComm:
+    """rb_shard_comm: the exchange driver below the C ABI (csrc/rb_comm.hip).  loopback(G): a hub for G virtual ranks of this
+    process (one host thread each); rccl(dist): one rank per process — rank 0's ncclUniqueId travels through torch.distributed."""
+
+    def __init__(self, h):
+        self.h = h
+
+    @classmethod
+    def loopback(cls, world):
+        h = C.c_void_p()
+        check(lib.rb_shard_comm_create_loopback(world, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def rccl(cls, dist, device, group=None):
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        uid = np.zeros(128, np.uint8)
+        if rank == 0:
+            check(lib.rb_shard_comm_unique_id(uid.ctypes.data_as(C.c_void_p)))
+        if world > 1:
+            box = [uid.tobytes()]
+            dist.broadcast_object_list(box, src=0, group=group)
+            uid = np.frombuffer(box[0], np.uint8).copy()
+        h = C.c_void_p()
+        check(lib.rb_shard_comm_create_rccl(uid.ctypes.data_as(C.c_void_p), rank, world, device, C.byref(h)))
+        return cls(h)
+
+    def destroy(self):
+        if self.h:
+            lib.rb_shard_comm_destroy(self.h)
+            self.h = None
+
+
+def add_range_native(rank, comm, batch, first, n, flags, reads_per_substep, pos_bits):
+    """ShardRank.add_range through rb_shard_add_range: every phase and every exchange inside the library (blocking call)"""
+    st = N.AddStats()
+    check(lib.rb_shard_add_range(rank.h, comm.h, batch.h, int(first), int(n), flags, int(reads_per_substep), pos_bits, rank.ordinal, C.byref(st)))
+    rank.ordinal += int(n)
+    for kk in ("kmers", "pairs", "distinct", "conflict_ops", "sorted_kmers", "reads"):
+        rank.stats[kk] += getattr(st, kk)
+    return st
+
+
+def run_native_loopback(ranks, comm, batch, first, n, flags, reads_per_substep, pos_bits):
+    """G virtual ranks of one process: one host thread per rank inside rb_shard_add_range (the calls release the GIL and meet
+    at the hub's barriers); an error on one rank fails the hub and surfaces on all"""
+    import threading
+    errs = [None] * len(ranks)
+
+    def work(i):
+        try:
+            add_range_native(ranks[i], comm, batch, first, n, flags, reads_per_substep, pos_bits)
+        except Exception as e:          # noqa: BLE001 — re-raised below
+            errs[i] = e
+    th = [threading.Thread(target=work, args=(i,)) for i in range(len(ranks))]
+    for t in th: t.start()
+    for t in th: t.join()
+    for e in errs:
+        if e is not None:
+            raise e
+
+
 def _split(t, counts):
     out, o = [], 0
     for c in counts:
@@ -648,12 +710,14 @@ class LoopbackCluster:
     """G virtual ranks on one GPU — exercises the full sharded protocol without a second device."""
 
     def __init__(self, count, dbgbfNumBits, cbfNumBytes, pkbfNumBits, dbgbfNumHash, cbfNumHash, pkbfNumHash, k, stranded,
-                 useReadPairedKmers, device=0, rngSeed=0, maxBatchKmers=0, groupBits=0, mode=None):
+                 useReadPairedKmers, device=0, rngSeed=0, maxBatchKmers=0, groupBits=0, mode=None, native=False):
         params = (dbgbfNumBits, cbfNumBytes, pkbfNumBits, dbgbfNumHash, cbfNumHash, pkbfNumHash, k, int(stranded),
                   int(useReadPairedKmers), device, groupBits, rngSeed, maxBatchKmers)
         self.k, self.count = k, count
         self.max_batch = maxBatchKmers or default_batch_kmers(count, mode)
         self.ranks = [ShardRank(params, r, count, device, mode) for r in range(count)]
+        # native=True: the exchange driver below the C ABI (rb_shard_add_range over a loopback hub, one thread per rank)
+        self.comm = NativeComm.loopback(count) if native else None
 
     def setReadPairedKmerDistance(self, d):
         for r in self.ranks:
@@ -665,6 +729,9 @@ class LoopbackCluster:
         pos_bits, rps = plan(max_len, self.k, self.count, self.max_batch)
         rps = reads_per_substep or rps
         n = batch.n_reads - first if n is None else n
+        if self.comm is not None:
+            run_native_loopback(self.ranks, self.comm, batch, first, n, flags, rps, pos_bits)
+            return
         run_loopback([r.add_range(batch, first, n, flags, rps, pos_bits) for r in self.ranks])
 
     def _query(self, what, per_rank_h0, which_bits=N.DBGBF):
@@ -712,3 +779,5 @@ class LoopbackCluster:
     def destroy(self):
         for r in self.ranks:
             r.destroy()
+        if self.comm is not None:
+            self.comm.destroy()

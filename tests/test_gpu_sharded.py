@@ -207,3 +207,74 @@ def test_get_kmers_and_neighbours_on_a_sharded_graph(G, stranded):
             f4, r4, c4 = res[rk]
             assert (f4 == ef4).all() and (r4 == er4).all() and (c4 == ec4).all()
     g1.destroy(); cl.destroy()
+
+
+# ---- the exchange driver below the C ABI (csrc/rb_comm.hip: rb_shard_add_range) ----
+@pytest.mark.parametrize("mode", ["replicated", "split"])
+@pytest.mark.parametrize("G", [1, 2, 4, 8])
+def test_native_driver_matches_oracle(G, mode):
+    """the whole protocol inside the library — one host thread per virtual rank in rb_shard_add_range, exchanges through the
+    loopback hub — against the sequential oracle, both files of a library, read pairs, many sub-batches"""
+    sizes = (400_003, 3_000_017, 90_001)
+    d = synth.generate_pairs(2400, G=25000, err=0.003, n_rate=1e-3, seed=31 + G)
+    og = rbo.Graph(*sizes, 2, 2, 2, 25, False, True, 9)
+    cl = LoopbackCluster(G, *sizes, 2, 2, 2, 25, False, True, rngSeed=9, mode=mode, native=True)
+    og.set_read_pair_distance(115); cl.setReadPairedKmerDistance(115)
+    for name, rc in (("left", False), ("right", True)):
+        s, off = synth.flat(d[name]); q, _ = synth.flat(d[name[0] + "qual"])
+        og.add_reads(s, q, off, 3, rbo.STORE_READ_PAIRS | (rbo.REVCOMP if rc else 0))
+        cl.addBatch(ReadBatch.from_ascii(s, q, off, 3), 150, reverseComplement=rc, storeReadPairedKmers=True, reads_per_substep=577)
+        check_filters(cl, og)
+    assert sum(r.stats["conflict_ops"] for r in cl.ranks) > 0 and sum(r.stats["reads"] for r in cl.ranks) == 4800
+    cl.destroy()
+
+
+@pytest.mark.parametrize("mode", ["replicated", "split"])
+def test_native_driver_high_multiplicity_and_python_driver_agree(mode):
+    """counters well into the probabilistic range, hot prefilter cache, look-ahead hashing: the native driver, the Python
+    driver and the oracle end in the same filters"""
+    d = synth.generate_pairs(5000, G=3000, err=0.001, n_rate=1e-3, seed=3, uniform_expr=True)
+    sizes = (100_003, 150_001, 20_011)
+    og = rbo.Graph(*sizes, 2, 2, 2, 25, False, True, 1)
+    s, off = synth.flat(d["left"]); q, _ = synth.flat(d["lqual"])
+    og.add_reads(s, q, off, 3, 0)
+    b = ReadBatch.from_ascii(s, q, off, 3)
+    got = []
+    for native in (True, False):
+        cl = LoopbackCluster(4, *sizes, 2, 2, 2, 25, False, True, rngSeed=1, mode=mode, native=native)
+        cl.addBatch(b, 150, reads_per_substep=500)
+        check_filters(cl, og, pairs=False)
+        got.append([sum(r.stats[kk] for r in cl.ranks) for kk in ("kmers", "sorted_kmers", "conflict_ops", "distinct")])
+        cl.destroy()
+    assert got[0][0] == got[1][0] and og.cbf_bytes().max() > 24
+
+
+def test_native_driver_over_rccl_world_1():
+    """the RCCL transport (ncclSend / ncclRecv groups on the handle's stream; librccl through dlopen) with one rank: every
+    exchange is a self-send, the rest of the path is what N processes run"""
+    from rnabloom import sharded
+    from rnabloom.sharded import NativeComm, ShardRank, add_range_native, plan
+
+    class _OneRank:                       # what NativeComm.rccl needs from torch.distributed at world 1
+        @staticmethod
+        def get_rank(group=None): return 0
+        @staticmethod
+        def get_world_size(group=None): return 1
+    sizes = (400_003, 3_000_017, 90_001)
+    d = synth.generate_pairs(2000, G=20000, err=0.003, n_rate=1e-3, seed=5)
+    og = rbo.Graph(*sizes, 2, 2, 2, 25, False, True, 9)
+    og.set_read_pair_distance(115)
+    comm = NativeComm.rccl(_OneRank, 0)
+    for mode in ("replicated", "split"):
+        og2 = rbo.Graph(*sizes, 2, 2, 2, 25, False, True, 9); og2.set_read_pair_distance(115)
+        rk = ShardRank((*sizes, 2, 2, 2, 25, 0, 1, 0, 0, 9, 0), 0, 1, 0, mode)
+        rk.set_read_pair_distance(115)
+        pos_bits, _ = plan(150, 25, 1)
+        for name, rc in (("left", False), ("right", True)):
+            s, off = synth.flat(d[name]); q, _ = synth.flat(d[name[0] + "qual"])
+            og2.add_reads(s, q, off, 3, rbo.STORE_READ_PAIRS | (rbo.REVCOMP if rc else 0))
+            add_range_native(rk, comm, ReadBatch.from_ascii(s, q, off, 3), 0, 2000, N.ADD_STORE_READ_PAIRS | (N.ADD_REVCOMP if rc else 0), 450, pos_bits)
+        assert (rk.local_filter(N.DBGBF) == og2.dbgbf_bytes()).all() and (rk.local_filter(N.CBF) == og2.cbf_bytes()).all()
+        assert (rk.local_filter(N.RPKBF) == og2.rpkbf_bytes()).all()
+        rk.destroy()
+    comm.destroy()

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch-kmers", type=int, default=0, help="global sub-batch size in k-mers (default 2^30)")
     ap.add_argument("--trace", action="store_true")
+    ap.add_argument("--native", action="store_true", help="exchange driver below the C ABI (rb_shard_add_range, one host thread per rank: the ranks' kernels overlap on the one GPU)")
     a = ap.parse_args()
     import torch
     torch.cuda.set_device(0)
@@ -47,11 +48,16 @@ def main():
         r.set_read_pair_distance(max(1, 150 - k - 10))
     pos_bits, rps = sharded.plan(150, k, G, a.batch_kmers or sharded.default_batch_kmers(G, ranks[0].mode))
 
+    comm = sharded.NativeComm.loopback(G) if a.native else None
+
     def step():
         for r in ranks:
             r.clear()
         for first, fl in ((0, N.ADD_STORE_READ_PAIRS), (a.pairs, N.ADD_STORE_READ_PAIRS | N.ADD_REVCOMP)):
-            sharded.run_loopback([r.add_range(batch, first, a.pairs, fl, rps, pos_bits) for r in ranks])
+            if comm is not None:
+                sharded.run_native_loopback(ranks, comm, batch, first, a.pairs, fl, rps, pos_bits)
+            else:
+                sharded.run_loopback([r.add_range(batch, first, a.pairs, fl, rps, pos_bits) for r in ranks])
 
     for _ in range(a.warmup):
         step()
@@ -68,7 +74,7 @@ def main():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / a.steps
     tot = {kk: sum(r.stats[kk] for r in ranks) // a.steps for kk in ranks[0].stats}
-    out = {"ranks": G, "pairs": a.pairs, "reads_per_substep": rps, "wall_ms_per_step": round(dt * 1e3, 1),
+    out = {"ranks": G, "driver": "native (threads overlap on one GPU)" if a.native else "python", "pairs": a.pairs, "reads_per_substep": rps, "wall_ms_per_step": round(dt * 1e3, 1),
            "per_rank_ms_if_concurrent": round(dt * 1e3 / G, 1),
            "projected_kmers_per_s_without_comm": round(tot["kmers"] / (dt / G)), "stats": tot}
     if a.trace:
