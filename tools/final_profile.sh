@@ -7,7 +7,7 @@ TAG=${1:-r02}
 OUT=$R/gpurun_out/final_$TAG
 mkdir -p $OUT
 cd $R
-python -m pytest tests -q -m gpu 2>&1 | tail -3 > $OUT/pytest_gpu.txt
+python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3 > $OUT/pytest_gpu.txt
 python bench.py > $OUT/bench.json 2> $OUT/bench.err
 RB_SERIAL=1 python bench.py --no-cpu-baseline > $OUT/bench_serial_stages.json 2> $OUT/bench_serial.err
 cd /tmp && export TMPDIR=/tmp
