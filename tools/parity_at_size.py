@@ -1,4 +1,4 @@
-"""Parity of the single-GPU engine and of the sharded engine (8 virtual ranks split, 2 replicated) with the CPU oracle on a
+"""Parity of the single-GPU engine and of the sharded engine (8 virtual ranks split, 2 replicated; both drivers) with the CPU oracle on a
 large synthetic paired-end set: N reads (default 4 M = 490 M k-mers; the oracle needs ~40 s for that), both files of the
 library, read-paired k-mers, filters sized so that counters reach the probabilistic range.  Prints one line per engine.
     python tools/parity_at_size.py [N [k]]        (k = 35: the three-words-per-lane prefilter, generic kernels in the sharded engine)"""
@@ -30,10 +30,10 @@ s2 = g.addBatch(batch, reverseComplement=True, storeReadPairedKmers=True, first=
 print("single: kmers", s1.kmers + s2.kmers, "sorted", s1.sorted_kmers + s2.sorted_kmers, "conflict ops", s1.conflict_ops + s2.conflict_ops,
       "equal:", [bool(np.array_equal(g.exportFilter(w), r)) for w, r in zip((N.DBGBF, N.CBF, N.RPKBF), ref)], "max counter", int(ref[1].max()), flush=True)
 g.destroy()
-for G, mode in ((8, "split"), (2, "replicated")):
-    cl = LoopbackCluster(G, bits, bits, bits, 2, 2, 2, K, False, True, device=0, rngSeed=1, mode=mode, maxBatchKmers=1 << 27)
+for G, mode, native in ((8, "split", False), (2, "replicated", False), (8, "split", True), (2, "replicated", True)):
+    cl = LoopbackCluster(G, bits, bits, bits, 2, 2, 2, K, False, True, device=0, rngSeed=1, mode=mode, maxBatchKmers=1 << 27, native=native)
     cl.setReadPairedKmerDistance(115)
     cl.addBatch(batch, 150, storeReadPairedKmers=True, first=0, n=n // 2)
     cl.addBatch(batch, 150, reverseComplement=True, storeReadPairedKmers=True, first=n // 2, n=n // 2)
-    print("sharded", G, mode, "equal:", [bool(np.array_equal(cl.exportFilter(w), r)) for w, r in zip((N.DBGBF, N.CBF, N.RPKBF), ref)], flush=True)
+    print("sharded", G, mode, "(exchange driver below the C ABI)" if native else "(python driver)", "equal:", [bool(np.array_equal(cl.exportFilter(w), r)) for w, r in zip((N.DBGBF, N.CBF, N.RPKBF), ref)], flush=True)
     cl.destroy()
