@@ -55,7 +55,8 @@ def algorithmic_bytes(stage, n_kmers, n_pairs, n_runs, words, n_sorted=None, gro
         "count_windows": words * 12,
         "strengths": n_kmers * 5,
         "distinct_runs": n_kmers * 8 + n_runs * 16,
-        # per run: h Bloom-bit sector reads + h counter claims (atomic = sector read + write) + 36 B of records
+        # per run: h Bloom-bit sector reads + h counter claims (atomic = sector read + write) + 36 B of records — an upper
+        # bound: runs of one occurrence whose k-mer is new claim nothing (k_late_claim), so the counters show about half
         "probe_claim": n_runs * (h * SECTOR + h * 2 * SECTOR + 36),
         # per run: h counter byte stores (sector write), one strength sector, 40 B of records
         "resolve_apply": n_runs * (h * SECTOR + SECTOR + 40),
@@ -104,6 +105,27 @@ def pmc_traffic(stage):
         per_dispatch = sum(float(r[2]) for r in hit) / sum(float(r[1]) for r in hit) * 1024.0
         tot += per_dispatch * (FETCH_FACTOR.get(stage, 1.0) if "fetch" in name else 1.0)
     return tot or None
+
+
+PMC_RUN_STEPS = 2        # the PMC passes ran `bench.py --steps 1 --warmup 1` (tools/final_profile.sh)
+
+
+def pmc_step_bytes(stage):
+    """HBM bytes per STEP of the stage's kernel(s) by the counters (corrected FETCH_SIZE + WRITE_SIZE), None if absent"""
+    kern = PMC_KERNELS.get(stage)
+    if not kern:
+        return None
+    tot = 0.0
+    for name in PMC_FILES:
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            return None
+        rows = [line.rsplit(",", 3) for line in open(path).read().splitlines()[1:]]
+        hit = [r for r in rows if len(r) == 4 and r[0].startswith(kern)]
+        if not hit:
+            return None
+        tot += sum(float(r[2]) for r in hit) * 1024.0 * (FETCH_FACTOR.get(stage, 1.0) if "fetch" in name else 1.0)
+    return tot / PMC_RUN_STEPS
 
 
 def parse():
@@ -244,16 +266,18 @@ def main():
         words = 2 * pairs_total * 5 * a.steps          # 32-base words this rank walks
         if sharded_mode and sr.mode == "split":
             words //= world
-        per_stage = {}
+        per_stage, per_stage_gb = {}, {}
+        default_cfg = (a.pairs, a.genome, a.nk, a.k, a.batch_kmers, sharded_mode) == (50_000_000, 64_000_000, 450_000_000, 25, 0, False)
         for name, (ms, launches) in prof.items():
             ab = algorithmic_bytes(name, kmers, pairs_ins, distinct, words, n_sorted, sharded=sharded_mode)
             if ab and ms > 0:
                 per_stage[name] = round(ab / (ms * 1e-3) / 1e9, 1)
+                cb = pmc_step_bytes(name) if default_cfg else None
+                per_stage_gb[name] = {"model": round(ab / a.steps / 1e9, 1), "counters": round(cb / 1e9, 1) if cb else None}
         if dom_launches:
             ab = algorithmic_bytes(dom_name, kmers, pairs_ins, distinct, words, n_sorted, sharded=sharded_mode)
             if ab:
                 achieved = ab / (dom_ms * 1e-3) / 1e9      # = bytes per launch / average launch duration
-                default_cfg = (a.pairs, a.genome, a.nk, a.k, a.batch_kmers, sharded_mode) == (50_000_000, 64_000_000, 450_000_000, 25, 0, False)
                 traffic = pmc_traffic(dom_name) if default_cfg else None      # the PMC passes profiled exactly this command
                 roof = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
@@ -261,7 +285,8 @@ def main():
                         "note": "dominant stage by HIP-event time on its own stream; achieved = model bytes / measured time, traffic = counters",
                         "algorithmic_bytes_per_launch": int(ab / dom_launches),
                         "avg_launch_ms": round(dom_ms / dom_launches, 3), "launches": dom_launches,
-                        "all_stages_model_GBps": per_stage}
+                        "all_stages_model_GBps": per_stage,
+                        "all_stages_GB_per_step": per_stage_gb}     # model bytes beside the counters' (committed PMC passes)
         out = {
             "metric": "k-mers/sec hashed+inserted into Bloom dBG (k=25, 50M 150bp reads)",
             "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
