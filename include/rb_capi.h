@@ -319,6 +319,11 @@ int rb_minimizer_set(int device, const char *seq, const int64_t *offsets, int64_
 int rb_fastq_split(const char *text, size_t len, int n_threads, char *seq, char *qual, int64_t *offsets, int64_t cap_reads,
                    int64_t *n_reads);
 
+/* FileUtils.getTextFileReader for ".gz" (R/util/FileUtils.java:50-57: GZIPInputStream, every member of a concatenated file).
+ * dst == NULL: *out_len = uncompressed size.  BGZF input (bgzip: members of at most 64 KiB that carry their own size) is
+ * inflated by n_threads threads at once (<= 0: all hardware threads); any other gzip file member after member on one thread. */
+int rb_gunzip(const void *src, size_t n, int n_threads, void *dst, size_t cap, size_t *out_len);
+
 /* The same on the GPU: the text is uploaded as it is and lines, records (same rules, same error texts) and the 2-bit
  * encoding + quality mask are found there — no host pass over the bytes, no intermediate buffers.
  * rb_batch_create_fastq: at most 4 GiB of text; final = 0: the text is a piece of a longer input (a last line without an

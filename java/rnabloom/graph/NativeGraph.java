@@ -105,6 +105,8 @@ public final class NativeGraph {
     /** FASTQ text -> seq / qual (direct buffers of at least textLen bytes; qual may be null) + offsets; returns the record count.
      *  Call with offsets == null for the count only. */
     public static native long fastqSplit(ByteBuffer text, long textLen, int nThreads, ByteBuffer seq, ByteBuffer qual, long[] offsets);
+    /** every member of a gzip byte string (direct buffers; dst == null: returns the uncompressed size); BGZF in parallel. */
+    public static native long gunzip(ByteBuffer src, long n, int nThreads, ByteBuffer dst, long cap);
     /** FASTQ text (direct buffer) parsed and encoded on the GPU; isFinal = false: a piece of a longer input, consumed[0] = where the
      *  next piece starts. */
     public static native long batchCreateFastq(int device, ByteBuffer text, long textLen, boolean isFinal, int minBaseQual, boolean useQual, long[] consumed);

@@ -368,6 +368,13 @@ jlong FN(fastqSplit)(JNIEnv *e, jclass c, jobject text, jlong len, jint threads,
     if (rc) throw_rc(e, rc);
     return n;
 }
+jlong FN(gunzip)(JNIEnv *e, jclass c, jobject src, jlong n, jint threads, jobject dst, jlong cap) {
+    size_t out = 0;
+    (void)c;
+    int rc = rb_gunzip(direct(e, src), (size_t)n, threads, direct(e, dst), (size_t)cap, &out);
+    if (rc) throw_rc(e, rc);
+    return (jlong)out;
+}
 jlong FN(nbitsEncode)(JNIEnv *e, jclass c, jobject seq, jlongArray offsets, jint n, jobject out, jlong cap) {
     size_t written = 0;
     jlong *off = la(e, offsets);

@@ -6,6 +6,7 @@
 // stops its stage 1 from scaling; here line starts are counted per chunk in parallel, and since a record is exactly four
 // lines the global line number of every chunk start tells which field a line is.
 #include <string.h>
+#include <zlib.h>
 
 #include <algorithm>
 #include <thread>
@@ -224,6 +225,128 @@ int rb_batch_create_fastq(int device, const char *text, size_t len, int final, i
         RB_REQUIRE(out && consumed, "rb_batch_create_fastq: null argument");
         const FastqChunk c = rb::fastq_batch_create(device, text, len, final != 0, min_base_qual, use_qual != 0, nullptr);
         *out = c.b; *consumed = c.consumed;
+    });
+}
+
+// FileUtils.getTextFileReader for ".gz" (R/util/FileUtils.java:50-57: a GZIPInputStream, which reads every member of a
+// concatenated file).  A gzip file is a sequence of members; a member announces its uncompressed size in its last four bytes
+// (ISIZE) but not its compressed size — except in BGZF files (bgzip: every member carries an extra field 'B','C' with its total
+// size and holds at most 64 KiB), where the member boundaries and therefore every member's place in the output are known up
+// front: those are inflated by all threads at once.  Anything else is inflated member after member on one thread.
+namespace {
+struct GzMember { size_t off, csize, usize, uoff; };
+// BGZF member at p (RFC 1952 header with FEXTRA and a 'B','C' subfield of length 2): its total size, else 0
+size_t bgzf_member_size(const unsigned char *p, size_t left) {
+    if (left < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || !(p[3] & 4)) return 0;
+    const size_t xlen = (size_t)p[10] | ((size_t)p[11] << 8);
+    if (12 + xlen > left) return 0;
+    for (size_t q = 12; q + 4 <= 12 + xlen;) {
+        const size_t slen = (size_t)p[q + 2] | ((size_t)p[q + 3] << 8);
+        if (p[q] == 'B' && p[q + 1] == 'C' && slen == 2 && q + 6 <= 12 + xlen) {
+            const size_t bsize = ((size_t)p[q + 4] | ((size_t)p[q + 5] << 8)) + 1;
+            return bsize >= 26 && bsize <= left ? bsize : 0;
+        }
+        q += 4 + slen;
+    }
+    return 0;
+}
+void inflate_member(const unsigned char *src, size_t n, unsigned char *dst, size_t cap, size_t *produced, size_t *consumed) {
+    z_stream z;
+    memset(&z, 0, sizeof z);
+    RB_REQUIRE(inflateInit2(&z, 15 + 16) == Z_OK, "rb_gunzip: inflateInit2 failed");
+    size_t in = 0, out = 0;
+    int rc = Z_OK;
+    while (rc != Z_STREAM_END) {
+        const size_t ci = std::min(n - in, (size_t)1 << 30), co = std::min(cap - out, (size_t)1 << 30);
+        z.next_in = const_cast<unsigned char *>(src + in); z.avail_in = (uInt)ci;
+        z.next_out = dst + out; z.avail_out = (uInt)co;
+        rc = inflate(&z, Z_NO_FLUSH);
+        in += ci - z.avail_in; out += co - z.avail_out;
+        if (rc == Z_STREAM_END) break;
+        if (rc != Z_OK || (z.avail_in == ci && z.avail_out == co)) {
+            inflateEnd(&z);
+            set_error((in >= n && out < cap) ? "rb_gunzip: unexpected end of the gzip data" : (out >= cap && (rc == Z_OK || rc == Z_BUF_ERROR)) ? "rb_gunzip: output buffer too small"
+                                                                                                       : "rb_gunzip: not in gzip format / corrupt data (zlib %d)", rc);
+            throw HipError{RB_ERR_INVALID};
+        }
+    }
+    inflateEnd(&z);
+    *produced = out; *consumed = in;
+}
+}  // namespace
+
+int rb_gunzip(const void *src_, size_t n, int n_threads, void *dst_, size_t cap, size_t *out_len) {
+    return guarded([&] {
+        RB_REQUIRE((src_ || n == 0) && out_len, "rb_gunzip: null argument");
+        const unsigned char *src = static_cast<const unsigned char *>(src_);
+        unsigned char *dst = static_cast<unsigned char *>(dst_);
+        // BGZF all the way?  then the members and their uncompressed sizes are known without inflating anything
+        std::vector<GzMember> mem;
+        size_t off = 0, total = 0;
+        bool bgzf = n > 0;
+        while (off < n) {
+            const size_t ms = bgzf_member_size(src + off, n - off);
+            if (!ms) { bgzf = false; break; }
+            const unsigned char *t = src + off + ms - 4;
+            const size_t us = (size_t)t[0] | ((size_t)t[1] << 8) | ((size_t)t[2] << 16) | ((size_t)t[3] << 24);
+            mem.push_back({off, ms, us, total});
+            off += ms; total += us;
+        }
+        if (bgzf) {
+            *out_len = total;
+            if (!dst) return;
+            RB_REQUIRE(cap >= total, "rb_gunzip: output buffer too small (%zu bytes needed)", total);
+            const int T = std::max(1, std::min(n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency(), 64));
+            std::vector<int> rcs((size_t)T, RB_OK);
+            std::vector<std::string> errs((size_t)T);
+            std::vector<std::thread> th;
+            for (int t = 0; t < T; ++t) th.emplace_back([&, t] {
+                rcs[(size_t)t] = guarded([&] {
+                    for (size_t i = mem.size() * (size_t)t / (size_t)T; i < mem.size() * (size_t)(t + 1) / (size_t)T; ++i) {
+                        size_t got = 0, used = 0;
+                        inflate_member(src + mem[i].off, mem[i].csize, dst + mem[i].uoff, mem[i].usize, &got, &used);
+                        RB_REQUIRE(got == mem[i].usize, "rb_gunzip: BGZF block %zu inflates to %zu bytes, its trailer says %zu", i, got, mem[i].usize);
+                    }
+                });
+                if (rcs[(size_t)t] != RB_OK) errs[(size_t)t] = rb_last_error();
+            });
+            for (auto &x : th) x.join();
+            for (int t = 0; t < T; ++t) if (rcs[(size_t)t] != RB_OK) { set_error("%s", errs[(size_t)t].c_str()); throw HipError{rcs[(size_t)t]}; }
+            return;
+        }
+        // generic gzip: member after member (GZIPInputStream reads concatenated members; trailing zero padding is ignored)
+        if (!dst) {     // size query: inflate into a scratch window and count
+            std::vector<unsigned char> scratch((size_t)8 << 20);
+            size_t in = 0, out = 0;
+            while (in < n) {
+                if (src[in] == 0) { ++in; continue; }
+                z_stream z;
+                memset(&z, 0, sizeof z);
+                RB_REQUIRE(inflateInit2(&z, 15 + 16) == Z_OK, "rb_gunzip: inflateInit2 failed");
+                int rc = Z_OK;
+                while (rc != Z_STREAM_END) {
+                    const size_t ci = std::min(n - in, (size_t)1 << 30);
+                    z.next_in = const_cast<unsigned char *>(src + in); z.avail_in = (uInt)ci;
+                    z.next_out = scratch.data(); z.avail_out = (uInt)scratch.size();
+                    rc = inflate(&z, Z_NO_FLUSH);
+                    in += ci - z.avail_in; out += scratch.size() - z.avail_out;
+                    if (rc == Z_BUF_ERROR && in >= n) { inflateEnd(&z); set_error("rb_gunzip: unexpected end of the gzip data"); throw HipError{RB_ERR_INVALID}; }
+                    if (rc != Z_OK && rc != Z_STREAM_END) { inflateEnd(&z); set_error("rb_gunzip: not in gzip format / corrupt data (zlib %d)", rc); throw HipError{RB_ERR_INVALID}; }
+                    if (rc == Z_OK && in >= n && z.avail_out == scratch.size()) { inflateEnd(&z); set_error("rb_gunzip: unexpected end of the gzip data"); throw HipError{RB_ERR_INVALID}; }
+                }
+                inflateEnd(&z);
+            }
+            *out_len = out;
+            return;
+        }
+        size_t in = 0, out = 0;
+        while (in < n) {
+            if (src[in] == 0) { ++in; continue; }
+            size_t got = 0, used = 0;
+            inflate_member(src + in, n - in, dst + out, cap - out, &got, &used);
+            in += used; out += got;
+        }
+        *out_len = out;
     });
 }
 

@@ -3,7 +3,6 @@
 sequence files (R/io/NucleotideBitsReader.java / NucleotideBitsWriter.java).  Record splitting is the library's threaded
 splitter; 2-bit encoding, quality segmentation and the .nbits bit permutation run on the GPU."""
 import ctypes as C
-import gzip
 
 import numpy as np
 
@@ -28,11 +27,26 @@ def splitFastq(text, threads=0, with_qual=True):
     return seq[:tot], (qual[:tot] if with_qual else None), off
 
 
+def gunzip(data, threads=0):
+    """every member of a gzip byte string (GZIPInputStream semantics) -> uint8 array; BGZF members are inflated in parallel"""
+    a = np.frombuffer(data, np.uint8) if not isinstance(data, np.ndarray) else np.ascontiguousarray(data, np.uint8)
+    n = C.c_size_t()
+    check(lib.rb_gunzip(_ptr(a), a.size, threads, None, 0, C.byref(n)))
+    out = np.empty(max(1, n.value), np.uint8)
+    check(lib.rb_gunzip(_ptr(a), a.size, threads, _ptr(out), out.size, C.byref(n)))
+    return out[:n.value]
+
+
+def readText(path, threads=0):
+    """FileUtils.getTextFileReader: the file's text as a uint8 array, inflated when the name ends in .gz (R/util/FileUtils.java:50-57)"""
+    path = str(path)
+    raw = np.fromfile(path, np.uint8)
+    return gunzip(raw, threads) if path.lower().endswith(".gz") else raw
+
+
 def readFastq(path, threads=0, with_qual=True):
     """getTextFileReader + FastqReader over a whole file (.gz by extension, as FileUtils.getTextFileReader decides)"""
-    path = str(path)
-    with (gzip.open(path, "rb") if path.lower().endswith(".gz") else open(path, "rb")) as f:
-        return splitFastq(f.read(), threads, with_qual)
+    return splitFastq(readText(path, threads), threads, with_qual)
 
 
 def batchFromFastq(text, device=0, minBaseQual=3, final=True, with_qual=True):

@@ -105,3 +105,57 @@ def test_nbits_encode_matches_seq_to_bits(tmp_path):
     assert n == len(data) and data == ref_nbits(seqs)
     with pytest.raises(N.NativeError, match="non-ACGTU"):
         RIO.writeNbits(tmp_path / "y.nbits", np.frombuffer(b"ACGNA", np.uint8), np.array([0, 5], np.int64))
+
+
+# ---- .gz input (FileUtils.getTextFileReader, R/util/FileUtils.java:50-57): every member of the file, BGZF in parallel ----
+def _bgzf(data, block=60000):
+    """the byte string bgzip writes: members of at most 64 KiB with a 'B','C' extra field holding the member's size, + the empty EOF member"""
+    import struct, zlib
+    out = []
+    for a in list(range(0, len(data), block)) + [None]:
+        chunk = b"" if a is None else data[a:a + block]
+        co = zlib.compressobj(6, zlib.DEFLATED, -15)
+        body = co.compress(chunk) + co.flush()
+        bsize = 12 + 6 + len(body) + 8 - 1
+        out.append(b"\x1f\x8b\x08\x04" + b"\x00" * 4 + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, bsize) + body
+                   + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+    return b"".join(out)
+
+
+@pytest.mark.parametrize("threads", [1, 5, 0])
+def test_gunzip_single_member_concatenated_members_and_bgzf(threads):
+    import gzip
+    text = make_fastq(3000, 9)
+    assert len(text) > 400_000
+    assert RIO.gunzip(gzip.compress(text), threads).tobytes() == text
+    parts = [text[:100], text[100:250_000], b"", text[250_000:]]
+    assert RIO.gunzip(b"".join(gzip.compress(p) for p in parts), threads).tobytes() == text          # GZIPInputStream reads every member
+    assert RIO.gunzip(gzip.compress(text) + b"\0" * 7, threads).tobytes() == text                   # zero padding after the last member
+    bg = _bgzf(text)
+    assert gzip.decompress(bg) == text                                                                 # the fixture is a valid gzip file
+    assert RIO.gunzip(bg, threads).tobytes() == text
+    assert RIO.gunzip(gzip.compress(b""), threads).size == 0 and RIO.gunzip(b"", threads).size == 0
+
+
+def test_gunzip_refuses_damaged_input():
+    import gzip
+    z = gzip.compress(make_fastq(500, 2))
+    for bad, what in ((z[:len(z) // 2], "unexpected end"), (b"@r1\nACGT\n+\nIIII\n", "not in gzip format"), (z[:40] + bytes([z[40] ^ 0x55]) + z[41:], "gzip")):
+        with pytest.raises(N.NativeError, match=what):
+            RIO.gunzip(bad)
+    bg = bytearray(_bgzf(make_fastq(800, 3), 20000))
+    bg[len(bg) // 2] ^= 0xFF
+    with pytest.raises(N.NativeError):
+        RIO.gunzip(bytes(bg), 4)
+
+
+def test_read_fastq_from_gz_file(tmp_path):
+    import gzip
+    text = make_fastq(400, 5, b"\r\n")
+    (tmp_path / "a.fq").write_bytes(text)
+    (tmp_path / "a.fq.gz").write_bytes(gzip.compress(text))
+    (tmp_path / "b.fq.GZ").write_bytes(_bgzf(text, 5000))
+    want = RIO.splitFastq(text)
+    for name in ("a.fq", "a.fq.gz", "b.fq.GZ"):
+        got = RIO.readFastq(tmp_path / name)
+        assert all((a == b).all() for a, b in zip(got, want))

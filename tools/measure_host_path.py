@@ -70,7 +70,26 @@ for rep in range(2):
     st4, nrec = g.addFastq(np.memmap(fq, np.uint8, "r"), 3, storeReadPairedKmers=True)      # no read() copy: the page cache is the source
     m1 = time.perf_counter()
 assert st4.kmers == km
+# ---- .gz input (FileUtils.getTextFileReader): a tenth of the text as one gzip member and as BGZF (bgzip) blocks ----
+import struct, zlib
+sub = np.fromfile(fq, np.uint8, count=(pairs // 10) * (fq_bytes // pairs)).tobytes()
+def _bgzf(data, block=65280):
+    out = []
+    for a0 in list(range(0, len(data), block)) + [None]:
+        chunk = b"" if a0 is None else data[a0:a0 + block]
+        co = zlib.compressobj(1, zlib.DEFLATED, -15)
+        body = co.compress(chunk) + co.flush()
+        out.append(b"\x1f\x8b\x08\x04" + b"\x00" * 4 + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(body) + 8 - 1) + body
+                   + struct.pack("<II", zlib.crc32(chunk) & 0xFFFFFFFF, len(chunk)))
+    return b"".join(out)
+gz_one = zlib.compressobj(1, zlib.DEFLATED, 31); gz_one = gz_one.compress(sub) + gz_one.flush()
+gz_blk = _bgzf(sub)
+z0 = time.perf_counter(); t1_ = rio.gunzip(gz_one); z1 = time.perf_counter(); t2_ = rio.gunzip(gz_blk); z2 = time.perf_counter()
+assert t1_.tobytes() == sub and t2_.tobytes() == sub
+gz_line = ("gunzip of %.2f GB of FASTQ text: one gzip member %.2f s (%.2f GB/s of text, one thread); BGZF blocks %.3f s (%.1f GB/s of text, all host threads)"
+           % (len(sub) / 1e9, z1 - z0, len(sub) / 1e9 / (z1 - z0), z2 - z1, len(sub) / 1e9 / (z2 - z1)))
 os.remove(fq)
+print(gz_line)
 print("FASTQ file path, records found on the GPU: read %.2f s, rb_graph_add_fastq %.2f s -> %.2f G k-mers/s end to end; from an mmap of the file: %.2f s -> %.2f G k-mers/s"
       % (u1 - u0, u2 - u1, km / (u2 - u0) / 1e9, m1 - m0, km / (m1 - m0) / 1e9))
 print("FASTQ file path (%.2f GB of text): read %.2f s (%.1f GB/s), rb_fastq_split %.2f s (%.1f GB/s), rb_graph_add_reads %.2f s -> %.2f G k-mers/s end to end"
