@@ -332,6 +332,12 @@ int rb_gunzip(const void *src, size_t n, int n_threads, void *dst, size_t cap, s
  * next piece is uploaded and parsed while the current one is inserted; *n_records (may be NULL) = records inserted. */
 int rb_batch_create_fastq(int device, const char *text, size_t len, int final, int min_base_qual, int use_qual, rb_batch **out, size_t *consumed);
 int rb_graph_add_fastq(rb_graph *g, const char *text, size_t len, int min_base_qual, unsigned flags, rb_add_stats *stats, int64_t *n_records);
+/* FASTA the same way (FastaReader.next, R/io/FastaReader.java:70-104: trimmed lines, '>' opens a record, the lines after it are joined,
+ * an empty line closes it and must be followed by a header — "Incorrect FASTA header format" — or by another empty line, which
+ * ends the iteration: *ended; a header that is the very last line is never handed out).  rb_graph_add_fasta = FastaToGraphWorker's
+ * loop (R/RNABloom.java:645-732), no quality pass.  A non-final piece leaves its last record unread. */
+int rb_batch_create_fasta(int device, const char *text, size_t len, int final, rb_batch **out, size_t *consumed, int *ended);
+int rb_graph_add_fasta(rb_graph *g, const char *text, size_t len, unsigned flags, rb_add_stats *stats, int64_t *n_records);
 /* .nbits files (R/io/NucleotideBitsReader.java, R/util/SeqBitsUtils.java:159-161, 236-263: per sequence a 4-byte
  * big-endian length, then ceil(len/4) bytes of four 2-bit bases each, first base in the top bits, value - 128) straight
  * into a packed device batch: the bytes are uploaded as they are and permuted on the GPU (every base is usable — the

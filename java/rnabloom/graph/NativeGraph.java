@@ -110,6 +110,10 @@ public final class NativeGraph {
     /** FASTQ text (direct buffer) parsed and encoded on the GPU; isFinal = false: a piece of a longer input, consumed[0] = where the
      *  next piece starts. */
     public static native long batchCreateFastq(int device, ByteBuffer text, long textLen, boolean isFinal, int minBaseQual, boolean useQual, long[] consumed);
+    /** FASTA text parsed on the GPU (FastaReader.next semantics); consumedAndEnded = {bytes consumed, 1 if an empty header line ended the iteration}. */
+    public static native long batchCreateFasta(int device, ByteBuffer text, long textLen, boolean isFinal, long[] consumedAndEnded);
+    /** FastaToGraphWorker's loop over the text of a whole FASTA file; nRecords[0] = records inserted. */
+    public static native long[] addFasta(long h, ByteBuffer text, long textLen, int flags, long[] nRecords);
     /** FastqToGraphWorker's loop over the text of a whole file (pieces of 1 GiB, parsed on the GPU); nRecords[0] = records inserted. */
     public static native long[] addFastq(long h, ByteBuffer text, long textLen, int minBaseQual, int flags, long[] nRecords);
     /** NucleotideBitsWriter.write for nReads sequences; out == null: returns the size needed. */

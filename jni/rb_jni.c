@@ -102,6 +102,16 @@ jlong FN(batchCreateFastq)(JNIEnv *e, jclass c, jint device, jobject text, jlong
     if (consumed) { jlong u = (jlong)used; (*e)->SetLongArrayRegion(e, consumed, 0, 1, &u); }
     return (jlong)(intptr_t)b;
 }
+jlong FN(batchCreateFasta)(JNIEnv *e, jclass c, jint device, jobject text, jlong len, jboolean final, jlongArray consumed) {
+    rb_batch *b = NULL;
+    size_t used = 0;
+    int ended = 0;
+    (void)c;
+    int rc = rb_batch_create_fasta(device, (const char *)direct(e, text), (size_t)len, final ? 1 : 0, &b, &used, &ended);
+    if (rc) { throw_rc(e, rc); return 0; }
+    if (consumed) { jlong u[2] = {(jlong)used, (jlong)ended}; (*e)->SetLongArrayRegion(e, consumed, 0, 2, u); }
+    return (jlong)(intptr_t)b;
+}
 void FN(batchDestroy)(JNIEnv *e, jclass c, jlong b) { (void)c; int rc = rb_batch_destroy(B(b)); if (rc) throw_rc(e, rc); }
 jlongArray FN(batchInfo)(JNIEnv *e, jclass c, jlong b) {
     int64_t v[3] = {0, 0, 0};
@@ -149,6 +159,15 @@ jlongArray FN(addFastq)(JNIEnv *e, jclass c, jlong h, jobject text, jlong len, j
     int64_t recs = 0;
     (void)c;
     int rc = rb_graph_add_fastq(G(h), (const char *)direct(e, text), (size_t)len, min_q, (unsigned)flags, &st, &recs);
+    if (rc) { throw_rc(e, rc); return NULL; }
+    if (n_records) { jlong u = (jlong)recs; (*e)->SetLongArrayRegion(e, n_records, 0, 1, &u); }
+    return stats_array(e, &st);
+}
+jlongArray FN(addFasta)(JNIEnv *e, jclass c, jlong h, jobject text, jlong len, jint flags, jlongArray n_records) {
+    rb_add_stats st;
+    int64_t recs = 0;
+    (void)c;
+    int rc = rb_graph_add_fasta(G(h), (const char *)direct(e, text), (size_t)len, (unsigned)flags, &st, &recs);
     if (rc) { throw_rc(e, rc); return NULL; }
     if (n_records) { jlong u = (jlong)recs; (*e)->SetLongArrayRegion(e, n_records, 0, 1, &u); }
     return stats_array(e, &st);

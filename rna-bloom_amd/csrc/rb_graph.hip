@@ -2343,6 +2343,61 @@ int rb_graph_add_fastq(rb_graph *g, const char *text, size_t len, int min_base_q
     return rc;
 }
 
+int rb_graph_add_fasta(rb_graph *g, const char *text, size_t len, unsigned flags, rb_add_stats *stats, int64_t *n_records) {
+    if (!g) { set_error("rb_graph_add_fasta: null graph"); return RB_ERR_INVALID; }
+    if (!text && len) { set_error("rb_graph_add_fasta: null text"); return RB_ERR_INVALID; }
+    hipStream_t st = nullptr;
+    const char *pinned = nullptr;
+    WriteLock wl(g->rw);
+    int rc = guarded([&] {
+        RB_HIP(hipSetDevice(g->p.device));
+        if (len > ((size_t)16 << 20) && !getenv("RB_NO_PIN")) {        // pinning is best effort (foreign mappings may refuse)
+            if (hipHostRegister(const_cast<char *>(text), len, hipHostRegisterDefault) == hipSuccess) pinned = text;
+            (void)hipGetLastError();
+        }
+        RB_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        // pieces of 1 GiB of text; a piece starts where the complete records of the one before ended.  The next piece is
+        // uploaded and parsed (helper thread, own stream) while the insert pipeline works on the current one.
+        const size_t piece_bytes = getenv("RB_FASTQ_PIECE") ? (size_t)std::max(64, atoi(getenv("RB_FASTQ_PIECE"))) : (size_t)1 << 30;
+        bool ended = false;                                       // FastaReader.next() returned null at an empty header line
+        auto piece = [&](size_t a) {
+            const size_t e = std::min(len, a + piece_bytes);
+            bool end_here = false;
+            rb::FastqChunk c = rb::fasta_batch_create(g->p.device, text + a, e - a, e == len, st, &end_here);
+            if (end_here) ended = true;
+            return c;
+        };
+        size_t a = 0;
+        int64_t recs = 0;
+        rb::FastqChunk cur = piece(0);
+        for (;;) {
+            struct G { rb_batch *b; ~G() { if (b) rb_batch_destroy(b); } } guard{cur.b};
+            recs += cur.records;
+            const bool last = a + piece_bytes >= len || ended;
+            const size_t next = a + cur.consumed;
+            RB_REQUIRE(last || cur.consumed > 0, "rb_graph_add_fasta: a record longer than %zu bytes", piece_bytes);
+            rb::FastqChunk nxt;
+            std::thread prep;
+            int prep_rc = RB_OK;
+            std::string prep_err;
+            if (!last) prep = std::thread([&] {
+                prep_rc = guarded([&] { nxt = piece(next); });
+                if (prep_rc != RB_OK) prep_err = rb_last_error();                      // the error text is thread-local
+            });
+            const int add_rc = guarded([&] { add_range(g, cur.b, 0, cur.b->n_reads, flags, stats); });
+            if (prep.joinable()) prep.join();
+            if (add_rc != RB_OK) { if (nxt.b) rb_batch_destroy(nxt.b); throw HipError{add_rc}; }
+            if (prep_rc != RB_OK) { set_error("%s", prep_err.c_str()); throw HipError{prep_rc}; }
+            if (last) break;
+            a = next; cur = nxt;
+        }
+        if (n_records) *n_records = recs;
+    });
+    if (pinned) (void)hipHostUnregister(const_cast<char *>(pinned));
+    if (st) (void)hipStreamDestroy(st);
+    return rc;
+}
+
 int rb_graph_apply(rb_graph *g, int op, const uint64_t *h0, size_t n) {
     return guarded([&] {
         RB_REQUIRE(g && (h0 || n == 0), "rb_graph_apply: null argument");

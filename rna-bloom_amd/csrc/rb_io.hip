@@ -133,6 +133,84 @@ __global__ void k_fq_encode(const uint8_t *__restrict__ t, const uint32_t *__res
     }
     codes[w] = c; valid[w] = v; word_read[w] = r;
 }
+// ---- FASTA (R/io/FastaReader.java:70-104, next()): lines are trimmed (String.trim: characters <= ' ' at both ends); a line that
+// starts with '>' opens a record, the lines after it are its sequence, joined; an empty line closes the record and the line
+// after it must be a header again ("Incorrect FASTA header format" otherwise) — or empty, which ENDS the iteration (next()
+// returns null: nothing behind it is read); a header that is the file's last line is never returned.
+// kind: 0 = empty, 1 = header, 2 = sequence
+__global__ void k_fa_lines(const uint8_t *__restrict__ t, uint32_t n, const uint32_t *__restrict__ ls, uint32_t n_lines, uint32_t *__restrict__ ts,
+                           uint32_t *__restrict__ tl, uint32_t *__restrict__ is_h, uint8_t *__restrict__ kind) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_lines) return;
+    uint32_t s = ls[i], j = ls[i + 1u] - 1u;                     // [s, j): the line without its end of line (j = n for an open last line)
+    j = j < n ? j : n;
+    while (s < j && t[s] <= 0x20u) ++s;
+    while (j > s && t[j - 1u] <= 0x20u) --j;
+    const uint32_t kd = s == j ? 0u : t[s] == '>' ? 1u : 2u;
+    ts[i] = s; tl[i] = kd == 2u ? j - s : 0u; is_h[i] = kd == 1u; kind[i] = (uint8_t)kd;
+}
+// res[0] = first sequence line in header position (an error unless the iteration ended before), res[1] = first empty line in
+// header position (the end of the iteration); header position = line 0 or the line after an empty line
+__global__ void k_fa_check(const uint8_t *__restrict__ kind, uint32_t n_lines, uint32_t *__restrict__ res) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_lines) return;
+    const bool header_pos = i == 0u || kind[i - 1u] == 0u;
+    if (!header_pos) return;
+    if (kind[i] == 2u) atomicMin(&res[0], i);
+    else if (kind[i] == 0u) atomicMin(&res[1], i);
+}
+__global__ void k_fa_header_lines(const uint32_t *__restrict__ is_h, const uint32_t *__restrict__ hidx, uint32_t limit, uint32_t *__restrict__ hl) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < limit && is_h[i]) hl[hidx[i]] = i;
+}
+// per record: sequence length = sequence bytes between its header line and the next one (cum = exclusive scan of the trimmed
+// lengths of the sequence lines), words, the extremes (err[3..5] as in k_fq_records), total bases
+__global__ void k_fa_records(const uint32_t *__restrict__ hl, const uint32_t *__restrict__ cum, uint32_t n_records, uint32_t *__restrict__ len,
+                             uint32_t *__restrict__ nwords, uint32_t *__restrict__ err, unsigned long long *__restrict__ bases) {
+    const uint32_t r = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t L = 0;
+    if (r < n_records) {
+        L = cum[hl[r + 1u]] - cum[hl[r]];
+        len[r] = L;
+        const uint32_t nwd = (L + 31u) >> 5;
+        nwords[r] = nwd;
+        atomicMax(&err[3], L); atomicMin(&err[4], nwd); atomicMax(&err[5], nwd);
+    }
+    unsigned long long tot = L;
+    for (int o = 32; o > 0; o >>= 1) tot += __shfl_down(tot, o, 64);
+    if ((threadIdx.x & 63u) == 0 && tot) atomicAdd(bases, tot);
+}
+// 2-bit encode straight from the text: the word's first base is byte g0 of the record's joined sequence; the line that holds it is
+// the last one with cum <= g0 among the record's lines; from there the bytes are walked across line ends
+__global__ void k_fa_encode(const uint8_t *__restrict__ t, const uint32_t *__restrict__ hl, const uint32_t *__restrict__ cum, const uint32_t *__restrict__ ts,
+                            const uint32_t *__restrict__ tl, const uint32_t *__restrict__ len, const uint32_t *__restrict__ woff, int64_t n_reads,
+                            int64_t n_words, uint64_t *__restrict__ codes, uint32_t *__restrict__ valid, uint32_t *__restrict__ word_read) {
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= n_words) return;
+    int64_t lo = 0, hi = n_reads;
+    while (hi - lo > 1) { const int64_t mid = (lo + hi) >> 1; if (woff[mid] <= (uint32_t)w) lo = mid; else hi = mid; }
+    const uint32_t r = (uint32_t)lo, L = len[r], b0 = (uint32_t)(w - woff[r]) * 32u;
+    const uint32_t g0 = cum[hl[r]] + b0;
+    uint32_t a = hl[r] + 1u, e = hl[r + 1u];                      // the record's lines: (header, next header)
+    while (e - a > 1u) { const uint32_t mid = (a + e) >> 1; if (cum[mid] <= g0) a = mid; else e = mid; }
+    uint32_t line = a, off = g0 - cum[line];
+    uint64_t c = 0;
+    uint32_t v = 0;
+    for (uint32_t i = 0; i < 32u && b0 + i < L; ++i) {
+        while (off >= tl[line]) { off -= tl[line]; ++line; }      // (also skips lines that contribute nothing)
+        uint32_t code = 4;
+        switch (t[ts[line] + off]) {                              // [ACGTU], CASE_INSENSITIVE (R/util/SeqUtils.java:1436-1438)
+            case 'A': case 'a': code = 0; break;
+            case 'C': case 'c': code = 1; break;
+            case 'G': case 'g': code = 2; break;
+            case 'T': case 't': case 'U': case 'u': code = 3; break;
+            default: break;
+        }
+        if (code < 4u) { c |= (uint64_t)code << (2u * i); v |= 1u << i; }
+        ++off;
+    }
+    codes[w] = c; valid[w] = v; word_read[w] = r;
+}
 struct TmpBuf {                                                      // freed on every way out
     void *p = nullptr;
     ~TmpBuf() { if (p) (void)hipFree(p); }
@@ -216,9 +294,128 @@ FastqChunk fastq_batch_create(int device, const char *text, size_t n, bool final
     out.b = b; guard.b = nullptr;
     return out;
 }
+// FASTA text -> packed batch on the GPU.  final = false: the text is a piece of a longer input; the last record then stays
+// unread (consumed = where its header line starts) because its sequence may continue in the next piece.
+FastqChunk fasta_batch_create(int device, const char *text, size_t n, bool final, hipStream_t st, bool *ended) {
+    RB_REQUIRE(text || n == 0, "rb_batch_create_fasta: null text");
+    RB_REQUIRE(n < 0xFFFFFF00ull, "rb_batch_create_fasta: at most 4 GiB of text per call (got %zu bytes)", n);
+    RB_HIP(hipSetDevice(device));
+    if (!final && n && text[n - 1] == '\r') --n;
+    FastqChunk out;
+    if (ended) *ended = false;
+    rb_batch *b = new rb_batch();
+    struct Guard { rb_batch *b; ~Guard() { if (b) rb_batch_destroy(b); } } guard{b};
+    b->device = device;
+    const uint32_t un = (uint32_t)n, ntiles = (un + FQ_TILE - 1) / FQ_TILE;
+    TmpBuf d_text, d_cnt, d_base, d_tmp, d_ls, d_ts, d_tl, d_ish, d_kind, d_cum, d_hidx, d_hl, d_len, d_nw, d_woff, d_err;
+    uint8_t *t = d_text.alloc<uint8_t>((size_t)ntiles * FQ_TILE + 64);
+    RB_HIP(hipMemsetAsync(t + n, 0, (size_t)ntiles * FQ_TILE + 64 - n, st));
+    if (n) RB_HIP(hipMemcpyAsync(t, text, n, hipMemcpyHostToDevice, st));
+    uint32_t *cnt = d_cnt.alloc<uint32_t>(ntiles + 1), *base = d_base.alloc<uint32_t>(ntiles + 1);
+    void *tmp = d_tmp.alloc<uint8_t>(scan_temp_bytes((size_t)ntiles + 1));
+    RB_HIP(hipMemsetAsync(cnt + ntiles, 0, 4, st));
+    if (ntiles) hipLaunchKernelGGL(k_fq_eol_count, dim3(ntiles), dim3(FQ_TPB), 0, st, t, un, cnt);
+    exclusive_scan_u32(tmp, scan_temp_bytes((size_t)ntiles + 1), cnt, base, (size_t)ntiles + 1, st);
+    uint32_t eols = 0;
+    RB_HIP(hipMemcpyAsync(&eols, base + ntiles, 4, hipMemcpyDeviceToHost, st));
+    RB_HIP(hipStreamSynchronize(st));
+    const bool open_tail = final && n > 0 && !(text[n - 1] == '\n' || text[n - 1] == '\r');
+    const uint32_t n_lines = eols + (open_tail ? 1u : 0u);          // a piece's unfinished last line belongs to the next piece
+    uint32_t *ls = d_ls.alloc<uint32_t>((size_t)eols + 2);
+    if (ntiles) hipLaunchKernelGGL(k_fq_line_starts, dim3(ntiles), dim3(FQ_TPB), 0, st, t, un, base, ls);
+    else RB_HIP(hipMemsetAsync(ls, 0, 4, st));
+    const uint32_t sentinel = un + 1u;
+    RB_HIP(hipMemcpyAsync(ls + eols + 1, &sentinel, 4, hipMemcpyHostToDevice, st));
+    const size_t nl1 = (size_t)n_lines + 1;
+    uint32_t *ts = d_ts.alloc<uint32_t>(nl1), *tl = d_tl.alloc<uint32_t>(nl1), *ish = d_ish.alloc<uint32_t>(nl1), *cum = d_cum.alloc<uint32_t>(nl1),
+             *hidx = d_hidx.alloc<uint32_t>(nl1);
+    uint8_t *kind = d_kind.alloc<uint8_t>(nl1);
+    uint32_t *err = d_err.alloc<uint32_t>(16);
+    const uint32_t err0[8] = {~0u, ~0u, 0u, 0u, ~0u, 0u, 0u, 0u};   // [0] bad line, [1] end line, [3] longest, [4..5] min / max words, [6..7] bases
+    RB_HIP(hipMemcpyAsync(err, err0, sizeof err0, hipMemcpyHostToDevice, st));
+    RB_HIP(hipMemsetAsync(tl + n_lines, 0, 4, st));
+    RB_HIP(hipMemsetAsync(ish + n_lines, 0, 4, st));
+    if (n_lines) {
+        hipLaunchKernelGGL(k_fa_lines, dim3((n_lines + 255u) / 256u), dim3(256), 0, st, t, un, ls, n_lines, ts, tl, ish, kind);
+        hipLaunchKernelGGL(k_fa_check, dim3((n_lines + 255u) / 256u), dim3(256), 0, st, kind, n_lines, err);
+    }
+    uint32_t h2[2] = {~0u, ~0u};
+    RB_HIP(hipMemcpyAsync(h2, err, 8, hipMemcpyDeviceToHost, st));
+    RB_HIP(hipStreamSynchronize(st));
+    RB_REQUIRE(h2[0] >= h2[1] || h2[0] == ~0u, "rb_batch_create_fasta: Incorrect FASTA header format");
+    const bool end_seen = h2[1] != ~0u;
+    const uint32_t limit = end_seen ? h2[1] : n_lines;                // lines that take part
+    if (ended) *ended = end_seen;
+    TmpBuf d_tmp2;
+    void *tmp2 = d_tmp2.alloc<uint8_t>(scan_temp_bytes(nl1));
+    exclusive_scan_u32(tmp2, scan_temp_bytes(nl1), tl, cum, nl1, st);
+    exclusive_scan_u32(tmp2, scan_temp_bytes(nl1), ish, hidx, nl1, st);
+    uint32_t n_headers = 0;
+    RB_HIP(hipMemcpyAsync(&n_headers, hidx + limit, 4, hipMemcpyDeviceToHost, st));
+    RB_HIP(hipStreamSynchronize(st));
+    uint32_t *hl = d_hl.alloc<uint32_t>((size_t)n_headers + 2);
+    if (limit) hipLaunchKernelGGL(k_fa_header_lines, dim3((limit + 255u) / 256u), dim3(256), 0, st, ish, hidx, limit, hl);
+    RB_HIP(hipMemcpyAsync(hl + n_headers, &limit, 4, hipMemcpyHostToDevice, st));
+    uint32_t last_h = 0;
+    if (n_headers) RB_HIP(hipMemcpyAsync(&last_h, hl + (n_headers - 1), 4, hipMemcpyDeviceToHost, st));
+    RB_HIP(hipStreamSynchronize(st));
+    // records handed out: all of them when the text ends here (or the iteration ended) — except a header that is the file's very
+    // last line (FastaReader.next returns null when nothing follows a pending header) — else all but the last one
+    uint32_t R = n_headers;
+    const bool whole = final || end_seen;
+    if (whole) { if (R && !end_seen && last_h == n_lines - 1u) --R; }
+    else if (R) --R;
+    uint32_t consumed_line = limit;                                   // first line that was not consumed
+    if (!whole) consumed_line = n_headers ? last_h : 0u;
+    uint32_t *ln = d_len.alloc<uint32_t>(R), *nw = d_nw.alloc<uint32_t>((size_t)R + 1), *woff = d_woff.alloc<uint32_t>((size_t)R + 1);
+    RB_HIP(hipMemsetAsync(nw + R, 0, 4, st));
+    if (R) hipLaunchKernelGGL(k_fa_records, dim3((R + 255u) / 256u), dim3(256), 0, st, hl, cum, R, ln, nw, err, reinterpret_cast<unsigned long long *>(err + 6));
+    TmpBuf d_tmp3;
+    void *tmp3 = d_tmp3.alloc<uint8_t>(scan_temp_bytes((size_t)R + 1));
+    exclusive_scan_u32(tmp3, scan_temp_bytes((size_t)R + 1), nw, woff, (size_t)R + 1, st);
+    uint32_t herr[8], consumed32 = 0;
+    b->h_woff.assign((size_t)R + 1, 0u);
+    RB_HIP(hipMemcpyAsync(herr, err, sizeof herr, hipMemcpyDeviceToHost, st));
+    RB_HIP(hipMemcpyAsync(b->h_woff.data(), woff, ((size_t)R + 1) * 4, hipMemcpyDeviceToHost, st));
+    if (consumed_line <= eols) RB_HIP(hipMemcpyAsync(&consumed32, ls + consumed_line, 4, hipMemcpyDeviceToHost, st));
+    RB_HIP(hipStreamSynchronize(st));
+    out.consumed = whole ? n : (size_t)consumed32;
+    out.records = R;
+    b->n_reads = R;
+    b->n_words = b->h_woff[R];
+    b->max_len = herr[3];
+    b->wpr_uniform = (R && herr[4] == herr[5]) ? herr[4] : 0u;
+    unsigned long long nb; memcpy(&nb, herr + 6, 8);
+    b->n_bases = (int64_t)nb;
+    RB_HIP(hipMalloc(&b->codes, (size_t)std::max<int64_t>(b->n_words, 1) * 8));
+    RB_HIP(hipMalloc(&b->valid, (size_t)std::max<int64_t>(b->n_words, 1) * 4));
+    RB_HIP(hipMalloc(&b->word_read, (size_t)std::max<int64_t>(b->n_words, 1) * 4));
+    RB_HIP(hipMalloc(&b->woff, ((size_t)R + 2) * 4));
+    RB_HIP(hipMalloc(&b->len, (size_t)std::max<uint32_t>(R, 1u) * 4));
+    b->device_bytes = (size_t)std::max<int64_t>(b->n_words, 1) * 16 + ((size_t)R + 2) * 4 + (size_t)std::max<uint32_t>(R, 1u) * 4;
+    RB_HIP(hipMemcpyAsync(b->woff, woff, ((size_t)R + 1) * 4, hipMemcpyDeviceToDevice, st));
+    if (R) RB_HIP(hipMemcpyAsync(b->len, ln, (size_t)R * 4, hipMemcpyDeviceToDevice, st));
+    if (b->n_words)
+        hipLaunchKernelGGL(k_fa_encode, dim3(blocks_for(b->n_words)), dim3(TPB), 0, st, t, hl, cum, ts, tl, ln, b->woff, (int64_t)R, b->n_words, b->codes, b->valid,
+                           b->word_read);
+    RB_HIP(hipGetLastError());
+    RB_HIP(hipStreamSynchronize(st));
+    out.b = b; guard.b = nullptr;
+    return out;
+}
 }  // namespace rb
 
 extern "C" {
+
+int rb_batch_create_fasta(int device, const char *text, size_t len, int final, rb_batch **out, size_t *consumed, int *ended) {
+    return guarded([&] {
+        RB_REQUIRE(out && consumed, "rb_batch_create_fasta: null argument");
+        bool e = false;
+        const FastqChunk c = rb::fasta_batch_create(device, text, len, final != 0, nullptr, &e);
+        *out = c.b; *consumed = c.consumed;
+        if (ended) *ended = e ? 1 : 0;
+    });
+}
 
 int rb_batch_create_fastq(int device, const char *text, size_t len, int final, int min_base_qual, int use_qual, rb_batch **out, size_t *consumed) {
     return guarded([&] {

@@ -60,4 +60,6 @@ void ascii_batch_abort(AsciiUpload &u);
 // records (where the next piece starts).  Synchronises `st`.
 struct FastqChunk { rb_batch *b = nullptr; size_t consumed = 0; int64_t records = 0; };
 FastqChunk fastq_batch_create(int device, const char *text, size_t n, bool final, int min_base_qual, bool use_qual, hipStream_t st);
+// FASTA text (FastaReader.next semantics) the same way; *ended: an empty line in header position ended the iteration
+FastqChunk fasta_batch_create(int device, const char *text, size_t n, bool final, hipStream_t st, bool *ended);
 }  // namespace rb

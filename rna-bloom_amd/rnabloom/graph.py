@@ -191,6 +191,16 @@ class BloomFilterDeBruijnGraph:
         check(lib.rb_graph_add_fastq(self.h, _ptr(t), t.size, minBaseQual, flags, C.byref(st), C.byref(n)))
         return st, n.value
 
+    def addFasta(self, text, reverseComplement=False, incrementIfPresent=False, storeReadPairedKmers=False):
+        """the text of a FASTA file through FastaToGraphWorker's loop (R/RNABloom.java:645-732), records found on the GPU;
+        returns (stats, records)"""
+        flags = (N.ADD_REVCOMP if reverseComplement else 0) | (N.ADD_COUNT_IF_PRESENT if incrementIfPresent else 0) \
+            | (N.ADD_STORE_READ_PAIRS if storeReadPairedKmers else 0)
+        t = np.frombuffer(text, np.uint8) if isinstance(text, (bytes, bytearray)) else np.ascontiguousarray(text, dtype=np.uint8)
+        st = N.AddStats(); n = C.c_int64()
+        check(lib.rb_graph_add_fasta(self.h, _ptr(t), t.size, flags, C.byref(st), C.byref(n)))
+        return st, n.value
+
     def addReads(self, seq, qual, offsets, minBaseQual=3, reverseComplement=False, incrementIfPresent=False,
                  storeReadPairedKmers=False):
         """host ASCII reads (the FastqToGraphWorker boundary): rb_graph_add_reads pins the buffers, uploads and

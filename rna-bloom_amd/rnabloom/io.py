@@ -58,6 +58,15 @@ def batchFromFastq(text, device=0, minBaseQual=3, final=True, with_qual=True):
     return ReadBatch(h, device), used.value
 
 
+def batchFromFasta(text, device=0, final=True):
+    """FASTA text -> ReadBatch on the device (FastaReader.next semantics, records found there); returns (batch, bytes consumed, ended)"""
+    from .graph import ReadBatch
+    t = np.frombuffer(text, np.uint8) if not isinstance(text, np.ndarray) else np.ascontiguousarray(text, np.uint8)
+    h = C.c_void_p(); used = C.c_size_t(); ended = C.c_int32()
+    check(lib.rb_batch_create_fasta(device, _ptr(t), t.size, int(final), C.byref(h), C.byref(used), C.byref(ended)))
+    return ReadBatch(h, device), used.value, bool(ended.value)
+
+
 def writeNbits(path, seq, offsets, append=False):
     """NucleotideBitsWriter: 4-byte big-endian length + 2-bit bases (first base in the top bits, value - 128) per sequence"""
     seq = np.ascontiguousarray(seq, np.uint8); off = np.ascontiguousarray(offsets, np.int64)

@@ -108,3 +108,128 @@ def test_add_fastq_equals_add_reads_of_the_split_text(monkeypatch):
             assert (g.exportFilter(which) == want.exportFilter(which)).all()
         g.destroy()
     want.destroy()
+
+
+# ---- FASTA on the GPU (rb_batch_create_fasta / rb_graph_add_fasta) against FastaReader.next restated over a line reader ----
+def _fasta_ref(text):
+    """BufferedReader.lines() + FastaReader.next() (R/io/FastaReader.java:70-104) -> (sequences, error)"""
+    s = text.decode("latin1")
+    lines, cur, i = [], [], 0
+    while i < len(s):
+        c = s[i]
+        if c == "\n" or c == "\r":
+            lines.append("".join(cur)); cur = []
+            if c == "\r" and i + 1 < len(s) and s[i + 1] == "\n": i += 1
+        else:
+            cur.append(c)
+        i += 1
+    if cur: lines.append("".join(cur))
+    trim = lambda x: x.strip("".join(chr(c) for c in range(0x21)))          # String.trim(): characters <= ' '
+    out, pos, header = [], 0, None
+    while True:
+        if pos >= len(lines): break                                            # !itr.hasNext() -> null
+        if header is None:
+            header = trim(lines[pos]); pos += 1
+        if header == "": break                                                 # null: the iteration ends
+        if header[0] != ">": return out, "Incorrect FASTA header format"
+        seq = []
+        while pos < len(lines):
+            line = trim(lines[pos]); pos += 1
+            if line == "": header = None; break
+            if line[0] == ">": header = line; break
+            seq.append(line)
+        else:
+            header = None if header is None else header
+            out.append("".join(seq))
+            # the loop ran out of lines: a later call sees !hasNext() and returns null whatever header is pending
+            break
+        out.append("".join(seq))
+    return out, None
+
+
+def _norm(seq):
+    t = {ord(a): ord(b) for a, b in zip("acgtuU", "ACGTTT")}
+    return "".join(ch if ch in "ACGT" else "N" for ch in seq.translate(t))
+
+
+def _make_fasta(n, seed, eol=b"\n", wrap=60, blanks=True):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        L = int(rng.integers(0, 400))
+        sq = bytes(rng.choice(np.frombuffer(b"ACGTNacgtu", np.uint8), L).tolist())
+        out.append(b">r%d some comment" % i + (b"  " if i % 5 == 0 else b"") + eol)
+        w = wrap if i % 3 else max(1, L)
+        for a in range(0, L, w):
+            out.append((b" \t" if i % 7 == 0 else b"") + sq[a:a + w] + (b" " if i % 4 == 0 else b"") + eol)
+        if blanks and i % 11 == 3: out.append(eol)                            # an empty line closes the record; a header follows
+    return b"".join(out)
+
+
+@pytest.mark.parametrize("eol", [b"\n", b"\r\n", b"\r"])
+def test_gpu_fasta_records_match_the_reader(eol):
+    from rnabloom import io as RIO
+    cases = [_make_fasta(n, 3 + n, eol) for n in (0, 1, 2, 40, 700)]
+    cases.append(_make_fasta(50, 8, eol) + eol + eol + _make_fasta(5, 9, eol))      # two empty lines: the iteration ends there
+    cases.append(_make_fasta(30, 10, eol) + b">last_header_without_sequence")       # never handed out
+    cases.append(_make_fasta(30, 11, eol) + b">hdr" + eol + b"ACGT")               # open last line
+    cases.append(eol + _make_fasta(3, 12, eol))                                     # empty first line: nothing
+    cases.append(b">a" + eol + eol + b">b" + eol + b"AC" + eol)                     # empty record, then one more
+    for text in cases:
+        want, err = _fasta_ref(text)
+        assert err is None
+        b, used, ended = RIO.batchFromFasta(text)
+        assert b.n_reads == len(want), (b.n_reads, len(want))
+        s, off = b.download()
+        got = [bytes(s[off[i]:off[i + 1]]).decode() for i in range(b.n_reads)]
+        assert got == [_norm(x) for x in want]
+        assert used == len(text)
+        b.close()
+
+
+def test_gpu_fasta_errors_pieces_and_insert(monkeypatch):
+    from rnabloom import io as RIO, _native as N
+    from rnabloom.graph import BloomFilterDeBruijnGraph
+    with pytest.raises(N.NativeError, match="Incorrect FASTA header format"):
+        RIO.batchFromFasta(b"ACGT\n>r\nACGT\n")
+    with pytest.raises(N.NativeError, match="Incorrect FASTA header format"):
+        RIO.batchFromFasta(b">r\nACGT\n\nACGT\n>s\nAC\n")                       # a sequence line where a header must stand
+    b, _, ended = RIO.batchFromFasta(b">r\nACGT\n\n\nACGT\n")                     # ... but not behind the end of the iteration
+    assert b.n_reads == 1 and ended
+    b.close()
+    # pieces: the last record of a piece that is not final stays unread
+    text = _make_fasta(300, 21, b"\n", blanks=False)
+    whole, _, _ = RIO.batchFromFasta(text)
+    sw, ow = whole.download()
+    for cut in (len(text) // 3, len(text) // 2 + 7, len(text) - 3):
+        first, u1, _ = RIO.batchFromFasta(text[:cut], final=False)
+        assert 0 < u1 <= cut and text[u1:u1 + 1] == b">"
+        rest, u2, _ = RIO.batchFromFasta(text[u1:], final=True)
+        s1, o1 = first.download(); s2, o2 = rest.download()
+        assert first.n_reads + rest.n_reads == whole.n_reads
+        assert (np.concatenate([s1, s2]) == sw).all() and (np.concatenate([o1, o2[1:] + o1[-1]]) == ow).all()
+        first.close(); rest.close()
+    whole.close()
+    # FastaToGraphWorker: the same filters as addReads of the reader's sequences, in one piece and in many
+    rng = np.random.default_rng(2)
+    genome = rng.choice(np.frombuffer(b"ACGT", np.uint8), 20000)
+    recs, seqs = [], []
+    for i in range(900):
+        p = int(rng.integers(0, genome.size - 2500)); L = int(rng.integers(200, 2500))
+        sq = genome[p:p + L].copy(); sq[rng.random(L) < 0.02] = ord("N")
+        seqs.append(sq.tobytes())
+        recs.append(b">read%d\n" % i + b"\n".join(sq.tobytes()[a:a + 70] for a in range(0, L, 70)) + b"\n")
+    text = b"".join(recs)
+    sz = N.lib.rb_expected_size(40000, 0.01, 2)
+    want = BloomFilterDeBruijnGraph(sz, sz, sz, 2, 2, 2, 31, False, False, rngSeed=4)
+    off = np.zeros(len(seqs) + 1, np.int64); np.cumsum([len(x) for x in seqs], out=off[1:])
+    st0 = want.addReads(np.frombuffer(b"".join(seqs), np.uint8), None, off, 3)
+    for piece in (None, "100000", "9000"):
+        if piece: monkeypatch.setenv("RB_FASTQ_PIECE", piece)
+        g = BloomFilterDeBruijnGraph(sz, sz, sz, 2, 2, 2, 31, False, False, rngSeed=4)
+        st, n = g.addFasta(text)
+        assert n == 900 and st.kmers == st0.kmers
+        for which in (N.DBGBF, N.CBF):
+            assert (g.exportFilter(which) == want.exportFilter(which)).all()
+        g.destroy()
+    want.destroy()
