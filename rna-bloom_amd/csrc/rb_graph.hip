@@ -308,6 +308,82 @@ __global__ void k_cs_build(const uint32_t *__restrict__ status, const uint64_t *
     }
 }
 
+// Which shared counters actually order anything?  A run's ops only ever raise its counters, and every success raises its
+// minimum by exactly one; as long as nobody else writes the counters it works on, its minimum after all its m occurrences is at
+// most m0 + m, so it writes a counter — and its behaviour depends on that counter's exact value — only if the counter's pre-batch
+// value is within reach: c <= m0 + m - 1.  (m = occurrences in the run, an upper bound of its ops.)  The runs that need the
+// ordered replay are the least set O with
+//   X in O  if X can reach a shared counter that another run can reach too            (writers >= 2), or
+//              X can reach a shared counter that a run of O claimed                     (that run's bound no longer holds:
+//                                                                                         others raise its minimum)
+// Every run outside O then works on counters nobody else writes (so its bound holds), and never writes a counter a run of O
+// claimed; the runs of O see pre-batch values plus each other's writes, in occurrence order: the sequential result.  A shared
+// counter a run cannot reach is left to whoever can (only the claim mark is dropped).  On config 2 two thirds of the ops that
+// used to be replayed are not in O.
+constexpr uint32_t ST_SHARED = 1u << 29, ST_ORDERED = 1u << 30;
+struct CsLookup {
+    const Slot *cs; uint32_t cs_log2; const uint32_t *csf; uint32_t csf_log2;
+    __device__ __forceinline__ const Slot *find(uint64_t idx) const {
+        const uint64_t b = slot_of(idx, csf_log2);                  // cache-resident bit filter in front of the table
+        if (csf && !((csf[b >> 5] >> (uint32_t)(b & 31u)) & 1u)) return nullptr;
+        return table_find(cs, cs_log2, idx);
+    }
+};
+// pass 1: which runs have a shared counter at all (ST_SHARED), and per shared counter the number of runs that can reach it
+__global__ void k_cs_writers(FilterView fv, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ counts, uint32_t n_distinct,
+                             uint32_t *__restrict__ status, const uint64_t *__restrict__ cvals, CsLookup L, uint32_t *__restrict__ writers) {
+    uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= n_distinct) return;
+    const uint32_t st = status[d];
+    if (!(st & ST_CLAIMED)) return;
+    const uint64_t cv0 = cvals[d], h0 = uniq[d];
+    uint32_t m0 = 255;
+    for (int j = 0; j < fv.cbf_h; ++j) { const uint32_t c = (uint32_t)(cv0 >> (8 * j)) & 0xFFu; m0 = c < m0 ? c : m0; }
+    const uint32_t reach = m0 + counts[d] - 1u;
+    uint64_t seen[RB_MAX_HASH];
+    bool shared = false;
+    for (int j = 0; j < fv.cbf_h; ++j) {
+        const uint64_t idx = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod);
+        bool dup = false;
+        for (int q = 0; q < j; ++q) dup |= seen[q] == idx;
+        seen[j] = idx;
+        if (dup) continue;                                          // the same counter twice: one run, one writer
+        const Slot *sl = L.find(idx);
+        if (!sl) continue;
+        shared = true;
+        if (((uint32_t)(cv0 >> (8 * j)) & 0xFFu) <= reach) atomicAdd(&writers[sl - L.cs], 1u);
+    }
+    if (shared) status[d] = st | ST_SHARED;
+}
+// pass 2, repeated until nothing changes: the closure above.  cflag[slot] = a run of O claimed the counter.
+__global__ void k_cs_order(FilterView fv, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ counts, uint32_t n_distinct,
+                           uint32_t *__restrict__ status, const uint64_t *__restrict__ cvals, CsLookup L, const uint32_t *__restrict__ writers,
+                           uint32_t *__restrict__ cflag, uint32_t *__restrict__ changed, int everything, const uint32_t *__restrict__ shared_list) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;       // n_distinct = length of the list of runs with a shared counter
+    if (i >= n_distinct) return;
+    const uint32_t d = shared_list[i];
+    const uint32_t st = status[d];
+    if (!(st & ST_SHARED) || (st & ST_ORDERED)) return;
+    const uint64_t cv0 = cvals[d], h0 = uniq[d];
+    uint32_t m0 = 255;
+    for (int j = 0; j < fv.cbf_h; ++j) { const uint32_t c = (uint32_t)(cv0 >> (8 * j)) & 0xFFu; m0 = c < m0 ? c : m0; }
+    const uint32_t reach = m0 + counts[d] - 1u;
+    const Slot *sl[RB_MAX_HASH];
+    bool ordered = everything != 0;                                 // (the closure did not settle in time: every shared run is ordered)
+    for (int j = 0; j < fv.cbf_h; ++j) {
+        sl[j] = L.find(index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod));
+        if (sl[j] && ((uint32_t)(cv0 >> (8 * j)) & 0xFFu) <= reach) {
+            const size_t q = (size_t)(sl[j] - L.cs);
+            if (writers[q] >= 2u || __hip_atomic_load(&cflag[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ordered = true;
+        }
+    }
+    if (!ordered) return;
+    status[d] = st | ST_ORDERED;
+    for (int j = 0; j < fv.cbf_h; ++j)
+        if (sl[j]) __hip_atomic_store(&cflag[sl[j] - L.cs], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *changed = 1u;
+}
+
 // ---- stage B: resolve the found-flag of the first occurrence, set Bloom bits, then apply the
 // counter updates of runs that own their counters alone; queue the rest ----
 __device__ unsigned long long g_dbg_hist[96];     // RB_DEBUG: ops by (true exponent, cached exponent); uncached ops by bucket occupancy
@@ -356,6 +432,7 @@ __global__ void k_resolve_apply(FilterView fv, const uint64_t *__restrict__ uniq
         }
     }
     nops[d] = ops;
+    const uint32_t st_in = st;                     // ST_SHARED / ST_ORDERED (k_cs_writers / k_cs_order) sit above the bits kept here
     st = (st & 0x7FFu) | (kfirst << 12) | (krest << 14);
     status[d] = st;
     if (dbgf && ops && (st & ST_CLAIMED)) {   // debug: expected fraction of ops that are guaranteed no-ops
@@ -378,12 +455,20 @@ __global__ void k_resolve_apply(FilterView fv, const uint64_t *__restrict__ uniq
     }
     if (!(st & ST_CLAIMED)) return;
     uint64_t idx[RB_MAX_HASH];
-    bool conflict = (st & ST_FOREIGN) != 0;
+    uint32_t c[RB_MAX_HASH];
+    const uint64_t cv = cvals[d];
+    for (int j = 0; j < fv.cbf_h; ++j) c[j] = (uint32_t)(cv >> (8 * j)) & 0xFFu;
+    uint32_t mn0 = c[0];
+    for (int j = 1; j < fv.cbf_h; ++j) mn0 = c[j] < mn0 ? c[j] : mn0;
+    // a run of the ordered set (k_cs_order) goes to the replay; the others apply their ops here, and leave alone the shared
+    // counters they did not change
+    const bool conflict = ops && (st_in & ST_ORDERED);
+    uint32_t shared = 0;
     for (int j = 0; j < fv.cbf_h; ++j) {
         idx[j] = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod);
-        if (n_foreign && !conflict) {               // did another run claim this counter after this one?  (most have not: bit filter first)
+        if ((st_in & ST_SHARED) && !conflict) {
             const uint64_t b = slot_of(idx[j], csf_log2);
-            if (!csf || ((csf[b >> 5] >> (uint32_t)(b & 31u)) & 1u)) conflict = table_find(cs, cs_log2, idx[j]) != nullptr;
+            if ((!csf || ((csf[b >> 5] >> (uint32_t)(b & 31u)) & 1u)) && table_find(cs, cs_log2, idx[j])) shared |= 1u << j;
         }
     }
     if (ops == 0) {                               // nothing to count: just drop the claim marks
@@ -392,13 +477,12 @@ __global__ void k_resolve_apply(FilterView fv, const uint64_t *__restrict__ uniq
     }
     if (conflict) { status[d] = st | RUN_CONFLICT; return; }   // marks are dropped by k_conf_release before the replay
     if (ops > LIGHT_OPS) { status[d] = st | RUN_HEAVY; return; }
-    uint32_t c[RB_MAX_HASH];
-    const uint64_t cv = cvals[d];
-    for (int j = 0; j < fv.cbf_h; ++j) c[j] = (uint32_t)(cv >> (8 * j)) & 0xFFu;
-    uint32_t mn0 = c[0];
-    for (int j = 1; j < fv.cbf_h; ++j) mn0 = c[j] < mn0 ? c[j] : mn0;
     run_ops(c, fv.cbf_h, kfirst, krest, tz, starts[d] + m - ops, ops);
-    for (int j = 0; j < fv.cbf_h; ++j) fv.cbf[idx[j]] = (uint8_t)c[j];   // also clears the claim mark
+    for (int j = 0; j < fv.cbf_h; ++j) {
+        // a shared counter this run did not change belongs to whoever can reach it: only the claim mark goes
+        if (((shared >> j) & 1u) && c[j] == ((uint32_t)(cv >> (8 * j)) & 0xFFu)) cbf_release(fv.cbf, idx[j]);
+        else fv.cbf[idx[j]] = (uint8_t)c[j];                    // also clears the claim mark
+    }
     if (cache_on(fv) && mode != M_COUNT_ONLY) {   // the k-mer is in dbgbf now; remember its counter exponent
         uint32_t mn = c[0];
         for (int j = 1; j < fv.cbf_h; ++j) mn = c[j] < mn ? c[j] : mn;
@@ -1657,6 +1741,31 @@ void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, ui
         RB_HIP(hipMemsetAsync(csf, 0, (size_t)1 << (csf_log2 - 3), s));
         hipLaunchKernelGGL(k_cs_build, dim3(blocks_for(D)), dim3(TPB), 0, s, status, g->foreign.as<uint64_t>(), D, g->cbf_h,
                            g->ctable.as<Slot>(), c_log2, csf, csf_log2);
+        // which of the runs with a shared counter need the ordered replay: reach counts, then the closure (2-3 rounds)
+        const size_t slots = (size_t)1 << c_log2;
+        g->cwriters.reserve(slots * 8 + 64);
+        RB_HIP(hipMemsetAsync(g->cwriters.p, 0, slots * 8 + 64, s));
+        uint32_t *writers = g->cwriters.as<uint32_t>(), *cflag = writers + slots, *changed = cflag + slots;
+        const CsLookup L{g->ctable.as<Slot>(), c_log2, csf, csf_log2};
+        hipLaunchKernelGGL(k_cs_writers, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, uniq, counts, D, status, g->cvals.as<uint64_t>(), L, writers);
+        // the runs with a shared counter, as a list (at most one per (run, counter) incidence <= 2 n_foreign): the rounds touch only these
+        g->temp.reserve(select2_temp_bytes(D));
+        g->cshared.reserve(((size_t)2 * n_foreign + 64) * 4);
+        select_flagged2(g->temp.p, g->temp.cap, status, D, ST_SHARED, g->cshared.as<uint32_t>(), 0u, g->cshared.as<uint32_t>(), changed + 8, s);
+        uint32_t n_shared = 0;
+        RB_HIP(hipMemcpyAsync(&n_shared, changed + 8, 4, hipMemcpyDeviceToHost, s));
+        RB_HIP(hipStreamSynchronize(s));
+        const bool old_rule = getenv("RB_ORDER_ALL_SHARED") != nullptr;     // every run with a shared counter is replayed (the rule before the closure)
+        for (int round = 0; n_shared; ++round) {
+            const int everything = (old_rule || round >= 16) ? 1 : 0;
+            hipLaunchKernelGGL(k_cs_order, dim3(blocks_for(n_shared)), dim3(TPB), 0, s, fv, uniq, counts, n_shared, status, g->cvals.as<uint64_t>(), L, writers, cflag,
+                               changed + (round & 7), everything, g->cshared.as<uint32_t>());
+            uint32_t ch = 0;
+            RB_HIP(hipMemcpyAsync(&ch, changed + (round & 7), 4, hipMemcpyDeviceToHost, s));
+            RB_HIP(hipStreamSynchronize(s));
+            if (!ch || everything) break;
+            if ((round & 7) == 7) RB_HIP(hipMemsetAsync(changed, 0, 32, s));
+        }
         g->prof_end("conflict_set");
     }
     g->prof_begin();
@@ -2064,7 +2173,7 @@ int rb_graph_destroy(rb_graph *g) {
     if (g->cbf) (void)hipFree(g->cbf);
     DevBuf *bufs[] = {&g->chunk_cnt, &g->chunk_off, &g->keys0,  &g->vals0,   
                        &g->status, &g->nops, &g->temp, &g->ftable, &g->ctable, &g->heavy, &g->confk,
-                      &g->conf_sizes, &g->conf_off, &g->opk0, &g->opk1, &g->opv0, &g->opv1, &g->label, &g->kk0, &g->kk1, &g->biglist, &g->cvals, &g->foreign,  &g->devctr, &g->qbuf0,
+                      &g->conf_sizes, &g->conf_off, &g->opk0, &g->opk1, &g->opv0, &g->opv1, &g->label, &g->kk0, &g->kk1, &g->biglist, &g->cvals, &g->foreign,  &g->devctr, &g->cwriters, &g->cshared, &g->comm_keep, &g->comm_dreply, &g->comm_creply, &g->qbuf0,
                       &g->qbuf1, &g->qbuf2, &g->qbuf3};
     for (auto *b : bufs) b->release();
     for (rb_query_ctx *c : g->qfree) {

@@ -268,7 +268,11 @@ static __global__ void __launch_bounds__(64) k_cbf_heavy(FilterView fv, const ui
                 for (int j = 0; j < fv.cbf_h; ++j) out |= (uint64_t)c[j] << (8 * j);
                 cfinal[d] = out;
             } else
-                for (int j = 0; j < fv.cbf_h; ++j) fv.cbf[idx[j]] = (uint8_t)c[j];   // clears the claim mark too
+                for (int j = 0; j < fv.cbf_h; ++j) {
+                    // an unchanged counter may be shared with a run that can reach it (k_cs_writers): leave its value alone
+                    if (c[j] == ((uint32_t)(cv >> (8 * j)) & 0xFFu)) cbf_release(fv.cbf, idx[j]);
+                    else fv.cbf[idx[j]] = (uint8_t)c[j];                             // clears the claim mark too
+                }
             if (cache_on(fv) && (st & ST_ALLPRE)) {   // remember how hard this k-mer has become to increment
                 uint32_t mn = c[0];
                 for (int j = 1; j < fv.cbf_h; ++j) mn = c[j] < mn ? c[j] : mn;
@@ -343,7 +347,8 @@ struct rb_graph {
     // scratch (grow-only)
     DevBuf chunk_cnt, chunk_off, keys0, vals0, status, nops, temp,
         ftable, ctable, heavy, confk, conf_sizes, conf_off, opk0, opk1, opv0, opv1, label, kk0, kk1, biglist, cvals, foreign, devctr, qbuf0, qbuf1, qbuf2, qbuf3,
-        comm_keep, comm_dreply, comm_creply;          // exchange driver below the C ABI (rb_comm.hip)
+        comm_keep, comm_dreply, comm_creply,          // exchange driver below the C ABI (rb_comm.hip)
+        cwriters, cshared;                            // per shared counter: runs that can reach it; the runs with a shared counter (k_cs_writers / k_cs_order)
     // profiling: HIP events recorded on the stream a stage runs on; resolved lazily (no host sync
     // inside the pipeline, so the two streams keep overlapping while timing is on)
     bool prof_on = false;
