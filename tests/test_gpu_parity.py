@@ -107,6 +107,24 @@ def test_stage1_paired_end_bit_exact(case):
     assert gg.getDbgbfFPR() == fo[0] and gg.getCbfFPR() == fo[1] and gg.getRpkbfFPR() == fo[2]
 
 
+@pytest.mark.parametrize("cbf_bytes,cbf_h,mb,old_rule", [(2_003, 2, 0, False), (2_003, 4, 20_000, False), (40_009, 3, 0, False), (313, 2, 7_000, False),
+                                                         (40_009, 3, 0, True)])
+def test_shared_counters_everywhere(monkeypatch, cbf_bytes, cbf_h, mb, old_rule):
+    """counting filters so small that nearly every run shares counters with others, chains of sharing included: the ordered
+    set (runs that can reach a shared counter somebody else can reach, closed over runs whose own bound no longer holds —
+    k_cs_writers / k_cs_order) must give the sequential result; deep coverage takes the counters far into the
+    probabilistic range, heavy runs and many sub-batches included.  old_rule: every run with a shared counter is replayed."""
+    if old_rule: monkeypatch.setenv("RB_ORDER_ALL_SHARED", "1")
+    (ls, lq, off), (rs, rq, _) = make_reads(2500, 6000, 0.002, 1e-3, seed=cbf_bytes + cbf_h)
+    og, gg = graph_pair(500_009, cbf_bytes, 50_021, cbf_h=cbf_h, max_batch=mb)
+    og.set_read_pair_distance(115); gg.setReadPairedKmerDistance(115)
+    og.add_reads(ls, lq, off, 3, rbo.STORE_READ_PAIRS); gg.addReads(ls, lq, off, 3, storeReadPairedKmers=True)
+    assert_same_state(og, gg)
+    og.add_reads(rs, rq, off, 3, rbo.STORE_READ_PAIRS | rbo.REVCOMP); gg.addReads(rs, rq, off, 3, reverseComplement=True, storeReadPairedKmers=True)
+    assert_same_state(og, gg)
+    assert og.cbf_bytes().max() >= 40
+
+
 @pytest.mark.parametrize("stranded", [False, True])
 @pytest.mark.parametrize("h", [(1, 1, 1), (3, 2, 1), (2, 4, 3)])
 def test_stage1_hash_counts_and_strandedness(stranded, h):
