@@ -320,7 +320,6 @@ __global__ void k_cs_build(const uint32_t *__restrict__ status, const uint64_t *
 // claimed; the runs of O see pre-batch values plus each other's writes, in occurrence order: the sequential result.  A shared
 // counter a run cannot reach is left to whoever can (only the claim mark is dropped).  On config 2 two thirds of the ops that
 // used to be replayed are not in O.
-constexpr uint32_t ST_SHARED = 1u << 29, ST_ORDERED = 1u << 30;
 struct CsLookup {
     const Slot *cs; uint32_t cs_log2; const uint32_t *csf; uint32_t csf_log2;
     __device__ __forceinline__ const Slot *find(uint64_t idx) const {
@@ -329,59 +328,104 @@ struct CsLookup {
         return table_find(cs, cs_log2, idx);
     }
 };
-// pass 1: which runs have a shared counter at all (ST_SHARED), and per shared counter the number of runs that can reach it
-__global__ void k_cs_writers(FilterView fv, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ counts, uint32_t n_distinct,
-                             uint32_t *__restrict__ status, const uint64_t *__restrict__ cvals, CsLookup L, uint32_t *__restrict__ writers) {
-    uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
-    if (d >= n_distinct) return;
-    const uint32_t st = status[d];
-    if (!(st & ST_CLAIMED)) return;
+// Stage B sets every run with a shared counter aside (they are few: the list `cand`); these three kernels decide which of them
+// need the ordered replay and finish the others.  All of it runs behind the point where the producer is released.
+// (1) per shared counter: how many candidates can reach it
+__global__ void k_cs_writers(FilterView fv, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ nops, const uint32_t *__restrict__ cand,
+                             uint32_t n_cand, const uint64_t *__restrict__ cvals, CsLookup L, uint32_t *__restrict__ writers) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_cand) return;
+    const uint32_t d = cand[i];
     const uint64_t cv0 = cvals[d], h0 = uniq[d];
     uint32_t m0 = 255;
     for (int j = 0; j < fv.cbf_h; ++j) { const uint32_t c = (uint32_t)(cv0 >> (8 * j)) & 0xFFu; m0 = c < m0 ? c : m0; }
-    const uint32_t reach = m0 + counts[d] - 1u;
+    const uint32_t reach = m0 + nops[d] - 1u;
     uint64_t seen[RB_MAX_HASH];
-    bool shared = false;
     for (int j = 0; j < fv.cbf_h; ++j) {
         const uint64_t idx = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod);
         bool dup = false;
         for (int q = 0; q < j; ++q) dup |= seen[q] == idx;
         seen[j] = idx;
-        if (dup) continue;                                          // the same counter twice: one run, one writer
+        if (dup || ((uint32_t)(cv0 >> (8 * j)) & 0xFFu) > reach) continue;       // (the same counter twice: one run, one writer)
         const Slot *sl = L.find(idx);
-        if (!sl) continue;
-        shared = true;
-        if (((uint32_t)(cv0 >> (8 * j)) & 0xFFu) <= reach) atomicAdd(&writers[sl - L.cs], 1u);
+        if (sl) atomicAdd(&writers[sl - L.cs], 1u);
     }
-    if (shared) status[d] = st | ST_SHARED;
 }
-// pass 2, repeated until nothing changes: the closure above.  cflag[slot] = a run of O claimed the counter.
-__global__ void k_cs_order(FilterView fv, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ counts, uint32_t n_distinct,
-                           uint32_t *__restrict__ status, const uint64_t *__restrict__ cvals, CsLookup L, const uint32_t *__restrict__ writers,
-                           uint32_t *__restrict__ cflag, uint32_t *__restrict__ changed, int everything, const uint32_t *__restrict__ shared_list) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;       // n_distinct = length of the list of runs with a shared counter
-    if (i >= n_distinct) return;
-    const uint32_t d = shared_list[i];
-    const uint32_t st = status[d];
-    if (!(st & ST_SHARED) || (st & ST_ORDERED)) return;
+// (2) repeated until nothing changes: the closure.  cflag[slot] = a run of O claimed the counter; ordered[i] = cand[i] is in O.
+__global__ void k_cs_order(FilterView fv, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ nops, const uint32_t *__restrict__ cand,
+                           uint32_t n_cand, const uint64_t *__restrict__ cvals, CsLookup L, const uint32_t *__restrict__ writers,
+                           uint32_t *__restrict__ cflag, uint32_t *__restrict__ ordered, uint32_t *__restrict__ changed, int everything) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_cand || ordered[i]) return;
+    const uint32_t d = cand[i];
     const uint64_t cv0 = cvals[d], h0 = uniq[d];
     uint32_t m0 = 255;
     for (int j = 0; j < fv.cbf_h; ++j) { const uint32_t c = (uint32_t)(cv0 >> (8 * j)) & 0xFFu; m0 = c < m0 ? c : m0; }
-    const uint32_t reach = m0 + counts[d] - 1u;
+    const uint32_t reach = m0 + nops[d] - 1u;
     const Slot *sl[RB_MAX_HASH];
-    bool ordered = everything != 0;                                 // (the closure did not settle in time: every shared run is ordered)
+    bool ord = everything != 0;                                     // (the closure did not settle in time: every candidate is ordered)
     for (int j = 0; j < fv.cbf_h; ++j) {
         sl[j] = L.find(index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod));
         if (sl[j] && ((uint32_t)(cv0 >> (8 * j)) & 0xFFu) <= reach) {
             const size_t q = (size_t)(sl[j] - L.cs);
-            if (writers[q] >= 2u || __hip_atomic_load(&cflag[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ordered = true;
+            if (writers[q] >= 2u || __hip_atomic_load(&cflag[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ord = true;
         }
     }
-    if (!ordered) return;
-    status[d] = st | ST_ORDERED;
+    if (!ord) return;
+    ordered[i] = 1u;
     for (int j = 0; j < fv.cbf_h; ++j)
         if (sl[j]) __hip_atomic_store(&cflag[sl[j] - L.cs], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     *changed = 1u;
+}
+// the ops of one light run on the register copy of its counters, the write-back, the prefilter cache (stage B proper and (3) below).
+// shared: counters another run claimed too — one this run did not change belongs to whoever can reach it: only the claim mark goes.
+__device__ __forceinline__ void apply_light_run(const FilterView &fv, uint64_t h0, uint32_t occ_first, const uint64_t *idx, uint64_t cv, uint32_t shared,
+                                                uint32_t kfirst, uint32_t krest, const uint8_t *__restrict__ tz, uint32_t first_op, uint32_t ops, int mode) {
+    uint32_t c[RB_MAX_HASH];
+    for (int j = 0; j < fv.cbf_h; ++j) c[j] = (uint32_t)(cv >> (8 * j)) & 0xFFu;
+    uint32_t mn0 = c[0];
+    for (int j = 1; j < fv.cbf_h; ++j) mn0 = c[j] < mn0 ? c[j] : mn0;
+    run_ops(c, fv.cbf_h, kfirst, krest, tz, first_op, ops);
+    for (int j = 0; j < fv.cbf_h; ++j) {
+        if (((shared >> j) & 1u) && c[j] == ((uint32_t)(cv >> (8 * j)) & 0xFFu)) cbf_release(fv.cbf, idx[j]);
+        else fv.cbf[idx[j]] = (uint8_t)c[j];                    // also clears the claim mark
+    }
+    if (cache_on(fv) && mode != M_COUNT_ONLY) {   // the k-mer is in dbgbf now; remember its counter exponent
+        uint32_t mn = c[0];
+        for (int j = 1; j < fv.cbf_h; ++j) mn = c[j] < mn ? c[j] : mn;
+        // ... unless the cache evidently knows it already: same exponent as before the sub-batch and every
+        // op of the run succeeded (an up-to-date entry lets through only draws that succeed; the minimum
+        // rises by one per success) — saves the bucket read + write for most runs in steady state
+        const bool cached = mn0 >= 16u && (mn >> 3) == (mn0 >> 3) && mn - mn0 == ops;
+        if (mn >= 16u && !cached) cache_store(fv, h0, occ_first, (mn >> 3) - 1u);
+    }
+}
+// (3) the candidates outside O: finished here (light) or handed to k_cbf_heavy (flag heavy2[i]); those of O keep RUN_CONFLICT
+__global__ void k_resolve_deferred(FilterView fv, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ counts, const uint32_t *__restrict__ starts,
+                                   const uint32_t *__restrict__ vals, const uint32_t *__restrict__ cand, uint32_t n_cand, const uint32_t *__restrict__ ordered,
+                                   int mode, uint32_t LIGHT_OPS, CsLookup L, uint32_t *__restrict__ status, const uint32_t *__restrict__ nops,
+                                   const uint64_t *__restrict__ cvals, const uint8_t *__restrict__ tz, uint32_t *__restrict__ heavy2) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_cand) return;
+    heavy2[i] = 0u;
+    if (ordered[i]) return;
+    const uint32_t d = cand[i], st = status[d] & ~RUN_CONFLICT, ops = nops[d];
+    if (ops > LIGHT_OPS) { status[d] = st | RUN_HEAVY; heavy2[i] = 1u; return; }
+    status[d] = st;
+    const uint64_t h0 = uniq[d];
+    uint64_t idx[RB_MAX_HASH];
+    uint32_t shared = 0;
+    for (int j = 0; j < fv.cbf_h; ++j) {
+        idx[j] = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod);
+        if (L.find(idx[j])) shared |= 1u << j;
+    }
+    apply_light_run(fv, h0, vals[starts[d]], idx, cvals[d], shared, (st >> 12) & 3u, (st >> 14) & 3u, tz, starts[d] + counts[d] - ops, ops, mode);
+}
+// stable compaction of the flagged entries of a (short) list: pos = exclusive scan of flag
+__global__ void k_list_compact(const uint32_t *__restrict__ list, const uint32_t *__restrict__ flag, const uint32_t *__restrict__ pos, uint32_t n,
+                               uint32_t *__restrict__ out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && flag[i]) out[pos[i]] = list[i];
 }
 
 // ---- stage B: resolve the found-flag of the first occurrence, set Bloom bits, then apply the
@@ -432,7 +476,6 @@ __global__ void k_resolve_apply(FilterView fv, const uint64_t *__restrict__ uniq
         }
     }
     nops[d] = ops;
-    const uint32_t st_in = st;                     // ST_SHARED / ST_ORDERED (k_cs_writers / k_cs_order) sit above the bits kept here
     st = (st & 0x7FFu) | (kfirst << 12) | (krest << 14);
     status[d] = st;
     if (dbgf && ops && (st & ST_CLAIMED)) {   // debug: expected fraction of ops that are guaranteed no-ops
@@ -455,43 +498,23 @@ __global__ void k_resolve_apply(FilterView fv, const uint64_t *__restrict__ uniq
     }
     if (!(st & ST_CLAIMED)) return;
     uint64_t idx[RB_MAX_HASH];
-    uint32_t c[RB_MAX_HASH];
-    const uint64_t cv = cvals[d];
-    for (int j = 0; j < fv.cbf_h; ++j) c[j] = (uint32_t)(cv >> (8 * j)) & 0xFFu;
-    uint32_t mn0 = c[0];
-    for (int j = 1; j < fv.cbf_h; ++j) mn0 = c[j] < mn0 ? c[j] : mn0;
-    // a run of the ordered set (k_cs_order) goes to the replay; the others apply their ops here, and leave alone the shared
-    // counters they did not change
-    const bool conflict = ops && (st_in & ST_ORDERED);
-    uint32_t shared = 0;
+    bool conflict = (st & ST_FOREIGN) != 0;
     for (int j = 0; j < fv.cbf_h; ++j) {
         idx[j] = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod);
-        if ((st_in & ST_SHARED) && !conflict) {
+        if (n_foreign && !conflict) {               // did another run claim this counter after this one?  (most have not: bit filter first)
             const uint64_t b = slot_of(idx[j], csf_log2);
-            if ((!csf || ((csf[b >> 5] >> (uint32_t)(b & 31u)) & 1u)) && table_find(cs, cs_log2, idx[j])) shared |= 1u << j;
+            if (!csf || ((csf[b >> 5] >> (uint32_t)(b & 31u)) & 1u)) conflict = table_find(cs, cs_log2, idx[j]) != nullptr;
         }
     }
     if (ops == 0) {                               // nothing to count: just drop the claim marks
         for (int j = 0; j < fv.cbf_h; ++j) cbf_release(fv.cbf, idx[j]);
         return;
     }
-    if (conflict) { status[d] = st | RUN_CONFLICT; return; }   // marks are dropped by k_conf_release before the replay
+    // a run with a shared counter is set aside: whether it needs the ordered replay is decided behind the point where the
+    // producer is released (k_cs_writers / k_cs_order / k_resolve_deferred); marks of replayed runs are dropped by k_conf_release
+    if (conflict) { status[d] = st | RUN_CONFLICT; return; }
     if (ops > LIGHT_OPS) { status[d] = st | RUN_HEAVY; return; }
-    run_ops(c, fv.cbf_h, kfirst, krest, tz, starts[d] + m - ops, ops);
-    for (int j = 0; j < fv.cbf_h; ++j) {
-        // a shared counter this run did not change belongs to whoever can reach it: only the claim mark goes
-        if (((shared >> j) & 1u) && c[j] == ((uint32_t)(cv >> (8 * j)) & 0xFFu)) cbf_release(fv.cbf, idx[j]);
-        else fv.cbf[idx[j]] = (uint8_t)c[j];                    // also clears the claim mark
-    }
-    if (cache_on(fv) && mode != M_COUNT_ONLY) {   // the k-mer is in dbgbf now; remember its counter exponent
-        uint32_t mn = c[0];
-        for (int j = 1; j < fv.cbf_h; ++j) mn = c[j] < mn ? c[j] : mn;
-        // ... unless the cache evidently knows it already: same exponent as before the sub-batch and every
-        // op of the run succeeded (an up-to-date entry lets through only draws that succeed; the minimum
-        // rises by one per success) — saves the bucket read + write for most runs in steady state
-        const bool cached = mn0 >= 16u && (mn >> 3) == (mn0 >> 3) && mn - mn0 == ops;
-        if (mn >= 16u && !cached) cache_store(fv, h0, vals[starts[d]], (mn >> 3) - 1u);
-    }
+    apply_light_run(fv, h0, vals[starts[d]], idx, cvals[d], 0u, kfirst, krest, tz, starts[d] + m - ops, ops, mode);
 }
 
 // drop the claim marks of the counters of conflicting runs before they are replayed in order
@@ -1741,31 +1764,6 @@ void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, ui
         RB_HIP(hipMemsetAsync(csf, 0, (size_t)1 << (csf_log2 - 3), s));
         hipLaunchKernelGGL(k_cs_build, dim3(blocks_for(D)), dim3(TPB), 0, s, status, g->foreign.as<uint64_t>(), D, g->cbf_h,
                            g->ctable.as<Slot>(), c_log2, csf, csf_log2);
-        // which of the runs with a shared counter need the ordered replay: reach counts, then the closure (2-3 rounds)
-        const size_t slots = (size_t)1 << c_log2;
-        g->cwriters.reserve(slots * 8 + 64);
-        RB_HIP(hipMemsetAsync(g->cwriters.p, 0, slots * 8 + 64, s));
-        uint32_t *writers = g->cwriters.as<uint32_t>(), *cflag = writers + slots, *changed = cflag + slots;
-        const CsLookup L{g->ctable.as<Slot>(), c_log2, csf, csf_log2};
-        hipLaunchKernelGGL(k_cs_writers, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, uniq, counts, D, status, g->cvals.as<uint64_t>(), L, writers);
-        // the runs with a shared counter, as a list (at most one per (run, counter) incidence <= 2 n_foreign): the rounds touch only these
-        g->temp.reserve(select2_temp_bytes(D));
-        g->cshared.reserve(((size_t)2 * n_foreign + 64) * 4);
-        select_flagged2(g->temp.p, g->temp.cap, status, D, ST_SHARED, g->cshared.as<uint32_t>(), 0u, g->cshared.as<uint32_t>(), changed + 8, s);
-        uint32_t n_shared = 0;
-        RB_HIP(hipMemcpyAsync(&n_shared, changed + 8, 4, hipMemcpyDeviceToHost, s));
-        RB_HIP(hipStreamSynchronize(s));
-        const bool old_rule = getenv("RB_ORDER_ALL_SHARED") != nullptr;     // every run with a shared counter is replayed (the rule before the closure)
-        for (int round = 0; n_shared; ++round) {
-            const int everything = (old_rule || round >= 16) ? 1 : 0;
-            hipLaunchKernelGGL(k_cs_order, dim3(blocks_for(n_shared)), dim3(TPB), 0, s, fv, uniq, counts, n_shared, status, g->cvals.as<uint64_t>(), L, writers, cflag,
-                               changed + (round & 7), everything, g->cshared.as<uint32_t>());
-            uint32_t ch = 0;
-            RB_HIP(hipMemcpyAsync(&ch, changed + (round & 7), 4, hipMemcpyDeviceToHost, s));
-            RB_HIP(hipStreamSynchronize(s));
-            if (!ch || everything) break;
-            if ((round & 7) == 7) RB_HIP(hipMemsetAsync(changed, 0, 32, s));
-        }
         g->prof_end("conflict_set");
     }
     g->prof_begin();
@@ -1774,8 +1772,13 @@ void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, ui
                        g->cvals.as<uint64_t>(), g->tz().as<uint8_t>(), getenv("RB_DEBUG") ? reinterpret_cast<float *>(ctr + 700) : (float *)nullptr);
     g->prof_end("resolve_apply");
     // the runs that own their counters alone have updated counters and prefilter cache: the producer may
-    // filter the next sub-batch now (heavy and conflicting runs follow below, overlapped with it)
-    if (after_resolve) (*after_resolve)();
+    // filter the next sub-batch now (heavy and replayed runs follow below, overlapped with it) — unless runs with shared counters
+    // were set aside: most of them are finished by k_resolve_deferred a few short kernels further down, and their cache
+    // updates (hot k-mers among them) are worth waiting for (released early, the next sub-batch keeps 10 % more conflicting ops)
+    bool released = false;
+    auto release = [&] { if (!released && after_resolve) (*after_resolve)(); released = true; };
+    const bool old_rule = getenv("RB_ORDER_ALL_SHARED") != nullptr;
+    if (!n_foreign || old_rule || getenv("RB_RELEASE_EARLY")) release();
     if (getenv("RB_DEBUG")) {
         float df[128];
         RB_HIP(hipMemcpyAsync(df, ctr + 700, sizeof df, hipMemcpyDeviceToHost, s));
@@ -1808,6 +1811,59 @@ void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, ui
     RB_HIP(hipMemcpyAsync(hc, ctr, 8, hipMemcpyDeviceToHost, s));
     RB_HIP(hipStreamSynchronize(s));
     g->prof_end("compact_lists");
+    if (hc[1] && !old_rule) {
+        // The runs with a shared counter were set aside by stage B (list confk).  Which of them need the ordered replay: reach
+        // counts per shared counter, then the closure (2-3 rounds over the list).  The others are finished here — light ones on
+        // the spot, long ones by a second k_cbf_heavy launch.  RB_ORDER_ALL_SHARED=1: every one of them is replayed (the old rule).
+        g->prof_begin();
+        const uint32_t nc0 = hc[1];
+        const size_t slots = (size_t)1 << c_log2;
+        g->cwriters.reserve(slots * 8 + 64);
+        g->cshared.reserve(((size_t)nc0 + 1) * 4 * 5 + 64);
+        RB_HIP(hipMemsetAsync(g->cwriters.p, 0, slots * 8 + 64, s));
+        uint32_t *writers = g->cwriters.as<uint32_t>(), *cflag = writers + slots, *changed = cflag + slots;
+        uint32_t *ordered = g->cshared.as<uint32_t>(), *heavy2 = ordered + (nc0 + 1), *pos_o = heavy2 + (nc0 + 1), *pos_h = pos_o + (nc0 + 1),
+                 *heavy2_list = pos_h + (nc0 + 1);
+        RB_HIP(hipMemsetAsync(ordered, 0, ((size_t)nc0 + 1) * 4 * 2, s));
+        const CsLookup L{g->ctable.as<Slot>(), c_log2, csf, csf_log2};
+        const uint32_t *cand = g->confk.as<uint32_t>();
+        hipLaunchKernelGGL(k_cs_writers, dim3(blocks_for(nc0)), dim3(TPB), 0, s, fv, uniq, nops, cand, nc0, g->cvals.as<uint64_t>(), L, writers);
+        for (int round = 0;; ++round) {
+            const int everything = round >= 16 ? 1 : 0;
+            hipLaunchKernelGGL(k_cs_order, dim3(blocks_for(nc0)), dim3(TPB), 0, s, fv, uniq, nops, cand, nc0, g->cvals.as<uint64_t>(), L, writers, cflag, ordered,
+                               changed + (round & 7), everything);
+            uint32_t ch = 0;
+            RB_HIP(hipMemcpyAsync(&ch, changed + (round & 7), 4, hipMemcpyDeviceToHost, s));
+            RB_HIP(hipStreamSynchronize(s));
+            if (!ch || everything) break;
+            if ((round & 7) == 7) RB_HIP(hipMemsetAsync(changed, 0, 32, s));
+        }
+        hipLaunchKernelGGL(k_resolve_deferred, dim3(blocks_for(nc0)), dim3(TPB), 0, s, fv, uniq, counts, starts, vals, cand, nc0, ordered, mode, g->light_ops, L,
+                           status, nops, g->cvals.as<uint64_t>(), g->tz().as<uint8_t>(), heavy2);
+        g->prof_end("conflict_set");
+        release();                                                             // (enqueues the next sub-batch's producer work; may wait on the host)
+        g->prof_begin();
+        g->temp.reserve(scan_temp_bytes((size_t)nc0 + 1));
+        exclusive_scan_u32(g->temp.p, g->temp.cap, ordered, pos_o, (size_t)nc0 + 1, s);
+        exclusive_scan_u32(g->temp.p, g->temp.cap, heavy2, pos_h, (size_t)nc0 + 1, s);
+        g->kk1.reserve((size_t)nc0 * 8);                                       // (free until the conflict path proper: the replayed runs, in run order)
+        uint32_t *conf2 = g->kk1.as<uint32_t>();
+        hipLaunchKernelGGL(k_list_compact, dim3(blocks_for(nc0)), dim3(TPB), 0, s, cand, ordered, pos_o, nc0, conf2);
+        hipLaunchKernelGGL(k_list_compact, dim3(blocks_for(nc0)), dim3(TPB), 0, s, cand, heavy2, pos_h, nc0, heavy2_list);
+        uint32_t n2[2] = {0, 0};
+        RB_HIP(hipMemcpyAsync(&n2[0], pos_o + nc0, 4, hipMemcpyDeviceToHost, s));
+        RB_HIP(hipMemcpyAsync(&n2[1], pos_h + nc0, 4, hipMemcpyDeviceToHost, s));
+        RB_HIP(hipStreamSynchronize(s));
+        if (n2[0]) RB_HIP(hipMemcpyAsync(g->confk.p, conf2, (size_t)n2[0] * 4, hipMemcpyDeviceToDevice, s));
+        if (n2[1]) {
+            RB_HIP(hipMemcpyAsync(changed + 12, &n2[1], 4, hipMemcpyHostToDevice, s));   // k_cbf_heavy takes the length from the device
+            hipLaunchKernelGGL(k_cbf_heavy, dim3(std::min<uint32_t>(n2[1], 262144u)), dim3(64), 0, s, fv, uniq, counts, starts,
+                               vals, status, nops, g->cvals.as<uint64_t>(), g->tz().as<uint8_t>(), heavy2_list, changed + 12, (uint64_t *)nullptr);
+        }
+        hc[1] = n2[0];
+        g->prof_end("conflict_set");
+    }
+    release();
     if (hc[0]) {
         g->prof_begin();
         hipLaunchKernelGGL(k_cbf_heavy, dim3(std::min<uint32_t>(hc[0], 262144u)), dim3(64), 0, s, fv, uniq, counts, starts,
