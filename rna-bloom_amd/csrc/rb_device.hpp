@@ -135,7 +135,13 @@ struct Npf {
     unsigned long long *tab;   // nullptr => disabled
     uint32_t log2n;            // log2 of the number of entries (8 per bucket), 16..28
 };
-__device__ __forceinline__ uint32_t npf_lookup(const Npf &c, uint64_t h0) {       // 0 = unknown
+// What an entry remembers: the exponent (min counter >> 3) - 1 = 1..14 of the k-mer's counting-Bloom minimum — or that the minimum
+// stands at 127, where MiniFloat.increment changes nothing any more (R/util/MiniFloat.java:32): EVERY further occurrence of such a
+// k-mer is a no-op.  (Config 2's most expressed transcripts get there within the first pass; capped at exponent 7 their k-mers
+// kept 1/128 of their occurrences: up to 29 000 records per k-mer and sub-batch, 7 % of all sorted records.)
+constexpr uint32_t RB_EXP_SATURATED = 15u;
+__host__ __device__ __forceinline__ uint32_t cache_exp(uint32_t mn) { return mn >= 127u ? RB_EXP_SATURATED : (mn >> 3) - 1u; }
+__device__ __forceinline__ uint32_t npf_lookup(const Npf &c, uint64_t h0) {       // 0 = unknown, 16 = saturated
     const uint32_t B = c.log2n - 3u;
     const ulonglong2 *b = reinterpret_cast<const ulonglong2 *>(c.tab + ((h0 & ((1ull << B) - 1ull)) << 3));
     const uint64_t tag = h0 >> B;
@@ -146,7 +152,7 @@ __device__ __forceinline__ uint32_t npf_lookup(const Npf &c, uint64_t h0) {     
         if ((e.x >> 4) == tag) { const uint32_t v = (uint32_t)(e.x & 15ull); s = v > s ? v : s; }
         if ((e.y >> 4) == tag) { const uint32_t v = (uint32_t)(e.y & 15ull); s = v > s ? v : s; }
     }
-    return s;
+    return s == RB_EXP_SATURATED ? 16u : s;      // a saturated k-mer: no draw is strong enough (strengths stop at 15)
 }
 // s in 1..14.  8-byte stores are never torn; two threads racing for one slot lose one entry at worst,
 // and a k-mer that ends up in two slots is harmless (lookup takes the larger exponent, both are true).
@@ -234,16 +240,22 @@ __host__ __device__ __forceinline__ uint32_t mpf_slot_a(uint64_t h0) { return ((
 __host__ __device__ __forceinline__ uint32_t mpf_slot_b(uint64_t h0) { return (((uint32_t)h0 >> 3) & 7u) * 2u + 1u; }
 __host__ __device__ __forceinline__ unsigned long long mpf_tag_a(uint64_t h0) { return h0 >> 3; }
 __host__ __device__ __forceinline__ unsigned long long mpf_tag_b(uint64_t h0) { return ((h0 >> 6) << 3) | (h0 & 7ull); }
-// s in 1..14.  Raise an existing entry; else take an empty candidate slot; else replace the candidate with the
+// s in 1..14, or RB_EXP_SATURATED.  The entry has three bits for it: 1..6 = that exponent, 7 = "7 to 10", 0 = "11 or more" (the
+// entry of a k-mer whose tag is 0 would then read as an empty slot: such a k-mer is simply not cached).  mpf_rank orders the codes:
+// when a bucket is full the k-mer of the higher class takes the slot — an uncached k-mer keeps ALL its occurrences, and the hotter
+// it is the more that costs (config 2: the records of uncached hot k-mers were what filled the buckets that do not fit LDS).
+// Raise an existing entry; else take an empty candidate slot; else replace the candidate with the
 // smaller exponent if ours is larger (the coldest k-mer costs the least when it misses).
+constexpr uint32_t RB_MPF_TOP_EXP = 11u;
+__host__ __device__ __forceinline__ uint32_t mpf_rank(uint32_t code) { return code ? code : 8u; }
 __device__ __forceinline__ void mpf_store(const Mpf &c, uint64_t bucket, uint64_t h0, uint32_t s) {
     unsigned long long *b = c.tab + (bucket << 4);
-    const uint32_t sa = mpf_slot_a(h0), sb = mpf_slot_b(h0), sv = s > 7u ? 7u : s;
+    const uint32_t sa = mpf_slot_a(h0), sb = mpf_slot_b(h0), sv = s >= RB_MPF_TOP_EXP ? 0u : (s > 7u ? 7u : s), rv = mpf_rank(sv);
     const unsigned long long na = (mpf_tag_a(h0) << 3) | sv, nb = (mpf_tag_b(h0) << 3) | sv;
     const unsigned long long ea = __hip_atomic_load(&b[sa], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long eb = __hip_atomic_load(&b[sb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (ea && (ea >> 3) == mpf_tag_a(h0)) { if ((uint32_t)(ea & 7ull) < sv) __hip_atomic_store(&b[sa], na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
-    if (eb && (eb >> 3) == mpf_tag_b(h0)) { if ((uint32_t)(eb & 7ull) < sv) __hip_atomic_store(&b[sb], nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+    if (ea && (ea >> 3) == mpf_tag_a(h0)) { if (mpf_rank((uint32_t)(ea & 7ull)) < rv) __hip_atomic_store(&b[sa], na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+    if (eb && (eb >> 3) == mpf_tag_b(h0)) { if (mpf_rank((uint32_t)(eb & 7ull)) < rv) __hip_atomic_store(&b[sb], nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
     if (!ea) { __hip_atomic_store(&b[sa], na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
     if (!eb) { __hip_atomic_store(&b[sb], nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
     {   // both taken: one cuckoo step — move an occupant to ITS other candidate slot if that one is free
@@ -264,15 +276,15 @@ __device__ __forceinline__ void mpf_store(const Mpf &c, uint64_t bucket, uint64_
             return;
         }
     }
-    const bool pick_b = (uint32_t)(eb & 7ull) < (uint32_t)(ea & 7ull);
-    if ((uint32_t)((pick_b ? eb : ea) & 7ull) < sv) __hip_atomic_store(&b[pick_b ? sb : sa], pick_b ? nb : na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool pick_b = mpf_rank((uint32_t)(eb & 7ull)) < mpf_rank((uint32_t)(ea & 7ull));
+    if (mpf_rank((uint32_t)((pick_b ? eb : ea) & 7ull)) < rv) __hip_atomic_store(&b[pick_b ? sb : sa], pick_b ? nb : na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // lookup in a bucket image held by the caller (16 words strided by `stride`)
 __device__ __forceinline__ uint32_t mpf_match(const unsigned long long *bkt, uint32_t stride, uint64_t h0) {
     const unsigned long long ea = bkt[mpf_slot_a(h0) * stride], eb = bkt[mpf_slot_b(h0) * stride];
-    uint32_t s = 0;
-    if (ea && (ea >> 3) == mpf_tag_a(h0)) s = (uint32_t)(ea & 7ull);
-    if (eb && (eb >> 3) == mpf_tag_b(h0)) { const uint32_t v = (uint32_t)(eb & 7ull); s = v > s ? v : s; }
+    uint32_t s = 0;                               // 0 = unknown, else a lower bound of the exponent: 1..7, or 11
+    if (ea && (ea >> 3) == mpf_tag_a(h0)) { const uint32_t v = (uint32_t)(ea & 7ull); s = v ? v : RB_MPF_TOP_EXP; }
+    if (eb && (eb >> 3) == mpf_tag_b(h0)) { const uint32_t v = (uint32_t)(eb & 7ull), r = v ? v : RB_MPF_TOP_EXP; s = r > s ? r : s; }
     return s;
 }
 

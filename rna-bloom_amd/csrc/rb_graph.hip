@@ -396,8 +396,8 @@ __device__ __forceinline__ void apply_light_run(const FilterView &fv, uint64_t h
         // ... unless the cache evidently knows it already: same exponent as before the sub-batch and every
         // op of the run succeeded (an up-to-date entry lets through only draws that succeed; the minimum
         // rises by one per success) — saves the bucket read + write for most runs in steady state
-        const bool cached = mn0 >= 16u && (mn >> 3) == (mn0 >> 3) && mn - mn0 == ops;
-        if (mn >= 16u && !cached) cache_store(fv, h0, occ_first, (mn >> 3) - 1u);
+        const bool cached = mn0 >= 16u && (mn >> 3) == (mn0 >> 3) && mn - mn0 == ops && !(mn >= 127u && mn0 < 127u);   // (reaching 127 is news: the k-mer is saturated)
+        if (mn >= 16u && !cached) cache_store(fv, h0, occ_first, cache_exp(mn));
     }
 }
 // (3) the candidates outside O: finished here (light) or handed to k_cbf_heavy (flag heavy2[i]); those of O keep RUN_CONFLICT
@@ -489,7 +489,7 @@ __global__ void k_resolve_apply(FilterView fv, const uint64_t *__restrict__ uniq
             const uint32_t occ = vals[starts[d]];
             const uint32_t r = fv.seq_first + (occ >> fv.pos_bits), p = occ & ((1u << fv.pos_bits) - 1u);
             const uint64_t bk = mpf_bucket(fv.mpf, window_min_order(fv.seq_codes + fv.seq_woff[r], p, (uint32_t)fv.k, fv.mpf.m));
-            const uint32_t sc = mpf_match(fv.mpf.tab + (bk << 4), 1u, h0), s0 = min((mn >> 3) - 1u, 7u);
+            const uint32_t sc = min(mpf_match(fv.mpf.tab + (bk << 4), 1u, h0), 7u), s0 = min((mn >> 3) - 1u, 7u);
             atomicAdd(&g_dbg_hist[s0 * 8u + sc], (unsigned long long)ops);
             uint32_t occupied = 0;
             for (uint32_t q = 0; q < 16u; ++q) occupied += fv.mpf.tab[(bk << 4) + q] != 0ull;
@@ -649,7 +649,7 @@ __global__ void k_conf_replay_small(FilterView fv, const uint64_t *__restrict__ 
                 const uint32_t c = *(volatile uint8_t *)&fv.cbf[index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod)];
                 mn = c < mn ? c : mn;
             }
-            if (mn >= 16u && mn < 128u) cache_store(fv, h0, vals[starts[dq]], (mn >> 3) - 1u);
+            if (mn >= 16u && mn < 128u) cache_store(fv, h0, vals[starts[dq]], cache_exp(mn));
         }
 }
 // one wavefront per large component: the component's counters live in LDS; 64 ops are examined at
@@ -760,7 +760,7 @@ __global__ void __launch_bounds__(64) k_conf_replay_big(FilterView fv, const uin
         if (store_cache && cache_on(fv) && lane < nk) {   // the component's k-mers are in dbgbf; remember their exponents
             uint32_t mn = s_val[s_slot[lane][0]];
             for (int j = 1; j < H; ++j) { const uint32_t c = s_val[s_slot[lane][j]]; mn = c < mn ? c : mn; }
-            if (mn >= 16u && mn < 128u) cache_store(fv, s_h0[lane], vals[starts[s_drun[lane]]], (mn >> 3) - 1u);
+            if (mn >= 16u && mn < 128u) cache_store(fv, s_h0[lane], vals[starts[s_drun[lane]]], cache_exp(mn));
         }
         __syncthreads();
     }
@@ -1647,7 +1647,12 @@ uint32_t rb::group_finish(rb_graph *g, int slot, hipStream_t st, DevBuf &temp, D
     RB_HIP(hipStreamSynchronize(st));
     RB_REQUIRE(D < (1u << 30), "sub-batch has too many distinct k-mers (%u)", D);
     S.D = D;
-    (void)temp; (void)scan_stream;   // the run starts come out of the grouping kernel
+    (void)scan_stream;   // the run starts come out of the grouping kernel
+    if (getenv("RB_DEBUG") && temp.p) {
+        uint32_t nb = 0, mx = 0; uint64_t rec = 0;
+        group_debug_big(temp.p, S.N, 64 - g->sort_begin_bit, g->shard ? 3072 : 0, &nb, &rec, &mx);
+        fprintf(stderr, "[rb] grouping: N=%zu runs=%u; buckets that did not fit LDS: %u with %llu records, largest %u\n", S.N, D, nb, (unsigned long long)rec, mx);
+    }
     return D;
 }
 uint32_t rb::group_records(rb_graph *g, size_t N, uint64_t ordinal0, uint32_t pos_bits, rb_add_stats *stats, uint32_t **ctr_out) {
@@ -2103,7 +2108,7 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
         const int slot = (int)(i & 1u);
         unsigned long long np = 0;
         if (pairs && subs[i].nw > 0) RB_HIP(hipMemcpyAsync(&np, reinterpret_cast<unsigned long long *>(g->devctr2.as<uint32_t>() + 12), 8, hipMemcpyDeviceToHost, sp));
-        const uint32_t D = group_finish(g, slot, sp, g->temp, g->devctr2, s);   // drains the producer stream
+        const uint32_t D = group_finish(g, slot, sp, g->temp2, g->devctr2, s);  // drains the producer stream
         if (stats) { stats->pairs += (int64_t)np; stats->distinct += D; }
         const bool serial = getenv("RB_SERIAL") != nullptr;   // debugging / clean per-stage timing
         const bool early = getenv("RB_PREPARE_EARLY") != nullptr;   // A/B: producer a whole sub-batch ahead (staler cache)

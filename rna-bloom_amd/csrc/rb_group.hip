@@ -756,6 +756,20 @@ static GroupPlan group_plan(size_t N, int group_bits, int bucket_target = 0) {
     return P;
 }
 
+// debugging aid (RB_DEBUG): the buckets that did not fit LDS in the last grouping of N records that used `temp` (call with the stream idle)
+void group_debug_big(const void *temp, size_t N, int group_bits, int bucket_target, uint32_t *n_big_out, uint64_t *records_out, uint32_t *largest_out) {
+    const GroupPlan P = group_plan(N, group_bits, bucket_target);
+    const char *tp = static_cast<const char *>(temp);
+    uint32_t tick[4] = {0, 0, 0, 0};
+    RB_HIP(hipMemcpy(tick, tp + P.off_ticket, 16, hipMemcpyDeviceToHost));
+    const uint32_t nb = std::min(tick[2], P.nbuckets);
+    std::vector<uint32_t> big(nb), bs((size_t)P.nbuckets + 1);
+    if (nb) RB_HIP(hipMemcpy(big.data(), tp + P.off_big, (size_t)nb * 4, hipMemcpyDeviceToHost));
+    RB_HIP(hipMemcpy(bs.data(), tp + P.off_bstart, ((size_t)P.nbuckets + 1) * 4, hipMemcpyDeviceToHost));
+    uint64_t rec = 0; uint32_t mx = 0;
+    for (uint32_t i = 0; i < nb; ++i) { const uint32_t c = bs[big[i] + 1] - bs[big[i]]; rec += c; mx = std::max(mx, c); }
+    *n_big_out = nb; *records_out = rec; *largest_out = mx;
+}
 size_t group_temp_bytes(size_t N, int group_bits, int bucket_target) { return group_plan(N, group_bits, bucket_target).total; }
 
 template <int TPB>

@@ -105,6 +105,7 @@ void run_length_encode_u64(void *temp, size_t temp_bytes, const uint64_t *keys, 
 // hand-written grouping stage of the insert pipeline (rb_group.hip): N (h0, occurrence) records -> occurrences in
 // grouped order, their draw strengths, runs (hash, count, start) and the run count, all on `st`, nothing synchronised.
 // keys0/vals0 are clobbered; keys_tmp/vals_tmp are scratch of the same size.
+void group_debug_big(const void *temp, size_t N, int group_bits, int bucket_target, uint32_t *n_big_out, uint64_t *records_out, uint32_t *largest_out);
 size_t group_temp_bytes(size_t N, int group_bits, int bucket_target = 0);
 void group_records_device(uint64_t *keys0, uint32_t *vals0, uint64_t *keys_tmp, uint32_t *vals_tmp, size_t N, int group_bits,
                           uint64_t seed, uint64_t ordinal0, uint32_t pos_bits, void *temp, size_t temp_bytes,

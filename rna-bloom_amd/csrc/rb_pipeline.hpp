@@ -276,7 +276,7 @@ static __global__ void __launch_bounds__(64) k_cbf_heavy(FilterView fv, const ui
             if (cache_on(fv) && (st & ST_ALLPRE)) {   // remember how hard this k-mer has become to increment
                 uint32_t mn = c[0];
                 for (int j = 1; j < fv.cbf_h; ++j) mn = c[j] < mn ? c[j] : mn;
-                if (mn >= 16u) { cache_store(fv, h0, vals[starts[d]], (mn >> 3) - 1u); if (cache_upd) cache_upd[d] = (uint8_t)((mn >> 3) - 1u); }
+                if (mn >= 16u) { cache_store(fv, h0, vals[starts[d]], cache_exp(mn)); if (cache_upd) cache_upd[d] = (uint8_t)cache_exp(mn); }
             }
         }
     }
