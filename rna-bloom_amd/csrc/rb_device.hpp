@@ -276,6 +276,36 @@ __device__ __forceinline__ void mpf_store(const Mpf &c, uint64_t bucket, uint64_
             return;
         }
     }
+    {   // ... and a second step: the occupant's other slot is taken too, but ITS occupant can move on (the k-mers of one minimizer
+        // crowd one bucket: up to 10 of them for 8 + 8 slots with two choices each; every extra placement is a k-mer that stops
+        // sending all its occurrences through the pipeline)
+        const uint64_t ha = ((ea >> 3) << 3) | (uint64_t)(sa >> 1);
+        const uint32_t ha_b = mpf_slot_b(ha);
+        const unsigned long long ec = __hip_atomic_load(&b[ha_b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // a B-type entry
+        if (ec && ha_b != sb) {
+            const uint64_t hc = (((ec >> 6) << 3 | (uint64_t)(ha_b >> 1)) << 3) | ((ec >> 3) & 7ull);
+            const uint32_t hc_a = mpf_slot_a(hc);
+            if (hc_a != sa && !__hip_atomic_load(&b[hc_a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                __hip_atomic_store(&b[hc_a], (mpf_tag_a(hc) << 3) | (ec & 7ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&b[ha_b], (mpf_tag_b(ha) << 3) | (ea & 7ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&b[sa], na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+        }
+        const uint64_t hb = (((eb >> 6) << 3 | (uint64_t)(sb >> 1)) << 3) | ((eb >> 3) & 7ull);
+        const uint32_t hb_a = mpf_slot_a(hb);
+        const unsigned long long ed = __hip_atomic_load(&b[hb_a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // an A-type entry
+        if (ed && hb_a != sa) {
+            const uint64_t hd = ((ed >> 3) << 3) | (uint64_t)(hb_a >> 1);
+            const uint32_t hd_b = mpf_slot_b(hd);
+            if (hd_b != sb && !__hip_atomic_load(&b[hd_b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                __hip_atomic_store(&b[hd_b], (mpf_tag_b(hd) << 3) | (ed & 7ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&b[hb_a], (mpf_tag_a(hb) << 3) | (eb & 7ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&b[sb], nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+        }
+    }
     const bool pick_b = mpf_rank((uint32_t)(eb & 7ull)) < mpf_rank((uint32_t)(ea & 7ull));
     if (mpf_rank((uint32_t)((pick_b ? eb : ea) & 7ull)) < rv) __hip_atomic_store(&b[pick_b ? sb : sa], pick_b ? nb : na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
