@@ -315,7 +315,7 @@ __device__ __forceinline__ uint32_t gr_look_back(const unsigned long long *statu
     }
 }
 
-template <int TPB>
+template <int TPB, bool PREFETCH>
 __global__ void __launch_bounds__(TPB) k_group_buckets(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                                                        const uint32_t *__restrict__ bstart, uint32_t nbuckets,
                                                        uint32_t shift_lo, uint32_t bits_lo, uint32_t shift_hi, uint32_t bits_hi,
@@ -331,31 +331,48 @@ __global__ void __launch_bounds__(TPB) k_group_buckets(const uint64_t *__restric
     __shared__ uint16_t s_wcnt[2][NW * NB];       // one table per pass: each is cleaned right after its use, two barriers before the next
     __shared__ unsigned long long s_wmask[NW * NB];
     __shared__ uint16_t s_dstart[NB];
-    __shared__ uint32_t s_wsum[NW], s_seg[ITEMS * NW], s_misc[2], s_fixn, s_redo;
+    __shared__ uint32_t s_wsum[NW], s_seg[ITEMS * NW], s_misc[3], s_fixn, s_redo;
     __shared__ uint16_t s_fixlist[64];
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     for (uint32_t d = threadIdx.x; d < NW * NB; d += TPB) { s_wmask[d] = 0ull; s_wcnt[0][d] = 0; s_wcnt[1][d] = 0; }
-    // persistent workgroups: buckets are taken in ticket order, so every predecessor of a bucket has been taken by
-    // a running workgroup (the look-back below never waits for work that has not started)
+    uint32_t c = 0, b0 = 0, b1 = 0;
+    uint64_t k[ITEMS];
+    uint32_t v[ITEMS], dig[ITEMS], rank[ITEMS];
+    auto load_bucket = [&](uint32_t cc, uint32_t &bb0, uint32_t &bb1, uint64_t (&kk)[ITEMS], uint32_t (&vv)[ITEMS]) {
+        bb0 = bstart[cc]; bb1 = bstart[cc + 1u];
+        const uint32_t n = bb1 - bb0 > GR_TILE ? 0u : bb1 - bb0;
+#pragma unroll
+        for (uint32_t r = 0; r < ITEMS; ++r) {
+            const uint32_t j = w * SEG + r * 64u + lane;
+            const bool ok = j < n;
+            kk[r] = ok ? keys_in[bb0 + j] : 0ull;
+            vv[r] = ok ? vals_in[bb0 + j] : 0u;
+        }
+    };
+    // persistent workgroups: buckets are taken in ticket order.  PREFETCH (only without the chained scan, which must never
+    // wait for a bucket whose workgroup is still busy with another one): the ticket of the NEXT bucket is taken when this one
+    // starts and its records are loaded (into the registers this bucket's records came in) once this one is grouped in LDS,
+    // so the ticket -> bounds -> records chain of global latencies runs behind the run extraction and the output of this bucket.
+    if (PREFETCH) {
+        if (threadIdx.x == 0) s_misc[0] = atomicAdd(ticket, 1u);
+        __syncthreads();
+        c = s_misc[0];
+        if (c >= nbuckets) return;
+        load_bucket(c, b0, b1, k, v);
+    }
     for (;;) {
     __syncthreads();
-    if (threadIdx.x == 0) { s_misc[0] = atomicAdd(ticket, 1u); s_fixn = 0; s_redo = 0; }
+    if (threadIdx.x == 0) { s_misc[PREFETCH ? 2 : 0] = atomicAdd(ticket, 1u); s_fixn = 0; s_redo = 0; }
     __syncthreads();
-    const uint32_t c = s_misc[0];
-    if (c >= nbuckets) return;
-    const uint32_t b0 = bstart[c], b1 = bstart[c + 1u];
+    if (!PREFETCH) {
+        c = s_misc[0];
+        if (c >= nbuckets) return;
+        load_bucket(c, b0, b1, k, v);
+    }
+    const uint32_t c_next = PREFETCH ? s_misc[2] : 0u;
     const bool big = b1 - b0 > GR_TILE;              // does not fit LDS: left to k_group_big (its runs are appended after all of these)
     const uint32_t cn = big ? 0u : b1 - b0;
     const uint32_t rows = cn > w * SEG ? min(ITEMS, (cn - w * SEG + 63u) / 64u) : 0u;
-    uint64_t k[ITEMS];
-    uint32_t v[ITEMS], dig[ITEMS], rank[ITEMS];
-#pragma unroll
-    for (uint32_t r = 0; r < ITEMS; ++r) {
-        const uint32_t j = w * SEG + r * 64u + lane;
-        const bool ok = j < cn;
-        k[r] = ok ? keys_in[b0 + j] : 0ull;
-        v[r] = ok ? vals_in[b0 + j] : 0u;
-    }
     if (big && threadIdx.x == 0) big_list[atomicAdd(n_big, 1u)] = c;
     bool in_lds = false;
     // one stable counting pass over the bucket (from the registers the records were loaded into, later from LDS)
@@ -445,8 +462,11 @@ __global__ void __launch_bounds__(TPB) k_group_buckets(const uint64_t *__restric
             __syncthreads();
         }
     };
-    sort_pass(shift_lo, bits_lo, s_wcnt[0]);
-    sort_pass(shift_hi, bits_hi, s_wcnt[1]);
+#ifndef GR_ABL
+#define GR_ABL 0
+#endif
+    if (!(GR_ABL & 16)) sort_pass(shift_lo, bits_lo, s_wcnt[0]);
+    if (!(GR_ABL & 20)) sort_pass(shift_hi, bits_hi, s_wcnt[1]);
     if (!in_lds) {      // no local digit at all: keep the order
 #pragma unroll
         for (uint32_t r = 0; r < ITEMS; ++r) {
@@ -455,7 +475,7 @@ __global__ void __launch_bounds__(TPB) k_group_buckets(const uint64_t *__restric
         }
         __syncthreads();
     }
-    if (do_fix && cn) {
+    if (do_fix && cn && !(GR_ABL & 2)) {
         fix_groups(shift_lo, bits_lo + bits_hi);
         if (do_fix > 1u && s_redo) {                             // (uniform: read behind the barriers of fix_groups)
             __syncthreads();
@@ -466,7 +486,10 @@ __global__ void __launch_bounds__(TPB) k_group_buckets(const uint64_t *__restric
             fix_groups(shift_lo - GR_LOCAL_BITS, bits_lo + bits_hi + GR_LOCAL_BITS);
         }
     }
-    // the bucket is grouped; thread t takes records t, t + TPB, ... : run heads first (their number is what the buckets after
+    // the bucket is grouped and lives in LDS: the registers that held its records take the next bucket's
+    uint32_t nb0 = 0, nb1 = 0;
+    if (PREFETCH && c_next < nbuckets) load_bucket(c_next, nb0, nb1, k, v);
+    // thread t takes records t, t + TPB, ... : run heads first (their number is what the buckets after
     // this one wait for), then — while wavefront 0 looks back — sorted occurrences and strengths
     unsigned long long hb[ITEMS];
     uint32_t occ[ITEMS];
@@ -492,7 +515,8 @@ __global__ void __launch_bounds__(TPB) k_group_buckets(const uint64_t *__restric
         s_seg[lane] = inc - mine;
         if (lane == 63u) {
             s_misc[1] = inc;
-            __hip_atomic_store(&status[c], (c == 0 ? GR_ST_PREFIX : GR_ST_AGG) | (unsigned long long)inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (status) __hip_atomic_store(&status[c], (c == 0 ? GR_ST_PREFIX : GR_ST_AGG) | (unsigned long long)inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            else s_misc[0] = atomicAdd(n_runs_out, inc);        // run slots in the order the buckets finish
         }
     }
     __syncthreads();                       // everybody holds its occurrences in registers: s_vals becomes the head positions
@@ -501,9 +525,9 @@ __global__ void __launch_bounds__(TPB) k_group_buckets(const uint64_t *__restric
 #pragma unroll
     for (uint32_t i = 0; i < ITEMS; ++i)
         if (head[i]) hpos[s_seg[i * NW + w] + gr_lanes_below(hb[i])] = (uint16_t)(i * TPB + threadIdx.x);
-    if (w == 0) {                          // global position of this bucket's runs: chained scan over the buckets
+    if (w == 0 && status) {                // runs in bucket order (RB_GROUP_ORDERED=1): chained scan over the buckets
         uint32_t rb_ = 0;
-        if (c != 0) rb_ = gr_look_back(status, c);
+        if (c != 0 && !(GR_ABL & 1)) rb_ = gr_look_back(status, c);
         if (lane == 0) {
             s_misc[0] = rb_;
             if (c != 0) __hip_atomic_store(&status[c], GR_ST_PREFIX | (unsigned long long)(rb_ + nruns), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -514,7 +538,7 @@ __global__ void __launch_bounds__(TPB) k_group_buckets(const uint64_t *__restric
 #pragma unroll
     for (uint32_t i = 0; i < ITEMS; ++i) {
         const uint32_t j = i * TPB + threadIdx.x;
-        if (j < cn) {
+        if (j < cn && !(GR_ABL & 8)) {
             vals_out[b0 + j] = occ[i];
             const uint32_t rr = rng31(rng.seed, rng.ordinal0 + (uint64_t)(occ[i] >> rng.pos_bits), occ[i] & pmask) | 0x8000u;
             tz_out[b0 + j] = (uint8_t)(__ffs((int)rr) - 1);
@@ -527,6 +551,10 @@ __global__ void __launch_bounds__(TPB) k_group_buckets(const uint64_t *__restric
         uniq[run_base + i] = s_keys[j];
         starts[run_base + i] = b0 + j;
         counts[run_base + i] = e - j;
+    }
+    if (PREFETCH) {
+        if (c_next >= nbuckets) return;
+        c = c_next; b0 = nb0; b1 = nb1;
     }
     }   // next bucket
 }
@@ -822,8 +850,19 @@ static void group_records_impl(const GroupPlan &P, uint64_t *keys0, uint32_t *va
     uint32_t *big_list = reinterpret_cast<uint32_t *>(tp + P.off_big), *n_big = ticket + 2;
     if (prof) prof->prof_begin(st);
     const uint32_t bucket_grid = std::min(P.nbuckets, (uint32_t)(getenv("RB_GROUP_GRID") ? atoi(getenv("RB_GROUP_GRID")) : 768));
-    hipLaunchKernelGGL(k_group_buckets<TPB>, dim3(bucket_grid), dim3(TPB), 0, st, kin, vin, bstart, P.nbuckets, P.lshift_lo, P.l_lo, P.lshift_hi, P.l_hi,
-                       rng, P.fix_cap, ticket, status, big_list, n_big, vals_out, tz_out, uniq, counts, starts, n_runs_dev);
+    // Run slots: nothing downstream depends on the order of the runs (the runs of oversized buckets were always appended in
+    // arbitrary order), so a bucket takes its slots with one atomicAdd when its run count is known.  RB_GROUP_ORDERED=1 keeps
+    // the runs in bucket order through a chained scan over the buckets (a quarter of the kernel's time: a bucket's look-back
+    // walks the ~500 buckets in flight before it).
+    static const bool ordered = getenv("RB_GROUP_ORDERED") && atoi(getenv("RB_GROUP_ORDERED")) != 0;
+    if (!ordered) RB_HIP(hipMemsetAsync(n_runs_dev, 0, 4, st));
+    static const bool prefetch = !(getenv("RB_GROUP_PREFETCH") && atoi(getenv("RB_GROUP_PREFETCH")) == 0);
+    if (ordered || !prefetch)
+        hipLaunchKernelGGL((k_group_buckets<TPB, false>), dim3(bucket_grid), dim3(TPB), 0, st, kin, vin, bstart, P.nbuckets, P.lshift_lo, P.l_lo, P.lshift_hi, P.l_hi,
+                           rng, P.fix_cap, ticket, ordered ? status : nullptr, big_list, n_big, vals_out, tz_out, uniq, counts, starts, n_runs_dev);
+    else
+        hipLaunchKernelGGL((k_group_buckets<TPB, true>), dim3(bucket_grid), dim3(TPB), 0, st, kin, vin, bstart, P.nbuckets, P.lshift_lo, P.l_lo, P.lshift_hi, P.l_hi,
+                           rng, P.fix_cap, ticket, nullptr, big_list, n_big, vals_out, tz_out, uniq, counts, starts, n_runs_dev);
     if (prof) { prof->prof_end("group_buckets", st); prof->prof_begin(st); }
     // the buckets that do not fit LDS (none in a warm steady state): sorted through the record buffer that is free now
     uint64_t *ka = const_cast<uint64_t *>(kin), *kb = kin == keys0 ? keys_tmp : keys0;
