@@ -179,6 +179,18 @@ int rb_filter_get_count(rb_graph *g, const uint64_t *h0, size_t n, float *out);
  * distributed graph come from one rb_shard_query_* exchange (rnabloom/sharded.py::ShardRank.getKmers). */
 int rb_graph_kmers(rb_graph *g, const char *seq, const int64_t *offsets, int64_t n_reads,
                    int64_t *koffsets, uint64_t *f, uint64_t *r, float *count);
+/* The counts of getKmers for reads that are already resident in HBM (an rb_batch): out[row(i) + p] = graph.getCount of window p of
+ * read first + i (0 for a window with a non-ACGTU base) — the per-read count profile stage 2 reads first
+ * (R/RNABloom.java:1984, 2097-2114: graph.getKmers(seq) before correctErrors); hashes are not returned (4 bytes per k-mer instead
+ * of 20: the call is bound by the copy back).  koffsets (host, n + 1 entries, koffsets[0] = 0): row(i) = koffsets[i], read i must
+ * have koffsets[i+1] - koffsets[i] = max(0, len_i - k + 1) windows; koffsets = NULL: rows of *stride_out = max_len - k + 1 counts
+ * (the batch's longest read), shorter reads padded with zeros — for uniform reads that is the packed layout.  out_on_device != 0:
+ * `out` is device memory of the graph's device and nothing is copied.  Host buffers are pinned for the call (see
+ * rb_graph_add_reads).  A window is usable where the batch marks all its bases valid: for getKmers(String) semantics the batch
+ * is one created without a quality threshold (min_base_qual 0 / no qualities).  Results equal rb_graph_kmers' counts and the
+ * oracle's (tests/test_gpu_queries.py). */
+int rb_graph_batch_counts(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, const int64_t *koffsets, float *out,
+                          int out_on_device, int64_t *stride_out);
 /* Kmer.getSuccessors/getPredecessors R/graph/Kmer.java:210-255, CanonicalKmer.java:226-270:
  * for each (f, r, char_out) the 4 neighbours in order A,C,G,T: forward hash, reverse hash and
  * graph.getCount.  direction 0 = successors (char_out = first base), 1 = predecessors

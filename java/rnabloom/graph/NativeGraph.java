@@ -62,6 +62,10 @@ public final class NativeGraph {
     public static native void filterLookupThenAdd(long h, int which, long[] baseHashes, int n, byte[] out);
     public static native void filterGetCount(long h, long[] baseHashes, int n, float[] out);
     public static native void filterIncrementAndGet(long h, long[] baseHashes, int n, float[] out);
+    /** Counts of getKmers for reads [first, first + n) of a resident batch (one float per window, no hashes): packed rows at koffsets[i]
+     *  (koffsets[n + 1], koffsets[0] = 0), or — koffsets == null — rows of the returned stride (longest read - k + 1), zero-padded.
+     *  Call with n = 0 to learn the stride before allocating `out`. */
+    public static native long batchCounts(long h, long batch, long first, long n, long[] koffsets, float[] out);
     /** getKmers of nReads sequences: koffsets[nReads + 1] is filled; pass f == null to size the outputs first. */
     public static native void getKmers(long h, ByteBuffer seq, long[] offsets, int nReads, long[] koffsets, long[] f, long[] r, float[] count);
     public static native void neighbors(long h, long[] f, long[] r, byte[] charOut, int n, int direction, long[] f4, long[] r4, float[] count4);

@@ -231,6 +231,16 @@ void FN(getKmers)(JNIEnv *e, jclass c, jlong h, jobject seq, jlongArray offsets,
     lr(e, offsets, off, JNI_ABORT); lr(e, koffsets, ko, 0); lr(e, f, pf, 0); lr(e, r, pr, 0); fr(e, count, pc, 0);
     if (rc) throw_rc(e, rc);
 }
+jlong FN(batchCounts)(JNIEnv *e, jclass c, jlong h, jlong batch, jlong first, jlong n, jlongArray koffsets, jfloatArray out) {
+    jlong *ko = la(e, koffsets);
+    jfloat *po = fa(e, out);
+    int64_t stride = 0;
+    (void)c;
+    int rc = rb_graph_batch_counts(G(h), B(batch), first, n, (const int64_t *)ko, po, 0, &stride);
+    lr(e, koffsets, ko, JNI_ABORT); fr(e, out, po, 0);
+    if (rc) throw_rc(e, rc);
+    return (jlong)stride;
+}
 void FN(neighbors)(JNIEnv *e, jclass c, jlong h, jlongArray f, jlongArray r, jbyteArray ch, jint n, jint direction, jlongArray f4, jlongArray r4, jfloatArray c4) {
     jlong *pf = la(e, f), *pr = la(e, r), *of = la(e, f4), *orr = la(e, r4);
     jbyte *pc = ba(e, ch);

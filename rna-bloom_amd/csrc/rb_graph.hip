@@ -1118,6 +1118,79 @@ __global__ void k_get_kmers(FilterView fv, int stranded, const uint64_t *__restr
     }
 }
 
+// getKmers' counts for reads that already sit in HBM (a resident rb_batch): count[row(r) + p] = graph.getCount of window p of read r,
+// 0 where the window holds an unusable base (R/bloom/hash/CanonicalHashFunction.java:46-78) — what stage 2 reads first of every
+// read (R/RNABloom.java:1984, 2097-2114).  One thread per 32-window word as in k_get_kmers; the hashes are rolled, nothing but the
+// counts is written.  Written for memory-level parallelism: a lane collects four usable windows, computes all their filter
+// indices, issues the 8 Bloom-bit loads, then the 8 counter loads, and only then combines them (graph_count per window would be
+// four dependent round trips each).  koff == nullptr: rows of `stride` counts (uniform reads).
+__global__ void __launch_bounds__(256) k_batch_counts(FilterView fv, int stranded, const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
+                                                      const uint32_t *__restrict__ word_read, const uint32_t *__restrict__ woff,
+                                                      const uint32_t *__restrict__ len, int64_t w_first, int64_t n_words, uint32_t r_first, int k,
+                                                      const int64_t *__restrict__ koff, int64_t stride, float *__restrict__ out_c) {
+    const int64_t w = w_first + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= w_first + n_words) return;
+    const uint32_t r = word_read[w], wr = woff[r], L = len[r];
+    const uint32_t b0 = (uint32_t)(w - wr) * 32u, uk = (uint32_t)k;
+    if ((uint64_t)b0 + uk > L) return;
+    const uint64_t bend64 = (uint64_t)b0 + 32u + uk - 1u;
+    const uint32_t bend = bend64 < L ? (uint32_t)bend64 : L;
+    const uint64_t *cw = codes + wr;
+    const uint32_t *vw = valid + wr;
+    const int64_t row = koff ? koff[r - r_first] : (int64_t)(r - r_first) * stride;
+    const bool h2 = fv.dbg_h == 2 && fv.cbf_h == 2;
+    uint64_t f = 0, rv = 0, pend_h[4];
+    uint32_t filled = 0, run = 0, pend_p[4], n_pend = 0;
+    auto flush = [&]() {
+        uint64_t bi[4][2], ci[4][2];
+        uint32_t bw[4][2], cb[4][2];
+#pragma unroll
+        for (uint32_t q = 0; q < 4u; ++q) {
+            const uint64_t h0 = q < n_pend ? pend_h[q] : pend_h[0], h1 = multi_hash(h0, 1u, fv.kmul);
+            bi[q][0] = index_of(h0, fv.dbg_mod); bi[q][1] = index_of(h1, fv.dbg_mod);
+            ci[q][0] = index_of(h0, fv.cbf_mod); ci[q][1] = index_of(h1, fv.cbf_mod);
+        }
+#pragma unroll
+        for (uint32_t q = 0; q < 4u; ++q) { bw[q][0] = fv.dbg[bi[q][0] >> 5]; bw[q][1] = fv.dbg[bi[q][1] >> 5]; }
+#pragma unroll
+        for (uint32_t q = 0; q < 4u; ++q) { cb[q][0] = fv.cbf[ci[q][0]]; cb[q][1] = fv.cbf[ci[q][1]]; }
+#pragma unroll
+        for (uint32_t q = 0; q < 4u; ++q) {
+            if (q >= n_pend) break;
+            const bool in = ((bw[q][0] >> (uint32_t)(bi[q][0] & 31u)) & (bw[q][1] >> (uint32_t)(bi[q][1] & 31u)) & 1u) != 0u;
+            const uint32_t mn = cb[q][0] < cb[q][1] ? cb[q][0] : cb[q][1];
+            out_c[row + pend_p[q]] = in ? minifloat_to_float(mn) + 1.0f : 0.0f;
+        }
+        n_pend = 0;
+    };
+    for (uint32_t b = b0; b < bend; ++b) {
+        const bool ok = (vw[b >> 5] >> (b & 31u)) & 1u;
+        const uint32_t ic = (uint32_t)(cw[b >> 5] >> (2u * (b & 31u))) & 3u;
+        const uint64_t s_in = ok ? seed_of(ic) : 0ull, sc_in = ok ? seed_of(3u - ic) : 0ull;
+        run = ok ? run + 1u : 0u;
+        if (filled < uk) { f = rotl(f, 1) ^ s_in; rv ^= rotl(sc_in, filled); ++filled; }
+        else {
+            const uint32_t bo = b - uk;
+            const bool oko = (vw[bo >> 5] >> (bo & 31u)) & 1u;
+            const uint32_t oc = (uint32_t)(cw[bo >> 5] >> (2u * (bo & 31u))) & 3u;
+            const uint64_t s_out = oko ? seed_of(oc) : 0ull, sc_out = oko ? seed_of(3u - oc) : 0ull;
+            f = rotl(f, 1) ^ rotl(s_out, uk) ^ s_in;
+            rv = rotr(rv, 1) ^ rotr(sc_out, 1) ^ rotl(sc_in, uk - 1u);
+        }
+        if (filled >= uk) {
+            const uint32_t p = b - uk + 1u;
+            const uint64_t base = stranded ? f : canonical(f, rv);
+            if (run < uk) out_c[row + p] = 0.0f;
+            else if (!h2) out_c[row + p] = graph_count(fv, base);
+            else {
+                pend_h[n_pend] = base; pend_p[n_pend] = p;
+                if (++n_pend == 4u) flush();
+            }
+        }
+    }
+    if (n_pend) flush();
+}
+
 // Kmer.getSuccessors / getPredecessors: the four neighbours' hashes and counts
 // (R/bloom/hash/{,Canonical}{Successors,Predecessors}NTHashIterator.java; R/graph/Kmer.java:210-255)
 __device__ __forceinline__ uint32_t code_of_char(uint32_t ch) {
@@ -2620,6 +2693,22 @@ int rb_graph_apply(rb_graph *g, int op, const uint64_t *h0, size_t n) {
     });
 }
 
+}  // extern "C"
+// Best-effort pinning of a caller's host buffer for the duration of a query call: pageable pages go over the link at
+// ~10-15 GB/s through the runtime's staging buffers, registered ones at ~57 GB/s (hipHostRegister itself: ~8 ms per GB).
+// Buffers that cannot be registered (foreign mappings, already registered) are copied the slow way.
+struct HostPin {
+    void *p = nullptr;
+    HostPin(const void *ptr, size_t bytes) {
+        if (ptr && bytes > ((size_t)16 << 20) && !getenv("RB_NO_PIN") &&
+            hipHostRegister(const_cast<void *>(ptr), bytes, hipHostRegisterDefault) == hipSuccess) p = const_cast<void *>(ptr);
+        else (void)hipGetLastError();
+    }
+    ~HostPin() { if (p) (void)hipHostUnregister(p); }
+    HostPin(const HostPin &) = delete;
+    HostPin &operator=(const HostPin &) = delete;
+};
+extern "C" {
 int rb_filter_lookup(rb_graph *g, int which, const uint64_t *h0, size_t n, uint8_t *out) {
     return guarded([&] {
         RB_REQUIRE(g && (n == 0 || (h0 && out)), "rb_filter_lookup: null argument");
@@ -2628,6 +2717,7 @@ int rb_filter_lookup(rb_graph *g, int which, const uint64_t *h0, size_t n, uint8
         RB_REQUIRE(!g->shard, "rb_filter_lookup: queries are not available on a shard handle");
         if (!f->bits) { set_error("rb_filter_lookup: filter %d not initialised", which); throw HipError{RB_ERR_STATE}; }
         if (!n) return;
+        HostPin pin_in(h0, n * 8), pin_out(out, n);
         QueryLease q(g);
         if (!f->bits) { set_error("rb_filter_lookup: filter %d not initialised", which); throw HipError{RB_ERR_STATE}; }
         uint64_t *d = upload_h0(g, q.c->b0, h0, n, q.c->st);
@@ -2674,6 +2764,7 @@ static int count_common(rb_graph *g, const uint64_t *h0, size_t n, float *out, b
         RB_REQUIRE(g && (n == 0 || (h0 && out)), "rb_graph_count: null argument");
         RB_REQUIRE(!g->shard, "rb_graph_count: queries are not available on a shard handle");
         if (!n) return;
+        HostPin pin_in(h0, n * 8), pin_out(out, n * 4);
         QueryLease q(g);
         uint64_t *d = upload_h0(g, q.c->b0, h0, n, q.c->st);
         q.c->b1.reserve(n * 4);
@@ -2710,6 +2801,9 @@ int rb_graph_kmers(rb_graph *g, const char *seq, const int64_t *offsets, int64_t
         }
         const int64_t total = koffsets[n_reads];
         if (!f || !count || total == 0) return;
+        RB_HIP(hipSetDevice(g->p.device));
+        HostPin pin_seq(seq + offsets[0], (size_t)(offsets[n_reads] - offsets[0])), pin_f(f, (size_t)total * 8), pin_r(r, (size_t)total * 8),
+                pin_c(count, (size_t)total * 4);
         rb_batch *b = nullptr;
         int rc = rb_batch_create_ascii(g->p.device, seq, nullptr, offsets, n_reads, 0, &b);
         if (rc != RB_OK) throw HipError{rc};
@@ -2734,6 +2828,61 @@ int rb_graph_kmers(rb_graph *g, const char *seq, const int64_t *offsets, int64_t
         if (r) RB_HIP(hipMemcpyAsync(r, q.c->b2.p, (size_t)total * 8, hipMemcpyDeviceToHost, s));
         RB_HIP(hipMemcpyAsync(count, q.c->b3.p, (size_t)total * 4, hipMemcpyDeviceToHost, s));
         RB_HIP(hipStreamSynchronize(s));
+    });
+}
+
+int rb_graph_batch_counts(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, const int64_t *koffsets, float *out, int out_on_device,
+                          int64_t *stride_out) {
+    return guarded([&] {
+        RB_REQUIRE(g && b && (n == 0 || out), "rb_graph_batch_counts: null argument");
+        RB_REQUIRE(first >= 0 && n >= 0 && first + n <= b->n_reads, "rb_graph_batch_counts: read range outside the batch");
+        RB_REQUIRE(!g->shard, "rb_graph_batch_counts: queries are not available on a shard handle");
+        RB_REQUIRE(b->device == g->p.device, "rb_graph_batch_counts: batch and graph live on different devices");
+        const int64_t stride = b->max_len >= (uint32_t)g->k ? (int64_t)b->max_len - g->k + 1 : 0;
+        if (stride_out) *stride_out = stride;
+        const int64_t total = koffsets ? (n ? koffsets[n] - koffsets[0] : 0) : n * stride;
+        if (n == 0 || total == 0) return;
+        RB_REQUIRE(!koffsets || koffsets[0] == 0, "rb_graph_batch_counts: koffsets[0] must be 0");
+        RB_REQUIRE(g->cbf, "rb_graph_batch_counts: the counting filter has been destroyed");
+        RB_HIP(hipSetDevice(g->p.device));
+        HostPin pin_out(out_on_device ? nullptr : out, (size_t)total * 4);
+        QueryLease q(g);
+        hipStream_t s = q.c->st;
+        const int64_t *dko = nullptr;
+        if (koffsets) {
+            q.c->b0.reserve(((size_t)n + 1) * 8);
+            RB_HIP(hipMemcpyAsync(q.c->b0.p, koffsets, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, s));
+            dko = q.c->b0.as<int64_t>();
+        }
+        float *dc = out;
+        if (!out_on_device) { q.c->b3.reserve((size_t)total * 4); dc = q.c->b3.as<float>(); }
+        // rows are padded where a read is shorter than the longest one (stride mode), and reads shorter than k have no thread at all
+        if (!koffsets) RB_HIP(hipMemsetAsync(dc, 0, (size_t)total * 4, s));
+        // to the host in pieces: the copy of piece c runs on its own stream beside the kernel of piece c + 1
+        const int64_t pieces = out_on_device ? 1 : std::max<int64_t>(1, std::min<int64_t>({(int64_t)16, total / ((int64_t)32 << 20), n}));
+        hipStream_t s2 = nullptr;
+        std::vector<hipEvent_t> ev;
+        struct Cleanup { hipStream_t &s2; std::vector<hipEvent_t> &ev; ~Cleanup() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); if (s2) (void)hipStreamDestroy(s2); } } cleanup{s2, ev};
+        if (!out_on_device) RB_HIP(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+        for (int64_t c = 0; c < pieces; ++c) {
+            const int64_t ra = n * c / pieces, rb_ = n * (c + 1) / pieces;
+            const int64_t w0 = b->h_woff[(size_t)(first + ra)], nw = (int64_t)b->h_woff[(size_t)(first + rb_)] - w0;
+            if (nw > 0)
+                hipLaunchKernelGGL(k_batch_counts, dim3(blocks_for(nw, 256)), dim3(256), 0, s, g->view(0, 0), (int)g->stranded, b->codes, b->valid,
+                                   b->word_read, b->woff, b->len, w0, nw, (uint32_t)first, g->k, dko, stride, dc);
+            RB_HIP(hipGetLastError());
+            if (out_on_device) continue;
+            const int64_t oa = koffsets ? koffsets[ra] : ra * stride, ob = koffsets ? koffsets[rb_] : rb_ * stride;
+            if (ob == oa) continue;
+            hipEvent_t e;
+            RB_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            ev.push_back(e);
+            RB_HIP(hipEventRecord(e, s));
+            RB_HIP(hipStreamWaitEvent(s2, e, 0));
+            RB_HIP(hipMemcpyAsync(out + oa, dc + oa, (size_t)(ob - oa) * 4, hipMemcpyDeviceToHost, s2));
+        }
+        RB_HIP(hipStreamSynchronize(s));
+        if (s2) RB_HIP(hipStreamSynchronize(s2));
     });
 }
 

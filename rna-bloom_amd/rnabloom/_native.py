@@ -76,6 +76,7 @@ SYMBOLS = [
     ("rb_filter_lookup_then_add", _i32, [_vp, _i32, _vp, _sz, _vp]),
     ("rb_filter_get_count", _i32, [_vp, _vp, _sz, _vp]),
     ("rb_graph_kmers", _i32, [_vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp]),
+    ("rb_graph_batch_counts", _i32, [_vp, _vp, _i64, _i64, _vp, _vp, _i32, _vp]),
     ("rb_graph_neighbors", _i32, [_vp, _vp, _vp, _vp, _sz, _i32, _vp, _vp, _vp]),
     ("rb_graph_walk", _i32, [_vp, _vp, _vp, _sz, _i32, _i32, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp]),
     ("rb_graph_greedy_extend", _i32, [_vp, _vp, _vp, _sz, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),

@@ -274,18 +274,40 @@ class BloomFilterDeBruijnGraph:
         check(lib.rb_filter_get_count(self.h, _ptr(a), a.size, _ptr(out)))
         return out
 
-    def getKmers(self, reads):
-        """getKmers(String) for a list of sequences -> (koffsets, f, r, count)."""
+    def getKmers(self, reads, out=None):
+        """getKmers(String) for a list of sequences -> (koffsets, f, r, count); out = (f, r, count) arrays to fill (large enough)."""
         lens = np.fromiter((len(r) for r in reads), np.int64, len(reads))
         off = np.zeros(len(reads) + 1, np.int64); np.cumsum(lens, out=off[1:])
         seq = np.frombuffer(b"".join(reads), np.uint8) if len(reads) else np.zeros(0, np.uint8)
         ko = np.zeros(len(reads) + 1, np.int64)
         check(lib.rb_graph_kmers(self.h, _ptr(seq), _ptr(off), len(reads), _ptr(ko), None, None, None))
         t = int(ko[-1])
-        f = np.zeros(t, np.uint64); r = np.zeros(t, np.uint64); c = np.zeros(t, np.float32)
+        if out is None:
+            f = np.zeros(t, np.uint64); r = np.zeros(t, np.uint64); c = np.zeros(t, np.float32)
+        else:
+            f, r, c = (a[:t] for a in out)
         if t:
             check(lib.rb_graph_kmers(self.h, _ptr(seq), _ptr(off), len(reads), _ptr(ko), _ptr(f), _ptr(r), _ptr(c)))
         return ko, f, r, c
+
+    def batchCounts(self, batch, first=0, n=None, koffsets=None, to_host=True, out=None):
+        """The count profile of getKmers for reads [first, first + n) of a resident ReadBatch (rb_graph_batch_counts): one float per
+        window, no hashes.  koffsets None: an [n, stride] array (stride = longest read - k + 1, shorter reads zero-padded) flattened;
+        else packed rows at koffsets[i].  to_host False: the counts stay on the device (a torch tensor is returned)."""
+        n = batch.n_reads - first if n is None else n
+        stride = C.c_int64(0)
+        ko = None if koffsets is None else np.ascontiguousarray(koffsets, np.int64)
+        check(lib.rb_graph_batch_counts(self.h, batch.h, first, 0, None, None, 0, C.byref(stride)))
+        total = int(ko[-1]) if ko is not None else n * stride.value
+        if to_host:
+            out = np.empty(total, np.float32) if out is None else out
+            assert out.dtype == np.float32 and out.size >= total and out.flags.c_contiguous
+            check(lib.rb_graph_batch_counts(self.h, batch.h, first, n, _ptr(ko) if ko is not None else None, _ptr(out), 0, None))
+            return out[:total]
+        import torch
+        out = torch.empty(total, dtype=torch.float32, device="cuda:%d" % self.device) if out is None else out
+        check(lib.rb_graph_batch_counts(self.h, batch.h, first, n, _ptr(ko) if ko is not None else None, C.c_void_p(out.data_ptr()), 1, None))
+        return out
 
     def getNeighbors(self, f, r, charOut, direction):
         """4 successors (direction 0) / predecessors (1) of each k-mer: (f4, r4, count4) shaped [n,4]."""
