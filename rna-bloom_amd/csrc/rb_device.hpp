@@ -156,7 +156,7 @@ __device__ __forceinline__ uint32_t npf_lookup(const Npf &c, uint64_t h0) {     
 }
 // s in 1..14.  8-byte stores are never torn; two threads racing for one slot lose one entry at worst,
 // and a k-mer that ends up in two slots is harmless (lookup takes the larger exponent, both are true).
-__device__ __forceinline__ void npf_store(const Npf &c, uint64_t h0, uint32_t s) {
+__device__ __forceinline__ bool npf_store(const Npf &c, uint64_t h0, uint32_t s) {      // true: the table changed
     const uint32_t B = c.log2n - 3u;
     unsigned long long *b = c.tab + ((h0 & ((1ull << B) - 1ull)) << 3);
     const uint64_t tag = h0 >> B;
@@ -167,13 +167,15 @@ __device__ __forceinline__ void npf_store(const Npf &c, uint64_t h0, uint32_t s)
         const uint32_t q = (i + rot) & 7u;
         const unsigned long long e = __hip_atomic_load(&b[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if ((e >> 4) == tag && e != 0ull) {                   // already here: raise, never lower
-            if ((uint32_t)(e & 15ull) < s) __hip_atomic_store(&b[q], (tag << 4) | (unsigned long long)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return;
+            if ((uint32_t)(e & 15ull) >= s) return false;
+            __hip_atomic_store(&b[q], (tag << 4) | (unsigned long long)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return true;
         }
         const uint32_t es = (uint32_t)(e & 15ull);            // empty slots read 0: preferred victims
         if (es < vmin) { vmin = es; victim = q; }
     }
     __hip_atomic_store(&b[victim], (tag << 4) | (unsigned long long)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
 }
 // ---- minimizer-bucketed prefilter cache: same contract as Npf, different address ----
 // The device serves ~54 G random 64-byte lines/s; one line request per window is what
@@ -248,16 +250,16 @@ __host__ __device__ __forceinline__ unsigned long long mpf_tag_b(uint64_t h0) { 
 // smaller exponent if ours is larger (the coldest k-mer costs the least when it misses).
 constexpr uint32_t RB_MPF_TOP_EXP = 11u;
 __host__ __device__ __forceinline__ uint32_t mpf_rank(uint32_t code) { return code ? code : 8u; }
-__device__ __forceinline__ void mpf_store(const Mpf &c, uint64_t bucket, uint64_t h0, uint32_t s) {
+__device__ __forceinline__ bool mpf_store(const Mpf &c, uint64_t bucket, uint64_t h0, uint32_t s) {
     unsigned long long *b = c.tab + (bucket << 4);
     const uint32_t sa = mpf_slot_a(h0), sb = mpf_slot_b(h0), sv = s >= RB_MPF_TOP_EXP ? 0u : (s > 7u ? 7u : s), rv = mpf_rank(sv);
     const unsigned long long na = (mpf_tag_a(h0) << 3) | sv, nb = (mpf_tag_b(h0) << 3) | sv;
     const unsigned long long ea = __hip_atomic_load(&b[sa], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long eb = __hip_atomic_load(&b[sb], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (ea && (ea >> 3) == mpf_tag_a(h0)) { if (mpf_rank((uint32_t)(ea & 7ull)) < rv) __hip_atomic_store(&b[sa], na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
-    if (eb && (eb >> 3) == mpf_tag_b(h0)) { if (mpf_rank((uint32_t)(eb & 7ull)) < rv) __hip_atomic_store(&b[sb], nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
-    if (!ea) { __hip_atomic_store(&b[sa], na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
-    if (!eb) { __hip_atomic_store(&b[sb], nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return; }
+    if (ea && (ea >> 3) == mpf_tag_a(h0)) { if (mpf_rank((uint32_t)(ea & 7ull)) < rv) { __hip_atomic_store(&b[sa], na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return true; } return false; }
+    if (eb && (eb >> 3) == mpf_tag_b(h0)) { if (mpf_rank((uint32_t)(eb & 7ull)) < rv) { __hip_atomic_store(&b[sb], nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return true; } return false; }
+    if (!ea) { __hip_atomic_store(&b[sa], na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return true; }
+    if (!eb) { __hip_atomic_store(&b[sb], nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return true; }
     {   // both taken: one cuckoo step — move an occupant to ITS other candidate slot if that one is free
         // (an entry plus its slot give the occupant's whole hash; every store writes a word that is valid for
         // the slot it goes to, so racing stores can lose an entry but never forge one)
@@ -266,14 +268,14 @@ __device__ __forceinline__ void mpf_store(const Mpf &c, uint64_t bucket, uint64_
         if (!__hip_atomic_load(&b[ha_b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
             __hip_atomic_store(&b[ha_b], (mpf_tag_b(ha) << 3) | (ea & 7ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&b[sa], na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return;
+            return true;
         }
         const uint64_t hb = (((eb >> 6) << 3 | (uint64_t)(sb >> 1)) << 3) | ((eb >> 3) & 7ull);    // occupant of my B slot
         const uint32_t hb_a = mpf_slot_a(hb);
         if (!__hip_atomic_load(&b[hb_a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
             __hip_atomic_store(&b[hb_a], (mpf_tag_a(hb) << 3) | (eb & 7ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&b[sb], nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return;
+            return true;
         }
     }
     {   // ... and a second step: the occupant's other slot is taken too, but ITS occupant can move on (the k-mers of one minimizer
@@ -289,7 +291,7 @@ __device__ __forceinline__ void mpf_store(const Mpf &c, uint64_t bucket, uint64_
                 __hip_atomic_store(&b[hc_a], (mpf_tag_a(hc) << 3) | (ec & 7ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&b[ha_b], (mpf_tag_b(ha) << 3) | (ea & 7ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&b[sa], na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return;
+                return true;
             }
         }
         const uint64_t hb = (((eb >> 6) << 3 | (uint64_t)(sb >> 1)) << 3) | ((eb >> 3) & 7ull);
@@ -302,12 +304,13 @@ __device__ __forceinline__ void mpf_store(const Mpf &c, uint64_t bucket, uint64_
                 __hip_atomic_store(&b[hd_b], (mpf_tag_b(hd) << 3) | (ed & 7ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&b[hb_a], (mpf_tag_a(hb) << 3) | (eb & 7ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&b[sb], nb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                return;
+                return true;
             }
         }
     }
     const bool pick_b = mpf_rank((uint32_t)(eb & 7ull)) < mpf_rank((uint32_t)(ea & 7ull));
-    if (mpf_rank((uint32_t)((pick_b ? eb : ea) & 7ull)) < rv) __hip_atomic_store(&b[pick_b ? sb : sa], pick_b ? nb : na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (mpf_rank((uint32_t)((pick_b ? eb : ea) & 7ull)) < rv) { __hip_atomic_store(&b[pick_b ? sb : sa], pick_b ? nb : na, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); return true; }
+    return false;      // nothing stored: the k-mer stays uncached (its bucket is full of k-mers that are at least as hot)
 }
 // lookup in a bucket image held by the caller (16 words strided by `stride`)
 __device__ __forceinline__ uint32_t mpf_match(const unsigned long long *bkt, uint32_t stride, uint64_t h0) {

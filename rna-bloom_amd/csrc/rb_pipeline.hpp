@@ -45,15 +45,19 @@ struct FilterView {
     uint32_t seq_first;          // read index of occurrence value 0's read
     int k;
 };
-// remember a k-mer's counter exponent in whichever cache the insert path uses; occ = any occurrence of it
-__device__ __forceinline__ void cache_store(const FilterView &fv, uint64_t h0, uint32_t occ, uint32_t s) {
+// remember a k-mer's counter exponent in whichever cache the insert path uses; occ = any occurrence of it.
+// Returns whether the cache changed (the sharded engine broadcasts only the stores that did: the replicas are alike, so a store
+// that changes nothing on the owner's replica changes nothing anywhere — e.g. the k-mer whose bucket is full of hotter ones tries
+// again every sub-batch).
+__device__ __forceinline__ bool cache_store(const FilterView &fv, uint64_t h0, uint32_t occ, uint32_t s) {
     if (fv.mpf.tab) {
-        if (!fv.seq_codes) return;
+        if (!fv.seq_codes) return false;
         const uint32_t r = fv.seq_first + (occ >> fv.pos_bits), p = occ & ((1u << fv.pos_bits) - 1u);
         const uint32_t ord = window_min_order(fv.seq_codes + fv.seq_woff[r], p, (uint32_t)fv.k, fv.mpf.m);
-        mpf_store(fv.mpf, mpf_bucket(fv.mpf, ord), h0, s);
+        return mpf_store(fv.mpf, mpf_bucket(fv.mpf, ord), h0, s);
     } else if (fv.npf.tab)
-        npf_store(fv.npf, h0, s);
+        return npf_store(fv.npf, h0, s);
+    return false;
 }
 __device__ __forceinline__ bool cache_on(const FilterView &fv) { return fv.mpf.tab ? fv.seq_codes != nullptr : fv.npf.tab != nullptr; }
 
@@ -276,7 +280,7 @@ static __global__ void __launch_bounds__(64) k_cbf_heavy(FilterView fv, const ui
             if (cache_on(fv) && (st & ST_ALLPRE)) {   // remember how hard this k-mer has become to increment
                 uint32_t mn = c[0];
                 for (int j = 1; j < fv.cbf_h; ++j) mn = c[j] < mn ? c[j] : mn;
-                if (mn >= 16u) { cache_store(fv, h0, vals[starts[d]], cache_exp(mn)); if (cache_upd) cache_upd[d] = (uint8_t)cache_exp(mn); }
+                if (mn >= 16u) { if (cache_store(fv, h0, vals[starts[d]], cache_exp(mn)) && cache_upd) cache_upd[d] = (uint8_t)cache_exp(mn); }
             }
         }
     }

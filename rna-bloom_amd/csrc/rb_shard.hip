@@ -279,7 +279,7 @@ __global__ void k_resolve_shard(FilterView fv, const uint32_t *__restrict__ coun
         if (cache_on(fv) && mode != M_COUNT_ONLY) {
             uint32_t mn = c[0];
             for (int j = 1; j < fv.cbf_h; ++j) mn = c[j] < mn ? c[j] : mn;
-            if (mn >= 16u) { cache_store(fv, uniq[d], vals[starts[d]], cache_exp(mn)); if (cache_upd) cache_upd[d] = (uint8_t)cache_exp(mn); }
+            if (mn >= 16u) { if (cache_store(fv, uniq[d], vals[starts[d]], cache_exp(mn)) && cache_upd) cache_upd[d] = (uint8_t)cache_exp(mn); }
         }
         return;
     }
@@ -296,7 +296,7 @@ __global__ void k_resolve_shard(FilterView fv, const uint32_t *__restrict__ coun
         for (int j = 1; j < fv.cbf_h; ++j) mn = c[j] < mn ? c[j] : mn;
         // (not when the cache evidently has it: same exponent and every op succeeded — see k_resolve_apply)
         const bool cached = mn0 >= 16u && (mn >> 3) == (mn0 >> 3) && mn - mn0 == ops && !(mn >= 127u && mn0 < 127u);   // (reaching 127 is news: the k-mer is saturated)
-        if (mn >= 16u && !cached) { cache_store(fv, uniq[d], vals[starts[d]], cache_exp(mn)); if (cache_upd) cache_upd[d] = (uint8_t)cache_exp(mn); }
+        if (mn >= 16u && !cached) { if (cache_store(fv, uniq[d], vals[starts[d]], cache_exp(mn)) && cache_upd) cache_upd[d] = (uint8_t)cache_exp(mn); }
     }
 }
 // cache updates of this sub-batch, compacted for the broadcast

@@ -1,0 +1,55 @@
+"""bench.py's one-line contract on a small workload: the single-GPU line (with roofline and cpu_baseline objects) and the line
+of a 2-rank run launched the way the driver launches it (torch.distributed.run; the two ranks share the test box's GPU, so the
+exchange goes over gloo — RCCL refuses two ranks on one device)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--pairs", "300000", "--genome", "500000", "--nk", "3000000", "--steps", "1", "--warmup", "1"]
+
+
+def last_json(out):
+    lines = [l for l in out.strip().splitlines() if l.startswith("{")]
+    assert lines, out[-2000:]
+    return json.loads(lines[-1])
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_single_gpu_line_and_two_rank_line():
+    env = dict(os.environ)
+    r = subprocess.run([sys.executable, "bench.py", "--cpu-sample-pairs", "40000"] + SMALL, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    j = last_json(r.stdout)
+    assert r.stdout.strip().splitlines()[-1].startswith("{"), "the JSON line must be the last line"
+    for key, typ in (("metric", str), ("value", float), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int), ("ms_per_step", float),
+                     ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict), ("roofline", dict), ("cpu_baseline", dict)):
+        assert isinstance(j[key], typ), key
+    assert j["n_gpus"] == 1 and j["steps"] == 1 and j["warmup"] == 1 and j["higher_is_better"] is True and j["vs_baseline"] is None
+    assert j["unit"] == "k-mers/s" and j["value"] > 0 and "workload" in j["config"] and "model" not in j["config"]
+    roof = j["roofline"]
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and roof["peak"] == 8000.0 and roof["achieved"] > 0
+    assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3 and "traffic" in roof
+    cpu = j["cpu_baseline"]
+    assert cpu["kind"] == "port" and cpu["value"] > 0 and cpu["unit"] == "k-mers/s" and cpu["cores"] >= 1 and cpu["sample"]
+    # two ranks, launched like the driver does it
+    env["RB_BENCH_BACKEND"] = "gloo"
+    r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                         "--master-port", str(free_port()), "bench.py", "--gpus", "2", "--no-cpu-baseline"] + SMALL,
+                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r2.returncode == 0, r2.stderr[-3000:]
+    j2 = last_json(r2.stdout)
+    assert j2["n_gpus"] == 2 and j2["scaling"] == "strong" and j2["value"] > 0
+    assert j2["config"]["kmers_per_step"] == j["config"]["kmers_per_step"], "both engines insert the same k-mers"
+    assert "cpu_baseline" not in j2
