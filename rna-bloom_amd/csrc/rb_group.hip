@@ -854,9 +854,9 @@ static void group_records_impl(const GroupPlan &P, uint64_t *keys0, uint32_t *va
     // arbitrary order), so a bucket takes its slots with one atomicAdd when its run count is known.  RB_GROUP_ORDERED=1 keeps
     // the runs in bucket order through a chained scan over the buckets (a quarter of the kernel's time: a bucket's look-back
     // walks the ~500 buckets in flight before it).
-    static const bool ordered = getenv("RB_GROUP_ORDERED") && atoi(getenv("RB_GROUP_ORDERED")) != 0;
+    const bool ordered = getenv("RB_GROUP_ORDERED") && atoi(getenv("RB_GROUP_ORDERED")) != 0;
     if (!ordered) RB_HIP(hipMemsetAsync(n_runs_dev, 0, 4, st));
-    static const bool prefetch = !(getenv("RB_GROUP_PREFETCH") && atoi(getenv("RB_GROUP_PREFETCH")) == 0);
+    const bool prefetch = !(getenv("RB_GROUP_PREFETCH") && atoi(getenv("RB_GROUP_PREFETCH")) == 0);
     if (ordered || !prefetch)
         hipLaunchKernelGGL((k_group_buckets<TPB, false>), dim3(bucket_grid), dim3(TPB), 0, st, kin, vin, bstart, P.nbuckets, P.lshift_lo, P.l_lo, P.lshift_hi, P.l_hi,
                            rng, P.fix_cap, ticket, ordered ? status : nullptr, big_list, n_big, vals_out, tz_out, uniq, counts, starts, n_runs_dev);
