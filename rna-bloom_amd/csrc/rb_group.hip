@@ -98,6 +98,38 @@ __device__ __forceinline__ void gr_wave_rank_lds(const uint32_t (&dig)[ITEMS], u
     }
 }
 
+// Digits of 9 or 10 bits with a 256-word mask table: the LDS mask gives the lanes that agree in the low 8 bits, one ballot per
+// remaining bit narrows them down to the lanes with the same digit (a 1024-word table per wavefront would be 64 KB of LDS).
+// The highest lane of the LOW-bits group clears the word; the highest lane of the digit's group keeps the counter.
+template <int ITEMS, typename CT>
+__device__ __forceinline__ void gr_wave_rank_lds_wide(const uint32_t (&dig)[ITEMS], uint32_t (&rank)[ITEMS], CT *wc, unsigned long long *wm, uint32_t bits,
+                                                      uint32_t rows) {
+    const uint32_t lane = threadIdx.x & 63u;
+#pragma unroll
+    for (int r = 0; r < ITEMS; ++r) {
+        if ((uint32_t)r < rows) {
+            const bool valid = dig[r] != ~0u;
+            uint64_t ml = 0;
+            uint32_t prior = 0;
+            if (valid) {
+                __hip_atomic_fetch_or(&wm[dig[r] & 255u], 1ull << lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                ml = __hip_atomic_load(&wm[dig[r] & 255u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                prior = (uint32_t)wc[dig[r]];
+            }
+            uint64_t m = ml;
+            for (uint32_t b = 8; b < bits; ++b) {
+                const bool bit = valid && ((dig[r] >> b) & 1u);
+                const uint64_t bal = __ballot(bit);
+                m &= bit ? bal : ~bal;
+            }
+            rank[r] = prior + gr_lanes_below(m);
+            if (valid && (ml >> lane) == 1ull) __hip_atomic_store(&wm[dig[r] & 255u], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (valid && (m >> lane) == 1ull) wc[dig[r]] = (CT)(prior + (uint32_t)__popcll(m));
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+}
+
 // exclusive scan of one value per thread over the block
 template <int TPB>
 __device__ __forceinline__ uint32_t gr_block_excl_scan(uint32_t v, uint32_t *s_wsum) {
@@ -204,24 +236,27 @@ __global__ void __launch_bounds__(TPB) k_part_count(const uint64_t *__restrict__
 template <int TPB, int MAXBITS>
 __global__ void __launch_bounds__(TPB) k_part_scatter(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, GrTiling tl,
                                                       uint32_t shift, uint32_t bits, const uint32_t *__restrict__ goffs /* exclusive scan of hist */,
-                                                      uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out) {
+                                                      uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t wide_lds) {
     constexpr uint32_t ITEMS = GR_TILE / TPB, NW = TPB / 64, SEG = 64 * ITEMS, MAXNB = 1u << MAXBITS;
     __shared__ uint64_t s_keys[GR_TILE];
     __shared__ uint32_t s_vals[GR_TILE];
     __shared__ uint32_t s_cnt[NW * MAXNB / 2 > MAXNB ? NW * MAXNB / 2 : MAXNB];   // u16 per (wavefront, digit); later: u32 global bases per digit
     __shared__ uint16_t s_dstart[MAXNB];
     __shared__ uint32_t s_wsum[NW];
-    // digits of up to 8 bits: match masks from LDS (gr_wave_rank_lds: the pass is bound by instruction issue, not by HBM);
-    // wider digits would need 64 KB of masks and keep the ballots
-    constexpr bool LDS_RANK = MAXBITS <= 8;
-    __shared__ unsigned long long s_wmask[LDS_RANK ? NW * MAXNB : 1];
+    // match masks from LDS (gr_wave_rank_lds: the pass is bound by instruction issue, not by HBM): a table of 2^bits words per
+    // wavefront for digits of up to 8 bits; wider digits use 256 words per wavefront plus a ballot per extra bit.  The table
+    // lives in s_vals — free until the ranked records are staged there, a barrier later — which keeps the 8-bit kernel at
+    // 53 KB of LDS: three workgroups per CU instead of two.
+    constexpr bool NARROW = MAXBITS <= 8;
+    static_assert(sizeof(s_vals) >= NW * 256u * sizeof(unsigned long long), "the mask table must fit the staging array");
+    unsigned long long *s_wmask = reinterpret_cast<unsigned long long *>(s_vals);
     uint16_t *s_wcnt = reinterpret_cast<uint16_t *>(s_cnt);
     GrTile t;
     if (!gr_get_tile(tl, t)) return;
     const uint32_t nb = 1u << bits;
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     for (uint32_t d = threadIdx.x; d < NW * nb; d += TPB) s_wcnt[d] = 0;
-    if (LDS_RANK) for (uint32_t d = threadIdx.x; d < NW * nb; d += TPB) s_wmask[d] = 0ull;
+    for (uint32_t d = threadIdx.x; d < NW * (NARROW ? nb : 256u); d += TPB) s_wmask[d] = 0ull;
     // rows of this wavefront: records w*SEG + r*64 + lane of the tile
     uint64_t k[ITEMS];
     uint32_t v[ITEMS], dig[ITEMS], rank[ITEMS];
@@ -235,7 +270,8 @@ __global__ void __launch_bounds__(TPB) k_part_scatter(const uint64_t *__restrict
     }
     const uint32_t rows = t.count > w * SEG ? min(ITEMS, (t.count - w * SEG + 63u) / 64u) : 0u;
     __syncthreads();
-    if (LDS_RANK) gr_wave_rank_lds<ITEMS>(dig, rank, s_wcnt + w * nb, s_wmask + w * nb, rows);
+    if (NARROW) gr_wave_rank_lds<ITEMS>(dig, rank, s_wcnt + w * nb, s_wmask + w * nb, rows);
+    else if (wide_lds) gr_wave_rank_lds_wide<ITEMS>(dig, rank, s_wcnt + w * nb, s_wmask + w * 256u, bits, rows);
     else gr_wave_rank<ITEMS>(dig, rank, s_wcnt + w * nb, bits, rows);
     __syncthreads();
     gr_digit_offsets<TPB>(s_wcnt, s_dstart, nb, s_wsum);
@@ -809,8 +845,9 @@ static void part_pass(const GrTiling &tl, size_t entries, uint32_t shift, uint32
     if (prof) { prof->prof_end("group_part_count", st); prof->prof_begin(st); }
     exclusive_scan_u32(scan_tmp, scan_bytes, hist, goffs, entries, st);
     if (prof) { prof->prof_end("group_scan", st); prof->prof_begin(st); }
-    if (bits <= 8u) hipLaunchKernelGGL((k_part_scatter<TPB, 8>), grid, blk, 0, st, kin, vin, tl, shift, bits, goffs, kout, vout);
-    else hipLaunchKernelGGL((k_part_scatter<TPB, GR_PART_MAX_BITS>), grid, blk, 0, st, kin, vin, tl, shift, bits, goffs, kout, vout);
+    const uint32_t wide = !(getenv("RB_GROUP_WIDE_LDS") && atoi(getenv("RB_GROUP_WIDE_LDS")) == 0);
+    if (bits <= 8u) hipLaunchKernelGGL((k_part_scatter<TPB, 8>), grid, blk, 0, st, kin, vin, tl, shift, bits, goffs, kout, vout, wide);
+    else hipLaunchKernelGGL((k_part_scatter<TPB, GR_PART_MAX_BITS>), grid, blk, 0, st, kin, vin, tl, shift, bits, goffs, kout, vout, wide);
     if (prof) prof->prof_end("group_part_scatter", st);
 }
 
