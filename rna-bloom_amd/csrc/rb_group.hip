@@ -325,6 +325,11 @@ __global__ void k_bucket_bounds(const uint32_t *__restrict__ goffs, uint32_t nti
 }
 
 // ---- bucket kernel: LDS sort on 2 x 8 bits, strengths, runs --------------------------------------------
+// GR_ABL (compile-time, tools/microbench/group_bench.hip only): parts of the bucket kernel compiled out to price them —
+// 1 look-back (ordered mode), 2 repair, 4 second counting pass, 8 output stores, 16 both counting passes.  Results are wrong then.
+#ifndef GR_ABL
+#define GR_ABL 0
+#endif
 struct GroupRng { uint64_t seed, ordinal0; uint32_t pos_bits; };
 constexpr unsigned long long GR_ST_AGG = 1ull << 62, GR_ST_PREFIX = 2ull << 62;
 
@@ -498,9 +503,6 @@ __global__ void __launch_bounds__(TPB) k_group_buckets(const uint64_t *__restric
             __syncthreads();
         }
     };
-#ifndef GR_ABL
-#define GR_ABL 0
-#endif
     if (!(GR_ABL & 16)) sort_pass(shift_lo, bits_lo, s_wcnt[0]);
     if (!(GR_ABL & 20)) sort_pass(shift_hi, bits_hi, s_wcnt[1]);
     if (!in_lds) {      // no local digit at all: keep the order
