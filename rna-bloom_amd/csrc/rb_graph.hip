@@ -1127,7 +1127,7 @@ __global__ void k_get_kmers(FilterView fv, int stranded, const uint64_t *__restr
 __global__ void __launch_bounds__(256) k_batch_counts(FilterView fv, int stranded, const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
                                                       const uint32_t *__restrict__ word_read, const uint32_t *__restrict__ woff,
                                                       const uint32_t *__restrict__ len, int64_t w_first, int64_t n_words, uint32_t r_first, int k,
-                                                      const int64_t *__restrict__ koff, int64_t stride, float *__restrict__ out_c) {
+                                                      const int64_t *__restrict__ koff, int64_t stride, int64_t row_base, float *__restrict__ out_c) {
     const int64_t w = w_first + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= w_first + n_words) return;
     const uint32_t r = word_read[w], wr = woff[r], L = len[r];
@@ -1137,7 +1137,7 @@ __global__ void __launch_bounds__(256) k_batch_counts(FilterView fv, int strande
     const uint32_t bend = bend64 < L ? (uint32_t)bend64 : L;
     const uint64_t *cw = codes + wr;
     const uint32_t *vw = valid + wr;
-    const int64_t row = koff ? koff[r - r_first] : (int64_t)(r - r_first) * stride;
+    const int64_t row = (koff ? koff[r - r_first] : (int64_t)(r - r_first) * stride) - row_base;
     const bool h2 = fv.dbg_h == 2 && fv.cbf_h == 2;
     uint64_t f = 0, rv = 0, pend_h[4];
     uint32_t filled = 0, run = 0, pend_p[4], n_pend = 0;
@@ -2854,35 +2854,58 @@ int rb_graph_batch_counts(rb_graph *g, const rb_batch *b, int64_t first, int64_t
             RB_HIP(hipMemcpyAsync(q.c->b0.p, koffsets, ((size_t)n + 1) * 8, hipMemcpyHostToDevice, s));
             dko = q.c->b0.as<int64_t>();
         }
-        float *dc = out;
-        if (!out_on_device) { q.c->b3.reserve((size_t)total * 4); dc = q.c->b3.as<float>(); }
-        // rows are padded where a read is shorter than the longest one (stride mode), and reads shorter than k have no thread at all
-        if (!koffsets) RB_HIP(hipMemsetAsync(dc, 0, (size_t)total * 4, s));
-        // to the host in pieces: the copy of piece c runs on its own stream beside the kernel of piece c + 1
-        const int64_t pieces = out_on_device ? 1 : std::max<int64_t>(1, std::min<int64_t>({(int64_t)16, total / ((int64_t)32 << 20), n}));
-        hipStream_t s2 = nullptr;
-        std::vector<hipEvent_t> ev;
-        struct Cleanup { hipStream_t &s2; std::vector<hipEvent_t> &ev; ~Cleanup() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); if (s2) (void)hipStreamDestroy(s2); } } cleanup{s2, ev};
-        if (!out_on_device) RB_HIP(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
-        for (int64_t c = 0; c < pieces; ++c) {
-            const int64_t ra = n * c / pieces, rb_ = n * (c + 1) / pieces;
+        auto launch = [&](int64_t ra, int64_t rb_, int64_t row_base, float *dst) {      // reads [first + ra, first + rb_): rows at dst + row - row_base
             const int64_t w0 = b->h_woff[(size_t)(first + ra)], nw = (int64_t)b->h_woff[(size_t)(first + rb_)] - w0;
             if (nw > 0)
                 hipLaunchKernelGGL(k_batch_counts, dim3(blocks_for(nw, 256)), dim3(256), 0, s, g->view(0, 0), (int)g->stranded, b->codes, b->valid,
-                                   b->word_read, b->woff, b->len, w0, nw, (uint32_t)first, g->k, dko, stride, dc);
+                                   b->word_read, b->woff, b->len, w0, nw, (uint32_t)first, g->k, dko, stride, row_base, dst);
             RB_HIP(hipGetLastError());
-            if (out_on_device) continue;
-            const int64_t oa = koffsets ? koffsets[ra] : ra * stride, ob = koffsets ? koffsets[rb_] : rb_ * stride;
-            if (ob == oa) continue;
-            hipEvent_t e;
-            RB_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-            ev.push_back(e);
+        };
+        // (stride mode: rows are padded where a read is shorter than the longest one, and reads shorter than k have no thread at all)
+        if (out_on_device) {
+            if (!koffsets) RB_HIP(hipMemsetAsync(out, 0, (size_t)total * 4, s));
+            launch(0, n, 0, out);
+            RB_HIP(hipStreamSynchronize(s));
+            return;
+        }
+        // To the host in pieces of <= 64 M counts through two device buffers: the copy of piece c runs on its own stream beside
+        // the kernel of piece c + 1, and the scratch stays at 512 MB however many reads are asked for.
+        const int64_t piece_max = getenv("RB_QUERY_PIECE") ? std::max<int64_t>(1, atoll(getenv("RB_QUERY_PIECE"))) : (int64_t)64 << 20;
+        std::vector<int64_t> cut{0};                              // read boundaries of the pieces (at least one read each)
+        auto row_of = [&](int64_t i) { return koffsets ? koffsets[i] : i * stride; };
+        int64_t largest = 0;
+        while (cut.back() < n) {
+            int64_t a = cut.back(), lo = a + 1, hi = n;
+            while (lo < hi) { const int64_t mid = (lo + hi + 1) >> 1; if (row_of(mid) - row_of(a) <= piece_max) lo = mid; else hi = mid - 1; }
+            cut.push_back(lo);
+            largest = std::max(largest, row_of(lo) - row_of(a));
+        }
+        q.c->b3.reserve((size_t)largest * 4 * 2);
+        float *buf[2] = {q.c->b3.as<float>(), q.c->b3.as<float>() + largest};
+        hipStream_t s2 = nullptr;
+        std::vector<hipEvent_t> ev;
+        struct Cleanup { hipStream_t &s2; std::vector<hipEvent_t> &ev; ~Cleanup() { for (hipEvent_t e : ev) (void)hipEventDestroy(e); if (s2) (void)hipStreamDestroy(s2); } } cleanup{s2, ev};
+        RB_HIP(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+        std::vector<hipEvent_t> copied;                           // per piece: its copy to the host is done (its buffer is free again)
+        for (size_t c = 0; c + 1 < cut.size(); ++c) {
+            const int64_t ra = cut[c], rb_ = cut[c + 1], oa = row_of(ra), ob = row_of(rb_);
+            float *dst = buf[c & 1];
+            if (c >= 2) RB_HIP(hipStreamWaitEvent(s, copied[c - 2], 0));
+            if (ob > oa) {
+                if (!koffsets) RB_HIP(hipMemsetAsync(dst, 0, (size_t)(ob - oa) * 4, s));
+                launch(ra, rb_, oa, dst);
+            }
+            hipEvent_t e, e2;
+            RB_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); ev.push_back(e);
+            RB_HIP(hipEventCreateWithFlags(&e2, hipEventDisableTiming)); ev.push_back(e2);
             RB_HIP(hipEventRecord(e, s));
             RB_HIP(hipStreamWaitEvent(s2, e, 0));
-            RB_HIP(hipMemcpyAsync(out + oa, dc + oa, (size_t)(ob - oa) * 4, hipMemcpyDeviceToHost, s2));
+            if (ob > oa) RB_HIP(hipMemcpyAsync(out + oa, dst, (size_t)(ob - oa) * 4, hipMemcpyDeviceToHost, s2));
+            RB_HIP(hipEventRecord(e2, s2));
+            copied.push_back(e2);
         }
         RB_HIP(hipStreamSynchronize(s));
-        if (s2) RB_HIP(hipStreamSynchronize(s2));
+        RB_HIP(hipStreamSynchronize(s2));
     });
 }
 

@@ -21,8 +21,10 @@ def expected_rows(og, reads, k):
 
 
 @pytest.mark.parametrize("stranded", [False, True])
-@pytest.mark.parametrize("hashes", [2, 3])
-def test_batch_counts_match_oracle_and_get_kmers(stranded, hashes):
+@pytest.mark.parametrize("hashes,piece", [(2, None), (3, None), (2, "1000"), (2, "1")])
+def test_batch_counts_match_oracle_and_get_kmers(monkeypatch, stranded, hashes, piece):
+    if piece:                                   # the host copy in many small pieces through the two device buffers
+        monkeypatch.setenv("RB_QUERY_PIECE", piece)
     (ls, lq, off), _ = make_reads(1500, 12000, 0.002, 1e-3, seed=33)
     og, gg = graph_pair(300_007, 2_000_003, 10_007, stranded=stranded, pairs=False, dbg_h=hashes, cbf_h=hashes)
     og.add_reads(ls, lq, off, 3, 0); gg.addReads(ls, lq, off, 3)

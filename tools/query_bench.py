@@ -49,7 +49,11 @@ if hasattr(g, "batchCounts"):
         g.batchCounts(batch, 0, nq, out=cc)
         dt = time.perf_counter() - t0
         print("  into an array that exists already: %.3f s = %.2f G k-mers/s" % (dt, cc.size / dt / 1e9))
+        import torch
+        dev = torch.empty(cc.size, dtype=torch.float32, device="cuda:0")
+        torch.cuda.synchronize()
         t0 = time.perf_counter()
-        g.batchCounts(batch, 0, nq, to_host=False)
+        g.batchCounts(batch, 0, nq, to_host=False, out=dev)
         dt = time.perf_counter() - t0
-        print("batchCounts (counts left on the device): %.3f s = %.2f G k-mers/s" % (dt, cc.size / dt / 1e9))
+        print("batchCounts (counts left on the device, in a tensor that exists already): %.3f s = %.2f G k-mers/s" % (dt, cc.size / dt / 1e9))
+        del dev
