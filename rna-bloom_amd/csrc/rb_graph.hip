@@ -2694,20 +2694,7 @@ int rb_graph_apply(rb_graph *g, int op, const uint64_t *h0, size_t n) {
 }
 
 }  // extern "C"
-// Best-effort pinning of a caller's host buffer for the duration of a query call: pageable pages go over the link at
-// ~10-15 GB/s through the runtime's staging buffers, registered ones at ~57 GB/s (hipHostRegister itself: ~8 ms per GB).
-// Buffers that cannot be registered (foreign mappings, already registered) are copied the slow way.
-struct HostPin {
-    void *p = nullptr;
-    HostPin(const void *ptr, size_t bytes) {
-        if (ptr && bytes > ((size_t)16 << 20) && !getenv("RB_NO_PIN") &&
-            hipHostRegister(const_cast<void *>(ptr), bytes, hipHostRegisterDefault) == hipSuccess) p = const_cast<void *>(ptr);
-        else (void)hipGetLastError();
-    }
-    ~HostPin() { if (p) (void)hipHostUnregister(p); }
-    HostPin(const HostPin &) = delete;
-    HostPin &operator=(const HostPin &) = delete;
-};
+using rb::HostPin;
 extern "C" {
 int rb_filter_lookup(rb_graph *g, int which, const uint64_t *h0, size_t n, uint8_t *out) {
     return guarded([&] {

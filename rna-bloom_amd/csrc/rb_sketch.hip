@@ -326,6 +326,7 @@ int rb_minimizers(int device, const char *seq, const int64_t *offsets, int64_t n
         }
         const int64_t total = moffsets[n_reads];
         if (!out_hash || !total) return;
+        rb::HostPin pin_h(out_hash, (size_t)total * 8), pin_p(out_pos, (size_t)total * 8);      // results are most of the call's time (PCIe)
         hash_all(device, seq, offsets, n_reads, k, mode, koff, d_koff, d_h);
         d_moff.reserve(((size_t)n_reads + 1) * 8); d_oh.reserve((size_t)total * 8); d_op.reserve((size_t)total * 8);
         RB_HIP(hipMemcpy(d_moff.p, moffsets, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice));
@@ -353,6 +354,7 @@ int rb_strobemers(int device, const char *seq, const int64_t *offsets, int64_t n
         }
         const int64_t total = soffsets[n_reads];
         if (!out_hash || !total) return;
+        rb::HostPin pin_h(out_hash, (size_t)total * 8), pin_s(out_start, (size_t)total * 4), pin_e(out_end, (size_t)total * 4);
         hash_all(device, seq, offsets, n_reads, k, 0, koff, d_koff, d_h);
         d_soff.reserve(((size_t)n_reads + 1) * 8); d_oh.reserve((size_t)total * 8); d_os.reserve((size_t)total * 4); d_oe.reserve((size_t)total * 4);
         RB_HIP(hipMemcpy(d_soff.p, soffsets, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice));

@@ -623,25 +623,29 @@ def _pack(reads):
     return seq, off
 
 
-def minimizers(reads, k, w, mode=1, device=0):
-    """MinimizerHashIterator over each read: (offsets[n+1], hash, pos)."""
-    seq, off = _pack(reads)
+def minimizers(reads, k, w, mode=1, device=0, out=None):
+    """MinimizerHashIterator over each read: (offsets[n+1], hash, pos).  reads: list of bytes, or (seq, offsets) arrays;
+    out = (hash, pos) arrays to fill."""
+    seq, off = reads if isinstance(reads, tuple) else _pack(reads)
+    reads = range(off.size - 1)
     mo = np.zeros(len(reads) + 1, np.int64)
     check(lib.rb_minimizers(device, _ptr(seq), _ptr(off), len(reads), k, w, mode, _ptr(mo), None, None))
     t = int(mo[-1])
-    h = np.zeros(t, np.uint64); p = np.zeros(t, np.int64)
+    h, p = (np.zeros(t, np.uint64), np.zeros(t, np.int64)) if out is None else (out[0][:t], out[1][:t])
     if t:
         check(lib.rb_minimizers(device, _ptr(seq), _ptr(off), len(reads), k, w, mode, _ptr(mo), _ptr(h), _ptr(p)))
     return mo, h, p
 
 
-def strobemers(reads, k, n, wmin, wmax, device=0):
-    """StrobeHashIterator.getInterval over each read: (offsets[n+1], hash, start, end)."""
-    seq, off = _pack(reads)
+def strobemers(reads, k, n, wmin, wmax, device=0, out=None):
+    """StrobeHashIterator.getInterval over each read: (offsets[n+1], hash, start, end).  reads: list of bytes, or (seq, offsets)
+    arrays; out = (hash, start, end) arrays to fill."""
+    seq, off = reads if isinstance(reads, tuple) else _pack(reads)
+    reads = range(off.size - 1)
     so = np.zeros(len(reads) + 1, np.int64)
     check(lib.rb_strobemers(device, _ptr(seq), _ptr(off), len(reads), k, n, wmin, wmax, _ptr(so), None, None, None))
     t = int(so[-1])
-    h = np.zeros(t, np.uint64); s = np.zeros(t, np.int32); e = np.zeros(t, np.int32)
+    h, s, e = (np.zeros(t, np.uint64), np.zeros(t, np.int32), np.zeros(t, np.int32)) if out is None else (out[0][:t], out[1][:t], out[2][:t])
     if t:
         check(lib.rb_strobemers(device, _ptr(seq), _ptr(off), len(reads), k, n, wmin, wmax, _ptr(so), _ptr(h), _ptr(s), _ptr(e)))
     return so, h, s, e
