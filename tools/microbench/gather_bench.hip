@@ -69,8 +69,34 @@ static int calib() {
     printf("issued %llu requests per kernel (k_calib<8>, <64>, <128>)\n", (unsigned long long)blocks * tpb * iters);
     return 0;
 }
+// `gather_bench big`: one 8 GB table (the size of config 2's counting filter), random 8-byte reads and random byte-granular atomicOr:
+// run it several times — each process gets its own placement of the table — to see how much of the run-to-run spread of the
+// insert pipeline's probe / resolve stages is the placement
+__global__ void k_scatter_or(uint32_t *__restrict__ tab, uint64_t mask, int iters, uint32_t *out) {
+    uint64_t s = mix((uint64_t)blockIdx.x * blockDim.x + threadIdx.x + 5), acc = 0;
+    for (int it = 0; it < iters; ++it) {
+        s = mix(s);
+        acc += atomicOr(&tab[s & mask], 0x80u);
+    }
+    if (acc == 0x1234567ull) out[0] = (uint32_t)acc;
+}
+static int big() {
+    uint64_t *out, *tab; const uint64_t n = 1ull << 30;            // 8 GB
+    CK(hipMalloc(&out, 64)); CK(hipMalloc(&tab, n * 8)); CK(hipMemset(tab, 1, n * 8));
+    const int blocks = 256 * 32, tpb = 256;
+    const double rd = run<4, 0>(tab, n, out, blocks, tpb, 64);
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    hipLaunchKernelGGL(k_scatter_or, dim3(blocks), dim3(tpb), 0, 0, (uint32_t *)tab, 2 * n - 1, 2, (uint32_t *)out);
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k_scatter_or, dim3(blocks), dim3(tpb), 0, 0, (uint32_t *)tab, 2 * n - 1, 128, (uint32_t *)out);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    printf("8 GB table: random 8-byte reads %.1f G/s, random returning atomicOr %.1f G/s\n", rd, (double)blocks * tpb * 128 / (ms * 1e-3) / 1e9);
+    return 0;
+}
 int main(int argc, char **argv) {
     if (argc > 1 && !strcmp(argv[1], "calib")) return calib();
+    if (argc > 1 && !strcmp(argv[1], "big")) return big();
     uint64_t *out; CK(hipMalloc(&out, 64));
     const int blocks = 256 * 32, tpb = 256;
     printf("%-10s %-6s %8s %8s %8s %8s\n", "table", "what", "K=1", "K=2", "K=4", "K=8");
