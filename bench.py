@@ -302,7 +302,7 @@ def main():
                        "conflict_ops_per_step": conflict // a.steps,
                        "mean_kmer_coverage": round(kmers_all / a.steps / max(1, a.genome), 1),
                        "prefilter_survival": round(n_sorted / max(1, kmers), 4),
-                       "note": "throughput depends on the coverage: the no-op prefilter drops occurrences that provably cannot change a counter (here all but the survival fraction); at low coverage or k > 64 the same engine sorts every occurrence (DESIGN.md s5)",
+                       "note": "throughput depends on the coverage: the no-op prefilter drops occurrences that provably cannot change a counter (here all but the survival fraction); at low coverage or k > 64 the same engine sorts every occurrence; substituted bases carry quality '#' and are masked (SURVEY s8(d)) - with every error passing the threshold (RB_SYNTH_KEEP_ERRORS=1) the step takes 1.3x as long (DESIGN.md s5)",
                        "parallelism": ("single GPU" if not sharded_mode else "filters index-sharded x%d, k-mers hash-sharded (%s mode), %s all_to_all"
                                        % (world, sr.mode, ("RCCL send/recv below the C ABI" if native else "RCCL") if backend == "nccl" else backend))},
             "stages_ms_per_step": {n: round(v[0] / a.steps, 2) for n, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},

@@ -102,7 +102,7 @@ __global__ void k_synth_reads(const uint64_t *__restrict__ genome, const int64_t
                               const int32_t *__restrict__ tlen, const float *__restrict__ cdf,
                               int n_tx, int64_t n_pairs, int L, int words_per_read, float frag_mean,
                               float frag_sd, float sub_rate, float n_rate, uint64_t seed, int64_t pair_offset,
-                              int64_t total_pairs, uint64_t *__restrict__ codes, uint32_t *__restrict__ valid,
+                              int64_t total_pairs, int keep_errors, uint64_t *__restrict__ codes, uint32_t *__restrict__ valid,
                               uint32_t *__restrict__ word_read) {
     int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     int64_t n_words = 2 * n_pairs * words_per_read;
@@ -141,7 +141,7 @@ __global__ void k_synth_reads(const uint64_t *__restrict__ genome, const int64_t
         float ue = (float)(e >> 40) * (1.0f / 16777216.0f);
         float un = (float)((e >> 16) & 0xFFFFFFu) * (1.0f / 16777216.0f);
         bool ok = true;
-        if (ue < sub_rate) { code = (code + 1u + (uint32_t)(e & 0xFFFFu) % 3u) & 3u; ok = false; }
+        if (ue < sub_rate) { code = (code + 1u + (uint32_t)(e & 0xFFFFu) % 3u) & 3u; ok = keep_errors != 0; }   // quality '#' (masked) unless asked otherwise
         if (un < n_rate) ok = false;
         cw |= (uint64_t)code << (2 * i);
         if (ok) vw |= 1u << i;
@@ -1324,7 +1324,11 @@ int rb_batch_create_synthetic(int device, const rb_synth_params *p, rb_batch **o
             hipLaunchKernelGGL(k_synth_reads, dim3(blocks_for(b->n_words)), dim3(TPB), 0, 0, d_genome, d_ts, d_tl,
                                d_cdf, (int)tlen.size(), p->n_pairs, (int)p->read_len, wpr, (float)p->frag_mean,
                                (float)p->frag_sd, p->sub_rate, p->n_rate, p->seed, p->pair_offset,
-                               p->total_pairs > 0 ? p->total_pairs : p->n_pairs, b->codes, b->valid, b->word_read);
+                               p->total_pairs > 0 ? p->total_pairs : p->n_pairs,
+                               // substituted bases carry quality '#' and are masked like any base below -q 3.  RB_SYNTH_KEEP_ERRORS=1
+                               // (measurement knob): they pass the threshold, so every error adds up to k k-mers that are seen once
+                               (getenv("RB_SYNTH_KEEP_ERRORS") && atoi(getenv("RB_SYNTH_KEEP_ERRORS")) != 0) ? 1 : 0,
+                               b->codes, b->valid, b->word_read);
             chk(hipGetLastError());
             chk(hipDeviceSynchronize());
         }

@@ -80,8 +80,29 @@ __global__ void k_scatter_or(uint32_t *__restrict__ tab, uint64_t mask, int iter
     }
     if (acc == 0x1234567ull) out[0] = (uint32_t)acc;
 }
-static int big() {
-    uint64_t *out, *tab; const uint64_t n = 1ull << 30;            // 8 GB
+// the same addresses first read, then OR-ed by a second kernel (what k_probe_h2 + k_set_bits do to the Bloom bits), and the
+// OR without a use of the old value
+template <int MODE /* 0 read, 1 returning atomicOr, 2 atomicOr whose result is not used */>
+__global__ void k_touch(uint32_t *__restrict__ tab, uint64_t mask, int iters, uint32_t *out) {
+    uint64_t s = mix((uint64_t)blockIdx.x * blockDim.x + threadIdx.x + 5), acc = 0;
+    for (int it = 0; it < iters; ++it) {
+        s = mix(s);
+        if (MODE == 0) acc += tab[s & mask];
+        else if (MODE == 1) acc += atomicOr(&tab[s & mask], 0x80u);
+        else atomicOr(&tab[s & mask], 0x40u);
+    }
+    if (acc == 0x1234567ull) out[0] = (uint32_t)acc;
+}
+template <int MODE> static double touch(uint32_t *tab, uint64_t words, uint32_t *out, int blocks, int tpb, int iters) {
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL(k_touch<MODE>, dim3(blocks), dim3(tpb), 0, 0, tab, words - 1, iters, out);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    return (double)blocks * tpb * iters / (ms * 1e-3) / 1e9;
+}
+static int big(int log2_gb) {
+    uint64_t *out, *tab; const uint64_t n = 1ull << (27 + log2_gb);            // 8 GB by default
     CK(hipMalloc(&out, 64)); CK(hipMalloc(&tab, n * 8)); CK(hipMemset(tab, 1, n * 8));
     const int blocks = 256 * 32, tpb = 256;
     const double rd = run<4, 0>(tab, n, out, blocks, tpb, 64);
@@ -91,12 +112,22 @@ static int big() {
     hipLaunchKernelGGL(k_scatter_or, dim3(blocks), dim3(tpb), 0, 0, (uint32_t *)tab, 2 * n - 1, 128, (uint32_t *)out);
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-    printf("8 GB table: random 8-byte reads %.1f G/s, random returning atomicOr %.1f G/s\n", rd, (double)blocks * tpb * 128 / (ms * 1e-3) / 1e9);
+    {
+        const uint64_t words = 2 * n;
+        const int b2 = 1 << 16, it2 = 4;                                   // 64 M touches per kernel, as one sub-batch
+        touch<0>((uint32_t *)tab, words, (uint32_t *)out, b2, tpb, it2);
+        const double r0 = touch<0>((uint32_t *)tab, words, (uint32_t *)out, 1 << 14, tpb, 64);
+        const double r1 = touch<1>((uint32_t *)tab, words, (uint32_t *)out, b2, tpb, it2);     // other addresses than the read before? no: same seeds -> same addresses as the first touch<0>
+        const double r2 = touch<2>((uint32_t *)tab, words, (uint32_t *)out, 1 << 14, tpb, 64);
+        const double r3 = touch<1>((uint32_t *)tab, words, (uint32_t *)out, 1 << 14, tpb, 64);
+        printf("  4-byte words: reads %.1f G/s; returning atomicOr on 64 M addresses read two kernels earlier %.1f G/s; atomicOr, result unused %.1f G/s; returning %.1f G/s\n", r0, r1, r2, r3);
+    }
+    printf("%d GB table: random 8-byte reads %.1f G/s, random returning atomicOr %.1f G/s\n", 1 << log2_gb, rd, (double)blocks * tpb * 128 / (ms * 1e-3) / 1e9);
     return 0;
 }
 int main(int argc, char **argv) {
     if (argc > 1 && !strcmp(argv[1], "calib")) return calib();
-    if (argc > 1 && !strcmp(argv[1], "big")) return big();
+    if (argc > 1 && !strcmp(argv[1], "big")) return big(argc > 2 ? atoi(argv[2]) : 3);
     uint64_t *out; CK(hipMalloc(&out, 64));
     const int blocks = 256 * 32, tpb = 256;
     printf("%-10s %-6s %8s %8s %8s %8s\n", "table", "what", "K=1", "K=2", "K=4", "K=8");
