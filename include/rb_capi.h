@@ -175,8 +175,8 @@ int rb_filter_get_count(rb_graph *g, const uint64_t *h0, size_t n, float *out);
 /* getKmers(String) :1224-1226 -> {Canonical,}HashFunction.getKmers: for every window of every
  * read of the batch: forward hash, reverse hash (0 when stranded), count (0 for windows that
  * contain a non-ACGTU base).  koffsets[n_reads+1] receives the per-read output offsets
- * (read i has max(0,len_i-k+1) windows); pass f=r=count=NULL to query sizes only.  Device scratch: 20 bytes per k-mer of the
- * call (call it per ~10^6 reads; rb_graph_batch_counts below streams through a bounded scratch).  * On a shard handle (rb_graph_create_shard) only the hashes are local: count = 1 for a usable window, 0 otherwise; the counts of a
+ * (read i has max(0,len_i-k+1) windows); pass f=r=count=NULL to query sizes only.  The call works in pieces of 16 M k-mers
+ * (320 MB of device scratch whatever the number of reads).  * On a shard handle (rb_graph_create_shard) only the hashes are local: count = 1 for a usable window, 0 otherwise; the counts of a
  * distributed graph come from one rb_shard_query_* exchange (rnabloom/sharded.py::ShardRank.getKmers). */
 int rb_graph_kmers(rb_graph *g, const char *seq, const int64_t *offsets, int64_t n_reads,
                    int64_t *koffsets, uint64_t *f, uint64_t *r, float *count);

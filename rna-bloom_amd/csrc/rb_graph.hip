@@ -2791,30 +2791,46 @@ int rb_graph_kmers(rb_graph *g, const char *seq, const int64_t *offsets, int64_t
         RB_HIP(hipSetDevice(g->p.device));
         HostPin pin_seq(seq + offsets[0], (size_t)(offsets[n_reads] - offsets[0])), pin_f(f, (size_t)total * 8), pin_r(r, (size_t)total * 8),
                 pin_c(count, (size_t)total * 4);
-        rb_batch *b = nullptr;
-        int rc = rb_batch_create_ascii(g->p.device, seq, nullptr, offsets, n_reads, 0, &b);
-        if (rc != RB_OK) throw HipError{rc};
-        struct G { rb_batch *b; ~G() { rb_batch_destroy(b); } } guard{b};
         QueryLease q(g);
         hipStream_t s = q.c->st;
-        q.c->b0.reserve(((size_t)n_reads + 1) * 8); q.c->b1.reserve((size_t)total * 8);
-        q.c->b2.reserve((size_t)total * 8); q.c->b3.reserve((size_t)total * 4);
-        RB_HIP(hipMemcpyAsync(q.c->b0.p, koffsets, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, s));
-        // on a shard of a distributed graph only the hashes are local (count = 1 for a usable window): the caller gets the
-        // counts with one rb_shard_query_* exchange (rnabloom/sharded.py::ShardRank.getKmers)
-        if (g->shard)
-            hipLaunchKernelGGL(k_get_kmers<true>, dim3(blocks_for(b->n_words)), dim3(TPB), 0, s, g->view(0, 0), (int)g->stranded,
-                               b->codes, b->valid, b->word_read, b->woff, b->len, b->n_words, g->k, q.c->b0.as<int64_t>(),
-                               q.c->b1.as<uint64_t>(), q.c->b2.as<uint64_t>(), q.c->b3.as<float>());
-        else
-            hipLaunchKernelGGL(k_get_kmers<false>, dim3(blocks_for(b->n_words)), dim3(TPB), 0, s, g->view(0, 0), (int)g->stranded,
-                               b->codes, b->valid, b->word_read, b->woff, b->len, b->n_words, g->k, q.c->b0.as<int64_t>(),
-                               q.c->b1.as<uint64_t>(), q.c->b2.as<uint64_t>(), q.c->b3.as<float>());
-        RB_HIP(hipGetLastError());
-        RB_HIP(hipMemcpyAsync(f, q.c->b1.p, (size_t)total * 8, hipMemcpyDeviceToHost, s));
-        if (r) RB_HIP(hipMemcpyAsync(r, q.c->b2.p, (size_t)total * 8, hipMemcpyDeviceToHost, s));
-        RB_HIP(hipMemcpyAsync(count, q.c->b3.p, (size_t)total * 4, hipMemcpyDeviceToHost, s));
-        RB_HIP(hipStreamSynchronize(s));
+        // in pieces of <= 16 M k-mers (20 bytes of device scratch each): the scratch stays at 320 MB however many reads are asked for
+        const int64_t piece_max = getenv("RB_QUERY_PIECE") ? std::max<int64_t>(1, atoll(getenv("RB_QUERY_PIECE"))) : (int64_t)16 << 20;
+        std::vector<int64_t> rel;
+        for (int64_t ra = 0; ra < n_reads;) {
+            int64_t lo = ra + 1, hi = n_reads;
+            while (lo < hi) { const int64_t mid = (lo + hi + 1) >> 1; if (koffsets[mid] - koffsets[ra] <= piece_max) lo = mid; else hi = mid - 1; }
+            const int64_t rb_ = lo, pn = rb_ - ra, pt = koffsets[rb_] - koffsets[ra];
+            if (pt > 0) {
+                rb::AsciiUpload up;
+                rb_batch *b = nullptr;
+                try {
+                    rb::ascii_batch_begin(up, g->p.device, seq, nullptr, offsets, ra, pn, 0, s);
+                    b = rb::ascii_batch_finish(up);
+                } catch (...) { rb::ascii_batch_abort(up); throw; }
+                struct G { rb_batch *b; ~G() { rb_batch_destroy(b); } } guard{b};
+                rel.resize((size_t)pn + 1);
+                for (int64_t i = 0; i <= pn; ++i) rel[(size_t)i] = koffsets[ra + i] - koffsets[ra];
+                q.c->b0.reserve(((size_t)pn + 1) * 8); q.c->b1.reserve((size_t)pt * 8); q.c->b2.reserve((size_t)pt * 8); q.c->b3.reserve((size_t)pt * 4);
+                RB_HIP(hipMemcpyAsync(q.c->b0.p, rel.data(), ((size_t)pn + 1) * 8, hipMemcpyHostToDevice, s));
+                // on a shard of a distributed graph only the hashes are local (count = 1 for a usable window): the caller gets the
+                // counts with one rb_shard_query_* exchange (rnabloom/sharded.py::ShardRank.getKmers)
+                if (g->shard)
+                    hipLaunchKernelGGL(k_get_kmers<true>, dim3(blocks_for(b->n_words)), dim3(TPB), 0, s, g->view(0, 0), (int)g->stranded,
+                                       b->codes, b->valid, b->word_read, b->woff, b->len, b->n_words, g->k, q.c->b0.as<int64_t>(),
+                                       q.c->b1.as<uint64_t>(), q.c->b2.as<uint64_t>(), q.c->b3.as<float>());
+                else
+                    hipLaunchKernelGGL(k_get_kmers<false>, dim3(blocks_for(b->n_words)), dim3(TPB), 0, s, g->view(0, 0), (int)g->stranded,
+                                       b->codes, b->valid, b->word_read, b->woff, b->len, b->n_words, g->k, q.c->b0.as<int64_t>(),
+                                       q.c->b1.as<uint64_t>(), q.c->b2.as<uint64_t>(), q.c->b3.as<float>());
+                RB_HIP(hipGetLastError());
+                const int64_t o = koffsets[ra];
+                RB_HIP(hipMemcpyAsync(f + o, q.c->b1.p, (size_t)pt * 8, hipMemcpyDeviceToHost, s));
+                if (r) RB_HIP(hipMemcpyAsync(r + o, q.c->b2.p, (size_t)pt * 8, hipMemcpyDeviceToHost, s));
+                RB_HIP(hipMemcpyAsync(count + o, q.c->b3.p, (size_t)pt * 4, hipMemcpyDeviceToHost, s));
+                RB_HIP(hipStreamSynchronize(s));                  // (rel and the piece's batch are released next)
+            }
+            ra = rb_;
+        }
     });
 }
 
