@@ -101,6 +101,26 @@ template <int MODE> static double touch(uint32_t *tab, uint64_t words, uint32_t 
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     return (double)blocks * tpb * iters / (ms * 1e-3) / 1e9;
 }
+// n touches at SORTED random places (touch i lies in the i-th of n equal slices of the table, so consecutive lanes go to
+// increasing addresses a few lines apart) against the same number at unsorted places: what ordering the runs of a sub-batch by
+// counter index would buy the claims
+template <int MODE /* 0 read, 1 returning atomicOr */, int SORTED>
+__global__ void k_touch_n(uint32_t *__restrict__ tab, uint64_t words, uint64_t n, uint32_t *out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t slice = words / n, r = mix(i + 99);
+    const uint64_t idx = SORTED ? i * slice + r % slice : r % words;
+    const uint32_t v = MODE == 0 ? tab[idx] : atomicOr(&tab[idx], 0x80u);
+    if (v == 0x12345u) out[0] = v;
+}
+template <int MODE, int SORTED> static double touch_n(uint32_t *tab, uint64_t words, uint64_t n, uint32_t *out) {
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0));
+    hipLaunchKernelGGL((k_touch_n<MODE, SORTED>), dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, tab, words, n, out);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    return (double)n / (ms * 1e-3) / 1e9;
+}
 static int big(int log2_gb) {
     uint64_t *out, *tab; const uint64_t n = 1ull << (27 + log2_gb);            // 8 GB by default
     CK(hipMalloc(&out, 64)); CK(hipMalloc(&tab, n * 8)); CK(hipMemset(tab, 1, n * 8));
@@ -121,6 +141,13 @@ static int big(int log2_gb) {
         const double r2 = touch<2>((uint32_t *)tab, words, (uint32_t *)out, 1 << 14, tpb, 64);
         const double r3 = touch<1>((uint32_t *)tab, words, (uint32_t *)out, 1 << 14, tpb, 64);
         printf("  4-byte words: reads %.1f G/s; returning atomicOr on 64 M addresses read two kernels earlier %.1f G/s; atomicOr, result unused %.1f G/s; returning %.1f G/s\n", r0, r1, r2, r3);
+    }
+    for (uint64_t m : {28000000ull, 112000000ull, 448000000ull}) {
+        const uint64_t words = 2 * n;
+        touch_n<0, 0>((uint32_t *)tab, words, m, (uint32_t *)out);
+        printf("  %llu M touches of 4-byte words: reads unsorted %.1f / sorted %.1f G/s; returning atomicOr unsorted %.1f / sorted %.1f G/s\n",
+               (unsigned long long)(m / 1000000), touch_n<0, 0>((uint32_t *)tab, words, m, (uint32_t *)out), touch_n<0, 1>((uint32_t *)tab, words, m, (uint32_t *)out),
+               touch_n<1, 0>((uint32_t *)tab, words, m, (uint32_t *)out), touch_n<1, 1>((uint32_t *)tab, words, m, (uint32_t *)out));
     }
     printf("%d GB table: random 8-byte reads %.1f G/s, random returning atomicOr %.1f G/s\n", 1 << log2_gb, rd, (double)blocks * tpb * 128 / (ms * 1e-3) / 1e9);
     return 0;
