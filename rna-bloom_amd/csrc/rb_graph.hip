@@ -488,7 +488,7 @@ __global__ void k_resolve_apply(FilterView fv, const uint64_t *__restrict__ uniq
         if (all_pre && mn >= 16u && fv.mpf.tab && fv.seq_codes) {     // what did the prefilter cache know about this k-mer?
             const uint32_t occ = vals[starts[d]];
             const uint32_t r = fv.seq_first + (occ >> fv.pos_bits), p = occ & ((1u << fv.pos_bits) - 1u);
-            const uint64_t bk = mpf_bucket(fv.mpf, window_min_order(fv.seq_codes + fv.seq_woff[r], p, (uint32_t)fv.k, fv.mpf.m));
+            const uint64_t bk = mpf_bucket(fv.mpf, window_min_order(fv.seq_codes + seq_word0(fv, r), p, (uint32_t)fv.k, fv.mpf.m));
             const uint32_t sc = min(mpf_match(fv.mpf.tab + (bk << 4), 1u, h0), 7u), s0 = min((mn >> 3) - 1u, 7u);
             atomicAdd(&g_dbg_hist[s0 * 8u + sc], (unsigned long long)ops);
             uint32_t occupied = 0;
@@ -2042,8 +2042,8 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
     // the minimizer-bucketed cache replaces the hash-bucketed one on this path (lookups here, stores by the
     // stages that retire runs, which find a k-mer's bucket from one of its occurrences in this batch)
     g->use_mpf = use_npf && g->mpf_log2b && !getenv("RB_NO_MPF") && (g->k > 31 || !getenv("RB_ONE_PASS_FILTER")) && (uint32_t)g->k >= g->mpf_m && (uint32_t)g->k - g->mpf_m + 1u <= RB_MPF_MAX_RING;
-    g->seq_codes = b->codes; g->seq_woff = b->woff;
-    struct MpfScope { rb_graph *g; ~MpfScope() { g->use_mpf = false; g->seq_codes = nullptr; g->seq_woff = nullptr; } } mpf_scope{g};
+    g->seq_codes = b->codes; g->seq_woff = b->woff; g->seq_wpr = b->wpr_uniform;
+    struct MpfScope { rb_graph *g; ~MpfScope() { g->use_mpf = false; g->seq_codes = nullptr; g->seq_woff = nullptr; g->seq_wpr = 0; } } mpf_scope{g};
     std::vector<Sub> subs;
     {
         int64_t r0 = first;

@@ -42,9 +42,14 @@ struct FilterView {
     Mpf mpf;
     const uint64_t *seq_codes;   // packed reads (nullptr: no sequence context, e.g. rb_graph_apply)
     const uint32_t *seq_woff;
+    uint32_t seq_wpr;            // words per read when every read of the batch has the same number (no offset lookup then), else 0
     uint32_t seq_first;          // read index of occurrence value 0's read
     int k;
 };
+// first packed word of read r of the batch view
+__device__ __forceinline__ uint64_t seq_word0(const FilterView &fv, uint32_t r) {
+    return fv.seq_wpr ? (uint64_t)r * fv.seq_wpr : (uint64_t)fv.seq_woff[r];
+}
 // remember a k-mer's counter exponent in whichever cache the insert path uses; occ = any occurrence of it.
 // Returns whether the cache changed (the sharded engine broadcasts only the stores that did: the replicas are alike, so a store
 // that changes nothing on the owner's replica changes nothing anywhere — e.g. the k-mer whose bucket is full of hotter ones tries
@@ -53,7 +58,7 @@ __device__ __forceinline__ bool cache_store(const FilterView &fv, uint64_t h0, u
     if (fv.mpf.tab) {
         if (!fv.seq_codes) return false;
         const uint32_t r = fv.seq_first + (occ >> fv.pos_bits), p = occ & ((1u << fv.pos_bits) - 1u);
-        const uint32_t ord = window_min_order(fv.seq_codes + fv.seq_woff[r], p, (uint32_t)fv.k, fv.mpf.m);
+        const uint32_t ord = window_min_order(fv.seq_codes + seq_word0(fv, r), p, (uint32_t)fv.k, fv.mpf.m);
         return mpf_store(fv.mpf, mpf_bucket(fv.mpf, ord), h0, s);
     } else if (fv.npf.tab)
         return npf_store(fv.npf, h0, s);
@@ -346,6 +351,7 @@ struct rb_graph {
     uint32_t mpf_log2b = 0, mpf_m = 0;
     const uint64_t *seq_codes = nullptr;   // read batch view of the sub-batch being retired (add_range sets it)
     const uint32_t *seq_woff = nullptr;
+    uint32_t seq_wpr = 0;
     uint32_t seq_first = 0;
     bool use_mpf = false;
     // scratch (grow-only)
@@ -379,7 +385,7 @@ struct rb_graph {
         fv.npf.log2n = npf_log2;
         fv.mpf.tab = (use_mpf && mpf_log2b) ? reinterpret_cast<unsigned long long *>(mpf.p) : nullptr;
         fv.mpf.log2b = mpf_log2b; fv.mpf.m = mpf_m;
-        fv.seq_codes = seq_codes; fv.seq_woff = seq_woff; fv.seq_first = seq_first; fv.k = k;
+        fv.seq_codes = seq_codes; fv.seq_woff = seq_woff; fv.seq_wpr = seq_wpr; fv.seq_first = seq_first; fv.k = k;
         return fv;
     }
     void prof_begin(hipStream_t st = nullptr) {

@@ -309,7 +309,7 @@ struct RouteUpd {
         if (fv.mpf.tab && fv.seq_codes) {          // the receivers do not know which of its reads the k-mer came from: ship the bucket
             const uint32_t occ = vals[starts[i]];
             const uint32_t r = fv.seq_first + (occ >> fv.pos_bits), p = occ & ((1u << fv.pos_bits) - 1u);
-            u.e |= mpf_bucket(fv.mpf, window_min_order(fv.seq_codes + fv.seq_woff[r], p, (uint32_t)fv.k, fv.mpf.m)) << 8;
+            u.e |= mpf_bucket(fv.mpf, window_min_order(fv.seq_codes + seq_word0(fv, r), p, (uint32_t)fv.k, fv.mpf.m)) << 8;
         }
         out[pos] = u;
     }
@@ -943,7 +943,7 @@ int rb_shard_hash_group(rb_graph *g, const rb_batch *b, int64_t first, int64_t n
         hipStream_t s = g->stream;
         for (int r = 0; r < S->G; ++r) dreq_counts[r] = creq_counts[r] = pair_counts[r] = 0;
         S->D = 0; S->n_conf = 0; S->n_kept = 0; S->ordinal0 = ordinal0; S->pos_bits = pos_bits;
-        g->seq_codes = b->codes; g->seq_woff = b->woff; g->seq_first = (uint32_t)first;   // occurrence ids -> bases, for the cache stores
+        g->seq_codes = b->codes; g->seq_woff = b->woff; g->seq_wpr = b->wpr_uniform; g->seq_first = (uint32_t)first;   // occurrence ids -> bases, for the cache stores
         S->slot_bytes[RB_SLOT_PAIR_IDX] = S->slot_bytes[RB_SLOT_DREQ_IDX] = S->slot_bytes[RB_SLOT_DREQ_PROBE] = S->slot_bytes[RB_SLOT_CREQ_IDX] = 0;
         const int mode_hash = g->stranded ? ((flags & RB_ADD_REVCOMP) ? 2 : 0) : 1;
         const int mode = (flags & RB_ADD_COUNT_IF_PRESENT) ? M_COUNT_IF_PRESENT : M_ADD;
@@ -1067,7 +1067,7 @@ int rb_shard_hash(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, int6
         RB_HIP(hipSetDevice(g->p.device));
         RB_HIP(hipStreamSynchronize(g->stream2));
         S->prep.stage = 0;
-        g->seq_codes = b->codes; g->seq_woff = b->woff; g->seq_first = (uint32_t)first;   // occurrence ids -> bases, for the cache stores
+        g->seq_codes = b->codes; g->seq_woff = b->woff; g->seq_wpr = b->wpr_uniform; g->seq_first = (uint32_t)first;   // occurrence ids -> bases, for the cache stores
         hipStream_t s = g->stream;
         for (int r = 0; r < S->G; ++r) rec_counts[r] = pair_counts[r] = 0;
         S->slot_bytes[RB_SLOT_REC_KEYS] = S->slot_bytes[RB_SLOT_REC_OCC] = S->slot_bytes[RB_SLOT_PAIR_IDX] = 0;
