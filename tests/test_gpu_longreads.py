@@ -212,3 +212,25 @@ def test_nbits_files_decode_on_the_device_and_insert_like_ascii(tmp_path):
     sb = gb.addBatch(batch)
     assert sa.kmers == sb.kmers > 10000
     assert (ga.exportFilter(N.DBGBF) == gb.exportFilter(N.DBGBF)).all() and (ga.exportFilter(N.CBF) == gb.exportFilter(N.CBF)).all()
+
+
+def test_sketch_calls_accept_packed_arrays_and_existing_outputs():
+    """minimizers / strobemers / getKmers from packed (sequence, offsets) arrays into result arrays that exist already
+    give what the list-of-bytes forms return"""
+    reads = long_reads(60, 11)
+    seq = np.frombuffer(b"".join(reads), np.uint8)
+    off = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.int64)
+    mo, h, p = G.minimizers(reads, 13, 15, 1)
+    oh, op = np.zeros(h.size + 7, np.uint64), np.zeros(h.size + 7, np.int64)
+    mo2, h2, p2 = G.minimizers((seq, off), 13, 15, 1, out=(oh, op))
+    assert (mo2 == mo).all() and (h2 == h).all() and (p2 == p).all() and h2.base is oh
+    so, sh, ss, se = G.strobemers(reads, 11, 3, 12, 61)
+    bh, bs, be = np.zeros(sh.size, np.uint64), np.zeros(sh.size, np.int32), np.zeros(sh.size, np.int32)
+    so2, sh2, ss2, se2 = G.strobemers((seq, off), 11, 3, 12, 61, out=(bh, bs, be))
+    assert (so2 == so).all() and (sh2 == sh).all() and (ss2 == ss).all() and (se2 == se).all()
+    gg = G.BloomFilterDeBruijnGraph(3_000_017, 6_000_011, 10_007, 2, 2, 2, 35, False, False, rngSeed=4)
+    gg.addReads(seq, None, off, 3)
+    ko, f, r, c = gg.getKmers(reads)
+    of, orr, oc = np.zeros(f.size, np.uint64), np.zeros(f.size, np.uint64), np.zeros(f.size, np.float32)
+    ko2, f2, r2, c2 = gg.getKmers(reads, out=(of, orr, oc))
+    assert (ko2 == ko).all() and (f2 == f).all() and (r2 == r).all() and (c2 == c).all() and c.max() > 1
