@@ -10,13 +10,14 @@
 // That freedom is what this file uses instead of a full 4-pass radix sort:
 //   1. MSD partition of the records on T = ceil(log2(N / 3072)) hash bits into 2^T "fine buckets" of ~2-3 K
 //      records, in one or two STABLE passes over HBM (k_part_count -> exclusive scan -> k_part_scatter; a tile
-//      of TPB x ITEMS records is ranked with wavefront ballots and staged through LDS so that every bucket
+//      of TPB x ITEMS records is ranked through LDS match masks and staged through LDS so that every bucket
 //      receives one contiguous piece per tile; consecutive tiles are given to the same XCD so that the pieces
 //      of neighbouring tiles meet in one L2).  The second pass is segmented: its tiles never straddle a
 //      first-pass bucket, so its scanned histogram IS the table of fine-bucket bounds.
 //   2. k_group_buckets: one workgroup per fine bucket sorts it in LDS on the next 16 hash bits (two stable
 //      8-bit counting passes), computes the strengths, finds the run heads and writes (hash, count, start)
-//      for its runs at a global position obtained by a chained scan over the buckets (ticket + look-back).
+//      for its runs into slots taken with one atomicAdd per bucket (nothing depends on the order of the runs;
+//      RB_GROUP_ORDERED=1: bucket order, through a chained scan over the buckets — ticket + look-back).
 // Records are read 3 times and written 2.x times (12-byte records) instead of 5 + 4 times, and the separate
 // strength and run-length passes are gone.
 #include <stdlib.h>
