@@ -121,9 +121,13 @@ template <int MODE, int SORTED> static double touch_n(uint32_t *tab, uint64_t wo
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     return (double)n / (ms * 1e-3) / 1e9;
 }
-static int big(int log2_gb) {
+static int big(int log2_gb, int alloc_flag = 0) {
     uint64_t *out, *tab; const uint64_t n = 1ull << (27 + log2_gb);            // 8 GB by default
-    CK(hipMalloc(&out, 64)); CK(hipMalloc(&tab, n * 8)); CK(hipMemset(tab, 1, n * 8));
+    CK(hipMalloc(&out, 64));
+    // `big <log2 GB> <flag>`: 1 = hipDeviceMallocFinegrained, 3 = hipDeviceMallocUncached, 4 = hipDeviceMallocContiguous
+    if (alloc_flag) { CK(hipExtMallocWithFlags((void **)&tab, n * 8, (unsigned)alloc_flag)); printf("(allocation flag %d) ", alloc_flag); }
+    else CK(hipMalloc(&tab, n * 8));
+    CK(hipMemset(tab, 1, n * 8));
     const int blocks = 256 * 32, tpb = 256;
     const double rd = run<4, 0>(tab, n, out, blocks, tpb, 64);
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -154,7 +158,7 @@ static int big(int log2_gb) {
 }
 int main(int argc, char **argv) {
     if (argc > 1 && !strcmp(argv[1], "calib")) return calib();
-    if (argc > 1 && !strcmp(argv[1], "big")) return big(argc > 2 ? atoi(argv[2]) : 3);
+    if (argc > 1 && !strcmp(argv[1], "big")) return big(argc > 2 ? atoi(argv[2]) : 3, argc > 3 ? atoi(argv[3]) : 0);
     uint64_t *out; CK(hipMalloc(&out, 64));
     const int blocks = 256 * 32, tpb = 256;
     printf("%-10s %-6s %8s %8s %8s %8s\n", "table", "what", "K=1", "K=2", "K=4", "K=8");
