@@ -249,6 +249,12 @@ int rb_filter_size(rb_graph *g, int which, int64_t *size /* bits or bytes */, in
 /* bit filters: set bits (UnsafeByteBuffer.bitPopCount :131-150); cbf: non-zero bytes (:121-129) */
 int rb_filter_popcount(rb_graph *g, int which, int64_t *out);
 int rb_filter_fpr(rb_graph *g, int which, float *out); /* BloomFilter.getFPR :185-194 */
+/* 64-bit digest of the filter bytes this handle holds, computed on the device: the wrapping sum, over the non-zero 32-bit
+ * little-endian words, of splitmix64(global word number * 0x9E3779B97F4A7C15 + word).  The digests of the shards of a
+ * distributed filter add up (mod 2^64) to the digest of the same filter on one GPU, so filters too large to export
+ * (BASELINE config 4: 150 GB of counters) are compared on the device.  No reference counterpart (the reference compares
+ * nothing); tests/test_gpu_config3.py, rnabloom.graph.fold_bytes is the host restatement. */
+int rb_filter_fold(rb_graph *g, int which, uint64_t *out);
 int rb_filter_export(rb_graph *g, int which, void *dst, size_t nbytes);
 int rb_filter_import(rb_graph *g, int which, const void *src, size_t nbytes);
 int64_t rb_expected_size(int64_t n, float fpr, int num_hash); /* BloomFilter.getExpectedSize :196-199 */

@@ -82,6 +82,8 @@ public final class NativeGraph {
     /** {size, bytes, numHash} */
     public static native long[] filterSize(long h, int which);
     public static native long popcount(long h, int which);
+    /** rb_filter_fold: 64-bit digest of the filter's bytes, computed on the device (compare filters without exporting them) */
+    public static native long fold(long h, int which);
     public static native float fpr(long h, int which);
     public static native void exportFilter(long h, int which, ByteBuffer dst, long nBytes);
     public static native void importFilter(long h, int which, ByteBuffer src, long nBytes);

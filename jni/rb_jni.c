@@ -299,6 +299,7 @@ jlongArray FN(filterSize)(JNIEnv *e, jclass c, jlong h, jint which) {
     return a;
 }
 jlong FN(popcount)(JNIEnv *e, jclass c, jlong h, jint which) { int64_t v = 0; (void)c; int rc = rb_filter_popcount(G(h), which, &v); if (rc) throw_rc(e, rc); return v; }
+jlong FN(fold)(JNIEnv *e, jclass c, jlong h, jint which) { uint64_t v = 0; (void)c; int rc = rb_filter_fold(G(h), which, &v); if (rc) throw_rc(e, rc); return (jlong)v; }
 jfloat FN(fpr)(JNIEnv *e, jclass c, jlong h, jint which) { float v = 0; (void)c; int rc = rb_filter_fpr(G(h), which, &v); if (rc) throw_rc(e, rc); return v; }
 void FN(exportFilter)(JNIEnv *e, jclass c, jlong h, jint which, jobject dst, jlong n) { (void)c; int rc = rb_filter_export(G(h), which, direct(e, dst), (size_t)n); if (rc) throw_rc(e, rc); }
 void FN(importFilter)(JNIEnv *e, jclass c, jlong h, jint which, jobject src, jlong n) { (void)c; int rc = rb_filter_import(G(h), which, direct(e, src), (size_t)n); if (rc) throw_rc(e, rc); }

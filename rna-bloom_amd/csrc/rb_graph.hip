@@ -1600,6 +1600,25 @@ __global__ void k_count_nonzero_bytes(const uint32_t *__restrict__ w, size_t n_w
     for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
     if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
 }
+// order-independent 64-bit digest of a filter's bytes: the wrapping sum over the non-zero 32-bit words of
+// mix(global word number, word).  Sums of the digests of index ranges = digest of the whole filter, so the
+// shards of a distributed filter and a single-GPU filter compare without exporting 150 GB (rb_filter_fold).
+__device__ __forceinline__ uint64_t fold_mix(uint64_t gw, uint32_t x) {
+    uint64_t z = gw * 0x9E3779B97F4A7C15ull + (uint64_t)x;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ void k_fold_words(const uint32_t *__restrict__ w, size_t n_words, uint64_t gw0, unsigned long long *out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long c = 0;
+    for (; i < n_words; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t x = w[i];
+        if (x) c += fold_mix(gw0 + i, x);
+    }
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o, 64);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(out, c);
+}
 // CountingBloomFilter.getBloomFilter(minCov) R/bloom/CountingBloomFilter.java:328-338: bit i of the new filter is set iff
 // MiniFloat.toFloat(counts[i]) >= minCov.  One thread per 32 counters = one output word.
 __global__ void k_cbf_to_bits(const uint8_t *__restrict__ cbf, int64_t n, float min_cov, uint32_t *__restrict__ bits) {
@@ -3095,31 +3114,52 @@ int rb_filter_size(rb_graph *g, int which, int64_t *size, int64_t *nbytes, int *
     return RB_OK;
 }
 
-int rb_filter_popcount(rb_graph *g, int which, int64_t *out) {
+// popcount (fold == false) or digest (fold == true) of the locally held part of a filter; a read-only call: shared lock + a
+// leased query context, so concurrent queries do not wait behind it
+static int filter_reduce(rb_graph *g, int which, bool fold, unsigned long long *out) {
     return guarded([&] {
-        RB_REQUIRE(g && out, "rb_filter_popcount: null argument");
-        WriteLock wl(g->rw);
-        RB_HIP(hipSetDevice(g->p.device));
-        g->devctr.reserve(DEVCTR_BYTES);
-        unsigned long long *acc = reinterpret_cast<unsigned long long *>(g->devctr.as<uint32_t>() + 14);
-        RB_HIP(hipMemsetAsync(acc, 0, 8, g->stream));
+        RB_REQUIRE(g && out, "rb_filter_popcount / rb_filter_fold: null argument");
+        QueryLease q(g);
+        RB_HIP(hipStreamSynchronize(g->stream));   // shard phases return with work in flight on the handle's stream
+        q.c->b0.reserve(64);
+        unsigned long long *acc = q.c->b0.as<unsigned long long>();
+        RB_HIP(hipMemsetAsync(acc, 0, 8, q.c->st));
+        const uint32_t *words; size_t nw; uint64_t gw0;
         if (which == RB_CBF) {
-            size_t nw = g->cbf_alloc / 4;   // padding bytes are zero
-            hipLaunchKernelGGL(k_count_nonzero_bytes, dim3(std::min<unsigned>(blocks_for((int64_t)nw), 8192u)), dim3(TPB), 0, g->stream,
-                               reinterpret_cast<const uint32_t *>(g->cbf), nw, acc);
+            if (!g->cbf) { set_error("rb_filter_popcount: filter %d not initialised", which); throw HipError{RB_ERR_STATE}; }
+            words = reinterpret_cast<const uint32_t *>(g->cbf); nw = g->cbf_alloc / 4;   // padding bytes are zero
+            gw0 = (uint64_t)g->cbf_lo / 4u;
         } else {
             BitFilter *f = bit_filter(g, which);
             RB_REQUIRE(f, "rb_filter_popcount: unknown filter %d", which);
             if (!f->bits) { set_error("rb_filter_popcount: filter %d not initialised", which); throw HipError{RB_ERR_STATE}; }
-            size_t nw = f->alloc / 4;
-            hipLaunchKernelGGL(k_popcount_bits, dim3(std::min<unsigned>(blocks_for((int64_t)nw), 8192u)), dim3(TPB), 0, g->stream, f->bits, nw, acc);
+            words = f->bits; nw = f->alloc / 4;
+            gw0 = (uint64_t)f->lo / 32u;
         }
+        const dim3 grid(std::min<unsigned>(blocks_for((int64_t)nw), 8192u));
+        if (fold) hipLaunchKernelGGL(k_fold_words, grid, dim3(TPB), 0, q.c->st, words, nw, gw0, acc);
+        else if (which == RB_CBF) hipLaunchKernelGGL(k_count_nonzero_bytes, grid, dim3(TPB), 0, q.c->st, words, nw, acc);
+        else hipLaunchKernelGGL(k_popcount_bits, grid, dim3(TPB), 0, q.c->st, words, nw, acc);
         RB_HIP(hipGetLastError());
         unsigned long long v = 0;
-        RB_HIP(hipMemcpyAsync(&v, acc, 8, hipMemcpyDeviceToHost, g->stream));
-        RB_HIP(hipStreamSynchronize(g->stream));
-        *out = (int64_t)v;
+        RB_HIP(hipMemcpyAsync(&v, acc, 8, hipMemcpyDeviceToHost, q.c->st));
+        RB_HIP(hipStreamSynchronize(q.c->st));
+        *out = v;
     });
+}
+int rb_filter_popcount(rb_graph *g, int which, int64_t *out) {
+    unsigned long long v = 0;
+    if (!out) { set_error("rb_filter_popcount: null argument"); return RB_ERR_INVALID; }
+    int rc = filter_reduce(g, which, false, &v);
+    if (rc == RB_OK) *out = (int64_t)v;
+    return rc;
+}
+int rb_filter_fold(rb_graph *g, int which, uint64_t *out) {
+    unsigned long long v = 0;
+    if (!out) { set_error("rb_filter_fold: null argument"); return RB_ERR_INVALID; }
+    int rc = filter_reduce(g, which, true, &v);
+    if (rc == RB_OK) *out = (uint64_t)v;
+    return rc;
 }
 
 int rb_filter_fpr(rb_graph *g, int which, float *out) {
@@ -3136,8 +3176,7 @@ int rb_filter_fpr(rb_graph *g, int which, float *out) {
 int rb_filter_export(rb_graph *g, int which, void *dst, size_t nbytes) {
     return guarded([&] {
         RB_REQUIRE(g && dst, "rb_filter_export: null argument");
-        WriteLock wl(g->rw);
-        RB_HIP(hipSetDevice(g->p.device));
+        QueryLease q(g);                      // read-only: shared lock (mutators finish their work before they release the handle)
         const void *src; size_t have;
         if (which == RB_CBF) { src = g->cbf; have = (size_t)(g->cbf_hi - g->cbf_lo); }
         else {
@@ -3148,7 +3187,8 @@ int rb_filter_export(rb_graph *g, int which, void *dst, size_t nbytes) {
         }
         RB_REQUIRE(nbytes == have, "rb_filter_export: buffer is %zu bytes, filter has %zu", nbytes, have);
         RB_HIP(hipStreamSynchronize(g->stream));
-        RB_HIP(hipMemcpy(dst, src, have, hipMemcpyDeviceToHost));
+        RB_HIP(hipMemcpyAsync(dst, src, have, hipMemcpyDeviceToHost, q.c->st));
+        RB_HIP(hipStreamSynchronize(q.c->st));
     });
 }
 

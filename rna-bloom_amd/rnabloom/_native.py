@@ -84,6 +84,7 @@ SYMBOLS = [
     ("rb_filter_size", _i32, [_vp, _i32, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i32)]),
     ("rb_filter_popcount", _i32, [_vp, _i32, C.POINTER(_i64)]),
     ("rb_filter_fpr", _i32, [_vp, _i32, C.POINTER(C.c_float)]),
+    ("rb_filter_fold", _i32, [_vp, _i32, C.POINTER(_u64)]),
     ("rb_filter_export", _i32, [_vp, _i32, _vp, _sz]),
     ("rb_filter_import", _i32, [_vp, _i32, _vp, _sz]),
     ("rb_expected_size", _i64, [_i64, C.c_float, _i32]),

@@ -568,6 +568,12 @@ class BloomFilterDeBruijnGraph:
         check(lib.rb_filter_popcount(self.h, which, C.byref(v)))
         return v.value
 
+    def fold(self, which):
+        """64-bit digest of the filter's bytes, computed on the device (rb_filter_fold; fold_bytes is the host form)"""
+        v = C.c_uint64()
+        check(lib.rb_filter_fold(self.h, which, C.byref(v)))
+        return v.value
+
     def _fpr(self, which):
         v = C.c_float()
         check(lib.rb_filter_fpr(self.h, which, C.byref(v)))
@@ -729,3 +735,20 @@ def getMinimizers(reads, k, w, mode=1, stale=None, device=0):
     st = None if stale is None else np.ascontiguousarray(stale, np.uint64)
     check(lib.rb_minimizer_set(device, _ptr(seq), _ptr(off), len(reads), k, w, mode, _ptr(st) if st is not None else None, _ptr(mo), _ptr(out)))
     return mo, out[:int(mo[-1])].copy()
+
+
+def fold_bytes(data, first_word=0):
+    """Host restatement of rb_filter_fold for a filter's exported bytes (numpy): wrapping sum over the non-zero 32-bit
+    little-endian words of splitmix64(global word number * 0x9E3779B97F4A7C15 + word)."""
+    a = np.ascontiguousarray(data, np.uint8)
+    pad = (-a.size) % 4
+    if pad:
+        a = np.concatenate([a, np.zeros(pad, np.uint8)])
+    w = a.view("<u4").astype(np.uint64)
+    nz = np.nonzero(w)[0]
+    with np.errstate(over="ignore"):
+        z = (nz.astype(np.uint64) + np.uint64(first_word)) * np.uint64(0x9E3779B97F4A7C15) + w[nz]
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+        return int(z.sum(dtype=np.uint64))

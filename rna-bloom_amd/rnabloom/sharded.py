@@ -129,6 +129,11 @@ class ShardRank:
         check(lib.rb_filter_popcount(self.h, which, C.byref(v)))
         return v.value
 
+    def local_fold(self, which):
+        v = C.c_uint64()
+        check(lib.rb_filter_fold(self.h, which, C.byref(v)))
+        return v.value
+
     # ---- one global sub-batch; yields exchange requests, receives their results ----
     def substep(self, batch, first, n, pos_bits, flags, nxt=None):
         """reads [first, first+n) of `batch` (every rank holds the same batch and passes the same range);
@@ -775,6 +780,10 @@ class LoopbackCluster:
 
     def popcount(self, which):
         return sum(r.local_popcount(which) for r in self.ranks)
+
+    def fold(self, which):
+        """digest of the whole distributed filter = sum of the shards' digests mod 2^64 (rb_filter_fold)"""
+        return sum(r.local_fold(which) for r in self.ranks) & 0xFFFFFFFFFFFFFFFF
 
     def destroy(self):
         for r in self.ranks:
