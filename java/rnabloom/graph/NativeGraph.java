@@ -18,6 +18,9 @@ public final class NativeGraph {
 
     private NativeGraph() { }
 
+    /** HIP device the drop-in classes create their handles on: -Drb.device=N (default 0) */
+    public static int defaultDevice() { return Integer.getInteger("rb.device", 0); }
+
     // filters (RB_DBGBF .. RB_FPKBF), add flags (RB_ADD_*), per-hash ops (RB_OP_*), neighbour directions
     public static final int DBGBF = 0, CBF = 1, RPKBF = 2, FPKBF = 3;
     public static final int ADD_REVCOMP = 1, ADD_COUNT_IF_PRESENT = 2, ADD_STORE_READ_PAIRS = 4, ADD_PAIRS_IF_PRESENT = 8;
@@ -87,6 +90,9 @@ public final class NativeGraph {
     public static native float fpr(long h, int which);
     public static native void exportFilter(long h, int which, ByteBuffer dst, long nBytes);
     public static native void importFilter(long h, int which, ByteBuffer src, long nBytes);
+    /** the same for filters of 2 GiB and more (beyond a direct ByteBuffer): the shim maps the file */
+    public static native void importFilterFromFile(long h, int which, String path, long nBytes);
+    public static native void exportFilterToFile(long h, int which, String path, long nBytes);
     public static native long expectedSize(long expNumElements, float fpr, int numHash);
     public static native void cbfToBloom(long src, float minCov, long dst, int which);
 

@@ -15,9 +15,13 @@
 #endif
 
 #ifdef RB_HAVE_JNI
+#define _POSIX_C_SOURCE 200809L   /* open / mmap / ftruncate under -std=c11 */
 #include <jni.h>
+#include <fcntl.h>
 #include <stdint.h>
 #include <string.h>
+#include <sys/mman.h>
+#include <unistd.h>
 
 #include "rb_capi.h"
 
@@ -303,6 +307,33 @@ jlong FN(fold)(JNIEnv *e, jclass c, jlong h, jint which) { uint64_t v = 0; (void
 jfloat FN(fpr)(JNIEnv *e, jclass c, jlong h, jint which) { float v = 0; (void)c; int rc = rb_filter_fpr(G(h), which, &v); if (rc) throw_rc(e, rc); return v; }
 void FN(exportFilter)(JNIEnv *e, jclass c, jlong h, jint which, jobject dst, jlong n) { (void)c; int rc = rb_filter_export(G(h), which, direct(e, dst), (size_t)n); if (rc) throw_rc(e, rc); }
 void FN(importFilter)(JNIEnv *e, jclass c, jlong h, jint which, jobject src, jlong n) { (void)c; int rc = rb_filter_import(G(h), which, direct(e, src), (size_t)n); if (rc) throw_rc(e, rc); }
+/* filters of 2 GiB and more (a direct ByteBuffer holds less): the file is mapped here and handed to the same two calls */
+void FN(importFilterFromFile)(JNIEnv *e, jclass c, jlong h, jint which, jstring path, jlong n) {
+    const char *p = (*e)->GetStringUTFChars(e, path, NULL);
+    int rc = RB_ERR_INVALID, fd = p ? open(p, O_RDONLY) : -1;
+    (void)c;
+    if (fd >= 0) {
+        void *m = mmap(NULL, (size_t)n, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m != MAP_FAILED) { rc = rb_filter_import(G(h), which, m, (size_t)n); munmap(m, (size_t)n); }
+        close(fd);
+    }
+    if (p) (*e)->ReleaseStringUTFChars(e, path, p);
+    if (rc) throw_rc(e, rc);
+}
+void FN(exportFilterToFile)(JNIEnv *e, jclass c, jlong h, jint which, jstring path, jlong n) {
+    const char *p = (*e)->GetStringUTFChars(e, path, NULL);
+    int rc = RB_ERR_INVALID, fd = p ? open(p, O_RDWR | O_CREAT | O_TRUNC, 0644) : -1;
+    (void)c;
+    if (fd >= 0) {
+        if (ftruncate(fd, (off_t)n) == 0) {
+            void *m = mmap(NULL, (size_t)n, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+            if (m != MAP_FAILED) { rc = rb_filter_export(G(h), which, m, (size_t)n); munmap(m, (size_t)n); }
+        }
+        close(fd);
+    }
+    if (p) (*e)->ReleaseStringUTFChars(e, path, p);
+    if (rc) throw_rc(e, rc);
+}
 jlong FN(expectedSize)(JNIEnv *e, jclass c, jlong n, jfloat fpr, jint nh) { (void)e; (void)c; return rb_expected_size(n, fpr, nh); }
 void FN(cbfToBloom)(JNIEnv *e, jclass c, jlong src, jfloat min_cov, jlong dst, jint which) { (void)c; int rc = rb_cbf_to_bloom(G(src), min_cov, G(dst), which); if (rc) throw_rc(e, rc); }
 

@@ -27,7 +27,7 @@ __global__ void k_encode_ascii(const uint8_t *__restrict__ seq, const uint8_t *_
                                const int64_t *__restrict__ off, const uint32_t *__restrict__ woff,
                                int64_t n_reads, int64_t n_words, int min_q,
                                uint64_t *__restrict__ codes, uint32_t *__restrict__ valid,
-                               uint32_t *__restrict__ word_read) {
+                               uint32_t *__restrict__ word_read, uint32_t *__restrict__ rnz = nullptr) {
     int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (w >= n_words) return;
     // owning read: largest r with woff[r] <= w  (reads with zero words are skipped automatically)
@@ -40,11 +40,20 @@ __global__ void k_encode_ascii(const uint8_t *__restrict__ seq, const uint8_t *_
     const int64_t base0 = off[r], len = off[r + 1] - base0;
     const int64_t b0 = (w - woff[r]) * 32;
     uint64_t c = 0;
-    uint32_t v = 0;
+    uint32_t v = 0, rz = 0;
     for (int i = 0; i < 32; ++i) {
         int64_t b = b0 + i;
         if (b >= len) break;
         uint32_t ch = seq[base0 + b];
+        if (rnz) {   // reverse-strand seed = seedTab[ch & 7] (NTHash.java:30, 133-166): classes 1 T, 3 G, 4 A, 5 A, 7 C, the others 0
+            const uint32_t cls = ch & 7u;
+            if ((0xBAu >> cls) & 1u) {          // classes 1, 3, 4, 5, 7
+                rz |= 1u << i;
+                // the code whose COMPLEMENT carries that seed (for A C G T U a c g t u: the base's own code)
+                const uint32_t rc = cls == 1u ? 0u : cls == 3u ? 1u : cls == 7u ? 2u : 3u;
+                c |= (uint64_t)rc << (2 * i);
+            }
+        }
         uint32_t code = 4;
         switch (ch) {   // [ACGTU], CASE_INSENSITIVE  (R/util/SeqUtils.java:1436-1438)
             case 'A': case 'a': code = 0; break;
@@ -59,12 +68,13 @@ __global__ void k_encode_ascii(const uint8_t *__restrict__ seq, const uint8_t *_
             ok = ok && (q >= (uint32_t)(33 + min_q)) && (q <= (uint32_t)'~');
         }
         if (ok) {
-            c |= (uint64_t)code << (2 * i);
+            c |= (uint64_t)code << (2 * i);       // (with rnz: the same two bits again)
             v |= 1u << i;
         }
     }
     codes[w] = c;
     valid[w] = v;
+    if (rnz) rnz[w] = rz;
     word_read[w] = (uint32_t)r;
 }
 
@@ -1117,6 +1127,7 @@ int rb_batch_destroy(rb_batch *b) {
     (void)hipSetDevice(b->device);
     if (b->codes) (void)hipFree(b->codes);
     if (b->valid) (void)hipFree(b->valid);
+    if (b->rnz) (void)hipFree(b->rnz);
     if (b->word_read) (void)hipFree(b->word_read);
     if (b->woff) (void)hipFree(b->woff);
     if (b->len) (void)hipFree(b->len);
@@ -1139,7 +1150,7 @@ namespace rb {
 // GPU-side 2-bit encode of one chunk with whatever the GPU does for the previous one: begin() allocates,
 // enqueues the copies + encode kernel on `st` and returns; finish() waits for them and frees the staging.
 void ascii_batch_begin(AsciiUpload &u, int device, const char *seq, const char *qual, const int64_t *offsets, int64_t first, int64_t n_reads,
-                       int min_base_qual, hipStream_t st) {
+                       int min_base_qual, hipStream_t st, bool want_rnz) {
     RB_REQUIRE(offsets && n_reads >= 0 && (seq || n_reads == 0 || offsets[first + n_reads] == offsets[first]), "rb_batch_create_ascii: null argument");
     RB_REQUIRE(min_base_qual >= 0 && min_base_qual < 94, "rb_batch_create_ascii: min_base_qual out of range");
     RB_HIP(hipSetDevice(device));
@@ -1187,8 +1198,9 @@ void ascii_batch_begin(AsciiUpload &u, int device, const char *seq, const char *
         for (int64_t i = 0; i <= n_reads; ++i) u.rel[(size_t)i] = offsets[i] - base0;
         RB_HIP(hipMalloc(&u.d_off, ((size_t)n_reads + 1) * 8));
         RB_HIP(hipMemcpyAsync(u.d_off, u.rel.data(), ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, st));
+        if (want_rnz) { RB_HIP(hipMalloc(&b->rnz, (size_t)words * 4)); b->device_bytes += (size_t)words * 4; }
         hipLaunchKernelGGL(k_encode_ascii, dim3(blocks_for((int64_t)words)), dim3(TPB), 0, st, u.d_seq, u.d_qual, u.d_off, b->woff, n_reads,
-                           (int64_t)words, min_base_qual, b->codes, b->valid, b->word_read);
+                           (int64_t)words, min_base_qual, b->codes, b->valid, b->word_read, b->rnz);
         RB_HIP(hipGetLastError());
     }
 }
@@ -1432,6 +1444,7 @@ int rb_batch_create_nbits(int device, const void *bytes, size_t nbytes, int64_t 
             const uint32_t l = ((uint32_t)p[pos] << 24) | ((uint32_t)p[pos + 1] << 16) | ((uint32_t)p[pos + 2] << 8) | (uint32_t)p[pos + 3];
             RB_REQUIRE(l < (1u << 30), "rb_batch_create_nbits: record %zu has an invalid length %u", len.size(), l);
             const size_t nb = ((size_t)l + 3) / 4;
+            if (l == 0) break;                                       // an empty sequence ends the iteration: fin.read(new byte[0]) is 0, not > 0, and next() returns null (NucleotideBitsReader.java:41-44)
             if (pos + 4 + nb > nbytes) break;                        // truncated record: the reader returns null
             rec_off.push_back((int64_t)(pos + 4)); len.push_back(l); woff.push_back((uint32_t)words);
             words += ((uint64_t)l + 31) / 32;

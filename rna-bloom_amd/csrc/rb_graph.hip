@@ -1078,7 +1078,8 @@ __global__ void k_cbf_count(FilterView fv, const uint64_t *__restrict__ h0, size
 // HASH_ONLY (a shard of a distributed graph: the counts come from a query exchange): out_c = 1 where the window is usable
 template <bool HASH_ONLY>
 __global__ void k_get_kmers(FilterView fv, int stranded, const uint64_t *__restrict__ codes,
-                            const uint32_t *__restrict__ valid, const uint32_t *__restrict__ word_read,
+                            const uint32_t *__restrict__ valid, const uint32_t *__restrict__ rnz /* reverse-strand seed non-zero (NTHash.java:30: ch & 7), or null */,
+                            const uint32_t *__restrict__ word_read,
                             const uint32_t *__restrict__ woff, const uint32_t *__restrict__ len,
                             int64_t n_words, int k, const int64_t *__restrict__ koff,
                             uint64_t *__restrict__ out_f, uint64_t *__restrict__ out_r, float *__restrict__ out_c) {
@@ -1091,19 +1092,20 @@ __global__ void k_get_kmers(FilterView fv, int stranded, const uint64_t *__restr
     const uint32_t bend = bend64 < L ? (uint32_t)bend64 : L;
     const uint64_t *cw = codes + wr;
     const uint32_t *vw = valid + wr;
+    const uint32_t *zw = rnz ? rnz + wr : vw;      // a base outside ACGTU may still carry a reverse-strand seed (K M S W Y I E ...)
     uint64_t f = 0, rv = 0;
     uint32_t filled = 0, run = 0;
     for (uint32_t b = b0; b < bend; ++b) {
-        const bool ok = (vw[b >> 5] >> (b & 31u)) & 1u;
+        const bool ok = (vw[b >> 5] >> (b & 31u)) & 1u, rok = (zw[b >> 5] >> (b & 31u)) & 1u;
         const uint64_t s_in = ok ? seed_of((uint32_t)(cw[b >> 5] >> (2u * (b & 31u))) & 3u) : 0ull;
-        const uint64_t sc_in = ok ? seed_of(3u - ((uint32_t)(cw[b >> 5] >> (2u * (b & 31u))) & 3u)) : 0ull;
+        const uint64_t sc_in = rok ? seed_of(3u - ((uint32_t)(cw[b >> 5] >> (2u * (b & 31u))) & 3u)) : 0ull;
         run = ok ? run + 1u : 0u;
         if (filled < uk) { f = rotl(f, 1) ^ s_in; rv ^= rotl(sc_in, filled); ++filled; }
         else {
             const uint32_t bo = b - uk;
-            const bool oko = (vw[bo >> 5] >> (bo & 31u)) & 1u;
+            const bool oko = (vw[bo >> 5] >> (bo & 31u)) & 1u, roko = (zw[bo >> 5] >> (bo & 31u)) & 1u;
             const uint32_t oc = (uint32_t)(cw[bo >> 5] >> (2u * (bo & 31u))) & 3u;
-            const uint64_t s_out = oko ? seed_of(oc) : 0ull, sc_out = oko ? seed_of(3u - oc) : 0ull;
+            const uint64_t s_out = oko ? seed_of(oc) : 0ull, sc_out = roko ? seed_of(3u - oc) : 0ull;
             f = rotl(f, 1) ^ rotl(s_out, uk) ^ s_in;
             rv = rotr(rv, 1) ^ rotr(sc_out, 1) ^ rotl(sc_in, uk - 1u);
         }
@@ -1373,6 +1375,15 @@ __global__ void k_naive_extend(FilterView fv, int stranded, int k, int direction
     for (;;) {
         const uint32_t oc = code_of_char(sq[len]);            // base about to leave: first base (right walk) / last base (left walk)
         const uint64_t s_out = seed_of(oc), sc_out = seed_of(3u - oc);
+        uint32_t n_nb = 0, best_in = 0;
+        uint64_t best_f = 0, best_r = 0;
+        for (uint32_t in = 0; in < 4u; ++in) {
+            uint64_t nf, nr = 0;
+            if (direction == 0) { nf = rotl(f, 1) ^ rotl(s_out, uk) ^ seed_of(in); if (!stranded) nr = rotr(r, 1) ^ rotr(sc_out, 1) ^ rotl(seed_of(3u - in), uk - 1u); }
+            else { nf = rotr(f, 1) ^ rotr(s_out, 1) ^ rotl(seed_of(in), uk - 1u); if (!stranded) nr = rotl(r, 1) ^ rotl(sc_out, uk) ^ seed_of(3u - in); }
+            if (graph_count(fv, stranded ? nf : smin(nf, nr)) >= min_cov) { if (n_nb++ == 0) { best_in = in; best_f = nf; best_r = nr; } }
+        }
+        if (n_nb == 0) { reason = 0; break; }                 // `while (!neighbors.isEmpty())`: a dead end ends the walk before the back-branch test (:6791)
         if (mode != 2) {                                      // back branches: variants of the current k-mer in that base
             bool back = false;
             for (uint32_t in = 0; in < 4u && !back; ++in) {
@@ -1384,15 +1395,6 @@ __global__ void k_naive_extend(FilterView fv, int stranded, int k, int direction
             }
             if (back) { reason = 1; break; }
         }
-        uint32_t n_nb = 0, best_in = 0;
-        uint64_t best_f = 0, best_r = 0;
-        for (uint32_t in = 0; in < 4u; ++in) {
-            uint64_t nf, nr = 0;
-            if (direction == 0) { nf = rotl(f, 1) ^ rotl(s_out, uk) ^ seed_of(in); if (!stranded) nr = rotr(r, 1) ^ rotr(sc_out, 1) ^ rotl(seed_of(3u - in), uk - 1u); }
-            else { nf = rotr(f, 1) ^ rotr(s_out, 1) ^ rotl(seed_of(in), uk - 1u); if (!stranded) nr = rotl(r, 1) ^ rotl(sc_out, uk) ^ seed_of(3u - in); }
-            if (graph_count(fv, stranded ? nf : smin(nf, nr)) >= min_cov) { if (n_nb++ == 0) { best_in = in; best_f = nf; best_r = nr; } }
-        }
-        if (n_nb == 0) { reason = 0; break; }
         if (n_nb > 1) { reason = 2; break; }
         if (mode == 0) {
             bool hit = false;
@@ -2823,7 +2825,7 @@ int rb_graph_kmers(rb_graph *g, const char *seq, const int64_t *offsets, int64_t
                 rb::AsciiUpload up;
                 rb_batch *b = nullptr;
                 try {
-                    rb::ascii_batch_begin(up, g->p.device, seq, nullptr, offsets, ra, pn, 0, s);
+                    rb::ascii_batch_begin(up, g->p.device, seq, nullptr, offsets, ra, pn, 0, s, true);
                     b = rb::ascii_batch_finish(up);
                 } catch (...) { rb::ascii_batch_abort(up); throw; }
                 struct G { rb_batch *b; ~G() { rb_batch_destroy(b); } } guard{b};
@@ -2835,11 +2837,11 @@ int rb_graph_kmers(rb_graph *g, const char *seq, const int64_t *offsets, int64_t
                 // counts with one rb_shard_query_* exchange (rnabloom/sharded.py::ShardRank.getKmers)
                 if (g->shard)
                     hipLaunchKernelGGL(k_get_kmers<true>, dim3(blocks_for(b->n_words)), dim3(TPB), 0, s, g->view(0, 0), (int)g->stranded,
-                                       b->codes, b->valid, b->word_read, b->woff, b->len, b->n_words, g->k, q.c->b0.as<int64_t>(),
+                                       b->codes, b->valid, b->rnz, b->word_read, b->woff, b->len, b->n_words, g->k, q.c->b0.as<int64_t>(),
                                        q.c->b1.as<uint64_t>(), q.c->b2.as<uint64_t>(), q.c->b3.as<float>());
                 else
                     hipLaunchKernelGGL(k_get_kmers<false>, dim3(blocks_for(b->n_words)), dim3(TPB), 0, s, g->view(0, 0), (int)g->stranded,
-                                       b->codes, b->valid, b->word_read, b->woff, b->len, b->n_words, g->k, q.c->b0.as<int64_t>(),
+                                       b->codes, b->valid, b->rnz, b->word_read, b->woff, b->len, b->n_words, g->k, q.c->b0.as<int64_t>(),
                                        q.c->b1.as<uint64_t>(), q.c->b2.as<uint64_t>(), q.c->b3.as<float>());
                 RB_HIP(hipGetLastError());
                 const int64_t o = koffsets[ra];

@@ -83,6 +83,10 @@ struct rb_batch {
     uint32_t wpr_uniform = 0;      // words per read when every read has the same word count, else 0
     uint64_t *codes = nullptr;     // [n_words]
     uint32_t *valid = nullptr;     // [n_words]
+    uint32_t *rnz = nullptr;       // [n_words] or nullptr: bit = the base's REVERSE-strand seed is non-zero.  The reference looks the complement's
+                                   // seed up by `ch & 7` (R/bloom/hash/NTHash.java:30, 133-166), so some non-ACGTU letters (K M S W Y I E L O Q D ...)
+                                   // hash as a base on the reverse strand and as nothing on the forward strand; for such a base the code bits hold
+                                   // the code whose complement's seed that is.  Only batches made for all-window hashing (getKmers, sketches) carry it.
     uint32_t *word_read = nullptr; // [n_words] owning read of each word
     uint32_t *woff = nullptr;      // [n_reads+1]
     uint32_t *len = nullptr;       // [n_reads]

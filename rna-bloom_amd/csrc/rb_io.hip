@@ -229,7 +229,7 @@ FastqChunk fastq_batch_create(int device, const char *text, size_t n, bool final
     rb_batch *b = new rb_batch();
     struct Guard { rb_batch *b; ~Guard() { if (b) rb_batch_destroy(b); } } guard{b};
     b->device = device;
-    const uint32_t un = (uint32_t)n, ntiles = (un + FQ_TILE - 1) / FQ_TILE;
+    const uint32_t un = (uint32_t)n, ntiles = (uint32_t)(((uint64_t)n + FQ_TILE - 1) / FQ_TILE);   // 64-bit: n + FQ_TILE - 1 wraps in 32 bits just below 4 GiB
     TmpBuf d_text, d_cnt, d_base, d_tmp, d_ls, d_sp, d_qp, d_len, d_nw, d_woff, d_err;
     uint8_t *t = d_text.alloc<uint8_t>((size_t)ntiles * FQ_TILE + 64);
     RB_HIP(hipMemsetAsync(t + n, 0, (size_t)ntiles * FQ_TILE + 64 - n, st));
@@ -306,7 +306,7 @@ FastqChunk fasta_batch_create(int device, const char *text, size_t n, bool final
     rb_batch *b = new rb_batch();
     struct Guard { rb_batch *b; ~Guard() { if (b) rb_batch_destroy(b); } } guard{b};
     b->device = device;
-    const uint32_t un = (uint32_t)n, ntiles = (un + FQ_TILE - 1) / FQ_TILE;
+    const uint32_t un = (uint32_t)n, ntiles = (uint32_t)(((uint64_t)n + FQ_TILE - 1) / FQ_TILE);   // 64-bit: n + FQ_TILE - 1 wraps in 32 bits just below 4 GiB
     TmpBuf d_text, d_cnt, d_base, d_tmp, d_ls, d_ts, d_tl, d_ish, d_kind, d_cum, d_hidx, d_hl, d_len, d_nw, d_woff, d_err;
     uint8_t *t = d_text.alloc<uint8_t>((size_t)ntiles * FQ_TILE + 64);
     RB_HIP(hipMemsetAsync(t + n, 0, (size_t)ntiles * FQ_TILE + 64 - n, st));

@@ -50,7 +50,7 @@ struct AsciiUpload {
     }
 };
 void ascii_batch_begin(AsciiUpload &u, int device, const char *seq, const char *qual, const int64_t *offsets, int64_t first, int64_t n_reads,
-                       int min_base_qual, hipStream_t st);
+                       int min_base_qual, hipStream_t st, bool want_rnz = false /* also build rb_batch::rnz (all-window hashing of raw strings) */);
 rb_batch *ascii_batch_finish(AsciiUpload &u);
 void ascii_batch_abort(AsciiUpload &u);
 

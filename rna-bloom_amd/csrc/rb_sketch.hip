@@ -8,7 +8,7 @@ namespace {
 
 // ntHash of EVERY window of a read (no segmentation): unusable bases contribute seed 0, exactly like
 // the zero rows of seedTab (R/bloom/hash/NTHash.java:133-166).  mode 0 forward, 1 canonical, 2 RC.
-__global__ void k_hash_all(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
+__global__ void k_hash_all(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid, const uint32_t *__restrict__ rnz,
                            const uint32_t *__restrict__ word_read, const uint32_t *__restrict__ woff,
                            const uint32_t *__restrict__ len, int64_t n_words, int k, int mode,
                            const int64_t *__restrict__ koff, uint64_t *__restrict__ out) {
@@ -21,18 +21,19 @@ __global__ void k_hash_all(const uint64_t *__restrict__ codes, const uint32_t *_
     const uint32_t bend = bend64 < L ? (uint32_t)bend64 : L;
     const uint64_t *cw = codes + wr;
     const uint32_t *vw = valid + wr;
+    const uint32_t *zw = rnz ? rnz + wr : vw;      // reverse-strand seed by `ch & 7`: non-zero for some letters outside ACGTU (rb_batch::rnz)
     uint64_t f = 0, rv = 0;
     uint32_t filled = 0;
     for (uint32_t b = b0; b < bend; ++b) {
-        const bool ok = (vw[b >> 5] >> (b & 31u)) & 1u;
+        const bool ok = (vw[b >> 5] >> (b & 31u)) & 1u, rok = (zw[b >> 5] >> (b & 31u)) & 1u;
         const uint32_t c = (uint32_t)(cw[b >> 5] >> (2u * (b & 31u))) & 3u;
-        const uint64_t s_in = ok ? seed_of(c) : 0ull, sc_in = ok ? seed_of(3u - c) : 0ull;
+        const uint64_t s_in = ok ? seed_of(c) : 0ull, sc_in = rok ? seed_of(3u - c) : 0ull;
         if (filled < uk) { f = rotl(f, 1) ^ s_in; rv ^= rotl(sc_in, filled); ++filled; }
         else {
             const uint32_t bo = b - uk;
-            const bool oko = (vw[bo >> 5] >> (bo & 31u)) & 1u;
+            const bool oko = (vw[bo >> 5] >> (bo & 31u)) & 1u, roko = (zw[bo >> 5] >> (bo & 31u)) & 1u;
             const uint32_t oc = (uint32_t)(cw[bo >> 5] >> (2u * (bo & 31u))) & 3u;
-            const uint64_t s_out = oko ? seed_of(oc) : 0ull, sc_out = oko ? seed_of(3u - oc) : 0ull;
+            const uint64_t s_out = oko ? seed_of(oc) : 0ull, sc_out = roko ? seed_of(3u - oc) : 0ull;
             f = rotl(f, 1) ^ rotl(s_out, uk) ^ s_in;
             rv = rotr(rv, 1) ^ rotr(sc_out, 1) ^ rotl(sc_in, uk - 1u);
         }
@@ -203,6 +204,228 @@ __global__ void k_strobe3(const uint64_t *__restrict__ hf, const uint64_t *__res
     if (out_pos) { out_pos[3 * t] = (int32_t)p1; out_pos[3 * t + 1] = (int32_t)pos; out_pos[3 * t + 2] = (int32_t)p3; }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Tile kernels (the ones the entry points use; the one-thread-per-output kernels above remain for windows too wide for LDS).
+//
+// A workgroup takes SK_TILE consecutive outputs of ONE read (host-built tile list: a read of c outputs has ceil(c / SK_TILE)
+// tiles), stages the k-mer hashes the tile's windows cover in LDS once (coalesced 8-byte loads: TILE + window span values,
+// instead of every thread walking its 50-120 window values through the vector caches), and every lane works on SK_PER
+// outputs, lane l on outputs l, l + 256, ...: in step i of a window scan the 64 lanes of a wavefront read 64 CONSECUTIVE LDS
+// words (conflict free).  The scan itself is the reference's loop: an argmin of combine(...) whose left operand differs
+// from strobemer to strobemer, so there is no sliding-window shortcut — W combine + compare steps per window are the
+// algorithmic work; a lane-per-strobemer loop does them at ~10 VALU instructions per step, a wavefront-wide reduction per
+// strobemer would cost 6 DPP rounds of the same comparison for every window (more instructions, not fewer).
+// combine(a, b) = a ^ (b + C + (a << 6) + (b >>> 2)) (HashFunction.java:260-263) is split into the part that depends on the
+// window value only, g(b) = b + (b >>> 2), staged in LDS next to b, and the per-strobemer constant C + (a << 6).
+constexpr int SK_TPB = 256, SK_PER = 4, SK_TILE = SK_TPB * SK_PER;
+struct SkTile { uint32_t read, first; };
+constexpr uint64_t SK_C = 0xFFFFFFFF9E3779B9ull;     // the sign-extended int literal of combineHashValues
+__device__ __forceinline__ uint64_t sk_g(uint64_t b) { return b + (b >> 2); }
+
+// StrobeHashIterator.next / get / getInterval and CanonicalStrobeHashIterator.next / get (see k_randstrobes above).
+// out_pos: n positions per strobemer, or out_start / out_end (getInterval's interval), or neither.
+// get / getInterval slide the chosen strobe across later EQUAL k-mer hashes (:96-164); an equal k-mer hash gives an equal
+// combined hash, which the `>=` of the comparison takes anyway — same strobe, same hash as next() — so one loop serves all.
+// The scan of a window that lies inside the read runs on the HIGH 32 bits of the combined hashes (7 VALU instructions per
+// candidate instead of 9-10: add with carry, xor, compare, two selects, equality); two candidates that agree in those 32 bits
+// (equal k-mers, or once in 2^32 / W otherwise) send the lane to the exact 64-bit loop for that window.
+__global__ void __launch_bounds__(SK_TPB) k_randstrobes_tile(const uint64_t *__restrict__ hf, const uint64_t *__restrict__ hr, const int64_t *__restrict__ koff,
+                                                             const int64_t *__restrict__ soff, const SkTile *__restrict__ tiles, int n, int wmin, int wmax,
+                                                             int canonical, int k, uint64_t *__restrict__ out_hash, int32_t *__restrict__ out_pos,
+                                                             int32_t *__restrict__ out_start, int32_t *__restrict__ out_end) {
+    extern __shared__ uint64_t sk_lds[];
+    const SkTile tl = tiles[blockIdx.x];
+    const int64_t kb = koff[tl.read], ob = soff[tl.read];
+    const int nk = (int)(koff[tl.read + 1] - kb), cnt = (int)(soff[tl.read + 1] - ob);
+    const int t0 = (int)tl.first, n_here = min(SK_TILE, cnt - t0), span = wmax * (n - 1);
+    const int n_stage = min(n_here + span, nk - t0);                 // k-mers [t0, t0 + n_stage) of the read
+    uint64_t *s_f = sk_lds, *s_g = sk_lds + (SK_TILE + span), *s_r = s_g + (SK_TILE + span);
+    for (int i = threadIdx.x; i < n_stage; i += SK_TPB) {
+        const uint64_t v = hf[kb + t0 + i];
+        s_f[i] = v; s_g[i] = sk_g(v);
+        if (canonical) s_r[i] = hr[kb + t0 + i];
+    }
+    __syncthreads();
+    const int lim = nk - t0;                                          // local index bound of the read's k-mers
+    const int wn = wmax - wmin;                                       // candidates of a window that is not cut by the read's end
+    for (int j = 0; j < SK_PER; ++j) {
+        const int t = (int)threadIdx.x + j * SK_TPB;                  // local index of the strobemer's own k-mer
+        if (t >= n_here) break;
+        uint64_t sh = s_f[t];
+        int pos[RB_MAX_STROBES];
+        pos[0] = t;
+#pragma unroll
+        for (int s = 0; s < RB_MAX_STROBES - 1; ++s) {
+            pos[s + 1] = 0;
+            if (s < n - 1) {
+                const int lo = t + s * wmax + wmin;
+                const uint64_t a1 = SK_C + (sh << 6);
+                int pos2 = lo;
+                uint64_t hv = sh ^ (s_g[lo] + a1);
+                bool exact = true;
+                if (__all(lo + wn <= lim)) {                          // the whole wavefront's windows are complete: uniform trip count
+                    const uint32_t shh = (uint32_t)(sh >> 32);
+                    uint32_t best = (uint32_t)(hv >> 32);
+                    bool amb = false;
+#pragma unroll 8
+                    for (int i = 1; i < wn; ++i) {
+                        const uint32_t x = shh ^ (uint32_t)((s_g[lo + i] + a1) >> 32);
+                        amb |= x == best;
+                        if (x <= best) { best = x; pos2 = lo + i; }
+                    }
+                    if (!amb) { hv = sh ^ (s_g[pos2] + a1); exact = false; }
+                    else pos2 = lo;
+                }
+                if (exact) {
+                    const int end = min(lo + wn, lim);
+                    for (int i = lo + 1; i < end; ++i) {
+                        const uint64_t h2 = sh ^ (s_g[i] + a1);
+                        if (hv >= h2) { pos2 = i; hv = h2; }          // Long.compareUnsigned(h, h2) >= 0
+                    }
+                }
+                sh = hv;
+                pos[s + 1] = pos2;
+            }
+        }
+        if (canonical) {                                              // reverse hashes of the same positions, combined back to front (:99-107)
+            uint64_t rs = 0;
+#pragma unroll
+            for (int s = RB_MAX_STROBES - 1; s >= 0; --s)
+                if (s < n) rs = (s == n - 1) ? s_r[pos[s]] : combine(s_r[pos[s]], rs);
+            sh = smin(sh, rs);
+        }
+        const int64_t o = ob + t0 + t;
+        out_hash[o] = sh;
+        if (out_pos) {
+#pragma unroll
+            for (int s = 0; s < RB_MAX_STROBES; ++s) if (s < n) out_pos[o * n + s] = pos[s] + t0;
+        }
+        if (out_start) {
+            int last = t;
+#pragma unroll
+            for (int s = 1; s < RB_MAX_STROBES; ++s) if (s < n) last = pos[s];
+            out_start[o] = t + t0;
+            out_end[o] = last + t0 + k - 1;
+        }
+    }
+}
+
+// Strobe3HashIterator / CanonicalStrobe3HashIterator (see k_strobe3 above) on LDS-staged hashes: the tile's middle k-mers are
+// pos = off + t0 .. , their windows cover k-mers [pos - wmax + 1, pos + wmax).
+__global__ void __launch_bounds__(SK_TPB) k_strobe3_tile(const uint64_t *__restrict__ hf, const uint64_t *__restrict__ hr, const int64_t *__restrict__ koff,
+                                                         const int64_t *__restrict__ soff, const SkTile *__restrict__ tiles, int wmin, int wmax, int canonical,
+                                                         uint64_t *__restrict__ out_hash, int32_t *__restrict__ out_pos) {
+    extern __shared__ uint64_t sk_lds[];
+    const SkTile tl = tiles[blockIdx.x];
+    const int64_t kb = koff[tl.read], ob = soff[tl.read];
+    const int nk = (int)(koff[tl.read + 1] - kb), cnt = (int)(soff[tl.read + 1] - ob);
+    const int t0 = (int)tl.first, n_here = min(SK_TILE, cnt - t0), off = canonical ? wmax : wmin;
+    const int base = max(0, t0 + off - wmax + 1);                     // first staged k-mer
+    const int n_stage = min(nk, t0 + off + n_here - 1 + wmax) - base;
+    const int cap = SK_TILE + 2 * wmax;
+    uint64_t *s_f = sk_lds, *s_g = sk_lds + cap, *s_r = s_g + cap;
+    for (int i = threadIdx.x; i < n_stage; i += SK_TPB) {
+        const uint64_t v = hf[kb + base + i];
+        s_f[i] = v; s_g[i] = sk_g(v);
+        if (canonical) s_r[i] = hr[kb + base + i];
+    }
+    __syncthreads();
+    for (int j = 0; j < SK_PER; ++j) {
+        const int t = (int)threadIdx.x + j * SK_TPB;
+        if (t >= n_here) break;
+        const int pos = t0 + t + off;                                 // k-mer position in the read
+        const int lp = pos - base;                                    // its LDS index
+        // upstream strobe: argmin of combine(f[i], fk) over [max(0, pos - wmax + 1), pos - wmin], strict (leftmost of equals)
+        int p1 = max(pos - wmax + 1, 0) - base;
+        const uint64_t b1 = s_g[lp] + SK_C;                           // fk + C + (fk >>> 2)
+        uint64_t h1; { const uint64_t a = s_f[p1]; h1 = a ^ (b1 + (a << 6)); }
+        for (int i = p1 + 1; i <= lp - wmin; ++i) { const uint64_t a = s_f[i]; const uint64_t h = a ^ (b1 + (a << 6)); if (h1 > h) { p1 = i; h1 = h; } }
+        // downstream strobe: argmin of combine(h1, f[i]) over [pos + wmin, min(pos + wmax, nk)), rightmost of equals when canonical
+        int p3 = lp + wmin;
+        const uint64_t a1 = SK_C + (h1 << 6);
+        uint64_t h3 = h1 ^ (s_g[p3] + a1);
+        const int end = min(pos + wmax, nk) - base;
+        if (canonical) { for (int i = p3 + 1; i < end; ++i) { const uint64_t h = h1 ^ (s_g[i] + a1); if (h3 >= h) { p3 = i; h3 = h; } } }
+        else { for (int i = p3 + 1; i < end; ++i) { const uint64_t h = h1 ^ (s_g[i] + a1); if (h3 > h) { p3 = i; h3 = h; } } }
+        uint64_t hv = h3;
+        if (canonical) {                                              // the reverse strand's chain: downstream first, then upstream (:118-143)
+            const uint64_t rk = s_r[lp];
+            int q3 = lp + wmin;
+            const uint64_t rb = rk + SK_C + (rk >> 2);
+            uint64_t rh3; { const uint64_t a = s_r[q3]; rh3 = a ^ (rb + (a << 6)); }
+            for (int i = q3 + 1; i < end; ++i) { const uint64_t a = s_r[i]; const uint64_t h = a ^ (rb + (a << 6)); if (rh3 >= h) { q3 = i; rh3 = h; } }
+            int q1 = max(pos - wmax + 1, 0) - base;
+            const uint64_t ra = SK_C + (rh3 << 6);
+            uint64_t rh1 = rh3 ^ (sk_g(s_r[q1]) + ra);
+            for (int i = q1 + 1; i <= lp - wmin; ++i) { const uint64_t h = rh3 ^ (sk_g(s_r[i]) + ra); if (rh1 > h) { q1 = i; rh1 = h; } }
+            if (h3 > rh1) { hv = rh1; p1 = q1; p3 = q3; }
+        }
+        const int64_t o = ob + t0 + t;
+        out_hash[o] = hv;
+        if (out_pos) { out_pos[3 * o] = p1 + base; out_pos[3 * o + 1] = pos; out_pos[3 * o + 2] = p3 + base; }
+    }
+}
+
+// Window minimizers, parallel over windows and still the exact replay of LongRollingWindow: the VALUE of a window is its signed
+// minimum whatever happened before; its POSITION is history-free too whenever the minimum occurs once in the window (the
+// buffer's min_index can only point at a slot holding the minimum) and in window 0 (array order = position order: leftmost).
+// Only windows in which the minimum occurs at two or more positions depend on the history (a new value replaces the minimum
+// only if strictly smaller, :55-57; a minimum that leaves is replaced by the first in SLOT order, :60-69).  Pass 1 (this
+// kernel): value, leftmost position and a tie flag per window.  Pass 2 (k_minimizer_ties): every maximal run of tied windows
+// is replayed by one lane from the tie-free window in front of it, whose state is known.
+__global__ void __launch_bounds__(SK_TPB) k_minimizers_tile(const uint64_t *__restrict__ h, const int64_t *__restrict__ koff, const int64_t *__restrict__ moff,
+                                                            const SkTile *__restrict__ tiles, int w, uint64_t *__restrict__ out_hash,
+                                                            int64_t *__restrict__ out_pos, uint8_t *__restrict__ tie) {
+    extern __shared__ uint64_t sk_lds[];
+    const SkTile tl = tiles[blockIdx.x];
+    const int64_t kb = koff[tl.read], ob = moff[tl.read];
+    const int cnt = (int)(moff[tl.read + 1] - ob);
+    const int t0 = (int)tl.first, n_here = min(SK_TILE, cnt - t0), n_stage = n_here + w - 1;
+    for (int i = threadIdx.x; i < n_stage; i += SK_TPB) sk_lds[i] = h[kb + t0 + i];
+    __syncthreads();
+    for (int j = 0; j < SK_PER; ++j) {
+        const int t = (int)threadIdx.x + j * SK_TPB;
+        if (t >= n_here) break;
+        int64_t mv = (int64_t)sk_lds[t];
+        int mp = t; bool tied = false;
+        for (int i = 1; i < w; ++i) {
+            const int64_t v = (int64_t)sk_lds[t + i];
+            if (v < mv) { mv = v; mp = t + i; tied = false; }
+            else if (v == mv) tied = true;
+        }
+        const int64_t o = ob + t0 + t;
+        out_hash[o] = (uint64_t)mv;
+        if (out_pos) out_pos[o] = (int64_t)(mp + t0);
+        tie[o] = (tied && t0 + t > 0) ? 1u : 0u;                     // window 0 reports the leftmost minimum
+    }
+}
+// one lane per window; the head of a run of tied windows replays the run
+__global__ void k_minimizer_ties(const uint64_t *__restrict__ h, const int64_t *__restrict__ koff, const int64_t *__restrict__ moff, int64_t n_reads,
+                                 int64_t total, int w, const uint8_t *__restrict__ tie, int64_t *__restrict__ out_pos) {
+    const int64_t o = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= total || !tie[o]) return;
+    int64_t lo = 0, hi = n_reads;
+    while (hi - lo > 1) { int64_t mid = (lo + hi) >> 1; if (moff[mid] <= o) lo = mid; else hi = mid; }
+    const int64_t p0 = o - moff[lo], nwin = moff[lo + 1] - moff[lo];
+    if (p0 > 0 && tie[o - 1]) return;                                // not the head of its run (window 0 is never tied)
+    const uint64_t *hh = h + koff[lo];
+    int64_t *op = out_pos + moff[lo];
+    int64_t cur = op[p0 - 1];                                         // tie-free window (or window 0): min_index is its unique / leftmost minimum
+    for (int64_t q = p0; q < nwin && tie[moff[lo] + q]; ++q) {
+        const int64_t e = q + w - 1;                                  // the k-mer rolled in
+        if (cur == q - 1) {                                           // the minimum is overwritten: rescan in slot order, strictly smaller wins (:60-69)
+            int64_t best = -1, bv = 0;
+            for (int sl = 0; sl < w; ++sl) {
+                int64_t d = ((int64_t)sl - q) % w; if (d < 0) d += w;  // the window's k-mer in slot sl
+                const int64_t x = (int64_t)hh[q + d];
+                if (best < 0 || x < bv) { bv = x; best = q + d; }
+            }
+            cur = best;
+        } else if ((int64_t)hh[e] < (int64_t)hh[cur]) cur = e;
+        op[q] = cur;
+    }
+}
+
 // SeqSubsampler.kmerBased pair hashes (R/util/SeqSubsampler.java:176-179, 266-268)
 __global__ void k_kmer_pairs(const uint64_t *__restrict__ hf, const uint64_t *__restrict__ hr, const int64_t *__restrict__ koff,
                              const int64_t *__restrict__ poff, int64_t n_reads, int64_t total, int shift, int canonical,
@@ -284,6 +507,39 @@ __global__ void k_unique_compact(const uint64_t *__restrict__ read, const uint64
 
 struct BatchGuard { rb_batch *b; ~BatchGuard() { if (b) rb_batch_destroy(b); } };
 
+// tile list of the tile kernels: read r with c = off[r+1] - off[r] outputs gets ceil(c / SK_TILE) tiles
+void make_tiles(const int64_t *off, int64_t n_reads, DevBuf &d_tiles, uint32_t *n_tiles) {
+    std::vector<SkTile> tiles;
+    tiles.reserve((size_t)(off[n_reads] / SK_TILE + n_reads));
+    for (int64_t r = 0; r < n_reads; ++r)
+        for (int64_t f = 0; f < off[r + 1] - off[r]; f += SK_TILE) tiles.push_back({(uint32_t)r, (uint32_t)f});
+    RB_REQUIRE(tiles.size() < 0x7FFFFFFFull, "sketch: too many tiles in one call");
+    *n_tiles = (uint32_t)tiles.size();
+    d_tiles.reserve(std::max<size_t>(tiles.size(), 1) * sizeof(SkTile));
+    if (!tiles.empty()) RB_HIP(hipMemcpy(d_tiles.p, tiles.data(), tiles.size() * sizeof(SkTile), hipMemcpyHostToDevice));
+}
+constexpr size_t SK_LDS_MAX = 60 * 1024;      // windows wider than this fall back to the one-thread-per-output kernels
+bool sk_force_simple() { const char *e = getenv("RB_SKETCH_SIMPLE"); return e && atoi(e) != 0; }
+// window minimizers of all reads: d_h = all-window hashes, d_moff = per-read window offsets (device), moff = the same on the host
+void launch_minimizers(const uint64_t *d_h, const int64_t *d_koff, const int64_t *d_moff, const int64_t *moff, int64_t n_reads, int64_t total, int w,
+                       uint64_t *d_oh, int64_t *d_op) {
+    const size_t lds = ((size_t)SK_TILE + (size_t)w) * 8;
+    if (lds > SK_LDS_MAX || sk_force_simple() || !d_op) {
+        hipLaunchKernelGGL(k_minimizers, dim3(blocks_for(n_reads, 64)), dim3(64), 0, 0, d_h, d_koff, d_moff, n_reads, total, w, d_oh, d_op);
+        RB_HIP(hipGetLastError());
+        return;
+    }
+    DevBuf d_tiles, d_tie;
+    struct Rel { DevBuf *a, *b; ~Rel() { a->release(); b->release(); } } rel{&d_tiles, &d_tie};
+    uint32_t nt = 0;
+    make_tiles(moff, n_reads, d_tiles, &nt);
+    d_tie.reserve((size_t)total + 8);
+    hipLaunchKernelGGL(k_minimizers_tile, dim3(nt), dim3(SK_TPB), lds, 0, d_h, d_koff, d_moff, d_tiles.as<SkTile>(), w, d_oh, d_op, d_tie.as<uint8_t>());
+    hipLaunchKernelGGL(k_minimizer_ties, dim3(blocks_for(total)), dim3(TPB), 0, 0, d_h, d_koff, d_moff, n_reads, total, w, d_tie.as<uint8_t>(), d_op);
+    RB_HIP(hipGetLastError());
+    RB_HIP(hipDeviceSynchronize());           // d_tiles / d_tie are released on return
+}
+
 // all-window hashes of a set of reads; returns device buffer h (caller releases) and host koff
 void hash_all(int device, const char *seq, const int64_t *offsets, int64_t n_reads, int k, int mode, std::vector<int64_t> &koff,
               DevBuf &d_koff, DevBuf &d_h) {
@@ -295,13 +551,16 @@ void hash_all(int device, const char *seq, const int64_t *offsets, int64_t n_rea
     const int64_t total = koff[(size_t)n_reads];
     if (!total) return;
     rb_batch *b = nullptr;
-    int rc = rb_batch_create_ascii(device, seq, nullptr, offsets, n_reads, 0, &b);
-    if (rc != RB_OK) throw HipError{rc};
+    {
+        rb::AsciiUpload up;
+        try { rb::ascii_batch_begin(up, device, seq, nullptr, offsets, 0, n_reads, 0, nullptr, true); b = rb::ascii_batch_finish(up); }
+        catch (...) { rb::ascii_batch_abort(up); throw; }
+    }
     BatchGuard guard{b};
     d_koff.reserve(((size_t)n_reads + 1) * 8);
     d_h.reserve((size_t)total * 8);
     RB_HIP(hipMemcpy(d_koff.p, koff.data(), ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_hash_all, dim3(blocks_for(b->n_words)), dim3(TPB), 0, 0, b->codes, b->valid, b->word_read, b->woff, b->len,
+    hipLaunchKernelGGL(k_hash_all, dim3(blocks_for(b->n_words)), dim3(TPB), 0, 0, b->codes, b->valid, b->rnz, b->word_read, b->woff, b->len,
                        b->n_words, k, mode, d_koff.as<int64_t>(), d_h.as<uint64_t>());
     RB_HIP(hipGetLastError());
     RB_HIP(hipDeviceSynchronize());
@@ -330,9 +589,7 @@ int rb_minimizers(int device, const char *seq, const int64_t *offsets, int64_t n
         hash_all(device, seq, offsets, n_reads, k, mode, koff, d_koff, d_h);
         d_moff.reserve(((size_t)n_reads + 1) * 8); d_oh.reserve((size_t)total * 8); d_op.reserve((size_t)total * 8);
         RB_HIP(hipMemcpy(d_moff.p, moffsets, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(k_minimizers, dim3(blocks_for(n_reads, 64)), dim3(64), 0, 0, d_h.as<uint64_t>(), d_koff.as<int64_t>(), d_moff.as<int64_t>(),
-                           n_reads, total, w, d_oh.as<uint64_t>(), d_op.as<int64_t>());
-        RB_HIP(hipGetLastError());
+        launch_minimizers(d_h.as<uint64_t>(), d_koff.as<int64_t>(), d_moff.as<int64_t>(), moffsets, n_reads, total, w, d_oh.as<uint64_t>(), d_op.as<int64_t>());
         RB_HIP(hipMemcpy(out_hash, d_oh.p, (size_t)total * 8, hipMemcpyDeviceToHost));
         if (out_pos) RB_HIP(hipMemcpy(out_pos, d_op.p, (size_t)total * 8, hipMemcpyDeviceToHost));
     });
@@ -340,8 +597,8 @@ int rb_minimizers(int device, const char *seq, const int64_t *offsets, int64_t n
 
 int rb_strobemers(int device, const char *seq, const int64_t *offsets, int64_t n_reads, int k, int n, int wmin, int wmax, int64_t *soffsets,
                   uint64_t *out_hash, int32_t *out_start, int32_t *out_end) {
-    DevBuf d_koff, d_h, d_soff, d_oh, d_os, d_oe;
-    struct Rel { DevBuf *b[6]; ~Rel() { for (auto x : b) x->release(); } } rel{{&d_koff, &d_h, &d_soff, &d_oh, &d_os, &d_oe}};
+    DevBuf d_koff, d_h, d_soff, d_oh, d_os, d_oe, d_tiles;
+    struct Rel { DevBuf *b[7]; ~Rel() { for (auto x : b) x->release(); } } rel{{&d_koff, &d_h, &d_soff, &d_oh, &d_os, &d_oe, &d_tiles}};
     return guarded([&] {
         RB_REQUIRE(offsets && soffsets && n_reads >= 0 && k >= 1 && k <= RB_MAX_K && n >= 2 && wmin >= 1 && wmax >= wmin, "rb_strobemers: bad argument");
         RB_HIP(hipSetDevice(device));
@@ -358,8 +615,16 @@ int rb_strobemers(int device, const char *seq, const int64_t *offsets, int64_t n
         hash_all(device, seq, offsets, n_reads, k, 0, koff, d_koff, d_h);
         d_soff.reserve(((size_t)n_reads + 1) * 8); d_oh.reserve((size_t)total * 8); d_os.reserve((size_t)total * 4); d_oe.reserve((size_t)total * 4);
         RB_HIP(hipMemcpy(d_soff.p, soffsets, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(k_strobemers, dim3(blocks_for(total)), dim3(TPB), 0, 0, d_h.as<uint64_t>(), d_koff.as<int64_t>(), d_soff.as<int64_t>(),
-                           n_reads, total, k, n, wmin, wmax, d_oh.as<uint64_t>(), d_os.as<int32_t>(), d_oe.as<int32_t>());
+        const size_t lds = ((size_t)SK_TILE + (size_t)wmax * (size_t)(n - 1)) * 16;
+        if (lds > SK_LDS_MAX || n > RB_MAX_STROBES || sk_force_simple())
+            hipLaunchKernelGGL(k_strobemers, dim3(blocks_for(total)), dim3(TPB), 0, 0, d_h.as<uint64_t>(), d_koff.as<int64_t>(), d_soff.as<int64_t>(),
+                               n_reads, total, k, n, wmin, wmax, d_oh.as<uint64_t>(), d_os.as<int32_t>(), d_oe.as<int32_t>());
+        else {
+            uint32_t nt = 0;
+            make_tiles(soffsets, n_reads, d_tiles, &nt);
+            hipLaunchKernelGGL(k_randstrobes_tile, dim3(nt), dim3(SK_TPB), lds, 0, d_h.as<uint64_t>(), (const uint64_t *)nullptr, d_koff.as<int64_t>(),
+                               d_soff.as<int64_t>(), d_tiles.as<SkTile>(), n, wmin, wmax, 0, k, d_oh.as<uint64_t>(), (int32_t *)nullptr, d_os.as<int32_t>(), d_oe.as<int32_t>());
+        }
         RB_HIP(hipGetLastError());
         RB_HIP(hipMemcpy(out_hash, d_oh.p, (size_t)total * 8, hipMemcpyDeviceToHost));
         if (out_start) RB_HIP(hipMemcpy(out_start, d_os.p, (size_t)total * 4, hipMemcpyDeviceToHost));
@@ -393,8 +658,8 @@ extern "C" {
 
 int rb_randstrobes(int device, const char *seq, const int64_t *offsets, int64_t n_reads, int k, int n, int wmin, int wmax, int flags,
                    rb_graph *count_in, int64_t *soffsets, uint64_t *out_hash, int32_t *out_pos, float *out_count) {
-    DevBuf d_koff, d_f, d_r, d_soff, d_oh, d_op, d_cnt;
-    Bufs rel{{&d_koff, &d_f, &d_r, &d_soff, &d_oh, &d_op, &d_cnt}};
+    DevBuf d_koff, d_f, d_r, d_soff, d_oh, d_op, d_cnt, d_tiles;
+    Bufs rel{{&d_koff, &d_f, &d_r, &d_soff, &d_oh, &d_op, &d_cnt, &d_tiles}};
     return guarded([&] {
         RB_REQUIRE(offsets && soffsets && n_reads >= 0 && k >= 1 && k <= RB_MAX_K && n >= 2 && n <= RB_MAX_STROBES && wmin >= 1 && wmax >= wmin,
                    "rb_randstrobes: bad argument");
@@ -411,8 +676,18 @@ int rb_randstrobes(int device, const char *seq, const int64_t *offsets, int64_t 
         d_soff.reserve(((size_t)n_reads + 1) * 8); d_oh.reserve((size_t)total * 8);
         if (out_pos) d_op.reserve((size_t)total * 4 * (size_t)n);
         RB_HIP(hipMemcpy(d_soff.p, soffsets, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(k_randstrobes, dim3(blocks_for(total)), dim3(TPB), 0, 0, d_f.as<uint64_t>(), d_r.as<uint64_t>(), d_koff.as<int64_t>(),
-                           d_soff.as<int64_t>(), n_reads, total, n, wmin, wmax, flags, d_oh.as<uint64_t>(), out_pos ? d_op.as<int32_t>() : nullptr);
+        const bool canon = (flags & RB_STROBE_CANONICAL) != 0, slide = (flags & RB_STROBE_SLIDE) && !canon;
+        const size_t lds = ((size_t)SK_TILE + (size_t)wmax * (size_t)(n - 1)) * (canon ? 24 : 16);
+        if (lds > SK_LDS_MAX || sk_force_simple())
+            hipLaunchKernelGGL(k_randstrobes, dim3(blocks_for(total)), dim3(TPB), 0, 0, d_f.as<uint64_t>(), d_r.as<uint64_t>(), d_koff.as<int64_t>(),
+                               d_soff.as<int64_t>(), n_reads, total, n, wmin, wmax, flags, d_oh.as<uint64_t>(), out_pos ? d_op.as<int32_t>() : nullptr);
+        else {
+            uint32_t nt = 0;
+            make_tiles(soffsets, n_reads, d_tiles, &nt);
+            (void)slide;                   // get()'s sliding across equal k-mer hashes is what `>=` does anyway (see the kernel)
+            hipLaunchKernelGGL(k_randstrobes_tile, dim3(nt), dim3(SK_TPB), lds, 0, d_f.as<uint64_t>(), d_r.as<uint64_t>(), d_koff.as<int64_t>(), d_soff.as<int64_t>(),
+                               d_tiles.as<SkTile>(), n, wmin, wmax, canon ? 1 : 0, k, d_oh.as<uint64_t>(), out_pos ? d_op.as<int32_t>() : nullptr, (int32_t *)nullptr, (int32_t *)nullptr);
+        }
         RB_HIP(hipGetLastError());
         RB_HIP(hipMemcpy(out_hash, d_oh.p, (size_t)total * 8, hipMemcpyDeviceToHost));
         if (out_pos) RB_HIP(hipMemcpy(out_pos, d_op.p, (size_t)total * 4 * (size_t)n, hipMemcpyDeviceToHost));
@@ -422,8 +697,8 @@ int rb_randstrobes(int device, const char *seq, const int64_t *offsets, int64_t 
 
 int rb_strobe3(int device, const char *seq, const int64_t *offsets, int64_t n_reads, int k, int wmin, int wmax, int canonical,
                rb_graph *count_in, int64_t *soffsets, uint64_t *out_hash, int32_t *out_pos, float *out_count) {
-    DevBuf d_koff, d_f, d_r, d_soff, d_oh, d_op, d_cnt;
-    Bufs rel{{&d_koff, &d_f, &d_r, &d_soff, &d_oh, &d_op, &d_cnt}};
+    DevBuf d_koff, d_f, d_r, d_soff, d_oh, d_op, d_cnt, d_tiles;
+    Bufs rel{{&d_koff, &d_f, &d_r, &d_soff, &d_oh, &d_op, &d_cnt, &d_tiles}};
     return guarded([&] {
         RB_REQUIRE(offsets && soffsets && n_reads >= 0 && k >= 1 && k <= RB_MAX_K && wmin >= 1 && wmax >= wmin, "rb_strobe3: bad argument");
         RB_HIP(hipSetDevice(device));
@@ -440,8 +715,16 @@ int rb_strobe3(int device, const char *seq, const int64_t *offsets, int64_t n_re
         d_soff.reserve(((size_t)n_reads + 1) * 8); d_oh.reserve((size_t)total * 8);
         if (out_pos) d_op.reserve((size_t)total * 12);
         RB_HIP(hipMemcpy(d_soff.p, soffsets, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(k_strobe3, dim3(blocks_for(total)), dim3(TPB), 0, 0, d_f.as<uint64_t>(), d_r.as<uint64_t>(), d_koff.as<int64_t>(),
-                           d_soff.as<int64_t>(), n_reads, total, wmin, wmax, canonical, d_oh.as<uint64_t>(), out_pos ? d_op.as<int32_t>() : nullptr);
+        const size_t lds = ((size_t)SK_TILE + 2 * (size_t)wmax) * (canonical ? 24 : 16);
+        if (lds > SK_LDS_MAX || sk_force_simple())
+            hipLaunchKernelGGL(k_strobe3, dim3(blocks_for(total)), dim3(TPB), 0, 0, d_f.as<uint64_t>(), d_r.as<uint64_t>(), d_koff.as<int64_t>(),
+                               d_soff.as<int64_t>(), n_reads, total, wmin, wmax, canonical, d_oh.as<uint64_t>(), out_pos ? d_op.as<int32_t>() : nullptr);
+        else {
+            uint32_t nt = 0;
+            make_tiles(soffsets, n_reads, d_tiles, &nt);
+            hipLaunchKernelGGL(k_strobe3_tile, dim3(nt), dim3(SK_TPB), lds, 0, d_f.as<uint64_t>(), d_r.as<uint64_t>(), d_koff.as<int64_t>(), d_soff.as<int64_t>(),
+                               d_tiles.as<SkTile>(), wmin, wmax, canonical ? 1 : 0, d_oh.as<uint64_t>(), out_pos ? d_op.as<int32_t>() : nullptr);
+        }
         RB_HIP(hipGetLastError());
         RB_HIP(hipMemcpy(out_hash, d_oh.p, (size_t)total * 8, hipMemcpyDeviceToHost));
         if (out_pos) RB_HIP(hipMemcpy(out_pos, d_op.p, (size_t)total * 12, hipMemcpyDeviceToHost));
@@ -488,9 +771,7 @@ static int64_t window_minimizers(int device, const char *seq, const int64_t *off
     if (!total) return 0;
     d_woff.reserve(((size_t)n_reads + 1) * 8); d_mh.reserve((size_t)total * 8); d_mp.reserve((size_t)total * 8);
     RB_HIP(hipMemcpy(d_woff.p, woff.data(), ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(k_minimizers, dim3(blocks_for(n_reads, 64)), dim3(64), 0, 0, d_h.as<uint64_t>(), d_koff.as<int64_t>(), d_woff.as<int64_t>(),
-                       n_reads, total, w, d_mh.as<uint64_t>(), d_mp.as<int64_t>());
-    RB_HIP(hipGetLastError());
+    launch_minimizers(d_h.as<uint64_t>(), d_koff.as<int64_t>(), d_woff.as<int64_t>(), woff.data(), n_reads, total, w, d_mh.as<uint64_t>(), d_mp.as<int64_t>());
     return total;
 }
 

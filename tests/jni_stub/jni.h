@@ -6,7 +6,7 @@
 #include <stdint.h>
 typedef int32_t jint; typedef int64_t jlong; typedef int8_t jbyte; typedef uint8_t jboolean; typedef float jfloat; typedef jint jsize;
 struct _jobject; typedef struct _jobject *jobject;
-typedef jobject jclass; typedef jobject jarray; typedef jarray jlongArray; typedef jarray jbyteArray; typedef jarray jfloatArray; typedef jarray jintArray;
+typedef jobject jclass; typedef jobject jstring; typedef jobject jarray; typedef jarray jlongArray; typedef jarray jbyteArray; typedef jarray jfloatArray; typedef jarray jintArray;
 #define JNIEXPORT __attribute__((visibility("default")))
 #define JNICALL
 #define JNI_ABORT 2
@@ -16,6 +16,8 @@ struct JNINativeInterface_ {
     jclass (*FindClass)(JNIEnv *, const char *);
     jint (*ThrowNew)(JNIEnv *, jclass, const char *);
     void *(*GetDirectBufferAddress)(JNIEnv *, jobject);
+    const char *(*GetStringUTFChars)(JNIEnv *, jstring, jboolean *);
+    void (*ReleaseStringUTFChars)(JNIEnv *, jstring, const char *);
     jsize (*GetArrayLength)(JNIEnv *, jarray);
     jlongArray (*NewLongArray)(JNIEnv *, jsize);
     void (*SetLongArrayRegion)(JNIEnv *, jlongArray, jsize, jsize, const jlong *);

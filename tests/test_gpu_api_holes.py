@@ -177,6 +177,25 @@ def test_naive_extension_and_extend_once_match_the_restatement(stranded):
                 assert (got[i], int(why[i])) == (eb, er), (direction, mode, kw, i, km)
                 reasons.add(er)
     assert {0, 1, 2, 3, 4, 5}.issubset(reasons), reasons
+    # a dead end that also has a back branch: the reference computes the neighbours first and never enters its loop
+    # (R/util/GraphUtils.java:6789-6791), so the walk ends for lack of neighbours (reason 0), not at the back branch (1)
+    acgt, rng2, dead = b"ACGT", np.random.default_rng(77), []
+    for _ in range(40):
+        x = bytes(np.frombuffer(acgt, np.uint8)[rng2.integers(0, 4, 25)])
+        xl = bytes([acgt[(acgt.index(x[0]) + 1) % 4]]) + x[1:]          # left variant: back branch of a right walk
+        xr = x[:-1] + bytes([acgt[(acgt.index(x[-1]) + 1) % 4]])        # right variant: back branch of a left walk
+        three = np.frombuffer(x + xl + xr, np.uint8)
+        og.add_reads(three, np.full(75, 73, np.uint8), np.array([0, 25, 50, 75], np.int64), 3, 0)
+        gg.addReads(three, np.full(75, 73, np.uint8), np.array([0, 25, 50, 75], np.int64), 3)
+        dead.append(x)
+    hit = 0
+    for direction in (0, 1):
+        got, why = gg.naiveExtend(dead, direction, 1, bound=5)
+        for i, km in enumerate(dead):
+            eb, er = rbo.naive_extend(og, km, direction, 1, bound=5)
+            assert (got[i], int(why[i])) == (eb, er), (direction, i, km)
+            hit += er == 0 and eb == b""
+    assert hit >= 40
     # greedyExtendRightOnce / LeftOnce = one step of the greedy extension
     clean = [km for km in seeds if b"N" not in km]
     for direction in (0, 1):

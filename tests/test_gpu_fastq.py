@@ -233,3 +233,24 @@ def test_gpu_fasta_errors_pieces_and_insert(monkeypatch):
             assert (g.exportFilter(which) == want.exportFilter(which)).all()
         g.destroy()
     want.destroy()
+
+
+def test_gpu_fastq_text_just_below_4_gib():
+    """text sizes in (0xFFFFE000, 0xFFFFFF00): the tile count used to be computed in 32 bits and wrapped to ~0 there
+    (rb_io.hip fastq_batch_create: too small a device buffer, an underflowed memset length).  One 4 GiB - 4 KiB text of
+    identical records, a record cut at the end."""
+    from rnabloom import io as RIO
+    rec = b"@r\n" + b"ACGTTGCAAGGCTTAC" * 16 + b"\n+\n" + b"I" * 256 + b"\n"          # 520 bytes, 256 bases
+    n = 0xFFFFF000
+    reps = n // len(rec) + 1
+    text = np.tile(np.frombuffer(rec, np.uint8), reps)[:n]
+    complete = n // len(rec)
+    b, used = RIO.batchFromFastq(text, final=False)
+    assert used == complete * len(rec)
+    info = b.info()
+    assert info["n_reads"] == complete and info["n_bases"] == complete * 256
+    seq, off = b.download(complete - 3, 3)
+    assert bytes(seq) == (b"ACGTTGCAAGGCTTAC" * 16) * 3 and list(off) == [0, 256, 512, 768]
+    b.close()
+    with pytest.raises(Exception, match="at most 4 GiB"):
+        RIO.batchFromFastq(np.zeros(0xFFFFFF00, np.uint8))

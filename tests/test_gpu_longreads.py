@@ -191,7 +191,7 @@ def test_nbits_files_decode_on_the_device_and_insert_like_ascii(tmp_path):
     """.nbits (R/io/NucleotideBits{Reader,Writer}.java) -> packed batch by a GPU bit permute; same filters as from ASCII"""
     from rnabloom import io as RIO
     rng = np.random.default_rng(21)
-    reads = [bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), int(L)).tolist()) for L in list(range(0, 70)) + [150] * 40 + [999, 1000, 1001, 4097]]
+    reads = [bytes(rng.choice(np.frombuffer(b"ACGT", np.uint8), int(L)).tolist()) for L in list(range(1, 70)) + [150] * 40 + [999, 1000, 1001, 4097]]
     seq, _, off = rbo.pack_reads(reads)
     RIO.writeNbits(tmp_path / "r.nbits", seq, off)
     data = (tmp_path / "r.nbits").read_bytes()
@@ -204,6 +204,12 @@ def test_nbits_files_decode_on_the_device_and_insert_like_ascii(tmp_path):
     assert b2.n_reads == len(reads) - 1 and used2 == len(data) - (4 + (4097 + 3) // 4)
     b3, _ = RIO.batchFromNbits(data, max_reads=5)
     assert b3.n_reads == 5
+    # an empty sequence ends the iteration, as in the reference: fin.read(new byte[0]) returns 0, which is not > 0, so
+    # NucleotideBitsReader.next() returns null there (R/io/NucleotideBitsReader.java:39-47)
+    s3, _, o3 = rbo.pack_reads([b"ACGTA", b"", b"GGATTCA"])
+    RIO.writeNbits(tmp_path / "e.nbits", s3, o3)
+    b4, used4 = RIO.batchFromNbits((tmp_path / "e.nbits").read_bytes())
+    assert b4.n_reads == 1 and used4 == 4 + 2 and bytes(b4.download()[0]) == b"ACGTA"
     # insert from the .nbits batch == insert from ASCII
     sizes = (600_011, 900_007, 64)
     ga = G.BloomFilterDeBruijnGraph(*sizes, 2, 2, 1, 25, False, False, rngSeed=1)
@@ -234,3 +240,114 @@ def test_sketch_calls_accept_packed_arrays_and_existing_outputs():
     of, orr, oc = np.zeros(f.size, np.uint64), np.zeros(f.size, np.uint64), np.zeros(f.size, np.float32)
     ko2, f2, r2, c2 = gg.getKmers(reads, out=(of, orr, oc))
     assert (ko2 == ko).all() and (f2 == f).all() and (r2 == r).all() and (c2 == c).all() and c.max() > 1
+
+
+def _nasty(seed, n=14, lo=90, hi=260):
+    """reads with letters outside ACGTU (reverse-strand seed by `ch & 7`, R/bloom/hash/NTHash.java:30, 133-166), homopolymers
+    and short tandem repeats (windows full of equal hashes: every tie rule matters)"""
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    out = []
+    for i in range(n):
+        L = int(rng.integers(lo, hi))
+        s = acgt[rng.integers(0, 4, L)].copy()
+        for _ in range(int(rng.integers(0, 4)) * max(1, L // 250)):
+            a = int(rng.integers(0, L - 40)); unit = acgt[rng.integers(0, 4, int(rng.integers(1, 4)))]
+            rep = np.tile(unit, 40)[:int(rng.integers(20, 40))]
+            s[a:a + rep.size] = rep[:max(0, min(rep.size, L - a))]
+        if i % 2:
+            for ch in b"KMSWYIELOQDRBHVNXacgtu":
+                for _ in range(max(1, L // 400)):
+                    if rng.random() < 0.5: s[int(rng.integers(0, L))] = ch
+        out.append(s.tobytes())
+    return out + [b"A" * 120, b"ACACACACAC" * 14, b"ACGT", b""]
+
+
+def test_three_way_sketches_hip_c_oracle_python_oracle():
+    """HIP == oracle/rb_oracle_sketch.c == oracle/rbo_py.py (written from the Java a second time, in another shape: hashes from
+    scratch, brute-force argmin, a literal LongRollingWindow) on reads where the tie rules and the `ch & 7` lookup matter"""
+    from oracle import rbo_py as P
+    reads = _nasty(3)
+    for mode in (0, 1, 2):
+        mo, h, p = G.minimizers(reads, 13, 15, mode)
+        nmo, nh, npos = G.nextMinimizers(reads, 13, 15, mode)
+        smo, sv = G.getMinimizers(reads, 13, 15, mode)
+        for i, s in enumerate(reads):
+            want = P.minimizers(s, 13, 15, mode)
+            eh, ep = rbo.minimizers(s, 13, 15, mode)
+            assert [int(x) for x in h[mo[i]:mo[i + 1]]] == [a for a, _ in want] == [int(x) for x in eh], (i, mode)
+            assert [int(x) for x in p[mo[i]:mo[i + 1]]] == [b for _, b in want] == [int(x) for x in ep], (i, mode)
+            assert list(zip([int(x) for x in nh[nmo[i]:nmo[i + 1]]], [int(x) for x in npos[nmo[i]:nmo[i + 1]]])) == P.minimizers_next(s, 13, 15, mode)
+            assert [int(x) for x in sv[smo[i]:smo[i + 1]]] == P.minimizer_set(s, 13, 15, mode)
+    so, sh, ss, se = G.strobemers(reads, 11, 3, 12, 31)
+    for i, s in enumerate(reads):
+        assert list(zip([int(x) for x in sh[so[i]:so[i + 1]]], [int(x) for x in ss[so[i]:so[i + 1]]], [int(x) for x in se[so[i]:so[i + 1]]])) == P.strobemer_intervals(s, 11, 3, 12, 31)
+    for canonical, slide in ((False, False), (False, True), (True, False)):
+        ro, rh, rp, _ = G.randstrobes(reads, 11, 3, 5, 20, canonical=canonical, slide=slide)
+        for i, s in enumerate(reads):
+            want = P.randstrobes(s, 11, 3, 5, 20, canonical)
+            assert [int(x) for x in rh[ro[i]:ro[i + 1]]] == [a for a, _ in want], (i, canonical, slide)
+            assert [list(map(int, r)) for r in rp[ro[i]:ro[i + 1]]] == [b for _, b in want]
+    for canonical in (False, True):
+        to, th, tp, _ = G.strobe3(reads, 11, 6, 25, canonical=canonical)
+        po, ph, _ = G.kmerPairHashes(reads, 13, 9, canonical=canonical)
+        for i, s in enumerate(reads):
+            want = P.strobe3(s, 11, 6, 25, canonical)
+            assert [int(x) for x in th[to[i]:to[i + 1]]] == [a for a, _ in want], (i, canonical)
+            assert [list(map(int, r)) for r in tp[to[i]:to[i + 1]]] == [b for _, b in want]
+            assert [int(x) for x in ph[po[i]:po[i + 1]]] == P.kmer_pair_hashes(s, 13, 9, canonical)
+
+
+def test_get_kmers_reproduces_the_reverse_seed_of_letters_outside_acgtu():
+    """getKmers on sequences holding K M S W Y I E L O Q D ...: the reference's reverse hash takes the complement's seed through
+    `ch & 7` (NTHash.java:30, 133-166), so such a letter hashes as a base on the reverse strand and as nothing on the forward
+    strand; forward hash, reverse hash and count equal the oracle's and the from-scratch Python hashes"""
+    from oracle import rbo_py as P
+    reads = [r for r in _nasty(9, 20, 60, 200) if len(r) >= 25]
+    assert any(ch in r for r in reads for ch in b"KMSWYIE")
+    for stranded in (False, True):
+        og = rbo.Graph(300_007, 500_009, 64, 2, 2, 1, 25, stranded, False, 2)
+        gg = G.BloomFilterDeBruijnGraph(300_007, 500_009, 64, 2, 2, 1, 25, stranded, False, rngSeed=2)
+        seq, _, off = rbo.pack_reads(reads)
+        og.add_reads(seq, None, off, 3, 0); gg.addReads(seq, None, off, 3)
+        ko, f, r, c = gg.getKmers(reads)
+        differs = 0
+        for i, s in enumerate(reads):
+            ef, er, ec = og.get_kmers(s)
+            pf, pr = P.kmer_hashes(s, 25)
+            a, b = ko[i], ko[i + 1]
+            assert [int(x) for x in f[a:b]] == pf == [int(x) for x in ef], i
+            if not stranded:
+                assert [int(x) for x in r[a:b]] == pr == [int(x) for x in er], i
+                # the validity-bit-only packing of round 2 gave these letters seed 0 on both strands
+                zr = P.kmer_hashes(bytes(ch if ch in b"ACGTUacgtu" else ord("N") for ch in s), 25)[1]
+                differs += sum(x != y for x, y in zip(pr, zr))
+            assert (c[a:b] == ec).all()
+        assert stranded or differs > 50
+
+
+@pytest.mark.parametrize("simple", [False, True])
+def test_tile_kernels_on_long_tie_heavy_reads(simple, monkeypatch):
+    """the tile kernels (LDS-staged hashes, several tiles per read) and the one-thread-per-output kernels they replace, on reads
+    of several thousand bases with homopolymers and tandem repeats: equal to the C oracle; minimizer positions in runs of tied
+    windows are replayed from the tie-free window in front of them"""
+    if simple: monkeypatch.setenv("RB_SKETCH_SIMPLE", "1")
+    reads = _nasty(21, 10, 2500, 6000) + long_reads(6, 5, mean=3000)
+    for mode in (0, 1):
+        mo, h, p = G.minimizers(reads, 13, 15, mode)
+        for i, s in enumerate(reads):
+            eh, ep = rbo.minimizers(s, 13, 15, mode)
+            assert (h[mo[i]:mo[i + 1]] == eh).all() and (p[mo[i]:mo[i + 1]] == ep).all(), (i, mode)
+    so, sh, ss, se = G.strobemers(reads, 11, 3, 12, 61)
+    ro, rh, rp, _ = G.randstrobes(reads, 11, 3, 12, 61, canonical=True)
+    to, th, tp, _ = G.strobe3(reads, 11, 12, 61, canonical=True)
+    uo, uh, up, _ = G.strobe3(reads, 11, 12, 61, canonical=False)
+    for i, s in enumerate(reads):
+        oh, os_, oe = rbo.strobemers(s, 11, 3, 12, 61)
+        assert (sh[so[i]:so[i + 1]] == oh).all() and (ss[so[i]:so[i + 1]] == os_).all() and (se[so[i]:so[i + 1]] == oe).all(), i
+        eh, ep = rbo.randstrobes(s, 11, 3, 12, 61, canonical=True)
+        assert (rh[ro[i]:ro[i + 1]] == eh).all() and (rp[ro[i]:ro[i + 1]] == ep).all(), i
+        eh, ep = rbo.strobe3(s, 11, 12, 61, canonical=True)
+        assert (th[to[i]:to[i + 1]] == eh).all() and (tp[to[i]:to[i + 1]] == ep).all(), i
+        eh, ep = rbo.strobe3(s, 11, 12, 61, canonical=False)
+        assert (uh[uo[i]:uo[i + 1]] == eh).all() and (up[uo[i]:uo[i + 1]] == ep).all(), i

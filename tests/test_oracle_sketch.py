@@ -150,3 +150,47 @@ def test_kmer_pair_hashes(canonical):
     if canonical:                                               # invariant under reverse complement (pair order flips)
         back = rbo.kmer_pair_hashes(revcomp(seq), k, shift, True)
         assert [int(x) for x in back] == [int(x) for x in got[::-1]]
+
+
+# ---- three-way check, CPU leg: the C restatement against the independent Python one (oracle/rbo_py.py: hashes from scratch,
+#      brute-force argmin, a literal LongRollingWindow) on reads with everything that makes the rules matter: letters outside
+#      ACGTU (reverse-strand seed by `ch & 7`), runs of one base and short tandem repeats (equal k-mer hashes: ties) ----
+def nasty_reads(seed, n=14):
+    rng = np.random.default_rng(seed)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    out = []
+    for i in range(n):
+        L = int(rng.integers(90, 260))
+        s = acgt[rng.integers(0, 4, L)].copy()
+        for _ in range(int(rng.integers(0, 4))):                 # homopolymers / tandem repeats: windows full of equal hashes
+            a = int(rng.integers(0, L - 40)); unit = acgt[rng.integers(0, 4, int(rng.integers(1, 4)))]
+            rep = np.tile(unit, 40)[:int(rng.integers(20, 40))]
+            s[a:a + rep.size] = rep[:max(0, min(rep.size, L - a))]
+        if i % 2:                                                # IUPAC and other letters, lower case, U
+            for ch in b"KMSWYIELOQDRBHVNXacgtu":
+                if rng.random() < 0.5: s[int(rng.integers(0, L))] = ch
+        out.append(s.tobytes())
+    return out + [b"A" * 120, b"ACACACACAC" * 14, b"ACGT", b""]
+
+
+def test_python_restatement_agrees_with_the_c_oracle():
+    from oracle import rbo_py as P
+    for s in nasty_reads(3):
+        for mode in (0, 1, 2):
+            eh, ep = rbo.minimizers(s, 13, 15, mode)
+            got = P.minimizers(s, 13, 15, mode)
+            assert [int(x) for x in eh] == [h for h, _ in got] and [int(x) for x in ep] == [p for _, p in got], (s, mode)
+            nh, npos = rbo.minimizers_next(s, 13, 15, mode)
+            assert list(zip([int(x) for x in nh], [int(x) for x in npos])) == P.minimizers_next(s, 13, 15, mode)
+            assert [int(x) for x in rbo.minimizer_set(s, 13, 15, mode, stale=7)] == P.minimizer_set(s, 13, 15, mode, stale=7)
+        oh, os_, oe = rbo.strobemers(s, 11, 3, 12, 31)
+        assert list(zip([int(x) for x in oh], [int(x) for x in os_], [int(x) for x in oe])) == P.strobemer_intervals(s, 11, 3, 12, 31)
+        for canonical, slide in ((False, False), (False, True), (True, False)):
+            rh, rp = rbo.randstrobes(s, 11, 3, 5, 20, canonical=canonical, slide=slide)
+            want = P.randstrobes(s, 11, 3, 5, 20, canonical)
+            assert [int(x) for x in rh] == [h for h, _ in want] and [list(map(int, r)) for r in rp] == [p for _, p in want], (s, canonical, slide)
+        for canonical in (False, True):
+            th, tp = rbo.strobe3(s, 11, 6, 25, canonical=canonical)
+            want = P.strobe3(s, 11, 6, 25, canonical)
+            assert [int(x) for x in th] == [h for h, _ in want] and [list(map(int, r)) for r in tp] == [p for _, p in want], (s, canonical)
+            assert [int(x) for x in rbo.kmer_pair_hashes(s, 13, 9, canonical)] == P.kmer_pair_hashes(s, 13, 9, canonical)
