@@ -102,3 +102,35 @@ def test_jni_shim_type_checks_against_the_jni_declarations_it_uses():
     r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I" + os.path.join(ROOT, "tests", "jni_stub"),
                         "-I" + os.path.join(ROOT, "include"), os.path.join(ROOT, "jni", "rb_jni.c")], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+# ---- the Java drop-in classes as source (java/rnabloom/{graph,bloom}/*.java): every public constructor and method of the
+#      reference classes the boundary keeps exists with the same name and parameter types; the list is a
+#      fixture made from the reference by tests/golden/gen_java_api.py (names and types only) ----
+def _java_public_methods(text):
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    out = set()
+    for m in re.finditer(r"\bpublic\s+((?:static\s+|final\s+|synchronized\s+)*)([\w<>\[\], ]+?\s+)?(\w+)\s*\(([^)]*)\)\s*(?:throws [\w, .]+)?\s*\{", text):
+        params = tuple(re.sub(r"\bfinal\s+", "", p).strip().rsplit(None, 1)[0].replace(" ", "") for p in m.group(4).split(",") if p.strip())
+        out.add((m.group(3), params, "static" in m.group(1)))
+    return out
+
+
+def test_java_drop_in_classes_keep_every_public_signature_of_the_reference():
+    import json
+    api = json.load(open(os.path.join(ROOT, "tests", "golden", "java_api.json")))
+    where = {"BloomFilterDeBruijnGraph": "graph", "BloomFilter": "bloom", "CountingBloomFilter": "bloom", "PairedKeysBloomFilter": "bloom"}
+    natives = set(re.findall(r"public static (?:native )?[\w\[\]]+ (\w+)\(", open(os.path.join(ROOT, "java", "rnabloom", "graph", "NativeGraph.java")).read()))
+    for cls, pkg in where.items():
+        src = open(os.path.join(ROOT, "java", "rnabloom", pkg, cls + ".java")).read()
+        have = _java_public_methods(src)
+        want = {(m["name"], tuple(m["params"]), m["static"]) for m in api[cls]}
+        assert len(want) >= 15
+        missing = want - have
+        assert not missing, (cls, sorted(missing))
+        # ... and the class really goes through the JNI surface: every NativeGraph member it names exists
+        used = set(re.findall(r"NativeGraph\.(\w+)\(", src))
+        assert used and used <= natives, (cls, used - natives)
+    worker = open(os.path.join(ROOT, "java", "rnabloom", "graph", "NativeFastqToGraphWorker.java")).read()
+    assert "NativeGraph.addReads(" in worker and "implements Runnable" in worker
