@@ -657,7 +657,7 @@ k_hash_windows_resume(const uint64_t *__restrict__ codes, const uint32_t *__rest
                       const uint32_t *__restrict__ len, int64_t w0, int64_t nw, int k,
                       const uint32_t *__restrict__ chunk_off, uint32_t first_read, uint32_t pos_bits,
                       uint64_t *__restrict__ keys, uint32_t *__restrict__ vals, const uint32_t *__restrict__ keepmask,
-                      const ulonglong2 *__restrict__ wstate) {
+                      const ulonglong2 *__restrict__ wstate, EmitRecheck rc) {
     constexpr uint32_t SLAB = RB_EMIT_SLAB, BW = RB_SPARSE_WORDS;
     __shared__ uint64_t s_key[SLAB + SLAB / 32 + 1];
     __shared__ uint32_t s_val[SLAB + SLAB / 32 + 1];
@@ -729,8 +729,16 @@ k_hash_windows_resume(const uint64_t *__restrict__ codes, const uint32_t *__rest
             __syncthreads();
             for (uint32_t x = threadIdx.x; x < slab1 - slab0; x += 64u) {
                 const uint32_t q = x + (x >> 5);
-                keys[O0 + slab0 + x] = s_key[q];
-                vals[O0 + slab0 + x] = s_val[q];
+                uint64_t key = s_key[q];
+                uint32_t val = s_val[q];
+                if (rc.rst.tab) {      // what the stages that retire runs have stored since this window was filtered
+                    const uint32_t s2 = rst_lookup(rc.rst, key);
+                    if (s2 && draw_strength(rng31(rc.seed, rc.ordinal0 + (uint64_t)(val >> pos_bits), val & ((1u << pos_bits) - 1u))) < s2) {
+                        key = ~0ull; val = ~0u;                   // a no-op after all: cancelled (rb_group.hip GR_DEAD_*)
+                    }
+                }
+                keys[O0 + slab0 + x] = key;
+                vals[O0 + slab0 + x] = val;
             }
             __syncthreads();
         }
@@ -1086,14 +1094,15 @@ void launch_filter_emit(const rb_batch *b, int64_t w0, int64_t nw, int k, int mo
 bool filter_saves_state(const rb_batch *b, int64_t nw, int k) { return read_lane_words(b, nw, k) != 0u && !(getenv("RB_EMIT_RESUME") && atoi(getenv("RB_EMIT_RESUME")) == 0); }
 void launch_hash_windows_masked(const rb_batch *b, int64_t w0, int64_t nw, int k, int mode, const uint32_t *chunk_off,
                                 const uint32_t *keepmask, uint32_t first_read, uint32_t pos_bits, uint64_t *keys, uint32_t *vals,
-                                hipStream_t s, const void *wstate) {
+                                hipStream_t s, const void *wstate, EmitRecheck recheck) {
     if (nw <= 0) return;
+    RB_REQUIRE(!recheck.rst.tab || (keepmask && wstate), "emit recheck is part of the resuming emit kernel only");
     const bool sparse = !(getenv("RB_SPARSE_EMIT") && atoi(getenv("RB_SPARSE_EMIT")) == 0);
     if (keepmask && wstate) {
         dim3 gs(blocks_for(nw, RB_SPARSE_WORDS)), ts(64);
 #define RB_LAUNCH_RS(M)                                                                                    \
     hipLaunchKernelGGL(k_hash_windows_resume<M>, gs, ts, 0, s, b->codes, b->valid, b->word_read, b->woff, \
-                       b->len, w0, nw, k, chunk_off, first_read, pos_bits, keys, vals, keepmask, reinterpret_cast<const ulonglong2 *>(wstate))
+                       b->len, w0, nw, k, chunk_off, first_read, pos_bits, keys, vals, keepmask, reinterpret_cast<const ulonglong2 *>(wstate), recheck)
         if (mode == 0) RB_LAUNCH_RS(0); else if (mode == 2) RB_LAUNCH_RS(2); else RB_LAUNCH_RS(1);
 #undef RB_LAUNCH_RS
         return;

@@ -51,29 +51,29 @@ __host__ __device__ __forceinline__ uint64_t combine(uint64_t a, uint64_t b) {
 }
 
 // getIndex: (hashVal >>> 1) % size, R/bloom/BloomFilter.java:108-111.
-// Exact remainder for an arbitrary 63-bit size via Lemire's fastmod with a 128-bit reciprocal
-// M = floor((2^128-1)/d) + 1:   x mod d = mulhi128(M * x mod 2^128, d).
+// Exact remainder of a 63-bit x by an arbitrary size d (Barrett with a 64-bit reciprocal R = floor(2^64 / d) and one
+// correction): q' = mulhi(x, R) satisfies q - 1 <= q' <= q for q = floor(x / d), because x / d - x R / 2^64 =
+// x (2^64 / d - R) / 2^64 < x / 2^64 < 1/2 for x < 2^63; so r' = x - q' d lies in [0, 2d) and one conditional subtraction
+// gives x mod d.  One mulhi64 + one mul64 instead of the three + three of a 128-bit fastmod (round 2): the index arithmetic of
+// every probe kernel and of the sharded engine's per-record owner test.  d = 1: R is clamped to 2^64 - 1, the result is 0.
 struct Mod {
-    uint64_t d, m_lo, m_hi;
+    uint64_t d, m_lo, m_hi;      // m_lo = R; m_hi unused (kept: the struct travels by value through every kernel signature)
 };
 __host__ inline Mod make_mod(uint64_t d) {
     Mod m;
     m.d = d;
-    unsigned __int128 M = ~(unsigned __int128)0 / d + 1;
-    m.m_lo = (uint64_t)M;
-    m.m_hi = (uint64_t)(M >> 64);
+    m.m_lo = d > 1 ? (uint64_t)(((unsigned __int128)1 << 64) / d) : ~0ull;
+    m.m_hi = 0;
     return m;
 }
-__device__ __forceinline__ uint64_t fastmod(uint64_t x, const Mod &m) {
-    // lowbits = (M * x) mod 2^128
-    uint64_t lo = m.m_lo * x;
-    uint64_t hi = __umul64hi(m.m_lo, x) + m.m_hi * x;
-    // result = (lowbits * d) >> 128
-    uint64_t t = __umul64hi(lo, m.d);            // carry part of lo*d
-    uint64_t p_lo = hi * m.d;
-    uint64_t p_hi = __umul64hi(hi, m.d);
-    uint64_t s = p_lo + t;
-    return p_hi + (s < p_lo ? 1ull : 0ull);
+__host__ __device__ __forceinline__ uint64_t fastmod(uint64_t x, const Mod &m) {      // x < 2^63
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint64_t q = __umul64hi(x, m.m_lo);
+#else
+    const uint64_t q = (uint64_t)(((unsigned __int128)x * m.m_lo) >> 64);
+#endif
+    const uint64_t r = x - q * m.d;
+    return r >= m.d ? r - m.d : r;
 }
 __device__ __forceinline__ uint64_t index_of(uint64_t h, const Mod &m) { return fastmod(h >> 1, m); }
 
@@ -176,6 +176,28 @@ __device__ __forceinline__ bool npf_store(const Npf &c, uint64_t h0, uint32_t s)
     }
     __hip_atomic_store(&b[victim], (tag << 4) | (unsigned long long)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return true;
+}
+// ---- recent stores (DESIGN.md §3 "two-phase prefilter"): a small direct-mapped table of what the stages that retire runs
+// have learnt lately, addressed by the hash itself (the emit pass knows the hash of every window it writes, not its minimizer
+// bucket's contents).  entry = h0 with its low four bits replaced by the exponent s (1..14, 15 = saturated), index = the low
+// log2n bits of h0 (log2n >= 4: the replaced bits are part of the index, so a match proves all 64 bits); 0 = empty.  Same
+// contract as the caches above: an entry asserts "in dbgbf, exponent >= s", true for ever; a lost or overwritten entry
+// only lets an occurrence through that could have been dropped.  2^21 entries = 16 MB: it stays in the Infinity Cache.
+struct Rst {
+    unsigned long long *tab;   // nullptr => disabled
+    uint32_t log2n;
+};
+__device__ __forceinline__ void rst_store(const Rst &c, uint64_t h0, uint32_t s) {            // s in 1..14 or RB_EXP_SATURATED
+    unsigned long long *e = c.tab + (h0 & ((1ull << c.log2n) - 1ull));
+    const unsigned long long cur = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((cur >> 4) == (h0 >> 4) && (uint32_t)(cur & 15ull) >= s) return;
+    __hip_atomic_store(e, (h0 & ~15ull) | (unsigned long long)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t rst_lookup(const Rst &c, uint64_t h0) {                   // 0 = unknown, 16 = saturated
+    const unsigned long long e = __hip_atomic_load(c.tab + (h0 & ((1ull << c.log2n) - 1ull)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t s = (uint32_t)(e & 15ull);
+    if (!s || (e >> 4) != (h0 >> 4)) return 0u;
+    return s == RB_EXP_SATURATED ? 16u : s;
 }
 // ---- minimizer-bucketed prefilter cache: same contract as Npf, different address ----
 // The device serves ~54 G random 64-byte lines/s; one line request per window is what

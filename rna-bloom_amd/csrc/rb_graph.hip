@@ -1713,9 +1713,9 @@ void rb::launch_pairs(rb_graph *g, const rb_batch *b, int64_t w0, int64_t nw, in
 // Stable grouping of N (h0, occ) records sitting in keys0/vals0 into slot `slot`: sort on the top hash
 // bits, draw strengths, run-length encode.  Asynchronous on `st`; group_finish reads the run count.
 void rb::group_enqueue(rb_graph *g, int slot, size_t N, uint64_t ordinal0, uint32_t pos_bits, hipStream_t st, DevBuf &temp,
-                       DevBuf &ctrbuf) {
+                       DevBuf &ctrbuf, int flags) {
     rb_graph::GroupSlot &S = g->slots[slot];
-    S.N = N; S.D = 0;
+    S.N = N; S.D = 0; S.flags = flags; S.live = (uint32_t)N;
     ctrbuf.reserve(DEVCTR_BYTES);
     uint32_t *ctr = ctrbuf.as<uint32_t>();
     RB_HIP(hipMemsetAsync(ctr, 0, DEVCTR_BYTES, st));
@@ -1726,18 +1726,20 @@ void rb::group_enqueue(rb_graph *g, int slot, size_t N, uint64_t ordinal0, uint3
     // ordered conflict replay already make exact (DESIGN.md §Pipeline "split runs").
     const int group_bits = 64 - g->sort_begin_bit;
     const int bucket_target = g->shard ? (getenv("RB_SHARD_GROUP_TARGET") ? atoi(getenv("RB_SHARD_GROUP_TARGET")) : 3072) : 0;
-    temp.reserve(group_temp_bytes(N, group_bits, bucket_target));
+    temp.reserve(group_temp_bytes(N, group_bits, bucket_target, flags));
     S.keys1.reserve(N * 8); S.valsT.reserve(N * 4); S.vals1.reserve(N * 4); S.tz.reserve(N + 16);
     S.uniq.reserve(N * 8); S.counts.reserve((N + 1) * 4); S.starts.reserve((N + 1) * 4);
     group_records_device(g->keys0.as<uint64_t>(), g->vals0.as<uint32_t>(), S.keys1.as<uint64_t>(), S.valsT.as<uint32_t>(), N, group_bits,
                          g->p.rng_seed, ordinal0, pos_bits, temp.p, temp.cap, S.vals1.as<uint32_t>(), S.tz.as<uint8_t>(), S.uniq.as<uint64_t>(),
-                         S.counts.as<uint32_t>(), S.starts.as<uint32_t>(), ctr + 8, st, g, bucket_target);
+                         S.counts.as<uint32_t>(), S.starts.as<uint32_t>(), ctr + 8, st, g, bucket_target, flags);
 }
 uint32_t rb::group_finish(rb_graph *g, int slot, hipStream_t st, DevBuf &temp, DevBuf &ctrbuf, hipStream_t scan_stream) {
     rb_graph::GroupSlot &S = g->slots[slot];
     if (S.N == 0) { RB_HIP(hipStreamSynchronize(st)); return 0; }
     uint32_t D = 0;
     RB_HIP(hipMemcpyAsync(&D, ctrbuf.as<uint32_t>() + 8, 4, hipMemcpyDeviceToHost, st));
+    if (S.flags & GR_FLAG_DEAD)
+        RB_HIP(hipMemcpyAsync(&S.live, group_live_count(temp.p, S.N, 64 - g->sort_begin_bit, g->shard ? 3072 : 0, S.flags), 4, hipMemcpyDeviceToHost, st));
     RB_HIP(hipStreamSynchronize(st));
     RB_REQUIRE(D < (1u << 30), "sub-batch has too many distinct k-mers (%u)", D);
     S.D = D;
@@ -2046,7 +2048,7 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
     const uint32_t max_pos = b->max_len >= (uint32_t)g->k ? b->max_len - (uint32_t)g->k : 0u;
     uint32_t pos_bits = 1;
     while ((1u << pos_bits) <= max_pos && pos_bits < 31) ++pos_bits;
-    const int64_t max_reads = (int64_t)1 << (32 - pos_bits);
+    const int64_t max_reads = ((int64_t)1 << (32 - pos_bits)) - 1;       // (- 1: the all-ones occurrence id marks a cancelled record, rb_group.hip)
     // max_batch_kmers bounds the RECORDS a sub-batch sorts.  With the prefilter most windows never
     // become records, so a sub-batch may span three times as many windows (fewer, larger runs per k-mer); a
     // sub-batch whose survivors exceed the bound after all (cold cache) is split and redone.
@@ -2197,6 +2199,117 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
         return true;
     };
     auto prepare = [&](size_t i) { while (!prepare_once(i)) {} };
+    // ---- two-phase prefilter (RB_TWO_PHASE=1; uniform batches on the minimizer-bucketed path) — an experiment that LOST ----
+    // The prefilter of sub-batch i+1 waits for the runs of sub-batch i to retire (their cache stores are what it feeds on), so
+    // producer and consumer alternate: ~10 ms of hashing / grouping, then ~6 ms of probing / resolving, 22 times a pass.
+    // Here phase 1 — pairs, the window walk against the cache AS IT IS, the scan — is enqueued when the consumer of sub-batch i
+    // STARTS and runs beside it, and phase 2 is folded into the emit pass, which waits for the release point as before: every
+    // window it writes is looked up in the recent-store table (what the consumer stored meanwhile, addressed by hash) and
+    // cancelled if it is a no-op after all; the first partition pass of the grouping drops the cancelled records.  A cache entry
+    // is true for ever, so dropping by a stale entry is as valid as by a fresh one: the filters end up bit for bit the same
+    // (182 parity / scale / sharded tests).  Measured on config 2 (profiles/r03_two_phase.txt): 380-389 ms per step against 342 —
+    // the two halves do overlap, but every kernel that runs beside another takes 1.5-2x as long (probe_claim 60 -> 119 ms,
+    // filter 84 -> 99, pairs 35 -> 60): the window walk is no pure instruction-issue load (it moves 0.46 of the HBM peak in bucket
+    // fetches) and the probes live on the same request path; stream priorities change nothing.  Kept behind the switch.
+    const bool two_phase = use_npf && g->use_mpf && g->rst_log2 && g->k <= 31 && !getenv("RB_ONE_PASS_FILTER") && !getenv("RB_SERIAL") &&
+                           !getenv("RB_PREPARE_EARLY") && (getenv("RB_TWO_PHASE") && atoi(getenv("RB_TWO_PHASE")) != 0) &&
+                           !subs.empty() && filter_saves_state(b, subs[0].nw, g->k) && !(getenv("RB_EMIT_RESUME") && atoi(getenv("RB_EMIT_RESUME")) == 0);
+    g->rst_on = two_phase;
+    struct RstScope { rb_graph *g; ~RstScope() { g->rst_on = false; } } rst_scope{g};
+    if (two_phase) {
+        uint32_t *pin = nullptr;                                 // [0] survivors of phase 1, [2..3] pairs, [16 + 16 q] usable windows
+        RB_HIP(hipHostMalloc(reinterpret_cast<void **>(&pin), 4096, hipHostMallocDefault));
+        struct PinFree { uint32_t *p; ~PinFree() { if (p) (void)hipHostFree(p); } } pin_free{pin};
+        auto phase_a = [&](size_t i) {                           // no host wait in here
+            const Sub &sb = subs[i];
+            if (sb.nw <= 0) return;
+            const uint64_t ord0 = g->ordinal + (uint64_t)(sb.r0 - first);
+            g->chunk_cnt.reserve(((size_t)sb.nw + 1) * 4); g->chunk_off.reserve(((size_t)sb.nw + 1) * 4); g->chunk_mask.reserve(((size_t)sb.nw + 1) * 4);
+            g->temp2.reserve(scan_temp_bytes((size_t)sb.nw + 1));
+            g->npf_tot.reserve(2048);
+            g->wstate.reserve(((size_t)sb.nw + 1) * 16);
+            RB_HIP(hipMemsetAsync(g->npf_tot.p, 0, 2048, sp));
+            RB_HIP(hipMemsetAsync(g->chunk_cnt.as<uint32_t>() + sb.nw, 0, 4, sp));
+            if (pairs) {
+                g->prof_begin(sp);
+                launch_pairs(g, b, sb.w0, sb.nw, mode_hash, nullptr, nullptr, reinterpret_cast<unsigned long long *>(g->npf_tot.as<uint32_t>() + 508), sp);
+                g->prof_end("pairs_insert", sp);
+            }
+            g->prof_begin(sp);
+            FilterView fvp = g->view(ord0, pos_bits);
+            launch_filter_windows(b, sb.w0, sb.nw, g->k, mode_hash, (uint32_t)sb.r0, pos_bits, g->p.rng_seed, ord0, fvp.npf,
+                                  g->chunk_cnt.as<uint32_t>(), g->chunk_mask.as<uint32_t>(), g->npf_tot.as<uint32_t>(), sp, 0u, 0u, fvp.mpf, g->wstate.p);
+            exclusive_scan_u32(g->temp2.p, g->temp2.cap, g->chunk_cnt.as<uint32_t>(), g->chunk_off.as<uint32_t>(), (size_t)sb.nw + 1, sp);
+            RB_HIP(hipMemcpyAsync(pin, g->chunk_off.as<uint32_t>() + sb.nw, 4, hipMemcpyDeviceToHost, sp));
+            RB_HIP(hipMemcpyAsync(pin + 16, g->npf_tot.p, 2048, hipMemcpyDeviceToHost, sp));
+            g->prof_end("filter_windows", sp);
+        };
+        // waits for phase 1, then emit (with the second look) + grouping; false: too many survivors, the sub-batch was halved
+        auto phase_b = [&](size_t i, unsigned long long *np_out) -> bool {
+            Sub &sb = subs[i];
+            sb.N = 0; sb.total = 0;
+            const int slot = (int)(i & 1u);
+            g->devctr2.reserve(DEVCTR_BYTES);
+            const uint64_t ord0 = g->ordinal + (uint64_t)(sb.r0 - first);
+            if (sb.nw > 0) {
+                RB_HIP(hipStreamSynchronize(sp));
+                sb.N = pin[0];
+                if ((int64_t)sb.N > g->max_batch_kmers && sb.r1 - sb.r0 > 1) {
+                    const int64_t mid = sb.r0 + (sb.r1 - sb.r0) / 2;
+                    Sub second{mid, sb.r1, (int64_t)wo[(size_t)mid], (int64_t)wo[(size_t)sb.r1] - (int64_t)wo[(size_t)mid], 0u, 0};
+                    sb.r1 = mid; sb.nw = (int64_t)wo[(size_t)mid] - sb.w0;
+                    subs.insert(subs.begin() + (std::ptrdiff_t)i + 1, second);   // invalidates sb; (the pairs of the whole range are in: ORs, harmless to repeat)
+                    return false;
+                }
+                for (int q = 0; q < 32; ++q) sb.total += pin[16 + 16 * q];
+                if (np_out) *np_out = *reinterpret_cast<unsigned long long *>(pin + 16 + 508);
+                if (sb.N) {
+                    g->prof_begin(sp);
+                    g->keys0.reserve((size_t)sb.N * 8); g->vals0.reserve((size_t)sb.N * 4);
+                    FilterView fvp = g->view(ord0, pos_bits);
+                    launch_hash_windows_masked(b, sb.w0, sb.nw, g->k, mode_hash, g->chunk_off.as<uint32_t>(), g->chunk_mask.as<uint32_t>(),
+                                               (uint32_t)sb.r0, pos_bits, g->keys0.as<uint64_t>(), g->vals0.as<uint32_t>(), sp, g->wstate.p,
+                                               EmitRecheck{fvp.rst, g->p.rng_seed, ord0});
+                    g->prof_end("hash_windows", sp);
+                }
+            }
+            group_enqueue(g, slot, sb.N, ord0, pos_bits, sp, g->temp2, g->devctr2, GR_FLAG_DEAD);
+            return true;
+        };
+        std::vector<unsigned long long> npairs(subs.size() + 64, 0ull);
+        auto both = [&](size_t i) {
+            for (;;) {
+                if (npairs.size() < subs.size() + 1) npairs.resize(subs.size() + 64, 0ull);
+                unsigned long long np = 0;
+                if (phase_b(i, &np)) { npairs[i] = np; return; }
+                phase_a(i);
+            }
+        };
+        phase_a(0);
+        both(0);
+        for (size_t i = 0; i < subs.size(); ++i) {
+            const int slot = (int)(i & 1u);
+            const uint32_t D = group_finish(g, slot, sp, g->temp2, g->devctr2, s);   // drains the producer stream
+            if (stats) { stats->pairs += (int64_t)npairs[i]; stats->distinct += D; }
+            if (i + 1 < subs.size()) phase_a(i + 1);                                 // beside the consumer of sub-batch i
+            g->cur = slot;
+            g->seq_first = (uint32_t)subs[i].r0;
+            const std::function<void()> next = [&]() {
+                if (i + 1 >= subs.size()) return;
+                RB_HIP(hipEventRecord(g->ev0, s));
+                RB_HIP(hipStreamWaitEvent(sp, g->ev0, 0));
+                both(i + 1);
+            };
+            run_core(g, subs[i].N, D, mode, g->ordinal + (uint64_t)(subs[i].r0 - first), pos_bits, stats, &next);
+            RB_HIP(hipStreamSynchronize(s));
+            if (stats) { stats->kmers += subs[i].total; stats->sorted_kmers += (int64_t)g->slots[slot].live; stats->reads += subs[i].r1 - subs[i].r0; }
+        }
+        g->ordinal += (uint64_t)n;
+        RB_HIP(hipStreamSynchronize(s));
+        RB_HIP(hipStreamSynchronize(sp));
+        g->prof_collect();
+        return;
+    }
     if (!subs.empty()) prepare(0);
     for (size_t i = 0; i < subs.size(); ++i) {
         const int slot = (int)(i & 1u);
@@ -2270,7 +2383,8 @@ int rb_graph_create(const rb_graph_params *p, rb_graph **out) {
         if (const char *e = getenv("RB_LIGHT_OPS")) g->light_ops = (uint32_t)std::max(1, atoi(e));
         if (const char *e = getenv("RB_SORT_BEGIN_BIT")) g->sort_begin_bit = std::max(0, std::min(63, atoi(e)));
         RB_REQUIRE(g->max_batch_kmers <= ((int64_t)1 << 31), "rb_graph_create: max_batch_kmers above 2^31");
-        RB_HIP(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
+        if (const char *e = getenv("RB_CONSUMER_PRIORITY")) RB_HIP(hipStreamCreateWithPriority(&g->stream, hipStreamNonBlocking, atoi(e)));
+        else RB_HIP(hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking));
         {   // the producer (hash + sort of the next sub-batch) is the critical path: give it priority
             int lo_p = 0, hi_p = 0;
             RB_HIP(hipDeviceGetStreamPriorityRange(&lo_p, &hi_p));
@@ -2308,6 +2422,15 @@ int rb_graph_create(const rb_graph_params *p, rb_graph **out) {
                 g->mpf.reserve((size_t)128 << lb);
                 RB_HIP(hipMemset(g->mpf.p, 0, (size_t)128 << lb));
                 g->mpf_log2b = lb;
+                if (getenv("RB_TWO_PHASE") && atoi(getenv("RB_TWO_PHASE")) != 0) {   // recent stores for the emit pass of the two-phase prefilter (an experiment, see add_range)
+                    uint32_t lr = 24;
+                    if (const char *er = getenv("RB_RST")) lr = (uint32_t)atoi(er);
+                    if (lr >= 8 && lr <= 26) {
+                        g->rst.reserve(sizeof(uint64_t) << lr);
+                        RB_HIP(hipMemset(g->rst.p, 0, sizeof(uint64_t) << lr));
+                        g->rst_log2 = lr;
+                    }
+                }
                 g->mpf_m = (uint32_t)std::min(getenv("RB_MPF_M") ? std::max(4, std::min(16, atoi(getenv("RB_MPF_M")))) : 16, p->k);
             }
         }
@@ -2343,7 +2466,7 @@ int rb_graph_destroy(rb_graph *g) {
     if (g->stream2) (void)hipStreamDestroy(g->stream2);
     for (auto e : g->prof_pool) (void)hipEventDestroy(e);
     for (auto &sl : g->slots) { sl.keys1.release(); sl.valsT.release(); sl.vals1.release(); sl.tz.release(); sl.uniq.release(); sl.counts.release(); sl.starts.release(); }
-    g->temp2.release(); g->devctr2.release(); g->npf.release(); g->mpf.release(); g->chunk_mask.release(); g->npf_tot.release(); g->wstate.release();
+    g->temp2.release(); g->devctr2.release(); g->npf.release(); g->mpf.release(); g->rst.release(); g->chunk_mask.release(); g->npf_tot.release(); g->wstate.release();
     delete g;
     return RB_OK;
 }
@@ -2374,6 +2497,7 @@ int rb_graph_clear(rb_graph *g, unsigned which_mask) {
         if ((which_mask & 8u) && g->fpk.bits) fast_zero(g->fpk.bits, g->fpk.alloc, g->stream);
         if ((which_mask & 3u) && g->npf_log2) fast_zero(g->npf.p, sizeof(uint64_t) << g->npf_log2, g->stream);   // cache entries speak about dbgbf + cbf
         if ((which_mask & 3u) && g->mpf_log2b) fast_zero(g->mpf.p, (size_t)128 << g->mpf_log2b, g->stream);
+        if ((which_mask & 3u) && g->rst_log2) fast_zero(g->rst.p, sizeof(uint64_t) << g->rst_log2, g->stream);
         if ((which_mask & 3u) == 3u) g->ordinal = 0;
         RB_HIP(hipStreamSynchronize(g->stream));
     });
@@ -3216,6 +3340,7 @@ int rb_filter_import(rb_graph *g, int which, const void *srcp, size_t nbytes) {
         RB_HIP(hipStreamSynchronize(g->stream));
         if (g->npf_log2 && (which == RB_CBF || which == RB_DBGBF)) RB_HIP(hipMemset(g->npf.p, 0, sizeof(uint64_t) << g->npf_log2));
         if (g->mpf_log2b && (which == RB_CBF || which == RB_DBGBF)) RB_HIP(hipMemset(g->mpf.p, 0, (size_t)128 << g->mpf_log2b));
+        if (g->rst_log2 && (which == RB_CBF || which == RB_DBGBF)) RB_HIP(hipMemset(g->rst.p, 0, sizeof(uint64_t) << g->rst_log2));
         RB_HIP(hipMemset(dst, 0, alloc));
         RB_HIP(hipMemcpy(dst, srcp, have, hipMemcpyHostToDevice));
         RB_HIP(hipDeviceSynchronize());
@@ -3297,6 +3422,7 @@ int rb_cbf_to_bloom(rb_graph *src, float min_cov, rb_graph *dst, int which) {
         if (which == RB_DBGBF) {
             if (dst->npf_log2) RB_HIP(hipMemset(dst->npf.p, 0, sizeof(uint64_t) << dst->npf_log2));
             if (dst->mpf_log2b) RB_HIP(hipMemset(dst->mpf.p, 0, (size_t)128 << dst->mpf_log2b));
+            if (dst->rst_log2) RB_HIP(hipMemset(dst->rst.p, 0, sizeof(uint64_t) << dst->rst_log2));
             RB_HIP(hipDeviceSynchronize());
         }
     });

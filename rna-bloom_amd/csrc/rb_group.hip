@@ -37,6 +37,12 @@ constexpr uint32_t GR_BUCKET_TARGET = 3072;  // T is chosen so that the average 
 constexpr uint32_t GR_LOCAL_BITS = 8;        // per local pass
 constexpr uint32_t GR_PART_MAX_BITS = 10;    // per partition pass
 
+// A record the emit pass cancelled after its slot was assigned (rb_batch.hip: the occurrence turned out to be a no-op against the
+// stores of the sub-batch before): key = all ones AND occurrence = all ones.  The first partition pass leaves such records
+// out (GR_FLAG_DEAD); every later stage sees a dense array of the live ones.  (An all-ones key alone proves nothing — it is a
+// possible hash — so the occurrence id is checked too; add_range never hands out the all-ones occurrence id.)
+constexpr uint64_t GR_DEAD_KEY = ~0ull;
+constexpr uint32_t GR_DEAD_VAL = ~0u;
 __device__ __forceinline__ uint32_t gr_digit(uint64_t key, uint32_t shift, uint32_t bits) {
     return (uint32_t)(key >> shift) & ((1u << bits) - 1u);
 }
@@ -210,7 +216,7 @@ __device__ __forceinline__ bool gr_get_tile(const GrTiling &tl, GrTile &t) {
 // ---- partition pass: histogram per (digit, tile) -----------------------------------------------------
 template <int TPB>
 __global__ void __launch_bounds__(TPB) k_part_count(const uint64_t *__restrict__ keys, GrTiling tl, uint32_t shift, uint32_t bits,
-                                                    uint32_t *__restrict__ hist) {
+                                                    uint32_t *__restrict__ hist, const uint32_t *__restrict__ dead_vals = nullptr) {
     constexpr int ITEMS = GR_TILE / TPB;
     __shared__ uint32_t s_h[1u << GR_PART_MAX_BITS];
     GrTile t;
@@ -227,7 +233,7 @@ __global__ void __launch_bounds__(TPB) k_part_count(const uint64_t *__restrict__
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const uint32_t j = (uint32_t)i * TPB + threadIdx.x;
-        if (j < t.count) atomicAdd(&s_h[gr_digit(k[i], shift, bits)], 1u);
+        if (j < t.count && !(dead_vals && k[i] == GR_DEAD_KEY && dead_vals[t.start + j] == GR_DEAD_VAL)) atomicAdd(&s_h[gr_digit(k[i], shift, bits)], 1u);
     }
     __syncthreads();
     for (uint32_t d = threadIdx.x; d < nb; d += TPB) hist[(size_t)t.hist_base + (size_t)d * t.hist_stride] = s_h[d];
@@ -237,7 +243,8 @@ __global__ void __launch_bounds__(TPB) k_part_count(const uint64_t *__restrict__
 template <int TPB, int MAXBITS>
 __global__ void __launch_bounds__(TPB) k_part_scatter(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, GrTiling tl,
                                                       uint32_t shift, uint32_t bits, const uint32_t *__restrict__ goffs /* exclusive scan of hist */,
-                                                      uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t wide_lds) {
+                                                      uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t wide_lds,
+                                                      uint32_t skip_dead = 0u) {
     constexpr uint32_t ITEMS = GR_TILE / TPB, NW = TPB / 64, SEG = 64 * ITEMS, MAXNB = 1u << MAXBITS;
     __shared__ uint64_t s_keys[GR_TILE];
     __shared__ uint32_t s_vals[GR_TILE];
@@ -264,9 +271,10 @@ __global__ void __launch_bounds__(TPB) k_part_scatter(const uint64_t *__restrict
 #pragma unroll
     for (uint32_t r = 0; r < ITEMS; ++r) {
         const uint32_t j = w * SEG + r * 64u + lane;
-        const bool ok = j < t.count;
+        bool ok = j < t.count;
         k[r] = ok ? keys_in[t.start + j] : 0ull;
         v[r] = ok ? vals_in[t.start + j] : 0u;
+        if (skip_dead && k[r] == GR_DEAD_KEY && v[r] == GR_DEAD_VAL) ok = false;          // cancelled by the emit pass: not scattered
         dig[r] = ok ? gr_digit(k[r], shift, bits) : ~0u;
     }
     const uint32_t rows = t.count > w * SEG ? min(ITEMS, (t.count - w * SEG + 63u) / 64u) : 0u;
@@ -284,9 +292,12 @@ __global__ void __launch_bounds__(TPB) k_part_scatter(const uint64_t *__restrict
             s_keys[p] = k[r]; s_vals[p] = v[r];
         }
     __syncthreads();
+    uint32_t live = 0;                               // records staged = sum of the digit totals (gr_digit_offsets left the per-wavefront sums in s_wsum)
+#pragma unroll
+    for (uint32_t i = 0; i < NW; ++i) live += s_wsum[i];
     for (uint32_t d = threadIdx.x; d < nb; d += TPB) s_cnt[d] = goffs[(size_t)t.hist_base + (size_t)d * t.hist_stride] - (uint32_t)s_dstart[d];
     __syncthreads();
-    for (uint32_t j = threadIdx.x; j < t.count; j += TPB) {
+    for (uint32_t j = threadIdx.x; j < live; j += TPB) {
         const uint64_t key = s_keys[j];
         const uint32_t g = s_cnt[gr_digit(key, shift, bits)] + j;
         keys_out[g] = key; vals_out[g] = s_vals[j];
@@ -296,9 +307,11 @@ __global__ void __launch_bounds__(TPB) k_part_scatter(const uint64_t *__restrict
 // first-pass bucket bounds -> tiles of the second pass.  One block; nb1 <= 1024 segments.
 __global__ void __launch_bounds__(1024) k_seg_tiles(const uint32_t *__restrict__ goffs1, uint32_t ntiles1, uint32_t nb1, uint32_t n, uint32_t nb2,
                                                     GrTile *__restrict__ desc, uint32_t *__restrict__ seg_tile_base /* [nb1 + 1] */,
-                                                    uint32_t *__restrict__ seg_start /* [nb1 + 1] */, uint32_t *__restrict__ ntiles2_dev) {
+                                                    uint32_t *__restrict__ seg_start /* [nb1 + 1] */, uint32_t *__restrict__ ntiles2_dev,
+                                                    const uint32_t *__restrict__ n_dev = nullptr /* live records after a pass that skipped dead ones */) {
     __shared__ uint32_t s_wsum[16];
     const uint32_t b = threadIdx.x;
+    if (n_dev) n = *n_dev;
     uint32_t s = 0, e = 0;
     if (b < nb1) { s = goffs1[(size_t)b * ntiles1]; e = b + 1u < nb1 ? goffs1[(size_t)(b + 1u) * ntiles1] : n; }
     const uint32_t nt = (e - s + GR_TILE - 1u) / GR_TILE;
@@ -314,8 +327,10 @@ __global__ void __launch_bounds__(1024) k_seg_tiles(const uint32_t *__restrict__
 }
 // fine-bucket bounds bstart[2^T + 1]
 __global__ void k_bucket_bounds(const uint32_t *__restrict__ goffs, uint32_t ntiles1, const uint32_t *__restrict__ seg_tile_base,
-                                const uint32_t *__restrict__ seg_start, uint32_t t_hi, uint32_t t_lo, uint32_t n, uint32_t *__restrict__ bstart) {
+                                const uint32_t *__restrict__ seg_start, uint32_t t_hi, uint32_t t_lo, uint32_t n, uint32_t *__restrict__ bstart,
+                                const uint32_t *__restrict__ n_dev = nullptr) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x, nbk = 1u << (t_hi + t_lo);
+    if (n_dev) n = *n_dev;
     if (p > nbk) return;
     if (p == nbk) { bstart[p] = n; return; }
     if (t_hi == 0) { bstart[p] = 0; return; }                                // no partition pass: one bucket
@@ -324,6 +339,8 @@ __global__ void k_bucket_bounds(const uint32_t *__restrict__ goffs, uint32_t nti
     const uint32_t tb = seg_tile_base[b], nt = seg_tile_base[b + 1u] - tb;
     bstart[p] = nt ? goffs[((size_t)tb << t_lo) + (size_t)lo * nt] : seg_start[b];
 }
+
+__global__ void k_copy_u32(uint32_t *__restrict__ dst, const uint32_t *__restrict__ src) { if (threadIdx.x == 0 && blockIdx.x == 0) *dst = *src; }
 
 // ---- bucket kernel: LDS sort on 2 x 8 bits, strengths, runs --------------------------------------------
 // GR_ABL (compile-time, tools/microbench/group_bench.hip only): parts of the bucket kernel compiled out to price them —
@@ -757,6 +774,7 @@ struct GroupPlan {
     uint32_t shift_lo = 0, shift_hi = 0;
     uint32_t l_lo = 0, l_hi = 0, lshift_lo = 0, lshift_hi = 0;   // local passes (LSD: lo first)
     uint32_t ntiles = 0, ntiles2_max = 0, nbuckets = 1;
+    bool dead = false;                       // the input may hold records the emit pass cancelled (GR_DEAD_KEY / GR_DEAD_VAL): the first partition pass drops them
     uint32_t tpb = 256;
     uint32_t fix_cap = 0;                    // 1: groups of up to 32 records that agree in all sorted bits are sorted on the full hash; 2: buckets with longer ones are redone
     int xcd_map = 1;
@@ -767,9 +785,10 @@ struct GroupPlan {
 };
 static size_t gr_align(size_t x) { return (x + 255) / 256 * 256; }
 
-static GroupPlan group_plan(size_t N, int group_bits, int bucket_target = 0) {
+static GroupPlan group_plan(size_t N, int group_bits, int bucket_target = 0, int flags = 0) {
     GroupPlan P;
     P.n = (uint32_t)N;
+    P.dead = (flags & GR_FLAG_DEAD) != 0;
     const uint32_t gb = (uint32_t)std::max(1, std::min<int>(group_bits, (int)GR_MAX_GROUP_BITS));
     uint32_t T = 0;
     // smaller buckets = fewer distinct hashes per bucket = fewer hashes that agree in the 16 locally sorted bits (1 % of the hashes
@@ -783,6 +802,7 @@ static GroupPlan group_plan(size_t N, int group_bits, int bucket_target = 0) {
     while ((target << T) < N) ++T;
     if (const char *e = getenv("RB_GROUP_T")) T = (uint32_t)std::max(0, atoi(e));
     T = std::min({T, gb, 2u * GR_PART_MAX_BITS});
+    if (P.dead && T == 0) T = 1;             // cancelled records leave in a partition pass: there has to be one
     P.T = T;
     if (T <= GR_PART_MAX_BITS) { P.t_hi = T; P.t_lo = 0; }
     else { P.t_hi = (T + 1u) / 2u; P.t_lo = T - P.t_hi; }
@@ -802,7 +822,7 @@ static GroupPlan group_plan(size_t N, int group_bits, int bucket_target = 0) {
     P.ntiles = (uint32_t)((N + GR_TILE - 1) / GR_TILE);
     P.ntiles2_max = P.t_lo ? P.ntiles + (1u << P.t_hi) : 0;
     P.nbuckets = 1u << T;
-    if (T) P.hist_entries = std::max((size_t)P.ntiles << P.t_hi, (size_t)P.ntiles2_max << P.t_lo) + 1;
+    if (T) P.hist_entries = std::max((size_t)P.ntiles << P.t_hi, (size_t)P.ntiles2_max << P.t_lo) + 2;
     size_t o = 0;
     P.off_status = o; o += gr_align((size_t)P.nbuckets * 8);
     P.off_ticket = o; o += 256;
@@ -824,8 +844,8 @@ static GroupPlan group_plan(size_t N, int group_bits, int bucket_target = 0) {
 }
 
 // debugging aid (RB_DEBUG): the buckets that did not fit LDS in the last grouping of N records that used `temp` (call with the stream idle)
-void group_debug_big(const void *temp, size_t N, int group_bits, int bucket_target, uint32_t *n_big_out, uint64_t *records_out, uint32_t *largest_out) {
-    const GroupPlan P = group_plan(N, group_bits, bucket_target);
+void group_debug_big(const void *temp, size_t N, int group_bits, int bucket_target, uint32_t *n_big_out, uint64_t *records_out, uint32_t *largest_out, int flags) {
+    const GroupPlan P = group_plan(N, group_bits, bucket_target, flags);
     const char *tp = static_cast<const char *>(temp);
     uint32_t tick[4] = {0, 0, 0, 0};
     RB_HIP(hipMemcpy(tick, tp + P.off_ticket, 16, hipMemcpyDeviceToHost));
@@ -837,20 +857,28 @@ void group_debug_big(const void *temp, size_t N, int group_bits, int bucket_targ
     for (uint32_t i = 0; i < nb; ++i) { const uint32_t c = bs[big[i] + 1] - bs[big[i]]; rec += c; mx = std::max(mx, c); }
     *n_big_out = nb; *records_out = rec; *largest_out = mx;
 }
-size_t group_temp_bytes(size_t N, int group_bits, int bucket_target) { return group_plan(N, group_bits, bucket_target).total; }
+size_t group_temp_bytes(size_t N, int group_bits, int bucket_target, int flags) { return group_plan(N, group_bits, bucket_target, flags).total; }
+// where the grouping of N records with GR_FLAG_DEAD leaves the number of live records (device address inside `temp`)
+const uint32_t *group_live_count(const void *temp, size_t N, int group_bits, int bucket_target, int flags) {
+    const GroupPlan P = group_plan(N, group_bits, bucket_target, flags);
+    return reinterpret_cast<const uint32_t *>(static_cast<const char *>(temp) + P.off_ticket) + 3;
+}
 
 template <int TPB>
 static void part_pass(const GrTiling &tl, size_t entries, uint32_t shift, uint32_t bits, const uint64_t *kin, const uint32_t *vin, uint64_t *kout,
-                      uint32_t *vout, uint32_t *hist, uint32_t *goffs, void *scan_tmp, size_t scan_bytes, hipStream_t st, rb_graph *prof) {
+                      uint32_t *vout, uint32_t *hist, uint32_t *goffs, void *scan_tmp, size_t scan_bytes, hipStream_t st, rb_graph *prof,
+                      uint32_t *n_live_dev = nullptr /* non-null: the pass drops cancelled records and leaves the number of live ones here */) {
     const dim3 grid(tl.grid_tiles), blk(TPB);
     if (prof) prof->prof_begin(st);
-    hipLaunchKernelGGL(k_part_count<TPB>, grid, blk, 0, st, kin, tl, shift, bits, hist);
+    if (n_live_dev) RB_HIP(hipMemsetAsync(hist + entries, 0, 4, st));        // one entry more: its scanned value is the total
+    hipLaunchKernelGGL(k_part_count<TPB>, grid, blk, 0, st, kin, tl, shift, bits, hist, n_live_dev ? vin : (const uint32_t *)nullptr);
     if (prof) { prof->prof_end("group_part_count", st); prof->prof_begin(st); }
-    exclusive_scan_u32(scan_tmp, scan_bytes, hist, goffs, entries, st);
+    exclusive_scan_u32(scan_tmp, scan_bytes, hist, goffs, entries + (n_live_dev ? 1 : 0), st);
+    if (n_live_dev) hipLaunchKernelGGL(k_copy_u32, dim3(1), dim3(64), 0, st, n_live_dev, goffs + entries);
     if (prof) { prof->prof_end("group_scan", st); prof->prof_begin(st); }
     const uint32_t wide = !(getenv("RB_GROUP_WIDE_LDS") && atoi(getenv("RB_GROUP_WIDE_LDS")) == 0);
-    if (bits <= 8u) hipLaunchKernelGGL((k_part_scatter<TPB, 8>), grid, blk, 0, st, kin, vin, tl, shift, bits, goffs, kout, vout, wide);
-    else hipLaunchKernelGGL((k_part_scatter<TPB, GR_PART_MAX_BITS>), grid, blk, 0, st, kin, vin, tl, shift, bits, goffs, kout, vout, wide);
+    if (bits <= 8u) hipLaunchKernelGGL((k_part_scatter<TPB, 8>), grid, blk, 0, st, kin, vin, tl, shift, bits, goffs, kout, vout, wide, n_live_dev ? 1u : 0u);
+    else hipLaunchKernelGGL((k_part_scatter<TPB, GR_PART_MAX_BITS>), grid, blk, 0, st, kin, vin, tl, shift, bits, goffs, kout, vout, wide, n_live_dev ? 1u : 0u);
     if (prof) prof->prof_end("group_part_scatter", st);
 }
 
@@ -871,20 +899,21 @@ static void group_records_impl(const GroupPlan &P, uint64_t *keys0, uint32_t *va
         uint32_t *hist = reinterpret_cast<uint32_t *>(tp + P.off_hist), *goffs = reinterpret_cast<uint32_t *>(tp + P.off_goffs);
         void *scan_tmp = tp + P.off_scan;
         GrTiling t1{nullptr, nullptr, P.n, P.ntiles, gr_grid_for_tiles(P.ntiles), P.xcd_map};
-        part_pass<TPB>(t1, (size_t)P.ntiles << P.t_hi, P.shift_hi, P.t_hi, kin, vin, keys_tmp, vals_tmp, hist, goffs, scan_tmp, P.scan_bytes, st, prof);
+        uint32_t *n_live = P.dead ? ticket + 3 : nullptr;      // (the status / ticket block was zeroed above)
+        part_pass<TPB>(t1, (size_t)P.ntiles << P.t_hi, P.shift_hi, P.t_hi, kin, vin, keys_tmp, vals_tmp, hist, goffs, scan_tmp, P.scan_bytes, st, prof, n_live);
         kin = keys_tmp; vin = vals_tmp;
         uint32_t *segtb = nullptr, *segst = nullptr;
         if (P.t_lo) {
             GrTile *desc = reinterpret_cast<GrTile *>(tp + P.off_desc);
             segtb = reinterpret_cast<uint32_t *>(tp + P.off_segtb); segst = reinterpret_cast<uint32_t *>(tp + P.off_segst);
             uint32_t *nt2 = ticket + 1;
-            hipLaunchKernelGGL(k_seg_tiles, dim3(1), dim3(1024), 0, st, goffs, P.ntiles, 1u << P.t_hi, P.n, 1u << P.t_lo, desc, segtb, segst, nt2);
+            hipLaunchKernelGGL(k_seg_tiles, dim3(1), dim3(1024), 0, st, goffs, P.ntiles, 1u << P.t_hi, P.n, 1u << P.t_lo, desc, segtb, segst, nt2, (const uint32_t *)n_live);
             RB_HIP(hipMemsetAsync(hist, 0, ((size_t)P.ntiles2_max << P.t_lo) * 4, st));
             GrTiling t2{desc, nt2, P.n, P.ntiles2_max, gr_grid_for_tiles(P.ntiles2_max), P.xcd_map};
             part_pass<TPB>(t2, (size_t)P.ntiles2_max << P.t_lo, P.shift_lo, P.t_lo, kin, vin, keys0, vals0, hist, goffs, scan_tmp, P.scan_bytes, st, prof);
             kin = keys0; vin = vals0;
         }
-        hipLaunchKernelGGL(k_bucket_bounds, dim3((P.nbuckets + 256u) / 256u), dim3(256), 0, st, goffs, P.ntiles, segtb, segst, P.t_hi, P.t_lo, P.n, bstart);
+        hipLaunchKernelGGL(k_bucket_bounds, dim3((P.nbuckets + 256u) / 256u), dim3(256), 0, st, goffs, P.ntiles, segtb, segst, P.t_hi, P.t_lo, P.n, bstart, (const uint32_t *)n_live);
     } else
         hipLaunchKernelGGL(k_bucket_bounds, dim3(1), dim3(64), 0, st, (const uint32_t *)nullptr, 0u, (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, 0u, P.n, bstart);
     uint32_t *big_list = reinterpret_cast<uint32_t *>(tp + P.off_big), *n_big = ticket + 2;
@@ -916,9 +945,9 @@ static void group_records_impl(const GroupPlan &P, uint64_t *keys0, uint32_t *va
 void group_records_device(uint64_t *keys0, uint32_t *vals0, uint64_t *keys_tmp, uint32_t *vals_tmp, size_t N, int group_bits,
                           uint64_t seed, uint64_t ordinal0, uint32_t pos_bits, void *temp, size_t temp_bytes,
                           uint32_t *vals_out, uint8_t *tz_out, uint64_t *uniq, uint32_t *counts, uint32_t *starts, uint32_t *n_runs_dev,
-                          hipStream_t st, rb_graph *prof, int bucket_target) {
+                          hipStream_t st, rb_graph *prof, int bucket_target, int flags) {
     RB_REQUIRE(N > 0 && N < (1ull << 32) - 2 * GR_TILE, "group_records_device: bad record count");
-    const GroupPlan P = group_plan(N, group_bits, bucket_target);
+    const GroupPlan P = group_plan(N, group_bits, bucket_target, flags);
     RB_REQUIRE(temp_bytes >= P.total, "group_records_device: temp too small");
     const GroupRng rng{seed, ordinal0, pos_bits};
     if (P.tpb == 512u) group_records_impl<512>(P, keys0, vals0, keys_tmp, vals_tmp, rng, static_cast<char *>(temp), vals_out, tz_out, uniq, counts, starts, n_runs_dev, st, prof);

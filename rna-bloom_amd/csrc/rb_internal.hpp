@@ -126,12 +126,14 @@ void run_length_encode_u64(void *temp, size_t temp_bytes, const uint64_t *keys, 
 // hand-written grouping stage of the insert pipeline (rb_group.hip): N (h0, occurrence) records -> occurrences in
 // grouped order, their draw strengths, runs (hash, count, start) and the run count, all on `st`, nothing synchronised.
 // keys0/vals0 are clobbered; keys_tmp/vals_tmp are scratch of the same size.
-void group_debug_big(const void *temp, size_t N, int group_bits, int bucket_target, uint32_t *n_big_out, uint64_t *records_out, uint32_t *largest_out);
-size_t group_temp_bytes(size_t N, int group_bits, int bucket_target = 0);
+constexpr int GR_FLAG_DEAD = 1;     // the records may include ones the emit pass cancelled (key and occurrence id all ones): dropped by the first partition pass
+void group_debug_big(const void *temp, size_t N, int group_bits, int bucket_target, uint32_t *n_big_out, uint64_t *records_out, uint32_t *largest_out, int flags = 0);
+size_t group_temp_bytes(size_t N, int group_bits, int bucket_target = 0, int flags = 0);
+const uint32_t *group_live_count(const void *temp, size_t N, int group_bits, int bucket_target, int flags);
 void group_records_device(uint64_t *keys0, uint32_t *vals0, uint64_t *keys_tmp, uint32_t *vals_tmp, size_t N, int group_bits,
                           uint64_t seed, uint64_t ordinal0, uint32_t pos_bits, void *temp, size_t temp_bytes,
                           uint32_t *vals_out, uint8_t *tz_out, uint64_t *uniq, uint32_t *counts, uint32_t *starts, uint32_t *n_runs_dev,
                           hipStream_t st, struct rb_graph *prof = nullptr /* per-kernel HIP-event timing into this handle's profile */,
-                          int bucket_target = 0 /* average fine-bucket size aimed at (0: the default, 3072) */);
+                          int bucket_target = 0 /* average fine-bucket size aimed at (0: the default, 3072) */, int flags = 0 /* GR_FLAG_* */);
 
 }  // namespace rb
