@@ -549,7 +549,7 @@ k_filter_windows_fast(const uint64_t *__restrict__ codes, const uint32_t *__rest
                       const uint32_t *__restrict__ len, int64_t w0, int64_t nw, int k, uint32_t first_read,
                       uint32_t pos_bits, uint64_t seed, uint64_t ordinal0, Npf cache, Mpf mcache, uint32_t *__restrict__ cnt,
                       uint32_t *__restrict__ keepmask, uint32_t *__restrict__ total_spread, uint32_t dbg_flags,
-                      uint32_t own_mask, uint32_t own_rank) {
+                      OwnRange own) {
     __shared__ uint64_t s_tf[25], s_tr[25];
     extern __shared__ uint32_t s_ring[];                        // [k-m+1][lane], dynamic: orders of the current block of m-mers / suffix minima of the previous one
     __shared__ unsigned long long s_bkt[MPF ? 16 * 64 : 1];     // [slot][lane]: image of the current bucket
@@ -603,7 +603,7 @@ k_filter_windows_fast(const uint64_t *__restrict__ codes, const uint32_t *__rest
                     const uint32_t p = b0 + j + 1u - uk;
                     const uint64_t h0 = (MODE == 0) ? f : (MODE == 2) ? rv : canonical(f, rv);
                     // sharded engine: every rank walks all reads and keeps the k-mers it owns
-                    if (((uint32_t)(h0 >> RB_OWNER_SHIFT) & own_mask) == own_rank) {
+                    if (own_mine(own, h0)) {
                         uint32_t s_known = 0;
                         if (MPF) {
                             // sliding-window minimum in O(1) (van Herk / Gil-Werman): the window's uw m-mers are the tail of the
@@ -766,7 +766,7 @@ k_filter_reads(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ 
                const uint32_t *__restrict__ word_read, const uint32_t *__restrict__ len, int64_t w0, int64_t nw, int k,
                uint32_t W, uint32_t first_read, uint32_t pos_bits, uint64_t seed, uint64_t ordinal0, Npf cache, Mpf mcache,
                uint32_t *__restrict__ cnt, uint32_t *__restrict__ keepmask, uint32_t *__restrict__ total_spread,
-               uint32_t dbg_flags, uint32_t own_mask, uint32_t own_rank, ulonglong2 *__restrict__ wstate) {
+               uint32_t dbg_flags, OwnRange own, ulonglong2 *__restrict__ wstate) {
     __shared__ uint64_t s_tf[25], s_tr[25];
     extern __shared__ uint32_t s_ring[];                        // [k-m+1][lane], dynamic: orders of the current block of m-mers / suffix minima of the previous one
     __shared__ unsigned long long s_bkt[MPF ? 16 * 64 : 1];     // [slot][lane]: image of the current bucket
@@ -838,7 +838,7 @@ k_filter_reads(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ 
                         const uint32_t p = b + 1u - uk;
                         const uint64_t h0 = (MODE == 0) ? f : (MODE == 2) ? rv : canonical(f, rv);
                         // sharded engine: every rank walks all reads and keeps the k-mers it owns
-                        if (((uint32_t)(h0 >> RB_OWNER_SHIFT) & own_mask) == own_rank) {
+                        if (own_mine(own, h0)) {
                             uint32_t s_known = 0;
                             if (MPF) {
                                 uint32_t omin = blk_p;           // sliding-window minimum, see k_filter_windows_fast
@@ -895,7 +895,7 @@ k_filter_emit(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ v
               const uint32_t *__restrict__ word_read, const uint32_t *__restrict__ woff,
               const uint32_t *__restrict__ len, int64_t w0, int64_t nw, int k, uint32_t first_read,
               uint32_t pos_bits, uint64_t seed, uint64_t ordinal0, Npf cache, uint32_t dbg_flags,
-              uint32_t own_mask, uint32_t own_rank, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
+              OwnRange own, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
               uint32_t cap, unsigned long long *state, uint32_t n_blocks, uint32_t *__restrict__ kept_out,
               uint32_t *__restrict__ total_spread) {
     __shared__ uint64_t s_key[64 * 33];
@@ -942,7 +942,7 @@ k_filter_emit(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ v
                 if (run >= uk) {
                     const uint32_t p = b0 + j + 1u - uk;
                     const uint64_t h0 = (MODE == 0) ? f : (MODE == 2) ? rv : canonical(f, rv);
-                    if (((uint32_t)(h0 >> RB_OWNER_SHIFT) & own_mask) == own_rank) {   // sharded engine: my k-mer?
+                    if (own_mine(own, h0)) {   // sharded engine: my k-mer?
                         const uint32_t s_known = (dbg_flags & 1u) ? 0u : npf_lookup(cache, h0);
                         bool keep = true;
                         if (s_known) keep = draw_strength(rng_pos(rstate, p)) >= s_known;
@@ -1046,14 +1046,14 @@ static uint32_t read_lane_words(const rb_batch *b, int64_t nw, int k) {
 }
 void launch_filter_windows(const rb_batch *b, int64_t w0, int64_t nw, int k, int mode, uint32_t first_read,
                            uint32_t pos_bits, uint64_t seed, uint64_t ordinal0, Npf cache, uint32_t *cnt, uint32_t *keepmask,
-                           uint32_t *total_spread, hipStream_t s, uint32_t own_mask, uint32_t own_rank, Mpf mcache, void *wstate) {
+                           uint32_t *total_spread, hipStream_t s, OwnRange own, Mpf mcache, void *wstate) {
     if (nw <= 0) return;
     uint32_t dbgf = getenv("RB_FILT_DBG") ? (uint32_t)atoi(getenv("RB_FILT_DBG")) : 0u;
     if (!cache.tab) dbgf |= 1u;                       // no cache: ownership test only
     dim3 g(blocks_for(nw, 64)), t(64);
 #define RB_LAUNCH_FILT(M, P, W)                                                                                 \
     hipLaunchKernelGGL((k_filter_windows_fast<M, P, W>), g, t, ring_bytes, s, b->codes, b->valid, b->word_read, b->woff, b->len, \
-                       w0, nw, k, first_read, pos_bits, seed, ordinal0, cache, mcache, cnt, keepmask, total_spread, dbgf, own_mask, own_rank)
+                       w0, nw, k, first_read, pos_bits, seed, ordinal0, cache, mcache, cnt, keepmask, total_spread, dbgf, own)
     RB_REQUIRE(k <= 64, "prefilter kernels take k <= 64");
     const bool use_m = mcache.tab && k <= RB_MPF_MAX_K && mcache.m <= (uint32_t)k && (uint32_t)k - mcache.m + 1u <= RB_MPF_MAX_RING;
     const size_t ring_bytes = use_m ? ((size_t)k - mcache.m + 1u) * 64u * sizeof(uint32_t) : 0;   // LDS per wavefront: 12.7 KB -> 11.2 KB at k = 25
@@ -1061,7 +1061,7 @@ void launch_filter_windows(const rb_batch *b, int64_t w0, int64_t nw, int k, int
         dim3 gc(blocks_for(nw / C, 64));
 #define RB_LAUNCH_FC(M, P)                                                                                        \
     hipLaunchKernelGGL((k_filter_reads<M, P>), gc, t, ring_bytes, s, b->codes, b->valid, b->word_read, b->len, w0, nw, k, C, \
-                       first_read, pos_bits, seed, ordinal0, cache, mcache, cnt, keepmask, total_spread, dbgf, own_mask, own_rank, \
+                       first_read, pos_bits, seed, ordinal0, cache, mcache, cnt, keepmask, total_spread, dbgf, own, \
                        reinterpret_cast<ulonglong2 *>(wstate))
         if (use_m) { if (mode == 0) RB_LAUNCH_FC(0, true); else if (mode == 2) RB_LAUNCH_FC(2, true); else RB_LAUNCH_FC(1, true); }
         else { if (mode == 0) RB_LAUNCH_FC(0, false); else if (mode == 2) RB_LAUNCH_FC(2, false); else RB_LAUNCH_FC(1, false); }
@@ -1077,7 +1077,7 @@ void launch_filter_windows(const rb_batch *b, int64_t w0, int64_t nw, int k, int
 }
 size_t filter_emit_state_bytes(int64_t nw) { return ((size_t)((nw + 63) / 64) + 2) * 8; }
 void launch_filter_emit(const rb_batch *b, int64_t w0, int64_t nw, int k, int mode, uint32_t first_read, uint32_t pos_bits,
-                        uint64_t seed, uint64_t ordinal0, Npf cache, uint32_t own_mask, uint32_t own_rank, uint64_t *keys,
+                        uint64_t seed, uint64_t ordinal0, Npf cache, OwnRange own, uint64_t *keys,
                         uint32_t *vals, uint32_t cap, void *state, uint32_t *kept_out, uint32_t *total_spread, hipStream_t s) {
     if (nw <= 0) return;
     const uint32_t nblk = (uint32_t)((nw + 63) / 64);
@@ -1086,7 +1086,7 @@ void launch_filter_emit(const rb_batch *b, int64_t w0, int64_t nw, int k, int mo
     dim3 g(nblk), t(64);
 #define RB_LAUNCH_FE(M)                                                                                      \
     hipLaunchKernelGGL(k_filter_emit<M>, g, t, 0, s, b->codes, b->valid, b->word_read, b->woff, b->len, w0, nw, k, \
-                       first_read, pos_bits, seed, ordinal0, cache, dbgf, own_mask, own_rank, keys, vals, cap,     \
+                       first_read, pos_bits, seed, ordinal0, cache, dbgf, own, keys, vals, cap,     \
                        reinterpret_cast<unsigned long long *>(state), nblk, kept_out, total_spread)
     if (mode == 0) RB_LAUNCH_FE(0); else if (mode == 2) RB_LAUNCH_FE(2); else RB_LAUNCH_FE(1);
 #undef RB_LAUNCH_FE

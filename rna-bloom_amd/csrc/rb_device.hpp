@@ -116,10 +116,29 @@ __host__ __device__ __forceinline__ float minifloat_to_float(uint32_t b) {
     return (float)(((b & 7u) | 8u) << e);          // exact: < 2^24
 }
 
-// k-mer owner in the sharded engine = hash bits [RB_OWNER_SHIFT, RB_OWNER_SHIFT + log2 G).  Not the top
-// bits: the canonical hash is a SIGNED minimum of two hashes, which skews the sign bit 3:1 and the
-// bits below it progressively less; bits around 40 are uniform, so ranks get equal shares.
-constexpr uint32_t RB_OWNER_SHIFT = 40;
+// k-mer owner in the sharded engine = the rank that holds the k-mer's FIRST COUNTER: idx_0 = (h0 >>> 1) % cbf_size lies in
+// exactly one rank's index range [lo, hi).  With the usual sizing (dbgbf bits = cbf bytes, both from
+// getExpectedSize(nk) with the same number of hash functions) idx_0 is also the k-mer's first Bloom bit, so probe 0 of both
+// filters is local to the k-mer's owner and only the other probes travel.  (Round 2 split the hash space by bits 40.. of the
+// hash: uniform too, but unrelated to where the filters live, so EVERY probe, claim and write was a routed request.)
+// hi == 0: no ownership test (single GPU).
+struct OwnRange {
+    Mod mod;
+    uint64_t lo, hi;
+};
+__device__ __forceinline__ bool own_mine(const OwnRange &o, uint64_t h0) {
+    if (!o.hi) return true;
+    const uint64_t idx = index_of(h0, o.mod);
+    return idx >= o.lo && idx < o.hi;
+}
+// rank of an index for shards of `span` indices each (span = roundup64(ceil(size / G)); inv = floor(2^64 / span)): one mulhi and one fix-up
+struct OwnSpan { uint64_t span, inv; };
+__host__ inline OwnSpan make_own_span(uint64_t span) { OwnSpan o; o.span = span; o.inv = span > 1 ? (uint64_t)(((unsigned __int128)1 << 64) / span) : ~0ull; return o; }
+__device__ __forceinline__ uint32_t own_rank_of(const OwnSpan &o, uint64_t idx) {
+    uint64_t q = __umul64hi(idx, o.inv);
+    if (idx - q * o.span >= o.span) ++q;
+    return (uint32_t)q;
+}
 
 // ---- no-op prefilter cache (DESIGN.md §3 "no-op prefilter") ----
 // 8-way set-associative table of 8-byte entries keyed by the FULL 64-bit base hash: a bucket is one

@@ -2122,7 +2122,7 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
                 void *wstate = nullptr;
                 if (filter_saves_state(b, sb.nw, g->k)) { g->wstate.reserve(((size_t)sb.nw + 1) * 16); wstate = g->wstate.p; }
                 launch_filter_windows(b, sb.w0, sb.nw, g->k, mode_hash, (uint32_t)sb.r0, pos_bits, g->p.rng_seed, ord0, fvp.npf,
-                                      g->chunk_cnt.as<uint32_t>(), g->chunk_mask.as<uint32_t>(), g->npf_tot.as<uint32_t>(), sp, 0u, 0u, fvp.mpf, wstate);
+                                      g->chunk_cnt.as<uint32_t>(), g->chunk_mask.as<uint32_t>(), g->npf_tot.as<uint32_t>(), sp, OwnRange{Mod{1, 0, 0}, 0, 0}, fvp.mpf, wstate);
                 exclusive_scan_u32(g->temp2.p, g->temp2.cap, g->chunk_cnt.as<uint32_t>(), g->chunk_off.as<uint32_t>(), (size_t)sb.nw + 1, sp);
                 uint32_t spread[16 * 32];
                 RB_HIP(hipMemcpyAsync(&sb.N, g->chunk_off.as<uint32_t>() + sb.nw, 4, hipMemcpyDeviceToHost, sp));
@@ -2163,7 +2163,7 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
                 const size_t cap = std::min<size_t>((size_t)sb.nw * 32, 0xFFFFFFF0ull);   // every window of the sub-batch
                 g->keys0.reserve(cap * 8); g->vals0.reserve(cap * 4);
                 g->chunk_mask.reserve(filter_emit_state_bytes(sb.nw));
-                launch_filter_emit(b, sb.w0, sb.nw, g->k, mode_hash, (uint32_t)sb.r0, pos_bits, g->p.rng_seed, ord0, fvp.npf, 0u, 0u,
+                launch_filter_emit(b, sb.w0, sb.nw, g->k, mode_hash, (uint32_t)sb.r0, pos_bits, g->p.rng_seed, ord0, fvp.npf, OwnRange{Mod{1, 0, 0}, 0, 0},
                                    g->keys0.as<uint64_t>(), g->vals0.as<uint32_t>(), (uint32_t)cap, g->chunk_mask.p,
                                    g->npf_tot.as<uint32_t>() + 500, g->npf_tot.as<uint32_t>(), sp);
                 uint32_t spread[16 * 32];
@@ -2238,7 +2238,7 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
             g->prof_begin(sp);
             FilterView fvp = g->view(ord0, pos_bits);
             launch_filter_windows(b, sb.w0, sb.nw, g->k, mode_hash, (uint32_t)sb.r0, pos_bits, g->p.rng_seed, ord0, fvp.npf,
-                                  g->chunk_cnt.as<uint32_t>(), g->chunk_mask.as<uint32_t>(), g->npf_tot.as<uint32_t>(), sp, 0u, 0u, fvp.mpf, g->wstate.p);
+                                  g->chunk_cnt.as<uint32_t>(), g->chunk_mask.as<uint32_t>(), g->npf_tot.as<uint32_t>(), sp, OwnRange{Mod{1, 0, 0}, 0, 0}, fvp.mpf, g->wstate.p);
             exclusive_scan_u32(g->temp2.p, g->temp2.cap, g->chunk_cnt.as<uint32_t>(), g->chunk_off.as<uint32_t>(), (size_t)sb.nw + 1, sp);
             RB_HIP(hipMemcpyAsync(pin, g->chunk_off.as<uint32_t>() + sb.nw, 4, hipMemcpyDeviceToHost, sp));
             RB_HIP(hipMemcpyAsync(pin + 16, g->npf_tot.p, 2048, hipMemcpyDeviceToHost, sp));

@@ -13,12 +13,12 @@ void launch_hash_windows(const rb_batch *b, int64_t w0, int64_t nw, int k, int m
                          hipStream_t s);
 
 // fast path with the no-op prefilter (k <= 31): per word the number of KEPT windows and their bit mask;
-// total usable windows are accumulated into total_spread[16*q], q < 32.  own_mask/own_rank: only
-// windows whose owner field ((h0 >> RB_OWNER_SHIFT) & own_mask) equals own_rank are considered at all
+// total usable windows are accumulated into total_spread[16*q], q < 32.  own: only
+// windows whose k-mer this rank owns (own_mine: first counter index inside [own.lo, own.hi)) are considered at all
 // (sharded engine; mask 0 = every window).  cache.tab == nullptr: no prefilter, ownership only.
 void launch_filter_windows(const rb_batch *b, int64_t w0, int64_t nw, int k, int mode, uint32_t first_read,
                            uint32_t pos_bits, uint64_t seed, uint64_t ordinal0, Npf cache, uint32_t *cnt, uint32_t *keepmask,
-                           uint32_t *total_spread, hipStream_t s, uint32_t own_mask = 0, uint32_t own_rank = 0,
+                           uint32_t *total_spread, hipStream_t s, OwnRange own = OwnRange{Mod{1, 0, 0}, 0, 0},
                            Mpf mcache = Mpf{nullptr, 0, 0},    // mcache.tab != nullptr: minimizer-bucketed cache instead of `cache`
                            void *wstate = nullptr);            // filter_saves_state(): 16 B per word for the resuming emit pass
 bool filter_saves_state(const rb_batch *b, int64_t nw, int k);
@@ -27,7 +27,7 @@ bool filter_saves_state(const rb_batch *b, int64_t nw, int k);
 // room).  `state`: scratch of filter_emit_state_bytes(nw) bytes.
 size_t filter_emit_state_bytes(int64_t nw);
 void launch_filter_emit(const rb_batch *b, int64_t w0, int64_t nw, int k, int mode, uint32_t first_read, uint32_t pos_bits,
-                        uint64_t seed, uint64_t ordinal0, Npf cache, uint32_t own_mask, uint32_t own_rank, uint64_t *keys,
+                        uint64_t seed, uint64_t ordinal0, Npf cache, OwnRange own, uint64_t *keys,
                         uint32_t *vals, uint32_t cap, void *state, uint32_t *kept_out, uint32_t *total_spread, hipStream_t s);
 // second look of the two-phase prefilter: the emit pass asks the recent-store table about every window it
 // writes and CANCELS the record (key and occurrence id all ones; the grouping stage drops such records) if the occurrence

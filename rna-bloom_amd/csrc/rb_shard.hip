@@ -2,8 +2,11 @@
 // [lo,hi) of every filter.  The phases mirror the single-GPU pipeline of rb_graph.hip, cut where data
 // has to move between ranks (see the protocol comment in include/rb_capi.h and DESIGN.md §6):
 //
-//   requester = owner of a k-mer (log2 G middle bits of its hash): holds all occurrences of its k-mers
-//               in order, decides found-flags / op counts / counter updates;
+//   requester = owner of a k-mer = the rank that holds its FIRST COUNTER (idx_0 = (h0 >>> 1) % cbf_size in the rank's range):
+//               holds all occurrences of its k-mers in order, decides found-flags / op counts / counter updates.  Probes
+//               that fall into its own ranges — probe 0 of the counting filter always, probe 0 of dbgbf too when both
+//               filters have the same size, any other probe with probability 1/G — never become requests: the run-based
+//               kernels of this file test / set / claim / write them in place (k_shard_probe, k_local_*, k_resolve_shard);
 //   owner     = owner of a filter index range: tests & sets bits, arbitrates first setters, hands
 //               out counter claims, stores counter bytes;
 //   component owner = rank that replays one connected component of the "runs that share a counter"
@@ -30,6 +33,10 @@ struct ShardState {
     uint32_t pos_bits = 0;
     DevBuf dreq_pos, creq_pos;                 // [D*h] position of (run, probe) in the bucketed request order
     DevBuf creq_dup;                           // [D*h] for a duplicated counter: the earlier probe it copies
+    DevBuf lctr;                               // 32 spread counters: local claims that met a claimed counter (k_shard_probe)
+    DevBuf lmask, lcoll, lcv;                  // per run: local probes (dbg mask | cbf mask << 8), local Bloom probes that met another probe, local claim replies (one byte per probe)
+    bool has_f = false, has_cs = false;        // serve left a collision table / a contested-counter table for resolve
+    uint32_t f_log2 = 1, cs_log2 = 1, csf_log2 = 16;
     DevBuf cfinal, conf_list;
     // routing scratch
     DevBuf stage0, stage1, stage2, stage3, rhist, roffs, bounds;
@@ -62,6 +69,8 @@ struct ShardState {
 
 namespace {
 
+// index ranges of the filters this rank holds
+struct LocalRanges { uint64_t dlo, dhi, clo, chi; };
 inline int64_t roundup64(int64_t x) { return (x + 63) / 64 * 64; }
 
 struct Geometry { int64_t span, lo, hi; };
@@ -71,6 +80,13 @@ Geometry geom(int64_t size, int rank, int count) {
     g.lo = std::min<int64_t>(size, g.span * rank);
     g.hi = std::min<int64_t>(size, g.span * (rank + 1));
     return g;
+}
+
+LocalRanges local_ranges(const rb_graph *g) { return LocalRanges{(uint64_t)g->dbg.lo, (uint64_t)g->dbg.hi, (uint64_t)g->cbf_lo, (uint64_t)g->cbf_hi}; }
+// the k-mers this rank owns: first counter index inside its range (no test at all on a single rank)
+OwnRange own_range(const rb_graph *g) {
+    if (g->shard_count <= 1) return OwnRange{Mod{1, 0, 0}, 0, 0};
+    return OwnRange{g->cbf_mod, (uint64_t)g->cbf_lo, (uint64_t)g->cbf_hi};
 }
 
 void *slot_reserve(ShardState *S, int slot, size_t bytes) {
@@ -184,12 +200,12 @@ struct RouteIdx {
 // generic window-hash path (k > 31): verdict per record — this rank owns the k-mer, and the no-op
 // prefilter does not know that the occurrence's draw cannot move a counter
 __global__ void k_rec_keep(FilterView fv, int use_cache, const uint64_t *__restrict__ keys, const uint32_t *__restrict__ occ, size_t n,
-                           uint32_t own_mask, uint32_t own_rank, uint8_t *__restrict__ keep, uint32_t *__restrict__ owned_spread) {
+                           OwnRange own, uint8_t *__restrict__ keep, uint32_t *__restrict__ owned_spread) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     bool mine = false, k = false;
     if (i < n) {
         const uint64_t h0 = keys[i];
-        mine = ((uint32_t)(h0 >> RB_OWNER_SHIFT) & own_mask) == own_rank;
+        mine = own_mine(own, h0);
         if (mine) {
             const uint32_t s = use_cache ? npf_lookup(fv.npf, h0) : 0u;
             k = !s || draw_strength(occ_rnd(fv, occ[i])) >= s;
@@ -199,51 +215,165 @@ __global__ void k_rec_keep(FilterView fv, int use_cache, const uint64_t *__restr
     const unsigned long long m = __ballot(mine);
     if ((threadIdx.x & 63u) == 0 && m) atomicAdd(&owned_spread[16u * (blockIdx.x & 31u)], (uint32_t)__popcll(m));
 }
-// per run: one Bloom-bit request per probe, one claim request per DISTINCT counter
-__global__ void k_make_requests(FilterView fv, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ starts,
-                                const uint32_t *__restrict__ vals, uint32_t D, int mode,
-                                uint64_t *__restrict__ d_idx, uint64_t *__restrict__ d_probe,
-                                uint64_t *__restrict__ c_idx, uint8_t *__restrict__ c_drop, uint8_t *__restrict__ c_dup) {
+// Stage A of a run at its k-mer's owner.  A probe that falls into this rank's own range is handled HERE, on the run: the
+// Bloom bit is tested against the pre-batch state (bits are set later, by k_local_dbg_set in the serve phase, after the
+// remote requests have been tested too), the counter is claimed at once (claims commute).  Only the other probes become
+// requests: (index, probe id) per Bloom bit, the index per DISTINCT counter.  lmask = local Bloom probes | local counter
+// probes << 8; lcv = the claim replies of the local counter probes, one byte per probe (bit 7 = claimed before).
+__global__ void k_shard_probe(FilterView fv, LocalRanges R, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ starts,
+                              const uint32_t *__restrict__ vals, uint32_t D, int mode,
+                              uint64_t *__restrict__ d_idx, uint64_t *__restrict__ d_probe, uint8_t *__restrict__ d_drop,
+                              uint64_t *__restrict__ c_idx, uint8_t *__restrict__ c_drop, uint8_t *__restrict__ c_dup,
+                              uint32_t *__restrict__ status, uint16_t *__restrict__ lmask, uint64_t *__restrict__ lcv,
+                              uint32_t *__restrict__ foreign_spread) {
+    uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t nforeign = 0;
+    if (d < D) {
+        const uint64_t h0 = uniq[d];
+        const unsigned long long v_first = vals[starts[d]];
+        uint32_t premask = 0, dm = 0, cm = 0;
+        if (mode != M_COUNT_ONLY)
+            for (int j = 0; j < fv.dbg_h; ++j) {
+                const size_t q = (size_t)d * fv.dbg_h + j;
+                const uint64_t idx = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.dbg_mod);
+                const bool local = idx >= R.dlo && idx < R.dhi;
+                d_idx[q] = idx;
+                d_probe[q] = (v_first << 4) | (unsigned long long)j;
+                d_drop[q] = local ? 1u : 0u;
+                if (local) { dm |= 1u << j; if (bit_test(fv.dbg, idx - R.dlo)) premask |= 1u << j; }
+            }
+        uint64_t cidx[RB_MAX_HASH], lc = 0;
+        for (int j = 0; j < fv.cbf_h; ++j) {
+            const size_t q = (size_t)d * fv.cbf_h + j;
+            cidx[j] = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod);
+            int dup = -1;
+            for (int p = 0; p < j; ++p) if (cidx[p] == cidx[j] && dup < 0) dup = p;
+            const bool local = dup < 0 && cidx[j] >= R.clo && cidx[j] < R.chi;
+            c_idx[q] = cidx[j];
+            c_drop[q] = (dup >= 0 || local) ? 1u : 0u;
+            c_dup[q] = (uint8_t)(dup >= 0 ? dup : j);
+            if (local) {
+                cm |= 1u << j;
+                const uint32_t byte = cbf_claim(fv.cbf, cidx[j] - R.clo);
+                lc |= (uint64_t)byte << (8 * j);
+                nforeign += (byte & CLAIM) ? 1u : 0u;
+            }
+        }
+        status[d] = premask;
+        lmask[d] = (uint16_t)(dm | (cm << 8));
+        lcv[d] = lc;
+    }
+    for (int o = 32; o > 0; o >>= 1) nforeign += __shfl_down(nforeign, o, 64);
+    if ((threadIdx.x & 63u) == 0 && nforeign) atomicAdd(&foreign_spread[16u * (blockIdx.x & 31u)], nforeign);
+}
+// serve phase, local half: set the local Bloom bits that were clear before the sub-batch; a bit found set now was met by
+// another probe of the sub-batch (local or remote) -> lcoll, counted
+__global__ void k_local_dbg_set(FilterView fv, LocalRanges R, const uint64_t *__restrict__ uniq, uint32_t D, const uint32_t *__restrict__ status,
+                                const uint16_t *__restrict__ lmask, uint8_t *__restrict__ lcoll, uint32_t *__restrict__ spread) {
+    uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t ncoll = 0;
+    if (d < D) {
+        uint32_t need = (lmask[d] & 0xFFu) & ~(status[d] & 0xFFu), coll = 0;
+        const uint64_t h0 = uniq[d];
+        while (need) {
+            const int j = __ffs((int)need) - 1;
+            need &= need - 1u;
+            const uint64_t b = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.dbg_mod) - R.dlo;
+            const uint32_t m = 1u << (uint32_t)(b & 31u);
+            if (atomicOr(&fv.dbg[b >> 5], m) & m) { coll |= 1u << j; ++ncoll; }
+        }
+        lcoll[d] = (uint8_t)coll;
+    }
+    for (int o = 32; o > 0; o >>= 1) ncoll += __shfl_down(ncoll, o, 64);
+    if ((threadIdx.x & 63u) == 0 && ncoll) atomicAdd(&spread[16u * (blockIdx.x & 31u)], ncoll);
+}
+// the local probes that met another probe enter the collision table (same table, same ids as the remote requests: k_own_collide_*)
+__global__ void k_local_collide_insert(FilterView fv, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ starts, const uint32_t *__restrict__ vals,
+                                       uint32_t D, const uint8_t *__restrict__ lcoll, Slot *ftable, uint32_t f_log2) {
     uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= D) return;
+    uint32_t coll = lcoll[d];
+    if (!coll) return;
     const uint64_t h0 = uniq[d];
     const unsigned long long v_first = vals[starts[d]];
-    if (mode != M_COUNT_ONLY)
-        for (int j = 0; j < fv.dbg_h; ++j) {
-            const size_t q = (size_t)d * fv.dbg_h + j;
-            d_idx[q] = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.dbg_mod);
-            d_probe[q] = (v_first << 4) | (unsigned long long)j;
-        }
-    uint64_t cidx[RB_MAX_HASH];
-    for (int j = 0; j < fv.cbf_h; ++j) {
-        const size_t q = (size_t)d * fv.cbf_h + j;
-        cidx[j] = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod);
-        int dup = -1;
-        for (int p = 0; p < j; ++p) if (cidx[p] == cidx[j] && dup < 0) dup = p;
-        c_idx[q] = cidx[j];
-        c_drop[q] = dup >= 0;
-        c_dup[q] = (uint8_t)(dup >= 0 ? dup : j);
+    while (coll) {
+        const int j = __ffs((int)coll) - 1;
+        coll &= coll - 1u;
+        Slot *sl = table_insert(ftable, f_log2, index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.dbg_mod));
+        atomicMin(&sl->val, (v_first << 4) | (unsigned long long)j);
+    }
+}
+// ... and the local probes that set their bit first must be in it too, if the bit has an entry
+__global__ void k_local_collide_fixup(FilterView fv, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ starts, const uint32_t *__restrict__ vals,
+                                      uint32_t D, const uint32_t *__restrict__ status, const uint16_t *__restrict__ lmask, const uint8_t *__restrict__ lcoll,
+                                      Slot *ftable, uint32_t f_log2) {
+    uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= D) return;
+    uint32_t setter = (lmask[d] & 0xFFu) & ~(status[d] & 0xFFu) & ~(uint32_t)lcoll[d];
+    if (!setter) return;
+    const uint64_t h0 = uniq[d];
+    const unsigned long long v_first = vals[starts[d]];
+    while (setter) {
+        const int j = __ffs((int)setter) - 1;
+        setter &= setter - 1u;
+        Slot *sl = const_cast<Slot *>(table_find(ftable, f_log2, index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.dbg_mod)));
+        if (sl) atomicMin(&sl->val, (v_first << 4) | (unsigned long long)j);
+    }
+}
+// local claims that found the counter claimed already: into the contested-counter table (next to the remote ones, k_own_cs_build)
+__global__ void k_local_cs_build(FilterView fv, const uint64_t *__restrict__ uniq, uint32_t D, const uint16_t *__restrict__ lmask, const uint64_t *__restrict__ lcv,
+                                 Slot *cs, uint32_t cs_log2, uint32_t *__restrict__ csf, uint32_t csf_log2) {
+    uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= D) return;
+    const uint64_t lc = lcv[d];
+    if (!(lc & 0x8080808080808080ull)) return;
+    uint32_t cm = (uint32_t)lmask[d] >> 8;
+    const uint64_t h0 = uniq[d];
+    while (cm) {
+        const int j = __ffs((int)cm) - 1;
+        cm &= cm - 1u;
+        if (!((lc >> (8 * j)) & 0x80ull)) continue;
+        const uint64_t idx = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod);
+        table_insert(cs, cs_log2, idx);
+        const uint64_t b = slot_of(idx, csf_log2);
+        atomicOr(&csf[b >> 5], 1u << (uint32_t)(b & 31u));
     }
 }
 
 // status bits 21..28: probes whose counter is claimed by another run of the sub-batch too
 constexpr uint32_t ST_CONTESTED_SHIFT = 21;
 
+// where a run's local probes find what the serve phase left: the collision table of the Bloom bits two probes met on and the
+// contested-counter table with its bit filter (either may be absent: nothing collided / nothing was contested)
+struct LocalTables { const Slot *ftab; uint32_t f_log2; const Slot *cs; uint32_t cs_log2; const uint32_t *csf; uint32_t csf_log2; };
 __global__ void k_resolve_shard(FilterView fv, const uint32_t *__restrict__ counts, const uint32_t *__restrict__ starts,
                                 uint32_t D, int mode, uint32_t light_ops, const uint32_t *__restrict__ dreq_pos,
                                 const uint8_t *__restrict__ dreply, const uint32_t *__restrict__ creq_pos,
                                 const uint8_t *__restrict__ c_dup, const uint8_t *__restrict__ creply,
                                 const uint8_t *__restrict__ tz, const uint64_t *__restrict__ uniq, uint32_t *__restrict__ status,
                                 uint32_t *__restrict__ nops, uint64_t *__restrict__ cvals, uint64_t *__restrict__ cfinal,
-                                uint8_t *__restrict__ cache_upd, const uint32_t *__restrict__ vals) {
+                                uint8_t *__restrict__ cache_upd, const uint32_t *__restrict__ vals,
+                                const uint16_t *__restrict__ lmask, const uint64_t *__restrict__ lcv, LocalTables T) {
     uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= D) return;
     if (cache_upd) cache_upd[d] = 0;
     const uint32_t m = counts[d];
+    const uint32_t dm = lmask[d] & 0xFFu, cm = (uint32_t)lmask[d] >> 8, lpre = status[d] & 0xFFu;
+    const uint64_t h0r = uniq[d], lc = lcv[d];
+    const bool sets = mode == M_ADD || mode == M_ADD_IF_ABSENT;
     uint32_t premask = 0;
     bool all_pre = true, found_first = true;
     if (mode != M_COUNT_ONLY) {
         for (int j = 0; j < fv.dbg_h; ++j) {
+            if ((dm >> j) & 1u) {                  // a local probe: pre-batch state from k_shard_probe, first setter from the collision table
+                if ((lpre >> j) & 1u) { premask |= 1u << j; continue; }
+                all_pre = false;
+                if (sets) {
+                    const Slot *sl = T.ftab ? table_find(T.ftab, T.f_log2, index_of(multi_hash(h0r, (uint32_t)j, fv.kmul), fv.dbg_mod)) : nullptr;
+                    if (!sl || sl->val == (((unsigned long long)vals[starts[d]] << 4) | (unsigned long long)j)) found_first = false;
+                }
+                continue;
+            }
             const uint8_t r = dreply[dreq_pos[(size_t)d * fv.dbg_h + j]];
             if (r & 1u) premask |= 1u << j;
             else { all_pre = false; if (r & 2u) found_first = false; }   // this probe was the first setter => bit was clear
@@ -261,7 +391,17 @@ __global__ void k_resolve_shard(FilterView fv, const uint32_t *__restrict__ coun
         const size_t q = (size_t)d * fv.cbf_h + j;
         const int src = c_dup[q];
         if (src != j) c[j] = c[src];
-        else {
+        else if ((cm >> j) & 1u) {             // a local counter: claimed by k_shard_probe; contested if anybody else's claim met it
+            const uint32_t r = (uint32_t)(lc >> (8 * j)) & 0xFFu;
+            c[j] = r & 0x7Fu;
+            bool con = (r & 0x80u) != 0u;
+            if (!con && T.cs) {
+                const uint64_t idx = index_of(multi_hash(h0r, (uint32_t)j, fv.kmul), fv.cbf_mod);
+                const uint64_t b = slot_of(idx, T.csf_log2);
+                con = ((T.csf[b >> 5] >> (uint32_t)(b & 31u)) & 1u) && table_find(T.cs, T.cs_log2, idx);
+            }
+            if (con) contested |= 1u << j;
+        } else {
             const uint8_t r = creply[creq_pos[q]];
             c[j] = r & 0x7Fu;
             if (r & 0x80u) contested |= 1u << j;
@@ -323,24 +463,30 @@ __global__ void k_cache_apply(FilterView fv, const CacheUpd *__restrict__ u, siz
 }
 // records of this rank's read slice, bucketed by the rank that owns their k-mer (stable)
 struct RouteRec {
-    const uint64_t *keys; const uint32_t *occ; const uint8_t *keep; uint32_t own_mask;
+    const uint64_t *keys; const uint32_t *occ; const uint8_t *keep; Mod cmod; OwnSpan cspan;
     uint64_t *out_keys; uint32_t *out_occ;
-    __device__ int dest(size_t i) const { return (keep && !keep[i]) ? -1 : (int)((uint32_t)(keys[i] >> RB_OWNER_SHIFT) & own_mask); }
+    __device__ int dest(size_t i) const { return (keep && !keep[i]) ? -1 : (int)own_rank_of(cspan, index_of(keys[i], cmod)); }
     __device__ void emit(size_t i, uint32_t pos) const { out_keys[pos] = keys[i]; out_occ[pos] = occ[i]; }
     __device__ void drop(size_t) const {}
 };
-__global__ void k_emit_writes(FilterView fv, const uint64_t *__restrict__ uniq, uint32_t D, const uint32_t *__restrict__ status,
-                              const uint8_t *__restrict__ c_dup, const uint64_t *__restrict__ cfinal,
+__global__ void k_emit_writes(FilterView fv, LocalRanges R, const uint64_t *__restrict__ uniq, uint32_t D, const uint32_t *__restrict__ status,
+                              const uint8_t *__restrict__ c_dup, const uint64_t *__restrict__ cfinal, const uint16_t *__restrict__ lmask,
                               uint64_t *__restrict__ w_idx, uint8_t *__restrict__ w_val, uint8_t *__restrict__ w_drop) {
     uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= D) return;
-    const uint32_t st = status[d];
+    const uint32_t st = status[d], cm = (uint32_t)lmask[d] >> 8;
     const uint64_t h0 = uniq[d], cf = cfinal[d];
     for (int j = 0; j < fv.cbf_h; ++j) {
         const size_t q = (size_t)d * fv.cbf_h + j;
-        const bool send = (c_dup[q] == j) && (st & (RUN_RELEASE | RUN_WRITES));
-        w_idx[q] = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod);
-        w_val[q] = (st & RUN_RELEASE) ? (uint8_t)0xFF : (uint8_t)(cf >> (8 * j));
+        bool send = (c_dup[q] == j) && (st & (RUN_RELEASE | RUN_WRITES));
+        const uint64_t idx = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod);
+        const uint8_t val = (st & RUN_RELEASE) ? (uint8_t)0xFF : (uint8_t)(cf >> (8 * j));
+        if (send && ((cm >> j) & 1u)) {        // this rank's own counter: written (or released) in place — the store drops the claim mark
+            if (val == 0xFFu) cbf_release(fv.cbf, idx - R.clo); else fv.cbf[idx - R.clo] = val;
+            send = false;
+        }
+        w_idx[q] = idx;
+        w_val[q] = val;
         w_drop[q] = !send;
     }
 }
@@ -753,7 +899,7 @@ void prep_filter(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, uint6
     P.wstate = wstate;
     launch_filter_windows(b, P.w0, P.nw, g->k, mode_hash, (uint32_t)first, pos_bits, g->p.rng_seed, ordinal0, cache,
                           g->chunk_cnt.as<uint32_t>(), g->chunk_mask.as<uint32_t>(), g->npf_tot.as<uint32_t>(), st,
-                          (uint32_t)S->G - 1u, (uint32_t)g->shard_rank, fv.mpf, wstate);
+                          own_range(g), fv.mpf, wstate);
     exclusive_scan_u32(g->temp2.p, g->temp2.cap, g->chunk_cnt.as<uint32_t>(), g->chunk_off.as<uint32_t>(), nw + 1, st);
     RB_HIP(hipMemcpyAsync(&S->pinned[0], g->chunk_off.as<uint32_t>() + nw, 4, hipMemcpyDeviceToHost, st));
     RB_HIP(hipMemcpyAsync(&S->pinned[16], g->npf_tot.p, 2048, hipMemcpyDeviceToHost, st));
@@ -765,19 +911,26 @@ void make_and_route_requests(rb_graph *g, uint32_t D, int mode, uint64_t ordinal
     hipStream_t s = g->stream;
     FilterView fv = g->view(ordinal0, pos_bits);
     const size_t nd = mode == M_COUNT_ONLY ? 0 : (size_t)D * fv.dbg_h, nc = (size_t)D * fv.cbf_h;
-    S->stage0.reserve(nd * 8 + 16); S->stage1.reserve(nd * 8 + 16); S->stage3.reserve(nc * 8 + 16); S->stage2.reserve(nc + 16);
+    S->stage0.reserve(nd * 8 + 16); S->stage1.reserve(nd * 8 + 16); S->stage3.reserve(nc * 8 + 16); S->stage2.reserve(nc + nd + 32);
     S->creq_dup.reserve(nc + 16);
     S->dreq_pos.reserve(nd * 4 + 16); S->creq_pos.reserve(nc * 4 + 16);
-    hipLaunchKernelGGL(k_make_requests, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, g->uniq().as<uint64_t>(), g->starts().as<uint32_t>(),
-                       g->vals1().as<uint32_t>(), D, mode, S->stage0.as<uint64_t>(), S->stage1.as<uint64_t>(),
-                       S->stage3.as<uint64_t>(), S->stage2.as<uint8_t>(), S->creq_dup.as<uint8_t>());
-    RouteIdx fd{S->stage0.as<uint64_t>(), nullptr, (uint64_t)S->span[RB_DBGBF], S->stage1.as<uint64_t>(), nullptr,
+    S->lmask.reserve((size_t)D * 2 + 16); S->lcv.reserve((size_t)D * 8 + 16); S->lcoll.reserve((size_t)D + 16);
+    S->lctr.reserve(2048);
+    g->status.reserve((size_t)D * 4);
+    RB_HIP(hipMemsetAsync(S->lctr.p, 0, 2048, s));
+    uint8_t *c_drop = S->stage2.as<uint8_t>(), *d_drop = c_drop + nc + 16;
+    // local probes are tested / claimed on the spot, the others become requests (k_shard_probe)
+    hipLaunchKernelGGL(k_shard_probe, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, local_ranges(g), g->uniq().as<uint64_t>(), g->starts().as<uint32_t>(),
+                       g->vals1().as<uint32_t>(), D, mode, S->stage0.as<uint64_t>(), S->stage1.as<uint64_t>(), d_drop,
+                       S->stage3.as<uint64_t>(), c_drop, S->creq_dup.as<uint8_t>(), g->status.as<uint32_t>(), S->lmask.as<uint16_t>(),
+                       S->lcv.as<uint64_t>(), S->lctr.as<uint32_t>());
+    RouteIdx fd{S->stage0.as<uint64_t>(), d_drop, (uint64_t)S->span[RB_DBGBF], S->stage1.as<uint64_t>(), nullptr,
                 nullptr, nullptr, nullptr, S->dreq_pos.as<uint32_t>()};
     route(g, fd, nd, dreq_counts, [&](RouteIdx &ff, size_t kept) {
         ff.out_idx = (uint64_t *)slot_reserve(S, RB_SLOT_DREQ_IDX, kept * 8);
         ff.out64 = (uint64_t *)slot_reserve(S, RB_SLOT_DREQ_PROBE, kept * 8);
     });
-    RouteIdx fc{S->stage3.as<uint64_t>(), S->stage2.as<uint8_t>(), (uint64_t)S->span[RB_CBF], nullptr, nullptr,
+    RouteIdx fc{S->stage3.as<uint64_t>(), c_drop, (uint64_t)S->span[RB_CBF], nullptr, nullptr,
                 nullptr, nullptr, nullptr, S->creq_pos.as<uint32_t>()};
     route(g, fc, nc, creq_counts, [&](RouteIdx &ff, size_t kept) { ff.out_idx = (uint64_t *)slot_reserve(S, RB_SLOT_CREQ_IDX, kept * 8); });
 }
@@ -950,7 +1103,6 @@ int rb_shard_hash_group(rb_graph *g, const rb_batch *b, int64_t first, int64_t n
         S->mode = mode;
         const bool pairs = (flags & RB_ADD_STORE_READ_PAIRS) != 0;
         if (pairs) RB_REQUIRE(g->rpk.bits && g->read_d > 0, "STORE_READ_PAIRS needs use_read_paired_kmers and a read pair distance > 0");
-        const uint32_t own_mask = (uint32_t)S->G - 1u, own_rank = (uint32_t)g->shard_rank;
         FilterView fv = g->view(ordinal0, pos_bits);
         const bool use_cache = g->npf_log2 != 0;
         // ---- every rank walks ALL reads of the sub-batch and keeps the windows whose k-mer it owns ----
@@ -987,7 +1139,7 @@ int rb_shard_hash_group(rb_graph *g, const rb_batch *b, int64_t first, int64_t n
                     launch_hash_windows(b, w0, nw, g->k, mode_hash, g->chunk_off.as<uint32_t>(), (uint32_t)first, pos_bits,
                                         S->stage0.as<uint64_t>(), S->stage1.as<uint32_t>(), nullptr, nullptr, s);
                     hipLaunchKernelGGL(k_rec_keep, dim3(blocks_for(NA)), dim3(TPB), 0, s, fv, (int)use_cache, S->stage0.as<uint64_t>(), S->stage1.as<uint32_t>(),
-                                       (size_t)NA, own_mask, own_rank, S->stage2.as<uint8_t>(), g->npf_tot.as<uint32_t>());
+                                       (size_t)NA, own_range(g), S->stage2.as<uint8_t>(), g->npf_tot.as<uint32_t>());
                     g->keys0.reserve((size_t)NA * 8); g->vals0.reserve((size_t)NA * 4);
                     RouteKeep fk{S->stage2.as<uint8_t>(), S->stage0.as<uint64_t>(), S->stage1.as<uint32_t>(), g->keys0.as<uint64_t>(), g->vals0.as<uint32_t>()};
                     int64_t kept_c[1];
@@ -1079,7 +1231,6 @@ int rb_shard_hash(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, int6
         if (nw <= 0) return;
         FilterView fv = g->view(ordinal0, pos_bits);
         const bool use_cache = g->npf_log2 != 0;
-        const uint32_t own_mask = (uint32_t)S->G - 1u;
         g->chunk_cnt.reserve(((size_t)nw + 1) * 4); g->chunk_off.reserve(((size_t)nw + 1) * 4);
         g->temp.reserve(scan_temp_bytes((size_t)nw + 1));
         g->npf_tot.reserve(2048);
@@ -1098,7 +1249,7 @@ int rb_shard_hash(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, int6
             void *wstate = nullptr;
             if (filter_saves_state(b, nw, g->k)) { g->wstate.reserve(((size_t)nw + 1) * 16); wstate = g->wstate.p; }
             launch_filter_windows(b, w0, nw, g->k, mode_hash, (uint32_t)first, pos_bits, g->p.rng_seed, ordinal0, cache,
-                                  g->chunk_cnt.as<uint32_t>(), g->chunk_mask.as<uint32_t>(), g->npf_tot.as<uint32_t>(), s, 0u, 0u, fv.mpf, wstate);
+                                  g->chunk_cnt.as<uint32_t>(), g->chunk_mask.as<uint32_t>(), g->npf_tot.as<uint32_t>(), s, OwnRange{Mod{1, 0, 0}, 0, 0}, fv.mpf, wstate);
             exclusive_scan_u32(g->temp.p, g->temp.cap, g->chunk_cnt.as<uint32_t>(), g->chunk_off.as<uint32_t>(), (size_t)nw + 1, s);
             RB_HIP(hipMemcpyAsync(&N, g->chunk_off.as<uint32_t>() + nw, 4, hipMemcpyDeviceToHost, s));
             RB_HIP(hipMemcpyAsync(spread, g->npf_tot.p, sizeof spread, hipMemcpyDeviceToHost, s));
@@ -1124,13 +1275,13 @@ int rb_shard_hash(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, int6
                 launch_hash_windows(b, w0, nw, g->k, mode_hash, g->chunk_off.as<uint32_t>(), (uint32_t)first, pos_bits,
                                     g->keys0.as<uint64_t>(), g->vals0.as<uint32_t>(), nullptr, nullptr, s);
                 hipLaunchKernelGGL(k_rec_keep, dim3(blocks_for(N)), dim3(TPB), 0, s, fv, (int)use_cache, g->keys0.as<uint64_t>(), g->vals0.as<uint32_t>(),
-                                   (size_t)N, 0u, 0u, S->stage2.as<uint8_t>(), g->npf_tot.as<uint32_t>());
+                                   (size_t)N, OwnRange{Mod{1, 0, 0}, 0, 0}, S->stage2.as<uint8_t>(), g->npf_tot.as<uint32_t>());
                 rk = g->keys0.as<uint64_t>(); ro = g->vals0.as<uint32_t>(); keep = S->stage2.as<uint8_t>();
             }
         }
         size_t kept = 0;
         if (N) {
-            RouteRec fr{rk, ro, keep, own_mask, nullptr, nullptr};
+            RouteRec fr{rk, ro, keep, g->cbf_mod, make_own_span((uint64_t)S->span[RB_CBF]), nullptr, nullptr};
             kept = route(g, fr, (size_t)N, rec_counts, [&](RouteRec &ff, size_t k_) {
                 ff.out_keys = (uint64_t *)slot_reserve(S, RB_SLOT_REC_KEYS, k_ * 8);
                 ff.out_occ = (uint32_t *)slot_reserve(S, RB_SLOT_REC_OCC, k_ * 4);
@@ -1204,44 +1355,53 @@ int rb_shard_serve(rb_graph *g, int mode, const void *dreq_idx_dev, const void *
         ShardState *S = g->shard;
         RB_HIP(hipSetDevice(g->p.device));
         hipStream_t s = g->stream;
-        if (nd) {
-            const int uses_f = (mode == M_ADD || mode == M_ADD_IF_ABSENT);
-            const uint64_t *didx = (const uint64_t *)dreq_idx_dev, *dprobe = (const uint64_t *)dreq_probe_dev;
-            uint8_t *dreply = (uint8_t *)dreply_dev;
-            hipLaunchKernelGGL(k_own_dbg_test, dim3(blocks_for(nd)), dim3(TPB), 0, s, g->dbg.bits, (uint64_t)g->dbg.lo, didx, (size_t)nd, dreply);
-            if (uses_f) {
-                g->devctr.reserve(DEVCTR_BYTES);
-                uint32_t *ctr = g->devctr.as<uint32_t>();
-                RB_HIP(hipMemsetAsync(ctr, 0, DEVCTR_BYTES, s));
-                hipLaunchKernelGGL(k_own_dbg_set, dim3(blocks_for(nd)), dim3(TPB), 0, s, g->dbg.bits, (uint64_t)g->dbg.lo, didx, (size_t)nd,
-                                   dreply, ctr + 16);
-                uint32_t n_collide = 0, spread[16 * 32];
-                RB_HIP(hipMemcpyAsync(spread, ctr + 16, sizeof spread, hipMemcpyDeviceToHost, s));
-                RB_HIP(hipStreamSynchronize(s));
-                for (int q = 0; q < 32; ++q) n_collide += spread[16 * q];
-                Slot *ftab = nullptr;
-                uint32_t f_log2 = 1;
-                if (n_collide) {
-                    f_log2 = log2_ceil(4ull * (uint64_t)n_collide + 2);
-                    S->own_f.reserve(sizeof(Slot) << f_log2);
-                    RB_HIP(hipMemsetAsync(S->own_f.p, 0xFF, sizeof(Slot) << f_log2, s));
-                    ftab = S->own_f.as<Slot>();
-                    hipLaunchKernelGGL(k_own_collide_insert, dim3(blocks_for(nd)), dim3(TPB), 0, s, didx, dprobe, (size_t)nd, dreply, ftab, f_log2);
-                    hipLaunchKernelGGL(k_own_collide_fixup, dim3(blocks_for(nd)), dim3(TPB), 0, s, didx, dprobe, (size_t)nd, dreply, ftab, f_log2);
-                }
-                hipLaunchKernelGGL(k_own_dbg_first, dim3(blocks_for(nd)), dim3(TPB), 0, s, didx, dprobe, (size_t)nd, ftab, f_log2, dreply);
-            }
-        }
-        if (nc) {
-            g->devctr.reserve(DEVCTR_BYTES);
-            uint32_t *ctr = g->devctr.as<uint32_t>();
+        // this rank's own runs take part too: their local probes were tested / claimed by k_shard_probe and are arbitrated here
+        // together with the requests of the other ranks (same collision table, same ids, same contested-counter table)
+        const uint32_t D = S->D;
+        const FilterView fv = g->view(S->ordinal0, S->pos_bits);
+        const LocalRanges R = local_ranges(g);
+        const uint64_t *uniq = g->uniq().as<uint64_t>();
+        const uint32_t *starts = g->starts().as<uint32_t>(), *vals = g->vals1().as<uint32_t>(), *status = g->status.as<uint32_t>();
+        const int uses_f = (mode == M_ADD || mode == M_ADD_IF_ABSENT);
+        S->has_f = S->has_cs = false;
+        g->devctr.reserve(DEVCTR_BYTES);
+        uint32_t *ctr = g->devctr.as<uint32_t>();
+        const uint64_t *didx = (const uint64_t *)dreq_idx_dev, *dprobe = (const uint64_t *)dreq_probe_dev;
+        uint8_t *dreply = (uint8_t *)dreply_dev;
+        if (nd) hipLaunchKernelGGL(k_own_dbg_test, dim3(blocks_for(nd)), dim3(TPB), 0, s, g->dbg.bits, (uint64_t)g->dbg.lo, didx, (size_t)nd, dreply);
+        if (uses_f && (nd || D)) {
             RB_HIP(hipMemsetAsync(ctr, 0, DEVCTR_BYTES, s));
-            hipLaunchKernelGGL(k_own_claim, dim3(blocks_for(nc)), dim3(TPB), 0, s, g->cbf, (uint64_t)g->cbf_lo, (const uint64_t *)creq_idx_dev,
-                               (size_t)nc, (uint8_t *)creply_dev, ctr + 16);
-            uint32_t nf = 0, spread[16 * 32];
+            if (nd) hipLaunchKernelGGL(k_own_dbg_set, dim3(blocks_for(nd)), dim3(TPB), 0, s, g->dbg.bits, (uint64_t)g->dbg.lo, didx, (size_t)nd, dreply, ctr + 16);
+            if (D) hipLaunchKernelGGL(k_local_dbg_set, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, R, uniq, D, status, S->lmask.as<uint16_t>(), S->lcoll.as<uint8_t>(), ctr + 17);
+            uint32_t n_collide = 0, spread[16 * 32];
             RB_HIP(hipMemcpyAsync(spread, ctr + 16, sizeof spread, hipMemcpyDeviceToHost, s));
             RB_HIP(hipStreamSynchronize(s));
-            for (int q = 0; q < 32; ++q) nf += spread[16 * q];
+            for (int q = 0; q < 32; ++q) n_collide += spread[16 * q] + ((16 * q + 1 < 16 * 32) ? spread[16 * q + 1] : 0u);
+            Slot *ftab = nullptr;
+            uint32_t f_log2 = 1;
+            if (n_collide) {
+                f_log2 = log2_ceil(4ull * (uint64_t)n_collide + 2);
+                S->own_f.reserve(sizeof(Slot) << f_log2);
+                RB_HIP(hipMemsetAsync(S->own_f.p, 0xFF, sizeof(Slot) << f_log2, s));
+                ftab = S->own_f.as<Slot>();
+                if (nd) hipLaunchKernelGGL(k_own_collide_insert, dim3(blocks_for(nd)), dim3(TPB), 0, s, didx, dprobe, (size_t)nd, dreply, ftab, f_log2);
+                if (D) hipLaunchKernelGGL(k_local_collide_insert, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, uniq, starts, vals, D, S->lcoll.as<uint8_t>(), ftab, f_log2);
+                if (nd) hipLaunchKernelGGL(k_own_collide_fixup, dim3(blocks_for(nd)), dim3(TPB), 0, s, didx, dprobe, (size_t)nd, dreply, ftab, f_log2);
+                if (D) hipLaunchKernelGGL(k_local_collide_fixup, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, uniq, starts, vals, D, status, S->lmask.as<uint16_t>(),
+                                          S->lcoll.as<uint8_t>(), ftab, f_log2);
+                S->has_f = true; S->f_log2 = f_log2;
+            }
+            if (nd) hipLaunchKernelGGL(k_own_dbg_first, dim3(blocks_for(nd)), dim3(TPB), 0, s, didx, dprobe, (size_t)nd, ftab, f_log2, dreply);
+        }
+        if (nc || D) {
+            RB_HIP(hipMemsetAsync(ctr, 0, DEVCTR_BYTES, s));
+            if (nc) hipLaunchKernelGGL(k_own_claim, dim3(blocks_for(nc)), dim3(TPB), 0, s, g->cbf, (uint64_t)g->cbf_lo, (const uint64_t *)creq_idx_dev,
+                                       (size_t)nc, (uint8_t *)creply_dev, ctr + 16);
+            uint32_t nf = 0, spread[16 * 32], lspread[16 * 32];
+            RB_HIP(hipMemcpyAsync(spread, ctr + 16, sizeof spread, hipMemcpyDeviceToHost, s));
+            if (D) RB_HIP(hipMemcpyAsync(lspread, S->lctr.p, sizeof lspread, hipMemcpyDeviceToHost, s));      // local claims that met a mark (k_shard_probe)
+            RB_HIP(hipStreamSynchronize(s));
+            for (int q = 0; q < 32; ++q) nf += spread[16 * q] + (D ? lspread[16 * q] : 0u);
             if (nf) {
                 const uint32_t cs_log2 = log2_ceil(2ull * nf + 2);
                 const uint32_t csf_log2 = std::max(16u, std::min(25u, log2_ceil(8ull * (uint64_t)nf)));
@@ -1250,10 +1410,13 @@ int rb_shard_serve(rb_graph *g, int mode, const void *dreq_idx_dev, const void *
                 uint32_t *csf = reinterpret_cast<uint32_t *>(static_cast<char *>(S->own_cs.p) + tab_bytes);
                 RB_HIP(hipMemsetAsync(S->own_cs.p, 0xFF, tab_bytes, s));
                 RB_HIP(hipMemsetAsync(csf, 0, (size_t)1 << (csf_log2 - 3), s));
-                hipLaunchKernelGGL(k_own_cs_build, dim3(blocks_for(nc)), dim3(TPB), 0, s, (const uint64_t *)creq_idx_dev, (const uint8_t *)creply_dev,
-                                   (size_t)nc, S->own_cs.as<Slot>(), cs_log2, csf, csf_log2);
-                hipLaunchKernelGGL(k_own_claim_fin, dim3(blocks_for(nc)), dim3(TPB), 0, s, (const uint64_t *)creq_idx_dev, (size_t)nc,
-                                   S->own_cs.as<Slot>(), cs_log2, csf, csf_log2, (uint8_t *)creply_dev);
+                if (nc) hipLaunchKernelGGL(k_own_cs_build, dim3(blocks_for(nc)), dim3(TPB), 0, s, (const uint64_t *)creq_idx_dev, (const uint8_t *)creply_dev,
+                                           (size_t)nc, S->own_cs.as<Slot>(), cs_log2, csf, csf_log2);
+                if (D) hipLaunchKernelGGL(k_local_cs_build, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, uniq, D, S->lmask.as<uint16_t>(), S->lcv.as<uint64_t>(),
+                                          S->own_cs.as<Slot>(), cs_log2, csf, csf_log2);
+                if (nc) hipLaunchKernelGGL(k_own_claim_fin, dim3(blocks_for(nc)), dim3(TPB), 0, s, (const uint64_t *)creq_idx_dev, (size_t)nc,
+                                           S->own_cs.as<Slot>(), cs_log2, csf, csf_log2, (uint8_t *)creply_dev);
+                S->has_cs = true; S->cs_log2 = cs_log2; S->csf_log2 = csf_log2;
             }
         }
         if (np) {
@@ -1285,11 +1448,14 @@ int rb_shard_resolve(rb_graph *g, int mode, const void *dreply_dev, const void *
         g->devctr.reserve(DEVCTR_BYTES);
         uint32_t *ctr = g->devctr.as<uint32_t>();
         RB_HIP(hipMemsetAsync(ctr, 0, DEVCTR_BYTES, s));
+        LocalTables T{S->has_f ? S->own_f.as<Slot>() : nullptr, S->f_log2, S->has_cs ? S->own_cs.as<Slot>() : nullptr, S->cs_log2,
+                      S->has_cs ? reinterpret_cast<const uint32_t *>(static_cast<const char *>(S->own_cs.p) + (sizeof(Slot) << S->cs_log2)) : nullptr, S->csf_log2};
         hipLaunchKernelGGL(k_resolve_shard, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, g->counts().as<uint32_t>(), g->starts().as<uint32_t>(), D, mode,
                            g->light_ops, S->dreq_pos.as<uint32_t>(), (const uint8_t *)dreply_dev, S->creq_pos.as<uint32_t>(),
                            S->creq_dup.as<uint8_t>(), (const uint8_t *)creply_dev, g->tz().as<uint8_t>(), g->uniq().as<uint64_t>(),
                            g->status.as<uint32_t>(), g->nops.as<uint32_t>(), g->cvals.as<uint64_t>(), S->cfinal.as<uint64_t>(),
-                           S->replicate_cache ? S->cache_upd.as<uint8_t>() : (uint8_t *)nullptr, g->vals1().as<uint32_t>());
+                           S->replicate_cache ? S->cache_upd.as<uint8_t>() : (uint8_t *)nullptr, g->vals1().as<uint32_t>(),
+                           S->lmask.as<uint16_t>(), S->lcv.as<uint64_t>(), T);
         g->temp.reserve(select2_temp_bytes(D));
         select_flagged2(g->temp.p, g->temp.cap, g->status.as<uint32_t>(), D, RUN_HEAVY, g->heavy.as<uint32_t>(), RUN_CONFLICT, S->conf_list.as<uint32_t>(), ctr + 0, s);
         uint32_t hc[2];
@@ -1309,8 +1475,8 @@ int rb_shard_resolve(rb_graph *g, int mode, const void *dreply_dev, const void *
         const size_t nc = (size_t)D * fv.cbf_h;
         S->stage0.reserve(nc * 8 + 16); S->stage2.reserve(2 * nc + 32);
         uint8_t *w_val = S->stage2.as<uint8_t>(), *w_drop = w_val + nc;
-        hipLaunchKernelGGL(k_emit_writes, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, g->uniq().as<uint64_t>(), D, g->status.as<uint32_t>(),
-                           S->creq_dup.as<uint8_t>(), S->cfinal.as<uint64_t>(), S->stage0.as<uint64_t>(), w_val, w_drop);
+        hipLaunchKernelGGL(k_emit_writes, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, local_ranges(g), g->uniq().as<uint64_t>(), D, g->status.as<uint32_t>(),
+                           S->creq_dup.as<uint8_t>(), S->cfinal.as<uint64_t>(), S->lmask.as<uint16_t>(), S->stage0.as<uint64_t>(), w_val, w_drop);
         RouteIdx fw{S->stage0.as<uint64_t>(), w_drop, (uint64_t)S->span[RB_CBF], nullptr, w_val, nullptr, nullptr, nullptr, nullptr};
         route(g, fw, nc, w_counts, [&](RouteIdx &ff, size_t kept) {
             ff.out_idx = (uint64_t *)slot_reserve(S, RB_SLOT_W_IDX, kept * 8);
@@ -1554,7 +1720,7 @@ void shard_free(rb_graph *g) {
     for (auto &b : S->slot) b.release();
     DevBuf *bufs[] = {&S->dreq_pos, &S->creq_pos, &S->creq_dup, &S->cfinal, &S->conf_list, &S->stage0, &S->stage1, &S->stage2, &S->stage3,
                       &S->rhist, &S->roffs, &S->bounds, &S->own_f, &S->own_cs, &S->esz, &S->eoff, &S->etab, &S->eslot, &S->elabel, &S->cdesc,
-                      &S->cpos, &S->cnops, &S->cnoff, &S->rk0, &S->rk1, &S->ok0, &S->ok1, &S->ov0, &S->ov1, &S->rtab, &S->rslot, &S->rbig, &S->q_h0, &S->q_bpos, &S->q_cpos, &S->q_out, &S->cache_upd};
+                      &S->cpos, &S->cnops, &S->cnoff, &S->rk0, &S->rk1, &S->ok0, &S->ok1, &S->ov0, &S->ov1, &S->rtab, &S->rslot, &S->rbig, &S->q_h0, &S->q_bpos, &S->q_cpos, &S->q_out, &S->cache_upd, &S->lmask, &S->lcoll, &S->lcv, &S->lctr};
     for (auto *b : bufs) b->release();
     if (S->pinned) (void)hipHostFree(S->pinned);
     delete S;
