@@ -357,6 +357,13 @@ int rb_graph_add_fastq(rb_graph *g, const char *text, size_t len, int min_base_q
  * loop (R/RNABloom.java:645-732), no quality pass.  A non-final piece leaves its last record unread. */
 int rb_batch_create_fasta(int device, const char *text, size_t len, int final, rb_batch **out, size_t *consumed, int *ended);
 int rb_graph_add_fasta(rb_graph *g, const char *text, size_t len, unsigned flags, rb_add_stats *stats, int64_t *n_records);
+/* The same two worker loops over a FILE, streamed as FastqReader / FastaReader stream theirs (R/io/FastqReader.java:140-186,
+ * R/io/FastaReader.java:70-104 over FileUtils.getTextFileReader, R/util/FileUtils.java:50-57: GZIPInputStream for gzip input — detected
+ * here by the magic bytes, every member of the file).  Pieces of 256 MiB of text (RB_FASTQ_PIECE): a reader thread reads — and
+ * inflates — piece c + 1 into pinned memory, uploads and parses it while the GPU inserts piece c, so the file never sits in memory
+ * as a whole and a single-member .gz (which nothing can inflate in parallel) costs max(inflate, insert) instead of their sum. */
+int rb_graph_add_fastq_file(rb_graph *g, const char *path, int min_base_qual, unsigned flags, rb_add_stats *stats, int64_t *n_records);
+int rb_graph_add_fasta_file(rb_graph *g, const char *path, unsigned flags, rb_add_stats *stats, int64_t *n_records);
 /* .nbits files (R/io/NucleotideBitsReader.java, R/util/SeqBitsUtils.java:159-161, 236-263: per sequence a 4-byte
  * big-endian length, then ceil(len/4) bytes of four 2-bit bases each, first base in the top bits, value - 128) straight
  * into a packed device batch: the bytes are uploaded as they are and permuted on the GPU (every base is usable — the

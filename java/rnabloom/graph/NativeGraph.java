@@ -128,6 +128,9 @@ public final class NativeGraph {
     public static native long[] addFasta(long h, ByteBuffer text, long textLen, int flags, long[] nRecords);
     /** FastqToGraphWorker's loop over the text of a whole file (pieces of 1 GiB, parsed on the GPU); nRecords[0] = records inserted. */
     public static native long[] addFastq(long h, ByteBuffer text, long textLen, int minBaseQual, int flags, long[] nRecords);
+    /** a FASTQ / FASTA FILE (plain or gzip) streamed piece by piece: the next piece is read / inflated and parsed while the current one is inserted */
+    public static native long[] addFastqFile(long h, String path, int minBaseQual, int flags, long[] nRecords);
+    public static native long[] addFastaFile(long h, String path, int flags, long[] nRecords);
     /** NucleotideBitsWriter.write for nReads sequences; out == null: returns the size needed. */
     public static native long nbitsEncode(ByteBuffer seq, long[] offsets, int nReads, ByteBuffer out, long cap);
 }

@@ -167,6 +167,30 @@ jlongArray FN(addFastq)(JNIEnv *e, jclass c, jlong h, jobject text, jlong len, j
     if (n_records) { jlong u = (jlong)recs; (*e)->SetLongArrayRegion(e, n_records, 0, 1, &u); }
     return stats_array(e, &st);
 }
+jlongArray FN(addFastqFile)(JNIEnv *e, jclass c, jlong h, jstring path, jint min_q, jint flags, jlongArray n_records) {
+    rb_add_stats st;
+    int64_t recs = 0;
+    const char *p = (*e)->GetStringUTFChars(e, path, NULL);
+    (void)c;
+    memset(&st, 0, sizeof st);
+    int rc = rb_graph_add_fastq_file(G(h), p, min_q, (unsigned)flags, &st, &recs);
+    if (p) (*e)->ReleaseStringUTFChars(e, path, p);
+    if (rc) { throw_rc(e, rc); return NULL; }
+    if (n_records) { jlong u = (jlong)recs; (*e)->SetLongArrayRegion(e, n_records, 0, 1, &u); }
+    return stats_array(e, &st);
+}
+jlongArray FN(addFastaFile)(JNIEnv *e, jclass c, jlong h, jstring path, jint flags, jlongArray n_records) {
+    rb_add_stats st;
+    int64_t recs = 0;
+    const char *p = (*e)->GetStringUTFChars(e, path, NULL);
+    (void)c;
+    memset(&st, 0, sizeof st);
+    int rc = rb_graph_add_fasta_file(G(h), p, (unsigned)flags, &st, &recs);
+    if (p) (*e)->ReleaseStringUTFChars(e, path, p);
+    if (rc) { throw_rc(e, rc); return NULL; }
+    if (n_records) { jlong u = (jlong)recs; (*e)->SetLongArrayRegion(e, n_records, 0, 1, &u); }
+    return stats_array(e, &st);
+}
 jlongArray FN(addFasta)(JNIEnv *e, jclass c, jlong h, jobject text, jlong len, jint flags, jlongArray n_records) {
     rb_add_stats st;
     int64_t recs = 0;

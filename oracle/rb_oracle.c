@@ -288,6 +288,24 @@ float rbo_bloom_fpr(const rbo_bloom *b) {
     return (float)pow((double)rbo_bloom_popcount(b) / (double)b->size, b->num_hash);
 }
 uint8_t *rbo_bloom_bytes(rbo_bloom *b, int64_t *nbytes) { if (nbytes) *nbytes = b->nbytes; return b->bytes; }
+/* 64-bit digest of filter bytes, the host twin of rb_filter_fold (include/rb_capi.h): wrapping sum over the non-zero 32-bit
+ * little-endian words of splitmix64(word number * 0x9E3779B97F4A7C15 + word); a last partial word is padded with zeros.  Lets
+ * filters too large to copy around (the 142 GB counting filter of the config-3-size runs) be compared in place. */
+uint64_t rbo_fold(const uint8_t *p, int64_t nbytes) {
+    uint64_t sum = 0;
+    const int64_t nw = (nbytes + 3) / 4;
+    for (int64_t i = 0; i < nw; ++i) {
+        uint32_t x = 0;
+        const int64_t rem = nbytes - 4 * i;
+        memcpy(&x, p + 4 * i, rem >= 4 ? 4 : (size_t)rem);
+        if (!x) continue;
+        uint64_t z = (uint64_t)i * 0x9E3779B97F4A7C15ULL + (uint64_t)x;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+        sum += z ^ (z >> 31);
+    }
+    return sum;
+}
 int64_t rbo_bloom_size(const rbo_bloom *b) { return b->size; }
 
 rbo_cbf *rbo_cbf_new(int64_t size_bytes, int num_hash) {

@@ -79,6 +79,7 @@ int      rbo_bloom_lookup_then_add(rbo_bloom *, const uint64_t *h);/* :147-155 *
 int64_t  rbo_bloom_popcount(const rbo_bloom *);                    /* UnsafeByteBuffer.java:131-150 */
 float    rbo_bloom_fpr(const rbo_bloom *);                         /* :185-194 */
 uint8_t *rbo_bloom_bytes(rbo_bloom *, int64_t *nbytes);
+uint64_t rbo_fold(const uint8_t *bytes, int64_t nbytes);   /* host twin of rb_filter_fold */
 int64_t  rbo_bloom_size(const rbo_bloom *);
 rbo_cbf *rbo_cbf_new(int64_t size_bytes, int num_hash);
 void     rbo_cbf_free(rbo_cbf *);

@@ -360,6 +360,24 @@ class Graph:
         p = self.L.rbo_cbf_bytes(c, C.byref(n))
         return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), (n.value,)).copy()
 
+    def folds(self):
+        """(dbgbf, cbf, rpkbf) digests computed in place (rbo_fold = the host twin of rb_filter_fold): no copy of the filters"""
+        L = self.L
+        L.rbo_fold.restype = C.c_uint64
+        L.rbo_fold.argtypes = [C.c_void_p, C.c_int64]
+        out = []
+        n = C.c_int64()
+        for get in (L.rbo_graph_dbgbf, None, L.rbo_graph_rpkbf):
+            if get is None:
+                p = L.rbo_cbf_bytes(L.rbo_graph_cbf(self.g), C.byref(n))
+            else:
+                b = get(self.g)
+                if not b:
+                    out.append(0); continue
+                p = L.rbo_bloom_bytes(b, C.byref(n))
+            out.append(int(L.rbo_fold(C.cast(p, C.c_void_p), n.value)))
+        return tuple(out)
+
     def popcounts(self):
         L = self.L
         r = L.rbo_graph_rpkbf(self.g)

@@ -28,6 +28,13 @@
 #include <string>
 #include <thread>
 
+#include <fcntl.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <string>
+#include <thread>
+
 #include "rb_pipeline.hpp"
 
 using namespace rb;
@@ -2799,6 +2806,143 @@ int rb_graph_add_fasta(rb_graph *g, const char *text, size_t len, unsigned flags
     if (pinned) (void)hipHostUnregister(const_cast<char *>(pinned));
     if (st) (void)hipStreamDestroy(st);
     return rc;
+}
+
+}  // extern "C"
+
+// ---- streaming ingest: a FASTQ / FASTA FILE (plain or .gz) goes through the stage-1 worker's loop piece by piece ----
+// FastqReader / FastaReader stream their file (R/io/FastqReader.java:140-186 over FileUtils.getTextFileReader, R/util/FileUtils.java:50-57:
+// a GZIPInputStream for ".gz"); rb_graph_add_fastq wants the whole text in memory.  Here a reader thread reads — and for gzip
+// input inflates — the next piece while the GPU inserts the current one: the file never exists as one buffer, and the inflate
+// of piece c + 1 hides behind the insert of piece c.  gzip members are inflated as they come (any number of them, zero padding
+// between them skipped, as GZIPInputStream does); BGZF input takes the same path (its blocks are small members).
+namespace {
+struct TextSource {
+    int fd = -1;
+    bool gz = false, eof = false;
+    z_stream z;
+    bool z_open = false, z_member_done = true;
+    std::vector<unsigned char> cbuf;           // compressed input window
+    size_t cpos = 0, cend = 0;
+    explicit TextSource(const char *path) {
+        fd = open(path, O_RDONLY);
+        RB_REQUIRE(fd >= 0, "cannot open %s", path);
+        unsigned char magic[2] = {0, 0};
+        const ssize_t got = pread(fd, magic, 2, 0);
+        gz = got == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+        if (gz) { cbuf.resize((size_t)4 << 20); memset(&z, 0, sizeof z); }
+    }
+    ~TextSource() { if (z_open) inflateEnd(&z); if (fd >= 0) close(fd); }
+    bool refill() {                             // more compressed bytes; false at the end of the file
+        if (cpos < cend) return true;
+        const ssize_t got = read(fd, cbuf.data(), cbuf.size());
+        RB_REQUIRE(got >= 0, "read error on the input file");
+        cpos = 0; cend = (size_t)got;
+        return got > 0;
+    }
+    // up to cap bytes of text into dst; returns the number written (0 only at the end of the input)
+    size_t fill(char *dst, size_t cap) {
+        size_t out = 0;
+        if (!gz) {
+            while (out < cap && !eof) {
+                const ssize_t got = read(fd, dst + out, std::min(cap - out, (size_t)1 << 30));
+                RB_REQUIRE(got >= 0, "read error on the input file");
+                if (got == 0) eof = true;
+                out += (size_t)got;
+            }
+            return out;
+        }
+        while (out < cap && !eof) {
+            if (z_member_done) {                // between members: zero padding is skipped, anything else must be a gzip header
+                if (!refill()) { eof = true; break; }
+                if (cbuf[cpos] == 0) { ++cpos; continue; }
+                if (z_open) inflateReset(&z);
+                else { RB_REQUIRE(inflateInit2(&z, 15 + 16) == Z_OK, "inflateInit2 failed"); z_open = true; }
+                z_member_done = false;
+            }
+            if (!refill()) { set_error("unexpected end of the gzip data"); throw HipError{RB_ERR_INVALID}; }
+            z.next_in = cbuf.data() + cpos; z.avail_in = (uInt)(cend - cpos);
+            z.next_out = reinterpret_cast<unsigned char *>(dst + out); z.avail_out = (uInt)std::min(cap - out, (size_t)1 << 30);
+            const uInt out0 = z.avail_out;
+            const int rc = inflate(&z, Z_NO_FLUSH);
+            cpos = cend - z.avail_in; out += out0 - z.avail_out;
+            if (rc == Z_STREAM_END) z_member_done = true;
+            else if (rc != Z_OK && rc != Z_BUF_ERROR) { set_error("not in gzip format / corrupt data (zlib %d)", rc); throw HipError{RB_ERR_INVALID}; }
+        }
+        return out;
+    }
+};
+
+// the loop of rb_graph_add_fastq / _fasta over pieces that come from a TextSource: piece c + 1 is read (inflated), uploaded and
+// parsed on a helper thread while piece c is inserted; what a piece leaves unparsed (an incomplete last record) is carried over
+int add_text_file(rb_graph *g, const char *path, bool fasta, int min_base_qual, unsigned flags, rb_add_stats *stats, int64_t *n_records) {
+    if (!g || !path) { set_error("rb_graph_add_%s_file: null argument", fasta ? "fasta" : "fastq"); return RB_ERR_INVALID; }
+    hipStream_t st = nullptr;
+    char *buf[2] = {nullptr, nullptr};
+    WriteLock wl(g->rw);
+    int rc = guarded([&] {
+        RB_HIP(hipSetDevice(g->p.device));
+        RB_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        TextSource src(path);
+        const size_t piece_bytes = getenv("RB_FASTQ_PIECE") ? (size_t)std::max(64, atoi(getenv("RB_FASTQ_PIECE"))) : (size_t)256 << 20;
+        for (auto &b : buf) RB_HIP(hipHostMalloc(reinterpret_cast<void **>(&b), piece_bytes, hipHostMallocDefault));
+        bool ended = false, src_done = false;
+        // piece into buf[w]: `carry` bytes of the piece before (already at the front of buf[w]) + fresh text
+        auto make = [&](int w, size_t carry, size_t *len_out) {
+            const size_t got = src.fill(buf[w] + carry, piece_bytes - carry);
+            const size_t len = carry + got;
+            const bool final = got < piece_bytes - carry;      // the source ran dry: this is the last piece
+            if (final) src_done = true;
+            *len_out = len;
+            bool end_here = false;
+            rb::FastqChunk c = fasta ? rb::fasta_batch_create(g->p.device, buf[w], len, final, st, &end_here)
+                                     : rb::fastq_batch_create(g->p.device, buf[w], len, final, min_base_qual, true, st);
+            if (end_here) ended = true;
+            return c;
+        };
+        int w = 0;
+        size_t len = 0;
+        int64_t recs = 0;
+        rb::FastqChunk cur = make(0, 0, &len);
+        for (;;) {
+            struct G { rb_batch *b; ~G() { if (b) rb_batch_destroy(b); } } guard{cur.b};
+            recs += cur.records;
+            const bool last = src_done || ended;
+            RB_REQUIRE(last || cur.consumed > 0, "a record longer than %zu bytes", piece_bytes);
+            rb::FastqChunk nxt;
+            size_t nlen = 0;
+            std::thread prep;
+            int prep_rc = RB_OK;
+            std::string prep_err;
+            if (!last) {
+                const size_t carry = len - cur.consumed;
+                memcpy(buf[1 - w], buf[w] + cur.consumed, carry);
+                prep = std::thread([&, carry] {
+                    prep_rc = guarded([&] { nxt = make(1 - w, carry, &nlen); });
+                    if (prep_rc != RB_OK) prep_err = rb_last_error();
+                });
+            }
+            const int add_rc = guarded([&] { if (cur.b && cur.b->n_reads) add_range(g, cur.b, 0, cur.b->n_reads, flags, stats); });
+            if (prep.joinable()) prep.join();
+            if (add_rc != RB_OK) { if (nxt.b) rb_batch_destroy(nxt.b); throw HipError{add_rc}; }
+            if (prep_rc != RB_OK) { set_error("%s", prep_err.c_str()); throw HipError{prep_rc}; }
+            if (last) break;
+            w = 1 - w; len = nlen; cur = nxt;
+        }
+        if (n_records) *n_records = recs;
+    });
+    for (auto b : buf) if (b) (void)hipHostFree(b);
+    if (st) (void)hipStreamDestroy(st);
+    return rc;
+}
+}  // namespace
+
+extern "C" {
+int rb_graph_add_fastq_file(rb_graph *g, const char *path, int min_base_qual, unsigned flags, rb_add_stats *stats, int64_t *n_records) {
+    return add_text_file(g, path, false, min_base_qual, flags, stats, n_records);
+}
+int rb_graph_add_fasta_file(rb_graph *g, const char *path, unsigned flags, rb_add_stats *stats, int64_t *n_records) {
+    return add_text_file(g, path, true, 0, flags, stats, n_records);
 }
 
 int rb_graph_apply(rb_graph *g, int op, const uint64_t *h0, size_t n) {

@@ -105,6 +105,8 @@ SYMBOLS = [
     ("rb_batch_create_fasta", _i32, [_i32, _vp, _sz, _i32, C.POINTER(_vp), C.POINTER(_sz), C.POINTER(_i32)]),
     ("rb_graph_add_fasta", _i32, [_vp, _vp, _sz, C.c_uint, C.POINTER(AddStats), C.POINTER(_i64)]),
     ("rb_graph_add_fastq", _i32, [_vp, _vp, _sz, _i32, C.c_uint, C.POINTER(AddStats), C.POINTER(_i64)]),
+    ("rb_graph_add_fastq_file", _i32, [_vp, C.c_char_p, _i32, C.c_uint, C.POINTER(AddStats), C.POINTER(_i64)]),
+    ("rb_graph_add_fasta_file", _i32, [_vp, C.c_char_p, C.c_uint, C.POINTER(AddStats), C.POINTER(_i64)]),
     ("rb_batch_create_nbits", _i32, [_i32, _vp, _sz, _i64, C.POINTER(_vp), C.POINTER(_sz)]),
     ("rb_nbits_encode", _i32, [_vp, _vp, _i64, _vp, _sz, C.POINTER(_sz)]),
     ("rb_graph_create_shard", _i32, [C.POINTER(GraphParams), _i32, _i32, C.POINTER(_vp)]),

@@ -5,6 +5,7 @@ BASE hash values (hashVals[0]); the library expands them with NTM64 using the gr
 All filter state lives in HBM behind the C handle; nothing is computed on the host.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -189,6 +190,23 @@ class BloomFilterDeBruijnGraph:
         t = np.frombuffer(text, np.uint8) if isinstance(text, (bytes, bytearray)) else np.ascontiguousarray(text, dtype=np.uint8)
         st = N.AddStats(); n = C.c_int64()
         check(lib.rb_graph_add_fastq(self.h, _ptr(t), t.size, minBaseQual, flags, C.byref(st), C.byref(n)))
+        return st, n.value
+
+    def addFastqFile(self, path, minBaseQual=3, reverseComplement=False, incrementIfPresent=False, storeReadPairedKmers=False):
+        """a FASTQ file (plain or gzip, detected by its magic bytes) streamed through FastqToGraphWorker's loop: the next piece is
+        read / inflated, uploaded and parsed while the current one is inserted; returns (stats, records)"""
+        flags = (N.ADD_REVCOMP if reverseComplement else 0) | (N.ADD_COUNT_IF_PRESENT if incrementIfPresent else 0) \
+            | (N.ADD_STORE_READ_PAIRS if storeReadPairedKmers else 0)
+        st = N.AddStats(); n = C.c_int64()
+        check(lib.rb_graph_add_fastq_file(self.h, os.fsencode(path), minBaseQual, flags, C.byref(st), C.byref(n)))
+        return st, n.value
+
+    def addFastaFile(self, path, reverseComplement=False, incrementIfPresent=False, storeReadPairedKmers=False):
+        """the same for a FASTA file (FastaToGraphWorker's loop)"""
+        flags = (N.ADD_REVCOMP if reverseComplement else 0) | (N.ADD_COUNT_IF_PRESENT if incrementIfPresent else 0) \
+            | (N.ADD_STORE_READ_PAIRS if storeReadPairedKmers else 0)
+        st = N.AddStats(); n = C.c_int64()
+        check(lib.rb_graph_add_fasta_file(self.h, os.fsencode(path), flags, C.byref(st), C.byref(n)))
         return st, n.value
 
     def addFasta(self, text, reverseComplement=False, incrementIfPresent=False, storeReadPairedKmers=False):

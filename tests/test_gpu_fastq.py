@@ -107,6 +107,46 @@ def test_add_fastq_equals_add_reads_of_the_split_text(monkeypatch):
         for which in (N.DBGBF, N.CBF, N.RPKBF):
             assert (g.exportFilter(which) == want.exportFilter(which)).all()
         g.destroy()
+    # ... and the same text from a FILE, streamed (rb_graph_add_fastq_file: read / inflate the next piece while this one is inserted):
+    # plain, one gzip member, several members with zero padding between them (GZIPInputStream reads them all), pieces of every size
+    import gzip, tempfile
+    monkeypatch.delenv("RB_FASTQ_PIECE", raising=False)
+    with tempfile.TemporaryDirectory() as d:
+        plain = os.path.join(d, "r.fq"); open(plain, "wb").write(text)
+        one = os.path.join(d, "r.fq.gz"); open(one, "wb").write(gzip.compress(text, 1))
+        cut = [0, 1000, len(text) // 3, len(text) // 3 + 1, len(text)]
+        many = os.path.join(d, "m.fq.gz")
+        open(many, "wb").write(b"".join(gzip.compress(text[a:b], 1) + b"\0" * (7 * i) for i, (a, b) in enumerate(zip(cut, cut[1:]))))
+        for path in (plain, one, many):
+            for piece in (None, "150000", "900"):
+                if piece: monkeypatch.setenv("RB_FASTQ_PIECE", piece)
+                else: monkeypatch.delenv("RB_FASTQ_PIECE", raising=False)
+                g = fresh()
+                st, n = g.addFastqFile(path, 3, storeReadPairedKmers=True)
+                assert n == 6000 and (st.kmers, st.pairs, st.reads) == (st0.kmers, st0.pairs, st0.reads), (path, piece)
+                for which in (N.DBGBF, N.CBF, N.RPKBF):
+                    assert (g.exportFilter(which) == want.exportFilter(which)).all(), (path, piece, which)
+                g.destroy()
+        monkeypatch.delenv("RB_FASTQ_PIECE", raising=False)
+        bad = os.path.join(d, "bad.gz"); open(bad, "wb").write(gzip.compress(text, 1)[:-200])
+        g = fresh()
+        with pytest.raises(Exception, match="gzip"):
+            g.addFastqFile(bad, 3)
+        with pytest.raises(Exception, match="cannot open"):
+            g.addFastqFile(os.path.join(d, "missing.fq"), 3)
+        g.destroy()
+        # FASTA file, streamed
+        fa = b"".join(b">s%d\n" % i + r.split(b"\n")[1] + b"\n" for i, r in enumerate(recs))
+        fpath = os.path.join(d, "t.fa.gz"); open(fpath, "wb").write(gzip.compress(fa, 1))
+        ga, gb = fresh(), fresh()
+        sa, na = ga.addFasta(fa, storeReadPairedKmers=True)
+        monkeypatch.setenv("RB_FASTQ_PIECE", "5000")
+        sb, nb = gb.addFastaFile(fpath, storeReadPairedKmers=True)
+        monkeypatch.delenv("RB_FASTQ_PIECE", raising=False)
+        assert na == nb == 6000 and (sa.kmers, sa.pairs) == (sb.kmers, sb.pairs)
+        for which in (N.DBGBF, N.CBF, N.RPKBF):
+            assert (ga.exportFilter(which) == gb.exportFilter(which)).all()
+        ga.destroy(); gb.destroy()
     want.destroy()
 
 

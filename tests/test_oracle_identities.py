@@ -284,3 +284,29 @@ def test_strobemers_reference_shape():
             cur = L.rbo_combine(cur, hv[best]); last = best
         assert int(sh[p]) == cur and ss[p] == p and se[p] == last + k - 1
     assert len(rbo.strobemers(s[:100], k, n, wmin, wmax)[0]) == 0
+
+
+def test_oracle_fold_is_the_digest_rb_filter_fold_computes():
+    """rbo_fold (in place, for filters too large to copy) == rnabloom.graph.fold_bytes over the same bytes — the numpy form the GPU
+    suite pins rb_filter_fold to (tests/test_gpu_config3.py)"""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "rna-bloom_amd", "rnabloom"))
+    rng = np.random.default_rng(5)
+    og = rbo.Graph(300_017, 240_011, 100_003, 2, 2, 2, 25, False, True, 9)
+    og.set_read_pair_distance(60)
+    seq = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, 150 * 300)]
+    og.add_reads(seq, None, np.arange(0, 150 * 301, 150, dtype=np.int64), 3, rbo.STORE_READ_PAIRS)
+
+    def fold_bytes(data):           # the text of rnabloom.graph.fold_bytes (that module needs the HIP library to import)
+        a = np.ascontiguousarray(data, np.uint8)
+        pad = (-a.size) % 4
+        if pad: a = np.concatenate([a, np.zeros(pad, np.uint8)])
+        w = a.view("<u4").astype(np.uint64)
+        nz = np.nonzero(w)[0]
+        with np.errstate(over="ignore"):
+            z = nz.astype(np.uint64) * np.uint64(0x9E3779B97F4A7C15) + w[nz]
+            z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+            z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+            return int((z ^ (z >> np.uint64(31))).sum(dtype=np.uint64))
+    assert og.folds() == tuple(fold_bytes(x) for x in (og.dbgbf_bytes(), og.cbf_bytes(), og.rpkbf_bytes()))
+    assert all(og.folds())

@@ -1,7 +1,9 @@
 """Parity of the single-GPU engine and of the sharded engine (8 virtual ranks split, 2 replicated; both drivers) with the CPU oracle on a
 large synthetic paired-end set: N reads (default 4 M = 490 M k-mers; the oracle needs ~40 s for that), both files of the
 library, read-paired k-mers, filters sized so that counters reach the probabilistic range.  Prints one line per engine.
-    python tools/parity_at_size.py [N [k]]        (k = 35: the three-words-per-lane prefilter, generic kernels in the sharded engine)"""
+    python tools/parity_at_size.py [N [k [nk [genome]]]]   (k = 35: the three-words-per-lane prefilter, generic kernels in the sharded engine;
+    nk: the filters are sized for nk distinct k-mers at FPR 0.01 — 7 500 000 000 gives the 142 G-entry filters of tests/test_gpu_config3.py, whose
+    indices need 38 bits: the oracle then holds 178 GB of host memory and the comparison moves 178 GB over PCIe per engine)"""
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "rna-bloom_amd")):
@@ -13,8 +15,11 @@ from rnabloom.graph import BloomFilterDeBruijnGraph, ReadBatch
 from rnabloom.sharded import LoopbackCluster
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4_000_000
 K = int(sys.argv[2]) if len(sys.argv) > 2 else 25
-bits = N.lib.rb_expected_size(18_000_000, 0.01, 2)
-batch = ReadBatch.synthetic(n // 2, 64_000_000 // 25, 150, 300, 30, 0.001, 1e-4, 2.0, seed=0x5EED, device=0)
+NK = int(sys.argv[3]) if len(sys.argv) > 3 else 18_000_000
+GENOME = int(sys.argv[4]) if len(sys.argv) > 4 else 64_000_000 // 25
+bits = N.lib.rb_expected_size(NK, 0.01, 2)
+print("filters: %d entries each (%.1f bits of index)" % (bits, __import__("math").log2(bits)), flush=True)
+batch = ReadBatch.synthetic(n // 2, GENOME, 150, 300, 30, 0.001, 1e-4, 2.0, seed=0x5EED, device=0)
 seq, off = batch.download(0, n)
 t = time.time()
 og = rbo.Graph(bits, bits, bits, 2, 2, 2, K, False, True, 1)
@@ -22,18 +27,25 @@ og.set_read_pair_distance(115)
 og.add_reads(seq[:off[n // 2]], None, off[:n // 2 + 1], 3, rbo.STORE_READ_PAIRS)
 og.add_reads(seq[off[n // 2]:], None, off[n // 2:] - off[n // 2], 3, rbo.STORE_READ_PAIRS | rbo.REVCOMP)
 print("oracle %.1f s" % (time.time() - t), flush=True)
-ref = (og.dbgbf_bytes(), og.cbf_bytes(), og.rpkbf_bytes())
+FOLD = NK > 1_000_000_000 or bool(os.environ.get("RB_PARITY_FOLD"))   # filters too large to copy: compare popcounts + 64-bit digests in place (rb_filter_fold / rbo_fold)
+if FOLD:
+    ref = tuple(zip(og.popcounts(), og.folds()))
+    print("oracle popcounts / digests:", ref, flush=True)
+    same = lambda eng: [(eng.popcount(w), eng.fold(w)) == r for w, r in zip((N.DBGBF, N.CBF, N.RPKBF), ref)]
+else:
+    ref = (og.dbgbf_bytes(), og.cbf_bytes(), og.rpkbf_bytes())
+    same = lambda eng: [bool(np.array_equal(eng.exportFilter(w), r)) for w, r in zip((N.DBGBF, N.CBF, N.RPKBF), ref)]
 g = BloomFilterDeBruijnGraph(bits, bits, bits, 2, 2, 2, K, False, True, device=0, rngSeed=1, maxBatchKmers=1 << 26)
 g.setReadPairedKmerDistance(115)
 s1 = g.addBatch(batch, storeReadPairedKmers=True, first=0, n=n // 2)
 s2 = g.addBatch(batch, reverseComplement=True, storeReadPairedKmers=True, first=n // 2, n=n // 2)
 print("single: kmers", s1.kmers + s2.kmers, "sorted", s1.sorted_kmers + s2.sorted_kmers, "conflict ops", s1.conflict_ops + s2.conflict_ops,
-      "equal:", [bool(np.array_equal(g.exportFilter(w), r)) for w, r in zip((N.DBGBF, N.CBF, N.RPKBF), ref)], "max counter", int(ref[1].max()), flush=True)
+      "equal:", same(g), "" if FOLD else "max counter %d" % int(ref[1].max()), flush=True)
 g.destroy()
 for G, mode, native in ((8, "split", False), (2, "replicated", False), (8, "split", True), (2, "replicated", True)):
     cl = LoopbackCluster(G, bits, bits, bits, 2, 2, 2, K, False, True, device=0, rngSeed=1, mode=mode, maxBatchKmers=1 << 27, native=native)
     cl.setReadPairedKmerDistance(115)
     cl.addBatch(batch, 150, storeReadPairedKmers=True, first=0, n=n // 2)
     cl.addBatch(batch, 150, reverseComplement=True, storeReadPairedKmers=True, first=n // 2, n=n // 2)
-    print("sharded", G, mode, "(exchange driver below the C ABI)" if native else "(python driver)", "equal:", [bool(np.array_equal(cl.exportFilter(w), r)) for w, r in zip((N.DBGBF, N.CBF, N.RPKBF), ref)], flush=True)
+    print("sharded", G, mode, "(exchange driver below the C ABI)" if native else "(python driver)", "equal:", same(cl), flush=True)
     cl.destroy()
