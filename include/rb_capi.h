@@ -339,7 +339,8 @@ int rb_fastq_split(const char *text, size_t len, int n_threads, char *seq, char 
                    int64_t *n_reads);
 
 /* FileUtils.getTextFileReader for ".gz" (R/util/FileUtils.java:50-57: GZIPInputStream, every member of a concatenated file).
- * dst == NULL: *out_len = uncompressed size.  BGZF input (bgzip: members of at most 64 KiB that carry their own size) is
+ * dst == NULL: *out_len = uncompressed size.  Whatever follows a member and is not another gzip header (padding, garbage) ends the stream
+ * silently, as GZIPInputStream.readTrailer does; the first member must be gzip.  BGZF input (bgzip: members of at most 64 KiB that carry their own size) is
  * inflated by n_threads threads at once (<= 0: all hardware threads); any other gzip file member after member on one thread. */
 int rb_gunzip(const void *src, size_t n, int n_threads, void *dst, size_t cap, size_t *out_len);
 

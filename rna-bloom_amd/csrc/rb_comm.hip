@@ -105,6 +105,7 @@ struct rb_shard_comm {
     int arrived = 0;
     uint64_t generation = 0;
     bool failed = false;
+    int in_call = 0;                    // ranks inside rb_shard_add_range: when the last one has left a failed call the hub is usable again
     const Part *pub_parts[MAX_WORLD];
     int pub_k[MAX_WORLD];
     // receive buffers and count staging, per (virtual) rank
@@ -449,8 +450,14 @@ int rb_shard_comm_destroy(rb_shard_comm *c) {
 int rb_shard_add_range(rb_graph *g, rb_shard_comm *c, const rb_batch *b, int64_t first, int64_t n, unsigned flags, int64_t reads_per_substep,
                        uint32_t pos_bits, uint64_t ordinal0, rb_add_stats *stats) {
     if (stats) memset(stats, 0, sizeof *stats);
+    struct InCall {                      // (loopback hub) a failed call poisons the hub only until every rank has left it
+        rb_shard_comm *c;
+        explicit InCall(rb_shard_comm *c_) : c(c_) { if (c && !c->is_rccl) { std::lock_guard<std::mutex> lk(c->m); ++c->in_call; } }
+        ~InCall() { if (c && !c->is_rccl) { std::lock_guard<std::mutex> lk(c->m); if (--c->in_call == 0 && c->failed) { c->failed = false; c->arrived = 0; } } }
+    } in_call(c);
     int rc = guarded([&] {
         RB_REQUIRE(g && g->shard && c && b && n >= 0 && reads_per_substep > 0, "rb_shard_add_range: bad argument");
+        rb::WriteLock wl(g->rw);          // a mutator like every other insert: queries on this shard handle wait (rb_graph_kmers, rb_shard_query_*)
         RB_HIP(hipSetDevice(g->p.device));
         const int overlap = getenv("RB_SHARD_OVERLAP") ? atoi(getenv("RB_SHARD_OVERLAP")) : 1;
         // cold start (first insert into cleared filters): short sub-batches first, doubling up to the full size

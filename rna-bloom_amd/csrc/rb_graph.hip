@@ -2814,8 +2814,8 @@ int rb_graph_add_fasta(rb_graph *g, const char *text, size_t len, unsigned flags
 // FastqReader / FastaReader stream their file (R/io/FastqReader.java:140-186 over FileUtils.getTextFileReader, R/util/FileUtils.java:50-57:
 // a GZIPInputStream for ".gz"); rb_graph_add_fastq wants the whole text in memory.  Here a reader thread reads — and for gzip
 // input inflates — the next piece while the GPU inserts the current one: the file never exists as one buffer, and the inflate
-// of piece c + 1 hides behind the insert of piece c.  gzip members are inflated as they come (any number of them, zero padding
-// between them skipped, as GZIPInputStream does); BGZF input takes the same path (its blocks are small members).
+// of piece c + 1 hides behind the insert of piece c.  gzip members are inflated as they come, any number of them; whatever follows a
+// member and is not another gzip header ends the stream, as in GZIPInputStream; BGZF input takes the same path (its blocks are small members).
 namespace {
 struct TextSource {
     int fd = -1;
@@ -2853,9 +2853,16 @@ struct TextSource {
             return out;
         }
         while (out < cap && !eof) {
-            if (z_member_done) {                // between members: zero padding is skipped, anything else must be a gzip header
+            if (z_member_done) {                // between members: GZIPInputStream takes anything that is not another gzip header for the end of the stream
                 if (!refill()) { eof = true; break; }
-                if (cbuf[cpos] == 0) { ++cpos; continue; }
+                if (z_open) {
+                    if (cend - cpos < 2) {          // the header's two magic bytes may straddle the window: pull one more byte in
+                        unsigned char b0 = cbuf[cpos], b1 = 0;
+                        const ssize_t got = read(fd, &b1, 1);
+                        if (got == 1) { cbuf[0] = b0; cbuf[1] = b1; cpos = 0; cend = 2; }
+                    }
+                    if (!(cend - cpos >= 2 && cbuf[cpos] == 0x1f && cbuf[cpos + 1] == 0x8b)) { eof = true; break; }
+                }
                 if (z_open) inflateReset(&z);
                 else { RB_REQUIRE(inflateInit2(&z, 15 + 16) == Z_OK, "inflateInit2 failed"); z_open = true; }
                 z_member_done = false;
@@ -3276,7 +3283,14 @@ int rb_graph_greedy_extend(rb_graph *g, const rb_graph *gate, const char *seeds,
         RB_REQUIRE(lookahead >= 0 && lookahead <= WALK_MAX_LOOKAHEAD, "rb_graph_greedy_extend: lookahead out of range [0, %d]", WALK_MAX_LOOKAHEAD);
         RB_REQUIRE(!g->shard, "rb_graph_greedy_extend: queries are not available on a shard handle");
         if (!n) return;
+        // the gate is read too: shared lock on it for the call (taken before g's when its address is lower: two calls that
+        // name each other as graph and gate cannot deadlock against a writer waiting in between)
+        rb_graph *gm = const_cast<rb_graph *>(gate);
+        std::shared_lock<std::shared_mutex> gate_lk;
+        if (gm && gm != g && gm < g) gate_lk = std::shared_lock<std::shared_mutex>(gm->rw);
         QueryLease q(g);
+        if (gm && gm != g && gm > g) gate_lk = std::shared_lock<std::shared_mutex>(gm->rw);
+        if (gate) RB_REQUIRE(gate->dbg.bits, "rb_graph_greedy_extend: the gate's filter has been destroyed");
         hipStream_t s = q.c->st;
         const size_t k = (size_t)g->k, nb = n * (size_t)bound, stride = k + (size_t)bound + (size_t)WALK_MAX_LOOKAHEAD + 1;
         q.c->b0.reserve(n * k + n * stride + nb + 64);          // seeds | seq | appended bases

@@ -511,12 +511,14 @@ int rb_gunzip(const void *src_, size_t n, int n_threads, void *dst_, size_t cap,
             for (int t = 0; t < T; ++t) if (rcs[(size_t)t] != RB_OK) { set_error("%s", errs[(size_t)t].c_str()); throw HipError{rcs[(size_t)t]}; }
             return;
         }
-        // generic gzip: member after member (GZIPInputStream reads concatenated members; trailing zero padding is ignored)
+        // generic gzip: member after member, as GZIPInputStream reads them — after a member it tries to read another header and
+        // treats ANYTHING that is not one (zero padding, garbage, a truncated header) as the end of the stream, silently
+        // (java.util.zip.GZIPInputStream.readTrailer: "catch (IOException ze) { return true; }"); only the FIRST member must be gzip
         if (!dst) {     // size query: inflate into a scratch window and count
             std::vector<unsigned char> scratch((size_t)8 << 20);
             size_t in = 0, out = 0;
             while (in < n) {
-                if (src[in] == 0) { ++in; continue; }
+                if (in > 0 && !(in + 1 < n && src[in] == 0x1f && src[in + 1] == 0x8b)) break;      // not another member: end of stream
                 z_stream z;
                 memset(&z, 0, sizeof z);
                 RB_REQUIRE(inflateInit2(&z, 15 + 16) == Z_OK, "rb_gunzip: inflateInit2 failed");
@@ -538,7 +540,7 @@ int rb_gunzip(const void *src_, size_t n, int n_threads, void *dst_, size_t cap,
         }
         size_t in = 0, out = 0;
         while (in < n) {
-            if (src[in] == 0) { ++in; continue; }
+            if (in > 0 && !(in + 1 < n && src[in] == 0x1f && src[in + 1] == 0x8b)) break;          // not another member: end of stream
             size_t got = 0, used = 0;
             inflate_member(src + in, n - in, dst + out, cap - out, &got, &used);
             in += used; out += got;

@@ -26,7 +26,7 @@ class BloomFilter:
     def getFPR(self):                                                           # :185-194 (remembers the popcount it used)
         self.popcount = self._g.popcount(N.DBGBF)
         return self._g.getDbgbfFPR()
-    def getPopCount(self): return self._g.popcount(N.DBGBF)
+    def getPopCount(self): return self.popcount                                # :201-203: the value cached by the last getFPR() (-1 before)
     def getOptimalSize(self, fpr):                                              # :205-213: from the popcount of the last getFPR()
         return self.getExpectedSize(self.popcount, fpr, self.numHash) if self.popcount > 0 else self.size
     def getNumHash(self): return self.numHash
@@ -49,6 +49,7 @@ class CountingBloomFilter:
 
     def __init__(self, size, numHash, k, device=0, rngSeed=0):
         self.size, self.numHash, self.k, self.device, self.rngSeed = int(size), int(numHash), int(k), int(device), int(rngSeed)
+        self.popcount = -1
         self._g = BloomFilterDeBruijnGraph(_TINY, self.size, 0, 1, self.numHash, 1, self.k, True, False, device=device, rngSeed=rngSeed)
 
     def increment(self, h0): self._g.addCountOnly(h0)                           # :170-194, in array order
@@ -58,8 +59,10 @@ class CountingBloomFilter:
         N.check(N.lib.rb_filter_increment_and_get(self._g.h, h.ctypes.data, h.size, out.ctypes.data))
         return out
     def getCount(self, h0): return self._g.getCbfCount(h0)                      # :235-251
-    def getFPR(self): return self._g.getCbfFPR()                                # :254-263
-    def getPopCount(self): return self._g.popcount(N.CBF)                       # non-zero counters
+    def getFPR(self):                                                           # :254-263 (remembers the popcount it used: non-zero counters)
+        self.popcount = self._g.popcount(N.CBF)
+        return self._g.getCbfFPR()
+    def getPopCount(self): return self.popcount                                # :280-282: cached by the last getFPR() (-1 before)
     def getNumHash(self): return self.numHash
     def getSize(self): return self.size
     def empty(self): self._g.clearCbf()

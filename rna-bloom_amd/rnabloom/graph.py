@@ -595,6 +595,7 @@ class BloomFilterDeBruijnGraph:
     def _fpr(self, which):
         v = C.c_float()
         check(lib.rb_filter_fpr(self.h, which, C.byref(v)))
+        self.__dict__.setdefault("_popcache", {})[which] = self.popcount(which)   # BloomFilter.java:185-194: getFPR() remembers its count
         return v.value
 
     def getDbgbfFPR(self): return self._fpr(N.DBGBF)
@@ -632,7 +633,7 @@ class _FilterOfGraph:
         if self.which != N.CBF: raise TypeError("getCount is a counting-filter method")
         return self.g.getCbfCount(h0)
     def getFPR(self): return self.g._fpr(self.which)
-    def getPopCount(self): return self.g.popcount(self.which)
+    def getPopCount(self): return self.g.__dict__.get("_popcache", {}).get(self.which, -1)   # :201-203: cached by the last getFPR(), -1 before
     def getNumHash(self): return self.g.filterSize(self.which)[2]
     def getSize(self): return self.g.filterSize(self.which)[0]
     def toBytes(self): return self.g.exportFilter(self.which)

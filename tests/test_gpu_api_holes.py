@@ -47,7 +47,7 @@ def test_paired_keys_bloom_filter_is_a_bloom_filter_on_pair_hashes():
     fresh = BloomFilter(1000, 2, 25)
     assert fresh.getOptimalSize(0.01) == 1000                        # popcount unknown (-1): the size itself
     pk.empty()
-    assert pk.getPopCount() == 0
+    assert pk.getPopCount() == pop and pk.getFPR() == 0 and pk.getPopCount() == 0     # the cached count moves with getFPR() only
     L.rbo_bloom_free(ob)
 
 

@@ -108,7 +108,8 @@ def test_add_fastq_equals_add_reads_of_the_split_text(monkeypatch):
             assert (g.exportFilter(which) == want.exportFilter(which)).all()
         g.destroy()
     # ... and the same text from a FILE, streamed (rb_graph_add_fastq_file: read / inflate the next piece while this one is inserted):
-    # plain, one gzip member, several members with zero padding between them (GZIPInputStream reads them all), pieces of every size
+    # plain, one gzip member, several members followed by bytes that are no gzip header (GZIPInputStream reads every member and takes
+    # such bytes for the end of the stream), pieces of every size
     import gzip, tempfile
     monkeypatch.delenv("RB_FASTQ_PIECE", raising=False)
     with tempfile.TemporaryDirectory() as d:
@@ -116,7 +117,7 @@ def test_add_fastq_equals_add_reads_of_the_split_text(monkeypatch):
         one = os.path.join(d, "r.fq.gz"); open(one, "wb").write(gzip.compress(text, 1))
         cut = [0, 1000, len(text) // 3, len(text) // 3 + 1, len(text)]
         many = os.path.join(d, "m.fq.gz")
-        open(many, "wb").write(b"".join(gzip.compress(text[a:b], 1) + b"\0" * (7 * i) for i, (a, b) in enumerate(zip(cut, cut[1:]))))
+        open(many, "wb").write(b"".join(gzip.compress(text[a:b], 1) for a, b in zip(cut, cut[1:])) + b"\0" * 9 + b"trailing bytes that are no gzip header end the stream")
         for path in (plain, one, many):
             for piece in (None, "150000", "900"):
                 if piece: monkeypatch.setenv("RB_FASTQ_PIECE", piece)

@@ -131,6 +131,10 @@ def test_gunzip_single_member_concatenated_members_and_bgzf(threads):
     parts = [text[:100], text[100:250_000], b"", text[250_000:]]
     assert RIO.gunzip(b"".join(gzip.compress(p) for p in parts), threads).tobytes() == text          # GZIPInputStream reads every member
     assert RIO.gunzip(gzip.compress(text) + b"\0" * 7, threads).tobytes() == text                   # zero padding after the last member
+    # what follows a member and is no gzip header ends the stream silently (GZIPInputStream.readTrailer swallows the header error);
+    # a member BEHIND such bytes is therefore never reached
+    assert RIO.gunzip(gzip.compress(text) + b"not a gzip header", threads).tobytes() == text
+    assert RIO.gunzip(gzip.compress(text[:5000]) + b"\0\0\0" + gzip.compress(text[5000:]), threads).tobytes() == text[:5000]
     bg = _bgzf(text)
     assert gzip.decompress(bg) == text                                                                 # the fixture is a valid gzip file
     assert RIO.gunzip(bg, threads).tobytes() == text
