@@ -2102,6 +2102,37 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
     }
     hipStream_t sp = g->stream2;
     unsigned long long *pc = nullptr;
+    // The paired k-mers of a sub-batch touch rpkbf and nothing else: their walker runs on a side stream of the producer, forked when
+    // the sub-batch's window walk is done (beside the emit pass and the first partition pass; joined when the grouping is enqueued).
+    // RB_PAIRS_SIDE: 0 = on the producer stream after the grouping (rounds 1-2), 1 = beside the window walk, 2 = beside the CONSUMER
+    // of the sub-batch before, 3 (default) = beside the emit pass, 4 = beside the grouping only.  Measured on config 2
+    // (profiles/r03_pairs_side.txt): 1 and 3 take 5-9 ms off a 336-356 ms step, 2 and 4 2-5 ms; every kernel that runs beside the
+    // walker takes about as much longer as the walker itself took (the window walk 84 -> 111 ms), which is why the gain is small.
+    // One counter for the whole call (a sub-batch that is halved and redone has its pairs in already: ORs, not launched again).
+    int pairs_mode = pairs ? 3 : 0;
+    if (pairs && getenv("RB_PAIRS_SIDE")) pairs_mode = atoi(getenv("RB_PAIRS_SIDE"));
+    if (getenv("RB_SERIAL") || pairs_mode < 0 || pairs_mode > 4) pairs_mode = 0;
+    const bool pairs_side = pairs_mode != 0;
+    int64_t pairs_upto = first;
+    bool pairs_pending = false;
+    if (pairs_side) {
+        g->pairs_ctr.reserve(64);
+        RB_HIP(hipMemsetAsync(g->pairs_ctr.p, 0, 64, g->stream3));
+    }
+    auto pairs_fork = [&](size_t i, bool after_producer) {
+        if (!pairs_side || i >= subs.size()) return;
+        const Sub &sb = subs[i];
+        if (sb.nw <= 0 || sb.r1 <= pairs_upto) return;
+        if (after_producer) {
+            RB_HIP(hipEventRecord(g->ev2, sp));
+            RB_HIP(hipStreamWaitEvent(g->stream3, g->ev2, 0));
+        }
+        g->prof_begin(g->stream3);
+        launch_pairs(g, b, sb.w0, sb.nw, mode_hash, nullptr, nullptr, g->pairs_ctr.as<unsigned long long>(), g->stream3);
+        g->prof_end("pairs_insert", g->stream3);
+        RB_HIP(hipEventRecord(g->ev3, g->stream3));
+        pairs_upto = sb.r1; pairs_pending = true;
+    };
     // producer: hash + group sub-batch i into slot i&1 on the producer stream (touches scratch and,
     // for the order-independent paired k-mers, rpkbf only)
     auto prepare_once = [&](size_t i) -> bool {
@@ -2110,6 +2141,7 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
         const int slot = (int)(i & 1u);
         g->devctr2.reserve(DEVCTR_BYTES);
         sb.total = 0;
+        if (pairs_mode == 1) pairs_fork(i, true);
         if (sb.nw > 0) {
             const uint64_t ord0 = g->ordinal + (uint64_t)(sb.r0 - first);
             g->chunk_cnt.reserve(((size_t)sb.nw + 1) * 4); g->chunk_off.reserve(((size_t)sb.nw + 1) * 4);
@@ -2153,6 +2185,7 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
                     fprintf(stderr, "[word stats] words %lld: empty %.3f, 1-4 %.3f, 5-16 %.3f, 17-31 %.3f, 32 %.3f; empty 64-word groups %.3f\n", (long long)sb.nw,
                             (double)h[0] / sb.nw, (double)h[1] / sb.nw, (double)h[2] / sb.nw, (double)h[3] / sb.nw, (double)h[4] / sb.nw, (double)empty_waves / waves);
                 }
+                if (pairs_mode == 3) pairs_fork(i, true);
                 if (sb.N) {
                     g->prof_begin(sp);
                     g->keys0.reserve((size_t)sb.N * 8); g->vals0.reserve((size_t)sb.N * 4);
@@ -2196,8 +2229,10 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
                 }
             }
         }
+        if (pairs_mode >= 3) pairs_fork(i, true);                // (3: already forked on the two-pass path; 4: beside the grouping only)
         group_enqueue(g, slot, sb.N, g->ordinal + (uint64_t)(sb.r0 - first), pos_bits, sp, g->temp2, g->devctr2);
-        if (pairs && sb.nw > 0) {   // after group_enqueue: it zeroes the producer's counter block
+        if (pairs_pending) { RB_HIP(hipStreamWaitEvent(sp, g->ev3, 0)); pairs_pending = false; }
+        if (pairs && !pairs_side && sb.nw > 0) {   // after group_enqueue: it zeroes the producer's counter block
             g->prof_begin(sp);
             pc = reinterpret_cast<unsigned long long *>(g->devctr2.as<uint32_t>() + 12);
             launch_pairs(g, b, sb.w0, sb.nw, mode_hash, nullptr, nullptr, pc, sp);
@@ -2321,12 +2356,13 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
     for (size_t i = 0; i < subs.size(); ++i) {
         const int slot = (int)(i & 1u);
         unsigned long long np = 0;
-        if (pairs && subs[i].nw > 0) RB_HIP(hipMemcpyAsync(&np, reinterpret_cast<unsigned long long *>(g->devctr2.as<uint32_t>() + 12), 8, hipMemcpyDeviceToHost, sp));
+        if (pairs && !pairs_side && subs[i].nw > 0) RB_HIP(hipMemcpyAsync(&np, reinterpret_cast<unsigned long long *>(g->devctr2.as<uint32_t>() + 12), 8, hipMemcpyDeviceToHost, sp));
         const uint32_t D = group_finish(g, slot, sp, g->temp2, g->devctr2, s);  // drains the producer stream
         if (stats) { stats->pairs += (int64_t)np; stats->distinct += D; }
         const bool serial = getenv("RB_SERIAL") != nullptr;   // debugging / clean per-stage timing
         const bool early = getenv("RB_PREPARE_EARLY") != nullptr;   // A/B: producer a whole sub-batch ahead (staler cache)
         if (!serial && early && i + 1 < subs.size()) prepare(i + 1);
+        if (pairs_mode == 2 && !serial && !early) pairs_fork(i + 1, false);
         g->cur = slot;
         g->seq_first = (uint32_t)subs[i].r0;             // occurrence ids of this sub-batch are relative to its first read
         // sub-batch i+1 is hashed / prefiltered as soon as sub-batch i's own-counter runs have retired (their
@@ -2346,6 +2382,12 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
     g->ordinal += (uint64_t)n;
     RB_HIP(hipStreamSynchronize(s));
     RB_HIP(hipStreamSynchronize(sp));
+    if (pairs_side) {
+        RB_HIP(hipStreamSynchronize(g->stream3));
+        unsigned long long np = 0;
+        RB_HIP(hipMemcpy(&np, g->pairs_ctr.p, 8, hipMemcpyDeviceToHost));
+        if (stats) stats->pairs += (int64_t)np;
+    }
     g->prof_collect();
 }
 
@@ -2398,9 +2440,12 @@ int rb_graph_create(const rb_graph_params *p, rb_graph **out) {
             int pr = hi_p;
             if (const char *e = getenv("RB_PRODUCER_PRIORITY")) pr = atoi(e);
             RB_HIP(hipStreamCreateWithPriority(&g->stream2, hipStreamNonBlocking, pr));
+            RB_HIP(hipStreamCreateWithPriority(&g->stream3, hipStreamNonBlocking, pr));
         }
         RB_HIP(hipEventCreate(&g->ev0));
         RB_HIP(hipEventCreate(&g->ev1));
+        RB_HIP(hipEventCreateWithFlags(&g->ev2, hipEventDisableTiming));
+        RB_HIP(hipEventCreateWithFlags(&g->ev3, hipEventDisableTiming));
         alloc_bits(g->dbg, p->dbgbf_bits, p->dbgbf_num_hash, 0, p->dbgbf_bits);
         g->cbf_size = p->cbf_bytes; g->cbf_lo = 0; g->cbf_hi = p->cbf_bytes;
         g->cbf_alloc = (((size_t)p->cbf_bytes + 3) / 4 + 1) * 4;
@@ -2453,6 +2498,7 @@ int rb_graph_destroy(rb_graph *g) {
     (void)hipSetDevice(g->p.device);
     if (g->stream) (void)hipStreamSynchronize(g->stream);
     if (g->stream2) (void)hipStreamSynchronize(g->stream2);
+    if (g->stream3) (void)hipStreamSynchronize(g->stream3);
     rb::shard_free(g);
     free_bits(g->dbg); free_bits(g->rpk); free_bits(g->fpk);
     if (g->cbf) (void)hipFree(g->cbf);
@@ -2469,11 +2515,14 @@ int rb_graph_destroy(rb_graph *g) {
     g->qfree.clear();
     if (g->ev0) (void)hipEventDestroy(g->ev0);
     if (g->ev1) (void)hipEventDestroy(g->ev1);
+    if (g->ev2) (void)hipEventDestroy(g->ev2);
+    if (g->ev3) (void)hipEventDestroy(g->ev3);
     if (g->stream) (void)hipStreamDestroy(g->stream);
     if (g->stream2) (void)hipStreamDestroy(g->stream2);
+    if (g->stream3) (void)hipStreamDestroy(g->stream3);
     for (auto e : g->prof_pool) (void)hipEventDestroy(e);
     for (auto &sl : g->slots) { sl.keys1.release(); sl.valsT.release(); sl.vals1.release(); sl.tz.release(); sl.uniq.release(); sl.counts.release(); sl.starts.release(); }
-    g->temp2.release(); g->devctr2.release(); g->npf.release(); g->mpf.release(); g->rst.release(); g->chunk_mask.release(); g->npf_tot.release(); g->wstate.release();
+    g->temp2.release(); g->devctr2.release(); g->pairs_ctr.release(); g->npf.release(); g->mpf.release(); g->rst.release(); g->chunk_mask.release(); g->npf_tot.release(); g->wstate.release();
     delete g;
     return RB_OK;
 }

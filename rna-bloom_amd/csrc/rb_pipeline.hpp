@@ -335,6 +335,7 @@ struct rb_graph {
     uint32_t light_ops = 96;
     hipStream_t stream = nullptr;    // consumer stream: everything that touches the filters
     hipStream_t stream2 = nullptr;   // producer stream: hashing + grouping of the NEXT sub-batch (scratch only)
+    hipStream_t stream3 = nullptr;   // side stream of the producer: the paired-k-mer walker (rpkbf only) beside the window walk
     // grouped sub-batch, double buffered so that grouping of sub-batch i+1 overlaps the filter stages of i
     struct GroupSlot { DevBuf keys1, valsT, vals1, tz, uniq, counts, starts; size_t N = 0; uint32_t D = 0; int flags = 0; uint32_t live = 0; };
     GroupSlot slots[2];
@@ -345,7 +346,7 @@ struct rb_graph {
     DevBuf &uniq() { return slots[cur].uniq; }
     DevBuf &counts() { return slots[cur].counts; }
     DevBuf &starts() { return slots[cur].starts; }
-    DevBuf temp2, devctr2;
+    DevBuf temp2, devctr2, pairs_ctr;
     // no-op prefilter
     DevBuf npf, chunk_mask, npf_tot, wstate;
     uint32_t npf_log2 = 0;
@@ -372,8 +373,8 @@ struct rb_graph {
     struct ProfPending { const char *name; hipEvent_t e0, e1; };
     std::vector<ProfPending> prof_pending;
     std::vector<hipEvent_t> prof_pool;
-    hipEvent_t prof_open[2] = {nullptr, nullptr};
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t prof_open[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
     hipEvent_t prof_event() {
         if (!prof_pool.empty()) { hipEvent_t e = prof_pool.back(); prof_pool.pop_back(); return e; }
         hipEvent_t e; RB_HIP(hipEventCreate(&e)); return e;
@@ -397,16 +398,16 @@ struct rb_graph {
     }
     void prof_begin(hipStream_t st = nullptr) {
         if (!prof_on) return;
-        const int w = (st && st == stream2) ? 1 : 0;
+        const int w = (st && st == stream2) ? 1 : (st && st == stream3) ? 2 : 0;
         prof_open[w] = prof_event();
-        RB_HIP(hipEventRecord(prof_open[w], w ? stream2 : stream));
+        RB_HIP(hipEventRecord(prof_open[w], w == 1 ? stream2 : w == 2 ? stream3 : stream));
     }
     void prof_end(const char *name, hipStream_t st = nullptr) {
         if (!prof_on) return;
-        const int w = (st && st == stream2) ? 1 : 0;
+        const int w = (st && st == stream2) ? 1 : (st && st == stream3) ? 2 : 0;
         if (!prof_open[w]) return;
         hipEvent_t e1 = prof_event();
-        RB_HIP(hipEventRecord(e1, w ? stream2 : stream));
+        RB_HIP(hipEventRecord(e1, w == 1 ? stream2 : w == 2 ? stream3 : stream));
         prof_pending.push_back({name, prof_open[w], e1});
         prof_open[w] = nullptr;
     }
