@@ -6,7 +6,7 @@ would leave behind, written in the reference's on-disk format by the CPU oracle.
 
 tests/golden/stage1_small pins the plain case (uniform 100 bp pairs).  One JVM session over THIS fixture
 (tools/replay_with_jar.sh) pins what it leaves out:
-  pe/        300 bp pairs, a third of the reads ragged (18..299 bases, some shorter than k: skipped, R/RNABloom.java:567-570),
+  pe/        300 bp pairs, half of the reads ragged (18..299 bases, some shorter than k: skipped, R/RNABloom.java:567-570),
              lower-case stretches, U for T, N, qualities '#' (PHRED 2: cuts a segment at -q 3) and '$' (PHRED 3: does not),
              -left / -right -revcomp-right: segmentation (R/util/SeqUtils.java:1432-1438), the reverse-complement iterators
              (R/RNABloom.java:540-545), the read-length quartiles behind the pair distance (:1010-1098)
