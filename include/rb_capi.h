@@ -480,6 +480,31 @@ int rb_shard_query_serve(rb_graph *g, int which_bits, const void *bidx_dev, int6
 int rb_shard_query_finish(rb_graph *g, int which_bits, const void *breply_dev, const void *creply_dev,
                           uint8_t *out8_host /* what 0 */, float *outf_host /* what 1, 2 */);
 
+/* ---- graph traversal on a sharded graph: rb_graph_walk / rb_graph_greedy_extend / rb_graph_naive_extend when no GPU holds the
+ * filters (BASELINE configs[3]: stage 2's inner loops, R/util/GraphUtils.java:1591-1675, :1906-1996, :6780-7112, over
+ * Kmer.getSuccessors / getPredecessors R/graph/Kmer.java:199-355).  Every rank drives its own walks with the SAME kernels the
+ * single-GPU calls run; the counts they need come from the owners of the filter ranges through the query exchange above:
+ *   begin (this rank's seeds; may be none) -> repeat { advance -> [all_to_all of slots Q_BIDX / Q_CIDX] -> rb_shard_query_serve ->
+ *   [all_to_all back] -> absorb } until no rank reports an active walk -> end.
+ * advance runs every walk up to the next neighbourhood whose counts it has not been told (a walk suspends at the start of its
+ * current step and replays it from there when the answers are in: the step's earlier questions are then cache hits), files the
+ * requests — the four neighbours of a k-mer go out together, a naive extension's back-branch variants with them — and makes the
+ * query for them (bit_counts / ctr_counts per destination rank, as rb_shard_query_make).  One exchange round per step for the
+ * max-coverage walk and the naive extension, one per neighbourhood the lookahead search opens for the greedy extension.
+ * kind 0 = rb_graph_walk (targets may be NULL), 1 = rb_graph_greedy_extend (mode_or_lookahead = lookahead; no gate filter on a
+ * sharded graph), 2 = rb_graph_naive_extend (mode_or_lookahead = mode; term_seq / term_off for mode 0); the other arguments, the
+ * outputs and the reasons are those calls'.  answer_cap: counts one step of a walk may hold (0: 4, 8, or
+ * 4 (1 + 4 (1 + 2 lookahead)) by kind); a greedy step whose search needs more ends the walk with reason 8.  Results equal the
+ * single-GPU calls on the same filters (tests/test_gpu_sharded_walks.py). */
+int rb_shard_trav_begin(rb_graph *g, int kind, const char *seeds, const char *targets, size_t n, int direction, int mode_or_lookahead,
+                        int bound, int cap, float min_cov, const char *term_seq, const int64_t *term_off, int answer_cap);
+int rb_shard_trav_advance(rb_graph *g, int64_t *n_active, int64_t *bit_counts, int64_t *ctr_counts);
+int rb_shard_trav_absorb(rb_graph *g, const void *breply_dev, const void *creply_dev);
+/* out_f: kinds 0 and 2 (forward hashes of the appended k-mers), out_r and out_count: kind 0, out_count: kinds 0 and 1; each may be
+ * NULL.  rounds (may be NULL): exchange rounds this rank's walks took.  Frees the traversal. */
+int rb_shard_trav_end(rb_graph *g, char *out_bases, uint64_t *out_f, uint64_t *out_r, float *out_count, int32_t *out_len,
+                      uint8_t *out_reason, int64_t *rounds);
+
 /* ---- the exchange driver below the C ABI (csrc/rb_comm.hip) ----
  * rb_shard_add_range = rnabloom/sharded.py::ShardRank.add_range in the library: all sub-batches of reads [first, first + n)
  * (the same call on every rank, every rank holding the same batch), every phase above and every exchange between them, on the

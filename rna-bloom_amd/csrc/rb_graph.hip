@@ -1235,6 +1235,62 @@ __global__ void k_neighbors(FilterView fv, int stranded, int k, int direction, c
     c4[t] = HASH_ONLY ? 0.0f : graph_count(fv, stranded ? nf : smin(nf, nr));
 }
 
+// ---- where a traversal kernel takes graph.getCount from ----
+// DirectCounts: the graph's own filters (one GPU holds them).  ReplayCounts: a SHARDED graph (rb_shard_trav_*): the counts live
+// on other ranks, so a walk runs until it needs a count it has not been told, files the request (the four neighbours of a k-mer
+// go out together) and suspends at the START of its current step; after the exchange round (rb_shard_query_* protocol) the
+// answers are in the walk's cache and the same kernel replays the step from its start — every count it asked before is now a
+// cache hit, so it gets exactly as far as the next unknown neighbourhood.  One body per traversal, two count sources: the
+// sharded walks cannot drift from the single-GPU ones.  A finished step empties the cache.
+struct TravArrays {
+    uint64_t *f, *r;            // per walk: hashes of the k-mer it stands on when suspended
+    int32_t *len;               // appended k-mers so far
+    uint8_t *phase;             // 0 fresh, 1 suspended, 2 finished
+    uint64_t *ckey; float *cval; uint32_t *cn; uint32_t ccap;       // answers [walk][ccap]
+    uint8_t *over;              // the answers of one step did not fit ccap
+    uint64_t *req; uint32_t *req_walk; uint32_t *ctr; uint32_t req_cap;   // this round's requests; ctr[0] = requests, ctr[1] = walks suspended
+};
+struct DirectCounts {
+    static constexpr bool kReplay = false;
+    FilterView fv;
+    struct Walk {
+        const FilterView *fv;
+        __device__ __forceinline__ bool get(uint64_t h0, float &c) const { c = graph_count(*fv, h0); return true; }
+        __device__ __forceinline__ void step_done() const {}
+    };
+    __device__ __forceinline__ Walk walk(size_t) const { return Walk{&fv}; }
+    __device__ __forceinline__ TravArrays arrays() const { return TravArrays{}; }
+};
+struct ReplayCounts {
+    static constexpr bool kReplay = true;
+    TravArrays t;
+    struct Walk {
+        const uint64_t *key; const float *val; uint32_t *cn; uint32_t n; uint64_t *req; uint32_t *req_walk; uint32_t *ctr; uint32_t req_cap, id;
+        __device__ __forceinline__ bool get(uint64_t h0, float &c) const {
+            for (uint32_t q = 0; q < n; ++q) if (key[q] == h0) { c = val[q]; return true; }
+            const uint32_t p = atomicAdd(&ctr[0], 1u);
+            if (p < req_cap) { req[p] = h0; req_walk[p] = id; }
+            c = 0.0f;
+            return false;
+        }
+        __device__ __forceinline__ void step_done() { *cn = 0u; n = 0u; }
+    };
+    __device__ __forceinline__ Walk walk(size_t i) const {
+        return Walk{t.ckey + i * t.ccap, t.cval + i * t.ccap, t.cn + i, min(t.cn[i], t.ccap), t.req, t.req_walk, t.ctr, t.req_cap, (uint32_t)i};
+    }
+    __device__ __forceinline__ TravArrays arrays() const { return t; }
+};
+constexpr uint8_t WALK_REASON_TOO_WIDE = 8;   // sharded graphs only: one step asked for more counts than the walk's answer cache holds
+// the answers of one exchange round go into the caches of the walks that asked
+__global__ void k_trav_absorb(TravArrays t, const float *__restrict__ ans, uint32_t n_req) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_req) return;
+    const uint32_t i = t.req_walk[j];
+    const uint32_t p = atomicAdd(&t.cn[i], 1u);
+    if (p < t.ccap) { t.ckey[(size_t)i * t.ccap + p] = t.req[j]; t.cval[(size_t)i * t.ccap + p] = ans[j]; }
+    else t.over[i] = 1;
+}
+
 // ---- greedy maximum-coverage walk: the loop around Kmer.getMaxCovSuccessor / getMaxCovPredecessor ----
 // One lane per walk (R/util/GraphUtils.java:1591-1675 getMaxCoveragePath runs two of them; :1906-1990 the
 // lookahead-free part of greedyExtend*).  Per step: the 4 neighbours in order A,C,G,T
@@ -1245,7 +1301,8 @@ __global__ void k_neighbors(FilterView fv, int stranded, int k, int direction, c
 // appended k-mers (3); a seed with a base outside ACGTU ends at once (4).
 // seq[i]: for a right walk the seed's bases followed by the appended ones; for a left walk the seed's bases
 // REVERSED followed by the prepended ones — either way k-mer number j of the walk (0-based) is seq[j+1 .. j+k].
-__global__ void k_walk_max_cov(FilterView fv, int stranded, int k, int direction, const uint8_t *__restrict__ seeds,
+template <class SRC>
+__global__ void k_walk_max_cov(SRC src, int stranded, int k, int direction, const uint8_t *__restrict__ seeds,
                                const uint8_t *__restrict__ targets, size_t n, int bound, float min_cov,
                                uint8_t *__restrict__ seq, uint8_t *__restrict__ out_b, uint64_t *__restrict__ out_f, uint64_t *__restrict__ out_r,
                                float *__restrict__ out_c, int32_t *__restrict__ out_len, uint8_t *__restrict__ out_reason) {
@@ -1253,6 +1310,11 @@ __global__ void k_walk_max_cov(FilterView fv, int stranded, int k, int direction
     for (int q = 0; q < 32; ++q) s_seen[q][threadIdx.x] = 0u;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const TravArrays ta = src.arrays();
+    if (SRC::kReplay && ta.phase[i] == 2) return;
+    if (SRC::kReplay && ta.over[i]) { out_len[i] = ta.len[i]; out_reason[i] = WALK_REASON_TOO_WIDE; ta.phase[i] = 2; return; }
+    const bool resume = SRC::kReplay && ta.phase[i] == 1;
+    auto w = src.walk(i);
     const uint32_t uk = (uint32_t)k;
     const size_t stride = (size_t)k + (size_t)bound;
     uint8_t *sq = seq + i * stride;
@@ -1271,19 +1333,24 @@ __global__ void k_walk_max_cov(FilterView fv, int stranded, int k, int direction
     };
     uint64_t f, r, tf = 0, tr = 0;
     const uint8_t *sb = seeds + i * (size_t)k;
-    if (!hash_kmer(sb, f, r)) { out_len[i] = 0; out_reason[i] = 4; return; }
+    if (!hash_kmer(sb, f, r)) { out_len[i] = 0; out_reason[i] = 4; if (SRC::kReplay) ta.phase[i] = 2; return; }
     const uint8_t *tb = targets ? targets + i * (size_t)k : nullptr;
     bool has_target = tb && hash_kmer(tb, tf, tr);
-    for (uint32_t q = 0; q < uk; ++q) sq[q] = (direction == 0) ? sb[q] : sb[uk - 1u - q];
     const uint8_t acgt[4] = {'A', 'C', 'G', 'T'};
     int len = 0;
     uint8_t reason = 3;
+    if (resume) {                                             // a suspended walk: where it stood, and the bitmap of what it appended
+        f = ta.f[i]; r = ta.r[i]; len = ta.len[i];
+        for (int j = 0; j < len; ++j) { const uint32_t hb = (uint32_t)((pf[j] * 0x9E3779B97F4A7C15ull) >> 54); s_seen[hb >> 5][threadIdx.x] |= 1u << (hb & 31u); }
+    } else
+        for (uint32_t q = 0; q < uk; ++q) sq[q] = (direction == 0) ? sb[q] : sb[uk - 1u - q];
     while (len < bound) {
         const uint32_t oc = code_of_char(sq[len]);            // base leaving: first base (right walk) / last base (left walk)
         const uint64_t s_out = seed_of(oc), sc_out = seed_of(3u - oc);
         float best_c = -1.0f;
         uint64_t best_f = 0, best_r = 0;
         uint32_t best_in = 0;
+        bool miss = false;
         for (uint32_t in = 0; in < 4u; ++in) {
             uint64_t nf, nr = 0;
             if (direction == 0) {
@@ -1293,9 +1360,11 @@ __global__ void k_walk_max_cov(FilterView fv, int stranded, int k, int direction
                 nf = rotr(f, 1) ^ rotr(s_out, 1) ^ rotl(seed_of(in), uk - 1u);
                 if (!stranded) nr = rotl(r, 1) ^ rotl(sc_out, uk) ^ seed_of(3u - in);
             }
-            const float c = graph_count(fv, stranded ? nf : smin(nf, nr));
+            float c;
+            if (!w.get(stranded ? nf : smin(nf, nr), c)) { miss = true; continue; }
             if (c >= min_cov && c > best_c) { best_c = c; best_f = nf; best_r = nr; best_in = in; }
         }
+        if (SRC::kReplay && miss) { ta.f[i] = f; ta.r[i] = r; ta.len[i] = len; ta.phase[i] = 1; atomicAdd(&ta.ctr[1], 1u); return; }
         if (best_c < 0.0f) { reason = 0; break; }
         const uint8_t nb = acgt[best_in];
         // bases of the candidate: seq[len+1 .. len+k-1] + nb
@@ -1327,9 +1396,11 @@ __global__ void k_walk_max_cov(FilterView fv, int stranded, int k, int direction
         pf[len] = best_f; pr[len] = best_r; pc[len] = best_c;
         f = best_f; r = best_r;
         ++len;
+        w.step_done();
     }
     out_len[i] = len;
     out_reason[i] = reason;
+    if (SRC::kReplay) ta.phase[i] = 2;
 }
 
 // ---- GraphUtils.naiveExtendRight / naiveExtendLeft (R/util/GraphUtils.java:6780-7112): extension through unbranched
@@ -1346,13 +1417,19 @@ __global__ void k_walk_max_cov(FilterView fv, int stranded, int k, int direction
 //     added last; else as mode 1.
 // reason: 0 no neighbour, 1 back branch, 2 several neighbours, 3 bound, 4 invalid seed, 5 terminator / used k-mer,
 // 6 output capacity reached (mode 0 has no bound of its own), 7 the candidate repeats the seed / the last k-mer.
-__global__ void k_naive_extend(FilterView fv, int stranded, int k, int direction, int mode, const uint8_t *__restrict__ seeds, size_t n,
+template <class SRC>
+__global__ void k_naive_extend(SRC src, int stranded, int k, int direction, int mode, const uint8_t *__restrict__ seeds, size_t n,
                                int bound, int cap, float min_cov, const uint8_t *__restrict__ term_seq, const int64_t *__restrict__ term_off,
                                const uint64_t *__restrict__ term_f, const int64_t *__restrict__ term_koff,
                                uint8_t *__restrict__ seq, uint8_t *__restrict__ out_b, uint64_t *__restrict__ wf,
                                int32_t *__restrict__ out_len, uint8_t *__restrict__ out_reason) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const TravArrays ta = src.arrays();
+    if (SRC::kReplay && ta.phase[i] == 2) return;
+    if (SRC::kReplay && ta.over[i]) { out_len[i] = ta.len[i]; out_reason[i] = WALK_REASON_TOO_WIDE; ta.phase[i] = 2; return; }
+    const bool resume = SRC::kReplay && ta.phase[i] == 1;
+    auto w = src.walk(i);
     const uint32_t uk = (uint32_t)k;
     const size_t stride = (size_t)k + (size_t)cap;
     uint8_t *sq = seq + i * stride;                       // walk orientation: seed (reversed for a left walk), then the added bases
@@ -1361,15 +1438,16 @@ __global__ void k_naive_extend(FilterView fv, int stranded, int k, int direction
     uint64_t f = 0, r = 0;
     for (uint32_t q = 0; q < uk; ++q) {
         const uint32_t c = code_of_char(sb[q]);
-        if (c > 3u) { out_len[i] = 0; out_reason[i] = 4; return; }
+        if (c > 3u) { out_len[i] = 0; out_reason[i] = 4; if (SRC::kReplay) ta.phase[i] = 2; return; }
         f = rotl(f, 1) ^ seed_of(c);
         r ^= rotl(seed_of(3u - c), q);
     }
-    for (uint32_t q = 0; q < uk; ++q) sq[q] = (direction == 0) ? sb[q] : sb[uk - 1u - q];
     const uint64_t seed_f = f;
     const uint8_t acgt[4] = {'A', 'C', 'G', 'T'};
     int len = 0;
     uint8_t reason = 3;
+    if (resume) { f = ta.f[i]; r = ta.r[i]; len = ta.len[i]; }
+    else for (uint32_t q = 0; q < uk; ++q) sq[q] = (direction == 0) ? sb[q] : sb[uk - 1u - q];
     // candidate (walk orientation: sq[len+1 .. len+k-1] + nb) against k bases given left to right
     auto cand_equals = [&](const uint8_t *other, uint32_t best_in) -> bool {
         for (uint32_t q = 0; q < uk; ++q) {
@@ -1384,24 +1462,30 @@ __global__ void k_naive_extend(FilterView fv, int stranded, int k, int direction
         const uint64_t s_out = seed_of(oc), sc_out = seed_of(3u - oc);
         uint32_t n_nb = 0, best_in = 0;
         uint64_t best_f = 0, best_r = 0;
+        bool miss = false;
         for (uint32_t in = 0; in < 4u; ++in) {
             uint64_t nf, nr = 0;
             if (direction == 0) { nf = rotl(f, 1) ^ rotl(s_out, uk) ^ seed_of(in); if (!stranded) nr = rotr(r, 1) ^ rotr(sc_out, 1) ^ rotl(seed_of(3u - in), uk - 1u); }
             else { nf = rotr(f, 1) ^ rotr(s_out, 1) ^ rotl(seed_of(in), uk - 1u); if (!stranded) nr = rotl(r, 1) ^ rotl(sc_out, uk) ^ seed_of(3u - in); }
-            if (graph_count(fv, stranded ? nf : smin(nf, nr)) >= min_cov) { if (n_nb++ == 0) { best_in = in; best_f = nf; best_r = nr; } }
+            float c;
+            if (!w.get(stranded ? nf : smin(nf, nr), c)) { miss = true; continue; }
+            if (c >= min_cov) { if (n_nb++ == 0) { best_in = in; best_f = nf; best_r = nr; } }
         }
-        if (n_nb == 0) { reason = 0; break; }                 // `while (!neighbors.isEmpty())`: a dead end ends the walk before the back-branch test (:6791)
+        if (!miss && n_nb == 0) { reason = 0; break; }        // `while (!neighbors.isEmpty())`: a dead end ends the walk before the back-branch test (:6791)
         if (mode != 2) {                                      // back branches: variants of the current k-mer in that base
-            bool back = false;
-            for (uint32_t in = 0; in < 4u && !back; ++in) {
+            bool back = false;                                // (a sharded graph asks for them in the same round as the neighbours)
+            for (uint32_t in = 0; in < 4u && (SRC::kReplay || !back); ++in) {
                 if (in == oc) continue;
                 uint64_t vf, vr = 0;
                 if (direction == 0) { vf = f ^ rotl(s_out, uk - 1u) ^ rotl(seed_of(in), uk - 1u); if (!stranded) vr = r ^ sc_out ^ seed_of(3u - in); }
                 else { vf = f ^ s_out ^ seed_of(in); if (!stranded) vr = r ^ rotl(sc_out, uk - 1u) ^ rotl(seed_of(3u - in), uk - 1u); }
-                back = graph_count(fv, stranded ? vf : smin(vf, vr)) >= 1.0f;
+                float c;
+                if (!w.get(stranded ? vf : smin(vf, vr), c)) { miss = true; continue; }
+                back = back || c >= 1.0f;
             }
+            if (SRC::kReplay && miss) { ta.f[i] = f; ta.r[i] = r; ta.len[i] = len; ta.phase[i] = 1; atomicAdd(&ta.ctr[1], 1u); return; }
             if (back) { reason = 1; break; }
-        }
+        } else if (SRC::kReplay && miss) { ta.f[i] = f; ta.r[i] = r; ta.len[i] = len; ta.phase[i] = 1; atomicAdd(&ta.ctr[1], 1u); return; }
         if (n_nb > 1) { reason = 2; break; }
         if (mode == 0) {
             bool hit = false;
@@ -1428,10 +1512,12 @@ __global__ void k_naive_extend(FilterView fv, int stranded, int k, int direction
         pf[len] = best_f;
         f = best_f; r = best_r;
         ++len;
+        w.step_done();
         if (mode != 0 && len > bound) { reason = 3; break; }
     }
     out_len[i] = len;
     out_reason[i] = reason;
+    if (SRC::kReplay) ta.phase[i] = 2;
 }
 
 // ---- greedy extension with lookahead: GraphUtils.greedyExtendRight / greedyExtendLeft ----
@@ -1445,10 +1531,13 @@ __global__ void k_naive_extend(FilterView fv, int stranded, int k, int direction
 constexpr int WALK_MAX_LOOKAHEAD = 16;
 struct WalkCand { uint64_t f, r; float c; uint32_t in; };
 struct WalkGate { const uint32_t *bits; Mod mod; int num_hash; };      // the extra BloomFilter of the `bf` variants, bits == nullptr: none
-__device__ __forceinline__ int walk_neighbors(const FilterView &fv, const WalkGate &gate, int stranded, uint32_t uk, int direction,
+// (-1: a count is not known yet — sharded graphs; the requests for all four neighbours are filed)
+template <class W>
+__device__ __forceinline__ int walk_neighbors(W &w, uint64_t kmul, const WalkGate &gate, int stranded, uint32_t uk, int direction,
                                               uint64_t f, uint64_t r, uint32_t oc, float min_cov, WalkCand *out) {
     const uint64_t s_out = seed_of(oc), sc_out = seed_of(3u - oc);
     int n = 0;
+    bool miss = false;
     for (uint32_t in = 0; in < 4u; ++in) {
         uint64_t nf, nr = 0;
         if (direction == 0) {
@@ -1459,17 +1548,24 @@ __device__ __forceinline__ int walk_neighbors(const FilterView &fv, const WalkGa
             if (!stranded) nr = rotl(r, 1) ^ rotl(sc_out, uk) ^ seed_of(3u - in);
         }
         const uint64_t h0 = stranded ? nf : smin(nf, nr);
-        if (gate.bits && !bits_lookup(gate.bits, gate.mod, gate.num_hash, fv.kmul, h0)) continue;   // Kmer.getSuccessors(k, numHash, graph, bf): bf.lookup first
-        const float c = graph_count(fv, h0);
+        if (gate.bits && !bits_lookup(gate.bits, gate.mod, gate.num_hash, kmul, h0)) continue;   // Kmer.getSuccessors(k, numHash, graph, bf): bf.lookup first
+        float c;
+        if (!w.get(h0, c)) { miss = true; continue; }
         if (c >= min_cov) { out[n].f = nf; out[n].r = nr; out[n].c = c; out[n].in = in; ++n; }
     }
-    return n;
+    return miss ? -1 : n;
 }
-__global__ void k_greedy_extend(FilterView fv, WalkGate gate, int stranded, int k, int direction, const uint8_t *__restrict__ seeds, size_t n,
+template <class SRC>
+__global__ void k_greedy_extend(SRC src, uint64_t kmul, WalkGate gate, int stranded, int k, int direction, const uint8_t *__restrict__ seeds, size_t n,
                                 int lookahead, int bound, uint8_t *__restrict__ seq, uint8_t *__restrict__ out_b,
                                 float *__restrict__ out_c, int32_t *__restrict__ out_len, uint8_t *__restrict__ out_reason) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const TravArrays ta = src.arrays();
+    if (SRC::kReplay && ta.phase[i] == 2) return;
+    if (SRC::kReplay && ta.over[i]) { out_len[i] = ta.len[i]; out_reason[i] = WALK_REASON_TOO_WIDE; ta.phase[i] = 2; return; }
+    const bool resume = SRC::kReplay && ta.phase[i] == 1;
+    auto w = src.walk(i);
     const uint32_t uk = (uint32_t)k;
     const size_t stride = (size_t)k + (size_t)bound + (size_t)WALK_MAX_LOOKAHEAD + 1;
     uint8_t *sq = seq + i * stride;                    // walk orientation, see k_walk_max_cov; the search writes ahead of the walk
@@ -1477,20 +1573,23 @@ __global__ void k_greedy_extend(FilterView fv, WalkGate gate, int stranded, int 
     uint64_t f = 0, r = 0;
     for (uint32_t q = 0; q < uk; ++q) {
         const uint32_t c = code_of_char(sb[q]);
-        if (c > 3u) { out_len[i] = 0; out_reason[i] = 4; return; }
+        if (c > 3u) { out_len[i] = 0; out_reason[i] = 4; if (SRC::kReplay) ta.phase[i] = 2; return; }
         f = rotl(f, 1) ^ seed_of(c);
         r ^= rotl(seed_of(3u - c), q);
     }
-    for (uint32_t q = 0; q < uk; ++q) sq[q] = (direction == 0) ? sb[q] : sb[uk - 1u - q];
     const uint8_t acgt[4] = {'A', 'C', 'G', 'T'};
     int len = 0;
     uint8_t reason = 3;
+    if (resume) { f = ta.f[i]; r = ta.r[i]; len = ta.len[i]; }
+    else for (uint32_t q = 0; q < uk; ++q) sq[q] = (direction == 0) ? sb[q] : sb[uk - 1u - q];
     WalkCand cand[4];
     WalkCand frontier[WALK_MAX_LOOKAHEAD][4];          // siblings not yet tried, per level of the search
     int fr_n[WALK_MAX_LOOKAHEAD], fr_next[WALK_MAX_LOOKAHEAD];
     WalkCand path[WALK_MAX_LOOKAHEAD + 1];             // path[0] = the candidate being scored ("source")
+    bool suspended = false;                            // sharded graphs: a neighbourhood whose counts are not known yet
     while (len < bound) {
-        const int nc = walk_neighbors(fv, gate, stranded, uk, direction, f, r, code_of_char(sq[len]), 1.0f, cand);
+        const int nc = walk_neighbors(w, kmul, gate, stranded, uk, direction, f, r, code_of_char(sq[len]), 1.0f, cand);
+        if (nc < 0) { suspended = true; break; }
         if (nc == 0) { reason = 0; break; }
         int best = 0;
         if (nc > 1) {
@@ -1502,7 +1601,8 @@ __global__ void k_greedy_extend(FilterView fv, WalkGate gate, int stranded, int 
                 path[0] = cand[ci];
                 int psize = 1, depth = 0;                // psize = path.size(); depth = frontier.size()
                 WalkCand nb[4];
-                int nn = walk_neighbors(fv, gate, stranded, uk, direction, cand[ci].f, cand[ci].r, code_of_char(sq[(size_t)len + 1u]), 1.0f, nb);
+                int nn = walk_neighbors(w, kmul, gate, stranded, uk, direction, cand[ci].f, cand[ci].r, code_of_char(sq[(size_t)len + 1u]), 1.0f, nb);
+                if (nn < 0) { suspended = true; break; }
                 if (nn == 0) score = (lookahead > 0) ? 0.0f : cand[ci].c;
                 else {
                     float best_path = 0.0f;
@@ -1514,7 +1614,8 @@ __global__ void k_greedy_extend(FilterView fv, WalkGate gate, int stranded, int 
                         if (psize < lookahead) {
                             const WalkCand &cur = path[psize - 1];
                             // cursor = k-mer number (psize-1) after the candidate: its leaving base is sq[len + 1 + (psize-1)]
-                            nn = walk_neighbors(fv, gate, stranded, uk, direction, cur.f, cur.r, code_of_char(sq[(size_t)len + (size_t)psize]), 1.0f, nb);
+                            nn = walk_neighbors(w, kmul, gate, stranded, uk, direction, cur.f, cur.r, code_of_char(sq[(size_t)len + (size_t)psize]), 1.0f, nb);
+                            if (nn < 0) { suspended = true; break; }
                             if (nn > 0) {
                                 for (int q = 0; q < nn; ++q) frontier[depth][q] = nb[q];
                                 fr_n[depth] = nn; fr_next[depth] = 1; ++depth;
@@ -1540,20 +1641,25 @@ __global__ void k_greedy_extend(FilterView fv, WalkGate gate, int stranded, int 
                             }
                         }
                     }
+                    if (suspended) break;
                     score = best_path;
                 }
                 if (score > best_cov) { best = ci; best_cov = score; }
                 else if (score == best_cov && cand[ci].c > cand[best].c) best = ci;
             }
+            if (suspended) break;
         }
         sq[(size_t)len + uk] = acgt[cand[best].in];
         out_b[i * (size_t)bound + (size_t)len] = acgt[cand[best].in];
         out_c[i * (size_t)bound + (size_t)len] = cand[best].c;
         f = cand[best].f; r = cand[best].r;
         ++len;
+        w.step_done();
     }
+    if (SRC::kReplay && suspended) { ta.f[i] = f; ta.r[i] = r; ta.len[i] = len; ta.phase[i] = 1; atomicAdd(&ta.ctr[1], 1u); return; }
     out_len[i] = len;
     out_reason[i] = reason;
+    if (SRC::kReplay) ta.phase[i] = 2;
 }
 
 // ---- BloomFilter.lookupThenAdd over an array, in array order (R/bloom/BloomFilter.java:147-155) ----
@@ -2141,7 +2247,7 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
         const int slot = (int)(i & 1u);
         g->devctr2.reserve(DEVCTR_BYTES);
         sb.total = 0;
-        if (pairs_mode == 1) pairs_fork(i, true);
+        if (pairs_mode == 1 || pairs_mode == 2) pairs_fork(i, true);   // (2: the first sub-batch, and any the fork beside the consumer did not cover)
         if (sb.nw > 0) {
             const uint64_t ord0 = g->ordinal + (uint64_t)(sb.r0 - first);
             g->chunk_cnt.reserve(((size_t)sb.nw + 1) * 4); g->chunk_off.reserve(((size_t)sb.nw + 1) * 4);
@@ -2499,6 +2605,7 @@ int rb_graph_destroy(rb_graph *g) {
     if (g->stream) (void)hipStreamSynchronize(g->stream);
     if (g->stream2) (void)hipStreamSynchronize(g->stream2);
     if (g->stream3) (void)hipStreamSynchronize(g->stream3);
+    rb::trav_free(g);
     rb::shard_free(g);
     free_bits(g->dbg); free_bits(g->rpk); free_bits(g->fpk);
     if (g->cbf) (void)hipFree(g->cbf);
@@ -3305,7 +3412,7 @@ int rb_graph_walk(rb_graph *g, const char *seeds, const char *targets, size_t n,
         uint8_t *dreason = reinterpret_cast<uint8_t *>(dlen + n);
         RB_HIP(hipMemcpyAsync(dseed, seeds, n * k, hipMemcpyHostToDevice, s));
         if (targets) RB_HIP(hipMemcpyAsync(dtarget, targets, n * k, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_walk_max_cov, dim3(blocks_for((int64_t)n, 64)), dim3(64), 0, s, g->view(0, 0), (int)g->stranded, g->k, direction,
+        hipLaunchKernelGGL(k_walk_max_cov<DirectCounts>, dim3(blocks_for((int64_t)n, 64)), dim3(64), 0, s, DirectCounts{g->view(0, 0)}, (int)g->stranded, g->k, direction,
                            dseed, targets ? dtarget : (const uint8_t *)nullptr, n, bound, min_cov, dseq, dbases, q.c->b1.as<uint64_t>(),
                            q.c->b2.as<uint64_t>(), dc, dlen, dreason);
         RB_HIP(hipGetLastError());
@@ -3350,7 +3457,7 @@ int rb_graph_greedy_extend(rb_graph *g, const rb_graph *gate, const char *seeds,
         uint8_t *dreason = reinterpret_cast<uint8_t *>(dlen + n);
         RB_HIP(hipMemcpyAsync(dseed, seeds, n * k, hipMemcpyHostToDevice, s));
         WalkGate wg{gate ? gate->dbg.bits : nullptr, gate ? gate->dbg.mod : g->dbg.mod, gate ? gate->dbg.num_hash : 0};
-        hipLaunchKernelGGL(k_greedy_extend, dim3(blocks_for((int64_t)n, 64)), dim3(64), 0, s, g->view(0, 0), wg, (int)g->stranded, g->k, direction,
+        hipLaunchKernelGGL(k_greedy_extend<DirectCounts>, dim3(blocks_for((int64_t)n, 64)), dim3(64), 0, s, DirectCounts{g->view(0, 0)}, kmul_of(g->k), wg, (int)g->stranded, g->k, direction,
                            dseed, n, lookahead, bound, dseq, dbases, dc, dlen, dreason);
         RB_HIP(hipGetLastError());
         RB_HIP(hipMemcpyAsync(out_len, dlen, n * 4, hipMemcpyDeviceToHost, s));
@@ -3359,6 +3466,35 @@ int rb_graph_greedy_extend(rb_graph *g, const rb_graph *gate, const char *seeds,
         RB_HIP(hipMemcpyAsync(out_bases, dbases, nb, hipMemcpyDeviceToHost, s));
         RB_HIP(hipStreamSynchronize(s));
     });
+}
+
+// naiveExtend*'s terminators (mode 0): forward hash of every k-mer of every terminator sequence, hashed on the host side of the
+// call (they are short — the k-mers of the fragment being extended); offsets relative to the first sequence
+static void naive_terminators(size_t k, size_t n, int mode, const char *term_seq, const int64_t *term_off, std::vector<int64_t> &tko,
+                              std::vector<int64_t> &rel, std::vector<uint64_t> &tf, size_t &tbytes) {
+    tko.assign(n + 1, 0); rel.assign(n + 1, 0);
+    tbytes = 0;
+    if (mode == 0) {
+        for (size_t i = 0; i < n; ++i) { const int64_t l = term_off[i + 1] - term_off[i]; tko[i + 1] = tko[i] + (l >= (int64_t)k ? l - (int64_t)k + 1 : 0); }
+        for (size_t i = 0; i <= n; ++i) rel[i] = term_off[i] - term_off[0];
+        tbytes = (size_t)(term_off[n] - term_off[0]);
+    }
+    tf.assign(std::max<size_t>((size_t)tko[n], 1), 0);
+    if (mode != 0) return;
+    for (size_t i = 0; i < n; ++i) {
+        const char *t = term_seq + term_off[i];
+        const int64_t l = term_off[i + 1] - term_off[i];
+        for (int64_t p = 0; p + (int64_t)k <= l; ++p) {   // NTP64: forward hash from scratch (an N hashes as seed 0 and never equals a candidate)
+            uint64_t f = 0;
+            for (size_t x = 0; x < k; ++x) {
+                uint64_t sd = 0;
+                switch (t[p + (int64_t)x]) { case 'A': case 'a': sd = 0x3c8bfbb395c60474ull; break; case 'C': case 'c': sd = 0x3193c18562a02b4cull; break;
+                                             case 'G': case 'g': sd = 0x20323ed082572324ull; break; case 'T': case 't': case 'U': case 'u': sd = 0x295549f54be24456ull; break; default: break; }
+                f = ((f << 1) | (f >> 63)) ^ sd;
+            }
+            tf[(size_t)tko[i] + (size_t)p] = f;
+        }
+    }
 }
 
 int rb_graph_naive_extend(rb_graph *g, const char *seeds, size_t n, int direction, int mode, int bound, int cap, float min_cov,
@@ -3375,32 +3511,11 @@ int rb_graph_naive_extend(rb_graph *g, const char *seeds, size_t n, int directio
         QueryLease q(g);
         hipStream_t s = q.c->st;
         const size_t k = (size_t)g->k, stride = k + (size_t)cap;
-        // terminators: forward hash of every k-mer of every terminator sequence (hashed on the host side of the call: they
-        // are short — the k-mers of the fragment being extended)
-        std::vector<int64_t> tko(n + 1, 0);
+        std::vector<int64_t> tko, rel;
+        std::vector<uint64_t> tf;
         size_t tbytes = 0;
-        if (mode == 0) {
-            for (size_t i = 0; i < n; ++i) { const int64_t l = term_off[i + 1] - term_off[i]; tko[i + 1] = tko[i] + (l >= (int64_t)k ? l - (int64_t)k + 1 : 0); }
-            tbytes = (size_t)(term_off[n] - term_off[0]);
-        }
+        naive_terminators(k, n, mode, term_seq, term_off, tko, rel, tf, tbytes);
         const size_t nt = (size_t)tko[n];
-        std::vector<uint64_t> tf(std::max<size_t>(nt, 1));
-        if (mode == 0) {
-            for (size_t i = 0; i < n; ++i) {
-                const char *t = term_seq + term_off[i];
-                const int64_t l = term_off[i + 1] - term_off[i];
-                for (int64_t p = 0; p + (int64_t)k <= l; ++p) {   // NTP64: forward hash from scratch (an N hashes as seed 0 and never equals a candidate)
-                    uint64_t f = 0;
-                    for (size_t x = 0; x < k; ++x) {
-                        uint64_t sd = 0;
-                        switch (t[p + (int64_t)x]) { case 'A': case 'a': sd = 0x3c8bfbb395c60474ull; break; case 'C': case 'c': sd = 0x3193c18562a02b4cull; break;
-                                                     case 'G': case 'g': sd = 0x20323ed082572324ull; break; case 'T': case 't': case 'U': case 'u': sd = 0x295549f54be24456ull; break; default: break; }
-                        f = ((f << 1) | (f >> 63)) ^ sd;
-                    }
-                    tf[(size_t)tko[i] + (size_t)p] = f;
-                }
-            }
-        }
         q.c->b0.reserve(n * k + n * stride + n * (size_t)cap + tbytes + 64);   // seeds | seq | out bases | terminator text
         q.c->b1.reserve(n * (size_t)cap * 8 + nt * 8 + 64);                    // walk hashes | terminator hashes
         q.c->b2.reserve((n + 1) * 16 + 64);                                   // terminator offsets | terminator k-mer offsets
@@ -3411,21 +3526,196 @@ int rb_graph_naive_extend(rb_graph *g, const char *seeds, size_t n, int directio
         int32_t *dlen = q.c->b3.as<int32_t>();
         uint8_t *dreason = reinterpret_cast<uint8_t *>(dlen + n);
         RB_HIP(hipMemcpyAsync(dseed, seeds, n * k, hipMemcpyHostToDevice, s));
-        std::vector<int64_t> rel(n + 1, 0);
         if (mode == 0) {
-            for (size_t i = 0; i <= n; ++i) rel[i] = term_off[i] - term_off[0];
             if (tbytes) RB_HIP(hipMemcpyAsync(dterm, term_seq + term_off[0], tbytes, hipMemcpyHostToDevice, s));
             if (nt) RB_HIP(hipMemcpyAsync(dtf, tf.data(), nt * 8, hipMemcpyHostToDevice, s));
         }
         RB_HIP(hipMemcpyAsync(dtoff, rel.data(), (n + 1) * 8, hipMemcpyHostToDevice, s));
         RB_HIP(hipMemcpyAsync(dtko, tko.data(), (n + 1) * 8, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_naive_extend, dim3(blocks_for((int64_t)n, 64)), dim3(64), 0, s, g->view(0, 0), (int)g->stranded, g->k, direction, mode, dseed, n,
+        hipLaunchKernelGGL(k_naive_extend<DirectCounts>, dim3(blocks_for((int64_t)n, 64)), dim3(64), 0, s, DirectCounts{g->view(0, 0)}, (int)g->stranded, g->k, direction, mode, dseed, n,
                            bound, cap, min_cov, dterm, dtoff, dtf, dtko, dseq, dbases, dwf, dlen, dreason);
         RB_HIP(hipGetLastError());
         RB_HIP(hipMemcpyAsync(out_len, dlen, n * 4, hipMemcpyDeviceToHost, s));
         RB_HIP(hipMemcpyAsync(out_reason, dreason, n, hipMemcpyDeviceToHost, s));
         RB_HIP(hipMemcpyAsync(out_bases, dbases, n * (size_t)cap, hipMemcpyDeviceToHost, s));
         RB_HIP(hipStreamSynchronize(s));
+    });
+}
+
+// ---- the same three traversals on a SHARDED graph (rb_shard_trav_*): begin -> { advance -> [all_to_all] -> rb_shard_query_serve
+// -> [all_to_all back] -> absorb } until no rank has a walk left -> end.  `advance` runs this rank's walks (the kernels above with
+// ReplayCounts) up to their next unanswered neighbourhood and makes the query for what they asked (slots Q_BIDX / Q_CIDX, as
+// rb_shard_query_make does); `absorb` turns the owners' replies into counts and files them in the walks' caches.
+}  // extern "C"
+struct rb_trav {
+    int kind = 0, direction = 0, mode = 0, lookahead = 0, bound = 0, cap = 0;
+    float min_cov = 1.0f;
+    size_t n = 0, per_walk = 0;            // per_walk: entries of out_bases (and of the hash / count rows) per walk
+    bool has_targets = false;
+    rb::DevBuf text, hashes, misc, state, reqw;
+    uint8_t *dseed = nullptr, *dtarget = nullptr, *dseq = nullptr, *dbases = nullptr, *dterm = nullptr, *dreason = nullptr;
+    uint64_t *df = nullptr, *dr = nullptr, *dtf = nullptr;
+    float *dc = nullptr;
+    int32_t *dlen = nullptr;
+    int64_t *dtoff = nullptr, *dtko = nullptr;
+    TravArrays ta{};
+    uint32_t n_req = 0;
+    int64_t rounds = 0;
+};
+namespace rb {
+void trav_free(rb_graph *g) {
+    if (!g->trav) return;
+    rb_trav *t = g->trav;
+    t->text.release(); t->hashes.release(); t->misc.release(); t->state.release(); t->reqw.release();
+    delete t;
+    g->trav = nullptr;
+}
+}  // namespace rb
+extern "C" {
+
+int rb_shard_trav_begin(rb_graph *g, int kind, const char *seeds, const char *targets, size_t n, int direction, int mode_or_lookahead,
+                        int bound, int cap, float min_cov, const char *term_seq, const int64_t *term_off, int answer_cap) {
+    return guarded([&] {
+        RB_REQUIRE(g && g->shard, "rb_shard_trav_begin: not a shard handle");
+        RB_REQUIRE(kind >= 0 && kind <= 2, "rb_shard_trav_begin: kind must be 0 (max-coverage walk), 1 (greedy extension) or 2 (naive extension)");
+        RB_REQUIRE(n == 0 || seeds, "rb_shard_trav_begin: null seeds");
+        RB_REQUIRE(direction == 0 || direction == 1, "rb_shard_trav_begin: direction must be 0 (right) or 1 (left)");
+        RB_REQUIRE(n < ((size_t)1 << 28), "rb_shard_trav_begin: too many walks in one call");
+        RB_REQUIRE(g->dbg.bits && g->cbf, "rb_shard_trav_begin: this call needs dbgbf and cbf");
+        int mode = 0, lookahead = 0;
+        if (kind == 0) RB_REQUIRE(bound >= 1 && bound <= (1 << 20), "rb_shard_trav_begin: bound out of range [1, 2^20]");
+        if (kind == 1) {
+            lookahead = mode_or_lookahead;
+            RB_REQUIRE(bound >= 1 && bound <= (1 << 20), "rb_shard_trav_begin: bound out of range [1, 2^20]");
+            RB_REQUIRE(lookahead >= 0 && lookahead <= WALK_MAX_LOOKAHEAD, "rb_shard_trav_begin: lookahead out of range [0, %d]", WALK_MAX_LOOKAHEAD);
+        }
+        if (kind == 2) {
+            mode = mode_or_lookahead;
+            RB_REQUIRE(mode >= 0 && mode <= 2, "rb_shard_trav_begin: mode must be 0 (terminators), 1 (bounded) or 2 (bounded, no back checks)");
+            RB_REQUIRE(mode == 0 ? (cap >= 1 && cap <= (1 << 20) && (n == 0 || (term_seq && term_off))) : (bound >= 0 && bound < (1 << 20)),
+                       "rb_shard_trav_begin: mode 0 needs a capacity and the terminator sequences, modes 1 / 2 a bound");
+            if (mode != 0) cap = bound + 1;
+        }
+        RB_HIP(hipSetDevice(g->p.device));
+        rb::trav_free(g);
+        rb_trav *t = new rb_trav();
+        g->trav = t;
+        t->kind = kind; t->direction = direction; t->mode = mode; t->lookahead = lookahead; t->bound = bound; t->cap = cap; t->min_cov = min_cov;
+        t->n = n; t->has_targets = targets != nullptr;
+        hipStream_t s = g->stream;
+        const size_t k = (size_t)g->k;
+        t->per_walk = kind == 2 ? (size_t)cap : (size_t)bound;
+        const size_t stride = kind == 0 ? k + (size_t)bound : kind == 1 ? k + (size_t)bound + (size_t)WALK_MAX_LOOKAHEAD + 1 : k + (size_t)cap;
+        const size_t rows = std::max<size_t>(n, 1) * t->per_walk;
+        std::vector<int64_t> tko(1, 0), rel(1, 0);
+        std::vector<uint64_t> tf(1, 0);
+        size_t tbytes = 0;
+        if (kind == 2) naive_terminators(k, n, mode, term_seq, term_off, tko, rel, tf, tbytes);
+        const size_t nt = kind == 2 ? (size_t)tko[n] : 0;
+        t->text.reserve(n * k * 2 + n * stride + rows + tbytes + 64);          // seeds | targets | seq | appended bases | terminator text
+        t->dseed = t->text.as<uint8_t>(); t->dtarget = t->dseed + n * k; t->dseq = t->dtarget + n * k; t->dbases = t->dseq + n * stride; t->dterm = t->dbases + rows;
+        t->hashes.reserve(rows * 16 + nt * 8 + 64);                            // forward | reverse hashes of the appended k-mers | terminator hashes
+        t->df = t->hashes.as<uint64_t>(); t->dr = t->df + rows; t->dtf = t->dr + rows;
+        t->misc.reserve(rows * 4 + (n + 1) * 16 + n * 4 + n + 128);            // counts | terminator offsets | lengths | reasons
+        t->dc = t->misc.as<float>();
+        t->dtoff = reinterpret_cast<int64_t *>(t->dc + rows + (rows & 1)); t->dtko = t->dtoff + (n + 1);
+        t->dlen = reinterpret_cast<int32_t *>(t->dtko + (n + 1)); t->dreason = reinterpret_cast<uint8_t *>(t->dlen + n);
+        // the walks' answer caches: a step of the max-coverage walk asks 4 counts, of the naive extension 7; a greedy step asks 4 per
+        // neighbourhood its depth-first search opens (answer_cap, default 4 * (1 + 4 * (1 + 2 * lookahead)) — two open branches per level)
+        uint32_t ccap = kind == 0 ? 4u : kind == 2 ? 8u : (uint32_t)(4 * (1 + 4 * (1 + 2 * std::max(lookahead, 1))));
+        if (answer_cap > 0) ccap = std::max<uint32_t>((uint32_t)answer_cap, kind == 2 ? 8u : 4u);
+        const size_t nn = std::max<size_t>(n, 1);
+        size_t off = 0;
+        auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 15) / 16 * 16; return o; };
+        const size_t o_f = take(nn * 8), o_r = take(nn * 8), o_key = take(nn * ccap * 8), o_val = take(nn * ccap * 4), o_cn = take(nn * 4), o_len = take(nn * 4),
+                     o_phase = take(nn), o_over = take(nn), o_ctr = take(64);
+        t->state.reserve(off);
+        char *base = static_cast<char *>(t->state.p);
+        RB_HIP(hipMemsetAsync(base, 0, off, s));
+        t->reqw.reserve(nn * 8 * 4);
+        t->ta = TravArrays{reinterpret_cast<uint64_t *>(base + o_f), reinterpret_cast<uint64_t *>(base + o_r), reinterpret_cast<int32_t *>(base + o_len),
+                           reinterpret_cast<uint8_t *>(base + o_phase), reinterpret_cast<uint64_t *>(base + o_key), reinterpret_cast<float *>(base + o_val),
+                           reinterpret_cast<uint32_t *>(base + o_cn), ccap, reinterpret_cast<uint8_t *>(base + o_over), nullptr, t->reqw.as<uint32_t>(),
+                           reinterpret_cast<uint32_t *>(base + o_ctr), (uint32_t)(nn * 8)};
+        if (n) {
+            RB_HIP(hipMemcpyAsync(t->dseed, seeds, n * k, hipMemcpyHostToDevice, s));
+            if (targets) RB_HIP(hipMemcpyAsync(t->dtarget, targets, n * k, hipMemcpyHostToDevice, s));
+            if (kind == 2) {
+                if (mode == 0 && tbytes) RB_HIP(hipMemcpyAsync(t->dterm, term_seq + term_off[0], tbytes, hipMemcpyHostToDevice, s));
+                if (mode == 0 && nt) RB_HIP(hipMemcpyAsync(t->dtf, tf.data(), nt * 8, hipMemcpyHostToDevice, s));
+                RB_HIP(hipMemcpyAsync(t->dtoff, rel.data(), (n + 1) * 8, hipMemcpyHostToDevice, s));
+                RB_HIP(hipMemcpyAsync(t->dtko, tko.data(), (n + 1) * 8, hipMemcpyHostToDevice, s));
+            }
+        }
+        RB_HIP(hipStreamSynchronize(s));                      // the host vectors above go out of scope
+    });
+}
+
+int rb_shard_trav_advance(rb_graph *g, int64_t *n_active, int64_t *bit_counts, int64_t *ctr_counts) {
+    return guarded([&] {
+        RB_REQUIRE(g && g->shard && g->trav && n_active && bit_counts && ctr_counts, "rb_shard_trav_advance: no traversal in progress on this handle");
+        rb_trav *t = g->trav;
+        RB_HIP(hipSetDevice(g->p.device));
+        hipStream_t s = g->stream;
+        const size_t n = t->n;
+        uint32_t ctr[2] = {0, 0};
+        if (n) {
+            t->ta.req = rb::shard_query_h0(g, n * 8);
+            RB_HIP(hipMemsetAsync(t->ta.ctr, 0, 8, s));
+            const ReplayCounts src{t->ta};
+            const dim3 gr(blocks_for((int64_t)n, 64)), th(64);
+            if (t->kind == 0)
+                hipLaunchKernelGGL(k_walk_max_cov<ReplayCounts>, gr, th, 0, s, src, (int)g->stranded, g->k, t->direction, t->dseed,
+                                   t->has_targets ? t->dtarget : (const uint8_t *)nullptr, n, t->bound, t->min_cov, t->dseq, t->dbases, t->df, t->dr, t->dc, t->dlen, t->dreason);
+            else if (t->kind == 1)
+                hipLaunchKernelGGL(k_greedy_extend<ReplayCounts>, gr, th, 0, s, src, kmul_of(g->k), WalkGate{nullptr, g->dbg.mod, 0}, (int)g->stranded, g->k, t->direction,
+                                   t->dseed, n, t->lookahead, t->bound, t->dseq, t->dbases, t->dc, t->dlen, t->dreason);
+            else
+                hipLaunchKernelGGL(k_naive_extend<ReplayCounts>, gr, th, 0, s, src, (int)g->stranded, g->k, t->direction, t->mode, t->dseed, n, t->bound, t->cap, t->min_cov,
+                                   t->dterm, t->dtoff, t->dtf, t->dtko, t->dseq, t->dbases, t->df, t->dlen, t->dreason);
+            RB_HIP(hipGetLastError());
+            RB_HIP(hipMemcpyAsync(ctr, t->ta.ctr, 8, hipMemcpyDeviceToHost, s));
+            RB_HIP(hipStreamSynchronize(s));
+            RB_REQUIRE(ctr[0] <= t->ta.req_cap, "rb_shard_trav_advance: %u requests from %zu walks", ctr[0], n);
+        }
+        t->n_req = ctr[0];
+        *n_active = (int64_t)ctr[1];
+        ++t->rounds;
+        rb::shard_query_make_dev(g, 2, RB_DBGBF, t->n_req, bit_counts, ctr_counts);
+    });
+}
+
+int rb_shard_trav_absorb(rb_graph *g, const void *breply_dev, const void *creply_dev) {
+    return guarded([&] {
+        RB_REQUIRE(g && g->shard && g->trav, "rb_shard_trav_absorb: no traversal in progress on this handle");
+        rb_trav *t = g->trav;
+        if (!t->n_req) return;
+        const float *ans = static_cast<const float *>(rb::shard_query_combine_dev(g, RB_DBGBF, breply_dev, creply_dev));
+        hipLaunchKernelGGL(k_trav_absorb, dim3(blocks_for((int64_t)t->n_req)), dim3(TPB), 0, g->stream, t->ta, ans, t->n_req);
+        RB_HIP(hipGetLastError());
+        RB_HIP(hipStreamSynchronize(g->stream));
+    });
+}
+
+int rb_shard_trav_end(rb_graph *g, char *out_bases, uint64_t *out_f, uint64_t *out_r, float *out_count, int32_t *out_len, uint8_t *out_reason, int64_t *rounds) {
+    return guarded([&] {
+        RB_REQUIRE(g && g->shard && g->trav, "rb_shard_trav_end: no traversal in progress on this handle");
+        rb_trav *t = g->trav;
+        RB_REQUIRE(t->n == 0 || (out_bases && out_len && out_reason), "rb_shard_trav_end: null argument");
+        RB_HIP(hipSetDevice(g->p.device));
+        hipStream_t s = g->stream;
+        const size_t n = t->n, rows = n * t->per_walk;
+        if (n) {
+            RB_HIP(hipMemcpyAsync(out_len, t->dlen, n * 4, hipMemcpyDeviceToHost, s));
+            RB_HIP(hipMemcpyAsync(out_reason, t->dreason, n, hipMemcpyDeviceToHost, s));
+            RB_HIP(hipMemcpyAsync(out_bases, t->dbases, rows, hipMemcpyDeviceToHost, s));
+            if (out_f && t->kind != 1) RB_HIP(hipMemcpyAsync(out_f, t->df, rows * 8, hipMemcpyDeviceToHost, s));
+            if (out_r && t->kind == 0) RB_HIP(hipMemcpyAsync(out_r, t->dr, rows * 8, hipMemcpyDeviceToHost, s));
+            if (out_count && t->kind != 2) RB_HIP(hipMemcpyAsync(out_count, t->dc, rows * 4, hipMemcpyDeviceToHost, s));
+            RB_HIP(hipStreamSynchronize(s));
+        }
+        if (rounds) *rounds = t->rounds;
+        rb::trav_free(g);
     });
 }
 

@@ -299,6 +299,7 @@ inline uint32_t log2_ceil(uint64_t x) { uint32_t l = 0; while ((1ull << l) < x) 
 
 // ------------------------------------------------------------------ graph object ----
 struct ShardState;
+struct rb_trav;
 using rb::BitFilter; using rb::FilterView; using rb::Mod; using rb::DevBuf; using rb::kmul_of;
 // Scratch + stream of one in-flight query.  The reference's stage-2 workers call contains / getCount / getKmers /
 // getSuccessors on ONE graph from T threads (R/RNABloom.java, e.g. :1984-2114), so every query call leases a context of
@@ -318,6 +319,7 @@ struct rb_graph {
     // sharded mode (rb_shard.hip): this handle owns index range [lo,hi) of every filter
     int shard_rank = 0, shard_count = 1;
     ShardState *shard = nullptr;
+    rb_trav *trav = nullptr;          // a traversal in progress on a sharded graph (rb_shard_trav_*, rb_graph.hip)
     rb_graph_params p{};
     int k = 0, H = 0;
     bool stranded = false;
@@ -465,6 +467,10 @@ void group_enqueue(rb_graph *g, int slot, size_t N, uint64_t ordinal0, uint32_t 
 uint32_t group_finish(rb_graph *g, int slot, hipStream_t st, DevBuf &temp, DevBuf &ctrbuf, hipStream_t scan_stream);
 // paired k-mer walker: inserts into g->rpk (out_idx == nullptr) or collects global bit indices
 void shard_free(rb_graph *g);   // rb_shard.hip
+uint64_t *shard_query_h0(rb_graph *g, size_t n);                                                 // rb_shard.hip: the query protocol with hashes already on the device
+void shard_query_make_dev(rb_graph *g, int what, int which_bits, size_t n, int64_t *bit_counts, int64_t *ctr_counts);
+const void *shard_query_combine_dev(rb_graph *g, int which_bits, const void *breply_dev, const void *creply_dev);
+void trav_free(rb_graph *g);    // rb_graph.hip: state of a traversal on a sharded graph
 void cbf_counts_device(rb_graph *g, const uint64_t *d_h0, size_t n, float *d_out);   // rb_graph.hip
 void launch_pairs(rb_graph *g, const rb_batch *b, int64_t w0, int64_t nw, int mode_hash, const uint32_t *chunk_off,
                   uint64_t *out_idx, unsigned long long *n_pairs_dev, hipStream_t st = nullptr);

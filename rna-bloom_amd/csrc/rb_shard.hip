@@ -1646,31 +1646,9 @@ int rb_shard_query_make(rb_graph *g, int what, int which_bits, const uint64_t *h
     return guarded([&] {
         RB_REQUIRE(g && g->shard && bit_counts && ctr_counts && (n == 0 || h0_host), "rb_shard_query_make: bad argument");
         RB_REQUIRE(what >= 0 && what <= 2, "rb_shard_query_make: what must be 0 (lookup), 1 (cbf count) or 2 (graph count)");
-        ShardState *S = g->shard;
         RB_HIP(hipSetDevice(g->p.device));
-        hipStream_t s = g->stream;
-        BitFilter *bf = which_bits == RB_DBGBF ? &g->dbg : which_bits == RB_RPKBF ? &g->rpk : nullptr;
-        if (what != 1) RB_REQUIRE(bf && bf->bits, "rb_shard_query_make: bit filter %d is not part of this sharded graph", which_bits);
-        for (int r = 0; r < S->G; ++r) bit_counts[r] = ctr_counts[r] = 0;
-        S->slot_bytes[RB_SLOT_Q_BIDX] = S->slot_bytes[RB_SLOT_Q_CIDX] = 0;
-        S->q_n = n; S->q_what = what;
-        if (!n) return;
-        const int bh = what != 1 ? bf->num_hash : 0, ch = what != 0 ? g->cbf_h : 0;
-        S->q_h0.reserve(n * 8); S->stage0.reserve(n * bh * 8 + 16); S->stage3.reserve(n * ch * 8 + 16);
-        S->q_bpos.reserve(n * bh * 4 + 16); S->q_cpos.reserve(n * ch * 4 + 16);
-        RB_HIP(hipMemcpyAsync(S->q_h0.p, h0_host, n * 8, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(k_query_idx, dim3(blocks_for((int64_t)n)), dim3(TPB), 0, s, kmul_of(g->k), bf ? bf->mod : g->cbf_mod, bh, g->cbf_mod, ch,
-                           S->q_h0.as<uint64_t>(), n, S->stage0.as<uint64_t>(), S->stage3.as<uint64_t>());
-        if (bh) {
-            RouteIdx fb{S->stage0.as<uint64_t>(), nullptr, (uint64_t)S->span[which_bits], nullptr, nullptr, nullptr, nullptr, nullptr, S->q_bpos.as<uint32_t>()};
-            route(g, fb, n * bh, bit_counts, [&](RouteIdx &ff, size_t kept) { ff.out_idx = (uint64_t *)slot_reserve(S, RB_SLOT_Q_BIDX, kept * 8); });
-        }
-        if (ch) {
-            RouteIdx fc{S->stage3.as<uint64_t>(), nullptr, (uint64_t)S->span[RB_CBF], nullptr, nullptr, nullptr, nullptr, nullptr, S->q_cpos.as<uint32_t>()};
-            route(g, fc, n * ch, ctr_counts, [&](RouteIdx &ff, size_t kept) { ff.out_idx = (uint64_t *)slot_reserve(S, RB_SLOT_Q_CIDX, kept * 8); });
-        }
-        RB_HIP(hipGetLastError());
-        RB_HIP(hipStreamSynchronize(s));
+        if (n) RB_HIP(hipMemcpyAsync(rb::shard_query_h0(g, n), h0_host, n * 8, hipMemcpyHostToDevice, g->stream));
+        rb::shard_query_make_dev(g, what, which_bits, n, bit_counts, ctr_counts);
     });
 }
 int rb_shard_query_serve(rb_graph *g, int which_bits, const void *bidx_dev, int64_t nb, const void *cidx_dev, int64_t nc,
@@ -1697,21 +1675,65 @@ int rb_shard_query_finish(rb_graph *g, int which_bits, const void *breply_dev, c
         if (!n) return;
         const int what = S->q_what;
         RB_REQUIRE(what == 0 ? out8_host != nullptr : outf_host != nullptr, "rb_shard_query_finish: missing output array");
-        RB_HIP(hipSetDevice(g->p.device));
+        const void *res = rb::shard_query_combine_dev(g, which_bits, breply_dev, creply_dev);
         hipStream_t s = g->stream;
-        BitFilter *bf = which_bits == RB_DBGBF ? &g->dbg : which_bits == RB_RPKBF ? &g->rpk : nullptr;
-        const int bh = what != 1 ? bf->num_hash : 0, ch = what != 0 ? g->cbf_h : 0;
-        S->q_out.reserve(n * 4 + 16);
-        hipLaunchKernelGGL(k_query_combine, dim3(blocks_for((int64_t)n)), dim3(TPB), 0, s, what, bh, ch, S->q_bpos.as<uint32_t>(), (const uint8_t *)breply_dev,
-                           S->q_cpos.as<uint32_t>(), (const uint8_t *)creply_dev, n, S->q_out.as<uint8_t>(), S->q_out.as<float>());
-        RB_HIP(hipGetLastError());
-        if (what == 0) RB_HIP(hipMemcpyAsync(out8_host, S->q_out.p, n, hipMemcpyDeviceToHost, s));
-        else RB_HIP(hipMemcpyAsync(outf_host, S->q_out.p, n * 4, hipMemcpyDeviceToHost, s));
+        if (what == 0) RB_HIP(hipMemcpyAsync(out8_host, res, n, hipMemcpyDeviceToHost, s));
+        else RB_HIP(hipMemcpyAsync(outf_host, res, n * 4, hipMemcpyDeviceToHost, s));
         RB_HIP(hipStreamSynchronize(s));
     });
 }
 
 }  // extern "C"
+
+namespace rb {
+// The query protocol with the hashes already on the device (rb_shard_query_make uploads them; the traversal kernels of a sharded
+// graph write them there themselves, rb_shard_trav_*): indices, bucketed by owner, into slots Q_BIDX / Q_CIDX.
+uint64_t *shard_query_h0(rb_graph *g, size_t n) {
+    ShardState *S = g->shard;
+    S->q_h0.reserve(std::max<size_t>(n, 1) * 8);
+    return S->q_h0.as<uint64_t>();
+}
+void shard_query_make_dev(rb_graph *g, int what, int which_bits, size_t n, int64_t *bit_counts, int64_t *ctr_counts) {
+    ShardState *S = g->shard;
+    RB_HIP(hipSetDevice(g->p.device));
+    hipStream_t s = g->stream;
+    BitFilter *bf = which_bits == RB_DBGBF ? &g->dbg : which_bits == RB_RPKBF ? &g->rpk : nullptr;
+    if (what != 1) RB_REQUIRE(bf && bf->bits, "rb_shard_query_make: bit filter %d is not part of this sharded graph", which_bits);
+    for (int r = 0; r < S->G; ++r) bit_counts[r] = ctr_counts[r] = 0;
+    S->slot_bytes[RB_SLOT_Q_BIDX] = S->slot_bytes[RB_SLOT_Q_CIDX] = 0;
+    S->q_n = n; S->q_what = what;
+    if (!n) return;
+    const int bh = what != 1 ? bf->num_hash : 0, ch = what != 0 ? g->cbf_h : 0;
+    S->stage0.reserve(n * bh * 8 + 16); S->stage3.reserve(n * ch * 8 + 16);
+    S->q_bpos.reserve(n * bh * 4 + 16); S->q_cpos.reserve(n * ch * 4 + 16);
+    hipLaunchKernelGGL(k_query_idx, dim3(blocks_for((int64_t)n)), dim3(TPB), 0, s, kmul_of(g->k), bf ? bf->mod : g->cbf_mod, bh, g->cbf_mod, ch,
+                       S->q_h0.as<uint64_t>(), n, S->stage0.as<uint64_t>(), S->stage3.as<uint64_t>());
+    if (bh) {
+        RouteIdx fb{S->stage0.as<uint64_t>(), nullptr, (uint64_t)S->span[which_bits], nullptr, nullptr, nullptr, nullptr, nullptr, S->q_bpos.as<uint32_t>()};
+        route(g, fb, n * bh, bit_counts, [&](RouteIdx &ff, size_t kept) { ff.out_idx = (uint64_t *)slot_reserve(S, RB_SLOT_Q_BIDX, kept * 8); });
+    }
+    if (ch) {
+        RouteIdx fc{S->stage3.as<uint64_t>(), nullptr, (uint64_t)S->span[RB_CBF], nullptr, nullptr, nullptr, nullptr, nullptr, S->q_cpos.as<uint32_t>()};
+        route(g, fc, n * ch, ctr_counts, [&](RouteIdx &ff, size_t kept) { ff.out_idx = (uint64_t *)slot_reserve(S, RB_SLOT_Q_CIDX, kept * 8); });
+    }
+    RB_HIP(hipGetLastError());
+    RB_HIP(hipStreamSynchronize(s));
+}
+// replies of the owners -> one answer per queried hash, left on the device (u8 for what == 0, else float); enqueued on g->stream
+const void *shard_query_combine_dev(rb_graph *g, int which_bits, const void *breply_dev, const void *creply_dev) {
+    ShardState *S = g->shard;
+    const size_t n = S->q_n;
+    const int what = S->q_what;
+    RB_HIP(hipSetDevice(g->p.device));
+    BitFilter *bf = which_bits == RB_DBGBF ? &g->dbg : which_bits == RB_RPKBF ? &g->rpk : nullptr;
+    const int bh = what != 1 ? bf->num_hash : 0, ch = what != 0 ? g->cbf_h : 0;
+    S->q_out.reserve(n * 4 + 16);
+    if (n) hipLaunchKernelGGL(k_query_combine, dim3(blocks_for((int64_t)n)), dim3(TPB), 0, g->stream, what, bh, ch, S->q_bpos.as<uint32_t>(), (const uint8_t *)breply_dev,
+                              S->q_cpos.as<uint32_t>(), (const uint8_t *)creply_dev, n, S->q_out.as<uint8_t>(), S->q_out.as<float>());
+    RB_HIP(hipGetLastError());
+    return S->q_out.p;
+}
+}  // namespace rb
 
 namespace rb {
 void shard_free(rb_graph *g) {

@@ -282,84 +282,63 @@ class ShardRank:
         if out is not None:
             out.append((f4, r4, res[0].reshape(n, 4)))
 
-    def walk(self, seeds, direction, bound, min_cov=1.0, out=None):
-        """Coroutine: greedy maximum-coverage walks (the semantics of rb_graph_walk without a target) on the SHARDED graph.
-        The filters are spread over the ranks, so every step is one query exchange for the 4 neighbours of every walk
-        that is still alive on any rank (rb_shard_query_*: 2 all-to-alls); the rolling hashes and the choice of the
-        neighbour are host arithmetic here (numpy) — a functional path for multi-GPU graphs, not a tuned one.
-        Every rank calls this with its own seeds (possibly none).  out gets (bases[n, bound], count[n, bound], len[n], reason[n])."""
-        k, stranded = int(self.p.k), bool(self.p.stranded)
+    def traverse(self, kind, seeds, direction, bound=0, mode_or_lookahead=0, min_cov=1.0, targets=None, terminators=None, cap=4096,
+                 answer_cap=0, out=None):
+        """Coroutine: rb_graph_walk (kind 0), rb_graph_greedy_extend (1) or rb_graph_naive_extend (2) for this rank's seed k-mers on
+        the SHARDED graph (rb_shard_trav_*).  The walks run on this rank's GPU in the kernels the single-GPU calls use; whenever
+        they need counts nobody has told them yet, all ranks do one query exchange (2 all-to-alls) and the walks replay their
+        current step with the answers.  Every rank calls this with its own seeds (possibly none).
+        out gets (bases[n, width], f[n, width] or None, r or None, count or None, len[n], reason[n], rounds)."""
+        G = self.count
+        k = int(self.p.k)
         n = len(seeds)
-        u64 = np.uint64
-        SEED = np.array([0x3c8bfbb395c60474, 0x3193c18562a02b4c, 0x20323ed082572324, 0x295549f54be24456], u64)   # NTHash.java:39-43
-        rotl = lambda v, s: (v << u64(s % 64)) | (v >> u64((64 - s % 64) % 64)) if s % 64 else v
-        rotr = lambda v, s: (v >> u64(s % 64)) | (v << u64((64 - s % 64) % 64)) if s % 64 else v
-        lut = np.full(256, 4, np.uint8)
-        for ch, c in ((b"A", 0), (b"C", 1), (b"G", 2), (b"T", 3), (b"U", 3), (b"a", 0), (b"c", 1), (b"g", 2), (b"t", 3), (b"u", 3)):
-            lut[ch[0]] = c
-        codes = lut[np.frombuffer(b"".join(seeds), np.uint8)].reshape(n, k) if n else np.zeros((0, k), np.uint8)
-        valid = (codes < 4).all(axis=1) if n else np.zeros(0, bool)
-        cc = np.where(codes < 4, codes, 0)
-        f = np.zeros(n, u64); r = np.zeros(n, u64)
-        with np.errstate(over="ignore"):
-            for q in range(k):                                     # NTP64 / NTP64RC from scratch (NTHash.java:332-337, 367-373)
-                f = rotl(f, 1) ^ SEED[cc[:, q]]
-                r = r ^ rotl(SEED[3 - cc[:, q]], q)
-        # seq[i]: the walk's bases in walk orientation (seed, reversed for a left walk, then the appended bases)
-        seq = np.zeros((n, k + bound), np.uint8)
-        seq[:, :k] = cc if direction == 0 else cc[:, ::-1]
-        hist = np.zeros((n, bound), u64)
-        bases = np.zeros((n, bound), np.uint8); counts = np.zeros((n, bound), np.float32)
-        ln = np.zeros(n, np.int32); reason = np.where(valid, 3, 4).astype(np.uint8)
-        alive = valid.copy()
-        acgt = np.frombuffer(b"ACGT", np.uint8)
-        for step in range(bound):
-            flags = yield ("ints", [int(alive.any())])
+        sb = np.frombuffer(b"".join(s if isinstance(s, bytes) else s.encode() for s in seeds), np.uint8) if n else np.zeros(1, np.uint8)
+        if n and sb.size != n * k: raise ValueError("traverse: every seed must be one k-mer")
+        tb = None
+        if targets is not None and n:
+            tb = np.frombuffer(b"".join(targets), np.uint8)
+            if tb.size != n * k: raise ValueError("traverse: every target must be one k-mer")
+        tseq = toff = None
+        if kind == 2 and mode_or_lookahead == 0:
+            from .graph import _pack
+            tseq, toff = _pack([t if isinstance(t, bytes) else t.encode() for t in (terminators if terminators is not None else [b""] * n)])
+            if tseq.size == 0: tseq = np.zeros(1, np.uint8)
+        vp = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
+        check(lib.rb_shard_trav_begin(self.h, kind, vp(sb), vp(tb), n, direction, mode_or_lookahead, bound, cap, C.c_float(min_cov), vp(tseq), vp(toff), answer_cap))
+        while True:
+            act = C.c_int64()
+            b_c, c_c = (C.c_int64 * G)(), (C.c_int64 * G)()
+            check(lib.rb_shard_trav_advance(self.h, C.byref(act), b_c, c_c))
+            flags = yield ("ints", [int(act.value > 0)])
             if not any(x[0] for x in flags):
                 break
-            idx = np.nonzero(alive)[0]
-            oc = seq[idx, step]                                    # base leaving the k-mer
-            s_out, sc_out = SEED[oc], SEED[3 - oc]
-            nf = np.zeros((idx.size, 4), u64); nr = np.zeros((idx.size, 4), u64)
-            with np.errstate(over="ignore"):
-                for b in range(4):
-                    if direction == 0:                             # NTHash.java:584-586 / :627-629
-                        nf[:, b] = rotl(f[idx], 1) ^ rotl(s_out, k) ^ SEED[b]
-                        nr[:, b] = rotr(r[idx], 1) ^ rotr(sc_out, 1) ^ rotl(SEED[3 - b], k - 1)
-                    else:                                          # NTM64B / NTPC64B :640-642 / :505-509
-                        nf[:, b] = rotr(f[idx], 1) ^ rotr(s_out, 1) ^ rotl(SEED[b], k - 1)
-                        nr[:, b] = rotl(r[idx], 1) ^ rotl(sc_out, k) ^ SEED[3 - b]
-            h0 = nf if stranded else np.where(nr.view(np.int64) < nf.view(np.int64), nr, nf)
-            res = []
-            yield from self.query(2, h0.reshape(-1), out=res)
-            c4 = res[0].reshape(-1, 4)
-            ok = c4 >= np.float32(min_cov)
-            masked = np.where(ok, c4, np.float32(-1))
-            best = masked.argmax(axis=1)                           # first strict maximum in A,C,G,T
-            has = ok.any(axis=1)
-            bf = nf[np.arange(idx.size), best]; br = nr[np.arange(idx.size), best]; bc = c4[np.arange(idx.size), best]
-            dead = idx[~has]
-            reason[dead] = 0; alive[dead] = False
-            keep = has.copy()
-            # a k-mer the walk appended before? (hash first, then the bases: Kmer.equals)
-            cand = np.nonzero(has)[0]
-            if step and cand.size:
-                hit = (hist[idx[cand], :step] == bf[cand, None])
-                for row in np.nonzero(hit.any(axis=1))[0]:
-                    i = idx[cand[row]]
-                    kmer = np.concatenate([seq[i, step + 1:step + k], [best[cand[row]]]])
-                    if any((seq[i, j + 1:j + 1 + k] == kmer).all() for j in np.nonzero(hit[row])[0]):
-                        keep[cand[row]] = False
-                        reason[i] = 2; alive[i] = False
-            sel = np.nonzero(keep)[0]
-            ii = idx[sel]
-            seq[ii, k + step] = best[sel]
-            hist[ii, step] = bf[sel]
-            bases[ii, step] = acgt[best[sel]]; counts[ii, step] = bc[sel]
-            f[ii] = bf[sel]; r[ii] = br[sel]
-            ln[ii] = step + 1
+            b_c, c_c = list(b_c), list(c_c)
+            (o_b, o_c), (o_bc, o_cc) = yield ("a2a", [self._slot(N.SLOT_Q_BIDX, 8 * sum(b_c)), self._slot(N.SLOT_Q_CIDX, 8 * sum(c_c))],
+                                              [[8 * c for c in b_c], [8 * c for c in c_c]])
+            nb, nc = sum(o_bc) // 8, sum(o_cc) // 8
+            brep = torch.empty(nb, dtype=torch.uint8, device=self.tdev)
+            crep = torch.empty(nc, dtype=torch.uint8, device=self.tdev)
+            check(lib.rb_shard_query_serve(self.h, N.DBGBF, _ptr(o_b), nb, _ptr(o_c), nc, _ptr(brep), _ptr(crep)))
+            (my_b, my_c), _ = yield ("a2a", [brep, crep], [[c // 8 for c in o_bc], [c // 8 for c in o_cc]], [b_c, c_c])
+            check(lib.rb_shard_trav_absorb(self.h, _ptr(my_b), _ptr(my_c)))
+        width = max(1, (cap if mode_or_lookahead == 0 else bound + 1) if kind == 2 else bound)
+        bases = np.zeros((n, width), np.uint8); ln = np.zeros(n, np.int32); reason = np.zeros(n, np.uint8)
+        f = np.zeros((n, width), np.uint64) if kind != 1 else None
+        r = np.zeros((n, width), np.uint64) if kind == 0 else None
+        c = np.zeros((n, width), np.float32) if kind != 2 else None
+        rounds = C.c_int64()
+        check(lib.rb_shard_trav_end(self.h, vp(bases), vp(f), vp(r), vp(c), vp(ln), vp(reason), C.byref(rounds)))
         if out is not None:
-            out.append((bases, counts, ln, reason))
+            out.append((bases, f, r, c, ln, reason, rounds.value))
+
+    def walk(self, seeds, direction, bound, min_cov=1.0, out=None, targets=None):
+        """Coroutine: greedy maximum-coverage walks (rb_graph_walk) on the SHARDED graph; out gets (bases[n, bound], count[n, bound],
+        len[n], reason[n])."""
+        res = []
+        yield from self.traverse(0, seeds, direction, bound, min_cov=min_cov, targets=targets, out=res)
+        if out is not None:
+            bases, _, _, c, ln, reason, _ = res[0]
+            out.append((bases, c, ln, reason))
 
     def add_range(self, batch, first, n, flags, reads_per_substep, pos_bits):
         """Coroutine over all sub-batches of reads [first, first+n) — the same call on every rank."""
@@ -756,6 +735,23 @@ class LoopbackCluster:
         outs = [[] for _ in self.ranks]
         run_loopback([r.walk(sd, direction, bound, minKmerCov, o) for r, sd, o in zip(self.ranks, per_rank_seeds, outs)])
         return [o[0] for o in outs]
+
+    def traverse(self, kind, per_rank_seeds, direction, targets=None, terminators=None, **kw):
+        """rb_graph_walk / _greedy_extend / _naive_extend (kind 0 / 1 / 2) on the sharded graph; targets / terminators: one list per
+        rank (or None).  -> per rank (bases, f, r, count, len, reason, rounds)"""
+        outs = [[] for _ in self.ranks]
+        run_loopback([r.traverse(kind, sd, direction, targets=targets[i] if targets else None, terminators=terminators[i] if terminators else None,
+                                 out=o, **kw) for i, (r, sd, o) in enumerate(zip(self.ranks, per_rank_seeds, outs))])
+        return [o[0] for o in outs]
+
+    def greedyExtend(self, per_rank_seeds, direction, lookahead, bound, answer_cap=0):
+        """GraphUtils.greedyExtendRight / Left on the sharded graph -> per rank (bases, count, len, reason), as graph.greedyExtend"""
+        return [(b, c, ln, rs) for b, _, _, c, ln, rs, _ in self.traverse(1, per_rank_seeds, direction, bound=bound, mode_or_lookahead=lookahead, answer_cap=answer_cap)]
+
+    def naiveExtend(self, per_rank_seeds, direction, mode=1, bound=0, minKmerCov=1.0, terminators=None, cap=4096):
+        """GraphUtils.naiveExtendRight / Left on the sharded graph -> per rank (list of appended bases, reason), as graph.naiveExtend"""
+        res = self.traverse(2, per_rank_seeds, direction, bound=bound, mode_or_lookahead=mode, min_cov=minKmerCov, terminators=terminators, cap=cap)
+        return [([bytes(b[i, :ln[i]]) for i in range(len(ln))], rs) for b, _, _, _, ln, rs, _ in res]
 
     def getKmers(self, per_rank_reads):
         """per_rank_reads[r] = the sequences virtual rank r asks about -> per rank (koffsets, f, r, count), as graph.getKmers"""

@@ -1,16 +1,3 @@
 cd $GRAFT_REPO_ROOT
-run() { name=$1; shift; env "$@" python bench.py --no-cpu-baseline --steps 2 --warmup 1 > gpurun_out/exp_$name.json 2>/dev/null; python - $name <<'PY'
-import json,sys
-d=json.load(open("gpurun_out/exp_%s.json"%sys.argv[1]))
-st=d["stages_ms_per_step"]
-print(sys.argv[1], "%.1f ms"%d["ms_per_step"], "pairs %d"%d["config"]["read_pairs_per_step"], {k:round(v) for k,v in st.items() if v>15})
-PY
-}
-python -c "import torch; print(torch.cuda.get_device_name(0))"
-run off A=1
-run side1 RB_PAIRS_SIDE=1
-run side3 RB_PAIRS_SIDE=3
-run side4 RB_PAIRS_SIDE=4
-run off_again A=1
-
-timeout 1200 python -m pytest tests/test_gpu_sharded.py -x -q 2>&1 | tail -3
+timeout 1500 python -m pytest tests/test_gpu_sharded_walks.py -x -q 2>&1 | tail -25
+timeout 1500 python -m pytest tests/test_gpu_sharded.py tests/test_gpu_sharded_multiproc.py tests/test_golden_stage1.py tests/test_gpu_parity.py tests/test_gpu_api_holes.py -x -q 2>&1 | grep -E "passed|failed|FAILED|Error" | tail -8
