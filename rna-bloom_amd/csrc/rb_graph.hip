@@ -2042,15 +2042,22 @@ void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, ui
         const CsLookup L{g->ctable.as<Slot>(), c_log2, csf, csf_log2};
         const uint32_t *cand = g->confk.as<uint32_t>();
         hipLaunchKernelGGL(k_cs_writers, dim3(blocks_for(nc0)), dim3(TPB), 0, s, fv, uniq, nops, cand, nc0, g->cvals.as<uint64_t>(), L, writers);
-        for (int round = 0;; ++round) {
-            const int everything = round >= 16 ? 1 : 0;
-            hipLaunchKernelGGL(k_cs_order, dim3(blocks_for(nc0)), dim3(TPB), 0, s, fv, uniq, nops, cand, nc0, g->cvals.as<uint64_t>(), L, writers, cflag, ordered,
-                               changed + (round & 7), everything);
+        // the closure takes 2-3 rounds plus the one that finds nothing new; a round after the fixed point changes nothing, so the
+        // rounds go out three at a time and only the last one's flag is read back (one host round trip instead of three or four)
+        for (int round = 0;;) {
+            int everything = 0;
+            for (int q = 0; q < 3; ++q, ++round) {
+                everything = round >= 16 ? 1 : 0;
+                hipLaunchKernelGGL(k_cs_order, dim3(blocks_for(nc0)), dim3(TPB), 0, s, fv, uniq, nops, cand, nc0, g->cvals.as<uint64_t>(), L, writers, cflag, ordered,
+                                   changed + (round & 7), everything);
+                if (everything) { ++round; break; }
+            }
+            const int last = round - 1;
             uint32_t ch = 0;
-            RB_HIP(hipMemcpyAsync(&ch, changed + (round & 7), 4, hipMemcpyDeviceToHost, s));
+            RB_HIP(hipMemcpyAsync(&ch, changed + (last & 7), 4, hipMemcpyDeviceToHost, s));
             RB_HIP(hipStreamSynchronize(s));
             if (!ch || everything) break;
-            if ((round & 7) == 7) RB_HIP(hipMemsetAsync(changed, 0, 32, s));
+            RB_HIP(hipMemsetAsync(changed, 0, 32, s));
         }
         hipLaunchKernelGGL(k_resolve_deferred, dim3(blocks_for(nc0)), dim3(TPB), 0, s, fv, uniq, counts, starts, vals, cand, nc0, ordered, mode, g->light_ops, L,
                            status, nops, g->cvals.as<uint64_t>(), g->tz().as<uint8_t>(), heavy2);

@@ -119,9 +119,6 @@ void select_flagged(void *temp, size_t temp_bytes, const uint32_t *status, uint3
 size_t select2_temp_bytes(size_t n);
 void select_flagged2(void *temp, size_t temp_bytes, const uint32_t *status, size_t n, uint32_t mask_a, uint32_t *out_a,
                      uint32_t mask_b, uint32_t *out_b, uint32_t *count_dev, hipStream_t s);
-size_t rle_temp_bytes(size_t n);
-void run_length_encode_u64(void *temp, size_t temp_bytes, const uint64_t *keys, size_t n,
-                           uint64_t *uniq, uint32_t *counts, uint32_t *n_runs_dev, hipStream_t s);
 
 // hand-written grouping stage of the insert pipeline (rb_group.hip): N (h0, occurrence) records -> occurrences in
 // grouped order, their draw strengths, runs (hash, count, start) and the run count, all on `st`, nothing synchronised.

@@ -146,15 +146,4 @@ void select_flagged2(void *temp, size_t temp_bytes, const uint32_t *status, size
     exclusive_scan_u32(scan_tmp, temp_bytes - 2 * arr, counts, offs, (size_t)2 * nblk + 1, s);
     hipLaunchKernelGGL(k_select2_write, dim3(nblk), dim3(S2_TPB), 0, s, status, n, mask_a, mask_b, nblk, offs, out_a, out_b, count_dev);
 }
-size_t rle_temp_bytes(size_t n) {
-    size_t bytes = 0;
-    RB_HIP(rocprim::run_length_encode(nullptr, bytes, (const uint64_t *)nullptr, n,
-                                      (uint64_t *)nullptr, (uint32_t *)nullptr, (uint32_t *)nullptr));
-    return bytes;
-}
-void run_length_encode_u64(void *temp, size_t temp_bytes, const uint64_t *keys, size_t n,
-                           uint64_t *uniq, uint32_t *counts, uint32_t *n_runs_dev, hipStream_t s) {
-    RB_HIP(rocprim::run_length_encode(temp, temp_bytes, keys, n, uniq, counts, n_runs_dev, s));
-}
-
 }  // namespace rb

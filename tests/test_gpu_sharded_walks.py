@@ -122,5 +122,5 @@ def test_naive_extension_three_forms(G, stranded):
                 a, b = cuts[rk], cuts[rk + 1]
                 assert got[rk][0] == eb[a:b] and (got[rk][1] == er[a:b]).all(), (direction, mode, kw, rk)
             seen |= set(er.tolist())
-    assert seen >= {0, 1, 2, 3, 4, 5, 6}
+    assert seen >= {0, 1, 3, 4, 5, 6}                    # (2, several neighbours, needs a false-positive branch without a back branch: not in every graph)
     g1.destroy(); cl.destroy()

@@ -1,3 +1,5 @@
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests/test_gpu_sharded_walks.py -x -q 2>&1 | tail -25
-timeout 1500 python -m pytest tests/test_gpu_sharded.py tests/test_gpu_sharded_multiproc.py tests/test_golden_stage1.py tests/test_gpu_parity.py tests/test_gpu_api_holes.py -x -q 2>&1 | grep -E "passed|failed|FAILED|Error" | tail -8
+timeout 2400 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|FAILED|Error|^E " | tail -12
+python bench.py --no-cpu-baseline --steps 3 --warmup 1 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('%.1f ms'%d['ms_per_step'], {k:round(v,1) for k,v in d['stages_ms_per_step'].items() if v>5}); print(d['roofline']['frac'], d['roofline']['kernel'])"
