@@ -67,7 +67,7 @@ def algorithmic_bytes(stage, n_kmers, n_pairs, n_runs, words, n_sorted=None, gro
     return model.get(stage)
 
 
-# dominant-stage kernels in the committed rocprofv3 PMC summaries (profiles/r01_final_pmc_*.csv: separate
+# dominant-stage kernels in the committed rocprofv3 PMC summaries (profiles/r03_pmc_*.csv: separate
 # --pmc FETCH_SIZE and --pmc WRITE_SIZE passes of this same command, values in KB per dispatch).
 # sort_occurrences is rocPRIM's onesweep: 1 histogram + 4 scatter dispatches per launch of the stage, under one kernel
 # name that also covers the (small) sorts of the conflict path, so its bytes are the name's total over the
@@ -75,10 +75,10 @@ def algorithmic_bytes(stage, n_kmers, n_pairs, n_runs, words, n_sorted=None, gro
 PMC_KERNELS = {"filter_windows": "rb::k_filter_reads", "hash_windows": "rb::k_hash_windows_resume",
                "probe_claim": "k_probe", "resolve_apply": "k_resolve_apply", "pairs_insert": "k_pairs_reads",
                "group_part_count": "rb::k_part_count", "group_part_scatter": "rb::k_part_scatter", "group_buckets": "rb::k_group_buckets"}
-PMC_FILES = ("r02_pmc_fetch_size.csv", "r02_pmc_write_size.csv")
+PMC_FILES = ("r03_pmc_fetch_size.csv", "r03_pmc_write_size.csv")
 # Correction of FETCH_SIZE (MI355X_MICROARCH.md, HBM / rocprofv3 section: the counter tallies 128-byte requests of wide
 # coalesced streaming reads as 64 bytes; "other access widths are uncalibrated: calibrate on a known byte count in your
-# own access pattern").  Calibration committed in profiles/r02_pmc_calibration.txt: (1) k_part_count reads exactly 8 bytes per
+# own access pattern").  Calibration committed in profiles/r03_pmc_calibration.txt: (1) k_part_count reads exactly 8 bytes per
 # record in the 8-bytes-per-lane streaming pattern all grouping kernels use, and its FETCH_SIZE comes out at half of that;
 # (2) tools/microbench/gather_bench calib: 2^28 random requests of 8 B, of one whole 64-byte line and of one whole 128-byte
 # bucket (8 x 16 B by one lane, the prefilter cache's access) are ALL tallied as 64 bytes per request.  So x 2 for the
@@ -283,7 +283,7 @@ def main():
                 traffic = pmc_traffic(dom_name) if default_cfg else None      # the PMC passes profiled exactly this command
                 roof = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                        "traffic_source": "profiles/r02_pmc_{fetch,write}_size.csv (separate rocprofv3 --pmc passes of this command), bytes per kernel launch, FETCH_SIZE x %.0f (calibration: profiles/r02_pmc_calibration.txt)" % FETCH_FACTOR.get(dom_name, 1.0) if traffic else None,
+                        "traffic_source": "profiles/r03_pmc_{fetch,write}_size.csv (separate rocprofv3 --pmc passes of this command), bytes per kernel launch, FETCH_SIZE x %.0f (calibration: profiles/r03_pmc_calibration.txt)" % FETCH_FACTOR.get(dom_name, 1.0) if traffic else None,
                         "note": "dominant stage by HIP-event time on its own stream; achieved = model bytes / measured time, traffic = counters",
                         "algorithmic_bytes_per_launch": int(ab / dom_launches),
                         "avg_launch_ms": round(dom_ms / dom_launches, 3), "launches": dom_launches,
@@ -359,14 +359,19 @@ def cpu_baseline(a, batch, dbg_bits, cbf_bytes, pk_bits, dist_pk):
         dt = time.perf_counter() - t0
         return st.kmers / dt, st.kmers, dt
 
+    def median3(fn):
+        runs = sorted(fn() for _ in range(3))
+        return runs[1], runs
+
     # the reference's workers serialise on one reader lock, so more threads is not always faster: 1/8 of the sample per candidate
     cands = sorted({t for t in (16, 32, 64, 128, ncpu) if t <= ncpu} | {min(8, ncpu)})
     sweep = {t: timed(max(1, n // 8), t)[0] for t in cands}
     best_t = max(sweep, key=sweep.get)
-    best_rate, best_kmers, best_dt = timed(n, best_t)
-    t8_rate, _, t8_dt = timed(max(1, n // 2), min(8, ncpu))
-    # with parsing: FASTQ text of a quarter of the sample (qualities 'I': the synthetic batch carries usable flags, not PHRED)
+    # every reported figure is the median of three runs over the SAME reads: the first quarter of the sample
     m = max(1, n // 4)
+    (best_rate, best_kmers, best_dt), best_runs = median3(lambda: timed(m, best_t))
+    (t8_rate, _, t8_dt), t8_runs = median3(lambda: timed(m, min(8, ncpu)))
+    # with parsing: FASTQ text of the same reads (qualities 'I': the synthetic batch carries usable flags, not PHRED)
     L = int(off[1] - off[0])
     rec = np.empty((m, 2 * L + 16), np.uint8)
     rec[:, :10] = np.frombuffer(b"@r" + b"0" * 8, np.uint8); rec[:, 10] = 10
@@ -374,17 +379,23 @@ def cpu_baseline(a, batch, dbg_bits, cbf_bytes, pk_bits, dist_pk):
     rec[:, 12 + L] = ord("+"); rec[:, 13 + L] = 10
     rec[:, 14 + L:14 + 2 * L] = ord("I"); rec[:, 14 + 2 * L] = 10
     text = np.ascontiguousarray(rec[:, :15 + 2 * L]).reshape(-1)
-    og.clear()
-    t0 = time.perf_counter()
-    stp = og.add_fastq(text, L, 3, rbo.STORE_READ_PAIRS, threads=best_t)
-    parse_dt = time.perf_counter() - t0
+
+    def parsed():
+        og.clear()
+        t0 = time.perf_counter()
+        stp = og.add_fastq(text, L, 3, rbo.STORE_READ_PAIRS, threads=best_t)
+        dt = time.perf_counter() - t0
+        return stp.kmers / dt, stp.kmers, dt
+    (parse_rate, _, parse_dt), parse_runs = median3(parsed)
     return {"value": best_rate, "unit": "k-mers/s", "cores": best_t, "kind": "port", "host_cpus": ncpu,
-            "t8_value": t8_rate, "with_fastq_parsing_value": stp.kmers / parse_dt,
+            "t8_value": t8_rate, "with_fastq_parsing_value": parse_rate,
+            "runs_Mkmers_per_s": {"value": [round(r[0] / 1e6, 2) for r in best_runs], "t8_value": [round(r[0] / 1e6, 2) for r in t8_runs],
+                                  "with_fastq_parsing_value": [round(r[0] / 1e6, 2) for r in parse_runs]},
             "thread_sweep_Mkmers_per_s": {t: round(r / 1e6, 2) for t, r in sweep.items()},
-            "sample": "first %d left reads of the same synthetic set (%d k-mers + read pairs) at the best of the probed thread counts (%.1f s); "
-                      "T = 8 on half of them (%.1f s); from FASTQ text under the reader lock on a quarter (%.1f s); the thread sweep uses an eighth per "
-                      "candidate; all on the full-size filters; C restatement of the reference's FastqToGraphWorker loop (no JVM in the image)"
-                      % (n, best_kmers, best_dt, t8_dt, parse_dt)}
+            "sample": "first %d left reads of the same synthetic set (%d k-mers + read pairs), the same reads for every figure, each the median of three "
+                      "runs: at the best of the probed thread counts (%.1f s a run), at T = 8 (%.1f s), from FASTQ text under the reader lock (%.1f s); the "
+                      "thread sweep uses %d reads per candidate, one run each; all on the full-size filters; C restatement of the reference's "
+                      "FastqToGraphWorker loop (no JVM in the image)" % (m, best_kmers, best_dt, t8_dt, parse_dt, max(1, n // 8))}
 
 
 if __name__ == "__main__":
