@@ -55,9 +55,10 @@ def algorithmic_bytes(stage, n_kmers, n_pairs, n_runs, words, n_sorted=None, gro
         "count_windows": words * 12,
         "strengths": n_kmers * 5,
         "distinct_runs": n_kmers * 8 + n_runs * 16,
-        # per run: h Bloom-bit sector reads + h counter claims (atomic = sector read + write) + 36 B of records — an upper
-        # bound: runs of one occurrence whose k-mer is new claim nothing (k_late_claim), so the counters show about half
-        "probe_claim": n_runs * (h * SECTOR + h * 2 * SECTOR + 36),
+        # per run: h Bloom-bit sector reads + h counter claims (an atomic in L2: the sector is fetched once; its write-back is
+        # the next stage's store to the same byte) + 36 B of records — still an upper bound: runs of one occurrence whose k-mer
+        # is new claim nothing (k_late_claim); the counters show 0.7 of this (round 2 counted the claim twice: 2x the counters)
+        "probe_claim": n_runs * (h * SECTOR + h * SECTOR + 36),
         # per run: h counter byte stores (sector write), one strength sector, 40 B of records
         "resolve_apply": n_runs * (h * SECTOR + SECTOR + 40),
         # per pair: h bit probes, test before set (one sector read; the write-back of the few new bits is not counted — the
