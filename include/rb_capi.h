@@ -491,15 +491,21 @@ int rb_shard_query_finish(rb_graph *g, int which_bits, const void *breply_dev, c
  * requests — the four neighbours of a k-mer go out together, a naive extension's back-branch variants with them — and makes the
  * query for them (bit_counts / ctr_counts per destination rank, as rb_shard_query_make).  One exchange round per step for the
  * max-coverage walk and the naive extension, one per neighbourhood the lookahead search opens for the greedy extension.
- * kind 0 = rb_graph_walk (targets may be NULL), 1 = rb_graph_greedy_extend (mode_or_lookahead = lookahead; no gate filter on a
- * sharded graph), 2 = rb_graph_naive_extend (mode_or_lookahead = mode; term_seq / term_off for mode 0); the other arguments, the
+ * kind 0 = rb_graph_walk (targets may be NULL), 1 = rb_graph_greedy_extend (mode_or_lookahead = lookahead; gate: rb_shard_trav_set_gate),
+ * 2 = rb_graph_naive_extend (mode_or_lookahead = mode; term_seq / term_off for mode 0); the other arguments, the
  * outputs and the reasons are those calls'.  answer_cap: counts one step of a walk may hold (0: 4, 8, or
  * 4 (1 + 4 (1 + 2 lookahead)) by kind); a greedy step whose search needs more ends the walk with reason 8.  Results equal the
  * single-GPU calls on the same filters (tests/test_gpu_sharded_walks.py). */
 int rb_shard_trav_begin(rb_graph *g, int kind, const char *seeds, const char *targets, size_t n, int direction, int mode_or_lookahead,
                         int bound, int cap, float min_cov, const char *term_seq, const int64_t *term_off, int answer_cap);
-int rb_shard_trav_advance(rb_graph *g, int64_t *n_active, int64_t *bit_counts, int64_t *ctr_counts);
-int rb_shard_trav_absorb(rb_graph *g, const void *breply_dev, const void *creply_dev);
+/* the `bf` variants of the greedy extension (R/util/GraphUtils.java:1978-1993, Kmer.getSuccessors(k, numHash, graph, bf)
+ * R/graph/Kmer.java:257-299): gate = this rank's shard handle of ANOTHER sharded graph (same k, strandedness, rank count) whose dbgbf is
+ * that filter.  Call after begin; every round then carries a second request: advance also fills slot Q_BIDX of the GATE handle
+ * (gate_bit_counts per destination rank) with the same k-mers as a lookup, to be exchanged, served by rb_shard_query_serve on the
+ * owners' gate handles and handed to absorb as gate_breply_dev.  A k-mer that fails the gate counts 0. */
+int rb_shard_trav_set_gate(rb_graph *g, rb_graph *gate);
+int rb_shard_trav_advance(rb_graph *g, int64_t *n_active, int64_t *bit_counts, int64_t *ctr_counts, int64_t *gate_bit_counts /* NULL without a gate */);
+int rb_shard_trav_absorb(rb_graph *g, const void *breply_dev, const void *creply_dev, const void *gate_breply_dev /* NULL without a gate */);
 /* out_f: kinds 0 and 2 (forward hashes of the appended k-mers), out_r and out_count: kind 0, out_count: kinds 0 and 1; each may be
  * NULL.  rounds (may be NULL): exchange rounds this rank's walks took.  Frees the traversal. */
 int rb_shard_trav_end(rb_graph *g, char *out_bases, uint64_t *out_f, uint64_t *out_r, float *out_count, int32_t *out_len,

@@ -1282,12 +1282,14 @@ struct ReplayCounts {
 };
 constexpr uint8_t WALK_REASON_TOO_WIDE = 8;   // sharded graphs only: one step asked for more counts than the walk's answer cache holds
 // the answers of one exchange round go into the caches of the walks that asked
-__global__ void k_trav_absorb(TravArrays t, const float *__restrict__ ans, uint32_t n_req) {
+// (gate: the extra BloomFilter of the `bf` variants, looked up by its owners in the same round — a k-mer that fails it counts 0:
+// Kmer.getSuccessors(k, numHash, graph, bf) skips it before its count is read, and every caller's threshold is >= 1)
+__global__ void k_trav_absorb(TravArrays t, const float *__restrict__ ans, const uint8_t *__restrict__ gate, uint32_t n_req) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j >= n_req) return;
     const uint32_t i = t.req_walk[j];
     const uint32_t p = atomicAdd(&t.cn[i], 1u);
-    if (p < t.ccap) { t.ckey[(size_t)i * t.ccap + p] = t.req[j]; t.cval[(size_t)i * t.ccap + p] = ans[j]; }
+    if (p < t.ccap) { t.ckey[(size_t)i * t.ccap + p] = t.req[j]; t.cval[(size_t)i * t.ccap + p] = (gate && !gate[j]) ? 0.0f : ans[j]; }
     else t.over[i] = 1;
 }
 
@@ -3568,6 +3570,7 @@ struct rb_trav {
     TravArrays ta{};
     uint32_t n_req = 0;
     int64_t rounds = 0;
+    rb_graph *gate = nullptr;              // greedy extension's gate filter: another shard handle of this rank (its dbgbf)
 };
 namespace rb {
 void trav_free(rb_graph *g) {
@@ -3658,9 +3661,21 @@ int rb_shard_trav_begin(rb_graph *g, int kind, const char *seeds, const char *ta
     });
 }
 
-int rb_shard_trav_advance(rb_graph *g, int64_t *n_active, int64_t *bit_counts, int64_t *ctr_counts) {
+int rb_shard_trav_set_gate(rb_graph *g, rb_graph *gate) {
+    return guarded([&] {
+        RB_REQUIRE(g && g->shard && g->trav, "rb_shard_trav_set_gate: no traversal in progress on this handle");
+        RB_REQUIRE(g->trav->kind == 1 && g->trav->rounds == 0, "rb_shard_trav_set_gate: a gate belongs to a greedy extension that has not started");
+        RB_REQUIRE(gate && gate != g && gate->shard && gate->dbg.bits && gate->p.device == g->p.device && gate->k == g->k && gate->stranded == g->stranded &&
+                   gate->shard_count == g->shard_count && gate->shard_rank == g->shard_rank,
+                   "rb_shard_trav_set_gate: the gate must be this rank's shard of a graph with the same k, strandedness and rank count");
+        g->trav->gate = gate;
+    });
+}
+
+int rb_shard_trav_advance(rb_graph *g, int64_t *n_active, int64_t *bit_counts, int64_t *ctr_counts, int64_t *gate_bit_counts) {
     return guarded([&] {
         RB_REQUIRE(g && g->shard && g->trav && n_active && bit_counts && ctr_counts, "rb_shard_trav_advance: no traversal in progress on this handle");
+        RB_REQUIRE(!g->trav->gate || gate_bit_counts, "rb_shard_trav_advance: this traversal has a gate: gate_bit_counts is needed");
         rb_trav *t = g->trav;
         RB_HIP(hipSetDevice(g->p.device));
         hipStream_t s = g->stream;
@@ -3689,16 +3704,26 @@ int rb_shard_trav_advance(rb_graph *g, int64_t *n_active, int64_t *bit_counts, i
         *n_active = (int64_t)ctr[1];
         ++t->rounds;
         rb::shard_query_make_dev(g, 2, RB_DBGBF, t->n_req, bit_counts, ctr_counts);
+        if (t->gate) {                                        // the same hashes, as a lookup in the gate's dbgbf (slot Q_BIDX of the gate handle)
+            std::vector<int64_t> none((size_t)g->shard_count, 0);
+            if (t->n_req) RB_HIP(hipMemcpyAsync(rb::shard_query_h0(t->gate, t->n_req), t->ta.req, (size_t)t->n_req * 8, hipMemcpyDeviceToDevice, t->gate->stream));
+            rb::shard_query_make_dev(t->gate, 0, RB_DBGBF, t->n_req, gate_bit_counts, none.data());
+        }
     });
 }
 
-int rb_shard_trav_absorb(rb_graph *g, const void *breply_dev, const void *creply_dev) {
+int rb_shard_trav_absorb(rb_graph *g, const void *breply_dev, const void *creply_dev, const void *gate_breply_dev) {
     return guarded([&] {
         RB_REQUIRE(g && g->shard && g->trav, "rb_shard_trav_absorb: no traversal in progress on this handle");
         rb_trav *t = g->trav;
         if (!t->n_req) return;
         const float *ans = static_cast<const float *>(rb::shard_query_combine_dev(g, RB_DBGBF, breply_dev, creply_dev));
-        hipLaunchKernelGGL(k_trav_absorb, dim3(blocks_for((int64_t)t->n_req)), dim3(TPB), 0, g->stream, t->ta, ans, t->n_req);
+        const uint8_t *gate = nullptr;
+        if (t->gate) {
+            gate = static_cast<const uint8_t *>(rb::shard_query_combine_dev(t->gate, RB_DBGBF, gate_breply_dev, nullptr));
+            RB_HIP(hipStreamSynchronize(t->gate->stream));
+        }
+        hipLaunchKernelGGL(k_trav_absorb, dim3(blocks_for((int64_t)t->n_req)), dim3(TPB), 0, g->stream, t->ta, ans, gate, t->n_req);
         RB_HIP(hipGetLastError());
         RB_HIP(hipStreamSynchronize(g->stream));
     });

@@ -129,8 +129,9 @@ SYMBOLS = [
     ("rb_shard_query_serve", _i32, [_vp, _i32, _vp, _i64, _vp, _i64, _vp, _vp]),
     ("rb_shard_query_finish", _i32, [_vp, _i32, _vp, _vp, _vp, _vp]),
     ("rb_shard_trav_begin", _i32, [_vp, _i32, _vp, _vp, _sz, _i32, _i32, _i32, _i32, C.c_float, _vp, _vp, _i32]),
-    ("rb_shard_trav_advance", _i32, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
-    ("rb_shard_trav_absorb", _i32, [_vp, _vp, _vp]),
+    ("rb_shard_trav_set_gate", _i32, [_vp, _vp]),
+    ("rb_shard_trav_advance", _i32, [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
+    ("rb_shard_trav_absorb", _i32, [_vp, _vp, _vp, _vp]),
     ("rb_shard_trav_end", _i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_i64)]),
     ("rb_shard_comm_unique_id", _i32, [_vp]),
     ("rb_shard_comm_create_rccl", _i32, [_vp, _i32, _i32, _i32, C.POINTER(_vp)]),

@@ -283,11 +283,12 @@ class ShardRank:
             out.append((f4, r4, res[0].reshape(n, 4)))
 
     def traverse(self, kind, seeds, direction, bound=0, mode_or_lookahead=0, min_cov=1.0, targets=None, terminators=None, cap=4096,
-                 answer_cap=0, out=None):
+                 answer_cap=0, gate=None, out=None):
         """Coroutine: rb_graph_walk (kind 0), rb_graph_greedy_extend (1) or rb_graph_naive_extend (2) for this rank's seed k-mers on
         the SHARDED graph (rb_shard_trav_*).  The walks run on this rank's GPU in the kernels the single-GPU calls use; whenever
         they need counts nobody has told them yet, all ranks do one query exchange (2 all-to-alls) and the walks replay their
-        current step with the answers.  Every rank calls this with its own seeds (possibly none).
+        current step with the answers.  Every rank calls this with its own seeds (possibly none).  gate (greedy extension only):
+        this rank's ShardRank of ANOTHER sharded graph whose dbgbf is the `bf` of greedyExtendRight(graph, source, lookahead, bound, bf).
         out gets (bases[n, width], f[n, width] or None, r or None, count or None, len[n], reason[n], rounds)."""
         G = self.count
         k = int(self.p.k)
@@ -305,22 +306,34 @@ class ShardRank:
             if tseq.size == 0: tseq = np.zeros(1, np.uint8)
         vp = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
         check(lib.rb_shard_trav_begin(self.h, kind, vp(sb), vp(tb), n, direction, mode_or_lookahead, bound, cap, C.c_float(min_cov), vp(tseq), vp(toff), answer_cap))
+        if gate is not None:
+            check(lib.rb_shard_trav_set_gate(self.h, gate.h))
         while True:
             act = C.c_int64()
-            b_c, c_c = (C.c_int64 * G)(), (C.c_int64 * G)()
-            check(lib.rb_shard_trav_advance(self.h, C.byref(act), b_c, c_c))
+            b_c, c_c, g_c = (C.c_int64 * G)(), (C.c_int64 * G)(), (C.c_int64 * G)()
+            check(lib.rb_shard_trav_advance(self.h, C.byref(act), b_c, c_c, g_c if gate is not None else None))
             flags = yield ("ints", [int(act.value > 0)])
             if not any(x[0] for x in flags):
                 break
-            b_c, c_c = list(b_c), list(c_c)
-            (o_b, o_c), (o_bc, o_cc) = yield ("a2a", [self._slot(N.SLOT_Q_BIDX, 8 * sum(b_c)), self._slot(N.SLOT_Q_CIDX, 8 * sum(c_c))],
-                                              [[8 * c for c in b_c], [8 * c for c in c_c]])
+            b_c, c_c, g_c = list(b_c), list(c_c), list(g_c)
+            req = [self._slot(N.SLOT_Q_BIDX, 8 * sum(b_c)), self._slot(N.SLOT_Q_CIDX, 8 * sum(c_c))]
+            cnt = [[8 * c for c in b_c], [8 * c for c in c_c]]
+            if gate is not None:                               # the gate's lookups travel with the counts
+                req.append(gate._slot(N.SLOT_Q_BIDX, 8 * sum(g_c))); cnt.append([8 * c for c in g_c])
+            got, got_c = yield ("a2a", req, cnt)
+            o_b, o_c, o_bc, o_cc = got[0], got[1], got_c[0], got_c[1]
             nb, nc = sum(o_bc) // 8, sum(o_cc) // 8
             brep = torch.empty(nb, dtype=torch.uint8, device=self.tdev)
             crep = torch.empty(nc, dtype=torch.uint8, device=self.tdev)
             check(lib.rb_shard_query_serve(self.h, N.DBGBF, _ptr(o_b), nb, _ptr(o_c), nc, _ptr(brep), _ptr(crep)))
-            (my_b, my_c), _ = yield ("a2a", [brep, crep], [[c // 8 for c in o_bc], [c // 8 for c in o_cc]], [b_c, c_c])
-            check(lib.rb_shard_trav_absorb(self.h, _ptr(my_b), _ptr(my_c)))
+            rep, rep_c, known = [brep, crep], [[c // 8 for c in o_bc], [c // 8 for c in o_cc]], [b_c, c_c]
+            if gate is not None:
+                ng = sum(got_c[2]) // 8
+                grep = torch.empty(ng, dtype=torch.uint8, device=self.tdev)
+                check(lib.rb_shard_query_serve(gate.h, N.DBGBF, _ptr(got[2]), ng, None, 0, _ptr(grep), None))
+                rep.append(grep); rep_c.append([c // 8 for c in got_c[2]]); known.append(g_c)
+            mine, _ = yield ("a2a", rep, rep_c, known)
+            check(lib.rb_shard_trav_absorb(self.h, _ptr(mine[0]), _ptr(mine[1]), _ptr(mine[2]) if gate is not None else None))
         width = max(1, (cap if mode_or_lookahead == 0 else bound + 1) if kind == 2 else bound)
         bases = np.zeros((n, width), np.uint8); ln = np.zeros(n, np.int32); reason = np.zeros(n, np.uint8)
         f = np.zeros((n, width), np.uint64) if kind != 1 else None
@@ -736,17 +749,19 @@ class LoopbackCluster:
         run_loopback([r.walk(sd, direction, bound, minKmerCov, o) for r, sd, o in zip(self.ranks, per_rank_seeds, outs)])
         return [o[0] for o in outs]
 
-    def traverse(self, kind, per_rank_seeds, direction, targets=None, terminators=None, **kw):
+    def traverse(self, kind, per_rank_seeds, direction, targets=None, terminators=None, gate=None, **kw):
         """rb_graph_walk / _greedy_extend / _naive_extend (kind 0 / 1 / 2) on the sharded graph; targets / terminators: one list per
-        rank (or None).  -> per rank (bases, f, r, count, len, reason, rounds)"""
+        rank (or None); gate: another LoopbackCluster with the same number of ranks whose dbgbf is the greedy extension's `bf`.
+        -> per rank (bases, f, r, count, len, reason, rounds)"""
         outs = [[] for _ in self.ranks]
         run_loopback([r.traverse(kind, sd, direction, targets=targets[i] if targets else None, terminators=terminators[i] if terminators else None,
-                                 out=o, **kw) for i, (r, sd, o) in enumerate(zip(self.ranks, per_rank_seeds, outs))])
+                                 gate=gate.ranks[i] if gate is not None else None, out=o, **kw) for i, (r, sd, o) in enumerate(zip(self.ranks, per_rank_seeds, outs))])
         return [o[0] for o in outs]
 
-    def greedyExtend(self, per_rank_seeds, direction, lookahead, bound, answer_cap=0):
-        """GraphUtils.greedyExtendRight / Left on the sharded graph -> per rank (bases, count, len, reason), as graph.greedyExtend"""
-        return [(b, c, ln, rs) for b, _, _, c, ln, rs, _ in self.traverse(1, per_rank_seeds, direction, bound=bound, mode_or_lookahead=lookahead, answer_cap=answer_cap)]
+    def greedyExtend(self, per_rank_seeds, direction, lookahead, bound, answer_cap=0, bf=None):
+        """GraphUtils.greedyExtendRight / Left on the sharded graph (bf: the gated variants' filter, a LoopbackCluster whose dbgbf it
+        is) -> per rank (bases, count, len, reason), as graph.greedyExtend"""
+        return [(b, c, ln, rs) for b, _, _, c, ln, rs, _ in self.traverse(1, per_rank_seeds, direction, bound=bound, mode_or_lookahead=lookahead, answer_cap=answer_cap, gate=bf)]
 
     def naiveExtend(self, per_rank_seeds, direction, mode=1, bound=0, minKmerCov=1.0, terminators=None, cap=4096):
         """GraphUtils.naiveExtendRight / Left on the sharded graph -> per rank (list of appended bases, reason), as graph.naiveExtend"""

@@ -124,3 +124,36 @@ def test_naive_extension_three_forms(G, stranded):
             seen |= set(er.tolist())
     assert seen >= {0, 1, 3, 4, 5, 6}                    # (2, several neighbours, needs a false-positive branch without a back branch: not in every graph)
     g1.destroy(); cl.destroy()
+
+
+@pytest.mark.parametrize("G", [1, 4])
+def test_greedy_extension_through_a_gate_filter(G):
+    """the `bf` variants (a neighbour must pass bf.lookup before its count is read): on a sharded graph the gate is another sharded
+    graph's dbgbf, looked up by its owners in the same exchange round; reference: rb_graph_greedy_extend with a stand-alone filter
+    holding the same k-mers (itself checked against the oracle in test_greedy_extend_with_bloom_filter_gate)"""
+    from rnabloom.bloom import BloomFilter
+    g1, cl, seeds, cuts, reads = build(G, False, err=0.01, seed=67)
+    third = reads[:500]
+    s = np.frombuffer(b"".join(third), np.uint8)
+    off = np.concatenate([[0], np.cumsum([len(r) for r in third])]).astype(np.int64)
+    gb = ReadBatch.from_ascii(s, None, off, 3)
+    bf = BloomFilter(400_009, 2, 25)
+    bf.add(gb.nthash(25, 1))
+    gate = LoopbackCluster(G, 400_009, 400_009, 0, 2, 2, 2, 25, False, False, rngSeed=1)
+    gate.addBatch(gb, 150, reads_per_substep=200)
+    from rnabloom import _native as N
+    assert (gate.exportFilter(N.DBGBF) == bf.toBytes()).all()
+    shorter = 0
+    for direction in (0, 1):
+        eb, ec, el, er = g1.greedyExtend(seeds, direction, 4, 30, bf=bf)
+        free = g1.greedyExtend(seeds, direction, 4, 30)[2]
+        got = cl.greedyExtend(split(seeds, cuts), direction, 4, 30, answer_cap=1024, bf=gate)
+        for rk in range(G):
+            bases, c, ln, reason = got[rk]
+            a, b = cuts[rk], cuts[rk + 1]
+            assert (ln == el[a:b]).all() and (reason == er[a:b]).all()
+            m = np.arange(30)[None, :] < ln[:, None]
+            assert (bases[m] == eb[a:b][m]).all() and (c[m] == ec[a:b][m]).all()
+        shorter += int((el < free).sum())
+    assert shorter > 0                      # the gate did stop walks
+    g1.destroy(); cl.destroy(); gate.destroy(); bf.destroy()
