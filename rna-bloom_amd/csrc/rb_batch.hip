@@ -880,6 +880,279 @@ k_filter_reads(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ 
     if (threadIdx.x == 0 && total) atomicAdd(&total_spread[16u * (blockIdx.x & 31u)], total);
 }
 
+// The read-per-lane prefilter with the bucket fetch taken off the critical path (RB_FILTER_PIPE=1; minimizer-bucketed cache,
+// single-GPU ownership).  In k_filter_reads a wavefront waits for a bucket in nearly every step — some lane's minimizer changes —
+// and the SQ counters show it: 55 % of a wavefront's life is spent waiting, the vector ALU is busy half of the time
+// (profiles/r03_sq_counters).  Here a step is reordered and its window is finished one step late:
+//   minimizer of base b -> bucket of window b  |  finish window b-1 (bucket image, match, draw)  |  ISSUE the loads of window
+//   b's bucket into registers if it changed  |  roll the hashes of base b  |  (next step) ... finish window b: registers -> LDS.
+// The loads are in flight while the wavefront rolls its hashes and runs the next step's minimizer update (and the other
+// wavefronts of the SIMD theirs); nothing else changes: same cache, same draws, same counts and masks per word.
+template <int MODE>
+__global__ void __launch_bounds__(64)
+k_filter_reads_pipe(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
+                    const uint32_t *__restrict__ word_read, const uint32_t *__restrict__ len, int64_t w0, int64_t nw, int k,
+                    uint32_t W, uint32_t first_read, uint32_t pos_bits, uint64_t seed, uint64_t ordinal0, Mpf mcache,
+                    uint32_t *__restrict__ cnt, uint32_t *__restrict__ keepmask, uint32_t *__restrict__ total_spread,
+                    uint32_t dbg_flags, ulonglong2 *__restrict__ wstate) {
+    __shared__ uint64_t s_tf[25], s_tr[25];
+    extern __shared__ uint32_t s_ring[];                        // [k-m+1][lane]
+    __shared__ unsigned long long s_bkt[16 * 64];               // [slot][lane]: image of the current bucket
+    const uint32_t uk = (uint32_t)k, lane = threadIdx.x;
+    if (threadIdx.x < 25) {
+        const uint32_t o = threadIdx.x / 5u, in = threadIdx.x % 5u;
+        const uint64_t so = o ? seed_of(o - 1u) : 0ull, si = in ? seed_of(in - 1u) : 0ull;
+        const uint64_t sco = o ? seed_of(4u - o) : 0ull, sci = in ? seed_of(4u - in) : 0ull;
+        s_tf[threadIdx.x] = rotl(so, uk) ^ si;
+        s_tr[threadIdx.x] = rotr(sco, 1) ^ rotl(sci, uk - 1u);
+    }
+    __syncthreads();
+    const int64_t w = ((int64_t)blockIdx.x * 64 + threadIdx.x) * (int64_t)W;
+    uint32_t total = 0;
+    if (w < nw) {
+        const int64_t gw = w0 + w;
+        const uint32_t r = word_read[gw], L = len[r];
+        uint32_t done = 0;
+        if (uk <= L) {
+            uint64_t carr[RB_READ_WORDS];
+            uint32_t varr[RB_READ_WORDS];
+#pragma unroll
+            for (int q = 0; q < RB_READ_WORDS; ++q) {
+                carr[q] = 0; varr[q] = 0;
+                if ((uint32_t)q < W) { carr[q] = codes[gw + q]; varr[q] = valid[gw + q]; }
+            }
+            const uint32_t rstate = rng_read_state(seed, ordinal0 + (uint64_t)(r - first_read));
+            const uint32_t sh_c = 2u * (uk - 1u), sh_v = uk - 1u;
+            const uint32_t um = mcache.m, uw = uk - um + 1u;
+            const uint32_t mmask = (um >= 16u) ? 0xFFFFFFFFu : ((1u << (2u * um)) - 1u);
+            uint32_t mf = 0, mr = 0, blk_a = 0, blk_p = 0;
+            uint64_t cur_bkt = ~0ull;
+            uint64_t f = 0, rv = 0, hc = 0, hv = 0, cur_c = 0;
+            uint32_t run = 0, kept = 0, mask = 0, cur_v = 0;
+            uint32_t b = 0;
+            // the window whose decision is pending: its hash, its position, whether its bucket is still in the registers
+            ulonglong2 R[8];
+            uint64_t pend_h0 = 0;
+            uint32_t pend_p = 0;
+            bool pend = false, pend_sw = false;
+            auto land = [&]() {                                  // the pending window's bucket: registers -> LDS image
+                if (pend && pend_sw) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { s_bkt[(2 * q) * 64 + lane] = R[q].x; s_bkt[(2 * q + 1) * 64 + lane] = R[q].y; }
+                }
+                pend_sw = false;
+            };
+            auto decide = [&]() {                                // ... and its lookup, draw and bookkeeping
+                if (!pend) return;
+                const uint32_t s_known = mpf_match(&s_bkt[lane], 64u, pend_h0);
+                bool keep = true;
+                if (s_known && !(dbg_flags & 2u)) keep = draw_strength(rng_pos(rstate, pend_p)) >= s_known;
+                ++total;
+                if (keep) { ++kept; mask |= 1u << (pend_p & 31u); }
+                pend = false;
+            };
+            auto finish = [&]() { land(); decide(); };
+            while (b < L) {
+                if ((b & 31u) == 0u) {
+                    const uint32_t wi = b >> 5;
+#pragma unroll
+                    for (int q = 0; q < RB_READ_WORDS; ++q) if ((uint32_t)q == wi) { cur_c = carr[q]; cur_v = varr[q]; }
+                }
+                const uint32_t pb = b + 1u - uk;
+                if ((pb & 31u) == 0u && (int32_t)pb > 0) {       // first window of a new word: the previous word is final once its last window is
+                    finish();
+                    cnt[w + done] = kept; keepmask[w + done] = mask; ++done; kept = 0; mask = 0;
+                }
+                const uint32_t d1 = 32u - (b & 31u), d2 = 32u - (pb & 31u);
+                uint32_t stop = b + (d1 < d2 ? d1 : d2);
+                stop = stop < L ? stop : L;
+#pragma nounroll
+                for (; b < stop; ++b) {
+                    const uint32_t code = (uint32_t)cur_c & 3u, ok = cur_v & 1u;
+                    cur_c >>= 2; cur_v >>= 1;
+                    run = ok ? run + 1u : 0u;
+                    // minimizer of the window that ends at this base (garbage while run < m: never consulted then)
+                    mf = ((mf << 2) | code) & mmask;
+                    mr = (mr >> 2) | ((3u - code) << (2u * (um - 1u)));
+                    const uint32_t o_cur = mmer_order(mf < mr ? mf : mr);
+                    s_ring[blk_a * 64u + lane] = o_cur;
+                    blk_p = blk_a ? (o_cur < blk_p ? o_cur : blk_p) : o_cur;
+                    const bool win = run >= uk;
+                    uint64_t bkt = cur_bkt;
+                    if (win) {
+                        uint32_t omin = blk_p;
+                        if (blk_a + 1u < uw) { const uint32_t sfx = s_ring[(blk_a + 1u) * 64u + lane]; omin = sfx < omin ? sfx : omin; }
+                        bkt = mpf_bucket(mcache, omin);
+                    }
+                    land();                                      // the window before: its bucket has had a step to arrive
+                    const bool sw = win && bkt != cur_bkt;
+                    if (sw) {                                    // new minimizer: the two lines of its bucket, into registers
+                        const ulonglong2 *bp = reinterpret_cast<const ulonglong2 *>(mcache.tab + (bkt << 4));
+#pragma unroll
+                        for (int q = 0; q < 8; ++q) R[q] = bp[q];
+                        cur_bkt = bkt;
+                    }
+                    decide();
+                    const uint32_t in5 = ok ? code + 1u : 0u;
+                    const uint32_t out5 = ((uint32_t)(hv >> sh_v) & 1u) ? ((uint32_t)(hc >> sh_c) & 3u) + 1u : 0u;
+                    const uint32_t tt = out5 * 5u + in5;
+                    if (MODE != 2) f = rotl(f, 1) ^ s_tf[tt];
+                    if (MODE != 0) rv = rotr(rv, 1) ^ s_tr[tt];
+                    hc = (hc << 2) | code; hv = (hv << 1) | ok;
+                    pend = win; pend_sw = sw;
+                    if (win) { pend_h0 = (MODE == 0) ? f : (MODE == 2) ? rv : canonical(f, rv); pend_p = b + 1u - uk; }
+                    if (blk_a + 1u == uw) {   // block complete: turn its ring entries into suffix minima
+                        uint32_t sm = 0xFFFFFFFFu;
+                        for (uint32_t q = uw; q-- > 0u;) { const uint32_t v = s_ring[q * 64u + lane]; sm = v < sm ? v : sm; s_ring[q * 64u + lane] = sm; }
+                        blk_a = 0;
+                    } else
+                        ++blk_a;
+                }
+                if (wstate && ((b + 1u - uk) & 31u) == 0u && b + 1u >= uk) wstate[w + ((b + 1u - uk) >> 5)] = make_ulonglong2(f, rv);
+            }
+            finish();
+            cnt[w + done] = kept; keepmask[w + done] = mask; ++done;
+        }
+        for (; done < W; ++done) { cnt[w + done] = 0; keepmask[w + done] = 0; }
+    }
+    for (int o = 32; o > 0; o >>= 1) total += __shfl_down(total, o, 64);
+    if (threadIdx.x == 0 && total) atomicAdd(&total_spread[16u * (blockIdx.x & 31u)], total);
+}
+
+// The same with the fetch TWO steps ahead of its use (RB_FILTER_PIPE=2): two register sets take turns (the step loop is unrolled
+// by two so that each set has a name), and the loads are issued by every lane in every step — a lane whose bucket did not change
+// reads the table's first line, one cached line for the whole wavefront — because only an unconditional issue lets the compiler
+// count: the finish of window b-2 waits for exactly its eight loads (s_waitcnt vmcnt(8)) while those of window b-1 stay in flight;
+// behind a divergent branch it has to assume the newer loads may not exist and waits for everything (vmcnt(0)).
+template <int MODE>
+__global__ void __launch_bounds__(64)
+k_filter_reads_pipe2(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
+                     const uint32_t *__restrict__ word_read, const uint32_t *__restrict__ len, int64_t w0, int64_t nw, int k,
+                     uint32_t W, uint32_t first_read, uint32_t pos_bits, uint64_t seed, uint64_t ordinal0, Mpf mcache,
+                     uint32_t *__restrict__ cnt, uint32_t *__restrict__ keepmask, uint32_t *__restrict__ total_spread,
+                     uint32_t dbg_flags, ulonglong2 *__restrict__ wstate) {
+    __shared__ uint64_t s_tf[25], s_tr[25];
+    extern __shared__ uint32_t s_ring[];                        // [k-m+1][lane]
+    __shared__ unsigned long long s_bkt[16 * 64];               // [slot][lane]: image of the current bucket
+    const uint32_t uk = (uint32_t)k, lane = threadIdx.x;
+    if (threadIdx.x < 25) {
+        const uint32_t o = threadIdx.x / 5u, in = threadIdx.x % 5u;
+        const uint64_t so = o ? seed_of(o - 1u) : 0ull, si = in ? seed_of(in - 1u) : 0ull;
+        const uint64_t sco = o ? seed_of(4u - o) : 0ull, sci = in ? seed_of(4u - in) : 0ull;
+        s_tf[threadIdx.x] = rotl(so, uk) ^ si;
+        s_tr[threadIdx.x] = rotr(sco, 1) ^ rotl(sci, uk - 1u);
+    }
+    __syncthreads();
+    const int64_t w = ((int64_t)blockIdx.x * 64 + threadIdx.x) * (int64_t)W;
+    uint32_t total = 0;
+    if (w < nw) {
+        const int64_t gw = w0 + w;
+        const uint32_t r = word_read[gw], L = len[r];
+        uint32_t done = 0;
+        if (uk <= L) {
+            uint64_t carr[RB_READ_WORDS];
+            uint32_t varr[RB_READ_WORDS];
+#pragma unroll
+            for (int q = 0; q < RB_READ_WORDS; ++q) {
+                carr[q] = 0; varr[q] = 0;
+                if ((uint32_t)q < W) { carr[q] = codes[gw + q]; varr[q] = valid[gw + q]; }
+            }
+            const uint32_t rstate = rng_read_state(seed, ordinal0 + (uint64_t)(r - first_read));
+            const uint32_t sh_c = 2u * (uk - 1u), sh_v = uk - 1u;
+            const uint32_t um = mcache.m, uw = uk - um + 1u;
+            const uint32_t mmask = (um >= 16u) ? 0xFFFFFFFFu : ((1u << (2u * um)) - 1u);
+            uint32_t mf = 0, mr = 0, blk_a = 0, blk_p = 0;
+            uint64_t cur_bkt = ~0ull;
+            uint64_t f = 0, rv = 0, hc = 0, hv = 0, cur_c = 0;
+            uint32_t run = 0, kept = 0, mask = 0, cur_v = 0;
+            uint32_t b = 0;
+            struct Pend { uint64_t h0; uint32_t p; bool on, sw; };
+            ulonglong2 RA[8], RB[8];
+            Pend pa{0, 0, false, false}, pb_{0, 0, false, false};
+            bool next_b = false;                                 // which set the next step uses (and whose window is the older one)
+            auto finish = [&](const ulonglong2 (&R)[8], Pend &pd) {
+                if (!pd.on) return;
+                if (pd.sw) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) { s_bkt[(2 * q) * 64 + lane] = R[q].x; s_bkt[(2 * q + 1) * 64 + lane] = R[q].y; }
+                }
+                const uint32_t s_known = mpf_match(&s_bkt[lane], 64u, pd.h0);
+                bool keep = true;
+                if (s_known && !(dbg_flags & 2u)) keep = draw_strength(rng_pos(rstate, pd.p)) >= s_known;
+                ++total;
+                if (keep) { ++kept; mask |= 1u << (pd.p & 31u); }
+                pd.on = false;
+            };
+            auto finish_all = [&]() {                           // older window first
+                if (!next_b) { finish(RA, pa); finish(RB, pb_); } else { finish(RB, pb_); finish(RA, pa); }
+            };
+            auto step = [&](ulonglong2 (&R)[8], Pend &pd) {
+                const uint32_t code = (uint32_t)cur_c & 3u, ok = cur_v & 1u;
+                cur_c >>= 2; cur_v >>= 1;
+                run = ok ? run + 1u : 0u;
+                mf = ((mf << 2) | code) & mmask;
+                mr = (mr >> 2) | ((3u - code) << (2u * (um - 1u)));
+                const uint32_t o_cur = mmer_order(mf < mr ? mf : mr);
+                s_ring[blk_a * 64u + lane] = o_cur;
+                blk_p = blk_a ? (o_cur < blk_p ? o_cur : blk_p) : o_cur;
+                const bool win = run >= uk;
+                uint64_t bkt = cur_bkt;
+                if (win) {
+                    uint32_t omin = blk_p;
+                    if (blk_a + 1u < uw) { const uint32_t sfx = s_ring[(blk_a + 1u) * 64u + lane]; omin = sfx < omin ? sfx : omin; }
+                    bkt = mpf_bucket(mcache, omin);
+                }
+                finish(R, pd);                                   // the window two steps back: the last user of this register set
+                const bool sw = win && bkt != cur_bkt;
+                const ulonglong2 *bp = reinterpret_cast<const ulonglong2 *>(mcache.tab + (sw ? (bkt << 4) : 0ull));
+#pragma unroll
+                for (int q = 0; q < 8; ++q) R[q] = bp[q];        // every lane, every step (see above)
+                if (sw) cur_bkt = bkt;
+                const uint32_t in5 = ok ? code + 1u : 0u;
+                const uint32_t out5 = ((uint32_t)(hv >> sh_v) & 1u) ? ((uint32_t)(hc >> sh_c) & 3u) + 1u : 0u;
+                const uint32_t tt = out5 * 5u + in5;
+                if (MODE != 2) f = rotl(f, 1) ^ s_tf[tt];
+                if (MODE != 0) rv = rotr(rv, 1) ^ s_tr[tt];
+                hc = (hc << 2) | code; hv = (hv << 1) | ok;
+                pd.on = win; pd.sw = sw;
+                if (win) { pd.h0 = (MODE == 0) ? f : (MODE == 2) ? rv : canonical(f, rv); pd.p = b + 1u - uk; }
+                if (blk_a + 1u == uw) {
+                    uint32_t sm = 0xFFFFFFFFu;
+                    for (uint32_t q = uw; q-- > 0u;) { const uint32_t v = s_ring[q * 64u + lane]; sm = v < sm ? v : sm; s_ring[q * 64u + lane] = sm; }
+                    blk_a = 0;
+                } else
+                    ++blk_a;
+                ++b;
+            };
+            while (b < L) {
+                if ((b & 31u) == 0u) {
+                    const uint32_t wi = b >> 5;
+#pragma unroll
+                    for (int q = 0; q < RB_READ_WORDS; ++q) if ((uint32_t)q == wi) { cur_c = carr[q]; cur_v = varr[q]; }
+                }
+                const uint32_t pb = b + 1u - uk;
+                if ((pb & 31u) == 0u && (int32_t)pb > 0) {
+                    finish_all();
+                    cnt[w + done] = kept; keepmask[w + done] = mask; ++done; kept = 0; mask = 0;
+                }
+                const uint32_t d1 = 32u - (b & 31u), d2 = 32u - (pb & 31u);
+                uint32_t stop = b + (d1 < d2 ? d1 : d2);
+                stop = stop < L ? stop : L;
+                if (next_b && b < stop) { step(RB, pb_); next_b = false; }
+#pragma nounroll
+                while (b + 1u < stop) { step(RA, pa); step(RB, pb_); }
+                if (b < stop) { step(RA, pa); next_b = true; }
+                if (wstate && ((b + 1u - uk) & 31u) == 0u && b + 1u >= uk) wstate[w + ((b + 1u - uk) >> 5)] = make_ulonglong2(f, rv);
+            }
+            finish_all();
+            cnt[w + done] = kept; keepmask[w + done] = mask; ++done;
+        }
+        for (; done < W; ++done) { cnt[w + done] = 0; keepmask[w + done] = 0; }
+    }
+    for (int o = 32; o > 0; o >>= 1) total += __shfl_down(total, o, 64);
+    if (threadIdx.x == 0 && total) atomicAdd(&total_spread[16u * (blockIdx.x & 31u)], total);
+}
+
 // One-pass prefilter + emit (k <= 31): the walker of k_filter_windows_fast, but every kept window's
 // (h0, occurrence) goes straight to its final position in the dense, read-ordered output.  A block
 // = one wavefront = 64 words; kept records are staged in LDS, the block's output offset comes from
@@ -1063,7 +1336,15 @@ void launch_filter_windows(const rb_batch *b, int64_t w0, int64_t nw, int k, int
     hipLaunchKernelGGL((k_filter_reads<M, P>), gc, t, ring_bytes, s, b->codes, b->valid, b->word_read, b->len, w0, nw, k, C, \
                        first_read, pos_bits, seed, ordinal0, cache, mcache, cnt, keepmask, total_spread, dbgf, own, \
                        reinterpret_cast<ulonglong2 *>(wstate))
-        if (use_m) { if (mode == 0) RB_LAUNCH_FC(0, true); else if (mode == 2) RB_LAUNCH_FC(2, true); else RB_LAUNCH_FC(1, true); }
+        const int pipe = getenv("RB_FILTER_PIPE") ? atoi(getenv("RB_FILTER_PIPE")) : 1;   // 0: k_filter_reads, 1 (default): fetch one step ahead, 2: two steps (slower: every lane loads in every step)
+        if (use_m && pipe && own.lo == 0 && own.hi == 0) {         // the whole index range is this handle's: the bucket fetch one / two steps ahead of its use
+#define RB_LAUNCH_FP(K, M)                                                                                           \
+    hipLaunchKernelGGL((K<M>), gc, t, ring_bytes, s, b->codes, b->valid, b->word_read, b->len, w0, nw, k, C,         \
+                       first_read, pos_bits, seed, ordinal0, mcache, cnt, keepmask, total_spread, dbgf, reinterpret_cast<ulonglong2 *>(wstate))
+            if (pipe == 2) { if (mode == 0) RB_LAUNCH_FP(k_filter_reads_pipe2, 0); else if (mode == 2) RB_LAUNCH_FP(k_filter_reads_pipe2, 2); else RB_LAUNCH_FP(k_filter_reads_pipe2, 1); }
+            else { if (mode == 0) RB_LAUNCH_FP(k_filter_reads_pipe, 0); else if (mode == 2) RB_LAUNCH_FP(k_filter_reads_pipe, 2); else RB_LAUNCH_FP(k_filter_reads_pipe, 1); }
+#undef RB_LAUNCH_FP
+        } else if (use_m) { if (mode == 0) RB_LAUNCH_FC(0, true); else if (mode == 2) RB_LAUNCH_FC(2, true); else RB_LAUNCH_FC(1, true); }
         else { if (mode == 0) RB_LAUNCH_FC(0, false); else if (mode == 2) RB_LAUNCH_FC(2, false); else RB_LAUNCH_FC(1, false); }
 #undef RB_LAUNCH_FC
     } else if (use_m) {
