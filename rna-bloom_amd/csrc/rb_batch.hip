@@ -942,13 +942,14 @@ k_filter_reads_pipe(const uint64_t *__restrict__ codes, const uint32_t *__restri
                 }
                 pend_sw = false;
             };
-            auto decide = [&]() {                                // ... and its lookup, draw and bookkeeping
-                if (!pend) return;
-                const uint32_t s_known = mpf_match(&s_bkt[lane], 64u, pend_h0);
-                bool keep = true;
-                if (s_known && !(dbg_flags & 2u)) keep = draw_strength(rng_pos(rstate, pend_p)) >= s_known;
-                ++total;
-                if (keep) { ++kept; mask |= 1u << (pend_p & 31u); }
+            const uint32_t no_drop = (dbg_flags & 2u) ? 1u : 0u;
+            auto decide = [&]() {                                // ... and its lookup, draw and bookkeeping — straight-line: a lane without a
+                const uint32_t s_known = mpf_match_flat(&s_bkt[lane], 64u, pend_h0);     // pending window computes on stale values and adds zero
+                const uint32_t strength = draw_strength(rng_pos(rstate, pend_p));
+                const uint32_t keep = (pend && (s_known == 0u || no_drop || strength >= s_known)) ? 1u : 0u;
+                total += pend ? 1u : 0u;
+                kept += keep;
+                mask |= keep << (pend_p & 31u);
                 pend = false;
             };
             auto finish = [&]() { land(); decide(); };
@@ -978,12 +979,11 @@ k_filter_reads_pipe(const uint64_t *__restrict__ codes, const uint32_t *__restri
                     s_ring[blk_a * 64u + lane] = o_cur;
                     blk_p = blk_a ? (o_cur < blk_p ? o_cur : blk_p) : o_cur;
                     const bool win = run >= uk;
-                    uint64_t bkt = cur_bkt;
-                    if (win) {
-                        uint32_t omin = blk_p;
-                        if (blk_a + 1u < uw) { const uint32_t sfx = s_ring[(blk_a + 1u) * 64u + lane]; omin = sfx < omin ? sfx : omin; }
-                        bkt = mpf_bucket(mcache, omin);
-                    }
+                    // (computed for every lane: while run < k the minimum is garbage and `win` keeps it from being used)
+                    const uint32_t nxt = blk_a + 1u < uw ? blk_a + 1u : blk_a;          // the block's last slot has no suffix to look at
+                    const uint32_t sfx = s_ring[nxt * 64u + lane];
+                    const uint32_t omin = (blk_a + 1u < uw && sfx < blk_p) ? sfx : blk_p;
+                    const uint64_t bkt = mpf_bucket(mcache, omin);
                     land();                                      // the window before: its bucket has had a step to arrive
                     const bool sw = win && bkt != cur_bkt;
                     if (sw) {                                    // new minimizer: the two lines of its bucket, into registers

@@ -362,6 +362,15 @@ __device__ __forceinline__ uint32_t mpf_match(const unsigned long long *bkt, uin
     return s;
 }
 
+// the same without a branch (k_filter_reads_pipe is bound by the NUMBER of instructions it issues, scalar and branch ones included)
+__device__ __forceinline__ uint32_t mpf_match_flat(const unsigned long long *bkt, uint32_t stride, uint64_t h0) {
+    const unsigned long long ea = bkt[mpf_slot_a(h0) * stride], eb = bkt[mpf_slot_b(h0) * stride];
+    const uint32_t va = (uint32_t)(ea & 7ull), vb = (uint32_t)(eb & 7ull);
+    const uint32_t ra = (ea && (ea >> 3) == mpf_tag_a(h0)) ? (va ? va : RB_MPF_TOP_EXP) : 0u;
+    const uint32_t rb = (eb && (eb >> 3) == mpf_tag_b(h0)) ? (vb ? vb : RB_MPF_TOP_EXP) : 0u;
+    return ra > rb ? ra : rb;
+}
+
 // trailing-zero strength of a draw, capped at 15 (see k_strength)
 __host__ __device__ __forceinline__ uint32_t draw_strength(uint32_t rnd31) {
     const uint32_t r = rnd31 | 0x8000u;

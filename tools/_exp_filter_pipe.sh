@@ -10,7 +10,5 @@ PY
 timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_scale.py tests/test_gpu_fullsize.py -x -q 2>&1 | grep -E "passed|failed|FAILED" | tail -3
 run base RB_FILTER_PIPE=0
 run pipe1 RB_FILTER_PIPE=1
-run pipe2 RB_FILTER_PIPE=2
 run base_again RB_FILTER_PIPE=0
 run pipe1_again RB_FILTER_PIPE=1
-run pipe2_again RB_FILTER_PIPE=2
