@@ -927,8 +927,8 @@ k_filter_reads_pipe(const uint64_t *__restrict__ codes, const uint32_t *__restri
             const uint32_t mmask = (um >= 16u) ? 0xFFFFFFFFu : ((1u << (2u * um)) - 1u);
             uint32_t mf = 0, mr = 0, blk_a = 0, blk_p = 0;
             uint64_t cur_bkt = ~0ull;
-            uint64_t f = 0, rv = 0, hc = 0, hv = 0, cur_c = 0;
-            uint32_t run = 0, kept = 0, mask = 0, cur_v = 0;
+            uint64_t f = 0, rv = 0, hc = 0, cur_c = 0;
+            uint32_t run = 0, kept = 0, mask = 0, cur_v = 0, hv = 0;     // (k <= 31: 32 bits of usable-base history suffice)
             uint32_t b = 0;
             // the window whose decision is pending: its hash, its position, whether its bucket is still in the registers
             ulonglong2 R[8];
@@ -994,7 +994,7 @@ k_filter_reads_pipe(const uint64_t *__restrict__ codes, const uint32_t *__restri
                     }
                     decide();
                     const uint32_t in5 = ok ? code + 1u : 0u;
-                    const uint32_t out5 = ((uint32_t)(hv >> sh_v) & 1u) ? ((uint32_t)(hc >> sh_c) & 3u) + 1u : 0u;
+                    const uint32_t out5 = ((hv >> sh_v) & 1u) ? ((uint32_t)(hc >> sh_c) & 3u) + 1u : 0u;
                     const uint32_t tt = out5 * 5u + in5;
                     if (MODE != 2) f = rotl(f, 1) ^ s_tf[tt];
                     if (MODE != 0) rv = rotr(rv, 1) ^ s_tr[tt];

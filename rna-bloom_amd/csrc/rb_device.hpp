@@ -17,11 +17,23 @@ __device__ __forceinline__ uint64_t seed_of(uint32_t code) {
     s = (code == 3) ? 0x295549f54be24456ull : s;         // T/U
     return s;
 }
+// rotation by ONE bit — the rolling step of both strands — as two funnel shifts (v_alignbit_b32) instead of the 64-bit shift,
+// 32-bit shift and OR the compiler makes of the general form: the window walkers are bound by their instruction count
+__device__ __forceinline__ uint64_t rotl1(uint64_t v) {
+    const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    return ((uint64_t)__builtin_amdgcn_alignbit(hi, lo, 31) << 32) | __builtin_amdgcn_alignbit(lo, hi, 31);
+}
+__device__ __forceinline__ uint64_t rotr1(uint64_t v) {
+    const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    return ((uint64_t)__builtin_amdgcn_alignbit(lo, hi, 1) << 32) | __builtin_amdgcn_alignbit(hi, lo, 1);
+}
 __device__ __forceinline__ uint64_t rotl(uint64_t v, uint32_t s) {
+    if (__builtin_constant_p(s) && s == 1u) return rotl1(v);
     s &= 63u;
     return (v << s) | (v >> ((64u - s) & 63u));
 }
 __device__ __forceinline__ uint64_t rotr(uint64_t v, uint32_t s) {
+    if (__builtin_constant_p(s) && s == 1u) return rotr1(v);
     s &= 63u;
     return (v >> s) | (v << ((64u - s) & 63u));
 }
