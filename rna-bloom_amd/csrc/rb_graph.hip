@@ -2112,13 +2112,15 @@ void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, ui
         hipLaunchKernelGGL(k_conf_release, dim3(blocks_for(nck)), dim3(TPB), 0, s, fv, uniq, confk, nck);
         // components by min-label propagation; ctr[3] = changed flag, ctr[4] = number of big components
         hipLaunchKernelGGL(k_label_init, dim3(blocks_for(nck)), dim3(TPB), 0, s, confk, nck, label);
-        for (int it = 0;; ++it) {
+        for (int it = 0;; ++it) {                                // (two propagation rounds per look at the flag: most components settle in 3-4)
             RB_REQUIRE(it < 100000, "component labelling did not converge");
             RB_HIP(hipMemsetAsync(ctr + 3, 0, 4, s));
-            hipLaunchKernelGGL(k_label_push, dim3(blocks_for(nck)), dim3(TPB), 0, s, fv, uniq, confk, nck,
-                               g->ctable.as<Slot>(), c_log2, label);
-            hipLaunchKernelGGL(k_label_pull, dim3(blocks_for(nck)), dim3(TPB), 0, s, fv, uniq, confk, nck,
-                               g->ctable.as<Slot>(), c_log2, label, ctr + 3);
+            for (int q = 0; q < 2; ++q) {
+                hipLaunchKernelGGL(k_label_push, dim3(blocks_for(nck)), dim3(TPB), 0, s, fv, uniq, confk, nck,
+                                   g->ctable.as<Slot>(), c_log2, label);
+                hipLaunchKernelGGL(k_label_pull, dim3(blocks_for(nck)), dim3(TPB), 0, s, fv, uniq, confk, nck,
+                                   g->ctable.as<Slot>(), c_log2, label, ctr + 3);
+            }
             uint32_t changed = 0;
             RB_HIP(hipMemcpyAsync(&changed, ctr + 3, 4, hipMemcpyDeviceToHost, s));
             RB_HIP(hipStreamSynchronize(s));
