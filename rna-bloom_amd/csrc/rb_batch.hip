@@ -926,7 +926,7 @@ k_filter_reads_pipe(const uint64_t *__restrict__ codes, const uint32_t *__restri
             const uint32_t um = mcache.m, uw = uk - um + 1u;
             const uint32_t mmask = (um >= 16u) ? 0xFFFFFFFFu : ((1u << (2u * um)) - 1u);
             uint32_t mf = 0, mr = 0, blk_a = 0, blk_p = 0;
-            uint64_t cur_bkt = ~0ull;
+            uint32_t cur_bkt = ~0u;                               // (bucket numbers have at most 25 bits)
             uint64_t f = 0, rv = 0, hc = 0, cur_c = 0;
             uint32_t run = 0, kept = 0, mask = 0, cur_v = 0, hv = 0;     // (k <= 31: 32 bits of usable-base history suffice)
             uint32_t b = 0;
@@ -946,8 +946,9 @@ k_filter_reads_pipe(const uint64_t *__restrict__ codes, const uint32_t *__restri
             auto decide = [&]() {                                // ... and its lookup, draw and bookkeeping — straight-line: a lane without a
                 const uint32_t s_known = mpf_match_flat(&s_bkt[lane], 64u, pend_h0);     // pending window computes on stale values and adds zero
                 const uint32_t strength = draw_strength(rng_pos(rstate, pend_p));
-                const uint32_t keep = (pend && (s_known == 0u || no_drop || strength >= s_known)) ? 1u : 0u;
-                total += pend ? 1u : 0u;
+                const uint32_t on = pend ? 1u : 0u;                                     // (bitwise: no short circuit, no branch)
+                const uint32_t keep = on & ((s_known == 0u ? 1u : 0u) | no_drop | (strength >= s_known ? 1u : 0u));
+                total += on;
                 kept += keep;
                 mask |= keep << (pend_p & 31u);
                 pend = false;
@@ -983,11 +984,11 @@ k_filter_reads_pipe(const uint64_t *__restrict__ codes, const uint32_t *__restri
                     const uint32_t nxt = blk_a + 1u < uw ? blk_a + 1u : blk_a;          // the block's last slot has no suffix to look at
                     const uint32_t sfx = s_ring[nxt * 64u + lane];
                     const uint32_t omin = (blk_a + 1u < uw && sfx < blk_p) ? sfx : blk_p;
-                    const uint64_t bkt = mpf_bucket(mcache, omin);
+                    const uint32_t bkt = (uint32_t)mpf_bucket(mcache, omin);
                     land();                                      // the window before: its bucket has had a step to arrive
                     const bool sw = win && bkt != cur_bkt;
                     if (sw) {                                    // new minimizer: the two lines of its bucket, into registers
-                        const ulonglong2 *bp = reinterpret_cast<const ulonglong2 *>(mcache.tab + (bkt << 4));
+                        const ulonglong2 *bp = reinterpret_cast<const ulonglong2 *>(mcache.tab + ((uint64_t)bkt << 4));
 #pragma unroll
                         for (int q = 0; q < 8; ++q) R[q] = bp[q];
                         cur_bkt = bkt;
@@ -1000,7 +1001,7 @@ k_filter_reads_pipe(const uint64_t *__restrict__ codes, const uint32_t *__restri
                     if (MODE != 0) rv = rotr(rv, 1) ^ s_tr[tt];
                     hc = (hc << 2) | code; hv = (hv << 1) | ok;
                     pend = win; pend_sw = sw;
-                    if (win) { pend_h0 = (MODE == 0) ? f : (MODE == 2) ? rv : canonical(f, rv); pend_p = b + 1u - uk; }
+                    pend_h0 = (MODE == 0) ? f : (MODE == 2) ? rv : canonical(f, rv); pend_p = b + 1u - uk;   // (unused unless pend)
                     if (blk_a + 1u == uw) {   // block complete: turn its ring entries into suffix minima
                         uint32_t sm = 0xFFFFFFFFu;
                         for (uint32_t q = uw; q-- > 0u;) { const uint32_t v = s_ring[q * 64u + lane]; sm = v < sm ? v : sm; s_ring[q * 64u + lane] = sm; }

@@ -378,8 +378,11 @@ __device__ __forceinline__ uint32_t mpf_match(const unsigned long long *bkt, uin
 __device__ __forceinline__ uint32_t mpf_match_flat(const unsigned long long *bkt, uint32_t stride, uint64_t h0) {
     const unsigned long long ea = bkt[mpf_slot_a(h0) * stride], eb = bkt[mpf_slot_b(h0) * stride];
     const uint32_t va = (uint32_t)(ea & 7ull), vb = (uint32_t)(eb & 7ull);
-    const uint32_t ra = (ea && (ea >> 3) == mpf_tag_a(h0)) ? (va ? va : RB_MPF_TOP_EXP) : 0u;
-    const uint32_t rb = (eb && (eb >> 3) == mpf_tag_b(h0)) ? (vb ? vb : RB_MPF_TOP_EXP) : 0u;
+    // an entry is (tag << 3) | exponent code: it matches iff it differs from (tag << 3) in the low three bits only
+    const uint32_t ha = (uint32_t)(((ea ^ (mpf_tag_a(h0) << 3)) < 8ull) & (ea != 0ull));
+    const uint32_t hb = (uint32_t)(((eb ^ (mpf_tag_b(h0) << 3)) < 8ull) & (eb != 0ull));
+    const uint32_t ra = ha ? (va ? va : RB_MPF_TOP_EXP) : 0u;
+    const uint32_t rb = hb ? (vb ? vb : RB_MPF_TOP_EXP) : 0u;
     return ra > rb ? ra : rb;
 }
 
