@@ -451,21 +451,11 @@ __global__ void k_resolve_apply(FilterView fv, const uint64_t *__restrict__ uniq
     const uint32_t m = counts[d];
     uint32_t st = status[d];
     // what the light-run path at the bottom needs, asked for up front: this kernel waits on memory for two thirds of its life
-    // (profiles/r03_sq_counters), one dependent load after the other
+    // (profiles/r03_sq_counters), one dependent load after the other.  (Also asking for the bit-filter words and the first line
+    // of strengths here measured 1 ms slower: 48.2 against 47.1 ms.)
     const uint32_t start_d = starts[d];
     const uint64_t cv_d = cvals[d];
     const uint32_t occ_d = vals[start_d];
-    // ... the words of the contested-counter bit filter this run will ask (two hash functions: the common shape) and the line
-    // its strengths start in (the op loop reads it 8 bytes at a time: the touch makes those loads cache hits)
-    const bool pre = (st & ST_CLAIMED) && fv.cbf_h == 2;
-    uint64_t pidx[2] = {0, 0};
-    uint32_t pcsf[2] = {0, 0};
-    if (pre) {
-        pidx[0] = index_of(h0, fv.cbf_mod); pidx[1] = index_of(multi_hash(h0, 1u, fv.kmul), fv.cbf_mod);
-        if (n_foreign && csf) { pcsf[0] = csf[slot_of(pidx[0], csf_log2) >> 5]; pcsf[1] = csf[slot_of(pidx[1], csf_log2) >> 5]; }
-        const uint64_t touch = *reinterpret_cast<const uint64_t *>(tz + (start_d & ~7u));
-        asm volatile("" ::"v"(touch));
-    }
     const bool all_pre = st & ST_ALLPRE;
     uint32_t ops = 0, kfirst = K_INC, krest = K_INC;
     if (mode == M_COUNT_ONLY) {
@@ -523,11 +513,10 @@ __global__ void k_resolve_apply(FilterView fv, const uint64_t *__restrict__ uniq
     uint64_t idx[RB_MAX_HASH];
     bool conflict = (st & ST_FOREIGN) != 0;
     for (int j = 0; j < fv.cbf_h; ++j) {
-        idx[j] = pre ? pidx[j & 1] : index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod);
+        idx[j] = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod);
         if (n_foreign && !conflict) {               // did another run claim this counter after this one?  (most have not: bit filter first)
             const uint64_t b = slot_of(idx[j], csf_log2);
-            const uint32_t word = !csf ? ~0u : pre ? pcsf[j & 1] : csf[b >> 5];
-            if ((word >> (uint32_t)(b & 31u)) & 1u) conflict = table_find(cs, cs_log2, idx[j]) != nullptr;
+            if (!csf || ((csf[b >> 5] >> (uint32_t)(b & 31u)) & 1u)) conflict = table_find(cs, cs_log2, idx[j]) != nullptr;
         }
     }
     if (ops == 0) {                               // nothing to count: just drop the claim marks
