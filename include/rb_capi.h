@@ -490,7 +490,7 @@ int rb_shard_query_finish(rb_graph *g, int which_bits, const void *breply_dev, c
  * current step and replays it from there when the answers are in: the step's earlier questions are then cache hits), files the
  * requests — the four neighbours of a k-mer go out together, a naive extension's back-branch variants with them — and makes the
  * query for them (bit_counts / ctr_counts per destination rank, as rb_shard_query_make).  One exchange round per step for the
- * max-coverage walk and the naive extension, one per neighbourhood the lookahead search opens for the greedy extension.
+ * max-coverage walk and the naive extension, one per level of the lookahead search for the greedy extension.
  * kind 0 = rb_graph_walk (targets may be NULL), 1 = rb_graph_greedy_extend (mode_or_lookahead = lookahead; gate: rb_shard_trav_set_gate),
  * 2 = rb_graph_naive_extend (mode_or_lookahead = mode; term_seq / term_off for mode 0); the other arguments, the
  * outputs and the reasons are those calls'.  answer_cap: counts one step of a walk may hold (0: 4, 8, or

@@ -1610,7 +1610,10 @@ __global__ void k_greedy_extend(SRC src, uint64_t kmul, WalkGate gate, int stran
                 int psize = 1, depth = 0;                // psize = path.size(); depth = frontier.size()
                 WalkCand nb[4];
                 int nn = walk_neighbors(w, kmul, gate, stranded, uk, direction, cand[ci].f, cand[ci].r, code_of_char(sq[(size_t)len + 1u]), 1.0f, nb);
-                if (nn < 0) { suspended = true; break; }
+                // (sharded graphs: an unknown neighbourhood is filed and taken for a dead end, and the search goes on — through the
+                // siblings and the other candidates — so that ONE exchange round brings every neighbourhood that can be asked for now:
+                // a level of the search per round instead of a neighbourhood per round.  The step is replayed anyway.)
+                if (nn < 0) { suspended = true; nn = 0; }
                 if (nn == 0) score = (lookahead > 0) ? 0.0f : cand[ci].c;
                 else {
                     float best_path = 0.0f;
@@ -1623,7 +1626,7 @@ __global__ void k_greedy_extend(SRC src, uint64_t kmul, WalkGate gate, int stran
                             const WalkCand &cur = path[psize - 1];
                             // cursor = k-mer number (psize-1) after the candidate: its leaving base is sq[len + 1 + (psize-1)]
                             nn = walk_neighbors(w, kmul, gate, stranded, uk, direction, cur.f, cur.r, code_of_char(sq[(size_t)len + (size_t)psize]), 1.0f, nb);
-                            if (nn < 0) { suspended = true; break; }
+                            if (nn < 0) { suspended = true; nn = 0; }
                             if (nn > 0) {
                                 for (int q = 0; q < nn; ++q) frontier[depth][q] = nb[q];
                                 fr_n[depth] = nn; fr_next[depth] = 1; ++depth;
@@ -1649,7 +1652,6 @@ __global__ void k_greedy_extend(SRC src, uint64_t kmul, WalkGate gate, int stran
                             }
                         }
                     }
-                    if (suspended) break;
                     score = best_path;
                 }
                 if (score > best_cov) { best = ci; best_cov = score; }
