@@ -764,9 +764,9 @@ template <int MODE, bool MPF>
 __global__ void __launch_bounds__(64)
 k_filter_reads(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
                const uint32_t *__restrict__ word_read, const uint32_t *__restrict__ len, int64_t w0, int64_t nw, int k,
-               uint32_t W, uint32_t first_read, uint32_t pos_bits, uint64_t seed, uint64_t ordinal0, Npf cache, Mpf mcache,
+               uint32_t W_, uint32_t first_read, uint32_t pos_bits, uint64_t seed, uint64_t ordinal0, Npf cache, Mpf mcache,
                uint32_t *__restrict__ cnt, uint32_t *__restrict__ keepmask, uint32_t *__restrict__ total_spread,
-               uint32_t dbg_flags, OwnRange own, ulonglong2 *__restrict__ wstate) {
+               uint32_t dbg_flags, OwnRange own, ulonglong2 *__restrict__ wstate, const uint32_t *__restrict__ woff, uint32_t rd0, uint32_t n_rd) {
     __shared__ uint64_t s_tf[25], s_tr[25];
     extern __shared__ uint32_t s_ring[];                        // [k-m+1][lane], dynamic: orders of the current block of m-mers / suffix minima of the previous one
     __shared__ unsigned long long s_bkt[MPF ? 16 * 64 : 1];     // [slot][lane]: image of the current bucket
@@ -779,11 +779,15 @@ k_filter_reads(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ 
         s_tr[threadIdx.x] = rotr(sco, 1) ^ rotl(sci, uk - 1u);
     }
     __syncthreads();
-    const int64_t w = ((int64_t)blockIdx.x * 64 + threadIdx.x) * (int64_t)W;   // the read's first word, relative to w0
+    // the lane's read: every read has W words (uniform batch), or — W_ == 0 — lane t takes read rd0 + t with its own word count
+    const int64_t lane_t = (int64_t)blockIdx.x * 64 + threadIdx.x;
+    const bool active = W_ ? lane_t * (int64_t)W_ < nw : lane_t < (int64_t)n_rd;
+    const int64_t w = !active ? nw : W_ ? lane_t * (int64_t)W_ : (int64_t)woff[rd0 + (uint32_t)lane_t] - w0;   // the read's first word, relative to w0
     uint32_t total = 0;
-    if (w < nw) {
+    if (active) {
         const int64_t gw = w0 + w;
-        const uint32_t r = word_read[gw], L = len[r];
+        const uint32_t r = W_ ? word_read[gw] : rd0 + (uint32_t)lane_t, L = len[r];
+        const uint32_t W = W_ ? W_ : (L + 31u) >> 5;
         uint32_t done = 0;                                       // words whose count and mask are written
         if (uk <= L) {
             uint64_t carr[RB_READ_WORDS];
@@ -892,9 +896,9 @@ template <int MODE>
 __global__ void __launch_bounds__(64)
 k_filter_reads_pipe(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
                     const uint32_t *__restrict__ word_read, const uint32_t *__restrict__ len, int64_t w0, int64_t nw, int k,
-                    uint32_t W, uint32_t first_read, uint32_t pos_bits, uint64_t seed, uint64_t ordinal0, Mpf mcache,
+                    uint32_t W_, uint32_t first_read, uint32_t pos_bits, uint64_t seed, uint64_t ordinal0, Mpf mcache,
                     uint32_t *__restrict__ cnt, uint32_t *__restrict__ keepmask, uint32_t *__restrict__ total_spread,
-                    uint32_t dbg_flags, ulonglong2 *__restrict__ wstate) {
+                    uint32_t dbg_flags, ulonglong2 *__restrict__ wstate, const uint32_t *__restrict__ woff, uint32_t rd0, uint32_t n_rd) {
     __shared__ uint64_t s_tf[25], s_tr[25];
     extern __shared__ uint32_t s_ring[];                        // [k-m+1][lane]
     __shared__ unsigned long long s_bkt[16 * 64];               // [slot][lane]: image of the current bucket
@@ -907,11 +911,14 @@ k_filter_reads_pipe(const uint64_t *__restrict__ codes, const uint32_t *__restri
         s_tr[threadIdx.x] = rotr(sco, 1) ^ rotl(sci, uk - 1u);
     }
     __syncthreads();
-    const int64_t w = ((int64_t)blockIdx.x * 64 + threadIdx.x) * (int64_t)W;
+    const int64_t lane_t = (int64_t)blockIdx.x * 64 + threadIdx.x;          // (lane -> read as in k_filter_reads)
+    const bool active = W_ ? lane_t * (int64_t)W_ < nw : lane_t < (int64_t)n_rd;
+    const int64_t w = !active ? nw : W_ ? lane_t * (int64_t)W_ : (int64_t)woff[rd0 + (uint32_t)lane_t] - w0;
     uint32_t total = 0;
-    if (w < nw) {
+    if (active) {
         const int64_t gw = w0 + w;
-        const uint32_t r = word_read[gw], L = len[r];
+        const uint32_t r = W_ ? word_read[gw] : rd0 + (uint32_t)lane_t, L = len[r];
+        const uint32_t W = W_ ? W_ : (L + 31u) >> 5;
         uint32_t done = 0;
         if (uk <= L) {
             uint64_t carr[RB_READ_WORDS];
@@ -1318,6 +1325,12 @@ static uint32_t read_lane_words(const rb_batch *b, int64_t nw, int k) {
     if (!off && k <= 31 && b->wpr_uniform && b->wpr_uniform <= (uint32_t)RB_READ_WORDS && nw % b->wpr_uniform == 0) return b->wpr_uniform;
     return 0u;
 }
+// ... and for batches whose reads differ in length (trimmed reads: 4 or 5 words each) but all fit RB_READ_WORDS words: a lane still
+// takes a whole read, found through the batch's word offsets (RB_RAGGED_LANES=0: the one-word kernels, as before round 3)
+static bool read_lanes_ragged(const rb_batch *b, int k) {
+    const bool off = (getenv("RB_READ_LANES") && atoi(getenv("RB_READ_LANES")) == 0) || (getenv("RB_RAGGED_LANES") && atoi(getenv("RB_RAGGED_LANES")) == 0);
+    return !off && k <= 31 && !b->wpr_uniform && b->max_len <= 32u * (uint32_t)RB_READ_WORDS && !b->h_woff.empty();
+}
 void launch_filter_windows(const rb_batch *b, int64_t w0, int64_t nw, int k, int mode, uint32_t first_read,
                            uint32_t pos_bits, uint64_t seed, uint64_t ordinal0, Npf cache, uint32_t *cnt, uint32_t *keepmask,
                            uint32_t *total_spread, hipStream_t s, OwnRange own, Mpf mcache, void *wstate) {
@@ -1331,19 +1344,29 @@ void launch_filter_windows(const rb_batch *b, int64_t w0, int64_t nw, int k, int
     RB_REQUIRE(k <= 64, "prefilter kernels take k <= 64");
     const bool use_m = mcache.tab && k <= RB_MPF_MAX_K && mcache.m <= (uint32_t)k && (uint32_t)k - mcache.m + 1u <= RB_MPF_MAX_RING;
     const size_t ring_bytes = use_m ? ((size_t)k - mcache.m + 1u) * 64u * sizeof(uint32_t) : 0;   // LDS per wavefront: 12.7 KB -> 11.2 KB at k = 25
-    if (const uint32_t C = read_lane_words(b, nw, k)) {
-        dim3 gc(blocks_for(nw / C, 64));
+    const uint32_t C = read_lane_words(b, nw, k);
+    if (C || read_lanes_ragged(b, k)) {
+        uint32_t rd0 = 0, n_rd = 0;
+        if (!C) {                                              // the reads of words [w0, w0 + nw): both ends are read boundaries
+            const auto &wo = b->h_woff;
+            const int64_t r0 = std::lower_bound(wo.begin(), wo.end(), (uint32_t)w0) - wo.begin();
+            const int64_t r1 = std::lower_bound(wo.begin(), wo.end(), (uint32_t)(w0 + nw)) - wo.begin();
+            RB_REQUIRE(r0 < (int64_t)wo.size() && wo[(size_t)r0] == (uint32_t)w0 && r1 < (int64_t)wo.size() && wo[(size_t)r1] == (uint32_t)(w0 + nw),
+                       "prefilter: word range does not start and end at read boundaries");
+            rd0 = (uint32_t)r0; n_rd = (uint32_t)(r1 - r0);
+        }
+        dim3 gc(blocks_for(C ? nw / C : (int64_t)n_rd, 64));
 #define RB_LAUNCH_FC(M, P)                                                                                        \
     hipLaunchKernelGGL((k_filter_reads<M, P>), gc, t, ring_bytes, s, b->codes, b->valid, b->word_read, b->len, w0, nw, k, C, \
                        first_read, pos_bits, seed, ordinal0, cache, mcache, cnt, keepmask, total_spread, dbgf, own, \
-                       reinterpret_cast<ulonglong2 *>(wstate))
+                       reinterpret_cast<ulonglong2 *>(wstate), b->woff, rd0, n_rd)
         const int pipe = getenv("RB_FILTER_PIPE") ? atoi(getenv("RB_FILTER_PIPE")) : 1;   // 0: k_filter_reads, 1 (default): fetch one step ahead, 2: two steps (slower: every lane loads in every step)
         if (use_m && pipe && own.lo == 0 && own.hi == 0) {         // the whole index range is this handle's: the bucket fetch one / two steps ahead of its use
-#define RB_LAUNCH_FP(K, M)                                                                                           \
+#define RB_LAUNCH_FP(K, M, ...)                                                                                      \
     hipLaunchKernelGGL((K<M>), gc, t, ring_bytes, s, b->codes, b->valid, b->word_read, b->len, w0, nw, k, C,         \
-                       first_read, pos_bits, seed, ordinal0, mcache, cnt, keepmask, total_spread, dbgf, reinterpret_cast<ulonglong2 *>(wstate))
-            if (pipe == 2) { if (mode == 0) RB_LAUNCH_FP(k_filter_reads_pipe2, 0); else if (mode == 2) RB_LAUNCH_FP(k_filter_reads_pipe2, 2); else RB_LAUNCH_FP(k_filter_reads_pipe2, 1); }
-            else { if (mode == 0) RB_LAUNCH_FP(k_filter_reads_pipe, 0); else if (mode == 2) RB_LAUNCH_FP(k_filter_reads_pipe, 2); else RB_LAUNCH_FP(k_filter_reads_pipe, 1); }
+                       first_read, pos_bits, seed, ordinal0, mcache, cnt, keepmask, total_spread, dbgf, reinterpret_cast<ulonglong2 *>(wstate), ##__VA_ARGS__)
+            if (pipe == 2 && C) { if (mode == 0) RB_LAUNCH_FP(k_filter_reads_pipe2, 0); else if (mode == 2) RB_LAUNCH_FP(k_filter_reads_pipe2, 2); else RB_LAUNCH_FP(k_filter_reads_pipe2, 1); }
+            else { if (mode == 0) RB_LAUNCH_FP(k_filter_reads_pipe, 0, b->woff, rd0, n_rd); else if (mode == 2) RB_LAUNCH_FP(k_filter_reads_pipe, 2, b->woff, rd0, n_rd); else RB_LAUNCH_FP(k_filter_reads_pipe, 1, b->woff, rd0, n_rd); }
 #undef RB_LAUNCH_FP
         } else if (use_m) { if (mode == 0) RB_LAUNCH_FC(0, true); else if (mode == 2) RB_LAUNCH_FC(2, true); else RB_LAUNCH_FC(1, true); }
         else { if (mode == 0) RB_LAUNCH_FC(0, false); else if (mode == 2) RB_LAUNCH_FC(2, false); else RB_LAUNCH_FC(1, false); }
@@ -1373,7 +1396,7 @@ void launch_filter_emit(const rb_batch *b, int64_t w0, int64_t nw, int k, int mo
     if (mode == 0) RB_LAUNCH_FE(0); else if (mode == 2) RB_LAUNCH_FE(2); else RB_LAUNCH_FE(1);
 #undef RB_LAUNCH_FE
 }
-bool filter_saves_state(const rb_batch *b, int64_t nw, int k) { return read_lane_words(b, nw, k) != 0u && !(getenv("RB_EMIT_RESUME") && atoi(getenv("RB_EMIT_RESUME")) == 0); }
+bool filter_saves_state(const rb_batch *b, int64_t nw, int k) { return (read_lane_words(b, nw, k) != 0u || read_lanes_ragged(b, k)) && !(getenv("RB_EMIT_RESUME") && atoi(getenv("RB_EMIT_RESUME")) == 0); }
 void launch_hash_windows_masked(const rb_batch *b, int64_t w0, int64_t nw, int k, int mode, const uint32_t *chunk_off,
                                 const uint32_t *keepmask, uint32_t first_read, uint32_t pos_bits, uint64_t *keys, uint32_t *vals,
                                 hipStream_t s, const void *wstate, EmitRecheck recheck) {
