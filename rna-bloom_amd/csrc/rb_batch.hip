@@ -758,7 +758,7 @@ k_hash_windows_resume(const uint64_t *__restrict__ codes, const uint32_t *__rest
 // (The emit pass stays one word per lane: its records are staged through LDS in output order, and with
 // a read per lane the 64 lanes of a wavefront fill a slab one after the other instead of together —
 // measured 36 -> 70 ms.)
-constexpr int RB_READ_WORDS = 8;
+constexpr int RB_READ_WORDS = 10;     // reads of up to 320 bases (2 x 300 libraries)
 
 template <int MODE, bool MPF>
 __global__ void __launch_bounds__(64)

@@ -397,14 +397,14 @@ def test_pipeline_switches_do_not_change_results(monkeypatch, env):
 @pytest.mark.parametrize("env", [{}, {"RB_RAGGED_LANES": "0"}, {"RB_FILTER_PIPE": "0"}, {"RB_NO_MPF": "1"}, {"RB_EMIT_RESUME": "0"}])
 @pytest.mark.parametrize("k", [25, 31])
 def test_trimmed_reads_take_a_read_per_lane(monkeypatch, env, k):
-    """reads of DIFFERENT lengths that all fit eight packed words (trimmed 150-base reads: 4 or 5 words, and every edge: empty, shorter
-    than k, exactly k, 32 / 33 / 64 / 65 / 256 bases) go through the read-per-lane prefilter with the lane's read found through the
+    """reads of DIFFERENT lengths that all fit ten packed words (trimmed 150-base reads: 4 or 5 words, and every edge: empty, shorter
+    than k, exactly k, 32 / 33 / 64 / 65 / 256 / 257 / 320 bases) go through the read-per-lane prefilter with the lane's read found through the
     word offsets; many sub-batches, a hot cache, qualities that cut reads into segments, both files of a pair"""
     for k_, v in env.items():
         monkeypatch.setenv(k_, v)
-    d = synth.generate_pairs(2600, G=4000, L=256, err=0.002, n_rate=1e-3, seed=91, uniform_expr=True, frag_mean=400.0, frag_sd=30.0)
+    d = synth.generate_pairs(2600, G=4000, L=320, err=0.002, n_rate=1e-3, seed=91, uniform_expr=True, frag_mean=450.0, frag_sd=30.0)
     rng = np.random.default_rng(6)
-    edges = [0, 1, k - 1, k, k + 1, 31, 32, 33, 63, 64, 65, 127, 128, 129, 150, 255, 256]
+    edges = [0, 1, k - 1, k, k + 1, 31, 32, 33, 63, 64, 65, 127, 128, 129, 150, 255, 256, 257, 288, 289, 319, 320]
     og, gg = graph_pair(300_007, 400_009, 60_013, k=k, max_batch=15_000)
     og.set_read_pair_distance(90); gg.setReadPairedKmerDistance(90)
     for name, rc in (("left", False), ("right", True)):
@@ -412,7 +412,7 @@ def test_trimmed_reads_take_a_read_per_lane(monkeypatch, env, k):
         n = reads.shape[0]
         lens = np.where(rng.random(n) < 0.6, 150, rng.integers(100, 151, n))
         lens[rng.integers(0, n, 200)] = rng.choice(edges, 200)
-        keep = np.arange(256)[None, :] < lens[:, None]
+        keep = np.arange(320)[None, :] < lens[:, None]
         s, q = reads[keep], quals[keep]
         off = np.zeros(n + 1, np.int64); np.cumsum(lens, out=off[1:])
         og.add_reads(s, q, off, 3, rbo.STORE_READ_PAIRS | (rbo.REVCOMP if rc else 0))
