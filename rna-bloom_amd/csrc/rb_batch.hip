@@ -578,7 +578,7 @@ k_filter_windows_fast(const uint64_t *__restrict__ codes, const uint32_t *__rest
             const uint32_t rstate = rng_read_state(seed, ordinal0 + (uint64_t)(r - first_read));
             const uint32_t sh_c = 2u * (uk - 1u), sh_v = uk - 1u;
             // minimizer state (MPF)
-            const uint32_t um = MPF ? mcache.m : 1u, uw = uk - um + 1u;           // m-mers per k-mer
+            const uint32_t um = MPF ? mcache.m : 1u, uw = mpf_kp(uk) - um + 1u;           // m-mers per k-mer
             const uint32_t mmask = (um >= 16u) ? 0xFFFFFFFFu : ((1u << (2u * um)) - 1u);
             uint32_t mf = 0, mr = 0, blk_a = 0, blk_p = 0;               // position inside the current block of uw m-mers, its prefix minimum
             uint64_t cur_bkt = ~0ull;
@@ -799,7 +799,7 @@ k_filter_reads(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ 
             }
             const uint32_t rstate = rng_read_state(seed, ordinal0 + (uint64_t)(r - first_read));
             const uint32_t sh_c = 2u * (uk - 1u), sh_v = uk - 1u;
-            const uint32_t um = MPF ? mcache.m : 1u, uw = uk - um + 1u;           // m-mers per k-mer
+            const uint32_t um = MPF ? mcache.m : 1u, uw = mpf_kp(uk) - um + 1u;           // m-mers per k-mer
             const uint32_t mmask = (um >= 16u) ? 0xFFFFFFFFu : ((1u << (2u * um)) - 1u);
             uint32_t mf = 0, mr = 0, blk_a = 0, blk_p = 0;       // minimizer state, see k_filter_windows_fast
             uint64_t cur_bkt = ~0ull;
@@ -892,7 +892,7 @@ k_filter_reads(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ 
 //   b's bucket into registers if it changed  |  roll the hashes of base b  |  (next step) ... finish window b: registers -> LDS.
 // The loads are in flight while the wavefront rolls its hashes and runs the next step's minimizer update (and the other
 // wavefronts of the SIMD theirs); nothing else changes: same cache, same draws, same counts and masks per word.
-template <int MODE>
+template <int MODE, bool WIDE>
 __global__ void __launch_bounds__(64)
 k_filter_reads_pipe(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
                     const uint32_t *__restrict__ word_read, const uint32_t *__restrict__ len, int64_t w0, int64_t nw, int k,
@@ -929,13 +929,16 @@ k_filter_reads_pipe(const uint64_t *__restrict__ codes, const uint32_t *__restri
                 if ((uint32_t)q < W) { carr[q] = codes[gw + q]; varr[q] = valid[gw + q]; }
             }
             const uint32_t rstate = rng_read_state(seed, ordinal0 + (uint64_t)(r - first_read));
-            const uint32_t sh_c = 2u * (uk - 1u), sh_v = uk - 1u;
-            const uint32_t um = mcache.m, uw = uk - um + 1u;
+            // WIDE (32 <= k <= 63): 64 bases of history in two words, and the minimizer is that of the k-mer's last 31 bases
+            const uint32_t sh_c = 2u * ((uk - 1u) & 31u), sh_v = uk - 1u;
+            const bool far = WIDE && uk > 32u;                   // the outgoing base sits in the older history word
+            const uint32_t um = mcache.m, uw = mpf_kp(uk) - um + 1u;
+            const uint32_t lag = WIDE ? mpf_lag(uk) : 0u;      // the minimizer's sub-window ends `lag` bases before the k-mer does (1 <= lag <= 19 when WIDE)
             const uint32_t mmask = (um >= 16u) ? 0xFFFFFFFFu : ((1u << (2u * um)) - 1u);
             uint32_t mf = 0, mr = 0, blk_a = 0, blk_p = 0;
             uint32_t cur_bkt = ~0u;                               // (bucket numbers have at most 25 bits)
-            uint64_t f = 0, rv = 0, hc = 0, cur_c = 0;
-            uint32_t run = 0, kept = 0, mask = 0, cur_v = 0, hv = 0;     // (k <= 31: 32 bits of usable-base history suffice)
+            uint64_t f = 0, rv = 0, hc = 0, hc2 = 0, hvw = 0, cur_c = 0;
+            uint32_t run = 0, kept = 0, mask = 0, cur_v = 0, hv = 0;     // (k <= 31: 32 bits of usable-base history suffice; WIDE: hvw)
             uint32_t b = 0;
             // the window whose decision is pending: its hash, its position, whether its bucket is still in the registers
             ulonglong2 R[8];
@@ -981,8 +984,10 @@ k_filter_reads_pipe(const uint64_t *__restrict__ codes, const uint32_t *__restri
                     cur_c >>= 2; cur_v >>= 1;
                     run = ok ? run + 1u : 0u;
                     // minimizer of the window that ends at this base (garbage while run < m: never consulted then)
-                    mf = ((mf << 2) | code) & mmask;
-                    mr = (mr >> 2) | ((3u - code) << (2u * (um - 1u)));
+                    // (WIDE: the base `lag` steps back, out of the history — base b-1 sits in bits 0..1 of hc before this step's push)
+                    const uint32_t mcode = WIDE ? (uint32_t)(hc >> (2u * (lag - 1u))) & 3u : code;
+                    mf = ((mf << 2) | mcode) & mmask;
+                    mr = (mr >> 2) | ((3u - mcode) << (2u * (um - 1u)));
                     const uint32_t o_cur = mmer_order(mf < mr ? mf : mr);
                     s_ring[blk_a * 64u + lane] = o_cur;
                     blk_p = blk_a ? (o_cur < blk_p ? o_cur : blk_p) : o_cur;
@@ -1002,11 +1007,13 @@ k_filter_reads_pipe(const uint64_t *__restrict__ codes, const uint32_t *__restri
                     }
                     decide();
                     const uint32_t in5 = ok ? code + 1u : 0u;
-                    const uint32_t out5 = ((hv >> sh_v) & 1u) ? ((uint32_t)(hc >> sh_c) & 3u) + 1u : 0u;
+                    const uint32_t ok_out = WIDE ? (uint32_t)(hvw >> sh_v) & 1u : (hv >> sh_v) & 1u;
+                    const uint32_t out5 = ok_out ? ((uint32_t)((far ? hc2 : hc) >> sh_c) & 3u) + 1u : 0u;
                     const uint32_t tt = out5 * 5u + in5;
                     if (MODE != 2) f = rotl(f, 1) ^ s_tf[tt];
                     if (MODE != 0) rv = rotr(rv, 1) ^ s_tr[tt];
-                    hc = (hc << 2) | code; hv = (hv << 1) | ok;
+                    if (WIDE) { hc2 = (hc2 << 2) | (hc >> 62); hvw = (hvw << 1) | ok; } else hv = (hv << 1) | ok;
+                    hc = (hc << 2) | code;
                     pend = win; pend_sw = sw;
                     pend_h0 = (MODE == 0) ? f : (MODE == 2) ? rv : canonical(f, rv); pend_p = b + 1u - uk;   // (unused unless pend)
                     if (blk_a + 1u == uw) {   // block complete: turn its ring entries into suffix minima
@@ -1067,7 +1074,7 @@ k_filter_reads_pipe2(const uint64_t *__restrict__ codes, const uint32_t *__restr
             }
             const uint32_t rstate = rng_read_state(seed, ordinal0 + (uint64_t)(r - first_read));
             const uint32_t sh_c = 2u * (uk - 1u), sh_v = uk - 1u;
-            const uint32_t um = mcache.m, uw = uk - um + 1u;
+            const uint32_t um = mcache.m, uw = mpf_kp(uk) - um + 1u;
             const uint32_t mmask = (um >= 16u) ? 0xFFFFFFFFu : ((1u << (2u * um)) - 1u);
             uint32_t mf = 0, mr = 0, blk_a = 0, blk_p = 0;
             uint64_t cur_bkt = ~0ull;
@@ -1320,16 +1327,23 @@ void launch_hash_windows(const rb_batch *b, int64_t w0, int64_t nw, int k, int m
 
 // words per read if the read-per-lane kernels apply (uniform batch of short reads), else 0: one word per lane
 // (RB_READ_LANES=0 forces the one-word kernels)
-static uint32_t read_lane_words(const rb_batch *b, int64_t nw, int k) {
+static uint32_t read_lane_words(const rb_batch *b, int64_t nw, int k, int kmax = 31) {
     const bool off = getenv("RB_READ_LANES") && atoi(getenv("RB_READ_LANES")) == 0;
-    if (!off && k <= 31 && b->wpr_uniform && b->wpr_uniform <= (uint32_t)RB_READ_WORDS && nw % b->wpr_uniform == 0) return b->wpr_uniform;
+    if (!off && k <= kmax && b->wpr_uniform && b->wpr_uniform <= (uint32_t)RB_READ_WORDS && nw % b->wpr_uniform == 0) return b->wpr_uniform;
     return 0u;
 }
 // ... and for batches whose reads differ in length (trimmed reads: 4 or 5 words each) but all fit RB_READ_WORDS words: a lane still
 // takes a whole read, found through the batch's word offsets (RB_RAGGED_LANES=0: the one-word kernels, as before round 3)
-static bool read_lanes_ragged(const rb_batch *b, int k) {
+static bool read_lanes_ragged(const rb_batch *b, int k, int kmax = 31) {
     const bool off = (getenv("RB_READ_LANES") && atoi(getenv("RB_READ_LANES")) == 0) || (getenv("RB_RAGGED_LANES") && atoi(getenv("RB_RAGGED_LANES")) == 0);
-    return !off && k <= 31 && !b->wpr_uniform && b->max_len <= 32u * (uint32_t)RB_READ_WORDS && !b->h_woff.empty();
+    return !off && k <= kmax && !b->wpr_uniform && b->max_len <= 32u * (uint32_t)RB_READ_WORDS && !b->h_woff.empty();
+}
+// may a call with 32 <= k <= 63 use the minimizer-bucketed cache?  Only the read-per-lane kernel with the fetch ahead looks it up there.
+bool filter_wide_mpf_ok(const rb_batch *b, int64_t nw, int k) {
+    if (k <= RB_MPF_MAX_K || k > RB_MPF_WIDE_MAX_K) return false;
+    if (getenv("RB_FILTER_PIPE") && atoi(getenv("RB_FILTER_PIPE")) != 1) return false;
+    if (getenv("RB_WIDE_MPF") && atoi(getenv("RB_WIDE_MPF")) == 0) return false;
+    return read_lane_words(b, nw, k, RB_MPF_WIDE_MAX_K) != 0u || read_lanes_ragged(b, k, RB_MPF_WIDE_MAX_K);
 }
 void launch_filter_windows(const rb_batch *b, int64_t w0, int64_t nw, int k, int mode, uint32_t first_read,
                            uint32_t pos_bits, uint64_t seed, uint64_t ordinal0, Npf cache, uint32_t *cnt, uint32_t *keepmask,
@@ -1342,10 +1356,12 @@ void launch_filter_windows(const rb_batch *b, int64_t w0, int64_t nw, int k, int
     hipLaunchKernelGGL((k_filter_windows_fast<M, P, W>), g, t, ring_bytes, s, b->codes, b->valid, b->word_read, b->woff, b->len, \
                        w0, nw, k, first_read, pos_bits, seed, ordinal0, cache, mcache, cnt, keepmask, total_spread, dbgf, own)
     RB_REQUIRE(k <= 64, "prefilter kernels take k <= 64");
-    const bool use_m = mcache.tab && k <= RB_MPF_MAX_K && mcache.m <= (uint32_t)k && (uint32_t)k - mcache.m + 1u <= RB_MPF_MAX_RING;
-    const size_t ring_bytes = use_m ? ((size_t)k - mcache.m + 1u) * 64u * sizeof(uint32_t) : 0;   // LDS per wavefront: 12.7 KB -> 11.2 KB at k = 25
-    const uint32_t C = read_lane_words(b, nw, k);
-    if (C || read_lanes_ragged(b, k)) {
+    const bool wide = mcache.tab && k > RB_MPF_MAX_K;          // 32 <= k <= 63 with the minimizer-bucketed cache: add_range asked filter_wide_mpf_ok
+    if (wide) RB_REQUIRE(filter_wide_mpf_ok(b, nw, k) && own.hi == 0, "prefilter: the minimizer-bucketed cache at k = %d needs a read per lane", k);
+    const bool use_m = mcache.tab && (wide || (k <= RB_MPF_MAX_K && mcache.m <= (uint32_t)k && (uint32_t)k - mcache.m + 1u <= RB_MPF_MAX_RING));
+    const size_t ring_bytes = use_m ? ((size_t)mpf_kp((uint32_t)k) - mcache.m + 1u) * 64u * sizeof(uint32_t) : 0;   // LDS per wavefront: 12.7 KB -> 11.2 KB at k = 25
+    const uint32_t C = read_lane_words(b, nw, k, wide ? RB_MPF_WIDE_MAX_K : 31);
+    if (C || read_lanes_ragged(b, k, wide ? RB_MPF_WIDE_MAX_K : 31)) {
         uint32_t rd0 = 0, n_rd = 0;
         if (!C) {                                              // the reads of words [w0, w0 + nw): both ends are read boundaries
             const auto &wo = b->h_woff;
@@ -1360,14 +1376,23 @@ void launch_filter_windows(const rb_batch *b, int64_t w0, int64_t nw, int k, int
     hipLaunchKernelGGL((k_filter_reads<M, P>), gc, t, ring_bytes, s, b->codes, b->valid, b->word_read, b->len, w0, nw, k, C, \
                        first_read, pos_bits, seed, ordinal0, cache, mcache, cnt, keepmask, total_spread, dbgf, own, \
                        reinterpret_cast<ulonglong2 *>(wstate), b->woff, rd0, n_rd)
-        const int pipe = getenv("RB_FILTER_PIPE") ? atoi(getenv("RB_FILTER_PIPE")) : 1;   // 0: k_filter_reads, 1 (default): fetch one step ahead, 2: two steps (slower: every lane loads in every step)
+        const int pipe = wide ? 1 : getenv("RB_FILTER_PIPE") ? atoi(getenv("RB_FILTER_PIPE")) : 1;   // 0: k_filter_reads, 1 (default): fetch one step ahead, 2: two steps (slower: every lane loads in every step)
         if (use_m && pipe && own.lo == 0 && own.hi == 0) {         // the whole index range is this handle's: the bucket fetch one / two steps ahead of its use
 #define RB_LAUNCH_FP(K, M, ...)                                                                                      \
     hipLaunchKernelGGL((K<M>), gc, t, ring_bytes, s, b->codes, b->valid, b->word_read, b->len, w0, nw, k, C,         \
                        first_read, pos_bits, seed, ordinal0, mcache, cnt, keepmask, total_spread, dbgf, reinterpret_cast<ulonglong2 *>(wstate), ##__VA_ARGS__)
+#define RB_LAUNCH_FN(M)                                                                                              \
+    hipLaunchKernelGGL((k_filter_reads_pipe<M, false>), gc, t, ring_bytes, s, b->codes, b->valid, b->word_read, b->len, w0, nw, k, C, \
+                       first_read, pos_bits, seed, ordinal0, mcache, cnt, keepmask, total_spread, dbgf, reinterpret_cast<ulonglong2 *>(wstate), b->woff, rd0, n_rd)
+#define RB_LAUNCH_FW(M)                                                                                              \
+    hipLaunchKernelGGL((k_filter_reads_pipe<M, true>), gc, t, ring_bytes, s, b->codes, b->valid, b->word_read, b->len, w0, nw, k, C, \
+                       first_read, pos_bits, seed, ordinal0, mcache, cnt, keepmask, total_spread, dbgf, (ulonglong2 *)nullptr, b->woff, rd0, n_rd)
             if (pipe == 2 && C) { if (mode == 0) RB_LAUNCH_FP(k_filter_reads_pipe2, 0); else if (mode == 2) RB_LAUNCH_FP(k_filter_reads_pipe2, 2); else RB_LAUNCH_FP(k_filter_reads_pipe2, 1); }
-            else { if (mode == 0) RB_LAUNCH_FP(k_filter_reads_pipe, 0, b->woff, rd0, n_rd); else if (mode == 2) RB_LAUNCH_FP(k_filter_reads_pipe, 2, b->woff, rd0, n_rd); else RB_LAUNCH_FP(k_filter_reads_pipe, 1, b->woff, rd0, n_rd); }
+            else if (wide) { if (mode == 0) RB_LAUNCH_FW(0); else if (mode == 2) RB_LAUNCH_FW(2); else RB_LAUNCH_FW(1); }
+            else { if (mode == 0) RB_LAUNCH_FN(0); else if (mode == 2) RB_LAUNCH_FN(2); else RB_LAUNCH_FN(1); }
 #undef RB_LAUNCH_FP
+#undef RB_LAUNCH_FN
+#undef RB_LAUNCH_FW
         } else if (use_m) { if (mode == 0) RB_LAUNCH_FC(0, true); else if (mode == 2) RB_LAUNCH_FC(2, true); else RB_LAUNCH_FC(1, true); }
         else { if (mode == 0) RB_LAUNCH_FC(0, false); else if (mode == 2) RB_LAUNCH_FC(2, false); else RB_LAUNCH_FC(1, false); }
 #undef RB_LAUNCH_FC

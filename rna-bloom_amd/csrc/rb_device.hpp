@@ -252,6 +252,14 @@ __device__ __forceinline__ uint32_t rst_lookup(const Rst &c, uint64_t h0) {     
 // records sorted instead of 1.9 / 1.8 / 1.6 G; step 552 / 664 / 726 ms against 498 / 466 / 440 ms).
 constexpr uint32_t RB_MPF_MAX_RING = 16u;
 constexpr int RB_MPF_MAX_K = 31;
+// k <= 31: the bucket of a k-mer is that of the minimizer (over canonical m-mers) of the whole k-mer.  32 <= k <= 63 (round 3,
+// k_filter_reads_pipe<., true>): of its MIDDLE mpf_kp(k) = 25 or 24 bases — any function of the k-mer that consecutive windows mostly
+// share will do, but it has to be the same for both strands of a canonical k-mer (a suffix of the k-mer is not: reads of the two
+// orientations then look a k-mer up in different buckets — measured: 3.6 G records instead of 1.9 G at k = 35), hence the middle, with
+// k - kp even; and 10 k-mers per minimizer occurrence, the headline's shape, fit a bucket's 16 two-choice slots where 16 do not.
+constexpr int RB_MPF_WIDE_MAX_K = 63;
+__host__ __device__ __forceinline__ uint32_t mpf_kp(uint32_t k) { return k <= 31u ? k : 25u - ((k & 1u) ^ 1u); }
+__host__ __device__ __forceinline__ uint32_t mpf_lag(uint32_t k) { return (k - mpf_kp(k)) >> 1; }      // bases between the sub-window's end and the k-mer's
 struct Mpf {
     unsigned long long *tab;   // nullptr => disabled
     uint32_t log2b;            // log2 of the number of buckets (16 slots = 128 B each)
@@ -273,6 +281,7 @@ __host__ __device__ __forceinline__ uint64_t mpf_bucket(const Mpf &c, uint32_t o
 // minimizer order of the k-mer at position p of a read whose packed words start at `rw` (store side:
 // the resolve stages know a k-mer by hash + one occurrence id)
 __device__ __forceinline__ uint32_t window_min_order(const uint64_t *__restrict__ rw, uint32_t p, uint32_t k, uint32_t m) {
+    if (k > mpf_kp(k)) { p += mpf_lag(k); k = mpf_kp(k); }            // (the minimizer of the k-mer's middle mpf_kp(k) bases)
     const uint32_t w = p >> 5, o = p & 31u;
     uint64_t lo = rw[w], hi = (o + k > 32u) ? rw[w + 1] : 0ull, h2 = (o + k > 64u) ? rw[w + 2] : 0ull;
     if (o) {                                           // bases p.. as a 192-bit stream (k <= 64: 3 words suffice)

@@ -2196,7 +2196,9 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
     const bool use_npf = npf_path && (mode == M_ADD || mode == M_COUNT_IF_PRESENT);
     // the minimizer-bucketed cache replaces the hash-bucketed one on this path (lookups here, stores by the
     // stages that retire runs, which find a k-mer's bucket from one of its occurrences in this batch)
-    g->use_mpf = use_npf && g->mpf_log2b && !getenv("RB_NO_MPF") && (g->k > 31 || !getenv("RB_ONE_PASS_FILTER")) && (uint32_t)g->k >= g->mpf_m && (uint32_t)g->k - g->mpf_m + 1u <= RB_MPF_MAX_RING;
+    g->use_mpf = use_npf && g->mpf_log2b && !getenv("RB_NO_MPF") && (g->k > 31 || !getenv("RB_ONE_PASS_FILTER")) && (uint32_t)g->k >= g->mpf_m &&
+                 (g->k <= RB_MPF_MAX_K ? (uint32_t)g->k - g->mpf_m + 1u <= RB_MPF_MAX_RING
+                                       : filter_wide_mpf_ok(b, b->h_woff.empty() ? 0 : (int64_t)b->h_woff[(size_t)(first + n)] - (int64_t)b->h_woff[(size_t)first], g->k));
     g->seq_codes = b->codes; g->seq_woff = b->woff; g->seq_wpr = b->wpr_uniform;
     struct MpfScope { rb_graph *g; ~MpfScope() { g->use_mpf = false; g->seq_codes = nullptr; g->seq_woff = nullptr; g->seq_wpr = 0; } } mpf_scope{g};
     std::vector<Sub> subs;
@@ -2595,7 +2597,7 @@ int rb_graph_create(const rb_graph_params *p, rb_graph **out) {
             uint32_t lb = log2_ceil((uint64_t)std::max<int64_t>(p->cbf_bytes / 256, 1));
             lb = std::max(12u, std::min(25u, lb));
             if (e) lb = (uint32_t)atoi(e);
-            if (lb >= 8 && lb <= 28 && p->k <= RB_MPF_MAX_K && p->k >= 8) {
+            if (lb >= 8 && lb <= 28 && p->k <= RB_MPF_WIDE_MAX_K && p->k >= 8) {       // (32 <= k <= 63: used by the read-per-lane prefilter only, add_range decides per batch)
                 g->mpf.reserve((size_t)128 << lb);
                 RB_HIP(hipMemset(g->mpf.p, 0, (size_t)128 << lb));
                 g->mpf_log2b = lb;

@@ -21,6 +21,7 @@ void launch_filter_windows(const rb_batch *b, int64_t w0, int64_t nw, int k, int
                            uint32_t *total_spread, hipStream_t s, OwnRange own = OwnRange{Mod{1, 0, 0}, 0, 0},
                            Mpf mcache = Mpf{nullptr, 0, 0},    // mcache.tab != nullptr: minimizer-bucketed cache instead of `cache`
                            void *wstate = nullptr);            // filter_saves_state(): 16 B per word for the resuming emit pass
+bool filter_wide_mpf_ok(const rb_batch *b, int64_t nw, int k);   // 32 <= k <= 63: may the minimizer-bucketed cache be used for this batch?
 bool filter_saves_state(const rb_batch *b, int64_t nw, int k);
 // one pass: ownership test + prefilter + dense ordered emit of the kept (h0, occurrence) records into
 // keys/vals (capacity `cap` records; *kept_out = number kept even if it exceeds cap — then retry with

@@ -488,8 +488,10 @@ def test_wide_k_takes_the_prefiltered_path(k, stranded, monkeypatch):
         seqs.append(s); quals.append(q)
     seq = np.concatenate(seqs); qual = np.concatenate(quals)
     off = np.concatenate([[0], np.cumsum([x.size for x in seqs])]).astype(np.int64)
-    for wide in ("1", "0"):
-        monkeypatch.setenv("RB_WIDE_PREFILTER", wide)
+    # (round 3: reads of up to 320 bases at k <= 63 take the read-per-lane prefilter with the minimizer-bucketed cache, the bucket of a
+    # k-mer being that of its last 31 bases' minimizer; RB_WIDE_MPF=0: the hash-bucketed cache and the one-word kernels as before)
+    for wide, wmpf in (("1", "1"), ("1", "0"), ("0", "1")):
+        monkeypatch.setenv("RB_WIDE_PREFILTER", wide); monkeypatch.setenv("RB_WIDE_MPF", wmpf)
         og, gg = graph_pair(150_001, 200_003, 30_011, k=k, stranded=stranded, max_batch=15_000)
         og.set_read_pair_distance(30); gg.setReadPairedKmerDistance(30)
         for rc in (False, True):
