@@ -578,7 +578,8 @@ k_filter_windows_fast(const uint64_t *__restrict__ codes, const uint32_t *__rest
             const uint32_t rstate = rng_read_state(seed, ordinal0 + (uint64_t)(r - first_read));
             const uint32_t sh_c = 2u * (uk - 1u), sh_v = uk - 1u;
             // minimizer state (MPF)
-            const uint32_t um = MPF ? mcache.m : 1u, uw = mpf_kp(uk) - um + 1u;           // m-mers per k-mer
+            const uint32_t um = MPF ? mcache.m : 1u, uw = mpf_kp(uk) - um + 1u;           // m-mers per k-mer (of its middle mpf_kp(k) bases)
+            const uint32_t lag = MPF ? mpf_lag(uk) : 0u;                                  // ... whose last base is `lag` bases behind the k-mer's
             const uint32_t mmask = (um >= 16u) ? 0xFFFFFFFFu : ((1u << (2u * um)) - 1u);
             uint32_t mf = 0, mr = 0, blk_a = 0, blk_p = 0;               // position inside the current block of uw m-mers, its prefix minimum
             uint64_t cur_bkt = ~0ull;
@@ -593,8 +594,9 @@ k_filter_windows_fast(const uint64_t *__restrict__ codes, const uint32_t *__rest
                 run = ok ? run + 1u : 0u;
                 uint32_t o_cur = 0;
                 if (MPF) {   // canonical m-mer ending at this base (garbage while run < m: never consulted then)
-                    mf = ((mf << 2) | code) & mmask;
-                    mr = (mr >> 2) | ((3u - code) << (2u * (um - 1u)));
+                    const uint32_t mcode = (uint32_t)(ww.hc >> (2u * lag)) & 3u;      // the base `lag` steps back (this step's base is in already)
+                    mf = ((mf << 2) | mcode) & mmask;
+                    mr = (mr >> 2) | ((3u - mcode) << (2u * (um - 1u)));
                     o_cur = mmer_order(mf < mr ? mf : mr);
                     s_ring[blk_a * 64u + lane] = o_cur;
                     blk_p = blk_a ? (o_cur < blk_p ? o_cur : blk_p) : o_cur;      // prefix minimum of the current block of uw positions
@@ -799,7 +801,8 @@ k_filter_reads(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ 
             }
             const uint32_t rstate = rng_read_state(seed, ordinal0 + (uint64_t)(r - first_read));
             const uint32_t sh_c = 2u * (uk - 1u), sh_v = uk - 1u;
-            const uint32_t um = MPF ? mcache.m : 1u, uw = mpf_kp(uk) - um + 1u;           // m-mers per k-mer
+            const uint32_t um = MPF ? mcache.m : 1u, uw = mpf_kp(uk) - um + 1u;           // m-mers per k-mer (of its middle mpf_kp(k) bases)
+            const uint32_t lag = MPF ? mpf_lag(uk) : 0u;
             const uint32_t mmask = (um >= 16u) ? 0xFFFFFFFFu : ((1u << (2u * um)) - 1u);
             uint32_t mf = 0, mr = 0, blk_a = 0, blk_p = 0;       // minimizer state, see k_filter_windows_fast
             uint64_t cur_bkt = ~0ull;
@@ -832,8 +835,9 @@ k_filter_reads(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ 
                     run = ok ? run + 1u : 0u;
                     uint32_t o_cur = 0;
                     if (MPF) {   // canonical m-mer ending at this base (garbage while run < m: never consulted then)
-                        mf = ((mf << 2) | code) & mmask;
-                        mr = (mr >> 2) | ((3u - code) << (2u * (um - 1u)));
+                        const uint32_t mcode = (uint32_t)(hc >> (2u * lag)) & 3u;     // the base `lag` steps back (this step's base is in already)
+                        mf = ((mf << 2) | mcode) & mmask;
+                        mr = (mr >> 2) | ((3u - mcode) << (2u * (um - 1u)));
                         o_cur = mmer_order(mf < mr ? mf : mr);
                         s_ring[blk_a * 64u + lane] = o_cur;
                         blk_p = blk_a ? (o_cur < blk_p ? o_cur : blk_p) : o_cur;
@@ -933,7 +937,7 @@ k_filter_reads_pipe(const uint64_t *__restrict__ codes, const uint32_t *__restri
             const uint32_t sh_c = 2u * ((uk - 1u) & 31u), sh_v = uk - 1u;
             const bool far = WIDE && uk > 32u;                   // the outgoing base sits in the older history word
             const uint32_t um = mcache.m, uw = mpf_kp(uk) - um + 1u;
-            const uint32_t lag = WIDE ? mpf_lag(uk) : 0u;      // the minimizer's sub-window ends `lag` bases before the k-mer does (1 <= lag <= 19 when WIDE)
+            const uint32_t lag = mpf_lag(uk);                  // the minimizer's sub-window ends `lag` bases before the k-mer does (0 for k <= 25, at most 19)
             const uint32_t mmask = (um >= 16u) ? 0xFFFFFFFFu : ((1u << (2u * um)) - 1u);
             uint32_t mf = 0, mr = 0, blk_a = 0, blk_p = 0;
             uint32_t cur_bkt = ~0u;                               // (bucket numbers have at most 25 bits)
@@ -985,7 +989,7 @@ k_filter_reads_pipe(const uint64_t *__restrict__ codes, const uint32_t *__restri
                     run = ok ? run + 1u : 0u;
                     // minimizer of the window that ends at this base (garbage while run < m: never consulted then)
                     // (WIDE: the base `lag` steps back, out of the history — base b-1 sits in bits 0..1 of hc before this step's push)
-                    const uint32_t mcode = WIDE ? (uint32_t)(hc >> (2u * (lag - 1u))) & 3u : code;
+                    const uint32_t mcode = lag ? (uint32_t)(hc >> (2u * (lag - 1u))) & 3u : code;
                     mf = ((mf << 2) | mcode) & mmask;
                     mr = (mr >> 2) | ((3u - mcode) << (2u * (um - 1u)));
                     const uint32_t o_cur = mmer_order(mf < mr ? mf : mr);
@@ -1074,7 +1078,7 @@ k_filter_reads_pipe2(const uint64_t *__restrict__ codes, const uint32_t *__restr
             }
             const uint32_t rstate = rng_read_state(seed, ordinal0 + (uint64_t)(r - first_read));
             const uint32_t sh_c = 2u * (uk - 1u), sh_v = uk - 1u;
-            const uint32_t um = mcache.m, uw = mpf_kp(uk) - um + 1u;
+            const uint32_t um = mcache.m, uw = mpf_kp(uk) - um + 1u, lag = mpf_lag(uk);
             const uint32_t mmask = (um >= 16u) ? 0xFFFFFFFFu : ((1u << (2u * um)) - 1u);
             uint32_t mf = 0, mr = 0, blk_a = 0, blk_p = 0;
             uint64_t cur_bkt = ~0ull;
@@ -1105,8 +1109,9 @@ k_filter_reads_pipe2(const uint64_t *__restrict__ codes, const uint32_t *__restr
                 const uint32_t code = (uint32_t)cur_c & 3u, ok = cur_v & 1u;
                 cur_c >>= 2; cur_v >>= 1;
                 run = ok ? run + 1u : 0u;
-                mf = ((mf << 2) | code) & mmask;
-                mr = (mr >> 2) | ((3u - code) << (2u * (um - 1u)));
+                const uint32_t mcode = lag ? (uint32_t)(hc >> (2u * (lag - 1u))) & 3u : code;
+                mf = ((mf << 2) | mcode) & mmask;
+                mr = (mr >> 2) | ((3u - mcode) << (2u * (um - 1u)));
                 const uint32_t o_cur = mmer_order(mf < mr ? mf : mr);
                 s_ring[blk_a * 64u + lane] = o_cur;
                 blk_p = blk_a ? (o_cur < blk_p ? o_cur : blk_p) : o_cur;

@@ -421,7 +421,7 @@ def test_trimmed_reads_take_a_read_per_lane(monkeypatch, env, k):
     assert og.cbf_bytes().max() > 30 and st.sorted_kmers < st.kmers
 
 
-@pytest.mark.parametrize("k", [9, 12, 16, 17, 20, 31])
+@pytest.mark.parametrize("k", [9, 12, 16, 17, 20, 26, 28, 29, 31])
 def test_small_and_boundary_k_through_the_prefiltered_path(k):
     """k = 31 uses all 16 slots of the minimizer ring (k - m + 1 = 16), k <= 16 makes the minimizer the k-mer
     itself, k = 9 is below the minimizer cache's range... all must stay exact"""
