@@ -699,13 +699,15 @@ k_hash_windows_resume(const uint64_t *__restrict__ codes, const uint32_t *__rest
             b0 = c * 32u;
             keep = keepmask[i];
             const uint32_t nwords = (L + 31u) >> 5;
-            const uint64_t cur = codes[w], nxt = (c + 1u < nwords) ? codes[w + 1] : 0ull;
-            const uint32_t curv = valid[w], nxtv = (c + 1u < nwords) ? valid[w + 1] : 0u;
+            const uint64_t cur = codes[w];
+            const uint32_t curv = valid[w];
             const uint32_t pl = c ? (uint32_t)(codes[w - 1] >> 62) : 0u, plv = c ? (valid[w - 1] >> 31) : 0u;
             outs = (cur << 2) | pl;  outv = (curv << 1) | plv;                       // base b0 - 1 + t
-            const uint32_t sh = uk - 1u;                                              // base b0 + k - 1 + t
-            ins = sh ? ((cur >> (2u * sh)) | (nxt << (64u - 2u * sh))) : cur;
-            inv = sh ? ((curv >> sh) | (nxtv << (32u - sh))) : curv;
+            const uint32_t q = (uk - 1u) >> 5, sh = (uk - 1u) & 31u;                  // base b0 + k - 1 + t: q words on (k <= 63: 0 or 1)
+            const uint64_t lo = q ? ((c + q < nwords) ? codes[w + q] : 0ull) : cur, hi = (c + q + 1u < nwords) ? codes[w + q + 1u] : 0ull;
+            const uint32_t lov = q ? ((c + q < nwords) ? valid[w + q] : 0u) : curv, hiv = (c + q + 1u < nwords) ? valid[w + q + 1u] : 0u;
+            ins = sh ? ((lo >> (2u * sh)) | (hi << (64u - 2u * sh))) : lo;
+            inv = sh ? ((lov >> sh) | (hiv << (32u - sh))) : lov;
             const ulonglong2 st = wstate[i];
             f = st.x; rv = st.y;
             out = chunk_off[i] - O0;
@@ -1391,7 +1393,7 @@ void launch_filter_windows(const rb_batch *b, int64_t w0, int64_t nw, int k, int
                        first_read, pos_bits, seed, ordinal0, mcache, cnt, keepmask, total_spread, dbgf, reinterpret_cast<ulonglong2 *>(wstate), b->woff, rd0, n_rd)
 #define RB_LAUNCH_FW(M)                                                                                              \
     hipLaunchKernelGGL((k_filter_reads_pipe<M, true>), gc, t, ring_bytes, s, b->codes, b->valid, b->word_read, b->len, w0, nw, k, C, \
-                       first_read, pos_bits, seed, ordinal0, mcache, cnt, keepmask, total_spread, dbgf, (ulonglong2 *)nullptr, b->woff, rd0, n_rd)
+                       first_read, pos_bits, seed, ordinal0, mcache, cnt, keepmask, total_spread, dbgf, reinterpret_cast<ulonglong2 *>(wstate), b->woff, rd0, n_rd)
             if (pipe == 2 && C) { if (mode == 0) RB_LAUNCH_FP(k_filter_reads_pipe2, 0); else if (mode == 2) RB_LAUNCH_FP(k_filter_reads_pipe2, 2); else RB_LAUNCH_FP(k_filter_reads_pipe2, 1); }
             else if (wide) { if (mode == 0) RB_LAUNCH_FW(0); else if (mode == 2) RB_LAUNCH_FW(2); else RB_LAUNCH_FW(1); }
             else { if (mode == 0) RB_LAUNCH_FN(0); else if (mode == 2) RB_LAUNCH_FN(2); else RB_LAUNCH_FN(1); }
@@ -1426,6 +1428,8 @@ void launch_filter_emit(const rb_batch *b, int64_t w0, int64_t nw, int k, int mo
     if (mode == 0) RB_LAUNCH_FE(0); else if (mode == 2) RB_LAUNCH_FE(2); else RB_LAUNCH_FE(1);
 #undef RB_LAUNCH_FE
 }
+// ... and at 32 <= k <= 63, when the call goes through the read-per-lane kernel with the minimizer-bucketed cache (add_range knows)
+bool filter_saves_state_wide(const rb_batch *b, int64_t nw, int k) { return filter_wide_mpf_ok(b, nw, k) && !(getenv("RB_EMIT_RESUME") && atoi(getenv("RB_EMIT_RESUME")) == 0); }
 bool filter_saves_state(const rb_batch *b, int64_t nw, int k) { return (read_lane_words(b, nw, k) != 0u || read_lanes_ragged(b, k)) && !(getenv("RB_EMIT_RESUME") && atoi(getenv("RB_EMIT_RESUME")) == 0); }
 void launch_hash_windows_masked(const rb_batch *b, int64_t w0, int64_t nw, int k, int mode, const uint32_t *chunk_off,
                                 const uint32_t *keepmask, uint32_t first_read, uint32_t pos_bits, uint64_t *keys, uint32_t *vals,

@@ -2286,7 +2286,7 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
                 RB_HIP(hipMemsetAsync(g->npf_tot.p, 0, 2048, sp));
                 FilterView fvp = g->view(ord0, pos_bits);
                 void *wstate = nullptr;
-                if (filter_saves_state(b, sb.nw, g->k)) { g->wstate.reserve(((size_t)sb.nw + 1) * 16); wstate = g->wstate.p; }
+                if (g->k > RB_MPF_MAX_K ? (g->use_mpf && filter_saves_state_wide(b, sb.nw, g->k)) : filter_saves_state(b, sb.nw, g->k)) { g->wstate.reserve(((size_t)sb.nw + 1) * 16); wstate = g->wstate.p; }
                 launch_filter_windows(b, sb.w0, sb.nw, g->k, mode_hash, (uint32_t)sb.r0, pos_bits, g->p.rng_seed, ord0, fvp.npf,
                                       g->chunk_cnt.as<uint32_t>(), g->chunk_mask.as<uint32_t>(), g->npf_tot.as<uint32_t>(), sp, OwnRange{Mod{1, 0, 0}, 0, 0}, fvp.mpf, wstate);
                 exclusive_scan_u32(g->temp2.p, g->temp2.cap, g->chunk_cnt.as<uint32_t>(), g->chunk_off.as<uint32_t>(), (size_t)sb.nw + 1, sp);

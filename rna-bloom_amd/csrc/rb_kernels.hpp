@@ -23,6 +23,7 @@ void launch_filter_windows(const rb_batch *b, int64_t w0, int64_t nw, int k, int
                            void *wstate = nullptr);            // filter_saves_state(): 16 B per word for the resuming emit pass
 bool filter_wide_mpf_ok(const rb_batch *b, int64_t nw, int k);   // 32 <= k <= 63: may the minimizer-bucketed cache be used for this batch?
 bool filter_saves_state(const rb_batch *b, int64_t nw, int k);
+bool filter_saves_state_wide(const rb_batch *b, int64_t nw, int k);
 // one pass: ownership test + prefilter + dense ordered emit of the kept (h0, occurrence) records into
 // keys/vals (capacity `cap` records; *kept_out = number kept even if it exceeds cap — then retry with
 // room).  `state`: scratch of filter_emit_state_bytes(nw) bytes.
