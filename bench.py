@@ -29,7 +29,7 @@ HBM_PEAK_GBS = 8000.0           # MI355X spec HBM3E bandwidth (MI355X_MICROARCH.
 SECTOR = 64                     # bytes moved per random probe (SURVEY.md §8(d) sector model; matches FETCH_SIZE)
 
 
-def algorithmic_bytes(stage, n_kmers, n_pairs, n_runs, words, n_sorted=None, group_bits=32, h=2, sharded=False):
+def algorithmic_bytes(stage, n_kmers, n_pairs, n_runs, words, n_sorted=None, group_bits=32, h=2, sharded=False, k=25):
     """ALGORITHMIC bytes one step moves in each pipeline stage.
     n_kmers = k-mer occurrences, n_sorted = occurrences that survive the no-op prefilter,
     n_pairs = paired k-mers, n_runs = distinct runs, words = 32-base words."""
@@ -41,7 +41,8 @@ def algorithmic_bytes(stage, n_kmers, n_pairs, n_runs, words, n_sorted=None, gro
         # single GPU: + the rolling state saved for the emit pass (16 B/word)
         # minimizer-bucketed cache (k <= 31): a 128 B bucket is fetched when the window's minimizer changes,
         # on average every (k - m + 2) / 2 = 5.5 windows (k = 25, m = 16); sharded engine: one 64 B line per window
-        "filter_windows": words * (24 if sharded else 40) + (n_all * 128 * 2 // 11 if not sharded else n_all * SECTOR),
+        # (round 3: the minimizer is that of the k-mer's middle kp = min(k, 21 or 20) bases: a fetch every (kp - m + 2) / 2 windows)
+        "filter_windows": words * (24 if sharded else 40) + (int(n_all * 128 * 2 / (mpf_kp(k) - min(16, k) + 2)) if not sharded else n_all * SECTOR),
         # one-pass prefilter + emit: packed reads in (16 B/word), one 64 B cache sector per window, survivors out (12 B)
         "filter_emit": words * 16 + n_all * SECTOR + n_kmers * 12,
         # grouping stage (csrc/rb_group.hip), per launch of each kernel: the histogram pass reads the 8-byte keys; a partition
@@ -86,6 +87,11 @@ PMC_FILES = ("r03_pmc_fetch_size.csv", "r03_pmc_write_size.csv")
 # streaming kernels and for filter_windows (its traffic is 128-byte bucket fetches), x 1 for kernels whose requests are
 # single words at random places.
 FETCH_FACTOR = {"filter_windows": 2.0, "group_part_count": 2.0, "group_part_scatter": 2.0, "group_buckets": 2.0, "hash_windows": 2.0}
+
+
+def mpf_kp(k):
+    """csrc/rb_device.hpp mpf_kp: width of the k-mer's middle piece whose minimizer picks the prefilter cache's bucket"""
+    return k if k <= 21 else 21 - ((k & 1) ^ 1)
 
 
 def pmc_traffic(stage):
@@ -272,13 +278,13 @@ def main():
         per_stage, per_stage_gb = {}, {}
         default_cfg = (a.pairs, a.genome, a.nk, a.k, a.batch_kmers, sharded_mode) == (50_000_000, 64_000_000, 450_000_000, 25, 0, False)
         for name, (ms, launches) in prof.items():
-            ab = algorithmic_bytes(name, kmers, pairs_ins, distinct, words, n_sorted, sharded=sharded_mode)
+            ab = algorithmic_bytes(name, kmers, pairs_ins, distinct, words, n_sorted, sharded=sharded_mode, k=k)
             if ab and ms > 0:
                 per_stage[name] = round(ab / (ms * 1e-3) / 1e9, 1)
                 cb = pmc_step_bytes(name) if default_cfg else None
                 per_stage_gb[name] = {"model": round(ab / a.steps / 1e9, 1), "counters": round(cb / 1e9, 1) if cb else None}
         if dom_launches:
-            ab = algorithmic_bytes(dom_name, kmers, pairs_ins, distinct, words, n_sorted, sharded=sharded_mode)
+            ab = algorithmic_bytes(dom_name, kmers, pairs_ins, distinct, words, n_sorted, sharded=sharded_mode, k=k)
             if ab:
                 achieved = ab / (dom_ms * 1e-3) / 1e9      # = bytes per launch / average launch duration
                 traffic = pmc_traffic(dom_name) if default_cfg else None      # the PMC passes profiled exactly this command

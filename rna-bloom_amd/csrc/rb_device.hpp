@@ -252,13 +252,16 @@ __device__ __forceinline__ uint32_t rst_lookup(const Rst &c, uint64_t h0) {     
 // records sorted instead of 1.9 / 1.8 / 1.6 G; step 552 / 664 / 726 ms against 498 / 466 / 440 ms).
 constexpr uint32_t RB_MPF_MAX_RING = 16u;
 constexpr int RB_MPF_MAX_K = 31;
-// k <= 25: the bucket of a k-mer is that of the minimizer (over canonical m-mers) of the whole k-mer.  26 <= k <= 63 (round 3; above 31
-// through k_filter_reads_pipe<., true> only): of its MIDDLE mpf_kp(k) = 25 or 24 bases — any function of the k-mer that consecutive windows mostly
+// k <= 21: the bucket of a k-mer is that of the minimizer (over canonical m-mers) of the whole k-mer.  22 <= k <= 63 (round 3; above 31
+// through k_filter_reads_pipe<., true> only): of its MIDDLE mpf_kp(k) = 21 or 20 bases — any function of the k-mer that consecutive windows mostly
 // share will do, but it has to be the same for both strands of a canonical k-mer (a suffix of the k-mer is not: reads of the two
 // orientations then look a k-mer up in different buckets — measured: 3.6 G records instead of 1.9 G at k = 35), hence the middle, with
 // k - kp even; and 10 k-mers per minimizer occurrence, the headline's shape, fit a bucket's 16 two-choice slots where 16 do not.
 constexpr int RB_MPF_WIDE_MAX_K = 63;
-__host__ __device__ __forceinline__ uint32_t mpf_kp(uint32_t k) { return k <= 25u ? k : 25u - ((k & 1u) ^ 1u); }
+#ifndef RB_MPF_KP_TARGET
+#define RB_MPF_KP_TARGET 21u      // (odd.  25 / 23 / 21 / 19 / 17 measured: profiles/r03_kp.txt — narrower = fewer k-mers per bucket = fewer records, but more fetches)
+#endif
+__host__ __device__ __forceinline__ uint32_t mpf_kp(uint32_t k) { return k <= RB_MPF_KP_TARGET ? k : RB_MPF_KP_TARGET - ((k & 1u) ^ 1u); }
 __host__ __device__ __forceinline__ uint32_t mpf_lag(uint32_t k) { return (k - mpf_kp(k)) >> 1; }      // bases between the sub-window's end and the k-mer's
 struct Mpf {
     unsigned long long *tab;   // nullptr => disabled
