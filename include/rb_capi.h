@@ -511,6 +511,10 @@ int rb_shard_trav_absorb(rb_graph *g, const void *breply_dev, const void *creply
 int rb_shard_trav_end(rb_graph *g, char *out_bases, uint64_t *out_f, uint64_t *out_r, float *out_count, int32_t *out_len,
                       uint8_t *out_reason, int64_t *rounds);
 
+/* development: milliseconds for 2 x 2^28 random returning atomics on the counting filter where it lies (mode 0: OR with 0, 1: XOR pairs that
+ * restore the contents) — tools/alloc_lottery.py looks for what the probe stages' allocation-dependent time follows */
+int rb_debug_probe_cbf(rb_graph *g, int mode, float *ms_out);
+
 /* ---- the exchange driver below the C ABI (csrc/rb_comm.hip) ----
  * rb_shard_add_range = rnabloom/sharded.py::ShardRank.add_range in the library: all sub-batches of reads [first, first + n)
  * (the same call on every rank, every rank holding the same batch), every phase above and every exchange between them, on the

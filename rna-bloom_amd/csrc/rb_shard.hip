@@ -991,8 +991,7 @@ int rb_graph_create_shard(const rb_graph_params *p, int shard_rank, int shard_co
         g->cbf_alloc = (((size_t)(gc.hi - gc.lo) + 3) / 4 + 1) * 4;
         g->cbf_h = p->cbf_num_hash;
         g->cbf_mod = make_mod((uint64_t)p->cbf_bytes);
-        RB_HIP(hipMalloc(&g->cbf, g->cbf_alloc));
-        RB_HIP(hipMemset(g->cbf, 0, g->cbf_alloc));
+        g->cbf = static_cast<uint8_t *>(rb::alloc_best_placed(g->cbf_alloc, "cbf shard"));
         if (p->use_read_paired_kmers) {
             RB_REQUIRE(p->pkbf_bits > 0 && p->pkbf_num_hash >= 1 && p->pkbf_num_hash <= RB_MAX_HASH, "rb_graph_create_shard: pair filter parameters invalid");
             Geometry gp = geom(p->pkbf_bits, shard_rank, shard_count);

@@ -90,7 +90,7 @@ def test_every_native_method_has_a_jni_function_that_calls_the_c_abi():
         called |= hits
     # everything a single-process host needs is reachable from Java (the rb_shard_* phases belong to the multi-GPU driver)
     missing = {s for s in exported - called if not s.startswith("rb_shard_") and s not in (
-        "rb_last_error", "rb_graph_create_shard", "rb_graph_profile_enable", "rb_graph_profile_get", "rb_batch_create_synthetic",
+        "rb_last_error", "rb_graph_create_shard", "rb_graph_profile_enable", "rb_graph_profile_get", "rb_batch_create_synthetic", "rb_debug_probe_cbf",
         "rb_batch_download_ascii", "rb_nthash_batch", "rb_graph_add_batch")}
     assert not missing, missing
 

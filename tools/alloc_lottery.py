@@ -31,6 +31,11 @@ for it in range(rounds):
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         pr = g.profileGet(True)
         res.append((dt * 1e3, pr["probe_claim"][0], pr["resolve_apply"][0], pr["filter_windows"][0]))
+    import ctypes as C
+    pr0, pr1 = C.c_float(), C.c_float()
+    N.check(N.lib.rb_debug_probe_cbf(g.h, 0, C.byref(pr0))); N.check(N.lib.rb_debug_probe_cbf(g.h, 1, C.byref(pr1)))
+    N.check(N.lib.rb_debug_probe_cbf(g.h, 0, C.byref(pr0))); N.check(N.lib.rb_debug_probe_cbf(g.h, 1, C.byref(pr1)))
+    print("   2 x 2^28 random atomics on its counting filter: OR 0 %.2f ms, XOR pairs %.2f ms" % (pr0.value, pr1.value))
     print("allocation %d%s: step %.1f ms, probe_claim %.1f, resolve_apply %.1f, filter_windows %.1f  (first step %.1f / %.1f)"
           % (it, " (made while the one before was still held)" if it % 2 == 1 else "", res[1][0], res[1][1], res[1][2], res[1][3], res[0][0], res[0][1]), flush=True)
     if it % 2 == 0: held = g
