@@ -1,3 +1,4 @@
+# A/B of RB_ALLOC_TRIES = 1 / 4 in fresh processes (profiles/r03_alloc_lottery.txt); run through gpurun
 cd $GRAFT_REPO_ROOT
 for i in 1 2 3; do
 for t in 1 4; do RB_ALLOC_TRIES=$t RB_ALLOC_DEBUG=1 python bench.py --no-cpu-baseline --steps 2 --warmup 1 2>/tmp/err.txt | python -c "

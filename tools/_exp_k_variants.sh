@@ -1,3 +1,4 @@
+# bench.py at other k and with unmasked errors (profiles/r03_variants.txt); run through gpurun
 cd $GRAFT_REPO_ROOT
 one() { name=$1; shift; env "$@" 2>/dev/null | python -c "
 import json,sys
