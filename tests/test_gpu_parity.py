@@ -394,6 +394,24 @@ def test_pipeline_switches_do_not_change_results(monkeypatch, env):
     assert st.sorted_kmers < st.kmers         # and the prefilter is doing something
 
 
+@pytest.mark.parametrize("tries", ["1", "4"])
+def test_counting_filter_placement_trial_leaves_the_filter_clear(monkeypatch, capfd, tries):
+    """a counting filter of 1 GB and more is placed by a trial (csrc/rb_graph.hip: alloc_best_placed: up to RB_ALLOC_TRIES
+    allocations, each timed with random XOR pairs, the fastest kept): the XORs must cancel — the filter starts clear and ends
+    as the oracle's, whichever allocation won"""
+    monkeypatch.setenv("RB_ALLOC_TRIES", tries); monkeypatch.setenv("RB_ALLOC_DEBUG", "1")
+    d = synth.generate_pairs(1500, G=20000, err=0.002, n_rate=1e-3, seed=5, uniform_expr=True)
+    og, gg = graph_pair(3_000_017, (1 << 30) + 12_345, 400_009)
+    err = capfd.readouterr().err
+    assert err.count("cbf allocation") == int(tries), err
+    assert gg.popcount(N.CBF) == 0
+    og.set_read_pair_distance(115); gg.setReadPairedKmerDistance(115)
+    s, off = synth.flat(d["left"]); q, _ = synth.flat(d["lqual"])
+    og.add_reads(s, q, off, 3, rbo.STORE_READ_PAIRS)
+    gg.addReads(s, q, off, 3, storeReadPairedKmers=True)
+    assert_same_state(og, gg)
+
+
 @pytest.mark.parametrize("env", [{}, {"RB_RAGGED_LANES": "0"}, {"RB_FILTER_PIPE": "0"}, {"RB_NO_MPF": "1"}, {"RB_EMIT_RESUME": "0"}])
 @pytest.mark.parametrize("k", [25, 31])
 def test_trimmed_reads_take_a_read_per_lane(monkeypatch, env, k):
