@@ -1902,7 +1902,7 @@ void rb::alloc_bits(BitFilter &f, int64_t bits, int num_hash, int64_t lo, int64_
 // ALLOCATION: graphs made one after the other in one process differ like that, each keeps its time for as long as it lives, and the time
 // follows what a short kernel of random read-modify-write atomics measures on the fresh allocation (24.8 ... 30.6 ms for 2 x 2^28 XORs;
 // random READS do not differ: tools/alloc_lottery.py, profiles/r03_alloc_lottery.txt).  Which physical pages an allocation gets is the
-// driver's business; what the library can do is look: up to RB_ALLOC_TRIES (default 4; 1 = take the first) allocations are made, each
+// driver's business; what the library can do is look: up to RB_ALLOC_TRIES (default 8; 1 = take the first) allocations are made, each
 // while the earlier ones are still held so that it gets other pages, each timed with 2 x 2^26 random XOR pairs (the second pass
 // restores the zeros), and the fastest is kept.  Only for filters of 1 GB and more, and only while the device has room for the copies.
 namespace {
@@ -1918,8 +1918,8 @@ __global__ void k_alloc_probe(uint32_t *words, uint64_t n_words, uint32_t per_th
 }
 }  // namespace
 void *rb::alloc_best_placed(size_t bytes, const char *what) {
-    int tries = getenv("RB_ALLOC_TRIES") ? atoi(getenv("RB_ALLOC_TRIES")) : 4;
-    tries = std::max(1, std::min(8, tries));
+    int tries = getenv("RB_ALLOC_TRIES") ? atoi(getenv("RB_ALLOC_TRIES")) : 8;
+    tries = std::max(1, std::min(16, tries));
     if (bytes < ((size_t)1 << 30)) tries = 1;
     void *best = nullptr;
     float best_ms = 0;
