@@ -484,7 +484,7 @@ def test_ragged_reads_fuzz(seed):
             assert_same_state(og, gg)
 
 
-@pytest.mark.parametrize("k,stranded", [(32, False), (33, False), (35, True), (47, False), (63, False), (64, False), (64, True)])
+@pytest.mark.parametrize("k,stranded", [(32, False), (33, False), (35, True), (40, True), (47, False), (48, False), (62, False), (63, False), (64, False), (64, True)])
 def test_wide_k_takes_the_prefiltered_path(k, stranded, monkeypatch):
     """32 <= k <= 64: the word-per-lane walkers with three words of input and 128 bits of history per lane
     (WordWalk<true>), hash-bucketed hot-k-mer cache, masked / sparse emit — ragged reads with N runs and
@@ -507,7 +507,7 @@ def test_wide_k_takes_the_prefiltered_path(k, stranded, monkeypatch):
     seq = np.concatenate(seqs); qual = np.concatenate(quals)
     off = np.concatenate([[0], np.cumsum([x.size for x in seqs])]).astype(np.int64)
     # (round 3: reads of up to 320 bases at k <= 63 take the read-per-lane prefilter with the minimizer-bucketed cache, the bucket of a
-    # k-mer being that of its last 31 bases' minimizer; RB_WIDE_MPF=0: the hash-bucketed cache and the one-word kernels as before)
+    # k-mer being that of the minimizer of its middle 21 (k odd) / 20 (k even) bases; RB_WIDE_MPF=0: the hash-bucketed cache and the one-word kernels as before)
     for wide, wmpf in (("1", "1"), ("1", "0"), ("0", "1")):
         monkeypatch.setenv("RB_WIDE_PREFILTER", wide); monkeypatch.setenv("RB_WIDE_MPF", wmpf)
         og, gg = graph_pair(150_001, 200_003, 30_011, k=k, stranded=stranded, max_batch=15_000)
