@@ -1893,11 +1893,10 @@ void rb::alloc_bits(BitFilter &f, int64_t bits, int num_hash, int64_t lo, int64_
     f.alloc = (((size_t)f.nbytes + 3) / 4 + 1) * 4;
     f.num_hash = num_hash;
     f.mod = make_mod((uint64_t)bits);
-    if (getenv("RB_ALLOC_BITS")) { f.bits = static_cast<uint32_t *>(rb::alloc_best_placed(f.alloc, "bits", (size_t)128 << 20)); return; }   // experiment
     RB_HIP(hipMalloc(&f.bits, f.alloc));
     RB_HIP(hipMemset(f.bits, 0, f.alloc));
     RB_HIP(hipDeviceSynchronize());   // hipMemset is asynchronous; the graph's stream is non-blocking
-}   // (the bit filters do not go through alloc_best_placed: tried, and one run in three the counting filter then found no good place at all)
+}   // (the bit filters do not go through alloc_best_placed: tried twice, before and after the counting filter's draw: no gain, profiles/r03_alloc_lottery.txt)
 // ---- where the counting filter's pages land ----
 // The stages that touch the counting filter at random (claims, counter stores) take 53-68 ms per step on config 2 depending on the
 // ALLOCATION: graphs made one after the other in one process differ like that, each keeps its time for as long as it lives, and the time
@@ -1918,10 +1917,10 @@ __global__ void k_alloc_probe(uint32_t *words, uint64_t n_words, uint32_t per_th
     if (acc == 0x12345678u) atomicAdd(sink, 1ull);          // (keeps the returns alive)
 }
 }  // namespace
-void *rb::alloc_best_placed(size_t bytes, const char *what, size_t min_bytes) {
+void *rb::alloc_best_placed(size_t bytes, const char *what) {
     int tries = getenv("RB_ALLOC_TRIES") ? atoi(getenv("RB_ALLOC_TRIES")) : 8;
     tries = std::max(1, std::min(16, tries));
-    if (bytes < min_bytes) tries = 1;
+    if (bytes < ((size_t)1 << 30)) tries = 1;
     void *best = nullptr;
     float best_ms = 0;
     std::vector<void *> losers;
@@ -2634,14 +2633,12 @@ int rb_graph_create(const rb_graph_params *p, rb_graph **out) {
         RB_HIP(hipEventCreate(&g->ev1));
         RB_HIP(hipEventCreateWithFlags(&g->ev2, hipEventDisableTiming));
         RB_HIP(hipEventCreateWithFlags(&g->ev3, hipEventDisableTiming));
-        const bool cbf_first = getenv("RB_ALLOC_BITS") && atoi(getenv("RB_ALLOC_BITS")) == 2;      // experiment: who draws first
-        if (!cbf_first) alloc_bits(g->dbg, p->dbgbf_bits, p->dbgbf_num_hash, 0, p->dbgbf_bits);
+        alloc_bits(g->dbg, p->dbgbf_bits, p->dbgbf_num_hash, 0, p->dbgbf_bits);
         g->cbf_size = p->cbf_bytes; g->cbf_lo = 0; g->cbf_hi = p->cbf_bytes;
         g->cbf_alloc = (((size_t)p->cbf_bytes + 3) / 4 + 1) * 4;
         g->cbf_h = p->cbf_num_hash;
         g->cbf_mod = make_mod((uint64_t)p->cbf_bytes);
         g->cbf = static_cast<uint8_t *>(rb::alloc_best_placed(g->cbf_alloc, "cbf"));
-        if (cbf_first) alloc_bits(g->dbg, p->dbgbf_bits, p->dbgbf_num_hash, 0, p->dbgbf_bits);
         if (p->use_read_paired_kmers) alloc_bits(g->rpk, p->pkbf_bits, p->pkbf_num_hash, 0, p->pkbf_bits);
         {   // no-op prefilter cache: one 8-byte entry per ~64 counters, 2^16..2^28 entries (8-way buckets fill well: 2^27 entries hold the 64 M hot k-mers of config 2 as completely as 2^28)
             const char *e = getenv("RB_NPF");

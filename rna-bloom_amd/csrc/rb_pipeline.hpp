@@ -467,7 +467,7 @@ void group_enqueue(rb_graph *g, int slot, size_t N, uint64_t ordinal0, uint32_t 
 uint32_t group_finish(rb_graph *g, int slot, hipStream_t st, DevBuf &temp, DevBuf &ctrbuf, hipStream_t scan_stream);
 // paired k-mer walker: inserts into g->rpk (out_idx == nullptr) or collects global bit indices
 void shard_free(rb_graph *g);   // rb_shard.hip
-void *alloc_best_placed(size_t bytes, const char *what, size_t min_bytes = (size_t)1 << 30);   // rb_graph.hip: zeroed device memory, the best placed of a few allocations (counting filters)
+void *alloc_best_placed(size_t bytes, const char *what);   // rb_graph.hip: zeroed device memory, the best placed of a few allocations (counting filters)
 uint64_t *shard_query_h0(rb_graph *g, size_t n);                                                 // rb_shard.hip: the query protocol with hashes already on the device
 void shard_query_make_dev(rb_graph *g, int what, int which_bits, size_t n, int64_t *bit_counts, int64_t *ctr_counts);
 const void *shard_query_combine_dev(rb_graph *g, int which_bits, const void *breply_dev, const void *creply_dev);
