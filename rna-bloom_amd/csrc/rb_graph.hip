@@ -2298,7 +2298,7 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
     // One counter for the whole call (a sub-batch that is halved and redone has its pairs in already: ORs, not launched again).
     int pairs_mode = pairs ? 3 : 0;
     if (pairs && getenv("RB_PAIRS_SIDE")) pairs_mode = atoi(getenv("RB_PAIRS_SIDE"));
-    if (getenv("RB_SERIAL") || pairs_mode < 0 || pairs_mode > 4) pairs_mode = 0;
+    if (getenv("RB_SERIAL") || pairs_mode < 0 || pairs_mode > 5) pairs_mode = 0;
     const bool pairs_side = pairs_mode != 0;
     int64_t pairs_upto = first;
     bool pairs_pending = false;
@@ -2319,6 +2319,22 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
         g->prof_end("pairs_insert", g->stream3);
         RB_HIP(hipEventRecord(g->ev3, g->stream3));
         pairs_upto = sb.r1; pairs_pending = true;
+    };
+    // 5: the walker only beside the two kernels that are not bound by memory — the first half of the sub-batch's reads beside the emit pass
+    // (joined before the partition passes start), the second half beside the bucket kernel
+    auto pairs_half = [&](size_t i, int half) {
+        const Sub &sb = subs[i];
+        if (sb.nw <= 0 || sb.r1 <= pairs_upto) return;
+        const int64_t rm = (sb.r0 + sb.r1) / 2, wm = (int64_t)wo[(size_t)rm];
+        const int64_t w0 = half ? wm : sb.w0, nw = half ? sb.w0 + sb.nw - wm : wm - sb.w0;
+        RB_HIP(hipEventRecord(g->ev2, sp));
+        RB_HIP(hipStreamWaitEvent(g->stream3, g->ev2, 0));
+        g->prof_begin(g->stream3);
+        if (nw > 0) launch_pairs(g, b, w0, nw, mode_hash, nullptr, nullptr, g->pairs_ctr.as<unsigned long long>(), g->stream3);
+        g->prof_end("pairs_insert", g->stream3);
+        RB_HIP(hipEventRecord(g->ev3, g->stream3));
+        if (half) pairs_upto = sb.r1;
+        pairs_pending = true;
     };
     // producer: hash + group sub-batch i into slot i&1 on the producer stream (touches scratch and,
     // for the order-independent paired k-mers, rpkbf only)
@@ -2373,12 +2389,18 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
                             (double)h[0] / sb.nw, (double)h[1] / sb.nw, (double)h[2] / sb.nw, (double)h[3] / sb.nw, (double)h[4] / sb.nw, (double)empty_waves / waves);
                 }
                 if (pairs_mode == 3) pairs_fork(i, true);
+                const bool halves = pairs_mode == 5 && sb.nw > 0 && sb.r1 > pairs_upto;
+                if (halves) pairs_half(i, 0);
                 if (sb.N) {
                     g->prof_begin(sp);
                     g->keys0.reserve((size_t)sb.N * 8); g->vals0.reserve((size_t)sb.N * 4);
                     launch_hash_windows_masked(b, sb.w0, sb.nw, g->k, mode_hash, g->chunk_off.as<uint32_t>(), g->chunk_mask.as<uint32_t>(),
                                                (uint32_t)sb.r0, pos_bits, g->keys0.as<uint64_t>(), g->vals0.as<uint32_t>(), sp, wstate);
                     g->prof_end("hash_windows", sp);
+                }
+                if (halves) {
+                    RB_HIP(hipStreamWaitEvent(sp, g->ev3, 0)); pairs_pending = false;
+                    g->before_buckets = [&pairs_half, i]() { pairs_half(i, 1); };
                 }
             } else if (use_npf) {
                 // one pass: hash every window, ask the hot-k-mer cache whether the occurrence can matter,
@@ -2416,8 +2438,9 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
                 }
             }
         }
-        if (pairs_mode >= 3) pairs_fork(i, true);                // (3: already forked on the two-pass path; 4: beside the grouping only)
+        if (pairs_mode == 3 || pairs_mode == 4 || (pairs_mode == 5 && !g->before_buckets)) pairs_fork(i, true);   // (3: already forked on the two-pass path; 4: beside the grouping only; 5: paths without the two passes)
         group_enqueue(g, slot, sb.N, g->ordinal + (uint64_t)(sb.r0 - first), pos_bits, sp, g->temp2, g->devctr2);
+        if (g->before_buckets) { auto f = std::move(g->before_buckets); g->before_buckets = nullptr; f(); }   // (a grouping that had no bucket kernel to launch)
         if (pairs_pending) { RB_HIP(hipStreamWaitEvent(sp, g->ev3, 0)); pairs_pending = false; }
         if (pairs && !pairs_side && sb.nw > 0) {   // after group_enqueue: it zeroes the producer's counter block
             g->prof_begin(sp);

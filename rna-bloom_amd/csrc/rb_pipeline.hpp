@@ -8,6 +8,7 @@
 #include <mutex>
 #include <new>
 #include <shared_mutex>
+#include <functional>
 #include <vector>
 
 #include "rb_internal.hpp"
@@ -398,6 +399,7 @@ struct rb_graph {
         fv.seq_codes = seq_codes; fv.seq_woff = seq_woff; fv.seq_wpr = seq_wpr; fv.seq_first = seq_first; fv.k = k;
         return fv;
     }
+    std::function<void()> before_buckets;     // RB_PAIRS_SIDE=5: called once by the grouping right before its bucket kernel is launched
     void prof_begin(hipStream_t st = nullptr) {
         if (!prof_on) return;
         const int w = (st && st == stream2) ? 1 : (st && st == stream3) ? 2 : 0;
