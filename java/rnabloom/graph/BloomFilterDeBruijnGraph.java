@@ -1,16 +1,8 @@
 package rnabloom.graph;
 
-import java.io.BufferedReader;
-import java.io.File;
-import java.io.FileNotFoundException;
-import java.io.FileReader;
-import java.io.FileWriter;
-import java.io.IOException;
-import java.util.ArrayDeque;
-import java.util.ArrayList;
-import java.util.Collection;
-import java.util.HashMap;
-import java.util.Iterator;
+import java.io.*;
+import java.nio.ByteBuffer;
+import java.util.*;
 import rnabloom.bloom.BloomFilter;
 import rnabloom.bloom.CountingBloomFilter;
 import rnabloom.bloom.hash.*;
@@ -33,49 +25,28 @@ import static rnabloom.util.SeqUtils.*;
  * have: `public int getK() { return k; }`.)
  */
 public class BloomFilterDeBruijnGraph {
-    private long handle;                       // rb_graph*: dbgbf, cbf, rpkbf, fpkbf on the device
-    private BloomFilter dbgbf;                 // views of the handle's filters (getDbgbf() etc.)
+    private long handle;                                   // rb_graph*: dbgbf, cbf, rpkbf, fpkbf live on the device behind it
+    private BloomFilter dbgbf, rpkbf, fpkbf;               // thin views of the handle's filters (getDbgbf() etc.); null = absent
     private CountingBloomFilter cbf;
-    private BloomFilter fpkbf = null;
-    private BloomFilter rpkbf = null;
-
-    private int dbgbfNumHash;
-    private int cbfNumHash;
-    private int dbgbfCbfMaxNumHash;
     private final HashFunction hashFunction;
-    private int k;
-    private int kMinus1;
+    private int k, kMinus1;
     private boolean stranded;
-    private int fragmentPairedKmersDistance = -1;
-    private int pkbfNumHash;
-    private int readPairedKmersDistance = -1;
+    private int dbgbfNumHash, cbfNumHash, pkbfNumHash, dbgbfCbfMaxNumHash;
+    private int readPairedKmersDistance = -1, fragmentPairedKmersDistance = -1;
 
     private static final String EXT_DESC = ".desc", EXT_DBGBF = ".dbgbf", EXT_CBF = ".cbf", EXT_FPKBF = ".fpkbf", EXT_RPKBF = ".rpkbf";
 
-    public BloomFilterDeBruijnGraph(long dbgbfNumBits,
-                                    long cbfNumBytes,
-                                    long pkbfNumBits,
-                                    int dbgbfNumHash,
-                                    int cbfNumHash,
-                                    int pkbfNumHash,
-                                    int k,
-                                    boolean stranded,
-                                    boolean useReadPairedKmers) {
-        this.k = k;
-        this.kMinus1 = k - 1;
-        this.stranded = stranded;
+    public BloomFilterDeBruijnGraph(long dbgbfNumBits, long cbfNumBytes, long pkbfNumBits, int dbgbfNumHash, int cbfNumHash, int pkbfNumHash,
+                                    int k, boolean stranded, boolean useReadPairedKmers) {
+        this.k = k; this.kMinus1 = k - 1; this.stranded = stranded;
+        this.dbgbfNumHash = dbgbfNumHash; this.cbfNumHash = cbfNumHash; this.pkbfNumHash = pkbfNumHash;
+        this.dbgbfCbfMaxNumHash = dbgbfNumHash > cbfNumHash ? dbgbfNumHash : cbfNumHash;
         this.hashFunction = stranded ? new HashFunction(k) : new CanonicalHashFunction(k);
-        this.dbgbfNumHash = dbgbfNumHash;
-        this.cbfNumHash = cbfNumHash;
-        this.pkbfNumHash = pkbfNumHash;
-        this.dbgbfCbfMaxNumHash = Math.max(dbgbfNumHash, cbfNumHash);
         this.handle = NativeGraph.create(dbgbfNumBits, cbfNumBytes, pkbfNumBits, dbgbfNumHash, cbfNumHash, pkbfNumHash, k, stranded,
                                          useReadPairedKmers, NativeGraph.defaultDevice(), 0L);
         this.dbgbf = new BloomFilter(handle, NativeGraph.DBGBF, dbgbfNumBits, dbgbfNumHash, hashFunction);
         this.cbf = new CountingBloomFilter(handle, cbfNumBytes, cbfNumHash, hashFunction);
-        if (useReadPairedKmers) {
-            this.rpkbf = new BloomFilter(handle, NativeGraph.RPKBF, pkbfNumBits, pkbfNumHash, hashFunction);
-        }
+        this.rpkbf = useReadPairedKmers ? new BloomFilter(handle, NativeGraph.RPKBF, pkbfNumBits, pkbfNumHash, hashFunction) : null;
     }
 
     private static HashMap<String, String> readLabels(File f) throws IOException {
@@ -256,9 +227,9 @@ public class BloomFilterDeBruijnGraph {
     private static long[] one(long v) { return new long[]{v}; }
 
     private long[] hashesOf(String kmer) {
-        final long[] hashVals = new long[dbgbfCbfMaxNumHash];
-        hashFunction.getHashValues(kmer, dbgbfCbfMaxNumHash, hashVals);
-        return hashVals;
+        final long[] h = new long[dbgbfCbfMaxNumHash];
+        hashFunction.getHashValues(kmer, h.length, h);
+        return h;
     }
 
     public void add(String kmer) { add(hashesOf(kmer)); }
@@ -364,27 +335,30 @@ public class BloomFilterDeBruijnGraph {
 
     public CharSequence getSuffixCharSeq(String kmer) { return kmer.subSequence(1, k); }
 
-    /** the k-mers that differ from `kmer` in its first base and are in the graph */
-    public ArrayDeque<String> getLeftVariants(String kmer) {
-        ArrayDeque<String> result = new ArrayDeque<>(4);
-        final String suffix = getSuffix(kmer);
-        for (char c : getAltNucleotides(kmer.charAt(0))) {
-            String v = c + suffix;
-            if (contains(v)) result.add(v);
+    /**
+     * The k-mers that differ from `kmer` in one END base and are in the graph (:1056-1068, :1113-1124): the alternatives are hashed on
+     * the host and looked up with ONE batched native call instead of one `contains` per alternative.
+     */
+    private ArrayDeque<String> endVariants(String kmer, boolean firstBase) {
+        final char[] alts = getAltNucleotides(kmer.charAt(firstBase ? 0 : kMinus1));
+        final String[] cand = new String[alts.length];
+        final long[] base = new long[alts.length];
+        final StringBuilder sb = new StringBuilder(kmer);
+        for (int i = 0; i < alts.length; ++i) {
+            sb.setCharAt(firstBase ? 0 : kMinus1, alts[i]);
+            cand[i] = sb.toString();
+            base[i] = hashesOf(cand[i])[0];
         }
-        return result;
+        final byte[] present = new byte[alts.length];
+        if (alts.length > 0) NativeGraph.contains(handle, base, alts.length, present);
+        final ArrayDeque<String> found = new ArrayDeque<>(4);
+        for (int i = 0; i < alts.length; ++i) if (present[i] != 0) found.add(cand[i]);
+        return found;
     }
 
-    /** the same for the last base */
-    public ArrayDeque<String> getRightVariants(String kmer) {
-        ArrayDeque<String> result = new ArrayDeque<>(4);
-        final String prefix = getPrefix(kmer);
-        for (char c : getAltNucleotides(kmer.charAt(kMinus1))) {
-            String v = prefix + c;
-            if (contains(v)) result.add(v);
-        }
-        return result;
-    }
+    public ArrayDeque<String> getLeftVariants(String kmer) { return endVariants(kmer, true); }
+
+    public ArrayDeque<String> getRightVariants(String kmer) { return endVariants(kmer, false); }
 
     public float[] getCounts(String[] kmers) {
         long[] h = new long[kmers.length];
@@ -394,22 +368,22 @@ public class BloomFilterDeBruijnGraph {
         return counts;
     }
 
-    /** every k-mer of seq is in dbgbf (:1181-1194): one batched lookup of the sequence's hashes */
+    /** every k-mer of seq is in dbgbf (:1181-1194): the iterator's base hashes are collected and looked up in one batched call */
     public boolean isValidSeq(String seq) {
-        NTHashIterator itr = getHashIterator();
-        itr.start(seq);
-        long[] hVals = itr.hVals;
-        ArrayList<Long> hs = new ArrayList<>();
-        while (itr.hasNext()) {
-            itr.next();
-            hs.add(hVals[0]);
+        final int windows = seq.length() - k + 1;
+        if (windows <= 0) return true;
+        final long[] base = new long[windows];
+        final NTHashIterator it = getHashIterator();
+        it.start(seq);
+        int n = 0;
+        for (; it.hasNext() && n < windows; ++n) {
+            it.next();
+            base[n] = it.hVals[0];
         }
-        if (hs.isEmpty()) return true;
-        long[] h = new long[hs.size()];
-        for (int i = 0; i < h.length; ++i) h[i] = hs.get(i);
-        byte[] o = new byte[h.length];
-        NativeGraph.contains(handle, h, h.length, o);
-        for (byte b : o) if (b == 0) return false;
+        if (n == 0) return true;
+        final byte[] present = new byte[n];
+        NativeGraph.contains(handle, base, n, present);
+        for (int i = 0; i < n; ++i) if (present[i] == 0) return false;
         return true;
     }
 
@@ -427,77 +401,132 @@ public class BloomFilterDeBruijnGraph {
 
     public PairedNTHashIterator getReverseComplementPairedHashIterator(int d) { return hashFunction.getReverseComplementPairedHashIterator(this.pkbfNumHash, d); }
 
-    public ArrayList<Kmer> getKmers(String seq) { return hashFunction.getKmers(seq, this.dbgbfCbfMaxNumHash, this); }
-
-    public ArrayList<Kmer> getKmers(String seq, float minCoverage) { return hashFunction.getKmers(seq, this.dbgbfCbfMaxNumHash, this, minCoverage); }
-
-    public ArrayList<Kmer> getKmers(String seq, int start, int end) { return hashFunction.getKmers(seq, start, end, this.dbgbfCbfMaxNumHash, this); }
-
-    // ---- k-mer lists back to sequences: the first k-mer whole, then one base of every following k-mer ----
-    private void appendWhole(StringBuilder sb, Kmer first) { for (byte b : first.bytes) sb.append((char) b); }
-
-    public String assemble(ArrayDeque<Kmer> kmers) { return assemble((Collection<Kmer>) kmers); }
-
-    public String assemble(ArrayList<Kmer> kmers, int start, int end) {
-        StringBuilder sb = new StringBuilder(end - start + kMinus1);
-        appendWhole(sb, kmers.get(start));
-        for (int i = start + 1; i < end; ++i) sb.append((char) kmers.get(i).bytes[kMinus1]);
-        return sb.toString();
+    /**
+     * getKmers (:1224-1234 -> {Canonical,}HashFunction.getKmers, src/rnabloom/bloom/hash/CanonicalHashFunction.java:46-170): the
+     * reference hashes window by window and asks graph.getCount per k-mer — here ONE NativeGraph.getKmers call returns forward hash,
+     * reverse hash and count of every window of seq[start, end) (count 0 for a window with a character outside ACGTU, :73-78), and the
+     * Kmer objects are built from the arrays.  Kmer / CanonicalKmer are the reference's own classes.
+     */
+    private static final class WindowProfile {
+        final byte[] bytes; final long[] f, r; final float[] count; final int n;
+        WindowProfile(byte[] bytes, long[] f, long[] r, float[] count, int n) { this.bytes = bytes; this.f = f; this.r = r; this.count = count; this.n = n; }
     }
 
-    public byte[] assembleBytes(ArrayList<Kmer> kmers, int start, int end) {
-        byte[] out = new byte[end - start + kMinus1];
-        System.arraycopy(kmers.get(start).bytes, 0, out, 0, k);
-        for (int i = start + 1, p = k; i < end; ++i) out[p++] = kmers.get(i).bytes[kMinus1];
+    private WindowProfile profile(String seq, int start, int end) {
+        final int len = end - start, n = len - k + 1;
+        final byte[] ascii = new byte[Math.max(len, 0)];
+        for (int i = 0; i < len; ++i) ascii[i] = (byte) seq.charAt(start + i);
+        if (n <= 0) return new WindowProfile(ascii, new long[0], new long[0], new float[0], 0);
+        final ByteBuffer text = ByteBuffer.allocateDirect(len);
+        text.put(ascii);
+        final long[] f = new long[n], r = new long[n], koff = new long[2];
+        final float[] count = new float[n];
+        NativeGraph.getKmers(handle, text, new long[]{0L, (long) len}, 1, koff, f, r, count);
+        return new WindowProfile(ascii, f, r, count, n);
+    }
+
+    private Kmer kmerAt(WindowProfile w, int i) {
+        final byte[] b = Arrays.copyOfRange(w.bytes, i, i + k);
+        return stranded ? new Kmer(b, w.count[i], w.f[i]) : new CanonicalKmer(b, w.count[i], w.f[i], w.r[i]);
+    }
+
+    public ArrayList<Kmer> getKmers(String seq) { return getKmers(seq, 0, seq.length()); }
+
+    public ArrayList<Kmer> getKmers(String seq, int start, int end) {
+        final ArrayList<Kmer> out = new ArrayList<>();
+        if (seq.length() < k) return out;
+        final WindowProfile w = profile(seq, start, end);
+        out.ensureCapacity(w.n);
+        for (int i = 0; i < w.n; ++i) out.add(kmerAt(w, i));
         return out;
+    }
+
+    /**
+     * "The longest stretch of consecutive k-mers with count >= minCoverage" as the reference computes it (:81-134), quirks included: a
+     * stretch is ranked (longer wins, then the larger minimum count, then the earlier) only when a k-mer below the threshold ENDS it, and the
+     * FIRST stretch is never ranked — it is what `longestSegment` points to from the start, so it is returned unless a later, ended stretch
+     * takes over, and the first one that ends always does (it is compared with length 0).  A last stretch that runs to the end of the
+     * sequence is returned only if it is the first.  (oracle/rbo.py::get_kmers_min_coverage is the same statement-by-statement.)
+     */
+    public ArrayList<Kmer> getKmers(String seq, float minCoverage) {
+        final ArrayList<Kmer> out = new ArrayList<>();
+        if (seq.length() < k) return out;
+        final WindowProfile w = profile(seq, 0, seq.length());
+        int keepAt = 0, keepLen = 0, stretches = 0, rankedLen = 0;
+        float rankedMin = Float.MAX_VALUE;
+        for (int i = 0; i < w.n; ) {
+            if (!(w.count[i] >= minCoverage)) { ++i; continue; }
+            int j = i;
+            float low = Float.MAX_VALUE;
+            for (; j < w.n && w.count[j] >= minCoverage; ++j) low = Math.min(low, w.count[j]);
+            final int len = j - i;
+            if (stretches++ == 0) { keepAt = i; keepLen = len; }
+            else if (j < w.n && (len > rankedLen || (len == rankedLen && low > rankedMin))) { keepAt = i; keepLen = len; rankedLen = len; rankedMin = low; }
+            i = j;
+        }
+        out.ensureCapacity(keepLen);
+        for (int i = keepAt; i < keepAt + keepLen; ++i) out.add(kmerAt(w, i));
+        return out;
+    }
+
+    // ---- k-mer lists back to sequences: all k bases of the first k-mer, then the last base of each one after it ----
+    private String spell(Iterator<Kmer> kmers, int count) {
+        final char[] text = new char[Math.max(count + kMinus1, 0)];
+        int at = 0;
+        while (kmers.hasNext()) {
+            final byte[] b = kmers.next().bytes;
+            if (at == 0) for (int i = 0; i < kMinus1; ++i) text[at++] = (char) b[i];
+            text[at++] = (char) b[kMinus1];
+        }
+        return new String(text, 0, at);
+    }
+
+    private static Iterator<Kmer> backwards(final ArrayList<Kmer> list) {
+        return new Iterator<Kmer>() {
+            private int next = list.size() - 1;
+            public boolean hasNext() { return next >= 0; }
+            public Kmer next() { return list.get(next--); }
+        };
+    }
+
+    public String assemble(Collection<Kmer> kmers) { return spell(kmers.iterator(), kmers.size()); }
+
+    public String assemble(ArrayDeque<Kmer> kmers) { return spell(kmers.iterator(), kmers.size()); }
+
+    public String assemble(ArrayList<Kmer> kmers, int start, int end) { return spell(kmers.subList(start, end).iterator(), end - start); }
+
+    public String assembleReverseOrder(ArrayDeque<Kmer> kmers) { return spell(kmers.descendingIterator(), kmers.size()); }
+
+    public String assembleReverseOrder(ArrayList<Kmer> kmers) { return spell(backwards(kmers), kmers.size()); }
+
+    public byte[] assembleBytes(ArrayList<Kmer> kmers, int start, int end) {
+        final byte[] text = new byte[end - start + kMinus1];
+        final byte[] head = kmers.get(start).bytes;
+        for (int i = 0; i < kMinus1; ++i) text[i] = head[i];
+        for (int i = start; i < end; ++i) text[kMinus1 + i - start] = kmers.get(i).bytes[kMinus1];
+        return text;
     }
 
     public byte[] assembleReverseComplementBytes(ArrayList<Kmer> kmers, int start, int end) {
-        byte[] fwd = assembleBytes(kmers, start, end);
-        byte[] out = new byte[fwd.length];
-        for (int i = 0; i < fwd.length; ++i) out[fwd.length - 1 - i] = complement(fwd[i]);
-        return out;
-    }
-
-    public String assembleReverseOrder(ArrayDeque<Kmer> kmers) {
-        StringBuilder sb = new StringBuilder(kmers.size() + kMinus1);
-        Iterator<Kmer> itr = kmers.descendingIterator();
-        if (itr.hasNext()) {
-            appendWhole(sb, itr.next());
-            while (itr.hasNext()) sb.append((char) itr.next().bytes[kMinus1]);
+        final byte[] text = assembleBytes(kmers, start, end);
+        for (int lo = 0, hi = text.length - 1; lo <= hi; ++lo, --hi) {
+            final byte a = complement(text[lo]), z = complement(text[hi]);
+            text[lo] = z;
+            text[hi] = a;
         }
-        return sb.toString();
+        return text;
     }
 
-    public String assembleReverseOrder(ArrayList<Kmer> kmers) {
-        final int n = kmers.size();
-        StringBuilder sb = new StringBuilder(n + kMinus1);
-        appendWhole(sb, kmers.get(n - 1));
-        for (int i = n - 2; i >= 0; --i) sb.append((char) kmers.get(i).bytes[kMinus1]);
-        return sb.toString();
+    private String column(Collection<Kmer> kmers, int which) {
+        final char[] text = new char[kmers.size()];
+        int at = 0;
+        for (Kmer kmer : kmers) text[at++] = (char) kmer.bytes[which];
+        return new String(text);
     }
 
-    public String assemble(Collection<Kmer> kmers) {
-        StringBuilder sb = new StringBuilder(kmers.size() + kMinus1);
-        Iterator<Kmer> itr = kmers.iterator();
-        if (itr.hasNext()) {
-            appendWhole(sb, itr.next());
-            while (itr.hasNext()) sb.append((char) itr.next().bytes[kMinus1]);
-        }
-        return sb.toString();
-    }
+    public String assembleFirstBase(Collection<Kmer> kmers) { return column(kmers, 0); }
 
-    public String assembleFirstBase(Collection<Kmer> kmers) {
-        StringBuilder sb = new StringBuilder(kmers.size());
-        for (Kmer kmer : kmers) sb.append((char) kmer.bytes[0]);
-        return sb.toString();
-    }
-
-    public String assembleLastBase(Collection<Kmer> kmers) {
-        StringBuilder sb = new StringBuilder(kmers.size());
-        for (Kmer kmer : kmers) sb.append((char) kmer.bytes[kMinus1]);
-        return sb.toString();
-    }
+    public String assembleLastBase(Collection<Kmer> kmers) { return column(kmers, kMinus1); }
 
     // ---- batched forms (not in the reference): what ported hot loops call instead of n per-element calls ----
     /** op = NativeGraph.OP_*: the n base hashes are applied in array order, exactly as n per-element calls would be */

@@ -20,7 +20,10 @@
 #include <fcntl.h>
 #include <stdint.h>
 #include <string.h>
+#include <errno.h>
+#include <stdio.h>
 #include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include "rb_capi.h"
@@ -35,6 +38,13 @@ static void throw_rc(JNIEnv *e, int rc) {
                     : rc == RB_ERR_STATE ? "java/lang/IllegalStateException" : "java/lang/RuntimeException";
     jclass c = (*e)->FindClass(e, cls);
     if (c) (*e)->ThrowNew(e, c, rb_last_error());
+}
+/* failures of the file plumbing in this shim (open / fstat / mmap / ftruncate): their own message, an IOException as the reference's save / load throw */
+static void throw_io(JNIEnv *e, const char *what, const char *path, const char *why) {
+    char msg[512];
+    jclass c = (*e)->FindClass(e, "java/io/IOException");
+    snprintf(msg, sizeof msg, "%s '%s': %s", what, path ? path : "(null)", why);
+    if (c) (*e)->ThrowNew(e, c, msg);
 }
 static void *direct(JNIEnv *e, jobject buf) { return buf ? (*e)->GetDirectBufferAddress(e, buf) : NULL; }
 /* pinned / copied views of primitive arrays; NULL arrays stay NULL */
@@ -334,29 +344,38 @@ void FN(importFilter)(JNIEnv *e, jclass c, jlong h, jint which, jobject src, jlo
 /* filters of 2 GiB and more (a direct ByteBuffer holds less): the file is mapped here and handed to the same two calls */
 void FN(importFilterFromFile)(JNIEnv *e, jclass c, jlong h, jint which, jstring path, jlong n) {
     const char *p = (*e)->GetStringUTFChars(e, path, NULL);
-    int rc = RB_ERR_INVALID, fd = p ? open(p, O_RDONLY) : -1;
+    int rc = RB_OK, fd = p ? open(p, O_RDONLY) : -1, io = 0;
+    struct stat sb;
     (void)c;
-    if (fd >= 0) {
+    if (fd < 0) { throw_io(e, "cannot open filter file", p, strerror(errno)); io = 1; }
+    else if (fstat(fd, &sb) != 0) { throw_io(e, "cannot stat filter file", p, strerror(errno)); io = 1; }
+    else if ((int64_t)sb.st_size < (int64_t)n) {        /* a truncated file would be a SIGBUS inside the import, not an exception */
+        char why[96];
+        snprintf(why, sizeof why, "%lld bytes, the filter needs %lld", (long long)sb.st_size, (long long)n);
+        throw_io(e, "filter file is too short", p, why); io = 1;
+    } else {
         void *m = mmap(NULL, (size_t)n, PROT_READ, MAP_PRIVATE, fd, 0);
-        if (m != MAP_FAILED) { rc = rb_filter_import(G(h), which, m, (size_t)n); munmap(m, (size_t)n); }
-        close(fd);
+        if (m == MAP_FAILED) { throw_io(e, "cannot map filter file", p, strerror(errno)); io = 1; }
+        else { rc = rb_filter_import(G(h), which, m, (size_t)n); munmap(m, (size_t)n); }
     }
+    if (fd >= 0) close(fd);
     if (p) (*e)->ReleaseStringUTFChars(e, path, p);
-    if (rc) throw_rc(e, rc);
+    if (!io && rc) throw_rc(e, rc);
 }
 void FN(exportFilterToFile)(JNIEnv *e, jclass c, jlong h, jint which, jstring path, jlong n) {
     const char *p = (*e)->GetStringUTFChars(e, path, NULL);
-    int rc = RB_ERR_INVALID, fd = p ? open(p, O_RDWR | O_CREAT | O_TRUNC, 0644) : -1;
+    int rc = RB_OK, fd = p ? open(p, O_RDWR | O_CREAT | O_TRUNC, 0644) : -1, io = 0;
     (void)c;
-    if (fd >= 0) {
-        if (ftruncate(fd, (off_t)n) == 0) {
-            void *m = mmap(NULL, (size_t)n, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-            if (m != MAP_FAILED) { rc = rb_filter_export(G(h), which, m, (size_t)n); munmap(m, (size_t)n); }
-        }
-        close(fd);
+    if (fd < 0) { throw_io(e, "cannot create filter file", p, strerror(errno)); io = 1; }
+    else if (ftruncate(fd, (off_t)n) != 0) { throw_io(e, "cannot size filter file", p, strerror(errno)); io = 1; }
+    else {
+        void *m = mmap(NULL, (size_t)n, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        if (m == MAP_FAILED) { throw_io(e, "cannot map filter file", p, strerror(errno)); io = 1; }
+        else { rc = rb_filter_export(G(h), which, m, (size_t)n); munmap(m, (size_t)n); }
     }
+    if (fd >= 0) close(fd);
     if (p) (*e)->ReleaseStringUTFChars(e, path, p);
-    if (rc) throw_rc(e, rc);
+    if (!io && rc) throw_rc(e, rc);
 }
 jlong FN(expectedSize)(JNIEnv *e, jclass c, jlong n, jfloat fpr, jint nh) { (void)e; (void)c; return rb_expected_size(n, fpr, nh); }
 void FN(cbfToBloom)(JNIEnv *e, jclass c, jlong src, jfloat min_cov, jlong dst, jint which) { (void)c; int rc = rb_cbf_to_bloom(G(src), min_cov, G(dst), which); if (rc) throw_rc(e, rc); }

@@ -210,3 +210,123 @@ def kmer_pair_hashes(seq, k, shift, canonical):
             pf = pr if s64(pr) < s64(pf) else pf
         out.append(pf)
     return out
+
+
+# ---- stage 1 (round 4): a second restatement of the INSERT, in another shape than oracle/rb_oracle.c ------------------------
+# rb_oracle.c follows FastqToGraphWorker and the filters byte array by byte array, with rolling hashes and a hand-written
+# segmentation loop; the HIP pipeline was written against it.  This one is written from the Java again: every k-mer hashed from
+# scratch (kmer_hashes above), the reads cut by the reference's OWN regular expressions (tests/golden/seq_patterns.json: the
+# literal parts of SeqUtils.getPhred33Pattern / getNucleotideCharsPattern, run by Python's re), the filters as a set of bit
+# indices and a dict of counters (no byte arrays, no words, no masks).  C oracle == this == HIP on the committed fixtures is
+# a three-way check of everything between the hash layer and the saved files.  Counters below 16 only (no random draw:
+# MiniFloat.increment is deterministic there, R/util/MiniFloat.java:31-37) — the fixtures are built that way.
+MULTI_SEED = 0x90b45d39fb6da1fa      # NTHash.java:33
+MULTI_SHIFT = 27                     # :32
+
+
+def multi_hashes(base, k, m):
+    """NTM64(bVal, hVal[], k, m) (NTHash.java:518-527): hVal[0] = b; hVal[i] = t ^ (t >>> 27), t = b * (i ^ (k * multiSeed))"""
+    out = [base & M64]
+    for i in range(1, m):
+        t = (base * (i ^ ((k * MULTI_SEED) & M64))) & M64
+        out.append(t ^ (t >> MULTI_SHIFT))
+    return out
+
+
+def index_of(h, size):
+    """BloomFilter.getIndex (R/bloom/BloomFilter.java:108-111): (hashVal >>> 1) % size"""
+    return (h >> 1) % size
+
+
+def worker_segments(seq, qual, k, min_qual, patterns):
+    """while (mQual.find()) { mSeq.region(...); while (mSeq.find()) ... } (R/RNABloom.java:572-577) with compiled patterns
+    (qual pattern, seq pattern); qual None: the FASTA worker's single pattern (:677-697)"""
+    mq, ms = patterns
+    if qual is None:
+        return [(m.start(), m.end()) for m in ms.finditer(seq)]
+    return [(m.start(), m.end()) for q in mq.finditer(qual) for m in ms.finditer(seq, q.start(), q.end())]
+
+
+class Stage1:
+    """BloomFilterDeBruijnGraph with dbgbf / rpkbf as sets of bit indices and cbf as {index: byte}."""
+
+    def __init__(self, dbg_bits, cbf_bytes, pk_bits, h_dbg, h_cbf, h_pk, k, stranded):
+        self.k, self.stranded = k, stranded
+        self.size = (dbg_bits, cbf_bytes, pk_bits)
+        self.h = (h_dbg, h_cbf, h_pk)
+        self.dbg, self.cbf, self.rpk = set(), {}, set()
+        self.kmers = self.pairs = 0
+
+    # -- BloomFilterDeBruijnGraph.add (R/graph/BloomFilterDeBruijnGraph.java:405-412)
+    def add(self, base):
+        hv = multi_hashes(base, self.k, max(self.h[0], self.h[1]))      # hashVals has max(dbgbfNumHash, cbfNumHash) entries (:90)
+        # BloomFilter.lookupThenAdd (R/bloom/BloomFilter.java:147-155): getAndSet on every index, no early exit
+        found = True
+        for j in range(self.h[0]):
+            i = index_of(hv[j], self.size[0])
+            found = (i in self.dbg) and found
+            self.dbg.add(i)
+        if found:
+            self.increment(hv)
+
+    # -- CountingBloomFilter.increment (R/bloom/CountingBloomFilter.java:170-194)
+    def increment(self, hv):
+        idx = [index_of(hv[j], self.size[1]) for j in range(self.h[1])]
+        mn = min(self.cbf.get(i, 0) for i in idx)                       # (the early exits at 0 change nothing: 0 is the minimum)
+        assert mn < 16, "Stage1 restates the deterministic range of MiniFloat.increment only"
+        updated = mn + 1                                                # b <= 7: +1; 8..15: 2^((b>>3)-1) = 1, the draw % 1 == 0 always
+        for i in idx:
+            if self.cbf.get(i, 0) == mn:                                # compareAndSwap(index, min, updated): "update min count only"
+                self.cbf[i] = updated
+
+    # -- addReadSingleKmerPair -> rpkbf.add (:455-457, BloomFilter.add :133-137)
+    def add_pair(self, base):
+        for hvj in multi_hashes(base, self.k, self.h[2]):
+            self.rpk.add(index_of(hvj, self.size[2]))
+
+    def add_reads(self, reads, quals, min_qual, patterns, reverse_complement=False, pair_distance=0):
+        """FastqToGraphWorker.run (R/RNABloom.java:551-634) for one file; reads / quals: lists of bytes (quals None: FASTA)"""
+        k, d = self.k, pair_distance
+        for n, seq in enumerate(reads):
+            if len(seq) < k:
+                continue                                                # :566-569
+            f, r = kmer_hashes(seq, k)
+            if self.stranded:
+                h0 = r if reverse_complement else f                     # ReverseComplementNTHashIterator / NTHashIterator (:540-545)
+            else:
+                h0 = [rv if s64(rv) < s64(fv) else fv for fv, rv in zip(f, r)]     # NTPC64: signed min (NTHash.java:465-475)
+            for s, e in worker_segments(seq, None if quals is None else quals[n], k, min_qual, patterns):
+                for p in range(s, e - k + 1):                           # itr.start(seq, start, end): positions start .. end - k
+                    self.add(h0[p])
+                    self.kmers += 1
+                if d > 0:
+                    for p in range(s, e - k - d + 1):                   # pitr: positions start .. end - k - d (PairedNTHashIterator.java:53-61)
+                        if self.stranded and not reverse_complement:
+                            pb = combine(f[p], f[p + d])                                   # PairedNTHashIterator :67-69
+                        elif self.stranded:
+                            pb = combine(r[p + d], r[p])                                   # ReverseComplementPaired... :40-42: combine(R, L)
+                        else:
+                            a, b = combine(f[p], f[p + d]), combine(r[p + d], r[p])        # CanonicalPaired... :43-45
+                            pb = b if s64(b) < s64(a) else a                               # Math.min(long, long)
+                        self.add_pair(pb)
+                        self.pairs += 1
+
+    # -- the saved bytes (UnsafeBitBuffer: bit i = byte i / 8, mask 1 << (i % 8), R/bloom/buffer/UnsafeBitBuffer.java:45-62; one byte per counter)
+    @staticmethod
+    def _bits_to_bytes(bits, size):
+        out = bytearray((size + 7) // 8)
+        for i in bits:
+            out[i >> 3] |= 1 << (i & 7)
+        return bytes(out)
+
+    def dbgbf_bytes(self):
+        return self._bits_to_bytes(self.dbg, self.size[0])
+
+    def rpkbf_bytes(self):
+        return self._bits_to_bytes(self.rpk, self.size[2])
+
+    def cbf_bytes(self):
+        out = bytearray(self.size[1])
+        for i, v in self.cbf.items():
+            out[i] = v
+        return bytes(out)

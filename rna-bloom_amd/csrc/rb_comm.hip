@@ -105,7 +105,8 @@ struct rb_shard_comm {
     int arrived = 0;
     uint64_t generation = 0;
     bool failed = false;
-    int in_call = 0;                    // ranks inside rb_shard_add_range: when the last one has left a failed call the hub is usable again
+    int in_call = 0;                    // ranks inside rb_shard_add_range
+    uint64_t entered = 0;               // entries into rb_shard_add_range so far: a failed call is over when ALL ranks have entered and left it
     const Part *pub_parts[MAX_WORLD];
     int pub_k[MAX_WORLD];
     // receive buffers and count staging, per (virtual) rank
@@ -450,10 +451,15 @@ int rb_shard_comm_destroy(rb_shard_comm *c) {
 int rb_shard_add_range(rb_graph *g, rb_shard_comm *c, const rb_batch *b, int64_t first, int64_t n, unsigned flags, int64_t reads_per_substep,
                        uint32_t pos_bits, uint64_t ordinal0, rb_add_stats *stats) {
     if (stats) memset(stats, 0, sizeof *stats);
-    struct InCall {                      // (loopback hub) a failed call poisons the hub only until every rank has left it
-        rb_shard_comm *c;
-        explicit InCall(rb_shard_comm *c_) : c(c_) { if (c && !c->is_rccl) { std::lock_guard<std::mutex> lk(c->m); ++c->in_call; } }
-        ~InCall() { if (c && !c->is_rccl) { std::lock_guard<std::mutex> lk(c->m); if (--c->in_call == 0 && c->failed) { c->failed = false; c->arrived = 0; } } }
+    struct InCall {                      // (loopback hub) a failed call poisons the hub until EVERY rank has entered and left it: a rank that fails
+        rb_shard_comm *c;                // before its peers have arrived must not un-poison the hub for them (they would wait at a barrier for ever)
+        explicit InCall(rb_shard_comm *c_) : c(c_) { if (c && !c->is_rccl) { std::lock_guard<std::mutex> lk(c->m); ++c->in_call; ++c->entered; } }
+        ~InCall() {
+            if (c && !c->is_rccl) {
+                std::lock_guard<std::mutex> lk(c->m);
+                if (--c->in_call == 0 && c->failed && c->entered % (uint64_t)c->world == 0) { c->failed = false; c->arrived = 0; }
+            }
+        }
     } in_call(c);
     int rc = guarded([&] {
         RB_REQUIRE(g && g->shard && c && b && n >= 0 && reads_per_substep > 0, "rb_shard_add_range: bad argument");

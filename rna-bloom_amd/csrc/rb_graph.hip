@@ -32,9 +32,6 @@
 #include <unistd.h>
 #include <zlib.h>
 
-#include <string>
-#include <thread>
-
 #include "rb_pipeline.hpp"
 
 using namespace rb;
@@ -1849,6 +1846,7 @@ void rb::group_enqueue(rb_graph *g, int slot, size_t N, uint64_t ordinal0, uint3
     // ordered conflict replay already make exact (DESIGN.md §Pipeline "split runs").
     const int group_bits = 64 - g->sort_begin_bit;
     const int bucket_target = g->shard ? (getenv("RB_SHARD_GROUP_TARGET") ? atoi(getenv("RB_SHARD_GROUP_TARGET")) : 3072) : 0;
+    S.bucket_target = bucket_target;
     temp.reserve(group_temp_bytes(N, group_bits, bucket_target, flags));
     S.keys1.reserve(N * 8); S.valsT.reserve(N * 4); S.vals1.reserve(N * 4); S.tz.reserve(N + 16);
     S.uniq.reserve(N * 8); S.counts.reserve((N + 1) * 4); S.starts.reserve((N + 1) * 4);
@@ -1862,14 +1860,14 @@ uint32_t rb::group_finish(rb_graph *g, int slot, hipStream_t st, DevBuf &temp, D
     uint32_t D = 0;
     RB_HIP(hipMemcpyAsync(&D, ctrbuf.as<uint32_t>() + 8, 4, hipMemcpyDeviceToHost, st));
     if (S.flags & GR_FLAG_DEAD)
-        RB_HIP(hipMemcpyAsync(&S.live, group_live_count(temp.p, S.N, 64 - g->sort_begin_bit, g->shard ? 3072 : 0, S.flags), 4, hipMemcpyDeviceToHost, st));
+        RB_HIP(hipMemcpyAsync(&S.live, group_live_count(temp.p, S.N, 64 - g->sort_begin_bit, S.bucket_target, S.flags), 4, hipMemcpyDeviceToHost, st));
     RB_HIP(hipStreamSynchronize(st));
     RB_REQUIRE(D < (1u << 30), "sub-batch has too many distinct k-mers (%u)", D);
     S.D = D;
     (void)scan_stream;   // the run starts come out of the grouping kernel
     if (getenv("RB_DEBUG") && temp.p) {
         uint32_t nb = 0, mx = 0; uint64_t rec = 0;
-        group_debug_big(temp.p, S.N, 64 - g->sort_begin_bit, g->shard ? 3072 : 0, &nb, &rec, &mx);
+        group_debug_big(temp.p, S.N, 64 - g->sort_begin_bit, S.bucket_target, &nb, &rec, &mx, S.flags);
         fprintf(stderr, "[rb] grouping: N=%zu runs=%u; buckets that did not fit LDS: %u with %llu records, largest %u\n", S.N, D, nb, (unsigned long long)rec, mx);
     }
     return D;
@@ -1921,39 +1919,49 @@ void *rb::alloc_best_placed(size_t bytes, const char *what) {
     int tries = getenv("RB_ALLOC_TRIES") ? atoi(getenv("RB_ALLOC_TRIES")) : 8;
     tries = std::max(1, std::min(16, tries));
     if (bytes < ((size_t)1 << 30)) tries = 1;
-    void *best = nullptr;
+    // everything the trial holds is released on every way out, an exception included (several multi-GB candidates otherwise)
+    struct Held {
+        void *best = nullptr, *cand = nullptr;
+        unsigned long long *sink = nullptr;
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~Held() {
+            if (best) (void)hipFree(best);
+            if (cand) (void)hipFree(cand);
+            if (sink) (void)hipFree(sink);
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+        }
+    } H;
+    std::vector<void *> losers;                               // held while later candidates are drawn (so that they get other pages)
+    struct Losers { std::vector<void *> &v; ~Losers() { for (void *p : v) (void)hipFree(p); } } losers_guard{losers};
     float best_ms = 0;
-    std::vector<void *> losers;
-    unsigned long long *sink = nullptr;
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (tries > 1) { RB_HIP(hipMalloc(&sink, 64)); RB_HIP(hipEventCreate(&e0)); RB_HIP(hipEventCreate(&e1)); }
+    if (tries > 1) { RB_HIP(hipMalloc(&H.sink, 64)); RB_HIP(hipEventCreate(&H.e0)); RB_HIP(hipEventCreate(&H.e1)); }
     for (int t = 0; t < tries; ++t) {
         if (t) {
             size_t free_b = 0, total_b = 0;
             RB_HIP(hipMemGetInfo(&free_b, &total_b));
             if (free_b < bytes + total_b / 4) break;           // leave a quarter of the device to everything else
         }
-        void *p = nullptr;
-        if (hipMalloc(&p, bytes) != hipSuccess) { (void)hipGetLastError(); if (t) break; RB_HIP(hipErrorOutOfMemory); }
-        RB_HIP(hipMemset(p, 0, bytes));
+        if (hipMalloc(&H.cand, bytes) != hipSuccess) { H.cand = nullptr; (void)hipGetLastError(); if (t) break; RB_HIP(hipErrorOutOfMemory); }
+        RB_HIP(hipMemset(H.cand, 0, bytes));
         float ms = 0;
         if (tries > 1) {
             RB_HIP(hipDeviceSynchronize());
-            RB_HIP(hipEventRecord(e0, nullptr));
+            RB_HIP(hipEventRecord(H.e0, nullptr));
             for (int pass = 0; pass < 2; ++pass)               // the same places twice: zeros again afterwards
-                hipLaunchKernelGGL(k_alloc_probe, dim3(16384), dim3(256), 0, nullptr, static_cast<uint32_t *>(p), (uint64_t)(bytes / 4), 16u, sink);
-            RB_HIP(hipEventRecord(e1, nullptr));
-            RB_HIP(hipEventSynchronize(e1));
-            RB_HIP(hipEventElapsedTime(&ms, e0, e1));
+                hipLaunchKernelGGL(k_alloc_probe, dim3(16384), dim3(256), 0, nullptr, static_cast<uint32_t *>(H.cand), (uint64_t)(bytes / 4), 16u, H.sink);
+            RB_HIP(hipEventRecord(H.e1, nullptr));
+            RB_HIP(hipEventSynchronize(H.e1));
+            RB_HIP(hipEventElapsedTime(&ms, H.e0, H.e1));
         }
         if (getenv("RB_ALLOC_DEBUG")) fprintf(stderr, "[rb] %s allocation %d: %.3f ms for 2 x 2^26 random XORs\n", what, t, ms);
-        if (!best || ms < best_ms) { if (best) losers.push_back(best); best = p; best_ms = ms; }
-        else losers.push_back(p);
+        if (!H.best || ms < best_ms) { if (H.best) losers.push_back(H.best); H.best = H.cand; best_ms = ms; }
+        else losers.push_back(H.cand);
+        H.cand = nullptr;
     }
-    for (void *p : losers) (void)hipFree(p);
-    if (sink) (void)hipFree(sink);
-    if (e0) { (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); }
     RB_HIP(hipDeviceSynchronize());
+    void *best = H.best;
+    H.best = nullptr;
     return best;
 }
 
@@ -2203,8 +2211,9 @@ void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, ui
         // labels are run numbers (< D); the list is in run order and the sort is stable, so the label bits suffice
         const int label_end = 32 + (int)std::max(1u, log2_ceil((uint64_t)D));
         sort_keys_u64(g->temp.p, g->temp.cap, g->kk0.as<uint64_t>(), g->kk1.as<uint64_t>(), nck, 32, label_end, s);
-        sort_pairs_u64_u32(g->temp.p, g->temp.cap, g->opk0.as<uint64_t>(), g->opk1.as<uint64_t>(),
-                           g->opv0.as<uint32_t>(), g->opv1.as<uint32_t>(), nco, 0, label_end, s);
+        // op keys are (component label << 32) | occurrence id, and occurrence ids stop at occ_bits: two bit ranges
+        sort_pairs_u64_u32_2r(g->temp.p, g->temp.cap, g->opk0.as<uint64_t>(), g->opk1.as<uint64_t>(),
+                              g->opv0.as<uint32_t>(), g->opv1.as<uint32_t>(), nco, 0, (int)std::min(32u, std::max(1u, g->occ_bits)), 32, label_end, s);
         g->prof_end("conflict_gather_sort");
         g->prof_begin();
         RB_HIP(hipMemsetAsync(ctr + 4, 0, 4, s));
@@ -2260,7 +2269,7 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
                  (g->k <= RB_MPF_MAX_K ? (uint32_t)g->k - g->mpf_m + 1u <= RB_MPF_MAX_RING
                                        : filter_wide_mpf_ok(b, b->h_woff.empty() ? 0 : (int64_t)b->h_woff[(size_t)(first + n)] - (int64_t)b->h_woff[(size_t)first], g->k));
     g->seq_codes = b->codes; g->seq_woff = b->woff; g->seq_wpr = b->wpr_uniform;
-    struct MpfScope { rb_graph *g; ~MpfScope() { g->use_mpf = false; g->seq_codes = nullptr; g->seq_woff = nullptr; g->seq_wpr = 0; } } mpf_scope{g};
+    struct MpfScope { rb_graph *g; ~MpfScope() { g->use_mpf = false; g->seq_codes = nullptr; g->seq_woff = nullptr; g->seq_wpr = 0; g->occ_bits = 32; g->before_buckets = nullptr; } } mpf_scope{g};
     std::vector<Sub> subs;
     {
         int64_t r0 = first;
@@ -2546,6 +2555,7 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
             if (i + 1 < subs.size()) phase_a(i + 1);                                 // beside the consumer of sub-batch i
             g->cur = slot;
             g->seq_first = (uint32_t)subs[i].r0;
+            g->occ_bits = pos_bits + log2_ceil((uint64_t)std::max<int64_t>(1, subs[i].r1 - subs[i].r0));
             const std::function<void()> next = [&]() {
                 if (i + 1 >= subs.size()) return;
                 RB_HIP(hipEventRecord(g->ev0, s));
@@ -2575,6 +2585,7 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
         if (pairs_mode == 2 && !serial && !early) pairs_fork(i + 1, false);
         g->cur = slot;
         g->seq_first = (uint32_t)subs[i].r0;             // occurrence ids of this sub-batch are relative to its first read
+        g->occ_bits = pos_bits + log2_ceil((uint64_t)std::max<int64_t>(1, subs[i].r1 - subs[i].r0));
         // sub-batch i+1 is hashed / prefiltered as soon as sub-batch i's own-counter runs have retired (their
         // cache updates are what the prefilter needs); its sort + grouping then overlap the heavy and
         // conflicting runs of sub-batch i
@@ -3792,7 +3803,10 @@ int rb_shard_trav_advance(rb_graph *g, int64_t *n_active, int64_t *bit_counts, i
             RB_HIP(hipGetLastError());
             RB_HIP(hipMemcpyAsync(ctr, t->ta.ctr, 8, hipMemcpyDeviceToHost, s));
             RB_HIP(hipStreamSynchronize(s));
-            RB_REQUIRE(ctr[0] <= t->ta.req_cap, "rb_shard_trav_advance: %u requests from %zu walks", ctr[0], n);
+            // A branchy greedy step files 4 requests per neighbourhood its lookahead opens (12-16 with two or three candidates), so few walks
+            // on a rank can ask for more than the buffer holds.  The kernel drops what does not fit (p < req_cap) and leaves the walk
+            // suspended at the start of its step; the answers that did fit are cached, the replayed step asks for the rest next round.
+            ctr[0] = std::min(ctr[0], t->ta.req_cap);
         }
         t->n_req = ctr[0];
         *n_active = (int64_t)ctr[1];
@@ -3883,6 +3897,45 @@ int rb_debug_probe_cbf(rb_graph *g, int mode, float *ms_out) {
     });
 }
 
+int rb_debug_scan_u32(int device, const uint32_t *in, size_t n, uint32_t *out, int misalign) {
+    DevBuf a, b, t;
+    struct Rel { DevBuf &a, &b, &t; ~Rel() { a.release(); b.release(); t.release(); } } rel{a, b, t};
+    return guarded([&] {
+        RB_REQUIRE((in && out) || n == 0, "rb_debug_scan_u32: null array");
+        RB_REQUIRE(misalign >= 0 && misalign < 4, "rb_debug_scan_u32: misalign in 0..3");
+        RB_HIP(hipSetDevice(device));
+        a.reserve((n + 8) * 4); b.reserve((n + 8) * 4); t.reserve(scan_temp_bytes(n));
+        uint32_t *di = a.as<uint32_t>() + misalign, *dout = b.as<uint32_t>() + ((misalign + 1) & 3);
+        if (n) RB_HIP(hipMemcpy(di, in, n * 4, hipMemcpyHostToDevice));
+        exclusive_scan_u32(t.p, t.cap, di, dout, n, nullptr);
+        RB_HIP(hipGetLastError());
+        RB_HIP(hipDeviceSynchronize());
+        if (n) RB_HIP(hipMemcpy(out, dout, n * 4, hipMemcpyDeviceToHost));
+    });
+}
+int rb_debug_sort_pairs(int device, uint64_t *keys, void *vals, int vals64, size_t n, int lo_begin, int lo_end, int hi_begin, int hi_end) {
+    DevBuf k0, k1, v0, v1, t;
+    struct Rel { DevBuf &a, &b, &c, &d, &t; ~Rel() { a.release(); b.release(); c.release(); d.release(); t.release(); } } rel{k0, k1, v0, v1, t};
+    return guarded([&] {
+        RB_REQUIRE(keys || n == 0, "rb_debug_sort_pairs: null keys");
+        RB_REQUIRE(!(vals64 && hi_begin >= 0), "rb_debug_sort_pairs: two ranges with 32-bit values only");
+        RB_HIP(hipSetDevice(device));
+        if (n == 0) return;
+        const size_t vb = vals64 ? 8 : 4;
+        k0.reserve(n * 8); k1.reserve(n * 8);
+        if (vals) { v0.reserve(n * vb); v1.reserve(n * vb); RB_HIP(hipMemcpy(v0.p, vals, n * vb, hipMemcpyHostToDevice)); }
+        RB_HIP(hipMemcpy(k0.p, keys, n * 8, hipMemcpyHostToDevice));
+        t.reserve(vals64 ? sort_pairs32_temp_bytes(n) : sort_pairs_temp_bytes(n));
+        if (vals64) sort_pairs_u64_u64(t.p, t.cap, k0.as<uint64_t>(), k1.as<uint64_t>(), v0.as<uint64_t>(), v1.as<uint64_t>(), n, lo_begin, lo_end, nullptr);
+        else if (hi_begin >= 0) sort_pairs_u64_u32_2r(t.p, t.cap, k0.as<uint64_t>(), k1.as<uint64_t>(), v0.as<uint32_t>(), v1.as<uint32_t>(), n, lo_begin, lo_end, hi_begin, hi_end, nullptr);
+        else if (vals) sort_pairs_u64_u32(t.p, t.cap, k0.as<uint64_t>(), k1.as<uint64_t>(), v0.as<uint32_t>(), v1.as<uint32_t>(), n, lo_begin, lo_end, nullptr);
+        else sort_keys_u64(t.p, t.cap, k0.as<uint64_t>(), k1.as<uint64_t>(), n, lo_begin, lo_end, nullptr);
+        RB_HIP(hipGetLastError());
+        RB_HIP(hipDeviceSynchronize());
+        RB_HIP(hipMemcpy(keys, k1.p, n * 8, hipMemcpyDeviceToHost));
+        if (vals) RB_HIP(hipMemcpy(vals, v1.p, n * vb, hipMemcpyDeviceToHost));
+    });
+}
 int rb_filter_size(rb_graph *g, int which, int64_t *size, int64_t *nbytes, int *num_hash) {
     if (!g) { set_error("null graph"); return RB_ERR_INVALID; }
     if (which == RB_CBF) {

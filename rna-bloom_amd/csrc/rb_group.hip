@@ -273,7 +273,7 @@ __global__ void __launch_bounds__(TPB) k_part_scatter(const uint64_t *__restrict
         const uint32_t j = w * SEG + r * 64u + lane;
         bool ok = j < t.count;
         k[r] = ok ? keys_in[t.start + j] : 0ull;
-        v[r] = ok ? vals_in[t.start + j] : 0u;
+        v[r] = (ok && vals_in) ? vals_in[t.start + j] : 0u;
         if (skip_dead && k[r] == GR_DEAD_KEY && v[r] == GR_DEAD_VAL) ok = false;          // cancelled by the emit pass: not scattered
         dig[r] = ok ? gr_digit(k[r], shift, bits) : ~0u;
     }
@@ -300,7 +300,8 @@ __global__ void __launch_bounds__(TPB) k_part_scatter(const uint64_t *__restrict
     for (uint32_t j = threadIdx.x; j < live; j += TPB) {
         const uint64_t key = s_keys[j];
         const uint32_t g = s_cnt[gr_digit(key, shift, bits)] + j;
-        keys_out[g] = key; vals_out[g] = s_vals[j];
+        keys_out[g] = key;
+        if (vals_out) vals_out[g] = s_vals[j];              // (uniform: key-only sorts pass no values)
     }
 }
 
@@ -880,6 +881,107 @@ static void part_pass(const GrTiling &tl, size_t entries, uint32_t shift, uint32
     if (bits <= 8u) hipLaunchKernelGGL((k_part_scatter<TPB, 8>), grid, blk, 0, st, kin, vin, tl, shift, bits, goffs, kout, vout, wide, n_live_dev ? 1u : 0u);
     else hipLaunchKernelGGL((k_part_scatter<TPB, GR_PART_MAX_BITS>), grid, blk, 0, st, kin, vin, tl, shift, bits, goffs, kout, vout, wide, n_live_dev ? 1u : 0u);
     if (prof) prof->prof_end("group_part_scatter", st);
+}
+
+// ---- LSD radix sort out of the same stable partition passes --------------------------------------------------
+// The conflict path (rb_graph.hip, rb_shard.hip) and the sketch sets (rb_sketch.hip) need a few full sorts of small arrays
+// (10^5 ... 10^7 keys).  A stable partition on one digit, repeated from the lowest digit up, IS an LSD radix sort, and the
+// stable partition exists above: k_part_count -> scan -> k_part_scatter on a uniform tiling.  Digits of up to 10 bits; the bit
+// ranges a caller knows to be constant are skipped; the passes ping-pong between the input and output arrays (the INPUT arrays
+// are scratch: every caller is done with them) and an even pass count ends with one copy.  Replaces rocPRIM's onesweep (rounds 1-3).
+namespace {
+struct LsdPlan {
+    uint32_t ntiles = 0, n_pass = 0, shift[16], bits[16];
+    size_t entries = 0, off_hist = 0, off_goffs = 0, off_scan = 0, scan_bytes = 0, off_idx = 0, total = 0;
+};
+LsdPlan lsd_plan(size_t n, const int (*ranges)[2], int n_ranges, bool idx_vals) {
+    LsdPlan P;
+    P.ntiles = (uint32_t)((n + GR_TILE - 1) / GR_TILE);
+    uint32_t maxbits = 0;
+    for (int r = 0; r < n_ranges; ++r) {
+        const uint32_t B = (uint32_t)std::max(0, ranges[r][1] - ranges[r][0]);
+        const uint32_t np = (B + GR_PART_MAX_BITS - 1) / GR_PART_MAX_BITS;      // digits of at most 10 bits, spread evenly
+        uint32_t lo = (uint32_t)ranges[r][0], left = B;
+        for (uint32_t q = 0; q < np; ++q) {
+            const uint32_t b = (left + (np - q) - 1) / (np - q);
+            P.shift[P.n_pass] = lo; P.bits[P.n_pass] = b; ++P.n_pass;
+            lo += b; left -= b;
+            maxbits = std::max(maxbits, b);
+        }
+    }
+    P.entries = ((size_t)P.ntiles << maxbits) + 2;
+    size_t o = 0;
+    P.off_hist = o; o += gr_align(P.entries * 4);
+    P.off_goffs = o; o += gr_align(P.entries * 4);
+    P.scan_bytes = gr_align(scan_temp_bytes(P.entries));
+    P.off_scan = o; o += P.scan_bytes;
+    if (idx_vals) { P.off_idx = o; o += 2 * gr_align(n * 4); }
+    P.total = o;
+    return P;
+}
+void lsd_sort(const LsdPlan &P, char *tp, uint64_t *k_in, uint64_t *k_out, uint32_t *v_in, uint32_t *v_out, size_t n, hipStream_t st) {
+    uint32_t *hist = reinterpret_cast<uint32_t *>(tp + P.off_hist), *goffs = reinterpret_cast<uint32_t *>(tp + P.off_goffs);
+    const GrTiling tl{nullptr, nullptr, (uint32_t)n, P.ntiles, gr_grid_for_tiles(P.ntiles), 1};
+    uint64_t *ka = k_in, *kb = k_out;
+    uint32_t *va = v_in, *vb = v_out;
+    for (uint32_t q = 0; q < P.n_pass; ++q) {
+        part_pass<512>(tl, (size_t)P.ntiles << P.bits[q], P.shift[q], P.bits[q], ka, va, kb, vb, hist, goffs, tp + P.off_scan, P.scan_bytes, st, nullptr);
+        std::swap(ka, kb); std::swap(va, vb);
+    }
+    if ((P.n_pass & 1u) == 0) {                         // an even number of passes (or none) leaves the result in the input arrays
+        RB_HIP(hipMemcpyAsync(k_out, k_in, n * 8, hipMemcpyDeviceToDevice, st));
+        if (v_in && v_out) RB_HIP(hipMemcpyAsync(v_out, v_in, n * 4, hipMemcpyDeviceToDevice, st));
+    }
+}
+__global__ void k_lsd_iota(uint32_t *__restrict__ v, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) v[i] = (uint32_t)i;
+}
+__global__ void k_lsd_gather64(const uint32_t *__restrict__ idx, const uint64_t *__restrict__ src, uint64_t *__restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[idx[i]];
+}
+}  // namespace
+
+size_t sort_pairs_temp_bytes(size_t n) { const int r[1][2] = {{0, 64}}; return lsd_plan(n, r, 1, false).total; }
+size_t sort_keys_temp_bytes(size_t n) { return sort_pairs_temp_bytes(n); }
+size_t sort_pairs32_temp_bytes(size_t n) { const int r[1][2] = {{0, 64}}; return lsd_plan(n, r, 1, true).total; }
+// stable sort of (key, value) pairs on key bits [begin_bit, end_bit); keys_in / vals_in are clobbered
+void sort_pairs_u64_u32(void *temp, size_t temp_bytes, uint64_t *keys_in, uint64_t *keys_out, uint32_t *vals_in, uint32_t *vals_out, size_t n,
+                        int begin_bit, int end_bit, hipStream_t s) {
+    if (n == 0) return;
+    RB_REQUIRE(n < (1ull << 32) - 2 * GR_TILE, "sort_pairs_u64_u32: too many records");
+    const int r[1][2] = {{begin_bit, end_bit}};
+    const LsdPlan P = lsd_plan(n, r, 1, false);
+    RB_REQUIRE(temp_bytes >= P.total, "sort_pairs_u64_u32: temp too small");
+    lsd_sort(P, static_cast<char *>(temp), keys_in, keys_out, vals_in, vals_out, n, s);
+}
+// the same on two bit ranges, the lower one first (the bits between them are known to be equal in all keys)
+void sort_pairs_u64_u32_2r(void *temp, size_t temp_bytes, uint64_t *keys_in, uint64_t *keys_out, uint32_t *vals_in, uint32_t *vals_out, size_t n,
+                           int lo_begin, int lo_end, int hi_begin, int hi_end, hipStream_t s) {
+    if (n == 0) return;
+    RB_REQUIRE(n < (1ull << 32) - 2 * GR_TILE, "sort_pairs_u64_u32_2r: too many records");
+    const int r[2][2] = {{lo_begin, lo_end}, {hi_begin, hi_end}};
+    const LsdPlan P = lsd_plan(n, r, 2, false);
+    RB_REQUIRE(temp_bytes >= P.total, "sort_pairs_u64_u32_2r: temp too small");
+    lsd_sort(P, static_cast<char *>(temp), keys_in, keys_out, vals_in, vals_out, n, s);
+}
+void sort_keys_u64(void *temp, size_t temp_bytes, uint64_t *keys_in, uint64_t *keys_out, size_t n, int begin_bit, int end_bit, hipStream_t s) {
+    sort_pairs_u64_u32(temp, temp_bytes, keys_in, keys_out, nullptr, nullptr, n, begin_bit, end_bit, s);
+}
+// 64-bit values: the pairs are sorted as (key, index) and the values gathered through the sorted indices
+void sort_pairs_u64_u64(void *temp, size_t temp_bytes, uint64_t *keys_in, uint64_t *keys_out, uint64_t *vals_in, uint64_t *vals_out, size_t n,
+                        int begin_bit, int end_bit, hipStream_t s) {
+    if (n == 0) return;
+    RB_REQUIRE(n < (1ull << 32) - 2 * GR_TILE, "sort_pairs_u64_u64: too many records");
+    const int r[1][2] = {{begin_bit, end_bit}};
+    const LsdPlan P = lsd_plan(n, r, 1, true);
+    RB_REQUIRE(temp_bytes >= P.total, "sort_pairs_u64_u64: temp too small");
+    char *tp = static_cast<char *>(temp);
+    uint32_t *i0 = reinterpret_cast<uint32_t *>(tp + P.off_idx), *i1 = reinterpret_cast<uint32_t *>(tp + P.off_idx + gr_align(n * 4));
+    hipLaunchKernelGGL(k_lsd_iota, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, i0, n);
+    lsd_sort(P, tp, keys_in, keys_out, i0, i1, n, s);
+    hipLaunchKernelGGL(k_lsd_gather64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, i1, vals_in, vals_out, n);
 }
 
 // Groups the N records (keys0, vals0) — both arrays are clobbered; (keys_tmp, vals_tmp) is scratch of the same size.

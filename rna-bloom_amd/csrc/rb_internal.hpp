@@ -96,11 +96,15 @@ struct rb_batch {
 
 namespace rb {
 
-// rocPRIM-backed primitives (rb_sort.hip)
+// device-wide sort / scan / selection primitives (hand-written: scans and selection in rb_sort.hip, the LSD radix sorts in
+// rb_group.hip on the grouping stage's stable partition passes).  The sorts clobber their INPUT arrays.
 size_t sort_pairs_temp_bytes(size_t n);
 void sort_pairs_u64_u32(void *temp, size_t temp_bytes, uint64_t *keys_in, uint64_t *keys_out,
                         uint32_t *vals_in, uint32_t *vals_out, size_t n, int begin_bit, int end_bit,
                         hipStream_t s);
+// the same on two bit ranges, the lower first (the bits in between are equal in all keys)
+void sort_pairs_u64_u32_2r(void *temp, size_t temp_bytes, uint64_t *keys_in, uint64_t *keys_out, uint32_t *vals_in, uint32_t *vals_out, size_t n,
+                           int lo_begin, int lo_end, int hi_begin, int hi_end, hipStream_t s);
 size_t sort_pairs32_temp_bytes(size_t n);
 void sort_pairs_u64_u64(void *temp, size_t temp_bytes, uint64_t *keys_in, uint64_t *keys_out,
                         uint64_t *vals_in, uint64_t *vals_out, size_t n, int begin_bit, int end_bit,

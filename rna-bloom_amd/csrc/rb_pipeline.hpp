@@ -340,7 +340,7 @@ struct rb_graph {
     hipStream_t stream2 = nullptr;   // producer stream: hashing + grouping of the NEXT sub-batch (scratch only)
     hipStream_t stream3 = nullptr;   // side stream of the producer: the paired-k-mer walker (rpkbf only) beside the window walk
     // grouped sub-batch, double buffered so that grouping of sub-batch i+1 overlaps the filter stages of i
-    struct GroupSlot { DevBuf keys1, valsT, vals1, tz, uniq, counts, starts; size_t N = 0; uint32_t D = 0; int flags = 0; uint32_t live = 0; };
+    struct GroupSlot { DevBuf keys1, valsT, vals1, tz, uniq, counts, starts; size_t N = 0; uint32_t D = 0; int flags = 0; uint32_t live = 0; int bucket_target = 0; /* what group_enqueue planned with */ };
     GroupSlot slots[2];
     int cur = 0;
     DevBuf &keys1() { return slots[cur].keys1; }
@@ -362,6 +362,7 @@ struct rb_graph {
     const uint32_t *seq_woff = nullptr;
     uint32_t seq_wpr = 0;
     uint32_t seq_first = 0;
+    uint32_t occ_bits = 32;       // occurrence ids of the sub-batch in flight are below 2^occ_bits (the conflict sort skips the bits above)
     bool use_mpf = false;
     // scratch (grow-only)
     DevBuf chunk_cnt, chunk_off, keys0, vals0, status, nops, temp,

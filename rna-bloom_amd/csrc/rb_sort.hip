@@ -1,79 +1,123 @@
-// rb_sort.hip — device-wide sort / scan / run-length primitives (rocPRIM), isolated in their own
-// translation unit because the templates are slow to compile.
+// rb_sort.hip — device-wide scan / selection primitives, written for gfx950 (no library code on the insert path).
+//
+// Rounds 1-3 called rocPRIM here.  Its decoupled look-back scan spins: a block waits for the published prefix of its
+// predecessors, and when the device is shared with another stream's kernels (the producer's window walk runs beside every
+// scan of the consumer) the predecessors may not even be resident — scans of 20 k-75 k threads took 1-3.5 ms each, 27.8 ms of
+// kernel time per step (profiles/r03_kernel_stats.csv, gpurun_out/r03_scans.txt).  The scans below never wait for another
+// workgroup: reduce per tile -> one workgroup scans the tile sums -> apply (the input is read twice instead of once, which
+// the arrays in question — at most a few hundred MB, mostly a few MB — do not notice), and arrays of up to 32 K entries are
+// scanned by a single workgroup in one launch.  The radix sorts of the conflict path are LSD passes of the grouping stage's
+// own stable partition kernels (rb_group.hip: lsd_sort_*).
 #include <cstring>
-
-#include <rocprim/rocprim.hpp>
 
 #include "rb_internal.hpp"
 
 namespace rb {
 
-// rocPRIM (ROCm 7.2) routes 4K < n <= 1M through a merge-sort sub-algorithm that returns WRONGLY
-// ORDERED output when begin_bit > 0 (verified on gfx950: bad order + instability at n = 250000,
-// begin_bit = 32; onesweep and the single-block sort are correct and stable).  MergeSortLimit = 0
-// disables that sub-algorithm.
-using sort_config = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config,
-                                               rocprim::default_config, 0>;
+namespace {
+constexpr uint32_t SC_VEC = 4;                       // items per thread per sub-tile
+constexpr uint32_t SC_TPB = 256, SC_SUB = SC_TPB * SC_VEC, SC_SUBS = 16, SC_TILE = SC_SUB * SC_SUBS;   // 16384 items per tile
+constexpr uint32_t SC_ONE_TPB = 1024, SC_ONE_MAX = 32768;   // single-workgroup path
 
-size_t sort_pairs_temp_bytes(size_t n) {
-    size_t bytes = 0;
-    RB_HIP(rocprim::radix_sort_pairs<sort_config>(nullptr, bytes, (uint64_t *)nullptr, (uint64_t *)nullptr,
-                                     (uint32_t *)nullptr, (uint32_t *)nullptr, n, 0, 64));
-    return bytes;
+// One sub-tile of TPB x 4 items at in[base ...): exclusive scan with `carry` added, written to out; returns carry + the
+// sub-tile's sum.  Striped (coalesced) global accesses, blocked scan through LDS; no alignment assumptions; in == out is fine.
+template <uint32_t TPB>
+__device__ __forceinline__ uint32_t sc_sub_scan(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, size_t base, size_t n, uint32_t carry,
+                                                uint32_t *s_data /* [TPB * 4], 16-byte aligned */, uint32_t *s_wsum /* [TPB / 64] */) {
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+#pragma unroll
+    for (uint32_t i = 0; i < SC_VEC; ++i) {
+        const size_t x = base + (size_t)i * TPB + tid;
+        s_data[i * TPB + tid] = x < n ? in[x] : 0u;
+    }
+    __syncthreads();
+    uint4 v = reinterpret_cast<const uint4 *>(s_data)[tid];
+    const uint32_t e1 = v.x, e2 = e1 + v.y, e3 = e2 + v.z, tot = e3 + v.w;
+    uint32_t inc = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const uint32_t t = __shfl_up(inc, o, 64);
+        if ((int)lane >= o) inc += t;
+    }
+    if (lane == 63u) s_wsum[w] = inc;
+    __syncthreads();
+    uint32_t wbase = 0, total = 0;
+#pragma unroll
+    for (uint32_t i = 0; i < TPB / 64; ++i) {
+        const uint32_t t = s_wsum[i];
+        if (i < w) wbase += t;
+        total += t;
+    }
+    const uint32_t b0 = carry + wbase + inc - tot;
+    reinterpret_cast<uint4 *>(s_data)[tid] = make_uint4(b0, b0 + e1, b0 + e2, b0 + e3);
+    __syncthreads();
+#pragma unroll
+    for (uint32_t i = 0; i < SC_VEC; ++i) {
+        const size_t x = base + (size_t)i * TPB + tid;
+        if (x < n) out[x] = s_data[i * TPB + tid];
+    }
+    __syncthreads();                                   // s_data / s_wsum are reused by the caller's next sub-tile
+    return carry + total;
 }
-void sort_pairs_u64_u32(void *temp, size_t temp_bytes, uint64_t *keys_in, uint64_t *keys_out,
-                        uint32_t *vals_in, uint32_t *vals_out, size_t n, int begin_bit, int end_bit,
-                        hipStream_t s) {
-    RB_HIP(rocprim::radix_sort_pairs<sort_config>(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n,
-                                     (unsigned)begin_bit, (unsigned)end_bit, s));
+
+__global__ void __launch_bounds__(SC_ONE_TPB) k_scan_one(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, size_t n) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_data[SC_ONE_TPB * SC_VEC];
+    __shared__ uint32_t s_wsum[SC_ONE_TPB / 64];
+    uint32_t carry = 0;
+    for (size_t base = 0; base < n; base += SC_ONE_TPB * SC_VEC) carry = sc_sub_scan<SC_ONE_TPB>(in, out, base, n, carry, s_data, s_wsum);
 }
-size_t sort_pairs32_temp_bytes(size_t n) {
-    size_t bytes = 0;
-    RB_HIP(rocprim::radix_sort_pairs<sort_config>(nullptr, bytes, (uint64_t *)nullptr, (uint64_t *)nullptr,
-                                     (uint64_t *)nullptr, (uint64_t *)nullptr, n, 0, 64));
-    return bytes;
+
+__global__ void __launch_bounds__(SC_TPB) k_scan_reduce(const uint32_t *__restrict__ in, size_t n, uint32_t *__restrict__ tile_sums) {
+    __shared__ uint32_t s_w[SC_TPB / 64];
+    const size_t base = (size_t)blockIdx.x * SC_TILE;
+    uint32_t sum = 0;
+#pragma unroll 8
+    for (uint32_t j = 0; j < SC_TILE / SC_TPB; ++j) {
+        const size_t x = base + (size_t)j * SC_TPB + threadIdx.x;
+        sum += x < n ? in[x] : 0u;
+    }
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_down(sum, o, 64);
+    if ((threadIdx.x & 63u) == 0) s_w[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (uint32_t q = 0; q < SC_TPB / 64; ++q) t += s_w[q];
+        tile_sums[blockIdx.x] = t;
+    }
 }
-void sort_pairs_u64_u64(void *temp, size_t temp_bytes, uint64_t *keys_in, uint64_t *keys_out,
-                        uint64_t *vals_in, uint64_t *vals_out, size_t n, int begin_bit, int end_bit,
-                        hipStream_t s) {
-    RB_HIP(rocprim::radix_sort_pairs<sort_config>(temp, temp_bytes, keys_in, keys_out, vals_in, vals_out, n,
-                                     (unsigned)begin_bit, (unsigned)end_bit, s));
+
+__global__ void __launch_bounds__(SC_TPB) k_scan_apply(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, size_t n,
+                                                       const uint32_t *__restrict__ tile_offs) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_data[SC_SUB];
+    __shared__ uint32_t s_wsum[SC_TPB / 64];
+    const size_t base = (size_t)blockIdx.x * SC_TILE;
+    uint32_t carry = tile_offs[blockIdx.x];
+    for (uint32_t q = 0; q < SC_SUBS; ++q) {
+        const size_t b = base + (size_t)q * SC_SUB;
+        if (b >= n) break;
+        carry = sc_sub_scan<SC_TPB>(in, out, b, n, carry, s_data, s_wsum);
+    }
 }
-size_t sort_keys_temp_bytes(size_t n) {
-    size_t bytes = 0;
-    RB_HIP(rocprim::radix_sort_keys<sort_config>(nullptr, bytes, (uint64_t *)nullptr, (uint64_t *)nullptr, n, 0, 64));
-    return bytes;
+}  // namespace
+
+size_t scan_temp_bytes(size_t n) { return ((n + SC_TILE - 1) / SC_TILE + 2) * 4 + 256; }
+
+// out[i] = in[0] + ... + in[i-1] (wrapping u32); in == out allowed.  Never waits for another workgroup.
+void exclusive_scan_u32(void *temp, size_t temp_bytes, const uint32_t *in, uint32_t *out, size_t n, hipStream_t s) {
+    if (n == 0) return;
+    if (n <= SC_ONE_MAX) {
+        hipLaunchKernelGGL(k_scan_one, dim3(1), dim3(SC_ONE_TPB), 0, s, in, out, n);
+        return;
+    }
+    const size_t nt = (n + SC_TILE - 1) / SC_TILE;
+    RB_REQUIRE(temp && temp_bytes >= scan_temp_bytes(n), "exclusive_scan_u32: temp too small");
+    RB_REQUIRE(nt < (1ull << 31), "exclusive_scan_u32: too many items");
+    uint32_t *sums = reinterpret_cast<uint32_t *>(temp);
+    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nt), dim3(SC_TPB), 0, s, in, n, sums);
+    hipLaunchKernelGGL(k_scan_one, dim3(1), dim3(SC_ONE_TPB), 0, s, sums, sums, nt);
+    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nt), dim3(SC_TPB), 0, s, in, out, n, sums);
 }
-void sort_keys_u64(void *temp, size_t temp_bytes, uint64_t *keys_in, uint64_t *keys_out, size_t n, int begin_bit,
-                   int end_bit, hipStream_t s) {
-    RB_HIP(rocprim::radix_sort_keys<sort_config>(temp, temp_bytes, keys_in, keys_out, n, (unsigned)begin_bit, (unsigned)end_bit, s));
-}
-size_t scan_temp_bytes(size_t n) {
-    size_t bytes = 0;
-    RB_HIP(rocprim::exclusive_scan(nullptr, bytes, (const uint32_t *)nullptr, (uint32_t *)nullptr,
-                                   0u, n, rocprim::plus<uint32_t>()));
-    return bytes;
-}
-void exclusive_scan_u32(void *temp, size_t temp_bytes, const uint32_t *in, uint32_t *out, size_t n,
-                        hipStream_t s) {
-    RB_HIP(rocprim::exclusive_scan(temp, temp_bytes, in, out, 0u, n, rocprim::plus<uint32_t>(), s));
-}
-struct MaskFlag {
-    uint32_t mask;
-    __host__ __device__ bool operator()(uint32_t st) const { return (st & mask) != 0u; }
-};
-size_t select_temp_bytes(size_t n) {
-    size_t bytes = 0;
-    auto flags = rocprim::make_transform_iterator((const uint32_t *)nullptr, MaskFlag{1u});
-    RB_HIP(rocprim::select(nullptr, bytes, rocprim::counting_iterator<uint32_t>(0), flags, (uint32_t *)nullptr,
-                           (uint32_t *)nullptr, n));
-    return bytes;
-}
-void select_flagged(void *temp, size_t temp_bytes, const uint32_t *status, uint32_t mask, size_t n, uint32_t *out,
-                    uint32_t *count_dev, hipStream_t s) {
-    auto flags = rocprim::make_transform_iterator(status, MaskFlag{mask});
-    RB_HIP(rocprim::select(temp, temp_bytes, rocprim::counting_iterator<uint32_t>(0), flags, out, count_dev, n, s));
-}
+
 // Two ordered index lists from one status array in two light passes (count per block, scan, write): the heavy and the
 // conflicting runs of a sub-batch are a few percent of the runs, and rocprim::select through a transform iterator
 // spent 0.75 ms per list on 36 M status words (190 GB/s) — this reads the words twice at full bandwidth instead.
@@ -128,7 +172,7 @@ __global__ void __launch_bounds__(S2_TPB) k_select2_write(const uint32_t *__rest
         if (st[i] & mask_a) out_a[oa + s_a[i * NW + wave] + (uint32_t)__popcll(ba[i] & below)] = x;
         if (st[i] & mask_b) out_b[ob + s_b[i * NW + wave] + (uint32_t)__popcll(bb[i] & below)] = x;
     }
-    if (blockIdx.x == 0 && threadIdx.x == 0) { count_dev[0] = tot_a; count_dev[1] = offs[2u * nblk] - tot_a; }
+    if (blockIdx.x == 0 && threadIdx.x == 0) { count_dev[0] = tot_a; if (mask_b) count_dev[1] = offs[2u * nblk] - tot_a; }
 }
 }  // namespace
 size_t select2_temp_bytes(size_t n) {
@@ -145,5 +189,12 @@ void select_flagged2(void *temp, size_t temp_bytes, const uint32_t *status, size
     hipLaunchKernelGGL(k_select2_count, dim3(nblk), dim3(S2_TPB), 0, s, status, n, mask_a, mask_b, nblk, counts);
     exclusive_scan_u32(scan_tmp, temp_bytes - 2 * arr, counts, offs, (size_t)2 * nblk + 1, s);
     hipLaunchKernelGGL(k_select2_write, dim3(nblk), dim3(S2_TPB), 0, s, status, n, mask_a, mask_b, nblk, offs, out_a, out_b, count_dev);
+}
+// one list: indices i with (status[i] & mask) != 0, in order; count to *count_dev
+size_t select_temp_bytes(size_t n) { return select2_temp_bytes(n); }
+void select_flagged(void *temp, size_t temp_bytes, const uint32_t *status, uint32_t mask, size_t n, uint32_t *out,
+                    uint32_t *count_dev, hipStream_t s) {
+    if (n == 0) { RB_HIP(hipMemsetAsync(count_dev, 0, 4, s)); return; }
+    select_flagged2(temp, temp_bytes, status, n, mask, out, 0u, out, count_dev, s);
 }
 }  // namespace rb

@@ -140,6 +140,8 @@ SYMBOLS = [
     ("rb_shard_add_range", _i32, [_vp, _vp, _vp, _i64, _i64, C.c_uint, _i64, C.c_uint32, C.c_uint64, C.POINTER(AddStats)]),
     ("rb_shard_span", _i32, [_vp, _i32, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64)]),
     ("rb_debug_probe_cbf", _i32, [_vp, _i32, C.POINTER(C.c_float)]),
+    ("rb_debug_scan_u32", _i32, [_i32, _vp, _sz, _vp, _i32]),
+    ("rb_debug_sort_pairs", _i32, [_i32, _vp, _vp, _i32, _sz, _i32, _i32, _i32, _i32]),
     ("rb_graph_profile_enable", _i32, [_vp, _i32]),
     ("rb_graph_profile_get", _i32, [_vp, C.POINTER(Profile), _i32]),
 ]

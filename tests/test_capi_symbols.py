@@ -90,7 +90,7 @@ def test_every_native_method_has_a_jni_function_that_calls_the_c_abi():
         called |= hits
     # everything a single-process host needs is reachable from Java (the rb_shard_* phases belong to the multi-GPU driver)
     missing = {s for s in exported - called if not s.startswith("rb_shard_") and s not in (
-        "rb_last_error", "rb_graph_create_shard", "rb_graph_profile_enable", "rb_graph_profile_get", "rb_batch_create_synthetic", "rb_debug_probe_cbf",
+        "rb_last_error", "rb_graph_create_shard", "rb_graph_profile_enable", "rb_graph_profile_get", "rb_batch_create_synthetic", "rb_debug_probe_cbf", "rb_debug_scan_u32", "rb_debug_sort_pairs",
         "rb_batch_download_ascii", "rb_nthash_batch", "rb_graph_add_batch")}
     assert not missing, missing
 
@@ -132,5 +132,20 @@ def test_java_drop_in_classes_keep_every_public_signature_of_the_reference():
         # ... and the class really goes through the JNI surface: every NativeGraph member it names exists
         used = set(re.findall(r"NativeGraph\.(\w+)\(", src))
         assert used and used <= natives, (cls, used - natives)
+    # the hottest query of the reference (graph.getKmers: 18 call sites) goes through the BATCHED native, not through one getCount per k-mer
+    g = open(os.path.join(ROOT, "java", "rnabloom", "graph", "BloomFilterDeBruijnGraph.java")).read()
+    g = re.sub(r"/\*.*?\*/", "", g, flags=re.S)
+    assert "hashFunction.getKmers(" not in g
+    prof = g[g.index("private WindowProfile profile("):]
+    assert "NativeGraph.getKmers(handle" in prof[:prof.index("\n    }\n")]
+    for sig in ("public ArrayList<Kmer> getKmers(String seq)", "public ArrayList<Kmer> getKmers(String seq, int start, int end)",
+                "public ArrayList<Kmer> getKmers(String seq, float minCoverage)"):
+        body = g[g.index(sig):]
+        body = body[:body.index("\n    }\n") if "\n    }\n" in body[:4000] and body.index("{") < body.index("\n") and not body[:body.index("\n")].rstrip().endswith("}") else body.index("\n")]
+        assert "profile(" in body or "getKmers(seq, 0, seq.length())" in body, sig
+    # the variants and isValidSeq are one batched lookup each
+    for name in ("endVariants", "isValidSeq"):
+        body = g[g.index(name + "("):]
+        assert "NativeGraph.contains(handle" in body[:body.index("\n    }\n")], name
     worker = open(os.path.join(ROOT, "java", "rnabloom", "graph", "NativeFastqToGraphWorker.java")).read()
     assert "NativeGraph.addReads(" in worker and "implements Runnable" in worker
