@@ -77,7 +77,8 @@ def algorithmic_bytes(stage, n_kmers, n_pairs, n_runs, words, n_sorted=None, gro
 PMC_KERNELS = {"filter_windows": "rb::k_filter_reads", "hash_windows": "rb::k_hash_windows_resume",
                "probe_claim": "k_probe", "resolve_apply": "k_resolve_apply", "pairs_insert": "k_pairs_reads",
                "group_part_count": "rb::k_part_count", "group_part_scatter": "rb::k_part_scatter", "group_buckets": "rb::k_group_buckets"}
-PMC_FILES = ("r03_pmc_fetch_size.csv", "r03_pmc_write_size.csv")
+PMC_TAG = next((t for t in ("r04", "r03") if os.path.exists(os.path.join(ROOT, "profiles", t + "_pmc_fetch_size.csv"))), "r04")
+PMC_FILES = (PMC_TAG + "_pmc_fetch_size.csv", PMC_TAG + "_pmc_write_size.csv")
 # Correction of FETCH_SIZE (MI355X_MICROARCH.md, HBM / rocprofv3 section: the counter tallies 128-byte requests of wide
 # coalesced streaming reads as 64 bytes; "other access widths are uncalibrated: calibrate on a known byte count in your
 # own access pattern").  Calibration committed in profiles/r03_pmc_calibration.txt: (1) k_part_count reads exactly 8 bytes per
@@ -133,6 +134,30 @@ def pmc_step_bytes(stage):
             return None
         tot += sum(float(r[2]) for r in hit) * 1024.0 * (FETCH_FACTOR.get(stage, 1.0) if "fetch" in name else 1.0)
     return tot / PMC_RUN_STEPS
+
+
+def pmc_path_bytes():
+    """HBM bytes per STEP of EVERY kernel of the step by the committed counters (FETCH_SIZE corrected per kernel as above, x 1 for the
+    kernels without a calibration, + WRITE_SIZE), and the part of it that is the prefilter cache's bucket fetches (filter_windows' FETCH_SIZE
+    beyond the 16 B per word of packed reads it streams): (total, cache_fetches) or None"""
+    factor_of = {PMC_KERNELS[st]: f for st, f in FETCH_FACTOR.items() if st in PMC_KERNELS}
+    total = cache = 0.0
+    for name in PMC_FILES:
+        path = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(path):
+            return None
+        for line in open(path).read().splitlines()[1:]:
+            r = line.rsplit(",", 3)
+            if len(r) != 4 or r[0].startswith("k_synth") or r[0].startswith("k_alloc_probe"):      # (outside the timed steps)
+                continue
+            f = 1.0
+            if "fetch" in name:
+                f = next((v for kk, v in factor_of.items() if r[0].startswith(kk)), 1.0)
+            b = float(r[2]) * 1024.0 * f
+            total += b
+            if "fetch" in name and r[0].startswith(PMC_KERNELS["filter_windows"]):
+                cache += b
+    return total / PMC_RUN_STEPS, cache / PMC_RUN_STEPS
 
 
 def parse():
@@ -290,12 +315,21 @@ def main():
                 traffic = pmc_traffic(dom_name) if default_cfg else None      # the PMC passes profiled exactly this command
                 roof = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                        "traffic_source": "profiles/r03_pmc_{fetch,write}_size.csv (separate rocprofv3 --pmc passes of this command), bytes per kernel launch, FETCH_SIZE x %.0f (calibration: profiles/r03_pmc_calibration.txt)" % FETCH_FACTOR.get(dom_name, 1.0) if traffic else None,
+                        "traffic_source": "profiles/%s_pmc_{fetch,write}_size.csv (separate rocprofv3 --pmc passes of this command), bytes per kernel launch, FETCH_SIZE x %.0f (calibration: profiles/%s_pmc_calibration.txt)" % (PMC_TAG, FETCH_FACTOR.get(dom_name, 1.0), PMC_TAG) if traffic else None,
                         "note": "dominant stage by HIP-event time on its own stream; achieved = model bytes / measured time, traffic = counters",
                         "algorithmic_bytes_per_launch": int(ab / dom_launches),
                         "avg_launch_ms": round(dom_ms / dom_launches, 3), "launches": dom_launches,
                         "all_stages_model_GBps": per_stage,
                         "all_stages_GB_per_step": per_stage_gb}     # model bytes beside the counters' (committed PMC passes)
+                # the PATH's roofline, not only the dominant kernel's: every HBM byte the counters saw in a step (all kernels) over the
+                # step's wall time; and how much of that is the prefilter cache deciding to DROP occurrences (bytes this design added)
+                pb = pmc_path_bytes() if default_cfg else None
+                if pb:
+                    streamed = 16.0 * words / a.steps                 # the packed reads the prefilter walks anyway
+                    roof["path_bytes_per_step"] = int(pb[0])
+                    roof["path_frac"] = round(pb[0] / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+                    roof["prefilter_cache_share"] = round(max(0.0, pb[1] - streamed) / pb[0], 4)
+                    roof["path_note"] = "path_frac = counter bytes of ALL kernels per step (profiles/%s_pmc_*.csv) / this run's ms_per_step / peak" % PMC_TAG
         out = {
             "metric": "k-mers/sec hashed+inserted into Bloom dBG (k=25, 50M 150bp reads)",
             "value": value, "unit": "k-mers/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,

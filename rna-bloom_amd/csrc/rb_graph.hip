@@ -1850,9 +1850,20 @@ void rb::group_enqueue(rb_graph *g, int slot, size_t N, uint64_t ordinal0, uint3
     temp.reserve(group_temp_bytes(N, group_bits, bucket_target, flags));
     S.keys1.reserve(N * 8); S.valsT.reserve(N * 4); S.vals1.reserve(N * 4); S.tz.reserve(N + 16);
     S.uniq.reserve(N * 8); S.counts.reserve((N + 1) * 4); S.starts.reserve((N + 1) * 4);
+    // Index-keyed first partition pass (rb_internal.hpp GrIdx): runs come out sweeping the filters by first index.  It costs three
+    // Barrett reductions per record in the first pass and buys locality of the first Bloom bit / first counter of consecutive runs, which pays
+    // when a sub-batch is mostly NEW k-mers (several first-probe atomics per filter line: long reads, low coverage) and about breaks even
+    // on config 2 (one touch per five lines): on when the sub-batch before had more runs than half its records.  RB_GROUP_IDX=0|1 forces it.
+    GrIdx gidx{Mod{1, 0, 0}, 0, 0};
+    bool want_idx = g->group_idx;
+    if (const char *e = getenv("RB_GROUP_IDX")) want_idx = atoi(e) != 0;
+    if (want_idx) {
+        if (g->cbf && g->cbf_size > 0) gidx = GrIdx{g->cbf_mod, (uint64_t)g->cbf_lo, (uint64_t)(g->cbf_hi - g->cbf_lo)};
+        else if (g->dbg.bits && g->dbg.size > 0) gidx = GrIdx{g->dbg.mod, (uint64_t)g->dbg.lo, (uint64_t)(g->dbg.hi - g->dbg.lo)};
+    }
     group_records_device(g->keys0.as<uint64_t>(), g->vals0.as<uint32_t>(), S.keys1.as<uint64_t>(), S.valsT.as<uint32_t>(), N, group_bits,
                          g->p.rng_seed, ordinal0, pos_bits, temp.p, temp.cap, S.vals1.as<uint32_t>(), S.tz.as<uint8_t>(), S.uniq.as<uint64_t>(),
-                         S.counts.as<uint32_t>(), S.starts.as<uint32_t>(), ctr + 8, st, g, bucket_target, flags);
+                         S.counts.as<uint32_t>(), S.starts.as<uint32_t>(), ctr + 8, st, g, bucket_target, flags, gidx);
 }
 uint32_t rb::group_finish(rb_graph *g, int slot, hipStream_t st, DevBuf &temp, DevBuf &ctrbuf, hipStream_t scan_stream) {
     rb_graph::GroupSlot &S = g->slots[slot];
@@ -1864,6 +1875,7 @@ uint32_t rb::group_finish(rb_graph *g, int slot, hipStream_t st, DevBuf &temp, D
     RB_HIP(hipStreamSynchronize(st));
     RB_REQUIRE(D < (1u << 30), "sub-batch has too many distinct k-mers (%u)", D);
     S.D = D;
+    g->group_idx = S.N >= 4096 && (uint64_t)D * 2u > (uint64_t)S.N;    // mostly single-occurrence runs: the next grouping sweeps the filters by index
     (void)scan_stream;   // the run starts come out of the grouping kernel
     if (getenv("RB_DEBUG") && temp.p) {
         uint32_t nb = 0, mx = 0; uint64_t rec = 0;

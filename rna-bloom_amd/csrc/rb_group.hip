@@ -46,6 +46,13 @@ constexpr uint32_t GR_DEAD_VAL = ~0u;
 __device__ __forceinline__ uint32_t gr_digit(uint64_t key, uint32_t shift, uint32_t bits) {
     return (uint32_t)(key >> shift) & ((1u << bits) - 1u);
 }
+// first-pass digit from the first filter index (GrIdx): floor((idx_0 - lo) * 2^bits / span), as one mulhi with mul = floor(2^(64+bits) / span)
+struct GrIdxDev { Mod mod; uint64_t lo, mul; };          // mul == 0: off (digits come from the hash bits)
+__device__ __forceinline__ uint32_t gr_idx_digit(uint64_t key, const GrIdxDev &ix, uint32_t bits) {
+    const uint64_t i = index_of(key, ix.mod) - ix.lo;    // (a key outside [lo, lo + span) — none exist on a shard — would land in the last bucket)
+    const uint32_t d = (uint32_t)__umul64hi(i, ix.mul);
+    return min(d, (1u << bits) - 1u);
+}
 __device__ __forceinline__ uint32_t gr_lanes_below(uint64_t m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
@@ -216,7 +223,8 @@ __device__ __forceinline__ bool gr_get_tile(const GrTiling &tl, GrTile &t) {
 // ---- partition pass: histogram per (digit, tile) -----------------------------------------------------
 template <int TPB>
 __global__ void __launch_bounds__(TPB) k_part_count(const uint64_t *__restrict__ keys, GrTiling tl, uint32_t shift, uint32_t bits,
-                                                    uint32_t *__restrict__ hist, const uint32_t *__restrict__ dead_vals = nullptr) {
+                                                    uint32_t *__restrict__ hist, const uint32_t *__restrict__ dead_vals = nullptr,
+                                                    GrIdxDev ix = GrIdxDev{Mod{1, 0, 0}, 0, 0}) {
     constexpr int ITEMS = GR_TILE / TPB;
     __shared__ uint32_t s_h[1u << GR_PART_MAX_BITS];
     GrTile t;
@@ -233,7 +241,8 @@ __global__ void __launch_bounds__(TPB) k_part_count(const uint64_t *__restrict__
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
         const uint32_t j = (uint32_t)i * TPB + threadIdx.x;
-        if (j < t.count && !(dead_vals && k[i] == GR_DEAD_KEY && dead_vals[t.start + j] == GR_DEAD_VAL)) atomicAdd(&s_h[gr_digit(k[i], shift, bits)], 1u);
+        if (j < t.count && !(dead_vals && k[i] == GR_DEAD_KEY && dead_vals[t.start + j] == GR_DEAD_VAL))
+            atomicAdd(&s_h[ix.mul ? gr_idx_digit(k[i], ix, bits) : gr_digit(k[i], shift, bits)], 1u);
     }
     __syncthreads();
     for (uint32_t d = threadIdx.x; d < nb; d += TPB) hist[(size_t)t.hist_base + (size_t)d * t.hist_stride] = s_h[d];
@@ -244,7 +253,7 @@ template <int TPB, int MAXBITS>
 __global__ void __launch_bounds__(TPB) k_part_scatter(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, GrTiling tl,
                                                       uint32_t shift, uint32_t bits, const uint32_t *__restrict__ goffs /* exclusive scan of hist */,
                                                       uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t wide_lds,
-                                                      uint32_t skip_dead = 0u) {
+                                                      uint32_t skip_dead = 0u, GrIdxDev ix = GrIdxDev{Mod{1, 0, 0}, 0, 0}) {
     constexpr uint32_t ITEMS = GR_TILE / TPB, NW = TPB / 64, SEG = 64 * ITEMS, MAXNB = 1u << MAXBITS;
     __shared__ uint64_t s_keys[GR_TILE];
     __shared__ uint32_t s_vals[GR_TILE];
@@ -275,7 +284,7 @@ __global__ void __launch_bounds__(TPB) k_part_scatter(const uint64_t *__restrict
         k[r] = ok ? keys_in[t.start + j] : 0ull;
         v[r] = (ok && vals_in) ? vals_in[t.start + j] : 0u;
         if (skip_dead && k[r] == GR_DEAD_KEY && v[r] == GR_DEAD_VAL) ok = false;          // cancelled by the emit pass: not scattered
-        dig[r] = ok ? gr_digit(k[r], shift, bits) : ~0u;
+        dig[r] = ok ? (ix.mul ? gr_idx_digit(k[r], ix, bits) : gr_digit(k[r], shift, bits)) : ~0u;
     }
     const uint32_t rows = t.count > w * SEG ? min(ITEMS, (t.count - w * SEG + 63u) / 64u) : 0u;
     __syncthreads();
@@ -299,7 +308,7 @@ __global__ void __launch_bounds__(TPB) k_part_scatter(const uint64_t *__restrict
     __syncthreads();
     for (uint32_t j = threadIdx.x; j < live; j += TPB) {
         const uint64_t key = s_keys[j];
-        const uint32_t g = s_cnt[gr_digit(key, shift, bits)] + j;
+        const uint32_t g = s_cnt[ix.mul ? gr_idx_digit(key, ix, bits) : gr_digit(key, shift, bits)] + j;
         keys_out[g] = key;
         if (vals_out) vals_out[g] = s_vals[j];              // (uniform: key-only sorts pass no values)
     }
@@ -868,18 +877,19 @@ const uint32_t *group_live_count(const void *temp, size_t N, int group_bits, int
 template <int TPB>
 static void part_pass(const GrTiling &tl, size_t entries, uint32_t shift, uint32_t bits, const uint64_t *kin, const uint32_t *vin, uint64_t *kout,
                       uint32_t *vout, uint32_t *hist, uint32_t *goffs, void *scan_tmp, size_t scan_bytes, hipStream_t st, rb_graph *prof,
-                      uint32_t *n_live_dev = nullptr /* non-null: the pass drops cancelled records and leaves the number of live ones here */) {
+                      uint32_t *n_live_dev = nullptr /* non-null: the pass drops cancelled records and leaves the number of live ones here */,
+                      GrIdxDev ix = GrIdxDev{Mod{1, 0, 0}, 0, 0}) {
     const dim3 grid(tl.grid_tiles), blk(TPB);
     if (prof) prof->prof_begin(st);
     if (n_live_dev) RB_HIP(hipMemsetAsync(hist + entries, 0, 4, st));        // one entry more: its scanned value is the total
-    hipLaunchKernelGGL(k_part_count<TPB>, grid, blk, 0, st, kin, tl, shift, bits, hist, n_live_dev ? vin : (const uint32_t *)nullptr);
+    hipLaunchKernelGGL(k_part_count<TPB>, grid, blk, 0, st, kin, tl, shift, bits, hist, n_live_dev ? vin : (const uint32_t *)nullptr, ix);
     if (prof) { prof->prof_end("group_part_count", st); prof->prof_begin(st); }
     exclusive_scan_u32(scan_tmp, scan_bytes, hist, goffs, entries + (n_live_dev ? 1 : 0), st);
     if (n_live_dev) hipLaunchKernelGGL(k_copy_u32, dim3(1), dim3(64), 0, st, n_live_dev, goffs + entries);
     if (prof) { prof->prof_end("group_scan", st); prof->prof_begin(st); }
     const uint32_t wide = !(getenv("RB_GROUP_WIDE_LDS") && atoi(getenv("RB_GROUP_WIDE_LDS")) == 0);
-    if (bits <= 8u) hipLaunchKernelGGL((k_part_scatter<TPB, 8>), grid, blk, 0, st, kin, vin, tl, shift, bits, goffs, kout, vout, wide, n_live_dev ? 1u : 0u);
-    else hipLaunchKernelGGL((k_part_scatter<TPB, GR_PART_MAX_BITS>), grid, blk, 0, st, kin, vin, tl, shift, bits, goffs, kout, vout, wide, n_live_dev ? 1u : 0u);
+    if (bits <= 8u) hipLaunchKernelGGL((k_part_scatter<TPB, 8>), grid, blk, 0, st, kin, vin, tl, shift, bits, goffs, kout, vout, wide, n_live_dev ? 1u : 0u, ix);
+    else hipLaunchKernelGGL((k_part_scatter<TPB, GR_PART_MAX_BITS>), grid, blk, 0, st, kin, vin, tl, shift, bits, goffs, kout, vout, wide, n_live_dev ? 1u : 0u, ix);
     if (prof) prof->prof_end("group_part_scatter", st);
 }
 
@@ -900,7 +910,10 @@ LsdPlan lsd_plan(size_t n, const int (*ranges)[2], int n_ranges, bool idx_vals) 
     uint32_t maxbits = 0;
     for (int r = 0; r < n_ranges; ++r) {
         const uint32_t B = (uint32_t)std::max(0, ranges[r][1] - ranges[r][0]);
-        const uint32_t np = (B + GR_PART_MAX_BITS - 1) / GR_PART_MAX_BITS;      // digits of at most 10 bits, spread evenly
+        // digits of at most 10 bits, spread evenly; 8 bits for small arrays: the histogram is tiles x 2^bits entries, and below ~1 M
+        // records a 10-bit histogram is a quarter of the records themselves and its scan the longest kernel of the pass
+        const uint32_t maxb = n <= ((size_t)1 << 20) ? 8u : GR_PART_MAX_BITS;
+        const uint32_t np = (B + maxb - 1) / maxb;
         uint32_t lo = (uint32_t)ranges[r][0], left = B;
         for (uint32_t q = 0; q < np; ++q) {
             const uint32_t b = (left + (np - q) - 1) / (np - q);
@@ -990,7 +1003,7 @@ void sort_pairs_u64_u64(void *temp, size_t temp_bytes, uint64_t *keys_in, uint64
 template <int TPB>
 static void group_records_impl(const GroupPlan &P, uint64_t *keys0, uint32_t *vals0, uint64_t *keys_tmp, uint32_t *vals_tmp, GroupRng rng, char *tp,
                                uint32_t *vals_out, uint8_t *tz_out, uint64_t *uniq, uint32_t *counts, uint32_t *starts, uint32_t *n_runs_dev,
-                               hipStream_t st, rb_graph *prof) {
+                               hipStream_t st, rb_graph *prof, GrIdx idx) {
     unsigned long long *status = reinterpret_cast<unsigned long long *>(tp + P.off_status);
     uint32_t *ticket = reinterpret_cast<uint32_t *>(tp + P.off_ticket);
     uint32_t *bstart = reinterpret_cast<uint32_t *>(tp + P.off_bstart);
@@ -1002,7 +1015,10 @@ static void group_records_impl(const GroupPlan &P, uint64_t *keys0, uint32_t *va
         void *scan_tmp = tp + P.off_scan;
         GrTiling t1{nullptr, nullptr, P.n, P.ntiles, gr_grid_for_tiles(P.ntiles), P.xcd_map};
         uint32_t *n_live = P.dead ? ticket + 3 : nullptr;      // (the status / ticket block was zeroed above)
-        part_pass<TPB>(t1, (size_t)P.ntiles << P.t_hi, P.shift_hi, P.t_hi, kin, vin, keys_tmp, vals_tmp, hist, goffs, scan_tmp, P.scan_bytes, st, prof, n_live);
+        GrIdxDev ix{Mod{1, 0, 0}, 0, 0};
+        if (idx.span > (1ull << P.t_hi))           // (mul must fit 64 bits: more indices than first-pass buckets — anything but a toy filter)
+            ix = GrIdxDev{idx.mod, idx.lo, (uint64_t)((((unsigned __int128)1 << 64) << P.t_hi) / idx.span)};
+        part_pass<TPB>(t1, (size_t)P.ntiles << P.t_hi, P.shift_hi, P.t_hi, kin, vin, keys_tmp, vals_tmp, hist, goffs, scan_tmp, P.scan_bytes, st, prof, n_live, ix);
         kin = keys_tmp; vin = vals_tmp;
         uint32_t *segtb = nullptr, *segst = nullptr;
         if (P.t_lo) {
@@ -1048,13 +1064,13 @@ static void group_records_impl(const GroupPlan &P, uint64_t *keys0, uint32_t *va
 void group_records_device(uint64_t *keys0, uint32_t *vals0, uint64_t *keys_tmp, uint32_t *vals_tmp, size_t N, int group_bits,
                           uint64_t seed, uint64_t ordinal0, uint32_t pos_bits, void *temp, size_t temp_bytes,
                           uint32_t *vals_out, uint8_t *tz_out, uint64_t *uniq, uint32_t *counts, uint32_t *starts, uint32_t *n_runs_dev,
-                          hipStream_t st, rb_graph *prof, int bucket_target, int flags) {
+                          hipStream_t st, rb_graph *prof, int bucket_target, int flags, GrIdx idx) {
     RB_REQUIRE(N > 0 && N < (1ull << 32) - 2 * GR_TILE, "group_records_device: bad record count");
     const GroupPlan P = group_plan(N, group_bits, bucket_target, flags);
     RB_REQUIRE(temp_bytes >= P.total, "group_records_device: temp too small");
     const GroupRng rng{seed, ordinal0, pos_bits};
-    if (P.tpb == 512u) group_records_impl<512>(P, keys0, vals0, keys_tmp, vals_tmp, rng, static_cast<char *>(temp), vals_out, tz_out, uniq, counts, starts, n_runs_dev, st, prof);
-    else group_records_impl<256>(P, keys0, vals0, keys_tmp, vals_tmp, rng, static_cast<char *>(temp), vals_out, tz_out, uniq, counts, starts, n_runs_dev, st, prof);
+    if (P.tpb == 512u) group_records_impl<512>(P, keys0, vals0, keys_tmp, vals_tmp, rng, static_cast<char *>(temp), vals_out, tz_out, uniq, counts, starts, n_runs_dev, st, prof, idx);
+    else group_records_impl<256>(P, keys0, vals0, keys_tmp, vals_tmp, rng, static_cast<char *>(temp), vals_out, tz_out, uniq, counts, starts, n_runs_dev, st, prof, idx);
 }
 
 }  // namespace rb

@@ -128,6 +128,15 @@ void select_flagged2(void *temp, size_t temp_bytes, const uint32_t *status, size
 // grouped order, their draw strengths, runs (hash, count, start) and the run count, all on `st`, nothing synchronised.
 // keys0/vals0 are clobbered; keys_tmp/vals_tmp are scratch of the same size.
 constexpr int GR_FLAG_DEAD = 1;     // the records may include ones the emit pass cancelled (key and occurrence id all ones): dropped by the first partition pass
+// Index-keyed first partition pass (round 4): the FIRST digit of the MSD partition is taken from the k-mer's first filter index
+// (idx_0 = (h0 >>> 1) % size, mapped onto 2^bits equal index ranges of [lo, lo + span)) instead of from the hash's top bits.  Any function
+// of the hash is a valid grouping key (equal hashes stay together); with this one the fine buckets — and the runs the bucket kernel emits,
+// in ticket order — sweep the filters by index range, so the first Bloom bit and the first counter of consecutive runs fall into a moving
+// window instead of all over the array (several touches per line when a sub-batch is mostly NEW k-mers: the long-read regime).
+struct GrIdx {
+    Mod mod;                    // the filter's size (index_of)
+    uint64_t lo = 0, span = 0;  // this handle's index range (a shard's; the whole filter otherwise).  span == 0: off
+};
 void group_debug_big(const void *temp, size_t N, int group_bits, int bucket_target, uint32_t *n_big_out, uint64_t *records_out, uint32_t *largest_out, int flags = 0);
 size_t group_temp_bytes(size_t N, int group_bits, int bucket_target = 0, int flags = 0);
 const uint32_t *group_live_count(const void *temp, size_t N, int group_bits, int bucket_target, int flags);
@@ -135,6 +144,7 @@ void group_records_device(uint64_t *keys0, uint32_t *vals0, uint64_t *keys_tmp, 
                           uint64_t seed, uint64_t ordinal0, uint32_t pos_bits, void *temp, size_t temp_bytes,
                           uint32_t *vals_out, uint8_t *tz_out, uint64_t *uniq, uint32_t *counts, uint32_t *starts, uint32_t *n_runs_dev,
                           hipStream_t st, struct rb_graph *prof = nullptr /* per-kernel HIP-event timing into this handle's profile */,
-                          int bucket_target = 0 /* average fine-bucket size aimed at (0: the default, 3072) */, int flags = 0 /* GR_FLAG_* */);
+                          int bucket_target = 0 /* average fine-bucket size aimed at (0: the default, 3072) */, int flags = 0 /* GR_FLAG_* */,
+                          GrIdx idx = GrIdx{Mod{1, 0, 0}, 0, 0} /* span != 0: first partition digit from the first filter index */);
 
 }  // namespace rb

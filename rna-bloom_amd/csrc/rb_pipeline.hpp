@@ -362,6 +362,8 @@ struct rb_graph {
     const uint32_t *seq_woff = nullptr;
     uint32_t seq_wpr = 0;
     uint32_t seq_first = 0;
+    bool group_idx = false;       // the next grouping takes its first partition digit from the first filter index (rb_group.hip GrIdx): set when the
+                                  // sub-batch before was mostly single-occurrence runs (new k-mers), RB_GROUP_IDX=0|1 overrides
     uint32_t occ_bits = 32;       // occurrence ids of the sub-batch in flight are below 2^occ_bits (the conflict sort skips the bits above)
     bool use_mpf = false;
     // scratch (grow-only)

@@ -5,8 +5,8 @@
 // scan of the consumer) the predecessors may not even be resident — scans of 20 k-75 k threads took 1-3.5 ms each, 27.8 ms of
 // kernel time per step (profiles/r03_kernel_stats.csv, gpurun_out/r03_scans.txt).  The scans below never wait for another
 // workgroup: reduce per tile -> one workgroup scans the tile sums -> apply (the input is read twice instead of once, which
-// the arrays in question — at most a few hundred MB, mostly a few MB — do not notice), and arrays of up to 32 K entries are
-// scanned by a single workgroup in one launch.  The radix sorts of the conflict path are LSD passes of the grouping stage's
+// the arrays in question — at most a few hundred MB, mostly a few MB — do not notice), and arrays of up to 64 K entries are
+// scanned by a single workgroup in one launch (16 K entries per round of four barriers).  The radix sorts of the conflict path are LSD passes of the grouping stage's
 // own stable partition kernels (rb_group.hip: lsd_sort_*).
 #include <cstring>
 
@@ -15,24 +15,29 @@
 namespace rb {
 
 namespace {
-constexpr uint32_t SC_VEC = 4;                       // items per thread per sub-tile
-constexpr uint32_t SC_TPB = 256, SC_SUB = SC_TPB * SC_VEC, SC_SUBS = 16, SC_TILE = SC_SUB * SC_SUBS;   // 16384 items per tile
-constexpr uint32_t SC_ONE_TPB = 1024, SC_ONE_MAX = 32768;   // single-workgroup path
+constexpr uint32_t SC_TPB = 256, SC_VEC = 4, SC_SUB = SC_TPB * SC_VEC, SC_SUBS = 16, SC_TILE = SC_SUB * SC_SUBS;   // 16384 items per tile
+constexpr uint32_t SC_ONE_TPB = 1024, SC_ONE_VEC = 16, SC_ONE_MAX = 65536;   // single-workgroup path: 16 K items per round of 4 barriers
 
-// One sub-tile of TPB x 4 items at in[base ...): exclusive scan with `carry` added, written to out; returns carry + the
+// One sub-tile of TPB x VEC items at in[base ...): exclusive scan with `carry` added, written to out; returns carry + the
 // sub-tile's sum.  Striped (coalesced) global accesses, blocked scan through LDS; no alignment assumptions; in == out is fine.
-template <uint32_t TPB>
+template <uint32_t TPB, uint32_t VEC>
 __device__ __forceinline__ uint32_t sc_sub_scan(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, size_t base, size_t n, uint32_t carry,
-                                                uint32_t *s_data /* [TPB * 4], 16-byte aligned */, uint32_t *s_wsum /* [TPB / 64] */) {
+                                                uint32_t *s_data /* [TPB * VEC], 16-byte aligned */, uint32_t *s_wsum /* [TPB / 64] */) {
+    static_assert(VEC % 4 == 0, "whole uint4 per thread");
     const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
 #pragma unroll
-    for (uint32_t i = 0; i < SC_VEC; ++i) {
+    for (uint32_t i = 0; i < VEC; ++i) {
         const size_t x = base + (size_t)i * TPB + tid;
         s_data[i * TPB + tid] = x < n ? in[x] : 0u;
     }
     __syncthreads();
-    uint4 v = reinterpret_cast<const uint4 *>(s_data)[tid];
-    const uint32_t e1 = v.x, e2 = e1 + v.y, e3 = e2 + v.z, tot = e3 + v.w;
+    uint32_t e[VEC];                                   // exclusive prefix inside the thread's VEC consecutive items
+    uint32_t tot = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < VEC / 4; ++q) {
+        const uint4 v = reinterpret_cast<const uint4 *>(s_data)[tid * (VEC / 4) + q];
+        e[4 * q] = tot; tot += v.x; e[4 * q + 1] = tot; tot += v.y; e[4 * q + 2] = tot; tot += v.z; e[4 * q + 3] = tot; tot += v.w;
+    }
     uint32_t inc = tot;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -49,10 +54,12 @@ __device__ __forceinline__ uint32_t sc_sub_scan(const uint32_t *__restrict__ in,
         total += t;
     }
     const uint32_t b0 = carry + wbase + inc - tot;
-    reinterpret_cast<uint4 *>(s_data)[tid] = make_uint4(b0, b0 + e1, b0 + e2, b0 + e3);
+#pragma unroll
+    for (uint32_t q = 0; q < VEC / 4; ++q)
+        reinterpret_cast<uint4 *>(s_data)[tid * (VEC / 4) + q] = make_uint4(b0 + e[4 * q], b0 + e[4 * q + 1], b0 + e[4 * q + 2], b0 + e[4 * q + 3]);
     __syncthreads();
 #pragma unroll
-    for (uint32_t i = 0; i < SC_VEC; ++i) {
+    for (uint32_t i = 0; i < VEC; ++i) {
         const size_t x = base + (size_t)i * TPB + tid;
         if (x < n) out[x] = s_data[i * TPB + tid];
     }
@@ -61,10 +68,17 @@ __device__ __forceinline__ uint32_t sc_sub_scan(const uint32_t *__restrict__ in,
 }
 
 __global__ void __launch_bounds__(SC_ONE_TPB) k_scan_one(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, size_t n) {
-    __shared__ __attribute__((aligned(16))) uint32_t s_data[SC_ONE_TPB * SC_VEC];
+    __shared__ __attribute__((aligned(16))) uint32_t s_data[SC_ONE_TPB * SC_ONE_VEC];
     __shared__ uint32_t s_wsum[SC_ONE_TPB / 64];
     uint32_t carry = 0;
-    for (size_t base = 0; base < n; base += SC_ONE_TPB * SC_VEC) carry = sc_sub_scan<SC_ONE_TPB>(in, out, base, n, carry, s_data, s_wsum);
+    for (size_t base = 0; base < n; base += SC_ONE_TPB * SC_ONE_VEC) carry = sc_sub_scan<SC_ONE_TPB, SC_ONE_VEC>(in, out, base, n, carry, s_data, s_wsum);
+}
+// the same with 256 threads for arrays of a few thousand entries (a 1024-thread workgroup is mostly barrier there)
+__global__ void __launch_bounds__(SC_TPB) k_scan_one_small(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, size_t n) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_data[SC_TPB * SC_ONE_VEC];
+    __shared__ uint32_t s_wsum[SC_TPB / 64];
+    uint32_t carry = 0;
+    for (size_t base = 0; base < n; base += SC_TPB * SC_ONE_VEC) carry = sc_sub_scan<SC_TPB, SC_ONE_VEC>(in, out, base, n, carry, s_data, s_wsum);
 }
 
 __global__ void __launch_bounds__(SC_TPB) k_scan_reduce(const uint32_t *__restrict__ in, size_t n, uint32_t *__restrict__ tile_sums) {
@@ -95,8 +109,12 @@ __global__ void __launch_bounds__(SC_TPB) k_scan_apply(const uint32_t *__restric
     for (uint32_t q = 0; q < SC_SUBS; ++q) {
         const size_t b = base + (size_t)q * SC_SUB;
         if (b >= n) break;
-        carry = sc_sub_scan<SC_TPB>(in, out, b, n, carry, s_data, s_wsum);
+        carry = sc_sub_scan<SC_TPB, SC_VEC>(in, out, b, n, carry, s_data, s_wsum);
     }
+}
+void scan_one(const uint32_t *in, uint32_t *out, size_t n, hipStream_t s) {
+    if (n <= 2 * SC_TPB * SC_ONE_VEC) hipLaunchKernelGGL(k_scan_one_small, dim3(1), dim3(SC_TPB), 0, s, in, out, n);
+    else hipLaunchKernelGGL(k_scan_one, dim3(1), dim3(SC_ONE_TPB), 0, s, in, out, n);
 }
 }  // namespace
 
@@ -105,16 +123,13 @@ size_t scan_temp_bytes(size_t n) { return ((n + SC_TILE - 1) / SC_TILE + 2) * 4 
 // out[i] = in[0] + ... + in[i-1] (wrapping u32); in == out allowed.  Never waits for another workgroup.
 void exclusive_scan_u32(void *temp, size_t temp_bytes, const uint32_t *in, uint32_t *out, size_t n, hipStream_t s) {
     if (n == 0) return;
-    if (n <= SC_ONE_MAX) {
-        hipLaunchKernelGGL(k_scan_one, dim3(1), dim3(SC_ONE_TPB), 0, s, in, out, n);
-        return;
-    }
+    if (n <= SC_ONE_MAX) { scan_one(in, out, n, s); return; }
     const size_t nt = (n + SC_TILE - 1) / SC_TILE;
     RB_REQUIRE(temp && temp_bytes >= scan_temp_bytes(n), "exclusive_scan_u32: temp too small");
     RB_REQUIRE(nt < (1ull << 31), "exclusive_scan_u32: too many items");
     uint32_t *sums = reinterpret_cast<uint32_t *>(temp);
     hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nt), dim3(SC_TPB), 0, s, in, n, sums);
-    hipLaunchKernelGGL(k_scan_one, dim3(1), dim3(SC_ONE_TPB), 0, s, sums, sums, nt);
+    scan_one(sums, sums, nt, s);
     hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nt), dim3(SC_TPB), 0, s, in, out, n, sums);
 }
 

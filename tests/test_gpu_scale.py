@@ -134,6 +134,34 @@ def test_sharded_engine_at_scale(monkeypatch, G, mode, general_pairs):
     cl.destroy()
 
 
+@pytest.mark.parametrize("k,err", [(25, 0.002), (35, 0.05)])
+def test_index_keyed_grouping_at_scale(monkeypatch, k, err):
+    """RB_GROUP_IDX=1: the first partition digit of the grouping comes from the k-mer's first filter index (csrc/rb_group.hip GrIdx; on
+    by itself when a sub-batch is mostly new k-mers).  Any grouping key that is a function of the hash is valid — the filters must
+    equal the oracle's on one GPU (many sub-batches, the 5 % error rate of long reads included: nearly every k-mer new) and on 4
+    virtual ranks, whose records all lie in the rank's own index range."""
+    monkeypatch.setenv("RB_GROUP_IDX", "1")
+    n = 160_000
+    batch, seq, off = synthetic(n, seed=90 + k, err=err)
+    dist = 150 - k - 10
+    og = rbo.Graph(BITS, BITS, BITS, 2, 2, 2, k, False, True, 6)
+    og.set_read_pair_distance(dist)
+    og.add_reads(seq, None, off, 0, rbo.STORE_READ_PAIRS)
+    # min_base_qual 0 below + usable flags: the batch's substituted bases are masked on the device; the oracle gets the same bases
+    g = BloomFilterDeBruijnGraph(BITS, BITS, BITS, 2, 2, 2, k, False, True, rngSeed=6, maxBatchKmers=3_000_000)
+    g.setReadPairedKmerDistance(dist)
+    st = g.addReads(seq, None, off, 0, storeReadPairedKmers=True)
+    assert st.kmers > 100 * n // 2
+    same_state(og, g)
+    g.destroy()
+    cl = LoopbackCluster(4, BITS, BITS, BITS, 2, 2, 2, k, False, True, rngSeed=6, mode="split")
+    cl.setReadPairedKmerDistance(dist)
+    b2 = ReadBatch.from_ascii(seq, None, off, 0, device=0)
+    cl.addBatch(b2, 150, storeReadPairedKmers=True, first=0, n=n, reads_per_substep=50_000)
+    same_state(og, cl)
+    cl.destroy()
+
+
 def test_queries_at_scale():
     """getKmers over 100 000 reads in one call, the 4 successors / predecessors of ~350 000 k-mers, and the window
     hashes of a whole 200 000-read batch (canonical and strand-specific), all against the oracle — the oracle is asked
