@@ -9,9 +9,10 @@ generated on the device before the timed region and stay resident in HBM (packed
     python bench.py [--gpus N] [--steps K] [--warmup W] [--pairs P] [--genome G] [--nk NK]
 
 For N>1 launch through torch.distributed.run (one rank per GPU): reads are data-parallel, every filter
-is sharded by index range and the k-mer space by hash bits; records / probes / replies / counter
-writes travel by RCCL all_to_all (rnabloom/sharded.py, csrc/rb_shard.hip).  The job
-(total read pairs) is fixed, so scaling is "strong".
+is sharded by index range and a k-mer belongs to the rank that holds its first counter; records / probes /
+replies / counter writes travel by RCCL send/recv groups inside the library (csrc/rb_comm.hip, csrc/rb_shard.hip;
+RB_SHARD_DRIVER=torch: all_to_all through rnabloom/sharded.py).  The job (total read pairs) is
+fixed, so scaling is "strong".
 Prints ONE JSON line on rank 0.
 """
 import argparse
@@ -223,20 +224,35 @@ def main():
             s2 = g.addBatch(batch, reverseComplement=True, storeReadPairedKmers=True, first=pairs_total, n=pairs_total)
             return s1, s2
     else:
-        # filters sharded by index range over the ranks, k-mer space by hash bits; reads are
-        # data-parallel; RCCL all_to_all / all_gather move records, probes, replies and writes
+        # filters sharded by index range over the ranks, a k-mer owned where its first counter lives; reads are
+        # data-parallel; RCCL moves records, probes, replies and writes
         from types import SimpleNamespace
         from rnabloom import sharded
         sr = sharded.ShardRank((dbg_bits, cbf_bytes, pk_bits, 2, 2, 2, k, 0, 1, local, 0, 1, a.batch_kmers), rank, world, local)
         sr.set_read_pair_distance(dist_pk)
         pos_bits, rps = sharded.plan(150, k, world, a.batch_kmers or sharded.default_batch_kmers(world, sr.mode))
         g = SimpleNamespace(profileEnable=lambda on: check_(sr, on), profileGet=lambda reset=True: prof_(sr, reset))
-        # RB_SHARD_DRIVER=native: phases AND exchanges inside the library (csrc/rb_comm.hip: ncclSend / ncclRecv groups on the
-        # library's stream, nothing interpreted between the phases).  The default stays the torch.distributed driver of
-        # rnabloom/sharded.py: it is the one that has run with several real processes (gloo, 2-4 ranks sharing the test GPU);
-        # the native driver has run with 1-8 virtual ranks (threads + device copies) and over RCCL at world 1 only.
-        native = os.environ.get("RB_SHARD_DRIVER", "").lower() == "native" and backend == "nccl"
-        comm = sharded.NativeComm.rccl(dist, local) if native else None
+        # The exchange driver: by default phases AND exchanges run inside the library (csrc/rb_comm.hip: ncclSend / ncclRecv groups on the
+        # library's stream, nothing interpreted between the phases — rb_shard_add_range).  Before the first step every rank runs the
+        # communicator's self-test (a small all-to-all and all-gather of known bytes through that transport); if it fails on ANY rank, all
+        # ranks fall back to the torch.distributed driver of rnabloom/sharded.py (RB_SHARD_DRIVER=torch selects that one directly).
+        # What has run where: the native driver with 1-8 virtual ranks (threads + device copies) and over RCCL at world 1; the torch
+        # driver between 2-4 real processes over gloo; neither has met a second physical GPU.
+        want_native = os.environ.get("RB_SHARD_DRIVER", "native").lower() != "torch" and backend == "nccl"
+        comm, native = None, False
+        if want_native:
+            ok = 1
+            try:
+                comm = sharded.NativeComm.rccl(dist, local)
+                N.check(N.lib.rb_shard_comm_selftest(comm.h, rank, local, 0))
+            except Exception as e:      # noqa: BLE001
+                ok = 0
+                print("[bench] rank %d: native exchange driver unavailable (%s)" % (rank, e), file=sys.stderr, flush=True)
+            flag = torch.tensor([ok], device="cuda", dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            native = bool(flag.item())
+            if not native and rank == 0:
+                print("[bench] falling back to the torch.distributed exchange driver", file=sys.stderr, flush=True)
 
         def step():
             sr.clear()
@@ -344,7 +360,7 @@ def main():
                        "mean_kmer_coverage": round(kmers_all / a.steps / max(1, a.genome), 1),
                        "prefilter_survival": round(n_sorted / max(1, kmers), 4),
                        "note": "throughput depends on the coverage: the no-op prefilter drops occurrences that provably cannot change a counter (here all but the survival fraction); at low coverage or k > 64 the same engine sorts every occurrence; substituted bases carry quality '#' and are masked (SURVEY s8(d)) - with every error passing the threshold (RB_SYNTH_KEEP_ERRORS=1) the step takes 1.3x as long (DESIGN.md s5)",
-                       "parallelism": ("single GPU" if not sharded_mode else "filters index-sharded x%d, k-mers hash-sharded (%s mode), %s all_to_all"
+                       "parallelism": ("single GPU" if not sharded_mode else "filters index-sharded x%d, k-mers owned by first counter (%s mode), %s all-to-all"
                                        % (world, sr.mode, ("RCCL send/recv below the C ABI" if native else "RCCL") if backend == "nccl" else backend))},
             "stages_ms_per_step": {n: round(v[0] / a.steps, 2) for n, v in sorted(prof.items(), key=lambda kv: -kv[1][0])},
             "roofline": roof,

@@ -535,6 +535,17 @@ typedef struct rb_shard_comm rb_shard_comm;
 int rb_shard_comm_unique_id(void *out128);
 int rb_shard_comm_create_rccl(const void *id128, int rank, int world, int device, rb_shard_comm **out);
 int rb_shard_comm_create_loopback(int world, rb_shard_comm **out);
+/* Read-pair filter of a sharded graph, replicated accumulation (round 4): rpkbf.add is a pure OR (R/bloom/BloomFilter.java:133-137),
+ * so while a file is inserted every rank ORs the pairs of its reads into a private full-size copy and the copies are merged into the
+ * owners' index ranges when the call ends: begin() hands out this rank's copy as ONE send buffer cut into `shard_count` consecutive
+ * pieces (counts[r] = bytes of rank r's range; all zero when the handle uses the routed path, RB_SHARD_PAIRS=route), the caller does
+ * the all-to-all, end() ORs the G received pieces (each the size of this rank's range) into the shard and clears the copy.  Every rank
+ * calls both at the end of every collective insert call (rb_shard_add_range and rnabloom/sharded.py::ShardRank.add_range do). */
+int rb_shard_pairs_flush_begin(rb_graph *g, void **send_dev, int64_t *counts);
+int rb_shard_pairs_flush_end(rb_graph *g, const void *recv_dev, const int64_t *recv_counts);
+/* a small all-to-all and all-gather of known bytes through the communicator's own transport, checked on arrival (every rank calls it;
+ * big_bytes is added to every message: > 256 MiB exercises the piece-wise path).  bench.py runs it before the first step. */
+int rb_shard_comm_selftest(rb_shard_comm *c, int rank, int device, int64_t big_bytes);
 int rb_shard_comm_destroy(rb_shard_comm *c);
 int rb_shard_add_range(rb_graph *g, rb_shard_comm *c, const rb_batch *b, int64_t first, int64_t n, unsigned flags,
                        int64_t reads_per_substep, uint32_t pos_bits, uint64_t ordinal0, rb_add_stats *stats);

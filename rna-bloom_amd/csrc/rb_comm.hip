@@ -436,6 +436,61 @@ int rb_shard_comm_create_loopback(int world, rb_shard_comm **out) {
     });
 }
 
+// A small all-to-all and all-gather with known bytes through the communicator's own transport (what rb_shard_add_range uses):
+// rank `me` sends (me * 7 + p * 3 + 1) * 1000 + big bytes to rank p, byte i = (me * 31 + p * 17 + i) & 255, and checks what arrives.
+// bench.py runs it before the first step with RCCL and falls back to the torch.distributed driver when it fails.
+int rb_shard_comm_selftest(rb_shard_comm *c, int me, int device, int64_t big_bytes) {
+    DevBuf sendbuf;
+    struct Rel { DevBuf &b; ~Rel() { b.release(); } } rel{sendbuf};
+    int rc = guarded([&] {
+        RB_REQUIRE(c && me >= 0 && me < c->world && big_bytes >= 0, "rb_shard_comm_selftest: bad argument");
+        RB_HIP(hipSetDevice(device));
+        hipStream_t st = nullptr;
+        RB_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        struct StreamDrop { hipStream_t s; ~StreamDrop() { (void)hipStreamDestroy(s); } } drop{st};
+        const int G = c->world;
+        auto len = [&](int from, int to) { return (int64_t)(from * 7 + to * 3 + 1) * 1000 + big_bytes; };
+        Part pa[1];
+        std::vector<uint8_t> host;
+        int64_t tot = 0;
+        for (int p2 = 0; p2 < G; ++p2) { pa[0].sc[p2] = len(me, p2); tot += pa[0].sc[p2]; }
+        host.resize((size_t)tot);
+        int64_t o = 0;
+        for (int p2 = 0; p2 < G; ++p2)
+            for (int64_t i = 0; i < pa[0].sc[p2]; ++i) host[(size_t)(o++)] = (uint8_t)((me * 31 + p2 * 17 + i) & 255);
+        sendbuf.reserve((size_t)tot);
+        RB_HIP(hipMemcpyAsync(sendbuf.p, host.data(), (size_t)tot, hipMemcpyHostToDevice, st));
+        pa[0].send = sendbuf.p;
+        try {
+            a2a(c, me, pa, 1, nullptr, st);
+        } catch (const HubFailed &) { set_error("rb_shard_comm_selftest: another rank of the loopback hub failed"); throw HipError{RB_ERR_STATE}; }
+        std::vector<uint8_t> got((size_t)pa[0].rtotal);
+        RB_HIP(hipMemcpy(got.data(), pa[0].recv, got.size(), hipMemcpyDeviceToHost));
+        o = 0;
+        for (int src = 0; src < G; ++src) {
+            RB_REQUIRE(pa[0].rc[src] == len(src, me), "rb_shard_comm_selftest: %lld bytes from rank %d, expected %lld", (long long)pa[0].rc[src], src, (long long)len(src, me));
+            for (int64_t i = 0; i < pa[0].rc[src]; ++i, ++o)
+                RB_REQUIRE(got[(size_t)o] == (uint8_t)((src * 31 + me * 17 + i) & 255), "rb_shard_comm_selftest: byte %lld from rank %d is wrong", (long long)i, src);
+        }
+        // all-gather of 1000 * (me + 1) bytes per rank
+        void *all = nullptr;
+        int64_t sizes[MAX_WORLD];
+        try {
+            gather(c, me, sendbuf.p, (int64_t)1000 * (me + 1), 0, &all, sizes, st);
+        } catch (const HubFailed &) { set_error("rb_shard_comm_selftest: another rank of the loopback hub failed"); throw HipError{RB_ERR_STATE}; }
+        int64_t gt = 0;
+        for (int src = 0; src < G; ++src) { RB_REQUIRE(sizes[src] == (int64_t)1000 * (src + 1), "rb_shard_comm_selftest: gathered size of rank %d is wrong", src); gt += sizes[src]; }
+        got.resize((size_t)gt);
+        RB_HIP(hipMemcpy(got.data(), all, got.size(), hipMemcpyDeviceToHost));
+        o = 0;
+        for (int src = 0; src < G; ++src)
+            for (int64_t i = 0; i < sizes[src]; ++i, ++o)
+                RB_REQUIRE(got[(size_t)o] == (uint8_t)((src * 31 + 0 * 17 + i) & 255), "rb_shard_comm_selftest: gathered byte %lld of rank %d is wrong", (long long)i, src);
+    });
+    if (rc != RB_OK && c && !c->is_rccl) hub_fail(c);
+    return rc;
+}
+
 int rb_shard_comm_destroy(rb_shard_comm *c) {
     if (!c) return RB_OK;
     if (c->is_rccl && c->nc && rccl().CommDestroy) (void)rccl().CommDestroy(c->nc);
@@ -476,6 +531,15 @@ int rb_shard_add_range(rb_graph *g, rb_shard_comm *c, const rb_batch *b, int64_t
                 const int64_t a = cuts[i], e = cuts[i + 1];
                 const bool have_next = i + 2 < cuts.size();
                 substep(g, c, b, first + a, e - a, pos_bits, flags, ordinal0 + (uint64_t)a, have_next, first + e, have_next ? cuts[i + 2] - e : 0, overlap, stats);
+            }
+            if (flags & RB_ADD_STORE_READ_PAIRS) {   // the ranks' read-pair accumulation copies -> the owners' shards: one all-to-all of G pieces
+                Part pa[1];
+                void *send = nullptr;
+                int64_t cnt[MAX_WORLD];
+                RB_CK(rb_shard_pairs_flush_begin(g, &send, cnt));
+                fill(pa[0], send, cnt, g->shard_count, 1);
+                a2a(c, g->shard_rank, pa, 1, nullptr, g->stream);
+                RB_CK(rb_shard_pairs_flush_end(g, pa[0].recv, pa[0].rc));
             }
         } catch (const HubFailed &) {
             set_error("rb_shard_add_range: another rank of the loopback hub failed");

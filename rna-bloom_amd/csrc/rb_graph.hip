@@ -194,6 +194,16 @@ __global__ void __launch_bounds__(256) k_probe_h2(FilterView fv, const uint64_t 
 // (premask) COLLIDES with another probe of the sub-batch.  Only colliding bits get a table entry (min probe id over
 // the colliders, then over the probe that happened to get there first — it learns about the collision from the
 // table); a bit without an entry was touched by one probe only, which therefore found it clear.
+// ff: bit filter in front of the collision table (k_collide_insert sets a bit per entry; nullptr: none).  The table is a few MB on
+// config 2 (cache-resident: the filter measured neutral there), but where most k-mers of a sub-batch are NEW — long reads — it holds
+// millions of entries and every run looks it up twice in k_collide_fixup and again in k_late_claim / stage B: 97 + 57 ms of a 0.9 s
+// pass (profiles/r04_longreads.txt); the filter answers "no entry" from L2 for all but the collided bits.
+struct FtFilter { const uint32_t *bits; uint32_t log2; };
+__device__ __forceinline__ bool ft_maybe(const FtFilter &ff, uint64_t idx) {
+    if (!ff.bits) return true;
+    const uint64_t b = slot_of(idx ^ 0x5851F42D4C957F2Dull, ff.log2);
+    return (ff.bits[b >> 5] >> (uint32_t)(b & 31u)) & 1u;
+}
 constexpr uint32_t ST_COLLIDE_SHIFT = 21;   // status bits 21..28: probe j found its bit set by another probe of the sub-batch
 __global__ void k_set_bits(FilterView fv, const uint64_t *__restrict__ uniq, uint32_t n_distinct, uint32_t *__restrict__ status,
                            uint32_t *__restrict__ counters) {
@@ -217,7 +227,7 @@ __global__ void k_set_bits(FilterView fv, const uint64_t *__restrict__ uniq, uin
 // colliders register their probe ids ...
 __global__ void k_collide_insert(FilterView fv, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ starts,
                                  const uint32_t *__restrict__ vals, uint32_t n_distinct, const uint32_t *__restrict__ status,
-                                 Slot *ftable, uint32_t f_log2) {
+                                 Slot *ftable, uint32_t f_log2, uint32_t *__restrict__ ffbits, uint32_t ff_log2) {
     uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= n_distinct) return;
     const uint32_t coll = (status[d] >> ST_COLLIDE_SHIFT) & 0xFFu;
@@ -226,14 +236,16 @@ __global__ void k_collide_insert(FilterView fv, const uint64_t *__restrict__ uni
     const unsigned long long v_first = vals[starts[d]];
     for (int j = 0; j < fv.dbg_h; ++j)
         if ((coll >> j) & 1u) {
-            Slot *s = table_insert(ftable, f_log2, index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.dbg_mod));
+            const uint64_t idx = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.dbg_mod);
+            Slot *s = table_insert(ftable, f_log2, idx);
             atomicMin(&s->val, (v_first << 4) | (unsigned long long)j);
+            if (ffbits) { const uint64_t b = slot_of(idx ^ 0x5851F42D4C957F2Dull, ff_log2); atomicOr(&ffbits[b >> 5], 1u << (uint32_t)(b & 31u)); }
         }
 }
 // ... and the probes whose atomicOr got there first join the entries of the bits somebody collided on
 __global__ void k_collide_fixup(FilterView fv, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ starts,
                                 const uint32_t *__restrict__ vals, uint32_t n_distinct, const uint32_t *__restrict__ status,
-                                Slot *ftable, uint32_t f_log2) {
+                                Slot *ftable, uint32_t f_log2, FtFilter ff) {
     uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= n_distinct) return;
     const uint32_t st = status[d];
@@ -244,15 +256,18 @@ __global__ void k_collide_fixup(FilterView fv, const uint64_t *__restrict__ uniq
     unsigned long long v_first = ~0ull;
     for (int j = 0; j < fv.dbg_h; ++j)
         if ((mine >> j) & 1u) {
-            Slot *s = const_cast<Slot *>(table_find(ftable, f_log2, index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.dbg_mod)));
+            const uint64_t idx = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.dbg_mod);
+            if (!ft_maybe(ff, idx)) continue;
+            Slot *s = const_cast<Slot *>(table_find(ftable, f_log2, idx));
             if (!s) continue;
             if (v_first == ~0ull) v_first = vals[starts[d]];
             atomicMin(&s->val, (v_first << 4) | (unsigned long long)j);
         }
 }
 // did an earlier probe of the sub-batch set bit idx?  (table of all missing bits, or of the collided ones only)
-__device__ __forceinline__ bool set_earlier(const Slot *ftable, uint32_t f_log2, uint64_t idx, unsigned long long id) {
+__device__ __forceinline__ bool set_earlier(const Slot *ftable, uint32_t f_log2, uint64_t idx, unsigned long long id, FtFilter ff = FtFilter{nullptr, 0}) {
     if (!ftable) return false;                    // no collision in this sub-batch at all
+    if (!ft_maybe(ff, idx)) return false;
     const Slot *s = table_find(ftable, f_log2, idx);
     return s && s->val < id;
 }
@@ -262,7 +277,7 @@ __device__ __forceinline__ bool set_earlier(const Slot *ftable, uint32_t f_log2,
 __global__ void k_late_claim(FilterView fv, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ starts,
                              const uint32_t *__restrict__ vals, uint32_t n_distinct, const Slot *ftable, uint32_t f_log2,
                              uint32_t *__restrict__ status, uint64_t *__restrict__ cvals, uint64_t *__restrict__ foreign_idx,
-                             uint32_t *__restrict__ counters) {
+                             uint32_t *__restrict__ counters, FtFilter ff) {
     uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= n_distinct) return;
     uint32_t st = status[d];
@@ -272,7 +287,7 @@ __global__ void k_late_claim(FilterView fv, const uint64_t *__restrict__ uniq, c
     bool found = true;
     for (int j = 0; j < fv.dbg_h && found; ++j) {
         if ((st >> j) & 1u) continue;
-        if (!set_earlier(ftable, f_log2, index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.dbg_mod), (v_first << 4) | (unsigned long long)j))
+        if (!set_earlier(ftable, f_log2, index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.dbg_mod), (v_first << 4) | (unsigned long long)j, ff))
             found = false;
     }
     if (!found) return;
@@ -437,7 +452,7 @@ __global__ void k_list_compact(const uint32_t *__restrict__ list, const uint32_t
 __device__ unsigned long long g_dbg_hist[96];     // RB_DEBUG: ops by (true exponent, cached exponent); uncached ops by bucket occupancy
 __global__ void k_resolve_apply(FilterView fv, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ counts,
                                 const uint32_t *__restrict__ starts, const uint32_t *__restrict__ vals,
-                                uint32_t n_distinct, int mode, uint32_t LIGHT_OPS, const Slot *ftable, uint32_t f_log2,
+                                uint32_t n_distinct, int mode, uint32_t LIGHT_OPS, const Slot *ftable, uint32_t f_log2, FtFilter ff,
                                 int bits_set /* k_set_bits ran */, const Slot *cs, uint32_t cs_log2, const uint32_t *__restrict__ csf, uint32_t csf_log2,
                                 uint32_t n_foreign,
                                 uint32_t *__restrict__ status, uint32_t *__restrict__ nops,
@@ -473,7 +488,7 @@ __global__ void k_resolve_apply(FilterView fv, const uint64_t *__restrict__ uniq
                 if ((st >> j) & 1u) continue;
                 uint64_t idx = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.dbg_mod);
                 // old bit value seen by this probe = an earlier probe of the batch already set it
-                if (!set_earlier(ftable, f_log2, idx, (v_first << 4) | (unsigned long long)j)) found_first = false;
+                if (!set_earlier(ftable, f_log2, idx, (v_first << 4) | (unsigned long long)j, ff)) found_first = false;
                 if (!bits_set) bit_set(fv.dbg, idx);
             }
         }
@@ -1802,19 +1817,20 @@ static void launch_pairs_reads(rb_graph *g, const rb_batch *b, int64_t w0, int64
 }
 
 void rb::launch_pairs(rb_graph *g, const rb_batch *b, int64_t w0, int64_t nw, int mode_hash, const uint32_t *chunk_off,
-                      uint64_t *out_idx, unsigned long long *pc, hipStream_t st) {
+                      uint64_t *out_idx, unsigned long long *pc, hipStream_t st, const BitFilter *into) {
     if (!st) st = g->stream;
     if (nw <= 0) return;
+    const BitFilter &rpk = into ? *into : g->rpk;
     const bool general = g->k > 64 || b->max_len > 384u || (getenv("RB_PAIRS_GENERAL") && atoi(getenv("RB_PAIRS_GENERAL")));
     if (!general) {
-        launch_pairs_reads(g, b, w0, nw, mode_hash, g->rpk, g->read_d, 0u, false, chunk_off, out_idx, pc, st);
+        launch_pairs_reads(g, b, w0, nw, mode_hash, rpk, g->read_d, 0u, false, chunk_off, out_idx, pc, st);
         return;
     }
     dim3 gr(blocks_for(nw)), th(TPB);
 #ifdef RB_DIAG_PAIRS
     if (getenv("RB_PAIRS_VARIANT") && atoi(getenv("RB_PAIRS_VARIANT")) == 9 && mode_hash == 1) {
         hipLaunchKernelGGL(k_pairs_insert_runtime_branch, gr, th, 0, st, b->codes, b->valid, b->word_read, b->woff, b->len, w0, nw, g->k, g->read_d,
-                           g->rpk.bits, g->rpk.mod, g->rpk.num_hash, kmul_of(g->k), pc, chunk_off, out_idx,
+                           rpk.bits, rpk.mod, rpk.num_hash, kmul_of(g->k), pc, chunk_off, out_idx,
                            (b->wpr_uniform && nw % b->wpr_uniform == 0) ? b->wpr_uniform : 0u);
         return;
     }
@@ -1823,7 +1839,7 @@ void rb::launch_pairs(rb_graph *g, const rb_batch *b, int64_t w0, int64_t nw, in
     if (out_idx) RB_LAUNCH_PAIRS2(M, true); else RB_LAUNCH_PAIRS2(M, false)
 #define RB_LAUNCH_PAIRS2(M, O)                                                                                      \
     hipLaunchKernelGGL((k_pairs_insert<M, O>), gr, th, 0, st, b->codes, b->valid, b->word_read, b->woff, b->len, w0, nw, \
-                       g->k, g->read_d, g->rpk.bits, g->rpk.mod, g->rpk.num_hash, kmul_of(g->k), pc, chunk_off, out_idx, \
+                       g->k, g->read_d, rpk.bits, rpk.mod, rpk.num_hash, kmul_of(g->k), pc, chunk_off, out_idx, \
                        (b->wpr_uniform && nw % b->wpr_uniform == 0) ? b->wpr_uniform : 0u)
     if (mode_hash == 0) { RB_LAUNCH_PAIRS(0); } else if (mode_hash == 2) { RB_LAUNCH_PAIRS(2); } else { RB_LAUNCH_PAIRS(1); }
 #undef RB_LAUNCH_PAIRS
@@ -1850,12 +1866,13 @@ void rb::group_enqueue(rb_graph *g, int slot, size_t N, uint64_t ordinal0, uint3
     temp.reserve(group_temp_bytes(N, group_bits, bucket_target, flags));
     S.keys1.reserve(N * 8); S.valsT.reserve(N * 4); S.vals1.reserve(N * 4); S.tz.reserve(N + 16);
     S.uniq.reserve(N * 8); S.counts.reserve((N + 1) * 4); S.starts.reserve((N + 1) * 4);
-    // Index-keyed first partition pass (rb_internal.hpp GrIdx): runs come out sweeping the filters by first index.  It costs three
-    // Barrett reductions per record in the first pass and buys locality of the first Bloom bit / first counter of consecutive runs, which pays
-    // when a sub-batch is mostly NEW k-mers (several first-probe atomics per filter line: long reads, low coverage) and about breaks even
-    // on config 2 (one touch per five lines): on when the sub-batch before had more runs than half its records.  RB_GROUP_IDX=0|1 forces it.
+    // Index-keyed partition passes (rb_internal.hpp GrIdx): fine buckets are index ranges, runs come out sweeping the filters by first
+    // index.  Three Barrett reductions per record and pass (invisible in the partition kernels' times: they wait on LDS and memory) buy
+    // locality of the first Bloom bit / first counter of consecutive runs: config 2 probe_claim 56 -> 51 ms, the all-new-k-mers regime of
+    // long reads 666 -> 574 ms with the first pass alone (profiles/r04_group_idx.txt).  RB_GROUP_IDX=0 is the hash-keyed partition of
+    // rounds 2-3.
     GrIdx gidx{Mod{1, 0, 0}, 0, 0};
-    bool want_idx = g->group_idx;
+    bool want_idx = true;
     if (const char *e = getenv("RB_GROUP_IDX")) want_idx = atoi(e) != 0;
     if (want_idx) {
         if (g->cbf && g->cbf_size > 0) gidx = GrIdx{g->cbf_mod, (uint64_t)g->cbf_lo, (uint64_t)(g->cbf_hi - g->cbf_lo)};
@@ -1875,7 +1892,6 @@ uint32_t rb::group_finish(rb_graph *g, int slot, hipStream_t st, DevBuf &temp, D
     RB_HIP(hipStreamSynchronize(st));
     RB_REQUIRE(D < (1u << 30), "sub-batch has too many distinct k-mers (%u)", D);
     S.D = D;
-    g->group_idx = S.N >= 4096 && (uint64_t)D * 2u > (uint64_t)S.N;    // mostly single-occurrence runs: the next grouping sweeps the filters by index
     (void)scan_stream;   // the run starts come out of the grouping kernel
     if (getenv("RB_DEBUG") && temp.p) {
         uint32_t nb = 0, mx = 0; uint64_t rec = 0;
@@ -2014,6 +2030,7 @@ void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, ui
     const bool full_table = getenv("RB_FIRST_SETTER_TABLE") && atoi(getenv("RB_FIRST_SETTER_TABLE"));   // the older scheme: every missing bit gets an entry
     const bool collide = uses_dbg && !full_table;
     Slot *ftab = nullptr;                        // first-setter arbitration table (null: nothing to arbitrate)
+    FtFilter ffl{nullptr, 0};                    // bit filter in front of it (large tables only)
     if (uses_dbg && full_table) {
         g->prof_begin();
         f_log2 = log2_ceil(2ull * (uint64_t)D * (uint64_t)g->dbg.num_hash + 2);
@@ -2039,16 +2056,26 @@ void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, ui
         for (int q = 0; q < 32; ++q) n_collide += spread[16 * q + 1];
         if (n_collide) {   // entries for the collided bits only: the colliders, then the probe that got there first
             f_log2 = log2_ceil(4ull * (uint64_t)n_collide + 2);
-            g->ftable.reserve(sizeof(Slot) << f_log2);
-            RB_HIP(hipMemsetAsync(g->ftable.p, 0xFF, sizeof(Slot) << f_log2, s));
+            // a bit filter in front of it once the table outgrows the caches (<= 12 % full; config 2's 13 MB table does without: measured neutral)
+            const size_t tab_bytes = sizeof(Slot) << f_log2;
+            const uint32_t ff_log2 = std::max(16u, std::min(30u, log2_ceil(8ull * (uint64_t)n_collide)));
+            const bool use_ff = getenv("RB_FT_FILTER") ? atoi(getenv("RB_FT_FILTER")) != 0 : tab_bytes > ((size_t)32 << 20);
+            g->ftable.reserve(tab_bytes + (use_ff ? ((size_t)1 << (ff_log2 - 3)) : 0));
+            RB_HIP(hipMemsetAsync(g->ftable.p, 0xFF, tab_bytes, s));
             ftab = g->ftable.as<Slot>();
-            hipLaunchKernelGGL(k_collide_insert, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, uniq, starts, vals, D, status, ftab, f_log2);
-            hipLaunchKernelGGL(k_collide_fixup, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, uniq, starts, vals, D, status, ftab, f_log2);
+            if (use_ff) {
+                uint32_t *fb = reinterpret_cast<uint32_t *>(static_cast<char *>(g->ftable.p) + tab_bytes);
+                RB_HIP(hipMemsetAsync(fb, 0, (size_t)1 << (ff_log2 - 3), s));
+                ffl = FtFilter{fb, ff_log2};
+            }
+            hipLaunchKernelGGL(k_collide_insert, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, uniq, starts, vals, D, status, ftab, f_log2,
+                               const_cast<uint32_t *>(ffl.bits), ffl.log2);
+            hipLaunchKernelGGL(k_collide_fixup, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, uniq, starts, vals, D, status, ftab, f_log2, ffl);
         }
     }
     if (mode == M_ADD)
         hipLaunchKernelGGL(k_late_claim, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, uniq, starts, vals, D, ftab, f_log2,
-                           status, g->cvals.as<uint64_t>(), g->foreign.as<uint64_t>(), ctr);
+                           status, g->cvals.as<uint64_t>(), g->foreign.as<uint64_t>(), ctr, ffl);
     uint32_t n_foreign = 0;
     {
         uint32_t spread[16 * 32];
@@ -2072,7 +2099,7 @@ void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, ui
     }
     g->prof_begin();
     hipLaunchKernelGGL(k_resolve_apply, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, uniq, counts, starts, vals, D, mode, g->light_ops,
-                       ftab, f_log2, (int)collide, g->ctable.as<Slot>(), c_log2, getenv("RB_NO_CS_FILTER") ? (uint32_t *)nullptr : csf, csf_log2, n_foreign, status, nops,
+                       ftab, f_log2, ffl, (int)collide, g->ctable.as<Slot>(), c_log2, getenv("RB_NO_CS_FILTER") ? (uint32_t *)nullptr : csf, csf_log2, n_foreign, status, nops,
                        g->cvals.as<uint64_t>(), g->tz().as<uint8_t>(), getenv("RB_DEBUG") ? reinterpret_cast<float *>(ctr + 700) : (float *)nullptr);
     g->prof_end("resolve_apply");
     // the runs that own their counters alone have updated counters and prefilter cache: the producer may
@@ -2783,6 +2810,7 @@ int rb_graph_clear(rb_graph *g, unsigned which_mask) {
         if ((which_mask & 1u) && g->dbg.bits) fast_zero(g->dbg.bits, g->dbg.alloc, g->stream);
         if ((which_mask & 2u) && g->cbf) fast_zero(g->cbf, g->cbf_alloc, g->stream);
         if ((which_mask & 4u) && g->rpk.bits) fast_zero(g->rpk.bits, g->rpk.alloc, g->stream);
+        if ((which_mask & 4u) && g->shard) rb::shard_clear_pairs_acc(g);
         if ((which_mask & 8u) && g->fpk.bits) fast_zero(g->fpk.bits, g->fpk.alloc, g->stream);
         if ((which_mask & 3u) && g->npf_log2) fast_zero(g->npf.p, sizeof(uint64_t) << g->npf_log2, g->stream);   // cache entries speak about dbgbf + cbf
         if ((which_mask & 3u) && g->mpf_log2b) fast_zero(g->mpf.p, (size_t)128 << g->mpf_log2b, g->stream);

@@ -46,12 +46,14 @@ constexpr uint32_t GR_DEAD_VAL = ~0u;
 __device__ __forceinline__ uint32_t gr_digit(uint64_t key, uint32_t shift, uint32_t bits) {
     return (uint32_t)(key >> shift) & ((1u << bits) - 1u);
 }
-// first-pass digit from the first filter index (GrIdx): floor((idx_0 - lo) * 2^bits / span), as one mulhi with mul = floor(2^(64+bits) / span)
-struct GrIdxDev { Mod mod; uint64_t lo, mul; };          // mul == 0: off (digits come from the hash bits)
+// partition digits from the first filter index (GrIdx): d = floor((idx_0 - lo) * 2^T / span) — one mulhi with mul = floor(2^(64+T) / span) —
+// is the number of the k-mer's FINE bucket, the T = t_hi + t_lo partition bits taken as 2^T equal index ranges; the first pass takes its
+// top t_hi bits (shift = t_lo), the second pass the rest (shift = 0)
+struct GrIdxDev { Mod mod; uint64_t lo, mul; uint32_t top, shift; };          // mul == 0: off (digits come from the hash bits); top = 2^T - 1
 __device__ __forceinline__ uint32_t gr_idx_digit(uint64_t key, const GrIdxDev &ix, uint32_t bits) {
-    const uint64_t i = index_of(key, ix.mod) - ix.lo;    // (a key outside [lo, lo + span) — none exist on a shard — would land in the last bucket)
-    const uint32_t d = (uint32_t)__umul64hi(i, ix.mul);
-    return min(d, (1u << bits) - 1u);
+    const uint64_t i = index_of(key, ix.mod) - ix.lo;    // (a key outside [lo, lo + span) — none exist on a shard — lands in the last bucket)
+    const uint32_t d = min((uint32_t)min(__umul64hi(i, ix.mul), (uint64_t)0xFFFFFFFFull), ix.top);
+    return (d >> ix.shift) & ((1u << bits) - 1u);
 }
 __device__ __forceinline__ uint32_t gr_lanes_below(uint64_t m) {
     return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
@@ -224,7 +226,7 @@ __device__ __forceinline__ bool gr_get_tile(const GrTiling &tl, GrTile &t) {
 template <int TPB>
 __global__ void __launch_bounds__(TPB) k_part_count(const uint64_t *__restrict__ keys, GrTiling tl, uint32_t shift, uint32_t bits,
                                                     uint32_t *__restrict__ hist, const uint32_t *__restrict__ dead_vals = nullptr,
-                                                    GrIdxDev ix = GrIdxDev{Mod{1, 0, 0}, 0, 0}) {
+                                                    GrIdxDev ix = GrIdxDev{Mod{1, 0, 0}, 0, 0, 0, 0}) {
     constexpr int ITEMS = GR_TILE / TPB;
     __shared__ uint32_t s_h[1u << GR_PART_MAX_BITS];
     GrTile t;
@@ -253,7 +255,7 @@ template <int TPB, int MAXBITS>
 __global__ void __launch_bounds__(TPB) k_part_scatter(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, GrTiling tl,
                                                       uint32_t shift, uint32_t bits, const uint32_t *__restrict__ goffs /* exclusive scan of hist */,
                                                       uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t wide_lds,
-                                                      uint32_t skip_dead = 0u, GrIdxDev ix = GrIdxDev{Mod{1, 0, 0}, 0, 0}) {
+                                                      uint32_t skip_dead = 0u, GrIdxDev ix = GrIdxDev{Mod{1, 0, 0}, 0, 0, 0, 0}) {
     constexpr uint32_t ITEMS = GR_TILE / TPB, NW = TPB / 64, SEG = 64 * ITEMS, MAXNB = 1u << MAXBITS;
     __shared__ uint64_t s_keys[GR_TILE];
     __shared__ uint32_t s_vals[GR_TILE];
@@ -878,7 +880,7 @@ template <int TPB>
 static void part_pass(const GrTiling &tl, size_t entries, uint32_t shift, uint32_t bits, const uint64_t *kin, const uint32_t *vin, uint64_t *kout,
                       uint32_t *vout, uint32_t *hist, uint32_t *goffs, void *scan_tmp, size_t scan_bytes, hipStream_t st, rb_graph *prof,
                       uint32_t *n_live_dev = nullptr /* non-null: the pass drops cancelled records and leaves the number of live ones here */,
-                      GrIdxDev ix = GrIdxDev{Mod{1, 0, 0}, 0, 0}) {
+                      GrIdxDev ix = GrIdxDev{Mod{1, 0, 0}, 0, 0, 0, 0}) {
     const dim3 grid(tl.grid_tiles), blk(TPB);
     if (prof) prof->prof_begin(st);
     if (n_live_dev) RB_HIP(hipMemsetAsync(hist + entries, 0, 4, st));        // one entry more: its scanned value is the total
@@ -1015,9 +1017,9 @@ static void group_records_impl(const GroupPlan &P, uint64_t *keys0, uint32_t *va
         void *scan_tmp = tp + P.off_scan;
         GrTiling t1{nullptr, nullptr, P.n, P.ntiles, gr_grid_for_tiles(P.ntiles), P.xcd_map};
         uint32_t *n_live = P.dead ? ticket + 3 : nullptr;      // (the status / ticket block was zeroed above)
-        GrIdxDev ix{Mod{1, 0, 0}, 0, 0};
-        if (idx.span > (1ull << P.t_hi))           // (mul must fit 64 bits: more indices than first-pass buckets — anything but a toy filter)
-            ix = GrIdxDev{idx.mod, idx.lo, (uint64_t)((((unsigned __int128)1 << 64) << P.t_hi) / idx.span)};
+        GrIdxDev ix{Mod{1, 0, 0}, 0, 0, 0, 0};
+        if (idx.span > (1ull << P.T))              // (mul must fit 64 bits: more indices than fine buckets — anything but a toy filter)
+            ix = GrIdxDev{idx.mod, idx.lo, (uint64_t)((((unsigned __int128)1 << 64) << P.T) / idx.span), (1u << P.T) - 1u, P.t_lo};
         part_pass<TPB>(t1, (size_t)P.ntiles << P.t_hi, P.shift_hi, P.t_hi, kin, vin, keys_tmp, vals_tmp, hist, goffs, scan_tmp, P.scan_bytes, st, prof, n_live, ix);
         kin = keys_tmp; vin = vals_tmp;
         uint32_t *segtb = nullptr, *segst = nullptr;
@@ -1028,7 +1030,8 @@ static void group_records_impl(const GroupPlan &P, uint64_t *keys0, uint32_t *va
             hipLaunchKernelGGL(k_seg_tiles, dim3(1), dim3(1024), 0, st, goffs, P.ntiles, 1u << P.t_hi, P.n, 1u << P.t_lo, desc, segtb, segst, nt2, (const uint32_t *)n_live);
             RB_HIP(hipMemsetAsync(hist, 0, ((size_t)P.ntiles2_max << P.t_lo) * 4, st));
             GrTiling t2{desc, nt2, P.n, P.ntiles2_max, gr_grid_for_tiles(P.ntiles2_max), P.xcd_map};
-            part_pass<TPB>(t2, (size_t)P.ntiles2_max << P.t_lo, P.shift_lo, P.t_lo, kin, vin, keys0, vals0, hist, goffs, scan_tmp, P.scan_bytes, st, prof);
+            ix.shift = 0;                          // (index-keyed: the low t_lo bits of the fine-bucket number)
+            part_pass<TPB>(t2, (size_t)P.ntiles2_max << P.t_lo, P.shift_lo, P.t_lo, kin, vin, keys0, vals0, hist, goffs, scan_tmp, P.scan_bytes, st, prof, nullptr, ix);
             kin = keys0; vin = vals0;
         }
         hipLaunchKernelGGL(k_bucket_bounds, dim3((P.nbuckets + 256u) / 256u), dim3(256), 0, st, goffs, P.ntiles, segtb, segst, P.t_hi, P.t_lo, P.n, bstart, (const uint32_t *)n_live);

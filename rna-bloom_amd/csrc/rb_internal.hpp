@@ -128,11 +128,11 @@ void select_flagged2(void *temp, size_t temp_bytes, const uint32_t *status, size
 // grouped order, their draw strengths, runs (hash, count, start) and the run count, all on `st`, nothing synchronised.
 // keys0/vals0 are clobbered; keys_tmp/vals_tmp are scratch of the same size.
 constexpr int GR_FLAG_DEAD = 1;     // the records may include ones the emit pass cancelled (key and occurrence id all ones): dropped by the first partition pass
-// Index-keyed first partition pass (round 4): the FIRST digit of the MSD partition is taken from the k-mer's first filter index
-// (idx_0 = (h0 >>> 1) % size, mapped onto 2^bits equal index ranges of [lo, lo + span)) instead of from the hash's top bits.  Any function
-// of the hash is a valid grouping key (equal hashes stay together); with this one the fine buckets — and the runs the bucket kernel emits,
-// in ticket order — sweep the filters by index range, so the first Bloom bit and the first counter of consecutive runs fall into a moving
-// window instead of all over the array (several touches per line when a sub-batch is mostly NEW k-mers: the long-read regime).
+// Index-keyed partition passes (round 4): the digits of the MSD partition are taken from the k-mer's first filter index (idx_0 =
+// (h0 >>> 1) % size, mapped onto 2^T equal index ranges of [lo, lo + span): a fine bucket IS an index range) instead of from the hash's top
+// bits.  Any function of the hash is a valid grouping key (equal hashes stay together); with this one the fine buckets — and the runs
+// the bucket kernel emits, in ticket order — sweep the filters by index range, so the first Bloom bit and the first counter of
+// consecutive runs fall into a moving window of a few hundred KB instead of all over the array.
 struct GrIdx {
     Mod mod;                    // the filter's size (index_of)
     uint64_t lo = 0, span = 0;  // this handle's index range (a shard's; the whole filter otherwise).  span == 0: off

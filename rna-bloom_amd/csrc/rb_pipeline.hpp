@@ -362,8 +362,6 @@ struct rb_graph {
     const uint32_t *seq_woff = nullptr;
     uint32_t seq_wpr = 0;
     uint32_t seq_first = 0;
-    bool group_idx = false;       // the next grouping takes its first partition digit from the first filter index (rb_group.hip GrIdx): set when the
-                                  // sub-batch before was mostly single-occurrence runs (new k-mers), RB_GROUP_IDX=0|1 overrides
     uint32_t occ_bits = 32;       // occurrence ids of the sub-batch in flight are below 2^occ_bits (the conflict sort skips the bits above)
     bool use_mpf = false;
     // scratch (grow-only)
@@ -472,6 +470,7 @@ void group_enqueue(rb_graph *g, int slot, size_t N, uint64_t ordinal0, uint32_t 
 uint32_t group_finish(rb_graph *g, int slot, hipStream_t st, DevBuf &temp, DevBuf &ctrbuf, hipStream_t scan_stream);
 // paired k-mer walker: inserts into g->rpk (out_idx == nullptr) or collects global bit indices
 void shard_free(rb_graph *g);   // rb_shard.hip
+void shard_clear_pairs_acc(rb_graph *g);   // rb_shard.hip
 void *alloc_best_placed(size_t bytes, const char *what);   // rb_graph.hip: zeroed device memory, the best placed of a few allocations (counting filters)
 uint64_t *shard_query_h0(rb_graph *g, size_t n);                                                 // rb_shard.hip: the query protocol with hashes already on the device
 void shard_query_make_dev(rb_graph *g, int what, int which_bits, size_t n, int64_t *bit_counts, int64_t *ctr_counts);
@@ -479,5 +478,5 @@ const void *shard_query_combine_dev(rb_graph *g, int which_bits, const void *bre
 void trav_free(rb_graph *g);    // rb_graph.hip: state of a traversal on a sharded graph
 void cbf_counts_device(rb_graph *g, const uint64_t *d_h0, size_t n, float *d_out);   // rb_graph.hip
 void launch_pairs(rb_graph *g, const rb_batch *b, int64_t w0, int64_t nw, int mode_hash, const uint32_t *chunk_off,
-                  uint64_t *out_idx, unsigned long long *n_pairs_dev, hipStream_t st = nullptr);
+                  uint64_t *out_idx, unsigned long long *n_pairs_dev, hipStream_t st = nullptr, const BitFilter *into = nullptr /* another bit array of the pair filter's geometry (the sharded engine's accumulation copy) */);
 }  // namespace rb

@@ -16,6 +16,8 @@
 // probes of the sub-batch; claim marks and the conflict set live at the counter's owner; runs whose
 // counters nobody else claimed commute; everything else is replayed in global occurrence order by
 // exactly one rank per component, on a private table of that component's counters.
+#include <string.h>
+
 #include "rb_pipeline.hpp"
 
 using namespace rb;
@@ -58,6 +60,13 @@ struct ShardState {
         uint32_t N = 0;
         uint64_t owned = 0;
     } prep;
+    // Read-pair filter, replicated accumulation (round 4).  rpkbf.add is a pure OR, so nothing about it needs the owner while a file is
+    // inserted: every rank ORs the pairs of ITS reads into a private full-size copy (the single-GPU walker, no index list, no routing
+    // pass, no exchange per sub-batch, no serve-side scatter) and at the end of the call the copies are merged range by range into the
+    // owners' shards — one all-to-all of G pieces of size/G bits (rb_shard_pairs_flush_begin / _end).  288 GB of HBM make the copy free
+    // (1 GB at config 2, 33 GB at configs[3]); RB_SHARD_PAIRS=route is the routed path of rounds 1-3.
+    BitFilter rpk_acc;                          // full range [0, bits); bits == nullptr: routed path
+    bool acc_dirty = false;                     // something was ORed into rpk_acc since the last flush
     bool replicate_cache = false;               // split-reads mode: cache updates are broadcast to every rank
     DevBuf cache_upd;                           // [D] exponent to broadcast per run (0 = none)
     uint32_t *pinned = nullptr;                 // [0] = kept records, [16 + 16 q] = owned windows (32 spread counters)
@@ -997,6 +1006,15 @@ int rb_graph_create_shard(const rb_graph_params *p, int shard_rank, int shard_co
             Geometry gp = geom(p->pkbf_bits, shard_rank, shard_count);
             S->span[RB_RPKBF] = gp.span;
             alloc_bits(g->rpk, p->pkbf_bits, p->pkbf_num_hash, gp.lo, gp.hi);
+            const char *pm = getenv("RB_SHARD_PAIRS");
+            if (shard_count > 1 && !(pm && !strcmp(pm, "route"))) {
+                size_t free_b = 0, total_b = 0;
+                RB_HIP(hipMemGetInfo(&free_b, &total_b));
+                // room for the copy with half of the device still free afterwards, else this rank routes its pairs as before (each rank decides
+                // for itself: the owners take pair bits both ways — virtual ranks that share one GPU run out of room at configs[2]'s sizes)
+                if ((size_t)(p->pkbf_bits / 8) + (total_b >> 1) < free_b)
+                    alloc_bits(S->rpk_acc, p->pkbf_bits, p->pkbf_num_hash, 0, p->pkbf_bits);
+            }
         }
         {   // no-op prefilter cache over this rank's k-mers (applied to the records it receives)
             const char *e = getenv("RB_NPF");
@@ -1157,7 +1175,21 @@ int rb_shard_hash_group(rb_graph *g, const rb_batch *b, int64_t first, int64_t n
         }
         S->n_kept = N;
         if (stats) { stats->kmers += (int64_t)owned; stats->sorted_kmers += (int64_t)N; }
-        // ---- read-paired k-mers of this rank's slice of the reads: bit indices bucketed by rpkbf owner ----
+        // ---- read-paired k-mers of this rank's slice of the reads: ORed into this rank's accumulation copy (merged into the owners'
+        //      shards when the call ends, rb_shard_pairs_flush_*), or — routed path — bit indices bucketed by rpkbf owner ----
+        if (pairs && pair_n > 0 && S->rpk_acc.bits) {
+            const int64_t pw0 = b->h_woff[(size_t)pair_first], pnw = (int64_t)b->h_woff[(size_t)(pair_first + pair_n)] - pw0;
+            if (pnw > 0) {
+                g->devctr.reserve(DEVCTR_BYTES);
+                unsigned long long *pc = reinterpret_cast<unsigned long long *>(g->devctr.as<uint32_t>() + 12), np_host = 0;
+                RB_HIP(hipMemsetAsync(pc, 0, 8, s));
+                launch_pairs(g, b, pw0, pnw, mode_hash, nullptr, nullptr, pc, s, &S->rpk_acc);
+                RB_HIP(hipMemcpyAsync(&np_host, pc, 8, hipMemcpyDeviceToHost, s));
+                RB_HIP(hipStreamSynchronize(s));
+                S->acc_dirty = true;
+                if (stats) stats->pairs += (int64_t)np_host;
+            }
+        } else
         if (pairs && pair_n > 0) {
             const int64_t pw0 = b->h_woff[(size_t)pair_first], pnw = (int64_t)b->h_woff[(size_t)(pair_first + pair_n)] - pw0;
             if (pnw > 0) {
@@ -1287,7 +1319,16 @@ int rb_shard_hash(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, int6
             });
         }
         if (stats) { stats->kmers += (int64_t)windows; stats->sorted_kmers += (int64_t)kept; }
-        if (pairs) {
+        if (pairs && S->rpk_acc.bits) {   // replicated accumulation: the single-GPU walker into this rank's copy (see ShardState::rpk_acc)
+            g->devctr.reserve(DEVCTR_BYTES);
+            unsigned long long *pc = reinterpret_cast<unsigned long long *>(g->devctr.as<uint32_t>() + 12), np_host = 0;
+            RB_HIP(hipMemsetAsync(pc, 0, 8, s));
+            launch_pairs(g, b, w0, nw, mode_hash, nullptr, nullptr, pc, s, &S->rpk_acc);
+            RB_HIP(hipMemcpyAsync(&np_host, pc, 8, hipMemcpyDeviceToHost, s));
+            RB_HIP(hipStreamSynchronize(s));
+            S->acc_dirty = true;
+            if (stats) stats->pairs += (int64_t)np_host;
+        } else if (pairs) {
             uint32_t P = 0;
             RB_HIP(hipMemsetAsync(g->chunk_cnt.as<uint32_t>() + nw, 0, 4, s));
             launch_count_windows(b, w0, nw, g->k + g->read_d, g->chunk_cnt.as<uint32_t>(), s);
@@ -1344,6 +1385,57 @@ int rb_shard_cache_apply(rb_graph *g, const void *upd_dev, int64_t n) {
         hipLaunchKernelGGL(k_cache_apply, dim3(blocks_for(n)), dim3(TPB), 0, g->stream, fv, (const CacheUpd *)upd_dev, (size_t)n);
         RB_HIP(hipGetLastError());
         RB_HIP(hipStreamSynchronize(g->stream));
+    });
+}
+
+// ---- read-pair filter: merge of the ranks' accumulation copies into the owners' shards (end of an insert call) ----
+namespace {
+__global__ void k_or_u64(unsigned long long *__restrict__ dst, const unsigned long long *__restrict__ src, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const unsigned long long v = src[i]; if (v) dst[i] |= v; }
+}
+__global__ void k_or_u8(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) { const uint8_t v = src[i]; if (v) dst[i] |= v; }
+}
+}  // namespace
+int rb_shard_pairs_flush_begin(rb_graph *g, void **send_dev, int64_t *counts) {
+    return guarded([&] {
+        RB_REQUIRE(g && g->shard && send_dev && counts, "rb_shard_pairs_flush_begin: bad argument");
+        ShardState *S = g->shard;
+        *send_dev = nullptr;
+        for (int r = 0; r < S->G; ++r) counts[r] = 0;
+        if (!S->rpk_acc.bits) return;            // routed path: nothing to merge.  (Every rank of a collective insert call flushes: the
+        RB_HIP(hipSetDevice(g->p.device));       //  pieces travel whether or not this rank's slice held a pair.)
+        RB_HIP(hipStreamSynchronize(g->stream));
+        const int64_t span_bytes = S->span[RB_RPKBF] / 8, total = S->rpk_acc.nbytes;      // spans are multiples of 64 bits
+        for (int r = 0; r < S->G; ++r) counts[r] = std::max<int64_t>(0, std::min<int64_t>(total, span_bytes * (r + 1)) - std::min<int64_t>(total, span_bytes * r));
+        *send_dev = S->rpk_acc.bits;
+    });
+}
+int rb_shard_pairs_flush_end(rb_graph *g, const void *recv_dev, const int64_t *recv_counts) {
+    return guarded([&] {
+        RB_REQUIRE(g && g->shard && recv_counts, "rb_shard_pairs_flush_end: bad argument");
+        ShardState *S = g->shard;
+        RB_HIP(hipSetDevice(g->p.device));
+        hipStream_t s = g->stream;
+        const int64_t mine = g->rpk.bits ? g->rpk.nbytes : 0;
+        int64_t off = 0;
+        for (int r = 0; r < S->G; ++r) {
+            const int64_t n = recv_counts[r];                 // (0: that rank routes its pairs and has nothing to merge)
+            RB_REQUIRE(n == mine || n == 0, "rb_shard_pairs_flush_end: rank %d sent %lld bytes of this rank's range, which has %lld", r, (long long)n, (long long)mine);
+            const char *src = static_cast<const char *>(recv_dev) + off;
+            if (n && (n % 8) == 0 && (reinterpret_cast<uintptr_t>(src) % 8) == 0)
+                hipLaunchKernelGGL(k_or_u64, dim3(blocks_for(n / 8)), dim3(TPB), 0, s, reinterpret_cast<unsigned long long *>(g->rpk.bits),
+                                   reinterpret_cast<const unsigned long long *>(src), (size_t)(n / 8));
+            else if (n)
+                hipLaunchKernelGGL(k_or_u8, dim3(blocks_for(n)), dim3(TPB), 0, s, reinterpret_cast<uint8_t *>(g->rpk.bits), reinterpret_cast<const uint8_t *>(src), (size_t)n);
+            off += n;
+        }
+        if (S->rpk_acc.bits) RB_HIP(hipMemsetAsync(S->rpk_acc.bits, 0, S->rpk_acc.alloc, s));
+        S->acc_dirty = false;
+        RB_HIP(hipGetLastError());
+        RB_HIP(hipStreamSynchronize(s));
     });
 }
 
@@ -1735,6 +1827,12 @@ const void *shard_query_combine_dev(rb_graph *g, int which_bits, const void *bre
 }  // namespace rb
 
 namespace rb {
+void shard_clear_pairs_acc(rb_graph *g) {       // rb_graph_clear of the pair filter: bits waiting in the accumulation copy go too
+    ShardState *S = g->shard;
+    if (!S || !S->rpk_acc.bits) return;
+    RB_HIP(hipMemsetAsync(S->rpk_acc.bits, 0, S->rpk_acc.alloc, g->stream));
+    S->acc_dirty = false;
+}
 void shard_free(rb_graph *g) {
     ShardState *S = g->shard;
     if (!S) return;
@@ -1743,6 +1841,7 @@ void shard_free(rb_graph *g) {
                       &S->rhist, &S->roffs, &S->bounds, &S->own_f, &S->own_cs, &S->esz, &S->eoff, &S->etab, &S->eslot, &S->elabel, &S->cdesc,
                       &S->cpos, &S->cnops, &S->cnoff, &S->rk0, &S->rk1, &S->ok0, &S->ok1, &S->ov0, &S->ov1, &S->rtab, &S->rslot, &S->rbig, &S->q_h0, &S->q_bpos, &S->q_cpos, &S->q_out, &S->cache_upd, &S->lmask, &S->lcoll, &S->lcv, &S->lctr};
     for (auto *b : bufs) b->release();
+    free_bits(S->rpk_acc);
     if (S->pinned) (void)hipHostFree(S->pinned);
     delete S;
     g->shard = nullptr;

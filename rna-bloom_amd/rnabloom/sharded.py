@@ -370,6 +370,21 @@ class ShardRank:
             a, b = cuts[i], cuts[i + 1]
             nxt = (first + b, cuts[i + 2] - b) if i + 2 < len(cuts) else None
             yield from self.substep(batch, first + a, b - a, pos_bits, flags, nxt)
+        if flags & N.ADD_STORE_READ_PAIRS:
+            yield from self.flush_pairs()
+
+    def flush_pairs(self):
+        """Coroutine: the ranks' read-pair accumulation copies -> the owners' shards (rb_shard_pairs_flush_*): one all-to-all of
+        G pieces of size / G bits, at the end of every collective insert call that stores read pairs (nothing travels on the routed
+        path, RB_SHARD_PAIRS=route)"""
+        G = self.count
+        cnts, p = (C.c_int64 * G)(), C.c_void_p()
+        check(lib.rb_shard_pairs_flush_begin(self.h, C.byref(p), cnts))
+        cnts = list(cnts)
+        send = torch.as_tensor(_DevView(p.value, sum(cnts)), device=self.tdev) if sum(cnts) else torch.empty(0, dtype=torch.uint8, device=self.tdev)
+        (recv,), (rc,) = yield ("a2a", [send], [cnts])
+        check(lib.rb_shard_pairs_flush_end(self.h, _ptr(recv), (C.c_int64 * G)(*rc)))
+        trace_mark("pairs_flush")
 
 
 # ------------------------------------------------------------------ drivers ----

@@ -53,3 +53,43 @@ def test_single_gpu_line_and_two_rank_line():
     assert j2["n_gpus"] == 2 and j2["scaling"] == "strong" and j2["value"] > 0
     assert j2["config"]["kmers_per_step"] == j["config"]["kmers_per_step"], "both engines insert the same k-mers"
     assert "cpu_baseline" not in j2
+
+
+def test_force_sharded_line_goes_through_the_native_rccl_driver_by_default():
+    """bench.py --force-sharded on one GPU: the sharded engine over RCCL at world 1 — since round 4 through the exchange driver below the
+    C ABI (rb_shard_add_range, ncclSend / ncclRecv groups) after the communicator's self-test; RB_SHARD_DRIVER=torch is the other driver.
+    Both lines insert the k-mers the single-GPU line inserts."""
+    base = None
+    for drv in ("native", "torch"):
+        env = dict(os.environ)
+        env["RB_SHARD_DRIVER"] = drv
+        env["MASTER_PORT"] = str(free_port())
+        r = subprocess.run([sys.executable, "bench.py", "--force-sharded", "--no-cpu-baseline"] + SMALL, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-3000:]
+        j = last_json(r.stdout)
+        assert j["n_gpus"] == 1 and j["value"] > 0
+        assert ("below the C ABI" in j["config"]["parallelism"]) == (drv == "native"), j["config"]["parallelism"]
+        assert "falling back" not in r.stderr
+        base = base or j["config"]["kmers_per_step"]
+        assert j["config"]["kmers_per_step"] == base
+
+
+def test_communicator_self_test_on_a_loopback_hub():
+    """rb_shard_comm_selftest with 4 virtual ranks (threads + device copies): an all-to-all and an all-gather of known bytes, messages of
+    a few KB and of 3 MB"""
+    import ctypes as C
+    import threading
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "rna-bloom_amd")]
+    from rnabloom import _native as N
+    from rnabloom import sharded
+    for big in (0, 3_000_000):
+        comm = sharded.NativeComm.loopback(4)
+        rc = [None] * 4
+
+        def work(i):
+            rc[i] = N.lib.rb_shard_comm_selftest(comm.h, i, 0, big)
+        th = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+        for t in th: t.start()
+        for t in th: t.join()
+        assert rc == [0, 0, 0, 0], (rc, N.lib.rb_last_error())
+        comm.destroy()
