@@ -727,7 +727,15 @@ class LoopbackCluster:
                   int(useReadPairedKmers), device, groupBits, rngSeed, maxBatchKmers)
         self.k, self.count = k, count
         self.max_batch = maxBatchKmers or default_batch_kmers(count, mode)
-        self.ranks = [ShardRank(params, r, count, device, mode) for r in range(count)]
+        # the virtual ranks share ONE device: the per-rank copies of the read-pair filter (rb_shard.hip ShardState::rpk_acc) are `count`
+        # full-size copies on it — fine at config 2 (8 x 1 GB), not beside filters sized for the whole device (configs[2]'s 17.8 GB each)
+        import os
+        crowded = count * (pkbfNumBits // 8) > (16 << 30) and "RB_SHARD_PAIRS" not in os.environ
+        if crowded: os.environ["RB_SHARD_PAIRS"] = "route"
+        try:
+            self.ranks = [ShardRank(params, r, count, device, mode) for r in range(count)]
+        finally:
+            if crowded: del os.environ["RB_SHARD_PAIRS"]
         # native=True: the exchange driver below the C ABI (rb_shard_add_range over a loopback hub, one thread per rank)
         self.comm = NativeComm.loopback(count) if native else None
 

@@ -278,3 +278,44 @@ def test_native_driver_over_rccl_world_1():
         assert (rk.local_filter(N.RPKBF) == og2.rpkbf_bytes()).all()
         rk.destroy()
     comm.destroy()
+
+
+@pytest.mark.parametrize("native", [False, True])
+@pytest.mark.parametrize("routed_ranks", [(), (0, 1, 2, 3), (1, 2)])
+def test_read_pair_filter_replicated_routed_and_mixed(monkeypatch, routed_ranks, native):
+    """Round 4: a rank ORs the read pairs of its reads into a private full-size copy of rpkbf, merged into the owners' shards when the
+    insert call ends (rb_shard_pairs_flush_*).  A rank without room for the copy keeps routing its pair indices (RB_SHARD_PAIRS=route),
+    and the two kinds of rank work side by side: all replicated, all routed and a mix must leave the oracle's filter, after one call
+    and after a second one into the same filters (the copies are cleared by the merge, the shards keep what they had)."""
+    import os
+    from rnabloom import sharded
+    G, sizes = 4, (300_007, 900_001, 120_011)
+    d = synth.generate_pairs(2000, G=30000, err=0.002, n_rate=1e-3, seed=23)
+    og = rbo.Graph(*sizes, 2, 2, 2, 25, False, True, 3)
+    cl = LoopbackCluster.__new__(LoopbackCluster)
+    params = (*sizes, 2, 2, 2, 25, 0, 1, 0, 0, 3, 0)
+    cl.k, cl.count, cl.max_batch = 25, G, sharded.default_batch_kmers(G, "split")
+    cl.ranks = []
+    for r in range(G):
+        if r in routed_ranks: monkeypatch.setenv("RB_SHARD_PAIRS", "route")
+        else: monkeypatch.delenv("RB_SHARD_PAIRS", raising=False)
+        cl.ranks.append(sharded.ShardRank(params, r, G, 0, "split"))
+    monkeypatch.delenv("RB_SHARD_PAIRS", raising=False)
+    cl.comm = sharded.NativeComm.loopback(G) if native else None
+    og.set_read_pair_distance(115); cl.setReadPairedKmerDistance(115)
+    want_pairs = 0
+    for name, rc in (("left", False), ("right", True)):
+        s, off = synth.flat(d[name]); q, _ = synth.flat(d[name[0] + "qual"])
+        want_pairs += og.add_reads(s, q, off, 3, rbo.STORE_READ_PAIRS | (rbo.REVCOMP if rc else 0)).pairs
+        cl.addBatch(ReadBatch.from_ascii(s, q, off, 3), 150, reverseComplement=rc, storeReadPairedKmers=True, reads_per_substep=600)
+        check_filters(cl, og)
+    assert cl.popcount(N.RPKBF) == og.popcounts()[2] > 10_000
+    assert sum(r.stats["pairs"] for r in cl.ranks) == want_pairs > 20_000
+    # clear and insert again: nothing of the first round is left in a rank's accumulation copy
+    for r in cl.ranks: r.clear()
+    og.clear(); og.set_read_pair_distance(115)
+    s, off = synth.flat(d["left"]); q, _ = synth.flat(d["lqual"])
+    og.add_reads(s, q, off, 3, rbo.STORE_READ_PAIRS)
+    cl.addBatch(ReadBatch.from_ascii(s, q, off, 3), 150, storeReadPairedKmers=True, reads_per_substep=600)
+    check_filters(cl, og)
+    cl.destroy()
