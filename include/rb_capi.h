@@ -438,9 +438,15 @@ int rb_shard_set_cache_replication(rb_graph *g, int on);
 int rb_shard_hash(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, int64_t own_first, int64_t own_n,
                   uint64_t ordinal0, uint32_t pos_bits, unsigned flags, int64_t *rec_counts /*[count]*/,
                   int64_t *pair_counts /*[count]*/, rb_add_stats *stats);
+/* (round 4: the records are grouped where they lie — keys_dev / occ_dev are scratch of the call and hold garbage afterwards) */
 int rb_shard_group(rb_graph *g, const void *keys_dev, const void *occ_dev, int64_t n, uint64_t ordinal0,
                    uint32_t pos_bits, unsigned flags, int64_t *dreq_counts, int64_t *creq_counts);
 int rb_shard_cache_apply(rb_graph *g, const void *upd_dev, int64_t n);
+/* split reads, look-ahead (k <= 31): the window walk + prefilter of this rank's slice [own_first, own_first + own_n) of the NEXT
+ * sub-batch, enqueued on the library's producer stream without waiting for the GPU.  Call it after rb_shard_cache_apply of the current
+ * sub-batch; rb_shard_hash with the same arguments then starts from its result.  Any other call in between simply discards it. */
+int rb_shard_hash_begin_split(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, int64_t own_first, int64_t own_n,
+                              uint64_t ordinal0, uint32_t pos_bits, unsigned flags);
 /* optional look-ahead (k <= 31): enqueue the window-hash/prefilter pass of the NEXT sub-batch on the
  * library's producer stream (begin), then its emit + sort + run grouping (emit; waits for the count of
  * kept records only) — both return without waiting for the GPU, so the work overlaps the serve /

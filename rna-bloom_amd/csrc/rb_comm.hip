@@ -376,6 +376,12 @@ void substep(rb_graph *g, rb_shard_comm *c, const rb_batch *b, int64_t first, in
         void *all_upd = nullptr;
         gather(c, me, upd.p, upd.nbytes, 1, &all_upd, u_sizes, st);
         RB_CK(rb_shard_cache_apply(g, all_upd, sum(u_sizes, G) / 16));
+        // look-ahead: this rank's slice of the NEXT sub-batch is walked against the cache as it stands now, on the producer stream,
+        // beside the conflict phases and exchanges below (RB_SHARD_OVERLAP=0: off)
+        if (have_next && overlap >= 1) {
+            const int64_t q0 = nxt_first + nxt_n * me / G, q1 = nxt_first + nxt_n * (me + 1) / G;
+            RB_CK(rb_shard_hash_begin_split(g, b, nxt_first, nxt_n, q0, q1 - q0, ordinal + (uint64_t)n, pos_bits, flags));
+        }
     }
     const int64_t e_total = sum(e_sizes, G);
     if (e_total) {

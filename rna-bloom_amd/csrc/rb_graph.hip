@@ -1878,7 +1878,10 @@ void rb::group_enqueue(rb_graph *g, int slot, size_t N, uint64_t ordinal0, uint3
         if (g->cbf && g->cbf_size > 0) gidx = GrIdx{g->cbf_mod, (uint64_t)g->cbf_lo, (uint64_t)(g->cbf_hi - g->cbf_lo)};
         else if (g->dbg.bits && g->dbg.size > 0) gidx = GrIdx{g->dbg.mod, (uint64_t)g->dbg.lo, (uint64_t)(g->dbg.hi - g->dbg.lo)};
     }
-    group_records_device(g->keys0.as<uint64_t>(), g->vals0.as<uint32_t>(), S.keys1.as<uint64_t>(), S.valsT.as<uint32_t>(), N, group_bits,
+    uint64_t *kin = g->group_in_keys ? g->group_in_keys : g->keys0.as<uint64_t>();
+    uint32_t *vin = g->group_in_vals ? g->group_in_vals : g->vals0.as<uint32_t>();
+    g->group_in_keys = nullptr; g->group_in_vals = nullptr;
+    group_records_device(kin, vin, S.keys1.as<uint64_t>(), S.valsT.as<uint32_t>(), N, group_bits,
                          g->p.rng_seed, ordinal0, pos_bits, temp.p, temp.cap, S.vals1.as<uint32_t>(), S.tz.as<uint8_t>(), S.uniq.as<uint64_t>(),
                          S.counts.as<uint32_t>(), S.starts.as<uint32_t>(), ctr + 8, st, g, bucket_target, flags, gidx);
 }

@@ -362,6 +362,8 @@ struct rb_graph {
     const uint32_t *seq_woff = nullptr;
     uint32_t seq_wpr = 0;
     uint32_t seq_first = 0;
+    uint64_t *group_in_keys = nullptr;   // one-shot: the next group_enqueue takes its records from here instead of keys0 / vals0 (clobbered;
+    uint32_t *group_in_vals = nullptr;   // the sharded engine groups the records it received where they arrived)
     uint32_t occ_bits = 32;       // occurrence ids of the sub-batch in flight are below 2^occ_bits (the conflict sort skips the bits above)
     bool use_mpf = false;
     // scratch (grow-only)

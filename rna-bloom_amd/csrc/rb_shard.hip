@@ -33,6 +33,8 @@ struct ShardState {
     uint64_t n_kept = 0;                        // records that survived the prefilter in the last group()
     uint64_t ordinal0 = 0;
     uint32_t pos_bits = 0;
+    uint32_t sub_reads_bits = 0, gid_bits = 32;  // the sub-batch in flight: occurrence ids are below 2^(pos_bits + sub_reads_bits), component labels below 2^gid_bits
+                                                // (the conflict replay sorts on those bits only)
     DevBuf dreq_pos, creq_pos;                 // [D*h] position of (run, probe) in the bucketed request order
     DevBuf creq_dup;                           // [D*h] for a duplicated counter: the earlier probe it copies
     DevBuf lctr;                               // 32 spread counters: local claims that met a claimed counter (k_shard_probe)
@@ -52,6 +54,8 @@ struct ShardState {
         int stage = 0;                          // 0 none, 1 filter pass enqueued, 2 emit + grouping enqueued
         const rb_batch *b = nullptr;
         int64_t first = 0, n = 0, w0 = 0, nw = 0;
+        int64_t own_first = 0, own_n = 0;     // split reads: the slice of the sub-batch this rank hashes (w0 / nw are the slice's words)
+        bool split = false;
         uint64_t ordinal0 = 0;
         uint32_t pos_bits = 0;
         void *wstate = nullptr;              // per-word rolling state of the prefilter pass (nullptr: none)
@@ -882,12 +886,15 @@ __global__ void k_query_combine(int what, int bh, int ch, const uint32_t *__rest
 // ---- window hashing of a sub-batch on the producer stream (k <= 31): ownership + prefilter pass,
 //      then masked emit + grouping into the other GroupSlot; no host wait except for the record count ----
 namespace {
-void prep_filter(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, uint64_t ordinal0, uint32_t pos_bits, unsigned flags, hipStream_t st) {
+void prep_filter(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, uint64_t ordinal0, uint32_t pos_bits, unsigned flags, hipStream_t st,
+                 bool split = false, int64_t own_first = 0, int64_t own_n = 0) {
     ShardState *S = g->shard;
     ShardState::Prep &P = S->prep;
     P = ShardState::Prep();
     P.b = b; P.first = first; P.n = n; P.ordinal0 = ordinal0; P.pos_bits = pos_bits; P.flags = flags;
-    P.w0 = b->h_woff[(size_t)first]; P.nw = (int64_t)b->h_woff[(size_t)(first + n)] - P.w0;
+    P.split = split; P.own_first = own_first; P.own_n = own_n;
+    const int64_t r0 = split ? own_first : first, rn = split ? own_n : n;       // split reads: this rank's slice, every window (no ownership test)
+    P.w0 = b->h_woff[(size_t)r0]; P.nw = (int64_t)b->h_woff[(size_t)(r0 + rn)] - P.w0;
     P.slot = 1 - g->cur;
     P.stage = 1;
     if (!S->pinned) RB_HIP(hipHostMalloc(reinterpret_cast<void **>(&S->pinned), 4096, hipHostMallocDefault));
@@ -908,7 +915,7 @@ void prep_filter(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, uint6
     P.wstate = wstate;
     launch_filter_windows(b, P.w0, P.nw, g->k, mode_hash, (uint32_t)first, pos_bits, g->p.rng_seed, ordinal0, cache,
                           g->chunk_cnt.as<uint32_t>(), g->chunk_mask.as<uint32_t>(), g->npf_tot.as<uint32_t>(), st,
-                          own_range(g), fv.mpf, wstate);
+                          split ? OwnRange{Mod{1, 0, 0}, 0, 0} : own_range(g), fv.mpf, wstate);
     exclusive_scan_u32(g->temp2.p, g->temp2.cap, g->chunk_cnt.as<uint32_t>(), g->chunk_off.as<uint32_t>(), nw + 1, st);
     RB_HIP(hipMemcpyAsync(&S->pinned[0], g->chunk_off.as<uint32_t>() + nw, 4, hipMemcpyDeviceToHost, st));
     RB_HIP(hipMemcpyAsync(&S->pinned[16], g->npf_tot.p, 2048, hipMemcpyDeviceToHost, st));
@@ -1090,6 +1097,22 @@ int rb_shard_hash_begin(rb_graph *g, const rb_batch *b, int64_t first, int64_t n
         prep_filter(g, b, first, n, ordinal0, pos_bits, flags, g->stream2);
     });
 }
+// split reads: the window walk + prefilter of THIS rank's slice of the next sub-batch, enqueued on the producer stream.  Call it when the
+// cache updates of the current sub-batch are in (rb_shard_cache_apply): the walk then runs beside the conflict phases and the remaining
+// exchanges of the current sub-batch; rb_shard_hash of the same sub-batch picks the result up instead of walking again.
+int rb_shard_hash_begin_split(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, int64_t own_first, int64_t own_n, uint64_t ordinal0,
+                              uint32_t pos_bits, unsigned flags) {
+    return guarded([&] {
+        RB_REQUIRE(g && g->shard && b, "rb_shard_hash_begin_split: bad argument");
+        RB_REQUIRE(b->device == g->p.device, "batch lives on device %d, shard on %d", b->device, g->p.device);
+        RB_REQUIRE(first >= 0 && n >= 0 && first + n <= b->n_reads && own_first >= first && own_n >= 0 && own_first + own_n <= first + n, "rb_shard_hash_begin_split: bad read range");
+        RB_REQUIRE(pos_bits >= 1 && pos_bits <= 31 && ((uint64_t)(b->max_len >= (uint32_t)g->k ? b->max_len - (uint32_t)g->k : 0u) >> pos_bits) == 0, "rb_shard_hash_begin_split: pos_bits too small for the reads");
+        RB_HIP(hipSetDevice(g->p.device));
+        g->shard->prep.stage = 0;
+        if (g->k > 31) return;                       // generic window-hash path: rb_shard_hash does it all
+        prep_filter(g, b, first, n, ordinal0, pos_bits, flags, g->stream2, true, own_first, own_n);
+    });
+}
 int rb_shard_hash_emit(rb_graph *g) {
     return guarded([&] {
         RB_REQUIRE(g && g->shard, "rb_shard_hash_emit: bad argument");
@@ -1108,6 +1131,7 @@ int rb_shard_hash_group(rb_graph *g, const rb_batch *b, int64_t first, int64_t n
         RB_REQUIRE(pair_first >= first && pair_n >= 0 && pair_first + pair_n <= first + n, "rb_shard_hash_group: pair slice outside the sub-batch");
         RB_REQUIRE(pos_bits >= 1 && pos_bits <= 31 && ((uint64_t)(b->max_len >= (uint32_t)g->k ? b->max_len - (uint32_t)g->k : 0u) >> pos_bits) == 0, "rb_shard_hash_group: pos_bits too small for the reads");
         RB_REQUIRE((uint64_t)n < (1ull << (32 - pos_bits)), "rb_shard_hash_group: too many reads for the occurrence id");
+        g->shard->sub_reads_bits = std::max(g->shard->sub_reads_bits, log2_ceil((uint64_t)std::max<int64_t>(1, n)));   // (never shrinks: a look-ahead may already be on the next, shorter sub-batch)
         ShardState *S = g->shard;
         RB_HIP(hipSetDevice(g->p.device));
         hipStream_t s = g->stream;
@@ -1246,9 +1270,15 @@ int rb_shard_hash(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, int6
         RB_REQUIRE(own_first >= first && own_n >= 0 && own_first + own_n <= first + n, "rb_shard_hash: own slice outside the sub-batch");
         RB_REQUIRE(pos_bits >= 1 && pos_bits <= 31 && ((uint64_t)(b->max_len >= (uint32_t)g->k ? b->max_len - (uint32_t)g->k : 0u) >> pos_bits) == 0, "rb_shard_hash: pos_bits too small for the reads");
         RB_REQUIRE((uint64_t)n < (1ull << (32 - pos_bits)), "rb_shard_hash: too many reads for the occurrence id");
+        g->shard->sub_reads_bits = std::max(g->shard->sub_reads_bits, log2_ceil((uint64_t)std::max<int64_t>(1, n)));   // (never shrinks: a look-ahead may already be on the next, shorter sub-batch)
         ShardState *S = g->shard;
         RB_HIP(hipSetDevice(g->p.device));
         RB_HIP(hipStreamSynchronize(g->stream2));
+        // the window walk of this very slice, done ahead on the producer stream (rb_shard_hash_begin_split)?
+        const ShardState::Prep &PP = S->prep;
+        const bool prepared = PP.stage == 1 && PP.split && PP.b == b && PP.first == first && PP.n == n && PP.own_first == own_first && PP.own_n == own_n &&
+                              PP.ordinal0 == ordinal0 && PP.pos_bits == pos_bits && PP.flags == flags && g->k <= 31;
+        void *prepared_wstate = prepared ? PP.wstate : nullptr;
         S->prep.stage = 0;
         g->seq_codes = b->codes; g->seq_woff = b->woff; g->seq_wpr = b->wpr_uniform; g->seq_first = (uint32_t)first;   // occurrence ids -> bases, for the cache stores
         hipStream_t s = g->stream;
@@ -1265,8 +1295,10 @@ int rb_shard_hash(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, int6
         g->chunk_cnt.reserve(((size_t)nw + 1) * 4); g->chunk_off.reserve(((size_t)nw + 1) * 4);
         g->temp.reserve(scan_temp_bytes((size_t)nw + 1));
         g->npf_tot.reserve(2048);
-        RB_HIP(hipMemsetAsync(g->npf_tot.p, 0, 2048, s));
-        RB_HIP(hipMemsetAsync(g->chunk_cnt.as<uint32_t>() + nw, 0, 4, s));
+        if (!prepared) {
+            RB_HIP(hipMemsetAsync(g->npf_tot.p, 0, 2048, s));
+            RB_HIP(hipMemsetAsync(g->chunk_cnt.as<uint32_t>() + nw, 0, 4, s));
+        }
         uint32_t spread[16 * 32], N = 0;
         uint64_t windows = 0;
         const uint8_t *keep = nullptr;
@@ -1274,19 +1306,24 @@ int rb_shard_hash(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, int6
         // occurrence id and generator ordinal are relative to the GLOBAL sub-batch start `first`
         if (g->k <= 31) {
             g->chunk_mask.reserve(((size_t)nw + 1) * 4);
-            Npf cache = fv.npf;
-            if (!use_cache) cache.tab = nullptr;
-            g->prof_begin();
-            void *wstate = nullptr;
-            if (filter_saves_state(b, nw, g->k)) { g->wstate.reserve(((size_t)nw + 1) * 16); wstate = g->wstate.p; }
-            launch_filter_windows(b, w0, nw, g->k, mode_hash, (uint32_t)first, pos_bits, g->p.rng_seed, ordinal0, cache,
-                                  g->chunk_cnt.as<uint32_t>(), g->chunk_mask.as<uint32_t>(), g->npf_tot.as<uint32_t>(), s, OwnRange{Mod{1, 0, 0}, 0, 0}, fv.mpf, wstate);
-            exclusive_scan_u32(g->temp.p, g->temp.cap, g->chunk_cnt.as<uint32_t>(), g->chunk_off.as<uint32_t>(), (size_t)nw + 1, s);
-            RB_HIP(hipMemcpyAsync(&N, g->chunk_off.as<uint32_t>() + nw, 4, hipMemcpyDeviceToHost, s));
-            RB_HIP(hipMemcpyAsync(spread, g->npf_tot.p, sizeof spread, hipMemcpyDeviceToHost, s));
-            g->prof_end("filter_windows");
-            RB_HIP(hipStreamSynchronize(s));
-            for (int q = 0; q < 32; ++q) windows += spread[16 * q];
+            void *wstate = prepared_wstate;
+            if (prepared) {            // counts, masks, offsets and rolling states are in place (the producer stream was drained above)
+                N = S->pinned[0];
+                for (int q = 0; q < 32; ++q) windows += S->pinned[16 + 16 * q];
+            } else {
+                Npf cache = fv.npf;
+                if (!use_cache) cache.tab = nullptr;
+                g->prof_begin();
+                if (filter_saves_state(b, nw, g->k)) { g->wstate.reserve(((size_t)nw + 1) * 16); wstate = g->wstate.p; }
+                launch_filter_windows(b, w0, nw, g->k, mode_hash, (uint32_t)first, pos_bits, g->p.rng_seed, ordinal0, cache,
+                                      g->chunk_cnt.as<uint32_t>(), g->chunk_mask.as<uint32_t>(), g->npf_tot.as<uint32_t>(), s, OwnRange{Mod{1, 0, 0}, 0, 0}, fv.mpf, wstate);
+                exclusive_scan_u32(g->temp.p, g->temp.cap, g->chunk_cnt.as<uint32_t>(), g->chunk_off.as<uint32_t>(), (size_t)nw + 1, s);
+                RB_HIP(hipMemcpyAsync(&N, g->chunk_off.as<uint32_t>() + nw, 4, hipMemcpyDeviceToHost, s));
+                RB_HIP(hipMemcpyAsync(spread, g->npf_tot.p, sizeof spread, hipMemcpyDeviceToHost, s));
+                g->prof_end("filter_windows");
+                RB_HIP(hipStreamSynchronize(s));
+                for (int q = 0; q < 32; ++q) windows += spread[16 * q];
+            }
             if (N) {
                 g->keys0.reserve((size_t)N * 8); g->vals0.reserve((size_t)N * 4);
                 g->prof_begin();
@@ -1366,9 +1403,10 @@ int rb_shard_group(rb_graph *g, const void *keys_dev, const void *occ_dev, int64
         const int mode = (flags & RB_ADD_COUNT_IF_PRESENT) ? M_COUNT_IF_PRESENT : M_ADD;
         S->mode = mode;
         if (n == 0) return;
-        g->keys0.reserve((size_t)n * 8); g->vals0.reserve((size_t)n * 4);
-        RB_HIP(hipMemcpyAsync(g->keys0.p, keys_dev, (size_t)n * 8, hipMemcpyDeviceToDevice, s));
-        RB_HIP(hipMemcpyAsync(g->vals0.p, occ_dev, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+        // grouped where they arrived: the receive buffers are the caller's scratch until its next exchange (both drivers), and the
+        // grouping clobbers its input anyway — no copy into keys0 / vals0 (24 GB per config-2 pass over all ranks)
+        g->group_in_keys = const_cast<uint64_t *>(static_cast<const uint64_t *>(keys_dev));
+        g->group_in_vals = const_cast<uint32_t *>(static_cast<const uint32_t *>(occ_dev));
         const uint32_t D = group_records(g, (size_t)n, ordinal0, pos_bits, nullptr, nullptr);
         S->D = D;
         make_and_route_requests(g, D, mode, ordinal0, pos_bits, dreq_counts, creq_counts);
@@ -1623,6 +1661,7 @@ int rb_shard_conflict_route(rb_graph *g, const void *edges_dev, int64_t n_edges,
         const size_t ne = (size_t)n_edges;
         // components of the global (run, contested counter) graph — identical on every rank
         const uint32_t log2cap = log2_ceil(2ull * ne + 2);
+        S->gid_bits = std::max(1u, log2_ceil((uint64_t)std::max<int64_t>(2, gid_bound)));
         S->etab.reserve(sizeof(Slot) << log2cap); S->eslot.reserve(ne * 4); S->elabel.reserve((size_t)gid_bound * 4 + 16);
         RB_HIP(hipMemsetAsync(S->etab.p, 0xFF, sizeof(Slot) << log2cap, s));
         g->devctr.reserve(DEVCTR_BYTES);
@@ -1703,11 +1742,15 @@ int rb_shard_conflict_replay(rb_graph *g, const void *runs_dev, int64_t n_runs, 
         hipLaunchKernelGGL(k_run_slots, dim3(blocks_for(R)), dim3(TPB), 0, s, fv, runs, R, S->rtab.as<Slot>(), log2cap, S->rslot.as<uint32_t>());
         RB_HIP(hipStreamSynchronize(s));
         RB_REQUIRE(total == O, "rb_shard_conflict_replay: runs announce %u ops, got %u", total, O);
-        sort_keys_u64(g->temp.p, g->temp.cap, S->rk0.as<uint64_t>(), S->rk1.as<uint64_t>(), R, 0, 64, s);
+        // run keys are (component label << 32) | arrival number and arrive in arrival order: a stable sort on the label bits is the sort on all 64
+        const int label_end = 32 + (int)std::min(32u, S->gid_bits);
+        sort_keys_u64(g->temp.p, g->temp.cap, S->rk0.as<uint64_t>(), S->rk1.as<uint64_t>(), R, 32, label_end, s);
         if (O) {
             hipLaunchKernelGGL(k_run_expand, dim3(blocks_for((int64_t)R * 64)), dim3(TPB), 0, s, runs, S->cnoff.as<uint32_t>(), (const uint32_t *)ops_dev, R,
                                S->ok0.as<uint64_t>(), S->ov0.as<uint32_t>());
-            sort_pairs_u64_u32(g->temp.p, g->temp.cap, S->ok0.as<uint64_t>(), S->ok1.as<uint64_t>(), S->ov0.as<uint32_t>(), S->ov1.as<uint32_t>(), O, 0, 64, s);
+            // op keys are (component label << 32) | occurrence id: the occurrence bits of this sub-batch, then the label bits
+            sort_pairs_u64_u32_2r(g->temp.p, g->temp.cap, S->ok0.as<uint64_t>(), S->ok1.as<uint64_t>(), S->ov0.as<uint32_t>(), S->ov1.as<uint32_t>(), O,
+                                  0, S->sub_reads_bits ? (int)std::min(32u, S->pos_bits + S->sub_reads_bits) : 32, 32, label_end, s);
             uint32_t *big_flag = S->rbig.as<uint32_t>(), *big_list = big_flag + R;
             g->devctr.reserve(DEVCTR_BYTES);
             uint32_t *ctr = g->devctr.as<uint32_t>();

@@ -15,7 +15,7 @@
 namespace rb {
 
 namespace {
-constexpr uint32_t SC_TPB = 256, SC_VEC = 4, SC_SUB = SC_TPB * SC_VEC, SC_SUBS = 16, SC_TILE = SC_SUB * SC_SUBS;   // 16384 items per tile
+constexpr uint32_t SC_TPB = 256, SC_VEC = 16, SC_SUB = SC_TPB * SC_VEC, SC_SUBS = 4, SC_TILE = SC_SUB * SC_SUBS;   // 16384 items per tile, 4 rounds of 4 barriers
 constexpr uint32_t SC_ONE_TPB = 1024, SC_ONE_VEC = 16, SC_ONE_MAX = 65536;   // single-workgroup path: 16 K items per round of 4 barriers
 
 // One sub-tile of TPB x VEC items at in[base ...): exclusive scan with `carry` added, written to out; returns carry + the

@@ -138,6 +138,7 @@ SYMBOLS = [
     ("rb_shard_comm_create_loopback", _i32, [_i32, C.POINTER(_vp)]),
     ("rb_shard_comm_destroy", _i32, [_vp]),
     ("rb_shard_comm_selftest", _i32, [_vp, _i32, _i32, _i64]),
+    ("rb_shard_hash_begin_split", _i32, [_vp, _vp, _i64, _i64, _i64, _i64, C.c_uint64, C.c_uint32, C.c_uint]),
     ("rb_shard_pairs_flush_begin", _i32, [_vp, C.POINTER(_vp), C.POINTER(_i64)]),
     ("rb_shard_pairs_flush_end", _i32, [_vp, _vp, C.POINTER(_i64)]),
     ("rb_shard_add_range", _i32, [_vp, _vp, _vp, _i64, _i64, C.c_uint, _i64, C.c_uint32, C.c_uint64, C.POINTER(AddStats)]),
