@@ -375,7 +375,12 @@ void substep(rb_graph *g, rb_shard_comm *c, const rb_batch *b, int64_t first, in
         SlotView upd = slot(g, RB_SLOT_CACHE_UPD, -1);
         void *all_upd = nullptr;
         gather(c, me, upd.p, upd.nbytes, 1, &all_upd, u_sizes, st);
-        RB_CK(rb_shard_cache_apply(g, all_upd, sum(u_sizes, G) / 16));
+        {   // every rank's updates but this rank's own (its replica got them when they were made, rb_shard_resolve)
+            int64_t before = 0, after = 0;
+            for (int r = 0; r < G; ++r) { if (r < me) before += u_sizes[r]; else if (r > me) after += u_sizes[r]; }
+            if (before) RB_CK(rb_shard_cache_apply(g, all_upd, before / 16));
+            if (after) RB_CK(rb_shard_cache_apply(g, static_cast<const char *>(all_upd) + before + u_sizes[me], after / 16));
+        }
         // look-ahead: this rank's slice of the NEXT sub-batch is walked against the cache as it stands now, on the producer stream,
         // beside the conflict phases and exchanges below (RB_SHARD_OVERLAP=0: off)
         if (have_next && overlap >= 1) {

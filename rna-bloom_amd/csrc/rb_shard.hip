@@ -195,11 +195,21 @@ struct RouteKeep {
     __device__ void drop(size_t) const {}
 };
 // the common case: items are global filter indices staged in an array, destination = index / span
+// idx / span without a 64-bit division per item and pass (the partition kernels call dest() 8 times per thread, twice): one mulhi + a fix-up
+struct SpanDiv {
+    uint64_t span, inv;
+    SpanDiv(uint64_t s) : span(s), inv(s > 1 ? (uint64_t)(((unsigned __int128)1 << 64) / s) : ~0ull) {}      // (implicit: the call sites pass the span)
+    __device__ __forceinline__ int of(uint64_t idx) const {
+        uint64_t q = __umul64hi(idx, inv);
+        if (idx - q * span >= span) ++q;
+        return (int)q;
+    }
+};
 struct RouteIdx {
-    const uint64_t *idx; const uint8_t *drop_flag; uint64_t span;
+    const uint64_t *idx; const uint8_t *drop_flag; SpanDiv span;
     const uint64_t *pay64; const uint8_t *pay8;             // optional payload columns
     uint64_t *out_idx, *out64; uint8_t *out8; uint32_t *pos_of;
-    __device__ int dest(size_t i) const { return (drop_flag && drop_flag[i]) ? -1 : (int)(idx[i] / span); }
+    __device__ int dest(size_t i) const { return (drop_flag && drop_flag[i]) ? -1 : span.of(idx[i]); }
     __device__ void emit(size_t i, uint32_t pos) const {
         out_idx[pos] = idx[i];
         if (pay64) out64[pos] = pay64[i];

@@ -198,7 +198,10 @@ class ShardRank:
         # the owners learnt about their k-mers' counters (for every rank's prefilter cache replica)
         if split:
             (all_edges, e_sizes), (upd, u_sizes) = yield ("gather", [self._slot(N.SLOT_CONF_EDGES, 16 * nedge.value), self._slot(N.SLOT_CACHE_UPD)])
-            check(lib.rb_shard_cache_apply(self.h, _ptr(upd), sum(u_sizes) // 16))
+            # every rank's updates but this rank's own (its replica got them when they were made, in rb_shard_resolve)
+            before, mine = sum(u_sizes[:self.rank]), u_sizes[self.rank]
+            if before: check(lib.rb_shard_cache_apply(self.h, _ptr(upd[:before]), before // 16))
+            if sum(u_sizes) - before - mine: check(lib.rb_shard_cache_apply(self.h, _ptr(upd[before + mine:]), (sum(u_sizes) - before - mine) // 16))
             if nxt and _OVERLAP >= 1:      # look-ahead: this rank's slice of the next sub-batch walked beside the conflict phases below
                 q0, q1 = nxt[0] + nxt[1] * self.rank // G, nxt[0] + nxt[1] * (self.rank + 1) // G
                 check(lib.rb_shard_hash_begin_split(self.h, batch.h, nxt[0], nxt[1], q0, q1 - q0, self.ordinal + int(n), pos_bits, flags))

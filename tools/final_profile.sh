@@ -29,7 +29,7 @@ known = 8.0 * 2 * sorted_total       # the histogram kernel reads the 8-byte key
 print("FETCH_SIZE calibration on rb::k_part_count (8-byte-per-lane coalesced streaming reads, nothing else read but %d B of tile descriptors):" % 16)
 print("  records per step %d x %d steps x 2 passes x 8 B = %.3f GB read by construction" % (b["config"]["sorted_kmers_per_step"], steps, known / 1e9))
 print("  FETCH_SIZE total over its %d dispatches        = %.3f GB" % (sum(int(r[1]) for r in hit), fetch / 1e9))
-print("  known / counter = %.3f   (the guide: 128-byte requests of coalesced streaming reads are tallied as 64 bytes -> x 2)" % (known / fetch))
+print("  known / counter = %.3f   (the guide: 128-byte requests of coalesced streaming reads are tallied as 64 bytes -> x 2; since round 4 the kernel name also covers the LSD passes of the conflict path's small sorts, whose reads are in the counter and not in the known bytes: 2.00 in rounds 2-3, a few percent lower now)" % (known / fetch))
 PY
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/prof_cal -o c -- $R/tools/microbench/gather_bench calib > $OUT/calib.log 2>&1
 python - <<PY >> $OUT/pmc_calibration.txt
