@@ -386,15 +386,17 @@ __device__ __forceinline__ uint32_t gr_look_back(const unsigned long long *statu
     }
 }
 
+// (two workgroups of 512 threads per CU = 4 wavefronts per SIMD: at most 128 VGPRs — the second launch bound keeps the compiler there; a
+// few registers more and only ONE workgroup fits a CU: 25 -> 39 ms, measured when the run ordering below first went in)
 template <int TPB, bool PREFETCH>
-__global__ void __launch_bounds__(TPB) k_group_buckets(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+__global__ void __launch_bounds__(TPB, (TPB == 512 ? 4 : 2)) k_group_buckets(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
                                                        const uint32_t *__restrict__ bstart, uint32_t nbuckets,
                                                        uint32_t shift_lo, uint32_t bits_lo, uint32_t shift_hi, uint32_t bits_hi,
                                                        GroupRng rng, uint32_t do_fix, uint32_t *__restrict__ ticket, unsigned long long *__restrict__ status,
                                                        uint32_t *__restrict__ big_list, uint32_t *__restrict__ n_big,
                                                        uint32_t *__restrict__ vals_out, uint8_t *__restrict__ tz_out,
                                                        uint64_t *__restrict__ uniq, uint32_t *__restrict__ counts, uint32_t *__restrict__ starts,
-                                                       uint32_t *__restrict__ n_runs_out) {
+                                                       uint32_t *__restrict__ n_runs_out, uint32_t by_class) {
     constexpr uint32_t ITEMS = GR_TILE / TPB, NW = TPB / 64, SEG = 64 * ITEMS, NB = 1u << GR_LOCAL_BITS;
     static_assert(ITEMS * NW == 64, "the segment scan below is one wavefront wide");
     __shared__ uint64_t s_keys[GR_TILE];
@@ -404,6 +406,7 @@ __global__ void __launch_bounds__(TPB) k_group_buckets(const uint64_t *__restric
     __shared__ uint16_t s_dstart[NB];
     __shared__ uint32_t s_wsum[NW], s_seg[ITEMS * NW], s_misc[3], s_fixn, s_redo;
     __shared__ uint16_t s_fixlist[64];
+    __shared__ uint32_t s_cls[16];
     const uint32_t w = threadIdx.x >> 6, lane = threadIdx.x & 63u;
     for (uint32_t d = threadIdx.x; d < NW * NB; d += TPB) { s_wmask[d] = 0ull; s_wcnt[0][d] = 0; s_wcnt[1][d] = 0; }
     uint32_t c = 0, b0 = 0, b1 = 0;
@@ -614,6 +617,28 @@ __global__ void __launch_bounds__(TPB) k_group_buckets(const uint64_t *__restric
     }
     __syncthreads();
     const uint32_t run_base = s_misc[0];
+    if (by_class && nruns > 64u) {
+        // Stage B walks a run's occurrences in a per-lane loop, so a wavefront takes as long as its longest run: the bucket's runs go out
+        // ordered by length class (1, 2, 3-4, 5-8, ... 65+; long ones first), which makes the 64 runs of a wavefront alike.  Nothing
+        // downstream depends on the order of the runs (ties anywhere are broken by occurrence ids).
+        if (threadIdx.x < 16u) s_cls[threadIdx.x] = 0u;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < nruns; i += TPB) {
+            const uint32_t j = hpos[i], e = i + 1u < nruns ? (uint32_t)hpos[i + 1u] : cn;
+            atomicAdd(&s_cls[min(7u, 32u - (uint32_t)__clz((int)(e - j - 1u)))], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) { uint32_t run = 0; for (int q = 7; q >= 0; --q) { const uint32_t t = s_cls[q]; s_cls[q] = run; run += t; } }
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < nruns; i += TPB) {
+            const uint32_t j = hpos[i], e = i + 1u < nruns ? (uint32_t)hpos[i + 1u] : cn;
+            const uint32_t q = min(7u, 32u - (uint32_t)__clz((int)(e - j - 1u)));
+            const uint32_t slot = run_base + s_cls[q] + atomicAdd(&s_cls[8u + q], 1u);
+            uniq[slot] = s_keys[j];
+            starts[slot] = b0 + j;
+            counts[slot] = e - j;
+        }
+    } else
     for (uint32_t i = threadIdx.x; i < nruns; i += TPB) {
         const uint32_t j = hpos[i], e = i + 1u < nruns ? (uint32_t)hpos[i + 1u] : cn;
         uniq[run_base + i] = s_keys[j];
@@ -1048,12 +1073,13 @@ static void group_records_impl(const GroupPlan &P, uint64_t *keys0, uint32_t *va
     const bool ordered = getenv("RB_GROUP_ORDERED") && atoi(getenv("RB_GROUP_ORDERED")) != 0;
     if (!ordered) RB_HIP(hipMemsetAsync(n_runs_dev, 0, 4, st));
     const bool prefetch = !(getenv("RB_GROUP_PREFETCH") && atoi(getenv("RB_GROUP_PREFETCH")) == 0);
+    const uint32_t by_class = getenv("RB_GROUP_CLASSES") ? (uint32_t)(atoi(getenv("RB_GROUP_CLASSES")) != 0) : 1u;    // a bucket's runs ordered by length class (stage B's wavefronts alike)
     if (ordered || !prefetch)
         hipLaunchKernelGGL((k_group_buckets<TPB, false>), dim3(bucket_grid), dim3(TPB), 0, st, kin, vin, bstart, P.nbuckets, P.lshift_lo, P.l_lo, P.lshift_hi, P.l_hi,
-                           rng, P.fix_cap, ticket, ordered ? status : nullptr, big_list, n_big, vals_out, tz_out, uniq, counts, starts, n_runs_dev);
+                           rng, P.fix_cap, ticket, ordered ? status : nullptr, big_list, n_big, vals_out, tz_out, uniq, counts, starts, n_runs_dev, 0u);
     else
         hipLaunchKernelGGL((k_group_buckets<TPB, true>), dim3(bucket_grid), dim3(TPB), 0, st, kin, vin, bstart, P.nbuckets, P.lshift_lo, P.l_lo, P.lshift_hi, P.l_hi,
-                           rng, P.fix_cap, ticket, nullptr, big_list, n_big, vals_out, tz_out, uniq, counts, starts, n_runs_dev);
+                           rng, P.fix_cap, ticket, nullptr, big_list, n_big, vals_out, tz_out, uniq, counts, starts, n_runs_dev, by_class);
     if (prof) { prof->prof_end("group_buckets", st); prof->prof_begin(st); }
     // the buckets that do not fit LDS (none in a warm steady state): sorted through the record buffer that is free now
     uint64_t *ka = const_cast<uint64_t *>(kin), *kb = kin == keys0 ? keys_tmp : keys0;

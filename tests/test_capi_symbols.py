@@ -149,3 +149,51 @@ def test_java_drop_in_classes_keep_every_public_signature_of_the_reference():
         assert "NativeGraph.contains(handle" in body[:body.index("\n    }\n")], name
     worker = open(os.path.join(ROOT, "java", "rnabloom", "graph", "NativeFastqToGraphWorker.java")).read()
     assert "NativeGraph.addReads(" in worker and "implements Runnable" in worker
+
+
+# ---- occupancy budget of the hot kernels, read from the code objects inside librb_hip.so (no GPU needed) ----
+def _kernel_resources():
+    """{demangled-ish kernel name: (vgprs, spilled vgprs, LDS bytes)} of every gfx950 kernel bundled in the library"""
+    import struct, subprocess, tempfile
+    readelf = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not os.path.exists(readelf):
+        pytest.skip("no llvm-readelf")
+    data = open(os.path.join(ROOT, "rna-bloom_amd", "lib", "librb_hip.so"), "rb").read()
+    out, at = {}, 0
+    while True:
+        at = data.find(b"__CLANG_OFFLOAD_BUNDLE__", at)
+        if at < 0:
+            break
+        n = struct.unpack_from("<Q", data, at + 24)[0]
+        o = at + 32
+        for _ in range(n):
+            off, size, tl = struct.unpack_from("<QQQ", data, o); o += 24
+            triple = data[o:o + tl]; o += tl
+            if b"gfx950" in triple and size:
+                with tempfile.NamedTemporaryFile(suffix=".co") as f:
+                    f.write(data[at + off: at + off + size]); f.flush()
+                    txt = subprocess.run([readelf, "--notes", f.name], capture_output=True, text=True).stdout
+                for blk in txt.split("- .agpr_count")[1:] if "- .agpr_count" in txt else txt.split("    - ")[1:]:
+                    nm = re.search(r"\.name:\s+(\S+)", blk); vg = re.search(r"\.vgpr_count:\s+(\d+)", blk)
+                    sp = re.search(r"\.vgpr_spill_count:\s+(\d+)", blk); lds = re.search(r"\.group_segment_fixed_size:\s+(\d+)", blk)
+                    if nm and vg:
+                        out[nm.group(1)] = (int(vg.group(1)), int(sp.group(1)) if sp else 0, int(lds.group(1)) if lds else 0)
+        at += 24
+    return out
+
+
+def test_hot_kernels_keep_their_occupancy_budget():
+    """k_group_buckets<512> runs two workgroups of 512 threads per CU = 4 wavefronts per SIMD, which needs <= 128 VGPRs: round 4 saw 132 after
+    an innocent addition and the kernel went from 25 to 39 ms per step (one workgroup per CU).  The register counts are in the code
+    objects: checked here, without a GPU, together with "no spills" for the kernels the step time is made of."""
+    res = _kernel_resources()
+    assert len(res) > 100, len(res)
+    pick = lambda frag: {k: v for k, v in res.items() if frag in k}
+    gb = pick("k_group_bucketsILi512E")
+    assert len(gb) == 2 and all(v[0] <= 128 and v[1] == 0 for v in gb.values()), gb
+    assert all(v[2] <= 80 * 1024 for v in gb.values()), gb                         # two workgroups share the CU's 160 KB of LDS
+    for frag in ("k_filter_reads_pipe", "k_part_scatterILi512E", "k_part_countILi512E", "k_probe_h2", "k_resolve_apply", "k_hash_windows_resume", "k_pairs_reads"):
+        ks = pick(frag)
+        assert ks and all(v[1] == 0 for v in ks.values()), (frag, ks)
+    ps = pick("k_part_scatterILi512ELi8E")
+    assert all(v[0] <= 64 and v[2] <= 53 * 1024 + 512 for v in ps.values()), ps     # three workgroups per CU (DESIGN s5)

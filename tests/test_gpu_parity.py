@@ -376,7 +376,7 @@ def test_cold_subbatch_is_split_when_survivors_exceed_the_bound():
                                  {"RB_PAIRS_SIDE": "0"}, {"RB_PAIRS_SIDE": "1"}, {"RB_PAIRS_SIDE": "2"}, {"RB_PAIRS_SIDE": "4"}, {"RB_PAIRS_SIDE": "5"},
                                  {"RB_FILTER_PIPE": "1"}, {"RB_FILTER_PIPE": "2"}, {"RB_FILTER_PIPE": "0"}, {"RB_RAGGED_LANES": "0"},
                                  {"RB_GROUP_IDX": "1"}, {"RB_GROUP_IDX": "0"}, {"RB_GROUP_IDX": "1", "RB_GROUP_T": "18"}, {"RB_GROUP_IDX": "1", "RB_GROUP_T": "3"},
-                                 {"RB_GROUP_IDX": "1", "RB_TWO_PHASE": "1"}, {"RB_FT_FILTER": "1"}, {"RB_FT_FILTER": "0"}])
+                                 {"RB_GROUP_IDX": "1", "RB_TWO_PHASE": "1"}, {"RB_FT_FILTER": "1"}, {"RB_FT_FILTER": "0"}, {"RB_GROUP_CLASSES": "0"}])
 def test_pipeline_switches_do_not_change_results(monkeypatch, env):
     """every scheduling / cache switch of the insert path (minimizer- vs hash-bucketed cache, tiny caches that
     thrash, minimizer length, cold-start ramp, producer one sub-batch ahead, serialised streams, one word or one

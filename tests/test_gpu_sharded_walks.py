@@ -157,3 +157,30 @@ def test_greedy_extension_through_a_gate_filter(G):
         shorter += int((el < free).sum())
     assert shorter > 0                      # the gate did stop walks
     g1.destroy(); cl.destroy(); gate.destroy(); bf.destroy()
+
+
+def test_few_walks_on_a_rank_ask_for_more_than_the_request_buffer_holds():
+    """rb_shard_trav_begin sizes the per-round request buffer at 8 entries per walk, and a branchy greedy step files 4
+    requests for every neighbourhood its lookahead search opens (12-16 with two or three candidates).  With one or two walks on a rank the
+    round's requests exceed the buffer: the kernel drops what does not fit, rb_shard_trav_advance sends what did (it used to fail the whole
+    traversal, leaving the peers in the all-to-all), and the suspended walk asks for the rest when its step is replayed.  Results must
+    equal the single-GPU calls — one or two seeds per rank, deep lookahead, the branchy graph."""
+    g1, cl, seeds, _, _ = build(2, False)
+    picked = 0
+    for base in range(0, 60, 3):
+        mine = [seeds[base:base + 1], seeds[base + 1:base + 3]]                 # rank 0: one walk, rank 1: two
+        flat = mine[0] + mine[1]
+        for direction, lookahead, bound in ((0, 6, 30), (1, 5, 25)):
+            eb, ec, el, er = g1.greedyExtend(flat, direction, lookahead, bound)
+            got = cl.greedyExtend(mine, direction, lookahead, bound, answer_cap=1024)
+            at = 0
+            for rk in range(2):
+                bases, c, ln, reason = got[rk]
+                n = len(mine[rk])
+                assert (ln == el[at:at + n]).all() and (reason == er[at:at + n]).all(), (base, direction, rk)
+                m = np.arange(bound)[None, :] < ln[:, None]
+                assert (bases[m] == eb[at:at + n][m]).all() and (c[m] == ec[at:at + n][m]).all()
+                at += n
+            picked += int((el > 3).sum())
+    assert picked > 20                                                          # the walks did get somewhere
+    g1.destroy(); cl.destroy()
