@@ -521,8 +521,8 @@ int rb_shard_trav_end(rb_graph *g, char *out_bases, uint64_t *out_f, uint64_t *o
  * restore the contents) — tools/alloc_lottery.py looks for what the probe stages' allocation-dependent time follows */
 int rb_debug_probe_cbf(rb_graph *g, int mode, float *ms_out);
 /* development / tests: the library's own device-wide primitives (csrc/rb_sort.hip, csrc/rb_group.hip; rocPRIM until round 3) on
- * host arrays.  rb_debug_scan_u32: out[i] = in[0] + ... + in[i-1] (wrapping); the device copies start `misalign` words past a
- * 16-byte boundary.  rb_debug_sort_pairs: stable sort of (key, value) on key bits [lo_begin, lo_end) then [hi_begin, hi_end)
+ * host arrays.  rb_debug_scan_u32: out[i] = in[0] + ... + in[i-1] (wrapping); the device copies start
+ * (misalign & 3) [input] and (misalign >> 2) [output] words past a 16-byte boundary (0: both aligned — the vectorised path).  rb_debug_sort_pairs: stable sort of (key, value) on key bits [lo_begin, lo_end) then [hi_begin, hi_end)
  * (hi_begin < 0: one range); vals may be NULL (keys only), vals64 != 0: 64-bit values. */
 int rb_debug_scan_u32(int device, const uint32_t *in, size_t n, uint32_t *out, int misalign);
 int rb_debug_sort_pairs(int device, uint64_t *keys, void *vals, int vals64, size_t n, int lo_begin, int lo_end, int hi_begin, int hi_end);

@@ -2153,12 +2153,13 @@ void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, ui
         const uint32_t nc0 = hc[1];
         const size_t slots = (size_t)1 << c_log2;
         g->cwriters.reserve(slots * 8 + 64);
-        g->cshared.reserve(((size_t)nc0 + 1) * 4 * 5 + 64);
+        const size_t cs_stride = ((size_t)nc0 + 1 + 3) / 4 * 4;                     // (16-byte aligned sub-arrays: the scans below take their vectorised path)
+        g->cshared.reserve(cs_stride * 4 * 5 + 64);
         RB_HIP(hipMemsetAsync(g->cwriters.p, 0, slots * 8 + 64, s));
         uint32_t *writers = g->cwriters.as<uint32_t>(), *cflag = writers + slots, *changed = cflag + slots;
-        uint32_t *ordered = g->cshared.as<uint32_t>(), *heavy2 = ordered + (nc0 + 1), *pos_o = heavy2 + (nc0 + 1), *pos_h = pos_o + (nc0 + 1),
-                 *heavy2_list = pos_h + (nc0 + 1);
-        RB_HIP(hipMemsetAsync(ordered, 0, ((size_t)nc0 + 1) * 4 * 2, s));
+        uint32_t *ordered = g->cshared.as<uint32_t>(), *heavy2 = ordered + cs_stride, *pos_o = heavy2 + cs_stride, *pos_h = pos_o + cs_stride,
+                 *heavy2_list = pos_h + cs_stride;
+        RB_HIP(hipMemsetAsync(ordered, 0, cs_stride * 4 * 2, s));
         const CsLookup L{g->ctable.as<Slot>(), c_log2, csf, csf_log2};
         const uint32_t *cand = g->confk.as<uint32_t>();
         hipLaunchKernelGGL(k_cs_writers, dim3(blocks_for(nc0)), dim3(TPB), 0, s, fv, uniq, nops, cand, nc0, g->cvals.as<uint64_t>(), L, writers);
@@ -3945,10 +3946,10 @@ int rb_debug_scan_u32(int device, const uint32_t *in, size_t n, uint32_t *out, i
     struct Rel { DevBuf &a, &b, &t; ~Rel() { a.release(); b.release(); t.release(); } } rel{a, b, t};
     return guarded([&] {
         RB_REQUIRE((in && out) || n == 0, "rb_debug_scan_u32: null array");
-        RB_REQUIRE(misalign >= 0 && misalign < 4, "rb_debug_scan_u32: misalign in 0..3");
+        RB_REQUIRE(misalign >= 0 && misalign < 16, "rb_debug_scan_u32: misalign in 0..15");
         RB_HIP(hipSetDevice(device));
         a.reserve((n + 8) * 4); b.reserve((n + 8) * 4); t.reserve(scan_temp_bytes(n));
-        uint32_t *di = a.as<uint32_t>() + misalign, *dout = b.as<uint32_t>() + ((misalign + 1) & 3);
+        uint32_t *di = a.as<uint32_t>() + (misalign & 3), *dout = b.as<uint32_t>() + ((misalign >> 2) & 3);   // words past a 16-byte boundary: input, output
         if (n) RB_HIP(hipMemcpy(di, in, n * 4, hipMemcpyHostToDevice));
         exclusive_scan_u32(t.p, t.cap, di, dout, n, nullptr);
         RB_HIP(hipGetLastError());

@@ -15,27 +15,33 @@
 namespace rb {
 
 namespace {
-constexpr uint32_t SC_TPB = 256, SC_VEC = 16, SC_SUB = SC_TPB * SC_VEC, SC_SUBS = 4, SC_TILE = SC_SUB * SC_SUBS;   // 16384 items per tile, 4 rounds of 4 barriers
+constexpr uint32_t SC_TPB = 256, SC_VEC = 4, SC_SUB = SC_TPB * SC_VEC, SC_SUBS = 16, SC_TILE = SC_SUB * SC_SUBS;   // 16384 items per tile.  (16 items per thread and
+// four rounds instead of sixteen measured TWICE as slow, 233 against 116 us for the 23 M-word chunk scan: a thread's 64 consecutive bytes put the lanes' uint4 reads
+// on the same LDS banks; at 4 items the blocked reads are conflict-free)
 constexpr uint32_t SC_ONE_TPB = 1024, SC_ONE_VEC = 16, SC_ONE_MAX = 65536;   // single-workgroup path: 16 K items per round of 4 barriers
 
 // One sub-tile of TPB x VEC items at in[base ...): exclusive scan with `carry` added, written to out; returns carry + the
 // sub-tile's sum.  Striped (coalesced) global accesses, blocked scan through LDS; no alignment assumptions; in == out is fine.
+// LDS index of logical item i: four words of padding after every 64, so that the lanes' blocked 16-byte accesses (a thread's VEC consecutive
+// items) fall on different banks for any VEC (unpadded, 16 items per thread put every fourth lane on the same banks: the scan ran twice as long)
+__device__ __forceinline__ uint32_t sc_pad(uint32_t i) { return i + ((i >> 6) << 2); }
+constexpr uint32_t sc_padded(uint32_t n) { return n + ((n >> 6) << 2) + 4u; }
 template <uint32_t TPB, uint32_t VEC>
 __device__ __forceinline__ uint32_t sc_sub_scan(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, size_t base, size_t n, uint32_t carry,
-                                                uint32_t *s_data /* [TPB * VEC], 16-byte aligned */, uint32_t *s_wsum /* [TPB / 64] */) {
+                                                uint32_t *s_data /* [sc_padded(TPB * VEC)], 16-byte aligned */, uint32_t *s_wsum /* [TPB / 64] */) {
     static_assert(VEC % 4 == 0, "whole uint4 per thread");
     const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
 #pragma unroll
     for (uint32_t i = 0; i < VEC; ++i) {
         const size_t x = base + (size_t)i * TPB + tid;
-        s_data[i * TPB + tid] = x < n ? in[x] : 0u;
+        s_data[sc_pad(i * TPB + tid)] = x < n ? in[x] : 0u;
     }
     __syncthreads();
     uint32_t e[VEC];                                   // exclusive prefix inside the thread's VEC consecutive items
     uint32_t tot = 0;
 #pragma unroll
     for (uint32_t q = 0; q < VEC / 4; ++q) {
-        const uint4 v = reinterpret_cast<const uint4 *>(s_data)[tid * (VEC / 4) + q];
+        const uint4 v = *reinterpret_cast<const uint4 *>(s_data + sc_pad(tid * VEC + 4u * q));
         e[4 * q] = tot; tot += v.x; e[4 * q + 1] = tot; tot += v.y; e[4 * q + 2] = tot; tot += v.z; e[4 * q + 3] = tot; tot += v.w;
     }
     uint32_t inc = tot;
@@ -56,37 +62,37 @@ __device__ __forceinline__ uint32_t sc_sub_scan(const uint32_t *__restrict__ in,
     const uint32_t b0 = carry + wbase + inc - tot;
 #pragma unroll
     for (uint32_t q = 0; q < VEC / 4; ++q)
-        reinterpret_cast<uint4 *>(s_data)[tid * (VEC / 4) + q] = make_uint4(b0 + e[4 * q], b0 + e[4 * q + 1], b0 + e[4 * q + 2], b0 + e[4 * q + 3]);
+        *reinterpret_cast<uint4 *>(s_data + sc_pad(tid * VEC + 4u * q)) = make_uint4(b0 + e[4 * q], b0 + e[4 * q + 1], b0 + e[4 * q + 2], b0 + e[4 * q + 3]);
     __syncthreads();
 #pragma unroll
     for (uint32_t i = 0; i < VEC; ++i) {
         const size_t x = base + (size_t)i * TPB + tid;
-        if (x < n) out[x] = s_data[i * TPB + tid];
+        if (x < n) out[x] = s_data[sc_pad(i * TPB + tid)];
     }
     __syncthreads();                                   // s_data / s_wsum are reused by the caller's next sub-tile
     return carry + total;
 }
 
 __global__ void __launch_bounds__(SC_ONE_TPB) k_scan_one(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, size_t n) {
-    __shared__ __attribute__((aligned(16))) uint32_t s_data[SC_ONE_TPB * SC_ONE_VEC];
+    __shared__ __attribute__((aligned(16))) uint32_t s_data[sc_padded(SC_ONE_TPB * SC_ONE_VEC)];
     __shared__ uint32_t s_wsum[SC_ONE_TPB / 64];
     uint32_t carry = 0;
     for (size_t base = 0; base < n; base += SC_ONE_TPB * SC_ONE_VEC) carry = sc_sub_scan<SC_ONE_TPB, SC_ONE_VEC>(in, out, base, n, carry, s_data, s_wsum);
 }
 // the same with 256 threads for arrays of a few thousand entries (a 1024-thread workgroup is mostly barrier there)
 __global__ void __launch_bounds__(SC_TPB) k_scan_one_small(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, size_t n) {
-    __shared__ __attribute__((aligned(16))) uint32_t s_data[SC_TPB * SC_ONE_VEC];
+    __shared__ __attribute__((aligned(16))) uint32_t s_data[sc_padded(SC_TPB * SC_ONE_VEC)];
     __shared__ uint32_t s_wsum[SC_TPB / 64];
     uint32_t carry = 0;
     for (size_t base = 0; base < n; base += SC_TPB * SC_ONE_VEC) carry = sc_sub_scan<SC_TPB, SC_ONE_VEC>(in, out, base, n, carry, s_data, s_wsum);
 }
 
-__global__ void __launch_bounds__(SC_TPB) k_scan_reduce(const uint32_t *__restrict__ in, size_t n, uint32_t *__restrict__ tile_sums) {
+__global__ void __launch_bounds__(SC_TPB) k_scan_reduce(const uint32_t *__restrict__ in, size_t n, uint32_t *__restrict__ tile_sums, uint32_t tile) {
     __shared__ uint32_t s_w[SC_TPB / 64];
-    const size_t base = (size_t)blockIdx.x * SC_TILE;
+    const size_t base = (size_t)blockIdx.x * tile;
     uint32_t sum = 0;
-#pragma unroll 8
-    for (uint32_t j = 0; j < SC_TILE / SC_TPB; ++j) {
+#pragma unroll 4
+    for (uint32_t j = 0; j < tile / SC_TPB; ++j) {
         const size_t x = base + (size_t)j * SC_TPB + threadIdx.x;
         sum += x < n ? in[x] : 0u;
     }
@@ -100,13 +106,42 @@ __global__ void __launch_bounds__(SC_TPB) k_scan_reduce(const uint32_t *__restri
     }
 }
 
-__global__ void __launch_bounds__(SC_TPB) k_scan_apply(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, size_t n,
-                                                       const uint32_t *__restrict__ tile_offs) {
-    __shared__ __attribute__((aligned(16))) uint32_t s_data[SC_SUB];
-    __shared__ uint32_t s_wsum[SC_TPB / 64];
-    const size_t base = (size_t)blockIdx.x * SC_TILE;
+// in and out 16-byte aligned (the pipeline's per-word arrays are): a thread's four items are ONE 16-byte access each way, nothing is staged
+// in LDS but the wavefront sums — half the instructions and two barriers less per 1024 items
+__global__ void __launch_bounds__(SC_TPB) k_scan_apply_v4(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, size_t n,
+                                                          const uint32_t *__restrict__ tile_offs, uint32_t tile) {
+    __shared__ uint32_t s_wsum[2][SC_TPB / 64];
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, w = tid >> 6;
+    const size_t base = (size_t)blockIdx.x * tile;
     uint32_t carry = tile_offs[blockIdx.x];
-    for (uint32_t q = 0; q < SC_SUBS; ++q) {
+    for (uint32_t q = 0; q < tile / (SC_TPB * 4u); ++q) {
+        const size_t x = base + (size_t)q * (SC_TPB * 4u) + (size_t)tid * 4u;
+        if (base + (size_t)q * (SC_TPB * 4u) >= n) break;
+        uint4 v = make_uint4(0u, 0u, 0u, 0u);
+        if (x + 3 < n) v = *reinterpret_cast<const uint4 *>(in + x);
+        else if (x < n) { v.x = in[x]; if (x + 1 < n) v.y = in[x + 1]; if (x + 2 < n) v.z = in[x + 2]; }
+        const uint32_t e1 = v.x, e2 = e1 + v.y, e3 = e2 + v.z, tot = e3 + v.w;
+        uint32_t inc = tot;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(inc, o, 64); if ((int)lane >= o) inc += t; }
+        if (lane == 63u) s_wsum[q & 1u][w] = inc;
+        __syncthreads();                               // (double-buffered sums: one barrier per round)
+        uint32_t wbase = 0, total = 0;
+#pragma unroll
+        for (uint32_t i = 0; i < SC_TPB / 64; ++i) { const uint32_t t = s_wsum[q & 1u][i]; if (i < w) wbase += t; total += t; }
+        const uint32_t b0 = carry + wbase + inc - tot;
+        if (x + 3 < n) *reinterpret_cast<uint4 *>(out + x) = make_uint4(b0, b0 + e1, b0 + e2, b0 + e3);
+        else if (x < n) { out[x] = b0; if (x + 1 < n) out[x + 1] = b0 + e1; if (x + 2 < n) out[x + 2] = b0 + e2; }
+        carry += total;
+    }
+}
+__global__ void __launch_bounds__(SC_TPB) k_scan_apply(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, size_t n,
+                                                       const uint32_t *__restrict__ tile_offs, uint32_t tile) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_data[sc_padded(SC_SUB)];
+    __shared__ uint32_t s_wsum[SC_TPB / 64];
+    const size_t base = (size_t)blockIdx.x * tile;
+    uint32_t carry = tile_offs[blockIdx.x];
+    for (uint32_t q = 0; q < tile / SC_SUB; ++q) {
         const size_t b = base + (size_t)q * SC_SUB;
         if (b >= n) break;
         carry = sc_sub_scan<SC_TPB, SC_VEC>(in, out, b, n, carry, s_data, s_wsum);
@@ -118,19 +153,30 @@ void scan_one(const uint32_t *in, uint32_t *out, size_t n, hipStream_t s) {
 }
 }  // namespace
 
-size_t scan_temp_bytes(size_t n) { return ((n + SC_TILE - 1) / SC_TILE + 2) * 4 + 256; }
+size_t scan_temp_bytes(size_t n) {           // tile sums of the finest tiling (1024 items) + the same again for the level above them
+    const size_t l1 = (n + SC_SUB - 1) / SC_SUB + 128, l2 = (l1 + SC_SUB - 1) / SC_SUB + 128;
+    return (l1 + l2 + 4096) * 4;
+}
 
 // out[i] = in[0] + ... + in[i-1] (wrapping u32); in == out allowed.  Never waits for another workgroup.
 void exclusive_scan_u32(void *temp, size_t temp_bytes, const uint32_t *in, uint32_t *out, size_t n, hipStream_t s) {
     if (n == 0) return;
     if (n <= SC_ONE_MAX) { scan_one(in, out, n, s); return; }
-    const size_t nt = (n + SC_TILE - 1) / SC_TILE;
+    // a tile is 1 ... 16 rounds of 1024 items: mid-sized arrays (a few million entries) get enough workgroups to fill the device instead of a
+    // hundred workgroups walking sixteen rounds each (178 us for 2 M entries, the latency of the rounds, not bandwidth)
+    const uint32_t rounds = (uint32_t)std::max<size_t>(1, std::min<size_t>(SC_SUBS, n / ((size_t)2048 * SC_SUB)));
+    const uint32_t tile = rounds * SC_SUB;
+    const size_t nt = (n + tile - 1) / tile;
     RB_REQUIRE(temp && temp_bytes >= scan_temp_bytes(n), "exclusive_scan_u32: temp too small");
     RB_REQUIRE(nt < (1ull << 31), "exclusive_scan_u32: too many items");
     uint32_t *sums = reinterpret_cast<uint32_t *>(temp);
-    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nt), dim3(SC_TPB), 0, s, in, n, sums);
-    scan_one(sums, sums, nt, s);
-    hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nt), dim3(SC_TPB), 0, s, in, out, n, sums);
+    hipLaunchKernelGGL(k_scan_reduce, dim3((unsigned)nt), dim3(SC_TPB), 0, s, in, n, sums, tile);
+    const size_t used = ((nt + 63) / 64) * 64 + 64;
+    exclusive_scan_u32(sums + used, temp_bytes - used * 4, sums, sums, nt, s);                     // (one workgroup up to 64 K tile sums; else one more level)
+    if (((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out)) & 15u) == 0)
+        hipLaunchKernelGGL(k_scan_apply_v4, dim3((unsigned)nt), dim3(SC_TPB), 0, s, in, out, n, sums, tile);
+    else
+        hipLaunchKernelGGL(k_scan_apply, dim3((unsigned)nt), dim3(SC_TPB), 0, s, in, out, n, sums, tile);
 }
 
 // Two ordered index lists from one status array in two light passes (count per block, scan, write): the heavy and the

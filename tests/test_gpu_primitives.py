@@ -26,7 +26,7 @@ def _excl(a):
 def test_exclusive_scan_matches_numpy(n):
     rng = np.random.default_rng(n + 7)
     a = rng.integers(0, 33, n, dtype=np.uint32)
-    for mis in (0, 1, 3):
+    for mis in (0, 1, 3, 4, 13):          # input / output offsets from a 16-byte boundary: (0,0) aligned = the vectorised path, (1,0), (3,0), (0,1), (1,3)
         assert np.array_equal(_scan(a, mis), _excl(a)), (n, mis)
 
 
