@@ -115,14 +115,27 @@ __global__ void k_probe(FilterView fv, const uint64_t *__restrict__ uniq, const 
         atomicAdd(&counters[16 + 16 * (blockIdx.x & 31u)], n_foreign);   // 32 spread counters
     }
 }
+constexpr uint32_t ST_COLLIDE_SHIFT = 21;   // status bits 21..28: probe j found its bit set by another probe of the sub-batch
+// after the swept Bloom-bit stage (two hash functions): bits 29..30 = probe j set its bit and another probe may have met it there, and
+// ST_SWEPT_KNOWN = a probe with neither mark had its bit to itself — the arbitration (k_late_claim, stage B) need not look it up.
+// (All of these live until stage B rewrites the status word.)
+constexpr uint32_t ST_JOIN_SHIFT = 29, ST_SWEPT_KNOWN = 1u << 31;
+__device__ __forceinline__ bool st_alone(uint32_t st, int j) {
+    return (st & ST_SWEPT_KNOWN) && !(((st >> (ST_COLLIDE_SHIFT + j)) | (st >> (ST_JOIN_SHIFT + j))) & 1u);
+}
 // The same stage for the common filter shape (2 hash functions each, no full first-setter table), written for memory-level
 // parallelism: a lane takes RUNS runs, computes all their indices, issues ALL Bloom-bit loads, then ALL counter claims
 // (returning atomics), and only then consumes the answers — 2 dependent round trips per lane instead of 4 per run
 // (k_probe spent 71 % of its wave cycles waiting, profiles/r01_sq_counters).  Semantics are k_probe's, line for line.
-template <int RUNS>
+// SWEPT: the Bloom bits were tested AND set by the swept stage (rb_group.hip sweep_bits_device); st0 / st1 hold what probe 0 / 1 of each run
+// found (0 set by this probe, 1 set before the sub-batch, 2 set by another probe of the sub-batch) and this kernel only assembles the
+// status words (k_set_bits' collision marks and count included) and claims the counters.
+template <int RUNS, bool SWEPT>
 __global__ void __launch_bounds__(256) k_probe_h2(FilterView fv, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ counts,
                                                    uint32_t n_distinct, int mode, uint32_t *__restrict__ status, uint64_t *__restrict__ cvals,
-                                                   uint64_t *__restrict__ foreign_idx, uint32_t *__restrict__ counters) {
+                                                   uint64_t *__restrict__ foreign_idx, uint32_t *__restrict__ counters,
+                                                   const uint8_t *__restrict__ st0 = nullptr, const uint8_t *__restrict__ st1 = nullptr,
+                                                   uint32_t mark_known = 0u /* every probe of the sub-batch went through the sweep */) {
     const uint32_t d0 = (blockIdx.x * blockDim.x + threadIdx.x) * RUNS;
     uint64_t h0[RUNS], bi[RUNS][2], ci[RUNS][2];
     uint32_t cnt[RUNS], w[RUNS][2];
@@ -133,13 +146,21 @@ __global__ void __launch_bounds__(256) k_probe_h2(FilterView fv, const uint64_t 
         h0[r] = live[r] ? uniq[d0 + r] : 0ull;
         cnt[r] = live[r] ? counts[d0 + r] : 0u;
     }
+    if (!SWEPT) {
 #pragma unroll
-    for (int r = 0; r < RUNS; ++r) {
-        const uint64_t h1 = multi_hash(h0[r], 1u, fv.kmul);
-        bi[r][0] = index_of(h0[r], fv.dbg_mod); bi[r][1] = index_of(h1, fv.dbg_mod);
-        ci[r][0] = index_of(h0[r], fv.cbf_mod); ci[r][1] = index_of(h1, fv.cbf_mod);
+        for (int r = 0; r < RUNS; ++r) {
+            const uint64_t h1 = multi_hash(h0[r], 1u, fv.kmul);
+            bi[r][0] = index_of(h0[r], fv.dbg_mod); bi[r][1] = index_of(h1, fv.dbg_mod);
+            ci[r][0] = index_of(h0[r], fv.cbf_mod); ci[r][1] = index_of(h1, fv.cbf_mod);
+        }
     }
-    if (mode != M_COUNT_ONLY) {
+    if (SWEPT) {
+#pragma unroll
+        for (int r = 0; r < RUNS; ++r) {
+            w[r][0] = live[r] ? (uint32_t)st0[d0 + r] : 1u;
+            w[r][1] = live[r] ? (uint32_t)st1[d0 + r] : 1u;
+        }
+    } else if (mode != M_COUNT_ONLY) {
 #pragma unroll
         for (int r = 0; r < RUNS; ++r) {                      // all bit loads in flight together
             w[r][0] = live[r] ? fv.dbg[bi[r][0] >> 5] : 0u;
@@ -148,18 +169,31 @@ __global__ void __launch_bounds__(256) k_probe_h2(FilterView fv, const uint64_t 
     }
     uint32_t st[RUNS];
     bool claim[RUNS], dup[RUNS];
+    uint32_t n_coll_total = 0, n_allpre = 0;
 #pragma unroll
     for (int r = 0; r < RUNS; ++r) {
-        uint32_t premask = 0, all = 1;
-        if (mode != M_COUNT_ONLY) {
+        uint32_t premask = 0, all = 1, coll = 0;
+        if (SWEPT) {
+            premask = (w[r][0] == 1u ? 1u : 0u) | (w[r][1] == 1u ? 2u : 0u);
+            all = premask == 3u;
+            coll = (w[r][0] == 2u ? 1u : 0u) | (w[r][1] == 2u ? 2u : 0u);
+            const uint32_t join = (w[r][0] == 3u ? 1u : 0u) | (w[r][1] == 3u ? 2u : 0u);
+            n_coll_total += (uint32_t)__popc(coll | (join << 2));
+            if (live[r]) coll |= (join << (ST_JOIN_SHIFT - ST_COLLIDE_SHIFT)) | (mark_known ? (ST_SWEPT_KNOWN >> ST_COLLIDE_SHIFT) : 0u);
+        } else if (mode != M_COUNT_ONLY) {
             if ((w[r][0] >> (uint32_t)(bi[r][0] & 31u)) & 1u) premask |= 1u; else all = 0;
             if ((w[r][1] >> (uint32_t)(bi[r][1] & 31u)) & 1u) premask |= 2u; else all = 0;
         }
-        st[r] = premask | (all ? ST_ALLPRE : 0u);
+        st[r] = premask | (all ? ST_ALLPRE : 0u) | (coll << ST_COLLIDE_SHIFT);
+        n_allpre += (live[r] && all) ? 1u : 0u;
         bool may_count = true;
         if (mode == M_COUNT_IF_PRESENT) may_count = all;
         if (mode == M_ADD && !all && cnt[r] == 1u) { may_count = false; st[r] |= ST_LATE; }
         claim[r] = live[r] && may_count;
+        if (SWEPT) {                                           // (most runs of the regime the sweep is for never claim: indices only where needed)
+            ci[r][0] = ci[r][1] = 0;
+            if (claim[r]) { ci[r][0] = index_of(h0[r], fv.cbf_mod); ci[r][1] = index_of(multi_hash(h0[r], 1u, fv.kmul), fv.cbf_mod); }
+        }
         dup[r] = ci[r][0] == ci[r][1];
     }
     uint32_t b0[RUNS], b1[RUNS];
@@ -185,7 +219,15 @@ __global__ void __launch_bounds__(256) k_probe_h2(FilterView fv, const uint64_t 
         }
         status[d] = st[r];
     }
-    if (n_foreign_total) atomicAdd(&counters[16 + 16 * (blockIdx.x & 31u)], n_foreign_total);
+    // one add per wavefront, not per lane: adds to one address go through at ~10 ns apiece whoever issues them (32 addresses: config 2's
+    // tens of millions of contested claims per step were seconds of lanes waiting in line)
+#pragma unroll
+    for (int o = 32; o; o >>= 1) { n_foreign_total += __shfl_xor(n_foreign_total, o, 64); n_coll_total += __shfl_xor(n_coll_total, o, 64); n_allpre += __shfl_xor(n_allpre, o, 64); }
+    if ((threadIdx.x & 63u) == 0u) {
+        if (n_allpre) atomicAdd(&counters[18 + 16 * (blockIdx.x & 31u)], n_allpre);     // (what the next sub-batch decides about the swept stage by)
+        if (n_foreign_total) atomicAdd(&counters[16 + 16 * (blockIdx.x & 31u)], n_foreign_total);
+        if (SWEPT && n_coll_total) atomicAdd(&counters[17 + 16 * (blockIdx.x & 31u)], n_coll_total);
+    }
 }
 // ---- first-setter arbitration without a table entry per new bit (the default) ----
 // Two new k-mers of one sub-batch rarely share a Bloom bit (touches^2 / 2 bits: ~0.2 M of 60 M on config 2), so
@@ -204,7 +246,6 @@ __device__ __forceinline__ bool ft_maybe(const FtFilter &ff, uint64_t idx) {
     const uint64_t b = slot_of(idx ^ 0x5851F42D4C957F2Dull, ff.log2);
     return (ff.bits[b >> 5] >> (uint32_t)(b & 31u)) & 1u;
 }
-constexpr uint32_t ST_COLLIDE_SHIFT = 21;   // status bits 21..28: probe j found its bit set by another probe of the sub-batch
 __global__ void k_set_bits(FilterView fv, const uint64_t *__restrict__ uniq, uint32_t n_distinct, uint32_t *__restrict__ status,
                            uint32_t *__restrict__ counters) {
     uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
@@ -230,7 +271,8 @@ __global__ void k_collide_insert(FilterView fv, const uint64_t *__restrict__ uni
                                  Slot *ftable, uint32_t f_log2, uint32_t *__restrict__ ffbits, uint32_t ff_log2) {
     uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= n_distinct) return;
-    const uint32_t coll = (status[d] >> ST_COLLIDE_SHIFT) & 0xFFu;
+    const uint32_t st_d = status[d];
+    const uint32_t coll = ((st_d >> ST_COLLIDE_SHIFT) & 0xFFu) | ((st_d >> ST_JOIN_SHIFT) & 3u);     // (swept stage: the probe that set the bit joins here, no k_collide_fixup)
     if (!coll) return;
     const uint64_t h0 = uniq[d];
     const unsigned long long v_first = vals[starts[d]];
@@ -282,12 +324,14 @@ __global__ void k_late_claim(FilterView fv, const uint64_t *__restrict__ uniq, c
     if (d >= n_distinct) return;
     uint32_t st = status[d];
     if (!(st & ST_LATE)) return;
+    for (int j = 0; j < fv.dbg_h; ++j)
+        if (!((st >> j) & 1u) && st_alone(st, j)) return;      // (swept stage: this probe had its bit to itself — nobody set it earlier)
     const uint64_t h0 = uniq[d];
     const unsigned long long v_first = vals[starts[d]];
     bool found = true;
     for (int j = 0; j < fv.dbg_h && found; ++j) {
         if ((st >> j) & 1u) continue;
-        if (!set_earlier(ftable, f_log2, index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.dbg_mod), (v_first << 4) | (unsigned long long)j, ff))
+        if (st_alone(st, j) || !set_earlier(ftable, f_log2, index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.dbg_mod), (v_first << 4) | (unsigned long long)j, ff))
             found = false;
     }
     if (!found) return;
@@ -486,6 +530,7 @@ __global__ void k_resolve_apply(FilterView fv, const uint64_t *__restrict__ uniq
             const unsigned long long v_first = vals[starts[d]];
             for (int j = 0; j < fv.dbg_h; ++j) {
                 if ((st >> j) & 1u) continue;
+                if (bits_set && st_alone(st, j)) { found_first = false; continue; }     // (swept stage: nobody else asked for this bit)
                 uint64_t idx = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.dbg_mod);
                 // old bit value seen by this probe = an earlier probe of the batch already set it
                 if (!set_earlier(ftable, f_log2, idx, (v_first << 4) | (unsigned long long)j, ff)) found_first = false;
@@ -1846,6 +1891,13 @@ void rb::launch_pairs(rb_graph *g, const rb_batch *b, int64_t w0, int64_t nw, in
 #undef RB_LAUNCH_PAIRS2
 }
 
+// is the swept Bloom-bit stage (rb_group.hip) a candidate for this graph at all?  RB_SWEEP: 0 never, 1 wherever it applies; otherwise for a whole
+// (unsharded) Bloom filter too large for the caches (the sub-batch decides in run_core)
+static bool sweep_wanted(const rb_graph *g) {
+    if (g->shard || !g->dbg.bits || g->dbg.lo != 0 || g->dbg.hi != g->dbg.size) return false;
+    if (const char *e = getenv("RB_SWEEP")) return atoi(e) != 0;
+    return g->dbg.nbytes >= ((int64_t)1 << 31);
+}
 // Stable grouping of N (h0, occ) records sitting in keys0/vals0 into slot `slot`: sort on the top hash
 // bits, draw strengths, run-length encode.  Asynchronous on `st`; group_finish reads the run count.
 void rb::group_enqueue(rb_graph *g, int slot, size_t N, uint64_t ordinal0, uint32_t pos_bits, hipStream_t st, DevBuf &temp,
@@ -1878,18 +1930,34 @@ void rb::group_enqueue(rb_graph *g, int slot, size_t N, uint64_t ordinal0, uint3
         if (g->cbf && g->cbf_size > 0) gidx = GrIdx{g->cbf_mod, (uint64_t)g->cbf_lo, (uint64_t)(g->cbf_hi - g->cbf_lo)};
         else if (g->dbg.bits && g->dbg.size > 0) gidx = GrIdx{g->dbg.mod, (uint64_t)g->dbg.lo, (uint64_t)(g->dbg.hi - g->dbg.lo)};
     }
+    // the swept Bloom-bit stage (run_core) works on the grouping's own index ranges: they have to be ranges of the Bloom filter's indices
+    // (the two filters have equal entries in the configurations this library is sized by; otherwise the grouping goes by the Bloom filter's
+    // where the sweep is wanted), and the bucket kernel leaves each range's run slots behind
+    GroupExport ex;
+    S.sweep_T = 0; S.n_main = 0;
+    if (want_idx && sweep_wanted(g)) {
+        const GrIdx didx{g->dbg.mod, 0, (uint64_t)g->dbg.size};
+        const bool same = gidx.span == didx.span && gidx.lo == 0 && gidx.mod.d == didx.mod.d;
+        if (!same) gidx = didx;
+        S.sweep_T = group_index_buckets(N, group_bits, bucket_target, flags, gidx);
+        if (S.sweep_T) {
+            S.brun.reserve(((size_t)4 << S.sweep_T) + 16); S.bnr.reserve(((size_t)4 << S.sweep_T) + 16);
+            ex = GroupExport{S.brun.as<uint32_t>(), S.bnr.as<uint32_t>(), ctr + 9};
+        }
+    }
     uint64_t *kin = g->group_in_keys ? g->group_in_keys : g->keys0.as<uint64_t>();
     uint32_t *vin = g->group_in_vals ? g->group_in_vals : g->vals0.as<uint32_t>();
     g->group_in_keys = nullptr; g->group_in_vals = nullptr;
     group_records_device(kin, vin, S.keys1.as<uint64_t>(), S.valsT.as<uint32_t>(), N, group_bits,
                          g->p.rng_seed, ordinal0, pos_bits, temp.p, temp.cap, S.vals1.as<uint32_t>(), S.tz.as<uint8_t>(), S.uniq.as<uint64_t>(),
-                         S.counts.as<uint32_t>(), S.starts.as<uint32_t>(), ctr + 8, st, g, bucket_target, flags, gidx);
+                         S.counts.as<uint32_t>(), S.starts.as<uint32_t>(), ctr + 8, st, g, bucket_target, flags, gidx, ex);
 }
 uint32_t rb::group_finish(rb_graph *g, int slot, hipStream_t st, DevBuf &temp, DevBuf &ctrbuf, hipStream_t scan_stream) {
     rb_graph::GroupSlot &S = g->slots[slot];
     if (S.N == 0) { RB_HIP(hipStreamSynchronize(st)); return 0; }
     uint32_t D = 0;
     RB_HIP(hipMemcpyAsync(&D, ctrbuf.as<uint32_t>() + 8, 4, hipMemcpyDeviceToHost, st));
+    if (S.sweep_T) RB_HIP(hipMemcpyAsync(&S.n_main, ctrbuf.as<uint32_t>() + 9, 4, hipMemcpyDeviceToHost, st));
     if (S.flags & GR_FLAG_DEAD)
         RB_HIP(hipMemcpyAsync(&S.live, group_live_count(temp.p, S.N, 64 - g->sort_begin_bit, S.bucket_target, S.flags), 4, hipMemcpyDeviceToHost, st));
     RB_HIP(hipStreamSynchronize(st));
@@ -2043,16 +2111,40 @@ void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, ui
         g->prof_end("table_clear");
     }
     g->prof_begin();
-    if (!ftab && fv.dbg_h == 2 && fv.cbf_h == 2 && !getenv("RB_PROBE_GENERIC")) {
+    // Swept Bloom-bit stage (rb_group.hip): worth the two passes over the filter it costs when the sub-batch has a run per <= 64 bytes of
+    // filter — the all-new-k-mers regime of long reads, where the random second probes are three quarters of the insert.  RB_SWEEP=1 forces
+    // it wherever it applies, 0 turns it off.
+    const rb_graph::GroupSlot &GS = g->slots[g->cur];
+    bool swept = false, swept_all = false;       // swept_all: no run of an oversized bucket among them (those probe outside the sweep)
+    if (collide && !ftab && fv.dbg_h == 2 && fv.cbf_h == 2 && !getenv("RB_PROBE_GENERIC") && GS.sweep_T && !g->shard && sweep_wanted(g)) {
+        const char *e = getenv("RB_SWEEP");
+        // (and most runs new: where the sub-batch before found most of its k-mers present the sweep only rewrites set bits — the plain loads are cheaper)
+        swept = (e && atoi(e) == 1) || ((uint64_t)D * 64ull >= (uint64_t)g->dbg.nbytes && g->last_present_frac < 0.5f);
+    }
+    if (swept) {
+        const GrIdx didx{g->dbg.mod, 0, (uint64_t)g->dbg.size};
+        swept_all = GS.n_main >= D;
+        const size_t st_pad = ((size_t)D + 15) & ~(size_t)15;
+        g->sw_st.reserve(st_pad + D + 16);
+        g->sw_temp.reserve(sweep_temp_bytes(D, GS.sweep_T));
+        uint8_t *st0 = g->sw_st.as<uint8_t>(), *st1 = st0 + st_pad;
+        // scratch for the (h1, run) records: arrays nobody reads before this stage is over (contested indices are written by the probe kernel below, op counts / lists in stage B)
+        uint64_t *ka = g->foreign.as<uint64_t>(), *kb = ka + D;
+        sweep_bits_device(g->dbg.bits, didx, GS.sweep_T, fv.kmul, uniq, D, GS.n_main, GS.brun.as<uint32_t>(), GS.bnr.as<uint32_t>(), ka, g->nops.as<uint32_t>(), kb,
+                          g->heavy.as<uint32_t>(), g->sw_temp.p, g->sw_temp.cap, st0, st1, s);
         constexpr int RUNS = 2;
-        hipLaunchKernelGGL(k_probe_h2<RUNS>, dim3(blocks_for(((int64_t)D + RUNS - 1) / RUNS)), dim3(TPB), 0, s, fv, uniq, counts, D, mode, status,
+        hipLaunchKernelGGL((k_probe_h2<RUNS, true>), dim3(blocks_for(((int64_t)D + RUNS - 1) / RUNS)), dim3(TPB), 0, s, fv, uniq, counts, D, mode, status,
+                           g->cvals.as<uint64_t>(), g->foreign.as<uint64_t>(), ctr, (const uint8_t *)st0, (const uint8_t *)st1, swept_all ? 1u : 0u);
+    } else if (!ftab && fv.dbg_h == 2 && fv.cbf_h == 2 && !getenv("RB_PROBE_GENERIC")) {
+        constexpr int RUNS = 2;
+        hipLaunchKernelGGL((k_probe_h2<RUNS, false>), dim3(blocks_for(((int64_t)D + RUNS - 1) / RUNS)), dim3(TPB), 0, s, fv, uniq, counts, D, mode, status,
                            g->cvals.as<uint64_t>(), g->foreign.as<uint64_t>(), ctr);
     } else
         hipLaunchKernelGGL(k_probe, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, uniq, counts, starts, vals, D, mode,
                            ftab, f_log2, status, g->cvals.as<uint64_t>(), g->foreign.as<uint64_t>(), ctr);
     if (collide) {
         // set the new bits now; the probes that meet another probe of the sub-batch on a bit are counted
-        hipLaunchKernelGGL(k_set_bits, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, uniq, D, status, ctr);
+        if (!swept) hipLaunchKernelGGL(k_set_bits, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, uniq, D, status, ctr);
         uint32_t spread[16 * 32], n_collide = 0;
         RB_HIP(hipMemcpyAsync(spread, ctr + 16, sizeof spread, hipMemcpyDeviceToHost, s));
         RB_HIP(hipStreamSynchronize(s));
@@ -2073,7 +2165,7 @@ void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, ui
             }
             hipLaunchKernelGGL(k_collide_insert, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, uniq, starts, vals, D, status, ftab, f_log2,
                                const_cast<uint32_t *>(ffl.bits), ffl.log2);
-            hipLaunchKernelGGL(k_collide_fixup, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, uniq, starts, vals, D, status, ftab, f_log2, ffl);
+            if (!swept_all) hipLaunchKernelGGL(k_collide_fixup, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, uniq, starts, vals, D, status, ftab, f_log2, ffl);
         }
     }
     if (mode == M_ADD)
@@ -2084,8 +2176,11 @@ void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, ui
         uint32_t spread[16 * 32];
         RB_HIP(hipMemcpyAsync(spread, ctr + 16, sizeof spread, hipMemcpyDeviceToHost, s));
         RB_HIP(hipStreamSynchronize(s));
-        for (int q = 0; q < 32; ++q) n_foreign += spread[16 * q];
+        uint32_t n_present = 0;
+        for (int q = 0; q < 32; ++q) { n_foreign += spread[16 * q]; n_present += spread[16 * q + 2]; }
+        g->last_present_frac = (float)n_present / (float)D;      // (0 on the generic probe kernel's path, which does not count them)
     }
+    if (getenv("RB_DEBUG") && swept) fprintf(stderr, "[rb] swept stage: %u runs (%u of oversized buckets), %u contested counters\n", D, D - std::min(D, GS.n_main), n_foreign);
     g->prof_end("probe_claim");
     if (n_foreign) {   // the set of counters claimed by more than one run
         g->prof_begin();
@@ -2402,7 +2497,12 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
             g->chunk_cnt.reserve(((size_t)sb.nw + 1) * 4); g->chunk_off.reserve(((size_t)sb.nw + 1) * 4);
             g->temp2.reserve(scan_temp_bytes((size_t)sb.nw + 1));
             RB_HIP(hipMemsetAsync(g->chunk_cnt.as<uint32_t>() + sb.nw, 0, 4, sp));
-            if (use_npf && (g->k > 31 || !getenv("RB_ONE_PASS_FILTER"))) {
+            // Where the cache has stopped dropping anything (two sub-batches in a row kept >= 97 % of their windows: long reads, nearly every
+            // k-mer new) the window walk against it is a hashing pass for nothing: the next 15 sub-batches count their usable windows instead
+            // and emit them all, then one is measured again.  RB_PF_SKIP=0: never; 2: sub-batches of any size count (tests).
+            bool filt_now = use_npf;
+            if (use_npf && g->pf_skip_left > 0 && !(getenv("RB_PF_SKIP") && atoi(getenv("RB_PF_SKIP")) == 0)) { filt_now = false; --g->pf_skip_left; }
+            if (filt_now && (g->k > 31 || !getenv("RB_ONE_PASS_FILTER"))) {
                 // pass 1 hashes every window and asks the cache (count + keep mask per word), scan, pass 2
                 // re-hashes and emits the survivors.  (The one-pass kernel below measures 12 ms faster on its
                 // own but 35 ms slower per step here: its 25 KB of LDS staging costs the occupancy that hides
@@ -2431,6 +2531,9 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
                     return false;
                 }
                 for (int q = 0; q < 32; ++q) sb.total += spread[16 * q];
+                const bool pf_force = getenv("RB_PF_SKIP") && atoi(getenv("RB_PF_SKIP")) == 2;       // (tests: sub-batches of any size count)
+                if (sb.total >= (pf_force ? 1 : ((int64_t)1 << 26)) && (double)sb.N >= 0.97 * (double)sb.total) { if (++g->pf_streak >= 2) { g->pf_skip_left = 15; g->pf_streak = 1; } }
+                else g->pf_streak = 0;               // (a small sub-batch says nothing: a cold cache drops nothing either)
                 if (getenv("RB_WORD_STATS")) {   // development: how many words keep nothing?
                     std::vector<uint32_t> hc((size_t)sb.nw);
                     RB_HIP(hipMemcpy(hc.data(), g->chunk_cnt.p, (size_t)sb.nw * 4, hipMemcpyDeviceToHost));
@@ -2454,7 +2557,7 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
                     RB_HIP(hipStreamWaitEvent(sp, g->ev3, 0)); pairs_pending = false;
                     g->before_buckets = [&pairs_half, i]() { pairs_half(i, 1); };
                 }
-            } else if (use_npf) {
+            } else if (filt_now) {
                 // one pass: hash every window, ask the hot-k-mer cache whether the occurrence can matter,
                 // write the survivors densely in read order (k_filter_emit)
                 g->prof_begin(sp);
@@ -2480,6 +2583,14 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
                 RB_HIP(hipMemcpyAsync(&sb.N, g->chunk_off.as<uint32_t>() + sb.nw, 4, hipMemcpyDeviceToHost, sp));
                 g->prof_end("count_windows", sp);
                 RB_HIP(hipStreamSynchronize(sp));
+                if (use_npf && (int64_t)sb.N > g->max_batch_kmers && sb.r1 - sb.r0 > 1) {   // (planned for a prefilter that drops most windows: halve and redo)
+                    const int64_t mid = sb.r0 + (sb.r1 - sb.r0) / 2;
+                    Sub second{mid, sb.r1, (int64_t)wo[(size_t)mid], (int64_t)wo[(size_t)sb.r1] - (int64_t)wo[(size_t)mid], 0u, 0};
+                    sb.r1 = mid; sb.nw = (int64_t)wo[(size_t)mid] - sb.w0;
+                    subs.insert(subs.begin() + (std::ptrdiff_t)i + 1, second);   // invalidates sb
+                    ++g->pf_skip_left;                                            // (the redo is not a sub-batch of its own)
+                    return false;
+                }
                 sb.total = sb.N;
                 if (sb.N) {
                     g->prof_begin(sp);
@@ -2623,7 +2734,8 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
         const uint32_t D = group_finish(g, slot, sp, g->temp2, g->devctr2, s);  // drains the producer stream
         if (stats) { stats->pairs += (int64_t)np; stats->distinct += D; }
         const bool serial = getenv("RB_SERIAL") != nullptr;   // debugging / clean per-stage timing
-        const bool early = getenv("RB_PREPARE_EARLY") != nullptr;   // A/B: producer a whole sub-batch ahead (staler cache)
+        const bool early = getenv("RB_PREPARE_EARLY") != nullptr;   // A/B: producer a whole sub-batch ahead (staler cache).  (Also tried from inside run_core, beside
+        // the swept stage of long reads where the cache has nothing to say anyway: 0.564 s against 0.562 — two memory-bound streams share one memory.)
         if (!serial && early && i + 1 < subs.size()) prepare(i + 1);
         if (pairs_mode == 2 && !serial && !early) pairs_fork(i + 1, false);
         g->cur = slot;
@@ -2819,7 +2931,7 @@ int rb_graph_clear(rb_graph *g, unsigned which_mask) {
         if ((which_mask & 3u) && g->npf_log2) fast_zero(g->npf.p, sizeof(uint64_t) << g->npf_log2, g->stream);   // cache entries speak about dbgbf + cbf
         if ((which_mask & 3u) && g->mpf_log2b) fast_zero(g->mpf.p, (size_t)128 << g->mpf_log2b, g->stream);
         if ((which_mask & 3u) && g->rst_log2) fast_zero(g->rst.p, sizeof(uint64_t) << g->rst_log2, g->stream);
-        if ((which_mask & 3u) == 3u) g->ordinal = 0;
+        if ((which_mask & 3u) == 3u) { g->ordinal = 0; g->pf_streak = 0; g->pf_skip_left = 0; g->last_present_frac = 0.0f; }
         RB_HIP(hipStreamSynchronize(g->stream));
     });
 }

@@ -396,7 +396,8 @@ __global__ void __launch_bounds__(TPB, (TPB == 512 ? 4 : 2)) k_group_buckets(con
                                                        uint32_t *__restrict__ big_list, uint32_t *__restrict__ n_big,
                                                        uint32_t *__restrict__ vals_out, uint8_t *__restrict__ tz_out,
                                                        uint64_t *__restrict__ uniq, uint32_t *__restrict__ counts, uint32_t *__restrict__ starts,
-                                                       uint32_t *__restrict__ n_runs_out, uint32_t by_class) {
+                                                       uint32_t *__restrict__ n_runs_out, uint32_t by_class,
+                                                       uint32_t *__restrict__ brun /* null, or per bucket: first run slot, */, uint32_t *__restrict__ bnr /* number of runs */) {
     constexpr uint32_t ITEMS = GR_TILE / TPB, NW = TPB / 64, SEG = 64 * ITEMS, NB = 1u << GR_LOCAL_BITS;
     static_assert(ITEMS * NW == 64, "the segment scan below is one wavefront wide");
     __shared__ uint64_t s_keys[GR_TILE];
@@ -617,7 +618,8 @@ __global__ void __launch_bounds__(TPB, (TPB == 512 ? 4 : 2)) k_group_buckets(con
     }
     __syncthreads();
     const uint32_t run_base = s_misc[0];
-    if (by_class && nruns > 64u) {
+    if (brun && threadIdx.x == 0) { brun[c] = run_base; bnr[c] = nruns; }     // (an oversized bucket: no runs here, k_group_big appends them)
+    if (by_class && nruns > 64u && nruns != cn) {          // (nruns == cn: every run is one occurrence long — the all-new-k-mers regime)
         // Stage B walks a run's occurrences in a per-lane loop, so a wavefront takes as long as its longest run: the bucket's runs go out
         // ordered by length class (1, 2, 3-4, 5-8, ... 65+; long ones first), which makes the 64 runs of a wavefront alike.  Nothing
         // downstream depends on the order of the runs (ties anywhere are broken by occurrence ids).
@@ -822,7 +824,7 @@ struct GroupPlan {
 };
 static size_t gr_align(size_t x) { return (x + 255) / 256 * 256; }
 
-static GroupPlan group_plan(size_t N, int group_bits, int bucket_target = 0, int flags = 0) {
+static GroupPlan group_plan(size_t N, int group_bits, int bucket_target = 0, int flags = 0, int force_T = -1) {
     GroupPlan P;
     P.n = (uint32_t)N;
     P.dead = (flags & GR_FLAG_DEAD) != 0;
@@ -838,6 +840,7 @@ static GroupPlan group_plan(size_t N, int group_bits, int bucket_target = 0, int
                         : bucket_target > 0 ? (size_t)bucket_target : (size_t)GR_BUCKET_TARGET;
     while ((target << T) < N) ++T;
     if (const char *e = getenv("RB_GROUP_T")) T = (uint32_t)std::max(0, atoi(e));
+    if (force_T >= 0) T = (uint32_t)force_T;   // (binning by index range into the fine buckets of another grouping: rb_sweep below)
     T = std::min({T, gb, 2u * GR_PART_MAX_BITS});
     if (P.dead && T == 0) T = 1;             // cancelled records leave in a partition pass: there has to be one
     P.T = T;
@@ -1024,13 +1027,16 @@ void sort_pairs_u64_u64(void *temp, size_t temp_bytes, uint64_t *keys_in, uint64
     hipLaunchKernelGGL(k_lsd_gather64, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, i1, vals_in, vals_out, n);
 }
 
-// Groups the N records (keys0, vals0) — both arrays are clobbered; (keys_tmp, vals_tmp) is scratch of the same size.
-// Outputs: vals_out[N] occurrences in grouped order, tz_out[N] their strengths, runs (uniq, counts, starts) and
-// *n_runs_dev.  Everything is enqueued on `st`; nothing is synchronised.
+// The MSD partition of the records into the plan's 2^T fine buckets (one or two stable passes); on return (*kin, *vin) is where the
+// partitioned records sit — keys0 / vals0 or the scratch pair — and bstart[2^T + 1] (inside tp) holds the bucket bounds.
+static GrIdxDev gr_idx_dev(const GroupPlan &P, const GrIdx &idx) {
+    if (idx.span > (1ull << P.T))              // (mul must fit 64 bits: more indices than fine buckets — anything but a toy filter)
+        return GrIdxDev{idx.mod, idx.lo, (uint64_t)((((unsigned __int128)1 << 64) << P.T) / idx.span), (1u << P.T) - 1u, P.t_lo};
+    return GrIdxDev{Mod{1, 0, 0}, 0, 0, 0, 0};
+}
 template <int TPB>
-static void group_records_impl(const GroupPlan &P, uint64_t *keys0, uint32_t *vals0, uint64_t *keys_tmp, uint32_t *vals_tmp, GroupRng rng, char *tp,
-                               uint32_t *vals_out, uint8_t *tz_out, uint64_t *uniq, uint32_t *counts, uint32_t *starts, uint32_t *n_runs_dev,
-                               hipStream_t st, rb_graph *prof, GrIdx idx) {
+static uint32_t *partition_records(const GroupPlan &P, uint64_t *keys0, uint32_t *vals0, uint64_t *keys_tmp, uint32_t *vals_tmp, char *tp, hipStream_t st,
+                                   rb_graph *prof, GrIdx idx, const uint64_t **kin_out, const uint32_t **vin_out) {
     unsigned long long *status = reinterpret_cast<unsigned long long *>(tp + P.off_status);
     uint32_t *ticket = reinterpret_cast<uint32_t *>(tp + P.off_ticket);
     uint32_t *bstart = reinterpret_cast<uint32_t *>(tp + P.off_bstart);
@@ -1042,9 +1048,7 @@ static void group_records_impl(const GroupPlan &P, uint64_t *keys0, uint32_t *va
         void *scan_tmp = tp + P.off_scan;
         GrTiling t1{nullptr, nullptr, P.n, P.ntiles, gr_grid_for_tiles(P.ntiles), P.xcd_map};
         uint32_t *n_live = P.dead ? ticket + 3 : nullptr;      // (the status / ticket block was zeroed above)
-        GrIdxDev ix{Mod{1, 0, 0}, 0, 0, 0, 0};
-        if (idx.span > (1ull << P.T))              // (mul must fit 64 bits: more indices than fine buckets — anything but a toy filter)
-            ix = GrIdxDev{idx.mod, idx.lo, (uint64_t)((((unsigned __int128)1 << 64) << P.T) / idx.span), (1u << P.T) - 1u, P.t_lo};
+        GrIdxDev ix = gr_idx_dev(P, idx);
         part_pass<TPB>(t1, (size_t)P.ntiles << P.t_hi, P.shift_hi, P.t_hi, kin, vin, keys_tmp, vals_tmp, hist, goffs, scan_tmp, P.scan_bytes, st, prof, n_live, ix);
         kin = keys_tmp; vin = vals_tmp;
         uint32_t *segtb = nullptr, *segst = nullptr;
@@ -1062,6 +1066,22 @@ static void group_records_impl(const GroupPlan &P, uint64_t *keys0, uint32_t *va
         hipLaunchKernelGGL(k_bucket_bounds, dim3((P.nbuckets + 256u) / 256u), dim3(256), 0, st, goffs, P.ntiles, segtb, segst, P.t_hi, P.t_lo, P.n, bstart, (const uint32_t *)n_live);
     } else
         hipLaunchKernelGGL(k_bucket_bounds, dim3(1), dim3(64), 0, st, (const uint32_t *)nullptr, 0u, (const uint32_t *)nullptr, (const uint32_t *)nullptr, 0u, 0u, P.n, bstart);
+    *kin_out = kin; *vin_out = vin;
+    return bstart;
+}
+
+// Groups the N records (keys0, vals0) — both arrays are clobbered; (keys_tmp, vals_tmp) is scratch of the same size.
+// Outputs: vals_out[N] occurrences in grouped order, tz_out[N] their strengths, runs (uniq, counts, starts) and
+// *n_runs_dev.  Everything is enqueued on `st`; nothing is synchronised.
+template <int TPB>
+static void group_records_impl(const GroupPlan &P, uint64_t *keys0, uint32_t *vals0, uint64_t *keys_tmp, uint32_t *vals_tmp, GroupRng rng, char *tp,
+                               uint32_t *vals_out, uint8_t *tz_out, uint64_t *uniq, uint32_t *counts, uint32_t *starts, uint32_t *n_runs_dev,
+                               hipStream_t st, rb_graph *prof, GrIdx idx, GroupExport ex) {
+    unsigned long long *status = reinterpret_cast<unsigned long long *>(tp + P.off_status);
+    uint32_t *ticket = reinterpret_cast<uint32_t *>(tp + P.off_ticket);
+    const uint64_t *kin = nullptr;
+    const uint32_t *vin = nullptr;
+    uint32_t *bstart = partition_records<TPB>(P, keys0, vals0, keys_tmp, vals_tmp, tp, st, prof, idx, &kin, &vin);
     uint32_t *big_list = reinterpret_cast<uint32_t *>(tp + P.off_big), *n_big = ticket + 2;
     if (prof && prof->before_buckets) { auto f = std::move(prof->before_buckets); prof->before_buckets = nullptr; f(); }
     if (prof) prof->prof_begin(st);
@@ -1076,10 +1096,11 @@ static void group_records_impl(const GroupPlan &P, uint64_t *keys0, uint32_t *va
     const uint32_t by_class = getenv("RB_GROUP_CLASSES") ? (uint32_t)(atoi(getenv("RB_GROUP_CLASSES")) != 0) : 1u;    // a bucket's runs ordered by length class (stage B's wavefronts alike)
     if (ordered || !prefetch)
         hipLaunchKernelGGL((k_group_buckets<TPB, false>), dim3(bucket_grid), dim3(TPB), 0, st, kin, vin, bstart, P.nbuckets, P.lshift_lo, P.l_lo, P.lshift_hi, P.l_hi,
-                           rng, P.fix_cap, ticket, ordered ? status : nullptr, big_list, n_big, vals_out, tz_out, uniq, counts, starts, n_runs_dev, 0u);
+                           rng, P.fix_cap, ticket, ordered ? status : nullptr, big_list, n_big, vals_out, tz_out, uniq, counts, starts, n_runs_dev, 0u, ex.brun, ex.bnr);
     else
         hipLaunchKernelGGL((k_group_buckets<TPB, true>), dim3(bucket_grid), dim3(TPB), 0, st, kin, vin, bstart, P.nbuckets, P.lshift_lo, P.l_lo, P.lshift_hi, P.l_hi,
-                           rng, P.fix_cap, ticket, nullptr, big_list, n_big, vals_out, tz_out, uniq, counts, starts, n_runs_dev, by_class);
+                           rng, P.fix_cap, ticket, nullptr, big_list, n_big, vals_out, tz_out, uniq, counts, starts, n_runs_dev, by_class, ex.brun, ex.bnr);
+    if (ex.n_main) hipLaunchKernelGGL(k_copy_u32, dim3(1), dim3(64), 0, st, ex.n_main, n_runs_dev);       // the runs from here on are the oversized buckets'
     if (prof) { prof->prof_end("group_buckets", st); prof->prof_begin(st); }
     // the buckets that do not fit LDS (none in a warm steady state): sorted through the record buffer that is free now
     uint64_t *ka = const_cast<uint64_t *>(kin), *kb = kin == keys0 ? keys_tmp : keys0;
@@ -1093,13 +1114,183 @@ static void group_records_impl(const GroupPlan &P, uint64_t *keys0, uint32_t *va
 void group_records_device(uint64_t *keys0, uint32_t *vals0, uint64_t *keys_tmp, uint32_t *vals_tmp, size_t N, int group_bits,
                           uint64_t seed, uint64_t ordinal0, uint32_t pos_bits, void *temp, size_t temp_bytes,
                           uint32_t *vals_out, uint8_t *tz_out, uint64_t *uniq, uint32_t *counts, uint32_t *starts, uint32_t *n_runs_dev,
-                          hipStream_t st, rb_graph *prof, int bucket_target, int flags, GrIdx idx) {
+                          hipStream_t st, rb_graph *prof, int bucket_target, int flags, GrIdx idx, GroupExport ex) {
     RB_REQUIRE(N > 0 && N < (1ull << 32) - 2 * GR_TILE, "group_records_device: bad record count");
     const GroupPlan P = group_plan(N, group_bits, bucket_target, flags);
     RB_REQUIRE(temp_bytes >= P.total, "group_records_device: temp too small");
     const GroupRng rng{seed, ordinal0, pos_bits};
-    if (P.tpb == 512u) group_records_impl<512>(P, keys0, vals0, keys_tmp, vals_tmp, rng, static_cast<char *>(temp), vals_out, tz_out, uniq, counts, starts, n_runs_dev, st, prof, idx);
-    else group_records_impl<256>(P, keys0, vals0, keys_tmp, vals_tmp, rng, static_cast<char *>(temp), vals_out, tz_out, uniq, counts, starts, n_runs_dev, st, prof, idx);
+    if (P.tpb == 512u) group_records_impl<512>(P, keys0, vals0, keys_tmp, vals_tmp, rng, static_cast<char *>(temp), vals_out, tz_out, uniq, counts, starts, n_runs_dev, st, prof, idx, ex);
+    else group_records_impl<256>(P, keys0, vals0, keys_tmp, vals_tmp, rng, static_cast<char *>(temp), vals_out, tz_out, uniq, counts, starts, n_runs_dev, st, prof, idx, ex);
+}
+uint32_t group_index_buckets(size_t N, int group_bits, int bucket_target, int flags, GrIdx idx) {
+    const GroupPlan P = group_plan(N, group_bits, bucket_target, flags);
+    return (P.T && idx.span > (1ull << P.T)) ? P.T : 0u;
+}
+
+// ---- swept Bloom-bit stage -------------------------------------------------------------------------------------------------
+// Stage A tests and sets two Bloom bits per run.  With the grouping keyed by the first index, probe 0 of the runs of fine bucket c falls
+// into c's index range, but probe 1 goes anywhere: a random word load and a returning device-scope atomicOr per run, which execute at the
+// memory side at 18-27 G/s however the words are laid out — 0.13 ms per million runs, three quarters of an insert where most k-mers are
+// new (long reads: profiles/r04_group_idx.txt).  Here the second probes are BINNED by the same 2^T index ranges (the grouping's own
+// stable partition passes over (h1, run) records), and one workgroup per range takes the range's words into LDS, applies the probes 0 of
+// its runs and the probes 1 binned to it with LDS atomics, and writes the words back: the filter is read and written once per sub-batch,
+// sequentially, and no probe leaves the CU.  What a probe reports is what k_probe_h2 + k_set_bits report: 1 = the bit was set before the
+// sub-batch, 2 = it was clear and another probe of the sub-batch set it first (resolved by the collision table as before), 0 = this probe
+// set it.  A probe that finds its bit set in LDS looks at the word in HBM — still the state before the sub-batch, the range is written
+// back after its probes — to tell 1 from 2.  Neighbouring ranges may share a word: words that are not wholly inside the range are
+// written back with atomicOr (bits are only ever set), the others with plain 16-byte stores.
+constexpr uint32_t SW_WORDS = 16384;          // 64 KB of filter per round (+ 4 KB of collision marks): two workgroups per CU (160 KB of LDS)
+constexpr uint32_t SW_MARKS = 1024;           // words of collision marks, addressed by the low bits of the bit index
+__device__ __forceinline__ uint32_t sw_digit(uint64_t x, const GrIdxDev &ix) {
+    return min((uint32_t)min(__umul64hi(x, ix.mul), (uint64_t)0xFFFFFFFFull), ix.top);
+}
+// first index (relative to ix.lo) of fine bucket c
+__device__ __forceinline__ uint64_t sw_first(uint32_t c, const GrIdxDev &ix, uint64_t span, uint32_t T) {
+    if (c == 0u) return 0ull;
+    if (c > ix.top) return span;
+    uint64_t e = ((uint64_t)c * span) >> T;
+    while (e > 0ull && sw_digit(e - 1ull, ix) >= c) --e;
+    while (e < span && sw_digit(e, ix) < c) ++e;
+    return e;
+}
+__global__ void k_sw_emit(const uint64_t *__restrict__ uniq, uint32_t D, uint64_t kmul, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
+    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= D) return;
+    keys[d] = multi_hash(uniq[d], 1u, kmul);
+    vals[d] = d;
+}
+// what a probe reports (st0 / st1): 0 it set the bit and nobody else asked for it; 1 set before the sub-batch; 2 clear before, set by another
+// probe of the sub-batch that got there first; 3 it set the bit and another probe MAY have met it there (marks are per low bits of the index:
+// a probe of another bit that shares them is told so too, and finds no entry in the collision table) — the probes with 2 or 3 are the ones
+// the first-setter arbitration has to look at, everybody else is done
+template <int TPB>
+__global__ void __launch_bounds__(TPB) k_sweep_bits(uint32_t *words, GrIdxDev ix, uint64_t span, uint32_t T, const uint64_t *__restrict__ uniq,
+                                                    const uint32_t *__restrict__ brun, const uint32_t *__restrict__ bnr,
+                                                    const uint64_t *__restrict__ k1, const uint32_t *__restrict__ v1, const uint32_t *__restrict__ bstart1,
+                                                    uint8_t *st0, uint8_t *st1, uint32_t SWW /* words of filter per round: dynamic LDS = (SWW + SW_MARKS) words */) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t sw_lds[];
+    uint32_t *s_w = sw_lds, *s_c = sw_lds + SWW;
+    __shared__ uint32_t s_any;
+    const uint32_t c = blockIdx.x;
+    const uint32_t r0 = brun[c], nr = bnr[c], p0 = bstart1[c], p1 = bstart1[c + 1u];
+    if (nr == 0u && p0 == p1) return;
+    const uint64_t x_lo = sw_first(c, ix, span, T), x_hi = sw_first(c + 1u, ix, span, T);
+    const uint64_t w_lo = (x_lo >> 5) & ~3ull, w_hi = (x_hi + 31ull) >> 5;          // words [w_lo, w_hi), from a 16-byte boundary
+    const uint64_t in_lo = (x_lo + 31ull) >> 5, in_hi = x_hi >> 5;                  // words [in_lo, in_hi) hold bits of this range only
+    for (uint64_t wb = w_lo; wb < w_hi; wb += SWW) {
+        const uint32_t cnt = (uint32_t)min((uint64_t)SWW, w_hi - wb);
+        for (uint32_t i = threadIdx.x * 4u; i < cnt; i += TPB * 4u) {
+            if (i + 4u <= cnt) *reinterpret_cast<uint4 *>(s_w + i) = *reinterpret_cast<const uint4 *>(words + wb + i);
+            else for (uint32_t q = i; q < cnt; ++q) s_w[q] = words[wb + q];
+        }
+        for (uint32_t i = threadIdx.x; i < SW_MARKS; i += TPB) s_c[i] = 0u;
+        if (threadIdx.x == 0) s_any = 0u;
+        __syncthreads();
+        // one probe: test-and-set in LDS; a bit found set is looked up in HBM (still the state before the sub-batch).  Returns the report and,
+        // for a probe that set its bit, where (the bit's offset in this round's words) — it may hear of a collision after the barrier.
+        auto probe = [&](uint64_t ib, uint32_t &mine) -> int {
+            mine = ~0u;
+            const uint64_t w = (ib >> 5) - wb;
+            if (w >= (uint64_t)cnt) return -1;                 // another round's
+            const uint32_t m = 1u << (uint32_t)(ib & 31ull);
+            if (!(atomicOr(&s_w[w], m) & m)) { mine = ((uint32_t)w << 5) | (uint32_t)(ib & 31ull); return 0; }
+            if (__hip_atomic_load(&words[ib >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & m) return 1;
+            atomicOr(&s_c[(uint32_t)w & (SW_MARKS - 1u)], m); s_any = 1u;
+            return 2;
+        };
+        constexpr uint32_t KEEP = GR_TILE / TPB;               // a bucket has at most GR_TILE runs: every probe 0 is remembered, and the first KEEP x TPB probes 1
+        uint32_t mine0[KEEP], mine1[KEEP];
+#pragma unroll
+        for (uint32_t it = 0; it < KEEP; ++it) {
+            const uint32_t r = it * TPB + threadIdx.x;
+            mine0[it] = ~0u;
+            if (r < nr) {
+                const int s = probe(index_of(uniq[r0 + r], ix.mod) - ix.lo, mine0[it]);
+                if (s >= 0) st0[r0 + r] = (uint8_t)s;
+            }
+        }
+#pragma unroll
+        for (uint32_t it = 0; it < KEEP; ++it) {
+            const uint32_t j = p0 + it * TPB + threadIdx.x;
+            mine1[it] = ~0u;
+            if (j < p1) {
+                const int s = probe(index_of(k1[j], ix.mod) - ix.lo, mine1[it]);
+                if (s > 0) st1[v1[j]] = (uint8_t)s;
+            }
+        }
+        for (uint32_t j = p0 + KEEP * TPB + threadIdx.x; j < p1; j += TPB) {       // (a bin far above the average)
+            uint32_t mine;
+            const int s = probe(index_of(k1[j], ix.mod) - ix.lo, mine);
+            if (s > 0) st1[v1[j]] = (uint8_t)s;
+        }
+        __syncthreads();
+        if (s_any) {                         // the probes that set a bit somebody else then met them on are told so
+            auto marked = [&](uint32_t loc) { return loc != ~0u && ((s_c[(loc >> 5) & (SW_MARKS - 1u)] >> (loc & 31u)) & 1u); };
+#pragma unroll
+            for (uint32_t it = 0; it < KEEP; ++it) {
+                if (marked(mine0[it])) st0[r0 + it * TPB + threadIdx.x] = 3;
+                if (marked(mine1[it])) st1[v1[p0 + it * TPB + threadIdx.x]] = 3;
+            }
+            for (uint32_t j = p0 + KEEP * TPB + threadIdx.x; j < p1; j += TPB) {
+                const uint64_t i1 = index_of(k1[j], ix.mod) - ix.lo;
+                const uint64_t w = (i1 >> 5) - wb;
+                if (w < (uint64_t)cnt && ((s_c[(uint32_t)w & (SW_MARKS - 1u)] >> (uint32_t)(i1 & 31ull)) & 1u)) {
+                    const uint32_t d = v1[j];
+                    if (st1[d] == 0) st1[d] = 3;
+                }
+            }
+        }
+        for (uint32_t i = threadIdx.x * 4u; i < cnt; i += TPB * 4u) {
+            const uint64_t gw = wb + i;
+            if (gw >= in_lo && gw + 4ull <= in_hi) *reinterpret_cast<uint4 *>(words + gw) = *reinterpret_cast<const uint4 *>(s_w + i);
+            else
+                for (uint32_t q = 0; q < 4u && i + q < cnt; ++q) {
+                    const uint64_t g = gw + q;
+                    if (g >= in_lo && g < in_hi) words[g] = s_w[i + q];
+                    else if ((g << 5) < x_hi && ((g + 1ull) << 5) > x_lo) atomicOr(&words[g], s_w[i + q]);     // shared with a neighbour: what was loaded was set, what is new is ours
+                }
+        }
+        __syncthreads();
+    }
+}
+// the runs of oversized buckets (appended by k_group_big; none in a warm steady state) are not contiguous per bucket: their probe 0 looks
+// at HBM before the sweep and sets its bit after it
+__global__ void k_sw_big_pre(const uint32_t *__restrict__ words, Mod mod, uint64_t lo, const uint64_t *__restrict__ uniq, uint32_t d0, uint32_t D, uint8_t *__restrict__ st0) {
+    const uint32_t d = d0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= D) return;
+    const uint64_t i0 = index_of(uniq[d], mod) - lo;
+    st0[d] = (words[i0 >> 5] >> (uint32_t)(i0 & 31ull)) & 1u;
+}
+__global__ void k_sw_big_set(uint32_t *__restrict__ words, Mod mod, uint64_t lo, const uint64_t *__restrict__ uniq, uint32_t d0, uint32_t D, uint8_t *__restrict__ st0) {
+    const uint32_t d = d0 + blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= D || st0[d]) return;
+    const uint64_t i0 = index_of(uniq[d], mod) - lo;
+    const uint32_t m = 1u << (uint32_t)(i0 & 31ull);
+    if (atomicOr(&words[i0 >> 5], m) & m) st0[d] = 2;
+}
+size_t sweep_temp_bytes(size_t D, uint32_t T) { return group_plan(D, 64, 0, 0, (int)T).total; }
+void sweep_bits_device(uint32_t *words, GrIdx idx, uint32_t T, uint64_t kmul, const uint64_t *uniq, uint32_t D, uint32_t n_main, const uint32_t *brun,
+                       const uint32_t *bnr, uint64_t *keys_a, uint32_t *vals_a, uint64_t *keys_b, uint32_t *vals_b, void *temp, size_t temp_bytes,
+                       uint8_t *st0, uint8_t *st1, hipStream_t st) {
+    RB_REQUIRE(D > 0 && T > 0 && idx.span > (1ull << T), "sweep_bits_device: nothing to sweep by");
+    const GroupPlan P = group_plan(D, 64, 0, 0, (int)T);
+    RB_REQUIRE(P.T == T && temp_bytes >= P.total, "sweep_bits_device: plan / temp mismatch");
+    RB_HIP(hipMemsetAsync(st1, 0, D, st));
+    hipLaunchKernelGGL(k_sw_emit, dim3((D + 255u) / 256u), dim3(256), 0, st, uniq, D, kmul, keys_a, vals_a);
+    const uint64_t *k1 = nullptr;
+    const uint32_t *v1 = nullptr;
+    const uint32_t *bstart1 = P.tpb == 512u ? partition_records<512>(P, keys_a, vals_a, keys_b, vals_b, static_cast<char *>(temp), st, nullptr, idx, &k1, &v1)
+                                            : partition_records<256>(P, keys_a, vals_a, keys_b, vals_b, static_cast<char *>(temp), st, nullptr, idx, &k1, &v1);
+    GrIdxDev ix = gr_idx_dev(P, idx);
+    const uint32_t n_big = D - std::min(n_main, D);
+    if (n_big) hipLaunchKernelGGL(k_sw_big_pre, dim3((n_big + 255u) / 256u), dim3(256), 0, st, (const uint32_t *)words, idx.mod, idx.lo, uniq, n_main, D, st0);
+    // a round holds a whole range where it fits 64 KB (then: the more workgroups per CU the shorter the ranges — up to four of 512 threads)
+    const uint64_t range_words = (idx.span >> T) / 32 + 16;
+    const uint32_t sww = (uint32_t)std::min<uint64_t>(SW_WORDS, (range_words + 1023) / 1024 * 1024);
+    RB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep_bits<512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((SW_WORDS + SW_MARKS) * 4)));
+    hipLaunchKernelGGL(k_sweep_bits<512>, dim3(P.nbuckets), dim3(512), (sww + SW_MARKS) * 4, st, words, ix, idx.span, T, uniq, brun, bnr, k1, v1, bstart1, st0, st1, sww);
+    if (n_big) hipLaunchKernelGGL(k_sw_big_set, dim3((n_big + 255u) / 256u), dim3(256), 0, st, words, idx.mod, idx.lo, uniq, n_main, D, st0);
+    RB_HIP(hipGetLastError());
 }
 
 }  // namespace rb

@@ -137,6 +137,9 @@ struct GrIdx {
     Mod mod;                    // the filter's size (index_of)
     uint64_t lo = 0, span = 0;  // this handle's index range (a shard's; the whole filter otherwise).  span == 0: off
 };
+// what a grouping can leave behind for the swept Bloom-bit stage below: per fine bucket the first run slot and the number of runs (the
+// bucket's runs are contiguous; an oversized bucket has none there), and the number of runs before the oversized buckets' (appended last)
+struct GroupExport { uint32_t *brun = nullptr, *bnr = nullptr, *n_main = nullptr; };
 void group_debug_big(const void *temp, size_t N, int group_bits, int bucket_target, uint32_t *n_big_out, uint64_t *records_out, uint32_t *largest_out, int flags = 0);
 size_t group_temp_bytes(size_t N, int group_bits, int bucket_target = 0, int flags = 0);
 const uint32_t *group_live_count(const void *temp, size_t N, int group_bits, int bucket_target, int flags);
@@ -145,6 +148,16 @@ void group_records_device(uint64_t *keys0, uint32_t *vals0, uint64_t *keys_tmp, 
                           uint32_t *vals_out, uint8_t *tz_out, uint64_t *uniq, uint32_t *counts, uint32_t *starts, uint32_t *n_runs_dev,
                           hipStream_t st, struct rb_graph *prof = nullptr /* per-kernel HIP-event timing into this handle's profile */,
                           int bucket_target = 0 /* average fine-bucket size aimed at (0: the default, 3072) */, int flags = 0 /* GR_FLAG_* */,
-                          GrIdx idx = GrIdx{Mod{1, 0, 0}, 0, 0} /* span != 0: first partition digit from the first filter index */);
+                          GrIdx idx = GrIdx{Mod{1, 0, 0}, 0, 0} /* span != 0: first partition digit from the first filter index */,
+                          GroupExport ex = GroupExport{});
+// T, the log2 of the number of index ranges (fine buckets) such a grouping partitions by; 0: it would not be index-keyed
+uint32_t group_index_buckets(size_t N, int group_bits, int bucket_target, int flags, GrIdx idx);
+// Swept Bloom-bit stage (rb_group.hip): both Bloom bits of the D runs of an index-keyed grouping with 2^T buckets are tested and set range by
+// range through LDS; st0[d] / st1[d] = what probe 0 / 1 of run d found: 0 it set the bit, 1 set before the sub-batch, 2 set by another probe of
+// the sub-batch.  keys_* / vals_* are scratch for D records each.  The filter must be whole (idx.lo = 0 is the filter's first bit).
+size_t sweep_temp_bytes(size_t D, uint32_t T);
+void sweep_bits_device(uint32_t *words, GrIdx idx, uint32_t T, uint64_t kmul, const uint64_t *uniq, uint32_t D, uint32_t n_main, const uint32_t *brun,
+                       const uint32_t *bnr, uint64_t *keys_a, uint32_t *vals_a, uint64_t *keys_b, uint32_t *vals_b, void *temp, size_t temp_bytes,
+                       uint8_t *st0, uint8_t *st1, hipStream_t st);
 
 }  // namespace rb

@@ -340,7 +340,7 @@ struct rb_graph {
     hipStream_t stream2 = nullptr;   // producer stream: hashing + grouping of the NEXT sub-batch (scratch only)
     hipStream_t stream3 = nullptr;   // side stream of the producer: the paired-k-mer walker (rpkbf only) beside the window walk
     // grouped sub-batch, double buffered so that grouping of sub-batch i+1 overlaps the filter stages of i
-    struct GroupSlot { DevBuf keys1, valsT, vals1, tz, uniq, counts, starts; size_t N = 0; uint32_t D = 0; int flags = 0; uint32_t live = 0; int bucket_target = 0; /* what group_enqueue planned with */ };
+    struct GroupSlot { DevBuf keys1, valsT, vals1, tz, uniq, counts, starts, brun, bnr /* swept stage: run slots per index range */; uint32_t sweep_T = 0, n_main = 0; size_t N = 0; uint32_t D = 0; int flags = 0; uint32_t live = 0; int bucket_target = 0; /* what group_enqueue planned with */ };
     GroupSlot slots[2];
     int cur = 0;
     DevBuf &keys1() { return slots[cur].keys1; }
@@ -350,6 +350,9 @@ struct rb_graph {
     DevBuf &counts() { return slots[cur].counts; }
     DevBuf &starts() { return slots[cur].starts; }
     DevBuf temp2, devctr2, pairs_ctr;
+    DevBuf sw_st, sw_temp;               // swept Bloom-bit stage: what the probes found, partition scratch
+    int pf_streak = 0, pf_skip_left = 0;   // sub-batches in a row the prefilter kept (nearly) everything of; sub-batches left to go without it
+    float last_present_frac = 0.0f;      // share of the last sub-batch's runs whose Bloom bits were all set before it
     // no-op prefilter
     DevBuf npf, chunk_mask, npf_tot, wstate;
     uint32_t npf_log2 = 0;

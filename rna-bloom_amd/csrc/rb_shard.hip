@@ -644,10 +644,11 @@ __global__ void k_own_dbg_first(const uint64_t *__restrict__ idx, const uint64_t
 __global__ void k_own_claim(uint8_t *cbf, uint64_t lo, const uint64_t *__restrict__ idx, size_t n, uint8_t *__restrict__ reply,
                             uint32_t *__restrict__ spread /* 32 counters, 16 words apart */) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint32_t byte = cbf_claim(cbf, idx[i] - lo);
-    if (byte & CLAIM) atomicAdd(&spread[16 * (blockIdx.x & 31u)], 1u);
-    reply[i] = (uint8_t)byte;                                         // bit 7 = claimed before by another run
+    const bool live = i < n;
+    const uint32_t byte = live ? cbf_claim(cbf, idx[i] - lo) : 0u;
+    const unsigned long long m = __ballot(live && (byte & CLAIM));    // one add per wavefront (adds to one address queue up at ~10 ns apiece)
+    if (m && (threadIdx.x & 63u) == 0u) atomicAdd(&spread[16 * (blockIdx.x & 31u)], (uint32_t)__popcll(m));
+    if (live) reply[i] = (uint8_t)byte;                               // bit 7 = claimed before by another run
 }
 // contested counters: a table of their indices and, in front of it, a cache-resident bit filter over the same keys (most
 // claims are not contested and never reach the table; same arrangement as stage B of the single-GPU engine)

@@ -15,10 +15,12 @@
 namespace rb {
 
 namespace {
-constexpr uint32_t SC_TPB = 256, SC_VEC = 4, SC_SUB = SC_TPB * SC_VEC, SC_SUBS = 16, SC_TILE = SC_SUB * SC_SUBS;   // 16384 items per tile.  (16 items per thread and
+constexpr uint32_t SC_TPB = 256, SC_VEC = 4, SC_SUB = SC_TPB * SC_VEC, SC_SUBS = 16;   // 16384 items per tile.  (16 items per thread and
 // four rounds instead of sixteen measured TWICE as slow, 233 against 116 us for the 23 M-word chunk scan: a thread's 64 consecutive bytes put the lanes' uint4 reads
 // on the same LDS banks; at 4 items the blocked reads are conflict-free)
-constexpr uint32_t SC_ONE_TPB = 1024, SC_ONE_VEC = 16, SC_ONE_MAX = 65536;   // single-workgroup path: 16 K items per round of 4 barriers
+constexpr uint32_t SC_ONE_TPB = 1024, SC_ONE_VEC = 8, SC_SMALL_VEC = 16, SC_ONE_MAX = 65536;   // single-workgroup path: 8 K items per round of 4 barriers.
+// (35 KB of LDS, not 70: a single-workgroup kernel of the consumer stream has to find room on a CU beside the producer's persistent bucket kernel —
+// three workgroups of 40 KB per CU for milliseconds; at 70 KB it waited for that kernel to END, 0.4-0.6 ms per call on average where the two overlap)
 
 // One sub-tile of TPB x VEC items at in[base ...): exclusive scan with `carry` added, written to out; returns carry + the
 // sub-tile's sum.  Striped (coalesced) global accesses, blocked scan through LDS; no alignment assumptions; in == out is fine.
@@ -81,10 +83,10 @@ __global__ void __launch_bounds__(SC_ONE_TPB) k_scan_one(const uint32_t *__restr
 }
 // the same with 256 threads for arrays of a few thousand entries (a 1024-thread workgroup is mostly barrier there)
 __global__ void __launch_bounds__(SC_TPB) k_scan_one_small(const uint32_t *__restrict__ in, uint32_t *__restrict__ out, size_t n) {
-    __shared__ __attribute__((aligned(16))) uint32_t s_data[sc_padded(SC_TPB * SC_ONE_VEC)];
+    __shared__ __attribute__((aligned(16))) uint32_t s_data[sc_padded(SC_TPB * SC_SMALL_VEC)];
     __shared__ uint32_t s_wsum[SC_TPB / 64];
     uint32_t carry = 0;
-    for (size_t base = 0; base < n; base += SC_TPB * SC_ONE_VEC) carry = sc_sub_scan<SC_TPB, SC_ONE_VEC>(in, out, base, n, carry, s_data, s_wsum);
+    for (size_t base = 0; base < n; base += SC_TPB * SC_SMALL_VEC) carry = sc_sub_scan<SC_TPB, SC_SMALL_VEC>(in, out, base, n, carry, s_data, s_wsum);
 }
 
 __global__ void __launch_bounds__(SC_TPB) k_scan_reduce(const uint32_t *__restrict__ in, size_t n, uint32_t *__restrict__ tile_sums, uint32_t tile) {
@@ -148,7 +150,7 @@ __global__ void __launch_bounds__(SC_TPB) k_scan_apply(const uint32_t *__restric
     }
 }
 void scan_one(const uint32_t *in, uint32_t *out, size_t n, hipStream_t s) {
-    if (n <= 2 * SC_TPB * SC_ONE_VEC) hipLaunchKernelGGL(k_scan_one_small, dim3(1), dim3(SC_TPB), 0, s, in, out, n);
+    if (n <= 2 * SC_TPB * SC_SMALL_VEC) hipLaunchKernelGGL(k_scan_one_small, dim3(1), dim3(SC_TPB), 0, s, in, out, n);
     else hipLaunchKernelGGL(k_scan_one, dim3(1), dim3(SC_ONE_TPB), 0, s, in, out, n);
 }
 }  // namespace

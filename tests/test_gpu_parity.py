@@ -376,7 +376,10 @@ def test_cold_subbatch_is_split_when_survivors_exceed_the_bound():
                                  {"RB_PAIRS_SIDE": "0"}, {"RB_PAIRS_SIDE": "1"}, {"RB_PAIRS_SIDE": "2"}, {"RB_PAIRS_SIDE": "4"}, {"RB_PAIRS_SIDE": "5"},
                                  {"RB_FILTER_PIPE": "1"}, {"RB_FILTER_PIPE": "2"}, {"RB_FILTER_PIPE": "0"}, {"RB_RAGGED_LANES": "0"},
                                  {"RB_GROUP_IDX": "1"}, {"RB_GROUP_IDX": "0"}, {"RB_GROUP_IDX": "1", "RB_GROUP_T": "18"}, {"RB_GROUP_IDX": "1", "RB_GROUP_T": "3"},
-                                 {"RB_GROUP_IDX": "1", "RB_TWO_PHASE": "1"}, {"RB_FT_FILTER": "1"}, {"RB_FT_FILTER": "0"}, {"RB_GROUP_CLASSES": "0"}])
+                                 {"RB_GROUP_IDX": "1", "RB_TWO_PHASE": "1"}, {"RB_FT_FILTER": "1"}, {"RB_FT_FILTER": "0"}, {"RB_GROUP_CLASSES": "0"},
+                                 {"RB_SWEEP": "1"}, {"RB_SWEEP": "1", "RB_GROUP_T": "18"}, {"RB_SWEEP": "1", "RB_GROUP_T": "3"}, {"RB_SWEEP": "1", "RB_GROUP_T": "11"},
+                                 {"RB_SWEEP": "1", "RB_SERIAL": "1"}, {"RB_SWEEP": "1", "RB_GROUP_ORDERED": "1"}, {"RB_SWEEP": "1", "RB_NO_MPF": "1"},
+                                 {"RB_SWEEP": "1", "RB_FT_FILTER": "1"}, {"RB_SWEEP": "1", "RB_PF_SKIP": "2"}, {"RB_SWEEP": "0"}])
 def test_pipeline_switches_do_not_change_results(monkeypatch, env):
     """every scheduling / cache switch of the insert path (minimizer- vs hash-bucketed cache, tiny caches that
     thrash, minimizer length, cold-start ramp, producer one sub-batch ahead, serialised streams, one word or one
@@ -394,6 +397,53 @@ def test_pipeline_switches_do_not_change_results(monkeypatch, env):
         assert_same_state(og, gg)
     assert og.cbf_bytes().max() > 30          # deep into the probabilistic counter range
     assert st.sorted_kmers < st.kmers         # and the prefilter is doing something
+
+
+@pytest.mark.parametrize("sizes", [(300_007, 300_007), (300_007, 400_009), (5_000_011, 5_000_011), (64 * 4096 * 8, 64 * 4096 * 8 + 1)])
+@pytest.mark.parametrize("T", ["2", "7", "12"])
+def test_swept_bloom_bit_stage_with_oversized_buckets_and_shared_words(monkeypatch, sizes, T):
+    """the swept Bloom-bit stage (csrc/rb_group.hip sweep_bits_device, forced with RB_SWEEP=1): index ranges that share words with their
+    neighbours (a few bits to a few thousand words per range), ranges longer than one 64 KB round, filters of equal and of different
+    entries (the grouping then goes by the Bloom filter's indices), and — prefilter off, one read 6000 times — a bucket too large for
+    LDS whose runs are appended out of range order: the filters come out as the oracle's"""
+    monkeypatch.setenv("RB_SWEEP", "1"); monkeypatch.setenv("RB_GROUP_T", T); monkeypatch.setenv("RB_NO_MPF", "1")
+    d = synth.generate_pairs(1500, G=6000, err=0.004, n_rate=1e-3, seed=int(T) + sizes[0] % 97, uniform_expr=True)
+    og, gg = graph_pair(sizes[0], sizes[1], 60_013, max_batch=0)
+    og.set_read_pair_distance(115); gg.setReadPairedKmerDistance(115)
+    reads = np.concatenate([d["left"], np.repeat(d["left"][3:4], 6000, axis=0), d["right"]])
+    quals = np.concatenate([d["lqual"], np.repeat(d["lqual"][3:4], 6000, axis=0), d["rqual"]])
+    for rep in range(2):                      # second pass: every k-mer present, every bit found set before the sub-batch
+        s, off = synth.flat(reads); q, _ = synth.flat(quals)
+        og.add_reads(s, q, off, 3, 0)
+        gg.addReads(s, q, off, 3)
+        assert_same_state(og, gg, pairs=False)
+    assert og.cbf_bytes().max() > 40
+
+
+@pytest.mark.parametrize("k", [25, 35])
+@pytest.mark.parametrize("sweep", ["0", "1"])
+def test_reads_without_repeats_stop_asking_the_prefilter_cache(monkeypatch, k, sweep):
+    """where the cache drops nothing (reads off a genome far larger than the reads cover: every k-mer new) the window walk against it is
+    skipped for 15 sub-batches at a time (csrc/rb_graph.hip add_range, RB_PF_SKIP=2: sub-batches of any size count) — the unfiltered emit
+    path and the filtered one alternate inside one call, with and without the swept stage; then
+    the same reads again (every k-mer present now, still nothing for the cache to drop: counters of 1 and 2 move at every sighting)"""
+    monkeypatch.setenv("RB_PF_SKIP", "2"); monkeypatch.setenv("RB_SWEEP", sweep)
+    rng = np.random.default_rng(99 + k)
+    acgt = np.frombuffer(b"ACGT", np.uint8)
+    genome = acgt[rng.integers(0, 4, 4_000_000, dtype=np.uint8)]
+    lens = rng.integers(60, 400, 6000)
+    starts = rng.integers(0, genome.size - 400, 6000)
+    seq = np.concatenate([genome[a:a + L] for a, L in zip(starts, lens)])
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    og, gg = graph_pair(20_000_003, 20_000_003, 60_013, k=k, pairs=False, max_batch=20_000)
+    tot = []
+    for rep in range(2):
+        o_st = og.add_reads(seq, None, off, 3, 0)
+        st = gg.addReads(seq, None, off, 3)
+        assert_same_state(og, gg, pairs=False)
+        assert st.kmers == o_st.kmers
+        tot.append((st.kmers, st.sorted_kmers))
+    assert tot[0][1] == tot[0][0], tot
 
 
 @pytest.mark.parametrize("tries", ["1", "4"])

@@ -1,0 +1,7 @@
+#!/bin/bash
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out; mkdir -p $O
+cd $R
+timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -k "swept" 2>&1 | tail -15 > $O/r04_r_tests.txt
+cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/prof_lr
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_lr -o s -- python $R/tools/longread_insert_ab.py 1500000 > $O/r04_r_longread.txt 2>&1
+python $R/profiles/summarize.py stats $(find /tmp/prof_lr -name '*kernel_stats.csv' | head -1) > $O/r04_r_kernel_stats.csv
