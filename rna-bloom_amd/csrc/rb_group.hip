@@ -1164,7 +1164,7 @@ __global__ void k_sw_emit(const uint64_t *__restrict__ uniq, uint32_t D, uint64_
 // a probe of another bit that shares them is told so too, and finds no entry in the collision table) — the probes with 2 or 3 are the ones
 // the first-setter arbitration has to look at, everybody else is done
 template <int TPB>
-__global__ void __launch_bounds__(TPB) k_sweep_bits(uint32_t *words, GrIdxDev ix, uint64_t span, uint32_t T, const uint64_t *__restrict__ uniq,
+__global__ void __launch_bounds__(TPB, 4) k_sweep_bits(uint32_t *words, GrIdxDev ix, uint64_t span, uint32_t T, const uint64_t *__restrict__ uniq,
                                                     const uint32_t *__restrict__ brun, const uint32_t *__restrict__ bnr,
                                                     const uint64_t *__restrict__ k1, const uint32_t *__restrict__ v1, const uint32_t *__restrict__ bstart1,
                                                     uint8_t *st0, uint8_t *st1, uint32_t SWW /* words of filter per round: dynamic LDS = (SWW + SW_MARKS) words */) {
@@ -1177,8 +1177,27 @@ __global__ void __launch_bounds__(TPB) k_sweep_bits(uint32_t *words, GrIdxDev ix
     const uint64_t x_lo = sw_first(c, ix, span, T), x_hi = sw_first(c + 1u, ix, span, T);
     const uint64_t w_lo = (x_lo >> 5) & ~3ull, w_hi = (x_hi + 31ull) >> 5;          // words [w_lo, w_hi), from a 16-byte boundary
     const uint64_t in_lo = (x_lo + 31ull) >> 5, in_hi = x_hi >> 5;                  // words [in_lo, in_hi) hold bits of this range only
+    // the range's probes: bit offsets from the range's first loaded word, into registers once and on their way while the first round's words are
+    // loaded (a bucket has at most GR_TILE runs: every probe 0, and the first KEEP x TPB probes 1; a bin far above the average walks the rest from memory)
+    constexpr uint32_t KEEP = GR_TILE / TPB;
+    constexpr uint32_t NONE = ~0u;
+    static_assert(KEEP <= 16, "one mask bit per remembered probe");
+    const uint64_t bit0 = w_lo << 5;
+    uint32_t i0[KEEP], i1[KEEP];
+    {
+        uint64_t h[KEEP];
+#pragma unroll
+        for (uint32_t it = 0; it < KEEP; ++it) { const uint32_t r = it * TPB + threadIdx.x; h[it] = r < nr ? uniq[r0 + r] : 0ull; }
+#pragma unroll
+        for (uint32_t it = 0; it < KEEP; ++it) { const uint32_t r = it * TPB + threadIdx.x; i0[it] = r < nr ? (uint32_t)(index_of(h[it], ix.mod) - ix.lo - bit0) : NONE; }
+#pragma unroll
+        for (uint32_t it = 0; it < KEEP; ++it) { const uint32_t j = p0 + it * TPB + threadIdx.x; h[it] = j < p1 ? k1[j] : 0ull; }
+#pragma unroll
+        for (uint32_t it = 0; it < KEEP; ++it) { const uint32_t j = p0 + it * TPB + threadIdx.x; i1[it] = j < p1 ? (uint32_t)(index_of(h[it], ix.mod) - ix.lo - bit0) : NONE; }
+    }
     for (uint64_t wb = w_lo; wb < w_hi; wb += SWW) {
         const uint32_t cnt = (uint32_t)min((uint64_t)SWW, w_hi - wb);
+        const uint32_t wrel = (uint32_t)(wb - w_lo);           // this round's first word, counted from the range's
         for (uint32_t i = threadIdx.x * 4u; i < cnt; i += TPB * 4u) {
             if (i + 4u <= cnt) *reinterpret_cast<uint4 *>(s_w + i) = *reinterpret_cast<const uint4 *>(words + wb + i);
             else for (uint32_t q = i; q < cnt; ++q) s_w[q] = words[wb + q];
@@ -1186,55 +1205,45 @@ __global__ void __launch_bounds__(TPB) k_sweep_bits(uint32_t *words, GrIdxDev ix
         for (uint32_t i = threadIdx.x; i < SW_MARKS; i += TPB) s_c[i] = 0u;
         if (threadIdx.x == 0) s_any = 0u;
         __syncthreads();
-        // one probe: test-and-set in LDS; a bit found set is looked up in HBM (still the state before the sub-batch).  Returns the report and,
-        // for a probe that set its bit, where (the bit's offset in this round's words) — it may hear of a collision after the barrier.
-        auto probe = [&](uint64_t ib, uint32_t &mine) -> int {
-            mine = ~0u;
-            const uint64_t w = (ib >> 5) - wb;
-            if (w >= (uint64_t)cnt) return -1;                 // another round's
-            const uint32_t m = 1u << (uint32_t)(ib & 31ull);
-            if (!(atomicOr(&s_w[w], m) & m)) { mine = ((uint32_t)w << 5) | (uint32_t)(ib & 31ull); return 0; }
-            if (__hip_atomic_load(&words[ib >> 5], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & m) return 1;
-            atomicOr(&s_c[(uint32_t)w & (SW_MARKS - 1u)], m); s_any = 1u;
+        // one probe (rel: its bit, counted from the range's first loaded word): test-and-set in LDS; a bit found set is looked up in HBM (still the
+        // state before the sub-batch).  Returns the report: -1 another round's, 0 set by this probe — it may hear of a collision after the barrier.
+        auto probe = [&](uint32_t rel) -> int {
+            const uint32_t w = (rel >> 5) - wrel;
+            if (rel == NONE || w >= cnt) return -1;
+            const uint32_t m = 1u << (rel & 31u);
+            if (!(atomicOr(&s_w[w], m) & m)) return 0;
+            if (__hip_atomic_load(&words[w_lo + (rel >> 5)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & m) return 1;
+            atomicOr(&s_c[w & (SW_MARKS - 1u)], m); s_any = 1u;
             return 2;
         };
-        constexpr uint32_t KEEP = GR_TILE / TPB;               // a bucket has at most GR_TILE runs: every probe 0 is remembered, and the first KEEP x TPB probes 1
-        uint32_t mine0[KEEP], mine1[KEEP];
+        uint32_t setmask = 0;                                  // bit it: probe 0 of iteration it set its bit in this round; bit 16 + it: probe 1
 #pragma unroll
         for (uint32_t it = 0; it < KEEP; ++it) {
-            const uint32_t r = it * TPB + threadIdx.x;
-            mine0[it] = ~0u;
-            if (r < nr) {
-                const int s = probe(index_of(uniq[r0 + r], ix.mod) - ix.lo, mine0[it]);
-                if (s >= 0) st0[r0 + r] = (uint8_t)s;
-            }
+            const int s = probe(i0[it]);
+            if (s >= 0) st0[r0 + it * TPB + threadIdx.x] = (uint8_t)s;
+            if (s == 0) setmask |= 1u << it;
         }
 #pragma unroll
         for (uint32_t it = 0; it < KEEP; ++it) {
-            const uint32_t j = p0 + it * TPB + threadIdx.x;
-            mine1[it] = ~0u;
-            if (j < p1) {
-                const int s = probe(index_of(k1[j], ix.mod) - ix.lo, mine1[it]);
-                if (s > 0) st1[v1[j]] = (uint8_t)s;
-            }
+            const int s = probe(i1[it]);
+            if (s > 0) st1[v1[p0 + it * TPB + threadIdx.x]] = (uint8_t)s;
+            if (s == 0) setmask |= 1u << (16u + it);
         }
         for (uint32_t j = p0 + KEEP * TPB + threadIdx.x; j < p1; j += TPB) {       // (a bin far above the average)
-            uint32_t mine;
-            const int s = probe(index_of(k1[j], ix.mod) - ix.lo, mine);
+            const int s = probe((uint32_t)(index_of(k1[j], ix.mod) - ix.lo - bit0));
             if (s > 0) st1[v1[j]] = (uint8_t)s;
         }
         __syncthreads();
         if (s_any) {                         // the probes that set a bit somebody else then met them on are told so
-            auto marked = [&](uint32_t loc) { return loc != ~0u && ((s_c[(loc >> 5) & (SW_MARKS - 1u)] >> (loc & 31u)) & 1u); };
+            auto marked = [&](uint32_t rel) { return ((s_c[((rel >> 5) - wrel) & (SW_MARKS - 1u)] >> (rel & 31u)) & 1u) != 0u; };
 #pragma unroll
             for (uint32_t it = 0; it < KEEP; ++it) {
-                if (marked(mine0[it])) st0[r0 + it * TPB + threadIdx.x] = 3;
-                if (marked(mine1[it])) st1[v1[p0 + it * TPB + threadIdx.x]] = 3;
+                if (((setmask >> it) & 1u) && marked(i0[it])) st0[r0 + it * TPB + threadIdx.x] = 3;
+                if (((setmask >> (16u + it)) & 1u) && marked(i1[it])) st1[v1[p0 + it * TPB + threadIdx.x]] = 3;
             }
             for (uint32_t j = p0 + KEEP * TPB + threadIdx.x; j < p1; j += TPB) {
-                const uint64_t i1 = index_of(k1[j], ix.mod) - ix.lo;
-                const uint64_t w = (i1 >> 5) - wb;
-                if (w < (uint64_t)cnt && ((s_c[(uint32_t)w & (SW_MARKS - 1u)] >> (uint32_t)(i1 & 31ull)) & 1u)) {
+                const uint32_t rel = (uint32_t)(index_of(k1[j], ix.mod) - ix.lo - bit0);
+                if ((rel >> 5) - wrel < cnt && marked(rel)) {
                     const uint32_t d = v1[j];
                     if (st1[d] == 0) st1[d] = 3;
                 }
