@@ -219,15 +219,21 @@ __global__ void __launch_bounds__(256) k_probe_h2(FilterView fv, const uint64_t 
         }
         status[d] = st[r];
     }
-    // one add per wavefront, not per lane: adds to one address go through at ~10 ns apiece whoever issues them (32 addresses: config 2's
-    // tens of millions of contested claims per step were seconds of lanes waiting in line)
+    // one add per WORKGROUP and counter, not per lane: adds to one address go through at ~10 ns apiece whoever issues them, and there are 32
+    // addresses per counter — with one add per wavefront a 390 M-run sub-batch still queued 0.57 M adds per address (6 ms of a 9 ms kernel)
+    __shared__ uint32_t s_acc[3];
+    if (threadIdx.x < 3u) s_acc[threadIdx.x] = 0u;
+    __syncthreads();
 #pragma unroll
     for (int o = 32; o; o >>= 1) { n_foreign_total += __shfl_xor(n_foreign_total, o, 64); n_coll_total += __shfl_xor(n_coll_total, o, 64); n_allpre += __shfl_xor(n_allpre, o, 64); }
     if ((threadIdx.x & 63u) == 0u) {
-        if (n_allpre) atomicAdd(&counters[18 + 16 * (blockIdx.x & 31u)], n_allpre);     // (what the next sub-batch decides about the swept stage by)
-        if (n_foreign_total) atomicAdd(&counters[16 + 16 * (blockIdx.x & 31u)], n_foreign_total);
-        if (SWEPT && n_coll_total) atomicAdd(&counters[17 + 16 * (blockIdx.x & 31u)], n_coll_total);
+        if (n_foreign_total) atomicAdd(&s_acc[0], n_foreign_total);
+        if (n_coll_total) atomicAdd(&s_acc[1], n_coll_total);
+        if (n_allpre) atomicAdd(&s_acc[2], n_allpre);
     }
+    __syncthreads();
+    if (threadIdx.x < 3u && s_acc[threadIdx.x] && (SWEPT || threadIdx.x != 1u))          // [16] contested claims, [17] collisions (swept stage only: k_set_bits counts them otherwise), [18] runs present before the sub-batch
+        atomicAdd(&counters[16 + threadIdx.x + 16 * (blockIdx.x & 31u)], s_acc[threadIdx.x]);
 }
 // ---- first-setter arbitration without a table entry per new bit (the default) ----
 // Two new k-mers of one sub-batch rarely share a Bloom bit (touches^2 / 2 bits: ~0.2 M of 60 M on config 2), so
