@@ -18,9 +18,10 @@ namespace {
 constexpr uint32_t SC_TPB = 256, SC_VEC = 4, SC_SUB = SC_TPB * SC_VEC, SC_SUBS = 16;   // 16384 items per tile.  (16 items per thread and
 // four rounds instead of sixteen measured TWICE as slow, 233 against 116 us for the 23 M-word chunk scan: a thread's 64 consecutive bytes put the lanes' uint4 reads
 // on the same LDS banks; at 4 items the blocked reads are conflict-free)
-constexpr uint32_t SC_ONE_TPB = 1024, SC_ONE_VEC = 8, SC_SMALL_VEC = 16, SC_ONE_MAX = 65536;   // single-workgroup path: 8 K items per round of 4 barriers.
-// (35 KB of LDS, not 70: a single-workgroup kernel of the consumer stream has to find room on a CU beside the producer's persistent bucket kernel —
-// three workgroups of 40 KB per CU for milliseconds; at 70 KB it waited for that kernel to END, 0.4-0.6 ms per call on average where the two overlap)
+constexpr uint32_t SC_ONE_TPB = 512, SC_ONE_VEC = 16, SC_SMALL_VEC = 16, SC_ONE_MAX = 65536;   // single-workgroup path: 8 K items per round of 4 barriers.
+// (512 threads and 35 KB of LDS, not 1024 and 70: a single-workgroup kernel of the consumer stream has to find room on a CU beside the producer's
+// persistent bucket kernel — three workgroups of 512 threads and 40 KB per CU for milliseconds; what does not fit beside them waits for that kernel to
+// END, 0.2-0.6 ms per call on average where the two overlap)
 
 // One sub-tile of TPB x VEC items at in[base ...): exclusive scan with `carry` added, written to out; returns carry + the
 // sub-tile's sum.  Striped (coalesced) global accesses, blocked scan through LDS; no alignment assumptions; in == out is fine.
