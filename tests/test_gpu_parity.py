@@ -422,11 +422,13 @@ def test_swept_bloom_bit_stage_with_oversized_buckets_and_shared_words(monkeypat
 
 @pytest.mark.parametrize("k", [25, 35])
 @pytest.mark.parametrize("sweep", ["0", "1"])
-def test_reads_without_repeats_stop_asking_the_prefilter_cache(monkeypatch, k, sweep):
+@pytest.mark.parametrize("pairs", [False, True])
+def test_reads_without_repeats_stop_asking_the_prefilter_cache(monkeypatch, k, sweep, pairs):
     """where the cache drops nothing (reads off a genome far larger than the reads cover: every k-mer new) the window walk against it is
     skipped for 15 sub-batches at a time (csrc/rb_graph.hip add_range, RB_PF_SKIP=2: sub-batches of any size count) — the unfiltered emit
-    path and the filtered one alternate inside one call, with and without the swept stage; then
-    the same reads again (every k-mer present now, still nothing for the cache to drop: counters of 1 and 2 move at every sighting)"""
+    path and the filtered one alternate inside one call, with and without the swept stage, with and without the paired k-mers' walker on its
+    side stream; then the same reads again (every k-mer present now, still nothing for the cache to drop: counters of 1 and 2 move at every
+    sighting)"""
     monkeypatch.setenv("RB_PF_SKIP", "2"); monkeypatch.setenv("RB_SWEEP", sweep)
     rng = np.random.default_rng(99 + k)
     acgt = np.frombuffer(b"ACGT", np.uint8)
@@ -435,12 +437,14 @@ def test_reads_without_repeats_stop_asking_the_prefilter_cache(monkeypatch, k, s
     starts = rng.integers(0, genome.size - 400, 6000)
     seq = np.concatenate([genome[a:a + L] for a, L in zip(starts, lens)])
     off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
-    og, gg = graph_pair(20_000_003, 20_000_003, 60_013, k=k, pairs=False, max_batch=20_000)
+    og, gg = graph_pair(20_000_003, 20_000_003, 2_000_003, k=k, pairs=pairs, max_batch=20_000)
+    if pairs:
+        og.set_read_pair_distance(40); gg.setReadPairedKmerDistance(40)
     tot = []
     for rep in range(2):
-        o_st = og.add_reads(seq, None, off, 3, 0)
-        st = gg.addReads(seq, None, off, 3)
-        assert_same_state(og, gg, pairs=False)
+        o_st = og.add_reads(seq, None, off, 3, rbo.STORE_READ_PAIRS if pairs else 0)
+        st = gg.addReads(seq, None, off, 3, storeReadPairedKmers=pairs)
+        assert_same_state(og, gg, pairs=pairs)
         assert st.kmers == o_st.kmers
         tot.append((st.kmers, st.sorted_kmers))
     assert tot[0][1] == tot[0][0], tot
