@@ -2184,7 +2184,8 @@ void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, ui
         RB_HIP(hipStreamSynchronize(s));
         uint32_t n_present = 0;
         for (int q = 0; q < 32; ++q) { n_foreign += spread[16 * q]; n_present += spread[16 * q + 2]; }
-        g->last_present_frac = (float)n_present / (float)D;      // (0 on the generic probe kernel's path, which does not count them)
+        const bool counted = !(uses_dbg && full_table) && fv.dbg_h == 2 && fv.cbf_h == 2 && !getenv("RB_PROBE_GENERIC");
+        g->last_present_frac = counted ? (float)n_present / (float)D : -1.0f;      // (-1: the generic probe kernel does not count them)
     }
     if (getenv("RB_DEBUG") && swept) fprintf(stderr, "[rb] swept stage: %u runs (%u of oversized buckets), %u contested counters\n", D, D - std::min(D, GS.n_main), n_foreign);
     g->prof_end("probe_claim");
@@ -2538,8 +2539,16 @@ void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigne
                 }
                 for (int q = 0; q < 32; ++q) sb.total += spread[16 * q];
                 const bool pf_force = getenv("RB_PF_SKIP") && atoi(getenv("RB_PF_SKIP")) == 2;       // (tests: sub-batches of any size count)
-                if (sb.total >= (pf_force ? 1 : ((int64_t)1 << 26)) && (double)sb.N >= 0.97 * (double)sb.total) { if (++g->pf_streak >= 2) { g->pf_skip_left = 15; g->pf_streak = 1; } }
-                else g->pf_streak = 0;               // (a small sub-batch says nothing: a cold cache drops nothing either)
+                // (a small sub-batch says nothing; and a COLD cache drops nothing either — the first sub-batches of a deep short-read library keep
+                // everything too, but there most k-mers are seen again at once: the consumer must have found under 0.3 of the last sub-batch's
+                // k-mers present (0.16 on the long reads this is for; over 0.5 from the second sub-batch of config 2 on), or the walk stays)
+                const bool mostly_new = pf_force || (g->last_present_frac >= 0.0f && g->last_present_frac < 0.3f);
+                if (sb.total >= (pf_force ? 1 : ((int64_t)1 << 26)) && (double)sb.N >= 0.97 * (double)sb.total && mostly_new) {
+                    if (++g->pf_streak >= 2) {
+                        g->pf_skip_left = 15; g->pf_streak = 1;
+                        if (getenv("RB_DEBUG")) fprintf(stderr, "[rb] prefilter: kept %u of %lld windows, %.2f of the last sub-batch's k-mers were present: the next 15 sub-batches go without the window walk\n", sb.N, (long long)sb.total, g->last_present_frac);
+                    }
+                } else g->pf_streak = 0;
                 if (getenv("RB_WORD_STATS")) {   // development: how many words keep nothing?
                     std::vector<uint32_t> hc((size_t)sb.nw);
                     RB_HIP(hipMemcpy(hc.data(), g->chunk_cnt.p, (size_t)sb.nw * 4, hipMemcpyDeviceToHost));
