@@ -2122,7 +2122,8 @@ void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, ui
     // it wherever it applies, 0 turns it off.
     const rb_graph::GroupSlot &GS = g->slots[g->cur];
     bool swept = false, swept_all = false;       // swept_all: no run of an oversized bucket among them (those probe outside the sweep)
-    if (collide && !ftab && fv.dbg_h == 2 && fv.cbf_h == 2 && !getenv("RB_PROBE_GENERIC") && GS.sweep_T && !g->shard && sweep_wanted(g)) {
+    if (collide && !ftab && fv.dbg_h == 2 && fv.cbf_h == 2 && !getenv("RB_PROBE_GENERIC") && GS.sweep_T && !g->shard && sweep_wanted(g) &&
+        ((uint64_t)g->dbg.size >> GS.sweep_T) < (1ull << 31)) {       // (the sweep counts a range's bits in 32 bits)
         const char *e = getenv("RB_SWEEP");
         // (and most runs new: where the sub-batch before found most of its k-mers present the sweep only rewrites set bits — the plain loads are cheaper)
         swept = (e && atoi(e) == 1) || ((uint64_t)D * 64ull >= (uint64_t)g->dbg.nbytes && g->last_present_frac < 0.5f);

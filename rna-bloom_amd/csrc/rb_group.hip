@@ -1281,7 +1281,7 @@ size_t sweep_temp_bytes(size_t D, uint32_t T) { return group_plan(D, 64, 0, 0, (
 void sweep_bits_device(uint32_t *words, GrIdx idx, uint32_t T, uint64_t kmul, const uint64_t *uniq, uint32_t D, uint32_t n_main, const uint32_t *brun,
                        const uint32_t *bnr, uint64_t *keys_a, uint32_t *vals_a, uint64_t *keys_b, uint32_t *vals_b, void *temp, size_t temp_bytes,
                        uint8_t *st0, uint8_t *st1, hipStream_t st) {
-    RB_REQUIRE(D > 0 && T > 0 && idx.span > (1ull << T), "sweep_bits_device: nothing to sweep by");
+    RB_REQUIRE(D > 0 && T > 0 && idx.span > (1ull << T) && (idx.span >> T) < (1ull << 31), "sweep_bits_device: nothing to sweep by / ranges of 2^31 bits and more");
     const GroupPlan P = group_plan(D, 64, 0, 0, (int)T);
     RB_REQUIRE(P.T == T && temp_bytes >= P.total, "sweep_bits_device: plan / temp mismatch");
     RB_HIP(hipMemsetAsync(st1, 0, D, st));
@@ -1293,7 +1293,7 @@ void sweep_bits_device(uint32_t *words, GrIdx idx, uint32_t T, uint64_t kmul, co
     GrIdxDev ix = gr_idx_dev(P, idx);
     const uint32_t n_big = D - std::min(n_main, D);
     if (n_big) hipLaunchKernelGGL(k_sw_big_pre, dim3((n_big + 255u) / 256u), dim3(256), 0, st, (const uint32_t *)words, idx.mod, idx.lo, uniq, n_main, D, st0);
-    // a round holds a whole range where it fits 64 KB (then: the more workgroups per CU the shorter the ranges — up to four of 512 threads)
+    // a round holds a whole range where it fits 64 KB; LDS is sized to the range (two workgroups per CU either way: 128 VGPRs)
     const uint64_t range_words = (idx.span >> T) / 32 + 16;
     const uint32_t sww = (uint32_t)std::min<uint64_t>(SW_WORDS, (range_words + 1023) / 1024 * 1024);
     RB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep_bits<512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((SW_WORDS + SW_MARKS) * 4)));
