@@ -197,3 +197,7 @@ def test_hot_kernels_keep_their_occupancy_budget():
         assert ks and all(v[1] == 0 for v in ks.values()), (frag, ks)
     ps = pick("k_part_scatterILi512ELi8E")
     assert all(v[0] <= 64 and v[2] <= 53 * 1024 + 512 for v in ps.values()), ps     # three workgroups per CU (DESIGN s5)
+    sw = pick("k_sweep_bitsILi512E")
+    assert sw and all(v[0] <= 128 for v in sw.values()), sw                           # swept Bloom-bit stage: two workgroups of 512 threads per CU (a few spilled registers are the price)
+    so = pick("k_scan_one")
+    assert so and all(v[2] <= 40 * 1024 for v in so.values()), so                      # single-workgroup scans must fit beside three bucket workgroups of 40 KB (DESIGN s5 "Round 4")
