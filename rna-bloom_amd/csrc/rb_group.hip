@@ -223,10 +223,11 @@ __device__ __forceinline__ bool gr_get_tile(const GrTiling &tl, GrTile &t) {
 }
 
 // ---- partition pass: histogram per (digit, tile) -----------------------------------------------------
-template <int TPB>
+// DERIVE (the swept stage's first binning pass): the records are not in memory yet — key = the second hash of the run's hash keys[j], value = j
+template <int TPB, bool DERIVE = false>
 __global__ void __launch_bounds__(TPB) k_part_count(const uint64_t *__restrict__ keys, GrTiling tl, uint32_t shift, uint32_t bits,
                                                     uint32_t *__restrict__ hist, const uint32_t *__restrict__ dead_vals = nullptr,
-                                                    GrIdxDev ix = GrIdxDev{Mod{1, 0, 0}, 0, 0, 0, 0}) {
+                                                    GrIdxDev ix = GrIdxDev{Mod{1, 0, 0}, 0, 0, 0, 0}, uint64_t kmul = 0) {
     constexpr int ITEMS = GR_TILE / TPB;
     __shared__ uint32_t s_h[1u << GR_PART_MAX_BITS];
     GrTile t;
@@ -239,6 +240,7 @@ __global__ void __launch_bounds__(TPB) k_part_count(const uint64_t *__restrict__
     for (int i = 0; i < ITEMS; ++i) {
         const uint32_t j = (uint32_t)i * TPB + threadIdx.x;
         k[i] = j < t.count ? keys[t.start + j] : 0ull;
+        if (DERIVE) k[i] = multi_hash(k[i], 1u, kmul);
     }
 #pragma unroll
     for (int i = 0; i < ITEMS; ++i) {
@@ -251,11 +253,11 @@ __global__ void __launch_bounds__(TPB) k_part_count(const uint64_t *__restrict__
 }
 
 // ---- partition pass: stable scatter ------------------------------------------------------------------
-template <int TPB, int MAXBITS>
+template <int TPB, int MAXBITS, bool DERIVE = false>
 __global__ void __launch_bounds__(TPB) k_part_scatter(const uint64_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in, GrTiling tl,
                                                       uint32_t shift, uint32_t bits, const uint32_t *__restrict__ goffs /* exclusive scan of hist */,
                                                       uint64_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t wide_lds,
-                                                      uint32_t skip_dead = 0u, GrIdxDev ix = GrIdxDev{Mod{1, 0, 0}, 0, 0, 0, 0}) {
+                                                      uint32_t skip_dead = 0u, GrIdxDev ix = GrIdxDev{Mod{1, 0, 0}, 0, 0, 0, 0}, uint64_t kmul = 0) {
     constexpr uint32_t ITEMS = GR_TILE / TPB, NW = TPB / 64, SEG = 64 * ITEMS, MAXNB = 1u << MAXBITS;
     __shared__ uint64_t s_keys[GR_TILE];
     __shared__ uint32_t s_vals[GR_TILE];
@@ -285,6 +287,7 @@ __global__ void __launch_bounds__(TPB) k_part_scatter(const uint64_t *__restrict
         bool ok = j < t.count;
         k[r] = ok ? keys_in[t.start + j] : 0ull;
         v[r] = (ok && vals_in) ? vals_in[t.start + j] : 0u;
+        if (DERIVE) { k[r] = multi_hash(k[r], 1u, kmul); v[r] = t.start + j; }
         if (skip_dead && k[r] == GR_DEAD_KEY && v[r] == GR_DEAD_VAL) ok = false;          // cancelled by the emit pass: not scattered
         dig[r] = ok ? (ix.mul ? gr_idx_digit(k[r], ix, bits) : gr_digit(k[r], shift, bits)) : ~0u;
     }
@@ -908,17 +911,21 @@ template <int TPB>
 static void part_pass(const GrTiling &tl, size_t entries, uint32_t shift, uint32_t bits, const uint64_t *kin, const uint32_t *vin, uint64_t *kout,
                       uint32_t *vout, uint32_t *hist, uint32_t *goffs, void *scan_tmp, size_t scan_bytes, hipStream_t st, rb_graph *prof,
                       uint32_t *n_live_dev = nullptr /* non-null: the pass drops cancelled records and leaves the number of live ones here */,
-                      GrIdxDev ix = GrIdxDev{Mod{1, 0, 0}, 0, 0, 0, 0}) {
+                      GrIdxDev ix = GrIdxDev{Mod{1, 0, 0}, 0, 0, 0, 0}, uint64_t derive_kmul = 0 /* != 0: kin holds run hashes, the records are (second hash, position) */) {
     const dim3 grid(tl.grid_tiles), blk(TPB);
     if (prof) prof->prof_begin(st);
     if (n_live_dev) RB_HIP(hipMemsetAsync(hist + entries, 0, 4, st));        // one entry more: its scanned value is the total
-    hipLaunchKernelGGL(k_part_count<TPB>, grid, blk, 0, st, kin, tl, shift, bits, hist, n_live_dev ? vin : (const uint32_t *)nullptr, ix);
+    if (derive_kmul) hipLaunchKernelGGL((k_part_count<TPB, true>), grid, blk, 0, st, kin, tl, shift, bits, hist, (const uint32_t *)nullptr, ix, derive_kmul);
+    else hipLaunchKernelGGL(k_part_count<TPB>, grid, blk, 0, st, kin, tl, shift, bits, hist, n_live_dev ? vin : (const uint32_t *)nullptr, ix);
     if (prof) { prof->prof_end("group_part_count", st); prof->prof_begin(st); }
     exclusive_scan_u32(scan_tmp, scan_bytes, hist, goffs, entries + (n_live_dev ? 1 : 0), st);
     if (n_live_dev) hipLaunchKernelGGL(k_copy_u32, dim3(1), dim3(64), 0, st, n_live_dev, goffs + entries);
     if (prof) { prof->prof_end("group_scan", st); prof->prof_begin(st); }
     const uint32_t wide = !(getenv("RB_GROUP_WIDE_LDS") && atoi(getenv("RB_GROUP_WIDE_LDS")) == 0);
-    if (bits <= 8u) hipLaunchKernelGGL((k_part_scatter<TPB, 8>), grid, blk, 0, st, kin, vin, tl, shift, bits, goffs, kout, vout, wide, n_live_dev ? 1u : 0u, ix);
+    if (derive_kmul) {
+        if (bits <= 8u) hipLaunchKernelGGL((k_part_scatter<TPB, 8, true>), grid, blk, 0, st, kin, (const uint32_t *)nullptr, tl, shift, bits, goffs, kout, vout, wide, 0u, ix, derive_kmul);
+        else hipLaunchKernelGGL((k_part_scatter<TPB, GR_PART_MAX_BITS, true>), grid, blk, 0, st, kin, (const uint32_t *)nullptr, tl, shift, bits, goffs, kout, vout, wide, 0u, ix, derive_kmul);
+    } else if (bits <= 8u) hipLaunchKernelGGL((k_part_scatter<TPB, 8>), grid, blk, 0, st, kin, vin, tl, shift, bits, goffs, kout, vout, wide, n_live_dev ? 1u : 0u, ix);
     else hipLaunchKernelGGL((k_part_scatter<TPB, GR_PART_MAX_BITS>), grid, blk, 0, st, kin, vin, tl, shift, bits, goffs, kout, vout, wide, n_live_dev ? 1u : 0u, ix);
     if (prof) prof->prof_end("group_part_scatter", st);
 }
@@ -1036,20 +1043,22 @@ static GrIdxDev gr_idx_dev(const GroupPlan &P, const GrIdx &idx) {
 }
 template <int TPB>
 static uint32_t *partition_records(const GroupPlan &P, uint64_t *keys0, uint32_t *vals0, uint64_t *keys_tmp, uint32_t *vals_tmp, char *tp, hipStream_t st,
-                                   rb_graph *prof, GrIdx idx, const uint64_t **kin_out, const uint32_t **vin_out) {
+                                   rb_graph *prof, GrIdx idx, const uint64_t **kin_out, const uint32_t **vin_out,
+                                   const uint64_t *derive_src = nullptr, uint64_t derive_kmul = 0 /* both given: the first pass makes its records from the
+                                   run hashes derive_src[0 .. n) — (second hash, position) — and keys0 / vals0 are scratch like the other pair */) {
     unsigned long long *status = reinterpret_cast<unsigned long long *>(tp + P.off_status);
     uint32_t *ticket = reinterpret_cast<uint32_t *>(tp + P.off_ticket);
     uint32_t *bstart = reinterpret_cast<uint32_t *>(tp + P.off_bstart);
     RB_HIP(hipMemsetAsync(status, 0, P.off_bstart, st));        // status words + ticket
-    const uint64_t *kin = keys0;
-    const uint32_t *vin = vals0;
+    const uint64_t *kin = derive_src ? derive_src : keys0;
+    const uint32_t *vin = derive_src ? nullptr : vals0;
     if (P.T) {
         uint32_t *hist = reinterpret_cast<uint32_t *>(tp + P.off_hist), *goffs = reinterpret_cast<uint32_t *>(tp + P.off_goffs);
         void *scan_tmp = tp + P.off_scan;
         GrTiling t1{nullptr, nullptr, P.n, P.ntiles, gr_grid_for_tiles(P.ntiles), P.xcd_map};
         uint32_t *n_live = P.dead ? ticket + 3 : nullptr;      // (the status / ticket block was zeroed above)
         GrIdxDev ix = gr_idx_dev(P, idx);
-        part_pass<TPB>(t1, (size_t)P.ntiles << P.t_hi, P.shift_hi, P.t_hi, kin, vin, keys_tmp, vals_tmp, hist, goffs, scan_tmp, P.scan_bytes, st, prof, n_live, ix);
+        part_pass<TPB>(t1, (size_t)P.ntiles << P.t_hi, P.shift_hi, P.t_hi, kin, vin, keys_tmp, vals_tmp, hist, goffs, scan_tmp, P.scan_bytes, st, prof, n_live, ix, derive_src ? derive_kmul : 0);
         kin = keys_tmp; vin = vals_tmp;
         uint32_t *segtb = nullptr, *segst = nullptr;
         if (P.t_lo) {
@@ -1152,12 +1161,6 @@ __device__ __forceinline__ uint64_t sw_first(uint32_t c, const GrIdxDev &ix, uin
     while (e > 0ull && sw_digit(e - 1ull, ix) >= c) --e;
     while (e < span && sw_digit(e, ix) < c) ++e;
     return e;
-}
-__global__ void k_sw_emit(const uint64_t *__restrict__ uniq, uint32_t D, uint64_t kmul, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals) {
-    const uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
-    if (d >= D) return;
-    keys[d] = multi_hash(uniq[d], 1u, kmul);
-    vals[d] = d;
 }
 // what a probe reports (st0 / st1): 0 it set the bit and nobody else asked for it; 1 set before the sub-batch; 2 clear before, set by another
 // probe of the sub-batch that got there first; 3 it set the bit and another probe MAY have met it there (marks are per low bits of the index:
@@ -1285,11 +1288,11 @@ void sweep_bits_device(uint32_t *words, GrIdx idx, uint32_t T, uint64_t kmul, co
     const GroupPlan P = group_plan(D, 64, 0, 0, (int)T);
     RB_REQUIRE(P.T == T && temp_bytes >= P.total, "sweep_bits_device: plan / temp mismatch");
     RB_HIP(hipMemsetAsync(st1, 0, D, st));
-    hipLaunchKernelGGL(k_sw_emit, dim3((D + 255u) / 256u), dim3(256), 0, st, uniq, D, kmul, keys_a, vals_a);
+    RB_REQUIRE(kmul != 0, "sweep_bits_device: kmul");
     const uint64_t *k1 = nullptr;
-    const uint32_t *v1 = nullptr;
-    const uint32_t *bstart1 = P.tpb == 512u ? partition_records<512>(P, keys_a, vals_a, keys_b, vals_b, static_cast<char *>(temp), st, nullptr, idx, &k1, &v1)
-                                            : partition_records<256>(P, keys_a, vals_a, keys_b, vals_b, static_cast<char *>(temp), st, nullptr, idx, &k1, &v1);
+    const uint32_t *v1 = nullptr;            // the (h1, run) records are made by the first binning pass itself, from the runs' hashes
+    const uint32_t *bstart1 = P.tpb == 512u ? partition_records<512>(P, keys_a, vals_a, keys_b, vals_b, static_cast<char *>(temp), st, nullptr, idx, &k1, &v1, uniq, kmul)
+                                            : partition_records<256>(P, keys_a, vals_a, keys_b, vals_b, static_cast<char *>(temp), st, nullptr, idx, &k1, &v1, uniq, kmul);
     GrIdxDev ix = gr_idx_dev(P, idx);
     const uint32_t n_big = D - std::min(n_main, D);
     if (n_big) hipLaunchKernelGGL(k_sw_big_pre, dim3((n_big + 255u) / 256u), dim3(256), 0, st, (const uint32_t *)words, idx.mod, idx.lo, uniq, n_main, D, st0);
