@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(256) k_probe_h2(FilterView fv, const uint64_t 
 #pragma unroll
     for (int r = 0; r < RUNS; ++r) {
         live[r] = d0 + r < n_distinct;
-        h0[r] = live[r] ? uniq[d0 + r] : 0ull;
+        h0[r] = (live[r] && !SWEPT) ? uniq[d0 + r] : 0ull;     // (swept: only the runs that claim need their hash, below)
         cnt[r] = live[r] ? counts[d0 + r] : 0u;
     }
     if (!SWEPT) {
@@ -192,7 +192,7 @@ __global__ void __launch_bounds__(256) k_probe_h2(FilterView fv, const uint64_t 
         claim[r] = live[r] && may_count;
         if (SWEPT) {                                           // (most runs of the regime the sweep is for never claim: indices only where needed)
             ci[r][0] = ci[r][1] = 0;
-            if (claim[r]) { ci[r][0] = index_of(h0[r], fv.cbf_mod); ci[r][1] = index_of(multi_hash(h0[r], 1u, fv.kmul), fv.cbf_mod); }
+            if (claim[r]) { h0[r] = uniq[d0 + r]; ci[r][0] = index_of(h0[r], fv.cbf_mod); ci[r][1] = index_of(multi_hash(h0[r], 1u, fv.kmul), fv.cbf_mod); }
         }
         dup[r] = ci[r][0] == ci[r][1];
     }
