@@ -274,9 +274,12 @@ __global__ void k_set_bits(FilterView fv, const uint64_t *__restrict__ uniq, uin
 // colliders register their probe ids ...
 __global__ void k_collide_insert(FilterView fv, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ starts,
                                  const uint32_t *__restrict__ vals, uint32_t n_distinct, const uint32_t *__restrict__ status,
-                                 Slot *ftable, uint32_t f_log2, uint32_t *__restrict__ ffbits, uint32_t ff_log2) {
+                                 Slot *ftable, uint32_t f_log2, uint32_t *__restrict__ ffbits, uint32_t ff_log2,
+                                 const uint32_t *__restrict__ list = nullptr /* the runs to look at, *list_n of them (at most n_distinct), instead of all */,
+                                 const uint32_t *__restrict__ list_n = nullptr) {
     uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= n_distinct) return;
+    if (list) { if (d >= *list_n) return; d = list[d]; }
     const uint32_t st_d = status[d];
     const uint32_t coll = ((st_d >> ST_COLLIDE_SHIFT) & 0xFFu) | ((st_d >> ST_JOIN_SHIFT) & 3u);     // (swept stage: the probe that set the bit joins here, no k_collide_fixup)
     if (!coll) return;
@@ -325,9 +328,11 @@ __device__ __forceinline__ bool set_earlier(const Slot *ftable, uint32_t f_log2,
 __global__ void k_late_claim(FilterView fv, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ starts,
                              const uint32_t *__restrict__ vals, uint32_t n_distinct, const Slot *ftable, uint32_t f_log2,
                              uint32_t *__restrict__ status, uint64_t *__restrict__ cvals, uint64_t *__restrict__ foreign_idx,
-                             uint32_t *__restrict__ counters, FtFilter ff) {
+                             uint32_t *__restrict__ counters, FtFilter ff,
+                             const uint32_t *__restrict__ list = nullptr /* as in k_collide_insert */, const uint32_t *__restrict__ list_n = nullptr) {
     uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= n_distinct) return;
+    if (list) { if (d >= *list_n) return; d = list[d]; }
     uint32_t st = status[d];
     if (!(st & ST_LATE)) return;
     for (int j = 0; j < fv.dbg_h; ++j)
@@ -2122,6 +2127,7 @@ void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, ui
     // it wherever it applies, 0 turns it off.
     const rb_graph::GroupSlot &GS = g->slots[g->cur];
     bool swept = false, swept_all = false;       // swept_all: no run of an oversized bucket among them (those probe outside the sweep)
+    uint32_t *involved = nullptr, n_involved_max = 0;   // swept_all: list of the runs with a probe that met another one (device count in ctr[12]; at most n_involved_max)
     if (collide && !ftab && fv.dbg_h == 2 && fv.cbf_h == 2 && !getenv("RB_PROBE_GENERIC") && GS.sweep_T && !g->shard && sweep_wanted(g) &&
         ((uint64_t)g->dbg.size >> GS.sweep_T) < (1ull << 31)) {       // (the sweep counts a range's bits in 32 bits)
         const char *e = getenv("RB_SWEEP");
@@ -2170,14 +2176,29 @@ void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, ui
                 RB_HIP(hipMemsetAsync(fb, 0, (size_t)1 << (ff_log2 - 3), s));
                 ffl = FtFilter{fb, ff_log2};
             }
+            if (swept_all) {
+                // after the sweep the runs with anything to do here are marked — a few per cent, one or two lanes of most wavefronts, each a chain of
+                // table atomics its whole wavefront waits for: they are listed (a scan, not an atomic counter) and the table kernels walk the list
+                // (k_collide_insert took 2.7 ms of a 390 M-run sub-batch over all runs; the list is the conflict list's buffer, free until stage B's compaction)
+                involved = g->confk.as<uint32_t>(); n_involved_max = n_collide;
+                g->temp.reserve(select_temp_bytes(D));
+                select_flagged(g->temp.p, g->temp.cap, status, (3u << ST_COLLIDE_SHIFT) | (3u << ST_JOIN_SHIFT), D, involved, ctr + 12, s);
+                hipLaunchKernelGGL(k_collide_insert, dim3(blocks_for(std::min(D, n_collide))), dim3(TPB), 0, s, fv, uniq, starts, vals, std::min(D, n_collide), status, ftab, f_log2,
+                                   const_cast<uint32_t *>(ffl.bits), ffl.log2, (const uint32_t *)involved, (const uint32_t *)(ctr + 12));
+            } else
             hipLaunchKernelGGL(k_collide_insert, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, uniq, starts, vals, D, status, ftab, f_log2,
                                const_cast<uint32_t *>(ffl.bits), ffl.log2);
             if (!swept_all) hipLaunchKernelGGL(k_collide_fixup, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, uniq, starts, vals, D, status, ftab, f_log2, ffl);
         }
     }
-    if (mode == M_ADD)
+    if (mode == M_ADD) {
+        if (swept_all) {      // only a run with a marked probe can find its bits set earlier: the list again (nothing at all where no two probes met)
+            if (involved) hipLaunchKernelGGL(k_late_claim, dim3(blocks_for(std::min(D, n_involved_max))), dim3(TPB), 0, s, fv, uniq, starts, vals, std::min(D, n_involved_max), ftab, f_log2,
+                                             status, g->cvals.as<uint64_t>(), g->foreign.as<uint64_t>(), ctr, ffl, (const uint32_t *)involved, (const uint32_t *)(ctr + 12));
+        } else
         hipLaunchKernelGGL(k_late_claim, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, uniq, starts, vals, D, ftab, f_log2,
                            status, g->cvals.as<uint64_t>(), g->foreign.as<uint64_t>(), ctr, ffl);
+    }
     uint32_t n_foreign = 0;
     {
         uint32_t spread[16 * 32];
