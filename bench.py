@@ -8,7 +8,10 @@ generated on the device before the timed region and stay resident in HBM (packed
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--pairs P] [--genome G] [--nk NK]
 
-For N>1 launch through torch.distributed.run (one rank per GPU): reads are data-parallel, every filter
+N>1: one rank per GPU.  Launched as `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` the
+script is a rank (RANK / WORLD_SIZE in the environment); launched plainly as `python bench.py --gpus N` it starts
+those N ranks itself (spawn_ranks: the same torch.distributed.run command on 127.0.0.1 with a free port) and hands
+their output through, so both forms print the same one line.  Reads are data-parallel, every filter
 is sharded by index range and a k-mer belongs to the rank that holds its first counter; records / probes /
 replies / counter writes travel by RCCL send/recv groups inside the library (csrc/rb_comm.hip, csrc/rb_shard.hip;
 RB_SHARD_DRIVER=torch: all_to_all through rnabloom/sharded.py).  The job (total read pairs) is
@@ -179,17 +182,43 @@ def parse():
     return ap.parse_args()
 
 
+def spawn_ranks(a):
+    """`python bench.py --gpus N` without a launcher around it: become the launcher.  The N ranks are started exactly as the
+    driver's own command starts them (torch.distributed.run, one node, 127.0.0.1, a free port); rank 0's JSON line is the
+    last line of their common stdout, which is this process's stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs between processes on this driver
+    env.setdefault("OMP_NUM_THREADS", "8")
+    sys.stdout.flush()
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     a = parse()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(a))
     import torch
     import torch.distributed as dist
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        # a launcher's world size is the number of ranks that exist; --gpus must say the same or the line would lie about n_gpus
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N ranks with --gpus N, or plain `python bench.py --gpus N`)" % (a.gpus, world))
     backend = os.environ.get("RB_BENCH_BACKEND", "nccl")     # "gloo": several ranks on ONE GPU (functional check of this script)
     if backend != "nccl":
         local %= max(1, torch.cuda.device_count())
+    elif local >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d needs GPU %d, this node shows %d (RB_BENCH_BACKEND=gloo runs several ranks on one GPU as a functional check)"
+                         % (rank, local, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     sharded_mode = world > 1 or a.force_sharded
     if sharded_mode:

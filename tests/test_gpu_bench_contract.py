@@ -53,6 +53,13 @@ def test_single_gpu_line_and_two_rank_line():
     assert j2["n_gpus"] == 2 and j2["scaling"] == "strong" and j2["value"] > 0
     assert j2["config"]["kmers_per_step"] == j["config"]["kmers_per_step"], "both engines insert the same k-mers"
     assert "cpu_baseline" not in j2
+    # the plain form: `python bench.py --gpus 2` with no launcher around it starts its two ranks itself and prints the same line
+    env.pop("WORLD_SIZE", None); env.pop("RANK", None); env.pop("LOCAL_RANK", None)
+    r3 = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--no-cpu-baseline"] + SMALL, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r3.returncode == 0, r3.stderr[-3000:]
+    j3 = last_json(r3.stdout)
+    assert r3.stdout.strip().splitlines()[-1].startswith("{"), "the JSON line must be the last line"
+    assert j3["n_gpus"] == 2 and j3["scaling"] == "strong" and j3["config"]["kmers_per_step"] == j["config"]["kmers_per_step"]
 
 
 def test_force_sharded_line_goes_through_the_native_rccl_driver_by_default():
