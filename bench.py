@@ -81,8 +81,19 @@ def algorithmic_bytes(stage, n_kmers, n_pairs, n_runs, words, n_sorted=None, gro
 PMC_KERNELS = {"filter_windows": "rb::k_filter_reads", "hash_windows": "rb::k_hash_windows_resume",
                "probe_claim": "k_probe", "resolve_apply": "k_resolve_apply", "pairs_insert": "k_pairs_reads",
                "group_part_count": "rb::k_part_count", "group_part_scatter": "rb::k_part_scatter", "group_buckets": "rb::k_group_buckets"}
-PMC_TAG = next((t for t in ("r04", "r03") if os.path.exists(os.path.join(ROOT, "profiles", t + "_pmc_fetch_size.csv"))), "r04")
+PMC_TAG = next((t for t in ("r05", "r04", "r03") if os.path.exists(os.path.join(ROOT, "profiles", t + "_pmc_fetch_size.csv"))), "r05")
 PMC_FILES = (PMC_TAG + "_pmc_fetch_size.csv", PMC_TAG + "_pmc_write_size.csv")
+
+
+def pmc_meta():
+    """Which tree the committed PMC summaries profiled: profiles/<tag>_pmc_meta.json, written by tools/final_profile.sh on the box that ran
+    the passes ({"csrc_id": tools/csrc_id.py of that tree = rb_build_id() of its library, "git_head": ...}).  Summaries without the file
+    (rounds 1-4) have no known tree."""
+    try:
+        with open(os.path.join(ROOT, "profiles", PMC_TAG + "_pmc_meta.json")) as fh:
+            return json.load(fh)
+    except (OSError, ValueError):
+        return {}
 # Correction of FETCH_SIZE (MI355X_MICROARCH.md, HBM / rocprofv3 section: the counter tallies 128-byte requests of wide
 # coalesced streaming reads as 64 bytes; "other access widths are uncalibrated: calibrate on a known byte count in your
 # own access pattern").  Calibration committed in profiles/r03_pmc_calibration.txt: (1) k_part_count reads exactly 8 bytes per
@@ -347,20 +358,26 @@ def main():
             words //= world
         per_stage, per_stage_gb = {}, {}
         default_cfg = (a.pairs, a.genome, a.nk, a.k, a.batch_kmers, sharded_mode) == (50_000_000, 64_000_000, 450_000_000, 25, 0, False)
+        # counter bytes are quoted only beside the code they were counted on: the PMC summaries' csrc id must be this library's
+        meta = pmc_meta()
+        build_id = (N.lib.rb_build_id() or b"").decode()
+        pmc_ok = default_cfg and bool(build_id) and meta.get("csrc_id") == build_id
         for name, (ms, launches) in prof.items():
             ab = algorithmic_bytes(name, kmers, pairs_ins, distinct, words, n_sorted, sharded=sharded_mode, k=k)
             if ab and ms > 0:
                 per_stage[name] = round(ab / (ms * 1e-3) / 1e9, 1)
-                cb = pmc_step_bytes(name) if default_cfg else None
+                cb = pmc_step_bytes(name) if pmc_ok else None
                 per_stage_gb[name] = {"model": round(ab / a.steps / 1e9, 1), "counters": round(cb / 1e9, 1) if cb else None}
         if dom_launches:
             ab = algorithmic_bytes(dom_name, kmers, pairs_ins, distinct, words, n_sorted, sharded=sharded_mode, k=k)
             if ab:
                 achieved = ab / (dom_ms * 1e-3) / 1e9      # = bytes per launch / average launch duration
-                traffic = pmc_traffic(dom_name) if default_cfg else None      # the PMC passes profiled exactly this command
+                traffic = pmc_traffic(dom_name) if pmc_ok else None      # the PMC passes profiled exactly this command on exactly this code
                 roof = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                         "traffic_source": "profiles/%s_pmc_{fetch,write}_size.csv (separate rocprofv3 --pmc passes of this command), bytes per kernel launch, FETCH_SIZE x %.0f (calibration: profiles/%s_pmc_calibration.txt)" % (PMC_TAG, FETCH_FACTOR.get(dom_name, 1.0), PMC_TAG) if traffic else None,
+                        "traffic_commit": meta.get("git_head"), "traffic_csrc_id": meta.get("csrc_id"), "build_csrc_id": build_id,
+                        "traffic_withheld": None if (pmc_ok or not default_cfg) else "the committed PMC summaries (profiles/%s_pmc_*) were counted on kernel sources %s, this library is %s: traffic, path_frac and the counters column are left out rather than mixed with this run's times" % (PMC_TAG, meta.get("csrc_id", "of an unrecorded tree"), build_id),
                         "note": "dominant stage by HIP-event time on its own stream; achieved = model bytes / measured time, traffic = counters",
                         "algorithmic_bytes_per_launch": int(ab / dom_launches),
                         "avg_launch_ms": round(dom_ms / dom_launches, 3), "launches": dom_launches,
@@ -368,7 +385,7 @@ def main():
                         "all_stages_GB_per_step": per_stage_gb}     # model bytes beside the counters' (committed PMC passes)
                 # the PATH's roofline, not only the dominant kernel's: every HBM byte the counters saw in a step (all kernels) over the
                 # step's wall time; and how much of that is the prefilter cache deciding to DROP occurrences (bytes this design added)
-                pb = pmc_path_bytes() if default_cfg else None
+                pb = pmc_path_bytes() if pmc_ok else None
                 if pb:
                     streamed = 16.0 * words / a.steps                 # the packed reads the prefilter walks anyway
                     roof["path_bytes_per_step"] = int(pb[0])

@@ -78,6 +78,9 @@ typedef struct rb_add_stats {
 
 const char *rb_last_error(void); /* thread-local message of the last failing call */
 int rb_version(void);
+/* 16 hex digits identifying the kernel sources this library was built from (tools/csrc_id.py); no reference counterpart:
+ * bench.py uses it to tie committed rocprofv3 counter summaries to the code they profiled */
+const char *rb_build_id(void);
 
 /* ---- graph lifetime: ctor :75-104, destroyXxx / clearXxx :332-350 (explicit off-heap lifetime,
  *      R/bloom/buffer/UnsafeByteBuffer.java:44,152-155) ---- */

@@ -1002,20 +1002,45 @@ __device__ __forceinline__ bool bits_lookup(const uint32_t *bits, const Mod &mod
 // contribute nothing (FragmentsToGraphWorker adds fragment pairs only where read pairs could start).  present: when
 // set, a pair is added only if both of its k-mers are in dbgbf (PairedKmersToGraphWorker with existingKmersOnly,
 // R/RNABloom.java:466-482: graph.contains(lHashVals) && graph.contains(rHashVals)).
-template <int MODE, int PAIR_WORDS>
+//
+// VAR — what happens to a pair's bit indices — is a template parameter (0: set the bits, 1: set them unless the SEEN-PAIR CACHE knows the
+// pair, 2: write the indices out), never a run-time branch inside the roll loop (see k_pairs_insert above and
+// tests/test_capi_symbols.py::test_no_kernel_picks_its_store_target_at_run_time_inside_a_loop).
+//
+// The seen-pair cache (VAR 1; BitFilter::seen).  At 191x coverage a step adds 943 M pairs that are sightings of ~50 M distinct ones: two
+// random line requests each for bits that are set already, 1.9 G requests at the device's random-line rate (37 ms, and the kernels that
+// run beside the walker pay again).  rpkbf.add is idempotent, so a pair that is KNOWN to be in the filter can be skipped: a table of
+// buckets of 16 pair hashes (128 bytes), an entry = "both bits of this pair hash have been set in this filter since it was last cleared"
+// (written after the bit_set calls; 64-bit compare, so a match is exact; entries stay true for ever: bits are never cleared without the
+// cache — BitFilter::seen is reset with the bits).  What makes it cheaper than the probes is the bucket function: consecutive pairs of a
+// read must share a bucket, and a pair must find the same bucket from whichever read it is seen in.  So the bucket is a function of the
+// pair's LEFT k-mer alone: the latest ANCHOR among its m-mers (m = min(16, k); an m-mer whose mixed canonical hash has its low two bits
+// clear: one in four), the k-mer's last m-mer if it has none — rolled along with the left window, one multiply per step.  A run of ~4
+// consecutive pairs shares an anchor: one 128-byte fetch into the lane's LDS image (entry e of lane l at [e][l]: conflict-free) per run
+// instead of 2 line requests per pair; a pair may sit in slot P & 15 or (P >> 4) & 15.  Stale or lost entries (races between lanes, L2
+// copies of another XCD) only cost the probes they would have saved.
+template <int MODE, int PAIR_WORDS, int VAR>
 __global__ void __launch_bounds__(64)
 k_pairs_reads(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid, const uint32_t *__restrict__ woff,
               const uint32_t *__restrict__ len, int64_t r0, int64_t nr, int64_t w0, int k, int dist, uint32_t *bits, Mod mod,
               int num_hash, uint64_t kmul, unsigned long long *__restrict__ n_pairs, const uint32_t *__restrict__ chunk_off,
-              uint64_t *__restrict__ out_idx, uint32_t min_len, const uint32_t *__restrict__ present, Mod present_mod, int present_h) {
+              uint64_t *__restrict__ out_idx, uint32_t min_len, const uint32_t *__restrict__ present, Mod present_mod, int present_h,
+              PairSeen seen) {
     __shared__ uint64_t s_tf[25], s_tr[25];
+    __shared__ uint64_t s_mf[VAR == 1 ? 25 : 1], s_mr[VAR == 1 ? 25 : 1];
+    __shared__ unsigned long long s_img[VAR == 1 ? 16 * 64 : 1];
     const uint32_t uk = (uint32_t)k, ud = (uint32_t)dist, span = uk + ud;
+    const uint32_t um = uk < 16u ? uk : 16u;                          // m-mer of the bucket function (VAR 1)
     if (threadIdx.x < 25) {
         const uint32_t o = threadIdx.x / 5u, in = threadIdx.x % 5u;   // 0 = null, 1..4 = A,C,G,T
         const uint64_t so = o ? seed_of(o - 1u) : 0ull, si = in ? seed_of(in - 1u) : 0ull;
         const uint64_t sco = o ? seed_of(4u - o) : 0ull, sci = in ? seed_of(4u - in) : 0ull;
         s_tf[threadIdx.x] = rotl(so, uk) ^ si;
         s_tr[threadIdx.x] = rotr(sco, 1) ^ rotl(sci, uk - 1u);
+        if (VAR == 1) {
+            s_mf[threadIdx.x] = rotl(so, um) ^ si;
+            s_mr[threadIdx.x] = rotr(sco, 1) ^ rotl(sci, um - 1u);
+        }
     }
     __syncthreads();
     const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
@@ -1059,6 +1084,8 @@ k_pairs_reads(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ v
             const uint32_t nsteps = L - ud;
             const int64_t wrel = (int64_t)wr - w0;                  // the read's first word, relative to w0 (out_idx mode)
             uint32_t obase = 0, ocnt = 0, oword = 0xFFFFFFFFu;
+            uint64_t fM = 0, rM = 0;                                 // VAR 1: the left stream's m-mer, its mixed hash, the latest anchor
+            uint32_t akey = 0, apos1 = 0, xnew = 0, curb = 0xFFFFFFFFu;
 #pragma nounroll
             for (uint32_t j = 0; j < nsteps; ++j) {
                 const uint32_t e = ud + j;                            // base entering the right window
@@ -1078,6 +1105,15 @@ k_pairs_reads(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ v
                     const uint32_t out5 = ((uint32_t)(hvL >> sh_v) & 1u) ? ((uint32_t)((far ? hcL2 : hcL) >> sh_c) & 3u) + 1u : 0u;
                     const uint32_t tt = out5 * 5u + in5;
                     fL = rotl(fL, 1) ^ s_tf[tt]; rL = rotr(rL, 1) ^ s_tr[tt];
+                    if (VAR == 1) {       // the m-mer that ends at base j (starts at j + 1 - m), mixed; an anchor if its low two bits are clear
+                        const uint32_t om5 = ((uint32_t)(hvL >> (um - 1u)) & 1u) ? ((uint32_t)(hcL >> (2u * (um - 1u))) & 3u) + 1u : 0u;
+                        const uint32_t tm = om5 * 5u + in5;
+                        fM = rotl(fM, 1) ^ s_mf[tm]; rM = rotr(rM, 1) ^ s_mr[tm];
+                        uint64_t x = (fM < rM ? fM : rM) * 0xff51afd7ed558ccdull;
+                        x ^= x >> 33;
+                        xnew = (uint32_t)(x >> 4);
+                        if (((uint32_t)x & seen.amask) == 0u && j + 1u >= um) { akey = xnew; apos1 = j + 2u - um; }
+                    }
                     hcL2 = (hcL2 << 2) | (hcL >> 62); hcL = (hcL << 2) | codeL; hvL = (hvL << 1) | okL;
                 }
                 lb = okR ? lb : e + 1u;
@@ -1094,11 +1130,36 @@ k_pairs_reads(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ v
                         if (MODE == 0) P = combine(fL, fR);                 // PairedNTHashIterator.java:69
                         else if (MODE == 2) P = combine(rR, rL);            // ReverseComplementPaired… :44
                         else P = smin(combine(fL, fR), combine(rR, rL));    // CanonicalPaired… :44 (signed min)
-                        if (out_idx) {
+                        if (VAR == 2) {
                             if ((p >> 5) != oword) { oword = p >> 5; obase = chunk_off[wrel + (int64_t)oword]; ocnt = 0; }
                             for (int h = 0; h < num_hash; ++h)
                                 out_idx[((size_t)obase + ocnt) * (size_t)num_hash + h] = index_of(multi_hash(P, (uint32_t)h, kmul), mod);
                             ++ocnt;
+                        } else if (VAR == 1) {
+                            // bucket of the left k-mer [p, p + k): its latest anchor (start >= p), else its last m-mer
+                            const uint32_t bk = (apos1 > p ? akey : xnew) & seen.mask;
+                            if (bk != curb) {                         // fetch the bucket into this lane's column of the image
+                                curb = bk;
+                                const uint4 *src = reinterpret_cast<const uint4 *>(seen.tab + ((size_t)bk << 4));
+                                uint4 v[8];
+#pragma unroll
+                                for (int q = 0; q < 8; ++q) v[q] = src[q];
+#pragma unroll
+                                for (int q = 0; q < 8; ++q) {
+                                    s_img[(2 * q) * 64 + threadIdx.x] = (unsigned long long)v[q].x | ((unsigned long long)v[q].y << 32);
+                                    s_img[(2 * q + 1) * 64 + threadIdx.x] = (unsigned long long)v[q].z | ((unsigned long long)v[q].w << 32);
+                                }
+                            }
+                            const uint32_t sa = (uint32_t)P & 15u, sb0 = ((uint32_t)P >> 4) & 15u, sb = sb0 == sa ? (sa ^ 1u) : sb0;
+                            const unsigned long long ea = s_img[sa * 64u + threadIdx.x], eb = s_img[sb * 64u + threadIdx.x];
+                            if (P == 0ull || (ea != P && eb != P)) {
+                                for (int h = 0; h < num_hash; ++h) bit_set(bits, index_of(multi_hash(P, (uint32_t)h, kmul), mod));
+                                if (P != 0ull) {                      // the entry follows the bits
+                                    const uint32_t sl = ea == 0ull ? sa : (eb == 0ull ? sb : sa);
+                                    s_img[sl * 64u + threadIdx.x] = P;
+                                    seen.tab[((size_t)bk << 4) + sl] = P;
+                                }
+                            }
                         } else {
                             for (int h = 0; h < num_hash; ++h) bit_set(bits, index_of(multi_hash(P, (uint32_t)h, kmul), mod));
                         }
@@ -1864,12 +1925,18 @@ static void launch_pairs_reads(rb_graph *g, const rb_batch *b, int64_t w0, int64
     if (r1 <= r0) return;
     dim3 gr(blocks_for(r1 - r0, 64)), th(64);
     const uint32_t *present = if_present ? g->dbg.bits : nullptr;
-#define RB_LAUNCH_PR(M, NW)                                                                                              \
-    hipLaunchKernelGGL((k_pairs_reads<M, NW>), gr, th, 0, st, b->codes, b->valid, b->woff, b->len, r0, r1 - r0, w0, g->k, \
-                       dist, f.bits, f.mod, f.num_hash, kmul_of(g->k), pc, chunk_off, out_idx, min_len, present, g->dbg.mod, g->dbg.num_hash)
+    // the seen-pair cache serves plain adds into the filter it belongs to (a gated add counts the pairs that pass the gate: it probes anyway)
+    const bool use_seen = f.seen && !out_idx && !present;
+    static const uint32_t anchor_bits = getenv("RB_PAIR_SEEN_ANCHOR") ? (uint32_t)std::max(0, std::min(4, atoi(getenv("RB_PAIR_SEEN_ANCHOR")))) : 2u;
+    const PairSeen seen{use_seen ? f.seen : nullptr, use_seen ? (1u << f.seen_log2b) - 1u : 0u, (1u << anchor_bits) - 1u};
+#define RB_LAUNCH_PR3(M, NW, V)                                                                                          \
+    hipLaunchKernelGGL((k_pairs_reads<M, NW, V>), gr, th, 0, st, b->codes, b->valid, b->woff, b->len, r0, r1 - r0, w0, g->k, \
+                       dist, f.bits, f.mod, f.num_hash, kmul_of(g->k), pc, chunk_off, out_idx, min_len, present, g->dbg.mod, g->dbg.num_hash, seen)
+#define RB_LAUNCH_PR(M, NW) do { if (out_idx) RB_LAUNCH_PR3(M, NW, 2); else if (use_seen) RB_LAUNCH_PR3(M, NW, 1); else RB_LAUNCH_PR3(M, NW, 0); } while (0)
     if (b->max_len <= 384u) { if (mode_hash == 0) RB_LAUNCH_PR(0, 12); else if (mode_hash == 2) RB_LAUNCH_PR(2, 12); else RB_LAUNCH_PR(1, 12); }
     else { if (mode_hash == 0) RB_LAUNCH_PR(0, 32); else if (mode_hash == 2) RB_LAUNCH_PR(2, 32); else RB_LAUNCH_PR(1, 32); }
 #undef RB_LAUNCH_PR
+#undef RB_LAUNCH_PR3
 }
 
 void rb::launch_pairs(rb_graph *g, const rb_batch *b, int64_t w0, int64_t nw, int mode_hash, const uint32_t *chunk_off,
@@ -1993,6 +2060,21 @@ uint32_t rb::group_records(rb_graph *g, size_t N, uint64_t ordinal0, uint32_t po
 namespace {
 
 }  // namespace
+// empty(): the filters of config 2 and the prefilter cache are 14.7 GB; the runtime's fill kernel writes them at 1.7 TB/s, plain
+// 16-byte stores from every CU at about twice that
+__global__ void __launch_bounds__(256) k_zero16(uint4 *__restrict__ p, size_t n16) {
+    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p[i] = z;
+}
+static void fast_zero(void *p, size_t bytes, hipStream_t s) {
+    if (!p || !bytes) return;
+    if (bytes < ((size_t)64 << 20) || (reinterpret_cast<uintptr_t>(p) & 15u)) { RB_HIP(hipMemsetAsync(p, 0, bytes, s)); return; }
+    const size_t n16 = bytes / 16;
+    hipLaunchKernelGGL(k_zero16, dim3(256 * 16), dim3(256), 0, s, static_cast<uint4 *>(p), n16);
+    RB_HIP(hipGetLastError());
+    if (bytes & 15u) RB_HIP(hipMemsetAsync(static_cast<char *>(p) + n16 * 16, 0, bytes & 15u, s));
+}
+
 void rb::alloc_bits(BitFilter &f, int64_t bits, int num_hash, int64_t lo, int64_t hi) {
     f.size = bits;
     f.lo = lo; f.hi = hi;
@@ -2075,7 +2157,23 @@ void *rb::alloc_best_placed(size_t bytes, const char *what) {
     return best;
 }
 
-void rb::free_bits(BitFilter &f) { if (f.bits) (void)hipFree(f.bits); f = BitFilter(); }
+void rb::free_bits(BitFilter &f) { if (f.bits) (void)hipFree(f.bits); if (f.seen) (void)hipFree(f.seen); f = BitFilter(); }
+// Seen-pair cache (k_pairs_reads): one 128-byte bucket of 16 pair hashes per 512 filter bits, 2^8 .. 2^24 buckets (config 2: 2 GB beside
+// the 1.07 GB filter); RB_PAIR_SEEN=0 none, RB_PAIR_SEEN=<log2 buckets> that many.
+void rb::alloc_pair_seen(BitFilter &f) {
+    if (!f.bits || f.seen) return;
+    uint32_t lb = std::max(8u, std::min(24u, log2_ceil((uint64_t)std::max<int64_t>(f.size / 512, 1))));
+    if (const char *e = getenv("RB_PAIR_SEEN")) { const int v = atoi(e); if (v <= 0) return; lb = (uint32_t)std::max(4, std::min(26, v)); }
+    size_t fr = 0, tot = 0;
+    if (hipMemGetInfo(&fr, &tot) == hipSuccess && ((size_t)128 << lb) > fr / 4) return;          // a hint, never at the expense of the filters
+    if (hipMalloc(&f.seen, (size_t)128 << lb) != hipSuccess) { (void)hipGetLastError(); f.seen = nullptr; return; }
+    RB_HIP(hipMemset(f.seen, 0, (size_t)128 << lb));
+    RB_HIP(hipDeviceSynchronize());
+    f.seen_log2b = lb;
+}
+void rb::seen_reset(BitFilter &f, hipStream_t s) {
+    if (f.seen) fast_zero(f.seen, (size_t)128 << f.seen_log2b, s);
+}
 namespace {
 
 
@@ -2865,7 +2963,7 @@ int rb_graph_create(const rb_graph_params *p, rb_graph **out) {
         g->cbf_h = p->cbf_num_hash;
         g->cbf_mod = make_mod((uint64_t)p->cbf_bytes);
         g->cbf = static_cast<uint8_t *>(rb::alloc_best_placed(g->cbf_alloc, "cbf"));
-        if (p->use_read_paired_kmers) alloc_bits(g->rpk, p->pkbf_bits, p->pkbf_num_hash, 0, p->pkbf_bits);
+        if (p->use_read_paired_kmers) { alloc_bits(g->rpk, p->pkbf_bits, p->pkbf_num_hash, 0, p->pkbf_bits); alloc_pair_seen(g->rpk); }
         {   // no-op prefilter cache: one 8-byte entry per ~64 counters, 2^16..2^28 entries (8-way buckets fill well: 2^27 entries hold the 64 M hot k-mers of config 2 as completely as 2^28)
             const char *e = getenv("RB_NPF");
             uint32_t l2 = log2_ceil((uint64_t)std::max<int64_t>(p->cbf_bytes / 64, 1));
@@ -2940,21 +3038,6 @@ int rb_graph_destroy(rb_graph *g) {
     return RB_OK;
 }
 
-// empty(): the filters of config 2 and the prefilter cache are 14.7 GB; the runtime's fill kernel writes them at 1.7 TB/s, plain
-// 16-byte stores from every CU at about twice that
-__global__ void __launch_bounds__(256) k_zero16(uint4 *__restrict__ p, size_t n16) {
-    const uint4 z = make_uint4(0u, 0u, 0u, 0u);
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += (size_t)gridDim.x * blockDim.x) p[i] = z;
-}
-static void fast_zero(void *p, size_t bytes, hipStream_t s) {
-    if (!p || !bytes) return;
-    if (bytes < ((size_t)64 << 20) || (reinterpret_cast<uintptr_t>(p) & 15u)) { RB_HIP(hipMemsetAsync(p, 0, bytes, s)); return; }
-    const size_t n16 = bytes / 16;
-    hipLaunchKernelGGL(k_zero16, dim3(256 * 16), dim3(256), 0, s, static_cast<uint4 *>(p), n16);
-    RB_HIP(hipGetLastError());
-    if (bytes & 15u) RB_HIP(hipMemsetAsync(static_cast<char *>(p) + n16 * 16, 0, bytes & 15u, s));
-}
-
 int rb_graph_clear(rb_graph *g, unsigned which_mask) {
     return guarded([&] {
         RB_REQUIRE(g, "rb_graph_clear: null graph");
@@ -2962,7 +3045,7 @@ int rb_graph_clear(rb_graph *g, unsigned which_mask) {
         RB_HIP(hipSetDevice(g->p.device));
         if ((which_mask & 1u) && g->dbg.bits) fast_zero(g->dbg.bits, g->dbg.alloc, g->stream);
         if ((which_mask & 2u) && g->cbf) fast_zero(g->cbf, g->cbf_alloc, g->stream);
-        if ((which_mask & 4u) && g->rpk.bits) fast_zero(g->rpk.bits, g->rpk.alloc, g->stream);
+        if ((which_mask & 4u) && g->rpk.bits) { fast_zero(g->rpk.bits, g->rpk.alloc, g->stream); seen_reset(g->rpk, g->stream); }
         if ((which_mask & 4u) && g->shard) rb::shard_clear_pairs_acc(g);
         if ((which_mask & 8u) && g->fpk.bits) fast_zero(g->fpk.bits, g->fpk.alloc, g->stream);
         if ((which_mask & 3u) && g->npf_log2) fast_zero(g->npf.p, sizeof(uint64_t) << g->npf_log2, g->stream);   // cache entries speak about dbgbf + cbf
@@ -4248,6 +4331,8 @@ int rb_filter_import(rb_graph *g, int which, const void *srcp, size_t nbytes) {
         if (g->npf_log2 && (which == RB_CBF || which == RB_DBGBF)) RB_HIP(hipMemset(g->npf.p, 0, sizeof(uint64_t) << g->npf_log2));
         if (g->mpf_log2b && (which == RB_CBF || which == RB_DBGBF)) RB_HIP(hipMemset(g->mpf.p, 0, (size_t)128 << g->mpf_log2b));
         if (g->rst_log2 && (which == RB_CBF || which == RB_DBGBF)) RB_HIP(hipMemset(g->rst.p, 0, sizeof(uint64_t) << g->rst_log2));
+        if (which != RB_CBF) seen_reset(*bit_filter(g, which), g->stream);      // the bits are replaced: what the seen-pair cache knew is void
+        RB_HIP(hipStreamSynchronize(g->stream));
         RB_HIP(hipMemset(dst, 0, alloc));
         RB_HIP(hipMemcpy(dst, srcp, have, hipMemcpyHostToDevice));
         RB_HIP(hipDeviceSynchronize());
@@ -4325,6 +4410,7 @@ int rb_cbf_to_bloom(rb_graph *src, float min_cov, rb_graph *dst, int which) {
         const int64_t words = (src->cbf_size + 31) / 32;
         hipLaunchKernelGGL(k_cbf_to_bits, dim3(blocks_for(words)), dim3(TPB), 0, src->stream, src->cbf, src->cbf_size, min_cov, f->bits);
         RB_HIP(hipGetLastError());
+        seen_reset(*f, src->stream);                 // every word of the filter was rewritten
         RB_HIP(hipStreamSynchronize(src->stream));
         if (which == RB_DBGBF) {
             if (dst->npf_log2) RB_HIP(hipMemset(dst->npf.p, 0, sizeof(uint64_t) << dst->npf_log2));

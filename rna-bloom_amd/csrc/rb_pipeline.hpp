@@ -27,6 +27,16 @@ struct BitFilter {
     int num_hash = 0;
     Mod mod{1, 0, 0};
     int64_t lo = 0, hi = 0;   // index range held locally ([0,size) unless sharded)
+    // seen-pair cache of a paired-k-mer filter (k_pairs_reads, rb_graph.hip): 2^seen_log2b buckets of 16 pair hashes whose bits are known
+    // to be set in `bits`.  Not part of the filter's state: whatever clears or replaces `bits` clears it (zero_bits / seen_reset).
+    unsigned long long *seen = nullptr;
+    uint32_t seen_log2b = 0;
+};
+// what the pair walker gets of it (by value)
+struct PairSeen {
+    unsigned long long *tab;
+    uint32_t mask;            // buckets - 1
+    uint32_t amask;           // an m-mer is an anchor when (mixed hash & amask) == 0: 3 = one in four (RB_PAIR_SEEN_ANCHOR=<log2 density>)
 };
 
 // everything a kernel needs to address the filters (passed by value)
@@ -209,6 +219,8 @@ template <typename F> int guarded(F &&f) {
 }
 void alloc_bits(BitFilter &f, int64_t bits, int num_hash, int64_t lo, int64_t hi);
 void free_bits(BitFilter &f);
+void alloc_pair_seen(BitFilter &f);                 // seen-pair cache for a paired-k-mer filter (RB_PAIR_SEEN=0: none)
+void seen_reset(BitFilter &f, hipStream_t s);       // after anything that clears or replaces f.bits
 // one wavefront per high-multiplicity run: lanes fetch 64 occurrences at a time, compute each
 // one's random draw, and the increment chain hops from success to success with ballots
 static __global__ void __launch_bounds__(64) k_cbf_heavy(FilterView fv, const uint64_t *__restrict__ uniq,

@@ -51,6 +51,7 @@ _vp, _i64, _i32, _u64, _u32, _sz = C.c_void_p, C.c_int64, C.c_int, C.c_uint64, C
 SYMBOLS = [
     ("rb_last_error", C.c_char_p, []),
     ("rb_version", _i32, []),
+    ("rb_build_id", C.c_char_p, []),
     ("rb_graph_create", _i32, [C.POINTER(GraphParams), C.POINTER(_vp)]),
     ("rb_graph_destroy", _i32, [_vp]),
     ("rb_graph_clear", _i32, [_vp, C.c_uint]),

@@ -90,7 +90,7 @@ def test_every_native_method_has_a_jni_function_that_calls_the_c_abi():
         called |= hits
     # everything a single-process host needs is reachable from Java (the rb_shard_* phases belong to the multi-GPU driver)
     missing = {s for s in exported - called if not s.startswith("rb_shard_") and s not in (
-        "rb_last_error", "rb_graph_create_shard", "rb_graph_profile_enable", "rb_graph_profile_get", "rb_batch_create_synthetic", "rb_debug_probe_cbf", "rb_debug_scan_u32", "rb_debug_sort_pairs",
+        "rb_last_error", "rb_build_id", "rb_graph_create_shard", "rb_graph_profile_enable", "rb_graph_profile_get", "rb_batch_create_synthetic", "rb_debug_probe_cbf", "rb_debug_scan_u32", "rb_debug_sort_pairs",
         "rb_batch_download_ascii", "rb_nthash_batch", "rb_graph_add_batch")}
     assert not missing, missing
 
@@ -201,3 +201,118 @@ def test_hot_kernels_keep_their_occupancy_budget():
     assert sw and all(v[0] <= 128 for v in sw.values()), sw                           # swept Bloom-bit stage: two workgroups of 512 threads per CU (a few spilled registers are the price)
     so = pick("k_scan_one")
     assert so and all(v[2] <= 40 * 1024 for v in so.values()), so                      # single-workgroup scans must fit beside three bucket workgroups of 40 KB (DESIGN s5 "Round 4")
+
+
+# ---- the k_pairs_insert miscompile (DESIGN s5): a kernel that picked its store target at run time inside a rolled loop was exact on every
+#      small test and set 2 % of its bits at wrong places once a SIMD held more than one of its wavefronts (hipcc 7.2 -O3, gfx950).  Which
+#      instruction sequence goes wrong was never isolated, so the pattern is fenced instead: no kernel may contain it. ----
+def _blank(m):
+    return re.sub(r"[^\n]", " ", m.group(0))
+
+
+def _match_close(s, i, o, c):
+    d = 0
+    while True:
+        d += s[i] == o; d -= s[i] == c; i += 1
+        if d == 0:
+            return i
+
+
+def _stmt_end(s, i):
+    """end of the statement that starts at s[i]: a block, or up to the ';' at nesting depth 0; an if carries its else along"""
+    while s[i].isspace():
+        i += 1
+    if s[i] == "{":
+        return _match_close(s, i, "{", "}")
+    m = re.match(r"(if|for|while)\b\s*", s[i:])
+    if m:
+        j = _stmt_end(s, _match_close(s, i + m.end(), "(", ")"))
+        if m.group(1) == "if":
+            e = re.match(r"\s*else\b", s[j:])
+            if e:
+                j = _stmt_end(s, j + e.end())
+        return j
+    d = 0
+    while True:
+        c = s[i]
+        d += c in "({["; d -= c in ")}]"
+        i += 1
+        if c == ";" and d == 0:
+            return i
+
+
+def _stores(txt):
+    return bool(re.search(r"\b\w+\s*\[[^;]*?\]\s*(?:[|&^+\-]?=)[^=]", txt) or re.search(r"\b(atomic\w+|bit_set|__hip_atomic\w+)\s*\(", txt))
+
+
+def run_time_store_target_choices(src):
+    """[(kernel, pointer, line)]: inside a loop of a __global__ function, `if (p) { ...store... } else { ...store... }` with p one of the
+    kernel's writable pointer parameters — the choice between two store targets made per iteration instead of per instantiation"""
+    src = re.sub(r"/\*.*?\*/", _blank, src, flags=re.S)
+    src = re.sub(r"//[^\n]*", _blank, src)
+    src = re.sub(r"#ifdef RB_DIAG_PAIRS.*?#endif", _blank, src, flags=re.S)       # the failing form itself, kept as the reproducer (never built by default)
+    hits = []
+    for m in re.finditer(r"__global__\s+void\s*(?:__launch_bounds__\s*\([^)]*\)\s*)?(\w+)\s*\(", src):
+        i = _match_close(src, m.end() - 1, "(", ")")
+        if not re.match(r"\s*\{", src[i:]):
+            continue
+        params, j = src[m.end():i - 1], src.index("{", i)
+        body, line0 = src[j:_match_close(src, j, "{", "}")], src.count("\n", 0, j) + 1
+        ptrs = [mm.group(2) for p in params.split(",") for mm in [re.match(r"(.*?)\*\s*(?:__restrict__\s*)?(\w+)$", p.strip())] if mm and "const" not in mm.group(1)]
+        loops = []
+        for lm in re.finditer(r"\b(for|while)\s*\(", body):
+            e = _match_close(body, lm.end() - 1, "(", ")")
+            if not re.match(r"\s*;", body[e:]):                  # (the tail of a do-while has no body)
+                loops.append((e, _stmt_end(body, e)))
+        for lm in re.finditer(r"\bdo\s*\{", body):
+            loops.append((lm.end() - 1, _match_close(body, lm.end() - 1, "{", "}")))
+        for im in re.finditer(r"\bif\s*\(\s*!?\s*(\w+)\s*\)", body):
+            if im.group(1) not in ptrs or not any(a <= im.start() < b for a, b in loops):
+                continue
+            t_end = _stmt_end(body, im.end())
+            e = re.match(r"\s*else\b", body[t_end:])
+            if e and _stores(body[im.end():t_end]) and _stores(body[t_end + e.end():_stmt_end(body, t_end + e.end())]):
+                hits.append((m.group(1), im.group(1), line0 + body.count("\n", 0, im.start())))
+    return hits
+
+
+def test_no_kernel_picks_its_store_target_at_run_time_inside_a_loop():
+    # the detector sees the form that failed ...
+    bad = """
+    __global__ void k_bad(const uint64_t *__restrict__ codes, uint32_t *bits, uint64_t *__restrict__ out_idx, int n) {
+        for (;;) {
+            if (out_idx) { for (int j = 0; j < n; ++j) out_idx[j] = codes[j]; }
+            else { for (int j = 0; j < n; ++j) bit_set(bits, codes[j]); }
+            if (n) break;
+        }
+    }"""
+    assert run_time_store_target_choices(bad) == [("k_bad", "out_idx", 4)]
+    # ... not an optional extra output, and not the choice made by a template parameter
+    ok = """
+    template <bool OUT> __global__ void k_ok(const uint64_t *__restrict__ codes, uint32_t *bits, uint64_t *__restrict__ out_idx, float *pos, int n) {
+        for (int i = 0; i < n; ++i) {
+            if (OUT) out_idx[i] = codes[i]; else bit_set(bits, codes[i]);
+            if (pos) pos[i] = 1.0f;
+        }
+    }"""
+    assert run_time_store_target_choices(ok) == []
+    # One place is allowed, by name: k_cbf_heavy hands a run's final counters either to the filter or to the sharded engine's reply array ONCE per
+    # run, after the loop that carries the run's state (rb_pipeline.hpp); both forms are compared with the oracle at sizes that fill the device
+    # (tests/test_gpu_scale.py, tests/test_gpu_sharded.py scale tests, tools/parity_at_size.py).
+    allowed = {("rb_pipeline.hpp", "k_cbf_heavy", "cfinal")}
+    d = os.path.join(ROOT, "rna-bloom_amd", "csrc")
+    found = set()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".hpp")):
+            for kern, ptr, line in run_time_store_target_choices(open(os.path.join(d, f)).read()):
+                found.add((f, kern, ptr))
+    assert found <= allowed, "run-time choice between store targets inside a kernel loop (make it a template parameter): %s" % sorted(found - allowed)
+
+
+def test_library_carries_the_id_of_the_sources_it_was_built_from():
+    """rb_build_id() == tools/csrc_id.py of the tree: what bench.py compares with the id stored beside the committed PMC summaries"""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import csrc_id
+    from rnabloom import _native as N
+    assert N.lib.rb_build_id().decode() == csrc_id.csrc_id(ROOT)

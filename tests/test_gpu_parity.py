@@ -630,6 +630,44 @@ def test_read_pairs_at_scale(monkeypatch, general):
     assert_same_state(og, gg)
 
 
+@pytest.mark.parametrize("seen", ["default", "0", "4", "12"])
+@pytest.mark.parametrize("stranded", [False, True])
+def test_seen_pair_cache_never_changes_the_read_pair_filter(monkeypatch, seen, stranded):
+    """k_pairs_reads behind its seen-pair cache (BitFilter::seen, round 5): deep coverage, so most pairs are sightings of pairs that are in
+    the filter already and are skipped on the cache's word — the filter must equal the oracle's after every call, with the cache at its
+    default size, switched off, with 16 buckets (every lookup evicts) and with 4096; after clearRpkbf (the cache has to forget), after an
+    import of other bytes (likewise), after a second pass over the same reads (every pair known), and with N bases / low qualities that
+    cut pairs out of the middle of reads."""
+    if seen != "default":
+        monkeypatch.setenv("RB_PAIR_SEEN", seen)
+    (ls, lq, off), (rs, rq, roff) = make_reads(6000, 9000, 0.003, 2e-3, seed=77)        # ~80x coverage of a 9 kb transcriptome
+    og, gg = graph_pair(400_009, 3_000_017, 250_007, stranded=stranded, max_batch=200_000)
+    og.set_read_pair_distance(115); gg.setReadPairedKmerDistance(115)
+    def both(seq, qual, o, rc):
+        og.add_reads(seq, qual, o, 3, rbo.STORE_READ_PAIRS | (rbo.REVCOMP if rc else 0))
+        st = gg.addReads(seq, qual, o, 3, reverseComplement=rc, storeReadPairedKmers=True)
+        assert (gg.exportFilter(N.RPKBF) == og.rpkbf_bytes()).all(), "rpkbf differs"
+        return st
+    st = both(ls, lq, off, False)
+    assert st.pairs > 30_000
+    both(rs, rq, roff, True)
+    both(ls, lq, off, False)                                     # every pair is known now
+    assert_same_state(og, gg)
+    # the filter is emptied: a cache that still vouched for its pairs would leave the bits unset
+    gg.clearRpkbf()
+    assert gg.popcount(N.RPKBF) == 0
+    og_b = rbo.Graph(400_009, 3_000_017, 250_007, 2, 2, 2, 25, stranded, True, 7)
+    og_b.set_read_pair_distance(115)
+    og_b.add_reads(rs, rq, roff, 3, rbo.STORE_READ_PAIRS | rbo.REVCOMP)
+    gg.addPairs(ReadBatch.from_ascii(rs, rq, roff, 3), reverseComplement=True)
+    assert (gg.exportFilter(N.RPKBF) == og_b.rpkbf_bytes()).all(), "rpkbf differs after clearRpkbf"
+    # other bytes are imported: the same
+    other = np.zeros_like(og_b.rpkbf_bytes()); other[::7] = 0x21
+    gg.importFilter(N.RPKBF, other)
+    gg.addPairs(ReadBatch.from_ascii(rs, rq, roff, 3), reverseComplement=True)
+    assert (gg.exportFilter(N.RPKBF) == (og_b.rpkbf_bytes() | other)).all(), "rpkbf differs after an import"
+
+
 @pytest.mark.parametrize("stranded", [False, True])
 def test_max_cov_walks_match_oracle(stranded):
     """rb_graph_walk: batched greedy maximum-coverage walks (Kmer.getMaxCovSuccessor / getMaxCovPredecessor in the loop

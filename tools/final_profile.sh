@@ -2,8 +2,10 @@
 # Collects everything profiles/ holds for a round (run through gpurun from the repo root):  tools/final_profile.sh r02
 #   GPU test suite, default bench line, rocprofv3 kernel stats, PMC FETCH_SIZE / WRITE_SIZE passes (each in its own run),
 #   serial stage times, FETCH_SIZE calibration on k_part_count (known byte count).
+#   second argument: the commit the tree was at (the GPU box has no .git):  tools/final_profile.sh r05 $(git rev-parse HEAD)
 R=$GRAFT_REPO_ROOT
 TAG=${1:-r02}
+HEAD_SHA=${2:-unrecorded}
 OUT=$R/gpurun_out/final_$TAG
 mkdir -p $OUT
 cd $R
@@ -17,6 +19,17 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/prof_$c -o p -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/bench_pmc_$c.json 2> $OUT/rocprof_$c.err
   python $R/profiles/summarize.py pmc $(find /tmp/prof_$c -name '*counter_collection.csv' | head -1) $c > $OUT/pmc_$c.csv
 done
+# which code the counter passes ran on: the id compiled into the library (= tools/csrc_id.py of the tree) and the commit; bench.py quotes
+# the counters only while its library carries the same id
+python - <<PY > $OUT/pmc_meta.json
+import json, sys
+sys.path[:0] = ["$R", "$R/rna-bloom_amd", "$R/tools"]
+from rnabloom import _native as N
+import csrc_id
+lib, src = N.lib.rb_build_id().decode(), csrc_id.csrc_id("$R")
+assert lib == src, "librb_hip.so was not built from this tree: %s vs %s" % (lib, src)
+print(json.dumps({"csrc_id": lib, "git_head": "$HEAD_SHA", "command": "bench.py --steps 1 --warmup 1 --no-cpu-baseline under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes)"}))
+PY
 python - <<PY > $OUT/pmc_calibration.txt
 import json
 b = json.load(open("$OUT/bench_pmc_FETCH_SIZE.json"))
