@@ -442,7 +442,7 @@ int rb_shard_hash(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, int6
                   uint64_t ordinal0, uint32_t pos_bits, unsigned flags, int64_t *rec_counts /*[count]*/,
                   int64_t *pair_counts /*[count]*/, rb_add_stats *stats);
 /* (round 4: the records are grouped where they lie — keys_dev / occ_dev are scratch of the call and hold garbage afterwards) */
-int rb_shard_group(rb_graph *g, const void *keys_dev, const void *occ_dev, int64_t n, uint64_t ordinal0,
+int rb_shard_group(rb_graph *g, void *keys_dev, void *occ_dev, int64_t n, uint64_t ordinal0,
                    uint32_t pos_bits, unsigned flags, int64_t *dreq_counts, int64_t *creq_counts);
 int rb_shard_cache_apply(rb_graph *g, const void *upd_dev, int64_t n);
 /* split reads, look-ahead (k <= 31): the window walk + prefilter of this rank's slice [own_first, own_first + own_n) of the NEXT

@@ -182,6 +182,7 @@ jlongArray FN(addFastqFile)(JNIEnv *e, jclass c, jlong h, jstring path, jint min
     int64_t recs = 0;
     const char *p = (*e)->GetStringUTFChars(e, path, NULL);
     (void)c;
+    if (!p) return NULL;      /* OutOfMemoryError pending */
     memset(&st, 0, sizeof st);
     int rc = rb_graph_add_fastq_file(G(h), p, min_q, (unsigned)flags, &st, &recs);
     if (p) (*e)->ReleaseStringUTFChars(e, path, p);
@@ -194,6 +195,7 @@ jlongArray FN(addFastaFile)(JNIEnv *e, jclass c, jlong h, jstring path, jint fla
     int64_t recs = 0;
     const char *p = (*e)->GetStringUTFChars(e, path, NULL);
     (void)c;
+    if (!p) return NULL;      /* OutOfMemoryError pending */
     memset(&st, 0, sizeof st);
     int rc = rb_graph_add_fasta_file(G(h), p, (unsigned)flags, &st, &recs);
     if (p) (*e)->ReleaseStringUTFChars(e, path, p);
@@ -344,9 +346,11 @@ void FN(importFilter)(JNIEnv *e, jclass c, jlong h, jint which, jobject src, jlo
 /* filters of 2 GiB and more (a direct ByteBuffer holds less): the file is mapped here and handed to the same two calls */
 void FN(importFilterFromFile)(JNIEnv *e, jclass c, jlong h, jint which, jstring path, jlong n) {
     const char *p = (*e)->GetStringUTFChars(e, path, NULL);
-    int rc = RB_OK, fd = p ? open(p, O_RDONLY) : -1, io = 0;
+    int rc = RB_OK, fd, io = 0;
     struct stat sb;
     (void)c;
+    if (!p) return;      /* OutOfMemoryError is pending: calling back into JNI now would be undefined; the exception propagates */
+    fd = open(p, O_RDONLY);
     if (fd < 0) { throw_io(e, "cannot open filter file", p, strerror(errno)); io = 1; }
     else if (fstat(fd, &sb) != 0) { throw_io(e, "cannot stat filter file", p, strerror(errno)); io = 1; }
     else if ((int64_t)sb.st_size < (int64_t)n) {        /* a truncated file would be a SIGBUS inside the import, not an exception */
@@ -364,8 +368,10 @@ void FN(importFilterFromFile)(JNIEnv *e, jclass c, jlong h, jint which, jstring 
 }
 void FN(exportFilterToFile)(JNIEnv *e, jclass c, jlong h, jint which, jstring path, jlong n) {
     const char *p = (*e)->GetStringUTFChars(e, path, NULL);
-    int rc = RB_OK, fd = p ? open(p, O_RDWR | O_CREAT | O_TRUNC, 0644) : -1, io = 0;
+    int rc = RB_OK, fd, io = 0;
     (void)c;
+    if (!p) return;      /* (as above) */
+    fd = open(p, O_RDWR | O_CREAT | O_TRUNC, 0644);
     if (fd < 0) { throw_io(e, "cannot create filter file", p, strerror(errno)); io = 1; }
     else if (ftruncate(fd, (off_t)n) != 0) { throw_io(e, "cannot size filter file", p, strerror(errno)); io = 1; }
     else {

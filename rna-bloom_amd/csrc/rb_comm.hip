@@ -105,8 +105,12 @@ struct rb_shard_comm {
     int arrived = 0;
     uint64_t generation = 0;
     bool failed = false;
-    int in_call = 0;                    // ranks inside rb_shard_add_range
-    uint64_t entered = 0;               // entries into rb_shard_add_range so far: a failed call is over when ALL ranks have entered and left it
+    // A failure poisons the hub until EVERY rank has entered and left the collective call it happened in.  Ranks make the same sequence of
+    // collective calls (rb_shard_add_range, rb_shard_comm_selftest), so a call is known by its number: calls[r] = calls rank r has entered,
+    // left[r] = the number of the last call it left, fail_call = the latest call number a failure (its own or a poisoned hub's) was seen in.
+    // A rank that fails fast and comes back finds the hub poisoned and fails again — which moves fail_call on to ITS call number, so the
+    // hub stays poisoned until its peers have failed that call as well and all ranks are in step again.
+    uint64_t calls[MAX_WORLD] = {}, left[MAX_WORLD] = {}, fail_call = 0;
     const Part *pub_parts[MAX_WORLD];
     int pub_k[MAX_WORLD];
     // receive buffers and count staging, per (virtual) rank
@@ -128,11 +132,28 @@ void hub_barrier(rb_shard_comm *c) {
     c->cv.wait(lk, [&] { return c->generation != gen || c->failed; });
     if (c->failed) throw HubFailed{};
 }
-void hub_fail(rb_shard_comm *c) {
+void hub_fail(rb_shard_comm *c, uint64_t call) {
     std::lock_guard<std::mutex> lk(c->m);
     c->failed = true;
+    c->fail_call = std::max(c->fail_call, call);
     c->cv.notify_all();
 }
+// one collective call of rank `me` on a loopback hub (see rb_shard_comm::calls)
+struct InCall {
+    rb_shard_comm *c; int me; uint64_t call = 0;
+    InCall(rb_shard_comm *c_, int me_) : c(c_ && !c_->is_rccl && me_ >= 0 && me_ < c_->world ? c_ : nullptr), me(me_) {
+        if (c) { std::lock_guard<std::mutex> lk(c->m); call = ++c->calls[me]; }
+    }
+    void failed() { if (c) hub_fail(c, call); }
+    ~InCall() {
+        if (!c) return;
+        std::lock_guard<std::mutex> lk(c->m);
+        c->left[me] = call;
+        if (!c->failed) return;
+        for (int r = 0; r < c->world; ++r) if (c->left[r] < c->fail_call) return;      // somebody has not been through the failed call yet
+        c->failed = false; c->arrived = 0; c->fail_call = 0;
+    }
+};
 rb_shard_comm::Pool &pool_of(rb_shard_comm *c, int me) {
     rb_shard_comm::Pool &p = c->pool[c->is_rccl ? 0 : me];
     if (!p.cnt_host) RB_HIP(hipHostMalloc(reinterpret_cast<void **>(&p.cnt_host), sizeof(int64_t) * 2 * MAX_PARTS * MAX_WORLD, hipHostMallocDefault));
@@ -453,6 +474,7 @@ int rb_shard_comm_create_loopback(int world, rb_shard_comm **out) {
 int rb_shard_comm_selftest(rb_shard_comm *c, int me, int device, int64_t big_bytes) {
     DevBuf sendbuf;
     struct Rel { DevBuf &b; ~Rel() { b.release(); } } rel{sendbuf};
+    InCall in_call(c, me);
     int rc = guarded([&] {
         RB_REQUIRE(c && me >= 0 && me < c->world && big_bytes >= 0, "rb_shard_comm_selftest: bad argument");
         RB_HIP(hipSetDevice(device));
@@ -498,7 +520,7 @@ int rb_shard_comm_selftest(rb_shard_comm *c, int me, int device, int64_t big_byt
             for (int64_t i = 0; i < sizes[src]; ++i, ++o)
                 RB_REQUIRE(got[(size_t)o] == (uint8_t)((src * 31 + 0 * 17 + i) & 255), "rb_shard_comm_selftest: gathered byte %lld of rank %d is wrong", (long long)i, src);
     });
-    if (rc != RB_OK && c && !c->is_rccl) hub_fail(c);
+    if (rc != RB_OK) in_call.failed();
     return rc;
 }
 
@@ -517,16 +539,7 @@ int rb_shard_comm_destroy(rb_shard_comm *c) {
 int rb_shard_add_range(rb_graph *g, rb_shard_comm *c, const rb_batch *b, int64_t first, int64_t n, unsigned flags, int64_t reads_per_substep,
                        uint32_t pos_bits, uint64_t ordinal0, rb_add_stats *stats) {
     if (stats) memset(stats, 0, sizeof *stats);
-    struct InCall {                      // (loopback hub) a failed call poisons the hub until EVERY rank has entered and left it: a rank that fails
-        rb_shard_comm *c;                // before its peers have arrived must not un-poison the hub for them (they would wait at a barrier for ever)
-        explicit InCall(rb_shard_comm *c_) : c(c_) { if (c && !c->is_rccl) { std::lock_guard<std::mutex> lk(c->m); ++c->in_call; ++c->entered; } }
-        ~InCall() {
-            if (c && !c->is_rccl) {
-                std::lock_guard<std::mutex> lk(c->m);
-                if (--c->in_call == 0 && c->failed && c->entered % (uint64_t)c->world == 0) { c->failed = false; c->arrived = 0; }
-            }
-        }
-    } in_call(c);
+    InCall in_call(c, g && g->shard ? g->shard_rank : -1);
     int rc = guarded([&] {
         RB_REQUIRE(g && g->shard && c && b && n >= 0 && reads_per_substep > 0, "rb_shard_add_range: bad argument");
         rb::WriteLock wl(g->rw);          // a mutator like every other insert: queries on this shard handle wait (rb_graph_kmers, rb_shard_query_*)
@@ -557,7 +570,7 @@ int rb_shard_add_range(rb_graph *g, rb_shard_comm *c, const rb_batch *b, int64_t
             throw HipError{RB_ERR_STATE};
         }
     });
-    if (rc != RB_OK && c && !c->is_rccl) hub_fail(c);
+    if (rc != RB_OK) in_call.failed();
     return rc;
 }
 

@@ -4332,6 +4332,7 @@ int rb_filter_import(rb_graph *g, int which, const void *srcp, size_t nbytes) {
         if (g->mpf_log2b && (which == RB_CBF || which == RB_DBGBF)) RB_HIP(hipMemset(g->mpf.p, 0, (size_t)128 << g->mpf_log2b));
         if (g->rst_log2 && (which == RB_CBF || which == RB_DBGBF)) RB_HIP(hipMemset(g->rst.p, 0, sizeof(uint64_t) << g->rst_log2));
         if (which != RB_CBF) seen_reset(*bit_filter(g, which), g->stream);      // the bits are replaced: what the seen-pair cache knew is void
+        if (which == RB_RPKBF && g->shard) rb::shard_clear_pairs_acc(g);        // (and what this rank's accumulation copy still holds must not come back)
         RB_HIP(hipStreamSynchronize(g->stream));
         RB_HIP(hipMemset(dst, 0, alloc));
         RB_HIP(hipMemcpy(dst, srcp, have, hipMemcpyHostToDevice));

@@ -1280,6 +1280,12 @@ __global__ void k_sw_big_set(uint32_t *__restrict__ words, Mod mod, uint64_t lo,
     const uint32_t m = 1u << (uint32_t)(i0 & 31ull);
     if (atomicOr(&words[i0 >> 5], m) & m) st0[d] = 2;
 }
+// INVARIANT of the swept stage: from the launch of k_sweep_bits to its end NOTHING else writes `words` — no other stream, no producer of
+// the next sub-batch.  A round loads a range's words into LDS, decides "set before the sub-batch" against the words still in HBM, and writes
+// the interior words back with plain 16-byte stores: a bit another writer set in between would be lost, and the 1-versus-2 report would be
+// wrong.  The callers (run_core, rb_graph.hip: the consumer stream owns dbgbf, the producer touches scratch and rpkbf only; the sharded
+// engine does not sweep) hold it; a future overlap that writes dbgbf beside the sweep has to switch the write-back to atomicOr of
+// (s_w & ~loaded) first.
 size_t sweep_temp_bytes(size_t D, uint32_t T) { return group_plan(D, 64, 0, 0, (int)T).total; }
 void sweep_bits_device(uint32_t *words, GrIdx idx, uint32_t T, uint64_t kmul, const uint64_t *uniq, uint32_t D, uint32_t n_main, const uint32_t *brun,
                        const uint32_t *bnr, uint64_t *keys_a, uint32_t *vals_a, uint64_t *keys_b, uint32_t *vals_b, void *temp, size_t temp_bytes,

@@ -1030,8 +1030,10 @@ int rb_graph_create_shard(const rb_graph_params *p, int shard_rank, int shard_co
                 RB_HIP(hipMemGetInfo(&free_b, &total_b));
                 // room for the copy with half of the device still free afterwards, else this rank routes its pairs as before (each rank decides
                 // for itself: the owners take pair bits both ways — virtual ranks that share one GPU run out of room at configs[2]'s sizes)
-                if ((size_t)(p->pkbf_bits / 8) + (total_b >> 1) < free_b)
+                if ((size_t)(p->pkbf_bits / 8) + (total_b >> 1) < free_b) {
                     alloc_bits(S->rpk_acc, p->pkbf_bits, p->pkbf_num_hash, 0, p->pkbf_bits);
+                    alloc_pair_seen(S->rpk_acc);         // the walker's seen-pair cache (rb_graph.hip), for this rank's copy
+                }
             }
         }
         {   // no-op prefilter cache over this rank's k-mers (applied to the records it receives)
@@ -1400,7 +1402,7 @@ int rb_shard_hash(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, int6
     });
 }
 // the records this rank received (concatenated in source-rank order = read order) -> runs -> requests
-int rb_shard_group(rb_graph *g, const void *keys_dev, const void *occ_dev, int64_t n, uint64_t ordinal0, uint32_t pos_bits,
+int rb_shard_group(rb_graph *g, void *keys_dev, void *occ_dev, int64_t n, uint64_t ordinal0, uint32_t pos_bits,
                    unsigned flags, int64_t *dreq_counts, int64_t *creq_counts) {
     return guarded([&] {
         RB_REQUIRE(g && g->shard && dreq_counts && creq_counts && n >= 0, "rb_shard_group: bad argument");
@@ -1416,8 +1418,11 @@ int rb_shard_group(rb_graph *g, const void *keys_dev, const void *occ_dev, int64
         if (n == 0) return;
         // grouped where they arrived: the receive buffers are the caller's scratch until its next exchange (both drivers), and the
         // grouping clobbers its input anyway — no copy into keys0 / vals0 (24 GB per config-2 pass over all ranks)
-        g->group_in_keys = const_cast<uint64_t *>(static_cast<const uint64_t *>(keys_dev));
-        g->group_in_vals = const_cast<uint32_t *>(static_cast<const uint32_t *>(occ_dev));
+        // (one-shot pointers: dropped on every way out of this call, so that a failure before group_enqueue consumes them cannot leave
+        //  them for the next, unrelated grouping to read and clobber)
+        struct DropInputs { rb_graph *g; ~DropInputs() { g->group_in_keys = nullptr; g->group_in_vals = nullptr; } } drop_inputs{g};
+        g->group_in_keys = static_cast<uint64_t *>(keys_dev);
+        g->group_in_vals = static_cast<uint32_t *>(occ_dev);
         const uint32_t D = group_records(g, (size_t)n, ordinal0, pos_bits, nullptr, nullptr);
         S->D = D;
         make_and_route_requests(g, D, mode, ordinal0, pos_bits, dreq_counts, creq_counts);
@@ -1481,7 +1486,10 @@ int rb_shard_pairs_flush_end(rb_graph *g, const void *recv_dev, const int64_t *r
                 hipLaunchKernelGGL(k_or_u8, dim3(blocks_for(n)), dim3(TPB), 0, s, reinterpret_cast<uint8_t *>(g->rpk.bits), reinterpret_cast<const uint8_t *>(src), (size_t)n);
             off += n;
         }
-        if (S->rpk_acc.bits) RB_HIP(hipMemsetAsync(S->rpk_acc.bits, 0, S->rpk_acc.alloc, s));
+        // The copy KEEPS its bits (round 5; it was cleared here before): they are in the owners' shards now, merging them again with the next
+        // call changes nothing (OR), and the walker's seen-pair cache — which vouches for bits of this copy — stays valid from one file of a
+        // library to the next.  Whatever empties or replaces the pair filter empties the copy and the cache with it (shard_clear_pairs_acc:
+        // rb_graph_clear, rb_filter_import).
         S->acc_dirty = false;
         RB_HIP(hipGetLastError());
         RB_HIP(hipStreamSynchronize(s));
@@ -1885,6 +1893,7 @@ void shard_clear_pairs_acc(rb_graph *g) {       // rb_graph_clear of the pair fi
     ShardState *S = g->shard;
     if (!S || !S->rpk_acc.bits) return;
     RB_HIP(hipMemsetAsync(S->rpk_acc.bits, 0, S->rpk_acc.alloc, g->stream));
+    seen_reset(S->rpk_acc, g->stream);
     S->acc_dirty = false;
 }
 void shard_free(rb_graph *g) {

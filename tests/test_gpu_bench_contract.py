@@ -100,3 +100,28 @@ def test_communicator_self_test_on_a_loopback_hub():
         for t in th: t.join()
         assert rc == [0, 0, 0, 0], (rc, N.lib.rb_last_error())
         comm.destroy()
+
+
+def test_a_rank_that_fails_fast_and_comes_back_does_not_unpoison_the_hub_for_its_peers():
+    """loopback hub, two ranks: rank 0 fails its first collective call at once (bad argument) and re-enters before rank 1 has arrived.  The
+    hub must stay poisoned until rank 1 has been through BOTH calls (a hub reset after rank 0's second entry — two entries, world two —
+    left rank 1 waiting at a barrier for ever); then the ranks are in step again and the third call succeeds on both."""
+    import threading
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "rna-bloom_amd")]
+    from rnabloom import _native as N
+    from rnabloom import sharded
+    comm = sharded.NativeComm.loopback(2)
+    st = lambda rank, big: N.lib.rb_shard_comm_selftest(comm.h, rank, 0, big)
+    assert st(0, -1) != 0                      # call 1 of rank 0 fails
+    assert st(0, 0) != 0                       # call 2 of rank 0: the hub is poisoned, fails at once instead of waiting for rank 1
+    rc = []
+    t = threading.Thread(target=lambda: rc.extend([st(1, 0), st(1, 0)]))     # calls 1 and 2 of rank 1: both must fail, neither may hang
+    t.start(); t.join(60)
+    assert not t.is_alive(), "rank 1 hangs at a barrier of a hub that was reset too early"
+    assert rc[0] != 0 and rc[1] != 0
+    res = [None, None]
+    th = [threading.Thread(target=lambda i=i: res.__setitem__(i, st(i, 0))) for i in range(2)]      # call 3: in step again
+    for x in th: x.start()
+    for x in th: x.join(60)
+    assert not any(x.is_alive() for x in th) and res == [0, 0], (res, N.lib.rb_last_error())
+    comm.destroy()
