@@ -55,8 +55,10 @@ def algorithmic_bytes(stage, n_kmers, n_pairs, n_runs, words, n_sorted=None, gro
         "group_part_count": n_kmers * 8 * 2,
         "group_part_scatter": n_kmers * 24 * 2,
         "group_buckets": n_kmers * (12 + 5) + n_runs * 16,
-        # packed reads in (8 B codes + 4 B validity + 4 B owner per word), (h0, occurrence) out
-        "hash_windows": words * (16 if sharded else 32) + n_kmers * 12,
+        # packed reads in (8 B codes + 4 B validity + 4 B owner per word), (h0, occurrence) out; single GPU: + the 16 B of rolling state the
+        # prefilter saved, + the word's output offset and keep mask (4 B each: round 5 — the emit pass reads only the 55 % of words that keep
+        # a window, but a gapped read touches every 128-byte line all the same: profiles/r05_gapped_fetch.txt)
+        "hash_windows": words * (16 if sharded else 40) + n_kmers * 12,
         "count_windows": words * 12,
         "strengths": n_kmers * 5,
         "distinct_runs": n_kmers * 8 + n_runs * 16,

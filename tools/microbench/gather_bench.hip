@@ -58,6 +58,66 @@ __global__ void k_calib(const uint64_t *__restrict__ tab, uint64_t mask, int ite
     }
     if (acc == 0x1234567ull) out[0] = acc;
 }
+
+// ---- FETCH_SIZE on a GAPPED streaming read (round 5: what k_hash_windows_resume does) ----
+// A wavefront takes 512 consecutive elements of an array, lists the ones it keeps (a fixed pseudo-random DENS percent, as the emit pass lists
+// the words that keep a window) and reads those, one element of BYTES bytes per lane, 64 listed elements per load instruction.  The host
+// counts what a sector- and a line-granular memory system must move for exactly that set: 64-byte sectors touched, 128-byte lines touched.
+// `gather_bench gapped` under rocprofv3 --pmc FETCH_SIZE says which of them the counter follows (profiles/r05_pmc_calibration.txt).
+__host__ __device__ __forceinline__ bool gap_keep(uint64_t i, uint32_t dens_pct) {
+    uint64_t z = i * 0x9E3779B97F4A7C15ull; z ^= z >> 29; z *= 0xBF58476D1CE4E5B9ull; z ^= z >> 32;
+    return (uint32_t)(z % 100u) < dens_pct;
+}
+template <int BYTES, int DENS>
+__global__ void __launch_bounds__(64) k_gapped(const uint32_t *__restrict__ a, uint64_t n, uint64_t *out) {
+    __shared__ uint16_t s_list[512];
+    const uint64_t base = (uint64_t)blockIdx.x * 512u;
+    const uint32_t lane = threadIdx.x;
+    uint32_t n_list = 0;
+    for (uint32_t q = 0; q < 512u; q += 64u) {
+        const uint64_t i = base + q + lane;
+        const bool ne = i < n && gap_keep(i, DENS);
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(ne);
+        if (ne) s_list[n_list + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (uint16_t)(q + lane);
+        n_list += (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    uint64_t acc = 0;
+    for (uint32_t e0 = 0; e0 < n_list; e0 += 64u) {
+        if (e0 + lane < n_list) {
+            const uint64_t i = base + s_list[e0 + lane];
+            const uint32_t *p = a + i * (BYTES / 4);
+            if (BYTES == 16) { const uint4 v = *reinterpret_cast<const uint4 *>(p); acc += v.x ^ v.y ^ v.z ^ v.w; }
+            else if (BYTES == 8) { const uint2 v = *reinterpret_cast<const uint2 *>(p); acc += v.x ^ v.y; }
+            else acc += p[0];
+        }
+    }
+    if (acc == 0x1234567ull) out[0] = acc;
+}
+template <int BYTES, int DENS> static void gapped_one(const uint32_t *a, uint64_t n, uint64_t *out) {
+    hipLaunchKernelGGL((k_gapped<BYTES, DENS>), dim3((unsigned)((n + 511) / 512)), dim3(64), 0, 0, a, n, out);
+    CK(hipDeviceSynchronize());
+    uint64_t kept = 0, sect = 0, lines = 0, last_s = ~0ull, last_l = ~0ull;
+    for (uint64_t i = 0; i < n; ++i) {
+        if (!gap_keep(i, DENS)) continue;
+        ++kept;
+        const uint64_t s64 = i * BYTES / 64, l128 = i * BYTES / 128;
+        if (s64 != last_s) { ++sect; last_s = s64; }
+        if (l128 != last_l) { ++lines; last_l = l128; }
+    }
+    printf("k_gapped<%d, %d>: %llu of %llu elements read = %.3f GB useful; %.3f GB in 64-byte sectors touched; %.3f GB in 128-byte lines touched (x 64: %.3f GB)\n", BYTES, DENS,
+           (unsigned long long)kept, (unsigned long long)n, kept * (double)BYTES / 1e9, sect * 64.0 / 1e9, lines * 128.0 / 1e9, lines * 64.0 / 1e9);
+}
+static int gapped() {
+    const uint64_t n = 1ull << 27;                      // 2 GB of 16-byte elements: past the Infinity Cache
+    uint32_t *a; uint64_t *out;
+    CK(hipMalloc(&a, n * 16)); CK(hipMalloc(&out, 8));
+    CK(hipMemset(a, 1, n * 16));
+    gapped_one<16, 100>(a, n, out); gapped_one<16, 55>(a, n, out); gapped_one<16, 25>(a, n, out); gapped_one<16, 10>(a, n, out);
+    gapped_one<8, 100>(a, n, out);  gapped_one<8, 55>(a, n, out);  gapped_one<8, 25>(a, n, out);
+    gapped_one<4, 100>(a, n, out);  gapped_one<4, 55>(a, n, out);  gapped_one<4, 25>(a, n, out);
+    return 0;
+}
 static int calib() {
     uint64_t *out, *tab; const uint64_t n = 1ull << 29;            // 4 GB
     CK(hipMalloc(&out, 64)); CK(hipMalloc(&tab, n * 8)); CK(hipMemset(tab, 1, n * 8));
@@ -158,6 +218,7 @@ static int big(int log2_gb, int alloc_flag = 0) {
 }
 int main(int argc, char **argv) {
     if (argc > 1 && !strcmp(argv[1], "calib")) return calib();
+    if (argc > 1 && !strcmp(argv[1], "gapped")) return gapped();
     if (argc > 1 && !strcmp(argv[1], "big")) return big(argc > 2 ? atoi(argv[2]) : 3, argc > 3 ? atoi(argv[3]) : 0);
     uint64_t *out; CK(hipMalloc(&out, 64));
     const int blocks = 256 * 32, tpb = 256;
