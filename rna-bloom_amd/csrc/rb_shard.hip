@@ -71,6 +71,7 @@ struct ShardState {
     // (1 GB at config 2, 33 GB at configs[3]); RB_SHARD_PAIRS=route is the routed path of rounds 1-3.
     BitFilter rpk_acc;                          // full range [0, bits); bits == nullptr: routed path
     bool acc_dirty = false;                     // something was ORed into rpk_acc since the last flush
+    bool pairs_direct = false;                  // one rank: its shard IS the filter — the walker ORs straight into g->rpk (round 5; the routed path cost 85 ms per pass there)
     bool replicate_cache = false;               // split-reads mode: cache updates are broadcast to every rank
     DevBuf cache_upd;                           // [D] exponent to broadcast per run (0 = none)
     uint32_t *pinned = nullptr;                 // [0] = kept records, [16 + 16 q] = owned windows (32 spread counters)
@@ -1025,6 +1026,7 @@ int rb_graph_create_shard(const rb_graph_params *p, int shard_rank, int shard_co
             S->span[RB_RPKBF] = gp.span;
             alloc_bits(g->rpk, p->pkbf_bits, p->pkbf_num_hash, gp.lo, gp.hi);
             const char *pm = getenv("RB_SHARD_PAIRS");
+            if (shard_count == 1 && !(pm && !strcmp(pm, "route"))) { S->pairs_direct = true; alloc_pair_seen(g->rpk); }
             if (shard_count > 1 && !(pm && !strcmp(pm, "route"))) {
                 size_t free_b = 0, total_b = 0;
                 RB_HIP(hipMemGetInfo(&free_b, &total_b));
@@ -1214,16 +1216,16 @@ int rb_shard_hash_group(rb_graph *g, const rb_batch *b, int64_t first, int64_t n
         if (stats) { stats->kmers += (int64_t)owned; stats->sorted_kmers += (int64_t)N; }
         // ---- read-paired k-mers of this rank's slice of the reads: ORed into this rank's accumulation copy (merged into the owners'
         //      shards when the call ends, rb_shard_pairs_flush_*), or — routed path — bit indices bucketed by rpkbf owner ----
-        if (pairs && pair_n > 0 && S->rpk_acc.bits) {
+        if (pairs && pair_n > 0 && (S->rpk_acc.bits || S->pairs_direct)) {
             const int64_t pw0 = b->h_woff[(size_t)pair_first], pnw = (int64_t)b->h_woff[(size_t)(pair_first + pair_n)] - pw0;
             if (pnw > 0) {
                 g->devctr.reserve(DEVCTR_BYTES);
                 unsigned long long *pc = reinterpret_cast<unsigned long long *>(g->devctr.as<uint32_t>() + 12), np_host = 0;
                 RB_HIP(hipMemsetAsync(pc, 0, 8, s));
-                launch_pairs(g, b, pw0, pnw, mode_hash, nullptr, nullptr, pc, s, &S->rpk_acc);
+                launch_pairs(g, b, pw0, pnw, mode_hash, nullptr, nullptr, pc, s, S->pairs_direct ? &g->rpk : &S->rpk_acc);
                 RB_HIP(hipMemcpyAsync(&np_host, pc, 8, hipMemcpyDeviceToHost, s));
                 RB_HIP(hipStreamSynchronize(s));
-                S->acc_dirty = true;
+                S->acc_dirty = !S->pairs_direct;
                 if (stats) stats->pairs += (int64_t)np_host;
             }
         } else
@@ -1369,14 +1371,14 @@ int rb_shard_hash(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, int6
             });
         }
         if (stats) { stats->kmers += (int64_t)windows; stats->sorted_kmers += (int64_t)kept; }
-        if (pairs && S->rpk_acc.bits) {   // replicated accumulation: the single-GPU walker into this rank's copy (see ShardState::rpk_acc)
+        if (pairs && (S->rpk_acc.bits || S->pairs_direct)) {   // replicated accumulation: the single-GPU walker into this rank's copy (see ShardState::rpk_acc) — or, one rank, into the filter
             g->devctr.reserve(DEVCTR_BYTES);
             unsigned long long *pc = reinterpret_cast<unsigned long long *>(g->devctr.as<uint32_t>() + 12), np_host = 0;
             RB_HIP(hipMemsetAsync(pc, 0, 8, s));
-            launch_pairs(g, b, w0, nw, mode_hash, nullptr, nullptr, pc, s, &S->rpk_acc);
+            launch_pairs(g, b, w0, nw, mode_hash, nullptr, nullptr, pc, s, S->pairs_direct ? &g->rpk : &S->rpk_acc);
             RB_HIP(hipMemcpyAsync(&np_host, pc, 8, hipMemcpyDeviceToHost, s));
             RB_HIP(hipStreamSynchronize(s));
-            S->acc_dirty = true;
+            S->acc_dirty = !S->pairs_direct;
             if (stats) stats->pairs += (int64_t)np_host;
         } else if (pairs) {
             uint32_t P = 0;
