@@ -34,7 +34,7 @@ SECTOR = 64                     # bytes moved per random probe (SURVEY.md §8(d)
 
 
 def algorithmic_bytes(stage, n_kmers, n_pairs, n_runs, words, n_sorted=None, group_bits=32, h=2, sharded=False, k=25):
-    """ALGORITHMIC bytes one step moves in each pipeline stage (DESIGN.md §Roofline).
+    """ALGORITHMIC bytes one step moves in each pipeline stage (DESIGN.md §5).
     n_kmers = k-mer occurrences, n_sorted = occurrences that survive the no-op prefilter,
     n_pairs = paired k-mers, n_runs = distinct runs, words = 32-base words."""
     passes = -(-group_bits // 8)

@@ -10,7 +10,7 @@
  * declaration cites the reference method(s) it replaces; R/ = src/rnabloom/ in the reference tree.
  *
  * Semantics are those of the reference run with ONE worker thread (-t 1): filters end up exactly as
- * if the reads had been processed one after another, k-mers left to right (DESIGN.md §Determinism).
+ * if the reads had been processed one after another, k-mers left to right (DESIGN.md §2-3).
  * All entry points are synchronous: when they return, results are visible to the next call.
  */
 #ifndef RB_CAPI_H

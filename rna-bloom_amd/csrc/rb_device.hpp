@@ -208,7 +208,7 @@ __device__ __forceinline__ bool npf_store(const Npf &c, uint64_t h0, uint32_t s)
     __hip_atomic_store(&b[victim], (tag << 4) | (unsigned long long)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return true;
 }
-// ---- recent stores (DESIGN.md §3 "two-phase prefilter"): a small direct-mapped table of what the stages that retire runs
+// ---- recent stores (HISTORY.md §5 "two-phase prefilter": exact, overlapping, slower — behind RB_TWO_PHASE=1): a small direct-mapped table of what the stages that retire runs
 // have learnt lately, addressed by the hash itself (the emit pass knows the hash of every window it writes, not its minimizer
 // bucket's contents).  entry = h0 with its low four bits replaced by the exponent s (1..14, 15 = saturated), index = the low
 // log2n bits of h0 (log2n >= 4: the replaced bits are part of the index, so a match proves all 64 bits); 0 = empty.  Same
@@ -416,6 +416,12 @@ __device__ __forceinline__ bool bit_test(const uint32_t *bits, uint64_t i) {
 __device__ __forceinline__ void bit_set(uint32_t *bits, uint64_t i) {
     uint32_t m = 1u << (uint32_t)(i & 31u);
     if (!(bits[i >> 5] & m)) atomicOr(&bits[i >> 5], m);   // test-before-set halves write traffic
+}
+// BloomFilter.lookup(long[]) with its early exit, R/bloom/BloomFilter.java:170-178
+__device__ __forceinline__ bool bits_lookup(const uint32_t *bits, const Mod &mod, int num_hash, uint64_t kmul, uint64_t h0) {
+    for (int j = 0; j < num_hash; ++j)
+        if (!bit_test(bits, index_of(multi_hash(h0, (uint32_t)j, kmul), mod))) return false;
+    return true;
 }
 
 }  // namespace rb

@@ -31,7 +31,7 @@ size_t filter_emit_state_bytes(int64_t nw);
 void launch_filter_emit(const rb_batch *b, int64_t w0, int64_t nw, int k, int mode, uint32_t first_read, uint32_t pos_bits,
                         uint64_t seed, uint64_t ordinal0, Npf cache, OwnRange own, uint64_t *keys,
                         uint32_t *vals, uint32_t cap, void *state, uint32_t *kept_out, uint32_t *total_spread, hipStream_t s);
-// second look of the two-phase prefilter: the emit pass asks the recent-store table about every window it
+// second look of the two-phase prefilter (HISTORY.md s5): the emit pass asks the recent-store table about every window it
 // writes and CANCELS the record (key and occurrence id all ones; the grouping stage drops such records) if the occurrence
 // is a no-op by what was learnt since the window was filtered.  tab == nullptr: off.  Only the resuming emit kernel does it.
 struct EmitRecheck { Rst rst; uint64_t seed, ordinal0; };

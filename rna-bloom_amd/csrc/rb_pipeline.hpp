@@ -219,6 +219,16 @@ template <typename F> int guarded(F &&f) {
 }
 void alloc_bits(BitFilter &f, int64_t bits, int num_hash, int64_t lo, int64_t hi);
 void free_bits(BitFilter &f);
+// shared by the translation units of the single-GPU engine (rb_graph.hip: pipeline; rb_capi.hip: entry points; rb_query.hip: queries)
+const char *last_error_text();                      // this thread's message of the last failing call (rb_last_error)
+BitFilter *bit_filter(rb_graph *g, int which);      // RB_DBGBF / RB_RPKBF / RB_FPKBF -> the handle's filter, nullptr otherwise
+uint64_t *upload_h0(rb_graph *g, DevBuf &buf, const uint64_t *h0, size_t n, hipStream_t st = nullptr);
+void fast_zero(void *p, size_t bytes, hipStream_t s);
+void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigned flags, rb_add_stats *stats);      // the stage-1 insert of reads [first, first + n)
+void run_pipeline(rb_graph *g, size_t N, int mode, uint64_t ordinal0, uint32_t pos_bits, rb_add_stats *stats);       // the consumer half on N records in keys0 / vals0
+void launch_pairs_reads(rb_graph *g, const rb_batch *b, int64_t w0, int64_t nw, int mode_hash, const BitFilter &f, int dist,
+                        uint32_t min_len, bool if_present, const uint32_t *chunk_off, uint64_t *out_idx, unsigned long long *pc, hipStream_t st);
+__global__ void k_bits_add(uint32_t *bits, Mod mod, int num_hash, uint64_t kmul, const uint64_t *__restrict__ h0, size_t n);   // rb_query.hip
 void alloc_pair_seen(BitFilter &f);                 // seen-pair cache for a paired-k-mer filter (RB_PAIR_SEEN=0: none)
 void seen_reset(BitFilter &f, hipStream_t s);       // after anything that clears or replaces f.bits
 // one wavefront per high-multiplicity run: lanes fetch 64 occurrences at a time, compute each
@@ -332,7 +342,7 @@ struct rb_graph {
     // sharded mode (rb_shard.hip): this handle owns index range [lo,hi) of every filter
     int shard_rank = 0, shard_count = 1;
     ShardState *shard = nullptr;
-    rb_trav *trav = nullptr;          // a traversal in progress on a sharded graph (rb_shard_trav_*, rb_graph.hip)
+    rb_trav *trav = nullptr;          // a traversal in progress on a sharded graph (rb_shard_trav_*, rb_query.hip)
     rb_graph_params p{};
     int k = 0, H = 0;
     bool stranded = false;
@@ -492,8 +502,8 @@ void *alloc_best_placed(size_t bytes, const char *what);   // rb_graph.hip: zero
 uint64_t *shard_query_h0(rb_graph *g, size_t n);                                                 // rb_shard.hip: the query protocol with hashes already on the device
 void shard_query_make_dev(rb_graph *g, int what, int which_bits, size_t n, int64_t *bit_counts, int64_t *ctr_counts);
 const void *shard_query_combine_dev(rb_graph *g, int which_bits, const void *breply_dev, const void *creply_dev);
-void trav_free(rb_graph *g);    // rb_graph.hip: state of a traversal on a sharded graph
-void cbf_counts_device(rb_graph *g, const uint64_t *d_h0, size_t n, float *d_out);   // rb_graph.hip
+void trav_free(rb_graph *g);    // rb_query.hip: state of a traversal on a sharded graph
+void cbf_counts_device(rb_graph *g, const uint64_t *d_h0, size_t n, float *d_out);   // rb_query.hip
 void launch_pairs(rb_graph *g, const rb_batch *b, int64_t w0, int64_t nw, int mode_hash, const uint32_t *chunk_off,
                   uint64_t *out_idx, unsigned long long *n_pairs_dev, hipStream_t st = nullptr, const BitFilter *into = nullptr /* another bit array of the pair filter's geometry (the sharded engine's accumulation copy) */);
 }  // namespace rb
