@@ -1017,7 +1017,7 @@ __global__ void k_pairs_insert_runtime_branch(const uint64_t *__restrict__ codes
 // cache — BitFilter::seen is reset with the bits).  What makes it cheaper than the probes is the bucket function: consecutive pairs of a
 // read must share a bucket, and a pair must find the same bucket from whichever read it is seen in.  So the bucket is a function of the
 // pair's LEFT k-mer alone: the latest ANCHOR among its m-mers (m = min(16, k); an m-mer whose mixed canonical hash has its low two bits
-// clear: one in four), the k-mer's last m-mer if it has none — rolled along with the left window, one multiply per step.  A run of ~4
+// clear: one in four), the k-mer's last m-mer if it has none — the m-mer's 2-bit code shifted along with the left window, one 32-bit multiply per step.  A run of ~4
 // consecutive pairs shares an anchor: one 128-byte fetch into the lane's LDS image (entry e of lane l at [e][l]: conflict-free) per run
 // instead of 2 line requests per pair; a pair may sit in slot P & 15 or (P >> 4) & 15.  Stale or lost entries (races between lanes, L2
 // copies of another XCD) only cost the probes they would have saved.
@@ -1029,7 +1029,6 @@ k_pairs_reads(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ v
               uint64_t *__restrict__ out_idx, uint32_t min_len, const uint32_t *__restrict__ present, Mod present_mod, int present_h,
               PairSeen seen) {
     __shared__ uint64_t s_tf[25], s_tr[25];
-    __shared__ uint64_t s_mf[VAR == 1 ? 25 : 1], s_mr[VAR == 1 ? 25 : 1];
     __shared__ unsigned long long s_img[VAR == 1 ? 16 * 64 : 1];
     const uint32_t uk = (uint32_t)k, ud = (uint32_t)dist, span = uk + ud;
     const uint32_t um = uk < 16u ? uk : 16u;                          // m-mer of the bucket function (VAR 1)
@@ -1039,10 +1038,6 @@ k_pairs_reads(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ v
         const uint64_t sco = o ? seed_of(4u - o) : 0ull, sci = in ? seed_of(4u - in) : 0ull;
         s_tf[threadIdx.x] = rotl(so, uk) ^ si;
         s_tr[threadIdx.x] = rotr(sco, 1) ^ rotl(sci, uk - 1u);
-        if (VAR == 1) {
-            s_mf[threadIdx.x] = rotl(so, um) ^ si;
-            s_mr[threadIdx.x] = rotr(sco, 1) ^ rotl(sci, um - 1u);
-        }
     }
     __syncthreads();
     const int64_t t = (int64_t)blockIdx.x * 64 + threadIdx.x;
@@ -1086,8 +1081,10 @@ k_pairs_reads(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ v
             const uint32_t nsteps = L - ud;
             const int64_t wrel = (int64_t)wr - w0;                  // the read's first word, relative to w0 (out_idx mode)
             uint32_t obase = 0, ocnt = 0, oword = 0xFFFFFFFFu;
-            uint64_t fM = 0, rM = 0;                                 // VAR 1: the left stream's m-mer, its mixed hash, the latest anchor
+            uint32_t mF = 0, mR = 0;                                 // VAR 1: the left stream's m-mer as 2-bit codes (both strands), the latest anchor
+            const uint32_t mmask = um >= 16u ? 0xFFFFFFFFu : ((1u << (2u * um)) - 1u), mtop = 2u * (um - 1u);
             uint32_t akey = 0, apos1 = 0, xnew = 0, curb = 0xFFFFFFFFu;
+            uint32_t dbg_miss = 0, dbg_fetch = 0;
 #pragma nounroll
             for (uint32_t j = 0; j < nsteps; ++j) {
                 const uint32_t e = ud + j;                            // base entering the right window
@@ -1107,14 +1104,13 @@ k_pairs_reads(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ v
                     const uint32_t out5 = ((uint32_t)(hvL >> sh_v) & 1u) ? ((uint32_t)((far ? hcL2 : hcL) >> sh_c) & 3u) + 1u : 0u;
                     const uint32_t tt = out5 * 5u + in5;
                     fL = rotl(fL, 1) ^ s_tf[tt]; rL = rotr(rL, 1) ^ s_tr[tt];
-                    if (VAR == 1) {       // the m-mer that ends at base j (starts at j + 1 - m), mixed; an anchor if its low two bits are clear
-                        const uint32_t om5 = ((uint32_t)(hvL >> (um - 1u)) & 1u) ? ((uint32_t)(hcL >> (2u * (um - 1u))) & 3u) + 1u : 0u;
-                        const uint32_t tm = om5 * 5u + in5;
-                        fM = rotl(fM, 1) ^ s_mf[tm]; rM = rotr(rM, 1) ^ s_mr[tm];
-                        uint64_t x = (fM < rM ? fM : rM) * 0xff51afd7ed558ccdull;
-                        x ^= x >> 33;
-                        xnew = (uint32_t)(x >> 4);
-                        if (((uint32_t)x & seen.amask) == 0u && j + 1u >= um) { akey = xnew; apos1 = j + 2u - um; }
+                    if (VAR == 1) {       // the m-mer that ends at base j (starts at j + 1 - m): canonical 2-bit code, mixed; an anchor if the mix's low bits are clear
+                        mF = ((mF << 2) | codeL) & mmask;                 // (an unusable base enters as whatever its code bits are: a pair whose
+                        mR = (mR >> 2) | ((3u - codeL) << mtop);          //  left k-mer holds one does not exist, and nobody asks for its bucket)
+                        uint32_t x = (mF < mR ? mF : mR) * 0x9E3779B1u;
+                        x ^= x >> 15;
+                        xnew = x >> 4;
+                        if ((x & seen.amask) == 0u && j + 1u >= um) { akey = xnew; apos1 = j + 2u - um; }
                     }
                     hcL2 = (hcL2 << 2) | (hcL >> 62); hcL = (hcL << 2) | codeL; hvL = (hvL << 1) | okL;
                 }
@@ -1141,7 +1137,7 @@ k_pairs_reads(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ v
                             // bucket of the left k-mer [p, p + k): its latest anchor (start >= p), else its last m-mer
                             const uint32_t bk = (apos1 > p ? akey : xnew) & seen.mask;
                             if (bk != curb) {                         // fetch the bucket into this lane's column of the image
-                                curb = bk;
+                                curb = bk; ++dbg_fetch;
                                 const uint4 *src = reinterpret_cast<const uint4 *>(seen.tab + ((size_t)bk << 4));
                                 uint4 v[8];
 #pragma unroll
@@ -1155,6 +1151,7 @@ k_pairs_reads(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ v
                             const uint32_t sa = (uint32_t)P & 15u, sb0 = ((uint32_t)P >> 4) & 15u, sb = sb0 == sa ? (sa ^ 1u) : sb0;
                             const unsigned long long ea = s_img[sa * 64u + threadIdx.x], eb = s_img[sb * 64u + threadIdx.x];
                             if (P == 0ull || (ea != P && eb != P)) {
+                                ++dbg_miss;
                                 for (int h = 0; h < num_hash; ++h) bit_set(bits, index_of(multi_hash(P, (uint32_t)h, kmul), mod));
                                 if (P != 0ull) {                      // the entry follows the bits
                                     const uint32_t sl = ea == 0ull ? sa : (eb == 0ull ? sb : sa);
@@ -1169,6 +1166,7 @@ k_pairs_reads(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ v
                     }
                 }
             }
+            if (VAR == 1 && seen.dbg) { atomicAdd(seen.dbg, (unsigned long long)dbg_miss); atomicAdd(seen.dbg + 1, (unsigned long long)dbg_fetch); }
         }
     }
     if (n_pairs) {
@@ -1197,7 +1195,9 @@ void rb::launch_pairs_reads(rb_graph *g, const rb_batch *b, int64_t w0, int64_t 
     // the seen-pair cache serves plain adds into the filter it belongs to (a gated add counts the pairs that pass the gate: it probes anyway)
     const bool use_seen = f.seen && !out_idx && !present;
     static const uint32_t anchor_bits = getenv("RB_PAIR_SEEN_ANCHOR") ? (uint32_t)std::max(0, std::min(4, atoi(getenv("RB_PAIR_SEEN_ANCHOR")))) : 2u;
-    const PairSeen seen{use_seen ? f.seen : nullptr, use_seen ? (1u << f.seen_log2b) - 1u : 0u, (1u << anchor_bits) - 1u};
+    // (RB_DEBUG: the main pipeline's pair counter block has room behind the pair count — add_range prints what it finds there)
+    const PairSeen seen{use_seen ? f.seen : nullptr, use_seen ? (1u << f.seen_log2b) - 1u : 0u, (1u << anchor_bits) - 1u,
+                        (use_seen && pc == g->pairs_ctr.as<unsigned long long>() && getenv("RB_DEBUG")) ? pc + 1 : nullptr};
 #define RB_LAUNCH_PR3(M, NW, V)                                                                                          \
     hipLaunchKernelGGL((k_pairs_reads<M, NW, V>), gr, th, 0, st, b->codes, b->valid, b->woff, b->len, r0, r1 - r0, w0, g->k, \
                        dist, f.bits, f.mod, f.num_hash, kmul_of(g->k), pc, chunk_off, out_idx, min_len, present, g->dbg.mod, g->dbg.num_hash, seen)
@@ -2172,6 +2172,12 @@ void rb::add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, uns
         unsigned long long np = 0;
         RB_HIP(hipMemcpy(&np, g->pairs_ctr.p, 8, hipMemcpyDeviceToHost));
         if (stats) stats->pairs += (int64_t)np;
+        if (getenv("RB_DEBUG") && g->rpk.seen) {
+            unsigned long long d[2] = {0, 0};
+            RB_HIP(hipMemcpy(d, g->pairs_ctr.as<unsigned long long>() + 1, 16, hipMemcpyDeviceToHost));
+            fprintf(stderr, "[rb] seen-pair cache: %llu pairs, %llu not known (%.1f %%), %llu bucket fetches (%.2f per pair)\n", np, d[0], 100.0 * (double)d[0] / (double)std::max(np, 1ull),
+                    d[1], (double)d[1] / (double)std::max(np, 1ull));
+        }
     }
     g->prof_collect();
 }

@@ -37,6 +37,7 @@ struct PairSeen {
     unsigned long long *tab;
     uint32_t mask;            // buckets - 1
     uint32_t amask;           // an m-mer is an anchor when (mixed hash & amask) == 0: 3 = one in four (RB_PAIR_SEEN_ANCHOR=<log2 density>)
+    unsigned long long *dbg;  // RB_DEBUG: [0] pairs the cache did not know, [1] bucket fetches (nullptr: not counted)
 };
 
 // everything a kernel needs to address the filters (passed by value)
