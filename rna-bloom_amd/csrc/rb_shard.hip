@@ -952,6 +952,13 @@ void make_and_route_requests(rb_graph *g, uint32_t D, int mode, uint64_t ordinal
                        g->vals1().as<uint32_t>(), D, mode, S->stage0.as<uint64_t>(), S->stage1.as<uint64_t>(), d_drop,
                        S->stage3.as<uint64_t>(), c_drop, S->creq_dup.as<uint8_t>(), g->status.as<uint32_t>(), S->lmask.as<uint16_t>(),
                        S->lcv.as<uint64_t>(), S->lctr.as<uint32_t>());
+    if (S->G == 1) {      // one rank holds every range: every probe was local, nothing becomes a request — no routing passes over lists of dropped items
+        dreq_counts[0] = creq_counts[0] = 0;
+        (void)slot_reserve(S, RB_SLOT_DREQ_IDX, 0); (void)slot_reserve(S, RB_SLOT_DREQ_PROBE, 0); (void)slot_reserve(S, RB_SLOT_CREQ_IDX, 0);
+        if (nd) RB_HIP(hipMemsetAsync(S->dreq_pos.p, 0xFF, nd * 4, s));          // "no request slot", as route() marks a dropped item
+        if (nc) RB_HIP(hipMemsetAsync(S->creq_pos.p, 0xFF, nc * 4, s));
+        return;
+    }
     RouteIdx fd{S->stage0.as<uint64_t>(), d_drop, (uint64_t)S->span[RB_DBGBF], S->stage1.as<uint64_t>(), nullptr,
                 nullptr, nullptr, nullptr, S->dreq_pos.as<uint32_t>()};
     route(g, fd, nd, dreq_counts, [&](RouteIdx &ff, size_t kept) {
