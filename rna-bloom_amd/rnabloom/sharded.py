@@ -411,12 +411,20 @@ class NativeComm:
     def rccl(cls, dist, device, group=None):
         rank, world = dist.get_rank(group), dist.get_world_size(group)
         uid = np.zeros(128, np.uint8)
+        err = None
         if rank == 0:
-            check(lib.rb_shard_comm_unique_id(uid.ctypes.data_as(C.c_void_p)))
+            try:
+                check(lib.rb_shard_comm_unique_id(uid.ctypes.data_as(C.c_void_p)))
+            except Exception as e:      # noqa: BLE001 — every rank has to hear of it: the others are waiting in the broadcast below
+                err = str(e)
         if world > 1:
-            box = [uid.tobytes()]
+            box = [None if err else uid.tobytes()]
             dist.broadcast_object_list(box, src=0, group=group)
+            if box[0] is None:          # all ranks raise together (a rank 0 that raised alone would leave its peers in the broadcast for ever)
+                raise RuntimeError("rank 0 could not make an RCCL unique id" + (": " + err if err else ""))
             uid = np.frombuffer(box[0], np.uint8).copy()
+        elif err:
+            raise RuntimeError(err)
         h = C.c_void_p()
         check(lib.rb_shard_comm_create_rccl(uid.ctypes.data_as(C.c_void_p), rank, world, device, C.byref(h)))
         return cls(h)
