@@ -138,7 +138,8 @@ __global__ void __launch_bounds__(256) k_probe_h2(FilterView fv, const uint64_t 
                                                    uint32_t n_distinct, int mode, uint32_t *__restrict__ status, uint64_t *__restrict__ cvals,
                                                    uint64_t *__restrict__ foreign_idx, uint32_t *__restrict__ counters,
                                                    const uint8_t *__restrict__ st0 = nullptr, const uint8_t *__restrict__ st1 = nullptr,
-                                                   uint32_t mark_known = 0u /* every probe of the sub-batch went through the sweep */) {
+                                                   uint32_t mark_known = 0u /* every probe of the sub-batch went through the sweep */,
+                                                   uint32_t plain_ok = 0u /* ... and a counter has its Bloom bit's index: an unmet run reads its counters without claiming */) {
     const uint32_t d0 = (blockIdx.x * blockDim.x + threadIdx.x) * RUNS;
     uint64_t h0[RUNS], bi[RUNS][2], ci[RUNS][2];
     uint32_t cnt[RUNS], w[RUNS][2];
@@ -171,13 +172,21 @@ __global__ void __launch_bounds__(256) k_probe_h2(FilterView fv, const uint64_t 
         }
     }
     uint32_t st[RUNS];
-    bool claim[RUNS], dup[RUNS];
+    bool claim[RUNS], dup[RUNS], plain[RUNS];
     uint32_t n_coll_total = 0, n_allpre = 0;
 #pragma unroll
     for (int r = 0; r < RUNS; ++r) {
         uint32_t premask = 0, all = 1, coll = 0;
+        plain[r] = false;
         if (SWEPT) {
-            premask = (w[r][0] == 1u ? 1u : 0u) | (w[r][1] == 1u ? 2u : 0u);
+            // (report 4 = set before the sub-batch like 1, and another probe of the sub-batch asked for the same bit: k_sweep_bits)
+            premask = ((w[r][0] == 1u || w[r][0] == 4u) ? 1u : 0u) | ((w[r][1] == 1u || w[r][1] == 4u) ? 2u : 0u);
+            // Counters without claims.  With filters of equal size probe j of the counting filter has probe j's Bloom-bit index, and the sweep
+            // has seen every probe of the sub-batch: a run whose two probes met NO other probe (reports 0 / 1) touches counters no other run of
+            // the sub-batch touches — neither a claim mark nor the contested-counter machinery has anything to find, so it reads its counters
+            // with plain loads (48.8 G/s) instead of two returning atomics (17.6 G/s).  Every run that did meet somebody (2, 3, 4 — marks go by
+            // the low bits of the index, so a few more than really did) claims as before, and so do all when the sweep missed a probe.
+            plain[r] = plain_ok && w[r][0] < 2u && w[r][1] < 2u;
             all = premask == 3u;
             coll = (w[r][0] == 2u ? 1u : 0u) | (w[r][1] == 2u ? 2u : 0u);
             const uint32_t join = (w[r][0] == 3u ? 1u : 0u) | (w[r][1] == 3u ? 2u : 0u);
@@ -198,12 +207,13 @@ __global__ void __launch_bounds__(256) k_probe_h2(FilterView fv, const uint64_t 
             if (claim[r]) { h0[r] = uniq[d0 + r]; ci[r][0] = index_of(h0[r], fv.cbf_mod); ci[r][1] = index_of(multi_hash(h0[r], 1u, fv.kmul), fv.cbf_mod); }
         }
         dup[r] = ci[r][0] == ci[r][1];
+        plain[r] = plain[r] && !dup[r];                          // (a run whose two probes are one counter met itself on the bit; belt and braces)
     }
     uint32_t b0[RUNS], b1[RUNS];
 #pragma unroll
-    for (int r = 0; r < RUNS; ++r) {                          // all claims in flight together
-        b0[r] = claim[r] ? cbf_claim(fv.cbf, ci[r][0]) : 0u;
-        b1[r] = (claim[r] && !dup[r]) ? cbf_claim(fv.cbf, ci[r][1]) : 0u;
+    for (int r = 0; r < RUNS; ++r) {                          // all claims (or loads) in flight together
+        b0[r] = !claim[r] ? 0u : plain[r] ? (uint32_t)fv.cbf[ci[r][0]] : cbf_claim(fv.cbf, ci[r][0]);
+        b1[r] = !(claim[r] && !dup[r]) ? 0u : plain[r] ? (uint32_t)fv.cbf[ci[r][1]] : cbf_claim(fv.cbf, ci[r][1]);
     }
     uint32_t n_foreign_total = 0;
 #pragma unroll
@@ -517,9 +527,17 @@ __global__ void k_resolve_apply(FilterView fv, const uint64_t *__restrict__ uniq
                                 const uint64_t *__restrict__ cvals, const uint8_t *__restrict__ tz, float *__restrict__ dbgf) {
     uint32_t d = blockIdx.x * blockDim.x + threadIdx.x;
     if (d >= n_distinct) return;
+    uint32_t st = status[d];
+    // A k-mer that is new, seen once in this sub-batch, and whose first sighting did find a clear bit (ST_LATE without ST_LATE_FOUND; its bits
+    // are set already): nothing to count, nothing to look up.  Five runs in six of a long-read insert are of this kind — they leave here
+    // on their status word alone instead of pulling hash, count, start, counter values and first occurrence through (28 B + a gather per run).
+    if (mode == M_ADD && bits_set && (st & (ST_LATE | ST_LATE_FOUND | ST_CLAIMED)) == ST_LATE) {
+        nops[d] = 0u;
+        status[d] = (st & 0x7FFu) | (K_INC << 12) | (K_INC << 14);
+        return;
+    }
     const uint64_t h0 = uniq[d];
     const uint32_t m = counts[d];
-    uint32_t st = status[d];
     // what the light-run path at the bottom needs, asked for up front: this kernel waits on memory for two thirds of its life
     // (profiles/r03_sq_counters), one dependent load after the other.  (Also asking for the bit-filter words and the first line
     // of strengths here measured 1 ms slower: 48.2 against 47.1 ms.)
@@ -1503,7 +1521,8 @@ void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, ui
         ((uint64_t)g->dbg.size >> GS.sweep_T) < (1ull << 31)) {       // (the sweep counts a range's bits in 32 bits)
         const char *e = getenv("RB_SWEEP");
         // (and most runs new: where the sub-batch before found most of its k-mers present the sweep only rewrites set bits — the plain loads are cheaper)
-        swept = (e && atoi(e) == 1) || ((uint64_t)D * 64ull >= (uint64_t)g->dbg.nbytes && g->last_present_frac < 0.5f);
+        static const float present_max = getenv("RB_SWEEP_PRESENT") ? (float)atof(getenv("RB_SWEEP_PRESENT")) : 0.5f;
+        swept = (e && atoi(e) == 1) || ((uint64_t)D * 64ull >= (uint64_t)g->dbg.nbytes && g->last_present_frac < present_max);
     }
     if (swept) {
         const GrIdx didx{g->dbg.mod, 0, (uint64_t)g->dbg.size};
@@ -1518,7 +1537,8 @@ void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, ui
                           g->heavy.as<uint32_t>(), g->sw_temp.p, g->sw_temp.cap, st0, st1, s);
         constexpr int RUNS = 2;
         hipLaunchKernelGGL((k_probe_h2<RUNS, true>), dim3(blocks_for(((int64_t)D + RUNS - 1) / RUNS)), dim3(TPB), 0, s, fv, uniq, counts, D, mode, status,
-                           g->cvals.as<uint64_t>(), g->foreign.as<uint64_t>(), ctr, (const uint8_t *)st0, (const uint8_t *)st1, swept_all ? 1u : 0u);
+                           g->cvals.as<uint64_t>(), g->foreign.as<uint64_t>(), ctr, (const uint8_t *)st0, (const uint8_t *)st1, swept_all ? 1u : 0u,
+                           (swept_all && (int64_t)g->dbg.size == g->cbf_size && g->cbf_lo == 0 && !(getenv("RB_SWEEP_CLAIMS") && atoi(getenv("RB_SWEEP_CLAIMS")))) ? 1u : 0u);
     } else if (!ftab && fv.dbg_h == 2 && fv.cbf_h == 2 && !getenv("RB_PROBE_GENERIC")) {
         constexpr int RUNS = 2;
         hipLaunchKernelGGL((k_probe_h2<RUNS, false>), dim3(blocks_for(((int64_t)D + RUNS - 1) / RUNS)), dim3(TPB), 0, s, fv, uniq, counts, D, mode, status,

@@ -1148,7 +1148,7 @@ uint32_t group_index_buckets(size_t N, int group_bits, int bucket_target, int fl
 // set it.  A probe that finds its bit set in LDS looks at the word in HBM — still the state before the sub-batch, the range is written
 // back after its probes — to tell 1 from 2.  Neighbouring ranges may share a word: words that are not wholly inside the range are
 // written back with atomicOr (bits are only ever set), the others with plain 16-byte stores.
-constexpr uint32_t SW_WORDS = 16384;          // 64 KB of filter per round (+ 4 KB of collision marks): two workgroups per CU (160 KB of LDS)
+constexpr uint32_t SW_WORDS = 16384;          // 64 KB of filter per round (+ 2 x 4 KB of marks: met, touched): two workgroups per CU (160 KB of LDS)
 constexpr uint32_t SW_MARKS = 1024;           // words of collision marks, addressed by the low bits of the bit index
 __device__ __forceinline__ uint32_t sw_digit(uint64_t x, const GrIdxDev &ix) {
     return min((uint32_t)min(__umul64hi(x, ix.mul), (uint64_t)0xFFFFFFFFull), ix.top);
@@ -1162,6 +1162,9 @@ __device__ __forceinline__ uint64_t sw_first(uint32_t c, const GrIdxDev &ix, uin
     while (e < span && sw_digit(e, ix) < c) ++e;
     return e;
 }
+// (round 5) 4 = set before the sub-batch AND another probe of the sub-batch asked (or may have asked: marks go by the low bits of the index)
+// for the same bit — irrelevant to the Bloom filter, but the counting filter has the same index: a run none of whose probes met anybody has its
+// counters to itself and reads them with plain loads instead of claiming them (k_probe_h2).
 // what a probe reports (st0 / st1): 0 it set the bit and nobody else asked for it; 1 set before the sub-batch; 2 clear before, set by another
 // probe of the sub-batch that got there first; 3 it set the bit and another probe MAY have met it there (marks are per low bits of the index:
 // a probe of another bit that shares them is told so too, and finds no entry in the collision table) — the probes with 2 or 3 are the ones
@@ -1172,7 +1175,7 @@ __global__ void __launch_bounds__(TPB, 4) k_sweep_bits(uint32_t *words, GrIdxDev
                                                     const uint64_t *__restrict__ k1, const uint32_t *__restrict__ v1, const uint32_t *__restrict__ bstart1,
                                                     uint8_t *st0, uint8_t *st1, uint32_t SWW /* words of filter per round: dynamic LDS = (SWW + SW_MARKS) words */) {
     extern __shared__ __attribute__((aligned(16))) uint32_t sw_lds[];
-    uint32_t *s_w = sw_lds, *s_c = sw_lds + SWW;
+    uint32_t *s_w = sw_lds, *s_c = sw_lds + SWW, *s_t = sw_lds + SWW + SW_MARKS;      // filter words of the round; "met" marks; "touched" marks of bits that were set before
     __shared__ uint32_t s_any;
     const uint32_t c = blockIdx.x;
     const uint32_t r0 = brun[c], nr = bnr[c], p0 = bstart1[c], p1 = bstart1[c + 1u];
@@ -1205,7 +1208,7 @@ __global__ void __launch_bounds__(TPB, 4) k_sweep_bits(uint32_t *words, GrIdxDev
             if (i + 4u <= cnt) *reinterpret_cast<uint4 *>(s_w + i) = *reinterpret_cast<const uint4 *>(words + wb + i);
             else for (uint32_t q = i; q < cnt; ++q) s_w[q] = words[wb + q];
         }
-        for (uint32_t i = threadIdx.x; i < SW_MARKS; i += TPB) s_c[i] = 0u;
+        for (uint32_t i = threadIdx.x; i < 2u * SW_MARKS; i += TPB) s_c[i] = 0u;          // (s_t lies behind s_c)
         if (threadIdx.x == 0) s_any = 0u;
         __syncthreads();
         // one probe (rel: its bit, counted from the range's first loaded word): test-and-set in LDS; a bit found set is looked up in HBM (still the
@@ -1215,22 +1218,30 @@ __global__ void __launch_bounds__(TPB, 4) k_sweep_bits(uint32_t *words, GrIdxDev
             if (rel == NONE || w >= cnt) return -1;
             const uint32_t m = 1u << (rel & 31u);
             if (!(atomicOr(&s_w[w], m) & m)) return 0;
-            if (__hip_atomic_load(&words[w_lo + (rel >> 5)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & m) return 1;
+            if (__hip_atomic_load(&words[w_lo + (rel >> 5)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & m) {
+                // set before the sub-batch: nothing to arbitrate — but whether ANOTHER probe of the sub-batch asks for the same bit decides whether the
+                // run may read its counter without claiming it (same index in the counting filter, k_probe_h2): the first such probe leaves a touch mark,
+                // a later one finds it, marks the bit as met and reports 4; the first one hears of it behind the barrier
+                if (atomicOr(&s_t[w & (SW_MARKS - 1u)], m) & m) { atomicOr(&s_c[w & (SW_MARKS - 1u)], m); s_any = 1u; return 4; }
+                return 1;
+            }
             atomicOr(&s_c[w & (SW_MARKS - 1u)], m); s_any = 1u;
             return 2;
         };
-        uint32_t setmask = 0;                                  // bit it: probe 0 of iteration it set its bit in this round; bit 16 + it: probe 1
+        uint32_t setmask = 0, premask = 0;                     // bit it: probe 0 of iteration it set its bit in this round (premask: found it set before the sub-batch); bit 16 + it: probe 1
 #pragma unroll
         for (uint32_t it = 0; it < KEEP; ++it) {
             const int s = probe(i0[it]);
             if (s >= 0) st0[r0 + it * TPB + threadIdx.x] = (uint8_t)s;
             if (s == 0) setmask |= 1u << it;
+            if (s == 1) premask |= 1u << it;
         }
 #pragma unroll
         for (uint32_t it = 0; it < KEEP; ++it) {
             const int s = probe(i1[it]);
             if (s > 0) st1[v1[p0 + it * TPB + threadIdx.x]] = (uint8_t)s;
             if (s == 0) setmask |= 1u << (16u + it);
+            if (s == 1) premask |= 1u << (16u + it);
         }
         for (uint32_t j = p0 + KEEP * TPB + threadIdx.x; j < p1; j += TPB) {       // (a bin far above the average)
             const int s = probe((uint32_t)(index_of(k1[j], ix.mod) - ix.lo - bit0));
@@ -1242,13 +1253,15 @@ __global__ void __launch_bounds__(TPB, 4) k_sweep_bits(uint32_t *words, GrIdxDev
 #pragma unroll
             for (uint32_t it = 0; it < KEEP; ++it) {
                 if (((setmask >> it) & 1u) && marked(i0[it])) st0[r0 + it * TPB + threadIdx.x] = 3;
+                if (((premask >> it) & 1u) && marked(i0[it])) st0[r0 + it * TPB + threadIdx.x] = 4;
                 if (((setmask >> (16u + it)) & 1u) && marked(i1[it])) st1[v1[p0 + it * TPB + threadIdx.x]] = 3;
+                if (((premask >> (16u + it)) & 1u) && marked(i1[it])) st1[v1[p0 + it * TPB + threadIdx.x]] = 4;
             }
             for (uint32_t j = p0 + KEEP * TPB + threadIdx.x; j < p1; j += TPB) {
                 const uint32_t rel = (uint32_t)(index_of(k1[j], ix.mod) - ix.lo - bit0);
                 if ((rel >> 5) - wrel < cnt && marked(rel)) {
                     const uint32_t d = v1[j];
-                    if (st1[d] == 0) st1[d] = 3;
+                    if (st1[d] == 0) st1[d] = 3; else if (st1[d] == 1) st1[d] = 4;
                 }
             }
         }
@@ -1305,8 +1318,8 @@ void sweep_bits_device(uint32_t *words, GrIdx idx, uint32_t T, uint64_t kmul, co
     // a round holds a whole range where it fits 64 KB; LDS is sized to the range (two workgroups per CU either way: 128 VGPRs)
     const uint64_t range_words = (idx.span >> T) / 32 + 16;
     const uint32_t sww = (uint32_t)std::min<uint64_t>(SW_WORDS, (range_words + 1023) / 1024 * 1024);
-    RB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep_bits<512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((SW_WORDS + SW_MARKS) * 4)));
-    hipLaunchKernelGGL(k_sweep_bits<512>, dim3(P.nbuckets), dim3(512), (sww + SW_MARKS) * 4, st, words, ix, idx.span, T, uniq, brun, bnr, k1, v1, bstart1, st0, st1, sww);
+    RB_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(k_sweep_bits<512>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)((SW_WORDS + 2 * SW_MARKS) * 4)));
+    hipLaunchKernelGGL(k_sweep_bits<512>, dim3(P.nbuckets), dim3(512), (sww + 2 * SW_MARKS) * 4, st, words, ix, idx.span, T, uniq, brun, bnr, k1, v1, bstart1, st0, st1, sww);
     if (n_big) hipLaunchKernelGGL(k_sw_big_set, dim3((n_big + 255u) / 256u), dim3(256), 0, st, words, idx.mod, idx.lo, uniq, n_main, D, st0);
     RB_HIP(hipGetLastError());
 }
