@@ -420,6 +420,27 @@ def test_swept_bloom_bit_stage_with_oversized_buckets_and_shared_words(monkeypat
     assert og.cbf_bytes().max() > 40
 
 
+@pytest.mark.parametrize("claims", ["0", "1"])
+@pytest.mark.parametrize("T", ["3", "9"])
+@pytest.mark.parametrize("size", [60_013, 200_003, 3_000_017])
+def test_swept_stage_reads_unmet_counters_without_claiming_them(monkeypatch, size, T, claims):
+    """round 5: behind the swept stage a run none of whose Bloom probes met another probe of the sub-batch reads its counters with plain loads
+    instead of claiming them (filters of EQUAL size: probe j of the counting filter has probe j's Bloom-bit index; k_probe_h2<., true>).  Filters
+    so small that most probes do meet somebody and counters are shared all over (60 013 entries), and sparser ones where most do not; deep
+    coverage (counters well into the probabilistic range), many sub-batches, no oversized bucket (one would switch the shortcut off), both
+    files of a library and a second pass in which every bit is found set; RB_SWEEP_CLAIMS=1 (everybody claims, round 4) gives the same bytes."""
+    monkeypatch.setenv("RB_SWEEP", "1"); monkeypatch.setenv("RB_SWEEP_CLAIMS", claims); monkeypatch.setenv("RB_GROUP_T", T)     # (T: index ranges per sub-batch — the sweep needs at least one partition bit)
+    (ls, lq, off), (rs, rq, roff) = make_reads(3000, 8000, 0.003, 1e-3, seed=size % 89)
+    og, gg = graph_pair(size, size, 30_011, max_batch=40_000)
+    og.set_read_pair_distance(115); gg.setReadPairedKmerDistance(115)
+    for rep in range(2):
+        for seq, qual, o, rc in ((ls, lq, off, False), (rs, rq, roff, True)):
+            og.add_reads(seq, qual, o, 3, rbo.REVCOMP if rc else 0)
+            gg.addReads(seq, qual, o, 3, reverseComplement=rc)
+            assert_same_state(og, gg, pairs=False)
+    assert og.cbf_bytes().max() > 40
+
+
 @pytest.mark.parametrize("k", [25, 35])
 @pytest.mark.parametrize("sweep", ["0", "1"])
 @pytest.mark.parametrize("pairs", [False, True])
