@@ -310,9 +310,16 @@ def test_no_kernel_picks_its_store_target_at_run_time_inside_a_loop():
 
 
 def test_library_carries_the_id_of_the_sources_it_was_built_from():
-    """rb_build_id() == tools/csrc_id.py of the tree: what bench.py compares with the id stored beside the committed PMC summaries"""
-    import sys
+    """rb_build_id() == tools/csrc_id.py of the tree: what bench.py compares with the id stored beside the committed PMC summaries.  A library
+    left over from before the last source edit is rebuilt first (make: seconds for the one small unit when nothing else changed) — the claim
+    under test is that THIS tree builds into a library that carries its id, asked of a fresh process."""
+    import subprocess, sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import csrc_id
-    from rnabloom import _native as N
-    assert N.lib.rb_build_id().decode() == csrc_id.csrc_id(ROOT)
+    want = csrc_id.csrc_id(ROOT)
+    ask = [sys.executable, "-c", "import sys; sys.path[:0] = [%r]; from rnabloom import _native as N; print(N.lib.rb_build_id().decode())" % os.path.join(ROOT, "rna-bloom_amd")]
+    got = subprocess.run(ask, capture_output=True, text=True, timeout=300).stdout.strip().splitlines()[-1:]
+    if got != [want]:
+        subprocess.run(["make", "-C", os.path.join(ROOT, "rna-bloom_amd"), "-j4"], capture_output=True, timeout=1800)
+        got = subprocess.run(ask, capture_output=True, text=True, timeout=300).stdout.strip().splitlines()[-1:]
+    assert got == [want], (got, want)
