@@ -33,6 +33,14 @@ for l in L[a:b + 1]:
     if add:
         for _ in range(int(add)): out.append('\ts_nop 7')
         n += 1
+if v.startswith('swap'):          # swapA_B: rename two single registers throughout the kernel (same instructions, same count: only WHICH value lives where)
+    ra, rb = re.match(r'swap(\d+)_(\d+)', v).groups()
+    k0 = len(L[:a])
+    def sw(line):
+        code, sep, cmt = line.partition(';')
+        code = re.sub(r'\bv(%s|%s)\b' % (ra, rb), lambda m: 'v' + (rb if m.group(1) == ra else ra), code)
+        return code + sep + cmt
+    out[k0:] = [sw(l) for l in out[k0:]]
 tail = L[b + 1:]
 # descriptor-only variants: no instruction changes, the kernel descriptor asks for more registers
 for vv in (v.split('+') if v.startswith(('sgpr', 'vgpr', 'accum')) else []):

@@ -6,6 +6,7 @@
 # so that an edited rb_graph-hip-amdgcn-amd-amdhsa-gfx950.s becomes build/rb_graph.o again.  mk_variant.py makes the edits; isa_probe.sh (run through
 # gpurun) loops over variants: rebuild, relink the library, count wrong bits with tools/pairs_variants.py.  Findings: profiles/r05_miscompile.md.
 set -e
+HERE=$(cd "$(dirname "$0")" && pwd)
 T=$(cd "$1" && pwd)/rna-bloom_amd; shift
 mkdir -p $T/build $T/st && cd $T/st
 hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -Wno-unused-function -DRB_DIAG_PAIRS "$@" -save-temps -v -c ../csrc/rb_graph.hip -o ../build/rb_graph.o > v.log 2>&1
@@ -18,5 +19,5 @@ assert len(sel) == 6, len(sel)
 open('rebuild_from_s.sh', 'w').write('#!/bin/bash\nset -e\ncd "$(dirname "$0")"\n' + '\n'.join(sel) + '\n')
 PY
 chmod +x rebuild_from_s.sh
-cp "$(dirname "$0")/mk_variant.py" . 2>/dev/null || true
+cp "$HERE/mk_variant.py" .
 echo "ready: $T/st (dev_orig.s, rebuild_from_s.sh, mk_variant.py)"
