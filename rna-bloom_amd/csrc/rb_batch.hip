@@ -1040,6 +1040,182 @@ k_filter_reads_pipe(const uint64_t *__restrict__ codes, const uint32_t *__restri
     if (threadIdx.x == 0 && total) atomicAdd(&total_spread[16u * (blockIdx.x & 31u)], total);
 }
 
+// The same walk with the bucket fetch done by the WAVEFRONT instead of by the lane that wants it (RB_FILTER_PIPE=3).
+// k_filter_reads_pipe issues eight 16-byte loads under the mask of the ~10 lanes (15 %) whose minimizer changed in a step, in nearly every step; the texture
+// path pays for a vector-memory instruction by its lanes' distinct lines, not by its bytes, and that — not the ALU, not HBM — bounds the kernel
+// (tools/microbench/bucket_fetch.hip: 28.6 G buckets/s for that shape against 56 G/s for the one below; the kernel ran at 21.6 G/s).  Here the lanes that
+// want a bucket post (bucket, lane) to a list in LDS and every group of four lanes fetches one posted bucket with two 16-byte loads per lane — a 64-byte
+// segment per group and instruction — for whoever asked; a step later the helpers store what arrived into the asker's image.  Two vector-memory
+// instructions a step instead of eight, 8 staging registers instead of 32.  For the helpers to exist every lane has to be in the loop: the step counter is
+// wave-uniform (a scalar), a lane whose read is shorter idles along with `live` off.  More than 16 askers in a step (the first window of a read: all 64)
+// are served in place after the lookup, sixteen at a time.  LDS is cut to 10 192 bytes for a fourth wavefront per SIMD: the images have no padding (slot s
+// of lane l sits at 16 l + (s ^ 2 (l & 7)): the XOR spreads the helpers' 16-byte stores and the lookups over the banks), the list has 16 entries.
+// Same cache, same draws, same counts and masks per word (RB_FILTER_CHECK=1 runs the other two walkers beside this one and compares every word).
+template <int MODE, bool WIDE>
+__global__ void __launch_bounds__(64)
+k_filter_reads_coop(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
+                    const uint32_t *__restrict__ word_read, const uint32_t *__restrict__ len, int64_t w0, int64_t nw, int k,
+                    uint32_t W_, uint32_t first_read, uint32_t pos_bits, uint64_t seed, uint64_t ordinal0, Mpf mcache,
+                    uint32_t *__restrict__ cnt, uint32_t *__restrict__ keepmask, uint32_t *__restrict__ total_spread,
+                    uint32_t dbg_flags, ulonglong2 *__restrict__ wstate, const uint32_t *__restrict__ woff, uint32_t rd0, uint32_t n_rd) {
+    __shared__ uint64_t s_tf[25], s_tr[25];
+    extern __shared__ uint32_t s_ring[];                        // [k-m+1][lane]
+    __shared__ __attribute__((aligned(16))) unsigned long long s_img[64 * 16];
+    __shared__ uint32_t s_list[16];                             // up to 16 askers of this step: bucket | lane << 26 (bucket numbers have at most 26 bits)
+    const uint32_t uk = (uint32_t)k, lane = threadIdx.x;
+    if (threadIdx.x < 25) {
+        const uint32_t o = threadIdx.x / 5u, in = threadIdx.x % 5u;
+        const uint64_t so = o ? seed_of(o - 1u) : 0ull, si = in ? seed_of(in - 1u) : 0ull;
+        const uint64_t sco = o ? seed_of(4u - o) : 0ull, sci = in ? seed_of(4u - in) : 0ull;
+        s_tf[threadIdx.x] = rotl(so, uk) ^ si;
+        s_tr[threadIdx.x] = rotr(sco, 1) ^ rotl(sci, uk - 1u);
+    }
+    __syncthreads();
+    const int64_t lane_t = (int64_t)blockIdx.x * 64 + threadIdx.x;          // (lane -> read as in k_filter_reads)
+    const bool active = W_ ? lane_t * (int64_t)W_ < nw : lane_t < (int64_t)n_rd;
+    const int64_t w = !active ? nw : W_ ? lane_t * (int64_t)W_ : (int64_t)woff[rd0 + (uint32_t)lane_t] - w0;
+    uint32_t L = 0, W = 0, r = 0;
+    if (active) {
+        r = W_ ? word_read[w0 + w] : rd0 + (uint32_t)lane_t; L = len[r];
+        W = W_ ? W_ : (L + 31u) >> 5;
+    }
+    const bool walk = active && uk <= L;
+    const uint32_t Lw = walk ? L : 0u;                          // the bases this lane walks
+    uint32_t Lmax = Lw;
+    for (int o = 32; o > 0; o >>= 1) { const uint32_t v = (uint32_t)__shfl_xor((int)Lmax, o, 64); Lmax = v > Lmax ? v : Lmax; }
+    Lmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)Lmax);
+    uint64_t carr[RB_READ_WORDS];
+    uint32_t varr[RB_READ_WORDS];
+#pragma unroll
+    for (int q = 0; q < RB_READ_WORDS; ++q) {
+        carr[q] = 0; varr[q] = 0;
+        if (walk && (uint32_t)q < W) { carr[q] = codes[w0 + w + q]; varr[q] = valid[w0 + w + q]; }
+    }
+    const uint32_t rstate = rng_read_state(seed, ordinal0 + (uint64_t)(r - first_read));
+    // WIDE (32 <= k <= 63): 64 bases of history in two words, and the minimizer is that of the k-mer's last 31 bases
+    const uint32_t sh_c = 2u * ((uk - 1u) & 31u), sh_v = uk - 1u;
+    const bool far = WIDE && uk > 32u;                   // the outgoing base sits in the older history word
+    const uint32_t um = mcache.m, uw = mpf_kp(uk) - um + 1u;
+    const uint32_t lag = mpf_lag(uk);                  // the minimizer's sub-window ends `lag` bases before the k-mer does (0 for k <= 25, at most 19)
+    const uint32_t mmask = (um >= 16u) ? 0xFFFFFFFFu : ((1u << (2u * um)) - 1u);
+    uint32_t mf = 0, mr = 0, blk_a = 0, blk_p = 0;
+    uint32_t cur_bkt = ~0u;
+    uint64_t f = 0, rv = 0, hc = 0, hc2 = 0, hvw = 0, cur_c = 0;
+    uint32_t run = 0, kept = 0, mask = 0, cur_v = 0, hv = 0, total = 0, done = 0;
+    // what this lane fetched for somebody in the step before: the asker (64 = nobody) and its quarter of the two 64-byte halves of the bucket
+    const uint32_t grp = lane >> 2, sub = lane & 3u;
+    const ulonglong2 *const tab2 = reinterpret_cast<const ulonglong2 *>(mcache.tab) + sub;
+    uint32_t tgt = 64u;
+    ulonglong2 V0 = make_ulonglong2(0, 0), V1 = make_ulonglong2(0, 0);
+    uint64_t pend_h0 = 0;
+    bool pend = false;
+    const uint32_t no_drop = (dbg_flags & 2u) ? 1u : 0u;
+    const unsigned long long *img = &s_img[lane * 16u];
+    const uint32_t swz = (lane & 7u) << 1;
+    // 16-byte granules `sub` and `4 + sub` of asker t's bucket -> its image (stored as the u64 words the lookups read)
+    auto put = [&](uint32_t t, const ulonglong2 &x0, const ulonglong2 &x1) {
+        unsigned long long *d = &s_img[t * 16u + ((sub ^ (t & 7u)) << 1)];
+        d[0] = x0.x; d[1] = x0.y;
+        unsigned long long *e = &s_img[t * 16u + (((sub ^ (t & 7u)) ^ 4u) << 1)];
+        e[0] = x1.x; e[1] = x1.y;
+    };
+    for (uint32_t b = 0; b < Lmax; ++b) {                  // b is the same in every lane: scalar bookkeeping
+        const bool live = b < Lw;
+        if ((b & 31u) == 0u) {
+            const uint32_t wi = b >> 5;
+#pragma unroll
+            for (int q = 0; q < RB_READ_WORDS; ++q) if ((uint32_t)q == wi) { cur_c = carr[q]; cur_v = varr[q]; }
+        }
+        const uint32_t pb = b + 1u - uk;
+        const uint32_t code = (uint32_t)cur_c & 3u, ok = live ? (cur_v & 1u) : 0u;
+        cur_c >>= 2; cur_v >>= 1;
+        run = ok ? run + 1u : 0u;
+        // minimizer of the window that ends at this base (garbage while run < m: never consulted then)
+        const uint32_t mcode = lag ? (uint32_t)(hc >> (2u * (lag - 1u))) & 3u : code;
+        mf = ((mf << 2) | mcode) & mmask;
+        mr = (mr >> 2) | ((3u - mcode) << (2u * (um - 1u)));
+        const uint32_t o_cur = mmer_order(mf < mr ? mf : mr);
+        s_ring[blk_a * 64u + lane] = o_cur;
+        blk_p = blk_a ? (o_cur < blk_p ? o_cur : blk_p) : o_cur;
+        const bool win = run >= uk;
+        const uint32_t nxt = blk_a + 1u < uw ? blk_a + 1u : blk_a;          // the block's last slot has no suffix to look at
+        const uint32_t sfx = s_ring[nxt * 64u + lane];
+        const uint32_t omin = (blk_a + 1u < uw && sfx < blk_p) ? sfx : blk_p;
+        const uint32_t bkt = (uint32_t)mpf_bucket(mcache, omin);
+        if (tgt < 64u) put(tgt, V0, V1);                 // the step before's buckets have had a step to arrive
+        tgt = 64u;
+        const bool sw = win && bkt != cur_bkt;
+        const unsigned long long asks = __ballot(sw);
+        uint32_t n_ask = 0, rank = 0;
+        if (asks) {                                      // (wave-uniform)
+            rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(asks >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)asks, 0u));
+            if (sw) { if (rank < 16u) s_list[rank] = bkt | (lane << 26); cur_bkt = bkt; }
+            n_ask = (uint32_t)__popcll(asks);
+            if (grp < n_ask) {
+                const uint32_t ent = s_list[grp];
+                const ulonglong2 *bp = tab2 + ((size_t)(ent & 0x3FFFFFFu) << 3);
+                V0 = bp[0]; V1 = bp[4];
+                tgt = ent >> 26;
+            }
+        }
+        {   // the pending window (the one that ended a base ago): lookup, draw and bookkeeping — straight-line: a lane without one computes on stale values and adds zero
+            const unsigned long long ea = img[mpf_slot_a(pend_h0) ^ swz], eb = img[mpf_slot_b(pend_h0) ^ swz];
+            const uint32_t s_known = mpf_match_entries(ea, eb, pend_h0);
+            const uint32_t strength = draw_strength(rng_pos(rstate, pb - 1u));
+            const uint32_t on = pend ? 1u : 0u;
+            const uint32_t keep = on & ((s_known == 0u ? 1u : 0u) | no_drop | (strength >= s_known ? 1u : 0u));
+            total += on;
+            kept += keep;
+            mask |= keep << ((pb - 1u) & 31u);
+        }
+        for (uint32_t e0 = 16u; e0 < n_ask; e0 += 16u) {   // a crowded step: the askers beyond the sixteenth, in place (their lookups are a step away)
+            if (sw && rank >= e0 && rank < e0 + 16u) s_list[rank - e0] = bkt | (lane << 26);
+            if (e0 + grp < n_ask) {
+                const uint32_t ent = s_list[grp];
+                const ulonglong2 *bp = tab2 + ((size_t)(ent & 0x3FFFFFFu) << 3);
+                const ulonglong2 x0 = bp[0], x1 = bp[4];
+                put(ent >> 26, x0, x1);
+            }
+        }
+        if ((pb & 31u) == 0u && (int32_t)pb > 0) {       // the window of this base starts a new word: the word before is final (its last window was just decided)
+            if (live) { cnt[w + done] = kept; keepmask[w + done] = mask; ++done; kept = 0; mask = 0; }
+        }
+        const uint32_t in5 = ok ? code + 1u : 0u;
+        const uint32_t ok_out = WIDE ? (uint32_t)(hvw >> sh_v) & 1u : (hv >> sh_v) & 1u;
+        const uint32_t out5 = ok_out ? ((uint32_t)((far ? hc2 : hc) >> sh_c) & 3u) + 1u : 0u;
+        const uint32_t tt = out5 * 5u + in5;
+        if (MODE != 2) f = rotl(f, 1) ^ s_tf[tt];
+        if (MODE != 0) rv = rotr(rv, 1) ^ s_tr[tt];
+        if (WIDE) { hc2 = (hc2 << 2) | (hc >> 62); hvw = (hvw << 1) | ok; } else hv = (hv << 1) | ok;
+        hc = (hc << 2) | code;
+        pend = win;
+        pend_h0 = (MODE == 0) ? f : (MODE == 2) ? rv : canonical(f, rv);   // (unused unless pend)
+        if (blk_a + 1u == uw) {   // block complete: turn its ring entries into suffix minima
+            uint32_t sm = 0xFFFFFFFFu;
+            for (uint32_t q = uw; q-- > 0u;) { const uint32_t v = s_ring[q * 64u + lane]; sm = v < sm ? v : sm; s_ring[q * 64u + lane] = sm; }
+            blk_a = 0;
+        } else
+            ++blk_a;
+        // the rolling state just before the first window of a word ends: the emit pass resumes from it
+        if (wstate && ((b + 2u - uk) & 31u) == 0u && b + 2u >= uk && live) wstate[w + ((b + 2u - uk) >> 5)] = make_ulonglong2(f, rv);
+    }
+    {   // the last window
+        if (tgt < 64u) put(tgt, V0, V1);
+        const unsigned long long ea = img[mpf_slot_a(pend_h0) ^ swz], eb = img[mpf_slot_b(pend_h0) ^ swz];
+        const uint32_t s_known = mpf_match_entries(ea, eb, pend_h0);
+        const uint32_t p = Lmax - uk;
+        const uint32_t on = pend ? 1u : 0u;
+        const uint32_t keep = on & ((s_known == 0u ? 1u : 0u) | no_drop | (draw_strength(rng_pos(rstate, p)) >= s_known ? 1u : 0u));
+        total += on; kept += keep; mask |= keep << (p & 31u);
+    }
+    if (active) {
+        if (walk) { cnt[w + done] = kept; keepmask[w + done] = mask; ++done; }       // the word the last window starts in
+        for (; done < W; ++done) { cnt[w + done] = 0; keepmask[w + done] = 0; }       // words no window starts in
+    }
+    for (int o = 32; o > 0; o >>= 1) total += __shfl_down(total, o, 64);
+    if (threadIdx.x == 0 && total) atomicAdd(&total_spread[16u * (blockIdx.x & 31u)], total);
+}
+
 // The same with the fetch TWO steps ahead of its use (RB_FILTER_PIPE=2): two register sets take turns (the step loop is unrolled
 // by two so that each set has a name), and the loads are issued by every lane in every step — a lane whose bucket did not change
 // reads the table's first line, one cached line for the whole wavefront — because only an unconditional issue lets the compiler
@@ -1348,7 +1524,7 @@ static bool read_lanes_ragged(const rb_batch *b, int k, int kmax = 31) {
 // may a call with 32 <= k <= 63 use the minimizer-bucketed cache?  Only the read-per-lane kernel with the fetch ahead looks it up there.
 bool filter_wide_mpf_ok(const rb_batch *b, int64_t nw, int k) {
     if (k <= RB_MPF_MAX_K || k > RB_MPF_WIDE_MAX_K) return false;
-    if (getenv("RB_FILTER_PIPE") && atoi(getenv("RB_FILTER_PIPE")) != 1) return false;
+    if (getenv("RB_FILTER_PIPE") && atoi(getenv("RB_FILTER_PIPE")) != 1 && atoi(getenv("RB_FILTER_PIPE")) != 3) return false;
     if (getenv("RB_WIDE_MPF") && atoi(getenv("RB_WIDE_MPF")) == 0) return false;
     return read_lane_words(b, nw, k, RB_MPF_WIDE_MAX_K) != 0u || read_lanes_ragged(b, k, RB_MPF_WIDE_MAX_K);
 }
@@ -1383,7 +1559,11 @@ void launch_filter_windows(const rb_batch *b, int64_t w0, int64_t nw, int k, int
     hipLaunchKernelGGL((k_filter_reads<M, P>), gc, t, ring_bytes, s, b->codes, b->valid, b->word_read, b->len, w0, nw, k, C, \
                        first_read, pos_bits, seed, ordinal0, cache, mcache, cnt, keepmask, total_spread, dbgf, own, \
                        reinterpret_cast<ulonglong2 *>(wstate), b->woff, rd0, n_rd)
-        const int pipe = wide ? 1 : getenv("RB_FILTER_PIPE") ? atoi(getenv("RB_FILTER_PIPE")) : 1;   // 0: k_filter_reads, 1 (default): fetch one step ahead, 2: two steps (slower: every lane loads in every step)
+        // 0: k_filter_reads (fetch in place), 1: each lane fetches its bucket one step ahead (default of rounds 3-4), 2: two steps ahead (slower: every lane loads in
+        // every step), 3 (default): the wavefront fetches cooperatively, one step ahead (its askers' list packs a bucket number into 26 bits)
+        const int pipe_env = getenv("RB_FILTER_PIPE") ? atoi(getenv("RB_FILTER_PIPE")) : 3;
+        const int pipe_fit = (pipe_env == 3 && mcache.log2b > 26u) ? 1 : pipe_env;
+        const int pipe = wide ? (pipe_fit == 3 ? 3 : 1) : pipe_fit;
         if (use_m && pipe && own.lo == 0 && own.hi == 0) {         // the whole index range is this handle's: the bucket fetch one / two steps ahead of its use
 #define RB_LAUNCH_FP(K, M, ...)                                                                                      \
     hipLaunchKernelGGL((K<M>), gc, t, ring_bytes, s, b->codes, b->valid, b->word_read, b->len, w0, nw, k, C,         \
@@ -1394,9 +1574,62 @@ void launch_filter_windows(const rb_batch *b, int64_t w0, int64_t nw, int k, int
 #define RB_LAUNCH_FW(M)                                                                                              \
     hipLaunchKernelGGL((k_filter_reads_pipe<M, true>), gc, t, ring_bytes, s, b->codes, b->valid, b->word_read, b->len, w0, nw, k, C, \
                        first_read, pos_bits, seed, ordinal0, mcache, cnt, keepmask, total_spread, dbgf, reinterpret_cast<ulonglong2 *>(wstate), b->woff, rd0, n_rd)
-            if (pipe == 2 && C) { if (mode == 0) RB_LAUNCH_FP(k_filter_reads_pipe2, 0); else if (mode == 2) RB_LAUNCH_FP(k_filter_reads_pipe2, 2); else RB_LAUNCH_FP(k_filter_reads_pipe2, 1); }
+#define RB_LAUNCH_FCO(M, WD)                                                                                         \
+    hipLaunchKernelGGL((k_filter_reads_coop<M, WD>), gc, t, ring_bytes, s, b->codes, b->valid, b->word_read, b->len, w0, nw, k, C, \
+                       first_read, pos_bits, seed, ordinal0, mcache, cnt, keepmask, total_spread, dbgf, reinterpret_cast<ulonglong2 *>(wstate), b->woff, rd0, n_rd)
+            if (pipe == 3) {
+                const bool check = getenv("RB_FILTER_CHECK") && atoi(getenv("RB_FILTER_CHECK"));
+                if (check && wstate) RB_HIP(hipMemsetAsync(wstate, 0xEE, (size_t)nw * 16, s));      // (words no state is stored for compare equal)
+                if (wide) { if (mode == 0) RB_LAUNCH_FCO(0, true); else if (mode == 2) RB_LAUNCH_FCO(2, true); else RB_LAUNCH_FCO(1, true); }
+                else { if (mode == 0) RB_LAUNCH_FCO(0, false); else if (mode == 2) RB_LAUNCH_FCO(2, false); else RB_LAUNCH_FCO(1, false); }
+                if (check) {
+                    // Verification (tests, and whoever touches these kernels): the cooperative walker only ever errs on the safe side if it errs — a lookup
+                    // in an image that is not the window's bucket misses, the window is kept, every filter byte still matches the oracle — so parity tests
+                    // cannot see a broken fetch.  Here the one-step walker (and, for k <= 31, the unpipelined one) decides the same words into scratch
+                    // arrays and every count, mask and resume state is compared; a difference fails the call.
+                    struct Scratch { uint32_t *c = nullptr, *m = nullptr, *t = nullptr; ulonglong2 *ws = nullptr;
+                                     ~Scratch() { (void)hipFree(c); (void)hipFree(m); (void)hipFree(t); (void)hipFree(ws); } } A, B;
+                    const size_t nb = (size_t)nw * 4;
+                    for (Scratch *x : {&A, &B}) {
+                        RB_HIP(hipMalloc(&x->c, nb)); RB_HIP(hipMalloc(&x->m, nb)); RB_HIP(hipMalloc(&x->t, 4096)); RB_HIP(hipMemsetAsync(x->t, 0, 4096, s));
+                        RB_HIP(hipMemsetAsync(x->c, 0xEE, nb, s)); RB_HIP(hipMemsetAsync(x->m, 0xEE, nb, s));
+                        if (wstate) { RB_HIP(hipMalloc(&x->ws, nb * 4)); RB_HIP(hipMemsetAsync(x->ws, 0xEE, nb * 4, s)); }
+                    }
+                    ulonglong2 *const ws_coop = reinterpret_cast<ulonglong2 *>(wstate);
+                    {   // the one-step walker
+                        uint32_t *cnt = A.c, *keepmask = A.m, *total_spread = A.t; void *wstate = A.ws;
+                        if (wide) { if (mode == 0) RB_LAUNCH_FW(0); else if (mode == 2) RB_LAUNCH_FW(2); else RB_LAUNCH_FW(1); }
+                        else { if (mode == 0) RB_LAUNCH_FN(0); else if (mode == 2) RB_LAUNCH_FN(2); else RB_LAUNCH_FN(1); }
+                    }
+                    if (!wide) {   // the walker that fetches in place
+                        uint32_t *cnt = B.c, *keepmask = B.m, *total_spread = B.t; void *wstate = B.ws;
+                        if (mode == 0) RB_LAUNCH_FC(0, true); else if (mode == 2) RB_LAUNCH_FC(2, true); else RB_LAUNCH_FC(1, true);
+                    }
+                    std::vector<uint32_t> hc(nw), hm(nw), ac(nw), am(nw), bc(nw), bm(nw);
+                    std::vector<unsigned long long> hw, aw;
+                    RB_HIP(hipMemcpyAsync(hc.data(), cnt, nb, hipMemcpyDeviceToHost, s)); RB_HIP(hipMemcpyAsync(hm.data(), keepmask, nb, hipMemcpyDeviceToHost, s));
+                    RB_HIP(hipMemcpyAsync(ac.data(), A.c, nb, hipMemcpyDeviceToHost, s)); RB_HIP(hipMemcpyAsync(am.data(), A.m, nb, hipMemcpyDeviceToHost, s));
+                    RB_HIP(hipMemcpyAsync(bc.data(), B.c, nb, hipMemcpyDeviceToHost, s)); RB_HIP(hipMemcpyAsync(bm.data(), B.m, nb, hipMemcpyDeviceToHost, s));
+                    if (wstate) {
+                        hw.resize((size_t)nw * 2); aw.resize((size_t)nw * 2);
+                        RB_HIP(hipMemcpyAsync(hw.data(), ws_coop, nb * 4, hipMemcpyDeviceToHost, s)); RB_HIP(hipMemcpyAsync(aw.data(), A.ws, nb * 4, hipMemcpyDeviceToHost, s));
+                    }
+                    RB_HIP(hipStreamSynchronize(s));
+                    int64_t bad = 0, first = -1;
+                    for (int64_t i = 0; i < nw; ++i) {
+                        const bool d = hc[i] != ac[i] || hm[i] != am[i] || (!wide && (hc[i] != bc[i] || hm[i] != bm[i])) ||
+                                       (wstate && (hw[2 * i] != aw[2 * i] || hw[2 * i + 1] != aw[2 * i + 1]));
+                        if (d) { if (first < 0) first = i; ++bad; }
+                    }
+                    if (atoi(getenv("RB_FILTER_CHECK")) > 1) fprintf(stderr, "[rb] filter check: %lld words, %lld differ\n", (long long)nw, (long long)bad);
+                    RB_REQUIRE(bad == 0, "prefilter check: %lld of %lld words differ between the walkers (first: word %lld, count %u / %u / %u, mask %08x / %08x / %08x)",
+                               (long long)bad, (long long)nw, (long long)first, hc[(size_t)std::max<int64_t>(first, 0)], ac[(size_t)std::max<int64_t>(first, 0)],
+                               bc[(size_t)std::max<int64_t>(first, 0)], hm[(size_t)std::max<int64_t>(first, 0)], am[(size_t)std::max<int64_t>(first, 0)], bm[(size_t)std::max<int64_t>(first, 0)]);
+                }
+            } else if (pipe == 2 && C) { if (mode == 0) RB_LAUNCH_FP(k_filter_reads_pipe2, 0); else if (mode == 2) RB_LAUNCH_FP(k_filter_reads_pipe2, 2); else RB_LAUNCH_FP(k_filter_reads_pipe2, 1); }
             else if (wide) { if (mode == 0) RB_LAUNCH_FW(0); else if (mode == 2) RB_LAUNCH_FW(2); else RB_LAUNCH_FW(1); }
             else { if (mode == 0) RB_LAUNCH_FN(0); else if (mode == 2) RB_LAUNCH_FN(2); else RB_LAUNCH_FN(1); }
+#undef RB_LAUNCH_FCO
 #undef RB_LAUNCH_FP
 #undef RB_LAUNCH_FN
 #undef RB_LAUNCH_FW

@@ -387,8 +387,12 @@ __device__ __forceinline__ uint32_t mpf_match(const unsigned long long *bkt, uin
 }
 
 // the same without a branch (k_filter_reads_pipe is bound by the NUMBER of instructions it issues, scalar and branch ones included)
+__device__ __forceinline__ uint32_t mpf_match_entries(unsigned long long ea, unsigned long long eb, uint64_t h0);
 __device__ __forceinline__ uint32_t mpf_match_flat(const unsigned long long *bkt, uint32_t stride, uint64_t h0) {
-    const unsigned long long ea = bkt[mpf_slot_a(h0) * stride], eb = bkt[mpf_slot_b(h0) * stride];
+    return mpf_match_entries(bkt[mpf_slot_a(h0) * stride], bkt[mpf_slot_b(h0) * stride], h0);
+}
+// ... on the two candidate entries, wherever the caller keeps them
+__device__ __forceinline__ uint32_t mpf_match_entries(unsigned long long ea, unsigned long long eb, uint64_t h0) {
     const uint32_t va = (uint32_t)(ea & 7ull), vb = (uint32_t)(eb & 7ull);
     // an entry is (tag << 3) | exponent code: it matches iff it differs from (tag << 3) in the low three bits only
     const uint32_t ha = (uint32_t)(((ea ^ (mpf_tag_a(h0) << 3)) < 8ull) & (ea != 0ull));

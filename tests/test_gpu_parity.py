@@ -516,6 +516,41 @@ def test_trimmed_reads_take_a_read_per_lane(monkeypatch, env, k):
     assert og.cbf_bytes().max() > 30 and st.sorted_kmers < st.kmers
 
 
+@pytest.mark.parametrize("k,stranded,trimmed", [(25, False, False), (25, True, False), (25, False, True), (31, False, True), (17, False, False),
+                                                (35, False, True), (47, True, True), (63, False, True)])
+def test_the_prefilter_walkers_agree_word_for_word(monkeypatch, capfd, k, stranded, trimmed):
+    """round 5: the default prefilter walker fetches its cache buckets cooperatively (csrc/rb_batch.hip k_filter_reads_coop: the lanes that need a
+    bucket post it, groups of four lanes fetch it, the helpers store it into the asker's LDS image a step later).  A broken fetch there cannot be
+    seen in the filters — a lookup in the wrong image misses, the window is kept, the result stays exact — so with RB_FILTER_CHECK the library
+    runs the walker of rounds 3-4 (and for k <= 31 the one that fetches in place) over the same words and fails the call on any difference in a
+    word's count, keep mask or resume state: canonical / forward / reverse-complement hashing, uniform and ragged reads (crowded first windows,
+    lanes that end early), the wide (32 <= k <= 63) walkers, many sub-batches on a hot cache"""
+    monkeypatch.setenv("RB_FILTER_CHECK", "2")
+    L = 320 if trimmed else 150
+    d = synth.generate_pairs(2600, G=4000, L=L, err=0.002, n_rate=1e-3, seed=17 + k, uniform_expr=True, frag_mean=450.0, frag_sd=30.0)
+    rng = np.random.default_rng(k)
+    og, gg = graph_pair(300_007, 400_009, 60_013, k=k, stranded=stranded, max_batch=15_000)
+    og.set_read_pair_distance(60); gg.setReadPairedKmerDistance(60)
+    for name, rc in (("left", False), ("right", True)):
+        reads, quals = d[name], d[name[0] + "qual"]
+        n = reads.shape[0]
+        if trimmed:
+            lens = np.where(rng.random(n) < 0.6, 150, rng.integers(100, 151, n))
+            lens[rng.integers(0, n, 200)] = rng.choice([0, 1, k - 1, k, k + 1, 32, 33, 64, 65, 150, 256, 257, 319, 320], 200)
+        else:
+            lens = np.full(n, L)
+        keep = np.arange(L)[None, :] < lens[:, None]
+        s, q = reads[keep], quals[keep]
+        off = np.zeros(n + 1, np.int64); np.cumsum(lens, out=off[1:])
+        og.add_reads(s, q, off, 3, rbo.STORE_READ_PAIRS | (rbo.REVCOMP if rc else 0))
+        st = gg.addReads(s, q, off, 3, reverseComplement=rc, storeReadPairedKmers=True)        # (raises if the walkers disagree)
+        assert_same_state(og, gg)
+    err = capfd.readouterr().err
+    checked = [ln for ln in err.splitlines() if "filter check" in ln]
+    assert len(checked) >= 4 and all(ln.endswith(" 0 differ") for ln in checked), err[-2000:]
+    assert st.sorted_kmers < st.kmers
+
+
 @pytest.mark.parametrize("k", [9, 12, 16, 17, 20, 26, 28, 29, 31])
 def test_small_and_boundary_k_through_the_prefiltered_path(k):
     """k = 31 uses all 16 slots of the minimizer ring (k - m + 1 = 16), k <= 16 makes the minimizer the k-mer
