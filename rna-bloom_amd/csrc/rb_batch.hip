@@ -1119,17 +1119,31 @@ k_filter_reads_coop(const uint64_t *__restrict__ codes, const uint32_t *__restri
         unsigned long long *e = &s_img[t * 16u + (((sub ^ (t & 7u)) ^ 4u) << 1)];
         e[0] = x1.x; e[1] = x1.y;
     };
-    for (uint32_t b = 0; b < Lmax; ++b) {                  // b is the same in every lane: scalar bookkeeping
+    // the pending window (position p, the one that ended a base ago) on its two candidate entries: draw and bookkeeping — straight-line: a lane without one
+    // computes on stale values and adds zero
+    auto decide = [&](unsigned long long ea, unsigned long long eb, uint32_t p) {
+        const uint32_t s_known = mpf_match_entries(ea, eb, pend_h0);
+        const uint32_t strength = draw_strength(rng_pos(rstate, p));
+        const uint32_t on = pend ? 1u : 0u;
+        const uint32_t keep = on & ((s_known == 0u ? 1u : 0u) | no_drop | (strength >= s_known ? 1u : 0u));
+        total += on;
+        kept += keep;
+        mask |= keep << (p & 31u);
+        pend = false;
+    };
+    auto step = [&](const uint32_t b) {
         const bool live = b < Lw;
-        if ((b & 31u) == 0u) {
-            const uint32_t wi = b >> 5;
-#pragma unroll
-            for (int q = 0; q < RB_READ_WORDS; ++q) if ((uint32_t)q == wi) { cur_c = carr[q]; cur_v = varr[q]; }
-        }
         const uint32_t pb = b + 1u - uk;
         const uint32_t code = (uint32_t)cur_c & 3u, ok = live ? (cur_v & 1u) : 0u;
         cur_c >>= 2; cur_v >>= 1;
         run = ok ? run + 1u : 0u;
+        // (the roll tables' entries are asked for here, the ring's suffix minimum and the pending window's candidate slots below: LDS reads ahead of the
+        // arithmetic that needs them)
+        const uint32_t in5 = ok ? code + 1u : 0u;
+        const uint32_t ok_out = WIDE ? (uint32_t)(hvw >> sh_v) & 1u : (hv >> sh_v) & 1u;
+        const uint32_t out5 = ok_out ? ((uint32_t)((far ? hc2 : hc) >> sh_c) & 3u) + 1u : 0u;
+        const uint32_t tt = out5 * 5u + in5;
+        const uint64_t tf_v = (MODE != 2) ? s_tf[tt] : 0ull, tr_v = (MODE != 0) ? s_tr[tt] : 0ull;
         // minimizer of the window that ends at this base (garbage while run < m: never consulted then)
         const uint32_t mcode = lag ? (uint32_t)(hc >> (2u * (lag - 1u))) & 3u : code;
         mf = ((mf << 2) | mcode) & mmask;
@@ -1140,10 +1154,11 @@ k_filter_reads_coop(const uint64_t *__restrict__ codes, const uint32_t *__restri
         const bool win = run >= uk;
         const uint32_t nxt = blk_a + 1u < uw ? blk_a + 1u : blk_a;          // the block's last slot has no suffix to look at
         const uint32_t sfx = s_ring[nxt * 64u + lane];
-        const uint32_t omin = (blk_a + 1u < uw && sfx < blk_p) ? sfx : blk_p;
-        const uint32_t bkt = (uint32_t)mpf_bucket(mcache, omin);
         if (tgt < 64u) put(tgt, V0, V1);                 // the step before's buckets have had a step to arrive
         tgt = 64u;
+        const unsigned long long ea = img[mpf_slot_a(pend_h0) ^ swz], eb = img[mpf_slot_b(pend_h0) ^ swz];      // the pending window's candidates
+        const uint32_t omin = (blk_a + 1u < uw && sfx < blk_p) ? sfx : blk_p;
+        const uint32_t bkt = (uint32_t)mpf_bucket(mcache, omin);
         const bool sw = win && bkt != cur_bkt;
         const unsigned long long asks = __ballot(sw);
         uint32_t n_ask = 0, rank = 0;
@@ -1158,16 +1173,7 @@ k_filter_reads_coop(const uint64_t *__restrict__ codes, const uint32_t *__restri
                 tgt = ent >> 26;
             }
         }
-        {   // the pending window (the one that ended a base ago): lookup, draw and bookkeeping — straight-line: a lane without one computes on stale values and adds zero
-            const unsigned long long ea = img[mpf_slot_a(pend_h0) ^ swz], eb = img[mpf_slot_b(pend_h0) ^ swz];
-            const uint32_t s_known = mpf_match_entries(ea, eb, pend_h0);
-            const uint32_t strength = draw_strength(rng_pos(rstate, pb - 1u));
-            const uint32_t on = pend ? 1u : 0u;
-            const uint32_t keep = on & ((s_known == 0u ? 1u : 0u) | no_drop | (strength >= s_known ? 1u : 0u));
-            total += on;
-            kept += keep;
-            mask |= keep << ((pb - 1u) & 31u);
-        }
+        decide(ea, eb, pb - 1u);
         for (uint32_t e0 = 16u; e0 < n_ask; e0 += 16u) {   // a crowded step: the askers beyond the sixteenth, in place (their lookups are a step away)
             if (sw && rank >= e0 && rank < e0 + 16u) s_list[rank - e0] = bkt | (lane << 26);
             if (e0 + grp < n_ask) {
@@ -1177,15 +1183,8 @@ k_filter_reads_coop(const uint64_t *__restrict__ codes, const uint32_t *__restri
                 put(ent >> 26, x0, x1);
             }
         }
-        if ((pb & 31u) == 0u && (int32_t)pb > 0) {       // the window of this base starts a new word: the word before is final (its last window was just decided)
-            if (live) { cnt[w + done] = kept; keepmask[w + done] = mask; ++done; kept = 0; mask = 0; }
-        }
-        const uint32_t in5 = ok ? code + 1u : 0u;
-        const uint32_t ok_out = WIDE ? (uint32_t)(hvw >> sh_v) & 1u : (hv >> sh_v) & 1u;
-        const uint32_t out5 = ok_out ? ((uint32_t)((far ? hc2 : hc) >> sh_c) & 3u) + 1u : 0u;
-        const uint32_t tt = out5 * 5u + in5;
-        if (MODE != 2) f = rotl(f, 1) ^ s_tf[tt];
-        if (MODE != 0) rv = rotr(rv, 1) ^ s_tr[tt];
+        if (MODE != 2) f = rotl(f, 1) ^ tf_v;
+        if (MODE != 0) rv = rotr(rv, 1) ^ tr_v;
         if (WIDE) { hc2 = (hc2 << 2) | (hc >> 62); hvw = (hvw << 1) | ok; } else hv = (hv << 1) | ok;
         hc = (hc << 2) | code;
         pend = win;
@@ -1196,18 +1195,31 @@ k_filter_reads_coop(const uint64_t *__restrict__ codes, const uint32_t *__restri
             blk_a = 0;
         } else
             ++blk_a;
-        // the rolling state just before the first window of a word ends: the emit pass resumes from it
-        if (wstate && ((b + 2u - uk) & 31u) == 0u && b + 2u >= uk && live) wstate[w + ((b + 2u - uk) >> 5)] = make_ulonglong2(f, rv);
+    };
+    uint32_t b = 0;                                        // the same in every lane: scalar bookkeeping
+    while (b < Lmax) {
+        if ((b & 31u) == 0u) {
+            const uint32_t wi = b >> 5;
+#pragma unroll
+            for (int q = 0; q < RB_READ_WORDS; ++q) if ((uint32_t)q == wi) { cur_c = carr[q]; cur_v = varr[q]; }
+        }
+        const uint32_t pb = b + 1u - uk;
+        if ((pb & 31u) == 0u && (int32_t)pb > 0) {       // the window of this base starts a new word: the word before is final once its last window is decided
+            if (tgt < 64u) put(tgt, V0, V1);
+            tgt = 64u;
+            decide(img[mpf_slot_a(pend_h0) ^ swz], img[mpf_slot_b(pend_h0) ^ swz], pb - 1u);
+            if (b < Lw) { cnt[w + done] = kept; keepmask[w + done] = mask; ++done; kept = 0; mask = 0; }
+        }
+        const uint32_t d1 = 32u - (b & 31u), d2 = 32u - (pb & 31u);
+        uint32_t stop = b + (d1 < d2 ? d1 : d2);
+        stop = stop < Lmax ? stop : Lmax;
+#pragma nounroll
+        for (; b < stop; ++b) step(b);
+        // the rolling state just before the first window of a word ends (the next base is word start + k - 1): the emit pass resumes from it
+        if (wstate && ((b + 1u - uk) & 31u) == 0u && b + 1u >= uk && b <= Lw) wstate[w + ((b + 1u - uk) >> 5)] = make_ulonglong2(f, rv);
     }
-    {   // the last window
-        if (tgt < 64u) put(tgt, V0, V1);
-        const unsigned long long ea = img[mpf_slot_a(pend_h0) ^ swz], eb = img[mpf_slot_b(pend_h0) ^ swz];
-        const uint32_t s_known = mpf_match_entries(ea, eb, pend_h0);
-        const uint32_t p = Lmax - uk;
-        const uint32_t on = pend ? 1u : 0u;
-        const uint32_t keep = on & ((s_known == 0u ? 1u : 0u) | no_drop | (draw_strength(rng_pos(rstate, p)) >= s_known ? 1u : 0u));
-        total += on; kept += keep; mask |= keep << (p & 31u);
-    }
+    if (tgt < 64u) put(tgt, V0, V1);                     // the last window
+    decide(img[mpf_slot_a(pend_h0) ^ swz], img[mpf_slot_b(pend_h0) ^ swz], Lmax - uk);
     if (active) {
         if (walk) { cnt[w + done] = kept; keepmask[w + done] = mask; ++done; }       // the word the last window starts in
         for (; done < W; ++done) { cnt[w + done] = 0; keepmask[w + done] = 0; }       // words no window starts in

@@ -86,6 +86,32 @@ __global__ void __launch_bounds__(64) k_coop4(const ulonglong2 *__restrict__ tab
     if (acc == 0x1234567ull) out[0] = acc;
 }
 
+// coop4 with BUFFER loads issued by every lane in every iteration: a lane without a task uses an offset outside the resource, which the hardware answers
+// with zeros without touching memory — straight-line code the compiler can count (vmcnt(N)) at no cost in cache requests
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(64) k_coop4_buf(const ulonglong2 *__restrict__ tab, uint32_t bmask, uint32_t thresh, unsigned long long *out) {
+    __shared__ uint32_t s_list[64];
+    const uint32_t lane = threadIdx.x, gid = blockIdx.x * 64u + lane, grp = lane >> 2, sub = lane & 3u;
+    const uint32_t bytes = (bmask + 1u) << 7;            // (tables below 4 GB)
+    __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)tab, (short)0, (int)bytes, 0x00020000);
+    unsigned long long acc = 0;
+    for (int it = 0; it < ITER; ++it) {
+        const uint32_t r = mix(gid * 2654435761u + (uint32_t)it);
+        const bool want = (r & 0xFFFFu) < thresh;
+        const unsigned long long m = __ballot(want);
+        if (want) s_list[__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u))] = (r >> 4) & bmask;
+        const uint32_t n = (uint32_t)__popcll(m);
+        for (uint32_t p = 0; p * 16u < n || p == 0; ++p) {                       // wave-uniform
+            const uint32_t e = p * 16u + grp;
+            const uint32_t ent = s_list[e & 63u];
+            const uint32_t off = e < n ? (ent << 7) + sub * 16u : 0xFFFFFFFFu;
+            const u32x4 v0 = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off, 0, 0), v1 = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)off + 64, 0, 0);
+            acc ^= (unsigned long long)(v0.x + v0.y + v0.z + v0.w + v1.x + v1.y + v1.z + v1.w);
+        }
+    }
+    if (acc == 0x1234567ull) out[0] = acc;
+}
+
 template <class K> static int run(const char *name, K k, const ulonglong2 *tab, uint32_t bmask, unsigned long long *out, int cus, int wps) {
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     const int grid = cus * 4 * wps;
@@ -118,5 +144,6 @@ int main(int argc, char **argv) {
     if (run("coop 1 x dwordx4", k_coop<0>, tab, bmask, out, cus, 4)) return 1;
     if (run("coop4 2 x dwordx4", k_coop4<false>, tab, bmask, out, cus, 4)) return 1;
     if (run("coop4 unconditional", k_coop4<true>, tab, bmask, out, cus, 4)) return 1;
+    if (lg < 32 && run("coop4 buffer, OOB idle", k_coop4_buf, tab, bmask, out, cus, 4)) return 1;
     return 0;
 }
