@@ -10,8 +10,6 @@ OUT=$R/gpurun_out/final_$TAG
 mkdir -p $OUT
 cd $R
 python -m pytest tests -q -m gpu 2>&1 | grep -E "passed|failed|error" | tail -3 > $OUT/pytest_gpu.txt
-python bench.py > $OUT/bench.json 2> $OUT/bench.err
-RB_SERIAL=1 python bench.py --no-cpu-baseline > $OUT/bench_serial_stages.json 2> $OUT/bench_serial.err
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o s -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/rocprof_stats.err
 python $R/profiles/summarize.py stats $(find /tmp/prof_stats -name '*kernel_stats.csv' | head -1) > $OUT/kernel_stats.csv
@@ -30,6 +28,10 @@ lib, src = N.lib.rb_build_id().decode(), csrc_id.csrc_id("$R")
 assert lib == src, "librb_hip.so was not built from this tree: %s vs %s" % (lib, src)
 print(json.dumps({"csrc_id": lib, "git_head": "$HEAD_SHA", "command": "bench.py --steps 1 --warmup 1 --no-cpu-baseline under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes)"}))
 PY
+# the bench lines come AFTER the counter passes: bench.py quotes counter bytes only from summaries whose csrc id is its library's, so this round's summaries
+# go where it looks (the box's copy of profiles/) first
+cp $OUT/pmc_FETCH_SIZE.csv $R/profiles/${TAG}_pmc_fetch_size.csv; cp $OUT/pmc_WRITE_SIZE.csv $R/profiles/${TAG}_pmc_write_size.csv; cp $OUT/pmc_meta.json $R/profiles/${TAG}_pmc_meta.json
+(cd $R && python bench.py > $OUT/bench.json 2> $OUT/bench.err; RB_SERIAL=1 python bench.py --no-cpu-baseline > $OUT/bench_serial_stages.json 2> $OUT/bench_serial.err)
 python - <<PY > $OUT/pmc_calibration.txt
 import json
 b = json.load(open("$OUT/bench_pmc_FETCH_SIZE.json"))
