@@ -704,7 +704,10 @@ def run_distributed(gen, group=None):
 
 
 def default_mode(count):
-    return _MODE or ("split" if count >= 4 else "replicated")
+    """split reads from two ranks on (round 5: 247 against 273 ms per rank at two ranks, loopback — a rank of the split engine walks its half of
+    the reads with the cooperative prefilter walker, a rank that hashes everything walks all of them with the ownership test in the loop;
+    rounds 3-4 split from four ranks); one rank hashes everything (394 against 439 ms: nothing to route)"""
+    return _MODE or ("split" if count >= 2 else "replicated")
 
 
 def default_batch_kmers(count, mode=None):
