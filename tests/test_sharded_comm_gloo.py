@@ -96,4 +96,4 @@ def test_plan_limits():
     assert (1 << pos_bits) > 100_000 - 35 and reads >= 1
     pos_bits, reads = plan(150, 25, 8, default_batch_kmers(8, "split"))       # 2^32 windows
     assert reads == (1 << 32) // 150 and pos_bits == 7 and reads < (1 << (32 - pos_bits))
-    assert default_batch_kmers(8, "replicated") == 1 << 30 and default_batch_kmers(4, "split") == 1 << 31
+    assert default_batch_kmers(8, "replicated") == 1 << 30 and default_batch_kmers(2, "split") == 1 << 31 and default_batch_kmers(4, "split") == 1 << 32
