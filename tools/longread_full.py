@@ -106,6 +106,12 @@ if rank == 0 and not os.environ.get("RB_LR_SKIP_INSERT"):
     g.profileEnable(False)
     t0 = time.perf_counter(); km2 = sum(g.addBatch(b).kmers for b in batches); dt2 = time.perf_counter() - t0
     print("  second pass over the same reads (all k-mers present): %.3f s, %.2f G k-mers/s" % (dt2, km2 / dt2 / 1e9), flush=True)
+    if os.environ.get("RB_LR_THIRD_PASS"):        # and once more, stage by stage (HIP events serialise the streams)
+        g.profileEnable(True); g.profileGet()
+        t0 = time.perf_counter(); km3 = sum(g.addBatch(b).kmers for b in batches); dt3 = time.perf_counter() - t0
+        prof = g.profileGet()
+        print("  third pass, stage by stage: %.3f s, %.2f G k-mers/s; stages (ms): " % (dt3, km3 / dt3 / 1e9)
+              + ", ".join("%s %.0f" % (k_, v[0]) for k_, v in sorted(prof.items(), key=lambda kv: -kv[1][0])[:14]), flush=True)
     del batches; g.destroy()
 
 # ---- sketches of this rank's pieces ----
