@@ -68,11 +68,34 @@ def algorithmic_bytes(stage, n_kmers, n_pairs, n_runs, words, n_sorted=None, gro
         "probe_claim": n_runs * (h * SECTOR + h * SECTOR + 36),
         # per run: h counter byte stores (sector write), one strength sector, 40 B of records
         "resolve_apply": n_runs * (h * SECTOR + SECTOR + 40),
-        # per pair: h bit probes, test before set (one sector read; the write-back of the few new bits is not counted — the
-        # counters show 134 B per pair for h = 2); reads are re-walked: 16 B per word
-        "pairs_insert": words * 16 + n_pairs * h * SECTOR,
+        # paired k-mers behind the seen-pair cache (round 5, DESIGN.md s3 step 7 / s5: 16 W + P (128 f + miss (h 64) + new (h 64 + 64))): the reads are
+        # re-walked (16 B per word); a 128-byte cache bucket is fetched once per anchor change (f = PAIR_FETCHES_PER_PAIR of a pair); a pair the
+        # cache does not know (PAIR_UNKNOWN) tests its h bits (one sector each); a pair that is new to the filter (PAIR_NEW) writes them back and
+        # stores its cache entry (one sector).  f / unknown / new are the rates the walker's own statistics print on this workload (RB_DEBUG=1)
+        "pairs_insert": words * 16 + int(n_pairs * (128 * PAIR_FETCHES_PER_PAIR + PAIR_UNKNOWN * h * SECTOR + PAIR_NEW * (h * SECTOR + SECTOR))),
     }
     return model.get(stage)
+
+
+# the pair walker's cache statistics on config 2 (profiles/r05_pairs_seen.txt, HISTORY "seen-pair cache"): bucket fetches per pair, the share of
+# pairs the cache does not vouch for (10.9 % of the first file's, 15.4 % of the second's), the share that sets a new bit (72 M of 943 M pairs)
+PAIR_FETCHES_PER_PAIR, PAIR_UNKNOWN, PAIR_NEW = 0.37, 0.131, 0.076
+
+
+def random_request_bytes(stage, n_pairs, h=2):
+    """The part of a stage's model that is single-sector requests at random places.  FETCH_SIZE tallies those at their true 64 bytes while it
+    tallies every 128-byte line of a streamed or bucket read as 64 (profiles/r05_pmc_calibration.txt), so for a stage that mixes the two the
+    corrected counter is 2 x FETCH_SIZE minus these bytes (doubling would count them twice)."""
+    if stage == "pairs_insert":
+        return n_pairs * PAIR_UNKNOWN * h * SECTOR
+    return 0.0
+
+
+# Stages whose model is an UPPER BOUND by construction (the contract test lets their counters / model ratio fall below 0.6), with the reason:
+UPPER_BOUND_MODELS = {
+    "probe_claim": "charges every run h Bloom-bit sectors + h counter claims; runs of one occurrence whose k-mer is new claim nothing (k_late_claim) "
+                   "and with index-keyed grouping probe 0 of consecutive runs shares sectors - the counters show 0.55-0.6 of it",
+}
 
 
 # dominant-stage kernels in the committed rocprofv3 PMC summaries (profiles/r03_pmc_*.csv: separate
@@ -104,7 +127,8 @@ def pmc_meta():
 # bucket (8 x 16 B by one lane, the prefilter cache's access) are ALL tallied as 64 bytes per request.  So x 2 for the
 # streaming kernels and for filter_windows (its traffic is 128-byte bucket fetches), x 1 for kernels whose requests are
 # single words at random places.
-FETCH_FACTOR = {"filter_windows": 2.0, "group_part_count": 2.0, "group_part_scatter": 2.0, "group_buckets": 2.0, "hash_windows": 2.0}
+FETCH_FACTOR = {"filter_windows": 2.0, "group_part_count": 2.0, "group_part_scatter": 2.0, "group_buckets": 2.0, "hash_windows": 2.0,
+                "pairs_insert": 2.0}     # (pairs_insert: streamed reads + 128-byte cache buckets x 2, minus its random bit tests — random_request_bytes)
 
 
 def mpf_kp(k):
@@ -112,13 +136,14 @@ def mpf_kp(k):
     return k if k <= 21 else 21 - ((k & 1) ^ 1)
 
 
-def pmc_traffic(stage):
+def pmc_traffic(stage, n_pairs_per_step=0):
     """HBM bytes per launch of the stage's kernel from the committed PMC summaries (None if absent): FETCH_SIZE (corrected
     as the guide prescribes, see FETCH_FACTOR) + WRITE_SIZE, both in KB per dispatch in the summaries."""
     kern = PMC_KERNELS.get(stage)
     if not kern:
         return None
     tot = 0.0
+    dispatches = 0.0
     for name in PMC_FILES:
         path = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(path):
@@ -127,15 +152,18 @@ def pmc_traffic(stage):
         hit = [r for r in rows if len(r) == 4 and r[0].startswith(kern)]
         if not hit:
             return None
-        per_dispatch = sum(float(r[2]) for r in hit) / sum(float(r[1]) for r in hit) * 1024.0
+        dispatches = sum(float(r[1]) for r in hit)
+        per_dispatch = sum(float(r[2]) for r in hit) / dispatches * 1024.0
         tot += per_dispatch * (FETCH_FACTOR.get(stage, 1.0) if "fetch" in name else 1.0)
+    if tot and dispatches:
+        tot -= random_request_bytes(stage, n_pairs_per_step) * PMC_RUN_STEPS / dispatches
     return tot or None
 
 
 PMC_RUN_STEPS = 2        # the PMC passes ran `bench.py --steps 1 --warmup 1` (tools/final_profile.sh)
 
 
-def pmc_step_bytes(stage):
+def pmc_step_bytes(stage, n_pairs_per_step=0):
     """HBM bytes per STEP of the stage's kernel(s) by the counters (corrected FETCH_SIZE + WRITE_SIZE), None if absent"""
     kern = PMC_KERNELS.get(stage)
     if not kern:
@@ -150,10 +178,10 @@ def pmc_step_bytes(stage):
         if not hit:
             return None
         tot += sum(float(r[2]) for r in hit) * 1024.0 * (FETCH_FACTOR.get(stage, 1.0) if "fetch" in name else 1.0)
-    return tot / PMC_RUN_STEPS
+    return tot / PMC_RUN_STEPS - random_request_bytes(stage, n_pairs_per_step)
 
 
-def pmc_path_bytes():
+def pmc_path_bytes(n_pairs_per_step=0):
     """HBM bytes per STEP of EVERY kernel of the step by the committed counters (FETCH_SIZE corrected per kernel as above, x 1 for the
     kernels without a calibration, + WRITE_SIZE), and the part of it that is the prefilter cache's bucket fetches (filter_windows' FETCH_SIZE
     beyond the 16 B per word of packed reads it streams): (total, cache_fetches) or None"""
@@ -174,7 +202,7 @@ def pmc_path_bytes():
             total += b
             if "fetch" in name and r[0].startswith(PMC_KERNELS["filter_windows"]):
                 cache += b
-    return total / PMC_RUN_STEPS, cache / PMC_RUN_STEPS
+    return total / PMC_RUN_STEPS - sum(random_request_bytes(st, n_pairs_per_step) for st in FETCH_FACTOR), cache / PMC_RUN_STEPS
 
 
 def parse():
@@ -192,6 +220,9 @@ def parse():
     ap.add_argument("--cpu-sample-pairs", type=int, default=6_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-sharded", action="store_true", help="use the sharded engine + RCCL collectives even on 1 GPU")
+    ap.add_argument("--no-host-leg", action="store_true", help="skip the host-resident leg (packed reads in pinned host memory, uploaded inside the timed region)")
+    ap.add_argument("--host-chunk-reads", type=int, default=12_500_000, help="reads per uploaded chunk of the host-resident leg")
+    ap.add_argument("--host-first-chunk", type=int, default=3_125_000, help="reads of a file's first chunk (its upload has nothing to hide behind at the start of a step)")
     return ap.parse_args()
 
 
@@ -368,13 +399,13 @@ def main():
             ab = algorithmic_bytes(name, kmers, pairs_ins, distinct, words, n_sorted, sharded=sharded_mode, k=k)
             if ab and ms > 0:
                 per_stage[name] = round(ab / (ms * 1e-3) / 1e9, 1)
-                cb = pmc_step_bytes(name) if pmc_ok else None
+                cb = pmc_step_bytes(name, pairs_ins // a.steps) if pmc_ok else None
                 per_stage_gb[name] = {"model": round(ab / a.steps / 1e9, 1), "counters": round(cb / 1e9, 1) if cb else None}
         if dom_launches:
             ab = algorithmic_bytes(dom_name, kmers, pairs_ins, distinct, words, n_sorted, sharded=sharded_mode, k=k)
             if ab:
                 achieved = ab / (dom_ms * 1e-3) / 1e9      # = bytes per launch / average launch duration
-                traffic = pmc_traffic(dom_name) if pmc_ok else None      # the PMC passes profiled exactly this command on exactly this code
+                traffic = pmc_traffic(dom_name, pairs_ins // a.steps) if pmc_ok else None      # the PMC passes profiled exactly this command on exactly this code
                 roof = {"bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                         "traffic_source": "profiles/%s_pmc_{fetch,write}_size.csv (separate rocprofv3 --pmc passes of this command), bytes per kernel launch, FETCH_SIZE x %.0f (calibration: profiles/%s_pmc_calibration.txt)" % (PMC_TAG, FETCH_FACTOR.get(dom_name, 1.0), PMC_TAG) if traffic else None,
@@ -384,10 +415,11 @@ def main():
                         "algorithmic_bytes_per_launch": int(ab / dom_launches),
                         "avg_launch_ms": round(dom_ms / dom_launches, 3), "launches": dom_launches,
                         "all_stages_model_GBps": per_stage,
-                        "all_stages_GB_per_step": per_stage_gb}     # model bytes beside the counters' (committed PMC passes)
+                        "all_stages_GB_per_step": per_stage_gb,     # model bytes beside the counters' (committed PMC passes)
+                        "upper_bound_models": UPPER_BOUND_MODELS}
                 # the PATH's roofline, not only the dominant kernel's: every HBM byte the counters saw in a step (all kernels) over the
                 # step's wall time; and how much of that is the prefilter cache deciding to DROP occurrences (bytes this design added)
-                pb = pmc_path_bytes() if pmc_ok else None
+                pb = pmc_path_bytes(pairs_ins // a.steps) if pmc_ok else None
                 if pb:
                     streamed = 16.0 * words / a.steps                 # the packed reads the prefilter walks anyway
                     roof["path_bytes_per_step"] = int(pb[0])
@@ -415,6 +447,8 @@ def main():
         }
         if sharded_mode and sharded.TRACE is not None:
             out["shard_phase_ms_per_step"] = {kk: round(v / a.steps, 1) for kk, v in sorted(sharded.TRACE.items(), key=lambda kv: -kv[1])}
+        if not sharded_mode and not a.no_host_leg:
+            out["host_resident"] = host_resident_leg(a, g, batch, pairs_total, kmers_all // a.steps)
         if not a.no_cpu_baseline and world == 1:       # the CPU baseline is timed on rank 0 at N = 1 only
             out["cpu_baseline"] = cpu_baseline(a, batch, dbg_bits, cbf_bytes, pk_bits, dist_pk)
     if sharded_mode:
@@ -429,6 +463,80 @@ def main():
             pass
         sys.stdout.flush()
         print(json.dumps(out), flush=True)
+
+
+def host_resident_leg(a, g, batch, pairs_total, kmers_per_step):
+    """The metric as SURVEY.md s8(d) words it: input resident in HOST memory in the build's batch format.  Both files of the read set sit
+    packed in pinned host memory (12 B per 32 bases + 4 B per read: rb_batch_download_packed); a step starts from cleared filters and
+    uploads every chunk INSIDE the timed region through a packed stream (include/rb_capi.h rb_packed_stream_*: two device batches taking
+    turns on a copy stream), chunk c + 1 travelling while chunk c is inserted.  A file's first chunk is short: at the start of a step its
+    upload has nothing to hide behind.  Same number of timed steps as the HBM-resident figure; `filters_equal_resident` compares the folds of
+    all three filters with the resident leg's (which ran last on the same handle)."""
+    import ctypes as C
+    import torch
+    from rnabloom import _native as N
+    from rnabloom.graph import PackedStream
+    fold = lambda: tuple(_fold(g, w) for w in (N.DBGBF, N.CBF, N.RPKBF))
+    ref = fold()
+    files = [(batch.downloadPacked(0, pairs_total), False), (batch.downloadPacked(pairs_total, pairs_total), True)]
+    plan = []
+    for ph, rc in files:
+        r0 = 0
+        while r0 < ph.n_reads:
+            n = min(ph.n_reads - r0, a.host_first_chunk if (r0 == 0 and a.host_first_chunk > 0) else a.host_chunk_reads)
+            plan.append((ph, rc, r0, n))
+            r0 += n
+    max_reads = max(p[3] for p in plan)
+    max_words = max(p[0].words_before(p[2] + p[3]) - p[0].words_before(p[2]) for p in plan)
+    ps = PackedStream(max_reads, max_words, device=g.device if hasattr(g, "device") else 0)
+    nbytes = sum(ph.nbytes() for ph, _ in files)
+
+    def step():
+        g.clearAllBf()
+        ps.begin(*_sl(plan[0]))
+        km = 0
+        for i, (ph, rc, r0, n) in enumerate(plan):
+            b = ps.finish()
+            if i + 1 < len(plan):
+                ps.begin(*_sl(plan[i + 1]))
+            km += g.addBatch(b, reverseComplement=rc, storeReadPairedKmers=True).kmers
+        return km
+
+    # the link alone: every chunk uploaded back to back, nothing inserted
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for pl in plan:
+        ps.begin(*_sl(pl)); ps.finish()
+    link_s = time.perf_counter() - t0
+    step()                                     # warm-up (scratch of the chunked calls)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    km = 0
+    for _ in range(a.steps):
+        km += step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    equal = fold() == ref
+    ps.close()
+    for ph, _ in files:
+        ph.close()
+    return {"value": km / dt, "unit": "k-mers/s", "ms_per_step": dt / a.steps * 1e3, "steps": a.steps, "kmers_per_step": km // a.steps,
+            "host_bytes_per_step": nbytes, "h2d_GBps": round(nbytes / link_s / 1e9, 1), "upload_alone_ms": round(link_s * 1e3, 1),
+            "chunks": [p[3] for p in plan], "filters_equal_resident": bool(equal) and km // a.steps == kmers_per_step,
+            "note": "packed reads in pinned host memory (rb_batch_download_packed format), every byte uploaded inside the timed region on a copy "
+                    "stream while the chunk before is inserted; `value` of the line itself times HBM-resident input"}
+
+
+def _sl(pl):
+    return pl[0], pl[2], pl[3]
+
+
+def _fold(g, which):
+    import ctypes as C
+    from rnabloom import _native as N
+    v = C.c_uint64()
+    N.check(N.lib.rb_filter_fold(g.h, which, C.byref(v)))
+    return v.value
 
 
 def check_(sr, on):

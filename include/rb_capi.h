@@ -374,6 +374,31 @@ int rb_graph_add_fasta_file(rb_graph *g, const char *path, unsigned flags, rb_ad
  * format has no code for N).  At most max_reads records (< 0: all); *consumed = bytes used; a truncated last record
  * is left unread, as NucleotideBitsReader.next() returns null for it. */
 int rb_batch_create_nbits(int device, const void *bytes, size_t nbytes, int64_t max_reads, rb_batch **out, size_t *consumed);
+/* ---- read batches packed in HOST memory ("input already resident in host memory in the build's batch format") ----
+ * The build's own batch format, as a host keeps it once its reads are packed (by rb_batch_download_packed, or by a caller's packer):
+ *   codes[w] u64: 32 bases, 2 bits each, base i of the word at bits 2i..2i+1 (A C G T = 0 1 2 3);  valid[w] u32: bit i = base i is usable
+ *   (ACGTU and quality >= the threshold the reads were packed with);  len[r] u32: read r owns ceil(len[r] / 32) consecutive words.
+ * 12 bytes per 32 bases + 4 per read over the link; the device-only columns of a batch are computed on the GPU.  The reader side of
+ * FastqToGraphWorker.run (R/RNABloom.java:551-634: reads are fetched while other workers insert) is the packed stream: two device
+ * batches taking turns, chunk c + 1 uploading on the stream's own HIP stream while the caller inserts chunk c. */
+typedef struct rb_packed_stream rb_packed_stream;
+/* pinned host memory (hipHostMalloc): uploads from it run at link speed without a registration pass per call */
+int rb_host_alloc(size_t bytes, void **out);
+int rb_host_free(void *p);
+/* reads [first, first + n) of a device batch in the host format; *n_words = words of those reads (all three arrays NULL: size query) */
+int rb_batch_download_packed(const rb_batch *b, int64_t first, int64_t n, uint64_t *codes, uint32_t *valid, uint32_t *len, int64_t *n_words);
+/* a stream whose chunks hold at most max_reads reads / max_words words (the two device batches are allocated here, once) */
+int rb_packed_stream_create(int device, int64_t max_reads, int64_t max_words, rb_packed_stream **out);
+/* start the upload of one chunk and return at once (a helper thread drives the copies); one chunk may be in flight */
+int rb_packed_stream_begin(rb_packed_stream *s, const uint64_t *codes, const uint32_t *valid, const uint32_t *len, int64_t n_reads, int64_t n_words);
+/* wait for the chunk begun last; *out is a device batch owned by the stream (never rb_batch_destroy it), valid until the begin() after
+ * next reuses its buffer.  An error (the lengths do not add up to n_words, a failed copy) is reported here. */
+int rb_packed_stream_finish(rb_packed_stream *s, const rb_batch **out);
+int rb_packed_stream_destroy(rb_packed_stream *s);
+/* convenience: n_reads packed reads through a packed stream in chunks of chunk_reads reads (0: 2^24), every chunk through
+ * rb_graph_add_batch with `flags`; same filters as one rb_graph_add_batch of the same reads */
+int rb_graph_add_packed(rb_graph *g, const uint64_t *codes, const uint32_t *valid, const uint32_t *len, int64_t n_reads, int64_t n_words,
+                        int64_t chunk_reads, unsigned flags, rb_add_stats *stats);
 /* NucleotideBitsWriter.write R/io/NucleotideBitsWriter.java:24-31 for n_reads sequences; out == NULL: *written = size
  * needed.  A base outside ACGTU is an error (the reference stores a RANDOM base there, SeqBitsUtils.java:154-155). */
 int rb_nbits_encode(const char *seq, const int64_t *offsets, int64_t n_reads, void *out, size_t cap, size_t *written);
@@ -406,6 +431,12 @@ int rb_nbits_encode(const char *seq, const int64_t *offsets, int64_t n_reads, vo
  *   [all_to_all runs, ops]
  *   conflict_replay   ordered replay of whole components on a private counter table
  *   [all_to_all final counter bytes]   apply_writes
+ *
+ * Read-pair filter of a sharded graph: every rank ORs the pairs of its reads into a private full-size copy and the copies are merged into
+ * the owners' shards at the end of an insert call; a copy KEEPS its bits afterwards (its seen-pair cache vouches for them) and merges them
+ * again with the next call.  Therefore rb_graph_clear and rb_filter_import of RB_RPKBF on a sharded graph are COLLECTIVE: every rank must
+ * clear (or import its shard) before any rank inserts again — a rank that does not would OR its old bits back into the peers' freshly
+ * cleared or imported shards at the next flush.  (rnabloom.sharded.ShardRank.clear / the Java driver clear all ranks.)
  */
 enum {
     RB_SLOT_REC_KEYS = 0,    /* split-reads mode: u64 h0 of the surviving records, bucketed by k-mer owner */

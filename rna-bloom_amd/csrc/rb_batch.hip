@@ -1062,6 +1062,8 @@ k_filter_reads_coop(const uint64_t *__restrict__ codes, const uint32_t *__restri
     extern __shared__ uint32_t s_ring[];                        // [k-m+1][lane]
     __shared__ __attribute__((aligned(16))) unsigned long long s_img[64 * 16];
     __shared__ uint32_t s_list[16];                             // up to 16 askers of this step: bucket | lane << 26 (bucket numbers have at most 26 bits)
+    // A workgroup is ONE wavefront (launch bounds 64, launched with 64 threads): lanes hand data to each other through LDS with no s_barrier, only
+    // wave-level ordering (__builtin_amdgcn_wave_barrier below) — a second wavefront in the group would break the s_list / s_img hand-over.
     const uint32_t uk = (uint32_t)k, lane = threadIdx.x;
     if (threadIdx.x < 25) {
         const uint32_t o = threadIdx.x / 5u, in = threadIdx.x % 5u;
@@ -1156,6 +1158,7 @@ k_filter_reads_coop(const uint64_t *__restrict__ codes, const uint32_t *__restri
         const uint32_t sfx = s_ring[nxt * 64u + lane];
         if (tgt < 64u) put(tgt, V0, V1);                 // the step before's buckets have had a step to arrive
         tgt = 64u;
+        __builtin_amdgcn_wave_barrier();                 // helpers stored into OTHER lanes' images: the lookups below must not move above those stores
         const unsigned long long ea = img[mpf_slot_a(pend_h0) ^ swz], eb = img[mpf_slot_b(pend_h0) ^ swz];      // the pending window's candidates
         const uint32_t omin = (blk_a + 1u < uw && sfx < blk_p) ? sfx : blk_p;
         const uint32_t bkt = (uint32_t)mpf_bucket(mcache, omin);
@@ -1166,6 +1169,7 @@ k_filter_reads_coop(const uint64_t *__restrict__ codes, const uint32_t *__restri
             rank = __builtin_amdgcn_mbcnt_hi((uint32_t)(asks >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)asks, 0u));
             if (sw) { if (rank < 16u) s_list[rank] = bkt | (lane << 26); cur_bkt = bkt; }
             n_ask = (uint32_t)__popcll(asks);
+            __builtin_amdgcn_wave_barrier();             // the askers' posts above are read by other lanes below: keep the LDS accesses in this order
             if (grp < n_ask) {
                 const uint32_t ent = s_list[grp];
                 const ulonglong2 *bp = tab2 + ((size_t)(ent & 0x3FFFFFFu) << 3);
@@ -1175,7 +1179,9 @@ k_filter_reads_coop(const uint64_t *__restrict__ codes, const uint32_t *__restri
         }
         decide(ea, eb, pb - 1u);
         for (uint32_t e0 = 16u; e0 < n_ask; e0 += 16u) {   // a crowded step: the askers beyond the sixteenth, in place (their lookups are a step away)
+            __builtin_amdgcn_wave_barrier();             // (the list's entries of the round before have been read)
             if (sw && rank >= e0 && rank < e0 + 16u) s_list[rank - e0] = bkt | (lane << 26);
+            __builtin_amdgcn_wave_barrier();
             if (e0 + grp < n_ask) {
                 const uint32_t ent = s_list[grp];
                 const ulonglong2 *bp = tab2 + ((size_t)(ent & 0x3FFFFFFu) << 3);

@@ -14,6 +14,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 #include <string.h>
+#include <time.h>
 
 #include <algorithm>
 #include <condition_variable>
@@ -150,7 +151,10 @@ struct InCall {
         std::lock_guard<std::mutex> lk(c->m);
         c->left[me] = call;
         if (!c->failed) return;
-        for (int r = 0; r < c->world; ++r) if (c->left[r] < c->fail_call) return;      // somebody has not been through the failed call yet
+        // The hub is cleaned only when NOBODY is inside a collective call (calls[r] == left[r]) and everybody has been through the failed
+        // one: a peer that already waits in a barrier of a LATER call (this rank failed after its last barrier) must still find the hub
+        // poisoned when it wakes — cleaning here would erase its arrival and it would wait for ever.
+        for (int r = 0; r < c->world; ++r) if (c->left[r] < c->fail_call || c->calls[r] != c->left[r]) return;
         c->failed = false; c->arrived = 0; c->fail_call = 0;
     }
 };
@@ -471,7 +475,11 @@ int rb_shard_comm_create_loopback(int world, rb_shard_comm **out) {
 // A small all-to-all and all-gather with known bytes through the communicator's own transport (what rb_shard_add_range uses):
 // rank `me` sends (me * 7 + p * 3 + 1) * 1000 + big bytes to rank p, byte i = (me * 31 + p * 17 + i) & 255, and checks what arrives.
 // bench.py runs it before the first step with RCCL and falls back to the torch.distributed driver when it fails.
+// big_bytes == -2 (fault injection for the hub's tests): run the whole exchange with big_bytes = 0, wait a moment, then fail AFTER the
+// last barrier — the peers have left this call by then and may already wait in the next one.
 int rb_shard_comm_selftest(rb_shard_comm *c, int me, int device, int64_t big_bytes) {
+    const bool fail_late = big_bytes == -2;
+    if (fail_late) big_bytes = 0;
     DevBuf sendbuf;
     struct Rel { DevBuf &b; ~Rel() { b.release(); } } rel{sendbuf};
     InCall in_call(c, me);
@@ -519,6 +527,11 @@ int rb_shard_comm_selftest(rb_shard_comm *c, int me, int device, int64_t big_byt
         for (int src = 0; src < G; ++src)
             for (int64_t i = 0; i < sizes[src]; ++i, ++o)
                 RB_REQUIRE(got[(size_t)o] == (uint8_t)((src * 31 + 0 * 17 + i) & 255), "rb_shard_comm_selftest: gathered byte %lld of rank %d is wrong", (long long)i, src);
+        if (fail_late) {
+            struct timespec ts = {0, 300 * 1000 * 1000};
+            nanosleep(&ts, nullptr);
+            RB_REQUIRE(false, "rb_shard_comm_selftest: injected failure after the last barrier");
+        }
     });
     if (rc != RB_OK) in_call.failed();
     return rc;

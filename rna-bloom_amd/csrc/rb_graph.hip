@@ -1535,10 +1535,15 @@ void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, ui
         uint64_t *ka = g->foreign.as<uint64_t>(), *kb = ka + D;
         sweep_bits_device(g->dbg.bits, didx, GS.sweep_T, fv.kmul, uniq, D, GS.n_main, GS.brun.as<uint32_t>(), GS.bnr.as<uint32_t>(), ka, g->nops.as<uint32_t>(), kb,
                           g->heavy.as<uint32_t>(), g->sw_temp.p, g->sw_temp.cap, st0, st1, s);
+        // counters without claims: "probe j of the counting filter has the index of probe j of the Bloom filter" needs the two filters to map a
+        // hash the same way — same size AND the same reduction constants (index_of), not only equal sizes
+        const bool same_index = (int64_t)g->dbg.size == g->cbf_size && g->cbf_lo == 0 && g->dbg.mod.d == g->cbf_mod.d && g->dbg.mod.m_lo == g->cbf_mod.m_lo &&
+                                g->dbg.mod.m_hi == g->cbf_mod.m_hi && fv.dbg_h == fv.cbf_h;
+        const bool plain_ok = swept_all && same_index && !(getenv("RB_SWEEP_CLAIMS") && atoi(getenv("RB_SWEEP_CLAIMS")));
         constexpr int RUNS = 2;
         hipLaunchKernelGGL((k_probe_h2<RUNS, true>), dim3(blocks_for(((int64_t)D + RUNS - 1) / RUNS)), dim3(TPB), 0, s, fv, uniq, counts, D, mode, status,
                            g->cvals.as<uint64_t>(), g->foreign.as<uint64_t>(), ctr, (const uint8_t *)st0, (const uint8_t *)st1, swept_all ? 1u : 0u,
-                           (swept_all && (int64_t)g->dbg.size == g->cbf_size && g->cbf_lo == 0 && !(getenv("RB_SWEEP_CLAIMS") && atoi(getenv("RB_SWEEP_CLAIMS")))) ? 1u : 0u);
+                           plain_ok ? 1u : 0u);
     } else if (!ftab && fv.dbg_h == 2 && fv.cbf_h == 2 && !getenv("RB_PROBE_GENERIC")) {
         constexpr int RUNS = 2;
         hipLaunchKernelGGL((k_probe_h2<RUNS, false>), dim3(blocks_for(((int64_t)D + RUNS - 1) / RUNS)), dim3(TPB), 0, s, fv, uniq, counts, D, mode, status,

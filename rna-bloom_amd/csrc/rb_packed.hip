@@ -1,0 +1,257 @@
+// rb_packed.hip — read batches in the build's own packed format, resident in HOST memory ("input already
+// resident in host memory in the build's batch format"), streamed into HBM while the insert pipeline works.
+//
+// Host format of n_reads reads (what rb_batch_download_packed writes and a caller that packs its reads once keeps):
+//   codes[w]  u64  32 bases of a read, 2 bits each, base i of the word at bits 2i..2i+1 (A C G T = 0 1 2 3)
+//   valid[w]  u32  bit i = base i is usable (one of ACGTU and quality >= the threshold used when the reads were packed)
+//   len[r]    u32  bases of read r; read r owns ceil(len[r] / 32) consecutive words, reads follow each other in order
+// 12 bytes per 32 bases + 4 per read (6.4 GB for config 2's 100 M reads of 150 bases: 112 ms at the 57 GB/s the link gives from
+// pinned memory).  The two device-only columns of a batch — the owning read of every word and the word offset of every
+// read — are computed on the GPU from len[] (one scan), not shipped.
+//
+// rb_packed_stream: two device batches that take turns.  begin() hands a chunk to a helper thread that enqueues the
+// copies and the offset kernels on the stream's own HIP stream and waits for them; finish() joins it and returns the
+// batch.  The caller inserts chunk c (rb_graph_add_batch) between begin(c + 1) and finish(c + 1): the upload of the next chunk
+// runs beside the insert of this one on the copy engines.  The reference's counterpart is the reader side of
+// FastqToGraphWorker (R/RNABloom.java:551-634: reads pulled from a FastqReader while other workers insert).
+#include <string.h>
+
+#include <algorithm>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "rb_pipeline.hpp"
+
+using namespace rb;
+
+namespace {
+// wc[r] = words of read r (wc[n] = 0 closes the scan); st: [0] longest read, [1] fewest / [2] most words of a read, [4..5] sum of len (u64)
+__global__ void k_packed_words(const uint32_t *__restrict__ len, int64_t n, uint32_t *__restrict__ wc, uint32_t *__restrict__ st) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t l = 0, w = 0;
+    const bool live = i < n;
+    if (live) { l = len[i]; w = (l + 31u) >> 5; wc[i] = w; }
+    if (i == n) wc[i] = 0;
+    uint32_t mx = l, wmin = live ? w : 0xFFFFFFFFu, wmax = w;
+    unsigned long long sum = l;
+    for (int o = 32; o > 0; o >>= 1) {
+        const uint32_t a = (uint32_t)__shfl_down((int)mx, o, 64), b = (uint32_t)__shfl_down((int)wmin, o, 64), c = (uint32_t)__shfl_down((int)wmax, o, 64);
+        mx = a > mx ? a : mx; wmin = b < wmin ? b : wmin; wmax = c > wmax ? c : wmax;
+        sum += __shfl_down(sum, o, 64);
+    }
+    if ((threadIdx.x & 63u) == 0u && __ballot(live)) {
+        atomicMax(&st[0], mx); atomicMin(&st[1], wmin); atomicMax(&st[2], wmax);
+        atomicAdd(reinterpret_cast<unsigned long long *>(st + 4), sum);
+    }
+}
+// the owning read of every word
+__global__ void k_packed_word_read(const uint32_t *__restrict__ woff, int64_t n, uint32_t *__restrict__ word_read) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const uint32_t a = woff[r], e = woff[r + 1];
+    for (uint32_t w = a; w < e; ++w) word_read[w] = (uint32_t)r;
+}
+}  // namespace
+
+struct rb_packed_stream {
+    int device = 0;
+    int64_t max_reads = 0, max_words = 0;
+    hipStream_t st = nullptr;
+    struct Buf {
+        rb_batch b;                               // its arrays point into the DevBufs below (never rb_batch_destroy'ed)
+        DevBuf codes, valid, word_read, woff, len, wc, temp, stats;
+    } buf[2];
+    uint32_t *h_stats = nullptr;                  // pinned, 8 words
+    int fill = 0;                                 // the buffer the next begin() fills
+    bool pending = false;
+    std::thread worker;
+    int worker_rc = RB_OK;
+    std::string worker_err;
+    int64_t pend_reads = 0, pend_words = 0;
+};
+
+namespace {
+void upload_chunk(rb_packed_stream *s, int slot, const uint64_t *codes, const uint32_t *valid, const uint32_t *len, int64_t n_reads, int64_t n_words) {
+    RB_HIP(hipSetDevice(s->device));
+    rb_packed_stream::Buf &B = s->buf[slot];
+    hipStream_t st = s->st;
+    const size_t nw = (size_t)std::max<int64_t>(n_words, 1), nr = (size_t)std::max<int64_t>(n_reads, 1);
+    B.codes.reserve(nw * 8); B.valid.reserve(nw * 4); B.word_read.reserve(nw * 4);
+    B.woff.reserve((nr + 1) * 4); B.len.reserve(nr * 4); B.wc.reserve((nr + 1) * 4); B.stats.reserve(64);
+    B.temp.reserve(scan_temp_bytes(nr + 1));
+    // caller's buffers: pinned for the call if they are not already (best effort; 8 ms per GB, here on the helper thread)
+    HostPin p0(codes, (size_t)n_words * 8), p1(valid, (size_t)n_words * 4), p2(len, (size_t)n_reads * 4);
+    uint32_t init[8] = {0u, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u, 0u};
+    memcpy(s->h_stats + 8, init, sizeof init);
+    RB_HIP(hipMemcpyAsync(B.stats.p, s->h_stats + 8, sizeof init, hipMemcpyHostToDevice, st));
+    if (n_reads) RB_HIP(hipMemcpyAsync(B.len.p, len, (size_t)n_reads * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_packed_words, dim3(blocks_for(n_reads + 1)), dim3(TPB), 0, st, B.len.as<uint32_t>(), n_reads, B.wc.as<uint32_t>(), B.stats.as<uint32_t>());
+    exclusive_scan_u32(B.temp.p, B.temp.cap, B.wc.as<uint32_t>(), B.woff.as<uint32_t>(), (size_t)n_reads + 1, st);
+    RB_HIP(hipMemcpyAsync(s->h_stats, B.stats.p, 32, hipMemcpyDeviceToHost, st));
+    B.b.h_woff.resize((size_t)n_reads + 1);
+    RB_HIP(hipMemcpyAsync(B.b.h_woff.data(), B.woff.p, ((size_t)n_reads + 1) * 4, hipMemcpyDeviceToHost, st));
+    if (n_words) {
+        RB_HIP(hipMemcpyAsync(B.codes.p, codes, (size_t)n_words * 8, hipMemcpyHostToDevice, st));
+        RB_HIP(hipMemcpyAsync(B.valid.p, valid, (size_t)n_words * 4, hipMemcpyHostToDevice, st));
+    }
+    RB_HIP(hipStreamSynchronize(st));
+    // the lengths must describe exactly the words that were handed over — checked before anything indexes by them
+    RB_REQUIRE((int64_t)B.b.h_woff[(size_t)n_reads] == n_words, "packed batch: the lengths of %lld reads add up to %u words, %lld were passed",
+               (long long)n_reads, B.b.h_woff[(size_t)n_reads], (long long)n_words);
+    if (n_reads) hipLaunchKernelGGL(k_packed_word_read, dim3(blocks_for(n_reads)), dim3(TPB), 0, st, B.woff.as<uint32_t>(), n_reads, B.word_read.as<uint32_t>());
+    RB_HIP(hipGetLastError());
+    RB_HIP(hipStreamSynchronize(st));
+    rb_batch &b = B.b;
+    b.device = s->device; b.n_reads = n_reads; b.n_words = n_words;
+    b.max_len = s->h_stats[0];
+    b.wpr_uniform = (n_reads && s->h_stats[1] == s->h_stats[2]) ? s->h_stats[1] : 0u;
+    b.n_bases = (int64_t)(((uint64_t)s->h_stats[5] << 32) | s->h_stats[4]);
+    b.codes = B.codes.as<uint64_t>(); b.valid = B.valid.as<uint32_t>(); b.word_read = B.word_read.as<uint32_t>();
+    b.woff = B.woff.as<uint32_t>(); b.len = B.len.as<uint32_t>(); b.rnz = nullptr;
+    b.device_bytes = nw * 16 + (nr + 1) * 4 + nr * 4;
+}
+}  // namespace
+
+extern "C" {
+
+int rb_host_alloc(size_t bytes, void **out) {
+    return guarded([&] {
+        RB_REQUIRE(out, "rb_host_alloc: null argument");
+        RB_HIP(hipHostMalloc(out, std::max<size_t>(bytes, 1), hipHostMallocDefault));
+    });
+}
+int rb_host_free(void *p) {
+    if (p) (void)hipHostFree(p);
+    return RB_OK;
+}
+
+int rb_batch_download_packed(const rb_batch *b, int64_t first, int64_t n, uint64_t *codes, uint32_t *valid, uint32_t *len, int64_t *n_words) {
+    return guarded([&] {
+        RB_REQUIRE(b && n_words && first >= 0 && n >= 0 && first + n <= b->n_reads, "rb_batch_download_packed: bad range");
+        RB_HIP(hipSetDevice(b->device));
+        const int64_t w0 = n ? (int64_t)b->h_woff[(size_t)first] : 0, w1 = n ? (int64_t)b->h_woff[(size_t)(first + n)] : 0;
+        *n_words = w1 - w0;
+        if (!codes && !valid && !len) return;                 // size query
+        RB_REQUIRE(codes && valid && len, "rb_batch_download_packed: null output array");
+        if (n) RB_HIP(hipMemcpy(len, b->len + first, (size_t)n * 4, hipMemcpyDeviceToHost));
+        if (w1 > w0) {
+            RB_HIP(hipMemcpy(codes, b->codes + w0, (size_t)(w1 - w0) * 8, hipMemcpyDeviceToHost));
+            RB_HIP(hipMemcpy(valid, b->valid + w0, (size_t)(w1 - w0) * 4, hipMemcpyDeviceToHost));
+        }
+    });
+}
+
+int rb_packed_stream_create(int device, int64_t max_reads, int64_t max_words, rb_packed_stream **out) {
+    rb_packed_stream *s = nullptr;
+    int rc = guarded([&] {
+        RB_REQUIRE(out && max_reads >= 0 && max_words >= 0 && max_words < 0xFFFFFFF0ll && max_reads < 0xFFFFFFF0ll, "rb_packed_stream_create: bad argument");
+        int ndev = 0;
+        RB_HIP(hipGetDeviceCount(&ndev));
+        RB_REQUIRE(device >= 0 && device < ndev, "rb_packed_stream_create: device %d not present", device);
+        RB_HIP(hipSetDevice(device));
+        s = new rb_packed_stream();
+        s->device = device; s->max_reads = max_reads; s->max_words = max_words;
+        RB_HIP(hipStreamCreateWithFlags(&s->st, hipStreamNonBlocking));
+        RB_HIP(hipHostMalloc(reinterpret_cast<void **>(&s->h_stats), 64, hipHostMallocDefault));
+        for (auto &B : s->buf) {                   // both buffers at their full size now: growing one later frees memory, and hipFree waits for the device
+            const size_t nw = (size_t)std::max<int64_t>(max_words, 1), nr = (size_t)std::max<int64_t>(max_reads, 1);
+            B.codes.reserve(nw * 8); B.valid.reserve(nw * 4); B.word_read.reserve(nw * 4);
+            B.woff.reserve((nr + 1) * 4); B.len.reserve(nr * 4); B.wc.reserve((nr + 1) * 4); B.stats.reserve(64);
+            B.temp.reserve(scan_temp_bytes(nr + 1));
+            B.b.h_woff.reserve(nr + 1);
+        }
+        *out = s;
+    });
+    if (rc != RB_OK && s) rb_packed_stream_destroy(s);
+    return rc;
+}
+
+int rb_packed_stream_begin(rb_packed_stream *s, const uint64_t *codes, const uint32_t *valid, const uint32_t *len, int64_t n_reads, int64_t n_words) {
+    return guarded([&] {
+        RB_REQUIRE(s && n_reads >= 0 && n_words >= 0 && (n_reads == 0 || len) && (n_words == 0 || (codes && valid)), "rb_packed_stream_begin: bad argument");
+        RB_REQUIRE(!s->pending, "rb_packed_stream_begin: the chunk begun before has not been finished");
+        RB_REQUIRE(n_words < 0xFFFFFFF0ll && n_reads < 0xFFFFFFF0ll, "rb_packed_stream_begin: chunk too large (> 2^32 words)");
+        if (s->worker.joinable()) s->worker.join();
+        const int slot = s->fill;
+        s->pending = true; s->pend_reads = n_reads; s->pend_words = n_words;
+        s->worker_rc = RB_OK; s->worker_err.clear();
+        s->worker = std::thread([=] {
+            s->worker_rc = guarded([&] { upload_chunk(s, slot, codes, valid, len, n_reads, n_words); });
+            if (s->worker_rc != RB_OK) s->worker_err = rb_last_error();       // (the error text is thread-local)
+        });
+    });
+}
+
+int rb_packed_stream_finish(rb_packed_stream *s, const rb_batch **out) {
+    return guarded([&] {
+        RB_REQUIRE(s && out, "rb_packed_stream_finish: null argument");
+        RB_REQUIRE(s->pending, "rb_packed_stream_finish: no chunk was begun");
+        if (s->worker.joinable()) s->worker.join();
+        s->pending = false;
+        if (s->worker_rc != RB_OK) { set_error("%s", s->worker_err.c_str()); throw HipError{s->worker_rc}; }
+        *out = &s->buf[s->fill].b;             // valid until the begin() after next reuses this buffer
+        s->fill ^= 1;
+    });
+}
+
+int rb_packed_stream_destroy(rb_packed_stream *s) {
+    if (!s) return RB_OK;
+    if (s->worker.joinable()) s->worker.join();
+    (void)hipSetDevice(s->device);
+    if (s->st) { (void)hipStreamSynchronize(s->st); (void)hipStreamDestroy(s->st); }
+    for (auto &B : s->buf) {
+        for (DevBuf *d : {&B.codes, &B.valid, &B.word_read, &B.woff, &B.len, &B.wc, &B.temp, &B.stats}) d->release();
+        B.b.codes = nullptr; B.b.valid = nullptr; B.b.word_read = nullptr; B.b.woff = nullptr; B.b.len = nullptr;
+    }
+    if (s->h_stats) (void)hipHostFree(s->h_stats);
+    delete s;
+    return RB_OK;
+}
+
+// FastqToGraphWorker.run over reads that are already packed in host memory: chunks of `chunk_reads` reads (0: 2^24) go through a
+// packed stream of the handle's device, chunk c + 1 uploading while chunk c is inserted.  Same results as rb_graph_add_batch of
+// the same reads (nothing depends on where a call is cut: DESIGN.md §3 (v)).
+int rb_graph_add_packed(rb_graph *g, const uint64_t *codes, const uint32_t *valid, const uint32_t *len, int64_t n_reads, int64_t n_words,
+                        int64_t chunk_reads, unsigned flags, rb_add_stats *stats) {
+    if (stats) memset(stats, 0, sizeof *stats);
+    if (!g) { set_error("rb_graph_add_packed: null graph"); return RB_ERR_INVALID; }
+    rb_packed_stream *s = nullptr;
+    int rc = guarded([&] {
+        RB_REQUIRE(n_reads >= 0 && n_words >= 0 && chunk_reads >= 0 && (n_reads == 0 || len) && (n_words == 0 || (codes && valid)), "rb_graph_add_packed: bad argument");
+        if (!n_reads) return;
+        const int64_t step = chunk_reads ? chunk_reads : ((int64_t)1 << 24);
+        // chunk boundaries in words: one pass over the lengths (host; 4 bytes per read)
+        std::vector<int64_t> rcut{0}, wcut{0};
+        int64_t w = 0, wmax = 0;
+        for (int64_t r = 0; r < n_reads; ++r) {
+            w += ((int64_t)len[r] + 31) >> 5;
+            if (r + 1 == n_reads || (r + 1) % step == 0) { rcut.push_back(r + 1); wmax = std::max(wmax, w - wcut.back()); wcut.push_back(w); }
+        }
+        RB_REQUIRE(w == n_words, "rb_graph_add_packed: the lengths add up to %lld words, %lld were passed", (long long)w, (long long)n_words);
+        int prc = rb_packed_stream_create(g->p.device, std::min(step, n_reads), wmax, &s);
+        if (prc != RB_OK) throw HipError{prc};
+        auto begin = [&](size_t c) {
+            int brc = rb_packed_stream_begin(s, codes + wcut[c], valid + wcut[c], len + rcut[c], rcut[c + 1] - rcut[c], wcut[c + 1] - wcut[c]);
+            if (brc != RB_OK) throw HipError{brc};
+        };
+        begin(0);
+        for (size_t c = 0; c + 1 < rcut.size(); ++c) {
+            const rb_batch *b = nullptr;
+            int frc = rb_packed_stream_finish(s, &b);
+            if (frc != RB_OK) throw HipError{frc};
+            if (c + 2 < rcut.size()) begin(c + 1);
+            rb_add_stats st1;
+            int arc = rb_graph_add_batch_range(g, b, 0, b->n_reads, flags, &st1);
+            if (arc != RB_OK) throw HipError{arc};
+            if (stats) {
+                stats->reads += st1.reads; stats->kmers += st1.kmers; stats->pairs += st1.pairs; stats->distinct += st1.distinct;
+                stats->conflict_ops += st1.conflict_ops; stats->sorted_kmers += st1.sorted_kmers;
+            }
+        }
+    });
+    if (s) rb_packed_stream_destroy(s);
+    return rc;
+}
+
+}  // extern "C"

@@ -110,6 +110,14 @@ SYMBOLS = [
     ("rb_graph_add_fasta_file", _i32, [_vp, C.c_char_p, C.c_uint, C.POINTER(AddStats), C.POINTER(_i64)]),
     ("rb_batch_create_nbits", _i32, [_i32, _vp, _sz, _i64, C.POINTER(_vp), C.POINTER(_sz)]),
     ("rb_nbits_encode", _i32, [_vp, _vp, _i64, _vp, _sz, C.POINTER(_sz)]),
+    ("rb_host_alloc", _i32, [_sz, C.POINTER(_vp)]),
+    ("rb_host_free", _i32, [_vp]),
+    ("rb_batch_download_packed", _i32, [_vp, _i64, _i64, _vp, _vp, _vp, C.POINTER(_i64)]),
+    ("rb_packed_stream_create", _i32, [_i32, _i64, _i64, C.POINTER(_vp)]),
+    ("rb_packed_stream_begin", _i32, [_vp, _vp, _vp, _vp, _i64, _i64]),
+    ("rb_packed_stream_finish", _i32, [_vp, C.POINTER(_vp)]),
+    ("rb_packed_stream_destroy", _i32, [_vp]),
+    ("rb_graph_add_packed", _i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, C.c_uint, C.POINTER(AddStats)]),
     ("rb_graph_create_shard", _i32, [C.POINTER(GraphParams), _i32, _i32, C.POINTER(_vp)]),
     ("rb_shard_set_cache_replication", _i32, [_vp, _i32]),
     ("rb_shard_hash", _i32, [_vp, _vp, _i64, _i64, _i64, _i64, _u64, _u32, C.c_uint, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(AddStats)]),

@@ -37,8 +37,86 @@ def _u64(a):
     return np.ascontiguousarray(a, dtype=np.uint64)
 
 
+class PackedHost:
+    """Packed reads in HOST memory (the build's batch format, include/rb_capi.h "read batches packed in HOST memory"): numpy views
+    codes (u64 per 32 bases), valid (u32 per 32 bases), len (u32 per read) — over pinned memory when pinned=True."""
+
+    def __init__(self, n_reads, n_words, pinned=True):
+        self.n_reads, self.n_words = int(n_reads), int(n_words)
+        self._raw = []
+
+        def arr(count, dtype):
+            nbytes = max(1, count) * np.dtype(dtype).itemsize
+            if not pinned:
+                return np.zeros(count, dtype)
+            p = C.c_void_p()
+            check(lib.rb_host_alloc(nbytes, C.byref(p)))
+            self._raw.append(p)
+            return np.frombuffer((C.c_uint8 * nbytes).from_address(p.value), dtype, count)
+        self.codes = arr(self.n_words, np.uint64)
+        self.valid = arr(self.n_words, np.uint32)
+        self.len = arr(self.n_reads, np.uint32)
+
+    def nbytes(self):
+        return self.n_words * 12 + self.n_reads * 4
+
+    def words_before(self, r):
+        """word offset of read r (uniform-length reads are the common case; the general case is a prefix sum)"""
+        if not hasattr(self, "_woff"):
+            self._woff = np.zeros(self.n_reads + 1, np.int64)
+            np.cumsum((self.len.astype(np.int64) + 31) >> 5, out=self._woff[1:])
+        return int(self._woff[r])
+
+    def close(self):
+        self.codes = self.valid = self.len = None
+        for p in self._raw:
+            lib.rb_host_free(p)
+        self._raw = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class PackedStream:
+    """rb_packed_stream: two device batches taking turns; begin() starts the upload of a chunk of a PackedHost and returns,
+    finish() waits for it and returns a (borrowed) ReadBatch for addBatch — the caller inserts chunk c between begin(c + 1) and
+    finish(c + 1), so the upload runs beside the insert."""
+
+    def __init__(self, max_reads, max_words, device=0):
+        self.h = C.c_void_p()
+        check(lib.rb_packed_stream_create(device, max_reads, max_words, C.byref(self.h)))
+        self.device = device
+
+    def begin(self, ph, first=0, n=None):
+        n = ph.n_reads - first if n is None else n
+        w0, w1 = ph.words_before(first), ph.words_before(first + n)
+        check(lib.rb_packed_stream_begin(self.h, ph.codes.ctypes.data + 8 * w0, ph.valid.ctypes.data + 4 * w0, ph.len.ctypes.data + 4 * first, n, w1 - w0))
+
+    def finish(self):
+        b = C.c_void_p()
+        check(lib.rb_packed_stream_finish(self.h, C.byref(b)))
+        rb = ReadBatch(b, self.device)
+        rb.borrowed = True
+        return rb
+
+    def close(self):
+        if self.h:
+            lib.rb_packed_stream_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class ReadBatch:
     """A batch of reads resident on the device in the packed 2-bit + validity format."""
+    borrowed = False                     # a batch owned by a PackedStream: never destroyed from here
 
     def __init__(self, handle, device):
         self.h = handle
@@ -92,6 +170,16 @@ class ReadBatch:
         check(lib.rb_batch_download_ascii(self.h, first, n, _ptr(seq), _ptr(off)))
         return seq, off
 
+    def downloadPacked(self, first=0, n=None, pinned=True):
+        """reads [first, first + n) in the build's host batch format (include/rb_capi.h: codes u64 / valid u32 per 32 bases, len u32 per
+        read) -> PackedHost; pinned: the arrays live in hipHostMalloc'ed memory (uploads at link speed, no registration pass)"""
+        n = self.n_reads - first if n is None else n
+        nw = C.c_int64()
+        check(lib.rb_batch_download_packed(self.h, first, n, None, None, None, C.byref(nw)))
+        ph = PackedHost(n, nw.value, pinned)
+        check(lib.rb_batch_download_packed(self.h, first, n, _ptr(ph.codes), _ptr(ph.valid), _ptr(ph.len), C.byref(nw)))
+        return ph
+
     def nthash(self, k, mode, first=0, n=None, with_positions=False):
         """{,Canonical,ReverseComplement}NTHashIterator over every usable segment (mode 0/1/2)."""
         n = self.n_reads - first if n is None else n
@@ -105,9 +193,9 @@ class ReadBatch:
         return (h0, rd, ps) if with_positions else h0
 
     def close(self):
-        if self.h:
+        if self.h and not self.borrowed:
             lib.rb_batch_destroy(self.h)
-            self.h = None
+        self.h = None
 
     def __del__(self):
         try:
@@ -180,6 +268,18 @@ class BloomFilterDeBruijnGraph:
         else:
             n = batch.n_reads - first if n is None else n
             check(lib.rb_graph_add_batch_range(self.h, batch.h, first, n, flags, C.byref(st)))
+        return st
+
+    def addPacked(self, ph, reverseComplement=False, incrementIfPresent=False, storeReadPairedKmers=False, first=0, n=None, chunkReads=0):
+        """reads [first, first + n) of a PackedHost through rb_graph_add_packed: chunks uploaded on a copy stream while the chunk before
+        is inserted (FastqToGraphWorker's loop over reads that are already packed in host memory)"""
+        flags = (N.ADD_REVCOMP if reverseComplement else 0) | (N.ADD_COUNT_IF_PRESENT if incrementIfPresent else 0) \
+            | (N.ADD_STORE_READ_PAIRS if storeReadPairedKmers else 0)
+        n = ph.n_reads - first if n is None else n
+        w0, w1 = ph.words_before(first), ph.words_before(first + n)
+        st = N.AddStats()
+        check(lib.rb_graph_add_packed(self.h, ph.codes.ctypes.data + 8 * w0, ph.valid.ctypes.data + 4 * w0, ph.len.ctypes.data + 4 * first,
+                                      n, w1 - w0, chunkReads, flags, C.byref(st)))
         return st
 
     def addFastq(self, text, minBaseQual=3, reverseComplement=False, incrementIfPresent=False, storeReadPairedKmers=False):

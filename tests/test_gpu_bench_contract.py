@@ -125,3 +125,30 @@ def test_a_rank_that_fails_fast_and_comes_back_does_not_unpoison_the_hub_for_its
     for x in th: x.join(60)
     assert not any(x.is_alive() for x in th) and res == [0, 0], (res, N.lib.rb_last_error())
     comm.destroy()
+
+
+def test_a_rank_that_fails_after_its_last_barrier_does_not_strand_a_peer_that_waits_in_the_next_call():
+    """loopback hub, two ranks: rank 0 fails call 1 AFTER the last barrier of that call (injected: big_bytes = -2), when rank 1 has left call 1
+    and already waits in the first barrier of call 2.  Rank 0's exit from call 1 must not clean the hub (everybody's `left` is >= the failed
+    call, but rank 1 is INSIDE a call): rank 1 would find `failed` false and its arrival erased, and wait for ever.  Rank 1's call 2 fails,
+    rank 0's call 2 fails at once, call 3 succeeds on both."""
+    import threading
+    sys.path[:0] = [ROOT, os.path.join(ROOT, "rna-bloom_amd")]
+    from rnabloom import _native as N
+    from rnabloom import sharded
+    comm = sharded.NativeComm.loopback(2)
+    st = lambda rank, big: N.lib.rb_shard_comm_selftest(comm.h, rank, 0, big)
+    r0, r1 = [], []
+    t0 = threading.Thread(target=lambda: r0.append(st(0, -2)))
+    t1 = threading.Thread(target=lambda: r1.extend([st(1, 0), st(1, 0)]))
+    t0.start(); t1.start()
+    t0.join(60); t1.join(60)
+    assert not t0.is_alive() and not t1.is_alive(), "a rank hangs at a barrier of a hub that was cleaned while it waited"
+    assert r0[0] != 0 and r1[0] == 0 and r1[1] != 0, (r0, r1)
+    assert st(0, 0) != 0                       # call 2 of rank 0: poisoned, fails at once
+    res = [None, None]
+    th = [threading.Thread(target=lambda i=i: res.__setitem__(i, st(i, 0))) for i in range(2)]      # call 3: in step again
+    for x in th: x.start()
+    for x in th: x.join(60)
+    assert not any(x.is_alive() for x in th) and res == [0, 0], (res, N.lib.rb_last_error())
+    comm.destroy()

@@ -1,0 +1,101 @@
+"""Read batches packed in HOST memory (include/rb_capi.h rb_batch_download_packed / rb_packed_stream_* / rb_graph_add_packed: the input format
+SURVEY.md §8(d) quotes the metric on): a packed round trip reproduces the batch word for word, an insert streamed from host memory in
+chunks leaves the filters the oracle leaves, and a chunk whose lengths do not describe its words is refused."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import rbo
+from rnabloom import _native as N
+from rnabloom import synth
+from rnabloom.graph import BloomFilterDeBruijnGraph, PackedHost, PackedStream, ReadBatch
+
+
+def ragged_reads(n, seed):
+    """reads of 0 .. 400 bases with N bases and low qualities sprinkled in"""
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(0, 400, n)
+    lens[rng.integers(0, n, n // 50)] = 0
+    lens[:7] = (0, 1, 31, 32, 33, 64, 65)
+    reads, quals = [], []
+    for L in lens.tolist():
+        s = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, L)].copy()
+        q = np.full(L, ord("I"), np.uint8)
+        if L:
+            s[rng.integers(0, L, max(1, L // 60))] = ord("N")
+            q[rng.integers(0, L, max(1, L // 40))] = ord("#")
+        reads.append(s.tobytes()); quals.append(q.tobytes())
+    return reads, quals
+
+
+@pytest.mark.parametrize("pinned", [True, False])
+def test_packed_round_trip_reproduces_the_batch(pinned):
+    reads, quals = ragged_reads(20_000, 3)
+    b = ReadBatch.from_reads(reads, quals, 3)
+    seq0, off0 = b.download()
+    ph = b.downloadPacked(pinned=pinned)
+    assert ph.n_reads == len(reads) and ph.n_words == int(((np.diff(off0) + 31) // 32).sum())
+    assert (ph.len == np.diff(off0)).all()
+    ps = PackedStream(8_000, int(ph.n_words))
+    got_seq, got_len = [], []
+    cuts = [0, 8_000, 8_001, 15_000, 20_000]                       # a chunk of one read among them; two buffers take turns
+    ps.begin(ph, cuts[0], cuts[1] - cuts[0])
+    for i in range(len(cuts) - 1):
+        c = ps.finish()
+        if i + 2 < len(cuts):
+            ps.begin(ph, cuts[i + 1], cuts[i + 2] - cuts[i + 1])
+        info = c.info()
+        assert info["n_reads"] == cuts[i + 1] - cuts[i] and info["n_bases"] == int(off0[cuts[i + 1]] - off0[cuts[i]])
+        s, o = c.download()
+        got_seq.append(s); got_len.append(np.diff(o))
+        # the device-only columns were rebuilt on the GPU: hashing every window of the uploaded chunk equals hashing the same reads of the original
+        assert (c.nthash(25, 1) == b.nthash(25, 1, cuts[i], cuts[i + 1] - cuts[i])).all()
+    assert (np.concatenate(got_len) == np.diff(off0)).all() and (np.concatenate(got_seq) == seq0).all()
+    ps.close(); ph.close()
+
+
+def test_an_insert_streamed_from_packed_host_memory_leaves_the_oracles_filters():
+    d = synth.generate_pairs(6000, G=60000, err=0.002, n_rate=1e-3, seed=4)
+    k, dist = 25, 150 - 25 - 10
+    sizes = (2_400_011, 19_200_013, 2_400_011)
+    og = rbo.Graph(*sizes, 2, 2, 2, k, False, True, 7)
+    gg = BloomFilterDeBruijnGraph(*sizes, 2, 2, 2, k, False, True, rngSeed=7)
+    og.set_read_pair_distance(dist); gg.setReadPairedKmerDistance(dist)
+    kmers = 0
+    for name, rc in (("left", False), ("right", True)):
+        seq, off = synth.flat(d[name])
+        qual, _ = synth.flat(d[name[0] + "qual"])
+        ost = og.add_reads(seq, qual, off, 3, rbo.STORE_READ_PAIRS | (rbo.REVCOMP if rc else 0))
+        b = ReadBatch.from_ascii(seq, qual, off, 3)
+        ph = b.downloadPacked()
+        st = gg.addPacked(ph, reverseComplement=rc, storeReadPairedKmers=True, chunkReads=1700)       # four chunks, the last one short
+        assert st.kmers == ost.kmers and st.pairs == ost.pairs and st.reads == len(d[name])
+        kmers += st.kmers
+        ph.close(); b.close()
+    assert kmers > 0
+    assert (gg.exportFilter(N.DBGBF) == og.dbgbf_bytes()).all()
+    assert (gg.exportFilter(N.CBF) == og.cbf_bytes()).all()
+    assert (gg.exportFilter(N.RPKBF) == og.rpkbf_bytes()).all()
+
+
+def test_a_chunk_whose_lengths_do_not_describe_its_words_is_refused_and_the_stream_lives_on():
+    reads, quals = ragged_reads(3000, 5)
+    b = ReadBatch.from_reads(reads, quals, 3)
+    ph = b.downloadPacked(pinned=False)
+    ps = PackedStream(3000, int(ph.n_words))
+    N.check(N.lib.rb_packed_stream_begin(ps.h, ph.codes.ctypes.data, ph.valid.ctypes.data, ph.len.ctypes.data, 3000, ph.n_words - 1))
+    out = C.c_void_p()
+    assert N.lib.rb_packed_stream_finish(ps.h, C.byref(out)) != 0 and b"add up to" in N.lib.rb_last_error()
+    assert N.lib.rb_packed_stream_finish(ps.h, C.byref(out)) != 0          # nothing in flight any more
+    ps.begin(ph)
+    with pytest.raises(N.NativeError):
+        ps.begin(ph)                                                        # one chunk in flight at a time
+    c = ps.finish()
+    assert (c.download()[0] == b.download()[0]).all()
+    g = BloomFilterDeBruijnGraph(100_003, 100_003, 100_003, 2, 2, 2, 25, False, False)
+    with pytest.raises(N.NativeError):
+        N.check(N.lib.rb_graph_add_packed(g.h, ph.codes.ctypes.data, ph.valid.ctypes.data, ph.len.ctypes.data, 3000, ph.n_words + 5, 0, 0, None))
+    ps.close()
