@@ -20,9 +20,9 @@ import static rnabloom.util.SeqUtils.*;
  * library re-derives hashVals[1..] with NTM64 from the graph's k (src/rnabloom/bloom/hash/NTHash.java:518-527) — which is
  * what every hashVals array in the reference was made with.
  *
- * Kmer, CanonicalKmer, HashFunction and the iterators stay the reference's own classes: they call back into
- * getCount(long) / contains(long[]) of this class exactly as before.  (HashFunction needs one accessor the reference does not
- * have: `public int getK() { return k; }`.)
+ * Kmer and CanonicalKmer have drop-ins beside this file (one NativeGraph.neighbors call per k-mer neighbourhood); HashFunction and the
+ * iterators stay the reference's own classes.  (HashFunction needs one accessor the reference does not have:
+ * `public int getK() { return k; }`.)
  */
 public class BloomFilterDeBruijnGraph {
     private long handle;                                   // rb_graph*: dbgbf, cbf, rpkbf, fpkbf live on the device behind it

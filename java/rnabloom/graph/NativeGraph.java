@@ -51,6 +51,21 @@ public final class NativeGraph {
     /** {reads, bases, device bytes} */
     public static native long[] batchInfo(long b);
 
+    // ---- reads packed in HOST memory (the build's batch format: codes 8 B + valid 4 B per 32 bases, len 4 B per read; little endian) ----
+    /** pinned host memory as a direct buffer: uploads from it run at link speed.  Free with hostFree — the collector does not own it. */
+    public static native ByteBuffer hostAlloc(long bytes);
+    public static native void hostFree(ByteBuffer buf);
+    /** reads [first, first + n) of a device batch into direct buffers; returns their word count (all buffers null: size query) */
+    public static native long batchDownloadPacked(long b, long first, long n, ByteBuffer codes, ByteBuffer valid, ByteBuffer len);
+    /** two device batches taking turns: begin() starts the upload of a chunk and returns, finish() waits and returns a BORROWED batch handle
+     *  (addBatch it, never batchDestroy it) that stays valid until the begin() after next */
+    public static native long packedStreamCreate(int device, long maxReads, long maxWords);
+    public static native void packedStreamBegin(long s, ByteBuffer codes, ByteBuffer valid, ByteBuffer len, long wordOffset, long readOffset, long nReads, long nWords);
+    public static native long packedStreamFinish(long s);
+    public static native void packedStreamDestroy(long s);
+    /** FastqToGraphWorker's loop over reads already packed in host memory: chunks of chunkReads reads (0: 2^24) upload while the chunk before is inserted */
+    public static native long[] addPacked(long h, ByteBuffer codes, ByteBuffer valid, ByteBuffer len, long nReads, long nWords, long chunkReads, int flags);
+
     // ---- stage-1 inserts; every add returns {reads, kmers, pairs, distinct, conflictOps, sortedKmers} ----
     public static native long[] addBatch(long h, long batch, long first, long n, int flags);
     public static native long[] addPairs(long h, long batch, long first, long n, int which, int flags);

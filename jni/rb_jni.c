@@ -107,6 +107,56 @@ jlong FN(batchCreateNbits)(JNIEnv *e, jclass c, jint device, jobject bytes, jlon
     if (consumed) { jlong u = (jlong)used; (*e)->SetLongArrayRegion(e, consumed, 0, 1, &u); }
     return (jlong)(intptr_t)b;
 }
+/* ---- packed reads in host memory (include/rb_capi.h "read batches packed in HOST memory") ---- */
+#define PS(h) ((rb_packed_stream *)(intptr_t)(h))
+/* pinned host memory as a direct ByteBuffer (free it with hostFree, never let the collector do it) */
+jobject FN(hostAlloc)(JNIEnv *e, jclass c, jlong bytes) {
+    void *p = NULL;
+    (void)c;
+    int rc = rb_host_alloc((size_t)bytes, &p);
+    if (rc) { throw_rc(e, rc); return NULL; }
+    return (*e)->NewDirectByteBuffer(e, p, bytes);
+}
+void FN(hostFree)(JNIEnv *e, jclass c, jobject buf) { (void)c; (void)rb_host_free(direct(e, buf)); }
+jlong FN(batchDownloadPacked)(JNIEnv *e, jclass c, jlong b, jlong first, jlong n, jobject codes, jobject valid, jobject len) {
+    int64_t nw = 0;
+    (void)c;
+    int rc = rb_batch_download_packed(B(b), first, n, (uint64_t *)direct(e, codes), (uint32_t *)direct(e, valid), (uint32_t *)direct(e, len), &nw);
+    if (rc) throw_rc(e, rc);
+    return (jlong)nw;
+}
+jlong FN(packedStreamCreate)(JNIEnv *e, jclass c, jint device, jlong max_reads, jlong max_words) {
+    rb_packed_stream *s = NULL;
+    (void)c;
+    int rc = rb_packed_stream_create(device, max_reads, max_words, &s);
+    if (rc) { throw_rc(e, rc); return 0; }
+    return (jlong)(intptr_t)s;
+}
+/* codes / valid / len: direct buffers; the chunk starts wordOffset words / readOffset reads into them */
+void FN(packedStreamBegin)(JNIEnv *e, jclass c, jlong s, jobject codes, jobject valid, jobject len, jlong word_off, jlong read_off, jlong n_reads, jlong n_words) {
+    const uint64_t *pc = (const uint64_t *)direct(e, codes);
+    const uint32_t *pv = (const uint32_t *)direct(e, valid), *pl = (const uint32_t *)direct(e, len);
+    (void)c;
+    int rc = rb_packed_stream_begin(PS(s), pc ? pc + word_off : NULL, pv ? pv + word_off : NULL, pl ? pl + read_off : NULL, n_reads, n_words);
+    if (rc) throw_rc(e, rc);
+}
+/* the batch handle is borrowed from the stream: pass it to addBatch, never to batchDestroy */
+jlong FN(packedStreamFinish)(JNIEnv *e, jclass c, jlong s) {
+    const rb_batch *b = NULL;
+    (void)c;
+    int rc = rb_packed_stream_finish(PS(s), &b);
+    if (rc) { throw_rc(e, rc); return 0; }
+    return (jlong)(intptr_t)b;
+}
+void FN(packedStreamDestroy)(JNIEnv *e, jclass c, jlong s) { (void)c; int rc = rb_packed_stream_destroy(PS(s)); if (rc) throw_rc(e, rc); }
+jlongArray FN(addPacked)(JNIEnv *e, jclass c, jlong h, jobject codes, jobject valid, jobject len, jlong n_reads, jlong n_words, jlong chunk_reads, jint flags) {
+    rb_add_stats st;
+    (void)c;
+    int rc = rb_graph_add_packed(G(h), (const uint64_t *)direct(e, codes), (const uint32_t *)direct(e, valid), (const uint32_t *)direct(e, len), n_reads, n_words,
+                                 chunk_reads, (unsigned)flags, &st);
+    if (rc) { throw_rc(e, rc); return NULL; }
+    return stats_array(e, &st);
+}
 jlong FN(batchCreateFastq)(JNIEnv *e, jclass c, jint device, jobject text, jlong len, jboolean final, jint min_q, jboolean use_qual, jlongArray consumed) {
     rb_batch *b = NULL;
     size_t used = 0;

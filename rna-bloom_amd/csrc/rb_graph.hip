@@ -1821,7 +1821,7 @@ void rb::add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, uns
     const bool npf_path = g->npf_log2 && (g->k <= 31 || (g->k <= 64 && !wide_off));
     const int wmul = getenv("RB_WINDOW_MUL") ? std::max(1, atoi(getenv("RB_WINDOW_MUL"))) : 3;
     const int64_t max_words = std::max<int64_t>(std::min<int64_t>((npf_path ? wmul : 1) * g->max_batch_kmers, (int64_t)7 << 29) / 32, 1);
-    const std::vector<uint32_t> &wo = b->h_woff;
+    const auto &wo = b->h_woff;
     // plan the sub-batches
     struct Sub { int64_t r0, r1, w0, nw; uint32_t N; int64_t total; };
     // occurrences that provably cannot change a counter are dropped before sorting (word-per-lane walkers: k <= 64;

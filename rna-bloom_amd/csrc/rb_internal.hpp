@@ -18,8 +18,16 @@ namespace rb {
 // Buffers that cannot be registered (foreign mappings, already registered) are copied the slow way.
 struct HostPin {
     void *p = nullptr;
+    // memory that is pinned already (hipHostMalloc'ed, or registered by the caller) is left alone: registering a piece of it again
+    // either fails or pins and unpins the pages once more — 8 ms per GB each way, which halved the rate of the packed stream's uploads
+    static bool pinned_already(const void *ptr) {
+        hipPointerAttribute_t a;
+        const bool yes = hipPointerGetAttributes(&a, ptr) == hipSuccess && a.type == hipMemoryTypeHost;
+        (void)hipGetLastError();
+        return yes;
+    }
     HostPin(const void *ptr, size_t bytes) {
-        if (ptr && bytes > ((size_t)16 << 20) && !getenv("RB_NO_PIN") &&
+        if (ptr && bytes > ((size_t)16 << 20) && !getenv("RB_NO_PIN") && !pinned_already(ptr) &&
             hipHostRegister(const_cast<void *>(ptr), bytes, hipHostRegisterDefault) == hipSuccess) p = const_cast<void *>(ptr);
         else (void)hipGetLastError();
     }
@@ -76,6 +84,26 @@ struct DevBuf {
 // ---- device-resident read batch (packed) ----
 // Read r occupies words [woff[r], woff[r+1]) ; word w holds 32 bases: 2-bit codes in codes[w]
 // (base i at bits 2i..2i+1, LSB first) and one usable-bit per base in valid[w].
+// host copy of a batch's word offsets: the batch's own vector, or — batches of a packed stream (rb_packed.hip) — pinned memory of the
+// stream the offsets were copied into at link speed (a pageable destination costs 10 ms per 50 MB chunk on the upload's critical path)
+struct HostWoff {
+    std::vector<uint32_t> own;
+    uint32_t *ext = nullptr;
+    size_t ext_n = 0;
+    const uint32_t *data() const { return ext ? ext : own.data(); }
+    uint32_t *data() { return ext ? ext : own.data(); }
+    size_t size() const { return ext ? ext_n : own.size(); }
+    bool empty() const { return size() == 0; }
+    const uint32_t &operator[](size_t i) const { return data()[i]; }
+    uint32_t &operator[](size_t i) { return data()[i]; }
+    const uint32_t *begin() const { return data(); }
+    const uint32_t *end() const { return data() + size(); }
+    void assign(size_t n, uint32_t v) { ext = nullptr; own.assign(n, v); }
+    void resize(size_t n) { ext = nullptr; own.resize(n); }
+    HostWoff &operator=(const std::vector<uint32_t> &v) { ext = nullptr; own = v; return *this; }
+    void borrow(uint32_t *p, size_t n) { own.clear(); ext = p; ext_n = n; }
+};
+
 struct rb_batch {
     int device = 0;
     int64_t n_reads = 0, n_bases = 0, n_words = 0;
@@ -91,7 +119,7 @@ struct rb_batch {
     uint32_t *woff = nullptr;      // [n_reads+1]
     uint32_t *len = nullptr;       // [n_reads]
     size_t device_bytes = 0;
-    std::vector<uint32_t> h_woff;  // host copy of woff (sub-batch splitting)
+    HostWoff h_woff;               // host copy of woff (sub-batch splitting)
 };
 
 namespace rb {

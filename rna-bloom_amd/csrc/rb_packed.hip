@@ -61,6 +61,8 @@ struct rb_packed_stream {
     struct Buf {
         rb_batch b;                               // its arrays point into the DevBufs below (never rb_batch_destroy'ed)
         DevBuf codes, valid, word_read, woff, len, wc, temp, stats;
+        uint32_t *h_woff = nullptr;               // pinned host copy of woff, (max_reads + 1) entries
+        int64_t h_woff_cap = -1;
     } buf[2];
     uint32_t *h_stats = nullptr;                  // pinned, 8 words
     int fill = 0;                                 // the buffer the next begin() fills
@@ -77,9 +79,8 @@ void upload_chunk(rb_packed_stream *s, int slot, const uint64_t *codes, const ui
     rb_packed_stream::Buf &B = s->buf[slot];
     hipStream_t st = s->st;
     const size_t nw = (size_t)std::max<int64_t>(n_words, 1), nr = (size_t)std::max<int64_t>(n_reads, 1);
-    B.codes.reserve(nw * 8); B.valid.reserve(nw * 4); B.word_read.reserve(nw * 4);
-    B.woff.reserve((nr + 1) * 4); B.len.reserve(nr * 4); B.wc.reserve((nr + 1) * 4); B.stats.reserve(64);
-    B.temp.reserve(scan_temp_bytes(nr + 1));
+    RB_REQUIRE(n_words <= s->max_words && n_reads <= s->max_reads, "packed stream: a chunk of %lld reads / %lld words, the stream was created for %lld / %lld",
+               (long long)n_reads, (long long)n_words, (long long)s->max_reads, (long long)s->max_words);
     // caller's buffers: pinned for the call if they are not already (best effort; 8 ms per GB, here on the helper thread)
     HostPin p0(codes, (size_t)n_words * 8), p1(valid, (size_t)n_words * 4), p2(len, (size_t)n_reads * 4);
     uint32_t init[8] = {0u, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u, 0u};
@@ -89,8 +90,9 @@ void upload_chunk(rb_packed_stream *s, int slot, const uint64_t *codes, const ui
     hipLaunchKernelGGL(k_packed_words, dim3(blocks_for(n_reads + 1)), dim3(TPB), 0, st, B.len.as<uint32_t>(), n_reads, B.wc.as<uint32_t>(), B.stats.as<uint32_t>());
     exclusive_scan_u32(B.temp.p, B.temp.cap, B.wc.as<uint32_t>(), B.woff.as<uint32_t>(), (size_t)n_reads + 1, st);
     RB_HIP(hipMemcpyAsync(s->h_stats, B.stats.p, 32, hipMemcpyDeviceToHost, st));
-    B.b.h_woff.resize((size_t)n_reads + 1);
-    RB_HIP(hipMemcpyAsync(B.b.h_woff.data(), B.woff.p, ((size_t)n_reads + 1) * 4, hipMemcpyDeviceToHost, st));
+    RB_REQUIRE(n_reads <= B.h_woff_cap, "packed stream: a chunk of %lld reads, the stream was created for %lld", (long long)n_reads, (long long)B.h_woff_cap);
+    B.b.h_woff.borrow(B.h_woff, (size_t)n_reads + 1);                  // pinned: the copy back runs at link speed
+    RB_HIP(hipMemcpyAsync(B.h_woff, B.woff.p, ((size_t)n_reads + 1) * 4, hipMemcpyDeviceToHost, st));
     if (n_words) {
         RB_HIP(hipMemcpyAsync(B.codes.p, codes, (size_t)n_words * 8, hipMemcpyHostToDevice, st));
         RB_HIP(hipMemcpyAsync(B.valid.p, valid, (size_t)n_words * 4, hipMemcpyHostToDevice, st));
@@ -159,7 +161,8 @@ int rb_packed_stream_create(int device, int64_t max_reads, int64_t max_words, rb
             B.codes.reserve(nw * 8); B.valid.reserve(nw * 4); B.word_read.reserve(nw * 4);
             B.woff.reserve((nr + 1) * 4); B.len.reserve(nr * 4); B.wc.reserve((nr + 1) * 4); B.stats.reserve(64);
             B.temp.reserve(scan_temp_bytes(nr + 1));
-            B.b.h_woff.reserve(nr + 1);
+            RB_HIP(hipHostMalloc(reinterpret_cast<void **>(&B.h_woff), (nr + 1) * 4, hipHostMallocDefault));
+            B.h_woff_cap = max_reads;
         }
         *out = s;
     });
@@ -202,6 +205,7 @@ int rb_packed_stream_destroy(rb_packed_stream *s) {
     if (s->st) { (void)hipStreamSynchronize(s->st); (void)hipStreamDestroy(s->st); }
     for (auto &B : s->buf) {
         for (DevBuf *d : {&B.codes, &B.valid, &B.word_read, &B.woff, &B.len, &B.wc, &B.temp, &B.stats}) d->release();
+        if (B.h_woff) (void)hipHostFree(B.h_woff);
         B.b.codes = nullptr; B.b.valid = nullptr; B.b.word_read = nullptr; B.b.woff = nullptr; B.b.len = nullptr;
     }
     if (s->h_stats) (void)hipHostFree(s->h_stats);

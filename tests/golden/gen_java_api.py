@@ -1,13 +1,14 @@
 #!/usr/bin/env python3
 """Writes tests/golden/java_api.json: the public constructors and methods (name + parameter types) of the reference classes
 the drop-in boundary keeps: rnabloom.graph.BloomFilterDeBruijnGraph and rnabloom.bloom.{BloomFilter,
-CountingBloomFilter, PairedKeysBloomFilter}.  A fixture is data: names and types, no method bodies.
+CountingBloomFilter, PairedKeysBloomFilter} and rnabloom.graph.{Kmer, CanonicalKmer} (round 6).  A fixture is data: names and types, no method bodies.
     python tests/golden/gen_java_api.py [/root/reference]"""
 import json, os, re, sys
 
 ref = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
 FILES = {"BloomFilterDeBruijnGraph": "src/rnabloom/graph/BloomFilterDeBruijnGraph.java", "BloomFilter": "src/rnabloom/bloom/BloomFilter.java",
-         "CountingBloomFilter": "src/rnabloom/bloom/CountingBloomFilter.java", "PairedKeysBloomFilter": "src/rnabloom/bloom/PairedKeysBloomFilter.java"}
+         "CountingBloomFilter": "src/rnabloom/bloom/CountingBloomFilter.java", "PairedKeysBloomFilter": "src/rnabloom/bloom/PairedKeysBloomFilter.java",
+         "Kmer": "src/rnabloom/graph/Kmer.java", "CanonicalKmer": "src/rnabloom/graph/CanonicalKmer.java"}
 
 
 def public_methods(text):

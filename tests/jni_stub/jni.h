@@ -16,6 +16,7 @@ struct JNINativeInterface_ {
     jclass (*FindClass)(JNIEnv *, const char *);
     jint (*ThrowNew)(JNIEnv *, jclass, const char *);
     void *(*GetDirectBufferAddress)(JNIEnv *, jobject);
+    jobject (*NewDirectByteBuffer)(JNIEnv *, void *, jlong);
     const char *(*GetStringUTFChars)(JNIEnv *, jstring, jboolean *);
     void (*ReleaseStringUTFChars)(JNIEnv *, jstring, const char *);
     jsize (*GetArrayLength)(JNIEnv *, jarray);

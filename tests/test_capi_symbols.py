@@ -120,18 +120,23 @@ def _java_public_methods(text):
 def test_java_drop_in_classes_keep_every_public_signature_of_the_reference():
     import json
     api = json.load(open(os.path.join(ROOT, "tests", "golden", "java_api.json")))
-    where = {"BloomFilterDeBruijnGraph": "graph", "BloomFilter": "bloom", "CountingBloomFilter": "bloom", "PairedKeysBloomFilter": "bloom"}
+    where = {"BloomFilterDeBruijnGraph": "graph", "BloomFilter": "bloom", "CountingBloomFilter": "bloom", "PairedKeysBloomFilter": "bloom",
+             "Kmer": "graph", "CanonicalKmer": "graph"}
     natives = set(re.findall(r"public static (?:native )?[\w\[\]]+ (\w+)\(", open(os.path.join(ROOT, "java", "rnabloom", "graph", "NativeGraph.java")).read()))
     for cls, pkg in where.items():
         src = open(os.path.join(ROOT, "java", "rnabloom", pkg, cls + ".java")).read()
         have = _java_public_methods(src)
+        if cls == "CanonicalKmer":              # a subclass: the public methods it does not override are Kmer's (constructors are never inherited)
+            assert re.search(r"public class CanonicalKmer extends Kmer\b", src)
+            kmer_src = open(os.path.join(ROOT, "java", "rnabloom", "graph", "Kmer.java")).read()
+            have |= {m for m in _java_public_methods(kmer_src) if m[0] != "Kmer"}
         want = {(m["name"], tuple(m["params"]), m["static"]) for m in api[cls]}
         assert len(want) >= 15
         missing = want - have
         assert not missing, (cls, sorted(missing))
         # ... and the class really goes through the JNI surface: every NativeGraph member it names exists
         used = set(re.findall(r"NativeGraph\.(\w+)\(", src))
-        assert used and used <= natives, (cls, used - natives)
+        assert (used or cls == "CanonicalKmer") and used <= natives, (cls, used - natives)
     # the hottest query of the reference (graph.getKmers: 18 call sites) goes through the BATCHED native, not through one getCount per k-mer
     g = open(os.path.join(ROOT, "java", "rnabloom", "graph", "BloomFilterDeBruijnGraph.java")).read()
     g = re.sub(r"/\*.*?\*/", "", g, flags=re.S)
@@ -147,6 +152,12 @@ def test_java_drop_in_classes_keep_every_public_signature_of_the_reference():
     for name in ("endVariants", "isValidSeq"):
         body = g[g.index(name + "("):]
         assert "NativeGraph.contains(handle" in body[:body.index("\n    }\n")], name
+    # the neighbour-extension inner loop: a k-mer's neighbourhood is ONE native call (the reference: four graph.getCount calls), and no method of
+    # the two classes falls back to the per-candidate iterators of the reference
+    km = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "java", "rnabloom", "graph", "Kmer.java")).read(), flags=re.S)
+    assert km.count("NativeGraph.neighbors(") == 1 and "NTHashIterator" not in km
+    ck = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "java", "rnabloom", "graph", "CanonicalKmer.java")).read(), flags=re.S)
+    assert "NTHashIterator" not in ck and "protected long reverseHashForNative()" in ck
     worker = open(os.path.join(ROOT, "java", "rnabloom", "graph", "NativeFastqToGraphWorker.java")).read()
     assert "NativeGraph.addReads(" in worker and "implements Runnable" in worker
 
