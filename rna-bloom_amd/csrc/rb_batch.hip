@@ -659,7 +659,7 @@ k_hash_windows_resume(const uint64_t *__restrict__ codes, const uint32_t *__rest
                       const uint32_t *__restrict__ len, int64_t w0, int64_t nw, int k,
                       const uint32_t *__restrict__ chunk_off, uint32_t first_read, uint32_t pos_bits,
                       uint64_t *__restrict__ keys, uint32_t *__restrict__ vals, const uint32_t *__restrict__ keepmask,
-                      const ulonglong2 *__restrict__ wstate, EmitRecheck rc) {
+                      const ulonglong2 *__restrict__ wstate) {
     constexpr uint32_t SLAB = RB_EMIT_SLAB, BW = RB_SPARSE_WORDS;
     __shared__ uint64_t s_key[SLAB + SLAB / 32 + 1];
     __shared__ uint32_t s_val[SLAB + SLAB / 32 + 1];
@@ -733,16 +733,8 @@ k_hash_windows_resume(const uint64_t *__restrict__ codes, const uint32_t *__rest
             __syncthreads();
             for (uint32_t x = threadIdx.x; x < slab1 - slab0; x += 64u) {
                 const uint32_t q = x + (x >> 5);
-                uint64_t key = s_key[q];
-                uint32_t val = s_val[q];
-                if (rc.rst.tab) {      // what the stages that retire runs have stored since this window was filtered
-                    const uint32_t s2 = rst_lookup(rc.rst, key);
-                    if (s2 && draw_strength(rng31(rc.seed, rc.ordinal0 + (uint64_t)(val >> pos_bits), val & ((1u << pos_bits) - 1u))) < s2) {
-                        key = ~0ull; val = ~0u;                   // a no-op after all: cancelled (rb_group.hip GR_DEAD_*)
-                    }
-                }
-                keys[O0 + slab0 + x] = key;
-                vals[O0 + slab0 + x] = val;
+                keys[O0 + slab0 + x] = s_key[q];
+                vals[O0 + slab0 + x] = s_val[q];
             }
             __syncthreads();
         }
@@ -1234,260 +1226,6 @@ k_filter_reads_coop(const uint64_t *__restrict__ codes, const uint32_t *__restri
     if (threadIdx.x == 0 && total) atomicAdd(&total_spread[16u * (blockIdx.x & 31u)], total);
 }
 
-// The same with the fetch TWO steps ahead of its use (RB_FILTER_PIPE=2): two register sets take turns (the step loop is unrolled
-// by two so that each set has a name), and the loads are issued by every lane in every step — a lane whose bucket did not change
-// reads the table's first line, one cached line for the whole wavefront — because only an unconditional issue lets the compiler
-// count: the finish of window b-2 waits for exactly its eight loads (s_waitcnt vmcnt(8)) while those of window b-1 stay in flight;
-// behind a divergent branch it has to assume the newer loads may not exist and waits for everything (vmcnt(0)).
-template <int MODE>
-__global__ void __launch_bounds__(64)
-k_filter_reads_pipe2(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
-                     const uint32_t *__restrict__ word_read, const uint32_t *__restrict__ len, int64_t w0, int64_t nw, int k,
-                     uint32_t W, uint32_t first_read, uint32_t pos_bits, uint64_t seed, uint64_t ordinal0, Mpf mcache,
-                     uint32_t *__restrict__ cnt, uint32_t *__restrict__ keepmask, uint32_t *__restrict__ total_spread,
-                     uint32_t dbg_flags, ulonglong2 *__restrict__ wstate) {
-    __shared__ uint64_t s_tf[25], s_tr[25];
-    extern __shared__ uint32_t s_ring[];                        // [k-m+1][lane]
-    __shared__ unsigned long long s_bkt[16 * 64];               // [slot][lane]: image of the current bucket
-    const uint32_t uk = (uint32_t)k, lane = threadIdx.x;
-    if (threadIdx.x < 25) {
-        const uint32_t o = threadIdx.x / 5u, in = threadIdx.x % 5u;
-        const uint64_t so = o ? seed_of(o - 1u) : 0ull, si = in ? seed_of(in - 1u) : 0ull;
-        const uint64_t sco = o ? seed_of(4u - o) : 0ull, sci = in ? seed_of(4u - in) : 0ull;
-        s_tf[threadIdx.x] = rotl(so, uk) ^ si;
-        s_tr[threadIdx.x] = rotr(sco, 1) ^ rotl(sci, uk - 1u);
-    }
-    __syncthreads();
-    const int64_t w = ((int64_t)blockIdx.x * 64 + threadIdx.x) * (int64_t)W;
-    uint32_t total = 0;
-    if (w < nw) {
-        const int64_t gw = w0 + w;
-        const uint32_t r = word_read[gw], L = len[r];
-        uint32_t done = 0;
-        if (uk <= L) {
-            uint64_t carr[RB_READ_WORDS];
-            uint32_t varr[RB_READ_WORDS];
-#pragma unroll
-            for (int q = 0; q < RB_READ_WORDS; ++q) {
-                carr[q] = 0; varr[q] = 0;
-                if ((uint32_t)q < W) { carr[q] = codes[gw + q]; varr[q] = valid[gw + q]; }
-            }
-            const uint32_t rstate = rng_read_state(seed, ordinal0 + (uint64_t)(r - first_read));
-            const uint32_t sh_c = 2u * (uk - 1u), sh_v = uk - 1u;
-            const uint32_t um = mcache.m, uw = mpf_kp(uk) - um + 1u, lag = mpf_lag(uk);
-            const uint32_t mmask = (um >= 16u) ? 0xFFFFFFFFu : ((1u << (2u * um)) - 1u);
-            uint32_t mf = 0, mr = 0, blk_a = 0, blk_p = 0;
-            uint64_t cur_bkt = ~0ull;
-            uint64_t f = 0, rv = 0, hc = 0, hv = 0, cur_c = 0;
-            uint32_t run = 0, kept = 0, mask = 0, cur_v = 0;
-            uint32_t b = 0;
-            struct Pend { uint64_t h0; uint32_t p; bool on, sw; };
-            ulonglong2 RA[8], RB[8];
-            Pend pa{0, 0, false, false}, pb_{0, 0, false, false};
-            bool next_b = false;                                 // which set the next step uses (and whose window is the older one)
-            auto finish = [&](const ulonglong2 (&R)[8], Pend &pd) {
-                if (!pd.on) return;
-                if (pd.sw) {
-#pragma unroll
-                    for (int q = 0; q < 8; ++q) { s_bkt[(2 * q) * 64 + lane] = R[q].x; s_bkt[(2 * q + 1) * 64 + lane] = R[q].y; }
-                }
-                const uint32_t s_known = mpf_match(&s_bkt[lane], 64u, pd.h0);
-                bool keep = true;
-                if (s_known && !(dbg_flags & 2u)) keep = draw_strength(rng_pos(rstate, pd.p)) >= s_known;
-                ++total;
-                if (keep) { ++kept; mask |= 1u << (pd.p & 31u); }
-                pd.on = false;
-            };
-            auto finish_all = [&]() {                           // older window first
-                if (!next_b) { finish(RA, pa); finish(RB, pb_); } else { finish(RB, pb_); finish(RA, pa); }
-            };
-            auto step = [&](ulonglong2 (&R)[8], Pend &pd) {
-                const uint32_t code = (uint32_t)cur_c & 3u, ok = cur_v & 1u;
-                cur_c >>= 2; cur_v >>= 1;
-                run = ok ? run + 1u : 0u;
-                const uint32_t mcode = lag ? (uint32_t)(hc >> (2u * (lag - 1u))) & 3u : code;
-                mf = ((mf << 2) | mcode) & mmask;
-                mr = (mr >> 2) | ((3u - mcode) << (2u * (um - 1u)));
-                const uint32_t o_cur = mmer_order(mf < mr ? mf : mr);
-                s_ring[blk_a * 64u + lane] = o_cur;
-                blk_p = blk_a ? (o_cur < blk_p ? o_cur : blk_p) : o_cur;
-                const bool win = run >= uk;
-                uint64_t bkt = cur_bkt;
-                if (win) {
-                    uint32_t omin = blk_p;
-                    if (blk_a + 1u < uw) { const uint32_t sfx = s_ring[(blk_a + 1u) * 64u + lane]; omin = sfx < omin ? sfx : omin; }
-                    bkt = mpf_bucket(mcache, omin);
-                }
-                finish(R, pd);                                   // the window two steps back: the last user of this register set
-                const bool sw = win && bkt != cur_bkt;
-                const ulonglong2 *bp = reinterpret_cast<const ulonglong2 *>(mcache.tab + (sw ? (bkt << 4) : 0ull));
-#pragma unroll
-                for (int q = 0; q < 8; ++q) R[q] = bp[q];        // every lane, every step (see above)
-                if (sw) cur_bkt = bkt;
-                const uint32_t in5 = ok ? code + 1u : 0u;
-                const uint32_t out5 = ((uint32_t)(hv >> sh_v) & 1u) ? ((uint32_t)(hc >> sh_c) & 3u) + 1u : 0u;
-                const uint32_t tt = out5 * 5u + in5;
-                if (MODE != 2) f = rotl(f, 1) ^ s_tf[tt];
-                if (MODE != 0) rv = rotr(rv, 1) ^ s_tr[tt];
-                hc = (hc << 2) | code; hv = (hv << 1) | ok;
-                pd.on = win; pd.sw = sw;
-                if (win) { pd.h0 = (MODE == 0) ? f : (MODE == 2) ? rv : canonical(f, rv); pd.p = b + 1u - uk; }
-                if (blk_a + 1u == uw) {
-                    uint32_t sm = 0xFFFFFFFFu;
-                    for (uint32_t q = uw; q-- > 0u;) { const uint32_t v = s_ring[q * 64u + lane]; sm = v < sm ? v : sm; s_ring[q * 64u + lane] = sm; }
-                    blk_a = 0;
-                } else
-                    ++blk_a;
-                ++b;
-            };
-            while (b < L) {
-                if ((b & 31u) == 0u) {
-                    const uint32_t wi = b >> 5;
-#pragma unroll
-                    for (int q = 0; q < RB_READ_WORDS; ++q) if ((uint32_t)q == wi) { cur_c = carr[q]; cur_v = varr[q]; }
-                }
-                const uint32_t pb = b + 1u - uk;
-                if ((pb & 31u) == 0u && (int32_t)pb > 0) {
-                    finish_all();
-                    cnt[w + done] = kept; keepmask[w + done] = mask; ++done; kept = 0; mask = 0;
-                }
-                const uint32_t d1 = 32u - (b & 31u), d2 = 32u - (pb & 31u);
-                uint32_t stop = b + (d1 < d2 ? d1 : d2);
-                stop = stop < L ? stop : L;
-                if (next_b && b < stop) { step(RB, pb_); next_b = false; }
-#pragma nounroll
-                while (b + 1u < stop) { step(RA, pa); step(RB, pb_); }
-                if (b < stop) { step(RA, pa); next_b = true; }
-                if (wstate && ((b + 1u - uk) & 31u) == 0u && b + 1u >= uk) wstate[w + ((b + 1u - uk) >> 5)] = make_ulonglong2(f, rv);
-            }
-            finish_all();
-            cnt[w + done] = kept; keepmask[w + done] = mask; ++done;
-        }
-        for (; done < W; ++done) { cnt[w + done] = 0; keepmask[w + done] = 0; }
-    }
-    for (int o = 32; o > 0; o >>= 1) total += __shfl_down(total, o, 64);
-    if (threadIdx.x == 0 && total) atomicAdd(&total_spread[16u * (blockIdx.x & 31u)], total);
-}
-
-// One-pass prefilter + emit (k <= 31): the walker of k_filter_windows_fast, but every kept window's
-// (h0, occurrence) goes straight to its final position in the dense, read-ordered output.  A block
-// = one wavefront = 64 words; kept records are staged in LDS, the block's output offset comes from
-// a decoupled look-back over per-block counts (blocks take their words in ticket order, so every
-// predecessor of a running block is itself running or finished), and the staged records are
-// written coalesced.  Replaces count/mask pass + scan + masked re-hash pass: the windows are
-// hashed once instead of twice and the per-word count / mask / offset arrays are gone.
-// state[0] = ticket counter, state[1 + b] = (status << 62) | value, status 1 = the block's own
-// count, 2 = inclusive prefix.  Records beyond `cap` are not written (the host retries with room).
-template <int MODE>
-__global__ void __launch_bounds__(64)
-k_filter_emit(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
-              const uint32_t *__restrict__ word_read, const uint32_t *__restrict__ woff,
-              const uint32_t *__restrict__ len, int64_t w0, int64_t nw, int k, uint32_t first_read,
-              uint32_t pos_bits, uint64_t seed, uint64_t ordinal0, Npf cache, uint32_t dbg_flags,
-              OwnRange own, uint64_t *__restrict__ keys, uint32_t *__restrict__ vals,
-              uint32_t cap, unsigned long long *state, uint32_t n_blocks, uint32_t *__restrict__ kept_out,
-              uint32_t *__restrict__ total_spread) {
-    __shared__ uint64_t s_key[64 * 33];
-    __shared__ uint32_t s_val[64 * 33];
-    __shared__ uint64_t s_tf[25], s_tr[25];
-    __shared__ uint32_t s_pref[65];
-    __shared__ uint32_t s_bid;
-    const uint32_t uk = (uint32_t)k, lane = threadIdx.x;
-    if (lane < 25) {
-        const uint32_t o = lane / 5u, in = lane % 5u;
-        const uint64_t so = o ? seed_of(o - 1u) : 0ull, si = in ? seed_of(in - 1u) : 0ull;
-        const uint64_t sco = o ? seed_of(4u - o) : 0ull, sci = in ? seed_of(4u - in) : 0ull;
-        s_tf[lane] = rotl(so, uk) ^ si;
-        s_tr[lane] = rotr(sco, 1) ^ rotl(sci, uk - 1u);
-    }
-    if (lane == 0) s_bid = (uint32_t)atomicAdd(&state[0], 1ull);
-    __syncthreads();
-    const uint32_t bid = s_bid;
-    const int64_t i = (int64_t)bid * 64 + lane;
-    uint32_t kept = 0, total = 0;
-    if (i < nw) {
-        const int64_t w = w0 + i;
-        const uint32_t r = word_read[w], wr = woff[r], L = len[r];
-        const uint32_t c = (uint32_t)(w - wr), b0 = c * 32u;
-        if ((uint64_t)b0 + uk <= L) {
-            const uint32_t nwords = (L + 31u) >> 5;
-            WordWalk<false> ww;
-            ww.load(codes, valid, w, c, nwords);
-            const uint32_t nb = ((b0 + 32u + uk - 1u < L) ? b0 + 32u + uk - 1u : L) - b0;
-            uint64_t f = 0, rv = 0;
-            uint32_t run = 0;
-            const uint32_t rstate = rng_read_state(seed, ordinal0 + (uint64_t)(r - first_read));
-            const uint32_t rel = (r - first_read) << pos_bits;
-            const uint32_t sh_c = 2u * (uk - 1u), sh_v = uk - 1u;
-            for (uint32_t j = 0; j < nb; ++j) {
-                uint32_t code, ok;
-                ww.next(code, ok);
-                const uint32_t in5 = ok ? code + 1u : 0u;
-                const uint32_t t = ww.out5(sh_c, sh_v) * 5u + in5;
-                if (MODE != 2) f = rotl(f, 1) ^ s_tf[t];
-                if (MODE != 0) rv = rotr(rv, 1) ^ s_tr[t];
-                ww.push(code, ok);
-                run = ok ? run + 1u : 0u;
-                if (run >= uk) {
-                    const uint32_t p = b0 + j + 1u - uk;
-                    const uint64_t h0 = (MODE == 0) ? f : (MODE == 2) ? rv : canonical(f, rv);
-                    if (own_mine(own, h0)) {   // sharded engine: my k-mer?
-                        const uint32_t s_known = (dbg_flags & 1u) ? 0u : npf_lookup(cache, h0);
-                        bool keep = true;
-                        if (s_known) keep = draw_strength(rng_pos(rstate, p)) >= s_known;
-                        ++total;
-                        if (keep) {
-                            s_key[lane * 33u + kept] = h0;
-                            s_val[lane * 33u + kept] = rel | p;
-                            ++kept;
-                        }
-                    }
-                }
-            }
-        }
-    }
-    // block prefix of the kept counts
-    uint32_t incl = kept;
-    for (uint32_t o = 1; o < 64u; o <<= 1) { const uint32_t v = __shfl_up(incl, o, 64); if (lane >= o) incl += v; }
-    s_pref[lane + 1u] = incl;
-    if (lane == 0) s_pref[0] = 0;
-    const uint32_t T = __shfl(incl, 63, 64);
-    // decoupled look-back for the block's global offset
-    constexpr unsigned long long VAL = (1ull << 62) - 1ull;
-    unsigned long long excl = 0;
-    if (bid == 0) {
-        if (lane == 0) __hip_atomic_store(&state[1], (2ull << 62) | (unsigned long long)T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-        if (lane == 0) __hip_atomic_store(&state[1 + bid], (1ull << 62) | (unsigned long long)T, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        int64_t idx = (int64_t)bid - 1;
-        for (;;) {
-            const int64_t my = idx - (int64_t)lane;
-            unsigned long long v = 2ull << 62;                       // before the first block: prefix 0
-            if (my >= 0)
-                do { v = __hip_atomic_load(&state[1 + my], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((v >> 62) == 0ull);
-            const unsigned long long is_p = __ballot((v >> 62) == 2ull);
-            const uint32_t first = is_p ? (uint32_t)__ffsll((long long)is_p) - 1u : 64u;
-            unsigned long long contrib = (lane <= first) ? (v & VAL) : 0ull;
-            for (int o = 32; o > 0; o >>= 1) contrib += __shfl_xor(contrib, o, 64);
-            excl += contrib;
-            if (is_p) break;
-            idx -= 64;
-        }
-        if (lane == 0) __hip_atomic_store(&state[1 + bid], (2ull << 62) | (excl + (unsigned long long)T), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (bid == n_blocks - 1u && lane == 0) *kept_out = (uint32_t)(excl + T);
-    __syncthreads();
-    for (uint32_t o = lane; o < T; o += 64u) {
-        uint32_t lo = 0, hi = 64;                                    // thread t with s_pref[t] <= o < s_pref[t+1]
-        while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (s_pref[mid + 1u] > o) hi = mid; else lo = mid + 1u; }
-        const uint32_t q = lo * 33u + (o - s_pref[lo]);
-        const unsigned long long dst = excl + o;
-        if (dst < (unsigned long long)cap) { keys[dst] = s_key[q]; vals[dst] = s_val[q]; }
-    }
-    for (int o = 32; o > 0; o >>= 1) total += __shfl_down(total, o, 64);
-    if (lane == 0 && total) atomicAdd(&total_spread[16u * (bid & 31u)], total);
-}
-
 void launch_count_windows(const rb_batch *b, int64_t w0, int64_t nw, int span, uint32_t *cnt, hipStream_t s) {
     if (nw <= 0) return;
     hipLaunchKernelGGL(k_count_windows, dim3(blocks_for(nw)), dim3(TPB), 0, s, b->valid, b->word_read,
@@ -1577,15 +1315,14 @@ void launch_filter_windows(const rb_batch *b, int64_t w0, int64_t nw, int k, int
     hipLaunchKernelGGL((k_filter_reads<M, P>), gc, t, ring_bytes, s, b->codes, b->valid, b->word_read, b->len, w0, nw, k, C, \
                        first_read, pos_bits, seed, ordinal0, cache, mcache, cnt, keepmask, total_spread, dbgf, own, \
                        reinterpret_cast<ulonglong2 *>(wstate), b->woff, rd0, n_rd)
-        // 0: k_filter_reads (fetch in place), 1: each lane fetches its bucket one step ahead (default of rounds 3-4), 2: two steps ahead (slower: every lane loads in
-        // every step), 3 (default): the wavefront fetches cooperatively, one step ahead (its askers' list packs a bucket number into 26 bits)
-        const int pipe_env = getenv("RB_FILTER_PIPE") ? atoi(getenv("RB_FILTER_PIPE")) : 3;
+        // 0: k_filter_reads (fetch in place), 1: each lane fetches its bucket one step ahead (default of rounds 3-4), 3 (default): the wavefront
+        // fetches cooperatively, one step ahead (its askers' list packs a bucket number into 26 bits).  (2, the fetch two steps ahead, was built
+        // twice and slower both times — HISTORY.md "Round 5" — and is gone.)  The walkers of 0 and 1 are also what RB_FILTER_CHECK compares with.
+        const int pipe_raw = getenv("RB_FILTER_PIPE") ? atoi(getenv("RB_FILTER_PIPE")) : 3;
+        const int pipe_env = pipe_raw == 2 ? 1 : pipe_raw;
         const int pipe_fit = (pipe_env == 3 && mcache.log2b > 26u) ? 1 : pipe_env;
         const int pipe = wide ? (pipe_fit == 3 ? 3 : 1) : pipe_fit;
         if (use_m && pipe && own.lo == 0 && own.hi == 0) {         // the whole index range is this handle's: the bucket fetch one / two steps ahead of its use
-#define RB_LAUNCH_FP(K, M, ...)                                                                                      \
-    hipLaunchKernelGGL((K<M>), gc, t, ring_bytes, s, b->codes, b->valid, b->word_read, b->len, w0, nw, k, C,         \
-                       first_read, pos_bits, seed, ordinal0, mcache, cnt, keepmask, total_spread, dbgf, reinterpret_cast<ulonglong2 *>(wstate), ##__VA_ARGS__)
 #define RB_LAUNCH_FN(M)                                                                                              \
     hipLaunchKernelGGL((k_filter_reads_pipe<M, false>), gc, t, ring_bytes, s, b->codes, b->valid, b->word_read, b->len, w0, nw, k, C, \
                        first_read, pos_bits, seed, ordinal0, mcache, cnt, keepmask, total_spread, dbgf, reinterpret_cast<ulonglong2 *>(wstate), b->woff, rd0, n_rd)
@@ -1644,11 +1381,10 @@ void launch_filter_windows(const rb_batch *b, int64_t w0, int64_t nw, int k, int
                                (long long)bad, (long long)nw, (long long)first, hc[(size_t)std::max<int64_t>(first, 0)], ac[(size_t)std::max<int64_t>(first, 0)],
                                bc[(size_t)std::max<int64_t>(first, 0)], hm[(size_t)std::max<int64_t>(first, 0)], am[(size_t)std::max<int64_t>(first, 0)], bm[(size_t)std::max<int64_t>(first, 0)]);
                 }
-            } else if (pipe == 2 && C) { if (mode == 0) RB_LAUNCH_FP(k_filter_reads_pipe2, 0); else if (mode == 2) RB_LAUNCH_FP(k_filter_reads_pipe2, 2); else RB_LAUNCH_FP(k_filter_reads_pipe2, 1); }
+            }
             else if (wide) { if (mode == 0) RB_LAUNCH_FW(0); else if (mode == 2) RB_LAUNCH_FW(2); else RB_LAUNCH_FW(1); }
             else { if (mode == 0) RB_LAUNCH_FN(0); else if (mode == 2) RB_LAUNCH_FN(2); else RB_LAUNCH_FN(1); }
 #undef RB_LAUNCH_FCO
-#undef RB_LAUNCH_FP
 #undef RB_LAUNCH_FN
 #undef RB_LAUNCH_FW
         } else if (use_m) { if (mode == 0) RB_LAUNCH_FC(0, true); else if (mode == 2) RB_LAUNCH_FC(2, true); else RB_LAUNCH_FC(1, true); }
@@ -1663,36 +1399,19 @@ void launch_filter_windows(const rb_batch *b, int64_t w0, int64_t nw, int k, int
     }
 #undef RB_LAUNCH_FILT
 }
-size_t filter_emit_state_bytes(int64_t nw) { return ((size_t)((nw + 63) / 64) + 2) * 8; }
-void launch_filter_emit(const rb_batch *b, int64_t w0, int64_t nw, int k, int mode, uint32_t first_read, uint32_t pos_bits,
-                        uint64_t seed, uint64_t ordinal0, Npf cache, OwnRange own, uint64_t *keys,
-                        uint32_t *vals, uint32_t cap, void *state, uint32_t *kept_out, uint32_t *total_spread, hipStream_t s) {
-    if (nw <= 0) return;
-    const uint32_t nblk = (uint32_t)((nw + 63) / 64);
-    const uint32_t dbgf = cache.tab ? 0u : 1u;               // no cache: ownership test only
-    RB_HIP(hipMemsetAsync(state, 0, filter_emit_state_bytes(nw), s));
-    dim3 g(nblk), t(64);
-#define RB_LAUNCH_FE(M)                                                                                      \
-    hipLaunchKernelGGL(k_filter_emit<M>, g, t, 0, s, b->codes, b->valid, b->word_read, b->woff, b->len, w0, nw, k, \
-                       first_read, pos_bits, seed, ordinal0, cache, dbgf, own, keys, vals, cap,     \
-                       reinterpret_cast<unsigned long long *>(state), nblk, kept_out, total_spread)
-    if (mode == 0) RB_LAUNCH_FE(0); else if (mode == 2) RB_LAUNCH_FE(2); else RB_LAUNCH_FE(1);
-#undef RB_LAUNCH_FE
-}
 // ... and at 32 <= k <= 63, when the call goes through the read-per-lane kernel with the minimizer-bucketed cache (add_range knows)
 bool filter_saves_state_wide(const rb_batch *b, int64_t nw, int k) { return filter_wide_mpf_ok(b, nw, k) && !(getenv("RB_EMIT_RESUME") && atoi(getenv("RB_EMIT_RESUME")) == 0); }
 bool filter_saves_state(const rb_batch *b, int64_t nw, int k) { return (read_lane_words(b, nw, k) != 0u || read_lanes_ragged(b, k)) && !(getenv("RB_EMIT_RESUME") && atoi(getenv("RB_EMIT_RESUME")) == 0); }
 void launch_hash_windows_masked(const rb_batch *b, int64_t w0, int64_t nw, int k, int mode, const uint32_t *chunk_off,
                                 const uint32_t *keepmask, uint32_t first_read, uint32_t pos_bits, uint64_t *keys, uint32_t *vals,
-                                hipStream_t s, const void *wstate, EmitRecheck recheck) {
+                                hipStream_t s, const void *wstate) {
     if (nw <= 0) return;
-    RB_REQUIRE(!recheck.rst.tab || (keepmask && wstate), "emit recheck is part of the resuming emit kernel only");
     const bool sparse = !(getenv("RB_SPARSE_EMIT") && atoi(getenv("RB_SPARSE_EMIT")) == 0);
     if (keepmask && wstate) {
         dim3 gs(blocks_for(nw, RB_SPARSE_WORDS)), ts(64);
 #define RB_LAUNCH_RS(M)                                                                                    \
     hipLaunchKernelGGL(k_hash_windows_resume<M>, gs, ts, 0, s, b->codes, b->valid, b->word_read, b->woff, \
-                       b->len, w0, nw, k, chunk_off, first_read, pos_bits, keys, vals, keepmask, reinterpret_cast<const ulonglong2 *>(wstate), recheck)
+                       b->len, w0, nw, k, chunk_off, first_read, pos_bits, keys, vals, keepmask, reinterpret_cast<const ulonglong2 *>(wstate))
         if (mode == 0) RB_LAUNCH_RS(0); else if (mode == 2) RB_LAUNCH_RS(2); else RB_LAUNCH_RS(1);
 #undef RB_LAUNCH_RS
         return;

@@ -173,15 +173,6 @@ int rb_graph_create(const rb_graph_params *p, rb_graph **out) {
                 g->mpf.reserve((size_t)128 << lb);
                 RB_HIP(hipMemset(g->mpf.p, 0, (size_t)128 << lb));
                 g->mpf_log2b = lb;
-                if (getenv("RB_TWO_PHASE") && atoi(getenv("RB_TWO_PHASE")) != 0) {   // recent stores for the emit pass of the two-phase prefilter (an experiment, see add_range)
-                    uint32_t lr = 24;
-                    if (const char *er = getenv("RB_RST")) lr = (uint32_t)atoi(er);
-                    if (lr >= 8 && lr <= 26) {
-                        g->rst.reserve(sizeof(uint64_t) << lr);
-                        RB_HIP(hipMemset(g->rst.p, 0, sizeof(uint64_t) << lr));
-                        g->rst_log2 = lr;
-                    }
-                }
                 g->mpf_m = (uint32_t)std::min(getenv("RB_MPF_M") ? std::max(4, std::min(16, atoi(getenv("RB_MPF_M")))) : 16, p->k);
             }
         }
@@ -222,7 +213,7 @@ int rb_graph_destroy(rb_graph *g) {
     if (g->stream3) (void)hipStreamDestroy(g->stream3);
     for (auto e : g->prof_pool) (void)hipEventDestroy(e);
     for (auto &sl : g->slots) { sl.keys1.release(); sl.valsT.release(); sl.vals1.release(); sl.tz.release(); sl.uniq.release(); sl.counts.release(); sl.starts.release(); }
-    g->temp2.release(); g->devctr2.release(); g->pairs_ctr.release(); g->npf.release(); g->mpf.release(); g->rst.release(); g->chunk_mask.release(); g->npf_tot.release(); g->wstate.release();
+    g->temp2.release(); g->devctr2.release(); g->pairs_ctr.release(); g->npf.release(); g->mpf.release(); g->chunk_mask.release(); g->npf_tot.release(); g->wstate.release();
     delete g;
     return RB_OK;
 }
@@ -239,7 +230,6 @@ int rb_graph_clear(rb_graph *g, unsigned which_mask) {
         if ((which_mask & 8u) && g->fpk.bits) fast_zero(g->fpk.bits, g->fpk.alloc, g->stream);
         if ((which_mask & 3u) && g->npf_log2) fast_zero(g->npf.p, sizeof(uint64_t) << g->npf_log2, g->stream);   // cache entries speak about dbgbf + cbf
         if ((which_mask & 3u) && g->mpf_log2b) fast_zero(g->mpf.p, (size_t)128 << g->mpf_log2b, g->stream);
-        if ((which_mask & 3u) && g->rst_log2) fast_zero(g->rst.p, sizeof(uint64_t) << g->rst_log2, g->stream);
         if ((which_mask & 3u) == 3u) { g->ordinal = 0; g->pf_streak = 0; g->pf_skip_left = 0; g->last_present_frac = 0.0f; }
         RB_HIP(hipStreamSynchronize(g->stream));
     });
@@ -919,7 +909,6 @@ int rb_filter_import(rb_graph *g, int which, const void *srcp, size_t nbytes) {
         RB_HIP(hipStreamSynchronize(g->stream));
         if (g->npf_log2 && (which == RB_CBF || which == RB_DBGBF)) RB_HIP(hipMemset(g->npf.p, 0, sizeof(uint64_t) << g->npf_log2));
         if (g->mpf_log2b && (which == RB_CBF || which == RB_DBGBF)) RB_HIP(hipMemset(g->mpf.p, 0, (size_t)128 << g->mpf_log2b));
-        if (g->rst_log2 && (which == RB_CBF || which == RB_DBGBF)) RB_HIP(hipMemset(g->rst.p, 0, sizeof(uint64_t) << g->rst_log2));
         if (which != RB_CBF) seen_reset(*bit_filter(g, which), g->stream);      // the bits are replaced: what the seen-pair cache knew is void
         if (which == RB_RPKBF && g->shard) rb::shard_clear_pairs_acc(g);        // (and what this rank's accumulation copy still holds must not come back)
         RB_HIP(hipStreamSynchronize(g->stream));
@@ -1005,7 +994,6 @@ int rb_cbf_to_bloom(rb_graph *src, float min_cov, rb_graph *dst, int which) {
         if (which == RB_DBGBF) {
             if (dst->npf_log2) RB_HIP(hipMemset(dst->npf.p, 0, sizeof(uint64_t) << dst->npf_log2));
             if (dst->mpf_log2b) RB_HIP(hipMemset(dst->mpf.p, 0, (size_t)128 << dst->mpf_log2b));
-            if (dst->rst_log2) RB_HIP(hipMemset(dst->rst.p, 0, sizeof(uint64_t) << dst->rst_log2));
             RB_HIP(hipDeviceSynchronize());
         }
     });

@@ -208,28 +208,6 @@ __device__ __forceinline__ bool npf_store(const Npf &c, uint64_t h0, uint32_t s)
     __hip_atomic_store(&b[victim], (tag << 4) | (unsigned long long)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return true;
 }
-// ---- recent stores (HISTORY.md §5 "two-phase prefilter": exact, overlapping, slower — behind RB_TWO_PHASE=1): a small direct-mapped table of what the stages that retire runs
-// have learnt lately, addressed by the hash itself (the emit pass knows the hash of every window it writes, not its minimizer
-// bucket's contents).  entry = h0 with its low four bits replaced by the exponent s (1..14, 15 = saturated), index = the low
-// log2n bits of h0 (log2n >= 4: the replaced bits are part of the index, so a match proves all 64 bits); 0 = empty.  Same
-// contract as the caches above: an entry asserts "in dbgbf, exponent >= s", true for ever; a lost or overwritten entry
-// only lets an occurrence through that could have been dropped.  2^21 entries = 16 MB: it stays in the Infinity Cache.
-struct Rst {
-    unsigned long long *tab;   // nullptr => disabled
-    uint32_t log2n;
-};
-__device__ __forceinline__ void rst_store(const Rst &c, uint64_t h0, uint32_t s) {            // s in 1..14 or RB_EXP_SATURATED
-    unsigned long long *e = c.tab + (h0 & ((1ull << c.log2n) - 1ull));
-    const unsigned long long cur = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if ((cur >> 4) == (h0 >> 4) && (uint32_t)(cur & 15ull) >= s) return;
-    __hip_atomic_store(e, (h0 & ~15ull) | (unsigned long long)s, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ uint32_t rst_lookup(const Rst &c, uint64_t h0) {                   // 0 = unknown, 16 = saturated
-    const unsigned long long e = __hip_atomic_load(c.tab + (h0 & ((1ull << c.log2n) - 1ull)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t s = (uint32_t)(e & 15ull);
-    if (!s || (e >> 4) != (h0 >> 4)) return 0u;
-    return s == RB_EXP_SATURATED ? 16u : s;
-}
 // ---- minimizer-bucketed prefilter cache: same contract as Npf, different address ----
 // The device serves ~54 G random 64-byte lines/s; one line request per window is what
 // bounds the prefilter.  Consecutive k-mers of a read share their minimizer (the smallest canonical

@@ -1829,11 +1829,11 @@ void rb::add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, uns
     const bool use_npf = npf_path && (mode == M_ADD || mode == M_COUNT_IF_PRESENT);
     // the minimizer-bucketed cache replaces the hash-bucketed one on this path (lookups here, stores by the
     // stages that retire runs, which find a k-mer's bucket from one of its occurrences in this batch)
-    g->use_mpf = use_npf && g->mpf_log2b && !getenv("RB_NO_MPF") && (g->k > 31 || !getenv("RB_ONE_PASS_FILTER")) && (uint32_t)g->k >= g->mpf_m &&
+    g->use_mpf = use_npf && g->mpf_log2b && !getenv("RB_NO_MPF") && (uint32_t)g->k >= g->mpf_m &&
                  (g->k <= RB_MPF_MAX_K ? (uint32_t)g->k - g->mpf_m + 1u <= RB_MPF_MAX_RING
                                        : filter_wide_mpf_ok(b, b->h_woff.empty() ? 0 : (int64_t)b->h_woff[(size_t)(first + n)] - (int64_t)b->h_woff[(size_t)first], g->k));
     g->seq_codes = b->codes; g->seq_woff = b->woff; g->seq_wpr = b->wpr_uniform;
-    struct MpfScope { rb_graph *g; ~MpfScope() { g->use_mpf = false; g->seq_codes = nullptr; g->seq_woff = nullptr; g->seq_wpr = 0; g->occ_bits = 32; g->before_buckets = nullptr; } } mpf_scope{g};
+    struct MpfScope { rb_graph *g; ~MpfScope() { g->use_mpf = false; g->seq_codes = nullptr; g->seq_woff = nullptr; g->seq_wpr = 0; g->occ_bits = 32; } } mpf_scope{g};
     std::vector<Sub> subs;
     {
         int64_t r0 = first;
@@ -1864,14 +1864,11 @@ void rb::add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, uns
     unsigned long long *pc = nullptr;
     // The paired k-mers of a sub-batch touch rpkbf and nothing else: their walker runs on a side stream of the producer, forked when
     // the sub-batch's window walk is done (beside the emit pass and the first partition pass; joined when the grouping is enqueued).
-    // RB_PAIRS_SIDE: 0 = on the producer stream after the grouping (rounds 1-2), 1 = beside the window walk, 2 = beside the CONSUMER
-    // of the sub-batch before, 3 (default) = beside the emit pass, 4 = beside the grouping only.  Measured on config 2
-    // (profiles/r03_pairs_side.txt): 1 and 3 take 5-9 ms off a 336-356 ms step, 2 and 4 2-5 ms; every kernel that runs beside the
-    // walker takes about as much longer as the walker itself took (the window walk 84 -> 111 ms), which is why the gain is small.
-    // One counter for the whole call (a sub-batch that is halved and redone has its pairs in already: ORs, not launched again).
-    int pairs_mode = pairs ? 3 : 0;
-    if (pairs && getenv("RB_PAIRS_SIDE")) pairs_mode = atoi(getenv("RB_PAIRS_SIDE"));
-    if (getenv("RB_SERIAL") || pairs_mode < 0 || pairs_mode > 5) pairs_mode = 0;
+    // (Rounds 3-5 measured the other placements — beside the window walk, beside the consumer of the sub-batch before, beside the grouping
+    // only, split over the emit pass and the bucket kernel: profiles/r03_pairs_side.txt, HISTORY.md; within 1 % of this one, and every
+    // kernel that runs beside the walker takes about as much longer as the walker itself took.  RB_SERIAL=1: on the producer stream, after
+    // the grouping.)  One counter for the whole call (a sub-batch that is halved and redone has its pairs in already: ORs, not launched again).
+    const int pairs_mode = (pairs && !getenv("RB_SERIAL")) ? 3 : 0;
     const bool pairs_side = pairs_mode != 0;
     int64_t pairs_upto = first;
     bool pairs_pending = false;
@@ -1893,22 +1890,6 @@ void rb::add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, uns
         RB_HIP(hipEventRecord(g->ev3, g->stream3));
         pairs_upto = sb.r1; pairs_pending = true;
     };
-    // 5: the walker only beside the two kernels that are not bound by memory — the first half of the sub-batch's reads beside the emit pass
-    // (joined before the partition passes start), the second half beside the bucket kernel
-    auto pairs_half = [&](size_t i, int half) {
-        const Sub &sb = subs[i];
-        if (sb.nw <= 0 || sb.r1 <= pairs_upto) return;
-        const int64_t rm = (sb.r0 + sb.r1) / 2, wm = (int64_t)wo[(size_t)rm];
-        const int64_t w0 = half ? wm : sb.w0, nw = half ? sb.w0 + sb.nw - wm : wm - sb.w0;
-        RB_HIP(hipEventRecord(g->ev2, sp));
-        RB_HIP(hipStreamWaitEvent(g->stream3, g->ev2, 0));
-        g->prof_begin(g->stream3);
-        if (nw > 0) launch_pairs(g, b, w0, nw, mode_hash, nullptr, nullptr, g->pairs_ctr.as<unsigned long long>(), g->stream3);
-        g->prof_end("pairs_insert", g->stream3);
-        RB_HIP(hipEventRecord(g->ev3, g->stream3));
-        if (half) pairs_upto = sb.r1;
-        pairs_pending = true;
-    };
     // producer: hash + group sub-batch i into slot i&1 on the producer stream (touches scratch and,
     // for the order-independent paired k-mers, rpkbf only)
     auto prepare_once = [&](size_t i) -> bool {
@@ -1917,7 +1898,6 @@ void rb::add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, uns
         const int slot = (int)(i & 1u);
         g->devctr2.reserve(DEVCTR_BYTES);
         sb.total = 0;
-        if (pairs_mode == 1 || pairs_mode == 2) pairs_fork(i, true);   // (2: the first sub-batch, and any the fork beside the consumer did not cover)
         if (sb.nw > 0) {
             const uint64_t ord0 = g->ordinal + (uint64_t)(sb.r0 - first);
             g->chunk_cnt.reserve(((size_t)sb.nw + 1) * 4); g->chunk_off.reserve(((size_t)sb.nw + 1) * 4);
@@ -1928,12 +1908,10 @@ void rb::add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, uns
             // and emit them all, then one is measured again.  RB_PF_SKIP=0: never; 2: sub-batches of any size count (tests).
             bool filt_now = use_npf;
             if (use_npf && g->pf_skip_left > 0 && !(getenv("RB_PF_SKIP") && atoi(getenv("RB_PF_SKIP")) == 0)) { filt_now = false; --g->pf_skip_left; }
-            if (filt_now && (g->k > 31 || !getenv("RB_ONE_PASS_FILTER"))) {
+            if (filt_now) {
                 // pass 1 hashes every window and asks the cache (count + keep mask per word), scan, pass 2
-                // re-hashes and emits the survivors.  (The one-pass kernel below measures 12 ms faster on its
-                // own but 35 ms slower per step here: its 25 KB of LDS staging costs the occupancy that hides
-                // the cache-lookup latency, and the stages after it slow down; it wins in the sharded engine,
-                // where 1/G of the windows are looked up and the hashing itself dominates.)
+                // re-hashes and emits the survivors.  (A one-pass kernel — hash, ask, write the survivors through an LDS stage — was
+                // 12 ms faster on its own and 35 ms slower per step, rounds 2-3: HISTORY.md; removed in round 6.)
                 g->prof_begin(sp);
                 g->chunk_mask.reserve(((size_t)sb.nw + 1) * 4);
                 g->npf_tot.reserve(2048);
@@ -1978,8 +1956,6 @@ void rb::add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, uns
                             (double)h[0] / sb.nw, (double)h[1] / sb.nw, (double)h[2] / sb.nw, (double)h[3] / sb.nw, (double)h[4] / sb.nw, (double)empty_waves / waves);
                 }
                 if (pairs_mode == 3) pairs_fork(i, true);
-                const bool halves = pairs_mode == 5 && sb.nw > 0 && sb.r1 > pairs_upto;
-                if (halves) pairs_half(i, 0);
                 if (sb.N) {
                     g->prof_begin(sp);
                     g->keys0.reserve((size_t)sb.N * 8); g->vals0.reserve((size_t)sb.N * 4);
@@ -1987,29 +1963,6 @@ void rb::add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, uns
                                                (uint32_t)sb.r0, pos_bits, g->keys0.as<uint64_t>(), g->vals0.as<uint32_t>(), sp, wstate);
                     g->prof_end("hash_windows", sp);
                 }
-                if (halves) {
-                    RB_HIP(hipStreamWaitEvent(sp, g->ev3, 0)); pairs_pending = false;
-                    g->before_buckets = [&pairs_half, i]() { pairs_half(i, 1); };
-                }
-            } else if (filt_now) {
-                // one pass: hash every window, ask the hot-k-mer cache whether the occurrence can matter,
-                // write the survivors densely in read order (k_filter_emit)
-                g->prof_begin(sp);
-                g->npf_tot.reserve(2048);
-                RB_HIP(hipMemsetAsync(g->npf_tot.p, 0, 2048, sp));
-                FilterView fvp = g->view(ord0, pos_bits);
-                const size_t cap = std::min<size_t>((size_t)sb.nw * 32, 0xFFFFFFF0ull);   // every window of the sub-batch
-                g->keys0.reserve(cap * 8); g->vals0.reserve(cap * 4);
-                g->chunk_mask.reserve(filter_emit_state_bytes(sb.nw));
-                launch_filter_emit(b, sb.w0, sb.nw, g->k, mode_hash, (uint32_t)sb.r0, pos_bits, g->p.rng_seed, ord0, fvp.npf, OwnRange{Mod{1, 0, 0}, 0, 0},
-                                   g->keys0.as<uint64_t>(), g->vals0.as<uint32_t>(), (uint32_t)cap, g->chunk_mask.p,
-                                   g->npf_tot.as<uint32_t>() + 500, g->npf_tot.as<uint32_t>(), sp);
-                uint32_t spread[16 * 32];
-                RB_HIP(hipMemcpyAsync(&sb.N, g->npf_tot.as<uint32_t>() + 500, 4, hipMemcpyDeviceToHost, sp));
-                RB_HIP(hipMemcpyAsync(spread, g->npf_tot.p, sizeof spread, hipMemcpyDeviceToHost, sp));
-                g->prof_end("filter_emit", sp);
-                RB_HIP(hipStreamSynchronize(sp));
-                for (int q = 0; q < 32; ++q) sb.total += spread[16 * q];
             } else {
                 g->prof_begin(sp);
                 launch_count_windows(b, sb.w0, sb.nw, g->k, g->chunk_cnt.as<uint32_t>(), sp);
@@ -2035,9 +1988,8 @@ void rb::add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, uns
                 }
             }
         }
-        if (pairs_mode == 3 || pairs_mode == 4 || (pairs_mode == 5 && !g->before_buckets)) pairs_fork(i, true);   // (3: already forked on the two-pass path; 4: beside the grouping only; 5: paths without the two passes)
+        if (pairs_mode == 3) pairs_fork(i, true);   // (already forked on the two-pass path; this is for the paths without the two passes)
         group_enqueue(g, slot, sb.N, g->ordinal + (uint64_t)(sb.r0 - first), pos_bits, sp, g->temp2, g->devctr2);
-        if (g->before_buckets) { auto f = std::move(g->before_buckets); g->before_buckets = nullptr; f(); }   // (a grouping that had no bucket kernel to launch)
         if (pairs_pending) { RB_HIP(hipStreamWaitEvent(sp, g->ev3, 0)); pairs_pending = false; }
         if (pairs && !pairs_side && sb.nw > 0) {   // after group_enqueue: it zeroes the producer's counter block
             g->prof_begin(sp);
@@ -2048,118 +2000,6 @@ void rb::add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, uns
         return true;
     };
     auto prepare = [&](size_t i) { while (!prepare_once(i)) {} };
-    // ---- two-phase prefilter (RB_TWO_PHASE=1; uniform batches on the minimizer-bucketed path) — an experiment that LOST ----
-    // The prefilter of sub-batch i+1 waits for the runs of sub-batch i to retire (their cache stores are what it feeds on), so
-    // producer and consumer alternate: ~10 ms of hashing / grouping, then ~6 ms of probing / resolving, 22 times a pass.
-    // Here phase 1 — pairs, the window walk against the cache AS IT IS, the scan — is enqueued when the consumer of sub-batch i
-    // STARTS and runs beside it, and phase 2 is folded into the emit pass, which waits for the release point as before: every
-    // window it writes is looked up in the recent-store table (what the consumer stored meanwhile, addressed by hash) and
-    // cancelled if it is a no-op after all; the first partition pass of the grouping drops the cancelled records.  A cache entry
-    // is true for ever, so dropping by a stale entry is as valid as by a fresh one: the filters end up bit for bit the same
-    // (182 parity / scale / sharded tests).  Measured on config 2 (profiles/r03_two_phase.txt): 380-389 ms per step against 342 —
-    // the two halves do overlap, but every kernel that runs beside another takes 1.5-2x as long (probe_claim 60 -> 119 ms,
-    // filter 84 -> 99, pairs 35 -> 60): the window walk is no pure instruction-issue load (it moves 0.46 of the HBM peak in bucket
-    // fetches) and the probes live on the same request path; stream priorities change nothing.  Kept behind the switch.
-    const bool two_phase = use_npf && g->use_mpf && g->rst_log2 && g->k <= 31 && !getenv("RB_ONE_PASS_FILTER") && !getenv("RB_SERIAL") &&
-                           !getenv("RB_PREPARE_EARLY") && (getenv("RB_TWO_PHASE") && atoi(getenv("RB_TWO_PHASE")) != 0) &&
-                           !subs.empty() && filter_saves_state(b, subs[0].nw, g->k) && !(getenv("RB_EMIT_RESUME") && atoi(getenv("RB_EMIT_RESUME")) == 0);
-    g->rst_on = two_phase;
-    struct RstScope { rb_graph *g; ~RstScope() { g->rst_on = false; } } rst_scope{g};
-    if (two_phase) {
-        uint32_t *pin = nullptr;                                 // [0] survivors of phase 1, [2..3] pairs, [16 + 16 q] usable windows
-        RB_HIP(hipHostMalloc(reinterpret_cast<void **>(&pin), 4096, hipHostMallocDefault));
-        struct PinFree { uint32_t *p; ~PinFree() { if (p) (void)hipHostFree(p); } } pin_free{pin};
-        auto phase_a = [&](size_t i) {                           // no host wait in here
-            const Sub &sb = subs[i];
-            if (sb.nw <= 0) return;
-            const uint64_t ord0 = g->ordinal + (uint64_t)(sb.r0 - first);
-            g->chunk_cnt.reserve(((size_t)sb.nw + 1) * 4); g->chunk_off.reserve(((size_t)sb.nw + 1) * 4); g->chunk_mask.reserve(((size_t)sb.nw + 1) * 4);
-            g->temp2.reserve(scan_temp_bytes((size_t)sb.nw + 1));
-            g->npf_tot.reserve(2048);
-            g->wstate.reserve(((size_t)sb.nw + 1) * 16);
-            RB_HIP(hipMemsetAsync(g->npf_tot.p, 0, 2048, sp));
-            RB_HIP(hipMemsetAsync(g->chunk_cnt.as<uint32_t>() + sb.nw, 0, 4, sp));
-            if (pairs) {
-                g->prof_begin(sp);
-                launch_pairs(g, b, sb.w0, sb.nw, mode_hash, nullptr, nullptr, reinterpret_cast<unsigned long long *>(g->npf_tot.as<uint32_t>() + 508), sp);
-                g->prof_end("pairs_insert", sp);
-            }
-            g->prof_begin(sp);
-            FilterView fvp = g->view(ord0, pos_bits);
-            launch_filter_windows(b, sb.w0, sb.nw, g->k, mode_hash, (uint32_t)sb.r0, pos_bits, g->p.rng_seed, ord0, fvp.npf,
-                                  g->chunk_cnt.as<uint32_t>(), g->chunk_mask.as<uint32_t>(), g->npf_tot.as<uint32_t>(), sp, OwnRange{Mod{1, 0, 0}, 0, 0}, fvp.mpf, g->wstate.p);
-            exclusive_scan_u32(g->temp2.p, g->temp2.cap, g->chunk_cnt.as<uint32_t>(), g->chunk_off.as<uint32_t>(), (size_t)sb.nw + 1, sp);
-            RB_HIP(hipMemcpyAsync(pin, g->chunk_off.as<uint32_t>() + sb.nw, 4, hipMemcpyDeviceToHost, sp));
-            RB_HIP(hipMemcpyAsync(pin + 16, g->npf_tot.p, 2048, hipMemcpyDeviceToHost, sp));
-            g->prof_end("filter_windows", sp);
-        };
-        // waits for phase 1, then emit (with the second look) + grouping; false: too many survivors, the sub-batch was halved
-        auto phase_b = [&](size_t i, unsigned long long *np_out) -> bool {
-            Sub &sb = subs[i];
-            sb.N = 0; sb.total = 0;
-            const int slot = (int)(i & 1u);
-            g->devctr2.reserve(DEVCTR_BYTES);
-            const uint64_t ord0 = g->ordinal + (uint64_t)(sb.r0 - first);
-            if (sb.nw > 0) {
-                RB_HIP(hipStreamSynchronize(sp));
-                sb.N = pin[0];
-                if ((int64_t)sb.N > g->max_batch_kmers && sb.r1 - sb.r0 > 1) {
-                    const int64_t mid = sb.r0 + (sb.r1 - sb.r0) / 2;
-                    Sub second{mid, sb.r1, (int64_t)wo[(size_t)mid], (int64_t)wo[(size_t)sb.r1] - (int64_t)wo[(size_t)mid], 0u, 0};
-                    sb.r1 = mid; sb.nw = (int64_t)wo[(size_t)mid] - sb.w0;
-                    subs.insert(subs.begin() + (std::ptrdiff_t)i + 1, second);   // invalidates sb; (the pairs of the whole range are in: ORs, harmless to repeat)
-                    return false;
-                }
-                for (int q = 0; q < 32; ++q) sb.total += pin[16 + 16 * q];
-                if (np_out) *np_out = *reinterpret_cast<unsigned long long *>(pin + 16 + 508);
-                if (sb.N) {
-                    g->prof_begin(sp);
-                    g->keys0.reserve((size_t)sb.N * 8); g->vals0.reserve((size_t)sb.N * 4);
-                    FilterView fvp = g->view(ord0, pos_bits);
-                    launch_hash_windows_masked(b, sb.w0, sb.nw, g->k, mode_hash, g->chunk_off.as<uint32_t>(), g->chunk_mask.as<uint32_t>(),
-                                               (uint32_t)sb.r0, pos_bits, g->keys0.as<uint64_t>(), g->vals0.as<uint32_t>(), sp, g->wstate.p,
-                                               EmitRecheck{fvp.rst, g->p.rng_seed, ord0});
-                    g->prof_end("hash_windows", sp);
-                }
-            }
-            group_enqueue(g, slot, sb.N, ord0, pos_bits, sp, g->temp2, g->devctr2, GR_FLAG_DEAD);
-            return true;
-        };
-        std::vector<unsigned long long> npairs(subs.size() + 64, 0ull);
-        auto both = [&](size_t i) {
-            for (;;) {
-                if (npairs.size() < subs.size() + 1) npairs.resize(subs.size() + 64, 0ull);
-                unsigned long long np = 0;
-                if (phase_b(i, &np)) { npairs[i] = np; return; }
-                phase_a(i);
-            }
-        };
-        phase_a(0);
-        both(0);
-        for (size_t i = 0; i < subs.size(); ++i) {
-            const int slot = (int)(i & 1u);
-            const uint32_t D = group_finish(g, slot, sp, g->temp2, g->devctr2, s);   // drains the producer stream
-            if (stats) { stats->pairs += (int64_t)npairs[i]; stats->distinct += D; }
-            if (i + 1 < subs.size()) phase_a(i + 1);                                 // beside the consumer of sub-batch i
-            g->cur = slot;
-            g->seq_first = (uint32_t)subs[i].r0;
-            g->occ_bits = pos_bits + log2_ceil((uint64_t)std::max<int64_t>(1, subs[i].r1 - subs[i].r0));
-            const std::function<void()> next = [&]() {
-                if (i + 1 >= subs.size()) return;
-                RB_HIP(hipEventRecord(g->ev0, s));
-                RB_HIP(hipStreamWaitEvent(sp, g->ev0, 0));
-                both(i + 1);
-            };
-            run_core(g, subs[i].N, D, mode, g->ordinal + (uint64_t)(subs[i].r0 - first), pos_bits, stats, &next);
-            RB_HIP(hipStreamSynchronize(s));
-            if (stats) { stats->kmers += subs[i].total; stats->sorted_kmers += (int64_t)g->slots[slot].live; stats->reads += subs[i].r1 - subs[i].r0; }
-        }
-        g->ordinal += (uint64_t)n;
-        RB_HIP(hipStreamSynchronize(s));
-        RB_HIP(hipStreamSynchronize(sp));
-        g->prof_collect();
-        return;
-    }
     if (!subs.empty()) prepare(0);
     for (size_t i = 0; i < subs.size(); ++i) {
         const int slot = (int)(i & 1u);
@@ -2168,10 +2008,6 @@ void rb::add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, uns
         const uint32_t D = group_finish(g, slot, sp, g->temp2, g->devctr2, s);  // drains the producer stream
         if (stats) { stats->pairs += (int64_t)np; stats->distinct += D; }
         const bool serial = getenv("RB_SERIAL") != nullptr;   // debugging / clean per-stage timing
-        const bool early = getenv("RB_PREPARE_EARLY") != nullptr;   // A/B: producer a whole sub-batch ahead (staler cache).  (Also tried from inside run_core, beside
-        // the swept stage of long reads where the cache has nothing to say anyway: 0.564 s against 0.562 — two memory-bound streams share one memory.)
-        if (!serial && early && i + 1 < subs.size()) prepare(i + 1);
-        if (pairs_mode == 2 && !serial && !early) pairs_fork(i + 1, false);
         g->cur = slot;
         g->seq_first = (uint32_t)subs[i].r0;             // occurrence ids of this sub-batch are relative to its first read
         g->occ_bits = pos_bits + log2_ceil((uint64_t)std::max<int64_t>(1, subs[i].r1 - subs[i].r0));
@@ -2179,7 +2015,7 @@ void rb::add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, uns
         // cache updates are what the prefilter needs); its sort + grouping then overlap the heavy and
         // conflicting runs of sub-batch i
         const std::function<void()> next = [&]() {
-            if (serial || early || i + 1 >= subs.size()) return;
+            if (serial || i + 1 >= subs.size()) return;
             RB_HIP(hipEventRecord(g->ev0, s));
             RB_HIP(hipStreamWaitEvent(sp, g->ev0, 0));
             prepare(i + 1);

@@ -1092,7 +1092,6 @@ static void group_records_impl(const GroupPlan &P, uint64_t *keys0, uint32_t *va
     const uint32_t *vin = nullptr;
     uint32_t *bstart = partition_records<TPB>(P, keys0, vals0, keys_tmp, vals_tmp, tp, st, prof, idx, &kin, &vin);
     uint32_t *big_list = reinterpret_cast<uint32_t *>(tp + P.off_big), *n_big = ticket + 2;
-    if (prof && prof->before_buckets) { auto f = std::move(prof->before_buckets); prof->before_buckets = nullptr; f(); }
     if (prof) prof->prof_begin(st);
     const uint32_t bucket_grid = std::min(P.nbuckets, (uint32_t)(getenv("RB_GROUP_GRID") ? atoi(getenv("RB_GROUP_GRID")) : 768));
     // Run slots: nothing downstream depends on the order of the runs (the runs of oversized buckets were always appended in

@@ -24,20 +24,9 @@ void launch_filter_windows(const rb_batch *b, int64_t w0, int64_t nw, int k, int
 bool filter_wide_mpf_ok(const rb_batch *b, int64_t nw, int k);   // 32 <= k <= 63: may the minimizer-bucketed cache be used for this batch?
 bool filter_saves_state(const rb_batch *b, int64_t nw, int k);
 bool filter_saves_state_wide(const rb_batch *b, int64_t nw, int k);
-// one pass: ownership test + prefilter + dense ordered emit of the kept (h0, occurrence) records into
-// keys/vals (capacity `cap` records; *kept_out = number kept even if it exceeds cap — then retry with
-// room).  `state`: scratch of filter_emit_state_bytes(nw) bytes.
-size_t filter_emit_state_bytes(int64_t nw);
-void launch_filter_emit(const rb_batch *b, int64_t w0, int64_t nw, int k, int mode, uint32_t first_read, uint32_t pos_bits,
-                        uint64_t seed, uint64_t ordinal0, Npf cache, OwnRange own, uint64_t *keys,
-                        uint32_t *vals, uint32_t cap, void *state, uint32_t *kept_out, uint32_t *total_spread, hipStream_t s);
-// second look of the two-phase prefilter (HISTORY.md s5): the emit pass asks the recent-store table about every window it
-// writes and CANCELS the record (key and occurrence id all ones; the grouping stage drops such records) if the occurrence
-// is a no-op by what was learnt since the window was filtered.  tab == nullptr: off.  Only the resuming emit kernel does it.
-struct EmitRecheck { Rst rst; uint64_t seed, ordinal0; };
 void launch_hash_windows_masked(const rb_batch *b, int64_t w0, int64_t nw, int k, int mode, const uint32_t *chunk_off,
                                 const uint32_t *keepmask, uint32_t first_read, uint32_t pos_bits, uint64_t *keys, uint32_t *vals,
-                                hipStream_t s, const void *wstate = nullptr, EmitRecheck recheck = EmitRecheck{Rst{nullptr, 0}, 0, 0});
+                                hipStream_t s, const void *wstate = nullptr);
 
 // ASCII reads -> packed batch in two halves (rb_batch.hip): begin() allocates and enqueues the copies + the
 // encode kernel on `st` and returns; finish() waits for them and frees the staging buffers

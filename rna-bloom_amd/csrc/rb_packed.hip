@@ -17,6 +17,9 @@
 #include <string.h>
 
 #include <algorithm>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -67,10 +70,41 @@ struct rb_packed_stream {
     uint32_t *h_stats = nullptr;                  // pinned, 8 words
     int fill = 0;                                 // the buffer the next begin() fills
     bool pending = false;
+    // ONE helper thread for the stream's lifetime (a thread's first HIP call sets up its context: milliseconds — per chunk, had every begin()
+    // started a thread of its own): begin() posts a job, finish() waits for it
     std::thread worker;
+    std::mutex m;
+    std::condition_variable cv;
+    std::function<void()> job;
+    bool job_posted = false, job_done = true, quit = false;
     int worker_rc = RB_OK;
     std::string worker_err;
-    int64_t pend_reads = 0, pend_words = 0;
+    void run() {
+        for (;;) {
+            std::function<void()> j;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv.wait(lk, [&] { return job_posted || quit; });
+                if (quit && !job_posted) return;
+                j = std::move(job); job_posted = false;
+            }
+            j();
+            { std::lock_guard<std::mutex> lk(m); job_done = true; }
+            cv.notify_all();
+        }
+    }
+    void post(std::function<void()> j) {
+        { std::lock_guard<std::mutex> lk(m); job = std::move(j); job_posted = true; job_done = false; }
+        cv.notify_all();
+    }
+    void wait_done() { std::unique_lock<std::mutex> lk(m); cv.wait(lk, [&] { return job_done; }); }
+    void stop() {
+        if (!worker.joinable()) return;
+        wait_done();
+        { std::lock_guard<std::mutex> lk(m); quit = true; }
+        cv.notify_all();
+        worker.join();
+    }
 };
 
 namespace {
@@ -175,11 +209,11 @@ int rb_packed_stream_begin(rb_packed_stream *s, const uint64_t *codes, const uin
         RB_REQUIRE(s && n_reads >= 0 && n_words >= 0 && (n_reads == 0 || len) && (n_words == 0 || (codes && valid)), "rb_packed_stream_begin: bad argument");
         RB_REQUIRE(!s->pending, "rb_packed_stream_begin: the chunk begun before has not been finished");
         RB_REQUIRE(n_words < 0xFFFFFFF0ll && n_reads < 0xFFFFFFF0ll, "rb_packed_stream_begin: chunk too large (> 2^32 words)");
-        if (s->worker.joinable()) s->worker.join();
         const int slot = s->fill;
-        s->pending = true; s->pend_reads = n_reads; s->pend_words = n_words;
+        s->pending = true;
         s->worker_rc = RB_OK; s->worker_err.clear();
-        s->worker = std::thread([=] {
+        if (!s->worker.joinable()) s->worker = std::thread([s] { s->run(); });
+        s->post([=] {
             s->worker_rc = guarded([&] { upload_chunk(s, slot, codes, valid, len, n_reads, n_words); });
             if (s->worker_rc != RB_OK) s->worker_err = rb_last_error();       // (the error text is thread-local)
         });
@@ -190,7 +224,7 @@ int rb_packed_stream_finish(rb_packed_stream *s, const rb_batch **out) {
     return guarded([&] {
         RB_REQUIRE(s && out, "rb_packed_stream_finish: null argument");
         RB_REQUIRE(s->pending, "rb_packed_stream_finish: no chunk was begun");
-        if (s->worker.joinable()) s->worker.join();
+        s->wait_done();
         s->pending = false;
         if (s->worker_rc != RB_OK) { set_error("%s", s->worker_err.c_str()); throw HipError{s->worker_rc}; }
         *out = &s->buf[s->fill].b;             // valid until the begin() after next reuses this buffer
@@ -200,7 +234,7 @@ int rb_packed_stream_finish(rb_packed_stream *s, const rb_batch **out) {
 
 int rb_packed_stream_destroy(rb_packed_stream *s) {
     if (!s) return RB_OK;
-    if (s->worker.joinable()) s->worker.join();
+    s->stop();
     (void)hipSetDevice(s->device);
     if (s->st) { (void)hipStreamSynchronize(s->st); (void)hipStreamDestroy(s->st); }
     for (auto &B : s->buf) {

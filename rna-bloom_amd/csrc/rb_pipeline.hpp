@@ -52,7 +52,6 @@ struct FilterView {
     // minimizer-bucketed variant (k <= 31 insert path): lookups in the window-hash kernel, stores here need
     // the k-mer's bases to find its bucket — the read batch view of the sub-batch being retired
     Mpf mpf;
-    Rst rst;              // recent stores, looked up by the emit pass of the two-phase prefilter (tab == nullptr: off)
     const uint64_t *seq_codes;   // packed reads (nullptr: no sequence context, e.g. rb_graph_apply)
     const uint32_t *seq_woff;
     uint32_t seq_wpr;            // words per read when every read of the batch has the same number (no offset lookup then), else 0
@@ -68,7 +67,6 @@ __device__ __forceinline__ uint64_t seq_word0(const FilterView &fv, uint32_t r) 
 // that changes nothing on the owner's replica changes nothing anywhere — e.g. the k-mer whose bucket is full of hotter ones tries
 // again every sub-batch).
 __device__ __forceinline__ bool cache_store(const FilterView &fv, uint64_t h0, uint32_t occ, uint32_t s) {
-    if (fv.rst.tab) rst_store(fv.rst, h0, s);      // whatever becomes of the bucket below: the next emit pass may use it
     if (fv.mpf.tab) {
         if (!fv.seq_codes) return false;
         const uint32_t r = fv.seq_first + (occ >> fv.pos_bits), p = occ & ((1u << fv.pos_bits) - 1u);
@@ -381,9 +379,6 @@ struct rb_graph {
     uint32_t npf_log2 = 0;
     DevBuf mpf;                         // minimizer-bucketed cache (single-GPU k <= 31 insert path)
     uint32_t mpf_log2b = 0, mpf_m = 0;
-    DevBuf rst;                         // recent stores (two-phase prefilter); rst_on: handed to the kernels of the current call
-    uint32_t rst_log2 = 0;
-    bool rst_on = false;
     const uint64_t *seq_codes = nullptr;   // read batch view of the sub-batch being retired (add_range sets it)
     const uint32_t *seq_woff = nullptr;
     uint32_t seq_wpr = 0;
@@ -423,12 +418,9 @@ struct rb_graph {
         fv.npf.log2n = npf_log2;
         fv.mpf.tab = (use_mpf && mpf_log2b) ? reinterpret_cast<unsigned long long *>(mpf.p) : nullptr;
         fv.mpf.log2b = mpf_log2b; fv.mpf.m = mpf_m;
-        fv.rst.tab = (rst_on && rst_log2) ? reinterpret_cast<unsigned long long *>(rst.p) : nullptr;
-        fv.rst.log2n = rst_log2;
         fv.seq_codes = seq_codes; fv.seq_woff = seq_woff; fv.seq_wpr = seq_wpr; fv.seq_first = seq_first; fv.k = k;
         return fv;
     }
-    std::function<void()> before_buckets;     // RB_PAIRS_SIDE=5: called once by the grouping right before its bucket kernel is launched
     void prof_begin(hipStream_t st = nullptr) {
         if (!prof_on) return;
         const int w = (st && st == stream2) ? 1 : (st && st == stream3) ? 2 : 0;

@@ -339,19 +339,6 @@ def test_synthetic_slices_are_the_whole_set():
         ReadBatch.synthetic(10, 1 << 16, pair_offset=5, total_pairs=12)
 
 
-def test_one_pass_filter_kernel_matches(monkeypatch):
-    """the experimental one-pass prefilter+emit kernel (decoupled look-back) gives the same filters"""
-    monkeypatch.setenv("RB_ONE_PASS_FILTER", "1")
-    d = synth.generate_pairs(3000, G=2000, err=0.002, n_rate=1e-3, seed=21, uniform_expr=True)
-    og, gg = graph_pair(200_003, 300_007, 50_021, max_batch=8_000)
-    og.set_read_pair_distance(115); gg.setReadPairedKmerDistance(115)
-    s, off = synth.flat(d["left"]); q, _ = synth.flat(d["lqual"])
-    og.add_reads(s, q, off, 3, rbo.STORE_READ_PAIRS)
-    st = gg.addReads(s, q, off, 3, storeReadPairedKmers=True)
-    assert_same_state(og, gg)
-    assert st.sorted_kmers < st.kmers
-
-
 def test_cold_subbatch_is_split_when_survivors_exceed_the_bound():
     """a sub-batch may span 2x max_batch windows; when (cold cache) more than max_batch of them survive
     the prefilter it is halved and redone — results stay exact and every k-mer is counted once"""
@@ -365,18 +352,16 @@ def test_cold_subbatch_is_split_when_survivors_exceed_the_bound():
     assert st.kmers == o_st.kmers and st.reads == 1200
 
 
-@pytest.mark.parametrize("env", [{}, {"RB_NO_MPF": "1"}, {"RB_NO_RAMP": "1"}, {"RB_PREPARE_EARLY": "1"}, {"RB_SERIAL": "1"},
+@pytest.mark.parametrize("env", [{}, {"RB_NO_MPF": "1"}, {"RB_NO_RAMP": "1"}, {"RB_SERIAL": "1"},
                                  {"RB_MPF": "8"}, {"RB_NPF": "8", "RB_NO_MPF": "1"}, {"RB_MPF_M": "9"},
                                  {"RB_READ_LANES": "0"}, {"RB_SPARSE_EMIT": "0"}, {"RB_READ_LANES": "0", "RB_NO_MPF": "1"},
                                  {"RB_EMIT_RESUME": "0"}, {"RB_EMIT_RESUME": "0", "RB_SPARSE_EMIT": "0"},
                                  {"RB_FIRST_SETTER_TABLE": "1"}, {"RB_NO_CS_FILTER": "1"},
                                  {"RB_GROUP_ORDERED": "1"}, {"RB_GROUP_PREFETCH": "0"}, {"RB_GROUP_FIX": "0"}, {"RB_GROUP_FIX": "2"},
                                  {"RB_GROUP_T": "18"}, {"RB_GROUP_T": "18", "RB_GROUP_WIDE_LDS": "0"},
-                                 {"RB_TWO_PHASE": "1"}, {"RB_TWO_PHASE": "1", "RB_RST": "8"},
-                                 {"RB_PAIRS_SIDE": "0"}, {"RB_PAIRS_SIDE": "1"}, {"RB_PAIRS_SIDE": "2"}, {"RB_PAIRS_SIDE": "4"}, {"RB_PAIRS_SIDE": "5"},
-                                 {"RB_FILTER_PIPE": "1"}, {"RB_FILTER_PIPE": "2"}, {"RB_FILTER_PIPE": "0"}, {"RB_RAGGED_LANES": "0"},
+                                 {"RB_FILTER_PIPE": "1"}, {"RB_FILTER_PIPE": "0"}, {"RB_RAGGED_LANES": "0"},
                                  {"RB_GROUP_IDX": "1"}, {"RB_GROUP_IDX": "0"}, {"RB_GROUP_IDX": "1", "RB_GROUP_T": "18"}, {"RB_GROUP_IDX": "1", "RB_GROUP_T": "3"},
-                                 {"RB_GROUP_IDX": "1", "RB_TWO_PHASE": "1"}, {"RB_FT_FILTER": "1"}, {"RB_FT_FILTER": "0"}, {"RB_GROUP_CLASSES": "0"},
+                                 {"RB_FT_FILTER": "1"}, {"RB_FT_FILTER": "0"}, {"RB_GROUP_CLASSES": "0"},
                                  {"RB_SWEEP": "1"}, {"RB_SWEEP": "1", "RB_GROUP_T": "18"}, {"RB_SWEEP": "1", "RB_GROUP_T": "3"}, {"RB_SWEEP": "1", "RB_GROUP_T": "11"},
                                  {"RB_SWEEP": "1", "RB_SERIAL": "1"}, {"RB_SWEEP": "1", "RB_GROUP_ORDERED": "1"}, {"RB_SWEEP": "1", "RB_NO_MPF": "1"},
                                  {"RB_SWEEP": "1", "RB_FT_FILTER": "1"}, {"RB_SWEEP": "1", "RB_PF_SKIP": "2"}, {"RB_SWEEP": "0"}])
