@@ -221,8 +221,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-sharded", action="store_true", help="use the sharded engine + RCCL collectives even on 1 GPU")
     ap.add_argument("--no-host-leg", action="store_true", help="skip the host-resident leg (packed reads in pinned host memory, uploaded inside the timed region)")
-    ap.add_argument("--host-chunk-reads", type=int, default=12_500_000, help="reads per uploaded chunk of the host-resident leg")
-    ap.add_argument("--host-first-chunk", type=int, default=3_125_000, help="reads of a file's first chunk (its upload has nothing to hide behind at the start of a step)")
+    ap.add_argument("--host-piece-reads", type=int, default=0, help="reads per uploaded piece of the host-resident leg (0: 2^20, doubling up to 2^23)")
     return ap.parse_args()
 
 
@@ -467,48 +466,37 @@ def main():
 
 def host_resident_leg(a, g, batch, pairs_total, kmers_per_step):
     """The metric as SURVEY.md s8(d) words it: input resident in HOST memory in the build's batch format.  Both files of the read set sit
-    packed in pinned host memory (12 B per 32 bases + 4 B per read: rb_batch_download_packed); a step starts from cleared filters and
-    uploads every chunk INSIDE the timed region through a packed stream (include/rb_capi.h rb_packed_stream_*: two device batches taking
-    turns on a copy stream), chunk c + 1 travelling while chunk c is inserted.  A file's first chunk is short: at the start of a step its
-    upload has nothing to hide behind.  Same number of timed steps as the HBM-resident figure; `filters_equal_resident` compares the folds of
-    all three filters with the resident leg's (which ran last on the same handle)."""
-    import ctypes as C
+    packed in pinned host memory (12 B per 32 bases + 4 B per read: rb_batch_download_packed); a step starts from cleared filters and every
+    byte is uploaded INSIDE the timed region: one rb_graph_add_packed call per file (include/rb_capi.h, csrc/rb_packed.hip) sends the lengths,
+    then codes / valid in pieces on a copy stream while the insert pipeline already works on the pieces that have arrived.  Same number of
+    timed steps as the HBM-resident figure; `filters_equal_resident` compares the folds of all three filters with the resident leg's (which
+    ran last on the same handle)."""
     import torch
     from rnabloom import _native as N
     from rnabloom.graph import PackedStream
     fold = lambda: tuple(_fold(g, w) for w in (N.DBGBF, N.CBF, N.RPKBF))
     ref = fold()
     files = [(batch.downloadPacked(0, pairs_total), False), (batch.downloadPacked(pairs_total, pairs_total), True)]
-    plan = []
-    for ph, rc in files:
-        r0 = 0
-        while r0 < ph.n_reads:
-            n = min(ph.n_reads - r0, a.host_first_chunk if (r0 == 0 and a.host_first_chunk > 0) else a.host_chunk_reads)
-            plan.append((ph, rc, r0, n))
-            r0 += n
-    max_reads = max(p[3] for p in plan)
-    max_words = max(p[0].words_before(p[2] + p[3]) - p[0].words_before(p[2]) for p in plan)
-    ps = PackedStream(max_reads, max_words, device=g.device if hasattr(g, "device") else 0)
     nbytes = sum(ph.nbytes() for ph, _ in files)
 
     def step():
         g.clearAllBf()
-        ps.begin(*_sl(plan[0]))
         km = 0
-        for i, (ph, rc, r0, n) in enumerate(plan):
-            b = ps.finish()
-            if i + 1 < len(plan):
-                ps.begin(*_sl(plan[i + 1]))
-            km += g.addBatch(b, reverseComplement=rc, storeReadPairedKmers=True).kmers
+        for ph, rc in files:
+            km += g.addPacked(ph, reverseComplement=rc, storeReadPairedKmers=True, pieceReads=a.host_piece_reads).kmers
         return km
 
-    # the link alone: every chunk uploaded back to back, nothing inserted
+    # the link alone: both files through a packed stream, chunk after chunk, nothing inserted
+    chunk = min(pairs_total, 12_500_000)
+    ps = PackedStream(chunk, max(ph.words_before(min(r0 + chunk, ph.n_reads)) - ph.words_before(r0) for ph, _ in files for r0 in range(0, ph.n_reads, chunk)), device=g.device)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for pl in plan:
-        ps.begin(*_sl(pl)); ps.finish()
+    for ph, _ in files:
+        for r0 in range(0, ph.n_reads, chunk):
+            ps.begin(ph, r0, min(chunk, ph.n_reads - r0)); ps.finish()
     link_s = time.perf_counter() - t0
-    step()                                     # warm-up (scratch of the chunked calls)
+    ps.close()
+    step()                                     # warm-up (the handle's ingest buffers)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     km = 0
@@ -517,18 +505,13 @@ def host_resident_leg(a, g, batch, pairs_total, kmers_per_step):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     equal = fold() == ref
-    ps.close()
     for ph, _ in files:
         ph.close()
     return {"value": km / dt, "unit": "k-mers/s", "ms_per_step": dt / a.steps * 1e3, "steps": a.steps, "kmers_per_step": km // a.steps,
             "host_bytes_per_step": nbytes, "h2d_GBps": round(nbytes / link_s / 1e9, 1), "upload_alone_ms": round(link_s * 1e3, 1),
-            "chunks": [p[3] for p in plan], "filters_equal_resident": bool(equal) and km // a.steps == kmers_per_step,
+            "piece_reads": a.host_piece_reads or "2^20 doubling to 2^23", "filters_equal_resident": bool(equal) and km // a.steps == kmers_per_step,
             "note": "packed reads in pinned host memory (rb_batch_download_packed format), every byte uploaded inside the timed region on a copy "
-                    "stream while the chunk before is inserted; `value` of the line itself times HBM-resident input"}
-
-
-def _sl(pl):
-    return pl[0], pl[2], pl[3]
+                    "stream beside the insert (rb_graph_add_packed, one call per file); `value` of the line itself times HBM-resident input"}
 
 
 def _fold(g, which):

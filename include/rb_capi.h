@@ -395,10 +395,12 @@ int rb_packed_stream_begin(rb_packed_stream *s, const uint64_t *codes, const uin
  * next reuses its buffer.  An error (the lengths do not add up to n_words, a failed copy) is reported here. */
 int rb_packed_stream_finish(rb_packed_stream *s, const rb_batch **out);
 int rb_packed_stream_destroy(rb_packed_stream *s);
-/* convenience: n_reads packed reads through a packed stream in chunks of chunk_reads reads (0: 2^24), every chunk through
- * rb_graph_add_batch with `flags`; same filters as one rb_graph_add_batch of the same reads */
+/* FastqToGraphWorker.run over n_reads packed reads in host memory as ONE insert: the lengths go up first (word offsets and owners are computed
+ * on the GPU), then codes / valid follow on the handle's copy stream in pieces of piece_reads reads (0: 2^20 reads, doubling up to 2^23) while
+ * the insert pipeline already works on the pieces that have arrived — a sub-batch waits only for the pieces its words lie in.  Same filters
+ * and statistics as rb_graph_add_batch of the same reads with `flags`; the caller's arrays are free again when the call returns. */
 int rb_graph_add_packed(rb_graph *g, const uint64_t *codes, const uint32_t *valid, const uint32_t *len, int64_t n_reads, int64_t n_words,
-                        int64_t chunk_reads, unsigned flags, rb_add_stats *stats);
+                        int64_t piece_reads, unsigned flags, rb_add_stats *stats);
 /* NucleotideBitsWriter.write R/io/NucleotideBitsWriter.java:24-31 for n_reads sequences; out == NULL: *written = size
  * needed.  A base outside ACGTU is an error (the reference stores a RANDOM base there, SeqBitsUtils.java:154-155). */
 int rb_nbits_encode(const char *seq, const int64_t *offsets, int64_t n_reads, void *out, size_t cap, size_t *written);

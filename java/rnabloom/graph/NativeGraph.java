@@ -63,8 +63,8 @@ public final class NativeGraph {
     public static native void packedStreamBegin(long s, ByteBuffer codes, ByteBuffer valid, ByteBuffer len, long wordOffset, long readOffset, long nReads, long nWords);
     public static native long packedStreamFinish(long s);
     public static native void packedStreamDestroy(long s);
-    /** FastqToGraphWorker's loop over reads already packed in host memory: chunks of chunkReads reads (0: 2^24) upload while the chunk before is inserted */
-    public static native long[] addPacked(long h, ByteBuffer codes, ByteBuffer valid, ByteBuffer len, long nReads, long nWords, long chunkReads, int flags);
+    /** FastqToGraphWorker's loop over reads already packed in host memory: ONE insert; the input goes up in pieces of pieceReads reads (0: 2^20 doubling to 2^23) on a copy stream while the pipeline works on what has arrived */
+    public static native long[] addPacked(long h, ByteBuffer codes, ByteBuffer valid, ByteBuffer len, long nReads, long nWords, long pieceReads, int flags);
 
     // ---- stage-1 inserts; every add returns {reads, kmers, pairs, distinct, conflictOps, sortedKmers} ----
     public static native long[] addBatch(long h, long batch, long first, long n, int flags);

@@ -149,11 +149,11 @@ jlong FN(packedStreamFinish)(JNIEnv *e, jclass c, jlong s) {
     return (jlong)(intptr_t)b;
 }
 void FN(packedStreamDestroy)(JNIEnv *e, jclass c, jlong s) { (void)c; int rc = rb_packed_stream_destroy(PS(s)); if (rc) throw_rc(e, rc); }
-jlongArray FN(addPacked)(JNIEnv *e, jclass c, jlong h, jobject codes, jobject valid, jobject len, jlong n_reads, jlong n_words, jlong chunk_reads, jint flags) {
+jlongArray FN(addPacked)(JNIEnv *e, jclass c, jlong h, jobject codes, jobject valid, jobject len, jlong n_reads, jlong n_words, jlong piece_reads, jint flags) {
     rb_add_stats st;
     (void)c;
     int rc = rb_graph_add_packed(G(h), (const uint64_t *)direct(e, codes), (const uint32_t *)direct(e, valid), (const uint32_t *)direct(e, len), n_reads, n_words,
-                                 chunk_reads, (unsigned)flags, &st);
+                                 piece_reads, (unsigned)flags, &st);
     if (rc) { throw_rc(e, rc); return NULL; }
     return stats_array(e, &st);
 }

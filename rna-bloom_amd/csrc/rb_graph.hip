@@ -1903,6 +1903,7 @@ void rb::add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, uns
             g->chunk_cnt.reserve(((size_t)sb.nw + 1) * 4); g->chunk_off.reserve(((size_t)sb.nw + 1) * 4);
             g->temp2.reserve(scan_temp_bytes((size_t)sb.nw + 1));
             RB_HIP(hipMemsetAsync(g->chunk_cnt.as<uint32_t>() + sb.nw, 0, 4, sp));
+            if (g->await_words) g->await_words(sb.w0 + sb.nw, sp);      // (a batch that is still being uploaded: rb_graph_add_packed)
             // Where the cache has stopped dropping anything (two sub-batches in a row kept >= 97 % of their windows: long reads, nearly every
             // k-mer new) the window walk against it is a hashing pass for nothing: the next 15 sub-batches count their usable windows instead
             // and emit them all, then one is measured again.  RB_PF_SKIP=0: never; 2: sub-batches of any size count (tests).

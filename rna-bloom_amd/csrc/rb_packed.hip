@@ -15,6 +15,7 @@
 // runs beside the insert of this one on the copy engines.  The reference's counterpart is the reader side of
 // FastqToGraphWorker (R/RNABloom.java:551-634: reads pulled from a FastqReader while other workers insert).
 #include <string.h>
+#include <time.h>
 
 #include <algorithm>
 #include <condition_variable>
@@ -31,19 +32,23 @@ using namespace rb;
 namespace {
 // wc[r] = words of read r (wc[n] = 0 closes the scan); st: [0] longest read, [1] fewest / [2] most words of a read, [4..5] sum of len (u64)
 __global__ void k_packed_words(const uint32_t *__restrict__ len, int64_t n, uint32_t *__restrict__ wc, uint32_t *__restrict__ st) {
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t l = 0, w = 0;
-    const bool live = i < n;
-    if (live) { l = len[i]; w = (l + 31u) >> 5; wc[i] = w; }
-    if (i == n) wc[i] = 0;
-    uint32_t mx = l, wmin = live ? w : 0xFFFFFFFFu, wmax = w;
-    unsigned long long sum = l;
+    // grid-stride: a few thousand wavefronts in all, so that the four same-address atomics at the end (they queue up at ~10 ns apiece at the memory
+    // side) are thousands, not one set per 64 reads — 200 K sets cost 9 ms of an 11 ms upload prologue when every wavefront of a flat grid did them
+    uint32_t mx = 0, wmin = 0xFFFFFFFFu, wmax = 0;
+    unsigned long long sum = 0;
+    bool any = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += (int64_t)gridDim.x * blockDim.x) {
+        if (i == n) { wc[i] = 0; break; }
+        const uint32_t l = len[i], w = (l + 31u) >> 5;
+        wc[i] = w;
+        mx = l > mx ? l : mx; wmin = w < wmin ? w : wmin; wmax = w > wmax ? w : wmax; sum += l; any = true;
+    }
     for (int o = 32; o > 0; o >>= 1) {
         const uint32_t a = (uint32_t)__shfl_down((int)mx, o, 64), b = (uint32_t)__shfl_down((int)wmin, o, 64), c = (uint32_t)__shfl_down((int)wmax, o, 64);
         mx = a > mx ? a : mx; wmin = b < wmin ? b : wmin; wmax = c > wmax ? c : wmax;
         sum += __shfl_down(sum, o, 64);
     }
-    if ((threadIdx.x & 63u) == 0u && __ballot(live)) {
+    if ((threadIdx.x & 63u) == 0u && __ballot(any)) {
         atomicMax(&st[0], mx); atomicMin(&st[1], wmin); atomicMax(&st[2], wmax);
         atomicAdd(reinterpret_cast<unsigned long long *>(st + 4), sum);
     }
@@ -112,6 +117,9 @@ void upload_chunk(rb_packed_stream *s, int slot, const uint64_t *codes, const ui
     RB_HIP(hipSetDevice(s->device));
     rb_packed_stream::Buf &B = s->buf[slot];
     hipStream_t st = s->st;
+    const bool tdbg = getenv("RB_HOST_TIMING") != nullptr;
+    auto now = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; };
+    const double t_0 = now();
     const size_t nw = (size_t)std::max<int64_t>(n_words, 1), nr = (size_t)std::max<int64_t>(n_reads, 1);
     RB_REQUIRE(n_words <= s->max_words && n_reads <= s->max_reads, "packed stream: a chunk of %lld reads / %lld words, the stream was created for %lld / %lld",
                (long long)n_reads, (long long)n_words, (long long)s->max_reads, (long long)s->max_words);
@@ -121,23 +129,28 @@ void upload_chunk(rb_packed_stream *s, int slot, const uint64_t *codes, const ui
     memcpy(s->h_stats + 8, init, sizeof init);
     RB_HIP(hipMemcpyAsync(B.stats.p, s->h_stats + 8, sizeof init, hipMemcpyHostToDevice, st));
     if (n_reads) RB_HIP(hipMemcpyAsync(B.len.p, len, (size_t)n_reads * 4, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_packed_words, dim3(blocks_for(n_reads + 1)), dim3(TPB), 0, st, B.len.as<uint32_t>(), n_reads, B.wc.as<uint32_t>(), B.stats.as<uint32_t>());
+    hipLaunchKernelGGL(k_packed_words, dim3(std::min<unsigned>(blocks_for(n_reads + 1), 2048u)), dim3(TPB), 0, st, B.len.as<uint32_t>(), n_reads, B.wc.as<uint32_t>(), B.stats.as<uint32_t>());
     exclusive_scan_u32(B.temp.p, B.temp.cap, B.wc.as<uint32_t>(), B.woff.as<uint32_t>(), (size_t)n_reads + 1, st);
     RB_HIP(hipMemcpyAsync(s->h_stats, B.stats.p, 32, hipMemcpyDeviceToHost, st));
     RB_REQUIRE(n_reads <= B.h_woff_cap, "packed stream: a chunk of %lld reads, the stream was created for %lld", (long long)n_reads, (long long)B.h_woff_cap);
     B.b.h_woff.borrow(B.h_woff, (size_t)n_reads + 1);                  // pinned: the copy back runs at link speed
     RB_HIP(hipMemcpyAsync(B.h_woff, B.woff.p, ((size_t)n_reads + 1) * 4, hipMemcpyDeviceToHost, st));
+    double t_1 = 0;
+    if (tdbg) { RB_HIP(hipStreamSynchronize(st)); t_1 = now(); }
     if (n_words) {
         RB_HIP(hipMemcpyAsync(B.codes.p, codes, (size_t)n_words * 8, hipMemcpyHostToDevice, st));
         RB_HIP(hipMemcpyAsync(B.valid.p, valid, (size_t)n_words * 4, hipMemcpyHostToDevice, st));
     }
     RB_HIP(hipStreamSynchronize(st));
+    const double t_2 = now();
     // the lengths must describe exactly the words that were handed over — checked before anything indexes by them
     RB_REQUIRE((int64_t)B.b.h_woff[(size_t)n_reads] == n_words, "packed batch: the lengths of %lld reads add up to %u words, %lld were passed",
                (long long)n_reads, B.b.h_woff[(size_t)n_reads], (long long)n_words);
     if (n_reads) hipLaunchKernelGGL(k_packed_word_read, dim3(blocks_for(n_reads)), dim3(TPB), 0, st, B.woff.as<uint32_t>(), n_reads, B.word_read.as<uint32_t>());
     RB_HIP(hipGetLastError());
     RB_HIP(hipStreamSynchronize(st));
+    if (tdbg) fprintf(stderr, "[rb] packed chunk of %lld reads / %lld words: lengths + offsets %.2f ms, codes + valid %.2f ms (%.1f GB/s), word owners %.2f ms\n", (long long)n_reads,
+                      (long long)n_words, t_1 - t_0, t_2 - t_1, (double)n_words * 12.0 / ((t_2 - t_1) * 1e6), now() - t_2);
     rb_batch &b = B.b;
     b.device = s->device; b.n_reads = n_reads; b.n_words = n_words;
     b.max_len = s->h_stats[0];
@@ -247,48 +260,92 @@ int rb_packed_stream_destroy(rb_packed_stream *s) {
     return RB_OK;
 }
 
-// FastqToGraphWorker.run over reads that are already packed in host memory: chunks of `chunk_reads` reads (0: 2^24) go through a
-// packed stream of the handle's device, chunk c + 1 uploading while chunk c is inserted.  Same results as rb_graph_add_batch of
-// the same reads (nothing depends on where a call is cut: DESIGN.md §3 (v)).
+// FastqToGraphWorker.run over reads that are already packed in host memory, as ONE insert call: the device batch is sized for all n_reads reads,
+// the lengths go up first (offsets and word owners are computed on the GPU, the offsets come back into pinned memory for the sub-batch plan),
+// then codes and valid follow on the handle's copy stream in pieces — piece_reads reads each (0: 2^20, doubling up to 2^23: the first piece is
+// all an insert has to wait for) — with an event behind every piece; add_range makes its producer stream wait for the pieces a sub-batch's words
+// lie in (rb_graph::await_words) and otherwise runs exactly as it does on a resident batch: one pipeline over the whole file, upload beside it.
+// Same filters as rb_graph_add_batch of the same reads.
 int rb_graph_add_packed(rb_graph *g, const uint64_t *codes, const uint32_t *valid, const uint32_t *len, int64_t n_reads, int64_t n_words,
-                        int64_t chunk_reads, unsigned flags, rb_add_stats *stats) {
+                        int64_t piece_reads, unsigned flags, rb_add_stats *stats) {
     if (stats) memset(stats, 0, sizeof *stats);
     if (!g) { set_error("rb_graph_add_packed: null graph"); return RB_ERR_INVALID; }
-    rb_packed_stream *s = nullptr;
+    WriteLock wl(g->rw);
+    struct HookOff { rb_graph *g; ~HookOff() { g->await_words = nullptr; } } hook_off{g};
     int rc = guarded([&] {
-        RB_REQUIRE(n_reads >= 0 && n_words >= 0 && chunk_reads >= 0 && (n_reads == 0 || len) && (n_words == 0 || (codes && valid)), "rb_graph_add_packed: bad argument");
+        RB_REQUIRE(n_reads >= 0 && n_words >= 0 && piece_reads >= 0 && (n_reads == 0 || len) && (n_words == 0 || (codes && valid)), "rb_graph_add_packed: bad argument");
+        RB_REQUIRE(n_words < 0xFFFFFFF0ll && n_reads < 0xFFFFFFF0ll, "rb_graph_add_packed: batch too large (> 2^32 words)");
         if (!n_reads) return;
-        const int64_t step = chunk_reads ? chunk_reads : ((int64_t)1 << 24);
-        // chunk boundaries in words: one pass over the lengths (host; 4 bytes per read)
-        std::vector<int64_t> rcut{0}, wcut{0};
-        int64_t w = 0, wmax = 0;
-        for (int64_t r = 0; r < n_reads; ++r) {
-            w += ((int64_t)len[r] + 31) >> 5;
-            if (r + 1 == n_reads || (r + 1) % step == 0) { rcut.push_back(r + 1); wmax = std::max(wmax, w - wcut.back()); wcut.push_back(w); }
+        RB_HIP(hipSetDevice(g->p.device));
+        rb_graph::PackedIngest &K = g->pk;
+        if (!K.st) RB_HIP(hipStreamCreateWithFlags(&K.st, hipStreamNonBlocking));
+        if (!K.h_stats) RB_HIP(hipHostMalloc(reinterpret_cast<void **>(&K.h_stats), 64, hipHostMallocDefault));
+        const size_t nw = (size_t)std::max<int64_t>(n_words, 1), nr = (size_t)n_reads;
+        K.codes.reserve(nw * 8); K.valid.reserve(nw * 4); K.word_read.reserve(nw * 4);
+        K.woff.reserve((nr + 1) * 4); K.len.reserve(nr * 4); K.wc.reserve((nr + 1) * 4); K.stats.reserve(64); K.temp.reserve(scan_temp_bytes(nr + 1));
+        if (K.h_woff_cap < nr + 1) {
+            if (K.h_woff) (void)hipHostFree(K.h_woff);
+            K.h_woff = nullptr; K.h_woff_cap = 0;
+            const size_t want = nr + 1 + (nr >> 3);
+            RB_HIP(hipHostMalloc(reinterpret_cast<void **>(&K.h_woff), want * 4, hipHostMallocDefault));
+            K.h_woff_cap = want;
         }
-        RB_REQUIRE(w == n_words, "rb_graph_add_packed: the lengths add up to %lld words, %lld were passed", (long long)w, (long long)n_words);
-        int prc = rb_packed_stream_create(g->p.device, std::min(step, n_reads), wmax, &s);
-        if (prc != RB_OK) throw HipError{prc};
-        auto begin = [&](size_t c) {
-            int brc = rb_packed_stream_begin(s, codes + wcut[c], valid + wcut[c], len + rcut[c], rcut[c + 1] - rcut[c], wcut[c + 1] - wcut[c]);
-            if (brc != RB_OK) throw HipError{brc};
-        };
-        begin(0);
-        for (size_t c = 0; c + 1 < rcut.size(); ++c) {
-            const rb_batch *b = nullptr;
-            int frc = rb_packed_stream_finish(s, &b);
-            if (frc != RB_OK) throw HipError{frc};
-            if (c + 2 < rcut.size()) begin(c + 1);
-            rb_add_stats st1;
-            int arc = rb_graph_add_batch_range(g, b, 0, b->n_reads, flags, &st1);
-            if (arc != RB_OK) throw HipError{arc};
-            if (stats) {
-                stats->reads += st1.reads; stats->kmers += st1.kmers; stats->pairs += st1.pairs; stats->distinct += st1.distinct;
-                stats->conflict_ops += st1.conflict_ops; stats->sorted_kmers += st1.sorted_kmers;
+        HostPin p0(codes, (size_t)n_words * 8), p1(valid, (size_t)n_words * 4), p2(len, nr * 4);
+        hipStream_t st = K.st;
+        uint32_t init[8] = {0u, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u, 0u};
+        memcpy(K.h_stats + 8, init, sizeof init);
+        RB_HIP(hipMemcpyAsync(K.stats.p, K.h_stats + 8, sizeof init, hipMemcpyHostToDevice, st));
+        RB_HIP(hipMemcpyAsync(K.len.p, len, nr * 4, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_packed_words, dim3(std::min<unsigned>(blocks_for(n_reads + 1), 2048u)), dim3(TPB), 0, st, K.len.as<uint32_t>(), n_reads, K.wc.as<uint32_t>(), K.stats.as<uint32_t>());
+        exclusive_scan_u32(K.temp.p, K.temp.cap, K.wc.as<uint32_t>(), K.woff.as<uint32_t>(), nr + 1, st);
+        RB_HIP(hipMemcpyAsync(K.h_stats, K.stats.p, 32, hipMemcpyDeviceToHost, st));
+        RB_HIP(hipMemcpyAsync(K.h_woff, K.woff.p, (nr + 1) * 4, hipMemcpyDeviceToHost, st));
+        hipLaunchKernelGGL(k_packed_word_read, dim3(blocks_for(n_reads)), dim3(TPB), 0, st, K.woff.as<uint32_t>(), n_reads, K.word_read.as<uint32_t>());
+        RB_HIP(hipGetLastError());
+        // (the pieces are cut at read boundaries, so the offsets have to be here before the first one goes up: 4 bytes per read each way, ~7 ms per 10^8 reads)
+        RB_HIP(hipStreamSynchronize(st));
+        RB_REQUIRE((int64_t)K.h_woff[nr] == n_words, "rb_graph_add_packed: the lengths of %lld reads add up to %u words, %lld were passed", (long long)n_reads, K.h_woff[nr], (long long)n_words);
+        rb_batch b;
+        b.device = g->p.device; b.n_reads = n_reads; b.n_words = n_words;
+        b.max_len = K.h_stats[0];
+        b.wpr_uniform = K.h_stats[1] == K.h_stats[2] ? K.h_stats[1] : 0u;
+        b.n_bases = (int64_t)(((uint64_t)K.h_stats[5] << 32) | K.h_stats[4]);
+        b.codes = K.codes.as<uint64_t>(); b.valid = K.valid.as<uint32_t>(); b.word_read = K.word_read.as<uint32_t>();
+        b.woff = K.woff.as<uint32_t>(); b.len = K.len.as<uint32_t>(); b.rnz = nullptr;
+        b.device_bytes = nw * 16 + (nr + 1) * 4 + nr * 4;
+        b.h_woff.borrow(K.h_woff, nr + 1);
+        // pieces: read boundaries -> word boundaries; an event behind each
+        std::vector<int64_t> wend;
+        {
+            int64_t r = 0, step = piece_reads ? piece_reads : ((int64_t)1 << 20);
+            while (r < n_reads) {
+                r = std::min(n_reads, r + step);
+                wend.push_back((int64_t)K.h_woff[(size_t)r]);
+                if (!piece_reads) step = std::min<int64_t>(step * 2, (int64_t)1 << 23);
             }
         }
+        while (K.ev.size() < wend.size()) { hipEvent_t e; RB_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); K.ev.push_back(e); }
+        int64_t w0 = 0;
+        for (size_t p = 0; p < wend.size(); ++p) {
+            const int64_t w1 = wend[p];
+            if (w1 > w0) {
+                RB_HIP(hipMemcpyAsync(K.codes.as<uint64_t>() + w0, codes + w0, (size_t)(w1 - w0) * 8, hipMemcpyHostToDevice, st));
+                RB_HIP(hipMemcpyAsync(K.valid.as<uint32_t>() + w0, valid + w0, (size_t)(w1 - w0) * 4, hipMemcpyHostToDevice, st));
+            }
+            RB_HIP(hipEventRecord(K.ev[p], st));
+            w0 = w1;
+        }
+        size_t waited = 0;                                   // pieces [0, waited) are known to the streams that asked
+        g->await_words = [&](int64_t w_end, hipStream_t on) {
+            size_t need = 0;
+            while (need < wend.size() && (need == 0 ? 0 : wend[need - 1]) < w_end) ++need;      // pieces 0 .. need-1 cover words [0, w_end)
+            // (the producer stream asks in increasing order; a stream waits for the LAST piece it needs: the copy stream is in order)
+            if (need > 0 && need > waited) { RB_HIP(hipStreamWaitEvent(on, K.ev[need - 1], 0)); waited = need; }
+        };
+        struct Drain { hipStream_t st; ~Drain() { (void)hipStreamSynchronize(st); } } drain{st};     // the caller's buffers are free again when the call returns
+        add_range(g, &b, 0, n_reads, flags, stats);
+        b.codes = nullptr; b.valid = nullptr; b.word_read = nullptr; b.woff = nullptr; b.len = nullptr;
     });
-    if (s) rb_packed_stream_destroy(s);
     return rc;
 }
 

@@ -402,6 +402,18 @@ struct rb_graph {
     std::vector<hipEvent_t> prof_pool;
     hipEvent_t prof_open[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
+    // rb_graph_add_packed: the batch being inserted is still arriving from host memory, piece by piece on a copy stream.  add_range calls this
+    // before it enqueues anything that reads words [0, w_end) of the batch on `st`; the hook makes `st` wait for the pieces that hold them.
+    std::function<void(int64_t w_end, hipStream_t st)> await_words;
+    // ... and what that call keeps between calls (rb_packed.hip): the device batch the host's reads are streamed into, the pinned copy of its word
+    // offsets, the copy stream and one event per uploaded piece
+    struct PackedIngest {
+        DevBuf codes, valid, word_read, woff, len, wc, temp, stats;
+        uint32_t *h_woff = nullptr, *h_stats = nullptr;
+        size_t h_woff_cap = 0;
+        hipStream_t st = nullptr;
+        std::vector<hipEvent_t> ev;
+    } pk;
     hipEvent_t prof_event() {
         if (!prof_pool.empty()) { hipEvent_t e = prof_pool.back(); prof_pool.pop_back(); return e; }
         hipEvent_t e; RB_HIP(hipEventCreate(&e)); return e;

@@ -270,16 +270,16 @@ class BloomFilterDeBruijnGraph:
             check(lib.rb_graph_add_batch_range(self.h, batch.h, first, n, flags, C.byref(st)))
         return st
 
-    def addPacked(self, ph, reverseComplement=False, incrementIfPresent=False, storeReadPairedKmers=False, first=0, n=None, chunkReads=0):
-        """reads [first, first + n) of a PackedHost through rb_graph_add_packed: chunks uploaded on a copy stream while the chunk before
-        is inserted (FastqToGraphWorker's loop over reads that are already packed in host memory)"""
+    def addPacked(self, ph, reverseComplement=False, incrementIfPresent=False, storeReadPairedKmers=False, first=0, n=None, pieceReads=0):
+        """reads [first, first + n) of a PackedHost through rb_graph_add_packed: ONE insert whose input arrives piece by piece on a copy stream
+        while the pipeline already works on what is there (FastqToGraphWorker's loop over reads that are already packed in host memory)"""
         flags = (N.ADD_REVCOMP if reverseComplement else 0) | (N.ADD_COUNT_IF_PRESENT if incrementIfPresent else 0) \
             | (N.ADD_STORE_READ_PAIRS if storeReadPairedKmers else 0)
         n = ph.n_reads - first if n is None else n
         w0, w1 = ph.words_before(first), ph.words_before(first + n)
         st = N.AddStats()
         check(lib.rb_graph_add_packed(self.h, ph.codes.ctypes.data + 8 * w0, ph.valid.ctypes.data + 4 * w0, ph.len.ctypes.data + 4 * first,
-                                      n, w1 - w0, chunkReads, flags, C.byref(st)))
+                                      n, w1 - w0, pieceReads, flags, C.byref(st)))
         return st
 
     def addFastq(self, text, minBaseQual=3, reverseComplement=False, incrementIfPresent=False, storeReadPairedKmers=False):

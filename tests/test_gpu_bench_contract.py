@@ -29,7 +29,7 @@ def free_port():
 
 def test_single_gpu_line_and_two_rank_line():
     env = dict(os.environ)
-    r = subprocess.run([sys.executable, "bench.py", "--cpu-sample-pairs", "40000", "--host-chunk-reads", "130000", "--host-first-chunk", "40000"] + SMALL,
+    r = subprocess.run([sys.executable, "bench.py", "--cpu-sample-pairs", "40000", "--host-piece-reads", "70000"] + SMALL,
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-3000:]
     j = last_json(r.stdout)
@@ -48,7 +48,7 @@ def test_single_gpu_line_and_two_rank_line():
     hr = j["host_resident"]
     assert hr["unit"] == "k-mers/s" and hr["value"] > 0 and hr["ms_per_step"] > 0 and hr["h2d_GBps"] > 0 and hr["steps"] == 1
     assert hr["kmers_per_step"] == j["config"]["kmers_per_step"] and hr["filters_equal_resident"] is True
-    assert len(hr["chunks"]) == 6 and sum(hr["chunks"]) == 600000 and hr["host_bytes_per_step"] == 600000 * (5 * 12 + 4)
+    assert hr["piece_reads"] == 70000 and hr["host_bytes_per_step"] == 600000 * (5 * 12 + 4)
     # two ranks, launched like the driver does it
     env["RB_BENCH_BACKEND"] = "gloo"
     r2 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",

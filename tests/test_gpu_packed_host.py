@@ -71,7 +71,7 @@ def test_an_insert_streamed_from_packed_host_memory_leaves_the_oracles_filters()
         ost = og.add_reads(seq, qual, off, 3, rbo.STORE_READ_PAIRS | (rbo.REVCOMP if rc else 0))
         b = ReadBatch.from_ascii(seq, qual, off, 3)
         ph = b.downloadPacked()
-        st = gg.addPacked(ph, reverseComplement=rc, storeReadPairedKmers=True, chunkReads=1700)       # four chunks, the last one short
+        st = gg.addPacked(ph, reverseComplement=rc, storeReadPairedKmers=True, pieceReads=1700)       # four pieces, the last one short
         assert st.kmers == ost.kmers and st.pairs == ost.pairs and st.reads == len(d[name])
         kmers += st.kmers
         ph.close(); b.close()
@@ -79,6 +79,24 @@ def test_an_insert_streamed_from_packed_host_memory_leaves_the_oracles_filters()
     assert (gg.exportFilter(N.DBGBF) == og.dbgbf_bytes()).all()
     assert (gg.exportFilter(N.CBF) == og.cbf_bytes()).all()
     assert (gg.exportFilter(N.RPKBF) == og.rpkbf_bytes()).all()
+
+
+def test_ragged_reads_streamed_in_small_pieces_through_several_sub_batches():
+    """reads of 0 .. 400 bases (empty ones, one-word ones), pieces of 900 reads, sub-batches of at most 20 000 records: every sub-batch waits for the
+    pieces its words lie in and nothing else — the filters are those of the same reads inserted from a resident batch"""
+    reads, quals = ragged_reads(12_000, 11)
+    b = ReadBatch.from_reads(reads, quals, 3)
+    ph = b.downloadPacked()
+    digests = []
+    for how in ("resident", "packed", "packed-one-piece"):
+        g = BloomFilterDeBruijnGraph(3_000_017, 3_000_017, 0, 2, 2, 1, 25, False, False, rngSeed=3, maxBatchKmers=20_000)
+        for rep in range(2):                                          # a second pass: every k-mer re-sighted
+            st = g.addBatch(b) if how == "resident" else g.addPacked(ph, pieceReads=900 if how == "packed" else 50_000)
+            assert st.reads == 12_000
+        digests.append((st.kmers, g.popcount(N.DBGBF), g.fold(N.DBGBF), g.fold(N.CBF)))
+        g.destroy()
+    assert digests[0] == digests[1] == digests[2], digests
+    ph.close(); b.close()
 
 
 def test_a_chunk_whose_lengths_do_not_describe_its_words_is_refused_and_the_stream_lives_on():
