@@ -468,7 +468,8 @@ def host_resident_leg(a, g, batch, pairs_total, kmers_per_step):
     """The metric as SURVEY.md s8(d) words it: input resident in HOST memory in the build's batch format.  Both files of the read set sit
     packed in pinned host memory (12 B per 32 bases + 4 B per read: rb_batch_download_packed); a step starts from cleared filters and every
     byte is uploaded INSIDE the timed region: one rb_graph_add_packed call per file (include/rb_capi.h, csrc/rb_packed.hip) sends the lengths,
-    then codes / valid in pieces on a copy stream while the insert pipeline already works on the pieces that have arrived.  Same number of
+    then codes / valid in pieces on a copy stream while the insert pipeline already works on the pieces that have arrived; the second file's
+    upload is started with the first one's (rb_graph_prefetch_packed) and travels while the first file is inserted.  Same number of
     timed steps as the HBM-resident figure; `filters_equal_resident` compares the folds of all three filters with the resident leg's (which
     ran last on the same handle)."""
     import torch
@@ -482,6 +483,8 @@ def host_resident_leg(a, g, batch, pairs_total, kmers_per_step):
     def step():
         g.clearAllBf()
         km = 0
+        for ph, _ in files:                   # both uploads are started (in file order, one copy stream): the second file travels while the first is inserted
+            g.prefetchPacked(ph, pieceReads=a.host_piece_reads)
         for ph, rc in files:
             km += g.addPacked(ph, reverseComplement=rc, storeReadPairedKmers=True, pieceReads=a.host_piece_reads).kmers
         return km
@@ -509,7 +512,7 @@ def host_resident_leg(a, g, batch, pairs_total, kmers_per_step):
         ph.close()
     return {"value": km / dt, "unit": "k-mers/s", "ms_per_step": dt / a.steps * 1e3, "steps": a.steps, "kmers_per_step": km // a.steps,
             "host_bytes_per_step": nbytes, "h2d_GBps": round(nbytes / link_s / 1e9, 1), "upload_alone_ms": round(link_s * 1e3, 1),
-            "piece_reads": a.host_piece_reads or "2^20 doubling to 2^23", "filters_equal_resident": bool(equal) and km // a.steps == kmers_per_step,
+            "piece_reads": a.host_piece_reads or "2^22 words doubling to 2^25", "filters_equal_resident": bool(equal) and km // a.steps == kmers_per_step,
             "note": "packed reads in pinned host memory (rb_batch_download_packed format), every byte uploaded inside the timed region on a copy "
                     "stream beside the insert (rb_graph_add_packed, one call per file); `value` of the line itself times HBM-resident input"}
 

@@ -401,6 +401,11 @@ int rb_packed_stream_destroy(rb_packed_stream *s);
  * and statistics as rb_graph_add_batch of the same reads with `flags`; the caller's arrays are free again when the call returns. */
 int rb_graph_add_packed(rb_graph *g, const uint64_t *codes, const uint32_t *valid, const uint32_t *len, int64_t n_reads, int64_t n_words,
                         int64_t piece_reads, unsigned flags, rb_add_stats *stats);
+/* Start the upload of a packed batch that a later rb_graph_add_packed call with THE SAME arrays and sizes will insert, and return at once (the
+ * reader side of stage 1 fetches the next file while the workers insert this one, R/RNABloom.java:7123-7188).  The arrays must stay as they
+ * are until that call returns.  Up to two batches may be on their way (uploads run in the order they were started). */
+int rb_graph_prefetch_packed(rb_graph *g, const uint64_t *codes, const uint32_t *valid, const uint32_t *len, int64_t n_reads, int64_t n_words,
+                             int64_t piece_reads);
 /* NucleotideBitsWriter.write R/io/NucleotideBitsWriter.java:24-31 for n_reads sequences; out == NULL: *written = size
  * needed.  A base outside ACGTU is an error (the reference stores a RANDOM base there, SeqBitsUtils.java:154-155). */
 int rb_nbits_encode(const char *seq, const int64_t *offsets, int64_t n_reads, void *out, size_t cap, size_t *written);

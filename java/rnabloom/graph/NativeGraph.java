@@ -66,6 +66,9 @@ public final class NativeGraph {
     /** FastqToGraphWorker's loop over reads already packed in host memory: ONE insert; the input goes up in pieces of pieceReads reads (0: 2^20 doubling to 2^23) on a copy stream while the pipeline works on what has arrived */
     public static native long[] addPacked(long h, ByteBuffer codes, ByteBuffer valid, ByteBuffer len, long nReads, long nWords, long pieceReads, int flags);
 
+    /** start the upload of a packed batch the next addPacked with the same buffers and sizes inserts; returns at once (the buffers must stay untouched until then) */
+    public static native void prefetchPacked(long h, ByteBuffer codes, ByteBuffer valid, ByteBuffer len, long nReads, long nWords, long pieceReads);
+
     // ---- stage-1 inserts; every add returns {reads, kmers, pairs, distinct, conflictOps, sortedKmers} ----
     public static native long[] addBatch(long h, long batch, long first, long n, int flags);
     public static native long[] addPairs(long h, long batch, long first, long n, int which, int flags);

@@ -157,6 +157,11 @@ jlongArray FN(addPacked)(JNIEnv *e, jclass c, jlong h, jobject codes, jobject va
     if (rc) { throw_rc(e, rc); return NULL; }
     return stats_array(e, &st);
 }
+void FN(prefetchPacked)(JNIEnv *e, jclass c, jlong h, jobject codes, jobject valid, jobject len, jlong n_reads, jlong n_words, jlong piece_reads) {
+    (void)c;
+    int rc = rb_graph_prefetch_packed(G(h), (const uint64_t *)direct(e, codes), (const uint32_t *)direct(e, valid), (const uint32_t *)direct(e, len), n_reads, n_words, piece_reads);
+    if (rc) throw_rc(e, rc);
+}
 jlong FN(batchCreateFastq)(JNIEnv *e, jclass c, jint device, jobject text, jlong len, jboolean final, jint min_q, jboolean use_qual, jlongArray consumed) {
     rb_batch *b = NULL;
     size_t used = 0;

@@ -204,11 +204,16 @@ int rb_graph_destroy(rb_graph *g) {
         delete c;
     }
     g->qfree.clear();
-    for (DevBuf *d : {&g->pk.codes, &g->pk.valid, &g->pk.word_read, &g->pk.woff, &g->pk.len, &g->pk.wc, &g->pk.temp, &g->pk.stats}) d->release();
-    if (g->pk.h_woff) (void)hipHostFree(g->pk.h_woff);
-    if (g->pk.h_stats) (void)hipHostFree(g->pk.h_stats);
-    for (auto e : g->pk.ev) (void)hipEventDestroy(e);
-    if (g->pk.st) (void)hipStreamDestroy(g->pk.st);
+    if (g->pk_stream) (void)hipStreamSynchronize(g->pk_stream);
+    for (auto &K : g->pk) {
+        for (DevBuf *d : {&K.codes, &K.valid, &K.word_read, &K.woff, &K.len, &K.wc, &K.temp, &K.stats}) d->release();
+        if (K.h_woff) (void)hipHostFree(K.h_woff);
+        if (K.h_stats) (void)hipHostFree(K.h_stats);
+        for (auto e : K.ev) (void)hipEventDestroy(e);
+        if (K.ev_woff) (void)hipEventDestroy(K.ev_woff);
+        for (void *p : K.pins) (void)hipHostUnregister(p);
+    }
+    if (g->pk_stream) (void)hipStreamDestroy(g->pk_stream);
     if (g->ev0) (void)hipEventDestroy(g->ev0);
     if (g->ev1) (void)hipEventDestroy(g->ev1);
     if (g->ev2) (void)hipEventDestroy(g->ev2);

@@ -20,7 +20,7 @@ struct HostPin {
     void *p = nullptr;
     // memory that is pinned already (hipHostMalloc'ed, or registered by the caller) is left alone: registering a piece of it again
     // either fails or pins and unpins the pages once more — 8 ms per GB each way, which halved the rate of the packed stream's uploads
-    static bool pinned_already(const void *ptr) {
+    static bool pinned_already(const void *ptr) {     // (public: rb_packed.hip registers arrays that outlive a scope)
         hipPointerAttribute_t a;
         const bool yes = hipPointerGetAttributes(&a, ptr) == hipSuccess && a.type == hipMemoryTypeHost;
         (void)hipGetLastError();

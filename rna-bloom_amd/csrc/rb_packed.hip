@@ -21,6 +21,7 @@
 #include <condition_variable>
 #include <functional>
 #include <mutex>
+#include <utility>
 #include <string>
 #include <thread>
 #include <vector>
@@ -260,93 +261,154 @@ int rb_packed_stream_destroy(rb_packed_stream *s) {
     return RB_OK;
 }
 
+}  // extern "C"
+
+namespace {
+// Everything an insert from packed host memory sends, enqueued on the handle's copy stream without waiting for any of it: the lengths, the kernels
+// that turn them into word offsets and word owners, the offsets' way back into pinned memory (event ev_woff), then codes and valid in pieces cut
+// at WORD boundaries (no offset is needed to cut them), an event behind each.
+void ingest_begin(rb_graph *g, rb_graph::PackedIngest &K, const uint64_t *codes, const uint32_t *valid, const uint32_t *len, int64_t n_reads, int64_t n_words, int64_t piece_reads) {
+    if (!g->pk_stream) RB_HIP(hipStreamCreateWithFlags(&g->pk_stream, hipStreamNonBlocking));
+    hipStream_t st = g->pk_stream;
+    if (!K.h_stats) RB_HIP(hipHostMalloc(reinterpret_cast<void **>(&K.h_stats), 64, hipHostMallocDefault));
+    if (!K.ev_woff) RB_HIP(hipEventCreateWithFlags(&K.ev_woff, hipEventDisableTiming));
+    const size_t nw = (size_t)std::max<int64_t>(n_words, 1), nr = (size_t)n_reads;
+    K.codes.reserve(nw * 8); K.valid.reserve(nw * 4); K.word_read.reserve(nw * 4);
+    K.woff.reserve((nr + 1) * 4); K.len.reserve(nr * 4); K.wc.reserve((nr + 1) * 4); K.stats.reserve(64); K.temp.reserve(scan_temp_bytes(nr + 1));
+    if (K.h_woff_cap < nr + 1) {
+        if (K.h_woff) (void)hipHostFree(K.h_woff);
+        K.h_woff = nullptr; K.h_woff_cap = 0;
+        const size_t want = nr + 1 + (nr >> 3);
+        RB_HIP(hipHostMalloc(reinterpret_cast<void **>(&K.h_woff), want * 4, hipHostMallocDefault));
+        K.h_woff_cap = want;
+    }
+    // the caller's arrays: registered for the upload unless they are pinned already (best effort; pageable memory makes every copy below a blocking one)
+    for (auto pr : {std::make_pair((const void *)codes, (size_t)n_words * 8), std::make_pair((const void *)valid, (size_t)n_words * 4), std::make_pair((const void *)len, nr * 4)})
+        if (pr.first && pr.second > ((size_t)16 << 20) && !getenv("RB_NO_PIN") && !HostPin::pinned_already(pr.first)) {
+            if (hipHostRegister(const_cast<void *>(pr.first), pr.second, hipHostRegisterDefault) == hipSuccess) K.pins.push_back(const_cast<void *>(pr.first));
+            else (void)hipGetLastError();
+        }
+    K.src = codes; K.n_reads = n_reads; K.n_words = n_words; K.inflight = true;
+    uint32_t init[8] = {0u, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u, 0u};
+    memcpy(K.h_stats + 8, init, sizeof init);
+    RB_HIP(hipMemcpyAsync(K.stats.p, K.h_stats + 8, sizeof init, hipMemcpyHostToDevice, st));
+    RB_HIP(hipMemcpyAsync(K.len.p, len, nr * 4, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_packed_words, dim3(std::min<unsigned>(blocks_for(n_reads + 1), 2048u)), dim3(TPB), 0, st, K.len.as<uint32_t>(), n_reads, K.wc.as<uint32_t>(), K.stats.as<uint32_t>());
+    exclusive_scan_u32(K.temp.p, K.temp.cap, K.wc.as<uint32_t>(), K.woff.as<uint32_t>(), nr + 1, st);
+    RB_HIP(hipMemcpyAsync(K.h_stats, K.stats.p, 32, hipMemcpyDeviceToHost, st));
+    RB_HIP(hipMemcpyAsync(K.h_woff, K.woff.p, (nr + 1) * 4, hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(k_packed_word_read, dim3(blocks_for(n_reads)), dim3(TPB), 0, st, K.woff.as<uint32_t>(), n_reads, K.word_read.as<uint32_t>());
+    RB_HIP(hipGetLastError());
+    RB_HIP(hipEventRecord(K.ev_woff, st));
+    // pieces of words: piece_reads reads' worth each (0: 2^22 words — 50 MB, a millisecond of link — doubling up to 2^25)
+    K.wend.clear();
+    {
+        const int64_t wpr = std::max<int64_t>(1, (n_words + n_reads - 1) / std::max<int64_t>(n_reads, 1));
+        int64_t w = 0, step = piece_reads ? std::max<int64_t>(1, piece_reads * wpr) : ((int64_t)1 << 22);
+        while (w < n_words) {
+            w = std::min(n_words, w + step);
+            K.wend.push_back(w);
+            if (!piece_reads) step = std::min<int64_t>(step * 2, (int64_t)1 << 25);
+        }
+    }
+    while (K.ev.size() < K.wend.size()) { hipEvent_t e; RB_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); K.ev.push_back(e); }
+    int64_t w0 = 0;
+    for (size_t p = 0; p < K.wend.size(); ++p) {
+        const int64_t w1 = K.wend[p];
+        RB_HIP(hipMemcpyAsync(K.codes.as<uint64_t>() + w0, codes + w0, (size_t)(w1 - w0) * 8, hipMemcpyHostToDevice, st));
+        RB_HIP(hipMemcpyAsync(K.valid.as<uint32_t>() + w0, valid + w0, (size_t)(w1 - w0) * 4, hipMemcpyHostToDevice, st));
+        RB_HIP(hipEventRecord(K.ev[p], st));
+        w0 = w1;
+    }
+}
+// the upload of a slot is over (or abandoned): wait for it, give the caller's arrays back
+void ingest_end(rb_graph *g, rb_graph::PackedIngest &K) {
+    if (!K.inflight) return;
+    if (!K.wend.empty()) (void)hipEventSynchronize(K.ev[K.wend.size() - 1]);
+    else if (K.ev_woff) (void)hipEventSynchronize(K.ev_woff);
+    for (void *p : K.pins) (void)hipHostUnregister(p);
+    K.pins.clear();
+    K.inflight = false; K.src = nullptr;
+}
+}  // namespace
+
+extern "C" {
+
+// Start the upload of a packed batch that a later rb_graph_add_packed call WITH THE SAME ARRAYS AND SIZES will insert, and return at once: the
+// reader side of the reference's stage 1 fetches the next file while the workers still insert this one (R/RNABloom.java:7123-7188).  The arrays
+// must stay as they are until that call returns.  One batch may be ahead; a second prefetch, or an add of other arrays, first finishes it.
+int rb_graph_prefetch_packed(rb_graph *g, const uint64_t *codes, const uint32_t *valid, const uint32_t *len, int64_t n_reads, int64_t n_words, int64_t piece_reads) {
+    if (!g) { set_error("rb_graph_prefetch_packed: null graph"); return RB_ERR_INVALID; }
+    return guarded([&] {
+        RB_REQUIRE(n_reads > 0 && n_words > 0 && piece_reads >= 0 && len && codes && valid, "rb_graph_prefetch_packed: bad argument");
+        RB_REQUIRE(n_words < 0xFFFFFFF0ll && n_reads < 0xFFFFFFF0ll, "rb_graph_prefetch_packed: batch too large (> 2^32 words)");
+        std::lock_guard<std::mutex> lk(g->pk_mutex);
+        RB_HIP(hipSetDevice(g->p.device));
+        rb_graph::PackedIngest *K = !g->pk[0].inflight ? &g->pk[0] : !g->pk[1].inflight ? &g->pk[1] : nullptr;
+        if (!K) { K = &g->pk[g->pk_busy == 0 ? 1 : 0]; ingest_end(g, *K); }     // both taken: the one no insert is reading gives way
+        ingest_begin(g, *K, codes, valid, len, n_reads, n_words, piece_reads);
+    });
+}
+
 // FastqToGraphWorker.run over reads that are already packed in host memory, as ONE insert call: the device batch is sized for all n_reads reads,
 // the lengths go up first (offsets and word owners are computed on the GPU, the offsets come back into pinned memory for the sub-batch plan),
-// then codes and valid follow on the handle's copy stream in pieces — piece_reads reads each (0: 2^20, doubling up to 2^23: the first piece is
-// all an insert has to wait for) — with an event behind every piece; add_range makes its producer stream wait for the pieces a sub-batch's words
-// lie in (rb_graph::await_words) and otherwise runs exactly as it does on a resident batch: one pipeline over the whole file, upload beside it.
+// codes and valid follow on the handle's copy stream in pieces — piece_reads reads' worth each (0: 2^22 words, doubling up to 2^25: the first
+// piece is all an insert has to wait for) — with an event behind every piece; add_range makes its producer stream wait for the pieces a
+// sub-batch's words lie in (rb_graph::await_words) and otherwise runs exactly as it does on a resident batch: one pipeline over the whole file,
+// the upload beside it.  A batch that rb_graph_prefetch_packed already started (same arrays, same sizes) is picked up where it is.
 // Same filters as rb_graph_add_batch of the same reads.
 int rb_graph_add_packed(rb_graph *g, const uint64_t *codes, const uint32_t *valid, const uint32_t *len, int64_t n_reads, int64_t n_words,
                         int64_t piece_reads, unsigned flags, rb_add_stats *stats) {
     if (stats) memset(stats, 0, sizeof *stats);
     if (!g) { set_error("rb_graph_add_packed: null graph"); return RB_ERR_INVALID; }
     WriteLock wl(g->rw);
-    struct HookOff { rb_graph *g; ~HookOff() { g->await_words = nullptr; } } hook_off{g};
-    int rc = guarded([&] {
+    rb_graph::PackedIngest *K = nullptr;
+    struct Done { rb_graph *g; rb_graph::PackedIngest **K; ~Done() {
+        g->await_words = nullptr;
+        std::lock_guard<std::mutex> lk(g->pk_mutex);
+        if (*K) ingest_end(g, **K);          // (also on failure: the caller's arrays are free again when the call returns)
+        g->pk_busy = -1;
+    } } done{g, &K};
+    return guarded([&] {
         RB_REQUIRE(n_reads >= 0 && n_words >= 0 && piece_reads >= 0 && (n_reads == 0 || len) && (n_words == 0 || (codes && valid)), "rb_graph_add_packed: bad argument");
         RB_REQUIRE(n_words < 0xFFFFFFF0ll && n_reads < 0xFFFFFFF0ll, "rb_graph_add_packed: batch too large (> 2^32 words)");
         if (!n_reads) return;
         RB_HIP(hipSetDevice(g->p.device));
-        rb_graph::PackedIngest &K = g->pk;
-        if (!K.st) RB_HIP(hipStreamCreateWithFlags(&K.st, hipStreamNonBlocking));
-        if (!K.h_stats) RB_HIP(hipHostMalloc(reinterpret_cast<void **>(&K.h_stats), 64, hipHostMallocDefault));
-        const size_t nw = (size_t)std::max<int64_t>(n_words, 1), nr = (size_t)n_reads;
-        K.codes.reserve(nw * 8); K.valid.reserve(nw * 4); K.word_read.reserve(nw * 4);
-        K.woff.reserve((nr + 1) * 4); K.len.reserve(nr * 4); K.wc.reserve((nr + 1) * 4); K.stats.reserve(64); K.temp.reserve(scan_temp_bytes(nr + 1));
-        if (K.h_woff_cap < nr + 1) {
-            if (K.h_woff) (void)hipHostFree(K.h_woff);
-            K.h_woff = nullptr; K.h_woff_cap = 0;
-            const size_t want = nr + 1 + (nr >> 3);
-            RB_HIP(hipHostMalloc(reinterpret_cast<void **>(&K.h_woff), want * 4, hipHostMallocDefault));
-            K.h_woff_cap = want;
+        {
+            std::lock_guard<std::mutex> lk(g->pk_mutex);
+            for (int q = 0; q < 2 && !K; ++q)
+                if (g->pk[q].inflight && g->pk[q].src == codes && g->pk[q].n_reads == n_reads && g->pk[q].n_words == n_words) { K = &g->pk[q]; g->pk_busy = q; }
+            if (!K) {
+                const int q = !g->pk[0].inflight ? 0 : !g->pk[1].inflight ? 1 : 0;
+                if (g->pk[q].inflight) ingest_end(g, g->pk[q]);
+                K = &g->pk[q]; g->pk_busy = q;
+                ingest_begin(g, *K, codes, valid, len, n_reads, n_words, piece_reads);
+            }
         }
-        HostPin p0(codes, (size_t)n_words * 8), p1(valid, (size_t)n_words * 4), p2(len, nr * 4);
-        hipStream_t st = K.st;
-        uint32_t init[8] = {0u, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u, 0u};
-        memcpy(K.h_stats + 8, init, sizeof init);
-        RB_HIP(hipMemcpyAsync(K.stats.p, K.h_stats + 8, sizeof init, hipMemcpyHostToDevice, st));
-        RB_HIP(hipMemcpyAsync(K.len.p, len, nr * 4, hipMemcpyHostToDevice, st));
-        hipLaunchKernelGGL(k_packed_words, dim3(std::min<unsigned>(blocks_for(n_reads + 1), 2048u)), dim3(TPB), 0, st, K.len.as<uint32_t>(), n_reads, K.wc.as<uint32_t>(), K.stats.as<uint32_t>());
-        exclusive_scan_u32(K.temp.p, K.temp.cap, K.wc.as<uint32_t>(), K.woff.as<uint32_t>(), nr + 1, st);
-        RB_HIP(hipMemcpyAsync(K.h_stats, K.stats.p, 32, hipMemcpyDeviceToHost, st));
-        RB_HIP(hipMemcpyAsync(K.h_woff, K.woff.p, (nr + 1) * 4, hipMemcpyDeviceToHost, st));
-        hipLaunchKernelGGL(k_packed_word_read, dim3(blocks_for(n_reads)), dim3(TPB), 0, st, K.woff.as<uint32_t>(), n_reads, K.word_read.as<uint32_t>());
-        RB_HIP(hipGetLastError());
-        // (the pieces are cut at read boundaries, so the offsets have to be here before the first one goes up: 4 bytes per read each way, ~7 ms per 10^8 reads)
-        RB_HIP(hipStreamSynchronize(st));
-        RB_REQUIRE((int64_t)K.h_woff[nr] == n_words, "rb_graph_add_packed: the lengths of %lld reads add up to %u words, %lld were passed", (long long)n_reads, K.h_woff[nr], (long long)n_words);
+        const size_t nr = (size_t)n_reads;
+        RB_HIP(hipEventSynchronize(K->ev_woff));                        // lengths up, offsets back: ~7 ms per 10^8 reads, the pieces keep going meanwhile
+        RB_REQUIRE((int64_t)K->h_woff[nr] == n_words, "rb_graph_add_packed: the lengths of %lld reads add up to %u words, %lld were passed", (long long)n_reads, K->h_woff[nr], (long long)n_words);
         rb_batch b;
         b.device = g->p.device; b.n_reads = n_reads; b.n_words = n_words;
-        b.max_len = K.h_stats[0];
-        b.wpr_uniform = K.h_stats[1] == K.h_stats[2] ? K.h_stats[1] : 0u;
-        b.n_bases = (int64_t)(((uint64_t)K.h_stats[5] << 32) | K.h_stats[4]);
-        b.codes = K.codes.as<uint64_t>(); b.valid = K.valid.as<uint32_t>(); b.word_read = K.word_read.as<uint32_t>();
-        b.woff = K.woff.as<uint32_t>(); b.len = K.len.as<uint32_t>(); b.rnz = nullptr;
-        b.device_bytes = nw * 16 + (nr + 1) * 4 + nr * 4;
-        b.h_woff.borrow(K.h_woff, nr + 1);
-        // pieces: read boundaries -> word boundaries; an event behind each
-        std::vector<int64_t> wend;
-        {
-            int64_t r = 0, step = piece_reads ? piece_reads : ((int64_t)1 << 20);
-            while (r < n_reads) {
-                r = std::min(n_reads, r + step);
-                wend.push_back((int64_t)K.h_woff[(size_t)r]);
-                if (!piece_reads) step = std::min<int64_t>(step * 2, (int64_t)1 << 23);
-            }
-        }
-        while (K.ev.size() < wend.size()) { hipEvent_t e; RB_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); K.ev.push_back(e); }
-        int64_t w0 = 0;
-        for (size_t p = 0; p < wend.size(); ++p) {
-            const int64_t w1 = wend[p];
-            if (w1 > w0) {
-                RB_HIP(hipMemcpyAsync(K.codes.as<uint64_t>() + w0, codes + w0, (size_t)(w1 - w0) * 8, hipMemcpyHostToDevice, st));
-                RB_HIP(hipMemcpyAsync(K.valid.as<uint32_t>() + w0, valid + w0, (size_t)(w1 - w0) * 4, hipMemcpyHostToDevice, st));
-            }
-            RB_HIP(hipEventRecord(K.ev[p], st));
-            w0 = w1;
-        }
-        size_t waited = 0;                                   // pieces [0, waited) are known to the streams that asked
-        g->await_words = [&](int64_t w_end, hipStream_t on) {
+        b.max_len = K->h_stats[0];
+        b.wpr_uniform = K->h_stats[1] == K->h_stats[2] ? K->h_stats[1] : 0u;
+        b.n_bases = (int64_t)(((uint64_t)K->h_stats[5] << 32) | K->h_stats[4]);
+        b.codes = K->codes.as<uint64_t>(); b.valid = K->valid.as<uint32_t>(); b.word_read = K->word_read.as<uint32_t>();
+        b.woff = K->woff.as<uint32_t>(); b.len = K->len.as<uint32_t>(); b.rnz = nullptr;
+        b.device_bytes = (size_t)std::max<int64_t>(n_words, 1) * 16 + (nr + 1) * 4 + nr * 4;
+        b.h_woff.borrow(K->h_woff, nr + 1);
+        size_t waited = 0;                                   // the producer stream has been told to wait for pieces [0, waited)
+        const std::vector<int64_t> &wend = K->wend;
+        rb_graph::PackedIngest *Kc = K;
+        g->await_words = [&waited, &wend, Kc](int64_t w_end, hipStream_t on) {
             size_t need = 0;
-            while (need < wend.size() && (need == 0 ? 0 : wend[need - 1]) < w_end) ++need;      // pieces 0 .. need-1 cover words [0, w_end)
-            // (the producer stream asks in increasing order; a stream waits for the LAST piece it needs: the copy stream is in order)
-            if (need > 0 && need > waited) { RB_HIP(hipStreamWaitEvent(on, K.ev[need - 1], 0)); waited = need; }
+            while (need < wend.size() && (need == 0 ? 0 : wend[need - 1]) < w_end) ++need;      // pieces 0 .. need - 1 cover words [0, w_end)
+            // (the producer stream asks in increasing order; waiting for the LAST piece it needs is enough: the copy stream is in order)
+            if (need > waited) { RB_HIP(hipStreamWaitEvent(on, Kc->ev[need - 1], 0)); waited = need; }
         };
-        struct Drain { hipStream_t st; ~Drain() { (void)hipStreamSynchronize(st); } } drain{st};     // the caller's buffers are free again when the call returns
         add_range(g, &b, 0, n_reads, flags, stats);
         b.codes = nullptr; b.valid = nullptr; b.word_read = nullptr; b.woff = nullptr; b.len = nullptr;
     });
-    return rc;
 }
 
 }  // extern "C"

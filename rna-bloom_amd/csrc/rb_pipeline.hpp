@@ -411,9 +411,18 @@ struct rb_graph {
         DevBuf codes, valid, word_read, woff, len, wc, temp, stats;
         uint32_t *h_woff = nullptr, *h_stats = nullptr;
         size_t h_woff_cap = 0;
-        hipStream_t st = nullptr;
-        std::vector<hipEvent_t> ev;
-    } pk;
+        std::vector<hipEvent_t> ev;              // one behind every uploaded piece
+        hipEvent_t ev_woff = nullptr;            // the word offsets are back in h_woff
+        std::vector<int64_t> wend;               // piece p holds words [wend[p - 1], wend[p])
+        // the upload in flight (rb_graph_prefetch_packed, or the add call itself): whose arrays, how many
+        const void *src = nullptr;
+        int64_t n_reads = 0, n_words = 0;
+        bool inflight = false;
+        std::vector<void *> pins;                // caller's arrays registered for the upload (hipHostUnregister when it is over)
+    } pk[2];
+    hipStream_t pk_stream = nullptr;             // the copy stream both slots upload on (in order: a prefetch queues behind the batch before it)
+    std::mutex pk_mutex;                         // slots are handed out under it (a prefetch may come from another thread than the insert)
+    int pk_busy = -1;                            // the slot the running rb_graph_add_packed reads
     hipEvent_t prof_event() {
         if (!prof_pool.empty()) { hipEvent_t e = prof_pool.back(); prof_pool.pop_back(); return e; }
         hipEvent_t e; RB_HIP(hipEventCreate(&e)); return e;

@@ -118,6 +118,7 @@ SYMBOLS = [
     ("rb_packed_stream_finish", _i32, [_vp, C.POINTER(_vp)]),
     ("rb_packed_stream_destroy", _i32, [_vp]),
     ("rb_graph_add_packed", _i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64, C.c_uint, C.POINTER(AddStats)]),
+    ("rb_graph_prefetch_packed", _i32, [_vp, _vp, _vp, _vp, _i64, _i64, _i64]),
     ("rb_graph_create_shard", _i32, [C.POINTER(GraphParams), _i32, _i32, C.POINTER(_vp)]),
     ("rb_shard_set_cache_replication", _i32, [_vp, _i32]),
     ("rb_shard_hash", _i32, [_vp, _vp, _i64, _i64, _i64, _i64, _u64, _u32, C.c_uint, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(AddStats)]),

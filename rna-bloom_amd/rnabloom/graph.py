@@ -282,6 +282,13 @@ class BloomFilterDeBruijnGraph:
                                       n, w1 - w0, pieceReads, flags, C.byref(st)))
         return st
 
+    def prefetchPacked(self, ph, first=0, n=None, pieceReads=0):
+        """start the upload of reads [first, first + n) of a PackedHost and return: a later addPacked of the same range picks it up where it is
+        (rb_graph_prefetch_packed: the next file travels while this one is inserted)"""
+        n = ph.n_reads - first if n is None else n
+        w0, w1 = ph.words_before(first), ph.words_before(first + n)
+        check(lib.rb_graph_prefetch_packed(self.h, ph.codes.ctypes.data + 8 * w0, ph.valid.ctypes.data + 4 * w0, ph.len.ctypes.data + 4 * first, n, w1 - w0, pieceReads))
+
     def addFastq(self, text, minBaseQual=3, reverseComplement=False, incrementIfPresent=False, storeReadPairedKmers=False):
         """the text of a FASTQ file (bytes / uint8 array / np.memmap) through FastqToGraphWorker's loop, R/RNABloom.java:526-643:
         uploaded as it is, records found and 2-bit encoded on the GPU; returns (stats, records)"""
