@@ -417,9 +417,13 @@ struct CsLookup {
 };
 // Stage B sets every run with a shared counter aside (they are few: the list `cand`); these three kernels decide which of them
 // need the ordered replay and finish the others.  All of it runs behind the point where the producer is released.
-// (1) per shared counter: how many candidates can reach it
+// (1) per shared counter: how many candidates can reach it.  The table lookups are done HERE, once: cslot[i * h + j] = the slot of candidate i's
+// counter j in the set (CS_NONE: not shared), bit 31 = the candidate can reach it — the closure rounds, the deferred resolve and (after the
+// compaction) the component labelling index the table directly instead of hashing and probing again in every round (long reads, every k-mer
+// re-sighted: 5 M candidates per sub-batch, 7 labelling rounds and 6 closure rounds of two lookups each were 170 of a pass's 1060 ms)
+constexpr uint32_t CS_NONE = 0xFFFFFFFFu, CS_REACH = 0x80000000u;
 __global__ void k_cs_writers(FilterView fv, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ nops, const uint32_t *__restrict__ cand,
-                             uint32_t n_cand, const uint64_t *__restrict__ cvals, CsLookup L, uint32_t *__restrict__ writers) {
+                             uint32_t n_cand, const uint64_t *__restrict__ cvals, CsLookup L, uint32_t *__restrict__ writers, uint32_t *__restrict__ cslot) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_cand) return;
     const uint32_t d = cand[i];
@@ -433,35 +437,30 @@ __global__ void k_cs_writers(FilterView fv, const uint64_t *__restrict__ uniq, c
         bool dup = false;
         for (int q = 0; q < j; ++q) dup |= seen[q] == idx;
         seen[j] = idx;
-        if (dup || ((uint32_t)(cv0 >> (8 * j)) & 0xFFu) > reach) continue;       // (the same counter twice: one run, one writer)
         const Slot *sl = L.find(idx);
-        if (sl) atomicAdd(&writers[sl - L.cs], 1u);
+        const bool can = ((uint32_t)(cv0 >> (8 * j)) & 0xFFu) <= reach;
+        cslot[(size_t)i * fv.cbf_h + j] = sl ? ((uint32_t)(sl - L.cs) | (can ? CS_REACH : 0u)) : CS_NONE;
+        if (sl && can && !dup) atomicAdd(&writers[sl - L.cs], 1u);           // (the same counter twice: one run, one writer)
     }
 }
 // (2) repeated until nothing changes: the closure.  cflag[slot] = a run of O claimed the counter; ordered[i] = cand[i] is in O.
-__global__ void k_cs_order(FilterView fv, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ nops, const uint32_t *__restrict__ cand,
-                           uint32_t n_cand, const uint64_t *__restrict__ cvals, CsLookup L, const uint32_t *__restrict__ writers,
+__global__ void k_cs_order(int h, uint32_t n_cand, const uint32_t *__restrict__ cslot, const uint32_t *__restrict__ writers,
                            uint32_t *__restrict__ cflag, uint32_t *__restrict__ ordered, uint32_t *__restrict__ changed, int everything) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_cand || ordered[i]) return;
-    const uint32_t d = cand[i];
-    const uint64_t cv0 = cvals[d], h0 = uniq[d];
-    uint32_t m0 = 255;
-    for (int j = 0; j < fv.cbf_h; ++j) { const uint32_t c = (uint32_t)(cv0 >> (8 * j)) & 0xFFu; m0 = c < m0 ? c : m0; }
-    const uint32_t reach = m0 + nops[d] - 1u;
-    const Slot *sl[RB_MAX_HASH];
+    uint32_t sl[RB_MAX_HASH];
     bool ord = everything != 0;                                     // (the closure did not settle in time: every candidate is ordered)
-    for (int j = 0; j < fv.cbf_h; ++j) {
-        sl[j] = L.find(index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod));
-        if (sl[j] && ((uint32_t)(cv0 >> (8 * j)) & 0xFFu) <= reach) {
-            const size_t q = (size_t)(sl[j] - L.cs);
+    for (int j = 0; j < h; ++j) {
+        sl[j] = cslot[(size_t)i * h + j];
+        if (sl[j] != CS_NONE && (sl[j] & CS_REACH)) {
+            const uint32_t q = sl[j] & ~CS_REACH;
             if (writers[q] >= 2u || __hip_atomic_load(&cflag[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) ord = true;
         }
     }
     if (!ord) return;
     ordered[i] = 1u;
-    for (int j = 0; j < fv.cbf_h; ++j)
-        if (sl[j]) __hip_atomic_store(&cflag[sl[j] - L.cs], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int j = 0; j < h; ++j)
+        if (sl[j] != CS_NONE) __hip_atomic_store(&cflag[sl[j] & ~CS_REACH], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     *changed = 1u;
 }
 // the ops of one light run on the register copy of its counters, the write-back, the prefilter cache (stage B proper and (3) below).
@@ -490,7 +489,7 @@ __device__ __forceinline__ void apply_light_run(const FilterView &fv, uint64_t h
 // (3) the candidates outside O: finished here (light) or handed to k_cbf_heavy (flag heavy2[i]); those of O keep RUN_CONFLICT
 __global__ void k_resolve_deferred(FilterView fv, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ counts, const uint32_t *__restrict__ starts,
                                    const uint32_t *__restrict__ vals, const uint32_t *__restrict__ cand, uint32_t n_cand, const uint32_t *__restrict__ ordered,
-                                   int mode, uint32_t LIGHT_OPS, CsLookup L, uint32_t *__restrict__ status, const uint32_t *__restrict__ nops,
+                                   int mode, uint32_t LIGHT_OPS, const uint32_t *__restrict__ cslot, uint32_t *__restrict__ status, const uint32_t *__restrict__ nops,
                                    const uint64_t *__restrict__ cvals, const uint8_t *__restrict__ tz, uint32_t *__restrict__ heavy2) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_cand) return;
@@ -504,7 +503,7 @@ __global__ void k_resolve_deferred(FilterView fv, const uint64_t *__restrict__ u
     uint32_t shared = 0;
     for (int j = 0; j < fv.cbf_h; ++j) {
         idx[j] = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod);
-        if (L.find(idx[j])) shared |= 1u << j;
+        if (cslot[(size_t)i * fv.cbf_h + j] != CS_NONE) shared |= 1u << j;
     }
     apply_light_run(fv, h0, vals[starts[d]], idx, cvals[d], shared, (st >> 12) & 3u, (st >> 14) & 3u, tz, starts[d] + counts[d] - ops, ops, mode);
 }
@@ -638,36 +637,43 @@ __global__ void k_conf_offsets(const uint32_t *__restrict__ conf_kmers, const ui
 // connected components of the "shares a counter" graph between conflicting k-mers, by min-label
 // propagation through the claim-table slots (components are tiny: the graph is far below the
 // percolation threshold for any sane filter size).  slot.lo starts as the smallest owner id.
-__global__ void k_label_init(const uint32_t *__restrict__ conf_kmers, uint32_t n_conf, uint32_t *__restrict__ label) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_conf) label[conf_kmers[i]] = conf_kmers[i];
-}
-__global__ void k_label_push(FilterView fv, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ conf_kmers,
-                             uint32_t n_conf, Slot *ctable, uint32_t c_log2, const uint32_t *__restrict__ label) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_conf) return;
-    const uint32_t d = conf_kmers[i], l = label[d];
-    const uint64_t h0 = uniq[d];
-    for (int j = 0; j < fv.cbf_h; ++j) {
-        Slot *sl = const_cast<Slot *>(table_find(ctable, c_log2, index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod)));
-        if (sl) atomicMin(reinterpret_cast<uint32_t *>(&sl->val), l);   // unshared counters are not in the set
-    }
-}
-__global__ void k_label_pull(FilterView fv, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ conf_kmers,
-                             uint32_t n_conf, const Slot *ctable, uint32_t c_log2, uint32_t *__restrict__ label,
-                             uint32_t *__restrict__ changed) {
+// (the table lookups once, into lslot[i * h + j] = slot or CS_NONE; every round then indexes the table)
+__global__ void k_label_init(FilterView fv, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ conf_kmers, uint32_t n_conf,
+                             const Slot *ctable, uint32_t c_log2, uint32_t *__restrict__ label, uint32_t *__restrict__ lslot) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_conf) return;
     const uint32_t d = conf_kmers[i];
+    label[d] = d;
     const uint64_t h0 = uniq[d];
-    uint32_t l = label[d], l0 = l;
     for (int j = 0; j < fv.cbf_h; ++j) {
         const Slot *sl = table_find(ctable, c_log2, index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod));
-        if (!sl) continue;
-        uint32_t v = __hip_atomic_load(reinterpret_cast<const uint32_t *>(&sl->val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lslot[(size_t)i * fv.cbf_h + j] = sl ? (uint32_t)(sl - ctable) : CS_NONE;          // unshared counters are not in the set
+    }
+}
+// One round of the propagation, pull and push in one kernel and in no particular order between the runs (every update is a min: any order
+// ends at the component's smallest run id): a run takes the smallest label its counters have seen, follows its own label one step (label[l] is
+// a run of the same component with a label at most l: pointer jumping, the long chains of a big component shrink by halves), and hands the
+// result to its counters.  A fixed point has label[d] == slot value on every edge; `changed` says whether this round moved anything.
+__global__ void k_label_round(int h, const uint32_t *__restrict__ conf_kmers, uint32_t n_conf, Slot *ctable, const uint32_t *__restrict__ lslot,
+                              uint32_t *__restrict__ label, uint32_t *__restrict__ changed) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_conf) return;
+    const uint32_t d = conf_kmers[i];
+    const uint32_t l0 = __hip_atomic_load(&label[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t l = l0, sl[RB_MAX_HASH];
+    for (int j = 0; j < h; ++j) {
+        sl[j] = lslot[(size_t)i * h + j];
+        if (sl[j] == CS_NONE) continue;
+        const uint32_t v = __hip_atomic_load(reinterpret_cast<const uint32_t *>(&ctable[sl[j]].val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         l = v < l ? v : l;
     }
-    if (l != l0) { label[d] = l; *changed = 1u; }
+    const uint32_t up = __hip_atomic_load(&label[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    l = up < l ? up : l;
+    bool moved = l != l0;
+    if (moved) __hip_atomic_store(&label[d], l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int j = 0; j < h; ++j)
+        if (sl[j] != CS_NONE && atomicMin(reinterpret_cast<uint32_t *>(&ctable[sl[j]].val), l) > l) moved = true;
+    if (moved) *changed = 1u;
 }
 __global__ void k_conf_kmer_keys(const uint32_t *__restrict__ conf_kmers, const uint32_t *__restrict__ label,
                                  uint32_t n_conf, uint64_t *__restrict__ keys) {
@@ -1674,23 +1680,25 @@ void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, ui
         const size_t slots = (size_t)1 << c_log2;
         g->cwriters.reserve(slots * 8 + 64);
         const size_t cs_stride = ((size_t)nc0 + 1 + 3) / 4 * 4;                     // (16-byte aligned sub-arrays: the scans below take their vectorised path)
-        g->cshared.reserve(cs_stride * 4 * 5 + 64);
+        const size_t hh = (size_t)fv.cbf_h;
+        g->cshared.reserve(cs_stride * 4 * (5 + hh) + 64);
         RB_HIP(hipMemsetAsync(g->cwriters.p, 0, slots * 8 + 64, s));
         uint32_t *writers = g->cwriters.as<uint32_t>(), *cflag = writers + slots, *changed = cflag + slots;
         uint32_t *ordered = g->cshared.as<uint32_t>(), *heavy2 = ordered + cs_stride, *pos_o = heavy2 + cs_stride, *pos_h = pos_o + cs_stride,
-                 *heavy2_list = pos_h + cs_stride;
+                 *heavy2_list = pos_h + cs_stride, *cslot = heavy2_list + cs_stride;      // cslot: [nc0][h] table slots of the candidates' counters
         RB_HIP(hipMemsetAsync(ordered, 0, cs_stride * 4 * 2, s));
         const CsLookup L{g->ctable.as<Slot>(), c_log2, csf, csf_log2};
         const uint32_t *cand = g->confk.as<uint32_t>();
-        hipLaunchKernelGGL(k_cs_writers, dim3(blocks_for(nc0)), dim3(TPB), 0, s, fv, uniq, nops, cand, nc0, g->cvals.as<uint64_t>(), L, writers);
+        hipLaunchKernelGGL(k_cs_writers, dim3(blocks_for(nc0)), dim3(TPB), 0, s, fv, uniq, nops, cand, nc0, g->cvals.as<uint64_t>(), L, writers, cslot);
         // the closure takes 2-3 rounds plus the one that finds nothing new; a round after the fixed point changes nothing, so the
-        // rounds go out three at a time and only the last one's flag is read back (one host round trip instead of three or four)
+        // rounds of a SHORT list go out three at a time and only the last one's flag is read back (one host round trip instead of three or
+        // four); where a round is worth more than a round trip (a million candidates and more: long reads) the flag is read after every round
+        const int per_look = nc0 >= (1u << 20) ? 1 : 3;
         for (int round = 0;;) {
             int everything = 0;
-            for (int q = 0; q < 3; ++q, ++round) {
+            for (int q = 0; q < per_look; ++q, ++round) {
                 everything = round >= 16 ? 1 : 0;
-                hipLaunchKernelGGL(k_cs_order, dim3(blocks_for(nc0)), dim3(TPB), 0, s, fv, uniq, nops, cand, nc0, g->cvals.as<uint64_t>(), L, writers, cflag, ordered,
-                                   changed + (round & 7), everything);
+                hipLaunchKernelGGL(k_cs_order, dim3(blocks_for(nc0)), dim3(TPB), 0, s, (int)fv.cbf_h, nc0, cslot, writers, cflag, ordered, changed + (round & 7), everything);
                 if (everything) { ++round; break; }
             }
             const int last = round - 1;
@@ -1700,7 +1708,7 @@ void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, ui
             if (!ch || everything) break;
             RB_HIP(hipMemsetAsync(changed, 0, 32, s));
         }
-        hipLaunchKernelGGL(k_resolve_deferred, dim3(blocks_for(nc0)), dim3(TPB), 0, s, fv, uniq, counts, starts, vals, cand, nc0, ordered, mode, g->light_ops, L,
+        hipLaunchKernelGGL(k_resolve_deferred, dim3(blocks_for(nc0)), dim3(TPB), 0, s, fv, uniq, counts, starts, vals, cand, nc0, ordered, mode, g->light_ops, cslot,
                            status, nops, g->cvals.as<uint64_t>(), g->tz().as<uint8_t>(), heavy2);
         g->prof_end("conflict_set");
         release();                                                             // (enqueues the next sub-batch's producer work; may wait on the host)
@@ -1750,16 +1758,18 @@ void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, ui
         uint32_t *label = g->label.as<uint32_t>();
         hipLaunchKernelGGL(k_conf_release, dim3(blocks_for(nck)), dim3(TPB), 0, s, fv, uniq, confk, nck);
         // components by min-label propagation; ctr[3] = changed flag, ctr[4] = number of big components
-        hipLaunchKernelGGL(k_label_init, dim3(blocks_for(nck)), dim3(TPB), 0, s, confk, nck, label);
-        for (int it = 0;; ++it) {                                // (two propagation rounds per look at the flag: most components settle in 3-4)
+        // (table slots of the runs' counters, looked up once; the scratch is opk1's — free until the sort of the replay keys below)
+        g->opk1.reserve(std::max((size_t)nco * 8, (size_t)nck * fv.cbf_h * 4));
+        uint32_t *lslot = g->opk1.as<uint32_t>();
+        hipLaunchKernelGGL(k_label_init, dim3(blocks_for(nck)), dim3(TPB), 0, s, fv, uniq, confk, nck, g->ctable.as<Slot>(), c_log2, label, lslot);
+        // one kernel per round (pull, one pointer jump, push); the flag is looked at after every round where a round is long (a million runs
+        // and more), after every second one otherwise — most components are pairs and settle in two rounds
+        const int per_look = nck >= (1u << 20) ? 1 : 2;
+        for (int it = 0;; ++it) {
             RB_REQUIRE(it < 100000, "component labelling did not converge");
             RB_HIP(hipMemsetAsync(ctr + 3, 0, 4, s));
-            for (int q = 0; q < 2; ++q) {
-                hipLaunchKernelGGL(k_label_push, dim3(blocks_for(nck)), dim3(TPB), 0, s, fv, uniq, confk, nck,
-                                   g->ctable.as<Slot>(), c_log2, label);
-                hipLaunchKernelGGL(k_label_pull, dim3(blocks_for(nck)), dim3(TPB), 0, s, fv, uniq, confk, nck,
-                                   g->ctable.as<Slot>(), c_log2, label, ctr + 3);
-            }
+            for (int q = 0; q < per_look; ++q)
+                hipLaunchKernelGGL(k_label_round, dim3(blocks_for(nck)), dim3(TPB), 0, s, (int)fv.cbf_h, confk, nck, g->ctable.as<Slot>(), lslot, label, ctr + 3);
             uint32_t changed = 0;
             RB_HIP(hipMemcpyAsync(&changed, ctr + 3, 4, hipMemcpyDeviceToHost, s));
             RB_HIP(hipStreamSynchronize(s));
