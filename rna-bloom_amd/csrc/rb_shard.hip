@@ -551,19 +551,25 @@ __global__ void k_edge_init(const ConfEdge *__restrict__ e, size_t n, Slot *tab,
     eslot[i] = (uint32_t)(table_insert(tab, log2cap, e[i].cidx) - tab);
     label[e[i].gid] = e[i].gid;
 }
-__global__ void k_edge_push(const ConfEdge *__restrict__ e, size_t n, Slot *tab, const uint32_t *__restrict__ eslot,
-                            const uint32_t *__restrict__ label) {
+// One round per kernel, one thread per edge (run, contested counter), in no particular order (every update is a min, any order ends at the
+// component's smallest run id — the same on every rank, which is all that matters): the edge takes the smaller of its run's label and its
+// counter's, follows the label one step (label[l] is a run of the same component with a label at most l: pointer jumping), and hands the result
+// to both ends.  A fixed point has equal values on both ends of every edge; `changed` says whether this round moved anything.
+__global__ void k_edge_round(const ConfEdge *__restrict__ e, size_t n, Slot *tab, const uint32_t *__restrict__ eslot,
+                             uint32_t *__restrict__ label, uint32_t *__restrict__ changed) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t l = __hip_atomic_load(&label[e[i].gid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    atomicMin(reinterpret_cast<uint32_t *>(&tab[eslot[i]].val), l);
-}
-__global__ void k_edge_pull(const ConfEdge *__restrict__ e, size_t n, const Slot *tab, const uint32_t *__restrict__ eslot,
-                            uint32_t *__restrict__ label, uint32_t *__restrict__ changed) {
-    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint32_t l = __hip_atomic_load(reinterpret_cast<const uint32_t *>(&tab[eslot[i]].val), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (atomicMin(&label[e[i].gid], l) > l) *changed = 1u;
+    const uint32_t gid = e[i].gid;
+    uint32_t *cv = reinterpret_cast<uint32_t *>(&tab[eslot[i]].val);
+    const uint32_t lr = __hip_atomic_load(&label[gid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t lc = __hip_atomic_load(cv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t l = lc < lr ? lc : lr;
+    const uint32_t up = __hip_atomic_load(&label[l], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    l = up < l ? up : l;
+    bool moved = false;
+    if (l < lr && atomicMin(&label[gid], l) > l) moved = true;
+    if (l < lc && atomicMin(cv, l) > l) moved = true;
+    if (moved) *changed = 1u;
 }
 __global__ void k_conf_desc(const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ conf_list, const uint32_t *__restrict__ status,
                             const uint32_t *__restrict__ nops, const uint64_t *__restrict__ cvals, const uint32_t *__restrict__ label,
@@ -1699,8 +1705,8 @@ int rb_shard_conflict_route(rb_graph *g, const void *edges_dev, int64_t n_edges,
         for (int it = 0;; ++it) {
             RB_REQUIRE(it < 100000, "conflict component labelling did not converge");
             RB_HIP(hipMemsetAsync(ctr + 3, 0, 4, s));
-            hipLaunchKernelGGL(k_edge_push, dim3(blocks_for((int64_t)ne)), dim3(TPB), 0, s, e, ne, S->etab.as<Slot>(), S->eslot.as<uint32_t>(), S->elabel.as<uint32_t>());
-            hipLaunchKernelGGL(k_edge_pull, dim3(blocks_for((int64_t)ne)), dim3(TPB), 0, s, e, ne, S->etab.as<Slot>(), S->eslot.as<uint32_t>(), S->elabel.as<uint32_t>(), ctr + 3);
+            for (int q = 0; q < (ne >= ((size_t)1 << 20) ? 1 : 2); ++q)      // (a short list: two rounds per look at the flag — most components are pairs)
+                hipLaunchKernelGGL(k_edge_round, dim3(blocks_for((int64_t)ne)), dim3(TPB), 0, s, e, ne, S->etab.as<Slot>(), S->eslot.as<uint32_t>(), S->elabel.as<uint32_t>(), ctr + 3);
             uint32_t changed = 0;
             RB_HIP(hipMemcpyAsync(&changed, ctr + 3, 4, hipMemcpyDeviceToHost, s));
             RB_HIP(hipStreamSynchronize(s));
