@@ -198,7 +198,6 @@ int rb_graph_destroy(rb_graph *g) {
                       &g->conf_sizes, &g->conf_off, &g->opk0, &g->opk1, &g->opv0, &g->opv1, &g->label, &g->kk0, &g->kk1, &g->biglist, &g->cvals, &g->foreign,  &g->devctr, &g->cwriters, &g->cshared, &g->comm_keep, &g->comm_dreply, &g->comm_creply, &g->qbuf0,
                       &g->qbuf1, &g->qbuf2, &g->qbuf3};
     for (auto *b : bufs) b->release();
-    g->conf_big.release();
     for (rb_query_ctx *c : g->qfree) {
         c->b0.release(); c->b1.release(); c->b2.release(); c->b3.release();
         if (c->st) (void)hipStreamDestroy(c->st);

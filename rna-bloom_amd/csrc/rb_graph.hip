@@ -760,84 +760,6 @@ __global__ void k_conf_replay_small(FilterView fv, const uint64_t *__restrict__ 
             if (mn >= 16u && mn < 128u) cache_store(fv, h0, vals[starts[dq]], cache_exp(mn));
         }
 }
-// The same replay WITHOUT the expanded, globally sorted op list (round 6).  A run's pending occurrences already lie in occurrence order in the
-// grouped array (vals[start + count - ops ..)), so a component of a few runs is a k-way merge of a few sorted lists: the head thread of a
-// component (runs sorted by label, like above) keeps one cursor per run and always takes the run whose next occurrence id is smallest — the
-// global occurrence order restricted to the component.  No k_conf_expand, no 50-bit LSD sort of (label, occurrence) keys: on config 2 that sort
-// was two thirds of the conflict path's tail (21 of 30 ms per step) for components of which none is large.  Components beyond MERGE_RUNS runs or
-// SMALL_COMPONENT_OPS ops set big_flag on their runs and go through the expand / sort / replay kernels above as before (rare).
-constexpr uint32_t MERGE_RUNS = 8;
-__global__ void k_conf_replay_merge(FilterView fv, const uint64_t *__restrict__ uniq, const uint64_t *__restrict__ kmer_keys, uint32_t n_conf,
-                                    const uint32_t *__restrict__ counts, const uint32_t *__restrict__ starts, const uint32_t *__restrict__ vals,
-                                    const uint32_t *__restrict__ status, const uint32_t *__restrict__ nops, uint32_t *__restrict__ big_flag,
-                                    uint32_t *__restrict__ n_big_runs, int store_cache, uint32_t max_ops) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_conf) return;
-    const uint32_t lab = (uint32_t)(kmer_keys[i] >> 32);
-    if (i > 0 && (uint32_t)(kmer_keys[i - 1] >> 32) == lab) return;   // not a component head
-    uint32_t nr = 0, total = 0;
-    uint32_t p[MERGE_RUNS], e[MERGE_RUNS], nxt[MERGE_RUNS], kinds[MERGE_RUNS];    // cursor / end into vals, next occurrence id, kfirst | krest << 2 | first-op flag << 4
-    uint64_t h0[MERGE_RUNS];
-    uint32_t q = i;
-    for (; q < n_conf && (uint32_t)(kmer_keys[q] >> 32) == lab; ++q) {
-        if (nr < MERGE_RUNS) {
-            const uint32_t d = (uint32_t)kmer_keys[q], ops = nops[d], st = status[d];
-            const uint32_t base = starts[d] + counts[d] - ops;
-#pragma unroll
-            for (uint32_t r = 0; r < MERGE_RUNS; ++r)
-                if (r == nr) { p[r] = base; e[r] = base + ops; nxt[r] = ops ? vals[base] : 0xFFFFFFFFu; kinds[r] = ((st >> 12) & 3u) | (((st >> 14) & 3u) << 2) | 16u; h0[r] = uniq[d]; }
-            total += ops;
-        }
-        ++nr;
-    }
-    if (nr > MERGE_RUNS || total > max_ops) {              // a large component: the sorted-list kernels take it
-        for (uint32_t z = i; z < q; ++z) big_flag[z] = 1u;
-        atomicAdd(n_big_runs, q - i);
-        return;
-    }
-#pragma unroll
-    for (uint32_t r = 0; r < MERGE_RUNS; ++r) if (r >= nr) { p[r] = e[r] = 0; nxt[r] = 0xFFFFFFFFu; kinds[r] = 0; h0[r] = 0; }
-    for (uint32_t it = 0; it < total; ++it) {
-        uint32_t sel = 0, best = nxt[0];
-#pragma unroll
-        for (uint32_t r = 1; r < MERGE_RUNS; ++r) if (nxt[r] < best) { best = nxt[r]; sel = r; }      // (occurrence ids are distinct: no ties)
-        uint64_t h = 0; uint32_t kd = 0;
-#pragma unroll
-        for (uint32_t r = 0; r < MERGE_RUNS; ++r) if (r == sel) { h = h0[r]; kd = kinds[r]; }
-        const uint32_t kind = (kd & 16u) ? (kd & 3u) : ((kd >> 2) & 3u);
-        uint64_t idx[RB_MAX_HASH];
-        uint32_t c[RB_MAX_HASH], c0[RB_MAX_HASH];
-        for (int j = 0; j < fv.cbf_h; ++j) {
-            idx[j] = index_of(multi_hash(h, (uint32_t)j, fv.kmul), fv.cbf_mod);
-            c0[j] = c[j] = *(volatile uint8_t *)&fv.cbf[idx[j]];
-        }
-        uint32_t mn = c[0];
-        for (int j = 1; j < fv.cbf_h; ++j) mn = c[j] < mn ? c[j] : mn;
-        cbf_step(c, fv.cbf_h, kind, (mn >= 16u && mn < 127u) ? occ_rnd(fv, best) : 0u);
-        for (int j = 0; j < fv.cbf_h; ++j)
-            if (c[j] != c0[j]) *(volatile uint8_t *)&fv.cbf[idx[j]] = (uint8_t)c[j];
-#pragma unroll
-        for (uint32_t r = 0; r < MERGE_RUNS; ++r)
-            if (r == sel) { ++p[r]; kinds[r] &= 15u; nxt[r] = p[r] < e[r] ? vals[p[r]] : 0xFFFFFFFFu; }
-    }
-    if (store_cache && cache_on(fv))   // the component's k-mers are in dbgbf; remember their counter exponents
-        for (uint32_t z = i; z < q; ++z) {
-            const uint32_t dq = (uint32_t)kmer_keys[z];
-            const uint64_t hz = uniq[dq];
-            uint32_t mn = 255u;
-            for (int j = 0; j < fv.cbf_h; ++j) {
-                const uint32_t cc = *(volatile uint8_t *)&fv.cbf[index_of(multi_hash(hz, (uint32_t)j, fv.kmul), fv.cbf_mod)];
-                mn = cc < mn ? cc : mn;
-            }
-            if (mn >= 16u && mn < 128u) cache_store(fv, hz, vals[starts[dq]], cache_exp(mn));
-        }
-}
-// the runs of the large components, in label order (flags from k_conf_replay_merge; pos = exclusive scan of the flags)
-__global__ void k_conf_big_runs(const uint64_t *__restrict__ kmer_keys, const uint32_t *__restrict__ flag, const uint32_t *__restrict__ pos, uint32_t n,
-                                uint32_t *__restrict__ out) {
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n && flag[i]) out[pos[i]] = (uint32_t)kmer_keys[i];
-}
 // one wavefront per large component: the component's counters live in LDS; 64 ops are examined at
 // a time against the current state and the chain hops from one state-changing op to the next
 __global__ void __launch_bounds__(64) k_conf_replay_big(FilterView fv, const uint64_t *__restrict__ uniq,
@@ -1855,66 +1777,25 @@ void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, ui
         }
         g->prof_end("conflict_components");
         g->prof_begin();
-        // runs sorted by component label: labels are run numbers (< D); the list is in run order and the sort is stable, so the label bits suffice
-        const int label_end = 32 + (int)std::max(1u, log2_ceil((uint64_t)D));
-        g->temp.reserve(std::max(sort_pairs_temp_bytes(nco), sort_keys_temp_bytes(nck)));
         hipLaunchKernelGGL(k_conf_kmer_keys, dim3(blocks_for(nck)), dim3(TPB), 0, s, confk, label, nck, g->kk0.as<uint64_t>());
+        g->temp.reserve(std::max(sort_pairs_temp_bytes(nco), sort_keys_temp_bytes(nck)));
+        hipLaunchKernelGGL(k_conf_expand, dim3(blocks_for((int64_t)nck * 8)), dim3(TPB), 0, s, confk, g->conf_off.as<uint32_t>(),
+                           counts, starts, vals, status, nops, label, nck, g->opk0.as<uint64_t>(), g->opv0.as<uint32_t>());
+        // labels are run numbers (< D); the list is in run order and the sort is stable, so the label bits suffice
+        const int label_end = 32 + (int)std::max(1u, log2_ceil((uint64_t)D));
         sort_keys_u64(g->temp.p, g->temp.cap, g->kk0.as<uint64_t>(), g->kk1.as<uint64_t>(), nck, 32, label_end, s);
+        // op keys are (component label << 32) | occurrence id, and occurrence ids stop at occ_bits: two bit ranges
+        sort_pairs_u64_u32_2r(g->temp.p, g->temp.cap, g->opk0.as<uint64_t>(), g->opk1.as<uint64_t>(),
+                              g->opv0.as<uint32_t>(), g->opv1.as<uint32_t>(), nco, 0, (int)std::min(32u, std::max(1u, g->occ_bits)), 32, label_end, s);
         g->prof_end("conflict_gather_sort");
-        // the components, replayed: a k-way merge of the runs' own (already ordered) occurrence lists by the component's head thread; whatever is too
-        // large for that (RB_CONF_MERGE=0: everything) goes through the expanded, sorted op list and the two kernels that walk it
-        const bool merge = !(getenv("RB_CONF_MERGE") && atoi(getenv("RB_CONF_MERGE")) == 0);
-        const uint32_t *list = confk;                          // the runs the sorted-list path replays, and how many
-        uint32_t n_list = nck, nco_list = nco;
-        if (merge) {
-            g->prof_begin();
-            g->opv0.reserve(((size_t)nck + 1) * 4); g->opv1.reserve(((size_t)nck + 1) * 4); g->conf_big.reserve((size_t)nck * 4);
-            uint32_t *flag = g->opv0.as<uint32_t>(), *pos = g->opv1.as<uint32_t>();
-            RB_HIP(hipMemsetAsync(flag, 0, ((size_t)nck + 1) * 4, s));
-            RB_HIP(hipMemsetAsync(ctr + 5, 0, 4, s));
-            hipLaunchKernelGGL(k_conf_replay_merge, dim3(blocks_for(nck)), dim3(TPB), 0, s, fv, uniq, g->kk1.as<uint64_t>(), nck, counts, starts, vals, status, nops,
-                               flag, ctr + 5, (int)(mode != M_COUNT_ONLY),
-                               getenv("RB_CONF_MERGE_OPS") ? (uint32_t)atoi(getenv("RB_CONF_MERGE_OPS")) : SMALL_COMPONENT_OPS);      // (tests: a small bound sends components both ways)
-            uint32_t nbr = 0;
-            RB_HIP(hipMemcpyAsync(&nbr, ctr + 5, 4, hipMemcpyDeviceToHost, s));
-            RB_HIP(hipStreamSynchronize(s));
-            n_list = nbr; nco_list = 0;
-            if (nbr) {
-                g->temp.reserve(scan_temp_bytes((size_t)nck + 1));
-                exclusive_scan_u32(g->temp.p, g->temp.cap, flag, pos, (size_t)nck + 1, s);
-                hipLaunchKernelGGL(k_conf_big_runs, dim3(blocks_for(nck)), dim3(TPB), 0, s, g->kk1.as<uint64_t>(), flag, pos, nck, g->conf_big.as<uint32_t>());
-                list = g->conf_big.as<uint32_t>();
-                hipLaunchKernelGGL(k_conf_offsets, dim3(blocks_for(nbr + 1)), dim3(TPB), 0, s, list, nops, nbr, g->conf_sizes.as<uint32_t>());
-                exclusive_scan_u32(g->temp.p, g->temp.cap, g->conf_sizes.as<uint32_t>(), g->conf_off.as<uint32_t>(), (size_t)nbr + 1, s);
-                RB_HIP(hipMemcpyAsync(&nco_list, g->conf_off.as<uint32_t>() + nbr, 4, hipMemcpyDeviceToHost, s));
-                RB_HIP(hipStreamSynchronize(s));
-            }
-            g->prof_end("conflict_replay");
-        }
-        if (n_list) {
-            g->prof_begin();
-            g->opk0.reserve((size_t)nco_list * 8); g->opk1.reserve((size_t)nco_list * 8);
-            g->opv0.reserve((size_t)nco_list * 4); g->opv1.reserve((size_t)nco_list * 4);
-            g->temp.reserve(std::max(sort_pairs_temp_bytes(nco_list), sort_keys_temp_bytes(n_list)));
-            if (merge) {      // (the sub-list's own keys: it is in label order already, the sort keeps it so)
-                hipLaunchKernelGGL(k_conf_kmer_keys, dim3(blocks_for(n_list)), dim3(TPB), 0, s, list, label, n_list, g->kk0.as<uint64_t>());
-                sort_keys_u64(g->temp.p, g->temp.cap, g->kk0.as<uint64_t>(), g->kk1.as<uint64_t>(), n_list, 32, label_end, s);
-            }
-            hipLaunchKernelGGL(k_conf_expand, dim3(blocks_for((int64_t)n_list * 8)), dim3(TPB), 0, s, list, g->conf_off.as<uint32_t>(),
-                               counts, starts, vals, status, nops, label, n_list, g->opk0.as<uint64_t>(), g->opv0.as<uint32_t>());
-            // op keys are (component label << 32) | occurrence id, and occurrence ids stop at occ_bits: two bit ranges
-            sort_pairs_u64_u32_2r(g->temp.p, g->temp.cap, g->opk0.as<uint64_t>(), g->opk1.as<uint64_t>(),
-                                  g->opv0.as<uint32_t>(), g->opv1.as<uint32_t>(), nco_list, 0, (int)std::min(32u, std::max(1u, g->occ_bits)), 32, label_end, s);
-            g->prof_end("conflict_gather_sort");
-            g->prof_begin();
-            RB_HIP(hipMemsetAsync(ctr + 4, 0, 4, s));
-            hipLaunchKernelGGL(k_conf_replay_small, dim3(blocks_for(n_list)), dim3(TPB), 0, s, fv, uniq, g->kk1.as<uint64_t>(), n_list,
-                               g->opk1.as<uint64_t>(), g->opv1.as<uint32_t>(), nco_list, g->biglist.as<uint32_t>(), ctr + 4, (int)(mode != M_COUNT_ONLY), starts, vals);
-            hipLaunchKernelGGL(k_conf_replay_big, dim3(std::min<uint32_t>(n_list, 262144u)), dim3(64), 0, s, fv, uniq, g->kk1.as<uint64_t>(), n_list,
-                               g->opk1.as<uint64_t>(), g->opv1.as<uint32_t>(), nco_list, g->biglist.as<uint32_t>(), ctr + 4,
-                               getenv("RB_DEBUG") ? ctr + 600 : (uint32_t *)nullptr, (int)(mode != M_COUNT_ONLY), starts, vals);
-            g->prof_end("conflict_replay");
-        }
+        g->prof_begin();
+        RB_HIP(hipMemsetAsync(ctr + 4, 0, 4, s));
+        hipLaunchKernelGGL(k_conf_replay_small, dim3(blocks_for(nck)), dim3(TPB), 0, s, fv, uniq, g->kk1.as<uint64_t>(), nck,
+                           g->opk1.as<uint64_t>(), g->opv1.as<uint32_t>(), nco, g->biglist.as<uint32_t>(), ctr + 4, (int)(mode != M_COUNT_ONLY), starts, vals);
+        hipLaunchKernelGGL(k_conf_replay_big, dim3(std::min<uint32_t>(nck, 262144u)), dim3(64), 0, s, fv, uniq, g->kk1.as<uint64_t>(), nck,
+                           g->opk1.as<uint64_t>(), g->opv1.as<uint32_t>(), nco, g->biglist.as<uint32_t>(), ctr + 4,
+                           getenv("RB_DEBUG") ? ctr + 600 : (uint32_t *)nullptr, (int)(mode != M_COUNT_ONLY), starts, vals);
+        g->prof_end("conflict_replay");
         if (getenv("RB_DEBUG")) {
             uint32_t nb = 0;
             RB_HIP(hipMemcpy(&nb, ctr + 4, 4, hipMemcpyDeviceToHost));

@@ -404,7 +404,6 @@ struct rb_graph {
     hipEvent_t ev0 = nullptr, ev1 = nullptr, ev2 = nullptr, ev3 = nullptr;
     // rb_graph_add_packed: the batch being inserted is still arriving from host memory, piece by piece on a copy stream.  add_range calls this
     // before it enqueues anything that reads words [0, w_end) of the batch on `st`; the hook makes `st` wait for the pieces that hold them.
-    DevBuf conf_big;                    // the runs of components too large for the merge replay (rb_graph.hip run_core)
     std::function<void(int64_t w_end, hipStream_t st)> await_words;
     // ... and what that call keeps between calls (rb_packed.hip): the device batch the host's reads are streamed into, the pinned copy of its word
     // offsets, the copy stream and one event per uploaded piece

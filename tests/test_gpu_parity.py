@@ -360,7 +360,6 @@ def test_cold_subbatch_is_split_when_survivors_exceed_the_bound():
                                  {"RB_GROUP_ORDERED": "1"}, {"RB_GROUP_PREFETCH": "0"}, {"RB_GROUP_FIX": "0"}, {"RB_GROUP_FIX": "2"},
                                  {"RB_GROUP_T": "18"}, {"RB_GROUP_T": "18", "RB_GROUP_WIDE_LDS": "0"},
                                  {"RB_FILTER_PIPE": "1"}, {"RB_FILTER_PIPE": "0"}, {"RB_RAGGED_LANES": "0"},
-                                 {"RB_CONF_MERGE": "0"}, {"RB_CONF_MERGE_OPS": "3"}, {"RB_CONF_MERGE_OPS": "0"},
                                  {"RB_GROUP_IDX": "1"}, {"RB_GROUP_IDX": "0"}, {"RB_GROUP_IDX": "1", "RB_GROUP_T": "18"}, {"RB_GROUP_IDX": "1", "RB_GROUP_T": "3"},
                                  {"RB_FT_FILTER": "1"}, {"RB_FT_FILTER": "0"}, {"RB_GROUP_CLASSES": "0"},
                                  {"RB_SWEEP": "1"}, {"RB_SWEEP": "1", "RB_GROUP_T": "18"}, {"RB_SWEEP": "1", "RB_GROUP_T": "3"}, {"RB_SWEEP": "1", "RB_GROUP_T": "11"},
