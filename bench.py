@@ -106,7 +106,7 @@ UPPER_BOUND_MODELS = {
 PMC_KERNELS = {"filter_windows": "rb::k_filter_reads", "hash_windows": "rb::k_hash_windows_resume",
                "probe_claim": "k_probe", "resolve_apply": "k_resolve_apply", "pairs_insert": "k_pairs_reads",
                "group_part_count": "rb::k_part_count", "group_part_scatter": "rb::k_part_scatter", "group_buckets": "rb::k_group_buckets"}
-PMC_TAG = next((t for t in ("r05", "r04", "r03") if os.path.exists(os.path.join(ROOT, "profiles", t + "_pmc_fetch_size.csv"))), "r05")
+PMC_TAG = next((t for t in ("r06", "r05", "r04", "r03") if os.path.exists(os.path.join(ROOT, "profiles", t + "_pmc_fetch_size.csv"))), "r06")
 PMC_FILES = (PMC_TAG + "_pmc_fetch_size.csv", PMC_TAG + "_pmc_write_size.csv")
 
 

@@ -560,8 +560,9 @@ int rb_shard_add_range(rb_graph *g, rb_shard_comm *c, const rb_batch *b, int64_t
         const int overlap = getenv("RB_SHARD_OVERLAP") ? atoi(getenv("RB_SHARD_OVERLAP")) : 1;
         // cold start (first insert into cleared filters): short sub-batches first, doubling up to the full size
         int64_t cur = reads_per_substep;
-        const int ramp_div = getenv("RB_SHARD_RAMP_DIV") ? std::max(1, atoi(getenv("RB_SHARD_RAMP_DIV"))) : 64;
-        if (ordinal0 == 0 && !getenv("RB_NO_RAMP") && reads_per_substep >= 64 * 1024) cur = std::max<int64_t>(reads_per_substep / ramp_div, 1024);
+        // (round 6 measured the ramp's start at 8 ranks: reads / 16 -> 64.9 ms per rank, / 64 (this) -> 66.3, / 4 -> 77.4: the short sub-batches are
+        // mostly launch overhead, but starting higher sorts more of the first windows unfiltered)
+        if (ordinal0 == 0 && !getenv("RB_NO_RAMP") && reads_per_substep >= 64 * 1024) cur = std::max<int64_t>(reads_per_substep / 64, 1024);
         std::vector<int64_t> cuts{0};
         for (int64_t a = 0; a < n;) { a = std::min(n, a + cur); cuts.push_back(a); cur = std::min(reads_per_substep, cur * 2); }
         try {
