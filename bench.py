@@ -160,7 +160,7 @@ def pmc_traffic(stage, n_pairs_per_step=0):
     return tot or None
 
 
-PMC_RUN_STEPS = 2        # the PMC passes ran `bench.py --steps 1 --warmup 1` (tools/final_profile.sh)
+PMC_RUN_STEPS = int(pmc_meta().get("run_steps", 2))        # steps of kernel work inside a PMC pass (tools/final_profile.sh writes it: `bench.py --steps 1 --warmup 1` = 2, + 2 when the host-resident leg ran too)
 
 
 def pmc_step_bytes(stage, n_pairs_per_step=0):

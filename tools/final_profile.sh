@@ -14,7 +14,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -o s -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/bench_under_rocprof.json 2> $OUT/rocprof_stats.err
 python $R/profiles/summarize.py stats $(find /tmp/prof_stats -name '*kernel_stats.csv' | head -1) > $OUT/kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/prof_$c -o p -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/bench_pmc_$c.json 2> $OUT/rocprof_$c.err
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/prof_$c -o p -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-host-leg > $OUT/bench_pmc_$c.json 2> $OUT/rocprof_$c.err
   python $R/profiles/summarize.py pmc $(find /tmp/prof_$c -name '*counter_collection.csv' | head -1) $c > $OUT/pmc_$c.csv
 done
 # which code the counter passes ran on: the id compiled into the library (= tools/csrc_id.py of the tree) and the commit; bench.py quotes
@@ -26,7 +26,7 @@ from rnabloom import _native as N
 import csrc_id
 lib, src = N.lib.rb_build_id().decode(), csrc_id.csrc_id("$R")
 assert lib == src, "librb_hip.so was not built from this tree: %s vs %s" % (lib, src)
-print(json.dumps({"csrc_id": lib, "git_head": "$HEAD_SHA", "command": "bench.py --steps 1 --warmup 1 --no-cpu-baseline under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes)"}))
+print(json.dumps({"csrc_id": lib, "git_head": "$HEAD_SHA", "run_steps": 2, "command": "bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-host-leg under rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes)"}))
 PY
 # the bench lines come AFTER the counter passes: bench.py quotes counter bytes only from summaries whose csrc id is its library's, so this round's summaries
 # go where it looks (the box's copy of profiles/) first

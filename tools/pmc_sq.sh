@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/pmc_sq
 mkdir -p $OUT
 pass() { n=$1; shift
-  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d /tmp/pmc_$n -o p -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline > $OUT/pass$n.log 2>&1
+  rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d /tmp/pmc_$n -o p -- python $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-host-leg > $OUT/pass$n.log 2>&1
   f=$(find /tmp/pmc_$n -name '*counter_collection.csv' | head -1)
   python - "$f" "$@" > $OUT/pass$n.txt <<'PY'
 import csv,sys,re
