@@ -1767,11 +1767,12 @@ void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, ui
         const int per_look = nck >= (1u << 20) ? 1 : 2;
         for (int it = 0;; ++it) {
             RB_REQUIRE(it < 100000, "component labelling did not converge");
-            RB_HIP(hipMemsetAsync(ctr + 3, 0, 4, s));
+            uint32_t *flag = ctr + 900 + (it & 31);                          // a fresh flag per look: 32 of them zeroed by one fill
+            if ((it & 31) == 0) RB_HIP(hipMemsetAsync(ctr + 900, 0, 128, s));
             for (int q = 0; q < per_look; ++q)
-                hipLaunchKernelGGL(k_label_round, dim3(blocks_for(nck)), dim3(TPB), 0, s, (int)fv.cbf_h, confk, nck, g->ctable.as<Slot>(), lslot, label, ctr + 3);
+                hipLaunchKernelGGL(k_label_round, dim3(blocks_for(nck)), dim3(TPB), 0, s, (int)fv.cbf_h, confk, nck, g->ctable.as<Slot>(), lslot, label, flag);
             uint32_t changed = 0;
-            RB_HIP(hipMemcpyAsync(&changed, ctr + 3, 4, hipMemcpyDeviceToHost, s));
+            RB_HIP(hipMemcpyAsync(&changed, flag, 4, hipMemcpyDeviceToHost, s));
             RB_HIP(hipStreamSynchronize(s));
             if (!changed) break;
         }

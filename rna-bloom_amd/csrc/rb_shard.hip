@@ -43,7 +43,7 @@ struct ShardState {
     uint32_t f_log2 = 1, cs_log2 = 1, csf_log2 = 16;
     DevBuf cfinal, conf_list;
     // routing scratch
-    DevBuf stage0, stage1, stage2, stage3, rhist, roffs, bounds;
+    DevBuf stage0, stage1, stage2, stage3, rhist, roffs, bounds, rcnt;
     // owner-side scratch
     DevBuf own_f, own_cs;
     // conflict path scratch
@@ -185,6 +185,100 @@ size_t route(rb_graph *g, F f, size_t n, int64_t *counts, P place, int buckets =
     const size_t kept = (size_t)b[B];
     place(f, kept);
     hipLaunchKernelGGL((k_route<F, true>), dim3(nb), dim3(RT_TPB), 0, s, f, n, (uint32_t)B, nb, S->roffs.as<uint32_t>());
+    return kept;
+}
+// The same partition where the order inside a destination bucket does not matter (requests, counter writes: the owner answers by position and
+// arbitrates by probe id, a counter is written by one run) — round 6.  The stable route above pays for its order with a [destination][tile]
+// histogram, its scan (three kernels) and a bounds kernel per call, four calls a sub-batch; here a count kernel adds up one number per destination
+// (LDS, then one global atomic per destination and block), the host turns the B totals into bases, and the scatter kernel reserves a tile's
+// share of a destination's range with one atomicAdd per (tile, destination): tiles land in whatever order they arrive, items keep their order
+// inside a tile.  emit(i, pos) still tells the caller where item i went (pos_of).
+struct RouteBases { uint32_t b[64]; };
+template <class F>
+__global__ void __launch_bounds__(RT_TPB) k_route_count(F f, size_t n, uint32_t G, uint32_t *__restrict__ cnt) {
+    __shared__ uint32_t s_c[64];
+    if (threadIdx.x < 64u) s_c[threadIdx.x] = 0u;
+    __syncthreads();
+    const size_t base = (size_t)blockIdx.x * RT_TILE;
+#pragma unroll
+    for (int q = 0; q < RT_IPT; ++q) {
+        const size_t i = base + (size_t)q * RT_TPB + threadIdx.x;
+        const int d = (i < n) ? f.dest(i) : -1;
+        // one LDS atomic per distinct destination of the wavefront's 64 items
+        unsigned long long pending = __ballot(d >= 0);
+        while (pending) {
+            const int leader = __ffsll((long long)pending) - 1;
+            const int dl = __shfl(d, leader, 64);
+            const unsigned long long m = __ballot(d == dl);
+            if ((int)(threadIdx.x & 63u) == leader) atomicAdd(&s_c[dl], (uint32_t)__popcll(m));
+            pending &= ~m;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < G && s_c[threadIdx.x]) atomicAdd(&cnt[threadIdx.x], s_c[threadIdx.x]);
+}
+template <class F>
+__global__ void __launch_bounds__(RT_TPB) k_route_scatter_any(F f, size_t n, uint32_t G, RouteBases bases, uint32_t *__restrict__ cursor) {
+    __shared__ uint32_t s_cnt[4 * RT_IPT][64];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (uint32_t r = threadIdx.x; r < 4u * RT_IPT * 64u; r += RT_TPB) (&s_cnt[0][0])[r] = 0u;
+    __syncthreads();
+    int dst[RT_IPT];
+    uint32_t rank[RT_IPT];
+    const size_t base = (size_t)blockIdx.x * RT_TILE + (size_t)wave * (64u * RT_IPT);
+#pragma unroll
+    for (int q = 0; q < RT_IPT; ++q) {
+        const size_t i = base + (size_t)q * 64u + lane;
+        const int d = (i < n) ? f.dest(i) : -1;
+        dst[q] = d; rank[q] = 0;
+        unsigned long long pending = __ballot(d >= 0);
+        while (pending) {
+            const int leader = __ffsll((long long)pending) - 1;
+            const int dl = __shfl(d, leader, 64);
+            const unsigned long long m = __ballot(d == dl);
+            if (d == dl) rank[q] = (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if ((int)lane == leader) s_cnt[wave * RT_IPT + q][dl] = (uint32_t)__popcll(m);
+            pending &= ~m;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < G) {
+        uint32_t total = 0;
+        for (int r = 0; r < 4 * RT_IPT; ++r) total += s_cnt[r][threadIdx.x];
+        uint32_t run = total ? bases.b[threadIdx.x] + atomicAdd(&cursor[threadIdx.x], total) : 0u;      // this tile's share of the destination's range
+        for (int r = 0; r < 4 * RT_IPT; ++r) { const uint32_t c = s_cnt[r][threadIdx.x]; s_cnt[r][threadIdx.x] = run; run += c; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < RT_IPT; ++q) {
+        const size_t i = base + (size_t)q * 64u + lane;
+        if (i >= n) continue;
+        if (dst[q] >= 0) f.emit(i, s_cnt[wave * RT_IPT + q][dst[q]] + rank[q]);
+        else f.drop(i);
+    }
+}
+template <class F, class P>
+size_t route_any_order(rb_graph *g, F f, size_t n, int64_t *counts, P place) {
+    ShardState *S = g->shard;
+    hipStream_t s = g->stream;
+    const int B = S->G;
+    RB_REQUIRE(B <= 64, "route: %d destinations", B);
+    for (int r = 0; r < B; ++r) counts[r] = 0;
+    if (n == 0) { place(f, (size_t)0); return 0; }
+    RB_REQUIRE(n < (1ull << 32), "route: too many items (%zu)", n);
+    const uint32_t nb = (uint32_t)((n + RT_TILE - 1) / RT_TILE);
+    S->rcnt.reserve(2 * 64 * 4);
+    uint32_t *cnt = S->rcnt.as<uint32_t>(), *cursor = cnt + 64;
+    RB_HIP(hipMemsetAsync(cnt, 0, 2 * 64 * 4, s));
+    hipLaunchKernelGGL((k_route_count<F>), dim3(nb), dim3(RT_TPB), 0, s, f, n, (uint32_t)B, cnt);
+    uint32_t h[64];
+    RB_HIP(hipMemcpyAsync(h, cnt, (size_t)B * 4, hipMemcpyDeviceToHost, s));
+    RB_HIP(hipStreamSynchronize(s));
+    RouteBases bases;
+    size_t kept = 0;
+    for (int r = 0; r < 64; ++r) { bases.b[r] = (uint32_t)kept; if (r < B) { counts[r] = h[r]; kept += h[r]; } }
+    place(f, kept);
+    hipLaunchKernelGGL((k_route_scatter_any<F>), dim3(nb), dim3(RT_TPB), 0, s, f, n, (uint32_t)B, bases, cursor);
     return kept;
 }
 // ordered compaction of the received records by the prefilter's verdicts (one bucket)
@@ -967,13 +1061,13 @@ void make_and_route_requests(rb_graph *g, uint32_t D, int mode, uint64_t ordinal
     }
     RouteIdx fd{S->stage0.as<uint64_t>(), d_drop, (uint64_t)S->span[RB_DBGBF], S->stage1.as<uint64_t>(), nullptr,
                 nullptr, nullptr, nullptr, S->dreq_pos.as<uint32_t>()};
-    route(g, fd, nd, dreq_counts, [&](RouteIdx &ff, size_t kept) {
+    route_any_order(g, fd, nd, dreq_counts, [&](RouteIdx &ff, size_t kept) {
         ff.out_idx = (uint64_t *)slot_reserve(S, RB_SLOT_DREQ_IDX, kept * 8);
         ff.out64 = (uint64_t *)slot_reserve(S, RB_SLOT_DREQ_PROBE, kept * 8);
     });
     RouteIdx fc{S->stage3.as<uint64_t>(), c_drop, (uint64_t)S->span[RB_CBF], nullptr, nullptr,
                 nullptr, nullptr, nullptr, S->creq_pos.as<uint32_t>()};
-    route(g, fc, nc, creq_counts, [&](RouteIdx &ff, size_t kept) { ff.out_idx = (uint64_t *)slot_reserve(S, RB_SLOT_CREQ_IDX, kept * 8); });
+    route_any_order(g, fc, nc, creq_counts, [&](RouteIdx &ff, size_t kept) { ff.out_idx = (uint64_t *)slot_reserve(S, RB_SLOT_CREQ_IDX, kept * 8); });
 }
 void prep_emit(rb_graph *g, hipStream_t st) {
     ShardState *S = g->shard;
@@ -1641,7 +1735,7 @@ int rb_shard_resolve(rb_graph *g, int mode, const void *dreply_dev, const void *
         hipLaunchKernelGGL(k_emit_writes, dim3(blocks_for(D)), dim3(TPB), 0, s, fv, local_ranges(g), g->uniq().as<uint64_t>(), D, g->status.as<uint32_t>(),
                            S->creq_dup.as<uint8_t>(), S->cfinal.as<uint64_t>(), S->lmask.as<uint16_t>(), S->stage0.as<uint64_t>(), w_val, w_drop);
         RouteIdx fw{S->stage0.as<uint64_t>(), w_drop, (uint64_t)S->span[RB_CBF], nullptr, w_val, nullptr, nullptr, nullptr, nullptr};
-        route(g, fw, nc, w_counts, [&](RouteIdx &ff, size_t kept) {
+        route_any_order(g, fw, nc, w_counts, [&](RouteIdx &ff, size_t kept) {
             ff.out_idx = (uint64_t *)slot_reserve(S, RB_SLOT_W_IDX, kept * 8);
             ff.out8 = (uint8_t *)slot_reserve(S, RB_SLOT_W_VAL, kept);
         });
@@ -1704,11 +1798,12 @@ int rb_shard_conflict_route(rb_graph *g, const void *edges_dev, int64_t n_edges,
                            S->elabel.as<uint32_t>());
         for (int it = 0;; ++it) {
             RB_REQUIRE(it < 100000, "conflict component labelling did not converge");
-            RB_HIP(hipMemsetAsync(ctr + 3, 0, 4, s));
+            uint32_t *flag = ctr + 900 + (it & 31);                          // a fresh flag per look: 32 of them zeroed by one fill, not one fill per look
+            if ((it & 31) == 0) RB_HIP(hipMemsetAsync(ctr + 900, 0, 128, s));
             for (int q = 0; q < (ne >= ((size_t)1 << 20) ? 1 : 2); ++q)      // (a short list: two rounds per look at the flag — most components are pairs)
-                hipLaunchKernelGGL(k_edge_round, dim3(blocks_for((int64_t)ne)), dim3(TPB), 0, s, e, ne, S->etab.as<Slot>(), S->eslot.as<uint32_t>(), S->elabel.as<uint32_t>(), ctr + 3);
+                hipLaunchKernelGGL(k_edge_round, dim3(blocks_for((int64_t)ne)), dim3(TPB), 0, s, e, ne, S->etab.as<Slot>(), S->eslot.as<uint32_t>(), S->elabel.as<uint32_t>(), flag);
             uint32_t changed = 0;
-            RB_HIP(hipMemcpyAsync(&changed, ctr + 3, 4, hipMemcpyDeviceToHost, s));
+            RB_HIP(hipMemcpyAsync(&changed, flag, 4, hipMemcpyDeviceToHost, s));
             RB_HIP(hipStreamSynchronize(s));
             if (!changed) break;
         }
@@ -1800,7 +1895,7 @@ int rb_shard_conflict_replay(rb_graph *g, const void *runs_dev, int64_t n_runs, 
         uint8_t *w_val = S->stage2.as<uint8_t>(), *w_drop = w_val + cap;
         hipLaunchKernelGGL(k_tab_emit, dim3(blocks_for((int64_t)cap)), dim3(TPB), 0, s, S->rtab.as<Slot>(), cap, S->stage0.as<uint64_t>(), w_val, w_drop);
         RouteIdx fw{S->stage0.as<uint64_t>(), w_drop, (uint64_t)S->span[RB_CBF], nullptr, w_val, nullptr, nullptr, nullptr, nullptr};
-        route(g, fw, cap, w_counts, [&](RouteIdx &ff, size_t kept) {
+        route_any_order(g, fw, cap, w_counts, [&](RouteIdx &ff, size_t kept) {
             ff.out_idx = (uint64_t *)slot_reserve(S, RB_SLOT_CW_IDX, kept * 8);
             ff.out8 = (uint8_t *)slot_reserve(S, RB_SLOT_CW_VAL, kept);
         });
@@ -1916,7 +2011,7 @@ void shard_free(rb_graph *g) {
     if (!S) return;
     for (auto &b : S->slot) b.release();
     DevBuf *bufs[] = {&S->dreq_pos, &S->creq_pos, &S->creq_dup, &S->cfinal, &S->conf_list, &S->stage0, &S->stage1, &S->stage2, &S->stage3,
-                      &S->rhist, &S->roffs, &S->bounds, &S->own_f, &S->own_cs, &S->esz, &S->eoff, &S->etab, &S->eslot, &S->elabel, &S->cdesc,
+                      &S->rhist, &S->roffs, &S->bounds, &S->rcnt, &S->own_f, &S->own_cs, &S->esz, &S->eoff, &S->etab, &S->eslot, &S->elabel, &S->cdesc,
                       &S->cpos, &S->cnops, &S->cnoff, &S->rk0, &S->rk1, &S->ok0, &S->ok1, &S->ov0, &S->ov1, &S->rtab, &S->rslot, &S->rbig, &S->q_h0, &S->q_bpos, &S->q_cpos, &S->q_out, &S->cache_upd, &S->lmask, &S->lcoll, &S->lcv, &S->lctr};
     for (auto *b : bufs) b->release();
     free_bits(S->rpk_acc);
