@@ -429,10 +429,14 @@ int rb_nbits_encode(const char *seq, const int64_t *offsets, int64_t n_reads, vo
  *   [all_to_all requests, pair probes]
  *   serve     owner: bit tests + first-setter arbitration + bit sets, counter claims, pair bit sets
  *   [all_to_all replies back]
- *   resolve   found flags, op counts, counter updates of runs that own their counters alone; for the
- *             runs that share a counter: the (run, contested counter) edges
- *   [all_to_all counter writes]     apply_writes
- *   [all_gather edges]
+ *   resolve   found flags, op counts, counter updates of runs that own their counters alone; the runs that share
+ *             a counter and can reach one of theirs ask those counters' owners who else can (RB_SLOT_ORD_IDX)
+ *   [all_to_all counter writes + ordered-set questions]     apply_writes, order_serve (claimants per counter)
+ *   [all_to_all answers]
+ *   order_finish   a run that can reach a contested counter another such run claimed is in the ordered set O* (a superset of the
+ *             single-GPU engine's set, without its closure rounds: csrc/rb_shard.hip) -> its (run, contested counter) edges; every
+ *             other run is finished in place, its writes to other ranks' counters follow the edges as tagged records
+ *   [all_gather edges + tagged writes]      apply_tagged (every rank: the writes that fall into its range)
  *   conflict_route    components of the edge graph (same on every rank); each rank sends its
  *             conflicting runs + their pending occurrence ids to the rank owning the component
  *   [all_to_all runs, ops]
@@ -454,7 +458,8 @@ enum {
     RB_SLOT_CREQ_IDX = 5,    /* u64 global counter index                 */
     RB_SLOT_W_IDX = 6,       /* u64 global counter index                 */
     RB_SLOT_W_VAL = 7,       /* u8 new byte, 0xFF = just drop the claim  */
-    RB_SLOT_CONF_EDGES = 8,  /* 16 B {u64 counter index, u32 run id, u32 0}; run id = local number * count + rank */
+    RB_SLOT_CONF_EDGES = 8,  /* 16 B {u64 counter index, u32 run id, u32 0}; run id = local number * count + rank.  Round 6: followed by the counter
+                              * writes of the runs finished outside the ordered set, {u64 counter index, u32 0xFFFFFFFF, u32 byte (0xFF: drop the claim)} */
     RB_SLOT_CONF_RUNS = 9,   /* 24 B {u64 h0, u64 counter bytes, u32 component, u32 n_ops | kinds << 28}, by component owner */
     RB_SLOT_CONF_OPS = 10,   /* u32 occurrence ids of those runs, run after run */
     RB_SLOT_CW_IDX = 11,     /* u64 global counter index (replayed components) */
@@ -462,7 +467,8 @@ enum {
     RB_SLOT_Q_BIDX = 13,     /* u64 global bit indices of a query, by owner   */
     RB_SLOT_Q_CIDX = 14,     /* u64 global counter indices of a query, by owner */
     RB_SLOT_CACHE_UPD = 15,  /* split-reads mode: 16 B {u64 h0, u64 exponent} prefilter-cache entries learnt this sub-batch */
-    RB_SLOT_COUNT = 16
+    RB_SLOT_ORD_IDX = 16,    /* u64 global counter index: the contested counters of the runs that can reach one (ordered-set question), by owner */
+    RB_SLOT_COUNT = 17
 };
 int rb_graph_create_shard(const rb_graph_params *p, int shard_rank, int shard_count, rb_graph **out);
 /* reads [first, first+n) = the global sub-batch (identical arguments on every rank); [pair_first,
@@ -502,8 +508,12 @@ int rb_shard_hash_group(rb_graph *g, const rb_batch *b, int64_t first, int64_t n
 int rb_shard_serve(rb_graph *g, int mode, const void *dreq_idx_dev, const void *dreq_probe_dev, int64_t nd,
                    const void *creq_idx_dev, int64_t nc, const void *pair_idx_dev, int64_t np,
                    void *dreply_dev /* u8[nd] */, void *creply_dev /* u8[nc] */);
-int rb_shard_resolve(rb_graph *g, int mode, const void *dreply_dev, const void *creply_dev, int64_t *w_counts,
-                     int64_t *n_conf_runs, int64_t *n_conf_edges, rb_add_stats *stats);
+int rb_shard_resolve(rb_graph *g, int mode, const void *dreply_dev, const void *creply_dev, int64_t *w_counts /*[count]*/,
+                     int64_t *ord_counts /*[count]: RB_SLOT_ORD_IDX entries per counter owner*/, rb_add_stats *stats);
+int rb_shard_order_serve(rb_graph *g, const void *ord_idx_dev, int64_t n, void *reply_dev /* u8[n]: claimants that can reach a contested counter */);
+int rb_shard_order_finish(rb_graph *g, int mode, const void *ord_reply_dev /* answers to this rank's RB_SLOT_ORD_IDX, in its order */,
+                          int64_t *n_conf_runs, int64_t *n_conf_records /* 16-byte records in RB_SLOT_CONF_EDGES: edges, then tagged writes */, rb_add_stats *stats);
+int rb_shard_apply_tagged(rb_graph *g, const void *records_dev /* the gathered RB_SLOT_CONF_EDGES of all ranks */, int64_t n_records);
 int rb_shard_apply_writes(rb_graph *g, const void *w_idx_dev, const void *w_val_dev, int64_t n);
 /* edges_dev: the edges of ALL ranks (rank order); gid_bound > every run id in them */
 int rb_shard_conflict_route(rb_graph *g, const void *edges_dev, int64_t n_edges, int64_t gid_bound, int64_t *run_counts,

@@ -381,21 +381,32 @@ void substep(rb_graph *g, rb_shard_comm *c, const rb_batch *b, int64_t first, in
     fill(pa[1], creply.p, o_cc, G, 1);
     { const int64_t *known[2] = {d_c, c_c}; a2a(c, me, pa, 2, known, st); }
     // resolve: runs that own their counters alone finish here
-    int64_t w_c[MAX_WORLD], nconf = 0, nedge = 0;
-    RB_CK(rb_shard_resolve(g, mode, pa[0].recv, pa[1].recv, w_c, &nconf, &nedge, &stats));
+    int64_t w_c[MAX_WORLD], ord_c[MAX_WORLD], nconf = 0, nedge = 0;
+    RB_CK(rb_shard_resolve(g, mode, pa[0].recv, pa[1].recv, w_c, ord_c, &stats));
     if (have_next && overlap == 1 && !split) RB_CK(rb_shard_hash_begin(g, b, nxt_first, nxt_n, ordinal + (uint64_t)n, pos_bits, flags));
-    {
-        const int64_t nw = sum(w_c, G);
+    {   // counter writes of the finished runs and, in the same exchange, the ordered-set questions; the answers come back by known counts
+        const int64_t nw = sum(w_c, G), no = sum(ord_c, G);
         fill(pa[0], slot(g, RB_SLOT_W_IDX, 8 * nw).p, w_c, G, 8);
         fill(pa[1], slot(g, RB_SLOT_W_VAL, nw).p, w_c, G, 1);
-        a2a(c, me, pa, 2, nullptr, st);
+        fill(pa[2], slot(g, RB_SLOT_ORD_IDX, 8 * no).p, ord_c, G, 8);
+        a2a(c, me, pa, 3, nullptr, st);
         RB_CK(rb_shard_apply_writes(g, pa[0].recv, pa[1].recv, pa[0].rtotal / 8));
+        int64_t o_oc[MAX_WORLD];
+        for (int s2 = 0; s2 < G; ++s2) o_oc[s2] = pa[2].rc[s2] / 8;
+        const int64_t n_ord = pa[2].rtotal / 8;
+        DevBuf &oreply = g->comm_creply;                       // (the claim replies are consumed: rb_shard_resolve is over)
+        oreply.reserve((size_t)std::max<int64_t>(n_ord, 1));
+        RB_CK(rb_shard_order_serve(g, pa[2].recv, n_ord, oreply.p));
+        fill(pa[0], oreply.p, o_oc, G, 1);
+        { const int64_t *known[1] = {ord_c}; a2a(c, me, pa, 1, known, st); }
+        RB_CK(rb_shard_order_finish(g, mode, pa[0].recv, &nconf, &nedge, &stats));
     }
     if (have_next && overlap == 1 && !split) RB_CK(rb_shard_hash_emit(g));
     // the (run, contested counter) edges of every rank and, in split mode, what the owners learnt for the cache replicas
     void *all_edges = nullptr;
     int64_t e_sizes[MAX_WORLD], u_sizes[MAX_WORLD];
     gather(c, me, slot(g, RB_SLOT_CONF_EDGES, 16 * nedge).p, 16 * nedge, 0, &all_edges, e_sizes, st);
+    if (sum(e_sizes, G)) RB_CK(rb_shard_apply_tagged(g, all_edges, sum(e_sizes, G) / 16));
     if (split) {
         SlotView upd = slot(g, RB_SLOT_CACHE_UPD, -1);
         void *all_upd = nullptr;

@@ -42,6 +42,8 @@ struct ShardState {
     bool has_f = false, has_cs = false;        // serve left a collision table / a contested-counter table for resolve
     uint32_t f_log2 = 1, cs_log2 = 1, csf_log2 = 16;
     DevBuf cfinal, conf_list;
+    DevBuf oinfo, ord_pos, conf2, deferred, heavy2;   // ordered-set classification (rb_shard_resolve -> rb_shard_order_finish)
+    uint32_t n_cand = 0;                       // runs with a contested counter in the sub-batch in flight
     // routing scratch
     DevBuf stage0, stage1, stage2, stage3, rhist, roffs, bounds, rcnt;
     // owner-side scratch
@@ -611,6 +613,10 @@ __global__ void k_emit_writes(FilterView fv, LocalRanges R, const uint64_t *__re
 
 // ---- conflict path, requester side: edges of the (run, contested counter) graph ----
 struct ConfEdge { uint64_t cidx; uint32_t gid, pad; };          // gid = local conflict-run number * G + rank
+// ... and, in the same 16 bytes and the same all-gather, the counter WRITES of the runs the ordered-set rule finished in place (round 6): gid =
+// EDGE_WRITE, pad = the byte (0xFF: drop the claim mark only).  Every rank applies the ones that fall into its range (k_apply_tagged); the
+// component kernels skip them.
+constexpr uint32_t EDGE_WRITE = 0xFFFFFFFFu;
 struct ConfRun { uint64_t h0, cv; uint32_t label, nops_kinds; }; // nops | kfirst << 28 | krest << 30
 constexpr uint32_t NOPS_MASK = 0x0FFFFFFFu;
 
@@ -637,11 +643,124 @@ __global__ void k_conf_edges(FilterView fv, const uint64_t *__restrict__ uniq, c
         out[o++] = e;
     }
 }
+// ---- which runs with a contested counter need the ordered replay at all (round 6; the single-GPU engine's k_cs_writers / k_cs_order, rb_graph.hip) ----
+// A run X only ever raises its counters; as long as nobody else writes the counters it works on, its minimum after its m ops is at most
+// m0 + m, so it writes a counter — and depends on that counter's exact value — only if the pre-batch value is within reach: c <= m0 + m - 1.
+// The single-GPU engine closes the set O = {can reach a contested counter two runs can reach, or one a run of O claimed} by rounds over one
+// table.  Here the claimants of a counter sit on different ranks and a round would be an exchange, so a SUPERSET that needs no closure is used:
+//     any(X)  =  X can reach at least one of its contested counters                                   (known where X lives)
+//     X in O* =  X can reach a contested counter c that ANOTHER claimant Y with any(Y) claimed        (one count per counter, at c's owner)
+// O is inside O*: "two runs can reach c" gives the other one any(); "a run of O claimed c" too, for every run of O can reach something.  A run
+// outside O* is the only writer of everything it can reach (the other claimants of such a counter reach nothing contested, their own bound
+// holds, they never get to it), so it is finished in place from the pre-batch values, and it never writes a counter an O* run shares with it
+// (it would be in O* through that run).  Hot k-mers whose co-claimants are cold ones stay outside — where most replayed ops were.
+// Protocol: the runs with any() send their contested counters to the owners (with the counter writes of the resolve phase), the owners count
+// claimants per counter and answer the count, k_order_decide classifies.
+__global__ void k_order_requests(FilterView fv, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ conf_list, uint32_t n,
+                                 const uint32_t *__restrict__ status, const uint32_t *__restrict__ nops, const uint64_t *__restrict__ cvals,
+                                 const uint8_t *__restrict__ c_dup, uint8_t *__restrict__ oinfo, uint64_t *__restrict__ o_idx, uint8_t *__restrict__ o_drop) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t d = conf_list[i], con = (status[d] >> ST_CONTESTED_SHIFT) & 0xFFu;
+    const uint64_t cv = cvals[d], h0 = uniq[d];
+    uint32_t m0 = 255u;
+    for (int j = 0; j < fv.cbf_h; ++j) { const uint32_t c = (uint32_t)(cv >> (8 * j)) & 0xFFu; m0 = c < m0 ? c : m0; }
+    const uint32_t reach = m0 + nops[d] - 1u;
+    uint32_t rmask = 0;
+    for (int j = 0; j < fv.cbf_h; ++j)
+        if (((con >> j) & 1u) && ((uint32_t)(cv >> (8 * j)) & 0xFFu) <= reach) rmask |= 1u << j;
+    oinfo[i] = (uint8_t)rmask;                                 // the contested counters this run can reach (0: finished in place without asking)
+    for (int j = 0; j < fv.cbf_h; ++j) {
+        const size_t q = (size_t)i * fv.cbf_h + j;
+        o_idx[q] = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod);
+        o_drop[q] = (rmask && ((con >> j) & 1u) && c_dup[(size_t)d * fv.cbf_h + j] == j) ? 0u : 1u;      // every contested counter of a run with any()
+    }
+}
+// owner: claimants with any() per contested counter (the slot's value starts at all ones: n adds leave n - 1)
+__global__ void k_order_count(const uint64_t *__restrict__ idx, size_t n, Slot *cs, uint32_t cs_log2) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Slot *sl = const_cast<Slot *>(table_find(cs, cs_log2, idx[i]));
+    if (sl) atomicAdd(&sl->val, 1ull);
+}
+__global__ void k_order_reply(const uint64_t *__restrict__ idx, size_t n, const Slot *cs, uint32_t cs_log2, uint8_t *__restrict__ reply) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const Slot *sl = cs ? table_find(cs, cs_log2, idx[i]) : nullptr;
+    const unsigned long long c = sl ? sl->val + 1ull : 255ull;                // (a counter the table does not know cannot happen; answered as "many")
+    reply[i] = (uint8_t)(c > 255ull ? 255ull : c);
+}
+// requester: in O* (stays RUN_CONFLICT, appended to conf2) or finished in place — light runs here, heavy ones by a second k_cbf_heavy launch.
+// A contested counter the run did not change is only released (byte 0xFF): it belongs to whoever can reach it.
+__global__ void k_order_decide(FilterView fv, const uint32_t *__restrict__ counts, const uint32_t *__restrict__ starts, const uint32_t *__restrict__ conf_list,
+                               uint32_t n, const uint8_t *__restrict__ oinfo, const uint32_t *__restrict__ ord_pos, const uint8_t *__restrict__ reply,
+                               uint32_t light_ops, int order_all, uint32_t *__restrict__ status, const uint32_t *__restrict__ nops,
+                               const uint64_t *__restrict__ cvals, const uint8_t *__restrict__ tz, uint64_t *__restrict__ cfinal,
+                               uint32_t *__restrict__ conf2, uint32_t *__restrict__ deferred, uint32_t *__restrict__ heavy2, uint32_t *__restrict__ ctr3 /* conf2, deferred, heavy2 counts */) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t d = conf_list[i], rmask = oinfo[i];
+    bool in_o = order_all != 0;
+    for (int j = 0; j < fv.cbf_h && !in_o; ++j)
+        if ((rmask >> j) & 1u) in_o = reply[ord_pos[(size_t)i * fv.cbf_h + j]] >= 2u;         // this run and at least one other with any()
+    if (in_o) { conf2[atomicAdd(&ctr3[0], 1u)] = d; return; }
+    const uint32_t st = status[d] & ~RUN_CONFLICT, ops = nops[d], con = (st >> ST_CONTESTED_SHIFT) & 0xFFu;
+    deferred[atomicAdd(&ctr3[1], 1u)] = d;
+    if (ops > light_ops) { status[d] = st | RUN_WRITES | RUN_HEAVY; heavy2[atomicAdd(&ctr3[2], 1u)] = d; return; }
+    status[d] = st | RUN_WRITES;
+    const uint64_t cv = cvals[d];
+    uint32_t c[RB_MAX_HASH];
+    for (int j = 0; j < fv.cbf_h; ++j) c[j] = (uint32_t)(cv >> (8 * j)) & 0xFFu;
+    run_ops(c, fv.cbf_h, (st >> 12) & 3u, (st >> 14) & 3u, tz, starts[d] + counts[d] - ops, ops);
+    uint64_t out = 0;
+    for (int j = 0; j < fv.cbf_h; ++j) {
+        const uint32_t c0 = (uint32_t)(cv >> (8 * j)) & 0xFFu;
+        out |= (uint64_t)((((con >> j) & 1u) && c[j] == c0) ? 0xFFu : c[j]) << (8 * j);
+    }
+    cfinal[d] = out;
+}
+// the heavy ones among them, after k_cbf_heavy left their final bytes: unchanged contested counters become releases
+__global__ void k_order_release_fix(int h, const uint32_t *__restrict__ heavy2, const uint32_t *__restrict__ n_heavy2, const uint32_t *__restrict__ status,
+                                    const uint64_t *__restrict__ cvals, uint64_t *__restrict__ cfinal) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *n_heavy2) return;
+    const uint32_t d = heavy2[i], con = (status[d] >> ST_CONTESTED_SHIFT) & 0xFFu;
+    const uint64_t cv = cvals[d];
+    uint64_t cf = cfinal[d];
+    for (int j = 0; j < h; ++j)
+        if (((con >> j) & 1u) && ((cf >> (8 * j)) & 0xFFull) == ((cv >> (8 * j)) & 0xFFull)) cf |= 0xFFull << (8 * j);
+    cfinal[d] = cf;
+}
+// their counter writes: this rank's own counters in place, the others as tagged records behind the edges (ctr[0] = records so far)
+__global__ void k_order_writes(FilterView fv, LocalRanges R, const uint64_t *__restrict__ uniq, const uint32_t *__restrict__ deferred, const uint32_t *__restrict__ n_def,
+                               const uint8_t *__restrict__ c_dup, const uint64_t *__restrict__ cfinal, const uint16_t *__restrict__ lmask,
+                               ConfEdge *__restrict__ out, uint32_t *__restrict__ n_out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *n_def) return;
+    const uint32_t d = deferred[i], cm = (uint32_t)lmask[d] >> 8;
+    const uint64_t h0 = uniq[d], cf = cfinal[d];
+    for (int j = 0; j < fv.cbf_h; ++j) {
+        if (c_dup[(size_t)d * fv.cbf_h + j] != j) continue;
+        const uint64_t idx = index_of(multi_hash(h0, (uint32_t)j, fv.kmul), fv.cbf_mod);
+        const uint8_t val = (uint8_t)(cf >> (8 * j));
+        if ((cm >> j) & 1u) { if (val == 0xFFu) cbf_release(fv.cbf, idx - R.clo); else fv.cbf[idx - R.clo] = val; continue; }
+        ConfEdge e; e.cidx = idx; e.gid = EDGE_WRITE; e.pad = val;
+        out[atomicAdd(n_out, 1u)] = e;
+    }
+}
+__global__ void k_apply_tagged(uint8_t *cbf, uint64_t lo, uint64_t hi, const ConfEdge *__restrict__ e, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || e[i].gid != EDGE_WRITE) return;
+    const uint64_t idx = e[i].cidx;
+    if (idx < lo || idx >= hi) return;
+    if ((e[i].pad & 0xFFu) == 0xFFu) cbf_release(cbf, idx - lo); else cbf[idx - lo] = (uint8_t)e[i].pad;
+}
+
 // ---- components of the global edge list by min-label propagation (every rank, identical result) ----
 __global__ void k_edge_init(const ConfEdge *__restrict__ e, size_t n, Slot *tab, uint32_t log2cap, uint32_t *__restrict__ eslot,
                             uint32_t *__restrict__ label) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    if (i >= n || e[i].gid == EDGE_WRITE) return;
     eslot[i] = (uint32_t)(table_insert(tab, log2cap, e[i].cidx) - tab);
     label[e[i].gid] = e[i].gid;
 }
@@ -654,6 +773,7 @@ __global__ void k_edge_round(const ConfEdge *__restrict__ e, size_t n, Slot *tab
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint32_t gid = e[i].gid;
+    if (gid == EDGE_WRITE) return;
     uint32_t *cv = reinterpret_cast<uint32_t *>(&tab[eslot[i]].val);
     const uint32_t lr = __hip_atomic_load(&label[gid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint32_t lc = __hip_atomic_load(cv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1686,16 +1806,15 @@ int rb_shard_serve(rb_graph *g, int mode, const void *dreq_idx_dev, const void *
 }
 
 int rb_shard_resolve(rb_graph *g, int mode, const void *dreply_dev, const void *creply_dev, int64_t *w_counts,
-                     int64_t *n_conf_runs, int64_t *n_conf_edges, rb_add_stats *stats) {
+                     int64_t *ord_counts, rb_add_stats *stats) {
     return guarded([&] {
-        RB_REQUIRE(g && g->shard && w_counts && n_conf_runs && n_conf_edges, "rb_shard_resolve: bad argument");
+        RB_REQUIRE(g && g->shard && w_counts && ord_counts, "rb_shard_resolve: bad argument");
         ShardState *S = g->shard;
         RB_HIP(hipSetDevice(g->p.device));
         hipStream_t s = g->stream;
-        for (int r = 0; r < S->G; ++r) w_counts[r] = 0;
-        *n_conf_runs = *n_conf_edges = 0;
-        S->n_conf = 0;
-        S->slot_bytes[RB_SLOT_W_IDX] = S->slot_bytes[RB_SLOT_W_VAL] = S->slot_bytes[RB_SLOT_CONF_EDGES] = S->slot_bytes[RB_SLOT_CACHE_UPD] = 0;
+        for (int r = 0; r < S->G; ++r) w_counts[r] = ord_counts[r] = 0;
+        S->n_conf = 0; S->n_cand = 0;
+        S->slot_bytes[RB_SLOT_W_IDX] = S->slot_bytes[RB_SLOT_W_VAL] = S->slot_bytes[RB_SLOT_CONF_EDGES] = S->slot_bytes[RB_SLOT_CACHE_UPD] = S->slot_bytes[RB_SLOT_ORD_IDX] = 0;
         const uint32_t D = S->D;
         if (!D) return;
         FilterView fv = g->view(S->ordinal0, S->pos_bits);
@@ -1728,7 +1847,7 @@ int rb_shard_resolve(rb_graph *g, int mode, const void *dreply_dev, const void *
             int64_t uc[1];
             route(g, fu, (size_t)D, uc, [&](RouteUpd &ff, size_t kept) { ff.out = (CacheUpd *)slot_reserve(S, RB_SLOT_CACHE_UPD, kept * sizeof(CacheUpd)); }, 1);
         }
-        // counter writes / releases, bucketed by counter owner
+        // counter writes / releases of the runs that are finished, bucketed by counter owner
         const size_t nc = (size_t)D * fv.cbf_h;
         S->stage0.reserve(nc * 8 + 16); S->stage2.reserve(2 * nc + 32);
         uint8_t *w_val = S->stage2.as<uint8_t>(), *w_drop = w_val + nc;
@@ -1739,27 +1858,115 @@ int rb_shard_resolve(rb_graph *g, int mode, const void *dreply_dev, const void *
             ff.out_idx = (uint64_t *)slot_reserve(S, RB_SLOT_W_IDX, kept * 8);
             ff.out8 = (uint8_t *)slot_reserve(S, RB_SLOT_W_VAL, kept);
         });
-        // conflicting runs: the edges (run, contested counter) every rank needs to find the components
+        // the runs with a contested counter: which of them can reach one — those ask the counters' owners who else can (rb_shard_order_*)
         if (hc[1]) {
             const uint32_t nck = hc[1];
-            RB_REQUIRE((uint64_t)nck * (uint64_t)S->G < (1ull << 32), "too many conflicting runs in one sub-batch (%u)", nck);
-            S->n_conf = nck;
-            S->esz.reserve(((size_t)nck + 1) * 4); S->eoff.reserve(((size_t)nck + 1) * 4);
-            hipLaunchKernelGGL(k_conf_sizes, dim3(blocks_for(nck + 1)), dim3(TPB), 0, s, S->conf_list.as<uint32_t>(), g->status.as<uint32_t>(), nck,
-                               S->esz.as<uint32_t>());
-            g->temp.reserve(scan_temp_bytes((size_t)nck + 1));
-            exclusive_scan_u32(g->temp.p, g->temp.cap, S->esz.as<uint32_t>(), S->eoff.as<uint32_t>(), (size_t)nck + 1, s);
-            uint32_t ne = 0;
-            RB_HIP(hipMemcpyAsync(&ne, S->eoff.as<uint32_t>() + nck, 4, hipMemcpyDeviceToHost, s));
-            RB_HIP(hipStreamSynchronize(s));
-            ConfEdge *eo = (ConfEdge *)slot_reserve(S, RB_SLOT_CONF_EDGES, (size_t)ne * sizeof(ConfEdge));
-            hipLaunchKernelGGL(k_conf_edges, dim3(blocks_for(nck)), dim3(TPB), 0, s, fv, g->uniq().as<uint64_t>(), S->conf_list.as<uint32_t>(),
-                               g->status.as<uint32_t>(), S->eoff.as<uint32_t>(), nck, (uint32_t)S->G, (uint32_t)g->shard_rank, eo);
-            *n_conf_runs = nck; *n_conf_edges = ne;
+            RB_REQUIRE((uint64_t)nck * (uint64_t)S->G < (1ull << 32), "too many runs with a contested counter in one sub-batch (%u)", nck);
+            S->n_cand = nck;
+            const size_t nq = (size_t)nck * fv.cbf_h;
+            S->oinfo.reserve((size_t)nck + 16); S->ord_pos.reserve(nq * 4 + 16);
+            S->stage3.reserve(nq * 8 + 16); S->stage1.reserve(nq + 16);
+            hipLaunchKernelGGL(k_order_requests, dim3(blocks_for(nck)), dim3(TPB), 0, s, fv, g->uniq().as<uint64_t>(), S->conf_list.as<uint32_t>(), nck,
+                               g->status.as<uint32_t>(), g->nops.as<uint32_t>(), g->cvals.as<uint64_t>(), S->creq_dup.as<uint8_t>(), S->oinfo.as<uint8_t>(),
+                               S->stage3.as<uint64_t>(), S->stage1.as<uint8_t>());
+            RouteIdx fo{S->stage3.as<uint64_t>(), S->stage1.as<uint8_t>(), (uint64_t)S->span[RB_CBF], nullptr, nullptr, nullptr, nullptr, nullptr, S->ord_pos.as<uint32_t>()};
+            route_any_order(g, fo, nq, ord_counts, [&](RouteIdx &ff, size_t kept) { ff.out_idx = (uint64_t *)slot_reserve(S, RB_SLOT_ORD_IDX, kept * 8); });
         }
         if (stats) stats->distinct += D;
         RB_HIP(hipGetLastError());
         RB_HIP(hipStreamSynchronize(s));
+    });
+}
+
+// owner: how many claimants that can reach something contested does each asked counter have (the table of contested counters of rb_shard_serve)
+int rb_shard_order_serve(rb_graph *g, const void *ord_idx_dev, int64_t n, void *reply_dev) {
+    return guarded([&] {
+        RB_REQUIRE(g && g->shard && n >= 0 && (n == 0 || (ord_idx_dev && reply_dev)), "rb_shard_order_serve: bad argument");
+        if (!n) return;
+        ShardState *S = g->shard;
+        RB_HIP(hipSetDevice(g->p.device));
+        hipStream_t s = g->stream;
+        RB_REQUIRE(S->has_cs, "rb_shard_order_serve: %lld requests but this rank found no contested counter in the serve phase", (long long)n);
+        hipLaunchKernelGGL(k_order_count, dim3(blocks_for(n)), dim3(TPB), 0, s, (const uint64_t *)ord_idx_dev, (size_t)n, S->own_cs.as<Slot>(), S->cs_log2);
+        hipLaunchKernelGGL(k_order_reply, dim3(blocks_for(n)), dim3(TPB), 0, s, (const uint64_t *)ord_idx_dev, (size_t)n, (const Slot *)S->own_cs.as<Slot>(), S->cs_log2,
+                           (uint8_t *)reply_dev);
+        RB_HIP(hipGetLastError());
+        RB_HIP(hipStreamSynchronize(s));
+    });
+}
+
+// requester: the answers are in — the runs in O* keep RUN_CONFLICT (their edges go to RB_SLOT_CONF_EDGES as before), the others are finished
+// here; their writes to other ranks' counters follow the edges in the same slot as tagged records (every rank applies its own: rb_shard_apply_tagged)
+int rb_shard_order_finish(rb_graph *g, int mode, const void *ord_reply_dev, int64_t *n_conf_runs, int64_t *n_conf_records, rb_add_stats *stats) {
+    return guarded([&] {
+        RB_REQUIRE(g && g->shard && n_conf_runs && n_conf_records, "rb_shard_order_finish: bad argument");
+        (void)mode; (void)stats;
+        ShardState *S = g->shard;
+        RB_HIP(hipSetDevice(g->p.device));
+        hipStream_t s = g->stream;
+        *n_conf_runs = *n_conf_records = 0;
+        S->n_conf = 0;
+        S->slot_bytes[RB_SLOT_CONF_EDGES] = 0;
+        const uint32_t nck = S->n_cand;
+        if (!nck) return;
+        FilterView fv = g->view(S->ordinal0, S->pos_bits);
+        uint32_t *ctr = g->devctr.as<uint32_t>();
+        S->conf2.reserve((size_t)nck * 4); S->deferred.reserve((size_t)nck * 4); S->heavy2.reserve((size_t)nck * 4);
+        RB_HIP(hipMemsetAsync(ctr + 940, 0, 32, s));            // [0] O* runs, [1] finished here, [2] heavy among those, [4] tagged records
+        const int order_all = (getenv("RB_SHARD_ORDER_ALL") && atoi(getenv("RB_SHARD_ORDER_ALL"))) ? 1 : 0;      // (A/B: every run with a contested counter is replayed, rounds 1-5)
+        hipLaunchKernelGGL(k_order_decide, dim3(blocks_for(nck)), dim3(TPB), 0, s, fv, g->counts().as<uint32_t>(), g->starts().as<uint32_t>(), S->conf_list.as<uint32_t>(), nck,
+                           S->oinfo.as<uint8_t>(), S->ord_pos.as<uint32_t>(), (const uint8_t *)ord_reply_dev, g->light_ops, order_all, g->status.as<uint32_t>(),
+                           g->nops.as<uint32_t>(), g->cvals.as<uint64_t>(), g->tz().as<uint8_t>(), S->cfinal.as<uint64_t>(), S->conf2.as<uint32_t>(),
+                           S->deferred.as<uint32_t>(), S->heavy2.as<uint32_t>(), ctr + 940);
+        uint32_t c3[3] = {0, 0, 0};
+        RB_HIP(hipMemcpyAsync(c3, ctr + 940, 12, hipMemcpyDeviceToHost, s));
+        RB_HIP(hipStreamSynchronize(s));
+        const uint32_t n_o = c3[0], n_def = c3[1], n_h2 = c3[2];
+        if (n_h2) {
+            hipLaunchKernelGGL(k_cbf_heavy, dim3(std::min<uint32_t>(n_h2, 262144u)), dim3(64), 0, s, fv, g->uniq().as<uint64_t>(), g->counts().as<uint32_t>(),
+                               g->starts().as<uint32_t>(), g->vals1().as<uint32_t>(), g->status.as<uint32_t>(), g->nops.as<uint32_t>(),
+                               g->cvals.as<uint64_t>(), g->tz().as<uint8_t>(), S->heavy2.as<uint32_t>(), ctr + 942, S->cfinal.as<uint64_t>(), (uint8_t *)nullptr);
+            hipLaunchKernelGGL(k_order_release_fix, dim3(blocks_for(n_h2)), dim3(TPB), 0, s, (int)fv.cbf_h, S->heavy2.as<uint32_t>(), ctr + 942, g->status.as<uint32_t>(),
+                               g->cvals.as<uint64_t>(), S->cfinal.as<uint64_t>());
+        }
+        // edges of the O* runs (conf_list <- conf2: local run number i of the edge ids counts inside THIS list)
+        uint32_t ne = 0;
+        if (n_o) {
+            RB_HIP(hipMemcpyAsync(S->conf_list.p, S->conf2.p, (size_t)n_o * 4, hipMemcpyDeviceToDevice, s));
+            S->n_conf = n_o;
+            S->esz.reserve(((size_t)n_o + 1) * 4); S->eoff.reserve(((size_t)n_o + 1) * 4);
+            hipLaunchKernelGGL(k_conf_sizes, dim3(blocks_for(n_o + 1)), dim3(TPB), 0, s, S->conf_list.as<uint32_t>(), g->status.as<uint32_t>(), n_o, S->esz.as<uint32_t>());
+            g->temp.reserve(scan_temp_bytes((size_t)n_o + 1));
+            exclusive_scan_u32(g->temp.p, g->temp.cap, S->esz.as<uint32_t>(), S->eoff.as<uint32_t>(), (size_t)n_o + 1, s);
+            RB_HIP(hipMemcpyAsync(&ne, S->eoff.as<uint32_t>() + n_o, 4, hipMemcpyDeviceToHost, s));
+            RB_HIP(hipStreamSynchronize(s));
+        }
+        ConfEdge *eo = (ConfEdge *)slot_reserve(S, RB_SLOT_CONF_EDGES, ((size_t)ne + (size_t)n_def * fv.cbf_h) * sizeof(ConfEdge));
+        if (n_o)
+            hipLaunchKernelGGL(k_conf_edges, dim3(blocks_for(n_o)), dim3(TPB), 0, s, fv, g->uniq().as<uint64_t>(), S->conf_list.as<uint32_t>(),
+                               g->status.as<uint32_t>(), S->eoff.as<uint32_t>(), n_o, (uint32_t)S->G, (uint32_t)g->shard_rank, eo);
+        uint32_t n_tag = 0;
+        if (n_def) {
+            hipLaunchKernelGGL(k_order_writes, dim3(blocks_for(n_def)), dim3(TPB), 0, s, fv, local_ranges(g), g->uniq().as<uint64_t>(), S->deferred.as<uint32_t>(), ctr + 941,
+                               S->creq_dup.as<uint8_t>(), S->cfinal.as<uint64_t>(), S->lmask.as<uint16_t>(), eo + ne, ctr + 944);
+            RB_HIP(hipMemcpyAsync(&n_tag, ctr + 944, 4, hipMemcpyDeviceToHost, s));
+            RB_HIP(hipStreamSynchronize(s));
+        }
+        S->slot_bytes[RB_SLOT_CONF_EDGES] = ((size_t)ne + n_tag) * sizeof(ConfEdge);
+        *n_conf_runs = n_o; *n_conf_records = (int64_t)ne + n_tag;
+        RB_HIP(hipGetLastError());
+        RB_HIP(hipStreamSynchronize(s));
+    });
+}
+
+// every rank, after the all-gather of the edge slots: the tagged counter writes that fall into this rank's range
+int rb_shard_apply_tagged(rb_graph *g, const void *records_dev, int64_t n) {
+    return guarded([&] {
+        RB_REQUIRE(g && g->shard && n >= 0, "rb_shard_apply_tagged: bad argument");
+        RB_HIP(hipSetDevice(g->p.device));
+        if (n) hipLaunchKernelGGL(k_apply_tagged, dim3(blocks_for(n)), dim3(TPB), 0, g->stream, g->cbf, (uint64_t)g->cbf_lo, (uint64_t)g->cbf_hi, (const ConfEdge *)records_dev, (size_t)n);
+        RB_HIP(hipGetLastError());
+        RB_HIP(hipStreamSynchronize(g->stream));
     });
 }
 
@@ -2010,7 +2217,7 @@ void shard_free(rb_graph *g) {
     ShardState *S = g->shard;
     if (!S) return;
     for (auto &b : S->slot) b.release();
-    DevBuf *bufs[] = {&S->dreq_pos, &S->creq_pos, &S->creq_dup, &S->cfinal, &S->conf_list, &S->stage0, &S->stage1, &S->stage2, &S->stage3,
+    DevBuf *bufs[] = {&S->dreq_pos, &S->creq_pos, &S->creq_dup, &S->cfinal, &S->conf_list, &S->oinfo, &S->ord_pos, &S->conf2, &S->deferred, &S->heavy2, &S->stage0, &S->stage1, &S->stage2, &S->stage3,
                       &S->rhist, &S->roffs, &S->bounds, &S->rcnt, &S->own_f, &S->own_cs, &S->esz, &S->eoff, &S->etab, &S->eslot, &S->elabel, &S->cdesc,
                       &S->cpos, &S->cnops, &S->cnoff, &S->rk0, &S->rk1, &S->ok0, &S->ok1, &S->ov0, &S->ov1, &S->rtab, &S->rslot, &S->rbig, &S->q_h0, &S->q_bpos, &S->q_cpos, &S->q_out, &S->cache_upd, &S->lmask, &S->lcoll, &S->lcv, &S->lctr};
     for (auto *b : bufs) b->release();

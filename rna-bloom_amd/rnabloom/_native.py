@@ -16,7 +16,7 @@ OP_ADD, OP_ADD_IF_ABSENT, OP_ADD_COUNT_IF_PRESENT, OP_ADD_DBG_ONLY, OP_ADD_COUNT
     OP_ADD_READ_PAIR, OP_ADD_FRAG_PAIR = range(7)
 PROF_MAX = 32
 SLOT_REC_KEYS, SLOT_REC_OCC, SLOT_PAIR_IDX, SLOT_DREQ_IDX, SLOT_DREQ_PROBE, SLOT_CREQ_IDX, SLOT_W_IDX, SLOT_W_VAL, \
-    SLOT_CONF_EDGES, SLOT_CONF_RUNS, SLOT_CONF_OPS, SLOT_CW_IDX, SLOT_CW_VAL, SLOT_Q_BIDX, SLOT_Q_CIDX, SLOT_CACHE_UPD = range(16)
+    SLOT_CONF_EDGES, SLOT_CONF_RUNS, SLOT_CONF_OPS, SLOT_CW_IDX, SLOT_CW_VAL, SLOT_Q_BIDX, SLOT_Q_CIDX, SLOT_CACHE_UPD, SLOT_ORD_IDX = range(17)
 MODE_ADD, MODE_COUNT_IF_PRESENT = 0, 2
 STROBE_CANONICAL, STROBE_SLIDE = 1, 2
 
@@ -129,7 +129,10 @@ SYMBOLS = [
     ("rb_shard_hash_group", _i32, [_vp, _vp, _i64, _i64, _i64, _i64, _u64, _u32, C.c_uint, C.POINTER(_i64), C.POINTER(_i64),
                              C.POINTER(_i64), C.POINTER(AddStats)]),
     ("rb_shard_serve", _i32, [_vp, _i32, _vp, _vp, _i64, _vp, _i64, _vp, _i64, _vp, _vp]),
-    ("rb_shard_resolve", _i32, [_vp, _i32, _vp, _vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_i64), C.POINTER(AddStats)]),
+    ("rb_shard_resolve", _i32, [_vp, _i32, _vp, _vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(AddStats)]),
+    ("rb_shard_order_serve", _i32, [_vp, _vp, _i64, _vp]),
+    ("rb_shard_order_finish", _i32, [_vp, _i32, _vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(AddStats)]),
+    ("rb_shard_apply_tagged", _i32, [_vp, _vp, _i64]),
     ("rb_shard_apply_writes", _i32, [_vp, _vp, _vp, _i64]),
     ("rb_shard_conflict_route", _i32, [_vp, _vp, _i64, _i64, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(AddStats)]),
     ("rb_shard_conflict_replay", _i32, [_vp, _vp, _i64, _vp, _i64, C.POINTER(_i64)]),

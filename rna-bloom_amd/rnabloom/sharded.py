@@ -183,21 +183,31 @@ class ShardRank:
         mark("serve")
         (my_dreply, my_creply), _ = yield ("a2a", [dreply, creply], [[c // 8 for c in o_dc], [c // 8 for c in o_cc]], [d_c, c_c])
         # resolve: runs that own their counters alone finish here
-        w_c, nconf, nedge = cnt(), C.c_int64(), C.c_int64()
-        check(lib.rb_shard_resolve(self.h, mode, _ptr(my_dreply), _ptr(my_creply), w_c, C.byref(nconf), C.byref(nedge), C.byref(st)))
-        w_c = list(w_c)
+        w_c, ord_c, nconf, nedge = cnt(), cnt(), C.c_int64(), C.c_int64()
+        check(lib.rb_shard_resolve(self.h, mode, _ptr(my_dreply), _ptr(my_creply), w_c, ord_c, C.byref(st)))
+        w_c, ord_c = list(w_c), list(ord_c)
         if nxt and _OVERLAP == 1 and not split:   # after the cache updates of this sub-batch: fresher prefilter, less overlap
             check(lib.rb_shard_hash_begin(self.h, batch.h, nxt[0], nxt[1], self.ordinal + int(n), pos_bits, flags))
         mark("resolve")
-        (o_widx, o_wval), (o_wc, _) = yield ("a2a", [self._slot(N.SLOT_W_IDX, 8 * sum(w_c)), self._slot(N.SLOT_W_VAL, sum(w_c))], [[8 * c for c in w_c], w_c])
+        # counter writes of the finished runs, and — same exchange — the contested counters of the runs that can reach one: who else can?
+        (o_widx, o_wval, o_ord), (o_wc, _, o_oc) = yield ("a2a", [self._slot(N.SLOT_W_IDX, 8 * sum(w_c)), self._slot(N.SLOT_W_VAL, sum(w_c)),
+                                                                  self._slot(N.SLOT_ORD_IDX, 8 * sum(ord_c))], [[8 * c for c in w_c], w_c, [8 * c for c in ord_c]])
         check(lib.rb_shard_apply_writes(self.h, _ptr(o_widx), _ptr(o_wval), sum(o_wc) // 8))
+        n_ord = sum(o_oc) // 8
+        oreply = torch.empty(n_ord, dtype=torch.uint8, device=self.tdev)
+        check(lib.rb_shard_order_serve(self.h, _ptr(o_ord), n_ord, _ptr(oreply)))
         if nxt and _OVERLAP == 1 and not split:
             check(lib.rb_shard_hash_emit(self.h))
         mark("writes")
+        (my_oreply,), _ = yield ("a2a", [oreply], [[c // 8 for c in o_oc]], [ord_c])
+        # the ordered set: runs in it keep their edges, the others are finished here (their remote writes ride behind the edges)
+        check(lib.rb_shard_order_finish(self.h, mode, _ptr(my_oreply), C.byref(nconf), C.byref(nedge), C.byref(st)))
+        mark("order")
         # one all_gather: the (run, contested counter) edges of the runs that share a counter and, in split mode, what
         # the owners learnt about their k-mers' counters (for every rank's prefilter cache replica)
         if split:
             (all_edges, e_sizes), (upd, u_sizes) = yield ("gather", [self._slot(N.SLOT_CONF_EDGES, 16 * nedge.value), self._slot(N.SLOT_CACHE_UPD)])
+            if sum(e_sizes): check(lib.rb_shard_apply_tagged(self.h, _ptr(all_edges), sum(e_sizes) // 16))
             # every rank's updates but this rank's own (its replica got them when they were made, in rb_shard_resolve)
             before, mine = sum(u_sizes[:self.rank]), u_sizes[self.rank]
             if before: check(lib.rb_shard_cache_apply(self.h, _ptr(upd[:before]), before // 16))
@@ -208,6 +218,7 @@ class ShardRank:
             mark("cache_upd")
         else:
             all_edges, e_sizes = yield ("gather", self._slot(N.SLOT_CONF_EDGES, 16 * nedge.value))
+            if sum(e_sizes): check(lib.rb_shard_apply_tagged(self.h, _ptr(all_edges), sum(e_sizes) // 16))
         # components -> component owner -> ordered replay -> counter owners
         if sum(e_sizes):
             run_c, op_c = cnt(), cnt()
