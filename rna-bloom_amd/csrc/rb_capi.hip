@@ -130,6 +130,7 @@ int rb_graph_create(const rb_graph_params *p, rb_graph **out) {
         RB_REQUIRE(p->group_bits >= 0 && p->group_bits <= 64, "rb_graph_create: group_bits out of range [0,64]");
         if (p->group_bits) g->sort_begin_bit = 64 - p->group_bits;
         if (const char *e = getenv("RB_LIGHT_OPS")) g->light_ops = (uint32_t)std::max(1, atoi(e));
+        if (const char *e = getenv("RB_SMALL_COMPONENT_OPS")) g->small_ops = (uint32_t)std::max(1, atoi(e));
         if (const char *e = getenv("RB_SORT_BEGIN_BIT")) g->sort_begin_bit = std::max(0, std::min(63, atoi(e)));
         RB_REQUIRE(g->max_batch_kmers <= ((int64_t)1 << 31), "rb_graph_create: max_batch_kmers above 2^31");
         if (const char *e = getenv("RB_CONSUMER_PRIORITY")) RB_HIP(hipStreamCreateWithPriority(&g->stream, hipStreamNonBlocking, atoi(e)));

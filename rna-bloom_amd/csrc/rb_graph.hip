@@ -732,21 +732,20 @@ __device__ void replay_serial(const FilterView &fv, const uint64_t *__restrict__
             if (c[j] != c0[j]) *(volatile uint8_t *)&fv.cbf[idx[j]] = (uint8_t)c[j];
     }
 }
-constexpr uint32_t SMALL_COMPONENT_OPS = 256;
 constexpr uint32_t MAX_COMPONENT_KMERS = 8;
 // one thread per conflicting k-mer (sorted by component label): component heads either replay a
 // small component themselves or queue it for the wave-cooperative kernel
 __global__ void k_conf_replay_small(FilterView fv, const uint64_t *__restrict__ uniq, const uint64_t *__restrict__ kmer_keys,
                                     uint32_t n_conf, const uint64_t *__restrict__ op_key, const uint32_t *__restrict__ op_val,
                                     uint32_t n_ops, uint32_t *__restrict__ big_list, uint32_t *__restrict__ n_big, int store_cache,
-                                    const uint32_t *__restrict__ starts, const uint32_t *__restrict__ vals) {
+                                    const uint32_t *__restrict__ starts, const uint32_t *__restrict__ vals, uint32_t small_ops) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_conf) return;
     const uint32_t lab = (uint32_t)(kmer_keys[i] >> 32);
     if (i > 0 && (uint32_t)(kmer_keys[i - 1] >> 32) == lab) return;   // not a component head
     const uint32_t os = lower_bound_u64(op_key, n_ops, (uint64_t)lab << 32);
     const uint32_t oe = lower_bound_u64(op_key, n_ops, ((uint64_t)lab + 1ull) << 32);
-    if (oe - os > SMALL_COMPONENT_OPS) { big_list[atomicAdd(n_big, 1u)] = i; return; }
+    if (oe - os > small_ops) { big_list[atomicAdd(n_big, 1u)] = i; return; }
     replay_serial(fv, uniq, op_key, op_val, os, oe);
     if (store_cache && cache_on(fv))   // the component's k-mers are in dbgbf; remember their counter exponents
         for (uint32_t q = i; q < n_conf && (uint32_t)(kmer_keys[q] >> 32) == lab; ++q) {
@@ -1792,7 +1791,7 @@ void run_core(rb_graph *g, size_t N, uint32_t D, int mode, uint64_t ordinal0, ui
         g->prof_begin();
         RB_HIP(hipMemsetAsync(ctr + 4, 0, 4, s));
         hipLaunchKernelGGL(k_conf_replay_small, dim3(blocks_for(nck)), dim3(TPB), 0, s, fv, uniq, g->kk1.as<uint64_t>(), nck,
-                           g->opk1.as<uint64_t>(), g->opv1.as<uint32_t>(), nco, g->biglist.as<uint32_t>(), ctr + 4, (int)(mode != M_COUNT_ONLY), starts, vals);
+                           g->opk1.as<uint64_t>(), g->opv1.as<uint32_t>(), nco, g->biglist.as<uint32_t>(), ctr + 4, (int)(mode != M_COUNT_ONLY), starts, vals, g->small_ops);
         hipLaunchKernelGGL(k_conf_replay_big, dim3(std::min<uint32_t>(nck, 262144u)), dim3(64), 0, s, fv, uniq, g->kk1.as<uint64_t>(), nck,
                            g->opk1.as<uint64_t>(), g->opv1.as<uint32_t>(), nco, g->biglist.as<uint32_t>(), ctr + 4,
                            getenv("RB_DEBUG") ? ctr + 600 : (uint32_t *)nullptr, (int)(mode != M_COUNT_ONLY), starts, vals);

@@ -357,6 +357,7 @@ struct rb_graph {
     int64_t max_batch_kmers = 0;
     int sort_begin_bit = 28;
     uint32_t light_ops = 96;
+    uint32_t small_ops = 32;             // a component of at most this many ops is replayed by one lane (k_conf_replay_small), a larger one by a wavefront; RB_SMALL_COMPONENT_OPS
     hipStream_t stream = nullptr;    // consumer stream: everything that touches the filters
     hipStream_t stream2 = nullptr;   // producer stream: hashing + grouping of the NEXT sub-batch (scratch only)
     hipStream_t stream3 = nullptr;   // side stream of the producer: the paired-k-mer walker (rpkbf only) beside the window walk

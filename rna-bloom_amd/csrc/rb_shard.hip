@@ -951,13 +951,12 @@ __device__ void replay_serial_tab(const FilterView &fv, Slot *tab, const uint32_
             if (c[j] != c0[j]) *(volatile unsigned long long *)&tab[sl[j]].val = c[j];
     }
 }
-constexpr uint32_t SMALL_COMPONENT_OPS = 256;
 constexpr uint32_t MAX_COMPONENT_KMERS = 8;
 // one thread per run (sorted by component label): component heads either replay a small component
 // themselves or flag it for the wave-cooperative kernel
 __global__ void k_replay_small(FilterView fv, Slot *tab, const uint32_t *__restrict__ rslot, const uint64_t *__restrict__ run_keys,
                                uint32_t R, const uint64_t *__restrict__ op_key, const uint32_t *__restrict__ op_val, uint32_t n_ops,
-                               uint32_t *__restrict__ big_flag) {
+                               uint32_t *__restrict__ big_flag, uint32_t small_ops) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= R) return;
     big_flag[i] = 0;
@@ -965,7 +964,7 @@ __global__ void k_replay_small(FilterView fv, Slot *tab, const uint32_t *__restr
     if (i > 0 && (uint32_t)(run_keys[i - 1] >> 32) == lab) return;   // not a component head
     const uint32_t os = lower_bound_u64(op_key, n_ops, (uint64_t)lab << 32);
     const uint32_t oe = lower_bound_u64(op_key, n_ops, ((uint64_t)lab + 1ull) << 32);
-    if (oe - os > SMALL_COMPONENT_OPS) { big_flag[i] = 1u; return; }
+    if (oe - os > small_ops) { big_flag[i] = 1u; return; }
     replay_serial_tab(fv, tab, rslot, op_key, op_val, os, oe);
 }
 // one wavefront per large component: the component's counters live in LDS; 64 ops are examined at
@@ -2092,7 +2091,7 @@ int rb_shard_conflict_replay(rb_graph *g, const void *runs_dev, int64_t n_runs, 
             g->devctr.reserve(DEVCTR_BYTES);
             uint32_t *ctr = g->devctr.as<uint32_t>();
             hipLaunchKernelGGL(k_replay_small, dim3(blocks_for(R)), dim3(TPB), 0, s, fv, S->rtab.as<Slot>(), S->rslot.as<uint32_t>(), S->rk1.as<uint64_t>(), R,
-                               S->ok1.as<uint64_t>(), S->ov1.as<uint32_t>(), O, big_flag);
+                               S->ok1.as<uint64_t>(), S->ov1.as<uint32_t>(), O, big_flag, g->small_ops);
             select_flagged(g->temp.p, g->temp.cap, big_flag, 1u, R, big_list, ctr + 4, s);
             hipLaunchKernelGGL(k_replay_big, dim3(std::min<uint32_t>(R, 65536u)), dim3(64), 0, s, fv, S->rtab.as<Slot>(), S->rslot.as<uint32_t>(), runs,
                                S->rk1.as<uint64_t>(), R, S->ok1.as<uint64_t>(), S->ov1.as<uint32_t>(), O, big_list, ctr + 4);
