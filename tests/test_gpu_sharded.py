@@ -111,6 +111,28 @@ def test_loopback_queries_match_single_gpu():
     cl.destroy(); gg.destroy() if hasattr(gg, "destroy") else None
 
 
+@pytest.mark.parametrize("env", [{"RB_SHARD_ORDER_ALL": "1"}, {"RB_SMALL_COMPONENT_OPS": "1"}, {"RB_SMALL_COMPONENT_OPS": "1000000"},
+                                 {"RB_SHARD_ORDER_ALL": "1", "RB_SMALL_COMPONENT_OPS": "1"}])
+@pytest.mark.parametrize("G", [2, 8])
+def test_conflict_path_switches_do_not_change_results(monkeypatch, env, G):
+    """which runs with a contested counter are replayed (the ordered set decided with the counters' owners, or every one of them as before
+    round 6) and whether a lane or a wavefront replays a component are scheduling choices: few k-mers at high multiplicity in small
+    filters — most runs share a counter — come out as the oracle's either way"""
+    for k_, v in env.items():
+        monkeypatch.setenv(k_, v)
+    d = synth.generate_pairs(3000, G=2500, err=0.002, n_rate=1e-3, seed=23, uniform_expr=True)
+    sizes = (60_013, 40_009, 9_001)
+    og = rbo.Graph(*sizes, 2, 2, 2, 25, False, True, 3)
+    cl = LoopbackCluster(G, *sizes, 2, 2, 2, 25, False, True, rngSeed=3, mode="split")
+    og.set_read_pair_distance(115); cl.setReadPairedKmerDistance(115)
+    s, off = synth.flat(d["left"]); q, _ = synth.flat(d["lqual"])
+    og.add_reads(s, q, off, 3, rbo.STORE_READ_PAIRS)
+    cl.addBatch(ReadBatch.from_ascii(s, q, off, 3), 150, storeReadPairedKmers=True, reads_per_substep=700)
+    check_filters(cl, og)
+    assert sum(r.stats["conflict_ops"] for r in cl.ranks) > 1000 and og.cbf_bytes().max() > 24
+    cl.destroy()
+
+
 @pytest.mark.parametrize("overlap", [0, 1, 2])
 def test_loopback_lookahead_modes(monkeypatch, overlap):
     """look-ahead hashing of the next sub-batch (replicated-hashing mode) is a scheduling choice only"""
