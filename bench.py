@@ -489,7 +489,21 @@ def host_resident_leg(a, g, batch, pairs_total, kmers_per_step):
             km += g.addPacked(ph, reverseComplement=rc, storeReadPairedKmers=True, pieceReads=a.host_piece_reads).kmers
         return km
 
-    # the link alone: both files through a packed stream, chunk after chunk, nothing inserted
+    step()                                     # warm-up (the handle's ingest buffers)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    km = 0
+    marks = [t0]
+    for _ in range(a.steps):
+        km += step()
+        marks.append(time.perf_counter())
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if os.environ.get("RB_HOST_TIMING"):
+        print("[bench] host-resident steps (ms): " + " ".join("%.1f" % ((marks[i + 1] - marks[i]) * 1e3) for i in range(a.steps)), file=sys.stderr, flush=True)
+    equal = fold() == ref
+    # the link alone: both files through a packed stream, chunk after chunk, nothing inserted (after the timed steps: it has device buffers and a
+    # stream of its own)
     chunk = min(pairs_total, 12_500_000)
     ps = PackedStream(chunk, max(ph.words_before(min(r0 + chunk, ph.n_reads)) - ph.words_before(r0) for ph, _ in files for r0 in range(0, ph.n_reads, chunk)), device=g.device)
     torch.cuda.synchronize()
@@ -499,15 +513,6 @@ def host_resident_leg(a, g, batch, pairs_total, kmers_per_step):
             ps.begin(ph, r0, min(chunk, ph.n_reads - r0)); ps.finish()
     link_s = time.perf_counter() - t0
     ps.close()
-    step()                                     # warm-up (the handle's ingest buffers)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    km = 0
-    for _ in range(a.steps):
-        km += step()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    equal = fold() == ref
     for ph, _ in files:
         ph.close()
     return {"value": km / dt, "unit": "k-mers/s", "ms_per_step": dt / a.steps * 1e3, "steps": a.steps, "kmers_per_step": km // a.steps,

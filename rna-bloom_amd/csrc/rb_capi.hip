@@ -143,6 +143,10 @@ int rb_graph_create(const rb_graph_params *p, rb_graph **out) {
             RB_HIP(hipStreamCreateWithPriority(&g->stream2, hipStreamNonBlocking, pr));
             RB_HIP(hipStreamCreateWithPriority(&g->stream3, hipStreamNonBlocking, pr));
         }
+        // the packed ingest's copy stream (rb_packed.hip) is created HERE, not at the first upload: HIP hands its streams to a few hardware queues in the
+        // order they are made, and a copy stream made after a query context's stream (rb_filter_fold before the first rb_graph_add_packed was enough)
+        // shared a queue with the insert's kernels — its pieces queued behind them, 10 ms of every 300 ms step (tools/host_gap.py, HISTORY "Round 6")
+        RB_HIP(hipStreamCreateWithFlags(&g->pk_stream, hipStreamNonBlocking));
         RB_HIP(hipEventCreate(&g->ev0));
         RB_HIP(hipEventCreate(&g->ev1));
         RB_HIP(hipEventCreateWithFlags(&g->ev2, hipEventDisableTiming));

@@ -34,4 +34,4 @@ def test_every_stage_model_is_within_reach_of_its_counters():
     assert abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-3
     # the host-resident leg is on the line, equal filters, and within reach of the HBM-resident figure
     hr = j["host_resident"]
-    assert hr["filters_equal_resident"] is True and hr["value"] >= 0.85 * j["value"]
+    assert hr["filters_equal_resident"] is True and hr["value"] >= 0.9 * j["value"]
