@@ -44,9 +44,12 @@ def resident():
 
 
 def packed():
-    g.clearAllBf()
+    if os.environ.get("HOST_GAP_CLEAR_FIRST"):
+        g.clearAllBf()
     for ph, _ in files:
         g.prefetchPacked(ph)
+    if not os.environ.get("HOST_GAP_CLEAR_FIRST"):
+        g.clearAllBf()                  # (as bench.py does: the clear waits for its memsets; the uploads are under way meanwhile)
     for ph, rc in files:
         g.addPacked(ph, reverseComplement=rc, storeReadPairedKmers=True)
 
