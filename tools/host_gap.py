@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Where the host-resident leg's extra milliseconds go (bench.py `host_resident` against the HBM-resident step), config 2 on one GPU:
   A  resident:      clear + addBatch x 2
-  B  as benched:    clear + prefetchPacked x 2 + addPacked x 2               (every byte uploaded inside the timed region)
+  B  as benched:    prefetchPacked x 2 + clear + addPacked x 2               (every byte uploaded inside the timed region; HOST_GAP_CLEAR_FIRST=1: the clear first)
   C  pre-uploaded:  prefetchPacked x 2, wait for the copies, THEN time clear + addPacked x 2   (the packed path without its link time)
   D  clear alone
   E  file 1 pre-uploaded, file 2 uploaded inside the timed region beside file 1's insert
