@@ -144,7 +144,12 @@ int rb_graph_add_fragments(rb_graph *g, const rb_batch *b, int64_t first, int64_
 /* reads [first, first+n) of the batch only */
 int rb_graph_add_batch_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigned flags,
                              rb_add_stats *stats);
-/* convenience: rb_batch_create_ascii + rb_graph_add_batch + rb_batch_destroy */
+/* FastqToGraphWorker.run (R/RNABloom.java:526-643) over host ASCII reads: the result of rb_batch_create_ascii + rb_graph_add_batch + rb_batch_destroy,
+ * as a pipeline.  The caller's arrays are registered for the call (best effort, slab by slab ahead of the copies) and handed back when it returns.
+ * Input of more than one piece (256 M bases): ONE insert over a device batch sized for the whole call — lengths and word offsets are computed on the
+ * GPU from `offsets`, bases and qualities follow piece by piece through two staging buffers and the 2-bit encode kernel on the handle's copy stream,
+ * and the insert works on the pieces that have arrived (csrc/rb_packed.hip add_reads_streamed; 17.7 G k-mers/s for 50 M reads of 150 bases = 15 GB
+ * over a 57 GB/s link, HISTORY "Round 6").  Smaller input: one chunk.  stats is added to, not cleared. */
 int rb_graph_add_reads(rb_graph *g, const char *seq, const char *qual, const int64_t *offsets,
                        int64_t n_reads, int min_base_qual, unsigned flags, rb_add_stats *stats);
 

@@ -23,21 +23,31 @@ constexpr int TPB = 256;
 inline unsigned blocks_for(int64_t n, int tpb = TPB) { return (unsigned)((n + tpb - 1) / tpb); }
 
 // ---------------------------------------------------------------- encode ----
-__global__ void k_encode_ascii(const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual,
-                               const int64_t *__restrict__ off, const uint32_t *__restrict__ woff,
-                               int64_t n_reads, int64_t n_words, int min_q,
-                               uint64_t *__restrict__ codes, uint32_t *__restrict__ valid,
-                               uint32_t *__restrict__ word_read, uint32_t *__restrict__ rnz = nullptr) {
+// PIECE: reads [r_first, r_first + n_reads) of a larger batch's tables (off, woff: the whole batch's), whose bytes start at seq[0] = base seq_base of
+// the caller's array (a staging buffer holds one piece at a time: rb_packed.hip, the streamed ASCII ingest); n_words is then an upper bound for
+// the grid, the piece's words are [woff[r_first], woff[r_first + n_reads)).  Otherwise a whole batch: off relative to seq[0], words [0, n_words).
+template <bool PIECE>
+__global__ void k_encode_ascii_t(const uint8_t *__restrict__ seq, const uint8_t *__restrict__ qual,
+                                 const int64_t *__restrict__ off, const uint32_t *__restrict__ woff,
+                                 int64_t n_reads, int64_t n_words, int min_q,
+                                 uint64_t *__restrict__ codes, uint32_t *__restrict__ valid,
+                                 uint32_t *__restrict__ word_read, uint32_t *__restrict__ rnz,
+                                 int64_t r_first, int64_t seq_base) {
     int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= n_words) return;
-    // owning read: largest r with woff[r] <= w  (reads with zero words are skipped automatically)
-    int64_t lo = 0, hi = n_reads;   // invariant woff[lo] <= w < woff[hi]
-    while (hi - lo > 1) {
-        int64_t mid = (lo + hi) >> 1;
-        if (woff[mid] <= (uint32_t)w) lo = mid; else hi = mid;
-    }
+    if (PIECE) { w += woff[r_first]; if (w >= (int64_t)woff[r_first + n_reads]) return; }
+    else if (w >= n_words) return;
+    // owning read: largest r with woff[r] <= w  (reads with zero words are skipped automatically).  A piece finds it in word_read, filled for the whole
+    // batch by one pass over the reads (rb_packed.hip k_packed_word_read): the 21-step search per word made a 256 M-base piece's encode 2 ms on a
+    // stream whose copies wait behind it
+    int64_t lo = r_first, hi = r_first + n_reads;   // invariant woff[lo] <= w < woff[hi]
+    if (PIECE) lo = word_read[w];
+    else
+        while (hi - lo > 1) {
+            int64_t mid = (lo + hi) >> 1;
+            if (woff[mid] <= (uint32_t)w) lo = mid; else hi = mid;
+        }
     const int64_t r = lo;
-    const int64_t base0 = off[r], len = off[r + 1] - base0;
+    const int64_t base0 = off[r] - seq_base, len = off[r + 1] - off[r];
     const int64_t b0 = (w - woff[r]) * 32;
     uint64_t c = 0;
     uint32_t v = 0, rz = 0;
@@ -75,9 +85,21 @@ __global__ void k_encode_ascii(const uint8_t *__restrict__ seq, const uint8_t *_
     codes[w] = c;
     valid[w] = v;
     if (rnz) rnz[w] = rz;
-    word_read[w] = (uint32_t)r;
+    if (!PIECE) word_read[w] = (uint32_t)r;
 }
 
+}  // namespace
+namespace rb {
+// one piece of a streamed ASCII ingest (rb_packed.hip): reads [r_first, r_first + n_reads) of the batch whose tables off_all / woff_all are, their bytes
+// in the staging arrays from the caller's base seq_base on; the grid covers words_ub >= the piece's words
+void launch_encode_ascii_piece(const uint8_t *seq, const uint8_t *qual, const int64_t *off_all, const uint32_t *woff_all, int64_t r_first, int64_t n_reads,
+                               int64_t seq_base, int64_t words_ub, int min_q, uint64_t *codes, uint32_t *valid, uint32_t *word_read, hipStream_t st) {
+    if (n_reads <= 0 || words_ub <= 0) return;
+    hipLaunchKernelGGL(k_encode_ascii_t<true>, dim3(blocks_for(words_ub)), dim3(TPB), 0, st, seq, qual, off_all, woff_all, n_reads, words_ub, min_q, codes, valid,
+                       word_read, (uint32_t *)nullptr, r_first, seq_base);
+}
+}  // namespace rb
+namespace {
 __global__ void k_decode_ascii(const uint64_t *__restrict__ codes, const uint32_t *__restrict__ valid,
                                const uint32_t *__restrict__ word_read, const uint32_t *__restrict__ woff,
                                const uint32_t *__restrict__ len, int64_t w0, int64_t nw,
@@ -168,11 +190,17 @@ struct HostGuard {   // frees partially built batches on exceptions
 
 void alloc_batch_arrays(rb_batch *b) {
     size_t nw = (size_t)std::max<int64_t>(b->n_words, 1), nr = (size_t)std::max<int64_t>(b->n_reads, 1);
-    RB_HIP(hipMalloc(&b->codes, nw * 8));
-    RB_HIP(hipMalloc(&b->valid, nw * 4));
-    RB_HIP(hipMalloc(&b->word_read, nw * 4));
-    RB_HIP(hipMalloc(&b->woff, (nr + 1) * 4));
-    RB_HIP(hipMalloc(&b->len, nr * 4));
+    if (b->pool) {
+        b->codes = static_cast<uint64_t *>(b->pool->get(nw * 8)); b->valid = static_cast<uint32_t *>(b->pool->get(nw * 4));
+        b->word_read = static_cast<uint32_t *>(b->pool->get(nw * 4));
+        b->woff = static_cast<uint32_t *>(b->pool->get((nr + 1) * 4)); b->len = static_cast<uint32_t *>(b->pool->get(nr * 4));
+    } else {
+        RB_HIP(hipMalloc(&b->codes, nw * 8));
+        RB_HIP(hipMalloc(&b->valid, nw * 4));
+        RB_HIP(hipMalloc(&b->word_read, nw * 4));
+        RB_HIP(hipMalloc(&b->woff, (nr + 1) * 4));
+        RB_HIP(hipMalloc(&b->len, nr * 4));
+    }
     b->device_bytes = nw * 16 + (nr + 1) * 4 + nr * 4;
 }
 
@@ -1443,6 +1471,11 @@ extern "C" {
 int rb_batch_destroy(rb_batch *b) {
     if (!b) return RB_OK;
     (void)hipSetDevice(b->device);
+    if (b->pool) {                      // (a chunk of a chunked ingest: the next chunk takes the blocks over — no hipFree, which waits for the device)
+        for (void *p : {(void *)b->codes, (void *)b->valid, (void *)b->rnz, (void *)b->word_read, (void *)b->woff, (void *)b->len}) b->pool->put(p);
+        delete b;
+        return RB_OK;
+    }
     if (b->codes) (void)hipFree(b->codes);
     if (b->valid) (void)hipFree(b->valid);
     if (b->rnz) (void)hipFree(b->rnz);
@@ -1475,50 +1508,58 @@ void ascii_batch_begin(AsciiUpload &u, int device, const char *seq, const char *
     offsets += first;
     rb_batch *b = new rb_batch();
     u.b = b; u.st = st;
+    b->pool = u.pool;
     b->device = device;
     b->n_reads = n_reads;
-    std::vector<uint32_t> woff((size_t)n_reads + 1);
-    u.len.assign((size_t)std::max<int64_t>(n_reads, 1), 0u);
-    uint64_t words = 0;
-    uint32_t max_len = 0;
-    for (int64_t i = 0; i < n_reads; ++i) {
-        int64_t l = offsets[i + 1] - offsets[i];
-        RB_REQUIRE(l >= 0 && l < (int64_t)1 << 30, "rb_batch_create_ascii: read %lld has invalid length", (long long)(first + i));
-        woff[(size_t)i] = (uint32_t)words;
-        u.len[(size_t)i] = (uint32_t)l;
-        words += (uint64_t)((l + 31) / 32);
-        RB_REQUIRE(words < 0xFFFFFFF0ull, "rb_batch_create_ascii: batch too large (> 2^32 words)");
-        max_len = std::max(max_len, (uint32_t)l);
-    }
-    woff[(size_t)n_reads] = (uint32_t)words;
-    b->n_words = (int64_t)words;
-    b->max_len = max_len;
-    {   // uniform word count per read?
-        uint32_t wpr = n_reads ? (uint32_t)((u.len[0] + 31) / 32) : 0;
-        for (int64_t i = 0; i < n_reads && wpr; ++i) if ((u.len[(size_t)i] + 31) / 32 != wpr) wpr = 0;
-        b->wpr_uniform = wpr;
+    // host-side tables of the chunk in ONE pass over the offsets: word offset and length of every read, base offsets relative to the chunk
+    // (rounds 1-5: three passes into fresh std::vectors, 16 ms per 1.7 M-read chunk against 8 ms of GPU work for it — the preparing thread was
+    // what rb_graph_add_reads waited for)
+    std::vector<uint32_t> woff_v;
+    uint32_t *woff = nullptr, *len = nullptr;
+    int64_t *rel = nullptr;
+    if (u.hs) { u.hs->reserve((size_t)n_reads + 1); woff = u.hs->woff; len = u.hs->len; rel = u.hs->rel; }
+    else {
+        woff_v.resize((size_t)n_reads + 1); u.len.resize((size_t)std::max<int64_t>(n_reads, 1)); u.rel.resize((size_t)n_reads + 1);
+        woff = woff_v.data(); len = u.len.data(); rel = u.rel.data();
     }
     const int64_t base0 = n_reads ? offsets[0] : 0;
+    uint64_t words = 0;
+    uint32_t max_len = 0, wpr = n_reads ? (uint32_t)((offsets[1] - offsets[0] + 31) / 32) : 0;
+    bool bad = false;
+    for (int64_t i = 0; i < n_reads; ++i) {
+        const int64_t l = offsets[i + 1] - offsets[i];
+        bad |= l < 0 || l >= (int64_t)1 << 30;
+        const uint32_t w = (uint32_t)((l + 31) >> 5);
+        woff[i] = (uint32_t)words; len[i] = (uint32_t)l; rel[i] = offsets[i] - base0;
+        words += w;
+        max_len = std::max(max_len, (uint32_t)l);
+        if (w != wpr) wpr = 0;
+    }
+    if (n_reads == 0) len[0] = 0;
+    RB_REQUIRE(!bad, "rb_batch_create_ascii: a read of the %lld from read %lld on has an invalid length", (long long)n_reads, (long long)first);
+    RB_REQUIRE(words < 0xFFFFFFF0ull, "rb_batch_create_ascii: batch too large (> 2^32 words)");
+    woff[n_reads] = (uint32_t)words; rel[n_reads] = offsets[n_reads] - base0;
+    b->n_words = (int64_t)words;
+    b->max_len = max_len;
+    b->wpr_uniform = wpr;
     b->n_bases = n_reads ? offsets[n_reads] - base0 : 0;
     alloc_batch_arrays(b);
-    b->h_woff = woff;
+    if (u.hs) b->h_woff.borrow(woff, (size_t)n_reads + 1); else b->h_woff = woff_v;
     RB_HIP(hipMemcpyAsync(b->woff, b->h_woff.data(), ((size_t)n_reads + 1) * 4, hipMemcpyHostToDevice, st));
-    if (n_reads) RB_HIP(hipMemcpyAsync(b->len, u.len.data(), (size_t)n_reads * 4, hipMemcpyHostToDevice, st));
+    if (n_reads) RB_HIP(hipMemcpyAsync(b->len, len, (size_t)n_reads * 4, hipMemcpyHostToDevice, st));
     if (words) {
         const size_t nb = (size_t)b->n_bases;
-        RB_HIP(hipMalloc(&u.d_seq, std::max<size_t>(nb, 1)));
+        u.d_seq = u.dev_alloc<uint8_t>(std::max<size_t>(nb, 1));
         RB_HIP(hipMemcpyAsync(u.d_seq, seq + base0, nb, hipMemcpyHostToDevice, st));
         if (qual) {
-            RB_HIP(hipMalloc(&u.d_qual, std::max<size_t>(nb, 1)));
+            u.d_qual = u.dev_alloc<uint8_t>(std::max<size_t>(nb, 1));
             RB_HIP(hipMemcpyAsync(u.d_qual, qual + base0, nb, hipMemcpyHostToDevice, st));
         }
-        u.rel.resize((size_t)n_reads + 1);
-        for (int64_t i = 0; i <= n_reads; ++i) u.rel[(size_t)i] = offsets[i] - base0;
-        RB_HIP(hipMalloc(&u.d_off, ((size_t)n_reads + 1) * 8));
-        RB_HIP(hipMemcpyAsync(u.d_off, u.rel.data(), ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, st));
-        if (want_rnz) { RB_HIP(hipMalloc(&b->rnz, (size_t)words * 4)); b->device_bytes += (size_t)words * 4; }
-        hipLaunchKernelGGL(k_encode_ascii, dim3(blocks_for((int64_t)words)), dim3(TPB), 0, st, u.d_seq, u.d_qual, u.d_off, b->woff, n_reads,
-                           (int64_t)words, min_base_qual, b->codes, b->valid, b->word_read, b->rnz);
+        u.d_off = u.dev_alloc<int64_t>(((size_t)n_reads + 1) * 8);
+        RB_HIP(hipMemcpyAsync(u.d_off, rel, ((size_t)n_reads + 1) * 8, hipMemcpyHostToDevice, st));
+        if (want_rnz) { b->rnz = u.dev_alloc<uint32_t>((size_t)words * 4); b->device_bytes += (size_t)words * 4; }
+        hipLaunchKernelGGL(k_encode_ascii_t<false>, dim3(blocks_for((int64_t)words)), dim3(TPB), 0, st, u.d_seq, u.d_qual, u.d_off, b->woff, n_reads,
+                           (int64_t)words, min_base_qual, b->codes, b->valid, b->word_read, b->rnz, (int64_t)0, (int64_t)0);
         RB_HIP(hipGetLastError());
     }
 }

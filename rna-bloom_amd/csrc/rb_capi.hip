@@ -378,18 +378,33 @@ int rb_graph_add_reads(rb_graph *g, const char *seq, const char *qual, const int
     if (!g) { set_error("rb_graph_add_reads: null graph"); return RB_ERR_INVALID; }
     if (!offsets || n_reads < 0) { set_error("rb_graph_add_reads: null argument"); return RB_ERR_INVALID; }
     rb::AsciiUpload up;
+    if (!getenv("RB_NO_INGEST_POOL")) up.pool = &g->ingest_pool;
     hipStream_t st = nullptr;
+    bool own_stream = false;
     const char *pin_seq = nullptr, *pin_qual = nullptr;
     WriteLock wl(g->rw);
     int rc = guarded([&] {
         RB_HIP(hipSetDevice(g->p.device));
         const int64_t base0 = n_reads ? offsets[0] : 0, nbases = n_reads ? offsets[n_reads] - base0 : 0;
+        {   // more than one piece: one insert over a batch that is still being uploaded and encoded (rb_packed.hip); RB_ASCII_PIECE=<bases> sets the piece
+            // (and with it the size from which a call is streamed), RB_ASCII_CHUNKED=1 keeps the chunk-by-chunk path below
+            const int64_t piece = getenv("RB_ASCII_PIECE") ? std::max<int64_t>(64, atoll(getenv("RB_ASCII_PIECE"))) : ((int64_t)256 << 20);
+            if (seq && n_reads > 1 && nbases > piece && !getenv("RB_ASCII_CHUNKED") && !g->shard) {
+                rb::add_reads_streamed(g, seq, qual, offsets, n_reads, min_base_qual, piece, flags, stats);
+                return;
+            }
+        }
+        const bool tdbg0 = getenv("RB_HOST_TIMING") != nullptr;
+        auto now0 = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; };
+        const double t_pin0 = now0();
         if (nbases > (16 << 20) && !getenv("RB_NO_PIN")) {        // pinning is best effort (foreign mappings may refuse)
             if (seq && hipHostRegister(const_cast<char *>(seq + base0), (size_t)nbases, hipHostRegisterDefault) == hipSuccess) pin_seq = seq + base0;
             if (qual && hipHostRegister(const_cast<char *>(qual + base0), (size_t)nbases, hipHostRegisterDefault) == hipSuccess) pin_qual = qual + base0;
             (void)hipGetLastError();
         }
-        RB_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        if (tdbg0) fprintf(stderr, "[rb] add_reads: pinning %.1f ms (seq %s, qual %s)\n", now0() - t_pin0, pin_seq ? "registered" : "not registered", pin_qual ? "registered" : "not registered");
+        st = getenv("RB_INGEST_OWN_STREAM") ? nullptr : g->pk_stream;      // the handle's copy stream (made with the graph: a hardware queue of its own, rb_graph_create)
+        if (!st) { RB_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); own_stream = true; }
         const int64_t chunk_bases = (int64_t)256 << 20;
         auto chunk_end = [&](int64_t a) {   // largest e > a with bases(a..e) <= chunk_bases (at least one read)
             int64_t lo = a + 1, hi = n_reads;
@@ -397,10 +412,14 @@ int rb_graph_add_reads(rb_graph *g, const char *seq, const char *qual, const int
             return std::min(lo, n_reads);
         };
         int64_t a = 0, e = n_reads ? chunk_end(0) : 0;
+        const double t_b0 = now0();
+        int turn = 0;
+        if (up.pool) up.hs = &g->ingest_host[turn];
         rb::ascii_batch_begin(up, g->p.device, seq, qual, offsets, a, e - a, min_base_qual, st);
+        if (tdbg0) fprintf(stderr, "[rb] add_reads: first chunk begun in %.1f ms\n", now0() - t_b0);
         const bool tdbg = getenv("RB_HOST_TIMING") != nullptr;
         auto now = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; };
-        double t_fin = 0, t_beg = 0, t_add = 0, t_des = 0;
+        double t_fin = 0, t_beg = 0, t_add = 0, t_des = 0, t_join = 0;
         for (;;) {
             double t0 = now();
             rb_batch *b = rb::ascii_batch_finish(up);
@@ -414,6 +433,8 @@ int rb_graph_add_reads(rb_graph *g, const char *seq, const char *qual, const int
             if (a < n_reads) {
                 e = chunk_end(a);
                 const int64_t ca = a, cn = e - a;
+                turn ^= 1;
+                if (up.pool) up.hs = &g->ingest_host[turn];
                 prep = std::thread([&, ca, cn] {
                     prep_rc = guarded([&] { rb::ascii_batch_begin(up, g->p.device, seq, qual, offsets, ca, cn, min_base_qual, st); });
                     if (prep_rc != RB_OK) prep_err = rb_last_error();      // the error text is thread-local
@@ -428,17 +449,24 @@ int rb_graph_add_reads(rb_graph *g, const char *seq, const char *qual, const int
                 t2 = now();
             }
             t_des += now() - t2;
-            if (prep.joinable()) prep.join();
+            { const double tj = now(); if (prep.joinable()) prep.join(); t_join += now() - tj; }
             if (add_rc != RB_OK) throw HipError{add_rc};
             if (prep_rc != RB_OK) { set_error("%s", prep_err.c_str()); throw HipError{prep_rc}; }
             if (a >= n_reads) break;
         }
+        if (tdbg) fprintf(stderr, "[rb] add_reads: %.1f ms since entry, %.1f ms of them waiting for the next chunk's preparation; ", now0() - t_pin0, t_join);
         if (tdbg) fprintf(stderr, "[rb] add_reads: wait upload %.1f ms, begin next %.1f ms, insert %.1f ms, destroy %.1f ms\n", t_fin, t_beg, t_add, t_des);
     });
     if (rc != RB_OK) rb::ascii_batch_abort(up);
-    if (pin_seq) (void)hipHostUnregister(const_cast<char *>(pin_seq));
-    if (pin_qual) (void)hipHostUnregister(const_cast<char *>(pin_qual));
-    if (st) (void)hipStreamDestroy(st);
+    if (st && !own_stream && rc != RB_OK) (void)hipStreamSynchronize(st);      // (a failed call leaves nothing of its own in flight on the shared stream)
+    {
+        timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
+        if (pin_seq) (void)hipHostUnregister(const_cast<char *>(pin_seq));
+        if (pin_qual) (void)hipHostUnregister(const_cast<char *>(pin_qual));
+        timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
+        if (getenv("RB_HOST_TIMING")) fprintf(stderr, "[rb] add_reads: unpinning %.1f ms\n", (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_nsec - t0.tv_nsec) * 1e-6);
+    }
+    if (st && own_stream) (void)hipStreamDestroy(st);
     return rc;
 }
 
@@ -446,6 +474,7 @@ int rb_graph_add_fastq(rb_graph *g, const char *text, size_t len, int min_base_q
     if (!g) { set_error("rb_graph_add_fastq: null graph"); return RB_ERR_INVALID; }
     if (!text && len) { set_error("rb_graph_add_fastq: null text"); return RB_ERR_INVALID; }
     hipStream_t st = nullptr;
+    bool own_stream = false;
     const char *pinned = nullptr;
     WriteLock wl(g->rw);
     int rc = guarded([&] {
@@ -454,7 +483,8 @@ int rb_graph_add_fastq(rb_graph *g, const char *text, size_t len, int min_base_q
             if (hipHostRegister(const_cast<char *>(text), len, hipHostRegisterDefault) == hipSuccess) pinned = text;
             (void)hipGetLastError();
         }
-        RB_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        st = getenv("RB_INGEST_OWN_STREAM") ? nullptr : g->pk_stream;      // the handle's copy stream (made with the graph: a hardware queue of its own, rb_graph_create)
+        if (!st) { RB_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); own_stream = true; }
         // pieces of 1 GiB of text; a piece starts where the complete records of the one before ended.  The next piece is
         // uploaded and parsed (helper thread, own stream) while the insert pipeline works on the current one.
         const size_t piece_bytes = getenv("RB_FASTQ_PIECE") ? (size_t)std::max(64, atoi(getenv("RB_FASTQ_PIECE"))) : (size_t)1 << 30;
@@ -488,8 +518,9 @@ int rb_graph_add_fastq(rb_graph *g, const char *text, size_t len, int min_base_q
         }
         if (n_records) *n_records = recs;
     });
+    if (st && !own_stream && rc != RB_OK) (void)hipStreamSynchronize(st);      // (a failed call leaves nothing of its own in flight on the shared stream)
     if (pinned) (void)hipHostUnregister(const_cast<char *>(pinned));
-    if (st) (void)hipStreamDestroy(st);
+    if (st && own_stream) (void)hipStreamDestroy(st);
     return rc;
 }
 
@@ -497,6 +528,7 @@ int rb_graph_add_fasta(rb_graph *g, const char *text, size_t len, unsigned flags
     if (!g) { set_error("rb_graph_add_fasta: null graph"); return RB_ERR_INVALID; }
     if (!text && len) { set_error("rb_graph_add_fasta: null text"); return RB_ERR_INVALID; }
     hipStream_t st = nullptr;
+    bool own_stream = false;
     const char *pinned = nullptr;
     WriteLock wl(g->rw);
     int rc = guarded([&] {
@@ -505,7 +537,8 @@ int rb_graph_add_fasta(rb_graph *g, const char *text, size_t len, unsigned flags
             if (hipHostRegister(const_cast<char *>(text), len, hipHostRegisterDefault) == hipSuccess) pinned = text;
             (void)hipGetLastError();
         }
-        RB_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        st = getenv("RB_INGEST_OWN_STREAM") ? nullptr : g->pk_stream;      // the handle's copy stream (made with the graph: a hardware queue of its own, rb_graph_create)
+        if (!st) { RB_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); own_stream = true; }
         // pieces of 1 GiB of text; a piece starts where the complete records of the one before ended.  The next piece is
         // uploaded and parsed (helper thread, own stream) while the insert pipeline works on the current one.
         const size_t piece_bytes = getenv("RB_FASTQ_PIECE") ? (size_t)std::max(64, atoi(getenv("RB_FASTQ_PIECE"))) : (size_t)1 << 30;
@@ -543,8 +576,9 @@ int rb_graph_add_fasta(rb_graph *g, const char *text, size_t len, unsigned flags
         }
         if (n_records) *n_records = recs;
     });
+    if (st && !own_stream && rc != RB_OK) (void)hipStreamSynchronize(st);      // (a failed call leaves nothing of its own in flight on the shared stream)
     if (pinned) (void)hipHostUnregister(const_cast<char *>(pinned));
-    if (st) (void)hipStreamDestroy(st);
+    if (st && own_stream) (void)hipStreamDestroy(st);
     return rc;
 }
 
@@ -625,11 +659,13 @@ struct TextSource {
 int add_text_file(rb_graph *g, const char *path, bool fasta, int min_base_qual, unsigned flags, rb_add_stats *stats, int64_t *n_records) {
     if (!g || !path) { set_error("rb_graph_add_%s_file: null argument", fasta ? "fasta" : "fastq"); return RB_ERR_INVALID; }
     hipStream_t st = nullptr;
+    bool own_stream = false;
     char *buf[2] = {nullptr, nullptr};
     WriteLock wl(g->rw);
     int rc = guarded([&] {
         RB_HIP(hipSetDevice(g->p.device));
-        RB_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        st = getenv("RB_INGEST_OWN_STREAM") ? nullptr : g->pk_stream;
+        if (!st) { RB_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); own_stream = true; }
         TextSource src(path);
         const size_t piece_bytes = getenv("RB_FASTQ_PIECE") ? (size_t)std::max(64, atoi(getenv("RB_FASTQ_PIECE"))) : (size_t)256 << 20;
         for (auto &b : buf) RB_HIP(hipHostMalloc(reinterpret_cast<void **>(&b), piece_bytes, hipHostMallocDefault));
@@ -678,8 +714,9 @@ int add_text_file(rb_graph *g, const char *path, bool fasta, int min_base_qual, 
         }
         if (n_records) *n_records = recs;
     });
+    if (st && !own_stream && rc != RB_OK) (void)hipStreamSynchronize(st);      // (a failed call leaves nothing of its own in flight on the shared stream)
     for (auto b : buf) if (b) (void)hipHostFree(b);
-    if (st) (void)hipStreamDestroy(st);
+    if (st && own_stream) (void)hipStreamDestroy(st);
     return rc;
 }
 }  // namespace

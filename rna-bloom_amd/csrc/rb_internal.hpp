@@ -5,7 +5,11 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <algorithm>
+#include <mutex>
 #include <string>
+#include <unordered_map>
+#include <utility>
 #include <vector>
 
 #include "../../include/rb_capi.h"
@@ -104,8 +108,78 @@ struct HostWoff {
     void borrow(uint32_t *p, size_t n) { own.clear(); ext = p; ext_n = n; }
 };
 
+// Device blocks that chunked ingests hand back and take again (rb_graph_add_reads cuts a call into chunks of 256 M bases, each a batch of six
+// arrays + three staging arrays: hipMalloc / hipFree of those cost 6 ms a chunk — a third of the call — and hipFree waits for the device).
+// get() takes the smallest cached block that fits and is at most twice the size, else allocates; put() keeps up to `limit` bytes.
+struct DevPool {
+    std::mutex m;
+    std::vector<std::pair<void *, size_t>> free_;
+    std::unordered_map<void *, size_t> out;      // blocks handed out -> capacity
+    size_t held = 0, limit = (size_t)12 << 30;
+    void *get(size_t bytes) {
+        bytes = std::max<size_t>((bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1), (size_t)2 << 20);
+        {
+            std::lock_guard<std::mutex> lk(m);
+            size_t best = free_.size();
+            for (size_t i = 0; i < free_.size(); ++i)
+                if (free_[i].second >= bytes && free_[i].second <= 2 * bytes && (best == free_.size() || free_[i].second < free_[best].second)) best = i;
+            if (best != free_.size()) {
+                void *p = free_[best].first; const size_t cap = free_[best].second;
+                free_.erase(free_.begin() + (std::ptrdiff_t)best);
+                held -= cap; out[p] = cap;
+                return p;
+            }
+        }
+        void *p = nullptr;
+        hipError_t e = hipMalloc(&p, bytes);
+        if (e != hipSuccess) { clear(); e = hipMalloc(&p, bytes); }        // (out of memory with blocks cached: give them back first)
+        if (e != hipSuccess) { (void)hipGetLastError(); rb::set_error("hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e)); throw rb::HipError{RB_ERR_NOMEM}; }
+        std::lock_guard<std::mutex> lk(m);
+        out[p] = bytes;
+        return p;
+    }
+    void put(void *p) {
+        if (!p) return;
+        size_t cap = 0;
+        {
+            std::lock_guard<std::mutex> lk(m);
+            auto it = out.find(p);
+            if (it != out.end()) { cap = it->second; out.erase(it); }
+            if (cap && held + cap <= limit) { free_.push_back({p, cap}); held += cap; return; }
+        }
+        (void)hipFree(p);
+    }
+    void clear() {
+        std::vector<std::pair<void *, size_t>> f;
+        { std::lock_guard<std::mutex> lk(m); f.swap(free_); held = 0; }
+        for (auto &b : f) (void)hipFree(b.first);
+    }
+    ~DevPool() { clear(); }
+};
+
+// Pinned host scratch of one chunk's preparation (word offsets, lengths, base offsets relative to the chunk): grow-only, two of them take turns on a
+// handle — chunk c + 1 is prepared in one while the insert of chunk c still reads the offsets in the other.  Pinned: the three copies to the
+// device are real asynchronous copies (from a std::vector they are staged, and the preparing thread waits for them).
+struct IngestHost {
+    uint32_t *woff = nullptr, *len = nullptr;
+    int64_t *rel = nullptr;
+    size_t cap = 0;
+    void reserve(size_t n) {
+        if (n <= cap) return;
+        release();
+        const size_t want = n + (n >> 2) + 1024;
+        void *p = nullptr;
+        if (hipHostMalloc(&p, want * 16, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); rb::set_error("hipHostMalloc of %zu bytes failed", want * 16); throw rb::HipError{RB_ERR_NOMEM}; }
+        rel = static_cast<int64_t *>(p); woff = reinterpret_cast<uint32_t *>(rel + want); len = woff + want;
+        cap = want;
+    }
+    void release() { if (rel) (void)hipHostFree(rel); rel = nullptr; woff = len = nullptr; cap = 0; }
+    ~IngestHost() { release(); }
+};
+
 struct rb_batch {
     int device = 0;
+    DevPool *pool = nullptr;       // the arrays below came out of this pool and go back to it (rb_batch_destroy); nullptr: hipMalloc / hipFree
     int64_t n_reads = 0, n_bases = 0, n_words = 0;
     uint32_t max_len = 0;
     uint32_t wpr_uniform = 0;      // words per read when every read has the same word count, else 0

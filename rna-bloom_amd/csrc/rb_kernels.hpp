@@ -37,10 +37,19 @@ struct AsciiUpload {
     std::vector<uint32_t> len;
     std::vector<int64_t> rel;
     hipStream_t st = nullptr;
+    DevPool *pool = nullptr;         // chunked ingests: staging and batch arrays are taken from / handed back to the handle's pool
+    IngestHost *hs = nullptr;        // ... and this begin() prepares its host-side tables in this pinned scratch (else in vectors)
+    template <class T> T *dev_alloc(size_t bytes) {
+        if (pool) return static_cast<T *>(pool->get(bytes));
+        void *p = nullptr;
+        RB_HIP(hipMalloc(&p, bytes));
+        return static_cast<T *>(p);
+    }
     void drop() {
-        if (d_seq) (void)hipFree(d_seq);
-        if (d_qual) (void)hipFree(d_qual);
-        if (d_off) (void)hipFree(d_off);
+        for (void *p : {(void *)d_seq, (void *)d_qual, (void *)d_off}) {
+            if (!p) continue;
+            if (pool) pool->put(p); else (void)hipFree(p);
+        }
         d_seq = d_qual = nullptr; d_off = nullptr;
     }
 };
@@ -48,6 +57,8 @@ void ascii_batch_begin(AsciiUpload &u, int device, const char *seq, const char *
                        int min_base_qual, hipStream_t st, bool want_rnz = false /* also build rb_batch::rnz (all-window hashing of raw strings) */);
 rb_batch *ascii_batch_finish(AsciiUpload &u);
 void ascii_batch_abort(AsciiUpload &u);
+void launch_encode_ascii_piece(const uint8_t *seq, const uint8_t *qual, const int64_t *off_all, const uint32_t *woff_all, int64_t r_first, int64_t n_reads,
+                               int64_t seq_base, int64_t words_ub, int min_q, uint64_t *codes, uint32_t *valid, uint32_t *word_read, hipStream_t st);
 
 // FASTQ text -> packed batch, parsed on the GPU (rb_io.hip): uploads text[0, n) on `st`, finds the lines and the records
 // there and 2-bit encodes the sequence lines in place of a host-side split.  `final`: the text ends the input (a last line

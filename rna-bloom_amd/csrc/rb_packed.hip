@@ -54,6 +54,16 @@ __global__ void k_packed_words(const uint32_t *__restrict__ len, int64_t n, uint
         atomicAdd(reinterpret_cast<unsigned long long *>(st + 4), sum);
     }
 }
+// streamed ASCII ingest: lengths from the caller's base offsets; an offset that runs backwards or a read of 2^30 bases and more raises st[6]
+__global__ void k_ascii_lens(const int64_t *__restrict__ off, int64_t n, uint32_t *__restrict__ len, uint32_t *__restrict__ st) {
+    bool bad = false;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t l = off[i + 1] - off[i];
+        if (l < 0 || l >= ((int64_t)1 << 30)) { bad = true; l = 0; }
+        len[i] = (uint32_t)l;
+    }
+    if (__ballot(bad) && (threadIdx.x & 63u) == 0u) atomicOr(&st[6], 1u);
+}
 // the owning read of every word
 __global__ void k_packed_word_read(const uint32_t *__restrict__ woff, int64_t n, uint32_t *__restrict__ word_read) {
     const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -324,13 +334,217 @@ void ingest_begin(rb_graph *g, rb_graph::PackedIngest &K, const uint64_t *codes,
 // the upload of a slot is over (or abandoned): wait for it, give the caller's arrays back
 void ingest_end(rb_graph *g, rb_graph::PackedIngest &K) {
     if (!K.inflight) return;
-    if (!K.wend.empty()) (void)hipEventSynchronize(K.ev[K.wend.size() - 1]);
+    if (K.feeder.joinable()) {             // (a streamed ASCII ingest: an abandoned one stops feeding at the next piece)
+        { std::lock_guard<std::mutex> lk(K.fm); K.cancel = true; }
+        K.feeder.join();
+    }
+    const size_t fed = K.enqueued;
+    if (!K.rend.empty()) {                   // a streamed ASCII ingest: whatever was fed is waited for (the stream is in order: its last operation)
+        if (g->pk_stream) (void)hipStreamSynchronize(g->pk_stream);
+        (void)fed;
+    } else if (!K.wend.empty()) (void)hipEventSynchronize(K.ev[K.wend.size() - 1]);
     else if (K.ev_woff) (void)hipEventSynchronize(K.ev_woff);
+    K.rend.clear(); K.enqueued = 0;
     for (void *p : K.pins) (void)hipHostUnregister(p);
     K.pins.clear();
     K.inflight = false; K.src = nullptr;
 }
 }  // namespace
+
+namespace {
+// Everything a streamed ASCII ingest sends, enqueued on the handle's copy stream without waiting: the caller's base offsets, the kernels that turn
+// them into lengths, word offsets (one scan) and their way back into pinned memory (event ev_woff), then piece after piece the bases and
+// qualities of <= piece_bases bases into one of two staging buffers and the encode kernel of that piece (k_encode_ascii_t<true>, rb_batch.hip)
+// behind it, an event behind each.  The stream is in order: the copy into a staging buffer queues behind the encode that last read it.
+void ingest_begin_ascii(rb_graph *g, rb_graph::PackedIngest &K, const char *seq, const char *qual, const int64_t *offsets, int64_t n_reads, int min_q, int64_t piece_bases) {
+    if (!g->pk_stream) RB_HIP(hipStreamCreateWithFlags(&g->pk_stream, hipStreamNonBlocking));
+    hipStream_t st = g->pk_stream;
+    if (!K.h_stats) RB_HIP(hipHostMalloc(reinterpret_cast<void **>(&K.h_stats), 64, hipHostMallocDefault));
+    if (!K.ev_woff) RB_HIP(hipEventCreateWithFlags(&K.ev_woff, hipEventDisableTiming));
+    const size_t nr = (size_t)n_reads;
+    const int64_t base0 = offsets[0], nbases = offsets[n_reads] - base0;
+    RB_REQUIRE(nbases >= 0, "rb_graph_add_reads: the offsets run backwards");
+    const size_t nw_ub = (size_t)nbases / 32 + nr + 1;                       // every read adds at most one partly filled word
+    RB_REQUIRE(nw_ub < 0xFFFFFFF0ull, "rb_graph_add_reads: batch too large (> 2^32 words)");
+    K.codes.reserve(nw_ub * 8); K.valid.reserve(nw_ub * 4); K.word_read.reserve(nw_ub * 4);
+    K.woff.reserve((nr + 1) * 4); K.len.reserve(nr * 4); K.wc.reserve((nr + 1) * 4); K.stats.reserve(64); K.temp.reserve(scan_temp_bytes(nr + 1));
+    K.off.reserve((nr + 1) * 8);
+    if (K.h_woff_cap < nr + 1) {
+        if (K.h_woff) (void)hipHostFree(K.h_woff);
+        K.h_woff = nullptr; K.h_woff_cap = 0;
+        const size_t want = nr + 1 + (nr >> 3);
+        RB_HIP(hipHostMalloc(reinterpret_cast<void **>(&K.h_woff), want * 4, hipHostMallocDefault));
+        K.h_woff_cap = want;
+    }
+    // the pieces: reads [rend[p - 1], rend[p]) of at most piece_bases bases (at least one read)
+    K.rend.clear(); K.wend.clear();
+    int64_t max_piece = 0;
+    for (int64_t a = 0; a < n_reads;) {
+        int64_t lo = a + 1, hi = n_reads;
+        while (lo < hi) { const int64_t mid = (lo + hi + 1) >> 1; if (offsets[mid] - offsets[a] <= piece_bases) lo = mid; else hi = mid - 1; }
+        RB_REQUIRE(offsets[lo] >= offsets[a], "rb_graph_add_reads: the offsets run backwards");
+        max_piece = std::max(max_piece, offsets[lo] - offsets[a]);
+        K.rend.push_back(lo);
+        a = lo;
+    }
+    for (int q = 0; q < 2; ++q) { K.stage_seq[q].reserve((size_t)std::max<int64_t>(max_piece, 1)); if (qual) K.stage_qual[q].reserve((size_t)std::max<int64_t>(max_piece, 1)); }
+    while (K.ev.size() < K.rend.size()) { hipEvent_t e; RB_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming)); K.ev.push_back(e); }
+    // the caller's offsets are registered here (they go up first); bases and qualities are registered slab by slab by the feeder below, ahead of the copies
+    if ((nr + 1) * 8 > ((size_t)16 << 20) && !getenv("RB_NO_PIN") && !HostPin::pinned_already(offsets)) {
+        if (hipHostRegister(const_cast<int64_t *>(offsets), (nr + 1) * 8, hipHostRegisterDefault) == hipSuccess) K.pins.push_back(const_cast<int64_t *>(offsets));
+        else (void)hipGetLastError();
+    }
+    K.src = seq; K.n_reads = n_reads; K.n_words = -1; K.inflight = true;
+    uint32_t init[8] = {0u, 0xFFFFFFFFu, 0u, 0u, 0u, 0u, 0u, 0u};
+    memcpy(K.h_stats + 8, init, sizeof init);
+    RB_HIP(hipMemcpyAsync(K.stats.p, K.h_stats + 8, sizeof init, hipMemcpyHostToDevice, st));
+    RB_HIP(hipMemcpyAsync(K.off.p, offsets, (nr + 1) * 8, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_ascii_lens, dim3(std::min<unsigned>(blocks_for(n_reads), 2048u)), dim3(TPB), 0, st, K.off.as<int64_t>(), n_reads, K.len.as<uint32_t>(), K.stats.as<uint32_t>());
+    hipLaunchKernelGGL(k_packed_words, dim3(std::min<unsigned>(blocks_for(n_reads + 1), 2048u)), dim3(TPB), 0, st, K.len.as<uint32_t>(), n_reads, K.wc.as<uint32_t>(), K.stats.as<uint32_t>());
+    exclusive_scan_u32(K.temp.p, K.temp.cap, K.wc.as<uint32_t>(), K.woff.as<uint32_t>(), nr + 1, st);
+    RB_HIP(hipMemcpyAsync(K.h_stats, K.stats.p, 32, hipMemcpyDeviceToHost, st));
+    RB_HIP(hipMemcpyAsync(K.h_woff, K.woff.p, (nr + 1) * 4, hipMemcpyDeviceToHost, st));
+    hipLaunchKernelGGL(k_packed_word_read, dim3(blocks_for(n_reads)), dim3(TPB), 0, st, K.woff.as<uint32_t>(), n_reads, K.word_read.as<uint32_t>());      // (the pieces' encode kernels look their words' reads up here)
+    RB_HIP(hipGetLastError());
+    RB_HIP(hipEventRecord(K.ev_woff, st));
+    // the feeder: registers what a piece's copies read (slabs that end on 256 MiB boundaries of the address: neighbours never share a page), then
+    // enqueues the piece and tells the insert (rb_graph::await_words waits for `enqueued` before it makes a stream wait for the piece's event)
+    { std::lock_guard<std::mutex> lk(K.fm); K.enqueued = 0; K.cancel = false; K.feeder_rc = RB_OK; K.feeder_err.clear(); }
+    rb_graph::PackedIngest *Kp = &K;
+    const int device = g->p.device;
+    K.feeder = std::thread([=] {
+        rb_graph::PackedIngest &K = *Kp;
+        const int rc = guarded([&] {
+            RB_HIP(hipSetDevice(device));
+            const bool pin = !getenv("RB_NO_PIN");
+            constexpr uintptr_t SLAB = (uintptr_t)256 << 20;       // slab boundaries are multiples of it: page-aligned, so neighbouring slabs never share a page
+            struct Cursor { const char *base; uintptr_t lo, hi, done; bool on; };
+            auto cursor = [&](const char *p) {
+                Cursor c{p, 0, 0, 0, false};
+                if (!p || !pin || (size_t)nbases <= ((size_t)16 << 20) || HostPin::pinned_already(p + base0)) return c;
+                c.lo = reinterpret_cast<uintptr_t>(p + base0); c.hi = c.lo + (uintptr_t)nbases; c.done = c.lo; c.on = true;      // (from the array's own first byte: what lies below it may not be mapped)
+                return c;
+            };
+            Cursor cs = cursor(seq), cq = cursor(qual);
+            const bool tdbg = getenv("RB_HOST_TIMING") != nullptr;
+            auto now = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; };
+            double t_pin = 0, t_enq = 0; const double t_f0 = now();
+            auto pin_to = [&](Cursor &c, uintptr_t need) {             // register slabs until [lo, need) is covered
+                while (c.on && c.done < need) {
+                    const uintptr_t a = c.done, e = std::min(c.hi, (a & ~(SLAB - 1)) + SLAB);
+                    if (hipHostRegister(reinterpret_cast<void *>(a), (size_t)(e - a), hipHostRegisterDefault) == hipSuccess) K.pins.push_back(reinterpret_cast<void *>(a));
+                    else { (void)hipGetLastError(); c.on = false; }       // (best effort: the copies still work from pageable memory, slowly)
+                    c.done = e;
+                }
+            };
+            int64_t ra = 0;
+            for (size_t p = 0; p < K.rend.size(); ++p) {
+                { std::lock_guard<std::mutex> lk(K.fm); if (K.cancel) break; }
+                const int64_t rb = K.rend[p], bytes = offsets[rb] - offsets[ra];
+                const int slot = (int)(p & 1u);
+                double tp1 = 0;
+                if (bytes) {
+                    const double tp0 = now();
+                    pin_to(cs, reinterpret_cast<uintptr_t>(seq + offsets[rb]));
+                    if (qual) pin_to(cq, reinterpret_cast<uintptr_t>(qual + offsets[rb]));
+                    tp1 = now(); t_pin += tp1 - tp0;
+                    // (a copy must stay inside ONE registration: a source range over two of them is refused as an invalid argument)
+                    auto copy_by_slab = [&](void *dst, const char *src, size_t n) {
+                        for (size_t o = 0; o < n;) {
+                            const uintptr_t at = reinterpret_cast<uintptr_t>(src + o);
+                            const size_t m = std::min<size_t>(n - o, (size_t)(((at & ~(SLAB - 1)) + SLAB) - at));
+                            RB_HIP(hipMemcpyAsync(static_cast<char *>(dst) + o, src + o, m, hipMemcpyHostToDevice, st));
+                            o += m;
+                        }
+                    };
+                    copy_by_slab(K.stage_seq[slot].p, seq + offsets[ra], (size_t)bytes);
+                    if (qual) copy_by_slab(K.stage_qual[slot].p, qual + offsets[ra], (size_t)bytes);
+                    launch_encode_ascii_piece(K.stage_seq[slot].as<uint8_t>(), qual ? K.stage_qual[slot].as<uint8_t>() : (const uint8_t *)nullptr, K.off.as<int64_t>(),
+                                              K.woff.as<uint32_t>(), ra, rb - ra, offsets[ra], bytes / 32 + (rb - ra) + 1, min_q, K.codes.as<uint64_t>(),
+                                              K.valid.as<uint32_t>(), K.word_read.as<uint32_t>(), st);
+                }
+                RB_HIP(hipGetLastError());
+                RB_HIP(hipEventRecord(K.ev[p], st));
+                if (bytes) t_enq += now() - tp1;
+                { std::lock_guard<std::mutex> lk(K.fm); K.enqueued = p + 1; }
+                K.fcv.notify_all();
+                ra = rb;
+            }
+            if (tdbg) fprintf(stderr, "[rb] add_reads feeder: %zu pieces in %.1f ms: registering %.1f ms, enqueueing %.1f ms\n", K.rend.size(), now() - t_f0, t_pin, t_enq);
+        });
+        { std::lock_guard<std::mutex> lk(K.fm); K.feeder_rc = rc; if (rc != RB_OK) K.feeder_err = rb_last_error(); K.enqueued = K.rend.size(); }   // (an error wakes every waiter)
+        K.fcv.notify_all();
+    });
+}
+}  // namespace
+
+// rb_graph_add_reads over host ASCII reads of more than one piece: FastqToGraphWorker's loop (R/RNABloom.java:526-643) as ONE insert.  The device batch
+// is sized for the whole call; lengths and word offsets are computed on the GPU from the caller's base offsets (the offsets come back into pinned
+// memory for the sub-batch plan), bases and qualities follow piece by piece through two staging buffers and the 2-bit encode kernel, an event
+// behind each piece; add_range makes its producer stream wait for the pieces a sub-batch's words lie in (rb_graph::await_words) — one pipeline over
+// the whole call with the upload beside it, where rounds 1-5 made one insert call per 256 M-base chunk (no overlap between a chunk's stages: 276 ms
+// of insert for 50 M reads that take 144 ms as one batch).  Same filters as the chunked path and as rb_graph_add_batch of the same reads.
+void rb::add_reads_streamed(rb_graph *g, const char *seq, const char *qual, const int64_t *offsets, int64_t n_reads, int min_q, int64_t piece_bases,
+                            unsigned flags, rb_add_stats *stats) {
+    RB_REQUIRE(min_q >= 0 && min_q < 94, "rb_batch_create_ascii: min_base_qual out of range");
+    rb_graph::PackedIngest *K = nullptr;
+    struct Done { rb_graph *g; rb_graph::PackedIngest **K; ~Done() {
+        g->await_words = nullptr;
+        std::lock_guard<std::mutex> lk(g->pk_mutex);
+        if (*K) ingest_end(g, **K);          // (also on failure: the caller's arrays are free again when the call returns)
+        g->pk_busy = -1;
+    } } done{g, &K};
+    RB_HIP(hipSetDevice(g->p.device));
+    {
+        std::lock_guard<std::mutex> lk(g->pk_mutex);
+        const int q = !g->pk[0].inflight ? 0 : !g->pk[1].inflight ? 1 : 0;
+        if (g->pk[q].inflight) ingest_end(g, g->pk[q]);
+        K = &g->pk[q]; g->pk_busy = q;
+        ingest_begin_ascii(g, *K, seq, qual, offsets, n_reads, min_q, piece_bases);
+    }
+    const size_t nr = (size_t)n_reads;
+    const bool tdbg = getenv("RB_HOST_TIMING") != nullptr;
+    auto now = [] { timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; };
+    const double t_m0 = now();
+    RB_HIP(hipEventSynchronize(K->ev_woff));
+    const double t_m1 = now();
+    RB_REQUIRE(!K->h_stats[6], "rb_batch_create_ascii: a read has an invalid length (offsets that run backwards, or 2^30 bases and more)");
+    K->wend.resize(K->rend.size());
+    for (size_t p = 0; p < K->rend.size(); ++p) K->wend[p] = (int64_t)K->h_woff[(size_t)K->rend[p]];
+    rb_batch b;
+    b.device = g->p.device; b.n_reads = n_reads; b.n_words = (int64_t)K->h_woff[nr];
+    b.max_len = K->h_stats[0];
+    b.wpr_uniform = K->h_stats[1] == K->h_stats[2] ? K->h_stats[1] : 0u;
+    b.n_bases = (int64_t)(((uint64_t)K->h_stats[5] << 32) | K->h_stats[4]);
+    b.codes = K->codes.as<uint64_t>(); b.valid = K->valid.as<uint32_t>(); b.word_read = K->word_read.as<uint32_t>();
+    b.woff = K->woff.as<uint32_t>(); b.len = K->len.as<uint32_t>(); b.rnz = nullptr;
+    b.device_bytes = (size_t)std::max<int64_t>(b.n_words, 1) * 16 + (nr + 1) * 4 + nr * 4;
+    b.h_woff.borrow(K->h_woff, nr + 1);
+    size_t waited = 0;
+    const std::vector<int64_t> &wend = K->wend;
+    rb_graph::PackedIngest *Kc = K;
+    g->await_words = [&waited, &wend, Kc](int64_t w_end, hipStream_t on) {
+        size_t need = 0;
+        while (need < wend.size() && (need == 0 ? 0 : wend[need - 1]) < w_end) ++need;
+        if (need > waited) {
+            {   // the feeder must have RECORDED the piece's event before a stream can be told to wait for it
+                std::unique_lock<std::mutex> lk(Kc->fm);
+                Kc->fcv.wait(lk, [&] { return Kc->enqueued >= need || Kc->feeder_rc != RB_OK; });
+                if (Kc->feeder_rc != RB_OK) { set_error("%s", Kc->feeder_err.c_str()); throw HipError{Kc->feeder_rc}; }
+            }
+            RB_HIP(hipStreamWaitEvent(on, Kc->ev[need - 1], 0));
+            waited = need;
+        }
+    };
+    add_range(g, &b, 0, n_reads, flags, stats);
+    if (tdbg) fprintf(stderr, "[rb] add_reads streamed: offsets back after %.1f ms, insert %.1f ms\n", t_m1 - t_m0, now() - t_m1);
+    b.codes = nullptr; b.valid = nullptr; b.word_read = nullptr; b.woff = nullptr; b.len = nullptr;
+    {   // a feeder that failed after the last piece the insert asked for still failed the call
+        std::unique_lock<std::mutex> lk(K->fm);
+        K->fcv.wait(lk, [&] { return K->enqueued >= K->rend.size() || K->feeder_rc != RB_OK; });
+        if (K->feeder_rc != RB_OK) { set_error("%s", K->feeder_err.c_str()); throw HipError{K->feeder_rc}; }
+    }
+}
 
 extern "C" {
 

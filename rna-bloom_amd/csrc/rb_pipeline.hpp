@@ -9,6 +9,8 @@
 #include <new>
 #include <shared_mutex>
 #include <functional>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "rb_internal.hpp"
@@ -223,6 +225,8 @@ const char *last_error_text();                      // this thread's message of 
 BitFilter *bit_filter(rb_graph *g, int which);      // RB_DBGBF / RB_RPKBF / RB_FPKBF -> the handle's filter, nullptr otherwise
 uint64_t *upload_h0(rb_graph *g, DevBuf &buf, const uint64_t *h0, size_t n, hipStream_t st = nullptr);
 void fast_zero(void *p, size_t bytes, hipStream_t s);
+void add_reads_streamed(rb_graph *g, const char *seq, const char *qual, const int64_t *offsets, int64_t n_reads, int min_base_qual, int64_t piece_bases,
+                        unsigned flags, rb_add_stats *stats);       // rb_packed.hip: host ASCII reads as ONE insert over a batch that is still being uploaded and encoded
 void add_range(rb_graph *g, const rb_batch *b, int64_t first, int64_t n, unsigned flags, rb_add_stats *stats);      // the stage-1 insert of reads [first, first + n)
 void run_pipeline(rb_graph *g, size_t N, int mode, uint64_t ordinal0, uint32_t pos_bits, rb_add_stats *stats);       // the consumer half on N records in keys0 / vals0
 void launch_pairs_reads(rb_graph *g, const rb_batch *b, int64_t w0, int64_t nw, int mode_hash, const BitFilter &f, int dist,
@@ -420,7 +424,22 @@ struct rb_graph {
         int64_t n_reads = 0, n_words = 0;
         bool inflight = false;
         std::vector<void *> pins;                // caller's arrays registered for the upload (hipHostUnregister when it is over)
+        // streamed ASCII ingest (rb_graph_add_reads over more than one piece): the caller's base offsets on the device, two staging buffers
+        // for the pieces' bases and qualities taking turns, the read each piece ends at
+        DevBuf off, stage_seq[2], stage_qual[2];
+        std::vector<int64_t> rend;
+        // ... and its feeder: a helper thread registers the caller's arrays slab by slab (hipHostRegister: 8 ms per GB — 120 ms for config 2's 15 GB per
+        // file if done up front, with the link idle meanwhile) and enqueues a piece's copies + encode as soon as its bytes are registered
+        std::thread feeder;
+        std::mutex fm;
+        std::condition_variable fcv;
+        size_t enqueued = 0;                     // pieces whose event has been recorded (a stream may only wait for a RECORDED event)
+        bool cancel = false;
+        int feeder_rc = 0;
+        std::string feeder_err;
     } pk[2];
+    IngestHost ingest_host[2];                   // pinned host scratch of the chunked text ingests' preparation, taking turns
+    DevPool ingest_pool;                         // device blocks of the chunked text ingests (rb_graph_add_reads): handed from chunk to chunk and call to call, freed with the graph
     hipStream_t pk_stream = nullptr;             // the copy stream both slots upload on (in order: a prefetch queues behind the batch before it)
     std::mutex pk_mutex;                         // slots are handed out under it (a prefetch may come from another thread than the insert)
     int pk_busy = -1;                            // the slot the running rb_graph_add_packed reads

@@ -119,3 +119,34 @@ def test_a_chunk_whose_lengths_do_not_describe_its_words_is_refused_and_the_stre
     with pytest.raises(N.NativeError):
         N.check(N.lib.rb_graph_add_packed(g.h, ph.codes.ctypes.data, ph.valid.ctypes.data, ph.len.ctypes.data, 3000, ph.n_words - 5, 0, 0, None))
     ps.close()
+
+
+@pytest.mark.parametrize("piece", ["401", "5000", "1000000000"])
+def test_host_ascii_reads_streamed_in_pieces_leave_the_oracles_filters(monkeypatch, piece):
+    """rb_graph_add_reads over more than one piece (csrc/rb_packed.hip add_reads_streamed; RB_ASCII_PIECE sets the piece): lengths and word offsets
+    computed on the GPU from the caller's offsets, bases + qualities through two staging buffers and the encode kernel piece by piece, one insert over
+    the batch that is still arriving — ragged reads (empty ones, one-word ones, a piece of one read), N bases, low qualities, sub-batches of at most
+    20 000 records, two passes; with a piece larger than the input the chunk-by-chunk path runs: all three leave what the oracle leaves"""
+    monkeypatch.setenv("RB_ASCII_PIECE", piece)
+    reads, quals = ragged_reads(9_000, 21)
+    seq = np.frombuffer(b"".join(reads), np.uint8); qual = np.frombuffer(b"".join(quals), np.uint8)
+    off = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.int64)
+    sizes = (2_000_003, 2_000_003, 300_007)
+    og = rbo.Graph(*sizes, 2, 2, 2, 25, False, True, 5)
+    gg = BloomFilterDeBruijnGraph(*sizes, 2, 2, 2, 25, False, True, rngSeed=5, maxBatchKmers=20_000)
+    og.set_read_pair_distance(60); gg.setReadPairedKmerDistance(60)
+    for rep in range(2):
+        ost = og.add_reads(seq, qual, off, 3, rbo.STORE_READ_PAIRS)
+        st = gg.addReads(seq, qual, off, 3, storeReadPairedKmers=True)
+        assert (st.kmers, st.pairs, st.reads) == (ost.kmers, ost.pairs, len(reads))
+    assert (gg.exportFilter(N.DBGBF) == og.dbgbf_bytes()).all()
+    assert (gg.exportFilter(N.CBF) == og.cbf_bytes()).all()
+    assert (gg.exportFilter(N.RPKBF) == og.rpkbf_bytes()).all()
+    # without qualities, and a bad offsets array: refused, the handle lives on
+    st2 = gg.addReads(seq, None, off, 0)
+    ost2 = og.add_reads(seq, None, off, 0, 0)
+    assert st2.kmers == ost2.kmers and (gg.exportFilter(N.CBF) == og.cbf_bytes()).all()
+    bad = off.copy(); bad[4000] = bad[3999] - 5
+    with pytest.raises(N.NativeError):
+        gg.addReads(seq, qual, bad, 3)
+    assert gg.addReads(seq, qual, off, 3).reads == len(reads)

@@ -365,7 +365,8 @@ def test_cold_subbatch_is_split_when_survivors_exceed_the_bound():
                                  {"RB_SWEEP": "1"}, {"RB_SWEEP": "1", "RB_GROUP_T": "18"}, {"RB_SWEEP": "1", "RB_GROUP_T": "3"}, {"RB_SWEEP": "1", "RB_GROUP_T": "11"},
                                  {"RB_SWEEP": "1", "RB_SERIAL": "1"}, {"RB_SWEEP": "1", "RB_GROUP_ORDERED": "1"}, {"RB_SWEEP": "1", "RB_NO_MPF": "1"},
                                  {"RB_SWEEP": "1", "RB_FT_FILTER": "1"}, {"RB_SWEEP": "1", "RB_PF_SKIP": "2"}, {"RB_SWEEP": "0"},
-                                 {"RB_SMALL_COMPONENT_OPS": "1"}, {"RB_SMALL_COMPONENT_OPS": "1000000"}, {"RB_RELEASE_EARLY": "1"}])
+                                 {"RB_SMALL_COMPONENT_OPS": "1"}, {"RB_SMALL_COMPONENT_OPS": "1000000"}, {"RB_RELEASE_EARLY": "1"},
+                                 {"RB_ASCII_PIECE": "30000"}, {"RB_ASCII_PIECE": "151"}, {"RB_ASCII_PIECE": "70000", "RB_SERIAL": "1"}, {"RB_ASCII_CHUNKED": "1"}, {"RB_NO_INGEST_POOL": "1"}])
 def test_pipeline_switches_do_not_change_results(monkeypatch, env):
     """every scheduling / cache switch of the insert path (minimizer- vs hash-bucketed cache, tiny caches that
     thrash, minimizer length, cold-start ramp, producer one sub-batch ahead, serialised streams, one word or one
