@@ -475,14 +475,11 @@ int rb_graph_add_fastq(rb_graph *g, const char *text, size_t len, int min_base_q
     if (!text && len) { set_error("rb_graph_add_fastq: null text"); return RB_ERR_INVALID; }
     hipStream_t st = nullptr;
     bool own_stream = false;
-    const char *pinned = nullptr;
+    SlabPin slabs;
     WriteLock wl(g->rw);
     int rc = guarded([&] {
         RB_HIP(hipSetDevice(g->p.device));
-        if (len > ((size_t)16 << 20) && !getenv("RB_NO_PIN")) {        // pinning is best effort (foreign mappings may refuse)
-            if (hipHostRegister(const_cast<char *>(text), len, hipHostRegisterDefault) == hipSuccess) pinned = text;
-            (void)hipGetLastError();
-        }
+        slabs.begin(text, len);                                      // registered slab by slab as the pieces advance (best effort)
         st = getenv("RB_INGEST_OWN_STREAM") ? nullptr : g->pk_stream;      // the handle's copy stream (made with the graph: a hardware queue of its own, rb_graph_create)
         if (!st) { RB_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); own_stream = true; }
         // pieces of 1 GiB of text; a piece starts where the complete records of the one before ended.  The next piece is
@@ -490,7 +487,8 @@ int rb_graph_add_fastq(rb_graph *g, const char *text, size_t len, int min_base_q
         const size_t piece_bytes = getenv("RB_FASTQ_PIECE") ? (size_t)std::max(64, atoi(getenv("RB_FASTQ_PIECE"))) : (size_t)1 << 30;
         auto piece = [&](size_t a) {
             const size_t e = std::min(len, a + piece_bytes);
-            return rb::fastq_batch_create(g->p.device, text + a, e - a, e == len, min_base_qual, true, st);
+            slabs.pin_to(text + e);
+            return rb::fastq_batch_create(g->p.device, text + a, e - a, e == len, min_base_qual, true, st, getenv("RB_NO_INGEST_POOL") ? nullptr : &g->ingest_pool);
         };
         size_t a = 0;
         int64_t recs = 0;
@@ -519,7 +517,7 @@ int rb_graph_add_fastq(rb_graph *g, const char *text, size_t len, int min_base_q
         if (n_records) *n_records = recs;
     });
     if (st && !own_stream && rc != RB_OK) (void)hipStreamSynchronize(st);      // (a failed call leaves nothing of its own in flight on the shared stream)
-    if (pinned) (void)hipHostUnregister(const_cast<char *>(pinned));
+    slabs.end();
     if (st && own_stream) (void)hipStreamDestroy(st);
     return rc;
 }
@@ -529,14 +527,11 @@ int rb_graph_add_fasta(rb_graph *g, const char *text, size_t len, unsigned flags
     if (!text && len) { set_error("rb_graph_add_fasta: null text"); return RB_ERR_INVALID; }
     hipStream_t st = nullptr;
     bool own_stream = false;
-    const char *pinned = nullptr;
+    SlabPin slabs;
     WriteLock wl(g->rw);
     int rc = guarded([&] {
         RB_HIP(hipSetDevice(g->p.device));
-        if (len > ((size_t)16 << 20) && !getenv("RB_NO_PIN")) {        // pinning is best effort (foreign mappings may refuse)
-            if (hipHostRegister(const_cast<char *>(text), len, hipHostRegisterDefault) == hipSuccess) pinned = text;
-            (void)hipGetLastError();
-        }
+        slabs.begin(text, len);                                      // registered slab by slab as the pieces advance (best effort)
         st = getenv("RB_INGEST_OWN_STREAM") ? nullptr : g->pk_stream;      // the handle's copy stream (made with the graph: a hardware queue of its own, rb_graph_create)
         if (!st) { RB_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking)); own_stream = true; }
         // pieces of 1 GiB of text; a piece starts where the complete records of the one before ended.  The next piece is
@@ -545,8 +540,9 @@ int rb_graph_add_fasta(rb_graph *g, const char *text, size_t len, unsigned flags
         bool ended = false;                                       // FastaReader.next() returned null at an empty header line
         auto piece = [&](size_t a) {
             const size_t e = std::min(len, a + piece_bytes);
+            slabs.pin_to(text + e);
             bool end_here = false;
-            rb::FastqChunk c = rb::fasta_batch_create(g->p.device, text + a, e - a, e == len, st, &end_here);
+            rb::FastqChunk c = rb::fasta_batch_create(g->p.device, text + a, e - a, e == len, st, &end_here, getenv("RB_NO_INGEST_POOL") ? nullptr : &g->ingest_pool);
             if (end_here) ended = true;
             return c;
         };
@@ -577,7 +573,7 @@ int rb_graph_add_fasta(rb_graph *g, const char *text, size_t len, unsigned flags
         if (n_records) *n_records = recs;
     });
     if (st && !own_stream && rc != RB_OK) (void)hipStreamSynchronize(st);      // (a failed call leaves nothing of its own in flight on the shared stream)
-    if (pinned) (void)hipHostUnregister(const_cast<char *>(pinned));
+    slabs.end();
     if (st && own_stream) (void)hipStreamDestroy(st);
     return rc;
 }
@@ -678,8 +674,9 @@ int add_text_file(rb_graph *g, const char *path, bool fasta, int min_base_qual, 
             if (final) src_done = true;
             *len_out = len;
             bool end_here = false;
-            rb::FastqChunk c = fasta ? rb::fasta_batch_create(g->p.device, buf[w], len, final, st, &end_here)
-                                     : rb::fastq_batch_create(g->p.device, buf[w], len, final, min_base_qual, true, st);
+            DevPool *pool = getenv("RB_NO_INGEST_POOL") ? nullptr : &g->ingest_pool;
+            rb::FastqChunk c = fasta ? rb::fasta_batch_create(g->p.device, buf[w], len, final, st, &end_here, pool)
+                                     : rb::fastq_batch_create(g->p.device, buf[w], len, final, min_base_qual, true, st, pool);
             if (end_here) ended = true;
             return c;
         };

@@ -108,6 +108,47 @@ struct HostWoff {
     void borrow(uint32_t *p, size_t n) { own.clear(); ext = p; ext_n = n; }
 };
 
+// A caller's large host array registered slab by slab as an upload advances through it, instead of as a whole before the first copy (hipHostRegister
+// takes 8 ms per GB: 126 ms for a 15.75 GB FASTQ text with the link idle meanwhile).  Slabs end on 256 MiB boundaries of the ADDRESS, so neighbours
+// never share a page; a copy must stay inside one registration (HIP refuses a source range over two as an invalid argument): copy() splits there.
+// Best effort: where registration fails the copies still work, from pageable memory.  One user at a time.
+struct SlabPin {
+    static constexpr uintptr_t SLAB = (uintptr_t)256 << 20;
+    uintptr_t hi = 0, done = 0;
+    bool on = false;
+    std::vector<void *> pins;
+    void begin(const void *p, size_t bytes) {
+        on = false;
+        if (!p || bytes <= ((size_t)16 << 20) || getenv("RB_NO_PIN")) return;
+        hipPointerAttribute_t a;
+        const bool pinned = hipPointerGetAttributes(&a, p) == hipSuccess && a.type == hipMemoryTypeHost;
+        (void)hipGetLastError();
+        if (pinned) return;
+        done = reinterpret_cast<uintptr_t>(p); hi = done + bytes; on = true;
+    }
+    void pin_to(const void *upto) {                    // register slabs until everything below `upto` is covered
+        const uintptr_t need = std::min(reinterpret_cast<uintptr_t>(upto), hi);
+        while (on && done < need) {
+            const uintptr_t a = done, e = std::min(hi, (a & ~(SLAB - 1)) + SLAB);
+            if (hipHostRegister(reinterpret_cast<void *>(a), (size_t)(e - a), hipHostRegisterDefault) == hipSuccess) pins.push_back(reinterpret_cast<void *>(a));
+            else { (void)hipGetLastError(); on = false; }
+            done = e;
+        }
+    }
+    void end() { for (void *q : pins) (void)hipHostUnregister(q); pins.clear(); on = false; }
+    ~SlabPin() { end(); }
+    static hipError_t copy(void *dst, const char *src, size_t n, hipStream_t st) {
+        for (size_t o = 0; o < n;) {
+            const uintptr_t at = reinterpret_cast<uintptr_t>(src + o);
+            const size_t m = std::min<size_t>(n - o, (size_t)(((at & ~(SLAB - 1)) + SLAB) - at));
+            const hipError_t e = hipMemcpyAsync(static_cast<char *>(dst) + o, src + o, m, hipMemcpyHostToDevice, st);
+            if (e != hipSuccess) return e;
+            o += m;
+        }
+        return hipSuccess;
+    }
+};
+
 // Device blocks that chunked ingests hand back and take again (rb_graph_add_reads cuts a call into chunks of 256 M bases, each a batch of six
 // arrays + three staging arrays: hipMalloc / hipFree of those cost 6 ms a chunk — a third of the call — and hipFree waits for the device).
 // get() takes the smallest cached block that fits and is at most twice the size, else allocates; put() keeps up to `limit` bytes.

@@ -211,15 +211,36 @@ __global__ void k_fa_encode(const uint8_t *__restrict__ t, const uint32_t *__res
     }
     codes[w] = c; valid[w] = v; word_read[w] = r;
 }
-struct TmpBuf {                                                      // freed on every way out
+struct TmpBuf {                                                      // given back on every way out
     void *p = nullptr;
-    ~TmpBuf() { if (p) (void)hipFree(p); }
-    template <class T> T *alloc(size_t n) { RB_HIP(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T))); return static_cast<T *>(p); }
+    DevPool *pool = nullptr;           // pieces of a file ingest: the blocks of piece c serve piece c + 1 (no hipMalloc / hipFree — which waits for the device — per piece)
+    ~TmpBuf() { if (!p) return; if (pool) pool->put(p); else (void)hipFree(p); }
+    template <class T> T *alloc(size_t n) {
+        const size_t bytes = std::max<size_t>(n, 1) * sizeof(T);
+        if (pool) p = pool->get(bytes); else RB_HIP(hipMalloc(&p, bytes));
+        return static_cast<T *>(p);
+    }
 };
+// the arrays of a batch made from text: out of the pool if there is one (rb_batch_destroy hands them back)
+void alloc_text_batch(rb_batch *b, uint32_t R, DevPool *pool) {
+    const size_t nw = (size_t)std::max<int64_t>(b->n_words, 1), nr = (size_t)std::max<uint32_t>(R, 1u);
+    b->pool = pool;
+    if (pool) {
+        b->codes = static_cast<uint64_t *>(pool->get(nw * 8)); b->valid = static_cast<uint32_t *>(pool->get(nw * 4)); b->word_read = static_cast<uint32_t *>(pool->get(nw * 4));
+        b->woff = static_cast<uint32_t *>(pool->get(((size_t)R + 2) * 4)); b->len = static_cast<uint32_t *>(pool->get(nr * 4));
+    } else {
+        RB_HIP(hipMalloc(&b->codes, nw * 8));
+        RB_HIP(hipMalloc(&b->valid, nw * 4));
+        RB_HIP(hipMalloc(&b->word_read, nw * 4));
+        RB_HIP(hipMalloc(&b->woff, ((size_t)R + 2) * 4));
+        RB_HIP(hipMalloc(&b->len, nr * 4));
+    }
+    b->device_bytes = nw * 16 + ((size_t)R + 2) * 4 + nr * 4;
+}
 }  // namespace
 
 namespace rb {
-FastqChunk fastq_batch_create(int device, const char *text, size_t n, bool final, int min_base_qual, bool use_qual, hipStream_t st) {
+FastqChunk fastq_batch_create(int device, const char *text, size_t n, bool final, int min_base_qual, bool use_qual, hipStream_t st, DevPool *pool) {
     RB_REQUIRE(text || n == 0, "rb_batch_create_fastq: null text");
     RB_REQUIRE(n < 0xFFFFFF00ull, "rb_batch_create_fastq: at most 4 GiB of text per call (got %zu bytes)", n);
     RB_REQUIRE(min_base_qual >= 0 && min_base_qual < 94, "rb_batch_create_fastq: min_base_qual out of range");
@@ -231,9 +252,10 @@ FastqChunk fastq_batch_create(int device, const char *text, size_t n, bool final
     b->device = device;
     const uint32_t un = (uint32_t)n, ntiles = (uint32_t)(((uint64_t)n + FQ_TILE - 1) / FQ_TILE);   // 64-bit: n + FQ_TILE - 1 wraps in 32 bits just below 4 GiB
     TmpBuf d_text, d_cnt, d_base, d_tmp, d_ls, d_sp, d_qp, d_len, d_nw, d_woff, d_err;
+    for (TmpBuf *q : {&d_text, &d_cnt, &d_base, &d_tmp, &d_ls, &d_sp, &d_qp, &d_len, &d_nw, &d_woff, &d_err}) q->pool = pool;
     uint8_t *t = d_text.alloc<uint8_t>((size_t)ntiles * FQ_TILE + 64);
     RB_HIP(hipMemsetAsync(t + n, 0, (size_t)ntiles * FQ_TILE + 64 - n, st));
-    if (n) RB_HIP(hipMemcpyAsync(t, text, n, hipMemcpyHostToDevice, st));
+    if (n) RB_HIP(SlabPin::copy(t, text, n, st));            // (split at the boundaries a slab-wise registration of the text would have: SlabPin)
     uint32_t *cnt = d_cnt.alloc<uint32_t>(ntiles + 1), *base = d_base.alloc<uint32_t>(ntiles + 1);
     void *tmp = d_tmp.alloc<uint8_t>(scan_temp_bytes((size_t)ntiles + 1));
     RB_HIP(hipMemsetAsync(cnt + ntiles, 0, 4, st));
@@ -259,6 +281,7 @@ FastqChunk fastq_batch_create(int device, const char *text, size_t n, bool final
     if (R) hipLaunchKernelGGL(k_fq_records, dim3((R + 255u) / 256u), dim3(256), 0, st, t, un, ls, R, use_qual ? 1 : 0, sp, qp, ln, nw, err,
                               reinterpret_cast<unsigned long long *>(err + 6));
     TmpBuf d_tmp2;
+    for (TmpBuf *q : {&d_tmp2}) q->pool = pool;
     void *tmp2 = d_tmp2.alloc<uint8_t>(scan_temp_bytes((size_t)R + 1));
     exclusive_scan_u32(tmp2, scan_temp_bytes((size_t)R + 1), nw, woff, (size_t)R + 1, st);
     uint32_t herr[8], consumed32 = 0;
@@ -278,12 +301,7 @@ FastqChunk fastq_batch_create(int device, const char *text, size_t n, bool final
     b->wpr_uniform = (R && herr[4] == herr[5]) ? herr[4] : 0u;
     unsigned long long nb; memcpy(&nb, herr + 6, 8);
     b->n_bases = (int64_t)nb;
-    RB_HIP(hipMalloc(&b->codes, (size_t)std::max<int64_t>(b->n_words, 1) * 8));
-    RB_HIP(hipMalloc(&b->valid, (size_t)std::max<int64_t>(b->n_words, 1) * 4));
-    RB_HIP(hipMalloc(&b->word_read, (size_t)std::max<int64_t>(b->n_words, 1) * 4));
-    RB_HIP(hipMalloc(&b->woff, ((size_t)R + 2) * 4));
-    RB_HIP(hipMalloc(&b->len, (size_t)std::max<uint32_t>(R, 1u) * 4));
-    b->device_bytes = (size_t)std::max<int64_t>(b->n_words, 1) * 16 + ((size_t)R + 2) * 4 + (size_t)std::max<uint32_t>(R, 1u) * 4;
+    alloc_text_batch(b, R, pool);
     RB_HIP(hipMemcpyAsync(b->woff, woff, ((size_t)R + 1) * 4, hipMemcpyDeviceToDevice, st));
     if (R) RB_HIP(hipMemcpyAsync(b->len, ln, (size_t)R * 4, hipMemcpyDeviceToDevice, st));
     if (b->n_words)
@@ -296,7 +314,7 @@ FastqChunk fastq_batch_create(int device, const char *text, size_t n, bool final
 }
 // FASTA text -> packed batch on the GPU.  final = false: the text is a piece of a longer input; the last record then stays
 // unread (consumed = where its header line starts) because its sequence may continue in the next piece.
-FastqChunk fasta_batch_create(int device, const char *text, size_t n, bool final, hipStream_t st, bool *ended) {
+FastqChunk fasta_batch_create(int device, const char *text, size_t n, bool final, hipStream_t st, bool *ended, DevPool *pool) {
     RB_REQUIRE(text || n == 0, "rb_batch_create_fasta: null text");
     RB_REQUIRE(n < 0xFFFFFF00ull, "rb_batch_create_fasta: at most 4 GiB of text per call (got %zu bytes)", n);
     RB_HIP(hipSetDevice(device));
@@ -308,9 +326,10 @@ FastqChunk fasta_batch_create(int device, const char *text, size_t n, bool final
     b->device = device;
     const uint32_t un = (uint32_t)n, ntiles = (uint32_t)(((uint64_t)n + FQ_TILE - 1) / FQ_TILE);   // 64-bit: n + FQ_TILE - 1 wraps in 32 bits just below 4 GiB
     TmpBuf d_text, d_cnt, d_base, d_tmp, d_ls, d_ts, d_tl, d_ish, d_kind, d_cum, d_hidx, d_hl, d_len, d_nw, d_woff, d_err;
+    for (TmpBuf *q : {&d_text, &d_cnt, &d_base, &d_tmp, &d_ls, &d_ts, &d_tl, &d_ish, &d_kind, &d_cum, &d_hidx, &d_hl, &d_len, &d_nw, &d_woff, &d_err}) q->pool = pool;
     uint8_t *t = d_text.alloc<uint8_t>((size_t)ntiles * FQ_TILE + 64);
     RB_HIP(hipMemsetAsync(t + n, 0, (size_t)ntiles * FQ_TILE + 64 - n, st));
-    if (n) RB_HIP(hipMemcpyAsync(t, text, n, hipMemcpyHostToDevice, st));
+    if (n) RB_HIP(SlabPin::copy(t, text, n, st));            // (split at the boundaries a slab-wise registration of the text would have: SlabPin)
     uint32_t *cnt = d_cnt.alloc<uint32_t>(ntiles + 1), *base = d_base.alloc<uint32_t>(ntiles + 1);
     void *tmp = d_tmp.alloc<uint8_t>(scan_temp_bytes((size_t)ntiles + 1));
     RB_HIP(hipMemsetAsync(cnt + ntiles, 0, 4, st));
@@ -347,6 +366,7 @@ FastqChunk fasta_batch_create(int device, const char *text, size_t n, bool final
     const uint32_t limit = end_seen ? h2[1] : n_lines;                // lines that take part
     if (ended) *ended = end_seen;
     TmpBuf d_tmp2;
+    for (TmpBuf *q : {&d_tmp2}) q->pool = pool;
     void *tmp2 = d_tmp2.alloc<uint8_t>(scan_temp_bytes(nl1));
     exclusive_scan_u32(tmp2, scan_temp_bytes(nl1), tl, cum, nl1, st);
     exclusive_scan_u32(tmp2, scan_temp_bytes(nl1), ish, hidx, nl1, st);
@@ -371,6 +391,7 @@ FastqChunk fasta_batch_create(int device, const char *text, size_t n, bool final
     RB_HIP(hipMemsetAsync(nw + R, 0, 4, st));
     if (R) hipLaunchKernelGGL(k_fa_records, dim3((R + 255u) / 256u), dim3(256), 0, st, hl, cum, R, ln, nw, err, reinterpret_cast<unsigned long long *>(err + 6));
     TmpBuf d_tmp3;
+    for (TmpBuf *q : {&d_tmp3}) q->pool = pool;
     void *tmp3 = d_tmp3.alloc<uint8_t>(scan_temp_bytes((size_t)R + 1));
     exclusive_scan_u32(tmp3, scan_temp_bytes((size_t)R + 1), nw, woff, (size_t)R + 1, st);
     uint32_t herr[8], consumed32 = 0;
@@ -387,12 +408,7 @@ FastqChunk fasta_batch_create(int device, const char *text, size_t n, bool final
     b->wpr_uniform = (R && herr[4] == herr[5]) ? herr[4] : 0u;
     unsigned long long nb; memcpy(&nb, herr + 6, 8);
     b->n_bases = (int64_t)nb;
-    RB_HIP(hipMalloc(&b->codes, (size_t)std::max<int64_t>(b->n_words, 1) * 8));
-    RB_HIP(hipMalloc(&b->valid, (size_t)std::max<int64_t>(b->n_words, 1) * 4));
-    RB_HIP(hipMalloc(&b->word_read, (size_t)std::max<int64_t>(b->n_words, 1) * 4));
-    RB_HIP(hipMalloc(&b->woff, ((size_t)R + 2) * 4));
-    RB_HIP(hipMalloc(&b->len, (size_t)std::max<uint32_t>(R, 1u) * 4));
-    b->device_bytes = (size_t)std::max<int64_t>(b->n_words, 1) * 16 + ((size_t)R + 2) * 4 + (size_t)std::max<uint32_t>(R, 1u) * 4;
+    alloc_text_batch(b, R, pool);
     RB_HIP(hipMemcpyAsync(b->woff, woff, ((size_t)R + 1) * 4, hipMemcpyDeviceToDevice, st));
     if (R) RB_HIP(hipMemcpyAsync(b->len, ln, (size_t)R * 4, hipMemcpyDeviceToDevice, st));
     if (b->n_words)

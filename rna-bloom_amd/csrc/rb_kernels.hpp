@@ -65,7 +65,7 @@ void launch_encode_ascii_piece(const uint8_t *seq, const uint8_t *qual, const in
 // without an end of line counts; otherwise it belongs to the caller's next piece).  consumed = bytes of the complete
 // records (where the next piece starts).  Synchronises `st`.
 struct FastqChunk { rb_batch *b = nullptr; size_t consumed = 0; int64_t records = 0; };
-FastqChunk fastq_batch_create(int device, const char *text, size_t n, bool final, int min_base_qual, bool use_qual, hipStream_t st);
+FastqChunk fastq_batch_create(int device, const char *text, size_t n, bool final, int min_base_qual, bool use_qual, hipStream_t st, DevPool *pool = nullptr);
 // FASTA text (FastaReader.next semantics) the same way; *ended: an empty line in header position ended the iteration
-FastqChunk fasta_batch_create(int device, const char *text, size_t n, bool final, hipStream_t st, bool *ended);
+FastqChunk fasta_batch_create(int device, const char *text, size_t n, bool final, hipStream_t st, bool *ended, DevPool *pool = nullptr);
 }  // namespace rb
