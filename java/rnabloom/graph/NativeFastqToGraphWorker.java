@@ -18,8 +18,11 @@ import rnabloom.io.FileFormatException;
  * For plain-text files NativeGraph.addFastq(handle, mappedText, ...) needs no Java-side record handling at all.
  */
 public class NativeFastqToGraphWorker implements Runnable {
-    public static final int BATCH_READS = 1 << 20;
-    private static final int BATCH_BASES = 1 << 28;
+    // A call of more than one piece (256 M bases) is streamed inside the library — lengths and offsets computed on the GPU, bases and qualities uploaded and
+    // encoded piece by piece beside ONE insert (csrc/rb_packed.hip add_reads_streamed: 17.7 G k-mers/s for a whole file in one call); calls do not overlap
+    // each other, so a batch is as large as two direct buffers may be: four pieces (2 x 1 GiB of direct memory, -XX:MaxDirectMemorySize permitting).
+    public static final int BATCH_READS = 1 << 23;
+    private static final int BATCH_BASES = 1 << 30;
 
     private final BloomFilterDeBruijnGraph graph;
     private final FastqReader fr;
