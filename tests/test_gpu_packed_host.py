@@ -150,3 +150,34 @@ def test_host_ascii_reads_streamed_in_pieces_leave_the_oracles_filters(monkeypat
     with pytest.raises(N.NativeError):
         gg.addReads(seq, qual, bad, 3)
     assert gg.addReads(seq, qual, off, 3).reads == len(reads)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6])
+def test_streamed_ascii_ingest_with_random_pieces_and_sub_batches(monkeypatch, seed):
+    """the same comparison over random shapes: piece size, sub-batch bound, read-length mix, stranded or not, with and without qualities and
+    read pairs — the piece boundaries fall anywhere relative to the sub-batches' and the reads' words"""
+    rng = np.random.default_rng(1000 + seed)
+    monkeypatch.setenv("RB_ASCII_PIECE", str(int(rng.integers(64, 60_000))))
+    n = int(rng.integers(500, 7000))
+    reads, quals = ragged_reads(n, 100 + seed)
+    if seed % 2:                                                   # a block of equal-length reads in the middle: the read-per-lane walkers
+        k0 = n // 3
+        for i in range(k0, 2 * k0):
+            reads[i] = (reads[i] * 3 + b"ACGTACGTAC" * 20)[:150]; quals[i] = b"I" * 150
+    seq = np.frombuffer(b"".join(reads), np.uint8); qual = np.frombuffer(b"".join(quals), np.uint8)
+    off = np.concatenate([[0], np.cumsum([len(r) for r in reads])]).astype(np.int64)
+    stranded, pairs, with_q = bool(seed & 2), bool(seed % 3), seed != 4
+    k = [25, 31, 36][seed % 3]
+    sizes = (1_000_003, 1_500_007, 200_003)
+    og = rbo.Graph(*sizes, 2, 2, 2, k, stranded, pairs, seed)
+    gg = BloomFilterDeBruijnGraph(*sizes, 2, 2, 2, k, stranded, pairs, rngSeed=seed, maxBatchKmers=int(rng.integers(3_000, 200_000)))
+    if pairs:
+        og.set_read_pair_distance(40); gg.setReadPairedKmerDistance(40)
+    for rc in (False, True):
+        fl = (rbo.STORE_READ_PAIRS if pairs else 0) | (rbo.REVCOMP if rc else 0)
+        ost = og.add_reads(seq, qual if with_q else None, off, 3 if with_q else 0, fl)
+        st = gg.addReads(seq, qual if with_q else None, off, 3 if with_q else 0, reverseComplement=rc, storeReadPairedKmers=pairs)
+        assert (st.kmers, st.pairs) == (ost.kmers, ost.pairs)
+    assert (gg.exportFilter(N.DBGBF) == og.dbgbf_bytes()).all() and (gg.exportFilter(N.CBF) == og.cbf_bytes()).all()
+    if pairs:
+        assert (gg.exportFilter(N.RPKBF) == og.rpkbf_bytes()).all()
